@@ -1,0 +1,12 @@
+"""gingr_amd -- MI355X (gfx950) implementation of GiNGR's per-iteration GP-regression update.
+
+Only what the hot path needs: `csrc/` (HIP kernels + the C ABI of include/gingr_hip.h), `_native` (ctypes binding) and
+`api` (host-side mirror of the reference's GingrConfig / GingrRegistrationState / GingrAlgorithm plugin surface).
+There is no CPU implementation in this package.
+"""
+from .api import (  # noqa: F401
+    Context, CorrespondencePairs, CpdConfiguration, CpdRegistration, CpdRegistrationState, DeviceModel, EulerAngles,
+    FittingStatuses, GeneralRegistrationState, GingrAlgorithm, GlobalTranformationType, IcpConfiguration,
+    IcpRegistration, IcpRegistrationState, LandmarkCorrespondences, ModelFittingParameters, PointDistributionModel,
+)
+from ._native import GingrNativeError  # noqa: F401

@@ -1,0 +1,125 @@
+"""ctypes binding of libgingr_hip.so (the C ABI declared in include/gingr_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, an exception is raised.
+The library is built in-tree by ``__graft_entry__.build()`` (``make -C gingr_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgingr_hip.so")
+
+GINGR_OK = 0
+ERR_BAD_ARGUMENT, ERR_HIP, ERR_NONFINITE, ERR_NOT_SPD, ERR_NO_DEVICE, ERR_STATE = 1, 2, 3, 4, 5, 6
+NUM_PHASES = 6
+NUM_SEGMENTS = 5
+
+_STATUS_NAMES = {
+    1: "GINGR_ERR_BAD_ARGUMENT", 2: "GINGR_ERR_HIP", 3: "GINGR_ERR_NONFINITE", 4: "GINGR_ERR_NOT_SPD",
+    5: "GINGR_ERR_NO_DEVICE", 6: "GINGR_ERR_STATE",
+}
+
+
+class GingrNativeError(RuntimeError):
+    def __init__(self, code: int, where: str, text: str = ""):
+        self.code = code
+        super().__init__(f"{where}: {_STATUS_NAMES.get(code, code)} {text}".strip())
+
+
+class StateScalars(ctypes.Structure):
+    """gingr_state_scalars"""
+    _fields_ = [
+        ("euler", c_double * 3), ("center", c_double * 3), ("translation", c_double * 3),
+        ("scale", c_double), ("sigma2", c_double), ("iteration", c_int32), ("status", c_int32),
+    ]
+
+
+class CpdParams(ctypes.Structure):
+    _fields_ = [("w", c_double), ("lambda_", c_double)]
+
+
+class IcpParams(ctypes.Structure):
+    _fields_ = [("initial_sigma", c_double), ("end_sigma", c_double), ("max_iterations", c_int32)]
+
+
+_dp = POINTER(c_double)
+_ip = POINTER(c_int32)
+
+# name -> (restype, argtypes); every symbol include/gingr_hip.h declares
+SIGNATURES = {
+    "gingr_device_count": (c_int, []),
+    "gingr_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "gingr_ctx_destroy": (None, [c_void_p]),
+    "gingr_last_error": (c_char_p, [c_void_p]),
+    "gingr_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
+    "gingr_ctx_get_stream": (c_void_p, [c_void_p]),
+    "gingr_ctx_synchronize": (c_int, [c_void_p]),
+    "gingr_build_info": (c_char_p, []),
+    "gingr_cpd_stats": (c_int, [c_void_p, c_int64, _dp, c_int64, _dp, c_double, c_double, _dp, _dp, _dp, _dp, _dp]),
+    "gingr_cpd_initial_sigma2": (c_int, [c_void_p, c_int64, _dp, c_int64, _dp, _dp]),
+    "gingr_nn": (c_int, [c_void_p, c_int64, _dp, c_int64, _dp, _ip, _dp, _dp]),
+    "gingr_gauss_block": (c_int, [c_void_p, c_int64, _dp, c_int64, _dp, c_double, c_double, _dp]),
+    "gingr_model_upload": (c_int, [c_void_p, c_int64, c_int32, _dp, _dp, _dp, _dp, c_int64, c_int64, POINTER(c_void_p)]),
+    "gingr_model_destroy": (None, [c_void_p]),
+    "gingr_model_gram_exchange": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),
+    "gingr_model_finalize": (c_int, [c_void_p, c_void_p]),
+    "gingr_model_num_points": (c_int64, [c_void_p]),
+    "gingr_model_rank": (c_int32, [c_void_p]),
+    "gingr_model_instance": (c_int, [c_void_p, c_void_p, _dp, _dp, _dp, _dp, c_double, _dp]),
+    "gingr_model_coefficients": (c_int, [c_void_p, c_void_p, _dp, _dp, _dp, _dp, _dp]),
+    "gingr_model_posterior_mean": (c_int, [c_void_p, c_void_p, _dp, _dp, _dp, _dp, _dp, c_int32, _ip, _dp, _dp, _dp, _dp]),
+    "gingr_fitter_create": (c_int, [c_void_p, c_void_p, POINTER(c_void_p)]),
+    "gingr_fitter_destroy": (None, [c_void_p]),
+    "gingr_fitter_set_target": (c_int, [c_void_p, c_int64, _dp]),
+    "gingr_fitter_set_landmarks": (c_int, [c_void_p, c_int32, _ip, _dp, _dp]),
+    "gingr_fitter_set_options": (c_int, [c_void_p, c_int32, c_double]),
+    "gingr_fitter_set_state": (c_int, [c_void_p, _dp, POINTER(StateScalars)]),
+    "gingr_fitter_get_state": (c_int, [c_void_p, _dp, POINTER(StateScalars), _dp]),
+    "gingr_fitter_get_cpd_stats": (c_int, [c_void_p, _dp, _dp, _dp, _dp]),
+    "gingr_fitter_get_icp_idx": (c_int, [c_void_p, _ip, _dp]),
+    "gingr_fitter_update_cpd_async": (c_int, [c_void_p, POINTER(CpdParams), c_int32]),
+    "gingr_fitter_update_icp_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32]),
+    "gingr_fitter_exchange": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64)]),
+    "gingr_fitter_cpd_phase_async": (c_int, [c_void_p, POINTER(CpdParams), c_int32]),
+    "gingr_fitter_icp_phase_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32]),
+    "gingr_ctx_timing_enable": (c_int, [c_void_p, c_int32]),
+    "gingr_ctx_timing_read": (c_int, [c_void_p, c_int32, _dp, POINTER(c_int64)]),
+    "gingr_ctx_timing_reset": (c_int, [c_void_p]),
+}
+
+_LIB = None
+
+
+def load():
+    """Load libgingr_hip.so and set the prototypes.  Raises if the library has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise GingrNativeError(
+                ERR_STATE, "load",
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return None if a is None else a.ctypes.data_as(_ip)

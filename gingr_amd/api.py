@@ -1,0 +1,570 @@
+"""Host-side mirror of GiNGR's plugin surface for the MI355X update path.
+
+The reference's host language is Scala (no JVM exists in this image, see INTEGRATION.md for the Scala/JNI binding);
+this module is the Python host layer over the same C ABI.  It keeps the reference's names, argument meaning and
+error behaviour so that tests read like uses of the reference API:
+
+  GingrConfig / GingrRegistrationState / GingrAlgorithm         G/api/GingrAlgorithm.scala:52-75,192-258
+  GeneralRegistrationState, ModelFittingParameters              G/api/GeneralRegistrationState.scala:28-41,
+                                                                G/api/ModelFittingParameters.scala:31-57
+  CpdConfiguration / CpdRegistrationState / CpdRegistration     G/api/registration/config/CPD.scala:52-155
+  IcpConfiguration / IcpRegistrationState / IcpRegistration     G/api/registration/config/ICP.scala:54-107
+  GlobalTranformationType, FittingStatuses                      G/api/GlobalTranformationType.scala:20-24,
+                                                                G/api/FittingStatuses.scala:22
+
+(G/ = src/main/scala/gingr/ of unibas-gravis/GiNGR.)  All arithmetic runs in libgingr_hip.so on the GPU; nothing
+here computes on the CPU and there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import dataclasses
+from ctypes import c_int64, c_void_p
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as nat
+from ._native import GingrNativeError, f64, dptr, iptr
+
+
+# ----------------------------------------------------------------------------- enums
+class GlobalTranformationType:  # sic: the reference spells it this way
+    NoTransforms = 0
+    RigidTransforms = 1
+    SimilarityTransforms = 2
+
+
+class FittingStatuses:
+    None_ = 0
+    Converged = 1
+    MaxIteration = 2
+    ModelFlexibilityError = 3
+
+
+def _check(ctx_handle, code: int, where: str):
+    if code != nat.GINGR_OK:
+        text = ""
+        if ctx_handle:
+            text = (nat.load().gingr_last_error(ctx_handle) or b"").decode("utf-8", "replace")
+        raise GingrNativeError(code, where, text)
+
+
+# ----------------------------------------------------------------------------- context + operators
+class Context:
+    """One device + one stream (gingr_ctx).  Not thread-safe; one per chain / per GPU."""
+
+    def __init__(self, device: int = 0):
+        self._lib = nat.load()
+        h = c_void_p()
+        code = self._lib.gingr_ctx_create(int(device), ctypes.byref(h))
+        if code != nat.GINGR_OK:
+            raise GingrNativeError(code, "gingr_ctx_create", "(no usable GPU: this package has no CPU path)")
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.gingr_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(self.handle, self._lib.gingr_ctx_synchronize(self.handle), "gingr_ctx_synchronize")
+
+    def set_stream(self, hip_stream: Optional[int]):
+        _check(self.handle, self._lib.gingr_ctx_set_stream(self.handle, c_void_p(hip_stream or 0)), "gingr_ctx_set_stream")
+
+    # timing hooks (bench.py roofline)
+    def timing_enable(self, on: bool = True):
+        _check(self.handle, self._lib.gingr_ctx_timing_enable(self.handle, 1 if on else 0), "timing_enable")
+
+    def timing_reset(self):
+        _check(self.handle, self._lib.gingr_ctx_timing_reset(self.handle), "timing_reset")
+
+    def timing_read(self, which: int) -> Tuple[float, int]:
+        ms = ctypes.c_double()
+        n = c_int64()
+        _check(self.handle, self._lib.gingr_ctx_timing_read(self.handle, which, ctypes.byref(ms), ctypes.byref(n)), "timing_read")
+        return ms.value, n.value
+
+    # ---- stateless all-pairs operators -------------------------------------------------
+    def cpd_stats(self, fit, target, sigma2: float, w: float = 0.0) -> dict:
+        """CPD statistics of one affinity evaluation (CPD.scala:54-75,36,133-147), P never materialised."""
+        y, x = f64(fit), f64(target)
+        M, N = y.shape[0], x.shape[0]
+        den, Pt1 = np.empty(N), np.empty(N)
+        P1, PX, sc = np.empty(M), np.empty((M, 3)), np.empty(6)
+        _check(self.handle, self._lib.gingr_cpd_stats(self.handle, M, dptr(y), N, dptr(x), float(sigma2), float(w),
+                                                      dptr(den), dptr(P1), dptr(PX), dptr(Pt1), dptr(sc)), "gingr_cpd_stats")
+        return dict(den=den, P1=P1, PX=PX, Pt1=Pt1, Np=float(sc[0]), xPx=float(sc[1]), trPXY=float(sc[2]),
+                    yPy=float(sc[3]), sigma2_next=float(sc[4]), c=float(sc[5]))
+
+    def cpd_initial_sigma2(self, reference, target) -> float:
+        y, x = f64(reference), f64(target)
+        out = ctypes.c_double()
+        _check(self.handle, self._lib.gingr_cpd_initial_sigma2(self.handle, y.shape[0], dptr(y), x.shape[0], dptr(x),
+                                                               ctypes.byref(out)), "gingr_cpd_initial_sigma2")
+        return out.value
+
+    def nn(self, query, target) -> Tuple[np.ndarray, np.ndarray, float]:
+        """Exact nearest neighbour, lowest index on ties (ClosestPointRegistrator.scala:133-148)."""
+        y, x = f64(query), f64(target)
+        idx = np.empty(y.shape[0], dtype=np.int32)
+        d2 = np.empty(y.shape[0])
+        md = ctypes.c_double()
+        _check(self.handle, self._lib.gingr_nn(self.handle, y.shape[0], dptr(y), x.shape[0], dptr(x), iptr(idx), dptr(d2),
+                                               ctypes.byref(md)), "gingr_nn")
+        return idx, d2, md.value
+
+    def gauss_block(self, A, B, sigma: float, scaling: float) -> np.ndarray:
+        """scaling * exp(-|a-b|^2 / sigma^2)  (GPMMHelper.scala:99-102)."""
+        A, B = f64(A), f64(B)
+        out = np.empty((A.shape[0], B.shape[0]))
+        _check(self.handle, self._lib.gingr_gauss_block(self.handle, A.shape[0], dptr(A), B.shape[0], dptr(B), float(sigma),
+                                                        float(scaling), dptr(out)), "gingr_gauss_block")
+        return out
+
+
+# ----------------------------------------------------------------------------- model
+@dataclasses.dataclass
+class PointDistributionModel:
+    """Numeric content of scalismo's PointDistributionModel: reference points, mean displacement, basisMatrix
+    (3M x r, element (row, k) = U[row, k]) and variance."""
+    reference: np.ndarray      # (M,3)
+    mean: np.ndarray           # (M,3) displacement
+    basis: np.ndarray          # (3M, r)
+    variance: np.ndarray       # (r,)
+
+    @property
+    def rank(self) -> int:
+        return int(self.variance.shape[0])
+
+    @property
+    def numberOfPoints(self) -> int:
+        return int(self.reference.shape[0])
+
+
+class DeviceModel:
+    """gingr_model: the (row shard of the) model resident in HBM."""
+
+    def __init__(self, ctx: Context, model: PointDistributionModel, row_begin: int = 0, row_end: Optional[int] = None):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        self.host = model
+        M = model.numberOfPoints
+        row_end = M if row_end is None else row_end
+        ref, mean = f64(model.reference), f64(model.mean)
+        basis = np.asfortranarray(model.basis, dtype=np.float64)   # column-major, as Breeze stores basisMatrix
+        var = f64(model.variance)
+        h = c_void_p()
+        _check(ctx.handle, self._lib.gingr_model_upload(ctx.handle, M, model.rank, dptr(ref), dptr(mean),
+                                                        basis.ctypes.data_as(nat._dp), dptr(var), int(row_begin),
+                                                        int(row_end), ctypes.byref(h)), "gingr_model_upload")
+        self.handle = h
+        self.row_begin, self.row_end = int(row_begin), int(row_end)
+        self.M_local = self.row_end - self.row_begin
+
+    def gram_exchange(self) -> Tuple[int, int]:
+        p, n = c_void_p(), c_int64()
+        _check(self.ctx.handle, self._lib.gingr_model_gram_exchange(self.handle, ctypes.byref(p), ctypes.byref(n)), "gram_exchange")
+        return p.value, n.value
+
+    def finalize(self):
+        _check(self.ctx.handle, self._lib.gingr_model_finalize(self.ctx.handle, self.handle), "gingr_model_finalize")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.gingr_model_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- stateless model operators ---------------------------------------------------------
+    def instance(self, alpha, euler=(0, 0, 0), center=(0, 0, 0), translation=(0, 0, 0), scale: float = 1.0) -> np.ndarray:
+        a, e, c, t = f64(alpha), f64(euler), f64(center), f64(translation)
+        out = np.empty((self.M_local, 3))
+        _check(self.ctx.handle, self._lib.gingr_model_instance(self.ctx.handle, self.handle, dptr(a), dptr(e), dptr(c), dptr(t),
+                                                               float(scale), dptr(out)), "gingr_model_instance")
+        return out
+
+    def coefficients(self, mesh, euler=(0, 0, 0), center=(0, 0, 0), translation=(0, 0, 0)) -> np.ndarray:
+        m, e, c, t = f64(mesh), f64(euler), f64(center), f64(translation)
+        out = np.empty(self.host.rank)
+        _check(self.ctx.handle, self._lib.gingr_model_coefficients(self.ctx.handle, self.handle, dptr(e), dptr(c), dptr(t),
+                                                                   dptr(m), dptr(out)), "gingr_model_coefficients")
+        return out
+
+    def posterior_mean(self, obs_points, weights, euler=(0, 0, 0), center=(0, 0, 0), translation=(0, 0, 0),
+                       landmarks: Optional["LandmarkCorrespondences"] = None) -> Tuple[np.ndarray, np.ndarray]:
+        o, w, e, c, t = f64(obs_points), f64(weights), f64(euler), f64(center), f64(translation)
+        mean = np.empty((self.M_local, 3))
+        coeffs = np.empty(self.host.rank)
+        if landmarks is not None and len(landmarks.pids) > 0:
+            lp = np.ascontiguousarray(landmarks.pids, dtype=np.int32)
+            lx, lc = f64(landmarks.points), f64(landmarks.covs)
+            n = lp.shape[0]
+        else:
+            lp = lx = lc = None
+            n = 0
+        _check(self.ctx.handle, self._lib.gingr_model_posterior_mean(
+            self.ctx.handle, self.handle, dptr(e), dptr(c), dptr(t), dptr(o), dptr(w), n, iptr(lp), dptr(lx), dptr(lc),
+            dptr(mean), dptr(coeffs)), "gingr_model_posterior_mean")
+        return mean, coeffs
+
+
+# ----------------------------------------------------------------------------- state records
+@dataclasses.dataclass(frozen=True)
+class EulerAngles:
+    phi: float = 0.0
+    theta: float = 0.0
+    psi: float = 0.0
+
+
+@dataclasses.dataclass(frozen=True)
+class ModelFittingParameters:
+    """scale, pose = (translation, Euler rotation about a centre), shape  (ModelFittingParameters.scala:31-57)."""
+    scale: float
+    translation: Tuple[float, float, float]
+    rotation: EulerAngles
+    center: Tuple[float, float, float]
+    shape: np.ndarray
+
+    @staticmethod
+    def zero(rank: int) -> "ModelFittingParameters":
+        return ModelFittingParameters(1.0, (0.0, 0.0, 0.0), EulerAngles(), (0.0, 0.0, 0.0), np.zeros(rank))
+
+
+@dataclasses.dataclass
+class LandmarkCorrespondences:
+    """(pid, target point, 3x3 covariance) triples (GeneralRegistrationState.scala:43-62)."""
+    pids: np.ndarray
+    points: np.ndarray
+    covs: np.ndarray
+
+
+@dataclasses.dataclass(frozen=True)
+class CorrespondencePairs:
+    """(PointId, Point) pairs (G/api/CorrespondencePairs.scala:23)."""
+    pids: np.ndarray
+    points: np.ndarray
+
+
+@dataclasses.dataclass(frozen=True)
+class GeneralRegistrationState:
+    model: PointDistributionModel
+    modelParameters: ModelFittingParameters
+    target: np.ndarray
+    fit: np.ndarray
+    sigma2: float = 1.0
+    globalTransformation: int = GlobalTranformationType.RigidTransforms
+    stepLength: float = 1.0
+    generatedBy: str = ""
+    iteration: int = 0
+    status: int = FittingStatuses.None_
+    landmarkCorrespondences: Optional[LandmarkCorrespondences] = None
+
+    def updateStatus(self, status: int) -> "GeneralRegistrationState":
+        return dataclasses.replace(self, status=status)
+
+    def updateSigma2(self, s2: float) -> "GeneralRegistrationState":
+        return dataclasses.replace(self, sigma2=s2)
+
+
+# ----------------------------------------------------------------------------- configs
+def _cpd_converged(last: GeneralRegistrationState, current: GeneralRegistrationState, threshold: float) -> bool:
+    return abs(last.sigma2 - current.sigma2) < threshold          # CPD.scala:108-110
+
+
+def _never_converged(last, current, threshold) -> bool:
+    return False                                                   # ICP.scala:57-58
+
+
+@dataclasses.dataclass(frozen=True)
+class CpdConfiguration:
+    maxIterations: int = 100
+    threshold: float = 1e-10
+    converged: Callable = _cpd_converged
+    useLandmarkCorrespondence: bool = True
+    initialSigma: Optional[float] = None
+    w: float = 0.0
+    lambda_: float = 1.0
+
+
+@dataclasses.dataclass(frozen=True)
+class IcpConfiguration:
+    maxIterations: int = 100
+    threshold: float = 1e-10
+    converged: Callable = _never_converged
+    useLandmarkCorrespondence: bool = True
+    initialSigma: float = 100.0
+    endSigma: float = 1.0
+    reverseCorrespondenceDirection: bool = False
+    correspondenceMethod: str = "PointcloudClosestPoint"
+
+    @property
+    def sigmaStep(self) -> float:
+        return (self.initialSigma - self.endSigma) / float(self.maxIterations)
+
+
+@dataclasses.dataclass(frozen=True)
+class CpdRegistrationState:
+    general: GeneralRegistrationState
+    config: CpdConfiguration
+
+    def updateGeneral(self, update: GeneralRegistrationState) -> "CpdRegistrationState":
+        return dataclasses.replace(self, general=update)
+
+
+@dataclasses.dataclass(frozen=True)
+class IcpRegistrationState:
+    general: GeneralRegistrationState
+    config: IcpConfiguration
+
+    def updateGeneral(self, update: GeneralRegistrationState) -> "IcpRegistrationState":
+        return dataclasses.replace(self, general=update)
+
+
+# ----------------------------------------------------------------------------- the algorithm
+class GingrAlgorithm:
+    """HIP-backed GingrAlgorithm: `update` is ONE native call sequence per iteration
+    (GingrAlgorithm.scala:192-254 + GingrGeneratorWrapper.propose).  Sub-classes supply the correspondence flavour."""
+
+    name = "GiNGR"
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        self._dev_model: Optional[DeviceModel] = None
+        self._fitter = None
+        self._model_id = None
+        self._target_id = None
+        self._lm_id = None
+        self._device_state_token = None   # identity of the python state currently mirrored on the device
+
+    # -- native plumbing ------------------------------------------------------------------
+    def _bind(self, general: GeneralRegistrationState, use_landmarks: bool):
+        if self._model_id != id(general.model):
+            self._release()
+            self._dev_model = DeviceModel(self.ctx, general.model)
+            h = c_void_p()
+            _check(self.ctx.handle, self._lib.gingr_fitter_create(self.ctx.handle, self._dev_model.handle, ctypes.byref(h)),
+                   "gingr_fitter_create")
+            self._fitter = h
+            self._model_id = id(general.model)
+            self._target_id = None
+            self._lm_id = None
+        if self._target_id != id(general.target):
+            x = f64(general.target)
+            _check(self.ctx.handle, self._lib.gingr_fitter_set_target(self._fitter, x.shape[0], dptr(x)), "gingr_fitter_set_target")
+            self._target_id = id(general.target)
+            self._device_state_token = None
+        lm = general.landmarkCorrespondences if use_landmarks else None
+        key = (id(lm), use_landmarks)
+        if self._lm_id != key:
+            if lm is not None and len(lm.pids) > 0:
+                lp = np.ascontiguousarray(lm.pids, dtype=np.int32)
+                lx, lc = f64(lm.points), f64(lm.covs)
+                _check(self.ctx.handle, self._lib.gingr_fitter_set_landmarks(self._fitter, lp.shape[0], iptr(lp), dptr(lx), dptr(lc)),
+                       "gingr_fitter_set_landmarks")
+            else:
+                _check(self.ctx.handle, self._lib.gingr_fitter_set_landmarks(self._fitter, 0, None, None, None),
+                       "gingr_fitter_set_landmarks")
+            self._lm_id = key
+        _check(self.ctx.handle, self._lib.gingr_fitter_set_options(self._fitter, int(general.globalTransformation),
+                                                                   float(general.stepLength)), "gingr_fitter_set_options")
+
+    def _release(self):
+        if self._fitter:
+            self._lib.gingr_fitter_destroy(self._fitter)
+            self._fitter = None
+        if self._dev_model is not None:
+            self._dev_model.close()
+            self._dev_model = None
+
+    def close(self):
+        self._release()
+
+    def _push_state(self, general: GeneralRegistrationState):
+        mp = general.modelParameters
+        s = nat.StateScalars()
+        s.euler[:] = [mp.rotation.phi, mp.rotation.theta, mp.rotation.psi]
+        s.center[:] = list(mp.center)
+        s.translation[:] = list(mp.translation)
+        s.scale = mp.scale
+        s.sigma2 = general.sigma2
+        s.iteration = general.iteration
+        s.status = general.status
+        a = f64(mp.shape)
+        _check(self.ctx.handle, self._lib.gingr_fitter_set_state(self._fitter, dptr(a), ctypes.byref(s)), "gingr_fitter_set_state")
+
+    def _pull_state(self, general: GeneralRegistrationState) -> GeneralRegistrationState:
+        r = general.model.rank
+        M = general.model.numberOfPoints
+        alpha = np.empty(r)
+        fit = np.empty((M, 3))
+        s = nat.StateScalars()
+        _check(self.ctx.handle, self._lib.gingr_fitter_get_state(self._fitter, dptr(alpha), ctypes.byref(s), dptr(fit)),
+               "gingr_fitter_get_state")
+        mp = ModelFittingParameters(scale=s.scale, translation=tuple(s.translation),
+                                    rotation=EulerAngles(*list(s.euler)), center=tuple(s.center), shape=alpha)
+        return dataclasses.replace(general, modelParameters=mp, fit=fit, sigma2=s.sigma2, iteration=s.iteration,
+                                   status=s.status, generatedBy=self.name)
+
+    def _native_update(self, current, n: int):
+        raise NotImplementedError
+
+    # -- the reference surface ----------------------------------------------------------------
+    def initializeState(self, general: GeneralRegistrationState, config):
+        raise NotImplementedError
+
+    def update(self, current, probabilistic: bool = False):
+        """One GiNGR iteration.  Numerical failure of the posterior / projections maps to
+        FittingStatuses.ModelFlexibilityError exactly like the reference's Try(...) handling (:194-208,248,251)."""
+        if probabilistic:
+            raise NotImplementedError("posterior sampling (probabilistic=True) is not on the accelerated path yet")
+        g = current.general
+        self._bind(g, current.config.useLandmarkCorrespondence)
+        if self._device_state_token != id(current):
+            self._push_state(g)
+        self._native_update(current, 1)
+        new_general = self._pull_state(g)
+        out = current.updateGeneral(new_general)
+        self._device_state_token = id(out)
+        self._keepalive = out
+        return out
+
+    def run(self, initialState, callBackLogger: Optional[Callable] = None):
+        """Deterministic registration loop (GingrAlgorithm.run, :115-175): the chain yields the initial state first,
+        so take(maxIterations) performs maxIterations-1 updates; stops on convergence or ModelFlexibilityError."""
+        state = initialState
+        last_general = None
+        converged = False
+        k = 0
+        while True:
+            # dropWhile body (:142-153)
+            if last_general is not None:
+                converged = bool(state.config.converged(last_general, state.general, state.config.threshold))
+            error = state.general.status == FittingStatuses.ModelFlexibilityError
+            last_general = state.general
+            if callBackLogger is not None:
+                callBackLogger(state)
+            k += 1
+            if converged or error or k >= state.config.maxIterations:
+                break
+            state = self.update(state, False)
+        if state.general.status == FittingStatuses.None_:
+            state = state.updateGeneral(state.general.updateStatus(
+                FittingStatuses.Converged if converged else FittingStatuses.MaxIteration))
+        return state
+
+
+def _initial_general(ctx: Context, model: PointDistributionModel, target: np.ndarray, sigma2: float,
+                     transform: int, stepLength: float, landmarks: Optional[LandmarkCorrespondences],
+                     initial_pose: Optional[Tuple[Sequence[float], Sequence[float]]] = None) -> GeneralRegistrationState:
+    """GeneralRegistrationState.apply (:135-179): alpha = 0, optional initial pose, fit = instance."""
+    mp = ModelFittingParameters.zero(model.rank)
+    if initial_pose is not None:
+        euler, t = initial_pose
+        mp = dataclasses.replace(mp, rotation=EulerAngles(*euler), translation=tuple(t))
+    dm = DeviceModel(ctx, model)
+    try:
+        fit = dm.instance(mp.shape, [mp.rotation.phi, mp.rotation.theta, mp.rotation.psi], mp.center, mp.translation, mp.scale)
+    finally:
+        dm.close()
+    return GeneralRegistrationState(model=model, modelParameters=mp, target=f64(target), fit=fit, sigma2=sigma2,
+                                    globalTransformation=transform, stepLength=stepLength,
+                                    landmarkCorrespondences=landmarks)
+
+
+class CpdRegistration(GingrAlgorithm):
+    name = "CPD"
+
+    def createInitialState(self, model: PointDistributionModel, target, config: CpdConfiguration,
+                           transform: int = GlobalTranformationType.RigidTransforms, stepLength: float = 1.0,
+                           landmarks: Optional[LandmarkCorrespondences] = None, initial_pose=None) -> CpdRegistrationState:
+        g = _initial_general(self.ctx, model, target, 1.0, transform, stepLength, landmarks, initial_pose)
+        return self.initializeState(g, config)
+
+    def initializeState(self, general: GeneralRegistrationState, config: CpdConfiguration) -> CpdRegistrationState:
+        # CpdRegistrationState.apply (CPD.scala:92-102): sigma2 = initialSigma or sum|x - y|^2/(3MN) over model MEAN vs target
+        if config.initialSigma is not None:
+            s2 = float(config.initialSigma)
+        else:
+            mean_pts = f64(general.model.reference) + f64(general.model.mean)
+            s2 = self.ctx.cpd_initial_sigma2(mean_pts, general.target)
+        return CpdRegistrationState(general.updateSigma2(s2), config)
+
+    def _native_update(self, current: CpdRegistrationState, n: int):
+        p = nat.CpdParams(current.config.w, current.config.lambda_)
+        _check(self.ctx.handle, self._lib.gingr_fitter_update_cpd_async(self._fitter, ctypes.byref(p), n),
+               "gingr_fitter_update_cpd_async")
+
+    # plugin accessors served from one streaming evaluation (the reference recomputes P for each of them)
+    def _stats(self, state: CpdRegistrationState) -> dict:
+        if getattr(self, "_stats_key", None) != id(state):
+            self._stats_cache = self.ctx.cpd_stats(state.general.fit, state.general.target, state.general.sigma2, state.config.w)
+            self._stats_key = id(state)
+            self._stats_keep = state
+        return self._stats_cache
+
+    def getCorrespondence(self, state: CpdRegistrationState) -> CorrespondencePairs:
+        st = self._stats(state)                                                       # CPD.scala:32-49
+        y = f64(state.general.fit)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            td = y + (st["PX"] * (1.0 / st["P1"])[:, None] - y)
+        return CorrespondencePairs(np.arange(y.shape[0]), td)
+
+    def getUncertainty(self, pid: int, state: CpdRegistrationState) -> np.ndarray:
+        st = self._stats(state)                                                       # CPD.scala:120-128
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return np.eye(3) * state.general.sigma2 * state.config.lambda_ * (1.0 / st["P1"][int(pid)])
+
+    def updateSigma2(self, state: CpdRegistrationState) -> float:
+        return self._stats(state)["sigma2_next"]                                      # CPD.scala:133-147
+
+
+class IcpRegistration(GingrAlgorithm):
+    name = "ICP"
+
+    def createInitialState(self, model: PointDistributionModel, target, config: IcpConfiguration,
+                           transform: int = GlobalTranformationType.RigidTransforms, stepLength: float = 1.0,
+                           landmarks: Optional[LandmarkCorrespondences] = None, initial_pose=None) -> IcpRegistrationState:
+        g = _initial_general(self.ctx, model, target, 1.0, transform, stepLength, landmarks, initial_pose)
+        return self.initializeState(g, config)
+
+    def initializeState(self, general: GeneralRegistrationState, config: IcpConfiguration) -> IcpRegistrationState:
+        if config.correspondenceMethod != "PointcloudClosestPoint" or config.reverseCorrespondenceDirection:
+            raise NotImplementedError("only the PointcloudClosestPoint flavour (ICP.scala:43) is on the accelerated path")
+        return IcpRegistrationState(general.updateSigma2(float(config.initialSigma)), config)   # ICP.scala:73-85
+
+    def _native_update(self, current: IcpRegistrationState, n: int):
+        c = current.config
+        p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
+        _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_async(self._fitter, ctypes.byref(p), n),
+               "gingr_fitter_update_icp_async")
+
+    def getCorrespondence(self, state: IcpRegistrationState) -> CorrespondencePairs:
+        idx, _, _ = self.ctx.nn(state.general.fit, state.general.target)              # ICP.scala:36-52
+        return CorrespondencePairs(np.arange(idx.shape[0]), f64(state.general.target)[idx])
+
+    def getUncertainty(self, pid: int, state: IcpRegistrationState) -> np.ndarray:
+        return np.eye(3) * state.general.sigma2                                       # ICP.scala:90-92
+
+    def updateSigma2(self, state: IcpRegistrationState) -> float:
+        return max(state.general.sigma2 - state.config.sigmaStep, state.config.endSigma)   # ICP.scala:96-99
+
+    def last_correspondence_indices(self) -> np.ndarray:
+        M = self._dev_model.M_local
+        idx = np.empty(M, dtype=np.int32)
+        _check(self.ctx.handle, self._lib.gingr_fitter_get_icp_idx(self._fitter, iptr(idx), None), "gingr_fitter_get_icp_idx")
+        return idx

@@ -1,0 +1,462 @@
+// All-pairs kernels of the GiNGR update path for gfx950 (MI355X): CPD soft-assignment statistics in two
+// streaming passes (P is never materialised), exact brute-force nearest neighbour, Gaussian kernel blocks.
+//
+// Reference loops replaced (G/ = src/main/scala/gingr/):
+//   cpd_colsum   : K_ij and its column sums               G/api/registration/config/CPD.scala:63-68,71
+//   cpd_rowstats : P_ij = K_ij/den_j, P1 = row sums, P*X  CPD.scala:36-45,74,138,144
+//   nn           : findClosestPoint per fit vertex        G/api/registration/utils/ClosestPointRegistrator.scala:139-145
+//   gauss_block  : GaussianKernel(sigma)*scaling          G/api/gpmm/GPMMHelper.scala:99-102
+//
+// Shape of both CPD passes: a thread keeps PT points of the "owned" side in registers (targets in pass 1, fit points
+// in pass 2), the other side streams through LDS in 256-point tiles read with wave-uniform (broadcast) 16-byte
+// reads, so HBM traffic is O(M+N) per block column and the kernels are bound by float64 VALU issue (the software
+// exponential), not by memory.  The streamed dimension is split into chunks (gridDim.y) so that >> 256 workgroups
+// exist; chunk partials are combined by a second kernel in a FIXED order (no float atomics: results are bitwise
+// reproducible run to run).
+#include "common.h"
+#include "fastexp.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kTile = 256;
+
+struct __attribute__((aligned(32))) P4 {
+    double x, y, z, w;
+};
+
+// ---------------------------------------------------------------- pass 1: column sums of K
+template <int PT>
+__global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt, const double *__restrict__ sigma2,
+                                                            int64_t rows_per_chunk, double *__restrict__ partial) {
+    __shared__ double T[GINGR_EXP_TABLE];
+    __shared__ P4 tile[kTile];
+    fastexp_table_init(T);
+    const double c64 = fastexp_scale_for_variance(2.0 * sigma2[0]);
+    const int tid = threadIdx.x;
+    const int64_t jbase = (int64_t)blockIdx.x * (kBlock * PT) + tid;
+    double x[PT], y[PT], z[PT], acc[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        const int64_t j = jbase + (int64_t)t * kBlock;
+        const bool ok = j < tgt.n;
+        x[t] = ok ? tgt.x[j] : 0.0;
+        y[t] = ok ? tgt.y[j] : 0.0;
+        z[t] = ok ? tgt.z[j] : 0.0;
+        acc[t] = 0.0;
+    }
+    const int64_t i0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t i1 = min(fit.n, i0 + rows_per_chunk);
+    for (int64_t ib = i0; ib < i1; ib += kTile) {
+        __syncthreads();
+        const int64_t i = ib + tid;
+        if (i < i1) tile[tid] = P4{fit.x[i], fit.y[i], fit.z[i], 0.0};
+        __syncthreads();
+        const int cnt = (int)min((int64_t)kTile, i1 - ib);
+#pragma unroll 2
+        for (int ii = 0; ii < cnt; ++ii) {
+            const P4 p = tile[ii];
+#pragma unroll
+            for (int t = 0; t < PT; ++t) {
+                const double dx = x[t] - p.x, dy = y[t] - p.y, dz = z[t] - p.z;
+                const double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+                acc[t] += fastexp2_64(d2 * c64, T);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        const int64_t j = jbase + (int64_t)t * kBlock;
+        if (j < tgt.n) partial[(int64_t)blockIdx.y * tgt.n + j] = acc[t];
+    }
+}
+
+// out[j] = sum over chunks (ascending) of partial[chunk][j]
+__global__ void chunk_reduce_kernel(const double *__restrict__ partial, int nchunks, int64_t n, double *__restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * n + j];
+    out[j] = s;
+}
+
+// block-wide fixed-order sum; result valid in thread 0
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+    sh[threadIdx.x] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    return sh[0];
+}
+
+// den[j] = colsum[j] + c ; inv_den ; Pt1 ; xPx = sum_j Pt1_j |x_j|^2 (single block, fixed order)
+__global__ __launch_bounds__(1024) void cpd_den_finalize_kernel(Cloud tgt, const double *__restrict__ sigma2, double w,
+                                                                double m_over_n, double *__restrict__ den,
+                                                                double *__restrict__ inv_den, double *__restrict__ Pt1,
+                                                                double *__restrict__ scalars) {
+    __shared__ double sh[1024];
+    const double s2 = sigma2[0];
+    // c = w/(1-w) * (2 pi sigma2)^(3/2) * (M/N)     CPD.scala:69-70
+    const double c = w / (1.0 - w) * pow(2.0 * 3.14159265358979323846 * s2, 1.5) * m_over_n;
+    double xpx = 0.0;
+    for (int64_t j = threadIdx.x; j < tgt.n; j += 1024) {
+        const double colsum = den[j];
+        const double d = colsum + c;
+        const double inv = 1.0 / d;
+        const double pt1 = colsum / d;
+        den[j] = d;
+        inv_den[j] = inv;
+        Pt1[j] = pt1;
+        const double xx = tgt.x[j], yy = tgt.y[j], zz = tgt.z[j];
+        xpx += pt1 * (xx * xx + yy * yy + zz * zz);
+    }
+    const double tot = block_sum<1024>(xpx, sh);
+    if (threadIdx.x == 0) {
+        scalars[1] = tot;
+        scalars[5] = c;
+    }
+}
+
+// ---------------------------------------------------------------- pass 2: row statistics
+template <int PT>
+__global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud tgt, const double *__restrict__ sigma2,
+                                                              const double *__restrict__ inv_den, int64_t cols_per_chunk,
+                                                              double *__restrict__ partial) {
+    __shared__ double T[GINGR_EXP_TABLE];
+    __shared__ P4 tile[kTile];
+    fastexp_table_init(T);
+    const double c64 = fastexp_scale_for_variance(2.0 * sigma2[0]);
+    const int tid = threadIdx.x;
+    const int64_t ibase = (int64_t)blockIdx.x * (kBlock * PT) + tid;
+    double x[PT], y[PT], z[PT], a1[PT], ax[PT], ay[PT], az[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        const int64_t i = ibase + (int64_t)t * kBlock;
+        const bool ok = i < fit.n;
+        x[t] = ok ? fit.x[i] : 0.0;
+        y[t] = ok ? fit.y[i] : 0.0;
+        z[t] = ok ? fit.z[i] : 0.0;
+        a1[t] = ax[t] = ay[t] = az[t] = 0.0;
+    }
+    const int64_t j0 = (int64_t)blockIdx.y * cols_per_chunk;
+    const int64_t j1 = min(tgt.n, j0 + cols_per_chunk);
+    for (int64_t jb = j0; jb < j1; jb += kTile) {
+        __syncthreads();
+        const int64_t j = jb + tid;
+        if (j < j1) tile[tid] = P4{tgt.x[j], tgt.y[j], tgt.z[j], inv_den[j]};
+        __syncthreads();
+        const int cnt = (int)min((int64_t)kTile, j1 - jb);
+#pragma unroll 2
+        for (int jj = 0; jj < cnt; ++jj) {
+            const P4 p = tile[jj];
+#pragma unroll
+            for (int t = 0; t < PT; ++t) {
+                const double dx = p.x - x[t], dy = p.y - y[t], dz = p.z - z[t];
+                const double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+                const double pij = fastexp2_64(d2 * c64, T) * p.w;
+                a1[t] += pij;
+                ax[t] = __builtin_fma(pij, p.x, ax[t]);
+                ay[t] = __builtin_fma(pij, p.y, ay[t]);
+                az[t] = __builtin_fma(pij, p.z, az[t]);
+            }
+        }
+    }
+    const int64_t M = fit.n;
+    double *base = partial + (int64_t)blockIdx.y * 4 * M;
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        const int64_t i = ibase + (int64_t)t * kBlock;
+        if (i < M) {
+            base[i] = a1[t];
+            base[M + i] = ax[t];
+            base[2 * M + i] = ay[t];
+            base[3 * M + i] = az[t];
+        }
+    }
+}
+
+// P1 / PX from chunk partials (ascending chunk order)
+__global__ void rowstats_reduce_kernel(const double *__restrict__ partial, int nchunks, int64_t M, double *__restrict__ P1,
+                                       double *__restrict__ PX) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    double s1 = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int c = 0; c < nchunks; ++c) {
+        const double *b = partial + (int64_t)c * 4 * M;
+        s1 += b[i];
+        sx += b[M + i];
+        sy += b[2 * M + i];
+        sz += b[3 * M + i];
+    }
+    P1[i] = s1;
+    PX[i] = sx;
+    PX[M + i] = sy;
+    PX[2 * M + i] = sz;
+}
+
+// Np = sum P1, trPXY = sum_i y_i . PX_i, yPy = sum_i P1_i |y_i|^2   over the local rows (single block, fixed order)
+__global__ __launch_bounds__(1024) void cpd_row_scalars_kernel(Cloud fit, const double *__restrict__ P1,
+                                                               const double *__restrict__ PX, double *__restrict__ scalars) {
+    __shared__ double sh[1024];
+    const int64_t M = fit.n;
+    double np = 0.0, tr = 0.0, ypy = 0.0;
+    for (int64_t i = threadIdx.x; i < M; i += 1024) {
+        const double p1 = P1[i];
+        const double yx = fit.x[i], yy = fit.y[i], yz = fit.z[i];
+        np += p1;
+        tr += yx * PX[i] + yy * PX[M + i] + yz * PX[2 * M + i];
+        ypy += p1 * (yx * yx + yy * yy + yz * yz);
+    }
+    const double a = block_sum<1024>(np, sh);
+    __syncthreads();
+    const double b = block_sum<1024>(tr, sh);
+    __syncthreads();
+    const double c = block_sum<1024>(ypy, sh);
+    if (threadIdx.x == 0) {
+        scalars[0] = a;
+        scalars[2] = b;
+        scalars[3] = c;
+    }
+}
+
+// ---------------------------------------------------------------- nearest neighbour (exact, lowest index on ties)
+// Distances use separately rounded multiplies and adds (no FMA contraction) so that d2 is bit-identical to the
+// reference expression dx*dx + dy*dy + dz*dz evaluated in float64 on a CPU; the argmin is then index-exact.
+__device__ __forceinline__ double norm2_exact(double dx, double dy, double dz) {
+    return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+}
+
+__global__ __launch_bounds__(kBlock) void nn_kernel(Cloud q, Cloud tgt, int64_t cols_per_chunk, double *__restrict__ pd2,
+                                                    int32_t *__restrict__ pidx) {
+    __shared__ P4 tile[kTile];
+    const int tid = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + tid;
+    const bool ok = i < q.n;
+    const double qx = ok ? q.x[i] : 0.0, qy = ok ? q.y[i] : 0.0, qz = ok ? q.z[i] : 0.0;
+    double best = __builtin_huge_val();
+    int32_t bi = -1;
+    const int64_t j0 = (int64_t)blockIdx.y * cols_per_chunk;
+    const int64_t j1 = min(tgt.n, j0 + cols_per_chunk);
+    for (int64_t jb = j0; jb < j1; jb += kTile) {
+        __syncthreads();
+        const int64_t j = jb + tid;
+        if (j < j1) tile[tid] = P4{tgt.x[j], tgt.y[j], tgt.z[j], 0.0};
+        __syncthreads();
+        const int cnt = (int)min((int64_t)kTile, j1 - jb);
+#pragma unroll 4
+        for (int jj = 0; jj < cnt; ++jj) {
+            const P4 p = tile[jj];
+            const double d2 = norm2_exact(p.x - qx, p.y - qy, p.z - qz);
+            if (d2 < best) {  // strict: the lowest index wins exact ties
+                best = d2;
+                bi = (int32_t)(jb + jj);
+            }
+        }
+    }
+    if (ok) {
+        pd2[(int64_t)blockIdx.y * q.n + i] = best;
+        pidx[(int64_t)blockIdx.y * q.n + i] = bi;
+    }
+}
+
+__global__ void nn_reduce_kernel(const double *__restrict__ pd2, const int32_t *__restrict__ pidx, int nchunks, int64_t M,
+                                 int32_t *__restrict__ idx, double *__restrict__ d2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    double best = pd2[i];
+    int32_t bi = pidx[i];
+    for (int c = 1; c < nchunks; ++c) {
+        const double v = pd2[(int64_t)c * M + i];
+        if (v < best) {  // chunks ascend in index, strict < keeps the lowest index
+            best = v;
+            bi = pidx[(int64_t)c * M + i];
+        }
+    }
+    idx[i] = bi;
+    d2[i] = best;
+}
+
+// ---------------------------------------------------------------- Gaussian kernel block
+__global__ __launch_bounds__(kBlock) void gauss_block_kernel(Cloud A, Cloud B, double sigma, double scaling,
+                                                             double *__restrict__ out) {
+    __shared__ double T[GINGR_EXP_TABLE];
+    fastexp_table_init(T);
+    __syncthreads();
+    const double c64 = fastexp_scale_for_variance(sigma * sigma);
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j >= B.n) return;
+    const double dx = A.x[i] - B.x[j], dy = A.y[i] - B.y[j], dz = A.z[i] - B.z[j];
+    const double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+    out[i * B.n + j] = scaling * fastexp2_64(d2 * c64, T);
+}
+
+// ---------------------------------------------------------------- sum of squared pair distances (initial sigma2)
+__global__ __launch_bounds__(kBlock) void sumsq_pairs_kernel(Cloud A, Cloud B, double *__restrict__ partial) {
+    __shared__ P4 tile[kTile];
+    __shared__ double sh[kBlock];
+    const int tid = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + tid;
+    const bool ok = i < A.n;
+    const double ax = ok ? A.x[i] : 0.0, ay = ok ? A.y[i] : 0.0, az = ok ? A.z[i] : 0.0;
+    double acc = 0.0;
+    for (int64_t jb = 0; jb < B.n; jb += kTile) {
+        __syncthreads();
+        const int64_t j = jb + tid;
+        if (j < B.n) tile[tid] = P4{B.x[j], B.y[j], B.z[j], 0.0};
+        __syncthreads();
+        const int cnt = (int)min((int64_t)kTile, B.n - jb);
+        for (int jj = 0; jj < cnt; ++jj) {
+            const P4 p = tile[jj];
+            const double dx = p.x - ax, dy = p.y - ay, dz = p.z - az;
+            acc += dx * dx + dy * dy + dz * dz;
+        }
+    }
+    if (!ok) acc = 0.0;
+    __syncthreads();
+    const double tot = block_sum<kBlock>(acc, sh);
+    if (tid == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(1024) void sum_vector_kernel(const double *__restrict__ v, int64_t n, double scale,
+                                                          double *__restrict__ out) {
+    __shared__ double sh[1024];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) acc += v[i];
+    const double tot = block_sum<1024>(acc, sh);
+    if (threadIdx.x == 0) out[0] = tot * scale;
+}
+
+__global__ void aos_to_soa_kernel(const double *__restrict__ aos, int64_t n, double *__restrict__ soa) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    soa[i] = aos[3 * i];
+    soa[n + i] = aos[3 * i + 1];
+    soa[2 * n + i] = aos[3 * i + 2];
+}
+
+__global__ void soa_to_aos_kernel(const double *__restrict__ soa, int64_t n, double *__restrict__ aos) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    aos[3 * i] = soa[i];
+    aos[3 * i + 1] = soa[n + i];
+    aos[3 * i + 2] = soa[2 * n + i];
+}
+
+constexpr int kPT = 2;            // points per thread in both CPD passes
+constexpr int kTargetBlocks = 2048;  // ~8 workgroups per CU
+
+// split `stream_len` into chunks so that block_cols * nchunks ~ kTargetBlocks; chunk length is a multiple of kTile
+inline void plan_chunks(int64_t owned, int owned_per_block, int64_t stream_len, int *nchunks, int64_t *chunk_len) {
+    const int64_t bx = ceil_div(owned, owned_per_block);
+    int64_t want = ceil_div(kTargetBlocks, bx > 0 ? bx : 1);
+    const int64_t max_chunks = ceil_div(stream_len, kTile);
+    if (want > max_chunks) want = max_chunks;
+    if (want < 1) want = 1;
+    int64_t len = round_up(ceil_div(stream_len, want), kTile);
+    if (len < kTile) len = kTile;
+    *chunk_len = len;
+    *nchunks = (int)ceil_div(stream_len > 0 ? stream_len : 1, len);
+}
+
+}  // namespace
+
+int64_t cpd_colsum_ws_doubles(int64_t M, int64_t N) {
+    int nch;
+    int64_t len;
+    plan_chunks(N, kBlock * kPT, M, &nch, &len);
+    return (int64_t)nch * N;
+}
+
+int64_t cpd_rowstats_ws_doubles(int64_t M, int64_t N) {
+    int nch;
+    int64_t len;
+    plan_chunks(M, kBlock * kPT, N, &nch, &len);
+    return (int64_t)nch * 4 * M;
+}
+
+int64_t nn_ws_bytes(int64_t M, int64_t N) {
+    int nch;
+    int64_t len;
+    plan_chunks(M, kBlock, N, &nch, &len);
+    return (int64_t)nch * M * (sizeof(double) + sizeof(int32_t));
+}
+
+void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, double *ws,
+                       double *den_partial) {
+    int nch;
+    int64_t len;
+    plan_chunks(target.n, kBlock * kPT, fit.n, &nch, &len);
+    dim3 grid((unsigned)ceil_div(target.n, kBlock * kPT), (unsigned)nch);
+    {
+        TimerScope ts(ctx, 0);
+        hipLaunchKernelGGL(cpd_colsum_kernel<kPT>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, len, ws);
+    }
+    hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)ceil_div(target.n, 256)), dim3(256), 0, ctx->stream, ws, nch,
+                       target.n, den_partial);
+}
+
+void launch_cpd_den_finalize(gingr_ctx *ctx, Cloud target, const double *sigma2_dev, double w, int64_t M_total,
+                             double *den, double *inv_den, double *Pt1, double *scalars_dev) {
+    hipLaunchKernelGGL(cpd_den_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream, target, sigma2_dev, w,
+                       (double)M_total / (double)target.n, den, inv_den, Pt1, scalars_dev);
+}
+
+void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *inv_den,
+                         double *ws, double *P1, double *PX_soa, double *scalars_dev) {
+    int nch;
+    int64_t len;
+    plan_chunks(fit.n, kBlock * kPT, target.n, &nch, &len);
+    dim3 grid((unsigned)ceil_div(fit.n, kBlock * kPT), (unsigned)nch);
+    {
+        TimerScope ts(ctx, 1);
+        hipLaunchKernelGGL(cpd_rowstats_kernel<kPT>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, inv_den,
+                           len, ws);
+    }
+    hipLaunchKernelGGL(rowstats_reduce_kernel, dim3((unsigned)ceil_div(fit.n, 256)), dim3(256), 0, ctx->stream, ws, nch,
+                       fit.n, P1, PX_soa);
+    hipLaunchKernelGGL(cpd_row_scalars_kernel, dim3(1), dim3(1024), 0, ctx->stream, fit, P1, PX_soa, scalars_dev);
+}
+
+void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, void *ws, int32_t *idx, double *d2) {
+    int nch;
+    int64_t len;
+    plan_chunks(query.n, kBlock, target.n, &nch, &len);
+    double *pd2 = reinterpret_cast<double *>(ws);
+    int32_t *pidx = reinterpret_cast<int32_t *>(pd2 + (int64_t)nch * query.n);
+    dim3 grid((unsigned)ceil_div(query.n, kBlock), (unsigned)nch);
+    hipLaunchKernelGGL(nn_kernel, grid, dim3(kBlock), 0, ctx->stream, query, target, len, pd2, pidx);
+    hipLaunchKernelGGL(nn_reduce_kernel, dim3((unsigned)ceil_div(query.n, 256)), dim3(256), 0, ctx->stream, pd2, pidx,
+                       nch, query.n, idx, d2);
+}
+
+void launch_gauss_block(gingr_ctx *ctx, Cloud A, Cloud B, double sigma, double scaling, double *out) {
+    // gridDim.y is limited to 65535 rows per launch
+    const int64_t max_rows = 65535;
+    for (int64_t r0 = 0; r0 < A.n; r0 += max_rows) {
+        const int64_t nr = A.n - r0 < max_rows ? A.n - r0 : max_rows;
+        Cloud sub{A.x + r0, A.y + r0, A.z + r0, nr};
+        dim3 grid((unsigned)ceil_div(B.n, kBlock), (unsigned)nr);
+        hipLaunchKernelGGL(gauss_block_kernel, grid, dim3(kBlock), 0, ctx->stream, sub, B, sigma, scaling, out + r0 * B.n);
+    }
+}
+
+void launch_sumsq_pairs(gingr_ctx *ctx, Cloud A, Cloud B, double *ws, double *out_scalar) {
+    const int64_t nb = ceil_div(A.n, kBlock);
+    hipLaunchKernelGGL(sumsq_pairs_kernel, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream, A, B, ws);
+    hipLaunchKernelGGL(sum_vector_kernel, dim3(1), dim3(1024), 0, ctx->stream, ws, nb, 1.0, out_scalar);
+}
+
+void launch_aos_to_soa(gingr_ctx *ctx, const double *aos, int64_t n, double *soa) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(aos_to_soa_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, aos, n, soa);
+}
+
+void launch_soa_to_aos(gingr_ctx *ctx, const double *soa, int64_t n, double *aos) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(soa_to_aos_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, soa, n, aos);
+}

@@ -1,0 +1,113 @@
+// Internal definitions shared by the translation units of libgingr_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gingr_hip.h"
+
+#define GINGR_TIMERS 4
+
+struct gingr_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+    // timing hooks (bench roofline): per-kernel event pairs recorded on `stream`
+    bool timing = false;
+    struct Span {
+        hipEvent_t a, b;
+        int which;
+    };
+    std::vector<Span> spans;     // recorded, not yet resolved
+    std::vector<hipEvent_t> pool;  // recycled events
+    double t_ms[GINGR_TIMERS] = {0, 0, 0, 0};
+    int64_t t_n[GINGR_TIMERS] = {0, 0, 0, 0};
+    // scratch kept across calls (grown on demand, never shrunk) so steady-state updates do not allocate
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+int gingr_set_error(gingr_ctx *ctx, int code, const char *fmt, ...);
+
+#define HIP_TRY(ctx, expr)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e__ = (expr);                                                                             \
+        if (e__ != hipSuccess)                                                                               \
+            return gingr_set_error((ctx), GINGR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                                   __FILE__, __LINE__);                                                      \
+    } while (0)
+
+#define GINGR_TRY(expr)          \
+    do {                         \
+        int s__ = (expr);        \
+        if (s__ != GINGR_OK) return s__; \
+    } while (0)
+
+// RAII device buffer for the stateless operators
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = n;
+        return hipMalloc(&p, n ? n : 8);
+    }
+    template <typename T>
+    T *as() const {
+        return reinterpret_cast<T *>(p);
+    }
+};
+
+struct TimerScope {
+    gingr_ctx *ctx;
+    int which;
+    hipEvent_t a = nullptr, b = nullptr;
+    TimerScope(gingr_ctx *c, int w);
+    ~TimerScope();
+};
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+// ---------------------------------------------------------------------------- affinity.hip (launchers, all async)
+// Points on the device are SoA: x[n], y[n], z[n] contiguous planes of one allocation (plane stride = n).
+struct Cloud {
+    const double *x, *y, *z;
+    int64_t n;
+};
+
+// workspace sizes (in doubles) the launchers need
+int64_t cpd_colsum_ws_doubles(int64_t M, int64_t N);
+int64_t cpd_rowstats_ws_doubles(int64_t M, int64_t N);
+int64_t nn_ws_bytes(int64_t M, int64_t N);
+
+// den_partial[N] = sum_{i in fit} exp(-|x_j - y_i|^2 / (2 sigma2))   (no outlier constant)
+void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, double *ws,
+                       double *den_partial);
+// den[j] += c; inv_den[j] = 1/den[j]; Pt1[j] = (den[j]-c)/den[j]; xpx partial -> scalars_dev[1]
+// M_total enters the outlier constant c = w/(1-w) (2 pi sigma2)^1.5 M_total/N.
+void launch_cpd_den_finalize(gingr_ctx *ctx, Cloud target, const double *sigma2_dev, double w, int64_t M_total,
+                             double *den, double *inv_den, double *Pt1, double *scalars_dev);
+// P1[i], PX (SoA planes px,py,pz of stride M) for the local rows, plus Np/trPXY/yPy partial sums into scalars_dev[0,2,3]
+void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *inv_den,
+                         double *ws, double *P1, double *PX_soa, double *scalars_dev);
+void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, void *ws, int32_t *idx, double *d2);
+void launch_gauss_block(gingr_ctx *ctx, Cloud A, Cloud B, double sigma, double scaling, double *out);
+void launch_sumsq_pairs(gingr_ctx *ctx, Cloud A, Cloud B, double *ws, double *out_scalar);
+// interleaved xyz (n*3) <-> SoA planes
+void launch_aos_to_soa(gingr_ctx *ctx, const double *aos, int64_t n, double *soa);
+void launch_soa_to_aos(gingr_ctx *ctx, const double *soa, int64_t n, double *aos);

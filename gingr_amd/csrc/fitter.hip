@@ -1,0 +1,779 @@
+// Model upload and the device-resident fitter: the host-side orchestration of one GiNGR update as a fixed sequence
+// of kernels with no host synchronisation (C ABI in include/gingr_hip.h).
+//
+// One update = GingrAlgorithm.update (G/api/GingrAlgorithm.scala:192-254) followed by GingrGeneratorWrapper.propose's
+// fit refresh and iteration++ (G/api/sampling/generators/GingrGeneratorWrapper.scala:28-39), split into six phases
+// whose boundaries are exactly the points where a row-sharded run exchanges partial sums:
+//   0  CPD column sums of K over the local rows (ICP: nearest neighbour, nothing to exchange)        -> segment 0
+//   1  den, row statistics, observations, weighted Gram + right-hand side (+ landmarks), sigma2 sums -> segment 1
+//   2  posterior solve (replicated), posterior mean, first projection Q^T d                          -> segment 2
+//   3  alpha_1, step blend, newshape / current shape, Umeyama partial sums                           -> segment 3
+//   4  Umeyama (replicated), second projection                                                       -> segment 4
+//   5  alpha', state commit or failure status, new fit
+#include "gp.h"
+
+#include <cmath>
+
+struct gingr_fitter {
+    gingr_ctx *ctx = nullptr;
+    const gingr_model *m = nullptr;
+    int64_t N = 0;
+    double *target = nullptr;  // SoA [3][N]
+    double *inv_den = nullptr, *Pt1 = nullptr;
+    double *fit = nullptr;  // SoA [3][M]
+    double *P1 = nullptr, *PX = nullptr;
+    int32_t *nn_idx = nullptr;
+    double *nn_d2 = nullptr;
+    double *weight = nullptr, *evec = nullptr, *newshape = nullptr;
+    double *alpha = nullptr, *acoef = nullptr, *alpha_c = nullptr;
+    DevState *st = nullptr;
+    DevPose *pose = nullptr;
+    gingr_state_scalars *hs_dev = nullptr;
+    double *scalars = nullptr;  // local {Np, xPx, trPXY, yPy, -, c, -, -}
+    double *xch = nullptr;
+    int64_t off[GINGR_NUM_SEGMENTS] = {0, 0, 0, 0, 0}, cnt[GINGR_NUM_SEGMENTS] = {0, 0, 0, 0, 0};
+    double *ws = nullptr;
+    int64_t ws_doubles = 0;
+    double *work = nullptr;
+    void *aos = nullptr;  // staging for interleaved transfers, max(3M, 3N) doubles
+    int32_t n_lm = 0;
+    int32_t *lm_pid = nullptr;
+    double *lm_xyz = nullptr, *lm_cov = nullptr;
+    int32_t *lm_mask = nullptr;
+    int32_t global_transform = GINGR_RIGID_TRANSFORMS;
+    double step_length = 1.0;
+    bool has_state = false;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(gingr_ctx *ctx, T **p, size_t count) {
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(p), (count ? count : 1) * sizeof(T)));
+    return GINGR_OK;
+}
+
+void dev_free(void *p) {
+    if (p) (void)hipFree(p);
+}
+
+int check_launch(gingr_ctx *ctx) {
+    HIP_TRY(ctx, hipGetLastError());
+    return GINGR_OK;
+}
+
+__global__ void pack_scalars_kernel(const double *__restrict__ local, int contribute_xpx, double *__restrict__ out8) {
+    const int i = threadIdx.x;
+    if (i >= 8) return;
+    double v = 0.0;
+    if (i == 0 || i == 2 || i == 3) v = local[i];
+    if (i == 1 && contribute_xpx) v = local[1];  // xPx is computed over ALL targets on every shard: count it once
+    out8[i] = v;
+}
+
+__global__ void zero_kernel(double *p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+
+Cloud cloud_of(const double *soa, int64_t n) { return Cloud{soa, soa + n, soa + 2 * n, n}; }
+
+SweepArgs base_args(const gingr_fitter *f) {
+    SweepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Q0 = f->m->Q0;
+    a.ref = f->m->ref;
+    a.mean = f->m->mean;
+    a.M = f->m->M;
+    a.rp = f->m->rp;
+    a.state = f->st;
+    a.pose = f->pose;
+    a.c0[0] = f->m->c0[0];
+    a.c0[1] = f->m->c0[1];
+    a.c0[2] = f->m->c0[2];
+    a.partial = f->ws;
+    return a;
+}
+
+// fit = modelInstanceShapePoseScale(model, state)
+void refresh_fit(gingr_fitter *f) {
+    SweepArgs a = base_args(f);
+    a.coef0 = f->alpha;
+    a.shape_out = f->fit;
+    launch_sweep(f->ctx, SWEEP_FIT, a);
+}
+
+int model_finalize_impl(gingr_ctx *ctx, gingr_model *m) {
+    DevBuf work, flag;
+    HIP_TRY(ctx, work.alloc((size_t)m->rp * m->rp * sizeof(double)));
+    HIP_TRY(ctx, flag.alloc(sizeof(int32_t)));
+    launch_binv(ctx, m->r, m->rp, m->gramS, work.as<double>(), m->Binv, flag.as<int32_t>());
+    GINGR_TRY(check_launch(ctx));
+    int32_t err = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&err, flag.p, sizeof(err), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (err) return gingr_set_error(ctx, GINGR_ERR_NOT_SPD, "model finalize: Q^T Q / 1e-5 + I is not positive definite");
+    m->finalized = true;
+    return GINGR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ===================================================================================================== model
+int gingr_model_upload(gingr_ctx *ctx, int64_t M_total, int32_t rank, const double *ref, const double *mean,
+                       const double *basis_colmajor, const double *variance, int64_t row_begin, int64_t row_end,
+                       gingr_model **out) {
+    if (!ctx || !out) return GINGR_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    if (M_total < 1 || rank < 1 || rank > 512 || !ref || !mean || !basis_colmajor || !variance)
+        return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "model_upload: need M >= 1 and 1 <= rank <= 512");
+    if (row_begin < 0 || row_end > M_total || row_begin >= row_end)
+        return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "model_upload: bad row shard [%lld,%lld)", (long long)row_begin,
+                               (long long)row_end);
+    for (int32_t k = 0; k < rank; ++k)
+        if (!(variance[k] >= 0.0)) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "model_upload: variance[%d] < 0", k);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    gingr_model *m = new gingr_model();
+    m->ctx = ctx;
+    m->M_total = M_total;
+    m->row_begin = row_begin;
+    m->row_end = row_end;
+    m->M = row_end - row_begin;
+    m->r = rank;
+    m->rp = (int32_t)round_up(rank, 16);
+    const int64_t M = m->M;
+    // centroid of the full reference (identical on every shard)
+    double c[3] = {0, 0, 0};
+    for (int64_t i = 0; i < M_total; ++i) {
+        c[0] += ref[3 * i];
+        c[1] += ref[3 * i + 1];
+        c[2] += ref[3 * i + 2];
+    }
+    for (int d = 0; d < 3; ++d) m->c0[d] = c[d] / (double)M_total;
+
+    int rc = GINGR_OK;
+    DevBuf stage, var, aos;
+    auto fail = [&](int code) {
+        gingr_model_destroy(m);
+        return code;
+    };
+    if ((rc = dev_alloc(ctx, &m->Q0, (size_t)3 * M * m->rp)) || (rc = dev_alloc(ctx, &m->ref, (size_t)3 * M)) ||
+        (rc = dev_alloc(ctx, &m->mean, (size_t)3 * M)) || (rc = dev_alloc(ctx, &m->gramS, (size_t)m->rp * m->rp)) ||
+        (rc = dev_alloc(ctx, &m->Binv, (size_t)m->rp * m->rp)))
+        return fail(rc);
+    if (stage.alloc((size_t)3 * M * rank * sizeof(double)) != hipSuccess || var.alloc(rank * sizeof(double)) != hipSuccess ||
+        aos.alloc((size_t)3 * M * sizeof(double)) != hipSuccess)
+        return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: out of device memory"));
+    // basis: column k of the shard = rows [3*row_begin, 3*row_end) of host column k
+    if (hipMemcpy2DAsync(stage.p, (size_t)3 * M * sizeof(double), basis_colmajor + 3 * row_begin,
+                         (size_t)3 * M_total * sizeof(double), (size_t)3 * M * sizeof(double), (size_t)rank,
+                         hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: basis copy failed"));
+    (void)hipMemcpyAsync(var.p, variance, rank * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    launch_pack_basis(ctx, stage.as<double>(), var.as<double>(), M, rank, m->rp, m->Q0);
+    (void)hipMemcpyAsync(aos.p, ref + 3 * row_begin, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    launch_aos_to_soa(ctx, aos.as<double>(), M, m->ref);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemcpyAsync(aos.p, mean + 3 * row_begin, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    launch_aos_to_soa(ctx, aos.as<double>(), M, m->mean);
+    // S_local = Q0^T Q0 (unit weights)
+    DevBuf gws;
+    if (gws.alloc((size_t)gram_ws_doubles(M, m->rp) * sizeof(double)) != hipSuccess)
+        return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: out of device memory"));
+    launch_gram(ctx, m->Q0, M, m->rp, nullptr, gws.as<double>(), m->gramS);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: kernel launch failed"));
+    if (row_begin == 0 && row_end == M_total) {
+        rc = model_finalize_impl(ctx, m);
+        if (rc) return fail(rc);
+    }
+    *out = m;
+    return GINGR_OK;
+}
+
+void gingr_model_destroy(gingr_model *m) {
+    if (!m) return;
+    if (m->ctx) (void)hipSetDevice(m->ctx->device);
+    dev_free(m->Q0);
+    dev_free(m->ref);
+    dev_free(m->mean);
+    dev_free(m->gramS);
+    dev_free(m->Binv);
+    delete m;
+}
+
+int64_t gingr_model_num_points(const gingr_model *m) { return m ? m->M : 0; }
+int32_t gingr_model_rank(const gingr_model *m) { return m ? m->r : 0; }
+
+int gingr_model_gram_exchange(gingr_model *m, void **dev_ptr, int64_t *count) {
+    if (!m || !dev_ptr || !count) return GINGR_ERR_BAD_ARGUMENT;
+    *dev_ptr = m->gramS;
+    *count = (int64_t)m->rp * m->rp;
+    return GINGR_OK;
+}
+
+int gingr_model_finalize(gingr_ctx *ctx, gingr_model *m) {
+    if (!ctx || !m) return GINGR_ERR_BAD_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return model_finalize_impl(ctx, m);
+}
+
+// ===================================================================================================== fitter
+int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter **out) {
+    if (!ctx || !model || !out) return GINGR_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    if (!model->finalized)
+        return gingr_set_error(ctx, GINGR_ERR_STATE, "fitter_create: sharded model not finalized (gingr_model_finalize)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    gingr_fitter *f = new gingr_fitter();
+    f->ctx = ctx;
+    f->m = model;
+    const int64_t M = model->M;
+    const int32_t rp = model->rp;
+    int rc;
+    if ((rc = dev_alloc(ctx, &f->fit, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->P1, (size_t)M)) ||
+        (rc = dev_alloc(ctx, &f->PX, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->nn_idx, (size_t)M)) ||
+        (rc = dev_alloc(ctx, &f->nn_d2, (size_t)M)) || (rc = dev_alloc(ctx, &f->weight, (size_t)M)) ||
+        (rc = dev_alloc(ctx, &f->evec, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->newshape, (size_t)3 * M)) ||
+        (rc = dev_alloc(ctx, &f->alpha, (size_t)rp)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
+        (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->st, 1)) ||
+        (rc = dev_alloc(ctx, &f->pose, 1)) || (rc = dev_alloc(ctx, &f->hs_dev, 1)) ||
+        (rc = dev_alloc(ctx, &f->scalars, 8)) || (rc = dev_alloc(ctx, &f->work, (size_t)rp * rp)) ||
+        (rc = dev_alloc(ctx, &f->lm_mask, (size_t)M))) {
+        gingr_fitter_destroy(f);
+        return rc;
+    }
+    (void)hipMemsetAsync(f->lm_mask, 0, (size_t)M * sizeof(int32_t), ctx->stream);
+    (void)hipMemsetAsync(f->alpha, 0, (size_t)rp * sizeof(double), ctx->stream);
+    (void)hipMemsetAsync(f->scalars, 0, 8 * sizeof(double), ctx->stream);
+    *out = f;
+    return GINGR_OK;
+}
+
+void gingr_fitter_destroy(gingr_fitter *f) {
+    if (!f) return;
+    if (f->ctx) {
+        (void)hipSetDevice(f->ctx->device);
+        (void)hipStreamSynchronize(f->ctx->stream);
+    }
+    dev_free(f->target);
+    dev_free(f->inv_den);
+    dev_free(f->Pt1);
+    dev_free(f->fit);
+    dev_free(f->P1);
+    dev_free(f->PX);
+    dev_free(f->nn_idx);
+    dev_free(f->nn_d2);
+    dev_free(f->weight);
+    dev_free(f->evec);
+    dev_free(f->newshape);
+    dev_free(f->alpha);
+    dev_free(f->acoef);
+    dev_free(f->alpha_c);
+    dev_free(f->st);
+    dev_free(f->pose);
+    dev_free(f->hs_dev);
+    dev_free(f->scalars);
+    dev_free(f->xch);
+    dev_free(f->ws);
+    dev_free(f->work);
+    dev_free(f->aos);
+    dev_free(f->lm_pid);
+    dev_free(f->lm_xyz);
+    dev_free(f->lm_cov);
+    dev_free(f->lm_mask);
+    delete f;
+}
+
+int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = f->ctx;
+    if (N < 1 || N > INT32_MAX || !target_xyz) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_target: bad N");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t M = f->m->M;
+    const int32_t rp = f->m->rp;
+    dev_free(f->target);
+    dev_free(f->inv_den);
+    dev_free(f->Pt1);
+    dev_free(f->xch);
+    dev_free(f->ws);
+    dev_free(f->aos);
+    f->target = f->inv_den = f->Pt1 = f->xch = f->ws = nullptr;
+    f->aos = nullptr;
+    f->N = N;
+    GINGR_TRY(dev_alloc(ctx, &f->target, (size_t)3 * N));
+    GINGR_TRY(dev_alloc(ctx, &f->inv_den, (size_t)N));
+    GINGR_TRY(dev_alloc(ctx, &f->Pt1, (size_t)N));
+    // exchange segments (float64 elements)
+    f->cnt[0] = N;
+    f->cnt[1] = (int64_t)rp * rp + rp + 8;
+    f->cnt[2] = rp;
+    f->cnt[3] = 24;
+    f->cnt[4] = rp;
+    int64_t o = 0;
+    for (int s = 0; s < GINGR_NUM_SEGMENTS; ++s) {
+        f->off[s] = o;
+        o += round_up(f->cnt[s], 32);  // 256-byte aligned segments
+    }
+    GINGR_TRY(dev_alloc(ctx, &f->xch, (size_t)o));
+    HIP_TRY(ctx, hipMemsetAsync(f->xch, 0, (size_t)o * sizeof(double), ctx->stream));
+    int64_t w = cpd_colsum_ws_doubles(M, N);
+    auto mx = [&](int64_t v) {
+        if (v > w) w = v;
+    };
+    mx(cpd_rowstats_ws_doubles(M, N));
+    mx(ceil_div(nn_ws_bytes(M, N), 8));
+    mx(gram_ws_doubles(M, rp));
+    mx(sweep_ws_doubles(M, rp));
+    f->ws_doubles = w;
+    GINGR_TRY(dev_alloc(ctx, &f->ws, (size_t)w));
+    const int64_t big = M > N ? M : N;
+    double *aos = nullptr;
+    GINGR_TRY(dev_alloc(ctx, &aos, (size_t)3 * big));
+    f->aos = aos;
+    HIP_TRY(ctx, hipMemcpyAsync(aos, target_xyz, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    launch_aos_to_soa(ctx, aos, N, f->target);
+    GINGR_TRY(check_launch(ctx));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GINGR_OK;
+}
+
+int gingr_fitter_set_landmarks(gingr_fitter *f, int32_t n_lm, const int32_t *lm_pid, const double *lm_xyz,
+                               const double *lm_cov) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = f->ctx;
+    if (n_lm < 0 || (n_lm > 0 && (!lm_pid || !lm_xyz || !lm_cov)))
+        return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_landmarks: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    dev_free(f->lm_pid);
+    dev_free(f->lm_xyz);
+    dev_free(f->lm_cov);
+    f->lm_pid = nullptr;
+    f->lm_xyz = f->lm_cov = nullptr;
+    f->n_lm = n_lm;
+    const int64_t M = f->m->M;
+    std::vector<int32_t> mask((size_t)M, 0), local((size_t)(n_lm > 0 ? n_lm : 1), -1);
+    for (int32_t l = 0; l < n_lm; ++l) {
+        if (lm_pid[l] < 0 || lm_pid[l] >= f->m->M_total)
+            return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_landmarks: point id %d out of range", lm_pid[l]);
+        const int64_t lp = (int64_t)lm_pid[l] - f->m->row_begin;
+        if (lp >= 0 && lp < M) {
+            local[(size_t)l] = (int32_t)lp;
+            mask[(size_t)lp] = 1;
+        }
+    }
+    HIP_TRY(ctx, hipMemcpy(f->lm_mask, mask.data(), (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (n_lm > 0) {
+        GINGR_TRY(dev_alloc(ctx, &f->lm_pid, (size_t)n_lm));
+        GINGR_TRY(dev_alloc(ctx, &f->lm_xyz, (size_t)3 * n_lm));
+        GINGR_TRY(dev_alloc(ctx, &f->lm_cov, (size_t)9 * n_lm));
+        HIP_TRY(ctx, hipMemcpy(f->lm_pid, local.data(), (size_t)n_lm * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(f->lm_xyz, lm_xyz, (size_t)3 * n_lm * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(f->lm_cov, lm_cov, (size_t)9 * n_lm * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return GINGR_OK;
+}
+
+int gingr_fitter_set_options(gingr_fitter *f, int32_t global_transform, double step_length) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    if (global_transform < 0 || global_transform > 2)
+        return gingr_set_error(f->ctx, GINGR_ERR_BAD_ARGUMENT, "set_options: unknown global transformation %d", global_transform);
+    f->global_transform = global_transform;
+    f->step_length = step_length;
+    return GINGR_OK;
+}
+
+int gingr_fitter_set_state(gingr_fitter *f, const double *alpha, const gingr_state_scalars *s) {
+    if (!f || !alpha || !s) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = f->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int32_t r = f->m->r, rp = f->m->rp;
+    std::vector<double> a((size_t)rp, 0.0);
+    memcpy(a.data(), alpha, (size_t)r * sizeof(double));
+    HIP_TRY(ctx, hipMemcpyAsync(f->alpha, a.data(), (size_t)rp * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(f->hs_dev, s, sizeof(*s), hipMemcpyHostToDevice, ctx->stream));
+    launch_state_init(ctx, f->st, f->hs_dev);
+    if (!f->ws) {  // no target yet: allocate the sweep workspace so the fit can be instantiated
+        f->ws_doubles = sweep_ws_doubles(f->m->M, rp);
+        GINGR_TRY(dev_alloc(ctx, &f->ws, (size_t)f->ws_doubles));
+    }
+    refresh_fit(f);
+    GINGR_TRY(check_launch(ctx));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    f->has_state = true;
+    return GINGR_OK;
+}
+
+int gingr_fitter_get_state(gingr_fitter *f, double *alpha, gingr_state_scalars *s, double *fit_xyz) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = f->ctx;
+    if (!f->has_state) return gingr_set_error(ctx, GINGR_ERR_STATE, "get_state: no state set");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t M = f->m->M;
+    DevState hst;
+    HIP_TRY(ctx, hipMemcpyAsync(&hst, f->st, sizeof(hst), hipMemcpyDeviceToHost, ctx->stream));
+    if (alpha) HIP_TRY(ctx, hipMemcpyAsync(alpha, f->alpha, (size_t)f->m->r * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DevBuf tmp;
+    if (fit_xyz) {
+        HIP_TRY(ctx, tmp.alloc((size_t)3 * M * sizeof(double)));
+        launch_soa_to_aos(ctx, f->fit, M, tmp.as<double>());
+        HIP_TRY(ctx, hipMemcpyAsync(fit_xyz, tmp.p, (size_t)3 * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (s) {
+        for (int q = 0; q < 3; ++q) {
+            s->euler[q] = hst.euler[q];
+            s->center[q] = hst.center[q];
+            s->translation[q] = hst.t[q];
+        }
+        s->scale = hst.scale;
+        s->sigma2 = hst.sigma2;
+        s->iteration = hst.iteration;
+        s->status = hst.status;
+    }
+    return GINGR_OK;
+}
+
+int gingr_fitter_get_cpd_stats(gingr_fitter *f, double *P1, double *PX, double *den, double *scalars6) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = f->ctx;
+    if (!f->target) return gingr_set_error(ctx, GINGR_ERR_STATE, "get_cpd_stats: no target");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t M = f->m->M;
+    DevBuf tmp;
+    if (P1) HIP_TRY(ctx, hipMemcpyAsync(P1, f->P1, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (PX) {
+        HIP_TRY(ctx, tmp.alloc((size_t)3 * M * sizeof(double)));
+        launch_soa_to_aos(ctx, f->PX, M, tmp.as<double>());
+        HIP_TRY(ctx, hipMemcpyAsync(PX, tmp.p, (size_t)3 * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (den) HIP_TRY(ctx, hipMemcpyAsync(den, f->xch + f->off[0], (size_t)f->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    double sc[8];
+    const double *red = f->xch + f->off[1] + (int64_t)f->m->rp * f->m->rp + f->m->rp;
+    HIP_TRY(ctx, hipMemcpyAsync(sc, red, sizeof(sc), hipMemcpyDeviceToHost, ctx->stream));
+    double loc[8];
+    HIP_TRY(ctx, hipMemcpyAsync(loc, f->scalars, sizeof(loc), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (scalars6) {
+        scalars6[0] = sc[0];
+        scalars6[1] = sc[1];
+        scalars6[2] = sc[2];
+        scalars6[3] = sc[3];
+        scalars6[4] = (sc[1] - 2 * sc[2] + sc[3]) / (sc[0] * 3.0);
+        scalars6[5] = loc[5];
+    }
+    return GINGR_OK;
+}
+
+int gingr_fitter_get_icp_idx(gingr_fitter *f, int32_t *idx, double *d2) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = f->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t M = f->m->M;
+    if (idx) HIP_TRY(ctx, hipMemcpyAsync(idx, f->nn_idx, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (d2) HIP_TRY(ctx, hipMemcpyAsync(d2, f->nn_d2, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GINGR_OK;
+}
+
+int gingr_fitter_exchange(gingr_fitter *f, void **dev_ptr, int64_t offsets[GINGR_NUM_SEGMENTS],
+                          int64_t counts[GINGR_NUM_SEGMENTS]) {
+    if (!f || !dev_ptr) return GINGR_ERR_BAD_ARGUMENT;
+    if (!f->xch) return gingr_set_error(f->ctx, GINGR_ERR_STATE, "exchange: no target set");
+    *dev_ptr = f->xch;
+    for (int s = 0; s < GINGR_NUM_SEGMENTS; ++s) {
+        if (offsets) offsets[s] = f->off[s];
+        if (counts) counts[s] = f->cnt[s];
+    }
+    return GINGR_OK;
+}
+
+}  // extern "C"
+
+// --------------------------------------------------------------------------------------------------- phases
+namespace {
+
+int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr_icp_params *ip, int phase) {
+    gingr_ctx *ctx = f->ctx;
+    const gingr_model *m = f->m;
+    const int64_t M = m->M;
+    const int32_t r = m->r, rp = m->rp;
+    double *seg0 = f->xch + f->off[0];
+    double *G = f->xch + f->off[1];
+    double *rhs = G + (int64_t)rp * rp;
+    double *sc8 = rhs + rp;
+    double *seg2 = f->xch + f->off[2];
+    double *seg3 = f->xch + f->off[3];
+    double *seg4 = f->xch + f->off[4];
+    const Cloud fit = cloud_of(f->fit, M);
+    const Cloud tgt = cloud_of(f->target, f->N);
+    switch (phase) {
+        case 0: {
+            if (icp)
+                launch_nn(ctx, fit, tgt, f->ws, f->nn_idx, f->nn_d2);
+            else
+                launch_cpd_colsum(ctx, fit, tgt, &f->st->sigma2, f->ws, seg0);
+            break;
+        }
+        case 1: {
+            if (icp) {
+                launch_obs_icp(ctx, m, f->st, tgt, f->nn_idx, f->lm_mask, f->weight, f->evec);
+                hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(64), 0, ctx->stream, sc8, (int64_t)8);
+            } else {
+                launch_cpd_den_finalize(ctx, tgt, &f->st->sigma2, cp->w, m->M_total, seg0, f->inv_den, f->Pt1, f->scalars);
+                launch_cpd_rowstats(ctx, fit, tgt, &f->st->sigma2, f->inv_den, f->ws, f->P1, f->PX, f->scalars);
+                launch_obs_cpd(ctx, m, f->st, fit, f->P1, f->PX, cp->lambda, f->lm_mask, f->weight, f->evec);
+                hipLaunchKernelGGL(pack_scalars_kernel, dim3(1), dim3(64), 0, ctx->stream, f->scalars, m->row_begin == 0 ? 1 : 0,
+                                   sc8);
+            }
+            launch_gram(ctx, m->Q0, M, rp, f->weight, f->ws, G);
+            SweepArgs a = base_args(f);
+            a.evec = f->evec;
+            a.out = rhs;
+            launch_sweep(ctx, SWEEP_RHS, a);
+            launch_landmarks(ctx, m, f->st, f->n_lm, f->lm_pid, f->lm_xyz, f->lm_cov, G, rhs);
+            break;
+        }
+        case 2: {
+            launch_posterior_solve(ctx, r, rp, G, rhs, f->work, f->acoef, f->st);
+            SweepArgs a = base_args(f);
+            a.coef0 = f->acoef;
+            a.out = seg2;
+            launch_sweep(ctx, SWEEP_PROJ1, a);
+            break;
+        }
+        case 3: {
+            launch_alpha_blend(ctx, r, rp, m->Binv, seg2, f->alpha, f->step_length, f->alpha_c);
+            SweepArgs a = base_args(f);
+            a.coef0 = f->alpha_c;
+            a.coef1 = f->alpha;
+            a.shape_out = f->newshape;
+            a.out = seg3;
+            launch_sweep(ctx, SWEEP_SHAPES, a);
+            break;
+        }
+        case 4: {
+            launch_umeyama(ctx, seg3, m->M_total, m->c0, f->global_transform, f->pose, f->st);
+            SweepArgs a = base_args(f);
+            a.shape_in = f->newshape;
+            a.out = seg4;
+            launch_sweep(ctx, SWEEP_PROJ2, a);
+            break;
+        }
+        case 5: {
+            CommitArgs c;
+            memset(&c, 0, sizeof(c));
+            c.r = r;
+            c.rp = rp;
+            c.Binv = m->Binv;
+            c.p2 = seg4;
+            c.scalars = sc8;
+            c.is_icp = icp ? 1 : 0;
+            if (icp) {
+                c.icp_step = (ip->initial_sigma - ip->end_sigma) / (double)ip->max_iterations;  // ICP.scala:65
+                c.icp_end = ip->end_sigma;
+            }
+            c.alpha = f->alpha;
+            c.pose = f->pose;
+            c.state = f->st;
+            launch_commit(ctx, c);
+            refresh_fit(f);
+            break;
+        }
+        default:
+            return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "phase %d out of range", phase);
+    }
+    return check_launch(ctx);
+}
+
+int check_ready(gingr_fitter *f) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    if (!f->target) return gingr_set_error(f->ctx, GINGR_ERR_STATE, "update: no target set (gingr_fitter_set_target)");
+    if (!f->has_state) return gingr_set_error(f->ctx, GINGR_ERR_STATE, "update: no state set (gingr_fitter_set_state)");
+    if (hipSetDevice(f->ctx->device) != hipSuccess) return gingr_set_error(f->ctx, GINGR_ERR_HIP, "hipSetDevice failed");
+    return GINGR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gingr_fitter_cpd_phase_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t phase) {
+    GINGR_TRY(check_ready(f));
+    if (!p || !(p->w >= 0.0 && p->w < 1.0) || !(p->lambda > 0.0))
+        return gingr_set_error(f->ctx, GINGR_ERR_BAD_ARGUMENT, "cpd params: need 0 <= w < 1 and lambda > 0");
+    return run_phase(f, false, p, nullptr, phase);
+}
+
+int gingr_fitter_icp_phase_async(gingr_fitter *f, const gingr_icp_params *p, int32_t phase) {
+    GINGR_TRY(check_ready(f));
+    if (!p || p->max_iterations < 1) return gingr_set_error(f->ctx, GINGR_ERR_BAD_ARGUMENT, "icp params: max_iterations < 1");
+    return run_phase(f, true, nullptr, p, phase);
+}
+
+int gingr_fitter_update_cpd_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t n_iterations) {
+    GINGR_TRY(check_ready(f));
+    if (f->m->M != f->m->M_total)
+        return gingr_set_error(f->ctx, GINGR_ERR_STATE, "update_cpd_async: sharded model needs the phase API + exchange");
+    for (int32_t it = 0; it < n_iterations; ++it) {
+        TimerScope ts(f->ctx, 3);
+        for (int ph = 0; ph < GINGR_NUM_PHASES; ++ph) GINGR_TRY(gingr_fitter_cpd_phase_async(f, p, ph));
+    }
+    return GINGR_OK;
+}
+
+int gingr_fitter_update_icp_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations) {
+    GINGR_TRY(check_ready(f));
+    if (f->m->M != f->m->M_total)
+        return gingr_set_error(f->ctx, GINGR_ERR_STATE, "update_icp_async: sharded model needs the phase API + exchange");
+    for (int32_t it = 0; it < n_iterations; ++it) {
+        TimerScope ts(f->ctx, 3);
+        for (int ph = 0; ph < GINGR_NUM_PHASES; ++ph) GINGR_TRY(gingr_fitter_icp_phase_async(f, p, ph));
+    }
+    return GINGR_OK;
+}
+
+// ===================================================================================== stateless model operators
+static void fill_scalars(gingr_state_scalars *s, const double euler[3], const double center[3], const double translation[3],
+                         double scale) {
+    memset(s, 0, sizeof(*s));
+    for (int q = 0; q < 3; ++q) {
+        s->euler[q] = euler[q];
+        s->center[q] = center[q];
+        s->translation[q] = translation[q];
+    }
+    s->scale = scale;
+    s->sigma2 = 1.0;
+}
+
+int gingr_model_instance(gingr_ctx *ctx, const gingr_model *model, const double *alpha, const double euler[3],
+                         const double center[3], const double translation[3], double scale, double *out_xyz) {
+    if (!ctx || !model || !alpha || !euler || !center || !translation || !out_xyz) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_fitter *f = nullptr;
+    // a non-finalized shard can still be instantiated: bypass the finalize check through a local flag
+    gingr_model *mm = const_cast<gingr_model *>(model);
+    const bool was = mm->finalized;
+    mm->finalized = true;
+    int rc = gingr_fitter_create(ctx, model, &f);
+    mm->finalized = was;
+    if (rc) return rc;
+    gingr_state_scalars s;
+    fill_scalars(&s, euler, center, translation, scale);
+    rc = gingr_fitter_set_state(f, alpha, &s);
+    if (!rc) rc = gingr_fitter_get_state(f, nullptr, nullptr, out_xyz);
+    gingr_fitter_destroy(f);
+    return rc;
+}
+
+int gingr_model_coefficients(gingr_ctx *ctx, const gingr_model *model, const double euler[3], const double center[3],
+                             const double translation[3], const double *mesh_xyz, double *alpha) {
+    if (!ctx || !model || !euler || !center || !translation || !mesh_xyz || !alpha) return GINGR_ERR_BAD_ARGUMENT;
+    if (model->M != model->M_total)
+        return gingr_set_error(ctx, GINGR_ERR_STATE, "model_coefficients: single-shard models only");
+    gingr_fitter *f = nullptr;
+    GINGR_TRY(gingr_fitter_create(ctx, model, &f));
+    const int64_t M = model->M;
+    const int32_t r = model->r, rp = model->rp;
+    int rc = GINGR_OK;
+    std::vector<double> zero((size_t)r, 0.0);
+    gingr_state_scalars s;
+    fill_scalars(&s, euler, center, translation, 1.0);
+    rc = gingr_fitter_set_state(f, zero.data(), &s);
+    DevBuf aos, pose_h;
+    if (!rc && aos.alloc((size_t)3 * M * sizeof(double)) != hipSuccess) rc = gingr_set_error(ctx, GINGR_ERR_HIP, "out of memory");
+    if (!rc) {
+        (void)hipMemcpyAsync(aos.p, mesh_xyz, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        launch_aos_to_soa(ctx, aos.as<double>(), M, f->newshape);
+        // pose := the state's rigid transform
+        DevState hst;
+        (void)hipMemcpyAsync(&hst, f->st, sizeof(hst), hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        DevPose hp;
+        memcpy(hp.R, hst.R, sizeof(hp.R));
+        memcpy(hp.euler, hst.euler, sizeof(hp.euler));
+        memcpy(hp.t, hst.t, sizeof(hp.t));
+        memcpy(hp.center, hst.center, sizeof(hp.center));
+        hp.scale = 1.0;
+        (void)hipMemcpyAsync(f->pose, &hp, sizeof(hp), hipMemcpyHostToDevice, ctx->stream);
+        SweepArgs a = base_args(f);
+        a.shape_in = f->newshape;
+        a.out = f->acoef;
+        launch_sweep(ctx, SWEEP_PROJ2, a);
+        launch_coeff_solve(ctx, r, rp, model->Binv, f->acoef, f->alpha_c);
+        rc = check_launch(ctx);
+        if (!rc && hipMemcpyAsync(alpha, f->alpha_c, (size_t)r * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+            rc = gingr_set_error(ctx, GINGR_ERR_HIP, "copy failed");
+        (void)hipStreamSynchronize(ctx->stream);
+        if (!rc)
+            for (int32_t k = 0; k < r; ++k)
+                if (!std::isfinite(alpha[k])) {
+                    rc = gingr_set_error(ctx, GINGR_ERR_NONFINITE, "model_coefficients: non-finite coefficient");
+                    break;
+                }
+    }
+    gingr_fitter_destroy(f);
+    return rc;
+}
+
+int gingr_model_posterior_mean(gingr_ctx *ctx, const gingr_model *model, const double euler[3], const double center[3],
+                               const double translation[3], const double *obs_xyz, const double *weight, int32_t n_lm,
+                               const int32_t *lm_pid, const double *lm_xyz, const double *lm_cov, double *mean_xyz,
+                               double *coeffs) {
+    if (!ctx || !model || !euler || !center || !translation || !obs_xyz || !weight) return GINGR_ERR_BAD_ARGUMENT;
+    if (model->M != model->M_total)
+        return gingr_set_error(ctx, GINGR_ERR_STATE, "model_posterior_mean: single-shard models only");
+    gingr_fitter *f = nullptr;
+    GINGR_TRY(gingr_fitter_create(ctx, model, &f));
+    const int64_t M = model->M;
+    const int32_t r = model->r, rp = model->rp;
+    int rc = GINGR_OK;
+    std::vector<double> zero((size_t)r, 0.0);
+    gingr_state_scalars s;
+    fill_scalars(&s, euler, center, translation, 1.0);
+    rc = gingr_fitter_set_state(f, zero.data(), &s);
+    if (!rc) rc = gingr_fitter_set_landmarks(f, n_lm, lm_pid, lm_xyz, lm_cov);
+    DevBuf aos, obs, win, G, gws;
+    if (!rc && (aos.alloc((size_t)3 * M * sizeof(double)) != hipSuccess || obs.alloc((size_t)3 * M * sizeof(double)) != hipSuccess ||
+                win.alloc((size_t)M * sizeof(double)) != hipSuccess ||
+                G.alloc(((size_t)rp * rp + rp) * sizeof(double)) != hipSuccess ||
+                gws.alloc((size_t)gram_ws_doubles(M, rp) * sizeof(double)) != hipSuccess))
+        rc = gingr_set_error(ctx, GINGR_ERR_HIP, "out of memory");
+    if (!rc) {
+        std::vector<double> wh((size_t)M);
+        for (int64_t i = 0; i < M; ++i) wh[(size_t)i] = weight[i];
+        for (int32_t l = 0; l < n_lm; ++l) wh[(size_t)lm_pid[l]] = 0.0;  // landmark pids carry weight 0
+        (void)hipMemcpyAsync(aos.p, obs_xyz, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        launch_aos_to_soa(ctx, aos.as<double>(), M, obs.as<double>());
+        (void)hipMemcpyAsync(win.p, wh.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        launch_obs_points(ctx, model, f->st, obs.as<double>(), win.as<double>(), f->weight, f->evec);
+        double *Gd = G.as<double>(), *rhs = Gd + (int64_t)rp * rp;
+        launch_gram(ctx, model->Q0, M, rp, f->weight, gws.as<double>(), Gd);
+        SweepArgs a = base_args(f);
+        a.evec = f->evec;
+        a.out = rhs;
+        launch_sweep(ctx, SWEEP_RHS, a);
+        launch_landmarks(ctx, model, f->st, f->n_lm, f->lm_pid, f->lm_xyz, f->lm_cov, Gd, rhs);
+        launch_posterior_solve(ctx, r, rp, Gd, rhs, f->work, f->acoef, f->st);
+        SweepArgs b = base_args(f);
+        b.coef0 = f->acoef;
+        b.shape_out = f->newshape;
+        launch_sweep(ctx, SWEEP_POSED, b);
+        launch_soa_to_aos(ctx, f->newshape, M, aos.as<double>());
+        rc = check_launch(ctx);
+        DevState hst;
+        (void)hipMemcpyAsync(&hst, f->st, sizeof(hst), hipMemcpyDeviceToHost, ctx->stream);
+        if (mean_xyz) (void)hipMemcpyAsync(mean_xyz, aos.p, (size_t)3 * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (coeffs) (void)hipMemcpyAsync(coeffs, f->acoef, (size_t)r * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = gingr_set_error(ctx, GINGR_ERR_HIP, "synchronize failed");
+        if (!rc && hst.err) rc = gingr_set_error(ctx, hst.err, "model_posterior_mean: posterior solve failed (%s)",
+                                                  hst.err == GINGR_ERR_NOT_SPD ? "not SPD" : "non-finite");
+    }
+    gingr_fitter_destroy(f);
+    return rc;
+}
+
+}  // extern "C"

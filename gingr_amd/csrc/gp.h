@@ -1,0 +1,129 @@
+// Low-rank GP kernels (gp.hip): device data structures and launchers.  Internal to libgingr_hip.so.
+#pragma once
+
+#include "common.h"
+
+// Regularisation of PointDistributionModel.coefficients (scalismo DiscreteLowRankGaussianProcess.coefficients:
+// "val sigma2 = 1e-5"); reached from G/api/GingrAlgorithm.scala:215,236.
+#define GINGR_COEFF_NOISE 1e-5
+
+// Device-resident pose/state scalars.  R is always euler_to_rot(euler) (the reference rebuilds Rotation(phi,theta,psi)
+// from the stored Euler angles every iteration, G/api/ModelFittingParameters.scala:39-41,60-64).
+struct DevState {
+    double R[9];  // row-major
+    double euler[3];
+    double center[3];
+    double t[3];
+    double scale;
+    double sigma2;
+    int32_t iteration;
+    int32_t status;  // gingr_fitting_status
+    int32_t err;     // sticky numerical-failure flag of the CURRENT update (0 ok, GINGR_ERR_NONFINITE, GINGR_ERR_NOT_SPD)
+    int32_t pad;
+};
+
+// Candidate global alignment produced by the Umeyama step (R2 went through the Euler parameterisation).
+struct DevPose {
+    double R[9];
+    double euler[3];
+    double t[3];
+    double center[3];
+    double scale;
+};
+
+struct gingr_model {
+    gingr_ctx *ctx = nullptr;
+    int64_t M_total = 0, row_begin = 0, row_end = 0, M = 0;  // M = local points
+    int32_t r = 0, rp = 0;                                    // rank and rank padded to a multiple of 16
+    double *Q0 = nullptr;     // [3M][rp] row-major, Q0[row][k] = U[row][k] * sqrt(lambda_k), zero padded
+    double *ref = nullptr;    // SoA [3][M]
+    double *mean = nullptr;   // SoA [3][M]
+    double *gramS = nullptr;  // [rp*rp] local Q0^T Q0 until finalize (exchange buffer for the one-off all-reduce)
+    double *Binv = nullptr;   // [rp*rp] (S/eps + I)^-1, valid after finalize
+    double c0[3] = {0, 0, 0};  // centroid of the FULL reference: fixed centring point of the Umeyama partial sums
+    bool finalized = false;
+};
+
+// ---- basis sweeps ------------------------------------------------------------------------------------------
+enum SweepMode {
+    SWEEP_RHS = 0,      // T only: out[k] = sum_i Q0_i^T e_i, e from evec planes
+    SWEEP_PROJ1 = 1,    // F(a) then T with e = Q0_i a
+    SWEEP_SHAPES = 2,   // F(alpha_c, alpha): newshape planes + Umeyama partial sums
+    SWEEP_PROJ2 = 3,    // T: e = R2^T (newshape - t2) - ref - mean
+    SWEEP_FIT = 4,      // F(alpha): xyz = s (R (ref + mean + v - c) + c + t) from DevState
+    SWEEP_POSED = 5     // F(a): xyz = R (ref + mean + v - c) + c + t  (posterior mean mesh; no scale)
+};
+
+struct SweepArgs {
+    const double *Q0;
+    const double *ref;
+    const double *mean;
+    int64_t M;
+    int32_t rp;
+    const double *coef0;   // forward coefficient vector(s), [rp] each
+    const double *coef1;
+    const double *evec;    // SoA [3][M] (SWEEP_RHS)
+    const double *shape_in;  // SoA [3][M] (SWEEP_PROJ2)
+    double *shape_out;     // SoA [3][M] (SWEEP_SHAPES: newshape; SWEEP_FIT / SWEEP_POSED: result)
+    const DevState *state;
+    const DevPose *pose;
+    double c0[3];
+    double *partial;       // [nblocks][rp] transposed partials or [nblocks][24] Umeyama partials
+    double *out;           // reduced result: [rp] or [24]
+};
+
+int sweep_num_blocks(int64_t M);
+int64_t sweep_ws_doubles(int64_t M, int32_t rp);
+void launch_sweep(gingr_ctx *ctx, SweepMode mode, const SweepArgs &a);
+
+// ---- weighted Gram (MFMA f64) -----------------------------------------------------------------------------
+int64_t gram_ws_doubles(int64_t M, int32_t rp);
+// G[rp*rp] (full symmetric) = sum_i w_i Q0_i^T Q0_i over local points; weight == nullptr means w = 1
+void launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, double *G);
+
+// ---- observations ------------------------------------------------------------------------------------------
+// CPD: yhat = y + (PX/P1 - y), weight = 1/(sigma2*lambda/P1)  (CPD.scala:37-46,126); e = w (R^T(yhat - c - t) - (ref - c) - mean)
+void launch_obs_cpd(gingr_ctx *ctx, const gingr_model *m, const DevState *st, Cloud fit, const double *P1,
+                    const double *PX, double lambda, const int32_t *lm_mask, double *weight, double *evec);
+// ICP: obs = target[idx], weight = 1/sigma2  (ICP.scala:90-92)
+void launch_obs_icp(gingr_ctx *ctx, const gingr_model *m, const DevState *st, Cloud target, const int32_t *idx,
+                    const int32_t *lm_mask, double *weight, double *evec);
+// generic: obs points given as SoA planes with per-point weights
+void launch_obs_points(gingr_ctx *ctx, const gingr_model *m, const DevState *st, const double *obs_soa,
+                       const double *weight_in, double *weight, double *evec);
+// landmarks with full 3x3 covariance added into G and rhs of the (reduced) exchange segment; local pids, local rows only
+void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, int32_t n_lm, const int32_t *lm_pid_local,
+                      const double *lm_xyz, const double *lm_cov, double *G, double *rhs);
+
+// ---- small dense kernels ------------------------------------------------------------------------------------
+// a = (I + G)^-1 rhs  by Cholesky (work: [rp*rp]); sets st->err on failure
+void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, double *work,
+                            double *a, DevState *st);
+// Binv = (S/eps + I)^-1  (work: [rp*rp]); *err_flag != 0 on failure
+void launch_binv(gingr_ctx *ctx, int32_t r, int32_t rp, const double *S, double *work, double *Binv, int32_t *err_flag);
+// alpha1 = Binv (p/eps); alpha_c = alpha + (alpha1 - alpha) * step      GingrAlgorithm.scala:218-220
+void launch_alpha_blend(gingr_ctx *ctx, int32_t r, int32_t rp, const double *Binv, const double *p, const double *alpha,
+                        double step, double *alpha_c);
+// out = Binv (p/eps)
+void launch_coeff_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *Binv, const double *p, double *out);
+// Umeyama from the 24 partial sums (count = M_total); writes the candidate pose
+void launch_umeyama(gingr_ctx *ctx, const double *sums, int64_t M_total, const double c0[3], int32_t global_transform,
+                    DevPose *pose, DevState *st);
+// commit: alpha' = Binv (p2/eps); accept or keep; sigma2 from scalars (CPD) or schedule (ICP); iteration++
+struct CommitArgs {
+    int32_t r, rp;
+    const double *Binv;
+    const double *p2;
+    const double *scalars;  // reduced {Np, xPx, trPXY, yPy,...} or nullptr for ICP
+    int32_t is_icp;
+    double icp_step, icp_end;
+    double *alpha;          // in/out
+    const DevPose *pose;
+    DevState *state;
+};
+void launch_commit(gingr_ctx *ctx, const CommitArgs &a);
+void launch_state_init(gingr_ctx *ctx, DevState *st, const gingr_state_scalars *host_scalars_dev);
+
+// basis packing: stage is column-major [r][3M] (local rows), out Q0 [3M][rp]
+void launch_pack_basis(gingr_ctx *ctx, const double *stage_colmajor, const double *variance_dev, int64_t M, int32_t r,
+                       int32_t rp, double *Q0);

@@ -1,0 +1,906 @@
+// Low-rank Gaussian-process kernels of the GiNGR update for gfx950 (MI355X).
+//
+// What they replace (the arithmetic lives in scalismo 1.0-RC1, reached from G/api/GingrAlgorithm.scala):
+//   gram_kernel       Q^T L Q of DiscreteLowRankGaussianProcess.regression (GingrAlgorithm.scala:300) -- the only
+//                     GEMM-shaped op of the path; float64 MFMA (v_mfma_f64_16x16x4_f64), split over row slabs
+//   sweep_kernel      every pass over the 3M x r basis: Q^T L (y - m) (:300), coefficients (:215,236),
+//                     instance (:222,224, ModelFittingParameters.scala:134), Umeyama partial sums (:260-279);
+//                     HBM-bound streaming of Q0, fused with the pose / projection epilogues
+//   posterior_solve   pinv(QtL Q + I) * QtL (y - m)  -> Cholesky solve of the SPD matrix I + G
+//   umeyama_kernel    LandmarkRegistration.rigid3D/similarity3DLandmarkRegistration (3x3 SVD + Euler round trip)
+//   commit_kernel     the state hand-over of update (:239-246) incl. the Try-failure path (:194-208,248,251)
+//
+// Layout: Q0 is row-major [3M][rp]: the 3 x rp block of one point is contiguous (2.7 KB at r = 100), so one point's
+// observation weight, rotation and epilogue touch one contiguous block; rp = rank rounded up to 16 (MFMA tile).
+// All reductions across workgroups go through per-block partials combined in a fixed order (bitwise reproducible).
+#include "gp.h"
+
+namespace {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------ rotation conventions
+// scalismo RotationSpace3D: R = Rz(phi) Ry(theta) Rx(psi) ("x-convention"), and Slabaugh's inverse.
+__host__ __device__ inline void euler_to_rot(const double e[3], double R[9]) {
+    const double cphi = cos(e[0]), sphi = sin(e[0]);
+    const double cth = cos(e[1]), sth = sin(e[1]);
+    const double cpsi = cos(e[2]), spsi = sin(e[2]);
+    R[0] = cth * cphi;
+    R[1] = spsi * sth * cphi - cpsi * sphi;
+    R[2] = spsi * sphi + cpsi * sth * cphi;
+    R[3] = cth * sphi;
+    R[4] = cpsi * cphi + spsi * sth * sphi;
+    R[5] = cpsi * sth * sphi - spsi * cphi;
+    R[6] = -sth;
+    R[7] = spsi * cth;
+    R[8] = cpsi * cth;
+}
+
+__host__ __device__ inline void rot_to_euler(const double R[9], double e[3]) {
+    if (fabs(fabs(R[6]) - 1) > 0.0001) {
+        const double theta = asin(-R[6]);
+        const double ct = cos(theta);
+        e[2] = atan2(R[7] / ct, R[8] / ct);
+        e[0] = atan2(R[3] / ct, R[0] / ct);
+        e[1] = theta;
+    } else {
+        e[0] = 0.0;  // gimbal lock: phi := 0
+        if (fabs(R[6] + 1) < 0.0001) {
+            e[1] = 3.14159265358979323846 / 2.0;
+            e[2] = e[0] + atan2(R[1], R[2]);
+        } else {
+            e[1] = -3.14159265358979323846 / 2.0;
+            e[2] = -e[0] + atan2(-R[1], -R[2]);
+        }
+    }
+}
+
+__device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= 1.79769313486231570815e308; }
+
+// ------------------------------------------------------------------------------------------------- basis packing
+__global__ void pack_basis_kernel(const double *__restrict__ stage, const double *__restrict__ variance, int64_t rows,
+                                  int32_t r, int32_t rp, double *__restrict__ Q0) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * rp) return;
+    const int64_t row = idx / rp;
+    const int32_t k = (int32_t)(idx - row * rp);
+    // Q(i, j) = eigenvector * sqrt(eigenvalue)   (scalismo genericRegressionComputations)
+    Q0[idx] = k < r ? stage[(int64_t)k * rows + row] * sqrt(variance[k]) : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------- basis sweeps
+constexpr int kSweepThreads = 256;
+constexpr int kGroups = kSweepThreads / 16;  // points per block step
+constexpr int kSweepMaxBlocks = 1024;
+
+__device__ __forceinline__ double group16_sum(double v) {
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+template <int MODE, int KMAX>
+__global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepArgs a) {
+    constexpr bool FWD = (MODE == SWEEP_PROJ1 || MODE == SWEEP_SHAPES || MODE == SWEEP_FIT || MODE == SWEEP_POSED);
+    constexpr bool FWD2 = (MODE == SWEEP_SHAPES);
+    constexpr bool TRANS = (MODE == SWEEP_RHS || MODE == SWEEP_PROJ1 || MODE == SWEEP_PROJ2);
+    extern __shared__ double lds[];  // [2*rp] coefficients, then [kGroups*rp] reduction scratch
+    const int tid = threadIdx.x, lane16 = tid & 15, grp = tid >> 4;
+    const int rp = a.rp, km = rp >> 4;
+    const int64_t M = a.M;
+    double *coef = lds;
+    double *red = lds + 2 * rp;
+    if (FWD) {
+        for (int k = tid; k < rp; k += kSweepThreads) {
+            coef[k] = a.coef0[k];
+            if (FWD2) coef[rp + k] = a.coef1[k];
+        }
+        __syncthreads();
+    }
+    // pose scalars (wave-uniform loads)
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tr[3] = {0, 0, 0}, cen[3] = {0, 0, 0}, scale = 1.0;
+    if (MODE == SWEEP_SHAPES || MODE == SWEEP_FIT || MODE == SWEEP_POSED) {
+        for (int q = 0; q < 9; ++q) R[q] = a.state->R[q];
+        for (int q = 0; q < 3; ++q) {
+            tr[q] = a.state->t[q];
+            cen[q] = a.state->center[q];
+        }
+        scale = a.state->scale;
+    } else if (MODE == SWEEP_PROJ2) {
+        for (int q = 0; q < 9; ++q) R[q] = a.pose->R[q];
+        for (int q = 0; q < 3; ++q) {
+            tr[q] = a.pose->t[q];
+            cen[q] = a.pose->center[q];
+        }
+    }
+    double acc[KMAX];
+#pragma unroll
+    for (int m = 0; m < KMAX; ++m) acc[m] = 0.0;
+    double us[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) us[s] = 0.0;
+
+    for (int64_t base = (int64_t)blockIdx.x * kGroups; base < M; base += (int64_t)gridDim.x * kGroups) {
+        const int64_t p = base + grp;
+        const bool valid = p < M;
+        const int64_t pc = valid ? p : 0;
+        const double *q0 = a.Q0 + (3 * pc) * rp + lane16;
+        const double *q1 = q0 + rp;
+        const double *q2 = q1 + rp;
+        double f0[3] = {0, 0, 0}, f1[3] = {0, 0, 0};
+        if (FWD) {
+#pragma unroll 4
+            for (int m = 0; m < km; ++m) {
+                const int k = m * 16;
+                const double c0 = coef[k + lane16];
+                const double u0 = q0[k], u1 = q1[k], u2 = q2[k];
+                f0[0] = __builtin_fma(u0, c0, f0[0]);
+                f0[1] = __builtin_fma(u1, c0, f0[1]);
+                f0[2] = __builtin_fma(u2, c0, f0[2]);
+                if (FWD2) {
+                    const double c1 = coef[rp + k + lane16];
+                    f1[0] = __builtin_fma(u0, c1, f1[0]);
+                    f1[1] = __builtin_fma(u1, c1, f1[1]);
+                    f1[2] = __builtin_fma(u2, c1, f1[2]);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                f0[d] = group16_sum(f0[d]);
+                if (FWD2) f1[d] = group16_sum(f1[d]);
+            }
+        }
+        double e[3] = {0, 0, 0};
+        const double rx = a.ref[pc], ry = a.ref[M + pc], rz = a.ref[2 * M + pc];
+        const double mx = a.mean[pc], my = a.mean[M + pc], mz = a.mean[2 * M + pc];
+        if (MODE == SWEEP_RHS) {
+            e[0] = a.evec[pc];
+            e[1] = a.evec[M + pc];
+            e[2] = a.evec[2 * M + pc];
+        } else if (MODE == SWEEP_PROJ1) {
+            // shape - ref' - mean' = R (Q0_i a); projecting back multiplies by R^T: e = Q0_i a
+            e[0] = f0[0];
+            e[1] = f0[1];
+            e[2] = f0[2];
+        } else if (MODE == SWEEP_SHAPES) {
+            // newshape = R (ref + mean + Q0_i alpha_c - c) + c + t      (transformedModelInit.instance, :222)
+            // cur0     = ref + mean + Q0_i alpha                        (model.instance, :224)
+            const double ix = rx + mx + f0[0] - cen[0], iy = ry + my + f0[1] - cen[1], iz = rz + mz + f0[2] - cen[2];
+            const double nx = R[0] * ix + R[1] * iy + R[2] * iz + cen[0] + tr[0];
+            const double ny = R[3] * ix + R[4] * iy + R[5] * iz + cen[1] + tr[1];
+            const double nz = R[6] * ix + R[7] * iy + R[8] * iz + cen[2] + tr[2];
+            if (valid && lane16 == 0) {
+                a.shape_out[p] = nx;
+                a.shape_out[M + p] = ny;
+                a.shape_out[2 * M + p] = nz;
+                const double x0 = rx + mx + f1[0] - a.c0[0], x1 = ry + my + f1[1] - a.c0[1], x2 = rz + mz + f1[2] - a.c0[2];
+                const double y0 = nx - a.c0[0], y1 = ny - a.c0[1], y2 = nz - a.c0[2];
+                us[0] += x0; us[1] += x1; us[2] += x2;
+                us[3] += y0; us[4] += y1; us[5] += y2;
+                us[6] += y0 * x0; us[7] += y0 * x1; us[8] += y0 * x2;
+                us[9] += y1 * x0; us[10] += y1 * x1; us[11] += y1 * x2;
+                us[12] += y2 * x0; us[13] += y2 * x1; us[14] += y2 * x2;
+                us[15] += x0 * x0 + x1 * x1 + x2 * x2;
+            }
+        } else if (MODE == SWEEP_PROJ2) {
+            // newshape - (R2 ref + t2) - R2 mean, rotated back by R2^T      (transformedModel.coefficients, :234-237)
+            const double sx = a.shape_in[pc] - cen[0] - tr[0], sy = a.shape_in[M + pc] - cen[1] - tr[1],
+                         sz = a.shape_in[2 * M + pc] - cen[2] - tr[2];
+            e[0] = R[0] * sx + R[3] * sy + R[6] * sz - (rx - cen[0]) - mx;
+            e[1] = R[1] * sx + R[4] * sy + R[7] * sz - (ry - cen[1]) - my;
+            e[2] = R[2] * sx + R[5] * sy + R[8] * sz - (rz - cen[2]) - mz;
+        } else if (MODE == SWEEP_FIT || MODE == SWEEP_POSED) {
+            // fit = s * (R (inst - c) + c + t)       ModelFittingParameters.scala:130-143
+            const double ix = rx + mx + f0[0] - cen[0], iy = ry + my + f0[1] - cen[1], iz = rz + mz + f0[2] - cen[2];
+            const double nx = R[0] * ix + R[1] * iy + R[2] * iz + cen[0] + tr[0];
+            const double ny = R[3] * ix + R[4] * iy + R[5] * iz + cen[1] + tr[1];
+            const double nz = R[6] * ix + R[7] * iy + R[8] * iz + cen[2] + tr[2];
+            if (valid && lane16 == 0) {
+                const double s = (MODE == SWEEP_FIT) ? scale : 1.0;
+                a.shape_out[p] = s * nx;
+                a.shape_out[M + p] = s * ny;
+                a.shape_out[2 * M + p] = s * nz;
+            }
+        }
+        if (TRANS) {
+            if (!valid) e[0] = e[1] = e[2] = 0.0;
+#pragma unroll
+            for (int m = 0; m < KMAX; ++m) {
+                if (m < km) {
+                    const int k = m * 16;
+                    acc[m] = __builtin_fma(q0[k], e[0], __builtin_fma(q1[k], e[1], __builtin_fma(q2[k], e[2], acc[m])));
+                }
+            }
+        }
+    }
+    if (TRANS) {
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < KMAX; ++m)
+            if (m < km) red[grp * rp + m * 16 + lane16] = acc[m];
+        __syncthreads();
+        for (int k = tid; k < rp; k += kSweepThreads) {
+            double s = 0.0;
+            for (int g = 0; g < kGroups; ++g) s += red[g * rp + k];
+            a.partial[(int64_t)blockIdx.x * rp + k] = s;
+        }
+    }
+    if (MODE == SWEEP_SHAPES) {
+        __syncthreads();
+        if (lane16 == 0)
+            for (int s = 0; s < 16; ++s) red[grp * 16 + s] = us[s];
+        __syncthreads();
+        if (tid < 24) {
+            double s = 0.0;
+            if (tid < 16)
+                for (int g = 0; g < kGroups; ++g) s += red[g * 16 + tid];
+            a.partial[(int64_t)blockIdx.x * 24 + tid] = s;
+        }
+    }
+}
+
+// out[k] = sum over blocks (ascending) of partial[b][k]
+__global__ void block_partials_reduce_kernel(const double *__restrict__ partial, int nblocks, int width,
+                                             double *__restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= width) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * width + k];
+    out[k] = s;
+}
+
+// ------------------------------------------------------------------------------------------------- weighted Gram
+// One wave per workgroup computes a 64x64 patch (4x4 MFMA tiles) of G over one slab of rows:
+//   D(16x16) += A(16x4) B(4x16),  A[i][k] = w_row * Q0[row0+k][a0+i],  B[k][j] = Q0[row0+k][b0+j]
+// lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]: both are Q0[row0 + (l>>4)][col0 + (l&15)], i.e. four
+// 128-byte row segments per load instruction.  D: lane holds col j = l&15, rows i = (l>>4) + 4*reg.
+__global__ __launch_bounds__(64) void gram_kernel(const double *__restrict__ Q0, int64_t rows, int rp,
+                                                  const double *__restrict__ weight, int64_t rows_per_slab, int nbp,
+                                                  double *__restrict__ partial) {
+    // triangular patch index -> (pa <= pb)
+    int pa = 0, pb = 0;
+    {
+        int t = blockIdx.y;
+        for (pa = 0; pa < nbp; ++pa) {
+            const int cnt = nbp - pa;
+            if (t < cnt) {
+                pb = pa + t;
+                break;
+            }
+            t -= cnt;
+        }
+    }
+    const int lane = threadIdx.x, kq = lane >> 4, cl = lane & 15;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
+    const int64_t r1 = min(rows, r0 + rows_per_slab);
+    v4f64 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = v4f64{0, 0, 0, 0};
+    bool va[4], vb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        va[t] = pa * 64 + 16 * t < rp;
+        vb[t] = pb * 64 + 16 * t < rp;
+    }
+    for (int64_t row = r0; row < r1; row += 4) {
+        const int64_t rr = row + kq;
+        const bool valid = rr < r1;
+        const int64_t rc = valid ? rr : r0;
+        const double wv = valid ? (weight ? weight[rc / 3] : 1.0) : 0.0;
+        const double *base = Q0 + rc * rp + cl;
+        double fa[4], fb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            fa[t] = va[t] ? base[pa * 64 + 16 * t] * wv : 0.0;
+            fb[t] = (vb[t] && valid) ? base[pb * 64 + 16 * t] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (va[i] && vb[j]) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    double *out = partial + (int64_t)blockIdx.x * rp * rp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (va[i] && vb[j]) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int gi = pa * 64 + 16 * i + kq + 4 * reg;
+                    const int gj = pb * 64 + 16 * j + cl;
+                    out[(int64_t)gi * rp + gj] = acc[i][j][reg];
+                }
+            }
+}
+
+// G[i][j] (i <= j taken from the upper patches, mirrored) = sum over slabs in ascending order
+__global__ void gram_reduce_kernel(const double *__restrict__ partial, int nslabs, int rp, double *__restrict__ G) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rp * rp) return;
+    const int i = idx / rp, j = idx - i * rp;
+    if (i > j) return;
+    double s = 0.0;
+    for (int b = 0; b < nslabs; ++b) s += partial[(int64_t)b * rp * rp + idx];
+    G[i * rp + j] = s;
+    G[j * rp + i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------- observations
+__global__ void obs_cpd_kernel(const double *__restrict__ ref, const double *__restrict__ mean, int64_t M,
+                               const DevState *__restrict__ st, Cloud fit, const double *__restrict__ P1,
+                               const double *__restrict__ PX, double lambda, const int32_t *__restrict__ lm_mask,
+                               double *__restrict__ weight, double *__restrict__ evec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    if (lm_mask && lm_mask[i]) {  // point overridden by a landmark observation (GingrAlgorithm.scala:289-292)
+        weight[i] = 0.0;
+        evec[i] = evec[M + i] = evec[2 * M + i] = 0.0;
+        return;
+    }
+    const double p1inv = 1.0 / P1[i];                         // CPD.scala:37
+    const double yx = fit.x[i], yy = fit.y[i], yz = fit.z[i];
+    // td = y + (sum_j P1inv*P_ij*x_j - y)                     CPD.scala:44-46
+    const double ox = yx + (PX[i] * p1inv - yx), oy = yy + (PX[M + i] * p1inv - yy), oz = yz + (PX[2 * M + i] * p1inv - yz);
+    const double var = st->sigma2 * lambda * p1inv;           // CPD.scala:126
+    const double w = 1.0 / var;
+    const double *R = st->R;
+    const double dx = ox - st->center[0] - st->t[0], dy = oy - st->center[1] - st->t[1], dz = oz - st->center[2] - st->t[2];
+    const double ex = R[0] * dx + R[3] * dy + R[6] * dz - (ref[i] - st->center[0]) - mean[i];
+    const double ey = R[1] * dx + R[4] * dy + R[7] * dz - (ref[M + i] - st->center[1]) - mean[M + i];
+    const double ez = R[2] * dx + R[5] * dy + R[8] * dz - (ref[2 * M + i] - st->center[2]) - mean[2 * M + i];
+    weight[i] = w;
+    evec[i] = w * ex;
+    evec[M + i] = w * ey;
+    evec[2 * M + i] = w * ez;
+}
+
+// obs point given explicitly (planes ox/oy/oz), weight given or derived from sigma2 (ICP)
+__global__ void obs_points_kernel(const double *__restrict__ ref, const double *__restrict__ mean, int64_t M,
+                                  const DevState *__restrict__ st, const double *__restrict__ obs, Cloud target,
+                                  const int32_t *__restrict__ idx, const double *__restrict__ weight_in,
+                                  const int32_t *__restrict__ lm_mask, double *__restrict__ weight,
+                                  double *__restrict__ evec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    double w;
+    double ox, oy, oz;
+    if (idx) {  // ICP: closest target point, cov = I3 * sigma2 (ICP.scala:90-92)
+        const int32_t j = idx[i];
+        ox = target.x[j];
+        oy = target.y[j];
+        oz = target.z[j];
+        w = 1.0 / st->sigma2;
+    } else {
+        ox = obs[i];
+        oy = obs[M + i];
+        oz = obs[2 * M + i];
+        w = weight_in[i];
+    }
+    if ((lm_mask && lm_mask[i]) || w == 0.0) {
+        weight[i] = 0.0;
+        evec[i] = evec[M + i] = evec[2 * M + i] = 0.0;
+        return;
+    }
+    const double *R = st->R;
+    const double dx = ox - st->center[0] - st->t[0], dy = oy - st->center[1] - st->t[1], dz = oz - st->center[2] - st->t[2];
+    const double ex = R[0] * dx + R[3] * dy + R[6] * dz - (ref[i] - st->center[0]) - mean[i];
+    const double ey = R[1] * dx + R[4] * dy + R[7] * dz - (ref[M + i] - st->center[1]) - mean[M + i];
+    const double ez = R[2] * dx + R[5] * dy + R[8] * dz - (ref[2 * M + i] - st->center[2]) - mean[2 * M + i];
+    weight[i] = w;
+    evec[i] = w * ex;
+    evec[M + i] = w * ey;
+    evec[2 * M + i] = w * ez;
+}
+
+// Landmark observations with a full 3x3 covariance: QtL block = Q_p^T Sigma^-1 in the posed frame, i.e.
+// W = R^T Sigma^-1 R in the model frame.  One block, landmarks applied sequentially (fixed order).
+__global__ __launch_bounds__(256) void landmarks_kernel(const double *__restrict__ Q0, const double *__restrict__ ref,
+                                                        const double *__restrict__ mean, int64_t M, int rp,
+                                                        const DevState *__restrict__ st, int n_lm,
+                                                        const int32_t *__restrict__ pid, const double *__restrict__ xyz,
+                                                        const double *__restrict__ cov, double *__restrict__ G,
+                                                        double *__restrict__ rhs) {
+    __shared__ double W[9], Wv[3];
+    for (int l = 0; l < n_lm; ++l) {
+        const int32_t p = pid[l];
+        if (p < 0 || p >= M) continue;  // owned by another shard
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double *C = cov + 9 * l;
+            const double det = C[0] * (C[4] * C[8] - C[5] * C[7]) - C[1] * (C[3] * C[8] - C[5] * C[6]) +
+                               C[2] * (C[3] * C[7] - C[4] * C[6]);
+            double Ci[9];
+            Ci[0] = (C[4] * C[8] - C[5] * C[7]) / det;
+            Ci[1] = (C[2] * C[7] - C[1] * C[8]) / det;
+            Ci[2] = (C[1] * C[5] - C[2] * C[4]) / det;
+            Ci[3] = (C[5] * C[6] - C[3] * C[8]) / det;
+            Ci[4] = (C[0] * C[8] - C[2] * C[6]) / det;
+            Ci[5] = (C[2] * C[3] - C[0] * C[5]) / det;
+            Ci[6] = (C[3] * C[7] - C[4] * C[6]) / det;
+            Ci[7] = (C[1] * C[6] - C[0] * C[7]) / det;
+            Ci[8] = (C[0] * C[4] - C[1] * C[3]) / det;
+            const double *R = st->R;
+            double T[9];  // Ci * R
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) T[a * 3 + b] = Ci[a * 3] * R[b] + Ci[a * 3 + 1] * R[3 + b] + Ci[a * 3 + 2] * R[6 + b];
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) W[a * 3 + b] = R[a] * T[b] + R[3 + a] * T[3 + b] + R[6 + a] * T[6 + b];
+            const double dx = xyz[3 * l] - st->center[0] - st->t[0], dy = xyz[3 * l + 1] - st->center[1] - st->t[1],
+                         dz = xyz[3 * l + 2] - st->center[2] - st->t[2];
+            double v[3];
+            v[0] = R[0] * dx + R[3] * dy + R[6] * dz - (ref[p] - st->center[0]) - mean[p];
+            v[1] = R[1] * dx + R[4] * dy + R[7] * dz - (ref[M + p] - st->center[1]) - mean[M + p];
+            v[2] = R[2] * dx + R[5] * dy + R[8] * dz - (ref[2 * M + p] - st->center[2]) - mean[2 * M + p];
+            for (int a = 0; a < 3; ++a) Wv[a] = W[a * 3] * v[0] + W[a * 3 + 1] * v[1] + W[a * 3 + 2] * v[2];
+        }
+        __syncthreads();
+        const double *q = Q0 + (int64_t)3 * p * rp;
+        for (int idx = threadIdx.x; idx < rp * rp; idx += blockDim.x) {
+            const int a = idx / rp, b = idx - a * rp;
+            double s = 0.0;
+            for (int d = 0; d < 3; ++d)
+                for (int e = 0; e < 3; ++e) s += q[d * rp + a] * W[d * 3 + e] * q[e * rp + b];
+            G[idx] += s;
+        }
+        for (int a = threadIdx.x; a < rp; a += blockDim.x)
+            rhs[a] += q[a] * Wv[0] + q[rp + a] * Wv[1] + q[2 * rp + a] * Wv[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- small dense
+constexpr int kDenseThreads = 256;
+
+// in-place lower Cholesky of the r x r leading block of A (row-major, leading dimension ld). returns false on a
+// non-positive / non-finite pivot.  Called by ALL threads of one block.
+__device__ bool block_cholesky(double *A, int r, int ld) {
+    __shared__ int ok_flag;
+    if (threadIdx.x == 0) ok_flag = 1;
+    __syncthreads();
+    for (int k = 0; k < r; ++k) {
+        if (threadIdx.x == 0) {
+            const double d = A[k * ld + k];
+            if (!(d > 0.0) || !finite_d(d)) {
+                ok_flag = 0;
+                A[k * ld + k] = 1.0;
+            } else {
+                A[k * ld + k] = sqrt(d);
+            }
+        }
+        __syncthreads();
+        const double dk = A[k * ld + k];
+        for (int i = k + 1 + threadIdx.x; i < r; i += blockDim.x) A[i * ld + k] /= dk;
+        __syncthreads();
+        const int n = r - k - 1;
+        for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+            const int ii = idx / n, jj = idx - ii * n;
+            if (jj <= ii) {
+                const int i = k + 1 + ii, j = k + 1 + jj;
+                A[i * ld + j] -= A[i * ld + k] * A[j * ld + k];
+            }
+        }
+        __syncthreads();
+    }
+    return ok_flag != 0;
+}
+
+__global__ __launch_bounds__(kDenseThreads) void posterior_solve_kernel(int r, int rp, const double *__restrict__ G,
+                                                                        const double *__restrict__ rhs,
+                                                                        double *__restrict__ work, double *__restrict__ a,
+                                                                        DevState *__restrict__ st) {
+    __shared__ double y[512];
+    __shared__ int bad;
+    // Mm = QtL Q + I     (scalismo genericRegressionComputations)
+    for (int idx = threadIdx.x; idx < r * r; idx += blockDim.x) {
+        const int i = idx / r, j = idx - i * r;
+        work[i * rp + j] = G[i * rp + j] + (i == j ? 1.0 : 0.0);
+    }
+    for (int k = threadIdx.x; k < rp; k += blockDim.x) y[k] = k < r ? rhs[k] : 0.0;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    const bool ok = block_cholesky(work, r, rp);
+    // L z = rhs
+    for (int k = 0; k < r; ++k) {
+        if (threadIdx.x == 0) y[k] /= work[k * rp + k];
+        __syncthreads();
+        const double yk = y[k];
+        for (int i = k + 1 + threadIdx.x; i < r; i += blockDim.x) y[i] -= work[i * rp + k] * yk;
+        __syncthreads();
+    }
+    // L^T a = z
+    for (int k = r - 1; k >= 0; --k) {
+        if (threadIdx.x == 0) y[k] /= work[k * rp + k];
+        __syncthreads();
+        const double yk = y[k];
+        for (int i = threadIdx.x; i < k; i += blockDim.x) y[i] -= work[k * rp + i] * yk;
+        __syncthreads();
+    }
+    for (int k = threadIdx.x; k < rp; k += blockDim.x) {
+        const double v = k < r ? y[k] : 0.0;
+        a[k] = v;
+        if (!finite_d(v)) bad = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (!ok)
+            st->err = GINGR_ERR_NOT_SPD;
+        else if (bad)
+            st->err = GINGR_ERR_NONFINITE;
+    }
+}
+
+__global__ __launch_bounds__(kDenseThreads) void binv_kernel(int r, int rp, const double *__restrict__ S,
+                                                             double *__restrict__ work, double *__restrict__ Binv,
+                                                             int32_t *__restrict__ err_flag) {
+    // M = Q^T Q / eps + I
+    for (int idx = threadIdx.x; idx < r * r; idx += blockDim.x) {
+        const int i = idx / r, j = idx - i * r;
+        work[i * rp + j] = S[i * rp + j] / GINGR_COEFF_NOISE + (i == j ? 1.0 : 0.0);
+    }
+    for (int idx = threadIdx.x; idx < rp * rp; idx += blockDim.x) Binv[idx] = 0.0;
+    __syncthreads();
+    const bool ok = block_cholesky(work, r, rp);
+    if (threadIdx.x == 0) *err_flag = ok ? 0 : GINGR_ERR_NOT_SPD;
+    // thread c solves L L^T x = e_c; Binv is symmetric, column c is stored as row c (contiguous)
+    for (int c = threadIdx.x; c < r; c += blockDim.x) {
+        double *x = Binv + (int64_t)c * rp;
+        for (int k = 0; k < r; ++k) {
+            double s = (k == c) ? 1.0 : 0.0;
+            for (int j = 0; j < k; ++j) s -= work[k * rp + j] * x[j];
+            x[k] = s / work[k * rp + k];
+        }
+        for (int k = r - 1; k >= 0; --k) {
+            double s = x[k];
+            for (int j = k + 1; j < r; ++j) s -= work[j * rp + k] * x[j];
+            x[k] = s / work[k * rp + k];
+        }
+    }
+}
+
+// out[i] = sum_j Binv[j][i] * p[j] / eps   (Binv symmetric; coalesced over i)
+__device__ __forceinline__ double binv_row_apply(const double *__restrict__ Binv, const double *__restrict__ p, int r, int rp,
+                                                 int i) {
+    double s = 0.0;
+    for (int j = 0; j < r; ++j) s = __builtin_fma(Binv[(int64_t)j * rp + i], p[j] / GINGR_COEFF_NOISE, s);
+    return s;
+}
+
+__global__ void alpha_blend_kernel(int r, int rp, const double *__restrict__ Binv, const double *__restrict__ p,
+                                   const double *__restrict__ alpha, double step, double *__restrict__ alpha_c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rp) return;
+    if (i >= r) {
+        alpha_c[i] = 0.0;
+        return;
+    }
+    const double a1 = binv_row_apply(Binv, p, r, rp, i);
+    const double a0 = alpha[i];
+    alpha_c[i] = a0 + (a1 - a0) * step;  // GingrAlgorithm.scala:219-220
+}
+
+__global__ void coeff_solve_kernel(int r, int rp, const double *__restrict__ Binv, const double *__restrict__ p,
+                                   double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rp) return;
+    out[i] = i < r ? binv_row_apply(Binv, p, r, rp, i) : 0.0;
+}
+
+// one-sided Jacobi SVD of a 3x3 matrix: A = U diag(s) V^T, s descending
+__device__ void svd3(const double Ain[9], double U[9], double s[3], double V[9]) {
+    double A[9];
+    for (int q = 0; q < 9; ++q) {
+        A[q] = Ain[q];
+        V[q] = (q % 4 == 0) ? 1.0 : 0.0;
+    }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < 3; ++i) {
+                    alpha += A[i * 3 + p] * A[i * 3 + p];
+                    beta += A[i * 3 + q] * A[i * 3 + q];
+                    gamma += A[i * 3 + p] * A[i * 3 + q];
+                }
+                const double lim = 1e-17 * sqrt(alpha * beta);
+                if (fabs(gamma) <= lim || gamma == 0.0) continue;
+                off = fmax(off, fabs(gamma) / sqrt(alpha * beta));
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int i = 0; i < 3; ++i) {
+                    const double ap = A[i * 3 + p], aq = A[i * 3 + q];
+                    A[i * 3 + p] = c * ap - sn * aq;
+                    A[i * 3 + q] = sn * ap + c * aq;
+                    const double vp = V[i * 3 + p], vq = V[i * 3 + q];
+                    V[i * 3 + p] = c * vp - sn * vq;
+                    V[i * 3 + q] = sn * vp + c * vq;
+                }
+            }
+        if (off < 1e-16) break;
+    }
+    double nrm[3];
+    for (int j = 0; j < 3; ++j) nrm[j] = sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
+    int ord[3] = {0, 1, 2};
+    for (int a = 0; a < 2; ++a)
+        for (int b = a + 1; b < 3; ++b)
+            if (nrm[ord[b]] > nrm[ord[a]]) {
+                const int t = ord[a];
+                ord[a] = ord[b];
+                ord[b] = t;
+            }
+    double Vs[9];
+    for (int j = 0; j < 3; ++j) {
+        const int o = ord[j];
+        s[j] = nrm[o];
+        for (int i = 0; i < 3; ++i) {
+            U[i * 3 + j] = nrm[o] > 0 ? A[i * 3 + o] / nrm[o] : 0.0;
+            Vs[i * 3 + j] = V[i * 3 + o];
+        }
+    }
+    for (int q = 0; q < 9; ++q) V[q] = Vs[q];
+    // complete a rank-deficient U to an orthonormal basis (third column = cross product)
+    if (!(s[2] > 1e-300 * s[0])) {
+        U[2] = U[3] * U[7] - U[6] * U[4];
+        U[5] = U[6] * U[1] - U[0] * U[7];
+        U[8] = U[0] * U[4] - U[3] * U[1];
+    }
+}
+
+// sums: [0..2] sum x~, [3..5] sum y~, [6..14] sum y~ x~^T (row-major), [15] sum |x~|^2; x~ = x - c0, y~ = y - c0
+__global__ void umeyama_kernel(const double *__restrict__ sums, double n, double c0x, double c0y, double c0z,
+                               int global_transform, DevPose *__restrict__ pose, DevState *__restrict__ st) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    DevPose P;
+    if (global_transform == GINGR_NO_TRANSFORMS) {  // identityTransformation, GingrAlgorithm.scala:230
+        for (int q = 0; q < 9; ++q) P.R[q] = (q % 4 == 0) ? 1.0 : 0.0;
+        P.euler[0] = P.euler[1] = P.euler[2] = 0.0;
+        P.t[0] = P.t[1] = P.t[2] = 0.0;
+        P.center[0] = P.center[1] = P.center[2] = 0.0;
+        P.scale = 1.0;
+        *pose = P;
+        return;
+    }
+    const double c0[3] = {c0x, c0y, c0z};
+    double mux[3], muy[3];
+    for (int a = 0; a < 3; ++a) {
+        mux[a] = sums[a] / n;
+        muy[a] = sums[3 + a] / n;
+    }
+    double Sxy[9];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) Sxy[a * 3 + b] = sums[6 + a * 3 + b] / n - muy[a] * mux[b];
+    const double sig2x = sums[15] / n - (mux[0] * mux[0] + mux[1] * mux[1] + mux[2] * mux[2]);
+    double U[9], D[3], V[9];
+    svd3(Sxy, U, D, V);
+    const double det = Sxy[0] * (Sxy[4] * Sxy[8] - Sxy[5] * Sxy[7]) - Sxy[1] * (Sxy[3] * Sxy[8] - Sxy[5] * Sxy[6]) +
+                       Sxy[2] * (Sxy[3] * Sxy[7] - Sxy[4] * Sxy[6]);
+    const double s3 = det < 0 ? -1.0 : 1.0;
+    double R[9];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) R[a * 3 + b] = U[a * 3] * V[b * 3] + U[a * 3 + 1] * V[b * 3 + 1] + s3 * U[a * 3 + 2] * V[b * 3 + 2];
+    const double c = (global_transform == GINGR_SIMILARITY_TRANSFORMS) ? (D[0] + D[1] + s3 * D[2]) / sig2x : 1.0;
+    // t = mu_y - c R mu_x in absolute coordinates (rotation about the origin)
+    double mxa[3], mya[3];
+    for (int a = 0; a < 3; ++a) {
+        mxa[a] = mux[a] + c0[a];
+        mya[a] = muy[a] + c0[a];
+    }
+    for (int a = 0; a < 3; ++a) P.t[a] = mya[a] - c * (R[a * 3] * mxa[0] + R[a * 3 + 1] * mxa[1] + R[a * 3 + 2] * mxa[2]);
+    // the registration result carries its rotation as Euler angles (rigid3DLandmarkRegistration builds Rotation3D)
+    rot_to_euler(R, P.euler);
+    euler_to_rot(P.euler, P.R);
+    P.center[0] = P.center[1] = P.center[2] = 0.0;  // estimate*Transform(..., Point(0,0,0))
+    P.scale = c;
+    bool fin = finite_d(c);
+    for (int q = 0; q < 9; ++q) fin = fin && finite_d(P.R[q]);
+    for (int q = 0; q < 3; ++q) fin = fin && finite_d(P.t[q]);
+    if (!fin && st->err == 0) st->err = GINGR_ERR_NONFINITE;
+    *pose = P;
+}
+
+__global__ __launch_bounds__(kDenseThreads) void commit_kernel(CommitArgs a) {
+    __shared__ double anew[512];
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    DevState *st = a.state;
+    if (st->status == GINGR_FIT_MODEL_FLEXIBILITY_ERROR) return;  // a failed fit stays as it is (run stops, :149-157)
+    for (int i = threadIdx.x; i < a.rp; i += blockDim.x) {
+        const double v = i < a.r ? binv_row_apply(a.Binv, a.p2, a.r, a.rp, i) : 0.0;
+        anew[i] = v;
+        if (!finite_d(v)) bad = 1;
+    }
+    __syncthreads();
+    const bool failed = (st->err != 0) || bad;
+    __syncthreads();
+    if (!failed) {
+        for (int i = threadIdx.x; i < a.rp; i += blockDim.x) a.alpha[i] = anew[i];
+    }
+    if (threadIdx.x == 0) {
+        if (!failed) {
+            for (int q = 0; q < 9; ++q) st->R[q] = a.pose->R[q];
+            for (int q = 0; q < 3; ++q) {
+                st->euler[q] = a.pose->euler[q];
+                st->center[q] = 0.0;  // Umeyama about Point(0,0,0), GingrAlgorithm.scala:81,266
+                st->t[q] = a.pose->t[q];
+            }
+            st->scale = a.pose->scale;
+            if (a.is_icp) {
+                const double ns = st->sigma2 - a.icp_step;       // ICP.scala:96-99
+                st->sigma2 = ns > a.icp_end ? ns : a.icp_end;
+            } else {
+                const double *sc = a.scalars;                    // CPD.scala:142-145
+                st->sigma2 = (sc[1] - 2 * sc[2] + sc[3]) / (sc[0] * 3.0);
+            }
+        } else if (st->iteration > 0) {
+            st->status = GINGR_FIT_MODEL_FLEXIBILITY_ERROR;       // GingrAlgorithm.scala:204,248,251 (iteration 0: :206-208)
+        }
+        st->pad = failed ? (st->err != 0 ? st->err : GINGR_ERR_NONFINITE) : 0;  // last error, readable by the host
+        st->err = 0;
+        st->iteration += 1;  // GingrGeneratorWrapper.propose: updateIteration()
+    }
+}
+
+__global__ void state_init_kernel(DevState *st, const gingr_state_scalars *h) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int q = 0; q < 3; ++q) {
+        st->euler[q] = h->euler[q];
+        st->center[q] = h->center[q];
+        st->t[q] = h->translation[q];
+    }
+    euler_to_rot(st->euler, st->R);
+    st->scale = h->scale;
+    st->sigma2 = h->sigma2;
+    st->iteration = h->iteration;
+    st->status = h->status;
+    st->err = 0;
+    st->pad = 0;
+}
+
+}  // namespace
+
+// =====================================================================================================  launchers
+int sweep_num_blocks(int64_t M) {
+    const int64_t nb = ceil_div(M, kGroups);
+    return (int)(nb < kSweepMaxBlocks ? (nb > 0 ? nb : 1) : kSweepMaxBlocks);
+}
+
+int64_t sweep_ws_doubles(int64_t M, int32_t rp) {
+    const int w = rp > 24 ? rp : 24;
+    return (int64_t)sweep_num_blocks(M) * w;
+}
+
+template <int MODE>
+static void launch_sweep_mode(gingr_ctx *ctx, const SweepArgs &a, int width) {
+    const int nb = sweep_num_blocks(a.M);
+    const size_t lds = (size_t)(2 * a.rp + kGroups * (a.rp > 16 ? a.rp : 16)) * sizeof(double);
+    if (a.rp <= 128) {
+        hipLaunchKernelGGL((sweep_kernel<MODE, 8>), dim3(nb), dim3(kSweepThreads), lds, ctx->stream, a);
+    } else {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_kernel<MODE, 32>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((sweep_kernel<MODE, 32>), dim3(nb), dim3(kSweepThreads), lds, ctx->stream, a);
+    }
+    if (width > 0)
+        hipLaunchKernelGGL(block_partials_reduce_kernel, dim3((unsigned)ceil_div(width, 64)), dim3(64), 0, ctx->stream,
+                           a.partial, nb, width, a.out);
+}
+
+void launch_sweep(gingr_ctx *ctx, SweepMode mode, const SweepArgs &a) {
+    switch (mode) {
+        case SWEEP_RHS: launch_sweep_mode<SWEEP_RHS>(ctx, a, a.rp); break;
+        case SWEEP_PROJ1: launch_sweep_mode<SWEEP_PROJ1>(ctx, a, a.rp); break;
+        case SWEEP_SHAPES: launch_sweep_mode<SWEEP_SHAPES>(ctx, a, 24); break;
+        case SWEEP_PROJ2: launch_sweep_mode<SWEEP_PROJ2>(ctx, a, a.rp); break;
+        case SWEEP_FIT: launch_sweep_mode<SWEEP_FIT>(ctx, a, 0); break;
+        case SWEEP_POSED: launch_sweep_mode<SWEEP_POSED>(ctx, a, 0); break;
+    }
+}
+
+static void gram_plan(int64_t M, int32_t rp, int *nbp, int *npatch, int *nslabs, int64_t *rows_per_slab) {
+    const int64_t rows = 3 * M;
+    *nbp = (rp + 63) / 64;
+    *npatch = *nbp * (*nbp + 1) / 2;
+    int64_t want = 1024 / *npatch;
+    if (want < 1) want = 1;
+    const int64_t max_slabs = ceil_div(rows, 64);
+    if (want > max_slabs) want = max_slabs;
+    if (want < 1) want = 1;
+    *rows_per_slab = round_up(ceil_div(rows, want), 4);
+    *nslabs = (int)ceil_div(rows, *rows_per_slab);
+}
+
+int64_t gram_ws_doubles(int64_t M, int32_t rp) {
+    int nbp, npatch, nslabs;
+    int64_t rps;
+    gram_plan(M, rp, &nbp, &npatch, &nslabs, &rps);
+    return (int64_t)nslabs * rp * rp;
+}
+
+void launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, double *G) {
+    int nbp, npatch, nslabs;
+    int64_t rps;
+    gram_plan(M, rp, &nbp, &npatch, &nslabs, &rps);
+    {
+        TimerScope ts(ctx, 2);
+        hipLaunchKernelGGL(gram_kernel, dim3(nslabs, npatch), dim3(64), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, nbp,
+                           ws);
+    }
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 256)), dim3(256), 0, ctx->stream, ws,
+                       nslabs, (int)rp, G);
+}
+
+void launch_obs_cpd(gingr_ctx *ctx, const gingr_model *m, const DevState *st, Cloud fit, const double *P1,
+                    const double *PX, double lambda, const int32_t *lm_mask, double *weight, double *evec) {
+    hipLaunchKernelGGL(obs_cpd_kernel, dim3((unsigned)ceil_div(m->M, 256)), dim3(256), 0, ctx->stream, m->ref, m->mean, m->M,
+                       st, fit, P1, PX, lambda, lm_mask, weight, evec);
+}
+
+void launch_obs_icp(gingr_ctx *ctx, const gingr_model *m, const DevState *st, Cloud target, const int32_t *idx,
+                    const int32_t *lm_mask, double *weight, double *evec) {
+    hipLaunchKernelGGL(obs_points_kernel, dim3((unsigned)ceil_div(m->M, 256)), dim3(256), 0, ctx->stream, m->ref, m->mean,
+                       m->M, st, (const double *)nullptr, target, idx, (const double *)nullptr, lm_mask, weight, evec);
+}
+
+void launch_obs_points(gingr_ctx *ctx, const gingr_model *m, const DevState *st, const double *obs_soa,
+                       const double *weight_in, double *weight, double *evec) {
+    Cloud none{nullptr, nullptr, nullptr, 0};
+    hipLaunchKernelGGL(obs_points_kernel, dim3((unsigned)ceil_div(m->M, 256)), dim3(256), 0, ctx->stream, m->ref, m->mean,
+                       m->M, st, obs_soa, none, (const int32_t *)nullptr, weight_in, (const int32_t *)nullptr, weight, evec);
+}
+
+void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, int32_t n_lm, const int32_t *lm_pid_local,
+                      const double *lm_xyz, const double *lm_cov, double *G, double *rhs) {
+    if (n_lm <= 0) return;
+    hipLaunchKernelGGL(landmarks_kernel, dim3(1), dim3(256), 0, ctx->stream, m->Q0, m->ref, m->mean, m->M, (int)m->rp, st,
+                       (int)n_lm, lm_pid_local, lm_xyz, lm_cov, G, rhs);
+}
+
+void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, double *work,
+                            double *a, DevState *st) {
+    hipLaunchKernelGGL(posterior_solve_kernel, dim3(1), dim3(kDenseThreads), 0, ctx->stream, (int)r, (int)rp, G, rhs, work, a,
+                       st);
+}
+
+void launch_binv(gingr_ctx *ctx, int32_t r, int32_t rp, const double *S, double *work, double *Binv, int32_t *err_flag) {
+    hipLaunchKernelGGL(binv_kernel, dim3(1), dim3(kDenseThreads), 0, ctx->stream, (int)r, (int)rp, S, work, Binv, err_flag);
+}
+
+void launch_alpha_blend(gingr_ctx *ctx, int32_t r, int32_t rp, const double *Binv, const double *p, const double *alpha,
+                        double step, double *alpha_c) {
+    hipLaunchKernelGGL(alpha_blend_kernel, dim3((unsigned)ceil_div(rp, 64)), dim3(64), 0, ctx->stream, (int)r, (int)rp, Binv,
+                       p, alpha, step, alpha_c);
+}
+
+void launch_coeff_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *Binv, const double *p, double *out) {
+    hipLaunchKernelGGL(coeff_solve_kernel, dim3((unsigned)ceil_div(rp, 64)), dim3(64), 0, ctx->stream, (int)r, (int)rp, Binv,
+                       p, out);
+}
+
+void launch_umeyama(gingr_ctx *ctx, const double *sums, int64_t M_total, const double c0[3], int32_t global_transform,
+                    DevPose *pose, DevState *st) {
+    hipLaunchKernelGGL(umeyama_kernel, dim3(1), dim3(64), 0, ctx->stream, sums, (double)M_total, c0[0], c0[1], c0[2],
+                       (int)global_transform, pose, st);
+}
+
+void launch_commit(gingr_ctx *ctx, const CommitArgs &a) {
+    hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(kDenseThreads), 0, ctx->stream, a);
+}
+
+void launch_state_init(gingr_ctx *ctx, DevState *st, const gingr_state_scalars *host_scalars_dev) {
+    hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, ctx->stream, st, host_scalars_dev);
+}
+
+void launch_pack_basis(gingr_ctx *ctx, const double *stage_colmajor, const double *variance_dev, int64_t M, int32_t r,
+                       int32_t rp, double *Q0) {
+    const int64_t total = 3 * M * rp;
+    hipLaunchKernelGGL(pack_basis_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, stage_colmajor,
+                       variance_dev, 3 * M, r, rp, Q0);
+}

@@ -1,0 +1,222 @@
+/*
+ * gingr_hip.h -- C ABI of libgingr_hip.so, the MI355X (gfx950) implementation of GiNGR's
+ * per-iteration update (reference: unibas-gravis/GiNGR, gingr/api/GingrAlgorithm.update).
+ *
+ * This header is the drop-in boundary: plain C, pointers and sizes only, no C++/torch/JVM types.
+ * A JVM host binds it through the JNI shim in jvm/ (see INTEGRATION.md); the Python host layer
+ * gingr_amd/ binds it with ctypes.  G/ = src/main/scala/gingr/ of the reference.
+ *
+ * Conventions
+ *  - every function returns a gingr_status (0 = ok); gingr_last_error(ctx) has the text.
+ *  - host point arrays are interleaved x,y,z float64 ("x1x,x1y,x1z,x2x,..."), the layout of
+ *    G/api/registration/utils/PointSequenceConverter.scala:54-59.
+ *  - the caller owns every host buffer; the library never keeps a host pointer after the call returns.
+ *  - a gingr_ctx binds ONE device and ONE stream and is not thread-safe; distinct contexts are independent
+ *    (one per MH chain / per GPU), mirroring the reference's "one algorithm instance per chain"
+ *    (G/api/GingrAlgorithm.scala:69-70 retryCounter is an unsynchronised var).
+ *  - functions whose name ends in _async only enqueue work on the context's stream.
+ */
+#ifndef GINGR_HIP_H
+#define GINGR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gingr_ctx gingr_ctx;
+typedef struct gingr_model gingr_model;
+typedef struct gingr_fitter gingr_fitter;
+
+typedef enum gingr_status {
+    GINGR_OK = 0,
+    GINGR_ERR_BAD_ARGUMENT = 1,
+    GINGR_ERR_HIP = 2,          /* a HIP runtime call failed */
+    GINGR_ERR_NONFINITE = 3,    /* a result is NaN/Inf (reference: exception inside Try => ModelFlexibilityError) */
+    GINGR_ERR_NOT_SPD = 4,      /* Cholesky pivot <= 0 in the posterior solve (same mapping) */
+    GINGR_ERR_NO_DEVICE = 5,
+    GINGR_ERR_STATE = 6         /* call order violated (e.g. update before target upload) */
+} gingr_status;
+
+/* G/api/GlobalTranformationType.scala:20-24 */
+typedef enum gingr_global_transform {
+    GINGR_NO_TRANSFORMS = 0,
+    GINGR_RIGID_TRANSFORMS = 1,
+    GINGR_SIMILARITY_TRANSFORMS = 2
+} gingr_global_transform;
+
+/* G/api/FittingStatuses.scala:22 */
+typedef enum gingr_fitting_status {
+    GINGR_FIT_NONE = 0,
+    GINGR_FIT_CONVERGED = 1,
+    GINGR_FIT_MAX_ITERATION = 2,
+    GINGR_FIT_MODEL_FLEXIBILITY_ERROR = 3
+} gingr_fitting_status;
+
+/* ------------------------------------------------------------------ context */
+
+int gingr_device_count(void);
+int gingr_ctx_create(int device, gingr_ctx **out);
+void gingr_ctx_destroy(gingr_ctx *ctx);
+const char *gingr_last_error(const gingr_ctx *ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. NULL restores it. */
+int gingr_ctx_set_stream(gingr_ctx *ctx, void *hip_stream);
+void *gingr_ctx_get_stream(gingr_ctx *ctx);
+int gingr_ctx_synchronize(gingr_ctx *ctx);
+const char *gingr_build_info(void);
+
+/* --------------------------------------------- stateless all-pairs operators
+ * Each call uploads its inputs, runs on the device, downloads and synchronises.
+ */
+
+/*
+ * CPD soft-assignment statistics of ONE affinity evaluation, P never materialised.
+ * Replaces CpdRegistrationState.P (G/api/registration/config/CPD.scala:54-75), the row/column sums of
+ * CPDCorrespondence.estimate (:36) and updateSigma2 (:133-147).
+ *   fit[3M], target[3N], sigma2, w  ->  den[N] (= colsum K + c), P1[M], PX[3M], Pt1[N],
+ *   scalars[6] = { Np, xPx, trPXY, yPy, sigma2_next, c }.   Any output pointer may be NULL.
+ */
+int gingr_cpd_stats(gingr_ctx *ctx, int64_t M, const double *fit, int64_t N, const double *target, double sigma2,
+                    double w, double *den, double *P1, double *PX, double *Pt1, double *scalars);
+
+/* sigma2_0 = sum_ij ||x_j - y_i||^2 / (3 M N)      (CPD.scala:81-90) */
+int gingr_cpd_initial_sigma2(gingr_ctx *ctx, int64_t M, const double *ref, int64_t N, const double *target,
+                             double *sigma2_out);
+
+/*
+ * Exact brute-force nearest neighbour, lowest index wins ties.
+ * Replaces ClosestPointUnstructuredPointsDomain3D.closestPointCorrespondence
+ * (G/api/registration/utils/ClosestPointRegistrator.scala:133-148) / scalismo findClosestPoint.
+ *   query[3M], target[3N] -> idx[M] (int32), d2[M] (squared distance), *mean_distance (mean of sqrt(d2)).
+ */
+int gingr_nn(gingr_ctx *ctx, int64_t M, const double *query, int64_t N, const double *target, int32_t *idx,
+             double *d2, double *mean_distance);
+
+/*
+ * Gaussian-kernel covariance block out[i*nb + j] = scaling * exp(-||a_i - b_j||^2 / sigma^2)
+ * (G/api/gpmm/GPMMHelper.scala:99-102: GaussianKernel(sigma) * scaling; the (x) I3 of DiagonalKernel is implicit;
+ *  with sigma = sqrt(2) beta, scaling = 1 it is CPDFactory.initializeKernelMatrixG,
+ *  G/other/algorithms/cpd/CPDFactory.scala:54-66).
+ */
+int gingr_gauss_block(gingr_ctx *ctx, int64_t na, const double *A, int64_t nb, const double *B, double sigma,
+                      double scaling, double *out);
+
+/* ------------------------------------------------------------------- model
+ * A point distribution model resident on the device: scalismo PointDistributionModel (reference, mean, basisMatrix,
+ * variance) as held by GeneralRegistrationState.model (G/api/GeneralRegistrationState.scala:29).
+ *   ref[3M], mean[3M] (mean DISPLACEMENT), basis[3M*r] COLUMN-major (3M rows) exactly as Breeze stores
+ *   basisMatrix, variance[r].
+ * Row sharding (multi-GPU): the model holds points [row_begin, row_end) of M_total; pass 0, M for one GPU.
+ * Host arrays are always the FULL model; only the shard is uploaded.
+ */
+int gingr_model_upload(gingr_ctx *ctx, int64_t M_total, int32_t rank, const double *ref, const double *mean,
+                       const double *basis_colmajor, const double *variance, int64_t row_begin, int64_t row_end,
+                       gingr_model **out);
+void gingr_model_destroy(gingr_model *model);
+/* Row-sharded models only: after upload every shard holds its partial Q^T Q (float64, count elements at dev_ptr);
+ * the host all-reduces (sum) it across shards once, then calls gingr_model_finalize, which factors
+ * Q^T Q / 1e-5 + I for the coefficient projections.  Single-shard uploads are finalized by gingr_model_upload. */
+int gingr_model_gram_exchange(gingr_model *model, void **dev_ptr, int64_t *count);
+int gingr_model_finalize(gingr_ctx *ctx, gingr_model *model);
+int64_t gingr_model_num_points(const gingr_model *model); /* local rows */
+int32_t gingr_model_rank(const gingr_model *model);
+
+/* PointDistributionModel.instance(alpha) posed and scaled:  s * (R (ref + mean + U sqrt(lam) alpha - c) + c + t)
+ * (G/api/ModelFittingParameters.scala:130-143).  out_xyz[3*M_local]. */
+int gingr_model_instance(gingr_ctx *ctx, const gingr_model *model, const double *alpha, const double euler[3],
+                         const double center[3], const double translation[3], double scale, double *out_xyz);
+
+/* PointDistributionModel.transform(rigid).coefficients(mesh): GP regression at all points with noise 1e-5 I3
+ * (G/api/GingrAlgorithm.scala:212-216,234-237).  mesh_xyz[3*M_local] -> alpha[r].  Single shard only. */
+int gingr_model_coefficients(gingr_ctx *ctx, const gingr_model *model, const double euler[3], const double center[3],
+                             const double translation[3], const double *mesh_xyz, double *alpha);
+
+/* PointDistributionModel.transform(rigid).posterior(obs).mean  (G/api/GingrAlgorithm.scala:297-301).
+ * Observations: every local point i with weight[i] > 0 is observed at obs_xyz[3i..] with covariance I3/weight[i];
+ * n_lm landmark observations (point id, target point, full 3x3 covariance, row-major) are appended and their point ids
+ * must carry weight 0.  Outputs: mean_xyz[3*M_local] (posterior mean mesh), coeffs[r] (regression coefficients). */
+int gingr_model_posterior_mean(gingr_ctx *ctx, const gingr_model *model, const double euler[3], const double center[3],
+                               const double translation[3], const double *obs_xyz, const double *weight,
+                               int32_t n_lm, const int32_t *lm_pid, const double *lm_xyz, const double *lm_cov,
+                               double *mean_xyz, double *coeffs);
+
+/* ------------------------------------------------------------------ fitter
+ * Device-resident registration state = the numeric content of GeneralRegistrationState
+ * (alpha, Euler angles, centre, translation, scale, sigma2, fit, iteration, status) plus target and
+ * configuration; one update = GingrAlgorithm.update followed by GingrGeneratorWrapper.propose's fit refresh
+ * (G/api/GingrAlgorithm.scala:192-254; G/api/sampling/generators/GingrGeneratorWrapper.scala:28-39).
+ */
+typedef struct gingr_state_scalars {
+    double euler[3];        /* phi, theta, psi  (EulerAngles, G/api/ModelFittingParameters.scala:35-37) */
+    double center[3];       /* rotation centre */
+    double translation[3];
+    double scale;
+    double sigma2;
+    int32_t iteration;
+    int32_t status;         /* gingr_fitting_status */
+} gingr_state_scalars;
+
+typedef struct gingr_cpd_params {   /* CpdConfiguration, CPD.scala:105-115 */
+    double w;
+    double lambda;
+} gingr_cpd_params;
+
+typedef struct gingr_icp_params {   /* IcpConfiguration, ICP.scala:54-66 (PointcloudClosestPoint flavour) */
+    double initial_sigma;
+    double end_sigma;
+    int32_t max_iterations;
+} gingr_icp_params;
+
+int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter **out);
+void gingr_fitter_destroy(gingr_fitter *f);
+/* target cloud, replicated on every shard */
+int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz);
+/* landmark observations (GeneralRegistrationState.landmarkCorrespondences, GeneralRegistrationState.scala:43-62);
+ * pids are GLOBAL point ids; cov row-major 3x3 per landmark.  n_lm = 0 clears. */
+int gingr_fitter_set_landmarks(gingr_fitter *f, int32_t n_lm, const int32_t *lm_pid, const double *lm_xyz,
+                               const double *lm_cov);
+int gingr_fitter_set_options(gingr_fitter *f, int32_t global_transform, double step_length);
+/* state in: alpha[r] + scalars; the fit is recomputed on the device (modelInstanceShapePoseScale). */
+int gingr_fitter_set_state(gingr_fitter *f, const double *alpha, const gingr_state_scalars *s);
+/* state out (synchronises): alpha[r], scalars, fit_xyz[3*M_local]; any pointer may be NULL. */
+int gingr_fitter_get_state(gingr_fitter *f, double *alpha, gingr_state_scalars *s, double *fit_xyz);
+/* diagnostics of the LAST update (synchronises): P1[M_local], PX[3*M_local] (CPD) or nn idx (ICP), coeffs. */
+int gingr_fitter_get_cpd_stats(gingr_fitter *f, double *P1, double *PX, double *den, double *scalars6);
+int gingr_fitter_get_icp_idx(gingr_fitter *f, int32_t *idx, double *d2);
+
+/* n_iterations updates back to back on the stream, no host synchronisation in between (single shard). */
+int gingr_fitter_update_cpd_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t n_iterations);
+int gingr_fitter_update_icp_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations);
+
+/* ---- row-sharded update, host-driven exchange (multi-GPU) -----------------------------------------------------
+ * One iteration = phases 0..GINGR_NUM_PHASES-1.  After phase p the host all-reduces (sum, float64) the exchange
+ * segment p across shards (RCCL over xGMI via torch.distributed, or nothing for one shard), then runs phase p+1.
+ * The exchange buffer is device memory owned by the library; gingr_fitter_exchange gives its address and the
+ * [offset, count) of every segment in float64 elements.
+ *   segment 0: den partial column sums [N]                      (the CPD column-sum exchange; empty for ICP)
+ *   segment 1: weighted Gram [rp*rp] + rhs [rp] + scalars [8]
+ *   segment 2: first projection Q^T d [rp]
+ *   segment 3: Umeyama partial sums [24]
+ *   segment 4: second projection [rp]
+ */
+#define GINGR_NUM_PHASES 6
+#define GINGR_NUM_SEGMENTS 5
+int gingr_fitter_exchange(gingr_fitter *f, void **dev_ptr, int64_t offsets[GINGR_NUM_SEGMENTS],
+                          int64_t counts[GINGR_NUM_SEGMENTS]);
+int gingr_fitter_cpd_phase_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t phase);
+int gingr_fitter_icp_phase_async(gingr_fitter *f, const gingr_icp_params *p, int32_t phase);
+
+/* -------------------------------------------------------------- timing hooks
+ * HIP-event timing of the dominant kernels on the context's stream (bench.py's live roofline measurement).
+ * which: 0 = cpd_colsum, 1 = cpd_rowstats, 2 = gram, 3 = whole update.  Returns accumulated ms and launches since
+ * the last reset.  Enabling adds two event records per launch. */
+int gingr_ctx_timing_enable(gingr_ctx *ctx, int32_t enable);
+int gingr_ctx_timing_read(gingr_ctx *ctx, int32_t which, double *total_ms, int64_t *launches);
+int gingr_ctx_timing_reset(gingr_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GINGR_HIP_H */

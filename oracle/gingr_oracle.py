@@ -1,0 +1,563 @@
+"""CPU oracle for GiNGR's per-iteration update -- TEST INFRASTRUCTURE ONLY.
+
+This module is a float64 numpy restatement of the reference algorithm
+(unibas-gravis/GiNGR @ 2024_10_08, Scala) for the one hot path this repo
+accelerates: ``gingr/api/GingrAlgorithm.update``.  It is the *checker* for the
+HIP path.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it; the product
+(``gingr_amd``) never does.
+
+PARITY UNPINNED.  The reference ships no test that pins a numeric result of
+this path (``src/test/scala/DummyTest.scala.scala:3`` is ``assert(1 > 0)``),
+the reference cannot be executed here (no JVM), and part of the arithmetic
+lives in the un-vendored dependency ``ch.unibas.cs.gravis::scalismo:1.0-RC1``
+(``build.sbt:39``).  Functions tagged [REF] follow source lines that are in
+``/root/reference``; functions tagged [SCALISMO] restate scalismo 1.0-RC1's
+published algorithm (``DiscreteLowRankGaussianProcess.regression`` /
+``.coefficients``, ``PointDistributionModel.transform``,
+``LandmarkRegistration`` (Umeyama), ``RotationSpace3D`` Euler conventions,
+``PivotedCholesky.computeApproximateEig``) and are anchored on GiNGR's own call
+sites.  They are cross-checked by closed-form known-answer tests in
+``tests/test_oracle_kat.py``, not by reference outputs.
+
+Path shorthand: G/ = src/main/scala/gingr/ in the reference.
+
+Conventions
+-----------
+* points are (n, 3) float64 arrays; a "3n-vector" is x1x,x1y,x1z,x2x,...
+  (G/api/registration/utils/PointSequenceConverter.scala:54-59).
+* a point distribution model (PDM) is (ref (M,3), mean (M,3) displacement,
+  U (3M, r) basis, lam (r,) variances)  -- scalismo ``PointDistributionModel``.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+# --------------------------------------------------------------------------
+# A.1  CPD soft-assignment matrix            [REF G/api/registration/config/CPD.scala:54-75]
+# --------------------------------------------------------------------------
+
+def cpd_affinity_K(fit: np.ndarray, target: np.ndarray, sigma2: float) -> np.ndarray:
+    """K_ij = exp(-||x_j - y_i||^2 / (2 sigma2)), M x N   (CPD.scala:55-57,64-68)."""
+    y = np.asarray(fit, dtype=np.float64)
+    x = np.asarray(target, dtype=np.float64)
+    # (x - y).norm2: component differences squared and summed x,y,z in order
+    d = x[None, :, :] - y[:, None, :]
+    n2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]
+    return np.exp(-n2 / (2.0 * sigma2))
+
+
+def cpd_outlier_constant(M: int, N: int, sigma2: float, w: float) -> float:
+    """c = w/(1-w) * (2 pi sigma2)^(3/2) * (M/N)      (CPD.scala:69-70)."""
+    return w / (1 - w) * math.pow(2.0 * math.pi * sigma2, 3.0 / 2.0) * (float(M) / float(N))
+
+
+def cpd_P(fit, target, sigma2: float, w: float) -> np.ndarray:
+    """Dense P = K / (colsum(K) + c), M x N            (CPD.scala:71-74).
+
+    No max-subtraction: a column whose sum underflows to 0 with w == 0 yields
+    0/0 = NaN exactly like the reference.
+    """
+    K = cpd_affinity_K(fit, target, sigma2)
+    M, N = K.shape
+    c = cpd_outlier_constant(M, N, sigma2, w)
+    # Breeze sum(P, Axis._0): per column, rows in ascending order
+    den = _colsum_in_order(K) + c
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return K / den[None, :]
+
+
+def _colsum_in_order(A: np.ndarray) -> np.ndarray:
+    # sequential accumulation over rows (order matters only at the 1e-16 level;
+    # kept explicit so the C restatement can be compared bit for bit)
+    acc = np.zeros(A.shape[1], dtype=np.float64)
+    for i in range(A.shape[0]):
+        acc += A[i]
+    return acc
+
+
+def _rowsum_in_order(A: np.ndarray) -> np.ndarray:
+    acc = np.zeros(A.shape[0], dtype=np.float64)
+    for j in range(A.shape[1]):
+        acc += A[:, j]
+    return acc
+
+
+# --------------------------------------------------------------------------
+# A.2  CPD correspondences + uncertainty     [REF CPD.scala:32-49, 120-128]
+# --------------------------------------------------------------------------
+
+def cpd_correspondence(P: np.ndarray, fit: np.ndarray, target: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Returns (P1, yhat).  P1_i = sum_j P_ij (CPD.scala:36);
+    yhat_i = y_i + (sum_j (P1inv_i * P_ij) * x_j - y_i) (CPD.scala:37-46)."""
+    y = np.asarray(fit, dtype=np.float64)
+    x = np.asarray(target, dtype=np.float64)
+    P1 = _rowsum_in_order(P)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        P1inv = 1.0 / P1
+        acc = np.zeros_like(y)
+        for j in range(x.shape[0]):
+            tmp = P1inv * P[:, j]
+            acc += tmp[:, None] * x[j][None, :]
+        deform = acc - y
+    return P1, y + deform
+
+
+def cpd_uncertainty_var(P1: np.ndarray, sigma2: float, lam: float) -> np.ndarray:
+    """Isotropic variance v_i with cov_i = I3 * sigma2 * lambda * (1/P1_i)  (CPD.scala:123-126)."""
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return sigma2 * lam * (1.0 / P1)
+
+
+# --------------------------------------------------------------------------
+# A.3  CPD sigma^2 update                    [REF CPD.scala:133-147]
+# --------------------------------------------------------------------------
+
+def cpd_update_sigma2(P: np.ndarray, target: np.ndarray, fit: np.ndarray) -> float:
+    X = np.asarray(target, dtype=np.float64)
+    TY = np.asarray(fit, dtype=np.float64)
+    P1 = _rowsum_in_order(P)
+    Pt1 = _colsum_in_order(P)
+    Np = float(np.sum(P1))
+    xPx = float(Pt1 @ np.sum(X * X, axis=1))
+    yPy = float(P1 @ np.sum(TY * TY, axis=1))
+    trPXY = float(np.sum(TY * (P @ X)))
+    return (xPx - 2 * trPXY + yPy) / (Np * 3.0)
+
+
+def cpd_initial_sigma2(reference_pts: np.ndarray, target: np.ndarray) -> float:
+    """sum_ij ||x_j - y_i||^2 / (3 N M)         (CPD.scala:81-90)."""
+    y = np.asarray(reference_pts, dtype=np.float64)
+    x = np.asarray(target, dtype=np.float64)
+    total = 0.0
+    for i in range(y.shape[0]):
+        d = x - y[i]
+        total += float(np.sum(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]))
+    return total / (3.0 * x.shape[0] * y.shape[0])
+
+
+@dataclasses.dataclass
+class CpdStats:
+    """Everything one affinity evaluation yields (what the HIP path produces
+    without materialising P)."""
+    den: np.ndarray      # (N,) column sums of K plus c
+    P1: np.ndarray       # (M,)
+    PX: np.ndarray       # (M,3)  sum_j P_ij x_j
+    Pt1: np.ndarray      # (N,)
+    Np: float
+    sigma2_next: float
+
+
+def cpd_stats_dense(fit, target, sigma2: float, w: float) -> CpdStats:
+    """Dense-P evaluation of all CPD statistics, following the reference formulas."""
+    y = np.asarray(fit, dtype=np.float64)
+    x = np.asarray(target, dtype=np.float64)
+    K = cpd_affinity_K(y, x, sigma2)
+    M, N = K.shape
+    c = cpd_outlier_constant(M, N, sigma2, w)
+    den = _colsum_in_order(K) + c
+    with np.errstate(invalid="ignore", divide="ignore"):
+        P = K / den[None, :]
+    P1 = _rowsum_in_order(P)
+    Pt1 = _colsum_in_order(P)
+    PX = P @ x
+    s2 = cpd_update_sigma2(P, x, y)
+    return CpdStats(den=den, P1=P1, PX=PX, Pt1=Pt1, Np=float(np.sum(P1)), sigma2_next=s2)
+
+
+# --------------------------------------------------------------------------
+# A.7  ICP closest point (point-cloud flavour)
+#      [REF G/api/registration/utils/ClosestPointRegistrator.scala:133-160; ICP.scala:36-52,90-99]
+# --------------------------------------------------------------------------
+
+def icp_closest_point(fit: np.ndarray, target: np.ndarray) -> Tuple[np.ndarray, np.ndarray, float]:
+    """idx_i = argmin_j ||x_j - y_i||, lowest j on exact ties; returns (idx int32, d2, mean distance)."""
+    y = np.asarray(fit, dtype=np.float64)
+    x = np.asarray(target, dtype=np.float64)
+    idx = np.empty(y.shape[0], dtype=np.int32)
+    d2 = np.empty(y.shape[0], dtype=np.float64)
+    for i in range(y.shape[0]):
+        d = x - y[i]
+        n2 = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]
+        j = int(np.argmin(n2))  # numpy argmin returns the first minimum
+        idx[i] = j
+        d2[i] = n2[j]
+    return idx, d2, float(np.mean(np.sqrt(d2)))
+
+
+def icp_update_sigma2(sigma2: float, initial_sigma: float, end_sigma: float, max_iterations: int) -> float:
+    """max(sigma2 - (initialSigma - endSigma)/maxIterations, endSigma)   (ICP.scala:65,96-99)."""
+    step = (initial_sigma - end_sigma) / float(max_iterations)
+    return max(sigma2 - step, end_sigma)
+
+
+# --------------------------------------------------------------------------
+# a12  Gaussian-kernel covariance block
+#      [REF G/api/gpmm/GPMMHelper.scala:99-102; scalismo GaussianKernel: exp(-r^2/sigma^2)]
+# --------------------------------------------------------------------------
+
+def gauss_block(A: np.ndarray, B: np.ndarray, sigma: float, scaling: float) -> np.ndarray:
+    """k(a_i, b_j) = scaling * exp(-||a_i - b_j||^2 / sigma^2), (m, b)  [SCALISMO GaussianKernel]."""
+    A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64)
+    d = A[:, None, :] - B[None, :, :]
+    n2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]
+    return scaling * np.exp(-n2 / (sigma * sigma))
+
+
+def cpd_g_block(A: np.ndarray, B: np.ndarray, beta: float) -> np.ndarray:
+    """exp(-||a-b||^2/(2 beta^2))  [REF G/other/algorithms/cpd/CPDFactory.scala:54-66]."""
+    return gauss_block(A, B, math.sqrt(2.0) * beta, 1.0)
+
+
+# --------------------------------------------------------------------------
+# A.6  rotation conventions                  [SCALISMO RotationSpace3D]
+# --------------------------------------------------------------------------
+
+def euler_to_rot(phi: float, theta: float, psi: float) -> np.ndarray:
+    """Rz(phi) Ry(theta) Rx(psi), scalismo 'x-convention' (eulerAnglesToRotMatrix3D)."""
+    cospsi, sinpsi = math.cos(psi), math.sin(psi)
+    costh, sinth = math.cos(theta), math.sin(theta)
+    cosphi, sinphi = math.cos(phi), math.sin(phi)
+    return np.array([
+        [costh * cosphi, sinpsi * sinth * cosphi - cospsi * sinphi, sinpsi * sinphi + cospsi * sinth * cosphi],
+        [costh * sinphi, cospsi * cosphi + sinpsi * sinth * sinphi, cospsi * sinth * sinphi - sinpsi * cosphi],
+        [-sinth, sinpsi * costh, cospsi * costh],
+    ], dtype=np.float64)
+
+
+def rot_to_euler(R: np.ndarray) -> Tuple[float, float, float]:
+    """Slabaugh's recipe as used by scalismo rotMatrixToEulerAngles; (phi, theta, psi)."""
+    if abs(abs(R[2, 0]) - 1) > 0.0001:
+        theta = math.asin(-R[2, 0])
+        ct = math.cos(theta)
+        psi = math.atan2(R[2, 1] / ct, R[2, 2] / ct)
+        phi = math.atan2(R[1, 0] / ct, R[0, 0] / ct)
+        return phi, theta, psi
+    phi = 0.0
+    if abs(R[2, 0] + 1) < 0.0001:
+        theta = math.pi / 2.0
+        psi = phi + math.atan2(R[0, 1], R[0, 2])
+    else:
+        theta = -math.pi / 2.0
+        psi = -phi + math.atan2(-R[0, 1], -R[0, 2])
+    return phi, theta, psi
+
+
+def umeyama(src: np.ndarray, dst: np.ndarray, similarity: bool) -> Tuple[np.ndarray, np.ndarray, float]:
+    """Least-squares rigid / similarity fit dst ~ s R src + t about the origin.
+    [SCALISMO LandmarkRegistration.computeRigidNDTransformParams, called at
+    G/api/GingrAlgorithm.scala:81,90,264,275 with center Point(0,0,0)].
+    Returns (R, t, s) where R already went through scalismo's Euler
+    parameterisation (rigid3DLandmarkRegistration builds Rotation3D from Euler angles)."""
+    X = np.asarray(src, dtype=np.float64)
+    Y = np.asarray(dst, dtype=np.float64)
+    n = X.shape[0]
+    mu_x = X.mean(axis=0)
+    mu_y = Y.mean(axis=0)
+    Xc = X - mu_x
+    Yc = Y - mu_y
+    sigma2_x = float(np.sum(Xc * Xc) / n)
+    Sigma_xy = (Yc.T @ Xc) / n
+    Um, D, Vt = np.linalg.svd(Sigma_xy)
+    S = np.eye(3)
+    if np.linalg.det(Sigma_xy) < 0:
+        S[2, 2] = -1.0
+    R = Um @ S @ Vt
+    c = (1.0 / sigma2_x) * float(np.trace(np.diag(D) @ S)) if similarity else 1.0
+    t = mu_y - c * (R @ mu_x)
+    R_euler = euler_to_rot(*rot_to_euler(R))
+    return R_euler, t, c
+
+
+# --------------------------------------------------------------------------
+# A.4  low-rank GP model and regression      [SCALISMO PointDistributionModel / DiscreteLowRankGaussianProcess]
+# --------------------------------------------------------------------------
+
+@dataclasses.dataclass
+class PDM:
+    ref: np.ndarray    # (M,3) reference points
+    mean: np.ndarray   # (M,3) mean displacement
+    U: np.ndarray      # (3M, r) basisMatrix
+    lam: np.ndarray    # (r,) variance
+
+    @property
+    def rank(self) -> int:
+        return int(self.lam.shape[0])
+
+    @property
+    def M(self) -> int:
+        return int(self.ref.shape[0])
+
+    def transform(self, R: np.ndarray, t: np.ndarray, center: Optional[np.ndarray] = None) -> "PDM":
+        """PointDistributionModel.transform(rigid): ref' = T(ref); every 3-vector of the mean and of each
+        basis column becomes T(p+u) - T(p) = R u  (G/api/GingrAlgorithm.scala:212,234,299)."""
+        c = np.zeros(3) if center is None else np.asarray(center, dtype=np.float64)
+        ref2 = (self.ref - c) @ R.T + c + t
+        mean2 = self.mean @ R.T
+        M, r = self.M, self.rank
+        U3 = self.U.reshape(M, 3, r)
+        U2 = np.einsum("ab,mbk->mak", R, U3).reshape(3 * M, r)
+        return PDM(ref2, mean2, U2, self.lam.copy())
+
+    def instance(self, alpha: np.ndarray) -> np.ndarray:
+        """ref + mean + U (sqrt(lam) * alpha)  (instanceVector; GingrAlgorithm.scala:222,224)."""
+        v = self.U @ (np.sqrt(self.lam) * np.asarray(alpha, dtype=np.float64))
+        return self.ref + self.mean + v.reshape(self.M, 3)
+
+    def mean_mesh(self) -> np.ndarray:
+        return self.ref + self.mean
+
+    # -- regression ------------------------------------------------------
+    def _regression(self, pids: np.ndarray, disp: np.ndarray, covs: np.ndarray):
+        """genericRegressionComputations: returns (Minv, QtL, yVec, mVec).
+        pids (K,), disp (K,3) observed displacement from the reference, covs (K,3,3)."""
+        r = self.rank
+        K = pids.shape[0]
+        rows = (3 * pids[:, None] + np.arange(3)[None, :]).reshape(-1)
+        Q = self.U[rows, :] * np.sqrt(self.lam)[None, :]            # 3K x r
+        QtL = Q.T.copy()                                            # r x 3K
+        for k in range(K):
+            QtL[:, 3 * k:3 * k + 3] = QtL[:, 3 * k:3 * k + 3] @ np.linalg.inv(covs[k])
+        Mm = QtL @ Q + np.eye(r)
+        Minv = np.linalg.pinv(Mm)
+        yVec = disp.reshape(-1)
+        mVec = self.mean[pids].reshape(-1)
+        return Minv, QtL, yVec, mVec
+
+    def posterior_mean(self, pids, points, covs) -> Tuple[np.ndarray, np.ndarray]:
+        """PointDistributionModel.posterior(obs).mean as a mesh, plus the coefficient vector a.
+        obs point -> displacement from the reference point (GingrAlgorithm.scala:297-301)."""
+        pids = np.asarray(pids, dtype=np.int64)
+        points = np.asarray(points, dtype=np.float64)
+        covs = np.asarray(covs, dtype=np.float64)
+        if not (np.all(np.isfinite(points)) and np.all(np.isfinite(covs))):
+            raise FloatingPointError("non-finite observation")
+        disp = points - self.ref[pids]
+        Minv, QtL, yVec, mVec = self._regression(pids, disp, covs)
+        a = (Minv @ QtL) @ (yVec - mVec)
+        mean_p = self.mean.reshape(-1) + self.U @ (np.sqrt(self.lam) * a)
+        return self.ref + mean_p.reshape(self.M, 3), a
+
+    def coefficients(self, mesh: np.ndarray) -> np.ndarray:
+        """PointDistributionModel.coefficients(mesh): GP regression at ALL points with noise 1e-5 I3
+        (GingrAlgorithm.scala:215,236)."""
+        eps = 1e-5
+        M = self.M
+        pids = np.arange(M, dtype=np.int64)
+        disp = np.asarray(mesh, dtype=np.float64) - self.ref
+        if not np.all(np.isfinite(disp)):
+            raise FloatingPointError("non-finite mesh")
+        # isotropic noise: Q^T L = Q^T / eps, avoid M 3x3 inversions
+        Q = self.U * np.sqrt(self.lam)[None, :]
+        QtL = Q.T / eps
+        Mm = QtL @ Q + np.eye(self.rank)
+        Minv = np.linalg.pinv(Mm)
+        return (Minv @ QtL) @ (disp.reshape(-1) - self.mean.reshape(-1))
+
+
+# --------------------------------------------------------------------------
+# state + A.5 the update map                 [REF G/api/GingrAlgorithm.scala:192-254, 281-302]
+# --------------------------------------------------------------------------
+
+NO_TRANSFORMS, RIGID_TRANSFORMS, SIMILARITY_TRANSFORMS = 0, 1, 2   # G/api/GlobalTranformationType.scala:20-24
+STATUS_NONE, STATUS_MODEL_FLEXIBILITY_ERROR = 0, 3                  # G/api/FittingStatuses.scala:22
+
+
+@dataclasses.dataclass
+class State:
+    """The numeric content of GeneralRegistrationState (G/api/GeneralRegistrationState.scala:28-41)."""
+    alpha: np.ndarray                       # shape parameters (r,)
+    euler: Tuple[float, float, float]       # (phi, theta, psi)
+    center: np.ndarray                      # rotation centre (3,)
+    translation: np.ndarray                 # (3,)
+    scale: float
+    sigma2: float
+    fit: np.ndarray                         # (M,3)
+    iteration: int = 0
+    status: int = STATUS_NONE
+    global_transformation: int = RIGID_TRANSFORMS
+    step_length: float = 1.0
+
+    def rotation(self) -> np.ndarray:
+        return euler_to_rot(*self.euler)
+
+
+def model_instance_shape_pose_scale(model: PDM, st: State) -> np.ndarray:
+    """fit = s * (R (inst - c) + c + t): scale applied AFTER the rigid transform, about the origin
+    (G/api/ModelFittingParameters.scala:130-143)."""
+    inst = model.instance(st.alpha)
+    R = st.rotation()
+    posed = (inst - st.center) @ R.T + st.center + st.translation
+    return st.scale * posed
+
+
+def initial_state(model: PDM, sigma2: float, global_transformation: int = RIGID_TRANSFORMS,
+                  step_length: float = 1.0, init_R: Optional[np.ndarray] = None,
+                  init_t: Optional[np.ndarray] = None) -> State:
+    """GeneralRegistrationState.apply (GeneralRegistrationState.scala:135-179): alpha = 0, optional initial pose."""
+    if init_R is not None:
+        euler = rot_to_euler(init_R)
+        t = np.asarray(init_t, dtype=np.float64)
+    else:
+        euler = (0.0, 0.0, 0.0)
+        t = np.zeros(3)
+    st = State(alpha=np.zeros(model.rank), euler=euler, center=np.zeros(3), translation=t, scale=1.0,
+               sigma2=sigma2, fit=np.zeros((model.M, 3)), global_transformation=global_transformation,
+               step_length=step_length)
+    st.fit = model_instance_shape_pose_scale(model, st)
+    return st
+
+
+@dataclasses.dataclass
+class Landmarks:
+    """landmarkCorrespondences (GeneralRegistrationState.scala:43-62): pid = closest reference vertex to the
+    model landmark, point = target landmark, cov = landmark uncertainty or I3."""
+    pids: np.ndarray     # (L,) int
+    points: np.ndarray   # (L,3)
+    covs: np.ndarray     # (L,3,3)
+
+
+def landmark_correspondences(model_ref: np.ndarray, model_lm: np.ndarray, target_lm: np.ndarray,
+                             covs: Optional[np.ndarray] = None) -> Landmarks:
+    idx, _, _ = icp_closest_point(model_lm, model_ref)
+    L = model_lm.shape[0]
+    if covs is None:
+        covs = np.tile(np.eye(3), (L, 1, 1))
+    return Landmarks(pids=idx.astype(np.int64), points=np.asarray(target_lm, dtype=np.float64), covs=covs)
+
+
+def compute_posterior_mean(model: PDM, st: State, pids, points, variances,
+                           landmarks: Optional[Landmarks]) -> Tuple[np.ndarray, np.ndarray, PDM]:
+    """computePosterior (GingrAlgorithm.scala:281-302) for isotropic per-point covariances plus optional
+    landmark override; returns (posterior mean mesh, a, posed model)."""
+    pids = np.asarray(pids, dtype=np.int64)
+    covs = np.asarray(variances, dtype=np.float64)[:, None, None] * np.eye(3)[None]
+    pts = np.asarray(points, dtype=np.float64)
+    if landmarks is not None and landmarks.pids.shape[0] > 0:
+        keep = ~np.isin(pids, landmarks.pids)                        # :289-292
+        pids = np.concatenate([pids[keep], landmarks.pids])           # :293
+        pts = np.concatenate([pts[keep], landmarks.points])
+        covs = np.concatenate([covs[keep], landmarks.covs])
+    posed = model.transform(st.rotation(), st.translation, st.center)  # :298-299
+    mean_mesh, a = posed.posterior_mean(pids, pts, covs)
+    return mean_mesh, a, posed
+
+
+def update_from_observations(model: PDM, st: State, pids, points, variances, sigma2_next: float,
+                             landmarks: Optional[Landmarks] = None) -> State:
+    """GingrAlgorithm.update (deterministic branch) given the correspondences (A.5 steps 1-7) followed by
+    GingrGeneratorWrapper.propose's fit refresh + iteration++ (step 8,
+    G/api/sampling/generators/GingrGeneratorWrapper.scala:28-39)."""
+    try:
+        shape, _, posed = compute_posterior_mean(model, st, pids, points, variances, landmarks)   # :193,211
+        if not np.all(np.isfinite(shape)):
+            raise FloatingPointError("posterior mean not finite")
+        alpha1 = posed.coefficients(shape)                                                       # :212-216
+        alpha_c = st.alpha + (alpha1 - st.alpha) * st.step_length                                # :218-220
+        newshape = posed.instance(alpha_c)                                                       # :222
+        cur0 = model.instance(st.alpha)                                                          # :224
+        if st.global_transformation == SIMILARITY_TRANSFORMS:                                    # :227-231
+            R2, t2, s2 = umeyama(cur0, newshape, True)
+        elif st.global_transformation == RIGID_TRANSFORMS:
+            R2, t2, s2 = umeyama(cur0, newshape, False)
+        else:
+            R2, t2, s2 = np.eye(3), np.zeros(3), 1.0
+        posed2 = model.transform(R2, t2, np.zeros(3))                                            # :232-234
+        alpha = posed2.coefficients(newshape)                                                    # :235-237
+        if not np.all(np.isfinite(alpha)):
+            raise FloatingPointError("alpha not finite")
+    except (FloatingPointError, np.linalg.LinAlgError):
+        # Try(...) failure: iteration 0 returns the state unchanged, otherwise ModelFlexibilityError (:194-208,248,251)
+        out = dataclasses.replace(st)
+        if st.iteration > 0:
+            out.status = STATUS_MODEL_FLEXIBILITY_ERROR
+        # GingrGeneratorWrapper.propose still refreshes fit and bumps the iteration
+        out.fit = model_instance_shape_pose_scale(model, out)
+        out.iteration = st.iteration + 1
+        return out
+    new = dataclasses.replace(
+        st, alpha=alpha, euler=rot_to_euler(R2), center=np.zeros(3), translation=np.asarray(t2, dtype=np.float64),
+        scale=float(s2), sigma2=float(sigma2_next))                                              # :239-246
+    new.fit = model_instance_shape_pose_scale(model, new)                                        # wrapper :30-37
+    new.iteration = st.iteration + 1
+    return new
+
+
+def cpd_update(model: PDM, target: np.ndarray, st: State, w: float = 0.0, lam: float = 1.0,
+               landmarks: Optional[Landmarks] = None, stats: Optional[CpdStats] = None) -> State:
+    """One CPD iteration: correspondences (A.2), uncertainties, posterior, update map, sigma^2 (A.3)."""
+    if stats is None:
+        stats = cpd_stats_dense(st.fit, target, st.sigma2, w)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        yhat = st.fit + (stats.PX * (1.0 / stats.P1)[:, None] - st.fit)
+        var = cpd_uncertainty_var(stats.P1, st.sigma2, lam)
+    pids = np.arange(model.M)
+    return update_from_observations(model, st, pids, yhat, var, stats.sigma2_next, landmarks)
+
+
+def icp_update(model: PDM, target: np.ndarray, st: State, initial_sigma: float, end_sigma: float,
+               max_iterations: int, landmarks: Optional[Landmarks] = None) -> Tuple[State, np.ndarray]:
+    """One ICP iteration with the point-cloud closest-point correspondence (A.7)."""
+    idx, _, _ = icp_closest_point(st.fit, target)
+    pts = np.asarray(target, dtype=np.float64)[idx]
+    var = np.full(model.M, st.sigma2)                                  # ICP.scala:90-92
+    s2n = icp_update_sigma2(st.sigma2, initial_sigma, end_sigma, max_iterations)
+    return update_from_observations(model, st, np.arange(model.M), pts, var, s2n, landmarks), idx
+
+
+# --------------------------------------------------------------------------
+# f3  GPMM construction (needed to synthesise test models; the reference gets them from scalismo)
+#     [REF G/api/gpmm/GPMMHelper.scala:39-52,99-102; SCALISMO PivotedCholesky.computeApproximateEig]
+# --------------------------------------------------------------------------
+
+def pivoted_cholesky_scalar(points: np.ndarray, sigma: float, scaling: float, rel_tol: float,
+                            max_rank: Optional[int] = None) -> np.ndarray:
+    """Pivoted Cholesky of the scalar kernel matrix k(x_i,x_j) = scaling*exp(-||.||^2/sigma^2); L is (M,k)
+    with K ~ L L^T, stopping when trace(residual) <= rel_tol * trace(K)."""
+    P = np.asarray(points, dtype=np.float64)
+    M = P.shape[0]
+    diag = np.full(M, scaling, dtype=np.float64)
+    tr0 = float(diag.sum())
+    cols = []
+    kmax = M if max_rank is None else min(M, max_rank)
+    while len(cols) < kmax and float(diag.sum()) > rel_tol * tr0:
+        p = int(np.argmax(diag))
+        col = gauss_block(P, P[p:p + 1], sigma, scaling)[:, 0]
+        for c in cols:
+            col = col - c * c[p]
+        piv = diag[p]
+        if piv <= 0:
+            break
+        col = col / math.sqrt(piv)
+        cols.append(col)
+        diag = np.maximum(diag - col * col, 0.0)
+    return np.stack(cols, axis=1)
+
+
+def build_gaussian_gpmm(ref: np.ndarray, sigma: float, scaling: float, rel_tol: float = 0.01,
+                        max_rank: Optional[int] = None) -> PDM:
+    """GPMMTriangleMesh3D.Gaussian: DiagonalKernel(GaussianKernel(sigma) * scaling, 3), zero mean,
+    low-rank approximation by pivoted Cholesky + eigendecomposition of L^T L."""
+    ref = np.asarray(ref, dtype=np.float64)
+    M = ref.shape[0]
+    L = pivoted_cholesky_scalar(ref, sigma, scaling, rel_tol,
+                                None if max_rank is None else (max_rank + 2) // 3)
+    evals, V = np.linalg.eigh(L.T @ L)
+    order = np.argsort(evals)[::-1]
+    evals, V = evals[order], V[:, order]
+    Us = L @ V / np.sqrt(evals)[None, :]                     # (M,k) orthonormal columns
+    k = Us.shape[1]
+    # the 3x3-diagonal kernel replicates every scalar eigenpair once per coordinate
+    U = np.zeros((3 * M, 3 * k), dtype=np.float64)
+    lam = np.zeros(3 * k, dtype=np.float64)
+    for d in range(3):
+        U[d::3, d::3] = Us
+        lam[d::3] = evals
+    if max_rank is not None and U.shape[1] > max_rank:
+        U, lam = U[:, :max_rank], lam[:max_rank]
+    return PDM(ref=ref, mean=np.zeros_like(ref), U=np.ascontiguousarray(U), lam=lam)
