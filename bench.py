@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- GiNGR update iterations/second, CPD 50k <-> 50k, on N MI355X (one process per GPU).
+
+A "step" is ONE full update iteration (GingrAlgorithm.update + the fit refresh) of the CPD configuration on the
+synthetic 50k <-> 50k workload of SURVEY.md section 8d: both all-pairs passes over the 50 000 x 50 000 affinity,
+the weighted Gram + posterior solve, two coefficient projections, Umeyama and the new fit.  Model, target and state
+are resident in HBM before the timed region.  With --gpus N the reference rows are sharded over N ranks and the
+partial sums are all-reduced over RCCL (strong scaling: the problem is fixed).
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the kernels' own stream in extra
+iterations after the timed region; `cpu_baseline` times the C restatement (oracle/, the checker -- never the product)
+on the host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector float64 peak (AMD datasheet)
+F64_MFMA_PEAK_TFLOPS = 78.6   # matrix float64 peak
+HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+# ------------------------------------------------------------------------------------------------ synthetic workload
+def synth_clouds(n_points: int):
+    """x_j ~ N(0, 50^2 I) (seed 1234, float32-rounded like a mesh file); y_i = x_pi(i) + N(0, 2^2 I) (seed 1235)."""
+    x = np.random.default_rng(1234).normal(0.0, 50.0, (n_points, 3)).astype(np.float32).astype(np.float64)
+    rng = np.random.default_rng(1235)
+    y = x[rng.permutation(n_points)] + rng.normal(0.0, 2.0, (n_points, 3))
+    return y, x
+
+
+def synth_gpmm(ref: np.ndarray, rank: int, sigma: float = 70.0, scaling: float = 50.0):
+    """Rank-`rank` Gaussian-kernel GPMM over `ref` (kernel defaults of the femur demo,
+    examples/DemoHelper/DemoDatasetLoader.scala:113-114): pivoted Cholesky of the scalar kernel + eigendecomposition,
+    replicated per coordinate (DiagonalKernel).  Workload synthesis only (numpy, not timed)."""
+    M = ref.shape[0]
+    k = (rank + 2) // 3
+    diag = np.full(M, scaling)
+    cols = []
+    for _ in range(k):
+        p = int(np.argmax(diag))
+        d = ref - ref[p]
+        col = scaling * np.exp(-(d * d).sum(1) / (sigma * sigma))
+        for c in cols:
+            col = col - c * c[p]
+        col = col / math.sqrt(diag[p])
+        cols.append(col)
+        diag = np.maximum(diag - col * col, 0.0)
+    L = np.stack(cols, 1)
+    ev, V = np.linalg.eigh(L.T @ L)
+    order = np.argsort(ev)[::-1]
+    ev, V = ev[order], V[:, order]
+    Us = L @ V / np.sqrt(ev)[None, :]
+    U = np.zeros((3 * M, 3 * k))
+    lam = np.zeros(3 * k)
+    for d in range(3):
+        U[d::3, d::3] = Us
+        lam[d::3] = ev
+    return U[:, :rank].copy(order="F"), lam[:rank].copy()
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(y, x, sigma2, w, budget_s=20.0):
+    """Time the C restatement of the two all-pairs passes (oracle/cpd_oracle.c, OpenMP over all host cores) on a row
+    sample of the SAME workload and scale to one iteration.  The GP part (O(M r^2)) is not included, which favours the
+    CPU number.  Returns the cpu_baseline JSON object."""
+    from oracle import c_oracle as co
+    cores = co.num_threads()
+    M, N = y.shape[0], x.shape[0]
+    # calibrate on a small slice, then pick the sample so that both passes take about budget_s
+    m0 = max(64, min(M, 16 * cores))
+    t0 = time.perf_counter()
+    co.cpd_colsum_partial(y, x, sigma2, 0, m0)
+    dt = time.perf_counter() - t0
+    per_row = dt / m0
+    ms = int(min(M, max(m0, budget_s / 2.0 / max(per_row, 1e-9))))
+    t0 = time.perf_counter()
+    den = co.cpd_colsum_partial(y, x, sigma2, 0, ms) + co.outlier_constant(M, N, sigma2, w) + 1e-300
+    co.cpd_rowstats_partial(y, x, sigma2, den, 0, ms)
+    dt = time.perf_counter() - t0
+    it_per_s = 1.0 / (dt * (M / ms))
+    return {"value": it_per_s, "unit": "iterations/s", "cores": cores, "kind": "port",
+            "sample": f"both all-pairs passes on rows [0,{ms}) of {M} x {N} targets, scaled x{M / ms:.2f}; "
+                      f"{dt:.1f} s measured; GP solve excluded"}
+
+
+# ------------------------------------------------------------------------------------------------ main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=50000)
+    ap.add_argument("--rank", type=int, default=100)
+    ap.add_argument("--w", type=float, default=0.1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    import gingr_amd as ga
+    from gingr_amd.sharded import ShardedFitter
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    M = N = args.points
+    y, x = synth_clouds(M)
+    basis, lam = synth_gpmm(y, args.rank)
+    model = ga.PointDistributionModel(reference=y, mean=np.zeros_like(y), basis=basis, variance=lam)
+
+    ctx = ga.Context(local_rank)
+    stream = torch.cuda.Stream(device=local_rank)
+    ctx.set_stream(stream.cuda_stream)
+
+    def all_reduce(t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    with torch.cuda.stream(stream):
+        fitter = ShardedFitter(ctx, model, x, rank=rank, world=world, all_reduce=all_reduce if world > 1 else None,
+                               global_transform=ga.GlobalTranformationType.RigidTransforms, step_length=1.0)
+        sigma2_0 = ctx.cpd_initial_sigma2(y, x)      # CpdRegistrationState.apply, CPD.scala:92-102 (mean == reference here)
+
+        def reset():
+            fitter.set_state(np.zeros(args.rank), sigma2_0)
+
+        def sync():
+            torch.cuda.synchronize(local_rank)
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize(local_rank)
+
+        reset()
+        fitter.update_cpd(args.w, 1.0, args.warmup)
+        sync()
+        t0 = time.perf_counter()
+        fitter.update_cpd(args.w, 1.0, args.steps)
+        sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        alpha, sc, fit = fitter.get_state()
+        ok = bool(np.all(np.isfinite(fit)) and sc.status == 0 and sc.iteration == args.warmup + args.steps)
+
+        # ---- live roofline of the dominant kernels (HIP events on the kernels' stream, extra iterations)
+        roof = None
+        kernels = []
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        fitter.update_cpd(args.w, 1.0, args.roofline_steps)
+        sync()
+        m_loc = fitter.end - fitter.begin
+        pairs = float(m_loc) * float(N)
+        names = {0: ("cpd_colsum_kernel", 11.0), 1: ("cpd_rowstats_kernel", 18.0)}
+        for which, (name, flops_per_pair) in names.items():
+            ms, n = ctx.timing_read(which)
+            if n:
+                avg = ms / n
+                ach = flops_per_pair * pairs / (avg * 1e-3) / 1e12
+                kernels.append({"kernel": name, "avg_ms": avg, "launches": n, "bound": "valu_f64",
+                                "achieved": ach, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": ach / F64_VALU_PEAK_TFLOPS, "algorithmic_flops_per_pair": flops_per_pair})
+        ms, n = ctx.timing_read(2)
+        if n:
+            avg = ms / n
+            rp = (args.rank + 15) // 16 * 16
+            ach = 6.0 * m_loc * rp * rp / (avg * 1e-3) / 1e12
+            kernels.append({"kernel": "gram_kernel", "avg_ms": avg, "launches": n, "bound": "mfma",
+                            "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach / F64_MFMA_PEAK_TFLOPS})
+        ms, n = ctx.timing_read(3)
+        upd_ms = ms / n if n else None
+        ctx.timing_enable(False)
+        dom = max((k for k in kernels if k["bound"] == "valu_f64"), key=lambda k: k["avg_ms"], default=None)
+        if dom is not None:
+            roof = {"bound": "valu_f64", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": dom["peak"],
+                    "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None,
+                    "note": "all-pairs kernel: O(M+N) bytes, O(M*N) float64 VALU flops (software exp counted as 1 flop); "
+                            "HBM and MFMA are not the binding resource"}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(y, x, sigma2_0, args.w)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "GiNGR update iters/sec, 50k<->50k CPD",
+            "value": args.steps / elapsed,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"CPD update, synthetic Gaussian clouds {M}<->{N}, GPMM rank {args.rank}, w={args.w}, "
+                                   f"rigid global transform, sigma2_0={sigma2_0:.3f}",
+                       "points": M, "targets": N, "rank": args.rank, "parallelism": f"row-shard x{world}"},
+            "valid": ok,
+            "update_ms_device": upd_ms,
+            "roofline": roof,
+            "kernels": kernels,
+            "cpu_baseline": cpu,
+        }
+        if cpu:
+            out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
+        print(json.dumps(out))
+    fitter.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,151 @@
+"""Row-sharded GiNGR update: one process per GPU, reference-point rows split across ranks.
+
+The N x M affinity matrix is sharded by reference (fit) rows; the target cloud and all r-sized state are replicated
+(SURVEY.md section 8e).  One iteration is the six phases of gingr_amd/csrc/fitter.hip; after phases 0..4 the partial
+sums in exchange segment p are all-reduced (sum, float64) across ranks:
+
+    segment 0  CPD column sums den_j (N doubles)          <- the column-sum exchange named in BASELINE.json north_star
+    segment 1  weighted Gram (rp*rp) + rhs (rp) + 8 sigma^2 partial sums
+    segment 2  first projection (rp)      segment 3  Umeyama sums (24)      segment 4  second projection (rp)
+
+The collective itself is plumbing: `torch.distributed.all_reduce` on a tensor that aliases the library's exchange
+buffer (backend "nccl" = RCCL over xGMI on the GPU box).  The r x r solve and the 3x3 SVD are replicated on every rank
+(deterministic, so no broadcast is needed).
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_int64, c_void_p
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+from . import _native as nat
+from .api import (Context, DeviceModel, PointDistributionModel, _check, f64, dptr)
+
+NUM_PHASES = nat.NUM_PHASES
+NUM_SEGMENTS = nat.NUM_SEGMENTS
+
+
+def shard_rows(M: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous balanced row ranges: the first (M mod world) ranks hold one extra row."""
+    base, extra = divmod(int(M), int(world))
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def drive_update(run_phase: Callable[[int], None], all_reduce_segment: Callable[[int], None], world: int,
+                 skip_segment0: bool = False) -> None:
+    """One iteration: phase p, then (for p < 5) the all-reduce of exchange segment p."""
+    for ph in range(NUM_PHASES):
+        run_phase(ph)
+        if world > 1 and ph < NUM_SEGMENTS and not (skip_segment0 and ph == 0):
+            all_reduce_segment(ph)
+
+
+class _DevArray:
+    """Minimal __cuda_array_interface__ view of device memory owned by libgingr_hip."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def as_torch(ptr: int, count: int, device_index: int = 0):
+    import torch
+    return torch.as_tensor(_DevArray(ptr, count), device=f"cuda:{device_index}")
+
+
+class ShardedFitter:
+    """The native fitter of one rank (rows [begin, end) of the model) plus the exchange plumbing.
+
+    all_reduce(tensor) must sum the float64 device tensor in place across all ranks; None means a single shard.
+    """
+
+    def __init__(self, ctx: Context, model: PointDistributionModel, target, rank: int = 0, world: int = 1,
+                 all_reduce: Optional[Callable] = None, global_transform: int = 1, step_length: float = 1.0):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self._lib = ctx._lib
+        self.all_reduce = all_reduce
+        self.begin, self.end = shard_rows(model.numberOfPoints, world, rank)
+        self.dev_model = DeviceModel(ctx, model, self.begin, self.end)
+        self.model = model
+        if world > 1:
+            ptr, n = self.dev_model.gram_exchange()
+            g = as_torch(ptr, n, ctx.device)
+            ctx.synchronize()
+            all_reduce(g)
+            self._sync_torch()
+            self.dev_model.finalize()
+        h = c_void_p()
+        _check(ctx.handle, self._lib.gingr_fitter_create(ctx.handle, self.dev_model.handle, ctypes.byref(h)), "gingr_fitter_create")
+        self.handle = h
+        x = f64(target)
+        _check(ctx.handle, self._lib.gingr_fitter_set_target(h, x.shape[0], dptr(x)), "gingr_fitter_set_target")
+        _check(ctx.handle, self._lib.gingr_fitter_set_options(h, int(global_transform), float(step_length)), "set_options")
+        p = c_void_p()
+        offs = (c_int64 * NUM_SEGMENTS)()
+        cnts = (c_int64 * NUM_SEGMENTS)()
+        _check(ctx.handle, self._lib.gingr_fitter_exchange(h, ctypes.byref(p), offs, cnts), "gingr_fitter_exchange")
+        self.offsets, self.counts = list(offs), list(cnts)
+        self.xch = None
+        if world > 1:
+            total = self.offsets[-1] + self.counts[-1]
+            self.xch = as_torch(p.value, total, ctx.device)
+
+    def _sync_torch(self):
+        import torch
+        torch.cuda.synchronize(self.ctx.device)
+
+    def set_state(self, alpha, sigma2: float, euler=(0.0, 0.0, 0.0), center=(0.0, 0.0, 0.0),
+                  translation=(0.0, 0.0, 0.0), scale: float = 1.0, iteration: int = 0, status: int = 0):
+        s = nat.StateScalars()
+        s.euler[:] = list(euler)
+        s.center[:] = list(center)
+        s.translation[:] = list(translation)
+        s.scale, s.sigma2, s.iteration, s.status = scale, sigma2, iteration, status
+        a = f64(alpha)
+        _check(self.ctx.handle, self._lib.gingr_fitter_set_state(self.handle, dptr(a), ctypes.byref(s)), "gingr_fitter_set_state")
+
+    def get_state(self):
+        r = self.model.rank
+        M = self.end - self.begin
+        alpha, fit = np.empty(r), np.empty((M, 3))
+        s = nat.StateScalars()
+        _check(self.ctx.handle, self._lib.gingr_fitter_get_state(self.handle, dptr(alpha), ctypes.byref(s), dptr(fit)),
+               "gingr_fitter_get_state")
+        return alpha, s, fit
+
+    def _segment(self, seg: int):
+        return self.xch[self.offsets[seg]: self.offsets[seg] + self.counts[seg]]
+
+    def update_cpd(self, w: float = 0.0, lambda_: float = 1.0, n_iterations: int = 1):
+        p = nat.CpdParams(w, lambda_)
+        if self.world == 1:
+            _check(self.ctx.handle, self._lib.gingr_fitter_update_cpd_async(self.handle, ctypes.byref(p), n_iterations),
+                   "gingr_fitter_update_cpd_async")
+            return
+        for _ in range(n_iterations):
+            drive_update(
+                lambda ph: _check(self.ctx.handle, self._lib.gingr_fitter_cpd_phase_async(self.handle, ctypes.byref(p), ph),
+                                  "gingr_fitter_cpd_phase_async"),
+                lambda seg: self.all_reduce(self._segment(seg)), self.world)
+
+    def update_icp(self, initial_sigma: float, end_sigma: float, max_iterations: int, n_iterations: int = 1):
+        p = nat.IcpParams(initial_sigma, end_sigma, max_iterations)
+        if self.world == 1:
+            _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_async(self.handle, ctypes.byref(p), n_iterations),
+                   "gingr_fitter_update_icp_async")
+            return
+        for _ in range(n_iterations):
+            drive_update(
+                lambda ph: _check(self.ctx.handle, self._lib.gingr_fitter_icp_phase_async(self.handle, ctypes.byref(p), ph),
+                                  "gingr_fitter_icp_phase_async"),
+                lambda seg: self.all_reduce(self._segment(seg)), self.world, skip_segment0=True)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.gingr_fitter_destroy(self.handle)
+            self.handle = None
+        if getattr(self, "dev_model", None) is not None:
+            self.dev_model.close()
+            self.dev_model = None
