@@ -26,13 +26,33 @@ struct __attribute__((aligned(32))) P4 {
 };
 
 // ---------------------------------------------------------------- pass 1: column sums of K
+template <int PT, bool CLAMP>
+__device__ __forceinline__ void colsum_tile(const P4 *tile, int cnt, const double (&x)[PT], const double (&y)[PT],
+                                            const double (&z)[PT], double (&acc)[PT], double c, double lim, const double *T) {
+#pragma unroll 2
+    for (int ii = 0; ii < cnt; ++ii) {
+        const P4 p = tile[ii];
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const double dx = x[t] - p.x, dy = y[t] - p.y, dz = z[t] - p.z;
+            double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+            if (CLAMP) d2 = fmin(d2, lim);
+            acc[t] += fastexp2_scaled(d2, c, T);
+        }
+    }
+}
+
 template <int PT>
 __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt, const double *__restrict__ sigma2,
-                                                            int64_t rows_per_chunk, double *__restrict__ partial) {
+                                                            const double *__restrict__ absmax, int64_t rows_per_chunk,
+                                                            double *__restrict__ partial) {
     __shared__ double T[GINGR_EXP_TABLE];
     __shared__ P4 tile[kTile];
     fastexp_table_init(T);
-    const double c64 = fastexp_scale_for_variance(2.0 * sigma2[0]);
+    const double c = fastexp_scale_for_variance(2.0 * sigma2[0]);
+    const double am = absmax[0] + absmax[1];
+    const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);  // wave-uniform
+    const double lim = fastexp_d2_limit(c);
     const int tid = threadIdx.x;
     const int64_t jbase = (int64_t)blockIdx.x * (kBlock * PT) + tid;
     double x[PT], y[PT], z[PT], acc[PT];
@@ -53,21 +73,35 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         if (i < i1) tile[tid] = P4{fit.x[i], fit.y[i], fit.z[i], 0.0};
         __syncthreads();
         const int cnt = (int)min((int64_t)kTile, i1 - ib);
-#pragma unroll 2
-        for (int ii = 0; ii < cnt; ++ii) {
-            const P4 p = tile[ii];
-#pragma unroll
-            for (int t = 0; t < PT; ++t) {
-                const double dx = x[t] - p.x, dy = y[t] - p.y, dz = z[t] - p.z;
-                const double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
-                acc[t] += fastexp2_64(d2 * c64, T);
-            }
-        }
+        if (clamp)
+            colsum_tile<PT, true>(tile, cnt, x, y, z, acc, c, lim, T);
+        else
+            colsum_tile<PT, false>(tile, cnt, x, y, z, acc, c, lim, T);
     }
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         const int64_t j = jbase + (int64_t)t * kBlock;
         if (j < tgt.n) partial[(int64_t)blockIdx.y * tgt.n + j] = acc[t];
+    }
+}
+
+// absmax[slot] = max over the cloud of |x|, |y|, |z| (atomic max on the bit pattern of a non-negative double:
+// order independent, hence deterministic).  The slot must be zeroed before the launch.
+__global__ __launch_bounds__(256) void cloud_absmax_kernel(Cloud c, double *__restrict__ slot) {
+    __shared__ double sh[256];
+    double m = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < c.n; i += (int64_t)gridDim.x * 256)
+        m = fmax(m, fmax(fabs(c.x[i]), fmax(fabs(c.y[i]), fabs(c.z[i]))));
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double v = sh[0];
+        if (!(v == v)) v = __builtin_huge_val();  // NaN coordinates: force the clamped path
+        atomicMax(reinterpret_cast<unsigned long long *>(slot), __builtin_bit_cast(unsigned long long, v));
     }
 }
 
@@ -93,17 +127,20 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
     return sh[0];
 }
 
-// den[j] = colsum[j] + c ; inv_den ; Pt1 ; xPx = sum_j Pt1_j |x_j|^2 (single block, fixed order)
-__global__ __launch_bounds__(1024) void cpd_den_finalize_kernel(Cloud tgt, const double *__restrict__ sigma2, double w,
-                                                                double m_over_n, double *__restrict__ den,
-                                                                double *__restrict__ inv_den, double *__restrict__ Pt1,
-                                                                double *__restrict__ scalars) {
-    __shared__ double sh[1024];
+// den[j] = colsum[j] + c ; inv_den ; Pt1 ; per-block partial of xPx = sum_j Pt1_j |x_j|^2.
+// Always launched with kScalarBlocks workgroups; part[0..kScalarBlocks) receives the xPx partials.
+constexpr int kScalarBlocks = 256;
+
+__global__ __launch_bounds__(256) void cpd_den_finalize_kernel(Cloud tgt, const double *__restrict__ sigma2, double w,
+                                                               double m_over_n, double *__restrict__ den,
+                                                               double *__restrict__ inv_den, double *__restrict__ Pt1,
+                                                               double *__restrict__ part, double *__restrict__ scalars) {
+    __shared__ double sh[256];
     const double s2 = sigma2[0];
     // c = w/(1-w) * (2 pi sigma2)^(3/2) * (M/N)     CPD.scala:69-70
     const double c = w / (1.0 - w) * pow(2.0 * 3.14159265358979323846 * s2, 1.5) * m_over_n;
     double xpx = 0.0;
-    for (int64_t j = threadIdx.x; j < tgt.n; j += 1024) {
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < tgt.n; j += (int64_t)kScalarBlocks * 256) {
         const double colsum = den[j];
         const double d = colsum + c;
         const double inv = 1.0 / d;
@@ -114,22 +151,47 @@ __global__ __launch_bounds__(1024) void cpd_den_finalize_kernel(Cloud tgt, const
         const double xx = tgt.x[j], yy = tgt.y[j], zz = tgt.z[j];
         xpx += pt1 * (xx * xx + yy * yy + zz * zz);
     }
-    const double tot = block_sum<1024>(xpx, sh);
+    const double tot = block_sum<256>(xpx, sh);
     if (threadIdx.x == 0) {
-        scalars[1] = tot;
-        scalars[5] = c;
+        part[blockIdx.x] = tot;
+        if (blockIdx.x == 0) scalars[5] = c;
     }
 }
 
 // ---------------------------------------------------------------- pass 2: row statistics
+template <int PT, bool CLAMP>
+__device__ __forceinline__ void rowstats_tile(const P4 *tile, int cnt, const double (&x)[PT], const double (&y)[PT],
+                                              const double (&z)[PT], double (&a1)[PT], double (&ax)[PT], double (&ay)[PT],
+                                              double (&az)[PT], double c, double lim, const double *T) {
+#pragma unroll 2
+    for (int jj = 0; jj < cnt; ++jj) {
+        const P4 p = tile[jj];
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const double dx = p.x - x[t], dy = p.y - y[t], dz = p.z - z[t];
+            double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+            if (CLAMP) d2 = fmin(d2, lim);
+            const double pij = fastexp2_scaled(d2, c, T) * p.w;
+            a1[t] += pij;
+            ax[t] = __builtin_fma(pij, p.x, ax[t]);
+            ay[t] = __builtin_fma(pij, p.y, ay[t]);
+            az[t] = __builtin_fma(pij, p.z, az[t]);
+        }
+    }
+}
+
 template <int PT>
 __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud tgt, const double *__restrict__ sigma2,
+                                                              const double *__restrict__ absmax,
                                                               const double *__restrict__ inv_den, int64_t cols_per_chunk,
                                                               double *__restrict__ partial) {
     __shared__ double T[GINGR_EXP_TABLE];
     __shared__ P4 tile[kTile];
     fastexp_table_init(T);
-    const double c64 = fastexp_scale_for_variance(2.0 * sigma2[0]);
+    const double c = fastexp_scale_for_variance(2.0 * sigma2[0]);
+    const double am = absmax[0] + absmax[1];
+    const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);  // wave-uniform
+    const double lim = fastexp_d2_limit(c);
     const int tid = threadIdx.x;
     const int64_t ibase = (int64_t)blockIdx.x * (kBlock * PT) + tid;
     double x[PT], y[PT], z[PT], a1[PT], ax[PT], ay[PT], az[PT];
@@ -150,20 +212,10 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
         if (j < j1) tile[tid] = P4{tgt.x[j], tgt.y[j], tgt.z[j], inv_den[j]};
         __syncthreads();
         const int cnt = (int)min((int64_t)kTile, j1 - jb);
-#pragma unroll 2
-        for (int jj = 0; jj < cnt; ++jj) {
-            const P4 p = tile[jj];
-#pragma unroll
-            for (int t = 0; t < PT; ++t) {
-                const double dx = p.x - x[t], dy = p.y - y[t], dz = p.z - z[t];
-                const double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
-                const double pij = fastexp2_64(d2 * c64, T) * p.w;
-                a1[t] += pij;
-                ax[t] = __builtin_fma(pij, p.x, ax[t]);
-                ay[t] = __builtin_fma(pij, p.y, ay[t]);
-                az[t] = __builtin_fma(pij, p.z, az[t]);
-            }
-        }
+        if (clamp)
+            rowstats_tile<PT, true>(tile, cnt, x, y, z, a1, ax, ay, az, c, lim, T);
+        else
+            rowstats_tile<PT, false>(tile, cnt, x, y, z, a1, ax, ay, az, c, lim, T);
     }
     const int64_t M = fit.n;
     double *base = partial + (int64_t)blockIdx.y * 4 * M;
@@ -179,47 +231,53 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
     }
 }
 
-// P1 / PX from chunk partials (ascending chunk order)
-__global__ void rowstats_reduce_kernel(const double *__restrict__ partial, int nchunks, int64_t M, double *__restrict__ P1,
-                                       double *__restrict__ PX) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    double s1 = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
-    for (int c = 0; c < nchunks; ++c) {
-        const double *b = partial + (int64_t)c * 4 * M;
-        s1 += b[i];
-        sx += b[M + i];
-        sy += b[2 * M + i];
-        sz += b[3 * M + i];
-    }
-    P1[i] = s1;
-    PX[i] = sx;
-    PX[M + i] = sy;
-    PX[2 * M + i] = sz;
-}
-
-// Np = sum P1, trPXY = sum_i y_i . PX_i, yPy = sum_i P1_i |y_i|^2   over the local rows (single block, fixed order)
-__global__ __launch_bounds__(1024) void cpd_row_scalars_kernel(Cloud fit, const double *__restrict__ P1,
-                                                               const double *__restrict__ PX, double *__restrict__ scalars) {
-    __shared__ double sh[1024];
+// P1 / PX from chunk partials (ascending chunk order) plus per-block partials of
+// Np = sum P1, trPXY = sum_i y_i . PX_i, yPy = sum_i P1_i |y_i|^2 over the local rows.
+// Always launched with kScalarBlocks workgroups; part[(1..3)*kScalarBlocks + block].
+__global__ __launch_bounds__(256) void rowstats_reduce_kernel(const double *__restrict__ partial, int nchunks, Cloud fit,
+                                                              double *__restrict__ P1, double *__restrict__ PX,
+                                                              double *__restrict__ part) {
+    __shared__ double sh[256];
     const int64_t M = fit.n;
     double np = 0.0, tr = 0.0, ypy = 0.0;
-    for (int64_t i = threadIdx.x; i < M; i += 1024) {
-        const double p1 = P1[i];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)kScalarBlocks * 256) {
+        double s1 = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+        for (int c = 0; c < nchunks; ++c) {
+            const double *b = partial + (int64_t)c * 4 * M;
+            s1 += b[i];
+            sx += b[M + i];
+            sy += b[2 * M + i];
+            sz += b[3 * M + i];
+        }
+        P1[i] = s1;
+        PX[i] = sx;
+        PX[M + i] = sy;
+        PX[2 * M + i] = sz;
         const double yx = fit.x[i], yy = fit.y[i], yz = fit.z[i];
-        np += p1;
-        tr += yx * PX[i] + yy * PX[M + i] + yz * PX[2 * M + i];
-        ypy += p1 * (yx * yx + yy * yy + yz * yz);
+        np += s1;
+        tr += yx * sx + yy * sy + yz * sz;
+        ypy += s1 * (yx * yx + yy * yy + yz * yz);
     }
-    const double a = block_sum<1024>(np, sh);
+    const double a = block_sum<256>(np, sh);
     __syncthreads();
-    const double b = block_sum<1024>(tr, sh);
+    const double b = block_sum<256>(tr, sh);
     __syncthreads();
-    const double c = block_sum<1024>(ypy, sh);
+    const double c = block_sum<256>(ypy, sh);
     if (threadIdx.x == 0) {
-        scalars[0] = a;
-        scalars[2] = b;
-        scalars[3] = c;
+        part[kScalarBlocks + blockIdx.x] = a;
+        part[2 * kScalarBlocks + blockIdx.x] = b;
+        part[3 * kScalarBlocks + blockIdx.x] = c;
+    }
+}
+
+// scalars[q] = sum of part[q*kScalarBlocks ..], q = 1 (xPx), 0 (Np), 2 (trPXY), 3 (yPy); fixed order
+__global__ __launch_bounds__(256) void cpd_scalars_finish_kernel(const double *__restrict__ part, double *__restrict__ scalars) {
+    __shared__ double sh[256];
+    const int map[4] = {1, 0, 2, 3};  // part slot -> scalar index
+    for (int q = 0; q < 4; ++q) {
+        const double tot = block_sum<256>(part[q * kScalarBlocks + threadIdx.x], sh);
+        if (threadIdx.x == 0) scalars[map[q]] = tot;
+        __syncthreads();
     }
 }
 
@@ -286,13 +344,13 @@ __global__ __launch_bounds__(kBlock) void gauss_block_kernel(Cloud A, Cloud B, d
     __shared__ double T[GINGR_EXP_TABLE];
     fastexp_table_init(T);
     __syncthreads();
-    const double c64 = fastexp_scale_for_variance(sigma * sigma);
+    const double c = fastexp_scale_for_variance(sigma * sigma);
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t i = blockIdx.y;
     if (j >= B.n) return;
     const double dx = A.x[i] - B.x[j], dy = A.y[i] - B.y[j], dz = A.z[i] - B.z[j];
-    const double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
-    out[i * B.n + j] = scaling * fastexp2_64(d2 * c64, T);
+    const double d2 = fmin(__builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx)), fastexp_d2_limit(c));
+    out[i * B.n + j] = scaling * fastexp2_scaled(d2, c, T);
 }
 
 // ---------------------------------------------------------------- sum of squared pair distances (initial sigma2)
@@ -386,40 +444,47 @@ int64_t nn_ws_bytes(int64_t M, int64_t N) {
     return (int64_t)nch * M * (sizeof(double) + sizeof(int32_t));
 }
 
-void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, double *ws,
-                       double *den_partial) {
+void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, double *slot) {
+    (void)hipMemsetAsync(slot, 0, sizeof(double), ctx->stream);
+    const int nb = (int)(ceil_div(c.n, 256) < 64 ? ceil_div(c.n, 256) : 64);
+    hipLaunchKernelGGL(cloud_absmax_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, ctx->stream, c, slot);
+}
+
+void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *absmax,
+                       double *ws, double *den_partial) {
     int nch;
     int64_t len;
     plan_chunks(target.n, kBlock * kPT, fit.n, &nch, &len);
     dim3 grid((unsigned)ceil_div(target.n, kBlock * kPT), (unsigned)nch);
     {
         TimerScope ts(ctx, 0);
-        hipLaunchKernelGGL(cpd_colsum_kernel<kPT>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, len, ws);
+        hipLaunchKernelGGL(cpd_colsum_kernel<kPT>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, absmax, len,
+                           ws);
     }
     hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)ceil_div(target.n, 256)), dim3(256), 0, ctx->stream, ws, nch,
                        target.n, den_partial);
 }
 
 void launch_cpd_den_finalize(gingr_ctx *ctx, Cloud target, const double *sigma2_dev, double w, int64_t M_total,
-                             double *den, double *inv_den, double *Pt1, double *scalars_dev) {
-    hipLaunchKernelGGL(cpd_den_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream, target, sigma2_dev, w,
-                       (double)M_total / (double)target.n, den, inv_den, Pt1, scalars_dev);
+                             double *den, double *inv_den, double *Pt1, double *part, double *scalars_dev) {
+    hipLaunchKernelGGL(cpd_den_finalize_kernel, dim3(kScalarBlocks), dim3(256), 0, ctx->stream, target, sigma2_dev, w,
+                       (double)M_total / (double)target.n, den, inv_den, Pt1, part, scalars_dev);
 }
 
-void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *inv_den,
-                         double *ws, double *P1, double *PX_soa, double *scalars_dev) {
+void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *absmax,
+                         const double *inv_den, double *ws, double *P1, double *PX_soa, double *part, double *scalars_dev) {
     int nch;
     int64_t len;
     plan_chunks(fit.n, kBlock * kPT, target.n, &nch, &len);
     dim3 grid((unsigned)ceil_div(fit.n, kBlock * kPT), (unsigned)nch);
     {
         TimerScope ts(ctx, 1);
-        hipLaunchKernelGGL(cpd_rowstats_kernel<kPT>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, inv_den,
-                           len, ws);
+        hipLaunchKernelGGL(cpd_rowstats_kernel<kPT>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, absmax,
+                           inv_den, len, ws);
     }
-    hipLaunchKernelGGL(rowstats_reduce_kernel, dim3((unsigned)ceil_div(fit.n, 256)), dim3(256), 0, ctx->stream, ws, nch,
-                       fit.n, P1, PX_soa);
-    hipLaunchKernelGGL(cpd_row_scalars_kernel, dim3(1), dim3(1024), 0, ctx->stream, fit, P1, PX_soa, scalars_dev);
+    hipLaunchKernelGGL(rowstats_reduce_kernel, dim3(kScalarBlocks), dim3(256), 0, ctx->stream, ws, nch, fit, P1, PX_soa,
+                       part);
+    hipLaunchKernelGGL(cpd_scalars_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, part, scalars_dev);
 }
 
 void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, void *ws, int32_t *idx, double *d2) {

@@ -96,15 +96,19 @@ int64_t cpd_rowstats_ws_doubles(int64_t M, int64_t N);
 int64_t nn_ws_bytes(int64_t M, int64_t N);
 
 // den_partial[N] = sum_{i in fit} exp(-|x_j - y_i|^2 / (2 sigma2))   (no outlier constant)
-void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, double *ws,
-                       double *den_partial);
-// den[j] += c; inv_den[j] = 1/den[j]; Pt1[j] = (den[j]-c)/den[j]; xpx partial -> scalars_dev[1]
-// M_total enters the outlier constant c = w/(1-w) (2 pi sigma2)^1.5 M_total/N.
+// absmax[0] / absmax[1]: largest |coordinate| of the target / fit cloud (launch_cloud_absmax); the kernels derive an
+// upper bound of d2 from them to decide (wave-uniformly) whether the exponent argument needs clamping.
+void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, double *slot);
+void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *absmax,
+                       double *ws, double *den_partial);
+// den[j] += c; inv_den[j] = 1/den[j]; Pt1[j] = (den[j]-c)/den[j]; xPx block partials -> part[0..256)
+// M_total enters the outlier constant c = w/(1-w) (2 pi sigma2)^1.5 M_total/N.  part: GINGR_SCALAR_PART doubles.
+#define GINGR_SCALAR_PART 1024
 void launch_cpd_den_finalize(gingr_ctx *ctx, Cloud target, const double *sigma2_dev, double w, int64_t M_total,
-                             double *den, double *inv_den, double *Pt1, double *scalars_dev);
-// P1[i], PX (SoA planes px,py,pz of stride M) for the local rows, plus Np/trPXY/yPy partial sums into scalars_dev[0,2,3]
-void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *inv_den,
-                         double *ws, double *P1, double *PX_soa, double *scalars_dev);
+                             double *den, double *inv_den, double *Pt1, double *part, double *scalars_dev);
+// P1[i], PX (SoA planes px,py,pz of stride M) for the local rows; Np/xPx/trPXY/yPy sums into scalars_dev[0..3]
+void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *absmax,
+                         const double *inv_den, double *ws, double *P1, double *PX_soa, double *part, double *scalars_dev);
 void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, void *ws, int32_t *idx, double *d2);
 void launch_gauss_block(gingr_ctx *ctx, Cloud A, Cloud B, double sigma, double scaling, double *out);
 void launch_sumsq_pairs(gingr_ctx *ctx, Cloud A, Cloud B, double *ws, double *out_scalar);

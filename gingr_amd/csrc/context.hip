@@ -161,7 +161,7 @@ int gingr_cpd_stats(gingr_ctx *ctx, int64_t M, const double *fit, int64_t N, con
     if (M < 1 || N < 1 || !fit || !target) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "cpd_stats: M, N must be >= 1");
     if (!(w >= 0.0 && w < 1.0)) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "cpd_stats: w must be in [0,1)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf sf, st, df, dt, dws, dden, dinv, dpt1, dp1, dpx, dsc, daos;
+    DevBuf sf, st, df, dt, dws, dden, dinv, dpt1, dp1, dpx, dsc, daos, dpart;
     Cloud cf, ct;
     GINGR_TRY(upload_cloud(ctx, M, fit, sf, df, &cf));
     GINGR_TRY(upload_cloud(ctx, N, target, st, dt, &ct));
@@ -174,13 +174,17 @@ int gingr_cpd_stats(gingr_ctx *ctx, int64_t M, const double *fit, int64_t N, con
     HIP_TRY(ctx, dpx.alloc(3 * M * sizeof(double)));
     HIP_TRY(ctx, daos.alloc(3 * M * sizeof(double)));
     HIP_TRY(ctx, dsc.alloc(16 * sizeof(double)));
+    HIP_TRY(ctx, dpart.alloc(GINGR_SCALAR_PART * sizeof(double)));
     HIP_TRY(ctx, hipMemsetAsync(dsc.p, 0, 16 * sizeof(double), ctx->stream));
     double *sc = dsc.as<double>();
     double *s2dev = sc + 8;
     HIP_TRY(ctx, hipMemcpyAsync(s2dev, &sigma2, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    launch_cpd_colsum(ctx, cf, ct, s2dev, dws.as<double>(), dden.as<double>());
-    launch_cpd_den_finalize(ctx, ct, s2dev, w, M, dden.as<double>(), dinv.as<double>(), dpt1.as<double>(), sc);
-    launch_cpd_rowstats(ctx, cf, ct, s2dev, dinv.as<double>(), dws.as<double>(), dp1.as<double>(), dpx.as<double>(), sc);
+    double *absmax = sc + 10;
+    launch_cloud_absmax(ctx, ct, absmax);
+    launch_cloud_absmax(ctx, cf, absmax + 1);
+    launch_cpd_colsum(ctx, cf, ct, s2dev, absmax, dws.as<double>(), dden.as<double>());
+    launch_cpd_den_finalize(ctx, ct, s2dev, w, M, dden.as<double>(), dinv.as<double>(), dpt1.as<double>(), dpart.as<double>(), sc);
+    launch_cpd_rowstats(ctx, cf, ct, s2dev, absmax, dinv.as<double>(), dws.as<double>(), dp1.as<double>(), dpx.as<double>(), dpart.as<double>(), sc);
     GINGR_TRY(check_launch(ctx));
     launch_soa_to_aos(ctx, dpx.as<double>(), M, daos.as<double>());
     double hsc[8];

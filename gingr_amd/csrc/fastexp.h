@@ -1,56 +1,75 @@
 // Table-driven float64 2^x for the all-pairs Gaussian kernels (device code, gfx950).
 //
 // The affinity kernels evaluate exp(-d2 / (2 sigma2)) once per (reference, target) pair; gfx950 has no float64
-// transcendental unit, so the kernel is bound by how many f64 VALU instructions one exponential costs.  The
-// library exp() is a ~25-instruction polynomial; this one needs 11 plus one 8-byte LDS read:
+// transcendental unit, so the kernels are bound by how many full-rate f64 VALU instructions one exponential costs
+// (every f64 op -- fma, add, mul, ldexp, rndne, cvt -- issues at 4 cycles per wave; profiles/r01_ubench_*).
+// The library exp() is a ~25-instruction polynomial; this one is 8 instructions plus one 8-byte LDS read:
 //
-//   t  = d2 * c64,  c64 = -64 log2(e) / (2 sigma2)        (argument in units of 1/64 octave)
-//   kf = rint(t);  f = t - kf  (exact, |f| <= 1/2);  k = (int)kf;  j = k & 63;  e = k >> 6
-//   2^(t/64) = 2^e * T[j] * 2^(f/64),   T[j] = 2^(j/64) from a 64-entry LDS table
-//   2^(f/64) = 1 + f*q(f),  q = degree-4 polynomial (Taylor of exp(f ln2/64); truncation 3.5e-17 relative)
+//   tm = fma(d2, c, MAGIC)          c = -2048 log2(e) / (2 sigma2): argument in units of 1/2048 octave;
+//                                   MAGIC = 1.5 * 2^52, so tm = MAGIC + k with k = round(d2*c) in the low mantissa bits
+//   kf = tm - MAGIC                 (exact)
+//   f  = fma(d2, c, -kf)            = d2*c - k with ONE rounding, |f| <= 1/2
+//   2^(d2*c/2048) = 2^e * T[j] * 2^(f/2048),  j = k & 2047,  e = k >> 11,  T[j] = 2^(j/2048) (16 KB LDS table)
+//   2^(f/2048) = 1 + f*q(f),  q = c1 + f*(c2 + f*c3)   (Taylor of exp(f ln2/2048); truncation 3.4e-17 relative)
+//   result = ldexp(fma(T[j], f*q, T[j]), e)
 //
-// Accuracy: <= 1 ulp of the correctly rounded result of its (already rounded) argument; v_ldexp_f64 produces
-// gradual underflow and flushes to +0 below 2^-1075 like Math.exp in the reference (CPD.scala:56).  NaN propagates.
-// v_cvt_i32_f64 saturates, so arguments far below the underflow threshold need no clamp.
+// Accuracy: <= 1 ulp of the correctly rounded result of its argument; v_ldexp_f64 gives gradual underflow and flushes
+// to +0 below 2^-1075 like Math.exp in the reference (CPD.scala:56).  NaN propagates (tm = NaN -> f = NaN).
+// Range: e is taken from mantissa bits 11..42 of tm, valid for |d2*c| < 2^42 (= 1.5e9 in units of d2/(2 sigma2));
+// callers clamp d2 when the inputs could exceed that (fastexp_needs_clamp).
 #pragma once
 
 #include <hip/hip_runtime.h>
 
-#define GINGR_EXP_TABLE 64
+#define GINGR_EXP_TABLE 2048
+#define GINGR_EXP_TABLE_LOG2 11
 
-// ln2/64 powers over factorials: 2^(f/64) = sum_n (f ln2/64)^n / n!
-#define GINGR_EXP_C1 1.08304246962491451e-02  /* ln2/64 */
-#define GINGR_EXP_C2 5.86490495505616929e-05  /* (ln2/64)^2/2 */
-#define GINGR_EXP_C3 2.11731371554647736e-07  /* (ln2/64)^3/6 */
-#define GINGR_EXP_C4 5.73285168864040189e-10  /* (ln2/64)^4/24 */
-#define GINGR_EXP_C5 1.24178437017169233e-12  /* (ln2/64)^5/120 */
+#define GINGR_EXP_C1 3.38450771757785784e-04  /* ln2/2048 */
+#define GINGR_EXP_C2 5.72744624517204032e-08  /* (ln2/2048)^2/2 */
+#define GINGR_EXP_C3 6.46152867293236500e-12  /* (ln2/2048)^3/6 */
+#define GINGR_EXP_MAGIC 6755399441055744.0    /* 1.5 * 2^52 */
 
 __device__ static const double gingr_exp_table_rom[GINGR_EXP_TABLE] = {
 #include "exp_table.inc"
 };
 
-// copy T[j] = 2^(j/64) into LDS; every thread of the block must call it, followed by __syncthreads()
+// copy T[j] = 2^(j/2048) into LDS; every thread of the block must call it, followed by __syncthreads()
 __device__ __forceinline__ void fastexp_table_init(double *T) {
     for (int j = threadIdx.x + threadIdx.y * blockDim.x; j < GINGR_EXP_TABLE; j += blockDim.x * blockDim.y)
         T[j] = gingr_exp_table_rom[j];
 }
 
-// returns 2^(t/64) for t <= 0 (any finite t is handled; large positive t overflows to inf as expected)
-__device__ __forceinline__ double fastexp2_64(double t, const double *T) {
-    double kf = __builtin_rint(t);
-    double f = t - kf;
-    int k = (int)kf;  // v_cvt_i32_f64: saturating
-    double q = __builtin_fma(f, GINGR_EXP_C5, GINGR_EXP_C4);
-    q = __builtin_fma(f, q, GINGR_EXP_C3);
-    q = __builtin_fma(f, q, GINGR_EXP_C2);
+// 2^(tm - MAGIC + f)/2048 given tm = MAGIC + k and the reduced argument f
+__device__ __forceinline__ double fastexp2_core(double tm, double f, const double *T) {
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, tm);
+    const unsigned lo = (unsigned)bits, hi = (unsigned)(bits >> 32);
+    const int j = (int)(lo & (GINGR_EXP_TABLE - 1));
+    const int e = (int)__builtin_amdgcn_alignbit(hi, lo, GINGR_EXP_TABLE_LOG2);  // bits 11..42: floor(k / 2048)
+    double q = __builtin_fma(f, GINGR_EXP_C3, GINGR_EXP_C2);
     q = __builtin_fma(f, q, GINGR_EXP_C1);
-    double tj = T[k & (GINGR_EXP_TABLE - 1)];
-    double fq = f * q;
-    double r = __builtin_fma(tj, fq, tj);
-    return __builtin_ldexp(r, k >> 6);
+    const double tj = T[j];
+    const double fq = f * q;
+    const double r = __builtin_fma(tj, fq, tj);
+    return __builtin_ldexp(r, e);
 }
 
-// c64 such that exp(-d2/(2 sigma2)) = 2^(d2*c64/64)
+// returns 2^(d2*c/2048); requires |d2*c| < 2^42 (see fastexp_needs_clamp)
+__device__ __forceinline__ double fastexp2_scaled(double d2, double c, const double *T) {
+    const double tm = __builtin_fma(d2, c, GINGR_EXP_MAGIC);
+    const double kf = tm - GINGR_EXP_MAGIC;
+    const double f = __builtin_fma(d2, c, -kf);
+    return fastexp2_core(tm, f, T);
+}
+
+// c such that exp(-d2 / two_sigma2) = 2^(d2*c/2048)
 __device__ __forceinline__ double fastexp_scale_for_variance(double two_sigma2) {
-    return -64.0 * 1.4426950408889634074 / two_sigma2;
+    return -(double)GINGR_EXP_TABLE * 1.4426950408889634074 / two_sigma2;
+}
+
+// largest d2 for which d2*c stays representable; beyond it the result is +0 anyway (2^-1100 underflows)
+__device__ __forceinline__ double fastexp_d2_limit(double c) { return -1100.0 * (double)GINGR_EXP_TABLE / c; }
+
+// true when an upper bound on d2 could push |d2*c| past 2^41 (a factor 2 of margin to the 2^42 limit)
+__device__ __forceinline__ bool fastexp_needs_clamp(double d2_bound, double c) {
+    return !(d2_bound * (-c) < 2199023255552.0);
 }

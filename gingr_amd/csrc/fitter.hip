@@ -30,6 +30,8 @@ struct gingr_fitter {
     DevPose *pose = nullptr;
     gingr_state_scalars *hs_dev = nullptr;
     double *scalars = nullptr;  // local {Np, xPx, trPXY, yPy, -, c, -, -}
+    double *part = nullptr;     // block partials of the scalar sums
+    double *absmax = nullptr;   // [0] target, [1] fit: largest |coordinate| (exponent-argument range check)
     double *xch = nullptr;
     int64_t off[GINGR_NUM_SEGMENTS] = {0, 0, 0, 0, 0}, cnt[GINGR_NUM_SEGMENTS] = {0, 0, 0, 0, 0};
     double *ws = nullptr;
@@ -240,7 +242,7 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
         (rc = dev_alloc(ctx, &f->alpha, (size_t)rp)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
         (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->st, 1)) ||
         (rc = dev_alloc(ctx, &f->pose, 1)) || (rc = dev_alloc(ctx, &f->hs_dev, 1)) ||
-        (rc = dev_alloc(ctx, &f->scalars, 8)) || (rc = dev_alloc(ctx, &f->work, (size_t)rp * rp)) ||
+        (rc = dev_alloc(ctx, &f->scalars, 8)) || (rc = dev_alloc(ctx, &f->part, GINGR_SCALAR_PART)) || (rc = dev_alloc(ctx, &f->absmax, 2)) || (rc = dev_alloc(ctx, &f->work, (size_t)rp * rp)) ||
         (rc = dev_alloc(ctx, &f->lm_mask, (size_t)M))) {
         gingr_fitter_destroy(f);
         return rc;
@@ -276,6 +278,8 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->pose);
     dev_free(f->hs_dev);
     dev_free(f->scalars);
+    dev_free(f->part);
+    dev_free(f->absmax);
     dev_free(f->xch);
     dev_free(f->ws);
     dev_free(f->work);
@@ -336,6 +340,7 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
     f->aos = aos;
     HIP_TRY(ctx, hipMemcpyAsync(aos, target_xyz, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     launch_aos_to_soa(ctx, aos, N, f->target);
+    launch_cloud_absmax(ctx, cloud_of(f->target, N), f->absmax);
     GINGR_TRY(check_launch(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GINGR_OK;
@@ -515,8 +520,10 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
         case 0: {
             if (icp)
                 launch_nn(ctx, fit, tgt, f->ws, f->nn_idx, f->nn_d2);
-            else
-                launch_cpd_colsum(ctx, fit, tgt, &f->st->sigma2, f->ws, seg0);
+            else {
+                launch_cloud_absmax(ctx, fit, f->absmax + 1);
+                launch_cpd_colsum(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->ws, seg0);
+            }
             break;
         }
         case 1: {
@@ -524,8 +531,8 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 launch_obs_icp(ctx, m, f->st, tgt, f->nn_idx, f->lm_mask, f->weight, f->evec);
                 hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(64), 0, ctx->stream, sc8, (int64_t)8);
             } else {
-                launch_cpd_den_finalize(ctx, tgt, &f->st->sigma2, cp->w, m->M_total, seg0, f->inv_den, f->Pt1, f->scalars);
-                launch_cpd_rowstats(ctx, fit, tgt, &f->st->sigma2, f->inv_den, f->ws, f->P1, f->PX, f->scalars);
+                launch_cpd_den_finalize(ctx, tgt, &f->st->sigma2, cp->w, m->M_total, seg0, f->inv_den, f->Pt1, f->part, f->scalars);
+                launch_cpd_rowstats(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->inv_den, f->ws, f->P1, f->PX, f->part, f->scalars);
                 launch_obs_cpd(ctx, m, f->st, fit, f->P1, f->PX, cp->lambda, f->lm_mask, f->weight, f->evec);
                 hipLaunchKernelGGL(pack_scalars_kernel, dim3(1), dim3(64), 0, ctx->stream, f->scalars, m->row_begin == 0 ? 1 : 0,
                                    sc8);

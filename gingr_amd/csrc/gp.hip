@@ -241,24 +241,34 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepArgs a) {
     }
 }
 
-// out[k] = sum over blocks (ascending) of partial[b][k]
-__global__ void block_partials_reduce_kernel(const double *__restrict__ partial, int nblocks, int width,
-                                             double *__restrict__ out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= width) return;
+// out[k] = sum over blocks of partial[b][k]: one workgroup per k, fixed summation tree (bitwise reproducible)
+__global__ __launch_bounds__(256) void block_partials_reduce_kernel(const double *__restrict__ partial, int nblocks, int width,
+                                                                    double *__restrict__ out) {
+    __shared__ double sh[256];
+    const int k = blockIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * width + k];
-    out[k] = s;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(int64_t)b * width + k];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+#pragma unroll
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[k] = sh[0];
 }
 
 // ------------------------------------------------------------------------------------------------- weighted Gram
-// One wave per workgroup computes a 64x64 patch (4x4 MFMA tiles) of G over one slab of rows:
+// A workgroup of 4 waves computes one 64x64 patch (4x4 MFMA tiles) of G over one slab of rows; the waves interleave
+// the 4-row steps of the slab and are summed through LDS in a fixed order.
 //   D(16x16) += A(16x4) B(4x16),  A[i][k] = w_row * Q0[row0+k][a0+i],  B[k][j] = Q0[row0+k][b0+j]
 // lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]: both are Q0[row0 + (l>>4)][col0 + (l&15)], i.e. four
 // 128-byte row segments per load instruction.  D: lane holds col j = l&15, rows i = (l>>4) + 4*reg.
-__global__ __launch_bounds__(64) void gram_kernel(const double *__restrict__ Q0, int64_t rows, int rp,
-                                                  const double *__restrict__ weight, int64_t rows_per_slab, int nbp,
-                                                  double *__restrict__ partial) {
+// The next step's fragments are loaded before the current step's 16 MFMAs are issued (software prefetch).
+__global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ Q0, int64_t rows, int rp,
+                                                   const double *__restrict__ weight, int64_t rows_per_slab, int nbp,
+                                                   double *__restrict__ partial) {
+    __shared__ double red[16 * 4 * 64];
     // triangular patch index -> (pa <= pb)
     int pa = 0, pb = 0;
     {
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(64) void gram_kernel(const double *__restrict__ Q0,
             t -= cnt;
         }
     }
-    const int lane = threadIdx.x, kq = lane >> 4, cl = lane & 15;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kq = lane >> 4, cl = lane & 15;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
     const int64_t r1 = min(rows, r0 + rows_per_slab);
     v4f64 acc[4][4];
@@ -286,24 +296,62 @@ __global__ __launch_bounds__(64) void gram_kernel(const double *__restrict__ Q0,
         va[t] = pa * 64 + 16 * t < rp;
         vb[t] = pb * 64 + 16 * t < rp;
     }
-    for (int64_t row = r0; row < r1; row += 4) {
+    const bool diag = pa == pb;
+    double ca[4], cb[4];
+    auto load = [&](int64_t row, double fa[4], double fb[4]) {
         const int64_t rr = row + kq;
         const bool valid = rr < r1;
         const int64_t rc = valid ? rr : r0;
         const double wv = valid ? (weight ? weight[rc / 3] : 1.0) : 0.0;
         const double *base = Q0 + rc * rp + cl;
-        double fa[4], fb[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            fa[t] = va[t] ? base[pa * 64 + 16 * t] * wv : 0.0;
-            fb[t] = (vb[t] && valid) ? base[pb * 64 + 16 * t] : 0.0;
+        for (int t = 0; t < 4; ++t) fb[t] = (vb[t] && valid) ? base[pb * 64 + 16 * t] : 0.0;
+        if (diag) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fa[t] = fb[t] * wv;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fa[t] = va[t] ? base[pa * 64 + 16 * t] * wv : 0.0;
         }
+    };
+    int64_t row = r0 + 4 * wave;
+    if (row < r1) load(row, ca, cb);
+    for (; row < r1; row += 16) {
+        double na[4] = {0, 0, 0, 0}, nb[4] = {0, 0, 0, 0};
+        if (row + 16 < r1) load(row + 16, na, nb);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (va[i] && vb[j]) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                if (va[i] && vb[j]) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[i], cb[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ca[t] = na[t];
+            cb[t] = nb[t];
+        }
     }
+    // waves 1..3 are added into wave 0 in order
+    for (int w = 1; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) red[((i * 4 + j) * 4 + reg) * 64 + lane] = acc[i][j][reg];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) acc[i][j][reg] += red[((i * 4 + j) * 4 + reg) * 64 + lane];
+        }
+    }
+    if (wave != 0) return;
     double *out = partial + (int64_t)blockIdx.x * rp * rp;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -476,12 +524,11 @@ __device__ bool block_cholesky(double *A, int r, int ld) {
         const double dk = A[k * ld + k];
         for (int i = k + 1 + threadIdx.x; i < r; i += blockDim.x) A[i * ld + k] /= dk;
         __syncthreads();
-        const int n = r - k - 1;
-        for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
-            const int ii = idx / n, jj = idx - ii * n;
-            if (jj <= ii) {
-                const int i = k + 1 + ii, j = k + 1 + jj;
-                A[i * ld + j] -= A[i * ld + k] * A[j * ld + k];
+        {
+            const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, ny = blockDim.x >> 4;
+            for (int i = k + 1 + ty; i < r; i += ny) {
+                const double lik = A[i * ld + k];
+                for (int j = k + 1 + tx; j <= i; j += 16) A[i * ld + j] -= lik * A[j * ld + k];
             }
         }
         __syncthreads();
@@ -534,6 +581,100 @@ __global__ __launch_bounds__(kDenseThreads) void posterior_solve_kernel(int r, i
     }
 }
 
+// Single-wave, LDS-resident variant for r <= 128: packed lower-triangular storage, left-looking Cholesky, no workgroup
+// barriers on the critical path (one wave executes its LDS operations in order).
+__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+__device__ __forceinline__ double wave_sum(double v) {
+    v += __shfl_xor(v, 32);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void posterior_solve_lds_kernel(int r, int rp, const double *__restrict__ G,
+                                                                 const double *__restrict__ rhs, double *__restrict__ a,
+                                                                 DevState *__restrict__ st) {
+    extern __shared__ double Ls[];  // r(r+1)/2 packed lower triangle, then y[r]
+    const int lane = threadIdx.x;
+    double *y = Ls + r * (r + 1) / 2;
+    // Mm = QtL Q + I     (scalismo genericRegressionComputations)
+    for (int i = 0; i < r; ++i)
+        for (int j = lane; j <= i; j += 64) Ls[tri(i, j)] = G[i * rp + j] + (i == j ? 1.0 : 0.0);
+    for (int k = lane; k < r; k += 64) y[k] = rhs[k];
+    __syncthreads();
+    int bad_spd = 0;
+    for (int k = 0; k < r; ++k) {
+        const int i0 = k + lane, i1 = k + lane + 64;
+        const bool two = k + 64 < r;  // wave-uniform
+        double s0 = i0 < r ? Ls[tri(i0, k)] : 0.0;
+        double s1 = (two && i1 < r) ? Ls[tri(i1, k)] : 0.0;
+        const int b0 = i0 < r ? tri(i0, 0) : 0, b1 = (two && i1 < r) ? tri(i1, 0) : 0, bk = tri(k, 0);
+        if (two) {
+            for (int j = 0; j < k; ++j) {
+                const double lkj = Ls[bk + j];
+                s0 = __builtin_fma(-Ls[b0 + j], lkj, s0);
+                s1 = __builtin_fma(-Ls[b1 + j], lkj, s1);
+            }
+        } else {
+            // four independent partial sums: the dependent-FMA chain, not the LDS, limits a single wave
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+            int j = 0;
+            for (; j + 4 <= k; j += 4) {
+                t0 = __builtin_fma(Ls[b0 + j], Ls[bk + j], t0);
+                t1 = __builtin_fma(Ls[b0 + j + 1], Ls[bk + j + 1], t1);
+                t2 = __builtin_fma(Ls[b0 + j + 2], Ls[bk + j + 2], t2);
+                t3 = __builtin_fma(Ls[b0 + j + 3], Ls[bk + j + 3], t3);
+            }
+            for (; j < k; ++j) t0 = __builtin_fma(Ls[b0 + j], Ls[bk + j], t0);
+            s0 -= (t0 + t1) + (t2 + t3);
+        }
+        double d = __shfl(s0, 0);
+        if (!(d > 0.0) || !finite_d(d)) {
+            bad_spd = 1;
+            d = 1.0;
+        }
+        const double dk = sqrt(d), rdk = 1.0 / dk;
+        __syncthreads();
+        if (i0 < r) Ls[tri(i0, k)] = lane == 0 ? dk : s0 * rdk;
+        if (two && i1 < r) Ls[tri(i1, k)] = s1 * rdk;
+        __syncthreads();
+    }
+    // L z = rhs, column oriented: once z_k is known every lane removes its contribution from its own rows
+    for (int k = 0; k < r; ++k) {
+        const double zk = y[k] / Ls[tri(k, k)];
+        __syncthreads();
+        if (lane == 0) y[k] = zk;
+        for (int i = k + 1 + lane; i < r; i += 64) y[i] = __builtin_fma(-Ls[tri(i, k)], zk, y[i]);
+        __syncthreads();
+    }
+    // L^T a = z
+    for (int k = r - 1; k >= 0; --k) {
+        const double ak = y[k] / Ls[tri(k, k)];
+        __syncthreads();
+        if (lane == 0) y[k] = ak;
+        const int bk = tri(k, 0);
+        for (int i = lane; i < k; i += 64) y[i] = __builtin_fma(-Ls[bk + i], ak, y[i]);
+        __syncthreads();
+    }
+    int bad = 0;
+    for (int k = lane; k < rp; k += 64) {
+        const double v = k < r ? y[k] : 0.0;
+        a[k] = v;
+        if (!finite_d(v)) bad = 1;
+    }
+    bad = __any(bad);
+    if (lane == 0) {
+        if (bad_spd)
+            st->err = GINGR_ERR_NOT_SPD;
+        else if (bad)
+            st->err = GINGR_ERR_NONFINITE;
+    }
+}
+
 __global__ __launch_bounds__(kDenseThreads) void binv_kernel(int r, int rp, const double *__restrict__ S,
                                                              double *__restrict__ work, double *__restrict__ Binv,
                                                              int32_t *__restrict__ err_flag) {
@@ -562,32 +703,36 @@ __global__ __launch_bounds__(kDenseThreads) void binv_kernel(int r, int rp, cons
     }
 }
 
-// out[i] = sum_j Binv[j][i] * p[j] / eps   (Binv symmetric; coalesced over i)
-__device__ __forceinline__ double binv_row_apply(const double *__restrict__ Binv, const double *__restrict__ p, int r, int rp,
-                                                 int i) {
+// out[i] = (sum_j Binv[i][j] * p[j]) / eps: 16 lanes per output row, fixed-order shuffle reduction.
+// Every lane of the 16-lane group returns the result.
+__device__ __forceinline__ double binv_row_apply16(const double *__restrict__ Binv, const double *__restrict__ p, int r, int rp,
+                                                   int i, int lane16) {
     double s = 0.0;
-    for (int j = 0; j < r; ++j) s = __builtin_fma(Binv[(int64_t)j * rp + i], p[j] / GINGR_COEFF_NOISE, s);
-    return s;
+    if (i < r)
+        for (int j = lane16; j < r; j += 16) s = __builtin_fma(Binv[(int64_t)i * rp + j], p[j], s);
+    s = group16_sum(s);
+    return s / GINGR_COEFF_NOISE;
 }
 
-__global__ void alpha_blend_kernel(int r, int rp, const double *__restrict__ Binv, const double *__restrict__ p,
-                                   const double *__restrict__ alpha, double step, double *__restrict__ alpha_c) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rp) return;
+__global__ __launch_bounds__(256) void alpha_blend_kernel(int r, int rp, const double *__restrict__ Binv,
+                                                          const double *__restrict__ p, const double *__restrict__ alpha,
+                                                          double step, double *__restrict__ alpha_c) {
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), lane16 = threadIdx.x & 15;
+    const double a1 = binv_row_apply16(Binv, p, r, rp, i, lane16);
+    if (i >= rp || lane16 != 0) return;
     if (i >= r) {
         alpha_c[i] = 0.0;
         return;
     }
-    const double a1 = binv_row_apply(Binv, p, r, rp, i);
     const double a0 = alpha[i];
     alpha_c[i] = a0 + (a1 - a0) * step;  // GingrAlgorithm.scala:219-220
 }
 
-__global__ void coeff_solve_kernel(int r, int rp, const double *__restrict__ Binv, const double *__restrict__ p,
-                                   double *__restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rp) return;
-    out[i] = i < r ? binv_row_apply(Binv, p, r, rp, i) : 0.0;
+__global__ __launch_bounds__(256) void coeff_solve_kernel(int r, int rp, const double *__restrict__ Binv,
+                                                          const double *__restrict__ p, double *__restrict__ out) {
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), lane16 = threadIdx.x & 15;
+    const double v = binv_row_apply16(Binv, p, r, rp, i, lane16);
+    if (i < rp && lane16 == 0) out[i] = i < r ? v : 0.0;
 }
 
 // one-sided Jacobi SVD of a 3x3 matrix: A = U diag(s) V^T, s descending
@@ -711,10 +856,13 @@ __global__ __launch_bounds__(kDenseThreads) void commit_kernel(CommitArgs a) {
     __syncthreads();
     DevState *st = a.state;
     if (st->status == GINGR_FIT_MODEL_FLEXIBILITY_ERROR) return;  // a failed fit stays as it is (run stops, :149-157)
-    for (int i = threadIdx.x; i < a.rp; i += blockDim.x) {
-        const double v = i < a.r ? binv_row_apply(a.Binv, a.p2, a.r, a.rp, i) : 0.0;
-        anew[i] = v;
-        if (!finite_d(v)) bad = 1;
+    for (int i0 = 0; i0 < a.rp; i0 += kDenseThreads / 16) {
+        const int i = i0 + (threadIdx.x >> 4);
+        const double v = binv_row_apply16(a.Binv, a.p2, a.r, a.rp, i, threadIdx.x & 15);
+        if (i < a.rp && (threadIdx.x & 15) == 0) {
+            anew[i] = i < a.r ? v : 0.0;
+            if (i < a.r && !finite_d(v)) bad = 1;
+        }
     }
     __syncthreads();
     const bool failed = (st->err != 0) || bad;
@@ -789,8 +937,8 @@ static void launch_sweep_mode(gingr_ctx *ctx, const SweepArgs &a, int width) {
         hipLaunchKernelGGL((sweep_kernel<MODE, 32>), dim3(nb), dim3(kSweepThreads), lds, ctx->stream, a);
     }
     if (width > 0)
-        hipLaunchKernelGGL(block_partials_reduce_kernel, dim3((unsigned)ceil_div(width, 64)), dim3(64), 0, ctx->stream,
-                           a.partial, nb, width, a.out);
+        hipLaunchKernelGGL(block_partials_reduce_kernel, dim3((unsigned)width), dim3(256), 0, ctx->stream, a.partial, nb,
+                           width, a.out);
 }
 
 void launch_sweep(gingr_ctx *ctx, SweepMode mode, const SweepArgs &a) {
@@ -808,12 +956,12 @@ static void gram_plan(int64_t M, int32_t rp, int *nbp, int *npatch, int *nslabs,
     const int64_t rows = 3 * M;
     *nbp = (rp + 63) / 64;
     *npatch = *nbp * (*nbp + 1) / 2;
-    int64_t want = 1024 / *npatch;
+    int64_t want = 768 / *npatch;  // ~3 workgroups of 4 waves per CU
     if (want < 1) want = 1;
     const int64_t max_slabs = ceil_div(rows, 64);
     if (want > max_slabs) want = max_slabs;
     if (want < 1) want = 1;
-    *rows_per_slab = round_up(ceil_div(rows, want), 4);
+    *rows_per_slab = round_up(ceil_div(rows, want), 16);
     *nslabs = (int)ceil_div(rows, *rows_per_slab);
 }
 
@@ -830,7 +978,7 @@ void launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const 
     gram_plan(M, rp, &nbp, &npatch, &nslabs, &rps);
     {
         TimerScope ts(ctx, 2);
-        hipLaunchKernelGGL(gram_kernel, dim3(nslabs, npatch), dim3(64), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, nbp,
+        hipLaunchKernelGGL(gram_kernel, dim3(nslabs, npatch), dim3(256), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, nbp,
                            ws);
     }
     hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 256)), dim3(256), 0, ctx->stream, ws,
@@ -865,6 +1013,14 @@ void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, 
 
 void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, double *work,
                             double *a, DevState *st) {
+    if (r <= 128) {
+        const size_t lds = ((size_t)r * (r + 1) / 2 + r) * sizeof(double);
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_solve_lds_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(posterior_solve_lds_kernel, dim3(1), dim3(64), lds, ctx->stream, (int)r, (int)rp, G, rhs, a, st);
+        return;
+    }
     hipLaunchKernelGGL(posterior_solve_kernel, dim3(1), dim3(kDenseThreads), 0, ctx->stream, (int)r, (int)rp, G, rhs, work, a,
                        st);
 }
@@ -875,12 +1031,12 @@ void launch_binv(gingr_ctx *ctx, int32_t r, int32_t rp, const double *S, double 
 
 void launch_alpha_blend(gingr_ctx *ctx, int32_t r, int32_t rp, const double *Binv, const double *p, const double *alpha,
                         double step, double *alpha_c) {
-    hipLaunchKernelGGL(alpha_blend_kernel, dim3((unsigned)ceil_div(rp, 64)), dim3(64), 0, ctx->stream, (int)r, (int)rp, Binv,
+    hipLaunchKernelGGL(alpha_blend_kernel, dim3((unsigned)ceil_div(rp, 16)), dim3(256), 0, ctx->stream, (int)r, (int)rp, Binv,
                        p, alpha, step, alpha_c);
 }
 
 void launch_coeff_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *Binv, const double *p, double *out) {
-    hipLaunchKernelGGL(coeff_solve_kernel, dim3((unsigned)ceil_div(rp, 64)), dim3(64), 0, ctx->stream, (int)r, (int)rp, Binv,
+    hipLaunchKernelGGL(coeff_solve_kernel, dim3((unsigned)ceil_div(rp, 16)), dim3(256), 0, ctx->stream, (int)r, (int)rp, Binv,
                        p, out);
 }
 
