@@ -62,19 +62,34 @@ class ShardedFitter:
     """
 
     def __init__(self, ctx: Context, model: PointDistributionModel, target, rank: int = 0, world: int = 1,
-                 all_reduce: Optional[Callable] = None, global_transform: int = 1, step_length: float = 1.0):
+                 all_reduce: Optional[Callable] = None, global_transform: int = 1, step_length: float = 1.0,
+                 defer_setup: bool = False):
         self.ctx, self.rank, self.world = ctx, rank, world
         self._lib = ctx._lib
         self.all_reduce = all_reduce
         self.begin, self.end = shard_rows(model.numberOfPoints, world, rank)
         self.dev_model = DeviceModel(ctx, model, self.begin, self.end)
         self.model = model
+        self._target, self._opts = target, (global_transform, step_length)
+        self.handle = None
+        if not defer_setup:
+            if world > 1:
+                g = self.gram_tensor()
+                ctx.synchronize()
+                all_reduce(g)
+                self._sync_torch()
+            self.finish_setup()
+
+    def gram_tensor(self):
+        """Device tensor aliasing this shard's partial Q^T Q (to be summed across shards once, before finish_setup)."""
+        ptr, n = self.dev_model.gram_exchange()
+        return as_torch(ptr, n, self.ctx.device)
+
+    def finish_setup(self):
+        ctx, world = self.ctx, self.world
+        target = self._target
+        global_transform, step_length = self._opts
         if world > 1:
-            ptr, n = self.dev_model.gram_exchange()
-            g = as_torch(ptr, n, ctx.device)
-            ctx.synchronize()
-            all_reduce(g)
-            self._sync_torch()
             self.dev_model.finalize()
         h = c_void_p()
         _check(ctx.handle, self._lib.gingr_fitter_create(ctx.handle, self.dev_model.handle, ctypes.byref(h)), "gingr_fitter_create")
