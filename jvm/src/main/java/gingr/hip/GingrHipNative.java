@@ -1,0 +1,46 @@
+package gingr.hip;
+
+/**
+ * JNI binding of libgingr_hip.so (C ABI: include/gingr_hip.h) through the thin shim jvm/native/gingr_jni.cpp.
+ * One static native method per C entry point the Scala plugin needs; only primitive arrays and opaque handles (long)
+ * cross the boundary -- no JVM objects, no callbacks into the JVM.  Every int return is a gingr_status (0 = ok).
+ *
+ * NOT COMPILED IN THIS REPOSITORY'S IMAGE (no JDK there); see INTEGRATION.md for the build recipe.
+ */
+public final class GingrHipNative {
+    static {
+        System.loadLibrary("gingr_jni"); // links libgingr_hip.so
+    }
+
+    private GingrHipNative() {}
+
+    public static native int deviceCount();
+    public static native long ctxCreate(int device);                       // 0 on failure
+    public static native void ctxDestroy(long ctx);
+    public static native String lastError(long ctx);
+
+    // stateless all-pairs operators (gingr_cpd_stats / gingr_nn / gingr_gauss_block / gingr_cpd_initial_sigma2)
+    public static native int cpdStats(long ctx, double[] fitXyz, double[] targetXyz, double sigma2, double w,
+                                      double[] den, double[] p1, double[] px, double[] pt1, double[] scalars6);
+    public static native int cpdInitialSigma2(long ctx, double[] refXyz, double[] targetXyz, double[] out1);
+    public static native int nn(long ctx, double[] queryXyz, double[] targetXyz, int[] idx, double[] d2, double[] meanDistance1);
+    public static native int gaussBlock(long ctx, double[] a, double[] b, double sigma, double scaling, double[] out);
+
+    // model resident on the device (gingr_model_upload): basis is Breeze's column-major basisMatrix.data
+    public static native long modelUpload(long ctx, long mTotal, int rank, double[] refXyz, double[] meanXyz,
+                                          double[] basisColMajor, double[] variance, long rowBegin, long rowEnd);
+    public static native void modelDestroy(long model);
+
+    // device-resident registration state (gingr_fitter_*)
+    public static native long fitterCreate(long ctx, long model);
+    public static native void fitterDestroy(long fitter);
+    public static native int fitterSetTarget(long fitter, double[] targetXyz);
+    public static native int fitterSetLandmarks(long fitter, int[] pid, double[] xyz, double[] cov9);
+    public static native int fitterSetOptions(long fitter, int globalTransform, double stepLength);
+    /** poseScalars = { phi, theta, psi, cx, cy, cz, tx, ty, tz, scale, sigma2 } */
+    public static native int fitterSetState(long fitter, double[] alpha, double[] poseScalars11, int iteration, int status);
+    public static native int fitterUpdateCpd(long fitter, double w, double lambda, int nIterations);
+    public static native int fitterUpdateIcp(long fitter, double initialSigma, double endSigma, int maxIterations, int nIterations);
+    /** iterStatus2 = { iteration, status }; fitXyz may be null */
+    public static native int fitterGetState(long fitter, double[] alpha, double[] poseScalars11, int[] iterStatus2, double[] fitXyz);
+}

@@ -1,0 +1,223 @@
+/*
+ * HIP-backed CPD / ICP plugins for GiNGR: the reference-side binding a maintainer adds to drop the MI355X update path
+ * in under the existing `run` / `update` API.  NOT COMPILED IN THIS REPOSITORY'S IMAGE (no JVM); see INTEGRATION.md.
+ *
+ * Lives in package gingr.api.registration.config next to CPD.scala / ICP.scala; it must be inside `gingr.api` because
+ * the state updaters it needs (updateTranslation, updateRotation, updateScaling, updateShapeParameters, updateSigma2)
+ * are `private[api]` (gingr/api/RegistrationState.scala:46-58).
+ *
+ * What changes w.r.t. the stock plugins:
+ *  - HipCpdRegistrationState has NO `P` member (CPD.scala:54-75 builds an M x N DenseMatrix on every case-class copy);
+ *  - `update` (GingrAlgorithm.scala:192-254) is overridden: ONE native call per iteration;
+ *  - getCorrespondence / getUncertainty / updateSigma2 stay available (served from one native affinity evaluation per
+ *    state) so that computePosterior-based callers (GeneratorWrapperStochastic.logTransitionProbability) keep working.
+ * `run`, the Metropolis-Hastings chain, loggers and evaluators are untouched.
+ */
+package gingr.api.registration.config
+
+import breeze.linalg.{DenseMatrix, DenseVector}
+import gingr.api._
+import gingr.hip.GingrHipNative
+import scalismo.common.PointId
+import scalismo.geometry.{_3D, EuclideanVector, Point}
+import scalismo.mesh.TriangleMesh
+import scalismo.statisticalmodel.{MultivariateNormalDistribution, PointDistributionModel}
+import scalismo.utils.Random
+
+/** Flat-array views of scalismo objects in the layout of include/gingr_hip.h (x1x,x1y,x1z,x2x,...). */
+private[config] object HipLayout {
+  def points(ps: Iterator[Point[_3D]], n: Int): Array[Double] = {
+    val a = new Array[Double](3 * n)
+    var i = 0
+    ps.foreach { p => a(i) = p.x; a(i + 1) = p.y; a(i + 2) = p.z; i += 3 }
+    a
+  }
+  def mesh(m: TriangleMesh[_3D]): Array[Double] = points(m.pointSet.points, m.pointSet.numberOfPoints)
+}
+
+/** Device-resident model + fitter for one (model, target) pair; one instance per chain (not thread-safe). */
+final class HipSession(device: Int) extends AutoCloseable {
+  private val ctx = GingrHipNative.ctxCreate(device)
+  require(ctx != 0L, "gingr_ctx_create failed: no usable GPU")
+  private var model = 0L
+  private var fitter = 0L
+  private var boundModel: AnyRef = null
+  private var boundTarget: AnyRef = null
+
+  private def check(rc: Int, what: String): Unit =
+    if (rc != 0) throw new RuntimeException(s"$what failed (gingr_status $rc): ${GingrHipNative.lastError(ctx)}")
+
+  def bind(general: GeneralRegistrationState, useLandmarks: Boolean): Unit = {
+    if (boundModel ne general.model) {
+      close0()
+      val pdm = general.model
+      val m = pdm.reference.pointSet.numberOfPoints
+      // gp.basisMatrix is a Breeze DenseMatrix (column-major data, 3M rows); meanVector / variance are DenseVectors
+      model = GingrHipNative.modelUpload(ctx, m.toLong, pdm.rank, HipLayout.mesh(pdm.reference), pdm.gp.meanVector.toArray,
+        pdm.gp.basisMatrix.toDenseMatrix.data, pdm.gp.variance.toArray, 0L, m.toLong)
+      require(model != 0L, s"gingr_model_upload failed: ${GingrHipNative.lastError(ctx)}")
+      fitter = GingrHipNative.fitterCreate(ctx, model)
+      require(fitter != 0L, s"gingr_fitter_create failed: ${GingrHipNative.lastError(ctx)}")
+      boundModel = pdm
+      boundTarget = null
+    }
+    if (boundTarget ne general.target) {
+      check(GingrHipNative.fitterSetTarget(fitter, HipLayout.mesh(general.target)), "gingr_fitter_set_target")
+      boundTarget = general.target
+    }
+    val lms = if (useLandmarks) general.landmarkCorrespondences else IndexedSeq()
+    check(
+      GingrHipNative.fitterSetLandmarks(fitter, lms.map(_._1.id).toArray, HipLayout.points(lms.iterator.map(_._2), lms.size),
+        lms.flatMap(l => l._3.cov.t.toArray).toArray), // row-major 3x3 per landmark
+      "gingr_fitter_set_landmarks")
+    val gt = general.globalTransformation match {
+      case NoTransforms         => 0
+      case RigidTransforms      => 1
+      case SimilarityTransforms => 2
+    }
+    check(GingrHipNative.fitterSetOptions(fitter, gt, general.stepLength), "gingr_fitter_set_options")
+  }
+
+  /** Pushes (alpha, pose, sigma2), runs ONE update, pulls the result.  Returns (alpha, pose11, status). */
+  def updateOnce(general: GeneralRegistrationState, run: Long => Int): (Array[Double], Array[Double], Int) = {
+    val mp = general.modelParameters
+    val a = mp.pose.rotation.angles
+    val c = mp.pose.rotation.center
+    val t = mp.pose.translation
+    val pose = Array(a.phi, a.theta, a.psi, c.x, c.y, c.z, t.x, t.y, t.z, mp.scale.s, general.sigma2)
+    val status = if (general.status == FittingStatuses.ModelFlexibilityError) 3 else 0
+    check(GingrHipNative.fitterSetState(fitter, mp.shape.parameters.toArray, pose, general.iteration, status), "gingr_fitter_set_state")
+    check(run(fitter), "gingr_fitter_update")
+    val alpha = new Array[Double](general.model.rank)
+    val poseOut = new Array[Double](11)
+    val iterStatus = new Array[Int](2)
+    check(GingrHipNative.fitterGetState(fitter, alpha, poseOut, iterStatus, null), "gingr_fitter_get_state")
+    (alpha, poseOut, iterStatus(1))
+  }
+
+  def cpdStats(fit: TriangleMesh[_3D], target: TriangleMesh[_3D], sigma2: Double, w: Double)
+    : (Array[Double], Array[Double], Double) = {
+    val m = fit.pointSet.numberOfPoints
+    val n = target.pointSet.numberOfPoints
+    val p1 = new Array[Double](m); val px = new Array[Double](3 * m); val sc = new Array[Double](6)
+    check(GingrHipNative.cpdStats(ctx, HipLayout.mesh(fit), HipLayout.mesh(target), sigma2, w, null, p1, px, null, sc), "gingr_cpd_stats")
+    (p1, px, sc(4))
+  }
+
+  def nn(fit: TriangleMesh[_3D], target: TriangleMesh[_3D]): Array[Int] = {
+    val idx = new Array[Int](fit.pointSet.numberOfPoints)
+    check(GingrHipNative.nn(ctx, HipLayout.mesh(fit), HipLayout.mesh(target), idx, null, null), "gingr_nn")
+    idx
+  }
+
+  private def close0(): Unit = {
+    if (fitter != 0L) { GingrHipNative.fitterDestroy(fitter); fitter = 0L }
+    if (model != 0L) { GingrHipNative.modelDestroy(model); model = 0L }
+  }
+  override def close(): Unit = { close0(); GingrHipNative.ctxDestroy(ctx) }
+}
+
+/** Applies a native result to the immutable Scala state exactly like GingrAlgorithm.update does (:239-246). */
+private[config] object HipStateUpdate {
+  def apply(general: GeneralRegistrationState, alpha: Array[Double], pose: Array[Double], status: Int): GeneralRegistrationState = {
+    if (status == 3) general.updateStatus(FittingStatuses.ModelFlexibilityError)
+    else
+      general
+        .updateTranslation(EuclideanVector(pose(6), pose(7), pose(8)))
+        .updateRotation(EulerRotation(EulerAngles(pose(0), pose(1), pose(2)), Point(pose(3), pose(4), pose(5))))
+        .updateScaling(ScaleParameter(pose(9)))
+        .updateShapeParameters(ShapeParameters(DenseVector(alpha)))
+        .updateSigma2(pose(10))
+    // fit and iteration are refreshed by GingrGeneratorWrapper.propose exactly as for the stock plugins
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------ CPD
+case class HipCpdRegistrationState(general: GeneralRegistrationState, config: CpdConfiguration)
+    extends GingrRegistrationState[HipCpdRegistrationState] {
+  override def updateGeneral(update: GeneralRegistrationState): HipCpdRegistrationState = this.copy(general = update)
+}
+
+class HipCpdRegistration(device: Int = 0) extends GingrAlgorithm[HipCpdRegistrationState, CpdConfiguration] with AutoCloseable {
+  private val session = new HipSession(device)
+  // one streaming affinity evaluation per state serves getCorrespondence, getUncertainty and updateSigma2
+  private var statsOf: HipCpdRegistrationState = null
+  private var stats: (Array[Double], Array[Double], Double) = null
+  private def statsFor(s: HipCpdRegistrationState) = {
+    if (statsOf ne s) { stats = session.cpdStats(s.general.fit, s.general.target, s.general.sigma2, s.config.w); statsOf = s }
+    stats
+  }
+
+  def name = "CPD-HIP"
+
+  override val getCorrespondence: HipCpdRegistrationState => CorrespondencePairs = (s: HipCpdRegistrationState) => {
+    val (p1, px, _) = statsFor(s)
+    val pts = s.general.fit.pointSet.points.toIndexedSeq
+    CorrespondencePairs(pts.indices.map { i =>
+      val y = pts(i); val inv = 1.0 / p1(i)
+      (PointId(i), Point(y.x + (px(3 * i) * inv - y.x), y.y + (px(3 * i + 1) * inv - y.y), y.z + (px(3 * i + 2) * inv - y.z)))
+    })
+  }
+  override val getUncertainty: (PointId, HipCpdRegistrationState) => MultivariateNormalDistribution =
+    (id: PointId, s: HipCpdRegistrationState) =>
+      MultivariateNormalDistribution(DenseVector.zeros[Double](3),
+        DenseMatrix.eye[Double](3) * s.general.sigma2 * s.config.lambda * (1.0 / statsFor(s)._1(id.id)))
+  override def updateSigma2(current: HipCpdRegistrationState): Double = statsFor(current)._3
+
+  override def initializeState(general: GeneralRegistrationState, config: CpdConfiguration): HipCpdRegistrationState = {
+    val init = CpdRegistrationState(general.copy(), config) // reuses computeInitialSigma2 semantics (CPD.scala:92-102)
+    HipCpdRegistrationState(init.general, config)
+  }
+
+  override def update(current: HipCpdRegistrationState, probabilistic: Boolean)(implicit rnd: Random): HipCpdRegistrationState = {
+    if (probabilistic) super.update(current, probabilistic) // posterior sampling stays on the stock path for now
+    else {
+      session.bind(current.general, current.config.useLandmarkCorrespondence)
+      val (alpha, pose, status) =
+        session.updateOnce(current.general, f => GingrHipNative.fitterUpdateCpd(f, current.config.w, current.config.lambda, 1))
+      current.updateGeneral(HipStateUpdate(current.general, alpha, pose, status))
+    }
+  }
+  override def close(): Unit = session.close()
+}
+
+// ------------------------------------------------------------------------------------------------------------ ICP
+case class HipIcpRegistrationState(general: GeneralRegistrationState, config: IcpConfiguration)
+    extends GingrRegistrationState[HipIcpRegistrationState] {
+  override def updateGeneral(update: GeneralRegistrationState): HipIcpRegistrationState = this.copy(general = update)
+}
+
+/** PointcloudClosestPoint flavour only (ICP.scala:43); the surface / along-normal flavours stay on the stock path. */
+class HipIcpRegistration(device: Int = 0) extends GingrAlgorithm[HipIcpRegistrationState, IcpConfiguration] with AutoCloseable {
+  private val session = new HipSession(device)
+  def name = "ICP-HIP"
+
+  override val getCorrespondence: HipIcpRegistrationState => CorrespondencePairs = (s: HipIcpRegistrationState) => {
+    val idx = session.nn(s.general.fit, s.general.target)
+    val tp = s.general.target.pointSet.points.toIndexedSeq
+    CorrespondencePairs(idx.indices.map(i => (PointId(i), tp(idx(i)))))
+  }
+  override val getUncertainty: (PointId, HipIcpRegistrationState) => MultivariateNormalDistribution =
+    (_: PointId, s: HipIcpRegistrationState) =>
+      MultivariateNormalDistribution(DenseVector.zeros[Double](3), DenseMatrix.eye[Double](3) * s.general.sigma2)
+  override def updateSigma2(current: HipIcpRegistrationState): Double =
+    math.max(current.general.sigma2 - current.config.sigmaStep, current.config.endSigma)
+
+  override def initializeState(general: GeneralRegistrationState, config: IcpConfiguration): HipIcpRegistrationState = {
+    require(config.correspondenceMethod == PointcloudClosestPoint && !config.reverseCorrespondenceDirection,
+      "HipIcpRegistration implements the PointcloudClosestPoint correspondence only")
+    HipIcpRegistrationState(IcpRegistrationState(general, config).general, config)
+  }
+
+  override def update(current: HipIcpRegistrationState, probabilistic: Boolean)(implicit rnd: Random): HipIcpRegistrationState = {
+    if (probabilistic) super.update(current, probabilistic)
+    else {
+      session.bind(current.general, current.config.useLandmarkCorrespondence)
+      val c = current.config
+      val (alpha, pose, status) =
+        session.updateOnce(current.general, f => GingrHipNative.fitterUpdateIcp(f, c.initialSigma, c.endSigma, c.maxIterations, 1))
+      current.updateGeneral(HipStateUpdate(current.general, alpha, pose, status))
+    }
+  }
+  override def close(): Unit = session.close()
+}
