@@ -427,14 +427,16 @@ int64_t cpd_colsum_ws_doubles(int64_t M, int64_t N) {
     int nch;
     int64_t len;
     plan_chunks(N, kBlock * kPT, M, &nch, &len);
-    return (int64_t)nch * N;
+    const int64_t a = (int64_t)nch * N, b = cpd_colsum_mfma_ws_doubles(M, N);
+    return a > b ? a : b;
 }
 
 int64_t cpd_rowstats_ws_doubles(int64_t M, int64_t N) {
     int nch;
     int64_t len;
     plan_chunks(M, kBlock * kPT, N, &nch, &len);
-    return (int64_t)nch * 4 * M;
+    const int64_t a = (int64_t)nch * 4 * M, b = cpd_rowstats_mfma_ws_doubles(M, N);
+    return a > b ? a : b;
 }
 
 int64_t nn_ws_bytes(int64_t M, int64_t N) {
@@ -450,16 +452,20 @@ void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, double *slot) {
     hipLaunchKernelGGL(cloud_absmax_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, ctx->stream, c, slot);
 }
 
-void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *absmax,
+void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
                        double *ws, double *den_partial) {
     int nch;
-    int64_t len;
-    plan_chunks(target.n, kBlock * kPT, fit.n, &nch, &len);
-    dim3 grid((unsigned)ceil_div(target.n, kBlock * kPT), (unsigned)nch);
     {
         TimerScope ts(ctx, 0);
-        hipLaunchKernelGGL(cpd_colsum_kernel<kPT>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, absmax, len,
-                           ws);
+        if (ctx->affinity_mfma) {
+            launch_cpd_colsum_mfma(ctx, fit, target, sigma2_dev, aux, ws, &nch);
+        } else {
+            int64_t len;
+            plan_chunks(target.n, kBlock * kPT, fit.n, &nch, &len);
+            dim3 grid((unsigned)ceil_div(target.n, kBlock * kPT), (unsigned)nch);
+            hipLaunchKernelGGL(cpd_colsum_kernel<kPT>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux, len,
+                               ws);
+        }
     }
     hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)ceil_div(target.n, 256)), dim3(256), 0, ctx->stream, ws, nch,
                        target.n, den_partial);
@@ -471,16 +477,20 @@ void launch_cpd_den_finalize(gingr_ctx *ctx, Cloud target, const double *sigma2_
                        (double)M_total / (double)target.n, den, inv_den, Pt1, part, scalars_dev);
 }
 
-void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *absmax,
+void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
                          const double *inv_den, double *ws, double *P1, double *PX_soa, double *part, double *scalars_dev) {
     int nch;
-    int64_t len;
-    plan_chunks(fit.n, kBlock * kPT, target.n, &nch, &len);
-    dim3 grid((unsigned)ceil_div(fit.n, kBlock * kPT), (unsigned)nch);
     {
         TimerScope ts(ctx, 1);
-        hipLaunchKernelGGL(cpd_rowstats_kernel<kPT>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, absmax,
-                           inv_den, len, ws);
+        if (ctx->affinity_mfma) {
+            launch_cpd_rowstats_mfma(ctx, fit, target, sigma2_dev, aux, inv_den, ws, &nch);
+        } else {
+            int64_t len;
+            plan_chunks(fit.n, kBlock * kPT, target.n, &nch, &len);
+            dim3 grid((unsigned)ceil_div(fit.n, kBlock * kPT), (unsigned)nch);
+            hipLaunchKernelGGL(cpd_rowstats_kernel<kPT>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux,
+                               inv_den, len, ws);
+        }
     }
     hipLaunchKernelGGL(rowstats_reduce_kernel, dim3(kScalarBlocks), dim3(256), 0, ctx->stream, ws, nch, fit, P1, PX_soa,
                        part);

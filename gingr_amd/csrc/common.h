@@ -29,6 +29,10 @@ struct gingr_ctx {
     std::vector<hipEvent_t> pool;  // recycled events
     double t_ms[GINGR_TIMERS] = {0, 0, 0, 0};
     int64_t t_n[GINGR_TIMERS] = {0, 0, 0, 0};
+    // all-pairs formulation: 0 = difference-based VALU kernels (affinity.hip, default), 1 = exponent arguments from the
+    // f64 matrix pipe (affinity_mfma.hip).  Measured on MI355X (profiles/r01_ubench_mfma_valu_overlap.txt): f64 MFMA and
+    // f64 VALU do not overlap (they share the DP hardware), so the MFMA form is not faster.  GINGR_AFFINITY=valu|mfma.
+    int affinity_mfma = 0;
     // scratch kept across calls (grown on demand, never shrunk) so steady-state updates do not allocate
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -96,8 +100,17 @@ int64_t cpd_rowstats_ws_doubles(int64_t M, int64_t N);
 int64_t nn_ws_bytes(int64_t M, int64_t N);
 
 // den_partial[N] = sum_{i in fit} exp(-|x_j - y_i|^2 / (2 sigma2))   (no outlier constant)
-// absmax[0] / absmax[1]: largest |coordinate| of the target / fit cloud (launch_cloud_absmax); the kernels derive an
-// upper bound of d2 from them to decide (wave-uniformly) whether the exponent argument needs clamping.
+// aux (GINGR_AUX doubles on the device): [0] / [1] largest |coordinate| of the target / fit cloud (launch_cloud_absmax);
+// the kernels derive an upper bound of d2 from them to decide (wave-uniformly) whether the exponent argument needs
+// clamping.  [2..4] centroid of the target cloud (launch_cloud_centroid): centring point of the MFMA formulation.
+#define GINGR_AUX 8
+void launch_cloud_centroid(gingr_ctx *ctx, Cloud c, double *out3);
+int64_t cpd_colsum_mfma_ws_doubles(int64_t M, int64_t N);
+int64_t cpd_rowstats_mfma_ws_doubles(int64_t M, int64_t N);
+int launch_cpd_colsum_mfma(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux, double *ws,
+                           int *nchunks_out);
+int launch_cpd_rowstats_mfma(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
+                             const double *inv_den, double *ws, int *nchunks_out);
 void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, double *slot);
 void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *absmax,
                        double *ws, double *den_partial);

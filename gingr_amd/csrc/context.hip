@@ -1,6 +1,8 @@
 // Context, error handling, timing hooks and the stateless all-pairs operators of the C ABI (include/gingr_hip.h).
 #include "common.h"
 
+#include <cstdlib>
+
 int gingr_set_error(gingr_ctx *ctx, int code, const char *fmt, ...) {
     if (ctx) {
         va_list ap;
@@ -73,6 +75,7 @@ int gingr_ctx_create(int device, gingr_ctx **out) {
         return GINGR_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (const char *m = getenv("GINGR_AFFINITY")) ctx->affinity_mfma = (strcmp(m, "mfma") == 0) ? 1 : 0;
     *out = ctx;
     return GINGR_OK;
 }
@@ -179,9 +182,12 @@ int gingr_cpd_stats(gingr_ctx *ctx, int64_t M, const double *fit, int64_t N, con
     double *sc = dsc.as<double>();
     double *s2dev = sc + 8;
     HIP_TRY(ctx, hipMemcpyAsync(s2dev, &sigma2, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    double *absmax = sc + 10;
+    DevBuf daux;
+    HIP_TRY(ctx, daux.alloc(GINGR_AUX * sizeof(double)));
+    double *absmax = daux.as<double>();
     launch_cloud_absmax(ctx, ct, absmax);
     launch_cloud_absmax(ctx, cf, absmax + 1);
+    launch_cloud_centroid(ctx, ct, absmax + 2);
     launch_cpd_colsum(ctx, cf, ct, s2dev, absmax, dws.as<double>(), dden.as<double>());
     launch_cpd_den_finalize(ctx, ct, s2dev, w, M, dden.as<double>(), dinv.as<double>(), dpt1.as<double>(), dpart.as<double>(), sc);
     launch_cpd_rowstats(ctx, cf, ct, s2dev, absmax, dinv.as<double>(), dws.as<double>(), dp1.as<double>(), dpx.as<double>(), dpart.as<double>(), sc);

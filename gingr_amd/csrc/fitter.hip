@@ -242,7 +242,7 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
         (rc = dev_alloc(ctx, &f->alpha, (size_t)rp)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
         (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->st, 1)) ||
         (rc = dev_alloc(ctx, &f->pose, 1)) || (rc = dev_alloc(ctx, &f->hs_dev, 1)) ||
-        (rc = dev_alloc(ctx, &f->scalars, 8)) || (rc = dev_alloc(ctx, &f->part, GINGR_SCALAR_PART)) || (rc = dev_alloc(ctx, &f->absmax, 2)) || (rc = dev_alloc(ctx, &f->work, (size_t)rp * rp)) ||
+        (rc = dev_alloc(ctx, &f->scalars, 8)) || (rc = dev_alloc(ctx, &f->part, GINGR_SCALAR_PART)) || (rc = dev_alloc(ctx, &f->absmax, GINGR_AUX)) || (rc = dev_alloc(ctx, &f->work, (size_t)rp * rp)) ||
         (rc = dev_alloc(ctx, &f->lm_mask, (size_t)M))) {
         gingr_fitter_destroy(f);
         return rc;
@@ -341,6 +341,7 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
     HIP_TRY(ctx, hipMemcpyAsync(aos, target_xyz, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     launch_aos_to_soa(ctx, aos, N, f->target);
     launch_cloud_absmax(ctx, cloud_of(f->target, N), f->absmax);
+    launch_cloud_centroid(ctx, cloud_of(f->target, N), f->absmax + 2);
     GINGR_TRY(check_launch(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GINGR_OK;
