@@ -225,6 +225,7 @@ def main():
                                    f"rigid global transform, sigma2_0={sigma2_0:.3f}",
                        "points": M, "targets": N, "rank": args.rank, "parallelism": f"row-shard x{world}"},
             "valid": ok,
+            "sigma2_after_timed_steps": float(sc.sigma2),
             "update_ms_device": upd_ms,
             "roofline": roof,
             "kernels": kernels,

@@ -16,8 +16,8 @@ LIB_PATH = os.path.join(_HERE, "libgingr_hip.so")
 
 GINGR_OK = 0
 ERR_BAD_ARGUMENT, ERR_HIP, ERR_NONFINITE, ERR_NOT_SPD, ERR_NO_DEVICE, ERR_STATE = 1, 2, 3, 4, 5, 6
-NUM_PHASES = 6
-NUM_SEGMENTS = 5
+NUM_PHASES = 3
+NUM_SEGMENTS = 2
 
 _STATUS_NAMES = {
     1: "GINGR_ERR_BAD_ARGUMENT", 2: "GINGR_ERR_HIP", 3: "GINGR_ERR_NONFINITE", 4: "GINGR_ERR_NOT_SPD",

@@ -42,20 +42,59 @@ __device__ __forceinline__ void colsum_tile(const P4 *tile, int cnt, const doubl
     }
 }
 
+// Accuracy-guarded fast path: exponent argument from the norm expansion
+//     t = c|x - y|^2 = c|x~|^2 + c|y~|^2 - 2c x~.y~     (x~, y~ centred on the target centroid)
+// = 1 add + 3 FMAs per pair instead of the 6 + 1 instructions of the difference form.  Its cancellation error is a
+// relative error of K_ij of about 7.7e-16 * R^2 / (2 sigma2) (R = cloud radius about the centroid), so it is used only
+// while that bound stays below kExpandTol; otherwise the kernels fall back to the exact differences (wave-uniform choice).
+constexpr double kExpandTol = 1e-12;
+
+__device__ __forceinline__ bool use_expansion(double rmax_centered, double c) {
+    // R^2 <= 3 rmax^2;  R^2 / (2 sigma2) = R^2 |c| ln2 / 2048
+    const double ratio = 3.0 * rmax_centered * rmax_centered * (-c) * (0.69314718055994530942 / GINGR_EXP_TABLE);
+    return ratio * 7.7e-16 < kExpandTol;
+}
+
+__device__ __forceinline__ double exp_from_t(double t, const double *T) {
+    const double tm = t + GINGR_EXP_MAGIC;
+    const double kf = tm - GINGR_EXP_MAGIC;
+    const double f = t - kf;  // exact
+    return fastexp2_core(tm, f, T);
+}
+
+// tile entries: (-2c y~, c|y~|^2); owned: x~ and n = c|x~|^2
+template <int PT>
+__device__ __forceinline__ void colsum_tile_expand(const P4 *tile, int cnt, const double (&x)[PT], const double (&y)[PT],
+                                                   const double (&z)[PT], const double (&n)[PT], double (&acc)[PT],
+                                                   const double *T) {
+#pragma unroll 2
+    for (int ii = 0; ii < cnt; ++ii) {
+        const P4 p = tile[ii];
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const double tt = __builtin_fma(z[t], p.z, __builtin_fma(y[t], p.y, __builtin_fma(x[t], p.x, p.w + n[t])));
+            acc[t] += exp_from_t(tt, T);
+        }
+    }
+}
+
 template <int PT>
 __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt, const double *__restrict__ sigma2,
-                                                            const double *__restrict__ absmax, int64_t rows_per_chunk,
+                                                            const double *__restrict__ aux, int64_t rows_per_chunk,
                                                             double *__restrict__ partial) {
     __shared__ double T[GINGR_EXP_TABLE];
     __shared__ P4 tile[kTile];
     fastexp_table_init(T);
     const double c = fastexp_scale_for_variance(2.0 * sigma2[0]);
-    const double am = absmax[0] + absmax[1];
-    const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);  // wave-uniform
+    const double am = aux[0] + aux[1];
+    const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);               // wave-uniform
+    const bool expand = use_expansion(fmax(aux[0], aux[1]), c);             // wave-uniform
     const double lim = fastexp_d2_limit(c);
+    const double cx = aux[2], cy = aux[3], cz = aux[4];
+    const double m2c = -2.0 * c;
     const int tid = threadIdx.x;
     const int64_t jbase = (int64_t)blockIdx.x * (kBlock * PT) + tid;
-    double x[PT], y[PT], z[PT], acc[PT];
+    double x[PT], y[PT], z[PT], n[PT], acc[PT];
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         const int64_t j = jbase + (int64_t)t * kBlock;
@@ -63,6 +102,12 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         x[t] = ok ? tgt.x[j] : 0.0;
         y[t] = ok ? tgt.y[j] : 0.0;
         z[t] = ok ? tgt.z[j] : 0.0;
+        if (expand) {
+            x[t] -= cx;
+            y[t] -= cy;
+            z[t] -= cz;
+        }
+        n[t] = c * __builtin_fma(z[t], z[t], __builtin_fma(y[t], y[t], x[t] * x[t]));
         acc[t] = 0.0;
     }
     const int64_t i0 = (int64_t)blockIdx.y * rows_per_chunk;
@@ -70,10 +115,19 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
     for (int64_t ib = i0; ib < i1; ib += kTile) {
         __syncthreads();
         const int64_t i = ib + tid;
-        if (i < i1) tile[tid] = P4{fit.x[i], fit.y[i], fit.z[i], 0.0};
+        if (i < i1) {
+            if (expand) {
+                const double fx = fit.x[i] - cx, fy = fit.y[i] - cy, fz = fit.z[i] - cz;
+                tile[tid] = P4{m2c * fx, m2c * fy, m2c * fz, c * __builtin_fma(fz, fz, __builtin_fma(fy, fy, fx * fx))};
+            } else {
+                tile[tid] = P4{fit.x[i], fit.y[i], fit.z[i], 0.0};
+            }
+        }
         __syncthreads();
         const int cnt = (int)min((int64_t)kTile, i1 - ib);
-        if (clamp)
+        if (expand)
+            colsum_tile_expand<PT>(tile, cnt, x, y, z, n, acc, T);
+        else if (clamp)
             colsum_tile<PT, true>(tile, cnt, x, y, z, acc, c, lim, T);
         else
             colsum_tile<PT, false>(tile, cnt, x, y, z, acc, c, lim, T);
@@ -85,13 +139,14 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
     }
 }
 
-// absmax[slot] = max over the cloud of |x|, |y|, |z| (atomic max on the bit pattern of a non-negative double:
-// order independent, hence deterministic).  The slot must be zeroed before the launch.
-__global__ __launch_bounds__(256) void cloud_absmax_kernel(Cloud c, double *__restrict__ slot) {
+// slot = max over the cloud of |x - cx|, |y - cy|, |z - cz| (ctr may be nullptr = origin).  Atomic max on the bit
+// pattern of a non-negative double: order independent, hence deterministic.  The slot must be zeroed before the launch.
+__global__ __launch_bounds__(256) void cloud_absmax_kernel(Cloud c, const double *__restrict__ ctr, double *__restrict__ slot) {
     __shared__ double sh[256];
+    const double cx = ctr ? ctr[0] : 0.0, cy = ctr ? ctr[1] : 0.0, cz = ctr ? ctr[2] : 0.0;
     double m = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < c.n; i += (int64_t)gridDim.x * 256)
-        m = fmax(m, fmax(fabs(c.x[i]), fmax(fabs(c.y[i]), fabs(c.z[i]))));
+        m = fmax(m, fmax(fabs(c.x[i] - cx), fmax(fabs(c.y[i] - cy), fabs(c.z[i] - cz))));
     sh[threadIdx.x] = m;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
@@ -100,7 +155,7 @@ __global__ __launch_bounds__(256) void cloud_absmax_kernel(Cloud c, double *__re
     }
     if (threadIdx.x == 0) {
         double v = sh[0];
-        if (!(v == v)) v = __builtin_huge_val();  // NaN coordinates: force the clamped path
+        if (!(v == v)) v = __builtin_huge_val();  // NaN coordinates: force the clamped exact path
         atomicMax(reinterpret_cast<unsigned long long *>(slot), __builtin_bit_cast(unsigned long long, v));
     }
 }
@@ -180,21 +235,48 @@ __device__ __forceinline__ void rowstats_tile(const P4 *tile, int cnt, const dou
     }
 }
 
+// expansion form of pass 2: tile entries (-2c x~, c|x~|^2) + 1/den; owned y~ and n = c|y~|^2.  P.X is accumulated as
+// sum_j p a_j with a_j = -2c x~_j and rescaled once at the end: PX = ctr*P1 - (sum_j p a_j) / (2c).
+template <int PT>
+__device__ __forceinline__ void rowstats_tile_expand(const P4 *tile, const double *tinv, int cnt, const double (&x)[PT],
+                                                     const double (&y)[PT], const double (&z)[PT], const double (&n)[PT],
+                                                     double (&a1)[PT], double (&ax)[PT], double (&ay)[PT], double (&az)[PT],
+                                                     const double *T) {
+#pragma unroll 2
+    for (int jj = 0; jj < cnt; ++jj) {
+        const P4 p = tile[jj];
+        const double inv = tinv[jj];
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const double tt = __builtin_fma(z[t], p.z, __builtin_fma(y[t], p.y, __builtin_fma(x[t], p.x, p.w + n[t])));
+            const double pij = exp_from_t(tt, T) * inv;
+            a1[t] += pij;
+            ax[t] = __builtin_fma(pij, p.x, ax[t]);
+            ay[t] = __builtin_fma(pij, p.y, ay[t]);
+            az[t] = __builtin_fma(pij, p.z, az[t]);
+        }
+    }
+}
+
 template <int PT>
 __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud tgt, const double *__restrict__ sigma2,
-                                                              const double *__restrict__ absmax,
+                                                              const double *__restrict__ aux,
                                                               const double *__restrict__ inv_den, int64_t cols_per_chunk,
                                                               double *__restrict__ partial) {
     __shared__ double T[GINGR_EXP_TABLE];
     __shared__ P4 tile[kTile];
+    __shared__ double tinv[kTile];
     fastexp_table_init(T);
     const double c = fastexp_scale_for_variance(2.0 * sigma2[0]);
-    const double am = absmax[0] + absmax[1];
-    const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);  // wave-uniform
+    const double am = aux[0] + aux[1];
+    const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);               // wave-uniform
+    const bool expand = use_expansion(fmax(aux[0], aux[1]), c);             // wave-uniform
     const double lim = fastexp_d2_limit(c);
+    const double cx = aux[2], cy = aux[3], cz = aux[4];
+    const double m2c = -2.0 * c;
     const int tid = threadIdx.x;
     const int64_t ibase = (int64_t)blockIdx.x * (kBlock * PT) + tid;
-    double x[PT], y[PT], z[PT], a1[PT], ax[PT], ay[PT], az[PT];
+    double x[PT], y[PT], z[PT], n[PT], a1[PT], ax[PT], ay[PT], az[PT];
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         const int64_t i = ibase + (int64_t)t * kBlock;
@@ -202,6 +284,12 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
         x[t] = ok ? fit.x[i] : 0.0;
         y[t] = ok ? fit.y[i] : 0.0;
         z[t] = ok ? fit.z[i] : 0.0;
+        if (expand) {
+            x[t] -= cx;
+            y[t] -= cy;
+            z[t] -= cz;
+        }
+        n[t] = c * __builtin_fma(z[t], z[t], __builtin_fma(y[t], y[t], x[t] * x[t]));
         a1[t] = ax[t] = ay[t] = az[t] = 0.0;
     }
     const int64_t j0 = (int64_t)blockIdx.y * cols_per_chunk;
@@ -209,24 +297,35 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
     for (int64_t jb = j0; jb < j1; jb += kTile) {
         __syncthreads();
         const int64_t j = jb + tid;
-        if (j < j1) tile[tid] = P4{tgt.x[j], tgt.y[j], tgt.z[j], inv_den[j]};
+        if (j < j1) {
+            if (expand) {
+                const double tx = tgt.x[j] - cx, ty = tgt.y[j] - cy, tz = tgt.z[j] - cz;
+                tile[tid] = P4{m2c * tx, m2c * ty, m2c * tz, c * __builtin_fma(tz, tz, __builtin_fma(ty, ty, tx * tx))};
+                tinv[tid] = inv_den[j];
+            } else {
+                tile[tid] = P4{tgt.x[j], tgt.y[j], tgt.z[j], inv_den[j]};
+            }
+        }
         __syncthreads();
         const int cnt = (int)min((int64_t)kTile, j1 - jb);
-        if (clamp)
+        if (expand)
+            rowstats_tile_expand<PT>(tile, tinv, cnt, x, y, z, n, a1, ax, ay, az, T);
+        else if (clamp)
             rowstats_tile<PT, true>(tile, cnt, x, y, z, a1, ax, ay, az, c, lim, T);
         else
             rowstats_tile<PT, false>(tile, cnt, x, y, z, a1, ax, ay, az, c, lim, T);
     }
     const int64_t M = fit.n;
     double *base = partial + (int64_t)blockIdx.y * 4 * M;
+    const double back = expand ? -0.5 / c : 1.0;  // sum_j p a_j -> sum_j p x~_j
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         const int64_t i = ibase + (int64_t)t * kBlock;
         if (i < M) {
             base[i] = a1[t];
-            base[M + i] = ax[t];
-            base[2 * M + i] = ay[t];
-            base[3 * M + i] = az[t];
+            base[M + i] = expand ? __builtin_fma(cx, a1[t], back * ax[t]) : ax[t];
+            base[2 * M + i] = expand ? __builtin_fma(cy, a1[t], back * ay[t]) : ay[t];
+            base[3 * M + i] = expand ? __builtin_fma(cz, a1[t], back * az[t]) : az[t];
         }
     }
 }
@@ -446,10 +545,10 @@ int64_t nn_ws_bytes(int64_t M, int64_t N) {
     return (int64_t)nch * M * (sizeof(double) + sizeof(int32_t));
 }
 
-void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, double *slot) {
+void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, const double *ctr, double *slot) {
     (void)hipMemsetAsync(slot, 0, sizeof(double), ctx->stream);
     const int nb = (int)(ceil_div(c.n, 256) < 64 ? ceil_div(c.n, 256) : 64);
-    hipLaunchKernelGGL(cloud_absmax_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, ctx->stream, c, slot);
+    hipLaunchKernelGGL(cloud_absmax_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, ctx->stream, c, ctr, slot);
 }
 
 void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,

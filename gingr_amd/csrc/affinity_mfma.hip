@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kThreads) void cpd_colsum_mfma_kernel(Cloud fit, Cl
     fastexp_table_init(T);
     const double c = fastexp_scale_for_variance(2.0 * sigma2[0]);
     const double am = aux[0] + aux[1];
-    const bool clamp = fastexp_needs_clamp(48.0 * am * am, c);  // wave-uniform
+    const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);  // wave-uniform
     const double cx = aux[2], cy = aux[3], cz = aux[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, cl = lane & 15;
     double b[4], acc[4];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kThreads) void cpd_rowstats_mfma_kernel(Cloud fit, 
     fastexp_table_init(T);
     const double c = fastexp_scale_for_variance(2.0 * sigma2[0]);
     const double am = aux[0] + aux[1];
-    const bool clamp = fastexp_needs_clamp(48.0 * am * am, c);  // wave-uniform
+    const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);  // wave-uniform
     const double cx = aux[2], cy = aux[3], cz = aux[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, cl = lane & 15;
     double b[4], a1[4], ax[4], ay[4], az[4];

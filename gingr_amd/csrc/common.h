@@ -100,9 +100,10 @@ int64_t cpd_rowstats_ws_doubles(int64_t M, int64_t N);
 int64_t nn_ws_bytes(int64_t M, int64_t N);
 
 // den_partial[N] = sum_{i in fit} exp(-|x_j - y_i|^2 / (2 sigma2))   (no outlier constant)
-// aux (GINGR_AUX doubles on the device): [0] / [1] largest |coordinate| of the target / fit cloud (launch_cloud_absmax);
-// the kernels derive an upper bound of d2 from them to decide (wave-uniformly) whether the exponent argument needs
-// clamping.  [2..4] centroid of the target cloud (launch_cloud_centroid): centring point of the MFMA formulation.
+// aux (GINGR_AUX doubles on the device): [2..4] centroid of the target cloud (launch_cloud_centroid); [0] / [1] largest
+// |coordinate - centroid| of the target / fit cloud (launch_cloud_absmax).  From them the kernels decide, wave-uniformly,
+// (a) whether the exponent argument needs clamping and (b) whether the cheaper norm-expansion form of c|x-y|^2 is
+// accurate enough (affinity.hip: use_expansion).
 #define GINGR_AUX 8
 void launch_cloud_centroid(gingr_ctx *ctx, Cloud c, double *out3);
 int64_t cpd_colsum_mfma_ws_doubles(int64_t M, int64_t N);
@@ -111,7 +112,7 @@ int launch_cpd_colsum_mfma(gingr_ctx *ctx, Cloud fit, Cloud target, const double
                            int *nchunks_out);
 int launch_cpd_rowstats_mfma(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
                              const double *inv_den, double *ws, int *nchunks_out);
-void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, double *slot);
+void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, const double *ctr, double *slot);
 void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *absmax,
                        double *ws, double *den_partial);
 // den[j] += c; inv_den[j] = 1/den[j]; Pt1[j] = (den[j]-c)/den[j]; xPx block partials -> part[0..256)

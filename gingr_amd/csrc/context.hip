@@ -185,9 +185,9 @@ int gingr_cpd_stats(gingr_ctx *ctx, int64_t M, const double *fit, int64_t N, con
     DevBuf daux;
     HIP_TRY(ctx, daux.alloc(GINGR_AUX * sizeof(double)));
     double *absmax = daux.as<double>();
-    launch_cloud_absmax(ctx, ct, absmax);
-    launch_cloud_absmax(ctx, cf, absmax + 1);
     launch_cloud_centroid(ctx, ct, absmax + 2);
+    launch_cloud_absmax(ctx, ct, absmax + 2, absmax);
+    launch_cloud_absmax(ctx, cf, absmax + 2, absmax + 1);
     launch_cpd_colsum(ctx, cf, ct, s2dev, absmax, dws.as<double>(), dden.as<double>());
     launch_cpd_den_finalize(ctx, ct, s2dev, w, M, dden.as<double>(), dinv.as<double>(), dpt1.as<double>(), dpart.as<double>(), sc);
     launch_cpd_rowstats(ctx, cf, ct, s2dev, absmax, dinv.as<double>(), dws.as<double>(), dp1.as<double>(), dpx.as<double>(), dpart.as<double>(), sc);

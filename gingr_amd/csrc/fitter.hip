@@ -2,14 +2,12 @@
 // of kernels with no host synchronisation (C ABI in include/gingr_hip.h).
 //
 // One update = GingrAlgorithm.update (G/api/GingrAlgorithm.scala:192-254) followed by GingrGeneratorWrapper.propose's
-// fit refresh and iteration++ (G/api/sampling/generators/GingrGeneratorWrapper.scala:28-39), split into six phases
+// fit refresh and iteration++ (G/api/sampling/generators/GingrGeneratorWrapper.scala:28-39), split into three phases
 // whose boundaries are exactly the points where a row-sharded run exchanges partial sums:
 //   0  CPD column sums of K over the local rows (ICP: nearest neighbour, nothing to exchange)        -> segment 0
 //   1  den, row statistics, observations, weighted Gram + right-hand side (+ landmarks), sigma2 sums -> segment 1
-//   2  posterior solve (replicated), posterior mean, first projection Q^T d                          -> segment 2
-//   3  alpha_1, step blend, newshape / current shape, Umeyama partial sums                           -> segment 3
-//   4  Umeyama (replicated), second projection                                                       -> segment 4
-//   5  alpha', state commit or failure status, new fit
+//   2  replicated O(r^2) algebra: posterior solve, then (moment form, gp.h) alpha_1, step blend, Umeyama, second
+//      projection, alpha', state commit or failure status; finally the new fit of the local rows (one pass over Q0)
 #include "gp.h"
 
 #include <cmath>
@@ -33,7 +31,7 @@ struct gingr_fitter {
     double *part = nullptr;     // block partials of the scalar sums
     double *absmax = nullptr;   // [0] target, [1] fit: largest |coordinate| (exponent-argument range check)
     double *xch = nullptr;
-    int64_t off[GINGR_NUM_SEGMENTS] = {0, 0, 0, 0, 0}, cnt[GINGR_NUM_SEGMENTS] = {0, 0, 0, 0, 0};
+    int64_t off[GINGR_NUM_SEGMENTS] = {0, 0}, cnt[GINGR_NUM_SEGMENTS] = {0, 0};
     double *ws = nullptr;
     int64_t ws_doubles = 0;
     double *work = nullptr;
@@ -109,7 +107,7 @@ int model_finalize_impl(gingr_ctx *ctx, gingr_model *m) {
     DevBuf work, flag;
     HIP_TRY(ctx, work.alloc((size_t)m->rp * m->rp * sizeof(double)));
     HIP_TRY(ctx, flag.alloc(sizeof(int32_t)));
-    launch_binv(ctx, m->r, m->rp, m->gramS, work.as<double>(), m->Binv, flag.as<int32_t>());
+    launch_binv(ctx, m->r, m->rp, m->mom, work.as<double>(), m->Binv, flag.as<int32_t>());
     GINGR_TRY(check_launch(ctx));
     int32_t err = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&err, flag.p, sizeof(err), hipMemcpyDeviceToHost, ctx->stream));
@@ -162,7 +160,7 @@ int gingr_model_upload(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doub
         return code;
     };
     if ((rc = dev_alloc(ctx, &m->Q0, (size_t)3 * M * m->rp)) || (rc = dev_alloc(ctx, &m->ref, (size_t)3 * M)) ||
-        (rc = dev_alloc(ctx, &m->mean, (size_t)3 * M)) || (rc = dev_alloc(ctx, &m->gramS, (size_t)m->rp * m->rp)) ||
+        (rc = dev_alloc(ctx, &m->mean, (size_t)3 * M)) || (rc = dev_alloc(ctx, &m->mom, (size_t)MomentLayout{m->rp}.total())) ||
         (rc = dev_alloc(ctx, &m->Binv, (size_t)m->rp * m->rp)))
         return fail(rc);
     if (stage.alloc((size_t)3 * M * rank * sizeof(double)) != hipSuccess || var.alloc(rank * sizeof(double)) != hipSuccess ||
@@ -180,13 +178,55 @@ int gingr_model_upload(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doub
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipMemcpyAsync(aos.p, mean + 3 * row_begin, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     launch_aos_to_soa(ctx, aos.as<double>(), M, m->mean);
-    // S_local = Q0^T Q0 (unit weights)
-    DevBuf gws;
-    if (gws.alloc((size_t)gram_ws_doubles(M, m->rp) * sizeof(double)) != hipSuccess)
-        return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: out of device memory"));
-    launch_gram(ctx, m->Q0, M, m->rp, nullptr, gws.as<double>(), m->gramS);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
-        return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: kernel launch failed"));
+    // one-off moments of the local rows (MomentLayout): S_tot, S[d][e], V[d][e], W[d]
+    {
+        const MomentLayout ml{m->rp};
+        DevBuf gws, sws, ptil, ev;
+        if (gws.alloc((size_t)gram_ws_doubles(M, m->rp) * sizeof(double)) != hipSuccess ||
+            sws.alloc((size_t)sweep_ws_doubles(M, m->rp) * sizeof(double)) != hipSuccess ||
+            ptil.alloc((size_t)3 * M * sizeof(double)) != hipSuccess || ev.alloc((size_t)3 * M * sizeof(double)) != hipSuccess)
+            return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: out of device memory"));
+        launch_gram(ctx, m->Q0, M, m->rp, nullptr, gws.as<double>(), m->mom + ml.stot());
+        for (int d = 0; d < 3; ++d)
+            for (int e = 0; e < 3; ++e) launch_moment_gram(ctx, m->Q0, M, m->rp, d, e, gws.as<double>(), m->mom + ml.S(d, e));
+        launch_centered_mean(ctx, m, ptil.as<double>());
+        std::vector<double> ones((size_t)M, 1.0);
+        DevBuf dones;
+        if (dones.alloc((size_t)M * sizeof(double)) != hipSuccess)
+            return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: out of device memory"));
+        (void)hipMemcpyAsync(dones.p, ones.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        SweepArgs a;
+        memset(&a, 0, sizeof(a));
+        a.Q0 = m->Q0;
+        a.ref = m->ref;
+        a.mean = m->mean;
+        a.M = M;
+        a.rp = m->rp;
+        a.evec = ev.as<double>();
+        a.partial = sws.as<double>();
+        for (int d = 0; d < 3; ++d)
+            for (int e = 0; e <= 3; ++e) {  // e == 3: the all-ones plane gives W[d]
+                (void)hipMemsetAsync(ev.p, 0, (size_t)3 * M * sizeof(double), ctx->stream);
+                const double *src = e < 3 ? ptil.as<double>() + (size_t)e * M : dones.as<double>();
+                (void)hipMemcpyAsync(ev.as<double>() + (size_t)d * M, src, (size_t)M * sizeof(double), hipMemcpyDeviceToDevice,
+                                     ctx->stream);
+                a.out = m->mom + (e < 3 ? ml.V(d, e) : ml.W(d));
+                launch_sweep(ctx, SWEEP_RHS, a);
+            }
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+            return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: kernel launch failed"));
+    }
+    // host moments of p~ over the FULL model (identical on every shard)
+    for (int q = 0; q < 9; ++q) m->Pp[q] = 0.0;
+    for (int q = 0; q < 3; ++q) m->Ps[q] = 0.0;
+    for (int64_t i = 0; i < M_total; ++i) {
+        double pt[3];
+        for (int d = 0; d < 3; ++d) pt[d] = ref[3 * i + d] + mean[3 * i + d] - m->c0[d];
+        for (int d = 0; d < 3; ++d) {
+            m->Ps[d] += pt[d];
+            for (int e = 0; e < 3; ++e) m->Pp[d * 3 + e] += pt[d] * pt[e];
+        }
+    }
     if (row_begin == 0 && row_end == M_total) {
         rc = model_finalize_impl(ctx, m);
         if (rc) return fail(rc);
@@ -201,7 +241,7 @@ void gingr_model_destroy(gingr_model *m) {
     dev_free(m->Q0);
     dev_free(m->ref);
     dev_free(m->mean);
-    dev_free(m->gramS);
+    dev_free(m->mom);
     dev_free(m->Binv);
     delete m;
 }
@@ -211,8 +251,8 @@ int32_t gingr_model_rank(const gingr_model *m) { return m ? m->r : 0; }
 
 int gingr_model_gram_exchange(gingr_model *m, void **dev_ptr, int64_t *count) {
     if (!m || !dev_ptr || !count) return GINGR_ERR_BAD_ARGUMENT;
-    *dev_ptr = m->gramS;
-    *count = (int64_t)m->rp * m->rp;
+    *dev_ptr = m->mom;
+    *count = MomentLayout{m->rp}.total();
     return GINGR_OK;
 }
 
@@ -314,9 +354,6 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
     // exchange segments (float64 elements)
     f->cnt[0] = N;
     f->cnt[1] = (int64_t)rp * rp + rp + 8;
-    f->cnt[2] = rp;
-    f->cnt[3] = 24;
-    f->cnt[4] = rp;
     int64_t o = 0;
     for (int s = 0; s < GINGR_NUM_SEGMENTS; ++s) {
         f->off[s] = o;
@@ -340,8 +377,8 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
     f->aos = aos;
     HIP_TRY(ctx, hipMemcpyAsync(aos, target_xyz, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     launch_aos_to_soa(ctx, aos, N, f->target);
-    launch_cloud_absmax(ctx, cloud_of(f->target, N), f->absmax);
     launch_cloud_centroid(ctx, cloud_of(f->target, N), f->absmax + 2);
+    launch_cloud_absmax(ctx, cloud_of(f->target, N), f->absmax + 2, f->absmax);
     GINGR_TRY(check_launch(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GINGR_OK;
@@ -512,9 +549,6 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
     double *G = f->xch + f->off[1];
     double *rhs = G + (int64_t)rp * rp;
     double *sc8 = rhs + rp;
-    double *seg2 = f->xch + f->off[2];
-    double *seg3 = f->xch + f->off[3];
-    double *seg4 = f->xch + f->off[4];
     const Cloud fit = cloud_of(f->fit, M);
     const Cloud tgt = cloud_of(f->target, f->N);
     switch (phase) {
@@ -522,7 +556,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
             if (icp)
                 launch_nn(ctx, fit, tgt, f->ws, f->nn_idx, f->nn_d2);
             else {
-                launch_cloud_absmax(ctx, fit, f->absmax + 1);
+                launch_cloud_absmax(ctx, fit, f->absmax + 2, f->absmax + 1);
                 launch_cpd_colsum(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->ws, seg0);
             }
             break;
@@ -548,47 +582,30 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
         }
         case 2: {
             launch_posterior_solve(ctx, r, rp, G, rhs, f->work, f->acoef, f->st);
-            SweepArgs a = base_args(f);
-            a.coef0 = f->acoef;
-            a.out = seg2;
-            launch_sweep(ctx, SWEEP_PROJ1, a);
-            break;
-        }
-        case 3: {
-            launch_alpha_blend(ctx, r, rp, m->Binv, seg2, f->alpha, f->step_length, f->alpha_c);
-            SweepArgs a = base_args(f);
-            a.coef0 = f->alpha_c;
-            a.coef1 = f->alpha;
-            a.shape_out = f->newshape;
-            a.out = seg3;
-            launch_sweep(ctx, SWEEP_SHAPES, a);
-            break;
-        }
-        case 4: {
-            launch_umeyama(ctx, seg3, m->M_total, m->c0, f->global_transform, f->pose, f->st);
-            SweepArgs a = base_args(f);
-            a.shape_in = f->newshape;
-            a.out = seg4;
-            launch_sweep(ctx, SWEEP_PROJ2, a);
-            break;
-        }
-        case 5: {
-            CommitArgs c;
-            memset(&c, 0, sizeof(c));
-            c.r = r;
-            c.rp = rp;
-            c.Binv = m->Binv;
-            c.p2 = seg4;
-            c.scalars = sc8;
-            c.is_icp = icp ? 1 : 0;
+            PostSolveArgs a;
+            memset(&a, 0, sizeof(a));
+            a.r = r;
+            a.rp = rp;
+            a.mom = m->mom;
+            a.Binv = m->Binv;
+            a.a = f->acoef;
+            a.alpha = f->alpha;
+            a.scalars = sc8;
+            a.is_icp = icp ? 1 : 0;
             if (icp) {
-                c.icp_step = (ip->initial_sigma - ip->end_sigma) / (double)ip->max_iterations;  // ICP.scala:65
-                c.icp_end = ip->end_sigma;
+                a.icp_step = (ip->initial_sigma - ip->end_sigma) / (double)ip->max_iterations;  // ICP.scala:65
+                a.icp_end = ip->end_sigma;
             }
-            c.alpha = f->alpha;
-            c.pose = f->pose;
-            c.state = f->st;
-            launch_commit(ctx, c);
+            a.step = f->step_length;
+            a.global_transform = f->global_transform;
+            a.n_total = (double)m->M_total;
+            for (int q = 0; q < 3; ++q) {
+                a.c0[q] = m->c0[q];
+                a.Ps[q] = m->Ps[q];
+            }
+            for (int q = 0; q < 9; ++q) a.Pp[q] = m->Pp[q];
+            a.state = f->st;
+            launch_post_solve(ctx, a);
             refresh_fit(f);
             break;
         }

@@ -31,6 +31,23 @@ struct DevPose {
     double scale;
 };
 
+// One-off moments of the basis (computed at upload, summed over ALL shards before finalize).  With them every step of the
+// update after the posterior solve -- both coefficient projections and the Umeyama sums -- is O(r^2) replicated algebra
+// with no pass over Q0 and no collective ("moment form"):
+//   p~_i = ref_i + mean_i - c0
+//   S_tot      = sum_i Q0_i^T Q0_i                        [rp*rp]   (= sum_d S[d][d])
+//   S[d][e]    = sum_i Q0[3i+d]^T Q0[3i+e]                 [9][rp*rp]
+//   V[d][e]    = sum_i Q0[3i+d]^T p~_i[e]                  [9][rp]
+//   W[d]       = sum_i Q0[3i+d]^T                          [3][rp]
+struct MomentLayout {
+    int32_t rp;
+    __host__ __device__ int64_t stot() const { return 0; }
+    __host__ __device__ int64_t S(int d, int e) const { return (int64_t)rp * rp * (1 + d * 3 + e); }
+    __host__ __device__ int64_t V(int d, int e) const { return (int64_t)rp * rp * 10 + (int64_t)rp * (d * 3 + e); }
+    __host__ __device__ int64_t W(int d) const { return (int64_t)rp * rp * 10 + (int64_t)rp * (9 + d); }
+    __host__ __device__ int64_t total() const { return (int64_t)rp * rp * 10 + (int64_t)rp * 12; }
+};
+
 struct gingr_model {
     gingr_ctx *ctx = nullptr;
     int64_t M_total = 0, row_begin = 0, row_end = 0, M = 0;  // M = local points
@@ -38,9 +55,11 @@ struct gingr_model {
     double *Q0 = nullptr;     // [3M][rp] row-major, Q0[row][k] = U[row][k] * sqrt(lambda_k), zero padded
     double *ref = nullptr;    // SoA [3][M]
     double *mean = nullptr;   // SoA [3][M]
-    double *gramS = nullptr;  // [rp*rp] local Q0^T Q0 until finalize (exchange buffer for the one-off all-reduce)
-    double *Binv = nullptr;   // [rp*rp] (S/eps + I)^-1, valid after finalize
-    double c0[3] = {0, 0, 0};  // centroid of the FULL reference: fixed centring point of the Umeyama partial sums
+    double *mom = nullptr;    // MomentLayout: local sums until finalize (the exchange buffer of the one-off all-reduce)
+    double *Binv = nullptr;   // [rp*rp] (S_tot/eps + I)^-1, valid after finalize
+    double c0[3] = {0, 0, 0};  // centroid of the FULL reference: fixed centring point of the Umeyama sums
+    double Pp[9] = {0};        // sum_i p~_i p~_i^T over the FULL model (host, identical on every shard)
+    double Ps[3] = {0};        // sum_i p~_i
     bool finalized = false;
 };
 
@@ -123,6 +142,30 @@ struct CommitArgs {
 };
 void launch_commit(gingr_ctx *ctx, const CommitArgs &a);
 void launch_state_init(gingr_ctx *ctx, DevState *st, const gingr_state_scalars *host_scalars_dev);
+
+// moment Gram S[d][e] (all patches, no symmetry): ws sized like gram_ws_doubles
+void launch_moment_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, int d, int e, double *ws, double *out);
+// p~ planes = ref + mean - c0
+void launch_centered_mean(gingr_ctx *ctx, const gingr_model *m, double *ptil);
+
+// Everything after the posterior solve in ONE workgroup: alpha_1, step blend, Umeyama from moments, second projection,
+// alpha', state commit / failure status, sigma2 update (GingrAlgorithm.scala:212-246).
+struct PostSolveArgs {
+    int32_t r, rp;
+    const double *mom;
+    const double *Binv;
+    const double *a;        // posterior regression coefficients
+    double *alpha;          // in/out: shape coefficients of the state
+    const double *scalars;  // reduced {Np, xPx, trPXY, yPy, ...} (CPD) or nullptr
+    int32_t is_icp;
+    double icp_step, icp_end;
+    double step;
+    int32_t global_transform;
+    double n_total;
+    double c0[3], Pp[9], Ps[3];
+    DevState *state;
+};
+void launch_post_solve(gingr_ctx *ctx, const PostSolveArgs &a);
 
 // basis packing: stage is column-major [r][3M] (local rows), out Q0 [3M][rp]
 void launch_pack_basis(gingr_ctx *ctx, const double *stage_colmajor, const double *variance_dev, int64_t M, int32_t r,

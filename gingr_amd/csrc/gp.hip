@@ -265,13 +265,18 @@ __global__ __launch_bounds__(256) void block_partials_reduce_kernel(const double
 // lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]: both are Q0[row0 + (l>>4)][col0 + (l&15)], i.e. four
 // 128-byte row segments per load instruction.  D: lane holds col j = l&15, rows i = (l>>4) + 4*reg.
 // The next step's fragments are loaded before the current step's 16 MFMAs are issued (software prefetch).
+// Generalised for the one-off moment Grams S[d][e] = sum_i Q0[3i+d]^T Q0[3i+e]: logical row L maps to the physical rows
+// L*row_stride + offA (A side) and L*row_stride + offB (B side); `full` enumerates all patches instead of pa <= pb.
 __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ Q0, int64_t rows, int rp,
                                                    const double *__restrict__ weight, int64_t rows_per_slab, int nbp,
+                                                   int row_stride, int offA, int offB, int full,
                                                    double *__restrict__ partial) {
     __shared__ double red[16 * 4 * 64];
-    // triangular patch index -> (pa <= pb)
     int pa = 0, pb = 0;
-    {
+    if (full) {
+        pa = blockIdx.y / nbp;
+        pb = blockIdx.y - pa * nbp;
+    } else {  // triangular patch index -> (pa <= pb)
         int t = blockIdx.y;
         for (pa = 0; pa < nbp; ++pa) {
             const int cnt = nbp - pa;
@@ -296,22 +301,23 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ Q0
         va[t] = pa * 64 + 16 * t < rp;
         vb[t] = pb * 64 + 16 * t < rp;
     }
-    const bool diag = pa == pb;
+    const bool diag = pa == pb && offA == offB;
     double ca[4], cb[4];
     auto load = [&](int64_t row, double fa[4], double fb[4]) {
         const int64_t rr = row + kq;
         const bool valid = rr < r1;
         const int64_t rc = valid ? rr : r0;
-        const double wv = valid ? (weight ? weight[rc / 3] : 1.0) : 0.0;
-        const double *base = Q0 + rc * rp + cl;
+        const double wv = valid ? (weight ? weight[row_stride == 1 ? rc / 3 : rc] : 1.0) : 0.0;
+        const double *baseB = Q0 + (rc * row_stride + offB) * rp + cl;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) fb[t] = (vb[t] && valid) ? base[pb * 64 + 16 * t] : 0.0;
+        for (int t = 0; t < 4; ++t) fb[t] = (vb[t] && valid) ? baseB[pb * 64 + 16 * t] : 0.0;
         if (diag) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) fa[t] = fb[t] * wv;
         } else {
+            const double *baseA = Q0 + (rc * row_stride + offA) * rp + cl;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) fa[t] = va[t] ? base[pa * 64 + 16 * t] * wv : 0.0;
+            for (int t = 0; t < 4; ++t) fa[t] = va[t] ? baseA[pa * 64 + 16 * t] * wv : 0.0;
         }
     };
     int64_t row = r0 + 4 * wave;
@@ -367,16 +373,36 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ Q0
             }
 }
 
-// G[i][j] (i <= j taken from the upper patches, mirrored) = sum over slabs in ascending order
-__global__ void gram_reduce_kernel(const double *__restrict__ partial, int nslabs, int rp, double *__restrict__ G) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// G[i][j] = sum over slabs (fixed tree): one 64-thread group per output element, 4 elements per workgroup.
+// symmetric: only i <= j is read (upper patches) and mirrored; otherwise every element is reduced.
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restrict__ partial, int nslabs, int rp, int symmetric,
+                                                          double *__restrict__ G) {
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (idx >= rp * rp) return;
     const int i = idx / rp, j = idx - i * rp;
-    if (i > j) return;
+    if (symmetric && i > j) return;
     double s = 0.0;
-    for (int b = 0; b < nslabs; ++b) s += partial[(int64_t)b * rp * rp + idx];
-    G[i * rp + j] = s;
-    G[j * rp + i] = s;
+    for (int b = lane; b < nslabs; b += 64) s += partial[(int64_t)b * rp * rp + idx];
+    s += __shfl_xor(s, 32);
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 8);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 1);
+    if (lane == 0) {
+        G[i * rp + j] = s;
+        if (symmetric) G[j * rp + i] = s;
+    }
+}
+
+__global__ void centered_mean_kernel(const double *__restrict__ ref, const double *__restrict__ mean, int64_t M, double c0x,
+                                     double c0y, double c0z, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    out[i] = ref[i] + mean[i] - c0x;
+    out[M + i] = ref[M + i] + mean[M + i] - c0y;
+    out[2 * M + i] = ref[2 * M + i] + mean[2 * M + i] - c0z;
 }
 
 // ------------------------------------------------------------------------------------------------- observations
@@ -581,93 +607,172 @@ __global__ __launch_bounds__(kDenseThreads) void posterior_solve_kernel(int r, i
     }
 }
 
-// Single-wave, LDS-resident variant for r <= 128: packed lower-triangular storage, left-looking Cholesky, no workgroup
-// barriers on the critical path (one wave executes its LDS operations in order).
-__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+// LDS-resident blocked Cholesky solve for r <= 128 (one workgroup of 256 threads, 16-wide panels):
+// per panel (1) wave 0 factors the 16x16 diagonal block IN REGISTERS (one row per lane, cross-lane broadcasts with
+// v_readlane: no LDS round trip on the sequential chain), (2) one thread per row solves the panel below it,
+// (3) all threads update the trailing matrix; forward / backward substitution are blocked the same way.
+// 3 workgroup barriers per panel instead of 2 per column.
+constexpr int kNB = 16;
 
-__device__ __forceinline__ double wave_sum(double v) {
-    v += __shfl_xor(v, 32);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 1);
-    return v;
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, l);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-__global__ __launch_bounds__(64) void posterior_solve_lds_kernel(int r, int rp, const double *__restrict__ G,
-                                                                 const double *__restrict__ rhs, double *__restrict__ a,
-                                                                 DevState *__restrict__ st) {
-    extern __shared__ double Ls[];  // r(r+1)/2 packed lower triangle, then y[r]
-    const int lane = threadIdx.x;
-    double *y = Ls + r * (r + 1) / 2;
-    // Mm = QtL Q + I     (scalismo genericRegressionComputations)
-    for (int i = 0; i < r; ++i)
-        for (int j = lane; j <= i; j += 64) Ls[tri(i, j)] = G[i * rp + j] + (i == j ? 1.0 : 0.0);
-    for (int k = lane; k < r; k += 64) y[k] = rhs[k];
+__global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp, const double *__restrict__ G,
+                                                                  const double *__restrict__ rhs, double *__restrict__ a,
+                                                                  DevState *__restrict__ st) {
+    extern __shared__ double sm[];
+    const int ld = r | 1;  // odd leading dimension: column walks hit distinct banks
+    double *A = sm;
+    double *y = sm + (size_t)r * ld;
+    double *rd = y + r;  // reciprocal diagonal of L
+    __shared__ int bad_spd;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) bad_spd = 0;
+    // Mm = QtL Q + I     (scalismo genericRegressionComputations); lower triangle only
+    for (int i = wave; i < r; i += 4)
+        for (int j = lane; j <= i; j += 64) A[i * ld + j] = G[i * rp + j] + (i == j ? 1.0 : 0.0);
+    for (int k = tid; k < r; k += 256) y[k] = rhs[k];
     __syncthreads();
-    int bad_spd = 0;
-    for (int k = 0; k < r; ++k) {
-        const int i0 = k + lane, i1 = k + lane + 64;
-        const bool two = k + 64 < r;  // wave-uniform
-        double s0 = i0 < r ? Ls[tri(i0, k)] : 0.0;
-        double s1 = (two && i1 < r) ? Ls[tri(i1, k)] : 0.0;
-        const int b0 = i0 < r ? tri(i0, 0) : 0, b1 = (two && i1 < r) ? tri(i1, 0) : 0, bk = tri(k, 0);
-        if (two) {
-            for (int j = 0; j < k; ++j) {
-                const double lkj = Ls[bk + j];
-                s0 = __builtin_fma(-Ls[b0 + j], lkj, s0);
-                s1 = __builtin_fma(-Ls[b1 + j], lkj, s1);
+    for (int kb = 0; kb < r; kb += kNB) {
+        const int nb = min(kNB, r - kb);
+        // (1) diagonal block in registers, wave 0: lane i holds row i (columns 0..i)
+        if (wave == 0) {
+            double row[kNB];
+#pragma unroll
+            for (int k = 0; k < kNB; ++k)
+                row[k] = (lane < nb && k <= lane) ? A[(kb + lane) * ld + kb + k] : (k == lane ? 1.0 : 0.0);
+            int bad = 0;
+#pragma unroll
+            for (int c = 0; c < kNB; ++c) {
+                double d = readlane_d(row[c], c);
+                if (c < nb && (!(d > 0.0) || !finite_d(d))) {
+                    bad = 1;
+                    d = 1.0;
+                }
+                const double dk = sqrt(d), rdk = 1.0 / dk;
+                const double lc = (lane == c) ? dk : row[c] * rdk;
+                row[c] = lc;
+#pragma unroll
+                for (int j = c + 1; j < kNB; ++j) {
+                    const double lj = readlane_d(lc, j);
+                    row[j] = __builtin_fma(-lc, lj, row[j]);
+                }
             }
-        } else {
-            // four independent partial sums: the dependent-FMA chain, not the LDS, limits a single wave
-            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-            int j = 0;
-            for (; j + 4 <= k; j += 4) {
-                t0 = __builtin_fma(Ls[b0 + j], Ls[bk + j], t0);
-                t1 = __builtin_fma(Ls[b0 + j + 1], Ls[bk + j + 1], t1);
-                t2 = __builtin_fma(Ls[b0 + j + 2], Ls[bk + j + 2], t2);
-                t3 = __builtin_fma(Ls[b0 + j + 3], Ls[bk + j + 3], t3);
+            if (lane < nb) {
+#pragma unroll
+                for (int k = 0; k < kNB; ++k)
+                    if (k <= lane) A[(kb + lane) * ld + kb + k] = row[k];
+#pragma unroll
+                for (int k = 0; k < kNB; ++k)
+                    if (k == lane) rd[kb + lane] = 1.0 / row[k];
             }
-            for (; j < k; ++j) t0 = __builtin_fma(Ls[b0 + j], Ls[bk + j], t0);
-            s0 -= (t0 + t1) + (t2 + t3);
+            if (bad && lane == 0) bad_spd = 1;
         }
-        double d = __shfl(s0, 0);
-        if (!(d > 0.0) || !finite_d(d)) {
-            bad_spd = 1;
-            d = 1.0;
+        __syncthreads();
+        // (2) panel below the diagonal block: x L11^T = A[i][kb:kb+nb]
+        for (int i = kb + nb + tid; i < r; i += 256) {
+            double x[kNB];
+#pragma unroll
+            for (int c = 0; c < kNB; ++c) {
+                if (c < nb) {
+                    double sacc = A[i * ld + kb + c];
+#pragma unroll
+                    for (int k = 0; k < kNB; ++k)
+                        if (k < c) sacc = __builtin_fma(-x[k], A[(kb + c) * ld + kb + k], sacc);
+                    x[c] = sacc * rd[kb + c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < kNB; ++c)
+                if (c < nb) A[i * ld + kb + c] = x[c];
         }
-        const double dk = sqrt(d), rdk = 1.0 / dk;
         __syncthreads();
-        if (i0 < r) Ls[tri(i0, k)] = lane == 0 ? dk : s0 * rdk;
-        if (two && i1 < r) Ls[tri(i1, k)] = s1 * rdk;
-        __syncthreads();
-    }
-    // L z = rhs, column oriented: once z_k is known every lane removes its contribution from its own rows
-    for (int k = 0; k < r; ++k) {
-        const double zk = y[k] / Ls[tri(k, k)];
-        __syncthreads();
-        if (lane == 0) y[k] = zk;
-        for (int i = k + 1 + lane; i < r; i += 64) y[i] = __builtin_fma(-Ls[tri(i, k)], zk, y[i]);
-        __syncthreads();
-    }
-    // L^T a = z
-    for (int k = r - 1; k >= 0; --k) {
-        const double ak = y[k] / Ls[tri(k, k)];
-        __syncthreads();
-        if (lane == 0) y[k] = ak;
-        const int bk = tri(k, 0);
-        for (int i = lane; i < k; i += 64) y[i] = __builtin_fma(-Ls[bk + i], ak, y[i]);
+        // (3) trailing update of the lower triangle
+        {
+            const int t0 = kb + nb, tx = tid & 15, ty = tid >> 4;
+            for (int i = t0 + ty; i < r; i += 16) {
+                double li[kNB];
+#pragma unroll
+                for (int k = 0; k < kNB; ++k) li[k] = k < nb ? A[i * ld + kb + k] : 0.0;
+                for (int j = t0 + tx; j <= i; j += 16) {
+                    double sacc = A[i * ld + j];
+#pragma unroll
+                    for (int k = 0; k < kNB; ++k)
+                        if (k < nb) sacc = __builtin_fma(-li[k], A[j * ld + kb + k], sacc);
+                    A[i * ld + j] = sacc;
+                }
+            }
+        }
         __syncthreads();
     }
-    int bad = 0;
-    for (int k = lane; k < rp; k += 64) {
+    // L z = rhs (blocked): the 16x16 triangular solve runs in registers of wave 0
+    for (int kb = 0; kb < r; kb += kNB) {
+        const int nb = min(kNB, r - kb);
+        if (wave == 0) {
+            double row[kNB];
+#pragma unroll
+            for (int k = 0; k < kNB; ++k) row[k] = (lane < nb && k < lane) ? A[(kb + lane) * ld + kb + k] : 0.0;
+            double yv = lane < nb ? y[kb + lane] : 0.0;
+            const double rdl = lane < nb ? rd[kb + lane] : 1.0;
+#pragma unroll
+            for (int c = 0; c < kNB; ++c) {
+                const double yc = readlane_d(yv, c) * readlane_d(rdl, c);
+                if (lane == c) yv = yc;
+                if (lane > c) yv = __builtin_fma(-row[c], yc, yv);
+            }
+            if (lane < nb) y[kb + lane] = yv;
+        }
+        __syncthreads();
+        for (int i = kb + nb + tid; i < r; i += 256) {
+            double sacc = y[i];
+#pragma unroll
+            for (int k = 0; k < kNB; ++k)
+                if (k < nb) sacc = __builtin_fma(-A[i * ld + kb + k], y[kb + k], sacc);
+            y[i] = sacc;
+        }
+        __syncthreads();
+    }
+    // L^T a = z (blocked, bottom up): lane c holds column c of the diagonal block
+    for (int kb = ((r - 1) / kNB) * kNB; kb >= 0; kb -= kNB) {
+        const int nb = min(kNB, r - kb);
+        if (wave == 0) {
+            double col[kNB];
+#pragma unroll
+            for (int k = 0; k < kNB; ++k) col[k] = (lane < nb && k < nb && k > lane) ? A[(kb + k) * ld + kb + lane] : 0.0;
+            double yv = lane < nb ? y[kb + lane] : 0.0;
+            const double rdl = lane < nb ? rd[kb + lane] : 1.0;
+#pragma unroll
+            for (int c = kNB - 1; c >= 0; --c) {
+                const double xc = readlane_d(yv, c) * readlane_d(rdl, c);
+                if (lane == c) yv = xc;
+                if (lane < c) yv = __builtin_fma(-col[c], xc, yv);
+            }
+            if (lane < nb) y[kb + lane] = yv;
+        }
+        __syncthreads();
+        for (int i = tid; i < kb; i += 256) {
+            double sacc = y[i];
+#pragma unroll
+            for (int k = 0; k < kNB; ++k)
+                if (k < nb) sacc = __builtin_fma(-A[(kb + k) * ld + i], y[kb + k], sacc);
+            y[i] = sacc;
+        }
+        __syncthreads();
+    }
+    __shared__ int bad;
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    for (int k = tid; k < rp; k += 256) {
         const double v = k < r ? y[k] : 0.0;
         a[k] = v;
         if (!finite_d(v)) bad = 1;
     }
-    bad = __any(bad);
-    if (lane == 0) {
+    __syncthreads();
+    if (tid == 0) {
         if (bad_spd)
             st->err = GINGR_ERR_NOT_SPD;
         else if (bad)
@@ -797,21 +902,17 @@ __device__ void svd3(const double Ain[9], double U[9], double s[3], double V[9])
     }
 }
 
-// sums: [0..2] sum x~, [3..5] sum y~, [6..14] sum y~ x~^T (row-major), [15] sum |x~|^2; x~ = x - c0, y~ = y - c0
-__global__ void umeyama_kernel(const double *__restrict__ sums, double n, double c0x, double c0y, double c0z,
-                               int global_transform, DevPose *__restrict__ pose, DevState *__restrict__ st) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    DevPose P;
+// sums: [0..2] sum x~, [3..5] sum y~, [6..14] sum y~ x~^T (row-major), [15] sum |x~|^2; x~ = x - c0, y~ = y - c0.
+// Returns false when the result is not finite.
+__device__ bool umeyama_from_sums(const double *sums, double n, const double c0[3], int global_transform, DevPose &P) {
     if (global_transform == GINGR_NO_TRANSFORMS) {  // identityTransformation, GingrAlgorithm.scala:230
         for (int q = 0; q < 9; ++q) P.R[q] = (q % 4 == 0) ? 1.0 : 0.0;
         P.euler[0] = P.euler[1] = P.euler[2] = 0.0;
         P.t[0] = P.t[1] = P.t[2] = 0.0;
         P.center[0] = P.center[1] = P.center[2] = 0.0;
         P.scale = 1.0;
-        *pose = P;
-        return;
+        return true;
     }
-    const double c0[3] = {c0x, c0y, c0z};
     double mux[3], muy[3];
     for (int a = 0; a < 3; ++a) {
         mux[a] = sums[a] / n;
@@ -845,8 +946,203 @@ __global__ void umeyama_kernel(const double *__restrict__ sums, double n, double
     bool fin = finite_d(c);
     for (int q = 0; q < 9; ++q) fin = fin && finite_d(P.R[q]);
     for (int q = 0; q < 3; ++q) fin = fin && finite_d(P.t[q]);
+    return fin;
+}
+
+__global__ void umeyama_kernel(const double *__restrict__ sums, double n, double c0x, double c0y, double c0z,
+                               int global_transform, DevPose *__restrict__ pose, DevState *__restrict__ st) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double c0[3] = {c0x, c0y, c0z};
+    DevPose P;
+    const bool fin = umeyama_from_sums(sums, n, c0, global_transform, P);
     if (!fin && st->err == 0) st->err = GINGR_ERR_NONFINITE;
     *pose = P;
+}
+
+// ------------------------------------------------------------------------------------------------- fused post-solve
+// out[k] = sum_j Mat[j*rp + k] * x[j]   (i.e. Mat^T x; pass the transposed partner for a non-symmetric matrix).
+// All threads of the workgroup take part: `parts` row strips are accumulated in parallel and combined in a fixed order.
+__device__ void block_matvec_T(const double *__restrict__ Mat, const double *x, double *out, int r, int rp, double *scratch) {
+    const int nt = blockDim.x;
+    int width = 16;
+    while (width < rp) width <<= 1;
+    const int parts = nt / width > 0 ? nt / width : 1;
+    const int k = threadIdx.x % width, part = threadIdx.x / width;
+    double s = 0.0;
+    if (part < parts && k < rp)
+        for (int j = part; j < r; j += parts) s = __builtin_fma(Mat[(int64_t)j * rp + k], x[j], s);
+    __syncthreads();
+    if (part < parts && k < rp) scratch[part * rp + k] = s;
+    __syncthreads();
+    for (int kk = threadIdx.x; kk < rp; kk += nt) {
+        double t = 0.0;
+        for (int p = 0; p < parts; ++p) t += scratch[p * rp + kk];
+        out[kk] = t;
+    }
+    __syncthreads();
+}
+
+// dot of two LDS vectors by one wave; every lane returns the result
+__device__ __forceinline__ double wave_dot(const double *x, const double *y, int r) {
+    double s = 0.0;
+    for (int k = threadIdx.x & 63; k < r; k += 64) s = __builtin_fma(x[k], y[k], s);
+    s += __shfl_xor(s, 32);
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 8);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 1);
+    return s;
+}
+
+constexpr int kPostThreads = 1024;
+
+__global__ __launch_bounds__(kPostThreads) void post_solve_kernel(PostSolveArgs A) {
+    extern __shared__ double sm[];
+    const int r = A.r, rp = A.rp, tid = threadIdx.x;
+    const MomentLayout ml{rp};
+    DevState *st = A.state;
+    if (st->status == GINGR_FIT_MODEL_FLEXIBILITY_ERROR) return;  // a failed fit stays as it is (run stops, :149-157)
+    double *va = sm, *valpha = va + rp, *vt = valpha + rp, *vac = vt + rp, *proj = vac + rp, *anew = proj + rp;
+    double *za = anew + rp;       // [9][rp]  S[d][e] alpha
+    double *zc = za + 9 * rp;     // [9][rp]  S[d][e] alpha_c
+    double *scratch = zc + 9 * rp;
+    __shared__ double dots[40];
+    __shared__ DevPose P;
+    __shared__ double Bm[9], BmI[9], hv[3];
+    __shared__ int bad;
+    for (int k = tid; k < rp; k += kPostThreads) {
+        va[k] = k < r ? A.a[k] : 0.0;
+        valpha[k] = k < r ? A.alpha[k] : 0.0;
+    }
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    // alpha_1 = Binv (S_tot a) / eps: coefficients of the posterior mean (transformedModelInit.coefficients, :212-216);
+    // Q^T (Q a) = S_tot a, and the R / R^T round trip of the displacement cancels
+    block_matvec_T(A.mom + ml.stot(), va, vt, r, rp, scratch);
+    block_matvec_T(A.Binv, vt, vac, r, rp, scratch);
+    for (int k = tid; k < rp; k += kPostThreads) {
+        const double a1 = vac[k] / GINGR_COEFF_NOISE;
+        vac[k] = k < r ? valpha[k] + (a1 - valpha[k]) * A.step : 0.0;  // :218-220
+    }
+    __syncthreads();
+    // z = S[d][e] alpha and S[d][e] alpha_c; (S[d][e] x)[k] = sum_j S[e][d][j][k] x[j]
+    for (int d = 0; d < 3; ++d)
+        for (int e = 0; e < 3; ++e) {
+            block_matvec_T(A.mom + ml.S(e, d), valpha, za + (d * 3 + e) * rp, r, rp, scratch);
+            block_matvec_T(A.mom + ml.S(e, d), vac, zc + (d * 3 + e) * rp, r, rp, scratch);
+        }
+    // 36 dot products, one wave each: [0..2] W[d].alpha, [3..5] W[d].alpha_c, [6..14] V[b][d].alpha (index d*3+b),
+    // [15..23] V[d][b].alpha_c, [24..32] alpha_c.za[d][b], [33..35] alpha.za[d][d]
+    for (int t = tid >> 6; t < 36; t += kPostThreads / 64) {
+        double v;
+        if (t < 3)
+            v = wave_dot(A.mom + ml.W(t), valpha, r);
+        else if (t < 6)
+            v = wave_dot(A.mom + ml.W(t - 3), vac, r);
+        else if (t < 15) {
+            const int d = (t - 6) / 3, b = (t - 6) % 3;
+            v = wave_dot(A.mom + ml.V(b, d), valpha, r);
+        } else if (t < 24) {
+            const int d = (t - 15) / 3, b = (t - 15) % 3;
+            v = wave_dot(A.mom + ml.V(d, b), vac, r);
+        } else if (t < 33) {
+            v = wave_dot(vac, za + (t - 24) * rp, r);
+        } else {
+            const int d = t - 33;
+            v = wave_dot(valpha, za + (d * 3 + d) * rp, r);
+        }
+        if ((tid & 63) == 0) dots[t] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // u~_i = p~_i + Q0_i alpha (current shape, unposed), v~_i = p~_i + Q0_i alpha_c, newshape - c0 = R v~_i + g~
+        const double *R = st->R;
+        double su[3], sv[3], Mvu[9], gt[3], sums[16];
+        for (int d = 0; d < 3; ++d) {
+            su[d] = A.Ps[d] + dots[d];
+            sv[d] = A.Ps[d] + dots[3 + d];
+        }
+        for (int d = 0; d < 3; ++d)
+            for (int b = 0; b < 3; ++b) Mvu[d * 3 + b] = A.Pp[d * 3 + b] + dots[6 + d * 3 + b] + dots[15 + d * 3 + b] + dots[24 + d * 3 + b];
+        for (int a = 0; a < 3; ++a) {
+            const double q0 = A.c0[0] - st->center[0], q1 = A.c0[1] - st->center[1], q2 = A.c0[2] - st->center[2];
+            gt[a] = R[a * 3] * q0 + R[a * 3 + 1] * q1 + R[a * 3 + 2] * q2 + st->center[a] + st->t[a] - A.c0[a];
+        }
+        for (int a = 0; a < 3; ++a) {
+            sums[a] = su[a];
+            sums[3 + a] = R[a * 3] * sv[0] + R[a * 3 + 1] * sv[1] + R[a * 3 + 2] * sv[2] + A.n_total * gt[a];
+            for (int b = 0; b < 3; ++b)
+                sums[6 + a * 3 + b] = R[a * 3] * Mvu[b] + R[a * 3 + 1] * Mvu[3 + b] + R[a * 3 + 2] * Mvu[6 + b] + gt[a] * su[b];
+        }
+        sums[15] = 0.0;
+        for (int d = 0; d < 3; ++d) sums[15] += A.Pp[d * 3 + d] + 2.0 * dots[6 + d * 3 + d] + dots[33 + d];
+        DevPose Pl;
+        const bool fin = umeyama_from_sums(sums, A.n_total, A.c0, A.global_transform, Pl);
+        if (!fin) bad = 1;
+        P = Pl;
+        // e_i = R2^T (newshape_i - t2) - p_i = (B - I) p~_i + B Q0_i alpha_c + h,  B = R2^T R
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                const double v = Pl.R[a] * R[b] + Pl.R[3 + a] * R[3 + b] + Pl.R[6 + a] * R[6 + b];
+                Bm[a * 3 + b] = v;
+                BmI[a * 3 + b] = v - (a == b ? 1.0 : 0.0);
+            }
+        double w3[3];
+        for (int a = 0; a < 3; ++a) w3[a] = gt[a] + A.c0[a] - Pl.t[a];
+        for (int a = 0; a < 3; ++a) {
+            const double rt = Pl.R[a] * w3[0] + Pl.R[3 + a] * w3[1] + Pl.R[6 + a] * w3[2];
+            hv[a] = rt - A.c0[a];  // h = R2^T (g~ + c0 - t2) - c0   (p_i = p~_i + c0)
+        }
+    }
+    __syncthreads();
+    // second projection Q^T e from the moments (transformedModel.coefficients(newshape), :234-237)
+    for (int k = tid; k < rp; k += kPostThreads) {
+        double s = 0.0;
+        for (int d = 0; d < 3; ++d) {
+            for (int e = 0; e < 3; ++e) {
+                s = __builtin_fma(BmI[d * 3 + e], A.mom[ml.V(d, e) + k], s);
+                s = __builtin_fma(Bm[d * 3 + e], zc[(d * 3 + e) * rp + k], s);
+            }
+            s = __builtin_fma(hv[d], A.mom[ml.W(d) + k], s);
+        }
+        proj[k] = k < r ? s : 0.0;
+    }
+    __syncthreads();
+    block_matvec_T(A.Binv, proj, anew, r, rp, scratch);
+    for (int k = tid; k < rp; k += kPostThreads) {
+        const double v = k < r ? anew[k] / GINGR_COEFF_NOISE : 0.0;
+        anew[k] = v;
+        if (!finite_d(v)) bad = 1;
+    }
+    __syncthreads();
+    const bool failed = (st->err != 0) || bad;
+    __syncthreads();
+    if (!failed)
+        for (int k = tid; k < rp; k += kPostThreads) A.alpha[k] = anew[k];
+    if (tid == 0) {
+        if (!failed) {
+            for (int q = 0; q < 9; ++q) st->R[q] = P.R[q];
+            for (int q = 0; q < 3; ++q) {
+                st->euler[q] = P.euler[q];
+                st->center[q] = 0.0;  // Umeyama about Point(0,0,0), GingrAlgorithm.scala:81,266
+                st->t[q] = P.t[q];
+            }
+            st->scale = P.scale;
+            if (A.is_icp) {
+                const double ns = st->sigma2 - A.icp_step;       // ICP.scala:96-99
+                st->sigma2 = ns > A.icp_end ? ns : A.icp_end;
+            } else {
+                const double *sc = A.scalars;                    // CPD.scala:142-145
+                st->sigma2 = (sc[1] - 2 * sc[2] + sc[3]) / (sc[0] * 3.0);
+            }
+        } else if (st->iteration > 0) {
+            st->status = GINGR_FIT_MODEL_FLEXIBILITY_ERROR;       // GingrAlgorithm.scala:204,248,251 (iteration 0: :206-208)
+        }
+        st->pad = failed ? (st->err != 0 ? st->err : GINGR_ERR_NONFINITE) : 0;  // last error, readable by the host
+        st->err = 0;
+        st->iteration += 1;  // GingrGeneratorWrapper.propose: updateIteration()
+    }
 }
 
 __global__ __launch_bounds__(kDenseThreads) void commit_kernel(CommitArgs a) {
@@ -978,11 +1274,29 @@ void launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const 
     gram_plan(M, rp, &nbp, &npatch, &nslabs, &rps);
     {
         TimerScope ts(ctx, 2);
-        hipLaunchKernelGGL(gram_kernel, dim3(nslabs, npatch), dim3(256), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, nbp,
-                           ws);
+        hipLaunchKernelGGL(gram_kernel, dim3(nslabs, npatch), dim3(256), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, nbp, 1,
+                           0, 0, 0, ws);
     }
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 256)), dim3(256), 0, ctx->stream, ws,
-                       nslabs, (int)rp, G);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 4)), dim3(256), 0, ctx->stream, ws,
+                       nslabs, (int)rp, 1, G);
+}
+
+void launch_moment_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, int d, int e, double *ws, double *out) {
+    // logical rows = points; same slab plan as the weighted Gram (its workspace is large enough: nslabs is capped by rows/64)
+    int nbp, npatch, nslabs;
+    int64_t rps;
+    gram_plan(M, rp, &nbp, &npatch, &nslabs, &rps);
+    rps = round_up(ceil_div(M, nslabs), 16);
+    nslabs = (int)ceil_div(M, rps);
+    hipLaunchKernelGGL(gram_kernel, dim3(nslabs, nbp * nbp), dim3(256), 0, ctx->stream, Q0, M, (int)rp,
+                       (const double *)nullptr, rps, nbp, 3, d, e, 1, ws);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 4)), dim3(256), 0, ctx->stream, ws,
+                       nslabs, (int)rp, 0, out);
+}
+
+void launch_centered_mean(gingr_ctx *ctx, const gingr_model *m, double *ptil) {
+    hipLaunchKernelGGL(centered_mean_kernel, dim3((unsigned)ceil_div(m->M, 256)), dim3(256), 0, ctx->stream, m->ref, m->mean,
+                       m->M, m->c0[0], m->c0[1], m->c0[2], ptil);
 }
 
 void launch_obs_cpd(gingr_ctx *ctx, const gingr_model *m, const DevState *st, Cloud fit, const double *P1,
@@ -1014,11 +1328,11 @@ void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, 
 void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, double *work,
                             double *a, DevState *st) {
     if (r <= 128) {
-        const size_t lds = ((size_t)r * (r + 1) / 2 + r) * sizeof(double);
+        const size_t lds = ((size_t)r * (r | 1) + 2 * r) * sizeof(double);
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_solve_lds_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(posterior_solve_lds_kernel, dim3(1), dim3(64), lds, ctx->stream, (int)r, (int)rp, G, rhs, a, st);
+        hipLaunchKernelGGL(posterior_solve_lds_kernel, dim3(1), dim3(256), lds, ctx->stream, (int)r, (int)rp, G, rhs, a, st);
         return;
     }
     hipLaunchKernelGGL(posterior_solve_kernel, dim3(1), dim3(kDenseThreads), 0, ctx->stream, (int)r, (int)rp, G, rhs, work, a,
@@ -1044,6 +1358,17 @@ void launch_umeyama(gingr_ctx *ctx, const double *sums, int64_t M_total, const d
                     DevPose *pose, DevState *st) {
     hipLaunchKernelGGL(umeyama_kernel, dim3(1), dim3(64), 0, ctx->stream, sums, (double)M_total, c0[0], c0[1], c0[2],
                        (int)global_transform, pose, st);
+}
+
+void launch_post_solve(gingr_ctx *ctx, const PostSolveArgs &a) {
+    int width = 16;
+    while (width < a.rp) width <<= 1;
+    const int parts = kPostThreads / width > 0 ? kPostThreads / width : 1;
+    const size_t lds = (size_t)((6 + 18 + parts) * a.rp) * sizeof(double);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&post_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    hipLaunchKernelGGL(post_solve_kernel, dim3(1), dim3(kPostThreads), lds, ctx->stream, a);
 }
 
 void launch_commit(gingr_ctx *ctx, const CommitArgs &a) {

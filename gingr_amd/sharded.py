@@ -1,12 +1,14 @@
 """Row-sharded GiNGR update: one process per GPU, reference-point rows split across ranks.
 
 The N x M affinity matrix is sharded by reference (fit) rows; the target cloud and all r-sized state are replicated
-(SURVEY.md section 8e).  One iteration is the six phases of gingr_amd/csrc/fitter.hip; after phases 0..4 the partial
+(SURVEY.md section 8e).  One iteration is the three phases of gingr_amd/csrc/fitter.hip; after phases 0 and 1 the partial
 sums in exchange segment p are all-reduced (sum, float64) across ranks:
 
     segment 0  CPD column sums den_j (N doubles)          <- the column-sum exchange named in BASELINE.json north_star
     segment 1  weighted Gram (rp*rp) + rhs (rp) + 8 sigma^2 partial sums
-    segment 2  first projection (rp)      segment 3  Umeyama sums (24)      segment 4  second projection (rp)
+
+Everything after the posterior solve is replicated O(r^2) algebra on one-off moments of the basis (all-reduced once at
+model finalisation), so phase 2 needs no collective.
 
 The collective itself is plumbing: `torch.distributed.all_reduce` on a tensor that aliases the library's exchange
 buffer (backend "nccl" = RCCL over xGMI on the GPU box).  The r x r solve and the 3x3 SVD are replicated on every rank
@@ -36,7 +38,7 @@ def shard_rows(M: int, world: int, rank: int) -> Tuple[int, int]:
 
 def drive_update(run_phase: Callable[[int], None], all_reduce_segment: Callable[[int], None], world: int,
                  skip_segment0: bool = False) -> None:
-    """One iteration: phase p, then (for p < 5) the all-reduce of exchange segment p."""
+    """One iteration: phase p, then (for p < NUM_SEGMENTS) the all-reduce of exchange segment p."""
     for ph in range(NUM_PHASES):
         run_phase(ph)
         if world > 1 and ph < NUM_SEGMENTS and not (skip_segment0 and ph == 0):

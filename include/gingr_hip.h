@@ -115,9 +115,10 @@ int gingr_model_upload(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doub
                        const double *basis_colmajor, const double *variance, int64_t row_begin, int64_t row_end,
                        gingr_model **out);
 void gingr_model_destroy(gingr_model *model);
-/* Row-sharded models only: after upload every shard holds its partial Q^T Q (float64, count elements at dev_ptr);
- * the host all-reduces (sum) it across shards once, then calls gingr_model_finalize, which factors
- * Q^T Q / 1e-5 + I for the coefficient projections.  Single-shard uploads are finalized by gingr_model_upload. */
+/* Row-sharded models only: after upload every shard holds its partial one-off moments of the basis (Q^T Q and the
+ * per-coordinate cross moments; float64, count elements at dev_ptr); the host all-reduces (sum) them across shards once,
+ * then calls gingr_model_finalize, which factors Q^T Q / 1e-5 + I for the coefficient projections.
+ * Single-shard uploads are finalized by gingr_model_upload. */
 int gingr_model_gram_exchange(gingr_model *model, void **dev_ptr, int64_t *count);
 int gingr_model_finalize(gingr_ctx *ctx, gingr_model *model);
 int64_t gingr_model_num_points(const gingr_model *model); /* local rows */
@@ -191,18 +192,17 @@ int gingr_fitter_update_cpd_async(gingr_fitter *f, const gingr_cpd_params *p, in
 int gingr_fitter_update_icp_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations);
 
 /* ---- row-sharded update, host-driven exchange (multi-GPU) -----------------------------------------------------
- * One iteration = phases 0..GINGR_NUM_PHASES-1.  After phase p the host all-reduces (sum, float64) the exchange
- * segment p across shards (RCCL over xGMI via torch.distributed, or nothing for one shard), then runs phase p+1.
+ * One iteration = phases 0..GINGR_NUM_PHASES-1.  After phase p < GINGR_NUM_SEGMENTS the host all-reduces (sum, float64)
+ * exchange segment p across shards (RCCL over xGMI via torch.distributed, or nothing for one shard), then runs phase p+1.
  * The exchange buffer is device memory owned by the library; gingr_fitter_exchange gives its address and the
  * [offset, count) of every segment in float64 elements.
- *   segment 0: den partial column sums [N]                      (the CPD column-sum exchange; empty for ICP)
- *   segment 1: weighted Gram [rp*rp] + rhs [rp] + scalars [8]
- *   segment 2: first projection Q^T d [rp]
- *   segment 3: Umeyama partial sums [24]
- *   segment 4: second projection [rp]
+ *   phase 0 -> segment 0: den partial column sums [N]           (the CPD column-sum exchange; unused for ICP)
+ *   phase 1 -> segment 1: weighted Gram [rp*rp] + rhs [rp] + sigma2 sums [8]
+ *   phase 2: replicated r x r algebra (posterior solve, projections and Umeyama from the model's one-off moments),
+ *            state commit, new fit of the local rows -- nothing to exchange.
  */
-#define GINGR_NUM_PHASES 6
-#define GINGR_NUM_SEGMENTS 5
+#define GINGR_NUM_PHASES 3
+#define GINGR_NUM_SEGMENTS 2
 int gingr_fitter_exchange(gingr_fitter *f, void **dev_ptr, int64_t offsets[GINGR_NUM_SEGMENTS],
                           int64_t counts[GINGR_NUM_SEGMENTS]);
 int gingr_fitter_cpd_phase_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t phase);

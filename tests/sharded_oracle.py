@@ -1,9 +1,10 @@
-"""Oracle-backed restatement of the six update phases for ONE row shard (test infrastructure).
+"""Oracle-backed restatement of the three update phases for ONE row shard (test infrastructure).
 
 Mirrors gingr_amd/csrc/fitter.hip phase by phase with numpy so that the sharding algebra -- which partial sums are
 exchanged, in which order, and what is replicated -- can be exercised across real processes (gloo) without a GPU.
-Segment layout = gingr_fitter_exchange: [den N] [G rp*rp | rhs rp | 8 scalars] [proj rp] [umeyama 24] [proj rp],
-with rp = r here (no MFMA padding needed on the CPU).
+Segment layout = gingr_fitter_exchange: [den N] [G rp*rp | rhs rp | 8 scalars], with rp = r here (no MFMA padding on
+the CPU).  Phase 2 is the "moment form": everything after the posterior solve is computed from one-off moments of the
+basis (summed over all shards once, like gingr_model_gram_exchange + gingr_model_finalize) with no further exchange.
 """
 import numpy as np
 
@@ -19,21 +20,36 @@ class OracleShard:
         self.b, self.e = begin, end
         self.gt, self.step, self.w, self.lam = global_transform, step_length, w, lam
         r, N = model.rank, self.x.shape[0]
-        self.counts = [N, r * r + r + 8, r, 24, r]
-        self.offsets = list(np.cumsum([0] + self.counts[:-1]))
+        self.counts = [N, r * r + r + 8]
+        self.offsets = [0, N]
         self.xch = np.zeros(sum(self.counts))
         rows = slice(3 * begin, 3 * end)
         self.Q0 = model.U[rows] * np.sqrt(model.lam)[None, :]         # local rows of Q0
         self.ref, self.mean = model.ref[begin:end], model.mean[begin:end]
         self.c0 = model.ref.mean(0)
-        self.S_local = self.Q0.T @ self.Q0                             # all-reduced once -> Binv
+        # local moments (MomentLayout of gp.h): S_tot, S[d][e], V[d][e], W[d]
+        Q3 = self.Q0.reshape(-1, 3, r)
+        pt = self.ref + self.mean - self.c0
+        self.mom_local = np.concatenate([
+            (self.Q0.T @ self.Q0).reshape(-1),
+            np.einsum("idk,iel->dekl", Q3, Q3).reshape(-1),
+            np.einsum("idk,ie->dek", Q3, pt).reshape(-1),
+            Q3.sum(0).reshape(-1)])
+        pt_all = model.ref + model.mean - self.c0                       # host moments use the FULL model
+        self.Pp, self.Ps = pt_all.T @ pt_all, pt_all.sum(0)
         self.Binv = None
 
     def seg(self, k):
         return self.xch[self.offsets[k]: self.offsets[k] + self.counts[k]]
 
-    def finalize(self, S_total):
-        self.Binv = np.linalg.inv(S_total / EPS + np.eye(self.m.rank))
+    def finalize(self, mom_total):
+        r = self.m.rank
+        o = 0
+        self.S_tot = mom_total[o:o + r * r].reshape(r, r); o += r * r
+        self.S = mom_total[o:o + 9 * r * r].reshape(3, 3, r, r); o += 9 * r * r
+        self.V = mom_total[o:o + 9 * r].reshape(3, 3, r); o += 9 * r
+        self.W = mom_total[o:o + 3 * r].reshape(3, r)
+        self.Binv = np.linalg.inv(self.S_tot / EPS + np.eye(r))
 
     def set_state(self, st: go.State):
         self.st = st
@@ -65,44 +81,43 @@ class OracleShard:
         elif ph == 2:
             s = self.seg(1)
             G, rhs = s[: r * r].reshape(r, r), s[r * r: r * r + r]
-            self.a = np.linalg.solve(np.eye(r) + G, rhs)
-            self.seg(2)[:] = self.Q0.T @ (self.Q0 @ self.a)
-        elif ph == 3:
-            alpha1 = self.Binv @ (self.seg(2) / EPS)
-            self.alpha_c = st.alpha + (alpha1 - st.alpha) * self.step
-            inst = self.ref + self.mean + (self.Q0 @ self.alpha_c).reshape(-1, 3)
-            self.newshape = (inst - st.center) @ R.T + st.center + st.translation
-            cur0 = self.ref + self.mean + (self.Q0 @ st.alpha).reshape(-1, 3)
-            xt, yt = cur0 - self.c0, self.newshape - self.c0
-            s = self.seg(3)
-            s[:] = 0
-            s[0:3], s[3:6] = xt.sum(0), yt.sum(0)
-            s[6:15] = (yt.T @ xt).reshape(-1)
-            s[15] = (xt ** 2).sum()
-        elif ph == 4:
-            s, n = self.seg(3), float(M_total)
+            a = np.linalg.solve(np.eye(r) + G, rhs)
+            alpha = st.alpha
+            alpha1 = self.Binv @ (self.S_tot @ a) / EPS                      # Q^T (Q a) = S_tot a
+            ac = alpha + (alpha1 - alpha) * self.step
+            n = float(M_total)
+            # u~ = p~ + Q0 alpha, v~ = p~ + Q0 alpha_c, newshape - c0 = R v~ + g~
+            su = self.Ps + self.W @ alpha
+            sv = self.Ps + self.W @ ac
+            Mvu = self.Pp + np.einsum("bdk,k->db", self.V, alpha) + np.einsum("dbk,k->db", self.V, ac) \
+                + np.einsum("k,dbkl,l->db", ac, self.S, alpha)
+            gt = R @ (self.c0 - st.center) + st.center + st.translation - self.c0
+            sy = R @ sv + n * gt
+            Syx = R @ Mvu + np.outer(gt, su)
+            sxx = float(np.trace(self.Pp) + 2 * sum(self.V[d, d] @ alpha for d in range(3))
+                        + sum(alpha @ self.S[d, d] @ alpha for d in range(3)))
             if self.gt == go.NO_TRANSFORMS:
-                self.R2, self.t2, self.s2 = np.eye(3), np.zeros(3), 1.0
+                R2, t2, s2 = np.eye(3), np.zeros(3), 1.0
             else:
-                mux, muy = s[0:3] / n, s[3:6] / n
-                Sxy = s[6:15].reshape(3, 3) / n - np.outer(muy, mux)
-                sig2x = s[15] / n - mux @ mux
+                mux, muy = su / n, sy / n
+                Sxy = Syx / n - np.outer(muy, mux)
+                sig2x = sxx / n - mux @ mux
                 U, D, Vt = np.linalg.svd(Sxy)
-                S = np.eye(3)
+                Sg = np.eye(3)
                 if np.linalg.det(Sxy) < 0:
-                    S[2, 2] = -1
-                Rr = U @ S @ Vt
-                c = float(np.trace(np.diag(D) @ S) / sig2x) if self.gt == go.SIMILARITY_TRANSFORMS else 1.0
-                self.t2 = (muy + self.c0) - c * (Rr @ (mux + self.c0))
-                self.R2 = go.euler_to_rot(*go.rot_to_euler(Rr))
-                self.s2 = c
-            e = (self.newshape - self.t2) @ self.R2 - self.ref - self.mean
-            self.seg(4)[:] = self.Q0.T @ e.reshape(-1)
-        elif ph == 5:
-            alpha = self.Binv @ (self.seg(4) / EPS)
-            sc = self.seg(1)[r * r + r:]
+                    Sg[2, 2] = -1
+                Rr = U @ Sg @ Vt
+                s2 = float(np.trace(np.diag(D) @ Sg) / sig2x) if self.gt == go.SIMILARITY_TRANSFORMS else 1.0
+                t2 = (muy + self.c0) - s2 * (Rr @ (mux + self.c0))
+                R2 = go.euler_to_rot(*go.rot_to_euler(Rr))
+            # e_i = R2^T (newshape_i - t2) - p_i = (B - I) p~_i + B Q0_i alpha_c + h
+            B = R2.T @ R
+            h = R2.T @ (gt + self.c0 - t2) - self.c0
+            proj = np.einsum("de,dek->k", B - np.eye(3), self.V) + np.einsum("de,dekl,l->k", B, self.S, ac) + h @ self.W
+            alpha_new = self.Binv @ proj / EPS
+            sc = s[r * r + r:]
             s2n = (sc[1] - 2 * sc[2] + sc[3]) / (sc[0] * 3.0)
-            new = go.State(alpha=alpha, euler=go.rot_to_euler(self.R2), center=np.zeros(3), translation=self.t2, scale=self.s2,
+            new = go.State(alpha=alpha_new, euler=go.rot_to_euler(R2), center=np.zeros(3), translation=t2, scale=s2,
                            sigma2=float(s2n), fit=np.zeros((m.M, 3)), iteration=st.iteration + 1,
                            global_transformation=st.global_transformation, step_length=st.step_length)
             self.set_state(new)

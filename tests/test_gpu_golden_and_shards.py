@@ -172,9 +172,10 @@ def test_single_rank_nccl_process_group_path(ctx):
             from gingr_amd.sharded import as_torch
             import ctypes
             from ctypes import c_int64, c_void_p
-            p = c_void_p(); offs = (c_int64 * 5)(); cnts = (c_int64 * 5)()
+            from gingr_amd.sharded import NUM_SEGMENTS
+            p = c_void_p(); offs = (c_int64 * NUM_SEGMENTS)(); cnts = (c_int64 * NUM_SEGMENTS)()
             assert f._lib.gingr_fitter_exchange(f.handle, ctypes.byref(p), offs, cnts) == 0
-            f.xch = as_torch(p.value, offs[4] + cnts[4], 0)
+            f.xch = as_torch(p.value, offs[NUM_SEGMENTS - 1] + cnts[NUM_SEGMENTS - 1], 0)
             s2 = c2.cpd_initial_sigma2(mo.ref, target)
             f.set_state(np.zeros(mo.rank), s2)
             f.update_cpd(0.0, 1.0, 2)

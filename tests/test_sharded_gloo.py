@@ -1,6 +1,6 @@
 """The N > 1 path on CPU: world_size-2 `gloo` run of the row-sharded update.
 
-Each rank owns half of the reference rows, runs the six phases (oracle-backed restatement of the native phases, same
+Each rank owns half of the reference rows, runs the three phases (oracle-backed restatement of the native phases, same
 exchange-segment layout) and all-reduces every segment with torch.distributed -- through the SAME driver loop
 (gingr_amd.sharded.drive_update) and the SAME row partition (shard_rows) that bench.py uses with RCCL on the GPUs.
 The result must equal the unsharded oracle update.
@@ -36,9 +36,9 @@ def _worker(rank, world, port, transform, out_dir):
     target = (mo.instance(rng.normal(0, 1, mo.rank)) @ go.euler_to_rot(0.1, -0.05, 0.08).T + 1.5)[:90] + rng.normal(0, 0.2, (90, 3))
     b, e = shard_rows(mo.M, world, rank)
     sh = OracleShard(mo, target, b, e, global_transform=transform, w=0.1)
-    S = torch.from_numpy(sh.S_local.copy())
-    dist.all_reduce(S)
-    sh.finalize(S.numpy())
+    mom = torch.from_numpy(sh.mom_local.copy())     # gingr_model_gram_exchange + all-reduce + gingr_model_finalize
+    dist.all_reduce(mom)
+    sh.finalize(mom.numpy())
     st = go.initial_state(mo, go.cpd_initial_sigma2(mo.ref + mo.mean, target), global_transformation=transform)
     sh.set_state(st)
 
