@@ -23,7 +23,7 @@ struct gingr_fitter {
     int32_t *nn_idx = nullptr;
     double *nn_d2 = nullptr;
     double *weight = nullptr, *evec = nullptr, *newshape = nullptr;
-    double *alpha = nullptr, *acoef = nullptr, *alpha_c = nullptr;
+    double *alpha = nullptr, *acoef = nullptr, *alpha_c = nullptr, *zbuf = nullptr;
     DevState *st = nullptr;
     DevPose *pose = nullptr;
     gingr_state_scalars *hs_dev = nullptr;
@@ -113,6 +113,15 @@ int model_finalize_impl(gingr_ctx *ctx, gingr_model *m) {
     HIP_TRY(ctx, hipMemcpyAsync(&err, flag.p, sizeof(err), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (err) return gingr_set_error(ctx, GINGR_ERR_NOT_SPD, "model finalize: Q^T Q / 1e-5 + I is not positive definite");
+    // constant products of the moment form: C = Binv S_tot / eps, T[d][e] = S[d][e] C
+    const MomentLayout ml{m->rp};
+    const int64_t rr = (int64_t)m->rp * m->rp;
+    launch_small_gemm(ctx, m->r, m->rp, m->Binv, m->mom + ml.stot(), 1.0 / GINGR_COEFF_NOISE, m->cmat);
+    for (int d = 0; d < 3; ++d)
+        for (int e = 0; e < 3; ++e)
+            launch_small_gemm(ctx, m->r, m->rp, m->mom + ml.S(d, e), m->cmat, 1.0, m->cmat + (1 + d * 3 + e) * rr);
+    GINGR_TRY(check_launch(ctx));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     m->finalized = true;
     return GINGR_OK;
 }
@@ -161,7 +170,8 @@ int gingr_model_upload(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doub
     };
     if ((rc = dev_alloc(ctx, &m->Q0, (size_t)3 * M * m->rp)) || (rc = dev_alloc(ctx, &m->ref, (size_t)3 * M)) ||
         (rc = dev_alloc(ctx, &m->mean, (size_t)3 * M)) || (rc = dev_alloc(ctx, &m->mom, (size_t)MomentLayout{m->rp}.total())) ||
-        (rc = dev_alloc(ctx, &m->Binv, (size_t)m->rp * m->rp)))
+        (rc = dev_alloc(ctx, &m->Binv, (size_t)m->rp * m->rp)) ||
+        (rc = dev_alloc(ctx, &m->cmat, (size_t)10 * m->rp * m->rp)))
         return fail(rc);
     if (stage.alloc((size_t)3 * M * rank * sizeof(double)) != hipSuccess || var.alloc(rank * sizeof(double)) != hipSuccess ||
         aos.alloc((size_t)3 * M * sizeof(double)) != hipSuccess)
@@ -243,6 +253,7 @@ void gingr_model_destroy(gingr_model *m) {
     dev_free(m->mean);
     dev_free(m->mom);
     dev_free(m->Binv);
+    dev_free(m->cmat);
     delete m;
 }
 
@@ -280,7 +291,7 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
         (rc = dev_alloc(ctx, &f->nn_d2, (size_t)M)) || (rc = dev_alloc(ctx, &f->weight, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->evec, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->newshape, (size_t)3 * M)) ||
         (rc = dev_alloc(ctx, &f->alpha, (size_t)rp)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
-        (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->st, 1)) ||
+        (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->zbuf, (size_t)19 * rp)) || (rc = dev_alloc(ctx, &f->st, 1)) ||
         (rc = dev_alloc(ctx, &f->pose, 1)) || (rc = dev_alloc(ctx, &f->hs_dev, 1)) ||
         (rc = dev_alloc(ctx, &f->scalars, 8)) || (rc = dev_alloc(ctx, &f->part, GINGR_SCALAR_PART)) || (rc = dev_alloc(ctx, &f->absmax, GINGR_AUX)) || (rc = dev_alloc(ctx, &f->work, (size_t)rp * rp)) ||
         (rc = dev_alloc(ctx, &f->lm_mask, (size_t)M))) {
@@ -314,6 +325,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->alpha);
     dev_free(f->acoef);
     dev_free(f->alpha_c);
+    dev_free(f->zbuf);
     dev_free(f->st);
     dev_free(f->pose);
     dev_free(f->hs_dev);
@@ -582,13 +594,14 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
         }
         case 2: {
             launch_posterior_solve(ctx, r, rp, G, rhs, f->work, f->acoef, f->st);
+            launch_post_matvecs(ctx, m, f->alpha, f->acoef, f->zbuf);
             PostSolveArgs a;
             memset(&a, 0, sizeof(a));
             a.r = r;
             a.rp = rp;
             a.mom = m->mom;
             a.Binv = m->Binv;
-            a.a = f->acoef;
+            a.zbuf = f->zbuf;
             a.alpha = f->alpha;
             a.scalars = sc8;
             a.is_icp = icp ? 1 : 0;

@@ -57,6 +57,8 @@ struct gingr_model {
     double *mean = nullptr;   // SoA [3][M]
     double *mom = nullptr;    // MomentLayout: local sums until finalize (the exchange buffer of the one-off all-reduce)
     double *Binv = nullptr;   // [rp*rp] (S_tot/eps + I)^-1, valid after finalize
+    double *cmat = nullptr;   // [10][rp*rp], valid after finalize: [0] C = Binv S_tot / eps (alpha_1 = C a),
+                              // [1 + 3d + e] T[d][e] = S[d][e] C  (S[d][e] alpha_1 = T[d][e] a)
     double c0[3] = {0, 0, 0};  // centroid of the FULL reference: fixed centring point of the Umeyama sums
     double Pp[9] = {0};        // sum_i p~_i p~_i^T over the FULL model (host, identical on every shard)
     double Ps[3] = {0};        // sum_i p~_i
@@ -154,7 +156,7 @@ struct PostSolveArgs {
     int32_t r, rp;
     const double *mom;
     const double *Binv;
-    const double *a;        // posterior regression coefficients
+    const double *zbuf;     // [19][rp] from launch_post_matvecs: [0..8] S[d][e] alpha, [9..17] T[d][e] a, [18] alpha_1 = C a
     double *alpha;          // in/out: shape coefficients of the state
     const double *scalars;  // reduced {Np, xPx, trPXY, yPy, ...} (CPD) or nullptr
     int32_t is_icp;
@@ -166,6 +168,10 @@ struct PostSolveArgs {
     DevState *state;
 };
 void launch_post_solve(gingr_ctx *ctx, const PostSolveArgs &a);
+// the 19 independent r x r mat-vecs the fused kernel consumes, one workgroup each (they only depend on alpha and a)
+void launch_post_matvecs(gingr_ctx *ctx, const gingr_model *m, const double *alpha, const double *a, double *zbuf);
+// out = scale * A B (r x r, leading dimension rp); one-off products at model finalisation
+void launch_small_gemm(gingr_ctx *ctx, int32_t r, int32_t rp, const double *A, const double *B, double scale, double *out);
 
 // basis packing: stage is column-major [r][3M] (local rows), out Q0 [3M][rp]
 void launch_pack_basis(gingr_ctx *ctx, const double *stage_colmajor, const double *variance_dev, int64_t M, int32_t r,

@@ -295,29 +295,29 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ Q0
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = v4f64{0, 0, 0, 0};
-    bool va[4], vb[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        va[t] = pa * 64 + 16 * t < rp;
-        vb[t] = pb * 64 + 16 * t < rp;
-    }
+    // Column interleave: tile t of the patch holds the columns {p*64 + 4*lane16 + t}, so the four fragment values a lane
+    // needs per side are 32 contiguous bytes (two 16-byte loads) instead of four 8-byte loads 128 bytes apart.
+    const bool vla = pa * 64 + 4 * cl < rp, vlb = pb * 64 + 4 * cl < rp;  // rp is a multiple of 16: all-or-nothing per lane
     const bool diag = pa == pb && offA == offB;
+    typedef double d4 __attribute__((ext_vector_type(4)));
     double ca[4], cb[4];
     auto load = [&](int64_t row, double fa[4], double fb[4]) {
         const int64_t rr = row + kq;
         const bool valid = rr < r1;
         const int64_t rc = valid ? rr : r0;
         const double wv = valid ? (weight ? weight[row_stride == 1 ? rc / 3 : rc] : 1.0) : 0.0;
-        const double *baseB = Q0 + (rc * row_stride + offB) * rp + cl;
+        d4 vb4 = d4{0, 0, 0, 0};
+        if (vlb && valid) vb4 = *reinterpret_cast<const d4 *>(Q0 + (rc * row_stride + offB) * rp + pb * 64 + 4 * cl);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) fb[t] = (vb[t] && valid) ? baseB[pb * 64 + 16 * t] : 0.0;
+        for (int t = 0; t < 4; ++t) fb[t] = vb4[t];
         if (diag) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) fa[t] = fb[t] * wv;
         } else {
-            const double *baseA = Q0 + (rc * row_stride + offA) * rp + cl;
+            d4 va4 = d4{0, 0, 0, 0};
+            if (vla && valid) va4 = *reinterpret_cast<const d4 *>(Q0 + (rc * row_stride + offA) * rp + pa * 64 + 4 * cl);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) fa[t] = va[t] ? baseA[pa * 64 + 16 * t] * wv : 0.0;
+            for (int t = 0; t < 4; ++t) fa[t] = va4[t] * wv;
         }
     };
     int64_t row = r0 + 4 * wave;
@@ -328,8 +328,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ Q0
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (va[i] && vb[j]) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[i], cb[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[i], cb[j], acc[i][j], 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             ca[t] = na[t];
@@ -359,18 +358,18 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ Q0
     }
     if (wave != 0) return;
     double *out = partial + (int64_t)blockIdx.x * rp * rp;
+    // D[i_row][j_col]: i_row = kq + 4*reg is the A-side lane index, j_col = cl the B-side lane index
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (va[i] && vb[j]) {
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int gi = pa * 64 + 16 * i + kq + 4 * reg;
-                    const int gj = pb * 64 + 16 * j + cl;
-                    out[(int64_t)gi * rp + gj] = acc[i][j][reg];
-                }
+            for (int reg = 0; reg < 4; ++reg) {
+                const int gi = pa * 64 + 4 * (kq + 4 * reg) + i;
+                const int gj = pb * 64 + 4 * cl + j;
+                if (gi < rp && gj < rp) out[(int64_t)gi * rp + gj] = acc[i][j][reg];
             }
+        }
 }
 
 // G[i][j] = sum over slabs (fixed tree): one 64-thread group per output element, 4 elements per workgroup.
@@ -995,6 +994,40 @@ __device__ __forceinline__ double wave_dot(const double *x, const double *y, int
     return s;
 }
 
+// one-off r x r products at finalisation
+__global__ void small_gemm_kernel(int r, int rp, const double *__restrict__ A, const double *__restrict__ B, double scale,
+                                  double *__restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rp * rp) return;
+    const int i = idx / rp, j = idx - i * rp;
+    double s = 0.0;
+    if (i < r && j < r)
+        for (int k = 0; k < r; ++k) s = __builtin_fma(A[i * rp + k], B[k * rp + j], s);
+    out[idx] = s * scale;
+}
+
+// zbuf[b] = M_b x_b, b = blockIdx.x: b < 9: S[d][e] alpha; 9 <= b < 18: T[d][e] a; b == 18: C a.  16 lanes per output row.
+__global__ __launch_bounds__(256) void post_matvecs_kernel(int r, int rp, const double *__restrict__ mom,
+                                                           const double *__restrict__ cmat, const double *__restrict__ alpha,
+                                                           const double *__restrict__ a, double *__restrict__ zbuf) {
+    __shared__ double x[512];
+    const int b = blockIdx.x;
+    const MomentLayout ml{rp};
+    const double *Mat = b < 9 ? mom + ml.S(b / 3, b % 3) : (b < 18 ? cmat + (int64_t)(1 + (b - 9)) * rp * rp : cmat);
+    const double *src = b < 9 ? alpha : a;
+    for (int k = threadIdx.x; k < rp; k += 256) x[k] = k < r ? src[k] : 0.0;
+    __syncthreads();
+    const int lane16 = threadIdx.x & 15;
+    for (int i0 = 0; i0 < rp; i0 += 16) {
+        const int i = i0 + (threadIdx.x >> 4);
+        double s = 0.0;
+        if (i < r)
+            for (int j = lane16; j < r; j += 16) s = __builtin_fma(Mat[(int64_t)i * rp + j], x[j], s);
+        s = group16_sum(s);
+        if (lane16 == 0 && i < rp) zbuf[(int64_t)b * rp + i] = i < r ? s : 0.0;
+    }
+}
+
 constexpr int kPostThreads = 1024;
 
 __global__ __launch_bounds__(kPostThreads) void post_solve_kernel(PostSolveArgs A) {
@@ -1003,7 +1036,7 @@ __global__ __launch_bounds__(kPostThreads) void post_solve_kernel(PostSolveArgs 
     const MomentLayout ml{rp};
     DevState *st = A.state;
     if (st->status == GINGR_FIT_MODEL_FLEXIBILITY_ERROR) return;  // a failed fit stays as it is (run stops, :149-157)
-    double *va = sm, *valpha = va + rp, *vt = valpha + rp, *vac = vt + rp, *proj = vac + rp, *anew = proj + rp;
+    double *valpha = sm, *vac = valpha + rp, *proj = vac + rp, *anew = proj + rp;
     double *za = anew + rp;       // [9][rp]  S[d][e] alpha
     double *zc = za + 9 * rp;     // [9][rp]  S[d][e] alpha_c
     double *scratch = zc + 9 * rp;
@@ -1011,27 +1044,22 @@ __global__ __launch_bounds__(kPostThreads) void post_solve_kernel(PostSolveArgs 
     __shared__ DevPose P;
     __shared__ double Bm[9], BmI[9], hv[3];
     __shared__ int bad;
-    for (int k = tid; k < rp; k += kPostThreads) {
-        va[k] = k < r ? A.a[k] : 0.0;
-        valpha[k] = k < r ? A.alpha[k] : 0.0;
-    }
+    for (int k = tid; k < rp; k += kPostThreads) valpha[k] = k < r ? A.alpha[k] : 0.0;
     if (tid == 0) bad = 0;
     __syncthreads();
-    // alpha_1 = Binv (S_tot a) / eps: coefficients of the posterior mean (transformedModelInit.coefficients, :212-216);
-    // Q^T (Q a) = S_tot a, and the R / R^T round trip of the displacement cancels
-    block_matvec_T(A.mom + ml.stot(), va, vt, r, rp, scratch);
-    block_matvec_T(A.Binv, vt, vac, r, rp, scratch);
+    // alpha_1 = Binv (S_tot a) / eps = C a: coefficients of the posterior mean (transformedModelInit.coefficients,
+    // :212-216; Q^T (Q a) = S_tot a and the R / R^T round trip of the displacement cancels); then the step blend (:218-220)
     for (int k = tid; k < rp; k += kPostThreads) {
-        const double a1 = vac[k] / GINGR_COEFF_NOISE;
-        vac[k] = k < r ? valpha[k] + (a1 - valpha[k]) * A.step : 0.0;  // :218-220
+        const double a1 = A.zbuf[18 * rp + k];
+        vac[k] = k < r ? valpha[k] + (a1 - valpha[k]) * A.step : 0.0;
+    }
+    // z_alpha = S[d][e] alpha; z_c = S[d][e] alpha_c = (1 - step) S[d][e] alpha + step T[d][e] a
+    for (int q = tid; q < 9 * rp; q += kPostThreads) {
+        const double zal = A.zbuf[q], zt = A.zbuf[9 * rp + q];
+        za[q] = zal;
+        zc[q] = (1.0 - A.step) * zal + A.step * zt;
     }
     __syncthreads();
-    // z = S[d][e] alpha and S[d][e] alpha_c; (S[d][e] x)[k] = sum_j S[e][d][j][k] x[j]
-    for (int d = 0; d < 3; ++d)
-        for (int e = 0; e < 3; ++e) {
-            block_matvec_T(A.mom + ml.S(e, d), valpha, za + (d * 3 + e) * rp, r, rp, scratch);
-            block_matvec_T(A.mom + ml.S(e, d), vac, zc + (d * 3 + e) * rp, r, rp, scratch);
-        }
     // 36 dot products, one wave each: [0..2] W[d].alpha, [3..5] W[d].alpha_c, [6..14] V[b][d].alpha (index d*3+b),
     // [15..23] V[d][b].alpha_c, [24..32] alpha_c.za[d][b], [33..35] alpha.za[d][d]
     for (int t = tid >> 6; t < 36; t += kPostThreads / 64) {
@@ -1364,11 +1392,21 @@ void launch_post_solve(gingr_ctx *ctx, const PostSolveArgs &a) {
     int width = 16;
     while (width < a.rp) width <<= 1;
     const int parts = kPostThreads / width > 0 ? kPostThreads / width : 1;
-    const size_t lds = (size_t)((6 + 18 + parts) * a.rp) * sizeof(double);
+    const size_t lds = (size_t)((4 + 18 + parts) * a.rp) * sizeof(double);
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&post_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
     hipLaunchKernelGGL(post_solve_kernel, dim3(1), dim3(kPostThreads), lds, ctx->stream, a);
+}
+
+void launch_post_matvecs(gingr_ctx *ctx, const gingr_model *m, const double *alpha, const double *a, double *zbuf) {
+    hipLaunchKernelGGL(post_matvecs_kernel, dim3(19), dim3(256), 0, ctx->stream, (int)m->r, (int)m->rp, m->mom, m->cmat, alpha, a,
+                       zbuf);
+}
+
+void launch_small_gemm(gingr_ctx *ctx, int32_t r, int32_t rp, const double *A, const double *B, double scale, double *out) {
+    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 256)), dim3(256), 0, ctx->stream, (int)r,
+                       (int)rp, A, B, scale, out);
 }
 
 void launch_commit(gingr_ctx *ctx, const CommitArgs &a) {
