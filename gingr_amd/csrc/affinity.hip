@@ -504,7 +504,10 @@ __global__ void soa_to_aos_kernel(const double *__restrict__ soa, int64_t n, dou
     aos[3 * i + 2] = soa[2 * n + i];
 }
 
-constexpr int kPT = 2;            // points per thread in both CPD passes
+#ifndef GINGR_PT
+#define GINGR_PT 2
+#endif
+constexpr int kPT = GINGR_PT;     // points per thread in both CPD passes
 constexpr int kTargetBlocks = 2048;  // ~8 workgroups per CU
 
 // split `stream_len` into chunks so that block_cols * nchunks ~ kTargetBlocks; chunk length is a multiple of kTile
