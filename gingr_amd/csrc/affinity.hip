@@ -505,7 +505,7 @@ __global__ void soa_to_aos_kernel(const double *__restrict__ soa, int64_t n, dou
 }
 
 #ifndef GINGR_PT
-#define GINGR_PT 2
+#define GINGR_PT 4
 #endif
 constexpr int kPT = GINGR_PT;     // points per thread in both CPD passes
 constexpr int kTargetBlocks = 2048;  // ~8 workgroups per CU
