@@ -106,6 +106,11 @@ def main():
     ap.add_argument("--w", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=3)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="testing: run the N>1 code path (process group + phase/all-reduce driver) with the given world")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="timing experiment on ONE GPU: own only rows of rank 0 of a world of this size (results are not a "
+                         "valid registration: the other shards' partial sums are missing); shows the per-rank cost at N GPUs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,9 +127,16 @@ def main():
     from gingr_amd.sharded import ShardedFitter
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist or args.emulate_world > 1
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:       # stand-alone test modes only; torchrun always provides it
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
 
     M = N = args.points
     y, x = synth_clouds(M)
@@ -139,8 +151,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
     with torch.cuda.stream(stream):
-        fitter = ShardedFitter(ctx, model, x, rank=rank, world=world, all_reduce=all_reduce if world > 1 else None,
+        shard_world = args.emulate_world if args.emulate_world > 1 else world
+        fitter = ShardedFitter(ctx, model, x, rank=rank, world=shard_world, all_reduce=all_reduce if use_dist else None,
                                global_transform=ga.GlobalTranformationType.RigidTransforms, step_length=1.0)
+        if args.force_dist and shard_world == 1:      # exercise the phase + all-reduce driver with one rank
+            from gingr_amd.sharded import as_torch, NUM_SEGMENTS
+            import ctypes
+            from ctypes import c_int64, c_void_p
+            pp = c_void_p(); offs = (c_int64 * NUM_SEGMENTS)(); cnts = (c_int64 * NUM_SEGMENTS)()
+            fitter._lib.gingr_fitter_exchange(fitter.handle, ctypes.byref(pp), offs, cnts)
+            fitter.xch = as_torch(pp.value, offs[NUM_SEGMENTS - 1] + cnts[NUM_SEGMENTS - 1], local_rank)
+            fitter.world = 2
         sigma2_0 = ctx.cpd_initial_sigma2(y, x)      # CpdRegistrationState.apply, CPD.scala:92-102 (mean == reference here)
 
         def reset():
@@ -148,7 +169,7 @@ def main():
 
         def sync():
             torch.cuda.synchronize(local_rank)
-            if world > 1:
+            if use_dist:
                 dist.barrier()
                 torch.cuda.synchronize(local_rank)
 
@@ -159,12 +180,13 @@ def main():
         fitter.update_cpd(args.w, 1.0, args.steps)
         sync()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         alpha, sc, fit = fitter.get_state()
-        ok = bool(np.all(np.isfinite(fit)) and sc.status == 0 and sc.iteration == args.warmup + args.steps)
+        ok = bool(np.all(np.isfinite(fit)) and sc.status == 0 and sc.iteration == args.warmup + args.steps
+                  and args.emulate_world <= 1)
 
         # ---- live roofline of the dominant kernels (HIP events on the kernels' stream, extra iterations)
         roof = None
@@ -192,6 +214,18 @@ def main():
             kernels.append({"kernel": "gram_kernel", "avg_ms": avg, "launches": n, "bound": "mfma",
                             "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / F64_MFMA_PEAK_TFLOPS})
+        ms, n = ctx.timing_read(4)
+        if n:
+            avg = ms / n
+            rp = (args.rank + 15) // 16 * 16
+            gbs = 24.0 * m_loc * rp / (avg * 1e-3) / 1e9
+            kernels.append({"kernel": "sweep_kernel", "avg_ms": avg, "launches": n, "bound": "hbm", "achieved": gbs,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                            "algorithmic_bytes": 24.0 * m_loc * rp,
+                            "traffic": "FETCH_SIZE x2 (gfx950 correction) = 134 MB at 50k, r=100: profiles/r01_pmc_traffic.md"})
+        ms, n = ctx.timing_read(5)
+        if n:
+            kernels.append({"kernel": "posterior_solve_lds_kernel", "avg_ms": ms / n, "launches": n, "bound": "latency"})
         ms, n = ctx.timing_read(3)
         upd_ms = ms / n if n else None
         ctx.timing_enable(False)
@@ -203,7 +237,7 @@ def main():
                             "HBM and MFMA are not the binding resource"}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.emulate_world:
         cpu = cpu_baseline(y, x, sigma2_0, args.w)
 
     if rank == 0:
@@ -223,7 +257,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"CPD update, synthetic Gaussian clouds {M}<->{N}, GPMM rank {args.rank}, w={args.w}, "
                                    f"rigid global transform, sigma2_0={sigma2_0:.3f}",
-                       "points": M, "targets": N, "rank": args.rank, "parallelism": f"row-shard x{world}"},
+                       "points": M, "targets": N, "rank": args.rank, "parallelism": f"row-shard x{world}",
+                       "emulated_world": args.emulate_world or None},
             "valid": ok,
             "sigma2_after_timed_steps": float(sc.sigma2),
             "update_ms_device": upd_ms,
@@ -233,11 +268,20 @@ def main():
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
-        print(json.dumps(out))
     fitter.close()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio; flush it first so that the JSON is the LAST line on stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+    return
 
 
 if __name__ == "__main__":

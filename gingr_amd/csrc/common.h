@@ -12,7 +12,7 @@
 
 #include "../../include/gingr_hip.h"
 
-#define GINGR_TIMERS 4
+#define GINGR_TIMERS 6
 
 struct gingr_ctx {
     int device = 0;
@@ -27,8 +27,8 @@ struct gingr_ctx {
     };
     std::vector<Span> spans;     // recorded, not yet resolved
     std::vector<hipEvent_t> pool;  // recycled events
-    double t_ms[GINGR_TIMERS] = {0, 0, 0, 0};
-    int64_t t_n[GINGR_TIMERS] = {0, 0, 0, 0};
+    double t_ms[GINGR_TIMERS] = {0, 0, 0, 0, 0, 0};
+    int64_t t_n[GINGR_TIMERS] = {0, 0, 0, 0, 0, 0};
     // all-pairs formulation: 0 = difference-based VALU kernels (affinity.hip, default), 1 = exponent arguments from the
     // f64 matrix pipe (affinity_mfma.hip).  Measured on MI355X (profiles/r01_ubench_mfma_valu_overlap.txt): f64 MFMA and
     // f64 VALU do not overlap (they share the DP hardware), so the MFMA form is not faster.  GINGR_AFFINITY=valu|mfma.
@@ -81,6 +81,7 @@ struct TimerScope {
     int which;
     hipEvent_t a = nullptr, b = nullptr;
     TimerScope(gingr_ctx *c, int w);
+    void stop();
     ~TimerScope();
 };
 

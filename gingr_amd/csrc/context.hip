@@ -31,11 +31,14 @@ TimerScope::TimerScope(gingr_ctx *c, int w) : ctx(c), which(w) {
     (void)hipEventRecord(a, ctx->stream);
 }
 
-TimerScope::~TimerScope() {
+void TimerScope::stop() {
     if (!a) return;
     (void)hipEventRecord(b, ctx->stream);
     ctx->spans.push_back({a, b, which});
+    a = nullptr;
 }
+
+TimerScope::~TimerScope() { stop(); }
 
 static void timing_resolve(gingr_ctx *ctx) {
     for (auto &s : ctx->spans) {

@@ -1252,6 +1252,7 @@ template <int MODE>
 static void launch_sweep_mode(gingr_ctx *ctx, const SweepArgs &a, int width) {
     const int nb = sweep_num_blocks(a.M);
     const size_t lds = (size_t)(2 * a.rp + kGroups * (a.rp > 16 ? a.rp : 16)) * sizeof(double);
+    TimerScope ts(ctx, 4);
     if (a.rp <= 128) {
         hipLaunchKernelGGL((sweep_kernel<MODE, 8>), dim3(nb), dim3(kSweepThreads), lds, ctx->stream, a);
     } else {
@@ -1260,6 +1261,7 @@ static void launch_sweep_mode(gingr_ctx *ctx, const SweepArgs &a, int width) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((sweep_kernel<MODE, 32>), dim3(nb), dim3(kSweepThreads), lds, ctx->stream, a);
     }
+    ts.stop();
     if (width > 0)
         hipLaunchKernelGGL(block_partials_reduce_kernel, dim3((unsigned)width), dim3(256), 0, ctx->stream, a.partial, nb,
                            width, a.out);
@@ -1355,6 +1357,7 @@ void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, 
 
 void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, double *work,
                             double *a, DevState *st) {
+    TimerScope ts(ctx, 5);
     if (r <= 128) {
         const size_t lds = ((size_t)r * (r | 1) + 2 * r) * sizeof(double);
         if (lds > 48 * 1024)

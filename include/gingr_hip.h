@@ -210,7 +210,8 @@ int gingr_fitter_icp_phase_async(gingr_fitter *f, const gingr_icp_params *p, int
 
 /* -------------------------------------------------------------- timing hooks
  * HIP-event timing of the dominant kernels on the context's stream (bench.py's live roofline measurement).
- * which: 0 = cpd_colsum, 1 = cpd_rowstats, 2 = gram, 3 = whole update.  Returns accumulated ms and launches since
+ * which: 0 = cpd_colsum, 1 = cpd_rowstats, 2 = gram, 3 = whole update, 4 = basis sweep (one streaming pass over Q0),
+ * 5 = posterior solve.  Returns accumulated ms and launches since
  * the last reset.  Enabling adds two event records per launch. */
 int gingr_ctx_timing_enable(gingr_ctx *ctx, int32_t enable);
 int gingr_ctx_timing_read(gingr_ctx *ctx, int32_t which, double *total_ms, int64_t *launches);
