@@ -631,9 +631,22 @@ __global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp,
     __shared__ int bad_spd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) bad_spd = 0;
-    // Mm = QtL Q + I     (scalismo genericRegressionComputations); lower triangle only
-    for (int i = wave; i < r; i += 4)
-        for (int j = lane; j <= i; j += 64) A[i * ld + j] = G[i * rp + j] + (i == j ? 1.0 : 0.0);
+    // Mm = QtL Q + I     (scalismo genericRegressionComputations).  G was produced on other CUs, so every load is an L2 /
+    // fabric round trip: issue them in independent batches of 8 per thread instead of one dependent loop.
+    for (int base = 0; base < r * rp; base += 256 * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256 + tid;
+            v[u] = idx < r * rp ? G[idx] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256 + tid;
+            const int i = idx / rp, j = idx - i * rp;
+            if (idx < r * rp && j <= i) A[i * ld + j] = v[u] + (i == j ? 1.0 : 0.0);
+        }
+    }
     for (int k = tid; k < r; k += 256) y[k] = rhs[k];
     __syncthreads();
     for (int kb = 0; kb < r; kb += kNB) {
@@ -652,7 +665,14 @@ __global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp,
                     bad = 1;
                     d = 1.0;
                 }
-                const double dk = sqrt(d), rdk = 1.0 / dk;
+                // 1/sqrt(d) by v_rsq_f64 + two Newton steps, sqrt(d) = d * rsqrt(d) + one residual correction: the IEEE
+                // sqrt and divide sequences are ~40 dependent instructions and sit on the sequential chain of every column
+                double rdk = __builtin_amdgcn_rsq(d);
+                const double hd = 0.5 * d;
+                rdk = rdk * __builtin_fma(-hd * rdk, rdk, 1.5);
+                rdk = rdk * __builtin_fma(-hd * rdk, rdk, 1.5);
+                double dk = d * rdk;
+                dk = __builtin_fma(0.5 * rdk, __builtin_fma(-dk, dk, d), dk);
                 const double lc = (lane == c) ? dk : row[c] * rdk;
                 row[c] = lc;
 #pragma unroll
