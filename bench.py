@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--w", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=3)
+    ap.add_argument("--sigma2", type=float, default=0.0,
+                    help="experiment: start from this sigma2 instead of the CPD initial value (late-iteration regime)")
     ap.add_argument("--force-dist", action="store_true",
                     help="testing: run the N>1 code path (process group + phase/all-reduce driver) with the given world")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -163,6 +165,9 @@ def main():
             fitter.xch = as_torch(pp.value, offs[NUM_SEGMENTS - 1] + cnts[NUM_SEGMENTS - 1], local_rank)
             fitter.world = 2
         sigma2_0 = ctx.cpd_initial_sigma2(y, x)      # CpdRegistrationState.apply, CPD.scala:92-102 (mean == reference here)
+
+        if args.sigma2 > 0:
+            sigma2_0 = args.sigma2
 
         def reset():
             fitter.set_state(np.zeros(args.rank), sigma2_0)

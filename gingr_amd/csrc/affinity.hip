@@ -16,6 +16,10 @@
 #include "common.h"
 #include "fastexp.h"
 
+#include <algorithm>
+#include <cstdlib>
+#include <utility>
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -24,6 +28,92 @@ constexpr int kTile = 256;
 struct __attribute__((aligned(32))) P4 {
     double x, y, z, w;
 };
+
+// ---------------------------------------------------------------- exact-zero culling
+// K_ij = 2^(c d2 / 2048) is flushed to exactly +0 by v_ldexp_f64 once c*d2/2048 < -1076, i.e. d2 > 1491.7 sigma2.  When the
+// bounding boxes of the owned block and of a streamed 256-point tile are farther apart than that (with margin: 1500
+// sigma2), every pair of the tile pair contributes exactly +0 to every sum and the tile is skipped: bit-identical results.
+// This only triggers when the points are spatially coherent (the fitter keeps model rows and targets in Morton order).
+constexpr double kCullScaled = 2.22e6;  // 1500 * sigma2 * (-c) = 1500 * 2048 * log2(e) / 2
+
+struct Box {
+    double lo[3], hi[3];
+};
+
+__device__ __forceinline__ double uniform_d(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ double box_gap2(const Box &a, const double *__restrict__ b /* lo[3], hi[3] */) {
+    double s = 0.0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const double g = fmax(fmax(a.lo[d] - b[3 + d], b[d] - a.hi[d]), 0.0);
+        s = __builtin_fma(g, g, s);
+    }
+    return s;
+}
+
+// bounding boxes of the owned points (invalid slots excluded): `wave` = this wave's 64*PT points, return value = the whole
+// workgroup's.  Both are wave-uniform and kept in scalar registers.
+template <int PT>
+__device__ __forceinline__ Box block_bbox(const double (&x)[PT], const double (&y)[PT], const double (&z)[PT],
+                                          const bool (&ok)[PT], double *sh /* >= 6*4 doubles */, Box *wave_box) {
+    double lo[3] = {__builtin_huge_val(), __builtin_huge_val(), __builtin_huge_val()};
+    double hi[3] = {-__builtin_huge_val(), -__builtin_huge_val(), -__builtin_huge_val()};
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+        if (ok[t]) {
+            lo[0] = fmin(lo[0], x[t]); hi[0] = fmax(hi[0], x[t]);
+            lo[1] = fmin(lo[1], y[t]); hi[1] = fmax(hi[1], y[t]);
+            lo[2] = fmin(lo[2], z[t]); hi[2] = fmax(hi[2], z[t]);
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = fmin(lo[d], __shfl_xor(lo[d], off));
+            hi[d] = fmax(hi[d], __shfl_xor(hi[d], off));
+        }
+    if (wave_box)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            wave_box->lo[d] = uniform_d(lo[d]);
+            wave_box->hi[d] = uniform_d(hi[d]);
+        }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            sh[wave * 6 + d] = lo[d];
+            sh[wave * 6 + 3 + d] = hi[d];
+        }
+    __syncthreads();
+    Box b;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        b.lo[d] = uniform_d(fmin(fmin(sh[d], sh[6 + d]), fmin(sh[12 + d], sh[18 + d])));
+        b.hi[d] = uniform_d(fmax(fmax(sh[3 + d], sh[9 + d]), fmax(sh[15 + d], sh[21 + d])));
+    }
+    __syncthreads();
+    return b;
+}
+
+// boxes[tile] = {lo[3], hi[3]} of the points [tile*256, tile*256+256) of a cloud
+__global__ __launch_bounds__(256) void tile_bbox_kernel(Cloud c, double *__restrict__ boxes) {
+    __shared__ double sh[24];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool ok1[1] = {i < c.n};
+    const double x[1] = {ok1[0] ? c.x[i] : 0.0}, y[1] = {ok1[0] ? c.y[i] : 0.0}, z[1] = {ok1[0] ? c.z[i] : 0.0};
+    const Box b = block_bbox<1>(x, y, z, ok1, sh, nullptr);
+    if (threadIdx.x < 3) {
+        boxes[(int64_t)blockIdx.x * 6 + threadIdx.x] = b.lo[threadIdx.x];
+        boxes[(int64_t)blockIdx.x * 6 + 3 + threadIdx.x] = b.hi[threadIdx.x];
+    }
+}
 
 // ---------------------------------------------------------------- pass 1: column sums of K
 template <int PT, bool CLAMP>
@@ -80,10 +170,12 @@ __device__ __forceinline__ void colsum_tile_expand(const P4 *tile, int cnt, cons
 
 template <int PT>
 __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt, const double *__restrict__ sigma2,
-                                                            const double *__restrict__ aux, int64_t rows_per_chunk,
+                                                            const double *__restrict__ aux,
+                                                            const double *__restrict__ fit_boxes, int64_t rows_per_chunk,
                                                             double *__restrict__ partial) {
     __shared__ double T[GINGR_EXP_TABLE];
     __shared__ P4 tile[kTile];
+    __shared__ double shbox[24];
     fastexp_table_init(T);
     const double c = fastexp_scale_for_variance(2.0 * sigma2[0]);
     const double am = aux[0] + aux[1];
@@ -93,15 +185,23 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
     const double cx = aux[2], cy = aux[3], cz = aux[4];
     const double m2c = -2.0 * c;
     const int tid = threadIdx.x;
-    const int64_t jbase = (int64_t)blockIdx.x * (kBlock * PT) + tid;
+    // a wave owns 64*PT CONSECUTIVE points (one 256-point k-d leaf at PT = 4): its bounding box is compact
+    const int64_t jbase = (int64_t)blockIdx.x * (kBlock * PT) + (int64_t)(tid >> 6) * (64 * PT) + (tid & 63);
     double x[PT], y[PT], z[PT], n[PT], acc[PT];
+    bool okv[PT];
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
-        const int64_t j = jbase + (int64_t)t * kBlock;
+        const int64_t j = jbase + (int64_t)t * 64;
         const bool ok = j < tgt.n;
+        okv[t] = ok;
         x[t] = ok ? tgt.x[j] : 0.0;
         y[t] = ok ? tgt.y[j] : 0.0;
         z[t] = ok ? tgt.z[j] : 0.0;
+    }
+    Box wown;
+    const Box own = block_bbox<PT>(x, y, z, okv, shbox, &wown);  // raw coordinates, before any centring
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
         if (expand) {
             x[t] -= cx;
             y[t] -= cy;
@@ -113,6 +213,7 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
     const int64_t i0 = (int64_t)blockIdx.y * rows_per_chunk;
     const int64_t i1 = min(fit.n, i0 + rows_per_chunk);
     for (int64_t ib = i0; ib < i1; ib += kTile) {
+        if (fit_boxes && box_gap2(own, fit_boxes + (ib / kTile) * 6) * (-c) > kCullScaled) continue;  // all pairs flush to +0
         __syncthreads();
         const int64_t i = ib + tid;
         if (i < i1) {
@@ -124,6 +225,8 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
             }
         }
         __syncthreads();
+        // this wave's own 64*PT points may be far from the tile although the workgroup's box is not
+        if (fit_boxes && box_gap2(wown, fit_boxes + (ib / kTile) * 6) * (-c) > kCullScaled) continue;
         const int cnt = (int)min((int64_t)kTile, i1 - ib);
         if (expand)
             colsum_tile_expand<PT>(tile, cnt, x, y, z, n, acc, T);
@@ -134,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
     }
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
-        const int64_t j = jbase + (int64_t)t * kBlock;
+        const int64_t j = jbase + (int64_t)t * 64;
         if (j < tgt.n) partial[(int64_t)blockIdx.y * tgt.n + j] = acc[t];
     }
 }
@@ -189,7 +292,8 @@ constexpr int kScalarBlocks = 256;
 __global__ __launch_bounds__(256) void cpd_den_finalize_kernel(Cloud tgt, const double *__restrict__ sigma2, double w,
                                                                double m_over_n, double *__restrict__ den,
                                                                double *__restrict__ inv_den, double *__restrict__ Pt1,
-                                                               double *__restrict__ part, double *__restrict__ scalars) {
+                                                               int32_t *__restrict__ tile_bad, double *__restrict__ part,
+                                                               double *__restrict__ scalars) {
     __shared__ double sh[256];
     const double s2 = sigma2[0];
     // c = w/(1-w) * (2 pi sigma2)^(3/2) * (M/N)     CPD.scala:69-70
@@ -203,6 +307,7 @@ __global__ __launch_bounds__(256) void cpd_den_finalize_kernel(Cloud tgt, const 
         den[j] = d;
         inv_den[j] = inv;
         Pt1[j] = pt1;
+        if (tile_bad && !(fabs(inv) <= 1.79769313486231570815e308)) tile_bad[j / kTile] = 1;  // never cull this tile
         const double xx = tgt.x[j], yy = tgt.y[j], zz = tgt.z[j];
         xpx += pt1 * (xx * xx + yy * yy + zz * zz);
     }
@@ -261,11 +366,14 @@ __device__ __forceinline__ void rowstats_tile_expand(const P4 *tile, const doubl
 template <int PT>
 __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud tgt, const double *__restrict__ sigma2,
                                                               const double *__restrict__ aux,
-                                                              const double *__restrict__ inv_den, int64_t cols_per_chunk,
+                                                              const double *__restrict__ inv_den,
+                                                              const double *__restrict__ tgt_boxes,
+                                                              const int32_t *__restrict__ tile_bad, int64_t cols_per_chunk,
                                                               double *__restrict__ partial) {
     __shared__ double T[GINGR_EXP_TABLE];
     __shared__ P4 tile[kTile];
     __shared__ double tinv[kTile];
+    __shared__ double shbox[24];
     fastexp_table_init(T);
     const double c = fastexp_scale_for_variance(2.0 * sigma2[0]);
     const double am = aux[0] + aux[1];
@@ -275,15 +383,22 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
     const double cx = aux[2], cy = aux[3], cz = aux[4];
     const double m2c = -2.0 * c;
     const int tid = threadIdx.x;
-    const int64_t ibase = (int64_t)blockIdx.x * (kBlock * PT) + tid;
+    const int64_t ibase = (int64_t)blockIdx.x * (kBlock * PT) + (int64_t)(tid >> 6) * (64 * PT) + (tid & 63);
     double x[PT], y[PT], z[PT], n[PT], a1[PT], ax[PT], ay[PT], az[PT];
+    bool okv[PT];
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
-        const int64_t i = ibase + (int64_t)t * kBlock;
+        const int64_t i = ibase + (int64_t)t * 64;
         const bool ok = i < fit.n;
+        okv[t] = ok;
         x[t] = ok ? fit.x[i] : 0.0;
         y[t] = ok ? fit.y[i] : 0.0;
         z[t] = ok ? fit.z[i] : 0.0;
+    }
+    Box wown;
+    const Box own = block_bbox<PT>(x, y, z, okv, shbox, &wown);  // raw coordinates, before any centring
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
         if (expand) {
             x[t] -= cx;
             y[t] -= cy;
@@ -295,6 +410,8 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
     const int64_t j0 = (int64_t)blockIdx.y * cols_per_chunk;
     const int64_t j1 = min(tgt.n, j0 + cols_per_chunk);
     for (int64_t jb = j0; jb < j1; jb += kTile) {
+        // all pairs flush to +0 -- unless a 1/den of the tile is inf/NaN: 0 * inf must stay NaN like the reference's 0/0
+        if (tgt_boxes && !tile_bad[jb / kTile] && box_gap2(own, tgt_boxes + (jb / kTile) * 6) * (-c) > kCullScaled) continue;
         __syncthreads();
         const int64_t j = jb + tid;
         if (j < j1) {
@@ -307,6 +424,7 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
             }
         }
         __syncthreads();
+        if (tgt_boxes && !tile_bad[jb / kTile] && box_gap2(wown, tgt_boxes + (jb / kTile) * 6) * (-c) > kCullScaled) continue;
         const int cnt = (int)min((int64_t)kTile, j1 - jb);
         if (expand)
             rowstats_tile_expand<PT>(tile, tinv, cnt, x, y, z, n, a1, ax, ay, az, T);
@@ -320,7 +438,7 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
     const double back = expand ? -0.5 / c : 1.0;  // sum_j p a_j -> sum_j p x~_j
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
-        const int64_t i = ibase + (int64_t)t * kBlock;
+        const int64_t i = ibase + (int64_t)t * 64;
         if (i < M) {
             base[i] = a1[t];
             base[M + i] = expand ? __builtin_fma(cx, a1[t], back * ax[t]) : ax[t];
@@ -387,29 +505,33 @@ __device__ __forceinline__ double norm2_exact(double dx, double dy, double dz) {
     return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
 }
 
-__global__ __launch_bounds__(kBlock) void nn_kernel(Cloud q, Cloud tgt, int64_t cols_per_chunk, double *__restrict__ pd2,
-                                                    int32_t *__restrict__ pidx) {
+__global__ __launch_bounds__(kBlock) void nn_kernel(Cloud q, Cloud tgt, const int32_t *__restrict__ orig, int64_t cols_per_chunk,
+                                                    double *__restrict__ pd2, int32_t *__restrict__ pidx,
+                                                    int32_t *__restrict__ porig) {
     __shared__ P4 tile[kTile];
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * kBlock + tid;
     const bool ok = i < q.n;
     const double qx = ok ? q.x[i] : 0.0, qy = ok ? q.y[i] : 0.0, qz = ok ? q.z[i] : 0.0;
-    double best = __builtin_huge_val();
+    double best = __builtin_huge_val(), bo = __builtin_huge_val();  // best distance and the ORIGINAL index that holds it
     int32_t bi = -1;
     const int64_t j0 = (int64_t)blockIdx.y * cols_per_chunk;
     const int64_t j1 = min(tgt.n, j0 + cols_per_chunk);
     for (int64_t jb = j0; jb < j1; jb += kTile) {
         __syncthreads();
         const int64_t j = jb + tid;
-        if (j < j1) tile[tid] = P4{tgt.x[j], tgt.y[j], tgt.z[j], 0.0};
+        if (j < j1) tile[tid] = P4{tgt.x[j], tgt.y[j], tgt.z[j], (double)(orig ? orig[j] : (int32_t)j)};
         __syncthreads();
         const int cnt = (int)min((int64_t)kTile, j1 - jb);
 #pragma unroll 4
         for (int jj = 0; jj < cnt; ++jj) {
             const P4 p = tile[jj];
             const double d2 = norm2_exact(p.x - qx, p.y - qy, p.z - qz);
-            if (d2 < best) {  // strict: the lowest index wins exact ties
+            // strictly closer, or exactly as close with a lower original index: "lowest index wins" independent of the
+            // (spatially sorted) device order
+            if (d2 < best || (d2 == best && p.w < bo)) {
                 best = d2;
+                bo = p.w;
                 bi = (int32_t)(jb + jj);
             }
         }
@@ -417,20 +539,24 @@ __global__ __launch_bounds__(kBlock) void nn_kernel(Cloud q, Cloud tgt, int64_t 
     if (ok) {
         pd2[(int64_t)blockIdx.y * q.n + i] = best;
         pidx[(int64_t)blockIdx.y * q.n + i] = bi;
+        porig[(int64_t)blockIdx.y * q.n + i] = (int32_t)(bo < 2147483648.0 ? bo : -1.0);
     }
 }
 
-__global__ void nn_reduce_kernel(const double *__restrict__ pd2, const int32_t *__restrict__ pidx, int nchunks, int64_t M,
-                                 int32_t *__restrict__ idx, double *__restrict__ d2) {
+__global__ void nn_reduce_kernel(const double *__restrict__ pd2, const int32_t *__restrict__ pidx,
+                                 const int32_t *__restrict__ porig, int nchunks, int64_t M, int32_t *__restrict__ idx,
+                                 double *__restrict__ d2) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     double best = pd2[i];
-    int32_t bi = pidx[i];
+    int32_t bi = pidx[i], bo = porig[i];
     for (int c = 1; c < nchunks; ++c) {
         const double v = pd2[(int64_t)c * M + i];
-        if (v < best) {  // chunks ascend in index, strict < keeps the lowest index
+        const int32_t o = porig[(int64_t)c * M + i];
+        if (v < best || (v == best && o >= 0 && (bo < 0 || o < bo))) {
             best = v;
             bi = pidx[(int64_t)c * M + i];
+            bo = o;
         }
     }
     idx[i] = bi;
@@ -488,20 +614,31 @@ __global__ __launch_bounds__(1024) void sum_vector_kernel(const double *__restri
     if (threadIdx.x == 0) out[0] = tot * scale;
 }
 
-__global__ void aos_to_soa_kernel(const double *__restrict__ aos, int64_t n, double *__restrict__ soa) {
+__global__ void aos_to_soa_kernel(const double *__restrict__ aos, int64_t n, const int32_t *__restrict__ perm,
+                                  double *__restrict__ soa) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    soa[i] = aos[3 * i];
-    soa[n + i] = aos[3 * i + 1];
-    soa[2 * n + i] = aos[3 * i + 2];
+    const int64_t o = perm ? perm[i] : i;
+    soa[i] = aos[3 * o];
+    soa[n + i] = aos[3 * o + 1];
+    soa[2 * n + i] = aos[3 * o + 2];
 }
 
-__global__ void soa_to_aos_kernel(const double *__restrict__ soa, int64_t n, double *__restrict__ aos) {
+__global__ void soa_to_aos_kernel(const double *__restrict__ soa, int64_t n, const int32_t *__restrict__ perm,
+                                  double *__restrict__ aos) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    aos[3 * i] = soa[i];
-    aos[3 * i + 1] = soa[n + i];
-    aos[3 * i + 2] = soa[2 * n + i];
+    const int64_t o = perm ? perm[i] : i;
+    aos[3 * o] = soa[i];
+    aos[3 * o + 1] = soa[n + i];
+    aos[3 * o + 2] = soa[2 * n + i];
+}
+
+__global__ void scatter_kernel(const double *__restrict__ in, int64_t n, const int32_t *__restrict__ perm,
+                               double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[perm ? perm[i] : i] = in[i];
 }
 
 #ifndef GINGR_PT
@@ -545,7 +682,7 @@ int64_t nn_ws_bytes(int64_t M, int64_t N) {
     int nch;
     int64_t len;
     plan_chunks(M, kBlock, N, &nch, &len);
-    return (int64_t)nch * M * (sizeof(double) + sizeof(int32_t));
+    return (int64_t)nch * M * (sizeof(double) + 2 * sizeof(int32_t));
 }
 
 void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, const double *ctr, double *slot) {
@@ -554,8 +691,14 @@ void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, const double *ctr, double *slo
     hipLaunchKernelGGL(cloud_absmax_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, ctx->stream, c, ctr, slot);
 }
 
+void launch_tile_bbox(gingr_ctx *ctx, Cloud c, double *boxes) {
+    if (c.n <= 0) return;
+
+    hipLaunchKernelGGL(tile_bbox_kernel, dim3((unsigned)ceil_div(c.n, kTile)), dim3(256), 0, ctx->stream, c, boxes);
+}
+
 void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
-                       double *ws, double *den_partial) {
+                       const double *fit_boxes, double *ws, double *den_partial) {
     int nch;
     {
         TimerScope ts(ctx, 0);
@@ -565,8 +708,8 @@ void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *si
             int64_t len;
             plan_chunks(target.n, kBlock * kPT, fit.n, &nch, &len);
             dim3 grid((unsigned)ceil_div(target.n, kBlock * kPT), (unsigned)nch);
-            hipLaunchKernelGGL(cpd_colsum_kernel<kPT>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux, len,
-                               ws);
+            hipLaunchKernelGGL(cpd_colsum_kernel<kPT>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux,
+                               ctx->cull ? fit_boxes : (const double *)nullptr, len, ws);
         }
     }
     hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)ceil_div(target.n, 256)), dim3(256), 0, ctx->stream, ws, nch,
@@ -574,13 +717,16 @@ void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *si
 }
 
 void launch_cpd_den_finalize(gingr_ctx *ctx, Cloud target, const double *sigma2_dev, double w, int64_t M_total,
-                             double *den, double *inv_den, double *Pt1, double *part, double *scalars_dev) {
+                             double *den, double *inv_den, double *Pt1, int32_t *tile_bad, double *part,
+                             double *scalars_dev) {
+    if (tile_bad) (void)hipMemsetAsync(tile_bad, 0, (size_t)ceil_div(target.n, kTile) * sizeof(int32_t), ctx->stream);
     hipLaunchKernelGGL(cpd_den_finalize_kernel, dim3(kScalarBlocks), dim3(256), 0, ctx->stream, target, sigma2_dev, w,
-                       (double)M_total / (double)target.n, den, inv_den, Pt1, part, scalars_dev);
+                       (double)M_total / (double)target.n, den, inv_den, Pt1, tile_bad, part, scalars_dev);
 }
 
 void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
-                         const double *inv_den, double *ws, double *P1, double *PX_soa, double *part, double *scalars_dev) {
+                         const double *inv_den, const double *tgt_boxes, const int32_t *tile_bad, double *ws, double *P1,
+                         double *PX_soa, double *part, double *scalars_dev) {
     int nch;
     {
         TimerScope ts(ctx, 1);
@@ -590,8 +736,9 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
             int64_t len;
             plan_chunks(fit.n, kBlock * kPT, target.n, &nch, &len);
             dim3 grid((unsigned)ceil_div(fit.n, kBlock * kPT), (unsigned)nch);
+            const bool cull = ctx->cull && tgt_boxes && tile_bad;
             hipLaunchKernelGGL(cpd_rowstats_kernel<kPT>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux,
-                               inv_den, len, ws);
+                               inv_den, cull ? tgt_boxes : (const double *)nullptr, tile_bad, len, ws);
         }
     }
     hipLaunchKernelGGL(rowstats_reduce_kernel, dim3(kScalarBlocks), dim3(256), 0, ctx->stream, ws, nch, fit, P1, PX_soa,
@@ -599,15 +746,16 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
     hipLaunchKernelGGL(cpd_scalars_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, part, scalars_dev);
 }
 
-void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, void *ws, int32_t *idx, double *d2) {
+void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, void *ws, int32_t *idx, double *d2) {
     int nch;
     int64_t len;
     plan_chunks(query.n, kBlock, target.n, &nch, &len);
     double *pd2 = reinterpret_cast<double *>(ws);
     int32_t *pidx = reinterpret_cast<int32_t *>(pd2 + (int64_t)nch * query.n);
+    int32_t *porig = pidx + (int64_t)nch * query.n;
     dim3 grid((unsigned)ceil_div(query.n, kBlock), (unsigned)nch);
-    hipLaunchKernelGGL(nn_kernel, grid, dim3(kBlock), 0, ctx->stream, query, target, len, pd2, pidx);
-    hipLaunchKernelGGL(nn_reduce_kernel, dim3((unsigned)ceil_div(query.n, 256)), dim3(256), 0, ctx->stream, pd2, pidx,
+    hipLaunchKernelGGL(nn_kernel, grid, dim3(kBlock), 0, ctx->stream, query, target, target_orig, len, pd2, pidx, porig);
+    hipLaunchKernelGGL(nn_reduce_kernel, dim3((unsigned)ceil_div(query.n, 256)), dim3(256), 0, ctx->stream, pd2, pidx, porig,
                        nch, query.n, idx, d2);
 }
 
@@ -628,12 +776,58 @@ void launch_sumsq_pairs(gingr_ctx *ctx, Cloud A, Cloud B, double *ws, double *ou
     hipLaunchKernelGGL(sum_vector_kernel, dim3(1), dim3(1024), 0, ctx->stream, ws, nb, 1.0, out_scalar);
 }
 
-void launch_aos_to_soa(gingr_ctx *ctx, const double *aos, int64_t n, double *soa) {
+void launch_aos_to_soa(gingr_ctx *ctx, const double *aos, int64_t n, double *soa, const int32_t *perm) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(aos_to_soa_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, aos, n, soa);
+    hipLaunchKernelGGL(aos_to_soa_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, aos, n, perm, soa);
 }
 
-void launch_soa_to_aos(gingr_ctx *ctx, const double *soa, int64_t n, double *aos) {
+void launch_soa_to_aos(gingr_ctx *ctx, const double *soa, int64_t n, double *aos, const int32_t *perm) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(soa_to_aos_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, soa, n, aos);
+    hipLaunchKernelGGL(soa_to_aos_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, soa, n, perm, aos);
+}
+
+void launch_scatter(gingr_ctx *ctx, const double *in, int64_t n, const int32_t *perm, double *out) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, in, n, perm, out);
+}
+
+// Spatial order for the tile culling: recursive median split along the longest axis of the bounding box (a balanced k-d
+// tree laid out in leaf order).  Every aligned run of 256 * 2^k points is one tree node, i.e. a compact box, which is what
+// the per-tile / per-workgroup bounding boxes of the CPD kernels need (a Z-curve order has seams whose chunks span the
+// whole domain).  Deterministic: ties are broken by the original index.
+static void kd_split(const double *xyz, int32_t *idx, int64_t n, int64_t leaf) {
+    if (n <= leaf) return;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int64_t i = 0; i < n; ++i)
+        for (int d = 0; d < 3; ++d) {
+            const double v = xyz[3 * (int64_t)idx[i] + d];
+            if (v == v) {
+                if (v < lo[d]) lo[d] = v;
+                if (v > hi[d]) hi[d] = v;
+            }
+        }
+    int ax = 0;
+    for (int d = 1; d < 3; ++d)
+        if (hi[d] - lo[d] > hi[ax] - lo[ax]) ax = d;
+    // left half gets a multiple of `leaf` points so that leaves stay aligned to 256-point tiles
+    int64_t half = ((n / leaf + 1) / 2) * leaf;
+    if (half >= n) half = n / 2;
+    auto key = [&](int32_t i) {
+        const double v = xyz[3 * (int64_t)i + ax];
+        return v == v ? v : 1e300;  // NaN coordinates sort last
+    };
+    std::nth_element(idx, idx + half, idx + n, [&](int32_t a, int32_t b) {
+        const double ka = key(a), kb = key(b);
+        return ka < kb || (ka == kb && a < b);
+    });
+    kd_split(xyz, idx, half, leaf);
+    kd_split(xyz, idx + half, n - half, leaf);
+}
+
+void morton_order(const double *xyz, int64_t n, std::vector<int32_t> &perm) {
+    perm.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) perm[(size_t)i] = (int32_t)i;
+    kd_split(xyz, perm.data(), n, 256);
+    // keep the original order inside a leaf (reproducible and cache friendly)
+    for (int64_t b = 0; b < n; b += 256) std::sort(perm.begin() + b, perm.begin() + (b + 256 < n ? b + 256 : n));
 }

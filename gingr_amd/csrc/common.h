@@ -33,6 +33,8 @@ struct gingr_ctx {
     // f64 matrix pipe (affinity_mfma.hip).  Measured on MI355X (profiles/r01_ubench_mfma_valu_overlap.txt): f64 MFMA and
     // f64 VALU do not overlap (they share the DP hardware), so the MFMA form is not faster.  GINGR_AFFINITY=valu|mfma.
     int affinity_mfma = 0;
+    // exact-zero tile culling of the CPD passes (affinity.hip); GINGR_CULL=0 disables it (results must stay bit-identical)
+    int cull = 1;
     // scratch kept across calls (grown on demand, never shrunk) so steady-state updates do not allocate
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -114,19 +116,32 @@ int launch_cpd_colsum_mfma(gingr_ctx *ctx, Cloud fit, Cloud target, const double
 int launch_cpd_rowstats_mfma(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
                              const double *inv_den, double *ws, int *nchunks_out);
 void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, const double *ctr, double *slot);
-void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *absmax,
-                       double *ws, double *den_partial);
+// boxes[tile] = {lo[3], hi[3]} of every 256-point tile of a cloud: input of the exact-zero tile culling
+void launch_tile_bbox(gingr_ctx *ctx, Cloud c, double *boxes);
+void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
+                       const double *fit_boxes, double *ws, double *den_partial);
 // den[j] += c; inv_den[j] = 1/den[j]; Pt1[j] = (den[j]-c)/den[j]; xPx block partials -> part[0..256)
 // M_total enters the outlier constant c = w/(1-w) (2 pi sigma2)^1.5 M_total/N.  part: GINGR_SCALAR_PART doubles.
+// tile_bad[tile] (nullable) is set when a 1/den of the tile is not finite: such tiles are never culled.
 #define GINGR_SCALAR_PART 1024
 void launch_cpd_den_finalize(gingr_ctx *ctx, Cloud target, const double *sigma2_dev, double w, int64_t M_total,
-                             double *den, double *inv_den, double *Pt1, double *part, double *scalars_dev);
+                             double *den, double *inv_den, double *Pt1, int32_t *tile_bad, double *part,
+                             double *scalars_dev);
 // P1[i], PX (SoA planes px,py,pz of stride M) for the local rows; Np/xPx/trPXY/yPy sums into scalars_dev[0..3]
-void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *absmax,
-                         const double *inv_den, double *ws, double *P1, double *PX_soa, double *part, double *scalars_dev);
-void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, void *ws, int32_t *idx, double *d2);
+void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
+                         const double *inv_den, const double *tgt_boxes, const int32_t *tile_bad, double *ws, double *P1,
+                         double *PX_soa, double *part, double *scalars_dev);
+// idx[i] = POSITION (in the device order of `target`) of the nearest target; exact ties are broken by the lowest ORIGINAL
+// index, taken from target_orig[position] (nullptr: the device order is the original order).
+void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, void *ws, int32_t *idx, double *d2);
 void launch_gauss_block(gingr_ctx *ctx, Cloud A, Cloud B, double sigma, double scaling, double *out);
 void launch_sumsq_pairs(gingr_ctx *ctx, Cloud A, Cloud B, double *ws, double *out_scalar);
-// interleaved xyz (n*3) <-> SoA planes
-void launch_aos_to_soa(gingr_ctx *ctx, const double *aos, int64_t n, double *soa);
-void launch_soa_to_aos(gingr_ctx *ctx, const double *soa, int64_t n, double *aos);
+// interleaved xyz (n*3) <-> SoA planes; perm (nullable) maps device position -> original index:
+// soa[s] = aos[perm[s]] resp. aos[perm[s]] = soa[s]
+void launch_aos_to_soa(gingr_ctx *ctx, const double *aos, int64_t n, double *soa, const int32_t *perm = nullptr);
+void launch_soa_to_aos(gingr_ctx *ctx, const double *soa, int64_t n, double *aos, const int32_t *perm = nullptr);
+// out[perm[s]] = in[s]  (perm nullable = copy)
+void launch_scatter(gingr_ctx *ctx, const double *in, int64_t n, const int32_t *perm, double *out);
+// spatial (balanced k-d tree, leaf = one 256-point tile) order of interleaved points: perm[s] = original index of the
+// point stored at device position s
+void morton_order(const double *xyz, int64_t n, std::vector<int32_t> &perm);

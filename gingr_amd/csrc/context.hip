@@ -79,6 +79,7 @@ int gingr_ctx_create(int device, gingr_ctx **out) {
     }
     ctx->stream = ctx->own_stream;
     if (const char *m = getenv("GINGR_AFFINITY")) ctx->affinity_mfma = (strcmp(m, "mfma") == 0) ? 1 : 0;
+    if (const char *m = getenv("GINGR_CULL")) ctx->cull = (strcmp(m, "0") == 0) ? 0 : 1;
     *out = ctx;
     return GINGR_OK;
 }
@@ -191,9 +192,9 @@ int gingr_cpd_stats(gingr_ctx *ctx, int64_t M, const double *fit, int64_t N, con
     launch_cloud_centroid(ctx, ct, absmax + 2);
     launch_cloud_absmax(ctx, ct, absmax + 2, absmax);
     launch_cloud_absmax(ctx, cf, absmax + 2, absmax + 1);
-    launch_cpd_colsum(ctx, cf, ct, s2dev, absmax, dws.as<double>(), dden.as<double>());
-    launch_cpd_den_finalize(ctx, ct, s2dev, w, M, dden.as<double>(), dinv.as<double>(), dpt1.as<double>(), dpart.as<double>(), sc);
-    launch_cpd_rowstats(ctx, cf, ct, s2dev, absmax, dinv.as<double>(), dws.as<double>(), dp1.as<double>(), dpx.as<double>(), dpart.as<double>(), sc);
+    launch_cpd_colsum(ctx, cf, ct, s2dev, absmax, nullptr, dws.as<double>(), dden.as<double>());
+    launch_cpd_den_finalize(ctx, ct, s2dev, w, M, dden.as<double>(), dinv.as<double>(), dpt1.as<double>(), nullptr, dpart.as<double>(), sc);
+    launch_cpd_rowstats(ctx, cf, ct, s2dev, absmax, dinv.as<double>(), nullptr, nullptr, dws.as<double>(), dp1.as<double>(), dpx.as<double>(), dpart.as<double>(), sc);
     GINGR_TRY(check_launch(ctx));
     launch_soa_to_aos(ctx, dpx.as<double>(), M, daos.as<double>());
     double hsc[8];
@@ -249,7 +250,7 @@ int gingr_nn(gingr_ctx *ctx, int64_t M, const double *query, int64_t N, const do
     HIP_TRY(ctx, dws.alloc((size_t)nn_ws_bytes(M, N)));
     HIP_TRY(ctx, didx.alloc(M * sizeof(int32_t)));
     HIP_TRY(ctx, dd2.alloc(M * sizeof(double)));
-    launch_nn(ctx, cq, ct, dws.p, didx.as<int32_t>(), dd2.as<double>());
+    launch_nn(ctx, cq, ct, nullptr, dws.p, didx.as<int32_t>(), dd2.as<double>());
     GINGR_TRY(check_launch(ctx));
     std::vector<double> hd2((size_t)M);
     if (idx) HIP_TRY(ctx, hipMemcpyAsync(idx, didx.p, M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

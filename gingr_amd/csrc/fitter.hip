@@ -30,6 +30,10 @@ struct gingr_fitter {
     double *scalars = nullptr;  // local {Np, xPx, trPXY, yPy, -, c, -, -}
     double *part = nullptr;     // block partials of the scalar sums
     double *absmax = nullptr;   // [0] target, [1] fit: largest |coordinate| (exponent-argument range check)
+    int32_t *tperm = nullptr;   // target cloud is kept in Morton order: tperm[s] = original target index of device position s
+    std::vector<int32_t> h_tperm;
+    double *tboxes = nullptr, *fboxes = nullptr;  // bounding boxes of the 256-point tiles of target / fit
+    int32_t *tile_bad = nullptr;                  // target tiles holding a non-finite 1/den (never culled)
     double *xch = nullptr;
     int64_t off[GINGR_NUM_SEGMENTS] = {0, 0}, cnt[GINGR_NUM_SEGMENTS] = {0, 0};
     double *ws = nullptr;
@@ -176,18 +180,29 @@ int gingr_model_upload(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doub
     if (stage.alloc((size_t)3 * M * rank * sizeof(double)) != hipSuccess || var.alloc(rank * sizeof(double)) != hipSuccess ||
         aos.alloc((size_t)3 * M * sizeof(double)) != hipSuccess)
         return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: out of device memory"));
+    // device row order = Morton order of the local mean shape
+    {
+        std::vector<double> pts((size_t)3 * M);
+        for (int64_t i = 0; i < 3 * M; ++i) pts[(size_t)i] = ref[3 * row_begin + i] + mean[3 * row_begin + i];
+        morton_order(pts.data(), M, m->hperm);
+        m->hiperm.resize((size_t)M);
+        for (int64_t sidx = 0; sidx < M; ++sidx) m->hiperm[(size_t)m->hperm[(size_t)sidx]] = (int32_t)sidx;
+        if ((rc = dev_alloc(ctx, &m->perm, (size_t)M))) return fail(rc);
+        if (hipMemcpy(m->perm, m->hperm.data(), (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: permutation copy failed"));
+    }
     // basis: column k of the shard = rows [3*row_begin, 3*row_end) of host column k
     if (hipMemcpy2DAsync(stage.p, (size_t)3 * M * sizeof(double), basis_colmajor + 3 * row_begin,
                          (size_t)3 * M_total * sizeof(double), (size_t)3 * M * sizeof(double), (size_t)rank,
                          hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: basis copy failed"));
     (void)hipMemcpyAsync(var.p, variance, rank * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    launch_pack_basis(ctx, stage.as<double>(), var.as<double>(), M, rank, m->rp, m->Q0);
+    launch_pack_basis(ctx, stage.as<double>(), var.as<double>(), M, rank, m->rp, m->perm, m->Q0);
     (void)hipMemcpyAsync(aos.p, ref + 3 * row_begin, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    launch_aos_to_soa(ctx, aos.as<double>(), M, m->ref);
+    launch_aos_to_soa(ctx, aos.as<double>(), M, m->ref, m->perm);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipMemcpyAsync(aos.p, mean + 3 * row_begin, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    launch_aos_to_soa(ctx, aos.as<double>(), M, m->mean);
+    launch_aos_to_soa(ctx, aos.as<double>(), M, m->mean, m->perm);
     // one-off moments of the local rows (MomentLayout): S_tot, S[d][e], V[d][e], W[d]
     {
         const MomentLayout ml{m->rp};
@@ -254,6 +269,7 @@ void gingr_model_destroy(gingr_model *m) {
     dev_free(m->mom);
     dev_free(m->Binv);
     dev_free(m->cmat);
+    dev_free(m->perm);
     delete m;
 }
 
@@ -332,6 +348,10 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->scalars);
     dev_free(f->part);
     dev_free(f->absmax);
+    dev_free(f->tperm);
+    dev_free(f->tboxes);
+    dev_free(f->fboxes);
+    dev_free(f->tile_bad);
     dev_free(f->xch);
     dev_free(f->ws);
     dev_free(f->work);
@@ -357,8 +377,13 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
     dev_free(f->xch);
     dev_free(f->ws);
     dev_free(f->aos);
-    f->target = f->inv_den = f->Pt1 = f->xch = f->ws = nullptr;
+    dev_free(f->tperm);
+    dev_free(f->tboxes);
+    dev_free(f->fboxes);
+    dev_free(f->tile_bad);
+    f->target = f->inv_den = f->Pt1 = f->xch = f->ws = f->tboxes = f->fboxes = nullptr;
     f->aos = nullptr;
+    f->tperm = f->tile_bad = nullptr;
     f->N = N;
     GINGR_TRY(dev_alloc(ctx, &f->target, (size_t)3 * N));
     GINGR_TRY(dev_alloc(ctx, &f->inv_den, (size_t)N));
@@ -388,7 +413,14 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
     GINGR_TRY(dev_alloc(ctx, &aos, (size_t)3 * big));
     f->aos = aos;
     HIP_TRY(ctx, hipMemcpyAsync(aos, target_xyz, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    launch_aos_to_soa(ctx, aos, N, f->target);
+    morton_order(target_xyz, N, f->h_tperm);
+    GINGR_TRY(dev_alloc(ctx, &f->tperm, (size_t)N));
+    HIP_TRY(ctx, hipMemcpyAsync(f->tperm, f->h_tperm.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    GINGR_TRY(dev_alloc(ctx, &f->tboxes, (size_t)ceil_div(N, 256) * 6));
+    GINGR_TRY(dev_alloc(ctx, &f->fboxes, (size_t)ceil_div(M, 256) * 6));
+    GINGR_TRY(dev_alloc(ctx, &f->tile_bad, (size_t)ceil_div(N, 256)));
+    launch_aos_to_soa(ctx, aos, N, f->target, f->tperm);
+    launch_tile_bbox(ctx, cloud_of(f->target, N), f->tboxes);
     launch_cloud_centroid(ctx, cloud_of(f->target, N), f->absmax + 2);
     launch_cloud_absmax(ctx, cloud_of(f->target, N), f->absmax + 2, f->absmax);
     GINGR_TRY(check_launch(ctx));
@@ -417,8 +449,9 @@ int gingr_fitter_set_landmarks(gingr_fitter *f, int32_t n_lm, const int32_t *lm_
             return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_landmarks: point id %d out of range", lm_pid[l]);
         const int64_t lp = (int64_t)lm_pid[l] - f->m->row_begin;
         if (lp >= 0 && lp < M) {
-            local[(size_t)l] = (int32_t)lp;
-            mask[(size_t)lp] = 1;
+            const int32_t pos = f->m->hiperm[(size_t)lp];  // device (Morton) position of the original point
+            local[(size_t)l] = pos;
+            mask[(size_t)pos] = 1;
         }
     }
     HIP_TRY(ctx, hipMemcpy(f->lm_mask, mask.data(), (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -475,7 +508,7 @@ int gingr_fitter_get_state(gingr_fitter *f, double *alpha, gingr_state_scalars *
     DevBuf tmp;
     if (fit_xyz) {
         HIP_TRY(ctx, tmp.alloc((size_t)3 * M * sizeof(double)));
-        launch_soa_to_aos(ctx, f->fit, M, tmp.as<double>());
+        launch_soa_to_aos(ctx, f->fit, M, tmp.as<double>(), f->m->perm);
         HIP_TRY(ctx, hipMemcpyAsync(fit_xyz, tmp.p, (size_t)3 * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -499,14 +532,22 @@ int gingr_fitter_get_cpd_stats(gingr_fitter *f, double *P1, double *PX, double *
     if (!f->target) return gingr_set_error(ctx, GINGR_ERR_STATE, "get_cpd_stats: no target");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t M = f->m->M;
-    DevBuf tmp;
-    if (P1) HIP_TRY(ctx, hipMemcpyAsync(P1, f->P1, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DevBuf tmp, tmp1, tmpd;
+    if (P1) {  // back to the caller's point order
+        HIP_TRY(ctx, tmp1.alloc((size_t)M * sizeof(double)));
+        launch_scatter(ctx, f->P1, M, f->m->perm, tmp1.as<double>());
+        HIP_TRY(ctx, hipMemcpyAsync(P1, tmp1.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (PX) {
         HIP_TRY(ctx, tmp.alloc((size_t)3 * M * sizeof(double)));
-        launch_soa_to_aos(ctx, f->PX, M, tmp.as<double>());
+        launch_soa_to_aos(ctx, f->PX, M, tmp.as<double>(), f->m->perm);
         HIP_TRY(ctx, hipMemcpyAsync(PX, tmp.p, (size_t)3 * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (den) HIP_TRY(ctx, hipMemcpyAsync(den, f->xch + f->off[0], (size_t)f->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (den) {
+        HIP_TRY(ctx, tmpd.alloc((size_t)f->N * sizeof(double)));
+        launch_scatter(ctx, f->xch + f->off[0], f->N, f->tperm, tmpd.as<double>());
+        HIP_TRY(ctx, hipMemcpyAsync(den, tmpd.p, (size_t)f->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
     double sc[8];
     const double *red = f->xch + f->off[1] + (int64_t)f->m->rp * f->m->rp + f->m->rp;
     HIP_TRY(ctx, hipMemcpyAsync(sc, red, sizeof(sc), hipMemcpyDeviceToHost, ctx->stream));
@@ -529,9 +570,18 @@ int gingr_fitter_get_icp_idx(gingr_fitter *f, int32_t *idx, double *d2) {
     gingr_ctx *ctx = f->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t M = f->m->M;
-    if (idx) HIP_TRY(ctx, hipMemcpyAsync(idx, f->nn_idx, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (d2) HIP_TRY(ctx, hipMemcpyAsync(d2, f->nn_d2, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<int32_t> hidx((size_t)M);
+    std::vector<double> hd2((size_t)M);
+    HIP_TRY(ctx, hipMemcpyAsync(hidx.data(), f->nn_idx, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(hd2.data(), f->nn_d2, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // device positions -> the caller's numbering (rows and targets are kept in Morton order on the device)
+    for (int64_t sidx = 0; sidx < M; ++sidx) {
+        const int32_t row = f->m->hperm[(size_t)sidx];
+        const int32_t pos = hidx[(size_t)sidx];
+        if (idx) idx[row] = (pos >= 0 && (size_t)pos < f->h_tperm.size()) ? f->h_tperm[(size_t)pos] : -1;
+        if (d2) d2[row] = hd2[(size_t)sidx];
+    }
     return GINGR_OK;
 }
 
@@ -566,10 +616,11 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
     switch (phase) {
         case 0: {
             if (icp)
-                launch_nn(ctx, fit, tgt, f->ws, f->nn_idx, f->nn_d2);
+                launch_nn(ctx, fit, tgt, f->tperm, f->ws, f->nn_idx, f->nn_d2);
             else {
                 launch_cloud_absmax(ctx, fit, f->absmax + 2, f->absmax + 1);
-                launch_cpd_colsum(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->ws, seg0);
+                launch_tile_bbox(ctx, fit, f->fboxes);
+                launch_cpd_colsum(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->fboxes, f->ws, seg0);
             }
             break;
         }
@@ -578,8 +629,10 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 launch_obs_icp(ctx, m, f->st, tgt, f->nn_idx, f->lm_mask, f->weight, f->evec);
                 hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(64), 0, ctx->stream, sc8, (int64_t)8);
             } else {
-                launch_cpd_den_finalize(ctx, tgt, &f->st->sigma2, cp->w, m->M_total, seg0, f->inv_den, f->Pt1, f->part, f->scalars);
-                launch_cpd_rowstats(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->inv_den, f->ws, f->P1, f->PX, f->part, f->scalars);
+                launch_cpd_den_finalize(ctx, tgt, &f->st->sigma2, cp->w, m->M_total, seg0, f->inv_den, f->Pt1, f->tile_bad, f->part,
+                                        f->scalars);
+                launch_cpd_rowstats(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->inv_den, f->tboxes, f->tile_bad, f->ws, f->P1,
+                                    f->PX, f->part, f->scalars);
                 launch_obs_cpd(ctx, m, f->st, fit, f->P1, f->PX, cp->lambda, f->lm_mask, f->weight, f->evec);
                 hipLaunchKernelGGL(pack_scalars_kernel, dim3(1), dim3(64), 0, ctx->stream, f->scalars, m->row_begin == 0 ? 1 : 0,
                                    sc8);
@@ -725,7 +778,7 @@ int gingr_model_coefficients(gingr_ctx *ctx, const gingr_model *model, const dou
     if (!rc && aos.alloc((size_t)3 * M * sizeof(double)) != hipSuccess) rc = gingr_set_error(ctx, GINGR_ERR_HIP, "out of memory");
     if (!rc) {
         (void)hipMemcpyAsync(aos.p, mesh_xyz, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-        launch_aos_to_soa(ctx, aos.as<double>(), M, f->newshape);
+        launch_aos_to_soa(ctx, aos.as<double>(), M, f->newshape, model->perm);
         // pose := the state's rigid transform
         DevState hst;
         (void)hipMemcpyAsync(&hst, f->st, sizeof(hst), hipMemcpyDeviceToHost, ctx->stream);
@@ -781,11 +834,12 @@ int gingr_model_posterior_mean(gingr_ctx *ctx, const gingr_model *model, const d
                 gws.alloc((size_t)gram_ws_doubles(M, rp) * sizeof(double)) != hipSuccess))
         rc = gingr_set_error(ctx, GINGR_ERR_HIP, "out of memory");
     if (!rc) {
-        std::vector<double> wh((size_t)M);
-        for (int64_t i = 0; i < M; ++i) wh[(size_t)i] = weight[i];
-        for (int32_t l = 0; l < n_lm; ++l) wh[(size_t)lm_pid[l]] = 0.0;  // landmark pids carry weight 0
+        std::vector<double> wo((size_t)M), wh((size_t)M);
+        for (int64_t i = 0; i < M; ++i) wo[(size_t)i] = weight[i];
+        for (int32_t l = 0; l < n_lm; ++l) wo[(size_t)lm_pid[l]] = 0.0;  // landmark pids carry weight 0
+        for (int64_t sidx = 0; sidx < M; ++sidx) wh[(size_t)sidx] = wo[(size_t)model->hperm[(size_t)sidx]];  // device order
         (void)hipMemcpyAsync(aos.p, obs_xyz, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-        launch_aos_to_soa(ctx, aos.as<double>(), M, obs.as<double>());
+        launch_aos_to_soa(ctx, aos.as<double>(), M, obs.as<double>(), model->perm);
         (void)hipMemcpyAsync(win.p, wh.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
         launch_obs_points(ctx, model, f->st, obs.as<double>(), win.as<double>(), f->weight, f->evec);
         double *Gd = G.as<double>(), *rhs = Gd + (int64_t)rp * rp;
@@ -800,7 +854,7 @@ int gingr_model_posterior_mean(gingr_ctx *ctx, const gingr_model *model, const d
         b.coef0 = f->acoef;
         b.shape_out = f->newshape;
         launch_sweep(ctx, SWEEP_POSED, b);
-        launch_soa_to_aos(ctx, f->newshape, M, aos.as<double>());
+        launch_soa_to_aos(ctx, f->newshape, M, aos.as<double>(), model->perm);
         rc = check_launch(ctx);
         DevState hst;
         (void)hipMemcpyAsync(&hst, f->st, sizeof(hst), hipMemcpyDeviceToHost, ctx->stream);

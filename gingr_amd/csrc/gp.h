@@ -56,6 +56,10 @@ struct gingr_model {
     double *ref = nullptr;    // SoA [3][M]
     double *mean = nullptr;   // SoA [3][M]
     double *mom = nullptr;    // MomentLayout: local sums until finalize (the exchange buffer of the one-off all-reduce)
+    // Rows live on the device in Morton (Z-curve) order of the local reference points so that a workgroup's points are
+    // spatially coherent (exact-zero tile culling in the CPD passes).  perm[s] = original local index of device row s.
+    int32_t *perm = nullptr;
+    std::vector<int32_t> hperm, hiperm;  // host copies: device position -> original, original -> device position
     double *Binv = nullptr;   // [rp*rp] (S_tot/eps + I)^-1, valid after finalize
     double *cmat = nullptr;   // [10][rp*rp], valid after finalize: [0] C = Binv S_tot / eps (alpha_1 = C a),
                               // [1 + 3d + e] T[d][e] = S[d][e] C  (S[d][e] alpha_1 = T[d][e] a)
@@ -173,6 +177,6 @@ void launch_post_matvecs(gingr_ctx *ctx, const gingr_model *m, const double *alp
 // out = scale * A B (r x r, leading dimension rp); one-off products at model finalisation
 void launch_small_gemm(gingr_ctx *ctx, int32_t r, int32_t rp, const double *A, const double *B, double scale, double *out);
 
-// basis packing: stage is column-major [r][3M] (local rows), out Q0 [3M][rp]
+// basis packing: stage is column-major [r][3M] (local rows, ORIGINAL order), out Q0 [3M][rp] in device (perm) order
 void launch_pack_basis(gingr_ctx *ctx, const double *stage_colmajor, const double *variance_dev, int64_t M, int32_t r,
-                       int32_t rp, double *Q0);
+                       int32_t rp, const int32_t *perm, double *Q0);

@@ -59,13 +59,15 @@ __device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= 1.7976931
 
 // ------------------------------------------------------------------------------------------------- basis packing
 __global__ void pack_basis_kernel(const double *__restrict__ stage, const double *__restrict__ variance, int64_t rows,
-                                  int32_t r, int32_t rp, double *__restrict__ Q0) {
+                                  int32_t r, int32_t rp, const int32_t *__restrict__ perm, double *__restrict__ Q0) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * rp) return;
     const int64_t row = idx / rp;
     const int32_t k = (int32_t)(idx - row * rp);
+    const int64_t pt = row / 3, d = row - 3 * pt;
+    const int64_t src = 3 * (int64_t)(perm ? perm[pt] : pt) + d;
     // Q(i, j) = eigenvector * sqrt(eigenvalue)   (scalismo genericRegressionComputations)
-    Q0[idx] = k < r ? stage[(int64_t)k * rows + row] * sqrt(variance[k]) : 0.0;
+    Q0[idx] = k < r ? stage[(int64_t)k * rows + src] * sqrt(variance[k]) : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------- basis sweeps
@@ -1441,8 +1443,8 @@ void launch_state_init(gingr_ctx *ctx, DevState *st, const gingr_state_scalars *
 }
 
 void launch_pack_basis(gingr_ctx *ctx, const double *stage_colmajor, const double *variance_dev, int64_t M, int32_t r,
-                       int32_t rp, double *Q0) {
+                       int32_t rp, const int32_t *perm, double *Q0) {
     const int64_t total = 3 * M * rp;
     hipLaunchKernelGGL(pack_basis_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, stage_colmajor,
-                       variance_dev, 3 * M, r, rp, Q0);
+                       variance_dev, 3 * M, r, rp, perm, Q0);
 }

@@ -163,3 +163,55 @@ def test_nan_input_is_reported_not_hidden(ctx):
     s2 = algo.update(s1)
     assert s2.general.status == ga.FittingStatuses.ModelFlexibilityError
     algo.close()
+
+
+# ------------------------------------------------------------------------------------------ exact-zero tile culling
+@pytest.mark.parametrize("sigma2,w", [(1.0, 0.1), (0.25, 0.3), (30.0, 0.0)])
+def test_tile_culling_is_bit_identical(sigma2, w):
+    """Model rows and targets live in Morton order on the device and tile pairs whose every K underflows to exactly +0 are
+    skipped.  Skipping must not change a single bit: compare against a context created with GINGR_CULL=0."""
+    import os
+    import gingr_amd as ga
+    mo, rng = synth_model(6000, 24, seed=77, spread=60.0)
+    target = (mo.ref + rng.normal(0, 0.4, mo.ref.shape))[rng.permutation(mo.M)[:5500]]
+    results = []
+    for cull in ("1", "0"):
+        os.environ["GINGR_CULL"] = cull
+        try:
+            c = ga.Context(0)
+        finally:
+            os.environ.pop("GINGR_CULL", None)
+        algo = ga.CpdRegistration(c)
+        state = algo.createInitialState(to_ga(mo), target, ga.CpdConfiguration(maxIterations=10, w=w, initialSigma=sigma2))
+        for _ in range(2):
+            state = algo.update(state)
+        results.append((state.general.fit.copy(), state.general.modelParameters.shape.copy(), state.general.sigma2,
+                        state.general.status))
+        algo.close()
+        c.close()
+    a, b = results
+    assert a[3] == b[3]
+    assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True)
+    assert (a[2] == b[2]) or (np.isnan(a[2]) and np.isnan(b[2]))
+    # and the culled run still matches the oracle
+    st = go.initial_state(mo, sigma2)
+    for _ in range(2):
+        st = go.cpd_update(mo, target, st, w=w, stats=co.cpd_stats(st.fit, target, st.sigma2, w))
+    assert st.status == a[3]
+    if st.status == 0:
+        assert rel(a[0], st.fit) < 1e-5
+
+
+def test_culled_underflow_column_still_fails_like_the_reference(ctx):
+    """w = 0 and a target far from every fit point: den_j = 0, 0/0 = NaN in the reference.  The far tile must not be culled
+    away (that would silently 'repair' the failure)."""
+    import gingr_amd as ga
+    mo, rng = synth_model(3000, 12, seed=78, spread=40.0)
+    far = np.array([[1e4, 1e4, 1e4]]) + rng.normal(0, 1.0, (300, 3))
+    target = np.concatenate([mo.ref + rng.normal(0, 0.2, mo.ref.shape), far])
+    algo = ga.CpdRegistration(ctx)
+    s0 = algo.createInitialState(to_ga(mo), target, ga.CpdConfiguration(maxIterations=5, w=0.0, initialSigma=1.0))
+    s1 = algo.update(s0)
+    s2 = algo.update(s1)
+    assert s1.general.status == ga.FittingStatuses.None_ and s2.general.status == ga.FittingStatuses.ModelFlexibilityError
+    algo.close()
