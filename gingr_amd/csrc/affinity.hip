@@ -505,34 +505,92 @@ __device__ __forceinline__ double norm2_exact(double dx, double dy, double dz) {
     return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
 }
 
-__global__ __launch_bounds__(kBlock) void nn_kernel(Cloud q, Cloud tgt, const int32_t *__restrict__ orig, int64_t cols_per_chunk,
-                                                    double *__restrict__ pd2, int32_t *__restrict__ pidx,
-                                                    int32_t *__restrict__ porig) {
+// One wave per workgroup owns 64 consecutive queries (spatially compact when the fitter keeps clouds in k-d leaf order)
+// and visits the target tiles of its chunk nearest-first; a tile whose bounding box is farther from the wave's box than the
+// worst current best distance of the wave cannot contain a closer (or equally close) point and is skipped -- exact
+// pruning, the result is the same as the full scan including the lowest-original-index tie rule.
+constexpr int kNNThreads = 64;
+
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+
+__global__ __launch_bounds__(kNNThreads) void nn_kernel(Cloud q, Cloud tgt, const int32_t *__restrict__ orig,
+                                                        const double *__restrict__ tgt_boxes, int64_t cols_per_chunk,
+                                                        double *__restrict__ pd2, int32_t *__restrict__ pidx,
+                                                        int32_t *__restrict__ porig) {
     __shared__ P4 tile[kTile];
-    const int tid = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + tid;
+    const int lane = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kNNThreads + lane;
     const bool ok = i < q.n;
     const double qx = ok ? q.x[i] : 0.0, qy = ok ? q.y[i] : 0.0, qz = ok ? q.z[i] : 0.0;
     double best = __builtin_huge_val(), bo = __builtin_huge_val();  // best distance and the ORIGINAL index that holds it
     int32_t bi = -1;
     const int64_t j0 = (int64_t)blockIdx.y * cols_per_chunk;
     const int64_t j1 = min(tgt.n, j0 + cols_per_chunk);
-    for (int64_t jb = j0; jb < j1; jb += kTile) {
-        __syncthreads();
-        const int64_t j = jb + tid;
-        if (j < j1) tile[tid] = P4{tgt.x[j], tgt.y[j], tgt.z[j], (double)(orig ? orig[j] : (int32_t)j)};
-        __syncthreads();
-        const int cnt = (int)min((int64_t)kTile, j1 - jb);
+    const int t0 = (int)(j0 / kTile), nt = (int)((j1 - j0 + kTile - 1) / kTile);
+    // the wave's own bounding box (invalid lanes excluded)
+    Box wb;
+    {
+        double lo[3] = {ok ? qx : __builtin_huge_val(), ok ? qy : __builtin_huge_val(), ok ? qz : __builtin_huge_val()};
+        double hi[3] = {ok ? qx : -__builtin_huge_val(), ok ? qy : -__builtin_huge_val(), ok ? qz : -__builtin_huge_val()};
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                lo[d] = fmin(lo[d], __shfl_xor(lo[d], off));
+                hi[d] = fmax(hi[d], __shfl_xor(hi[d], off));
+            }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            wb.lo[d] = uniform_d(lo[d]);
+            wb.hi[d] = uniform_d(hi[d]);
+        }
+    }
+    // Two sweeps over the chunk's tiles: first the tiles whose box touches the wave's box (they almost always hold the true
+    // neighbours, so `best` becomes small), then all others, each visited only if for at least one lane the tile's box is
+    // not farther from that lane's query than the lane's current best (strict test with a relative rounding margin; a NaN
+    // box or query never prunes).  Ties at equal distance are inside the margin, so the lowest-original-index rule holds.
+    for (int phase = 0; phase < 2; ++phase) {
+        for (int t = 0; t < nt; ++t) {
+            if (tgt_boxes) {
+                const double *bx = tgt_boxes + (int64_t)(t0 + t) * 6;
+                const double g = box_gap2(wb, bx);
+                if (phase == 0) {
+                    if (g > 0.0) continue;
+                } else {
+                    if (!(g > 0.0)) continue;  // visited in the first sweep (also taken for NaN boxes: g is NaN -> not > 0)
+                    const double gx = fmax(fmax(bx[0] - qx, qx - bx[3]), 0.0), gy = fmax(fmax(bx[1] - qy, qy - bx[4]), 0.0),
+                                 gz = fmax(fmax(bx[2] - qz, qz - bx[5]), 0.0);
+                    const double pd = __builtin_fma(gz, gz, __builtin_fma(gy, gy, gx * gx));
+                    const bool need = ok && !(pd > best * (1.0 + 1e-12));
+                    if (!__any(need)) continue;
+                }
+            } else if (phase == 1) {
+                continue;  // no boxes: the first sweep visits everything
+            }
+            const int64_t jb = j0 + (int64_t)t * kTile;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < kTile / kNNThreads; ++u) {
+                const int64_t j = jb + u * kNNThreads + lane;
+                if (j < j1) tile[u * kNNThreads + lane] = P4{tgt.x[j], tgt.y[j], tgt.z[j], (double)(orig ? orig[j] : (int32_t)j)};
+            }
+            __syncthreads();
+            const int cnt = (int)min((int64_t)kTile, j1 - jb);
 #pragma unroll 4
-        for (int jj = 0; jj < cnt; ++jj) {
-            const P4 p = tile[jj];
-            const double d2 = norm2_exact(p.x - qx, p.y - qy, p.z - qz);
-            // strictly closer, or exactly as close with a lower original index: "lowest index wins" independent of the
-            // (spatially sorted) device order
-            if (d2 < best || (d2 == best && p.w < bo)) {
-                best = d2;
-                bo = p.w;
-                bi = (int32_t)(jb + jj);
+            for (int jj = 0; jj < cnt; ++jj) {
+                const P4 p = tile[jj];
+                const double d2 = norm2_exact(p.x - qx, p.y - qy, p.z - qz);
+                // strictly closer, or exactly as close with a lower original index: "lowest index wins" independent of
+                // the (spatially sorted) device order and of the visiting order
+                if (d2 < best || (d2 == best && p.w < bo)) {
+                    best = d2;
+                    bo = p.w;
+                    bi = (int32_t)(jb + jj);
+                }
             }
         }
     }
@@ -678,10 +736,12 @@ int64_t cpd_rowstats_ws_doubles(int64_t M, int64_t N) {
     return a > b ? a : b;
 }
 
+static void plan_nn(int64_t nq, int64_t nt_points, bool pruned, int *nchunks, int64_t *chunk_len);
+
 int64_t nn_ws_bytes(int64_t M, int64_t N) {
     int nch;
     int64_t len;
-    plan_chunks(M, kBlock, N, &nch, &len);
+    plan_nn(M, N, false, &nch, &len);  // the unpruned plan has the most chunks
     return (int64_t)nch * M * (sizeof(double) + 2 * sizeof(int32_t));
 }
 
@@ -746,15 +806,33 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
     hipLaunchKernelGGL(cpd_scalars_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, part, scalars_dev);
 }
 
-void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, void *ws, int32_t *idx, double *d2) {
+static void plan_nn(int64_t nq, int64_t nt_points, bool pruned, int *nchunks, int64_t *chunk_len) {
+    const int64_t bx = ceil_div(nq, kNNThreads);
+    // Splitting the targets into chunks weakens the pruning (a chunk far from the queries has no near tile to shrink the
+    // bound), so with pruning chunks are only used when there are too few query waves to occupy the chip; the full scan
+    // wants ~8 waves per CU.
+    int64_t want = pruned ? (bx >= 256 ? 1 : ceil_div(512, bx > 0 ? bx : 1)) : ceil_div(2048, bx > 0 ? bx : 1);
+    const int64_t max_chunks = ceil_div(nt_points, kTile);
+    if (want > max_chunks) want = max_chunks;
+    if (want < 1) want = 1;
+    int64_t len = round_up(ceil_div(nt_points, want), kTile);
+    if (len < kTile) len = kTile;
+    *chunk_len = len;
+    *nchunks = (int)ceil_div(nt_points > 0 ? nt_points : 1, len);
+}
+
+void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, const double *tgt_boxes, void *ws,
+               int32_t *idx, double *d2) {
     int nch;
     int64_t len;
-    plan_chunks(query.n, kBlock, target.n, &nch, &len);
+    const bool pruned = ctx->cull && tgt_boxes != nullptr;
+    plan_nn(query.n, target.n, pruned, &nch, &len);
     double *pd2 = reinterpret_cast<double *>(ws);
     int32_t *pidx = reinterpret_cast<int32_t *>(pd2 + (int64_t)nch * query.n);
     int32_t *porig = pidx + (int64_t)nch * query.n;
-    dim3 grid((unsigned)ceil_div(query.n, kBlock), (unsigned)nch);
-    hipLaunchKernelGGL(nn_kernel, grid, dim3(kBlock), 0, ctx->stream, query, target, target_orig, len, pd2, pidx, porig);
+    dim3 grid((unsigned)ceil_div(query.n, kNNThreads), (unsigned)nch);
+    hipLaunchKernelGGL(nn_kernel, grid, dim3(kNNThreads), 0, ctx->stream, query, target, target_orig,
+                       pruned ? tgt_boxes : (const double *)nullptr, len, pd2, pidx, porig);
     hipLaunchKernelGGL(nn_reduce_kernel, dim3((unsigned)ceil_div(query.n, 256)), dim3(256), 0, ctx->stream, pd2, pidx, porig,
                        nch, query.n, idx, d2);
 }

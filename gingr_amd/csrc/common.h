@@ -133,7 +133,9 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
                          double *PX_soa, double *part, double *scalars_dev);
 // idx[i] = POSITION (in the device order of `target`) of the nearest target; exact ties are broken by the lowest ORIGINAL
 // index, taken from target_orig[position] (nullptr: the device order is the original order).
-void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, void *ws, int32_t *idx, double *d2);
+// tgt_boxes (nullable): bounding boxes of the 256-point target tiles (launch_tile_bbox) for exact nearest-first pruning.
+void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, const double *tgt_boxes, void *ws,
+               int32_t *idx, double *d2);
 void launch_gauss_block(gingr_ctx *ctx, Cloud A, Cloud B, double sigma, double scaling, double *out);
 void launch_sumsq_pairs(gingr_ctx *ctx, Cloud A, Cloud B, double *ws, double *out_scalar);
 // interleaved xyz (n*3) <-> SoA planes; perm (nullable) maps device position -> original index:

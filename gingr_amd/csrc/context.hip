@@ -250,7 +250,7 @@ int gingr_nn(gingr_ctx *ctx, int64_t M, const double *query, int64_t N, const do
     HIP_TRY(ctx, dws.alloc((size_t)nn_ws_bytes(M, N)));
     HIP_TRY(ctx, didx.alloc(M * sizeof(int32_t)));
     HIP_TRY(ctx, dd2.alloc(M * sizeof(double)));
-    launch_nn(ctx, cq, ct, nullptr, dws.p, didx.as<int32_t>(), dd2.as<double>());
+    launch_nn(ctx, cq, ct, nullptr, nullptr, dws.p, didx.as<int32_t>(), dd2.as<double>());
     GINGR_TRY(check_launch(ctx));
     std::vector<double> hd2((size_t)M);
     if (idx) HIP_TRY(ctx, hipMemcpyAsync(idx, didx.p, M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

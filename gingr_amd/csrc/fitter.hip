@@ -616,7 +616,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
     switch (phase) {
         case 0: {
             if (icp)
-                launch_nn(ctx, fit, tgt, f->tperm, f->ws, f->nn_idx, f->nn_d2);
+                launch_nn(ctx, fit, tgt, f->tperm, f->tboxes, f->ws, f->nn_idx, f->nn_d2);
             else {
                 launch_cloud_absmax(ctx, fit, f->absmax + 2, f->absmax + 1);
                 launch_tile_bbox(ctx, fit, f->fboxes);

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""ICP update rate (point-cloud closest point) on the synthetic 50k <-> 50k workload: one step = nearest-neighbour search +
+GP update.  GINGR_CULL=0 disables the exact nearest-first tile pruning (full brute-force scan)."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401
+import gingr_amd as ga
+from gingr_amd.sharded import ShardedFitter
+from bench import synth_clouds, synth_gpmm
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
+y, x = synth_clouds(M)
+basis, lam = synth_gpmm(y, 100)
+ctx = ga.Context(0)
+f = ShardedFitter(ctx, ga.PointDistributionModel(y, np.zeros_like(y), basis, lam), x)
+f.set_state(np.zeros(100), 100.0)
+f.update_icp(100.0, 1.0, 100, 3)
+ctx.synchronize()
+t0 = time.perf_counter()
+n = 20
+f.update_icp(100.0, 1.0, 100, n)
+ctx.synchronize()
+dt = time.perf_counter() - t0
+a, sc, fit = f.get_state()
+print(json.dumps({"what": "ICP update (nn + GP), synthetic clouds", "points": M, "iterations_per_s": n / dt,
+                  "ms_per_iteration": dt / n * 1e3, "cull": os.environ.get("GINGR_CULL", "1"), "status": sc.status,
+                  "fit_checksum": float(np.abs(fit).sum())}))
