@@ -84,6 +84,10 @@ SIGNATURES = {
     "gingr_fitter_get_icp_idx": (c_int, [c_void_p, _ip, _dp]),
     "gingr_fitter_update_cpd_async": (c_int, [c_void_p, POINTER(CpdParams), c_int32]),
     "gingr_fitter_update_icp_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32]),
+    "gingr_fitter_update_cpd_sample_async": (c_int, [c_void_p, POINTER(CpdParams), _dp]),
+    "gingr_fitter_update_icp_sample_async": (c_int, [c_void_p, POINTER(IcpParams), _dp]),
+    "gingr_fitter_posterior_logpdf_cpd": (c_int, [c_void_p, POINTER(CpdParams), _dp, _dp]),
+    "gingr_fitter_posterior_logpdf_icp": (c_int, [c_void_p, POINTER(IcpParams), _dp, _dp]),
     "gingr_fitter_exchange": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64)]),
     "gingr_fitter_cpd_phase_async": (c_int, [c_void_p, POINTER(CpdParams), c_int32]),
     "gingr_fitter_icp_phase_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32]),

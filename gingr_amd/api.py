@@ -427,21 +427,51 @@ class GingrAlgorithm:
     def initializeState(self, general: GeneralRegistrationState, config):
         raise NotImplementedError
 
-    def update(self, current, probabilistic: bool = False):
+    def update(self, current, probabilistic: bool = False, rnd: Optional[np.random.Generator] = None):
         """One GiNGR iteration.  Numerical failure of the posterior / projections maps to
-        FittingStatuses.ModelFlexibilityError exactly like the reference's Try(...) handling (:194-208,248,251)."""
-        if probabilistic:
-            raise NotImplementedError("posterior sampling (probabilistic=True) is not on the accelerated path yet")
+        FittingStatuses.ModelFlexibilityError exactly like the reference's Try(...) handling (:194-208,248,251).
+        probabilistic=True proposes posterior.sample() instead of posterior.mean (:211); the standard-normal draws come from
+        `rnd` (the reference's `implicit rnd: Random`)."""
         g = current.general
         self._bind(g, current.config.useLandmarkCorrespondence)
         if self._device_state_token != id(current):
             self._push_state(g)
-        self._native_update(current, 1)
+        if probabilistic:
+            if rnd is None:
+                raise ValueError("probabilistic update needs a random generator (rnd)")
+            self._native_update_sample(current, f64(rnd.standard_normal(g.model.rank)))
+        else:
+            self._native_update(current, 1)
         new_general = self._pull_state(g)
         out = current.updateGeneral(new_general)
         self._device_state_token = id(out)
         self._keepalive = out
         return out
+
+    def logTransitionProbability(self, from_state, to_state) -> float:
+        """GeneratorWrapperStochastic.logTransitionProbability (GeneratorWrapperStochastic.scala:42-63): log-density, under
+        the posterior model of `from_state`, of the mesh the reference projects -- from.fit when stepLength == 1, otherwise
+        the unposed instance of the step-compensated coefficients.  -inf when the posterior cannot be computed."""
+        g = from_state.general
+        if g.stepLength != 1.0:
+            a0, a1 = f64(g.modelParameters.shape), f64(to_state.general.modelParameters.shape)
+            comp = a0 + (a1 - a0) / g.stepLength
+            dm = DeviceModel(self.ctx, g.model)
+            try:
+                mesh = dm.instance(comp)
+            finally:
+                dm.close()
+        else:
+            mesh = f64(g.fit)
+        self._bind(g, from_state.config.useLandmarkCorrespondence)
+        self._push_state(g)
+        self._device_state_token = None
+        try:
+            return self._native_logpdf(from_state, mesh)
+        except GingrNativeError as e:
+            if e.code in (nat.ERR_NOT_SPD, nat.ERR_NONFINITE):
+                return float("-inf")
+            raise
 
     def run(self, initialState, callBackLogger: Optional[Callable] = None):
         """Deterministic registration loop (GingrAlgorithm.run, :115-175): the chain yields the initial state first,
@@ -509,6 +539,18 @@ class CpdRegistration(GingrAlgorithm):
         _check(self.ctx.handle, self._lib.gingr_fitter_update_cpd_async(self._fitter, ctypes.byref(p), n),
                "gingr_fitter_update_cpd_async")
 
+    def _native_update_sample(self, current: CpdRegistrationState, z: np.ndarray):
+        p = nat.CpdParams(current.config.w, current.config.lambda_)
+        _check(self.ctx.handle, self._lib.gingr_fitter_update_cpd_sample_async(self._fitter, ctypes.byref(p), dptr(z)),
+               "gingr_fitter_update_cpd_sample_async")
+
+    def _native_logpdf(self, state: CpdRegistrationState, mesh: np.ndarray) -> float:
+        p = nat.CpdParams(state.config.w, state.config.lambda_)
+        out = ctypes.c_double()
+        _check(self.ctx.handle, self._lib.gingr_fitter_posterior_logpdf_cpd(self._fitter, ctypes.byref(p), dptr(mesh),
+                                                                             ctypes.byref(out)), "gingr_fitter_posterior_logpdf_cpd")
+        return out.value
+
     # plugin accessors served from one streaming evaluation (the reference recomputes P for each of them)
     def _stats(self, state: CpdRegistrationState) -> dict:
         if getattr(self, "_stats_key", None) != id(state):
@@ -552,6 +594,20 @@ class IcpRegistration(GingrAlgorithm):
         p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
         _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_async(self._fitter, ctypes.byref(p), n),
                "gingr_fitter_update_icp_async")
+
+    def _native_update_sample(self, current: IcpRegistrationState, z: np.ndarray):
+        c = current.config
+        p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
+        _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_sample_async(self._fitter, ctypes.byref(p), dptr(z)),
+               "gingr_fitter_update_icp_sample_async")
+
+    def _native_logpdf(self, state: IcpRegistrationState, mesh: np.ndarray) -> float:
+        c = state.config
+        p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
+        out = ctypes.c_double()
+        _check(self.ctx.handle, self._lib.gingr_fitter_posterior_logpdf_icp(self._fitter, ctypes.byref(p), dptr(mesh),
+                                                                             ctypes.byref(out)), "gingr_fitter_posterior_logpdf_icp")
+        return out.value
 
     def getCorrespondence(self, state: IcpRegistrationState) -> CorrespondencePairs:
         idx, _, _ = self.ctx.nn(state.general.fit, state.general.target)              # ICP.scala:36-52

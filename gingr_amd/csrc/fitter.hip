@@ -24,6 +24,8 @@ struct gingr_fitter {
     double *nn_d2 = nullptr;
     double *weight = nullptr, *evec = nullptr, *newshape = nullptr;
     double *alpha = nullptr, *acoef = nullptr, *alpha_c = nullptr, *zbuf = nullptr;
+    double *zrand = nullptr;     // [rp] standard-normal draws of a probabilistic update (posterior.sample())
+    bool zrand_active = false;
     DevState *st = nullptr;
     DevPose *pose = nullptr;
     gingr_state_scalars *hs_dev = nullptr;
@@ -307,7 +309,7 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
         (rc = dev_alloc(ctx, &f->nn_d2, (size_t)M)) || (rc = dev_alloc(ctx, &f->weight, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->evec, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->newshape, (size_t)3 * M)) ||
         (rc = dev_alloc(ctx, &f->alpha, (size_t)rp)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
-        (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->zbuf, (size_t)19 * rp)) || (rc = dev_alloc(ctx, &f->st, 1)) ||
+        (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->zbuf, (size_t)19 * rp)) || (rc = dev_alloc(ctx, &f->zrand, (size_t)rp)) || (rc = dev_alloc(ctx, &f->st, 1)) ||
         (rc = dev_alloc(ctx, &f->pose, 1)) || (rc = dev_alloc(ctx, &f->hs_dev, 1)) ||
         (rc = dev_alloc(ctx, &f->scalars, 8)) || (rc = dev_alloc(ctx, &f->part, GINGR_SCALAR_PART)) || (rc = dev_alloc(ctx, &f->absmax, GINGR_AUX)) || (rc = dev_alloc(ctx, &f->work, (size_t)rp * rp)) ||
         (rc = dev_alloc(ctx, &f->lm_mask, (size_t)M))) {
@@ -342,6 +344,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->acoef);
     dev_free(f->alpha_c);
     dev_free(f->zbuf);
+    dev_free(f->zrand);
     dev_free(f->st);
     dev_free(f->pose);
     dev_free(f->hs_dev);
@@ -646,7 +649,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
             break;
         }
         case 2: {
-            launch_posterior_solve(ctx, r, rp, G, rhs, f->work, f->acoef, f->st);
+            launch_posterior_solve(ctx, r, rp, G, rhs, f->zrand_active ? f->zrand : nullptr, f->work, f->acoef, f->st);
             launch_post_matvecs(ctx, m, f->alpha, f->acoef, f->zbuf);
             PostSolveArgs a;
             memset(&a, 0, sizeof(a));
@@ -726,6 +729,99 @@ int gingr_fitter_update_icp_async(gingr_fitter *f, const gingr_icp_params *p, in
         for (int ph = 0; ph < GINGR_NUM_PHASES; ++ph) GINGR_TRY(gingr_fitter_icp_phase_async(f, p, ph));
     }
     return GINGR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ probabilistic proposal
+static int sample_update(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr_icp_params *ip, const double *z) {
+    GINGR_TRY(check_ready(f));
+    gingr_ctx *ctx = f->ctx;
+    if (!z) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "update_sample: z is null");
+    if (f->m->M != f->m->M_total) return gingr_set_error(ctx, GINGR_ERR_STATE, "update_sample: single shard only");
+    const int32_t r = f->m->r, rp = f->m->rp;
+    std::vector<double> zz((size_t)rp, 0.0);
+    memcpy(zz.data(), z, (size_t)r * sizeof(double));
+    HIP_TRY(ctx, hipMemcpyAsync(f->zrand, zz.data(), (size_t)rp * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    f->zrand_active = true;
+    int rc = GINGR_OK;
+    for (int ph = 0; ph < GINGR_NUM_PHASES && rc == GINGR_OK; ++ph)
+        rc = icp ? gingr_fitter_icp_phase_async(f, ip, ph) : gingr_fitter_cpd_phase_async(f, cp, ph);
+    f->zrand_active = false;
+    return rc;
+}
+
+int gingr_fitter_update_cpd_sample_async(gingr_fitter *f, const gingr_cpd_params *p, const double *z) {
+    return sample_update(f, false, p, nullptr, z);
+}
+
+int gingr_fitter_update_icp_sample_async(gingr_fitter *f, const gingr_icp_params *p, const double *z) {
+    return sample_update(f, true, nullptr, p, z);
+}
+
+static int posterior_logpdf(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr_icp_params *ip,
+                            const double *mesh_xyz, double *logpdf) {
+    GINGR_TRY(check_ready(f));
+    gingr_ctx *ctx = f->ctx;
+    const gingr_model *m = f->m;
+    if (!mesh_xyz || !logpdf) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "posterior_logpdf: null argument");
+    if (m->M != m->M_total) return gingr_set_error(ctx, GINGR_ERR_STATE, "posterior_logpdf: single shard only");
+    if (m->r > 128) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "posterior_logpdf: rank > 128 not supported");
+    const int64_t M = m->M;
+    const int32_t r = m->r, rp = m->rp;
+    // posterior of the current state: correspondences, Gram, right-hand side (phases 0 and 1 do not touch the state)
+    for (int ph = 0; ph < 2; ++ph) GINGR_TRY(icp ? gingr_fitter_icp_phase_async(f, ip, ph) : gingr_fitter_cpd_phase_async(f, cp, ph));
+    double *G = f->xch + f->off[1];
+    double *rhs = G + (int64_t)rp * rp;
+    // the solve flags failures in st->err, which belongs to the update in flight: save / restore it around this query
+    DevState before;
+    HIP_TRY(ctx, hipMemcpyAsync(&before, f->st, sizeof(before), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    launch_posterior_solve(ctx, r, rp, G, rhs, nullptr, f->work, f->acoef, f->st);
+    // Q0^T e with e = R^T(mesh - c - t) - (ref - c) - mean in the pose of the state
+    DevBuf out2;
+    HIP_TRY(ctx, out2.alloc(2 * sizeof(double)));
+    double *aos = reinterpret_cast<double *>(f->aos);
+    HIP_TRY(ctx, hipMemcpyAsync(aos, mesh_xyz, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    launch_aos_to_soa(ctx, aos, M, f->newshape, m->perm);
+    DevPose hp;
+    memcpy(hp.R, before.R, sizeof(hp.R));
+    memcpy(hp.euler, before.euler, sizeof(hp.euler));
+    memcpy(hp.t, before.t, sizeof(hp.t));
+    memcpy(hp.center, before.center, sizeof(hp.center));
+    hp.scale = 1.0;
+    HIP_TRY(ctx, hipMemcpyAsync(f->pose, &hp, sizeof(hp), hipMemcpyHostToDevice, ctx->stream));
+    SweepArgs a = base_args(f);
+    a.shape_in = f->newshape;
+    a.out = f->alpha_c;
+    launch_sweep(ctx, SWEEP_PROJ2, a);
+    GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, m->mom + MomentLayout{rp}.stot(), f->alpha_c, f->acoef, out2.as<double>()));
+    GINGR_TRY(check_launch(ctx));
+    double res[2] = {0, 0};
+    DevState after;
+    HIP_TRY(ctx, hipMemcpyAsync(res, out2.p, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&after, f->st, sizeof(after), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int32_t err = after.err;
+    if (after.err != before.err) {
+        after.err = before.err;
+        HIP_TRY(ctx, hipMemcpy(f->st, &after, sizeof(after), hipMemcpyHostToDevice));
+    }
+    if (err) return gingr_set_error(ctx, err, "posterior_logpdf: posterior of the current state failed");
+    if (!std::isfinite(res[0])) return gingr_set_error(ctx, GINGR_ERR_NONFINITE, "posterior_logpdf: non-finite result");
+    *logpdf = res[0];
+    return GINGR_OK;
+}
+
+int gingr_fitter_posterior_logpdf_cpd(gingr_fitter *f, const gingr_cpd_params *p, const double *mesh_xyz, double *logpdf) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    if (!p || !(p->w >= 0.0 && p->w < 1.0) || !(p->lambda > 0.0))
+        return gingr_set_error(f->ctx, GINGR_ERR_BAD_ARGUMENT, "cpd params: need 0 <= w < 1 and lambda > 0");
+    return posterior_logpdf(f, false, p, nullptr, mesh_xyz, logpdf);
+}
+
+int gingr_fitter_posterior_logpdf_icp(gingr_fitter *f, const gingr_icp_params *p, const double *mesh_xyz, double *logpdf) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    if (!p || p->max_iterations < 1) return gingr_set_error(f->ctx, GINGR_ERR_BAD_ARGUMENT, "icp params: max_iterations < 1");
+    return posterior_logpdf(f, true, nullptr, p, mesh_xyz, logpdf);
 }
 
 // ===================================================================================== stateless model operators
@@ -849,7 +945,7 @@ int gingr_model_posterior_mean(gingr_ctx *ctx, const gingr_model *model, const d
         a.out = rhs;
         launch_sweep(ctx, SWEEP_RHS, a);
         launch_landmarks(ctx, model, f->st, f->n_lm, f->lm_pid, f->lm_xyz, f->lm_cov, Gd, rhs);
-        launch_posterior_solve(ctx, r, rp, Gd, rhs, f->work, f->acoef, f->st);
+        launch_posterior_solve(ctx, r, rp, Gd, rhs, nullptr, f->work, f->acoef, f->st);
         SweepArgs b = base_args(f);
         b.coef0 = f->acoef;
         b.shape_out = f->newshape;

@@ -565,16 +565,21 @@ __device__ bool block_cholesky(double *A, int r, int ld) {
 
 __global__ __launch_bounds__(kDenseThreads) void posterior_solve_kernel(int r, int rp, const double *__restrict__ G,
                                                                         const double *__restrict__ rhs,
+                                                                        const double *__restrict__ zrand,
                                                                         double *__restrict__ work, double *__restrict__ a,
                                                                         DevState *__restrict__ st) {
     __shared__ double y[512];
+    __shared__ double y2[512];
     __shared__ int bad;
     // Mm = QtL Q + I     (scalismo genericRegressionComputations)
     for (int idx = threadIdx.x; idx < r * r; idx += blockDim.x) {
         const int i = idx / r, j = idx - i * r;
         work[i * rp + j] = G[i * rp + j] + (i == j ? 1.0 : 0.0);
     }
-    for (int k = threadIdx.x; k < rp; k += blockDim.x) y[k] = k < r ? rhs[k] : 0.0;
+    for (int k = threadIdx.x; k < rp; k += blockDim.x) {
+        y[k] = k < r ? rhs[k] : 0.0;
+        y2[k] = (k < r && zrand) ? zrand[k] : 0.0;
+    }
     if (threadIdx.x == 0) bad = 0;
     __syncthreads();
     const bool ok = block_cholesky(work, r, rp);
@@ -594,8 +599,17 @@ __global__ __launch_bounds__(kDenseThreads) void posterior_solve_kernel(int r, i
         for (int i = threadIdx.x; i < k; i += blockDim.x) y[i] -= work[k * rp + i] * yk;
         __syncthreads();
     }
+    if (zrand) {  // sampling direction: L^T w = z
+        for (int k = r - 1; k >= 0; --k) {
+            if (threadIdx.x == 0) y2[k] /= work[k * rp + k];
+            __syncthreads();
+            const double yk = y2[k];
+            for (int i = threadIdx.x; i < k; i += blockDim.x) y2[i] -= work[k * rp + i] * yk;
+            __syncthreads();
+        }
+    }
     for (int k = threadIdx.x; k < rp; k += blockDim.x) {
-        const double v = k < r ? y[k] : 0.0;
+        const double v = k < r ? y[k] + y2[k] : 0.0;
         a[k] = v;
         if (!finite_d(v)) bad = 1;
     }
@@ -622,35 +636,35 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-__global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp, const double *__restrict__ G,
-                                                                  const double *__restrict__ rhs, double *__restrict__ a,
-                                                                  DevState *__restrict__ st) {
-    extern __shared__ double sm[];
-    const int ld = r | 1;  // odd leading dimension: column walks hit distinct banks
-    double *A = sm;
-    double *y = sm + (size_t)r * ld;
-    double *rd = y + r;  // reciprocal diagonal of L
-    __shared__ int bad_spd;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) bad_spd = 0;
-    // Mm = QtL Q + I     (scalismo genericRegressionComputations).  G was produced on other CUs, so every load is an L2 /
-    // fabric round trip: issue them in independent batches of 8 per thread instead of one dependent loop.
+// ---- building blocks (all threads of a 256-thread workgroup call them; A is r x r in LDS with odd leading dimension ld) ----
+
+// A (lower triangle) = ca * G + cs * S + ci * I from global r x rp matrices (S may be nullptr).  G / S were produced on other
+// CUs, so every load is an L2 / fabric round trip: issue them in independent batches of 8 per thread.
+__device__ void lds_load_spd(double *A, int ld, int r, int rp, const double *__restrict__ G, double ca,
+                             const double *__restrict__ S, double cs, double ci) {
+    const int tid = threadIdx.x;
     for (int base = 0; base < r * rp; base += 256 * 8) {
         double v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int idx = base + u * 256 + tid;
-            v[u] = idx < r * rp ? G[idx] : 0.0;
+            double t = idx < r * rp ? ca * G[idx] : 0.0;
+            if (S && idx < r * rp) t = __builtin_fma(cs, S[idx], t);
+            v[u] = t;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int idx = base + u * 256 + tid;
             const int i = idx / rp, j = idx - i * rp;
-            if (idx < r * rp && j <= i) A[i * ld + j] = v[u] + (i == j ? 1.0 : 0.0);
+            if (idx < r * rp && j <= i) A[i * ld + j] = v[u] + (i == j ? ci : 0.0);
         }
     }
-    for (int k = tid; k < r; k += 256) y[k] = rhs[k];
     __syncthreads();
+}
+
+// in-place blocked Cholesky (lower); rd[k] = 1 / L[k][k]; *bad_spd (LDS) is set on a non-positive / non-finite pivot
+__device__ void lds_cholesky(double *A, int ld, int r, double *rd, int *bad_spd) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int kb = 0; kb < r; kb += kNB) {
         const int nb = min(kNB, r - kb);
         // (1) diagonal block in registers, wave 0: lane i holds row i (columns 0..i)
@@ -667,15 +681,13 @@ __global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp,
                     bad = 1;
                     d = 1.0;
                 }
-                // 1/sqrt(d) by v_rsq_f64 + two Newton steps, sqrt(d) = d * rsqrt(d) + one residual correction: the IEEE
-                // sqrt and divide sequences are ~40 dependent instructions and sit on the sequential chain of every column
+                // 1/sqrt(d) by v_rsq_f64 + two Newton steps; lane c's own element d * rsqrt(d) is sqrt(d): the IEEE sqrt and
+                // divide sequences are ~40 dependent instructions and would sit on the sequential chain of every column
                 double rdk = __builtin_amdgcn_rsq(d);
                 const double hd = 0.5 * d;
                 rdk = rdk * __builtin_fma(-hd * rdk, rdk, 1.5);
                 rdk = rdk * __builtin_fma(-hd * rdk, rdk, 1.5);
-                double dk = d * rdk;
-                dk = __builtin_fma(0.5 * rdk, __builtin_fma(-dk, dk, d), dk);
-                const double lc = (lane == c) ? dk : row[c] * rdk;
+                const double lc = row[c] * rdk;
                 row[c] = lc;
 #pragma unroll
                 for (int j = c + 1; j < kNB; ++j) {
@@ -691,7 +703,7 @@ __global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp,
                 for (int k = 0; k < kNB; ++k)
                     if (k == lane) rd[kb + lane] = 1.0 / row[k];
             }
-            if (bad && lane == 0) bad_spd = 1;
+            if (bad && lane == 0) *bad_spd = 1;
         }
         __syncthreads();
         // (2) panel below the diagonal block: x L11^T = A[i][kb:kb+nb]
@@ -730,7 +742,11 @@ __global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp,
         }
         __syncthreads();
     }
-    // L z = rhs (blocked): the 16x16 triangular solve runs in registers of wave 0
+}
+
+// y <- L^-1 y (blocked; the 16x16 triangular solves run in registers of wave 0)
+__device__ void lds_forward(const double *A, int ld, int r, const double *rd, double *y) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int kb = 0; kb < r; kb += kNB) {
         const int nb = min(kNB, r - kb);
         if (wave == 0) {
@@ -757,7 +773,11 @@ __global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp,
         }
         __syncthreads();
     }
-    // L^T a = z (blocked, bottom up): lane c holds column c of the diagonal block
+}
+
+// y <- L^-T y (blocked, bottom up: lane c holds column c of the diagonal block)
+__device__ void lds_backward(const double *A, int ld, int r, const double *rd, double *y) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int kb = ((r - 1) / kNB) * kNB; kb >= 0; kb -= kNB) {
         const int nb = min(kNB, r - kb);
         if (wave == 0) {
@@ -784,11 +804,39 @@ __global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp,
         }
         __syncthreads();
     }
-    __shared__ int bad;
-    if (tid == 0) bad = 0;
-    __syncthreads();
+}
+
+// a = (I + G)^-1 rhs; with zrand != nullptr a posterior SAMPLE of the coefficients: a + L^-T z, z ~ N(0, I)
+// (Cov = L^-T L^-1 = (I + G)^-1, the posterior covariance of the coefficients: the same distribution as
+//  posterior.sample() of scalismo's SVD-parameterised posterior model, G/api/GingrAlgorithm.scala:211).
+__global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp, const double *__restrict__ G,
+                                                                  const double *__restrict__ rhs,
+                                                                  const double *__restrict__ zrand, double *__restrict__ a,
+                                                                  DevState *__restrict__ st) {
+    extern __shared__ double sm[];
+    const int ld = r | 1;  // odd leading dimension: column walks hit distinct banks
+    double *A = sm;
+    double *y = sm + (size_t)r * ld;
+    double *rd = y + r;   // reciprocal diagonal of L
+    double *y2 = rd + r;  // sampling direction
+    __shared__ int bad_spd, bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        bad_spd = 0;
+        bad = 0;
+    }
+    for (int k = tid; k < r; k += 256) {
+        y[k] = rhs[k];
+        y2[k] = zrand ? zrand[k] : 0.0;
+    }
+    // Mm = QtL Q + I     (scalismo genericRegressionComputations)
+    lds_load_spd(A, ld, r, rp, G, 1.0, nullptr, 0.0, 1.0);
+    lds_cholesky(A, ld, r, rd, &bad_spd);
+    lds_forward(A, ld, r, rd, y);
+    lds_backward(A, ld, r, rd, y);
+    if (zrand) lds_backward(A, ld, r, rd, y2);
     for (int k = tid; k < rp; k += 256) {
-        const double v = k < r ? y[k] : 0.0;
+        const double v = k < r ? y[k] + y2[k] : 0.0;
         a[k] = v;
         if (!finite_d(v)) bad = 1;
     }
@@ -798,6 +846,60 @@ __global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp,
             st->err = GINGR_ERR_NOT_SPD;
         else if (bad)
             st->err = GINGR_ERR_NONFINITE;
+    }
+}
+
+// log-density of a mesh under the posterior model in scalismo's parameterisation:
+//   posterior.gp.logpdf(posterior.coefficients(mesh))   (G/api/sampling/generators/GeneratorWrapperStochastic.scala:42-63)
+// With N = Q0' L^-T (any square root of the posterior covariance gives the same norm) the ridge-regression coefficients are
+//   c = (N^T N + eps I)^-1 N^T d = L^T (S_tot + eps (I + G))^-1 b,   b = Q0^T e - S_tot a,
+// e = R^T(mesh - c - t) - (ref - c) - mean (model frame residual), a = posterior coefficients;  logpdf = -|c|^2/2 - r/2 log(2 pi).
+__global__ __launch_bounds__(256) void posterior_logpdf_lds_kernel(int r, int rp, const double *__restrict__ G,
+                                                                   const double *__restrict__ Stot,
+                                                                   const double *__restrict__ qte,
+                                                                   const double *__restrict__ a, double *__restrict__ out2) {
+    extern __shared__ double sm[];
+    const int ld = r | 1;
+    double *A = sm;
+    double *u = sm + (size_t)r * ld;
+    double *rd = u + r;
+    double *cv = rd + r;
+    __shared__ int bad_spd;
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    if (tid == 0) bad_spd = 0;
+    // b = Q0^T e - S_tot a
+    for (int k = tid; k < r; k += 256) {
+        double s = qte[k];
+        for (int j = 0; j < r; ++j) s = __builtin_fma(-Stot[(int64_t)j * rp + k], a[j], s);  // S_tot symmetric: coalesced
+        u[k] = s;
+    }
+    lds_load_spd(A, ld, r, rp, G, GINGR_COEFF_NOISE, Stot, 1.0, GINGR_COEFF_NOISE);  // S_tot + eps (I + G)
+    lds_cholesky(A, ld, r, rd, &bad_spd);
+    lds_forward(A, ld, r, rd, u);
+    lds_backward(A, ld, r, rd, u);
+    __syncthreads();
+    // c = L^T u with L the factor of I + G
+    lds_load_spd(A, ld, r, rp, G, 1.0, nullptr, 0.0, 1.0);
+    lds_cholesky(A, ld, r, rd, &bad_spd);
+    for (int k = tid; k < r; k += 256) {
+        double s = 0.0;
+        for (int i = k; i < r; ++i) s = __builtin_fma(A[i * ld + k], u[i], s);
+        cv[k] = s;
+    }
+    __syncthreads();
+    double part = 0.0;
+    for (int k = tid; k < r; k += 256) part = __builtin_fma(cv[k], cv[k], part);
+    red[tid] = part;
+    __syncthreads();
+    for (int st2 = 128; st2 > 0; st2 >>= 1) {
+        if (tid < st2) red[tid] += red[tid + st2];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double n2 = red[0];
+        out2[0] = bad_spd ? __builtin_nan("") : -0.5 * n2 - 0.5 * (double)r * 1.8378770664093454836;  // log(2 pi)
+        out2[1] = n2;
     }
 }
 
@@ -1377,19 +1479,31 @@ void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, 
                        (int)n_lm, lm_pid_local, lm_xyz, lm_cov, G, rhs);
 }
 
-void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, double *work,
-                            double *a, DevState *st) {
+void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *zrand,
+                            double *work, double *a, DevState *st) {
     TimerScope ts(ctx, 5);
     if (r <= 128) {
-        const size_t lds = ((size_t)r * (r | 1) + 2 * r) * sizeof(double);
+        const size_t lds = ((size_t)r * (r | 1) + 3 * r) * sizeof(double);
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_solve_lds_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(posterior_solve_lds_kernel, dim3(1), dim3(256), lds, ctx->stream, (int)r, (int)rp, G, rhs, a, st);
+        hipLaunchKernelGGL(posterior_solve_lds_kernel, dim3(1), dim3(256), lds, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a,
+                           st);
         return;
     }
-    hipLaunchKernelGGL(posterior_solve_kernel, dim3(1), dim3(kDenseThreads), 0, ctx->stream, (int)r, (int)rp, G, rhs, work, a,
-                       st);
+    hipLaunchKernelGGL(posterior_solve_kernel, dim3(1), dim3(kDenseThreads), 0, ctx->stream, (int)r, (int)rp, G, rhs, zrand, work,
+                       a, st);
+}
+
+int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *Stot, const double *qte,
+                            const double *a, double *out2) {
+    if (r > 128) return GINGR_ERR_BAD_ARGUMENT;  // LDS-resident implementation only
+    const size_t lds = ((size_t)r * (r | 1) + 3 * r) * sizeof(double);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_lds_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(posterior_logpdf_lds_kernel, dim3(1), dim3(256), lds, ctx->stream, (int)r, (int)rp, G, Stot, qte, a, out2);
+    return GINGR_OK;
 }
 
 void launch_binv(gingr_ctx *ctx, int32_t r, int32_t rp, const double *S, double *work, double *Binv, int32_t *err_flag) {

@@ -191,6 +191,20 @@ int gingr_fitter_get_icp_idx(gingr_fitter *f, int32_t *idx, double *d2);
 int gingr_fitter_update_cpd_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t n_iterations);
 int gingr_fitter_update_icp_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations);
 
+/* ---- probabilistic proposal (single shard) ------------------------------------------------
+ * update(current, probabilistic = true): the shape proposal is posterior.sample() instead of posterior.mean
+ * (G/api/GingrAlgorithm.scala:211).  z[r] are standard-normal draws from the HOST's random generator (the JVM's
+ * scalismo.utils.Random there, numpy here); the sample is a + L^-T z with L L^T = I + Q^T L Q, which has exactly the
+ * distribution of scalismo's SVD-parameterised posterior sample.  One iteration per call. */
+int gingr_fitter_update_cpd_sample_async(gingr_fitter *f, const gingr_cpd_params *p, const double *z);
+int gingr_fitter_update_icp_sample_async(gingr_fitter *f, const gingr_icp_params *p, const double *z);
+/* posterior(of the fitter's CURRENT state).gp.logpdf(posterior.coefficients(mesh)): the quantity
+ * GeneratorWrapperStochastic.logTransitionProbability evaluates (G/api/sampling/generators/GeneratorWrapperStochastic.scala:42-63).
+ * mesh_xyz[3*M]; the state is not modified.  rank <= 128.  A failed posterior gives GINGR_ERR_NOT_SPD / _NONFINITE
+ * (the reference returns -infinity in that case). */
+int gingr_fitter_posterior_logpdf_cpd(gingr_fitter *f, const gingr_cpd_params *p, const double *mesh_xyz, double *logpdf);
+int gingr_fitter_posterior_logpdf_icp(gingr_fitter *f, const gingr_icp_params *p, const double *mesh_xyz, double *logpdf);
+
 /* ---- row-sharded update, host-driven exchange (multi-GPU) -----------------------------------------------------
  * One iteration = phases 0..GINGR_NUM_PHASES-1.  After phase p < GINGR_NUM_SEGMENTS the host all-reduces (sum, float64)
  * exchange segment p across shards (RCCL over xGMI via torch.distributed, or nothing for one shard), then runs phase p+1.

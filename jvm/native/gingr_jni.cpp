@@ -114,6 +114,28 @@ JFN(jint, fitterUpdateIcp)(JNIEnv *, jclass, jlong f, jdouble initialSigma, jdou
     gingr_icp_params p{initialSigma, endSigma, maxIterations};
     return gingr_fitter_update_icp_async(P<gingr_fitter>(f), &p, n);
 }
+JFN(jint, fitterUpdateCpdSample)(JNIEnv *env, jclass, jlong f, jdouble w, jdouble lambda, jdoubleArray z) {
+    gingr_cpd_params p{w, lambda};
+    Pin a(env, z, true);
+    return gingr_fitter_update_cpd_sample_async(P<gingr_fitter>(f), &p, a.as<double>());
+}
+JFN(jint, fitterUpdateIcpSample)(JNIEnv *env, jclass, jlong f, jdouble initialSigma, jdouble endSigma, jint maxIterations,
+                                 jdoubleArray z) {
+    gingr_icp_params p{initialSigma, endSigma, maxIterations};
+    Pin a(env, z, true);
+    return gingr_fitter_update_icp_sample_async(P<gingr_fitter>(f), &p, a.as<double>());
+}
+JFN(jint, fitterPosteriorLogpdfCpd)(JNIEnv *env, jclass, jlong f, jdouble w, jdouble lambda, jdoubleArray mesh, jdoubleArray out) {
+    gingr_cpd_params p{w, lambda};
+    Pin a(env, mesh, true), b(env, out, false);
+    return gingr_fitter_posterior_logpdf_cpd(P<gingr_fitter>(f), &p, a.as<double>(), b.as<double>());
+}
+JFN(jint, fitterPosteriorLogpdfIcp)(JNIEnv *env, jclass, jlong f, jdouble initialSigma, jdouble endSigma, jint maxIterations,
+                                    jdoubleArray mesh, jdoubleArray out) {
+    gingr_icp_params p{initialSigma, endSigma, maxIterations};
+    Pin a(env, mesh, true), b(env, out, false);
+    return gingr_fitter_posterior_logpdf_icp(P<gingr_fitter>(f), &p, a.as<double>(), b.as<double>());
+}
 JFN(jint, fitterGetState)(JNIEnv *env, jclass, jlong f, jdoubleArray alpha, jdoubleArray pose, jintArray iterStatus, jdoubleArray fit) {
     gingr_state_scalars s;
     int rc;

@@ -41,6 +41,13 @@ public final class GingrHipNative {
     public static native int fitterSetState(long fitter, double[] alpha, double[] poseScalars11, int iteration, int status);
     public static native int fitterUpdateCpd(long fitter, double w, double lambda, int nIterations);
     public static native int fitterUpdateIcp(long fitter, double initialSigma, double endSigma, int maxIterations, int nIterations);
+    /** probabilistic = true: ONE update whose proposal is posterior.sample(); z = rank standard-normal draws of the JVM's Random */
+    public static native int fitterUpdateCpdSample(long fitter, double w, double lambda, double[] z);
+    public static native int fitterUpdateIcpSample(long fitter, double initialSigma, double endSigma, int maxIterations, double[] z);
+    /** posterior(current state).gp.logpdf(posterior.coefficients(mesh)); out1[0] receives the value */
+    public static native int fitterPosteriorLogpdfCpd(long fitter, double w, double lambda, double[] meshXyz, double[] out1);
+    public static native int fitterPosteriorLogpdfIcp(long fitter, double initialSigma, double endSigma, int maxIterations,
+                                                      double[] meshXyz, double[] out1);
     /** iterStatus2 = { iteration, status }; fitXyz may be null */
     public static native int fitterGetState(long fitter, double[] alpha, double[] poseScalars11, int[] iterStatus2, double[] fitXyz);
 }

@@ -170,13 +170,17 @@ class HipCpdRegistration(device: Int = 0) extends GingrAlgorithm[HipCpdRegistrat
   }
 
   override def update(current: HipCpdRegistrationState, probabilistic: Boolean)(implicit rnd: Random): HipCpdRegistrationState = {
-    if (probabilistic) super.update(current, probabilistic) // posterior sampling stays on the stock path for now
-    else {
-      session.bind(current.general, current.config.useLandmarkCorrespondence)
-      val (alpha, pose, status) =
+    session.bind(current.general, current.config.useLandmarkCorrespondence)
+    val (alpha, pose, status) =
+      if (probabilistic) {
+        // posterior.sample(): the native side maps rank standard-normal draws of THIS chain's Random through L^-T
+        val z = Array.fill(current.general.model.rank)(rnd.scalaRandom.nextGaussian())
+        session.updateOnce(current.general, f => GingrHipNative.fitterUpdateCpdSample(f, current.config.w, current.config.lambda, z))
+      } else
         session.updateOnce(current.general, f => GingrHipNative.fitterUpdateCpd(f, current.config.w, current.config.lambda, 1))
-      current.updateGeneral(HipStateUpdate(current.general, alpha, pose, status))
-    }
+    // the probabilistic retry counter (GingrAlgorithm.scala:196-202) is private to the trait; a failed sampled proposal is
+    // reported as ModelFlexibilityError like a failed deterministic one
+    current.updateGeneral(HipStateUpdate(current.general, alpha, pose, status))
   }
   override def close(): Unit = session.close()
 }
@@ -210,14 +214,15 @@ class HipIcpRegistration(device: Int = 0) extends GingrAlgorithm[HipIcpRegistrat
   }
 
   override def update(current: HipIcpRegistrationState, probabilistic: Boolean)(implicit rnd: Random): HipIcpRegistrationState = {
-    if (probabilistic) super.update(current, probabilistic)
-    else {
-      session.bind(current.general, current.config.useLandmarkCorrespondence)
-      val c = current.config
-      val (alpha, pose, status) =
+    session.bind(current.general, current.config.useLandmarkCorrespondence)
+    val c = current.config
+    val (alpha, pose, status) =
+      if (probabilistic) {
+        val z = Array.fill(current.general.model.rank)(rnd.scalaRandom.nextGaussian())
+        session.updateOnce(current.general, f => GingrHipNative.fitterUpdateIcpSample(f, c.initialSigma, c.endSigma, c.maxIterations, z))
+      } else
         session.updateOnce(current.general, f => GingrHipNative.fitterUpdateIcp(f, c.initialSigma, c.endSigma, c.maxIterations, 1))
-      current.updateGeneral(HipStateUpdate(current.general, alpha, pose, status))
-    }
+    current.updateGeneral(HipStateUpdate(current.general, alpha, pose, status))
   }
   override def close(): Unit = session.close()
 }

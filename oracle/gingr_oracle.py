@@ -343,6 +343,20 @@ class PDM:
         mean_p = self.mean.reshape(-1) + self.U @ (np.sqrt(self.lam) * a)
         return self.ref + mean_p.reshape(self.M, 3), a
 
+    def posterior_model(self, pids, points, covs) -> "PDM":
+        """The full posterior model of DiscreteLowRankGaussianProcess.regression: mean_p, lambda_p = SVD(D Minv D),
+        U_p = U innerU  (needed by posterior.sample() and posterior.gp.logpdf)."""
+        pids = np.asarray(pids, dtype=np.int64)
+        points = np.asarray(points, dtype=np.float64)
+        covs = np.asarray(covs, dtype=np.float64)
+        disp = points - self.ref[pids]
+        Minv, QtL, yVec, mVec = self._regression(pids, disp, covs)
+        a = (Minv @ QtL) @ (yVec - mVec)
+        mean_p = self.mean.reshape(-1) + self.U @ (np.sqrt(self.lam) * a)
+        D = np.diag(np.sqrt(self.lam))
+        innerU, innerD2, _ = np.linalg.svd(D @ Minv @ D)
+        return PDM(self.ref, mean_p.reshape(self.M, 3), self.U @ innerU, innerD2)
+
     def coefficients(self, mesh: np.ndarray) -> np.ndarray:
         """PointDistributionModel.coefficients(mesh): GP regression at ALL points with noise 1e-5 I3
         (GingrAlgorithm.scala:215,236)."""
@@ -448,13 +462,52 @@ def compute_posterior_mean(model: PDM, st: State, pids, points, variances,
     return mean_mesh, a, posed
 
 
+def gp_logpdf(coefficients: np.ndarray) -> float:
+    """DiscreteLowRankGaussianProcess.logpdf: standard normal log-density of the coefficient vector [SCALISMO]."""
+    c = np.asarray(coefficients, dtype=np.float64)
+    return float(-0.5 * (c @ c) - 0.5 * c.shape[0] * math.log(2.0 * math.pi))
+
+
+def _observations(model: PDM, st: State, pids, points, variances, landmarks: Optional["Landmarks"]):
+    pids = np.asarray(pids, dtype=np.int64)
+    covs = np.asarray(variances, dtype=np.float64)[:, None, None] * np.eye(3)[None]
+    pts = np.asarray(points, dtype=np.float64)
+    if landmarks is not None and landmarks.pids.shape[0] > 0:
+        keep = ~np.isin(pids, landmarks.pids)
+        pids = np.concatenate([pids[keep], landmarks.pids])
+        pts = np.concatenate([pts[keep], landmarks.points])
+        covs = np.concatenate([covs[keep], landmarks.covs])
+    return pids, pts, covs
+
+
+def posterior_logpdf_of_mesh(model: PDM, st: State, pids, points, variances, mesh: np.ndarray,
+                             landmarks: Optional["Landmarks"] = None) -> float:
+    """posterior.gp.logpdf(posterior.coefficients(mesh)) for the posterior of state `st`
+    [REF G/api/sampling/generators/GeneratorWrapperStochastic.scala:42-63]."""
+    pids, pts, covs = _observations(model, st, pids, points, variances, landmarks)
+    posed = model.transform(st.rotation(), st.translation, st.center)
+    post = posed.posterior_model(pids, pts, covs)
+    return gp_logpdf(post.coefficients(mesh))
+
+
 def update_from_observations(model: PDM, st: State, pids, points, variances, sigma2_next: float,
-                             landmarks: Optional[Landmarks] = None) -> State:
+                             landmarks: Optional[Landmarks] = None, z: Optional[np.ndarray] = None) -> State:
     """GingrAlgorithm.update (deterministic branch) given the correspondences (A.5 steps 1-7) followed by
     GingrGeneratorWrapper.propose's fit refresh + iteration++ (step 8,
     G/api/sampling/generators/GingrGeneratorWrapper.scala:28-39)."""
     try:
-        shape, _, posed = compute_posterior_mean(model, st, pids, points, variances, landmarks)   # :193,211
+        shape, a, posed = compute_posterior_mean(model, st, pids, points, variances, landmarks)   # :193,211
+        if z is not None:
+            # probabilistic = true: posterior.sample().  A sample of the coefficient posterior N(a, Mm^-1) is a + L^-T z with
+            # L L^T = Mm; scalismo draws it in its SVD basis (same distribution).  z comes from the caller's generator.
+            op, opts, ocovs = _observations(model, st, pids, points, variances, landmarks)
+            Q = posed.U[(3 * op[:, None] + np.arange(3)[None, :]).reshape(-1)] * np.sqrt(posed.lam)[None, :]
+            QtL = Q.T.copy()
+            for k in range(op.shape[0]):
+                QtL[:, 3 * k:3 * k + 3] = QtL[:, 3 * k:3 * k + 3] @ np.linalg.inv(ocovs[k])
+            L = np.linalg.cholesky(QtL @ Q + np.eye(model.rank))
+            a_s = a + np.linalg.solve(L.T, np.asarray(z, dtype=np.float64))
+            shape = posed.ref + posed.mean + (posed.U @ (np.sqrt(posed.lam) * a_s)).reshape(model.M, 3)
         if not np.all(np.isfinite(shape)):
             raise FloatingPointError("posterior mean not finite")
         alpha1 = posed.coefficients(shape)                                                       # :212-216
@@ -489,7 +542,8 @@ def update_from_observations(model: PDM, st: State, pids, points, variances, sig
 
 
 def cpd_update(model: PDM, target: np.ndarray, st: State, w: float = 0.0, lam: float = 1.0,
-               landmarks: Optional[Landmarks] = None, stats: Optional[CpdStats] = None) -> State:
+               landmarks: Optional[Landmarks] = None, stats: Optional[CpdStats] = None,
+               z: Optional[np.ndarray] = None) -> State:
     """One CPD iteration: correspondences (A.2), uncertainties, posterior, update map, sigma^2 (A.3)."""
     if stats is None:
         stats = cpd_stats_dense(st.fit, target, st.sigma2, w)
@@ -497,7 +551,14 @@ def cpd_update(model: PDM, target: np.ndarray, st: State, w: float = 0.0, lam: f
         yhat = st.fit + (stats.PX * (1.0 / stats.P1)[:, None] - st.fit)
         var = cpd_uncertainty_var(stats.P1, st.sigma2, lam)
     pids = np.arange(model.M)
-    return update_from_observations(model, st, pids, yhat, var, stats.sigma2_next, landmarks)
+    return update_from_observations(model, st, pids, yhat, var, stats.sigma2_next, landmarks, z)
+
+
+def cpd_observations(model: PDM, target: np.ndarray, st: State, w: float = 0.0, lam: float = 1.0):
+    """(pids, points, variances) of the CPD correspondences of state `st` (A.2)."""
+    stats = cpd_stats_dense(st.fit, target, st.sigma2, w)
+    yhat = st.fit + (stats.PX * (1.0 / stats.P1)[:, None] - st.fit)
+    return np.arange(model.M), yhat, cpd_uncertainty_var(stats.P1, st.sigma2, lam)
 
 
 def icp_update(model: PDM, target: np.ndarray, st: State, initial_sigma: float, end_sigma: float,

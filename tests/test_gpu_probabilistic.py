@@ -1,0 +1,121 @@
+"""GPU tests of the probabilistic proposal: update(probabilistic=True) = posterior.sample(), and the
+log transition probability of GeneratorWrapperStochastic, against the oracle's restatement of scalismo's posterior model."""
+import numpy as np
+import pytest
+
+from oracle import gingr_oracle as go
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300))
+
+
+def setup(M=500, rank=28, seed=3, step=1.0, transform=1):
+    import gingr_amd as ga
+    rng = np.random.default_rng(seed)
+    ref = rng.normal(0, 40, (M, 3))
+    mo = go.build_gaussian_gpmm(ref, 60.0, 30.0, rel_tol=1e-9, max_rank=rank)
+    mo.mean = rng.normal(0, 0.2, (M, 3))
+    target = mo.instance(rng.normal(0, 1.0, mo.rank)) @ go.euler_to_rot(0.1, 0.05, -0.08).T + np.array([1.0, 2.0, -1.0])
+    nt = min(450, M - M // 10)
+    target = target[rng.permutation(M)[:nt]] + rng.normal(0, 0.3, (nt, 3))
+    model = ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam)
+    return mo, model, target
+
+
+@pytest.mark.parametrize("algo_name", ["cpd", "icp"])
+def test_sample_update_matches_oracle_with_the_same_draws(ctx, algo_name):
+    import gingr_amd as ga
+    mo, model, target = setup()
+    if algo_name == "cpd":
+        algo, cfg = ga.CpdRegistration(ctx), ga.CpdConfiguration(maxIterations=50, w=0.1)
+    else:
+        algo, cfg = ga.IcpRegistration(ctx), ga.IcpConfiguration(maxIterations=50, initialSigma=30.0, endSigma=1.0)
+    state = algo.createInitialState(model, target, cfg)
+    st = go.initial_state(mo, state.general.sigma2)
+    r1, r2 = np.random.default_rng(99), np.random.default_rng(99)
+    for it in range(3):
+        probabilistic = it != 1                      # mix sampled and mean proposals
+        state = algo.update(state, probabilistic=probabilistic, rnd=r1)
+        z = r2.standard_normal(mo.rank) if probabilistic else None
+        if algo_name == "cpd":
+            st = go.cpd_update(mo, target, st, w=0.1, z=z)
+        else:
+            idx, _, _ = go.icp_closest_point(st.fit, target)
+            s2n = go.icp_update_sigma2(st.sigma2, 30.0, 1.0, 50)
+            st = go.update_from_observations(mo, st, np.arange(mo.M), target[idx], np.full(mo.M, st.sigma2), s2n, None, z)
+        assert state.general.status == st.status == 0
+        assert rel(state.general.fit, st.fit) < 1e-5, (it, rel(state.general.fit, st.fit))
+        assert rel(state.general.modelParameters.shape, st.alpha) < 1e-4
+    # the sampled proposal really differs from the mean proposal
+    s_mean = algo.update(state, probabilistic=False)
+    s_samp = algo.update(state, probabilistic=True, rnd=np.random.default_rng(1))
+    assert rel(s_samp.general.fit, s_mean.general.fit) > 1e-6
+    algo.close()
+
+
+def test_sample_covariance_is_the_posterior_covariance(ctx):
+    """Empirical check of the sampling distribution through the C ABI: with a one-step update map the coefficients of the
+    sampled proposals scatter with covariance close to (I + G)^-1 (here: their projected shape parameters have the oracle's
+    posterior spread); a cheap sanity check that z really enters as L^-T z."""
+    import gingr_amd as ga
+    mo, model, target = setup(M=300, rank=6, seed=8)
+    algo = ga.CpdRegistration(ctx)
+    s0 = algo.createInitialState(model, target[:250], ga.CpdConfiguration(maxIterations=50, w=0.1),
+                                 transform=ga.GlobalTranformationType.NoTransforms)
+    rnd = np.random.default_rng(5)
+    samples = np.array([algo.update(s0, probabilistic=True, rnd=rnd).general.modelParameters.shape for _ in range(400)])
+    mean_prop = algo.update(s0, probabilistic=False).general.modelParameters.shape
+    assert np.allclose(samples.mean(0), mean_prop, atol=4 * samples.std(0).max() / np.sqrt(400) + 1e-6)
+    # oracle covariance of alpha' for sampled proposals: alpha' ~ B S (a + L^-T z) / eps  =>  Cov = J Minv J^T
+    st = go.initial_state(mo, s0.general.sigma2, global_transformation=go.NO_TRANSFORMS)
+    pids, pts, var = go.cpd_observations(mo, target[:250], st, w=0.1)
+    Q = mo.U * np.sqrt(mo.lam)
+    Mm = np.eye(mo.rank) + Q.T @ (Q / np.repeat(var, 3)[:, None])
+    S = Q.T @ Q
+    J = np.linalg.solve(S / 1e-5 + np.eye(mo.rank), S / 1e-5)
+    cov = J @ np.linalg.inv(Mm) @ J.T
+    emp = np.cov(samples.T)
+    assert np.allclose(np.sqrt(np.diag(emp)), np.sqrt(np.diag(cov)), rtol=0.2)
+    algo.close()
+
+
+@pytest.mark.parametrize("step", [1.0, 0.5])
+def test_log_transition_probability(ctx, step):
+    import gingr_amd as ga
+    mo, model, target = setup(seed=13)
+    algo = ga.CpdRegistration(ctx)
+    cfg = ga.CpdConfiguration(maxIterations=50, w=0.05, lambda_=1.5)
+    s0 = algo.createInitialState(model, target, cfg, stepLength=step)
+    s1 = algo.update(s0)
+    s2 = algo.update(s1, probabilistic=True, rnd=np.random.default_rng(2))
+    got = algo.logTransitionProbability(s1, s2)
+    # oracle: posterior of s1, mesh as in GeneratorWrapperStochastic.scala:48-53
+    st = go.initial_state(mo, s0.general.sigma2, step_length=step)
+    st = go.cpd_update(mo, target, st, w=0.05, lam=1.5)
+    assert rel(s1.general.fit, st.fit) < 1e-6
+    if step != 1.0:
+        comp = st.alpha + (s2.general.modelParameters.shape - st.alpha) / step
+        mesh = mo.instance(comp)
+    else:
+        mesh = st.fit
+    want = go.posterior_logpdf_of_mesh(mo, st, *go.cpd_observations(mo, target, st, w=0.05, lam=1.5), mesh=mesh)
+    assert np.isfinite(got) and abs(got - want) < 1e-5 * abs(want), (got, want)
+    # querying must not disturb the chain: the next deterministic update is unchanged
+    a = algo.update(s1).general.fit
+    _ = algo.logTransitionProbability(s1, s2)
+    b = algo.update(s1).general.fit
+    assert np.array_equal(a, b)
+    algo.close()
+
+
+def test_log_transition_probability_of_failed_posterior_is_minus_infinity(ctx):
+    import gingr_amd as ga
+    mo, model, _ = setup(M=200, rank=8, seed=21)
+    target = np.concatenate([mo.ref + mo.mean, [[5000.0, 0, 0]]])
+    algo = ga.CpdRegistration(ctx)
+    s0 = algo.createInitialState(model, target, ga.CpdConfiguration(maxIterations=10, initialSigma=1.0, w=0.0))
+    assert algo.logTransitionProbability(s0, s0) == float("-inf")
+    algo.close()

@@ -254,3 +254,32 @@ def test_golden_update_trajectory_one_step(gold):
     pose = exp["cpd_rigid_it1_pose"]
     assert np.allclose([*st.euler, *st.translation, st.scale, st.sigma2], pose[:8], rtol=1e-8, atol=1e-11)
     assert all(exp[f"{t}_it5_pose"][8] == 0 for t in ("cpd_rigid", "cpd_rigid_lm_w"))
+
+
+# ---------------------------------------------------------------------------------------- posterior sample / logpdf (8f rank 1)
+def test_posterior_model_covariance_and_sampling_square_roots():
+    """scalismo samples the posterior in its SVD basis (U innerU, lambda_p); the HIP path samples a + L^-T z.  Both are square
+    roots of the same coefficient covariance D Minv D, and the coefficient norm used by logpdf is basis independent."""
+    mo, rng = small_model(M=60, rank=12)
+    pids = np.arange(mo.M)
+    obs = mo.instance(rng.normal(0, 1, mo.rank)) + rng.normal(0, 0.3, (mo.M, 3))
+    var = rng.uniform(0.5, 3.0, mo.M)
+    covs = var[:, None, None] * np.eye(3)[None]
+    post = mo.posterior_model(pids, obs, covs)
+    Q = mo.U * np.sqrt(mo.lam)
+    Mm = np.eye(mo.rank) + Q.T @ (Q / np.repeat(var, 3)[:, None])
+    Minv = np.linalg.inv(Mm)
+    cov_scalismo = (post.U * post.lam) @ post.U.T                    # U_p Lambda_p U_p^T
+    assert np.allclose(cov_scalismo, Q @ Minv @ Q.T, atol=1e-9)
+    L = np.linalg.cholesky(Mm)
+    F = np.linalg.solve(L.T, np.eye(mo.rank))                         # L^-T: Cov(a + L^-T z) = Minv
+    assert np.allclose(F @ F.T, Minv, atol=1e-12)
+    # logpdf of a mesh: scalismo's route vs the closed form c = L^T (S + eps Mm)^-1 (Q^T d - S a)
+    mesh = post.instance(rng.normal(0, 1, mo.rank))
+    c_ref = post.coefficients(mesh)
+    S = Q.T @ Q
+    a = Minv @ (Q.T @ ((obs - mo.ref - mo.mean).reshape(-1) / np.repeat(var, 3)))
+    b = Q.T @ (mesh - mo.ref - mo.mean).reshape(-1) - S @ a
+    c_closed = L.T @ np.linalg.solve(S + 1e-5 * Mm, b)
+    assert abs(c_ref @ c_ref - c_closed @ c_closed) < 1e-6 * (c_ref @ c_ref)
+    assert abs(go.gp_logpdf(c_ref) - (-0.5 * c_closed @ c_closed - 0.5 * mo.rank * math.log(2 * math.pi))) < 1e-6 * abs(go.gp_logpdf(c_ref))
