@@ -1,7 +1,11 @@
 // CPD affinity passes with the scaled squared distances produced by the f64 matrix pipe (gfx950).
 //
-// The VALU formulation (affinity.hip) spends 6 of its 15 / 21 f64 instructions per pair on d2 = |x - y|^2.  The matrix
-// pipe is idle in those kernels and runs concurrently with the VALU, so here the exponent argument
+// OPT-IN EXPERIMENT (GINGR_AFFINITY=mfma), parity-green but NOT faster than affinity.hip: measured on gfx950, f64 MFMA and
+// f64 VALU instructions do not overlap (they share the double-precision hardware; profiles/r01_ubench_mfma_valu_overlap.txt),
+// so moving d2 to the matrix pipe only moves the time.  Kept as the evidence for DESIGN.md section 4.
+//
+// The VALU formulation (affinity.hip) spends 6 of its 15 / 19 f64 instructions per pair on d2 = |x - y|^2.  The idea was
+// to produce the exponent argument on the matrix pipe:
 //     t_ij = c*|x_j - y_i|^2 = c|x_j|^2 + c|y_i|^2 - 2c x_j.y_i        (c = -2048 log2(e) / (2 sigma2))
 // is one v_mfma_f64_16x16x4_f64 per 16x16 pair tile: A row = (-2c y, c|y|^2) of the streamed point, B column =
 // (x, 1) of the owned point, C = c|x|^2 (a per-lane constant).  The VALU is left with the exponential only:
