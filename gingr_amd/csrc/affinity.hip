@@ -29,6 +29,12 @@ struct __attribute__((aligned(32))) P4 {
     double x, y, z, w;
 };
 
+// polynomial degree of the exponential in the two CPD passes (fastexp.h): 2 = one FMA less, 2e-13 on K_ij; 3 = 1 ulp
+#ifndef GINGR_CPD_EXP_DEGREE
+#define GINGR_CPD_EXP_DEGREE 2
+#endif
+constexpr int kDeg = GINGR_CPD_EXP_DEGREE;
+
 // ---------------------------------------------------------------- exact-zero culling
 // K_ij = 2^(c d2 / 2048) is flushed to exactly +0 by v_ldexp_f64 once c*d2/2048 < -1076, i.e. d2 > 1491.7 sigma2.  When the
 // bounding boxes of the owned block and of a streamed 256-point tile are farther apart than that (with margin: 1500
@@ -127,7 +133,7 @@ __device__ __forceinline__ void colsum_tile(const P4 *tile, int cnt, const doubl
             const double dx = x[t] - p.x, dy = y[t] - p.y, dz = z[t] - p.z;
             double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
             if (CLAMP) d2 = fmin(d2, lim);
-            acc[t] += fastexp2_scaled(d2, c, T);
+            acc[t] += fastexp2_scaled<kDeg>(d2, c, T);
         }
     }
 }
@@ -149,7 +155,7 @@ __device__ __forceinline__ double exp_from_t(double t, const double *T) {
     const double tm = t + GINGR_EXP_MAGIC;
     const double kf = tm - GINGR_EXP_MAGIC;
     const double f = t - kf;  // exact
-    return fastexp2_core(tm, f, T);
+    return fastexp2_core<kDeg>(tm, f, T);
 }
 
 // tile entries: (-2c y~, c|y~|^2); owned: x~ and n = c|x~|^2
@@ -319,46 +325,51 @@ __global__ __launch_bounds__(256) void cpd_den_finalize_kernel(Cloud tgt, const 
 }
 
 // ---------------------------------------------------------------- pass 2: row statistics
+// tile entries: (x, y, z, 1/den); tw entries: (x, y, z)/den, so that P1 and P.X are four FMAs on K_ij (the product
+// K * (x/den) instead of (K/den) * x: one rounding placed differently, one instruction less per pair)
 template <int PT, bool CLAMP>
-__device__ __forceinline__ void rowstats_tile(const P4 *tile, int cnt, const double (&x)[PT], const double (&y)[PT],
-                                              const double (&z)[PT], double (&a1)[PT], double (&ax)[PT], double (&ay)[PT],
-                                              double (&az)[PT], double c, double lim, const double *T) {
+__device__ __forceinline__ void rowstats_tile(const P4 *tile, const P4 *tw, int cnt, const double (&x)[PT],
+                                              const double (&y)[PT], const double (&z)[PT], double (&a1)[PT],
+                                              double (&ax)[PT], double (&ay)[PT], double (&az)[PT], double c, double lim,
+                                              const double *T) {
 #pragma unroll 2
     for (int jj = 0; jj < cnt; ++jj) {
         const P4 p = tile[jj];
+        const P4 q = tw[jj];
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
             const double dx = p.x - x[t], dy = p.y - y[t], dz = p.z - z[t];
             double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
             if (CLAMP) d2 = fmin(d2, lim);
-            const double pij = fastexp2_scaled(d2, c, T) * p.w;
-            a1[t] += pij;
-            ax[t] = __builtin_fma(pij, p.x, ax[t]);
-            ay[t] = __builtin_fma(pij, p.y, ay[t]);
-            az[t] = __builtin_fma(pij, p.z, az[t]);
+            const double k = fastexp2_scaled<kDeg>(d2, c, T);
+            a1[t] = __builtin_fma(k, p.w, a1[t]);
+            ax[t] = __builtin_fma(k, q.x, ax[t]);
+            ay[t] = __builtin_fma(k, q.y, ay[t]);
+            az[t] = __builtin_fma(k, q.z, az[t]);
         }
     }
 }
 
 // expansion form of pass 2: tile entries (-2c x~, c|x~|^2) + 1/den; owned y~ and n = c|y~|^2.  P.X is accumulated as
 // sum_j p a_j with a_j = -2c x~_j and rescaled once at the end: PX = ctr*P1 - (sum_j p a_j) / (2c).
+// tw entries: (a_j / den_j, 1 / den_j)
 template <int PT>
-__device__ __forceinline__ void rowstats_tile_expand(const P4 *tile, const double *tinv, int cnt, const double (&x)[PT],
+__device__ __forceinline__ void rowstats_tile_expand(const P4 *tile, const P4 *tw, int cnt, const double (&x)[PT],
                                                      const double (&y)[PT], const double (&z)[PT], const double (&n)[PT],
                                                      double (&a1)[PT], double (&ax)[PT], double (&ay)[PT], double (&az)[PT],
                                                      const double *T) {
 #pragma unroll 2
     for (int jj = 0; jj < cnt; ++jj) {
         const P4 p = tile[jj];
-        const double inv = tinv[jj];
+        const P4 q = tw[jj];
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
             const double tt = __builtin_fma(z[t], p.z, __builtin_fma(y[t], p.y, __builtin_fma(x[t], p.x, p.w + n[t])));
-            const double pij = exp_from_t(tt, T) * inv;
-            a1[t] += pij;
-            ax[t] = __builtin_fma(pij, p.x, ax[t]);
-            ay[t] = __builtin_fma(pij, p.y, ay[t]);
-            az[t] = __builtin_fma(pij, p.z, az[t]);
+            const double k = exp_from_t(tt, T);
+            a1[t] = __builtin_fma(k, q.w, a1[t]);
+            ax[t] = __builtin_fma(k, q.x, ax[t]);
+            ay[t] = __builtin_fma(k, q.y, ay[t]);
+            az[t] = __builtin_fma(k, q.z, az[t]);
         }
     }
 }
@@ -372,7 +383,7 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
                                                               double *__restrict__ partial) {
     __shared__ double T[GINGR_EXP_TABLE];
     __shared__ P4 tile[kTile];
-    __shared__ double tinv[kTile];
+    __shared__ P4 tw[kTile];
     __shared__ double shbox[24];
     fastexp_table_init(T);
     const double c = fastexp_scale_for_variance(2.0 * sigma2[0]);
@@ -415,23 +426,27 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
         __syncthreads();
         const int64_t j = jb + tid;
         if (j < j1) {
+            const double inv = inv_den[j];
             if (expand) {
                 const double tx = tgt.x[j] - cx, ty = tgt.y[j] - cy, tz = tgt.z[j] - cz;
-                tile[tid] = P4{m2c * tx, m2c * ty, m2c * tz, c * __builtin_fma(tz, tz, __builtin_fma(ty, ty, tx * tx))};
-                tinv[tid] = inv_den[j];
+                const double ax_ = m2c * tx, ay_ = m2c * ty, az_ = m2c * tz;
+                tile[tid] = P4{ax_, ay_, az_, c * __builtin_fma(tz, tz, __builtin_fma(ty, ty, tx * tx))};
+                tw[tid] = P4{ax_ * inv, ay_ * inv, az_ * inv, inv};
             } else {
-                tile[tid] = P4{tgt.x[j], tgt.y[j], tgt.z[j], inv_den[j]};
+                const double tx = tgt.x[j], ty = tgt.y[j], tz = tgt.z[j];
+                tile[tid] = P4{tx, ty, tz, inv};
+                tw[tid] = P4{tx * inv, ty * inv, tz * inv, inv};
             }
         }
         __syncthreads();
         if (tgt_boxes && !tile_bad[jb / kTile] && box_gap2(wown, tgt_boxes + (jb / kTile) * 6) * (-c) > kCullScaled) continue;
         const int cnt = (int)min((int64_t)kTile, j1 - jb);
         if (expand)
-            rowstats_tile_expand<PT>(tile, tinv, cnt, x, y, z, n, a1, ax, ay, az, T);
+            rowstats_tile_expand<PT>(tile, tw, cnt, x, y, z, n, a1, ax, ay, az, T);
         else if (clamp)
-            rowstats_tile<PT, true>(tile, cnt, x, y, z, a1, ax, ay, az, c, lim, T);
+            rowstats_tile<PT, true>(tile, tw, cnt, x, y, z, a1, ax, ay, az, c, lim, T);
         else
-            rowstats_tile<PT, false>(tile, cnt, x, y, z, a1, ax, ay, az, c, lim, T);
+            rowstats_tile<PT, false>(tile, tw, cnt, x, y, z, a1, ax, ay, az, c, lim, T);
     }
     const int64_t M = fit.n;
     double *base = partial + (int64_t)blockIdx.y * 4 * M;

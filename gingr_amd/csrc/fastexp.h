@@ -13,7 +13,11 @@
 //   2^(f/2048) = 1 + f*q(f),  q = c1 + f*(c2 + f*c3)   (Taylor of exp(f ln2/2048); truncation 3.4e-17 relative)
 //   result = ldexp(fma(T[j], f*q, T[j]), e)
 //
-// Accuracy: <= 1 ulp of the correctly rounded result of its argument; v_ldexp_f64 gives gradual underflow and flushes
+// DEG = 2 variant (the CPD passes): q = c1' + f*c2 with the cubic term economised into c1' (Chebyshev: f^3 ~ 3/16 f on
+// |f| <= 1/2); one FMA less, relative error <= 2.02e-13 -- the same 1e-12 budget on K_ij as the guarded norm expansion,
+// against the 1e-5 bar on vertex positions.  Zero / subnormal / NaN behaviour is identical (it comes from v_ldexp_f64).
+//
+// Accuracy (DEG = 3): <= 1 ulp of the correctly rounded result of its argument; v_ldexp_f64 gives gradual underflow and flushes
 // to +0 below 2^-1075 like Math.exp in the reference (CPD.scala:56).  NaN propagates (tm = NaN -> f = NaN).
 // Range: e is taken from mantissa bits 11..42 of tm, valid for |d2*c| < 2^42 (= 1.5e9 in units of d2/(2 sigma2));
 // callers clamp d2 when the inputs could exceed that (fastexp_needs_clamp).
@@ -27,6 +31,7 @@
 #define GINGR_EXP_C1 3.38450771757785784e-04  /* ln2/2048 */
 #define GINGR_EXP_C2 5.72744624517204032e-08  /* (ln2/2048)^2/2 */
 #define GINGR_EXP_C3 6.46152867293236500e-12  /* (ln2/2048)^3/6 */
+#define GINGR_EXP_C1_D2 3.384507729693224e-04  /* ln2/2048 + (ln2/2048)^3/6 * 3/16: minimax degree 2 on |f| <= 1/2 */
 #define GINGR_EXP_MAGIC 6755399441055744.0    /* 1.5 * 2^52 */
 
 __device__ static const double gingr_exp_table_rom[GINGR_EXP_TABLE] = {
@@ -40,13 +45,19 @@ __device__ __forceinline__ void fastexp_table_init(double *T) {
 }
 
 // 2^(tm - MAGIC + f)/2048 given tm = MAGIC + k and the reduced argument f
+template <int DEG = 3>
 __device__ __forceinline__ double fastexp2_core(double tm, double f, const double *T) {
     const unsigned long long bits = __builtin_bit_cast(unsigned long long, tm);
     const unsigned lo = (unsigned)bits, hi = (unsigned)(bits >> 32);
     const int j = (int)(lo & (GINGR_EXP_TABLE - 1));
     const int e = (int)__builtin_amdgcn_alignbit(hi, lo, GINGR_EXP_TABLE_LOG2);  // bits 11..42: floor(k / 2048)
-    double q = __builtin_fma(f, GINGR_EXP_C3, GINGR_EXP_C2);
-    q = __builtin_fma(f, q, GINGR_EXP_C1);
+    double q;
+    if (DEG == 3) {
+        q = __builtin_fma(f, GINGR_EXP_C3, GINGR_EXP_C2);
+        q = __builtin_fma(f, q, GINGR_EXP_C1);
+    } else {
+        q = __builtin_fma(f, GINGR_EXP_C2, GINGR_EXP_C1_D2);
+    }
     const double tj = T[j];
     const double fq = f * q;
     const double r = __builtin_fma(tj, fq, tj);
@@ -54,11 +65,12 @@ __device__ __forceinline__ double fastexp2_core(double tm, double f, const doubl
 }
 
 // returns 2^(d2*c/2048); requires |d2*c| < 2^42 (see fastexp_needs_clamp)
+template <int DEG = 3>
 __device__ __forceinline__ double fastexp2_scaled(double d2, double c, const double *T) {
     const double tm = __builtin_fma(d2, c, GINGR_EXP_MAGIC);
     const double kf = tm - GINGR_EXP_MAGIC;
     const double f = __builtin_fma(d2, c, -kf);
-    return fastexp2_core(tm, f, T);
+    return fastexp2_core<DEG>(tm, f, T);
 }
 
 // c such that exp(-d2 / two_sigma2) = 2^(d2*c/2048)
