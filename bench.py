@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--points", type=int, default=50000)
     ap.add_argument("--rank", type=int, default=100)
     ap.add_argument("--w", type=float, default=0.1)
+    ap.add_argument("--host-gpmm", action="store_true", help="synthesise the GPMM with numpy on the host and upload it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=3)
     ap.add_argument("--sigma2", type=float, default=0.0,
@@ -142,12 +143,17 @@ def main():
 
     M = N = args.points
     y, x = synth_clouds(M)
-    basis, lam = synth_gpmm(y, args.rank)
-    model = ga.PointDistributionModel(reference=y, mean=np.zeros_like(y), basis=basis, variance=lam)
 
     ctx = ga.Context(local_rank)
     stream = torch.cuda.Stream(device=local_rank)
     ctx.set_stream(stream.cuda_stream)
+    if args.host_gpmm:
+        basis, lam = synth_gpmm(y, args.rank)
+        model = ga.PointDistributionModel(reference=y, mean=np.zeros_like(y), basis=basis, variance=lam)
+    else:
+        # GPMMTriangleMesh3D(reference, tol).Gaussian(sigma, scaling) built in HBM (femur demo kernel,
+        # examples/DemoHelper/DemoDatasetLoader.scala:113-114), stopped at exactly `rank` columns; untimed set-up
+        model = ga.GPMMTriangleMesh3D(ctx, y, relativeTolerance=0.0, maxRank=args.rank).Gaussian(70.0, 50.0)
 
     def all_reduce(t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -8,5 +8,6 @@ from .api import (  # noqa: F401
     Context, CorrespondencePairs, CpdConfiguration, CpdRegistration, CpdRegistrationState, DeviceModel, EulerAngles,
     FittingStatuses, GeneralRegistrationState, GingrAlgorithm, GlobalTranformationType, IcpConfiguration,
     IcpRegistration, IcpRegistrationState, LandmarkCorrespondences, ModelFittingParameters, PointDistributionModel,
+    DevicePointDistributionModel, GaussianKernelParameters, GPMMTriangleMesh3D, PointSetHelper, automaticGPMMfromTemplate,
 )
 from ._native import GingrNativeError  # noqa: F401

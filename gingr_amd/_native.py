@@ -68,6 +68,10 @@ SIGNATURES = {
     "gingr_model_destroy": (None, [c_void_p]),
     "gingr_model_gram_exchange": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),
     "gingr_model_finalize": (c_int, [c_void_p, c_void_p]),
+    "gingr_gpmm_build_gaussian": (c_int, [c_void_p, c_int64, _dp, c_int32, _dp, _dp, c_double, c_int32, c_int64, c_int64,
+                                          POINTER(c_void_p)]),
+    "gingr_pointset_distance_extrema": (c_int, [c_void_p, _dp, c_int64, _dp, _dp]),
+    "gingr_model_download": (c_int, [c_void_p, c_void_p, _dp, _dp, _dp, _dp]),
     "gingr_model_num_points": (c_int64, [c_void_p]),
     "gingr_model_rank": (c_int32, [c_void_p]),
     "gingr_model_instance": (c_int, [c_void_p, c_void_p, _dp, _dp, _dp, _dp, c_double, _dp]),

@@ -150,25 +150,163 @@ class PointDistributionModel:
         return int(self.reference.shape[0])
 
 
-class DeviceModel:
-    """gingr_model: the (row shard of the) model resident in HBM."""
+class DevicePointDistributionModel:
+    """A PointDistributionModel whose basis lives in HBM: the result of the on-device GPMM construction
+    (gingr_gpmm_build_gaussian).  Quacks like PointDistributionModel (reference / mean / basis / variance / rank /
+    numberOfPoints); basis and variance are downloaded lazily, only if somebody asks for them."""
 
-    def __init__(self, ctx: Context, model: PointDistributionModel, row_begin: int = 0, row_end: Optional[int] = None):
+    def __init__(self, ctx: Context, reference, sigmas: Sequence[float], scalings: Sequence[float],
+                 relativeTolerance: float, maxRank: int = 0):
+        self.ctx = ctx
+        self.reference = f64(reference)
+        self._sig, self._sc = f64(sigmas), f64(scalings)
+        self._tol, self._maxrank = float(relativeTolerance), int(maxRank)
+        self._full: Optional["DeviceModel"] = None
+        self._host: Optional[PointDistributionModel] = None
+
+    def _build(self, ctx: Context, row_begin: int, row_end: int):
+        h = c_void_p()
+        _check(ctx.handle, ctx._lib.gingr_gpmm_build_gaussian(ctx.handle, self.numberOfPoints, dptr(self.reference),
+                                                              len(self._sig), dptr(self._sig), dptr(self._sc), self._tol,
+                                                              self._maxrank, row_begin, row_end, ctypes.byref(h)),
+               "gingr_gpmm_build_gaussian")
+        return h
+
+    def device(self) -> "DeviceModel":
+        if self._full is None:
+            M = self.numberOfPoints
+            self._full = DeviceModel._adopt(self.ctx, self._build(self.ctx, 0, M), self, M)
+        return self._full
+
+    @property
+    def numberOfPoints(self) -> int:
+        return int(self.reference.shape[0])
+
+    @property
+    def rank(self) -> int:
+        return self.device().rank
+
+    @property
+    def mean(self) -> np.ndarray:
+        return np.zeros_like(self.reference)       # GaussianProcess(kernel): zero mean (GPMMHelper.scala:45)
+
+    def to_host(self, basis: bool = True) -> PointDistributionModel:
+        if self._host is None or (basis and self._host.basis is None):
+            self._host = self.device().download(basis=basis)
+        return self._host
+
+    @property
+    def variance(self) -> np.ndarray:
+        return self.to_host(basis=False).variance
+
+    @property
+    def basis(self) -> np.ndarray:
+        return self.to_host(basis=True).basis
+
+
+@dataclasses.dataclass
+class GaussianKernelParameters:
+    """GPMMHelper.scala:94"""
+    sigma: float
+    scaling: float
+
+
+class PointSetHelper:
+    """GPMMHelper.scala:73-91: the O(n^2) scans behind the automatic kernel parameters, on the device."""
+
+    def __init__(self, ctx: Context, reference):
+        self.ctx, self.reference = ctx, f64(reference)
+        self._ext: Optional[Tuple[float, float]] = None
+
+    def _extrema(self) -> Tuple[float, float]:
+        if self._ext is None:
+            mx, mn = ctypes.c_double(), ctypes.c_double()
+            _check(self.ctx.handle, self.ctx._lib.gingr_pointset_distance_extrema(
+                self.ctx.handle, dptr(self.reference), self.reference.shape[0], ctypes.byref(mx), ctypes.byref(mn)),
+                "gingr_pointset_distance_extrema")
+            self._ext = (mx.value, mn.value)
+        return self._ext
+
+    def maximumPointDistance(self) -> float:
+        return self._extrema()[0]
+
+    def minimumPointDistance(self) -> float:
+        return self._extrema()[1]
+
+
+class GPMMTriangleMesh3D:
+    """GPMMTriangleMesh3D(reference, relativeTolerance) (GPMMHelper.scala:96-130), Gaussian kernels only."""
+
+    def __init__(self, ctx: Context, reference, relativeTolerance: float = 0.01, maxRank: int = 0):
+        self.ctx, self.reference, self.relativeTolerance, self.maxRank = ctx, f64(reference), relativeTolerance, maxRank
+
+    def Gaussian(self, sigma: float, scaling: float) -> DevicePointDistributionModel:
+        return self.GaussianMixture([GaussianKernelParameters(sigma, scaling)])
+
+    def GaussianMixture(self, pars: Sequence[GaussianKernelParameters]) -> DevicePointDistributionModel:
+        return DevicePointDistributionModel(self.ctx, self.reference, [p.sigma for p in pars], [p.scaling for p in pars],
+                                            self.relativeTolerance, self.maxRank)
+
+    def AutomaticGaussian(self) -> DevicePointDistributionModel:
+        mx = PointSetHelper(self.ctx, self.reference).maximumPointDistance()
+        return self.GaussianMixture([GaussianKernelParameters(mx / 4.0, mx / 8.0), GaussianKernelParameters(mx / 8.0, mx / 16.0)])
+
+
+def automaticGPMMfromTemplate(ctx: Context, template, relativeTolerance: float = 0.1) -> DevicePointDistributionModel:
+    """registration/utils/GPMMHelper.scala:39-69 (on the model's own points the TriangleMeshInterpolator is the identity)."""
+    h = PointSetHelper(ctx, template)
+    mx, mn = h.maximumPointDistance(), h.minimumPointDistance()
+    sig = [mx / 4, mx / 8, mn * 5]
+    return DevicePointDistributionModel(ctx, template, sig, [v / 2 for v in sig], relativeTolerance)
+
+
+class DeviceModel:
+    """gingr_model: the (row shard of the) model resident in HBM.  `model` is either a host PointDistributionModel
+    (uploaded) or a DevicePointDistributionModel (built on the device; full-row handles are shared with it)."""
+
+    def __init__(self, ctx: Context, model, row_begin: int = 0, row_end: Optional[int] = None):
         self.ctx = ctx
         self._lib = ctx._lib
         self.host = model
         M = model.numberOfPoints
         row_end = M if row_end is None else row_end
-        ref, mean = f64(model.reference), f64(model.mean)
-        basis = np.asfortranarray(model.basis, dtype=np.float64)   # column-major, as Breeze stores basisMatrix
-        var = f64(model.variance)
-        h = c_void_p()
-        _check(ctx.handle, self._lib.gingr_model_upload(ctx.handle, M, model.rank, dptr(ref), dptr(mean),
-                                                        basis.ctypes.data_as(nat._dp), dptr(var), int(row_begin),
-                                                        int(row_end), ctypes.byref(h)), "gingr_model_upload")
-        self.handle = h
+        self._owner = True
+        if isinstance(model, DevicePointDistributionModel):
+            if int(row_begin) == 0 and int(row_end) == M and model.ctx is ctx:
+                self.handle = model.device().handle     # shared, owned by the model
+                self._owner = False
+            else:
+                self.handle = model._build(ctx, int(row_begin), int(row_end))
+        else:
+            ref, mean = f64(model.reference), f64(model.mean)
+            basis = np.asfortranarray(model.basis, dtype=np.float64)   # column-major, as Breeze stores basisMatrix
+            var = f64(model.variance)
+            h = c_void_p()
+            _check(ctx.handle, self._lib.gingr_model_upload(ctx.handle, M, model.rank, dptr(ref), dptr(mean),
+                                                            basis.ctypes.data_as(nat._dp), dptr(var), int(row_begin),
+                                                            int(row_end), ctypes.byref(h)), "gingr_model_upload")
+            self.handle = h
         self.row_begin, self.row_end = int(row_begin), int(row_end)
         self.M_local = self.row_end - self.row_begin
+        self.rank = int(self._lib.gingr_model_rank(self.handle))
+
+    @classmethod
+    def _adopt(cls, ctx: Context, handle, model, M: int) -> "DeviceModel":
+        self = cls.__new__(cls)
+        self.ctx, self._lib, self.host, self.handle, self._owner = ctx, ctx._lib, model, handle, True
+        self.row_begin, self.row_end, self.M_local = 0, M, M
+        self.rank = int(self._lib.gingr_model_rank(handle))
+        return self
+
+    def download(self, basis: bool = True) -> "PointDistributionModel":
+        """Local rows back on the host in gingr_model_upload's layout (gingr_model_download)."""
+        M, r = self.M_local, self.rank
+        ref, mean, var = np.empty((M, 3)), np.empty((M, 3)), np.empty(r)
+        U = np.empty((3 * M, r), order="F") if basis else None
+        _check(self.ctx.handle, self._lib.gingr_model_download(self.ctx.handle, self.handle, dptr(ref), dptr(mean),
+                                                               U.ctypes.data_as(nat._dp) if basis else None, dptr(var)),
+               "gingr_model_download")
+        return PointDistributionModel(reference=ref, mean=mean, basis=U, variance=var)
 
     def gram_exchange(self) -> Tuple[int, int]:
         p, n = c_void_p(), c_int64()
@@ -180,7 +318,8 @@ class DeviceModel:
 
     def close(self):
         if getattr(self, "handle", None):
-            self._lib.gingr_model_destroy(self.handle)
+            if self._owner:
+                self._lib.gingr_model_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -199,7 +338,7 @@ class DeviceModel:
 
     def coefficients(self, mesh, euler=(0, 0, 0), center=(0, 0, 0), translation=(0, 0, 0)) -> np.ndarray:
         m, e, c, t = f64(mesh), f64(euler), f64(center), f64(translation)
-        out = np.empty(self.host.rank)
+        out = np.empty(self.rank)
         _check(self.ctx.handle, self._lib.gingr_model_coefficients(self.ctx.handle, self.handle, dptr(e), dptr(c), dptr(t),
                                                                    dptr(m), dptr(out)), "gingr_model_coefficients")
         return out
@@ -208,7 +347,7 @@ class DeviceModel:
                        landmarks: Optional["LandmarkCorrespondences"] = None) -> Tuple[np.ndarray, np.ndarray]:
         o, w, e, c, t = f64(obs_points), f64(weights), f64(euler), f64(center), f64(translation)
         mean = np.empty((self.M_local, 3))
-        coeffs = np.empty(self.host.rank)
+        coeffs = np.empty(self.rank)
         if landmarks is not None and len(landmarks.pids) > 0:
             lp = np.ascontiguousarray(landmarks.pids, dtype=np.int32)
             lx, lc = f64(landmarks.points), f64(landmarks.covs)

@@ -11,6 +11,7 @@
 #include "gp.h"
 
 #include <cmath>
+#include <functional>
 
 struct gingr_fitter {
     gingr_ctx *ctx = nullptr;
@@ -134,15 +135,17 @@ int model_finalize_impl(gingr_ctx *ctx, gingr_model *m) {
 
 }  // namespace
 
-extern "C" {
-
 // ===================================================================================================== model
-int gingr_model_upload(gingr_ctx *ctx, int64_t M_total, int32_t rank, const double *ref, const double *mean,
-                       const double *basis_colmajor, const double *variance, int64_t row_begin, int64_t row_end,
-                       gingr_model **out) {
+
+// Shared by gingr_model_upload (basis from the host) and the on-device GPMM builder (gpmm.hip): everything of a model
+// except how Q0 = U sqrt(lambda) gets filled.  fill_basis runs after the row permutation exists and must write all of
+// m->Q0 ([3M][rp], device row order, zero padded) on ctx->stream.
+int model_create_impl(gingr_ctx *ctx, int64_t M_total, int32_t rank, const double *ref, const double *mean,
+                      const double *variance, int64_t row_begin, int64_t row_end,
+                      const std::function<int(gingr_model *)> &fill_basis, gingr_model **out) {
     if (!ctx || !out) return GINGR_ERR_BAD_ARGUMENT;
     *out = nullptr;
-    if (M_total < 1 || rank < 1 || rank > 512 || !ref || !mean || !basis_colmajor || !variance)
+    if (M_total < 1 || rank < 1 || rank > 512 || !ref || !mean || !variance)
         return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "model_upload: need M >= 1 and 1 <= rank <= 512");
     if (row_begin < 0 || row_end > M_total || row_begin >= row_end)
         return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "model_upload: bad row shard [%lld,%lld)", (long long)row_begin,
@@ -158,6 +161,7 @@ int gingr_model_upload(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doub
     m->M = row_end - row_begin;
     m->r = rank;
     m->rp = (int32_t)round_up(rank, 16);
+    m->variance.assign(variance, variance + rank);
     const int64_t M = m->M;
     // centroid of the full reference (identical on every shard)
     double c[3] = {0, 0, 0};
@@ -169,7 +173,7 @@ int gingr_model_upload(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doub
     for (int d = 0; d < 3; ++d) m->c0[d] = c[d] / (double)M_total;
 
     int rc = GINGR_OK;
-    DevBuf stage, var, aos;
+    DevBuf aos;
     auto fail = [&](int code) {
         gingr_model_destroy(m);
         return code;
@@ -179,8 +183,7 @@ int gingr_model_upload(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doub
         (rc = dev_alloc(ctx, &m->Binv, (size_t)m->rp * m->rp)) ||
         (rc = dev_alloc(ctx, &m->cmat, (size_t)10 * m->rp * m->rp)))
         return fail(rc);
-    if (stage.alloc((size_t)3 * M * rank * sizeof(double)) != hipSuccess || var.alloc(rank * sizeof(double)) != hipSuccess ||
-        aos.alloc((size_t)3 * M * sizeof(double)) != hipSuccess)
+    if (aos.alloc((size_t)3 * M * sizeof(double)) != hipSuccess)
         return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: out of device memory"));
     // device row order = Morton order of the local mean shape
     {
@@ -193,13 +196,7 @@ int gingr_model_upload(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doub
         if (hipMemcpy(m->perm, m->hperm.data(), (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
             return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: permutation copy failed"));
     }
-    // basis: column k of the shard = rows [3*row_begin, 3*row_end) of host column k
-    if (hipMemcpy2DAsync(stage.p, (size_t)3 * M * sizeof(double), basis_colmajor + 3 * row_begin,
-                         (size_t)3 * M_total * sizeof(double), (size_t)3 * M * sizeof(double), (size_t)rank,
-                         hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-        return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: basis copy failed"));
-    (void)hipMemcpyAsync(var.p, variance, rank * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    launch_pack_basis(ctx, stage.as<double>(), var.as<double>(), M, rank, m->rp, m->perm, m->Q0);
+    if ((rc = fill_basis(m))) return fail(rc);
     (void)hipMemcpyAsync(aos.p, ref + 3 * row_begin, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     launch_aos_to_soa(ctx, aos.as<double>(), M, m->ref, m->perm);
     (void)hipStreamSynchronize(ctx->stream);
@@ -260,6 +257,31 @@ int gingr_model_upload(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doub
     }
     *out = m;
     return GINGR_OK;
+}
+
+extern "C" {
+
+int gingr_model_upload(gingr_ctx *ctx, int64_t M_total, int32_t rank, const double *ref, const double *mean,
+                       const double *basis_colmajor, const double *variance, int64_t row_begin, int64_t row_end,
+                       gingr_model **out) {
+    if (!ctx || !out) return GINGR_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    if (!basis_colmajor) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "model_upload: basis is null");
+    DevBuf stage, var;
+    auto fill = [&](gingr_model *m) -> int {
+        const int64_t M = m->M;
+        if (stage.alloc((size_t)3 * M * rank * sizeof(double)) != hipSuccess || var.alloc(rank * sizeof(double)) != hipSuccess)
+            return gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: out of device memory");
+        // basis: column k of the shard = rows [3*row_begin, 3*row_end) of host column k
+        if (hipMemcpy2DAsync(stage.p, (size_t)3 * M * sizeof(double), basis_colmajor + 3 * row_begin,
+                             (size_t)3 * M_total * sizeof(double), (size_t)3 * M * sizeof(double), (size_t)rank,
+                             hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            return gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: basis copy failed");
+        (void)hipMemcpyAsync(var.p, variance, rank * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        launch_pack_basis(ctx, stage.as<double>(), var.as<double>(), M, rank, m->rp, m->perm, m->Q0);
+        return GINGR_OK;
+    };
+    return model_create_impl(ctx, M_total, rank, ref, mean, variance, row_begin, row_end, fill, out);
 }
 
 void gingr_model_destroy(gingr_model *m) {

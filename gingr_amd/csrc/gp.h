@@ -3,6 +3,8 @@
 
 #include "common.h"
 
+#include <functional>
+
 // Regularisation of PointDistributionModel.coefficients (scalismo DiscreteLowRankGaussianProcess.coefficients:
 // "val sigma2 = 1e-5"); reached from G/api/GingrAlgorithm.scala:215,236.
 #define GINGR_COEFF_NOISE 1e-5
@@ -66,8 +68,14 @@ struct gingr_model {
     double c0[3] = {0, 0, 0};  // centroid of the FULL reference: fixed centring point of the Umeyama sums
     double Pp[9] = {0};        // sum_i p~_i p~_i^T over the FULL model (host, identical on every shard)
     double Ps[3] = {0};        // sum_i p~_i
+    std::vector<double> variance;  // host copy of lambda (gingr_model_download)
     bool finalized = false;
 };
+
+// fitter.hip: common part of model construction; fill_basis writes m->Q0 on ctx->stream (see gingr_model_upload)
+int model_create_impl(gingr_ctx *ctx, int64_t M_total, int32_t rank, const double *ref, const double *mean,
+                      const double *variance, int64_t row_begin, int64_t row_end,
+                      const std::function<int(gingr_model *)> &fill_basis, gingr_model **out);
 
 // ---- basis sweeps ------------------------------------------------------------------------------------------
 enum SweepMode {

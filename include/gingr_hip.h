@@ -121,6 +121,24 @@ void gingr_model_destroy(gingr_model *model);
  * Single-shard uploads are finalized by gingr_model_upload. */
 int gingr_model_gram_exchange(gingr_model *model, void **dev_ptr, int64_t *count);
 int gingr_model_finalize(gingr_ctx *ctx, gingr_model *model);
+/* ---- GPMM construction on the device ----------------------------------------------------------
+ * Replaces GPMMTriangleMesh3D(reference, relativeTolerance).Gaussian / .GaussianMixture / .AutomaticGaussian
+ * (G/api/gpmm/GPMMHelper.scala:96-130) and automaticGPMMfromTemplate (G/api/registration/utils/GPMMHelper.scala:39-69):
+ * zero-mean GP with DiagonalKernel(sum_i scaling_i * GaussianKernel(sigma_i), 3), low-rank approximation by scalismo's
+ * pivoted Cholesky (stopped at relative_tolerance * trace, or at max_rank columns; max_rank <= 0 means the model limit
+ * 512) and the eigen-decomposition of its factor (LowRankGaussianProcess.approximateGPCholesky, GPMM.construct :39-55).
+ * The basis is produced in HBM; the result is a finished (single shard) or to-be-finalized (row shard) gingr_model exactly
+ * as from gingr_model_upload.  ref = interleaved xyz of the FULL reference; row_end <= 0 means M_total. */
+int gingr_gpmm_build_gaussian(gingr_ctx *ctx, int64_t M_total, const double *ref, int32_t n_kernels, const double *sigmas,
+                              const double *scalings, double relative_tolerance, int32_t max_rank, int64_t row_begin,
+                              int64_t row_end, gingr_model **out);
+/* PointSetHelper.maximumPointDistance / minimumPointDistance (GPMMHelper.scala:75-87; the O(n^2) scans behind
+ * AutomaticGaussian and automaticGPMMfromTemplate): largest pairwise distance, smallest distance to the nearest OTHER point. */
+int gingr_pointset_distance_extrema(gingr_ctx *ctx, const double *xyz, int64_t n, double *max_distance, double *min_distance);
+/* Copy the local rows of a model back to the host in gingr_model_upload's layout (any pointer may be NULL):
+ * ref / mean [3 M_local], basis column-major [3 M_local x rank] (unit columns: Q0 / sqrt(variance)), variance [rank]. */
+int gingr_model_download(gingr_ctx *ctx, const gingr_model *model, double *ref, double *mean, double *basis_colmajor,
+                         double *variance);
 int64_t gingr_model_num_points(const gingr_model *model); /* local rows */
 int32_t gingr_model_rank(const gingr_model *model);
 

@@ -157,6 +157,28 @@ JFN(jint, fitterGetState)(JNIEnv *env, jclass, jlong f, jdoubleArray alpha, jdou
     d.as<int32_t>()[1] = s.status;
     return rc;
 }
+JFN(jlong, gpmmBuildGaussian)(JNIEnv *env, jclass, jlong ctx, jlong mTotal, jdoubleArray ref, jdoubleArray sigmas,
+                               jdoubleArray scalings, jdouble relTol, jint maxRank, jlong rowBegin, jlong rowEnd) {
+    const jint nk = env->GetArrayLength(sigmas);
+    Pin a(env, ref, true), b(env, sigmas, true), c(env, scalings, true);
+    gingr_model *m = nullptr;
+    if (gingr_gpmm_build_gaussian(P<gingr_ctx>(ctx), mTotal, a.as<double>(), nk, b.as<double>(), c.as<double>(), relTol, maxRank,
+                                  rowBegin, rowEnd, &m) != GINGR_OK)
+        return 0;
+    return reinterpret_cast<jlong>(m);
+}
+JFN(jint, pointsetDistanceExtrema)(JNIEnv *env, jclass, jlong ctx, jdoubleArray xyz, jdoubleArray out2) {
+    const jlong n = env->GetArrayLength(xyz) / 3;
+    Pin a(env, xyz, true), b(env, out2, false);
+    return gingr_pointset_distance_extrema(P<gingr_ctx>(ctx), a.as<double>(), n, b.as<double>(), b.as<double>() + 1);
+}
+JFN(jint, modelDownload)(JNIEnv *env, jclass, jlong ctx, jlong model, jdoubleArray ref, jdoubleArray mean, jdoubleArray basis,
+                         jdoubleArray variance) {
+    Pin a(env, ref, false), b(env, mean, false), c(env, basis, false), d(env, variance, false);
+    return gingr_model_download(P<gingr_ctx>(ctx), P<gingr_model>(model), a.as<double>(), b.as<double>(), c.as<double>(),
+                                d.as<double>());
+}
+JFN(jint, modelRank)(JNIEnv *, jclass, jlong model) { return gingr_model_rank(P<gingr_model>(model)); }
 #else
 // No JDK headers on this machine: the shim is not built (the C ABI it wraps is still covered by the Python tests).
 #endif

@@ -50,4 +50,14 @@ public final class GingrHipNative {
                                                       double[] meshXyz, double[] out1);
     /** iterStatus2 = { iteration, status }; fitXyz may be null */
     public static native int fitterGetState(long fitter, double[] alpha, double[] poseScalars11, int[] iterStatus2, double[] fitXyz);
+
+    // ---- GPMM construction in HBM (GPMMTriangleMesh3D.Gaussian / GaussianMixture / AutomaticGaussian, automaticGPMMfromTemplate)
+    /** returns the gingr_model handle (0 on failure; see lastError); maxRank <= 0 = model limit; rowEnd <= 0 = all rows */
+    public static native long gpmmBuildGaussian(long ctx, long mTotal, double[] refXyz, double[] sigmas, double[] scalings,
+                                                double relativeTolerance, int maxRank, long rowBegin, long rowEnd);
+    /** out2 = { maximumPointDistance, minimumPointDistance } (PointSetHelper) */
+    public static native int pointsetDistanceExtrema(long ctx, double[] xyz, double[] out2);
+    /** any array may be null; basisColMajor is 3 M_local x rank, unit columns */
+    public static native int modelDownload(long ctx, long model, double[] ref, double[] mean, double[] basisColMajor, double[] variance);
+    public static native int modelRank(long model);
 }

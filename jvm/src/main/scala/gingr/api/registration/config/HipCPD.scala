@@ -226,3 +226,46 @@ class HipIcpRegistration(device: Int = 0) extends GingrAlgorithm[HipIcpRegistrat
   }
   override def close(): Unit = session.close()
 }
+
+// ------------------------------------------------------------------------------------------------ GPMM construction
+/** GPMMTriangleMesh3D(reference, relativeTolerance).Gaussian / GaussianMixture / AutomaticGaussian
+  * (gingr/api/gpmm/GPMMHelper.scala:96-130) with the pivoted Cholesky, the eigen-decomposition and the O(n^2) distance
+  * scans on the GPU.  Returns an ordinary scalismo PointDistributionModel (one download of the 3M x r basis); a session
+  * that only registers can instead keep the native model handle and never materialise the basis on the JVM. */
+object HipGPMM {
+  import scalismo.common.DiscreteField
+  import scalismo.statisticalmodel.DiscreteLowRankGaussianProcess
+
+  def GaussianMixture(reference: TriangleMesh[_3D], pars: Seq[(Double, Double)], relativeTolerance: Double = 0.01, device: Int = 0)
+    : PointDistributionModel[_3D, TriangleMesh] = {
+    val ctx = GingrHipNative.ctxCreate(device)
+    require(ctx != 0L, "gingr_ctx_create failed: no usable GPU")
+    try {
+      val m = reference.pointSet.numberOfPoints
+      val h = GingrHipNative.gpmmBuildGaussian(ctx, m.toLong, HipLayout.mesh(reference), pars.map(_._1).toArray,
+        pars.map(_._2).toArray, relativeTolerance, 0, 0L, 0L)
+      require(h != 0L, s"gingr_gpmm_build_gaussian failed: ${GingrHipNative.lastError(ctx)}")
+      try {
+        val r = GingrHipNative.modelRank(h)
+        val basis = new Array[Double](3 * m * r); val variance = new Array[Double](r); val mean = new Array[Double](3 * m)
+        val rc = GingrHipNative.modelDownload(ctx, h, null, mean, basis, variance)
+        require(rc == 0, s"gingr_model_download failed ($rc): ${GingrHipNative.lastError(ctx)}")
+        val gp = new DiscreteLowRankGaussianProcess[_3D, TriangleMesh, EuclideanVector[_3D]](
+          reference, DenseVector(mean), DenseVector(variance), new DenseMatrix(3 * m, r, basis)) // column-major, as Breeze
+        PointDistributionModel(gp)
+      } finally GingrHipNative.modelDestroy(h)
+    } finally GingrHipNative.ctxDestroy(ctx)
+  }
+
+  def Gaussian(reference: TriangleMesh[_3D], sigma: Double, scaling: Double, relativeTolerance: Double = 0.01)
+    : PointDistributionModel[_3D, TriangleMesh] = GaussianMixture(reference, Seq((sigma, scaling)), relativeTolerance)
+
+  def AutomaticGaussian(reference: TriangleMesh[_3D], relativeTolerance: Double = 0.01): PointDistributionModel[_3D, TriangleMesh] = {
+    val ctx = GingrHipNative.ctxCreate(0)
+    val ext = new Array[Double](2)
+    try require(GingrHipNative.pointsetDistanceExtrema(ctx, HipLayout.mesh(reference), ext) == 0)
+    finally GingrHipNative.ctxDestroy(ctx)
+    val maxDist = ext(0)
+    GaussianMixture(reference, Seq((maxDist / 4.0, maxDist / 8.0), (maxDist / 8.0, maxDist / 16.0)), relativeTolerance)
+  }
+}

@@ -1,0 +1,171 @@
+"""GPU tests of the on-device GPMM construction against the oracle's faithful restatement of
+scalismo's route (pivoted Cholesky over the 3M (point, coordinate) indices + eigen-decomposition of the factor).
+
+Eigenvectors are only defined up to sign (and up to a rotation inside the x/y/z triplets of equal eigenvalues), so the
+comparison is on what the reference's downstream code sees: rank, eigenvalues, the covariance U diag(lambda) U^T, and
+registration results computed with the model."""
+import numpy as np
+import pytest
+
+from oracle import gingr_oracle as go
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300))
+
+
+def cov_of(U, lam, rows):
+    A = U[rows] * np.sqrt(lam)[None, :]
+    return A @ A.T
+
+
+def cloud(M=400, seed=5, scale=40.0):
+    return np.random.default_rng(seed).normal(0, scale, (M, 3))
+
+
+def check_model_against_oracle(dm_host, mo, tol_lam=1e-9, tol_cov=1e-9):
+    assert dm_host.variance.shape[0] == mo.rank
+    assert rel(dm_host.variance, mo.lam) < tol_lam
+    U = np.asarray(dm_host.basis)
+    # unit, mutually orthogonal columns
+    G = U.T @ U
+    assert np.abs(G - np.eye(G.shape[0])).max() < 1e-9
+    rows = np.random.default_rng(0).permutation(U.shape[0])[:300]
+    Cd, Co = cov_of(U, dm_host.variance, rows), cov_of(mo.U, mo.lam, rows)
+    assert np.abs(Cd - Co).max() < tol_cov * np.abs(Co).max()
+
+
+def test_distance_extrema_bit_exact(ctx):
+    import gingr_amd as ga
+    for M, seed in [(1, 0), (2, 1), (257, 2), (1500, 3)]:
+        P = cloud(M, seed)
+        h = ga.PointSetHelper(ctx, P)
+        mx, mn = go.pointset_distance_extrema(P)
+        assert h.maximumPointDistance() == mx
+        assert h.minimumPointDistance() == mn
+    P = cloud(300, 4)
+    P[17] = P[200]                                  # coincident points: the minimum is 0
+    assert ga.PointSetHelper(ctx, P).minimumPointDistance() == 0.0
+
+
+@pytest.mark.parametrize("sigma,scaling,tol", [(60.0, 30.0, 0.01), (40.0, 5.0, 0.05), (120.0, 100.0, 0.001)])
+def test_gaussian_gpmm_matches_scalismo_route(ctx, sigma, scaling, tol):
+    import gingr_amd as ga
+    ref = cloud(400, 11)
+    mo = go.build_gpmm_mixture(ref, [sigma], [scaling], tol)
+    dm = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=tol).Gaussian(sigma, scaling)
+    assert dm.rank == mo.rank, (dm.rank, mo.rank)
+    host = dm.to_host()
+    assert np.array_equal(host.reference, ref) and not host.mean.any()
+    check_model_against_oracle(host, mo)
+
+
+@pytest.mark.parametrize("max_rank", [30, 31, 32, 1, 2])
+def test_rank_not_a_multiple_of_three(ctx, max_rank):
+    """The generic pivot order is (P,x),(P,y),(P,z): stopping after 3j+e pivots leaves the coordinates with j+1 / j columns."""
+    import gingr_amd as ga
+    ref = cloud(300, 12)
+    mo = go.build_gpmm_mixture(ref, [50.0], [20.0], 0.0, max_rank)
+    dm = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.0, maxRank=max_rank).Gaussian(50.0, 20.0)
+    assert dm.rank == mo.rank == max_rank
+    check_model_against_oracle(dm.to_host(), mo)
+
+
+def test_tolerance_stop_between_coordinates(ctx):
+    """Find tolerances for which scalismo's loop stops after the x (resp. x and y) pivot of a point."""
+    import gingr_amd as ga
+    ref = cloud(250, 13)
+    seen = set()
+    for tol in np.linspace(0.02, 0.2, 37):
+        mo = go.build_gpmm_mixture(ref, [45.0], [10.0], float(tol))
+        if mo.rank % 3 == 0 or mo.rank % 3 in seen:
+            continue
+        seen.add(mo.rank % 3)
+        dm = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=float(tol)).Gaussian(45.0, 10.0)
+        assert dm.rank == mo.rank
+        check_model_against_oracle(dm.to_host(), mo)
+    assert seen, "no tolerance in the scan stops between coordinates; widen the scan"
+
+
+def test_automatic_gaussian_and_template_models(ctx):
+    import gingr_amd as ga
+    femur = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "inputs.npz"))["femur"][::3]
+    sig, sc = go.automatic_gaussian_parameters(femur)
+    mo = go.build_gpmm_mixture(femur, sig, sc, 0.01)
+    dm = ga.GPMMTriangleMesh3D(ctx, femur, relativeTolerance=0.01).AutomaticGaussian()
+    assert dm.rank == mo.rank
+    check_model_against_oracle(dm.to_host(), mo)
+    sig, sc = go.automatic_template_parameters(femur)
+    mo = go.build_gpmm_mixture(femur, sig, sc, 0.1)
+    dm = ga.automaticGPMMfromTemplate(ctx, femur, relativeTolerance=0.1)
+    assert dm.rank == mo.rank
+    check_model_against_oracle(dm.to_host(), mo)
+
+
+def test_registration_with_a_device_built_model(ctx):
+    """CPD with the model built in HBM == CPD with the oracle-built model (results do not depend on eigenvector signs),
+    and == the same model round-tripped through download / upload."""
+    import gingr_amd as ga
+    rng = np.random.default_rng(21)
+    ref = cloud(350, 14)
+    mo = go.build_gpmm_mixture(ref, [70.0], [40.0], 0.02)
+    target = mo.instance(rng.normal(0, 1, mo.rank)) @ go.euler_to_rot(0.05, -0.1, 0.07).T + np.array([2.0, -1.0, 0.5])
+    target = target[rng.permutation(350)[:300]]
+    dm = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.02).Gaussian(70.0, 40.0)
+    cfg = ga.CpdConfiguration(maxIterations=20, w=0.05)
+    algo = ga.CpdRegistration(ctx)
+    s_dev = algo.createInitialState(dm, target, cfg)
+    st = go.initial_state(mo, s_dev.general.sigma2)
+    for _ in range(4):
+        s_dev = algo.update(s_dev)
+        st = go.cpd_update(mo, target, st, w=0.05)
+    assert s_dev.general.status == st.status == 0
+    assert rel(s_dev.general.fit, st.fit) < 1e-5, rel(s_dev.general.fit, st.fit)
+    assert abs(s_dev.general.sigma2 - st.sigma2) < 1e-6 * st.sigma2
+    algo.close()
+    host = dm.to_host()
+    algo2 = ga.CpdRegistration(ctx)
+    s_up = algo2.createInitialState(ga.PointDistributionModel(host.reference, host.mean, np.asarray(host.basis), host.variance),
+                                    target, cfg)
+    for _ in range(4):
+        s_up = algo2.update(s_up)
+    assert rel(s_up.general.fit, s_dev.general.fit) < 1e-9
+    algo2.close()
+
+
+def test_row_shards_hold_the_rows_of_the_full_model(ctx):
+    import gingr_amd as ga
+    ref = cloud(700, 15)
+    dm = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.02).Gaussian(55.0, 12.0)
+    full = dm.to_host()
+    for b, e in [(0, 300), (300, 700)]:
+        shard = ga.DeviceModel(ctx, dm, b, e)
+        h = shard.download()
+        assert shard.rank == dm.rank
+        assert np.array_equal(h.reference, ref[b:e])
+        assert np.array_equal(h.variance, full.variance)
+        assert np.array_equal(np.asarray(h.basis), np.asarray(full.basis)[3 * b:3 * e])
+        shard.close()
+
+
+def test_upload_download_round_trip(ctx):
+    import gingr_amd as ga
+    ref = cloud(260, 16)
+    mo = go.build_gaussian_gpmm(ref, 60.0, 30.0, rel_tol=1e-9, max_rank=20)
+    mo.mean = np.random.default_rng(1).normal(0, 0.3, ref.shape)
+    d = ga.DeviceModel(ctx, ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam))
+    h = d.download()
+    assert np.array_equal(h.reference, mo.ref) and np.array_equal(h.mean, mo.mean) and np.array_equal(h.variance, mo.lam)
+    assert np.abs(np.asarray(h.basis) - mo.U).max() < 1e-15
+    d.close()
+
+
+def test_builder_argument_errors(ctx):
+    import gingr_amd as ga
+    ref = cloud(50, 17)
+    for sig, sc, tol in [([0.0], [1.0], 0.01), ([10.0], [-1.0], 0.01), ([10.0], [1.0], 1.0), ([10.0], [1.0], float("nan")),
+                         ([10.0] * 9, [1.0] * 9, 0.01)]:
+        with pytest.raises(ga.GingrNativeError):
+            ga.DevicePointDistributionModel(ctx, ref, sig, sc, tol).device()

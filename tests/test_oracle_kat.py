@@ -283,3 +283,52 @@ def test_posterior_model_covariance_and_sampling_square_roots():
     c_closed = L.T @ np.linalg.solve(S + 1e-5 * Mm, b)
     assert abs(c_ref @ c_ref - c_closed @ c_closed) < 1e-6 * (c_ref @ c_ref)
     assert abs(go.gp_logpdf(c_ref) - (-0.5 * c_closed @ c_closed - 0.5 * mo.rank * math.log(2 * math.pi))) < 1e-6 * abs(go.gp_logpdf(c_ref))
+
+
+# ------------------------------------------------------------------------------------------- GPMM construction (8f rank 3)
+def test_matrix_valued_pivoted_cholesky_is_three_interleaved_scalar_factorisations():
+    """DiagonalKernel: pivots come as (P,x),(P,y),(P,z); the generic factor restricted to one coordinate is the scalar
+    factor; the residual trace obeys the stopping rule."""
+    rng = np.random.default_rng(8)
+    P = rng.normal(0, 30, (120, 3))
+    sig, sc, tol = [35.0, 12.0], [9.0, 2.0], 0.03
+    L = go.pivoted_cholesky_matrix_valued(P, sig, sc, tol)
+    n = L.shape[1]
+    K = go.gaussian_mixture_kernel(P, P, sig, sc)
+    Kf = np.zeros((360, 360))
+    for d in range(3):
+        Kf[d::3, d::3] = K
+    resid = np.trace(Kf - L @ L.T)
+    assert resid < tol * np.trace(Kf)
+    Lprev = L[:, :n - 1]
+    assert np.trace(Kf - Lprev @ Lprev.T) >= tol * np.trace(Kf)       # one column fewer would not have stopped
+    _, piv = go.pivoted_cholesky_matrix_valued(P, sig, sc, tol, return_pivots=True)
+    assert [q % 3 for q in piv] == [k % 3 for k in range(n)]
+    assert all(piv[3 * i] // 3 == piv[3 * i + 1] // 3 == piv[3 * i + 2] // 3 for i in range(n // 3))
+    # scalar factor of the same kernel: columns of coordinate x
+    Ls = L[0::3][:, 0::3]
+    ks = Ls.shape[1]
+    assert np.abs(Ls @ Ls.T - (L @ L.T)[0::3, 0::3]).max() < 1e-12
+    assert ks == (n + 2) // 3
+
+
+def test_approximate_eig_is_the_eigendecomposition_of_the_low_rank_kernel():
+    rng = np.random.default_rng(9)
+    P = rng.normal(0, 20, (90, 3))
+    m = go.build_gpmm_mixture(P, [25.0], [4.0], 0.02)
+    L = go.pivoted_cholesky_matrix_valued(P, [25.0], [4.0], 0.02)
+    assert np.abs(m.U.T @ m.U - np.eye(m.rank)).max() < 1e-10
+    assert np.all(np.diff(m.lam) <= 1e-9 * m.lam[0])
+    assert np.abs((m.U * m.lam) @ m.U.T - L @ L.T).max() < 1e-10 * m.lam[0]
+    ev = np.linalg.eigvalsh(L @ L.T)[::-1][:m.rank]
+    assert np.abs(ev - m.lam).max() < 1e-9 * m.lam[0]
+
+
+def test_pointset_distance_extrema_against_scipy():
+    from scipy.spatial.distance import pdist
+    P = np.random.default_rng(10).normal(0, 50, (200, 3))
+    mx, mn = go.pointset_distance_extrema(P)
+    d = pdist(P)
+    assert abs(mx - d.max()) < 1e-12 * mx and abs(mn - d.min()) < 1e-12 * mx
+    sig, sc = go.automatic_gaussian_parameters(P)
+    assert sig == [mx / 4.0, mx / 8.0] and sc == [mx / 8.0, mx / 16.0]
