@@ -108,8 +108,11 @@ __device__ __forceinline__ Box block_bbox(const double (&x)[PT], const double (&
     return b;
 }
 
-// boxes[tile] = {lo[3], hi[3]} of the points [tile*256, tile*256+256) of a cloud
-__global__ __launch_bounds__(256) void tile_bbox_kernel(Cloud c, double *__restrict__ boxes) {
+// boxes[tile] = {lo[3], hi[3]} of the points [tile*256, tile*256+256) of a cloud.  With slot != nullptr also
+// slot = max over the cloud of |coordinate - ctr| (atomic max on the bit pattern of a non-negative double: order independent,
+// deterministic); the slot must have been zeroed by an EARLIER launch on the stream.
+__global__ __launch_bounds__(256) void tile_bbox_kernel(Cloud c, double *__restrict__ boxes, const double *__restrict__ ctr,
+                                                        double *__restrict__ slot) {
     __shared__ double sh[24];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool ok1[1] = {i < c.n};
@@ -118,6 +121,15 @@ __global__ __launch_bounds__(256) void tile_bbox_kernel(Cloud c, double *__restr
     if (threadIdx.x < 3) {
         boxes[(int64_t)blockIdx.x * 6 + threadIdx.x] = b.lo[threadIdx.x];
         boxes[(int64_t)blockIdx.x * 6 + 3 + threadIdx.x] = b.hi[threadIdx.x];
+    }
+    if (slot && threadIdx.x == 0) {
+        double m = 0.0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double cc = ctr ? ctr[d] : 0.0;
+            m = fmax(m, fmax(fabs(b.lo[d] - cc), fabs(b.hi[d] - cc)));
+        }
+        atomicMax(reinterpret_cast<unsigned long long *>(slot), __builtin_bit_cast(unsigned long long, m));
     }
 }
 
@@ -305,7 +317,11 @@ __global__ __launch_bounds__(256) void cpd_den_finalize_kernel(Cloud tgt, const 
     // c = w/(1-w) * (2 pi sigma2)^(3/2) * (M/N)     CPD.scala:69-70
     const double c = w / (1.0 - w) * pow(2.0 * 3.14159265358979323846 * s2, 1.5) * m_over_n;
     double xpx = 0.0;
-    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < tgt.n; j += (int64_t)kScalarBlocks * 256) {
+    // one 256-point tile per workgroup and pass (block stride = tile size), so tile_bad needs no clearing beforehand
+    for (int64_t jt = (int64_t)blockIdx.x * 256; jt < tgt.n; jt += (int64_t)kScalarBlocks * 256) {
+        const int64_t j = jt + threadIdx.x;
+        int bad = 0;
+        if (j < tgt.n) {
         const double colsum = den[j];
         const double d = colsum + c;
         const double inv = 1.0 / d;
@@ -313,9 +329,12 @@ __global__ __launch_bounds__(256) void cpd_den_finalize_kernel(Cloud tgt, const 
         den[j] = d;
         inv_den[j] = inv;
         Pt1[j] = pt1;
-        if (tile_bad && !(fabs(inv) <= 1.79769313486231570815e308)) tile_bad[j / kTile] = 1;  // never cull this tile
+        bad = !(fabs(inv) <= 1.79769313486231570815e308);  // never cull this tile
         const double xx = tgt.x[j], yy = tgt.y[j], zz = tgt.z[j];
         xpx += pt1 * (xx * xx + yy * yy + zz * zz);
+        }
+        const int any_bad = __syncthreads_or(bad);
+        if (tile_bad && threadIdx.x == 0) tile_bad[jt / kTile] = any_bad;
     }
     const double tot = block_sum<256>(xpx, sh);
     if (threadIdx.x == 0) {
@@ -469,26 +488,39 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
 __global__ __launch_bounds__(256) void rowstats_reduce_kernel(const double *__restrict__ partial, int nchunks, Cloud fit,
                                                               double *__restrict__ P1, double *__restrict__ PX,
                                                               double *__restrict__ part) {
+    // 16 rows per pass; per row 16 threads = 4 planes (P1, PX.x, PX.y, PX.z) x 4 interleaved chunk groups, combined in a
+    // fixed order ((g0 + g1) + (g2 + g3)): the partials are read with 65536 threads whatever the shard size
     __shared__ double sh[256];
+    __shared__ double sg[16][17];
     const int64_t M = fit.n;
+    const int tid = threadIdx.x, il = tid & 15, sub = tid >> 4, q = sub >> 2, g = sub & 3;
     double np = 0.0, tr = 0.0, ypy = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)kScalarBlocks * 256) {
-        double s1 = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
-        for (int c = 0; c < nchunks; ++c) {
-            const double *b = partial + (int64_t)c * 4 * M;
-            s1 += b[i];
-            sx += b[M + i];
-            sy += b[2 * M + i];
-            sz += b[3 * M + i];
+    const int64_t ngroups = (M + 15) / 16;
+    for (int64_t rg = blockIdx.x; rg < ngroups; rg += kScalarBlocks) {
+        const int64_t i = rg * 16 + il;
+        double acc = 0.0;
+        if (i < M) {
+            const double *b = partial + (int64_t)q * M + i;
+#pragma unroll 8
+            for (int c = g; c < nchunks; c += 4) acc += b[(int64_t)c * 4 * M];
         }
-        P1[i] = s1;
-        PX[i] = sx;
-        PX[M + i] = sy;
-        PX[2 * M + i] = sz;
-        const double yx = fit.x[i], yy = fit.y[i], yz = fit.z[i];
-        np += s1;
-        tr += yx * sx + yy * sy + yz * sz;
-        ypy += s1 * (yx * yx + yy * yy + yz * yz);
+        sg[sub][il] = acc;
+        __syncthreads();
+        if (tid < 16 && i < M) {
+            double v[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                v[qq] = (sg[qq * 4][il] + sg[qq * 4 + 1][il]) + (sg[qq * 4 + 2][il] + sg[qq * 4 + 3][il]);
+            P1[i] = v[0];
+            PX[i] = v[1];
+            PX[M + i] = v[2];
+            PX[2 * M + i] = v[3];
+            const double yx = fit.x[i], yy = fit.y[i], yz = fit.z[i];
+            np += v[0];
+            tr += yx * v[1] + yy * v[2] + yz * v[3];
+            ypy += v[0] * (yx * yx + yy * yy + yz * yz);
+        }
+        __syncthreads();
     }
     const double a = block_sum<256>(np, sh);
     __syncthreads();
@@ -501,16 +533,20 @@ __global__ __launch_bounds__(256) void rowstats_reduce_kernel(const double *__re
         part[3 * kScalarBlocks + blockIdx.x] = c;
     }
 }
-
-// scalars[q] = sum of part[q*kScalarBlocks ..], q = 1 (xPx), 0 (Np), 2 (trPXY), 3 (yPy); fixed order
-__global__ __launch_bounds__(256) void cpd_scalars_finish_kernel(const double *__restrict__ part, double *__restrict__ scalars) {
+__global__ __launch_bounds__(256) void cpd_scalars_finish_kernel(const double *__restrict__ part, double *__restrict__ scalars,
+                                                                 double *__restrict__ xch8, int contribute_xpx) {
     __shared__ double sh[256];
     const int map[4] = {1, 0, 2, 3};  // part slot -> scalar index
     for (int q = 0; q < 4; ++q) {
         const double tot = block_sum<256>(part[q * kScalarBlocks + threadIdx.x], sh);
-        if (threadIdx.x == 0) scalars[map[q]] = tot;
+        if (threadIdx.x == 0) {
+            scalars[map[q]] = tot;
+            // xPx is a sum over ALL targets, computed on every shard: only one of them may contribute it
+            if (xch8) xch8[map[q]] = (map[q] == 1 && !contribute_xpx) ? 0.0 : tot;
+        }
         __syncthreads();
     }
+    if (xch8 && threadIdx.x >= 4 && threadIdx.x < 8) xch8[threadIdx.x] = 0.0;
 }
 
 // ---------------------------------------------------------------- nearest neighbour (exact, lowest index on ties)
@@ -766,10 +802,10 @@ void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, const double *ctr, double *slo
     hipLaunchKernelGGL(cloud_absmax_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, ctx->stream, c, ctr, slot);
 }
 
-void launch_tile_bbox(gingr_ctx *ctx, Cloud c, double *boxes) {
+void launch_tile_bbox(gingr_ctx *ctx, Cloud c, double *boxes, const double *ctr, double *absmax_slot) {
     if (c.n <= 0) return;
-
-    hipLaunchKernelGGL(tile_bbox_kernel, dim3((unsigned)ceil_div(c.n, kTile)), dim3(256), 0, ctx->stream, c, boxes);
+    hipLaunchKernelGGL(tile_bbox_kernel, dim3((unsigned)ceil_div(c.n, kTile)), dim3(256), 0, ctx->stream, c, boxes, ctr,
+                       absmax_slot);
 }
 
 void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
@@ -794,14 +830,13 @@ void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *si
 void launch_cpd_den_finalize(gingr_ctx *ctx, Cloud target, const double *sigma2_dev, double w, int64_t M_total,
                              double *den, double *inv_den, double *Pt1, int32_t *tile_bad, double *part,
                              double *scalars_dev) {
-    if (tile_bad) (void)hipMemsetAsync(tile_bad, 0, (size_t)ceil_div(target.n, kTile) * sizeof(int32_t), ctx->stream);
     hipLaunchKernelGGL(cpd_den_finalize_kernel, dim3(kScalarBlocks), dim3(256), 0, ctx->stream, target, sigma2_dev, w,
                        (double)M_total / (double)target.n, den, inv_den, Pt1, tile_bad, part, scalars_dev);
 }
 
 void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
                          const double *inv_den, const double *tgt_boxes, const int32_t *tile_bad, double *ws, double *P1,
-                         double *PX_soa, double *part, double *scalars_dev) {
+                         double *PX_soa, double *part, double *scalars_dev, double *xch8, int contribute_xpx) {
     int nch;
     {
         TimerScope ts(ctx, 1);
@@ -818,7 +853,7 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
     }
     hipLaunchKernelGGL(rowstats_reduce_kernel, dim3(kScalarBlocks), dim3(256), 0, ctx->stream, ws, nch, fit, P1, PX_soa,
                        part);
-    hipLaunchKernelGGL(cpd_scalars_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, part, scalars_dev);
+    hipLaunchKernelGGL(cpd_scalars_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, part, scalars_dev, xch8, contribute_xpx);
 }
 
 static void plan_nn(int64_t nq, int64_t nt_points, bool pruned, int *nchunks, int64_t *chunk_len) {

@@ -117,7 +117,9 @@ int launch_cpd_rowstats_mfma(gingr_ctx *ctx, Cloud fit, Cloud target, const doub
                              const double *inv_den, double *ws, int *nchunks_out);
 void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, const double *ctr, double *slot);
 // boxes[tile] = {lo[3], hi[3]} of every 256-point tile of a cloud: input of the exact-zero tile culling
-void launch_tile_bbox(gingr_ctx *ctx, Cloud c, double *boxes);
+// with absmax_slot != nullptr also *absmax_slot = max |coordinate - ctr| (same value launch_cloud_absmax produces); the slot
+// must have been zeroed by an earlier launch on the stream
+void launch_tile_bbox(gingr_ctx *ctx, Cloud c, double *boxes, const double *ctr = nullptr, double *absmax_slot = nullptr);
 void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
                        const double *fit_boxes, double *ws, double *den_partial);
 // den[j] += c; inv_den[j] = 1/den[j]; Pt1[j] = (den[j]-c)/den[j]; xPx block partials -> part[0..256)
@@ -128,9 +130,10 @@ void launch_cpd_den_finalize(gingr_ctx *ctx, Cloud target, const double *sigma2_
                              double *den, double *inv_den, double *Pt1, int32_t *tile_bad, double *part,
                              double *scalars_dev);
 // P1[i], PX (SoA planes px,py,pz of stride M) for the local rows; Np/xPx/trPXY/yPy sums into scalars_dev[0..3]
+// xch8 (nullable): the 8 scalars of the exchange segment {Np, xPx (only when contribute_xpx), trPXY, yPy, 0...}
 void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
                          const double *inv_den, const double *tgt_boxes, const int32_t *tile_bad, double *ws, double *P1,
-                         double *PX_soa, double *part, double *scalars_dev);
+                         double *PX_soa, double *part, double *scalars_dev, double *xch8 = nullptr, int contribute_xpx = 1);
 // idx[i] = POSITION (in the device order of `target`) of the nearest target; exact ties are broken by the lowest ORIGINAL
 // index, taken from target_orig[position] (nullptr: the device order is the original order).
 // tgt_boxes (nullable): bounding boxes of the 256-point target tiles (launch_tile_bbox) for exact nearest-first pruning.

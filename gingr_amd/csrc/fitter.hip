@@ -69,15 +69,6 @@ int check_launch(gingr_ctx *ctx) {
     return GINGR_OK;
 }
 
-__global__ void pack_scalars_kernel(const double *__restrict__ local, int contribute_xpx, double *__restrict__ out8) {
-    const int i = threadIdx.x;
-    if (i >= 8) return;
-    double v = 0.0;
-    if (i == 0 || i == 2 || i == 3) v = local[i];
-    if (i == 1 && contribute_xpx) v = local[1];  // xPx is computed over ALL targets on every shard: count it once
-    out8[i] = v;
-}
-
 __global__ void zero_kernel(double *p, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.0;
@@ -107,6 +98,7 @@ void refresh_fit(gingr_fitter *f) {
     SweepArgs a = base_args(f);
     a.coef0 = f->alpha;
     a.shape_out = f->fit;
+    a.zero_slot = f->absmax + 1;
     launch_sweep(f->ctx, SWEEP_FIT, a);
 }
 
@@ -643,8 +635,8 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
             if (icp)
                 launch_nn(ctx, fit, tgt, f->tperm, f->tboxes, f->ws, f->nn_idx, f->nn_d2);
             else {
-                launch_cloud_absmax(ctx, fit, f->absmax + 2, f->absmax + 1);
-                launch_tile_bbox(ctx, fit, f->fboxes);
+                // boxes of the fit tiles + its |coordinate - centroid| maximum (slot cleared by the pass that wrote the fit)
+                launch_tile_bbox(ctx, fit, f->fboxes, f->absmax + 2, f->absmax + 1);
                 launch_cpd_colsum(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->fboxes, f->ws, seg0);
             }
             break;
@@ -657,10 +649,8 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 launch_cpd_den_finalize(ctx, tgt, &f->st->sigma2, cp->w, m->M_total, seg0, f->inv_den, f->Pt1, f->tile_bad, f->part,
                                         f->scalars);
                 launch_cpd_rowstats(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->inv_den, f->tboxes, f->tile_bad, f->ws, f->P1,
-                                    f->PX, f->part, f->scalars);
+                                    f->PX, f->part, f->scalars, sc8, m->row_begin == 0 ? 1 : 0);
                 launch_obs_cpd(ctx, m, f->st, fit, f->P1, f->PX, cp->lambda, f->lm_mask, f->weight, f->evec);
-                hipLaunchKernelGGL(pack_scalars_kernel, dim3(1), dim3(64), 0, ctx->stream, f->scalars, m->row_begin == 0 ? 1 : 0,
-                                   sc8);
             }
             launch_gram(ctx, m->Q0, M, rp, f->weight, f->ws, G);
             SweepArgs a = base_args(f);

@@ -103,6 +103,7 @@ struct SweepArgs {
     double c0[3];
     double *partial;       // [nblocks][rp] transposed partials or [nblocks][24] Umeyama partials
     double *out;           // reduced result: [rp] or [24]
+    double *zero_slot;     // nullable: one double the pass clears (consumed by a LATER launch on the stream)
 };
 
 int sweep_num_blocks(int64_t M);

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepArgs a) {
     const int64_t M = a.M;
     double *coef = lds;
     double *red = lds + 2 * rp;
+    if (a.zero_slot && blockIdx.x == 0 && tid == 0) *a.zero_slot = 0.0;  // e.g. the |coordinate| maximum of the fit this pass rewrites
     if (FWD) {
         for (int k = tid; k < rp; k += kSweepThreads) {
             coef[k] = a.coef0[k];
