@@ -15,11 +15,11 @@ for p in ("p1", "p2"):
     for f in glob.glob(f"gpurun_out/pmc_sq/{p}/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for row in csv.DictReader(open(f)):
-            k = row["Kernel_Name"].split("(")[0][:40]
+            k = next((n for n in ("cpd_colsum", "cpd_rowstats", "nn_kernel", "gram_kernel") if n in row["Kernel_Name"]), None)
+            if k is None: continue
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
         with open(f"gpurun_out/pmc_sq/{p}_summary.txt", "w") as o:
             for k, d in acc.items():
-                if not any(s in k for s in ("cpd_colsum", "cpd_rowstats", "nn_kernel", "gram_kernel")): continue
                 o.write(k + "\n")
                 for c, v in d.items():
                     o.write(f"   {c:28s} mean {sum(v)/len(v):16.1f}  n={len(v)}\n")
