@@ -34,13 +34,23 @@ struct __attribute__((aligned(32))) P4 {
 #define GINGR_CPD_EXP_DEGREE 2
 #endif
 constexpr int kDeg = GINGR_CPD_EXP_DEGREE;
+// Table of the two CPD passes: 2^11 entries (16 KB of LDS).  -DGINGR_CPD_TBITS=13 selects the 8192-entry table whose
+// byte offset is ONE SDWA shift (fastexp.h): half a VALU instruction less per pair and 3e-15 instead of 2e-13 on K, but
+// 64 KB of LDS per 256-thread workgroup leaves 2 waves per SIMD and the kernels turn latency bound -- measured SLOWER
+// (colsum 1.26 vs 1.14 ms at 50k); it would need 16-wave workgroups sharing one table to pay off.
+#ifndef GINGR_CPD_TBITS
+#define GINGR_CPD_TBITS 11
+#endif
+constexpr int kTB = GINGR_CPD_TBITS;
+constexpr int kTabN = 1 << kTB;
 
 // ---------------------------------------------------------------- exact-zero culling
-// K_ij = 2^(c d2 / 2048) is flushed to exactly +0 by v_ldexp_f64 once c*d2/2048 < -1076, i.e. d2 > 1491.7 sigma2.  When the
+// K_ij = 2^(c d2 / table size) is flushed to exactly +0 by v_ldexp_f64 once c*d2/size < -1076, i.e. d2 > 1491.7 sigma2.  When the
 // bounding boxes of the owned block and of a streamed 256-point tile are farther apart than that (with margin: 1500
 // sigma2), every pair of the tile pair contributes exactly +0 to every sum and the tile is skipped: bit-identical results.
 // This only triggers when the points are spatially coherent (the fitter keeps model rows and targets in Morton order).
-constexpr double kCullScaled = 2.22e6;  // 1500 * sigma2 * (-c) = 1500 * 2048 * log2(e) / 2
+// 1500 * sigma2 * (-c), with -c = table size * log2(e) / (2 sigma2)
+#define GINGR_CULL_SCALED(entries) (1084.0 * (double)(entries))
 
 struct Box {
     double lo[3], hi[3];
@@ -145,7 +155,7 @@ __device__ __forceinline__ void colsum_tile(const P4 *tile, int cnt, const doubl
             const double dx = x[t] - p.x, dy = y[t] - p.y, dz = z[t] - p.z;
             double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
             if (CLAMP) d2 = fmin(d2, lim);
-            acc[t] += fastexp2_scaled<kDeg>(d2, c, T);
+            acc[t] += fastexp2_scaled<kDeg, kTB>(d2, c, T);
         }
     }
 }
@@ -158,8 +168,8 @@ __device__ __forceinline__ void colsum_tile(const P4 *tile, int cnt, const doubl
 constexpr double kExpandTol = 1e-12;
 
 __device__ __forceinline__ bool use_expansion(double rmax_centered, double c) {
-    // R^2 <= 3 rmax^2;  R^2 / (2 sigma2) = R^2 |c| ln2 / 2048
-    const double ratio = 3.0 * rmax_centered * rmax_centered * (-c) * (0.69314718055994530942 / GINGR_EXP_TABLE);
+    // R^2 <= 3 rmax^2;  R^2 / (2 sigma2) = R^2 |c| ln2 / table size
+    const double ratio = 3.0 * rmax_centered * rmax_centered * (-c) * (0.69314718055994530942 / kTabN);
     return ratio * 7.7e-16 < kExpandTol;
 }
 
@@ -167,7 +177,7 @@ __device__ __forceinline__ double exp_from_t(double t, const double *T) {
     const double tm = t + GINGR_EXP_MAGIC;
     const double kf = tm - GINGR_EXP_MAGIC;
     const double f = t - kf;  // exact
-    return fastexp2_core<kDeg>(tm, f, T);
+    return fastexp2_core<kDeg, kTB>(tm, f, T);
 }
 
 // tile entries: (-2c y~, c|y~|^2); owned: x~ and n = c|x~|^2
@@ -191,15 +201,15 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
                                                             const double *__restrict__ aux,
                                                             const double *__restrict__ fit_boxes, int64_t rows_per_chunk,
                                                             double *__restrict__ partial) {
-    __shared__ double T[GINGR_EXP_TABLE];
+    __shared__ double T[kTabN];
     __shared__ P4 tile[kTile];
     __shared__ double shbox[24];
-    fastexp_table_init(T);
-    const double c = fastexp_scale_for_variance(2.0 * sigma2[0]);
+    fastexp_table_init<kTB>(T);
+    const double c = fastexp_scale_for_variance<kTB>(2.0 * sigma2[0]);
     const double am = aux[0] + aux[1];
     const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);               // wave-uniform
     const bool expand = use_expansion(fmax(aux[0], aux[1]), c);             // wave-uniform
-    const double lim = fastexp_d2_limit(c);
+    const double lim = fastexp_d2_limit<kTB>(c);
     const double cx = aux[2], cy = aux[3], cz = aux[4];
     const double m2c = -2.0 * c;
     const int tid = threadIdx.x;
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
     const int64_t i0 = (int64_t)blockIdx.y * rows_per_chunk;
     const int64_t i1 = min(fit.n, i0 + rows_per_chunk);
     for (int64_t ib = i0; ib < i1; ib += kTile) {
-        if (fit_boxes && box_gap2(own, fit_boxes + (ib / kTile) * 6) * (-c) > kCullScaled) continue;  // all pairs flush to +0
+        if (fit_boxes && box_gap2(own, fit_boxes + (ib / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;  // all pairs flush to +0
         __syncthreads();
         const int64_t i = ib + tid;
         if (i < i1) {
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         }
         __syncthreads();
         // this wave's own 64*PT points may be far from the tile although the workgroup's box is not
-        if (fit_boxes && box_gap2(wown, fit_boxes + (ib / kTile) * 6) * (-c) > kCullScaled) continue;
+        if (fit_boxes && box_gap2(wown, fit_boxes + (ib / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;
         const int cnt = (int)min((int64_t)kTile, i1 - ib);
         if (expand)
             colsum_tile_expand<PT>(tile, cnt, x, y, z, n, acc, T);
@@ -360,7 +370,7 @@ __device__ __forceinline__ void rowstats_tile(const P4 *tile, const P4 *tw, int 
             const double dx = p.x - x[t], dy = p.y - y[t], dz = p.z - z[t];
             double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
             if (CLAMP) d2 = fmin(d2, lim);
-            const double k = fastexp2_scaled<kDeg>(d2, c, T);
+            const double k = fastexp2_scaled<kDeg, kTB>(d2, c, T);
             a1[t] = __builtin_fma(k, p.w, a1[t]);
             ax[t] = __builtin_fma(k, q.x, ax[t]);
             ay[t] = __builtin_fma(k, q.y, ay[t]);
@@ -400,16 +410,16 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
                                                               const double *__restrict__ tgt_boxes,
                                                               const int32_t *__restrict__ tile_bad, int64_t cols_per_chunk,
                                                               double *__restrict__ partial) {
-    __shared__ double T[GINGR_EXP_TABLE];
+    __shared__ double T[kTabN];
     __shared__ P4 tile[kTile];
     __shared__ P4 tw[kTile];
     __shared__ double shbox[24];
-    fastexp_table_init(T);
-    const double c = fastexp_scale_for_variance(2.0 * sigma2[0]);
+    fastexp_table_init<kTB>(T);
+    const double c = fastexp_scale_for_variance<kTB>(2.0 * sigma2[0]);
     const double am = aux[0] + aux[1];
     const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);               // wave-uniform
     const bool expand = use_expansion(fmax(aux[0], aux[1]), c);             // wave-uniform
-    const double lim = fastexp_d2_limit(c);
+    const double lim = fastexp_d2_limit<kTB>(c);
     const double cx = aux[2], cy = aux[3], cz = aux[4];
     const double m2c = -2.0 * c;
     const int tid = threadIdx.x;
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
     const int64_t j1 = min(tgt.n, j0 + cols_per_chunk);
     for (int64_t jb = j0; jb < j1; jb += kTile) {
         // all pairs flush to +0 -- unless a 1/den of the tile is inf/NaN: 0 * inf must stay NaN like the reference's 0/0
-        if (tgt_boxes && !tile_bad[jb / kTile] && box_gap2(own, tgt_boxes + (jb / kTile) * 6) * (-c) > kCullScaled) continue;
+        if (tgt_boxes && !tile_bad[jb / kTile] && box_gap2(own, tgt_boxes + (jb / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;
         __syncthreads();
         const int64_t j = jb + tid;
         if (j < j1) {
@@ -458,7 +468,7 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
             }
         }
         __syncthreads();
-        if (tgt_boxes && !tile_bad[jb / kTile] && box_gap2(wown, tgt_boxes + (jb / kTile) * 6) * (-c) > kCullScaled) continue;
+        if (tgt_boxes && !tile_bad[jb / kTile] && box_gap2(wown, tgt_boxes + (jb / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;
         const int cnt = (int)min((int64_t)kTile, j1 - jb);
         if (expand)
             rowstats_tile_expand<PT>(tile, tw, cnt, x, y, z, n, a1, ax, ay, az, T);

@@ -25,61 +25,93 @@
 
 #include <hip/hip_runtime.h>
 
+// Table sizes: TB = 11 (2048 entries, 16 KB: gauss_block, GPMM builder, the MFMA experiment) and TB = 13 (8192 entries,
+// 64 KB: the two CPD passes).  With 8192 entries the byte offset of T[k & 8191] is ((k << 3) & 0xFFFF): ONE SDWA shift
+// (v_lshlrev_b32_sdwa ... dst_sel:WORD_0) instead of v_and + v_lshl, and the economised degree-2 polynomial is good to
+// 3.2e-15 (tools/gen_exp_table.py prints the constants).
 #define GINGR_EXP_TABLE 2048
 #define GINGR_EXP_TABLE_LOG2 11
-
-#define GINGR_EXP_C1 3.38450771757785784e-04  /* ln2/2048 */
-#define GINGR_EXP_C2 5.72744624517204032e-08  /* (ln2/2048)^2/2 */
-#define GINGR_EXP_C3 6.46152867293236500e-12  /* (ln2/2048)^3/6 */
-#define GINGR_EXP_C1_D2 3.384507729693224e-04  /* ln2/2048 + (ln2/2048)^3/6 * 3/16: minimax degree 2 on |f| <= 1/2 */
 #define GINGR_EXP_MAGIC 6755399441055744.0    /* 1.5 * 2^52 */
 
-__device__ static const double gingr_exp_table_rom[GINGR_EXP_TABLE] = {
-#include "exp_table.inc"
+template <int TB>
+struct ExpTab;
+template <>
+struct ExpTab<11> {
+    static constexpr double C1 = 3.38450771757785784e-04;    // ln2/2048
+    static constexpr double C2 = 5.72744624517204032e-08;    // (ln2/2048)^2/2
+    static constexpr double C3 = 6.46152867293236500e-12;    // (ln2/2048)^3/6
+    static constexpr double C1_D2 = 3.384507729693224e-04;   // C1 + C3 * 3/16: minimax degree 2 on |f| <= 1/2 (2.0e-13)
+};
+template <>
+struct ExpTab<13> {
+    static constexpr double C1 = 8.461269293944645e-05;      // ln2/8192
+    static constexpr double C2 = 3.5796539032325256e-09;
+    static constexpr double C3 = 1.0096138551456822e-13;
+    static constexpr double C1_D2 = 8.461269295837671e-05;   // economised degree 2: 3.2e-15
 };
 
-// copy T[j] = 2^(j/2048) into LDS; every thread of the block must call it, followed by __syncthreads()
+__device__ static const double gingr_exp_table_rom[2048] = {
+#include "exp_table.inc"
+};
+__device__ static const double gingr_exp_table8k_rom[8192] = {
+#include "exp_table8k.inc"
+};
+
+// copy T[j] = 2^(j/2^TB) into LDS; every thread of the block must call it, followed by __syncthreads()
+template <int TB = 11>
 __device__ __forceinline__ void fastexp_table_init(double *T) {
-    for (int j = threadIdx.x + threadIdx.y * blockDim.x; j < GINGR_EXP_TABLE; j += blockDim.x * blockDim.y)
-        T[j] = gingr_exp_table_rom[j];
+    const double *rom = TB == 13 ? gingr_exp_table8k_rom : gingr_exp_table_rom;
+    for (int j = threadIdx.x + threadIdx.y * blockDim.x; j < (1 << TB); j += blockDim.x * blockDim.y) T[j] = rom[j];
 }
 
-// 2^(tm - MAGIC + f)/2048 given tm = MAGIC + k and the reduced argument f
-template <int DEG = 3>
+// 2^((tm - MAGIC + f) / 2^TB) given tm = MAGIC + k and the reduced argument f
+template <int DEG = 3, int TB = 11>
 __device__ __forceinline__ double fastexp2_core(double tm, double f, const double *T) {
     const unsigned long long bits = __builtin_bit_cast(unsigned long long, tm);
     const unsigned lo = (unsigned)bits, hi = (unsigned)(bits >> 32);
-    const int j = (int)(lo & (GINGR_EXP_TABLE - 1));
-    const int e = (int)__builtin_amdgcn_alignbit(hi, lo, GINGR_EXP_TABLE_LOG2);  // bits 11..42: floor(k / 2048)
+    const int e = (int)__builtin_amdgcn_alignbit(hi, lo, TB);  // bits TB..TB+31: floor(k / 2^TB)
     double q;
     if (DEG == 3) {
-        q = __builtin_fma(f, GINGR_EXP_C3, GINGR_EXP_C2);
-        q = __builtin_fma(f, q, GINGR_EXP_C1);
+        q = __builtin_fma(f, ExpTab<TB>::C3, ExpTab<TB>::C2);
+        q = __builtin_fma(f, q, ExpTab<TB>::C1);
     } else {
-        q = __builtin_fma(f, GINGR_EXP_C2, GINGR_EXP_C1_D2);
+        q = __builtin_fma(f, ExpTab<TB>::C2, ExpTab<TB>::C1_D2);
     }
-    const double tj = T[j];
+    double tj;
+    if (TB == 13) {
+        unsigned off;  // ((lo << 3) & 0xFFFF) = 8 * (k & 8191): the 16-bit destination select does the masking
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD"
+            : "=v"(off)
+            : "v"(3u), "v"(lo));
+        tj = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(T) + off);
+    } else {
+        tj = T[lo & ((1u << TB) - 1)];
+    }
     const double fq = f * q;
     const double r = __builtin_fma(tj, fq, tj);
     return __builtin_ldexp(r, e);
 }
 
-// returns 2^(d2*c/2048); requires |d2*c| < 2^42 (see fastexp_needs_clamp)
-template <int DEG = 3>
+// returns 2^(d2*c/2^TB); requires |d2*c| < 2^42 (see fastexp_needs_clamp)
+template <int DEG = 3, int TB = 11>
 __device__ __forceinline__ double fastexp2_scaled(double d2, double c, const double *T) {
     const double tm = __builtin_fma(d2, c, GINGR_EXP_MAGIC);
     const double kf = tm - GINGR_EXP_MAGIC;
     const double f = __builtin_fma(d2, c, -kf);
-    return fastexp2_core<DEG>(tm, f, T);
+    return fastexp2_core<DEG, TB>(tm, f, T);
 }
 
-// c such that exp(-d2 / two_sigma2) = 2^(d2*c/2048)
+// c such that exp(-d2 / two_sigma2) = 2^(d2*c/2^TB)
+template <int TB = 11>
 __device__ __forceinline__ double fastexp_scale_for_variance(double two_sigma2) {
-    return -(double)GINGR_EXP_TABLE * 1.4426950408889634074 / two_sigma2;
+    return -(double)(1 << TB) * 1.4426950408889634074 / two_sigma2;
 }
 
 // largest d2 for which d2*c stays representable; beyond it the result is +0 anyway (2^-1100 underflows)
-__device__ __forceinline__ double fastexp_d2_limit(double c) { return -1100.0 * (double)GINGR_EXP_TABLE / c; }
+template <int TB = 11>
+__device__ __forceinline__ double fastexp_d2_limit(double c) {
+    return -1100.0 * (double)(1 << TB) / c;
+}
 
 // true when an upper bound on d2 could push |d2*c| past 2^41 (a factor 2 of margin to the 2^42 limit)
 __device__ __forceinline__ bool fastexp_needs_clamp(double d2_bound, double c) {

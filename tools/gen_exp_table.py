@@ -1,0 +1,24 @@
+"""Generates gingr_amd/csrc/exp_table*.inc: T[j] = 2^(j/N), correctly rounded float64 (mpmath, 200 bits), and prints the
+polynomial constants of fastexp.h for that table size."""
+import sys
+
+from mpmath import mp, mpf, log
+
+mp.prec = 200
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+out = sys.argv[2] if len(sys.argv) > 2 else "gingr_amd/csrc/exp_table.inc"
+rows = []
+for j in range(N):
+    v = float(mpf(2) ** (mpf(j) / N))          # mpf -> float rounds to nearest
+    rows.append(v.hex())
+with open(out, "w") as f:
+    f.write(f"// 2^(j/{N}), j = 0..{N - 1}, correctly rounded float64 (generated with mpmath at 200 bits)\n")
+    for i in range(0, N, 4):
+        f.write("    " + ", ".join(rows[i:i + 4]) + ",\n")
+a = log(2) / N
+h = mpf("0.5")
+print("C1 ", repr(float(a)))
+print("C2 ", repr(float(a * a / 2)))
+print("C3 ", repr(float(a ** 3 / 6)))
+print("C1_D2 (economised) ", repr(float(a + a ** 3 / 6 * mpf(3) / 4 * h * h)))
+print("deg-2 economised error ", float(a ** 3 / 6 * h ** 3 / 4), " deg-3 Taylor remainder ", float((a * h) ** 4 / 24))
