@@ -95,6 +95,57 @@ def cpu_baseline(y, x, sigma2, w, budget_s=20.0):
                       f"{dt:.1f} s measured; GP solve excluded"}
 
 
+def cpu_baseline_stock_structure(with_gpu: bool):
+    """`--config1-stock-structure` (mode B): config 1 (femur, 1 622 <-> 1 622) as an EMULATION of the stock
+    plugin's cost structure with the numpy oracle -- not a JVM measurement (no JVM exists on either box).  One stock
+    iteration materialises the M x N matrix P four times (every case-class copy re-runs the constructor, CPD.scala:54-77
+    via GingrAlgorithm.scala:244,246 and the generator wrappers) and recomputes all row sums of P inside every one of
+    the M getUncertainty calls (CPD.scala:120-128: O(M^2 N)).  Prints its own JSON object (not the bench line)."""
+    from oracle import gingr_oracle as go
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "inputs.npz"))
+    ref, target = d["femur"], d["femur_target"]
+    M = ref.shape[0]
+    model = go.build_gaussian_gpmm(ref, 70.0, 50.0, rel_tol=0.0, max_rank=100)   # femur demo kernel, truncate(100)
+    st = go.initial_state(model, go.cpd_initial_sigma2(ref, target))
+    w, lam = 0.0, 1.0
+    t0 = time.perf_counter()
+    for _ in range(4):                                       # four constructor runs per update
+        P = go.cpd_P(st.fit, target, st.sigma2, w)
+    t_p = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    var = np.empty(M)
+    for i in range(M):                                       # getUncertainty(id): sum(P, Axis._1) recomputed per id
+        P1 = P.sum(axis=1)
+        var[i] = st.sigma2 * lam / P1[i]
+    t_u = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    go.cpd_update(model, target, st, w=w, lam=lam)           # correspondences, posterior, projections, Umeyama, sigma2
+    t_r = time.perf_counter() - t0
+    out = {"config": "femur DemoCPD, 1622 <-> 1622 vertices, rank-100 Gaussian GPMM (sigma 70, scaling 50), w = 0",
+           "kind": "emulation of the stock plugin's cost structure with the numpy oracle (NOT a JVM measurement)",
+           "host_cores": os.cpu_count(),
+           "stock_structure_s_per_iteration": t_p + t_u + t_r,
+           "breakdown_s": {"four_P_materialisations": t_p, "M_getUncertainty_calls_each_recomputing_row_sums": t_u,
+                           "one_algorithm_faithful_iteration": t_r}}
+    if with_gpu:
+        import torch  # noqa: F401  (first: one HIP runtime per process)
+        import gingr_amd as ga
+        ctx = ga.Context(0)
+        algo = ga.CpdRegistration(ctx)
+        s = algo.createInitialState(ga.PointDistributionModel(model.ref, model.mean, model.U, model.lam), target,
+                                    ga.CpdConfiguration(maxIterations=200, w=w))
+        s = algo.update(s)                                   # warm-up (upload, first launches)
+        n = 50
+        t0 = time.perf_counter()
+        for _ in range(n):
+            s = algo.update(s)                               # host-boundary call: push state, one iteration, pull the fit
+        dt = (time.perf_counter() - t0) / n
+        out["hip_update_s_per_iteration_host_boundary"] = dt
+        out["hip_vs_stock_structure"] = (t_p + t_u + t_r) / dt
+        algo.close()
+    print(json.dumps(out))
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -114,7 +165,13 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="timing experiment on ONE GPU: own only rows of rank 0 of a world of this size (results are not a "
                          "valid registration: the other shards' partial sums are missing); shows the per-rank cost at N GPUs")
+    ap.add_argument("--config1-stock-structure", choices=["cpu", "gpu"], default=None,
+                    help="instead of the benchmark: config 1 (femur) stock-structure emulation (SURVEY 8d mode B); 'gpu' "
+                         "also times the HIP path on the same inputs")
     args = ap.parse_args()
+    if args.config1_stock_structure:
+        cpu_baseline_stock_structure(args.config1_stock_structure == "gpu")
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
