@@ -228,6 +228,7 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
     }
     Box wown;
     const Box own = block_bbox<PT>(x, y, z, okv, shbox, &wown);  // raw coordinates, before any centring
+    const bool wave_owns_any = __builtin_amdgcn_readfirstlane((int)okv[0]) != 0;  // lane 0, slot 0 is the wave's first point
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         if (expand) {
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         }
         __syncthreads();
         // this wave's own 64*PT points may be far from the tile although the workgroup's box is not
+        if (!wave_owns_any) continue;  // a wave past the end of the cloud only takes part in the barriers
         if (fit_boxes && box_gap2(wown, fit_boxes + (ib / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;
         const int cnt = (int)min((int64_t)kTile, i1 - ib);
         if (expand)
@@ -437,6 +439,7 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
     }
     Box wown;
     const Box own = block_bbox<PT>(x, y, z, okv, shbox, &wown);  // raw coordinates, before any centring
+    const bool wave_owns_any = __builtin_amdgcn_readfirstlane((int)okv[0]) != 0;  // lane 0, slot 0 is the wave's first point
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         if (expand) {
@@ -468,6 +471,7 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
             }
         }
         __syncthreads();
+        if (!wave_owns_any) continue;  // a wave past the end of the shard only takes part in the barriers
         if (tgt_boxes && !tile_bad[jb / kTile] && box_gap2(wown, tgt_boxes + (jb / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;
         const int cnt = (int)min((int64_t)kTile, j1 - jb);
         if (expand)

@@ -15,6 +15,8 @@
 // All reductions across workgroups go through per-block partials combined in a fixed order (bitwise reproducible).
 #include "gp.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -623,65 +625,114 @@ __global__ __launch_bounds__(kDenseThreads) void posterior_solve_kernel(int r, i
     }
 }
 
-// LDS-resident blocked Cholesky solve for r <= 128 (one workgroup of 256 threads, 16-wide panels):
-// per panel (1) wave 0 factors the 16x16 diagonal block IN REGISTERS (one row per lane, cross-lane broadcasts with
-// v_readlane: no LDS round trip on the sequential chain), (2) one thread per row solves the panel below it,
-// (3) all threads update the trailing matrix; forward / backward substitution are blocked the same way.
-// 3 workgroup barriers per panel instead of 2 per column.
+// LDS-resident blocked Cholesky solve for r <= 128 (one workgroup of 256 threads = one wave per SIMD, 16-wide panels).
+// With one wave per SIMD the kernel is bound by the NUMBER of instructions it issues (5-8 cycles each), so everything is
+// laid out to need no masks: the matrix is padded with an identity to n = rp (a multiple of 16: every panel is full), right-hand
+// sides ride along as 16 extra rows of the bordered matrix (so the forward substitution is a by-product of the panel solves
+// and trailing updates), loads are unconditional, and the three stages of a panel use the cross-lane hardware directly:
+//   (1) wave 0 factors the 16x16 diagonal block in registers, one row per lane; the rank-1 updates fetch the pivot column
+//       through the DPP of the FMA itself (v_fmac_f64_dpp row_newbcast) -- no LDS, no scalar round trip on the chain,
+//   (2) the panel below it is solved by 16 lanes per matrix row with the same DPP recurrence, four rows interleaved,
+//   (3) the trailing update runs on the matrix pipe, one wave per 16x16 tile (v_mfma_f64_16x16x4).
+// The backward substitution is blocked the same way.  3 workgroup barriers per panel.
 constexpr int kNB = 16;
 
-__device__ __forceinline__ double readlane_d(double v, int l) {
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, l);
-    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+// stage clock of tools/ubench_solve.hip (accumulates shader cycles per stage); nothing in the library build
+#ifndef GINGR_STAGE_CLOCK
+#define GINGR_STAGE_CLOCK(slot)
+#endif
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = BEGIN .. END-1 (DPP controls must be immediates)
+template <int BEGIN, int END, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (BEGIN < END) {
+        f(std::integral_constant<int, BEGIN>{});
+        static_for<BEGIN + 1, END>(f);
+    }
 }
 
-// ---- building blocks (all threads of a 256-thread workgroup call them; A is r x r in LDS with odd leading dimension ld) ----
+// value of lane J of the caller's 16-lane row, in every lane of that row: one v_mov_b64_dpp (gfx90a+ row_newbcast) instead of
+// two v_readlane_b32 through the scalar file.  A VGPR written by a VALU instruction may be read through DPP only two wait
+// states later and the compiler does not look into inline asm, hence the s_nop inside the statement.
+template <int J>
+__device__ __forceinline__ double row_bcast(double v) {
+    double out;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(v), "n"(J));
+    return out;
+}
 
-// A (lower triangle) = ca * G + cs * S + ci * I from global r x rp matrices (S may be nullptr).  G / S were produced on other
-// CUs, so every load is an L2 / fabric round trip: issue them in independent batches of 8 per thread.
-__device__ void lds_load_spd(double *A, int ld, int r, int rp, const double *__restrict__ G, double ca,
-                             const double *__restrict__ S, double cs, double ci) {
-    const int tid = threadIdx.x;
-    for (int base = 0; base < r * rp; base += 256 * 8) {
+// acc += (lane J's a) * b, one v_fmac_f64_dpp.  FRESH = true puts the two wait states into the same asm statement (use it
+// whenever `a` could have been produced by the preceding instructions).
+template <int J, bool FRESH>
+__device__ __forceinline__ void fmac_row_bcast(double &acc, double a, double b) {
+    if (FRESH)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc)
+                     : "v"(a), "v"(b), "n"(J));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(J));
+}
+
+// ---- building blocks: all 256 threads call them.  A is (n + xr) x n in LDS, n and xr multiples of 16, odd leading dimension ld.
+
+// doubles of LDS the blocks need for an r x r system with xr extra rows
+__host__ __device__ inline size_t lds_solve_doubles(int rp, int xr) { return (size_t)(rp + xr) * (rp | 1) + 2 * (size_t)rp; }
+
+// A (lower triangle of the leading r x r) = ca * G + cs * S + ci * I from global r x rp matrices (S may be nullptr), identity
+// on the padding r <= i < n.  16 x 16 element blocks, one element per thread and block, eight blocks in flight; the loads are
+// unconditional (clamped indices), only the value is selected.
+__device__ __forceinline__ void lds_load_spd(double *A, int ld, int r, int n, const double *__restrict__ G, double ca,
+                                             const double *__restrict__ S, double cs, double ci) {
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    int ib = 0, jb = 0;  // block origin (wave-uniform)
+    while (ib < n) {
         double v[8];
+        int off[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * 256 + tid;
-            double t = idx < r * rp ? ca * G[idx] : 0.0;
-            if (S && idx < r * rp) t = __builtin_fma(cs, S[idx], t);
-            v[u] = t;
+            const int i = ib + ty, j = jb + tx;
+            const int g = min(i, r - 1) * n + min(j, r - 1);  // the global matrices have row stride rp == n
+            double t = ca * G[g];
+            if (S) t = __builtin_fma(cs, S[g], t);
+            if (i == j) t += ci;
+            v[u] = (i < r && j < r) ? t : (i == j ? 1.0 : 0.0);
+            off[u] = (ib < n && j <= i) ? i * ld + j : -1;
+            jb += 16;
+            if (jb > ib) {
+                jb = 0;
+                ib += 16;
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * 256 + tid;
-            const int i = idx / rp, j = idx - i * rp;
-            if (idx < r * rp && j <= i) A[i * ld + j] = v[u] + (i == j ? ci : 0.0);
-        }
+        for (int u = 0; u < 8; ++u)
+            if (off[u] >= 0) A[off[u]] = v[u];
     }
     __syncthreads();
 }
 
-// in-place blocked Cholesky (lower); rd[k] = 1 / L[k][k]; *bad_spd (LDS) is set on a non-positive / non-finite pivot
-__device__ void lds_cholesky(double *A, int ld, int r, double *rd, int *bad_spd) {
+// in-place blocked Cholesky (lower) of the leading n x n; rd[k] = 1 / L[k][k]; *bad_spd (LDS) is set on a non-positive /
+// non-finite pivot.  Rows n .. n+xr-1 hold right-hand sides b^T; they ride along through the panel solves and the trailing
+// updates (Cholesky of the bordered matrix), so on return they hold (L^-1 b)^T.
+__device__ __forceinline__ void lds_cholesky(double *A, int ld, int n, double *rd, int *bad_spd, int xr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int kb = 0; kb < r; kb += kNB) {
-        const int nb = min(kNB, r - kb);
-        // (1) diagonal block in registers, wave 0: lane i holds row i (columns 0..i)
+    const int rows = n + xr;
+    for (int kb = 0; kb < n; kb += kNB) {
+        // (1) diagonal block in registers, wave 0 (all four 16-lane rows do the same work: DPP needs the source lanes active)
         if (wave == 0) {
+            const int l15 = lane & 15;
             double row[kNB];
 #pragma unroll
-            for (int k = 0; k < kNB; ++k)
-                row[k] = (lane < nb && k <= lane) ? A[(kb + lane) * ld + kb + k] : (k == lane ? 1.0 : 0.0);
-            int bad = 0;
-#pragma unroll
-            for (int c = 0; c < kNB; ++c) {
-                double d = readlane_d(row[c], c);
-                if (c < nb && (!(d > 0.0) || !finite_d(d))) {
-                    bad = 1;
-                    d = 1.0;
-                }
+            for (int k = 0; k < kNB; ++k) {
+                const double v = A[(kb + l15) * ld + kb + k];  // the upper part may hold anything: selected away
+                row[k] = k <= l15 ? v : 0.0;
+            }
+            double rd_own = 1.0;  // 1 / L[lane][lane]
+            static_for<0, kNB>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                // the pivot, from lane c of this 16-lane row.  A non-positive or non-finite pivot is not tested here (the test
+                // would sit on the sequential chain): it turns lc into NaN (rsq(d <= 0) * d, rsq(inf) * inf), the NaN reaches every
+                // later diagonal entry of the block, and the check after the loop sees it.
+                const double d = row_bcast<c>(row[c]);
                 // 1/sqrt(d) by v_rsq_f64 + two Newton steps; lane c's own element d * rsqrt(d) is sqrt(d): the IEEE sqrt and
                 // divide sequences are ~40 dependent instructions and would sit on the sequential chain of every column
                 double rdk = __builtin_amdgcn_rsq(d);
@@ -689,118 +740,116 @@ __device__ void lds_cholesky(double *A, int ld, int r, double *rd, int *bad_spd)
                 rdk = rdk * __builtin_fma(-hd * rdk, rdk, 1.5);
                 rdk = rdk * __builtin_fma(-hd * rdk, rdk, 1.5);
                 const double lc = row[c] * rdk;
+                const double nlc = -lc;
                 row[c] = lc;
+                if (l15 == c) rd_own = rdk;  // 1/sqrt(d): the reciprocal of this lane's diagonal entry d * rdk
+                // row[j] -= L[lane][c] * L[j][c]: L[j][c] is lane j's lc, fetched by the DPP of the FMA itself
+                static_for<c + 1, kNB>([&](auto jj) {
+                    constexpr int j = decltype(jj)::value;
+                    fmac_row_bcast<j, j == c + 1>(row[j], lc, nlc);
+                });
+            });
+            if (lane < kNB) {
+                double diag = 0.0;
 #pragma unroll
-                for (int j = c + 1; j < kNB; ++j) {
-                    const double lj = readlane_d(lc, j);
-                    row[j] = __builtin_fma(-lc, lj, row[j]);
-                }
-            }
-            if (lane < nb) {
-#pragma unroll
-                for (int k = 0; k < kNB; ++k)
+                for (int k = 0; k < kNB; ++k) {
                     if (k <= lane) A[(kb + lane) * ld + kb + k] = row[k];
-#pragma unroll
-                for (int k = 0; k < kNB; ++k)
-                    if (k == lane) rd[kb + lane] = 1.0 / row[k];
-            }
-            if (bad && lane == 0) *bad_spd = 1;
-        }
-        __syncthreads();
-        // (2) panel below the diagonal block: x L11^T = A[i][kb:kb+nb]
-        for (int i = kb + nb + tid; i < r; i += 256) {
-            double x[kNB];
-#pragma unroll
-            for (int c = 0; c < kNB; ++c) {
-                if (c < nb) {
-                    double sacc = A[i * ld + kb + c];
-#pragma unroll
-                    for (int k = 0; k < kNB; ++k)
-                        if (k < c) sacc = __builtin_fma(-x[k], A[(kb + c) * ld + kb + k], sacc);
-                    x[c] = sacc * rd[kb + c];
+                    if (k == lane) diag = row[k];
                 }
+                rd[kb + lane] = rd_own;
+                if (!(diag > 0.0) || !finite_d(diag) || !finite_d(rd_own)) *bad_spd = 1;
             }
-#pragma unroll
-            for (int c = 0; c < kNB; ++c)
-                if (c < nb) A[i * ld + kb + c] = x[c];
         }
         __syncthreads();
-        // (3) trailing update of the lower triangle
+        GINGR_STAGE_CLOCK(1)
+        // (2) panel below the diagonal block: x L11^T = A[i][kb:kb+16].  Sixteen lanes per matrix row: lane c keeps x[c] and
+        // row c of L11 in registers; at step k every lane with c > k takes x[k] / L[k][k] from lane k through the DPP of its
+        // FMA.  No LDS traffic inside the recurrence; four matrix rows per 16-lane group are interleaved to fill the chain.
         {
-            const int t0 = kb + nb, tx = tid & 15, ty = tid >> 4;
-            for (int i = t0 + ty; i < r; i += 16) {
-                double li[kNB];
+            const int grp = tid >> 4, c16 = tid & 15;
+            double nL[kNB];  // -L11[c16][k] for k < c16, else 0 (lanes c <= k must not move)
 #pragma unroll
-                for (int k = 0; k < kNB; ++k) li[k] = k < nb ? A[i * ld + kb + k] : 0.0;
-                for (int j = t0 + tx; j <= i; j += 16) {
-                    double sacc = A[i * ld + j];
+            for (int k = 0; k < kNB; ++k) {
+                const double v = A[(kb + c16) * ld + kb + k];
+                nL[k] = k < c16 ? -v : 0.0;
+            }
+            const double rdl = rd[kb + c16];
+            for (int ib = kb + kNB; ib < rows; ib += 64) {  // workgroup-uniform trip count
+                const int i0 = ib + grp;
+                double x[4];
 #pragma unroll
-                    for (int k = 0; k < kNB; ++k)
-                        if (k < nb) sacc = __builtin_fma(-li[k], A[j * ld + kb + k], sacc);
-                    A[i * ld + j] = sacc;
+                for (int u = 0; u < 4; ++u) x[u] = A[min(i0 + 16 * u, rows - 1) * ld + kb + c16];
+                static_for<0, kNB>([&](auto kk) {
+                    constexpr int k = decltype(kk)::value;
+                    double t[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) t[u] = x[u] * rdl;  // lane k: the finished x[k]
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) fmac_row_bcast<k, true>(x[u], t[u], nL[k]);
+                });
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + 16 * u < rows) A[(i0 + 16 * u) * ld + kb + c16] = x[u] * rdl;
+            }
+        }
+        __syncthreads();
+        GINGR_STAGE_CLOCK(2)
+        // (3) trailing update on the matrix pipe: one wave per 16x16 output tile, D = C - L_I L_J^T as four
+        // v_mfma_f64_16x16x4 (k = 16).  Fragment layout as in gram_kernel: lane l supplies A[i = l & 15][k = l >> 4] and
+        // B[k = l >> 4][j = l & 15]; it holds D[i = (l >> 4) + 4 reg][j = l & 15].  All tiles are full; the upper half of a
+        // diagonal tile is updated too (nobody reads it).
+        {
+            const int t0 = kb + kNB;
+            const int nti = (rows - t0) >> 4, ntj = (n - t0) >> 4;
+            const int l15 = lane & 15, l4 = lane >> 4;
+            int tcount = 0;
+            for (int ti = 0; ti < nti; ++ti)
+                for (int tj = 0; tj <= ti && tj < ntj; ++tj, ++tcount) {
+                    if ((tcount & 3) != wave) continue;  // wave-uniform
+                    const int i0 = t0 + 16 * ti, j0 = t0 + 16 * tj;
+                    const double *pa = A + (i0 + l15) * ld + kb + l4, *pb = A + (j0 + l15) * ld + kb + l4;
+                    double *pc = A + (i0 + l4) * ld + j0 + l15;
+                    v4f64 acc;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = pc[4 * g * ld];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * q], pb[4 * q], acc, 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) pc[4 * g * ld] = acc[g];
                 }
-            }
         }
         __syncthreads();
+        GINGR_STAGE_CLOCK(3)
     }
 }
 
-// y <- L^-1 y (blocked; the 16x16 triangular solves run in registers of wave 0)
-__device__ void lds_forward(const double *A, int ld, int r, const double *rd, double *y) {
+// y <- L^-T y for the n entries of y (blocked, bottom up; the 16x16 triangular solves run in registers of wave 0 with the DPP
+// recurrence: lane c holds column c of the diagonal block)
+__device__ __forceinline__ void lds_backward(const double *A, int ld, int n, const double *rd, double *y) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int kb = 0; kb < r; kb += kNB) {
-        const int nb = min(kNB, r - kb);
+    for (int kb = n - kNB; kb >= 0; kb -= kNB) {
         if (wave == 0) {
-            double row[kNB];
+            const int l15 = lane & 15;
+            double ncol[kNB];  // -L11[k][lane] for k > lane, else 0 (lanes >= k must not move at step k)
 #pragma unroll
-            for (int k = 0; k < kNB; ++k) row[k] = (lane < nb && k < lane) ? A[(kb + lane) * ld + kb + k] : 0.0;
-            double yv = lane < nb ? y[kb + lane] : 0.0;
-            const double rdl = lane < nb ? rd[kb + lane] : 1.0;
-#pragma unroll
-            for (int c = 0; c < kNB; ++c) {
-                const double yc = readlane_d(yv, c) * readlane_d(rdl, c);
-                if (lane == c) yv = yc;
-                if (lane > c) yv = __builtin_fma(-row[c], yc, yv);
+            for (int k = 0; k < kNB; ++k) {
+                const double v = A[(kb + k) * ld + kb + l15];
+                ncol[k] = k > l15 ? -v : 0.0;
             }
-            if (lane < nb) y[kb + lane] = yv;
-        }
-        __syncthreads();
-        for (int i = kb + nb + tid; i < r; i += 256) {
-            double sacc = y[i];
-#pragma unroll
-            for (int k = 0; k < kNB; ++k)
-                if (k < nb) sacc = __builtin_fma(-A[i * ld + kb + k], y[kb + k], sacc);
-            y[i] = sacc;
-        }
-        __syncthreads();
-    }
-}
-
-// y <- L^-T y (blocked, bottom up: lane c holds column c of the diagonal block)
-__device__ void lds_backward(const double *A, int ld, int r, const double *rd, double *y) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int kb = ((r - 1) / kNB) * kNB; kb >= 0; kb -= kNB) {
-        const int nb = min(kNB, r - kb);
-        if (wave == 0) {
-            double col[kNB];
-#pragma unroll
-            for (int k = 0; k < kNB; ++k) col[k] = (lane < nb && k < nb && k > lane) ? A[(kb + k) * ld + kb + lane] : 0.0;
-            double yv = lane < nb ? y[kb + lane] : 0.0;
-            const double rdl = lane < nb ? rd[kb + lane] : 1.0;
-#pragma unroll
-            for (int c = kNB - 1; c >= 0; --c) {
-                const double xc = readlane_d(yv, c) * readlane_d(rdl, c);
-                if (lane == c) yv = xc;
-                if (lane < c) yv = __builtin_fma(-col[c], xc, yv);
-            }
-            if (lane < nb) y[kb + lane] = yv;
+            double yv = y[kb + l15];
+            const double rdl = rd[kb + l15];
+            static_for<0, kNB>([&](auto cc) {
+                constexpr int c = kNB - 1 - decltype(cc)::value;
+                const double t = yv * rdl;  // lane c: x_c (its yv is complete)
+                fmac_row_bcast<c, true>(yv, t, ncol[c]);
+            });
+            if (lane < kNB) y[kb + lane] = yv * rdl;
         }
         __syncthreads();
         for (int i = tid; i < kb; i += 256) {
             double sacc = y[i];
 #pragma unroll
-            for (int k = 0; k < kNB; ++k)
-                if (k < nb) sacc = __builtin_fma(-A[(kb + k) * ld + i], y[kb + k], sacc);
+            for (int k = 0; k < kNB; ++k) sacc = __builtin_fma(-A[(kb + k) * ld + i], y[kb + k], sacc);
             y[i] = sacc;
         }
         __syncthreads();
@@ -815,27 +864,29 @@ __global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp,
                                                                   const double *__restrict__ zrand, double *__restrict__ a,
                                                                   DevState *__restrict__ st) {
     extern __shared__ double sm[];
-    const int ld = r | 1;  // odd leading dimension: column walks hit distinct banks
+    const int n = rp, ld = n | 1;  // odd leading dimension: column walks hit distinct banks
     double *A = sm;
-    double *y = sm + (size_t)r * ld;
-    double *rd = y + r;   // reciprocal diagonal of L
-    double *y2 = rd + r;  // sampling direction
+    double *y = sm + (size_t)n * ld;   // row n of the bordered matrix: the right-hand side (rows n+1 .. n+15 are zero)
+    double *rd = sm + (size_t)(n + kNB) * ld;  // reciprocal diagonal of L
+    double *y2 = rd + n;                       // sampling direction
     __shared__ int bad_spd, bad;
     const int tid = threadIdx.x;
     if (tid == 0) {
         bad_spd = 0;
         bad = 0;
     }
-    for (int k = tid; k < r; k += 256) {
-        y[k] = rhs[k];
-        y2[k] = zrand ? zrand[k] : 0.0;
-    }
+    for (int k = tid; k < kNB * ld; k += 256) y[k] = k < r ? rhs[k] : 0.0;
+    for (int k = tid; k < n; k += 256) y2[k] = (zrand && k < r) ? zrand[k] : 0.0;
     // Mm = QtL Q + I     (scalismo genericRegressionComputations)
-    lds_load_spd(A, ld, r, rp, G, 1.0, nullptr, 0.0, 1.0);
-    lds_cholesky(A, ld, r, rd, &bad_spd);
-    lds_forward(A, ld, r, rd, y);
-    lds_backward(A, ld, r, rd, y);
-    if (zrand) lds_backward(A, ld, r, rd, y2);
+    GINGR_STAGE_CLOCK(7)
+    lds_load_spd(A, ld, r, n, G, 1.0, nullptr, 0.0, 1.0);
+    GINGR_STAGE_CLOCK(0)
+    lds_cholesky(A, ld, n, rd, &bad_spd, kNB);  // y <- L^-1 y on the way
+    GINGR_STAGE_CLOCK(4)
+    lds_backward(A, ld, n, rd, y);
+    GINGR_STAGE_CLOCK(5)
+    GINGR_STAGE_CLOCK(6)
+    if (zrand) lds_backward(A, ld, n, rd, y2);
     for (int k = tid; k < rp; k += 256) {
         const double v = k < r ? y[k] + y2[k] : 0.0;
         a[k] = v;
@@ -860,29 +911,30 @@ __global__ __launch_bounds__(256) void posterior_logpdf_lds_kernel(int r, int rp
                                                                    const double *__restrict__ qte,
                                                                    const double *__restrict__ a, double *__restrict__ out2) {
     extern __shared__ double sm[];
-    const int ld = r | 1;
+    const int n = rp, ld = n | 1;
     double *A = sm;
-    double *u = sm + (size_t)r * ld;
-    double *rd = u + r;
-    double *cv = rd + r;
+    double *u = sm + (size_t)n * ld;  // extra row block of the bordered matrix
+    double *rd = sm + (size_t)(n + kNB) * ld;
+    double *cv = rd + n;
     __shared__ int bad_spd;
     __shared__ double red[256];
     const int tid = threadIdx.x;
     if (tid == 0) bad_spd = 0;
+    for (int k = tid; k < kNB * ld; k += 256) u[k] = 0.0;
+    __syncthreads();
     // b = Q0^T e - S_tot a
     for (int k = tid; k < r; k += 256) {
         double s = qte[k];
         for (int j = 0; j < r; ++j) s = __builtin_fma(-Stot[(int64_t)j * rp + k], a[j], s);  // S_tot symmetric: coalesced
         u[k] = s;
     }
-    lds_load_spd(A, ld, r, rp, G, GINGR_COEFF_NOISE, Stot, 1.0, GINGR_COEFF_NOISE);  // S_tot + eps (I + G)
-    lds_cholesky(A, ld, r, rd, &bad_spd);
-    lds_forward(A, ld, r, rd, u);
-    lds_backward(A, ld, r, rd, u);
+    lds_load_spd(A, ld, r, n, G, GINGR_COEFF_NOISE, Stot, 1.0, GINGR_COEFF_NOISE);  // S_tot + eps (I + G)
+    lds_cholesky(A, ld, n, rd, &bad_spd, kNB);                                        // u <- L^-1 u on the way
+    lds_backward(A, ld, n, rd, u);
     __syncthreads();
     // c = L^T u with L the factor of I + G
-    lds_load_spd(A, ld, r, rp, G, 1.0, nullptr, 0.0, 1.0);
-    lds_cholesky(A, ld, r, rd, &bad_spd);
+    lds_load_spd(A, ld, r, n, G, 1.0, nullptr, 0.0, 1.0);
+    lds_cholesky(A, ld, n, rd, &bad_spd, 0);
     for (int k = tid; k < r; k += 256) {
         double s = 0.0;
         for (int i = k; i < r; ++i) s = __builtin_fma(A[i * ld + k], u[i], s);
@@ -1484,10 +1536,13 @@ void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
                             double *work, double *a, DevState *st) {
     TimerScope ts(ctx, 5);
     if (r <= 128) {
-        const size_t lds = ((size_t)r * (r | 1) + 3 * r) * sizeof(double);
-        if (lds > 48 * 1024)
+        const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
+        static size_t lds_granted = 48 * 1024;  // the attribute is per function, not per launch
+        if (lds > lds_granted) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_solve_lds_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            lds_granted = lds;
+        }
         hipLaunchKernelGGL(posterior_solve_lds_kernel, dim3(1), dim3(256), lds, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a,
                            st);
         return;
@@ -1499,7 +1554,7 @@ void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
 int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *Stot, const double *qte,
                             const double *a, double *out2) {
     if (r > 128) return GINGR_ERR_BAD_ARGUMENT;  // LDS-resident implementation only
-    const size_t lds = ((size_t)r * (r | 1) + 3 * r) * sizeof(double);
+    const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_lds_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
