@@ -768,6 +768,11 @@ __global__ void scatter_kernel(const double *__restrict__ in, int64_t n, const i
 #define GINGR_PT 4
 #endif
 constexpr int kPT = GINGR_PT;     // points per thread in both CPD passes
+// Row statistics of a SMALL shard (an 8-GPU rank owns 6250 rows at 50k): two points per thread halve the workgroup's rows,
+// which doubles the workgroups along the row axis, halves the chunk count (and the chunk partials) and lets a fourth
+// workgroup fit a CU; measured -5 % per iteration at 6250 rows, +6 % at 50000 (tools/prof_emu8.sh), hence the threshold.
+constexpr int64_t kSmallShardRows = 8192;
+inline int rowstats_pt(int64_t rows) { return (kPT > 2 && rows <= kSmallShardRows) ? 2 : kPT; }
 constexpr int kTargetBlocks = 2048;  // ~8 workgroups per CU
 
 // split `stream_len` into chunks so that block_cols * nchunks ~ kTargetBlocks; chunk length is a multiple of kTile
@@ -796,7 +801,7 @@ int64_t cpd_colsum_ws_doubles(int64_t M, int64_t N) {
 int64_t cpd_rowstats_ws_doubles(int64_t M, int64_t N) {
     int nch;
     int64_t len;
-    plan_chunks(M, kBlock * kPT, N, &nch, &len);
+    plan_chunks(M, kBlock * rowstats_pt(M), N, &nch, &len);
     const int64_t a = (int64_t)nch * 4 * M, b = cpd_rowstats_mfma_ws_doubles(M, N);
     return a > b ? a : b;
 }
@@ -858,10 +863,15 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
             launch_cpd_rowstats_mfma(ctx, fit, target, sigma2_dev, aux, inv_den, ws, &nch);
         } else {
             int64_t len;
-            plan_chunks(fit.n, kBlock * kPT, target.n, &nch, &len);
-            dim3 grid((unsigned)ceil_div(fit.n, kBlock * kPT), (unsigned)nch);
+            const int pt = rowstats_pt(fit.n);
+            plan_chunks(fit.n, kBlock * pt, target.n, &nch, &len);
+            dim3 grid((unsigned)ceil_div(fit.n, kBlock * pt), (unsigned)nch);
             const bool cull = ctx->cull && tgt_boxes && tile_bad;
-            hipLaunchKernelGGL(cpd_rowstats_kernel<kPT>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux,
+            if (pt == 2)
+                hipLaunchKernelGGL(cpd_rowstats_kernel<2>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux,
+                               inv_den, cull ? tgt_boxes : (const double *)nullptr, tile_bad, len, ws);
+            else
+                hipLaunchKernelGGL(cpd_rowstats_kernel<kPT>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux,
                                inv_den, cull ? tgt_boxes : (const double *)nullptr, tile_bad, len, ws);
         }
     }
