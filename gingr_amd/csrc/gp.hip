@@ -1183,26 +1183,33 @@ __global__ void small_gemm_kernel(int r, int rp, const double *__restrict__ A, c
     out[idx] = s * scale;
 }
 
-// zbuf[b] = M_b x_b, b = blockIdx.x: b < 9: S[d][e] alpha; 9 <= b < 18: T[d][e] a; b == 18: C a.  16 lanes per output row.
+// zbuf[b] = M_b x_b, b = blockIdx.x: b < 9: S[d][e] alpha; 9 <= b < 18: T[d][e] a; b == 18: C a.  blockIdx.y picks a strip of
+// 16 output rows, 16 lanes per row; a lane's (up to 8) matrix elements are all requested before the first FMA -- the matrices
+// live in L2 and a dependent load-FMA chain costs one round trip per element.
 __global__ __launch_bounds__(256) void post_matvecs_kernel(int r, int rp, const double *__restrict__ mom,
                                                            const double *__restrict__ cmat, const double *__restrict__ alpha,
                                                            const double *__restrict__ a, double *__restrict__ zbuf) {
-    __shared__ double x[512];
     const int b = blockIdx.x;
     const MomentLayout ml{rp};
     const double *Mat = b < 9 ? mom + ml.S(b / 3, b % 3) : (b < 18 ? cmat + (int64_t)(1 + (b - 9)) * rp * rp : cmat);
     const double *src = b < 9 ? alpha : a;
-    for (int k = threadIdx.x; k < rp; k += 256) x[k] = k < r ? src[k] : 0.0;
-    __syncthreads();
     const int lane16 = threadIdx.x & 15;
-    for (int i0 = 0; i0 < rp; i0 += 16) {
-        const int i = i0 + (threadIdx.x >> 4);
-        double s = 0.0;
-        if (i < r)
-            for (int j = lane16; j < r; j += 16) s = __builtin_fma(Mat[(int64_t)i * rp + j], x[j], s);
-        s = group16_sum(s);
-        if (lane16 == 0 && i < rp) zbuf[(int64_t)b * rp + i] = i < r ? s : 0.0;
-    }
+    const int i = blockIdx.y * 16 + (threadIdx.x >> 4);  // < rp (the grid covers rp / 16 strips)
+    const double *row = Mat + (int64_t)i * rp;
+    double m[32], x[32];  // rp <= 512
+    const int nj = rp >> 4;
+#pragma unroll
+    for (int jj = 0; jj < 32; ++jj)
+        if (jj < nj) {
+            m[jj] = row[lane16 + 16 * jj];
+            x[jj] = src[lane16 + 16 * jj];  // padding entries of alpha / a are zero
+        }
+    double s = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < 32; ++jj)
+        if (jj < nj) s = __builtin_fma(m[jj], x[jj], s);
+    s = group16_sum(s);
+    if (lane16 == 0) zbuf[(int64_t)b * rp + i] = i < r ? s : 0.0;
 }
 
 constexpr int kPostThreads = 1024;
@@ -1595,8 +1602,8 @@ void launch_post_solve(gingr_ctx *ctx, const PostSolveArgs &a) {
 }
 
 void launch_post_matvecs(gingr_ctx *ctx, const gingr_model *m, const double *alpha, const double *a, double *zbuf) {
-    hipLaunchKernelGGL(post_matvecs_kernel, dim3(19), dim3(256), 0, ctx->stream, (int)m->r, (int)m->rp, m->mom, m->cmat, alpha, a,
-                       zbuf);
+    hipLaunchKernelGGL(post_matvecs_kernel, dim3(19, (unsigned)(m->rp / 16)), dim3(256), 0, ctx->stream, (int)m->r, (int)m->rp,
+                       m->mom, m->cmat, alpha, a, zbuf);
 }
 
 void launch_small_gemm(gingr_ctx *ctx, int32_t r, int32_t rp, const double *A, const double *B, double scale, double *out) {
