@@ -377,26 +377,29 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ Q0
         }
 }
 
-// G[i][j] = sum over slabs (fixed tree): one 64-thread group per output element, 4 elements per workgroup.
-// symmetric: only i <= j is read (upper patches) and mirrored; otherwise every element is reduced.
+// G[i][j] = sum over slabs (fixed order): 32 consecutive elements x 8 slab groups per workgroup, so every load instruction
+// reads 256-byte runs of one slab; group g adds the slabs g, g+8, ... in ascending order, the groups are combined as
+// ((0+1)+(2+3))+((4+5)+(6+7)).  symmetric: only i <= j is read (upper patches) and mirrored; otherwise every element.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restrict__ partial, int nslabs, int rp, int symmetric,
                                                           double *__restrict__ G) {
-    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (idx >= rp * rp) return;
+    __shared__ double sh[8][33];
+    const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + el;
+    const int rr = rp * rp;
     const int i = idx / rp, j = idx - i * rp;
-    if (symmetric && i > j) return;
+    const bool need = idx < rr && !(symmetric && i > j);
     double s = 0.0;
-    for (int b = lane; b < nslabs; b += 64) s += partial[(int64_t)b * rp * rp + idx];
-    s += __shfl_xor(s, 32);
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 8);
-    s += __shfl_xor(s, 4);
-    s += __shfl_xor(s, 2);
-    s += __shfl_xor(s, 1);
-    if (lane == 0) {
-        G[i * rp + j] = s;
-        if (symmetric) G[j * rp + i] = s;
+    if (need) {
+        const double *p = partial + idx;
+#pragma unroll 8
+        for (int b = g; b < nslabs; b += 8) s += p[(int64_t)b * rr];
+    }
+    sh[g][el] = s;
+    __syncthreads();
+    if (g == 0 && need) {
+        const double t = ((sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el])) + ((sh[4][el] + sh[5][el]) + (sh[6][el] + sh[7][el]));
+        G[i * rp + j] = t;
+        if (symmetric) G[j * rp + i] = t;
     }
 }
 
@@ -1468,7 +1471,8 @@ static void gram_plan(int64_t M, int32_t rp, int *nbp, int *npatch, int *nslabs,
     *npatch = *nbp * (*nbp + 1) / 2;
     int64_t want = 768 / *npatch;  // ~3 workgroups of 4 waves per CU
     if (want < 1) want = 1;
-    const int64_t max_slabs = ceil_div(rows, 64);
+    // a slab writes a full rp x rp partial: below ~256 rows per slab the partials cost more than the rows they summarise
+    const int64_t max_slabs = ceil_div(rows, 256);
     if (want > max_slabs) want = max_slabs;
     if (want < 1) want = 1;
     *rows_per_slab = round_up(ceil_div(rows, want), 16);
@@ -1491,7 +1495,7 @@ void launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const 
         hipLaunchKernelGGL(gram_kernel, dim3(nslabs, npatch), dim3(256), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, nbp, 1,
                            0, 0, 0, ws);
     }
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 4)), dim3(256), 0, ctx->stream, ws,
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 32)), dim3(256), 0, ctx->stream, ws,
                        nslabs, (int)rp, 1, G);
 }
 
@@ -1504,7 +1508,7 @@ void launch_moment_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp,
     nslabs = (int)ceil_div(M, rps);
     hipLaunchKernelGGL(gram_kernel, dim3(nslabs, nbp * nbp), dim3(256), 0, ctx->stream, Q0, M, (int)rp,
                        (const double *)nullptr, rps, nbp, 3, d, e, 1, ws);
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 4)), dim3(256), 0, ctx->stream, ws,
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 32)), dim3(256), 0, ctx->stream, ws,
                        nslabs, (int)rp, 0, out);
 }
 
