@@ -140,6 +140,7 @@ class PointDistributionModel:
     mean: np.ndarray           # (M,3) displacement
     basis: np.ndarray          # (3M, r)
     variance: np.ndarray       # (r,)
+    cells: Optional[np.ndarray] = None   # (T,3) int: triangulation of the reference mesh (TriangleMesh.triangulation)
 
     @property
     def rank(self) -> int:
@@ -411,6 +412,7 @@ class GeneralRegistrationState:
     iteration: int = 0
     status: int = FittingStatuses.None_
     landmarkCorrespondences: Optional[LandmarkCorrespondences] = None
+    targetCells: Optional[np.ndarray] = None   # (T,3) int: triangulation of the target mesh (surface ICP only)
 
     def updateStatus(self, status: int) -> "GeneralRegistrationState":
         return dataclasses.replace(self, status=status)
@@ -502,11 +504,20 @@ class GingrAlgorithm:
             self._model_id = id(general.model)
             self._target_id = None
             self._lm_id = None
+            self._mesh_id = None
         if self._target_id != id(general.target):
             x = f64(general.target)
             _check(self.ctx.handle, self._lib.gingr_fitter_set_target(self._fitter, x.shape[0], dptr(x)), "gingr_fitter_set_target")
             self._target_id = id(general.target)
             self._device_state_token = None
+            self._mesh_id = None
+        mcells = getattr(general.model, "cells", None)
+        if mcells is not None and general.targetCells is not None and getattr(self, "_mesh_id", None) != (id(mcells), id(general.targetCells)):
+            mt = np.ascontiguousarray(mcells, dtype=np.int32).reshape(-1, 3)
+            tt = np.ascontiguousarray(general.targetCells, dtype=np.int32).reshape(-1, 3)
+            _check(self.ctx.handle, self._lib.gingr_fitter_set_meshes(self._fitter, mt.shape[0], iptr(mt), tt.shape[0], iptr(tt)),
+                   "gingr_fitter_set_meshes")
+            self._mesh_id = (id(mcells), id(general.targetCells))
         lm = general.landmarkCorrespondences if use_landmarks else None
         key = (id(lm), use_landmarks)
         if self._lm_id != key:
@@ -639,7 +650,8 @@ class GingrAlgorithm:
 
 def _initial_general(ctx: Context, model: PointDistributionModel, target: np.ndarray, sigma2: float,
                      transform: int, stepLength: float, landmarks: Optional[LandmarkCorrespondences],
-                     initial_pose: Optional[Tuple[Sequence[float], Sequence[float]]] = None) -> GeneralRegistrationState:
+                     initial_pose: Optional[Tuple[Sequence[float], Sequence[float]]] = None,
+                     targetCells: Optional[np.ndarray] = None) -> GeneralRegistrationState:
     """GeneralRegistrationState.apply (:135-179): alpha = 0, optional initial pose, fit = instance."""
     mp = ModelFittingParameters.zero(model.rank)
     if initial_pose is not None:
@@ -652,7 +664,7 @@ def _initial_general(ctx: Context, model: PointDistributionModel, target: np.nda
         dm.close()
     return GeneralRegistrationState(model=model, modelParameters=mp, target=f64(target), fit=fit, sigma2=sigma2,
                                     globalTransformation=transform, stepLength=stepLength,
-                                    landmarkCorrespondences=landmarks)
+                                    landmarkCorrespondences=landmarks, targetCells=targetCells)
 
 
 class CpdRegistration(GingrAlgorithm):
@@ -719,23 +731,50 @@ class IcpRegistration(GingrAlgorithm):
 
     def createInitialState(self, model: PointDistributionModel, target, config: IcpConfiguration,
                            transform: int = GlobalTranformationType.RigidTransforms, stepLength: float = 1.0,
-                           landmarks: Optional[LandmarkCorrespondences] = None, initial_pose=None) -> IcpRegistrationState:
-        g = _initial_general(self.ctx, model, target, 1.0, transform, stepLength, landmarks, initial_pose)
+                           landmarks: Optional[LandmarkCorrespondences] = None, initial_pose=None,
+                           targetCells: Optional[np.ndarray] = None) -> IcpRegistrationState:
+        g = _initial_general(self.ctx, model, target, 1.0, transform, stepLength, landmarks, initial_pose, targetCells)
         return self.initializeState(g, config)
 
     def initializeState(self, general: GeneralRegistrationState, config: IcpConfiguration) -> IcpRegistrationState:
-        if config.correspondenceMethod != "PointcloudClosestPoint" or config.reverseCorrespondenceDirection:
-            raise NotImplementedError("only the PointcloudClosestPoint flavour (ICP.scala:43) is on the accelerated path")
+        if config.reverseCorrespondenceDirection or config.correspondenceMethod not in ("PointcloudClosestPoint", "TriangularClosestPoint"):
+            raise NotImplementedError("accelerated ICP flavours: PointcloudClosestPoint and TriangularClosestPoint (ICP.scala:40-44), "
+                                      "forward direction")
+        if config.correspondenceMethod == "TriangularClosestPoint" and (getattr(general.model, "cells", None) is None
+                                                                        or general.targetCells is None):
+            raise ValueError("TriangularClosestPoint needs the triangulations: model.cells and targetCells")
         return IcpRegistrationState(general.updateSigma2(float(config.initialSigma)), config)   # ICP.scala:73-85
 
     def _native_update(self, current: IcpRegistrationState, n: int):
         c = current.config
         p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
-        _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_async(self._fitter, ctypes.byref(p), n),
-               "gingr_fitter_update_icp_async")
+        if c.correspondenceMethod == "TriangularClosestPoint":
+            _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_surface_async(self._fitter, ctypes.byref(p), n),
+                   "gingr_fitter_update_icp_surface_async")
+        else:
+            _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_async(self._fitter, ctypes.byref(p), n),
+                   "gingr_fitter_update_icp_async")
+
+    def surfaceCorrespondence(self, state: IcpRegistrationState) -> Tuple[np.ndarray, np.ndarray]:
+        """ClosestPointTriangleMesh3D.closestPointCorrespondence(fit, target) (ClosestPointRegistrator.scala:75-100) for the
+        state's fit: (closest surface points (M,3), weights in {0,1})."""
+        g, c = state.general, state.config
+        self._bind(g, c.useLandmarkCorrespondence)
+        self._push_state(g)
+        self._device_state_token = None
+        p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
+        _check(self.ctx.handle, self._lib.gingr_fitter_icp_surface_phase_async(self._fitter, ctypes.byref(p), 0),
+               "gingr_fitter_icp_surface_phase_async")
+        M = g.model.numberOfPoints
+        cp, w = np.empty((M, 3)), np.empty(M)
+        _check(self.ctx.handle, self._lib.gingr_fitter_get_surface_correspondence(self._fitter, dptr(cp), dptr(w)),
+               "gingr_fitter_get_surface_correspondence")
+        return cp, w
 
     def _native_update_sample(self, current: IcpRegistrationState, z: np.ndarray):
         c = current.config
+        if c.correspondenceMethod != "PointcloudClosestPoint":
+            raise NotImplementedError("probabilistic proposals are on the accelerated path for PointcloudClosestPoint only")
         p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
         _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_sample_async(self._fitter, ctypes.byref(p), dptr(z)),
                "gingr_fitter_update_icp_sample_async")
@@ -749,6 +788,10 @@ class IcpRegistration(GingrAlgorithm):
         return out.value
 
     def getCorrespondence(self, state: IcpRegistrationState) -> CorrespondencePairs:
+        if state.config.correspondenceMethod == "TriangularClosestPoint":             # ICP.scala:40,50
+            cp, w = self.surfaceCorrespondence(state)
+            keep = np.flatnonzero(w == 1.0)
+            return CorrespondencePairs(keep, cp[keep])
         idx, _, _ = self.ctx.nn(state.general.fit, state.general.target)              # ICP.scala:36-52
         return CorrespondencePairs(np.arange(idx.shape[0]), f64(state.general.target)[idx])
 

@@ -141,6 +141,22 @@ void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_
                int32_t *idx, double *d2);
 void launch_gauss_block(gingr_ctx *ctx, Cloud A, Cloud B, double sigma, double scaling, double *out);
 void launch_sumsq_pairs(gingr_ctx *ctx, Cloud A, Cloud B, double *ws, double *out_scalar);
+// ---------------------------------------------------------------------------- surface.hip (ICP surface correspondence)
+// tri: [3*T] vertex POSITIONS in the cloud `v`, in a spatial triangle order; boxes: one {lo, hi} per 256 triangles
+void launch_cell_normals(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *cn_soa);
+void launch_vertex_normals(gingr_ctx *ctx, const int32_t *adj_ptr, const int32_t *adj_tri, const double *cn_soa, int64_t T,
+                           int64_t n, double *vn_soa);
+void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *boxes);
+// closest point of the triangle soup to every query (SoA out); exact ties: lowest tri_orig
+void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T,
+                                  const double *boxes, double *cp_soa, double *d2);
+void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, const int32_t *tri, int64_t T, const double *boxes,
+                           const int32_t *skip, int32_t *flag);
+void launch_surface_prereject(gingr_ctx *ctx, int64_t M, const int32_t *nn_vertex, const int32_t *tgt_boundary,
+                              const double *fit_vn, const double *tgt_vn, int64_t N, int32_t *pre);
+void launch_surface_weight(gingr_ctx *ctx, int64_t M, const int32_t *pre, const int32_t *hit, const double *sigma2_dev, double *w01,
+                           double *weight_in);
+
 // interleaved xyz (n*3) <-> SoA planes; perm (nullable) maps device position -> original index:
 // soa[s] = aos[perm[s]] resp. aos[perm[s]] = soa[s]
 void launch_aos_to_soa(gingr_ctx *ctx, const double *aos, int64_t n, double *soa, const int32_t *perm = nullptr);

@@ -10,6 +10,7 @@
 //      projection, alpha', state commit or failure status; finally the new fit of the local rows (one pass over Q0)
 #include "gp.h"
 
+#include <algorithm>
 #include <cmath>
 #include <functional>
 
@@ -50,6 +51,16 @@ struct gingr_fitter {
     int32_t global_transform = GINGR_RIGID_TRANSFORMS;
     double step_length = 1.0;
     bool has_state = false;
+    // ---- ICP surface correspondence (surface.hip): triangles in device vertex positions and a spatial triangle order
+    bool icp_surface = false;                      // correspondence flavour of the ICP phases
+    int64_t Tm = 0, Tt = 0;                        // model / target triangle counts
+    int32_t *mtri = nullptr, *ttri = nullptr, *ttri_orig = nullptr;
+    int32_t *madj_ptr = nullptr, *madj_tri = nullptr, *tadj_ptr = nullptr, *tadj_tri = nullptr;  // vertex -> triangles
+    double *mcn = nullptr, *tcn = nullptr, *mvn = nullptr, *tvn = nullptr;  // cell / vertex normals (SoA)
+    double *mtboxes = nullptr, *ttboxes = nullptr;  // triangle tile boxes
+    int32_t *tboundary = nullptr;                   // target boundary vertices (device target positions)
+    double *surf_cp = nullptr, *surf_d2 = nullptr, *surf_w01 = nullptr, *surf_win = nullptr, *surf_nnd2 = nullptr;
+    int32_t *surf_nn = nullptr, *surf_pre = nullptr, *surf_hit = nullptr;
 };
 
 namespace {
@@ -100,6 +111,18 @@ void refresh_fit(gingr_fitter *f) {
     a.shape_out = f->fit;
     a.zero_slot = f->absmax + 1;
     launch_sweep(f->ctx, SWEEP_FIT, a);
+}
+
+void free_meshes(gingr_fitter *f) {
+    void *ptrs[] = {f->mtri, f->ttri, f->ttri_orig, f->madj_ptr, f->madj_tri, f->tadj_ptr, f->tadj_tri, f->mcn, f->tcn, f->mvn,
+                    f->tvn, f->mtboxes, f->ttboxes, f->tboundary, f->surf_cp, f->surf_d2, f->surf_w01, f->surf_win, f->surf_nnd2,
+                    f->surf_nn, f->surf_pre, f->surf_hit};
+    for (void *p : ptrs) dev_free(p);
+    f->mtri = f->ttri = f->ttri_orig = f->madj_ptr = f->madj_tri = f->tadj_ptr = f->tadj_tri = f->tboundary = nullptr;
+    f->mcn = f->tcn = f->mvn = f->tvn = f->mtboxes = f->ttboxes = nullptr;
+    f->surf_cp = f->surf_d2 = f->surf_w01 = f->surf_win = f->surf_nnd2 = nullptr;
+    f->surf_nn = f->surf_pre = f->surf_hit = nullptr;
+    f->Tm = f->Tt = 0;
 }
 
 int model_finalize_impl(gingr_ctx *ctx, gingr_model *m) {
@@ -377,6 +400,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->lm_xyz);
     dev_free(f->lm_cov);
     dev_free(f->lm_mask);
+    free_meshes(f);
     delete f;
 }
 
@@ -398,6 +422,7 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
     dev_free(f->tboxes);
     dev_free(f->fboxes);
     dev_free(f->tile_bad);
+    free_meshes(f);  // the target triangles refer to the previous target
     f->target = f->inv_den = f->Pt1 = f->xch = f->ws = f->tboxes = f->fboxes = nullptr;
     f->aos = nullptr;
     f->tperm = f->tile_bad = nullptr;
@@ -632,7 +657,17 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
     const Cloud tgt = cloud_of(f->target, f->N);
     switch (phase) {
         case 0: {
-            if (icp)
+            if (icp && f->icp_surface) {
+                // ClosestPointTriangleMesh3D.closestPointCorrespondence (ClosestPointRegistrator.scala:75-100)
+                launch_cell_normals(ctx, fit, f->mtri, f->Tm, f->mcn);
+                launch_vertex_normals(ctx, f->madj_ptr, f->madj_tri, f->mcn, f->Tm, M, f->mvn);
+                launch_tri_tile_bbox(ctx, fit, f->mtri, f->Tm, f->mtboxes);
+                launch_surface_closest_point(ctx, fit, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, f->surf_cp, f->surf_d2);
+                launch_nn(ctx, cloud_of(f->surf_cp, M), tgt, f->tperm, f->tboxes, f->ws, f->surf_nn, f->surf_nnd2);
+                launch_surface_prereject(ctx, M, f->surf_nn, f->tboundary, f->mvn, f->tvn, f->N, f->surf_pre);
+                launch_self_intersect(ctx, fit, f->surf_cp, f->mtri, f->Tm, f->mtboxes, f->surf_pre, f->surf_hit);
+                launch_surface_weight(ctx, M, f->surf_pre, f->surf_hit, &f->st->sigma2, f->surf_w01, f->surf_win);
+            } else if (icp)
                 launch_nn(ctx, fit, tgt, f->tperm, f->tboxes, f->ws, f->nn_idx, f->nn_d2);
             else {
                 // boxes of the fit tiles + its |coordinate - centroid| maximum (slot cleared by the pass that wrote the fit)
@@ -643,7 +678,10 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
         }
         case 1: {
             if (icp) {
-                launch_obs_icp(ctx, m, f->st, tgt, f->nn_idx, f->lm_mask, f->weight, f->evec);
+                if (f->icp_surface)  // only the weight-1 pairs are observed (ICP.scala:50): weight 0 drops the row
+                    launch_obs_points(ctx, m, f->st, f->surf_cp, f->surf_win, f->weight, f->evec, f->lm_mask);
+                else
+                    launch_obs_icp(ctx, m, f->st, tgt, f->nn_idx, f->lm_mask, f->weight, f->evec);
                 hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(64), 0, ctx->stream, sc8, (int64_t)8);
             } else {
                 launch_cpd_den_finalize(ctx, tgt, &f->st->sigma2, cp->w, m->M_total, seg0, f->inv_den, f->Pt1, f->tile_bad, f->part,
@@ -718,6 +756,7 @@ int gingr_fitter_cpd_phase_async(gingr_fitter *f, const gingr_cpd_params *p, int
 int gingr_fitter_icp_phase_async(gingr_fitter *f, const gingr_icp_params *p, int32_t phase) {
     GINGR_TRY(check_ready(f));
     if (!p || p->max_iterations < 1) return gingr_set_error(f->ctx, GINGR_ERR_BAD_ARGUMENT, "icp params: max_iterations < 1");
+    f->icp_surface = false;
     return run_phase(f, true, nullptr, p, phase);
 }
 
@@ -740,6 +779,157 @@ int gingr_fitter_update_icp_async(gingr_fitter *f, const gingr_icp_params *p, in
         TimerScope ts(f->ctx, 3);
         for (int ph = 0; ph < GINGR_NUM_PHASES; ++ph) GINGR_TRY(gingr_fitter_icp_phase_async(f, p, ph));
     }
+    return GINGR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ ICP, surface correspondence
+int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t *model_tri, int64_t n_target_tri,
+                            const int32_t *target_tri) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = f->ctx;
+    if (!f->target) return gingr_set_error(ctx, GINGR_ERR_STATE, "set_meshes: no target set (gingr_fitter_set_target)");
+    if (f->m->M != f->m->M_total) return gingr_set_error(ctx, GINGR_ERR_STATE, "set_meshes: single shard only");
+    if (n_model_tri < 1 || n_target_tri < 1 || !model_tri || !target_tri)
+        return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_meshes: need at least one triangle per mesh");
+    const int64_t M = f->m->M, N = f->N;
+    for (int64_t k = 0; k < 3 * n_model_tri; ++k)
+        if (model_tri[k] < 0 || model_tri[k] >= M) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_meshes: model vertex id out of range");
+    for (int64_t k = 0; k < 3 * n_target_tri; ++k)
+        if (target_tri[k] < 0 || target_tri[k] >= N) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_meshes: target vertex id out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_meshes(f);
+    // device vertex positions of the two clouds (orig -> device) and their coordinates in device order
+    std::vector<int32_t> tinv((size_t)N);
+    for (int64_t s2 = 0; s2 < N; ++s2) tinv[(size_t)f->h_tperm[(size_t)s2]] = (int32_t)s2;
+    std::vector<double> mpos((size_t)3 * M), mmean((size_t)3 * M), tpos((size_t)3 * N);
+    HIP_TRY(ctx, hipMemcpy(mpos.data(), f->m->ref, mpos.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(mmean.data(), f->m->mean, mmean.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(tpos.data(), f->target, tpos.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < mpos.size(); ++k) mpos[k] += mmean[k];
+    struct Built {
+        std::vector<int32_t> tri, orig, adj_ptr, adj_tri;
+    };
+    auto build = [&](int64_t T, const int32_t *tri, const std::vector<int32_t> &inv, const std::vector<double> &soa, int64_t n,
+                     Built &b) {
+        std::vector<double> cen((size_t)3 * T);
+        for (int64_t t = 0; t < T; ++t)
+            for (int d = 0; d < 3; ++d) {
+                double c = 0.0;
+                for (int k = 0; k < 3; ++k) c += soa[(size_t)d * n + inv[(size_t)tri[3 * t + k]]];
+                cen[(size_t)3 * t + d] = c / 3.0;
+            }
+        morton_order(cen.data(), T, b.orig);  // orig[s] = original index of the triangle at device position s
+        std::vector<int32_t> tpos2((size_t)T);
+        b.tri.resize((size_t)3 * T);
+        for (int64_t s2 = 0; s2 < T; ++s2) {
+            const int32_t t = b.orig[(size_t)s2];
+            tpos2[(size_t)t] = (int32_t)s2;
+            for (int k = 0; k < 3; ++k) b.tri[(size_t)3 * s2 + k] = inv[(size_t)tri[3 * t + k]];
+        }
+        // vertex -> triangles, in ascending ORIGINAL triangle index (the order the normals are averaged in)
+        std::vector<int32_t> cnt((size_t)n + 1, 0);
+        for (int64_t k = 0; k < 3 * T; ++k) cnt[(size_t)inv[(size_t)tri[k]] + 1]++;
+        for (int64_t v = 0; v < n; ++v) cnt[(size_t)v + 1] += cnt[(size_t)v];
+        b.adj_ptr = cnt;
+        b.adj_tri.resize((size_t)3 * T);
+        std::vector<int32_t> fill(cnt.begin(), cnt.end() - 1);
+        for (int64_t t = 0; t < T; ++t)
+            for (int k = 0; k < 3; ++k) b.adj_tri[(size_t)fill[(size_t)inv[(size_t)tri[3 * t + k]]]++] = tpos2[(size_t)t];
+    };
+    Built bm, bt;
+    build(n_model_tri, model_tri, f->m->hiperm, mpos, M, bm);
+    build(n_target_tri, target_tri, tinv, tpos, N, bt);
+    // target boundary vertices: on an edge with exactly one adjacent triangle (TriangleMesh3DOperations.pointIsOnBoundary)
+    std::vector<int32_t> bnd((size_t)N, 0);
+    {
+        std::vector<std::pair<uint64_t, int>> edges;
+        edges.reserve((size_t)3 * n_target_tri);
+        for (int64_t t = 0; t < n_target_tri; ++t)
+            for (int k = 0; k < 3; ++k) {
+                const uint64_t a = (uint64_t)target_tri[3 * t + k], b = (uint64_t)target_tri[3 * t + (k + 1) % 3];
+                edges.push_back({(a < b ? a : b) << 32 | (a < b ? b : a), 0});
+            }
+        std::sort(edges.begin(), edges.end());
+        for (size_t i = 0; i < edges.size();) {
+            size_t j = i;
+            while (j < edges.size() && edges[j].first == edges[i].first) ++j;
+            if (j - i == 1) {
+                bnd[(size_t)tinv[(size_t)(edges[i].first >> 32)]] = 1;
+                bnd[(size_t)tinv[(size_t)(edges[i].first & 0xffffffffu)]] = 1;
+            }
+            i = j;
+        }
+    }
+    f->Tm = n_model_tri;
+    f->Tt = n_target_tri;
+    const int64_t ntm = ceil_div(f->Tm, 256), ntt = ceil_div(f->Tt, 256);
+    int rc;
+    if ((rc = dev_alloc(ctx, &f->mtri, (size_t)3 * f->Tm)) || (rc = dev_alloc(ctx, &f->ttri, (size_t)3 * f->Tt)) ||
+        (rc = dev_alloc(ctx, &f->ttri_orig, (size_t)f->Tt)) || (rc = dev_alloc(ctx, &f->madj_ptr, (size_t)M + 1)) ||
+        (rc = dev_alloc(ctx, &f->madj_tri, (size_t)3 * f->Tm)) || (rc = dev_alloc(ctx, &f->tadj_ptr, (size_t)N + 1)) ||
+        (rc = dev_alloc(ctx, &f->tadj_tri, (size_t)3 * f->Tt)) || (rc = dev_alloc(ctx, &f->mcn, (size_t)3 * f->Tm)) ||
+        (rc = dev_alloc(ctx, &f->tcn, (size_t)3 * f->Tt)) || (rc = dev_alloc(ctx, &f->mvn, (size_t)3 * M)) ||
+        (rc = dev_alloc(ctx, &f->tvn, (size_t)3 * N)) || (rc = dev_alloc(ctx, &f->mtboxes, (size_t)6 * ntm)) ||
+        (rc = dev_alloc(ctx, &f->ttboxes, (size_t)6 * ntt)) || (rc = dev_alloc(ctx, &f->tboundary, (size_t)N)) ||
+        (rc = dev_alloc(ctx, &f->surf_cp, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->surf_d2, (size_t)M)) ||
+        (rc = dev_alloc(ctx, &f->surf_w01, (size_t)M)) || (rc = dev_alloc(ctx, &f->surf_win, (size_t)M)) ||
+        (rc = dev_alloc(ctx, &f->surf_nnd2, (size_t)M)) || (rc = dev_alloc(ctx, &f->surf_nn, (size_t)M)) ||
+        (rc = dev_alloc(ctx, &f->surf_pre, (size_t)M)) || (rc = dev_alloc(ctx, &f->surf_hit, (size_t)M)))
+        return rc;
+    auto up = [&](int32_t *dst, const std::vector<int32_t> &src) {
+        return hipMemcpy(dst, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    };
+    HIP_TRY(ctx, up(f->mtri, bm.tri));
+    HIP_TRY(ctx, up(f->ttri, bt.tri));
+    HIP_TRY(ctx, up(f->ttri_orig, bt.orig));
+    HIP_TRY(ctx, up(f->madj_ptr, bm.adj_ptr));
+    HIP_TRY(ctx, up(f->madj_tri, bm.adj_tri));
+    HIP_TRY(ctx, up(f->tadj_ptr, bt.adj_ptr));
+    HIP_TRY(ctx, up(f->tadj_tri, bt.adj_tri));
+    HIP_TRY(ctx, up(f->tboundary, bnd));
+    // static target side: cell normals, vertex normals, triangle tile boxes
+    const Cloud tgt = cloud_of(f->target, N);
+    launch_cell_normals(ctx, tgt, f->ttri, f->Tt, f->tcn);
+    launch_vertex_normals(ctx, f->tadj_ptr, f->tadj_tri, f->tcn, f->Tt, N, f->tvn);
+    launch_tri_tile_bbox(ctx, tgt, f->ttri, f->Tt, f->ttboxes);
+    GINGR_TRY(check_launch(ctx));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GINGR_OK;
+}
+
+int gingr_fitter_icp_surface_phase_async(gingr_fitter *f, const gingr_icp_params *p, int32_t phase) {
+    GINGR_TRY(check_ready(f));
+    if (!p || p->max_iterations < 1) return gingr_set_error(f->ctx, GINGR_ERR_BAD_ARGUMENT, "icp params: max_iterations < 1");
+    if (!f->Tm || !f->Tt) return gingr_set_error(f->ctx, GINGR_ERR_STATE, "icp surface: no meshes set (gingr_fitter_set_meshes)");
+    f->icp_surface = true;
+    return run_phase(f, true, nullptr, p, phase);
+}
+
+int gingr_fitter_update_icp_surface_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations) {
+    GINGR_TRY(check_ready(f));
+    for (int32_t it = 0; it < n_iterations; ++it) {
+        TimerScope ts(f->ctx, 3);
+        for (int ph = 0; ph < GINGR_NUM_PHASES; ++ph) GINGR_TRY(gingr_fitter_icp_surface_phase_async(f, p, ph));
+    }
+    return GINGR_OK;
+}
+
+int gingr_fitter_get_surface_correspondence(gingr_fitter *f, double *cp_xyz, double *w) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = f->ctx;
+    if (!f->surf_cp) return gingr_set_error(ctx, GINGR_ERR_STATE, "get_surface_correspondence: no meshes set");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t M = f->m->M;
+    if (cp_xyz) {
+        launch_soa_to_aos(ctx, f->surf_cp, M, reinterpret_cast<double *>(f->aos), f->m->perm);
+        HIP_TRY(ctx, hipMemcpyAsync(cp_xyz, f->aos, (size_t)3 * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    std::vector<double> hw((size_t)M);
+    HIP_TRY(ctx, hipMemcpyAsync(hw.data(), f->surf_w01, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (w)
+        for (int64_t s2 = 0; s2 < M; ++s2) w[f->m->hperm[(size_t)s2]] = hw[(size_t)s2];
     return GINGR_OK;
 }
 

@@ -124,7 +124,7 @@ void launch_obs_icp(gingr_ctx *ctx, const gingr_model *m, const DevState *st, Cl
                     const int32_t *lm_mask, double *weight, double *evec);
 // generic: obs points given as SoA planes with per-point weights
 void launch_obs_points(gingr_ctx *ctx, const gingr_model *m, const DevState *st, const double *obs_soa,
-                       const double *weight_in, double *weight, double *evec);
+                       const double *weight_in, double *weight, double *evec, const int32_t *lm_mask = nullptr);
 // landmarks with full 3x3 covariance added into G and rhs of the (reduced) exchange segment; local pids, local rows only
 void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, int32_t n_lm, const int32_t *lm_pid_local,
                       const double *lm_xyz, const double *lm_cov, double *G, double *rhs);

@@ -1530,10 +1530,10 @@ void launch_obs_icp(gingr_ctx *ctx, const gingr_model *m, const DevState *st, Cl
 }
 
 void launch_obs_points(gingr_ctx *ctx, const gingr_model *m, const DevState *st, const double *obs_soa,
-                       const double *weight_in, double *weight, double *evec) {
+                       const double *weight_in, double *weight, double *evec, const int32_t *lm_mask) {
     Cloud none{nullptr, nullptr, nullptr, 0};
     hipLaunchKernelGGL(obs_points_kernel, dim3((unsigned)ceil_div(m->M, 256)), dim3(256), 0, ctx->stream, m->ref, m->mean,
-                       m->M, st, obs_soa, none, (const int32_t *)nullptr, weight_in, (const int32_t *)nullptr, weight, evec);
+                       m->M, st, obs_soa, none, (const int32_t *)nullptr, weight_in, lm_mask, weight, evec);
 }
 
 void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, int32_t n_lm, const int32_t *lm_pid_local,

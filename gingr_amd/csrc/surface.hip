@@ -1,0 +1,350 @@
+// ICP with the surface correspondence: the reference's DEFAULT ICP method
+//     ICPCorrespondence.estimate with TriangularClosestPoint (G/api/registration/config/ICP.scala:36-52,63)
+//       -> ClosestPointTriangleMesh3D.closestPointCorrespondence (G/api/registration/utils/ClosestPointRegistrator.scala:75-100)
+// For every template (fit) vertex p:  cp = target.operations.closestPointOnSurface(p);  v = the target VERTEX closest to cp;
+// weight 0 when v is a boundary vertex (:53-55), when the vertex normals of p and v point into opposite half spaces (:57-60),
+// or when the line through p along p - cp meets the template itself closer than |p - cp| (:62-72); else 1.  Only weight-1
+// pairs become observations (ICP.scala:50).
+//
+// scalismo's mesh queries are restated (oracle/gingr_oracle.py, section f2): exact point-triangle closest point (Ericson
+// 5.1.5), vertex normal = mean of the adjacent unit cell normals, boundary vertex = on an edge with one adjacent triangle,
+// line-triangle intersection = Moeller-Trumbore on the infinite line with inclusive barycentric bounds (UNPINNED: scalismo's
+// own intersection routine is not available; with this formulation a triangle that has p as a corner returns exactly p,
+// which the reference filters out).  Arithmetic is written without FMA contraction in the oracle's operation order.
+//
+// Triangles live in a spatial (k-d leaf) order with one bounding box per 256-triangle tile; a wave owns 64 spatially
+// coherent queries and skips every tile whose box cannot hold anything closer than what each lane already has -- the same
+// exact pruning as the nearest-neighbour kernel (affinity.hip).
+#include "common.h"
+
+namespace {
+
+constexpr int kTriTile = 256;
+constexpr int kSurfThreads = 64;
+
+struct V3 {
+    double x, y, z;
+};
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ double dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ V3 cross3(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ V3 madd(V3 a, V3 d, double s) { return V3{a.x + d.x * s, a.y + d.y * s, a.z + d.z * s}; }
+
+__device__ __forceinline__ double uniform_dd(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// closest point of triangle (A, B, C) to p: Ericson, Real-Time Collision Detection 5.1.5 (region tests in his order)
+__device__ __forceinline__ V3 closest_on_triangle(V3 p, V3 A, V3 B, V3 C) {
+    const V3 ab = sub(B, A), ac = sub(C, A), ap = sub(p, A);
+    const double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+    if (d1 <= 0.0 && d2 <= 0.0) return A;
+    const V3 bp = sub(p, B);
+    const double d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+    if (d3 >= 0.0 && d4 <= d3) return B;
+    const double vc = d1 * d4 - d3 * d2;
+    if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) return madd(A, ab, d1 / (d1 - d3));
+    const V3 cp = sub(p, C);
+    const double d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+    if (d6 >= 0.0 && d5 <= d6) return C;
+    const double vb = d5 * d2 - d1 * d6;
+    if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) return madd(A, ac, d2 / (d2 - d6));
+    const double va = d3 * d6 - d5 * d4;
+    if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) return madd(B, sub(C, B), (d4 - d3) / ((d4 - d3) + (d5 - d6)));
+    const double denom = 1.0 / ((va + vb) + vc);
+    const double v = vb * denom, w = vc * denom;
+    return madd(madd(A, ab, v), ac, w);
+}
+
+__device__ __forceinline__ double point_box_gap2(double qx, double qy, double qz, const double *__restrict__ bx) {
+    const double gx = fmax(fmax(bx[0] - qx, qx - bx[3]), 0.0), gy = fmax(fmax(bx[1] - qy, qy - bx[4]), 0.0),
+                 gz = fmax(fmax(bx[2] - qz, qz - bx[5]), 0.0);
+    return __builtin_fma(gz, gz, __builtin_fma(gy, gy, gx * gx));
+}
+
+// cn (SoA [3][T]) = unit normal (b - a) x (c - a) of every triangle
+__global__ __launch_bounds__(256) void cell_normals_kernel(Cloud v, const int32_t *__restrict__ tri, int64_t T,
+                                                           double *__restrict__ cn) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const int32_t a = tri[3 * t], b = tri[3 * t + 1], c = tri[3 * t + 2];
+    const V3 A{v.x[a], v.y[a], v.z[a]}, B{v.x[b], v.y[b], v.z[b]}, C{v.x[c], v.y[c], v.z[c]};
+    const V3 n = cross3(sub(B, A), sub(C, A));
+    const double len = sqrt((n.x * n.x + n.y * n.y) + n.z * n.z);
+    cn[t] = n.x / len;
+    cn[T + t] = n.y / len;
+    cn[2 * T + t] = n.z / len;
+}
+
+// vn (SoA [3][n]) = mean of the adjacent cell normals, adjacency lists in ascending ORIGINAL triangle index
+__global__ __launch_bounds__(256) void vertex_normals_kernel(const int32_t *__restrict__ adj_ptr, const int32_t *__restrict__ adj_tri,
+                                                             const double *__restrict__ cn, int64_t T, int64_t n,
+                                                             double *__restrict__ vn) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    const int32_t b = adj_ptr[i], e = adj_ptr[i + 1];
+    for (int32_t k = b; k < e; ++k) {
+        const int32_t t = adj_tri[k];
+        sx += cn[t];
+        sy += cn[T + t];
+        sz += cn[2 * T + t];
+    }
+    const double cnt = e > b ? (double)(e - b) : 1.0;
+    vn[i] = sx / cnt;
+    vn[n + i] = sy / cnt;
+    vn[2 * n + i] = sz / cnt;
+}
+
+// boxes[tile] = {lo[3], hi[3]} over the corners of the triangles [tile*256, tile*256+256)
+__global__ __launch_bounds__(256) void tri_tile_bbox_kernel(Cloud v, const int32_t *__restrict__ tri, int64_t T,
+                                                            double *__restrict__ boxes) {
+    __shared__ double sh[6][256];
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double lo[3] = {__builtin_huge_val(), __builtin_huge_val(), __builtin_huge_val()};
+    double hi[3] = {-__builtin_huge_val(), -__builtin_huge_val(), -__builtin_huge_val()};
+    if (t < T)
+        for (int c = 0; c < 3; ++c) {
+            const int32_t a = tri[3 * t + c];
+            const double p[3] = {v.x[a], v.y[a], v.z[a]};
+            for (int d = 0; d < 3; ++d) {
+                lo[d] = fmin(lo[d], p[d]);
+                hi[d] = fmax(hi[d], p[d]);
+            }
+        }
+    for (int d = 0; d < 3; ++d) {
+        sh[d][threadIdx.x] = lo[d];
+        sh[3 + d][threadIdx.x] = hi[d];
+    }
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int d = 0; d < 3; ++d) {
+                sh[d][threadIdx.x] = fmin(sh[d][threadIdx.x], sh[d][threadIdx.x + off]);
+                sh[3 + d][threadIdx.x] = fmax(sh[3 + d][threadIdx.x], sh[3 + d][threadIdx.x + off]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) boxes[(int64_t)blockIdx.x * 6 + threadIdx.x] = sh[threadIdx.x][0];
+}
+
+struct Tri9 {
+    double ax, ay, az, bx, by, bz, cx, cy, cz, orig;
+};
+
+__device__ __forceinline__ void stage_tile(Tri9 *tile, Cloud v, const int32_t *__restrict__ tri,
+                                           const int32_t *__restrict__ tri_orig, int64_t tb, int64_t T, int lane) {
+#pragma unroll
+    for (int u = 0; u < kTriTile / kSurfThreads; ++u) {
+        const int64_t t = tb + u * kSurfThreads + lane;
+        if (t < T) {
+            const int32_t a = tri[3 * t], b = tri[3 * t + 1], c = tri[3 * t + 2];
+            tile[u * kSurfThreads + lane] = Tri9{v.x[a], v.y[a], v.z[a], v.x[b], v.y[b], v.z[b], v.x[c], v.y[c], v.z[c],
+                                                 (double)(tri_orig ? tri_orig[t] : (int32_t)t)};
+        }
+    }
+}
+
+// wave-wide bounding box of the valid lanes' points
+__device__ __forceinline__ void wave_box(bool ok, double qx, double qy, double qz, double wb[6]) {
+    double lo[3] = {ok ? qx : __builtin_huge_val(), ok ? qy : __builtin_huge_val(), ok ? qz : __builtin_huge_val()};
+    double hi[3] = {ok ? qx : -__builtin_huge_val(), ok ? qy : -__builtin_huge_val(), ok ? qz : -__builtin_huge_val()};
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = fmin(lo[d], __shfl_xor(lo[d], off));
+            hi[d] = fmax(hi[d], __shfl_xor(hi[d], off));
+        }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        wb[d] = uniform_dd(lo[d]);
+        wb[3 + d] = uniform_dd(hi[d]);
+    }
+}
+
+__device__ __forceinline__ double box_box_gap2(const double a[6], const double *__restrict__ b) {
+    double s = 0.0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const double g = fmax(fmax(a[d] - b[3 + d], b[d] - a[3 + d]), 0.0);
+        s = __builtin_fma(g, g, s);
+    }
+    return s;
+}
+
+// cp (SoA [3][nq]) / d2: closest point of the triangle soup to every query; exact ties go to the lowest ORIGINAL triangle.
+__global__ __launch_bounds__(kSurfThreads) void surface_cp_kernel(Cloud q, Cloud v, const int32_t *__restrict__ tri,
+                                                                 const int32_t *__restrict__ tri_orig, int64_t T,
+                                                                 const double *__restrict__ boxes, double *__restrict__ cp,
+                                                                 double *__restrict__ d2out) {
+    __shared__ Tri9 tile[kTriTile];
+    const int lane = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kSurfThreads + lane;
+    const bool ok = i < q.n;
+    const double qx = ok ? q.x[i] : 0.0, qy = ok ? q.y[i] : 0.0, qz = ok ? q.z[i] : 0.0;
+    const V3 p{qx, qy, qz};
+    double best = __builtin_huge_val(), bo = __builtin_huge_val();
+    V3 bp{qx, qy, qz};
+    double wb[6];
+    wave_box(ok, qx, qy, qz, wb);
+    const int nt = (int)((T + kTriTile - 1) / kTriTile);
+    // sweep 0: tiles touching the wave's box; sweep 1: the others, only while some lane could still improve (see nn_kernel)
+    for (int phase = 0; phase < 2; ++phase)
+        for (int t = 0; t < nt; ++t) {
+            const double *bx = boxes + (int64_t)t * 6;
+            const double g = box_box_gap2(wb, bx);
+            if (phase == 0) {
+                if (g > 0.0) continue;
+            } else {
+                if (!(g > 0.0)) continue;
+                const double pd = point_box_gap2(qx, qy, qz, bx);
+                const bool need = ok && !(pd > best * (1.0 + 1e-12));
+                if (!__any(need)) continue;
+            }
+            const int64_t tb = (int64_t)t * kTriTile;
+            __syncthreads();
+            stage_tile(tile, v, tri, tri_orig, tb, T, lane);
+            __syncthreads();
+            const int cnt = (int)min((int64_t)kTriTile, T - tb);
+            for (int jj = 0; jj < cnt; ++jj) {
+                const Tri9 tr = tile[jj];
+                const V3 c = closest_on_triangle(p, V3{tr.ax, tr.ay, tr.az}, V3{tr.bx, tr.by, tr.bz}, V3{tr.cx, tr.cy, tr.cz});
+                const V3 dd = sub(c, p);
+                const double dist = (dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z;
+                if (dist < best || (dist == best && tr.orig < bo)) {
+                    best = dist;
+                    bo = tr.orig;
+                    bp = c;
+                }
+            }
+        }
+    if (ok) {
+        cp[i] = bp.x;
+        cp[q.n + i] = bp.y;
+        cp[2 * q.n + i] = bp.z;
+        d2out[i] = best;
+    }
+}
+
+// flag[i] = 1 when the line through fit_i along fit_i - cp_i meets the mesh (v, tri) in a point != fit_i that is closer to fit_i
+// than cp_i is (ClosestPointRegistrator.scala:62-72).  Lanes with skip[i] != 0 do no work (their weight is already 0).
+__global__ __launch_bounds__(kSurfThreads) void self_intersect_kernel(Cloud fit, const double *__restrict__ cp, Cloud v,
+                                                                     const int32_t *__restrict__ tri, int64_t T,
+                                                                     const double *__restrict__ boxes,
+                                                                     const int32_t *__restrict__ skip,
+                                                                     int32_t *__restrict__ flag) {
+    __shared__ Tri9 tile[kTriTile];
+    const int lane = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kSurfThreads + lane;
+    const bool ok = i < fit.n && !(skip && skip[i]);
+    const int64_t ic = i < fit.n ? i : 0;
+    const V3 p{fit.x[ic], fit.y[ic], fit.z[ic]};
+    const V3 dir = sub(p, V3{cp[ic], cp[fit.n + ic], cp[2 * fit.n + ic]});
+    const double vv = dot3(dir, dir);
+    const double vnorm = sqrt(vv);
+    int hit = 0;
+    const int nt = (int)((T + kTriTile - 1) / kTriTile);
+    for (int t = 0; t < nt; ++t) {
+        // an intersection point closer than |v| lies inside the ball of radius |v| around p
+        const double pd = point_box_gap2(p.x, p.y, p.z, boxes + (int64_t)t * 6);
+        const bool need = ok && !hit && !(pd > vv * (1.0 + 1e-12));
+        if (!__any(need)) continue;
+        const int64_t tb = (int64_t)t * kTriTile;
+        __syncthreads();
+        stage_tile(tile, v, tri, nullptr, tb, T, lane);
+        __syncthreads();
+        const int cnt = (int)min((int64_t)kTriTile, T - tb);
+        if (need)
+            for (int jj = 0; jj < cnt; ++jj) {
+                const Tri9 tr = tile[jj];
+                const V3 A{tr.ax, tr.ay, tr.az};
+                const V3 e1 = sub(V3{tr.bx, tr.by, tr.bz}, A), e2 = sub(V3{tr.cx, tr.cy, tr.cz}, A);
+                const V3 pv = cross3(dir, e2);
+                const double det = dot3(e1, pv);
+                const double inv = 1.0 / det;
+                const V3 tv = sub(p, A);
+                const double u = dot3(tv, pv) * inv;
+                const V3 qv = cross3(tv, e1);
+                const double w = dot3(qv, dir) * inv;
+                const double tt = dot3(e2, qv) * inv;
+                if (det != 0.0 && u >= 0.0 && u <= 1.0 && w >= 0.0 && u + w <= 1.0) {
+                    const V3 ip{p.x + tt * dir.x, p.y + tt * dir.y, p.z + tt * dir.z};
+                    if (ip.x != p.x || ip.y != p.y || ip.z != p.z) {
+                        const V3 dd = sub(ip, p);
+                        if (sqrt((dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z) < vnorm) hit = 1;
+                    }
+                }
+            }
+    }
+    if (i < fit.n) flag[i] = hit;
+}
+
+// first two rejection tests (boundary vertex, opposite normals): pre[i] = 1 when the pair is already rejected
+__global__ __launch_bounds__(256) void surface_prereject_kernel(int64_t M, const int32_t *__restrict__ nn_vertex,
+                                                                const int32_t *__restrict__ tgt_boundary,
+                                                                const double *__restrict__ fit_vn, const double *__restrict__ tgt_vn,
+                                                                int64_t N, int32_t *__restrict__ pre) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int32_t j = nn_vertex[i];
+    int r = 0;
+    if (j < 0)
+        r = 1;
+    else if (tgt_boundary[j])
+        r = 1;
+    else {
+        const double d = (fit_vn[i] * tgt_vn[j] + fit_vn[M + i] * tgt_vn[N + j]) + fit_vn[2 * M + i] * tgt_vn[2 * N + j];
+        if (d < 0.0) r = 1;
+    }
+    pre[i] = r;
+}
+
+// w[i] in {0, 1}; weight_in[i] = w[i] / sigma2 (isotropic observation noise, ICP.scala:90-92)
+__global__ __launch_bounds__(256) void surface_weight_kernel(int64_t M, const int32_t *__restrict__ pre,
+                                                             const int32_t *__restrict__ hit, const double *__restrict__ sigma2,
+                                                             double *__restrict__ w01, double *__restrict__ weight_in) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const double w = (pre[i] || hit[i]) ? 0.0 : 1.0;
+    w01[i] = w;
+    weight_in[i] = w / sigma2[0];
+}
+
+}  // namespace
+
+void launch_cell_normals(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *cn) {
+    if (T <= 0) return;
+    hipLaunchKernelGGL(cell_normals_kernel, dim3((unsigned)ceil_div(T, 256)), dim3(256), 0, ctx->stream, v, tri, T, cn);
+}
+void launch_vertex_normals(gingr_ctx *ctx, const int32_t *adj_ptr, const int32_t *adj_tri, const double *cn, int64_t T,
+                           int64_t n, double *vn) {
+    hipLaunchKernelGGL(vertex_normals_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, adj_ptr, adj_tri, cn,
+                       T, n, vn);
+}
+void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *boxes) {
+    if (T <= 0) return;
+    hipLaunchKernelGGL(tri_tile_bbox_kernel, dim3((unsigned)ceil_div(T, kTriTile)), dim3(256), 0, ctx->stream, v, tri, T, boxes);
+}
+void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T,
+                                  const double *boxes, double *cp_soa, double *d2) {
+    hipLaunchKernelGGL(surface_cp_kernel, dim3((unsigned)ceil_div(q.n, kSurfThreads)), dim3(kSurfThreads), 0, ctx->stream, q, v,
+                       tri, tri_orig, T, boxes, cp_soa, d2);
+}
+void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, const int32_t *tri, int64_t T, const double *boxes,
+                           const int32_t *skip, int32_t *flag) {
+    hipLaunchKernelGGL(self_intersect_kernel, dim3((unsigned)ceil_div(fit.n, kSurfThreads)), dim3(kSurfThreads), 0, ctx->stream,
+                       fit, cp_soa, fit, tri, T, boxes, skip, flag);
+}
+void launch_surface_prereject(gingr_ctx *ctx, int64_t M, const int32_t *nn_vertex, const int32_t *tgt_boundary,
+                              const double *fit_vn, const double *tgt_vn, int64_t N, int32_t *pre) {
+    hipLaunchKernelGGL(surface_prereject_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, ctx->stream, M, nn_vertex,
+                       tgt_boundary, fit_vn, tgt_vn, N, pre);
+}
+void launch_surface_weight(gingr_ctx *ctx, int64_t M, const int32_t *pre, const int32_t *hit, const double *sigma2_dev, double *w01,
+                           double *weight_in) {
+    hipLaunchKernelGGL(surface_weight_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, ctx->stream, M, pre, hit, sigma2_dev,
+                       w01, weight_in);
+}

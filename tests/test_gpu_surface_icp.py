@@ -1,0 +1,145 @@
+"""GPU tests of ICP with the surface correspondence (the reference's default ICP method,
+ICP.scala:63 TriangularClosestPoint -> ClosestPointRegistrator.scala:75-100) against the oracle's restatement."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import gingr_oracle as go
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(__file__)
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300))
+
+
+def femur():
+    d = np.load(os.path.join(HERE, "golden", "inputs.npz"))
+    m = np.load(os.path.join(HERE, "golden", "femur_mesh.npz"))
+    return (d["femur"].astype(np.float64), m["femur_cells"].astype(np.int32), d["femur_target"].astype(np.float64),
+            m["femur_target_cells"].astype(np.int32))
+
+
+def grid_mesh(n, size, height, seed):
+    """Open height-field surface: (n*n vertices, 2(n-1)^2 triangles) with a boundary."""
+    rng = np.random.default_rng(seed)
+    xs = np.linspace(-size, size, n)
+    X, Y = np.meshgrid(xs, xs, indexing="ij")
+    Z = height * np.sin(X / size * 2.0) * np.cos(Y / size * 1.5) + rng.normal(0, 0.05, X.shape)
+    v = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1)
+    idx = np.arange(n * n).reshape(n, n)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, 1:].ravel()
+    tris = np.concatenate([np.stack([a, b, c], 1), np.stack([b, d, c], 1)]).astype(np.int32)
+    return v, tris
+
+
+def model_over(ref, cells, rank=24, seed=0):
+    mo = go.build_gaussian_gpmm(ref, 60.0, 20.0, rel_tol=1e-9, max_rank=rank)
+    return mo
+
+
+def make_state(ctx, ref, cells, target, tcells, rank=24, initial_pose=None, sigma=(20.0, 1.0), iters=30):
+    import gingr_amd as ga
+    mo = model_over(ref, cells, rank)
+    model = ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam, cells=cells)
+    algo = ga.IcpRegistration(ctx)
+    cfg = ga.IcpConfiguration(maxIterations=iters, initialSigma=sigma[0], endSigma=sigma[1],
+                              correspondenceMethod="TriangularClosestPoint")
+    state = algo.createInitialState(model, target, cfg, targetCells=tcells, initial_pose=initial_pose)
+    return mo, algo, state
+
+
+def test_surface_correspondence_femur(ctx):
+    ref, cells, target, tcells = femur()
+    mo, algo, state = make_state(ctx, ref, cells, target, tcells, initial_pose=((0.02, -0.03, 0.01), (1.0, -2.0, 0.5)))
+    cp, w = algo.surfaceCorrespondence(state)
+    ocp, ow, _ = go.surface_correspondence(np.asarray(state.general.fit), cells, target, tcells)
+    assert np.array_equal(w, ow), (int((w != ow).sum()), w.shape)
+    assert np.abs(cp - ocp).max() < 1e-10 * np.abs(target).max()
+    assert 0 < w.sum() < w.shape[0]          # the femur pair produces accepted and rejected pairs
+    pairs = algo.getCorrespondence(state)
+    assert np.array_equal(pairs.pids, np.flatnonzero(ow == 1.0)) and np.abs(pairs.points - ocp[ow == 1.0]).max() < 1e-9
+    algo.close()
+
+
+def test_rejections_boundary_normals_selfintersection(ctx):
+    """Open target (boundary vertices), a template facing the wrong way (opposite normals) and a folded template (the
+    closest-point line crosses its own second sheet): every rejection rule fires and matches the oracle."""
+    tv, tt = grid_mesh(24, 40.0, 6.0, 1)
+    # template: a patch reaching past the target's rim, plus a second sheet folded back underneath part of it
+    sv, st_ = grid_mesh(14, 46.0, 4.0, 2)
+    sv = sv + np.array([3.0, -2.0, 5.0])
+    fold = sv.copy()
+    fold[:, 2] -= 2.5                                   # second sheet between the first one and the target
+    fold_t = st_[:, [0, 2, 1]] + sv.shape[0]            # facing down
+    tmpl = np.concatenate([sv, fold[: sv.shape[0] // 2]])
+    keep = (fold_t < tmpl.shape[0]).all(1)
+    tmpl_t = np.concatenate([st_, fold_t[keep]]).astype(np.int32)
+    used = np.zeros(tmpl.shape[0], bool)
+    used[tmpl_t.ravel()] = True
+    assert used.all()
+    mo, algo, state = make_state(ctx, tmpl, tmpl_t, tv, tt, rank=12)
+    cp, w = algo.surfaceCorrespondence(state)
+    ocp, ow, _ = go.surface_correspondence(np.asarray(state.general.fit), tmpl_t, tv, tt)
+    assert np.array_equal(w, ow), int((w != ow).sum())
+    assert np.abs(cp - ocp).max() < 1e-10 * 40.0
+    # all three rules are exercised
+    nn_idx, _, _ = go.icp_closest_point(ocp, tv)
+    bnd = go.boundary_vertices(tv.shape[0], tt)
+    nt, ng = go.vertex_normals(np.asarray(state.general.fit), tmpl_t), go.vertex_normals(tv, tt)
+    opposite = (nt * ng[nn_idx]).sum(1) < 0
+    assert bnd[nn_idx].any() and (opposite & ~bnd[nn_idx]).any()
+    assert ((ow == 0) & ~bnd[nn_idx] & ~opposite).any()         # rejected by the self-intersection rule only
+    assert (ow == 1).any()
+    algo.close()
+
+
+def oracle_state_of(g, transform):
+    mp = g.modelParameters
+    return go.State(alpha=np.asarray(mp.shape, dtype=np.float64).copy(), euler=(mp.rotation.phi, mp.rotation.theta, mp.rotation.psi),
+                    center=np.asarray(mp.center, dtype=np.float64), translation=np.asarray(mp.translation, dtype=np.float64),
+                    scale=float(mp.scale), sigma2=float(g.sigma2), fit=np.asarray(g.fit, dtype=np.float64).copy(),
+                    iteration=int(g.iteration), status=int(g.status), global_transformation=transform, step_length=g.stepLength)
+
+
+@pytest.mark.parametrize("transform", [0, 1])
+def test_icp_surface_updates_match_oracle(ctx, transform):
+    """Every update is checked against the oracle's update of the SAME input state: the accept / reject decisions are
+    discontinuous in the fit, so two trajectories that differ by 1e-10 may legitimately part ways after a borderline pair flips;
+    what must hold is that one update maps identical states to identical states."""
+    import gingr_amd as ga
+    ref, cells, target, tcells = femur()
+    mo, algo, state = make_state(ctx, ref, cells, target, tcells, rank=30)
+    if transform != 1:
+        state = algo.createInitialState(ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam, cells=cells), target, state.config,
+                                        transform=transform, targetCells=tcells)
+    for it in range(4):
+        st_in = oracle_state_of(state.general, transform)
+        state = algo.update(state)
+        st, (ocp, ow) = go.icp_surface_update(mo, cells, target, tcells, st_in, 20.0, 1.0, 30)
+        assert state.general.status == st.status == 0
+        assert rel(state.general.fit, st.fit) < 1e-5, (it, rel(state.general.fit, st.fit))
+        assert abs(state.general.sigma2 - st.sigma2) < 1e-12
+        assert 0 < ow.sum() < ow.shape[0]
+    # and the registration actually moves towards the target surface
+    _, d2_first = go.mesh_closest_point(mo.mean_mesh()[::10], target, tcells)
+    _, d2_last = go.mesh_closest_point(np.asarray(state.general.fit)[::10], target, tcells)
+    assert np.sqrt(d2_last).mean() < np.sqrt(d2_first).mean()
+    algo.close()
+
+
+def test_surface_icp_argument_errors(ctx):
+    import gingr_amd as ga
+    ref, cells, target, tcells = femur()
+    mo = model_over(ref[:200], None, 6)
+    algo = ga.IcpRegistration(ctx)
+    cfg = ga.IcpConfiguration(correspondenceMethod="TriangularClosestPoint")
+    with pytest.raises(ValueError):                                     # no triangulations
+        algo.createInitialState(ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam), target, cfg)
+    bad = np.array([[0, 1, 5000]], dtype=np.int32)                      # vertex id out of range
+    state = algo.createInitialState(ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam, cells=bad), target, cfg, targetCells=tcells)
+    with pytest.raises(ga.GingrNativeError):
+        algo.update(state)
+    algo.close()

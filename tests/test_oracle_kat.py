@@ -332,3 +332,45 @@ def test_pointset_distance_extrema_against_scipy():
     assert abs(mx - d.max()) < 1e-12 * mx and abs(mn - d.min()) < 1e-12 * mx
     sig, sc = go.automatic_gaussian_parameters(P)
     assert sig == [mx / 4.0, mx / 8.0] and sc == [mx / 8.0, mx / 16.0]
+
+
+# ------------------------------------------------------------------------------------------- surface ICP (8f rank 2)
+def test_closest_point_on_triangle_regions():
+    A, B, C = np.array([[0.0, 0, 0]]), np.array([[4.0, 0, 0]]), np.array([[0.0, 3, 0]])
+    cases = {(1.0, 1.0, 2.0): (1.0, 1.0, 0.0),        # interior: orthogonal projection
+             (-1.0, -1.0, 1.0): (0.0, 0.0, 0.0),      # vertex A
+             (6.0, -1.0, 0.0): (4.0, 0.0, 0.0),       # vertex B
+             (-1.0, 5.0, 0.0): (0.0, 3.0, 0.0),       # vertex C
+             (2.0, -3.0, 1.0): (2.0, 0.0, 0.0),       # edge AB
+             (-2.0, 1.5, 0.0): (0.0, 1.5, 0.0)}       # edge AC
+    for p, q in cases.items():
+        assert np.allclose(go.closest_point_on_triangles(np.array(p), A, B, C)[0], q, atol=1e-15), p
+    q = go.closest_point_on_triangles(np.array([4.0, 3.0, 0.0]), A, B, C)[0]      # edge BC: foot of the perpendicular
+    assert abs((q - B[0]) @ (C[0] - B[0]) / 25.0 - 0.36) < 1e-15 and abs(np.cross(q - B[0], C[0] - B[0])).max() < 1e-12
+    # brute force: no sampled surface point is closer
+    rng = np.random.default_rng(2)
+    for _ in range(50):
+        T = rng.normal(0, 1, (3, 3))
+        p = rng.normal(0, 2, 3)
+        c = go.closest_point_on_triangles(p, T[0:1], T[1:2], T[2:3])[0]
+        u = rng.dirichlet([1, 1, 1], 4000)
+        samples = u @ T
+        assert ((samples - p) ** 2).sum(1).min() >= ((c - p) ** 2).sum() - 1e-12
+
+
+def test_mesh_topology_helpers():
+    # 3 x 3 grid: the 8 outer vertices are boundary, the centre is not; normals of a flat CCW sheet point to +z
+    idx = np.arange(9).reshape(3, 3)
+    v = np.array([[i, j, 0.0] for i in range(3) for j in range(3)])
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, 1:].ravel()
+    tris = np.concatenate([np.stack([a, b, c], 1), np.stack([b, d, c], 1)])
+    bnd = go.boundary_vertices(9, tris)
+    assert bnd.sum() == 8 and not bnd[4]
+    n = go.vertex_normals(v, tris)
+    assert np.allclose(n, [0, 0, 1])
+    # a line through the sheet hits it once; a line through a corner vertex returns exactly that vertex
+    ip = go.line_mesh_intersections(np.array([0.7, 0.6, 2.0]), np.array([0.0, 0.0, -1.0]), v, tris)
+    assert ip.shape[0] >= 1 and np.allclose(ip, [0.7, 0.6, 0.0])
+    p = v[4]
+    ips = go.line_mesh_intersections(p, np.array([0.3, -0.2, 1.0]), v, tris)
+    assert ips.shape[0] >= 1 and all(np.array_equal(q, p) for q in ips)
