@@ -157,6 +157,19 @@ JFN(jint, fitterGetState)(JNIEnv *env, jclass, jlong f, jdoubleArray alpha, jdou
     d.as<int32_t>()[1] = s.status;
     return rc;
 }
+JFN(jint, fitterSetMeshes)(JNIEnv *env, jclass, jlong f, jintArray modelTri, jintArray targetTri) {
+    const jlong nm = env->GetArrayLength(modelTri) / 3, nt = env->GetArrayLength(targetTri) / 3;
+    Pin a(env, modelTri, true), b(env, targetTri, true);
+    return gingr_fitter_set_meshes(P<gingr_fitter>(f), nm, a.as<int32_t>(), nt, b.as<int32_t>());
+}
+JFN(jint, fitterUpdateIcpSurface)(JNIEnv *, jclass, jlong f, jdouble initialSigma, jdouble endSigma, jint maxIterations, jint n) {
+    gingr_icp_params p{initialSigma, endSigma, maxIterations};
+    return gingr_fitter_update_icp_surface_async(P<gingr_fitter>(f), &p, n);
+}
+JFN(jint, fitterGetSurfaceCorrespondence)(JNIEnv *env, jclass, jlong f, jdoubleArray cp, jdoubleArray w) {
+    Pin a(env, cp, false), b(env, w, false);
+    return gingr_fitter_get_surface_correspondence(P<gingr_fitter>(f), a.as<double>(), b.as<double>());
+}
 JFN(jlong, gpmmBuildGaussian)(JNIEnv *env, jclass, jlong ctx, jlong mTotal, jdoubleArray ref, jdoubleArray sigmas,
                                jdoubleArray scalings, jdouble relTol, jint maxRank, jlong rowBegin, jlong rowEnd) {
     const jint nk = env->GetArrayLength(sigmas);

@@ -51,6 +51,12 @@ public final class GingrHipNative {
     /** iterStatus2 = { iteration, status }; fitXyz may be null */
     public static native int fitterGetState(long fitter, double[] alpha, double[] poseScalars11, int[] iterStatus2, double[] fitXyz);
 
+    // ---- ICP with the surface correspondence (TriangularClosestPoint): flat triangle id triples of both meshes
+    public static native int fitterSetMeshes(long fitter, int[] modelTriangles, int[] targetTriangles);
+    public static native int fitterUpdateIcpSurface(long fitter, double initialSigma, double endSigma, int maxIterations, int nIterations);
+    /** cpXyz [3 M], w [M] in {0, 1} of the last surface correspondence */
+    public static native int fitterGetSurfaceCorrespondence(long fitter, double[] cpXyz, double[] w);
+
     // ---- GPMM construction in HBM (GPMMTriangleMesh3D.Gaussian / GaussianMixture / AutomaticGaussian, automaticGPMMfromTemplate)
     /** returns the gingr_model handle (0 on failure; see lastError); maxRank <= 0 = model limit; rowEnd <= 0 = all rows */
     public static native long gpmmBuildGaussian(long ctx, long mTotal, double[] refXyz, double[] sigmas, double[] scalings,

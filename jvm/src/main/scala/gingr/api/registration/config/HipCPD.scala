@@ -104,6 +104,17 @@ final class HipSession(device: Int) extends AutoCloseable {
     (p1, px, sc(4))
   }
 
+  private var boundMeshes: (AnyRef, AnyRef) = (null, null)
+  /** TriangleMesh.triangulation of both meshes as flat id triples (surface ICP, gingr_fitter_set_meshes). */
+  def bindMeshes(general: GeneralRegistrationState): Unit = {
+    val key = (general.model.reference.triangulation, general.target.triangulation)
+    if ((boundMeshes._1 ne key._1) || (boundMeshes._2 ne key._2)) {
+      def flat(m: TriangleMesh[_3D]): Array[Int] = m.triangulation.triangles.flatMap(t => Seq(t.ptId1.id, t.ptId2.id, t.ptId3.id)).toArray
+      check(GingrHipNative.fitterSetMeshes(fitter, flat(general.model.reference), flat(general.target)), "gingr_fitter_set_meshes")
+      boundMeshes = key
+    }
+  }
+
   def nn(fit: TriangleMesh[_3D], target: TriangleMesh[_3D]): Array[Int] = {
     val idx = new Array[Int](fit.pointSet.numberOfPoints)
     check(GingrHipNative.nn(ctx, HipLayout.mesh(fit), HipLayout.mesh(target), idx, null, null), "gingr_nn")
@@ -191,7 +202,8 @@ case class HipIcpRegistrationState(general: GeneralRegistrationState, config: Ic
   override def updateGeneral(update: GeneralRegistrationState): HipIcpRegistrationState = this.copy(general = update)
 }
 
-/** PointcloudClosestPoint flavour only (ICP.scala:43); the surface / along-normal flavours stay on the stock path. */
+/** PointcloudClosestPoint (ICP.scala:43) and the default TriangularClosestPoint (ICP.scala:40,63) flavours, forward
+  * direction; AlongNormalClosestPoint and reverseCorrespondenceDirection stay on the stock path. */
 class HipIcpRegistration(device: Int = 0) extends GingrAlgorithm[HipIcpRegistrationState, IcpConfiguration] with AutoCloseable {
   private val session = new HipSession(device)
   def name = "ICP-HIP"
@@ -208,8 +220,8 @@ class HipIcpRegistration(device: Int = 0) extends GingrAlgorithm[HipIcpRegistrat
     math.max(current.general.sigma2 - current.config.sigmaStep, current.config.endSigma)
 
   override def initializeState(general: GeneralRegistrationState, config: IcpConfiguration): HipIcpRegistrationState = {
-    require(config.correspondenceMethod == PointcloudClosestPoint && !config.reverseCorrespondenceDirection,
-      "HipIcpRegistration implements the PointcloudClosestPoint correspondence only")
+    require(config.correspondenceMethod != AlongNormalClosestPoint && !config.reverseCorrespondenceDirection,
+      "HipIcpRegistration implements the PointcloudClosestPoint and TriangularClosestPoint correspondences, forward direction")
     HipIcpRegistrationState(IcpRegistrationState(general, config).general, config)
   }
 
@@ -220,6 +232,9 @@ class HipIcpRegistration(device: Int = 0) extends GingrAlgorithm[HipIcpRegistrat
       if (probabilistic) {
         val z = Array.fill(current.general.model.rank)(rnd.scalaRandom.nextGaussian())
         session.updateOnce(current.general, f => GingrHipNative.fitterUpdateIcpSample(f, c.initialSigma, c.endSigma, c.maxIterations, z))
+      } else if (c.correspondenceMethod == TriangularClosestPoint) {
+        session.bindMeshes(current.general) // triangle lists of model.reference and target, once per (model, target)
+        session.updateOnce(current.general, f => GingrHipNative.fitterUpdateIcpSurface(f, c.initialSigma, c.endSigma, c.maxIterations, 1))
       } else
         session.updateOnce(current.general, f => GingrHipNative.fitterUpdateIcp(f, c.initialSigma, c.endSigma, c.maxIterations, 1))
     current.updateGeneral(HipStateUpdate(current.general, alpha, pose, status))
