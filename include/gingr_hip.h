@@ -121,22 +121,6 @@ void gingr_model_destroy(gingr_model *model);
  * Single-shard uploads are finalized by gingr_model_upload. */
 int gingr_model_gram_exchange(gingr_model *model, void **dev_ptr, int64_t *count);
 int gingr_model_finalize(gingr_ctx *ctx, gingr_model *model);
-/* ---- ICP with the surface correspondence (SURVEY 8f rank 2) -----------------------------------------------------------
- * The reference's DEFAULT ICP method: ICPCorrespondence.estimate with TriangularClosestPoint (ICP.scala:36-52,63) ->
- * ClosestPointTriangleMesh3D.closestPointCorrespondence (ClosestPointRegistrator.scala:75-100): closest point on the target
- * SURFACE, rejected (weight 0) when the nearest target vertex is a boundary vertex, when the vertex normals are opposite, or
- * when the line through the template vertex along the closest-point vector meets the template itself first.
- * gingr_fitter_set_meshes: triangle lists (vertex ids of the model reference resp. of the target set by
- * gingr_fitter_set_target, 3 ids per triangle); call it after gingr_fitter_set_target.  Single shard only.
- * The self-intersection test restates scalismo's getIntersectionPoints as a Moeller-Trumbore line/triangle test
- * (DESIGN.md 2d: semantics unpinned without the scalismo source). */
-int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_triangles, const int32_t *model_triangles,
-                            int64_t n_target_triangles, const int32_t *target_triangles);
-int gingr_fitter_update_icp_surface_async(gingr_fitter *f, const gingr_icp_params *params, int32_t n_iterations);
-int gingr_fitter_icp_surface_phase_async(gingr_fitter *f, const gingr_icp_params *params, int32_t phase);
-/* correspondences of the last surface phase 0: closest surface point [3 M] and weight in {0, 1} [M] per model vertex */
-int gingr_fitter_get_surface_correspondence(gingr_fitter *f, double *cp_xyz, double *w);
-
 /* ---- GPMM construction on the device ----------------------------------------------------------
  * Replaces GPMMTriangleMesh3D(reference, relativeTolerance).Gaussian / .GaussianMixture / .AutomaticGaussian
  * (G/api/gpmm/GPMMHelper.scala:96-130) and automaticGPMMfromTemplate (G/api/registration/utils/GPMMHelper.scala:39-69):
@@ -224,6 +208,23 @@ int gingr_fitter_get_icp_idx(gingr_fitter *f, int32_t *idx, double *d2);
 /* n_iterations updates back to back on the stream, no host synchronisation in between (single shard). */
 int gingr_fitter_update_cpd_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t n_iterations);
 int gingr_fitter_update_icp_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations);
+
+/* ---- ICP with the surface correspondence (SURVEY 8f rank 2) -----------------------------------------------------------
+ * The reference's DEFAULT ICP method: ICPCorrespondence.estimate with TriangularClosestPoint (ICP.scala:36-52,63) ->
+ * ClosestPointTriangleMesh3D.closestPointCorrespondence (ClosestPointRegistrator.scala:75-100): closest point on the target
+ * SURFACE, rejected (weight 0) when the nearest target vertex is a boundary vertex, when the vertex normals are opposite, or
+ * when the line through the template vertex along the closest-point vector meets the template itself first.
+ * gingr_fitter_set_meshes: triangle lists (vertex ids of the model reference resp. of the target set by
+ * gingr_fitter_set_target, 3 ids per triangle); call it after gingr_fitter_set_target.  Single shard only.
+ * The self-intersection test restates scalismo's getIntersectionPoints as a Moeller-Trumbore line/triangle test
+ * (DESIGN.md 2d: semantics unpinned without the scalismo source). */
+int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_triangles, const int32_t *model_triangles,
+                            int64_t n_target_triangles, const int32_t *target_triangles);
+int gingr_fitter_update_icp_surface_async(gingr_fitter *f, const gingr_icp_params *params, int32_t n_iterations);
+int gingr_fitter_icp_surface_phase_async(gingr_fitter *f, const gingr_icp_params *params, int32_t phase);
+/* correspondences of the last surface phase 0: closest surface point [3 M] and weight in {0, 1} [M] per model vertex */
+int gingr_fitter_get_surface_correspondence(gingr_fitter *f, double *cp_xyz, double *w);
+
 
 /* ---- probabilistic proposal (single shard) ------------------------------------------------
  * update(current, probabilistic = true): the shape proposal is posterior.sample() instead of posterior.mean

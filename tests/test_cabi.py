@@ -66,3 +66,20 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle|#include.*oracle|cpd_oracle|libcpd_oracle", src, flags=re.M), f
+
+
+def test_header_is_self_contained_c():
+    """The boundary header must compile on its own as plain C (what a cgo / JNI / FFI binding generator feeds on): catches
+    C++-isms and declarations that use a type before its definition."""
+    import shutil
+    import subprocess
+    import tempfile
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    hdr = os.path.join(ROOT, "include", "gingr_hip.h")
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        with open(src, "w") as f:
+            f.write('#include "gingr_hip.h"\nint main(void) { return (int)sizeof(gingr_state_scalars) == 0; }\n')
+        subprocess.check_call([cc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.dirname(hdr), src])
