@@ -215,3 +215,27 @@ def test_culled_underflow_column_still_fails_like_the_reference(ctx):
     s2 = algo.update(s1)
     assert s1.general.status == ga.FittingStatuses.None_ and s2.general.status == ga.FittingStatuses.ModelFlexibilityError
     algo.close()
+
+
+def test_long_run_parity_does_not_drift(ctx):
+    """Forty CPD iterations from the initial sigma2 down to the noise floor (guarded fast form early, exact form and tile
+    culling late, similarity transform): the trajectories of the HIP path and of the oracle stay together."""
+    import gingr_amd as ga
+    mo, rng = synth_model(420, 36, 77)
+    target = 1.05 * (mo.instance(rng.normal(0, 1.0, mo.rank)) @ go.euler_to_rot(0.08, -0.05, 0.06).T) + np.array([3.0, -2.0, 1.0])
+    target = target[rng.permutation(mo.M)[:390]] + rng.normal(0, 0.2, (390, 3))
+    model = ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam)
+    algo = ga.CpdRegistration(ctx)
+    cfg = ga.CpdConfiguration(maxIterations=100, w=0.05)
+    state = algo.createInitialState(model, target, cfg, transform=ga.GlobalTranformationType.SimilarityTransforms)
+    st = go.initial_state(mo, state.general.sigma2, global_transformation=go.SIMILARITY_TRANSFORMS)
+    s2_0 = st.sigma2
+    for it in range(40):
+        state = algo.update(state)
+        st = go.cpd_update(mo, target, st, w=0.05)
+        assert state.general.status == st.status == 0, it
+    assert st.sigma2 < 1e-3 * s2_0                      # the run really went through the regimes
+    assert abs(state.general.sigma2 - st.sigma2) < 1e-6 * st.sigma2
+    assert rel(state.general.fit, st.fit) < 1e-6
+    assert rel(state.general.modelParameters.shape, st.alpha) < 1e-5
+    algo.close()
