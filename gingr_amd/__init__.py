@@ -11,3 +11,4 @@ from .api import (  # noqa: F401
     DevicePointDistributionModel, GaussianKernelParameters, GPMMTriangleMesh3D, PointSetHelper, automaticGPMMfromTemplate,
 )
 from ._native import GingrNativeError  # noqa: F401
+from . import io  # noqa: F401  (file / wire formats shared with the Scala host)
