@@ -348,7 +348,7 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
         (rc = dev_alloc(ctx, &f->alpha, (size_t)rp)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
         (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->zbuf, (size_t)19 * rp)) || (rc = dev_alloc(ctx, &f->zrand, (size_t)rp)) || (rc = dev_alloc(ctx, &f->st, 1)) ||
         (rc = dev_alloc(ctx, &f->pose, 1)) || (rc = dev_alloc(ctx, &f->hs_dev, 1)) ||
-        (rc = dev_alloc(ctx, &f->scalars, 8)) || (rc = dev_alloc(ctx, &f->part, GINGR_SCALAR_PART)) || (rc = dev_alloc(ctx, &f->absmax, GINGR_AUX)) || (rc = dev_alloc(ctx, &f->work, (size_t)rp * rp)) ||
+        (rc = dev_alloc(ctx, &f->scalars, 8)) || (rc = dev_alloc(ctx, &f->part, GINGR_SCALAR_PART)) || (rc = dev_alloc(ctx, &f->absmax, GINGR_AUX)) || (rc = dev_alloc(ctx, &f->work, (size_t)std::max<int64_t>((int64_t)rp * rp, posterior_work_doubles(rp)))) ||
         (rc = dev_alloc(ctx, &f->lm_mask, (size_t)M))) {
         gingr_fitter_destroy(f);
         return rc;
@@ -966,7 +966,6 @@ static int posterior_logpdf(gingr_fitter *f, bool icp, const gingr_cpd_params *c
     const gingr_model *m = f->m;
     if (!mesh_xyz || !logpdf) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "posterior_logpdf: null argument");
     if (m->M != m->M_total) return gingr_set_error(ctx, GINGR_ERR_STATE, "posterior_logpdf: single shard only");
-    if (m->r > 128) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "posterior_logpdf: rank > 128 not supported");
     const int64_t M = m->M;
     const int32_t r = m->r, rp = m->rp;
     // posterior of the current state: correspondences, Gram, right-hand side (phases 0 and 1 do not touch the state)
@@ -995,7 +994,7 @@ static int posterior_logpdf(gingr_fitter *f, bool icp, const gingr_cpd_params *c
     a.shape_in = f->newshape;
     a.out = f->alpha_c;
     launch_sweep(ctx, SWEEP_PROJ2, a);
-    GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, m->mom + MomentLayout{rp}.stot(), f->alpha_c, f->acoef, out2.as<double>()));
+    GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, m->mom + MomentLayout{rp}.stot(), f->alpha_c, f->acoef, f->work, out2.as<double>()));
     GINGR_TRY(check_launch(ctx));
     double res[2] = {0, 0};
     DevState after;

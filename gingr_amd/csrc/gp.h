@@ -130,13 +130,15 @@ void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, 
                       const double *lm_xyz, const double *lm_cov, double *G, double *rhs);
 
 // ---- small dense kernels ------------------------------------------------------------------------------------
-// a = (I + G)^-1 rhs  by Cholesky (work: [rp*rp]); sets st->err on failure
+// a = (I + G)^-1 rhs  by Cholesky (work: posterior_work_doubles(rp)); sets st->err on failure
 // zrand (nullable, [r] on the device): standard-normal draws; the result is then a posterior SAMPLE a + L^-T z
 void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *zrand,
                             double *work, double *a, DevState *st);
-// out2[0] = posterior.gp.logpdf(posterior.coefficients(mesh)), out2[1] = |c|^2; qte = Q0^T e (model-frame residual); r <= 128
+// out2[0] = posterior.gp.logpdf(posterior.coefficients(mesh)), out2[1] = |c|^2; qte = Q0^T e (model-frame residual)
 int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *Stot, const double *qte,
-                            const double *a, double *out2);
+                            const double *a, double *work, double *out2);
+// doubles of the `work` buffer launch_posterior_solve / launch_posterior_logpdf need (used when r > 128)
+int64_t posterior_work_doubles(int32_t rp);
 // Binv = (S/eps + I)^-1  (work: [rp*rp]); *err_flag != 0 on failure
 void launch_binv(gingr_ctx *ctx, int32_t r, int32_t rp, const double *S, double *work, double *Binv, int32_t *err_flag);
 // alpha1 = Binv (p/eps); alpha_c = alpha + (alpha1 - alpha) * step      GingrAlgorithm.scala:218-220

@@ -569,66 +569,9 @@ __device__ bool block_cholesky(double *A, int r, int ld) {
     return ok_flag != 0;
 }
 
-__global__ __launch_bounds__(kDenseThreads) void posterior_solve_kernel(int r, int rp, const double *__restrict__ G,
-                                                                        const double *__restrict__ rhs,
-                                                                        const double *__restrict__ zrand,
-                                                                        double *__restrict__ work, double *__restrict__ a,
-                                                                        DevState *__restrict__ st) {
-    __shared__ double y[512];
-    __shared__ double y2[512];
-    __shared__ int bad;
-    // Mm = QtL Q + I     (scalismo genericRegressionComputations)
-    for (int idx = threadIdx.x; idx < r * r; idx += blockDim.x) {
-        const int i = idx / r, j = idx - i * r;
-        work[i * rp + j] = G[i * rp + j] + (i == j ? 1.0 : 0.0);
-    }
-    for (int k = threadIdx.x; k < rp; k += blockDim.x) {
-        y[k] = k < r ? rhs[k] : 0.0;
-        y2[k] = (k < r && zrand) ? zrand[k] : 0.0;
-    }
-    if (threadIdx.x == 0) bad = 0;
-    __syncthreads();
-    const bool ok = block_cholesky(work, r, rp);
-    // L z = rhs
-    for (int k = 0; k < r; ++k) {
-        if (threadIdx.x == 0) y[k] /= work[k * rp + k];
-        __syncthreads();
-        const double yk = y[k];
-        for (int i = k + 1 + threadIdx.x; i < r; i += blockDim.x) y[i] -= work[i * rp + k] * yk;
-        __syncthreads();
-    }
-    // L^T a = z
-    for (int k = r - 1; k >= 0; --k) {
-        if (threadIdx.x == 0) y[k] /= work[k * rp + k];
-        __syncthreads();
-        const double yk = y[k];
-        for (int i = threadIdx.x; i < k; i += blockDim.x) y[i] -= work[k * rp + i] * yk;
-        __syncthreads();
-    }
-    if (zrand) {  // sampling direction: L^T w = z
-        for (int k = r - 1; k >= 0; --k) {
-            if (threadIdx.x == 0) y2[k] /= work[k * rp + k];
-            __syncthreads();
-            const double yk = y2[k];
-            for (int i = threadIdx.x; i < k; i += blockDim.x) y2[i] -= work[k * rp + i] * yk;
-            __syncthreads();
-        }
-    }
-    for (int k = threadIdx.x; k < rp; k += blockDim.x) {
-        const double v = k < r ? y[k] + y2[k] : 0.0;
-        a[k] = v;
-        if (!finite_d(v)) bad = 1;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (!ok)
-            st->err = GINGR_ERR_NOT_SPD;
-        else if (bad)
-            st->err = GINGR_ERR_NONFINITE;
-    }
-}
 
-// LDS-resident blocked Cholesky solve for r <= 128 (one workgroup of 256 threads = one wave per SIMD, 16-wide panels).
+// Blocked Cholesky solve in one workgroup (256 threads = one wave per SIMD, 16-wide panels); the bordered matrix is LDS resident
+// for r <= 128 and lives in an L2-resident global workspace above that (same code through flat addressing).
 // With one wave per SIMD the kernel is bound by the NUMBER of instructions it issues (5-8 cycles each), so everything is
 // laid out to need no masks: the matrix is padded with an identity to n = rp (a multiple of 16: every panel is full), right-hand
 // sides ride along as 16 extra rows of the bordered matrix (so the forward substitution is a by-product of the panel solves
@@ -862,11 +805,15 @@ __device__ __forceinline__ void lds_backward(const double *A, int ld, int n, con
 // a = (I + G)^-1 rhs; with zrand != nullptr a posterior SAMPLE of the coefficients: a + L^-T z, z ~ N(0, I)
 // (Cov = L^-T L^-1 = (I + G)^-1, the posterior covariance of the coefficients: the same distribution as
 //  posterior.sample() of scalismo's SVD-parameterised posterior model, G/api/GingrAlgorithm.scala:211).
+// gwork == nullptr: the bordered matrix lives in LDS (r <= 128).  Otherwise it lives in the global workspace `gwork`
+// (lds_solve_doubles(rp, 16) doubles, L2 resident): the same building blocks through flat addressing, for 128 < r <= 512 --
+// one workgroup, so the workgroup barriers order its global writes.
 __global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp, const double *__restrict__ G,
                                                                   const double *__restrict__ rhs,
                                                                   const double *__restrict__ zrand, double *__restrict__ a,
-                                                                  DevState *__restrict__ st) {
-    extern __shared__ double sm[];
+                                                                  DevState *__restrict__ st, double *gwork) {
+    extern __shared__ double lds_sm[];
+    double *sm = gwork ? gwork : lds_sm;
     const int n = rp, ld = n | 1;  // odd leading dimension: column walks hit distinct banks
     double *A = sm;
     double *y = sm + (size_t)n * ld;   // row n of the bordered matrix: the right-hand side (rows n+1 .. n+15 are zero)
@@ -912,8 +859,10 @@ __global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp,
 __global__ __launch_bounds__(256) void posterior_logpdf_lds_kernel(int r, int rp, const double *__restrict__ G,
                                                                    const double *__restrict__ Stot,
                                                                    const double *__restrict__ qte,
-                                                                   const double *__restrict__ a, double *__restrict__ out2) {
-    extern __shared__ double sm[];
+                                                                   const double *__restrict__ a, double *__restrict__ out2,
+                                                                   double *gwork) {
+    extern __shared__ double lds_sm[];
+    double *sm = gwork ? gwork : lds_sm;
     const int n = rp, ld = n | 1;
     double *A = sm;
     double *u = sm + (size_t)n * ld;  // extra row block of the bordered matrix
@@ -1543,6 +1492,8 @@ void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, 
                        (int)n_lm, lm_pid_local, lm_xyz, lm_cov, G, rhs);
 }
 
+int64_t posterior_work_doubles(int32_t rp) { return (int64_t)lds_solve_doubles(rp, kNB); }
+
 void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *zrand,
                             double *work, double *a, DevState *st) {
     TimerScope ts(ctx, 5);
@@ -1555,21 +1506,26 @@ void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
             lds_granted = lds;
         }
         hipLaunchKernelGGL(posterior_solve_lds_kernel, dim3(1), dim3(256), lds, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a,
-                           st);
+                           st, (double *)nullptr);
         return;
     }
-    hipLaunchKernelGGL(posterior_solve_kernel, dim3(1), dim3(kDenseThreads), 0, ctx->stream, (int)r, (int)rp, G, rhs, zrand, work,
-                       a, st);
+    // r > 128: the bordered matrix does not fit the LDS; same kernel on the global workspace (posterior_work_doubles)
+    hipLaunchKernelGGL(posterior_solve_lds_kernel, dim3(1), dim3(256), 0, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a, st, work);
 }
 
 int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *Stot, const double *qte,
-                            const double *a, double *out2) {
-    if (r > 128) return GINGR_ERR_BAD_ARGUMENT;  // LDS-resident implementation only
-    const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_lds_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(posterior_logpdf_lds_kernel, dim3(1), dim3(256), lds, ctx->stream, (int)r, (int)rp, G, Stot, qte, a, out2);
+                            const double *a, double *work, double *out2) {
+    if (r <= 128) {
+        const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_lds_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(posterior_logpdf_lds_kernel, dim3(1), dim3(256), lds, ctx->stream, (int)r, (int)rp, G, Stot, qte, a, out2,
+                           (double *)nullptr);
+    } else {
+        hipLaunchKernelGGL(posterior_logpdf_lds_kernel, dim3(1), dim3(256), 0, ctx->stream, (int)r, (int)rp, G, Stot, qte, a, out2,
+                           work);
+    }
     return GINGR_OK;
 }
 
