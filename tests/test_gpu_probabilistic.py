@@ -119,3 +119,30 @@ def test_log_transition_probability_of_failed_posterior_is_minus_infinity(ctx):
     s0 = algo.createInitialState(model, target, ga.CpdConfiguration(maxIterations=10, initialSigma=1.0, w=0.0))
     assert algo.logTransitionProbability(s0, s0) == float("-inf")
     algo.close()
+
+
+def test_rank_above_128_uses_the_global_workspace(ctx):
+    """r > 128: the bordered solve and the log transition density run on the L2-resident workspace (same code as r <= 128)."""
+    import gingr_amd as ga
+    rng = np.random.default_rng(31)
+    M = 400
+    ref = rng.normal(0, 40, (M, 3))
+    U, _ = np.linalg.qr(rng.normal(0, 1, (3 * M, 150)))
+    lam = np.sort(rng.uniform(1.0, 300.0, 150))[::-1].copy()
+    mo = go.PDM(ref=ref, mean=rng.normal(0, 0.2, (M, 3)), U=np.ascontiguousarray(U), lam=lam)
+    target = mo.instance(rng.normal(0, 1.0, 150)) + rng.normal(0, 0.3, (M, 3))
+    model = ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam)
+    algo = ga.CpdRegistration(ctx)
+    cfg = ga.CpdConfiguration(maxIterations=50, w=0.05)
+    s0 = algo.createInitialState(model, target, cfg)
+    s1 = algo.update(s0)
+    st = go.cpd_update(mo, target, go.initial_state(mo, s0.general.sigma2), w=0.05)
+    assert rel(s1.general.fit, st.fit) < 1e-6
+    z = np.random.default_rng(5).standard_normal(150)
+    s2 = algo.update(s1, probabilistic=True, rnd=np.random.default_rng(5))
+    st2 = go.cpd_update(mo, target, st, w=0.05, z=z)
+    assert rel(s2.general.fit, st2.fit) < 1e-5
+    got = algo.logTransitionProbability(s1, s2)
+    want = go.posterior_logpdf_of_mesh(mo, st, *go.cpd_observations(mo, target, st, w=0.05), mesh=st.fit)
+    assert np.isfinite(got) and abs(got - want) < 1e-5 * abs(want), (got, want)
+    algo.close()
