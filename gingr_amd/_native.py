@@ -12,7 +12,8 @@ from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_void_
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgingr_hip.so")
+# GINGR_HIP_LIB: A/B timing of two builds on one box (development aid); default = the in-tree library
+LIB_PATH = os.environ.get("GINGR_HIP_LIB") or os.path.join(_HERE, "libgingr_hip.so")
 
 GINGR_OK = 0
 ERR_BAD_ARGUMENT, ERR_HIP, ERR_NONFINITE, ERR_NOT_SPD, ERR_NO_DEVICE, ERR_STATE = 1, 2, 3, 4, 5, 6

@@ -51,6 +51,7 @@ constexpr int kTabN = 1 << kTB;
 // This only triggers when the points are spatially coherent (the fitter keeps model rows and targets in Morton order).
 // 1500 * sigma2 * (-c), with -c = table size * log2(e) / (2 sigma2)
 #define GINGR_CULL_SCALED(entries) (1084.0 * (double)(entries))
+constexpr double kFineCullRatio = 16.0;  // fine culling once the flush radius is below a quarter of the largest possible distance
 
 struct Box {
     double lo[3], hi[3];
@@ -118,19 +119,63 @@ __device__ __forceinline__ Box block_bbox(const double (&x)[PT], const double (&
     return b;
 }
 
-// boxes[tile] = {lo[3], hi[3]} of the points [tile*256, tile*256+256) of a cloud.  With slot != nullptr also
-// slot = max over the cloud of |coordinate - ctr| (atomic max on the bit pattern of a non-negative double: order independent,
-// deterministic); the slot must have been zeroed by an EARLIER launch on the stream.
+// bounding box of each owned slot t over the wave: the 64 consecutive points {base + 64 t + lane} (a quarter k-d leaf); wave
+// uniform, kept in scalar registers (measured faster than a round trip through LDS, spills included)
+template <int PT>
+__device__ __forceinline__ void slot_boxes(const double (&x)[PT], const double (&y)[PT], const double (&z)[PT],
+                                           const bool (&ok)[PT], Box (&sb)[PT]) {
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        double lo[3] = {ok[t] ? x[t] : __builtin_huge_val(), ok[t] ? y[t] : __builtin_huge_val(), ok[t] ? z[t] : __builtin_huge_val()};
+        double hi[3] = {ok[t] ? x[t] : -__builtin_huge_val(), ok[t] ? y[t] : -__builtin_huge_val(), ok[t] ? z[t] : -__builtin_huge_val()};
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                lo[d] = fmin(lo[d], __shfl_xor(lo[d], off));
+                hi[d] = fmax(hi[d], __shfl_xor(hi[d], off));
+            }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            sb[t].lo[d] = uniform_d(lo[d]);
+            sb[t].hi[d] = uniform_d(hi[d]);
+        }
+    }
+}
+
+// mask of the owned slots that can receive a non-zero from the 64-point quarter whose box is sub6
+template <int PT>
+__device__ __forceinline__ unsigned quarter_mask(const Box (&sb)[PT], const double *__restrict__ sub6, double negc) {
+    unsigned m = 0;
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+        if (!(box_gap2(sb[t], sub6) * negc > GINGR_CULL_SCALED(kTabN))) m |= 1u << t;  // NaN boxes are never culled
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)m);  // wave-uniform by construction: make it a scalar for the branches
+}
+
+// boxes[tile] = {lo[3], hi[3]} of the points [tile*256, tile*256+256) of a cloud, followed (at boxes + 6 * ntiles) by the boxes
+// of its four 64-point quarters, [tile*4 + q]: the k-d leaf order makes those compact too (finer exact-zero culling).
+// With slot != nullptr also slot = max over the cloud of |coordinate - ctr| (atomic max on the bit pattern of a non-negative
+// double: order independent, deterministic); the slot must have been zeroed by an EARLIER launch on the stream.
 __global__ __launch_bounds__(256) void tile_bbox_kernel(Cloud c, double *__restrict__ boxes, const double *__restrict__ ctr,
                                                         double *__restrict__ slot) {
     __shared__ double sh[24];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool ok1[1] = {i < c.n};
     const double x[1] = {ok1[0] ? c.x[i] : 0.0}, y[1] = {ok1[0] ? c.y[i] : 0.0}, z[1] = {ok1[0] ? c.z[i] : 0.0};
-    const Box b = block_bbox<1>(x, y, z, ok1, sh, nullptr);
+    Box wb;
+    const Box b = block_bbox<1>(x, y, z, ok1, sh, &wb);
     if (threadIdx.x < 3) {
         boxes[(int64_t)blockIdx.x * 6 + threadIdx.x] = b.lo[threadIdx.x];
         boxes[(int64_t)blockIdx.x * 6 + 3 + threadIdx.x] = b.hi[threadIdx.x];
+    }
+    {
+        double *sub = boxes + (int64_t)gridDim.x * 6 + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 6;
+        const int l = threadIdx.x & 63;
+        if (l < 3) {
+            sub[l] = wb.lo[l];
+            sub[3 + l] = wb.hi[l];
+        }
     }
     if (slot && threadIdx.x == 0) {
         double m = 0.0;
@@ -144,14 +189,18 @@ __global__ __launch_bounds__(256) void tile_bbox_kernel(Cloud c, double *__restr
 }
 
 // ---------------------------------------------------------------- pass 1: column sums of K
-template <int PT, bool CLAMP>
-__device__ __forceinline__ void colsum_tile(const P4 *tile, int cnt, const double (&x)[PT], const double (&y)[PT],
-                                            const double (&z)[PT], double (&acc)[PT], double c, double lim, const double *T) {
+// Tile loops.  [j0, j1) is a range of tile entries (the whole tile or one 64-point quarter); with MASKED only the owned slots
+// t whose bit is set in `mask` (wave-uniform) are updated -- the others are known to receive exact zeros from this range.
+template <int PT, bool CLAMP, bool MASKED>
+__device__ __forceinline__ void colsum_tile(const P4 *tile, int j0, int j1, unsigned mask, const double (&x)[PT],
+                                            const double (&y)[PT], const double (&z)[PT], double (&acc)[PT], double c, double lim,
+                                            const double *T) {
 #pragma unroll 2
-    for (int ii = 0; ii < cnt; ++ii) {
+    for (int ii = j0; ii < j1; ++ii) {
         const P4 p = tile[ii];
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
+            if (MASKED && !((mask >> t) & 1u)) continue;
             const double dx = x[t] - p.x, dy = y[t] - p.y, dz = z[t] - p.z;
             double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
             if (CLAMP) d2 = fmin(d2, lim);
@@ -181,32 +230,39 @@ __device__ __forceinline__ double exp_from_t(double t, const double *T) {
 }
 
 // tile entries: (-2c y~, c|y~|^2); owned: x~ and n = c|x~|^2
-template <int PT>
-__device__ __forceinline__ void colsum_tile_expand(const P4 *tile, int cnt, const double (&x)[PT], const double (&y)[PT],
-                                                   const double (&z)[PT], const double (&n)[PT], double (&acc)[PT],
-                                                   const double *T) {
+template <int PT, bool MASKED>
+__device__ __forceinline__ void colsum_tile_expand(const P4 *tile, int j0, int j1, unsigned mask, const double (&x)[PT],
+                                                   const double (&y)[PT], const double (&z)[PT], const double (&n)[PT],
+                                                   double (&acc)[PT], const double *T) {
 #pragma unroll 2
-    for (int ii = 0; ii < cnt; ++ii) {
+    for (int ii = j0; ii < j1; ++ii) {
         const P4 p = tile[ii];
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
+            if (MASKED && !((mask >> t) & 1u)) continue;
             const double tt = __builtin_fma(z[t], p.z, __builtin_fma(y[t], p.y, __builtin_fma(x[t], p.x, p.w + n[t])));
             acc[t] += exp_from_t(tt, T);
         }
     }
 }
 
-template <int PT>
+// FINE selects the variant with the quarter-tile x slot culling.  The regime is a property of (sigma2, cloud extents), known on
+// the device only, so when boxes are available BOTH variants are launched and the one that does not match the regime returns
+// at once (check_regime); the plain variant thereby stays exactly the code it was before the fine culling existed -- sharing
+// one kernel cost the plain regime 7 % in the row-statistics pass.
+template <int PT, bool FINE>
 __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt, const double *__restrict__ sigma2,
                                                             const double *__restrict__ aux,
                                                             const double *__restrict__ fit_boxes, int64_t rows_per_chunk,
-                                                            double *__restrict__ partial) {
+                                                            double *__restrict__ partial, int check_regime) {
     __shared__ double T[kTabN];
     __shared__ P4 tile[kTile];
     __shared__ double shbox[24];
-    fastexp_table_init<kTB>(T);
     const double c = fastexp_scale_for_variance<kTB>(2.0 * sigma2[0]);
     const double am = aux[0] + aux[1];
+    // regime of the fine culling: the zero-flush radius is well inside the clouds' extent (3 am^2 bounds every squared distance)
+    if (check_regime && (fit_boxes && 3.0 * am * am * (-c) > kFineCullRatio * GINGR_CULL_SCALED(kTabN)) != FINE) return;
+    fastexp_table_init<kTB>(T);
     const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);               // wave-uniform
     const bool expand = use_expansion(fmax(aux[0], aux[1]), c);             // wave-uniform
     const double lim = fastexp_d2_limit<kTB>(c);
@@ -229,6 +285,11 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
     Box wown;
     const Box own = block_bbox<PT>(x, y, z, okv, shbox, &wown);  // raw coordinates, before any centring
     const bool wave_owns_any = __builtin_amdgcn_readfirstlane((int)okv[0]) != 0;  // lane 0, slot 0 is the wave's first point
+    constexpr unsigned kAllSlots = (1u << PT) - 1u;
+    constexpr bool fine_on = FINE;
+    Box sown[PT];  // per owned slot (64 consecutive points)
+    if (fine_on) slot_boxes<PT>(x, y, z, okv, sown);
+    const double *fit_sub = fit_boxes ? fit_boxes + ((fit.n + kTile - 1) / kTile) * 6 : nullptr;
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         if (expand) {
@@ -258,12 +319,34 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         if (!wave_owns_any) continue;  // a wave past the end of the cloud only takes part in the barriers
         if (fit_boxes && box_gap2(wown, fit_boxes + (ib / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;
         const int cnt = (int)min((int64_t)kTile, i1 - ib);
-        if (expand)
-            colsum_tile_expand<PT>(tile, cnt, x, y, z, n, acc, T);
-        else if (clamp)
-            colsum_tile<PT, true>(tile, cnt, x, y, z, acc, c, lim, T);
-        else
-            colsum_tile<PT, false>(tile, cnt, x, y, z, acc, c, lim, T);
+        if (!fine_on) {
+            if (expand)
+                colsum_tile_expand<PT, false>(tile, 0, cnt, kAllSlots, x, y, z, n, acc, T);
+            else if (clamp)
+                colsum_tile<PT, true, false>(tile, 0, cnt, kAllSlots, x, y, z, acc, c, lim, T);
+            else
+                colsum_tile<PT, false, false>(tile, 0, cnt, kAllSlots, x, y, z, acc, c, lim, T);
+            continue;
+        }
+        // quarter of the tile x owned slot: skip what provably receives exact zeros
+        for (int sub = 0; sub * 64 < cnt; ++sub) {
+            const int q0 = sub * 64, q1 = min(cnt, q0 + 64);
+            const unsigned mask = quarter_mask<PT>(sown, fit_sub + ((ib / kTile) * 4 + sub) * 6, -c);
+            if (!mask) continue;
+            if (expand) {
+                if (mask == kAllSlots)
+                    colsum_tile_expand<PT, false>(tile, q0, q1, mask, x, y, z, n, acc, T);
+                else
+                    colsum_tile_expand<PT, true>(tile, q0, q1, mask, x, y, z, n, acc, T);
+            } else if (clamp) {
+                colsum_tile<PT, true, true>(tile, q0, q1, mask, x, y, z, acc, c, lim, T);
+            } else {
+                if (mask == kAllSlots)
+                    colsum_tile<PT, false, false>(tile, q0, q1, mask, x, y, z, acc, c, lim, T);
+                else
+                    colsum_tile<PT, false, true>(tile, q0, q1, mask, x, y, z, acc, c, lim, T);
+            }
+        }
     }
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
@@ -358,17 +441,18 @@ __global__ __launch_bounds__(256) void cpd_den_finalize_kernel(Cloud tgt, const 
 // ---------------------------------------------------------------- pass 2: row statistics
 // tile entries: (x, y, z, 1/den); tw entries: (x, y, z)/den, so that P1 and P.X are four FMAs on K_ij (the product
 // K * (x/den) instead of (K/den) * x: one rounding placed differently, one instruction less per pair)
-template <int PT, bool CLAMP>
-__device__ __forceinline__ void rowstats_tile(const P4 *tile, const P4 *tw, int cnt, const double (&x)[PT],
-                                              const double (&y)[PT], const double (&z)[PT], double (&a1)[PT],
-                                              double (&ax)[PT], double (&ay)[PT], double (&az)[PT], double c, double lim,
-                                              const double *T) {
+template <int PT, bool CLAMP, bool MASKED>
+__device__ __forceinline__ void rowstats_tile(const P4 *tile, const P4 *tw, int j0, int j1, unsigned mask,
+                                              const double (&x)[PT], const double (&y)[PT], const double (&z)[PT],
+                                              double (&a1)[PT], double (&ax)[PT], double (&ay)[PT], double (&az)[PT], double c,
+                                              double lim, const double *T) {
 #pragma unroll 2
-    for (int jj = 0; jj < cnt; ++jj) {
+    for (int jj = j0; jj < j1; ++jj) {
         const P4 p = tile[jj];
         const P4 q = tw[jj];
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
+            if (MASKED && !((mask >> t) & 1u)) continue;
             const double dx = p.x - x[t], dy = p.y - y[t], dz = p.z - z[t];
             double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
             if (CLAMP) d2 = fmin(d2, lim);
@@ -384,17 +468,18 @@ __device__ __forceinline__ void rowstats_tile(const P4 *tile, const P4 *tw, int 
 // expansion form of pass 2: tile entries (-2c x~, c|x~|^2) + 1/den; owned y~ and n = c|y~|^2.  P.X is accumulated as
 // sum_j p a_j with a_j = -2c x~_j and rescaled once at the end: PX = ctr*P1 - (sum_j p a_j) / (2c).
 // tw entries: (a_j / den_j, 1 / den_j)
-template <int PT>
-__device__ __forceinline__ void rowstats_tile_expand(const P4 *tile, const P4 *tw, int cnt, const double (&x)[PT],
-                                                     const double (&y)[PT], const double (&z)[PT], const double (&n)[PT],
-                                                     double (&a1)[PT], double (&ax)[PT], double (&ay)[PT], double (&az)[PT],
-                                                     const double *T) {
+template <int PT, bool MASKED>
+__device__ __forceinline__ void rowstats_tile_expand(const P4 *tile, const P4 *tw, int j0, int j1, unsigned mask,
+                                                     const double (&x)[PT], const double (&y)[PT], const double (&z)[PT],
+                                                     const double (&n)[PT], double (&a1)[PT], double (&ax)[PT], double (&ay)[PT],
+                                                     double (&az)[PT], const double *T) {
 #pragma unroll 2
-    for (int jj = 0; jj < cnt; ++jj) {
+    for (int jj = j0; jj < j1; ++jj) {
         const P4 p = tile[jj];
         const P4 q = tw[jj];
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
+            if (MASKED && !((mask >> t) & 1u)) continue;
             const double tt = __builtin_fma(z[t], p.z, __builtin_fma(y[t], p.y, __builtin_fma(x[t], p.x, p.w + n[t])));
             const double k = exp_from_t(tt, T);
             a1[t] = __builtin_fma(k, q.w, a1[t]);
@@ -405,20 +490,21 @@ __device__ __forceinline__ void rowstats_tile_expand(const P4 *tile, const P4 *t
     }
 }
 
-template <int PT>
+template <int PT, bool FINE>  // FINE / check_regime: see cpd_colsum_kernel
 __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud tgt, const double *__restrict__ sigma2,
                                                               const double *__restrict__ aux,
                                                               const double *__restrict__ inv_den,
                                                               const double *__restrict__ tgt_boxes,
                                                               const int32_t *__restrict__ tile_bad, int64_t cols_per_chunk,
-                                                              double *__restrict__ partial) {
+                                                              double *__restrict__ partial, int check_regime) {
     __shared__ double T[kTabN];
     __shared__ P4 tile[kTile];
     __shared__ P4 tw[kTile];
     __shared__ double shbox[24];
-    fastexp_table_init<kTB>(T);
     const double c = fastexp_scale_for_variance<kTB>(2.0 * sigma2[0]);
     const double am = aux[0] + aux[1];
+    if (check_regime && (tgt_boxes && 3.0 * am * am * (-c) > kFineCullRatio * GINGR_CULL_SCALED(kTabN)) != FINE) return;
+    fastexp_table_init<kTB>(T);
     const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);               // wave-uniform
     const bool expand = use_expansion(fmax(aux[0], aux[1]), c);             // wave-uniform
     const double lim = fastexp_d2_limit<kTB>(c);
@@ -440,6 +526,11 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
     Box wown;
     const Box own = block_bbox<PT>(x, y, z, okv, shbox, &wown);  // raw coordinates, before any centring
     const bool wave_owns_any = __builtin_amdgcn_readfirstlane((int)okv[0]) != 0;  // lane 0, slot 0 is the wave's first point
+    constexpr unsigned kAllSlots = (1u << PT) - 1u;
+    constexpr bool fine_on = FINE;
+    Box sown[PT];  // per owned slot (64 consecutive points)
+    if (fine_on) slot_boxes<PT>(x, y, z, okv, sown);
+    const double *tgt_sub = tgt_boxes ? tgt_boxes + ((tgt.n + kTile - 1) / kTile) * 6 : nullptr;
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         if (expand) {
@@ -474,12 +565,34 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
         if (!wave_owns_any) continue;  // a wave past the end of the shard only takes part in the barriers
         if (tgt_boxes && !tile_bad[jb / kTile] && box_gap2(wown, tgt_boxes + (jb / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;
         const int cnt = (int)min((int64_t)kTile, j1 - jb);
-        if (expand)
-            rowstats_tile_expand<PT>(tile, tw, cnt, x, y, z, n, a1, ax, ay, az, T);
-        else if (clamp)
-            rowstats_tile<PT, true>(tile, tw, cnt, x, y, z, a1, ax, ay, az, c, lim, T);
-        else
-            rowstats_tile<PT, false>(tile, tw, cnt, x, y, z, a1, ax, ay, az, c, lim, T);
+        if (!(fine_on && !tile_bad[jb / kTile])) {  // a tile holding a non-finite 1/den is never culled (0 * inf = NaN)
+            if (expand)
+                rowstats_tile_expand<PT, false>(tile, tw, 0, cnt, kAllSlots, x, y, z, n, a1, ax, ay, az, T);
+            else if (clamp)
+                rowstats_tile<PT, true, false>(tile, tw, 0, cnt, kAllSlots, x, y, z, a1, ax, ay, az, c, lim, T);
+            else
+                rowstats_tile<PT, false, false>(tile, tw, 0, cnt, kAllSlots, x, y, z, a1, ax, ay, az, c, lim, T);
+            continue;
+        }
+        // quarter of the tile x owned slot: skip what provably receives exact zeros
+        for (int sub = 0; sub * 64 < cnt; ++sub) {
+            const int q0 = sub * 64, q1 = min(cnt, q0 + 64);
+            const unsigned mask = quarter_mask<PT>(sown, tgt_sub + ((jb / kTile) * 4 + sub) * 6, -c);
+            if (!mask) continue;
+            if (expand) {
+                if (mask == kAllSlots)
+                    rowstats_tile_expand<PT, false>(tile, tw, q0, q1, mask, x, y, z, n, a1, ax, ay, az, T);
+                else
+                    rowstats_tile_expand<PT, true>(tile, tw, q0, q1, mask, x, y, z, n, a1, ax, ay, az, T);
+            } else if (clamp) {
+                rowstats_tile<PT, true, true>(tile, tw, q0, q1, mask, x, y, z, a1, ax, ay, az, c, lim, T);
+            } else {
+                if (mask == kAllSlots)
+                    rowstats_tile<PT, false, false>(tile, tw, q0, q1, mask, x, y, z, a1, ax, ay, az, c, lim, T);
+                else
+                    rowstats_tile<PT, false, true>(tile, tw, q0, q1, mask, x, y, z, a1, ax, ay, az, c, lim, T);
+            }
+        }
     }
     const int64_t M = fit.n;
     double *base = partial + (int64_t)blockIdx.y * 4 * M;
@@ -838,8 +951,13 @@ void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *si
             int64_t len;
             plan_chunks(target.n, kBlock * kPT, fit.n, &nch, &len);
             dim3 grid((unsigned)ceil_div(target.n, kBlock * kPT), (unsigned)nch);
-            hipLaunchKernelGGL(cpd_colsum_kernel<kPT>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux,
-                               ctx->cull ? fit_boxes : (const double *)nullptr, len, ws);
+            const double *boxes = ctx->cull ? fit_boxes : (const double *)nullptr;
+            // with boxes: both variants, the device picks by regime (the other returns at once); without: the plain one
+            hipLaunchKernelGGL((cpd_colsum_kernel<kPT, false>), grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux,
+                               boxes, len, ws, boxes ? 1 : 0);
+            if (boxes)
+                hipLaunchKernelGGL((cpd_colsum_kernel<kPT, true>), grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux,
+                                   boxes, len, ws, 1);
         }
     }
     hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)ceil_div(target.n, 256)), dim3(256), 0, ctx->stream, ws, nch,
@@ -867,12 +985,19 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
             plan_chunks(fit.n, kBlock * pt, target.n, &nch, &len);
             dim3 grid((unsigned)ceil_div(fit.n, kBlock * pt), (unsigned)nch);
             const bool cull = ctx->cull && tgt_boxes && tile_bad;
-            if (pt == 2)
-                hipLaunchKernelGGL(cpd_rowstats_kernel<2>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux,
-                               inv_den, cull ? tgt_boxes : (const double *)nullptr, tile_bad, len, ws);
-            else
-                hipLaunchKernelGGL(cpd_rowstats_kernel<kPT>, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux,
-                               inv_den, cull ? tgt_boxes : (const double *)nullptr, tile_bad, len, ws);
+            const double *boxes = cull ? tgt_boxes : (const double *)nullptr;
+            auto launch = [&](auto kern, int check) {
+                hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux, inv_den, boxes, tile_bad,
+                                   len, ws, check);
+            };
+            // with boxes: both variants, the device picks by regime (the other returns at once); without: the plain one
+            if (pt == 2) {
+                launch(cpd_rowstats_kernel<2, false>, boxes ? 1 : 0);
+                if (boxes) launch(cpd_rowstats_kernel<2, true>, 1);
+            } else {
+                launch(cpd_rowstats_kernel<kPT, false>, boxes ? 1 : 0);
+                if (boxes) launch(cpd_rowstats_kernel<kPT, true>, 1);
+            }
         }
     }
     hipLaunchKernelGGL(rowstats_reduce_kernel, dim3(kScalarBlocks), dim3(256), 0, ctx->stream, ws, nch, fit, P1, PX_soa,
@@ -980,6 +1105,11 @@ void morton_order(const double *xyz, int64_t n, std::vector<int32_t> &perm) {
     perm.resize((size_t)n);
     for (int64_t i = 0; i < n; ++i) perm[(size_t)i] = (int32_t)i;
     kd_split(xyz, perm.data(), n, 256);
-    // keep the original order inside a leaf (reproducible and cache friendly)
-    for (int64_t b = 0; b < n; b += 256) std::sort(perm.begin() + b, perm.begin() + (b + 256 < n ? b + 256 : n));
+    // every 256-point leaf is split further into four spatially compact 64-point quarters (the unit of the fine exact-zero
+    // culling: one owned slot of a wave, one quarter of a streamed tile); original order inside a quarter (reproducible)
+    for (int64_t b = 0; b < n; b += 256) {
+        const int64_t m = b + 256 < n ? 256 : n - b;
+        kd_split(xyz, perm.data() + b, m, 64);
+        for (int64_t q = 0; q < m; q += 64) std::sort(perm.begin() + b + q, perm.begin() + b + (q + 64 < m ? q + 64 : m));
+    }
 }

@@ -458,8 +458,8 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
     morton_order(target_xyz, N, f->h_tperm);
     GINGR_TRY(dev_alloc(ctx, &f->tperm, (size_t)N));
     HIP_TRY(ctx, hipMemcpyAsync(f->tperm, f->h_tperm.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    GINGR_TRY(dev_alloc(ctx, &f->tboxes, (size_t)ceil_div(N, 256) * 6));
-    GINGR_TRY(dev_alloc(ctx, &f->fboxes, (size_t)ceil_div(M, 256) * 6));
+    GINGR_TRY(dev_alloc(ctx, &f->tboxes, (size_t)ceil_div(N, 256) * 30));  // tile boxes + four quarter boxes per tile
+    GINGR_TRY(dev_alloc(ctx, &f->fboxes, (size_t)ceil_div(M, 256) * 30));
     GINGR_TRY(dev_alloc(ctx, &f->tile_bad, (size_t)ceil_div(N, 256)));
     launch_aos_to_soa(ctx, aos, N, f->target, f->tperm);
     launch_tile_bbox(ctx, cloud_of(f->target, N), f->tboxes);
