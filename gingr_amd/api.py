@@ -773,18 +773,21 @@ class IcpRegistration(GingrAlgorithm):
 
     def _native_update_sample(self, current: IcpRegistrationState, z: np.ndarray):
         c = current.config
-        if c.correspondenceMethod != "PointcloudClosestPoint":
-            raise NotImplementedError("probabilistic proposals are on the accelerated path for PointcloudClosestPoint only")
         p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
-        _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_sample_async(self._fitter, ctypes.byref(p), dptr(z)),
-               "gingr_fitter_update_icp_sample_async")
+        if c.correspondenceMethod == "TriangularClosestPoint":
+            _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_surface_sample_async(self._fitter, ctypes.byref(p), dptr(z)),
+                   "gingr_fitter_update_icp_surface_sample_async")
+        else:
+            _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_sample_async(self._fitter, ctypes.byref(p), dptr(z)),
+                   "gingr_fitter_update_icp_sample_async")
 
     def _native_logpdf(self, state: IcpRegistrationState, mesh: np.ndarray) -> float:
         c = state.config
         p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
         out = ctypes.c_double()
-        _check(self.ctx.handle, self._lib.gingr_fitter_posterior_logpdf_icp(self._fitter, ctypes.byref(p), dptr(mesh),
-                                                                             ctypes.byref(out)), "gingr_fitter_posterior_logpdf_icp")
+        fn = (self._lib.gingr_fitter_posterior_logpdf_icp_surface if c.correspondenceMethod == "TriangularClosestPoint"
+              else self._lib.gingr_fitter_posterior_logpdf_icp)
+        _check(self.ctx.handle, fn(self._fitter, ctypes.byref(p), dptr(mesh), ctypes.byref(out)), "gingr_fitter_posterior_logpdf_icp")
         return out.value
 
     def getCorrespondence(self, state: IcpRegistrationState) -> CorrespondencePairs:

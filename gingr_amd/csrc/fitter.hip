@@ -934,7 +934,14 @@ int gingr_fitter_get_surface_correspondence(gingr_fitter *f, double *cp_xyz, dou
 }
 
 // ------------------------------------------------------------------------------------------ probabilistic proposal
-static int sample_update(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr_icp_params *ip, const double *z) {
+// correspondence flavour of a probabilistic query: 0 CPD, 1 ICP point cloud, 2 ICP surface
+static int flavour_phase(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int ph) {
+    if (flavour == 0) return gingr_fitter_cpd_phase_async(f, cp, ph);
+    if (flavour == 1) return gingr_fitter_icp_phase_async(f, ip, ph);
+    return gingr_fitter_icp_surface_phase_async(f, ip, ph);
+}
+
+static int sample_update(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, const double *z) {
     GINGR_TRY(check_ready(f));
     gingr_ctx *ctx = f->ctx;
     if (!z) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "update_sample: z is null");
@@ -945,21 +952,24 @@ static int sample_update(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, 
     HIP_TRY(ctx, hipMemcpyAsync(f->zrand, zz.data(), (size_t)rp * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     f->zrand_active = true;
     int rc = GINGR_OK;
-    for (int ph = 0; ph < GINGR_NUM_PHASES && rc == GINGR_OK; ++ph)
-        rc = icp ? gingr_fitter_icp_phase_async(f, ip, ph) : gingr_fitter_cpd_phase_async(f, cp, ph);
+    for (int ph = 0; ph < GINGR_NUM_PHASES && rc == GINGR_OK; ++ph) rc = flavour_phase(f, flavour, cp, ip, ph);
     f->zrand_active = false;
     return rc;
 }
 
 int gingr_fitter_update_cpd_sample_async(gingr_fitter *f, const gingr_cpd_params *p, const double *z) {
-    return sample_update(f, false, p, nullptr, z);
+    return sample_update(f, 0, p, nullptr, z);
 }
 
 int gingr_fitter_update_icp_sample_async(gingr_fitter *f, const gingr_icp_params *p, const double *z) {
-    return sample_update(f, true, nullptr, p, z);
+    return sample_update(f, 1, nullptr, p, z);
 }
 
-static int posterior_logpdf(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr_icp_params *ip,
+int gingr_fitter_update_icp_surface_sample_async(gingr_fitter *f, const gingr_icp_params *p, const double *z) {
+    return sample_update(f, 2, nullptr, p, z);
+}
+
+static int posterior_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,
                             const double *mesh_xyz, double *logpdf) {
     GINGR_TRY(check_ready(f));
     gingr_ctx *ctx = f->ctx;
@@ -969,7 +979,7 @@ static int posterior_logpdf(gingr_fitter *f, bool icp, const gingr_cpd_params *c
     const int64_t M = m->M;
     const int32_t r = m->r, rp = m->rp;
     // posterior of the current state: correspondences, Gram, right-hand side (phases 0 and 1 do not touch the state)
-    for (int ph = 0; ph < 2; ++ph) GINGR_TRY(icp ? gingr_fitter_icp_phase_async(f, ip, ph) : gingr_fitter_cpd_phase_async(f, cp, ph));
+    for (int ph = 0; ph < 2; ++ph) GINGR_TRY(flavour_phase(f, flavour, cp, ip, ph));
     double *G = f->xch + f->off[1];
     double *rhs = G + (int64_t)rp * rp;
     // the solve flags failures in st->err, which belongs to the update in flight: save / restore it around this query
@@ -1016,13 +1026,19 @@ int gingr_fitter_posterior_logpdf_cpd(gingr_fitter *f, const gingr_cpd_params *p
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
     if (!p || !(p->w >= 0.0 && p->w < 1.0) || !(p->lambda > 0.0))
         return gingr_set_error(f->ctx, GINGR_ERR_BAD_ARGUMENT, "cpd params: need 0 <= w < 1 and lambda > 0");
-    return posterior_logpdf(f, false, p, nullptr, mesh_xyz, logpdf);
+    return posterior_logpdf(f, 0, p, nullptr, mesh_xyz, logpdf);
 }
 
 int gingr_fitter_posterior_logpdf_icp(gingr_fitter *f, const gingr_icp_params *p, const double *mesh_xyz, double *logpdf) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
     if (!p || p->max_iterations < 1) return gingr_set_error(f->ctx, GINGR_ERR_BAD_ARGUMENT, "icp params: max_iterations < 1");
-    return posterior_logpdf(f, true, nullptr, p, mesh_xyz, logpdf);
+    return posterior_logpdf(f, 1, nullptr, p, mesh_xyz, logpdf);
+}
+
+int gingr_fitter_posterior_logpdf_icp_surface(gingr_fitter *f, const gingr_icp_params *p, const double *mesh_xyz, double *logpdf) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    if (!p || p->max_iterations < 1) return gingr_set_error(f->ctx, GINGR_ERR_BAD_ARGUMENT, "icp params: max_iterations < 1");
+    return posterior_logpdf(f, 2, nullptr, p, mesh_xyz, logpdf);
 }
 
 // ===================================================================================== stateless model operators

@@ -222,6 +222,10 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_triangles, const in
                             int64_t n_target_triangles, const int32_t *target_triangles);
 int gingr_fitter_update_icp_surface_async(gingr_fitter *f, const gingr_icp_params *params, int32_t n_iterations);
 int gingr_fitter_icp_surface_phase_async(gingr_fitter *f, const gingr_icp_params *params, int32_t phase);
+/* probabilistic proposal / log transition density with the surface correspondence (see the _sample / _logpdf entry points below) */
+int gingr_fitter_update_icp_surface_sample_async(gingr_fitter *f, const gingr_icp_params *params, const double *z);
+int gingr_fitter_posterior_logpdf_icp_surface(gingr_fitter *f, const gingr_icp_params *params, const double *mesh_xyz,
+                                              double *logpdf);
 /* correspondences of the last surface phase 0: closest surface point [3 M] and weight in {0, 1} [M] per model vertex */
 int gingr_fitter_get_surface_correspondence(gingr_fitter *f, double *cp_xyz, double *w);
 

@@ -166,6 +166,18 @@ JFN(jint, fitterUpdateIcpSurface)(JNIEnv *, jclass, jlong f, jdouble initialSigm
     gingr_icp_params p{initialSigma, endSigma, maxIterations};
     return gingr_fitter_update_icp_surface_async(P<gingr_fitter>(f), &p, n);
 }
+JFN(jint, fitterUpdateIcpSurfaceSample)(JNIEnv *env, jclass, jlong f, jdouble initialSigma, jdouble endSigma, jint maxIterations,
+                                        jdoubleArray z) {
+    gingr_icp_params p{initialSigma, endSigma, maxIterations};
+    Pin a(env, z, true);
+    return gingr_fitter_update_icp_surface_sample_async(P<gingr_fitter>(f), &p, a.as<double>());
+}
+JFN(jint, fitterPosteriorLogpdfIcpSurface)(JNIEnv *env, jclass, jlong f, jdouble initialSigma, jdouble endSigma, jint maxIterations,
+                                           jdoubleArray mesh, jdoubleArray out) {
+    gingr_icp_params p{initialSigma, endSigma, maxIterations};
+    Pin a(env, mesh, true), b(env, out, false);
+    return gingr_fitter_posterior_logpdf_icp_surface(P<gingr_fitter>(f), &p, a.as<double>(), b.as<double>());
+}
 JFN(jint, fitterGetSurfaceCorrespondence)(JNIEnv *env, jclass, jlong f, jdoubleArray cp, jdoubleArray w) {
     Pin a(env, cp, false), b(env, w, false);
     return gingr_fitter_get_surface_correspondence(P<gingr_fitter>(f), a.as<double>(), b.as<double>());

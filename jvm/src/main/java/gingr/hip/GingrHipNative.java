@@ -54,6 +54,9 @@ public final class GingrHipNative {
     // ---- ICP with the surface correspondence (TriangularClosestPoint): flat triangle id triples of both meshes
     public static native int fitterSetMeshes(long fitter, int[] modelTriangles, int[] targetTriangles);
     public static native int fitterUpdateIcpSurface(long fitter, double initialSigma, double endSigma, int maxIterations, int nIterations);
+    public static native int fitterUpdateIcpSurfaceSample(long fitter, double initialSigma, double endSigma, int maxIterations, double[] z);
+    public static native int fitterPosteriorLogpdfIcpSurface(long fitter, double initialSigma, double endSigma, int maxIterations,
+                                                             double[] meshXyz, double[] out1);
     /** cpXyz [3 M], w [M] in {0, 1} of the last surface correspondence */
     public static native int fitterGetSurfaceCorrespondence(long fitter, double[] cpXyz, double[] w);
 

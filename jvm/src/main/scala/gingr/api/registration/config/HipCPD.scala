@@ -231,7 +231,11 @@ class HipIcpRegistration(device: Int = 0) extends GingrAlgorithm[HipIcpRegistrat
     val (alpha, pose, status) =
       if (probabilistic) {
         val z = Array.fill(current.general.model.rank)(rnd.scalaRandom.nextGaussian())
-        session.updateOnce(current.general, f => GingrHipNative.fitterUpdateIcpSample(f, c.initialSigma, c.endSigma, c.maxIterations, z))
+        if (c.correspondenceMethod == TriangularClosestPoint) {
+          session.bindMeshes(current.general)
+          session.updateOnce(current.general, f => GingrHipNative.fitterUpdateIcpSurfaceSample(f, c.initialSigma, c.endSigma, c.maxIterations, z))
+        } else
+          session.updateOnce(current.general, f => GingrHipNative.fitterUpdateIcpSample(f, c.initialSigma, c.endSigma, c.maxIterations, z))
       } else if (c.correspondenceMethod == TriangularClosestPoint) {
         session.bindMeshes(current.general) // triangle lists of model.reference and target, once per (model, target)
         session.updateOnce(current.general, f => GingrHipNative.fitterUpdateIcpSurface(f, c.initialSigma, c.endSigma, c.maxIterations, 1))

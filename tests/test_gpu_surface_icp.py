@@ -143,3 +143,21 @@ def test_surface_icp_argument_errors(ctx):
     with pytest.raises(ga.GingrNativeError):
         algo.update(state)
     algo.close()
+
+
+def test_probabilistic_surface_icp(ctx):
+    """update(probabilistic = true) and logTransitionProbability with the surface correspondence."""
+    ref, cells, target, tcells = femur()
+    mo, algo, state = make_state(ctx, ref, cells, target, tcells, rank=20)
+    s1 = algo.update(state)
+    st_in = oracle_state_of(s1.general, 1)
+    z = np.random.default_rng(11).standard_normal(mo.rank)
+    s2 = algo.update(s1, probabilistic=True, rnd=np.random.default_rng(11))
+    st2, (ocp, ow) = go.icp_surface_update(mo, cells, target, tcells, st_in, 20.0, 1.0, 30, z=z)
+    assert s2.general.status == st2.status == 0
+    assert rel(s2.general.fit, st2.fit) < 1e-5
+    got = algo.logTransitionProbability(s1, s2)
+    pids = np.flatnonzero(ow == 1.0)
+    want = go.posterior_logpdf_of_mesh(mo, st_in, pids, ocp[pids], np.full(pids.shape[0], st_in.sigma2), mesh=st_in.fit)
+    assert np.isfinite(got) and abs(got - want) < 1e-5 * abs(want), (got, want)
+    algo.close()
