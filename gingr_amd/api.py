@@ -728,6 +728,15 @@ class CpdRegistration(GingrAlgorithm):
 
 class IcpRegistration(GingrAlgorithm):
     name = "ICP"
+    _METHODS = ("PointcloudClosestPoint", "TriangularClosestPoint", "AlongNormalClosestPoint")
+
+    @staticmethod
+    def _surface(config: IcpConfiguration) -> bool:
+        return config.correspondenceMethod in ("TriangularClosestPoint", "AlongNormalClosestPoint")
+
+    def _select_surface_method(self, config: IcpConfiguration):
+        _check(self.ctx.handle, self._lib.gingr_fitter_set_surface_method(
+            self._fitter, 1 if config.correspondenceMethod == "AlongNormalClosestPoint" else 0), "gingr_fitter_set_surface_method")
 
     def createInitialState(self, model: PointDistributionModel, target, config: IcpConfiguration,
                            transform: int = GlobalTranformationType.RigidTransforms, stepLength: float = 1.0,
@@ -737,18 +746,18 @@ class IcpRegistration(GingrAlgorithm):
         return self.initializeState(g, config)
 
     def initializeState(self, general: GeneralRegistrationState, config: IcpConfiguration) -> IcpRegistrationState:
-        if config.reverseCorrespondenceDirection or config.correspondenceMethod not in ("PointcloudClosestPoint", "TriangularClosestPoint"):
-            raise NotImplementedError("accelerated ICP flavours: PointcloudClosestPoint and TriangularClosestPoint (ICP.scala:40-44), "
-                                      "forward direction")
-        if config.correspondenceMethod == "TriangularClosestPoint" and (getattr(general.model, "cells", None) is None
-                                                                        or general.targetCells is None):
-            raise ValueError("TriangularClosestPoint needs the triangulations: model.cells and targetCells")
+        if config.reverseCorrespondenceDirection or config.correspondenceMethod not in self._METHODS:
+            raise NotImplementedError("accelerated ICP flavours: PointcloudClosestPoint, TriangularClosestPoint and "
+                                      "AlongNormalClosestPoint (ICP.scala:32-44), forward direction")
+        if self._surface(config) and (getattr(general.model, "cells", None) is None or general.targetCells is None):
+            raise ValueError(config.correspondenceMethod + " needs the triangulations: model.cells and targetCells")
         return IcpRegistrationState(general.updateSigma2(float(config.initialSigma)), config)   # ICP.scala:73-85
 
     def _native_update(self, current: IcpRegistrationState, n: int):
         c = current.config
         p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
-        if c.correspondenceMethod == "TriangularClosestPoint":
+        if self._surface(c):
+            self._select_surface_method(c)
             _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_surface_async(self._fitter, ctypes.byref(p), n),
                    "gingr_fitter_update_icp_surface_async")
         else:
@@ -762,6 +771,7 @@ class IcpRegistration(GingrAlgorithm):
         self._bind(g, c.useLandmarkCorrespondence)
         self._push_state(g)
         self._device_state_token = None
+        self._select_surface_method(c)
         p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
         _check(self.ctx.handle, self._lib.gingr_fitter_icp_surface_phase_async(self._fitter, ctypes.byref(p), 0),
                "gingr_fitter_icp_surface_phase_async")
@@ -774,7 +784,8 @@ class IcpRegistration(GingrAlgorithm):
     def _native_update_sample(self, current: IcpRegistrationState, z: np.ndarray):
         c = current.config
         p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
-        if c.correspondenceMethod == "TriangularClosestPoint":
+        if self._surface(c):
+            self._select_surface_method(c)
             _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_surface_sample_async(self._fitter, ctypes.byref(p), dptr(z)),
                    "gingr_fitter_update_icp_surface_sample_async")
         else:
@@ -785,13 +796,14 @@ class IcpRegistration(GingrAlgorithm):
         c = state.config
         p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
         out = ctypes.c_double()
-        fn = (self._lib.gingr_fitter_posterior_logpdf_icp_surface if c.correspondenceMethod == "TriangularClosestPoint"
-              else self._lib.gingr_fitter_posterior_logpdf_icp)
+        if self._surface(c):
+            self._select_surface_method(c)
+        fn = self._lib.gingr_fitter_posterior_logpdf_icp_surface if self._surface(c) else self._lib.gingr_fitter_posterior_logpdf_icp
         _check(self.ctx.handle, fn(self._fitter, ctypes.byref(p), dptr(mesh), ctypes.byref(out)), "gingr_fitter_posterior_logpdf_icp")
         return out.value
 
     def getCorrespondence(self, state: IcpRegistrationState) -> CorrespondencePairs:
-        if state.config.correspondenceMethod == "TriangularClosestPoint":             # ICP.scala:40,50
+        if self._surface(state.config):                                               # ICP.scala:40-41,50
             cp, w = self.surfaceCorrespondence(state)
             keep = np.flatnonzero(w == 1.0)
             return CorrespondencePairs(keep, cp[keep])

@@ -53,6 +53,7 @@ struct gingr_fitter {
     bool has_state = false;
     // ---- ICP surface correspondence (surface.hip): triangles in device vertex positions and a spatial triangle order
     bool icp_surface = false;                      // correspondence flavour of the ICP phases
+    int32_t surface_method = 0;                    // 0 TriangularClosestPoint, 1 AlongNormalClosestPoint (ICP.scala:32-34)
     int64_t Tm = 0, Tt = 0;                        // model / target triangle counts
     int32_t *mtri = nullptr, *ttri = nullptr, *ttri_orig = nullptr;
     int32_t *madj_ptr = nullptr, *madj_tri = nullptr, *tadj_ptr = nullptr, *tadj_tri = nullptr;  // vertex -> triangles
@@ -662,9 +663,14 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 launch_cell_normals(ctx, fit, f->mtri, f->Tm, f->mcn);
                 launch_vertex_normals(ctx, f->madj_ptr, f->madj_tri, f->mcn, f->Tm, M, f->mvn);
                 launch_tri_tile_bbox(ctx, fit, f->mtri, f->Tm, f->mtboxes);
-                launch_surface_closest_point(ctx, fit, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, f->surf_cp, f->surf_d2);
+                const bool along = f->surface_method == 1;  // ClosestPointAlongNormalTriangleMesh3D (:102-131)
+                if (along)
+                    launch_line_nearest(ctx, fit, f->mvn, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, f->surf_cp, f->surf_hit);
+                else
+                    launch_surface_closest_point(ctx, fit, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, f->surf_cp, f->surf_d2);
                 launch_nn(ctx, cloud_of(f->surf_cp, M), tgt, f->tperm, f->tboxes, f->ws, f->surf_nn, f->surf_nnd2);
-                launch_surface_prereject(ctx, M, f->surf_nn, f->tboundary, f->mvn, f->tvn, f->N, f->surf_pre);
+                launch_surface_prereject(ctx, M, f->surf_nn, f->tboundary, f->mvn, f->tvn, f->N, along ? f->surf_hit : nullptr,
+                                         f->surf_pre);
                 launch_self_intersect(ctx, fit, f->surf_cp, f->mtri, f->Tm, f->mtboxes, f->surf_pre, f->surf_hit);
                 launch_surface_weight(ctx, M, f->surf_pre, f->surf_hit, &f->st->sigma2, f->surf_w01, f->surf_win);
             } else if (icp)
@@ -895,6 +901,13 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
     launch_tri_tile_bbox(ctx, tgt, f->ttri, f->Tt, f->ttboxes);
     GINGR_TRY(check_launch(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GINGR_OK;
+}
+
+int gingr_fitter_set_surface_method(gingr_fitter *f, int32_t method) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    if (method != 0 && method != 1) return gingr_set_error(f->ctx, GINGR_ERR_BAD_ARGUMENT, "set_surface_method: 0 or 1");
+    f->surface_method = method;
     return GINGR_OK;
 }
 

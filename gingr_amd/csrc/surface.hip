@@ -282,16 +282,100 @@ __global__ __launch_bounds__(kSurfThreads) void self_intersect_kernel(Cloud fit,
     if (i < fit.n) flag[i] = hit;
 }
 
+// ClosestPointAlongNormalTriangleMesh3D (ClosestPointRegistrator.scala:102-131): for every fit vertex the intersection of the
+// line {p + t n} (n = its vertex normal, both directions) with the mesh (v, tri) that is closest to p and != p; found[i] = 0 and
+// cp = p when there is none.  A tile is visited only if some lane's line passes through its (slightly inflated) box and the box
+// is not farther from p than the lane's current hit; exact ties go to the lowest ORIGINAL triangle.
+__global__ __launch_bounds__(kSurfThreads) void line_nearest_kernel(Cloud fit, const double *__restrict__ dirs, Cloud v,
+                                                                   const int32_t *__restrict__ tri,
+                                                                   const int32_t *__restrict__ tri_orig, int64_t T,
+                                                                   const double *__restrict__ boxes, double *__restrict__ cp,
+                                                                   int32_t *__restrict__ found) {
+    __shared__ Tri9 tile[kTriTile];
+    const int lane = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kSurfThreads + lane;
+    const bool ok = i < fit.n;
+    const int64_t ic = ok ? i : 0;
+    const V3 p{fit.x[ic], fit.y[ic], fit.z[ic]};
+    const V3 dir{dirs[ic], dirs[fit.n + ic], dirs[2 * fit.n + ic]};
+    const double pa[3] = {p.x, p.y, p.z}, da[3] = {dir.x, dir.y, dir.z};
+    double best = __builtin_huge_val(), bo = __builtin_huge_val();  // distance |p - ip| and the original triangle that holds it
+    V3 bp = p;
+    const int nt = (int)((T + kTriTile - 1) / kTriTile);
+    for (int t = 0; t < nt; ++t) {
+        const double *bx = boxes + (int64_t)t * 6;
+        // slab test of the infinite line against the box inflated by a relative rounding margin
+        double tmin = -__builtin_huge_val(), tmax = __builtin_huge_val();
+        bool miss = false;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double eps = 1e-9 * (fabs(bx[d]) + fabs(bx[3 + d]) + fabs(pa[d]) + 1e-300);
+            const double lo = bx[d] - eps, hi = bx[3 + d] + eps;
+            if (da[d] == 0.0) {
+                if (pa[d] < lo || pa[d] > hi) miss = true;
+            } else {
+                const double t1 = (lo - pa[d]) / da[d], t2 = (hi - pa[d]) / da[d];
+                tmin = fmax(tmin, fmin(t1, t2));
+                tmax = fmin(tmax, fmax(t1, t2));
+            }
+        }
+        if (tmin > tmax) miss = true;
+        const double pd = point_box_gap2(p.x, p.y, p.z, bx);
+        const bool need = ok && !miss && !(pd > best * best * (1.0 + 1e-12));
+        if (!__any(need)) continue;
+        const int64_t tb = (int64_t)t * kTriTile;
+        __syncthreads();
+        stage_tile(tile, v, tri, tri_orig, tb, T, lane);
+        __syncthreads();
+        const int cnt = (int)min((int64_t)kTriTile, T - tb);
+        if (need)
+            for (int jj = 0; jj < cnt; ++jj) {
+                const Tri9 tr = tile[jj];
+                const V3 A{tr.ax, tr.ay, tr.az};
+                const V3 e1 = sub(V3{tr.bx, tr.by, tr.bz}, A), e2 = sub(V3{tr.cx, tr.cy, tr.cz}, A);
+                const V3 pv = cross3(dir, e2);
+                const double det = dot3(e1, pv);
+                const double inv = 1.0 / det;
+                const V3 tv = sub(p, A);
+                const double u = dot3(tv, pv) * inv;
+                const V3 qv = cross3(tv, e1);
+                const double w = dot3(qv, dir) * inv;
+                const double tt = dot3(e2, qv) * inv;
+                if (det != 0.0 && u >= 0.0 && u <= 1.0 && w >= 0.0 && u + w <= 1.0) {
+                    const V3 ip{p.x + tt * dir.x, p.y + tt * dir.y, p.z + tt * dir.z};
+                    if (ip.x != p.x || ip.y != p.y || ip.z != p.z) {
+                        const V3 dd = sub(ip, p);
+                        const double dist = sqrt((dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z);
+                        if (dist < best || (dist == best && tr.orig < bo)) {
+                            best = dist;
+                            bo = tr.orig;
+                            bp = ip;
+                        }
+                    }
+                }
+            }
+    }
+    if (ok) {
+        cp[i] = bp.x;
+        cp[fit.n + i] = bp.y;
+        cp[2 * fit.n + i] = bp.z;
+        found[i] = best < __builtin_huge_val() ? 1 : 0;
+    }
+}
+
 // first two rejection tests (boundary vertex, opposite normals): pre[i] = 1 when the pair is already rejected
 __global__ __launch_bounds__(256) void surface_prereject_kernel(int64_t M, const int32_t *__restrict__ nn_vertex,
                                                                 const int32_t *__restrict__ tgt_boundary,
                                                                 const double *__restrict__ fit_vn, const double *__restrict__ tgt_vn,
-                                                                int64_t N, int32_t *__restrict__ pre) {
+                                                                int64_t N, const int32_t *__restrict__ found,
+                                                                int32_t *__restrict__ pre) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
     const int32_t j = nn_vertex[i];
     int r = 0;
-    if (j < 0)
+    if (found && !found[i])  // along-normal flavour: no intersection -> (p, weight 0)
+        r = 1;
+    else if (j < 0)
         r = 1;
     else if (tgt_boundary[j])
         r = 1;
@@ -339,9 +423,14 @@ void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, cons
                        fit, cp_soa, fit, tri, T, boxes, skip, flag);
 }
 void launch_surface_prereject(gingr_ctx *ctx, int64_t M, const int32_t *nn_vertex, const int32_t *tgt_boundary,
-                              const double *fit_vn, const double *tgt_vn, int64_t N, int32_t *pre) {
+                              const double *fit_vn, const double *tgt_vn, int64_t N, const int32_t *found, int32_t *pre) {
     hipLaunchKernelGGL(surface_prereject_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, ctx->stream, M, nn_vertex,
-                       tgt_boundary, fit_vn, tgt_vn, N, pre);
+                       tgt_boundary, fit_vn, tgt_vn, N, found, pre);
+}
+void launch_line_nearest(gingr_ctx *ctx, Cloud fit, const double *dirs_soa, Cloud v, const int32_t *tri, const int32_t *tri_orig,
+                         int64_t T, const double *boxes, double *cp_soa, int32_t *found) {
+    hipLaunchKernelGGL(line_nearest_kernel, dim3((unsigned)ceil_div(fit.n, kSurfThreads)), dim3(kSurfThreads), 0, ctx->stream, fit,
+                       dirs_soa, v, tri, tri_orig, T, boxes, cp_soa, found);
 }
 void launch_surface_weight(gingr_ctx *ctx, int64_t M, const int32_t *pre, const int32_t *hit, const double *sigma2_dev, double *w01,
                            double *weight_in) {

@@ -220,6 +220,9 @@ int gingr_fitter_update_icp_async(gingr_fitter *f, const gingr_icp_params *p, in
  * (semantics unpinned without the scalismo source). */
 int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_triangles, const int32_t *model_triangles,
                             int64_t n_target_triangles, const int32_t *target_triangles);
+/* 0 = TriangularClosestPoint (default), 1 = AlongNormalClosestPoint (ClosestPointRegistrator.scala:102-131: the target point
+ * hit first by the line through the template vertex along its vertex normal; no hit = rejected) */
+int gingr_fitter_set_surface_method(gingr_fitter *f, int32_t method);
 int gingr_fitter_update_icp_surface_async(gingr_fitter *f, const gingr_icp_params *params, int32_t n_iterations);
 int gingr_fitter_icp_surface_phase_async(gingr_fitter *f, const gingr_icp_params *params, int32_t phase);
 /* probabilistic proposal / log transition density with the surface correspondence (see the _sample / _logpdf entry points below) */

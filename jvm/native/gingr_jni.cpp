@@ -162,6 +162,9 @@ JFN(jint, fitterSetMeshes)(JNIEnv *env, jclass, jlong f, jintArray modelTri, jin
     Pin a(env, modelTri, true), b(env, targetTri, true);
     return gingr_fitter_set_meshes(P<gingr_fitter>(f), nm, a.as<int32_t>(), nt, b.as<int32_t>());
 }
+JFN(jint, fitterSetSurfaceMethod)(JNIEnv *, jclass, jlong f, jint method) {
+    return gingr_fitter_set_surface_method(P<gingr_fitter>(f), method);
+}
 JFN(jint, fitterUpdateIcpSurface)(JNIEnv *, jclass, jlong f, jdouble initialSigma, jdouble endSigma, jint maxIterations, jint n) {
     gingr_icp_params p{initialSigma, endSigma, maxIterations};
     return gingr_fitter_update_icp_surface_async(P<gingr_fitter>(f), &p, n);

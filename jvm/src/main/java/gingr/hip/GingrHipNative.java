@@ -53,6 +53,8 @@ public final class GingrHipNative {
 
     // ---- ICP with the surface correspondence (TriangularClosestPoint): flat triangle id triples of both meshes
     public static native int fitterSetMeshes(long fitter, int[] modelTriangles, int[] targetTriangles);
+    /** 0 = TriangularClosestPoint, 1 = AlongNormalClosestPoint */
+    public static native int fitterSetSurfaceMethod(long fitter, int method);
     public static native int fitterUpdateIcpSurface(long fitter, double initialSigma, double endSigma, int maxIterations, int nIterations);
     public static native int fitterUpdateIcpSurfaceSample(long fitter, double initialSigma, double endSigma, int maxIterations, double[] z);
     public static native int fitterPosteriorLogpdfIcpSurface(long fitter, double initialSigma, double endSigma, int maxIterations,

@@ -202,8 +202,8 @@ case class HipIcpRegistrationState(general: GeneralRegistrationState, config: Ic
   override def updateGeneral(update: GeneralRegistrationState): HipIcpRegistrationState = this.copy(general = update)
 }
 
-/** PointcloudClosestPoint (ICP.scala:43) and the default TriangularClosestPoint (ICP.scala:40,63) flavours, forward
-  * direction; AlongNormalClosestPoint and reverseCorrespondenceDirection stay on the stock path. */
+/** All three correspondence flavours (ICP.scala:32-44), forward direction; reverseCorrespondenceDirection stays on the
+  * stock path. */
 class HipIcpRegistration(device: Int = 0) extends GingrAlgorithm[HipIcpRegistrationState, IcpConfiguration] with AutoCloseable {
   private val session = new HipSession(device)
   def name = "ICP-HIP"
@@ -220,8 +220,7 @@ class HipIcpRegistration(device: Int = 0) extends GingrAlgorithm[HipIcpRegistrat
     math.max(current.general.sigma2 - current.config.sigmaStep, current.config.endSigma)
 
   override def initializeState(general: GeneralRegistrationState, config: IcpConfiguration): HipIcpRegistrationState = {
-    require(config.correspondenceMethod != AlongNormalClosestPoint && !config.reverseCorrespondenceDirection,
-      "HipIcpRegistration implements the PointcloudClosestPoint and TriangularClosestPoint correspondences, forward direction")
+    require(!config.reverseCorrespondenceDirection, "HipIcpRegistration implements the forward correspondence direction")
     HipIcpRegistrationState(IcpRegistrationState(general, config).general, config)
   }
 
@@ -231,14 +230,20 @@ class HipIcpRegistration(device: Int = 0) extends GingrAlgorithm[HipIcpRegistrat
     val (alpha, pose, status) =
       if (probabilistic) {
         val z = Array.fill(current.general.model.rank)(rnd.scalaRandom.nextGaussian())
-        if (c.correspondenceMethod == TriangularClosestPoint) {
+        if (c.correspondenceMethod != PointcloudClosestPoint) {
           session.bindMeshes(current.general)
-          session.updateOnce(current.general, f => GingrHipNative.fitterUpdateIcpSurfaceSample(f, c.initialSigma, c.endSigma, c.maxIterations, z))
+          session.updateOnce(current.general, f => {
+            GingrHipNative.fitterSetSurfaceMethod(f, if (c.correspondenceMethod == AlongNormalClosestPoint) 1 else 0)
+            GingrHipNative.fitterUpdateIcpSurfaceSample(f, c.initialSigma, c.endSigma, c.maxIterations, z)
+          })
         } else
           session.updateOnce(current.general, f => GingrHipNative.fitterUpdateIcpSample(f, c.initialSigma, c.endSigma, c.maxIterations, z))
-      } else if (c.correspondenceMethod == TriangularClosestPoint) {
+      } else if (c.correspondenceMethod != PointcloudClosestPoint) {
         session.bindMeshes(current.general) // triangle lists of model.reference and target, once per (model, target)
-        session.updateOnce(current.general, f => GingrHipNative.fitterUpdateIcpSurface(f, c.initialSigma, c.endSigma, c.maxIterations, 1))
+        session.updateOnce(current.general, f => {
+          GingrHipNative.fitterSetSurfaceMethod(f, if (c.correspondenceMethod == AlongNormalClosestPoint) 1 else 0)
+          GingrHipNative.fitterUpdateIcpSurface(f, c.initialSigma, c.endSigma, c.maxIterations, 1)
+        })
       } else
         session.updateOnce(current.general, f => GingrHipNative.fitterUpdateIcp(f, c.initialSigma, c.endSigma, c.maxIterations, 1))
     current.updateGeneral(HipStateUpdate(current.general, alpha, pose, status))

@@ -879,3 +879,40 @@ def icp_surface_update(model: PDM, tmpl_tris: np.ndarray, target: np.ndarray, tg
     var = np.full(pids.shape[0], st.sigma2)
     s2n = icp_update_sigma2(st.sigma2, initial_sigma, end_sigma, max_iterations)
     return update_from_observations(model, st, pids, cp[pids], var, s2n, landmarks, z), (cp, w)
+
+
+def along_normal_correspondence(tmpl: np.ndarray, tmpl_tris: np.ndarray, tgt: np.ndarray, tgt_tris: np.ndarray):
+    """ClosestPointAlongNormalTriangleMesh3D.closestPointCorrespondence (ClosestPointRegistrator.scala:102-131): the target
+    intersection of the line through the template vertex along its vertex normal that is closest to the vertex (the vertex
+    itself with weight 0 when there is none), then the same three rejection rules as the surface flavour."""
+    n_tmpl, n_tgt = vertex_normals(tmpl, tmpl_tris), vertex_normals(tgt, tgt_tris)
+    bnd = boundary_vertices(tgt.shape[0], tgt_tris)
+    cp = tmpl.astype(np.float64).copy()
+    w = np.zeros(tmpl.shape[0])
+    dist = 0.0
+    for i in range(tmpl.shape[0]):
+        p = tmpl[i]
+        ips = line_mesh_intersections(p, n_tmpl[i], tgt, tgt_tris)
+        keep = np.any(ips != p, axis=1) if ips.shape[0] else np.zeros(0, bool)
+        if keep.any():
+            cand = ips[keep]
+            dd = cand - p
+            k = int(np.argmin(np.sqrt((dd * dd).sum(1))))             # minBy(ip => (p - ip).norm): first minimum
+            c = cand[k]
+            j = int(icp_closest_point(c[None, :], tgt)[0][0])
+            wi = 1.0
+            if bnd[j]:
+                wi = 0.0
+            elif float(n_tmpl[i] @ n_tgt[j]) < 0:
+                wi = 0.0
+            else:
+                v = p - c
+                sp = line_mesh_intersections(p, v, tmpl, tmpl_tris)
+                ks = np.any(sp != p, axis=1) if sp.shape[0] else np.zeros(0, bool)
+                if ks.any():
+                    d2 = sp[ks] - p
+                    if math.sqrt(float((d2 * d2).sum(1).min())) < math.sqrt(float(v @ v)):
+                        wi = 0.0
+            cp[i], w[i] = c, wi
+        dist += math.sqrt(float(((p - cp[i]) ** 2).sum()))
+    return cp, w, dist / tmpl.shape[0]

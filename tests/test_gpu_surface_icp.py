@@ -161,3 +161,41 @@ def test_probabilistic_surface_icp(ctx):
     want = go.posterior_logpdf_of_mesh(mo, st_in, pids, ocp[pids], np.full(pids.shape[0], st_in.sigma2), mesh=st_in.fit)
     assert np.isfinite(got) and abs(got - want) < 1e-5 * abs(want), (got, want)
     algo.close()
+
+
+def test_along_normal_flavour(ctx):
+    """AlongNormalClosestPoint (ClosestPointRegistrator.scala:102-131): correspondences and one update against the oracle, on the
+    femur pair (closed meshes) and on the open / folded synthetic pair (misses, boundary, opposite normals, self-intersection)."""
+    import gingr_amd as ga
+    for case in ("femur", "synthetic"):
+        if case == "femur":
+            ref, cells, target, tcells = femur()
+            rank, pose = 20, ((0.02, -0.01, 0.015), (0.8, -1.0, 0.4))
+        else:
+            target, tcells = grid_mesh(24, 40.0, 6.0, 1)
+            sv, st_ = grid_mesh(14, 46.0, 4.0, 2)
+            sv = sv + np.array([3.0, -2.0, 5.0])
+            fold = sv.copy()
+            fold[:, 2] -= 2.5
+            fold_t = st_[:, [0, 2, 1]] + sv.shape[0]
+            ref = np.concatenate([sv, fold[: sv.shape[0] // 2]])
+            cells = np.concatenate([st_, fold_t[(fold_t < ref.shape[0]).all(1)]]).astype(np.int32)
+            rank, pose = 12, None
+        mo = model_over(ref, cells, rank)
+        model = ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam, cells=cells)
+        algo = ga.IcpRegistration(ctx)
+        cfg = ga.IcpConfiguration(maxIterations=30, initialSigma=20.0, endSigma=1.0, correspondenceMethod="AlongNormalClosestPoint")
+        state = algo.createInitialState(model, target, cfg, targetCells=tcells, initial_pose=pose)
+        cp, w = algo.surfaceCorrespondence(state)
+        ocp, ow, _ = go.along_normal_correspondence(np.asarray(state.general.fit), cells, target, tcells)
+        assert np.array_equal(w, ow), (case, int((w != ow).sum()))
+        assert np.abs(cp - ocp).max() < 1e-9 * max(1.0, np.abs(target).max()), case
+        assert 0 < w.sum() < w.shape[0], case
+        # one update from the same state
+        st_in = oracle_state_of(state.general, 1)
+        s1 = algo.update(state)
+        pids = np.flatnonzero(ow == 1.0)
+        st1 = go.update_from_observations(mo, st_in, pids, ocp[pids], np.full(pids.shape[0], st_in.sigma2),
+                                          go.icp_update_sigma2(st_in.sigma2, 20.0, 1.0, 30), None, None)
+        assert s1.general.status == st1.status == 0 and rel(s1.general.fit, st1.fit) < 1e-5, case
+        algo.close()
