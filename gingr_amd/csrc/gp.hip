@@ -15,6 +15,7 @@
 // All reductions across workgroups go through per-block partials combined in a fixed order (bitwise reproducible).
 #include "gp.h"
 
+#include <algorithm>
 #include <type_traits>
 
 namespace {
@@ -375,6 +376,84 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ Q0
                 if (gi < rp && gj < rp) out[(int64_t)gi * rp + gj] = acc[i][j][reg];
             }
         }
+}
+
+// Weighted Gram for rp <= 112 (NT = rp / 16 <= 7 column tiles): every wave keeps the WHOLE upper triangle of G -- NT (NT + 1) / 2
+// accumulator tiles, 224 registers at NT = 7, the matrix pipe takes them from the AGPR half of the file -- so a 4-row step needs
+// only NT fragment loads for NT (NT + 1) / 2 MFMAs (7 : 28 instead of 8 : 16 for the 64 x 64 patches), no padded tile is ever
+// multiplied and the symmetric half is never computed.  A = w * fragment, B = fragment: one load serves both operands.
+// The waves of a workgroup interleave the 4-row steps of the slab (fragments are fetched two steps ahead) and are summed through
+// LDS in a fixed order.  Same fragment layout and output layout as gram_kernel.
+template <int NT>
+__global__ __launch_bounds__(256) void gram_tri_kernel(const double *__restrict__ Q0, int64_t rows, int rp,
+                                                       const double *__restrict__ weight, int64_t rows_per_slab,
+                                                       double *__restrict__ partial) {
+    constexpr int kTiles = NT * (NT + 1) / 2;
+    __shared__ double red[kTiles * 4 * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kq = lane >> 4, cl = lane & 15;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
+    const int64_t r1 = min(rows, r0 + rows_per_slab);
+    v4f64 acc[kTiles];
+#pragma unroll
+    for (int q = 0; q < kTiles; ++q) acc[q] = v4f64{0, 0, 0, 0};
+    auto load = [&](int64_t row, double (&f)[NT], double &w) {
+        const int64_t rr = row + kq;
+        const bool valid = rr < r1;
+        const int64_t rc = valid ? rr : r0;
+        w = valid ? (weight ? weight[rc / 3] : 1.0) : 0.0;
+        const double *p = Q0 + rc * rp + cl;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) f[t] = p[16 * t];
+    };
+    double cur[NT], n1[NT], n2[NT], wc = 0.0, w1 = 0.0, w2 = 0.0;
+    int64_t row = r0 + 4 * wave;
+    if (row < r1) load(row, cur, wc);
+    if (row + 16 < r1) load(row + 16, n1, w1);
+    for (; row < r1; row += 16) {
+        if (row + 32 < r1) load(row + 32, n2, w2);
+        double a[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[t] = cur[t] * wc;  // invalid rows: w = 0
+        int q = 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int u = t; u < NT; ++u, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], cur[u], acc[q], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            cur[t] = n1[t];
+            n1[t] = n2[t];
+        }
+        wc = w1;
+        w1 = w2;
+    }
+    // waves 1..3 are added into wave 0 in order
+    for (int w = 1; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int q = 0; q < kTiles; ++q)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) red[(q * 4 + reg) * 64 + lane] = acc[q][reg];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int q = 0; q < kTiles; ++q)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) acc[q][reg] += red[(q * 4 + reg) * 64 + lane];
+        }
+    }
+    if (wave != 0) return;
+    double *out = partial + (int64_t)blockIdx.x * rp * rp;
+    // D[i][j] of tile (t, u): i = kq + 4 reg is the A-side index (column 16 t + i of Q0), j = cl the B-side index
+    int q = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int u = t; u < NT; ++u, ++q)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) out[(int64_t)(16 * t + kq + 4 * reg) * rp + 16 * u + cl] = acc[q][reg];
 }
 
 // G[i][j] = sum over slabs (fixed order): 32 consecutive elements x 8 slab groups per workgroup, so every load instruction
@@ -1428,11 +1507,20 @@ static void gram_plan(int64_t M, int32_t rp, int *nbp, int *npatch, int *nslabs,
     *nslabs = (int)ceil_div(rows, *rows_per_slab);
 }
 
+// slabs of gram_tri_kernel (one workgroup each): 256 = one per CU; small shards keep at least 64 rows per slab
+static void gram_tri_plan(int64_t M, int *nslabs, int64_t *rows_per_slab) {
+    const int64_t rows = 3 * M;
+    const int64_t want = std::min<int64_t>(256, std::max<int64_t>(1, ceil_div(rows, 64)));
+    *rows_per_slab = round_up(ceil_div(rows, want), 16);
+    *nslabs = (int)ceil_div(rows, *rows_per_slab);
+}
+
 int64_t gram_ws_doubles(int64_t M, int32_t rp) {
-    int nbp, npatch, nslabs;
+    int nbp, npatch, nslabs, nslabs_tri;
     int64_t rps;
     gram_plan(M, rp, &nbp, &npatch, &nslabs, &rps);
-    return (int64_t)nslabs * rp * rp;
+    gram_tri_plan(M, &nslabs_tri, &rps);
+    return (int64_t)std::max(nslabs, nslabs_tri) * rp * rp;
 }
 
 void launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, double *G) {
@@ -1441,8 +1529,27 @@ void launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const 
     gram_plan(M, rp, &nbp, &npatch, &nslabs, &rps);
     {
         TimerScope ts(ctx, 2);
-        hipLaunchKernelGGL(gram_kernel, dim3(nslabs, npatch), dim3(256), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, nbp, 1,
-                           0, 0, 0, ws);
+        const int nt = rp / 16;
+        if (nt <= 7) {
+            // whole upper triangle per wave: one workgroup per slab; ~3 slabs' worth of waves per SIMD is not needed (one wave per
+            // SIMD, deep prefetch), so 256 slabs = one workgroup per CU
+            gram_tri_plan(M, &nslabs, &rps);
+            auto go = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(nslabs), dim3(256), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, ws);
+            };
+            switch (nt) {
+                case 1: go(gram_tri_kernel<1>); break;
+                case 2: go(gram_tri_kernel<2>); break;
+                case 3: go(gram_tri_kernel<3>); break;
+                case 4: go(gram_tri_kernel<4>); break;
+                case 5: go(gram_tri_kernel<5>); break;
+                case 6: go(gram_tri_kernel<6>); break;
+                default: go(gram_tri_kernel<7>); break;
+            }
+        } else {
+            hipLaunchKernelGGL(gram_kernel, dim3(nslabs, npatch), dim3(256), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, nbp,
+                               1, 0, 0, 0, ws);
+        }
     }
     hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 32)), dim3(256), 0, ctx->stream, ws,
                        nslabs, (int)rp, 1, G);
