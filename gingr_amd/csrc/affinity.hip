@@ -689,12 +689,6 @@ __device__ __forceinline__ double norm2_exact(double dx, double dy, double dz) {
 // pruning, the result is the same as the full scan including the lowest-original-index tie rule.
 constexpr int kNNThreads = 64;
 
-__device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-    return v;
-}
-
 __global__ __launch_bounds__(kNNThreads) void nn_kernel(Cloud q, Cloud tgt, const int32_t *__restrict__ orig,
                                                         const double *__restrict__ tgt_boxes, int64_t cols_per_chunk,
                                                         double *__restrict__ pd2, int32_t *__restrict__ pidx,
