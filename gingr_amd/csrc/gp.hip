@@ -378,24 +378,23 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ Q0
         }
 }
 
-// Weighted Gram for rp <= 112 (NT = rp / 16 <= 7 column tiles): every wave keeps the WHOLE upper triangle of G -- NT (NT + 1) / 2
-// accumulator tiles, 224 registers at NT = 7, the matrix pipe takes them from the AGPR half of the file -- so a 4-row step needs
-// only NT fragment loads for NT (NT + 1) / 2 MFMAs (7 : 28 instead of 8 : 16 for the 64 x 64 patches), no padded tile is ever
-// multiplied and the symmetric half is never computed.  A = w * fragment, B = fragment: one load serves both operands.
-// The waves of a workgroup interleave the 4-row steps of the slab (fragments are fetched two steps ahead) and are summed through
-// LDS in a fixed order.  Same fragment layout and output layout as gram_kernel.
-template <int NT>
-__global__ __launch_bounds__(256) void gram_tri_kernel(const double *__restrict__ Q0, int64_t rows, int rp,
-                                                       const double *__restrict__ weight, int64_t rows_per_slab,
-                                                       double *__restrict__ partial) {
+// Weighted Gram for rp <= 112 (NT = rp / 16 <= 7 column tiles): a PAIR of waves keeps the whole upper triangle of G -- the
+// NT (NT + 1) / 2 accumulator tiles are dealt alternately to the two waves (14 + 14 at NT = 7) -- so a 4-row step needs NT fragment
+// loads per wave for half of NT (NT + 1) / 2 MFMAs (7 : 14 instead of 8 : 16 for the 64 x 64 patches, and twice per pair), no
+// padded tile is ever multiplied and the symmetric half is never computed.  A = w * fragment, B = fragment: one load serves both
+// operands.  Eight waves per workgroup = four K groups (they interleave the 4-row steps of the slab) x two tile halves, two waves
+// per SIMD: 112 accumulator registers per wave stay in VGPRs.  (One wave holding all 28 tiles needs the AGPR half of the file and
+// the compiler then copies all 224 accumulator registers to and from it in every step: 85 us at 50k points instead of 59 us.)
+// The K groups are summed through LDS in a fixed order.  Same fragment layout and output layout as gram_kernel.
+template <int NT, int HALF>
+__device__ __forceinline__ void gram_tri_half(const double *__restrict__ Q0, int rp, const double *__restrict__ weight, int64_t r0,
+                                              int64_t r1, int kgroup, int kq, int cl, int lane, double *red,
+                                              double *__restrict__ out) {
     constexpr int kTiles = NT * (NT + 1) / 2;
-    __shared__ double red[kTiles * 4 * 64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kq = lane >> 4, cl = lane & 15;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
-    const int64_t r1 = min(rows, r0 + rows_per_slab);
-    v4f64 acc[kTiles];
+    constexpr int kMine = HALF == 0 ? (kTiles + 1) / 2 : kTiles / 2;
+    v4f64 acc[kMine > 0 ? kMine : 1];
 #pragma unroll
-    for (int q = 0; q < kTiles; ++q) acc[q] = v4f64{0, 0, 0, 0};
+    for (int q = 0; q < kMine; ++q) acc[q] = v4f64{0, 0, 0, 0};
     auto load = [&](int64_t row, double (&f)[NT], double &w) {
         const int64_t rr = row + kq;
         const bool valid = rr < r1;
@@ -405,12 +404,11 @@ __global__ __launch_bounds__(256) void gram_tri_kernel(const double *__restrict_
 #pragma unroll
         for (int t = 0; t < NT; ++t) f[t] = p[16 * t];
     };
-    double cur[NT], n1[NT], n2[NT], wc = 0.0, w1 = 0.0, w2 = 0.0;
-    int64_t row = r0 + 4 * wave;
+    double cur[NT], n1[NT], wc = 0.0, w1 = 0.0;
+    int64_t row = r0 + 4 * kgroup;
     if (row < r1) load(row, cur, wc);
-    if (row + 16 < r1) load(row + 16, n1, w1);
     for (; row < r1; row += 16) {
-        if (row + 32 < r1) load(row + 32, n2, w2);
+        if (row + 16 < r1) load(row + 16, n1, w1);
         double a[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) a[t] = cur[t] * wc;  // invalid rows: w = 0
@@ -418,42 +416,56 @@ __global__ __launch_bounds__(256) void gram_tri_kernel(const double *__restrict_
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int u = t; u < NT; ++u, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], cur[u], acc[q], 0, 0, 0);
+            for (int u = t; u < NT; ++u, ++q)
+                if ((q & 1) == HALF) acc[q >> 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], cur[u], acc[q >> 1], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            cur[t] = n1[t];
-            n1[t] = n2[t];
-        }
+        for (int t = 0; t < NT; ++t) cur[t] = n1[t];
         wc = w1;
-        w1 = w2;
     }
-    // waves 1..3 are added into wave 0 in order
+    // K groups 1..3 are added into group 0 in order (both halves at once, disjoint parts of `red`)
+    double *mine = red + HALF * ((kTiles + 1) / 2) * 256;
     for (int w = 1; w < 4; ++w) {
         __syncthreads();
-        if (wave == w) {
+        if (kgroup == w) {
 #pragma unroll
-            for (int q = 0; q < kTiles; ++q)
+            for (int q = 0; q < kMine; ++q)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) red[(q * 4 + reg) * 64 + lane] = acc[q][reg];
+                for (int reg = 0; reg < 4; ++reg) mine[(q * 4 + reg) * 64 + lane] = acc[q][reg];
         }
         __syncthreads();
-        if (wave == 0) {
+        if (kgroup == 0) {
 #pragma unroll
-            for (int q = 0; q < kTiles; ++q)
+            for (int q = 0; q < kMine; ++q)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) acc[q][reg] += red[(q * 4 + reg) * 64 + lane];
+                for (int reg = 0; reg < 4; ++reg) acc[q][reg] += mine[(q * 4 + reg) * 64 + lane];
         }
     }
-    if (wave != 0) return;
-    double *out = partial + (int64_t)blockIdx.x * rp * rp;
+    if (kgroup != 0) return;
     // D[i][j] of tile (t, u): i = kq + 4 reg is the A-side index (column 16 t + i of Q0), j = cl the B-side index
     int q = 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int u = t; u < NT; ++u, ++q)
+            if ((q & 1) == HALF)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) out[(int64_t)(16 * t + kq + 4 * reg) * rp + 16 * u + cl] = acc[q][reg];
+                for (int reg = 0; reg < 4; ++reg) out[(int64_t)(16 * t + kq + 4 * reg) * rp + 16 * u + cl] = acc[q >> 1][reg];
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void gram_tri_kernel(const double *__restrict__ Q0, int64_t rows, int rp,
+                                                       const double *__restrict__ weight, int64_t rows_per_slab,
+                                                       double *__restrict__ partial) {
+    constexpr int kTiles = NT * (NT + 1) / 2;
+    __shared__ double red[(kTiles + 1) * 256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kq = lane >> 4, cl = lane & 15;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
+    const int64_t r1 = min(rows, r0 + rows_per_slab);
+    double *out = partial + (int64_t)blockIdx.x * rp * rp;
+    if ((wave >> 2) == 0)
+        gram_tri_half<NT, 0>(Q0, rp, weight, r0, r1, wave & 3, kq, cl, lane, red, out);
+    else
+        gram_tri_half<NT, 1>(Q0, rp, weight, r0, r1, wave & 3, kq, cl, lane, red, out);
 }
 
 // G[i][j] = sum over slabs (fixed order): 32 consecutive elements x 8 slab groups per workgroup, so every load instruction
@@ -1535,7 +1547,7 @@ void launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const 
             // SIMD, deep prefetch), so 256 slabs = one workgroup per CU
             gram_tri_plan(M, &nslabs, &rps);
             auto go = [&](auto kern) {
-                hipLaunchKernelGGL(kern, dim3(nslabs), dim3(256), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, ws);
+                hipLaunchKernelGGL(kern, dim3(nslabs), dim3(512), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, ws);
             };
             switch (nt) {
                 case 1: go(gram_tri_kernel<1>); break;
