@@ -71,6 +71,8 @@ SIGNATURES = {
     "gingr_model_finalize": (c_int, [c_void_p, c_void_p]),
     "gingr_fitter_set_meshes": (c_int, [c_void_p, c_int64, POINTER(c_int32), c_int64, POINTER(c_int32)]),
     "gingr_fitter_set_surface_method": (c_int, [c_void_p, c_int32]),
+    "gingr_fitter_set_correspondence_direction": (c_int, [c_void_p, c_int32]),
+    "gingr_fitter_get_reversed_correspondence": (c_int, [c_void_p, POINTER(c_int32), _dp]),
     "gingr_fitter_update_icp_surface_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32]),
     "gingr_fitter_icp_surface_phase_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32]),
     "gingr_fitter_get_surface_correspondence": (c_int, [c_void_p, _dp, _dp]),

@@ -738,6 +738,36 @@ class IcpRegistration(GingrAlgorithm):
         _check(self.ctx.handle, self._lib.gingr_fitter_set_surface_method(
             self._fitter, 1 if config.correspondenceMethod == "AlongNormalClosestPoint" else 0), "gingr_fitter_set_surface_method")
 
+    def _select_direction(self, config: IcpConfiguration):
+        _check(self.ctx.handle, self._lib.gingr_fitter_set_correspondence_direction(
+            self._fitter, 1 if config.reverseCorrespondenceDirection else 0), "gingr_fitter_set_correspondence_direction")
+
+    def _phase0(self, state: "IcpRegistrationState"):
+        g, c = state.general, state.config
+        self._bind(g, c.useLandmarkCorrespondence)
+        self._push_state(g)
+        self._device_state_token = None
+        self._select_direction(c)
+        p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
+        if self._surface(c):
+            self._select_surface_method(c)
+            _check(self.ctx.handle, self._lib.gingr_fitter_icp_surface_phase_async(self._fitter, ctypes.byref(p), 0),
+                   "gingr_fitter_icp_surface_phase_async")
+        else:
+            _check(self.ctx.handle, self._lib.gingr_fitter_icp_phase_async(self._fitter, ctypes.byref(p), 0), "gingr_fitter_icp_phase_async")
+
+    def reversedCorrespondence(self, state: "IcpRegistrationState") -> Tuple[np.ndarray, np.ndarray]:
+        """closestPointCorrespondenceReversal (ClosestPointRegistrator.scala:34-49) for the state's fit: per TARGET vertex the
+        template vertex it is assigned to and its weight in {0, 1}."""
+        if not state.config.reverseCorrespondenceDirection:
+            raise ValueError("the configuration does not reverse the correspondence direction")
+        self._phase0(state)
+        N = np.asarray(state.general.target).shape[0]
+        tid, w = np.empty(N, dtype=np.int32), np.empty(N)
+        _check(self.ctx.handle, self._lib.gingr_fitter_get_reversed_correspondence(self._fitter, iptr(tid), dptr(w)),
+               "gingr_fitter_get_reversed_correspondence")
+        return tid, w
+
     def createInitialState(self, model: PointDistributionModel, target, config: IcpConfiguration,
                            transform: int = GlobalTranformationType.RigidTransforms, stepLength: float = 1.0,
                            landmarks: Optional[LandmarkCorrespondences] = None, initial_pose=None,
@@ -746,9 +776,8 @@ class IcpRegistration(GingrAlgorithm):
         return self.initializeState(g, config)
 
     def initializeState(self, general: GeneralRegistrationState, config: IcpConfiguration) -> IcpRegistrationState:
-        if config.reverseCorrespondenceDirection or config.correspondenceMethod not in self._METHODS:
-            raise NotImplementedError("accelerated ICP flavours: PointcloudClosestPoint, TriangularClosestPoint and "
-                                      "AlongNormalClosestPoint (ICP.scala:32-44), forward direction")
+        if config.correspondenceMethod not in self._METHODS:
+            raise NotImplementedError("ICP flavours: PointcloudClosestPoint, TriangularClosestPoint, AlongNormalClosestPoint (ICP.scala:32-44)")
         if self._surface(config) and (getattr(general.model, "cells", None) is None or general.targetCells is None):
             raise ValueError(config.correspondenceMethod + " needs the triangulations: model.cells and targetCells")
         return IcpRegistrationState(general.updateSigma2(float(config.initialSigma)), config)   # ICP.scala:73-85
@@ -756,6 +785,7 @@ class IcpRegistration(GingrAlgorithm):
     def _native_update(self, current: IcpRegistrationState, n: int):
         c = current.config
         p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
+        self._select_direction(c)
         if self._surface(c):
             self._select_surface_method(c)
             _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_surface_async(self._fitter, ctypes.byref(p), n),
@@ -768,13 +798,9 @@ class IcpRegistration(GingrAlgorithm):
         """ClosestPointTriangleMesh3D.closestPointCorrespondence(fit, target) (ClosestPointRegistrator.scala:75-100) for the
         state's fit: (closest surface points (M,3), weights in {0,1})."""
         g, c = state.general, state.config
-        self._bind(g, c.useLandmarkCorrespondence)
-        self._push_state(g)
-        self._device_state_token = None
-        self._select_surface_method(c)
-        p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
-        _check(self.ctx.handle, self._lib.gingr_fitter_icp_surface_phase_async(self._fitter, ctypes.byref(p), 0),
-               "gingr_fitter_icp_surface_phase_async")
+        if c.reverseCorrespondenceDirection:
+            raise ValueError("reversed direction: use reversedCorrespondence (entries are per target vertex)")
+        self._phase0(state)
         M = g.model.numberOfPoints
         cp, w = np.empty((M, 3)), np.empty(M)
         _check(self.ctx.handle, self._lib.gingr_fitter_get_surface_correspondence(self._fitter, dptr(cp), dptr(w)),
@@ -784,6 +810,7 @@ class IcpRegistration(GingrAlgorithm):
     def _native_update_sample(self, current: IcpRegistrationState, z: np.ndarray):
         c = current.config
         p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
+        self._select_direction(c)
         if self._surface(c):
             self._select_surface_method(c)
             _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_surface_sample_async(self._fitter, ctypes.byref(p), dptr(z)),
@@ -796,6 +823,7 @@ class IcpRegistration(GingrAlgorithm):
         c = state.config
         p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
         out = ctypes.c_double()
+        self._select_direction(c)
         if self._surface(c):
             self._select_surface_method(c)
         fn = self._lib.gingr_fitter_posterior_logpdf_icp_surface if self._surface(c) else self._lib.gingr_fitter_posterior_logpdf_icp
@@ -803,6 +831,10 @@ class IcpRegistration(GingrAlgorithm):
         return out.value
 
     def getCorrespondence(self, state: IcpRegistrationState) -> CorrespondencePairs:
+        if state.config.reverseCorrespondenceDirection:                               # ICP.scala:46-50
+            tid, w = self.reversedCorrespondence(state)
+            keep = np.flatnonzero(w == 1.0)
+            return CorrespondencePairs(tid[keep].astype(np.int64), f64(state.general.target)[keep])
         if self._surface(state.config):                                               # ICP.scala:40-41,50
             cp, w = self.surfaceCorrespondence(state)
             keep = np.flatnonzero(w == 1.0)

@@ -161,6 +161,14 @@ void launch_line_nearest(gingr_ctx *ctx, Cloud fit, const double *dirs_soa, Clou
 void launch_surface_weight(gingr_ctx *ctx, int64_t M, const int32_t *pre, const int32_t *hit, const double *sigma2_dev, double *w01,
                            double *weight_in);
 
+// reversed correspondence direction: from (nearest template vertex, rejection flags) per TARGET vertex to one observation per
+// template vertex (mean of the accepted targets that map to it, weight = count / sigma2); w01_targets (nullable) gets 0 / 1 per target
+size_t reversal_sort_temp_bytes(int64_t N);
+void launch_reversal_observations(gingr_ctx *ctx, int64_t M, Cloud tgt, const int32_t *nn_vertex, const int32_t *pre,
+                                  const int32_t *hit, const double *sigma2_dev, int32_t *keys, int32_t *vals, int32_t *skeys,
+                                  int32_t *svals, void *sort_temp, size_t sort_temp_bytes, double *w01_targets, double *obs_soa,
+                                  double *weight_in);
+
 // interleaved xyz (n*3) <-> SoA planes; perm (nullable) maps device position -> original index:
 // soa[s] = aos[perm[s]] resp. aos[perm[s]] = soa[s]
 void launch_aos_to_soa(gingr_ctx *ctx, const double *aos, int64_t n, double *soa, const int32_t *perm = nullptr);

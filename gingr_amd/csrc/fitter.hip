@@ -54,6 +54,13 @@ struct gingr_fitter {
     // ---- ICP surface correspondence (surface.hip): triangles in device vertex positions and a spatial triangle order
     bool icp_surface = false;                      // correspondence flavour of the ICP phases
     int32_t surface_method = 0;                    // 0 TriangularClosestPoint, 1 AlongNormalClosestPoint (ICP.scala:32-34)
+    // reversed correspondence direction (ICP.scala:46-48): per TARGET vertex buffers, then one observation per model vertex
+    bool reversed = false;
+    int32_t *mtri_orig = nullptr, *mboundary = nullptr;
+    double *rcp = nullptr, *rd2 = nullptr, *rnnd2 = nullptr, *rw01 = nullptr, *robs = nullptr, *rwin = nullptr;
+    int32_t *rnn = nullptr, *rpre = nullptr, *rhit = nullptr, *rkeys = nullptr, *rvals = nullptr, *rskeys = nullptr, *rsvals = nullptr;
+    void *rsort = nullptr;
+    size_t rsort_bytes = 0;
     int64_t Tm = 0, Tt = 0;                        // model / target triangle counts
     int32_t *mtri = nullptr, *ttri = nullptr, *ttri_orig = nullptr;
     int32_t *madj_ptr = nullptr, *madj_tri = nullptr, *tadj_ptr = nullptr, *tadj_tri = nullptr;  // vertex -> triangles
@@ -115,6 +122,14 @@ void refresh_fit(gingr_fitter *f) {
 }
 
 void free_meshes(gingr_fitter *f) {
+    void *rptrs[] = {f->mtri_orig, f->mboundary, f->rcp, f->rd2, f->rnnd2, f->rw01, f->robs, f->rwin, f->rnn, f->rpre, f->rhit,
+                     f->rkeys, f->rvals, f->rskeys, f->rsvals, f->rsort};
+    for (void *p : rptrs) dev_free(p);
+    f->mtri_orig = f->mboundary = f->rnn = f->rpre = f->rhit = f->rkeys = f->rvals = f->rskeys = f->rsvals = nullptr;
+    f->rcp = f->rd2 = f->rnnd2 = f->rw01 = f->robs = f->rwin = nullptr;
+    f->rsort = nullptr;
+    f->rsort_bytes = 0;
+    f->reversed = false;
     void *ptrs[] = {f->mtri, f->ttri, f->ttri_orig, f->madj_ptr, f->madj_tri, f->tadj_ptr, f->tadj_tri, f->mcn, f->tcn, f->mvn,
                     f->tvn, f->mtboxes, f->ttboxes, f->tboundary, f->surf_cp, f->surf_d2, f->surf_w01, f->surf_win, f->surf_nnd2,
                     f->surf_nn, f->surf_pre, f->surf_hit};
@@ -447,6 +462,7 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
     };
     mx(cpd_rowstats_ws_doubles(M, N));
     mx(ceil_div(nn_ws_bytes(M, N), 8));
+    mx(ceil_div(nn_ws_bytes(N, M), 8));  // reversed correspondence direction: the targets query the model vertices
     mx(gram_ws_doubles(M, rp));
     mx(sweep_ws_doubles(M, rp));
     f->ws_doubles = w;
@@ -658,7 +674,31 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
     const Cloud tgt = cloud_of(f->target, f->N);
     switch (phase) {
         case 0: {
-            if (icp && f->icp_surface) {
+            if (icp && f->reversed) {
+                // closestPointCorrespondenceReversal (ClosestPointRegistrator.scala:34-49): the roles of the two meshes are swapped,
+                // then every accepted target vertex becomes an observation of the template vertex nearest to its match
+                const int64_t N = f->N;
+                launch_tile_bbox(ctx, fit, f->fboxes);
+                if (f->icp_surface) {
+                    const bool along = f->surface_method == 1;
+                    launch_cell_normals(ctx, fit, f->mtri, f->Tm, f->mcn);
+                    launch_vertex_normals(ctx, f->madj_ptr, f->madj_tri, f->mcn, f->Tm, M, f->mvn);
+                    launch_tri_tile_bbox(ctx, fit, f->mtri, f->Tm, f->mtboxes);
+                    if (along)
+                        launch_line_nearest(ctx, tgt, f->tvn, fit, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, f->rcp, f->rhit);
+                    else
+                        launch_surface_closest_point(ctx, tgt, fit, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, f->rcp, f->rd2);
+                    launch_nn(ctx, cloud_of(f->rcp, N), fit, f->m->perm, f->fboxes, f->ws, f->rnn, f->rnnd2);
+                    launch_surface_prereject(ctx, N, f->rnn, f->mboundary, f->tvn, f->mvn, M, along ? f->rhit : nullptr, f->rpre);
+                    launch_self_intersect(ctx, tgt, f->rcp, f->ttri, f->Tt, f->ttboxes, f->rpre, f->rhit);
+                    launch_reversal_observations(ctx, M, tgt, f->rnn, f->rpre, f->rhit, &f->st->sigma2, f->rkeys, f->rvals, f->rskeys,
+                                                 f->rsvals, f->rsort, f->rsort_bytes, f->rw01, f->robs, f->rwin);
+                } else {  // ClosestPointTriangleMesh3DSimple: nearest template vertex, weight 1
+                    launch_nn(ctx, tgt, fit, f->m->perm, f->fboxes, f->ws, f->rnn, f->rnnd2);
+                    launch_reversal_observations(ctx, M, tgt, f->rnn, nullptr, nullptr, &f->st->sigma2, f->rkeys, f->rvals, f->rskeys,
+                                                 f->rsvals, f->rsort, f->rsort_bytes, f->rw01, f->robs, f->rwin);
+                }
+            } else if (icp && f->icp_surface) {
                 // ClosestPointTriangleMesh3D.closestPointCorrespondence (ClosestPointRegistrator.scala:75-100)
                 launch_cell_normals(ctx, fit, f->mtri, f->Tm, f->mcn);
                 launch_vertex_normals(ctx, f->madj_ptr, f->madj_tri, f->mcn, f->Tm, M, f->mvn);
@@ -684,7 +724,9 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
         }
         case 1: {
             if (icp) {
-                if (f->icp_surface)  // only the weight-1 pairs are observed (ICP.scala:50): weight 0 drops the row
+                if (f->reversed)  // one observation per template vertex: mean of its accepted targets, weight count / sigma2
+                    launch_obs_points(ctx, m, f->st, f->robs, f->rwin, f->weight, f->evec, f->lm_mask);
+                else if (f->icp_surface)  // only the weight-1 pairs are observed (ICP.scala:50): weight 0 drops the row
                     launch_obs_points(ctx, m, f->st, f->surf_cp, f->surf_win, f->weight, f->evec, f->lm_mask);
                 else
                     launch_obs_icp(ctx, m, f->st, tgt, f->nn_idx, f->lm_mask, f->weight, f->evec);
@@ -867,6 +909,27 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
             i = j;
         }
     }
+    // model boundary vertices (reversed direction: the rejection rules run on the template side)
+    std::vector<int32_t> mbnd((size_t)M, 0);
+    {
+        std::vector<uint64_t> edges;
+        edges.reserve((size_t)3 * n_model_tri);
+        for (int64_t t = 0; t < n_model_tri; ++t)
+            for (int k = 0; k < 3; ++k) {
+                const uint64_t a = (uint64_t)model_tri[3 * t + k], b = (uint64_t)model_tri[3 * t + (k + 1) % 3];
+                edges.push_back((a < b ? a : b) << 32 | (a < b ? b : a));
+            }
+        std::sort(edges.begin(), edges.end());
+        for (size_t i = 0; i < edges.size();) {
+            size_t j = i;
+            while (j < edges.size() && edges[j] == edges[i]) ++j;
+            if (j - i == 1) {
+                mbnd[(size_t)f->m->hiperm[(size_t)(edges[i] >> 32)]] = 1;
+                mbnd[(size_t)f->m->hiperm[(size_t)(edges[i] & 0xffffffffu)]] = 1;
+            }
+            i = j;
+        }
+    }
     f->Tm = n_model_tri;
     f->Tt = n_target_tri;
     const int64_t ntm = ceil_div(f->Tm, 256), ntt = ceil_div(f->Tt, 256);
@@ -881,7 +944,8 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
         (rc = dev_alloc(ctx, &f->surf_cp, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->surf_d2, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->surf_w01, (size_t)M)) || (rc = dev_alloc(ctx, &f->surf_win, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->surf_nnd2, (size_t)M)) || (rc = dev_alloc(ctx, &f->surf_nn, (size_t)M)) ||
-        (rc = dev_alloc(ctx, &f->surf_pre, (size_t)M)) || (rc = dev_alloc(ctx, &f->surf_hit, (size_t)M)))
+        (rc = dev_alloc(ctx, &f->surf_pre, (size_t)M)) || (rc = dev_alloc(ctx, &f->surf_hit, (size_t)M)) ||
+        (rc = dev_alloc(ctx, &f->mtri_orig, (size_t)f->Tm)) || (rc = dev_alloc(ctx, &f->mboundary, (size_t)M)))
         return rc;
     auto up = [&](int32_t *dst, const std::vector<int32_t> &src) {
         return hipMemcpy(dst, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice);
@@ -894,6 +958,8 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
     HIP_TRY(ctx, up(f->tadj_ptr, bt.adj_ptr));
     HIP_TRY(ctx, up(f->tadj_tri, bt.adj_tri));
     HIP_TRY(ctx, up(f->tboundary, bnd));
+    HIP_TRY(ctx, up(f->mtri_orig, bm.orig));
+    HIP_TRY(ctx, up(f->mboundary, mbnd));
     // static target side: cell normals, vertex normals, triangle tile boxes
     const Cloud tgt = cloud_of(f->target, N);
     launch_cell_normals(ctx, tgt, f->ttri, f->Tt, f->tcn);
@@ -908,6 +974,54 @@ int gingr_fitter_set_surface_method(gingr_fitter *f, int32_t method) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
     if (method != 0 && method != 1) return gingr_set_error(f->ctx, GINGR_ERR_BAD_ARGUMENT, "set_surface_method: 0 or 1");
     f->surface_method = method;
+    return GINGR_OK;
+}
+
+int gingr_fitter_set_correspondence_direction(gingr_fitter *f, int32_t reversed) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = f->ctx;
+    if (!reversed) {
+        f->reversed = false;
+        return GINGR_OK;
+    }
+    if (!f->target) return gingr_set_error(ctx, GINGR_ERR_STATE, "set_correspondence_direction: no target set");
+    if (f->m->M != f->m->M_total) return gingr_set_error(ctx, GINGR_ERR_STATE, "set_correspondence_direction: single shard only");
+    if (!f->rnn) {  // buffers per target vertex + the sort workspace, once per target
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        const int64_t M = f->m->M, N = f->N;
+        int rc;
+        if ((rc = dev_alloc(ctx, &f->rcp, (size_t)3 * N)) || (rc = dev_alloc(ctx, &f->rd2, (size_t)N)) ||
+            (rc = dev_alloc(ctx, &f->rnnd2, (size_t)N)) || (rc = dev_alloc(ctx, &f->rw01, (size_t)N)) ||
+            (rc = dev_alloc(ctx, &f->robs, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->rwin, (size_t)M)) ||
+            (rc = dev_alloc(ctx, &f->rnn, (size_t)N)) || (rc = dev_alloc(ctx, &f->rpre, (size_t)N)) ||
+            (rc = dev_alloc(ctx, &f->rhit, (size_t)N)) || (rc = dev_alloc(ctx, &f->rkeys, (size_t)N)) ||
+            (rc = dev_alloc(ctx, &f->rvals, (size_t)N)) || (rc = dev_alloc(ctx, &f->rskeys, (size_t)N)) ||
+            (rc = dev_alloc(ctx, &f->rsvals, (size_t)N)))
+            return rc;
+        f->rsort_bytes = reversal_sort_temp_bytes(N);
+        HIP_TRY(ctx, hipMalloc(&f->rsort, f->rsort_bytes ? f->rsort_bytes : 8));
+    }
+    f->reversed = true;
+    return GINGR_OK;
+}
+
+int gingr_fitter_get_reversed_correspondence(gingr_fitter *f, int32_t *template_id, double *w) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = f->ctx;
+    if (!f->rnn) return gingr_set_error(ctx, GINGR_ERR_STATE, "get_reversed_correspondence: direction not reversed");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t N = f->N;
+    std::vector<int32_t> hid((size_t)N);
+    std::vector<double> hw((size_t)N);
+    HIP_TRY(ctx, hipMemcpyAsync(hid.data(), f->rnn, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(hw.data(), f->rw01, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t s2 = 0; s2 < N; ++s2) {  // device target position -> original target id; device model row -> original vertex id
+        const int32_t j = f->h_tperm[(size_t)s2];
+        const int32_t row = hid[(size_t)s2];
+        if (template_id) template_id[j] = (row >= 0 && row < f->m->M) ? f->m->hperm[(size_t)row] : -1;
+        if (w) w[j] = hw[(size_t)s2];
+    }
     return GINGR_OK;
 }
 

@@ -17,6 +17,8 @@
 // exact pruning as the nearest-neighbour kernel (affinity.hip).
 #include "common.h"
 
+#include <hipcub/hipcub.hpp>
+
 namespace {
 
 constexpr int kTriTile = 256;
@@ -397,7 +399,73 @@ __global__ __launch_bounds__(256) void surface_weight_kernel(int64_t M, const in
     weight_in[i] = w / sigma2[0];
 }
 
+// ---- reversed correspondence direction (ClosestPointRegistrator.scala:34-49): N entries (template vertex, target vertex, w)
+// keys[j] = template vertex of target j when accepted, else `sentinel` (sorts last); vals[j] = j
+__global__ __launch_bounds__(256) void reversal_keys_kernel(int64_t N, const int32_t *__restrict__ nn_vertex,
+                                                            const int32_t *__restrict__ pre, const int32_t *__restrict__ hit,
+                                                            int32_t sentinel, int32_t *__restrict__ keys, int32_t *__restrict__ vals,
+                                                            double *__restrict__ w01) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const bool rejected = (pre && pre[j]) || (hit && hit[j]) || nn_vertex[j] < 0;
+    keys[j] = rejected ? sentinel : nn_vertex[j];
+    vals[j] = (int32_t)j;
+    if (w01) w01[j] = rejected ? 0.0 : 1.0;
+}
+
+// Per template vertex i: the accepted target vertices that map to it are a run of the (stably) sorted keys; their mean is the
+// observed point and their number times 1 / sigma2 the observation weight (k isotropic observations of one point = one
+// observation of their mean with k-fold precision).  The run is summed in ascending target position: deterministic.
+__global__ __launch_bounds__(256) void reversal_gather_kernel(int64_t M, int64_t N, const int32_t *__restrict__ skeys,
+                                                              const int32_t *__restrict__ svals, Cloud tgt,
+                                                              const double *__restrict__ sigma2, double *__restrict__ obs,
+                                                              double *__restrict__ weight_in) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    int64_t lo = 0, hi = N;  // first position with key >= i
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (skeys[mid] < (int32_t)i)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    int64_t k = 0;
+    for (int64_t p = lo; p < N && skeys[p] == (int32_t)i; ++p, ++k) {
+        const int32_t j = svals[p];
+        sx += tgt.x[j];
+        sy += tgt.y[j];
+        sz += tgt.z[j];
+    }
+    const double kk = k > 0 ? (double)k : 1.0;
+    obs[i] = sx / kk;
+    obs[M + i] = sy / kk;
+    obs[2 * M + i] = sz / kk;
+    weight_in[i] = (double)k / sigma2[0];
+}
+
 }  // namespace
+
+size_t reversal_sort_temp_bytes(int64_t N) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const int32_t *)nullptr, (int32_t *)nullptr, (const int32_t *)nullptr,
+                                             (int32_t *)nullptr, (int)N);
+    return bytes;
+}
+
+void launch_reversal_observations(gingr_ctx *ctx, int64_t M, Cloud tgt, const int32_t *nn_vertex, const int32_t *pre,
+                                  const int32_t *hit, const double *sigma2_dev, int32_t *keys, int32_t *vals, int32_t *skeys,
+                                  int32_t *svals, void *sort_temp, size_t sort_temp_bytes, double *w01_targets, double *obs_soa,
+                                  double *weight_in) {
+    const int64_t N = tgt.n;
+    hipLaunchKernelGGL(reversal_keys_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, N, nn_vertex, pre, hit,
+                       (int32_t)M, keys, vals, w01_targets);
+    // LSD radix sort: stable, so equal keys keep ascending target positions
+    (void)hipcub::DeviceRadixSort::SortPairs(sort_temp, sort_temp_bytes, keys, skeys, vals, svals, (int)N, 0, 32, ctx->stream);
+    hipLaunchKernelGGL(reversal_gather_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, ctx->stream, M, N, skeys, svals, tgt,
+                       sigma2_dev, obs_soa, weight_in);
+}
 
 void launch_cell_normals(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *cn) {
     if (T <= 0) return;

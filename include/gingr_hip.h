@@ -223,6 +223,12 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_triangles, const in
 /* 0 = TriangularClosestPoint (default), 1 = AlongNormalClosestPoint (ClosestPointRegistrator.scala:102-131: the target point
  * hit first by the line through the template vertex along its vertex normal; no hit = rejected) */
 int gingr_fitter_set_surface_method(gingr_fitter *f, int32_t method);
+/* reverseCorrespondenceDirection (ICP.scala:46-48, ClosestPointRegistrator.scala:34-49): the correspondence is computed from the
+ * target to the template and inverted; holds for all three ICP flavours until reset (call after gingr_fitter_set_target and, for
+ * the surface flavours, gingr_fitter_set_meshes).  gingr_fitter_get_reversed_correspondence: per TARGET vertex the template vertex
+ * it was assigned to and its weight in {0, 1} (last phase 0). */
+int gingr_fitter_set_correspondence_direction(gingr_fitter *f, int32_t reversed);
+int gingr_fitter_get_reversed_correspondence(gingr_fitter *f, int32_t *model_vertex_id, double *w);
 int gingr_fitter_update_icp_surface_async(gingr_fitter *f, const gingr_icp_params *params, int32_t n_iterations);
 int gingr_fitter_icp_surface_phase_async(gingr_fitter *f, const gingr_icp_params *params, int32_t phase);
 /* probabilistic proposal / log transition density with the surface correspondence (see the _sample / _logpdf entry points below) */

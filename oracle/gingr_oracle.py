@@ -916,3 +916,29 @@ def along_normal_correspondence(tmpl: np.ndarray, tmpl_tris: np.ndarray, tgt: np
             cp[i], w[i] = c, wi
         dist += math.sqrt(float(((p - cp[i]) ** 2).sum()))
     return cp, w, dist / tmpl.shape[0]
+
+
+def correspondence_reversal(tmpl: np.ndarray, tmpl_tris, tgt: np.ndarray, tgt_tris, method: str = "TriangularClosestPoint"):
+    """ClosestPointRegistrator.closestPointCorrespondenceReversal (ClosestPointRegistrator.scala:34-49): the correspondence is
+    computed FROM the target TO the template and inverted: (template vertex closest to the found point, the target vertex, w),
+    one entry per target vertex (a template vertex may appear several times)."""
+    if method == "PointcloudClosestPoint":
+        idx, _, _ = icp_closest_point(tgt, tmpl)                 # ClosestPointTriangleMesh3DSimple, roles swapped: weight 1
+        return idx.astype(np.int64), tgt.astype(np.float64), np.ones(tgt.shape[0])
+    if method == "TriangularClosestPoint":
+        cp, w, _ = surface_correspondence(tgt, tgt_tris, tmpl, tmpl_tris)
+    else:
+        cp, w, _ = along_normal_correspondence(tgt, tgt_tris, tmpl, tmpl_tris)
+    tid, _, _ = icp_closest_point(cp, tmpl)                      # template.pointSet.findClosestPoint(p).id
+    return tid.astype(np.int64), tgt.astype(np.float64), w
+
+
+def icp_reversed_update(model: PDM, tmpl_tris, target: np.ndarray, tgt_tris, st: State, initial_sigma: float, end_sigma: float,
+                        max_iterations: int, method: str = "TriangularClosestPoint", landmarks: Optional["Landmarks"] = None):
+    """One ICP update with reverseCorrespondenceDirection = true (ICP.scala:46-48): every accepted target vertex is an
+    observation of the template vertex it maps to (several observations per vertex are possible)."""
+    tid, pts, w = correspondence_reversal(st.fit, tmpl_tris, target, tgt_tris, method)
+    keep = np.flatnonzero(w == 1.0)
+    var = np.full(keep.shape[0], st.sigma2)
+    s2n = icp_update_sigma2(st.sigma2, initial_sigma, end_sigma, max_iterations)
+    return update_from_observations(model, st, tid[keep], pts[keep], var, s2n, landmarks, None), (tid, w)

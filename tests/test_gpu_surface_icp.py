@@ -199,3 +199,29 @@ def test_along_normal_flavour(ctx):
                                           go.icp_update_sigma2(st_in.sigma2, 20.0, 1.0, 30), None, None)
         assert s1.general.status == st1.status == 0 and rel(s1.general.fit, st1.fit) < 1e-5, case
         algo.close()
+
+
+@pytest.mark.parametrize("method", ["TriangularClosestPoint", "AlongNormalClosestPoint", "PointcloudClosestPoint"])
+def test_reversed_correspondence_direction(ctx, method):
+    """reverseCorrespondenceDirection = true (ICP.scala:46-48): per-target assignments and one update against the oracle."""
+    import gingr_amd as ga
+    ref, cells, target, tcells = femur()
+    target, tcells = target[:], tcells
+    mo = model_over(ref, cells, 16)
+    model = ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam, cells=cells)
+    algo = ga.IcpRegistration(ctx)
+    cfg = ga.IcpConfiguration(maxIterations=30, initialSigma=20.0, endSigma=1.0, correspondenceMethod=method,
+                              reverseCorrespondenceDirection=True)
+    state = algo.createInitialState(model, target, cfg, targetCells=tcells, initial_pose=((0.01, 0.02, -0.01), (0.5, 0.3, -0.4)))
+    tid, w = algo.reversedCorrespondence(state)
+    otid, opts, ow = go.correspondence_reversal(np.asarray(state.general.fit), cells, target, tcells, method)
+    assert np.array_equal(w, ow), (method, int((w != ow).sum()))
+    assert np.array_equal(tid[ow == 1.0], otid[ow == 1.0]), method
+    assert ow.sum() > 0 and np.bincount(otid[ow == 1.0]).max() > 1      # some template vertices receive several observations
+    st_in = oracle_state_of(state.general, 1)
+    s1 = algo.update(state)
+    st1, _ = go.icp_reversed_update(mo, cells, target, tcells, st_in, 20.0, 1.0, 30, method)
+    assert s1.general.status == st1.status == 0 and rel(s1.general.fit, st1.fit) < 1e-5, (method, rel(s1.general.fit, st1.fit))
+    pairs = algo.getCorrespondence(state)
+    assert np.array_equal(pairs.pids, otid[ow == 1.0]) and np.array_equal(pairs.points, target[ow == 1.0])
+    algo.close()
