@@ -165,6 +165,13 @@ JFN(jint, fitterSetMeshes)(JNIEnv *env, jclass, jlong f, jintArray modelTri, jin
 JFN(jint, fitterSetSurfaceMethod)(JNIEnv *, jclass, jlong f, jint method) {
     return gingr_fitter_set_surface_method(P<gingr_fitter>(f), method);
 }
+JFN(jint, fitterSetCorrespondenceDirection)(JNIEnv *, jclass, jlong f, jint reversed) {
+    return gingr_fitter_set_correspondence_direction(P<gingr_fitter>(f), reversed);
+}
+JFN(jint, fitterGetReversedCorrespondence)(JNIEnv *env, jclass, jlong f, jintArray ids, jdoubleArray w) {
+    Pin a(env, ids, false), b(env, w, false);
+    return gingr_fitter_get_reversed_correspondence(P<gingr_fitter>(f), a.as<int32_t>(), b.as<double>());
+}
 JFN(jint, fitterUpdateIcpSurface)(JNIEnv *, jclass, jlong f, jdouble initialSigma, jdouble endSigma, jint maxIterations, jint n) {
     gingr_icp_params p{initialSigma, endSigma, maxIterations};
     return gingr_fitter_update_icp_surface_async(P<gingr_fitter>(f), &p, n);

@@ -55,6 +55,9 @@ public final class GingrHipNative {
     public static native int fitterSetMeshes(long fitter, int[] modelTriangles, int[] targetTriangles);
     /** 0 = TriangularClosestPoint, 1 = AlongNormalClosestPoint */
     public static native int fitterSetSurfaceMethod(long fitter, int method);
+    /** reverseCorrespondenceDirection (all ICP flavours); call after fitterSetTarget / fitterSetMeshes */
+    public static native int fitterSetCorrespondenceDirection(long fitter, int reversed);
+    public static native int fitterGetReversedCorrespondence(long fitter, int[] modelVertexId, double[] w);
     public static native int fitterUpdateIcpSurface(long fitter, double initialSigma, double endSigma, int maxIterations, int nIterations);
     public static native int fitterUpdateIcpSurfaceSample(long fitter, double initialSigma, double endSigma, int maxIterations, double[] z);
     public static native int fitterPosteriorLogpdfIcpSurface(long fitter, double initialSigma, double endSigma, int maxIterations,

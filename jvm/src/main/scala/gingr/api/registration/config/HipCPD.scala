@@ -115,6 +115,9 @@ final class HipSession(device: Int) extends AutoCloseable {
     }
   }
 
+  def setDirection(reversed: Boolean): Unit =
+    check(GingrHipNative.fitterSetCorrespondenceDirection(fitter, if (reversed) 1 else 0), "gingr_fitter_set_correspondence_direction")
+
   def nn(fit: TriangleMesh[_3D], target: TriangleMesh[_3D]): Array[Int] = {
     val idx = new Array[Int](fit.pointSet.numberOfPoints)
     check(GingrHipNative.nn(ctx, HipLayout.mesh(fit), HipLayout.mesh(target), idx, null, null), "gingr_nn")
@@ -202,8 +205,7 @@ case class HipIcpRegistrationState(general: GeneralRegistrationState, config: Ic
   override def updateGeneral(update: GeneralRegistrationState): HipIcpRegistrationState = this.copy(general = update)
 }
 
-/** All three correspondence flavours (ICP.scala:32-44), forward direction; reverseCorrespondenceDirection stays on the
-  * stock path. */
+/** All three correspondence flavours (ICP.scala:32-44), both correspondence directions. */
 class HipIcpRegistration(device: Int = 0) extends GingrAlgorithm[HipIcpRegistrationState, IcpConfiguration] with AutoCloseable {
   private val session = new HipSession(device)
   def name = "ICP-HIP"
@@ -220,13 +222,14 @@ class HipIcpRegistration(device: Int = 0) extends GingrAlgorithm[HipIcpRegistrat
     math.max(current.general.sigma2 - current.config.sigmaStep, current.config.endSigma)
 
   override def initializeState(general: GeneralRegistrationState, config: IcpConfiguration): HipIcpRegistrationState = {
-    require(!config.reverseCorrespondenceDirection, "HipIcpRegistration implements the forward correspondence direction")
     HipIcpRegistrationState(IcpRegistrationState(general, config).general, config)
   }
 
   override def update(current: HipIcpRegistrationState, probabilistic: Boolean)(implicit rnd: Random): HipIcpRegistrationState = {
     session.bind(current.general, current.config.useLandmarkCorrespondence)
     val c = current.config
+    if (c.correspondenceMethod != PointcloudClosestPoint) session.bindMeshes(current.general)
+    session.setDirection(c.reverseCorrespondenceDirection) // after the target / meshes are bound
     val (alpha, pose, status) =
       if (probabilistic) {
         val z = Array.fill(current.general.model.rank)(rnd.scalaRandom.nextGaussian())
