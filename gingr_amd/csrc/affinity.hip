@@ -721,27 +721,44 @@ __global__ __launch_bounds__(kNNThreads) void nn_kernel(Cloud q, Cloud tgt, cons
             wb.hi[d] = uniform_d(hi[d]);
         }
     }
-    // Two sweeps over the chunk's tiles: first the tiles whose box touches the wave's box (they almost always hold the true
-    // neighbours, so `best` becomes small), then all others, each visited only if for at least one lane the tile's box is
-    // not farther from that lane's query than the lane's current best (strict test with a relative rounding margin; a NaN
-    // box or query never prunes).  Ties at equal distance are inside the margin, so the lowest-original-index rule holds.
+    // Two sweeps over the chunk's tiles: first the tiles at the smallest gap to the wave's box (normally gap 0, the touching
+    // tiles: they almost always hold the true neighbours, so `best` becomes small), then all others, each visited only if for
+    // at least one lane the tile's box is not farther from that lane's query than the lane's current best (strict test with a
+    // relative rounding margin; a NaN box or query never prunes).  Ties at equal distance are inside the margin, so the
+    // lowest-original-index rule holds.  The lanes test 64 tile boxes at a time against the wave's box (ballot, then a scalar
+    // walk over the set bits), so the per-query test runs on the few candidate tiles only.
+    double gmin = __builtin_huge_val();
+    if (tgt_boxes) {
+        for (int t = lane; t < nt; t += 64) gmin = fmin(gmin, box_gap2(wb, tgt_boxes + (int64_t)(t0 + t) * 6));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) gmin = fmin(gmin, __shfl_xor(gmin, off));
+        gmin = uniform_d(gmin);
+    }
     for (int phase = 0; phase < 2; ++phase) {
-        for (int t = 0; t < nt; ++t) {
-            if (tgt_boxes) {
+        if (!tgt_boxes && phase == 1) break;  // no boxes: the first sweep visits everything
+        double bmax = ok ? best : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bmax = fmax(bmax, __shfl_xor(bmax, off));
+        bmax = uniform_d(bmax) * (1.0 + 1e-12);
+        for (int tc = 0; tc < nt; tc += 64) {
+          const int tl = tc + lane;
+          bool take = tl < nt;
+          if (tgt_boxes && take) {
+              const double g = box_gap2(wb, tgt_boxes + (int64_t)(t0 + tl) * 6);
+              // a NaN box gives g = NaN: taken in the first sweep
+              take = phase == 0 ? !(g > gmin) : (g > gmin && !(g > bmax));
+          }
+          unsigned long long cand = __ballot(take);
+          while (cand) {
+            const int t = tc + __builtin_ctzll(cand);
+            cand &= cand - 1;
+            if (phase == 1) {
                 const double *bx = tgt_boxes + (int64_t)(t0 + t) * 6;
-                const double g = box_gap2(wb, bx);
-                if (phase == 0) {
-                    if (g > 0.0) continue;
-                } else {
-                    if (!(g > 0.0)) continue;  // visited in the first sweep (also taken for NaN boxes: g is NaN -> not > 0)
-                    const double gx = fmax(fmax(bx[0] - qx, qx - bx[3]), 0.0), gy = fmax(fmax(bx[1] - qy, qy - bx[4]), 0.0),
-                                 gz = fmax(fmax(bx[2] - qz, qz - bx[5]), 0.0);
-                    const double pd = __builtin_fma(gz, gz, __builtin_fma(gy, gy, gx * gx));
-                    const bool need = ok && !(pd > best * (1.0 + 1e-12));
-                    if (!__any(need)) continue;
-                }
-            } else if (phase == 1) {
-                continue;  // no boxes: the first sweep visits everything
+                const double gx = fmax(fmax(bx[0] - qx, qx - bx[3]), 0.0), gy = fmax(fmax(bx[1] - qy, qy - bx[4]), 0.0),
+                             gz = fmax(fmax(bx[2] - qz, qz - bx[5]), 0.0);
+                const double pd = __builtin_fma(gz, gz, __builtin_fma(gy, gy, gx * gx));
+                const bool need = ok && !(pd > best * (1.0 + 1e-12));
+                if (!__any(need)) continue;
             }
             const int64_t jb = j0 + (int64_t)t * kTile;
             __syncthreads();
@@ -764,6 +781,7 @@ __global__ __launch_bounds__(kNNThreads) void nn_kernel(Cloud q, Cloud tgt, cons
                     bi = (int32_t)(jb + jj);
                 }
             }
+          }
         }
     }
     if (ok) {

@@ -939,8 +939,8 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
         (rc = dev_alloc(ctx, &f->madj_tri, (size_t)3 * f->Tm)) || (rc = dev_alloc(ctx, &f->tadj_ptr, (size_t)N + 1)) ||
         (rc = dev_alloc(ctx, &f->tadj_tri, (size_t)3 * f->Tt)) || (rc = dev_alloc(ctx, &f->mcn, (size_t)3 * f->Tm)) ||
         (rc = dev_alloc(ctx, &f->tcn, (size_t)3 * f->Tt)) || (rc = dev_alloc(ctx, &f->mvn, (size_t)3 * M)) ||
-        (rc = dev_alloc(ctx, &f->tvn, (size_t)3 * N)) || (rc = dev_alloc(ctx, &f->mtboxes, (size_t)6 * ntm)) ||
-        (rc = dev_alloc(ctx, &f->ttboxes, (size_t)6 * ntt)) || (rc = dev_alloc(ctx, &f->tboundary, (size_t)N)) ||
+        (rc = dev_alloc(ctx, &f->tvn, (size_t)3 * N)) || (rc = dev_alloc(ctx, &f->mtboxes, (size_t)30 * ntm)) ||
+        (rc = dev_alloc(ctx, &f->ttboxes, (size_t)30 * ntt)) || (rc = dev_alloc(ctx, &f->tboundary, (size_t)N)) ||
         (rc = dev_alloc(ctx, &f->surf_cp, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->surf_d2, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->surf_w01, (size_t)M)) || (rc = dev_alloc(ctx, &f->surf_win, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->surf_nnd2, (size_t)M)) || (rc = dev_alloc(ctx, &f->surf_nn, (size_t)M)) ||

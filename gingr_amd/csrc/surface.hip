@@ -30,7 +30,6 @@ struct V3 {
 __device__ __forceinline__ V3 sub(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ double dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ V3 cross3(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-__device__ __forceinline__ V3 madd(V3 a, V3 d, double s) { return V3{a.x + d.x * s, a.y + d.y * s, a.z + d.z * s}; }
 
 __device__ __forceinline__ double uniform_dd(double v) {
     const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
@@ -38,26 +37,31 @@ __device__ __forceinline__ double uniform_dd(double v) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-// closest point of triangle (A, B, C) to p: Ericson, Real-Time Collision Detection 5.1.5 (region tests in his order)
+// closest point of triangle (A, B, C) to p: Ericson, Real-Time Collision Detection 5.1.5, with his region tests in his order but
+// evaluated as selects: on a wavefront every lane lands in a different Voronoi region, so the branching form executes all seven
+// paths (and their four divisions) one after the other.  Here the region picks a numerator, a denominator, a base corner and two
+// edge vectors; ONE division; the result is  base + e1 * s1 + e2 * s2  -- the same floating-point expressions as the branching
+// form (an edge region adds  e2 * 0  = +0, a vertex region adds two zeros).
 __device__ __forceinline__ V3 closest_on_triangle(V3 p, V3 A, V3 B, V3 C) {
-    const V3 ab = sub(B, A), ac = sub(C, A), ap = sub(p, A);
-    const double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
-    if (d1 <= 0.0 && d2 <= 0.0) return A;
-    const V3 bp = sub(p, B);
-    const double d3 = dot3(ab, bp), d4 = dot3(ac, bp);
-    if (d3 >= 0.0 && d4 <= d3) return B;
-    const double vc = d1 * d4 - d3 * d2;
-    if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) return madd(A, ab, d1 / (d1 - d3));
-    const V3 cp = sub(p, C);
-    const double d5 = dot3(ab, cp), d6 = dot3(ac, cp);
-    if (d6 >= 0.0 && d5 <= d6) return C;
-    const double vb = d5 * d2 - d1 * d6;
-    if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) return madd(A, ac, d2 / (d2 - d6));
-    const double va = d3 * d6 - d5 * d4;
-    if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) return madd(B, sub(C, B), (d4 - d3) / ((d4 - d3) + (d5 - d6)));
-    const double denom = 1.0 / ((va + vb) + vc);
-    const double v = vb * denom, w = vc * denom;
-    return madd(madd(A, ab, v), ac, w);
+    const V3 ab = sub(B, A), ac = sub(C, A), bc = sub(C, B), ap = sub(p, A), bp = sub(p, B), cp = sub(p, C);
+    const double d1 = dot3(ab, ap), d2 = dot3(ac, ap), d3 = dot3(ab, bp), d4 = dot3(ac, bp), d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+    const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    const bool rA = d1 <= 0.0 && d2 <= 0.0;
+    const bool rB = !rA && d3 >= 0.0 && d4 <= d3;
+    const bool rAB = !rA && !rB && vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0;
+    const bool rC = !rA && !rB && !rAB && d6 >= 0.0 && d5 <= d6;
+    const bool rAC = !rA && !rB && !rAB && !rC && vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0;
+    const bool rBC = !rA && !rB && !rAB && !rC && !rAC && va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0;
+    const bool vertex = rA || rB || rC;
+    const double num = vertex ? 0.0 : (rAB ? d1 : (rAC ? d2 : (rBC ? (d4 - d3) : 1.0)));
+    const double den = vertex ? 1.0 : (rAB ? (d1 - d3) : (rAC ? (d2 - d6) : (rBC ? ((d4 - d3) + (d5 - d6)) : ((va + vb) + vc))));
+    const double q = num / den;
+    const bool interior = !vertex && !rAB && !rAC && !rBC;
+    const V3 base = (rB || rBC) ? B : (rC ? C : A);
+    const V3 e1 = rBC ? bc : (rAC ? ac : ab);
+    const double s1 = vertex ? 0.0 : (interior ? vb * q : q);
+    const double s2 = interior ? vc * q : 0.0;
+    return V3{(base.x + e1.x * s1) + ac.x * s2, (base.y + e1.y * s1) + ac.y * s2, (base.z + e1.z * s1) + ac.z * s2};
 }
 
 __device__ __forceinline__ double point_box_gap2(double qx, double qy, double qz, const double *__restrict__ bx) {
@@ -100,7 +104,8 @@ __global__ __launch_bounds__(256) void vertex_normals_kernel(const int32_t *__re
     vn[2 * n + i] = sz / cnt;
 }
 
-// boxes[tile] = {lo[3], hi[3]} over the corners of the triangles [tile*256, tile*256+256)
+// boxes[tile] = {lo[3], hi[3]} over the corners of the triangles [tile*256, tile*256+256), followed (at boxes + 6 * ntiles) by the
+// boxes of its four 64-triangle quarters [tile*4 + q] (the triangle order is a k-d order down to 64-triangle leaves)
 __global__ __launch_bounds__(256) void tri_tile_bbox_kernel(Cloud v, const int32_t *__restrict__ tri, int64_t T,
                                                             double *__restrict__ boxes) {
     __shared__ double sh[6][256];
@@ -130,11 +135,38 @@ __global__ __launch_bounds__(256) void tri_tile_bbox_kernel(Cloud v, const int32
         __syncthreads();
     }
     if (threadIdx.x < 6) boxes[(int64_t)blockIdx.x * 6 + threadIdx.x] = sh[threadIdx.x][0];
+    // quarter boxes: wave w reduces its own 64 triangles with shuffles
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = fmin(lo[d], __shfl_xor(lo[d], off));
+            hi[d] = fmax(hi[d], __shfl_xor(hi[d], off));
+        }
+    if ((threadIdx.x & 63) == 0) {
+        double *sub = boxes + (int64_t)gridDim.x * 6 + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 6;
+        for (int d = 0; d < 3; ++d) {
+            sub[d] = lo[d];
+            sub[3 + d] = hi[d];
+        }
+    }
 }
 
 struct Tri9 {
     double ax, ay, az, bx, by, bz, cx, cy, cz, orig;
 };
+
+// squared distance from p to the axis-aligned box of a staged triangle: a lower bound of the distance to the triangle, ~12
+// instructions against the ~150 (closest point) or ~60 (line intersection) of the exact test; the exact test runs only if some
+// lane of the wave could still gain from this triangle
+__device__ __forceinline__ double tri_box_gap2(const Tri9 &t, V3 p) {
+    const double lx = fmin(fmin(t.ax, t.bx), t.cx), hx = fmax(fmax(t.ax, t.bx), t.cx);
+    const double ly = fmin(fmin(t.ay, t.by), t.cy), hy = fmax(fmax(t.ay, t.by), t.cy);
+    const double lz = fmin(fmin(t.az, t.bz), t.cz), hz = fmax(fmax(t.az, t.bz), t.cz);
+    const double gx = fmax(fmax(lx - p.x, p.x - hx), 0.0), gy = fmax(fmax(ly - p.y, p.y - hy), 0.0),
+                 gz = fmax(fmax(lz - p.z, p.z - hz), 0.0);
+    return __builtin_fma(gz, gz, __builtin_fma(gy, gy, gx * gx));
+}
 
 __device__ __forceinline__ void stage_tile(Tri9 *tile, Cloud v, const int32_t *__restrict__ tri,
                                            const int32_t *__restrict__ tri_orig, int64_t tb, int64_t T, int lane) {
@@ -178,69 +210,124 @@ __device__ __forceinline__ double box_box_gap2(const double a[6], const double *
 }
 
 // cp (SoA [3][nq]) / d2: closest point of the triangle soup to every query; exact ties go to the lowest ORIGINAL triangle.
-__global__ __launch_bounds__(kSurfThreads) void surface_cp_kernel(Cloud q, Cloud v, const int32_t *__restrict__ tri,
-                                                                 const int32_t *__restrict__ tri_orig, int64_t T,
-                                                                 const double *__restrict__ boxes, double *__restrict__ cp,
-                                                                 double *__restrict__ d2out) {
+// A workgroup of four waves serves 64 queries: every wave holds the same queries and scans ONE 64-triangle quarter of each
+// staged tile, visited only if that quarter's box is not farther from a lane's query than the lane's best so far.  Sweep 0
+// takes the tiles nearest to the queries' bounding box, then the four waves share their best distances (the bound only), and
+// sweep 1 takes the remaining tiles under that bound.  Four times the parallelism of one wave per 64 queries, and the pruning
+// works on quarters instead of tiles.
+constexpr int kCpThreads = 256;
+
+__global__ __launch_bounds__(kCpThreads) void surface_cp_kernel(Cloud q, Cloud v, const int32_t *__restrict__ tri,
+                                                               const int32_t *__restrict__ tri_orig, int64_t T,
+                                                               const double *__restrict__ boxes, double *__restrict__ cp,
+                                                               double *__restrict__ d2out) {
     __shared__ Tri9 tile[kTriTile];
-    const int lane = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * kSurfThreads + lane;
+    __shared__ double sbest[4][64], sorig[4][64], spt[4][3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
     const bool ok = i < q.n;
     const double qx = ok ? q.x[i] : 0.0, qy = ok ? q.y[i] : 0.0, qz = ok ? q.z[i] : 0.0;
     const V3 p{qx, qy, qz};
-    double best = __builtin_huge_val(), bo = __builtin_huge_val();
+    double best = __builtin_huge_val(), bo = __builtin_huge_val(), bound = __builtin_huge_val();
     V3 bp{qx, qy, qz};
     double wb[6];
     wave_box(ok, qx, qy, qz, wb);
     const int nt = (int)((T + kTriTile - 1) / kTriTile);
-    // sweep 0: tiles touching the wave's box; sweep 1: the others, only while some lane could still improve (see nn_kernel)
-    for (int phase = 0; phase < 2; ++phase)
-        for (int t = 0; t < nt; ++t) {
-            const double *bx = boxes + (int64_t)t * 6;
-            const double g = box_box_gap2(wb, bx);
-            if (phase == 0) {
-                if (g > 0.0) continue;
-            } else {
-                if (!(g > 0.0)) continue;
-                const double pd = point_box_gap2(qx, qy, qz, bx);
-                const bool need = ok && !(pd > best * (1.0 + 1e-12));
-                if (!__any(need)) continue;
-            }
-            const int64_t tb = (int64_t)t * kTriTile;
-            __syncthreads();
-            stage_tile(tile, v, tri, tri_orig, tb, T, lane);
-            __syncthreads();
-            const int cnt = (int)min((int64_t)kTriTile, T - tb);
-            for (int jj = 0; jj < cnt; ++jj) {
-                const Tri9 tr = tile[jj];
-                const V3 c = closest_on_triangle(p, V3{tr.ax, tr.ay, tr.az}, V3{tr.bx, tr.by, tr.bz}, V3{tr.cx, tr.cy, tr.cz});
-                const V3 dd = sub(c, p);
-                const double dist = (dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z;
-                if (dist < best || (dist == best && tr.orig < bo)) {
-                    best = dist;
-                    bo = tr.orig;
-                    bp = c;
+    const double *qboxes = boxes + (int64_t)nt * 6;
+    // Sweep 0 must produce a finite bound or sweep 1 degenerates into a full scan: two surfaces a few units apart have thin tile
+    // boxes that often do not touch the queries' box at all.  So sweep 0 = the tiles at the SMALLEST box-to-box gap (usually gap
+    // 0 = the touching tiles), sweep 1 = the rest under the bound.  Both sweeps find their tiles with the lanes testing 64 tile
+    // boxes at a time against the queries' box (a ballot, then a scalar walk over the set bits): the per-query quarter test runs
+    // on the few candidates only, not on every tile of the mesh.
+    double gmin = __builtin_huge_val();
+    for (int t = lane; t < nt; t += 64) gmin = fmin(gmin, box_box_gap2(wb, boxes + (int64_t)t * 6));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gmin = fmin(gmin, __shfl_xor(gmin, off));
+    gmin = uniform_dd(gmin);
+    for (int phase = 0; phase < 2; ++phase) {
+        // the largest bound of the wave's queries: no query can gain from a tile whose box is farther from the queries' box
+        double bmax = ok ? bound : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bmax = fmax(bmax, __shfl_xor(bmax, off));
+        bmax = uniform_dd(bmax) * (1.0 + 1e-12);
+        for (int tc = 0; tc < nt; tc += 64) {
+            const int tl = tc + lane;
+            const double g = tl < nt ? box_box_gap2(wb, boxes + (int64_t)tl * 6) : __builtin_huge_val();
+            unsigned long long cand = __ballot(tl < nt && (phase == 0 ? !(g > gmin) : (g > gmin && !(g > bmax))));
+            while (cand) {  // workgroup-uniform (same queries, same bound in every wave)
+                const int t = tc + __builtin_ctzll(cand);
+                cand &= cand - 1;
+            // this wave's quarter of the tile
+            const int64_t tb = (int64_t)t * kTriTile, q0 = tb + 64 * wave;
+            const double pd = point_box_gap2(qx, qy, qz, qboxes + ((int64_t)t * 4 + wave) * 6);
+            const bool need = ok && q0 < T && !(pd > fmin(best, bound) * (1.0 + 1e-12));
+            const bool wave_needs = __any(need);
+            if (!__syncthreads_or(wave_needs)) continue;
+            {
+                const int64_t tt = tb + threadIdx.x;
+                if (tt < T) {
+                    const int32_t a = tri[3 * tt], b = tri[3 * tt + 1], c = tri[3 * tt + 2];
+                    tile[threadIdx.x] = Tri9{v.x[a], v.y[a], v.z[a], v.x[b], v.y[b], v.z[b], v.x[c], v.y[c], v.z[c],
+                                             (double)(tri_orig ? tri_orig[tt] : (int32_t)tt)};
                 }
             }
+            __syncthreads();
+            if (wave_needs) {
+                const int cnt = (int)min((int64_t)64, T - q0);
+                for (int jj = 0; jj < cnt; ++jj) {
+                    const Tri9 tr = tile[64 * wave + jj];
+                    if (!__any(ok && !(tri_box_gap2(tr, p) > fmin(best, bound) * (1.0 + 1e-12)))) continue;
+                    const V3 c = closest_on_triangle(p, V3{tr.ax, tr.ay, tr.az}, V3{tr.bx, tr.by, tr.bz}, V3{tr.cx, tr.cy, tr.cz});
+                    const V3 dd = sub(c, p);
+                    const double dist = (dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z;
+                    if (dist < best || (dist == best && tr.orig < bo)) {
+                        best = dist;
+                        bo = tr.orig;
+                        bp = c;
+                    }
+                }
+            }
+            __syncthreads();  // the tile is restaged by the next visited tile
+            }
         }
-    if (ok) {
-        cp[i] = bp.x;
-        cp[q.n + i] = bp.y;
-        cp[2 * q.n + i] = bp.z;
-        d2out[i] = best;
+        if (phase == 0) {  // share the distance bound of sweep 0
+            sbest[wave][lane] = best;
+            __syncthreads();
+            bound = fmin(bound, fmin(fmin(sbest[0][lane], sbest[1][lane]), fmin(sbest[2][lane], sbest[3][lane])));
+            __syncthreads();
+        }
+    }
+    // combine the four waves: smallest distance, ties -> lowest original triangle
+    sbest[wave][lane] = best;
+    sorig[wave][lane] = bo;
+    spt[wave][0][lane] = bp.x;
+    spt[wave][1][lane] = bp.y;
+    spt[wave][2][lane] = bp.z;
+    __syncthreads();
+    if (wave == 0 && ok) {
+        int w = 0;
+        for (int k = 1; k < 4; ++k)
+            if (sbest[k][lane] < sbest[w][lane] || (sbest[k][lane] == sbest[w][lane] && sorig[k][lane] < sorig[w][lane])) w = k;
+        cp[i] = spt[w][0][lane];
+        cp[q.n + i] = spt[w][1][lane];
+        cp[2 * q.n + i] = spt[w][2][lane];
+        d2out[i] = sbest[w][lane];
     }
 }
 
 // flag[i] = 1 when the line through fit_i along fit_i - cp_i meets the mesh (v, tri) in a point != fit_i that is closer to fit_i
 // than cp_i is (ClosestPointRegistrator.scala:62-72).  Lanes with skip[i] != 0 do no work (their weight is already 0).
-__global__ __launch_bounds__(kSurfThreads) void self_intersect_kernel(Cloud fit, const double *__restrict__ cp, Cloud v,
-                                                                     const int32_t *__restrict__ tri, int64_t T,
-                                                                     const double *__restrict__ boxes,
-                                                                     const int32_t *__restrict__ skip,
-                                                                     int32_t *__restrict__ flag) {
+__global__ __launch_bounds__(kCpThreads) void self_intersect_kernel(Cloud fit, const double *__restrict__ cp, Cloud v,
+                                                                   const int32_t *__restrict__ tri, int64_t T,
+                                                                   const double *__restrict__ boxes,
+                                                                   const int32_t *__restrict__ skip,
+                                                                   int32_t *__restrict__ flag) {
     __shared__ Tri9 tile[kTriTile];
-    const int lane = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * kSurfThreads + lane;
+    __shared__ int shit[4][64];
+    // four waves hold the same 64 points; each scans one 64-triangle quarter of a staged tile (as surface_cp_kernel); "some
+    // triangle holds a closer intersection" does not depend on the order, so the waves' flags are OR-ed at the end
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
     const bool ok = i < fit.n && !(skip && skip[i]);
     const int64_t ic = i < fit.n ? i : 0;
     const V3 p{fit.x[ic], fit.y[ic], fit.z[ic]};
@@ -249,39 +336,68 @@ __global__ __launch_bounds__(kSurfThreads) void self_intersect_kernel(Cloud fit,
     const double vnorm = sqrt(vv);
     int hit = 0;
     const int nt = (int)((T + kTriTile - 1) / kTriTile);
-    for (int t = 0; t < nt; ++t) {
-        // an intersection point closer than |v| lies inside the ball of radius |v| around p
-        const double pd = point_box_gap2(p.x, p.y, p.z, boxes + (int64_t)t * 6);
-        const bool need = ok && !hit && !(pd > vv * (1.0 + 1e-12));
-        if (!__any(need)) continue;
-        const int64_t tb = (int64_t)t * kTriTile;
-        __syncthreads();
-        stage_tile(tile, v, tri, nullptr, tb, T, lane);
-        __syncthreads();
-        const int cnt = (int)min((int64_t)kTriTile, T - tb);
-        if (need)
-            for (int jj = 0; jj < cnt; ++jj) {
-                const Tri9 tr = tile[jj];
-                const V3 A{tr.ax, tr.ay, tr.az};
-                const V3 e1 = sub(V3{tr.bx, tr.by, tr.bz}, A), e2 = sub(V3{tr.cx, tr.cy, tr.cz}, A);
-                const V3 pv = cross3(dir, e2);
-                const double det = dot3(e1, pv);
-                const double inv = 1.0 / det;
-                const V3 tv = sub(p, A);
-                const double u = dot3(tv, pv) * inv;
-                const V3 qv = cross3(tv, e1);
-                const double w = dot3(qv, dir) * inv;
-                const double tt = dot3(e2, qv) * inv;
-                if (det != 0.0 && u >= 0.0 && u <= 1.0 && w >= 0.0 && u + w <= 1.0) {
-                    const V3 ip{p.x + tt * dir.x, p.y + tt * dir.y, p.z + tt * dir.z};
-                    if (ip.x != p.x || ip.y != p.y || ip.z != p.z) {
-                        const V3 dd = sub(ip, p);
-                        if (sqrt((dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z) < vnorm) hit = 1;
+    const double *qboxes = boxes + (int64_t)nt * 6;
+    // the lanes test 64 tile boxes at a time against the box of the wave's points grown by the largest radius; the per-point test
+    // below runs on those candidates only
+    double wb[6];
+    wave_box(ok, p.x, p.y, p.z, wb);
+    double vmax = ok ? vv : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmax(vmax, __shfl_xor(vmax, off));
+    vmax = uniform_dd(vmax) * (1.0 + 1e-12);
+    for (int tc = 0; tc < nt; tc += 64) {
+        const int tl = tc + lane;
+        unsigned long long cand = __ballot(tl < nt && !(box_box_gap2(wb, boxes + (int64_t)tl * 6) > vmax));
+        while (cand) {  // workgroup-uniform
+            const int t = tc + __builtin_ctzll(cand);
+            cand &= cand - 1;
+            // an intersection point closer than |v| lies inside the ball of radius |v| around p
+            const int64_t tb = (int64_t)t * kTriTile, q0 = tb + 64 * wave;
+            const double pd = point_box_gap2(p.x, p.y, p.z, qboxes + ((int64_t)t * 4 + wave) * 6);
+            const bool need = ok && !hit && q0 < T && !(pd > vv * (1.0 + 1e-12));
+            const bool wave_needs = __any(need);
+            if (!__syncthreads_or(wave_needs)) continue;
+            {
+                const int64_t tt = tb + threadIdx.x;
+                if (tt < T) {
+                    const int32_t a = tri[3 * tt], b = tri[3 * tt + 1], c = tri[3 * tt + 2];
+                    tile[threadIdx.x] = Tri9{v.x[a], v.y[a], v.z[a], v.x[b], v.y[b], v.z[b], v.x[c], v.y[c], v.z[c], 0.0};
+                }
+            }
+            __syncthreads();
+            if (wave_needs) {
+                const int cnt = (int)min((int64_t)64, T - q0);
+                for (int jj = 0; jj < cnt; ++jj) {
+                    const Tri9 tr = tile[64 * wave + jj];
+                    // only triangles reaching into the ball of radius |v| around p can hold a closer intersection point
+                    if (!__any(need && !hit && !(tri_box_gap2(tr, p) > vv * (1.0 + 1e-9)))) continue;
+                    if (need && !hit) {
+                        const V3 A{tr.ax, tr.ay, tr.az};
+                        const V3 e1 = sub(V3{tr.bx, tr.by, tr.bz}, A), e2 = sub(V3{tr.cx, tr.cy, tr.cz}, A);
+                        const V3 pv = cross3(dir, e2);
+                        const double det = dot3(e1, pv);
+                        const double inv = 1.0 / det;
+                        const V3 tv = sub(p, A);
+                        const double u = dot3(tv, pv) * inv;
+                        const V3 qv = cross3(tv, e1);
+                        const double w = dot3(qv, dir) * inv;
+                        const double tt = dot3(e2, qv) * inv;
+                        if (det != 0.0 && u >= 0.0 && u <= 1.0 && w >= 0.0 && u + w <= 1.0) {
+                            const V3 ip{p.x + tt * dir.x, p.y + tt * dir.y, p.z + tt * dir.z};
+                            if (ip.x != p.x || ip.y != p.y || ip.z != p.z) {
+                                const V3 dd = sub(ip, p);
+                                if (sqrt((dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z) < vnorm) hit = 1;
+                            }
+                        }
                     }
                 }
             }
+            __syncthreads();  // the tile is restaged by the next visited tile
+        }
     }
-    if (i < fit.n) flag[i] = hit;
+    shit[wave][lane] = hit;
+    __syncthreads();
+    if (wave == 0 && i < fit.n) flag[i] = shit[0][lane] | shit[1][lane] | shit[2][lane] | shit[3][lane];
 }
 
 // ClosestPointAlongNormalTriangleMesh3D (ClosestPointRegistrator.scala:102-131): for every fit vertex the intersection of the
@@ -482,12 +598,12 @@ void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T
 }
 void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T,
                                   const double *boxes, double *cp_soa, double *d2) {
-    hipLaunchKernelGGL(surface_cp_kernel, dim3((unsigned)ceil_div(q.n, kSurfThreads)), dim3(kSurfThreads), 0, ctx->stream, q, v,
-                       tri, tri_orig, T, boxes, cp_soa, d2);
+    hipLaunchKernelGGL(surface_cp_kernel, dim3((unsigned)ceil_div(q.n, 64)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig,
+                       T, boxes, cp_soa, d2);
 }
 void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, const int32_t *tri, int64_t T, const double *boxes,
                            const int32_t *skip, int32_t *flag) {
-    hipLaunchKernelGGL(self_intersect_kernel, dim3((unsigned)ceil_div(fit.n, kSurfThreads)), dim3(kSurfThreads), 0, ctx->stream,
+    hipLaunchKernelGGL(self_intersect_kernel, dim3((unsigned)ceil_div(fit.n, 64)), dim3(kCpThreads), 0, ctx->stream,
                        fit, cp_soa, fit, tri, T, boxes, skip, flag);
 }
 void launch_surface_prereject(gingr_ctx *ctx, int64_t M, const int32_t *nn_vertex, const int32_t *tgt_boundary,
