@@ -898,19 +898,39 @@ constexpr int kPT = GINGR_PT;     // points per thread in both CPD passes
 // workgroup fit a CU; measured -5 % per iteration at 6250 rows, +6 % at 50000 (tools/prof_emu8.sh), hence the threshold.
 constexpr int64_t kSmallShardRows = 8192;
 inline int rowstats_pt(int64_t rows) { return (kPT > 2 && rows <= kSmallShardRows) ? 2 : kPT; }
-constexpr int kTargetBlocks = 2048;  // ~8 workgroups per CU
+// Workgroups per all-pairs launch.  A CU holds 3-4 of them and one lives for (tiles per chunk) x ~30 us, so the launch ends with
+// a tail of about one workgroup's life: many short workgroups beat few long ones until the per-chunk partials (written here,
+// read by the reduce kernels) cost more than the tail.  Measured with GINGR_COLSUM_TILES / GINGR_ROWSTATS_TILES at 50k <-> 50k
+// on shards of 1/1, 1/2, 1/4, 1/8 of the rows (profiles/r01_chunk_length_sweep.txt): two tiles per chunk (~4900 workgroups)
+// is 5 % faster than five (~2000) on the whole cloud, one tile is best on the shards.
+constexpr int kTargetBlocks = 5120;
 
-// split `stream_len` into chunks so that block_cols * nchunks ~ kTargetBlocks; chunk length is a multiple of kTile
-inline void plan_chunks(int64_t owned, int owned_per_block, int64_t stream_len, int *nchunks, int64_t *chunk_len) {
+// split `stream_len` into chunks so that block_cols * nchunks ~ kTargetBlocks; chunk length is a multiple of kTile.
+// `tiles_override` > 0 (developer knob, environment GINGR_COLSUM_TILES / GINGR_ROWSTATS_TILES) fixes the tiles per chunk.
+inline void plan_chunks(int64_t owned, int owned_per_block, int64_t stream_len, int *nchunks, int64_t *chunk_len,
+                        int tiles_override = 0) {
     const int64_t bx = ceil_div(owned, owned_per_block);
     int64_t want = ceil_div(kTargetBlocks, bx > 0 ? bx : 1);
     const int64_t max_chunks = ceil_div(stream_len, kTile);
     if (want > max_chunks) want = max_chunks;
     if (want < 1) want = 1;
     int64_t len = round_up(ceil_div(stream_len, want), kTile);
+    if (tiles_override > 0) len = (int64_t)tiles_override * kTile;
     if (len < kTile) len = kTile;
     *chunk_len = len;
     *nchunks = (int)ceil_div(stream_len > 0 ? stream_len : 1, len);
+}
+inline int env_tiles(const char *name) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+inline int colsum_tiles_override() {
+    static const int v = env_tiles("GINGR_COLSUM_TILES");
+    return v;
+}
+inline int rowstats_tiles_override() {
+    static const int v = env_tiles("GINGR_ROWSTATS_TILES");
+    return v;
 }
 
 }  // namespace
@@ -918,7 +938,7 @@ inline void plan_chunks(int64_t owned, int owned_per_block, int64_t stream_len, 
 int64_t cpd_colsum_ws_doubles(int64_t M, int64_t N) {
     int nch;
     int64_t len;
-    plan_chunks(N, kBlock * kPT, M, &nch, &len);
+    plan_chunks(N, kBlock * kPT, M, &nch, &len, colsum_tiles_override());
     const int64_t a = (int64_t)nch * N, b = cpd_colsum_mfma_ws_doubles(M, N);
     return a > b ? a : b;
 }
@@ -926,7 +946,7 @@ int64_t cpd_colsum_ws_doubles(int64_t M, int64_t N) {
 int64_t cpd_rowstats_ws_doubles(int64_t M, int64_t N) {
     int nch;
     int64_t len;
-    plan_chunks(M, kBlock * rowstats_pt(M), N, &nch, &len);
+    plan_chunks(M, kBlock * rowstats_pt(M), N, &nch, &len, rowstats_tiles_override());
     const int64_t a = (int64_t)nch * 4 * M, b = cpd_rowstats_mfma_ws_doubles(M, N);
     return a > b ? a : b;
 }
@@ -961,7 +981,7 @@ void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *si
             launch_cpd_colsum_mfma(ctx, fit, target, sigma2_dev, aux, ws, &nch);
         } else {
             int64_t len;
-            plan_chunks(target.n, kBlock * kPT, fit.n, &nch, &len);
+            plan_chunks(target.n, kBlock * kPT, fit.n, &nch, &len, colsum_tiles_override());
             dim3 grid((unsigned)ceil_div(target.n, kBlock * kPT), (unsigned)nch);
             const double *boxes = ctx->cull ? fit_boxes : (const double *)nullptr;
             // with boxes: both variants, the device picks by regime (the other returns at once); without: the plain one
@@ -994,7 +1014,7 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
         } else {
             int64_t len;
             const int pt = rowstats_pt(fit.n);
-            plan_chunks(fit.n, kBlock * pt, target.n, &nch, &len);
+            plan_chunks(fit.n, kBlock * pt, target.n, &nch, &len, rowstats_tiles_override());
             dim3 grid((unsigned)ceil_div(fit.n, kBlock * pt), (unsigned)nch);
             const bool cull = ctx->cull && tgt_boxes && tile_bad;
             const double *boxes = cull ? tgt_boxes : (const double *)nullptr;
