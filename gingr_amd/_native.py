@@ -76,6 +76,8 @@ SIGNATURES = {
     "gingr_fitter_update_icp_surface_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32]),
     "gingr_fitter_icp_surface_phase_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32]),
     "gingr_fitter_get_surface_correspondence": (c_int, [c_void_p, _dp, _dp]),
+    "gingr_fitter_surface_distance_stats": (c_int, [c_void_p, c_int32, c_int64, _dp, c_int32, c_double, _dp]),
+    "gingr_mesh_distance_stats": (c_int, [c_void_p, c_int64, _dp, c_int64, _dp, c_int64, POINTER(c_int32), c_int32, c_double, _dp]),
     "gingr_fitter_update_icp_surface_sample_async": (c_int, [c_void_p, POINTER(IcpParams), _dp]),
     "gingr_fitter_posterior_logpdf_icp_surface": (c_int, [c_void_p, POINTER(IcpParams), _dp, POINTER(c_double)]),
     "gingr_gpmm_build_gaussian": (c_int, [c_void_p, c_int64, _dp, c_int32, _dp, _dp, c_double, c_int32, c_int64, c_int64,

@@ -130,6 +130,18 @@ class Context:
                                                         float(scaling), dptr(out)), "gingr_gauss_block")
         return out
 
+    def mesh_distance_stats(self, points, vertices, cells, boundary_aware: bool = False, sdev: float = 0.0
+                            ) -> Tuple[float, float, int, float]:
+        """(sum, max, count, sum of log N(d; 0, sdev)) of d = |p - closestPointOnSurface(p)| for the rows of `points` against
+        the triangle mesh (vertices, cells); boundary_aware as RegistrationComparison.avgDistanceBoundaryAware (:63-73)."""
+        p, v = f64(points), f64(vertices)
+        c = np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, 3)
+        out = np.zeros(4)
+        _check(self.handle, self._lib.gingr_mesh_distance_stats(self.handle, p.shape[0], dptr(p), v.shape[0], dptr(v), c.shape[0],
+                                                                iptr(c), int(bool(boundary_aware)), float(sdev), dptr(out)),
+               "gingr_mesh_distance_stats")
+        return float(out[0]), float(out[1]), int(out[2]), float(out[3])
+
 
 # ----------------------------------------------------------------------------- model
 @dataclasses.dataclass
@@ -598,6 +610,43 @@ class GingrAlgorithm:
         self._keepalive = out
         return out
 
+    def _ensure_device_state(self, state):
+        """Make the fitter hold `state` (model, target, meshes, parameters; the fit is re-instantiated on the device)."""
+        g = state.general
+        self._bind(g, state.config.useLandmarkCorrespondence)
+        if self._device_state_token != id(state):
+            self._push_state(g)
+            self._device_state_token = id(state)
+            self._keepalive = state
+
+    def proposeParameters(self, current, modelParameters: ModelFittingParameters, generatedBy: str):
+        """GingrGeneratorWrapper.propose for a proposal that only rewrites the parameters (GingrGeneratorWrapper.scala:28-39):
+        fit = modelInstanceShapePoseScale(model, parameters) -- instantiated on the device -- and iteration + 1."""
+        g = dataclasses.replace(current.general, modelParameters=modelParameters, iteration=current.general.iteration + 1)
+        self._bind(g, current.config.useLandmarkCorrespondence)
+        self._push_state(g)
+        new_general = dataclasses.replace(self._pull_state(g), generatedBy=generatedBy)
+        out = current.updateGeneral(new_general)
+        self._device_state_token = id(out)
+        self._keepalive = out
+        return out
+
+    def surfaceDistanceStats(self, state, direction: int, n_points: int = 0, points=None, boundary_aware: bool = False,
+                             sdev: float = 0.0) -> Tuple[float, float, int, float]:
+        """(sum, max, count, sum of log N(d; 0, sdev)) of the closest-point distances between the fit of `state` and the target
+        surface: direction 0 = fit vertices -> target surface, 1 = target vertices (or `points`) -> fit surface."""
+        g = state.general
+        if getattr(g.model, "cells", None) is None or g.targetCells is None:
+            raise ValueError("surface distances need model.cells and targetCells")
+        self._ensure_device_state(state)
+        out = np.zeros(4)
+        pts = None if points is None else f64(points)
+        n = int(n_points) if pts is None else pts.shape[0]
+        _check(self.ctx.handle, self._lib.gingr_fitter_surface_distance_stats(
+            self._fitter, int(direction), n, None if pts is None else dptr(pts), int(bool(boundary_aware)), float(sdev), dptr(out)),
+            "gingr_fitter_surface_distance_stats")
+        return float(out[0]), float(out[1]), int(out[2]), float(out[3])
+
     def logTransitionProbability(self, from_state, to_state) -> float:
         """GeneratorWrapperStochastic.logTransitionProbability (GeneratorWrapperStochastic.scala:42-63): log-density, under
         the posterior model of `from_state`, of the mesh the reference projects -- from.fit when stepLength == 1, otherwise
@@ -623,9 +672,15 @@ class GingrAlgorithm:
                 return float("-inf")
             raise
 
-    def run(self, initialState, callBackLogger: Optional[Callable] = None):
-        """Deterministic registration loop (GingrAlgorithm.run, :115-175): the chain yields the initial state first,
-        so take(maxIterations) performs maxIterations-1 updates; stops on convergence or ModelFlexibilityError."""
+    def run(self, initialState, callBackLogger: Optional[Callable] = None, acceptRejectLogger=None, probabilisticSettings=None,
+            generators=None, rnd=None):
+        """GingrAlgorithm.run (:115-175).  Without probabilisticSettings: the deterministic registration loop -- the chain
+        yields the initial state first, so take(maxIterations) performs maxIterations-1 updates; stops on convergence or
+        ModelFlexibilityError.  With them: the Metropolis-Hastings chain of gingr_amd.sampling (informed + random-walk
+        proposals, evaluator, best sample)."""
+        if probabilisticSettings is not None or acceptRejectLogger is not None or generators is not None:
+            from . import sampling
+            return sampling.run(self, initialState, acceptRejectLogger, callBackLogger, probabilisticSettings, generators, rnd)
         state = initialState
         last_general = None
         converged = False
@@ -672,8 +727,11 @@ class CpdRegistration(GingrAlgorithm):
 
     def createInitialState(self, model: PointDistributionModel, target, config: CpdConfiguration,
                            transform: int = GlobalTranformationType.RigidTransforms, stepLength: float = 1.0,
-                           landmarks: Optional[LandmarkCorrespondences] = None, initial_pose=None) -> CpdRegistrationState:
-        g = _initial_general(self.ctx, model, target, 1.0, transform, stepLength, landmarks, initial_pose)
+                           landmarks: Optional[LandmarkCorrespondences] = None, initial_pose=None,
+                           targetCells: Optional[np.ndarray] = None) -> CpdRegistrationState:
+        """targetCells (with model.cells): the target's triangulation -- CPD itself works on the vertices; the surface
+        likelihood of a probabilistic run (sampling.IndependentPointDistanceEvaluator) needs both meshes."""
+        g = _initial_general(self.ctx, model, target, 1.0, transform, stepLength, landmarks, initial_pose, targetCells)
         return self.initializeState(g, config)
 
     def initializeState(self, general: GeneralRegistrationState, config: CpdConfiguration) -> CpdRegistrationState:

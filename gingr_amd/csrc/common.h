@@ -150,6 +150,10 @@ void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T
 // closest point of the triangle soup to every query (SoA out); exact ties: lowest tri_orig
 void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T,
                                   const double *boxes, double *cp_soa, double *d2);
+// out4 = {sum of sqrt(d2), max, count, sum of log N(sqrt(d2); 0, sdev)} over the counted points (surface.hip)
+int distance_stats_ws_doubles();
+void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const int32_t *orig, int64_t orig_limit, const int32_t *nn,
+                           const int32_t *boundary, double sdev, double *partial, double *out4);
 void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, const int32_t *tri, int64_t T, const double *boxes,
                            const int32_t *skip, int32_t *flag);
 // found (nullable): along-normal flavour, 0 = no intersection (rejected)

@@ -1309,3 +1309,165 @@ int gingr_model_posterior_mean(gingr_ctx *ctx, const gingr_model *model, const d
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------ surface distance statistics
+namespace {
+
+// out4 = {sum d, max d, count, sum log N(d; 0, sdev)} of d = |q - closest point of the mesh (v, tri)| over the queries q.
+// `nn_orig` / `nn_boxes` / `boundary` (all three or none): the boundary-aware variant.  `scratch` holds what the kernels write.
+struct StatScratch {
+    DevBuf cp, d2, nn, nnd2, ws, part, out;
+};
+
+int run_distance_stats(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T, const double *tboxes,
+                       const int32_t *q_orig, int64_t q_limit, const int32_t *v_orig, const double *v_boxes,
+                       const int32_t *boundary, double sdev, StatScratch &sc, double out4[4]) {
+    const int64_t K = q.n;
+    HIP_TRY(ctx, sc.cp.alloc((size_t)3 * K * sizeof(double)));
+    HIP_TRY(ctx, sc.d2.alloc((size_t)K * sizeof(double)));
+    HIP_TRY(ctx, sc.part.alloc((size_t)distance_stats_ws_doubles() * sizeof(double)));
+    HIP_TRY(ctx, sc.out.alloc(4 * sizeof(double)));
+    launch_surface_closest_point(ctx, q, v, tri, tri_orig, T, tboxes, sc.cp.as<double>(), sc.d2.as<double>());
+    if (boundary) {
+        HIP_TRY(ctx, sc.nn.alloc((size_t)K * sizeof(int32_t)));
+        HIP_TRY(ctx, sc.nnd2.alloc((size_t)K * sizeof(double)));
+        HIP_TRY(ctx, sc.ws.alloc((size_t)nn_ws_bytes(K, v.n)));
+        launch_nn(ctx, cloud_of(sc.cp.as<double>(), K), v, v_orig, v_boxes, sc.ws.p, sc.nn.as<int32_t>(), sc.nnd2.as<double>());
+    }
+    launch_distance_stats(ctx, K, sc.d2.as<double>(), q_orig, q_limit, boundary ? sc.nn.as<int32_t>() : nullptr, boundary, sdev,
+                          sc.part.as<double>(), sc.out.as<double>());
+    GINGR_TRY(check_launch(ctx));
+    HIP_TRY(ctx, hipMemcpyAsync(out4, sc.out.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GINGR_OK;
+}
+
+// SoA planes of host points taken in the order `order` (device position -> input index)
+void gather_soa(const double *xyz, const std::vector<int32_t> &order, std::vector<double> &soa) {
+    const size_t n = order.size();
+    soa.resize(3 * n);
+    for (size_t s2 = 0; s2 < n; ++s2)
+        for (int d = 0; d < 3; ++d) soa[(size_t)d * n + s2] = xyz[(size_t)3 * order[s2] + d];
+}
+
+}  // namespace
+
+extern "C" {
+
+int gingr_fitter_surface_distance_stats(gingr_fitter *f, int32_t direction, int64_t n_points, const double *points,
+                                        int32_t boundary_aware, double sdev, double out[4]) {
+    GINGR_TRY(check_ready(f));
+    gingr_ctx *ctx = f->ctx;
+    if (!out || (direction != 0 && direction != 1) || n_points < 0 || !(sdev >= 0.0))
+        return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "surface_distance_stats: bad argument");
+    if (!f->Tm || !f->Tt) return gingr_set_error(ctx, GINGR_ERR_STATE, "surface_distance_stats: no meshes set (gingr_fitter_set_meshes)");
+    const gingr_model *m = f->m;
+    const int64_t M = m->M, N = f->N;
+    const Cloud fit = cloud_of(f->fit, M), tgt = cloud_of(f->target, N);
+    StatScratch sc;
+    if (direction == 0) {
+        // the first n_points vertices of the current fit (original numbering; 0 = all) against the target surface
+        if (points) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "surface_distance_stats: model -> target takes no point list");
+        if (n_points > M) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "surface_distance_stats: more points than model vertices");
+        const bool all = n_points == 0 || n_points == M;
+        return run_distance_stats(ctx, fit, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, all ? nullptr : m->perm, n_points, f->tperm,
+                                  f->tboxes, boundary_aware ? f->tboundary : nullptr, sdev, sc, out);
+    }
+    // `points` (null: every target vertex) against the surface of the current fit
+    launch_tri_tile_bbox(ctx, fit, f->mtri, f->Tm, f->mtboxes);
+    if (boundary_aware) launch_tile_bbox(ctx, fit, f->fboxes);
+    const int32_t *bnd = boundary_aware ? f->mboundary : nullptr;
+    if (!points)
+        return run_distance_stats(ctx, tgt, fit, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, nullptr, 0, m->perm, f->fboxes, bnd, sdev, sc,
+                                  out);
+    if (n_points < 1) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "surface_distance_stats: empty point list");
+    std::vector<int32_t> order;
+    morton_order(points, n_points, order);
+    std::vector<double> soa;
+    gather_soa(points, order, soa);
+    DevBuf q;
+    HIP_TRY(ctx, q.alloc(soa.size() * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpyAsync(q.p, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return run_distance_stats(ctx, cloud_of(q.as<double>(), n_points), fit, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, nullptr, 0, m->perm,
+                              f->fboxes, bnd, sdev, sc, out);
+}
+
+int gingr_mesh_distance_stats(gingr_ctx *ctx, int64_t n_points, const double *points, int64_t n_vertices, const double *vertices,
+                              int64_t n_triangles, const int32_t *triangles, int32_t boundary_aware, double sdev, double out[4]) {
+    if (!ctx) return GINGR_ERR_BAD_ARGUMENT;
+    if (!points || !vertices || !triangles || !out || n_points < 1 || n_vertices < 1 || n_triangles < 1 || !(sdev >= 0.0) ||
+        n_vertices > INT32_MAX || n_triangles > INT32_MAX || n_points > INT32_MAX)
+        return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "mesh_distance_stats: bad argument");
+    for (int64_t k = 0; k < 3 * n_triangles; ++k)
+        if (triangles[k] < 0 || triangles[k] >= n_vertices)
+            return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "mesh_distance_stats: vertex id out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // spatial orders: queries, vertices (device position -> original) and triangles (by centroid)
+    std::vector<int32_t> qorder, vorder, torder;
+    morton_order(points, n_points, qorder);
+    morton_order(vertices, n_vertices, vorder);
+    std::vector<int32_t> vinv((size_t)n_vertices);
+    for (int64_t s2 = 0; s2 < n_vertices; ++s2) vinv[(size_t)vorder[(size_t)s2]] = (int32_t)s2;
+    std::vector<double> cen((size_t)3 * n_triangles);
+    for (int64_t t = 0; t < n_triangles; ++t)
+        for (int d = 0; d < 3; ++d) {
+            double c = 0.0;
+            for (int k = 0; k < 3; ++k) c += vertices[(size_t)3 * triangles[3 * t + k] + d];
+            cen[(size_t)3 * t + d] = c / 3.0;
+        }
+    morton_order(cen.data(), n_triangles, torder);
+    std::vector<int32_t> tri((size_t)3 * n_triangles);
+    for (int64_t s2 = 0; s2 < n_triangles; ++s2)
+        for (int k = 0; k < 3; ++k) tri[(size_t)3 * s2 + k] = vinv[(size_t)triangles[(size_t)3 * torder[(size_t)s2] + k]];
+    std::vector<int32_t> bnd;
+    if (boundary_aware) {  // on an edge with exactly one adjacent triangle (TriangleMesh3DOperations.pointIsOnBoundary)
+        bnd.assign((size_t)n_vertices, 0);
+        std::vector<uint64_t> edges;
+        edges.reserve((size_t)3 * n_triangles);
+        for (int64_t t = 0; t < n_triangles; ++t)
+            for (int k = 0; k < 3; ++k) {
+                const uint64_t a = (uint64_t)triangles[3 * t + k], b = (uint64_t)triangles[3 * t + (k + 1) % 3];
+                edges.push_back((a < b ? a : b) << 32 | (a < b ? b : a));
+            }
+        std::sort(edges.begin(), edges.end());
+        for (size_t i = 0; i < edges.size();) {
+            size_t j = i;
+            while (j < edges.size() && edges[j] == edges[i]) ++j;
+            if (j - i == 1) {
+                bnd[(size_t)vinv[(size_t)(edges[i] >> 32)]] = 1;
+                bnd[(size_t)vinv[(size_t)(edges[i] & 0xffffffffu)]] = 1;
+            }
+            i = j;
+        }
+    }
+    std::vector<double> qsoa, vsoa;
+    gather_soa(points, qorder, qsoa);
+    gather_soa(vertices, vorder, vsoa);
+    const int64_t ntiles = ceil_div(n_triangles, 256), nvt = ceil_div(n_vertices, 256);
+    DevBuf dq, dv, dtri, dorig, dtb, dvorig, dvb, dbnd;
+    HIP_TRY(ctx, dq.alloc(qsoa.size() * sizeof(double)));
+    HIP_TRY(ctx, dv.alloc(vsoa.size() * sizeof(double)));
+    HIP_TRY(ctx, dtri.alloc(tri.size() * sizeof(int32_t)));
+    HIP_TRY(ctx, dorig.alloc(torder.size() * sizeof(int32_t)));
+    HIP_TRY(ctx, dtb.alloc((size_t)30 * ntiles * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpyAsync(dq.p, qsoa.data(), qsoa.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dv.p, vsoa.data(), vsoa.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dtri.p, tri.data(), tri.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dorig.p, torder.data(), torder.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    const Cloud q = cloud_of(dq.as<double>(), n_points), v = cloud_of(dv.as<double>(), n_vertices);
+    launch_tri_tile_bbox(ctx, v, dtri.as<int32_t>(), n_triangles, dtb.as<double>());
+    if (boundary_aware) {
+        HIP_TRY(ctx, dvorig.alloc(vorder.size() * sizeof(int32_t)));
+        HIP_TRY(ctx, dvb.alloc((size_t)30 * nvt * sizeof(double)));
+        HIP_TRY(ctx, dbnd.alloc(bnd.size() * sizeof(int32_t)));
+        HIP_TRY(ctx, hipMemcpyAsync(dvorig.p, vorder.data(), vorder.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dbnd.p, bnd.data(), bnd.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        launch_tile_bbox(ctx, v, dvb.as<double>());
+    }
+    StatScratch sc;
+    return run_distance_stats(ctx, q, v, dtri.as<int32_t>(), dorig.as<int32_t>(), n_triangles, dtb.as<double>(), nullptr, 0,
+                              boundary_aware ? dvorig.as<int32_t>() : nullptr, boundary_aware ? dvb.as<double>() : nullptr,
+                              boundary_aware ? dbnd.as<int32_t>() : nullptr, sdev, sc, out);
+}
+
+}  // extern "C"

@@ -561,6 +561,63 @@ __global__ __launch_bounds__(256) void reversal_gather_kernel(int64_t M, int64_t
     weight_in[i] = (double)k / sigma2[0];
 }
 
+// ---------------------------------------------------------------------------------------- surface distance statistics
+// IndependentPointDistanceEvaluator (G/api/sampling/evaluators/IndependentPointDistanceEvaluator.scala:54-70) and the accuracy
+// metrics of RegistrationComparison (G/api/helper/RegistrationComparison.scala:24-73) are reductions over
+// d_i = |p_i - closestPointOnSurface(p_i)|: partial[b] = {sum d, max d, count, sum log N(d; 0, sdev)} of block b, points counted
+// when orig[i] < orig_limit (the first orig_limit points in the caller's numbering; orig == null: all) and, with `boundary`,
+// when the mesh vertex nearest to the surface point is not a boundary vertex (:67-69).  Fixed grid, fixed reduction order.
+constexpr int kStatBlocks = 64;
+
+__global__ __launch_bounds__(256) void dist_stats_kernel(int64_t n, const double *__restrict__ d2, const int32_t *__restrict__ orig,
+                                                         int64_t orig_limit, const int32_t *__restrict__ nn,
+                                                         const int32_t *__restrict__ boundary, double sdev, double lognorm,
+                                                         double *__restrict__ partial) {
+    __shared__ double sh[4][256];
+    double s = 0.0, mx = 0.0, cnt = 0.0, ll = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)kStatBlocks * 256) {
+        bool take = !orig || orig[i] < orig_limit;
+        if (take && boundary) {
+            const int32_t j = nn[i];
+            take = j >= 0 && !boundary[j];
+        }
+        if (!take) continue;
+        const double d = sqrt(d2[i]);
+        s += d;
+        mx = fmax(mx, d);
+        cnt += 1.0;
+        if (sdev > 0.0) {
+            const double u = d / sdev;
+            ll += -u * u / 2.0 - lognorm;  // breeze Gaussian.logPdf
+        }
+    }
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = mx;
+    sh[2][threadIdx.x] = cnt;
+    sh[3][threadIdx.x] = ll;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + off];
+            sh[1][threadIdx.x] = fmax(sh[1][threadIdx.x], sh[1][threadIdx.x + off]);
+            sh[2][threadIdx.x] += sh[2][threadIdx.x + off];
+            sh[3][threadIdx.x] += sh[3][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) partial[(int64_t)blockIdx.x * 4 + threadIdx.x] = sh[threadIdx.x][0];
+}
+
+__global__ void dist_stats_finish_kernel(const double *__restrict__ partial, double *__restrict__ out) {
+    if (threadIdx.x >= 4) return;
+    double v = 0.0;
+    for (int b = 0; b < kStatBlocks; ++b) {
+        const double x = partial[b * 4 + threadIdx.x];
+        v = threadIdx.x == 1 ? fmax(v, x) : v + x;
+    }
+    out[threadIdx.x] = v;
+}
+
 }  // namespace
 
 size_t reversal_sort_temp_bytes(int64_t N) {
@@ -600,6 +657,14 @@ void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_
                                   const double *boxes, double *cp_soa, double *d2) {
     hipLaunchKernelGGL(surface_cp_kernel, dim3((unsigned)ceil_div(q.n, 64)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig,
                        T, boxes, cp_soa, d2);
+}
+int distance_stats_ws_doubles() { return kStatBlocks * 4; }
+void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const int32_t *orig, int64_t orig_limit, const int32_t *nn,
+                           const int32_t *boundary, double sdev, double *partial, double *out4) {
+    const double lognorm = sdev > 0.0 ? log(sqrt(2.0 * M_PI)) + log(sdev) : 0.0;
+    hipLaunchKernelGGL(dist_stats_kernel, dim3(kStatBlocks), dim3(256), 0, ctx->stream, n, d2, orig, orig_limit, nn, boundary, sdev,
+                       lognorm, partial);
+    hipLaunchKernelGGL(dist_stats_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, partial, out4);
 }
 void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, const int32_t *tri, int64_t T, const double *boxes,
                            const int32_t *skip, int32_t *flag) {

@@ -1,0 +1,503 @@
+"""Host side of GiNGR's probabilistic registration (BASELINE config 5: Metropolis-Hastings over GiNGR updates): evaluators,
+proposal generators, the chain and the accuracy metrics, with every data-parallel step on the GPU --
+
+  the informed proposal                  GingrAlgorithm.update(probabilistic = true)        (native posterior sample)
+  its transition density                 GingrAlgorithm.logTransitionProbability            (native posterior log-density)
+  the likelihood                         IndependentPointDistanceEvaluator                  (native closest-point reduction)
+  re-instantiating a random-walk proposal GingrAlgorithm.proposeParameters                  (native model instance)
+
+and only r-sized arithmetic and control flow here.  Mirrors (G/ = src/main/scala/gingr/):
+
+  IndependentPointDistanceEvaluator, EvaluationMode      G/api/sampling/evaluators/IndependentPointDistanceEvaluator.scala:27-84
+  ModelEvaluator, AcceptAllEvaluator, EvaluatorWrapper   G/api/sampling/evaluators/{ModelEvaluator,AcceptAllEvaluator,EvaluatorWrapper}.scala
+  IndependentPoints, AcceptAll                           G/api/sampling/Evaluator.scala:33-60
+  RandomShapeUpdateProposal                              G/api/sampling/generators/RandomShapeUpdateProposal.scala:22-50
+  GaussianAxisRotation/TranslationProposal               G/api/sampling/generators/RandomPoseUpdateProposal.scala:28-117
+  Generator (RandomShape/Rotation/Translation/Pose, DefaultRandom)   G/api/sampling/Generator.scala:25-88
+  GeneratorWrapperStochastic / Deterministic             G/api/sampling/generators/GeneratorWrapper{Stochastic,Deterministic}.scala
+  BestAndCurrentSampleLogger                             G/api/sampling/loggers/BestAndCurrentSampleLogger.scala:23-47
+  run(...)                                               G/api/GingrAlgorithm.scala:115-190
+  RegistrationComparison                                 G/api/helper/RegistrationComparison.scala:22-99
+
+scalismo's MixtureProposal and MetropolisHastings (1.0-RC1, not vendored) are restated from their published behaviour
+[SCALISMO-RECALL, parity unpinned]: a mixture picks the first component whose cumulative normalised weight reaches one
+uniform draw, its transition density is the weighted sum of the components' densities; a Metropolis-Hastings step accepts when
+a = log p(proposal) - log p(current) - (log q(current -> proposal) - log q(proposal -> current)) is positive or a uniform draw is
+below exp(a), where the bracket counts as 0 when both densities are -inf (the deterministic wrapper).
+
+Random numbers: the JVM streams (scala.util.Random behind scalismo.utils.Random, and breeze's FixedSeed basis used by the pose
+proposals) cannot be reproduced; `Random` below carries two numpy generators in their place and the call ORDER of the reference
+is kept, including the discarded draw of GaussianAxisTranslationProposal (RandomPoseUpdateProposal.scala:89).
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .api import (Context, EulerAngles, FittingStatuses, GingrAlgorithm, ModelFittingParameters)
+
+ModelToTargetEvaluation = "ModelToTargetEvaluation"
+TargetToModelEvaluation = "TargetToModelEvaluation"
+SymmetricEvaluation = "SymmetricEvaluation"
+
+
+class Random:
+    """scalismo.utils.Random (`scalaRandom`) plus breeze's Rand.FixedSeed basis."""
+
+    def __init__(self, seed: int, breeze_seed: int = 0):
+        self.scalaRandom = np.random.default_rng(seed)
+        self.breeze = np.random.default_rng(breeze_seed)
+
+    def nextDouble(self) -> float:
+        return float(self.scalaRandom.random())
+
+    def nextGaussian(self, n: Optional[int] = None):
+        return self.scalaRandom.standard_normal(n) if n is not None else float(self.scalaRandom.standard_normal())
+
+    def breezeGaussian(self, sdev: float) -> float:
+        return float(self.breeze.standard_normal()) * sdev
+
+
+def gaussian_logpdf(x: float, sdev: float) -> float:
+    """breeze Gaussian(0, sdev).logPdf(x) / scalismo GaussianEvaluator.logDensity(x, 0, sdev)."""
+    d = x / sdev
+    return -d * d / 2.0 - (math.log(math.sqrt(2.0 * math.pi)) + math.log(sdev))
+
+
+class _Memoize:
+    """scalismo.utils.Memoize(f, n): the last n results, keyed by the state object."""
+
+    def __init__(self, f: Callable, n: int):
+        self.f, self.n, self.keys, self.vals = f, n, [], []
+
+    def __call__(self, state):
+        for k, v in zip(self.keys, self.vals):
+            if k is state:
+                return v
+        v = self.f(state)
+        self.keys.append(state)
+        self.vals.append(v)
+        if len(self.keys) > self.n:
+            self.keys.pop(0)
+            self.vals.pop(0)
+        return v
+
+
+# ------------------------------------------------------------------------------------------------------------ evaluators
+class IndependentPointDistanceEvaluator:
+    """Sum over the compared points of log N(|p - closestPointOnSurface(p)|; 0, uncertainty), reduced on the GPU.
+
+    `uncertainty` stands for the reference's `likelihoodModel = Gaussian(0, uncertainty)` (Evaluator.scala:47).  The reference's
+    numberOfPointsForComparison decimates instance and target with scalismo's mesh decimation, which is not restated; its effect
+    -- the first n' vertices of the sample (point ids of the decimated instance, :49-50,55) and the points of the decimated target
+    (:49) -- is passed in as modelPointCount / targetPoints."""
+
+    def __init__(self, algorithm: GingrAlgorithm, sample, uncertainty: float, evaluationMode: str = ModelToTargetEvaluation,
+                 numberOfPointsForComparison: Optional[int] = None, modelPointCount: Optional[int] = None, targetPoints=None):
+        if numberOfPointsForComparison is not None:
+            raise NotImplementedError("mesh decimation is scalismo's: pass modelPointCount / targetPoints")
+        if evaluationMode not in (ModelToTargetEvaluation, TargetToModelEvaluation, SymmetricEvaluation):
+            raise ValueError(evaluationMode)
+        self.algorithm, self.uncertainty, self.evaluationMode = algorithm, float(uncertainty), evaluationMode
+        self.modelPointCount = modelPointCount
+        self.targetPoints = None if targetPoints is None else np.ascontiguousarray(targetPoints, dtype=np.float64)
+        self._memo = _Memoize(self.computeLogValue, 3)       # EvaluationCaching (EvaluationCaching.scala:26-37)
+
+    def distModelToTarget(self, state) -> float:
+        return self.algorithm.surfaceDistanceStats(state, 0, self.modelPointCount or 0, None, False, self.uncertainty)[3]
+
+    def distTargetToModel(self, state) -> float:
+        return self.algorithm.surfaceDistanceStats(state, 1, 0, self.targetPoints, False, self.uncertainty)[3]
+
+    def computeLogValue(self, state) -> float:
+        if self.evaluationMode == ModelToTargetEvaluation:
+            return self.distModelToTarget(state)
+        if self.evaluationMode == TargetToModelEvaluation:
+            return self.distTargetToModel(state)
+        return 0.5 * self.distModelToTarget(state) + 0.5 * self.distTargetToModel(state)
+
+    def logValue(self, state) -> float:
+        return self._memo(state)
+
+
+class ModelEvaluator:
+    """log N(shape coefficients; 0, I_r)  (ModelEvaluator.scala:25-33)."""
+
+    def __init__(self, modelrank: int):
+        self.modelrank = modelrank
+
+    def logValue(self, state) -> float:
+        a = np.asarray(state.general.modelParameters.shape, dtype=np.float64)
+        return float(-0.5 * (a @ a) - 0.5 * self.modelrank * math.log(2.0 * math.pi))
+
+
+class AcceptAllEvaluator:
+    def logValue(self, state) -> float:
+        return 0.0
+
+
+class ProductEvaluator:
+    """scalismo.sampling.evaluators.ProductEvaluator: the sum of the log values."""
+
+    def __init__(self, evaluators: Sequence):
+        self.evaluators = list(evaluators)
+
+    def logValue(self, state) -> float:
+        return float(sum(e.logValue(state) for e in self.evaluators))
+
+
+@dataclasses.dataclass
+class EvaluatorIdentifier:
+    name: str
+    evaluator: object
+
+
+class AcceptAll:
+    def evaluator(self) -> List[EvaluatorIdentifier]:
+        return [EvaluatorIdentifier("AcceptAll", AcceptAllEvaluator())]
+
+    def productEvaluator(self) -> ProductEvaluator:
+        return ProductEvaluator([e.evaluator for e in self.evaluator()])
+
+
+class IndependentPoints(AcceptAll):
+    """Prior on the coefficients x independent point distances (Evaluator.scala:41-60)."""
+
+    def __init__(self, algorithm: GingrAlgorithm, state, uncertainty: float, mode: str = ModelToTargetEvaluation,
+                 evaluatedPoints: Optional[int] = None, modelPointCount: Optional[int] = None, targetPoints=None):
+        self._evals = [
+            EvaluatorIdentifier("Prior", ModelEvaluator(state.general.model.rank)),
+            EvaluatorIdentifier("Distance", IndependentPointDistanceEvaluator(algorithm, state, uncertainty, mode, evaluatedPoints,
+                                                                              modelPointCount, targetPoints)),
+        ]
+
+    def evaluator(self) -> List[EvaluatorIdentifier]:
+        return self._evals
+
+
+class EvaluatorWrapper:
+    def __init__(self, probabilistic: bool, evaluator: AcceptAll):
+        self.probabilistic, self._eval = probabilistic, evaluator.productEvaluator()
+
+    def logValue(self, state) -> float:
+        return self._eval.logValue(state) if self.probabilistic else 0.0
+
+
+@dataclasses.dataclass
+class ProbabilisticSettings:
+    evaluators: AcceptAll
+    randomMixture: float = 0.5
+
+    def __post_init__(self):
+        if not (0.0 <= self.randomMixture <= 1.0):
+            raise ValueError("requirement failed: randomMixture in [0, 1]")
+
+
+# ------------------------------------------------------------------------------------------------------------ generators
+def _same_parameters(a: ModelFittingParameters, b: ModelFittingParameters) -> bool:
+    return (a.scale == b.scale and tuple(a.translation) == tuple(b.translation) and a.rotation == b.rotation
+            and tuple(a.center) == tuple(b.center) and np.array_equal(np.asarray(a.shape), np.asarray(b.shape)))
+
+
+class RandomShapeUpdateProposal:
+    def __init__(self, algorithm: GingrAlgorithm, stdev: float, rnd: Random, generatedBy: str = "RandomShapeUpdateProposal"):
+        self.algorithm, self.stdev, self.rnd, self.generatedBy = algorithm, float(stdev), rnd, generatedBy
+
+    def propose(self, theta):
+        mp = theta.general.modelParameters
+        a = np.asarray(mp.shape, dtype=np.float64)
+        if a.shape[0] == 0:
+            raise ValueError("requirement failed: cannot propose change on empty vector")
+        new = a + self.stdev * self.rnd.nextGaussian(a.shape[0])            # GaussianDenseVectorProposal.propose (:29-32)
+        return self.algorithm.proposeParameters(theta, dataclasses.replace(mp, shape=new), self.generatedBy)
+
+    def logTransitionProbability(self, frm, to) -> float:
+        f, t = frm.general.modelParameters, to.general.modelParameters
+        if not _same_parameters(dataclasses.replace(t, shape=f.shape), f):
+            return -math.inf
+        return float(sum(gaussian_logpdf(tv - fv, self.stdev) for tv, fv in zip(np.asarray(t.shape), np.asarray(f.shape))))
+
+
+RollAxis, PitchAxis, YawAxis = "phi", "theta", "psi"
+
+
+class GaussianAxisRotationProposal:
+    def __init__(self, algorithm: GingrAlgorithm, sdevRot: float, axis: str, rnd: Random, generatedBy: str = "RotationProposal"):
+        self.algorithm, self.sdev, self.axis, self.rnd, self.generatedBy = algorithm, float(sdevRot), axis, rnd, generatedBy
+
+    def propose(self, theta):
+        mp = theta.general.modelParameters
+        rot = dataclasses.replace(mp.rotation, **{self.axis: getattr(mp.rotation, self.axis) + self.rnd.breezeGaussian(self.sdev)})
+        return self.algorithm.proposeParameters(theta, dataclasses.replace(mp, rotation=rot), self.generatedBy)
+
+    def logTransitionProbability(self, frm, to) -> float:
+        f, t = frm.general.modelParameters, to.general.modelParameters
+        if not _same_parameters(dataclasses.replace(t, rotation=f.rotation, center=f.center), f):
+            return -math.inf
+        return gaussian_logpdf(getattr(t.rotation, self.axis) - getattr(f.rotation, self.axis), self.sdev)
+
+
+class GaussianAxisTranslationProposal:
+    def __init__(self, algorithm: GingrAlgorithm, sdevTrans: float, axis: int, rnd: Random, generatedBy: str = "TranslationProposal"):
+        if not axis < 3:
+            raise ValueError("requirement failed")
+        self.algorithm, self.sdev, self.axis, self.rnd, self.generatedBy = algorithm, float(sdevTrans), axis, rnd, generatedBy
+
+    def propose(self, theta):
+        self.rnd.breezeGaussian(self.sdev)                                   # the discarded sample (:89)
+        mp = theta.general.modelParameters
+        t = list(mp.translation)
+        t[self.axis] = t[self.axis] + self.rnd.breezeGaussian(self.sdev)
+        return self.algorithm.proposeParameters(theta, dataclasses.replace(mp, translation=tuple(t)), self.generatedBy)
+
+    def logTransitionProbability(self, frm, to) -> float:
+        f, t = frm.general.modelParameters, to.general.modelParameters
+        if not _same_parameters(dataclasses.replace(t, translation=f.translation), f):
+            return -math.inf
+        return gaussian_logpdf(t.translation[self.axis] - f.translation[self.axis], self.sdev)
+
+
+class MixtureProposal:
+    """scalismo MixtureProposal with transition probability [SCALISMO-RECALL]."""
+
+    def __init__(self, components: Sequence[Tuple[float, object]], rnd: Random):
+        tot = float(sum(w for w, _ in components))
+        self.factors = [w / tot for w, _ in components]
+        self.generators = [g for _, g in components]
+        self.cumulative = list(np.cumsum(self.factors))
+        self.rnd = rnd
+
+    def propose(self, current):
+        r = self.rnd.nextDouble()
+        i = next((k for k, c in enumerate(self.cumulative) if c >= r), len(self.generators) - 1)
+        return self.generators[i].propose(current)
+
+    def logTransitionProbability(self, frm, to) -> float:
+        ts = [g.logTransitionProbability(frm, to) for g in self.generators]
+        if any(math.isnan(t) for t in ts):
+            raise ArithmeticError("NaN transition probability encountered!")
+        s = sum(f * math.exp(t) for f, t in zip(self.factors, ts))
+        return math.log(s) if s > 0 else -math.inf
+
+
+class Generator:
+    """The reference's stock random-walk mixtures (Generator.scala:25-88)."""
+
+    defaultTranslation = 0.1
+    defaultRotation = 0.01
+
+    def __init__(self, algorithm: GingrAlgorithm, rnd: Random):
+        self.algorithm, self.rnd = algorithm, rnd
+
+    def RandomShape(self, steps: Sequence[float] = (1.0, 0.1, 0.01)) -> MixtureProposal:
+        return MixtureProposal([(1.0 / len(steps), RandomShapeUpdateProposal(self.algorithm, d, self.rnd, f"RandomShape-{d}"))
+                                for d in steps], self.rnd)
+
+    def RandomRotation(self, rotYaw=None, rotPitch=None, rotRoll=None) -> MixtureProposal:
+        y, p, r = (self.defaultRotation if v is None else v for v in (rotYaw, rotPitch, rotRoll))
+        return MixtureProposal([(0.5, GaussianAxisRotationProposal(self.algorithm, y, YawAxis, self.rnd, f"RotationYaw-{y}")),
+                                (0.5, GaussianAxisRotationProposal(self.algorithm, p, PitchAxis, self.rnd, f"RotationPitch-{p}")),
+                                (0.5, GaussianAxisRotationProposal(self.algorithm, r, RollAxis, self.rnd, f"RotationRoll-{r}"))],
+                               self.rnd)
+
+    def RandomTranslation(self, transX=None, transY=None, transZ=None) -> MixtureProposal:
+        x, y, z = (self.defaultTranslation if v is None else v for v in (transX, transY, transZ))
+        return MixtureProposal([(0.5, GaussianAxisTranslationProposal(self.algorithm, x, 0, self.rnd, f"TranslationX-{x}")),
+                                (0.5, GaussianAxisTranslationProposal(self.algorithm, y, 1, self.rnd, f"TranslationY-{y}")),
+                                (0.5, GaussianAxisTranslationProposal(self.algorithm, z, 2, self.rnd, f"TranslationZ-{z}"))],
+                               self.rnd)
+
+    def RandomPose(self, **kw) -> MixtureProposal:
+        rot = {k: v for k, v in kw.items() if k.startswith("rot")}
+        tr = {k: v for k, v in kw.items() if k.startswith("trans")}
+        return MixtureProposal([(0.5, self.RandomRotation(**rot)), (0.5, self.RandomTranslation(**tr))], self.rnd)
+
+    def DefaultRandom(self) -> MixtureProposal:
+        return MixtureProposal([(0.5, self.RandomPose()), (0.5, self.RandomShape())], self.rnd)
+
+
+class GeneratorWrapperStochastic:
+    """The informed proposal: update(current, probabilistic = true); transition density from the posterior of `from`."""
+
+    def __init__(self, algorithm: GingrAlgorithm, rnd: Random, generatedBy: str = "InformedProposal"):
+        self.algorithm, self.rnd, self.generatedBy = algorithm, rnd, generatedBy
+        self._memo = _Memoize(lambda pair: self.algorithm.logTransitionProbability(pair[0], pair[1]), 1)
+
+    def propose(self, current):
+        new = self.algorithm.update(current, True, self.rnd.scalaRandom)
+        out = new.updateGeneral(dataclasses.replace(new.general, generatedBy=self.generatedBy))
+        self.algorithm._device_state_token = id(out)
+        self.algorithm._keepalive = out
+        return out
+
+    def logTransitionProbability(self, frm, to) -> float:
+        return self.algorithm.logTransitionProbability(frm, to)
+
+
+class GeneratorWrapperDeterministic:
+    def __init__(self, algorithm: GingrAlgorithm, generatedBy: str = "Deterministic"):
+        self.algorithm, self.generatedBy = algorithm, generatedBy
+
+    def propose(self, current):
+        new = self.algorithm.update(current, False)
+        out = new.updateGeneral(dataclasses.replace(new.general, generatedBy=self.generatedBy))
+        self.algorithm._device_state_token = id(out)
+        self.algorithm._keepalive = out
+        return out
+
+    def logTransitionProbability(self, frm, to) -> float:
+        return -math.inf
+
+
+# ------------------------------------------------------------------------------------------------------------ the chain
+class BestAndCurrentSampleLogger:
+    def __init__(self, evaluator):
+        self.evaluator, self._best, self._bestValue, self._current = evaluator, None, None, None
+
+    def logState(self, sample):
+        v = self.evaluator.logValue(sample)
+        if self._best is None or v > self._bestValue:
+            self._best, self._bestValue = sample, v
+        self._current = sample
+
+    def currentSample(self):
+        return self._current
+
+    def currentBestSample(self):
+        return self._best
+
+    def currentBestValue(self):
+        return self._bestValue
+
+
+class MetropolisHastings:
+    """scalismo.sampling.algorithms.MetropolisHastings [SCALISMO-RECALL]."""
+
+    def __init__(self, generator, evaluator, rnd: Random):
+        self.generator, self.evaluator, self.rnd = generator, evaluator, rnd
+
+    def logTransitionRatio(self, start, end) -> float:
+        fw = self.generator.logTransitionProbability(start, end)
+        bw = self.generator.logTransitionProbability(end, start)
+        if math.isnan(fw) or math.isnan(bw):
+            raise ArithmeticError("NaN transition probability encountered!")
+        if fw == -math.inf and bw == -math.inf:
+            return 0.0
+        return fw - bw
+
+    def next(self, current, logger=None):
+        proposal = self.generator.propose(current)
+        currentP = self.evaluator.logValue(current)
+        proposalP = self.evaluator.logValue(proposal)
+        t = self.logTransitionRatio(current, proposal)
+        a = proposalP - currentP - t
+        if a > 0.0 or self.rnd.nextDouble() < math.exp(a):
+            if logger is not None:
+                logger.accept(current, proposal, self.generator, self.evaluator)
+            return proposal
+        if logger is not None:
+            logger.reject(current, proposal, self.generator, self.evaluator)
+        return current
+
+
+def generatorCombined(algorithm: GingrAlgorithm, probabilisticSettings: Optional[ProbabilisticSettings], mixing, rnd: Random):
+    """GingrAlgorithm.generatorCombined (GingrAlgorithm.scala:177-190)."""
+    if probabilisticSettings is None:
+        return GeneratorWrapperDeterministic(algorithm, algorithm.name)
+    mix = mixing if mixing is not None else Generator(algorithm, rnd).DefaultRandom()
+    informed = GeneratorWrapperStochastic(algorithm, rnd, algorithm.name)
+    w = probabilisticSettings.randomMixture
+    return MixtureProposal([(w, mix), (1.0 - w, informed)], rnd)
+
+
+def run(algorithm: GingrAlgorithm, initialState, acceptRejectLogger=None, callBackLogger: Optional[Callable] = None,
+        probabilisticSettings: Optional[ProbabilisticSettings] = None, generators=None, rnd: Optional[Random] = None):
+    """GingrAlgorithm.run (GingrAlgorithm.scala:115-175).  The chain yields the initial state first, so take(maxIterations)
+    makes maxIterations - 1 Metropolis-Hastings steps.  Deterministic (no settings): every proposal is accepted, the run stops
+    on convergence or ModelFlexibilityError and returns the last state; probabilistic: stops on ModelFlexibilityError only and
+    returns the best state under the evaluator."""
+    rnd = rnd if rnd is not None else Random(0)
+    probabilistic = probabilisticSettings is not None
+    settings = probabilisticSettings if probabilistic else ProbabilisticSettings(AcceptAll(), 0.0)
+    evaluator = EvaluatorWrapper(probabilistic, settings.evaluators)
+    generator = generatorCombined(algorithm, probabilisticSettings, generators, rnd)
+    best = BestAndCurrentSampleLogger(evaluator)
+    chain = MetropolisHastings(generator, evaluator, rnd)
+    if acceptRejectLogger is not None:
+        acceptRejectLogger.accept(initialState, initialState, generator, evaluator)
+    state, last_general, converged, k = initialState, None, False, 0
+    while True:
+        if callBackLogger is not None:
+            callBackLogger(state)
+        best.logState(state)
+        if not probabilistic and last_general is not None:
+            converged = bool(state.config.converged(last_general, state.general, state.config.threshold))
+        error = state.general.status == FittingStatuses.ModelFlexibilityError
+        last_general = state.general
+        k += 1
+        if converged or error or k >= state.config.maxIterations:
+            break
+        state = chain.next(state, acceptRejectLogger)
+    fit = best.currentBestSample() if probabilistic else best.currentSample()
+    if fit.general.status == FittingStatuses.None_:
+        fit = fit.updateGeneral(fit.general.updateStatus(FittingStatuses.Converged if converged else FittingStatuses.MaxIteration))
+    return fit
+
+
+# ------------------------------------------------------------------------------------------------------------ metrics
+@dataclasses.dataclass(frozen=True)
+class TriangleMesh3D:
+    points: np.ndarray   # (n, 3) float64
+    cells: np.ndarray    # (T, 3) int
+
+
+class RegistrationComparison:
+    """Accuracy metrics of a registration (G/api/helper/RegistrationComparison.scala:22-99); every closest-point scan and
+    reduction runs on the GPU (gingr_mesh_distance_stats)."""
+
+    def __init__(self, ctx: Context, verbose: bool = True):
+        self.ctx, self.verbose = ctx, verbose
+
+    def _stats(self, m1: TriangleMesh3D, m2: TriangleMesh3D, boundary_aware: bool = False):
+        return self.ctx.mesh_distance_stats(m1.points, m2.points, m2.cells, boundary_aware)
+
+    def avgDistance(self, m1: TriangleMesh3D, m2: TriangleMesh3D) -> float:
+        """scalismo MeshMetrics.avgDistance: mean distance of m1's vertices to the surface of m2."""
+        s, _, n, _ = self._stats(m1, m2)
+        return s / n
+
+    def maxDistance(self, m1: TriangleMesh3D, m2: TriangleMesh3D) -> float:
+        return self._stats(m1, m2)[1]
+
+    def hausdorffDistance(self, m1: TriangleMesh3D, m2: TriangleMesh3D) -> float:
+        return max(self.maxDistance(m1, m2), self.maxDistance(m2, m1))
+
+    def evaluateReconstruction2GroundTruth(self, id: str, reconstruction: TriangleMesh3D, groundTruth: TriangleMesh3D):
+        avg = self.avgDistance(reconstruction, groundTruth)
+        hd = self.hausdorffDistance(reconstruction, groundTruth)
+        md = self.maxDistance(reconstruction, groundTruth)
+        if self.verbose:
+            print(f"ID: {id} average2surface: {avg} max: {md}, hausdorff: {hd}")
+        return avg, md, hd
+
+    def evaluateReconstruction2GroundTruthDouble(self, id: str, reconstruction: TriangleMesh3D, groundTruth: TriangleMesh3D):
+        avg = (self.avgDistance(reconstruction, groundTruth) + self.avgDistance(groundTruth, reconstruction)) / 2.0
+        hd = self.hausdorffDistance(reconstruction, groundTruth)
+        if self.verbose:
+            print(f"ID: {id} average2surface: {avg} hausdorff: {hd}")
+        return avg, hd
+
+    def avgDistanceBoundaryAware(self, m1: TriangleMesh3D, m2: TriangleMesh3D) -> Tuple[float, float]:
+        s, mx, n, _ = self._stats(m1, m2, True)
+        return s / n, mx
+
+    def evaluateReconstruction2GroundTruthBoundaryAware(self, id: str, reconstruction: TriangleMesh3D, groundTruth: TriangleMesh3D):
+        a1, m1 = self.avgDistanceBoundaryAware(reconstruction, groundTruth)
+        a2, m2 = self.avgDistanceBoundaryAware(groundTruth, reconstruction)
+        avg, mx = (a1 + a2) / 2.0, max(m1, m2)
+        if self.verbose:
+            print(f"ID: {id} average2surface: {avg} max: {mx}")
+        return avg, mx

@@ -238,6 +238,26 @@ int gingr_fitter_posterior_logpdf_icp_surface(gingr_fitter *f, const gingr_icp_p
 /* correspondences of the last surface phase 0: closest surface point [3 M] and weight in {0, 1} [M] per model vertex */
 int gingr_fitter_get_surface_correspondence(gingr_fitter *f, double *cp_xyz, double *w);
 
+/* ---- surface distance statistics ("the same query inside IndependentPointDistanceEvaluator") ----
+ * d_i = |p_i - closestPointOnSurface(p_i)| reduced on the device: out = {sum d, max d, number of points counted,
+ * sum of log N(d; 0, sdev)} (the last is 0 when sdev == 0; breeze Gaussian(0, sdev).logPdf).
+ * gingr_fitter_surface_distance_stats works on the fitter's CURRENT state (meshes from gingr_fitter_set_meshes):
+ *   direction 0: the first n_points vertices of the current fit (0 = all; `points` must be NULL) against the target surface
+ *                = IndependentPointDistanceEvaluator.distModelToTarget
+ *                  (G/api/sampling/evaluators/IndependentPointDistanceEvaluator.scala:54-60; with numberOfPointsForComparison
+ *                  the reference walks the decimated instance's point ids 0..n'-1 over the full sample, :49-50);
+ *   direction 1: `points` [3 n_points] (NULL = every target vertex) against the surface of the current fit
+ *                = distTargetToModel (:62-67).
+ * boundary_aware != 0 skips the points whose surface point lies nearest to a boundary vertex of the mesh
+ * (G/api/helper/RegistrationComparison.scala:63-73, avgDistanceBoundaryAware).
+ * gingr_mesh_distance_stats is the same reduction for any point list against any triangle mesh (host arrays):
+ * MeshMetrics.avgDistance = out[0] / out[2], RegistrationComparison.maxDistance (:24-35) = out[1], Hausdorff = the larger of
+ * the two directed maxima.  Both calls synchronise. */
+int gingr_fitter_surface_distance_stats(gingr_fitter *f, int32_t direction, int64_t n_points, const double *points,
+                                        int32_t boundary_aware, double sdev, double out[4]);
+int gingr_mesh_distance_stats(gingr_ctx *ctx, int64_t n_points, const double *points, int64_t n_vertices, const double *vertices,
+                              int64_t n_triangles, const int32_t *triangles, int32_t boundary_aware, double sdev, double out[4]);
+
 
 /* ---- probabilistic proposal (single shard) ------------------------------------------------
  * update(current, probabilistic = true): the shape proposal is posterior.sample() instead of posterior.mean

@@ -192,6 +192,21 @@ JFN(jint, fitterGetSurfaceCorrespondence)(JNIEnv *env, jclass, jlong f, jdoubleA
     Pin a(env, cp, false), b(env, w, false);
     return gingr_fitter_get_surface_correspondence(P<gingr_fitter>(f), a.as<double>(), b.as<double>());
 }
+JFN(jint, fitterSurfaceDistanceStats)(JNIEnv *env, jclass, jlong f, jint direction, jlong nPoints, jdoubleArray pts, jint boundaryAware,
+                                      jdouble sdev, jdoubleArray out4) {
+    Pin o(env, out4, false);
+    if (!pts) return gingr_fitter_surface_distance_stats(P<gingr_fitter>(f), direction, nPoints, nullptr, boundaryAware, sdev, o.as<double>());
+    Pin a(env, pts, true);
+    return gingr_fitter_surface_distance_stats(P<gingr_fitter>(f), direction, env->GetArrayLength(pts) / 3, a.as<double>(), boundaryAware,
+                                               sdev, o.as<double>());
+}
+JFN(jint, meshDistanceStats)(JNIEnv *env, jclass, jlong ctx, jdoubleArray pts, jdoubleArray verts, jintArray tris, jint boundaryAware,
+                             jdouble sdev, jdoubleArray out4) {
+    const jlong np = env->GetArrayLength(pts) / 3, nv = env->GetArrayLength(verts) / 3, nt = env->GetArrayLength(tris) / 3;
+    Pin a(env, pts, true), b(env, verts, true), c(env, tris, true), o(env, out4, false);
+    return gingr_mesh_distance_stats(P<gingr_ctx>(ctx), np, a.as<double>(), nv, b.as<double>(), nt, c.as<int32_t>(), boundaryAware, sdev,
+                                     o.as<double>());
+}
 JFN(jlong, gpmmBuildGaussian)(JNIEnv *env, jclass, jlong ctx, jlong mTotal, jdoubleArray ref, jdoubleArray sigmas,
                                jdoubleArray scalings, jdouble relTol, jint maxRank, jlong rowBegin, jlong rowEnd) {
     const jint nk = env->GetArrayLength(sigmas);

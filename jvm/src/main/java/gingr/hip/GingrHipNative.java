@@ -64,6 +64,11 @@ public final class GingrHipNative {
                                                              double[] meshXyz, double[] out1);
     /** cpXyz [3 M], w [M] in {0, 1} of the last surface correspondence */
     public static native int fitterGetSurfaceCorrespondence(long fitter, double[] cpXyz, double[] w);
+    // gingr_fitter_surface_distance_stats / gingr_mesh_distance_stats: out4 = {sum d, max d, count, sum log N(d; 0, sdev)}
+    public static native int fitterSurfaceDistanceStats(long fitter, int direction, long nPoints, double[] pointsXyzOrNull,
+                                                        int boundaryAware, double sdev, double[] out4);
+    public static native int meshDistanceStats(long ctx, double[] pointsXyz, double[] verticesXyz, int[] triangles, int boundaryAware,
+                                               double sdev, double[] out4);
 
     // ---- GPMM construction in HBM (GPMMTriangleMesh3D.Gaussian / GaussianMixture / AutomaticGaussian, automaticGPMMfromTemplate)
     /** returns the gingr_model handle (0 on failure; see lastError); maxRank <= 0 = model limit; rowEnd <= 0 = all rows */

@@ -79,6 +79,19 @@ final class HipSession(device: Int) extends AutoCloseable {
   }
 
   /** Pushes (alpha, pose, sigma2), runs ONE update, pulls the result.  Returns (alpha, pose11, status). */
+  /** push the parameters of `general` (the device re-instantiates the fit) and run a query on the fitter */
+  def withState(general: GeneralRegistrationState, run: Long => Int): Unit = {
+    val mp = general.modelParameters
+    val a = mp.pose.rotation.angles
+    val c = mp.pose.rotation.center
+    val t = mp.pose.translation
+    val pose = Array(a.phi, a.theta, a.psi, c.x, c.y, c.z, t.x, t.y, t.z, mp.scale.s, general.sigma2)
+    val status = if (general.status == FittingStatuses.ModelFlexibilityError) 3 else 0
+    bind(general, useLandmarks = false)
+    check(GingrHipNative.fitterSetState(fitter, mp.shape.parameters.toArray, pose, general.iteration, status), "gingr_fitter_set_state")
+    check(run(fitter), "gingr_fitter query")
+  }
+
   def updateOnce(general: GeneralRegistrationState, run: Long => Int): (Array[Double], Array[Double], Int) = {
     val mp = general.modelParameters
     val a = mp.pose.rotation.angles
@@ -294,5 +307,54 @@ object HipGPMM {
     finally GingrHipNative.ctxDestroy(ctx)
     val maxDist = ext(0)
     GaussianMixture(reference, Seq((maxDist / 4.0, maxDist / 8.0), (maxDist / 8.0, maxDist / 16.0)), relativeTolerance)
+  }
+}
+
+// ------------------------------------------------------------------------------------ surface likelihood and metrics
+/** IndependentPointDistanceEvaluator (gingr/api/sampling/evaluators/IndependentPointDistanceEvaluator.scala:35-84) with the
+  * closest-point scan and the reduction on the GPU.  Drop-in for the case the reference uses, likelihoodModel = Gaussian(0, sdev)
+  * (gingr/api/sampling/Evaluator.scala:47) without decimation; the state is evaluated through the session of the algorithm
+  * that produced it (model, target and meshes are already resident). */
+case class HipIndependentPointDistanceEvaluator[State <: GingrRegistrationState[State]](
+  session: HipSession,
+  sdev: Double,
+  evaluationMode: gingr.api.sampling.evaluators.EvaluationMode
+) extends scalismo.sampling.DistributionEvaluator[State]
+    with gingr.api.sampling.evaluators.EvaluationCaching[State] {
+  import gingr.api.sampling.evaluators._
+  private def stats(sample: State, direction: Int): Double = {
+    session.bindMeshes(sample.general)
+    val out = new Array[Double](4)
+    session.withState(sample.general, f =>
+      GingrHipNative.fitterSurfaceDistanceStats(f, direction, 0L, null, 0, sdev, out))
+    out(3)
+  }
+  override def computeLogValue(sample: State): Double = evaluationMode match {
+    case ModelToTargetEvaluation => stats(sample, 0)
+    case TargetToModelEvaluation => stats(sample, 1)
+    case SymmetricEvaluation     => 0.5 * stats(sample, 0) + 0.5 * stats(sample, 1)
+  }
+}
+
+/** RegistrationComparison (gingr/api/helper/RegistrationComparison.scala:22-99) on the GPU. */
+object HipRegistrationComparison {
+  private def flat(m: TriangleMesh[_3D]): Array[Int] =
+    m.triangulation.triangles.flatMap(t => Seq(t.ptId1.id, t.ptId2.id, t.ptId3.id)).toArray
+  /** (sum, max, count) of the distances from m1's vertices to the surface of m2 */
+  def stats(m1: TriangleMesh[_3D], m2: TriangleMesh[_3D], boundaryAware: Boolean = false, device: Int = 0): (Double, Double, Int) = {
+    val ctx = GingrHipNative.ctxCreate(device)
+    require(ctx != 0L, "gingr_ctx_create failed: no usable GPU")
+    try {
+      val out = new Array[Double](4)
+      val rc = GingrHipNative.meshDistanceStats(ctx, HipLayout.mesh(m1), HipLayout.mesh(m2), flat(m2), if (boundaryAware) 1 else 0, 0.0, out)
+      require(rc == 0, s"gingr_mesh_distance_stats failed: ${GingrHipNative.lastError(ctx)}")
+      (out(0), out(1), out(2).toInt)
+    } finally GingrHipNative.ctxDestroy(ctx)
+  }
+  def avgDistance(m1: TriangleMesh[_3D], m2: TriangleMesh[_3D]): Double = { val (s, _, n) = stats(m1, m2); s / n }
+  def maxDistance(m1: TriangleMesh[_3D], m2: TriangleMesh[_3D]): Double = stats(m1, m2)._2
+  def hausdorffDistance(m1: TriangleMesh[_3D], m2: TriangleMesh[_3D]): Double = math.max(maxDistance(m1, m2), maxDistance(m2, m1))
+  def avgDistanceBoundaryAware(m1: TriangleMesh[_3D], m2: TriangleMesh[_3D]): (Double, Double) = {
+    val (s, mx, n) = stats(m1, m2, boundaryAware = true); (s / n, mx)
   }
 }

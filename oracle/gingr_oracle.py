@@ -942,3 +942,246 @@ def icp_reversed_update(model: PDM, tmpl_tris, target: np.ndarray, tgt_tris, st:
     var = np.full(keep.shape[0], st.sigma2)
     s2n = icp_update_sigma2(st.sigma2, initial_sigma, end_sigma, max_iterations)
     return update_from_observations(model, st, tid[keep], pts[keep], var, s2n, landmarks, None), (tid, w)
+
+
+# --------------------------------------------------------------------------
+# (f2b) surface distances: the likelihood of the probabilistic path and the accuracy metrics
+#     [G/api/sampling/evaluators/IndependentPointDistanceEvaluator.scala:54-82, G/api/sampling/Evaluator.scala:41-60,
+#      G/api/sampling/evaluators/ModelEvaluator.scala:25-33, G/api/helper/RegistrationComparison.scala:24-99]
+#     [BREEZE (transitive, not vendored) -- restated: Gaussian(mu, sigma).logPdf(x) = -((x - mu) / sigma)^2 / 2
+#        - (log(sqrt(2 pi)) + log(sigma)).
+#      SCALISMO 1.0-RC1 -- restated: MeshMetrics.avgDistance(m1, m2) = mean over the vertices p of m1 of
+#        |p - m2.closestPointOnSurface(p)|; MeshMetrics.hausdorffDistance = max of the two directed maxima;
+#        MultivariateNormalDistribution(0, I_r).logpdf(a) = -a.a / 2 - r log(2 pi) / 2.]
+# --------------------------------------------------------------------------
+
+def gaussian_logpdf(x, sdev: float):
+    """breeze.stats.distributions.Gaussian(0, sdev).logPdf(x)."""
+    d = np.asarray(x, dtype=np.float64) / sdev
+    return -d * d / 2.0 - (math.log(math.sqrt(2.0 * math.pi)) + math.log(sdev))
+
+
+def surface_distances(points: np.ndarray, verts: np.ndarray, tris: np.ndarray, boundary_aware: bool = False):
+    """|p - closestPointOnSurface(p)| for every row of `points`, and the mask of the rows that count: all of them, or with
+    boundary_aware only those whose surface point lies nearest to a non-boundary vertex (RegistrationComparison.scala:63-73)."""
+    cp, d2 = mesh_closest_point(np.asarray(points, dtype=np.float64), verts, tris)
+    keep = np.ones(cp.shape[0], dtype=bool)
+    if boundary_aware:
+        idx, _, _ = icp_closest_point(cp, verts)
+        keep = ~boundary_vertices(verts.shape[0], tris)[idx]
+    return np.sqrt(d2), keep
+
+
+def surface_distance_stats(points, verts, tris, boundary_aware: bool = False, sdev: float = 0.0):
+    """(sum of distances, largest distance, number of points counted, sum of log N(d; 0, sdev)), sums in point order."""
+    d, keep = surface_distances(points, verts, tris, boundary_aware)
+    d = d[keep]
+    s = 0.0
+    for v in d:
+        s += float(v)
+    ll = 0.0
+    if sdev > 0:
+        for v in gaussian_logpdf(d, sdev):
+            ll += float(v)
+    return s, (float(d.max()) if d.size else 0.0), int(d.size), ll
+
+
+def independent_point_distance_logvalue(fit, model_tris, target, target_tris, sdev: float, mode: str = "ModelToTarget",
+                                        n_model_points: Optional[int] = None, target_points=None) -> float:
+    """IndependentPointDistanceEvaluator.computeLogValue (:72-82).  With numberOfPointsForComparison the reference walks the
+    point IDS of the decimated instance over the FULL sample (:49-50,55), i.e. the first n' vertices of the sample, and the
+    POINTS of the decimated target (:49); both selections are inputs here (scalismo's decimation is not restated)."""
+    fit = np.asarray(fit, dtype=np.float64)
+    def m2t():
+        pts = fit if n_model_points is None else fit[:n_model_points]
+        return surface_distance_stats(pts, target, target_tris, False, sdev)[3]
+    def t2m():
+        pts = target if target_points is None else np.asarray(target_points, dtype=np.float64)
+        return surface_distance_stats(pts, fit, model_tris, False, sdev)[3]
+    if mode == "ModelToTarget":
+        return m2t()
+    if mode == "TargetToModel":
+        return t2m()
+    return 0.5 * m2t() + 0.5 * t2m()
+
+
+def model_evaluator_logvalue(alpha: np.ndarray) -> float:
+    """ModelEvaluator.logValue (ModelEvaluator.scala:25-33): log-density of the coefficients under N(0, I_r)."""
+    a = np.asarray(alpha, dtype=np.float64)
+    return float(-0.5 * (a @ a) - 0.5 * a.shape[0] * math.log(2.0 * math.pi))
+
+
+def avg_distance(m1_verts, m2_verts, m2_tris) -> float:
+    s, _, n, _ = surface_distance_stats(m1_verts, m2_verts, m2_tris)
+    return s / n
+
+
+def max_distance(m1_verts, m2_verts, m2_tris) -> float:
+    """RegistrationComparison.maxDistance (:24-35)."""
+    return surface_distance_stats(m1_verts, m2_verts, m2_tris)[1]
+
+
+def hausdorff_distance(v1, t1, v2, t2) -> float:
+    return max(max_distance(v1, v2, t2), max_distance(v2, v1, t1))
+
+
+def avg_distance_boundary_aware(m1_verts, m2_verts, m2_tris) -> Tuple[float, float]:
+    """RegistrationComparison.avgDistanceBoundaryAware (:63-73): (mean, max) over the points that do not map to a boundary."""
+    s, mx, n, _ = surface_distance_stats(m1_verts, m2_verts, m2_tris, True)
+    return s / n, mx
+
+
+# --------------------------------------------------------------------------
+# (f1b) the Metropolis-Hastings chain around the update map (BASELINE config 5)
+#     [G/api/GingrAlgorithm.scala:115-190, G/api/sampling/Generator.scala:25-88,
+#      G/api/sampling/generators/{RandomShapeUpdateProposal,RandomPoseUpdateProposal,GaussianDenseVectorProposal,
+#      GeneratorWrapperStochastic,GeneratorWrapperDeterministic}.scala, G/api/sampling/loggers/BestAndCurrentSampleLogger.scala]
+#     [SCALISMO 1.0-RC1 MixtureProposal / MetropolisHastings, not vendored -- restated, parity unpinned: first component whose
+#      cumulative normalised weight >= one uniform draw; mixture density = sum of weighted component densities; accept when
+#      a = logp(proposal) - logp(current) - (logq(cur->prop) - logq(prop->cur)) > 0 or uniform < exp(a); the bracket is 0 when
+#      both densities are -inf.]
+#     Random draws come from `rnd` (two numpy generators standing in for scalismo.utils.Random and breeze's FixedSeed basis)
+#     in the reference's call order.
+# --------------------------------------------------------------------------
+
+class ChainRandom:
+    def __init__(self, seed: int, breeze_seed: int = 0):
+        self.scala = np.random.default_rng(seed)
+        self.breeze = np.random.default_rng(breeze_seed)
+
+
+def _reinstantiate(model: PDM, st: State, **changes) -> State:
+    new = dataclasses.replace(st, **changes)
+    new.fit = model_instance_shape_pose_scale(model, new)
+    new.iteration = st.iteration + 1
+    return new
+
+
+def _same_pose_shape(a: State, b: State, skip: str) -> bool:
+    ok = a.scale == b.scale
+    if skip != "shape":
+        ok = ok and np.array_equal(a.alpha, b.alpha)
+    if skip != "translation":
+        ok = ok and np.array_equal(np.asarray(a.translation), np.asarray(b.translation))
+    if skip != "rotation":
+        ok = ok and tuple(a.euler) == tuple(b.euler) and np.array_equal(np.asarray(a.center), np.asarray(b.center))
+    return ok
+
+
+class _ShapeWalk:
+    def __init__(self, model, sdev, rnd):
+        self.model, self.sdev, self.rnd = model, sdev, rnd
+
+    def propose(self, st):
+        return _reinstantiate(self.model, st, alpha=st.alpha + self.sdev * self.rnd.scala.standard_normal(st.alpha.shape[0]))
+
+    def logq(self, f, t):
+        if not _same_pose_shape(f, t, "shape"):
+            return -math.inf
+        return float(sum(float(gaussian_logpdf(tv - fv, self.sdev)) for tv, fv in zip(t.alpha, f.alpha)))
+
+
+class _RotationWalk:
+    def __init__(self, model, sdev, axis, rnd):
+        self.model, self.sdev, self.axis, self.rnd = model, sdev, axis, rnd       # axis: 0 phi (roll), 1 theta (pitch), 2 psi (yaw)
+
+    def propose(self, st):
+        e = list(st.euler)
+        e[self.axis] = e[self.axis] + float(self.rnd.breeze.standard_normal()) * self.sdev
+        return _reinstantiate(self.model, st, euler=tuple(e))
+
+    def logq(self, f, t):
+        if not _same_pose_shape(f, t, "rotation") or not np.array_equal(np.asarray(f.center), np.asarray(t.center)):
+            return -math.inf
+        return float(gaussian_logpdf(t.euler[self.axis] - f.euler[self.axis], self.sdev))
+
+
+class _TranslationWalk:
+    def __init__(self, model, sdev, axis, rnd):
+        self.model, self.sdev, self.axis, self.rnd = model, sdev, axis, rnd
+
+    def propose(self, st):
+        self.rnd.breeze.standard_normal()                                  # discarded sample (RandomPoseUpdateProposal.scala:89)
+        t = np.array(st.translation, dtype=np.float64)
+        t[self.axis] = t[self.axis] + float(self.rnd.breeze.standard_normal()) * self.sdev
+        return _reinstantiate(self.model, st, translation=t)
+
+    def logq(self, f, t):
+        if not _same_pose_shape(f, t, "translation"):
+            return -math.inf
+        return float(gaussian_logpdf(t.translation[self.axis] - f.translation[self.axis], self.sdev))
+
+
+class _Mixture:
+    def __init__(self, comps, rnd):
+        tot = sum(w for w, _ in comps)
+        self.w = [w / tot for w, _ in comps]
+        self.g = [g for _, g in comps]
+        self.cum = list(np.cumsum(self.w))
+        self.rnd = rnd
+
+    def propose(self, st):
+        r = float(self.rnd.scala.random())
+        i = next((k for k, c in enumerate(self.cum) if c >= r), len(self.g) - 1)
+        return self.g[i].propose(st)
+
+    def logq(self, f, t):
+        s = sum(w * math.exp(g.logq(f, t)) for w, g in zip(self.w, self.g))
+        return math.log(s) if s > 0 else -math.inf
+
+
+class _Informed:
+    def __init__(self, update_fn, logq_fn, rank, rnd):
+        self.update_fn, self.logq_fn, self.rank, self.rnd = update_fn, logq_fn, rank, rnd
+
+    def propose(self, st):
+        return self.update_fn(st, self.rnd.scala.standard_normal(self.rank))
+
+    def logq(self, f, t):
+        return self.logq_fn(f, t)
+
+
+def default_random_generator(model: PDM, rnd: ChainRandom) -> _Mixture:
+    """Generator.DefaultRandom (Generator.scala:80-86) with the stock step sizes (:27-28,31)."""
+    rot = _Mixture([(0.5, _RotationWalk(model, 0.01, 2, rnd)), (0.5, _RotationWalk(model, 0.01, 1, rnd)),
+                    (0.5, _RotationWalk(model, 0.01, 0, rnd))], rnd)
+    tr = _Mixture([(0.5, _TranslationWalk(model, 0.1, a, rnd)) for a in range(3)], rnd)
+    pose = _Mixture([(0.5, rot), (0.5, tr)], rnd)
+    shape = _Mixture([(1.0 / 3.0, _ShapeWalk(model, d, rnd)) for d in (1.0, 0.1, 0.01)], rnd)
+    return _Mixture([(0.5, pose), (0.5, shape)], rnd)
+
+
+def mh_run(model: PDM, st0: State, max_iterations: int, update_fn, logq_fn, logvalue_fn, random_mixture: float,
+           rnd: ChainRandom):
+    """GingrAlgorithm.run with probabilisticSettings (GingrAlgorithm.scala:115-175): returns (best state, list of chain states,
+    list of accept flags).  update_fn(st, z) = the informed proposal, logq_fn(from, to) = its transition log-density,
+    logvalue_fn(st) = the evaluator's log value."""
+    gen = _Mixture([(random_mixture, default_random_generator(model, rnd)),
+                    (1.0 - random_mixture, _Informed(update_fn, logq_fn, model.rank, rnd))], rnd)
+    cache = {}
+
+    def logvalue(st):
+        if id(st) not in cache:
+            cache[id(st)] = (st, logvalue_fn(st))
+        return cache[id(st)][1]
+
+    states, accepts = [st0], []
+    best, best_v = st0, logvalue(st0)
+    st = st0
+    k = 1
+    while st.status != STATUS_MODEL_FLEXIBILITY_ERROR and k < max_iterations:
+        prop = gen.propose(st)
+        cur_p, prop_p = logvalue(st), logvalue(prop)
+        fw, bw = gen.logq(st, prop), gen.logq(prop, st)
+        t = 0.0 if (fw == -math.inf and bw == -math.inf) else fw - bw
+        a = prop_p - cur_p - t
+        acc = a > 0.0 or float(rnd.scala.random()) < math.exp(a)
+        accepts.append(bool(acc))
+        if acc:
+            st = prop
+        states.append(st)
+        v = logvalue(st)
+        if v > best_v:
+            best, best_v = st, v
+        k += 1
+    return best, states, accepts
