@@ -12,6 +12,7 @@ from .api import (  # noqa: F401
 )
 from ._native import GingrNativeError  # noqa: F401
 from . import io  # noqa: F401  (file / wire formats shared with the Scala host)
+from . import classic  # noqa: F401  (the reference's other/ CPD family on the device)
 from . import sampling  # noqa: F401  (Metropolis-Hastings chain, evaluators, proposals, accuracy metrics)
 from .sampling import (  # noqa: F401
     IndependentPointDistanceEvaluator, IndependentPoints, ModelEvaluator, ProbabilisticSettings, RegistrationComparison,

@@ -77,6 +77,11 @@ SIGNATURES = {
     "gingr_fitter_icp_surface_phase_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32]),
     "gingr_fitter_get_surface_correspondence": (c_int, [c_void_p, _dp, _dp]),
     "gingr_fitter_surface_distance_stats": (c_int, [c_void_p, c_int32, c_int64, _dp, c_int32, c_double, _dp]),
+    "gingr_classic_cpd_create": (c_int, [c_void_p, c_int32, c_int64, _dp, c_int64, _dp, c_double, c_double, c_double, POINTER(c_void_p)]),
+    "gingr_classic_cpd_destroy": (None, [c_void_p]),
+    "gingr_classic_cpd_iterate": (c_int, [c_void_p, c_int32]),
+    "gingr_classic_cpd_get": (c_int, [c_void_p, _dp, POINTER(c_double), _dp, _dp]),
+    "gingr_classic_cpd_set": (c_int, [c_void_p, _dp, c_double]),
     "gingr_mesh_distance_stats": (c_int, [c_void_p, c_int64, _dp, c_int64, _dp, c_int64, POINTER(c_int32), c_int32, c_double, _dp]),
     "gingr_fitter_update_icp_surface_sample_async": (c_int, [c_void_p, POINTER(IcpParams), _dp]),
     "gingr_fitter_posterior_logpdf_icp_surface": (c_int, [c_void_p, POINTER(IcpParams), _dp, POINTER(c_double)]),

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         // quarter of the tile x owned slot: skip what provably receives exact zeros
         for (int sub = 0; sub * 64 < cnt; ++sub) {
             const int q0 = sub * 64, q1 = min(cnt, q0 + 64);
-            const unsigned mask = quarter_mask<PT>(sown, fit_sub + ((ib / kTile) * 4 + sub) * 6, -c);
+            const unsigned mask = quarter_mask<PT>(sown, fit_sub + (ib / 64 + sub) * 6, -c);
             if (!mask) continue;
             if (expand) {
                 if (mask == kAllSlots)
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
         // quarter of the tile x owned slot: skip what provably receives exact zeros
         for (int sub = 0; sub * 64 < cnt; ++sub) {
             const int q0 = sub * 64, q1 = min(cnt, q0 + 64);
-            const unsigned mask = quarter_mask<PT>(sown, tgt_sub + ((jb / kTile) * 4 + sub) * 6, -c);
+            const unsigned mask = quarter_mask<PT>(sown, tgt_sub + (jb / 64 + sub) * 6, -c);
             if (!mask) continue;
             if (expand) {
                 if (mask == kAllSlots)
@@ -904,25 +904,38 @@ inline int rowstats_pt(int64_t rows) { return (kPT > 2 && rows <= kSmallShardRow
 // on shards of 1/1, 1/2, 1/4, 1/8 of the rows (profiles/r01_chunk_length_sweep.txt): two tiles per chunk (~4900 workgroups)
 // is 5 % faster than five (~2000) on the whole cloud, one tile is best on the shards.
 constexpr int kTargetBlocks = 5120;
+#ifndef GINGR_MIN_CHUNK
+#define GINGR_MIN_CHUNK 256
+#endif
+constexpr int kMinChunk = GINGR_MIN_CHUNK;  // shortest chunk the planner picks by itself (64, 128 or 256 points)
 
-// split `stream_len` into chunks so that block_cols * nchunks ~ kTargetBlocks; chunk length is a multiple of kTile.
-// `tiles_override` > 0 (developer knob, environment GINGR_COLSUM_TILES / GINGR_ROWSTATS_TILES) fixes the tiles per chunk.
+// split `stream_len` into chunks so that block_cols * nchunks ~ kTargetBlocks.  A chunk is a whole number of tiles, or -- when
+// even one tile per chunk leaves too few workgroups (small shards) -- a half or a quarter of a tile: 64-point quarters are the
+// unit of the culling boxes, and a chunk that divides a tile never straddles two tiles' boxes.
+// `quarters_override` > 0 (developer knob, environment GINGR_COLSUM_TILES / GINGR_ROWSTATS_TILES, in tiles, may be 0.25 / 0.5)
+// fixes the chunk length.
 inline void plan_chunks(int64_t owned, int owned_per_block, int64_t stream_len, int *nchunks, int64_t *chunk_len,
-                        int tiles_override = 0) {
+                        int quarters_override = 0) {
     const int64_t bx = ceil_div(owned, owned_per_block);
     int64_t want = ceil_div(kTargetBlocks, bx > 0 ? bx : 1);
-    const int64_t max_chunks = ceil_div(stream_len, kTile);
-    if (want > max_chunks) want = max_chunks;
     if (want < 1) want = 1;
-    int64_t len = round_up(ceil_div(stream_len, want), kTile);
-    if (tiles_override > 0) len = (int64_t)tiles_override * kTile;
-    if (len < kTile) len = kTile;
+    int64_t len = round_up(ceil_div(stream_len > 0 ? stream_len : 1, want), 64);
+    if (quarters_override > 0) len = (int64_t)quarters_override * 64;
+    if (len >= kTile)
+        len = round_up(len, kTile);
+    else if (len > 128)
+        len = kTile;
+    else if (len > 64)
+        len = 128;
+    else
+        len = 64;
+    if (quarters_override <= 0 && len < kMinChunk) len = kMinChunk;
     *chunk_len = len;
     *nchunks = (int)ceil_div(stream_len > 0 ? stream_len : 1, len);
 }
-inline int env_tiles(const char *name) {
+inline int env_tiles(const char *name) {  // tiles -> quarters
     const char *e = getenv(name);
-    return e ? atoi(e) : 0;
+    return e ? (int)(atof(e) * 4.0 + 0.5) : 0;
 }
 inline int colsum_tiles_override() {
     static const int v = env_tiles("GINGR_COLSUM_TILES");

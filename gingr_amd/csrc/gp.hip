@@ -14,6 +14,7 @@
 // observation weight, rotation and epilogue touch one contiguous block; rp = rank rounded up to 16 (MFMA tile).
 // All reductions across workgroups go through per-block partials combined in a fixed order (bitwise reproducible).
 #include "gp.h"
+#include "svd3.h"
 
 #include <algorithm>
 #include <type_traits>
@@ -893,6 +894,34 @@ __device__ __forceinline__ void lds_backward(const double *A, int ld, int n, con
     }
 }
 
+// Diagonal block of a blocked Cholesky that runs over many workgroups (classic_cpd.hip): factor the 64 x 64 block k of the
+// row-major matrix Aw in LDS with the building blocks above and invert the factor on the way -- the identity rides along as 64
+// extra rows, which come back as (L^-1 e_c)^T = row c of L^-T.  Aw block <- L (upper part zeroed), Linv[k] <- L^-1 (64 x 64, dense).
+__global__ __launch_bounds__(256) void chol_block64_kernel(double *__restrict__ Aw, int64_t ld, int k, double *__restrict__ Linv,
+                                                           int32_t *__restrict__ flag) {
+    extern __shared__ double lds_sm[];
+    constexpr int n = 64, lda = 65;
+    double *A = lds_sm, *rd = A + 2 * n * lda;
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    double *blk = Aw + ((int64_t)k * n) * ld + (int64_t)k * n;
+    for (int e = tid; e < n * n; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        A[r * lda + c] = blk[(int64_t)r * ld + c];
+        A[(n + r) * lda + c] = r == c ? 1.0 : 0.0;
+    }
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    lds_cholesky(A, lda, n, rd, &bad, n);
+    double *li = Linv + (int64_t)k * n * n;
+    for (int e = tid; e < n * n; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        blk[(int64_t)r * ld + c] = c <= r ? A[r * lda + c] : 0.0;
+        li[e] = c <= r ? A[(n + c) * lda + r] : 0.0;
+    }
+    if (tid == 0 && bad) *flag = GINGR_ERR_NOT_SPD;
+}
+
 // a = (I + G)^-1 rhs; with zrand != nullptr a posterior SAMPLE of the coefficients: a + L^-T z, z ~ N(0, I)
 // (Cov = L^-T L^-1 = (I + G)^-1, the posterior covariance of the coefficients: the same distribution as
 //  posterior.sample() of scalismo's SVD-parameterised posterior model, G/api/GingrAlgorithm.scala:211).
@@ -1057,68 +1086,6 @@ __global__ __launch_bounds__(256) void coeff_solve_kernel(int r, int rp, const d
     const int i = blockIdx.x * 16 + (threadIdx.x >> 4), lane16 = threadIdx.x & 15;
     const double v = binv_row_apply16(Binv, p, r, rp, i, lane16);
     if (i < rp && lane16 == 0) out[i] = i < r ? v : 0.0;
-}
-
-// one-sided Jacobi SVD of a 3x3 matrix: A = U diag(s) V^T, s descending
-__device__ void svd3(const double Ain[9], double U[9], double s[3], double V[9]) {
-    double A[9];
-    for (int q = 0; q < 9; ++q) {
-        A[q] = Ain[q];
-        V[q] = (q % 4 == 0) ? 1.0 : 0.0;
-    }
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.0;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                double alpha = 0, beta = 0, gamma = 0;
-                for (int i = 0; i < 3; ++i) {
-                    alpha += A[i * 3 + p] * A[i * 3 + p];
-                    beta += A[i * 3 + q] * A[i * 3 + q];
-                    gamma += A[i * 3 + p] * A[i * 3 + q];
-                }
-                const double lim = 1e-17 * sqrt(alpha * beta);
-                if (fabs(gamma) <= lim || gamma == 0.0) continue;
-                off = fmax(off, fabs(gamma) / sqrt(alpha * beta));
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-                for (int i = 0; i < 3; ++i) {
-                    const double ap = A[i * 3 + p], aq = A[i * 3 + q];
-                    A[i * 3 + p] = c * ap - sn * aq;
-                    A[i * 3 + q] = sn * ap + c * aq;
-                    const double vp = V[i * 3 + p], vq = V[i * 3 + q];
-                    V[i * 3 + p] = c * vp - sn * vq;
-                    V[i * 3 + q] = sn * vp + c * vq;
-                }
-            }
-        if (off < 1e-16) break;
-    }
-    double nrm[3];
-    for (int j = 0; j < 3; ++j) nrm[j] = sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
-    int ord[3] = {0, 1, 2};
-    for (int a = 0; a < 2; ++a)
-        for (int b = a + 1; b < 3; ++b)
-            if (nrm[ord[b]] > nrm[ord[a]]) {
-                const int t = ord[a];
-                ord[a] = ord[b];
-                ord[b] = t;
-            }
-    double Vs[9];
-    for (int j = 0; j < 3; ++j) {
-        const int o = ord[j];
-        s[j] = nrm[o];
-        for (int i = 0; i < 3; ++i) {
-            U[i * 3 + j] = nrm[o] > 0 ? A[i * 3 + o] / nrm[o] : 0.0;
-            Vs[i * 3 + j] = V[i * 3 + o];
-        }
-    }
-    for (int q = 0; q < 9; ++q) V[q] = Vs[q];
-    // complete a rank-deficient U to an orthonormal basis (third column = cross product)
-    if (!(s[2] > 1e-300 * s[0])) {
-        U[2] = U[3] * U[7] - U[6] * U[4];
-        U[5] = U[6] * U[1] - U[0] * U[7];
-        U[8] = U[0] * U[4] - U[3] * U[1];
-    }
 }
 
 // sums: [0..2] sum x~, [3..5] sum y~, [6..14] sum y~ x~^T (row-major), [15] sum |x~|^2; x~ = x - c0, y~ = y - c0.
@@ -1612,6 +1579,17 @@ void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, 
 }
 
 int64_t posterior_work_doubles(int32_t rp) { return (int64_t)lds_solve_doubles(rp, kNB); }
+
+void launch_chol_block64(gingr_ctx *ctx, double *Aw, int64_t ld, int k, double *Linv, int32_t *flag) {
+    const size_t lds = lds_solve_doubles(64, 64) * sizeof(double);
+    static bool granted = false;  // the attribute is per function, not per launch
+    if (!granted) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_block64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        granted = true;
+    }
+    hipLaunchKernelGGL(chol_block64_kernel, dim3(1), dim3(256), lds, ctx->stream, Aw, ld, k, Linv, flag);
+}
 
 void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *zrand,
                             double *work, double *a, DevState *st) {

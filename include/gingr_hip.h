@@ -299,6 +299,24 @@ int gingr_ctx_timing_enable(gingr_ctx *ctx, int32_t enable);
 int gingr_ctx_timing_read(gingr_ctx *ctx, int32_t which, double *total_ms, int64_t *launches);
 int gingr_ctx_timing_reset(gingr_ctx *ctx);
 
+/* ---- classic Coherent Point Drift (the reference's `other/` CPD family as a second consumer of the
+ * affinity statistics and of the Gaussian kernel block) ----------------------------------------------------------------------
+ * One handle = CPDFactory(templatePoints, lambda, beta, w).registerRigidly / registerAffine / registerNonRigidly(targetPoints)
+ * (G/other/algorithms/cpd/CPDFactory.scala:28-80); kind 0 rigid (similarity: s, R, t; RigidCPD.scala:107-137), 1 affine
+ * (AffineCPD.scala:35-60), 2 non-rigid (G + lambda sigma2 diag(1/P1)) W = diag(1/P1) P X - Y, TY = Y + G W
+ * (NonRigidCPD.scala:45-88).  The state (TY, sigma2) of RigidCPD.Registration (:59-83) lives on the device; it starts at
+ * (template, sum |y_m - x_n|^2 / (3 M N)).  gingr_classic_cpd_iterate runs n Iteration()s (:85-88) back to back and synchronises;
+ * the caller owns the convergence test |sigma2' - sigma2| < tolerance (:70-78).  gingr_classic_cpd_get: any of ty_xyz [3 M],
+ * sigma2, transform13 = {s, R or B row-major [9], t [3]} (rigid / affine, last Maximization), w_xyz [3 M] (non-rigid) may be NULL.
+ * moving_xyz = the templatePoints [3 M], target_xyz = the targetPoints [3 N]. */
+typedef struct gingr_classic_cpd gingr_classic_cpd;
+int gingr_classic_cpd_create(gingr_ctx *ctx, int32_t kind, int64_t M, const double *moving_xyz, int64_t N, const double *target_xyz,
+                             double lambda, double beta, double w, gingr_classic_cpd **out);
+void gingr_classic_cpd_destroy(gingr_classic_cpd *h);
+int gingr_classic_cpd_iterate(gingr_classic_cpd *h, int32_t n_iterations);
+int gingr_classic_cpd_get(gingr_classic_cpd *h, double *ty_xyz, double *sigma2, double *transform13, double *w_xyz);
+int gingr_classic_cpd_set(gingr_classic_cpd *h, const double *ty_xyz, double sigma2);
+
 #ifdef __cplusplus
 }
 #endif

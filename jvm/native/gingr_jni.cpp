@@ -200,6 +200,24 @@ JFN(jint, fitterSurfaceDistanceStats)(JNIEnv *env, jclass, jlong f, jint directi
     return gingr_fitter_surface_distance_stats(P<gingr_fitter>(f), direction, env->GetArrayLength(pts) / 3, a.as<double>(), boundaryAware,
                                                sdev, o.as<double>());
 }
+JFN(jlong, classicCpdCreate)(JNIEnv *env, jclass, jlong ctx, jint kind, jdoubleArray tmpl, jdoubleArray target, jdouble lambda,
+                             jdouble beta, jdouble w) {
+    const jlong m = env->GetArrayLength(tmpl) / 3, n = env->GetArrayLength(target) / 3;
+    Pin a(env, tmpl, true), b(env, target, true);
+    gingr_classic_cpd *h = nullptr;
+    if (gingr_classic_cpd_create(P<gingr_ctx>(ctx), kind, m, a.as<double>(), n, b.as<double>(), lambda, beta, w, &h) != GINGR_OK) return 0;
+    return reinterpret_cast<jlong>(h);
+}
+JFN(void, classicCpdDestroy)(JNIEnv *, jclass, jlong h) { gingr_classic_cpd_destroy(P<gingr_classic_cpd>(h)); }
+JFN(jint, classicCpdIterate)(JNIEnv *, jclass, jlong h, jint n) { return gingr_classic_cpd_iterate(P<gingr_classic_cpd>(h), n); }
+JFN(jint, classicCpdGet)(JNIEnv *env, jclass, jlong h, jdoubleArray ty, jdoubleArray s2, jdoubleArray tr, jdoubleArray w) {
+    Pin a(env, ty, false), b(env, s2, false), c(env, tr, false), d(env, w, false);   // a null array pins to a null pointer
+    return gingr_classic_cpd_get(P<gingr_classic_cpd>(h), a.as<double>(), b.as<double>(), c.as<double>(), d.as<double>());
+}
+JFN(jint, classicCpdSet)(JNIEnv *env, jclass, jlong h, jdoubleArray ty, jdouble s2) {
+    Pin a(env, ty, true);
+    return gingr_classic_cpd_set(P<gingr_classic_cpd>(h), a.as<double>(), s2);
+}
 JFN(jint, meshDistanceStats)(JNIEnv *env, jclass, jlong ctx, jdoubleArray pts, jdoubleArray verts, jintArray tris, jint boundaryAware,
                              jdouble sdev, jdoubleArray out4) {
     const jlong np = env->GetArrayLength(pts) / 3, nv = env->GetArrayLength(verts) / 3, nt = env->GetArrayLength(tris) / 3;

@@ -67,6 +67,14 @@ public final class GingrHipNative {
     // gingr_fitter_surface_distance_stats / gingr_mesh_distance_stats: out4 = {sum d, max d, count, sum log N(d; 0, sdev)}
     public static native int fitterSurfaceDistanceStats(long fitter, int direction, long nPoints, double[] pointsXyzOrNull,
                                                         int boundaryAware, double sdev, double[] out4);
+    // gingr_classic_cpd_*: kind 0 rigid, 1 affine, 2 non-rigid; the handle owns (TY, sigma2) on the device
+    public static native long classicCpdCreate(long ctx, int kind, double[] templateXyz, double[] targetXyz, double lambda, double beta,
+                                               double w);                                                            // 0 on failure
+    public static native void classicCpdDestroy(long h);
+    public static native int classicCpdIterate(long h, int nIterations);
+    public static native int classicCpdGet(long h, double[] tyXyzOrNull, double[] sigma2OrNull1, double[] transform13OrNull,
+                                           double[] wXyzOrNull);
+    public static native int classicCpdSet(long h, double[] tyXyzOrNull, double sigma2);
     public static native int meshDistanceStats(long ctx, double[] pointsXyz, double[] verticesXyz, int[] triangles, int boundaryAware,
                                                double sdev, double[] out4);
 

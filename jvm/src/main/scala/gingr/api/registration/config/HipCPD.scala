@@ -358,3 +358,33 @@ object HipRegistrationComparison {
     val (s, mx, n) = stats(m1, m2, boundaryAware = true); (s / n, mx)
   }
 }
+
+// ------------------------------------------------------------------------------------------------ classic CPD (other/)
+/** Drop-in for gingr.other.algorithms.cpd.{RigidCPD, AffineCPD, NonRigidCPD} behind CPDFactory.register*
+  * (gingr/other/algorithms/cpd/CPDFactory.scala:68-79): Expectation and Maximization run on the GPU (no M x N matrix; blocked
+  * Cholesky for the non-rigid M x M system), the Registration loop with its tolerance test (RigidCPD.scala:59-83) stays here. */
+final class HipClassicCPD(templatePoints: Seq[scalismo.geometry.Point[_3D]], targetPoints: Seq[scalismo.geometry.Point[_3D]], kind: Int,
+                          lambda: Double = 2, beta: Double = 2, w: Double = 0, device: Int = 0) extends AutoCloseable {
+  require(0.0 <= w && w <= 1.0); require(beta > 0); require(lambda > 0)
+  private def flat(ps: Seq[scalismo.geometry.Point[_3D]]): Array[Double] = ps.flatMap(p => Seq(p.x, p.y, p.z)).toArray
+  private val ctx = GingrHipNative.ctxCreate(device)
+  require(ctx != 0L, "gingr_ctx_create failed: no usable GPU")
+  private val h = GingrHipNative.classicCpdCreate(ctx, kind, flat(templatePoints), flat(targetPoints), lambda, beta, w)
+  require(h != 0L, s"gingr_classic_cpd_create failed: ${GingrHipNative.lastError(ctx)}")
+  private def sigma2(): Double = { val s = new Array[Double](1); GingrHipNative.classicCpdGet(h, null, s, null, null); s(0) }
+
+  def Registration(max_iteration: Int, tolerance: Double = 0.001): Seq[scalismo.geometry.Point[_3D]] = {
+    var i = 0; var converged = false; var current = sigma2()
+    while (i < max_iteration && !converged) {
+      println(s"CPD, iteration: ${i}, variance: ${current}")
+      require(GingrHipNative.classicCpdIterate(h, 1) == 0, GingrHipNative.lastError(ctx))
+      val next = sigma2()
+      if (math.abs(next - current) < tolerance) { println("Converged"); converged = true } else i += 1
+      current = next
+    }
+    val ty = new Array[Double](3 * templatePoints.length)
+    GingrHipNative.classicCpdGet(h, ty, null, null, null)
+    ty.grouped(3).map(a => scalismo.geometry.Point(a(0), a(1), a(2))).toIndexedSeq
+  }
+  override def close(): Unit = { GingrHipNative.classicCpdDestroy(h); GingrHipNative.ctxDestroy(ctx) }
+}

@@ -1185,3 +1185,97 @@ def mh_run(model: PDM, st0: State, max_iterations: int, update_fn, logq_fn, logv
             best, best_v = st, v
         k += 1
     return best, states, accepts
+
+
+# --------------------------------------------------------------------------
+# (f4) classic Coherent Point Drift (the reference's `other/` family): a second consumer of the affinity statistics and of
+#      the Gaussian kernel block
+#     [G/other/algorithms/cpd/CPDFactory.scala:28-80, RigidCPD.scala:46-139, AffineCPD.scala:35-61, NonRigidCPD.scala:45-88]
+#     Breeze: svd.SVD(u, _, v) returns v = V^T; `A \ B` is an LU solve (here numpy.linalg.solve).
+# --------------------------------------------------------------------------
+
+def classic_cpd_initial_sigma2(template: np.ndarray, target: np.ndarray) -> float:
+    """RigidCPD.initializeGaussianKernel (:46-57): sum_mn |y_m - x_n|^2 / (dim N M)."""
+    Y, X = np.asarray(template, dtype=np.float64), np.asarray(target, dtype=np.float64)
+    d = Y[:, None, :] - X[None, :, :]
+    return float((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]).sum() / (3.0 * X.shape[0] * Y.shape[0]))
+
+
+def classic_cpd_expectation(X: np.ndarray, Y: np.ndarray, sigma2: float, w: float) -> np.ndarray:
+    """RigidCPD.Expectation (:90-105): the same P as GiNGR's CPD (rows = template points Y, columns = target points X)."""
+    return cpd_P(Y, X, sigma2, w)
+
+
+def classic_cpd_maximization_rigid(X, Y, P):
+    """RigidCPD.Maximization (:107-137): similarity transform (s, R, t); returns (TY, sigma2, (s, R, t))."""
+    N, M = X.shape[0], Y.shape[0]
+    P1, Pt1 = P.sum(1), P.sum(0)
+    Np = P1.sum()
+    muX = (X.T @ (P.T @ np.ones(M))) / Np
+    muY = (Y.T @ P1) / Np
+    Xhat, Yhat = X - muX[None, :], Y - muY[None, :]
+    A = Xhat.T @ P.T @ Yhat
+    u, _, vt = np.linalg.svd(A)
+    C = np.ones(3)
+    C[2] = np.linalg.det(u @ vt.T)
+    R = u @ np.diag(C) @ vt
+    s = np.trace(A.T @ R) / np.trace(Yhat.T @ np.diag(P1) @ Yhat)
+    s1 = np.trace(Xhat.T @ np.diag(Pt1) @ Xhat)
+    s2 = s * np.trace(A.T @ R)
+    t = muX - s * (R @ muY)
+    sigma2 = (s1 - s2) / (Np * 3)
+    return s * Y @ R.T + t[None, :], float(sigma2), (float(s), R, t)
+
+
+def classic_cpd_maximization_affine(X, Y, P):
+    """AffineCPD.Maximization (:35-60): affine map (B, t); returns (TY, sigma2, (B, t))."""
+    M = Y.shape[0]
+    P1, Pt1 = P.sum(1), P.sum(0)
+    Np = P1.sum()
+    muX = (X.T @ (P.T @ np.ones(M))) / Np
+    muY = (Y.T @ P1) / Np
+    Xhat, Yhat = X - muX[None, :], Y - muY[None, :]
+    XPY = Xhat.T @ P.T @ Yhat
+    B = XPY @ np.linalg.inv(Yhat.T @ np.diag(P1) @ Yhat)
+    t = muX - B @ muY
+    s1 = np.trace(Xhat.T @ np.diag(Pt1) @ Xhat)
+    s2 = np.trace(XPY @ B.T)
+    return Y @ B.T + t[None, :], float((s1 - s2) / (Np * 3)), (B, t)
+
+
+def classic_cpd_maximization_nonrigid(X, Y, P, sigma2: float, G: np.ndarray, lam: float):
+    """NonRigidCPD.Maximization (:45-88): (G + lambda sigma2 diag(1/P1)) W = diag(1/P1) P X - Y; TY = Y + G W."""
+    P1, Pt1 = P.sum(1), P.sum(0)
+    Np = P1.sum()
+    PX = P @ X
+    A = G + np.diag(1.0 / P1) * (lam * sigma2)
+    B = PX / P1[:, None] - Y
+    W = np.linalg.solve(A, B)
+    TY = Y + G @ W
+    xPx = float(Pt1 @ (X * X).sum(1))
+    yPy = float(P1 @ (TY * TY).sum(1))
+    trPXY = float((TY * PX).sum())
+    return TY, (xPx - 2 * trPXY + yPy) / (Np * 3), W
+
+
+def classic_cpd_registration(template, target, kind: str, lam: float = 2.0, beta: float = 2.0, w: float = 0.0,
+                             max_iteration: int = 100, tolerance: float = 0.001):
+    """RigidCPD.Registration (:59-83) for kind in {rigid, affine, nonrigid}: returns (TY, sigma2, iterations, converged)."""
+    X, Y0 = np.asarray(target, dtype=np.float64), np.asarray(template, dtype=np.float64)
+    G = cpd_g_block(Y0, Y0, beta) if kind == "nonrigid" else None
+    TY, sigma2 = Y0, classic_cpd_initial_sigma2(Y0, X)
+    i, converged = 0, False
+    while i < max_iteration and not converged:
+        P = classic_cpd_expectation(X, TY, sigma2, w)
+        if kind == "rigid":
+            TY, new, _ = classic_cpd_maximization_rigid(X, TY, P)
+        elif kind == "affine":
+            TY, new, _ = classic_cpd_maximization_affine(X, TY, P)
+        else:
+            TY, new, _ = classic_cpd_maximization_nonrigid(X, TY, P, sigma2, G, lam)
+        if abs(new - sigma2) < tolerance:
+            converged = True
+        else:
+            i += 1
+        sigma2 = new
+    return TY, sigma2, i, converged
