@@ -301,8 +301,12 @@ def main():
         if dom is not None:
             roof = {"bound": "valu_f64", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": dom["peak"],
                     "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None,
+                    "nearest_contract_bound": "mfma",
                     "note": "all-pairs kernel: O(M+N) bytes, O(M*N) float64 VALU flops (software exp counted as 1 flop); "
-                            "HBM and MFMA are not the binding resource"}
+                            "HBM and MFMA are not the binding resource.  In the contract's hbm|mfma vocabulary this is the "
+                            "compute side: the peak used, 78.6 TFLOP/s, is also the dense f64 MFMA peak -- on gfx950 the f64 "
+                            "vector and matrix pipes share the issue slots (profiles/r01_ubench_mfma_valu_overlap.txt), so "
+                            "moving the K=3 contraction to MFMA does not raise the ceiling (GINGR_AFFINITY=mfma measures it)"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.emulate_world:
