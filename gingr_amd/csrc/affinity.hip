@@ -246,22 +246,26 @@ __device__ __forceinline__ void colsum_tile_expand(const P4 *tile, int j0, int j
     }
 }
 
-// FINE selects the variant with the quarter-tile x slot culling.  The regime is a property of (sigma2, cloud extents), known on
-// the device only, so when boxes are available BOTH variants are launched and the one that does not match the regime returns
-// at once (check_regime); the plain variant thereby stays exactly the code it was before the fine culling existed -- sharing
-// one kernel cost the plain regime 7 % in the row-statistics pass.
+// FINE selects the variant with the quarter-tile x slot culling; it pays when the cull radius is small against the clouds (the
+// regime, a property of sigma2 and the cloud extents that only the device knows).  Both variants give bit-identical results, so
+// the host launches ONE of them, picked from the regime word the previous launches left in pinned host memory (regime_out;
+// possibly stale -- that only costs time).  Two kernels rather than one with a switch: sharing one kernel cost the plain regime
+// 7 % in the row-statistics pass.
 template <int PT, bool FINE>
 __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt, const double *__restrict__ sigma2,
                                                             const double *__restrict__ aux,
                                                             const double *__restrict__ fit_boxes, int64_t rows_per_chunk,
-                                                            double *__restrict__ partial, int check_regime) {
+                                                            double *__restrict__ partial, int32_t *regime_out) {
     __shared__ double T[kTabN];
     __shared__ P4 tile[kTile];
     __shared__ double shbox[24];
     const double c = fastexp_scale_for_variance<kTB>(2.0 * sigma2[0]);
     const double am = aux[0] + aux[1];
     // regime of the fine culling: the zero-flush radius is well inside the clouds' extent (3 am^2 bounds every squared distance)
-    if (check_regime && (fit_boxes && 3.0 * am * am * (-c) > kFineCullRatio * GINGR_CULL_SCALED(kTabN)) != FINE) return;
+    if (regime_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        *regime_out = (fit_boxes && 3.0 * am * am * (-c) > kFineCullRatio * GINGR_CULL_SCALED(kTabN)) ? 1 : 0;
+        __threadfence_system();
+    }
     fastexp_table_init<kTB>(T);
     const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);               // wave-uniform
     const bool expand = use_expansion(fmax(aux[0], aux[1]), c);             // wave-uniform
@@ -490,20 +494,23 @@ __device__ __forceinline__ void rowstats_tile_expand(const P4 *tile, const P4 *t
     }
 }
 
-template <int PT, bool FINE>  // FINE / check_regime: see cpd_colsum_kernel
+template <int PT, bool FINE>  // FINE / regime_out: see cpd_colsum_kernel
 __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud tgt, const double *__restrict__ sigma2,
                                                               const double *__restrict__ aux,
                                                               const double *__restrict__ inv_den,
                                                               const double *__restrict__ tgt_boxes,
                                                               const int32_t *__restrict__ tile_bad, int64_t cols_per_chunk,
-                                                              double *__restrict__ partial, int check_regime) {
+                                                              double *__restrict__ partial, int32_t *regime_out) {
     __shared__ double T[kTabN];
     __shared__ P4 tile[kTile];
     __shared__ P4 tw[kTile];
     __shared__ double shbox[24];
     const double c = fastexp_scale_for_variance<kTB>(2.0 * sigma2[0]);
     const double am = aux[0] + aux[1];
-    if (check_regime && (tgt_boxes && 3.0 * am * am * (-c) > kFineCullRatio * GINGR_CULL_SCALED(kTabN)) != FINE) return;
+    if (regime_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        *regime_out = (tgt_boxes && 3.0 * am * am * (-c) > kFineCullRatio * GINGR_CULL_SCALED(kTabN)) ? 1 : 0;
+        __threadfence_system();
+    }
     fastexp_table_init<kTB>(T);
     const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);               // wave-uniform
     const bool expand = use_expansion(fmax(aux[0], aux[1]), c);             // wave-uniform
@@ -997,12 +1004,15 @@ void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *si
             plan_chunks(target.n, kBlock * kPT, fit.n, &nch, &len, colsum_tiles_override());
             dim3 grid((unsigned)ceil_div(target.n, kBlock * kPT), (unsigned)nch);
             const double *boxes = ctx->cull ? fit_boxes : (const double *)nullptr;
-            // with boxes: both variants, the device picks by regime (the other returns at once); without: the plain one
-            hipLaunchKernelGGL((cpd_colsum_kernel<kPT, false>), grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux,
-                               boxes, len, ws, boxes ? 1 : 0);
-            if (boxes)
+            // one variant, picked from the regime the device last reported (stale at worst: the results are the same)
+            const bool fine = boxes && (ctx->fine_override >= 0 ? ctx->fine_override != 0
+                                                                : (ctx->regime_host && *(volatile int32_t *)ctx->regime_host != 0));
+            if (fine)
                 hipLaunchKernelGGL((cpd_colsum_kernel<kPT, true>), grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux,
-                                   boxes, len, ws, 1);
+                                   boxes, len, ws, ctx->regime_dev);
+            else
+                hipLaunchKernelGGL((cpd_colsum_kernel<kPT, false>), grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux,
+                                   boxes, len, ws, boxes ? ctx->regime_dev : (int32_t *)nullptr);
         }
     }
     hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)ceil_div(target.n, 256)), dim3(256), 0, ctx->stream, ws, nch,
@@ -1031,17 +1041,24 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
             dim3 grid((unsigned)ceil_div(fit.n, kBlock * pt), (unsigned)nch);
             const bool cull = ctx->cull && tgt_boxes && tile_bad;
             const double *boxes = cull ? tgt_boxes : (const double *)nullptr;
-            auto launch = [&](auto kern, int check) {
+            const bool fine = boxes && (ctx->fine_override >= 0 ? ctx->fine_override != 0
+                                                                : (ctx->regime_host && *(volatile int32_t *)ctx->regime_host != 0));
+            int32_t *regime_out = boxes ? ctx->regime_dev : (int32_t *)nullptr;
+            auto launch = [&](auto kern) {
                 hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux, inv_den, boxes, tile_bad,
-                                   len, ws, check);
+                                   len, ws, regime_out);
             };
-            // with boxes: both variants, the device picks by regime (the other returns at once); without: the plain one
+            // one variant, picked from the regime the device last reported (stale at worst: the results are the same)
             if (pt == 2) {
-                launch(cpd_rowstats_kernel<2, false>, boxes ? 1 : 0);
-                if (boxes) launch(cpd_rowstats_kernel<2, true>, 1);
+                if (fine)
+                    launch(cpd_rowstats_kernel<2, true>);
+                else
+                    launch(cpd_rowstats_kernel<2, false>);
             } else {
-                launch(cpd_rowstats_kernel<kPT, false>, boxes ? 1 : 0);
-                if (boxes) launch(cpd_rowstats_kernel<kPT, true>, 1);
+                if (fine)
+                    launch(cpd_rowstats_kernel<kPT, true>);
+                else
+                    launch(cpd_rowstats_kernel<kPT, false>);
             }
         }
     }

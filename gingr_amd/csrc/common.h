@@ -35,6 +35,11 @@ struct gingr_ctx {
     int affinity_mfma = 0;
     // exact-zero tile culling of the CPD passes (affinity.hip); GINGR_CULL=0 disables it (results must stay bit-identical)
     int cull = 1;
+    // Culling regime of the CPD passes as the DEVICE last saw it (0 plain, 1 quarter-tile culling pays): pinned host word the
+    // all-pairs kernels write, read -- unsynchronised, possibly a few launches stale -- when the next launch picks its kernel
+    // variant.  Both variants compute bit-identical results, so a stale value only costs time.  Null: always the plain variant.
+    int32_t *regime_host = nullptr, *regime_dev = nullptr;
+    int fine_override = -1;  // GINGR_FINE_CULL=0|1 pins the variant (tests: both must give bit-identical results); -1: by regime
     // scratch kept across calls (grown on demand, never shrunk) so steady-state updates do not allocate
     void *scratch = nullptr;
     size_t scratch_bytes = 0;

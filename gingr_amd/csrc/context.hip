@@ -80,6 +80,18 @@ int gingr_ctx_create(int device, gingr_ctx **out) {
     ctx->stream = ctx->own_stream;
     if (const char *m = getenv("GINGR_AFFINITY")) ctx->affinity_mfma = (strcmp(m, "mfma") == 0) ? 1 : 0;
     if (const char *m = getenv("GINGR_CULL")) ctx->cull = (strcmp(m, "0") == 0) ? 0 : 1;
+    if (const char *m = getenv("GINGR_FINE_CULL")) ctx->fine_override = (strcmp(m, "1") == 0) ? 1 : (strcmp(m, "0") == 0 ? 0 : -1);
+    void *hp = nullptr, *dp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
+        memset(hp, 0, 64);
+        if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            ctx->regime_host = static_cast<int32_t *>(hp);
+            ctx->regime_dev = static_cast<int32_t *>(dp);
+        } else {
+            (void)hipHostFree(hp);
+        }
+    }
+    (void)hipGetLastError();
     *out = ctx;
     return GINGR_OK;
 }
@@ -91,6 +103,7 @@ void gingr_ctx_destroy(gingr_ctx *ctx) {
     timing_resolve(ctx);
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->regime_host) (void)hipHostFree(ctx->regime_host);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

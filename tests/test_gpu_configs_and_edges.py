@@ -175,27 +175,31 @@ def test_tile_culling_is_bit_identical(sigma2, w):
     mo, rng = synth_model(6000, 24, seed=77, spread=60.0)
     target = (mo.ref + rng.normal(0, 0.4, mo.ref.shape))[rng.permutation(mo.M)[:5500]]
     results = []
-    for cull in ("1", "0"):
-        os.environ["GINGR_CULL"] = cull
+    # culling on with the kernel variant picked by the device-reported regime (possibly stale), culling off, and culling on with
+    # each of the two variants pinned (tile-level only / quarter-tile x slot): all four must agree bit for bit
+    for env in ({"GINGR_CULL": "1"}, {"GINGR_CULL": "0"}, {"GINGR_FINE_CULL": "0"}, {"GINGR_FINE_CULL": "1"}):
+        os.environ.update(env)
         try:
             c = ga.Context(0)
         finally:
-            os.environ.pop("GINGR_CULL", None)
+            for k in env:
+                os.environ.pop(k, None)
         algo = ga.CpdRegistration(c)
         state = algo.createInitialState(to_ga(mo), target, ga.CpdConfiguration(maxIterations=10, w=w, initialSigma=sigma2))
-        for _ in range(2):
+        for _ in range(3):
             state = algo.update(state)
         results.append((state.general.fit.copy(), state.general.modelParameters.shape.copy(), state.general.sigma2,
                         state.general.status))
         algo.close()
         c.close()
-    a, b = results
-    assert a[3] == b[3]
-    assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True)
-    assert (a[2] == b[2]) or (np.isnan(a[2]) and np.isnan(b[2]))
+    a = results[0]
+    for b in results[1:]:
+        assert a[3] == b[3]
+        assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True)
+        assert (a[2] == b[2]) or (np.isnan(a[2]) and np.isnan(b[2]))
     # and the culled run still matches the oracle
     st = go.initial_state(mo, sigma2)
-    for _ in range(2):
+    for _ in range(3):
         st = go.cpd_update(mo, target, st, w=w, stats=co.cpd_stats(st.fit, target, st.sigma2, w))
     assert st.status == a[3]
     if st.status == 0:
