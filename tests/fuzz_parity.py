@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off randomized parity sweep (development aid, not part of the test suite): random sizes / ranks / transforms / outlier
-weights / landmarks, three CPD or ICP updates each, HIP path vs the oracle.   PYTHONPATH=. python tools/fuzz_parity.py [n] [seed]"""
+weights / landmarks, three CPD or ICP updates each, HIP path vs the oracle.   PYTHONPATH=. python tests/fuzz_parity.py [n] [seed]  (lives under tests/: it uses the oracle)"""
 import sys
 
 import numpy as np
