@@ -69,6 +69,22 @@ struct gingr_fitter {
     int32_t *tboundary = nullptr;                   // target boundary vertices (device target positions)
     double *surf_cp = nullptr, *surf_d2 = nullptr, *surf_w01 = nullptr, *surf_win = nullptr, *surf_nnd2 = nullptr;
     int32_t *surf_nn = nullptr, *surf_pre = nullptr, *surf_hit = nullptr;
+    // ---- memo of the posterior inputs (the reference keeps Memoize(computePosterior, 10), GingrAlgorithm.scala:68): phases 0 and
+    // 1 (correspondences, Gram, right-hand side) depend only on (shape, pose, sigma2) of the state and on the flavour / its
+    // parameters.  state_key describes the state last written by gingr_fitter_set_state while the device still holds it; post_key
+    // the state whose phase-0/1 results sit in the exchange buffer.  A Metropolis-Hastings step asks for the posterior of the same
+    // state up to three times (proposal, both transition densities); single shard only (a sharded run all-reduces the buffer).
+    struct Key {
+        std::vector<double> v;  // alpha[r], euler, center, translation, scale, sigma2
+        int flavour = -1;       // 0 CPD, 1 ICP point cloud, 2 ICP surface; + method / direction bits
+        double p0 = 0, p1 = 0;  // CPD: w, lambda
+        bool same(const Key &o) const { return flavour == o.flavour && p0 == o.p0 && p1 == o.p1 && v == o.v; }
+    };
+    Key state_key, post_key;
+    bool state_key_valid = false;
+    int post_stage = 0;       // 0 nothing, 1 phase 0 done, 2 phases 0 and 1 done for post_key
+    bool skip_phase1 = false;
+    double *small = nullptr;  // 8 doubles of device scratch for scalar results
 };
 
 namespace {
@@ -362,6 +378,7 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
         (rc = dev_alloc(ctx, &f->nn_d2, (size_t)M)) || (rc = dev_alloc(ctx, &f->weight, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->evec, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->newshape, (size_t)3 * M)) ||
         (rc = dev_alloc(ctx, &f->alpha, (size_t)rp)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
+        (rc = dev_alloc(ctx, &f->small, (size_t)8)) ||
         (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->zbuf, (size_t)19 * rp)) || (rc = dev_alloc(ctx, &f->zrand, (size_t)rp)) || (rc = dev_alloc(ctx, &f->st, 1)) ||
         (rc = dev_alloc(ctx, &f->pose, 1)) || (rc = dev_alloc(ctx, &f->hs_dev, 1)) ||
         (rc = dev_alloc(ctx, &f->scalars, 8)) || (rc = dev_alloc(ctx, &f->part, GINGR_SCALAR_PART)) || (rc = dev_alloc(ctx, &f->absmax, GINGR_AUX)) || (rc = dev_alloc(ctx, &f->work, (size_t)std::max<int64_t>((int64_t)rp * rp, posterior_work_doubles(rp)))) ||
@@ -402,6 +419,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->pose);
     dev_free(f->hs_dev);
     dev_free(f->scalars);
+    dev_free(f->small);
     dev_free(f->part);
     dev_free(f->absmax);
     dev_free(f->tperm);
@@ -422,6 +440,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
 
 int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    f->post_stage = 0;  // the posterior memo describes other inputs
     gingr_ctx *ctx = f->ctx;
     if (N < 1 || N > INT32_MAX || !target_xyz) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_target: bad N");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -490,6 +509,7 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
 int gingr_fitter_set_landmarks(gingr_fitter *f, int32_t n_lm, const int32_t *lm_pid, const double *lm_xyz,
                                const double *lm_cov) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    f->post_stage = 0;  // the posterior memo describes other inputs
     gingr_ctx *ctx = f->ctx;
     if (n_lm < 0 || (n_lm > 0 && (!lm_pid || !lm_xyz || !lm_cov)))
         return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_landmarks: bad argument");
@@ -552,6 +572,13 @@ int gingr_fitter_set_state(gingr_fitter *f, const double *alpha, const gingr_sta
     GINGR_TRY(check_launch(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     f->has_state = true;
+    f->state_key.v.assign(alpha, alpha + r);
+    for (int q = 0; q < 3; ++q) f->state_key.v.push_back(s->euler[q]);
+    for (int q = 0; q < 3; ++q) f->state_key.v.push_back(s->center[q]);
+    for (int q = 0; q < 3; ++q) f->state_key.v.push_back(s->translation[q]);
+    f->state_key.v.push_back(s->scale);
+    f->state_key.v.push_back(s->sigma2);
+    f->state_key_valid = true;
     return GINGR_OK;
 }
 
@@ -672,6 +699,36 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
     double *sc8 = rhs + rp;
     const Cloud fit = cloud_of(f->fit, M);
     const Cloud tgt = cloud_of(f->target, f->N);
+    // posterior memo (see gingr_fitter::Key): skip phases 0 and 1 when their results for exactly this state are still in place
+    if (phase == 0) {
+        f->skip_phase1 = false;
+        gingr_fitter::Key k;
+        k.flavour = !icp ? 0 : ((f->icp_surface ? 2 : 1) + 4 * f->surface_method + 16 * (f->reversed ? 1 : 0));
+        if (!icp) {
+            k.p0 = cp->w;
+            k.p1 = cp->lambda;
+        }
+        const bool single = m->M == m->M_total;
+        if (single && f->state_key_valid) {
+            k.v = f->state_key.v;
+            if (f->post_stage == 2 && f->post_key.same(k)) {
+                f->skip_phase1 = true;
+                return GINGR_OK;
+            }
+            f->post_key = k;
+            f->post_stage = 1;
+        } else {
+            f->post_stage = 0;
+        }
+    } else if (phase == 1) {
+        if (f->skip_phase1) {
+            f->skip_phase1 = false;
+            return GINGR_OK;
+        }
+        if (f->post_stage == 1) f->post_stage = 2;
+    } else {
+        f->state_key_valid = false;  // the commit moves the device state away from the key
+    }
     switch (phase) {
         case 0: {
             if (icp && f->reversed) {
@@ -834,6 +891,7 @@ int gingr_fitter_update_icp_async(gingr_fitter *f, const gingr_icp_params *p, in
 int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t *model_tri, int64_t n_target_tri,
                             const int32_t *target_tri) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    f->post_stage = 0;  // the posterior memo describes other inputs
     gingr_ctx *ctx = f->ctx;
     if (!f->target) return gingr_set_error(ctx, GINGR_ERR_STATE, "set_meshes: no target set (gingr_fitter_set_target)");
     if (f->m->M != f->m->M_total) return gingr_set_error(ctx, GINGR_ERR_STATE, "set_meshes: single shard only");
@@ -1115,8 +1173,7 @@ static int posterior_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     launch_posterior_solve(ctx, r, rp, G, rhs, nullptr, f->work, f->acoef, f->st);
     // Q0^T e with e = R^T(mesh - c - t) - (ref - c) - mean in the pose of the state
-    DevBuf out2;
-    HIP_TRY(ctx, out2.alloc(2 * sizeof(double)));
+    double *out2 = f->small;
     double *aos = reinterpret_cast<double *>(f->aos);
     HIP_TRY(ctx, hipMemcpyAsync(aos, mesh_xyz, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     launch_aos_to_soa(ctx, aos, M, f->newshape, m->perm);
@@ -1131,11 +1188,11 @@ static int posterior_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params
     a.shape_in = f->newshape;
     a.out = f->alpha_c;
     launch_sweep(ctx, SWEEP_PROJ2, a);
-    GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, m->mom + MomentLayout{rp}.stot(), f->alpha_c, f->acoef, f->work, out2.as<double>()));
+    GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, m->mom + MomentLayout{rp}.stot(), f->alpha_c, f->acoef, f->work, out2));
     GINGR_TRY(check_launch(ctx));
     double res[2] = {0, 0};
     DevState after;
-    HIP_TRY(ctx, hipMemcpyAsync(res, out2.p, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(res, out2, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(&after, f->st, sizeof(after), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const int32_t err = after.err;
