@@ -462,7 +462,7 @@ class IcpConfiguration:
     initialSigma: float = 100.0
     endSigma: float = 1.0
     reverseCorrespondenceDirection: bool = False
-    correspondenceMethod: str = "PointcloudClosestPoint"
+    correspondenceMethod: str = "TriangularClosestPoint"    # the reference's default (ICP.scala:63); needs both triangulations
 
     @property
     def sigmaStep(self) -> float:
@@ -837,7 +837,8 @@ class IcpRegistration(GingrAlgorithm):
         if config.correspondenceMethod not in self._METHODS:
             raise NotImplementedError("ICP flavours: PointcloudClosestPoint, TriangularClosestPoint, AlongNormalClosestPoint (ICP.scala:32-44)")
         if self._surface(config) and (getattr(general.model, "cells", None) is None or general.targetCells is None):
-            raise ValueError(config.correspondenceMethod + " needs the triangulations: model.cells and targetCells")
+            raise ValueError(config.correspondenceMethod + " needs the triangulations (model.cells and targetCells); for point "
+                             "clouds choose correspondenceMethod=\"PointcloudClosestPoint\"")
         return IcpRegistrationState(general.updateSigma2(float(config.initialSigma)), config)   # ICP.scala:73-85
 
     def _native_update(self, current: IcpRegistrationState, n: int):
@@ -858,6 +859,8 @@ class IcpRegistration(GingrAlgorithm):
         g, c = state.general, state.config
         if c.reverseCorrespondenceDirection:
             raise ValueError("reversed direction: use reversedCorrespondence (entries are per target vertex)")
+        if not self._surface(c):
+            raise ValueError("surfaceCorrespondence needs a surface correspondenceMethod (the state uses " + c.correspondenceMethod + ")")
         self._phase0(state)
         M = g.model.numberOfPoints
         cp, w = np.empty((M, 3)), np.empty(M)

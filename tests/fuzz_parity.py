@@ -37,7 +37,7 @@ for case in range(n_cases):
     model = ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam)
     icp = bool(rng.integers(0, 2))
     if icp:
-        algo, cfg = ga.IcpRegistration(ctx), ga.IcpConfiguration(maxIterations=20, initialSigma=30.0, endSigma=2.0)
+        algo, cfg = ga.IcpRegistration(ctx), ga.IcpConfiguration(maxIterations=20, initialSigma=30.0, endSigma=2.0, correspondenceMethod="PointcloudClosestPoint")
     else:
         algo, cfg = ga.CpdRegistration(ctx), ga.CpdConfiguration(maxIterations=20, w=w)
     state = algo.createInitialState(model, target, cfg, transform=transform, stepLength=step, landmarks=lms)

@@ -75,7 +75,7 @@ def test_config5_replicas_are_independent_and_reproducible():
     outs = []
     ctxs = [ga.Context(0), ga.Context(0)]
     algos = [ga.IcpRegistration(c) for c in ctxs]
-    cfg = ga.IcpConfiguration(maxIterations=20, initialSigma=10.0, endSigma=1.0)
+    cfg = ga.IcpConfiguration(maxIterations=20, initialSigma=10.0, endSigma=1.0, correspondenceMethod="PointcloudClosestPoint")
     states = [a.createInitialState(to_ga(mo), target, cfg) for a in algos]
     for _ in range(3):                      # interleave the two chains
         states = [a.update(s) for a, s in zip(algos, states)]

@@ -81,7 +81,7 @@ def test_golden_femur_icp(ctx, gold):
     inp, exp = gold
     x = inp["femur_target"].astype(np.float64)
     algo = ga.IcpRegistration(ctx)
-    state = algo.createInitialState(_femur_model(gold), x, ga.IcpConfiguration(maxIterations=10, initialSigma=100.0, endSigma=1.0),
+    state = algo.createInitialState(_femur_model(gold), x, ga.IcpConfiguration(maxIterations=10, initialSigma=100.0, endSigma=1.0, correspondenceMethod="PointcloudClosestPoint"),
                                     transform=ga.GlobalTranformationType.NoTransforms)
     for _ in range(3):
         state = algo.update(state)

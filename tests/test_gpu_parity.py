@@ -190,7 +190,7 @@ def run_pair(ctx, mo, target, algo_name, n_iter, transform, cfg_kwargs, landmark
         cfg = ga.CpdConfiguration(**cfg_kwargs)
     else:
         algo = ga.IcpRegistration(ctx)
-        cfg = ga.IcpConfiguration(**cfg_kwargs)
+        cfg = ga.IcpConfiguration(**{"correspondenceMethod": "PointcloudClosestPoint", **cfg_kwargs})
     state = algo.createInitialState(model, target, cfg, transform=transform, stepLength=step, landmarks=lm_ga)
     st = go.initial_state(mo, state.general.sigma2, global_transformation=transform, step_length=step)
     assert rel(state.general.fit, st.fit) < 1e-13

@@ -32,7 +32,7 @@ def test_sample_update_matches_oracle_with_the_same_draws(ctx, algo_name):
     if algo_name == "cpd":
         algo, cfg = ga.CpdRegistration(ctx), ga.CpdConfiguration(maxIterations=50, w=0.1)
     else:
-        algo, cfg = ga.IcpRegistration(ctx), ga.IcpConfiguration(maxIterations=50, initialSigma=30.0, endSigma=1.0)
+        algo, cfg = ga.IcpRegistration(ctx), ga.IcpConfiguration(maxIterations=50, initialSigma=30.0, endSigma=1.0, correspondenceMethod="PointcloudClosestPoint")
     state = algo.createInitialState(model, target, cfg)
     st = go.initial_state(mo, state.general.sigma2)
     r1, r2 = np.random.default_rng(99), np.random.default_rng(99)
