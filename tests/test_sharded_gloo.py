@@ -1,6 +1,6 @@
-"""The N > 1 path on CPU: world_size-2 `gloo` run of the row-sharded update.
+"""The N > 1 path on CPU: world_size-2 and -3 `gloo` runs of the row-sharded update.
 
-Each rank owns half of the reference rows, runs the three phases (oracle-backed restatement of the native phases, same
+Each rank owns a contiguous share of the reference rows (uneven: 101 rows), runs the three phases (oracle-backed restatement of the native phases, same
 exchange-segment layout) and all-reduces every segment with torch.distributed -- through the SAME driver loop
 (gingr_amd.sharded.drive_update) and the SAME row partition (shard_rows) that bench.py uses with RCCL on the GPUs.
 The result must equal the unsharded oracle update.
@@ -53,11 +53,10 @@ def _worker(rank, world, port, transform, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("transform", [1, 2])
-def test_two_rank_gloo_update_equals_unsharded(tmp_path, transform):
+@pytest.mark.parametrize("world,transform", [(2, 1), (2, 2), (3, 1)])
+def test_gloo_update_equals_unsharded(tmp_path, world, transform):
     import torch.multiprocessing as mp
     from oracle import gingr_oracle as go
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), transform, str(tmp_path)), nprocs=world, join=True)
     rng = np.random.default_rng(5)
     ref = rng.normal(0, 30, (101, 3))
@@ -69,13 +68,14 @@ def test_two_rank_gloo_update_equals_unsharded(tmp_path, transform):
     assert st.status == 0
     parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     fit = np.concatenate([p["fit"] for p in parts])
-    assert int(parts[0]["e"]) == int(parts[1]["b"]) and int(parts[1]["e"]) == mo.M
+    assert int(parts[0]["b"]) == 0 and int(parts[-1]["e"]) == mo.M
+    assert all(int(parts[r]["e"]) == int(parts[r + 1]["b"]) for r in range(world - 1))
     assert np.linalg.norm(fit - st.fit) / np.linalg.norm(st.fit) < 1e-9
     for p in parts:   # replicated state is identical on every rank and equals the unsharded state
         assert np.allclose(p["alpha"], st.alpha, rtol=1e-6, atol=1e-9)
         assert abs(float(p["sigma2"]) - st.sigma2) < 1e-9 * st.sigma2
         assert np.allclose(p["euler"], st.euler, atol=1e-10) and np.allclose(p["t"], st.translation, atol=1e-8)
-    assert np.array_equal(parts[0]["alpha"], parts[1]["alpha"])
+    assert all(np.array_equal(parts[0]["alpha"], p["alpha"]) for p in parts[1:])
 
 
 def test_shard_rows_partition():
