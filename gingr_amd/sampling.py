@@ -15,7 +15,7 @@ and only r-sized arithmetic and control flow here.  Mirrors (G/ = src/main/scala
   GaussianAxisRotation/TranslationProposal               G/api/sampling/generators/RandomPoseUpdateProposal.scala:28-117
   Generator (RandomShape/Rotation/Translation/Pose, DefaultRandom)   G/api/sampling/Generator.scala:25-88
   GeneratorWrapperStochastic / Deterministic             G/api/sampling/generators/GeneratorWrapper{Stochastic,Deterministic}.scala
-  BestAndCurrentSampleLogger                             G/api/sampling/loggers/BestAndCurrentSampleLogger.scala:23-47
+  BestAndCurrentSampleLogger, JSONStateLogger            G/api/sampling/loggers/{BestAndCurrentSampleLogger,JSONStateLogger}.scala
   run(...)                                               G/api/GingrAlgorithm.scala:115-190
   RegistrationComparison                                 G/api/helper/RegistrationComparison.scala:22-99
 
@@ -371,6 +371,83 @@ class BestAndCurrentSampleLogger:
 
     def currentBestValue(self):
         return self._bestValue
+
+
+class JSONStateLogger:
+    """JSONStateLogger (G/api/sampling/loggers/JSONStateLogger.scala:52-201): accept / reject logger that records, per proposal, the
+    generator's name, the value of every evaluator plus their product, and -- for accepted proposals only -- the parameters (a
+    rejected entry means "the state of the last accepted entry", :128-130).  File layout: gingr_amd.io (write_log / read_log)."""
+
+    def __init__(self, evaluators: AcceptAll, filePath: Optional[str] = None):
+        import os
+        from . import io as _io
+        self._io = _io
+        self.evaluators, self.filePath = evaluators, filePath
+        self._product = evaluators.productEvaluator()
+        self.numOfRejected = self.numOfAccepted = 0
+        self.generatedBy = set()
+        self.log = []
+        if filePath is not None:
+            parent = os.path.dirname(os.path.abspath(filePath))
+            if not os.path.isdir(parent):
+                raise IOError(f"JSON log path does not exist: {parent}!")
+            if os.path.exists(filePath) and not os.access(filePath, os.W_OK):
+                raise IOError(f"JSON file exist and cannot be overwritten: {filePath}!")
+
+    @property
+    def totalSamples(self) -> int:
+        return self.numOfRejected + self.numOfAccepted
+
+    def _values(self, sample) -> dict:
+        vals = {e.name: float(e.evaluator.logValue(sample)) for e in self.evaluators.evaluator()}
+        vals["product"] = float(self._product.logValue(sample))
+        return vals
+
+    def accept(self, current, sample, generator, evaluator):
+        self.generatedBy.add(sample.general.generatedBy)
+        self.log.append(self._io.log_entry(self.totalSamples, sample.general, self._values(sample), True))
+        self.numOfAccepted += 1
+
+    def reject(self, current, sample, generator, evaluator):
+        self.generatedBy.add(sample.general.generatedBy)
+        self.log.append(self._io.log_entry(self.totalSamples, sample.general, self._values(sample), False))
+        self.numOfRejected += 1
+
+    @property
+    def percentRejected(self) -> float:
+        return round(self.numOfRejected / self.totalSamples + 1e-12, 2)    # BigDecimal HALF_UP to two digits (:149-150)
+
+    @property
+    def percentAccepted(self) -> float:
+        return 1.0 - self.percentRejected
+
+    def percentAcceptedOfType(self, name: str, log=None) -> float:
+        rows = [e for e in (self.log if log is None else log) if e.name == name]
+        return sum(1 for e in rows if e.status) / len(rows)
+
+    def writeLog(self):
+        if self.filePath is None:
+            print("JSON logFile NOT written - no filepath given")
+            return
+        self._io.write_log(self.log, self.filePath)
+        print("Log written to: " + self.filePath)
+
+    def printAcceptInfo(self, id: str = ""):
+        lastX = 100
+        print(f"{id} Total accepted ({self.totalSamples}): {self.percentAccepted}")
+        names = sorted(n for n in self.generatedBy if n)
+        for n in names:
+            print(f"{id} {n}: {self.percentAcceptedOfType(n)}")
+        if len(self.log) > lastX:
+            tail = self.log[-lastX:]
+            print(f"{id} Last {lastX} samples accepted ({lastX}): {sum(1.0 for e in tail if e.status) / lastX}")
+            for n in names:
+                if any(e.name == n for e in tail):
+                    print(f"{id} {n}: {self.percentAcceptedOfType(n, tail)}")
+
+    def __str__(self):
+        return (f"# of Accepted: {self.numOfAccepted} = {self.percentAccepted}%\n"
+                f"# of Rejected: {self.numOfRejected} = {self.percentRejected}%")
 
 
 class MetropolisHastings:

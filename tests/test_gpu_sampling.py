@@ -201,7 +201,7 @@ def test_deterministic_run_through_the_chain_equals_plain_run(ctx):
     a1.close(); a2.close()
 
 
-def test_surface_icp_chain_runs_and_improves(ctx):
+def test_surface_icp_chain_runs_and_improves(ctx, tmp_path):
     """The reference's DemoICP configuration in small: surface ICP proposals + random walks; the best sample's posterior value
     is not below the initial one and the chain states stay finite."""
     import gingr_amd as ga
@@ -211,7 +211,14 @@ def test_surface_icp_chain_runs_and_improves(ctx):
     settings = sp.ProbabilisticSettings(sp.IndependentPoints(algo, s0, 5.0), randomMixture=0.5)
     ev = sp.EvaluatorWrapper(True, settings.evaluators)
     v0 = ev.logValue(s0)
-    best = algo.run(s0, probabilisticSettings=settings, rnd=sp.Random(1))
+    log = sp.JSONStateLogger(settings.evaluators, str(tmp_path / "targetFittingICP.json"))      # as SimpleRegistrator.run (:141)
+    best = algo.run(s0, acceptRejectLogger=log, probabilisticSettings=settings, rnd=sp.Random(1))
     assert np.all(np.isfinite(best.general.fit))
     assert ev.logValue(best) >= v0
+    assert log.totalSamples == 15 and log.log[0].status and log.log[0].index == 0       # accept(initial, initial) + 14 steps
+    assert all(set(e.logvalue) == {"Prior", "Distance", "product"} for e in log.log)
+    log.writeLog()
+    back = ga.io.read_log(str(tmp_path / "targetFittingICP.json"))
+    last = ga.io.parameters_of_log_entry(back, len(back) - 1)
+    assert last.shape.shape[0] == s0.general.model.rank
     algo.close()

@@ -142,3 +142,52 @@ def test_best_and_current_sample_logger():
         log.logState(_State(x))
     assert log.currentSample().x == 2.0 and log.currentBestSample().x == 1.05
     assert abs(log.currentBestValue() - scipy.stats.norm.logpdf(1.05, 1.0, 0.5)) < 1e-14
+
+
+def test_json_state_logger_entries_and_file(tmp_path):
+    """JSONStateLogger (JSONStateLogger.scala:103-146): accepted entries carry the parameters, rejected ones do not; the index is
+    the running sample count; the file round-trips through gingr_amd.io and reconstructs the chain state at any position."""
+    import dataclasses
+    import torch  # noqa: F401
+    import gingr_amd as ga
+    from gingr_amd import sampling as sp
+
+    @dataclasses.dataclass
+    class G:
+        modelParameters: object
+        generatedBy: str
+
+    @dataclasses.dataclass
+    class S:
+        general: G
+
+    def state(a, name):
+        mp = ga.ModelFittingParameters(1.0, (0.1 * a, 0.0, -a), ga.EulerAngles(0.01 * a, 0.0, 0.02), (0.0, 0.0, 0.0), np.array([a, -a, 2.0 * a]))
+        return S(G(mp, name))
+
+    class Ev(sp.AcceptAll):
+        def evaluator(self):
+            class E:
+                def logValue(self_inner, s):
+                    return -float(np.sum(np.asarray(s.general.modelParameters.shape) ** 2))
+            return [sp.EvaluatorIdentifier("Prior", E()), sp.EvaluatorIdentifier("Distance", sp.AcceptAllEvaluator())]
+
+    path = str(tmp_path / "chain.json")
+    log = sp.JSONStateLogger(Ev(), path)
+    s0, s1, s2, s3 = state(0.0, ""), state(1.0, "ICP"), state(2.0, "RandomShape-0.1"), state(3.0, "ICP")
+    log.accept(s0, s0, None, None)
+    log.accept(s0, s1, None, None)
+    log.reject(s1, s2, None, None)
+    log.accept(s1, s3, None, None)
+    assert [e.index for e in log.log] == [0, 1, 2, 3] and [e.status for e in log.log] == [True, True, False, True]
+    assert log.log[2].modelParameters == [] and log.log[2].name == "RandomShape-0.1"
+    assert log.log[1].logvalue == {"Prior": -6.0, "Distance": 0.0, "product": -6.0}
+    assert log.totalSamples == 4 and log.percentRejected == 0.25 and log.percentAcceptedOfType("ICP") == 1.0
+    log.writeLog()
+    back = ga.io.read_log(path)
+    assert len(back) == 4
+    at2 = ga.io.parameters_of_log_entry(back, 2)                 # the rejected entry: the state is still s1's
+    assert np.array_equal(at2.shape, s1.general.modelParameters.shape) and at2.translation == s1.general.modelParameters.translation
+    import pytest
+    with pytest.raises(IOError):
+        sp.JSONStateLogger(Ev(), str(tmp_path / "missing_dir" / "x.json"))
