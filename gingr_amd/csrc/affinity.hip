@@ -120,6 +120,25 @@ __device__ __forceinline__ Box block_bbox(const double (&x)[PT], const double (&
 }
 
 // bounding box of each owned slot t over the wave: the 64 consecutive points {base + 64 t + lane} (a quarter k-d leaf); wave
+// The streamed side of an all-pairs launch is cut into chunks (one workgroup per owned block and chunk): n_big chunks of len_big
+// points, then chunks of len_tail points.  Long chunks first and short ones last shorten the tail of the launch (the last
+// workgroups to be dispatched are the cheap ones) without multiplying the per-chunk partials; len_tail == len_big is the uniform cut.
+struct ChunkPlan {
+    int64_t len_big, len_tail;
+    int32_t n_big;
+    __host__ __device__ void range(int64_t y, int64_t n, int64_t *b, int64_t *e) const {
+        const int64_t lo = y < n_big ? y * len_big : (int64_t)n_big * len_big + (y - n_big) * len_tail;
+        const int64_t hi = lo + (y < n_big ? len_big : len_tail);
+        *b = lo;
+        *e = hi < n ? hi : n;
+    }
+    __host__ int chunks(int64_t n) const {
+        const int64_t head = (int64_t)n_big * len_big;
+        if (head >= n) return (int)((n + len_big - 1) / len_big);
+        return n_big + (int)((n - head + len_tail - 1) / len_tail);
+    }
+};
+
 // uniform, kept in scalar registers (measured faster than a round trip through LDS, spills included)
 template <int PT>
 __device__ __forceinline__ void slot_boxes(const double (&x)[PT], const double (&y)[PT], const double (&z)[PT],
@@ -254,7 +273,7 @@ __device__ __forceinline__ void colsum_tile_expand(const P4 *tile, int j0, int j
 template <int PT, bool FINE>
 __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt, const double *__restrict__ sigma2,
                                                             const double *__restrict__ aux,
-                                                            const double *__restrict__ fit_boxes, int64_t rows_per_chunk,
+                                                            const double *__restrict__ fit_boxes, ChunkPlan plan,
                                                             double *__restrict__ partial, int32_t *regime_out) {
     __shared__ double T[kTabN];
     __shared__ P4 tile[kTile];
@@ -304,8 +323,8 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         n[t] = c * __builtin_fma(z[t], z[t], __builtin_fma(y[t], y[t], x[t] * x[t]));
         acc[t] = 0.0;
     }
-    const int64_t i0 = (int64_t)blockIdx.y * rows_per_chunk;
-    const int64_t i1 = min(fit.n, i0 + rows_per_chunk);
+    int64_t i0, i1;
+    plan.range(blockIdx.y, fit.n, &i0, &i1);
     for (int64_t ib = i0; ib < i1; ib += kTile) {
         if (fit_boxes && box_gap2(own, fit_boxes + (ib / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;  // all pairs flush to +0
         __syncthreads();
@@ -499,7 +518,7 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
                                                               const double *__restrict__ aux,
                                                               const double *__restrict__ inv_den,
                                                               const double *__restrict__ tgt_boxes,
-                                                              const int32_t *__restrict__ tile_bad, int64_t cols_per_chunk,
+                                                              const int32_t *__restrict__ tile_bad, ChunkPlan plan,
                                                               double *__restrict__ partial, int32_t *regime_out) {
     __shared__ double T[kTabN];
     __shared__ P4 tile[kTile];
@@ -548,8 +567,8 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
         n[t] = c * __builtin_fma(z[t], z[t], __builtin_fma(y[t], y[t], x[t] * x[t]));
         a1[t] = ax[t] = ay[t] = az[t] = 0.0;
     }
-    const int64_t j0 = (int64_t)blockIdx.y * cols_per_chunk;
-    const int64_t j1 = min(tgt.n, j0 + cols_per_chunk);
+    int64_t j0, j1;
+    plan.range(blockIdx.y, tgt.n, &j0, &j1);
     for (int64_t jb = j0; jb < j1; jb += kTile) {
         // all pairs flush to +0 -- unless a 1/den of the tile is inf/NaN: 0 * inf must stay NaN like the reference's 0/0
         if (tgt_boxes && !tile_bad[jb / kTile] && box_gap2(own, tgt_boxes + (jb / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;
@@ -921,12 +940,22 @@ constexpr int kMinChunk = GINGR_MIN_CHUNK;  // shortest chunk the planner picks 
 // unit of the culling boxes, and a chunk that divides a tile never straddles two tiles' boxes.
 // `quarters_override` > 0 (developer knob, environment GINGR_COLSUM_TILES / GINGR_ROWSTATS_TILES, in tiles, may be 0.25 / 0.5)
 // fixes the chunk length.
-inline void plan_chunks(int64_t owned, int owned_per_block, int64_t stream_len, int *nchunks, int64_t *chunk_len,
-                        int quarters_override = 0) {
+struct ChunkShape {  // developer knob GINGR_CHUNK_SHAPE="big_tiles,fraction,tail_tiles": long chunks over `fraction` of the stream
+    double big = 0, frac = 0, tail = 0;
+};
+inline ChunkShape env_chunk_shape() {
+    ChunkShape c;
+    if (const char *e = getenv("GINGR_CHUNK_SHAPE")) {
+        if (sscanf(e, "%lf,%lf,%lf", &c.big, &c.frac, &c.tail) != 3) c = ChunkShape();
+    }
+    return c;
+}
+inline ChunkPlan plan_chunks(int64_t owned, int owned_per_block, int64_t stream_len, int *nchunks, int quarters_override = 0) {
     const int64_t bx = ceil_div(owned, owned_per_block);
     int64_t want = ceil_div(kTargetBlocks, bx > 0 ? bx : 1);
     if (want < 1) want = 1;
-    int64_t len = round_up(ceil_div(stream_len > 0 ? stream_len : 1, want), 64);
+    const int64_t n = stream_len > 0 ? stream_len : 1;
+    int64_t len = round_up(ceil_div(n, want), 64);
     if (quarters_override > 0) len = (int64_t)quarters_override * 64;
     if (len >= kTile)
         len = round_up(len, kTile);
@@ -937,8 +966,15 @@ inline void plan_chunks(int64_t owned, int owned_per_block, int64_t stream_len, 
     else
         len = 64;
     if (quarters_override <= 0 && len < kMinChunk) len = kMinChunk;
-    *chunk_len = len;
-    *nchunks = (int)ceil_div(stream_len > 0 ? stream_len : 1, len);
+    ChunkPlan p{len, len, (int32_t)ceil_div(n, len)};
+    static const ChunkShape shape = env_chunk_shape();
+    if (shape.big >= 1 && shape.tail >= 1 && shape.frac > 0 && shape.frac < 1 && quarters_override <= 0) {
+        p.len_big = (int64_t)shape.big * kTile;
+        p.len_tail = (int64_t)shape.tail * kTile;
+        p.n_big = (int32_t)((double)n * shape.frac / (double)p.len_big);
+    }
+    *nchunks = p.chunks(n);
+    return p;
 }
 inline int env_tiles(const char *name) {  // tiles -> quarters
     const char *e = getenv(name);
@@ -957,16 +993,14 @@ inline int rowstats_tiles_override() {
 
 int64_t cpd_colsum_ws_doubles(int64_t M, int64_t N) {
     int nch;
-    int64_t len;
-    plan_chunks(N, kBlock * kPT, M, &nch, &len, colsum_tiles_override());
+    plan_chunks(N, kBlock * kPT, M, &nch, colsum_tiles_override());
     const int64_t a = (int64_t)nch * N, b = cpd_colsum_mfma_ws_doubles(M, N);
     return a > b ? a : b;
 }
 
 int64_t cpd_rowstats_ws_doubles(int64_t M, int64_t N) {
     int nch;
-    int64_t len;
-    plan_chunks(M, kBlock * rowstats_pt(M), N, &nch, &len, rowstats_tiles_override());
+    plan_chunks(M, kBlock * rowstats_pt(M), N, &nch, rowstats_tiles_override());
     const int64_t a = (int64_t)nch * 4 * M, b = cpd_rowstats_mfma_ws_doubles(M, N);
     return a > b ? a : b;
 }
@@ -1000,8 +1034,7 @@ void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *si
         if (ctx->affinity_mfma) {
             launch_cpd_colsum_mfma(ctx, fit, target, sigma2_dev, aux, ws, &nch);
         } else {
-            int64_t len;
-            plan_chunks(target.n, kBlock * kPT, fit.n, &nch, &len, colsum_tiles_override());
+            const ChunkPlan len = plan_chunks(target.n, kBlock * kPT, fit.n, &nch, colsum_tiles_override());
             dim3 grid((unsigned)ceil_div(target.n, kBlock * kPT), (unsigned)nch);
             const double *boxes = ctx->cull ? fit_boxes : (const double *)nullptr;
             // one variant, picked from the regime the device last reported (stale at worst: the results are the same)
@@ -1035,9 +1068,8 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
         if (ctx->affinity_mfma) {
             launch_cpd_rowstats_mfma(ctx, fit, target, sigma2_dev, aux, inv_den, ws, &nch);
         } else {
-            int64_t len;
             const int pt = rowstats_pt(fit.n);
-            plan_chunks(fit.n, kBlock * pt, target.n, &nch, &len, rowstats_tiles_override());
+            const ChunkPlan len = plan_chunks(fit.n, kBlock * pt, target.n, &nch, rowstats_tiles_override());
             dim3 grid((unsigned)ceil_div(fit.n, kBlock * pt), (unsigned)nch);
             const bool cull = ctx->cull && tgt_boxes && tile_bad;
             const double *boxes = cull ? tgt_boxes : (const double *)nullptr;
