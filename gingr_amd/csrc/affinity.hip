@@ -325,11 +325,14 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
     }
     int64_t i0, i1;
     plan.range(blockIdx.y, fit.n, &i0, &i1);
-    for (int64_t ib = i0; ib < i1; ib += kTile) {
+    // a chunk starts and ends on 64-point quarters, not necessarily on tiles: every pass handles the part of ONE box tile that
+    // lies inside the chunk, so the tile / quarter boxes apply unchanged
+    for (int64_t ib = i0, ie; ib < i1; ib = ie) {
+        ie = min(i1, (ib / kTile + 1) * kTile);
         if (fit_boxes && box_gap2(own, fit_boxes + (ib / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;  // all pairs flush to +0
         __syncthreads();
         const int64_t i = ib + tid;
-        if (i < i1) {
+        if (i < ie) {
             if (expand) {
                 const double fx = fit.x[i] - cx, fy = fit.y[i] - cy, fz = fit.z[i] - cz;
                 tile[tid] = P4{m2c * fx, m2c * fy, m2c * fz, c * __builtin_fma(fz, fz, __builtin_fma(fy, fy, fx * fx))};
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         // this wave's own 64*PT points may be far from the tile although the workgroup's box is not
         if (!wave_owns_any) continue;  // a wave past the end of the cloud only takes part in the barriers
         if (fit_boxes && box_gap2(wown, fit_boxes + (ib / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;
-        const int cnt = (int)min((int64_t)kTile, i1 - ib);
+        const int cnt = (int)(ie - ib);
         if (!fine_on) {
             if (expand)
                 colsum_tile_expand<PT, false>(tile, 0, cnt, kAllSlots, x, y, z, n, acc, T);
@@ -569,12 +572,13 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
     }
     int64_t j0, j1;
     plan.range(blockIdx.y, tgt.n, &j0, &j1);
-    for (int64_t jb = j0; jb < j1; jb += kTile) {
+    for (int64_t jb = j0, je; jb < j1; jb = je) {  // one box tile (or the part of it inside the chunk) per pass, see cpd_colsum_kernel
+        je = min(j1, (jb / kTile + 1) * kTile);
         // all pairs flush to +0 -- unless a 1/den of the tile is inf/NaN: 0 * inf must stay NaN like the reference's 0/0
         if (tgt_boxes && !tile_bad[jb / kTile] && box_gap2(own, tgt_boxes + (jb / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;
         __syncthreads();
         const int64_t j = jb + tid;
-        if (j < j1) {
+        if (j < je) {
             const double inv = inv_den[j];
             if (expand) {
                 const double tx = tgt.x[j] - cx, ty = tgt.y[j] - cy, tz = tgt.z[j] - cz;
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
         __syncthreads();
         if (!wave_owns_any) continue;  // a wave past the end of the shard only takes part in the barriers
         if (tgt_boxes && !tile_bad[jb / kTile] && box_gap2(wown, tgt_boxes + (jb / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;
-        const int cnt = (int)min((int64_t)kTile, j1 - jb);
+        const int cnt = (int)(je - jb);
         if (!(fine_on && !tile_bad[jb / kTile])) {  // a tile holding a non-finite 1/den is never culled (0 * inf = NaN)
             if (expand)
                 rowstats_tile_expand<PT, false>(tile, tw, 0, cnt, kAllSlots, x, y, z, n, a1, ax, ay, az, T);
@@ -940,6 +944,10 @@ constexpr int kMinChunk = GINGR_MIN_CHUNK;  // shortest chunk the planner picks 
 // unit of the culling boxes, and a chunk that divides a tile never straddles two tiles' boxes.
 // `quarters_override` > 0 (developer knob, environment GINGR_COLSUM_TILES / GINGR_ROWSTATS_TILES, in tiles, may be 0.25 / 0.5)
 // fixes the chunk length.
+inline int env_int(const char *name) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : 0;
+}
 struct ChunkShape {  // developer knob GINGR_CHUNK_SHAPE="big_tiles,fraction,tail_tiles": long chunks over `fraction` of the stream
     double big = 0, frac = 0, tail = 0;
 };
@@ -950,7 +958,8 @@ inline ChunkShape env_chunk_shape() {
     }
     return c;
 }
-inline ChunkPlan plan_chunks(int64_t owned, int owned_per_block, int64_t stream_len, int *nchunks, int quarters_override = 0) {
+inline ChunkPlan plan_chunks(int64_t owned, int owned_per_block, int64_t stream_len, int *nchunks, int quarters_override = 0,
+                             int forced_chunks = 0) {
     const int64_t bx = ceil_div(owned, owned_per_block);
     int64_t want = ceil_div(kTargetBlocks, bx > 0 ? bx : 1);
     if (want < 1) want = 1;
@@ -973,6 +982,21 @@ inline ChunkPlan plan_chunks(int64_t owned, int owned_per_block, int64_t stream_
         p.len_tail = (int64_t)shape.tail * kTile;
         p.n_big = (int32_t)((double)n * shape.frac / (double)p.len_big);
     }
+    // developer knobs GINGR_COLSUM_CHUNKS / GINGR_ROWSTATS_CHUNKS=<n>: exactly n chunks balanced to a 64-point quarter (lengths
+    // differ by at most 64; the kernels handle chunks that start inside a tile).
+    const int forced = forced_chunks;
+    if (forced > 0) {
+        const int64_t Q = ceil_div(n, 64), q = Q / forced, rem = Q % forced;
+        if (q >= 1) {
+            p.len_big = (q + 1) * 64;
+            p.len_tail = q * 64;
+            p.n_big = (int32_t)rem;
+            if (rem == 0) {
+                p.len_big = p.len_tail;
+                p.n_big = forced;
+            }
+        }
+    }
     *nchunks = p.chunks(n);
     return p;
 }
@@ -984,6 +1008,14 @@ inline int colsum_tiles_override() {
     static const int v = env_tiles("GINGR_COLSUM_TILES");
     return v;
 }
+inline int colsum_chunks_override() {
+    static const int v = env_int("GINGR_COLSUM_CHUNKS");
+    return v;
+}
+inline int rowstats_chunks_override() {
+    static const int v = env_int("GINGR_ROWSTATS_CHUNKS");
+    return v;
+}
 inline int rowstats_tiles_override() {
     static const int v = env_tiles("GINGR_ROWSTATS_TILES");
     return v;
@@ -993,14 +1025,14 @@ inline int rowstats_tiles_override() {
 
 int64_t cpd_colsum_ws_doubles(int64_t M, int64_t N) {
     int nch;
-    plan_chunks(N, kBlock * kPT, M, &nch, colsum_tiles_override());
+    plan_chunks(N, kBlock * kPT, M, &nch, colsum_tiles_override(), colsum_chunks_override());
     const int64_t a = (int64_t)nch * N, b = cpd_colsum_mfma_ws_doubles(M, N);
     return a > b ? a : b;
 }
 
 int64_t cpd_rowstats_ws_doubles(int64_t M, int64_t N) {
     int nch;
-    plan_chunks(M, kBlock * rowstats_pt(M), N, &nch, rowstats_tiles_override());
+    plan_chunks(M, kBlock * rowstats_pt(M), N, &nch, rowstats_tiles_override(), rowstats_chunks_override());
     const int64_t a = (int64_t)nch * 4 * M, b = cpd_rowstats_mfma_ws_doubles(M, N);
     return a > b ? a : b;
 }
@@ -1034,7 +1066,7 @@ void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *si
         if (ctx->affinity_mfma) {
             launch_cpd_colsum_mfma(ctx, fit, target, sigma2_dev, aux, ws, &nch);
         } else {
-            const ChunkPlan len = plan_chunks(target.n, kBlock * kPT, fit.n, &nch, colsum_tiles_override());
+            const ChunkPlan len = plan_chunks(target.n, kBlock * kPT, fit.n, &nch, colsum_tiles_override(), colsum_chunks_override());
             dim3 grid((unsigned)ceil_div(target.n, kBlock * kPT), (unsigned)nch);
             const double *boxes = ctx->cull ? fit_boxes : (const double *)nullptr;
             // one variant, picked from the regime the device last reported (stale at worst: the results are the same)
@@ -1069,7 +1101,7 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
             launch_cpd_rowstats_mfma(ctx, fit, target, sigma2_dev, aux, inv_den, ws, &nch);
         } else {
             const int pt = rowstats_pt(fit.n);
-            const ChunkPlan len = plan_chunks(fit.n, kBlock * pt, target.n, &nch, rowstats_tiles_override());
+            const ChunkPlan len = plan_chunks(fit.n, kBlock * pt, target.n, &nch, rowstats_tiles_override(), rowstats_chunks_override());
             dim3 grid((unsigned)ceil_div(fit.n, kBlock * pt), (unsigned)nch);
             const bool cull = ctx->cull && tgt_boxes && tile_bad;
             const double *boxes = cull ? tgt_boxes : (const double *)nullptr;
