@@ -181,6 +181,12 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
 
+    if rank != 0:
+        # only rank 0 reports; RCCL prints a version banner through C stdio on every rank, which would otherwise be flushed into
+        # the shared stdout at an arbitrary time (possibly after rank 0's JSON line)
+        sys.stdout.flush()
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+
     import torch
     import torch.distributed as dist
     import gingr_amd as ga
