@@ -247,6 +247,11 @@ def main():
                 dist.barrier()
                 torch.cuda.synchronize(local_rank)
 
+        # one-time costs (code-object loads, LDS-size attributes, clock ramp) are paid on a throw-away run of three updates; the
+        # state is then reset, so the W warm-up and K timed steps below run the workload from sigma2_0 exactly as specified
+        reset()
+        fitter.update_cpd(args.w, 1.0, 3)
+        sync()
         reset()
         fitter.update_cpd(args.w, 1.0, args.warmup)
         sync()
