@@ -792,6 +792,9 @@ def mesh_closest_point(P: np.ndarray, verts: np.ndarray, tris: np.ndarray):
         q = closest_point_on_triangles(P[i], A, B, C)
         dd = q - P[i]
         dist = dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1] + dd[:, 2] * dd[:, 2]
+        # a zero-area triangle yields 0/0 in the interior branch only; such a candidate never wins (UNPINNED: what scalismo does
+        # with degenerate cells is not known; its vertex / edge regions are still served by the neighbouring branches)
+        dist = np.where(np.isnan(dist), np.inf, dist)
         t = int(np.argmin(dist))
         pts[i], d2[i] = q[t], dist[t]
     return pts, d2

@@ -222,3 +222,19 @@ def test_surface_icp_chain_runs_and_improves(ctx, tmp_path):
     last = ga.io.parameters_of_log_entry(back, len(back) - 1)
     assert last.shape.shape[0] == s0.general.model.rank
     algo.close()
+
+
+def test_tiny_and_degenerate_meshes(ctx):
+    """Single triangles, triangle counts around the 64 / 256 tile sizes, and zero-area cells (their interior branch is 0/0 and never
+    wins; their corners and edges still serve)."""
+    rng = np.random.default_rng(0)
+    for T, K in [(1, 1), (1, 70), (63, 5), (64, 64), (65, 200), (256, 257), (257, 300)]:
+        v = rng.normal(0, 5, (3 * T, 3))
+        t = np.arange(3 * T, dtype=np.int32).reshape(T, 3)
+        p = rng.normal(0, 8, (K, 3))
+        check_stats(ctx.mesh_distance_stats(p, v, t, sdev=2.0), go.surface_distance_stats(p, v, t, False, 2.0))
+        assert ctx.mesh_distance_stats(p, v, t, boundary_aware=True)[2] == 0            # every vertex of a soup is a boundary vertex
+    v = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0], [0, 1, 0], [0, 0, 0.0]])
+    t = np.array([[0, 1, 2], [0, 1, 3], [0, 4, 3]], dtype=np.int32)
+    p = rng.normal(0, 2, (50, 3))
+    check_stats(ctx.mesh_distance_stats(p, v, t), go.surface_distance_stats(p, v, t))

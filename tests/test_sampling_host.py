@@ -40,6 +40,14 @@ def test_surface_distance_stats_known_answers():
         0.5 * go.independent_point_distance_logvalue(v2, t, v, t, 1.0, "TargetToModel")
 
 
+def test_degenerate_triangles_never_win():
+    v = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0], [0, 1, 0], [0, 0, 0.0]])
+    t = np.array([[0, 1, 2], [0, 1, 3], [0, 4, 3]], dtype=np.int32)       # collinear cell, proper cell, cell with a repeated point
+    p = np.array([[0.25, 0.25, 1.0], [3.0, 0.0, 0.0], [-1.0, -1.0, 0.0]])
+    cp, d2 = go.mesh_closest_point(p, v, t)
+    assert np.all(np.isfinite(cp)) and np.allclose(d2, [1.0, 1.0, 2.0])
+
+
 # ---------------------------------------------------------------------------------------- host chain logic on stubs
 class _State:
     def __init__(self, x):
