@@ -238,3 +238,48 @@ def test_tiny_and_degenerate_meshes(ctx):
     t = np.array([[0, 1, 2], [0, 1, 3], [0, 4, 3]], dtype=np.int32)
     p = rng.normal(0, 2, (50, 3))
     check_stats(ctx.mesh_distance_stats(p, v, t), go.surface_distance_stats(p, v, t))
+
+
+def _icosphere(level):
+    t = (1.0 + 5 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1),
+         (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = [np.asarray(p, dtype=np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(level):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[key] = len(v) - 1
+            return cache[key]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.asarray(v), np.asarray(f, dtype=np.int32)
+
+
+def test_full_size_surface_scan_properties(ctx):
+    """82k triangles / 41k vertices (the surface-ICP benchmark size), where the oracle is too slow: properties that do not depend
+    on the size -- points of the surface are at distance 0, the surface is never farther than the nearest vertex, distances to a
+    sphere-like mesh are bounded by the radial offset."""
+    v, f = _icosphere(6)
+    v = v * 50.0
+    assert v.shape[0] == 40962 and f.shape[0] == 81920
+    cen = (v[f[:, 0]] + v[f[:, 1]] + v[f[:, 2]]) / 3.0
+    s, mx, n, _ = ctx.mesh_distance_stats(cen[::7], v, f)
+    assert n == cen[::7].shape[0] and mx < 1e-10
+    assert ctx.mesh_distance_stats(v[::5], v, f)[1] == 0.0
+    rng = np.random.default_rng(1)
+    p = v[rng.permutation(v.shape[0])[:20000]] * (1.0 + rng.uniform(-0.05, 0.08, (20000, 1)))
+    s, mx, n, _ = ctx.mesh_distance_stats(p, v, f)
+    idx, d2, _ = ctx.nn(p, v)
+    assert s <= float(np.sqrt(d2).sum()) * (1 + 1e-12) and mx <= float(np.sqrt(d2).max()) * (1 + 1e-12)
+    radial = np.abs(np.linalg.norm(p, axis=1) - 50.0)
+    assert mx <= radial.max() + 50.0 * 2e-3               # the facets lie within 0.2 % of the sphere at this subdivision
+    assert s >= radial.sum() - 20000 * 50.0 * 2e-3
