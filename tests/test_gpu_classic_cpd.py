@@ -92,3 +92,28 @@ def test_classic_cpd_errors(ctx):
     TY, s2 = reg.Iteration()
     assert np.all(np.isfinite(TY)) and np.isfinite(s2)
     reg.close()
+
+
+def test_nonrigid_system_residual_at_2000_points(ctx):
+    """32 panels of the blocked Cholesky: W must satisfy (G + lambda sigma2 diag(1/P1)) W = diag(1/P1) P X - Y, and TY = Y + G W,
+    with P1 and P X taken from the stateless statistics call (no M x N matrix on the host either)."""
+    from gingr_amd import classic as cl
+    M = N = 2000
+    Y, X = pair(M, N, 11, noise=0.4)
+    beta, lam, w = 4.0, 2.0, 0.1
+    reg = cl.CPDFactory(ctx, Y, lambda_=lam, beta=beta, w=w).registerNonRigidly(X)
+    s2 = reg.sigma2()
+    st = ctx.cpd_stats(Y, X, s2, w)
+    TY, s2n = reg.Iteration()
+    W = reg.W()
+    d = Y[:, None, :] - Y[None, :, :]
+    G = np.exp(-(d * d).sum(-1) / (2 * beta * beta))
+    P1, PX = st["P1"], st["PX"]
+    rhs = PX / P1[:, None] - Y
+    lhs = G @ W + lam * s2 * W / P1[:, None]
+    assert rel(lhs, rhs) < 1e-9, rel(lhs, rhs)
+    assert rel(TY, Y + G @ W) < 1e-12
+    xPx = float(st["Pt1"] @ (X * X).sum(1))
+    want = (xPx - 2 * float((TY * PX).sum()) + float(P1 @ (TY * TY).sum(1))) / (P1.sum() * 3)
+    assert abs(s2n - want) < 1e-9 * abs(want)
+    reg.close()
