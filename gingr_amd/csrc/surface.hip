@@ -217,14 +217,20 @@ __device__ __forceinline__ double box_box_gap2(const double a[6], const double *
 // works on quarters instead of tiles.
 constexpr int kCpThreads = 256;
 
+// H = 1: 64 queries per workgroup, one per lane.  H = 2: 32 queries per workgroup, held twice (lane and lane + 32); the two half-waves
+// take alternate triangles of the quarter.  Same arithmetic per (query, triangle) pair, half the scan per workgroup and twice the
+// workgroups: the kernel is bound by its longest workgroups, not by the vector ALU (a third busy at 64 queries per workgroup).
+template <int H>
 __global__ __launch_bounds__(kCpThreads) void surface_cp_kernel(Cloud q, Cloud v, const int32_t *__restrict__ tri,
                                                                const int32_t *__restrict__ tri_orig, int64_t T,
                                                                const double *__restrict__ boxes, double *__restrict__ cp,
                                                                double *__restrict__ d2out) {
     __shared__ Tri9 tile[kTriTile];
-    __shared__ double sbest[4][64], sorig[4][64], spt[4][3][64];
+    constexpr int QPB = 64 / H;      // queries per workgroup
+    __shared__ double sbest[4 * H][QPB], sorig[4 * H][QPB], spt[4 * H][3][QPB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const int ql = lane & (QPB - 1), half = lane / QPB, slot = wave * H + half;
+    const int64_t i = (int64_t)blockIdx.x * QPB + ql;
     const bool ok = i < q.n;
     const double qx = ok ? q.x[i] : 0.0, qy = ok ? q.y[i] : 0.0, qz = ok ? q.z[i] : 0.0;
     const V3 p{qx, qy, qz};
@@ -274,13 +280,15 @@ __global__ __launch_bounds__(kCpThreads) void surface_cp_kernel(Cloud q, Cloud v
             __syncthreads();
             if (wave_needs) {
                 const int cnt = (int)min((int64_t)64, T - q0);
-                for (int jj = 0; jj < cnt; ++jj) {
-                    const Tri9 tr = tile[64 * wave + jj];
-                    if (!__any(ok && !(tri_box_gap2(tr, p) > fmin(best, bound) * (1.0 + 1e-12)))) continue;
+                for (int j0 = 0; j0 < cnt; j0 += H) {
+                    const int jj = j0 + half;
+                    const bool live = jj < cnt;
+                    const Tri9 tr = tile[64 * wave + (live ? jj : cnt - 1)];
+                    if (!__any(ok && live && !(tri_box_gap2(tr, p) > fmin(best, bound) * (1.0 + 1e-12)))) continue;
                     const V3 c = closest_on_triangle(p, V3{tr.ax, tr.ay, tr.az}, V3{tr.bx, tr.by, tr.bz}, V3{tr.cx, tr.cy, tr.cz});
                     const V3 dd = sub(c, p);
                     const double dist = (dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z;
-                    if (dist < best || (dist == best && tr.orig < bo)) {
+                    if (live && (dist < best || (dist == best && tr.orig < bo))) {
                         best = dist;
                         bo = tr.orig;
                         bp = c;
@@ -291,27 +299,28 @@ __global__ __launch_bounds__(kCpThreads) void surface_cp_kernel(Cloud q, Cloud v
             }
         }
         if (phase == 0) {  // share the distance bound of sweep 0
-            sbest[wave][lane] = best;
+            sbest[slot][ql] = best;
             __syncthreads();
-            bound = fmin(bound, fmin(fmin(sbest[0][lane], sbest[1][lane]), fmin(sbest[2][lane], sbest[3][lane])));
+#pragma unroll
+            for (int k = 0; k < 4 * H; ++k) bound = fmin(bound, sbest[k][ql]);
             __syncthreads();
         }
     }
     // combine the four waves: smallest distance, ties -> lowest original triangle
-    sbest[wave][lane] = best;
-    sorig[wave][lane] = bo;
-    spt[wave][0][lane] = bp.x;
-    spt[wave][1][lane] = bp.y;
-    spt[wave][2][lane] = bp.z;
+    sbest[slot][ql] = best;
+    sorig[slot][ql] = bo;
+    spt[slot][0][ql] = bp.x;
+    spt[slot][1][ql] = bp.y;
+    spt[slot][2][ql] = bp.z;
     __syncthreads();
-    if (wave == 0 && ok) {
+    if (wave == 0 && half == 0 && ok) {
         int w = 0;
-        for (int k = 1; k < 4; ++k)
-            if (sbest[k][lane] < sbest[w][lane] || (sbest[k][lane] == sbest[w][lane] && sorig[k][lane] < sorig[w][lane])) w = k;
-        cp[i] = spt[w][0][lane];
-        cp[q.n + i] = spt[w][1][lane];
-        cp[2 * q.n + i] = spt[w][2][lane];
-        d2out[i] = sbest[w][lane];
+        for (int k = 1; k < 4 * H; ++k)
+            if (sbest[k][ql] < sbest[w][ql] || (sbest[k][ql] == sbest[w][ql] && sorig[k][ql] < sorig[w][ql])) w = k;
+        cp[i] = spt[w][0][ql];
+        cp[q.n + i] = spt[w][1][ql];
+        cp[2 * q.n + i] = spt[w][2][ql];
+        d2out[i] = sbest[w][ql];
     }
 }
 
@@ -655,8 +664,17 @@ void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T
 }
 void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T,
                                   const double *boxes, double *cp_soa, double *d2) {
-    hipLaunchKernelGGL(surface_cp_kernel, dim3((unsigned)ceil_div(q.n, 64)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig,
-                       T, boxes, cp_soa, d2);
+    // developer knob GINGR_SURFACE_H = 1 | 2 | 4: queries per workgroup = 64 / H
+    static const int h = getenv("GINGR_SURFACE_H") ? atoi(getenv("GINGR_SURFACE_H")) : 2;
+    if (h == 1)
+        hipLaunchKernelGGL(surface_cp_kernel<1>, dim3((unsigned)ceil_div(q.n, 64)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig,
+                           T, boxes, cp_soa, d2);
+    else if (h == 4)
+        hipLaunchKernelGGL(surface_cp_kernel<4>, dim3((unsigned)ceil_div(q.n, 16)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig,
+                           T, boxes, cp_soa, d2);
+    else
+        hipLaunchKernelGGL(surface_cp_kernel<2>, dim3((unsigned)ceil_div(q.n, 32)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig,
+                           T, boxes, cp_soa, d2);
 }
 int distance_stats_ws_doubles() { return kStatBlocks * 4; }
 void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const int32_t *orig, int64_t orig_limit, const int32_t *nn,
