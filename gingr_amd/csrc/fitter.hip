@@ -85,6 +85,7 @@ struct gingr_fitter {
     int post_stage = 0;       // 0 nothing, 1 phase 0 done, 2 phases 0 and 1 done for post_key
     bool skip_phase1 = false;
     double *small = nullptr;  // 8 doubles of device scratch for scalar results
+    double *lsave = nullptr;  // [rp][rp]: Cholesky factor of I + G kept across the two systems of the transition-density query
 };
 
 namespace {
@@ -107,6 +108,18 @@ int check_launch(gingr_ctx *ctx) {
 __global__ void zero_kernel(double *p, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.0;
+}
+
+// pose <- rigid part of the state (scale 1): the frame a mesh is projected in by the transition-density query
+__global__ void pose_of_state_kernel(const DevState *__restrict__ st, DevPose *__restrict__ pose) {
+    const int t = threadIdx.x;
+    if (t < 9) pose->R[t] = st->R[t];
+    if (t < 3) {
+        pose->euler[t] = st->euler[t];
+        pose->t[t] = st->t[t];
+        pose->center[t] = st->center[t];
+    }
+    if (t == 0) pose->scale = 1.0;
 }
 
 Cloud cloud_of(const double *soa, int64_t n) { return Cloud{soa, soa + n, soa + 2 * n, n}; }
@@ -378,7 +391,7 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
         (rc = dev_alloc(ctx, &f->nn_d2, (size_t)M)) || (rc = dev_alloc(ctx, &f->weight, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->evec, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->newshape, (size_t)3 * M)) ||
         (rc = dev_alloc(ctx, &f->alpha, (size_t)rp)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
-        (rc = dev_alloc(ctx, &f->small, (size_t)8)) ||
+        (rc = dev_alloc(ctx, &f->small, (size_t)8)) || (rc = dev_alloc(ctx, &f->lsave, (size_t)rp * rp)) ||
         (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->zbuf, (size_t)19 * rp)) || (rc = dev_alloc(ctx, &f->zrand, (size_t)rp)) || (rc = dev_alloc(ctx, &f->st, 1)) ||
         (rc = dev_alloc(ctx, &f->pose, 1)) || (rc = dev_alloc(ctx, &f->hs_dev, 1)) ||
         (rc = dev_alloc(ctx, &f->scalars, 8)) || (rc = dev_alloc(ctx, &f->part, GINGR_SCALAR_PART)) || (rc = dev_alloc(ctx, &f->absmax, GINGR_AUX)) || (rc = dev_alloc(ctx, &f->work, (size_t)std::max<int64_t>((int64_t)rp * rp, posterior_work_doubles(rp)))) ||
@@ -420,6 +433,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->hs_dev);
     dev_free(f->scalars);
     dev_free(f->small);
+    dev_free(f->lsave);
     dev_free(f->part);
     dev_free(f->absmax);
     dev_free(f->tperm);
@@ -1167,40 +1181,23 @@ static int posterior_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params
     for (int ph = 0; ph < 2; ++ph) GINGR_TRY(flavour_phase(f, flavour, cp, ip, ph));
     double *G = f->xch + f->off[1];
     double *rhs = G + (int64_t)rp * rp;
-    // the solve flags failures in st->err, which belongs to the update in flight: save / restore it around this query
-    DevState before;
-    HIP_TRY(ctx, hipMemcpyAsync(&before, f->st, sizeof(before), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    launch_posterior_solve(ctx, r, rp, G, rhs, nullptr, f->work, f->acoef, f->st);
-    // Q0^T e with e = R^T(mesh - c - t) - (ref - c) - mean in the pose of the state
+    // Q0^T e with e = R^T(mesh - c - t) - (ref - c) - mean in the pose of the state (copied on the device, no host round trip)
     double *out2 = f->small;
     double *aos = reinterpret_cast<double *>(f->aos);
     HIP_TRY(ctx, hipMemcpyAsync(aos, mesh_xyz, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     launch_aos_to_soa(ctx, aos, M, f->newshape, m->perm);
-    DevPose hp;
-    memcpy(hp.R, before.R, sizeof(hp.R));
-    memcpy(hp.euler, before.euler, sizeof(hp.euler));
-    memcpy(hp.t, before.t, sizeof(hp.t));
-    memcpy(hp.center, before.center, sizeof(hp.center));
-    hp.scale = 1.0;
-    HIP_TRY(ctx, hipMemcpyAsync(f->pose, &hp, sizeof(hp), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(pose_of_state_kernel, dim3(1), dim3(64), 0, ctx->stream, f->st, f->pose);
     SweepArgs a = base_args(f);
     a.shape_in = f->newshape;
     a.out = f->alpha_c;
     launch_sweep(ctx, SWEEP_PROJ2, a);
-    GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, m->mom + MomentLayout{rp}.stot(), f->alpha_c, f->acoef, f->work, out2));
+    // one kernel: posterior coefficients a = (I + G)^-1 rhs, then the ridge projection of the mesh and its log-density
+    GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, rhs, m->mom + MomentLayout{rp}.stot(), f->alpha_c, f->lsave, f->work, out2));
     GINGR_TRY(check_launch(ctx));
     double res[2] = {0, 0};
-    DevState after;
     HIP_TRY(ctx, hipMemcpyAsync(res, out2, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(&after, f->st, sizeof(after), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const int32_t err = after.err;
-    if (after.err != before.err) {
-        after.err = before.err;
-        HIP_TRY(ctx, hipMemcpy(f->st, &after, sizeof(after), hipMemcpyHostToDevice));
-    }
-    if (err) return gingr_set_error(ctx, err, "posterior_logpdf: posterior of the current state failed");
+    if (res[1] != 0.0) return gingr_set_error(ctx, GINGR_ERR_NOT_SPD, "posterior_logpdf: posterior of the current state failed");
     if (!std::isfinite(res[0])) return gingr_set_error(ctx, GINGR_ERR_NONFINITE, "posterior_logpdf: non-finite result");
     *logpdf = res[0];
     return GINGR_OK;

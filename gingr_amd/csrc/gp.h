@@ -135,8 +135,8 @@ void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, 
 void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *zrand,
                             double *work, double *a, DevState *st);
 // out2[0] = posterior.gp.logpdf(posterior.coefficients(mesh)), out2[1] = |c|^2; qte = Q0^T e (model-frame residual)
-int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *Stot, const double *qte,
-                            const double *a, double *work, double *out2);
+int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *Stot,
+                            const double *qte, double *lsave, double *work, double *out2);
 // doubles of the `work` buffer launch_posterior_solve / launch_posterior_logpdf need (used when r > 128)
 int64_t posterior_work_doubles(int32_t rp);
 // Binv = (S/eps + I)^-1  (work: [rp*rp]); *err_flag != 0 on failure

@@ -977,10 +977,11 @@ __global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp,
 //   c = (N^T N + eps I)^-1 N^T d = L^T (S_tot + eps (I + G))^-1 b,   b = Q0^T e - S_tot a,
 // e = R^T(mesh - c - t) - (ref - c) - mean (model frame residual), a = posterior coefficients;  logpdf = -|c|^2/2 - r/2 log(2 pi).
 __global__ __launch_bounds__(256) void posterior_logpdf_lds_kernel(int r, int rp, const double *__restrict__ G,
+                                                                   const double *__restrict__ rhs,
                                                                    const double *__restrict__ Stot,
                                                                    const double *__restrict__ qte,
-                                                                   const double *__restrict__ a, double *__restrict__ out2,
-                                                                   double *gwork) {
+                                                                   double *__restrict__ lsave /* [rp][rp] global scratch */,
+                                                                   double *__restrict__ out2, double *gwork) {
     extern __shared__ double lds_sm[];
     double *sm = gwork ? gwork : lds_sm;
     const int n = rp, ld = n | 1;
@@ -990,26 +991,38 @@ __global__ __launch_bounds__(256) void posterior_logpdf_lds_kernel(int r, int rp
     double *cv = rd + n;
     __shared__ int bad_spd;
     __shared__ double red[256];
+    __shared__ double av[512];  // posterior coefficients a (rp <= 512)
     const int tid = threadIdx.x;
     if (tid == 0) bad_spd = 0;
+    // (1) a = (I + G)^-1 rhs: the posterior coefficients of the state (what posterior_solve_lds_kernel computes); the factor L of
+    //     I + G is needed again at the end (c = L^T u) and does not fit the LDS next to the second system: it goes to `lsave`
+    for (int k = tid; k < kNB * ld; k += 256) u[k] = k < r ? rhs[k] : 0.0;
+    lds_load_spd(A, ld, r, n, G, 1.0, nullptr, 0.0, 1.0);
+    lds_cholesky(A, ld, n, rd, &bad_spd, kNB);  // u <- L^-1 rhs on the way
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, k = e - i * n;
+        lsave[e] = k <= i ? A[i * ld + k] : 0.0;
+    }
+    lds_backward(A, ld, n, rd, u);
+    for (int k = tid; k < rp; k += 256) av[k] = k < r ? u[k] : 0.0;
+    __syncthreads();
+    // (2) b = Q0^T e - S_tot a
     for (int k = tid; k < kNB * ld; k += 256) u[k] = 0.0;
     __syncthreads();
-    // b = Q0^T e - S_tot a
     for (int k = tid; k < r; k += 256) {
         double s = qte[k];
-        for (int j = 0; j < r; ++j) s = __builtin_fma(-Stot[(int64_t)j * rp + k], a[j], s);  // S_tot symmetric: coalesced
+        for (int j = 0; j < r; ++j) s = __builtin_fma(-Stot[(int64_t)j * rp + k], av[j], s);  // S_tot symmetric: coalesced
         u[k] = s;
     }
-    lds_load_spd(A, ld, r, n, G, GINGR_COEFF_NOISE, Stot, 1.0, GINGR_COEFF_NOISE);  // S_tot + eps (I + G)
-    lds_cholesky(A, ld, n, rd, &bad_spd, kNB);                                        // u <- L^-1 u on the way
+    // (3) u = (S_tot + eps (I + G))^-1 b
+    lds_load_spd(A, ld, r, n, G, GINGR_COEFF_NOISE, Stot, 1.0, GINGR_COEFF_NOISE);
+    lds_cholesky(A, ld, n, rd, &bad_spd, kNB);                                        // u <- L2^-1 u on the way
     lds_backward(A, ld, n, rd, u);
     __syncthreads();
-    // c = L^T u with L the factor of I + G
-    lds_load_spd(A, ld, r, n, G, 1.0, nullptr, 0.0, 1.0);
-    lds_cholesky(A, ld, n, rd, &bad_spd, 0);
+    // (4) c = L^T u with the saved factor of I + G (written by this workgroup before the barriers above; L2 resident)
     for (int k = tid; k < r; k += 256) {
         double s = 0.0;
-        for (int i = k; i < r; ++i) s = __builtin_fma(A[i * ld + k], u[i], s);
+        for (int i = k; i < r; ++i) s = __builtin_fma(lsave[i * n + k], u[i], s);
         cv[k] = s;
     }
     __syncthreads();
@@ -1024,7 +1037,7 @@ __global__ __launch_bounds__(256) void posterior_logpdf_lds_kernel(int r, int rp
     if (tid == 0) {
         const double n2 = red[0];
         out2[0] = bad_spd ? __builtin_nan("") : -0.5 * n2 - 0.5 * (double)r * 1.8378770664093454836;  // log(2 pi)
-        out2[1] = n2;
+        out2[1] = bad_spd ? 1.0 : 0.0;
     }
 }
 
@@ -1610,18 +1623,21 @@ void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
     hipLaunchKernelGGL(posterior_solve_lds_kernel, dim3(1), dim3(256), 0, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a, st, work);
 }
 
-int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *Stot, const double *qte,
-                            const double *a, double *work, double *out2) {
+int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *Stot,
+                            const double *qte, double *lsave, double *work, double *out2) {
     if (r <= 128) {
         const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
-        if (lds > 48 * 1024)
+        static size_t lds_granted = 48 * 1024;  // the attribute is per function, not per launch
+        if (lds > lds_granted) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_lds_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(posterior_logpdf_lds_kernel, dim3(1), dim3(256), lds, ctx->stream, (int)r, (int)rp, G, Stot, qte, a, out2,
-                           (double *)nullptr);
+            lds_granted = lds;
+        }
+        hipLaunchKernelGGL(posterior_logpdf_lds_kernel, dim3(1), dim3(256), lds, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte, lsave,
+                           out2, (double *)nullptr);
     } else {
-        hipLaunchKernelGGL(posterior_logpdf_lds_kernel, dim3(1), dim3(256), 0, ctx->stream, (int)r, (int)rp, G, Stot, qte, a, out2,
-                           work);
+        hipLaunchKernelGGL(posterior_logpdf_lds_kernel, dim3(1), dim3(256), 0, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte, lsave,
+                           out2, work);
     }
     return GINGR_OK;
 }
