@@ -218,7 +218,9 @@ class RandomShapeUpdateProposal:
         f, t = frm.general.modelParameters, to.general.modelParameters
         if not _same_parameters(dataclasses.replace(t, shape=f.shape), f):
             return -math.inf
-        return float(sum(gaussian_logpdf(tv - fv, self.stdev) for tv, fv in zip(np.asarray(t.shape), np.asarray(f.shape))))
+        d = (np.asarray(t.shape, dtype=np.float64) - np.asarray(f.shape, dtype=np.float64)) / self.stdev
+        terms = -d * d / 2.0 - (math.log(math.sqrt(2.0 * math.pi)) + math.log(self.stdev))    # GaussianEvaluator.logDensity per entry
+        return float(terms.sum())
 
 
 RollAxis, PitchAxis, YawAxis = "phi", "theta", "psi"
