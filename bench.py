@@ -311,7 +311,12 @@ def main():
         dom = max((k for k in kernels if k["bound"] == "valu_f64"), key=lambda k: k["avg_ms"], default=None)
         if dom is not None:
             roof = {"bound": "valu_f64", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": dom["peak"],
-                    "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None,
+                    "unit": "TFLOP/s", "frac": dom["frac"],
+                    # PMC FETCH_SIZE + WRITE_SIZE per launch (separate passes, profiles/r01_pmc_traffic.md), default workload only:
+                    # 13 MB read + 157 MB of per-chunk partial sums written (98 chunks x 4 planes x 50k rows), hidden under 1.3 ms of
+                    # VALU work and read back once by rowstats_reduce_kernel
+                    "traffic": 170.0e6 if (M == 50000 and N == 50000 and world == 1 and not args.emulate_world
+                                           and dom["kernel"] == "cpd_rowstats_kernel") else None,
                     "nearest_contract_bound": "mfma",
                     "note": "all-pairs kernel: O(M+N) bytes, O(M*N) float64 VALU flops (software exp counted as 1 flop); "
                             "HBM and MFMA are not the binding resource.  In the contract's hbm|mfma vocabulary this is the "
