@@ -268,8 +268,11 @@ int gingr_fitter_update_cpd_sample_async(gingr_fitter *f, const gingr_cpd_params
 int gingr_fitter_update_icp_sample_async(gingr_fitter *f, const gingr_icp_params *p, const double *z);
 /* posterior(of the fitter's CURRENT state).gp.logpdf(posterior.coefficients(mesh)): the quantity
  * GeneratorWrapperStochastic.logTransitionProbability evaluates (G/api/sampling/generators/GeneratorWrapperStochastic.scala:42-63).
- * mesh_xyz[3*M]; the state is not modified.  rank <= 128.  A failed posterior gives GINGR_ERR_NOT_SPD / _NONFINITE
- * (the reference returns -infinity in that case). */
+ * mesh_xyz[3*M]; the state is not modified.  rank <= 512.  A failed posterior gives GINGR_ERR_NOT_SPD / _NONFINITE
+ * (the reference returns -infinity in that case).  Like the reference's Memoize(computePosterior, 10)
+ * (G/api/GingrAlgorithm.scala:68) the fitter remembers which state the correspondences / Gram / right-hand side in its buffers
+ * belong to: when gingr_fitter_set_state writes exactly that state again (same coefficients, pose, sigma2, flavour and
+ * parameters), the update and these queries reuse them instead of recomputing (single shard; invisible in the results). */
 int gingr_fitter_posterior_logpdf_cpd(gingr_fitter *f, const gingr_cpd_params *p, const double *mesh_xyz, double *logpdf);
 int gingr_fitter_posterior_logpdf_icp(gingr_fitter *f, const gingr_icp_params *p, const double *mesh_xyz, double *logpdf);
 
