@@ -607,9 +607,13 @@ int gingr_fitter_get_state(gingr_fitter *f, double *alpha, gingr_state_scalars *
     if (alpha) HIP_TRY(ctx, hipMemcpyAsync(alpha, f->alpha, (size_t)f->m->r * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     DevBuf tmp;
     if (fit_xyz) {
-        HIP_TRY(ctx, tmp.alloc((size_t)3 * M * sizeof(double)));
-        launch_soa_to_aos(ctx, f->fit, M, tmp.as<double>(), f->m->perm);
-        HIP_TRY(ctx, hipMemcpyAsync(fit_xyz, tmp.p, (size_t)3 * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        double *stage = reinterpret_cast<double *>(f->aos);  // the fitter's interleaved staging buffer (max(3M, 3N) doubles)
+        if (!stage) {                                        // no target yet: a temporary
+            HIP_TRY(ctx, tmp.alloc((size_t)3 * M * sizeof(double)));
+            stage = tmp.as<double>();
+        }
+        launch_soa_to_aos(ctx, f->fit, M, stage, f->m->perm);
+        HIP_TRY(ctx, hipMemcpyAsync(fit_xyz, stage, (size_t)3 * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (s) {
