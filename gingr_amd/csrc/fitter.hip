@@ -85,6 +85,7 @@ struct gingr_fitter {
     int post_stage = 0;       // 0 nothing, 1 phase 0 done, 2 phases 0 and 1 done for post_key
     bool skip_phase1 = false;
     double *small = nullptr;  // 8 doubles of device scratch for scalar results
+    void *stat_scratch = nullptr;  // StatScratch of gingr_fitter_surface_distance_stats (kept across calls)
     double *lsave = nullptr;  // [rp][rp]: Cholesky factor of I + G kept across the two systems of the transition-density query
 };
 
@@ -319,6 +320,8 @@ int model_create_impl(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doubl
     return GINGR_OK;
 }
 
+static void free_stat_scratch(void *p);  // defined next to StatScratch (surface distance statistics)
+
 extern "C" {
 
 int gingr_model_upload(gingr_ctx *ctx, int64_t M_total, int32_t rank, const double *ref, const double *mean,
@@ -412,6 +415,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
         (void)hipSetDevice(f->ctx->device);
         (void)hipStreamSynchronize(f->ctx->stream);
     }
+    free_stat_scratch(f->stat_scratch);
     dev_free(f->target);
     dev_free(f->inv_den);
     dev_free(f->Pt1);
@@ -1377,19 +1381,26 @@ struct StatScratch {
     DevBuf cp, d2, nn, nnd2, ws, part, out;
 };
 
+}  // namespace
+static void free_stat_scratch(void *p) { delete static_cast<StatScratch *>(p); }
+namespace {
+
+// grow-only: steady-state queries (one likelihood evaluation per Metropolis-Hastings step) do not allocate
+hipError_t ensure(DevBuf &b, size_t bytes) { return b.p && b.bytes >= bytes ? hipSuccess : b.alloc(bytes); }
+
 int run_distance_stats(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T, const double *tboxes,
                        const int32_t *q_orig, int64_t q_limit, const int32_t *v_orig, const double *v_boxes,
                        const int32_t *boundary, double sdev, StatScratch &sc, double out4[4]) {
     const int64_t K = q.n;
-    HIP_TRY(ctx, sc.cp.alloc((size_t)3 * K * sizeof(double)));
-    HIP_TRY(ctx, sc.d2.alloc((size_t)K * sizeof(double)));
-    HIP_TRY(ctx, sc.part.alloc((size_t)distance_stats_ws_doubles() * sizeof(double)));
-    HIP_TRY(ctx, sc.out.alloc(4 * sizeof(double)));
+    HIP_TRY(ctx, ensure(sc.cp, (size_t)3 * K * sizeof(double)));
+    HIP_TRY(ctx, ensure(sc.d2, (size_t)K * sizeof(double)));
+    HIP_TRY(ctx, ensure(sc.part, (size_t)distance_stats_ws_doubles() * sizeof(double)));
+    HIP_TRY(ctx, ensure(sc.out, 4 * sizeof(double)));
     launch_surface_closest_point(ctx, q, v, tri, tri_orig, T, tboxes, sc.cp.as<double>(), sc.d2.as<double>());
     if (boundary) {
-        HIP_TRY(ctx, sc.nn.alloc((size_t)K * sizeof(int32_t)));
-        HIP_TRY(ctx, sc.nnd2.alloc((size_t)K * sizeof(double)));
-        HIP_TRY(ctx, sc.ws.alloc((size_t)nn_ws_bytes(K, v.n)));
+        HIP_TRY(ctx, ensure(sc.nn, (size_t)K * sizeof(int32_t)));
+        HIP_TRY(ctx, ensure(sc.nnd2, (size_t)K * sizeof(double)));
+        HIP_TRY(ctx, ensure(sc.ws, (size_t)nn_ws_bytes(K, v.n)));
         launch_nn(ctx, cloud_of(sc.cp.as<double>(), K), v, v_orig, v_boxes, sc.ws.p, sc.nn.as<int32_t>(), sc.nnd2.as<double>());
     }
     launch_distance_stats(ctx, K, sc.d2.as<double>(), q_orig, q_limit, boundary ? sc.nn.as<int32_t>() : nullptr, boundary, sdev,
@@ -1422,7 +1433,8 @@ int gingr_fitter_surface_distance_stats(gingr_fitter *f, int32_t direction, int6
     const gingr_model *m = f->m;
     const int64_t M = m->M, N = f->N;
     const Cloud fit = cloud_of(f->fit, M), tgt = cloud_of(f->target, N);
-    StatScratch sc;
+    if (!f->stat_scratch) f->stat_scratch = new StatScratch;
+    StatScratch &sc = *static_cast<StatScratch *>(f->stat_scratch);
     if (direction == 0) {
         // the first n_points vertices of the current fit (original numbering; 0 = all) against the target surface
         if (points) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "surface_distance_stats: model -> target takes no point list");
