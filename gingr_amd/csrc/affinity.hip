@@ -713,27 +713,34 @@ __device__ __forceinline__ double norm2_exact(double dx, double dy, double dz) {
     return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
 }
 
-// One wave per workgroup owns 64 consecutive queries (spatially compact when the fitter keeps clouds in k-d leaf order)
-// and visits the target tiles of its chunk nearest-first; a tile whose bounding box is farther from the wave's box than the
-// worst current best distance of the wave cannot contain a closer (or equally close) point and is skipped -- exact
-// pruning, the result is the same as the full scan including the lowest-original-index tie rule.
-constexpr int kNNThreads = 64;
+// A workgroup of four waves serves 64 consecutive queries (spatially compact when the fitter keeps clouds in k-d leaf order):
+// every wave holds the same queries and scans ONE 64-point quarter of each staged target tile, visited only if that quarter's box
+// is not farther from a lane's query than the lane's best so far.  Tiles are found with the lanes testing 64 tile boxes at a time
+// against the queries' box; the tiles at the smallest gap come first, then the four waves share their best distances (the bound
+// only) and the remaining tiles are visited under that bound -- exact pruning: the result is the same as the full scan including
+// the lowest-original-index tie rule (a NaN box or query never prunes).
+constexpr int kNNThreads = 64;   // queries per workgroup
+constexpr int kNNBlock = 256;    // threads per workgroup
 
-__global__ __launch_bounds__(kNNThreads) void nn_kernel(Cloud q, Cloud tgt, const int32_t *__restrict__ orig,
-                                                        const double *__restrict__ tgt_boxes, int64_t cols_per_chunk,
-                                                        double *__restrict__ pd2, int32_t *__restrict__ pidx,
-                                                        int32_t *__restrict__ porig) {
+__global__ __launch_bounds__(kNNBlock) void nn_kernel(Cloud q, Cloud tgt, const int32_t *__restrict__ orig,
+                                                      const double *__restrict__ tgt_boxes, int64_t cols_per_chunk,
+                                                      double *__restrict__ pd2, int32_t *__restrict__ pidx,
+                                                      int32_t *__restrict__ porig) {
     __shared__ P4 tile[kTile];
-    const int lane = threadIdx.x;
+    __shared__ double sbest[4][kNNThreads], sorig[4][kNNThreads];
+    __shared__ int32_t sidx[4][kNNThreads];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * kNNThreads + lane;
     const bool ok = i < q.n;
     const double qx = ok ? q.x[i] : 0.0, qy = ok ? q.y[i] : 0.0, qz = ok ? q.z[i] : 0.0;
     double best = __builtin_huge_val(), bo = __builtin_huge_val();  // best distance and the ORIGINAL index that holds it
+    double bound = __builtin_huge_val();                            // best of all four waves after the first sweep
     int32_t bi = -1;
     const int64_t j0 = (int64_t)blockIdx.y * cols_per_chunk;
     const int64_t j1 = min(tgt.n, j0 + cols_per_chunk);
     const int t0 = (int)(j0 / kTile), nt = (int)((j1 - j0 + kTile - 1) / kTile);
-    // the wave's own bounding box (invalid lanes excluded)
+    const double *qboxes = tgt_boxes ? tgt_boxes + ((tgt.n + kTile - 1) / kTile) * 6 : nullptr;
+    // the queries' bounding box (invalid lanes excluded)
     Box wb;
     {
         double lo[3] = {ok ? qx : __builtin_huge_val(), ok ? qy : __builtin_huge_val(), ok ? qz : __builtin_huge_val()};
@@ -751,12 +758,6 @@ __global__ __launch_bounds__(kNNThreads) void nn_kernel(Cloud q, Cloud tgt, cons
             wb.hi[d] = uniform_d(hi[d]);
         }
     }
-    // Two sweeps over the chunk's tiles: first the tiles at the smallest gap to the wave's box (normally gap 0, the touching
-    // tiles: they almost always hold the true neighbours, so `best` becomes small), then all others, each visited only if for
-    // at least one lane the tile's box is not farther from that lane's query than the lane's current best (strict test with a
-    // relative rounding margin; a NaN box or query never prunes).  Ties at equal distance are inside the margin, so the
-    // lowest-original-index rule holds.  The lanes test 64 tile boxes at a time against the wave's box (ballot, then a scalar
-    // walk over the set bits), so the per-query test runs on the few candidate tiles only.
     double gmin = __builtin_huge_val();
     if (tgt_boxes) {
         for (int t = lane; t < nt; t += 64) gmin = fmin(gmin, box_gap2(wb, tgt_boxes + (int64_t)(t0 + t) * 6));
@@ -766,58 +767,76 @@ __global__ __launch_bounds__(kNNThreads) void nn_kernel(Cloud q, Cloud tgt, cons
     }
     for (int phase = 0; phase < 2; ++phase) {
         if (!tgt_boxes && phase == 1) break;  // no boxes: the first sweep visits everything
-        double bmax = ok ? best : 0.0;
+        double bmax = ok ? fmin(best, bound) : 0.0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) bmax = fmax(bmax, __shfl_xor(bmax, off));
-        bmax = uniform_d(bmax) * (1.0 + 1e-12);
+        bmax = uniform_d(bmax) * (1.0 + 1e-12);  // identical in the four waves in the second sweep (bound is shared)
         for (int tc = 0; tc < nt; tc += 64) {
-          const int tl = tc + lane;
-          bool take = tl < nt;
-          if (tgt_boxes && take) {
-              const double g = box_gap2(wb, tgt_boxes + (int64_t)(t0 + tl) * 6);
-              // a NaN box gives g = NaN: taken in the first sweep
-              take = phase == 0 ? !(g > gmin) : (g > gmin && !(g > bmax));
-          }
-          unsigned long long cand = __ballot(take);
-          while (cand) {
-            const int t = tc + __builtin_ctzll(cand);
-            cand &= cand - 1;
-            if (phase == 1) {
-                const double *bx = tgt_boxes + (int64_t)(t0 + t) * 6;
-                const double gx = fmax(fmax(bx[0] - qx, qx - bx[3]), 0.0), gy = fmax(fmax(bx[1] - qy, qy - bx[4]), 0.0),
-                             gz = fmax(fmax(bx[2] - qz, qz - bx[5]), 0.0);
-                const double pd = __builtin_fma(gz, gz, __builtin_fma(gy, gy, gx * gx));
-                const bool need = ok && !(pd > best * (1.0 + 1e-12));
-                if (!__any(need)) continue;
+            const int tl = tc + lane;
+            bool take = tl < nt;
+            if (tgt_boxes && take) {
+                const double g = box_gap2(wb, tgt_boxes + (int64_t)(t0 + tl) * 6);
+                // a NaN box gives g = NaN: taken in the first sweep
+                take = phase == 0 ? !(g > gmin) : (g > gmin && !(g > bmax));
             }
-            const int64_t jb = j0 + (int64_t)t * kTile;
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < kTile / kNNThreads; ++u) {
-                const int64_t j = jb + u * kNNThreads + lane;
-                if (j < j1) tile[u * kNNThreads + lane] = P4{tgt.x[j], tgt.y[j], tgt.z[j], (double)(orig ? orig[j] : (int32_t)j)};
-            }
-            __syncthreads();
-            const int cnt = (int)min((int64_t)kTile, j1 - jb);
-#pragma unroll 4
-            for (int jj = 0; jj < cnt; ++jj) {
-                const P4 p = tile[jj];
-                const double d2 = norm2_exact(p.x - qx, p.y - qy, p.z - qz);
-                // strictly closer, or exactly as close with a lower original index: "lowest index wins" independent of
-                // the (spatially sorted) device order and of the visiting order
-                if (d2 < best || (d2 == best && p.w < bo)) {
-                    best = d2;
-                    bo = p.w;
-                    bi = (int32_t)(jb + jj);
+            unsigned long long cand = __ballot(take);  // workgroup-uniform: same queries, same gmin / bound in every wave
+            while (cand) {
+                const int t = tc + __builtin_ctzll(cand);
+                cand &= cand - 1;
+                const int64_t jb = j0 + (int64_t)t * kTile, q0 = jb + 64 * wave;
+                bool need = ok && q0 < j1;
+                if (qboxes) {
+                    const double *bx = qboxes + ((int64_t)(t0 + t) * 4 + wave) * 6;
+                    const double gx = fmax(fmax(bx[0] - qx, qx - bx[3]), 0.0), gy = fmax(fmax(bx[1] - qy, qy - bx[4]), 0.0),
+                                 gz = fmax(fmax(bx[2] - qz, qz - bx[5]), 0.0);
+                    const double pd = __builtin_fma(gz, gz, __builtin_fma(gy, gy, gx * gx));
+                    need = need && !(pd > fmin(best, bound) * (1.0 + 1e-12));
                 }
+                const bool wave_needs = __any(need);
+                if (!__syncthreads_or(wave_needs)) continue;
+                {
+                    const int64_t j = jb + threadIdx.x;
+                    if (j < j1) tile[threadIdx.x] = P4{tgt.x[j], tgt.y[j], tgt.z[j], (double)(orig ? orig[j] : (int32_t)j)};
+                }
+                __syncthreads();
+                if (wave_needs) {
+                    const int cnt = (int)min((int64_t)64, j1 - q0);
+#pragma unroll 4
+                    for (int jj = 0; jj < cnt; ++jj) {
+                        const P4 p = tile[64 * wave + jj];
+                        const double d2 = norm2_exact(p.x - qx, p.y - qy, p.z - qz);
+                        // strictly closer, or exactly as close with a lower original index: "lowest index wins" independent of
+                        // the (spatially sorted) device order and of the visiting order
+                        if (d2 < best || (d2 == best && p.w < bo)) {
+                            best = d2;
+                            bo = p.w;
+                            bi = (int32_t)(q0 + jj);
+                        }
+                    }
+                }
+                __syncthreads();  // the tile is restaged by the next visited tile
             }
-          }
+        }
+        if (phase == 0 && tgt_boxes) {  // share the distance bound of the first sweep
+            sbest[wave][lane] = best;
+            __syncthreads();
+            bound = fmin(fmin(sbest[0][lane], sbest[1][lane]), fmin(sbest[2][lane], sbest[3][lane]));
+            __syncthreads();
         }
     }
-    if (ok) {
-        pd2[(int64_t)blockIdx.y * q.n + i] = best;
-        pidx[(int64_t)blockIdx.y * q.n + i] = bi;
-        porig[(int64_t)blockIdx.y * q.n + i] = (int32_t)(bo < 2147483648.0 ? bo : -1.0);
+    // combine the four waves: smallest distance, ties -> lowest original index
+    sbest[wave][lane] = best;
+    sorig[wave][lane] = bo;
+    sidx[wave][lane] = bi;
+    __syncthreads();
+    if (wave == 0 && ok) {
+        int w = 0;
+        for (int k = 1; k < 4; ++k)
+            if (sbest[k][lane] < sbest[w][lane] || (sbest[k][lane] == sbest[w][lane] && sorig[k][lane] < sorig[w][lane])) w = k;
+        const double wo = sorig[w][lane];
+        pd2[(int64_t)blockIdx.y * q.n + i] = sbest[w][lane];
+        pidx[(int64_t)blockIdx.y * q.n + i] = sidx[w][lane];
+        porig[(int64_t)blockIdx.y * q.n + i] = (int32_t)(wo < 2147483648.0 ? wo : -1.0);
     }
 }
 
@@ -1156,7 +1175,7 @@ void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_
     int32_t *pidx = reinterpret_cast<int32_t *>(pd2 + (int64_t)nch * query.n);
     int32_t *porig = pidx + (int64_t)nch * query.n;
     dim3 grid((unsigned)ceil_div(query.n, kNNThreads), (unsigned)nch);
-    hipLaunchKernelGGL(nn_kernel, grid, dim3(kNNThreads), 0, ctx->stream, query, target, target_orig,
+    hipLaunchKernelGGL(nn_kernel, grid, dim3(kNNBlock), 0, ctx->stream, query, target, target_orig,
                        pruned ? tgt_boxes : (const double *)nullptr, len, pd2, pidx, porig);
     hipLaunchKernelGGL(nn_reduce_kernel, dim3((unsigned)ceil_div(query.n, 256)), dim3(256), 0, ctx->stream, pd2, pidx, porig,
                        nch, query.n, idx, d2);
