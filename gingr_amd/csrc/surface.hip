@@ -326,17 +326,20 @@ __global__ __launch_bounds__(kCpThreads) void surface_cp_kernel(Cloud q, Cloud v
 
 // flag[i] = 1 when the line through fit_i along fit_i - cp_i meets the mesh (v, tri) in a point != fit_i that is closer to fit_i
 // than cp_i is (ClosestPointRegistrator.scala:62-72).  Lanes with skip[i] != 0 do no work (their weight is already 0).
+template <int H>  // 64 / H points per workgroup, as surface_cp_kernel
 __global__ __launch_bounds__(kCpThreads) void self_intersect_kernel(Cloud fit, const double *__restrict__ cp, Cloud v,
                                                                    const int32_t *__restrict__ tri, int64_t T,
                                                                    const double *__restrict__ boxes,
                                                                    const int32_t *__restrict__ skip,
                                                                    int32_t *__restrict__ flag) {
     __shared__ Tri9 tile[kTriTile];
-    __shared__ int shit[4][64];
+    constexpr int QPB = 64 / H;
+    __shared__ int shit[4 * H][QPB];
     // four waves hold the same 64 points; each scans one 64-triangle quarter of a staged tile (as surface_cp_kernel); "some
     // triangle holds a closer intersection" does not depend on the order, so the waves' flags are OR-ed at the end
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const int ql = lane & (QPB - 1), half = lane / QPB;
+    const int64_t i = (int64_t)blockIdx.x * QPB + ql;
     const bool ok = i < fit.n && !(skip && skip[i]);
     const int64_t ic = i < fit.n ? i : 0;
     const V3 p{fit.x[ic], fit.y[ic], fit.z[ic]};
@@ -376,11 +379,13 @@ __global__ __launch_bounds__(kCpThreads) void self_intersect_kernel(Cloud fit, c
             __syncthreads();
             if (wave_needs) {
                 const int cnt = (int)min((int64_t)64, T - q0);
-                for (int jj = 0; jj < cnt; ++jj) {
-                    const Tri9 tr = tile[64 * wave + jj];
+                for (int jb = 0; jb < cnt; jb += H) {
+                    const int jj = jb + half;
+                    const bool live = jj < cnt;
+                    const Tri9 tr = tile[64 * wave + (live ? jj : cnt - 1)];
                     // only triangles reaching into the ball of radius |v| around p can hold a closer intersection point
-                    if (!__any(need && !hit && !(tri_box_gap2(tr, p) > vv * (1.0 + 1e-9)))) continue;
-                    if (need && !hit) {
+                    if (!__any(need && live && !hit && !(tri_box_gap2(tr, p) > vv * (1.0 + 1e-9)))) continue;
+                    if (need && live && !hit) {
                         const V3 A{tr.ax, tr.ay, tr.az};
                         const V3 e1 = sub(V3{tr.bx, tr.by, tr.bz}, A), e2 = sub(V3{tr.cx, tr.cy, tr.cz}, A);
                         const V3 pv = cross3(dir, e2);
@@ -404,9 +409,14 @@ __global__ __launch_bounds__(kCpThreads) void self_intersect_kernel(Cloud fit, c
             __syncthreads();  // the tile is restaged by the next visited tile
         }
     }
-    shit[wave][lane] = hit;
+    shit[wave * H + half][ql] = hit;
     __syncthreads();
-    if (wave == 0 && i < fit.n) flag[i] = shit[0][lane] | shit[1][lane] | shit[2][lane] | shit[3][lane];
+    if (wave == 0 && half == 0 && i < fit.n) {
+        int any = 0;
+#pragma unroll
+        for (int q2 = 0; q2 < 4 * H; ++q2) any |= shit[q2][ql];
+        flag[i] = any;
+    }
 }
 
 // ClosestPointAlongNormalTriangleMesh3D (ClosestPointRegistrator.scala:102-131): for every fit vertex the intersection of the
@@ -686,7 +696,7 @@ void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const in
 }
 void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, const int32_t *tri, int64_t T, const double *boxes,
                            const int32_t *skip, int32_t *flag) {
-    hipLaunchKernelGGL(self_intersect_kernel, dim3((unsigned)ceil_div(fit.n, 64)), dim3(kCpThreads), 0, ctx->stream,
+    hipLaunchKernelGGL(self_intersect_kernel<2>, dim3((unsigned)ceil_div(fit.n, 32)), dim3(kCpThreads), 0, ctx->stream,
                        fit, cp_soa, fit, tri, T, boxes, skip, flag);
 }
 void launch_surface_prereject(gingr_ctx *ctx, int64_t M, const int32_t *nn_vertex, const int32_t *tgt_boundary,
