@@ -696,8 +696,16 @@ void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const in
 }
 void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, const int32_t *tri, int64_t T, const double *boxes,
                            const int32_t *skip, int32_t *flag) {
-    hipLaunchKernelGGL(self_intersect_kernel<2>, dim3((unsigned)ceil_div(fit.n, 32)), dim3(kCpThreads), 0, ctx->stream,
-                       fit, cp_soa, fit, tri, T, boxes, skip, flag);
+    static const int h = getenv("GINGR_SURFACE_H") ? atoi(getenv("GINGR_SURFACE_H")) : 2;  // developer knob, as launch_surface_closest_point
+    if (h == 4)
+        hipLaunchKernelGGL(self_intersect_kernel<4>, dim3((unsigned)ceil_div(fit.n, 16)), dim3(kCpThreads), 0, ctx->stream,
+                           fit, cp_soa, fit, tri, T, boxes, skip, flag);
+    else if (h == 1)
+        hipLaunchKernelGGL(self_intersect_kernel<1>, dim3((unsigned)ceil_div(fit.n, 64)), dim3(kCpThreads), 0, ctx->stream,
+                           fit, cp_soa, fit, tri, T, boxes, skip, flag);
+    else
+        hipLaunchKernelGGL(self_intersect_kernel<2>, dim3((unsigned)ceil_div(fit.n, 32)), dim3(kCpThreads), 0, ctx->stream,
+                           fit, cp_soa, fit, tri, T, boxes, skip, flag);
 }
 void launch_surface_prereject(gingr_ctx *ctx, int64_t M, const int32_t *nn_vertex, const int32_t *tgt_boundary,
                               const double *fit_vn, const double *tgt_vn, int64_t N, const int32_t *found, int32_t *pre) {
