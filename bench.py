@@ -181,6 +181,9 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
 
+    # must be in the environment before the HIP / HSA runtime initialises (the pool's driver only supports dmabuf IPC; RCCL and
+    # cross-process tensor sharing fail with the legacy mode); normally already exported
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if rank != 0:
         # only rank 0 reports; RCCL prints a version banner through C stdio on every rank, which would otherwise be flushed into
         # the shared stdout at an arbitrary time (possibly after rank 0's JSON line)
