@@ -662,9 +662,7 @@ class GingrAlgorithm:
                 dm.close()
         else:
             mesh = f64(g.fit)
-        self._bind(g, from_state.config.useLandmarkCorrespondence)
-        self._push_state(g)
-        self._device_state_token = None
+        self._ensure_device_state(from_state)     # the query leaves the device state as it is: no push when it already holds `from`
         try:
             return self._native_logpdf(from_state, mesh)
         except GingrNativeError as e:

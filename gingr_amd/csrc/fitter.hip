@@ -638,6 +638,15 @@ int gingr_fitter_get_state(gingr_fitter *f, double *alpha, gingr_state_scalars *
         s->iteration = hst.iteration;
         s->status = hst.status;
     }
+    if (alpha) {  // what was just read IS the device state: the posterior memo can recognise it without a gingr_fitter_set_state
+        f->state_key.v.assign(alpha, alpha + f->m->r);
+        for (int q = 0; q < 3; ++q) f->state_key.v.push_back(hst.euler[q]);
+        for (int q = 0; q < 3; ++q) f->state_key.v.push_back(hst.center[q]);
+        for (int q = 0; q < 3; ++q) f->state_key.v.push_back(hst.t[q]);
+        f->state_key.v.push_back(hst.scale);
+        f->state_key.v.push_back(hst.sigma2);
+        f->state_key_valid = true;
+    }
     return GINGR_OK;
 }
 
