@@ -29,11 +29,6 @@ struct __attribute__((aligned(32))) P4 {
     double x, y, z, w;
 };
 
-// polynomial degree of the exponential in the two CPD passes (fastexp.h): 2 = one FMA less, 2e-13 on K_ij; 3 = 1 ulp
-#ifndef GINGR_CPD_EXP_DEGREE
-#define GINGR_CPD_EXP_DEGREE 2
-#endif
-constexpr int kDeg = GINGR_CPD_EXP_DEGREE;
 // Table of the two CPD passes: 2^11 entries (16 KB of LDS).  -DGINGR_CPD_TBITS=13 selects the 8192-entry table whose
 // byte offset is ONE SDWA shift (fastexp.h): half a VALU instruction less per pair and 3e-15 instead of 2e-13 on K, but
 // 64 KB of LDS per 256-thread workgroup leaves 2 waves per SIMD and the kernels turn latency bound -- measured SLOWER
@@ -223,7 +218,7 @@ __device__ __forceinline__ void colsum_tile(const P4 *tile, int j0, int j1, unsi
             const double dx = x[t] - p.x, dy = y[t] - p.y, dz = z[t] - p.z;
             double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
             if (CLAMP) d2 = fmin(d2, lim);
-            acc[t] += fastexp2_scaled<kDeg, kTB>(d2, c, T);
+            acc[t] += fastexp2_floor_scaled(d2, c, T);
         }
     }
 }
@@ -241,17 +236,21 @@ __device__ __forceinline__ bool use_expansion(double rmax_centered, double c) {
     return ratio * 7.7e-16 < kExpandTol;
 }
 
-__device__ __forceinline__ double exp_from_t(double t, const double *T) {
-    const double tm = t + GINGR_EXP_MAGIC;
-    const double kf = tm - GINGR_EXP_MAGIC;
-    const double f = t - kf;  // exact
-    return fastexp2_core<kDeg, kTB>(tm, f, T);
+// Owned-side constants of the expansion form.  n = c|x~|^2 of an owned point is split into its nearest integer, folded into the
+// magic constant of the range reduction (mg = MAGIC + rint(n): the table index and the exponent then come out for A + rint(n)
+// although only A is ever added), and the fraction n - rint(n) in [-1/2, 1/2], which is a constant FACTOR 2^(frac/2048) of every
+// K of that owned point and is applied once to the finished sums (expand_owned_scale).  One add per pair less.
+__device__ __forceinline__ double expand_owned_magic(double n, double *frac) {
+    const double ni = __builtin_rint(n);
+    *frac = n - ni;  // exact
+    return GINGR_EXP_MAGIC8 + ni;
 }
+__device__ __forceinline__ double expand_owned_scale(double frac) { return exp2(frac * (1.0 / kTabN)); }
 
-// tile entries: (-2c y~, c|y~|^2); owned: x~ and n = c|x~|^2
+// tile entries: (-2c y~, c|y~|^2); owned: x~ and mg = MAGIC + rint(c|x~|^2)   (float64 rounding mode: toward -inf)
 template <int PT, bool MASKED>
 __device__ __forceinline__ void colsum_tile_expand(const P4 *tile, int j0, int j1, unsigned mask, const double (&x)[PT],
-                                                   const double (&y)[PT], const double (&z)[PT], const double (&n)[PT],
+                                                   const double (&y)[PT], const double (&z)[PT], const double (&mg)[PT],
                                                    double (&acc)[PT], const double *T) {
 #pragma unroll 2
     for (int ii = j0; ii < j1; ++ii) {
@@ -259,8 +258,8 @@ __device__ __forceinline__ void colsum_tile_expand(const P4 *tile, int j0, int j
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
             if (MASKED && !((mask >> t) & 1u)) continue;
-            const double tt = __builtin_fma(z[t], p.z, __builtin_fma(y[t], p.y, __builtin_fma(x[t], p.x, p.w + n[t])));
-            acc[t] += exp_from_t(tt, T);
+            const double A = __builtin_fma(z[t], p.z, __builtin_fma(y[t], p.y, __builtin_fma(x[t], p.x, p.w)));
+            acc[t] += fastexp2_floor_core(A + mg[t], __builtin_amdgcn_fract(A), T);
         }
     }
 }
@@ -278,6 +277,7 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
     __shared__ double T[kTabN];
     __shared__ P4 tile[kTile];
     __shared__ double shbox[24];
+    __shared__ double sfrac[kBlock * PT];  // per owned point: fraction of c|x~|^2 (expansion form), parked until the epilogue
     const double c = fastexp_scale_for_variance<kTB>(2.0 * sigma2[0]);
     const double am = aux[0] + aux[1];
     // regime of the fine culling: the zero-flush radius is well inside the clouds' extent (3 am^2 bounds every squared distance)
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         *regime_out = (fit_boxes && 3.0 * am * am * (-c) > kFineCullRatio * GINGR_CULL_SCALED(kTabN)) ? 1 : 0;
         __threadfence_system();
     }
-    fastexp_table_init<kTB>(T);
+    fastexp_floor_table_init(T);
     const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);               // wave-uniform
     const bool expand = use_expansion(fmax(aux[0], aux[1]), c);             // wave-uniform
     const double lim = fastexp_d2_limit<kTB>(c);
@@ -320,11 +320,14 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
             y[t] -= cy;
             z[t] -= cz;
         }
-        n[t] = c * __builtin_fma(z[t], z[t], __builtin_fma(y[t], y[t], x[t] * x[t]));
+        double fr;
+        n[t] = expand_owned_magic(c * __builtin_fma(z[t], z[t], __builtin_fma(y[t], y[t], x[t] * x[t])), &fr);
+        sfrac[t * kBlock + tid] = fr;  // read back by the same thread only
         acc[t] = 0.0;
     }
     int64_t i0, i1;
     plan.range(blockIdx.y, fit.n, &i0, &i1);
+    fastexp_round_down();  // the floor form of the exponential needs it; every float64 result up to the epilogue rounds down
     // a chunk starts and ends on 64-point quarters, not necessarily on tiles: every pass handles the part of ONE box tile that
     // lies inside the chunk, so the tile / quarter boxes apply unchanged
     for (int64_t ib = i0, ie; ib < i1; ib = ie) {
@@ -374,9 +377,11 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
             }
         }
     }
+    fastexp_round_nearest();
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         const int64_t j = jbase + (int64_t)t * 64;
+        if (expand) acc[t] *= expand_owned_scale(sfrac[t * kBlock + tid]);
         if (j < tgt.n) partial[(int64_t)blockIdx.y * tgt.n + j] = acc[t];
     }
 }
@@ -482,7 +487,7 @@ __device__ __forceinline__ void rowstats_tile(const P4 *tile, const P4 *tw, int 
             const double dx = p.x - x[t], dy = p.y - y[t], dz = p.z - z[t];
             double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
             if (CLAMP) d2 = fmin(d2, lim);
-            const double k = fastexp2_scaled<kDeg, kTB>(d2, c, T);
+            const double k = fastexp2_floor_scaled(d2, c, T);
             a1[t] = __builtin_fma(k, p.w, a1[t]);
             ax[t] = __builtin_fma(k, q.x, ax[t]);
             ay[t] = __builtin_fma(k, q.y, ay[t]);
@@ -497,7 +502,7 @@ __device__ __forceinline__ void rowstats_tile(const P4 *tile, const P4 *tw, int 
 template <int PT, bool MASKED>
 __device__ __forceinline__ void rowstats_tile_expand(const P4 *tile, const P4 *tw, int j0, int j1, unsigned mask,
                                                      const double (&x)[PT], const double (&y)[PT], const double (&z)[PT],
-                                                     const double (&n)[PT], double (&a1)[PT], double (&ax)[PT], double (&ay)[PT],
+                                                     const double (&mg)[PT], double (&a1)[PT], double (&ax)[PT], double (&ay)[PT],
                                                      double (&az)[PT], const double *T) {
 #pragma unroll 2
     for (int jj = j0; jj < j1; ++jj) {
@@ -506,8 +511,8 @@ __device__ __forceinline__ void rowstats_tile_expand(const P4 *tile, const P4 *t
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
             if (MASKED && !((mask >> t) & 1u)) continue;
-            const double tt = __builtin_fma(z[t], p.z, __builtin_fma(y[t], p.y, __builtin_fma(x[t], p.x, p.w + n[t])));
-            const double k = exp_from_t(tt, T);
+            const double A = __builtin_fma(z[t], p.z, __builtin_fma(y[t], p.y, __builtin_fma(x[t], p.x, p.w)));
+            const double k = fastexp2_floor_core(A + mg[t], __builtin_amdgcn_fract(A), T);
             a1[t] = __builtin_fma(k, q.w, a1[t]);
             ax[t] = __builtin_fma(k, q.x, ax[t]);
             ay[t] = __builtin_fma(k, q.y, ay[t]);
@@ -527,13 +532,14 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
     __shared__ P4 tile[kTile];
     __shared__ P4 tw[kTile];
     __shared__ double shbox[24];
+    __shared__ double sfrac[kBlock * PT];  // see cpd_colsum_kernel
     const double c = fastexp_scale_for_variance<kTB>(2.0 * sigma2[0]);
     const double am = aux[0] + aux[1];
     if (regime_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         *regime_out = (tgt_boxes && 3.0 * am * am * (-c) > kFineCullRatio * GINGR_CULL_SCALED(kTabN)) ? 1 : 0;
         __threadfence_system();
     }
-    fastexp_table_init<kTB>(T);
+    fastexp_floor_table_init(T);
     const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);               // wave-uniform
     const bool expand = use_expansion(fmax(aux[0], aux[1]), c);             // wave-uniform
     const double lim = fastexp_d2_limit<kTB>(c);
@@ -567,11 +573,14 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
             y[t] -= cy;
             z[t] -= cz;
         }
-        n[t] = c * __builtin_fma(z[t], z[t], __builtin_fma(y[t], y[t], x[t] * x[t]));
+        double fr;
+        n[t] = expand_owned_magic(c * __builtin_fma(z[t], z[t], __builtin_fma(y[t], y[t], x[t] * x[t])), &fr);
+        sfrac[t * kBlock + tid] = fr;
         a1[t] = ax[t] = ay[t] = az[t] = 0.0;
     }
     int64_t j0, j1;
     plan.range(blockIdx.y, tgt.n, &j0, &j1);
+    fastexp_round_down();  // see cpd_colsum_kernel
     for (int64_t jb = j0, je; jb < j1; jb = je) {  // one box tile (or the part of it inside the chunk) per pass, see cpd_colsum_kernel
         je = min(j1, (jb / kTile + 1) * kTile);
         // all pairs flush to +0 -- unless a 1/den of the tile is inf/NaN: 0 * inf must stay NaN like the reference's 0/0
@@ -624,12 +633,20 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
             }
         }
     }
+    fastexp_round_nearest();
     const int64_t M = fit.n;
     double *base = partial + (int64_t)blockIdx.y * 4 * M;
     const double back = expand ? -0.5 / c : 1.0;  // sum_j p a_j -> sum_j p x~_j
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         const int64_t i = ibase + (int64_t)t * 64;
+        if (expand) {
+            const double e = expand_owned_scale(sfrac[t * kBlock + tid]);
+            a1[t] *= e;
+            ax[t] *= e;
+            ay[t] *= e;
+            az[t] *= e;
+        }
         if (i < M) {
             base[i] = a1[t];
             base[M + i] = expand ? __builtin_fma(cx, a1[t], back * ax[t]) : ax[t];

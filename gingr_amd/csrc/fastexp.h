@@ -101,6 +101,59 @@ __device__ __forceinline__ double fastexp2_scaled(double d2, double c, const dou
     return fastexp2_core<DEG, TB>(tm, f, T);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Floor form (the two CPD passes): two f64 instructions for the range reduction instead of three.
+//
+// With the wave's float64 rounding mode set to round-toward-minus-infinity (fastexp_round_down()), tm = u + MAGIC holds
+// floor(u) in its low mantissa bits and v_fract_f64 gives f = u - floor(u) in [0, 1) EXACTLY -- one add and
+// one fract instead of add, subtract, subtract.  The polynomial is the economised degree-2 one of ExpTab<11> re-centred on
+// [0, 1):  2^((j + f)/2048) = T'[j] (1 + f (Q0 + Q1 f)),  T'[j] = T[j] * S,  S = 2^(1/4096) (1 - C1_D2/2 + C2/4); same
+// 2.02e-13 bound (tools/gen_exp_table.py floor).  Everything a wave computes while the mode is set rounds down: sums of n
+// terms carry a bias of at most n 2^-53 relative (1e-13 over a 512-point chunk), inside the same budget.  Zero / subnormal /
+// NaN behaviour is unchanged (v_ldexp_f64; v_fract_f64 of NaN is NaN, of +-inf NaN as well -- callers clamp beforehand).
+struct ExpFloor11 {
+    static constexpr double Q0 = 3.384507681227659e-04;
+    static constexpr double Q1 = 5.728415556485551e-08;
+    static constexpr double S = 0x1.000000000038dp+0;
+};
+
+// MODE.FP_ROUND[3:2] (float64 / float16 rounding) <- 2 (toward -inf) resp. 0 (nearest even).  Inline assembly on purpose: the
+// compiler's mode-register pass (SIModeRegister) tracks s_setreg it can see and restores the default rounding in front of the
+// next float64 instruction (observed: `s_setreg_imm32_b32 hwreg(HW_REG_MODE, 3, 1), 0` right behind the builtin's setreg).
+__device__ __forceinline__ void fastexp_round_down() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\ts_nop 3" ::: "memory"); }
+__device__ __forceinline__ void fastexp_round_nearest() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0\n\ts_nop 3" ::: "memory"); }
+
+// table of the floor form: T'[j] = 2^(j/2048) * S; every thread of the block must call it, followed by __syncthreads()
+__device__ __forceinline__ void fastexp_floor_table_init(double *T) {
+    for (int j = threadIdx.x + threadIdx.y * blockDim.x; j < 2048; j += blockDim.x * blockDim.y)
+        T[j] = gingr_exp_table_rom[j] * ExpFloor11::S;
+}
+
+// The magic constant of the floor form is 1.5 * 2^49 (ulp 1/8): tm = u + MAGIC8 then holds floor(8u) = 8 floor(u) + s in its low
+// mantissa bits, s in [0, 7] being three fraction bits nobody needs -- f comes from v_fract_f64, not from tm -- so the BYTE
+// offset of T'[floor(u) & 2047] is (lo & 0x3FF8): one v_and instead of v_and + v_lshl, and the exponent is bits 14..45.
+#define GINGR_EXP_MAGIC8 844424930131968.0    /* 1.5 * 2^49 */
+
+// 2^((k + f)/2048) with tm = MAGIC8 + k + s/8 (k = floor of the argument, any integer offset already folded into MAGIC8) and f in
+// [0, 1); valid for |k| < 2^45
+__device__ __forceinline__ double fastexp2_floor_core(double tm, double f, const double *T) {
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, tm);
+    const unsigned lo = (unsigned)bits, hi = (unsigned)(bits >> 32);
+    const int e = (int)__builtin_amdgcn_alignbit(hi, lo, 14);
+    const double q = __builtin_fma(f, ExpFloor11::Q1, ExpFloor11::Q0);
+    const double tj = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(T) + (lo & 0x3FF8u));
+    const double fq = f * q;
+    const double r = __builtin_fma(tj, fq, tj);
+    return __builtin_ldexp(r, e);
+}
+
+// 2^(d2*c/2048), difference form (requires round-down mode).  The product is rounded before the reduction: a relative error of
+// K of |ln K| 2^-53 <= 8e-14, below the polynomial's.
+__device__ __forceinline__ double fastexp2_floor_scaled(double d2, double c, const double *T) {
+    const double u = d2 * c;
+    return fastexp2_floor_core(u + GINGR_EXP_MAGIC8, __builtin_amdgcn_fract(u), T);
+}
+
 // c such that exp(-d2 / two_sigma2) = 2^(d2*c/2^TB)
 template <int TB = 11>
 __device__ __forceinline__ double fastexp_scale_for_variance(double two_sigma2) {

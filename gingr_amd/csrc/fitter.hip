@@ -87,6 +87,7 @@ struct gingr_fitter {
     double *small = nullptr;  // 8 doubles of device scratch for scalar results
     void *stat_scratch = nullptr;  // StatScratch of gingr_fitter_surface_distance_stats (kept across calls)
     double *lsave = nullptr;  // [rp][rp]: Cholesky factor of I + G kept across the two systems of the transition-density query
+    int32_t *retry = nullptr;  // device word: retryCounter of the algorithm instance this fitter stands for (GingrAlgorithm.scala:69-70)
 };
 
 namespace {
@@ -409,6 +410,14 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
         gingr_fitter_destroy(f);
         return rc;
     }
+    if ((rc = dev_alloc(ctx, &f->retry, 1))) {
+        gingr_fitter_destroy(f);
+        return rc;
+    }
+    {
+        const int32_t init = GINGR_RETRY_INIT;
+        HIP_TRY(ctx, hipMemcpy(f->retry, &init, sizeof(init), hipMemcpyHostToDevice));
+    }
     (void)hipMemsetAsync(f->lm_mask, 0, (size_t)M * sizeof(int32_t), ctx->stream);
     (void)hipMemsetAsync(f->alpha, 0, (size_t)rp * sizeof(double), ctx->stream);
     (void)hipMemsetAsync(f->scalars, 0, 8 * sizeof(double), ctx->stream);
@@ -445,6 +454,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->scalars);
     dev_free(f->small);
     dev_free(f->lsave);
+    dev_free(f->retry);
     dev_free(f->part);
     dev_free(f->absmax);
     dev_free(f->tperm);
@@ -709,6 +719,18 @@ int gingr_fitter_get_icp_idx(gingr_fitter *f, int32_t *idx, double *d2) {
     return GINGR_OK;
 }
 
+int gingr_fitter_retry_counter(gingr_fitter *f, int32_t set_to, int32_t *value_out) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = f->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (set_to >= 0) HIP_TRY(ctx, hipMemcpyAsync(f->retry, &set_to, sizeof(set_to), hipMemcpyHostToDevice, ctx->stream));
+    int32_t v = set_to;
+    if (value_out && set_to < 0) HIP_TRY(ctx, hipMemcpyAsync(&v, f->retry, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (value_out) *value_out = v;
+    return GINGR_OK;
+}
+
 int gingr_fitter_exchange(gingr_fitter *f, void **dev_ptr, int64_t offsets[GINGR_NUM_SEGMENTS],
                           int64_t counts[GINGR_NUM_SEGMENTS]) {
     if (!f || !dev_ptr) return GINGR_ERR_BAD_ARGUMENT;
@@ -875,6 +897,8 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
             }
             for (int q = 0; q < 9; ++q) a.Pp[q] = m->Pp[q];
             a.state = f->st;
+            a.retry = f->retry;
+            a.probabilistic = f->zrand_active ? 1 : 0;
             launch_post_solve(ctx, a);
             refresh_fit(f);
             break;

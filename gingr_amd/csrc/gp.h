@@ -141,27 +141,8 @@ int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
 int64_t posterior_work_doubles(int32_t rp);
 // Binv = (S/eps + I)^-1  (work: [rp*rp]); *err_flag != 0 on failure
 void launch_binv(gingr_ctx *ctx, int32_t r, int32_t rp, const double *S, double *work, double *Binv, int32_t *err_flag);
-// alpha1 = Binv (p/eps); alpha_c = alpha + (alpha1 - alpha) * step      GingrAlgorithm.scala:218-220
-void launch_alpha_blend(gingr_ctx *ctx, int32_t r, int32_t rp, const double *Binv, const double *p, const double *alpha,
-                        double step, double *alpha_c);
 // out = Binv (p/eps)
 void launch_coeff_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *Binv, const double *p, double *out);
-// Umeyama from the 24 partial sums (count = M_total); writes the candidate pose
-void launch_umeyama(gingr_ctx *ctx, const double *sums, int64_t M_total, const double c0[3], int32_t global_transform,
-                    DevPose *pose, DevState *st);
-// commit: alpha' = Binv (p2/eps); accept or keep; sigma2 from scalars (CPD) or schedule (ICP); iteration++
-struct CommitArgs {
-    int32_t r, rp;
-    const double *Binv;
-    const double *p2;
-    const double *scalars;  // reduced {Np, xPx, trPXY, yPy,...} or nullptr for ICP
-    int32_t is_icp;
-    double icp_step, icp_end;
-    double *alpha;          // in/out
-    const DevPose *pose;
-    DevState *state;
-};
-void launch_commit(gingr_ctx *ctx, const CommitArgs &a);
 void launch_state_init(gingr_ctx *ctx, DevState *st, const gingr_state_scalars *host_scalars_dev);
 
 // moment Gram S[d][e] (all patches, no symmetry): ws sized like gram_ws_doubles
@@ -185,7 +166,10 @@ struct PostSolveArgs {
     double n_total;
     double c0[3], Pp[9], Ps[3];
     DevState *state;
+    int32_t *retry;         // retryCounter of the algorithm instance (GingrAlgorithm.scala:69-70), device word; nullable
+    int32_t probabilistic;  // update(current, probabilistic = true)
 };
+#define GINGR_RETRY_INIT 10 /* retryCounterInitialize, GingrAlgorithm.scala:69 */
 void launch_post_solve(gingr_ctx *ctx, const PostSolveArgs &a);
 // the 19 independent r x r mat-vecs the fused kernel consumes, one workgroup each (they only depend on alpha and a)
 void launch_post_matvecs(gingr_ctx *ctx, const gingr_model *m, const double *alpha, const double *a, double *zbuf);

@@ -7,8 +7,9 @@
 //                     instance (:222,224, ModelFittingParameters.scala:134), Umeyama partial sums (:260-279);
 //                     HBM-bound streaming of Q0, fused with the pose / projection epilogues
 //   posterior_solve   pinv(QtL Q + I) * QtL (y - m)  -> Cholesky solve of the SPD matrix I + G
-//   umeyama_kernel    LandmarkRegistration.rigid3D/similarity3DLandmarkRegistration (3x3 SVD + Euler round trip)
-//   commit_kernel     the state hand-over of update (:239-246) incl. the Try-failure path (:194-208,248,251)
+//   post_solve_kernel LandmarkRegistration.rigid3D/similarity3DLandmarkRegistration (3x3 SVD + Euler round trip) from the moments,
+//                     second projection, the state hand-over of update (:239-246) incl. the Try-failure paths and the retry
+//                     counter of the probabilistic proposal (:194-210,248,251)
 //
 // Layout: Q0 is row-major [3M][rp]: the 3 x rp block of one point is contiguous (2.7 KB at r = 100), so one point's
 // observation weight, rotation and epilogue touch one contiguous block; rp = rank rounded up to 16 (MFMA tile).
@@ -1080,19 +1081,6 @@ __device__ __forceinline__ double binv_row_apply16(const double *__restrict__ Bi
     return s / GINGR_COEFF_NOISE;
 }
 
-__global__ __launch_bounds__(256) void alpha_blend_kernel(int r, int rp, const double *__restrict__ Binv,
-                                                          const double *__restrict__ p, const double *__restrict__ alpha,
-                                                          double step, double *__restrict__ alpha_c) {
-    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), lane16 = threadIdx.x & 15;
-    const double a1 = binv_row_apply16(Binv, p, r, rp, i, lane16);
-    if (i >= rp || lane16 != 0) return;
-    if (i >= r) {
-        alpha_c[i] = 0.0;
-        return;
-    }
-    const double a0 = alpha[i];
-    alpha_c[i] = a0 + (a1 - a0) * step;  // GingrAlgorithm.scala:219-220
-}
 
 __global__ __launch_bounds__(256) void coeff_solve_kernel(int r, int rp, const double *__restrict__ Binv,
                                                           const double *__restrict__ p, double *__restrict__ out) {
@@ -1148,15 +1136,6 @@ __device__ bool umeyama_from_sums(const double *sums, double n, const double c0[
     return fin;
 }
 
-__global__ void umeyama_kernel(const double *__restrict__ sums, double n, double c0x, double c0y, double c0z,
-                               int global_transform, DevPose *__restrict__ pose, DevState *__restrict__ st) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double c0[3] = {c0x, c0y, c0z};
-    DevPose P;
-    const bool fin = umeyama_from_sums(sums, n, c0, global_transform, P);
-    if (!fin && st->err == 0) st->err = GINGR_ERR_NONFINITE;
-    *pose = P;
-}
 
 // ------------------------------------------------------------------------------------------------- fused post-solve
 // out[k] = sum_j Mat[j*rp + k] * x[j]   (i.e. Mat^T x; pass the transposed partner for a non-symmetric matrix).
@@ -1351,11 +1330,33 @@ __global__ __launch_bounds__(kPostThreads) void post_solve_kernel(PostSolveArgs 
         if (!finite_d(v)) bad = 1;
     }
     __syncthreads();
-    const bool failed = (st->err != 0) || bad;
+    // Failure semantics of GingrAlgorithm.update (G/api/GingrAlgorithm.scala:192-254):
+    //   posterior failed (Try of computePosterior, here: the solve flagged st->err)
+    //       iteration 0                      -> state unchanged                                          (:206-208)
+    //       iteration > 0, deterministic     -> ModelFlexibilityError                                    (:203-205)
+    //       iteration > 0, probabilistic     -> retryCounter == 0 ? ModelFlexibilityError
+    //                                           : { retryCounter -= 1; state unchanged }                  (:196-202)
+    //   posterior fine                       -> retryCounter = min(10, retryCounter + 1)                  (:210)
+    //       a coefficients() projection (or the alignment between them) failed -> ModelFlexibilityError at ANY iteration
+    //                                                                                                     (:248-251)
+    // Non-finite values count as failures: in the reference they make Breeze's SVD throw inside the Try.
+    const bool posterior_failed = st->err != 0;
+    const bool failed = posterior_failed || bad;
     __syncthreads();
     if (!failed)
         for (int k = tid; k < rp; k += kPostThreads) A.alpha[k] = anew[k];
     if (tid == 0) {
+        if (posterior_failed) {
+            if (st->iteration > 0) {
+                if (A.probabilistic && A.retry && *A.retry > 0)
+                    *A.retry -= 1;
+                else
+                    st->status = GINGR_FIT_MODEL_FLEXIBILITY_ERROR;
+            }
+        } else {
+            if (A.retry) *A.retry = *A.retry + 1 < GINGR_RETRY_INIT ? *A.retry + 1 : GINGR_RETRY_INIT;
+            if (bad) st->status = GINGR_FIT_MODEL_FLEXIBILITY_ERROR;
+        }
         if (!failed) {
             for (int q = 0; q < 9; ++q) st->R[q] = P.R[q];
             for (int q = 0; q < 3; ++q) {
@@ -1371,54 +1372,6 @@ __global__ __launch_bounds__(kPostThreads) void post_solve_kernel(PostSolveArgs 
                 const double *sc = A.scalars;                    // CPD.scala:142-145
                 st->sigma2 = (sc[1] - 2 * sc[2] + sc[3]) / (sc[0] * 3.0);
             }
-        } else if (st->iteration > 0) {
-            st->status = GINGR_FIT_MODEL_FLEXIBILITY_ERROR;       // GingrAlgorithm.scala:204,248,251 (iteration 0: :206-208)
-        }
-        st->pad = failed ? (st->err != 0 ? st->err : GINGR_ERR_NONFINITE) : 0;  // last error, readable by the host
-        st->err = 0;
-        st->iteration += 1;  // GingrGeneratorWrapper.propose: updateIteration()
-    }
-}
-
-__global__ __launch_bounds__(kDenseThreads) void commit_kernel(CommitArgs a) {
-    __shared__ double anew[512];
-    __shared__ int bad;
-    if (threadIdx.x == 0) bad = 0;
-    __syncthreads();
-    DevState *st = a.state;
-    if (st->status == GINGR_FIT_MODEL_FLEXIBILITY_ERROR) return;  // a failed fit stays as it is (run stops, :149-157)
-    for (int i0 = 0; i0 < a.rp; i0 += kDenseThreads / 16) {
-        const int i = i0 + (threadIdx.x >> 4);
-        const double v = binv_row_apply16(a.Binv, a.p2, a.r, a.rp, i, threadIdx.x & 15);
-        if (i < a.rp && (threadIdx.x & 15) == 0) {
-            anew[i] = i < a.r ? v : 0.0;
-            if (i < a.r && !finite_d(v)) bad = 1;
-        }
-    }
-    __syncthreads();
-    const bool failed = (st->err != 0) || bad;
-    __syncthreads();
-    if (!failed) {
-        for (int i = threadIdx.x; i < a.rp; i += blockDim.x) a.alpha[i] = anew[i];
-    }
-    if (threadIdx.x == 0) {
-        if (!failed) {
-            for (int q = 0; q < 9; ++q) st->R[q] = a.pose->R[q];
-            for (int q = 0; q < 3; ++q) {
-                st->euler[q] = a.pose->euler[q];
-                st->center[q] = 0.0;  // Umeyama about Point(0,0,0), GingrAlgorithm.scala:81,266
-                st->t[q] = a.pose->t[q];
-            }
-            st->scale = a.pose->scale;
-            if (a.is_icp) {
-                const double ns = st->sigma2 - a.icp_step;       // ICP.scala:96-99
-                st->sigma2 = ns > a.icp_end ? ns : a.icp_end;
-            } else {
-                const double *sc = a.scalars;                    // CPD.scala:142-145
-                st->sigma2 = (sc[1] - 2 * sc[2] + sc[3]) / (sc[0] * 3.0);
-            }
-        } else if (st->iteration > 0) {
-            st->status = GINGR_FIT_MODEL_FLEXIBILITY_ERROR;       // GingrAlgorithm.scala:204,248,251 (iteration 0: :206-208)
         }
         st->pad = failed ? (st->err != 0 ? st->err : GINGR_ERR_NONFINITE) : 0;  // last error, readable by the host
         st->err = 0;
@@ -1646,22 +1599,12 @@ void launch_binv(gingr_ctx *ctx, int32_t r, int32_t rp, const double *S, double 
     hipLaunchKernelGGL(binv_kernel, dim3(1), dim3(kDenseThreads), 0, ctx->stream, (int)r, (int)rp, S, work, Binv, err_flag);
 }
 
-void launch_alpha_blend(gingr_ctx *ctx, int32_t r, int32_t rp, const double *Binv, const double *p, const double *alpha,
-                        double step, double *alpha_c) {
-    hipLaunchKernelGGL(alpha_blend_kernel, dim3((unsigned)ceil_div(rp, 16)), dim3(256), 0, ctx->stream, (int)r, (int)rp, Binv,
-                       p, alpha, step, alpha_c);
-}
 
 void launch_coeff_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *Binv, const double *p, double *out) {
     hipLaunchKernelGGL(coeff_solve_kernel, dim3((unsigned)ceil_div(rp, 16)), dim3(256), 0, ctx->stream, (int)r, (int)rp, Binv,
                        p, out);
 }
 
-void launch_umeyama(gingr_ctx *ctx, const double *sums, int64_t M_total, const double c0[3], int32_t global_transform,
-                    DevPose *pose, DevState *st) {
-    hipLaunchKernelGGL(umeyama_kernel, dim3(1), dim3(64), 0, ctx->stream, sums, (double)M_total, c0[0], c0[1], c0[2],
-                       (int)global_transform, pose, st);
-}
 
 void launch_post_solve(gingr_ctx *ctx, const PostSolveArgs &a) {
     int width = 16;
@@ -1684,9 +1627,6 @@ void launch_small_gemm(gingr_ctx *ctx, int32_t r, int32_t rp, const double *A, c
                        (int)rp, A, B, scale, out);
 }
 
-void launch_commit(gingr_ctx *ctx, const CommitArgs &a) {
-    hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(kDenseThreads), 0, ctx->stream, a);
-}
 
 void launch_state_init(gingr_ctx *ctx, DevState *st, const gingr_state_scalars *host_scalars_dev) {
     hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, ctx->stream, st, host_scalars_dev);

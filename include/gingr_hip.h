@@ -276,6 +276,13 @@ int gingr_fitter_update_icp_sample_async(gingr_fitter *f, const gingr_icp_params
 int gingr_fitter_posterior_logpdf_cpd(gingr_fitter *f, const gingr_cpd_params *p, const double *mesh_xyz, double *logpdf);
 int gingr_fitter_posterior_logpdf_icp(gingr_fitter *f, const gingr_icp_params *p, const double *mesh_xyz, double *logpdf);
 
+/* The retry counter of the probabilistic proposal (G/api/GingrAlgorithm.scala:69-70,196-202,210: `retryCounter`, a private var
+ * of the algorithm INSTANCE): a sampled proposal whose posterior cannot be computed returns the state unchanged up to 10 times in
+ * a row before the state is marked ModelFlexibilityError; every successful posterior gives one retry back (at most 10).  The
+ * fitter is the device-side stand-in of one algorithm instance, so the counter lives with it (it survives gingr_fitter_set_state).
+ * set_to >= 0 writes the counter, set_to < 0 only reads; value_out (nullable) receives the value.  Synchronises. */
+int gingr_fitter_retry_counter(gingr_fitter *f, int32_t set_to, int32_t *value_out);
+
 /* ---- row-sharded update, host-driven exchange (multi-GPU) -----------------------------------------------------
  * One iteration = phases 0..GINGR_NUM_PHASES-1.  After phase p < GINGR_NUM_SEGMENTS the host all-reduces (sum, float64)
  * exchange segment p across shards (RCCL over xGMI via torch.distributed, or nothing for one shard), then runs phase p+1.
