@@ -11,6 +11,7 @@ from .api import (  # noqa: F401
     DevicePointDistributionModel, GaussianKernelParameters, GPMMTriangleMesh3D, PointSetHelper, automaticGPMMfromTemplate,
 )
 from ._native import GingrNativeError  # noqa: F401
+from .group import DeviceGroup  # noqa: F401  (in-library multi-GPU group: gingr_group_*)
 from . import io  # noqa: F401  (file / wire formats shared with the Scala host)
 from . import classic  # noqa: F401  (the reference's other/ CPD family on the device)
 from . import sampling  # noqa: F401  (Metropolis-Hastings chain, evaluators, proposals, accuracy metrics)

@@ -109,9 +109,27 @@ SIGNATURES = {
     "gingr_fitter_update_icp_sample_async": (c_int, [c_void_p, POINTER(IcpParams), _dp]),
     "gingr_fitter_posterior_logpdf_cpd": (c_int, [c_void_p, POINTER(CpdParams), _dp, _dp]),
     "gingr_fitter_posterior_logpdf_icp": (c_int, [c_void_p, POINTER(IcpParams), _dp, _dp]),
+    "gingr_fitter_retry_counter": (c_int, [c_void_p, c_int32, POINTER(c_int32)]),
     "gingr_fitter_exchange": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64)]),
     "gingr_fitter_cpd_phase_async": (c_int, [c_void_p, POINTER(CpdParams), c_int32]),
     "gingr_fitter_icp_phase_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32]),
+    "gingr_group_create": (c_int, [c_int32, _ip, POINTER(c_void_p)]),
+    "gingr_group_destroy": (None, [c_void_p]),
+    "gingr_group_size": (c_int32, [c_void_p]),
+    "gingr_group_last_error": (c_char_p, [c_void_p]),
+    "gingr_group_ctx": (c_void_p, [c_void_p, c_int32]),
+    "gingr_group_shard_rows": (c_int, [c_void_p, c_int32, POINTER(c_int64), POINTER(c_int64)]),
+    "gingr_group_model_upload": (c_int, [c_void_p, c_int64, c_int32, _dp, _dp, _dp, _dp]),
+    "gingr_group_gpmm_build_gaussian": (c_int, [c_void_p, c_int64, _dp, c_int32, _dp, _dp, c_double, c_int32]),
+    "gingr_group_model_rank": (c_int32, [c_void_p]),
+    "gingr_group_set_target": (c_int, [c_void_p, c_int64, _dp]),
+    "gingr_group_set_landmarks": (c_int, [c_void_p, c_int32, _ip, _dp, _dp]),
+    "gingr_group_set_options": (c_int, [c_void_p, c_int32, c_double]),
+    "gingr_group_set_state": (c_int, [c_void_p, _dp, POINTER(StateScalars)]),
+    "gingr_group_get_state": (c_int, [c_void_p, _dp, POINTER(StateScalars), _dp]),
+    "gingr_group_update_cpd_async": (c_int, [c_void_p, POINTER(CpdParams), c_int32]),
+    "gingr_group_update_icp_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32]),
+    "gingr_group_synchronize": (c_int, [c_void_p]),
     "gingr_ctx_timing_enable": (c_int, [c_void_p, c_int32]),
     "gingr_ctx_timing_read": (c_int, [c_void_p, c_int32, _dp, POINTER(c_int64)]),
     "gingr_ctx_timing_reset": (c_int, [c_void_p]),

@@ -499,40 +499,43 @@ class GingrAlgorithm:
         self._lib = ctx._lib
         self._dev_model: Optional[DeviceModel] = None
         self._fitter = None
-        self._model_id = None
-        self._target_id = None
-        self._lm_id = None
-        self._device_state_token = None   # identity of the python state currently mirrored on the device
+        # The objects currently bound on the device.  Strong references compared with `is` (an id() of a collected object can be
+        # reused by a new one of the same shape); arrays are treated as immutable, like the reference's case-class fields.
+        self._bound_model = None
+        self._bound_target = None
+        self._bound_lm = None
+        self._bound_mesh = None
+        self._device_state = None         # the python state currently mirrored on the device (strong reference, compared with `is`)
 
     # -- native plumbing ------------------------------------------------------------------
     def _bind(self, general: GeneralRegistrationState, use_landmarks: bool):
-        if self._model_id != id(general.model):
+        if self._bound_model is not general.model:
             self._release()
             self._dev_model = DeviceModel(self.ctx, general.model)
             h = c_void_p()
             _check(self.ctx.handle, self._lib.gingr_fitter_create(self.ctx.handle, self._dev_model.handle, ctypes.byref(h)),
                    "gingr_fitter_create")
             self._fitter = h
-            self._model_id = id(general.model)
-            self._target_id = None
-            self._lm_id = None
-            self._mesh_id = None
-        if self._target_id != id(general.target):
+            self._bound_model = general.model
+            self._bound_target = None
+            self._bound_lm = None
+            self._bound_mesh = None
+        if self._bound_target is not general.target:
             x = f64(general.target)
             _check(self.ctx.handle, self._lib.gingr_fitter_set_target(self._fitter, x.shape[0], dptr(x)), "gingr_fitter_set_target")
-            self._target_id = id(general.target)
-            self._device_state_token = None
-            self._mesh_id = None
+            self._bound_target = general.target
+            self._device_state = None
+            self._bound_mesh = None
         mcells = getattr(general.model, "cells", None)
-        if mcells is not None and general.targetCells is not None and getattr(self, "_mesh_id", None) != (id(mcells), id(general.targetCells)):
+        if mcells is not None and general.targetCells is not None and not (
+                self._bound_mesh is not None and self._bound_mesh[0] is mcells and self._bound_mesh[1] is general.targetCells):
             mt = np.ascontiguousarray(mcells, dtype=np.int32).reshape(-1, 3)
             tt = np.ascontiguousarray(general.targetCells, dtype=np.int32).reshape(-1, 3)
             _check(self.ctx.handle, self._lib.gingr_fitter_set_meshes(self._fitter, mt.shape[0], iptr(mt), tt.shape[0], iptr(tt)),
                    "gingr_fitter_set_meshes")
-            self._mesh_id = (id(mcells), id(general.targetCells))
+            self._bound_mesh = (mcells, general.targetCells)
         lm = general.landmarkCorrespondences if use_landmarks else None
-        key = (id(lm), use_landmarks)
-        if self._lm_id != key:
+        if not (self._bound_lm is not None and self._bound_lm[0] is lm and self._bound_lm[1] == use_landmarks):
             if lm is not None and len(lm.pids) > 0:
                 lp = np.ascontiguousarray(lm.pids, dtype=np.int32)
                 lx, lc = f64(lm.points), f64(lm.covs)
@@ -541,7 +544,7 @@ class GingrAlgorithm:
             else:
                 _check(self.ctx.handle, self._lib.gingr_fitter_set_landmarks(self._fitter, 0, None, None, None),
                        "gingr_fitter_set_landmarks")
-            self._lm_id = key
+            self._bound_lm = (lm, use_landmarks)
         _check(self.ctx.handle, self._lib.gingr_fitter_set_options(self._fitter, int(general.globalTransformation),
                                                                    float(general.stepLength)), "gingr_fitter_set_options")
 
@@ -552,9 +555,20 @@ class GingrAlgorithm:
         if self._dev_model is not None:
             self._dev_model.close()
             self._dev_model = None
+        self._bound_model = self._bound_target = self._bound_lm = self._bound_mesh = None
+        self._device_state = None
 
     def close(self):
         self._release()
+
+    @property
+    def retryCounter(self) -> int:
+        """`retryCounter` of this algorithm instance (GingrAlgorithm.scala:69-70); it lives on the device next to the state."""
+        if not self._fitter:
+            return 10
+        v = ctypes.c_int32()
+        _check(self.ctx.handle, self._lib.gingr_fitter_retry_counter(self._fitter, -1, ctypes.byref(v)), "gingr_fitter_retry_counter")
+        return int(v.value)
 
     def _push_state(self, general: GeneralRegistrationState):
         mp = general.modelParameters
@@ -590,13 +604,16 @@ class GingrAlgorithm:
         raise NotImplementedError
 
     def update(self, current, probabilistic: bool = False, rnd: Optional[np.random.Generator] = None):
-        """One GiNGR iteration.  Numerical failure of the posterior / projections maps to
-        FittingStatuses.ModelFlexibilityError exactly like the reference's Try(...) handling (:194-208,248,251).
+        """One GiNGR iteration.  Failure handling as in the reference's Try(...) logic, decided on the device (post_solve_kernel):
+        a failed posterior leaves the state unchanged at iteration 0, gives ModelFlexibilityError in a deterministic update,
+        and in a probabilistic one uses up one of the instance's 10 retries (state unchanged) before it gives
+        ModelFlexibilityError (:194-208; successes give retries back, :210); a failed coefficient projection is a
+        ModelFlexibilityError at any iteration (:248-251).
         probabilistic=True proposes posterior.sample() instead of posterior.mean (:211); the standard-normal draws come from
         `rnd` (the reference's `implicit rnd: Random`)."""
         g = current.general
         self._bind(g, current.config.useLandmarkCorrespondence)
-        if self._device_state_token != id(current):
+        if self._device_state is not current:
             self._push_state(g)
         if probabilistic:
             if rnd is None:
@@ -606,18 +623,16 @@ class GingrAlgorithm:
             self._native_update(current, 1)
         new_general = self._pull_state(g)
         out = current.updateGeneral(new_general)
-        self._device_state_token = id(out)
-        self._keepalive = out
+        self._device_state = out
         return out
 
     def _ensure_device_state(self, state):
         """Make the fitter hold `state` (model, target, meshes, parameters; the fit is re-instantiated on the device)."""
         g = state.general
         self._bind(g, state.config.useLandmarkCorrespondence)
-        if self._device_state_token != id(state):
+        if self._device_state is not state:
             self._push_state(g)
-            self._device_state_token = id(state)
-            self._keepalive = state
+            self._device_state = state
 
     def proposeParameters(self, current, modelParameters: ModelFittingParameters, generatedBy: str):
         """GingrGeneratorWrapper.propose for a proposal that only rewrites the parameters (GingrGeneratorWrapper.scala:28-39):
@@ -627,8 +642,7 @@ class GingrAlgorithm:
         self._push_state(g)
         new_general = dataclasses.replace(self._pull_state(g), generatedBy=generatedBy)
         out = current.updateGeneral(new_general)
-        self._device_state_token = id(out)
-        self._keepalive = out
+        self._device_state = out
         return out
 
     def surfaceDistanceStats(self, state, direction: int, n_points: int = 0, points=None, boundary_aware: bool = False,
@@ -760,9 +774,9 @@ class CpdRegistration(GingrAlgorithm):
 
     # plugin accessors served from one streaming evaluation (the reference recomputes P for each of them)
     def _stats(self, state: CpdRegistrationState) -> dict:
-        if getattr(self, "_stats_key", None) != id(state):
+        if getattr(self, "_stats_state", None) is not state:
             self._stats_cache = self.ctx.cpd_stats(state.general.fit, state.general.target, state.general.sigma2, state.config.w)
-            self._stats_key = id(state)
+            self._stats_state = state
             self._stats_keep = state
         return self._stats_cache
 
@@ -802,7 +816,7 @@ class IcpRegistration(GingrAlgorithm):
         g, c = state.general, state.config
         self._bind(g, c.useLandmarkCorrespondence)
         self._push_state(g)
-        self._device_state_token = None
+        self._device_state = None
         self._select_direction(c)
         p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
         if self._surface(c):

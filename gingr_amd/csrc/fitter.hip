@@ -87,6 +87,10 @@ struct gingr_fitter {
     double *small = nullptr;  // 8 doubles of device scratch for scalar results
     void *stat_scratch = nullptr;  // StatScratch of gingr_fitter_surface_distance_stats (kept across calls)
     double *lsave = nullptr;  // [rp][rp]: Cholesky factor of I + G kept across the two systems of the transition-density query
+    // Where phases 0 / 1 put THIS shard's partial sums (same segment layout as xch).  nullptr: into xch itself (single shard, or a
+    // host that all-reduces xch in place -- torch.distributed).  The device group (group.hip) points it at the shard's send
+    // buffer: peers read that while the summed result lands in xch, so nobody overwrites what a peer may still be reading.
+    double *partial_out = nullptr;
     int32_t *retry = nullptr;  // device word: retryCounter of the algorithm instance this fitter stands for (GingrAlgorithm.scala:69-70)
 };
 
@@ -745,6 +749,11 @@ int gingr_fitter_exchange(gingr_fitter *f, void **dev_ptr, int64_t offsets[GINGR
 
 }  // extern "C"
 
+// --------------------------------------------------------------------------------------------------- internal hooks (group.hip)
+void fitter_set_partial_output(gingr_fitter *f, double *base) { f->partial_out = base; }
+gingr_ctx *fitter_ctx(gingr_fitter *f) { return f->ctx; }
+const gingr_model *fitter_model(gingr_fitter *f) { return f->m; }
+
 // --------------------------------------------------------------------------------------------------- phases
 namespace {
 
@@ -753,10 +762,17 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
     const gingr_model *m = f->m;
     const int64_t M = m->M;
     const int32_t r = m->r, rp = m->rp;
+    // reduced (summed over shards) segments, read by phases 1 and 2 ...
     double *seg0 = f->xch + f->off[0];
     double *G = f->xch + f->off[1];
     double *rhs = G + (int64_t)rp * rp;
     double *sc8 = rhs + rp;
+    // ... and where this shard's partial sums are written by phases 0 and 1
+    double *wbase = f->partial_out ? f->partial_out : f->xch;
+    double *seg0w = wbase + f->off[0];
+    double *Gw = wbase + f->off[1];
+    double *rhsw = Gw + (int64_t)rp * rp;
+    double *sc8w = rhsw + rp;
     const Cloud fit = cloud_of(f->fit, M);
     const Cloud tgt = cloud_of(f->target, f->N);
     // posterior memo (see gingr_fitter::Key): skip phases 0 and 1 when their results for exactly this state are still in place
@@ -835,7 +851,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
             else {
                 // boxes of the fit tiles + its |coordinate - centroid| maximum (slot cleared by the pass that wrote the fit)
                 launch_tile_bbox(ctx, fit, f->fboxes, f->absmax + 2, f->absmax + 1);
-                launch_cpd_colsum(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->fboxes, f->ws, seg0);
+                launch_cpd_colsum(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->fboxes, f->ws, seg0w);
             }
             break;
         }
@@ -847,12 +863,12 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                     launch_obs_points(ctx, m, f->st, f->surf_cp, f->surf_win, f->weight, f->evec, f->lm_mask);
                 else
                     launch_obs_icp(ctx, m, f->st, tgt, f->nn_idx, f->lm_mask, f->weight, f->evec);
-                hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(64), 0, ctx->stream, sc8, (int64_t)8);
+                hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(64), 0, ctx->stream, sc8w, (int64_t)8);
             } else {
                 launch_cpd_den_finalize(ctx, tgt, &f->st->sigma2, cp->w, m->M_total, seg0, f->inv_den, f->Pt1, f->tile_bad, f->part,
                                         f->scalars);
                 launch_cpd_rowstats(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->inv_den, f->tboxes, f->tile_bad, f->ws, f->P1,
-                                    f->PX, f->part, f->scalars, sc8, m->row_begin == 0 ? 1 : 0);
+                                    f->PX, f->part, f->scalars, sc8w, m->row_begin == 0 ? 1 : 0);
                 launch_obs_cpd(ctx, m, f->st, fit, f->P1, f->PX, cp->lambda, f->lm_mask, f->weight, f->evec);
             }
             if (icp && !f->icp_surface && !f->reversed && f->n_lm == 0) {
@@ -860,15 +876,15 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 // is the model's one-off moment Q^T Q scaled -- no pass over the basis.  mom holds the total over ALL shards: the
                 // shard that owns row 0 contributes it, the others contribute zero to the exchange.
                 hipLaunchKernelGGL(scaled_copy_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 256)), dim3(256), 0, ctx->stream,
-                                   m->mom + MomentLayout{rp}.stot(), (int64_t)rp * rp, &f->st->sigma2, m->row_begin == 0 ? 1 : 0, G);
+                                   m->mom + MomentLayout{rp}.stot(), (int64_t)rp * rp, &f->st->sigma2, m->row_begin == 0 ? 1 : 0, Gw);
             } else {
-                launch_gram(ctx, m->Q0, M, rp, f->weight, f->ws, G);
+                launch_gram(ctx, m->Q0, M, rp, f->weight, f->ws, Gw);
             }
             SweepArgs a = base_args(f);
             a.evec = f->evec;
-            a.out = rhs;
+            a.out = rhsw;
             launch_sweep(ctx, SWEEP_RHS, a);
-            launch_landmarks(ctx, m, f->st, f->n_lm, f->lm_pid, f->lm_xyz, f->lm_cov, G, rhs);
+            launch_landmarks(ctx, m, f->st, f->n_lm, f->lm_pid, f->lm_xyz, f->lm_cov, Gw, rhsw);
             break;
         }
         case 2: {

@@ -77,6 +77,11 @@ int model_create_impl(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doubl
                       const double *variance, int64_t row_begin, int64_t row_end,
                       const std::function<int(gingr_model *)> &fill_basis, gingr_model **out);
 
+// fitter.hip hooks for the device group (group.hip): where phases 0 / 1 write this shard's partial exchange segments
+void fitter_set_partial_output(gingr_fitter *f, double *base);
+gingr_ctx *fitter_ctx(gingr_fitter *f);
+const gingr_model *fitter_model(gingr_fitter *f);
+
 // ---- basis sweeps ------------------------------------------------------------------------------------------
 enum SweepMode {
     SWEEP_RHS = 0,      // T only: out[k] = sum_i Q0_i^T e_i, e from evec planes

@@ -1,0 +1,470 @@
+// Device group: the row-sharded GiNGR update across several GPUs of one node, driven from ONE host process through the C ABI
+// (gingr_group_* in include/gingr_hip.h) -- what SURVEY.md section 8b calls gingr_group_create: a JVM / C host has no
+// torch.distributed, so the exchange lives in the library.
+//
+// Partitioning (BASELINE.json north_star): contiguous row shards of the reference / fit points, one
+// gingr_ctx + gingr_model + gingr_fitter per device; target cloud and all r-sized state replicated.  Per iteration the two
+// exchange segments of fitter.hip (CPD column sums den[N]; Gram + right-hand side + sigma2 sums) are summed across shards
+// by a ONE-SHOT all-reduce over peer pointers: every shard writes its partial segment into its own send buffer, records an
+// event, waits for the events of all peers and then sums the n send buffers -- its own and, through the xGMI peer
+// mapping, the remote ones -- in rank order into its exchange buffer.  Both messages are small (400 KB and 100 KB at
+// 50k points, rank 100), so the exchange is latency bound and one hop beats a ring; every shard adds the
+// same numbers in the same order, so the replicated r x r solve sees bit-identical inputs on every device and the results do
+// not depend on timing.
+//
+// Host side: one worker thread per device enqueues that device's kernels (one thread serving 8 devices would be launch
+// bound: ~20 launches x 8 devices per iteration against ~0.4 ms of device time); the workers meet at a host barrier once per
+// exchange, because hipStreamWaitEvent only orders against an event that has already been RECORDED.  Nothing waits for the
+// GPU inside an update: n iterations are enqueued back to back.
+//
+// Send buffers are double buffered by iteration parity: a shard may run ahead of a peer by less than one exchange (it waits
+// for the peer's NEXT event before it can finish its own next all-reduce), so the buffer it overwrites two iterations later is
+// no longer being read.  They are fine-grained device allocations (coherent across devices) and the events release at system
+// scope.  Several shards may live on ONE device (devices = {0, 0}): that is how the protocol is tested on a one-GPU box.
+#include "gp.h"
+
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+constexpr int kMaxGroup = 16;
+
+struct PeerPtrs {
+    const double *p[kMaxGroup];
+};
+
+// out[i] = p[0][i] + p[1][i] + ... in rank order (left to right); two doubles per thread (16-byte accesses)
+__global__ __launch_bounds__(256) void peer_sum_kernel(double *__restrict__ out, PeerPtrs src, int n, int64_t count) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i + 1 < count) {
+        double2 s = *reinterpret_cast<const double2 *>(src.p[0] + i);
+        for (int q = 1; q < n; ++q) {
+            const double2 v = *reinterpret_cast<const double2 *>(src.p[q] + i);
+            s.x += v.x;
+            s.y += v.y;
+        }
+        *reinterpret_cast<double2 *>(out + i) = s;
+    } else if (i < count) {
+        double s = src.p[0][i];
+        for (int q = 1; q < n; ++q) s += src.p[q][i];
+        out[i] = s;
+    }
+}
+
+struct SpinBarrier {
+    std::atomic<int> count{0}, gen{0};
+    int n = 1;
+    void wait() {
+        const int g = gen.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+            count.store(0, std::memory_order_relaxed);
+            gen.fetch_add(1, std::memory_order_acq_rel);
+        } else {
+            while (gen.load(std::memory_order_acquire) == g) std::this_thread::yield();
+        }
+    }
+};
+
+}  // namespace
+
+struct gingr_group {
+    int n = 0;
+    std::vector<int> dev;
+    std::vector<gingr_ctx *> ctx;
+    std::vector<gingr_model *> model;
+    std::vector<gingr_fitter *> fit;
+    std::vector<int64_t> begin, end;
+    int64_t M_total = 0, N = 0;
+    int32_t rank = 0;
+    // exchange
+    std::vector<double *> send[2];                              // [parity][shard]: partial segments, layout of the fitter's xch
+    std::vector<hipEvent_t> ready[2][GINGR_NUM_SEGMENTS];       // [parity][segment][shard]
+    std::vector<double *> xch;                                  // the fitters' exchange buffers
+    int64_t off[GINGR_NUM_SEGMENTS] = {0, 0}, cnt[GINGR_NUM_SEGMENTS] = {0, 0};
+    int64_t iteration = 0;                                      // parity of the send buffers
+    SpinBarrier bar;
+    // workers
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::function<int(int)> job;
+    uint64_t generation = 0;
+    int pending = 0;
+    bool quit = false;
+    std::vector<int> status;
+    char err[640] = {0};
+
+    int run(const std::function<int(int)> &fn) {  // fn(shard) on every worker; first non-zero status wins
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            job = fn;
+            pending = n;
+            ++generation;
+        }
+        cv_job.notify_all();
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+        for (int r = 0; r < n; ++r)
+            if (status[(size_t)r] != GINGR_OK) {
+                snprintf(err, sizeof(err), "shard %d (device %d): %s", r, dev[(size_t)r], gingr_last_error(ctx[(size_t)r]));
+                return status[(size_t)r];
+            }
+        return GINGR_OK;
+    }
+};
+
+namespace {
+
+void worker_main(gingr_group *g, int r) {
+    (void)hipSetDevice(g->dev[(size_t)r]);
+    uint64_t seen = 0;
+    for (;;) {
+        std::function<int(int)> fn;
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->cv_job.wait(lk, [&] { return g->quit || g->generation != seen; });
+            if (g->quit) return;
+            seen = g->generation;
+            fn = g->job;
+        }
+        const int rc = fn(r);
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->status[(size_t)r] = rc;
+            if (--g->pending == 0) g->cv_done.notify_all();
+        }
+    }
+}
+
+int group_fail(gingr_group *g, int code, const char *what) {
+    snprintf(g->err, sizeof(g->err), "%s", what);
+    return code;
+}
+
+void shard_rows(int64_t M, int n, int r, int64_t *b, int64_t *e) {  // the first (M mod n) shards hold one extra row
+    const int64_t base = M / n, extra = M % n;
+    *b = r * base + (r < extra ? r : extra);
+    *e = *b + base + (r < extra ? 1 : 0);
+}
+
+void free_exchange(gingr_group *g) {
+    for (int p = 0; p < 2; ++p) {
+        for (size_t r = 0; r < g->send[p].size(); ++r)
+            if (g->send[p][r]) {
+                (void)hipSetDevice(g->dev[r]);
+                (void)hipFree(g->send[p][r]);
+            }
+        g->send[p].clear();
+        for (int s = 0; s < GINGR_NUM_SEGMENTS; ++s) {
+            for (size_t r = 0; r < g->ready[p][s].size(); ++r)
+                if (g->ready[p][s][r]) (void)hipEventDestroy(g->ready[p][s][r]);
+            g->ready[p][s].clear();
+        }
+    }
+    g->xch.clear();
+}
+
+void free_fitters(gingr_group *g) {
+    for (size_t r = 0; r < g->fit.size(); ++r) {
+        if (g->fit[r]) gingr_fitter_destroy(g->fit[r]);
+        g->fit[r] = nullptr;
+    }
+    free_exchange(g);
+}
+
+void free_models(gingr_group *g) {
+    free_fitters(g);
+    for (size_t r = 0; r < g->model.size(); ++r) {
+        if (g->model[r]) gingr_model_destroy(g->model[r]);
+        g->model[r] = nullptr;
+    }
+}
+
+// after every shard's model exists: sum the one-off basis moments over the shards (host, rank order) and finalize
+int finish_models(gingr_group *g) {
+    const int n = g->n;
+    if (n > 1) {
+        void *p0 = nullptr;
+        int64_t count = 0;
+        GINGR_TRY(gingr_model_gram_exchange(g->model[0], &p0, &count));
+        std::vector<double> tot((size_t)count, 0.0), part((size_t)count);
+        for (int r = 0; r < n; ++r) {
+            void *p = nullptr;
+            int64_t c = 0;
+            GINGR_TRY(gingr_model_gram_exchange(g->model[(size_t)r], &p, &c));
+            if (c != count) return group_fail(g, GINGR_ERR_STATE, "group: shards disagree on the model rank");
+            if (hipSetDevice(g->dev[(size_t)r]) != hipSuccess ||
+                hipMemcpy(part.data(), p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+                return group_fail(g, GINGR_ERR_HIP, "group: moment download failed");
+            for (int64_t i = 0; i < count; ++i) tot[(size_t)i] += part[(size_t)i];
+        }
+        for (int r = 0; r < n; ++r) {
+            void *p = nullptr;
+            int64_t c = 0;
+            GINGR_TRY(gingr_model_gram_exchange(g->model[(size_t)r], &p, &c));
+            if (hipSetDevice(g->dev[(size_t)r]) != hipSuccess ||
+                hipMemcpy(p, tot.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+                return group_fail(g, GINGR_ERR_HIP, "group: moment upload failed");
+        }
+        GINGR_TRY(g->run([&](int r) { return gingr_model_finalize(g->ctx[(size_t)r], g->model[(size_t)r]); }));
+    }
+    g->rank = gingr_model_rank(g->model[0]);
+    // one fitter per shard
+    g->fit.assign((size_t)n, nullptr);
+    return g->run([&](int r) { return gingr_fitter_create(g->ctx[(size_t)r], g->model[(size_t)r], &g->fit[(size_t)r]); });
+}
+
+// all-reduce of exchange segment s (partials in send[parity], sums into the fitters' xch); called by every worker.
+// `ok` false: the worker still takes part in the barrier (so nobody deadlocks) but enqueues nothing.
+int exchange_segment(gingr_group *g, int r, int s, int parity, bool ok) {
+    gingr_ctx *ctx = g->ctx[(size_t)r];
+    int rc = GINGR_OK;
+    if (ok && hipEventRecord(g->ready[parity][s][(size_t)r], ctx->stream) != hipSuccess)
+        rc = gingr_set_error(ctx, GINGR_ERR_HIP, "group: hipEventRecord failed");
+    g->bar.wait();  // every peer has RECORDED its event (a wait on a never-recorded event would be a no-op)
+    if (!ok || rc) return rc;
+    PeerPtrs src;
+    for (int q = 0; q < g->n; ++q) {
+        if (q != r && hipStreamWaitEvent(ctx->stream, g->ready[parity][s][(size_t)q], 0) != hipSuccess)
+            return gingr_set_error(ctx, GINGR_ERR_HIP, "group: hipStreamWaitEvent failed");
+        src.p[q] = g->send[parity][(size_t)q] + g->off[s];
+    }
+    const int64_t count = g->cnt[s];
+    hipLaunchKernelGGL(peer_sum_kernel, dim3((unsigned)ceil_div(ceil_div(count, 2), 256)), dim3(256), 0, ctx->stream,
+                       g->xch[(size_t)r] + g->off[s], src, g->n, count);
+    if (hipGetLastError() != hipSuccess) return gingr_set_error(ctx, GINGR_ERR_HIP, "group: all-reduce kernel launch failed");
+    return GINGR_OK;
+}
+
+int group_update(gingr_group *g, bool icp, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations) {
+    if (!g || n_iterations < 0) return GINGR_ERR_BAD_ARGUMENT;
+    if (g->fit.empty() || !g->fit[0] || g->xch.empty()) return group_fail(g, GINGR_ERR_STATE, "group update: no model / target set");
+    if (g->n == 1)
+        return g->run([&](int) {
+            return icp ? gingr_fitter_update_icp_async(g->fit[0], ip, n_iterations) : gingr_fitter_update_cpd_async(g->fit[0], cp, n_iterations);
+        });
+    const int64_t it0 = g->iteration;
+    g->iteration += n_iterations;
+    return g->run([&](int r) {
+        int rc = GINGR_OK;
+        gingr_fitter *f = g->fit[(size_t)r];
+        for (int32_t it = 0; it < n_iterations; ++it) {
+            const int parity = (int)((it0 + it) & 1);
+            if (!rc) fitter_set_partial_output(f, g->send[parity][(size_t)r]);
+            TimerScope ts(g->ctx[(size_t)r], 3);
+            for (int ph = 0; ph < GINGR_NUM_PHASES; ++ph) {
+                if (!rc) rc = icp ? gingr_fitter_icp_phase_async(f, ip, ph) : gingr_fitter_cpd_phase_async(f, cp, ph);
+                // ICP: the nearest-neighbour phase has nothing to exchange (rows are independent)
+                if (ph < GINGR_NUM_SEGMENTS && !(icp && ph == 0)) {
+                    const int xrc = exchange_segment(g, r, ph, parity, rc == GINGR_OK);
+                    if (!rc) rc = xrc;
+                }
+            }
+        }
+        return rc;
+    });
+}
+
+}  // namespace
+
+extern "C" {
+
+int gingr_group_create(int32_t ndev, const int32_t *devices, gingr_group **out) {
+    if (!out) return GINGR_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    if (ndev < 1 || ndev > kMaxGroup || !devices) return GINGR_ERR_BAD_ARGUMENT;
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return GINGR_ERR_NO_DEVICE;
+    for (int r = 0; r < ndev; ++r)
+        if (devices[r] < 0 || devices[r] >= have) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_group *g = new gingr_group();
+    g->n = ndev;
+    g->dev.assign(devices, devices + ndev);
+    g->ctx.assign((size_t)ndev, nullptr);
+    g->model.assign((size_t)ndev, nullptr);
+    g->fit.assign((size_t)ndev, nullptr);
+    g->begin.assign((size_t)ndev, 0);
+    g->end.assign((size_t)ndev, 0);
+    g->status.assign((size_t)ndev, GINGR_OK);
+    g->bar.n = ndev;
+    for (int r = 0; r < ndev; ++r) {
+        const int rc = gingr_ctx_create(devices[r], &g->ctx[(size_t)r]);
+        if (rc) {
+            for (auto c : g->ctx)
+                if (c) gingr_ctx_destroy(c);
+            delete g;
+            return rc;
+        }
+    }
+    // peer mappings between distinct devices (a kernel on device a reads the send buffers that live on device b)
+    for (int a = 0; a < ndev; ++a)
+        for (int b = 0; b < ndev; ++b) {
+            if (devices[a] == devices[b]) continue;
+            int can = 0;
+            (void)hipDeviceCanAccessPeer(&can, devices[a], devices[b]);
+            if (!can) {
+                for (auto c : g->ctx) gingr_ctx_destroy(c);
+                delete g;
+                return GINGR_ERR_HIP;  // no peer path between two devices of the group
+            }
+            (void)hipSetDevice(devices[a]);
+            const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                for (auto c : g->ctx) gingr_ctx_destroy(c);
+                delete g;
+                return GINGR_ERR_HIP;
+            }
+            (void)hipGetLastError();
+        }
+    for (int r = 0; r < ndev; ++r) g->workers.emplace_back(worker_main, g, r);
+    *out = g;
+    return GINGR_OK;
+}
+
+void gingr_group_destroy(gingr_group *g) {
+    if (!g) return;
+    (void)gingr_group_synchronize(g);
+    {
+        std::unique_lock<std::mutex> lk(g->mu);
+        g->quit = true;
+    }
+    g->cv_job.notify_all();
+    for (auto &t : g->workers) t.join();
+    free_models(g);
+    for (auto c : g->ctx)
+        if (c) gingr_ctx_destroy(c);
+    delete g;
+}
+
+int32_t gingr_group_size(const gingr_group *g) { return g ? g->n : 0; }
+const char *gingr_group_last_error(const gingr_group *g) { return g ? g->err : "null group"; }
+gingr_ctx *gingr_group_ctx(gingr_group *g, int32_t shard) { return (g && shard >= 0 && shard < g->n) ? g->ctx[(size_t)shard] : nullptr; }
+
+int gingr_group_shard_rows(const gingr_group *g, int32_t shard, int64_t *row_begin, int64_t *row_end) {
+    if (!g || shard < 0 || shard >= g->n || g->M_total <= 0) return GINGR_ERR_BAD_ARGUMENT;
+    if (row_begin) *row_begin = g->begin[(size_t)shard];
+    if (row_end) *row_end = g->end[(size_t)shard];
+    return GINGR_OK;
+}
+
+int gingr_group_model_upload(gingr_group *g, int64_t M_total, int32_t rank, const double *ref, const double *mean,
+                             const double *basis_colmajor, const double *variance) {
+    if (!g) return GINGR_ERR_BAD_ARGUMENT;
+    if (M_total < g->n) return group_fail(g, GINGR_ERR_BAD_ARGUMENT, "group: fewer points than shards");
+    free_models(g);
+    g->M_total = M_total;
+    for (int r = 0; r < g->n; ++r) shard_rows(M_total, g->n, r, &g->begin[(size_t)r], &g->end[(size_t)r]);
+    GINGR_TRY(g->run([&](int r) {
+        return gingr_model_upload(g->ctx[(size_t)r], M_total, rank, ref, mean, basis_colmajor, variance, g->begin[(size_t)r],
+                                  g->end[(size_t)r], &g->model[(size_t)r]);
+    }));
+    return finish_models(g);
+}
+
+int gingr_group_gpmm_build_gaussian(gingr_group *g, int64_t M_total, const double *ref, int32_t n_kernels, const double *sigmas,
+                                    const double *scalings, double relative_tolerance, int32_t max_rank) {
+    if (!g) return GINGR_ERR_BAD_ARGUMENT;
+    if (M_total < g->n) return group_fail(g, GINGR_ERR_BAD_ARGUMENT, "group: fewer points than shards");
+    free_models(g);
+    g->M_total = M_total;
+    for (int r = 0; r < g->n; ++r) shard_rows(M_total, g->n, r, &g->begin[(size_t)r], &g->end[(size_t)r]);
+    GINGR_TRY(g->run([&](int r) {
+        return gingr_gpmm_build_gaussian(g->ctx[(size_t)r], M_total, ref, n_kernels, sigmas, scalings, relative_tolerance, max_rank,
+                                         g->begin[(size_t)r], g->end[(size_t)r], &g->model[(size_t)r]);
+    }));
+    return finish_models(g);
+}
+
+int32_t gingr_group_model_rank(const gingr_group *g) { return g ? g->rank : 0; }
+
+int gingr_group_set_target(gingr_group *g, int64_t N, const double *target_xyz) {
+    if (!g) return GINGR_ERR_BAD_ARGUMENT;
+    if (g->fit.empty() || !g->fit[0]) return group_fail(g, GINGR_ERR_STATE, "group set_target: no model");
+    GINGR_TRY(gingr_group_synchronize(g));
+    free_exchange(g);
+    GINGR_TRY(g->run([&](int r) { return gingr_fitter_set_target(g->fit[(size_t)r], N, target_xyz); }));
+    g->N = N;
+    g->xch.assign((size_t)g->n, nullptr);
+    for (int r = 0; r < g->n; ++r) {
+        void *p = nullptr;
+        int64_t off[GINGR_NUM_SEGMENTS], cnt[GINGR_NUM_SEGMENTS];
+        GINGR_TRY(gingr_fitter_exchange(g->fit[(size_t)r], &p, off, cnt));
+        g->xch[(size_t)r] = static_cast<double *>(p);
+        for (int s = 0; s < GINGR_NUM_SEGMENTS; ++s) {
+            g->off[s] = off[s];
+            g->cnt[s] = cnt[s];
+        }
+    }
+    if (g->n == 1) return GINGR_OK;
+    const int64_t total = round_up(g->off[GINGR_NUM_SEGMENTS - 1] + g->cnt[GINGR_NUM_SEGMENTS - 1], 32);
+    for (int p = 0; p < 2; ++p) {
+        g->send[p].assign((size_t)g->n, nullptr);
+        for (int s = 0; s < GINGR_NUM_SEGMENTS; ++s) g->ready[p][s].assign((size_t)g->n, nullptr);
+        for (int r = 0; r < g->n; ++r) {
+            if (hipSetDevice(g->dev[(size_t)r]) != hipSuccess) return group_fail(g, GINGR_ERR_HIP, "group: hipSetDevice failed");
+            void *buf = nullptr;
+            // fine-grained: coherent for the peers' reads; plain device memory if the flag is not supported
+            if (hipExtMallocWithFlags(&buf, (size_t)total * sizeof(double), hipDeviceMallocFinegrained) != hipSuccess) {
+                (void)hipGetLastError();
+                if (hipMalloc(&buf, (size_t)total * sizeof(double)) != hipSuccess)
+                    return group_fail(g, GINGR_ERR_HIP, "group: out of device memory (send buffer)");
+            }
+            if (hipMemset(buf, 0, (size_t)total * sizeof(double)) != hipSuccess) return group_fail(g, GINGR_ERR_HIP, "group: memset failed");
+            g->send[p][(size_t)r] = static_cast<double *>(buf);
+            for (int s = 0; s < GINGR_NUM_SEGMENTS; ++s)
+                if (hipEventCreateWithFlags(&g->ready[p][s][(size_t)r], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess)
+                    return group_fail(g, GINGR_ERR_HIP, "group: hipEventCreate failed");
+        }
+    }
+    return GINGR_OK;
+}
+
+int gingr_group_set_landmarks(gingr_group *g, int32_t n_lm, const int32_t *lm_pid, const double *lm_xyz, const double *lm_cov) {
+    if (!g) return GINGR_ERR_BAD_ARGUMENT;
+    if (g->fit.empty() || !g->fit[0]) return group_fail(g, GINGR_ERR_STATE, "group set_landmarks: no model");
+    return g->run([&](int r) { return gingr_fitter_set_landmarks(g->fit[(size_t)r], n_lm, lm_pid, lm_xyz, lm_cov); });
+}
+
+int gingr_group_set_options(gingr_group *g, int32_t global_transform, double step_length) {
+    if (!g) return GINGR_ERR_BAD_ARGUMENT;
+    if (g->fit.empty() || !g->fit[0]) return group_fail(g, GINGR_ERR_STATE, "group set_options: no model");
+    for (int r = 0; r < g->n; ++r) GINGR_TRY(gingr_fitter_set_options(g->fit[(size_t)r], global_transform, step_length));
+    return GINGR_OK;
+}
+
+int gingr_group_set_state(gingr_group *g, const double *alpha, const gingr_state_scalars *s) {
+    if (!g) return GINGR_ERR_BAD_ARGUMENT;
+    if (g->fit.empty() || !g->fit[0]) return group_fail(g, GINGR_ERR_STATE, "group set_state: no model");
+    return g->run([&](int r) { return gingr_fitter_set_state(g->fit[(size_t)r], alpha, s); });
+}
+
+int gingr_group_get_state(gingr_group *g, double *alpha, gingr_state_scalars *s, double *fit_xyz) {
+    if (!g) return GINGR_ERR_BAD_ARGUMENT;
+    if (g->fit.empty() || !g->fit[0]) return group_fail(g, GINGR_ERR_STATE, "group get_state: no model");
+    return g->run([&](int r) {
+        return gingr_fitter_get_state(g->fit[(size_t)r], r == 0 ? alpha : nullptr, r == 0 ? s : nullptr,
+                                      fit_xyz ? fit_xyz + 3 * g->begin[(size_t)r] : nullptr);
+    });
+}
+
+int gingr_group_update_cpd_async(gingr_group *g, const gingr_cpd_params *p, int32_t n_iterations) {
+    if (!g || !p) return GINGR_ERR_BAD_ARGUMENT;
+    return group_update(g, false, p, nullptr, n_iterations);
+}
+
+int gingr_group_update_icp_async(gingr_group *g, const gingr_icp_params *p, int32_t n_iterations) {
+    if (!g || !p) return GINGR_ERR_BAD_ARGUMENT;
+    return group_update(g, true, nullptr, p, n_iterations);
+}
+
+int gingr_group_synchronize(gingr_group *g) {
+    if (!g) return GINGR_ERR_BAD_ARGUMENT;
+    for (int r = 0; r < g->n; ++r) GINGR_TRY(gingr_ctx_synchronize(g->ctx[(size_t)r]));
+    return GINGR_OK;
+}
+
+}  // extern "C"

@@ -331,8 +331,7 @@ class GeneratorWrapperStochastic:
     def propose(self, current):
         new = self.algorithm.update(current, True, self.rnd.scalaRandom)
         out = new.updateGeneral(dataclasses.replace(new.general, generatedBy=self.generatedBy))
-        self.algorithm._device_state_token = id(out)
-        self.algorithm._keepalive = out
+        self.algorithm._device_state = out
         return out
 
     def logTransitionProbability(self, frm, to) -> float:
@@ -346,8 +345,7 @@ class GeneratorWrapperDeterministic:
     def propose(self, current):
         new = self.algorithm.update(current, False)
         out = new.updateGeneral(dataclasses.replace(new.general, generatedBy=self.generatedBy))
-        self.algorithm._device_state_token = id(out)
-        self.algorithm._keepalive = out
+        self.algorithm._device_state = out
         return out
 
     def logTransitionProbability(self, frm, to) -> float:

@@ -300,6 +300,42 @@ int gingr_fitter_exchange(gingr_fitter *f, void **dev_ptr, int64_t offsets[GINGR
 int gingr_fitter_cpd_phase_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t phase);
 int gingr_fitter_icp_phase_async(gingr_fitter *f, const gingr_icp_params *p, int32_t phase);
 
+/* ---- device group: the row-sharded update across the GPUs of ONE node from ONE host process (multi-GPU for a C / JVM host) ----
+ * SURVEY.md section 8b "gingr_group_create(ndev, devs[], ...) wrapping the same calls with row-sharding".  The group owns one
+ * context, one model shard (contiguous rows, the first M mod n shards hold one extra row) and one fitter per entry of `devices`;
+ * the target cloud and the r-sized state are replicated.  Per iteration the two exchange segments above are summed across the
+ * shards inside the library: every shard writes its partial segment to a send buffer, the shards exchange HIP events, and each
+ * shard sums all send buffers in rank order (its own and, through the xGMI peer mapping, the remote ones) with one kernel --
+ * a one-shot all-reduce; both messages are small (N doubles; rp*rp + rp + 8), so it is latency bound.  Every shard computes
+ * bit-identical sums, the r x r solve is replicated, results do not depend on timing.  One host thread per device enqueues
+ * that device's kernels; gingr_group_update_*_async returns when n iterations are ENQUEUED on every device
+ * (gingr_group_synchronize / gingr_group_get_state wait for them).  Not thread-safe: one caller thread per group.
+ * The same device may be listed several times (logical shards on one GPU: how the protocol is tested on a one-GPU box).
+ * Reference: the reference is single-process / single-device; the calls mirror gingr_model_upload / gingr_gpmm_build_gaussian /
+ * gingr_fitter_* one to one (same argument meaning; host arrays are always the FULL model / cloud / fit).
+ * Errors: the gingr_status of the first failing shard; gingr_group_last_error has the text. */
+typedef struct gingr_group gingr_group;
+int gingr_group_create(int32_t ndev, const int32_t *devices, gingr_group **out);
+void gingr_group_destroy(gingr_group *g);
+int32_t gingr_group_size(const gingr_group *g);
+const char *gingr_group_last_error(const gingr_group *g);
+gingr_ctx *gingr_group_ctx(gingr_group *g, int32_t shard);      /* e.g. for the timing hooks of one shard */
+int gingr_group_shard_rows(const gingr_group *g, int32_t shard, int64_t *row_begin, int64_t *row_end);
+int gingr_group_model_upload(gingr_group *g, int64_t M_total, int32_t rank, const double *ref, const double *mean,
+                             const double *basis_colmajor, const double *variance);
+int gingr_group_gpmm_build_gaussian(gingr_group *g, int64_t M_total, const double *ref, int32_t n_kernels, const double *sigmas,
+                                    const double *scalings, double relative_tolerance, int32_t max_rank);
+int32_t gingr_group_model_rank(const gingr_group *g);
+int gingr_group_set_target(gingr_group *g, int64_t N, const double *target_xyz);
+int gingr_group_set_landmarks(gingr_group *g, int32_t n_lm, const int32_t *lm_pid, const double *lm_xyz, const double *lm_cov);
+int gingr_group_set_options(gingr_group *g, int32_t global_transform, double step_length);
+int gingr_group_set_state(gingr_group *g, const double *alpha, const gingr_state_scalars *s);
+/* alpha[r] and scalars from shard 0 (replicated state), fit_xyz[3*M_total] gathered from all shards; synchronises */
+int gingr_group_get_state(gingr_group *g, double *alpha, gingr_state_scalars *s, double *fit_xyz);
+int gingr_group_update_cpd_async(gingr_group *g, const gingr_cpd_params *p, int32_t n_iterations);
+int gingr_group_update_icp_async(gingr_group *g, const gingr_icp_params *p, int32_t n_iterations);
+int gingr_group_synchronize(gingr_group *g);
+
 /* -------------------------------------------------------------- timing hooks
  * HIP-event timing of the dominant kernels on the context's stream (bench.py's live roofline measurement).
  * which: 0 = cpd_colsum, 1 = cpd_rowstats, 2 = gram, 3 = whole update, 4 = basis sweep (one streaming pass over Q0),

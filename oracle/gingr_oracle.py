@@ -490,15 +490,50 @@ def posterior_logpdf_of_mesh(model: PDM, st: State, pids, points, variances, mes
     return gp_logpdf(post.coefficients(mesh))
 
 
+class RetryCounter:
+    """retryCounter / retryCounterInitialize of ONE algorithm instance [REF G/api/GingrAlgorithm.scala:69-70]: how many more
+    consecutive sampled proposals with a failed posterior are answered by "state unchanged" before the state is marked
+    ModelFlexibilityError; every successful posterior gives one back (:210)."""
+
+    def __init__(self, initialize: int = 10):
+        self.initialize = int(initialize)
+        self.value = int(initialize)
+
+
 def update_from_observations(model: PDM, st: State, pids, points, variances, sigma2_next: float,
-                             landmarks: Optional[Landmarks] = None, z: Optional[np.ndarray] = None) -> State:
-    """GingrAlgorithm.update (deterministic branch) given the correspondences (A.5 steps 1-7) followed by
-    GingrGeneratorWrapper.propose's fit refresh + iteration++ (step 8,
-    G/api/sampling/generators/GingrGeneratorWrapper.scala:28-39)."""
+                             landmarks: Optional[Landmarks] = None, z: Optional[np.ndarray] = None,
+                             retry: Optional[RetryCounter] = None) -> State:
+    """GingrAlgorithm.update given the correspondences (A.5 steps 1-7) followed by GingrGeneratorWrapper.propose's fit
+    refresh + iteration++ (step 8, G/api/sampling/generators/GingrGeneratorWrapper.scala:28-39).
+    z is None: update(current, probabilistic = false); otherwise probabilistic = true with z the standard-normal draws of
+    posterior.sample().  `retry` is the instance's retry counter (None: a fresh one, i.e. 10 retries left)."""
+    if retry is None:
+        retry = RetryCounter()
+
+    def wrapped(out: State) -> State:
+        # GingrGeneratorWrapper.propose refreshes fit and bumps the iteration whatever update returned
+        out.fit = model_instance_shape_pose_scale(model, out)
+        out.iteration = st.iteration + 1
+        return out
+
     try:
-        shape, a, posed = compute_posterior_mean(model, st, pids, points, variances, landmarks)   # :193,211
+        shape, a, posed = compute_posterior_mean(model, st, pids, points, variances, landmarks)   # :193 cashedPosterior
+        if not (np.all(np.isfinite(shape)) and np.all(np.isfinite(a))):
+            raise FloatingPointError("posterior not finite")
+    except (FloatingPointError, np.linalg.LinAlgError):
+        # posterior.isFailure (:194-208): iteration 0 -> unchanged; deterministic -> ModelFlexibilityError; probabilistic ->
+        # unchanged while retries are left, each one used up
+        out = dataclasses.replace(st)
+        if st.iteration > 0:
+            if z is not None and retry.value > 0:
+                retry.value -= 1
+            else:
+                out.status = STATUS_MODEL_FLEXIBILITY_ERROR
+        return wrapped(out)
+    retry.value = min(retry.initialize, retry.value + 1)                                          # :210
+    try:
         if z is not None:
-            # probabilistic = true: posterior.sample().  A sample of the coefficient posterior N(a, Mm^-1) is a + L^-T z with
+            # probabilistic = true: posterior.sample() (:211).  A sample of the coefficient posterior N(a, Mm^-1) is a + L^-T z with
             # L L^T = Mm; scalismo draws it in its SVD basis (same distribution).  z comes from the caller's generator.
             op, opts, ocovs = _observations(model, st, pids, points, variances, landmarks)
             Q = posed.U[(3 * op[:, None] + np.arange(3)[None, :]).reshape(-1)] * np.sqrt(posed.lam)[None, :]
@@ -509,7 +544,7 @@ def update_from_observations(model: PDM, st: State, pids, points, variances, sig
             a_s = a + np.linalg.solve(L.T, np.asarray(z, dtype=np.float64))
             shape = posed.ref + posed.mean + (posed.U @ (np.sqrt(posed.lam) * a_s)).reshape(model.M, 3)
         if not np.all(np.isfinite(shape)):
-            raise FloatingPointError("posterior mean not finite")
+            raise FloatingPointError("shape proposal not finite")
         alpha1 = posed.coefficients(shape)                                                       # :212-216
         alpha_c = st.alpha + (alpha1 - st.alpha) * st.step_length                                # :218-220
         newshape = posed.instance(alpha_c)                                                       # :222
@@ -525,25 +560,19 @@ def update_from_observations(model: PDM, st: State, pids, points, variances, sig
         if not np.all(np.isfinite(alpha)):
             raise FloatingPointError("alpha not finite")
     except (FloatingPointError, np.linalg.LinAlgError):
-        # Try(...) failure: iteration 0 returns the state unchanged, otherwise ModelFlexibilityError (:194-208,248,251)
+        # a failed coefficients() projection: ModelFlexibilityError at ANY iteration (:248-251)
         out = dataclasses.replace(st)
-        if st.iteration > 0:
-            out.status = STATUS_MODEL_FLEXIBILITY_ERROR
-        # GingrGeneratorWrapper.propose still refreshes fit and bumps the iteration
-        out.fit = model_instance_shape_pose_scale(model, out)
-        out.iteration = st.iteration + 1
-        return out
+        out.status = STATUS_MODEL_FLEXIBILITY_ERROR
+        return wrapped(out)
     new = dataclasses.replace(
         st, alpha=alpha, euler=rot_to_euler(R2), center=np.zeros(3), translation=np.asarray(t2, dtype=np.float64),
         scale=float(s2), sigma2=float(sigma2_next))                                              # :239-246
-    new.fit = model_instance_shape_pose_scale(model, new)                                        # wrapper :30-37
-    new.iteration = st.iteration + 1
-    return new
+    return wrapped(new)
 
 
 def cpd_update(model: PDM, target: np.ndarray, st: State, w: float = 0.0, lam: float = 1.0,
                landmarks: Optional[Landmarks] = None, stats: Optional[CpdStats] = None,
-               z: Optional[np.ndarray] = None) -> State:
+               z: Optional[np.ndarray] = None, retry: Optional[RetryCounter] = None) -> State:
     """One CPD iteration: correspondences (A.2), uncertainties, posterior, update map, sigma^2 (A.3)."""
     if stats is None:
         stats = cpd_stats_dense(st.fit, target, st.sigma2, w)
@@ -551,7 +580,7 @@ def cpd_update(model: PDM, target: np.ndarray, st: State, w: float = 0.0, lam: f
         yhat = st.fit + (stats.PX * (1.0 / stats.P1)[:, None] - st.fit)
         var = cpd_uncertainty_var(stats.P1, st.sigma2, lam)
     pids = np.arange(model.M)
-    return update_from_observations(model, st, pids, yhat, var, stats.sigma2_next, landmarks, z)
+    return update_from_observations(model, st, pids, yhat, var, stats.sigma2_next, landmarks, z, retry)
 
 
 def cpd_observations(model: PDM, target: np.ndarray, st: State, w: float = 0.0, lam: float = 1.0):
@@ -562,13 +591,14 @@ def cpd_observations(model: PDM, target: np.ndarray, st: State, w: float = 0.0, 
 
 
 def icp_update(model: PDM, target: np.ndarray, st: State, initial_sigma: float, end_sigma: float,
-               max_iterations: int, landmarks: Optional[Landmarks] = None) -> Tuple[State, np.ndarray]:
+               max_iterations: int, landmarks: Optional[Landmarks] = None, z: Optional[np.ndarray] = None,
+               retry: Optional[RetryCounter] = None) -> Tuple[State, np.ndarray]:
     """One ICP iteration with the point-cloud closest-point correspondence (A.7)."""
     idx, _, _ = icp_closest_point(st.fit, target)
     pts = np.asarray(target, dtype=np.float64)[idx]
     var = np.full(model.M, st.sigma2)                                  # ICP.scala:90-92
     s2n = icp_update_sigma2(st.sigma2, initial_sigma, end_sigma, max_iterations)
-    return update_from_observations(model, st, np.arange(model.M), pts, var, s2n, landmarks), idx
+    return update_from_observations(model, st, np.arange(model.M), pts, var, s2n, landmarks, z, retry), idx
 
 
 # --------------------------------------------------------------------------
@@ -874,14 +904,15 @@ def surface_correspondence(tmpl: np.ndarray, tmpl_tris: np.ndarray, tgt: np.ndar
 
 def icp_surface_update(model: PDM, tmpl_tris: np.ndarray, target: np.ndarray, tgt_tris: np.ndarray, st: State,
                        initial_sigma: float, end_sigma: float, max_iterations: int,
-                       landmarks: Optional["Landmarks"] = None, z: Optional[np.ndarray] = None):
+                       landmarks: Optional["Landmarks"] = None, z: Optional[np.ndarray] = None,
+                       retry: Optional[RetryCounter] = None):
     """One update of IcpRegistration with correspondenceMethod = TriangularClosestPoint (ICP.scala:36-52): only the
     correspondences with weight 1 are observed."""
     cp, w, _ = surface_correspondence(st.fit, tmpl_tris, target, tgt_tris)
     pids = np.flatnonzero(w == 1.0)
     var = np.full(pids.shape[0], st.sigma2)
     s2n = icp_update_sigma2(st.sigma2, initial_sigma, end_sigma, max_iterations)
-    return update_from_observations(model, st, pids, cp[pids], var, s2n, landmarks, z), (cp, w)
+    return update_from_observations(model, st, pids, cp[pids], var, s2n, landmarks, z, retry), (cp, w)
 
 
 def along_normal_correspondence(tmpl: np.ndarray, tmpl_tris: np.ndarray, tgt: np.ndarray, tgt_tris: np.ndarray):

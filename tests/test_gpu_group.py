@@ -1,0 +1,131 @@
+"""GPU tests of the in-library device group (gingr_group_*, gingr_amd/csrc/group.hip): the row-sharded update with the
+one-shot all-reduce over peer pointers, driven from one process.  On a one-GPU box the shards are LOGICAL (devices = [0, 0, ...]):
+worker threads, events, send-buffer parity and the rank-ordered sums are the real code path, only the xGMI hop is missing.  With
+two or more GPUs visible the same tests run with one shard per device."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import gingr_oracle as go
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300))
+
+
+def _devices(n):
+    from gingr_amd import _native as nat
+    have = nat.load().gingr_device_count()
+    return [r % have for r in range(n)] if have >= 2 else [0] * n
+
+
+def _case(seed=11, M=1203, N=1100, rank=40):
+    rng = np.random.default_rng(seed)
+    ref = rng.normal(0, 40, (M, 3))
+    mo = go.build_gaussian_gpmm(ref, 60.0, 30.0, rel_tol=1e-9, max_rank=rank)
+    target = (mo.instance(rng.normal(0, 1, mo.rank)) @ go.euler_to_rot(0.05, -0.03, 0.04).T)[:N] + rng.normal(0, 0.3, (N, 3)) + 1.0
+    return mo, target
+
+
+@pytest.mark.parametrize("nshards", [2, 3, 8])
+def test_group_cpd_equals_single_shard_and_oracle(ctx, nshards):
+    import gingr_amd as ga
+    from gingr_amd.sharded import ShardedFitter
+    mo, target = _case()
+    model = ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam)
+    s2 = ctx.cpd_initial_sigma2(mo.ref, target)
+    single = ShardedFitter(ctx, model, target)
+    single.set_state(np.zeros(mo.rank), s2)
+    single.update_cpd(0.1, 1.0, 4)
+    a1, sc1, fit1 = single.get_state()
+    single.close()
+
+    g = ga.DeviceGroup(_devices(nshards))
+    assert g.size == nshards
+    g.upload_model(mo.ref, mo.mean, mo.U, mo.lam)
+    rows = [g.shard_rows(r) for r in range(nshards)]
+    assert rows[0][0] == 0 and rows[-1][1] == mo.M and all(rows[i][1] == rows[i + 1][0] for i in range(nshards - 1))
+    g.set_target(target)
+    g.set_options(1, 1.0)
+    g.set_state(np.zeros(mo.rank), s2)
+    g.update_cpd(0.1, 1.0, 3)
+    g.update_cpd(0.1, 1.0, 1)          # a second call continues with the other send-buffer parity
+    a, sc, fit = g.get_state()
+    assert sc.iteration == 4 and sc.status == 0
+    assert abs(sc.sigma2 - sc1.sigma2) < 1e-10 * sc1.sigma2
+    assert rel(fit, fit1) < 1e-9 and rel(a, a1) < 1e-7
+    # and the oracle's unsharded trajectory
+    st = go.initial_state(mo, s2)
+    for _ in range(4):
+        st = go.cpd_update(mo, target, st, w=0.1)
+    assert rel(fit, st.fit) < 1e-5 and abs(sc.sigma2 - st.sigma2) < 1e-8 * st.sigma2
+    # run-to-run reproducibility of the sharded sums: bit-identical
+    g.set_state(np.zeros(mo.rank), s2)
+    g.update_cpd(0.1, 1.0, 4)
+    a2, sc2, fit2 = g.get_state()
+    assert np.array_equal(fit2, fit) and np.array_equal(a2, a) and sc2.sigma2 == sc.sigma2
+    g.close()
+
+
+def test_group_icp_with_landmarks_equals_single_shard(ctx):
+    import gingr_amd as ga
+    from gingr_amd.sharded import ShardedFitter
+    from gingr_amd import _native as nat
+    mo, target = _case(seed=12, M=900, N=900, rank=24)
+    model = ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam)
+    lm_pid = np.array([5, 450, 899], dtype=np.int32)
+    lm_xyz = target[[5, 450, 899]] + 0.1
+    lm_cov = np.tile(np.diag([1.0, 2.0, 0.5]), (3, 1, 1))
+    single = ShardedFitter(ctx, model, target)
+    assert single._lib.gingr_fitter_set_landmarks(single.handle, 3, lm_pid.ctypes.data_as(nat._ip), nat.dptr(nat.f64(lm_xyz)),
+                                                  nat.dptr(nat.f64(lm_cov))) == 0
+    single.set_state(np.zeros(mo.rank), 30.0)
+    single.update_icp(30.0, 1.0, 20, 3)
+    a1, sc1, fit1 = single.get_state()
+    single.close()
+    g = ga.DeviceGroup(_devices(3))
+    g.upload_model(mo.ref, mo.mean, mo.U, mo.lam)
+    g.set_target(target)
+    g.set_landmarks(lm_pid, lm_xyz, lm_cov)
+    g.set_options(1, 1.0)
+    g.set_state(np.zeros(mo.rank), 30.0)
+    g.update_icp(30.0, 1.0, 20, 3)
+    a, sc, fit = g.get_state()
+    assert sc.iteration == 3 and sc.status == 0 and sc.sigma2 == sc1.sigma2
+    assert rel(fit, fit1) < 1e-9 and rel(a, a1) < 1e-7
+    g.close()
+
+
+def test_group_device_built_gpmm_and_failure_status(ctx):
+    """Model built in HBM on every shard (row shards of the pivoted Cholesky) + a failing posterior: every shard reports the
+    same ModelFlexibilityError (the failure rules are replicated with the r x r algebra)."""
+    import gingr_amd as ga
+    rng = np.random.default_rng(13)
+    ref = rng.normal(0, 40, (1500, 3))
+    target = ref[:1400] + rng.normal(0, 0.5, (1400, 3))
+    g = ga.DeviceGroup(_devices(2))
+    g.build_gaussian_gpmm(ref, [60.0], [30.0], 0.0, 30)
+    assert g.rank == 30
+    g.set_target(target)
+    g.set_state(np.zeros(30), 25.0)
+    g.update_cpd(0.1, 1.0, 2)
+    a, sc, fit = g.get_state()
+    model = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.0, maxRank=30).Gaussian(60.0, 30.0)
+    from gingr_amd.sharded import ShardedFitter
+    single = ShardedFitter(ctx, model, target)
+    single.set_state(np.zeros(30), 25.0)
+    single.update_cpd(0.1, 1.0, 2)
+    a1, sc1, fit1 = single.get_state()
+    single.close()
+    assert rel(fit, fit1) < 1e-9 and abs(sc.sigma2 - sc1.sigma2) < 1e-10 * sc1.sigma2
+    # a far-away target point at a tiny sigma2: den = 0 -> P = 0/0 -> ModelFlexibilityError at iteration > 0
+    bad = np.concatenate([target, [[9.0e5, 0.0, 0.0]]])
+    g.set_target(bad)
+    g.set_state(a, 1e-3, iteration=2)
+    g.update_cpd(0.0, 1.0, 1)
+    a2, sc2, _ = g.get_state(fit=False)
+    assert sc2.status == ga.FittingStatuses.ModelFlexibilityError and np.array_equal(a2, a)
+    g.close()

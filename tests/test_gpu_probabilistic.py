@@ -146,3 +146,53 @@ def test_rank_above_128_uses_the_global_workspace(ctx):
     want = go.posterior_logpdf_of_mesh(mo, st, *go.cpd_observations(mo, target, st, w=0.05), mesh=st.fit)
     assert np.isfinite(got) and abs(got - want) < 1e-5 * abs(want), (got, want)
     algo.close()
+
+
+def test_retry_counter_of_the_probabilistic_proposal(ctx):
+    """GingrAlgorithm.scala:69-70,194-210 on the device: 11 consecutive sampled proposals with a failing posterior -> 10 unchanged
+    states, then ModelFlexibilityError; a success gives one retry back; deterministic updates never retry; iteration 0 is
+    forgiven.  Same sequence as the oracle (tests/test_oracle_kat.py::test_probabilistic_retry_counter_semantics)."""
+    import dataclasses
+    import gingr_amd as ga
+    mo, model, target = setup(M=200, rank=12)
+    bad_target = np.concatenate([mo.ref, [[9.0e5, 0.0, 0.0]]])     # sigma2 = 1: one column of K underflows to 0, P = 0/0
+    algo = ga.CpdRegistration(ctx)
+    cfg = ga.CpdConfiguration(maxIterations=50, w=0.0, initialSigma=1.0)
+    st = algo.createInitialState(model, bad_target, cfg)
+    assert abs(st.general.sigma2 - 1.0) < 1e-12 and algo.retryCounter == 10
+    rnd = np.random.default_rng(5)
+    s0 = algo.update(st, probabilistic=True, rnd=rnd)              # iteration 0: unchanged, no error, counter untouched
+    assert s0.general.status == 0 and s0.general.iteration == 1 and algo.retryCounter == 10
+    cur = s0
+    for k in range(10):
+        nxt = algo.update(cur, probabilistic=True, rnd=rnd)
+        assert nxt.general.status == 0 and nxt.general.iteration == cur.general.iteration + 1
+        assert np.array_equal(nxt.general.modelParameters.shape, cur.general.modelParameters.shape)
+        assert nxt.general.sigma2 == cur.general.sigma2 and algo.retryCounter == 9 - k
+        cur = nxt
+    failed = algo.update(cur, probabilistic=True, rnd=rnd)
+    assert failed.general.status == ga.FittingStatuses.ModelFlexibilityError and algo.retryCounter == 0
+    # a good posterior (same algorithm instance, other target) gives one retry back
+    good = dataclasses.replace(cur.general, target=target, sigma2=50.0)
+    ok = algo.update(cur.updateGeneral(good), probabilistic=True, rnd=rnd)
+    assert ok.general.status == 0 and algo.retryCounter == 1
+    # deterministic: immediate error, counter untouched
+    det = algo.update(cur, probabilistic=False)
+    assert det.general.status == ga.FittingStatuses.ModelFlexibilityError and algo.retryCounter == 1
+    algo.close()
+
+
+def test_failed_projection_at_iteration_zero_is_an_error(ctx):
+    """GingrAlgorithm.scala:248-251 vs :206-208: the iteration-0 exemption covers the posterior only."""
+    import gingr_amd as ga
+    mo, model, target = setup(M=200, rank=12)
+    algo = ga.CpdRegistration(ctx)
+    st = algo.createInitialState(model, target, ga.CpdConfiguration(maxIterations=50, w=0.1), stepLength=float("inf"))
+    s1 = algo.update(st)
+    st_o = go.initial_state(mo, st.general.sigma2, step_length=float("inf"))
+    with np.errstate(all="ignore"):
+        o1 = go.cpd_update(mo, target, st_o, w=0.1)
+    assert st.general.iteration == 0
+    assert s1.general.status == o1.status == ga.FittingStatuses.ModelFlexibilityError
+    assert np.array_equal(s1.general.modelParameters.shape, st.general.modelParameters.shape)
+    algo.close()

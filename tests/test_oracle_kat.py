@@ -210,6 +210,46 @@ def test_update_failure_semantics():
     assert s2.status == go.STATUS_MODEL_FLEXIBILITY_ERROR
 
 
+def test_probabilistic_retry_counter_semantics():
+    """GingrAlgorithm.scala:69-70,194-210: a sampled proposal whose posterior fails returns the state unchanged while the
+    instance's retry counter lasts (10), then ModelFlexibilityError; successes give retries back; iteration 0 never fails."""
+    mo, rng = small_model(M=40, rank=6)
+    bad_target = np.concatenate([mo.ref, [[9000.0, 0, 0]]])        # one target far from every point at sigma2 = 1: den = 0, P = 0/0
+    good_target = mo.ref + rng.normal(0, 0.1, mo.ref.shape)
+    retry = go.RetryCounter()
+    st = go.initial_state(mo, 1.0)
+    st.iteration = 3
+    z = rng.standard_normal(mo.rank)
+    for k in range(10):
+        st2 = go.cpd_update(mo, bad_target, st, z=z, retry=retry)
+        assert st2.status == go.STATUS_NONE and st2.iteration == st.iteration + 1 and np.array_equal(st2.alpha, st.alpha)
+        assert retry.value == 9 - k
+        st = st2
+    st11 = go.cpd_update(mo, bad_target, st, z=z, retry=retry)
+    assert st11.status == go.STATUS_MODEL_FLEXIBILITY_ERROR and retry.value == 0
+    # a success replenishes ONE retry (math.min(retryCounterInitialize, retryCounter + 1))
+    ok = go.cpd_update(mo, good_target, st, z=z, retry=retry)
+    assert ok.status == go.STATUS_NONE and retry.value == 1 and not np.array_equal(ok.alpha, st.alpha)
+    # deterministic updates never retry
+    retry = go.RetryCounter()
+    assert go.cpd_update(mo, bad_target, st, retry=retry).status == go.STATUS_MODEL_FLEXIBILITY_ERROR and retry.value == 10
+    # iteration 0: unchanged, no error, counter untouched
+    st0 = go.initial_state(mo, 1.0)
+    s1 = go.cpd_update(mo, bad_target, st0, z=z, retry=retry)
+    assert s1.status == go.STATUS_NONE and retry.value == 10
+
+
+def test_failed_projection_is_an_error_even_at_iteration_zero():
+    """GingrAlgorithm.scala:248-251: only the POSTERIOR failure is forgiven at iteration 0; a failed coefficients() gives
+    ModelFlexibilityError at any iteration.  An infinite step length makes the blended coefficients non-finite."""
+    mo, rng = small_model(M=40, rank=6)
+    target = mo.ref + rng.normal(0, 0.1, mo.ref.shape)
+    st = go.initial_state(mo, 1.0, step_length=float("inf"))
+    with np.errstate(all="ignore"):
+        s1 = go.cpd_update(mo, target, st)
+    assert st.iteration == 0 and s1.status == go.STATUS_MODEL_FLEXIBILITY_ERROR and np.array_equal(s1.alpha, st.alpha)
+
+
 def test_fit_scale_is_applied_after_the_rigid_transform():
     mo, rng = small_model(M=30, rank=6)
     st = go.State(alpha=rng.normal(0, 1, 6), euler=(0.1, 0.2, 0.3), center=np.zeros(3), translation=np.array([1.0, 2, 3]),
