@@ -7,9 +7,20 @@ the weighted Gram + posterior solve, two coefficient projections, Umeyama and th
 are resident in HBM before the timed region.  With --gpus N the reference rows are sharded over N ranks and the
 partial sums are all-reduced over RCCL (strong scaling: the problem is fixed).
 
+Launch forms:
+  python bench.py                      one GPU
+  torchrun ... bench.py --gpus N       one process per GPU, exchange = torch.distributed all-reduce (RCCL over xGMI)
+  python bench.py --gpus N             no torchrun around it: spawns exactly that torchrun command as a child process (before
+                                       anything touches the GPU) and passes its JSON line through
+  python bench.py --gpus N --group     ONE process, the in-library device group (gingr_group_*: worker thread per device,
+                                       one-shot all-reduce over peer pointers) -- the path a C / JVM host uses
+  python bench.py --group --logical-shards N    N logical shards on device 0 (protocol test / timing on a one-GPU box)
+
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the kernels' own stream in extra
-iterations after the timed region; `cpu_baseline` times the C restatement (oracle/, the checker -- never the product)
-on the host cores on a bounded sample of the same workload.
+iterations after the timed region; `parity_check` compares the affinity statistics and the sigma2 update of the state the
+timed region ended in with the strict C oracle (outside the timed region; folded into `valid`); `cpu_baseline` times the
+optimised C restatement (oracle/cpd_baseline.c, built here with -O3 -march=native -fopenmp) plus the numpy GP part on the
+host cores on a bounded sample of the same workload.  oracle/ is the checker and the reported baseline -- never the product.
 """
 from __future__ import annotations
 
@@ -71,28 +82,81 @@ def synth_gpmm(ref: np.ndarray, rank: int, sigma: float = 70.0, scaling: float =
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(y, x, sigma2, w, budget_s=20.0):
-    """Time the C restatement of the two all-pairs passes (oracle/cpd_oracle.c, OpenMP over all host cores) on a row
-    sample of the SAME workload and scale to one iteration.  The GP part (O(M r^2)) is not included, which favours the
-    CPU number.  Returns the cpu_baseline JSON object."""
+def cpu_gp_part(Q, ref_flat, P1, PX, fit, sigma2, lam_cpd, Binv_eps, rank):
+    """The GP part of one update on the CPU with numpy / the host BLAS (identity pose, zero mean -- the first iteration of the
+    workload): weighted Gram, posterior solve, posterior mean, two coefficient projections (the ridge system factored once per
+    model: the optimised form), three instances, Umeyama.  Returns nothing: only its time is of interest."""
+    M = P1.shape[0]
+    wgt = P1 / (sigma2 * lam_cpd)
+    yhat = PX / P1[:, None]
+    e = (yhat.reshape(-1) - ref_flat)
+    w3 = np.repeat(wgt, 3)
+    Qw = Q * w3[:, None]
+    G = Qw.T @ Q
+    rhs = Qw.T @ e
+    a = np.linalg.solve(np.eye(rank) + G, rhs)
+    shape = ref_flat + Q @ a                                   # posterior mean
+    alpha1 = Binv_eps @ (Q.T @ (shape - ref_flat))             # coefficients(), ridge system pre-factored
+    newshape = (ref_flat + Q @ alpha1).reshape(M, 3)           # instance
+    cur = ref_flat.reshape(M, 3)
+    mu_a, mu_b = cur.mean(0), newshape.mean(0)                 # Umeyama (rigid)
+    U_, _, Vt = np.linalg.svd((newshape - mu_b).T @ (cur - mu_a))
+    R = U_ @ np.diag([1.0, 1.0, np.sign(np.linalg.det(U_ @ Vt))]) @ Vt
+    t = mu_b - R @ mu_a
+    alpha = Binv_eps @ (Q.T @ (((newshape - t) @ R).reshape(-1) - ref_flat))
+    return (ref_flat + Q @ alpha).reshape(M, 3) @ R.T + t      # the new fit
+
+
+def cpu_baseline(y, x, sigma2, w, model=None, budget_s=16.0):
+    """CPU baseline of ONE update iteration on the host cores: the optimised C restatement of the two all-pairs passes
+    (oracle/cpd_baseline.c: -O3 -march=native -fopenmp, SIMD exponential, built on this host) timed on a row sample of the SAME
+    workload and scaled to all rows, PLUS the GP part (numpy / host BLAS) when the model is given.  Also reports the strict
+    checker build (oracle/cpd_oracle.c: -O2 -ffp-contract=off, scalar libm exp) on a smaller sample, for reference."""
+    from oracle import c_baseline as cb
     from oracle import c_oracle as co
-    cores = co.num_threads()
+    cores = cb.num_threads()
     M, N = y.shape[0], x.shape[0]
-    # calibrate on a small slice, then pick the sample so that both passes take about budget_s
-    m0 = max(64, min(M, 16 * cores))
+    ys, xs = cb.soa(y), cb.soa(x)
+    m0 = max(64, min(M, 8 * cores))
+    cb.colsum(np.ascontiguousarray(ys[:, :m0]), xs, sigma2)                      # warm-up: thread pool, page faults
     t0 = time.perf_counter()
-    co.cpd_colsum_partial(y, x, sigma2, 0, m0)
-    dt = time.perf_counter() - t0
-    per_row = dt / m0
-    ms = int(min(M, max(m0, budget_s / 2.0 / max(per_row, 1e-9))))
+    cb.colsum(np.ascontiguousarray(ys[:, :m0]), xs, sigma2)
+    per_row = (time.perf_counter() - t0) / m0
+    ms = int(min(M, max(m0, budget_s / 2.2 / max(per_row, 1e-9))))
+    ysub = np.ascontiguousarray(ys[:, :ms])
     t0 = time.perf_counter()
-    den = co.cpd_colsum_partial(y, x, sigma2, 0, ms) + co.outlier_constant(M, N, sigma2, w) + 1e-300
-    co.cpd_rowstats_partial(y, x, sigma2, den, 0, ms)
-    dt = time.perf_counter() - t0
-    it_per_s = 1.0 / (dt * (M / ms))
-    return {"value": it_per_s, "unit": "iterations/s", "cores": cores, "kind": "port",
-            "sample": f"both all-pairs passes on rows [0,{ms}) of {M} x {N} targets, scaled x{M / ms:.2f}; "
-                      f"{dt:.1f} s measured; GP solve excluded"}
+    den = cb.colsum(ysub, xs, sigma2) * (M / ms) + co.outlier_constant(M, N, sigma2, w)
+    P1s, PXs = cb.rowstats(ysub, xs, sigma2, 1.0 / den)
+    t_pairs = (time.perf_counter() - t0) * (M / ms)
+    sample = (f"both all-pairs passes (optimised C, {cores} threads) on rows [0,{ms}) of {M} x {N} targets, scaled x{M / ms:.2f}: "
+              f"{t_pairs:.3f} s per iteration")
+    t_gp = None
+    if model is not None:
+        host = model.to_host() if hasattr(model, "to_host") else model
+        rank = host.variance.shape[0]
+        Q = np.ascontiguousarray(host.basis) * np.sqrt(host.variance)[None, :]
+        ref_flat = np.ascontiguousarray(host.reference).reshape(-1)
+        Binv_eps = np.linalg.inv(Q.T @ Q / 1e-5 + np.eye(rank)) / 1e-5           # once per model (not timed)
+        P1 = np.resize(P1s, M)
+        PX = np.resize(PXs.T, (M, 3))
+        cpu_gp_part(Q, ref_flat, P1, PX, y, sigma2, 1.0, Binv_eps, rank)        # warm-up
+        t0 = time.perf_counter()
+        cpu_gp_part(Q, ref_flat, P1, PX, y, sigma2, 1.0, Binv_eps, rank)
+        t_gp = time.perf_counter() - t0
+        sample += f"; GP part (numpy / host BLAS, full size, rank {rank}): {t_gp:.3f} s"
+    # the strict checker build, for reference (bounded to ~4 s)
+    mc = int(min(ms, max(16, 2.0 / max(per_row * 8.0, 1e-9))))
+    t0 = time.perf_counter()
+    dc = co.cpd_colsum_partial(y, x, sigma2, 0, mc) + co.outlier_constant(M, N, sigma2, w) + 1e-300
+    co.cpd_rowstats_partial(y, x, sigma2, dc, 0, mc)
+    t_strict = (time.perf_counter() - t0) * (M / mc)
+    total = t_pairs + (t_gp or 0.0)
+    return {"value": 1.0 / total, "unit": "iterations/s", "cores": cores, "kind": "port", "sample": sample,
+            "build": "gcc " + " ".join(cb.CFLAGS[:3]) + " (oracle/cpd_baseline.c), SIMD exponential checked <= 1e-12 against libm",
+            "seconds_per_iteration": {"all_pairs": t_pairs, "gp_part": t_gp},
+            "strict_checker_build": {"value": 1.0 / t_strict, "unit": "iterations/s (all-pairs passes only)",
+                                     "build": "gcc -O2 -fopenmp -ffp-contract=off, scalar libm exp (oracle/cpd_oracle.c)",
+                                     "sample_rows": mc}}
 
 
 def cpu_baseline_stock_structure(with_gpu: bool):
@@ -147,6 +211,40 @@ def cpu_baseline_stock_structure(with_gpu: bool):
 
 
 # ------------------------------------------------------------------------------------------------ main
+def spawn_ranks(n_gpus: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start the contract's launch line as a CHILD process -- one rank
+    per GPU under torch.distributed.run -- and pass its stdout through.  Nothing in this process has touched the GPU (torch is
+    not even imported yet), and nothing is exec'ed: the child is an ordinary subprocess whose exit code we return."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def load_pmc_traffic(kernel: str, points: int, rank: int):
+    """HBM bytes per launch of `kernel` from the tracked PMC artefact tools/pmc_traffic.sh produced for THIS workload
+    (profiles/r02_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes, as the
+    microarchitecture guide prescribes).  None when no artefact matches -- bench.py never invents the number."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None, None
+    wl = d.get("workload", {})
+    if wl.get("points") != points or wl.get("rank") != rank or wl.get("gpus", 1) != 1:
+        return None, None
+    k = d.get("kernels", {}).get(kernel)
+    if not k:
+        return None, None
+    return float(k["hbm_bytes_per_launch"]), f"profiles/r02_pmc_traffic.json ({k.get('note', 'FETCH_SIZE + WRITE_SIZE per launch')})"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,9 +255,15 @@ def main():
     ap.add_argument("--w", type=float, default=0.1)
     ap.add_argument("--host-gpmm", action="store_true", help="synthesise the GPMM with numpy on the host and upload it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=3)
     ap.add_argument("--sigma2", type=float, default=0.0,
                     help="experiment: start from this sigma2 instead of the CPD initial value (late-iteration regime)")
+    ap.add_argument("--group", action="store_true",
+                    help="ONE process drives all GPUs through the in-library device group (gingr_group_*) instead of one process per "
+                         "GPU with torch.distributed")
+    ap.add_argument("--logical-shards", type=int, default=0,
+                    help="with --group: this many LOGICAL shards on device 0 (protocol test on a one-GPU box; the shards share the GPU)")
     ap.add_argument("--force-dist", action="store_true",
                     help="testing: run the N>1 code path (process group + phase/all-reduce driver) with the given world")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -171,14 +275,16 @@ def main():
     args = ap.parse_args()
     if args.config1_stock_structure:
         cpu_baseline_stock_structure(args.config1_stock_structure == "gpu")
-        return
+        return 0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.group:
+        return spawn_ranks(args.gpus, sys.argv[1:])          # before torch / HIP are touched
+    if args.group:
+        world, rank, local_rank = 1, 0, 0                     # one process whatever the launcher said
+    elif world != args.gpus:
         args.gpus = world
 
     # must be in the environment before the HIP / HSA runtime initialises (the pool's driver only supports dmabuf IPC; RCCL and
@@ -196,9 +302,8 @@ def main():
     from gingr_amd.sharded import ShardedFitter
 
     torch.cuda.set_device(local_rank)
-    use_dist = world > 1 or args.force_dist or args.emulate_world > 1
+    use_dist = (world > 1 or args.force_dist or args.emulate_world > 1) and not args.group
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:       # stand-alone test modes only; torchrun always provides it
             import socket
@@ -209,135 +314,241 @@ def main():
 
     M = N = args.points
     y, x = synth_clouds(M)
+    n_shards = world
 
-    ctx = ga.Context(local_rank)
-    stream = torch.cuda.Stream(device=local_rank)
-    ctx.set_stream(stream.cuda_stream)
-    if args.host_gpmm:
-        basis, lam = synth_gpmm(y, args.rank)
-        model = ga.PointDistributionModel(reference=y, mean=np.zeros_like(y), basis=basis, variance=lam)
-    else:
-        # GPMMTriangleMesh3D(reference, tol).Gaussian(sigma, scaling) built in HBM (femur demo kernel,
-        # examples/DemoHelper/DemoDatasetLoader.scala:113-114), stopped at exactly `rank` columns; untimed set-up
-        model = ga.GPMMTriangleMesh3D(ctx, y, relativeTolerance=0.0, maxRank=args.rank).Gaussian(70.0, 50.0)
+    # ---------------------------------------------------------------------------------------------- set-up (untimed)
+    stream = None
+    if args.group:
+        # one process, the in-library group: one shard per GPU, or logical shards on device 0
+        n_shards = args.logical_shards if args.logical_shards > 0 else args.gpus
+        devices = [0] * n_shards if args.logical_shards > 0 else list(range(args.gpus))
+        group = ga.DeviceGroup(devices)
+        if args.host_gpmm:
+            basis, lam = synth_gpmm(y, args.rank)
+            group.upload_model(y, np.zeros_like(y), basis, lam)
+        else:
+            group.build_gaussian_gpmm(y, [70.0], [50.0], 0.0, args.rank)
+        group.set_target(x)
+        group.set_options(ga.GlobalTranformationType.RigidTransforms, 1.0)
+        ctx = ga.Context(0)                                   # stateless helpers (initial sigma2) + nothing else
+        tctx_handle = group.ctx_handle(0)                     # timing hooks of shard 0
+        model = None
+        m_loc = group.shard_rows(0)[1] - group.shard_rows(0)[0]
 
-    def all_reduce(t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        class Runner:
+            def reset(self, s2):
+                group.set_state(np.zeros(args.rank), s2)
 
-    with torch.cuda.stream(stream):
-        shard_world = args.emulate_world if args.emulate_world > 1 else world
-        fitter = ShardedFitter(ctx, model, x, rank=rank, world=shard_world, all_reduce=all_reduce if use_dist else None,
-                               global_transform=ga.GlobalTranformationType.RigidTransforms, step_length=1.0)
-        if args.force_dist and shard_world == 1:      # exercise the phase + all-reduce driver with one rank
-            from gingr_amd.sharded import as_torch, NUM_SEGMENTS
+            def update(self, n):
+                group.update_cpd(args.w, 1.0, n)
+
+            def sync(self):
+                group.synchronize()
+
+            def state(self):
+                return group.get_state()
+
+            def stats(self):
+                return None                                   # per-shard statistics are not exposed through the group
+
+            def close(self):
+                group.close()
+        runner = Runner()
+        lib = group._lib
+
+        def timing(which=None, enable=None, reset=False):
             import ctypes
-            from ctypes import c_int64, c_void_p
-            pp = c_void_p(); offs = (c_int64 * NUM_SEGMENTS)(); cnts = (c_int64 * NUM_SEGMENTS)()
-            fitter._lib.gingr_fitter_exchange(fitter.handle, ctypes.byref(pp), offs, cnts)
-            fitter.xch = as_torch(pp.value, offs[NUM_SEGMENTS - 1] + cnts[NUM_SEGMENTS - 1], local_rank)
-            fitter.world = 2
-        sigma2_0 = ctx.cpd_initial_sigma2(y, x)      # CpdRegistrationState.apply, CPD.scala:92-102 (mean == reference here)
+            if enable is not None:
+                lib.gingr_ctx_timing_enable(tctx_handle, 1 if enable else 0)
+            if reset:
+                lib.gingr_ctx_timing_reset(tctx_handle)
+            if which is not None:
+                ms, n = ctypes.c_double(), ctypes.c_int64()
+                lib.gingr_ctx_timing_read(tctx_handle, which, ctypes.byref(ms), ctypes.byref(n))
+                return ms.value, n.value
+    else:
+        ctx = ga.Context(local_rank)
+        stream = torch.cuda.Stream(device=local_rank)
+        ctx.set_stream(stream.cuda_stream)
+        if args.host_gpmm:
+            basis, lam = synth_gpmm(y, args.rank)
+            model = ga.PointDistributionModel(reference=y, mean=np.zeros_like(y), basis=basis, variance=lam)
+        else:
+            # GPMMTriangleMesh3D(reference, tol).Gaussian(sigma, scaling) built in HBM (femur demo kernel,
+            # examples/DemoHelper/DemoDatasetLoader.scala:113-114), stopped at exactly `rank` columns; untimed set-up
+            model = ga.GPMMTriangleMesh3D(ctx, y, relativeTolerance=0.0, maxRank=args.rank).Gaussian(70.0, 50.0)
 
-        if args.sigma2 > 0:
-            sigma2_0 = args.sigma2
+        def all_reduce(t):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
-        def reset():
-            fitter.set_state(np.zeros(args.rank), sigma2_0)
-
-        def sync():
-            torch.cuda.synchronize(local_rank)
-            if use_dist:
-                dist.barrier()
-                torch.cuda.synchronize(local_rank)
-
-        # one-time costs (code-object loads, LDS-size attributes, clock ramp) are paid on a throw-away run of three updates; the
-        # state is then reset, so the W warm-up and K timed steps below run the workload from sigma2_0 exactly as specified
-        reset()
-        fitter.update_cpd(args.w, 1.0, 3)
-        sync()
-        reset()
-        fitter.update_cpd(args.w, 1.0, args.warmup)
-        sync()
-        t0 = time.perf_counter()
-        fitter.update_cpd(args.w, 1.0, args.steps)
-        sync()
-        elapsed = time.perf_counter() - t0
-        if use_dist:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
-        alpha, sc, fit = fitter.get_state()
-        ok = bool(np.all(np.isfinite(fit)) and sc.status == 0 and sc.iteration == args.warmup + args.steps
-                  and args.emulate_world <= 1)
-
-        # ---- live roofline of the dominant kernels (HIP events on the kernels' stream, extra iterations)
-        roof = None
-        kernels = []
-        ctx.timing_enable(True)
-        ctx.timing_reset()
-        fitter.update_cpd(args.w, 1.0, args.roofline_steps)
-        sync()
+        with torch.cuda.stream(stream):
+            shard_world = args.emulate_world if args.emulate_world > 1 else world
+            fitter = ShardedFitter(ctx, model, x, rank=rank, world=shard_world, all_reduce=all_reduce if use_dist else None,
+                                   global_transform=ga.GlobalTranformationType.RigidTransforms, step_length=1.0)
+            if args.force_dist and shard_world == 1:      # exercise the phase + all-reduce driver with one rank
+                from gingr_amd.sharded import as_torch, NUM_SEGMENTS
+                import ctypes
+                from ctypes import c_int64, c_void_p
+                pp = c_void_p(); offs = (c_int64 * NUM_SEGMENTS)(); cnts = (c_int64 * NUM_SEGMENTS)()
+                fitter._lib.gingr_fitter_exchange(fitter.handle, ctypes.byref(pp), offs, cnts)
+                fitter.xch = as_torch(pp.value, offs[NUM_SEGMENTS - 1] + cnts[NUM_SEGMENTS - 1], local_rank)
+                fitter.world = 2
         m_loc = fitter.end - fitter.begin
-        pairs = float(m_loc) * float(N)
-        names = {0: ("cpd_colsum_kernel", 11.0), 1: ("cpd_rowstats_kernel", 18.0)}
-        for which, (name, flops_per_pair) in names.items():
-            ms, n = ctx.timing_read(which)
-            if n:
-                avg = ms / n
-                ach = flops_per_pair * pairs / (avg * 1e-3) / 1e12
-                kernels.append({"kernel": name, "avg_ms": avg, "launches": n, "bound": "valu_f64",
-                                "achieved": ach, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": ach / F64_VALU_PEAK_TFLOPS, "algorithmic_flops_per_pair": flops_per_pair})
-        ms, n = ctx.timing_read(2)
+
+        class Runner:
+            def reset(self, s2):
+                with torch.cuda.stream(stream):
+                    fitter.set_state(np.zeros(args.rank), s2)
+
+            def update(self, n):
+                with torch.cuda.stream(stream):
+                    fitter.update_cpd(args.w, 1.0, n)
+
+            def sync(self):
+                torch.cuda.synchronize(local_rank)
+                if use_dist:
+                    dist.barrier()
+                    torch.cuda.synchronize(local_rank)
+
+            def state(self):
+                return fitter.get_state()
+
+            def stats(self):
+                return fitter.get_cpd_stats()
+
+            def close(self):
+                fitter.close()
+        runner = Runner()
+
+        def timing(which=None, enable=None, reset=False):
+            if enable is not None:
+                ctx.timing_enable(enable)
+            if reset:
+                ctx.timing_reset()
+            if which is not None:
+                return ctx.timing_read(which)
+
+    sigma2_0 = ctx.cpd_initial_sigma2(y, x)      # CpdRegistrationState.apply, CPD.scala:92-102 (mean == reference here)
+    if args.sigma2 > 0:
+        sigma2_0 = args.sigma2
+
+    # ---------------------------------------------------------------------------------------------- the contract's timing
+    # one-time costs (code-object loads, LDS-size attributes, clock ramp) are paid on a throw-away run of three updates; the
+    # state is then reset, so the W warm-up and K timed steps below run the workload from sigma2_0 exactly as specified
+    runner.reset(sigma2_0)
+    runner.update(3)
+    runner.sync()
+    runner.reset(sigma2_0)
+    runner.update(args.warmup)
+    runner.sync()
+    t0 = time.perf_counter()
+    runner.update(args.steps)
+    runner.sync()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    alpha, sc, fit = runner.state()
+    ok = bool(np.all(np.isfinite(fit)) and sc.status == 0 and sc.iteration == args.warmup + args.steps
+              and args.emulate_world <= 1)
+
+    # ---- parity of the state the timed region ended in (outside the timed region): ONE more update on the device, then the
+    # affinity statistics of that evaluation (P1, PX of this rank's rows; den, Np) and the sigma2 it committed against the strict
+    # C oracle evaluated at the pre-update state (full size: ~2.5e9 pair evaluations on the host cores)
+    parity = None
+    if not args.no_parity_check and args.emulate_world <= 1 and rank == 0 and not args.group and world == 1:
+        from oracle import c_oracle as co
+        runner.update(1)
+        runner.sync()
+        _, sc_next, _ = runner.state()
+        got = runner.stats()
+        want = co.cpd_stats(fit, x, float(sc.sigma2), args.w)
+        e_p1 = float(np.max(np.abs(got["P1"] - want.P1) / np.maximum(np.abs(want.P1), 1e-300)))
+        e_px = float(np.linalg.norm(got["PX"] - want.PX) / np.linalg.norm(want.PX))
+        e_den = float(np.max(np.abs(got["den"] - want.den) / want.den))
+        e_s2 = float(abs(sc_next.sigma2 - want.sigma2_next) / want.sigma2_next)
+        parity = {"against": "oracle/cpd_oracle.c (strict C restatement, parity unpinned), state after the timed steps",
+                  "rows_checked": int(want.P1.shape[0]), "P1_max_rel": e_p1, "PX_rel_l2": e_px, "den_max_rel": e_den,
+                  "sigma2_next_rel": e_s2, "tolerance": 1e-8}
+        parity["ok"] = bool(max(e_p1, e_px, e_den, e_s2) < 1e-8)
+        ok = ok and parity["ok"]
+        runner.reset(sigma2_0)                                 # the roofline iterations start from the same regime as the timed ones
+        runner.update(args.warmup + args.steps)
+        runner.sync()
+
+    # ---- live roofline of the dominant kernels (HIP events on the kernels' stream, extra iterations)
+    roof = None
+    kernels = []
+    timing(enable=True, reset=True)
+    runner.update(args.roofline_steps)
+    runner.sync()
+    pairs = float(m_loc) * float(N)
+    names = {0: ("cpd_colsum_kernel", 11.0), 1: ("cpd_rowstats_kernel", 18.0)}
+    for which, (name, flops_per_pair) in names.items():
+        ms, n = timing(which)
         if n:
             avg = ms / n
-            rp = (args.rank + 15) // 16 * 16
-            ach = 6.0 * m_loc * rp * rp / (avg * 1e-3) / 1e12
-            kernels.append({"kernel": "gram_kernel", "avg_ms": avg, "launches": n, "bound": "mfma",
-                            "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": ach / F64_MFMA_PEAK_TFLOPS})
-        ms, n = ctx.timing_read(4)
-        if n:
-            avg = ms / n
-            rp = (args.rank + 15) // 16 * 16
-            gbs = 24.0 * m_loc * rp / (avg * 1e-3) / 1e9
-            kernels.append({"kernel": "sweep_kernel", "avg_ms": avg, "launches": n, "bound": "hbm", "achieved": gbs,
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                            "algorithmic_bytes": 24.0 * m_loc * rp,
-                            "traffic": "FETCH_SIZE x2 (gfx950 correction) = 134 MB at 50k, r=100: profiles/r01_pmc_traffic.md"})
-        ms, n = ctx.timing_read(5)
-        if n:
-            kernels.append({"kernel": "posterior_solve_lds_kernel", "avg_ms": ms / n, "launches": n, "bound": "latency"})
-        ms, n = ctx.timing_read(3)
-        upd_ms = ms / n if n else None
-        ctx.timing_enable(False)
-        dom = max((k for k in kernels if k["bound"] == "valu_f64"), key=lambda k: k["avg_ms"], default=None)
-        if dom is not None:
-            roof = {"bound": "valu_f64", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": dom["peak"],
-                    "unit": "TFLOP/s", "frac": dom["frac"],
-                    # PMC FETCH_SIZE + WRITE_SIZE per launch (separate passes, profiles/r01_pmc_traffic.md), default workload only:
-                    # 13 MB read + 157 MB of per-chunk partial sums written (98 chunks x 4 planes x 50k rows), hidden under 1.3 ms of
-                    # VALU work and read back once by rowstats_reduce_kernel
-                    "traffic": 170.0e6 if (M == 50000 and N == 50000 and world == 1 and not args.emulate_world
-                                           and dom["kernel"] == "cpd_rowstats_kernel") else None,
-                    "nearest_contract_bound": "mfma",
-                    "note": "all-pairs kernel: O(M+N) bytes, O(M*N) float64 VALU flops (software exp counted as 1 flop); "
-                            "HBM and MFMA are not the binding resource.  In the contract's hbm|mfma vocabulary this is the "
-                            "compute side: the peak used, 78.6 TFLOP/s, is also the dense f64 MFMA peak -- on gfx950 the f64 "
-                            "vector and matrix pipes share the issue slots (profiles/r01_ubench_mfma_valu_overlap.txt), so "
-                            "moving the K=3 contraction to MFMA does not raise the ceiling (GINGR_AFFINITY=mfma measures it)"}
+            ach = flops_per_pair * pairs / (avg * 1e-3) / 1e12
+            kernels.append({"kernel": name, "avg_ms": avg, "launches": n, "bound": "valu_f64",
+                            "achieved": ach, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach / F64_VALU_PEAK_TFLOPS, "algorithmic_flops_per_pair": flops_per_pair})
+    ms, n = timing(2)
+    if n:
+        avg = ms / n
+        rp = (args.rank + 15) // 16 * 16
+        ach = 6.0 * m_loc * rp * rp / (avg * 1e-3) / 1e12
+        kernels.append({"kernel": "gram_kernel", "avg_ms": avg, "launches": n, "bound": "mfma",
+                        "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / F64_MFMA_PEAK_TFLOPS,
+                        "note": "algorithmic flops of the full symmetric product (6 M rp^2); the kernel multiplies the upper triangle "
+                                "only, so the matrix pipe issues about half of them",
+                        "issued_flops_frac_of_peak": (ach * (rp / 16 + 1) / (2.0 * rp / 16)) / F64_MFMA_PEAK_TFLOPS})
+    ms, n = timing(4)
+    if n:
+        avg = ms / n
+        rp = (args.rank + 15) // 16 * 16
+        gbs = 24.0 * m_loc * rp / (avg * 1e-3) / 1e9
+        tr, src = load_pmc_traffic("sweep_kernel", M, args.rank) if n_shards == 1 else (None, None)
+        kernels.append({"kernel": "sweep_kernel", "avg_ms": avg, "launches": n, "bound": "hbm", "achieved": gbs,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "algorithmic_bytes": 24.0 * m_loc * rp, "traffic": tr, "traffic_source": src})
+    ms, n = timing(5)
+    if n:
+        kernels.append({"kernel": "posterior_solve_lds_kernel", "avg_ms": ms / n, "launches": n, "bound": "latency"})
+    ms, n = timing(3)
+    upd_ms = ms / n if n else None
+    timing(enable=False)
+    dom = max((k for k in kernels if k["bound"] == "valu_f64"), key=lambda k: k["avg_ms"], default=None)
+    if dom is not None:
+        tr, src = (load_pmc_traffic(dom["kernel"], M, args.rank)
+                   if (n_shards == 1 and not args.emulate_world and M == N) else (None, None))
+        roof = {"bound": "valu_f64", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": dom["peak"],
+                "unit": "TFLOP/s", "frac": dom["frac"],
+                # HBM bytes per launch from the PMC counters (separate FETCH_SIZE / WRITE_SIZE passes), read from the tracked
+                # artefact of tools/pmc_traffic.sh for this workload; null when there is none
+                "traffic": tr, "traffic_source": src,
+                "algorithmic_bytes": 24.0 * (m_loc + N) + 32.0 * m_loc,
+                "nearest_contract_bound": "mfma",
+                "note": "all-pairs kernel: O(M+N) bytes, O(M*N) float64 VALU flops (software exp counted as 1 flop); "
+                        "HBM and MFMA are not the binding resource.  In the contract's hbm|mfma vocabulary this is the "
+                        "compute side: the peak used, 78.6 TFLOP/s, is also the dense f64 MFMA peak -- on gfx950 the f64 "
+                        "vector and matrix pipes share the issue slots (profiles/r01_ubench_mfma_valu_overlap.txt), so "
+                        "moving the K=3 contraction to MFMA does not raise the ceiling (GINGR_AFFINITY=mfma measures it)"}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.emulate_world:
-        cpu = cpu_baseline(y, x, sigma2_0, args.w)
+    if rank == 0 and n_shards == 1 and not args.no_cpu_baseline and not args.emulate_world:
+        cpu = cpu_baseline(y, x, sigma2_0, args.w, model=model)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
+        mode = ("in-library device group, one process" + (" (logical shards on device 0)" if args.logical_shards > 0 else "")
+                if args.group else ("torch.distributed (RCCL), one process per GPU" if n_shards > 1 else "single shard"))
         out = {
             "metric": "GiNGR update iters/sec, 50k<->50k CPD",
             "value": args.steps / elapsed,
             "unit": "iterations/s",
-            "n_gpus": world,
+            "n_gpus": args.gpus if args.group else world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
@@ -348,9 +559,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"CPD update, synthetic Gaussian clouds {M}<->{N}, GPMM rank {args.rank}, w={args.w}, "
                                    f"rigid global transform, sigma2_0={sigma2_0:.3f}",
-                       "points": M, "targets": N, "rank": args.rank, "parallelism": f"row-shard x{world}",
-                       "emulated_world": args.emulate_world or None},
+                       "points": M, "targets": N, "rank": args.rank, "parallelism": f"row-shard x{n_shards}",
+                       "exchange": mode, "emulated_world": args.emulate_world or None},
             "valid": ok,
+            "parity_check": parity,
             "sigma2_after_timed_steps": float(sc.sigma2),
             "update_ms_device": upd_ms,
             "roofline": roof,
@@ -359,7 +571,7 @@ def main():
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
-    fitter.close()
+    runner.close()
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
@@ -372,8 +584,8 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
-    return
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -81,6 +81,10 @@ class Context:
         _check(self.handle, self._lib.gingr_ctx_set_stream(self.handle, c_void_p(hip_stream or 0)), "gingr_ctx_set_stream")
 
     # timing hooks (bench.py roofline)
+    def get_stream(self) -> int:
+        """The hipStream_t (as an integer) the context's kernels are enqueued on."""
+        return int(self._lib.gingr_ctx_get_stream(self.handle) or 0)
+
     def timing_enable(self, on: bool = True):
         _check(self.handle, self._lib.gingr_ctx_timing_enable(self.handle, 1 if on else 0), "timing_enable")
 

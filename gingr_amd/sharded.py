@@ -61,6 +61,12 @@ class ShardedFitter:
     """The native fitter of one rank (rows [begin, end) of the model) plus the exchange plumbing.
 
     all_reduce(tensor) must sum the float64 device tensor in place across all ranks; None means a single shard.
+
+    Stream contract (world > 1): the phase kernels run on the context's stream, the collective on torch's CURRENT stream.  When
+    the two are the same stream (bench.py: `ctx.set_stream(stream.cuda_stream)` + `with torch.cuda.stream(stream)`) stream
+    order alone makes the exchange correct and nothing waits on the host.  Otherwise every exchange is bracketed by host
+    synchronisation of both streams (correct, slower) -- checked per call, so a caller cannot race the collective against the
+    column-sum / Gram kernels by accident.
     """
 
     def __init__(self, ctx: Context, model: PointDistributionModel, target, rank: int = 0, world: int = 1,
@@ -132,8 +138,32 @@ class ShardedFitter:
                "gingr_fitter_get_state")
         return alpha, s, fit
 
+    def get_cpd_stats(self) -> dict:
+        """Affinity statistics of the LAST CPD evaluation of this shard (gingr_fitter_get_cpd_stats): P1 / PX of the local rows, den
+        of every target (reduced), scalars {Np, xPx, trPXY, yPy, sigma2_next, c}."""
+        M = self.end - self.begin
+        N = self.counts[0]
+        P1, PX, den, sc = np.empty(M), np.empty((M, 3)), np.empty(N), np.empty(6)
+        _check(self.ctx.handle, self._lib.gingr_fitter_get_cpd_stats(self.handle, dptr(P1), dptr(PX), dptr(den), dptr(sc)),
+               "gingr_fitter_get_cpd_stats")
+        return {"P1": P1, "PX": PX, "den": den, "Np": float(sc[0]), "sigma2_next": float(sc[4]), "c": float(sc[5])}
+
     def _segment(self, seg: int):
         return self.xch[self.offsets[seg]: self.offsets[seg] + self.counts[seg]]
+
+    def _same_stream(self) -> bool:
+        import torch
+        return int(self.ctx.get_stream() or 0) == int(torch.cuda.current_stream(self.ctx.device).cuda_stream or 0)
+
+    def _exchange(self, seg: int):
+        """all-reduce of exchange segment `seg`, ordered against the library's kernels (see the class docstring)"""
+        if self._same_stream():
+            self.all_reduce(self._segment(seg))
+            return
+        import torch
+        self.ctx.synchronize()                                     # the partial sums are complete
+        self.all_reduce(self._segment(seg))
+        torch.cuda.current_stream(self.ctx.device).synchronize()    # the sums are in place before the next phase reads them
 
     def update_cpd(self, w: float = 0.0, lambda_: float = 1.0, n_iterations: int = 1):
         p = nat.CpdParams(w, lambda_)
@@ -145,7 +175,7 @@ class ShardedFitter:
             drive_update(
                 lambda ph: _check(self.ctx.handle, self._lib.gingr_fitter_cpd_phase_async(self.handle, ctypes.byref(p), ph),
                                   "gingr_fitter_cpd_phase_async"),
-                lambda seg: self.all_reduce(self._segment(seg)), self.world)
+                self._exchange, self.world)
 
     def update_icp(self, initial_sigma: float, end_sigma: float, max_iterations: int, n_iterations: int = 1):
         p = nat.IcpParams(initial_sigma, end_sigma, max_iterations)
@@ -157,7 +187,7 @@ class ShardedFitter:
             drive_update(
                 lambda ph: _check(self.ctx.handle, self._lib.gingr_fitter_icp_phase_async(self.handle, ctypes.byref(p), ph),
                                   "gingr_fitter_icp_phase_async"),
-                lambda seg: self.all_reduce(self._segment(seg)), self.world, skip_segment0=True)
+                self._exchange, self.world, skip_segment0=True)
 
     def close(self):
         if getattr(self, "handle", None):

@@ -288,6 +288,10 @@ int gingr_fitter_retry_counter(gingr_fitter *f, int32_t set_to, int32_t *value_o
  * exchange segment p across shards (RCCL over xGMI via torch.distributed, or nothing for one shard), then runs phase p+1.
  * The exchange buffer is device memory owned by the library; gingr_fitter_exchange gives its address and the
  * [offset, count) of every segment in float64 elements.
+ * Stream contract: phase kernels are enqueued on the context's stream (gingr_ctx_set_stream / gingr_ctx_get_stream).  A host that
+ * runs its collective on another stream must order the two itself: wait for the context's stream before the all-reduce and for
+ * the collective before the next phase (gingr_amd/sharded.py does exactly that when the streams differ).  The in-library
+ * alternative that needs no host collective at all is the device group below (gingr_group_*).
  *   phase 0 -> segment 0: den partial column sums [N]           (the CPD column-sum exchange; unused for ICP)
  *   phase 1 -> segment 1: weighted Gram [rp*rp] + rhs [rp] + sigma2 sums [8]
  *   phase 2: replicated r x r algebra (posterior solve, projections and Umeyama from the model's one-off moments),

@@ -223,3 +223,69 @@ def test_50k_properties_and_sampled_oracle(ctx):
     assert np.array_equal(idx[rows], si) and np.array_equal(d2[rows], sd2)
     idx_self, d2_self, _ = ctx.nn(x[:5000], x)
     assert np.array_equal(idx_self, np.arange(5000)) and np.all(d2_self == 0.0)
+
+
+def test_two_logical_shards_through_sharded_fitter_update_itself(ctx):
+    """ShardedFitter.update_cpd / update_icp -- the driver loop bench.py uses for N > 1, including its stream contract (the
+    contexts run on their own streams here, torch's collective stand-in on the current stream: every exchange must be
+    bracketed by synchronisation) -- on two logical shards in two threads with a barrier all-reduce."""
+    import threading
+    import torch
+    import gingr_amd as ga
+    from gingr_amd.sharded import ShardedFitter
+    rng = np.random.default_rng(78)
+    ref = rng.normal(0, 40, (777, 3))
+    mo = go.build_gaussian_gpmm(ref, 60.0, 30.0, rel_tol=1e-9, max_rank=32)
+    model = ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam)
+    target = mo.instance(rng.normal(0, 1, mo.rank))[:700] + rng.normal(0, 0.3, (700, 3)) + 1.0
+    s2 = ctx.cpd_initial_sigma2(mo.ref, target)
+    single = ShardedFitter(ctx, model, target)
+    single.set_state(np.zeros(mo.rank), s2)
+    single.update_cpd(0.1, 1.0, 3)
+    single.update_icp(20.0, 1.0, 10, 2)
+    a1, sc1, fit1 = single.get_state()
+    single.close()
+
+    world = 2
+    ctxs = [ga.Context(0) for _ in range(world)]              # own non-blocking streams: NOT torch's current stream
+    barrier = threading.Barrier(world)
+    slots = [None] * world
+    results, errors = [None] * world, []
+
+    def make_all_reduce(r):
+        def all_reduce(t):
+            slots[r] = t
+            barrier.wait()
+            tot = torch.stack([slots[q] for q in range(world)]).sum(0)   # same order on both shards: bit-identical sums
+            barrier.wait()                                               # everybody has read every partial
+            t.copy_(tot)
+            torch.cuda.synchronize()
+        return all_reduce
+
+    def work(r):
+        try:
+            f = ShardedFitter(ctxs[r], model, target, rank=r, world=world, all_reduce=make_all_reduce(r))
+            assert not f._same_stream()
+            f.set_state(np.zeros(mo.rank), s2)
+            f.update_cpd(0.1, 1.0, 3)
+            f.update_icp(20.0, 1.0, 10, 2)
+            results[r] = f.get_state()
+            f.close()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    fit = np.concatenate([results[r][2] for r in range(world)])
+    for r in range(world):
+        a, sc, _ = results[r]
+        assert sc.iteration == 5 and sc.status == 0 and sc.sigma2 == sc1.sigma2
+        assert rel(a, a1) < 1e-7
+    assert rel(fit, fit1) < 1e-9
+    for c in ctxs:
+        c.close()
