@@ -36,6 +36,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the oracle's OpenMP threads must sleep, not spin, once a CPU leg is over: spinning threads slow the thread that feeds the GPU
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 
 F64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector float64 peak (AMD datasheet)
 F64_MFMA_PEAK_TFLOPS = 78.6   # matrix float64 peak
@@ -452,30 +454,7 @@ def main():
     alpha, sc, fit = runner.state()
     ok = bool(np.all(np.isfinite(fit)) and sc.status == 0 and sc.iteration == args.warmup + args.steps
               and args.emulate_world <= 1)
-
-    # ---- parity of the state the timed region ended in (outside the timed region): ONE more update on the device, then the
-    # affinity statistics of that evaluation (P1, PX of this rank's rows; den, Np) and the sigma2 it committed against the strict
-    # C oracle evaluated at the pre-update state (full size: ~2.5e9 pair evaluations on the host cores)
-    parity = None
-    if not args.no_parity_check and args.emulate_world <= 1 and rank == 0 and not args.group and world == 1:
-        from oracle import c_oracle as co
-        runner.update(1)
-        runner.sync()
-        _, sc_next, _ = runner.state()
-        got = runner.stats()
-        want = co.cpd_stats(fit, x, float(sc.sigma2), args.w)
-        e_p1 = float(np.max(np.abs(got["P1"] - want.P1) / np.maximum(np.abs(want.P1), 1e-300)))
-        e_px = float(np.linalg.norm(got["PX"] - want.PX) / np.linalg.norm(want.PX))
-        e_den = float(np.max(np.abs(got["den"] - want.den) / want.den))
-        e_s2 = float(abs(sc_next.sigma2 - want.sigma2_next) / want.sigma2_next)
-        parity = {"against": "oracle/cpd_oracle.c (strict C restatement, parity unpinned), state after the timed steps",
-                  "rows_checked": int(want.P1.shape[0]), "P1_max_rel": e_p1, "PX_rel_l2": e_px, "den_max_rel": e_den,
-                  "sigma2_next_rel": e_s2, "tolerance": 1e-8}
-        parity["ok"] = bool(max(e_p1, e_px, e_den, e_s2) < 1e-8)
-        ok = ok and parity["ok"]
-        runner.reset(sigma2_0)                                 # the roofline iterations start from the same regime as the timed ones
-        runner.update(args.warmup + args.steps)
-        runner.sync()
+    sigma2_timed = float(sc.sigma2)
 
     # ---- live roofline of the dominant kernels (HIP events on the kernels' stream, extra iterations)
     roof = None
@@ -536,6 +515,28 @@ def main():
                         "vector and matrix pipes share the issue slots (profiles/r01_ubench_mfma_valu_overlap.txt), so "
                         "moving the K=3 contraction to MFMA does not raise the ceiling (GINGR_AFFINITY=mfma measures it)"}
 
+    # ---- parity of the state the measurements ended in (outside every timed region): ONE more update on the device, then the
+    # affinity statistics of that evaluation (P1, PX of this rank's rows; den, Np) and the sigma2 it committed against the strict
+    # C oracle evaluated at the pre-update state (full size: ~2.5e9 pair evaluations on the host cores)
+    parity = None
+    if not args.no_parity_check and args.emulate_world <= 1 and rank == 0 and not args.group and world == 1:
+        from oracle import c_oracle as co
+        _, sc, fit = runner.state()                            # the state after the timed + roofline iterations
+        runner.update(1)
+        runner.sync()
+        _, sc_next, _ = runner.state()
+        got = runner.stats()
+        want = co.cpd_stats(fit, x, float(sc.sigma2), args.w)
+        e_p1 = float(np.max(np.abs(got["P1"] - want.P1) / np.maximum(np.abs(want.P1), 1e-300)))
+        e_px = float(np.linalg.norm(got["PX"] - want.PX) / np.linalg.norm(want.PX))
+        e_den = float(np.max(np.abs(got["den"] - want.den) / want.den))
+        e_s2 = float(abs(sc_next.sigma2 - want.sigma2_next) / want.sigma2_next)
+        parity = {"against": "oracle/cpd_oracle.c (strict C restatement, parity unpinned), one update from the state after the timed + roofline steps",
+                  "rows_checked": int(want.P1.shape[0]), "P1_max_rel": e_p1, "PX_rel_l2": e_px, "den_max_rel": e_den,
+                  "sigma2_next_rel": e_s2, "tolerance": 1e-8}
+        parity["ok"] = bool(max(e_p1, e_px, e_den, e_s2) < 1e-8)
+        ok = ok and parity["ok"]
+
     cpu = None
     if rank == 0 and n_shards == 1 and not args.no_cpu_baseline and not args.emulate_world:
         cpu = cpu_baseline(y, x, sigma2_0, args.w, model=model)
@@ -563,7 +564,7 @@ def main():
                        "exchange": mode, "emulated_world": args.emulate_world or None},
             "valid": ok,
             "parity_check": parity,
-            "sigma2_after_timed_steps": float(sc.sigma2),
+            "sigma2_after_timed_steps": sigma2_timed,
             "update_ms_device": upd_ms,
             "roofline": roof,
             "kernels": kernels,
