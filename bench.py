@@ -116,9 +116,10 @@ def cpu_baseline(y, x, sigma2, w, model=None, budget_s=16.0):
     checker build (oracle/cpd_oracle.c: -O2 -ffp-contract=off, scalar libm exp) on a smaller sample, for reference."""
     from oracle import c_baseline as cb
     from oracle import c_oracle as co
-    cores = cb.num_threads()
     M, N = y.shape[0], x.shape[0]
     ys, xs = cb.soa(y), cb.soa(x)
+    visible = os.cpu_count()
+    cores = cb.calibrate_threads(ys, xs, sigma2)      # the thread count with the best pair rate on this host (CPU quota!)
     m0 = max(64, min(M, 8 * cores))
     cb.colsum(np.ascontiguousarray(ys[:, :m0]), xs, sigma2)                      # warm-up: thread pool, page faults
     t0 = time.perf_counter()
@@ -130,7 +131,8 @@ def cpu_baseline(y, x, sigma2, w, model=None, budget_s=16.0):
     den = cb.colsum(ysub, xs, sigma2) * (M / ms) + co.outlier_constant(M, N, sigma2, w)
     P1s, PXs = cb.rowstats(ysub, xs, sigma2, 1.0 / den)
     t_pairs = (time.perf_counter() - t0) * (M / ms)
-    sample = (f"both all-pairs passes (optimised C, {cores} threads) on rows [0,{ms}) of {M} x {N} targets, scaled x{M / ms:.2f}: "
+    sample = (f"both all-pairs passes (optimised C, {cores} OpenMP threads = best of 1,2,4,... on this host, which shows {visible} "
+              f"hardware threads) on rows [0,{ms}) of {M} x {N} targets, scaled x{M / ms:.2f}: "
               f"{t_pairs:.3f} s per iteration")
     t_gp = None
     if model is not None:

@@ -304,3 +304,167 @@ def write_ply(path: str, vertices: np.ndarray, cells: Optional[np.ndarray] = Non
             rec = np.zeros(c.shape[0], dtype=np.dtype([("n", "u1"), ("v", "<i4", 3)]))
             rec["n"], rec["v"] = 3, c
             f.write(rec.tobytes())
+
+
+# ------------------------------------------------------------------------------------------- statistical model (.h5.json)
+# scalismo's StatisticalModelIO.read/writeStatisticalTriangleMeshModel3D on a `.h5.json` file -- how the reference's demos keep
+# their GPMMs (examples/DemoHelper/DemoDatasetLoader.scala:47-53: "<name>_dec-<n>_<kernel>_<pars>.h5.json").
+#
+# [SCALISMO-RECALL] The format lives in the un-vendored dependency scalismo 1.0-RC1 and no such file ships with the reference
+# (the model files are git-ignored there), so BOTH layers below are restated from memory and stay marked UNPINNED until a real
+# file confirms them:
+#   (1) the statismo model layout inside the HDF5 tree:
+#         /version/majorVersion = 0, /version/minorVersion = 9
+#         /model/mean            float[3M]   the mean SHAPE (reference point + mean deformation), point-interleaved x,y,z
+#         /model/pcaBasis        float[3M][r] orthonormal columns (statismo 0.9: not scaled by the standard deviations)
+#         /model/pcaVariance     float[r]
+#         /model/noiseVariance   float[1]
+#         /representer           group, attributes name = "itkStandardMeshRepresenter", datasetType = "POLYGON_MESH"
+#         /representer/points    float[3][M]  (one ROW per coordinate)
+#         /representer/cells     int[3][T]
+#         /modelinfo/...         free-form build information (ignored on read)
+#   (2) the JSON encoding of that tree: the HDF Group's hdf5-json layout -- {"apiVersion", "root": <id>, "groups": {<id>:
+#       {"alias": [path], "attributes": [...], "links": [{"class": "H5L_TYPE_HARD", "collection": "groups" | "datasets", "id",
+#       "title"}]}}, "datasets": {<id>: {"alias": [path], "shape": {"class": "H5S_SIMPLE", "dims": [...]}, "type": {"class":
+#       "H5T_FLOAT" | "H5T_INTEGER", "base": "H5T_IEEE_F32LE" | ...}, "value": nested lists}}}.
+# The reader resolves paths by walking the links from the root (aliases are only used as a fallback), accepts float32 or float64
+# payloads and either orientation of points / cells; the writer produces exactly the layout above (float32 like scalismo's
+# statismo writer unless told otherwise -- round trips through float32 lose ~1e-7 relative, as they do in the reference).
+
+_H5_FLOAT = {"float32": "H5T_IEEE_F32LE", "float64": "H5T_IEEE_F64LE"}
+
+
+def _h5json_resolve(doc: dict, path: str):
+    """dataset / group object at `path`, following hard links from the root group"""
+    parts = [p for p in path.split("/") if p]
+    groups, datasets = doc.get("groups", {}), doc.get("datasets", {})
+    node, kind = groups.get(doc.get("root")), "groups"
+    for k, title in enumerate(parts):
+        if node is None or kind != "groups":
+            node = None
+            break
+        nxt = next((l for l in node.get("links", []) if l.get("title") == title), None)
+        if nxt is None:
+            node = None
+            break
+        kind = nxt.get("collection", "groups")
+        node = doc.get(kind, {}).get(nxt.get("id"))
+    if node is None:                                   # fallback: alias lookup
+        want = "/" + "/".join(parts)
+        for coll in (datasets, groups):
+            for obj in coll.values():
+                if want in obj.get("alias", []):
+                    return obj
+        raise ValueError(f"h5.json: no object at {want}")
+    return node
+
+
+def _h5json_array(doc: dict, path: str, dtype=np.float64) -> np.ndarray:
+    obj = _h5json_resolve(doc, path)
+    if "value" not in obj:
+        raise ValueError(f"h5.json: {path} is not a dataset")
+    a = np.asarray(obj["value"], dtype=dtype)
+    dims = (obj.get("shape") or {}).get("dims")
+    if dims:
+        a = a.reshape([int(v) for v in dims])
+    return a
+
+
+def read_statistical_mesh_model(path: str):
+    """StatisticalModelIO.readStatisticalTriangleMeshModel3D(file.h5.json) -> gingr_amd.PointDistributionModel (reference points,
+    mean DEFORMATION, orthonormal basis, variance, cells).  [SCALISMO-RECALL], see above."""
+    from .api import PointDistributionModel
+    with open(path) as f:
+        doc = json.load(f)
+    pts = _h5json_array(doc, "/representer/points")
+    if pts.ndim != 2 or 3 not in pts.shape:
+        raise ValueError("h5.json: /representer/points is not 3 x M")
+    ref = np.ascontiguousarray(pts.T if pts.shape[0] == 3 and pts.shape[1] != 3 else (pts if pts.shape[1] == 3 else pts.T))
+    if pts.shape == (3, 3):
+        ref = np.ascontiguousarray(pts.T)              # statismo orientation wins for the ambiguous 3 x 3 case
+    M = ref.shape[0]
+    cells = None
+    try:
+        c = _h5json_array(doc, "/representer/cells", dtype=np.int64)
+        cells = np.ascontiguousarray((c.T if c.shape[0] == 3 and c.shape[1] != 3 else (c if c.shape[1] == 3 else c.T)).astype(np.int32))
+        if c.shape == (3, 3):
+            cells = np.ascontiguousarray(c.T.astype(np.int32))
+    except ValueError:
+        pass
+    mean_shape = _h5json_array(doc, "/model/mean").reshape(-1)
+    var = _h5json_array(doc, "/model/pcaVariance").reshape(-1)
+    basis = _h5json_array(doc, "/model/pcaBasis")
+    if mean_shape.shape[0] != 3 * M:
+        raise ValueError(f"h5.json: /model/mean has {mean_shape.shape[0]} entries for {M} points")
+    if basis.shape == (var.shape[0], 3 * M) and var.shape[0] != 3 * M:
+        basis = basis.T
+    if basis.shape != (3 * M, var.shape[0]):
+        raise ValueError(f"h5.json: /model/pcaBasis is {basis.shape}, expected {(3 * M, var.shape[0])}")
+    try:
+        minor = int(np.asarray(_h5json_resolve(doc, "/version/minorVersion").get("value")).reshape(-1)[0])
+    except (ValueError, TypeError):
+        minor = 9
+    if minor == 81:                                    # statismo 0.81: columns scaled by the standard deviations
+        basis = basis / np.sqrt(np.where(var > 0, var, 1.0))[None, :]
+    return PointDistributionModel(reference=ref, mean=(mean_shape.reshape(M, 3) - ref), basis=np.ascontiguousarray(basis),
+                                  variance=var, cells=cells)
+
+
+def write_statistical_mesh_model(model, path: str, dtype: str = "float32", noise_variance: float = 0.0) -> None:
+    """StatisticalModelIO.writeStatisticalTriangleMeshModel3D(model, file.h5.json).  `model`: PointDistributionModel (a
+    DevicePointDistributionModel is downloaded first).  [SCALISMO-RECALL], see above."""
+    import uuid
+    if dtype not in _H5_FLOAT:
+        raise ValueError("dtype must be float32 or float64")
+    host = model.to_host() if hasattr(model, "to_host") else model
+    ref = np.asarray(host.reference, dtype=np.float64)
+    M = ref.shape[0]
+    mean_shape = (ref + np.asarray(host.mean, dtype=np.float64)).reshape(-1)
+    basis = np.asarray(host.basis, dtype=np.float64)
+    var = np.asarray(host.variance, dtype=np.float64)
+    cells = getattr(host, "cells", None)
+    np_t = np.float32 if dtype == "float32" else np.float64
+    doc = {"apiVersion": "1.1.1", "groups": {}, "datasets": {}}
+
+    def new_group(alias, attributes=None):
+        gid = str(uuid.uuid4())
+        doc["groups"][gid] = {"alias": [alias], "attributes": attributes or [], "links": []}
+        return gid
+
+    def link(parent, coll, oid, title):
+        doc["groups"][parent]["links"].append({"class": "H5L_TYPE_HARD", "collection": coll, "id": oid, "title": title})
+
+    def new_dataset(parent, alias, title, arr, integer=False):
+        did = str(uuid.uuid4())
+        a = np.asarray(arr)
+        typ = ({"class": "H5T_INTEGER", "base": "H5T_STD_I32LE"} if integer else {"class": "H5T_FLOAT", "base": _H5_FLOAT[dtype]})
+        val = a.astype(np.int32).tolist() if integer else a.astype(np_t).astype(np.float64).tolist()
+        doc["datasets"][did] = {"alias": [alias], "shape": {"class": "H5S_SIMPLE", "dims": list(a.shape)}, "type": typ, "value": val}
+        link(parent, "datasets", did, title)
+
+    def string_attr(name, value):
+        return {"name": name, "shape": {"class": "H5S_SCALAR"},
+                "type": {"class": "H5T_STRING", "charSet": "H5T_CSET_ASCII", "length": "H5T_VARIABLE", "strPad": "H5T_STR_NULLTERM"},
+                "value": value}
+
+    root = new_group("/")
+    doc["root"] = root
+    g_model = new_group("/model")
+    link(root, "groups", g_model, "model")
+    new_dataset(g_model, "/model/mean", "mean", mean_shape)
+    new_dataset(g_model, "/model/noiseVariance", "noiseVariance", np.array([noise_variance]))
+    new_dataset(g_model, "/model/pcaBasis", "pcaBasis", basis)
+    new_dataset(g_model, "/model/pcaVariance", "pcaVariance", var)
+    g_rep = new_group("/representer", [string_attr("name", "itkStandardMeshRepresenter"), string_attr("datasetType", "POLYGON_MESH")])
+    link(root, "groups", g_rep, "representer")
+    new_dataset(g_rep, "/representer/points", "points", ref.T)
+    if cells is not None:
+        new_dataset(g_rep, "/representer/cells", "cells", np.asarray(cells, dtype=np.int32).T, integer=True)
+    g_ver = new_group("/version")
+    link(root, "groups", g_ver, "version")
+    new_dataset(g_ver, "/version/majorVersion", "majorVersion", np.array([0]), integer=True)
+    new_dataset(g_ver, "/version/minorVersion", "minorVersion", np.array([9]), integer=True)
+    g_info = new_group("/modelinfo", [string_attr("build-time", _dt.datetime.now().isoformat(timespec="seconds"))])
+    link(root, "groups", g_info, "modelinfo")
+    with open(path, "w") as f:
+        json.dump(doc, f)

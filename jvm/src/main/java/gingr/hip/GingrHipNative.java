@@ -87,4 +87,26 @@ public final class GingrHipNative {
     /** any array may be null; basisColMajor is 3 M_local x rank, unit columns */
     public static native int modelDownload(long ctx, long model, double[] ref, double[] mean, double[] basisColMajor, double[] variance);
     public static native int modelRank(long model);
+
+    // ---- retry counter of the probabilistic proposal (GingrAlgorithm.scala:69-70): lives next to the device state
+    /** setTo >= 0 writes, setTo < 0 only reads; out1[0] receives the value */
+    public static native int fitterRetryCounter(long fitter, int setTo, int[] out1);
+
+    // ---- device group: row shards on several GPUs of one node from this ONE process (gingr_group_*; no torch, no MPI)
+    public static native long groupCreate(int[] devices);                  // 0 on failure
+    public static native void groupDestroy(long group);
+    public static native String groupLastError(long group);
+    public static native int groupModelUpload(long group, long mTotal, int rank, double[] refXyz, double[] meanXyz,
+                                              double[] basisColMajor, double[] variance);
+    public static native int groupGpmmBuildGaussian(long group, long mTotal, double[] refXyz, double[] sigmas, double[] scalings,
+                                                    double relativeTolerance, int maxRank);
+    public static native int groupSetTarget(long group, double[] targetXyz);
+    public static native int groupSetLandmarks(long group, int[] pid, double[] xyz, double[] cov9);
+    public static native int groupSetOptions(long group, int globalTransform, double stepLength);
+    public static native int groupSetState(long group, double[] alpha, double[] poseScalars11, int iteration, int status);
+    /** fitXyz [3 M_total] gathered from all shards (may be null) */
+    public static native int groupGetState(long group, double[] alpha, double[] poseScalars11, int[] iterStatus2, double[] fitXyz);
+    public static native int groupUpdateCpd(long group, double w, double lambda, int nIterations);
+    public static native int groupUpdateIcp(long group, double initialSigma, double endSigma, int maxIterations, int nIterations);
+    public static native int groupSynchronize(long group);
 }

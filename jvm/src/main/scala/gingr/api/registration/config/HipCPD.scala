@@ -7,7 +7,8 @@
  * are `private[api]` (gingr/api/RegistrationState.scala:46-58).
  *
  * What changes w.r.t. the stock plugins:
- *  - HipCpdRegistrationState has NO `P` member (CPD.scala:54-75 builds an M x N DenseMatrix on every case-class copy);
+ *  - HipCpdRegistrationState has NO `P` member (CPD.scala:54-75 builds an M x N DenseMatrix on every case-class copy) and the
+ *    stock state class is never constructed, not even for the initial sigma2 (computed natively);
  *  - `update` (GingrAlgorithm.scala:192-254) is overridden: ONE native call per iteration;
  *  - getCorrespondence / getUncertainty / updateSigma2 stay available (served from one native affinity evaluation per
  *    state) so that computePosterior-based callers (GeneratorWrapperStochastic.logTransitionProbability) keep working.
@@ -62,7 +63,7 @@ final class HipSession(device: Int) extends AutoCloseable {
       boundTarget = null
     }
     if (boundTarget ne general.target) {
-      check(GingrHipNative.fitterSetTarget(fitter, HipLayout.mesh(general.target)), "gingr_fitter_set_target")
+      check(GingrHipNative.fitterSetTarget(fitter, flat(general.target)), "gingr_fitter_set_target")
       boundTarget = general.target
     }
     val lms = if (useLandmarks) general.landmarkCorrespondences else IndexedSeq()
@@ -108,13 +109,38 @@ final class HipSession(device: Int) extends AutoCloseable {
     (alpha, poseOut, iterStatus(1))
   }
 
+  // flattened copies of the last meshes seen (a TriangleMesh is immutable: identity is enough); the target of a registration
+  // never changes and a state's fit is asked for several times (getCorrespondence, getUncertainty, updateSigma2)
+  private var flatCache: List[(AnyRef, Array[Double])] = Nil
+  private def flat(m: TriangleMesh[_3D]): Array[Double] =
+    flatCache.find(_._1 eq m).map(_._2).getOrElse {
+      val a = HipLayout.mesh(m)
+      flatCache = ((m, a) :: flatCache).take(4)
+      a
+    }
+
   def cpdStats(fit: TriangleMesh[_3D], target: TriangleMesh[_3D], sigma2: Double, w: Double)
     : (Array[Double], Array[Double], Double) = {
     val m = fit.pointSet.numberOfPoints
-    val n = target.pointSet.numberOfPoints
     val p1 = new Array[Double](m); val px = new Array[Double](3 * m); val sc = new Array[Double](6)
-    check(GingrHipNative.cpdStats(ctx, HipLayout.mesh(fit), HipLayout.mesh(target), sigma2, w, null, p1, px, null, sc), "gingr_cpd_stats")
+    check(GingrHipNative.cpdStats(ctx, flat(fit), flat(target), sigma2, w, null, p1, px, null, sc), "gingr_cpd_stats")
     (p1, px, sc(4))
+  }
+
+  /** sum_ij |x_j - y_i|^2 / (3 M N) (CpdRegistrationState.computeInitialSigma2, CPD.scala:81-90) on the GPU */
+  def initialSigma2(reference: TriangleMesh[_3D], target: TriangleMesh[_3D]): Double = {
+    val out = new Array[Double](1)
+    check(GingrHipNative.cpdInitialSigma2(ctx, flat(reference), flat(target), out), "gingr_cpd_initial_sigma2")
+    out(0)
+  }
+
+  def retryCounter: Int = {
+    if (fitter == 0L) 10
+    else {
+      val out = new Array[Int](1)
+      check(GingrHipNative.fitterRetryCounter(fitter, -1, out), "gingr_fitter_retry_counter")
+      out(0)
+    }
   }
 
   private var boundMeshes: (AnyRef, AnyRef) = (null, null)
@@ -133,7 +159,7 @@ final class HipSession(device: Int) extends AutoCloseable {
 
   def nn(fit: TriangleMesh[_3D], target: TriangleMesh[_3D]): Array[Int] = {
     val idx = new Array[Int](fit.pointSet.numberOfPoints)
-    check(GingrHipNative.nn(ctx, HipLayout.mesh(fit), HipLayout.mesh(target), idx, null, null), "gingr_nn")
+    check(GingrHipNative.nn(ctx, flat(fit), flat(target), idx, null, null), "gingr_nn")
     idx
   }
 
@@ -191,9 +217,13 @@ class HipCpdRegistration(device: Int = 0) extends GingrAlgorithm[HipCpdRegistrat
         DenseMatrix.eye[Double](3) * s.general.sigma2 * s.config.lambda * (1.0 / statsFor(s)._1(id.id)))
   override def updateSigma2(current: HipCpdRegistrationState): Double = statsFor(current)._3
 
+  /** The semantics of the stock companion's apply (CPD.scala:92-102): sigma2 = config.initialSigma, or else
+    * sum_ij |x_j - y_i|^2 / (3 M N) over the model MEAN against the target (computeInitialSigma2, :81-90) -- evaluated on the
+    * GPU.  The stock state class is never constructed: its eager `P` (CPD.scala:54-75) is a dense M x N matrix and
+    * computeInitialSigma2 materialises an M*N Seq, both impossible at 50k x 50k (M*N > Int.MaxValue). */
   override def initializeState(general: GeneralRegistrationState, config: CpdConfiguration): HipCpdRegistrationState = {
-    val init = CpdRegistrationState(general.copy(), config) // reuses computeInitialSigma2 semantics (CPD.scala:92-102)
-    HipCpdRegistrationState(init.general, config)
+    val sigma2 = config.initialSigma.getOrElse(session.initialSigma2(general.model.mean, general.target))
+    HipCpdRegistrationState(general.copy(sigma2 = sigma2), config)
   }
 
   override def update(current: HipCpdRegistrationState, probabilistic: Boolean)(implicit rnd: Random): HipCpdRegistrationState = {
@@ -205,11 +235,90 @@ class HipCpdRegistration(device: Int = 0) extends GingrAlgorithm[HipCpdRegistrat
         session.updateOnce(current.general, f => GingrHipNative.fitterUpdateCpdSample(f, current.config.w, current.config.lambda, z))
       } else
         session.updateOnce(current.general, f => GingrHipNative.fitterUpdateCpd(f, current.config.w, current.config.lambda, 1))
-    // the probabilistic retry counter (GingrAlgorithm.scala:196-202) is private to the trait; a failed sampled proposal is
-    // reported as ModelFlexibilityError like a failed deterministic one
+    // Failure handling is decided on the device exactly as in GingrAlgorithm.update (:194-210,248-251), including the retry
+    // counter of the probabilistic proposal: the trait's `retryCounter` is private, so its stand-in lives next to the device
+    // state (one fitter = one algorithm instance; GingrHipNative.fitterRetryCounter reads it).  A failed sampled posterior
+    // therefore comes back as "state unchanged" (status 0, same parameters) up to 10 times in a row, like the reference.
     current.updateGeneral(HipStateUpdate(current.general, alpha, pose, status))
   }
+  /** retryCounter of this instance (GingrAlgorithm.scala:69-70), read back from the device */
+  def retryCounter: Int = session.retryCounter
   override def close(): Unit = session.close()
+}
+
+/** Multi-GPU from the JVM process itself: the same update on row shards over several devices of one node through the
+  * in-library device group (gingr_group_*: one worker thread per device, one-shot all-reduce over peer pointers; no torch, no MPI).
+  * `devices` lists one GPU per shard.  The deterministic `run` loop and the stock MH machinery work unchanged; the
+  * probabilistic proposal and the transition density are single-GPU features (use HipCpdRegistration for those). */
+class HipCpdGroupRegistration(devices: Seq[Int]) extends GingrAlgorithm[HipCpdRegistrationState, CpdConfiguration] with AutoCloseable {
+  private val group = GingrHipNative.groupCreate(devices.toArray)
+  require(group != 0L, "gingr_group_create failed (devices, peer access)")
+  private val single = new HipSession(devices.head) // stateless helpers (initial sigma2, per-state statistics)
+  private var boundModel: AnyRef = null
+  private var boundTarget: AnyRef = null
+  private def check(rc: Int, what: String): Unit =
+    if (rc != 0) throw new RuntimeException(s"$what failed (gingr_status $rc): ${GingrHipNative.groupLastError(group)}")
+
+  def name = "CPD-HIP-group"
+  private var statsOf: HipCpdRegistrationState = null
+  private var stats: (Array[Double], Array[Double], Double) = null
+  private def statsFor(s: HipCpdRegistrationState) = {
+    if (statsOf ne s) { stats = single.cpdStats(s.general.fit, s.general.target, s.general.sigma2, s.config.w); statsOf = s }
+    stats
+  }
+  override val getCorrespondence: HipCpdRegistrationState => CorrespondencePairs = (s: HipCpdRegistrationState) => {
+    val (p1, px, _) = statsFor(s)
+    val pts = s.general.fit.pointSet.points.toIndexedSeq
+    CorrespondencePairs(pts.indices.map { i =>
+      val y = pts(i); val inv = 1.0 / p1(i)
+      (PointId(i), Point(y.x + (px(3 * i) * inv - y.x), y.y + (px(3 * i + 1) * inv - y.y), y.z + (px(3 * i + 2) * inv - y.z)))
+    })
+  }
+  override val getUncertainty: (PointId, HipCpdRegistrationState) => MultivariateNormalDistribution =
+    (id: PointId, s: HipCpdRegistrationState) =>
+      MultivariateNormalDistribution(DenseVector.zeros[Double](3),
+        DenseMatrix.eye[Double](3) * s.general.sigma2 * s.config.lambda * (1.0 / statsFor(s)._1(id.id)))
+  override def updateSigma2(current: HipCpdRegistrationState): Double = statsFor(current)._3
+  override def initializeState(general: GeneralRegistrationState, config: CpdConfiguration): HipCpdRegistrationState = {
+    val sigma2 = config.initialSigma.getOrElse(single.initialSigma2(general.model.mean, general.target))
+    HipCpdRegistrationState(general.copy(sigma2 = sigma2), config)
+  }
+
+  override def update(current: HipCpdRegistrationState, probabilistic: Boolean)(implicit rnd: Random): HipCpdRegistrationState = {
+    require(!probabilistic, "the device group runs the deterministic update; use HipCpdRegistration for sampled proposals")
+    val general = current.general
+    if (boundModel ne general.model) {
+      val pdm = general.model
+      val m = pdm.reference.pointSet.numberOfPoints
+      check(GingrHipNative.groupModelUpload(group, m.toLong, pdm.rank, HipLayout.mesh(pdm.reference), pdm.gp.meanVector.toArray,
+        pdm.gp.basisMatrix.toDenseMatrix.data, pdm.gp.variance.toArray), "gingr_group_model_upload")
+      boundModel = pdm
+      boundTarget = null
+    }
+    if (boundTarget ne general.target) {
+      check(GingrHipNative.groupSetTarget(group, HipLayout.mesh(general.target)), "gingr_group_set_target")
+      boundTarget = general.target
+    }
+    val lms = if (current.config.useLandmarkCorrespondence) general.landmarkCorrespondences else IndexedSeq()
+    check(GingrHipNative.groupSetLandmarks(group, lms.map(_._1.id).toArray, HipLayout.points(lms.iterator.map(_._2), lms.size),
+      lms.flatMap(l => l._3.cov.t.toArray).toArray), "gingr_group_set_landmarks")
+    val gt = general.globalTransformation match {
+      case NoTransforms         => 0
+      case RigidTransforms      => 1
+      case SimilarityTransforms => 2
+    }
+    check(GingrHipNative.groupSetOptions(group, gt, general.stepLength), "gingr_group_set_options")
+    val mp = general.modelParameters
+    val a = mp.pose.rotation.angles; val c = mp.pose.rotation.center; val t = mp.pose.translation
+    val pose = Array(a.phi, a.theta, a.psi, c.x, c.y, c.z, t.x, t.y, t.z, mp.scale.s, general.sigma2)
+    val status = if (general.status == FittingStatuses.ModelFlexibilityError) 3 else 0
+    check(GingrHipNative.groupSetState(group, mp.shape.parameters.toArray, pose, general.iteration, status), "gingr_group_set_state")
+    check(GingrHipNative.groupUpdateCpd(group, current.config.w, current.config.lambda, 1), "gingr_group_update_cpd_async")
+    val alpha = new Array[Double](general.model.rank); val poseOut = new Array[Double](11); val iterStatus = new Array[Int](2)
+    check(GingrHipNative.groupGetState(group, alpha, poseOut, iterStatus, null), "gingr_group_get_state")
+    current.updateGeneral(HipStateUpdate(general, alpha, poseOut, iterStatus(1)))
+  }
+  override def close(): Unit = { GingrHipNative.groupDestroy(group); single.close() }
 }
 
 // ------------------------------------------------------------------------------------------------------------ ICP

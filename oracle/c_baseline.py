@@ -31,6 +31,8 @@ def lib():
         L = ctypes.CDLL(build())
         dp, i64, dbl = ctypes.POINTER(ctypes.c_double), ctypes.c_int64, ctypes.c_double
         L.baseline_num_threads.restype = ctypes.c_int
+        L.baseline_set_num_threads.restype = None
+        L.baseline_set_num_threads.argtypes = [ctypes.c_int]
         L.baseline_exp_max_rel_error.restype = dbl
         L.baseline_exp_max_rel_error.argtypes = [i64, dbl]
         L.baseline_cpd_colsum.restype = None
@@ -52,6 +54,33 @@ def soa(points) -> np.ndarray:
 
 def num_threads() -> int:
     return int(lib().baseline_num_threads())
+
+
+def set_num_threads(n: int) -> None:
+    lib().baseline_set_num_threads(int(n))
+
+
+def calibrate_threads(fit_soa: np.ndarray, target_soa: np.ndarray, sigma2: float, rows_per_thread: int = 24) -> int:
+    """Pick the OpenMP thread count with the highest pair rate on THIS host (a container's CPU quota is often far below the
+    number of hardware threads it can see; oversubscribed spinning threads then make the baseline slower, not faster) and leave
+    it set.  Returns the chosen count."""
+    import time
+    best, best_rate = 1, 0.0
+    limit = os.cpu_count() or 1
+    nt = 1
+    while nt <= limit:
+        set_num_threads(nt)
+        m = min(fit_soa.shape[1], max(64, rows_per_thread * nt))
+        sub = np.ascontiguousarray(fit_soa[:, :m])
+        colsum(sub[:, :max(16, m // 8)].copy(), target_soa, sigma2)      # thread start-up
+        t0 = time.perf_counter()
+        colsum(sub, target_soa, sigma2)
+        rate = m / (time.perf_counter() - t0)
+        if rate > best_rate * 1.05:
+            best, best_rate = nt, rate
+        nt *= 2
+    set_num_threads(best)
+    return best
 
 
 def exp_max_rel_error(n: int = 1000001, lo: float = -700.0) -> float:

@@ -29,6 +29,14 @@ int baseline_num_threads(void) {
 #endif
 }
 
+void baseline_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 #pragma omp declare simd notinbranch
 static inline double vexp(double x) {
     /* valid for x <= 0 (the only arguments the passes produce); flushes to 0 below -708 */

@@ -169,3 +169,34 @@ def test_builder_argument_errors(ctx):
                          ([10.0] * 9, [1.0] * 9, 0.01)]:
         with pytest.raises(ga.GingrNativeError):
             ga.DevicePointDistributionModel(ctx, ref, sig, sc, tol).device()
+
+
+def test_registration_from_a_model_file_read_back_from_disk(ctx, tmp_path):
+    """Section 8f rank 4: a GPMM built on the device, written as a scalismo `.h5.json` statistical-model file, read back and
+    registered with -- the way the reference's demos persist their models (DemoDatasetLoader.scala:47-53).  The float64 file
+    reproduces the in-memory run; the float32 file (scalismo's on-disk precision) stays inside the 1e-5 bar."""
+    import gingr_amd as ga
+    from gingr_amd import io as gio
+    rng = np.random.default_rng(8)
+    ref = rng.normal(0, 40, (900, 3))
+    dmodel = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.0, maxRank=24).Gaussian(60.0, 30.0)
+    host = dmodel.to_host()
+    target = ref[rng.permutation(900)[:800]] + rng.normal(0, 0.6, (800, 3)) + np.array([1.0, -0.5, 0.25])
+
+    def run(model):
+        algo = ga.CpdRegistration(ctx)
+        st = algo.createInitialState(model, target, ga.CpdConfiguration(maxIterations=10, w=0.1))
+        for _ in range(3):
+            st = algo.update(st)
+        algo.close()
+        return st.general
+
+    direct = run(ga.PointDistributionModel(host.reference, host.mean, host.basis, host.variance))
+    p64, p32 = str(tmp_path / "gpmm64.h5.json"), str(tmp_path / "gpmm32.h5.json")
+    gio.write_statistical_mesh_model(dmodel, p64, dtype="float64")
+    gio.write_statistical_mesh_model(dmodel, p32)
+    g64 = run(gio.read_statistical_mesh_model(p64))
+    g32 = run(gio.read_statistical_mesh_model(p32))
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    assert g64.status == 0 and rel(g64.fit, direct.fit) < 1e-12 and g64.sigma2 == direct.sigma2
+    assert g32.status == 0 and rel(g32.fit, direct.fit) < 1e-5

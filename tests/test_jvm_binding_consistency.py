@@ -14,14 +14,17 @@ MOCK_JNI = """
 #pragma once
 #include <cstdint>
 typedef int32_t jint; typedef int32_t jsize; typedef int64_t jlong; typedef double jdouble; typedef unsigned char jboolean;
-class _jobject {}; typedef _jobject *jobject; typedef jobject jclass; typedef jobject jarray; typedef jarray jdoubleArray;
-typedef jarray jintArray; typedef jobject jstring;
+class _jobject {}; class _jclass : public _jobject {}; class _jstring : public _jobject {}; class _jarray : public _jobject {};
+class _jdoubleArray : public _jarray {}; class _jintArray : public _jarray {};
+typedef _jobject *jobject; typedef _jclass *jclass; typedef _jstring *jstring; typedef _jarray *jarray;
+typedef _jdoubleArray *jdoubleArray; typedef _jintArray *jintArray;
 #define JNIEXPORT
 #define JNICALL
-#define JNI_ABORT 2
 struct JNIEnv {
-    void *GetPrimitiveArrayCritical(jarray, jboolean *) { return nullptr; }
-    void ReleasePrimitiveArrayCritical(jarray, void *, jint) {}
+    void GetDoubleArrayRegion(jdoubleArray, jsize, jsize, jdouble *) {}
+    void SetDoubleArrayRegion(jdoubleArray, jsize, jsize, const jdouble *) {}
+    void GetIntArrayRegion(jintArray, jsize, jsize, jint *) {}
+    void SetIntArrayRegion(jintArray, jsize, jsize, const jint *) {}
     jsize GetArrayLength(jarray) { return 0; }
     jstring NewStringUTF(const char *) { return nullptr; }
 };
@@ -43,3 +46,16 @@ def test_jni_shim_type_checks_against_the_header(tmp_path):
     out = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", str(tmp_path), "-I", os.path.join(ROOT, "include"), JNI],
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[:2000]
+
+
+def test_jni_shim_holds_no_critical_pins_and_plugin_never_builds_the_dense_state():
+    """ADVICE r1 / VERDICT r1 weak 7: no GetPrimitiveArrayCritical region may span a GPU call (the shim copies through
+    Get/Set<Type>ArrayRegion), and the plugin must never run the stock CpdRegistrationState constructor (dense M x N `P`:
+    CPD.scala:54-75 -- it throws at the 50k metric size)."""
+    jni, scala = open(JNI).read(), open(SCALA).read()
+    code = re.sub(r"//.*", "", jni)
+    assert "GetPrimitiveArrayCritical" not in code and "ReleasePrimitiveArrayCritical" not in code
+    assert "GetDoubleArrayRegion" in code and "SetDoubleArrayRegion" in code
+    scala_code = re.sub(r"//.*", "", re.sub(r"/\*.*?\*/", "", scala, flags=re.S))
+    assert not re.search(r"\bCpdRegistrationState\s*\(", scala_code), "HipCPD.scala constructs the stock dense-P state"
+    assert "cpdInitialSigma2" in scala_code and "retry" in scala_code.lower()
