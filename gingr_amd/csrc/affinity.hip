@@ -114,6 +114,36 @@ __device__ __forceinline__ Box block_bbox(const double (&x)[PT], const double (&
     return b;
 }
 
+// bounding box of a wave's owned points (invalid slots excluded), wave-uniform, in scalar registers.  In the CPD passes all four
+// waves of a workgroup hold the SAME owned points, so this is also the workgroup's box -- computed redundantly, no LDS, and
+// bit-identical in every wave (block-uniform branches may depend on it).
+template <int PT>
+__device__ __forceinline__ Box wave_bbox(const double (&x)[PT], const double (&y)[PT], const double (&z)[PT], const bool (&ok)[PT]) {
+    double lo[3] = {__builtin_huge_val(), __builtin_huge_val(), __builtin_huge_val()};
+    double hi[3] = {-__builtin_huge_val(), -__builtin_huge_val(), -__builtin_huge_val()};
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+        if (ok[t]) {
+            lo[0] = fmin(lo[0], x[t]); hi[0] = fmax(hi[0], x[t]);
+            lo[1] = fmin(lo[1], y[t]); hi[1] = fmax(hi[1], y[t]);
+            lo[2] = fmin(lo[2], z[t]); hi[2] = fmax(hi[2], z[t]);
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = fmin(lo[d], __shfl_xor(lo[d], off));
+            hi[d] = fmax(hi[d], __shfl_xor(hi[d], off));
+        }
+    Box b;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        b.lo[d] = uniform_d(lo[d]);
+        b.hi[d] = uniform_d(hi[d]);
+    }
+    return b;
+}
+
 // bounding box of each owned slot t over the wave: the 64 consecutive points {base + 64 t + lane} (a quarter k-d leaf); wave
 // The streamed side of an all-pairs launch is cut into chunks (one workgroup per owned block and chunk): n_big chunks of len_big
 // points, then chunks of len_tail points.  Long chunks first and short ones last shorten the tail of the launch (the last
@@ -198,7 +228,11 @@ __global__ __launch_bounds__(256) void tile_bbox_kernel(Cloud c, double *__restr
             const double cc = ctr ? ctr[d] : 0.0;
             m = fmax(m, fmax(fabs(b.lo[d] - cc), fabs(b.hi[d] - cc)));
         }
-        atomicMax(reinterpret_cast<unsigned long long *>(slot), __builtin_bit_cast(unsigned long long, m));
+        // one atomic per workgroup on ONE word serialises (~0.13 us each: 26 us for the 196 tiles of 50k points): only a workgroup
+        // whose value exceeds what is already there needs to write at all (a stale read only costs a redundant atomic)
+        const unsigned long long mb = __builtin_bit_cast(unsigned long long, m);
+        if (mb > __hip_atomic_load(reinterpret_cast<unsigned long long *>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(reinterpret_cast<unsigned long long *>(slot), mb);
     }
 }
 
@@ -264,11 +298,17 @@ __device__ __forceinline__ void colsum_tile_expand(const P4 *tile, int j0, int j
     }
 }
 
+// Work split of both CPD passes.  A workgroup owns 64*PT points (one 256-point k-d leaf at PT = 4) and ALL FOUR of its waves hold
+// the same owned points in registers; of every streamed 256-point tile wave q takes the 64-point quarter q.  The four waves'
+// accumulators are added in LDS in a fixed order ((w0 + w1) + (w2 + w3)) before anything goes to memory, so a workgroup covers a
+// chunk four times as long as it would with one accumulator set per wave and the launch writes a quarter of the chunk partials
+// (50k x 50k: 25 instead of 98 chunks; 40 MB instead of 157 MB of row-statistics partials) for the same number of workgroups.
+//
 // FINE selects the variant with the quarter-tile x slot culling; it pays when the cull radius is small against the clouds (the
-// regime, a property of sigma2 and the cloud extents that only the device knows).  Both variants give bit-identical results, so
-// the host launches ONE of them, picked from the regime word the previous launches left in pinned host memory (regime_out;
-// possibly stale -- that only costs time).  Two kernels rather than one with a switch: sharing one kernel cost the plain regime
-// 7 % in the row-statistics pass.
+// regime, a property of sigma2 and the cloud extents that only the device knows).  The plain variant culls per (workgroup, tile)
+// and per (wave's quarter).  Both variants give bit-identical results, so the host launches ONE of them, picked from the regime
+// word the previous launches left in pinned host memory (regime_out; possibly stale -- that only costs time).  Two kernels
+// rather than one with a switch: sharing one kernel cost the plain regime 7 % in the row-statistics pass.
 template <int PT, bool FINE>
 __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt, const double *__restrict__ sigma2,
                                                             const double *__restrict__ aux,
@@ -276,8 +316,8 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
                                                             double *__restrict__ partial, int32_t *regime_out) {
     __shared__ double T[kTabN];
     __shared__ P4 tile[kTile];
-    __shared__ double shbox[24];
-    __shared__ double sfrac[kBlock * PT];  // per owned point: fraction of c|x~|^2 (expansion form), parked until the epilogue
+    __shared__ double sred[4][64 * PT];  // the waves' accumulators, combined in the epilogue
+    __shared__ double sfrac[64 * PT];    // per owned point: fraction of c|x~|^2 (expansion form), parked until the epilogue
     const double c = fastexp_scale_for_variance<kTB>(2.0 * sigma2[0]);
     const double am = aux[0] + aux[1];
     // regime of the fine culling: the zero-flush radius is well inside the clouds' extent (3 am^2 bounds every squared distance)
@@ -291,9 +331,10 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
     const double lim = fastexp_d2_limit<kTB>(c);
     const double cx = aux[2], cy = aux[3], cz = aux[4];
     const double m2c = -2.0 * c;
-    const int tid = threadIdx.x;
-    // a wave owns 64*PT CONSECUTIVE points (one 256-point k-d leaf at PT = 4): its bounding box is compact
-    const int64_t jbase = (int64_t)blockIdx.x * (kBlock * PT) + (int64_t)(tid >> 6) * (64 * PT) + (tid & 63);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave's number, provably uniform: loop bounds and LDS bases stay scalar
+    // the workgroup's 64*PT CONSECUTIVE points (one 256-point k-d leaf at PT = 4: a compact box), the same in every wave
+    const int64_t jbase = (int64_t)blockIdx.x * (64 * PT) + lane;
     double x[PT], y[PT], z[PT], n[PT], acc[PT];
     bool okv[PT];
 #pragma unroll
@@ -305,13 +346,10 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         y[t] = ok ? tgt.y[j] : 0.0;
         z[t] = ok ? tgt.z[j] : 0.0;
     }
-    Box wown;
-    const Box own = block_bbox<PT>(x, y, z, okv, shbox, &wown);  // raw coordinates, before any centring
-    const bool wave_owns_any = __builtin_amdgcn_readfirstlane((int)okv[0]) != 0;  // lane 0, slot 0 is the wave's first point
+    const Box own = wave_bbox<PT>(x, y, z, okv);  // raw coordinates, before any centring
     constexpr unsigned kAllSlots = (1u << PT) - 1u;
-    constexpr bool fine_on = FINE;
     Box sown[PT];  // per owned slot (64 consecutive points)
-    if (fine_on) slot_boxes<PT>(x, y, z, okv, sown);
+    if (FINE) slot_boxes<PT>(x, y, z, okv, sown);
     const double *fit_sub = fit_boxes ? fit_boxes + ((fit.n + kTile - 1) / kTile) * 6 : nullptr;
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
@@ -322,67 +360,97 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         }
         double fr;
         n[t] = expand_owned_magic(c * __builtin_fma(z[t], z[t], __builtin_fma(y[t], y[t], x[t] * x[t])), &fr);
-        sfrac[t * kBlock + tid] = fr;  // read back by the same thread only
+        if (q == 0) sfrac[t * 64 + lane] = fr;
         acc[t] = 0.0;
     }
     int64_t i0, i1;
     plan.range(blockIdx.y, fit.n, &i0, &i1);
+    __syncthreads();       // the exponential table (filled by all four waves) and sfrac are complete
     fastexp_round_down();  // the floor form of the exponential needs it; every float64 result up to the epilogue rounds down
-    // a chunk starts and ends on 64-point quarters, not necessarily on tiles: every pass handles the part of ONE box tile that
-    // lies inside the chunk, so the tile / quarter boxes apply unchanged
-    for (int64_t ib = i0, ie; ib < i1; ib = ie) {
-        ie = min(i1, (ib / kTile + 1) * kTile);
-        if (fit_boxes && box_gap2(own, fit_boxes + (ib / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;  // all pairs flush to +0
-        __syncthreads();
-        const int64_t i = ib + tid;
-        if (i < ie) {
+    // A chunk starts and ends on 64-point quarters, not necessarily on tiles: every step handles the part of ONE box tile that lies
+    // inside the chunk, so the tile / quarter boxes apply unchanged.  Of each part wave q takes the quarter q: it stages those 64
+    // entries itself into its own slice of `tile` and is the only reader, so the pair loop has no workgroup barrier -- the waves
+    // run decoupled -- and the loads of the wave's NEXT quarter are issued before the pairs of the current one are computed.
+    const int q0 = q * 64;
+    struct Work {
+        int64_t ib, ie;
+        unsigned mask;
+        bool valid;
+    };
+    auto find = [&](int64_t from) {  // next tile part of the chunk in which this wave's quarter can receive non-zeros
+        Work w{from, from, kAllSlots, false};
+        for (int64_t ib = from, ie; ib < i1; ib = ie) {
+            ie = min(i1, (ib / kTile + 1) * kTile);
+            if (q0 >= (int)(ie - ib)) continue;
+            if (fit_boxes) {
+                const double *qbox = fit_sub + (ib / 64 + q) * 6;  // the quarter's own box (inside the tile's: no separate tile test)
+                if (FINE) {
+                    w.mask = quarter_mask<PT>(sown, qbox, -c);  // owned slots that can receive non-zeros from this quarter
+                    if (!w.mask) continue;
+                } else if (box_gap2(own, qbox) * (-c) > GINGR_CULL_SCALED(kTabN)) {
+                    continue;
+                }
+            }
+            w.ib = ib;
+            w.ie = ie;
+            w.valid = true;
+            break;
+        }
+        return w;
+    };
+    double lx = 0.0, ly = 0.0, lz = 0.0;  // the staged point of the quarter about to be computed (in flight during the previous one)
+    auto issue = [&](const Work &w) {
+        const int64_t i = w.ib + q0 + lane;
+        if (i < w.ie) {
+            lx = fit.x[i];
+            ly = fit.y[i];
+            lz = fit.z[i];
+        }
+    };
+    Work cur = find(i0);
+    if (cur.valid) issue(cur);
+    while (cur.valid) {
+        __builtin_amdgcn_wave_barrier();  // (compiler fence) the previous quarter's reads are issued before the slice is rewritten
+        if (cur.ib + q0 + lane < cur.ie) {
             if (expand) {
-                const double fx = fit.x[i] - cx, fy = fit.y[i] - cy, fz = fit.z[i] - cz;
-                tile[tid] = P4{m2c * fx, m2c * fy, m2c * fz, c * __builtin_fma(fz, fz, __builtin_fma(fy, fy, fx * fx))};
+                const double fx = lx - cx, fy = ly - cy, fz = lz - cz;
+                tile[q0 + lane] = P4{m2c * fx, m2c * fy, m2c * fz, c * __builtin_fma(fz, fz, __builtin_fma(fy, fy, fx * fx))};
             } else {
-                tile[tid] = P4{fit.x[i], fit.y[i], fit.z[i], 0.0};
+                tile[q0 + lane] = P4{lx, ly, lz, 0.0};
             }
         }
-        __syncthreads();
-        // this wave's own 64*PT points may be far from the tile although the workgroup's box is not
-        if (!wave_owns_any) continue;  // a wave past the end of the cloud only takes part in the barriers
-        if (fit_boxes && box_gap2(wown, fit_boxes + (ib / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;
-        const int cnt = (int)(ie - ib);
-        if (!fine_on) {
-            if (expand)
-                colsum_tile_expand<PT, false>(tile, 0, cnt, kAllSlots, x, y, z, n, acc, T);
-            else if (clamp)
-                colsum_tile<PT, true, false>(tile, 0, cnt, kAllSlots, x, y, z, acc, c, lim, T);
+        __builtin_amdgcn_wave_barrier();  // LDS serves one wave's accesses in order: its reads below see its own writes
+        const Work nxt = find(cur.ie);
+        if (nxt.valid) issue(nxt);
+        const int q1 = min((int)(cur.ie - cur.ib), q0 + 64);
+        const unsigned mask = cur.mask;
+        if (expand) {
+            if (!FINE || mask == kAllSlots)
+                colsum_tile_expand<PT, false>(tile, q0, q1, mask, x, y, z, n, acc, T);
             else
-                colsum_tile<PT, false, false>(tile, 0, cnt, kAllSlots, x, y, z, acc, c, lim, T);
-            continue;
-        }
-        // quarter of the tile x owned slot: skip what provably receives exact zeros
-        for (int sub = 0; sub * 64 < cnt; ++sub) {
-            const int q0 = sub * 64, q1 = min(cnt, q0 + 64);
-            const unsigned mask = quarter_mask<PT>(sown, fit_sub + (ib / 64 + sub) * 6, -c);
-            if (!mask) continue;
-            if (expand) {
-                if (mask == kAllSlots)
-                    colsum_tile_expand<PT, false>(tile, q0, q1, mask, x, y, z, n, acc, T);
-                else
-                    colsum_tile_expand<PT, true>(tile, q0, q1, mask, x, y, z, n, acc, T);
-            } else if (clamp) {
+                colsum_tile_expand<PT, true>(tile, q0, q1, mask, x, y, z, n, acc, T);
+        } else if (clamp) {
+            if (!FINE || mask == kAllSlots)
+                colsum_tile<PT, true, false>(tile, q0, q1, mask, x, y, z, acc, c, lim, T);
+            else
                 colsum_tile<PT, true, true>(tile, q0, q1, mask, x, y, z, acc, c, lim, T);
-            } else {
-                if (mask == kAllSlots)
-                    colsum_tile<PT, false, false>(tile, q0, q1, mask, x, y, z, acc, c, lim, T);
-                else
-                    colsum_tile<PT, false, true>(tile, q0, q1, mask, x, y, z, acc, c, lim, T);
-            }
+        } else {
+            if (!FINE || mask == kAllSlots)
+                colsum_tile<PT, false, false>(tile, q0, q1, mask, x, y, z, acc, c, lim, T);
+            else
+                colsum_tile<PT, false, true>(tile, q0, q1, mask, x, y, z, acc, c, lim, T);
         }
+        cur = nxt;
     }
     fastexp_round_nearest();
 #pragma unroll
-    for (int t = 0; t < PT; ++t) {
-        const int64_t j = jbase + (int64_t)t * 64;
-        if (expand) acc[t] *= expand_owned_scale(sfrac[t * kBlock + tid]);
-        if (j < tgt.n) partial[(int64_t)blockIdx.y * tgt.n + j] = acc[t];
+    for (int t = 0; t < PT; ++t) sred[q][t * 64 + lane] = acc[t];
+    __syncthreads();
+    for (int p = tid; p < 64 * PT; p += kBlock) {
+        double v = (sred[0][p] + sred[1][p]) + (sred[2][p] + sred[3][p]);
+        if (expand) v *= expand_owned_scale(sfrac[p]);
+        const int64_t j = (int64_t)blockIdx.x * (64 * PT) + p;
+        if (j < tgt.n) partial[(int64_t)blockIdx.y * tgt.n + j] = v;
     }
 }
 
@@ -433,11 +501,14 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
 // Always launched with kScalarBlocks workgroups; part[0..kScalarBlocks) receives the xPx partials.
 constexpr int kScalarBlocks = 256;
 
+// chunk_partial != nullptr (single shard): the column sums are still spread over the nchunks chunk partials of the column-sum
+// pass and are added up here, in ascending chunk order like chunk_reduce_kernel (one launch and one pass over den less).
 __global__ __launch_bounds__(256) void cpd_den_finalize_kernel(Cloud tgt, const double *__restrict__ sigma2, double w,
                                                                double m_over_n, double *__restrict__ den,
                                                                double *__restrict__ inv_den, double *__restrict__ Pt1,
                                                                int32_t *__restrict__ tile_bad, double *__restrict__ part,
-                                                               double *__restrict__ scalars) {
+                                                               double *__restrict__ scalars,
+                                                               const double *__restrict__ chunk_partial, int nchunks) {
     __shared__ double sh[256];
     const double s2 = sigma2[0];
     // c = w/(1-w) * (2 pi sigma2)^(3/2) * (M/N)     CPD.scala:69-70
@@ -448,7 +519,13 @@ __global__ __launch_bounds__(256) void cpd_den_finalize_kernel(Cloud tgt, const 
         const int64_t j = jt + threadIdx.x;
         int bad = 0;
         if (j < tgt.n) {
-        const double colsum = den[j];
+        double colsum;
+        if (chunk_partial) {
+            colsum = 0.0;
+            for (int ch = 0; ch < nchunks; ++ch) colsum += chunk_partial[(int64_t)ch * tgt.n + j];
+        } else {
+            colsum = den[j];
+        }
         const double d = colsum + c;
         const double inv = 1.0 / d;
         const double pt1 = colsum / d;
@@ -521,18 +598,24 @@ __device__ __forceinline__ void rowstats_tile_expand(const P4 *tile, const P4 *t
     }
 }
 
-template <int PT, bool FINE>  // FINE / regime_out: see cpd_colsum_kernel
-__global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud tgt, const double *__restrict__ sigma2,
+// __launch_bounds__'s second argument (waves per SIMD): with four points per thread the kernel cannot hold four waves anyway; telling
+// the compiler that three are enough lets it use up to 168 registers instead of parking values in accumulator registers inside
+// the pair loop (17 extra v_accvgpr moves per 8 pairs at the default heuristic).
+template <int PT, bool FINE>  // work split, FINE / regime_out: see cpd_colsum_kernel
+__global__ __launch_bounds__(kBlock, (PT >= 4 ? 3 : 4)) void cpd_rowstats_kernel(Cloud fit, Cloud tgt, const double *__restrict__ sigma2,
                                                               const double *__restrict__ aux,
                                                               const double *__restrict__ inv_den,
                                                               const double *__restrict__ tgt_boxes,
                                                               const int32_t *__restrict__ tile_bad, ChunkPlan plan,
                                                               double *__restrict__ partial, int32_t *regime_out) {
-    __shared__ double T[kTabN];
-    __shared__ P4 tile[kTile];
-    __shared__ P4 tw[kTile];
-    __shared__ double shbox[24];
-    __shared__ double sfrac[kBlock * PT];  // see cpd_colsum_kernel
+    // one LDS block: [T | tile | tw] during the pair loop, the waves' accumulators [4 waves][4 planes][64 PT] in the epilogue
+    constexpr int kRed = 4 * 4 * 64 * PT;
+    constexpr int kLoop = kTabN + 4 * kTile + 4 * kTile;
+    __shared__ double smem[kRed > kLoop ? kRed : kLoop];
+    __shared__ double sfrac[64 * PT];  // see cpd_colsum_kernel
+    double *T = smem;
+    P4 *tile = reinterpret_cast<P4 *>(smem + kTabN);
+    P4 *tw = reinterpret_cast<P4 *>(smem + kTabN + 4 * kTile);
     const double c = fastexp_scale_for_variance<kTB>(2.0 * sigma2[0]);
     const double am = aux[0] + aux[1];
     if (regime_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
@@ -545,8 +628,9 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
     const double lim = fastexp_d2_limit<kTB>(c);
     const double cx = aux[2], cy = aux[3], cz = aux[4];
     const double m2c = -2.0 * c;
-    const int tid = threadIdx.x;
-    const int64_t ibase = (int64_t)blockIdx.x * (kBlock * PT) + (int64_t)(tid >> 6) * (64 * PT) + (tid & 63);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave's number, provably uniform: loop bounds and LDS bases stay scalar
+    const int64_t ibase = (int64_t)blockIdx.x * (64 * PT) + lane;
     double x[PT], y[PT], z[PT], n[PT], a1[PT], ax[PT], ay[PT], az[PT];
     bool okv[PT];
 #pragma unroll
@@ -558,13 +642,10 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
         y[t] = ok ? fit.y[i] : 0.0;
         z[t] = ok ? fit.z[i] : 0.0;
     }
-    Box wown;
-    const Box own = block_bbox<PT>(x, y, z, okv, shbox, &wown);  // raw coordinates, before any centring
-    const bool wave_owns_any = __builtin_amdgcn_readfirstlane((int)okv[0]) != 0;  // lane 0, slot 0 is the wave's first point
+    const Box own = wave_bbox<PT>(x, y, z, okv);  // raw coordinates, before any centring; identical in every wave
     constexpr unsigned kAllSlots = (1u << PT) - 1u;
-    constexpr bool fine_on = FINE;
     Box sown[PT];  // per owned slot (64 consecutive points)
-    if (fine_on) slot_boxes<PT>(x, y, z, okv, sown);
+    if (FINE) slot_boxes<PT>(x, y, z, okv, sown);
     const double *tgt_sub = tgt_boxes ? tgt_boxes + ((tgt.n + kTile - 1) / kTile) * 6 : nullptr;
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
@@ -575,83 +656,126 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
         }
         double fr;
         n[t] = expand_owned_magic(c * __builtin_fma(z[t], z[t], __builtin_fma(y[t], y[t], x[t] * x[t])), &fr);
-        sfrac[t * kBlock + tid] = fr;
+        if (q == 0) sfrac[t * 64 + lane] = fr;
         a1[t] = ax[t] = ay[t] = az[t] = 0.0;
     }
     int64_t j0, j1;
     plan.range(blockIdx.y, tgt.n, &j0, &j1);
+    __syncthreads();       // the exponential table (filled by all four waves) and sfrac are complete
     fastexp_round_down();  // see cpd_colsum_kernel
-    for (int64_t jb = j0, je; jb < j1; jb = je) {  // one box tile (or the part of it inside the chunk) per pass, see cpd_colsum_kernel
-        je = min(j1, (jb / kTile + 1) * kTile);
-        // all pairs flush to +0 -- unless a 1/den of the tile is inf/NaN: 0 * inf must stay NaN like the reference's 0/0
-        if (tgt_boxes && !tile_bad[jb / kTile] && box_gap2(own, tgt_boxes + (jb / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;
-        __syncthreads();
-        const int64_t j = jb + tid;
-        if (j < je) {
-            const double inv = inv_den[j];
+    // one box tile (or the part of it inside the chunk) per step, wave q on quarter q, next quarter's loads in flight: see
+    // cpd_colsum_kernel
+    const int q0 = q * 64;
+    struct Work {
+        int64_t jb, je;
+        unsigned mask;
+        bool valid;
+    };
+    auto find = [&](int64_t from) {
+        Work w{from, from, kAllSlots, false};
+        for (int64_t jb = from, je; jb < j1; jb = je) {
+            je = min(j1, (jb / kTile + 1) * kTile);
+            if (q0 >= (int)(je - jb)) continue;
+            // a tile holding a non-finite 1/den is never culled: 0 * inf must stay NaN like the reference's 0/0
+            if (tgt_boxes && !tile_bad[jb / kTile]) {
+                const double *qbox = tgt_sub + (jb / 64 + q) * 6;
+                if (FINE) {
+                    w.mask = quarter_mask<PT>(sown, qbox, -c);
+                    if (!w.mask) continue;
+                } else if (box_gap2(own, qbox) * (-c) > GINGR_CULL_SCALED(kTabN)) {
+                    continue;
+                }
+            } else {
+                w.mask = kAllSlots;
+            }
+            w.jb = jb;
+            w.je = je;
+            w.valid = true;
+            break;
+        }
+        return w;
+    };
+    double lx = 0.0, ly = 0.0, lz = 0.0, linv = 0.0;
+    auto issue = [&](const Work &w) {
+        const int64_t j = w.jb + q0 + lane;
+        if (j < w.je) {
+            lx = tgt.x[j];
+            ly = tgt.y[j];
+            lz = tgt.z[j];
+            linv = inv_den[j];
+        }
+    };
+    Work cur = find(j0);
+    if (cur.valid) issue(cur);
+    while (cur.valid) {
+        __builtin_amdgcn_wave_barrier();
+        if (cur.jb + q0 + lane < cur.je) {
+            const double inv = linv;
             if (expand) {
-                const double tx = tgt.x[j] - cx, ty = tgt.y[j] - cy, tz = tgt.z[j] - cz;
+                const double tx = lx - cx, ty = ly - cy, tz = lz - cz;
                 const double ax_ = m2c * tx, ay_ = m2c * ty, az_ = m2c * tz;
-                tile[tid] = P4{ax_, ay_, az_, c * __builtin_fma(tz, tz, __builtin_fma(ty, ty, tx * tx))};
-                tw[tid] = P4{ax_ * inv, ay_ * inv, az_ * inv, inv};
+                tile[q0 + lane] = P4{ax_, ay_, az_, c * __builtin_fma(tz, tz, __builtin_fma(ty, ty, tx * tx))};
+                tw[q0 + lane] = P4{ax_ * inv, ay_ * inv, az_ * inv, inv};
             } else {
-                const double tx = tgt.x[j], ty = tgt.y[j], tz = tgt.z[j];
-                tile[tid] = P4{tx, ty, tz, inv};
-                tw[tid] = P4{tx * inv, ty * inv, tz * inv, inv};
+                tile[q0 + lane] = P4{lx, ly, lz, inv};
+                tw[q0 + lane] = P4{lx * inv, ly * inv, lz * inv, inv};
             }
         }
-        __syncthreads();
-        if (!wave_owns_any) continue;  // a wave past the end of the shard only takes part in the barriers
-        if (tgt_boxes && !tile_bad[jb / kTile] && box_gap2(wown, tgt_boxes + (jb / kTile) * 6) * (-c) > GINGR_CULL_SCALED(kTabN)) continue;
-        const int cnt = (int)(je - jb);
-        if (!(fine_on && !tile_bad[jb / kTile])) {  // a tile holding a non-finite 1/den is never culled (0 * inf = NaN)
-            if (expand)
-                rowstats_tile_expand<PT, false>(tile, tw, 0, cnt, kAllSlots, x, y, z, n, a1, ax, ay, az, T);
-            else if (clamp)
-                rowstats_tile<PT, true, false>(tile, tw, 0, cnt, kAllSlots, x, y, z, a1, ax, ay, az, c, lim, T);
+        __builtin_amdgcn_wave_barrier();
+        const Work nxt = find(cur.je);
+        if (nxt.valid) issue(nxt);
+        const int q1 = min((int)(cur.je - cur.jb), q0 + 64);
+        const unsigned mask = cur.mask;
+        if (expand) {
+            if (!FINE || mask == kAllSlots)
+                rowstats_tile_expand<PT, false>(tile, tw, q0, q1, mask, x, y, z, n, a1, ax, ay, az, T);
             else
-                rowstats_tile<PT, false, false>(tile, tw, 0, cnt, kAllSlots, x, y, z, a1, ax, ay, az, c, lim, T);
-            continue;
-        }
-        // quarter of the tile x owned slot: skip what provably receives exact zeros
-        for (int sub = 0; sub * 64 < cnt; ++sub) {
-            const int q0 = sub * 64, q1 = min(cnt, q0 + 64);
-            const unsigned mask = quarter_mask<PT>(sown, tgt_sub + (jb / 64 + sub) * 6, -c);
-            if (!mask) continue;
-            if (expand) {
-                if (mask == kAllSlots)
-                    rowstats_tile_expand<PT, false>(tile, tw, q0, q1, mask, x, y, z, n, a1, ax, ay, az, T);
-                else
-                    rowstats_tile_expand<PT, true>(tile, tw, q0, q1, mask, x, y, z, n, a1, ax, ay, az, T);
-            } else if (clamp) {
+                rowstats_tile_expand<PT, true>(tile, tw, q0, q1, mask, x, y, z, n, a1, ax, ay, az, T);
+        } else if (clamp) {
+            if (!FINE || mask == kAllSlots)
+                rowstats_tile<PT, true, false>(tile, tw, q0, q1, mask, x, y, z, a1, ax, ay, az, c, lim, T);
+            else
                 rowstats_tile<PT, true, true>(tile, tw, q0, q1, mask, x, y, z, a1, ax, ay, az, c, lim, T);
-            } else {
-                if (mask == kAllSlots)
-                    rowstats_tile<PT, false, false>(tile, tw, q0, q1, mask, x, y, z, a1, ax, ay, az, c, lim, T);
-                else
-                    rowstats_tile<PT, false, true>(tile, tw, q0, q1, mask, x, y, z, a1, ax, ay, az, c, lim, T);
-            }
+        } else {
+            if (!FINE || mask == kAllSlots)
+                rowstats_tile<PT, false, false>(tile, tw, q0, q1, mask, x, y, z, a1, ax, ay, az, c, lim, T);
+            else
+                rowstats_tile<PT, false, true>(tile, tw, q0, q1, mask, x, y, z, a1, ax, ay, az, c, lim, T);
         }
+        cur = nxt;
     }
     fastexp_round_nearest();
+    // combine the four waves in a fixed order; the LDS block is reused, so everybody must be done with T / tile / tw first
+    __syncthreads();
+    constexpr int kPts = 64 * PT;
+    double *sred = smem;
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        sred[(q * 4 + 0) * kPts + t * 64 + lane] = a1[t];
+        sred[(q * 4 + 1) * kPts + t * 64 + lane] = ax[t];
+        sred[(q * 4 + 2) * kPts + t * 64 + lane] = ay[t];
+        sred[(q * 4 + 3) * kPts + t * 64 + lane] = az[t];
+    }
+    __syncthreads();
     const int64_t M = fit.n;
     double *base = partial + (int64_t)blockIdx.y * 4 * M;
     const double back = expand ? -0.5 / c : 1.0;  // sum_j p a_j -> sum_j p x~_j
+    for (int p = tid; p < kPts; p += kBlock) {
+        double v[4];
 #pragma unroll
-    for (int t = 0; t < PT; ++t) {
-        const int64_t i = ibase + (int64_t)t * 64;
+        for (int pl = 0; pl < 4; ++pl)
+            v[pl] = (sred[(0 * 4 + pl) * kPts + p] + sred[(1 * 4 + pl) * kPts + p]) + (sred[(2 * 4 + pl) * kPts + p] + sred[(3 * 4 + pl) * kPts + p]);
         if (expand) {
-            const double e = expand_owned_scale(sfrac[t * kBlock + tid]);
-            a1[t] *= e;
-            ax[t] *= e;
-            ay[t] *= e;
-            az[t] *= e;
+            const double e = expand_owned_scale(sfrac[p]);
+#pragma unroll
+            for (int pl = 0; pl < 4; ++pl) v[pl] *= e;
         }
+        const int64_t i = (int64_t)blockIdx.x * kPts + p;
         if (i < M) {
-            base[i] = a1[t];
-            base[M + i] = expand ? __builtin_fma(cx, a1[t], back * ax[t]) : ax[t];
-            base[2 * M + i] = expand ? __builtin_fma(cy, a1[t], back * ay[t]) : ay[t];
-            base[3 * M + i] = expand ? __builtin_fma(cz, a1[t], back * az[t]) : az[t];
+            base[i] = v[0];
+            base[M + i] = expand ? __builtin_fma(cx, v[0], back * v[1]) : v[1];
+            base[2 * M + i] = expand ? __builtin_fma(cy, v[0], back * v[2]) : v[2];
+            base[3 * M + i] = expand ? __builtin_fma(cz, v[0], back * v[3]) : v[3];
         }
     }
 }
@@ -659,42 +783,55 @@ __global__ __launch_bounds__(kBlock) void cpd_rowstats_kernel(Cloud fit, Cloud t
 // P1 / PX from chunk partials (ascending chunk order) plus per-block partials of
 // Np = sum P1, trPXY = sum_i y_i . PX_i, yPy = sum_i P1_i |y_i|^2 over the local rows.
 // Always launched with kScalarBlocks workgroups; part[(1..3)*kScalarBlocks + block].
+// One row per thread (rows of a pass are consecutive: every load instruction reads 2 KB runs of one chunk plane); the four
+// planes' chunk sums are independent chains, so a thread keeps 4 loads in flight per chunk step.
+// obs.weight != nullptr: the CPD observations of the rows (CPDCorrespondence.estimate + getUncertainty, CPD.scala:36-46,120-128)
+// are produced in the same pass -- weight_i = P1_i / (sigma2 lambda), e_i = weight_i (R^T (yhat_i - c - t) - (ref_i - c) - mean_i)
+// with yhat_i = y_i + (PX_i / P1_i - y_i); rows overridden by a landmark get weight 0 (GingrAlgorithm.scala:289-292).
 __global__ __launch_bounds__(256) void rowstats_reduce_kernel(const double *__restrict__ partial, int nchunks, Cloud fit,
                                                               double *__restrict__ P1, double *__restrict__ PX,
-                                                              double *__restrict__ part) {
-    // 16 rows per pass; per row 16 threads = 4 planes (P1, PX.x, PX.y, PX.z) x 4 interleaved chunk groups, combined in a
-    // fixed order ((g0 + g1) + (g2 + g3)): the partials are read with 65536 threads whatever the shard size
+                                                              double *__restrict__ part, CpdObsArgs obs) {
     __shared__ double sh[256];
-    __shared__ double sg[16][17];
     const int64_t M = fit.n;
-    const int tid = threadIdx.x, il = tid & 15, sub = tid >> 4, q = sub >> 2, g = sub & 3;
     double np = 0.0, tr = 0.0, ypy = 0.0;
-    const int64_t ngroups = (M + 15) / 16;
-    for (int64_t rg = blockIdx.x; rg < ngroups; rg += kScalarBlocks) {
-        const int64_t i = rg * 16 + il;
-        double acc = 0.0;
-        if (i < M) {
-            const double *b = partial + (int64_t)q * M + i;
-#pragma unroll 8
-            for (int c = g; c < nchunks; c += 4) acc += b[(int64_t)c * 4 * M];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)kScalarBlocks * 256) {
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
+        const double *b = partial + i;
+#pragma unroll 4
+        for (int c = 0; c < nchunks; ++c) {
+            const double *bc = b + (int64_t)c * 4 * M;
+            v[0] += bc[0];
+            v[1] += bc[M];
+            v[2] += bc[2 * M];
+            v[3] += bc[3 * M];
         }
-        sg[sub][il] = acc;
-        __syncthreads();
-        if (tid < 16 && i < M) {
-            double v[4];
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq)
-                v[qq] = (sg[qq * 4][il] + sg[qq * 4 + 1][il]) + (sg[qq * 4 + 2][il] + sg[qq * 4 + 3][il]);
-            P1[i] = v[0];
-            PX[i] = v[1];
-            PX[M + i] = v[2];
-            PX[2 * M + i] = v[3];
-            const double yx = fit.x[i], yy = fit.y[i], yz = fit.z[i];
-            np += v[0];
-            tr += yx * v[1] + yy * v[2] + yz * v[3];
-            ypy += v[0] * (yx * yx + yy * yy + yz * yz);
+        P1[i] = v[0];
+        PX[i] = v[1];
+        PX[M + i] = v[2];
+        PX[2 * M + i] = v[3];
+        const double yx = fit.x[i], yy = fit.y[i], yz = fit.z[i];
+        if (obs.weight) {
+            if (obs.lm_mask && obs.lm_mask[i]) {
+                obs.weight[i] = 0.0;
+                obs.evec[i] = obs.evec[M + i] = obs.evec[2 * M + i] = 0.0;
+            } else {
+                const double p1inv = 1.0 / v[0];                                                  // CPD.scala:37
+                const double ox = yx + (v[1] * p1inv - yx), oy = yy + (v[2] * p1inv - yy), oz = yz + (v[3] * p1inv - yz);
+                const double wgt = 1.0 / (obs.sigma2[0] * obs.lambda * p1inv);                     // CPD.scala:126
+                const double *R = obs.R;
+                const double dx = ox - obs.center[0] - obs.t[0], dy = oy - obs.center[1] - obs.t[1], dz = oz - obs.center[2] - obs.t[2];
+                const double ex = R[0] * dx + R[3] * dy + R[6] * dz - (obs.ref[i] - obs.center[0]) - obs.mean[i];
+                const double ey = R[1] * dx + R[4] * dy + R[7] * dz - (obs.ref[M + i] - obs.center[1]) - obs.mean[M + i];
+                const double ez = R[2] * dx + R[5] * dy + R[8] * dz - (obs.ref[2 * M + i] - obs.center[2]) - obs.mean[2 * M + i];
+                obs.weight[i] = wgt;
+                obs.evec[i] = wgt * ex;
+                obs.evec[M + i] = wgt * ey;
+                obs.evec[2 * M + i] = wgt * ez;
+            }
         }
-        __syncthreads();
+        np += v[0];
+        tr += yx * v[1] + yy * v[2] + yz * v[3];
+        ypy += v[0] * (yx * yx + yy * yy + yz * yz);
     }
     const double a = block_sum<256>(np, sh);
     __syncthreads();
@@ -1061,14 +1198,14 @@ inline int rowstats_tiles_override() {
 
 int64_t cpd_colsum_ws_doubles(int64_t M, int64_t N) {
     int nch;
-    plan_chunks(N, kBlock * kPT, M, &nch, colsum_tiles_override(), colsum_chunks_override());
+    plan_chunks(N, 64 * kPT, M, &nch, colsum_tiles_override(), colsum_chunks_override());
     const int64_t a = (int64_t)nch * N, b = cpd_colsum_mfma_ws_doubles(M, N);
     return a > b ? a : b;
 }
 
 int64_t cpd_rowstats_ws_doubles(int64_t M, int64_t N) {
     int nch;
-    plan_chunks(M, kBlock * rowstats_pt(M), N, &nch, rowstats_tiles_override(), rowstats_chunks_override());
+    plan_chunks(M, 64 * rowstats_pt(M), N, &nch, rowstats_tiles_override(), rowstats_chunks_override());
     const int64_t a = (int64_t)nch * 4 * M, b = cpd_rowstats_mfma_ws_doubles(M, N);
     return a > b ? a : b;
 }
@@ -1094,16 +1231,16 @@ void launch_tile_bbox(gingr_ctx *ctx, Cloud c, double *boxes, const double *ctr,
                        absmax_slot);
 }
 
-void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
-                       const double *fit_boxes, double *ws, double *den_partial) {
+int launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
+                      const double *fit_boxes, double *ws, double *den_partial) {
     int nch;
     {
         TimerScope ts(ctx, 0);
         if (ctx->affinity_mfma) {
             launch_cpd_colsum_mfma(ctx, fit, target, sigma2_dev, aux, ws, &nch);
         } else {
-            const ChunkPlan len = plan_chunks(target.n, kBlock * kPT, fit.n, &nch, colsum_tiles_override(), colsum_chunks_override());
-            dim3 grid((unsigned)ceil_div(target.n, kBlock * kPT), (unsigned)nch);
+            const ChunkPlan len = plan_chunks(target.n, 64 * kPT, fit.n, &nch, colsum_tiles_override(), colsum_chunks_override());
+            dim3 grid((unsigned)ceil_div(target.n, 64 * kPT), (unsigned)nch);
             const double *boxes = ctx->cull ? fit_boxes : (const double *)nullptr;
             // one variant, picked from the regime the device last reported (stale at worst: the results are the same)
             const bool fine = boxes && (ctx->fine_override >= 0 ? ctx->fine_override != 0
@@ -1116,20 +1253,23 @@ void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *si
                                    boxes, len, ws, boxes ? ctx->regime_dev : (int32_t *)nullptr);
         }
     }
-    hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)ceil_div(target.n, 256)), dim3(256), 0, ctx->stream, ws, nch,
-                       target.n, den_partial);
+    if (den_partial)  // nullptr: the caller adds the chunk partials up itself (launch_cpd_den_finalize with the returned count)
+        hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)ceil_div(target.n, 256)), dim3(256), 0, ctx->stream, ws, nch,
+                           target.n, den_partial);
+    return nch;
 }
 
 void launch_cpd_den_finalize(gingr_ctx *ctx, Cloud target, const double *sigma2_dev, double w, int64_t M_total,
                              double *den, double *inv_den, double *Pt1, int32_t *tile_bad, double *part,
-                             double *scalars_dev) {
+                             double *scalars_dev, const double *chunk_partial, int nchunks) {
     hipLaunchKernelGGL(cpd_den_finalize_kernel, dim3(kScalarBlocks), dim3(256), 0, ctx->stream, target, sigma2_dev, w,
-                       (double)M_total / (double)target.n, den, inv_den, Pt1, tile_bad, part, scalars_dev);
+                       (double)M_total / (double)target.n, den, inv_den, Pt1, tile_bad, part, scalars_dev, chunk_partial, nchunks);
 }
 
 void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
                          const double *inv_den, const double *tgt_boxes, const int32_t *tile_bad, double *ws, double *P1,
-                         double *PX_soa, double *part, double *scalars_dev, double *xch8, int contribute_xpx) {
+                         double *PX_soa, double *part, double *scalars_dev, double *xch8, int contribute_xpx,
+                         const CpdObsArgs *obs, bool finish_scalars) {
     int nch;
     {
         TimerScope ts(ctx, 1);
@@ -1137,8 +1277,8 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
             launch_cpd_rowstats_mfma(ctx, fit, target, sigma2_dev, aux, inv_den, ws, &nch);
         } else {
             const int pt = rowstats_pt(fit.n);
-            const ChunkPlan len = plan_chunks(fit.n, kBlock * pt, target.n, &nch, rowstats_tiles_override(), rowstats_chunks_override());
-            dim3 grid((unsigned)ceil_div(fit.n, kBlock * pt), (unsigned)nch);
+            const ChunkPlan len = plan_chunks(fit.n, 64 * pt, target.n, &nch, rowstats_tiles_override(), rowstats_chunks_override());
+            dim3 grid((unsigned)ceil_div(fit.n, 64 * pt), (unsigned)nch);
             const bool cull = ctx->cull && tgt_boxes && tile_bad;
             const double *boxes = cull ? tgt_boxes : (const double *)nullptr;
             const bool fine = boxes && (ctx->fine_override >= 0 ? ctx->fine_override != 0
@@ -1162,9 +1302,12 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
             }
         }
     }
+    CpdObsArgs none;
+    memset(&none, 0, sizeof(none));
     hipLaunchKernelGGL(rowstats_reduce_kernel, dim3(kScalarBlocks), dim3(256), 0, ctx->stream, ws, nch, fit, P1, PX_soa,
-                       part);
-    hipLaunchKernelGGL(cpd_scalars_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, part, scalars_dev, xch8, contribute_xpx);
+                       part, obs ? *obs : none);
+    if (finish_scalars)  // otherwise the caller's phase-1 finalize kernel sums the block partials (cpd_scalar_partials_layout)
+        hipLaunchKernelGGL(cpd_scalars_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, part, scalars_dev, xch8, contribute_xpx);
 }
 
 static void plan_nn(int64_t nq, int64_t nt_points, bool pruned, int *nchunks, int64_t *chunk_len) {

@@ -125,20 +125,35 @@ void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, const double *ctr, double *slo
 // with absmax_slot != nullptr also *absmax_slot = max |coordinate - ctr| (same value launch_cloud_absmax produces); the slot
 // must have been zeroed by an earlier launch on the stream
 void launch_tile_bbox(gingr_ctx *ctx, Cloud c, double *boxes, const double *ctr = nullptr, double *absmax_slot = nullptr);
-void launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
-                       const double *fit_boxes, double *ws, double *den_partial);
+// returns the number of chunk partials left in ws ([chunk][N]); den_partial == nullptr skips their reduction (the caller passes
+// ws and the count to launch_cpd_den_finalize, which then adds them up itself: single shard, one launch less)
+int launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
+                      const double *fit_boxes, double *ws, double *den_partial);
 // den[j] += c; inv_den[j] = 1/den[j]; Pt1[j] = (den[j]-c)/den[j]; xPx block partials -> part[0..256)
 // M_total enters the outlier constant c = w/(1-w) (2 pi sigma2)^1.5 M_total/N.  part: GINGR_SCALAR_PART doubles.
 // tile_bad[tile] (nullable) is set when a 1/den of the tile is not finite: such tiles are never culled.
 #define GINGR_SCALAR_PART 1024
 void launch_cpd_den_finalize(gingr_ctx *ctx, Cloud target, const double *sigma2_dev, double w, int64_t M_total,
                              double *den, double *inv_den, double *Pt1, int32_t *tile_bad, double *part,
-                             double *scalars_dev);
+                             double *scalars_dev, const double *chunk_partial = nullptr, int nchunks = 0);
+// CPD observations fused into the row-statistics reduction (rowstats_reduce_kernel): pointers into the model / state
+struct CpdObsArgs {
+    const double *ref, *mean;       // SoA planes of the local rows
+    const double *sigma2;           // device scalars of the state: sigma2, R (row-major 3x3), center, translation
+    const double *R, *center, *t;
+    double lambda;
+    const int32_t *lm_mask;         // nullable
+    double *weight, *evec;          // out: [M], SoA [3][M]; weight == nullptr: no observations
+};
+// the four block-partial arrays (GINGR_SCALAR_BLOCKS entries each) the CPD passes leave in `part`: slot 0 xPx (den_finalize),
+// 1 Np, 2 trPXY, 3 yPy (rowstats_reduce); scalar index of slot q: {1, 0, 2, 3}[q]
+#define GINGR_SCALAR_BLOCKS 256
 // P1[i], PX (SoA planes px,py,pz of stride M) for the local rows; Np/xPx/trPXY/yPy sums into scalars_dev[0..3]
 // xch8 (nullable): the 8 scalars of the exchange segment {Np, xPx (only when contribute_xpx), trPXY, yPy, 0...}
 void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
                          const double *inv_den, const double *tgt_boxes, const int32_t *tile_bad, double *ws, double *P1,
-                         double *PX_soa, double *part, double *scalars_dev, double *xch8 = nullptr, int contribute_xpx = 1);
+                         double *PX_soa, double *part, double *scalars_dev, double *xch8 = nullptr, int contribute_xpx = 1,
+                         const CpdObsArgs *obs = nullptr, bool finish_scalars = true);
 // idx[i] = POSITION (in the device order of `target`) of the nearest target; exact ties are broken by the lowest ORIGINAL
 // index, taken from target_orig[position] (nullptr: the device order is the original order).
 // tgt_boxes (nullable): bounding boxes of the 256-point target tiles (launch_tile_bbox) for exact nearest-first pruning.

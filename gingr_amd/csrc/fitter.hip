@@ -42,6 +42,7 @@ struct gingr_fitter {
     int64_t off[GINGR_NUM_SEGMENTS] = {0, 0}, cnt[GINGR_NUM_SEGMENTS] = {0, 0};
     double *ws = nullptr;
     int64_t ws_doubles = 0;
+    int colsum_chunks = 0;  // > 0: the column sums of phase 0 are still chunk partials in ws (single shard; added up by den_finalize)
     double *work = nullptr;
     void *aos = nullptr;  // staging for interleaved transfers, max(3M, 3N) doubles
     int32_t n_lm = 0;
@@ -109,11 +110,6 @@ void dev_free(void *p) {
 int check_launch(gingr_ctx *ctx) {
     HIP_TRY(ctx, hipGetLastError());
     return GINGR_OK;
-}
-
-__global__ void zero_kernel(double *p, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0.0;
 }
 
 // pose <- rigid part of the state (scale 1): the frame a mesh is projected in by the transition-density query
@@ -521,8 +517,7 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
     mx(cpd_rowstats_ws_doubles(M, N));
     mx(ceil_div(nn_ws_bytes(M, N), 8));
     mx(ceil_div(nn_ws_bytes(N, M), 8));  // reversed correspondence direction: the targets query the model vertices
-    mx(gram_ws_doubles(M, rp));
-    mx(sweep_ws_doubles(M, rp));
+    mx(gram_ws_doubles(M, rp) + sweep_ws_doubles(M, rp));  // phase 1 keeps both sets of partials until its finalize kernel
     f->ws_doubles = w;
     GINGR_TRY(dev_alloc(ctx, &f->ws, (size_t)w));
     const int64_t big = M > N ? M : N;
@@ -851,11 +846,20 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
             else {
                 // boxes of the fit tiles + its |coordinate - centroid| maximum (slot cleared by the pass that wrote the fit)
                 launch_tile_bbox(ctx, fit, f->fboxes, f->absmax + 2, f->absmax + 1);
-                launch_cpd_colsum(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->fboxes, f->ws, seg0w);
+                // single shard: nothing is exchanged, so the chunk partials stay in ws and phase 1's den_finalize adds them up
+                const bool alone = m->M == m->M_total && !f->partial_out;
+                f->colsum_chunks = launch_cpd_colsum(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->fboxes, f->ws, alone ? nullptr : seg0w);
+                if (!alone) f->colsum_chunks = 0;
             }
             break;
         }
         case 1: {
+            Phase1FinalizeArgs fa;
+            memset(&fa, 0, sizeof(fa));
+            fa.rp = rp;
+            fa.G = Gw;
+            fa.rhs = rhsw;
+            fa.sc8 = sc8w;
             if (icp) {
                 if (f->reversed)  // one observation per template vertex: mean of its accepted targets, weight count / sigma2
                     launch_obs_points(ctx, m, f->st, f->robs, f->rwin, f->weight, f->evec, f->lm_mask);
@@ -863,27 +867,52 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                     launch_obs_points(ctx, m, f->st, f->surf_cp, f->surf_win, f->weight, f->evec, f->lm_mask);
                 else
                     launch_obs_icp(ctx, m, f->st, tgt, f->nn_idx, f->lm_mask, f->weight, f->evec);
-                hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(64), 0, ctx->stream, sc8w, (int64_t)8);
+                fa.scalar_mode = 0;
             } else {
                 launch_cpd_den_finalize(ctx, tgt, &f->st->sigma2, cp->w, m->M_total, seg0, f->inv_den, f->Pt1, f->tile_bad, f->part,
-                                        f->scalars);
+                                        f->scalars, f->colsum_chunks > 0 ? f->ws : nullptr, f->colsum_chunks);
+                f->colsum_chunks = 0;
+                // observations (correspondence point, uncertainty) come out of the row-statistics reduction; the scalar sums are
+                // finished by the finalize kernel below
+                CpdObsArgs ob;
+                memset(&ob, 0, sizeof(ob));
+                ob.ref = m->ref;
+                ob.mean = m->mean;
+                ob.sigma2 = &f->st->sigma2;
+                ob.R = f->st->R;
+                ob.center = f->st->center;
+                ob.t = f->st->t;
+                ob.lambda = cp->lambda;
+                ob.lm_mask = f->lm_mask;
+                ob.weight = f->weight;
+                ob.evec = f->evec;
                 launch_cpd_rowstats(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->inv_den, f->tboxes, f->tile_bad, f->ws, f->P1,
-                                    f->PX, f->part, f->scalars, sc8w, m->row_begin == 0 ? 1 : 0);
-                launch_obs_cpd(ctx, m, f->st, fit, f->P1, f->PX, cp->lambda, f->lm_mask, f->weight, f->evec);
+                                    f->PX, f->part, f->scalars, nullptr, 0, &ob, false);
+                fa.scalar_mode = 1;
+                fa.part = f->part;
+                fa.scalars_local = f->scalars;
+                fa.contribute_xpx = m->row_begin == 0 ? 1 : 0;
             }
+            double *gram_ws = f->ws, *sweep_ws = f->ws + gram_ws_doubles(M, rp);
             if (icp && !f->icp_surface && !f->reversed && f->n_lm == 0) {
                 // point-cloud ICP without landmarks: every row has the same weight 1 / sigma2 (ICP.scala:90-92), so the weighted Gram
                 // is the model's one-off moment Q^T Q scaled -- no pass over the basis.  mom holds the total over ALL shards: the
                 // shard that owns row 0 contributes it, the others contribute zero to the exchange.
                 hipLaunchKernelGGL(scaled_copy_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 256)), dim3(256), 0, ctx->stream,
                                    m->mom + MomentLayout{rp}.stot(), (int64_t)rp * rp, &f->st->sigma2, m->row_begin == 0 ? 1 : 0, Gw);
+                fa.nslabs = 0;
             } else {
-                launch_gram(ctx, m->Q0, M, rp, f->weight, f->ws, Gw);
+                fa.gram_partial = gram_ws;
+                fa.nslabs = launch_gram(ctx, m->Q0, M, rp, f->weight, gram_ws, nullptr);
             }
             SweepArgs a = base_args(f);
             a.evec = f->evec;
-            a.out = rhsw;
+            a.partial = sweep_ws;
+            a.no_reduce = 1;
             launch_sweep(ctx, SWEEP_RHS, a);
+            fa.sweep_partial = sweep_ws;
+            fa.sweep_blocks = sweep_num_blocks(M);
+            launch_phase1_finalize(ctx, fa);
             launch_landmarks(ctx, m, f->st, f->n_lm, f->lm_pid, f->lm_xyz, f->lm_cov, Gw, rhsw);
             break;
         }

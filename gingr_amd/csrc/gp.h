@@ -109,6 +109,7 @@ struct SweepArgs {
     double *partial;       // [nblocks][rp] transposed partials or [nblocks][24] Umeyama partials
     double *out;           // reduced result: [rp] or [24]
     double *zero_slot;     // nullable: one double the pass clears (consumed by a LATER launch on the stream)
+    int32_t no_reduce;     // != 0: leave the [nblocks][rp] partials in `partial` (the phase-1 finalize kernel adds them up)
 };
 
 int sweep_num_blocks(int64_t M);
@@ -118,7 +119,25 @@ void launch_sweep(gingr_ctx *ctx, SweepMode mode, const SweepArgs &a);
 // ---- weighted Gram (MFMA f64) -----------------------------------------------------------------------------
 int64_t gram_ws_doubles(int64_t M, int32_t rp);
 // G[rp*rp] (full symmetric) = sum_i w_i Q0_i^T Q0_i over local points; weight == nullptr means w = 1
-void launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, double *G);
+// returns the number of slab partials in ws; G == nullptr leaves them unreduced (launch_phase1_finalize adds them up)
+int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, double *G);
+
+// one launch for the reductions at the end of phase 1 (gp.hip: phase1_finalize_kernel)
+struct Phase1FinalizeArgs {
+    int32_t rp;
+    const double *gram_partial;   // [nslabs][rp*rp] (upper patches); nslabs == 0: G is not touched
+    int32_t nslabs;
+    double *G;
+    const double *sweep_partial;  // [sweep_blocks][rp]
+    int32_t sweep_blocks;
+    double *rhs;
+    int32_t scalar_mode;          // 0: clear the 8 scalars (ICP); 1: the four sums of the CPD passes from `part`
+    const double *part;           // GINGR_SCALAR_PART block partials (affinity.hip)
+    double *scalars_local;        // nullable: the shard's own copy {Np, xPx, trPXY, yPy}
+    double *sc8;                  // the 8 scalars of the exchange segment
+    int32_t contribute_xpx;
+};
+void launch_phase1_finalize(gingr_ctx *ctx, const Phase1FinalizeArgs &a);
 
 // ---- observations ------------------------------------------------------------------------------------------
 // CPD: yhat = y + (PX/P1 - y), weight = 1/(sigma2*lambda/P1)  (CPD.scala:37-46,126); e = w (R^T(yhat - c - t) - (ref - c) - mean)

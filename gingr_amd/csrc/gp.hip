@@ -496,6 +496,76 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restri
     }
 }
 
+// Everything that turns the partial sums of phase 1 into the shard's exchange segment, in ONE launch (instead of gram_reduce +
+// block_partials_reduce + cpd_scalars_finish): workgroups [0, nG) reduce the Gram slab partials exactly like gram_reduce_kernel
+// (same grouping, same order), workgroups [nG, nG + rp) the right-hand-side partials of the basis sweep exactly like
+// block_partials_reduce_kernel, and the last workgroup the four scalar sums of the CPD passes like cpd_scalars_finish_kernel
+// (scalar_mode 1) or just clears the eight scalars (mode 0: ICP).  nslabs == 0: G was produced elsewhere (scaled moment copy).
+__global__ __launch_bounds__(256) void phase1_finalize_kernel(Phase1FinalizeArgs A) {
+    __shared__ double sh[8][33];
+    __shared__ double sv[256];
+    const int rp = A.rp, rr = rp * rp;
+    const int nG = A.nslabs > 0 ? (rr + 31) / 32 : 0;
+    const int b = blockIdx.x;
+    if (b < nG) {
+        const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+        const int idx = b * 32 + el;
+        const int i = idx / rp, j = idx - i * rp;
+        const bool need = idx < rr && !(i > j);
+        double s = 0.0;
+        if (need) {
+            const double *p = A.gram_partial + idx;
+#pragma unroll 8
+            for (int q = g; q < A.nslabs; q += 8) s += p[(int64_t)q * rr];
+        }
+        sh[g][el] = s;
+        __syncthreads();
+        if (g == 0 && need) {
+            const double t = ((sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el])) + ((sh[4][el] + sh[5][el]) + (sh[6][el] + sh[7][el]));
+            A.G[i * rp + j] = t;
+            A.G[j * rp + i] = t;
+        }
+        return;
+    }
+    if (b < nG + rp) {
+        const int k = b - nG;
+        double s = 0.0;
+        for (int q = threadIdx.x; q < A.sweep_blocks; q += 256) s += A.sweep_partial[(int64_t)q * rp + k];
+        sv[threadIdx.x] = s;
+        __syncthreads();
+#pragma unroll
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) sv[threadIdx.x] += sv[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) A.rhs[k] = sv[0];
+        return;
+    }
+    // scalars
+    if (A.scalar_mode == 1) {
+        const int map[4] = {1, 0, 2, 3};  // part slot -> scalar index (cpd_scalars_finish_kernel)
+        for (int q = 0; q < 4; ++q) {
+            sv[threadIdx.x] = A.part[q * GINGR_SCALAR_BLOCKS + threadIdx.x];
+            __syncthreads();
+#pragma unroll
+            for (int st = 128; st > 0; st >>= 1) {
+                if ((int)threadIdx.x < st) sv[threadIdx.x] += sv[threadIdx.x + st];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                const double tot = sv[0];
+                if (A.scalars_local) A.scalars_local[map[q]] = tot;
+                // xPx is a sum over ALL targets, computed on every shard: only one of them may contribute it
+                A.sc8[map[q]] = (map[q] == 1 && !A.contribute_xpx) ? 0.0 : tot;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x >= 4 && threadIdx.x < 8) A.sc8[threadIdx.x] = 0.0;
+    } else if (threadIdx.x < 8) {
+        A.sc8[threadIdx.x] = 0.0;
+    }
+}
+
 __global__ void centered_mean_kernel(const double *__restrict__ ref, const double *__restrict__ mean, int64_t M, double c0x,
                                      double c0y, double c0z, double *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1422,7 +1492,7 @@ static void launch_sweep_mode(gingr_ctx *ctx, const SweepArgs &a, int width) {
         hipLaunchKernelGGL((sweep_kernel<MODE, 32>), dim3(nb), dim3(kSweepThreads), lds, ctx->stream, a);
     }
     ts.stop();
-    if (width > 0)
+    if (width > 0 && !a.no_reduce)
         hipLaunchKernelGGL(block_partials_reduce_kernel, dim3((unsigned)width), dim3(256), 0, ctx->stream, a.partial, nb,
                            width, a.out);
 }
@@ -1468,7 +1538,7 @@ int64_t gram_ws_doubles(int64_t M, int32_t rp) {
     return (int64_t)std::max(nslabs, nslabs_tri) * rp * rp;
 }
 
-void launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, double *G) {
+int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, double *G) {
     int nbp, npatch, nslabs;
     int64_t rps;
     gram_plan(M, rp, &nbp, &npatch, &nslabs, &rps);
@@ -1496,8 +1566,15 @@ void launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const 
                                1, 0, 0, 0, ws);
         }
     }
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 32)), dim3(256), 0, ctx->stream, ws,
-                       nslabs, (int)rp, 1, G);
+    if (G)  // nullptr: the caller reduces the slab partials itself (launch_phase1_finalize with the returned slab count)
+        hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 32)), dim3(256), 0, ctx->stream, ws,
+                           nslabs, (int)rp, 1, G);
+    return nslabs;
+}
+
+void launch_phase1_finalize(gingr_ctx *ctx, const Phase1FinalizeArgs &a) {
+    const int nG = a.nslabs > 0 ? (a.rp * a.rp + 31) / 32 : 0;
+    hipLaunchKernelGGL(phase1_finalize_kernel, dim3((unsigned)(nG + a.rp + 1)), dim3(256), 0, ctx->stream, a);
 }
 
 void launch_moment_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, int d, int e, double *ws, double *out) {

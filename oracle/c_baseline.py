@@ -60,23 +60,25 @@ def set_num_threads(n: int) -> None:
     lib().baseline_set_num_threads(int(n))
 
 
-def calibrate_threads(fit_soa: np.ndarray, target_soa: np.ndarray, sigma2: float, rows_per_thread: int = 24) -> int:
+def calibrate_threads(fit_soa: np.ndarray, target_soa: np.ndarray, sigma2: float, rows: int = 2048) -> int:
     """Pick the OpenMP thread count with the highest pair rate on THIS host (a container's CPU quota is often far below the
-    number of hardware threads it can see; oversubscribed spinning threads then make the baseline slower, not faster) and leave
-    it set.  Returns the chosen count."""
+    number of hardware threads it can see; oversubscribed threads then make the baseline slower, not faster) and leave it
+    set.  Every candidate (1, 2, 4, ... hardware threads) runs the column-sum pass over the same `rows` rows twice; the better
+    of the two counts.  Returns the chosen count."""
     import time
     best, best_rate = 1, 0.0
     limit = os.cpu_count() or 1
+    m = min(fit_soa.shape[1], rows)
+    sub = np.ascontiguousarray(fit_soa[:, :m])
     nt = 1
     while nt <= limit:
         set_num_threads(nt)
-        m = min(fit_soa.shape[1], max(64, rows_per_thread * nt))
-        sub = np.ascontiguousarray(fit_soa[:, :m])
-        colsum(sub[:, :max(16, m // 8)].copy(), target_soa, sigma2)      # thread start-up
-        t0 = time.perf_counter()
-        colsum(sub, target_soa, sigma2)
-        rate = m / (time.perf_counter() - t0)
-        if rate > best_rate * 1.05:
+        rate = 0.0
+        for _ in range(2):
+            t0 = time.perf_counter()
+            colsum(sub, target_soa, sigma2)
+            rate = max(rate, m / (time.perf_counter() - t0))
+        if rate > best_rate * 1.03:
             best, best_rate = nt, rate
         nt *= 2
     set_num_threads(best)
