@@ -236,6 +236,89 @@ __global__ __launch_bounds__(256) void tile_bbox_kernel(Cloud c, double *__restr
     }
 }
 
+// Lane-parallel exact-zero culling for one wave: the tile parts of a chunk (part p = box tile t0 + p, clipped to the chunk
+// [c0, c1)) are tested 64 at a time -- lane l tests part pbase + l against the box of the wave's quarter q of that part -- and the
+// outcome comes back as wave-uniform bit masks, so the walk over the parts (PartWalk::next) is scalar code with no per-part box
+// arithmetic (uniform float64 arithmetic still costs full VALU instructions on gfx950: 12 per test, ~1.5 % of a dense pass).
+//   act     bit l: the wave's quarter of part pbase + l exists and can receive non-zeros
+//   slot[t] (FINE) bit l: owned slot t can receive non-zeros from it
+// bad (nullable): per box tile, non-zero = never cull (a non-finite 1/den: 0 * inf must stay NaN).  boxes == nullptr: nothing is culled.
+template <int PT, bool FINE>
+struct PartWalk {
+    int64_t c0, c1, t0;
+    int nparts, pbase, q;
+    unsigned long long act, slot[PT];
+    const double *sub;      // quarter boxes, [6] per 64 points of the streamed cloud
+    const int32_t *bad;
+    double negc;
+
+    __device__ __forceinline__ void init(int64_t c0_, int64_t c1_, int q_, const double *sub_, const int32_t *bad_, double negc_) {
+        c0 = c0_;
+        c1 = c1_;
+        q = q_;
+        sub = sub_;
+        bad = bad_;
+        negc = negc_;
+        t0 = c0 / kTile;
+        nparts = c1 > c0 ? (int)((c1 - 1) / kTile - t0 + 1) : 0;
+        pbase = 0;
+        act = 0;
+    }
+    __device__ __forceinline__ void bounds(int p, int64_t *ib, int64_t *ie) const {
+        const int64_t a = (t0 + p) * kTile, b = a + kTile;
+        *ib = a > c0 ? a : c0;
+        *ie = b < c1 ? b : c1;
+    }
+    __device__ __forceinline__ void batch(const Box &own, const Box (&sown)[PT]) {
+        const int lane = threadIdx.x & 63;
+        const int p = pbase + lane;
+        int64_t ib, ie;
+        bounds(p, &ib, &ie);
+        const bool has = p < nparts && q * 64 < (int)(ie - ib);
+        bool on = has;
+        bool son[PT];
+#pragma unroll
+        for (int t = 0; t < PT; ++t) son[t] = has;
+        if (has && sub && !(bad && bad[(t0 + p)])) {
+            const double *qbox = sub + (ib / 64 + q) * 6;
+            if (FINE) {
+                on = false;
+#pragma unroll
+                for (int t = 0; t < PT; ++t) {
+                    son[t] = !(box_gap2(sown[t], qbox) * negc > GINGR_CULL_SCALED(kTabN));  // NaN boxes are never culled
+                    on = on || son[t];
+                }
+            } else {
+                on = !(box_gap2(own, qbox) * negc > GINGR_CULL_SCALED(kTabN));
+            }
+        }
+        act = __ballot(on);
+        if (FINE) {
+#pragma unroll
+            for (int t = 0; t < PT; ++t) slot[t] = __ballot(son[t]);
+        }
+        pbase += 64;
+    }
+    // next part with work for this wave: false when the chunk is exhausted
+    __device__ __forceinline__ bool next(const Box &own, const Box (&sown)[PT], int64_t *ib, int64_t *ie, unsigned *mask) {
+        while (act == 0) {
+            if (pbase >= nparts) return false;
+            batch(own, sown);
+        }
+        const int l = __builtin_ctzll(act);
+        act &= act - 1;
+        bounds(pbase - 64 + l, ib, ie);
+        unsigned m = (1u << PT) - 1u;
+        if (FINE) {
+            m = 0;
+#pragma unroll
+            for (int t = 0; t < PT; ++t) m |= (unsigned)((slot[t] >> l) & 1ull) << t;
+        }
+        *mask = m;
+        return true;
+    }
+};
+
 // ---------------------------------------------------------------- pass 1: column sums of K
 // Tile loops.  [j0, j1) is a range of tile entries (the whole tile or one 64-point quarter); with MASKED only the owned slots
 // t whose bit is set in `mask` (wave-uniform) are updated -- the others are known to receive exact zeros from this range.
@@ -377,25 +460,11 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         unsigned mask;
         bool valid;
     };
-    auto find = [&](int64_t from) {  // next tile part of the chunk in which this wave's quarter can receive non-zeros
-        Work w{from, from, kAllSlots, false};
-        for (int64_t ib = from, ie; ib < i1; ib = ie) {
-            ie = min(i1, (ib / kTile + 1) * kTile);
-            if (q0 >= (int)(ie - ib)) continue;
-            if (fit_boxes) {
-                const double *qbox = fit_sub + (ib / 64 + q) * 6;  // the quarter's own box (inside the tile's: no separate tile test)
-                if (FINE) {
-                    w.mask = quarter_mask<PT>(sown, qbox, -c);  // owned slots that can receive non-zeros from this quarter
-                    if (!w.mask) continue;
-                } else if (box_gap2(own, qbox) * (-c) > GINGR_CULL_SCALED(kTabN)) {
-                    continue;
-                }
-            }
-            w.ib = ib;
-            w.ie = ie;
-            w.valid = true;
-            break;
-        }
+    PartWalk<PT, FINE> walk;
+    walk.init(i0, i1, q, fit_boxes ? fit_sub : nullptr, nullptr, -c);
+    auto find = [&]() {  // next tile part of the chunk in which this wave's quarter can receive non-zeros
+        Work w{0, 0, kAllSlots, false};
+        w.valid = walk.next(own, sown, &w.ib, &w.ie, &w.mask);
         return w;
     };
     double lx = 0.0, ly = 0.0, lz = 0.0;  // the staged point of the quarter about to be computed (in flight during the previous one)
@@ -407,7 +476,7 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
             lz = fit.z[i];
         }
     };
-    Work cur = find(i0);
+    Work cur = find();
     if (cur.valid) issue(cur);
     while (cur.valid) {
         __builtin_amdgcn_wave_barrier();  // (compiler fence) the previous quarter's reads are issued before the slice is rewritten
@@ -420,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
             }
         }
         __builtin_amdgcn_wave_barrier();  // LDS serves one wave's accesses in order: its reads below see its own writes
-        const Work nxt = find(cur.ie);
+        const Work nxt = find();
         if (nxt.valid) issue(nxt);
         const int q1 = min((int)(cur.ie - cur.ib), q0 + 64);
         const unsigned mask = cur.mask;
@@ -671,28 +740,11 @@ __global__ __launch_bounds__(kBlock, (PT >= 4 ? 3 : 4)) void cpd_rowstats_kernel
         unsigned mask;
         bool valid;
     };
-    auto find = [&](int64_t from) {
-        Work w{from, from, kAllSlots, false};
-        for (int64_t jb = from, je; jb < j1; jb = je) {
-            je = min(j1, (jb / kTile + 1) * kTile);
-            if (q0 >= (int)(je - jb)) continue;
-            // a tile holding a non-finite 1/den is never culled: 0 * inf must stay NaN like the reference's 0/0
-            if (tgt_boxes && !tile_bad[jb / kTile]) {
-                const double *qbox = tgt_sub + (jb / 64 + q) * 6;
-                if (FINE) {
-                    w.mask = quarter_mask<PT>(sown, qbox, -c);
-                    if (!w.mask) continue;
-                } else if (box_gap2(own, qbox) * (-c) > GINGR_CULL_SCALED(kTabN)) {
-                    continue;
-                }
-            } else {
-                w.mask = kAllSlots;
-            }
-            w.jb = jb;
-            w.je = je;
-            w.valid = true;
-            break;
-        }
+    PartWalk<PT, FINE> walk;
+    walk.init(j0, j1, q, tgt_boxes ? tgt_sub : nullptr, tgt_boxes ? tile_bad : nullptr, -c);
+    auto find = [&]() {
+        Work w{0, 0, kAllSlots, false};
+        w.valid = walk.next(own, sown, &w.jb, &w.je, &w.mask);
         return w;
     };
     double lx = 0.0, ly = 0.0, lz = 0.0, linv = 0.0;
@@ -705,7 +757,7 @@ __global__ __launch_bounds__(kBlock, (PT >= 4 ? 3 : 4)) void cpd_rowstats_kernel
             linv = inv_den[j];
         }
     };
-    Work cur = find(j0);
+    Work cur = find();
     if (cur.valid) issue(cur);
     while (cur.valid) {
         __builtin_amdgcn_wave_barrier();
@@ -722,7 +774,7 @@ __global__ __launch_bounds__(kBlock, (PT >= 4 ? 3 : 4)) void cpd_rowstats_kernel
             }
         }
         __builtin_amdgcn_wave_barrier();
-        const Work nxt = find(cur.je);
+        const Work nxt = find();
         if (nxt.valid) issue(nxt);
         const int q1 = min((int)(cur.je - cur.jb), q0 + 64);
         const unsigned mask = cur.mask;
