@@ -131,8 +131,9 @@ def cpu_baseline(y, x, sigma2, w, model=None, budget_s=16.0):
     den = cb.colsum(ysub, xs, sigma2) * (M / ms) + co.outlier_constant(M, N, sigma2, w)
     P1s, PXs = cb.rowstats(ysub, xs, sigma2, 1.0 / den)
     t_pairs = (time.perf_counter() - t0) * (M / ms)
-    sample = (f"both all-pairs passes (optimised C, {cores} OpenMP threads = best of 1,2,4,... on this host, which shows {visible} "
-              f"hardware threads) on rows [0,{ms}) of {M} x {N} targets, scaled x{M / ms:.2f}: "
+    quota = cb.cpu_quota()
+    sample = (f"both all-pairs passes (optimised C, {cores} OpenMP threads = best of 1,2,4,... up to the container's CPU quota "
+              f"({'%.0f cores' % quota if quota else 'none'}; the host shows {visible} hardware threads)) on rows [0,{ms}) of {M} x {N} targets, scaled x{M / ms:.2f}: "
               f"{t_pairs:.3f} s per iteration")
     t_gp = None
     if model is not None:
@@ -158,6 +159,8 @@ def cpu_baseline(y, x, sigma2, w, model=None, budget_s=16.0):
     return {"value": 1.0 / total, "unit": "iterations/s", "cores": cores, "kind": "port", "sample": sample,
             "build": "gcc " + " ".join(cb.CFLAGS[:3]) + " (oracle/cpd_baseline.c), SIMD exponential checked <= 1e-12 against libm",
             "seconds_per_iteration": {"all_pairs": t_pairs, "gp_part": t_gp},
+            "thread_calibration_gpairs_per_s": {str(k): round(v, 3) for k, v in cb.LAST_CALIBRATION.items()},
+            "cpu_quota_cores": cb.cpu_quota(),
             "strict_checker_build": {"value": 1.0 / t_strict, "unit": "iterations/s (all-pairs passes only)",
                                      "build": "gcc -O2 -fopenmp -ffp-contract=off, scalar libm exp (oracle/cpd_oracle.c)",
                                      "sample_rows": mc}}

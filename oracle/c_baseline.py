@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+LAST_CALIBRATION = {}
 CFLAGS = ["-O3", "-march=native", "-fopenmp", "-fPIC", "-shared"]
 
 
@@ -60,14 +61,34 @@ def set_num_threads(n: int) -> None:
     lib().baseline_set_num_threads(int(n))
 
 
+def cpu_quota():
+    """the container's CPU quota in cores (cgroup v2 cpu.max / v1 cfs quota); None when unlimited or unknown"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
+
+
 def calibrate_threads(fit_soa: np.ndarray, target_soa: np.ndarray, sigma2: float, rows: int = 2048) -> int:
     """Pick the OpenMP thread count with the highest pair rate on THIS host (a container's CPU quota is often far below the
     number of hardware threads it can see; oversubscribed threads then make the baseline slower, not faster) and leave it
     set.  Every candidate (1, 2, 4, ... hardware threads) runs the column-sum pass over the same `rows` rows twice; the better
     of the two counts.  Returns the chosen count."""
     import time
+    global LAST_CALIBRATION
+    LAST_CALIBRATION = {}
     best, best_rate = 1, 0.0
     limit = os.cpu_count() or 1
+    quota = cpu_quota()
+    if quota:   # a burst of more threads than the quota looks fast for a few milliseconds and is throttled in a sustained run
+        limit = max(1, min(limit, int(quota + 0.5)))
     m = min(fit_soa.shape[1], rows)
     sub = np.ascontiguousarray(fit_soa[:, :m])
     nt = 1
@@ -78,9 +99,10 @@ def calibrate_threads(fit_soa: np.ndarray, target_soa: np.ndarray, sigma2: float
             t0 = time.perf_counter()
             colsum(sub, target_soa, sigma2)
             rate = max(rate, m / (time.perf_counter() - t0))
+        LAST_CALIBRATION[nt] = rate * target_soa.shape[1] / 1e9          # Gpair/s of the column-sum pass
         if rate > best_rate * 1.03:
             best, best_rate = nt, rate
-        nt *= 2
+        nt = nt * 2 if nt * 2 <= limit or nt == limit else limit
     set_num_threads(best)
     return best
 

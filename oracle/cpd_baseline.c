@@ -83,7 +83,7 @@ double baseline_exp_max_rel_error(int64_t n, double lo) {
 void baseline_cpd_colsum(int64_t M, const double *fx, const double *fy, const double *fz, int64_t N, const double *tx, const double *ty,
                          const double *tz, double sigma2, double *den_partial) {
     const double c = -1.0 / (2.0 * sigma2);
-    enum { JB = 256 };
+    enum { JB = 64 };
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t jb = 0; jb < N; jb += JB) {
         const int64_t nj = N - jb < JB ? N - jb : JB;

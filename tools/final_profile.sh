@@ -1,9 +1,25 @@
 #!/bin/bash
-# Round-end evidence: the default bench line, the rocprofv3 kernel statistics of the same command, SQ counters.
+# Round-end evidence in one gpurun call: the default bench line, the rocprofv3 kernel statistics of the same command, the PMC
+# traffic (separate FETCH_SIZE / WRITE_SIZE passes), the SQ counters and the emulated per-rank shard times.  Everything lands in
+# gpurun_out/final/; copy what is to be judged to profiles/rNN_*.
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/final
-cd $R && python3 bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/final/stats -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/final/stats.log 2>&1
-cd $R && bash tools/pmc_sq.sh > gpurun_out/final/pmc.log 2>&1
-tail -c 600 gpurun_out/final/bench.json
+F=$R/gpurun_out/final
+rm -rf $F; mkdir -p $F
+cd $R
+bash tools/pmc_traffic.sh > $F/pmc_traffic.txt 2>&1 && cp gpurun_out/pmc_traffic.json $F/pmc_traffic.json && cp gpurun_out/pmc_traffic.json profiles/r02_pmc_traffic.json
+python3 bench.py 2> $F/bench.err | tail -1 > $F/bench.json
+bash tools/prof_stats.sh final > $F/kernel_stats.txt 2>&1; cp gpurun_out/prof_final/kernel_stats.csv $F/kernel_stats.csv
+bash tools/pmc_sq.sh > $F/pmc_sq.txt 2>&1
+for n in 1 2 4 8; do python3 bench.py --emulate-world $n --no-cpu-baseline --no-parity-check --steps 100 --warmup 10 --roofline-steps 0 2>/dev/null | tail -1 > $F/emu$n.json; done
+python3 bench.py --sigma2 4 --no-cpu-baseline --no-parity-check 2>/dev/null | tail -1 > $F/bench_sigma2_4.json
+python3 bench.py --group --logical-shards 2 --no-cpu-baseline 2>/dev/null | tail -1 > $F/bench_group_logical2.json
+python3 - <<'PY'
+import json
+d = json.load(open("gpurun_out/final/bench.json"))
+print("bench", d["value"], d["ms_per_step"], d["valid"], d["roofline"]["frac"], d["roofline"]["traffic"], d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"])
+print({k["kernel"]: round(k["avg_ms"], 4) for k in d["kernels"]})
+for n in (1, 2, 4, 8):
+    print("emulated", n, json.load(open(f"gpurun_out/final/emu{n}.json"))["ms_per_step"])
+print("sigma2=4", json.load(open("gpurun_out/final/bench_sigma2_4.json"))["ms_per_step"])
+print("group x2 logical", json.load(open("gpurun_out/final/bench_group_logical2.json"))["ms_per_step"])
+PY

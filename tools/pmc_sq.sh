@@ -5,9 +5,9 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_sq
 mkdir -p $OUT
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
-  --kernel-trace -d $OUT/p1 -o p1 --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --roofline-steps 1 > $OUT/p1.log 2>&1
+  --kernel-trace -d $OUT/p1 -o p1 --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-check --roofline-steps 1 > $OUT/p1.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_ACTIVE_INST_SCA \
-  --kernel-trace -d $OUT/p2 -o p2 --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --roofline-steps 1 > $OUT/p2.log 2>&1
+  --kernel-trace -d $OUT/p2 -o p2 --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-check --roofline-steps 1 > $OUT/p2.log 2>&1
 cd $R
 python3 - <<'PY'
 import csv, glob, collections
