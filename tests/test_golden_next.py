@@ -1,6 +1,7 @@
 """Committed golden vectors of the SURVEY 8f rows (tests/golden/expected_next.npz, made by tests/golden/make_golden_next.py with the
 oracle).  CPU: the oracle still reproduces them (regression pin of the restatement; the quick parts only).  GPU: the HIP path
-reproduces them through the C ABI."""
+reproduces them through the C ABI.  Regression pins made by the repository's own oracle -- not reference-derived truth (that is
+what tests/test_reference_golden.py waits for)."""
 import os
 
 import numpy as np

@@ -1,4 +1,9 @@
-"""GPU tests against the committed fixtures, logical row shards on one device, and BASELINE-size property checks."""
+"""GPU tests against the committed fixtures, logical row shards on one device, and BASELINE-size property checks.
+
+The fixtures under tests/golden/*.npz are REGRESSION PINS: inputs taken from the reference's demo data, expected values produced
+by this repository's own oracle (tests/golden/make_golden*.py) -- they catch drift of the HIP path and of the oracle, not a
+misreading shared by both.  Truth derived from the real reference would come from tests/golden/reference/ (see
+tests/test_reference_golden.py); none exists yet: parity unpinned."""
 import os
 
 import numpy as np
