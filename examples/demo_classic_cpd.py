@@ -5,6 +5,8 @@ import os
 import time
 
 import numpy as np
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import torch  # noqa: F401  (first: one HIP runtime per process)
 
 import gingr_amd as ga
