@@ -24,6 +24,10 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kTile = 256;
+#ifndef GINGR_PT
+#define GINGR_PT 4
+#endif
+#define GINGR_PT_DEFAULT GINGR_PT
 
 struct __attribute__((aligned(32))) P4 {
     double x, y, z, w;
@@ -1144,10 +1148,7 @@ __global__ void scatter_kernel(const double *__restrict__ in, int64_t n, const i
     out[perm ? perm[i] : i] = in[i];
 }
 
-#ifndef GINGR_PT
-#define GINGR_PT 4
-#endif
-constexpr int kPT = GINGR_PT;     // points per thread in both CPD passes
+constexpr int kPT = GINGR_PT_DEFAULT;     // points per thread in both CPD passes
 // Row statistics of a SMALL shard (an 8-GPU rank owns 6250 rows at 50k): two points per thread halve the workgroup's rows,
 // which doubles the workgroups along the row axis, halves the chunk count (and the chunk partials) and lets a fourth
 // workgroup fit a CU; measured -5 % per iteration at 6250 rows, +6 % at 50000 (tools/prof_emu8.sh), hence the threshold.
@@ -1183,8 +1184,33 @@ inline ChunkShape env_chunk_shape() {
     }
     return c;
 }
+// Resident workgroups of the chip for one of the all-pairs kernels (compute units x workgroups per unit), queried once.  Launches
+// come in rounds of that many workgroups and the last, partly filled round costs almost a full one (measured at 50k x 50k:
+// 4.79 -> 4.98 rounds of the column-sum pass is 2.7 % FASTER, 6.38 -> 5.87 rounds of the row-statistics pass 3 %), so the chunk
+// planner below makes the number of workgroups come out just under a whole number of rounds.
+inline int resident_workgroups(int which /* 0 column sums, 1 row statistics PT = 2, 2 row statistics PT = kPT */) {
+    static int cache[3] = {0, 0, 0};
+    if (cache[which] > 0) return cache[which];
+    int per_cu = 0, dev = 0;
+    hipError_t e;
+    if (which == 0)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cpd_colsum_kernel<GINGR_PT_DEFAULT, false>, kBlock, 0);
+    else if (which == 1)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cpd_rowstats_kernel<2, false>, kBlock, 0);
+    else
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cpd_rowstats_kernel<GINGR_PT_DEFAULT, false>, kBlock, 0);
+    if (e != hipSuccess || per_cu < 1) per_cu = which == 2 ? 3 : 4;
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    (void)hipGetLastError();
+    cache[which] = per_cu * cus;
+    return cache[which];
+}
+
 inline ChunkPlan plan_chunks(int64_t owned, int owned_per_block, int64_t stream_len, int *nchunks, int quarters_override = 0,
-                             int forced_chunks = 0) {
+                             int forced_chunks = 0, int resident = 0) {
     const int64_t bx = ceil_div(owned, owned_per_block);
     int64_t want = ceil_div(kTargetBlocks, bx > 0 ? bx : 1);
     if (want < 1) want = 1;
@@ -1208,8 +1234,22 @@ inline ChunkPlan plan_chunks(int64_t owned, int owned_per_block, int64_t stream_
         p.n_big = (int32_t)((double)n * shape.frac / (double)p.len_big);
     }
     // developer knobs GINGR_COLSUM_CHUNKS / GINGR_ROWSTATS_CHUNKS=<n>: exactly n chunks balanced to a 64-point quarter (lengths
-    // differ by at most 64; the kernels handle chunks that start inside a tile).
-    const int forced = forced_chunks;
+    // differ by at most 64; the kernels handle chunks that start inside a tile).  Default (no knob, `resident` known): the
+    // largest chunk count whose workgroups fill k whole launch rounds, k = kTargetBlocks / resident rounded -- see
+    // resident_workgroups -- with the same balanced lengths.
+    int forced = forced_chunks;
+    if (forced <= 0 && quarters_override <= 0 && resident > 0 && shape.big < 1) {
+        int64_t k = (kTargetBlocks + resident / 2) / resident;
+        if (k < 1) k = 1;
+        int64_t nc = k * resident / (bx > 0 ? bx : 1);
+        const int64_t Qmax = ceil_div(n, 64);
+        if (nc > Qmax) nc = Qmax;
+        if (nc < 1) nc = 1;
+        // Short chunks stay whole tiles: wave q works on quarter q of every tile part, so a chunk of 3 quarters leaves one wave
+        // idle; only from ~16 quarters per chunk on is the unevenness (one quarter per wave at most) small against the round gain
+        // (emulated 8-GPU shard: 0.517 ms with tile-aligned chunks, 0.530 ms with balanced 192/256-point chunks).
+        if (Qmax / nc >= 16) forced = (int)nc;
+    }
     if (forced > 0) {
         const int64_t Q = ceil_div(n, 64), q = Q / forced, rem = Q % forced;
         if (q >= 1) {
@@ -1250,14 +1290,15 @@ inline int rowstats_tiles_override() {
 
 int64_t cpd_colsum_ws_doubles(int64_t M, int64_t N) {
     int nch;
-    plan_chunks(N, 64 * kPT, M, &nch, colsum_tiles_override(), colsum_chunks_override());
+    plan_chunks(N, 64 * kPT, M, &nch, colsum_tiles_override(), colsum_chunks_override(), resident_workgroups(0));
     const int64_t a = (int64_t)nch * N, b = cpd_colsum_mfma_ws_doubles(M, N);
     return a > b ? a : b;
 }
 
 int64_t cpd_rowstats_ws_doubles(int64_t M, int64_t N) {
     int nch;
-    plan_chunks(M, 64 * rowstats_pt(M), N, &nch, rowstats_tiles_override(), rowstats_chunks_override());
+    plan_chunks(M, 64 * rowstats_pt(M), N, &nch, rowstats_tiles_override(), rowstats_chunks_override(),
+                resident_workgroups(rowstats_pt(M) == 2 ? 1 : 2));
     const int64_t a = (int64_t)nch * 4 * M, b = cpd_rowstats_mfma_ws_doubles(M, N);
     return a > b ? a : b;
 }
@@ -1291,7 +1332,8 @@ int launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sig
         if (ctx->affinity_mfma) {
             launch_cpd_colsum_mfma(ctx, fit, target, sigma2_dev, aux, ws, &nch);
         } else {
-            const ChunkPlan len = plan_chunks(target.n, 64 * kPT, fit.n, &nch, colsum_tiles_override(), colsum_chunks_override());
+            const ChunkPlan len = plan_chunks(target.n, 64 * kPT, fit.n, &nch, colsum_tiles_override(), colsum_chunks_override(),
+                                              resident_workgroups(0));
             dim3 grid((unsigned)ceil_div(target.n, 64 * kPT), (unsigned)nch);
             const double *boxes = ctx->cull ? fit_boxes : (const double *)nullptr;
             // one variant, picked from the regime the device last reported (stale at worst: the results are the same)
@@ -1329,7 +1371,8 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
             launch_cpd_rowstats_mfma(ctx, fit, target, sigma2_dev, aux, inv_den, ws, &nch);
         } else {
             const int pt = rowstats_pt(fit.n);
-            const ChunkPlan len = plan_chunks(fit.n, 64 * pt, target.n, &nch, rowstats_tiles_override(), rowstats_chunks_override());
+            const ChunkPlan len = plan_chunks(fit.n, 64 * pt, target.n, &nch, rowstats_tiles_override(), rowstats_chunks_override(),
+                                              resident_workgroups(pt == 2 ? 1 : 2));
             dim3 grid((unsigned)ceil_div(fit.n, 64 * pt), (unsigned)nch);
             const bool cull = ctx->cull && tgt_boxes && tile_bad;
             const double *boxes = cull ? tgt_boxes : (const double *)nullptr;
