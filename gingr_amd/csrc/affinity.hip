@@ -1149,11 +1149,19 @@ __global__ void scatter_kernel(const double *__restrict__ in, int64_t n, const i
 }
 
 constexpr int kPT = GINGR_PT_DEFAULT;     // points per thread in both CPD passes
-// Row statistics of a SMALL shard (an 8-GPU rank owns 6250 rows at 50k): two points per thread halve the workgroup's rows,
-// which doubles the workgroups along the row axis, halves the chunk count (and the chunk partials) and lets a fourth
-// workgroup fit a CU; measured -5 % per iteration at 6250 rows, +6 % at 50000 (tools/prof_emu8.sh), hence the threshold.
-constexpr int64_t kSmallShardRows = 8192;
-inline int rowstats_pt(int64_t rows) { return (kPT > 2 && rows <= kSmallShardRows) ? 2 : kPT; }
+// Row statistics of a TINY shard: two points per thread halve the workgroup's rows (more workgroups along the row axis, a fourth
+// workgroup per CU).  With round 2's work split (a workgroup owns 256 rows whatever PT is) four points per thread win from a few
+// thousand rows on: 8-GPU shard of the 50k workload (6250 rows) 0.50 ms per iteration with PT = 2, 0.49 ms with PT = 4.
+constexpr int64_t kSmallShardRows = 2048;
+inline int env_int_early(const char *name) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+inline int rowstats_pt(int64_t rows) {
+    static const int forced = env_int_early("GINGR_ROWSTATS_PT");  // developer knob: 2 or 4 points per thread whatever the shard size
+    if (forced == 2 || forced == kPT) return forced;
+    return (kPT > 2 && rows <= kSmallShardRows) ? 2 : kPT;
+}
 // Workgroups per all-pairs launch.  A CU holds 3-4 of them and one lives for (tiles per chunk) x ~30 us, so the launch ends with
 // a tail of about one workgroup's life: many short workgroups beat few long ones until the per-chunk partials (written here,
 // read by the reduce kernels) cost more than the tail.  Measured with GINGR_COLSUM_TILES / GINGR_ROWSTATS_TILES at 50k <-> 50k
@@ -1239,7 +1247,12 @@ inline ChunkPlan plan_chunks(int64_t owned, int owned_per_block, int64_t stream_
     // resident_workgroups -- with the same balanced lengths.
     int forced = forced_chunks;
     if (forced <= 0 && quarters_override <= 0 && resident > 0 && shape.big < 1) {
+        // rounds: as many as kTargetBlocks asks for (finer balancing when culling makes workgroup costs uneven), but not so many that
+        // a chunk drops below ~1024 streamed points -- every workgroup pays ~3-4 us of prologue (table fill, owned points, boxes),
+        // which short chunks do not amortise (8-GPU shard of the 50k workload: 0.52 -> 0.49 ms per iteration with one round)
         int64_t k = (kTargetBlocks + resident / 2) / resident;
+        const int64_t kmax = (n / 1024) * (bx > 0 ? bx : 1) / resident;
+        if (k > kmax) k = kmax;
         if (k < 1) k = 1;
         int64_t nc = k * resident / (bx > 0 ? bx : 1);
         const int64_t Qmax = ceil_div(n, 64);
