@@ -12,6 +12,9 @@ bash tools/prof_stats.sh final > $F/kernel_stats.txt 2>&1; cp gpurun_out/prof_fi
 bash tools/pmc_sq.sh > $F/pmc_sq.txt 2>&1
 for n in 1 2 4 8; do python3 bench.py --emulate-world $n --no-cpu-baseline --no-parity-check --steps 100 --warmup 10 --roofline-steps 0 2>/dev/null | tail -1 > $F/emu$n.json; done
 python3 bench.py --sigma2 4 --no-cpu-baseline --no-parity-check 2>/dev/null | tail -1 > $F/bench_sigma2_4.json
+python3 bench.py --points 15000 --no-cpu-baseline 2>/dev/null | tail -1 > $F/bench_15k.json
+python3 bench.py --points 100000 --no-cpu-baseline 2>/dev/null | tail -1 > $F/bench_100k.json
+for n in 2 4 8; do python3 bench.py --points 100000 --emulate-world $n --no-cpu-baseline --no-parity-check --steps 40 --warmup 5 --roofline-steps 0 2>/dev/null | tail -1 > $F/emu100k_$n.json; done
 python3 bench.py --group --logical-shards 2 --no-cpu-baseline 2>/dev/null | tail -1 > $F/bench_group_logical2.json
 python3 - <<'PY'
 import json
@@ -22,4 +25,9 @@ for n in (1, 2, 4, 8):
     print("emulated", n, json.load(open(f"gpurun_out/final/emu{n}.json"))["ms_per_step"])
 print("sigma2=4", json.load(open("gpurun_out/final/bench_sigma2_4.json"))["ms_per_step"])
 print("group x2 logical", json.load(open("gpurun_out/final/bench_group_logical2.json"))["ms_per_step"])
+for t in ("15k", "100k"):
+    d = json.load(open(f"gpurun_out/final/bench_{t}.json"))
+    print(t, d["ms_per_step"], d["valid"], d["parity_check"] and d["parity_check"]["ok"])
+for n in (2, 4, 8):
+    print("emulated 100k", n, json.load(open(f"gpurun_out/final/emu100k_{n}.json"))["ms_per_step"])
 PY
