@@ -33,14 +33,9 @@ struct __attribute__((aligned(32))) P4 {
     double x, y, z, w;
 };
 
-// Table of the two CPD passes: 2^11 entries (16 KB of LDS).  -DGINGR_CPD_TBITS=13 selects the 8192-entry table whose
-// byte offset is ONE SDWA shift (fastexp.h): half a VALU instruction less per pair and 3e-15 instead of 2e-13 on K, but
-// 64 KB of LDS per 256-thread workgroup leaves 2 waves per SIMD and the kernels turn latency bound -- measured SLOWER
-// (colsum 1.26 vs 1.14 ms at 50k); it would need 16-wave workgroups sharing one table to pay off.
-#ifndef GINGR_CPD_TBITS
-#define GINGR_CPD_TBITS 11
-#endif
-constexpr int kTB = GINGR_CPD_TBITS;
+// Table of the two CPD passes: 2^11 entries (16 KB of LDS), floor form (fastexp.h).  An 8192-entry table (byte offset by one SDWA
+// shift) was measured in round 1 and lost to its LDS footprint; the floor form gets the one-instruction offset with 2048 entries.
+constexpr int kTB = 11;
 constexpr int kTabN = 1 << kTB;
 
 // ---------------------------------------------------------------- exact-zero culling
@@ -189,16 +184,6 @@ __device__ __forceinline__ void slot_boxes(const double (&x)[PT], const double (
             sb[t].hi[d] = uniform_d(hi[d]);
         }
     }
-}
-
-// mask of the owned slots that can receive a non-zero from the 64-point quarter whose box is sub6
-template <int PT>
-__device__ __forceinline__ unsigned quarter_mask(const Box (&sb)[PT], const double *__restrict__ sub6, double negc) {
-    unsigned m = 0;
-#pragma unroll
-    for (int t = 0; t < PT; ++t)
-        if (!(box_gap2(sb[t], sub6) * negc > GINGR_CULL_SCALED(kTabN))) m |= 1u << t;  // NaN boxes are never culled
-    return (unsigned)__builtin_amdgcn_readfirstlane((int)m);  // wave-uniform by construction: make it a scalar for the branches
 }
 
 // boxes[tile] = {lo[3], hi[3]} of the points [tile*256, tile*256+256) of a cloud, followed (at boxes + 6 * ntiles) by the boxes
