@@ -450,6 +450,7 @@ def main():
     runner.sync()
     t0 = time.perf_counter()
     runner.update(args.steps)
+    enqueue_s = time.perf_counter() - t0          # the call returns when the K steps are ENQUEUED: host cost of the launches
     runner.sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -571,6 +572,8 @@ def main():
             "parity_check": parity,
             "sigma2_after_timed_steps": sigma2_timed,
             "update_ms_device": upd_ms,
+            # host time to enqueue one step (12 kernel launches, no synchronisation inside): what a HIP graph could save at most
+            "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
             "roofline": roof,
             "kernels": kernels,
             "cpu_baseline": cpu,
