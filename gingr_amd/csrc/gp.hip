@@ -1193,15 +1193,20 @@ __device__ bool umeyama_from_sums(const double *sums, double n, const double c0[
     for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b) Sxy[a * 3 + b] = sums[6 + a * 3 + b] / n - muy[a] * mux[b];
     const double sig2x = sums[15] / n - (mux[0] * mux[0] + mux[1] * mux[1] + mux[2] * mux[2]);
-    double U[9], D[3], V[9];
-    svd3(Sxy, U, D, V);
-    const double det = Sxy[0] * (Sxy[4] * Sxy[8] - Sxy[5] * Sxy[7]) - Sxy[1] * (Sxy[3] * Sxy[8] - Sxy[5] * Sxy[6]) +
-                       Sxy[2] * (Sxy[3] * Sxy[7] - Sxy[4] * Sxy[6]);
-    const double s3 = det < 0 ? -1.0 : 1.0;
-    double R[9];
-    for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) R[a * 3 + b] = U[a * 3] * V[b * 3] + U[a * 3 + 1] * V[b * 3 + 1] + s3 * U[a * 3 + 2] * V[b * 3 + 2];
-    const double c = (global_transform == GINGR_SIMILARITY_TRANSFORMS) ? (D[0] + D[1] + s3 * D[2]) / sig2x : 1.0;
+    // R = U diag(1, 1, sign det) V^T and, for similarity transforms, c = (d1 + d2 + sign d3) / var_x.  With det > 0 (every
+    // non-degenerate registration) R is the polar factor of Sxy and d1 + d2 + d3 = trace(R^T Sxy): no SVD (svd3.h)
+    double R[9], trace_ds = 0.0;
+    if (!polar3_rotation(Sxy, R, &trace_ds)) {
+        double U[9], D[3], V[9];
+        svd3(Sxy, U, D, V);
+        const double det = Sxy[0] * (Sxy[4] * Sxy[8] - Sxy[5] * Sxy[7]) - Sxy[1] * (Sxy[3] * Sxy[8] - Sxy[5] * Sxy[6]) +
+                           Sxy[2] * (Sxy[3] * Sxy[7] - Sxy[4] * Sxy[6]);
+        const double s3 = det < 0 ? -1.0 : 1.0;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) R[a * 3 + b] = U[a * 3] * V[b * 3] + U[a * 3 + 1] * V[b * 3 + 1] + s3 * U[a * 3 + 2] * V[b * 3 + 2];
+        trace_ds = D[0] + D[1] + s3 * D[2];
+    }
+    const double c = (global_transform == GINGR_SIMILARITY_TRANSFORMS) ? trace_ds / sig2x : 1.0;
     // t = mu_y - c R mu_x in absolute coordinates (rotation about the origin)
     double mxa[3], mya[3];
     for (int a = 0; a < 3; ++a) {

@@ -64,3 +64,59 @@ __device__ inline void svd3(const double Ain[9], double U[9], double s[3], doubl
     }
 }
 
+
+// Orthogonal polar factor R of a 3x3 matrix with positive determinant (A = R H, H symmetric positive definite) by the scaled
+// Newton iteration X <- (g X + X^-T / g) / 2, g = (|X^-1|_F / |X|_F)^(1/2) (Higham).  For det A > 0 this IS the rotation
+// U diag(1, 1, det(U V^T)) V^T = U V^T that Kabsch / Umeyama build from the SVD, and trace(R^T A) is the sum of the singular values --
+// so the Umeyama step needs no SVD in that case: ~8 short iterations of 3x3 cofactor algebra instead of Jacobi sweeps full of
+// dependent float64 square roots and divisions run by ONE thread (the latency of that thread is on the critical path of every
+// iteration: everything after the posterior solve is replicated O(r^2) work).  Returns false -- the caller falls back to svd3 --
+// when det A <= 0, A is not finite, or the iteration does not settle (ill-conditioned A).
+__device__ inline bool polar3_rotation(const double A[9], double R[9], double *trace_RtA) {
+    const double det0 = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+    if (!(det0 > 0.0) || !(det0 < 1.79769313486231570815e308)) return false;
+    double X[9];
+    for (int q = 0; q < 9; ++q) X[q] = A[q];
+    bool done = false;
+    for (int it = 0; it < 40 && !done; ++it) {
+        // cofactor matrix C (X^-T = C / det)
+        double C[9];
+        C[0] = X[4] * X[8] - X[5] * X[7];
+        C[1] = X[5] * X[6] - X[3] * X[8];
+        C[2] = X[3] * X[7] - X[4] * X[6];
+        C[3] = X[2] * X[7] - X[1] * X[8];
+        C[4] = X[0] * X[8] - X[2] * X[6];
+        C[5] = X[1] * X[6] - X[0] * X[7];
+        C[6] = X[1] * X[5] - X[2] * X[4];
+        C[7] = X[2] * X[3] - X[0] * X[5];
+        C[8] = X[0] * X[4] - X[1] * X[3];
+        const double det = X[0] * C[0] + X[1] * C[1] + X[2] * C[2];
+        if (!(det > 0.0)) return false;
+        double nx = 0.0, nc = 0.0;
+        for (int q = 0; q < 9; ++q) {
+            nx += X[q] * X[q];
+            nc += C[q] * C[q];
+        }
+        const double idet = 1.0 / det;
+        // g^2 = |X^-1|_F / |X|_F = sqrt(nc) / (det sqrt(nx))
+        const double g2 = sqrt(nc / nx) * idet;
+        const double g = sqrt(g2);
+        const double a = 0.5 * g, b = 0.5 * idet / g;
+        double diff = 0.0;
+        for (int q = 0; q < 9; ++q) {
+            const double xn = a * X[q] + b * C[q];
+            diff = fmax(diff, fabs(xn - X[q]));
+            X[q] = xn;
+        }
+        if (!(diff == diff)) return false;
+        done = diff < 4e-16;  // entries of a rotation are <= 1 in magnitude: absolute = relative accuracy
+    }
+    if (!done) return false;
+    double tr = 0.0;
+    for (int q = 0; q < 9; ++q) {
+        R[q] = X[q];
+        tr += X[q] * A[q];
+    }
+    *trace_RtA = tr;
+    return true;
+}
