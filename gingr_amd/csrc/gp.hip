@@ -393,48 +393,63 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ Q0
 #endif
 template <int NT, int HALF>
 __device__ __forceinline__ void gram_tri_half(const double *__restrict__ Q0, int rp, const double *__restrict__ weight, int64_t r0,
-                                              int64_t r1, int kgroup, int kq, int cl, int lane, double *red,
+                                              int64_t r1, int kgroup, int kq, int cl, int lane, double *red, double *xchg,
                                               double *__restrict__ out) {
     constexpr int kTiles = NT * (NT + 1) / 2;
     constexpr int kMine = HALF == 0 ? (kTiles + 1) / 2 : kTiles / 2;
     v4f64 acc[kMine > 0 ? kMine : 1];
 #pragma unroll
     for (int q = 0; q < kMine; ++q) acc[q] = v4f64{0, 0, 0, 0};
-    auto load = [&](int64_t row, double (&f)[NT], double &w) {
+    // The two waves of a K group need the SAME NT fragments of every 4-row step.  Each loads only every other one (HALF 0: tiles
+    // 0, 2, 4, ...; HALF 1: 1, 3, 5, ...) and the pair exchanges them through LDS -- loading all of them in both waves fetched every
+    // basis row twice from the fabric (PMC FETCH_SIZE 221 MB for 134 MB of basis at 50k points, rank 100: the second request for
+    // a line arrives while the first is still in flight and is not merged).  Global loads run kDepth steps ahead of the step
+    // being multiplied (a step lasts ~1 800 cycles of matrix work at two waves per SIMD, less than an HBM round trip under load);
+    // the LDS hand-over is double buffered, one workgroup barrier per step.
+    constexpr int kDepth = GINGR_GRAM_DEPTH;
+    constexpr int kOwn = HALF == 0 ? (NT + 1) / 2 : NT / 2;  // fragments this wave loads
+    auto load_own = [&](int64_t row, double (&f)[kOwn > 0 ? kOwn : 1], double &w) {
         const int64_t rr = row + kq;
         const bool valid = rr < r1;
         const int64_t rc = valid ? rr : r0;
         w = valid ? (weight ? weight[rc / 3] : 1.0) : 0.0;
         const double *p = Q0 + rc * rp + cl;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) f[t] = p[16 * t];
+        for (int k = 0; k < kOwn; ++k) f[k] = p[16 * (2 * k + HALF)];
     };
-    // software pipeline: with two waves per SIMD a 4-row step lasts ~1 800 cycles of matrix work, less than an HBM round trip under
-    // load, so the fragments of step s + kDepth are requested while step s is multiplied (registers are plentiful at two waves per
-    // SIMD); measured at 50k points, rank 100: depth 1 58.9 us, depth 2 51.2 us
-    constexpr int kDepth = GINGR_GRAM_DEPTH;  // steps in flight ahead of the one being multiplied
-    double ring[kDepth + 1][NT], wr[kDepth + 1];
-    int64_t row = r0 + 4 * kgroup;
+    double ring[kDepth + 1][kOwn > 0 ? kOwn : 1], wr[kDepth + 1];
+    const int64_t row0 = r0 + 4 * kgroup;
+    // every wave of the workgroup runs the same number of steps (the barrier inside is workgroup wide): the K group with the
+    // most rows sets it; steps past a wave's own rows multiply zeros (w = 0, clamped addresses)
+    const int64_t nsteps = (r1 - r0 + 15) / 16;
 #pragma unroll
     for (int d = 0; d <= kDepth; ++d) {
         wr[d] = 0.0;
-        if (d < kDepth && row + 16 * d < r1) load(row + 16 * d, ring[d], wr[d]);
+        if (d < kDepth) load_own(row0 + 16 * d, ring[d], wr[d]);
     }
-    for (; row < r1; row += 16) {
-        if (row + 16 * kDepth < r1) load(row + 16 * kDepth, ring[kDepth], wr[kDepth]);
-        double a[NT];
+    double *xbuf = xchg + (size_t)kgroup * NT * 64;  // [2 buffers][4 K groups][NT][64 lanes]
+    for (int64_t st = 0; st < nsteps; ++st) {
+        double *xb = xbuf + (size_t)(st & 1) * 4 * NT * 64;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) a[t] = ring[0][t] * wr[0];  // invalid rows: w = 0
+        for (int k = 0; k < kOwn; ++k) xb[(2 * k + HALF) * 64 + lane] = ring[0][k];
+        __syncthreads();
+        load_own(row0 + 16 * (st + kDepth), ring[kDepth], wr[kDepth]);
+        double cur[NT], a[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            cur[t] = xb[t * 64 + lane];
+            a[t] = cur[t] * wr[0];  // invalid rows: w = 0
+        }
         int q = 0;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int u = t; u < NT; ++u, ++q)
-                if ((q & 1) == HALF) acc[q >> 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], ring[0][u], acc[q >> 1], 0, 0, 0);
+                if ((q & 1) == HALF) acc[q >> 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], cur[u], acc[q >> 1], 0, 0, 0);
 #pragma unroll
         for (int d = 0; d < kDepth; ++d) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) ring[d][t] = ring[d + 1][t];
+            for (int k = 0; k < kOwn; ++k) ring[d][k] = ring[d + 1][k];
             wr[d] = wr[d + 1];
         }
     }
@@ -474,14 +489,15 @@ __global__ __launch_bounds__(512) void gram_tri_kernel(const double *__restrict_
                                                        double *__restrict__ partial) {
     constexpr int kTiles = NT * (NT + 1) / 2;
     __shared__ double red[(kTiles + 1) * 256];
+    __shared__ double xchg[2 * 4 * NT * 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kq = lane >> 4, cl = lane & 15;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
     const int64_t r1 = min(rows, r0 + rows_per_slab);
     double *out = partial + (int64_t)blockIdx.x * rp * rp;
     if ((wave >> 2) == 0)
-        gram_tri_half<NT, 0>(Q0, rp, weight, r0, r1, wave & 3, kq, cl, lane, red, out);
+        gram_tri_half<NT, 0>(Q0, rp, weight, r0, r1, wave & 3, kq, cl, lane, red, xchg, out);
     else
-        gram_tri_half<NT, 1>(Q0, rp, weight, r0, r1, wave & 3, kq, cl, lane, red, out);
+        gram_tri_half<NT, 1>(Q0, rp, weight, r0, r1, wave & 3, kq, cl, lane, red, xchg, out);
 }
 
 // G[i][j] = sum over slabs (fixed order): 32 consecutive elements x 8 slab groups per workgroup, so every load instruction

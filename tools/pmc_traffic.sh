@@ -2,9 +2,10 @@
 # HBM traffic per kernel from PMC counters, collected as /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and
 # WRITE_SIZE in SEPARATE rocprofv3 --pmc passes with --kernel-trace only (no other trace domain).  Writes
 # gpurun_out/pmc_traffic.json (copy it to profiles/rNN_pmc_traffic.json: bench.py reads roofline.traffic from that tracked file)
-# and prints a table.  gfx950 corrections (same guide): FETCH_SIZE reports half the bytes of wide (16 B / lane) coalesced
-# streaming reads -- applied to the basis-streaming kernels (sweep, Gram), whose loads are of that kind; the all-pairs kernels
-# read 8 B / lane (uncalibrated: reported as counted); WRITE_SIZE is exact.
+# and prints a table.  gfx950 corrections (same guide): FETCH_SIZE reports half the bytes of coalesced streaming reads; the guide
+# calibrates that for 16 B / lane, tools/pmc_fetch_calibration.sh (tools/ubench_fetch.hip: three kernels reading 256 MiB once)
+# shows the same factor 2.000 for 8 B / lane and for the Gram kernel's 4 x 128-byte segments, so x2 is applied to every kernel;
+# WRITE_SIZE is exact.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 POINTS=${POINTS:-50000}
@@ -21,7 +22,8 @@ points, rank = int(sys.argv[1]), int(sys.argv[2])
 names = {"cpd_colsum_kernel": "cpd_colsum", "cpd_rowstats_kernel": "cpd_rowstats", "rowstats_reduce_kernel": "rowstats_reduce",
          "cpd_den_finalize_kernel": "cpd_den_finalize", "gram_kernel": "gram_tri", "phase1_finalize_kernel": "phase1_finalize",
          "sweep_kernel": "sweep_kernel<", "posterior_solve_lds_kernel": "posterior_solve", "tile_bbox_kernel": "tile_bbox"}
-wide = {"gram_kernel", "sweep_kernel"}       # 16 B / lane streaming reads: FETCH_SIZE x 2 (gfx950)
+wide = set(names)       # FETCH_SIZE x 2 on gfx950 for EVERY load width this library uses: calibrated with tools/pmc_fetch_calibration.sh
+                        # (16 B / lane, 8 B / lane contiguous and the Gram kernel's 4 x 128-byte row segments all report exactly half)
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"gpurun_out/pmc_{c}/**/*counter_collection.csv", recursive=True)[0]
