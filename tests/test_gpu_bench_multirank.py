@@ -1,0 +1,34 @@
+"""The contract's launch line for N > 1 -- `python bench.py --gpus N` starting one rank per GPU under torch.distributed.run -- run
+end to end on a ONE-GPU box: GINGR_BENCH_SHARED_DEVICE=1 puts every rank on device 0 and sends the exchange through gloo on host
+copies (RCCL refuses two ranks on one device).  Everything else is the code the driver's scaling run executes: rank environment,
+shard split, phase / exchange ordering, max-over-ranks clock, only rank 0 printing, the JSON line last on stdout, and the
+`shard_consistency` check (the sharded run must end in the state ONE shard reaches from the same start)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world,points", [(2, 6000), (3, 5003)])
+def test_bench_launch_line_with_ranks_sharing_the_device(world, points):
+    env = dict(os.environ, GINGR_BENCH_SHARED_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "1",
+                        "--points", str(points), "--rank", "40", "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    out = json.loads(lines[-1])                      # the JSON line is the LAST line, printed once (rank 0 only)
+    assert sum(1 for ln in lines if ln.startswith('{"metric"')) == 1
+    assert out["n_gpus"] == world and out["config"]["parallelism"] == f"row-shard x{world}"
+    sc = out["shard_consistency"]
+    assert sc is not None and sc["ok"], sc
+    assert sc["iterations"] == 1 + 4 + 3            # warm-up + timed + roofline steps
+    assert sc["sigma2_rel"] < 1e-10 and sc["alpha_max_abs"] < 1e-9, sc
+    assert out["valid"] is True

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries of one `tools/final_profile.sh` run (gpurun_out/final/) into profiles/rNN_*.
+    python tools/collect_profiles.py [round=02]"""
+import json
+import os
+import shutil
+import sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "02"
+F, P = os.path.join(root, "gpurun_out", "final"), os.path.join(root, "profiles")
+
+
+def load(name):
+    return json.load(open(os.path.join(F, name)))
+
+
+shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, f"r{rnd}_bench50k_final.json"))
+shutil.copy(os.path.join(F, "kernel_stats.csv"), os.path.join(P, f"r{rnd}_bench50k_kernel_stats_final.csv"))
+shutil.copy(os.path.join(F, "pmc_traffic.json"), os.path.join(P, f"r{rnd}_pmc_traffic.json"))
+shutil.copy(os.path.join(F, "pmc_sq.txt"), os.path.join(P, f"r{rnd}_pmc_sq_counters.txt"))
+
+e50 = {str(n): load(f"emu{n}.json")["ms_per_step"] for n in (1, 2, 4, 8)}
+one100 = load("bench_100k.json")
+e100 = {"1": one100["ms_per_step"], **{str(n): load(f"emu100k_{n}.json")["ms_per_step"] for n in (2, 4, 8)}}
+json.dump({
+    "what": "emulated per-rank iteration time of a row shard (one GPU runs rank 0's share of an N-rank job; exchange = 1-rank "
+            "all-reduce through torch.distributed; timing experiment, not a valid registration)",
+    "command": "python bench.py --emulate-world N --no-cpu-baseline --no-parity-check --steps 100 --warmup 10 --roofline-steps 0 "
+               "(100k: --points 100000 --steps 40 --warmup 5)",
+    "ms_per_iteration_50k": e50,
+    "ms_per_iteration_100k": e100,
+    "ratio_to_one_gpu_50k": {k: e50["1"] / v for k, v in e50.items()},
+    "ratio_to_one_gpu_100k": {k: e100["1"] / v for k, v in e100.items() if k != "1"},
+}, open(os.path.join(P, f"r{rnd}_emulated_shard_times.json"), "w"), indent=1)
+
+
+def cfg(d):
+    return {"ms_per_step": d["ms_per_step"], "iterations_per_s": d["value"], "valid": d["valid"], "parity_check": d["parity_check"]}
+
+
+json.dump({
+    "config3_15k": cfg(load("bench_15k.json")),
+    "config4_100k_one_gpu": cfg(one100),
+    "late_regime_sigma2_4_50k": load("bench_sigma2_4.json")["ms_per_step"],
+    "device_group_two_logical_shards_50k": load("bench_group_logical2.json")["ms_per_step"],
+}, open(os.path.join(P, f"r{rnd}_configs_3_4_and_variants.json"), "w"), indent=1)
+print("profiles updated from", F)
