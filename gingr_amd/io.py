@@ -154,7 +154,8 @@ def landmark_correspondences(model_reference: np.ndarray, model_landmarks: Seque
                              target_landmarks: Sequence[Landmark]) -> LandmarkCorrespondences:
     """GeneralRegistrationState.apply's landmark triples (GeneralRegistrationState.scala:43-62): landmarks are paired by id; pid =
     the reference vertex closest to the model landmark (lowest index on ties), point = the target landmark, covariance = the
-    target landmark's uncertainty or the identity."""
+    MODEL landmark's uncertainty (`mPoint.uncertainty.getOrElse(identity)`, :55-57 -- not the target landmark's) or the identity.
+    Order: the model landmarks' order (`m.map(_.id) intersect t.map(_.id)`, :47)."""
     ref = np.asarray(model_reference, dtype=np.float64)
     by_id = {lm.id: lm for lm in target_landmarks}
     pids, pts, covs = [], [], []
@@ -166,7 +167,7 @@ def landmark_correspondences(model_reference: np.ndarray, model_landmarks: Seque
         pids.append(int(np.argmin(d2)))
         t = by_id[lm.id]
         pts.append(t.coordinates)
-        covs.append(np.eye(3) if t.covariance is None else t.covariance)
+        covs.append(np.eye(3) if lm.covariance is None else lm.covariance)
     return LandmarkCorrespondences(np.asarray(pids, dtype=np.int32), np.asarray(pts, dtype=np.float64).reshape(-1, 3),
                                    np.asarray(covs, dtype=np.float64).reshape(-1, 3, 3))
 

@@ -67,11 +67,15 @@ def test_landmark_json_both_shipped_variants(tmp_path):
     cov = (R * np.array([9.0, 4.0, 1.0])) @ R.T
     io.write_landmarks([io.Landmark("X", np.array([1.0, 2.0, 3.0]), cov)], str(f1))
     assert np.allclose(io.read_landmarks(str(f1))[0].covariance, cov, atol=1e-12)
-    # landmark triples of GeneralRegistrationState.apply: paired by id, pid = closest reference vertex
+    # landmark triples of GeneralRegistrationState.apply (GeneralRegistrationState.scala:43-62): paired by id, pid = closest
+    # reference vertex, point = the TARGET landmark, covariance = the MODEL landmark's uncertainty (:55-57) or the identity
     ref = np.array([[0.0, 0, 0], [10.0, 0, 0], [0.0, 10, 0]])
-    lc = io.landmark_correspondences(ref, [io.Landmark("p", np.array([9.0, 1.0, 0.0])), io.Landmark("q", np.zeros(3))],
-                                     [io.Landmark("p", np.array([5.0, 5.0, 5.0]), cov)])
+    lc = io.landmark_correspondences(ref, [io.Landmark("p", np.array([9.0, 1.0, 0.0]), cov), io.Landmark("q", np.zeros(3))],
+                                     [io.Landmark("p", np.array([5.0, 5.0, 5.0]), 4.0 * np.eye(3))])
     assert list(lc.pids) == [1] and np.allclose(lc.points, [[5.0, 5.0, 5.0]]) and np.allclose(lc.covs[0], cov)
+    lc = io.landmark_correspondences(ref, [io.Landmark("p", np.array([9.0, 1.0, 0.0]))],
+                                     [io.Landmark("p", np.array([5.0, 5.0, 5.0]), 4.0 * np.eye(3))])
+    assert np.allclose(lc.covs[0], np.eye(3))            # no model-side uncertainty: identity, whatever the target file says
 
 
 def test_stl_reader_reproduces_the_golden_vertex_numbering(tmp_path):
