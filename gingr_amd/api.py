@@ -436,6 +436,18 @@ class GeneralRegistrationState:
     def updateSigma2(self, s2: float) -> "GeneralRegistrationState":
         return dataclasses.replace(self, sigma2=s2)
 
+    def statusText(self) -> str:
+        """GeneralRegistrationState.printStatus (GeneralRegistrationState.scala:103-114)"""
+        n = self.iteration + 1
+        return {FittingStatuses.None_: "Initial state - no iterations performed!",
+                FittingStatuses.Converged: f"Fitting converged after {n} accepted iterations!",
+                FittingStatuses.MaxIteration: f"Fitting finished the MaxIterations with ({n}) accepted iterations!",
+                FittingStatuses.ModelFlexibilityError:
+                    f"Model not flexible enough to compute posterior model - finished after {n} accepted iterations!"}[self.status]
+
+    def printStatus(self) -> None:
+        print(self.statusText())
+
 
 # ----------------------------------------------------------------------------- configs
 def _cpd_converged(last: GeneralRegistrationState, current: GeneralRegistrationState, threshold: float) -> bool:
