@@ -51,6 +51,15 @@ class IcpParams(ctypes.Structure):
 _dp = POINTER(c_double)
 _ip = POINTER(c_int32)
 
+KERNEL_GAUSSIAN_MIXTURE, KERNEL_DOT, KERNEL_LOOKUP = 0, 1, 2
+
+
+class ScalarKernel(ctypes.Structure):
+    """gingr_scalar_kernel"""
+    _fields_ = [("kind", c_int32), ("n_kernels", c_int32), ("sigmas", _dp), ("scalings", _dp), ("mirror", c_double),
+                ("scaling", c_double), ("lookup", _dp)]
+
+
 # name -> (restype, argtypes); every symbol include/gingr_hip.h declares
 SIGNATURES = {
     "gingr_device_count": (c_int, []),
@@ -85,6 +94,8 @@ SIGNATURES = {
     "gingr_mesh_distance_stats": (c_int, [c_void_p, c_int64, _dp, c_int64, _dp, c_int64, POINTER(c_int32), c_int32, c_double, _dp]),
     "gingr_fitter_update_icp_surface_sample_async": (c_int, [c_void_p, POINTER(IcpParams), _dp]),
     "gingr_fitter_posterior_logpdf_icp_surface": (c_int, [c_void_p, POINTER(IcpParams), _dp, POINTER(c_double)]),
+    "gingr_gpmm_build_diagonal": (c_int, [c_void_p, c_int64, _dp, POINTER(ScalarKernel), POINTER(ScalarKernel), POINTER(ScalarKernel),
+                                          c_double, c_int32, c_int64, c_int64, POINTER(c_void_p)]),
     "gingr_gpmm_build_gaussian": (c_int, [c_void_p, c_int64, _dp, c_int32, _dp, _dp, c_double, c_int32, c_int64, c_int64,
                                           POINTER(c_void_p)]),
     "gingr_pointset_distance_extrema": (c_int, [c_void_p, _dp, c_int64, _dp, _dp]),

@@ -167,22 +167,65 @@ class PointDistributionModel:
         return int(self.reference.shape[0])
 
 
+@dataclasses.dataclass(frozen=True)
+class ScalarKernelSpec:
+    """One scalar kernel of a DiagonalKernel (gingr_scalar_kernel): `kind` "gauss" (mixture of scaling_i exp(-|x-y|^2/sigma_i^2),
+    optionally + mirror * the x-mirrored mixture), "dot" (scaling * x.y) or "lookup" (scaling * lookup[i, j])."""
+    kind: str
+    sigmas: Tuple[float, ...] = ()
+    scalings: Tuple[float, ...] = ()
+    mirror: float = 0.0
+    scaling: float = 1.0
+    lookup: Optional[np.ndarray] = None
+
+    def _native(self, keep: list) -> "nat.ScalarKernel":
+        k = nat.ScalarKernel()
+        k.kind = {"gauss": nat.KERNEL_GAUSSIAN_MIXTURE, "dot": nat.KERNEL_DOT, "lookup": nat.KERNEL_LOOKUP}[self.kind]
+        if self.kind == "gauss":
+            sg, sc = f64(self.sigmas), f64(self.scalings)
+            keep += [sg, sc]
+            k.n_kernels, k.sigmas, k.scalings, k.mirror = len(self.sigmas), dptr(sg), dptr(sc), float(self.mirror)
+        else:
+            k.scaling = float(self.scaling)
+            if self.kind == "lookup":
+                m = f64(self.lookup)
+                keep.append(m)
+                k.lookup = dptr(m)
+        return k
+
+
 class DevicePointDistributionModel:
     """A PointDistributionModel whose basis lives in HBM: the result of the on-device GPMM construction
-    (gingr_gpmm_build_gaussian).  Quacks like PointDistributionModel (reference / mean / basis / variance / rank /
-    numberOfPoints); basis and variance are downloaded lazily, only if somebody asks for them."""
+    (gingr_gpmm_build_gaussian / gingr_gpmm_build_diagonal).  Quacks like PointDistributionModel (reference / mean / basis /
+    variance / rank / numberOfPoints); basis and variance are downloaded lazily, only if somebody asks for them."""
 
     def __init__(self, ctx: Context, reference, sigmas: Sequence[float], scalings: Sequence[float],
-                 relativeTolerance: float, maxRank: int = 0):
+                 relativeTolerance: float, maxRank: int = 0, kernels: Optional[Sequence[ScalarKernelSpec]] = None,
+                 cells: Optional[np.ndarray] = None):
         self.ctx = ctx
         self.reference = f64(reference)
         self._sig, self._sc = f64(sigmas), f64(scalings)
         self._tol, self._maxrank = float(relativeTolerance), int(maxRank)
+        self._kernels = None if kernels is None else tuple(kernels)          # (k_x, k_y, k_z) of a DiagonalKernel
+        self.cells = cells
         self._full: Optional["DeviceModel"] = None
         self._host: Optional[PointDistributionModel] = None
 
     def _build(self, ctx: Context, row_begin: int, row_end: int):
         h = c_void_p()
+        if self._kernels is not None:
+            keep: list = []
+            uniq = {}
+            nk = []
+            for spec in self._kernels:                     # equal specs -> the SAME native struct (one factorisation)
+                if id(spec) not in uniq:
+                    uniq[id(spec)] = spec._native(keep)
+                nk.append(uniq[id(spec)])
+            _check(ctx.handle, ctx._lib.gingr_gpmm_build_diagonal(ctx.handle, self.numberOfPoints, dptr(self.reference),
+                                                                  ctypes.byref(nk[0]), ctypes.byref(nk[1]), ctypes.byref(nk[2]),
+                                                                  self._tol, self._maxrank, row_begin, row_end, ctypes.byref(h)),
+                   "gingr_gpmm_build_diagonal")
+            return h
         _check(ctx.handle, ctx._lib.gingr_gpmm_build_gaussian(ctx.handle, self.numberOfPoints, dptr(self.reference),
                                                               len(self._sig), dptr(self._sig), dptr(self._sc), self._tol,
                                                               self._maxrank, row_begin, row_end, ctypes.byref(h)),
@@ -252,21 +295,97 @@ class PointSetHelper:
 
 
 class GPMMTriangleMesh3D:
-    """GPMMTriangleMesh3D(reference, relativeTolerance) (GPMMHelper.scala:96-130), Gaussian kernels only."""
+    """GPMMTriangleMesh3D(reference, relativeTolerance) (GPMMHelper.scala:96-153): every kernel of the reference, the low-rank
+    factorisation built in HBM.  `cells` (the triangulation) is only needed by the Laplacian kernels; it is handed on to the model."""
 
-    def __init__(self, ctx: Context, reference, relativeTolerance: float = 0.01, maxRank: int = 0):
+    def __init__(self, ctx: Context, reference, relativeTolerance: float = 0.01, maxRank: int = 0, cells=None):
         self.ctx, self.reference, self.relativeTolerance, self.maxRank = ctx, f64(reference), relativeTolerance, maxRank
+        self.cells = None if cells is None else np.ascontiguousarray(cells, dtype=np.int32)
 
     def Gaussian(self, sigma: float, scaling: float) -> DevicePointDistributionModel:
         return self.GaussianMixture([GaussianKernelParameters(sigma, scaling)])
 
     def GaussianMixture(self, pars: Sequence[GaussianKernelParameters]) -> DevicePointDistributionModel:
         return DevicePointDistributionModel(self.ctx, self.reference, [p.sigma for p in pars], [p.scaling for p in pars],
-                                            self.relativeTolerance, self.maxRank)
+                                            self.relativeTolerance, self.maxRank, cells=self.cells)
 
     def AutomaticGaussian(self) -> DevicePointDistributionModel:
         mx = PointSetHelper(self.ctx, self.reference).maximumPointDistance()
         return self.GaussianMixture([GaussianKernelParameters(mx / 4.0, mx / 8.0), GaussianKernelParameters(mx / 8.0, mx / 16.0)])
+
+    def _diagonal(self, kx: ScalarKernelSpec, ky: ScalarKernelSpec, kz: ScalarKernelSpec) -> DevicePointDistributionModel:
+        return DevicePointDistributionModel(self.ctx, self.reference, [], [], self.relativeTolerance, self.maxRank,
+                                            kernels=(kx, ky, kz), cells=self.cells)
+
+    def GaussianDot(self, sigma: float, scaling: float) -> DevicePointDistributionModel:
+        """GPMMHelper.scala:103-106: DotProductKernel(GaussianKernel(sigma), 1.0) * scaling.  DotProductKernel.k returns
+        x.dot(y) and ignores both the wrapped kernel and gamma (KernelHelper.scala:43-51), so sigma has no effect -- mirrored."""
+        k = ScalarKernelSpec("dot", scaling=scaling)
+        return self._diagonal(k, k, k)
+
+    def GaussianSymmetry(self, sigma: float, scaling: float) -> DevicePointDistributionModel:
+        """GPMMHelper.scala:107-111 + KernelHelper.symmetrizeKernel (:25-31): DiagonalKernel(k, 3) + DiagonalKernel(-km, km, km)
+        with km(x, y) = k((-x0, x1, x2), y): the x coordinate gets k - km, y and z get k + km."""
+        kx = ScalarKernelSpec("gauss", (float(sigma),), (float(scaling),), mirror=-1.0)
+        kyz = ScalarKernelSpec("gauss", (float(sigma),), (float(scaling),), mirror=1.0)
+        return self._diagonal(kx, kyz, kyz)
+
+    def InverseLaplacian(self, scaling: float) -> DevicePointDistributionModel:
+        """GPMMHelper.scala:132-136: LookupKernel(reference, pinv(graph Laplacian)) * scaling.  The dense pseudo-inverse is one-off
+        host work exactly as in the reference (LaplacianHelper, MatrixHelper.pinv); the low-rank factorisation runs on the device."""
+        k = ScalarKernelSpec("lookup", scaling=scaling, lookup=LaplacianHelper(self.reference.shape[0], self._need_cells()).inverseLaplacianMatrix())
+        return self._diagonal(k, k, k)
+
+    def InverseLaplacianDot(self, scaling: float, gamma: float) -> DevicePointDistributionModel:
+        """GPMMHelper.scala:138-142: DotProductKernel(LookupKernel(..), gamma) * scaling = scaling * x.y (see GaussianDot); the
+        reference still computes the pseudo-inverse it never uses -- skipped."""
+        return self.GaussianDot(0.0, scaling)
+
+    def _need_cells(self) -> np.ndarray:
+        if self.cells is None:
+            raise ValueError("the Laplacian kernels need the triangulation: GPMMTriangleMesh3D(ctx, reference, tol, cells=...)")
+        return self.cells
+
+    def computeDistanceAbsMesh(self, model, lmId: int) -> np.ndarray:
+        """GPMMHelper.scala:144-153: sum_i |cov(lmId, pid)_ii| per vertex, cov = U diag(variance) U^T (3 x 3 blocks)."""
+        U = f64(model.basis).reshape(model.numberOfPoints, 3, -1)
+        w = U[int(lmId)] * f64(model.variance)[None, :]                   # (3, r)
+        return np.abs(np.einsum("pdr,dr->pd", U, w)).sum(axis=1)
+
+
+class LaplacianHelper:
+    """G/api/gpmm/LaplacianHelper.scala:25-55 and MatrixHelper.pinv (MatrixHelper.scala:21-26): combinatorial graph Laplacian of
+    the triangulation (degree on the diagonal, -1 for adjacent vertices) and its SVD pseudo-inverse with the 1e-5 cut-off."""
+
+    def __init__(self, n: int, cells):
+        self.n = int(n)
+        c = np.asarray(cells, dtype=np.int64).reshape(-1, 3)
+        a = np.zeros((self.n, self.n), dtype=bool)
+        for i, j in ((0, 1), (1, 2), (0, 2)):
+            a[c[:, i], c[:, j]] = True
+            a[c[:, j], c[:, i]] = True
+        np.fill_diagonal(a, False)
+        self.adjacency = a
+
+    def laplacianMatrix(self, inverse: bool = False) -> np.ndarray:
+        m = np.where(self.adjacency, -1.0, 0.0)
+        m[np.arange(self.n), np.arange(self.n)] = self.adjacency.sum(axis=1).astype(np.float64)
+        return self.pinv(m) if inverse else m
+
+    def inverseLaplacianMatrix(self) -> np.ndarray:
+        return self.pinv(self.laplacianMatrix())
+
+    def laplacianNormalizedMatrix(self, inverse: bool = False) -> np.ndarray:
+        deg = self.adjacency.sum(axis=1).astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            m = np.where(self.adjacency, -1.0 / np.sqrt(deg[:, None] * deg[None, :]), 0.0)
+        m[np.arange(self.n), np.arange(self.n)] = (deg != 0).astype(np.float64)
+        return self.pinv(m) if inverse else m
+
+    @staticmethod
+    def pinv(m: np.ndarray, precision: float = 0.00001) -> np.ndarray:
+        u, s, vt = np.linalg.svd(m)
+        return (u * np.where(s > precision, 1.0 / np.where(s > precision, s, 1.0), 0.0)[None, :]) @ vt
 
 
 def automaticGPMMfromTemplate(ctx: Context, template, relativeTolerance: float = 0.1) -> DevicePointDistributionModel:

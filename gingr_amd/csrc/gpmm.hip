@@ -43,6 +43,38 @@ __device__ __forceinline__ double mixture_value(const Mixture &mix, double d2, c
     return v;
 }
 
+// One scalar kernel of a DiagonalKernel(k_x, k_y, k_z) (GPMMHelper.scala:96-142, KernelHelper.scala:25-84):
+//   kind 0  sum_i scaling_i exp(-|x-y|^2/sigma_i^2)  [+ mirror * the same kernel at (Mx, y), M = diag(-1,1,1): the x-mirrored
+//           kernel of KernelHelper.symmetrizeKernel -- xMirroredKernel3D evaluates kernel(Point(-x0, x1, x2), y)]
+//   kind 1  scale * (x . y)          DotProductKernel.k returns x.dot(y) whatever kernel / gamma it wraps (KernelHelper.scala:43-51)
+//   kind 2  scale * m[i][j]          LookupKernel on the reference points themselves (closest reference point of a reference
+//                                     point = the point), m = pinv(graph Laplacian) (LaplacianHelper.scala:27-41)
+struct KSpec {
+    int32_t kind;
+    Mixture mix;
+    double mirror;
+    double scale;
+    const double *lookup;  // device, M x M row-major
+};
+
+__device__ __forceinline__ double kspec_value(const KSpec &k, const Cloud &pts, int64_t c, int64_t p, double px, double py,
+                                              double pz, const double *T) {
+    if (k.kind == 1) {
+        const double dot = __dadd_rn(__dadd_rn(__dmul_rn(pts.x[c], px), __dmul_rn(pts.y[c], py)), __dmul_rn(pts.z[c], pz));
+        return __dmul_rn(dot, k.scale);
+    }
+    if (k.kind == 2) return __dmul_rn(k.lookup[c * pts.n + p], k.scale);
+    const double dx = pts.x[c] - px, dy = pts.y[c] - py, dz = pts.z[c] - pz;
+    const double d2 = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+    double v = mixture_value(k.mix, d2, T);
+    if (k.mirror != 0.0) {
+        const double mx = __dmul_rn(pts.x[c], -1.0) - px;
+        const double m2 = __dadd_rn(__dadd_rn(__dmul_rn(mx, mx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+        v = __dadd_rn(v, __dmul_rn(mixture_value(k.mix, m2, T), k.mirror));
+    }
+    return v;
+}
+
 struct Best {
     double v;
     int32_t i;
@@ -73,18 +105,27 @@ __device__ __forceinline__ void block_best_sum(Best &b, double &sum, Best *shb, 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(kPcBlock) void pc_init_kernel(int64_t M, Mixture mix, double *__restrict__ diag,
+__global__ __launch_bounds__(kPcBlock) void pc_init_kernel(Cloud pts, KSpec spec, double *__restrict__ diag,
                                                            int32_t *__restrict__ pivoted, double *__restrict__ pmax,
                                                            int32_t *__restrict__ pidx, double *__restrict__ ptr,
                                                            int32_t *__restrict__ ctl) {
+    __shared__ double T[GINGR_EXP_TABLE];
     __shared__ Best shb[kPcBlock];
     __shared__ double shs[kPcBlock];
-    double d0 = 0.0;
-    for (int i = 0; i < mix.n; ++i) d0 = i == 0 ? mix.s[i] : d0 + mix.s[i];  // k(x,x) = sum scaling_i * exp(0)
+    fastexp_table_init(T);
+    __syncthreads();
+    const int64_t M = pts.n;
     const int64_t c = (int64_t)blockIdx.x * kPcBlock + threadIdx.x;
     Best b{0.0, -1};
     double tr = 0.0;
     if (c < M) {
+        double d0;
+        if (spec.kind == 0 && spec.mirror == 0.0) {
+            d0 = 0.0;
+            for (int i = 0; i < spec.mix.n; ++i) d0 = i == 0 ? spec.mix.s[i] : d0 + spec.mix.s[i];  // k(x,x) = sum scaling_i * exp(0)
+        } else {
+            d0 = kspec_value(spec, pts, c, c, pts.x[c], pts.y[c], pts.z[c], T);
+        }
         diag[c] = d0;
         pivoted[c] = 0;
         b = Best{d0, (int32_t)c};
@@ -101,7 +142,10 @@ __global__ __launch_bounds__(kPcBlock) void pc_init_kernel(int64_t M, Mixture mi
 
 // One pivot step.  Every workgroup first reduces the previous step's block partials (same data, same tree => same pivot
 // everywhere, no grid synchronisation), then fills its rows of column k.
-__global__ __launch_bounds__(kPcBlock) void pc_step_kernel(Cloud pts, Mixture mix, int32_t k, int32_t kmax, double rel_tol,
+// peek != 0: only the reduction of the previous step's partials -- trace[k], pval[k], pivots[k] of the NEXT pivot are recorded, no
+// column is produced and the stop flag is only raised on exhaustion (the per-coordinate merge of gingr_gpmm_build_diagonal looks
+// one pivot ahead before it decides which coordinate advances).
+__global__ __launch_bounds__(kPcBlock) void pc_step_kernel(Cloud pts, KSpec mix, int32_t k, int32_t kmax, double rel_tol,
                                                            int32_t nblocks, double *__restrict__ L /* [kmax][M] */,
                                                            double *__restrict__ diag, int32_t *__restrict__ pivoted,
                                                            const double *__restrict__ pmax_in,
@@ -109,7 +153,8 @@ __global__ __launch_bounds__(kPcBlock) void pc_step_kernel(Cloud pts, Mixture mi
                                                            const double *__restrict__ ptr_in, double *__restrict__ pmax,
                                                            int32_t *__restrict__ pidx, double *__restrict__ ptr,
                                                            int32_t *__restrict__ ctl, double *__restrict__ trace,
-                                                           int32_t *__restrict__ pivots) {
+                                                           int32_t *__restrict__ pivots, double *__restrict__ pval,
+                                                           int32_t peek) {
     __shared__ double T[GINGR_EXP_TABLE];
     __shared__ Best shb[kPcBlock];
     __shared__ double shs[kPcBlock];
@@ -128,9 +173,11 @@ __global__ __launch_bounds__(kPcBlock) void pc_step_kernel(Cloud pts, Mixture mi
     }
     block_best_sum(g, gtr, shb, shs);
     const double tol = rel_tol * trace[0];  // trace[0] was written by step 0 (k == 0 uses gtr itself)
-    const bool stop = k >= kmax || g.i < 0 || !(gtr >= (k == 0 ? rel_tol * gtr : tol)) || !(g.v > 0.0);
+    const bool exhausted = g.i < 0 || !(g.v > 0.0);
+    const bool stop = exhausted || (!peek && (k >= kmax || !(gtr >= (k == 0 ? rel_tol * gtr : tol))));
     if (blockIdx.x == 0 && t == 0) {
         trace[k] = gtr;
+        pval[k] = exhausted ? 0.0 : g.v;
         if (stop) {
             ctl[0] = k;
             ctl[1] = 1;
@@ -138,7 +185,7 @@ __global__ __launch_bounds__(kPcBlock) void pc_step_kernel(Cloud pts, Mixture mi
             pivots[k] = g.i;
         }
     }
-    if (stop) return;
+    if (stop || peek) return;
     const int64_t M = pts.n;
     const int64_t p = g.i;
     const double lpk = sqrt(g.v);
@@ -158,9 +205,7 @@ __global__ __launch_bounds__(kPcBlock) void pc_step_kernel(Cloud pts, Mixture mi
         } else {
             double S = 0.0;
             for (int r = 0; r < k; ++r) S = __dadd_rn(S, __dmul_rn(L[(int64_t)r * M + c], Lp[r]));
-            const double dx = pts.x[c] - px, dy = pts.y[c] - py, dz = pts.z[c] - pz;
-            const double d2 = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
-            l = (mixture_value(mix, d2, T) - S) / lpk;
+            l = (kspec_value(mix, pts, c, p, px, py, pz, T) - S) / lpk;
             const double dc = __dadd_rn(diag[c], -__dmul_rn(l, l));
             diag[c] = dc;
             b = Best{dc, (int32_t)c};
@@ -308,7 +353,7 @@ __global__ __launch_bounds__(256) void lv_kernel(const double *__restrict__ L, i
 
 // Q0[(3s+d)*rp + q] = B_set(q)[idx(q)][row_begin + perm[s]] when coordinate(q) == d, else 0
 __global__ __launch_bounds__(256) void gpmm_pack_kernel(const double *__restrict__ BA, const double *__restrict__ BB,
-                                                        int64_t M_total, int64_t row_begin, int64_t M, int32_t r, int32_t rp,
+                                                        const double *__restrict__ BC, int64_t M_total, int64_t row_begin, int64_t M, int32_t r, int32_t rp,
                                                         const int32_t *__restrict__ perm, const int32_t *__restrict__ qdim,
                                                         const int32_t *__restrict__ qset, const int32_t *__restrict__ qidx,
                                                         double *__restrict__ Q0) {
@@ -321,7 +366,7 @@ __global__ __launch_bounds__(256) void gpmm_pack_kernel(const double *__restrict
     double v = 0.0;
     if (q < r && qdim[q] == d) {
         const int64_t c = row_begin + (perm ? perm[s] : s);
-        v = (qset[q] == 0 ? BA : BB)[(int64_t)qidx[q] * M_total + c];
+        v = (qset[q] == 0 ? BA : (qset[q] == 1 ? BB : BC))[(int64_t)qidx[q] * M_total + c];
     }
     Q0[idx] = v;
 }
@@ -420,118 +465,299 @@ int gingr_pointset_distance_extrema(gingr_ctx *ctx, const double *xyz, int64_t n
     return GINGR_OK;
 }
 
-int gingr_gpmm_build_gaussian(gingr_ctx *ctx, int64_t M_total, const double *ref, int32_t n_kernels, const double *sigmas,
-                              const double *scalings, double relative_tolerance, int32_t max_rank, int64_t row_begin,
-                              int64_t row_end, gingr_model **out) {
+// ---- host side of the construction --------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+// The pivoted Cholesky factor of ONE scalar kernel over the M points, grown on demand.
+struct ScalarFactor {
+    gingr_ctx *ctx = nullptr;
+    KSpec spec{};
+    Cloud pts{};
+    int64_t M = 0;
+    int nb = 0;
+    int32_t kcap = 0;   // columns the buffers can hold
+    int32_t ks = 0;     // columns computed so far
+    int32_t known = -1; // trace / pval / pivots are known on the host for steps 0 .. known
+    bool finished = false;  // the device raised the stop flag (tolerance, capacity or exhaustion) at step `stop_at`
+    int32_t stop_at = 0;
+    DevBuf Lb, diag, piv, part, ctl, trace, pivots, pval;
+    std::vector<double> htrace, hpval;
+    std::vector<int32_t> hpiv;
+    double *pmaxv[2]{}, *ptrv[2]{};
+    int32_t *pidxv[2]{};
+
+    int init(gingr_ctx *c, const KSpec &k, const Cloud &p, int32_t cap) {
+        ctx = c, spec = k, pts = p, M = p.n, kcap = cap;
+        nb = (int)ceil_div(M, kPcBlock);
+        HIP_TRY(ctx, Lb.alloc((size_t)kcap * M * sizeof(double)));
+        HIP_TRY(ctx, diag.alloc((size_t)M * sizeof(double)));
+        HIP_TRY(ctx, piv.alloc((size_t)M * sizeof(int32_t)));
+        HIP_TRY(ctx, part.alloc((size_t)2 * nb * (2 * sizeof(double) + sizeof(int32_t)) + 64));
+        HIP_TRY(ctx, ctl.alloc(2 * sizeof(int32_t)));
+        HIP_TRY(ctx, trace.alloc((size_t)(kcap + 1) * sizeof(double)));
+        HIP_TRY(ctx, pval.alloc((size_t)(kcap + 1) * sizeof(double)));
+        HIP_TRY(ctx, pivots.alloc((size_t)(kcap + 1) * sizeof(int32_t)));
+        pmaxv[0] = part.as<double>(), pmaxv[1] = part.as<double>() + nb;
+        ptrv[0] = part.as<double>() + 2 * nb, ptrv[1] = part.as<double>() + 3 * nb;
+        pidxv[0] = reinterpret_cast<int32_t *>(part.as<double>() + 4 * nb), pidxv[1] = pidxv[0] + nb;
+        hipLaunchKernelGGL(pc_init_kernel, dim3(nb), dim3(kPcBlock), 0, ctx->stream, pts, spec, diag.as<double>(), piv.as<int32_t>(),
+                           pmaxv[0], pidxv[0], ptrv[0], ctl.as<int32_t>());
+        return check(ctx);
+    }
+
+    void launch(int32_t k, double rel_tol, int32_t peek) {
+        const int in = k & 1, o = in ^ 1;
+        hipLaunchKernelGGL(pc_step_kernel, dim3(nb), dim3(kPcBlock), 0, ctx->stream, pts, spec, k, kcap, rel_tol, nb, Lb.as<double>(),
+                           diag.as<double>(), piv.as<int32_t>(), pmaxv[in], pidxv[in], ptrv[in], pmaxv[o], pidxv[o], ptrv[o],
+                           ctl.as<int32_t>(), trace.as<double>(), pivots.as<int32_t>(), pval.as<double>(), peek);
+    }
+
+    int read_back(int32_t upto) {  // steps 0 .. upto
+        htrace.resize((size_t)upto + 1), hpval.resize((size_t)upto + 1), hpiv.resize((size_t)upto + 1);
+        HIP_TRY(ctx, hipMemcpyAsync(htrace.data(), trace.p, htrace.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(hpval.data(), pval.p, hpval.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(hpiv.data(), pivots.p, hpiv.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        known = upto;
+        return GINGR_OK;
+    }
+
+    // the whole factorisation under the scalar stopping rule (one kernel for all three coordinates)
+    int run_to_tolerance(double rel_tol) {
+        int32_t hctl[2] = {0, 0};
+        for (int32_t k = 0; k <= kcap; ++k) {
+            launch(k, rel_tol, 0);
+            if ((k & 15) == 15 || k == kcap) {  // look at the stop flag now and then instead of queueing no-op launches
+                GINGR_TRY(check(ctx));
+                HIP_TRY(ctx, hipMemcpyAsync(hctl, ctl.p, sizeof(hctl), hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                if (hctl[1]) break;
+            }
+        }
+        if (!hctl[1]) return gingr_set_error(ctx, GINGR_ERR_STATE, "gpmm_build: pivoted Cholesky did not terminate");
+        finished = true, stop_at = ks = hctl[0];
+        return read_back(ks);
+    }
+
+    // make trace / pval / pivots of step j known (columns 0 .. j-1 computed, step j peeked); no tolerance: the merge decides
+    int ensure(int32_t j) {
+        if (j <= known) return GINGR_OK;
+        if (finished) return GINGR_OK;  // nothing beyond stop_at will ever exist
+        const int32_t target = std::min<int32_t>(kcap, std::max<int32_t>(j, known + 16));
+        for (int32_t k = ks; k < target; ++k) launch(k, 0.0, 0);
+        launch(target, 0.0, 1);
+        GINGR_TRY(check(ctx));
+        int32_t hctl[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpyAsync(hctl, ctl.p, sizeof(hctl), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (hctl[1]) {
+            finished = true, stop_at = hctl[0];
+            ks = stop_at;
+            return read_back(stop_at);
+        }
+        ks = target;
+        if (target == kcap) finished = true, stop_at = kcap;
+        return read_back(target);
+    }
+};
+
+bool same_kernel(const gingr_scalar_kernel *a, const gingr_scalar_kernel *b) {
+    if (a == b) return true;
+    if (a->kind != b->kind) return false;
+    if (a->kind == GINGR_KERNEL_GAUSSIAN_MIXTURE) {
+        if (a->n_kernels != b->n_kernels || a->mirror != b->mirror) return false;
+        for (int i = 0; i < a->n_kernels; ++i)
+            if (a->sigmas[i] != b->sigmas[i] || a->scalings[i] != b->scalings[i]) return false;
+        return true;
+    }
+    return a->scaling == b->scaling && a->lookup == b->lookup;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gingr_gpmm_build_diagonal(gingr_ctx *ctx, int64_t M_total, const double *ref, const gingr_scalar_kernel *kx,
+                              const gingr_scalar_kernel *ky, const gingr_scalar_kernel *kz, double relative_tolerance,
+                              int32_t max_rank, int64_t row_begin, int64_t row_end, gingr_model **out) {
     if (!ctx || !out) return GINGR_ERR_BAD_ARGUMENT;
     *out = nullptr;
-    if (M_total < 1 || !ref || n_kernels < 1 || n_kernels > kMaxMix || !sigmas || !scalings)
-        return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: need M >= 1 and 1..%d kernels", kMaxMix);
+    if (M_total < 1 || !ref || !kx || !ky || !kz) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: need M >= 1, a reference and three kernels");
     if (!(relative_tolerance >= 0.0) || !(relative_tolerance < 1.0))
         return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: relative tolerance must be in [0, 1)");
-    Mixture mix;
-    memset(&mix, 0, sizeof(mix));
-    mix.n = n_kernels;
-    for (int i = 0; i < n_kernels; ++i) {
-        if (!(sigmas[i] > 0.0) || !(scalings[i] > 0.0) || !std::isfinite(sigmas[i]) || !std::isfinite(scalings[i]))
-            return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: sigma and scaling must be positive");
-        mix.c[i] = -(double)GINGR_EXP_TABLE * 1.4426950408889634074 / (sigmas[i] * sigmas[i]);
-        mix.s[i] = scalings[i];
+    const gingr_scalar_kernel *kd[3] = {kx, ky, kz};
+    // distinct kernels -> factor sets
+    int dim_set[3], nsets = 0;
+    const gingr_scalar_kernel *set_k[3];
+    for (int d = 0; d < 3; ++d) {
+        int s = -1;
+        for (int q = 0; q < nsets; ++q)
+            if (same_kernel(set_k[q], kd[d])) s = q;
+        if (s < 0) set_k[s = nsets++] = kd[d];
+        dim_set[d] = s;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t M = M_total;
+    DevBuf lookups[3];
+    KSpec specs[3];
+    for (int q = 0; q < nsets; ++q) {
+        const gingr_scalar_kernel *k = set_k[q];
+        KSpec &sp = specs[q];
+        memset(&sp, 0, sizeof(sp));
+        sp.kind = k->kind;
+        if (k->kind == GINGR_KERNEL_GAUSSIAN_MIXTURE) {
+            if (k->n_kernels < 1 || k->n_kernels > kMaxMix || !k->sigmas || !k->scalings)
+                return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: need M >= 1 and 1..%d kernels", kMaxMix);
+            if (!(k->mirror == 0.0 || k->mirror == 1.0 || k->mirror == -1.0))
+                return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: mirror must be 0, +1 or -1");
+            sp.mix.n = k->n_kernels;
+            sp.mirror = k->mirror;
+            for (int i = 0; i < k->n_kernels; ++i) {
+                if (!(k->sigmas[i] > 0.0) || !(k->scalings[i] > 0.0) || !std::isfinite(k->sigmas[i]) || !std::isfinite(k->scalings[i]))
+                    return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: sigma and scaling must be positive");
+                sp.mix.c[i] = -(double)GINGR_EXP_TABLE * 1.4426950408889634074 / (k->sigmas[i] * k->sigmas[i]);
+                sp.mix.s[i] = k->scalings[i];
+            }
+        } else if (k->kind == GINGR_KERNEL_DOT || k->kind == GINGR_KERNEL_LOOKUP) {
+            if (!(k->scaling > 0.0) || !std::isfinite(k->scaling))
+                return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: scaling must be positive");
+            sp.scale = k->scaling;
+            if (k->kind == GINGR_KERNEL_LOOKUP) {
+                if (!k->lookup) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: lookup kernel without a matrix");
+                HIP_TRY(ctx, lookups[q].alloc((size_t)M * M * sizeof(double)));
+                HIP_TRY(ctx, hipMemcpyAsync(lookups[q].p, k->lookup, (size_t)M * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+                sp.lookup = lookups[q].as<double>();
+            }
+        } else {
+            return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: unknown kernel kind %d", (int)k->kind);
+        }
     }
     if (max_rank <= 0 || max_rank > 512) max_rank = 512;  // the model's rank limit (gingr_model_upload)
     if ((int64_t)max_rank > 3 * M_total) max_rank = (int32_t)(3 * M_total);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int64_t M = M_total;
-    const int32_t kmax = (int32_t)std::min<int64_t>(M, (max_rank + 2) / 3);  // scalar columns that can ever be needed
-    const int nb = (int)ceil_div(M, kPcBlock);
 
-    DevBuf aos, soa, Lb, diag, piv, part, ctl, trace, pivots;
+    DevBuf aos, soa;
     HIP_TRY(ctx, aos.alloc((size_t)3 * M * sizeof(double)));
     HIP_TRY(ctx, soa.alloc((size_t)3 * M * sizeof(double)));
-    HIP_TRY(ctx, Lb.alloc((size_t)kmax * M * sizeof(double)));
-    HIP_TRY(ctx, diag.alloc((size_t)M * sizeof(double)));
-    HIP_TRY(ctx, piv.alloc((size_t)M * sizeof(int32_t)));
-    HIP_TRY(ctx, part.alloc((size_t)2 * nb * (2 * sizeof(double) + sizeof(int32_t)) + 64));
-    HIP_TRY(ctx, ctl.alloc(2 * sizeof(int32_t)));
-    HIP_TRY(ctx, trace.alloc((size_t)(kmax + 1) * sizeof(double)));
-    HIP_TRY(ctx, pivots.alloc((size_t)(kmax + 1) * sizeof(int32_t)));
     HIP_TRY(ctx, hipMemcpyAsync(aos.p, ref, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     launch_aos_to_soa(ctx, aos.as<double>(), M, soa.as<double>());
-    const double *sp = soa.as<double>();
-    const Cloud pts{sp, sp + M, sp + 2 * M, M};
-    double *pmaxv[2] = {part.as<double>(), part.as<double>() + nb};
-    double *ptrv[2] = {part.as<double>() + 2 * nb, part.as<double>() + 3 * nb};
-    int32_t *pidxv[2] = {reinterpret_cast<int32_t *>(part.as<double>() + 4 * nb),
-                         reinterpret_cast<int32_t *>(part.as<double>() + 4 * nb) + nb};
-    hipLaunchKernelGGL(pc_init_kernel, dim3(nb), dim3(kPcBlock), 0, ctx->stream, M, mix, diag.as<double>(), piv.as<int32_t>(),
-                       pmaxv[0], pidxv[0], ptrv[0], ctl.as<int32_t>());
-    int32_t hctl[2] = {0, 0};
-    for (int32_t k = 0; k <= kmax; ++k) {
-        const int in = k & 1, o = in ^ 1;
-        hipLaunchKernelGGL(pc_step_kernel, dim3(nb), dim3(kPcBlock), 0, ctx->stream, pts, mix, k, kmax, relative_tolerance, nb,
-                           Lb.as<double>(), diag.as<double>(), piv.as<int32_t>(), pmaxv[in], pidxv[in], ptrv[in], pmaxv[o],
-                           pidxv[o], ptrv[o], ctl.as<int32_t>(), trace.as<double>(), pivots.as<int32_t>());
-        if ((k & 15) == 15 || k == kmax) {  // look at the stop flag now and then instead of queueing no-op launches
-            GINGR_TRY(check(ctx));
-            HIP_TRY(ctx, hipMemcpyAsync(hctl, ctl.p, sizeof(hctl), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            if (hctl[1]) break;
+    const double *sp0 = soa.as<double>();
+    const Cloud pts{sp0, sp0 + M, sp0 + 2 * M, M};
+
+    ScalarFactor fac[3];
+    int32_t cnt[3] = {0, 0, 0};  // columns per coordinate
+    int32_t n = 0;               // generic pivots = rank
+    if (nsets == 1) {
+        // one kernel for all coordinates: the generic pivot sequence is (P0,x),(P0,y),(P0,z),(P1,x),... with P0,P1,.. the scalar
+        // pivots; after n = 3j + e pivots the residual trace is (3-e) tr_s(j) + e tr_s(j+1)
+        const int32_t kmax = (int32_t)std::min<int64_t>(M, (max_rank + 2) / 3);  // scalar columns that can ever be needed
+        GINGR_TRY(fac[0].init(ctx, specs[0], pts, kmax));
+        GINGR_TRY(fac[0].run_to_tolerance(relative_tolerance));
+        const int32_t ks = fac[0].ks;
+        if (ks < 1) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: empty model (tolerance too large)");
+        const std::vector<double> &htr = fac[0].htrace;
+        const double tol_g = relative_tolerance * (3.0 * htr[0]);
+        const int32_t nmax = std::min<int32_t>(max_rank, 3 * ks);
+        while (n < nmax) {
+            const int32_t j = n / 3, e = n % 3;
+            const double tr = e == 0 ? 3.0 * htr[(size_t)j] : (3 - e) * htr[(size_t)j] + e * htr[(size_t)j + 1];
+            if (!(tr >= tol_g)) break;
+            ++n;
+        }
+        for (int d = 0; d < 3; ++d) cnt[d] = n / 3 + (d < n % 3 ? 1 : 0);
+    } else {
+        // coordinates with different kernels: every kernel keeps its own scalar factorisation and the generic pivot loop
+        // (argmax of the residual diagonal over all 3M (point, coordinate) indices, stop at relTol * trace) is replayed on the
+        // recorded pivot values and traces, looking one pivot ahead per coordinate
+        const int32_t kcap = (int32_t)std::min<int64_t>(M, max_rank);
+        for (int q = 0; q < nsets; ++q) GINGR_TRY(fac[q].init(ctx, specs[q], pts, kcap));
+        for (int q = 0; q < nsets; ++q) GINGR_TRY(fac[q].ensure(0));
+        double tr0 = 0.0;
+        for (int d = 0; d < 3; ++d) tr0 += fac[dim_set[d]].htrace[0];
+        const double tol_g = relative_tolerance * tr0;
+        // scalismo's loop takes the FIRST maximal residual in its current permuted index order (every step swaps the pivot to
+        // position n).  Between coordinates with the same kernel (y and z of a mirrored kernel) equal values are the rule, and with
+        // irregularly interleaved x pivots the displaced (Q,y) / (Q,z) entries do not keep their order -- so the permutation is
+        // replayed here.  (Ties INSIDE one coordinate are resolved by the device factorisation: lowest point index.)
+        std::vector<int32_t> perm((size_t)3 * M), pos((size_t)3 * M);
+        for (int64_t i = 0; i < 3 * M; ++i) perm[(size_t)i] = pos[(size_t)i] = (int32_t)i;
+        while (n < max_rank) {
+            double tr = 0.0;
+            int best = -1;
+            double bv = 0.0;
+            int64_t bflat = 0;
+            for (int d = 0; d < 3; ++d) {
+                ScalarFactor &f = fac[dim_set[d]];
+                GINGR_TRY(f.ensure(cnt[d]));
+                const int32_t j = cnt[d];
+                if (j > f.known) continue;  // finished before pivot j: this coordinate is exhausted, residual 0
+                tr += f.htrace[(size_t)j];
+                const bool avail = !(f.finished && j >= f.stop_at) && f.hpval[(size_t)j] > 0.0;
+                if (!avail) continue;
+                const double v = f.hpval[(size_t)j];
+                const int64_t flat = 3 * (int64_t)f.hpiv[(size_t)j] + d;
+                if (best < 0 || v > bv || (v == bv && pos[(size_t)flat] < pos[(size_t)bflat])) best = d, bv = v, bflat = flat;
+            }
+            if (!(tr >= tol_g) || best < 0) break;
+            {
+                const int32_t i = pos[(size_t)bflat], a = perm[(size_t)n];
+                perm[(size_t)n] = (int32_t)bflat, perm[(size_t)i] = a;
+                pos[(size_t)bflat] = n, pos[(size_t)a] = i;
+            }
+            ++cnt[best];
+            ++n;
         }
     }
-    if (!hctl[1]) return gingr_set_error(ctx, GINGR_ERR_STATE, "gpmm_build: pivoted Cholesky did not terminate");
-    const int32_t ks = hctl[0];
-    if (ks < 1) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: empty model (tolerance too large)");
-    std::vector<double> htr((size_t)ks + 1);
-    HIP_TRY(ctx, hipMemcpy(htr.data(), trace.p, htr.size() * sizeof(double), hipMemcpyDeviceToHost));
-    // generic (3M-index) stopping rule on the scalar traces: after n = 3j + e pivots tr = (3-e) tr_s(j) + e tr_s(j+1)
-    const double tol_g = relative_tolerance * (3.0 * htr[0]);
-    int32_t n = 0;
-    const int32_t nmax = std::min<int32_t>(max_rank, 3 * ks);
-    while (n < nmax) {
-        const int32_t j = n / 3, e = n % 3;
-        const double tr = e == 0 ? 3.0 * htr[(size_t)j] : (3 - e) * htr[(size_t)j] + e * htr[(size_t)j + 1];
-        if (!(tr >= tol_g)) break;
-        ++n;
-    }
     if (n < 1) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: empty model (tolerance too large)");
-    const int32_t j = n / 3, e = n % 3;
-    const int32_t nA = e ? j + 1 : 0, nB = j;  // coordinates d < e own nA scalar columns, the others nB
-    const int32_t kk = std::max(nA, nB);
 
-    // Gram of the scalar factor and the eigen-decompositions of its leading blocks
-    DevBuf G, wA, wV, evA, evB, VA, VB, BA, BB, sw;
-    HIP_TRY(ctx, G.alloc((size_t)kk * kk * sizeof(double)));
-    HIP_TRY(ctx, wA.alloc((size_t)kk * kk * sizeof(double)));
-    HIP_TRY(ctx, wV.alloc((size_t)kk * kk * sizeof(double)));
-    HIP_TRY(ctx, evA.alloc((size_t)(nA + 1) * sizeof(double)));
-    HIP_TRY(ctx, evB.alloc((size_t)(nB + 1) * sizeof(double)));
-    HIP_TRY(ctx, VA.alloc((size_t)(nA * nA + 1) * sizeof(double)));
-    HIP_TRY(ctx, VB.alloc((size_t)(nB * nB + 1) * sizeof(double)));
-    HIP_TRY(ctx, BA.alloc(((size_t)nA * M + 1) * sizeof(double)));
-    HIP_TRY(ctx, BB.alloc(((size_t)nB * M + 1) * sizeof(double)));
-    HIP_TRY(ctx, sw.alloc(2 * sizeof(int32_t)));
-    HIP_TRY(ctx, hipMemsetAsync(sw.p, 0, 2 * sizeof(int32_t), ctx->stream));
-    hipLaunchKernelGGL(pc_gram_kernel, dim3(kk, kk), dim3(kPcBlock), 0, ctx->stream, Lb.as<double>(), M, kk, G.as<double>());
-    if (nA) {
-        hipLaunchKernelGGL(jacobi_eig_kernel, dim3(1), dim3(kJacThreads), 0, ctx->stream, G.as<double>(), kk, nA, wA.as<double>(),
-                           wV.as<double>(), evA.as<double>(), VA.as<double>(), sw.as<int32_t>());
-        hipLaunchKernelGGL(lv_kernel, dim3((unsigned)ceil_div(M, 256), nA), dim3(256), 0, ctx->stream, Lb.as<double>(), M, nA,
-                           VA.as<double>(), BA.as<double>());
+    // blocks = distinct (kernel, column count) among the coordinates; eigen-decomposition of L_s[:, :count]^T L_s[:, :count]
+    int dim_block[3] = {-1, -1, -1}, nblocks = 0, block_set[3] = {0, 0, 0};
+    int32_t block_n[3] = {0, 0, 0};
+    for (int d = 0; d < 3; ++d) {
+        if (cnt[d] == 0) continue;
+        int b = -1;
+        for (int q = 0; q < nblocks; ++q)
+            if (block_set[q] == dim_set[d] && block_n[q] == cnt[d]) b = q;
+        if (b < 0) b = nblocks++, block_set[b] = dim_set[d], block_n[b] = cnt[d];
+        dim_block[d] = b;
     }
-    if (nB) {
-        hipLaunchKernelGGL(jacobi_eig_kernel, dim3(1), dim3(kJacThreads), 0, ctx->stream, G.as<double>(), kk, nB, wA.as<double>(),
-                           wV.as<double>(), evB.as<double>(), VB.as<double>(), sw.as<int32_t>() + 1);
-        hipLaunchKernelGGL(lv_kernel, dim3((unsigned)ceil_div(M, 256), nB), dim3(256), 0, ctx->stream, Lb.as<double>(), M, nB,
-                           VB.as<double>(), BB.as<double>());
+    DevBuf G[3], wA, wV, ev[3], V[3], B[3], sw;
+    int32_t kkmax = 0;
+    for (int b = 0; b < nblocks; ++b) kkmax = std::max(kkmax, block_n[b]);
+    HIP_TRY(ctx, wA.alloc((size_t)kkmax * kkmax * sizeof(double)));
+    HIP_TRY(ctx, wV.alloc((size_t)kkmax * kkmax * sizeof(double)));
+    HIP_TRY(ctx, sw.alloc(4 * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMemsetAsync(sw.p, 0, 4 * sizeof(int32_t), ctx->stream));
+    int32_t set_kk[3] = {0, 0, 0};
+    for (int b = 0; b < nblocks; ++b) set_kk[block_set[b]] = std::max(set_kk[block_set[b]], block_n[b]);
+    for (int q = 0; q < nsets; ++q) {
+        if (!set_kk[q]) continue;
+        HIP_TRY(ctx, G[q].alloc((size_t)set_kk[q] * set_kk[q] * sizeof(double)));
+        hipLaunchKernelGGL(pc_gram_kernel, dim3(set_kk[q], set_kk[q]), dim3(kPcBlock), 0, ctx->stream, fac[q].Lb.as<double>(), M,
+                           set_kk[q], G[q].as<double>());
+    }
+    std::vector<double> hev[3];
+    for (int b = 0; b < nblocks; ++b) {
+        const int32_t nb_ = block_n[b];
+        const int q = block_set[b];
+        HIP_TRY(ctx, ev[b].alloc((size_t)(nb_ + 1) * sizeof(double)));
+        HIP_TRY(ctx, V[b].alloc((size_t)(nb_ * nb_ + 1) * sizeof(double)));
+        HIP_TRY(ctx, B[b].alloc(((size_t)nb_ * M + 1) * sizeof(double)));
+        hipLaunchKernelGGL(jacobi_eig_kernel, dim3(1), dim3(kJacThreads), 0, ctx->stream, G[q].as<double>(), set_kk[q], nb_,
+                           wA.as<double>(), wV.as<double>(), ev[b].as<double>(), V[b].as<double>(), sw.as<int32_t>() + b);
+        hipLaunchKernelGGL(lv_kernel, dim3((unsigned)ceil_div(M, 256), nb_), dim3(256), 0, ctx->stream, fac[q].Lb.as<double>(), M, nb_,
+                           V[b].as<double>(), B[b].as<double>());
+        hev[b].resize((size_t)nb_);
     }
     GINGR_TRY(check(ctx));
-    std::vector<double> hA((size_t)nA + 1), hB((size_t)nB + 1);
-    int32_t hsw[2] = {0, 0};
-    HIP_TRY(ctx, hipMemcpyAsync(hA.data(), evA.p, (size_t)nA * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(hB.data(), evB.p, (size_t)nB * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    int32_t hsw[4] = {0, 0, 0, 0};
+    for (int b = 0; b < nblocks; ++b)
+        HIP_TRY(ctx, hipMemcpyAsync(hev[b].data(), ev[b].p, hev[b].size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(hsw, sw.p, sizeof(hsw), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (hsw[0] >= 60 || hsw[1] >= 60) return gingr_set_error(ctx, GINGR_ERR_NONFINITE, "gpmm_build: Jacobi did not converge");
+    for (int b = 0; b < nblocks; ++b)
+        if (hsw[b] >= 60) return gingr_set_error(ctx, GINGR_ERR_NONFINITE, "gpmm_build: Jacobi did not converge");
 
     // merged eigenpairs, descending; equal eigenvalues keep coordinate order (x, y, z)
     struct Col {
@@ -539,11 +765,8 @@ int gingr_gpmm_build_gaussian(gingr_ctx *ctx, int64_t M_total, const double *ref
         int32_t dim, set, idx;
     };
     std::vector<Col> cols;
-    for (int d = 0; d < 3; ++d) {
-        const bool a = d < e;
-        const int32_t cnt = a ? nA : nB;
-        for (int32_t i = 0; i < cnt; ++i) cols.push_back(Col{a ? hA[(size_t)i] : hB[(size_t)i], d, a ? 0 : 1, i});
-    }
+    for (int d = 0; d < 3; ++d)
+        for (int32_t i = 0; i < cnt[d]; ++i) cols.push_back(Col{hev[dim_block[d]][(size_t)i], d, dim_block[d], i});
     std::stable_sort(cols.begin(), cols.end(), [](const Col &x, const Col &y) {
         if (x.lam != y.lam) return x.lam > y.lam;
         if (x.idx != y.idx) return x.idx < y.idx;
@@ -566,12 +789,25 @@ int gingr_gpmm_build_gaussian(gingr_ctx *ctx, int64_t M_total, const double *ref
     std::vector<double> zero_mean((size_t)3 * M_total, 0.0);
     auto fill = [&](gingr_model *m) -> int {
         const int64_t total = 3 * m->M * m->rp;
-        hipLaunchKernelGGL(gpmm_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, BA.as<double>(),
-                           BB.as<double>(), M_total, m->row_begin, m->M, m->r, m->rp, m->perm, dq.as<int32_t>(),
+        hipLaunchKernelGGL(gpmm_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, B[0].as<double>(),
+                           B[1].as<double>(), B[2].as<double>(), M_total, m->row_begin, m->M, m->r, m->rp, m->perm, dq.as<int32_t>(),
                            dq.as<int32_t>() + rank, dq.as<int32_t>() + 2 * rank, m->Q0);
         return check(ctx);
     };
     return model_create_impl(ctx, M_total, rank, ref, zero_mean.data(), variance.data(), row_begin, row_end, fill, out);
+}
+
+int gingr_gpmm_build_gaussian(gingr_ctx *ctx, int64_t M_total, const double *ref, int32_t n_kernels, const double *sigmas,
+                              const double *scalings, double relative_tolerance, int32_t max_rank, int64_t row_begin,
+                              int64_t row_end, gingr_model **out) {
+    if (!ctx || !out) return GINGR_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    if (M_total < 1 || !ref || n_kernels < 1 || n_kernels > kMaxMix || !sigmas || !scalings)
+        return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: need M >= 1 and 1..%d kernels", kMaxMix);
+    gingr_scalar_kernel k;
+    memset(&k, 0, sizeof(k));
+    k.kind = GINGR_KERNEL_GAUSSIAN_MIXTURE, k.n_kernels = n_kernels, k.sigmas = sigmas, k.scalings = scalings;
+    return gingr_gpmm_build_diagonal(ctx, M_total, ref, &k, &k, &k, relative_tolerance, max_rank, row_begin, row_end, out);
 }
 
 int gingr_model_download(gingr_ctx *ctx, const gingr_model *m, double *ref, double *mean, double *basis_colmajor,

@@ -16,7 +16,7 @@ from typing import Callable, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .api import (Context, CpdConfiguration, CpdRegistration, DeviceModel, EulerAngles, FittingStatuses, GeneralRegistrationState,
+from .api import (GPMMTriangleMesh3D, Context, CpdConfiguration, CpdRegistration, DeviceModel, EulerAngles, FittingStatuses, GeneralRegistrationState,
                   GlobalTranformationType, IcpConfiguration, IcpRegistration, ModelFittingParameters, PointDistributionModel, f64)
 from . import io as gio
 from .sampling import (IndependentPoints, JSONStateLogger, ModelToTargetEvaluation, ProbabilisticSettings, Random,
@@ -263,3 +263,85 @@ class GingrInterface:
 
     def ICP(self, config: IcpConfiguration) -> SimpleRegistrator:
         return SimpleRegistrator(IcpRegistration(self.ctx), config, **self._kw)
+
+
+# ------------------------------------------------------------------------------------------------ SimpleModels
+@dataclasses.dataclass(frozen=True)
+class InvLapKernel:
+    scaling: float
+    name = "InvLap"
+
+    @property
+    def printpars(self) -> str:
+        return str(self.scaling)
+
+
+@dataclasses.dataclass(frozen=True)
+class InvLapDotKernel:
+    scaling: float
+    gamma: float
+    name = "InvLapDot"
+
+    @property
+    def printpars(self) -> str:
+        return f"{self.scaling}_{self.gamma}"
+
+
+@dataclasses.dataclass(frozen=True)
+class GaussKernel:
+    scaling: float
+    sigma: float
+    name = "Gauss"
+
+    @property
+    def printpars(self) -> str:
+        return f"{self.scaling}_{self.sigma}"
+
+
+@dataclasses.dataclass(frozen=True)
+class GaussMixKernel:
+    name = "GaussMix"
+    printpars = ""
+
+
+@dataclasses.dataclass(frozen=True)
+class GaussDotKernel:
+    scaling: float
+    sigma: float
+    name = "GaussDot"
+
+    @property
+    def printpars(self) -> str:
+        return f"{self.scaling}_{self.sigma}"
+
+
+@dataclasses.dataclass(frozen=True)
+class GaussMirrorKernel:
+    scaling: float
+    sigma: float
+    name = "GaussMirror"
+
+    @property
+    def printpars(self) -> str:
+        return f"{self.scaling}_{self.sigma}"
+
+
+class SimpleTriangleModels3D:
+    """G/simple/SimpleModels.scala:52-75: one call from a kernel choice to a model, built in HBM."""
+
+    @staticmethod
+    def create(ctx: Context, reference: TriangleMesh3D, kernelSelect, relativeTolerance: float = 0.01, maxRank: int = 0):
+        g = GPMMTriangleMesh3D(ctx, reference.points, relativeTolerance=relativeTolerance, maxRank=maxRank, cells=reference.cells)
+        if isinstance(kernelSelect, InvLapKernel):
+            return g.InverseLaplacian(scaling=kernelSelect.scaling)
+        if isinstance(kernelSelect, InvLapDotKernel):
+            return g.InverseLaplacianDot(scaling=kernelSelect.scaling, gamma=kernelSelect.gamma)
+        if isinstance(kernelSelect, GaussKernel):
+            return g.Gaussian(sigma=kernelSelect.sigma, scaling=kernelSelect.scaling)
+        if isinstance(kernelSelect, GaussMixKernel):
+            return g.AutomaticGaussian()
+        if isinstance(kernelSelect, GaussDotKernel):
+            return g.GaussianDot(sigma=kernelSelect.sigma, scaling=kernelSelect.scaling)
+        if isinstance(kernelSelect, GaussMirrorKernel):
+            return g.GaussianSymmetry(sigma=kernelSelect.sigma, scaling=kernelSelect.scaling)
+        raise TypeError(f"unknown kernel choice {kernelSelect!r}")

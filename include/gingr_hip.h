@@ -132,6 +132,33 @@ int gingr_model_finalize(gingr_ctx *ctx, gingr_model *model);
 int gingr_gpmm_build_gaussian(gingr_ctx *ctx, int64_t M_total, const double *ref, int32_t n_kernels, const double *sigmas,
                               const double *scalings, double relative_tolerance, int32_t max_rank, int64_t row_begin,
                               int64_t row_end, gingr_model **out);
+/* The other kernels of GPMMTriangleMesh3D (G/api/gpmm/GPMMHelper.scala:96-142) and gingr.simple.SimpleTriangleModels3D.create
+ * (G/simple/SimpleModels.scala:52-75): a DiagonalKernel with one scalar kernel per coordinate,
+ *   GINGR_KERNEL_GAUSSIAN_MIXTURE  sum_i scalings[i] exp(-|x-y|^2 / sigmas[i]^2), plus mirror * the same kernel evaluated at
+ *                                  (diag(-1,1,1) x, y) when mirror = +-1 -- KernelHelper.symmetrizeKernel (KernelHelper.scala:25-38):
+ *                                  GaussianSymmetry = (mirror -1 for x, +1 for y and z)
+ *   GINGR_KERNEL_DOT               scaling * (x . y) -- DotProductKernel.k returns x.dot(y) whatever kernel / gamma it wraps
+ *                                  (KernelHelper.scala:40-51): GaussianDot(sigma, scaling), InverseLaplacianDot(scaling, gamma)
+ *   GINGR_KERNEL_LOOKUP            scaling * lookup[i * M_total + j] -- LookupKernel(reference, m) on the reference points
+ *                                  (KernelHelper.scala:76-84), m = pinv(graph Laplacian) for InverseLaplacian (host array)
+ * Coordinates whose kernels are equal share one scalar pivoted Cholesky; the generic pivot order over the 3M (point, coordinate)
+ * indices and the relTol * trace stopping rule are replayed across the coordinates.  kx / ky / kz may be the same pointer.
+ * gingr_gpmm_build_gaussian(..) == gingr_gpmm_build_diagonal with the same mixture (mirror 0) three times. */
+#define GINGR_KERNEL_GAUSSIAN_MIXTURE 0
+#define GINGR_KERNEL_DOT 1
+#define GINGR_KERNEL_LOOKUP 2
+typedef struct gingr_scalar_kernel {
+    int32_t kind;
+    int32_t n_kernels;       /* mixture */
+    const double *sigmas;    /* mixture, host */
+    const double *scalings;  /* mixture, host */
+    double mirror;           /* mixture: 0, +1 or -1 */
+    double scaling;          /* dot / lookup */
+    const double *lookup;    /* lookup: host, M_total x M_total row-major */
+} gingr_scalar_kernel;
+int gingr_gpmm_build_diagonal(gingr_ctx *ctx, int64_t M_total, const double *ref, const gingr_scalar_kernel *kx,
+                              const gingr_scalar_kernel *ky, const gingr_scalar_kernel *kz, double relative_tolerance,
+                              int32_t max_rank, int64_t row_begin, int64_t row_end, gingr_model **out);
 /* PointSetHelper.maximumPointDistance / minimumPointDistance (GPMMHelper.scala:75-87; the O(n^2) scans behind
  * AutomaticGaussian and automaticGPMMfromTemplate): largest pairwise distance, smallest distance to the nearest OTHER point. */
 int gingr_pointset_distance_extrema(gingr_ctx *ctx, const double *xyz, int64_t n, double *max_distance, double *min_distance);

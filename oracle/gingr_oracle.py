@@ -680,15 +680,18 @@ def gaussian_mixture_kernel(A: np.ndarray, B: np.ndarray, sigmas: Sequence[float
     return out
 
 
-def pivoted_cholesky_matrix_valued(points: np.ndarray, sigmas: Sequence[float], scalings: Sequence[float],
-                                   rel_tol: float, max_cols: Optional[int] = None, return_pivots: bool = False):
-    """L (3M x k) of DiagonalKernel(mixture, 3) over xs = [(point i, coordinate d)] in point-major order."""
-    P = np.asarray(points, dtype=np.float64)
-    M = P.shape[0]
+def pivoted_cholesky_diagonal_kernel(n_points: int, kfun, rel_tol: float, max_cols: Optional[int] = None,
+                                     return_pivots: bool = False):
+    """[SCALISMO PivotedCholesky.computeApproximateCholesky, generic over the 3M (point, coordinate) indices in point-major
+    order] for a DiagonalKernel(k_0, k_1, k_2): kfun(d, rows, j) -> k_d(point rows[i], point j) as a vector.  Coordinates never
+    interact; the pivot is the first maximal residual diagonal in the current permuted order; stops when the residual trace falls
+    below rel_tol * trace."""
+    M = int(n_points)
     n = 3 * M
     p = np.arange(n)
-    d = np.full(n, float(sum(float(s) for s in scalings)))
-    d[:] = gaussian_mixture_kernel(P[:1], P[:1], sigmas, scalings)[0, 0]
+    d = np.empty(n)
+    for dim in range(3):
+        d[dim::3] = np.array([kfun(dim, np.array([i]), i)[0] for i in range(M)])
     tr = float(d.sum())
     tol = rel_tol * tr
     cols: List[np.ndarray] = []
@@ -707,7 +710,7 @@ def pivoted_cholesky_matrix_valued(points: np.ndarray, sigmas: Sequence[float], 
         same = (rest % 3) == (pk % 3)
         kv = np.zeros(rest.shape[0])
         if same.any():
-            kv[same] = gaussian_mixture_kernel(P[rest[same] // 3], P[pk // 3:pk // 3 + 1], sigmas, scalings)[:, 0]
+            kv[same] = kfun(pk % 3, rest[same] // 3, pk // 3)
         col[rest] = (kv - S) / col[pk]
         d[rest] = d[rest] - col[rest] * col[rest]
         tr = float(d[rest].sum())
@@ -715,6 +718,66 @@ def pivoted_cholesky_matrix_valued(points: np.ndarray, sigmas: Sequence[float], 
         k += 1
     L = np.stack(cols, axis=1) if cols else np.zeros((n, 0))
     return (L, [int(v) for v in p[:k]]) if return_pivots else L
+
+
+def pivoted_cholesky_matrix_valued(points: np.ndarray, sigmas: Sequence[float], scalings: Sequence[float],
+                                   rel_tol: float, max_cols: Optional[int] = None, return_pivots: bool = False):
+    """L (3M x k) of DiagonalKernel(mixture, 3) over xs = [(point i, coordinate d)] in point-major order."""
+    P = np.asarray(points, dtype=np.float64)
+    return pivoted_cholesky_diagonal_kernel(
+        P.shape[0], lambda dim, rows, j: gaussian_mixture_kernel(P[rows], P[j:j + 1], sigmas, scalings)[:, 0], rel_tol, max_cols,
+        return_pivots)
+
+
+# the other kernels of GPMMTriangleMesh3D (G/api/gpmm/GPMMHelper.scala:103-142, KernelHelper.scala, LaplacianHelper.scala)
+def dot_kernel_fun(points: np.ndarray, scaling: float):
+    """DotProductKernel(kernel, gamma) * scaling: k(x, y) = x.dot(y) -- the wrapped kernel and gamma are ignored by the
+    reference (KernelHelper.scala:43-51); in-order unfused products."""
+    P = np.asarray(points, dtype=np.float64)
+    return lambda dim, rows, j: (P[rows, 0] * P[j, 0] + P[rows, 1] * P[j, 1] + P[rows, 2] * P[j, 2]) * scaling
+
+
+def symmetric_gauss_kernel_fun(points: np.ndarray, sigma: float, scaling: float):
+    """KernelHelper.symmetrizeKernel(GaussianKernel(sigma) * scaling) (:25-38): DiagonalKernel(k, 3) + DiagonalKernel(-km, km, km),
+    km(x, y) = k((-x0, x1, x2), y)."""
+    P = np.asarray(points, dtype=np.float64)
+    Pm = P * np.array([-1.0, 1.0, 1.0])
+
+    def f(dim, rows, j):
+        k = gaussian_mixture_kernel(P[rows], P[j:j + 1], [sigma], [scaling])[:, 0]
+        km = gaussian_mixture_kernel(Pm[rows], P[j:j + 1], [sigma], [scaling])[:, 0]
+        return k + (km * -1.0 if dim == 0 else km)
+    return f
+
+
+def graph_laplacian(n: int, cells: np.ndarray) -> np.ndarray:
+    """LaplacianHelper.laplacianMatrix (LaplacianHelper.scala:33-40): degree on the diagonal, -1 between adjacent vertices."""
+    m = np.zeros((n, n))
+    c = np.asarray(cells, dtype=np.int64)
+    for a, b in ((0, 1), (1, 2), (0, 2)):
+        m[c[:, a], c[:, b]] = -1.0
+        m[c[:, b], c[:, a]] = -1.0
+    np.fill_diagonal(m, 0.0)
+    np.fill_diagonal(m, -m.sum(axis=1))
+    return m
+
+
+def pinv_svd(m: np.ndarray, precision: float = 0.00001) -> np.ndarray:
+    """MatrixHelper.pinv (MatrixHelper.scala:21-26)"""
+    u, sv, vt = np.linalg.svd(m)
+    return u @ np.diag([1.0 / v if v > precision else 0.0 for v in sv]) @ vt
+
+
+def lookup_kernel_fun(m: np.ndarray, scaling: float):
+    """LookupKernel(reference, m) * scaling on the reference points themselves (KernelHelper.scala:76-84)."""
+    return lambda dim, rows, j: m[rows, j] * scaling
+
+
+def build_gpmm_diagonal(ref: np.ndarray, kfun, rel_tol: float = 0.01, max_rank: Optional[int] = None) -> PDM:
+    ref = np.asarray(ref, dtype=np.float64)
+    L = pivoted_cholesky_diagonal_kernel(ref.shape[0], kfun, rel_tol, max_rank)
+    U, lam = approximate_eig(L)
+    return PDM(ref=ref, mean=np.zeros_like(ref), U=np.ascontiguousarray(U), lam=lam)
 
 
 def approximate_eig(L: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
