@@ -146,6 +146,18 @@ class Context:
                "gingr_mesh_distance_stats")
         return float(out[0]), float(out[1]), int(out[2]), float(out[3])
 
+    def mesh_closest_points(self, points, vertices, cells) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+        """mesh.operations.closestPointOnSurface for every row of `points`: (closest points (n,3), squared distances (n,), triangle
+        ids (n,), barycentric weights of that triangle's corners (n,3)) -- gingr_mesh_closest_points."""
+        p, v = f64(points).reshape(-1, 3), f64(vertices).reshape(-1, 3)
+        c = np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, 3)
+        n = p.shape[0]
+        cp, d2, tid, bary = np.empty((n, 3)), np.empty(n), np.empty(n, dtype=np.int32), np.empty((n, 3))
+        _check(self.handle, self._lib.gingr_mesh_closest_points(self.handle, n, dptr(p), v.shape[0], dptr(v), c.shape[0], iptr(c),
+                                                                dptr(cp), dptr(d2), iptr(tid), dptr(bary)),
+               "gingr_mesh_closest_points")
+        return cp, d2, tid, bary
+
 
 # ----------------------------------------------------------------------------- model
 @dataclasses.dataclass
@@ -262,6 +274,38 @@ class DevicePointDistributionModel:
     @property
     def basis(self) -> np.ndarray:
         return self.to_host(basis=True).basis
+
+
+class InterpolatedDevicePointDistributionModel(DevicePointDistributionModel):
+    """model.newReference(newReference, interpolator) with the basis gathered in HBM (gingr_model_new_reference): every new point
+    takes the fixed combination sum_k weights[i, k] * (value at source point vertex_ids[i, k]) of mean and basis functions;
+    eigenvalues and rank are the source's."""
+
+    def __init__(self, ctx: Context, source, new_reference, vertex_ids, weights, cells=None):
+        self.ctx = ctx
+        self.reference = f64(new_reference).reshape(-1, 3)
+        self._ids = np.ascontiguousarray(vertex_ids, dtype=np.int32).reshape(-1, 3)
+        self._w = f64(weights).reshape(-1, 3)
+        if self._ids.shape[0] != self.reference.shape[0] or self._w.shape[0] != self.reference.shape[0]:
+            raise ValueError("one (vertex_ids, weights) triple per new reference point")
+        self._source = source
+        # the source model resident on this context (a device-built model shares its handle; a host model is uploaded once)
+        self._src_dev = DeviceModel(ctx, source)
+        self.cells = None if cells is None else np.ascontiguousarray(cells, dtype=np.int32)
+        self._kernels, self._full, self._host = None, None, None
+
+    def _build(self, ctx: Context, row_begin: int, row_end: int):
+        if ctx is not self.ctx:
+            raise ValueError("an interpolated model lives on the context of its source; download it (to_host) for another device")
+        h = c_void_p()
+        _check(ctx.handle, ctx._lib.gingr_model_new_reference(ctx.handle, self._src_dev.handle, self.numberOfPoints, dptr(self.reference),
+                                                              iptr(self._ids), dptr(self._w), row_begin, row_end, ctypes.byref(h)),
+               "gingr_model_new_reference")
+        return h
+
+    @property
+    def mean(self) -> np.ndarray:
+        return self.to_host(basis=False).mean
 
 
 @dataclasses.dataclass

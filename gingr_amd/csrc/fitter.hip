@@ -1633,4 +1633,116 @@ int gingr_mesh_distance_stats(gingr_ctx *ctx, int64_t n_points, const double *po
                               boundary_aware ? dbnd.as<int32_t>() : nullptr, sdev, sc, out);
 }
 
+int gingr_mesh_closest_points(gingr_ctx *ctx, int64_t n_points, const double *points, int64_t n_vertices, const double *vertices,
+                              int64_t n_triangles, const int32_t *triangles, double *cp_xyz, double *d2, int32_t *tri_id,
+                              double *bary) {
+    if (!ctx) return GINGR_ERR_BAD_ARGUMENT;
+    if (!points || !vertices || !triangles || n_points < 1 || n_vertices < 1 || n_triangles < 1 || n_vertices > INT32_MAX ||
+        n_triangles > INT32_MAX || n_points > INT32_MAX)
+        return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "mesh_closest_points: bad argument");
+    for (int64_t k = 0; k < 3 * n_triangles; ++k)
+        if (triangles[k] < 0 || triangles[k] >= n_vertices)
+            return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "mesh_closest_points: vertex id out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<int32_t> qorder, vorder, torder;
+    morton_order(points, n_points, qorder);
+    morton_order(vertices, n_vertices, vorder);
+    std::vector<int32_t> vinv((size_t)n_vertices);
+    for (int64_t s2 = 0; s2 < n_vertices; ++s2) vinv[(size_t)vorder[(size_t)s2]] = (int32_t)s2;
+    std::vector<double> cen((size_t)3 * n_triangles);
+    for (int64_t t = 0; t < n_triangles; ++t)
+        for (int d = 0; d < 3; ++d) {
+            double c = 0.0;
+            for (int k = 0; k < 3; ++k) c += vertices[(size_t)3 * triangles[3 * t + k] + d];
+            cen[(size_t)3 * t + d] = c / 3.0;
+        }
+    morton_order(cen.data(), n_triangles, torder);
+    std::vector<int32_t> tri((size_t)3 * n_triangles), tri_by_orig((size_t)3 * n_triangles);
+    for (int64_t s2 = 0; s2 < n_triangles; ++s2)
+        for (int k = 0; k < 3; ++k) tri[(size_t)3 * s2 + k] = vinv[(size_t)triangles[(size_t)3 * torder[(size_t)s2] + k]];
+    for (int64_t k = 0; k < 3 * n_triangles; ++k) tri_by_orig[(size_t)k] = vinv[(size_t)triangles[(size_t)k]];
+    std::vector<double> qsoa, vsoa;
+    gather_soa(points, qorder, qsoa);
+    gather_soa(vertices, vorder, vsoa);
+    const int64_t ntiles = ceil_div(n_triangles, 256);
+    DevBuf dq, dv, dtri, dorig, dtb, dcp, dd2, dtid, dtbo, dbary;
+    HIP_TRY(ctx, dq.alloc(qsoa.size() * sizeof(double)));
+    HIP_TRY(ctx, dv.alloc(vsoa.size() * sizeof(double)));
+    HIP_TRY(ctx, dtri.alloc(tri.size() * sizeof(int32_t)));
+    HIP_TRY(ctx, dtbo.alloc(tri.size() * sizeof(int32_t)));
+    HIP_TRY(ctx, dorig.alloc(torder.size() * sizeof(int32_t)));
+    HIP_TRY(ctx, dtb.alloc((size_t)30 * ntiles * sizeof(double)));
+    HIP_TRY(ctx, dcp.alloc((size_t)3 * n_points * sizeof(double)));
+    HIP_TRY(ctx, dd2.alloc((size_t)n_points * sizeof(double)));
+    HIP_TRY(ctx, dtid.alloc((size_t)n_points * sizeof(int32_t)));
+    HIP_TRY(ctx, dbary.alloc((size_t)3 * n_points * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpyAsync(dq.p, qsoa.data(), qsoa.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dv.p, vsoa.data(), vsoa.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dtri.p, tri.data(), tri.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dtbo.p, tri_by_orig.data(), tri.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dorig.p, torder.data(), torder.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    const Cloud q = cloud_of(dq.as<double>(), n_points), v = cloud_of(dv.as<double>(), n_vertices);
+    launch_tri_tile_bbox(ctx, v, dtri.as<int32_t>(), n_triangles, dtb.as<double>());
+    launch_surface_closest_point(ctx, q, v, dtri.as<int32_t>(), dorig.as<int32_t>(), n_triangles, dtb.as<double>(), dcp.as<double>(),
+                                 dd2.as<double>(), dtid.as<int32_t>());
+    launch_barycentric(ctx, q, v, dtbo.as<int32_t>(), dtid.as<int32_t>(), dbary.as<double>());
+    GINGR_TRY(check_launch(ctx));
+    std::vector<double> hcp((size_t)3 * n_points), hd2((size_t)n_points), hb((size_t)3 * n_points);
+    std::vector<int32_t> ht((size_t)n_points);
+    HIP_TRY(ctx, hipMemcpyAsync(hcp.data(), dcp.p, hcp.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(hd2.data(), dd2.p, hd2.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(hb.data(), dbary.p, hb.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ht.data(), dtid.p, ht.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t s2 = 0; s2 < n_points; ++s2) {  // device position -> input index
+        const size_t o = (size_t)qorder[(size_t)s2];
+        if (cp_xyz)
+            for (int d = 0; d < 3; ++d) cp_xyz[3 * o + d] = hcp[(size_t)d * n_points + s2];
+        if (d2) d2[o] = hd2[(size_t)s2];
+        if (tri_id) tri_id[o] = ht[(size_t)s2];
+        if (bary)
+            for (int d = 0; d < 3; ++d) bary[3 * o + d] = hb[(size_t)3 * s2 + d];
+    }
+    return GINGR_OK;
+}
+
+int gingr_model_new_reference(gingr_ctx *ctx, const gingr_model *src, int64_t M_new, const double *new_ref,
+                              const int32_t *vertex_ids, const double *weights, int64_t row_begin, int64_t row_end,
+                              gingr_model **out) {
+    if (!ctx || !out) return GINGR_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    if (!src || !new_ref || !vertex_ids || !weights || M_new < 1)
+        return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "model_new_reference: bad argument");
+    if (src->ctx != ctx || src->row_begin != 0 || src->row_end != src->M_total)
+        return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "model_new_reference: the source must be a complete model of this context");
+    const int64_t Ms = src->M;
+    for (int64_t k = 0; k < 3 * M_new; ++k)
+        if (vertex_ids[k] < 0 || vertex_ids[k] >= Ms)
+            return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "model_new_reference: source vertex id out of range");
+    if (row_end <= 0) row_end = M_new;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // mean displacement of the new points (host: 3 M_new values)
+    std::vector<double> smean((size_t)3 * Ms), nmean((size_t)3 * M_new);
+    GINGR_TRY(gingr_model_download(ctx, src, nullptr, smean.data(), nullptr, nullptr));
+    for (int64_t i = 0; i < M_new; ++i)
+        for (int d = 0; d < 3; ++d) {
+            double acc = 0.0;
+            for (int k = 0; k < 3; ++k) acc += weights[3 * i + k] * smean[(size_t)3 * vertex_ids[3 * i + k] + d];
+            nmean[(size_t)3 * i + d] = acc;
+        }
+    DevBuf dids, dw, dinv;
+    HIP_TRY(ctx, dids.alloc((size_t)3 * M_new * sizeof(int32_t)));
+    HIP_TRY(ctx, dw.alloc((size_t)3 * M_new * sizeof(double)));
+    HIP_TRY(ctx, dinv.alloc((size_t)Ms * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMemcpyAsync(dids.p, vertex_ids, (size_t)3 * M_new * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dw.p, weights, (size_t)3 * M_new * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dinv.p, src->hiperm.data(), (size_t)Ms * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    auto fill = [&](gingr_model *m) -> int {
+        launch_interp_pack(ctx, src->Q0, src->rp, dinv.as<int32_t>(), dids.as<int32_t>(), dw.as<double>(), m->perm, m->row_begin, m->M,
+                           m->Q0);
+        return check_launch(ctx);
+    };
+    return model_create_impl(ctx, M_new, src->r, new_ref, nmean.data(), src->variance.data(), row_begin, row_end, fill, out);
+}
+
 }  // extern "C"

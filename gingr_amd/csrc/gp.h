@@ -72,6 +72,10 @@ struct gingr_model {
     bool finalized = false;
 };
 
+// gp.hip: basis rows of a model on a new reference as fixed convex combinations of three source rows (gingr_model_new_reference)
+void launch_interp_pack(gingr_ctx *ctx, const double *Qs, int32_t rp, const int32_t *inv_src, const int32_t *ids, const double *w,
+                        const int32_t *perm_new, int64_t row_begin, int64_t M, double *Q0);
+
 // fitter.hip: common part of model construction; fill_basis writes m->Q0 on ctx->stream (see gingr_model_upload)
 int model_create_impl(gingr_ctx *ctx, int64_t M_total, int32_t rank, const double *ref, const double *mean,
                       const double *variance, int64_t row_begin, int64_t row_end,

@@ -62,6 +62,29 @@ __host__ __device__ inline void rot_to_euler(const double R[9], double e[3]) {
 
 __device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= 1.79769313486231570815e308; }
 
+// Basis of a model on a NEW reference whose every point takes a fixed convex combination of three source points (nearest
+// neighbour: weights (1,0,0); triangle-mesh interpolation: barycentric weights of the closest surface point):
+//   Q0_new[(3 s + d) rp + q] = sum_k w[3 o + k] Q0_src[(3 inv_src[ids[3 o + k]] + d) rp + q],   o = row_begin + perm_new[s]
+__global__ __launch_bounds__(256) void interp_pack_kernel(const double *__restrict__ Qs, int32_t rp, const int32_t *__restrict__ inv_src,
+                                                          const int32_t *__restrict__ ids, const double *__restrict__ w,
+                                                          const int32_t *__restrict__ perm_new, int64_t row_begin, int64_t M,
+                                                          double *__restrict__ Q0) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 3 * M * rp) return;
+    const int64_t row = idx / rp;
+    const int32_t q = (int32_t)(idx - row * rp);
+    const int64_t s = row / 3;
+    const int d = (int)(row - 3 * s);
+    const int64_t o = row_begin + perm_new[s];
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double wk = w[3 * o + k];
+        if (wk != 0.0) acc += wk * Qs[((int64_t)3 * inv_src[ids[3 * o + k]] + d) * rp + q];
+    }
+    Q0[idx] = acc;
+}
+
 // ------------------------------------------------------------------------------------------------- basis packing
 __global__ void pack_basis_kernel(const double *__restrict__ stage, const double *__restrict__ variance, int64_t rows,
                                   int32_t r, int32_t rp, const int32_t *__restrict__ perm, double *__restrict__ Q0) {
@@ -1744,6 +1767,12 @@ void launch_state_init(gingr_ctx *ctx, DevState *st, const gingr_state_scalars *
     hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, ctx->stream, st, host_scalars_dev);
 }
 
+void launch_interp_pack(gingr_ctx *ctx, const double *Qs, int32_t rp, const int32_t *inv_src, const int32_t *ids, const double *w,
+                        const int32_t *perm_new, int64_t row_begin, int64_t M, double *Q0) {
+    const int64_t total = 3 * M * rp;
+    hipLaunchKernelGGL(interp_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, Qs, rp, inv_src, ids, w,
+                       perm_new, row_begin, M, Q0);
+}
 void launch_pack_basis(gingr_ctx *ctx, const double *stage_colmajor, const double *variance_dev, int64_t M, int32_t r,
                        int32_t rp, const int32_t *perm, double *Q0) {
     const int64_t total = 3 * M * rp;

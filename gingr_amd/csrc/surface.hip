@@ -224,7 +224,7 @@ template <int H>
 __global__ __launch_bounds__(kCpThreads) void surface_cp_kernel(Cloud q, Cloud v, const int32_t *__restrict__ tri,
                                                                const int32_t *__restrict__ tri_orig, int64_t T,
                                                                const double *__restrict__ boxes, double *__restrict__ cp,
-                                                               double *__restrict__ d2out) {
+                                                               double *__restrict__ d2out, int32_t *__restrict__ tri_out) {
     __shared__ Tri9 tile[kTriTile];
     constexpr int QPB = 64 / H;      // queries per workgroup
     __shared__ double sbest[4 * H][QPB], sorig[4 * H][QPB], spt[4 * H][3][QPB];
@@ -321,7 +321,49 @@ __global__ __launch_bounds__(kCpThreads) void surface_cp_kernel(Cloud q, Cloud v
         cp[q.n + i] = spt[w][1][ql];
         cp[2 * q.n + i] = spt[w][2][ql];
         d2out[i] = sbest[w][ql];
+        if (tri_out) tri_out[i] = (int32_t)sorig[w][ql];  // the winning ORIGINAL triangle (lowest on exact ties)
     }
+}
+
+// Barycentric weights (of A, B, C) of the closest point of triangle (A, B, C) to p: the region logic of closest_on_triangle with
+// the weights spelled out -- vertex regions (1,0,0), edge regions (1-q, q, 0), interior (1 - v - w, v, w).
+__device__ __forceinline__ V3 closest_barycentric(V3 p, V3 A, V3 B, V3 C) {
+    const V3 ab = sub(B, A), ac = sub(C, A), ap = sub(p, A), bp = sub(p, B), cp = sub(p, C);
+    const double d1 = dot3(ab, ap), d2 = dot3(ac, ap), d3 = dot3(ab, bp), d4 = dot3(ac, bp), d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+    const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    if (d1 <= 0.0 && d2 <= 0.0) return V3{1.0, 0.0, 0.0};
+    if (d3 >= 0.0 && d4 <= d3) return V3{0.0, 1.0, 0.0};
+    if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) {
+        const double q = d1 / (d1 - d3);
+        return V3{1.0 - q, q, 0.0};
+    }
+    if (d6 >= 0.0 && d5 <= d6) return V3{0.0, 0.0, 1.0};
+    if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) {
+        const double q = d2 / (d2 - d6);
+        return V3{1.0 - q, 0.0, q};
+    }
+    if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) {
+        const double q = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        return V3{0.0, 1.0 - q, q};
+    }
+    const double q = 1.0 / ((va + vb) + vc);
+    const double v = vb * q, w = vc * q;
+    return V3{(1.0 - v) - w, v, w};
+}
+
+// bary[3 i + k]: weight of corner k of triangle tri_id[i] (original numbering; corners given in `tri_corners` [3 T] as positions in
+// the cloud v) for query i
+__global__ __launch_bounds__(256) void barycentric_kernel(Cloud q, Cloud v, const int32_t *__restrict__ tri_by_orig,
+                                                          const int32_t *__restrict__ tri_id, double *__restrict__ bary) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= q.n) return;
+    const int64_t t = tri_id[i];
+    const int32_t a = tri_by_orig[3 * t], b = tri_by_orig[3 * t + 1], c = tri_by_orig[3 * t + 2];
+    const V3 w = closest_barycentric(V3{q.x[i], q.y[i], q.z[i]}, V3{v.x[a], v.y[a], v.z[a]}, V3{v.x[b], v.y[b], v.z[b]},
+                                     V3{v.x[c], v.y[c], v.z[c]});
+    bary[3 * i] = w.x;
+    bary[3 * i + 1] = w.y;
+    bary[3 * i + 2] = w.z;
 }
 
 // flag[i] = 1 when the line through fit_i along fit_i - cp_i meets the mesh (v, tri) in a point != fit_i that is closer to fit_i
@@ -672,19 +714,22 @@ void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T
     if (T <= 0) return;
     hipLaunchKernelGGL(tri_tile_bbox_kernel, dim3((unsigned)ceil_div(T, kTriTile)), dim3(256), 0, ctx->stream, v, tri, T, boxes);
 }
+void launch_barycentric(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri_by_orig, const int32_t *tri_id, double *bary) {
+    hipLaunchKernelGGL(barycentric_kernel, dim3((unsigned)ceil_div(q.n, 256)), dim3(256), 0, ctx->stream, q, v, tri_by_orig, tri_id, bary);
+}
 void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T,
-                                  const double *boxes, double *cp_soa, double *d2) {
+                                  const double *boxes, double *cp_soa, double *d2, int32_t *tri_out) {
     // developer knob GINGR_SURFACE_H = 1 | 2 | 4: queries per workgroup = 64 / H
     static const int h = getenv("GINGR_SURFACE_H") ? atoi(getenv("GINGR_SURFACE_H")) : 2;
     if (h == 1)
         hipLaunchKernelGGL(surface_cp_kernel<1>, dim3((unsigned)ceil_div(q.n, 64)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig,
-                           T, boxes, cp_soa, d2);
+                           T, boxes, cp_soa, d2, tri_out);
     else if (h == 4)
         hipLaunchKernelGGL(surface_cp_kernel<4>, dim3((unsigned)ceil_div(q.n, 16)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig,
-                           T, boxes, cp_soa, d2);
+                           T, boxes, cp_soa, d2, tri_out);
     else
         hipLaunchKernelGGL(surface_cp_kernel<2>, dim3((unsigned)ceil_div(q.n, 32)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig,
-                           T, boxes, cp_soa, d2);
+                           T, boxes, cp_soa, d2, tri_out);
 }
 int distance_stats_ws_doubles() { return kStatBlocks * 4; }
 void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const int32_t *orig, int64_t orig_limit, const int32_t *nn,

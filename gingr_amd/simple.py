@@ -16,7 +16,7 @@ from typing import Callable, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .api import (GPMMTriangleMesh3D, Context, CpdConfiguration, CpdRegistration, DeviceModel, EulerAngles, FittingStatuses, GeneralRegistrationState,
+from .api import (GPMMTriangleMesh3D, InterpolatedDevicePointDistributionModel, Context, CpdConfiguration, CpdRegistration, DeviceModel, EulerAngles, FittingStatuses, GeneralRegistrationState,
                   GlobalTranformationType, IcpConfiguration, IcpRegistration, ModelFittingParameters, PointDistributionModel, f64)
 from . import io as gio
 from .sampling import (IndependentPoints, JSONStateLogger, ModelToTargetEvaluation, ProbabilisticSettings, Random,
@@ -61,18 +61,29 @@ class TranslationAfterRotation:
 
 
 # ------------------------------------------------------------------------------------------------ model on a new reference
-def new_reference_nearest_neighbor(ctx: Context, model: PointDistributionModel, new_reference, new_cells=None) -> PointDistributionModel:
+def new_reference_nearest_neighbor(ctx: Context, model, new_reference, new_cells=None):
     """model.newReference(newRef, NearestNeighborInterpolator())  (SimpleRegistrator.scala:89-90) [SCALISMO-RECALL]: the
     continuous GP takes mean and eigenfunctions of the closest OLD reference point; discretising it on the new points is a row
     gather -- eigenvalues and the number of components are unchanged, nothing is re-orthonormalised.  The closest-point search is
-    the exact device search of the ICP path (lowest index on ties)."""
+    the exact device search of the ICP path (lowest index on ties); the rows are gathered in HBM (gingr_model_new_reference)."""
     new_reference = f64(new_reference).reshape(-1, 3)
     idx, _, _ = ctx.nn(new_reference, f64(model.reference))
-    idx = np.asarray(idx, dtype=np.int64)
-    rows = (3 * idx[:, None] + np.arange(3)[None, :]).reshape(-1)
-    return PointDistributionModel(reference=new_reference, mean=f64(model.mean)[idx], basis=np.ascontiguousarray(f64(model.basis)[rows]),
-                                  variance=f64(model.variance).copy(),
-                                  cells=None if new_cells is None else np.ascontiguousarray(new_cells, dtype=np.int32))
+    ids = np.repeat(np.asarray(idx, dtype=np.int32)[:, None], 3, axis=1)
+    w = np.tile(np.array([1.0, 0.0, 0.0]), (new_reference.shape[0], 1))
+    return InterpolatedDevicePointDistributionModel(ctx, model, new_reference, ids, w, new_cells)
+
+
+def new_reference_triangle_mesh(ctx: Context, model, new_reference, new_cells=None):
+    """model.newReference(fullReference, TriangleMeshInterpolator3D())  (examples/DemoHelper/DemoDatasetLoader.scala:58-62: the
+    demos build their model on a decimated reference and carry it to the full-resolution mesh) [SCALISMO-RECALL]: the field value
+    at a new point is taken at its closest point on the OLD surface -- a vertex value, the linear blend along an edge, or the
+    barycentric blend inside a triangle; in all three cases the barycentric combination of the triangle's corners."""
+    if model.cells is None:
+        raise ValueError("the source model needs its triangulation (model.cells)")
+    new_reference = f64(new_reference).reshape(-1, 3)
+    _, _, tid, bary = ctx.mesh_closest_points(new_reference, model.reference, model.cells)
+    ids = np.ascontiguousarray(model.cells, dtype=np.int32).reshape(-1, 3)[tid]
+    return InterpolatedDevicePointDistributionModel(ctx, model, new_reference, ids, bary, new_cells)
 
 
 def cluster_decimate(vertices, cells, n_target: int) -> Tuple[np.ndarray, np.ndarray]:

@@ -286,6 +286,24 @@ int gingr_mesh_distance_stats(gingr_ctx *ctx, int64_t n_points, const double *po
                               int64_t n_triangles, const int32_t *triangles, int32_t boundary_aware, double sdev, double out[4]);
 
 
+/* Closest point of a triangle mesh to every query point (scalismo mesh.operations.closestPointOnSurface, the query behind
+ * ClosestPointTriangleMesh3D, ClosestPointRegistrator.scala:75-100, and TriangleMeshInterpolator3D): cp_xyz[3n], squared
+ * distance d2[n], the triangle tri_id[n] it lies in (lowest triangle number on exact ties) and the barycentric weights bary[3n] of
+ * that triangle's three corners at the closest point (vertex -> (1,0,0), edge -> (1-q, q, 0)).  Any output may be NULL. */
+int gingr_mesh_closest_points(gingr_ctx *ctx, int64_t n_points, const double *points, int64_t n_vertices, const double *vertices,
+                              int64_t n_triangles, const int32_t *triangles, double *cp_xyz, double *d2, int32_t *tri_id,
+                              double *bary);
+/* model.newReference(newReference, interpolator) (scalismo PointDistributionModel; used as
+ * SimpleRegistrator.scala:89-90 with NearestNeighborInterpolator and as examples/DemoHelper/DemoDatasetLoader.scala:58-62 with
+ * TriangleMeshInterpolator3D): mean and every basis function of the new point i are the fixed combination
+ * sum_k weights[3i+k] * (value at source point vertex_ids[3i+k]); eigenvalues and rank are unchanged, nothing is
+ * re-orthonormalised.  Nearest neighbour: ids (nn, nn, nn), weights (1, 0, 0); triangle mesh: the corners of the triangle from
+ * gingr_mesh_closest_points and its barycentric weights.  The basis is gathered in HBM from the source model (a complete model
+ * of the same context); the result is a model like any other (row shard [row_begin, row_end) of M_new; row_end <= 0 = M_new). */
+int gingr_model_new_reference(gingr_ctx *ctx, const gingr_model *src, int64_t M_new, const double *new_ref,
+                              const int32_t *vertex_ids, const double *weights, int64_t row_begin, int64_t row_end,
+                              gingr_model **out);
+
 /* ---- probabilistic proposal (single shard) ------------------------------------------------
  * update(current, probabilistic = true): the shape proposal is posterior.sample() instead of posterior.mean
  * (G/api/GingrAlgorithm.scala:211).  z[r] are standard-normal draws from the HOST's random generator (the JVM's

@@ -32,6 +32,7 @@ def femur(ctx):
 
 def test_new_reference_is_a_row_gather_by_the_closest_old_point(ctx, femur):
     from gingr_amd.simple import cluster_decimate, new_reference_nearest_neighbor
+    import gingr_amd as ga
     model, _, _, _ = femur
     rng = np.random.default_rng(3)
     new_ref = model.reference[rng.choice(model.numberOfPoints, 300, replace=False)] + rng.normal(0, 0.3, (300, 3))
@@ -41,16 +42,68 @@ def test_new_reference_is_a_row_gather_by_the_closest_old_point(ctx, femur):
     assert np.array_equal(dm.reference, new_ref) and np.array_equal(dm.variance, model.variance) and dm.rank == model.rank
     assert np.array_equal(dm.mean, model.mean[idx])
     B = model.basis.reshape(model.numberOfPoints, 3, model.rank)
-    assert np.array_equal(dm.basis.reshape(300, 3, model.rank), B[idx])
+    assert np.allclose(dm.basis.reshape(300, 3, model.rank), B[idx], atol=1e-13)     # gathered in HBM as U sqrt(lambda)
     # hence: the displacement field of any instance is the full model's displacement at the closest old point
-    import gingr_amd as ga
     a = rng.normal(0, 1, model.rank)
     full = ga.DeviceModel(ctx, model).instance(a) - model.reference
     part = ga.DeviceModel(ctx, dm).instance(a) - new_ref
     assert np.allclose(part, full[idx], atol=1e-11)
     dv, dc = cluster_decimate(model.reference, model.cells, 400)
     dm2 = new_reference_nearest_neighbor(ctx, model, dv, dc)
-    assert dm2.cells is dc or np.array_equal(dm2.cells, dc)
+    assert np.array_equal(dm2.cells, dc)
+    # a row shard of the transferred model holds the rows of the whole one
+    part = ga.DeviceModel(ctx, dm, 100, 300).download()
+    assert np.allclose(part.basis, dm.basis[300:900], atol=1e-15) and np.array_equal(part.mean, dm.mean[100:300])
+
+
+def test_closest_points_with_triangle_and_barycentric_weights(ctx, femur):
+    model, target, _, _ = femur
+    rng = np.random.default_rng(4)
+    V, C = target.points, target.cells
+    P = np.concatenate([model.reference[::7] + rng.normal(0, 1.0, model.reference[::7].shape),
+                        V[:40],                                                   # exactly on vertices
+                        0.5 * (V[C[:40, 0]] + V[C[:40, 1]]),                      # exactly on edges
+                        (V[C[:40, 0]] + V[C[:40, 1]] + V[C[:40, 2]]) / 3.0])      # inside triangles
+    cp, d2, tid, bary = ctx.mesh_closest_points(P, V, C)
+    want_cp, want_d2 = go.mesh_closest_point(P, V, C)
+    assert np.allclose(cp, want_cp, atol=1e-10) and np.allclose(d2, want_d2, atol=1e-9)
+    assert tid.min() >= 0 and tid.max() < C.shape[0]
+    assert np.all(bary >= 0.0) and np.allclose(bary.sum(1), 1.0, atol=1e-14)
+    rebuilt = (bary[:, :, None] * V[C[tid]]).sum(1)                               # the weights reproduce the closest point
+    assert np.allclose(rebuilt, cp, atol=1e-10)
+    n0 = model.reference[::7].shape[0]
+    assert np.allclose(d2[n0:n0 + 120], 0.0, atol=1e-20)
+    assert np.all(np.sort(bary[n0:n0 + 40], axis=1)[:, :2] == 0.0)                # vertex queries: one weight is 1
+
+
+def test_triangle_mesh_interpolated_model_as_the_demo_loader_builds_it(ctx, femur):
+    """DemoDatasetLoader.model (examples/DemoHelper/DemoDatasetLoader.scala:43-64): model on the decimated reference, then
+    newReference(fullReference, TriangleMeshInterpolator3D())."""
+    import gingr_amd as ga
+    from gingr_amd.simple import cluster_decimate, new_reference_triangle_mesh
+    model, target, _, _ = femur
+    dv, dc = cluster_decimate(model.reference, model.cells, 500)
+    dec = ga.GPMMTriangleMesh3D(ctx, dv, relativeTolerance=0.01, cells=dc).Gaussian(70.0, 50.0)
+    full = new_reference_triangle_mesh(ctx, dec, model.reference, model.cells)
+    assert full.rank == dec.rank and full.numberOfPoints == model.numberOfPoints
+    assert np.array_equal(full.variance, dec.to_host().variance)
+    cp, _, tid, bary = ctx.mesh_closest_points(model.reference, dv, dc)
+    U = dec.to_host().basis.reshape(dv.shape[0], 3, dec.rank)
+    want = (bary[:, :, None, None] * U[dc[tid]]).sum(1)                           # (M, 3, r)
+    assert np.allclose(full.basis.reshape(-1, 3, dec.rank), want, atol=1e-13)
+    assert not full.mean.any()
+    # the decimated vertices are a subset of the full mesh: there the transferred model IS the decimated one
+    lut = {tuple(p): i for i, p in enumerate(model.reference)}
+    ids = np.array([lut[tuple(p)] for p in dv])
+    assert np.allclose(full.basis.reshape(-1, 3, dec.rank)[ids], U, atol=1e-13)
+    # and it registers: CPD against the femur target, full resolution
+    cpd = ga.CpdRegistration(ctx)
+    # (20 iterations: run on, sigma2 falls until some vertex has P1 = 0 -- the reference's NaN hazard, SURVEY A.1)
+    st = cpd.run(cpd.createInitialState(full, target.points, ga.CpdConfiguration(maxIterations=20, w=0.05)))
+    cmp_ = ga.RegistrationComparison(ctx, verbose=False)
+    d0 = cmp_.avgDistance(ga.TriangleMesh3D(model.reference, model.cells), target)
+    d1 = cmp_.avgDistance(ga.TriangleMesh3D(st.general.fit, model.cells), target)
+    assert st.general.status in (ga.FittingStatuses.Converged, ga.FittingStatuses.MaxIteration) and d1 < 0.5 * d0, (d0, d1)
 
 
 def test_run_equals_the_direct_path_and_returns_the_full_resolution_fit(ctx, femur):
