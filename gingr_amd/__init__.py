@@ -15,6 +15,7 @@ from .group import DeviceGroup  # noqa: F401  (in-library multi-GPU group: gingr
 from . import io  # noqa: F401  (file / wire formats shared with the Scala host)
 from . import classic  # noqa: F401  (the reference's other/ CPD family on the device)
 from . import sampling  # noqa: F401  (Metropolis-Hastings chain, evaluators, proposals, accuracy metrics)
+from . import helper  # noqa: F401  (log -> shapes, posterior variance maps, progress call-back)
 from . import simple  # noqa: F401  (GingrInterface / SimpleRegistrator: the entry points of the reference's demos)
 from .simple import GingrInterface, SimpleRegistrator, TranslationAfterRotation  # noqa: F401
 from .sampling import (  # noqa: F401

@@ -199,3 +199,31 @@ def test_probabilistic_run_decimated_writes_the_log_and_returns_the_best_sample(
     assert len(entries) == 25 and entries[0]["status"] is True            # the initial state + 24 Metropolis-Hastings steps
     assert best.general.status in (ga.FittingStatuses.MaxIteration, ga.FittingStatuses.ModelFlexibilityError)
     assert best.general.fit.shape == (model.numberOfPoints, 3) and np.all(np.isfinite(best.general.fit))
+
+
+def test_posterior_visualisation_flow_of_the_demo(ctx, femur, tmp_path):
+    """examples/DemoPosteriorVisualizationFemur.scala: chain log -> samples -> shapes (device) -> per-vertex variance maps, with
+    the SimpleLogger call-back scoring the fit while the chain runs."""
+    import gingr_amd as ga
+    from gingr_amd import helper
+    model, target, _, _ = femur
+    log = tmp_path / "chain.json"
+    gi = ga.GingrInterface(ctx, model, target, evaluatorUncertainty=5.0, logFileFittingParameters=str(log), rnd=ga.sampling.Random(3),
+                           verbose=False)
+    cb = helper.SimpleLogger(ctx, printUpdateFrequency=20, verbose=False)
+    best = gi.ICP(ga.IcpConfiguration(maxIterations=61, initialSigma=1.0, endSigma=1.0)).runDecimated(
+        150, 150, globalTransformation=ga.GlobalTranformationType.NoTransforms, probabilistic=True, callback=cb)
+    assert cb.counter == 61 and [c for c, _, _ in cb.history] == [20, 40, 60] and all(a > 0 for _, a, _ in cb.history)
+    full = helper.loadLog(str(log))
+    assert len(full) == 61
+    samples = helper.samplesFromLog(full, takeEveryN=5, total=10000, burnIn=10)
+    shapes = helper.logSamples2shapes(ctx, model, [e for e, _ in samples])
+    assert len(shapes) == len(samples) == 11 and all(sh.shape == (model.numberOfPoints, 3) for sh in shapes)
+    # a logged shape is the instance of its parameters: the best state of the log reproduces the returned fit
+    bestp = helper.jsonFormatToModelFittingParameters(helper.getBestStateFromLog(full))
+    assert np.allclose(np.asarray(bestp.shape), np.asarray(best.general.modelParameters.shape), atol=0)
+    bshape = helper.logSamples2shapes(ctx, model, [helper.getBestStateFromLog(full)])[0]
+    assert np.allclose(bshape, best.general.fit, atol=1e-9)
+    tot = helper.computeDistanceMapFromMeshesTotal(shapes)
+    nrm = helper.computeDistanceMapFromMeshesNormal(shapes, ga.TriangleMesh3D(bshape, model.cells))
+    assert tot.shape == nrm.shape == (model.numberOfPoints,) and np.all(tot >= 0) and np.all(nrm <= tot + 1e-9) and tot.max() > 0
