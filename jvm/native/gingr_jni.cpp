@@ -263,6 +263,60 @@ JFN(jlong, gpmmBuildGaussian)(JNIEnv *env, jclass, jlong ctx, jlong mTotal, jdou
         return 0;
     return reinterpret_cast<jlong>(m);
 }
+JFN(jlong, gpmmBuildDiagonal)(JNIEnv *env, jclass, jlong ctx, jlong mTotal, jdoubleArray ref, jintArray kind3, jobjectArray sigmas3,
+                               jobjectArray scalings3, jdoubleArray mirror3, jdoubleArray scaling3, jobjectArray lookup3, jdouble relTol,
+                               jint maxRank, jlong rowBegin, jlong rowEnd) {
+    Arr<double> a(env, ref, true); Arr<int32_t> kd(env, kind3, true); Arr<double> mi(env, mirror3, true); Arr<double> sc(env, scaling3, true);
+    if (kd.buf.size() != 3 || mi.buf.size() != 3 || sc.buf.size() != 3) return 0;
+    std::vector<double> sig[3], scl[3], lut[3];
+    gingr_scalar_kernel k[3];
+    auto copy = [&](jobjectArray outer, int d, std::vector<double> &dst) {
+        if (!outer) return;
+        jdoubleArray inner = static_cast<jdoubleArray>(env->GetObjectArrayElement(outer, d));
+        if (!inner) return;
+        const jsize n = env->GetArrayLength(inner);
+        dst.resize((size_t)n);
+        if (n > 0) env->GetDoubleArrayRegion(inner, 0, n, dst.data());
+        env->DeleteLocalRef(inner);
+    };
+    for (int d = 0; d < 3; ++d) {
+        copy(sigmas3, d, sig[d]);
+        copy(scalings3, d, scl[d]);
+        copy(lookup3, d, lut[d]);
+        k[d].kind = kd.buf[(size_t)d];
+        k[d].n_kernels = (int32_t)sig[d].size();
+        k[d].sigmas = sig[d].empty() ? nullptr : sig[d].data();
+        k[d].scalings = scl[d].empty() ? nullptr : scl[d].data();
+        k[d].mirror = mi.buf[(size_t)d];
+        k[d].scaling = sc.buf[(size_t)d];
+        k[d].lookup = lut[d].empty() ? nullptr : lut[d].data();
+    }
+    // equal kernels -> one factorisation: the library compares contents, but lookup tables by pointer
+    for (int d = 1; d < 3; ++d)
+        for (int e = 0; e < d; ++e)
+            if (k[d].kind == GINGR_KERNEL_LOOKUP && k[e].kind == GINGR_KERNEL_LOOKUP && lut[d] == lut[e]) k[d].lookup = k[e].lookup;
+    gingr_model *m = nullptr;
+    if (gingr_gpmm_build_diagonal(P<gingr_ctx>(ctx), mTotal, a.ptr(), &k[0], &k[1], &k[2], relTol, maxRank, rowBegin, rowEnd, &m) !=
+        GINGR_OK)
+        return 0;
+    return reinterpret_cast<jlong>(m);
+}
+JFN(jint, meshClosestPoints)(JNIEnv *env, jclass, jlong ctx, jdoubleArray pts, jdoubleArray verts, jintArray tris, jdoubleArray cp,
+                              jdoubleArray d2, jintArray triId, jdoubleArray bary) {
+    Arr<double> a(env, pts, true); Arr<double> b(env, verts, true); Arr<int32_t> c(env, tris, true);
+    Arr<double> o1(env, cp, false); Arr<double> o2(env, d2, false); Arr<int32_t> o3(env, triId, false); Arr<double> o4(env, bary, false);
+    return gingr_mesh_closest_points(P<gingr_ctx>(ctx), (int64_t)a.buf.size() / 3, a.ptr(), (int64_t)b.buf.size() / 3, b.ptr(),
+                                     (int64_t)c.buf.size() / 3, c.ptr(), o1.ptr(), o2.ptr(), o3.ptr(), o4.ptr());
+}
+JFN(jlong, modelNewReference)(JNIEnv *env, jclass, jlong ctx, jlong src, jdoubleArray newRef, jintArray ids, jdoubleArray weights,
+                               jlong rowBegin, jlong rowEnd) {
+    Arr<double> a(env, newRef, true); Arr<int32_t> b(env, ids, true); Arr<double> c(env, weights, true);
+    gingr_model *m = nullptr;
+    if (gingr_model_new_reference(P<gingr_ctx>(ctx), P<gingr_model>(src), (int64_t)a.buf.size() / 3, a.ptr(), b.ptr(), c.ptr(), rowBegin,
+                                  rowEnd, &m) != GINGR_OK)
+        return 0;
+    return reinterpret_cast<jlong>(m);
+}
 JFN(jint, pointsetDistanceExtrema)(JNIEnv *env, jclass, jlong ctx, jdoubleArray xyz, jdoubleArray out2) {
     const jlong n = env->GetArrayLength(xyz) / 3;
     Arr<double> a(env, xyz, true); Arr<double> b(env, out2, false);

@@ -82,6 +82,19 @@ public final class GingrHipNative {
     /** returns the gingr_model handle (0 on failure; see lastError); maxRank <= 0 = model limit; rowEnd <= 0 = all rows */
     public static native long gpmmBuildGaussian(long ctx, long mTotal, double[] refXyz, double[] sigmas, double[] scalings,
                                                 double relativeTolerance, int maxRank, long rowBegin, long rowEnd);
+    /** gingr_gpmm_build_diagonal: one scalar kernel per coordinate, each kernel k = { kind (0 Gaussian mixture, 1 dot, 2 lookup),
+     *  sigmas, scalings, mirror, scaling, lookup (M x M row-major or null) } spread over parallel arrays of length 3 (x, y, z);
+     *  coordinates whose entries are equal share one factorisation.  GaussianSymmetry = kind 0 with mirror {-1, +1, +1}. */
+    public static native long gpmmBuildDiagonal(long ctx, long mTotal, double[] refXyz, int[] kind3, double[][] sigmas3,
+                                                double[][] scalings3, double[] mirror3, double[] scaling3, double[][] lookup3,
+                                                double relativeTolerance, int maxRank, long rowBegin, long rowEnd);
+    /** closestPointOnSurface for every point: any output may be null (cpXyz[3n], d2[n], triId[n], bary[3n]) */
+    public static native int meshClosestPoints(long ctx, double[] pointsXyz, double[] verticesXyz, int[] triangles, double[] cpXyz,
+                                               double[] d2, int[] triId, double[] bary);
+    /** model.newReference(newReference, interpolator): new point i = sum_k weights[3i+k] * source point vertexIds[3i+k];
+     *  returns the model handle or 0 */
+    public static native long modelNewReference(long ctx, long sourceModel, double[] newRefXyz, int[] vertexIds, double[] weights,
+                                                long rowBegin, long rowEnd);
     /** out2 = { maximumPointDistance, minimumPointDistance } (PointSetHelper) */
     public static native int pointsetDistanceExtrema(long ctx, double[] xyz, double[] out2);
     /** any array may be null; basisColMajor is 3 M_local x rank, unit columns */

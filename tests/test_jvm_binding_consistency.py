@@ -15,9 +15,9 @@ MOCK_JNI = """
 #include <cstdint>
 typedef int32_t jint; typedef int32_t jsize; typedef int64_t jlong; typedef double jdouble; typedef unsigned char jboolean;
 class _jobject {}; class _jclass : public _jobject {}; class _jstring : public _jobject {}; class _jarray : public _jobject {};
-class _jdoubleArray : public _jarray {}; class _jintArray : public _jarray {};
+class _jdoubleArray : public _jarray {}; class _jintArray : public _jarray {}; class _jobjectArray : public _jarray {};
 typedef _jobject *jobject; typedef _jclass *jclass; typedef _jstring *jstring; typedef _jarray *jarray;
-typedef _jdoubleArray *jdoubleArray; typedef _jintArray *jintArray;
+typedef _jdoubleArray *jdoubleArray; typedef _jintArray *jintArray; typedef _jobjectArray *jobjectArray;
 #define JNIEXPORT
 #define JNICALL
 struct JNIEnv {
@@ -27,6 +27,8 @@ struct JNIEnv {
     void SetIntArrayRegion(jintArray, jsize, jsize, const jint *) {}
     jsize GetArrayLength(jarray) { return 0; }
     jstring NewStringUTF(const char *) { return nullptr; }
+    jobject GetObjectArrayElement(jobjectArray, jsize) { return nullptr; }
+    void DeleteLocalRef(jobject) {}
 };
 """
 
