@@ -835,6 +835,26 @@ __device__ __forceinline__ void fmac_row_bcast(double &acc, double a, double b) 
         asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(J));
 }
 
+// One step of the panel recurrence for four interleaved matrix rows: t_u = x_u * rdl (lane K: the finished x_u[K]), then
+// x_u += (lane K's t_u) * nl.  One asm statement: the four products are written four instructions before the DPP reads them, which
+// covers the two wait states the DPP needs without any s_nop (the compiler cannot be trusted to keep plain multiplies away from
+// an asm that follows them).
+template <int K>
+__device__ __forceinline__ void panel_step4(double (&x)[4], double rdl, double nl) {
+    double t0, t1, t2, t3;
+    asm volatile(
+        "v_mul_f64 %4, %0, %8\n\t"
+        "v_mul_f64 %5, %1, %8\n\t"
+        "v_mul_f64 %6, %2, %8\n\t"
+        "v_mul_f64 %7, %3, %8\n\t"
+        "v_fmac_f64_dpp %0, %4, %9 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %5, %9 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %6, %9 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %7, %9 row_newbcast:%10 row_mask:0xf bank_mask:0xf"
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(rdl), "v"(nl), "n"(K));
+}
+
 // ---- building blocks: all 256 threads call them.  A is (n + xr) x n in LDS, n and xr multiples of 16, odd leading dimension ld.
 
 // doubles of LDS the blocks need for an r x r system with xr extra rows
@@ -843,10 +863,12 @@ __host__ __device__ inline size_t lds_solve_doubles(int rp, int xr) { return (si
 // A (lower triangle of the leading r x r) = ca * G + cs * S + ci * I from global r x rp matrices (S may be nullptr), identity
 // on the padding r <= i < n.  16 x 16 element blocks, one element per thread and block, eight blocks in flight; the loads are
 // unconditional (clamped indices), only the value is selected.
+template <int NT>
 __device__ __forceinline__ void lds_load_spd(double *A, int ld, int r, int n, const double *__restrict__ G, double ca,
                                              const double *__restrict__ S, double cs, double ci) {
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    int ib = 0, jb = 0;  // block origin (wave-uniform)
+    constexpr int RB = NT / 16;  // rows per block of 16 columns: one element per thread and block, eight blocks in flight
+    int ib = 0, jb = 0;          // block origin (workgroup-uniform)
     while (ib < n) {
         double v[8];
         int off[8];
@@ -858,11 +880,11 @@ __device__ __forceinline__ void lds_load_spd(double *A, int ld, int r, int n, co
             if (S) t = __builtin_fma(cs, S[g], t);
             if (i == j) t += ci;
             v[u] = (i < r && j < r) ? t : (i == j ? 1.0 : 0.0);
-            off[u] = (ib < n && j <= i) ? i * ld + j : -1;
+            off[u] = (ib < n && i < n && j <= i) ? i * ld + j : -1;
             jb += 16;
-            if (jb > ib) {
+            if (jb > ib + RB - 16 || jb >= n) {  // past the last column any row of this block needs
                 jb = 0;
-                ib += 16;
+                ib += RB;
             }
         }
 #pragma unroll
@@ -875,20 +897,27 @@ __device__ __forceinline__ void lds_load_spd(double *A, int ld, int r, int n, co
 // in-place blocked Cholesky (lower) of the leading n x n; rd[k] = 1 / L[k][k]; *bad_spd (LDS) is set on a non-positive /
 // non-finite pivot.  Rows n .. n+xr-1 hold right-hand sides b^T; they ride along through the panel solves and the trailing
 // updates (Cholesky of the bordered matrix), so on return they hold (L^-1 b)^T.
+// NT threads (a multiple of 256): the panel solves and the trailing updates spread over NT / 64 waves.  With one wave per SIMD
+// every stage is bound by the number of instructions that wave issues (~5 cycles each).
+template <int NT>
 __device__ __forceinline__ void lds_cholesky(double *A, int ld, int n, double *rd, int *bad_spd, int xr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = NT / 64;           // waves
+    constexpr int PU = NT >= 1024 ? 2 : 4;  // matrix rows interleaved per 16-lane group in the panel solve
+    constexpr int PR = (NT / 16) * PU;     // matrix rows per panel pass
     const int rows = n + xr;
     for (int kb = 0; kb < n; kb += kNB) {
-        // (1) diagonal block in registers, wave 0 (all four 16-lane rows do the same work: DPP needs the source lanes active)
+        // (1) diagonal block in registers, wave 0 (all four 16-lane rows do the same work: DPP needs the source lanes active).
+        // No masks anywhere: the upper part of the block is loaded, carried and stored as it comes -- lane i's entries right of the
+        // diagonal only ever feed lane i's own entries right of the diagonal, and nobody reads the upper part of A (the selects,
+        // compares and exec-mask juggling of a masked version were a third of this stage's instructions).  The stage is bound by
+        // the NUMBER of instructions the one wave issues, not by the dependent chain: a fraction-free variant (no reciprocal square
+        // root on the chain, one more multiply per entry) measured slower, 24.5k against 21.4k cycles for seven blocks.
         if (wave == 0) {
             const int l15 = lane & 15;
             double row[kNB];
 #pragma unroll
-            for (int k = 0; k < kNB; ++k) {
-                const double v = A[(kb + l15) * ld + kb + k];  // the upper part may hold anything: selected away
-                row[k] = k <= l15 ? v : 0.0;
-            }
-            double rd_own = 1.0;  // 1 / L[lane][lane]
+            for (int k = 0; k < kNB; ++k) row[k] = A[(kb + l15) * ld + kb + k];
             static_for<0, kNB>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
                 // the pivot, from lane c of this 16-lane row.  A non-positive or non-finite pivot is not tested here (the test
@@ -904,7 +933,7 @@ __device__ __forceinline__ void lds_cholesky(double *A, int ld, int n, double *r
                 const double lc = row[c] * rdk;
                 const double nlc = -lc;
                 row[c] = lc;
-                if (l15 == c) rd_own = rdk;  // 1/sqrt(d): the reciprocal of this lane's diagonal entry d * rdk
+                rd[kb + c] = rdk;  // 1 / L[c][c]; the same value from every lane
                 // row[j] -= L[lane][c] * L[j][c]: L[j][c] is lane j's lc, fetched by the DPP of the FMA itself
                 static_for<c + 1, kNB>([&](auto jj) {
                     constexpr int j = decltype(jj)::value;
@@ -912,14 +941,11 @@ __device__ __forceinline__ void lds_cholesky(double *A, int ld, int n, double *r
                 });
             });
             if (lane < kNB) {
-                double diag = 0.0;
 #pragma unroll
-                for (int k = 0; k < kNB; ++k) {
-                    if (k <= lane) A[(kb + lane) * ld + kb + k] = row[k];
-                    if (k == lane) diag = row[k];
-                }
-                rd[kb + lane] = rd_own;
-                if (!(diag > 0.0) || !finite_d(diag) || !finite_d(rd_own)) *bad_spd = 1;
+                for (int k = 0; k < kNB; ++k) A[(kb + lane) * ld + kb + k] = row[k];
+                // L[lane][lane] = row[lane]: a register array cannot be indexed by the lane; read it back
+                const double diag = A[(kb + lane) * ld + kb + lane];
+                if (!(diag > 0.0) || !finite_d(diag)) *bad_spd = 1;
             }
         }
         __syncthreads();
@@ -936,22 +962,26 @@ __device__ __forceinline__ void lds_cholesky(double *A, int ld, int n, double *r
                 nL[k] = k < c16 ? -v : 0.0;
             }
             const double rdl = rd[kb + c16];
-            for (int ib = kb + kNB; ib < rows; ib += 64) {  // workgroup-uniform trip count
+            for (int ib = kb + kNB; ib < rows; ib += PR) {  // workgroup-uniform trip count
                 const int i0 = ib + grp;
-                double x[4];
+                double x[PU];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = A[min(i0 + 16 * u, rows - 1) * ld + kb + c16];
+                for (int u = 0; u < PU; ++u) x[u] = A[min(i0 + (NT / 16) * u, rows - 1) * ld + kb + c16];
                 static_for<0, kNB>([&](auto kk) {
                     constexpr int k = decltype(kk)::value;
-                    double t[4];
+                    if constexpr (PU == 4) {
+                        panel_step4<k>(x, rdl, nL[k]);
+                    } else {
+                        double t[PU];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) t[u] = x[u] * rdl;  // lane k: the finished x[k]
+                        for (int u = 0; u < PU; ++u) t[u] = x[u] * rdl;  // lane k: the finished x[k]
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) fmac_row_bcast<k, true>(x[u], t[u], nL[k]);
+                        for (int u = 0; u < PU; ++u) fmac_row_bcast<k, true>(x[u], t[u], nL[k]);
+                    }
                 });
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (i0 + 16 * u < rows) A[(i0 + 16 * u) * ld + kb + c16] = x[u] * rdl;
+                for (int u = 0; u < PU; ++u)
+                    if (i0 + (NT / 16) * u < rows) A[(i0 + (NT / 16) * u) * ld + kb + c16] = x[u] * rdl;
             }
         }
         __syncthreads();
@@ -964,10 +994,12 @@ __device__ __forceinline__ void lds_cholesky(double *A, int ld, int n, double *r
             const int t0 = kb + kNB;
             const int nti = (rows - t0) >> 4, ntj = (n - t0) >> 4;
             const int l15 = lane & 15, l4 = lane >> 4;
+            // (measured: bound by the LDS traffic of the fragments -- C in, A, B, C out = 8 KB per tile -- not by latency: issuing
+            // two tiles' loads ahead of their MFMA chains changed nothing)
             int tcount = 0;
             for (int ti = 0; ti < nti; ++ti)
                 for (int tj = 0; tj <= ti && tj < ntj; ++tj, ++tcount) {
-                    if ((tcount & 3) != wave) continue;  // wave-uniform
+                    if (tcount % NW != wave) continue;  // wave-uniform
                     const int i0 = t0 + 16 * ti, j0 = t0 + 16 * tj;
                     const double *pa = A + (i0 + l15) * ld + kb + l4, *pb = A + (j0 + l15) * ld + kb + l4;
                     double *pc = A + (i0 + l4) * ld + j0 + l15;
@@ -987,6 +1019,7 @@ __device__ __forceinline__ void lds_cholesky(double *A, int ld, int n, double *r
 
 // y <- L^-T y for the n entries of y (blocked, bottom up; the 16x16 triangular solves run in registers of wave 0 with the DPP
 // recurrence: lane c holds column c of the diagonal block)
+template <int NT>
 __device__ __forceinline__ void lds_backward(const double *A, int ld, int n, const double *rd, double *y) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int kb = n - kNB; kb >= 0; kb -= kNB) {
@@ -1008,7 +1041,7 @@ __device__ __forceinline__ void lds_backward(const double *A, int ld, int n, con
             if (lane < kNB) y[kb + lane] = yv * rdl;
         }
         __syncthreads();
-        for (int i = tid; i < kb; i += 256) {
+        for (int i = tid; i < kb; i += NT) {
             double sacc = y[i];
 #pragma unroll
             for (int k = 0; k < kNB; ++k) sacc = __builtin_fma(-A[(kb + k) * ld + i], y[kb + k], sacc);
@@ -1036,7 +1069,7 @@ __global__ __launch_bounds__(256) void chol_block64_kernel(double *__restrict__ 
     }
     if (tid == 0) bad = 0;
     __syncthreads();
-    lds_cholesky(A, lda, n, rd, &bad, n);
+    lds_cholesky<256>(A, lda, n, rd, &bad, n);
     double *li = Linv + (int64_t)k * n * n;
     for (int e = tid; e < n * n; e += 256) {
         const int r = e >> 6, c = e & 63;
@@ -1052,12 +1085,25 @@ __global__ __launch_bounds__(256) void chol_block64_kernel(double *__restrict__ 
 // gwork == nullptr: the bordered matrix lives in LDS (r <= 128).  Otherwise it lives in the global workspace `gwork`
 // (lds_solve_doubles(rp, 16) doubles, L2 resident): the same building blocks through flat addressing, for 128 < r <= 512 --
 // one workgroup, so the workgroup barriers order its global writes.
-__global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp, const double *__restrict__ G,
+// Threads of the one-workgroup solve kernels.  Measured (tools/ubench_solve.hip, r = 100): 1024 threads shorten the load stage
+// (9.9k -> 6.8k cycles) but lengthen the trailing update (25k -> 37k: every wave walks the whole tile list) and leave the panel
+// solve where it is (its per-thread set-up is replicated in four times the waves): 46 us against 42 us at 256 threads.
+constexpr int kSolveThreads = 256;
+
+// GW = false: the workspace is the dynamic LDS block and nothing else -- the compiler then proves every access of the building
+// blocks to be address space 3 and emits ds_read / ds_write.  (With one kernel choosing between LDS and a global pointer at run
+// time every access was a FLAT instruction: ~3x the latency of the LDS path, 64-bit address arithmetic, SGPR spills.)
+template <bool GW>
+__global__ __launch_bounds__(kSolveThreads) void posterior_solve_lds_kernel(int r, int rp, const double *__restrict__ G,
                                                                   const double *__restrict__ rhs,
                                                                   const double *__restrict__ zrand, double *__restrict__ a,
                                                                   DevState *__restrict__ st, double *gwork) {
     extern __shared__ double lds_sm[];
-    double *sm = gwork ? gwork : lds_sm;
+    double *sm;
+    if constexpr (GW)
+        sm = gwork;
+    else
+        sm = lds_sm;
     const int n = rp, ld = n | 1;  // odd leading dimension: column walks hit distinct banks
     double *A = sm;
     double *y = sm + (size_t)n * ld;   // row n of the bordered matrix: the right-hand side (rows n+1 .. n+15 are zero)
@@ -1069,19 +1115,19 @@ __global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp,
         bad_spd = 0;
         bad = 0;
     }
-    for (int k = tid; k < kNB * ld; k += 256) y[k] = k < r ? rhs[k] : 0.0;
-    for (int k = tid; k < n; k += 256) y2[k] = (zrand && k < r) ? zrand[k] : 0.0;
+    for (int k = tid; k < kNB * ld; k += kSolveThreads) y[k] = k < r ? rhs[k] : 0.0;
+    for (int k = tid; k < n; k += kSolveThreads) y2[k] = (zrand && k < r) ? zrand[k] : 0.0;
     // Mm = QtL Q + I     (scalismo genericRegressionComputations)
     GINGR_STAGE_CLOCK(7)
-    lds_load_spd(A, ld, r, n, G, 1.0, nullptr, 0.0, 1.0);
+    lds_load_spd<kSolveThreads>(A, ld, r, n, G, 1.0, nullptr, 0.0, 1.0);
     GINGR_STAGE_CLOCK(0)
-    lds_cholesky(A, ld, n, rd, &bad_spd, kNB);  // y <- L^-1 y on the way
+    lds_cholesky<kSolveThreads>(A, ld, n, rd, &bad_spd, kNB);  // y <- L^-1 y on the way
     GINGR_STAGE_CLOCK(4)
-    lds_backward(A, ld, n, rd, y);
+    lds_backward<kSolveThreads>(A, ld, n, rd, y);
     GINGR_STAGE_CLOCK(5)
     GINGR_STAGE_CLOCK(6)
-    if (zrand) lds_backward(A, ld, n, rd, y2);
-    for (int k = tid; k < rp; k += 256) {
+    if (zrand) lds_backward<kSolveThreads>(A, ld, n, rd, y2);
+    for (int k = tid; k < rp; k += kSolveThreads) {
         const double v = k < r ? y[k] + y2[k] : 0.0;
         a[k] = v;
         if (!finite_d(v)) bad = 1;
@@ -1100,61 +1146,66 @@ __global__ __launch_bounds__(256) void posterior_solve_lds_kernel(int r, int rp,
 // With N = Q0' L^-T (any square root of the posterior covariance gives the same norm) the ridge-regression coefficients are
 //   c = (N^T N + eps I)^-1 N^T d = L^T (S_tot + eps (I + G))^-1 b,   b = Q0^T e - S_tot a,
 // e = R^T(mesh - c - t) - (ref - c) - mean (model frame residual), a = posterior coefficients;  logpdf = -|c|^2/2 - r/2 log(2 pi).
-__global__ __launch_bounds__(256) void posterior_logpdf_lds_kernel(int r, int rp, const double *__restrict__ G,
+template <bool GW>  // see posterior_solve_lds_kernel
+__global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_lds_kernel(int r, int rp, const double *__restrict__ G,
                                                                    const double *__restrict__ rhs,
                                                                    const double *__restrict__ Stot,
                                                                    const double *__restrict__ qte,
                                                                    double *__restrict__ lsave /* [rp][rp] global scratch */,
                                                                    double *__restrict__ out2, double *gwork) {
     extern __shared__ double lds_sm[];
-    double *sm = gwork ? gwork : lds_sm;
+    double *sm;
+    if constexpr (GW)
+        sm = gwork;
+    else
+        sm = lds_sm;
     const int n = rp, ld = n | 1;
     double *A = sm;
     double *u = sm + (size_t)n * ld;  // extra row block of the bordered matrix
     double *rd = sm + (size_t)(n + kNB) * ld;
     double *cv = rd + n;
     __shared__ int bad_spd;
-    __shared__ double red[256];
+    __shared__ double red[kSolveThreads];
     __shared__ double av[512];  // posterior coefficients a (rp <= 512)
     const int tid = threadIdx.x;
     if (tid == 0) bad_spd = 0;
     // (1) a = (I + G)^-1 rhs: the posterior coefficients of the state (what posterior_solve_lds_kernel computes); the factor L of
     //     I + G is needed again at the end (c = L^T u) and does not fit the LDS next to the second system: it goes to `lsave`
-    for (int k = tid; k < kNB * ld; k += 256) u[k] = k < r ? rhs[k] : 0.0;
-    lds_load_spd(A, ld, r, n, G, 1.0, nullptr, 0.0, 1.0);
-    lds_cholesky(A, ld, n, rd, &bad_spd, kNB);  // u <- L^-1 rhs on the way
-    for (int e = tid; e < n * n; e += 256) {
+    for (int k = tid; k < kNB * ld; k += kSolveThreads) u[k] = k < r ? rhs[k] : 0.0;
+    lds_load_spd<kSolveThreads>(A, ld, r, n, G, 1.0, nullptr, 0.0, 1.0);
+    lds_cholesky<kSolveThreads>(A, ld, n, rd, &bad_spd, kNB);  // u <- L^-1 rhs on the way
+    for (int e = tid; e < n * n; e += kSolveThreads) {
         const int i = e / n, k = e - i * n;
         lsave[e] = k <= i ? A[i * ld + k] : 0.0;
     }
-    lds_backward(A, ld, n, rd, u);
-    for (int k = tid; k < rp; k += 256) av[k] = k < r ? u[k] : 0.0;
+    lds_backward<kSolveThreads>(A, ld, n, rd, u);
+    for (int k = tid; k < rp; k += kSolveThreads) av[k] = k < r ? u[k] : 0.0;
     __syncthreads();
     // (2) b = Q0^T e - S_tot a
-    for (int k = tid; k < kNB * ld; k += 256) u[k] = 0.0;
+    for (int k = tid; k < kNB * ld; k += kSolveThreads) u[k] = 0.0;
     __syncthreads();
-    for (int k = tid; k < r; k += 256) {
+    for (int k = tid; k < r; k += kSolveThreads) {
         double s = qte[k];
         for (int j = 0; j < r; ++j) s = __builtin_fma(-Stot[(int64_t)j * rp + k], av[j], s);  // S_tot symmetric: coalesced
         u[k] = s;
     }
     // (3) u = (S_tot + eps (I + G))^-1 b
-    lds_load_spd(A, ld, r, n, G, GINGR_COEFF_NOISE, Stot, 1.0, GINGR_COEFF_NOISE);
-    lds_cholesky(A, ld, n, rd, &bad_spd, kNB);                                        // u <- L2^-1 u on the way
-    lds_backward(A, ld, n, rd, u);
+    lds_load_spd<kSolveThreads>(A, ld, r, n, G, GINGR_COEFF_NOISE, Stot, 1.0, GINGR_COEFF_NOISE);
+    lds_cholesky<kSolveThreads>(A, ld, n, rd, &bad_spd, kNB);                                        // u <- L2^-1 u on the way
+    lds_backward<kSolveThreads>(A, ld, n, rd, u);
     __syncthreads();
     // (4) c = L^T u with the saved factor of I + G (written by this workgroup before the barriers above; L2 resident)
-    for (int k = tid; k < r; k += 256) {
+    for (int k = tid; k < r; k += kSolveThreads) {
         double s = 0.0;
         for (int i = k; i < r; ++i) s = __builtin_fma(lsave[i * n + k], u[i], s);
         cv[k] = s;
     }
     __syncthreads();
     double part = 0.0;
-    for (int k = tid; k < r; k += 256) part = __builtin_fma(cv[k], cv[k], part);
+    for (int k = tid; k < r; k += kSolveThreads) part = __builtin_fma(cv[k], cv[k], part);
     red[tid] = part;
     __syncthreads();
-    for (int st2 = 128; st2 > 0; st2 >>= 1) {
+    for (int st2 = kSolveThreads / 2; st2 > 0; st2 >>= 1) {
         if (tid < st2) red[tid] += red[tid + st2];
         __syncthreads();
     }
@@ -1699,16 +1750,16 @@ void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
         const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
         static size_t lds_granted = 48 * 1024;  // the attribute is per function, not per launch
         if (lds > lds_granted) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_solve_lds_kernel),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_solve_lds_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             lds_granted = lds;
         }
-        hipLaunchKernelGGL(posterior_solve_lds_kernel, dim3(1), dim3(256), lds, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a,
+        hipLaunchKernelGGL(posterior_solve_lds_kernel<false>, dim3(1), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a,
                            st, (double *)nullptr);
         return;
     }
     // r > 128: the bordered matrix does not fit the LDS; same kernel on the global workspace (posterior_work_doubles)
-    hipLaunchKernelGGL(posterior_solve_lds_kernel, dim3(1), dim3(256), 0, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a, st, work);
+    hipLaunchKernelGGL(posterior_solve_lds_kernel<true>, dim3(1), dim3(kSolveThreads), 0, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a, st, work);
 }
 
 int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *Stot,
@@ -1717,14 +1768,14 @@ int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
         const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
         static size_t lds_granted = 48 * 1024;  // the attribute is per function, not per launch
         if (lds > lds_granted) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_lds_kernel),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_lds_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             lds_granted = lds;
         }
-        hipLaunchKernelGGL(posterior_logpdf_lds_kernel, dim3(1), dim3(256), lds, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte, lsave,
-                           out2, (double *)nullptr);
+        hipLaunchKernelGGL(posterior_logpdf_lds_kernel<false>, dim3(1), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte,
+                           lsave, out2, (double *)nullptr);
     } else {
-        hipLaunchKernelGGL(posterior_logpdf_lds_kernel, dim3(1), dim3(256), 0, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte, lsave,
+        hipLaunchKernelGGL(posterior_logpdf_lds_kernel<true>, dim3(1), dim3(kSolveThreads), 0, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte, lsave,
                            out2, work);
     }
     return GINGR_OK;

@@ -7,7 +7,7 @@ mkdir -p $R/gpurun_out/ab
 for i in 1 2 3; do
   for v in prev cur; do
     if [ $v = prev ]; then export GINGR_HIP_LIB=$R/gingr_amd/libgingr_hip_prev.so; else unset GINGR_HIP_LIB; fi
-    python3 $R/bench.py --no-cpu-baseline --no-parity-check "$@" > $R/gpurun_out/ab/$v$i.json 2> $R/gpurun_out/ab/$v$i.err
+    python3 $R/bench.py --no-cpu-baseline --no-parity-check "$@" 2> $R/gpurun_out/ab/$v$i.err | tail -1 > $R/gpurun_out/ab/$v$i.json
   done
 done
 python3 - <<PY

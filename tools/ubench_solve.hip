@@ -53,7 +53,7 @@ int main() {
     hipMemcpy(dG, G.data(), G.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(drhs, rhs.data(), rp * 8, hipMemcpyHostToDevice);
     const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_solve_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_solve_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
     const int reps = 50;
     unsigned long long zero[8] = {0};
@@ -64,7 +64,7 @@ int main() {
         hipMemcpyToSymbol(HIP_SYMBOL(g_stage), zero, sizeof(zero));
         hipEventRecord(a);
         for (int i = 0; i < reps; ++i)
-            hipLaunchKernelGGL(posterior_solve_lds_kernel, dim3(1), dim3(256), lds, 0, r, rp, dG, drhs, (const double *)nullptr, da, st);
+            hipLaunchKernelGGL(posterior_solve_lds_kernel<false>, dim3(1), dim3(kSolveThreads), lds, 0, r, rp, dG, drhs, (const double *)nullptr, da, st, (double *)nullptr);
         hipEventRecord(b);
         hipDeviceSynchronize();
     }
