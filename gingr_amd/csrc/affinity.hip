@@ -1202,6 +1202,11 @@ inline int resident_workgroups(int which /* 0 column sums, 1 row statistics PT =
     return cache[which];
 }
 
+// The quarter-tile x slot culling variant (FINE) pays for its longer prologue and per-part slot tests only when the streamed cloud
+// is long: measured in the late regime (tools/fine_cull_sweep.sh, sigma2 = 4) it wins 3 % at 50k streamed points, 1 % at 30k and
+// LOSES 4 % at 15k, 8 % at 1.6k (femur) -- bit-identical results either way.
+constexpr int64_t kFineMinStream = 24576;
+
 inline ChunkPlan plan_chunks(int64_t owned, int owned_per_block, int64_t stream_len, int *nchunks, int quarters_override = 0,
                              int forced_chunks = 0, int resident = 0) {
     const int64_t bx = ceil_div(owned, owned_per_block);
@@ -1336,7 +1341,8 @@ int launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sig
             const double *boxes = ctx->cull ? fit_boxes : (const double *)nullptr;
             // one variant, picked from the regime the device last reported (stale at worst: the results are the same)
             const bool fine = boxes && (ctx->fine_override >= 0 ? ctx->fine_override != 0
-                                                                : (ctx->regime_host && *(volatile int32_t *)ctx->regime_host != 0));
+                                                                : (fit.n >= kFineMinStream && ctx->regime_host &&
+                                                                   *(volatile int32_t *)ctx->regime_host != 0));
             if (fine)
                 hipLaunchKernelGGL((cpd_colsum_kernel<kPT, true>), grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux,
                                    boxes, len, ws, ctx->regime_dev);
@@ -1375,7 +1381,8 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
             const bool cull = ctx->cull && tgt_boxes && tile_bad;
             const double *boxes = cull ? tgt_boxes : (const double *)nullptr;
             const bool fine = boxes && (ctx->fine_override >= 0 ? ctx->fine_override != 0
-                                                                : (ctx->regime_host && *(volatile int32_t *)ctx->regime_host != 0));
+                                                                : (target.n >= kFineMinStream && ctx->regime_host &&
+                                                                   *(volatile int32_t *)ctx->regime_host != 0));
             int32_t *regime_out = boxes ? ctx->regime_dev : (int32_t *)nullptr;
             auto launch = [&](auto kern) {
                 hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux, inv_den, boxes, tile_bad,
