@@ -714,22 +714,36 @@ void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T
     if (T <= 0) return;
     hipLaunchKernelGGL(tri_tile_bbox_kernel, dim3((unsigned)ceil_div(T, kTriTile)), dim3(256), 0, ctx->stream, v, tri, T, boxes);
 }
+// copies of every query held per workgroup (see surface_cp_kernel); default from the number of queries
+static int surface_h(int64_t nq) {
+    static const int forced = getenv("GINGR_SURFACE_H") ? atoi(getenv("GINGR_SURFACE_H")) : 0;
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) return forced;
+    // measured (femur chain, 1 622 queries x 3 240 triangles: 1 007 / 1 151 / 1 237 / 1 257 steps per second at H = 2 / 4 / 8 / 16;
+    // 41k queries x 82k triangles: 1 452 / 1 470 / 1 441 / 1 275 iterations per second): small meshes want many short workgroups
+    return nq <= 4096 ? 16 : (nq <= 16384 ? 8 : 4);
+}
 void launch_barycentric(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri_by_orig, const int32_t *tri_id, double *bary) {
     hipLaunchKernelGGL(barycentric_kernel, dim3((unsigned)ceil_div(q.n, 256)), dim3(256), 0, ctx->stream, q, v, tri_by_orig, tri_id, bary);
 }
 void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T,
                                   const double *boxes, double *cp_soa, double *d2, int32_t *tri_out) {
-    // developer knob GINGR_SURFACE_H = 1 | 2 | 4: queries per workgroup = 64 / H
-    static const int h = getenv("GINGR_SURFACE_H") ? atoi(getenv("GINGR_SURFACE_H")) : 2;
+    // queries per workgroup = 64 / H (developer knob GINGR_SURFACE_H = 1 | 2 | 4 | 8 | 16).  The kernel is bound by its longest
+    // workgroups: fewer queries per workgroup = more, shorter workgroups and a tighter query box for the tile pruning.
+    const int h = surface_h(q.n);
+    auto go = [&](auto kern, int qpb) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(q.n, qpb)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig, T, boxes,
+                           cp_soa, d2, tri_out);
+    };
     if (h == 1)
-        hipLaunchKernelGGL(surface_cp_kernel<1>, dim3((unsigned)ceil_div(q.n, 64)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig,
-                           T, boxes, cp_soa, d2, tri_out);
-    else if (h == 4)
-        hipLaunchKernelGGL(surface_cp_kernel<4>, dim3((unsigned)ceil_div(q.n, 16)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig,
-                           T, boxes, cp_soa, d2, tri_out);
+        go(surface_cp_kernel<1>, 64);
+    else if (h == 2)
+        go(surface_cp_kernel<2>, 32);
+    else if (h == 8)
+        go(surface_cp_kernel<8>, 8);
+    else if (h == 16)
+        go(surface_cp_kernel<16>, 4);
     else
-        hipLaunchKernelGGL(surface_cp_kernel<2>, dim3((unsigned)ceil_div(q.n, 32)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig,
-                           T, boxes, cp_soa, d2, tri_out);
+        go(surface_cp_kernel<4>, 16);
 }
 int distance_stats_ws_doubles() { return kStatBlocks * 4; }
 void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const int32_t *orig, int64_t orig_limit, const int32_t *nn,
@@ -741,16 +755,21 @@ void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const in
 }
 void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, const int32_t *tri, int64_t T, const double *boxes,
                            const int32_t *skip, int32_t *flag) {
-    static const int h = getenv("GINGR_SURFACE_H") ? atoi(getenv("GINGR_SURFACE_H")) : 2;  // developer knob, as launch_surface_closest_point
-    if (h == 4)
-        hipLaunchKernelGGL(self_intersect_kernel<4>, dim3((unsigned)ceil_div(fit.n, 16)), dim3(kCpThreads), 0, ctx->stream,
-                           fit, cp_soa, fit, tri, T, boxes, skip, flag);
-    else if (h == 1)
-        hipLaunchKernelGGL(self_intersect_kernel<1>, dim3((unsigned)ceil_div(fit.n, 64)), dim3(kCpThreads), 0, ctx->stream,
-                           fit, cp_soa, fit, tri, T, boxes, skip, flag);
+    const int h = surface_h(fit.n);
+    auto go = [&](auto kern, int qpb) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(fit.n, qpb)), dim3(kCpThreads), 0, ctx->stream, fit, cp_soa, fit, tri, T, boxes,
+                           skip, flag);
+    };
+    if (h == 1)
+        go(self_intersect_kernel<1>, 64);
+    else if (h == 2)
+        go(self_intersect_kernel<2>, 32);
+    else if (h == 8)
+        go(self_intersect_kernel<8>, 8);
+    else if (h == 16)
+        go(self_intersect_kernel<16>, 4);
     else
-        hipLaunchKernelGGL(self_intersect_kernel<2>, dim3((unsigned)ceil_div(fit.n, 32)), dim3(kCpThreads), 0, ctx->stream,
-                           fit, cp_soa, fit, tri, T, boxes, skip, flag);
+        go(self_intersect_kernel<4>, 16);
 }
 void launch_surface_prereject(gingr_ctx *ctx, int64_t M, const int32_t *nn_vertex, const int32_t *tgt_boundary,
                               const double *fit_vn, const double *tgt_vn, int64_t N, const int32_t *found, int32_t *pre) {
