@@ -867,7 +867,40 @@ template <int NT>
 __device__ __forceinline__ void lds_load_spd(double *A, int ld, int r, int n, const double *__restrict__ G, double ca,
                                              const double *__restrict__ S, double cs, double ci) {
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    constexpr int RB = NT / 16;  // rows per block of 16 columns: one element per thread and block, eight blocks in flight
+    constexpr int RB = NT / 16;  // rows per block of 16 columns: one element per thread and block
+    if (RB == 16 && n <= 128) {
+        // The LDS-resident case: all (at most 36) lower blocks are requested before the first value is used.  A lone workgroup
+        // sees the full memory latency per dependent batch; with batches of eight blocks this stage was four round trips.
+        double v[36];
+        int idx = 0;
+#pragma unroll
+        for (int bi = 0; bi < 8; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj, ++idx) {
+                const int i = bi * 16 + ty, j = bj * 16 + tx;
+                double t = 0.0;
+                if (bi * 16 < n) {  // workgroup-uniform
+                    const int g = min(i, r - 1) * n + min(j, r - 1);  // the global matrices have row stride rp == n
+                    t = ca * G[g];
+                    if (S) t = __builtin_fma(cs, S[g], t);
+                }
+                v[idx] = t;
+            }
+        idx = 0;
+#pragma unroll
+        for (int bi = 0; bi < 8; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj, ++idx) {
+                const int i = bi * 16 + ty, j = bj * 16 + tx;
+                if (bi * 16 < n && j <= i) {
+                    double t = v[idx];
+                    if (i == j) t += ci;
+                    A[i * ld + j] = (i < r && j < r) ? t : (i == j ? 1.0 : 0.0);
+                }
+            }
+        __syncthreads();
+        return;
+    }
     int ib = 0, jb = 0;          // block origin (workgroup-uniform)
     while (ib < n) {
         double v[8];
