@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_lds_kernel(int
                                                                    const double *__restrict__ rhs,
                                                                    const double *__restrict__ Stot,
                                                                    const double *__restrict__ qte,
-                                                                   double *__restrict__ lsave /* [rp][rp] global scratch */,
+                                                                   double *__restrict__ /* unused: was the parked factor */,
                                                                    double *__restrict__ out2, double *gwork) {
     extern __shared__ double lds_sm[];
     double *sm;
@@ -1196,46 +1196,67 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_lds_kernel(int
     double *A = sm;
     double *u = sm + (size_t)n * ld;  // extra row block of the bordered matrix
     double *rd = sm + (size_t)(n + kNB) * ld;
-    double *cv = rd + n;
     __shared__ int bad_spd;
     __shared__ double red[kSolveThreads];
     __shared__ double av[512];  // posterior coefficients a (rp <= 512)
+    __shared__ double hv[2][512];  // the two half sums of the mat-vecs
+    static_assert(kSolveThreads == 256, "the mat-vecs below split 256 threads into 128 entries x 2 halves");
     const int tid = threadIdx.x;
     if (tid == 0) bad_spd = 0;
-    // (1) a = (I + G)^-1 rhs: the posterior coefficients of the state (what posterior_solve_lds_kernel computes); the factor L of
-    //     I + G is needed again at the end (c = L^T u) and does not fit the LDS next to the second system: it goes to `lsave`
+    // (1) a = (I + G)^-1 rhs: the posterior coefficients of the state (what posterior_solve_lds_kernel computes)
     for (int k = tid; k < kNB * ld; k += kSolveThreads) u[k] = k < r ? rhs[k] : 0.0;
     lds_load_spd<kSolveThreads>(A, ld, r, n, G, 1.0, nullptr, 0.0, 1.0);
     lds_cholesky<kSolveThreads>(A, ld, n, rd, &bad_spd, kNB);  // u <- L^-1 rhs on the way
-    for (int e = tid; e < n * n; e += kSolveThreads) {
-        const int i = e / n, k = e - i * n;
-        lsave[e] = k <= i ? A[i * ld + k] : 0.0;
-    }
     lds_backward<kSolveThreads>(A, ld, n, rd, u);
     for (int k = tid; k < rp; k += kSolveThreads) av[k] = k < r ? u[k] : 0.0;
     __syncthreads();
-    // (2) b = Q0^T e - S_tot a
+    // (2) b = Q0^T e - S_tot a.  Two threads per entry (column halves of the symmetric S_tot: coalesced), four loads in flight
     for (int k = tid; k < kNB * ld; k += kSolveThreads) u[k] = 0.0;
     __syncthreads();
-    for (int k = tid; k < r; k += kSolveThreads) {
-        double s = qte[k];
-        for (int j = 0; j < r; ++j) s = __builtin_fma(-Stot[(int64_t)j * rp + k], av[j], s);  // S_tot symmetric: coalesced
-        u[k] = s;
+    {
+        const int k = tid & 127, half = tid >> 7;  // kSolveThreads == 256, r <= 512: entries k, k + 128, ...
+        for (int kk = k; kk < r; kk += 128) {
+            const int j0 = half ? (r + 1) / 2 : 0, j1 = half ? r : (r + 1) / 2;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int j = j0;
+            for (; j + 3 < j1; j += 4) {
+                s0 = __builtin_fma(Stot[(int64_t)j * rp + kk], av[j], s0);
+                s1 = __builtin_fma(Stot[(int64_t)(j + 1) * rp + kk], av[j + 1], s1);
+                s2 = __builtin_fma(Stot[(int64_t)(j + 2) * rp + kk], av[j + 2], s2);
+                s3 = __builtin_fma(Stot[(int64_t)(j + 3) * rp + kk], av[j + 3], s3);
+            }
+            for (; j < j1; ++j) s0 = __builtin_fma(Stot[(int64_t)j * rp + kk], av[j], s0);
+            hv[half][kk] = (s0 + s1) + (s2 + s3);
+        }
     }
+    __syncthreads();
+    for (int k = tid; k < r; k += kSolveThreads) u[k] = qte[k] - (hv[0][k] + hv[1][k]);
     // (3) u = (S_tot + eps (I + G))^-1 b
     lds_load_spd<kSolveThreads>(A, ld, r, n, G, GINGR_COEFF_NOISE, Stot, 1.0, GINGR_COEFF_NOISE);
     lds_cholesky<kSolveThreads>(A, ld, n, rd, &bad_spd, kNB);                                        // u <- L2^-1 u on the way
     lds_backward<kSolveThreads>(A, ld, n, rd, u);
     __syncthreads();
-    // (4) c = L^T u with the saved factor of I + G (written by this workgroup before the barriers above; L2 resident)
-    for (int k = tid; k < r; k += kSolveThreads) {
-        double s = 0.0;
-        for (int i = k; i < r; ++i) s = __builtin_fma(lsave[i * n + k], u[i], s);
-        cv[k] = s;
-    }
-    __syncthreads();
+    // (4) |c|^2 with c = L^T u, L L^T = I + G:  |c|^2 = u^T (I + G) u -- a quadratic form with G itself, so the first factor does
+    //     not have to survive the second factorisation (it used to be parked in a global scratch and read back)
     double part = 0.0;
-    for (int k = tid; k < r; k += kSolveThreads) part = __builtin_fma(cv[k], cv[k], part);
+    {
+        const int k = tid & 127, half = tid >> 7;
+        for (int kk = k; kk < r; kk += 128) {
+            const int j0 = half ? (r + 1) / 2 : 0, j1 = half ? r : (r + 1) / 2;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int j = j0;
+            for (; j + 3 < j1; j += 4) {  // G symmetric: G[j][kk], coalesced over kk
+                s0 = __builtin_fma(G[(int64_t)j * rp + kk], u[j], s0);
+                s1 = __builtin_fma(G[(int64_t)(j + 1) * rp + kk], u[j + 1], s1);
+                s2 = __builtin_fma(G[(int64_t)(j + 2) * rp + kk], u[j + 2], s2);
+                s3 = __builtin_fma(G[(int64_t)(j + 3) * rp + kk], u[j + 3], s3);
+            }
+            for (; j < j1; ++j) s0 = __builtin_fma(G[(int64_t)j * rp + kk], u[j], s0);
+            double g = (s0 + s1) + (s2 + s3);
+            if (half == 0) g += u[kk];
+            part = __builtin_fma(u[kk], g, part);
+        }
+    }
     red[tid] = part;
     __syncthreads();
     for (int st2 = kSolveThreads / 2; st2 > 0; st2 >>= 1) {
