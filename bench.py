@@ -616,6 +616,9 @@ def main():
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
+    if use_dist:
+        # rank 0 may still be busy with its single-shard replay / parity work: everybody leaves the process group together
+        dist.barrier()
     runner.close()
     ctx.close()
     if use_dist:
