@@ -142,3 +142,48 @@ def test_row_shards_of_a_two_kernel_model(ctx):
         part = ga.DeviceModel(ctx, dm, lo, hi).download()
         assert np.array_equal(part.variance, full.variance)
         assert np.array_equal(part.basis, full.basis[3 * lo:3 * hi])
+
+
+def test_argument_errors_of_the_new_entry_points(ctx):
+    """gingr_gpmm_build_diagonal / gingr_mesh_closest_points / gingr_model_new_reference refuse bad input with BAD_ARGUMENT."""
+    import ctypes
+    import gingr_amd as ga
+    from gingr_amd import _native as nat
+    from gingr_amd.api import ScalarKernelSpec, DevicePointDistributionModel, InterpolatedDevicePointDistributionModel
+    ref = cloud(50, 30)
+
+    def build(kx, ky, kz, tol=0.01):
+        return DevicePointDistributionModel(ctx, ref, [], [], tol, 0, kernels=(kx, ky, kz)).rank
+
+    g = ScalarKernelSpec("gauss", (40.0,), (5.0,))
+    for bad in (ScalarKernelSpec("gauss", (40.0,), (5.0,), mirror=0.5), ScalarKernelSpec("gauss", (-1.0,), (5.0,)),
+                ScalarKernelSpec("gauss", (), ()), ScalarKernelSpec("dot", scaling=0.0), ScalarKernelSpec("dot", scaling=float("nan"))):
+        with pytest.raises(ga.GingrNativeError) as e:
+            build(bad, g, g)
+        assert e.value.code == nat.ERR_BAD_ARGUMENT
+    with pytest.raises(ga.GingrNativeError):
+        build(g, g, g, tol=1.5)
+    k = nat.ScalarKernel()
+    k.kind = nat.KERNEL_LOOKUP
+    k.scaling = 1.0                                       # lookup table missing
+    h = ctypes.c_void_p()
+    rc = ctx._lib.gingr_gpmm_build_diagonal(ctx.handle, 50, nat.dptr(ref), ctypes.byref(k), ctypes.byref(k), ctypes.byref(k), 0.01, 0, 0, 0,
+                                            ctypes.byref(h))
+    assert rc == nat.ERR_BAD_ARGUMENT and not h.value
+    # closest points: vertex id out of range
+    V = cloud(10, 31)
+    with pytest.raises(ga.GingrNativeError):
+        ctx.mesh_closest_points(ref[:5], V, np.array([[0, 1, 10]]))
+    # new reference: source ids out of range, and a row-sharded source
+    model = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.05).Gaussian(40.0, 5.0)
+    ids = np.zeros((4, 3), dtype=np.int32)
+    ids[2, 1] = 50
+    with pytest.raises(ga.GingrNativeError):
+        InterpolatedDevicePointDistributionModel(ctx, model, ref[:4], ids, np.tile([1.0, 0, 0], (4, 1))).rank
+    shard = ga.DeviceModel(ctx, model, 0, 25)
+    out = ctypes.c_void_p()
+    ids[:] = 0
+    w = np.tile([1.0, 0.0, 0.0], (4, 1))
+    rc = ctx._lib.gingr_model_new_reference(ctx.handle, shard.handle, 4, nat.dptr(np.ascontiguousarray(ref[:4])), nat.iptr(ids), nat.dptr(w),
+                                            0, 0, ctypes.byref(out))
+    assert rc == nat.ERR_BAD_ARGUMENT and not out.value
