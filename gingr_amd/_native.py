@@ -94,6 +94,11 @@ SIGNATURES = {
     "gingr_mesh_distance_stats": (c_int, [c_void_p, c_int64, _dp, c_int64, _dp, c_int64, POINTER(c_int32), c_int32, c_double, _dp]),
     "gingr_fitter_update_icp_surface_sample_async": (c_int, [c_void_p, POINTER(IcpParams), _dp]),
     "gingr_fitter_posterior_logpdf_icp_surface": (c_int, [c_void_p, POINTER(IcpParams), _dp, POINTER(c_double)]),
+    "gingr_rigid_icp_create": (c_int, [c_void_p, c_int32, c_int64, _dp, c_int64, _dp, POINTER(c_void_p)]),
+    "gingr_rigid_icp_destroy": (None, [c_void_p]),
+    "gingr_rigid_icp_iterate": (c_int, [c_void_p, c_int32, _dp]),
+    "gingr_rigid_icp_get": (c_int, [c_void_p, _dp, _dp]),
+    "gingr_rigid_icp_set": (c_int, [c_void_p, _dp]),
     "gingr_mesh_closest_points": (c_int, [c_void_p, c_int64, _dp, c_int64, _dp, c_int64, _ip, _dp, _dp, _ip, _dp]),
     "gingr_model_new_reference": (c_int, [c_void_p, c_void_p, c_int64, _dp, _ip, _dp, c_int64, c_int64, POINTER(c_void_p)]),
     "gingr_gpmm_build_diagonal": (c_int, [c_void_p, c_int64, _dp, POINTER(ScalarKernel), POINTER(ScalarKernel), POINTER(ScalarKernel),

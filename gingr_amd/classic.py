@@ -142,3 +142,105 @@ class NonRigidCPDRegistration(RigidCPDRegistration):
 
 class AffineCPDRegistration(RigidCPDRegistration):
     _kind = AFFINE
+
+
+# ------------------------------------------------------------------------------------------------ classic rigid ICP
+RIGID_REGISTRATOR, AFFINE_REGISTRATOR = 0, 1   # PoseRegistrator.RigidRegistrator3D / AffineRegistrator3D (= similarity)
+
+
+class RigidICP:
+    """G/other/algorithms/icp/RigidICP.scala:24-84 over csrc/rigid_icp.hip: closest points, Umeyama and the transform of the
+    template run on the GPU; this class keeps `Registration`'s loop and convergence test."""
+
+    def __init__(self, factory: "ICPFactory", targetPoints):
+        self.icp = factory
+        self.target = f64(targetPoints)
+        self._lib = factory.ctx._lib
+        h = c_void_p()
+        _check(factory.ctx.handle, self._lib.gingr_rigid_icp_create(factory.ctx.handle, int(factory.registrator), factory.M,
+                                                                    dptr(factory.template), self.target.shape[0], dptr(self.target),
+                                                                    ctypes.byref(h)), "gingr_rigid_icp_create")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._lib.gingr_rigid_icp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def points(self) -> np.ndarray:
+        p = np.empty((self.icp.M, 3))
+        _check(self.icp.ctx.handle, self._lib.gingr_rigid_icp_get(self._h, dptr(p), None), "gingr_rigid_icp_get")
+        return p
+
+    def transform(self) -> Tuple[float, np.ndarray, np.ndarray]:
+        """(s, R, t) of the last iteration: p -> s R p + t"""
+        t = np.empty(13)
+        _check(self.icp.ctx.handle, self._lib.gingr_rigid_icp_get(self._h, None, dptr(t)), "gingr_rigid_icp_get")
+        return float(t[0]), t[1:10].reshape(3, 3).copy(), t[10:13].copy()
+
+    def Iteration(self, template=None) -> Tuple[np.ndarray, float]:
+        """(registered points, mean closest-point distance BEFORE the move)  (:75-82)"""
+        if template is not None:
+            tp = f64(template)
+            _check(self.icp.ctx.handle, self._lib.gingr_rigid_icp_set(self._h, dptr(tp)), "gingr_rigid_icp_set")
+        d = np.empty(1)
+        _check(self.icp.ctx.handle, self._lib.gingr_rigid_icp_iterate(self._h, 1, dptr(d)), "gingr_rigid_icp_iterate")
+        return self.points(), float(d[0])
+
+    def Registration(self, max_iteration: int, tolerance: float = 0.001, verbose: bool = False) -> np.ndarray:
+        """:30-55: stop when the mean distance changes by less than `tolerance` between two iterations (first comparison against
+        0.0); the converged iteration's points are the result."""
+        _check(self.icp.ctx.handle, self._lib.gingr_rigid_icp_set(self._h, dptr(self.icp.template)), "gingr_rigid_icp_set")
+        last = 0.0
+        i, converged = 0, False
+        self.iterations = 0
+        d = np.empty(1)
+        while i < max_iteration and not converged:
+            _check(self.icp.ctx.handle, self._lib.gingr_rigid_icp_iterate(self._h, 1, dptr(d)), "gingr_rigid_icp_iterate")
+            if verbose:
+                print(f"ICP, iteration: {i}, distance: {d[0]}")
+            if abs(d[0] - last) < tolerance:
+                if verbose:
+                    print("Converged")
+                converged = True
+            last = float(d[0])
+            i += 1
+        self.iterations, self.converged, self.distance = i, converged, last
+        return self.points()
+
+
+class ICPFactory:
+    """G/other/algorithms/icp/ICPFactory.scala:28-38 (`registrator`: RIGID_REGISTRATOR or AFFINE_REGISTRATOR, the implicit
+    Registrator of the reference)."""
+
+    def __init__(self, ctx: Context, templatePoints, registrator: int = RIGID_REGISTRATOR):
+        self.ctx, self.template, self.registrator = ctx, f64(templatePoints), registrator
+        self.M = self.template.shape[0]
+
+    def registerRigidly(self, targetPoints) -> RigidICP:
+        return RigidICP(self, targetPoints)
+
+
+class RigidICPRegistration:
+    """G/other/algorithms/RigidICPRegistration.scala:24-46.  As in the reference the warp field pairs the TARGET's points with the
+    registered template points by index (`target.points zip registration.points`, :40-43), i.e. the result is the registered
+    template carried on the target's topology -- both point sets must have the same size for that to mean anything."""
+
+    def __init__(self, ctx: Context, template, max_iterations: int = 100, registrator: int = RIGID_REGISTRATOR):
+        self.icp, self.max_iterations = ICPFactory(ctx, template, registrator), max_iterations
+
+    def register(self, target) -> np.ndarray:
+        task = self.icp.registerRigidly(target)
+        try:
+            reg = task.Registration(self.max_iterations)
+        finally:
+            task.close()
+        tgt = f64(target)
+        n = min(tgt.shape[0], reg.shape[0])
+        return tgt[:n] + (reg[:n] - tgt[:n])

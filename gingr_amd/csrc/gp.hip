@@ -24,41 +24,7 @@ namespace {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-// ------------------------------------------------------------------------------------------ rotation conventions
-// scalismo RotationSpace3D: R = Rz(phi) Ry(theta) Rx(psi) ("x-convention"), and Slabaugh's inverse.
-__host__ __device__ inline void euler_to_rot(const double e[3], double R[9]) {
-    const double cphi = cos(e[0]), sphi = sin(e[0]);
-    const double cth = cos(e[1]), sth = sin(e[1]);
-    const double cpsi = cos(e[2]), spsi = sin(e[2]);
-    R[0] = cth * cphi;
-    R[1] = spsi * sth * cphi - cpsi * sphi;
-    R[2] = spsi * sphi + cpsi * sth * cphi;
-    R[3] = cth * sphi;
-    R[4] = cpsi * cphi + spsi * sth * sphi;
-    R[5] = cpsi * sth * sphi - spsi * cphi;
-    R[6] = -sth;
-    R[7] = spsi * cth;
-    R[8] = cpsi * cth;
-}
-
-__host__ __device__ inline void rot_to_euler(const double R[9], double e[3]) {
-    if (fabs(fabs(R[6]) - 1) > 0.0001) {
-        const double theta = asin(-R[6]);
-        const double ct = cos(theta);
-        e[2] = atan2(R[7] / ct, R[8] / ct);
-        e[0] = atan2(R[3] / ct, R[0] / ct);
-        e[1] = theta;
-    } else {
-        e[0] = 0.0;  // gimbal lock: phi := 0
-        if (fabs(R[6] + 1) < 0.0001) {
-            e[1] = 3.14159265358979323846 / 2.0;
-            e[2] = e[0] + atan2(R[1], R[2]);
-        } else {
-            e[1] = -3.14159265358979323846 / 2.0;
-            e[2] = -e[0] + atan2(-R[1], -R[2]);
-        }
-    }
-}
+// rotation conventions (euler_to_rot / rot_to_euler): svd3.h
 
 __device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= 1.79769313486231570815e308; }
 

@@ -412,6 +412,23 @@ int gingr_classic_cpd_iterate(gingr_classic_cpd *h, int32_t n_iterations);
 int gingr_classic_cpd_get(gingr_classic_cpd *h, double *ty_xyz, double *sigma2, double *transform13, double *w_xyz);
 int gingr_classic_cpd_set(gingr_classic_cpd *h, const double *ty_xyz, double sigma2);
 
+/* ---- classic rigid / similarity ICP (the reference's other/ baseline) ------------------------------------------------
+ * G/other/algorithms/icp/RigidICP.scala:24-84 (Iteration / Registration), ICPFactory.scala:28-38, RigidICPRegistration.scala:24-46
+ * with the two registrators of G/other/utils/PoseRegistrator.scala:27-43: kind 0 = RigidRegistrator3D
+ * (LandmarkRegistration.rigid3DLandmarkRegistration about the origin), kind 1 = AffineRegistrator3D
+ * (similarity3DLandmarkRegistration).  One iteration = closest target point of every template point (exact, lowest index on
+ * ties), least-squares transform of the pairs, template <- transform(template); the template lives in HBM.
+ * gingr_rigid_icp_iterate: distances[k] (nullable) = mean closest-point distance measured by iteration k BEFORE it moves the
+ * template (RigidICP.scala:60-71,79-82) -- what Registration's convergence test compares.  _get: current template [3M] and the
+ * last transform {s, R[9] row-major, t[3]} (either may be NULL).  _set: replace the template points. */
+typedef struct gingr_rigid_icp gingr_rigid_icp;
+int gingr_rigid_icp_create(gingr_ctx *ctx, int32_t kind, int64_t M, const double *moving_xyz, int64_t N, const double *target_xyz,
+                           gingr_rigid_icp **out);
+void gingr_rigid_icp_destroy(gingr_rigid_icp *h);
+int gingr_rigid_icp_iterate(gingr_rigid_icp *h, int32_t n_iterations, double *distances);
+int gingr_rigid_icp_get(gingr_rigid_icp *h, double *points_xyz, double *transform13);
+int gingr_rigid_icp_set(gingr_rigid_icp *h, const double *points_xyz);
+
 #ifdef __cplusplus
 }
 #endif

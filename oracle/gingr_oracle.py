@@ -1376,3 +1376,29 @@ def classic_cpd_registration(template, target, kind: str, lam: float = 2.0, beta
             i += 1
         sigma2 = new
     return TY, sigma2, i, converged
+
+
+# --------------------------------------------------------------------------
+# classic rigid ICP baseline   [REF G/other/algorithms/icp/RigidICP.scala, G/other/utils/PoseRegistrator.scala]
+# --------------------------------------------------------------------------
+
+def rigid_icp_iteration(template: np.ndarray, target: np.ndarray, similarity: bool = False):
+    """RigidICP.Iteration (:75-82): closest target point of every template point, the landmark registration of the pairs about the
+    origin (rigid3D / similarity3DLandmarkRegistration), the template moved by it; the distance is measured before the move."""
+    idx, d2, dist = icp_closest_point(template, target)
+    R, t, s = umeyama(template, target[idx], similarity)
+    return s * (template @ R.T) + t, dist, (s, R, t)
+
+
+def rigid_icp_registration(template: np.ndarray, target: np.ndarray, max_iteration: int, tolerance: float = 0.001,
+                           similarity: bool = False):
+    """RigidICP.Registration (:30-55) -> (points, iterations, converged)"""
+    fit, last = np.asarray(template, dtype=np.float64), 0.0
+    i, converged = 0, False
+    while i < max_iteration and not converged:
+        ty, dist, _ = rigid_icp_iteration(fit, target, similarity)
+        if abs(dist - last) < tolerance:
+            converged = True
+        fit, last = ty, dist
+        i += 1
+    return fit, i, converged
