@@ -80,22 +80,56 @@ struct Best {
     int32_t i;
 };
 
-__device__ __forceinline__ Best better(Best a, Best b) {  // larger value; ties -> lower index; NaN never wins
+// scalismo's loop takes the FIRST maximal residual in its current PERMUTED index order: step s swaps the pivot into slot s and the
+// element that sat there into the pivot's old slot.  With distinct residuals the order is irrelevant, but structured inputs tie
+// exactly (a regular grid under a stationary kernel, mirror partners under the mirrored kernel, all entries at step 0), and a rank
+// cut inside a group of tied pivots then depends on who went first.  The swaps are kept as a log -- step s: pivot piv[s], displaced
+// element dis[s], the pivot's old slot old[s] -- and a tie is resolved by replaying it for the two candidates (O(steps), ties are
+// rare).  `vp / vd / vo` is one more entry that is not in memory yet (the step a kernel is executing).
+struct PosLog {
+    const int32_t *piv, *dis, *old;
+    int32_t n;           // entries in memory
+    int32_t vp, vd, vo;  // virtual entry (vp < 0: none)
+};
+
+__device__ __forceinline__ int32_t log_position(const PosLog &lg, int32_t e) {
+    int32_t q = e;
+    for (int32_t s = 0; s < lg.n; ++s) {
+        if (lg.piv[s] == e) return s;  // pivots stay where they were put (they never compete again)
+        if (lg.dis[s] == e) q = lg.old[s];
+    }
+    if (lg.vp >= 0) {
+        if (lg.vp == e) return lg.n;
+        if (lg.vd == e) q = lg.vo;
+    }
+    return q;
+}
+
+// the element in slot `slot` (>= lg.n) after the logged swaps
+__device__ __forceinline__ int32_t log_occupant(const PosLog &lg, int32_t slot) {
+    int32_t e = slot;
+    for (int32_t s = 0; s < lg.n; ++s)
+        if (lg.old[s] == slot) e = lg.dis[s];
+    return e;
+}
+
+__device__ __forceinline__ Best better(Best a, Best b, const PosLog &lg) {  // larger value; ties -> earlier slot; NaN never wins
     if (b.i < 0) return a;
     if (a.i < 0) return b;
-    if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+    if (b.v > a.v) return b;
+    if (b.v == a.v && log_position(lg, b.i) < log_position(lg, a.i)) return b;
     return a;
 }
 
 // block-wide (max, argmax, sum) with a fixed tree: identical in every workgroup that reduces the same data
-__device__ __forceinline__ void block_best_sum(Best &b, double &sum, Best *shb, double *shs) {
+__device__ __forceinline__ void block_best_sum(Best &b, double &sum, Best *shb, double *shs, const PosLog &lg) {
     const int t = threadIdx.x;
     shb[t] = b;
     shs[t] = sum;
     __syncthreads();
     for (int off = kPcBlock / 2; off > 0; off >>= 1) {
         if (t < off) {
-            shb[t] = better(shb[t], shb[t + off]);
+            shb[t] = better(shb[t], shb[t + off], lg);
             shs[t] += shs[t + off];
         }
         __syncthreads();
@@ -105,7 +139,15 @@ __device__ __forceinline__ void block_best_sum(Best &b, double &sum, Best *shb, 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(kPcBlock) void pc_init_kernel(Cloud pts, KSpec spec, double *__restrict__ diag,
+// GEN = false: one scalar kernel, entries = points.  GEN = true: the generic factorisation over the 3M (point, coordinate) entries
+// of a DiagonalKernel(k_x, k_y, k_z) whose coordinates have DIFFERENT kernels (entry e = 3 point + coordinate; entries of
+// different coordinates never interact: their column values are exact zeros).
+struct KSpec3 {
+    KSpec k[3];
+};
+
+template <bool GEN>
+__global__ __launch_bounds__(kPcBlock) void pc_init_kernel(Cloud pts, KSpec3 specs, double *__restrict__ diag,
                                                            int32_t *__restrict__ pivoted, double *__restrict__ pmax,
                                                            int32_t *__restrict__ pidx, double *__restrict__ ptr,
                                                            int32_t *__restrict__ ctl) {
@@ -114,24 +156,27 @@ __global__ __launch_bounds__(kPcBlock) void pc_init_kernel(Cloud pts, KSpec spec
     __shared__ double shs[kPcBlock];
     fastexp_table_init(T);
     __syncthreads();
-    const int64_t M = pts.n;
+    const int64_t n = GEN ? 3 * pts.n : pts.n;
     const int64_t c = (int64_t)blockIdx.x * kPcBlock + threadIdx.x;
     Best b{0.0, -1};
     double tr = 0.0;
-    if (c < M) {
+    if (c < n) {
+        const int64_t pc = GEN ? c / 3 : c;
+        const KSpec &spec = specs.k[GEN ? (int)(c - 3 * pc) : 0];
         double d0;
         if (spec.kind == 0 && spec.mirror == 0.0) {
             d0 = 0.0;
             for (int i = 0; i < spec.mix.n; ++i) d0 = i == 0 ? spec.mix.s[i] : d0 + spec.mix.s[i];  // k(x,x) = sum scaling_i * exp(0)
         } else {
-            d0 = kspec_value(spec, pts, c, c, pts.x[c], pts.y[c], pts.z[c], T);
+            d0 = kspec_value(spec, pts, pc, pc, pts.x[pc], pts.y[pc], pts.z[pc], T);
         }
         diag[c] = d0;
         pivoted[c] = 0;
         b = Best{d0, (int32_t)c};
         tr = d0;
     }
-    block_best_sum(b, tr, shb, shs);
+    const PosLog none{nullptr, nullptr, nullptr, 0, -1, 0, 0};  // nothing swapped yet: ties -> lowest index
+    block_best_sum(b, tr, shb, shs, none);
     if (threadIdx.x == 0) {
         pmax[blockIdx.x] = b.v;
         pidx[blockIdx.x] = b.i;
@@ -142,78 +187,90 @@ __global__ __launch_bounds__(kPcBlock) void pc_init_kernel(Cloud pts, KSpec spec
 
 // One pivot step.  Every workgroup first reduces the previous step's block partials (same data, same tree => same pivot
 // everywhere, no grid synchronisation), then fills its rows of column k.
-// peek != 0: only the reduction of the previous step's partials -- trace[k], pval[k], pivots[k] of the NEXT pivot are recorded, no
-// column is produced and the stop flag is only raised on exhaustion (the per-coordinate merge of gingr_gpmm_build_diagonal looks
-// one pivot ahead before it decides which coordinate advances).
-__global__ __launch_bounds__(kPcBlock) void pc_step_kernel(Cloud pts, KSpec mix, int32_t k, int32_t kmax, double rel_tol,
-                                                           int32_t nblocks, double *__restrict__ L /* [kmax][M] */,
+template <bool GEN>
+__global__ __launch_bounds__(kPcBlock) void pc_step_kernel(Cloud pts, KSpec3 specs, int32_t k, int32_t kmax, double rel_tol,
+                                                           int32_t nblocks, double *__restrict__ L /* [kmax][n] */,
                                                            double *__restrict__ diag, int32_t *__restrict__ pivoted,
                                                            const double *__restrict__ pmax_in,
                                                            const int32_t *__restrict__ pidx_in,
                                                            const double *__restrict__ ptr_in, double *__restrict__ pmax,
                                                            int32_t *__restrict__ pidx, double *__restrict__ ptr,
                                                            int32_t *__restrict__ ctl, double *__restrict__ trace,
-                                                           int32_t *__restrict__ pivots, double *__restrict__ pval,
-                                                           int32_t peek) {
+                                                           int32_t *__restrict__ pivots, int32_t *__restrict__ sw_dis,
+                                                           int32_t *__restrict__ sw_old) {
     __shared__ double T[GINGR_EXP_TABLE];
     __shared__ Best shb[kPcBlock];
     __shared__ double shs[kPcBlock];
     __shared__ double Lp[512];
-    __shared__ int32_t finished;
+    __shared__ int32_t finished, sh_dis, sh_old;
     const int t = threadIdx.x;
     if (t == 0) finished = ctl[1];  // set by an earlier launch (or, harmlessly, by workgroup 0 of this one)
     __syncthreads();
     if (finished) return;
     fastexp_table_init(T);
+    PosLog lg{pivots, sw_dis, sw_old, k, -1, 0, 0};  // the swaps of steps 0 .. k-1 (written by earlier launches)
     Best g{0.0, -1};
     double gtr = 0.0;
     for (int b = t; b < nblocks; b += kPcBlock) {
-        g = better(g, Best{pmax_in[b], pidx_in[b]});
+        g = better(g, Best{pmax_in[b], pidx_in[b]}, lg);
         gtr += ptr_in[b];
     }
-    block_best_sum(g, gtr, shb, shs);
+    block_best_sum(g, gtr, shb, shs, lg);
     const double tol = rel_tol * trace[0];  // trace[0] was written by step 0 (k == 0 uses gtr itself)
-    const bool exhausted = g.i < 0 || !(g.v > 0.0);
-    const bool stop = exhausted || (!peek && (k >= kmax || !(gtr >= (k == 0 ? rel_tol * gtr : tol))));
+    const bool stop = k >= kmax || g.i < 0 || !(gtr >= (k == 0 ? rel_tol * gtr : tol)) || !(g.v > 0.0);
+    if (t == 0 && !stop) {  // this step's swap: every workgroup derives it, workgroup 0 records it
+        sh_old = log_position(lg, g.i);
+        sh_dis = log_occupant(lg, k);
+    }
     if (blockIdx.x == 0 && t == 0) {
         trace[k] = gtr;
-        pval[k] = exhausted ? 0.0 : g.v;
         if (stop) {
             ctl[0] = k;
             ctl[1] = 1;
         } else {
             pivots[k] = g.i;
+            sw_dis[k] = sh_dis;
+            sw_old[k] = sh_old;
         }
     }
-    if (stop || peek) return;
-    const int64_t M = pts.n;
+    if (stop) return;
+    const int64_t M = pts.n, n = GEN ? 3 * M : M;
     const int64_t p = g.i;
+    const int64_t pp = GEN ? p / 3 : p;
+    const int pd = GEN ? (int)(p - 3 * pp) : 0;
+    const KSpec &spec = specs.k[pd];
     const double lpk = sqrt(g.v);
-    for (int r = t; r < k; r += kPcBlock) Lp[r] = L[(int64_t)r * M + p];
+    for (int r = t; r < k; r += kPcBlock) Lp[r] = L[(int64_t)r * n + p];
     __syncthreads();
-    const double px = pts.x[p], py = pts.y[p], pz = pts.z[p];
+    lg.vp = (int32_t)p, lg.vd = sh_dis, lg.vo = sh_old;  // the candidates of the NEXT step compete in the order after this swap
+    const double px = pts.x[pp], py = pts.y[pp], pz = pts.z[pp];
     const int64_t c = (int64_t)blockIdx.x * kPcBlock + t;
     Best b{0.0, -1};
     double tr = 0.0;
-    if (c < M) {
+    if (c < n) {
+        const int64_t pc = GEN ? c / 3 : c;
         double l;
         if (c == p) {
             l = lpk;
             pivoted[c] = 1;
         } else if (pivoted[c]) {
             l = 0.0;
+        } else if (GEN && (int)(c - 3 * pc) != pd) {
+            l = 0.0;  // another coordinate: exact zero, the residual is untouched
+            b = Best{diag[c], (int32_t)c};
+            tr = b.v;
         } else {
             double S = 0.0;
-            for (int r = 0; r < k; ++r) S = __dadd_rn(S, __dmul_rn(L[(int64_t)r * M + c], Lp[r]));
-            l = (kspec_value(mix, pts, c, p, px, py, pz, T) - S) / lpk;
+            for (int r = 0; r < k; ++r) S = __dadd_rn(S, __dmul_rn(L[(int64_t)r * n + c], Lp[r]));
+            l = (kspec_value(spec, pts, pc, pp, px, py, pz, T) - S) / lpk;
             const double dc = __dadd_rn(diag[c], -__dmul_rn(l, l));
             diag[c] = dc;
             b = Best{dc, (int32_t)c};
             tr = dc;
         }
-        L[(int64_t)k * M + c] = l;
+        L[(int64_t)k * n + c] = l;
     }
-    block_best_sum(b, tr, shb, shs);
+    block_best_sum(b, tr, shb, shs, lg);
     if (t == 0) {
         pmax[blockIdx.x] = b.v;
         pidx[blockIdx.x] = b.i;
@@ -470,65 +527,63 @@ int gingr_pointset_distance_extrema(gingr_ctx *ctx, const double *xyz, int64_t n
 
 namespace {
 
-// The pivoted Cholesky factor of ONE scalar kernel over the M points, grown on demand.
-struct ScalarFactor {
+// The pivoted Cholesky factorisation on the device: over the M points for one scalar kernel, or (gen) over the 3M (point,
+// coordinate) entries of a DiagonalKernel whose coordinates have different kernels.
+struct Factor {
     gingr_ctx *ctx = nullptr;
-    KSpec spec{};
+    KSpec3 specs{};
     Cloud pts{};
-    int64_t M = 0;
+    bool gen = false;
+    int64_t n = 0;     // entries
     int nb = 0;
-    int32_t kcap = 0;   // columns the buffers can hold
-    int32_t ks = 0;     // columns computed so far
-    int32_t known = -1; // trace / pval / pivots are known on the host for steps 0 .. known
-    bool finished = false;  // the device raised the stop flag (tolerance, capacity or exhaustion) at step `stop_at`
-    int32_t stop_at = 0;
-    DevBuf Lb, diag, piv, part, ctl, trace, pivots, pval;
-    std::vector<double> htrace, hpval;
-    std::vector<int32_t> hpiv;
+    int32_t kcap = 0;  // columns the buffers can hold
+    int32_t ks = 0;    // columns computed
+    DevBuf Lb, diag, piv, part, ctl, trace, pivots, swd, swo;
+    std::vector<double> htrace;
     double *pmaxv[2]{}, *ptrv[2]{};
     int32_t *pidxv[2]{};
 
-    int init(gingr_ctx *c, const KSpec &k, const Cloud &p, int32_t cap) {
-        ctx = c, spec = k, pts = p, M = p.n, kcap = cap;
-        nb = (int)ceil_div(M, kPcBlock);
-        HIP_TRY(ctx, Lb.alloc((size_t)kcap * M * sizeof(double)));
-        HIP_TRY(ctx, diag.alloc((size_t)M * sizeof(double)));
-        HIP_TRY(ctx, piv.alloc((size_t)M * sizeof(int32_t)));
+    int init(gingr_ctx *c, const KSpec3 &k, const Cloud &p, bool generic, int32_t cap) {
+        ctx = c, specs = k, pts = p, gen = generic, n = generic ? 3 * p.n : p.n, kcap = cap;
+        nb = (int)ceil_div(n, kPcBlock);
+        HIP_TRY(ctx, Lb.alloc((size_t)kcap * n * sizeof(double)));
+        HIP_TRY(ctx, diag.alloc((size_t)n * sizeof(double)));
+        HIP_TRY(ctx, piv.alloc((size_t)n * sizeof(int32_t)));
         HIP_TRY(ctx, part.alloc((size_t)2 * nb * (2 * sizeof(double) + sizeof(int32_t)) + 64));
         HIP_TRY(ctx, ctl.alloc(2 * sizeof(int32_t)));
         HIP_TRY(ctx, trace.alloc((size_t)(kcap + 1) * sizeof(double)));
-        HIP_TRY(ctx, pval.alloc((size_t)(kcap + 1) * sizeof(double)));
         HIP_TRY(ctx, pivots.alloc((size_t)(kcap + 1) * sizeof(int32_t)));
+        HIP_TRY(ctx, swd.alloc((size_t)(kcap + 1) * sizeof(int32_t)));
+        HIP_TRY(ctx, swo.alloc((size_t)(kcap + 1) * sizeof(int32_t)));
         pmaxv[0] = part.as<double>(), pmaxv[1] = part.as<double>() + nb;
         ptrv[0] = part.as<double>() + 2 * nb, ptrv[1] = part.as<double>() + 3 * nb;
         pidxv[0] = reinterpret_cast<int32_t *>(part.as<double>() + 4 * nb), pidxv[1] = pidxv[0] + nb;
-        hipLaunchKernelGGL(pc_init_kernel, dim3(nb), dim3(kPcBlock), 0, ctx->stream, pts, spec, diag.as<double>(), piv.as<int32_t>(),
-                           pmaxv[0], pidxv[0], ptrv[0], ctl.as<int32_t>());
+        if (gen)
+            hipLaunchKernelGGL(pc_init_kernel<true>, dim3(nb), dim3(kPcBlock), 0, ctx->stream, pts, specs, diag.as<double>(),
+                               piv.as<int32_t>(), pmaxv[0], pidxv[0], ptrv[0], ctl.as<int32_t>());
+        else
+            hipLaunchKernelGGL(pc_init_kernel<false>, dim3(nb), dim3(kPcBlock), 0, ctx->stream, pts, specs, diag.as<double>(),
+                               piv.as<int32_t>(), pmaxv[0], pidxv[0], ptrv[0], ctl.as<int32_t>());
         return check(ctx);
     }
 
-    void launch(int32_t k, double rel_tol, int32_t peek) {
+    void launch(int32_t k, double rel_tol) {
         const int in = k & 1, o = in ^ 1;
-        hipLaunchKernelGGL(pc_step_kernel, dim3(nb), dim3(kPcBlock), 0, ctx->stream, pts, spec, k, kcap, rel_tol, nb, Lb.as<double>(),
-                           diag.as<double>(), piv.as<int32_t>(), pmaxv[in], pidxv[in], ptrv[in], pmaxv[o], pidxv[o], ptrv[o],
-                           ctl.as<int32_t>(), trace.as<double>(), pivots.as<int32_t>(), pval.as<double>(), peek);
+        if (gen)
+            hipLaunchKernelGGL(pc_step_kernel<true>, dim3(nb), dim3(kPcBlock), 0, ctx->stream, pts, specs, k, kcap, rel_tol, nb,
+                               Lb.as<double>(), diag.as<double>(), piv.as<int32_t>(), pmaxv[in], pidxv[in], ptrv[in], pmaxv[o], pidxv[o],
+                               ptrv[o], ctl.as<int32_t>(), trace.as<double>(), pivots.as<int32_t>(), swd.as<int32_t>(), swo.as<int32_t>());
+        else
+            hipLaunchKernelGGL(pc_step_kernel<false>, dim3(nb), dim3(kPcBlock), 0, ctx->stream, pts, specs, k, kcap, rel_tol, nb,
+                               Lb.as<double>(), diag.as<double>(), piv.as<int32_t>(), pmaxv[in], pidxv[in], ptrv[in], pmaxv[o], pidxv[o],
+                               ptrv[o], ctl.as<int32_t>(), trace.as<double>(), pivots.as<int32_t>(), swd.as<int32_t>(), swo.as<int32_t>());
     }
 
-    int read_back(int32_t upto) {  // steps 0 .. upto
-        htrace.resize((size_t)upto + 1), hpval.resize((size_t)upto + 1), hpiv.resize((size_t)upto + 1);
-        HIP_TRY(ctx, hipMemcpyAsync(htrace.data(), trace.p, htrace.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(hpval.data(), pval.p, hpval.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(hpiv.data(), pivots.p, hpiv.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        known = upto;
-        return GINGR_OK;
-    }
-
-    // the whole factorisation under the scalar stopping rule (one kernel for all three coordinates)
+    // the whole factorisation under the device's stopping rule (residual trace below rel_tol * trace, capacity, exhaustion)
     int run_to_tolerance(double rel_tol) {
         int32_t hctl[2] = {0, 0};
         for (int32_t k = 0; k <= kcap; ++k) {
-            launch(k, rel_tol, 0);
+            launch(k, rel_tol);
             if ((k & 15) == 15 || k == kcap) {  // look at the stop flag now and then instead of queueing no-op launches
                 GINGR_TRY(check(ctx));
                 HIP_TRY(ctx, hipMemcpyAsync(hctl, ctl.p, sizeof(hctl), hipMemcpyDeviceToHost, ctx->stream));
@@ -537,31 +592,26 @@ struct ScalarFactor {
             }
         }
         if (!hctl[1]) return gingr_set_error(ctx, GINGR_ERR_STATE, "gpmm_build: pivoted Cholesky did not terminate");
-        finished = true, stop_at = ks = hctl[0];
-        return read_back(ks);
-    }
-
-    // make trace / pval / pivots of step j known (columns 0 .. j-1 computed, step j peeked); no tolerance: the merge decides
-    int ensure(int32_t j) {
-        if (j <= known) return GINGR_OK;
-        if (finished) return GINGR_OK;  // nothing beyond stop_at will ever exist
-        const int32_t target = std::min<int32_t>(kcap, std::max<int32_t>(j, known + 16));
-        for (int32_t k = ks; k < target; ++k) launch(k, 0.0, 0);
-        launch(target, 0.0, 1);
-        GINGR_TRY(check(ctx));
-        int32_t hctl[2] = {0, 0};
-        HIP_TRY(ctx, hipMemcpyAsync(hctl, ctl.p, sizeof(hctl), hipMemcpyDeviceToHost, ctx->stream));
+        ks = hctl[0];
+        htrace.resize((size_t)ks + 1);
+        HIP_TRY(ctx, hipMemcpyAsync(htrace.data(), trace.p, htrace.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (hctl[1]) {
-            finished = true, stop_at = hctl[0];
-            ks = stop_at;
-            return read_back(stop_at);
-        }
-        ks = target;
-        if (target == kcap) finished = true, stop_at = kcap;
-        return read_back(target);
+        return GINGR_OK;
     }
 };
+
+// Q0[(3s+d)*rp + q] = B[q][3 (row_begin + perm[s]) + d]: the generic factor's columns are already (point, coordinate) interleaved
+__global__ __launch_bounds__(256) void gpmm_pack_generic_kernel(const double *__restrict__ B, int64_t M_total, int64_t row_begin,
+                                                                int64_t M, int32_t r, int32_t rp, const int32_t *__restrict__ perm,
+                                                                double *__restrict__ Q0) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 3 * M * rp) return;
+    const int64_t row = idx / rp;
+    const int32_t q = (int32_t)(idx - row * rp);
+    const int64_t s = row / 3;
+    const int d = (int)(row - 3 * s);
+    Q0[idx] = q < r ? B[(int64_t)q * 3 * M_total + 3 * (row_begin + (perm ? perm[s] : s)) + d] : 0.0;
+}
 
 bool same_kernel(const gingr_scalar_kernel *a, const gingr_scalar_kernel *b) {
     if (a == b) return true;
@@ -645,14 +695,59 @@ int gingr_gpmm_build_diagonal(gingr_ctx *ctx, int64_t M_total, const double *ref
     const double *sp0 = soa.as<double>();
     const Cloud pts{sp0, sp0 + M, sp0 + 2 * M, M};
 
-    ScalarFactor fac[3];
+    if (row_end <= 0) row_end = M_total;
+    std::vector<double> zero_mean((size_t)3 * M_total, 0.0);
+    KSpec3 sp3;
+    for (int d = 0; d < 3; ++d) sp3.k[d] = specs[dim_set[d]];
+    if (nsets > 1) {
+        // Coordinates with different kernels: scalismo's generic factorisation itself, over the 3M (point, coordinate) entries --
+        // argmax of the residual diagonal in the permuted entry order, stop at relTol * trace -- then the eigen-decomposition of
+        // L^T L and U sqrt(lambda) = L V, exactly as for any matrix-valued kernel.
+        Factor fg;
+        GINGR_TRY(fg.init(ctx, sp3, pts, true, (int32_t)std::min<int64_t>(3 * M, max_rank)));
+        GINGR_TRY(fg.run_to_tolerance(relative_tolerance));
+        const int32_t n = fg.ks;
+        if (n < 1) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: empty model (tolerance too large)");
+        DevBuf G, wA, wV, ev, V, B, sw;
+        HIP_TRY(ctx, G.alloc((size_t)n * n * sizeof(double)));
+        HIP_TRY(ctx, wA.alloc((size_t)n * n * sizeof(double)));
+        HIP_TRY(ctx, wV.alloc((size_t)n * n * sizeof(double)));
+        HIP_TRY(ctx, ev.alloc((size_t)(n + 1) * sizeof(double)));
+        HIP_TRY(ctx, V.alloc((size_t)(n * n + 1) * sizeof(double)));
+        HIP_TRY(ctx, B.alloc((size_t)n * 3 * M * sizeof(double)));
+        HIP_TRY(ctx, sw.alloc(sizeof(int32_t)));
+        HIP_TRY(ctx, hipMemsetAsync(sw.p, 0, sizeof(int32_t), ctx->stream));
+        hipLaunchKernelGGL(pc_gram_kernel, dim3(n, n), dim3(kPcBlock), 0, ctx->stream, fg.Lb.as<double>(), 3 * M, n, G.as<double>());
+        hipLaunchKernelGGL(jacobi_eig_kernel, dim3(1), dim3(kJacThreads), 0, ctx->stream, G.as<double>(), n, n, wA.as<double>(),
+                           wV.as<double>(), ev.as<double>(), V.as<double>(), sw.as<int32_t>());
+        hipLaunchKernelGGL(lv_kernel, dim3((unsigned)ceil_div(3 * M, 256), n), dim3(256), 0, ctx->stream, fg.Lb.as<double>(), 3 * M, n,
+                           V.as<double>(), B.as<double>());
+        GINGR_TRY(check(ctx));
+        std::vector<double> hev((size_t)n);
+        int32_t hsw = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(hev.data(), ev.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&hsw, sw.p, sizeof(hsw), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (hsw >= 60) return gingr_set_error(ctx, GINGR_ERR_NONFINITE, "gpmm_build: Jacobi did not converge");
+        for (auto &v : hev) v = v > 0.0 ? v : 0.0;
+        auto fill = [&](gingr_model *m) -> int {
+            const int64_t total = 3 * m->M * m->rp;
+            hipLaunchKernelGGL(gpmm_pack_generic_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, B.as<double>(),
+                               M_total, m->row_begin, m->M, m->r, m->rp, m->perm, m->Q0);
+            return check(ctx);
+        };
+        return model_create_impl(ctx, M_total, n, ref, zero_mean.data(), hev.data(), row_begin, row_end, fill, out);
+    }
+
+    // One kernel for all coordinates: the generic pivot sequence is (P0,x),(P0,y),(P0,z),(P1,x),... with P0,P1,.. the scalar
+    // pivots (the three coordinates swap in triplets, so "first in the permuted order" among the entries of one coordinate is
+    // the scalar factorisation's own permuted order); after n = 3j + e pivots the residual trace is (3-e) tr_s(j) + e tr_s(j+1).
+    Factor fac[1];
     int32_t cnt[3] = {0, 0, 0};  // columns per coordinate
     int32_t n = 0;               // generic pivots = rank
-    if (nsets == 1) {
-        // one kernel for all coordinates: the generic pivot sequence is (P0,x),(P0,y),(P0,z),(P1,x),... with P0,P1,.. the scalar
-        // pivots; after n = 3j + e pivots the residual trace is (3-e) tr_s(j) + e tr_s(j+1)
+    {
         const int32_t kmax = (int32_t)std::min<int64_t>(M, (max_rank + 2) / 3);  // scalar columns that can ever be needed
-        GINGR_TRY(fac[0].init(ctx, specs[0], pts, kmax));
+        GINGR_TRY(fac[0].init(ctx, sp3, pts, false, kmax));
         GINGR_TRY(fac[0].run_to_tolerance(relative_tolerance));
         const int32_t ks = fac[0].ks;
         if (ks < 1) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: empty model (tolerance too large)");
@@ -666,60 +761,18 @@ int gingr_gpmm_build_diagonal(gingr_ctx *ctx, int64_t M_total, const double *ref
             ++n;
         }
         for (int d = 0; d < 3; ++d) cnt[d] = n / 3 + (d < n % 3 ? 1 : 0);
-    } else {
-        // coordinates with different kernels: every kernel keeps its own scalar factorisation and the generic pivot loop
-        // (argmax of the residual diagonal over all 3M (point, coordinate) indices, stop at relTol * trace) is replayed on the
-        // recorded pivot values and traces, looking one pivot ahead per coordinate
-        const int32_t kcap = (int32_t)std::min<int64_t>(M, max_rank);
-        for (int q = 0; q < nsets; ++q) GINGR_TRY(fac[q].init(ctx, specs[q], pts, kcap));
-        for (int q = 0; q < nsets; ++q) GINGR_TRY(fac[q].ensure(0));
-        double tr0 = 0.0;
-        for (int d = 0; d < 3; ++d) tr0 += fac[dim_set[d]].htrace[0];
-        const double tol_g = relative_tolerance * tr0;
-        // scalismo's loop takes the FIRST maximal residual in its current permuted index order (every step swaps the pivot to
-        // position n).  Between coordinates with the same kernel (y and z of a mirrored kernel) equal values are the rule, and with
-        // irregularly interleaved x pivots the displaced (Q,y) / (Q,z) entries do not keep their order -- so the permutation is
-        // replayed here.  (Ties INSIDE one coordinate are resolved by the device factorisation: lowest point index.)
-        std::vector<int32_t> perm((size_t)3 * M), pos((size_t)3 * M);
-        for (int64_t i = 0; i < 3 * M; ++i) perm[(size_t)i] = pos[(size_t)i] = (int32_t)i;
-        while (n < max_rank) {
-            double tr = 0.0;
-            int best = -1;
-            double bv = 0.0;
-            int64_t bflat = 0;
-            for (int d = 0; d < 3; ++d) {
-                ScalarFactor &f = fac[dim_set[d]];
-                GINGR_TRY(f.ensure(cnt[d]));
-                const int32_t j = cnt[d];
-                if (j > f.known) continue;  // finished before pivot j: this coordinate is exhausted, residual 0
-                tr += f.htrace[(size_t)j];
-                const bool avail = !(f.finished && j >= f.stop_at) && f.hpval[(size_t)j] > 0.0;
-                if (!avail) continue;
-                const double v = f.hpval[(size_t)j];
-                const int64_t flat = 3 * (int64_t)f.hpiv[(size_t)j] + d;
-                if (best < 0 || v > bv || (v == bv && pos[(size_t)flat] < pos[(size_t)bflat])) best = d, bv = v, bflat = flat;
-            }
-            if (!(tr >= tol_g) || best < 0) break;
-            {
-                const int32_t i = pos[(size_t)bflat], a = perm[(size_t)n];
-                perm[(size_t)n] = (int32_t)bflat, perm[(size_t)i] = a;
-                pos[(size_t)bflat] = n, pos[(size_t)a] = i;
-            }
-            ++cnt[best];
-            ++n;
-        }
     }
     if (n < 1) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: empty model (tolerance too large)");
 
-    // blocks = distinct (kernel, column count) among the coordinates; eigen-decomposition of L_s[:, :count]^T L_s[:, :count]
+    // blocks = distinct column counts among the coordinates; eigen-decomposition of L_s[:, :count]^T L_s[:, :count]
     int dim_block[3] = {-1, -1, -1}, nblocks = 0, block_set[3] = {0, 0, 0};
     int32_t block_n[3] = {0, 0, 0};
     for (int d = 0; d < 3; ++d) {
         if (cnt[d] == 0) continue;
         int b = -1;
         for (int q = 0; q < nblocks; ++q)
-            if (block_set[q] == dim_set[d] && block_n[q] == cnt[d]) b = q;
-        if (b < 0) b = nblocks++, block_set[b] = dim_set[d], block_n[b] = cnt[d];
+            if (block_n[q] == cnt[d]) b = q;
+        if (b < 0) b = nblocks++, block_n[b] = cnt[d];
         dim_block[d] = b;
     }
     DevBuf G[3], wA, wV, ev[3], V[3], B[3], sw;
@@ -729,14 +782,10 @@ int gingr_gpmm_build_diagonal(gingr_ctx *ctx, int64_t M_total, const double *ref
     HIP_TRY(ctx, wV.alloc((size_t)kkmax * kkmax * sizeof(double)));
     HIP_TRY(ctx, sw.alloc(4 * sizeof(int32_t)));
     HIP_TRY(ctx, hipMemsetAsync(sw.p, 0, 4 * sizeof(int32_t), ctx->stream));
-    int32_t set_kk[3] = {0, 0, 0};
-    for (int b = 0; b < nblocks; ++b) set_kk[block_set[b]] = std::max(set_kk[block_set[b]], block_n[b]);
-    for (int q = 0; q < nsets; ++q) {
-        if (!set_kk[q]) continue;
-        HIP_TRY(ctx, G[q].alloc((size_t)set_kk[q] * set_kk[q] * sizeof(double)));
-        hipLaunchKernelGGL(pc_gram_kernel, dim3(set_kk[q], set_kk[q]), dim3(kPcBlock), 0, ctx->stream, fac[q].Lb.as<double>(), M,
-                           set_kk[q], G[q].as<double>());
-    }
+    int32_t set_kk[3] = {kkmax, 0, 0};
+    HIP_TRY(ctx, G[0].alloc((size_t)kkmax * kkmax * sizeof(double)));
+    hipLaunchKernelGGL(pc_gram_kernel, dim3(kkmax, kkmax), dim3(kPcBlock), 0, ctx->stream, fac[0].Lb.as<double>(), M, kkmax,
+                       G[0].as<double>());
     std::vector<double> hev[3];
     for (int b = 0; b < nblocks; ++b) {
         const int32_t nb_ = block_n[b];
@@ -785,8 +834,6 @@ int gingr_gpmm_build_diagonal(gingr_ctx *ctx, int64_t M_total, const double *ref
     HIP_TRY(ctx, dq.alloc(qmap.size() * sizeof(int32_t)));
     HIP_TRY(ctx, hipMemcpy(dq.p, qmap.data(), qmap.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 
-    if (row_end <= 0) row_end = M_total;
-    std::vector<double> zero_mean((size_t)3 * M_total, 0.0);
     auto fill = [&](gingr_model *m) -> int {
         const int64_t total = 3 * m->M * m->rp;
         hipLaunchKernelGGL(gpmm_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, B[0].as<double>(),

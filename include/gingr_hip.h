@@ -141,8 +141,9 @@ int gingr_gpmm_build_gaussian(gingr_ctx *ctx, int64_t M_total, const double *ref
  *                                  (KernelHelper.scala:40-51): GaussianDot(sigma, scaling), InverseLaplacianDot(scaling, gamma)
  *   GINGR_KERNEL_LOOKUP            scaling * lookup[i * M_total + j] -- LookupKernel(reference, m) on the reference points
  *                                  (KernelHelper.scala:76-84), m = pinv(graph Laplacian) for InverseLaplacian (host array)
- * Coordinates whose kernels are equal share one scalar pivoted Cholesky; the generic pivot order over the 3M (point, coordinate)
- * indices and the relTol * trace stopping rule are replayed across the coordinates.  kx / ky / kz may be the same pointer.
+ * Three equal kernels run one scalar pivoted Cholesky (the coordinates swap in triplets); different kernels run scalismo's
+ * generic factorisation over the 3M (point, coordinate) entries.  Exact ties follow scalismo's rule (first maximum in the
+ * permuted index order).  kx / ky / kz may be the same pointer.
  * gingr_gpmm_build_gaussian(..) == gingr_gpmm_build_diagonal with the same mixture (mirror 0) three times. */
 #define GINGR_KERNEL_GAUSSIAN_MIXTURE 0
 #define GINGR_KERNEL_DOT 1

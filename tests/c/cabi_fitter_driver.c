@@ -314,6 +314,67 @@ int main(int argc, char **argv) {
         free(ty);
     }
 
+    /* ---------------------------------------------------------------- G: per-coordinate GPMM kernels, closest surface points,
+     *                                                                      model transfer, classic rigid ICP */
+    {
+        const double sg[1] = {60.0}, scl[1] = {30.0};
+        gingr_scalar_kernel kx, kyz, kdot;
+        memset(&kx, 0, sizeof(kx));
+        kx.kind = GINGR_KERNEL_GAUSSIAN_MIXTURE, kx.n_kernels = 1, kx.sigmas = sg, kx.scalings = scl, kx.mirror = -1.0;
+        kyz = kx;
+        kyz.mirror = 1.0;
+        memset(&kdot, 0, sizeof(kdot));
+        kdot.kind = GINGR_KERNEL_DOT, kdot.scaling = 0.01;
+        gingr_model *sym = NULL, *dot = NULL;
+        CHECK(gingr_gpmm_build_diagonal(ctx, M, ref, &kx, &kyz, &kyz, 0.0, 14, 0, M, &sym));
+        if (gingr_model_rank(sym) != 14) return 17;
+        double *sv = xmalloc(8 * 14);
+        CHECK(gingr_model_download(ctx, sym, NULL, NULL, NULL, sv));
+        put("G_sym_variance", sv, 14);
+        CHECK(gingr_gpmm_build_diagonal(ctx, M, ref, &kdot, &kdot, &kdot, 0.0, 9, 0, M, &dot));
+        double dv[9];
+        const int32_t dr = gingr_model_rank(dot);
+        CHECK(gingr_model_download(ctx, dot, NULL, NULL, NULL, dv));
+        put("G_dot_variance", dv, dr);
+        gingr_model_destroy(dot);
+        /* closest points of the model reference on the target surface, then the symmetric model carried to 40 new points */
+        double *cpp = xmalloc(8 * 3 * M), *d2 = xmalloc(8 * M), *bary = xmalloc(8 * 3 * M);
+        int32_t *tid = xmalloc(4 * M);
+        CHECK(gingr_mesh_closest_points(ctx, M, ref, N, target, Tt, ttri, cpp, d2, tid, bary));
+        put("G_cp", cpp, 3 * M);
+        put("G_bary", bary, 3 * M);
+        const int64_t Mn = 40;
+        int32_t *ids = xmalloc(4 * 3 * Mn);
+        double *wts = xmalloc(8 * 3 * Mn), *nref = xmalloc(8 * 3 * Mn), *nb = xmalloc(8 * 3 * Mn * 14);
+        for (int64_t i = 0; i < Mn; ++i) {
+            for (int k = 0; k < 3; ++k) ids[3 * i + k] = (int32_t)((7 * i + 3 * k) % M);
+            wts[3 * i] = 0.5, wts[3 * i + 1] = 0.3, wts[3 * i + 2] = 0.2;
+            for (int d = 0; d < 3; ++d)
+                nref[3 * i + d] = 0.5 * ref[3 * ids[3 * i] + d] + 0.3 * ref[3 * ids[3 * i + 1] + d] + 0.2 * ref[3 * ids[3 * i + 2] + d];
+        }
+        gingr_model *moved = NULL;
+        CHECK(gingr_model_new_reference(ctx, sym, Mn, nref, ids, wts, 0, Mn, &moved));
+        CHECK(gingr_model_download(ctx, moved, NULL, NULL, nb, NULL));
+        put("G_new_basis", nb, 3 * Mn * 14);
+        double *ob = xmalloc(8 * 3 * M * 14);
+        CHECK(gingr_model_download(ctx, sym, NULL, NULL, ob, NULL));
+        put("G_sym_basis", ob, 3 * M * 14);
+        gingr_model_destroy(moved);
+        gingr_model_destroy(sym);
+        /* two iterations of the classic rigid ICP */
+        gingr_rigid_icp *icp = NULL;
+        double dist[2], tr13[13];
+        double *pts = xmalloc(8 * 3 * M);
+        CHECK(gingr_rigid_icp_create(ctx, 0, M, ref, N, target, &icp));
+        CHECK(gingr_rigid_icp_iterate(icp, 2, dist));
+        CHECK(gingr_rigid_icp_get(icp, pts, tr13));
+        put("G_icp_dist", dist, 2);
+        put("G_icp_points", pts, 3 * M);
+        CHECK(gingr_rigid_icp_set(icp, ref));
+        gingr_rigid_icp_destroy(icp);
+        free(sv); free(cpp); free(d2); free(bary); free(tid); free(ids); free(wts); free(nref); free(nb); free(ob); free(pts);
+    }
+
     gingr_fitter_destroy(f);
     gingr_model_destroy(model);
     gingr_ctx_destroy(ctx);

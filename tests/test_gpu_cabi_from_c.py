@@ -61,7 +61,8 @@ def rel(a, b):
 def test_plain_c_consumer_of_the_fused_path(tmp_path):
     """tests/c/cabi_fitter_driver.c: model upload -> fitter -> fused updates -> state; the 3-phase / 2-segment protocol on two row
     shards with the exchange summed on the host in C; the in-library device group; stateless operators; the ICP flavours;
-    probabilistic proposal; classic CPD -- all from a C program, compared with the oracle."""
+    probabilistic proposal; classic CPD; the per-coordinate GPMM builder, closest surface points, model transfer and the classic
+    rigid ICP -- all from a C program, compared with the oracle."""
     exe = str(tmp_path / "cabi_fitter_driver")
     libdir = os.path.join(ROOT, "gingr_amd")
     subprocess.check_call(["gcc", "-std=gnu99", "-O1", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
@@ -149,3 +150,22 @@ def test_plain_c_consumer_of_the_fused_path(tmp_path):
     ty, s2c, iters, _ = go.classic_cpd_registration(mo.ref, target, "rigid", lam=2.0, beta=2.0, w=0.0, max_iteration=3, tolerance=0.0)
     assert iters == 3 and rel(got["F_classic_ty"].reshape(M, 3), ty) < 1e-8 and abs(got["F_classic_sigma2"][0] - s2c) < 1e-8 * s2c
     assert np.allclose(got["F_mesh_stats"], go.surface_distance_stats(mo.ref, target, tcells, sdev=0.0), rtol=1e-6)
+
+    # G: per-coordinate GPMM kernels, closest surface points, model transfer, classic rigid ICP
+    msym = go.build_gpmm_diagonal(mo.ref, go.symmetric_gauss_kernel_fun(mo.ref, 60.0, 30.0), 0.0, 14)
+    assert np.allclose(got["G_sym_variance"], msym.lam, rtol=1e-8)
+    mdot = go.build_gpmm_diagonal(mo.ref, go.dot_kernel_fun(mo.ref, 0.01), 0.0, 9)
+    assert got["G_dot_variance"].shape[0] == mdot.rank and np.allclose(got["G_dot_variance"], mdot.lam, rtol=1e-7)
+    ocp2, _ = go.mesh_closest_point(mo.ref, target, tcells)
+    assert np.abs(got["G_cp"].reshape(M, 3) - ocp2).max() < 1e-9
+    bary = got["G_bary"].reshape(M, 3)
+    assert np.all(bary >= 0) and np.allclose(bary.sum(1), 1.0, atol=1e-13)
+    Us = got["G_sym_basis"].reshape(14, 3 * M).T.reshape(M, 3, 14)              # column-major download
+    ids = np.array([[(7 * i + 3 * k) % M for k in range(3)] for i in range(40)])
+    want_nb = 0.5 * Us[ids[:, 0]] + 0.3 * Us[ids[:, 1]] + 0.2 * Us[ids[:, 2]]
+    assert np.allclose(got["G_new_basis"].reshape(14, 120).T.reshape(40, 3, 14), want_nb, atol=1e-13)
+    fit_i, dists = mo.ref, []
+    for _ in range(2):
+        fit_i, dd, _ = go.rigid_icp_iteration(fit_i, target)
+        dists.append(dd)
+    assert np.allclose(got["G_icp_dist"], dists, rtol=1e-11) and np.abs(got["G_icp_points"].reshape(M, 3) - fit_i).max() < 1e-9

@@ -187,3 +187,36 @@ def test_argument_errors_of_the_new_entry_points(ctx):
     rc = ctx._lib.gingr_model_new_reference(ctx.handle, shard.handle, 4, nat.dptr(np.ascontiguousarray(ref[:4])), nat.iptr(ids), nat.dptr(w),
                                             0, 0, ctypes.byref(out))
     assert rc == nat.ERR_BAD_ARGUMENT and not out.value
+
+
+def _regular_grid(n=9, size=40.0):
+    xs = np.linspace(-size, size, n)
+    X, Y = np.meshgrid(xs, xs, indexing="ij")
+    return np.stack([X.ravel(), Y.ravel(), np.zeros(X.size)], axis=1)
+
+
+@pytest.mark.parametrize("max_rank", [15, 16, 17, 18, 21, 24, 30])
+def test_exact_ties_follow_the_permuted_order_single_kernel(ctx, max_rank):
+    """An exactly regular grid under a stationary kernel: symmetric points tie bit for bit, and scalismo's loop takes the first
+    maximum in its PERMUTED index order (every step swaps the pivot to the front) -- a rank cut inside a group of tied pivots
+    depends on that order (lowest-index tie breaking picks point 4 where the permuted order picks 36)."""
+    import gingr_amd as ga
+    ref = _regular_grid()
+    mo = go.build_gpmm_mixture(ref, [30.0], [10.0], 0.0, max_rank)
+    dm = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.0, maxRank=max_rank).Gaussian(30.0, 10.0)
+    assert dm.rank == mo.rank == max_rank
+    check_model_against_oracle(dm.to_host(), mo, tol_lam=1e-8, tol_cov=1e-8)
+
+
+@pytest.mark.parametrize("max_rank,tol", [(14, 0.0), (23, 0.0), (0, 0.05)])
+def test_exact_ties_follow_the_permuted_order_mirrored_kernel(ctx, max_rank, tol):
+    """The mirrored kernel on a grid: 2 n points share every |x|, so the x coordinate's residuals tie in groups, and the y / z
+    coordinates tie pairwise all the time."""
+    import gingr_amd as ga
+    rng = np.random.default_rng(2)
+    ref = _regular_grid(8, 35.0)
+    ref[:, 2] = rng.normal(0, 3.0, ref.shape[0])                     # heights break the y / z symmetry, not the |x| ties
+    mo = go.build_gpmm_diagonal(ref, go.symmetric_gauss_kernel_fun(ref, 50.0, 20.0), tol, max_rank or None)
+    dm = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=tol, maxRank=max_rank).GaussianSymmetry(50.0, 20.0)
+    assert dm.rank == mo.rank, (dm.rank, mo.rank)
+    check_model_against_oracle(dm.to_host(), mo, tol_lam=1e-8, tol_cov=1e-8)
