@@ -876,6 +876,9 @@ class GingrAlgorithm:
         last_general = None
         converged = False
         k = 0
+        if callBackLogger is None and state.config.converged in (_cpd_converged, _never_converged) \
+                and state.general.status != FittingStatuses.ModelFlexibilityError and state.config.maxIterations > 1:
+            return self._run_resident(state)
         while True:
             # dropWhile body (:142-153)
             if last_general is not None:
@@ -892,6 +895,37 @@ class GingrAlgorithm:
             state = state.updateGeneral(state.general.updateStatus(
                 FittingStatuses.Converged if converged else FittingStatuses.MaxIteration))
         return state
+
+
+def _run_resident_impl(self, state):
+    """The deterministic loop of `run` with the state resident on the device: nobody watches the intermediate states (no
+    call-back) and the convergence rule is one of the reference's own (|sigma2 - last sigma2| < threshold for CPD, never for ICP),
+    so an iteration only reads back the scalars; shape coefficients and fit come back once, at the end.  Same states, same stopping
+    iteration as the generic loop below."""
+    g = state.general
+    self._bind(g, state.config.useLandmarkCorrespondence)
+    if self._device_state is not state:
+        self._push_state(g)
+    cpd_rule = state.config.converged is _cpd_converged
+    last_sigma2, k, converged = g.sigma2, 1, False
+    sc = nat.StateScalars()
+    while k < state.config.maxIterations:
+        self._native_update(state, 1)
+        _check(self.ctx.handle, self._lib.gingr_fitter_get_state(self._fitter, None, ctypes.byref(sc), None), "gingr_fitter_get_state")
+        k += 1
+        if cpd_rule:
+            converged = abs(last_sigma2 - sc.sigma2) < state.config.threshold
+        last_sigma2 = sc.sigma2
+        if converged or sc.status == FittingStatuses.ModelFlexibilityError:
+            break
+    out = state.updateGeneral(self._pull_state(g))
+    self._device_state = out
+    if out.general.status == FittingStatuses.None_:
+        out = out.updateGeneral(out.general.updateStatus(FittingStatuses.Converged if converged else FittingStatuses.MaxIteration))
+    return out
+
+
+GingrAlgorithm._run_resident = _run_resident_impl
 
 
 def _initial_general(ctx: Context, model: PointDistributionModel, target: np.ndarray, sigma2: float,

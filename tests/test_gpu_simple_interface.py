@@ -227,3 +227,26 @@ def test_posterior_visualisation_flow_of_the_demo(ctx, femur, tmp_path):
     tot = helper.computeDistanceMapFromMeshesTotal(shapes)
     nrm = helper.computeDistanceMapFromMeshesNormal(shapes, ga.TriangleMesh3D(bshape, model.cells))
     assert tot.shape == nrm.shape == (model.numberOfPoints,) and np.all(tot >= 0) and np.all(nrm <= tot + 1e-9) and tot.max() > 0
+
+
+def test_resident_run_loop_equals_the_generic_loop(ctx, femur):
+    """`run` without a call-back keeps the state on the device and reads back scalars only; with a call-back it goes through the
+    per-iteration `update`.  Same states, same stopping iteration, same final status -- CPD (converges) and ICP (runs out)."""
+    import gingr_amd as ga
+    model, target, lm_m, lm_t = femur
+    lms = ga.io.landmark_correspondences(model.reference, lm_m, lm_t)
+    seen = []
+    for algo, cfg in ((ga.CpdRegistration(ctx), ga.CpdConfiguration(maxIterations=60, threshold=1e-3, w=0.05)),
+                      (ga.IcpRegistration(ctx), ga.IcpConfiguration(maxIterations=12, initialSigma=5.0, endSigma=1.0)),
+                      (ga.CpdRegistration(ctx), ga.CpdConfiguration(maxIterations=2))):
+        init = algo.createInitialState(model, target.points, cfg, landmarks=lms, targetCells=target.cells)
+        fast = algo.run(init)
+        seen.clear()
+        slow = algo.run(init, callBackLogger=lambda s: seen.append(s.general.iteration))
+        assert fast.general.iteration == slow.general.iteration == seen[-1] and fast.general.status == slow.general.status
+        assert fast.general.sigma2 == slow.general.sigma2
+        assert np.array_equal(fast.general.modelParameters.shape, slow.general.modelParameters.shape)
+        assert np.array_equal(fast.general.fit, slow.general.fit)
+        assert fast.general.modelParameters.rotation == slow.general.modelParameters.rotation
+    # the CPD run above stopped on its threshold, well before maxIterations
+    assert len(seen) == 2
