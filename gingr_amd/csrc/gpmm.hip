@@ -14,6 +14,12 @@
 // n from the recorded scalar traces, eigen-decomposes the leading (j+1)x(j+1) and jxj blocks of L_s^T L_s (cyclic Jacobi,
 // one workgroup) and scatters  Q0 = U sqrt(lambda) = L_s V  into the three coordinate planes of the basis.
 //
+// The other kernels of GPMMTriangleMesh3D (GPMMHelper.scala:103-142) go through gingr_gpmm_build_diagonal: one scalar kernel per
+// coordinate (Gaussian mixture with an optional x-mirrored copy, linear, lookup table).  Three equal kernels take the scalar route
+// above; different kernels (GaussianSymmetry) run the generic factorisation over the 3M entries themselves (pc_*_kernel<true>).
+// Exact ties between residuals follow scalismo's rule -- the first maximum in the permuted index order -- through a log of the
+// swaps that is replayed for tied candidates (PosLog).
+//
 // Kernels here are one-off (model construction), not the per-iteration path; they are written for exactness of the pivot
 // rule (unfused |x-y|^2, multiply-then-add dot products in ascending column order like the JVM) rather than for speed.
 #include "gp.h"
