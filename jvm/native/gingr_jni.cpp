@@ -317,6 +317,26 @@ JFN(jlong, modelNewReference)(JNIEnv *env, jclass, jlong ctx, jlong src, jdouble
         return 0;
     return reinterpret_cast<jlong>(m);
 }
+JFN(jlong, rigidIcpCreate)(JNIEnv *env, jclass, jlong ctx, jint kind, jdoubleArray tpl, jdoubleArray target) {
+    Arr<double> a(env, tpl, true); Arr<double> b(env, target, true);
+    gingr_rigid_icp *h = nullptr;
+    if (gingr_rigid_icp_create(P<gingr_ctx>(ctx), kind, (int64_t)a.buf.size() / 3, a.ptr(), (int64_t)b.buf.size() / 3, b.ptr(), &h) != GINGR_OK)
+        return 0;
+    return reinterpret_cast<jlong>(h);
+}
+JFN(void, rigidIcpDestroy)(JNIEnv *, jclass, jlong h) { gingr_rigid_icp_destroy(P<gingr_rigid_icp>(h)); }
+JFN(jint, rigidIcpIterate)(JNIEnv *env, jclass, jlong h, jint n, jdoubleArray distances) {
+    Arr<double> d(env, distances, false);
+    return gingr_rigid_icp_iterate(P<gingr_rigid_icp>(h), n, d.ptr());
+}
+JFN(jint, rigidIcpGet)(JNIEnv *env, jclass, jlong h, jdoubleArray pts, jdoubleArray tr13) {
+    Arr<double> a(env, pts, false); Arr<double> b(env, tr13, false);
+    return gingr_rigid_icp_get(P<gingr_rigid_icp>(h), a.ptr(), b.ptr());
+}
+JFN(jint, rigidIcpSet)(JNIEnv *env, jclass, jlong h, jdoubleArray pts) {
+    Arr<double> a(env, pts, true);
+    return gingr_rigid_icp_set(P<gingr_rigid_icp>(h), a.ptr());
+}
 JFN(jint, pointsetDistanceExtrema)(JNIEnv *env, jclass, jlong ctx, jdoubleArray xyz, jdoubleArray out2) {
     const jlong n = env->GetArrayLength(xyz) / 3;
     Arr<double> a(env, xyz, true); Arr<double> b(env, out2, false);

@@ -95,6 +95,13 @@ public final class GingrHipNative {
      *  returns the model handle or 0 */
     public static native long modelNewReference(long ctx, long sourceModel, double[] newRefXyz, int[] vertexIds, double[] weights,
                                                 long rowBegin, long rowEnd);
+    // ---- classic rigid / similarity ICP (other/algorithms/icp/RigidICP.scala; kind 0 = RigidRegistrator3D, 1 = AffineRegistrator3D)
+    public static native long rigidIcpCreate(long ctx, int kind, double[] templateXyz, double[] targetXyz);
+    public static native void rigidIcpDestroy(long handle);
+    /** distances[k] = mean closest-point distance iteration k measured before moving the template (may be null) */
+    public static native int rigidIcpIterate(long handle, int nIterations, double[] distances);
+    public static native int rigidIcpGet(long handle, double[] pointsXyz, double[] transform13);
+    public static native int rigidIcpSet(long handle, double[] pointsXyz);
     /** out2 = { maximumPointDistance, minimumPointDistance } (PointSetHelper) */
     public static native int pointsetDistanceExtrema(long ctx, double[] xyz, double[] out2);
     /** any array may be null; basisColMajor is 3 M_local x rank, unit columns */
