@@ -284,7 +284,8 @@ __global__ __launch_bounds__(kCpThreads) void surface_cp_kernel(Cloud q, Cloud v
                 // survives (55 % of the steps at a pair survival rate of 1.2 %, 41k x 82k).  Splitting it -- survivors into per-lane
                 // bit masks, then every lane evaluating its own survivors -- was measured twice and is slower (1 470 -> 1 340
                 // iterations/s): the masks are built against the bound at the start of the quarter, while here every improvement of
-                // `best` prunes the rest of the quarter at once.
+                // `best` prunes the rest of the quarter at once.  What does pay is compacting the surviving PAIRS across the wave:
+                // surface_cp_queue_kernel below (the default; this kernel stays as GINGR_SURFACE_QUEUE=0 for same-box comparisons).
                 for (int j0 = 0; j0 < cnt; j0 += H) {
                     const int jj = j0 + half;
                     const bool live = jj < cnt;
@@ -327,6 +328,160 @@ __global__ __launch_bounds__(kCpThreads) void surface_cp_kernel(Cloud q, Cloud v
         cp[2 * q.n + i] = spt[w][2][ql];
         d2out[i] = sbest[w][ql];
         if (tri_out) tri_out[i] = (int32_t)sorig[w][ql];  // the winning ORIGINAL triangle (lowest on exact ties)
+    }
+}
+
+// QUEUED variant of surface_cp_kernel (same interface, bit-identical results).  In the kernel above the exact closest-point test
+// (~170 instructions) runs for all 64 lanes whenever ANY of a step's 64 (query, triangle) pairs survives its box test -- 55 % of
+// the steps at a pair survival rate of 1.2 % (41k queries x 82k triangles): 98 % of the exact tests are wasted lanes.  Here the
+// survivors of the box tests are COMPACTED across the wave: every lane appends its surviving pair to a per-wave LDS queue (ballot
+// + prefix count), and as soon as 64 pairs are queued every lane pops one and runs the exact test on ITS pair -- a different
+// query and a different triangle in every lane.  The result goes to the owning query through LDS: an atomic minimum on the
+// squared distance (non-negative doubles order like their bit patterns), then an atomic minimum on the original triangle number
+// among the lanes that hold that minimum (the tie rule), then the winner stores its point.  All copies of a query prune against
+// the shared best after every flush.  The queue is drained before the tile in LDS is replaced.
+template <int H>
+__global__ __launch_bounds__(kCpThreads) void surface_cp_queue_kernel(Cloud q, Cloud v, const int32_t *__restrict__ tri,
+                                                                     const int32_t *__restrict__ tri_orig, int64_t T,
+                                                                     const double *__restrict__ boxes, double *__restrict__ cp,
+                                                                     double *__restrict__ d2out, int32_t *__restrict__ tri_out) {
+    __shared__ double tbox[kTriTile][6];  // staged tile: the triangles' bounding boxes only (the exact test reads memory)
+    constexpr int QPB = 64 / H;  // queries per workgroup
+    __shared__ unsigned long long qbest[4][QPB];  // per wave and query: bits of the best squared distance so far
+    __shared__ unsigned int qorig[4][QPB];        // ... its original triangle (lowest on ties)
+    __shared__ double qpt[4][3][QPB];             // ... its point
+    __shared__ double sq[3][QPB];                 // the queries
+    __shared__ unsigned int wqueue[4][128];  // (query slot << 26) | position of the triangle in `tri`
+    __shared__ double sbound[4][QPB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ql = lane & (QPB - 1), half = lane / QPB;
+    const int64_t i = (int64_t)blockIdx.x * QPB + ql;
+    const bool ok = i < q.n;
+    const double qx = ok ? q.x[i] : 0.0, qy = ok ? q.y[i] : 0.0, qz = ok ? q.z[i] : 0.0;
+    const V3 p{qx, qy, qz};
+    const unsigned long long kInfBits = 0x7FF0000000000000ull;
+    if (half == 0) {
+        qbest[wave][ql] = kInfBits;
+        qorig[wave][ql] = 0xFFFFFFFFu;
+        qpt[wave][0][ql] = qx, qpt[wave][1][ql] = qy, qpt[wave][2][ql] = qz;
+        if (wave == 0) sq[0][ql] = qx, sq[1][ql] = qy, sq[2][ql] = qz;
+    }
+    __syncthreads();
+    double best = __builtin_huge_val(), bound = __builtin_huge_val();
+    int tail = 0;  // queued pairs (wave-uniform)
+    double wb[6];
+    wave_box(ok, qx, qy, qz, wb);
+    const int nt = (int)((T + kTriTile - 1) / kTriTile);
+    const double *qboxes = boxes + (int64_t)nt * 6;
+    // pops up to 64 queued pairs, one per lane
+    auto flush = [&](int count) {
+        __builtin_amdgcn_wave_barrier();
+        const bool mine = lane < count;
+        const unsigned e = wqueue[wave][mine ? lane : 0];
+        const int tq = (int)(e >> 26);
+        const int64_t tg = (int64_t)(e & 0x3FFFFFFu);
+        const V3 pp{sq[0][tq], sq[1][tq], sq[2][tq]};
+        Tri9 tr;  // the queue outlives the staged tile: the triangle comes from memory (L2: it was staged a moment ago)
+        {
+            const int32_t va = tri[3 * tg], vb = tri[3 * tg + 1], vc = tri[3 * tg + 2];
+            tr = Tri9{v.x[va], v.y[va], v.z[va], v.x[vb], v.y[vb], v.z[vb], v.x[vc], v.y[vc], v.z[vc],
+                      (double)(tri_orig ? tri_orig[tg] : (int32_t)tg)};
+        }
+        const V3 c = closest_on_triangle(pp, V3{tr.ax, tr.ay, tr.az}, V3{tr.bx, tr.by, tr.bz}, V3{tr.cx, tr.cy, tr.cz});
+        const V3 dd = sub(c, pp);
+        const double dist = (dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z;
+        const unsigned long long db = __builtin_bit_cast(unsigned long long, dist);
+        const unsigned long long old = qbest[wave][tq];
+        if (mine && db <= old) atomicMin(&qbest[wave][tq], db);
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long now = qbest[wave][tq];
+        const bool top = mine && db == now;
+        if (top && now < old) qorig[wave][tq] = 0xFFFFFFFFu;  // a strictly better distance: the old triangle no longer competes
+        __builtin_amdgcn_wave_barrier();
+        if (top) atomicMin(&qorig[wave][tq], (unsigned)tr.orig);
+        __builtin_amdgcn_wave_barrier();
+        if (top && qorig[wave][tq] == (unsigned)tr.orig) qpt[wave][0][tq] = c.x, qpt[wave][1][tq] = c.y, qpt[wave][2][tq] = c.z;
+        __builtin_amdgcn_wave_barrier();
+        best = __builtin_bit_cast(double, qbest[wave][ql]);  // every copy of the query prunes against the shared best
+        // entries beyond `count` move to the front
+        if (tail > count) {
+            const unsigned rest = lane + count < tail ? wqueue[wave][lane + count] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (lane + count < tail) wqueue[wave][lane] = rest;
+        }
+        tail -= count;
+    };
+    double gmin = __builtin_huge_val();
+    for (int t = lane; t < nt; t += 64) gmin = fmin(gmin, box_box_gap2(wb, boxes + (int64_t)t * 6));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gmin = fmin(gmin, __shfl_xor(gmin, off));
+    gmin = uniform_dd(gmin);
+    for (int phase = 0; phase < 2; ++phase) {
+        double bmax = ok ? bound : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bmax = fmax(bmax, __shfl_xor(bmax, off));
+        bmax = uniform_dd(bmax) * (1.0 + 1e-12);
+        for (int tc = 0; tc < nt; tc += 64) {
+            const int tl = tc + lane;
+            const double g = tl < nt ? box_box_gap2(wb, boxes + (int64_t)tl * 6) : __builtin_huge_val();
+            unsigned long long cand = __ballot(tl < nt && (phase == 0 ? !(g > gmin) : (g > gmin && !(g > bmax))));
+            while (cand) {  // workgroup-uniform (same queries, same bound in every wave)
+                const int t = tc + __builtin_ctzll(cand);
+                cand &= cand - 1;
+                const int64_t tb = (int64_t)t * kTriTile, q0 = tb + 64 * wave;
+                const double pd = point_box_gap2(qx, qy, qz, qboxes + ((int64_t)t * 4 + wave) * 6);
+                const bool need = ok && q0 < T && !(pd > fmin(best, bound) * (1.0 + 1e-12));
+                const bool wave_needs = __any(need);
+                if (!__syncthreads_or(wave_needs)) continue;
+                {
+                    const int64_t tt = tb + threadIdx.x;
+                    if (tt < T) {
+                        const int32_t a = tri[3 * tt], b = tri[3 * tt + 1], c = tri[3 * tt + 2];
+                        const double ax = v.x[a], ay = v.y[a], az = v.z[a], bx = v.x[b], by = v.y[b], bz = v.z[b], cx = v.x[c], cy = v.y[c],
+                                     cz = v.z[c];
+                        double *bb = tbox[threadIdx.x];
+                        bb[0] = fmin(fmin(ax, bx), cx), bb[1] = fmin(fmin(ay, by), cy), bb[2] = fmin(fmin(az, bz), cz);
+                        bb[3] = fmax(fmax(ax, bx), cx), bb[4] = fmax(fmax(ay, by), cy), bb[5] = fmax(fmax(az, bz), cz);
+                    }
+                }
+                __syncthreads();
+                if (wave_needs) {
+                    const int cnt = (int)min((int64_t)64, T - q0);
+                    for (int j0 = 0; j0 < cnt; j0 += H) {
+                        const int jj = j0 + half;
+                        const bool live = jj < cnt;
+                        const double gap = point_box_gap2(qx, qy, qz, tbox[64 * wave + (live ? jj : cnt - 1)]);
+                        const bool pass = need && live && !(gap > fmin(best, bound) * (1.0 + 1e-12));
+                        const unsigned long long m = __ballot(pass);
+                        if (m) {
+                            if (pass) wqueue[wave][tail + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = ((unsigned)ql << 26) | (unsigned)(q0 + jj);
+                            tail += __builtin_popcountll(m);
+                            if (tail >= 64) flush(64);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (tail > 0) flush(tail);  // drain: the sweep's results feed the bound / the answer
+        if (phase == 0) {  // share the distance bound of sweep 0 between the waves
+            if (half == 0) sbound[wave][ql] = __builtin_bit_cast(double, qbest[wave][ql]);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bound = fmin(bound, sbound[k][ql]);
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && half == 0 && ok) {  // combine the four waves: smallest distance, ties -> lowest original triangle
+        int w = 0;
+        for (int k = 1; k < 4; ++k)
+            if (qbest[k][ql] < qbest[w][ql] || (qbest[k][ql] == qbest[w][ql] && qorig[k][ql] < qorig[w][ql])) w = k;
+        cp[i] = qpt[w][0][ql];
+        cp[q.n + i] = qpt[w][1][ql];
+        cp[2 * q.n + i] = qpt[w][2][ql];
+        d2out[i] = __builtin_bit_cast(double, qbest[w][ql]);
+        if (tri_out) tri_out[i] = (int32_t)qorig[w][ql];
     }
 }
 
@@ -464,6 +619,126 @@ __global__ __launch_bounds__(kCpThreads) void self_intersect_kernel(Cloud fit, c
         for (int q2 = 0; q2 < 4 * H; ++q2) any |= shit[q2][ql];
         flag[i] = any;
     }
+}
+
+// QUEUED variant of self_intersect_kernel (see surface_cp_queue_kernel): the staged tile holds bounding boxes only, (point,
+// triangle) pairs whose box reaches into the ball of radius |v| around the point are compacted across the wave, and every lane runs
+// the line / triangle test on its own pair, reading the triangle from memory.  A hit is OR-ed into the point's flag in LDS; points
+// that are already hit stop producing pairs.
+template <int H>
+__global__ __launch_bounds__(kCpThreads) void self_intersect_queue_kernel(Cloud fit, const double *__restrict__ cp, Cloud v,
+                                                                         const int32_t *__restrict__ tri, int64_t T,
+                                                                         const double *__restrict__ boxes,
+                                                                         const int32_t *__restrict__ skip,
+                                                                         int32_t *__restrict__ flag) {
+    __shared__ double tbox[kTriTile][6];
+    constexpr int QPB = 64 / H;
+    __shared__ int qhit[QPB];
+    __shared__ double sp[3][QPB], sdir[3][QPB], snorm[QPB];
+    __shared__ unsigned int wqueue[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ql = lane & (QPB - 1), half = lane / QPB;
+    const int64_t i = (int64_t)blockIdx.x * QPB + ql;
+    const bool ok = i < fit.n && !(skip && skip[i]);
+    const int64_t ic = i < fit.n ? i : 0;
+    const V3 p{fit.x[ic], fit.y[ic], fit.z[ic]};
+    const V3 dir = sub(p, V3{cp[ic], cp[fit.n + ic], cp[2 * fit.n + ic]});
+    const double vv = dot3(dir, dir);
+    const double vnorm = sqrt(vv);
+    if (wave == 0 && half == 0) {
+        qhit[ql] = 0;
+        sp[0][ql] = p.x, sp[1][ql] = p.y, sp[2][ql] = p.z;
+        sdir[0][ql] = dir.x, sdir[1][ql] = dir.y, sdir[2][ql] = dir.z;
+        snorm[ql] = vnorm;
+    }
+    __syncthreads();
+    int hit = 0, tail = 0;
+    auto flush = [&](int count) {
+        __builtin_amdgcn_wave_barrier();
+        const bool mine = lane < count;
+        const unsigned e = wqueue[wave][mine ? lane : 0];
+        const int tq = (int)(e >> 26);
+        const int64_t tg = (int64_t)(e & 0x3FFFFFFu);
+        const V3 pp{sp[0][tq], sp[1][tq], sp[2][tq]}, dd0{sdir[0][tq], sdir[1][tq], sdir[2][tq]};
+        const int32_t va = tri[3 * tg], vb = tri[3 * tg + 1], vc = tri[3 * tg + 2];
+        const V3 A{v.x[va], v.y[va], v.z[va]};
+        const V3 e1 = sub(V3{v.x[vb], v.y[vb], v.z[vb]}, A), e2 = sub(V3{v.x[vc], v.y[vc], v.z[vc]}, A);
+        const V3 pv = cross3(dd0, e2);
+        const double det = dot3(e1, pv);
+        const double inv = 1.0 / det;
+        const V3 tv = sub(pp, A);
+        const double u = dot3(tv, pv) * inv;
+        const V3 qv = cross3(tv, e1);
+        const double w = dot3(qv, dd0) * inv;
+        const double tt = dot3(e2, qv) * inv;
+        if (mine && det != 0.0 && u >= 0.0 && u <= 1.0 && w >= 0.0 && u + w <= 1.0) {
+            const V3 ip{pp.x + tt * dd0.x, pp.y + tt * dd0.y, pp.z + tt * dd0.z};
+            if (ip.x != pp.x || ip.y != pp.y || ip.z != pp.z) {
+                const V3 dd = sub(ip, pp);
+                if (sqrt((dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z) < snorm[tq]) qhit[tq] = 1;  // same value from every writer
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        hit = qhit[ql];
+        if (tail > count) {
+            const unsigned rest = lane + count < tail ? wqueue[wave][lane + count] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (lane + count < tail) wqueue[wave][lane] = rest;
+        }
+        tail -= count;
+    };
+    const int nt = (int)((T + kTriTile - 1) / kTriTile);
+    const double *qboxes = boxes + (int64_t)nt * 6;
+    double wb[6];
+    wave_box(ok, p.x, p.y, p.z, wb);
+    double vmax = ok ? vv : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmax(vmax, __shfl_xor(vmax, off));
+    vmax = uniform_dd(vmax) * (1.0 + 1e-12);
+    for (int tc = 0; tc < nt; tc += 64) {
+        const int tl = tc + lane;
+        unsigned long long cand = __ballot(tl < nt && !(box_box_gap2(wb, boxes + (int64_t)tl * 6) > vmax));
+        while (cand) {  // workgroup-uniform
+            const int t = tc + __builtin_ctzll(cand);
+            cand &= cand - 1;
+            const int64_t tb = (int64_t)t * kTriTile, q0 = tb + 64 * wave;
+            const double pd = point_box_gap2(p.x, p.y, p.z, qboxes + ((int64_t)t * 4 + wave) * 6);
+            const bool need = ok && !hit && q0 < T && !(pd > vv * (1.0 + 1e-12));
+            const bool wave_needs = __any(need);
+            if (!__syncthreads_or(wave_needs)) continue;
+            {
+                const int64_t tt = tb + threadIdx.x;
+                if (tt < T) {
+                    const int32_t a = tri[3 * tt], b = tri[3 * tt + 1], c = tri[3 * tt + 2];
+                    const double ax = v.x[a], ay = v.y[a], az = v.z[a], bx = v.x[b], by = v.y[b], bz = v.z[b], cx = v.x[c], cy = v.y[c],
+                                 cz = v.z[c];
+                    double *bb = tbox[threadIdx.x];
+                    bb[0] = fmin(fmin(ax, bx), cx), bb[1] = fmin(fmin(ay, by), cy), bb[2] = fmin(fmin(az, bz), cz);
+                    bb[3] = fmax(fmax(ax, bx), cx), bb[4] = fmax(fmax(ay, by), cy), bb[5] = fmax(fmax(az, bz), cz);
+                }
+            }
+            __syncthreads();
+            if (wave_needs) {
+                const int cnt = (int)min((int64_t)64, T - q0);
+                for (int jb = 0; jb < cnt; jb += H) {
+                    const int jj = jb + half;
+                    const bool live = jj < cnt;
+                    const double gap = point_box_gap2(p.x, p.y, p.z, tbox[64 * wave + (live ? jj : cnt - 1)]);
+                    const bool pass = need && live && !hit && !(gap > vv * (1.0 + 1e-9));
+                    const unsigned long long m = __ballot(pass);
+                    if (m) {
+                        if (pass) wqueue[wave][tail + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = ((unsigned)ql << 26) | (unsigned)(q0 + jj);
+                        tail += __builtin_popcountll(m);
+                        if (tail >= 64) flush(64);
+                    }
+                }
+            }
+            __syncthreads();  // the tile is restaged by the next visited tile
+        }
+    }
+    if (tail > 0) flush(tail);
+    __syncthreads();
+    if (wave == 0 && half == 0 && i < fit.n) flag[i] = qhit[ql];
 }
 
 // ClosestPointAlongNormalTriangleMesh3D (ClosestPointRegistrator.scala:102-131): for every fit vertex the intersection of the
@@ -739,6 +1014,20 @@ void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_
         hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(q.n, qpb)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig, T, boxes,
                            cp_soa, d2, tri_out);
     };
+    static const int queued = getenv("GINGR_SURFACE_QUEUE") ? atoi(getenv("GINGR_SURFACE_QUEUE")) : 1;
+    if (queued) {
+        if (h == 1)
+            go(surface_cp_queue_kernel<1>, 64);
+        else if (h == 2)
+            go(surface_cp_queue_kernel<2>, 32);
+        else if (h == 8)
+            go(surface_cp_queue_kernel<8>, 8);
+        else if (h == 16)
+            go(surface_cp_queue_kernel<16>, 4);
+        else
+            go(surface_cp_queue_kernel<4>, 16);
+        return;
+    }
     if (h == 1)
         go(surface_cp_kernel<1>, 64);
     else if (h == 2)
@@ -765,6 +1054,20 @@ void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, cons
         hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(fit.n, qpb)), dim3(kCpThreads), 0, ctx->stream, fit, cp_soa, fit, tri, T, boxes,
                            skip, flag);
     };
+    static const int queued = getenv("GINGR_SURFACE_QUEUE") ? atoi(getenv("GINGR_SURFACE_QUEUE")) : 1;
+    if (queued) {
+        if (h == 1)
+            go(self_intersect_queue_kernel<1>, 64);
+        else if (h == 2)
+            go(self_intersect_queue_kernel<2>, 32);
+        else if (h == 8)
+            go(self_intersect_queue_kernel<8>, 8);
+        else if (h == 16)
+            go(self_intersect_queue_kernel<16>, 4);
+        else
+            go(self_intersect_queue_kernel<4>, 16);
+        return;
+    }
     if (h == 1)
         go(self_intersect_kernel<1>, 64);
     else if (h == 2)
