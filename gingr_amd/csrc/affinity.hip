@@ -150,6 +150,7 @@ __device__ __forceinline__ Box wave_bbox(const double (&x)[PT], const double (&y
 struct ChunkPlan {
     int64_t len_big, len_tail;
     int32_t n_big;
+    int32_t fair = 0;  // one launch round: waves lower their issue priority as they advance (fair_priority)
     __host__ __device__ void range(int64_t y, int64_t n, int64_t *b, int64_t *e) const {
         const int64_t lo = y < n_big ? y * len_big : (int64_t)n_big * len_big + (y - n_big) * len_tail;
         const int64_t hi = lo + (y < n_big ? len_big : len_tail);
@@ -307,6 +308,22 @@ struct PartWalk {
         return true;
     }
 };
+
+// One launch round (every workgroup resident from the start, e.g. the row shard of an 8-rank job): the SIMD arbiter favours the
+// oldest wave, so the four waves of a SIMD finish one after the other (time stamps: 53 / 80 / 107 / 141 us of a 148 us launch) and
+// the last one runs alone at the single-wave rate of one instruction per ~5.3 cycles.  Lowering a wave's priority as it advances
+// keeps the four abreast until the end.  Not used when rounds overlap: there the stagger hides the prologues.
+__device__ __forceinline__ void fair_priority(int64_t done, int64_t total) {
+    const int64_t f = total > 0 ? (4 * done) / total : 3;
+    if (f <= 0)
+        __builtin_amdgcn_s_setprio(3);
+    else if (f == 1)
+        __builtin_amdgcn_s_setprio(2);
+    else if (f == 2)
+        __builtin_amdgcn_s_setprio(1);
+    else
+        __builtin_amdgcn_s_setprio(0);
+}
 
 // ---------------------------------------------------------------- pass 1: column sums of K
 // Tile loops.  [j0, j1) is a range of tile entries (the whole tile or one 64-point quarter); with MASKED only the owned slots
@@ -468,6 +485,7 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
     Work cur = find();
     if (cur.valid) issue(cur);
     while (cur.valid) {
+        if (plan.fair) fair_priority(cur.ib - i0, i1 - i0);
         __builtin_amdgcn_wave_barrier();  // (compiler fence) the previous quarter's reads are issued before the slice is rewritten
         if (cur.ib + q0 + lane < cur.ie) {
             if (expand) {
@@ -749,6 +767,7 @@ __global__ __launch_bounds__(kBlock, (PT >= 4 ? 3 : 4)) void cpd_rowstats_kernel
     Work cur = find();
     if (cur.valid) issue(cur);
     while (cur.valid) {
+        if (plan.fair) fair_priority(cur.jb - j0, j1 - j0);
         __builtin_amdgcn_wave_barrier();
         if (cur.jb + q0 + lane < cur.je) {
             const double inv = linv;
@@ -1224,7 +1243,7 @@ inline ChunkPlan plan_chunks(int64_t owned, int owned_per_block, int64_t stream_
     else
         len = 64;
     if (quarters_override <= 0 && len < kMinChunk) len = kMinChunk;
-    ChunkPlan p{len, len, (int32_t)ceil_div(n, len)};
+    ChunkPlan p{len, len, (int32_t)ceil_div(n, len), 0};
     static const ChunkShape shape = env_chunk_shape();
     if (shape.big >= 1 && shape.tail >= 1 && shape.frac > 0 && shape.frac < 1 && quarters_override <= 0) {
         p.len_big = (int64_t)shape.big * kTile;
@@ -1266,6 +1285,8 @@ inline ChunkPlan plan_chunks(int64_t owned, int owned_per_block, int64_t stream_
         }
     }
     *nchunks = p.chunks(n);
+    static const int fair_env = getenv("GINGR_FAIR_PRIORITY") ? atoi(getenv("GINGR_FAIR_PRIORITY")) : 1;
+    p.fair = (fair_env == 2 || (fair_env == 1 && resident > 0 && (int64_t)*nchunks * bx <= resident)) ? 1 : 0;
     return p;
 }
 inline int env_tiles(const char *name) {  // tiles -> quarters
