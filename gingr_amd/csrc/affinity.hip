@@ -191,38 +191,67 @@ __device__ __forceinline__ void slot_boxes(const double (&x)[PT], const double (
 // of its four 64-point quarters, [tile*4 + q]: the k-d leaf order makes those compact too (finer exact-zero culling).
 // With slot != nullptr also slot = max over the cloud of |coordinate - ctr| (atomic max on the bit pattern of a non-negative
 // double: order independent, deterministic); the slot must have been zeroed by an EARLIER launch on the stream.
+constexpr int kBoxTilesPerBlock = 8;
+// One workgroup handles kBoxTilesPerBlock consecutive tiles (wave q the quarter q of each), so the launch ends with one atomic per
+// 2048 points: agent-scope atomics on one word are served at the memory side, one after the other (~0.13 us each: with one tile per
+// workgroup the 196 tiles of 50k points took 26 us, all of it the atomics).  The 64-lane minima / maxima are not butterflies of
+// cross-lane shuffles (6 dependent LDS round trips per quantity: 14 us for the 48 quantities of a wave) but column scans: the wave
+// parks its values in LDS, [quantity][lane], and lane j < 48 scans the 64 entries of ITS quantity, starting at entry j so that the
+// lanes of one read sit in different banks.  fmin ignores NaN like the butterfly did (a NaN point never widens a box).
 __global__ __launch_bounds__(256) void tile_bbox_kernel(Cloud c, double *__restrict__ boxes, const double *__restrict__ ctr,
-                                                        double *__restrict__ slot) {
-    __shared__ double sh[24];
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool ok1[1] = {i < c.n};
-    const double x[1] = {ok1[0] ? c.x[i] : 0.0}, y[1] = {ok1[0] ? c.y[i] : 0.0}, z[1] = {ok1[0] ? c.z[i] : 0.0};
-    Box wb;
-    const Box b = block_bbox<1>(x, y, z, ok1, sh, &wb);
-    if (threadIdx.x < 3) {
-        boxes[(int64_t)blockIdx.x * 6 + threadIdx.x] = b.lo[threadIdx.x];
-        boxes[(int64_t)blockIdx.x * 6 + 3 + threadIdx.x] = b.hi[threadIdx.x];
-    }
-    {
-        double *sub = boxes + (int64_t)gridDim.x * 6 + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 6;
-        const int l = threadIdx.x & 63;
-        if (l < 3) {
-            sub[l] = wb.lo[l];
-            sub[3 + l] = wb.hi[l];
-        }
-    }
-    if (slot && threadIdx.x == 0) {
-        double m = 0.0;
+                                                        double *__restrict__ slot, int64_t ntiles) {
+    constexpr int Q = kBoxTilesPerBlock * 3;          // quantities per wave: (tile, coordinate)
+    __shared__ double park[4][Q][64];
+    __shared__ double sh[kBoxTilesPerBlock][4][6];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t tile0 = (int64_t)blockIdx.x * kBoxTilesPerBlock;
+    double v[Q];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const double cc = ctr ? ctr[d] : 0.0;
-            m = fmax(m, fmax(fabs(b.lo[d] - cc), fabs(b.hi[d] - cc)));
+    for (int t = 0; t < kBoxTilesPerBlock; ++t) {  // all loads in flight; an absent point is NaN: fmin / fmax skip it
+        const int64_t i = (tile0 + t) * kTile + threadIdx.x;
+        const bool ok = i < c.n;
+        v[3 * t] = ok ? c.x[i] : __builtin_nan("");
+        v[3 * t + 1] = ok ? c.y[i] : __builtin_nan("");
+        v[3 * t + 2] = ok ? c.z[i] : __builtin_nan("");
+    }
+#pragma unroll
+    for (int k = 0; k < Q; ++k) park[wave][k][lane] = v[k];
+    __builtin_amdgcn_wave_barrier();  // wave-local data: LDS serves one wave's accesses in order
+    if (lane < 2 * Q) {
+        const int k = lane >> 1;
+        const double sgn = (lane & 1) ? -1.0 : 1.0;  // odd lanes: maximum as -min(-x)
+        double m = __builtin_huge_val();
+#pragma unroll 8
+        for (int e = 0; e < 64; ++e) m = fmin(m, sgn * park[wave][k][(e + lane) & 63]);
+        const int t = k / 3, d = k % 3;
+        const double r = sgn * m;  // (+huge, -huge) for a quarter without points, as before
+        if (tile0 + t < ntiles) {
+            boxes[ntiles * 6 + ((tile0 + t) * 4 + wave) * 6 + (lane & 1) * 3 + d] = r;
+            sh[t][wave][(lane & 1) * 3 + d] = r;
         }
-        // one atomic per workgroup on ONE word serialises (~0.13 us each: 26 us for the 196 tiles of 50k points): only a workgroup
-        // whose value exceeds what is already there needs to write at all (a stale read only costs a redundant atomic)
-        const unsigned long long mb = __builtin_bit_cast(unsigned long long, m);
-        if (mb > __hip_atomic_load(reinterpret_cast<unsigned long long *>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(reinterpret_cast<unsigned long long *>(slot), mb);
+    }
+    __syncthreads();
+    double m = 0.0;
+    if (threadIdx.x < kBoxTilesPerBlock * 3) {  // thread (t, d): both bounds of coordinate d of tile t
+        const int t = threadIdx.x / 3, d = threadIdx.x % 3;
+        if (tile0 + t < ntiles) {
+            const double lo = fmin(fmin(sh[t][0][d], sh[t][1][d]), fmin(sh[t][2][d], sh[t][3][d]));
+            const double hi = fmax(fmax(sh[t][0][3 + d], sh[t][1][3 + d]), fmax(sh[t][2][3 + d], sh[t][3][3 + d]));
+            boxes[(tile0 + t) * 6 + d] = lo;
+            boxes[(tile0 + t) * 6 + 3 + d] = hi;
+            const double cc = ctr ? ctr[d] : 0.0;
+            m = fmax(fabs(lo - cc), fabs(hi - cc));
+        }
+    }
+    if (slot && wave == 0) {  // kBoxTilesPerBlock * 3 <= 64: the candidates all sit in wave 0
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+        if (lane == 0) {
+            // non-negative doubles order like their bit patterns; only a value above what is already there needs the atomic
+            const unsigned long long mb = __builtin_bit_cast(unsigned long long, m);
+            if (mb > __hip_atomic_load(reinterpret_cast<unsigned long long *>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(reinterpret_cast<unsigned long long *>(slot), mb);
+        }
     }
 }
 
@@ -1344,8 +1373,9 @@ void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, const double *ctr, double *slo
 
 void launch_tile_bbox(gingr_ctx *ctx, Cloud c, double *boxes, const double *ctr, double *absmax_slot) {
     if (c.n <= 0) return;
-    hipLaunchKernelGGL(tile_bbox_kernel, dim3((unsigned)ceil_div(c.n, kTile)), dim3(256), 0, ctx->stream, c, boxes, ctr,
-                       absmax_slot);
+    const int64_t ntiles = ceil_div(c.n, kTile);
+    hipLaunchKernelGGL(tile_bbox_kernel, dim3((unsigned)ceil_div(ntiles, kBoxTilesPerBlock)), dim3(256), 0, ctx->stream, c, boxes, ctr,
+                       absmax_slot, ntiles);
 }
 
 int launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
