@@ -627,7 +627,8 @@ __global__ __launch_bounds__(256) void cpd_den_finalize_kernel(Cloud tgt, const 
         double colsum;
         if (chunk_partial) {
             colsum = 0.0;
-            for (int ch = 0; ch < nchunks; ++ch) colsum += chunk_partial[(int64_t)ch * tgt.n + j];
+#pragma unroll 8
+            for (int ch = 0; ch < nchunks; ++ch) colsum += chunk_partial[(int64_t)ch * tgt.n + j];  // loads ahead, adds in order
         } else {
             colsum = den[j];
         }
