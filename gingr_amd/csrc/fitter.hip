@@ -87,7 +87,25 @@ struct gingr_fitter {
     bool skip_phase1 = false;
     double *small = nullptr;  // 8 doubles of device scratch for scalar results
     void *stat_scratch = nullptr;  // StatScratch of gingr_fitter_surface_distance_stats (kept across calls)
-    double *lsave = nullptr;  // [rp][rp]: Cholesky factor of I + G kept across the two systems of the transition-density query
+    // Second memo slot and the factor cache of the transition-density query.  A Metropolis-Hastings step works on two states, the
+    // current x and the candidate x' (proposal from x, q(x'|x), q(x|x')), and the next step starts from one of the two: `alt_seg`
+    // keeps the [G, rhs, scalars] segment of the state the live memo held before (alt_key), and is swapped back in instead of
+    // recomputing phases 0 and 1.  Only the probabilistic entry points use it (allow_alt): after a swap the correspondence arrays
+    // on the device belong to the other state (corr_stale), which the getters of the deterministic path must never see.
+    // fxbuf[live] / fxbuf[live ^ 1] go with the live / alt slot: [rp*rp] factor of S_tot + eps (I + G), [rp] posterior
+    // coefficients, [rp] reciprocal diagonal -- what posterior_logpdf_lds_kernel leaves for posterior_logpdf_cached_kernel.
+    double *alt_seg = nullptr;
+    Key alt_key;
+    int alt_stage = 0;
+    bool allow_alt = false, corr_stale = false;
+    double *fxbuf[2] = {nullptr, nullptr};
+    bool fx_valid[2] = {false, false};
+    int live = 0;
+    void forget_posteriors() {
+        post_stage = 0;
+        alt_stage = 0;
+        fx_valid[0] = fx_valid[1] = false;
+    }
     // Where phases 0 / 1 put THIS shard's partial sums (same segment layout as xch).  nullptr: into xch itself (single shard, or a
     // host that all-reduces xch in place -- torch.distributed).  The device group (group.hip) points it at the shard's send
     // buffer: peers read that while the summed result lands in xch, so nobody overwrites what a peer may still be reading.
@@ -96,6 +114,15 @@ struct gingr_fitter {
 };
 
 namespace {
+
+// a <-> b (exchange != 0) or a <- b: the [G, rhs, scalars] segments of the two posterior memo slots
+__global__ __launch_bounds__(256) void swap_segments_kernel(double *__restrict__ a, double *__restrict__ b, int64_t n, int exchange) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double va = a[i], vb = b[i];
+    a[i] = vb;
+    if (exchange) b[i] = va;
+}
 
 template <typename T>
 int dev_alloc(gingr_ctx *ctx, T **p, size_t count) {
@@ -402,7 +429,8 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
         (rc = dev_alloc(ctx, &f->nn_d2, (size_t)M)) || (rc = dev_alloc(ctx, &f->weight, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->evec, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->newshape, (size_t)3 * M)) ||
         (rc = dev_alloc(ctx, &f->alpha, (size_t)rp)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
-        (rc = dev_alloc(ctx, &f->small, (size_t)8)) || (rc = dev_alloc(ctx, &f->lsave, (size_t)rp * rp)) ||
+        (rc = dev_alloc(ctx, &f->small, (size_t)8)) || (rc = dev_alloc(ctx, &f->fxbuf[0], (size_t)rp * rp + 2 * rp)) || (rc = dev_alloc(ctx, &f->fxbuf[1], (size_t)rp * rp + 2 * rp)) ||
+        (rc = dev_alloc(ctx, &f->alt_seg, (size_t)rp * rp + rp + 8)) ||
         (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->zbuf, (size_t)19 * rp)) || (rc = dev_alloc(ctx, &f->zrand, (size_t)rp)) || (rc = dev_alloc(ctx, &f->st, 1)) ||
         (rc = dev_alloc(ctx, &f->pose, 1)) || (rc = dev_alloc(ctx, &f->hs_dev, 1)) ||
         (rc = dev_alloc(ctx, &f->scalars, 8)) || (rc = dev_alloc(ctx, &f->part, GINGR_SCALAR_PART)) || (rc = dev_alloc(ctx, &f->absmax, GINGR_AUX)) || (rc = dev_alloc(ctx, &f->work, (size_t)std::max<int64_t>((int64_t)rp * rp, posterior_work_doubles(rp)))) ||
@@ -453,7 +481,9 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->hs_dev);
     dev_free(f->scalars);
     dev_free(f->small);
-    dev_free(f->lsave);
+    dev_free(f->fxbuf[0]);
+    dev_free(f->fxbuf[1]);
+    dev_free(f->alt_seg);
     dev_free(f->retry);
     dev_free(f->part);
     dev_free(f->absmax);
@@ -475,7 +505,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
 
 int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
-    f->post_stage = 0;  // the posterior memo describes other inputs
+    f->forget_posteriors();  // the posterior memos describe other inputs
     gingr_ctx *ctx = f->ctx;
     if (N < 1 || N > INT32_MAX || !target_xyz) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_target: bad N");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -543,7 +573,7 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
 int gingr_fitter_set_landmarks(gingr_fitter *f, int32_t n_lm, const int32_t *lm_pid, const double *lm_xyz,
                                const double *lm_cov) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
-    f->post_stage = 0;  // the posterior memo describes other inputs
+    f->forget_posteriors();  // the posterior memos describe other inputs
     gingr_ctx *ctx = f->ctx;
     if (n_lm < 0 || (n_lm > 0 && (!lm_pid || !lm_xyz || !lm_cov)))
         return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_landmarks: bad argument");
@@ -662,6 +692,8 @@ int gingr_fitter_get_state(gingr_fitter *f, double *alpha, gingr_state_scalars *
 int gingr_fitter_get_cpd_stats(gingr_fitter *f, double *P1, double *PX, double *den, double *scalars6) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
     gingr_ctx *ctx = f->ctx;
+    if (f->corr_stale)  // see gingr_fitter::alt_seg
+        return gingr_set_error(ctx, GINGR_ERR_STATE, "get_cpd_stats: a probabilistic query brought another state's posterior back; the correspondences on the device are not this state's -- run an update or a phase first");
     if (!f->target) return gingr_set_error(ctx, GINGR_ERR_STATE, "get_cpd_stats: no target");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t M = f->m->M;
@@ -701,6 +733,8 @@ int gingr_fitter_get_cpd_stats(gingr_fitter *f, double *P1, double *PX, double *
 int gingr_fitter_get_icp_idx(gingr_fitter *f, int32_t *idx, double *d2) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
     gingr_ctx *ctx = f->ctx;
+    if (f->corr_stale)  // see gingr_fitter::alt_seg
+        return gingr_set_error(ctx, GINGR_ERR_STATE, "get_icp_idx: a probabilistic query brought another state's posterior back; the correspondences on the device are not this state's -- run an update or a phase first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t M = f->m->M;
     std::vector<int32_t> hidx((size_t)M);
@@ -786,11 +820,39 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 f->skip_phase1 = true;
                 return GINGR_OK;
             }
+            const int64_t seg = (int64_t)rp * rp + rp + 8;  // G, rhs, scalars: contiguous from off[1]
+            if (f->allow_alt && !f->partial_out && f->alt_stage == 2 && f->alt_key.same(k)) {
+                // the other slot holds this state: exchange the two (or copy, when the live slot holds nothing finished)
+                const bool both = f->post_stage == 2;
+                hipLaunchKernelGGL(swap_segments_kernel, dim3((unsigned)ceil_div(seg, 256)), dim3(256), 0, ctx->stream, Gw, f->alt_seg,
+                                   seg, both ? 1 : 0);
+                if (both) {
+                    std::swap(f->post_key, f->alt_key);
+                } else {
+                    f->post_key = f->alt_key;
+                    f->fx_valid[f->live] = false;  // becomes the alt slot's buffer: the alt segment stays, its factors move over
+                }
+                f->live ^= 1;
+                f->post_stage = 2;
+                f->corr_stale = true;
+                f->skip_phase1 = true;
+                return GINGR_OK;
+            }
+            if (f->allow_alt && !f->partial_out && f->post_stage == 2) {  // keep what is about to be overwritten
+                hipLaunchKernelGGL(swap_segments_kernel, dim3((unsigned)ceil_div(seg, 256)), dim3(256), 0, ctx->stream, f->alt_seg, Gw, seg,
+                                   0);
+                f->alt_key = f->post_key;
+                f->alt_stage = 2;
+                f->live ^= 1;  // its factors stay with it
+            }
+            f->fx_valid[f->live] = false;
             f->post_key = k;
             f->post_stage = 1;
         } else {
             f->post_stage = 0;
+            f->fx_valid[f->live] = false;
         }
+        f->corr_stale = false;  // phase 0 recomputes the correspondences of this state
     } else if (phase == 1) {
         if (f->skip_phase1) {
             f->skip_phase1 = false;
@@ -1006,7 +1068,7 @@ int gingr_fitter_update_icp_async(gingr_fitter *f, const gingr_icp_params *p, in
 int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t *model_tri, int64_t n_target_tri,
                             const int32_t *target_tri) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
-    f->post_stage = 0;  // the posterior memo describes other inputs
+    f->forget_posteriors();  // the posterior memos describe other inputs
     gingr_ctx *ctx = f->ctx;
     if (!f->target) return gingr_set_error(ctx, GINGR_ERR_STATE, "set_meshes: no target set (gingr_fitter_set_target)");
     if (f->m->M != f->m->M_total) return gingr_set_error(ctx, GINGR_ERR_STATE, "set_meshes: single shard only");
@@ -1181,6 +1243,8 @@ int gingr_fitter_set_correspondence_direction(gingr_fitter *f, int32_t reversed)
 int gingr_fitter_get_reversed_correspondence(gingr_fitter *f, int32_t *template_id, double *w) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
     gingr_ctx *ctx = f->ctx;
+    if (f->corr_stale)  // see gingr_fitter::alt_seg
+        return gingr_set_error(ctx, GINGR_ERR_STATE, "get_reversed_correspondence: a probabilistic query brought another state's posterior back; the correspondences on the device are not this state's -- run an update or a phase first");
     if (!f->rnn) return gingr_set_error(ctx, GINGR_ERR_STATE, "get_reversed_correspondence: direction not reversed");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t N = f->N;
@@ -1218,6 +1282,8 @@ int gingr_fitter_update_icp_surface_async(gingr_fitter *f, const gingr_icp_param
 int gingr_fitter_get_surface_correspondence(gingr_fitter *f, double *cp_xyz, double *w) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
     gingr_ctx *ctx = f->ctx;
+    if (f->corr_stale)  // see gingr_fitter::alt_seg
+        return gingr_set_error(ctx, GINGR_ERR_STATE, "get_surface_correspondence: a probabilistic query brought another state's posterior back; the correspondences on the device are not this state's -- run an update or a phase first");
     if (!f->surf_cp) return gingr_set_error(ctx, GINGR_ERR_STATE, "get_surface_correspondence: no meshes set");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t M = f->m->M;
@@ -1252,7 +1318,9 @@ static int sample_update(gingr_fitter *f, int flavour, const gingr_cpd_params *c
     HIP_TRY(ctx, hipMemcpyAsync(f->zrand, zz.data(), (size_t)rp * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     f->zrand_active = true;
     int rc = GINGR_OK;
+    f->allow_alt = true;
     for (int ph = 0; ph < GINGR_NUM_PHASES && rc == GINGR_OK; ++ph) rc = flavour_phase(f, flavour, cp, ip, ph);
+    f->allow_alt = false;
     f->zrand_active = false;
     return rc;
 }
@@ -1279,7 +1347,12 @@ static int posterior_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params
     const int64_t M = m->M;
     const int32_t r = m->r, rp = m->rp;
     // posterior of the current state: correspondences, Gram, right-hand side (phases 0 and 1 do not touch the state)
-    for (int ph = 0; ph < 2; ++ph) GINGR_TRY(flavour_phase(f, flavour, cp, ip, ph));
+    f->allow_alt = true;
+    int prc = GINGR_OK;
+    for (int ph = 0; ph < 2 && prc == GINGR_OK; ++ph) prc = flavour_phase(f, flavour, cp, ip, ph);
+    f->allow_alt = false;
+    GINGR_TRY(prc);
+    const bool cached = f->fx_valid[f->live];  // this state's factors are on the device: only the mesh-dependent part is left
     double *G = f->xch + f->off[1];
     double *rhs = G + (int64_t)rp * rp;
     // Q0^T e with e = R^T(mesh - c - t) - (ref - c) - mean in the pose of the state (copied on the device, no host round trip)
@@ -1293,13 +1366,15 @@ static int posterior_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params
     a.out = f->alpha_c;
     launch_sweep(ctx, SWEEP_PROJ2, a);
     // one kernel: posterior coefficients a = (I + G)^-1 rhs, then the ridge projection of the mesh and its log-density
-    GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, rhs, m->mom + MomentLayout{rp}.stot(), f->alpha_c, f->lsave, f->work, out2));
+    GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, rhs, m->mom + MomentLayout{rp}.stot(), f->alpha_c, f->fxbuf[f->live], cached, f->work,
+                                      out2));
     GINGR_TRY(check_launch(ctx));
     double res[2] = {0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(res, out2, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (res[1] != 0.0) return gingr_set_error(ctx, GINGR_ERR_NOT_SPD, "posterior_logpdf: posterior of the current state failed");
     if (!std::isfinite(res[0])) return gingr_set_error(ctx, GINGR_ERR_NONFINITE, "posterior_logpdf: non-finite result");
+    if (f->post_stage == 2) f->fx_valid[f->live] = true;  // (not memoised: sharded / state unknown to the host -> nothing to key it by)
     *logpdf = res[0];
     return GINGR_OK;
 }

@@ -162,9 +162,11 @@ void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, 
 // zrand (nullable, [r] on the device): standard-normal draws; the result is then a posterior SAMPLE a + L^-T z
 void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *zrand,
                             double *work, double *a, DevState *st);
-// out2[0] = posterior.gp.logpdf(posterior.coefficients(mesh)), out2[1] = |c|^2; qte = Q0^T e (model-frame residual)
+// out2[0] = posterior.gp.logpdf(posterior.coefficients(mesh)), out2[1] != 0: the posterior failed; qte = Q0^T e (model-frame
+// residual).  fx ([rp*rp + 2*rp], nullable): receives the state-only part of the computation (cached == false) or provides it
+// (cached == true: only the mesh-dependent part runs).
 int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *Stot,
-                            const double *qte, double *lsave, double *work, double *out2);
+                            const double *qte, double *fx, bool cached, double *work, double *out2);
 // doubles of the `work` buffer launch_posterior_solve / launch_posterior_logpdf need (used when r > 128)
 int64_t posterior_work_doubles(int32_t rp);
 // Binv = (S/eps + I)^-1  (work: [rp*rp]); *err_flag != 0 on failure

@@ -1050,6 +1050,40 @@ __device__ __forceinline__ void lds_backward(const double *A, int ld, int n, con
     }
 }
 
+// y <- L^-1 y for the n entries of y (blocked, top down): the mirror image of lds_backward -- lane c of wave 0 holds ROW c of the
+// diagonal block, at step c every lane below takes x_c from lane c through the DPP of its FMA.
+template <int NT>
+__device__ __forceinline__ void lds_forward(const double *A, int ld, int n, const double *rd, double *y) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int kb = 0; kb < n; kb += kNB) {
+        if (wave == 0) {
+            const int l15 = lane & 15;
+            double nrow[kNB];  // -L11[lane][k] for k < lane, else 0 (lanes <= k must not move at step k)
+#pragma unroll
+            for (int k = 0; k < kNB; ++k) {
+                const double v = A[(kb + l15) * ld + kb + k];
+                nrow[k] = k < l15 ? -v : 0.0;
+            }
+            double yv = y[kb + l15];
+            const double rdl = rd[kb + l15];
+            static_for<0, kNB>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                const double t = yv * rdl;  // lane c: x_c (its yv is complete)
+                fmac_row_bcast<c, true>(yv, t, nrow[c]);
+            });
+            if (lane < kNB) y[kb + lane] = yv * rdl;
+        }
+        __syncthreads();
+        for (int i = kb + kNB + tid; i < n; i += NT) {
+            double sacc = y[i];
+#pragma unroll
+            for (int k = 0; k < kNB; ++k) sacc = __builtin_fma(-A[i * ld + kb + k], y[kb + k], sacc);
+            y[i] = sacc;
+        }
+        __syncthreads();
+    }
+}
+
 // Diagonal block of a blocked Cholesky that runs over many workgroups (classic_cpd.hip): factor the 64 x 64 block k of the
 // row-major matrix Aw in LDS with the building blocks above and invert the factor on the way -- the identity rides along as 64
 // extra rows, which come back as (L^-1 e_c)^T = row c of L^-T.  Aw block <- L (upper part zeroed), Linv[k] <- L^-1 (64 x 64, dense).
@@ -1150,7 +1184,7 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_lds_kernel(int
                                                                    const double *__restrict__ rhs,
                                                                    const double *__restrict__ Stot,
                                                                    const double *__restrict__ qte,
-                                                                   double *__restrict__ /* unused: was the parked factor */,
+                                                                   double *__restrict__ fx /* nullable: [rp*rp] second factor, [rp] a, [rp] 1/diag */,
                                                                    double *__restrict__ out2, double *gwork) {
     extern __shared__ double lds_sm[];
     double *sm;
@@ -1174,7 +1208,10 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_lds_kernel(int
     lds_load_spd<kSolveThreads>(A, ld, r, n, G, 1.0, nullptr, 0.0, 1.0);
     lds_cholesky<kSolveThreads>(A, ld, n, rd, &bad_spd, kNB);  // u <- L^-1 rhs on the way
     lds_backward<kSolveThreads>(A, ld, n, rd, u);
-    for (int k = tid; k < rp; k += kSolveThreads) av[k] = k < r ? u[k] : 0.0;
+    for (int k = tid; k < rp; k += kSolveThreads) {
+        av[k] = k < r ? u[k] : 0.0;
+        if (fx) fx[(int64_t)rp * rp + k] = av[k];
+    }
     __syncthreads();
     // (2) b = Q0^T e - S_tot a.  Two threads per entry (column halves of the symmetric S_tot: coalesced), four loads in flight
     for (int k = tid; k < kNB * ld; k += kSolveThreads) u[k] = 0.0;
@@ -1202,6 +1239,13 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_lds_kernel(int
     lds_cholesky<kSolveThreads>(A, ld, n, rd, &bad_spd, kNB);                                        // u <- L2^-1 u on the way
     lds_backward<kSolveThreads>(A, ld, n, rd, u);
     __syncthreads();
+    if (fx) {  // everything of the second system that depends on the state alone: posterior_logpdf_cached_kernel starts from here
+        for (int idx = tid; idx < n * n; idx += kSolveThreads) {
+            const int i = idx / n, j = idx - i * n;
+            fx[(int64_t)i * rp + j] = A[i * ld + j];
+        }
+        for (int k = tid; k < n; k += kSolveThreads) fx[(int64_t)rp * rp + rp + k] = rd[k];
+    }
     // (4) |c|^2 with c = L^T u, L L^T = I + G:  |c|^2 = u^T (I + G) u -- a quadratic form with G itself, so the first factor does
     //     not have to survive the second factorisation (it used to be parked in a global scratch and read back)
     double part = 0.0;
@@ -1233,6 +1277,92 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_lds_kernel(int
         const double n2 = red[0];
         out2[0] = bad_spd ? __builtin_nan("") : -0.5 * n2 - 0.5 * (double)r * 1.8378770664093454836;  // log(2 pi)
         out2[1] = bad_spd ? 1.0 : 0.0;
+    }
+}
+
+// The same log-density for a state whose posterior_logpdf_lds_kernel has run before (fx: its posterior coefficients and the factor
+// of S_tot + eps (I + G), both functions of the state alone): only the mesh-dependent part is left -- b, two triangular solves, the
+// quadratic form.  A Metropolis-Hastings step asks for q(x' | x) of a state x that was the x' or the x of the step before.
+template <bool GW>
+__global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_cached_kernel(int r, int rp, const double *__restrict__ G,
+                                                                      const double *__restrict__ Stot,
+                                                                      const double *__restrict__ qte,
+                                                                      const double *__restrict__ fx, double *__restrict__ out2,
+                                                                      double *gwork) {
+    extern __shared__ double lds_sm[];
+    double *sm;
+    if constexpr (GW)
+        sm = gwork;
+    else
+        sm = lds_sm;
+    const int n = rp, ld = n | 1;
+    double *A = sm;
+    double *u = sm + (size_t)n * ld;
+    double *rd = sm + (size_t)(n + kNB) * ld;
+    __shared__ double red[kSolveThreads];
+    __shared__ double av[512];
+    __shared__ double hv[2][512];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < n * n; idx += kSolveThreads) {
+        const int i = idx / n, j = idx - i * n;
+        A[i * ld + j] = fx[(int64_t)i * rp + j];
+    }
+    for (int k = tid; k < n; k += kSolveThreads) {
+        rd[k] = fx[(int64_t)rp * rp + rp + k];
+        av[k] = k < r ? fx[(int64_t)rp * rp + k] : 0.0;
+    }
+    for (int k = tid; k < kNB * ld; k += kSolveThreads) u[k] = 0.0;
+    __syncthreads();
+    {  // b = Q0^T e - S_tot a   (step (2) of posterior_logpdf_lds_kernel, same order of operations)
+        const int k = tid & 127, half = tid >> 7;
+        for (int kk = k; kk < r; kk += 128) {
+            const int j0 = half ? (r + 1) / 2 : 0, j1 = half ? r : (r + 1) / 2;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int j = j0;
+            for (; j + 3 < j1; j += 4) {
+                s0 = __builtin_fma(Stot[(int64_t)j * rp + kk], av[j], s0);
+                s1 = __builtin_fma(Stot[(int64_t)(j + 1) * rp + kk], av[j + 1], s1);
+                s2 = __builtin_fma(Stot[(int64_t)(j + 2) * rp + kk], av[j + 2], s2);
+                s3 = __builtin_fma(Stot[(int64_t)(j + 3) * rp + kk], av[j + 3], s3);
+            }
+            for (; j < j1; ++j) s0 = __builtin_fma(Stot[(int64_t)j * rp + kk], av[j], s0);
+            hv[half][kk] = (s0 + s1) + (s2 + s3);
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < r; k += kSolveThreads) u[k] = qte[k] - (hv[0][k] + hv[1][k]);
+    __syncthreads();
+    lds_forward<kSolveThreads>(A, ld, n, rd, u);
+    lds_backward<kSolveThreads>(A, ld, n, rd, u);
+    __syncthreads();
+    double part = 0.0;
+    {  // |c|^2 = u^T (I + G) u   (step (4))
+        const int k = tid & 127, half = tid >> 7;
+        for (int kk = k; kk < r; kk += 128) {
+            const int j0 = half ? (r + 1) / 2 : 0, j1 = half ? r : (r + 1) / 2;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int j = j0;
+            for (; j + 3 < j1; j += 4) {
+                s0 = __builtin_fma(G[(int64_t)j * rp + kk], u[j], s0);
+                s1 = __builtin_fma(G[(int64_t)(j + 1) * rp + kk], u[j + 1], s1);
+                s2 = __builtin_fma(G[(int64_t)(j + 2) * rp + kk], u[j + 2], s2);
+                s3 = __builtin_fma(G[(int64_t)(j + 3) * rp + kk], u[j + 3], s3);
+            }
+            for (; j < j1; ++j) s0 = __builtin_fma(G[(int64_t)j * rp + kk], u[j], s0);
+            double g = (s0 + s1) + (s2 + s3);
+            if (half == 0) g += u[kk];
+            part = __builtin_fma(u[kk], g, part);
+        }
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (int st2 = kSolveThreads / 2; st2 > 0; st2 >>= 1) {
+        if (tid < st2) red[tid] += red[tid + st2];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out2[0] = -0.5 * red[0] - 0.5 * (double)r * 1.8378770664093454836;  // log(2 pi)
+        out2[1] = 0.0;
     }
 }
 
@@ -1783,9 +1913,25 @@ void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
 }
 
 int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *Stot,
-                            const double *qte, double *lsave, double *work, double *out2) {
+                            const double *qte, double *fx, bool cached, double *work, double *out2) {
+    const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
+    if (cached) {  // fx holds what an earlier launch for this state left
+        if (r <= 128) {
+            static size_t lds_granted = 48 * 1024;  // the attribute is per function, not per launch
+            if (lds > lds_granted) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_cached_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                lds_granted = lds;
+            }
+            hipLaunchKernelGGL(posterior_logpdf_cached_kernel<false>, dim3(1), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, G, Stot,
+                               qte, fx, out2, (double *)nullptr);
+        } else {
+            hipLaunchKernelGGL(posterior_logpdf_cached_kernel<true>, dim3(1), dim3(kSolveThreads), 0, ctx->stream, (int)r, (int)rp, G, Stot, qte,
+                               fx, out2, work);
+        }
+        return GINGR_OK;
+    }
     if (r <= 128) {
-        const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
         static size_t lds_granted = 48 * 1024;  // the attribute is per function, not per launch
         if (lds > lds_granted) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_lds_kernel<false>),
@@ -1793,9 +1939,9 @@ int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
             lds_granted = lds;
         }
         hipLaunchKernelGGL(posterior_logpdf_lds_kernel<false>, dim3(1), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte,
-                           lsave, out2, (double *)nullptr);
+                           fx, out2, (double *)nullptr);
     } else {
-        hipLaunchKernelGGL(posterior_logpdf_lds_kernel<true>, dim3(1), dim3(kSolveThreads), 0, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte, lsave,
+        hipLaunchKernelGGL(posterior_logpdf_lds_kernel<true>, dim3(1), dim3(kSolveThreads), 0, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte, fx,
                            out2, work);
     }
     return GINGR_OK;

@@ -196,3 +196,56 @@ def test_failed_projection_at_iteration_zero_is_an_error(ctx):
     assert s1.general.status == o1.status == ga.FittingStatuses.ModelFlexibilityError
     assert np.array_equal(s1.general.modelParameters.shape, st.general.modelParameters.shape)
     algo.close()
+
+
+@pytest.mark.parametrize("rank", [28, 150])
+def test_transition_density_memo_slots_and_cached_factors(ctx, rank):
+    """A Metropolis-Hastings step alternates between two states (GingrAlgorithm.scala:68 memoises computePosterior): the second
+    memo slot brings a state's [G, rhs] back instead of recomputing it, and a state whose factors are on the device answers
+    further density queries from them.  Every route must give the value a fresh instance computes from scratch."""
+    import gingr_amd as ga
+    if rank <= 128:
+        mo, model, target = setup(seed=17, rank=rank)
+    else:
+        rng = np.random.default_rng(33)
+        M = 400
+        ref = rng.normal(0, 40, (M, 3))
+        U, _ = np.linalg.qr(rng.normal(0, 1, (3 * M, rank)))
+        lam = np.sort(rng.uniform(1.0, 300.0, rank))[::-1].copy()
+        mo = go.PDM(ref=ref, mean=rng.normal(0, 0.2, (M, 3)), U=np.ascontiguousarray(U), lam=lam)
+        target = mo.instance(rng.normal(0, 1.0, rank)) + rng.normal(0, 0.3, (M, 3))
+        model = ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam)
+    cfg = ga.CpdConfiguration(maxIterations=50, w=0.05)
+
+    def fresh():
+        a = ga.CpdRegistration(ctx)
+        return a, a.createInitialState(model, target, cfg)
+
+    algo, s0 = fresh()
+    A = algo.update(s0)
+    B = algo.update(A, probabilistic=True, rnd=np.random.default_rng(4))
+    C = algo.update(B, probabilistic=True, rnd=np.random.default_rng(5))
+    # reference values: one fresh instance per query (nothing memoised)
+    want = {}
+    for name, (frm, to) in {"AB": (A, B), "BA": (B, A), "AC": (A, C), "BC": (B, C)}.items():
+        a2, _ = fresh()
+        want[name] = a2.logTransitionProbability(frm, to)
+        a2.close()
+    # the sequence of a chain: q(B|A), q(A|B) [A goes to the second slot], q(C|A) [swap back, cached factors], q(C|B) [swap, cached]
+    got = [algo.logTransitionProbability(A, B), algo.logTransitionProbability(B, A), algo.logTransitionProbability(A, C),
+           algo.logTransitionProbability(B, C), algo.logTransitionProbability(A, B)]
+    for g, k in zip(got, ["AB", "BA", "AC", "BC", "AB"]):
+        assert np.isfinite(g) and abs(g - want[k]) <= 1e-9 * abs(want[k]), (k, g, want[k])
+    # a sampled proposal from a state that comes back from the second slot = the proposal of a fresh instance (same draws)
+    _ = algo.logTransitionProbability(B, A)                     # live: B, second slot: A
+    p1 = algo.update(A, probabilistic=True, rnd=np.random.default_rng(8))
+    a3, _ = fresh()
+    p2 = a3.update(A, probabilistic=True, rnd=np.random.default_rng(8))
+    assert np.array_equal(p1.general.fit, p2.general.fit) and p1.general.sigma2 == p2.general.sigma2
+    # and the deterministic path never takes a posterior out of the second slot (its correspondence getters must stay valid)
+    _ = algo.logTransitionProbability(B, A)
+    d1 = algo.update(A)
+    d2 = a3.update(A)
+    assert np.array_equal(d1.general.fit, d2.general.fit)
+    a3.close()
+    algo.close()
