@@ -99,6 +99,9 @@ SIGNATURES = {
     "gingr_rigid_icp_iterate": (c_int, [c_void_p, c_int32, _dp]),
     "gingr_rigid_icp_get": (c_int, [c_void_p, _dp, _dp]),
     "gingr_rigid_icp_set": (c_int, [c_void_p, _dp]),
+    "gingr_fitter_set_fit_points": (c_int, [c_void_p, _dp]),
+    "gingr_nicp_solve": (c_int, [c_void_p, c_int32, c_int64, _dp, c_int64, _ip, _dp, _dp, c_int32, _ip, _dp, c_double, c_double, c_double,
+                                 _dp, _dp]),
     "gingr_mesh_closest_points": (c_int, [c_void_p, c_int64, _dp, c_int64, _dp, c_int64, _ip, _dp, _dp, _ip, _dp]),
     "gingr_model_new_reference": (c_int, [c_void_p, c_void_p, c_int64, _dp, _ip, _dp, c_int64, c_int64, POINTER(c_void_p)]),
     "gingr_gpmm_build_diagonal": (c_int, [c_void_p, c_int64, _dp, POINTER(ScalarKernel), POINTER(ScalarKernel), POINTER(ScalarKernel),

@@ -244,3 +244,126 @@ class RigidICPRegistration:
         tgt = f64(target)
         n = min(tgt.shape[0], reg.shape[0])
         return tgt[:n] + (reg[:n] - tgt[:n])
+
+
+# ------------------------------------------------------------------------------------------------ optimal-step non-rigid ICP
+NICP_DEFAULT_ALPHA = [1e1] * 11   # NonRigidOptimalStepICP.scala:63-65: the scanLeft / reverse chain ends in `.map(_ => 1e1)`
+
+
+def nicp_edges(cells) -> np.ndarray:
+    """trianglesToEdges (:67-76): the unique sorted vertex pairs of the triangles, (E, 2) int32 with p1 < p2 (the reference keeps
+    them in a Set's iteration order; the order of the rows of M does not change the least-squares solution)."""
+    t = np.sort(np.asarray(cells, dtype=np.int64).reshape(-1, 3), axis=1)
+    e = np.concatenate([t[:, [0, 1]], t[:, [0, 2]], t[:, [1, 2]]])
+    return np.ascontiguousarray(np.unique(e, axis=0), dtype=np.int32)
+
+
+class NonRigidOptimalStepICP:
+    """G/other/algorithms/icp/NonRigidOptimalStepICP.scala:31-284 (Amberg et al., "Optimal Step Nonrigid ICP Algorithms for Surface
+    Registration"): `kind` "T" = N-ICP-T (one displacement per vertex), "A" = N-ICP-A (one affine 4 x 3 map per vertex).
+    Both halves of an iteration run on the GPU: the correspondence (closest target surface point + the three rejection tests of
+    ClosestPointTriangleMesh3D: the surface-ICP query of the GiNGR path, asked for the current template through
+    gingr_fitter_set_fit_points) and the least-squares step (gingr_nicp_solve: normal equations, blocked MFMA Cholesky).
+    Landmarks: two mappings id -> point; the common ids are used (:45-55)."""
+
+    def __init__(self, ctx: Context, templateMesh, targetMesh, templateLandmarks=None, targetLandmarks=None, gamma: float = 1.0,
+                 kind: str = "T"):
+        from . import api as ga
+        if gamma < 0:
+            raise ValueError("gamma >= 0 required")
+        if kind not in ("T", "A"):
+            raise ValueError("kind is 'T' or 'A'")
+        self.ctx, self.kind, self.gamma = ctx, kind, float(gamma)
+        self.template = f64(templateMesh[0])
+        self.cells = np.ascontiguousarray(templateMesh[1], dtype=np.int32).reshape(-1, 3)
+        self.target = f64(targetMesh[0])
+        self.targetCells = np.ascontiguousarray(targetMesh[1], dtype=np.int32).reshape(-1, 3)
+        self.n = self.template.shape[0]
+        self.edges = nicp_edges(self.cells)
+        tl, gl = dict(templateLandmarks or {}), dict(targetLandmarks or {})
+        common = [k for k in tl if k in gl]
+        if common:
+            tp = f64(np.array([tl[k] for k in common]))
+            gp = f64(np.array([gl[k] for k in common]))
+            self.lmIdsOnTemplate = ctx.nn(tp, self.template)[0].astype(np.int32)       # closest template VERTEX of each landmark
+            self.UL = self.target[ctx.nn(gp, self.target)[0]].copy()                    # closest target VERTEX (not the landmark)
+        else:
+            self.lmIdsOnTemplate, self.UL = np.zeros(0, dtype=np.int32), np.zeros((0, 3))
+        # carrier of the correspondence query: a fitter over the template's topology (the basis is never used)
+        M = self.n
+        self._model = ga.PointDistributionModel(self.template, np.zeros((M, 3)), np.zeros((3 * M, 1)), np.ones(1), cells=self.cells)
+        self._algo = ga.IcpRegistration(ctx)
+        cfg = ga.IcpConfiguration(maxIterations=1, initialSigma=1.0, endSigma=1.0, correspondenceMethod="TriangularClosestPoint")
+        self._state = self._algo.createInitialState(self._model, self.target, cfg, transform=ga.GlobalTranformationType.NoTransforms,
+                                                    targetCells=self.targetCells)
+        self._lib = ctx._lib
+
+    def close(self):
+        if self._algo is not None:
+            self._algo.close()
+            self._algo = None
+
+    def getClosestPoints(self, template) -> Tuple[np.ndarray, np.ndarray, float]:
+        """(:118-128) (closest target surface points, weights in {0, 1}, mean distance) of the given template points."""
+        from . import _native as nat
+        a, st = self._algo, self._state
+        g, c = st.general, st.config
+        pts = f64(template)
+        a._bind(g, c.useLandmarkCorrespondence)
+        a._push_state(g)
+        a._device_state = None
+        a._select_direction(c)
+        a._select_surface_method(c)
+        _check(self.ctx.handle, self._lib.gingr_fitter_set_fit_points(a._fitter, dptr(pts)), "gingr_fitter_set_fit_points")
+        p = nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
+        _check(self.ctx.handle, self._lib.gingr_fitter_icp_surface_phase_async(a._fitter, ctypes.byref(p), 0),
+               "gingr_fitter_icp_surface_phase_async")
+        cp, w = np.empty((self.n, 3)), np.empty(self.n)
+        _check(self.ctx.handle, self._lib.gingr_fitter_get_surface_correspondence(a._fitter, dptr(cp), dptr(w)),
+               "gingr_fitter_get_surface_correspondence")
+        dd = cp - pts
+        dist = float(np.sqrt((dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2]).sum() / self.n)
+        return cp, w, dist
+
+    def Iteration(self, template, alpha: float, beta: float):
+        """(:151-190 / :241-283) -> (moved template points, mean distance BEFORE the move, moved landmark vertices)"""
+        if alpha < 0 or beta < 0:
+            raise ValueError("alpha, beta >= 0 required")
+        from ._native import iptr
+        pts = f64(template)
+        cp, w, dist = self.getClosestPoints(pts)
+        out, lm = np.empty((self.n, 3)), np.empty((self.lmIdsOnTemplate.shape[0], 3))
+        _check(self.ctx.handle, self._lib.gingr_nicp_solve(
+            self.ctx.handle, 0 if self.kind == "T" else 1, self.n, dptr(pts), self.edges.shape[0], iptr(self.edges), dptr(w), dptr(cp),
+            self.lmIdsOnTemplate.shape[0], iptr(self.lmIdsOnTemplate) if len(self.lmIdsOnTemplate) else None,
+            dptr(self.UL) if len(self.UL) else None, float(alpha), float(beta), self.gamma, dptr(out), dptr(lm) if len(lm) else None),
+            "gingr_nicp_solve")
+        return out, dist, lm
+
+    def Registration(self, max_iteration: int, tolerance: float = 0.001, alpha=None, beta=None, verbose: bool = False) -> np.ndarray:
+        """(:89-121): one stage per (alpha, beta) pair, each up to max_iteration steps or until the mean distance measured before
+        a step is below the tolerance."""
+        alpha = NICP_DEFAULT_ALPHA if alpha is None else list(alpha)
+        beta = alpha if beta is None else list(beta)
+        if len(alpha) != len(beta):
+            raise ValueError("alpha and beta need the same length")
+        fit = self.template
+        self.iterations = 0
+        for j, (a, b) in enumerate(zip(alpha, beta)):
+            dist, i = float("inf"), 0
+            while i < max_iteration and dist >= tolerance:
+                fit, dist, _ = self.Iteration(fit, a, b)
+                if verbose:
+                    print(f"ICP, iteration: {j * max_iteration + i}/{max_iteration * len(alpha)}, alpha: {a}, beta: {b}, "
+                          f"average distance to target: {dist}")
+                i += 1
+                self.iterations += 1
+        return fit
+
+
+def NonRigidOptimalStepICP_T(ctx, templateMesh, targetMesh, templateLandmarks=None, targetLandmarks=None, gamma: float = 1.0):
+    return NonRigidOptimalStepICP(ctx, templateMesh, targetMesh, templateLandmarks, targetLandmarks, gamma, "T")
+
+
+def NonRigidOptimalStepICP_A(ctx, templateMesh, targetMesh, templateLandmarks=None, targetLandmarks=None, gamma: float = 1.0):
+    return NonRigidOptimalStepICP(ctx, templateMesh, targetMesh, templateLandmarks, targetLandmarks, gamma, "A")

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "svd3.h"
 
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -341,6 +342,105 @@ __global__ void nonrigid_finish_kernel(const double *__restrict__ partial, doubl
     if (!(fabs(ns) <= 1.79769313486231570815e308)) *flag = GINGR_ERR_NONFINITE;
 }
 
+// Aw ((Mp + 64) x Mp, lower triangle of an SPD matrix + three right-hand sides in the border rows Mp .. Mp + 2, see
+// build_system_kernel) -> W (three planes of stride Mp): blocked right-looking Cholesky, then the blocked backward substitution.
+// *flag receives GINGR_ERR_NOT_SPD when a diagonal block fails.
+void dense_spd_solve3(gingr_ctx *ctx, double *Aw, int64_t Mp, double *Linv, double *W, int32_t *flag) {
+    const int nb = (int)(Mp / kNBc);
+    for (int k = 0; k < nb; ++k) {
+        launch_chol_block64(ctx, Aw, Mp, k, Linv, flag);
+        hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)(nb - k)), dim3(256), 0, ctx->stream, Aw, Mp, k, Linv);
+        if (k + 1 < nb)
+            hipLaunchKernelGGL(chol_trailing_kernel, dim3((unsigned)(nb - k - 1), (unsigned)(nb - k)), dim3(256), 0, ctx->stream, Aw, Mp, k,
+                               nb);
+    }
+    for (int k = nb - 1; k >= 0; --k)
+        hipLaunchKernelGGL(chol_backward_kernel, dim3((unsigned)(k + 1)), dim3(256), 0, ctx->stream, Aw, Mp, Mp, k, Linv, W);
+}
+
+// ------------------------------------------------------------------------------------------------ optimal-step non-rigid ICP
+// Normal equations of the stacked least-squares systems of NonRigidOptimalStepICP.scala (the reference solves `A \ B` on the sparse
+// stack; A has full column rank, so the solution is the same).  With Lg = M^T M the graph Laplacian of the template's edges:
+//   N-ICP-T (:151-190)   unknown X (n x 3):   (alpha^2 Lg + W^2 + E_L) X = W^2 (U - V) + E_L^T beta (UL - VL)
+//                        E_L: the reference's A3 has its ones at (i, i), i < L -- the first L columns, unscaled by beta
+//   N-ICP-A (:241-283)   unknown X (4n x 3):  (alpha^2 Lg (x) G^2 + D^T W^2 D + beta^2 DL^T DL) X = D^T W^2 U + beta^2 DL^T UL
+//                        D row i = [p_i, 1] in the columns 4i .. 4i+3; W zeroed at the landmark vertices; G = diag(1, 1, 1, gamma)
+// One thread per entry of the lower triangle / the border rows; the matrix is dense on the device (n of a registration template:
+// thousands) and goes through the blocked MFMA Cholesky of the non-rigid CPD.
+struct NicpArgs {
+    int64_t n, dim, Mp, n_edges;
+    int kind;  // 0 T, 1 A
+    const double *v;        // template, SoA [3][n]
+    const double *u;        // closest points, SoA
+    const double *w;        // weights (A: already zero at the landmark vertices)
+    const int32_t *deg;     // edges per vertex
+    const int32_t *lmcount; // landmarks mapped to the vertex (A) / 1 for the first L vertices (T)
+    const double *lmsum;    // SoA [3][n]: A: sum of the landmark targets of the vertex; T: beta (UL_i - VL_i) for i < L
+    double alpha2, beta2, gamma2;
+};
+
+__global__ __launch_bounds__(256) void nicp_fill_kernel(NicpArgs a, double *__restrict__ Aw) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.Mp) return;
+    for (int64_t r = blockIdx.y; r < a.Mp + kNBc; r += gridDim.y) {
+    double val = 0.0;
+    if (r < a.dim) {
+        if (a.kind == 0) {
+            if (c == r) val = a.alpha2 * (double)a.deg[r] + a.w[r] * a.w[r] + (double)a.lmcount[r];
+        } else if (c <= r && (c >> 2) == (r >> 2)) {  // the 4 x 4 block of vertex i
+            const int64_t i = r >> 2;
+            const int ra = (int)(r & 3), ca = (int)(c & 3);
+            const double qr = ra < 3 ? a.v[ra * a.n + i] : 1.0, qc = ca < 3 ? a.v[ca * a.n + i] : 1.0;
+            val = (a.w[i] * a.w[i] + a.beta2 * (double)a.lmcount[i]) * qr * qc;
+            if (ra == ca) val += a.alpha2 * (double)a.deg[i] * (ra < 3 ? 1.0 : a.gamma2);
+        }
+    } else if (r < a.Mp) {
+        val = c == r ? 1.0 : 0.0;  // padding
+    } else if (r < a.Mp + 3 && c < a.dim) {
+        const int d = (int)(r - a.Mp);
+        if (a.kind == 0) {
+            val = a.w[c] * a.w[c] * (a.u[d * a.n + c] - a.v[d * a.n + c]) + a.lmsum[d * a.n + c];
+        } else {
+            const int64_t i = c >> 2;
+            const int ca = (int)(c & 3);
+            const double qc = ca < 3 ? a.v[ca * a.n + i] : 1.0;
+            val = qc * (a.w[i] * a.w[i] * a.u[d * a.n + i] + a.beta2 * a.lmsum[d * a.n + i]);
+        }
+    }
+    Aw[r * a.Mp + c] = val;
+    }
+}
+
+// the off-diagonal entries of alpha^2 Lg (x) G^2: -alpha^2 g_a^2 at ((p2, a), (p1, a)) for every edge p1 < p2
+__global__ __launch_bounds__(256) void nicp_edges_kernel(NicpArgs a, const int32_t *__restrict__ edges, double *__restrict__ Aw) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.n_edges) return;
+    const int64_t p1 = edges[2 * e], p2 = edges[2 * e + 1];
+    if (a.kind == 0) {
+        Aw[p2 * a.Mp + p1] = -a.alpha2;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Aw[(4 * p2 + k) * a.Mp + 4 * p1 + k] = -a.alpha2 * (k < 3 ? 1.0 : a.gamma2);
+    }
+}
+
+// T: out = V + X;  A: out_i = [p_i, 1] X_i  (D X)
+__global__ __launch_bounds__(256) void nicp_apply_kernel(NicpArgs a, const double *__restrict__ W, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        double r;
+        if (a.kind == 0) {
+            r = a.v[d * a.n + i] + W[d * a.Mp + i];
+        } else {
+            const double *x = W + d * a.Mp + 4 * i;
+            r = ((a.v[i] * x[0] + a.v[a.n + i] * x[1]) + a.v[2 * a.n + i] * x[2]) + x[3];
+        }
+        out[d * a.n + i] = r;
+    }
+}
+
 }  // namespace
 
 struct gingr_classic_cpd {
@@ -467,20 +567,10 @@ int gingr_classic_cpd_iterate(gingr_classic_cpd *h, int32_t n_iterations) {
             hipLaunchKernelGGL(apply_transform_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, ctx->stream, M, ty,
                                h->params.as<double>());
         } else {
-            const int nb = (int)(Mp / kNBc);
             double *Aw = h->Aw.as<double>(), *Linv = h->Linv.as<double>();
             hipLaunchKernelGGL(build_system_kernel, dim3((unsigned)ceil_div(Mp, 256), (unsigned)(Mp + kNBc)), dim3(256), 0, ctx->stream, M, Mp,
                                h->G.as<double>(), h->P1.as<double>(), h->PX.as<double>(), ty, sc, h->lambda, Aw);
-            for (int k = 0; k < nb; ++k) {
-                launch_chol_block64(ctx, Aw, Mp, k, Linv, flag);
-                hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)(nb - k)), dim3(256), 0, ctx->stream, Aw, Mp, k, Linv);
-                if (k + 1 < nb)
-                    hipLaunchKernelGGL(chol_trailing_kernel, dim3((unsigned)(nb - k - 1), (unsigned)(nb - k)), dim3(256), 0, ctx->stream, Aw,
-                                       Mp, k, nb);
-            }
-            for (int k = nb - 1; k >= 0; --k)
-                hipLaunchKernelGGL(chol_backward_kernel, dim3((unsigned)(k + 1)), dim3(256), 0, ctx->stream, Aw, Mp, Mp, k, Linv,
-                                   h->W.as<double>());
+            dense_spd_solve3(ctx, Aw, Mp, Linv, h->W.as<double>(), flag);
             hipLaunchKernelGGL(deform_kernel, dim3((unsigned)ceil_div(M, 16)), dim3(256), 0, ctx->stream, M, Mp, h->G.as<double>(),
                                h->W.as<double>(), ty);
             hipLaunchKernelGGL(nonrigid_sums_kernel, dim3(kRedBlocks), dim3(256), 0, ctx->stream, M, ty, h->P1.as<double>(),
@@ -533,6 +623,88 @@ int gingr_classic_cpd_set(gingr_classic_cpd *h, const double *ty_xyz, double sig
     }
     HIP_TRY(ctx, hipMemcpyAsync(h->sc.as<double>() + 8, &sigma2, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GINGR_OK;
+}
+
+int gingr_nicp_solve(gingr_ctx *ctx, int32_t kind, int64_t n, const double *moving_xyz, int64_t n_edges, const int32_t *edges,
+                     const double *w, const double *cp_xyz, int32_t n_lm, const int32_t *lm_ids, const double *lm_target_xyz, double alpha,
+                     double beta, double gamma, double *out_xyz, double *out_lm_xyz) {
+    if (!ctx) return GINGR_ERR_BAD_ARGUMENT;
+    if ((kind != 0 && kind != 1) || n < 1 || n_edges < 0 || n_lm < 0 || !moving_xyz || !w || !cp_xyz || !out_xyz || (n_edges > 0 && !edges) ||
+        (n_lm > 0 && (!lm_ids || !lm_target_xyz)) || !(alpha >= 0.0) || !(beta >= 0.0) || !(gamma >= 0.0) || n_lm > n)
+        return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "nicp_solve: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t dim = kind == 0 ? n : 4 * n, Mp = round_up(dim, kNBc), nb = Mp / kNBc;
+    // host side: SoA clouds, vertex degrees, the landmark terms per vertex
+    std::vector<double> hv((size_t)3 * n), hu((size_t)3 * n), hw((size_t)n), hs((size_t)3 * n, 0.0);
+    std::vector<int32_t> hdeg((size_t)n, 0), hcnt((size_t)n, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        for (int d = 0; d < 3; ++d) {
+            hv[(size_t)(d * n + i)] = moving_xyz[3 * i + d];
+            hu[(size_t)(d * n + i)] = cp_xyz[3 * i + d];
+        }
+        hw[(size_t)i] = w[i];
+    }
+    for (int64_t e = 0; e < n_edges; ++e) {
+        const int32_t p1 = edges[2 * e], p2 = edges[2 * e + 1];
+        if (p1 < 0 || p2 <= p1 || p2 >= n) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "nicp_solve: edge %lld is not p1 < p2 < n", (long long)e);
+        ++hdeg[(size_t)p1];
+        ++hdeg[(size_t)p2];
+    }
+    for (int32_t l = 0; l < n_lm; ++l) {
+        const int32_t id = lm_ids[l];
+        if (id < 0 || id >= n) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "nicp_solve: landmark id out of range");
+        if (kind == 0) {  // row l of A3 has its one in COLUMN l; B3 row l = beta (UL_l - V[id_l])
+            hcnt[(size_t)l] = 1;
+            for (int d = 0; d < 3; ++d) hs[(size_t)(d * n + l)] = beta * (lm_target_xyz[3 * l + d] - moving_xyz[3 * (int64_t)id + d]);
+        } else {
+            hw[(size_t)id] = 0.0;  // W(i, i) = 0 at the landmark vertices (:251-253)
+            ++hcnt[(size_t)id];
+            for (int d = 0; d < 3; ++d) hs[(size_t)(d * n + id)] += lm_target_xyz[3 * l + d];
+        }
+    }
+    DevBuf dv, du, dw, ds, ddeg, dcnt, dedges, Aw, Linv, W, flag, dout;
+    if (dv.alloc(hv.size() * 8) != hipSuccess || du.alloc(hu.size() * 8) != hipSuccess || dw.alloc(hw.size() * 8) != hipSuccess ||
+        ds.alloc(hs.size() * 8) != hipSuccess || ddeg.alloc(hdeg.size() * 4) != hipSuccess || dcnt.alloc(hcnt.size() * 4) != hipSuccess ||
+        dedges.alloc((size_t)(n_edges > 0 ? n_edges : 1) * 8) != hipSuccess || Aw.alloc((size_t)(Mp + kNBc) * Mp * sizeof(double)) != hipSuccess ||
+        Linv.alloc((size_t)nb * kNBc * kNBc * sizeof(double)) != hipSuccess || W.alloc((size_t)3 * Mp * sizeof(double)) != hipSuccess ||
+        flag.alloc(sizeof(int32_t)) != hipSuccess || dout.alloc((size_t)3 * n * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        return gingr_set_error(ctx, GINGR_ERR_HIP, "nicp_solve: out of device memory (the system is dense: %lld x %lld doubles)", (long long)Mp,
+                               (long long)Mp);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(dv.p, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(du.p, hu.data(), hu.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dw.p, hw.data(), hw.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ds.p, hs.data(), hs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ddeg.p, hdeg.data(), hdeg.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dcnt.p, hcnt.data(), hcnt.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (n_edges > 0) HIP_TRY(ctx, hipMemcpyAsync(dedges.p, edges, (size_t)n_edges * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(flag.p, 0, sizeof(int32_t), ctx->stream));
+    NicpArgs a{n, dim, Mp, n_edges, kind, dv.as<double>(), du.as<double>(), dw.as<double>(), ddeg.as<int32_t>(), dcnt.as<int32_t>(),
+               ds.as<double>(), alpha * alpha, beta * beta, gamma * gamma};
+    hipLaunchKernelGGL(nicp_fill_kernel, dim3((unsigned)ceil_div(Mp, 256), (unsigned)std::min<int64_t>(Mp + kNBc, 65535)), dim3(256), 0, ctx->stream, a, Aw.as<double>());
+    if (n_edges > 0)
+        hipLaunchKernelGGL(nicp_edges_kernel, dim3((unsigned)ceil_div(n_edges, 256)), dim3(256), 0, ctx->stream, a, dedges.as<int32_t>(),
+                           Aw.as<double>());
+    dense_spd_solve3(ctx, Aw.as<double>(), Mp, Linv.as<double>(), W.as<double>(), flag.as<int32_t>());
+    hipLaunchKernelGGL(nicp_apply_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, a, W.as<double>(), dout.as<double>());
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<double> ho((size_t)3 * n);
+    int32_t err = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(ho.data(), dout.p, ho.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&err, flag.p, sizeof(err), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (err) return gingr_set_error(ctx, GINGR_ERR_NOT_SPD, "nicp_solve: the normal equations are not positive definite (a mesh component without any weighted vertex or landmark)");
+    for (int64_t i = 0; i < n; ++i)
+        for (int d = 0; d < 3; ++d) {
+            const double val = ho[(size_t)(d * n + i)];
+            if (!std::isfinite(val)) return gingr_set_error(ctx, GINGR_ERR_NONFINITE, "nicp_solve: non-finite result");
+            out_xyz[3 * i + d] = val;
+        }
+    if (out_lm_xyz)  // N-ICP-A: DL X = the moved landmark vertices (:278-282); N-ICP-T has no such output: the moved vertices too
+        for (int32_t l = 0; l < n_lm; ++l)
+            for (int d = 0; d < 3; ++d) out_lm_xyz[3 * l + d] = out_xyz[3 * (int64_t)lm_ids[l] + d];
     return GINGR_OK;
 }
 

@@ -646,6 +646,23 @@ int gingr_fitter_set_state(gingr_fitter *f, const double *alpha, const gingr_sta
     return GINGR_OK;
 }
 
+int gingr_fitter_set_fit_points(gingr_fitter *f, const double *fit_xyz) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = f->ctx;
+    if (!fit_xyz) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_fit_points: null argument");
+    if (!f->has_state) return gingr_set_error(ctx, GINGR_ERR_STATE, "set_fit_points: set a state first (its pose / sigma2 stay in force)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t M = f->m->M;
+    double *stage = reinterpret_cast<double *>(f->aos);
+    HIP_TRY(ctx, hipMemcpyAsync(stage, fit_xyz, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    launch_aos_to_soa(ctx, stage, M, f->fit, f->m->perm);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the caller's buffer is free again
+    // the shape on the device is no instance of the model any more: nothing memoised describes it
+    f->forget_posteriors();
+    f->state_key_valid = false;
+    return GINGR_OK;
+}
+
 int gingr_fitter_get_state(gingr_fitter *f, double *alpha, gingr_state_scalars *s, double *fit_xyz) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
     gingr_ctx *ctx = f->ctx;

@@ -358,7 +358,6 @@ __global__ __launch_bounds__(kCpThreads) void surface_cp_queue_kernel(Cloud q, C
     const int64_t i = (int64_t)blockIdx.x * QPB + ql;
     const bool ok = i < q.n;
     const double qx = ok ? q.x[i] : 0.0, qy = ok ? q.y[i] : 0.0, qz = ok ? q.z[i] : 0.0;
-    const V3 p{qx, qy, qz};
     const unsigned long long kInfBits = 0x7FF0000000000000ull;
     if (half == 0) {
         qbest[wave][ql] = kInfBits;

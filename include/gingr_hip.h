@@ -430,6 +430,27 @@ int gingr_rigid_icp_iterate(gingr_rigid_icp *h, int32_t n_iterations, double *di
 int gingr_rigid_icp_get(gingr_rigid_icp *h, double *points_xyz, double *transform13);
 int gingr_rigid_icp_set(gingr_rigid_icp *h, const double *points_xyz);
 
+
+/* ---- optimal-step non-rigid ICP baselines (G/other/algorithms/icp/NonRigidOptimalStepICP.scala:31-284) ------------------------
+ * The reference's loop is: closest-point correspondence of the current template mesh (ClosestPointTriangleMesh3D, the same
+ * query as the GiNGR ICP path), then one sparse least-squares solve `A \ B`.  Both halves run on the device:
+ *
+ * gingr_fitter_set_fit_points: replace the shape the fitter's NEXT correspondence query looks at (normally the instance of the
+ * current state) by explicit points [3M] -- the N-ICP template is no instance of a model.  Then
+ * gingr_fitter_icp_surface_phase_async(f, p, 0) + gingr_fitter_get_surface_correspondence give (closest points, weights).
+ *
+ * gingr_nicp_solve: the least-squares step as its normal equations (dense on the device, blocked MFMA Cholesky), kind 0 = N-ICP-T
+ * (:151-190, unknown n x 3 displacements), kind 1 = N-ICP-A (:241-283, one 4 x 3 affine map per vertex).  edges [2E]: the unique
+ * vertex pairs p1 < p2 of the template triangles (trianglesToEdges :67-76); w [n], cp_xyz [3n]: the correspondence; lm_ids [L]
+ * template vertices of the landmarks, lm_target_xyz [3L] their targets (UL); alpha stiffness, beta landmark weight, gamma the
+ * fourth diagonal entry of G (N-ICP-A).  out_xyz [3n]: the moved template; out_lm_xyz (nullable, [3L]): the moved landmark
+ * vertices (DL X of N-ICP-A).  Quirks of the reference kept: N-ICP-T's landmark rows put their ones into the FIRST L columns and
+ * are not scaled by beta (only their right-hand side is); N-ICP-A zeroes the weights of the landmark vertices. */
+int gingr_fitter_set_fit_points(gingr_fitter *f, const double *fit_xyz);
+int gingr_nicp_solve(gingr_ctx *ctx, int32_t kind, int64_t n, const double *moving_xyz, int64_t n_edges, const int32_t *edges,
+                     const double *w, const double *cp_xyz, int32_t n_lm, const int32_t *lm_ids, const double *lm_target_xyz, double alpha,
+                     double beta, double gamma, double *out_xyz, double *out_lm_xyz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -337,6 +337,19 @@ JFN(jint, rigidIcpSet)(JNIEnv *env, jclass, jlong h, jdoubleArray pts) {
     Arr<double> a(env, pts, true);
     return gingr_rigid_icp_set(P<gingr_rigid_icp>(h), a.ptr());
 }
+JFN(jint, fitterSetFitPoints)(JNIEnv *env, jclass, jlong f, jdoubleArray pts) {
+    Arr<double> a(env, pts, true);
+    return gingr_fitter_set_fit_points(P<gingr_fitter>(f), a.ptr());
+}
+JFN(jint, nicpSolve)(JNIEnv *env, jclass, jlong ctx, jint kind, jdoubleArray tpl, jintArray edges, jdoubleArray w, jdoubleArray cp,
+                     jintArray lmIds, jdoubleArray lmTargets, jdouble alpha, jdouble beta, jdouble gamma, jdoubleArray out, jdoubleArray outLm) {
+    const jlong n = env->GetArrayLength(tpl) / 3, ne = edges ? env->GetArrayLength(edges) / 2 : 0;
+    const jint nl = lmIds ? env->GetArrayLength(lmIds) : 0;
+    Arr<double> a(env, tpl, true); Arr<int32_t> e(env, edges, true); Arr<double> ww(env, w, true); Arr<double> c(env, cp, true);
+    Arr<int32_t> li(env, lmIds, true); Arr<double> lt(env, lmTargets, true); Arr<double> o(env, out, false); Arr<double> ol(env, outLm, false);
+    return gingr_nicp_solve(P<gingr_ctx>(ctx), kind, n, a.ptr(), ne, e.ptr(), ww.ptr(), c.ptr(), nl, li.ptr(), lt.ptr(), alpha, beta, gamma,
+                            o.ptr(), ol.ptr());
+}
 JFN(jint, pointsetDistanceExtrema)(JNIEnv *env, jclass, jlong ctx, jdoubleArray xyz, jdoubleArray out2) {
     const jlong n = env->GetArrayLength(xyz) / 3;
     Arr<double> a(env, xyz, true); Arr<double> b(env, out2, false);

@@ -102,6 +102,13 @@ public final class GingrHipNative {
     public static native int rigidIcpIterate(long handle, int nIterations, double[] distances);
     public static native int rigidIcpGet(long handle, double[] pointsXyz, double[] transform13);
     public static native int rigidIcpSet(long handle, double[] pointsXyz);
+
+    // ---- optimal-step non-rigid ICP (gingr/other/algorithms/icp/NonRigidOptimalStepICP.scala): the correspondence of an explicit
+    // template through the surface-ICP query (fitterSetFitPoints + fitterIcpSurfacePhase(…, 0) + fitterGetSurfaceCorrespondence),
+    // and the least-squares step; kind 0 = N-ICP-T, 1 = N-ICP-A; edges = unique (p1 < p2) vertex pairs; outLmXyz may be null
+    public static native int fitterSetFitPoints(long fitter, double[] fitXyz);
+    public static native int nicpSolve(long ctx, int kind, double[] templateXyz, int[] edges, double[] w, double[] cpXyz, int[] lmIds,
+                                       double[] lmTargetXyz, double alpha, double beta, double gamma, double[] outXyz, double[] outLmXyz);
     /** out2 = { maximumPointDistance, minimumPointDistance } (PointSetHelper) */
     public static native int pointsetDistanceExtrema(long ctx, double[] xyz, double[] out2);
     /** any array may be null; basisColMajor is 3 M_local x rank, unit columns */

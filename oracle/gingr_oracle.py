@@ -1402,3 +1402,93 @@ def rigid_icp_registration(template: np.ndarray, target: np.ndarray, max_iterati
         fit, last = ty, dist
         i += 1
     return fit, i, converged
+
+
+# --------------------------------------------------------------------------
+# optimal-step non-rigid ICP baselines   [REF G/other/algorithms/icp/NonRigidOptimalStepICP.scala]
+# --------------------------------------------------------------------------
+
+def nicp_edges(tris: np.ndarray) -> np.ndarray:
+    """trianglesToEdges (:67-76): the three sorted vertex pairs of every triangle, duplicates removed.  The reference keeps them in
+    the iteration order of a Scala Set; the row order of M does not change the least-squares solution, so they are sorted here."""
+    t = np.sort(np.asarray(tris, dtype=np.int64), axis=1)
+    e = np.concatenate([t[:, [0, 1]], t[:, [0, 2]], t[:, [1, 2]]])
+    return np.unique(e, axis=0)
+
+
+def nicp_matrix_m(edges: np.ndarray, n: int) -> np.ndarray:
+    """InitializeMatrixM (:78-87): +1 at the smaller id, -1 at the larger, one row per edge."""
+    m = np.zeros((edges.shape[0], n))
+    m[np.arange(edges.shape[0]), edges[:, 0]] = 1.0
+    m[np.arange(edges.shape[0]), edges[:, 1]] = -1.0
+    return m
+
+
+NICP_DEFAULT_ALPHA = [1e1] * 11   # (:63-65): the scanLeft / reverse chain ends in `.map(_ => 1e1)`: eleven times 10.0
+
+
+def nicp_landmarks(template: np.ndarray, target: np.ndarray, tmpl_lm: np.ndarray, tgt_lm: np.ndarray):
+    """(:45-55): landmark ids = closest TEMPLATE vertices; landmark targets = closest TARGET VERTICES (not the landmarks themselves)."""
+    ids = icp_closest_point(tmpl_lm, template)[0].astype(np.int64) if len(tmpl_lm) else np.zeros(0, dtype=np.int64)
+    ul = target[icp_closest_point(tgt_lm, target)[0]] if len(tgt_lm) else np.zeros((0, 3))
+    return ids, ul
+
+
+def nicp_iteration_t(template: np.ndarray, tmpl_tris: np.ndarray, target: np.ndarray, tgt_tris: np.ndarray, edges: np.ndarray,
+                     lm_ids: np.ndarray, ul: np.ndarray, alpha: float, beta: float):
+    """NonRigidOptimalStepICP_T.Iteration (:151-190).  A3 puts its ones at (i, i) -- the first L COLUMNS, not the landmark ids -- and
+    is not scaled by beta (only B3 is); both kept."""
+    n = template.shape[0]
+    cp, w, dist = surface_correspondence(template, tmpl_tris, target, tgt_tris)[:3]
+    M = nicp_matrix_m(edges, n)
+    L = lm_ids.shape[0]
+    A3 = np.zeros((L, n))
+    A3[np.arange(L), np.arange(L)] = 1.0
+    A = np.vstack([M * alpha, np.diag(w), A3])
+    B = np.vstack([np.zeros((edges.shape[0], 3)), w[:, None] * (cp - template), (ul - template[lm_ids]) * beta])
+    X = np.linalg.lstsq(A, B, rcond=None)[0]
+    return template + X, dist
+
+
+def nicp_iteration_a(template: np.ndarray, tmpl_tris: np.ndarray, target: np.ndarray, tgt_tris: np.ndarray, edges: np.ndarray,
+                     lm_ids: np.ndarray, ul: np.ndarray, alpha: float, beta: float, gamma: float = 1.0):
+    """NonRigidOptimalStepICP_A.Iteration (:241-283): one 4 x 3 affine map per vertex; returns (points, distance, moved landmarks)."""
+    n = template.shape[0]
+    cp, w, dist = surface_correspondence(template, tmpl_tris, target, tgt_tris)[:3]
+    w = w.copy()
+    w[lm_ids] = 0.0
+    q = np.concatenate([template, np.ones((n, 1))], axis=1)
+    D = np.zeros((n, 4 * n))
+    for i in range(n):
+        D[i, 4 * i:4 * i + 4] = q[i]
+    DL = np.zeros((lm_ids.shape[0], 4 * n))
+    for l, i in enumerate(lm_ids):
+        DL[l, 4 * i:4 * i + 4] = q[i]
+    G = np.diag([1.0, 1.0, 1.0, gamma])
+    A = np.vstack([np.kron(nicp_matrix_m(edges, n), G) * alpha, w[:, None] * D, DL * beta])
+    B = np.vstack([np.zeros((4 * edges.shape[0], 3)), w[:, None] * cp, ul * beta])
+    X = np.linalg.lstsq(A, B, rcond=None)[0]
+    return D @ X, dist, DL @ X
+
+
+def nicp_registration(template, tmpl_tris, target, tgt_tris, tmpl_lm, tgt_lm, kind: str, max_iteration: int, tolerance: float = 0.001,
+                      alpha: Optional[Sequence[float]] = None, beta: Optional[Sequence[float]] = None, gamma: float = 1.0):
+    """Registration (:89-121): for every (alpha, beta) pair up to max_iteration inner steps, stopping a stage once the mean
+    closest-point distance MEASURED BEFORE the step falls below the tolerance."""
+    alpha = NICP_DEFAULT_ALPHA if alpha is None else list(alpha)
+    beta = alpha if beta is None else list(beta)
+    assert len(alpha) == len(beta)
+    edges = nicp_edges(tmpl_tris)
+    lm_ids, ul = nicp_landmarks(template, target, np.asarray(tmpl_lm, dtype=np.float64).reshape(-1, 3),
+                                np.asarray(tgt_lm, dtype=np.float64).reshape(-1, 3))
+    fit = np.asarray(template, dtype=np.float64)
+    for a, b in zip(alpha, beta):
+        dist = float("inf")
+        i = 0
+        while i < max_iteration and dist >= tolerance:
+            if kind == "T":
+                fit, dist = nicp_iteration_t(fit, tmpl_tris, target, tgt_tris, edges, lm_ids, ul, a, b)
+            else:
+                fit, dist, _ = nicp_iteration_a(fit, tmpl_tris, target, tgt_tris, edges, lm_ids, ul, a, b, gamma)
+            i += 1
+    return fit

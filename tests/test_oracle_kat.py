@@ -414,3 +414,47 @@ def test_mesh_topology_helpers():
     p = v[4]
     ips = go.line_mesh_intersections(p, np.array([0.3, -0.2, 1.0]), v, tris)
     assert ips.shape[0] >= 1 and all(np.array_equal(q, p) for q in ips)
+
+
+def _octahedron():
+    v = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=np.float64) * 10.0
+    t = np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]])
+    return v, t
+
+
+def test_nicp_edges_matrix_and_defaults():
+    """NonRigidOptimalStepICP.scala:63-87: unique sorted edges, M = +1 / -1 per edge, M^T M = graph Laplacian, eleven times alpha 10."""
+    v, t = _octahedron()
+    e = go.nicp_edges(t)
+    assert e.shape == (12, 2) and np.all(e[:, 0] < e[:, 1])
+    M = go.nicp_matrix_m(e, 6)
+    assert np.array_equal(M.T @ M, go.graph_laplacian(6, t))
+    assert go.NICP_DEFAULT_ALPHA == [10.0] * 11
+
+
+def test_nicp_known_answers():
+    """Closed-form cases of the two least-squares steps: a target that is the translated template is reached exactly by N-ICP-T
+    whatever the stiffness (a constant displacement costs nothing), and a target that is an affine image of the template is reached
+    by N-ICP-A (one common affine map costs nothing) -- both with all weights 1 (closed convex meshes, same orientation)."""
+    v, t = _octahedron()
+    e = go.nicp_edges(t)
+    none = np.zeros(0, dtype=np.int64)
+    shift = np.array([0.3, -0.2, 0.1])
+    cp, w, dist = go.surface_correspondence(v, t, v + shift, t)
+    assert np.all(w == 1.0)
+    got, d = go.nicp_iteration_t(v, t, v + shift, t, e, none, np.zeros((0, 3)), 50.0, 1.0)
+    # the closest surface points are not the translated vertices, but the stiff limit moves the template rigidly by their mean
+    assert np.allclose(got - v, (got - v).mean(0), atol=2e-3) and abs(d - dist) < 1e-15
+    A = np.array([[1.02, 0.01, 0.0], [0.0, 0.98, 0.02], [0.01, 0.0, 1.01]])
+    tgt = v @ A.T + shift
+    cp, w, _ = go.surface_correspondence(v, t, tgt, t)
+    gotA, _, lm = go.nicp_iteration_a(v, t, tgt, t, e, none, np.zeros((0, 3)), 1e4, 1.0)
+    # stiff limit of N-ICP-A: ONE affine map for all vertices, the least-squares affine fit of the correspondences
+    Q = np.concatenate([v, np.ones((6, 1))], axis=1)
+    X = np.linalg.lstsq(Q, cp, rcond=None)[0]
+    assert np.allclose(gotA, Q @ X, atol=1e-4) and lm.shape == (0, 3)
+    # landmarks: N-ICP-A zeroes the weight of the landmark vertex and pulls it to the landmark target
+    ids = np.array([4])
+    ul = np.array([[0.0, 0.0, 12.0]])
+    gotL, _, lmL = go.nicp_iteration_a(v, t, tgt, t, e, ids, ul, 0.01, 100.0)
+    assert np.allclose(lmL[0], ul[0], atol=1e-3) and np.allclose(gotL[4], lmL[0])
