@@ -372,6 +372,39 @@ int main(int argc, char **argv) {
         put("G_icp_points", pts, 3 * M);
         CHECK(gingr_rigid_icp_set(icp, ref));
         gingr_rigid_icp_destroy(icp);
+        /* one optimal-step non-rigid ICP iteration (N-ICP-T, then N-ICP-A) of the model reference against the target surface:
+           correspondence of explicit points through the fitter, edges of the triangulation, the least-squares step */
+        {
+            int32_t *edges = xmalloc(4 * 2 * 3 * Tm);
+            int64_t ne = 0;
+            for (int64_t t = 0; t < Tm; ++t)
+                for (int k = 0; k < 3; ++k) {
+                    int32_t a = mtri[3 * t + k], b = mtri[3 * t + (k + 1) % 3];
+                    if (a > b) { int32_t tmp = a; a = b; b = tmp; }
+                    int dup = 0;
+                    for (int64_t e = 0; e < ne && !dup; ++e) dup = edges[2 * e] == a && edges[2 * e + 1] == b;
+                    if (!dup) { edges[2 * ne] = a; edges[2 * ne + 1] = b; ++ne; }
+                }
+            gingr_icp_params ip2 = {1.0, 1.0, 1};
+            double *cps = xmalloc(8 * 3 * M), *ws = xmalloc(8 * M), *moved_t = xmalloc(8 * 3 * M), *moved_a = xmalloc(8 * 3 * M);
+            const int32_t lmid[2] = {5, 17};
+            double lmt[6], lmo[6];
+            for (int l = 0; l < 2; ++l)
+                for (int d = 0; d < 3; ++d) lmt[3 * l + d] = target[3 * (int64_t)(11 + 7 * l) + d];
+            CHECK(gingr_fitter_set_surface_method(f, 0));
+            CHECK(gingr_fitter_set_correspondence_direction(f, 0));
+            CHECK(gingr_fitter_set_state(f, zero, &s0));
+            CHECK(gingr_fitter_set_fit_points(f, ref));
+            CHECK(gingr_fitter_icp_surface_phase_async(f, &ip2, 0));
+            CHECK(gingr_fitter_get_surface_correspondence(f, cps, ws));
+            CHECK(gingr_nicp_solve(ctx, 0, M, ref, ne, edges, ws, cps, 2, lmid, lmt, 10.0, 5.0, 1.0, moved_t, NULL));
+            CHECK(gingr_nicp_solve(ctx, 1, M, ref, ne, edges, ws, cps, 2, lmid, lmt, 10.0, 5.0, 0.5, moved_a, lmo));
+            put("G_nicp_w", ws, M);
+            put("G_nicp_t", moved_t, 3 * M);
+            put("G_nicp_a", moved_a, 3 * M);
+            put("G_nicp_lm", lmo, 6);
+            free(edges); free(cps); free(ws); free(moved_t); free(moved_a);
+        }
         free(sv); free(cpp); free(d2); free(bary); free(tid); free(ids); free(wts); free(nref); free(nb); free(ob); free(pts);
     }
 

@@ -61,8 +61,8 @@ def rel(a, b):
 def test_plain_c_consumer_of_the_fused_path(tmp_path):
     """tests/c/cabi_fitter_driver.c: model upload -> fitter -> fused updates -> state; the 3-phase / 2-segment protocol on two row
     shards with the exchange summed on the host in C; the in-library device group; stateless operators; the ICP flavours;
-    probabilistic proposal; classic CPD; the per-coordinate GPMM builder, closest surface points, model transfer and the classic
-    rigid ICP -- all from a C program, compared with the oracle."""
+    probabilistic proposal; classic CPD; the per-coordinate GPMM builder, closest surface points, model transfer, the classic
+    rigid ICP and the optimal-step non-rigid ICP -- all from a C program, compared with the oracle."""
     exe = str(tmp_path / "cabi_fitter_driver")
     libdir = os.path.join(ROOT, "gingr_amd")
     subprocess.check_call(["gcc", "-std=gnu99", "-O1", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
@@ -169,3 +169,12 @@ def test_plain_c_consumer_of_the_fused_path(tmp_path):
         fit_i, dd, _ = go.rigid_icp_iteration(fit_i, target)
         dists.append(dd)
     assert np.allclose(got["G_icp_dist"], dists, rtol=1e-11) and np.abs(got["G_icp_points"].reshape(M, 3) - fit_i).max() < 1e-9
+    # one N-ICP-T and one N-ICP-A iteration of the model reference (explicit points through gingr_fitter_set_fit_points)
+    edges = go.nicp_edges(cells)
+    lm_ids, ul = np.array([5, 17]), target[[11, 18]]
+    _, ow, _ = go.surface_correspondence(mo.ref, cells, target, tcells)
+    assert np.array_equal(got["G_nicp_w"], ow)
+    want_t, _ = go.nicp_iteration_t(mo.ref, cells, target, tcells, edges, lm_ids, ul, 10.0, 5.0)
+    want_a, _, want_lm = go.nicp_iteration_a(mo.ref, cells, target, tcells, edges, lm_ids, ul, 10.0, 5.0, 0.5)
+    assert np.abs(got["G_nicp_t"].reshape(M, 3) - want_t).max() < 1e-7
+    assert np.abs(got["G_nicp_a"].reshape(M, 3) - want_a).max() < 1e-7 and np.abs(got["G_nicp_lm"].reshape(2, 3) - want_lm).max() < 1e-7
