@@ -367,6 +367,14 @@ void dense_spd_solve3(gingr_ctx *ctx, double *Aw, int64_t Mp, double *Linv, doub
 //                        D row i = [p_i, 1] in the columns 4i .. 4i+3; W zeroed at the landmark vertices; G = diag(1, 1, 1, gamma)
 // One thread per entry of the lower triangle / the border rows; the matrix is dense on the device (n of a registration template:
 // thousands) and goes through the blocked MFMA Cholesky of the non-rigid CPD.
+struct ScratchPart {  // a slice of the context's grow-only scratch
+    void *p = nullptr;
+    template <typename T>
+    T *as() const {
+        return reinterpret_cast<T *>(p);
+    }
+};
+
 struct NicpArgs {
     int64_t n, dim, Mp, n_edges;
     int kind;  // 0 T, 1 A
@@ -663,15 +671,33 @@ int gingr_nicp_solve(gingr_ctx *ctx, int32_t kind, int64_t n, const double *movi
             for (int d = 0; d < 3; ++d) hs[(size_t)(d * n + id)] += lm_target_xyz[3 * l + d];
         }
     }
-    DevBuf dv, du, dw, ds, ddeg, dcnt, dedges, Aw, Linv, W, flag, dout;
-    if (dv.alloc(hv.size() * 8) != hipSuccess || du.alloc(hu.size() * 8) != hipSuccess || dw.alloc(hw.size() * 8) != hipSuccess ||
-        ds.alloc(hs.size() * 8) != hipSuccess || ddeg.alloc(hdeg.size() * 4) != hipSuccess || dcnt.alloc(hcnt.size() * 4) != hipSuccess ||
-        dedges.alloc((size_t)(n_edges > 0 ? n_edges : 1) * 8) != hipSuccess || Aw.alloc((size_t)(Mp + kNBc) * Mp * sizeof(double)) != hipSuccess ||
-        Linv.alloc((size_t)nb * kNBc * kNBc * sizeof(double)) != hipSuccess || W.alloc((size_t)3 * Mp * sizeof(double)) != hipSuccess ||
-        flag.alloc(sizeof(int32_t)) != hipSuccess || dout.alloc((size_t)3 * n * sizeof(double)) != hipSuccess) {
-        (void)hipGetLastError();
-        return gingr_set_error(ctx, GINGR_ERR_HIP, "nicp_solve: out of device memory (the system is dense: %lld x %lld doubles)", (long long)Mp,
-                               (long long)Mp);
+    // one grow-only scratch of the context, carved up (an N-ICP run calls this once per iteration with the same sizes)
+    ScratchPart dv, du, dw, ds, ddeg, dcnt, dedges, Aw, Linv, W, flag, dout;
+    {
+        const size_t sizes[12] = {hv.size() * 8, hu.size() * 8, hw.size() * 8, hs.size() * 8, hdeg.size() * 4, hcnt.size() * 4,
+                                  (size_t)(n_edges > 0 ? n_edges : 1) * 8, (size_t)(Mp + kNBc) * Mp * sizeof(double),
+                                  (size_t)nb * kNBc * kNBc * sizeof(double), (size_t)3 * Mp * sizeof(double), sizeof(int32_t),
+                                  (size_t)3 * n * sizeof(double)};
+        ScratchPart *parts[12] = {&dv, &du, &dw, &ds, &ddeg, &dcnt, &dedges, &Aw, &Linv, &W, &flag, &dout};
+        size_t total = 0;
+        for (int q = 0; q < 12; ++q) total += (sizes[q] + 255) & ~(size_t)255;
+        if (ctx->scratch_bytes < total) {
+            if (ctx->scratch) (void)hipFree(ctx->scratch);
+            ctx->scratch = nullptr;
+            ctx->scratch_bytes = 0;
+            if (hipMalloc(&ctx->scratch, total) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->scratch = nullptr;
+                return gingr_set_error(ctx, GINGR_ERR_HIP, "nicp_solve: out of device memory (the system is dense: %lld x %lld doubles)",
+                                       (long long)Mp, (long long)Mp);
+            }
+            ctx->scratch_bytes = total;
+        }
+        size_t off = 0;
+        for (int q = 0; q < 12; ++q) {
+            parts[q]->p = static_cast<char *>(ctx->scratch) + off;
+            off += (sizes[q] + 255) & ~(size_t)255;
+        }
     }
     HIP_TRY(ctx, hipMemcpyAsync(dv.p, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(du.p, hu.data(), hu.size() * 8, hipMemcpyHostToDevice, ctx->stream));
