@@ -99,6 +99,8 @@ struct gingr_fitter {
     int alt_stage = 0;
     bool allow_alt = false, corr_stale = false;
     double *fxbuf[2] = {nullptr, nullptr};
+    unsigned *lp_sync = nullptr;  // hand-over words of posterior_logpdf_split_kernel
+    unsigned lp_epoch = 0;
     bool fx_valid[2] = {false, false};
     int live = 0;
     void forget_posteriors() {
@@ -430,7 +432,7 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
         (rc = dev_alloc(ctx, &f->evec, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->newshape, (size_t)3 * M)) ||
         (rc = dev_alloc(ctx, &f->alpha, (size_t)rp)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
         (rc = dev_alloc(ctx, &f->small, (size_t)8)) || (rc = dev_alloc(ctx, &f->fxbuf[0], (size_t)rp * rp + 2 * rp)) || (rc = dev_alloc(ctx, &f->fxbuf[1], (size_t)rp * rp + 2 * rp)) ||
-        (rc = dev_alloc(ctx, &f->alt_seg, (size_t)rp * rp + rp + 8)) ||
+        (rc = dev_alloc(ctx, &f->alt_seg, (size_t)rp * rp + rp + 8)) || (rc = dev_alloc(ctx, &f->lp_sync, (size_t)2)) ||
         (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->zbuf, (size_t)19 * rp)) || (rc = dev_alloc(ctx, &f->zrand, (size_t)rp)) || (rc = dev_alloc(ctx, &f->st, 1)) ||
         (rc = dev_alloc(ctx, &f->pose, 1)) || (rc = dev_alloc(ctx, &f->hs_dev, 1)) ||
         (rc = dev_alloc(ctx, &f->scalars, 8)) || (rc = dev_alloc(ctx, &f->part, GINGR_SCALAR_PART)) || (rc = dev_alloc(ctx, &f->absmax, GINGR_AUX)) || (rc = dev_alloc(ctx, &f->work, (size_t)std::max<int64_t>((int64_t)rp * rp, posterior_work_doubles(rp)))) ||
@@ -484,6 +486,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->fxbuf[0]);
     dev_free(f->fxbuf[1]);
     dev_free(f->alt_seg);
+    dev_free(f->lp_sync);
     dev_free(f->retry);
     dev_free(f->part);
     dev_free(f->absmax);
@@ -1369,6 +1372,7 @@ static int posterior_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params
     for (int ph = 0; ph < 2 && prc == GINGR_OK; ++ph) prc = flavour_phase(f, flavour, cp, ip, ph);
     f->allow_alt = false;
     GINGR_TRY(prc);
+    if (f->lp_epoch == 0) HIP_TRY(ctx, hipMemsetAsync(f->lp_sync, 0, 2 * sizeof(unsigned), ctx->stream));  // before the first hand-over
     const bool cached = f->fx_valid[f->live];  // this state's factors are on the device: only the mesh-dependent part is left
     double *G = f->xch + f->off[1];
     double *rhs = G + (int64_t)rp * rp;
@@ -1384,7 +1388,7 @@ static int posterior_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params
     launch_sweep(ctx, SWEEP_PROJ2, a);
     // one kernel: posterior coefficients a = (I + G)^-1 rhs, then the ridge projection of the mesh and its log-density
     GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, rhs, m->mom + MomentLayout{rp}.stot(), f->alpha_c, f->fxbuf[f->live], cached, f->work,
-                                      out2));
+                                      out2, f->lp_sync, ++f->lp_epoch));
     GINGR_TRY(check_launch(ctx));
     double res[2] = {0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(res, out2, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));

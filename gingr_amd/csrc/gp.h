@@ -164,9 +164,11 @@ void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
                             double *work, double *a, DevState *st);
 // out2[0] = posterior.gp.logpdf(posterior.coefficients(mesh)), out2[1] != 0: the posterior failed; qte = Q0^T e (model-frame
 // residual).  fx ([rp*rp + 2*rp], nullable): receives the state-only part of the computation (cached == false) or provides it
-// (cached == true: only the mesh-dependent part runs).
+// (cached == true: only the mesh-dependent part runs).  sync (2 zero-initialised words on the device) + a launch number `epoch`
+// that never repeats: r <= 128 then runs the two factorisations on two workgroups.
 int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *Stot,
-                            const double *qte, double *fx, bool cached, double *work, double *out2);
+                            const double *qte, double *fx, bool cached, double *work, double *out2, unsigned *sync = nullptr,
+                            unsigned epoch = 0);
 // doubles of the `work` buffer launch_posterior_solve / launch_posterior_logpdf need (used when r > 128)
 int64_t posterior_work_doubles(int32_t rp);
 // Binv = (S/eps + I)^-1  (work: [rp*rp]); *err_flag != 0 on failure
