@@ -341,6 +341,10 @@ JFN(jint, fitterSetFitPoints)(JNIEnv *env, jclass, jlong f, jdoubleArray pts) {
     Arr<double> a(env, pts, true);
     return gingr_fitter_set_fit_points(P<gingr_fitter>(f), a.ptr());
 }
+JFN(jint, fitterIcpSurfacePhase)(JNIEnv *, jclass, jlong f, jdouble initialSigma, jdouble endSigma, jint maxIterations, jint phase) {
+    gingr_icp_params p{initialSigma, endSigma, maxIterations};
+    return gingr_fitter_icp_surface_phase_async(P<gingr_fitter>(f), &p, phase);
+}
 JFN(jint, nicpSolve)(JNIEnv *env, jclass, jlong ctx, jint kind, jdoubleArray tpl, jintArray edges, jdoubleArray w, jdoubleArray cp,
                      jintArray lmIds, jdoubleArray lmTargets, jdouble alpha, jdouble beta, jdouble gamma, jdoubleArray out, jdoubleArray outLm) {
     const jlong n = env->GetArrayLength(tpl) / 3, ne = edges ? env->GetArrayLength(edges) / 2 : 0;

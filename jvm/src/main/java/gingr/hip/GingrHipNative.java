@@ -107,6 +107,8 @@ public final class GingrHipNative {
     // template through the surface-ICP query (fitterSetFitPoints + fitterIcpSurfacePhase(…, 0) + fitterGetSurfaceCorrespondence),
     // and the least-squares step; kind 0 = N-ICP-T, 1 = N-ICP-A; edges = unique (p1 < p2) vertex pairs; outLmXyz may be null
     public static native int fitterSetFitPoints(long fitter, double[] fitXyz);
+    /** one phase of the surface-ICP update (gingr_fitter_icp_surface_phase_async); phase 0 = the correspondence query alone */
+    public static native int fitterIcpSurfacePhase(long fitter, double initialSigma, double endSigma, int maxIterations, int phase);
     public static native int nicpSolve(long ctx, int kind, double[] templateXyz, int[] edges, double[] w, double[] cpXyz, int[] lmIds,
                                        double[] lmTargetXyz, double alpha, double beta, double gamma, double[] outXyz, double[] outLmXyz);
     /** out2 = { maximumPointDistance, minimumPointDistance } (PointSetHelper) */

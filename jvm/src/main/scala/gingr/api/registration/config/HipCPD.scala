@@ -497,3 +497,113 @@ final class HipClassicCPD(templatePoints: Seq[scalismo.geometry.Point[_3D]], tar
   }
   override def close(): Unit = { GingrHipNative.classicCpdDestroy(h); GingrHipNative.ctxDestroy(ctx) }
 }
+
+// ------------------------------------------------------------------------------------------------ classic ICP baselines (other/)
+/** Drop-in for gingr.other.algorithms.icp.RigidICP (RigidICP.scala:24-84) behind ICPFactory.registerRigidly: closest points,
+  * the least-squares transform (kind 0 = PoseRegistrator.RigidRegistrator3D, 1 = AffineRegistrator3D) and the move of the template run
+  * on the GPU; the Registration loop with its test on the change of the mean distance (:30-55) stays here. */
+final class HipRigidICP(templatePoints: Seq[scalismo.geometry.Point[_3D]], targetPoints: Seq[scalismo.geometry.Point[_3D]], kind: Int = 0,
+                        device: Int = 0) extends AutoCloseable {
+  private def flat(ps: Seq[scalismo.geometry.Point[_3D]]): Array[Double] = ps.flatMap(p => Seq(p.x, p.y, p.z)).toArray
+  private val ctx = GingrHipNative.ctxCreate(device)
+  require(ctx != 0L, "gingr_ctx_create failed: no usable GPU")
+  private val h = GingrHipNative.rigidIcpCreate(ctx, kind, flat(templatePoints), flat(targetPoints))
+  require(h != 0L, s"gingr_rigid_icp_create failed: ${GingrHipNative.lastError(ctx)}")
+
+  def Registration(max_iteration: Int, tolerance: Double = 0.001): Seq[scalismo.geometry.Point[_3D]] = {
+    var i = 0; var converged = false; var last = 0.0
+    val d = new Array[Double](1)
+    while (i < max_iteration && !converged) {
+      require(GingrHipNative.rigidIcpIterate(h, 1, d) == 0, GingrHipNative.lastError(ctx))
+      println(s"ICP, iteration: ${i}, distance: ${d(0)}")
+      if (math.abs(d(0) - last) < tolerance) { println("Converged"); converged = true }
+      last = d(0); i += 1
+    }
+    val pts = new Array[Double](3 * templatePoints.length)
+    GingrHipNative.rigidIcpGet(h, pts, null)
+    pts.grouped(3).map(a => scalismo.geometry.Point(a(0), a(1), a(2))).toIndexedSeq
+  }
+  override def close(): Unit = { GingrHipNative.rigidIcpDestroy(h); GingrHipNative.ctxDestroy(ctx) }
+}
+
+/** Drop-in for gingr.other.algorithms.icp.NonRigidOptimalStepICP_T / _A (NonRigidOptimalStepICP.scala:31-284): per iteration the
+  * correspondence of the current template (ClosestPointTriangleMesh3D: the surface query of the GiNGR ICP path, asked for explicit
+  * points through gingr_fitter_set_fit_points) and the least-squares step (gingr_nicp_solve) run on the GPU; landmark bookkeeping,
+  * edges and the stage / inner loops (:89-121) stay here.  affine = false: N-ICP-T, true: N-ICP-A. */
+final class HipNonRigidOptimalStepICP(templateMesh: TriangleMesh[_3D], targetMesh: TriangleMesh[_3D],
+                                      templateLandmarks: Seq[scalismo.geometry.Landmark[_3D]], targetLandmarks: Seq[scalismo.geometry.Landmark[_3D]],
+                                      gamma: Double = 1.0, affine: Boolean = false, device: Int = 0) extends AutoCloseable {
+  require(gamma >= 0)
+  private val n = templateMesh.pointSet.numberOfPoints
+  private def tri(m: TriangleMesh[_3D]): Array[Int] = m.triangulation.triangles.flatMap(t => Seq(t.ptId1.id, t.ptId2.id, t.ptId3.id)).toArray
+  private val commonLmNames = templateLandmarks.map(_.id) intersect targetLandmarks.map(_.id)
+  val lmIdsOnTemplate: Array[Int] = commonLmNames.map(name => templateLandmarks.find(_.id == name).get)
+    .map(lm => templateMesh.pointSet.findClosestPoint(lm.point).id.id).toArray
+  private val UL: Array[Double] = commonLmNames.map(name => targetLandmarks.find(_.id == name).get)
+    .map(lm => targetMesh.pointSet.findClosestPoint(lm.point).point).flatMap(p => Seq(p.x, p.y, p.z)).toArray
+  // trianglesToEdges (:67-76): unique sorted vertex pairs, flat (p1, p2, p1, p2, ...)
+  private val edges: Array[Int] = templateMesh.triangulation.triangles.flatMap { t =>
+    val s = t.pointIds.map(_.id).sorted
+    Seq((s(0), s(1)), (s(0), s(2)), (s(1), s(2)))
+  }.toSet.toArray.flatMap(e => Seq(e._1, e._2))
+
+  private val ctx = GingrHipNative.ctxCreate(device)
+  require(ctx != 0L, "gingr_ctx_create failed: no usable GPU")
+  // carrier of the correspondence query: a rank-1 model over the template's points (its basis is never used)
+  private val model = GingrHipNative.modelUpload(ctx, n.toLong, 1, HipLayout.mesh(templateMesh), new Array[Double](3 * n), new Array[Double](3 * n),
+    Array(1.0), 0L, n.toLong)
+  require(model != 0L, s"gingr_model_upload failed: ${GingrHipNative.lastError(ctx)}")
+  private val fitter = GingrHipNative.fitterCreate(ctx, model)
+  private def check(rc: Int, what: String): Unit =
+    if (rc != 0) throw new RuntimeException(s"$what failed (gingr_status $rc): ${GingrHipNative.lastError(ctx)}")
+  check(GingrHipNative.fitterSetTarget(fitter, HipLayout.mesh(targetMesh)), "gingr_fitter_set_target")
+  check(GingrHipNative.fitterSetMeshes(fitter, tri(templateMesh), tri(targetMesh)), "gingr_fitter_set_meshes")
+  check(GingrHipNative.fitterSetOptions(fitter, 0, 1.0), "gingr_fitter_set_options")
+
+  private val defaultAlpha: Seq[Double] = Seq.fill(11)(1e1) // (:63-65): the scanLeft chain ends in `.map(_ => 1e1)`
+
+  /** (closest points, weights, mean distance) of the given template points (:118-128) */
+  def getClosestPoints(points: Array[Double]): (Array[Double], Array[Double], Double) = {
+    val pose = Array(0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 1.0)
+    check(GingrHipNative.fitterSetState(fitter, Array(0.0), pose, 0, 0), "gingr_fitter_set_state")
+    check(GingrHipNative.fitterSetFitPoints(fitter, points), "gingr_fitter_set_fit_points")
+    check(GingrHipNative.fitterIcpSurfacePhase(fitter, 1.0, 1.0, 1, 0), "gingr_fitter_icp_surface_phase_async")
+    val cp = new Array[Double](3 * n); val w = new Array[Double](n)
+    check(GingrHipNative.fitterGetSurfaceCorrespondence(fitter, cp, w), "gingr_fitter_get_surface_correspondence")
+    var dist = 0.0
+    var i = 0
+    while (i < n) {
+      val dx = cp(3 * i) - points(3 * i); val dy = cp(3 * i + 1) - points(3 * i + 1); val dz = cp(3 * i + 2) - points(3 * i + 2)
+      dist += math.sqrt(dx * dx + dy * dy + dz * dz); i += 1
+    }
+    (cp, w, dist / n)
+  }
+
+  /** one iteration: (moved points, mean distance before the move, moved landmark vertices) (:151-190 / :241-283) */
+  def Iteration(points: Array[Double], alpha: Double, beta: Double): (Array[Double], Double, Array[Double]) = {
+    require(alpha >= 0.0); require(beta >= 0.0)
+    val (cp, w, dist) = getClosestPoints(points)
+    val out = new Array[Double](3 * n); val lm = new Array[Double](3 * lmIdsOnTemplate.length)
+    check(GingrHipNative.nicpSolve(ctx, if (affine) 1 else 0, points, edges, w, cp, lmIdsOnTemplate, UL, alpha, beta, gamma, out,
+      if (lm.isEmpty) null else lm), "gingr_nicp_solve")
+    (out, dist, lm)
+  }
+
+  def Registration(max_iteration: Int, tolerance: Double = 0.001, alpha: Seq[Double] = defaultAlpha, beta: Seq[Double] = defaultAlpha)
+      : TriangleMesh[_3D] = {
+    require(alpha.length == beta.length)
+    var fit = HipLayout.mesh(templateMesh)
+    alpha.zip(beta).zipWithIndex.foreach { case ((a, b), j) =>
+      var dist = Double.PositiveInfinity
+      var i = 0
+      while (i < max_iteration && dist >= tolerance) {
+        val (ty, d, _) = Iteration(fit, a, b)
+        println(s"ICP, iteration: ${j * max_iteration + i}/${max_iteration * alpha.length}, alpha: ${a}, beta: ${b}, average distance to target: ${d}")
+        fit = ty; dist = d; i += 1
+      }
+    }
+    val pts = fit.grouped(3).map(a => scalismo.geometry.Point(a(0), a(1), a(2))).toIndexedSeq
+    templateMesh.copy(pointSet = scalismo.common.UnstructuredPoints(pts))
+  }
+  override def close(): Unit = { GingrHipNative.fitterDestroy(fitter); GingrHipNative.modelDestroy(model); GingrHipNative.ctxDestroy(ctx) }
+}
