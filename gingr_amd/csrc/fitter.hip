@@ -226,6 +226,8 @@ int model_finalize_impl(gingr_ctx *ctx, gingr_model *m) {
         for (int e = 0; e < 3; ++e)
             launch_small_gemm(ctx, m->r, m->rp, m->mom + ml.S(d, e), m->cmat, 1.0, m->cmat + (1 + d * 3 + e) * rr);
     GINGR_TRY(check_launch(ctx));
+    // S_tot = V diag(lam) V^T once per model: the uniform-weight posterior (I + S_tot / sigma2)^-1 rhs is two mat-vecs then
+    if (m->r <= 512) GINGR_TRY(launch_jacobi_eig(ctx, m->mom + ml.stot(), m->rp, m->r, m->eigL, m->eigV));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     m->finalized = true;
     return GINGR_OK;
@@ -278,7 +280,8 @@ int model_create_impl(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doubl
     };
     if ((rc = dev_alloc(ctx, &m->Q0, (size_t)3 * M * m->rp)) || (rc = dev_alloc(ctx, &m->ref, (size_t)3 * M)) ||
         (rc = dev_alloc(ctx, &m->mean, (size_t)3 * M)) || (rc = dev_alloc(ctx, &m->mom, (size_t)MomentLayout{m->rp}.total())) ||
-        (rc = dev_alloc(ctx, &m->Binv, (size_t)m->rp * m->rp)) ||
+        (rc = dev_alloc(ctx, &m->Binv, (size_t)m->rp * m->rp)) || (rc = dev_alloc(ctx, &m->eigV, (size_t)m->r * m->r)) ||
+        (rc = dev_alloc(ctx, &m->eigL, (size_t)m->r)) ||
         (rc = dev_alloc(ctx, &m->cmat, (size_t)10 * m->rp * m->rp)))
         return fail(rc);
     if (aos.alloc((size_t)3 * M * sizeof(double)) != hipSuccess)
@@ -392,6 +395,8 @@ void gingr_model_destroy(gingr_model *m) {
     dev_free(m->mean);
     dev_free(m->mom);
     dev_free(m->Binv);
+    dev_free(m->eigV);
+    dev_free(m->eigL);
     dev_free(m->cmat);
     dev_free(m->perm);
     delete m;
@@ -999,7 +1004,13 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
             break;
         }
         case 2: {
-            launch_posterior_solve(ctx, r, rp, G, rhs, f->zrand_active ? f->zrand : nullptr, f->work, f->acoef, f->st);
+            // the posterior mean of the uniform-weight case comes from the model's eigen-decomposition (no factorisation); a sampled
+            // proposal needs the Cholesky factor itself (its square root of the covariance is part of the parity contract)
+            static const int eig_env = getenv("GINGR_EIG_SOLVE") ? atoi(getenv("GINGR_EIG_SOLVE")) : 1;
+            if (eig_env && icp && !f->icp_surface && !f->reversed && f->n_lm == 0 && !f->zrand_active && r <= 512)
+                launch_posterior_solve_eig(ctx, r, rp, m->eigV, m->eigL, &f->st->sigma2, rhs, f->acoef, f->st);
+            else
+                launch_posterior_solve(ctx, r, rp, G, rhs, f->zrand_active ? f->zrand : nullptr, f->work, f->acoef, f->st);
             launch_post_matvecs(ctx, m, f->alpha, f->acoef, f->zbuf);
             PostSolveArgs a;
             memset(&a, 0, sizeof(a));

@@ -63,6 +63,8 @@ struct gingr_model {
     int32_t *perm = nullptr;
     std::vector<int32_t> hperm, hiperm;  // host copies: device position -> original, original -> device position
     double *Binv = nullptr;   // [rp*rp] (S_tot/eps + I)^-1, valid after finalize
+    double *eigV = nullptr;   // [r*r] eigenvectors of S_tot = Q^T Q (column k, row stride r) and
+    double *eigL = nullptr;   // [r] its eigenvalues (descending), valid after finalize: uniform-weight posterior (launch_posterior_solve_eig)
     double *cmat = nullptr;   // [10][rp*rp], valid after finalize: [0] C = Binv S_tot / eps (alpha_1 = C a),
                               // [1 + 3d + e] T[d][e] = S[d][e] C  (S[d][e] alpha_1 = T[d][e] a)
     double c0[3] = {0, 0, 0};  // centroid of the FULL reference: fixed centring point of the Umeyama sums
@@ -169,6 +171,13 @@ void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
 int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *Stot,
                             const double *qte, double *fx, bool cached, double *work, double *out2, unsigned *sync = nullptr,
                             unsigned epoch = 0);
+// a = (I + S_tot / sigma2)^-1 rhs through the one-off eigen-decomposition S_tot = V diag(lam) V^T: a = V ((V^T rhs) / (1 + lam / sigma2)).
+// The posterior of point-cloud ICP without landmarks -- every row weighs 1 / sigma2 (ICP.scala:90-92) -- needs no factorisation.
+void launch_posterior_solve_eig(gingr_ctx *ctx, int32_t r, int32_t rp, const double *eigV, const double *eigL, const double *sigma2,
+                                const double *rhs, double *a, DevState *st);
+// eigen-decomposition of the leading n x n block of the symmetric G (row stride ldg): evals [n] descending, Vs [n*n] (Vs[i*n + k] =
+// component i of eigenvector k); one workgroup, cyclic Jacobi (gpmm.hip)
+int launch_jacobi_eig(gingr_ctx *ctx, const double *G, int32_t ldg, int32_t n, double *evals, double *Vs);
 // doubles of the `work` buffer launch_posterior_solve / launch_posterior_logpdf need (used when r > 128)
 int64_t posterior_work_doubles(int32_t rp);
 // Binv = (S/eps + I)^-1  (work: [rp*rp]); *err_flag != 0 on failure

@@ -1942,6 +1942,45 @@ void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
     hipLaunchKernelGGL(posterior_solve_lds_kernel<true>, dim3(1), dim3(kSolveThreads), 0, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a, st, work);
 }
 
+namespace {
+// a = V ((V^T rhs) / (1 + lam / sigma2)): two r x r mat-vecs (V from L2), one workgroup; 16 lanes per output entry
+__global__ __launch_bounds__(1024) void posterior_solve_eig_kernel(int r, int rp, const double *__restrict__ V,
+                                                                   const double *__restrict__ lam, const double *__restrict__ sigma2,
+                                                                   const double *__restrict__ rhs, double *__restrict__ a, DevState *st) {
+    __shared__ double x[512], t[512];
+    __shared__ int bad;
+    const int tid = threadIdx.x, lane16 = tid & 15, grp = tid >> 4;
+    if (tid == 0) bad = 0;
+    for (int k = tid; k < r; k += 1024) x[k] = rhs[k];
+    __syncthreads();
+    const double inv_s2 = 1.0 / sigma2[0];
+    for (int k = grp; k < r; k += 64) {  // t_k = (V[:, k] . rhs) / (1 + lam_k / sigma2)
+        double s = 0.0;
+        for (int i = lane16; i < r; i += 16) s = __builtin_fma(V[(int64_t)i * r + k], x[i], s);
+        s = group16_sum(s);
+        if (lane16 == 0) t[k] = s / (1.0 + lam[k] * inv_s2);
+    }
+    __syncthreads();
+    for (int i = grp; i < rp; i += 64) {  // a_i = V[i, :] . t
+        double s = 0.0;
+        if (i < r)
+            for (int k = lane16; k < r; k += 16) s = __builtin_fma(V[(int64_t)i * r + k], t[k], s);
+        s = group16_sum(s);
+        if (lane16 == 0) {
+            a[i] = i < r ? s : 0.0;
+            if (!finite_d(s)) bad = 1;
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && bad) st->err = GINGR_ERR_NONFINITE;
+}
+}  // namespace
+
+void launch_posterior_solve_eig(gingr_ctx *ctx, int32_t r, int32_t rp, const double *eigV, const double *eigL, const double *sigma2,
+                                const double *rhs, double *a, DevState *st) {
+    hipLaunchKernelGGL(posterior_solve_eig_kernel, dim3(1), dim3(1024), 0, ctx->stream, (int)r, (int)rp, eigV, eigL, sigma2, rhs, a, st);
+}
+
 int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *Stot,
                             const double *qte, double *fx, bool cached, double *work, double *out2, unsigned *sync, unsigned epoch) {
     const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);

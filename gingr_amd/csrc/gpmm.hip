@@ -497,6 +497,21 @@ int check(gingr_ctx *ctx) {
 
 }  // namespace
 
+int launch_jacobi_eig(gingr_ctx *ctx, const double *G, int32_t ldg, int32_t n, double *evals, double *Vs) {
+    if (n < 1 || n > kJacMaxN) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "jacobi_eig: n = %d outside 1..%d", (int)n, kJacMaxN);
+    DevBuf wA, wV, sw;
+    HIP_TRY(ctx, wA.alloc((size_t)n * n * sizeof(double)));
+    HIP_TRY(ctx, wV.alloc((size_t)n * n * sizeof(double)));
+    HIP_TRY(ctx, sw.alloc(sizeof(int32_t)));
+    hipLaunchKernelGGL(jacobi_eig_kernel, dim3(1), dim3(kJacThreads), 0, ctx->stream, G, ldg, n, wA.as<double>(), wV.as<double>(), evals, Vs,
+                       sw.as<int32_t>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the work buffers go out of scope
+    return GINGR_OK;
+}
+
+
+
 extern "C" {
 
 int gingr_pointset_distance_extrema(gingr_ctx *ctx, const double *xyz, int64_t n, double *max_distance,
