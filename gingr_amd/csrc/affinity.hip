@@ -969,7 +969,7 @@ constexpr int kNNBlock = 256;    // threads per workgroup
 __global__ __launch_bounds__(kNNBlock) void nn_kernel(Cloud q, Cloud tgt, const int32_t *__restrict__ orig,
                                                       const double *__restrict__ tgt_boxes, int64_t cols_per_chunk,
                                                       double *__restrict__ pd2, int32_t *__restrict__ pidx,
-                                                      int32_t *__restrict__ porig) {
+                                                      int32_t *__restrict__ porig, const int32_t *__restrict__ warm) {
     __shared__ P4 tile[kTile];
     __shared__ double sbest[4][kNNThreads], sorig[4][kNNThreads];
     __shared__ int32_t sidx[4][kNNThreads];
@@ -980,6 +980,20 @@ __global__ __launch_bounds__(kNNBlock) void nn_kernel(Cloud q, Cloud tgt, const 
     double best = __builtin_huge_val(), bo = __builtin_huge_val();  // best distance and the ORIGINAL index that holds it
     double bound = __builtin_huge_val();                            // best of all four waves after the first sweep
     int32_t bi = -1;
+    // Warm start (nullable): the position of the target this query matched LAST time (an ICP iteration moves the queries a little).
+    // Its distance, computed with the arithmetic of the scan, is a valid candidate and prunes from the first tile on; the result is
+    // the same exact minimum with the same tie rule (a tile holding an equally close target has a gap <= the bound and is visited).
+    if (warm && ok) {
+        const int32_t p = warm[i];
+        if (p >= 0 && p < tgt.n) {
+            const double d2 = norm2_exact(tgt.x[p] - qx, tgt.y[p] - qy, tgt.z[p] - qz);
+            if (d2 == d2) {  // a NaN query keeps the cold-start behaviour
+                best = d2;
+                bo = (double)(orig ? orig[p] : p);
+                bi = p;
+            }
+        }
+    }
     const int64_t j0 = (int64_t)blockIdx.y * cols_per_chunk;
     const int64_t j1 = min(tgt.n, j0 + cols_per_chunk);
     const int t0 = (int)(j0 / kTile), nt = (int)((j1 - j0 + kTile - 1) / kTile);
@@ -1478,7 +1492,9 @@ static void plan_nn(int64_t nq, int64_t nt_points, bool pruned, int *nchunks, in
 }
 
 void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, const double *tgt_boxes, void *ws,
-               int32_t *idx, double *d2) {
+               int32_t *idx, double *d2, const int32_t *warm) {
+    static const int warm_env = getenv("GINGR_NN_WARM") ? atoi(getenv("GINGR_NN_WARM")) : 1;
+    if (!warm_env) warm = nullptr;
     int nch;
     int64_t len;
     const bool pruned = ctx->cull && tgt_boxes != nullptr;
@@ -1488,7 +1504,7 @@ void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_
     int32_t *porig = pidx + (int64_t)nch * query.n;
     dim3 grid((unsigned)ceil_div(query.n, kNNThreads), (unsigned)nch);
     hipLaunchKernelGGL(nn_kernel, grid, dim3(kNNBlock), 0, ctx->stream, query, target, target_orig,
-                       pruned ? tgt_boxes : (const double *)nullptr, len, pd2, pidx, porig);
+                       pruned ? tgt_boxes : (const double *)nullptr, len, pd2, pidx, porig, warm);
     hipLaunchKernelGGL(nn_reduce_kernel, dim3((unsigned)ceil_div(query.n, 256)), dim3(256), 0, ctx->stream, pd2, pidx, porig,
                        nch, query.n, idx, d2);
 }

@@ -158,7 +158,7 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
 // index, taken from target_orig[position] (nullptr: the device order is the original order).
 // tgt_boxes (nullable): bounding boxes of the 256-point target tiles (launch_tile_bbox) for exact nearest-first pruning.
 void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, const double *tgt_boxes, void *ws,
-               int32_t *idx, double *d2);
+               int32_t *idx, double *d2, const int32_t *warm = nullptr);
 void launch_gauss_block(gingr_ctx *ctx, Cloud A, Cloud B, double sigma, double scaling, double *out);
 void launch_sumsq_pairs(gingr_ctx *ctx, Cloud A, Cloud B, double *ws, double *out_scalar);
 // ---------------------------------------------------------------------------- surface.hip (ICP surface correspondence)

@@ -103,6 +103,7 @@ struct gingr_fitter {
     unsigned lp_epoch = 0;
     bool fx_valid[2] = {false, false};
     int live = 0;
+    bool nn_warm = false, surf_nn_warm = false;  // nn_idx / surf_nn hold last time's matches against the CURRENT target
     void forget_posteriors() {
         post_stage = 0;
         alt_stage = 0;
@@ -513,6 +514,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
 
 int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    f->nn_warm = f->surf_nn_warm = false;  // positions in another target (any in-range position would still be a valid start)
     f->forget_posteriors();  // the posterior memos describe other inputs
     gingr_ctx *ctx = f->ctx;
     if (N < 1 || N > INT32_MAX || !target_xyz) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_target: bad N");
@@ -923,14 +925,17 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                     launch_line_nearest(ctx, fit, f->mvn, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, f->surf_cp, f->surf_hit);
                 else
                     launch_surface_closest_point(ctx, fit, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, f->surf_cp, f->surf_d2);
-                launch_nn(ctx, cloud_of(f->surf_cp, M), tgt, f->tperm, f->tboxes, f->ws, f->surf_nn, f->surf_nnd2);
+                launch_nn(ctx, cloud_of(f->surf_cp, M), tgt, f->tperm, f->tboxes, f->ws, f->surf_nn, f->surf_nnd2,
+                          f->surf_nn_warm ? f->surf_nn : nullptr);
+                f->surf_nn_warm = true;
                 launch_surface_prereject(ctx, M, f->surf_nn, f->tboundary, f->mvn, f->tvn, f->N, along ? f->surf_hit : nullptr,
                                          f->surf_pre);
                 launch_self_intersect(ctx, fit, f->surf_cp, f->mtri, f->Tm, f->mtboxes, f->surf_pre, f->surf_hit);
                 launch_surface_weight(ctx, M, f->surf_pre, f->surf_hit, &f->st->sigma2, f->surf_w01, f->surf_win);
-            } else if (icp)
-                launch_nn(ctx, fit, tgt, f->tperm, f->tboxes, f->ws, f->nn_idx, f->nn_d2);
-            else {
+            } else if (icp) {
+                launch_nn(ctx, fit, tgt, f->tperm, f->tboxes, f->ws, f->nn_idx, f->nn_d2, f->nn_warm ? f->nn_idx : nullptr);
+                f->nn_warm = true;
+            } else {
                 // boxes of the fit tiles + its |coordinate - centroid| maximum (slot cleared by the pass that wrote the fit)
                 launch_tile_bbox(ctx, fit, f->fboxes, f->absmax + 2, f->absmax + 1);
                 // single shard: nothing is exchanged, so the chunk partials stay in ws and phase 1's den_finalize adds them up

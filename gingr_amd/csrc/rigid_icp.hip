@@ -17,6 +17,7 @@ struct gingr_rigid_icp {
     DevBuf stage, tpl, tgt, torig, tboxes, ws, idx, d2, part, tr;
     double c0[3] = {0, 0, 0};  // fixed centring point of the sums (centroid of the initial template)
     double last_distance = 0.0;
+    bool warm = false;  // idx holds the previous iteration's matches
 };
 
 namespace {
@@ -188,7 +189,9 @@ int gingr_rigid_icp_iterate(gingr_rigid_icp *h, int32_t n_iterations, double *di
     const double *t = h->tgt.as<double>();
     const Cloud cp{p, p + M, p + 2 * M, M}, ct{t, t + N, t + 2 * N, N};
     for (int32_t k = 0; k < n_iterations; ++k) {
-        launch_nn(ctx, cp, ct, h->torig.as<int32_t>(), h->tboxes.as<double>(), h->ws.p, h->idx.as<int32_t>(), h->d2.as<double>());
+        launch_nn(ctx, cp, ct, h->torig.as<int32_t>(), h->tboxes.as<double>(), h->ws.p, h->idx.as<int32_t>(), h->d2.as<double>(),
+                  h->warm ? h->idx.as<int32_t>() : nullptr);
+        h->warm = true;  // the next iteration starts every query from this one's match
         hipLaunchKernelGGL(icp_sums_kernel, dim3(kIcpBlocks), dim3(256), 0, ctx->stream, cp, ct, h->idx.as<int32_t>(), h->d2.as<double>(),
                            h->c0[0], h->c0[1], h->c0[2], h->part.as<double>());
         hipLaunchKernelGGL(icp_transform_kernel, dim3(1), dim3(64), 0, ctx->stream, h->part.as<double>(), (double)M, h->c0[0], h->c0[1],
