@@ -169,7 +169,8 @@ void launch_vertex_normals(gingr_ctx *ctx, const int32_t *adj_ptr, const int32_t
 void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *boxes);
 // closest point of the triangle soup to every query (SoA out); exact ties: lowest tri_orig
 void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T,
-                                  const double *boxes, double *cp_soa, double *d2, int32_t *tri_out = nullptr);
+                                  const double *boxes, double *cp_soa, double *d2, int32_t *tri_out = nullptr, int32_t *warm = nullptr,
+                                  bool warm_valid = false);
 // bary[3 i + k] = weight of corner k of triangle tri_id[i] at the closest point of that triangle to query i; tri_by_orig [3 T]:
 // corner positions in the cloud v, indexed by ORIGINAL triangle number
 void launch_barycentric(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri_by_orig, const int32_t *tri_id, double *bary);

@@ -103,6 +103,8 @@ struct gingr_fitter {
     unsigned lp_epoch = 0;
     bool fx_valid[2] = {false, false};
     int live = 0;
+    int32_t *surf_tri_pos = nullptr;  // per model vertex: position (in ttri) of its closest target triangle of the last scan
+    bool surf_tri_warm = false;
     bool nn_warm = false, surf_nn_warm = false;  // nn_idx / surf_nn hold last time's matches against the CURRENT target
     void forget_posteriors() {
         post_stage = 0;
@@ -200,12 +202,13 @@ void free_meshes(gingr_fitter *f) {
     f->reversed = false;
     void *ptrs[] = {f->mtri, f->ttri, f->ttri_orig, f->madj_ptr, f->madj_tri, f->tadj_ptr, f->tadj_tri, f->mcn, f->tcn, f->mvn,
                     f->tvn, f->mtboxes, f->ttboxes, f->tboundary, f->surf_cp, f->surf_d2, f->surf_w01, f->surf_win, f->surf_nnd2,
-                    f->surf_nn, f->surf_pre, f->surf_hit};
+                    f->surf_nn, f->surf_pre, f->surf_hit, f->surf_tri_pos};
     for (void *p : ptrs) dev_free(p);
     f->mtri = f->ttri = f->ttri_orig = f->madj_ptr = f->madj_tri = f->tadj_ptr = f->tadj_tri = f->tboundary = nullptr;
     f->mcn = f->tcn = f->mvn = f->tvn = f->mtboxes = f->ttboxes = nullptr;
     f->surf_cp = f->surf_d2 = f->surf_w01 = f->surf_win = f->surf_nnd2 = nullptr;
-    f->surf_nn = f->surf_pre = f->surf_hit = nullptr;
+    f->surf_nn = f->surf_pre = f->surf_hit = f->surf_tri_pos = nullptr;
+    f->surf_tri_warm = f->surf_nn_warm = false;
     f->Tm = f->Tt = 0;
 }
 
@@ -514,7 +517,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
 
 int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
-    f->nn_warm = f->surf_nn_warm = false;  // positions in another target (any in-range position would still be a valid start)
+    f->nn_warm = f->surf_nn_warm = f->surf_tri_warm = false;  // positions in another target (any in-range position would still be a valid start)
     f->forget_posteriors();  // the posterior memos describe other inputs
     gingr_ctx *ctx = f->ctx;
     if (N < 1 || N > INT32_MAX || !target_xyz) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_target: bad N");
@@ -924,7 +927,11 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 if (along)
                     launch_line_nearest(ctx, fit, f->mvn, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, f->surf_cp, f->surf_hit);
                 else
-                    launch_surface_closest_point(ctx, fit, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, f->surf_cp, f->surf_d2);
+                {
+                    launch_surface_closest_point(ctx, fit, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, f->surf_cp, f->surf_d2, nullptr,
+                                                 f->surf_tri_pos, f->surf_tri_warm);
+                    f->surf_tri_warm = true;
+                }
                 launch_nn(ctx, cloud_of(f->surf_cp, M), tgt, f->tperm, f->tboxes, f->ws, f->surf_nn, f->surf_nnd2,
                           f->surf_nn_warm ? f->surf_nn : nullptr);
                 f->surf_nn_warm = true;
@@ -1216,6 +1223,7 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
         (rc = dev_alloc(ctx, &f->surf_w01, (size_t)M)) || (rc = dev_alloc(ctx, &f->surf_win, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->surf_nnd2, (size_t)M)) || (rc = dev_alloc(ctx, &f->surf_nn, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->surf_pre, (size_t)M)) || (rc = dev_alloc(ctx, &f->surf_hit, (size_t)M)) ||
+        (rc = dev_alloc(ctx, &f->surf_tri_pos, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->mtri_orig, (size_t)f->Tm)) || (rc = dev_alloc(ctx, &f->mboundary, (size_t)M)))
         return rc;
     auto up = [&](int32_t *dst, const std::vector<int32_t> &src) {

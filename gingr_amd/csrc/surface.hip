@@ -344,12 +344,14 @@ template <int H>
 __global__ __launch_bounds__(kCpThreads) void surface_cp_queue_kernel(Cloud q, Cloud v, const int32_t *__restrict__ tri,
                                                                      const int32_t *__restrict__ tri_orig, int64_t T,
                                                                      const double *__restrict__ boxes, double *__restrict__ cp,
-                                                                     double *__restrict__ d2out, int32_t *__restrict__ tri_out) {
+                                                                     double *__restrict__ d2out, int32_t *__restrict__ tri_out,
+                                                                     const int32_t *warm_in, int32_t *pos_out /* may alias warm_in */) {
     __shared__ double tbox[kTriTile][6];  // staged tile: the triangles' bounding boxes only (the exact test reads memory)
     constexpr int QPB = 64 / H;  // queries per workgroup
     __shared__ unsigned long long qbest[4][QPB];  // per wave and query: bits of the best squared distance so far
     __shared__ unsigned int qorig[4][QPB];        // ... its original triangle (lowest on ties)
     __shared__ double qpt[4][3][QPB];             // ... its point
+    __shared__ int qpos[4][QPB];                  // ... its position in `tri` (the next call's warm start)
     __shared__ double sq[3][QPB];                 // the queries
     __shared__ unsigned int wqueue[4][128];  // (query slot << 26) | position of the triangle in `tri`
     __shared__ double sbound[4][QPB];
@@ -359,14 +361,39 @@ __global__ __launch_bounds__(kCpThreads) void surface_cp_queue_kernel(Cloud q, C
     const bool ok = i < q.n;
     const double qx = ok ? q.x[i] : 0.0, qy = ok ? q.y[i] : 0.0, qz = ok ? q.z[i] : 0.0;
     const unsigned long long kInfBits = 0x7FF0000000000000ull;
+    // Warm start (nullable): the triangle (position in `tri`) that was closest to this query LAST time -- a template vertex moves
+    // little between two ICP iterations.  Its exact distance is a valid candidate: the bound is tight before the first tile instead
+    // of after the first 64 evaluated pairs of every wave.  Same minimum, same tie rule (an equally close triangle lies in a tile
+    // whose gap does not exceed the bound, so it is still evaluated and wins on the lower original id).
+    unsigned long long wbits = kInfBits;
+    unsigned worig = 0xFFFFFFFFu;
+    int wpos = -1;
+    V3 wpt{qx, qy, qz};
+    if (warm_in && ok) {
+        const int32_t tg = warm_in[i];
+        if (tg >= 0 && tg < T) {
+            const int32_t va = tri[3 * (int64_t)tg], vb = tri[3 * (int64_t)tg + 1], vc = tri[3 * (int64_t)tg + 2];
+            const V3 pq{qx, qy, qz};
+            const V3 c = closest_on_triangle(pq, V3{v.x[va], v.y[va], v.z[va]}, V3{v.x[vb], v.y[vb], v.z[vb]}, V3{v.x[vc], v.y[vc], v.z[vc]});
+            const V3 dd = sub(c, pq);
+            const double dist = (dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z;
+            if (dist == dist) {  // NaN: cold start
+                wbits = __builtin_bit_cast(unsigned long long, dist);
+                worig = (unsigned)(tri_orig ? tri_orig[tg] : tg);
+                wpos = tg;
+                wpt = c;
+            }
+        }
+    }
     if (half == 0) {
-        qbest[wave][ql] = kInfBits;
-        qorig[wave][ql] = 0xFFFFFFFFu;
-        qpt[wave][0][ql] = qx, qpt[wave][1][ql] = qy, qpt[wave][2][ql] = qz;
+        qbest[wave][ql] = wbits;
+        qorig[wave][ql] = worig;
+        qpos[wave][ql] = wpos;
+        qpt[wave][0][ql] = wpt.x, qpt[wave][1][ql] = wpt.y, qpt[wave][2][ql] = wpt.z;
         if (wave == 0) sq[0][ql] = qx, sq[1][ql] = qy, sq[2][ql] = qz;
     }
     __syncthreads();
-    double best = __builtin_huge_val(), bound = __builtin_huge_val();
+    double best = __builtin_bit_cast(double, wbits), bound = __builtin_huge_val();
     int tail = 0;  // queued pairs (wave-uniform)
     double wb[6];
     wave_box(ok, qx, qy, qz, wb);
@@ -399,7 +426,10 @@ __global__ __launch_bounds__(kCpThreads) void surface_cp_queue_kernel(Cloud q, C
         __builtin_amdgcn_wave_barrier();
         if (top) atomicMin(&qorig[wave][tq], (unsigned)tr.orig);
         __builtin_amdgcn_wave_barrier();
-        if (top && qorig[wave][tq] == (unsigned)tr.orig) qpt[wave][0][tq] = c.x, qpt[wave][1][tq] = c.y, qpt[wave][2][tq] = c.z;
+        if (top && qorig[wave][tq] == (unsigned)tr.orig) {
+            qpt[wave][0][tq] = c.x, qpt[wave][1][tq] = c.y, qpt[wave][2][tq] = c.z;
+            qpos[wave][tq] = (int)tg;
+        }
         __builtin_amdgcn_wave_barrier();
         best = __builtin_bit_cast(double, qbest[wave][ql]);  // every copy of the query prunes against the shared best
         // entries beyond `count` move to the front
@@ -481,6 +511,7 @@ __global__ __launch_bounds__(kCpThreads) void surface_cp_queue_kernel(Cloud q, C
         cp[2 * q.n + i] = qpt[w][2][ql];
         d2out[i] = __builtin_bit_cast(double, qbest[w][ql]);
         if (tri_out) tri_out[i] = (int32_t)qorig[w][ql];
+        if (pos_out) pos_out[i] = qpos[w][ql];
     }
 }
 
@@ -1005,7 +1036,7 @@ void launch_barycentric(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri_by_
     hipLaunchKernelGGL(barycentric_kernel, dim3((unsigned)ceil_div(q.n, 256)), dim3(256), 0, ctx->stream, q, v, tri_by_orig, tri_id, bary);
 }
 void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T,
-                                  const double *boxes, double *cp_soa, double *d2, int32_t *tri_out) {
+                                  const double *boxes, double *cp_soa, double *d2, int32_t *tri_out, int32_t *warm, bool warm_valid) {
     // queries per workgroup = 64 / H (developer knob GINGR_SURFACE_H = 1 | 2 | 4 | 8 | 16).  The kernel is bound by its longest
     // workgroups: fewer queries per workgroup = more, shorter workgroups and a tighter query box for the tile pruning.
     const int h = surface_h(q.n);
@@ -1015,16 +1046,23 @@ void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_
     };
     static const int queued = getenv("GINGR_SURFACE_QUEUE") ? atoi(getenv("GINGR_SURFACE_QUEUE")) : 1;
     if (queued) {
+        // warm: one int32 per query, read as last call's winning triangles when warm_valid, rewritten with this call's
+        static const int warm_env = getenv("GINGR_SURFACE_WARM") ? atoi(getenv("GINGR_SURFACE_WARM")) : 1;
+        const int32_t *win = (warm && warm_valid && warm_env) ? warm : (const int32_t *)nullptr;
+        auto goq = [&](auto kern, int qpb) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(q.n, qpb)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig, T, boxes,
+                               cp_soa, d2, tri_out, win, warm);
+        };
         if (h == 1)
-            go(surface_cp_queue_kernel<1>, 64);
+            goq(surface_cp_queue_kernel<1>, 64);
         else if (h == 2)
-            go(surface_cp_queue_kernel<2>, 32);
+            goq(surface_cp_queue_kernel<2>, 32);
         else if (h == 8)
-            go(surface_cp_queue_kernel<8>, 8);
+            goq(surface_cp_queue_kernel<8>, 8);
         else if (h == 16)
-            go(surface_cp_queue_kernel<16>, 4);
+            goq(surface_cp_queue_kernel<16>, 4);
         else
-            go(surface_cp_queue_kernel<4>, 16);
+            goq(surface_cp_queue_kernel<4>, 16);
         return;
     }
     if (h == 1)
