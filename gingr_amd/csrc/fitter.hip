@@ -1592,6 +1592,11 @@ namespace {
 // `nn_orig` / `nn_boxes` / `boundary` (all three or none): the boundary-aware variant.  `scratch` holds what the kernels write.
 struct StatScratch {
     DevBuf cp, d2, nn, nnd2, ws, part, out;
+    // warm start of the closest-point scan: last call's winning triangle per query, valid for the same number of queries against the
+    // same triangle array (successive likelihood evaluations of a chain look at nearby shapes)
+    DevBuf pos;
+    int64_t pos_K = -1, pos_T = -1;
+    const int32_t *pos_tri = nullptr;
 };
 
 }  // namespace
@@ -1609,7 +1614,11 @@ int run_distance_stats(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, con
     HIP_TRY(ctx, ensure(sc.d2, (size_t)K * sizeof(double)));
     HIP_TRY(ctx, ensure(sc.part, (size_t)distance_stats_ws_doubles() * sizeof(double)));
     HIP_TRY(ctx, ensure(sc.out, 4 * sizeof(double)));
-    launch_surface_closest_point(ctx, q, v, tri, tri_orig, T, tboxes, sc.cp.as<double>(), sc.d2.as<double>());
+    HIP_TRY(ctx, ensure(sc.pos, (size_t)K * sizeof(int32_t)));
+    const bool warm = sc.pos_K == K && sc.pos_T == T && sc.pos_tri == tri;
+    launch_surface_closest_point(ctx, q, v, tri, tri_orig, T, tboxes, sc.cp.as<double>(), sc.d2.as<double>(), nullptr, sc.pos.as<int32_t>(),
+                                 warm);
+    sc.pos_K = K, sc.pos_T = T, sc.pos_tri = tri;
     if (boundary) {
         HIP_TRY(ctx, ensure(sc.nn, (size_t)K * sizeof(int32_t)));
         HIP_TRY(ctx, ensure(sc.nnd2, (size_t)K * sizeof(double)));
