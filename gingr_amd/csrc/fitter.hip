@@ -993,6 +993,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 fa.contribute_xpx = m->row_begin == 0 ? 1 : 0;
             }
             double *gram_ws = f->ws, *sweep_ws = f->ws + gram_ws_doubles(M, rp);
+            bool rhs_done = false;
             if (icp && !f->icp_surface && !f->reversed && f->n_lm == 0) {
                 // point-cloud ICP without landmarks: every row has the same weight 1 / sigma2 (ICP.scala:90-92), so the weighted Gram
                 // is the model's one-off moment Q^T Q scaled -- no pass over the basis.  mom holds the total over ALL shards: the
@@ -1002,15 +1003,19 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 fa.nslabs = 0;
             } else {
                 fa.gram_partial = gram_ws;
-                fa.nslabs = launch_gram(ctx, m->Q0, M, rp, f->weight, gram_ws, nullptr);
+                fa.nslabs = launch_gram(ctx, m->Q0, M, rp, f->weight, gram_ws, nullptr, f->evec, sweep_ws, &rhs_done);
             }
-            SweepArgs a = base_args(f);
-            a.evec = f->evec;
-            a.partial = sweep_ws;
-            a.no_reduce = 1;
-            launch_sweep(ctx, SWEEP_RHS, a);
             fa.sweep_partial = sweep_ws;
-            fa.sweep_blocks = sweep_num_blocks(M);
+            if (rhs_done) {  // the Gram pass left the right-hand-side partials, one row per slab
+                fa.sweep_blocks = fa.nslabs;
+            } else {
+                SweepArgs a = base_args(f);
+                a.evec = f->evec;
+                a.partial = sweep_ws;
+                a.no_reduce = 1;
+                launch_sweep(ctx, SWEEP_RHS, a);
+                fa.sweep_blocks = sweep_num_blocks(M);
+            }
             launch_phase1_finalize(ctx, fa);
             launch_landmarks(ctx, m, f->st, f->n_lm, f->lm_pid, f->lm_xyz, f->lm_cov, Gw, rhsw);
             break;

@@ -126,7 +126,10 @@ void launch_sweep(gingr_ctx *ctx, SweepMode mode, const SweepArgs &a);
 int64_t gram_ws_doubles(int64_t M, int32_t rp);
 // G[rp*rp] (full symmetric) = sum_i w_i Q0_i^T Q0_i over local points; weight == nullptr means w = 1
 // returns the number of slab partials in ws; G == nullptr leaves them unreduced (launch_phase1_finalize adds them up)
-int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, double *G);
+int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, double *G,
+                const double *evec = nullptr, double *rhs_partial = nullptr, bool *rhs_done = nullptr);
+// evec ([3][M] planes) + rhs_partial ([slabs][rp]) + rhs_done: when the triangle kernel runs (rp <= 112) it also leaves the slab
+// partials of Q0^T evec and sets *rhs_done -- the caller then skips its SWEEP_RHS pass and reduces over the returned slab count.
 
 // one launch for the reductions at the end of phase 1 (gp.hip: phase1_finalize_kernel)
 struct Phase1FinalizeArgs {

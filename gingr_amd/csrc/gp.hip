@@ -383,7 +383,8 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ Q0
 template <int NT, int HALF>
 __device__ __forceinline__ void gram_tri_half(const double *__restrict__ Q0, int rp, const double *__restrict__ weight, int64_t r0,
                                               int64_t r1, int kgroup, int kq, int cl, int lane, double *red, double *xchg,
-                                              double *__restrict__ out) {
+                                              double *__restrict__ out, const double *__restrict__ evec, int64_t npts,
+                                              double *__restrict__ rhs_out, double *rsh) {
     constexpr int kTiles = NT * (NT + 1) / 2;
     constexpr int kMine = HALF == 0 ? (kTiles + 1) / 2 : kTiles / 2;
     v4f64 acc[kMine > 0 ? kMine : 1];
@@ -397,16 +398,24 @@ __device__ __forceinline__ void gram_tri_half(const double *__restrict__ Q0, int
     // the LDS hand-over is double buffered, one workgroup barrier per step.
     constexpr int kDepth = GINGR_GRAM_DEPTH;
     constexpr int kOwn = HALF == 0 ? (NT + 1) / 2 : NT / 2;  // fragments this wave loads
-    auto load_own = [&](int64_t row, double (&f)[kOwn > 0 ? kOwn : 1], double &w) {
+    // evec != nullptr (HALF 0 only): the right-hand side Q0^T evec rides along -- the wave holds every fragment of the rows it
+    // multiplies anyway, so the separate pass over the basis (SWEEP_RHS) is NT FMAs per step here.  evec: SoA planes [3][npts].
+    const bool with_rhs = HALF == 0 && evec != nullptr;
+    auto load_own = [&](int64_t row, double (&f)[kOwn > 0 ? kOwn : 1], double &w, double &ev) {
         const int64_t rr = row + kq;
         const bool valid = rr < r1;
         const int64_t rc = valid ? rr : r0;
-        w = valid ? (weight ? weight[rc / 3] : 1.0) : 0.0;
+        const int64_t pt = rc / 3;
+        w = valid ? (weight ? weight[pt] : 1.0) : 0.0;
+        ev = (with_rhs && valid) ? evec[(rc - 3 * pt) * npts + pt] : 0.0;
         const double *p = Q0 + rc * rp + cl;
 #pragma unroll
         for (int k = 0; k < kOwn; ++k) f[k] = p[16 * (2 * k + HALF)];
     };
-    double ring[kDepth + 1][kOwn > 0 ? kOwn : 1], wr[kDepth + 1];
+    double ring[kDepth + 1][kOwn > 0 ? kOwn : 1], wr[kDepth + 1], er[kDepth + 1];
+    double racc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) racc[t] = 0.0;
     const int64_t row0 = r0 + 4 * kgroup;
     // every wave of the workgroup runs the same number of steps (the barrier inside is workgroup wide): the K group with the
     // most rows sets it; steps past a wave's own rows multiply zeros (w = 0, clamped addresses)
@@ -414,7 +423,8 @@ __device__ __forceinline__ void gram_tri_half(const double *__restrict__ Q0, int
 #pragma unroll
     for (int d = 0; d <= kDepth; ++d) {
         wr[d] = 0.0;
-        if (d < kDepth) load_own(row0 + 16 * d, ring[d], wr[d]);
+        er[d] = 0.0;
+        if (d < kDepth) load_own(row0 + 16 * d, ring[d], wr[d], er[d]);
     }
     double *xbuf = xchg + (size_t)kgroup * NT * 64;  // [2 buffers][4 K groups][NT][64 lanes]
     for (int64_t st = 0; st < nsteps; ++st) {
@@ -422,12 +432,13 @@ __device__ __forceinline__ void gram_tri_half(const double *__restrict__ Q0, int
 #pragma unroll
         for (int k = 0; k < kOwn; ++k) xb[(2 * k + HALF) * 64 + lane] = ring[0][k];
         __syncthreads();
-        load_own(row0 + 16 * (st + kDepth), ring[kDepth], wr[kDepth]);
+        load_own(row0 + 16 * (st + kDepth), ring[kDepth], wr[kDepth], er[kDepth]);
         double cur[NT], a[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             cur[t] = xb[t * 64 + lane];
             a[t] = cur[t] * wr[0];  // invalid rows: w = 0
+            if (HALF == 0) racc[t] = __builtin_fma(cur[t], er[0], racc[t]);  // er = 0 without evec / past the rows
         }
         int q = 0;
 #pragma unroll
@@ -440,7 +451,25 @@ __device__ __forceinline__ void gram_tri_half(const double *__restrict__ Q0, int
 #pragma unroll
             for (int k = 0; k < kOwn; ++k) ring[d][k] = ring[d + 1][k];
             wr[d] = wr[d + 1];
+            er[d] = er[d + 1];
         }
+    }
+    if (evec) {  // workgroup-uniform.  Right-hand side: lanes of a column (the four kq) first, then the K groups 0..3 in order
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            racc[t] += __shfl_xor(racc[t], 16);
+            racc[t] += __shfl_xor(racc[t], 32);
+        }
+        if (HALF == 0 && kq == 0)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) rsh[kgroup * (NT * 16) + t * 16 + cl] = racc[t];
+        __syncthreads();
+        if (HALF == 0 && kgroup == 0 && kq == 0)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = t * 16 + cl;
+                rhs_out[c] = ((rsh[c] + rsh[NT * 16 + c]) + rsh[2 * NT * 16 + c]) + rsh[3 * NT * 16 + c];
+            }
     }
     // K groups 1..3 are added into group 0 in order (both halves at once, disjoint parts of `red`)
     double *mine = red + HALF * ((kTiles + 1) / 2) * 256;
@@ -475,18 +504,21 @@ __device__ __forceinline__ void gram_tri_half(const double *__restrict__ Q0, int
 template <int NT>
 __global__ __launch_bounds__(512) void gram_tri_kernel(const double *__restrict__ Q0, int64_t rows, int rp,
                                                        const double *__restrict__ weight, int64_t rows_per_slab,
-                                                       double *__restrict__ partial) {
+                                                       double *__restrict__ partial, const double *__restrict__ evec, int64_t npts,
+                                                       double *__restrict__ rhs_partial) {
     constexpr int kTiles = NT * (NT + 1) / 2;
     __shared__ double red[(kTiles + 1) * 256];
     __shared__ double xchg[2 * 4 * NT * 64];
+    __shared__ double rsh[4 * NT * 16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kq = lane >> 4, cl = lane & 15;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
     const int64_t r1 = min(rows, r0 + rows_per_slab);
     double *out = partial + (int64_t)blockIdx.x * rp * rp;
+    double *rhs_out = rhs_partial ? rhs_partial + (int64_t)blockIdx.x * rp : nullptr;  // one row of right-hand-side partials per slab
     if ((wave >> 2) == 0)
-        gram_tri_half<NT, 0>(Q0, rp, weight, r0, r1, wave & 3, kq, cl, lane, red, xchg, out);
+        gram_tri_half<NT, 0>(Q0, rp, weight, r0, r1, wave & 3, kq, cl, lane, red, xchg, out, evec, npts, rhs_out, rsh);
     else
-        gram_tri_half<NT, 1>(Q0, rp, weight, r0, r1, wave & 3, kq, cl, lane, red, xchg, out);
+        gram_tri_half<NT, 1>(Q0, rp, weight, r0, r1, wave & 3, kq, cl, lane, red, xchg, out, evec, npts, rhs_out, rsh);
 }
 
 // G[i][j] = sum over slabs (fixed order): 32 consecutive elements x 8 slab groups per workgroup, so every load instruction
@@ -1827,7 +1859,9 @@ int64_t gram_ws_doubles(int64_t M, int32_t rp) {
     return (int64_t)std::max(nslabs, nslabs_tri) * rp * rp;
 }
 
-int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, double *G) {
+int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, double *G, const double *evec,
+                double *rhs_partial, bool *rhs_done) {
+    if (rhs_done) *rhs_done = false;
     int nbp, npatch, nslabs;
     int64_t rps;
     gram_plan(M, rp, &nbp, &npatch, &nslabs, &rps);
@@ -1838,8 +1872,12 @@ int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const d
             // whole upper triangle per wave: one workgroup per slab; ~3 slabs' worth of waves per SIMD is not needed (one wave per
             // SIMD, deep prefetch), so 256 slabs = one workgroup per CU
             gram_tri_plan(M, &nslabs, &rps);
+            static const int fuse_env = getenv("GINGR_GRAM_RHS") ? atoi(getenv("GINGR_GRAM_RHS")) : 1;
+            const bool fuse = fuse_env && evec && rhs_partial && rhs_done;  // Q0^T evec out of the same pass: [nslabs][rp] partials
+            if (fuse) *rhs_done = true;
             auto go = [&](auto kern) {
-                hipLaunchKernelGGL(kern, dim3(nslabs), dim3(512), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, ws);
+                hipLaunchKernelGGL(kern, dim3(nslabs), dim3(512), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, ws,
+                                   fuse ? evec : (const double *)nullptr, M, fuse ? rhs_partial : (double *)nullptr);
             };
             switch (nt) {
                 case 1: go(gram_tri_kernel<1>); break;
