@@ -31,6 +31,11 @@ struct gingr_fitter {
     DevState *st = nullptr;
     DevPose *pose = nullptr;
     gingr_state_scalars *hs_dev = nullptr;
+    // alpha [rp], hs_dev and st live in ONE allocation (state_block), in this order: set_state pushes [alpha | scalars] and get_state
+    // pulls [alpha | scalars | DevState] in a single transfer each, through the pinned host buffer `pin` (no pageable staging)
+    double *state_block = nullptr;
+    double *pin = nullptr;
+    size_t pin_doubles = 0;
     double *scalars = nullptr;  // local {Np, xPx, trPXY, yPy, -, c, -, -}
     double *part = nullptr;     // block partials of the scalar sums
     double *absmax = nullptr;   // [0] target, [1] fit: largest |coordinate| (exponent-argument range check)
@@ -117,6 +122,8 @@ struct gingr_fitter {
     double *partial_out = nullptr;
     int32_t *retry = nullptr;  // device word: retryCounter of the algorithm instance this fitter stands for (GingrAlgorithm.scala:69-70)
 };
+
+constexpr size_t kScalarsDoubles = (sizeof(gingr_state_scalars) + 7) / 8, kDevStateDoubles = (sizeof(DevState) + 7) / 8;
 
 namespace {
 
@@ -439,15 +446,25 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
         (rc = dev_alloc(ctx, &f->PX, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->nn_idx, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->nn_d2, (size_t)M)) || (rc = dev_alloc(ctx, &f->weight, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->evec, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->newshape, (size_t)3 * M)) ||
-        (rc = dev_alloc(ctx, &f->alpha, (size_t)rp)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
+        (rc = dev_alloc(ctx, &f->state_block, (size_t)rp + kScalarsDoubles + kDevStateDoubles)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
         (rc = dev_alloc(ctx, &f->small, (size_t)8)) || (rc = dev_alloc(ctx, &f->fxbuf[0], (size_t)rp * rp + 2 * rp)) || (rc = dev_alloc(ctx, &f->fxbuf[1], (size_t)rp * rp + 2 * rp)) ||
         (rc = dev_alloc(ctx, &f->alt_seg, (size_t)rp * rp + rp + 8)) || (rc = dev_alloc(ctx, &f->lp_sync, (size_t)2)) ||
-        (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->zbuf, (size_t)19 * rp)) || (rc = dev_alloc(ctx, &f->zrand, (size_t)rp)) || (rc = dev_alloc(ctx, &f->st, 1)) ||
-        (rc = dev_alloc(ctx, &f->pose, 1)) || (rc = dev_alloc(ctx, &f->hs_dev, 1)) ||
+        (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->zbuf, (size_t)19 * rp)) || (rc = dev_alloc(ctx, &f->zrand, (size_t)rp)) ||
+        (rc = dev_alloc(ctx, &f->pose, 1)) ||
         (rc = dev_alloc(ctx, &f->scalars, 8)) || (rc = dev_alloc(ctx, &f->part, GINGR_SCALAR_PART)) || (rc = dev_alloc(ctx, &f->absmax, GINGR_AUX)) || (rc = dev_alloc(ctx, &f->work, (size_t)std::max<int64_t>((int64_t)rp * rp, posterior_work_doubles(rp)))) ||
         (rc = dev_alloc(ctx, &f->lm_mask, (size_t)M))) {
         gingr_fitter_destroy(f);
         return rc;
+    }
+    f->alpha = f->state_block;
+    f->hs_dev = reinterpret_cast<gingr_state_scalars *>(f->state_block + rp);
+    f->st = reinterpret_cast<DevState *>(f->state_block + rp + kScalarsDoubles);
+    f->pin_doubles = (size_t)3 * M + rp + kScalarsDoubles + kDevStateDoubles;
+    if (hipHostMalloc(reinterpret_cast<void **>(&f->pin), f->pin_doubles * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        f->pin = nullptr;
+        gingr_fitter_destroy(f);
+        return gingr_set_error(ctx, GINGR_ERR_HIP, "fitter_create: pinned host buffer");
     }
     if ((rc = dev_alloc(ctx, &f->retry, 1))) {
         gingr_fitter_destroy(f);
@@ -482,14 +499,13 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->weight);
     dev_free(f->evec);
     dev_free(f->newshape);
-    dev_free(f->alpha);
+    dev_free(f->state_block);
+    if (f->pin) (void)hipHostFree(f->pin);
     dev_free(f->acoef);
     dev_free(f->alpha_c);
     dev_free(f->zbuf);
     dev_free(f->zrand);
-    dev_free(f->st);
     dev_free(f->pose);
-    dev_free(f->hs_dev);
     dev_free(f->scalars);
     dev_free(f->small);
     dev_free(f->fxbuf[0]);
@@ -636,10 +652,10 @@ int gingr_fitter_set_state(gingr_fitter *f, const double *alpha, const gingr_sta
     gingr_ctx *ctx = f->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int32_t r = f->m->r, rp = f->m->rp;
-    std::vector<double> a((size_t)rp, 0.0);
-    memcpy(a.data(), alpha, (size_t)r * sizeof(double));
-    HIP_TRY(ctx, hipMemcpyAsync(f->alpha, a.data(), (size_t)rp * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(f->hs_dev, s, sizeof(*s), hipMemcpyHostToDevice, ctx->stream));
+    memset(f->pin, 0, ((size_t)rp + kScalarsDoubles) * sizeof(double));
+    memcpy(f->pin, alpha, (size_t)r * sizeof(double));
+    memcpy(f->pin + rp, s, sizeof(*s));
+    HIP_TRY(ctx, hipMemcpyAsync(f->state_block, f->pin, ((size_t)rp + kScalarsDoubles) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     launch_state_init(ctx, f->st, f->hs_dev);
     if (!f->ws) {  // no target yet: allocate the sweep workspace so the fit can be instantiated
         f->ws_doubles = sweep_ws_doubles(f->m->M, rp);
@@ -682,9 +698,9 @@ int gingr_fitter_get_state(gingr_fitter *f, double *alpha, gingr_state_scalars *
     if (!f->has_state) return gingr_set_error(ctx, GINGR_ERR_STATE, "get_state: no state set");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t M = f->m->M;
-    DevState hst;
-    HIP_TRY(ctx, hipMemcpyAsync(&hst, f->st, sizeof(hst), hipMemcpyDeviceToHost, ctx->stream));
-    if (alpha) HIP_TRY(ctx, hipMemcpyAsync(alpha, f->alpha, (size_t)f->m->r * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    const int32_t rp_ = f->m->rp;
+    const size_t head = (size_t)rp_ + kScalarsDoubles + kDevStateDoubles;  // [alpha | scalars | DevState], one transfer
+    HIP_TRY(ctx, hipMemcpyAsync(f->pin, f->state_block, head * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     DevBuf tmp;
     if (fit_xyz) {
         double *stage = reinterpret_cast<double *>(f->aos);  // the fitter's interleaved staging buffer (max(3M, 3N) doubles)
@@ -693,9 +709,13 @@ int gingr_fitter_get_state(gingr_fitter *f, double *alpha, gingr_state_scalars *
             stage = tmp.as<double>();
         }
         launch_soa_to_aos(ctx, f->fit, M, stage, f->m->perm);
-        HIP_TRY(ctx, hipMemcpyAsync(fit_xyz, stage, (size_t)3 * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(f->pin + head, stage, (size_t)3 * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    DevState hst;
+    memcpy(&hst, f->pin + rp_ + kScalarsDoubles, sizeof(hst));
+    if (alpha) memcpy(alpha, f->pin, (size_t)f->m->r * sizeof(double));
+    if (fit_xyz) memcpy(fit_xyz, f->pin + head, (size_t)3 * M * sizeof(double));
     if (s) {
         for (int q = 0; q < 3; ++q) {
             s->euler[q] = hst.euler[q];
