@@ -1382,6 +1382,8 @@ static int sample_update(gingr_fitter *f, int flavour, const gingr_cpd_params *c
     if (!z) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "update_sample: z is null");
     if (f->m->M != f->m->M_total) return gingr_set_error(ctx, GINGR_ERR_STATE, "update_sample: single shard only");
     const int32_t r = f->m->r, rp = f->m->rp;
+    // (pageable on purpose: this entry point returns without synchronising, and a copy from pageable memory has consumed its source
+    // when the call returns -- the pinned buffer of the synchronous entry points must not be rewritten under a pending transfer)
     std::vector<double> zz((size_t)rp, 0.0);
     memcpy(zz.data(), z, (size_t)r * sizeof(double));
     HIP_TRY(ctx, hipMemcpyAsync(f->zrand, zz.data(), (size_t)rp * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -1428,7 +1430,8 @@ static int posterior_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params
     // Q0^T e with e = R^T(mesh - c - t) - (ref - c) - mean in the pose of the state (copied on the device, no host round trip)
     double *out2 = f->small;
     double *aos = reinterpret_cast<double *>(f->aos);
-    HIP_TRY(ctx, hipMemcpyAsync(aos, mesh_xyz, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    memcpy(f->pin, mesh_xyz, (size_t)3 * M * sizeof(double));  // pinned: the copy is a plain asynchronous DMA
+    HIP_TRY(ctx, hipMemcpyAsync(aos, f->pin, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     launch_aos_to_soa(ctx, aos, M, f->newshape, m->perm);
     hipLaunchKernelGGL(pose_of_state_kernel, dim3(1), dim3(64), 0, ctx->stream, f->st, f->pose);
     SweepArgs a = base_args(f);
@@ -1439,8 +1442,8 @@ static int posterior_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params
     GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, rhs, m->mom + MomentLayout{rp}.stot(), f->alpha_c, f->fxbuf[f->live], cached, f->work,
                                       out2, f->lp_sync, ++f->lp_epoch));
     GINGR_TRY(check_launch(ctx));
-    double res[2] = {0, 0};
-    HIP_TRY(ctx, hipMemcpyAsync(res, out2, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    double *res = f->pin + (size_t)3 * M;  // behind the mesh (pin holds 3M + rp + ... doubles)
+    HIP_TRY(ctx, hipMemcpyAsync(res, out2, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (res[1] != 0.0) return gingr_set_error(ctx, GINGR_ERR_NOT_SPD, "posterior_logpdf: posterior of the current state failed");
     if (!std::isfinite(res[0])) return gingr_set_error(ctx, GINGR_ERR_NONFINITE, "posterior_logpdf: non-finite result");
