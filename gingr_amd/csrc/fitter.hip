@@ -1636,7 +1636,7 @@ hipError_t ensure(DevBuf &b, size_t bytes) { return b.p && b.bytes >= bytes ? hi
 
 int run_distance_stats(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T, const double *tboxes,
                        const int32_t *q_orig, int64_t q_limit, const int32_t *v_orig, const double *v_boxes,
-                       const int32_t *boundary, double sdev, StatScratch &sc, double out4[4]) {
+                       const int32_t *boundary, double sdev, StatScratch &sc, double out4[4], double *pinned4 = nullptr) {
     const int64_t K = q.n;
     HIP_TRY(ctx, ensure(sc.cp, (size_t)3 * K * sizeof(double)));
     HIP_TRY(ctx, ensure(sc.d2, (size_t)K * sizeof(double)));
@@ -1656,8 +1656,9 @@ int run_distance_stats(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, con
     launch_distance_stats(ctx, K, sc.d2.as<double>(), q_orig, q_limit, boundary ? sc.nn.as<int32_t>() : nullptr, boundary, sdev,
                           sc.part.as<double>(), sc.out.as<double>());
     GINGR_TRY(check_launch(ctx));
-    HIP_TRY(ctx, hipMemcpyAsync(out4, sc.out.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(pinned4 ? pinned4 : out4, sc.out.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (pinned4) memcpy(out4, pinned4, 4 * sizeof(double));
     return GINGR_OK;
 }
 
@@ -1691,7 +1692,7 @@ int gingr_fitter_surface_distance_stats(gingr_fitter *f, int32_t direction, int6
         if (n_points > M) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "surface_distance_stats: more points than model vertices");
         const bool all = n_points == 0 || n_points == M;
         return run_distance_stats(ctx, fit, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, all ? nullptr : m->perm, n_points, f->tperm,
-                                  f->tboxes, boundary_aware ? f->tboundary : nullptr, sdev, sc, out);
+                                  f->tboxes, boundary_aware ? f->tboundary : nullptr, sdev, sc, out, f->pin);
     }
     // `points` (null: every target vertex) against the surface of the current fit
     launch_tri_tile_bbox(ctx, fit, f->mtri, f->Tm, f->mtboxes);
@@ -1699,7 +1700,7 @@ int gingr_fitter_surface_distance_stats(gingr_fitter *f, int32_t direction, int6
     const int32_t *bnd = boundary_aware ? f->mboundary : nullptr;
     if (!points)
         return run_distance_stats(ctx, tgt, fit, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, nullptr, 0, m->perm, f->fboxes, bnd, sdev, sc,
-                                  out);
+                                  out, f->pin);
     if (n_points < 1) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "surface_distance_stats: empty point list");
     std::vector<int32_t> order;
     morton_order(points, n_points, order);
