@@ -680,6 +680,7 @@ int gingr_fitter_set_fit_points(gingr_fitter *f, const double *fit_xyz) {
     gingr_ctx *ctx = f->ctx;
     if (!fit_xyz) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_fit_points: null argument");
     if (!f->has_state) return gingr_set_error(ctx, GINGR_ERR_STATE, "set_fit_points: set a state first (its pose / sigma2 stay in force)");
+    if (!f->aos) return gingr_set_error(ctx, GINGR_ERR_STATE, "set_fit_points: set a target first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t M = f->m->M;
     double *stage = reinterpret_cast<double *>(f->aos);
