@@ -166,11 +166,11 @@ void launch_sumsq_pairs(gingr_ctx *ctx, Cloud A, Cloud B, double *ws, double *ou
 void launch_cell_normals(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *cn_soa);
 void launch_vertex_normals(gingr_ctx *ctx, const int32_t *adj_ptr, const int32_t *adj_tri, const double *cn_soa, int64_t T,
                            int64_t n, double *vn_soa);
-void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *boxes);
+void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *boxes, double *tribox = nullptr);
 // closest point of the triangle soup to every query (SoA out); exact ties: lowest tri_orig
 void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T,
                                   const double *boxes, double *cp_soa, double *d2, int32_t *tri_out = nullptr, int32_t *warm = nullptr,
-                                  bool warm_valid = false);
+                                  bool warm_valid = false, const double *tribox = nullptr);
 // bary[3 i + k] = weight of corner k of triangle tri_id[i] at the closest point of that triangle to query i; tri_by_orig [3 T]:
 // corner positions in the cloud v, indexed by ORIGINAL triangle number
 void launch_barycentric(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri_by_orig, const int32_t *tri_id, double *bary);
@@ -182,7 +182,7 @@ int distance_stats_ws_doubles();
 void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const int32_t *orig, int64_t orig_limit, const int32_t *nn,
                            const int32_t *boundary, double sdev, double *partial, double *out4);
 void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, const int32_t *tri, int64_t T, const double *boxes,
-                           const int32_t *skip, int32_t *flag);
+                           const int32_t *skip, int32_t *flag, const double *tribox = nullptr);
 // found (nullable): along-normal flavour, 0 = no intersection (rejected)
 void launch_surface_prereject(gingr_ctx *ctx, int64_t M, const int32_t *nn_vertex, const int32_t *tgt_boundary,
                               const double *fit_vn, const double *tgt_vn, int64_t N, const int32_t *found, int32_t *pre);

@@ -72,6 +72,7 @@ struct gingr_fitter {
     int32_t *madj_ptr = nullptr, *madj_tri = nullptr, *tadj_ptr = nullptr, *tadj_tri = nullptr;  // vertex -> triangles
     double *mcn = nullptr, *tcn = nullptr, *mvn = nullptr, *tvn = nullptr;  // cell / vertex normals (SoA)
     double *mtboxes = nullptr, *ttboxes = nullptr;  // triangle tile boxes
+    double *mtribox = nullptr, *ttribox = nullptr;  // per-triangle boxes [T][6] (tri_tile_bbox_kernel), staged by the scan kernels
     int32_t *tboundary = nullptr;                   // target boundary vertices (device target positions)
     double *surf_cp = nullptr, *surf_d2 = nullptr, *surf_w01 = nullptr, *surf_win = nullptr, *surf_nnd2 = nullptr;
     int32_t *surf_nn = nullptr, *surf_pre = nullptr, *surf_hit = nullptr;
@@ -209,10 +210,10 @@ void free_meshes(gingr_fitter *f) {
     f->reversed = false;
     void *ptrs[] = {f->mtri, f->ttri, f->ttri_orig, f->madj_ptr, f->madj_tri, f->tadj_ptr, f->tadj_tri, f->mcn, f->tcn, f->mvn,
                     f->tvn, f->mtboxes, f->ttboxes, f->tboundary, f->surf_cp, f->surf_d2, f->surf_w01, f->surf_win, f->surf_nnd2,
-                    f->surf_nn, f->surf_pre, f->surf_hit, f->surf_tri_pos};
+                    f->surf_nn, f->surf_pre, f->surf_hit, f->surf_tri_pos, f->mtribox, f->ttribox};
     for (void *p : ptrs) dev_free(p);
     f->mtri = f->ttri = f->ttri_orig = f->madj_ptr = f->madj_tri = f->tadj_ptr = f->tadj_tri = f->tboundary = nullptr;
-    f->mcn = f->tcn = f->mvn = f->tvn = f->mtboxes = f->ttboxes = nullptr;
+    f->mcn = f->tcn = f->mvn = f->tvn = f->mtboxes = f->ttboxes = f->mtribox = f->ttribox = nullptr;
     f->surf_cp = f->surf_d2 = f->surf_w01 = f->surf_win = f->surf_nnd2 = nullptr;
     f->surf_nn = f->surf_pre = f->surf_hit = f->surf_tri_pos = nullptr;
     f->surf_tri_warm = f->surf_nn_warm = false;
@@ -924,14 +925,15 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                     const bool along = f->surface_method == 1;
                     launch_cell_normals(ctx, fit, f->mtri, f->Tm, f->mcn);
                     launch_vertex_normals(ctx, f->madj_ptr, f->madj_tri, f->mcn, f->Tm, M, f->mvn);
-                    launch_tri_tile_bbox(ctx, fit, f->mtri, f->Tm, f->mtboxes);
+                    launch_tri_tile_bbox(ctx, fit, f->mtri, f->Tm, f->mtboxes, f->mtribox);
                     if (along)
                         launch_line_nearest(ctx, tgt, f->tvn, fit, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, f->rcp, f->rhit);
                     else
-                        launch_surface_closest_point(ctx, tgt, fit, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, f->rcp, f->rd2);
+                        launch_surface_closest_point(ctx, tgt, fit, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, f->rcp, f->rd2, nullptr, nullptr,
+                                                     false, f->mtribox);
                     launch_nn(ctx, cloud_of(f->rcp, N), fit, f->m->perm, f->fboxes, f->ws, f->rnn, f->rnnd2);
                     launch_surface_prereject(ctx, N, f->rnn, f->mboundary, f->tvn, f->mvn, M, along ? f->rhit : nullptr, f->rpre);
-                    launch_self_intersect(ctx, tgt, f->rcp, f->ttri, f->Tt, f->ttboxes, f->rpre, f->rhit);
+                    launch_self_intersect(ctx, tgt, f->rcp, f->ttri, f->Tt, f->ttboxes, f->rpre, f->rhit, f->ttribox);
                     launch_reversal_observations(ctx, M, tgt, f->rnn, f->rpre, f->rhit, &f->st->sigma2, f->rkeys, f->rvals, f->rskeys,
                                                  f->rsvals, f->rsort, f->rsort_bytes, f->rw01, f->robs, f->rwin);
                 } else {  // ClosestPointTriangleMesh3DSimple: nearest template vertex, weight 1
@@ -943,14 +945,14 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 // ClosestPointTriangleMesh3D.closestPointCorrespondence (ClosestPointRegistrator.scala:75-100)
                 launch_cell_normals(ctx, fit, f->mtri, f->Tm, f->mcn);
                 launch_vertex_normals(ctx, f->madj_ptr, f->madj_tri, f->mcn, f->Tm, M, f->mvn);
-                launch_tri_tile_bbox(ctx, fit, f->mtri, f->Tm, f->mtboxes);
+                launch_tri_tile_bbox(ctx, fit, f->mtri, f->Tm, f->mtboxes, f->mtribox);
                 const bool along = f->surface_method == 1;  // ClosestPointAlongNormalTriangleMesh3D (:102-131)
                 if (along)
                     launch_line_nearest(ctx, fit, f->mvn, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, f->surf_cp, f->surf_hit);
                 else
                 {
                     launch_surface_closest_point(ctx, fit, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, f->surf_cp, f->surf_d2, nullptr,
-                                                 f->surf_tri_pos, f->surf_tri_warm);
+                                                 f->surf_tri_pos, f->surf_tri_warm, f->ttribox);
                     f->surf_tri_warm = true;
                 }
                 launch_nn(ctx, cloud_of(f->surf_cp, M), tgt, f->tperm, f->tboxes, f->ws, f->surf_nn, f->surf_nnd2,
@@ -958,7 +960,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 f->surf_nn_warm = true;
                 launch_surface_prereject(ctx, M, f->surf_nn, f->tboundary, f->mvn, f->tvn, f->N, along ? f->surf_hit : nullptr,
                                          f->surf_pre);
-                launch_self_intersect(ctx, fit, f->surf_cp, f->mtri, f->Tm, f->mtboxes, f->surf_pre, f->surf_hit);
+                launch_self_intersect(ctx, fit, f->surf_cp, f->mtri, f->Tm, f->mtboxes, f->surf_pre, f->surf_hit, f->mtribox);
                 launch_surface_weight(ctx, M, f->surf_pre, f->surf_hit, &f->st->sigma2, f->surf_w01, f->surf_win);
             } else if (icp) {
                 launch_nn(ctx, fit, tgt, f->tperm, f->tboxes, f->ws, f->nn_idx, f->nn_d2, f->nn_warm ? f->nn_idx : nullptr);
@@ -1249,7 +1251,8 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
         (rc = dev_alloc(ctx, &f->surf_w01, (size_t)M)) || (rc = dev_alloc(ctx, &f->surf_win, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->surf_nnd2, (size_t)M)) || (rc = dev_alloc(ctx, &f->surf_nn, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->surf_pre, (size_t)M)) || (rc = dev_alloc(ctx, &f->surf_hit, (size_t)M)) ||
-        (rc = dev_alloc(ctx, &f->surf_tri_pos, (size_t)M)) ||
+        (rc = dev_alloc(ctx, &f->surf_tri_pos, (size_t)M)) || (rc = dev_alloc(ctx, &f->mtribox, (size_t)6 * f->Tm)) ||
+        (rc = dev_alloc(ctx, &f->ttribox, (size_t)6 * f->Tt)) ||
         (rc = dev_alloc(ctx, &f->mtri_orig, (size_t)f->Tm)) || (rc = dev_alloc(ctx, &f->mboundary, (size_t)M)))
         return rc;
     auto up = [&](int32_t *dst, const std::vector<int32_t> &src) {
@@ -1269,7 +1272,7 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
     const Cloud tgt = cloud_of(f->target, N);
     launch_cell_normals(ctx, tgt, f->ttri, f->Tt, f->tcn);
     launch_vertex_normals(ctx, f->tadj_ptr, f->tadj_tri, f->tcn, f->Tt, N, f->tvn);
-    launch_tri_tile_bbox(ctx, tgt, f->ttri, f->Tt, f->ttboxes);
+    launch_tri_tile_bbox(ctx, tgt, f->ttri, f->Tt, f->ttboxes, f->ttribox);
     GINGR_TRY(check_launch(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GINGR_OK;
@@ -1637,7 +1640,8 @@ hipError_t ensure(DevBuf &b, size_t bytes) { return b.p && b.bytes >= bytes ? hi
 
 int run_distance_stats(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T, const double *tboxes,
                        const int32_t *q_orig, int64_t q_limit, const int32_t *v_orig, const double *v_boxes,
-                       const int32_t *boundary, double sdev, StatScratch &sc, double out4[4], double *pinned4 = nullptr) {
+                       const int32_t *boundary, double sdev, StatScratch &sc, double out4[4], double *pinned4 = nullptr,
+                       const double *tribox = nullptr) {
     const int64_t K = q.n;
     HIP_TRY(ctx, ensure(sc.cp, (size_t)3 * K * sizeof(double)));
     HIP_TRY(ctx, ensure(sc.d2, (size_t)K * sizeof(double)));
@@ -1646,7 +1650,7 @@ int run_distance_stats(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, con
     HIP_TRY(ctx, ensure(sc.pos, (size_t)K * sizeof(int32_t)));
     const bool warm = sc.pos_K == K && sc.pos_T == T && sc.pos_tri == tri;
     launch_surface_closest_point(ctx, q, v, tri, tri_orig, T, tboxes, sc.cp.as<double>(), sc.d2.as<double>(), nullptr, sc.pos.as<int32_t>(),
-                                 warm);
+                                 warm, tribox);
     sc.pos_K = K, sc.pos_T = T, sc.pos_tri = tri;
     if (boundary) {
         HIP_TRY(ctx, ensure(sc.nn, (size_t)K * sizeof(int32_t)));
@@ -1693,15 +1697,15 @@ int gingr_fitter_surface_distance_stats(gingr_fitter *f, int32_t direction, int6
         if (n_points > M) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "surface_distance_stats: more points than model vertices");
         const bool all = n_points == 0 || n_points == M;
         return run_distance_stats(ctx, fit, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, all ? nullptr : m->perm, n_points, f->tperm,
-                                  f->tboxes, boundary_aware ? f->tboundary : nullptr, sdev, sc, out, f->pin);
+                                  f->tboxes, boundary_aware ? f->tboundary : nullptr, sdev, sc, out, f->pin, f->ttribox);
     }
     // `points` (null: every target vertex) against the surface of the current fit
-    launch_tri_tile_bbox(ctx, fit, f->mtri, f->Tm, f->mtboxes);
+    launch_tri_tile_bbox(ctx, fit, f->mtri, f->Tm, f->mtboxes, f->mtribox);
     if (boundary_aware) launch_tile_bbox(ctx, fit, f->fboxes);
     const int32_t *bnd = boundary_aware ? f->mboundary : nullptr;
     if (!points)
         return run_distance_stats(ctx, tgt, fit, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, nullptr, 0, m->perm, f->fboxes, bnd, sdev, sc,
-                                  out, f->pin);
+                                  out, f->pin, f->mtribox);
     if (n_points < 1) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "surface_distance_stats: empty point list");
     std::vector<int32_t> order;
     morton_order(points, n_points, order);

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void vertex_normals_kernel(const int32_t *__re
 // boxes[tile] = {lo[3], hi[3]} over the corners of the triangles [tile*256, tile*256+256), followed (at boxes + 6 * ntiles) by the
 // boxes of its four 64-triangle quarters [tile*4 + q] (the triangle order is a k-d order down to 64-triangle leaves)
 __global__ __launch_bounds__(256) void tri_tile_bbox_kernel(Cloud v, const int32_t *__restrict__ tri, int64_t T,
-                                                            double *__restrict__ boxes) {
+                                                            double *__restrict__ boxes, double *__restrict__ tribox) {
     __shared__ double sh[6][256];
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double lo[3] = {__builtin_huge_val(), __builtin_huge_val(), __builtin_huge_val()};
@@ -121,6 +121,10 @@ __global__ __launch_bounds__(256) void tri_tile_bbox_kernel(Cloud v, const int32
                 hi[d] = fmax(hi[d], p[d]);
             }
         }
+    if (tribox && t < T) {  // per-triangle boxes: the scan kernels stage these (one 48-byte read) instead of rebuilding them from
+        double *tb = tribox + 6 * t;  // three index loads and nine gathered coordinates per visited triangle and workgroup
+        tb[0] = lo[0], tb[1] = lo[1], tb[2] = lo[2], tb[3] = hi[0], tb[4] = hi[1], tb[5] = hi[2];
+    }
     for (int d = 0; d < 3; ++d) {
         sh[d][threadIdx.x] = lo[d];
         sh[3 + d][threadIdx.x] = hi[d];
@@ -345,7 +349,8 @@ __global__ __launch_bounds__(kCpThreads) void surface_cp_queue_kernel(Cloud q, C
                                                                      const int32_t *__restrict__ tri_orig, int64_t T,
                                                                      const double *__restrict__ boxes, double *__restrict__ cp,
                                                                      double *__restrict__ d2out, int32_t *__restrict__ tri_out,
-                                                                     const int32_t *warm_in, int32_t *pos_out /* may alias warm_in */) {
+                                                                     const int32_t *warm_in, int32_t *pos_out /* may alias warm_in */,
+                                                                     const double *__restrict__ tribox) {
     __shared__ double tbox[kTriTile][6];  // staged tile: the triangles' bounding boxes only (the exact test reads memory)
     constexpr int QPB = 64 / H;  // queries per workgroup
     __shared__ unsigned long long qbest[4][QPB];  // per wave and query: bits of the best squared distance so far
@@ -465,12 +470,17 @@ __global__ __launch_bounds__(kCpThreads) void surface_cp_queue_kernel(Cloud q, C
                 {
                     const int64_t tt = tb + threadIdx.x;
                     if (tt < T) {
-                        const int32_t a = tri[3 * tt], b = tri[3 * tt + 1], c = tri[3 * tt + 2];
-                        const double ax = v.x[a], ay = v.y[a], az = v.z[a], bx = v.x[b], by = v.y[b], bz = v.z[b], cx = v.x[c], cy = v.y[c],
-                                     cz = v.z[c];
                         double *bb = tbox[threadIdx.x];
-                        bb[0] = fmin(fmin(ax, bx), cx), bb[1] = fmin(fmin(ay, by), cy), bb[2] = fmin(fmin(az, bz), cz);
-                        bb[3] = fmax(fmax(ax, bx), cx), bb[4] = fmax(fmax(ay, by), cy), bb[5] = fmax(fmax(az, bz), cz);
+                        if (tribox) {  // precomputed by tri_tile_bbox_kernel: one contiguous read
+                            const double *sb = tribox + 6 * tt;
+                            bb[0] = sb[0], bb[1] = sb[1], bb[2] = sb[2], bb[3] = sb[3], bb[4] = sb[4], bb[5] = sb[5];
+                        } else {
+                            const int32_t a = tri[3 * tt], b = tri[3 * tt + 1], c = tri[3 * tt + 2];
+                            const double ax = v.x[a], ay = v.y[a], az = v.z[a], bx = v.x[b], by = v.y[b], bz = v.z[b], cx = v.x[c],
+                                         cy = v.y[c], cz = v.z[c];
+                            bb[0] = fmin(fmin(ax, bx), cx), bb[1] = fmin(fmin(ay, by), cy), bb[2] = fmin(fmin(az, bz), cz);
+                            bb[3] = fmax(fmax(ax, bx), cx), bb[4] = fmax(fmax(ay, by), cy), bb[5] = fmax(fmax(az, bz), cz);
+                        }
                     }
                 }
                 __syncthreads();
@@ -660,7 +670,7 @@ __global__ __launch_bounds__(kCpThreads) void self_intersect_queue_kernel(Cloud 
                                                                          const int32_t *__restrict__ tri, int64_t T,
                                                                          const double *__restrict__ boxes,
                                                                          const int32_t *__restrict__ skip,
-                                                                         int32_t *__restrict__ flag) {
+                                                                         int32_t *__restrict__ flag, const double *__restrict__ tribox) {
     __shared__ double tbox[kTriTile][6];
     constexpr int QPB = 64 / H;
     __shared__ int qhit[QPB];
@@ -739,12 +749,17 @@ __global__ __launch_bounds__(kCpThreads) void self_intersect_queue_kernel(Cloud 
             {
                 const int64_t tt = tb + threadIdx.x;
                 if (tt < T) {
-                    const int32_t a = tri[3 * tt], b = tri[3 * tt + 1], c = tri[3 * tt + 2];
-                    const double ax = v.x[a], ay = v.y[a], az = v.z[a], bx = v.x[b], by = v.y[b], bz = v.z[b], cx = v.x[c], cy = v.y[c],
-                                 cz = v.z[c];
                     double *bb = tbox[threadIdx.x];
-                    bb[0] = fmin(fmin(ax, bx), cx), bb[1] = fmin(fmin(ay, by), cy), bb[2] = fmin(fmin(az, bz), cz);
-                    bb[3] = fmax(fmax(ax, bx), cx), bb[4] = fmax(fmax(ay, by), cy), bb[5] = fmax(fmax(az, bz), cz);
+                    if (tribox) {  // precomputed by tri_tile_bbox_kernel
+                        const double *sb = tribox + 6 * tt;
+                        bb[0] = sb[0], bb[1] = sb[1], bb[2] = sb[2], bb[3] = sb[3], bb[4] = sb[4], bb[5] = sb[5];
+                    } else {
+                        const int32_t a = tri[3 * tt], b = tri[3 * tt + 1], c = tri[3 * tt + 2];
+                        const double ax = v.x[a], ay = v.y[a], az = v.z[a], bx = v.x[b], by = v.y[b], bz = v.z[b], cx = v.x[c], cy = v.y[c],
+                                     cz = v.z[c];
+                        bb[0] = fmin(fmin(ax, bx), cx), bb[1] = fmin(fmin(ay, by), cy), bb[2] = fmin(fmin(az, bz), cz);
+                        bb[3] = fmax(fmax(ax, bx), cx), bb[4] = fmax(fmax(ay, by), cy), bb[5] = fmax(fmax(az, bz), cz);
+                    }
                 }
             }
             __syncthreads();
@@ -1020,9 +1035,9 @@ void launch_vertex_normals(gingr_ctx *ctx, const int32_t *adj_ptr, const int32_t
     hipLaunchKernelGGL(vertex_normals_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, adj_ptr, adj_tri, cn,
                        T, n, vn);
 }
-void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *boxes) {
+void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *boxes, double *tribox) {
     if (T <= 0) return;
-    hipLaunchKernelGGL(tri_tile_bbox_kernel, dim3((unsigned)ceil_div(T, kTriTile)), dim3(256), 0, ctx->stream, v, tri, T, boxes);
+    hipLaunchKernelGGL(tri_tile_bbox_kernel, dim3((unsigned)ceil_div(T, kTriTile)), dim3(256), 0, ctx->stream, v, tri, T, boxes, tribox);
 }
 // copies of every query held per workgroup (see surface_cp_kernel); default from the number of queries
 static int surface_h(int64_t nq) {
@@ -1036,7 +1051,8 @@ void launch_barycentric(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri_by_
     hipLaunchKernelGGL(barycentric_kernel, dim3((unsigned)ceil_div(q.n, 256)), dim3(256), 0, ctx->stream, q, v, tri_by_orig, tri_id, bary);
 }
 void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T,
-                                  const double *boxes, double *cp_soa, double *d2, int32_t *tri_out, int32_t *warm, bool warm_valid) {
+                                  const double *boxes, double *cp_soa, double *d2, int32_t *tri_out, int32_t *warm, bool warm_valid,
+                                  const double *tribox) {
     // queries per workgroup = 64 / H (developer knob GINGR_SURFACE_H = 1 | 2 | 4 | 8 | 16).  The kernel is bound by its longest
     // workgroups: fewer queries per workgroup = more, shorter workgroups and a tighter query box for the tile pruning.
     const int h = surface_h(q.n);
@@ -1051,7 +1067,7 @@ void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_
         const int32_t *win = (warm && warm_valid && warm_env) ? warm : (const int32_t *)nullptr;
         auto goq = [&](auto kern, int qpb) {
             hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(q.n, qpb)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig, T, boxes,
-                               cp_soa, d2, tri_out, win, warm);
+                               cp_soa, d2, tri_out, win, warm, (getenv("GINGR_TRIBOX") && !atoi(getenv("GINGR_TRIBOX"))) ? (const double *)nullptr : tribox);
         };
         if (h == 1)
             goq(surface_cp_queue_kernel<1>, 64);
@@ -1085,7 +1101,7 @@ void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const in
     hipLaunchKernelGGL(dist_stats_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, partial, out4);
 }
 void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, const int32_t *tri, int64_t T, const double *boxes,
-                           const int32_t *skip, int32_t *flag) {
+                           const int32_t *skip, int32_t *flag, const double *tribox) {
     const int h = surface_h(fit.n);
     auto go = [&](auto kern, int qpb) {
         hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(fit.n, qpb)), dim3(kCpThreads), 0, ctx->stream, fit, cp_soa, fit, tri, T, boxes,
@@ -1093,16 +1109,22 @@ void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, cons
     };
     static const int queued = getenv("GINGR_SURFACE_QUEUE") ? atoi(getenv("GINGR_SURFACE_QUEUE")) : 1;
     if (queued) {
+        static const int tb_env = getenv("GINGR_TRIBOX") ? atoi(getenv("GINGR_TRIBOX")) : 1;
+        const double *tbx = tb_env ? tribox : (const double *)nullptr;
+        auto goq = [&](auto kern, int qpb) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(fit.n, qpb)), dim3(kCpThreads), 0, ctx->stream, fit, cp_soa, fit, tri, T,
+                               boxes, skip, flag, tbx);
+        };
         if (h == 1)
-            go(self_intersect_queue_kernel<1>, 64);
+            goq(self_intersect_queue_kernel<1>, 64);
         else if (h == 2)
-            go(self_intersect_queue_kernel<2>, 32);
+            goq(self_intersect_queue_kernel<2>, 32);
         else if (h == 8)
-            go(self_intersect_queue_kernel<8>, 8);
+            goq(self_intersect_queue_kernel<8>, 8);
         else if (h == 16)
-            go(self_intersect_queue_kernel<16>, 4);
+            goq(self_intersect_queue_kernel<16>, 4);
         else
-            go(self_intersect_queue_kernel<4>, 16);
+            goq(self_intersect_queue_kernel<4>, 16);
         return;
     }
     if (h == 1)
