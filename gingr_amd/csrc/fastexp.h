@@ -25,10 +25,9 @@
 
 #include <hip/hip_runtime.h>
 
-// Table sizes: TB = 11 (2048 entries, 16 KB: gauss_block, GPMM builder, the MFMA experiment) and TB = 13 (8192 entries,
-// 64 KB: the two CPD passes).  With 8192 entries the byte offset of T[k & 8191] is ((k << 3) & 0xFFFF): ONE SDWA shift
-// (v_lshlrev_b32_sdwa ... dst_sel:WORD_0) instead of v_and + v_lshl, and the economised degree-2 polynomial is good to
-// 3.2e-15 (tools/gen_exp_table.py prints the constants).
+// Table size: TB = 11 (2048 entries, 16 KB).  An 8192-entry table (byte offset of T[k & 8191] by ONE SDWA shift, economised degree-2
+// polynomial good to 3.2e-15) was used by the CPD passes in round 1 and lost to its LDS footprint once the floor form below got the
+// one-instruction offset with 2048 entries; tools/gen_exp_table.py still prints its constants.
 #define GINGR_EXP_TABLE 2048
 #define GINGR_EXP_TABLE_LOG2 11
 #define GINGR_EXP_MAGIC 6755399441055744.0    /* 1.5 * 2^52 */
@@ -42,25 +41,14 @@ struct ExpTab<11> {
     static constexpr double C3 = 6.46152867293236500e-12;    // (ln2/2048)^3/6
     static constexpr double C1_D2 = 3.384507729693224e-04;   // C1 + C3 * 3/16: minimax degree 2 on |f| <= 1/2 (2.0e-13)
 };
-template <>
-struct ExpTab<13> {
-    static constexpr double C1 = 8.461269293944645e-05;      // ln2/8192
-    static constexpr double C2 = 3.5796539032325256e-09;
-    static constexpr double C3 = 1.0096138551456822e-13;
-    static constexpr double C1_D2 = 8.461269295837671e-05;   // economised degree 2: 3.2e-15
-};
-
 __device__ static const double gingr_exp_table_rom[2048] = {
 #include "exp_table.inc"
 };
-__device__ static const double gingr_exp_table8k_rom[8192] = {
-#include "exp_table8k.inc"
-};
-
 // copy T[j] = 2^(j/2^TB) into LDS; every thread of the block must call it, followed by __syncthreads()
 template <int TB = 11>
 __device__ __forceinline__ void fastexp_table_init(double *T) {
-    const double *rom = TB == 13 ? gingr_exp_table8k_rom : gingr_exp_table_rom;
+    static_assert(TB == 11, "one table size");
+    const double *rom = gingr_exp_table_rom;
     for (int j = threadIdx.x + threadIdx.y * blockDim.x; j < (1 << TB); j += blockDim.x * blockDim.y) T[j] = rom[j];
 }
 
@@ -77,16 +65,7 @@ __device__ __forceinline__ double fastexp2_core(double tm, double f, const doubl
     } else {
         q = __builtin_fma(f, ExpTab<TB>::C2, ExpTab<TB>::C1_D2);
     }
-    double tj;
-    if (TB == 13) {
-        unsigned off;  // ((lo << 3) & 0xFFFF) = 8 * (k & 8191): the 16-bit destination select does the masking
-        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD"
-            : "=v"(off)
-            : "v"(3u), "v"(lo));
-        tj = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(T) + off);
-    } else {
-        tj = T[lo & ((1u << TB) - 1)];
-    }
+    const double tj = T[lo & ((1u << TB) - 1)];
     const double fq = f * q;
     const double r = __builtin_fma(tj, fq, tj);
     return __builtin_ldexp(r, e);
