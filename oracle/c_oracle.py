@@ -41,6 +41,8 @@ def lib():
         L.oracle_gauss_block.argtypes = [i64, i64, dp, dp, ctypes.c_double, ctypes.c_double, dp]
         L.oracle_gauss_block.restype = None
         L.oracle_num_threads.restype = ctypes.c_int
+        L.oracle_mesh_closest_point.argtypes = [i64, dp, i64, dp, ctypes.POINTER(ctypes.c_int32), dp, dp, ctypes.POINTER(ctypes.c_int32)]
+        L.oracle_mesh_closest_point.restype = None
         _LIB = L
     return _LIB
 
@@ -104,3 +106,15 @@ def gauss_block(A, B, sigma: float, scaling: float):
     out = np.empty((A.shape[0], B.shape[0]))
     lib().oracle_gauss_block(A.shape[0], B.shape[0], _p(A), _p(B), sigma, scaling, _p(out))
     return out
+
+
+def mesh_closest_point(points, verts, tris):
+    """closestPointOnSurface of every row of `points` on the mesh (verts, tris), brute force in C:
+    (closest points (K,3), squared distances (K,), triangle index (K,)); ties -> lowest triangle index."""
+    p, v = _c(points), _c(verts)
+    t = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+    K = p.shape[0]
+    cp, d2, tid = np.empty((K, 3)), np.empty(K), np.empty(K, dtype=np.int32)
+    lib().oracle_mesh_closest_point(K, _p(p), t.shape[0], _p(v), t.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _p(cp), _p(d2),
+                                    tid.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    return cp, d2, tid

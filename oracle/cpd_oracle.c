@@ -172,3 +172,67 @@ void oracle_gauss_block(int64_t na, int64_t nb, const double *A, const double *B
         for (int64_t j = 0; j < nb; ++j)
             out[i * nb + j] = scaling * exp(-norm2_3(A + 3 * i, B + 3 * j) / (sigma * sigma));
 }
+
+/* ---- closest point on a triangle mesh, brute force (restates oracle/gingr_oracle.py:closest_point_on_triangles / mesh_closest_point:
+ * Ericson, Real-Time Collision Detection 5.1.5, the region tests in the numpy version's order of precedence; [SCALISMO]
+ * closestPointOnSurface, ties -> lowest triangle index).  verts [3V] / tris [3T] as in the mesh files; out_cp [3K], out_d2 [K],
+ * out_tri [K].  Lets the tests check the device scan on samples of full-size meshes, where the numpy version is too slow. */
+static void closest_on_triangle(const double *p, const double *a, const double *b, const double *c, double *out) {
+    double ab[3], ac[3], ap[3], bp[3], cp[3];
+    for (int d = 0; d < 3; ++d) {
+        ab[d] = b[d] - a[d];
+        ac[d] = c[d] - a[d];
+        ap[d] = p[d] - a[d];
+        bp[d] = p[d] - b[d];
+        cp[d] = p[d] - c[d];
+    }
+#define DOT3(u, v) (((u)[0] * (v)[0] + (u)[1] * (v)[1]) + (u)[2] * (v)[2])
+    const double d1 = DOT3(ab, ap), d2 = DOT3(ac, ap), d3 = DOT3(ab, bp), d4 = DOT3(ac, bp), d5 = DOT3(ab, cp), d6 = DOT3(ac, cp);
+#undef DOT3
+    const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    if (d1 <= 0.0 && d2 <= 0.0) { out[0] = a[0], out[1] = a[1], out[2] = a[2]; return; }
+    if (d3 >= 0.0 && d4 <= d3) { out[0] = b[0], out[1] = b[1], out[2] = b[2]; return; }
+    if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) {
+        const double v = d1 / (d1 - d3);
+        for (int d = 0; d < 3; ++d) out[d] = a[d] + ab[d] * v;
+        return;
+    }
+    if (d6 >= 0.0 && d5 <= d6) { out[0] = c[0], out[1] = c[1], out[2] = c[2]; return; }
+    if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) {
+        const double w = d2 / (d2 - d6);
+        for (int d = 0; d < 3; ++d) out[d] = a[d] + ac[d] * w;
+        return;
+    }
+    if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) {
+        const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        for (int d = 0; d < 3; ++d) out[d] = b[d] + (c[d] - b[d]) * w;
+        return;
+    }
+    const double denom = 1.0 / (va + vb + vc);
+    const double v = vb * denom, w = vc * denom;
+    for (int d = 0; d < 3; ++d) out[d] = a[d] + ab[d] * v + ac[d] * w;
+}
+
+void oracle_mesh_closest_point(int64_t K, const double *points, int64_t T, const double *verts, const int32_t *tris, double *out_cp,
+                               double *out_d2, int32_t *out_tri) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < K; ++i) {
+        const double *p = points + 3 * i;
+        double best = INFINITY, bp[3] = {0, 0, 0};
+        int32_t bt = -1;
+        for (int64_t t = 0; t < T; ++t) {
+            double q[3];
+            closest_on_triangle(p, verts + 3 * (int64_t)tris[3 * t], verts + 3 * (int64_t)tris[3 * t + 1], verts + 3 * (int64_t)tris[3 * t + 2], q);
+            const double dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
+            const double dist = (dx * dx + dy * dy) + dz * dz;
+            if (dist < best) {  /* NaN (zero-area triangle in the interior branch) never wins; first minimum = lowest index */
+                best = dist;
+                bt = (int32_t)t;
+                bp[0] = q[0], bp[1] = q[1], bp[2] = q[2];
+            }
+        }
+        out_cp[3 * i] = bp[0], out_cp[3 * i + 1] = bp[1], out_cp[3 * i + 2] = bp[2];
+        out_d2[i] = best;
+        out_tri[i] = bt;
+    }
+}

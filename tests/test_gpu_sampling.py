@@ -283,3 +283,26 @@ def test_full_size_surface_scan_properties(ctx):
     radial = np.abs(np.linalg.norm(p, axis=1) - 50.0)
     assert mx <= radial.max() + 50.0 * 2e-3               # the facets lie within 0.2 % of the sphere at this subdivision
     assert s >= radial.sum() - 20000 * 50.0 * 2e-3
+
+
+def test_full_size_surface_scan_against_the_brute_force_checker(ctx):
+    """82k triangles / 41k vertices (the surface-ICP benchmark size): the device scan (tile / quarter boxes, pair queue, tie rule)
+    against the C checker's brute force over ALL triangles, for 4 000 sampled queries: same closest points, the same squared
+    distances bit for bit where the winning triangle is the same, the same triangle unless two triangles are exactly as close."""
+    from oracle import c_oracle as co
+    v, f = _icosphere(6)
+    rng = np.random.default_rng(9)
+    v = v * 50.0 * (1.0 + 0.03 * np.sin(3.0 * v[:, :1]) * np.cos(2.0 * v[:, 1:2]))          # bumpy: not every facet equidistant
+    n = 4000
+    p = v[rng.permutation(v.shape[0])[:n]] * (1.0 + rng.uniform(-0.06, 0.08, (n, 1))) + rng.normal(0, 0.3, (n, 3))
+    cp, d2, tri, bary = ctx.mesh_closest_points(p, v, f)
+    ocp, od2, otri = co.mesh_closest_point(p, v, f)
+    assert np.abs(cp - ocp).max() < 1e-10
+    assert np.abs(d2 - od2).max() <= 1e-12 * od2.max()
+    same = tri == otri
+    assert same.mean() > 0.95 and np.array_equal(d2[same], od2[same])
+    # a different triangle only where both are (numerically) as close: shared edge / vertex of the two
+    assert np.all(np.abs(d2[~same] - od2[~same]) <= 1e-12 * (1.0 + od2[~same]))
+    # barycentric weights reproduce the point on the reported triangle
+    rec = (bary[:, :, None] * v[f[tri]]).sum(1)
+    assert np.abs(rec - cp).max() < 1e-9

@@ -458,3 +458,24 @@ def test_nicp_known_answers():
     ul = np.array([[0.0, 0.0, 12.0]])
     gotL, _, lmL = go.nicp_iteration_a(v, t, tgt, t, e, ids, ul, 0.01, 100.0)
     assert np.allclose(lmL[0], ul[0], atol=1e-3) and np.allclose(gotL[4], lmL[0])
+
+
+def test_c_mesh_closest_point_equals_the_numpy_restatement():
+    """oracle/cpd_oracle.c:oracle_mesh_closest_point (brute force, used to check the device scan on full-size meshes) against
+    gingr_oracle.mesh_closest_point: same points, distances and tie rule, bit for bit."""
+    from scipy.spatial import ConvexHull
+    rng = np.random.default_rng(12)
+    v = rng.normal(size=(80, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v *= 10.0
+    t = ConvexHull(v).simplices
+    P = np.concatenate([rng.normal(size=(150, 3)) * 12.0, v[:20], (v[t[:10, 0]] + v[t[:10, 1]]) / 2.0])   # off-surface, vertices, edge midpoints
+    cp, d2, tid = co.mesh_closest_point(P, v, t)
+    ocp, od2 = go.mesh_closest_point(P, v, t)
+    assert np.array_equal(cp, ocp) and np.array_equal(d2, od2)
+    A, B, C = v[t[:, 0]], v[t[:, 1]], v[t[:, 2]]
+    for i in range(P.shape[0]):                                    # the reported triangle is the first minimum
+        q = go.closest_point_on_triangles(P[i], A, B, C)
+        dd = q - P[i]
+        dist = dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1] + dd[:, 2] * dd[:, 2]
+        assert tid[i] == int(np.argmin(dist))
