@@ -225,3 +225,89 @@ def test_reversed_correspondence_direction(ctx, method):
     pairs = algo.getCorrespondence(state)
     assert np.array_equal(pairs.pids, otid[ow == 1.0]) and np.array_equal(pairs.points, target[ow == 1.0])
     algo.close()
+
+
+def _icosphere(level):
+    t = (1.0 + 5 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1),
+         (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = [np.asarray(p, dtype=np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(level):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[key] = len(v) - 1
+            return cache[key]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.asarray(v), np.asarray(f, dtype=np.int32)
+
+
+def test_benchmark_size_correspondence_against_sampled_oracle(ctx):
+    """41k vertices / 82k triangles with a hole (boundary) in the target: the whole correspondence (closest surface point,
+    nearest target vertex, boundary / opposite-normal / self-intersection rejections) of the device against the oracle's rules
+    evaluated for 1 200 sampled template vertices -- closest points through the C brute force, line tests through the numpy
+    restatement over ALL 82k template triangles."""
+    import gingr_amd as ga
+    from oracle import c_oracle as co
+    verts, cells = _icosphere(6)
+    ref = verts * 80.0
+    bump = 1.0 + 0.08 * np.sin(3 * verts[:, 0]) * np.cos(2 * verts[:, 1]) + 0.05 * np.sin(5 * verts[:, 2])
+    c, s = np.cos(0.05), np.sin(0.05)
+    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    tgt = (ref * bump[:, None]) @ R.T + np.array([1.5, -1.0, 0.5])
+    tcells = cells[~np.all(verts[cells][:, :, 2] > 0.93, axis=1)]              # a hole around the north pole: boundary vertices
+    M = ref.shape[0]
+    rng = np.random.default_rng(3)
+    model = ga.PointDistributionModel(ref, np.zeros_like(ref), np.linalg.qr(rng.normal(size=(3 * M, 4)))[0], np.ones(4), cells=cells)
+    algo = ga.IcpRegistration(ctx)
+    cfg = ga.IcpConfiguration(maxIterations=10, initialSigma=10.0, endSigma=1.0, correspondenceMethod="TriangularClosestPoint")
+    state = algo.createInitialState(model, tgt, cfg, targetCells=tcells)
+    cp, w = algo.surfaceCorrespondence(state)
+    algo.close()
+    # oracle on a sample (go.surface_correspondence, ClosestPointRegistrator.scala:75-100, restricted to `ids`)
+    ids = np.sort(np.concatenate([rng.choice(M, 1000, replace=False), np.flatnonzero(verts[:, 2] > 0.9)[:200]]))
+    ocp, od2, _ = co.mesh_closest_point(ref[ids], tgt, tcells)
+    assert np.abs(cp[ids] - ocp).max() < 1e-9
+    nn_idx = co.nn(ocp, tgt)[0]
+    bnd = go.boundary_vertices(tgt.shape[0], tcells)
+    cn_t, cn_g = go.cell_normals(ref, cells), go.cell_normals(tgt, tcells)
+    n_tmpl, n_tgt = np.zeros_like(ref), np.zeros_like(tgt)
+    cnt_t, cnt_g = np.zeros(M), np.zeros(tgt.shape[0])
+    for k in range(3):                                                       # vertex_normals, vectorised (same sums, index order)
+        np.add.at(n_tmpl, cells[:, k], cn_t), np.add.at(cnt_t, cells[:, k], 1.0)
+        np.add.at(n_tgt, tcells[:, k], cn_g), np.add.at(cnt_g, tcells[:, k], 1.0)
+    n_tmpl /= np.maximum(cnt_t, 1)[:, None]
+    n_tgt /= np.maximum(cnt_g, 1)[:, None]
+    want = np.ones(ids.shape[0])
+    unsure = np.zeros(ids.shape[0], dtype=bool)
+    for q, i in enumerate(ids):
+        j = int(nn_idx[q])
+        dotn = float(n_tmpl[i] @ n_tgt[j])
+        if bnd[j]:
+            want[q] = 0.0
+        elif dotn < 0:
+            want[q] = 0.0
+        else:
+            v = ref[i] - ocp[q]
+            ips = go.line_mesh_intersections(ref[i], v, ref, cells)
+            keep = np.any(ips != ref[i], axis=1)
+            if keep.any():
+                dd = ips[keep] - ref[i]
+                closest = np.sqrt((dd * dd).sum(1).min())
+                vn = np.sqrt(v @ v)
+                if closest < vn:
+                    want[q] = 0.0
+                unsure[q] = abs(closest - vn) < 1e-9 * max(vn, 1e-300)
+        unsure[q] |= abs(dotn) < 1e-12
+    assert bnd.any() and (want == 0).sum() > 20 and (want == 1).sum() > 500
+    differ = (w[ids] != want) & ~unsure
+    assert not differ.any(), (ids[differ][:10], w[ids][differ][:10], want[differ][:10])
