@@ -272,6 +272,17 @@ def test_benchmark_size_correspondence_against_sampled_oracle(ctx):
     cfg = ga.IcpConfiguration(maxIterations=10, initialSigma=10.0, endSigma=1.0, correspondenceMethod="TriangularClosestPoint")
     state = algo.createInitialState(model, tgt, cfg, targetCells=tcells)
     cp, w = algo.surfaceCorrespondence(state)
+    # the fused update at this size against the oracle's update from the SAME correspondences (its own Python search over 41k x 82k
+    # would take minutes; the correspondences themselves are checked on the sample below): Gram, solve, projections, pose, sigma2
+    st_in = oracle_state_of(state.general, 1)
+    new_state = algo.update(state)
+    mo = go.PDM(ref=ref, mean=np.zeros_like(ref), U=np.asarray(model.basis), lam=np.ones(4))
+    pids = np.flatnonzero(w == 1.0)
+    st = go.update_from_observations(mo, st_in, pids, cp[pids], np.full(pids.shape[0], st_in.sigma2),
+                                     go.icp_update_sigma2(st_in.sigma2, 10.0, 1.0, 10), None)
+    assert new_state.general.status == st.status == 0
+    assert rel(new_state.general.fit, st.fit) < 1e-6 and abs(new_state.general.sigma2 - st.sigma2) < 1e-12
+    assert rel(new_state.general.modelParameters.shape, st.alpha) < 1e-5
     algo.close()
     # oracle on a sample (go.surface_correspondence, ClosestPointRegistrator.scala:75-100, restricted to `ids`)
     ids = np.sort(np.concatenate([rng.choice(M, 1000, replace=False), np.flatnonzero(verts[:, 2] > 0.9)[:200]]))
