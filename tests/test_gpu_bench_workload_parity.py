@@ -115,3 +115,25 @@ def test_fused_update_50k_two_logical_shards_against_oracle(ctx):
     assert rel(np.concatenate(fits), st1.fit) < 1e-5
     for s in shards:
         s.close()
+
+
+def test_fused_icp_update_at_bench_size_against_oracle(ctx):
+    """Point-cloud ICP at 50k <-> 50k (the secondary measurement of profiles/r02_icp_pointcloud_50k.json): one update from the state
+    after three device iterations against the oracle -- correspondences by the C checker's exact nearest neighbour (bit-exact
+    indices), GP part in numpy.  Covers the eigen-form posterior of the uniform-weight case at this size."""
+    from gingr_amd.sharded import ShardedFitter
+    y, x, model, mo = _workload(ctx, 50000, 100)
+    f = ShardedFitter(ctx, model, x)
+    f.set_state(np.zeros(mo.rank), 25.0)
+    f.update_icp(25.0, 1.0, 20, 3)
+    alpha, sc, fit = f.get_state()
+    st = _oracle_state(mo, alpha, sc, fit)
+    idx, d2, _ = co.nn(st.fit, x)
+    s2n = go.icp_update_sigma2(st.sigma2, 25.0, 1.0, 20)
+    st1 = go.update_from_observations(mo, st, np.arange(mo.M), x[idx], np.full(mo.M, st.sigma2), s2n, None)
+    f.update_icp(25.0, 1.0, 20, 1)
+    a1, sc1, fit1 = f.get_state()
+    assert sc1.status == st1.status == 0 and sc1.iteration == st1.iteration
+    assert rel(fit1, st1.fit) < 1e-5 and abs(sc1.sigma2 - st1.sigma2) <= 1e-12 * st1.sigma2 and rel(a1, st1.alpha) < 1e-4
+    assert np.allclose(sc1.euler, st1.euler, atol=1e-8) and np.allclose(sc1.translation, st1.translation, atol=1e-6)
+    f.close()
