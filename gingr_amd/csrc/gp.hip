@@ -2022,8 +2022,11 @@ void launch_posterior_solve_eig(gingr_ctx *ctx, int32_t r, int32_t rp, const dou
 int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *Stot,
                             const double *qte, double *fx, bool cached, double *work, double *out2, unsigned *sync, unsigned epoch) {
     const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
+    // the log-density kernels keep 14 KB of static LDS (mat-vec scratch) next to the bordered matrix: with rp = 128 the two exceed the
+    // 160 KB of a compute unit, so ranks above 112 take the global-workspace variants (the plain solve fits up to rp = 128)
+    const bool in_lds = rp <= 112;
     static const int split_env = getenv("GINGR_LOGPDF_SPLIT") ? atoi(getenv("GINGR_LOGPDF_SPLIT")) : 1;
-    if (!cached && r <= 128 && fx && sync && split_env) {  // the two factorisations side by side
+    if (!cached && in_lds && fx && sync && split_env) {  // the two factorisations side by side
         static size_t lds_granted = 48 * 1024;
         if (lds > lds_granted) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2035,7 +2038,7 @@ int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
         return GINGR_OK;
     }
     if (cached) {  // fx holds what an earlier launch for this state left
-        if (r <= 128) {
+        if (in_lds) {
             static size_t lds_granted = 48 * 1024;  // the attribute is per function, not per launch
             if (lds > lds_granted) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_cached_kernel<false>),
@@ -2050,7 +2053,7 @@ int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
         }
         return GINGR_OK;
     }
-    if (r <= 128) {
+    if (in_lds) {
         static size_t lds_granted = 48 * 1024;  // the attribute is per function, not per launch
         if (lds > lds_granted) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_lds_kernel<false>),
