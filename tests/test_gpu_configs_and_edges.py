@@ -89,7 +89,8 @@ def test_config5_replicas_are_independent_and_reproducible():
 
 
 # ------------------------------------------------------------------------------------------ ranks and sizes off the tile grid
-@pytest.mark.parametrize("M,N,rank", [(1, 1, 1), (3, 2, 1), (17, 5, 3), (130, 77, 17), (500, 450, 130), (260, 300, 64)])
+@pytest.mark.parametrize("M,N,rank", [(1, 1, 1), (3, 2, 1), (17, 5, 3), (130, 77, 17), (500, 450, 130), (260, 300, 64), (400, 380, 120),
+                                      (700, 650, 512)])
 def test_ragged_sizes_and_ranks(ctx, M, N, rank):
     """Sizes that are not multiples of any tile (1 point, rank 1, rank > 128 -> global-memory Cholesky + wide sweeps)."""
     import gingr_amd as ga
