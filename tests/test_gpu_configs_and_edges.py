@@ -244,3 +244,27 @@ def test_long_run_parity_does_not_drift(ctx):
     assert rel(state.general.fit, st.fit) < 1e-6
     assert rel(state.general.modelParameters.shape, st.alpha) < 1e-5
     algo.close()
+
+
+@pytest.mark.parametrize("rank", [1, 120, 512])
+def test_point_cloud_icp_at_the_rank_limits(ctx, rank):
+    """The uniform-weight posterior of point-cloud ICP comes from the model's eigen-decomposition of Q^T Q (cyclic Jacobi, at most
+    512 x 512): ranks 1, 120 (padded to 128) and 512 against the oracle's Cholesky-free numpy regression."""
+    import gingr_amd as ga
+    rng = np.random.default_rng(rank)
+    M = 600
+    ref = rng.normal(0, 30, (M, 3))
+    U, _ = np.linalg.qr(rng.normal(0, 1, (3 * M, rank)))
+    lam = np.sort(rng.uniform(1.0, 400.0, rank))[::-1].copy()
+    mo = go.PDM(ref=ref, mean=rng.normal(0, 0.1, (M, 3)), U=U, lam=lam)
+    target = mo.instance(rng.normal(0, 0.5, rank)) + rng.normal(0, 0.2, (M, 3))
+    algo = ga.IcpRegistration(ctx)
+    cfg = ga.IcpConfiguration(maxIterations=10, initialSigma=20.0, endSigma=1.0, correspondenceMethod="PointcloudClosestPoint")
+    state = algo.createInitialState(to_ga(mo), target, cfg)
+    st = go.initial_state(mo, state.general.sigma2)
+    for it in range(3):
+        state = algo.update(state)
+        st, _ = go.icp_update(mo, target, st, 20.0, 1.0, 10)
+        assert state.general.status == st.status == 0
+        assert rel(state.general.fit, st.fit) < 1e-6 and state.general.sigma2 == st.sigma2, (rank, it)
+    algo.close()

@@ -198,7 +198,7 @@ def test_failed_projection_at_iteration_zero_is_an_error(ctx):
     algo.close()
 
 
-@pytest.mark.parametrize("rank", [28, 120, 150])
+@pytest.mark.parametrize("rank", [28, 120, 150, 512])
 def test_transition_density_memo_slots_and_cached_factors(ctx, rank):
     """A Metropolis-Hastings step alternates between two states (GingrAlgorithm.scala:68 memoises computePosterior): the second
     memo slot brings a state's [G, rhs] back instead of recomputing it, and a state whose factors are on the device answers
