@@ -1,6 +1,7 @@
 // CPD affinity passes with the scaled squared distances produced by the f64 matrix pipe (gfx950).
 //
-// OPT-IN EXPERIMENT (GINGR_AFFINITY=mfma), parity-green but NOT faster than affinity.hip: measured on gfx950, f64 MFMA and
+// RECORD OF A CLOSED EXPERIMENT -- not built, not part of libgingr_hip.so (rounds 1-2 shipped it behind GINGR_AFFINITY=mfma; round 3
+// moved it here, the launch hooks in affinity.hip / common.h are gone).  Parity-green but NOT faster than affinity.hip: measured on gfx950, f64 MFMA and
 // f64 VALU instructions do not overlap (they share the double-precision hardware; profiles/r01_ubench_mfma_valu_overlap.txt),
 // so moving d2 to the matrix pipe only moves the time.  Kept as the evidence for DESIGN.md section 4.
 //
