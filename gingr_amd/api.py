@@ -97,6 +97,15 @@ class Context:
         _check(self.handle, self._lib.gingr_ctx_timing_read(self.handle, which, ctypes.byref(ms), ctypes.byref(n)), "timing_read")
         return ms.value, n.value
 
+    def nn_counting(self, on: bool = True):
+        """Diagnostics: count the distance tests the nearest-neighbour launches of this context really execute (clears the counter)."""
+        _check(self.handle, self._lib.gingr_ctx_nn_counting(self.handle, 1 if on else 0), "nn_counting")
+
+    def nn_tests(self) -> int:
+        n = c_int64()
+        _check(self.handle, self._lib.gingr_ctx_nn_tests(self.handle, ctypes.byref(n)), "nn_tests")
+        return int(n.value)
+
     # ---- stateless all-pairs operators -------------------------------------------------
     def cpd_stats(self, fit, target, sigma2: float, w: float = 0.0) -> dict:
         """CPD statistics of one affinity evaluation (CPD.scala:54-75,36,133-147), P never materialised."""

@@ -559,6 +559,30 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
     }
 }
 
+// centroid of a cloud into out[0..2] (single workgroup, fixed order)
+__global__ __launch_bounds__(1024) void cloud_centroid_kernel(Cloud c, double *__restrict__ out) {
+    __shared__ double sh[3][1024];
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int64_t i = threadIdx.x; i < c.n; i += 1024) {
+        sx += c.x[i];
+        sy += c.y[i];
+        sz += c.z[i];
+    }
+    sh[0][threadIdx.x] = sx;
+    sh[1][threadIdx.x] = sy;
+    sh[2][threadIdx.x] = sz;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st)
+            for (int d = 0; d < 3; ++d) sh[d][threadIdx.x] += sh[d][threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) {
+        const double v = sh[threadIdx.x][0] / (double)c.n;
+        out[threadIdx.x] = (v == v && fabs(v) < 1e300) ? v : 0.0;  // a non-finite centroid would poison every pair
+    }
+}
+
 // slot = max over the cloud of |x - cx|, |y - cy|, |z - cz| (ctr may be nullptr = origin).  Atomic max on the bit
 // pattern of a non-negative double: order independent, hence deterministic.  The slot must be zeroed before the launch.
 __global__ __launch_bounds__(256) void cloud_absmax_kernel(Cloud c, const double *__restrict__ ctr, double *__restrict__ slot) {
@@ -870,68 +894,113 @@ __global__ __launch_bounds__(kBlock, (PT >= 4 ? 3 : 4)) void cpd_rowstats_kernel
     }
 }
 
-// P1 / PX from chunk partials (ascending chunk order) plus per-block partials of
+// P1 / PX from chunk partials plus per-block partials of
 // Np = sum P1, trPXY = sum_i y_i . PX_i, yPy = sum_i P1_i |y_i|^2 over the local rows.
 // Always launched with kScalarBlocks workgroups; part[(1..3)*kScalarBlocks + block].
-// One row per thread (rows of a pass are consecutive: every load instruction reads 2 KB runs of one chunk plane); the four
-// planes' chunk sums are independent chains, so a thread keeps 4 loads in flight per chunk step.
+// A workgroup of 1024 threads takes 256 consecutive rows at a time: thread (g, row) adds the chunks of quarter g of the chunk range,
+// [g nch / 4, (g + 1) nch / 4), in ascending order -- every load instruction reads a 512-byte run of one chunk plane, the four planes
+// are independent chains, so a thread keeps 4 x 4 loads in flight -- and the four quarter sums of a row are combined as
+// (q0 + q1) + (q2 + q3): a fixed order.  (Round 2 used one thread per row over all chunks: the 30 chunks of a 6250-row shard were 8
+// dependent batches of loads, 9.5 us of pure latency; four threads per row need two.)
 // obs.weight != nullptr: the CPD observations of the rows (CPDCorrespondence.estimate + getUncertainty, CPD.scala:36-46,120-128)
 // are produced in the same pass -- weight_i = P1_i / (sigma2 lambda), e_i = weight_i (R^T (yhat_i - c - t) - (ref_i - c) - mean_i)
 // with yhat_i = y_i + (PX_i / P1_i - y_i); rows overridden by a landmark get weight 0 (GingrAlgorithm.scala:289-292).
-__global__ __launch_bounds__(256) void rowstats_reduce_kernel(const double *__restrict__ partial, int nchunks, Cloud fit,
-                                                              double *__restrict__ P1, double *__restrict__ PX,
-                                                              double *__restrict__ part, CpdObsArgs obs) {
+constexpr int kRowReduceThreads = 1024;
+__global__ __launch_bounds__(kRowReduceThreads) void rowstats_reduce_kernel(const double *__restrict__ partial, int nchunks, Cloud fit,
+                                                                            double *__restrict__ P1, double *__restrict__ PX,
+                                                                            double *__restrict__ part, CpdObsArgs obs) {
     __shared__ double sh[256];
+    __shared__ double quart[3][4][256];  // [quarter 1..3][plane][row]
     const int64_t M = fit.n;
+    const int row = threadIdx.x & 255, g = threadIdx.x >> 8;
+    const int c0 = (int)((int64_t)g * nchunks / 4), c1 = (int)((int64_t)(g + 1) * nchunks / 4);
     double np = 0.0, tr = 0.0, ypy = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)kScalarBlocks * 256) {
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < M; i0 += (int64_t)kScalarBlocks * 256) {
+        const int64_t i = i0 + row;
+        const bool ok = i < M;
         double v[4] = {0.0, 0.0, 0.0, 0.0};
-        const double *b = partial + i;
+        double yx = 0.0, yy = 0.0, yz = 0.0, rf[3] = {0.0, 0.0, 0.0}, mn[3] = {0.0, 0.0, 0.0};
+        int masked = 0;
+        if (ok) {
+            if (g == 0) {  // what the finishing thread of the row needs besides the sums: requested together with them
+                yx = fit.x[i];
+                yy = fit.y[i];
+                yz = fit.z[i];
+                if (obs.weight) {
+                    masked = obs.lm_mask ? obs.lm_mask[i] : 0;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        rf[d] = obs.ref[d * M + i];
+                        mn[d] = obs.mean[d * M + i];
+                    }
+                }
+            }
+            const double *b = partial + i;
 #pragma unroll 4
-        for (int c = 0; c < nchunks; ++c) {
-            const double *bc = b + (int64_t)c * 4 * M;
-            v[0] += bc[0];
-            v[1] += bc[M];
-            v[2] += bc[2 * M];
-            v[3] += bc[3 * M];
-        }
-        P1[i] = v[0];
-        PX[i] = v[1];
-        PX[M + i] = v[2];
-        PX[2 * M + i] = v[3];
-        const double yx = fit.x[i], yy = fit.y[i], yz = fit.z[i];
-        if (obs.weight) {
-            if (obs.lm_mask && obs.lm_mask[i]) {
-                obs.weight[i] = 0.0;
-                obs.evec[i] = obs.evec[M + i] = obs.evec[2 * M + i] = 0.0;
-            } else {
-                const double p1inv = 1.0 / v[0];                                                  // CPD.scala:37
-                const double ox = yx + (v[1] * p1inv - yx), oy = yy + (v[2] * p1inv - yy), oz = yz + (v[3] * p1inv - yz);
-                const double wgt = 1.0 / (obs.sigma2[0] * obs.lambda * p1inv);                     // CPD.scala:126
-                const double *R = obs.R;
-                const double dx = ox - obs.center[0] - obs.t[0], dy = oy - obs.center[1] - obs.t[1], dz = oz - obs.center[2] - obs.t[2];
-                const double ex = R[0] * dx + R[3] * dy + R[6] * dz - (obs.ref[i] - obs.center[0]) - obs.mean[i];
-                const double ey = R[1] * dx + R[4] * dy + R[7] * dz - (obs.ref[M + i] - obs.center[1]) - obs.mean[M + i];
-                const double ez = R[2] * dx + R[5] * dy + R[8] * dz - (obs.ref[2 * M + i] - obs.center[2]) - obs.mean[2 * M + i];
-                obs.weight[i] = wgt;
-                obs.evec[i] = wgt * ex;
-                obs.evec[M + i] = wgt * ey;
-                obs.evec[2 * M + i] = wgt * ez;
+            for (int c = c0; c < c1; ++c) {
+                const double *bc = b + (int64_t)c * 4 * M;
+                v[0] += bc[0];
+                v[1] += bc[M];
+                v[2] += bc[2 * M];
+                v[3] += bc[3 * M];
             }
         }
-        np += v[0];
-        tr += yx * v[1] + yy * v[2] + yz * v[3];
-        ypy += v[0] * (yx * yx + yy * yy + yz * yz);
+        if (g > 0) {
+#pragma unroll
+            for (int pl = 0; pl < 4; ++pl) quart[g - 1][pl][row] = v[pl];
+        }
+        __syncthreads();
+        if (g == 0 && ok) {
+#pragma unroll
+            for (int pl = 0; pl < 4; ++pl) v[pl] = (v[pl] + quart[0][pl][row]) + (quart[1][pl][row] + quart[2][pl][row]);
+            P1[i] = v[0];
+            PX[i] = v[1];
+            PX[M + i] = v[2];
+            PX[2 * M + i] = v[3];
+            if (obs.weight) {
+                if (masked) {
+                    obs.weight[i] = 0.0;
+                    obs.evec[i] = obs.evec[M + i] = obs.evec[2 * M + i] = 0.0;
+                } else {
+                    const double p1inv = 1.0 / v[0];                                                  // CPD.scala:37
+                    const double ox = yx + (v[1] * p1inv - yx), oy = yy + (v[2] * p1inv - yy), oz = yz + (v[3] * p1inv - yz);
+                    const double wgt = 1.0 / (obs.sigma2[0] * obs.lambda * p1inv);                     // CPD.scala:126
+                    const double *R = obs.R;
+                    const double dx = ox - obs.center[0] - obs.t[0], dy = oy - obs.center[1] - obs.t[1], dz = oz - obs.center[2] - obs.t[2];
+                    const double ex = R[0] * dx + R[3] * dy + R[6] * dz - (rf[0] - obs.center[0]) - mn[0];
+                    const double ey = R[1] * dx + R[4] * dy + R[7] * dz - (rf[1] - obs.center[1]) - mn[1];
+                    const double ez = R[2] * dx + R[5] * dy + R[8] * dz - (rf[2] - obs.center[2]) - mn[2];
+                    obs.weight[i] = wgt;
+                    obs.evec[i] = wgt * ex;
+                    obs.evec[M + i] = wgt * ey;
+                    obs.evec[2 * M + i] = wgt * ez;
+                }
+            }
+            np += v[0];
+            tr += yx * v[1] + yy * v[2] + yz * v[3];
+            ypy += v[0] * (yx * yx + yy * yy + yz * yz);
+        }
+        __syncthreads();  // quart is rewritten by the next group of rows
     }
-    const double a = block_sum<256>(np, sh);
-    __syncthreads();
-    const double b = block_sum<256>(tr, sh);
-    __syncthreads();
-    const double c = block_sum<256>(ypy, sh);
+    // the scalar partials of the block: only the 256 finishing threads hold values
+    double tot[3] = {0.0, 0.0, 0.0};
+    const double vals[3] = {np, tr, ypy};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        if (g == 0) sh[row] = vals[q];
+        __syncthreads();
+#pragma unroll
+        for (int st = 128; st > 0; st >>= 1) {
+            if (g == 0 && row < st) sh[row] += sh[row + st];
+            __syncthreads();
+        }
+        tot[q] = sh[0];
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        part[kScalarBlocks + blockIdx.x] = a;
-        part[2 * kScalarBlocks + blockIdx.x] = b;
-        part[3 * kScalarBlocks + blockIdx.x] = c;
+        part[kScalarBlocks + blockIdx.x] = tot[0];
+        part[2 * kScalarBlocks + blockIdx.x] = tot[1];
+        part[3 * kScalarBlocks + blockIdx.x] = tot[2];
     }
 }
 __global__ __launch_bounds__(256) void cpd_scalars_finish_kernel(const double *__restrict__ part, double *__restrict__ scalars,
@@ -966,10 +1035,15 @@ __device__ __forceinline__ double norm2_exact(double dx, double dy, double dz) {
 constexpr int kNNThreads = 64;   // queries per workgroup
 constexpr int kNNBlock = 256;    // threads per workgroup
 
+// COUNT (diagnostics, gingr_ctx_nn_counting): *tests += the distance tests the launch really executed (64 lanes x the entries of every
+// scanned quarter), one integer atomic per wave at its end -- the denominator of the kernel's roofline figure after pruning.
+template <bool COUNT>
 __global__ __launch_bounds__(kNNBlock) void nn_kernel(Cloud q, Cloud tgt, const int32_t *__restrict__ orig,
                                                       const double *__restrict__ tgt_boxes, int64_t cols_per_chunk,
                                                       double *__restrict__ pd2, int32_t *__restrict__ pidx,
-                                                      int32_t *__restrict__ porig, const int32_t *__restrict__ warm) {
+                                                      int32_t *__restrict__ porig, const int32_t *__restrict__ warm,
+                                                      unsigned long long *tests) {
+    unsigned long long scanned = 0;  // wave-uniform
     __shared__ P4 tile[kTile];
     __shared__ double sbest[4][kNNThreads], sorig[4][kNNThreads];
     __shared__ int32_t sidx[4][kNNThreads];
@@ -1059,6 +1133,7 @@ __global__ __launch_bounds__(kNNBlock) void nn_kernel(Cloud q, Cloud tgt, const 
                 __syncthreads();
                 if (wave_needs) {
                     const int cnt = (int)min((int64_t)64, j1 - q0);
+                    if (COUNT) scanned += (unsigned long long)cnt * 64ull;
 #pragma unroll 4
                     for (int jj = 0; jj < cnt; ++jj) {
                         const P4 p = tile[64 * wave + jj];
@@ -1096,6 +1171,7 @@ __global__ __launch_bounds__(kNNBlock) void nn_kernel(Cloud q, Cloud tgt, const 
         pidx[(int64_t)blockIdx.y * q.n + i] = sidx[w][lane];
         porig[(int64_t)blockIdx.y * q.n + i] = (int32_t)(wo < 2147483648.0 ? wo : -1.0);
     }
+    if (COUNT && lane == 0 && scanned) atomicAdd(tests, scanned);
 }
 
 __global__ void nn_reduce_kernel(const double *__restrict__ pd2, const int32_t *__restrict__ pidx,
@@ -1359,16 +1435,14 @@ inline int rowstats_tiles_override() {
 int64_t cpd_colsum_ws_doubles(int64_t M, int64_t N) {
     int nch;
     plan_chunks(N, 64 * kPT, M, &nch, colsum_tiles_override(), colsum_chunks_override(), resident_workgroups(0));
-    const int64_t a = (int64_t)nch * N, b = cpd_colsum_mfma_ws_doubles(M, N);
-    return a > b ? a : b;
+    return (int64_t)nch * N;
 }
 
 int64_t cpd_rowstats_ws_doubles(int64_t M, int64_t N) {
     int nch;
     plan_chunks(M, 64 * rowstats_pt(M), N, &nch, rowstats_tiles_override(), rowstats_chunks_override(),
                 resident_workgroups(rowstats_pt(M) == 2 ? 1 : 2));
-    const int64_t a = (int64_t)nch * 4 * M, b = cpd_rowstats_mfma_ws_doubles(M, N);
-    return a > b ? a : b;
+    return (int64_t)nch * 4 * M;
 }
 
 static void plan_nn(int64_t nq, int64_t nt_points, bool pruned, int *nchunks, int64_t *chunk_len);
@@ -1378,6 +1452,10 @@ int64_t nn_ws_bytes(int64_t M, int64_t N) {
     int64_t len;
     plan_nn(M, N, false, &nch, &len);  // the unpruned plan has the most chunks
     return (int64_t)nch * M * (sizeof(double) + 2 * sizeof(int32_t));
+}
+
+void launch_cloud_centroid(gingr_ctx *ctx, Cloud c, double *out3) {
+    hipLaunchKernelGGL(cloud_centroid_kernel, dim3(1), dim3(1024), 0, ctx->stream, c, out3);
 }
 
 void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, const double *ctr, double *slot) {
@@ -1398,9 +1476,7 @@ int launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sig
     int nch;
     {
         TimerScope ts(ctx, 0);
-        if (ctx->affinity_mfma) {
-            launch_cpd_colsum_mfma(ctx, fit, target, sigma2_dev, aux, ws, &nch);
-        } else {
+        {
             const ChunkPlan len = plan_chunks(target.n, 64 * kPT, fit.n, &nch, colsum_tiles_override(), colsum_chunks_override(),
                                               resident_workgroups(0));
             dim3 grid((unsigned)ceil_div(target.n, 64 * kPT), (unsigned)nch);
@@ -1437,9 +1513,7 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
     int nch;
     {
         TimerScope ts(ctx, 1);
-        if (ctx->affinity_mfma) {
-            launch_cpd_rowstats_mfma(ctx, fit, target, sigma2_dev, aux, inv_den, ws, &nch);
-        } else {
+        {
             const int pt = rowstats_pt(fit.n);
             const ChunkPlan len = plan_chunks(fit.n, 64 * pt, target.n, &nch, rowstats_tiles_override(), rowstats_chunks_override(),
                                               resident_workgroups(pt == 2 ? 1 : 2));
@@ -1470,7 +1544,7 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
     }
     CpdObsArgs none;
     memset(&none, 0, sizeof(none));
-    hipLaunchKernelGGL(rowstats_reduce_kernel, dim3(kScalarBlocks), dim3(256), 0, ctx->stream, ws, nch, fit, P1, PX_soa,
+    hipLaunchKernelGGL(rowstats_reduce_kernel, dim3(kScalarBlocks), dim3(kRowReduceThreads), 0, ctx->stream, ws, nch, fit, P1, PX_soa,
                        part, obs ? *obs : none);
     if (finish_scalars)  // otherwise the caller's phase-1 finalize kernel sums the block partials (cpd_scalar_partials_layout)
         hipLaunchKernelGGL(cpd_scalars_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, part, scalars_dev, xch8, contribute_xpx);
@@ -1503,8 +1577,15 @@ void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_
     int32_t *pidx = reinterpret_cast<int32_t *>(pd2 + (int64_t)nch * query.n);
     int32_t *porig = pidx + (int64_t)nch * query.n;
     dim3 grid((unsigned)ceil_div(query.n, kNNThreads), (unsigned)nch);
-    hipLaunchKernelGGL(nn_kernel, grid, dim3(kNNBlock), 0, ctx->stream, query, target, target_orig,
-                       pruned ? tgt_boxes : (const double *)nullptr, len, pd2, pidx, porig, warm);
+    {
+        TimerScope ts(ctx, 8);
+        if (ctx->nn_tests)
+            hipLaunchKernelGGL(nn_kernel<true>, grid, dim3(kNNBlock), 0, ctx->stream, query, target, target_orig,
+                               pruned ? tgt_boxes : (const double *)nullptr, len, pd2, pidx, porig, warm, ctx->nn_tests);
+        else
+            hipLaunchKernelGGL(nn_kernel<false>, grid, dim3(kNNBlock), 0, ctx->stream, query, target, target_orig,
+                               pruned ? tgt_boxes : (const double *)nullptr, len, pd2, pidx, porig, warm, (unsigned long long *)nullptr);
+    }
     hipLaunchKernelGGL(nn_reduce_kernel, dim3((unsigned)ceil_div(query.n, 256)), dim3(256), 0, ctx->stream, pd2, pidx, porig,
                        nch, query.n, idx, d2);
 }

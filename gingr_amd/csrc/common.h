@@ -12,7 +12,7 @@
 
 #include "../../include/gingr_hip.h"
 
-#define GINGR_TIMERS 6
+#define GINGR_TIMERS 10
 
 struct gingr_ctx {
     int device = 0;
@@ -27,12 +27,8 @@ struct gingr_ctx {
     };
     std::vector<Span> spans;     // recorded, not yet resolved
     std::vector<hipEvent_t> pool;  // recycled events
-    double t_ms[GINGR_TIMERS] = {0, 0, 0, 0, 0, 0};
-    int64_t t_n[GINGR_TIMERS] = {0, 0, 0, 0, 0, 0};
-    // all-pairs formulation: 0 = difference-based VALU kernels (affinity.hip, default), 1 = exponent arguments from the
-    // f64 matrix pipe (affinity_mfma.hip).  Measured on MI355X (profiles/r01_ubench_mfma_valu_overlap.txt): f64 MFMA and
-    // f64 VALU do not overlap (they share the DP hardware), so the MFMA form is not faster.  GINGR_AFFINITY=valu|mfma.
-    int affinity_mfma = 0;
+    double t_ms[GINGR_TIMERS] = {0};
+    int64_t t_n[GINGR_TIMERS] = {0};
     // exact-zero tile culling of the CPD passes (affinity.hip); GINGR_CULL=0 disables it (results must stay bit-identical)
     int cull = 1;
     // Culling regime of the CPD passes as the DEVICE last saw it (0 plain, 1 quarter-tile culling pays): pinned host word the
@@ -40,6 +36,8 @@ struct gingr_ctx {
     // variant.  Both variants compute bit-identical results, so a stale value only costs time.  Null: always the plain variant.
     int32_t *regime_host = nullptr, *regime_dev = nullptr;
     int fine_override = -1;  // GINGR_FINE_CULL=0|1 pins the variant (tests: both must give bit-identical results); -1: by regime
+    // diagnostics (gingr_ctx_nn_counting): device counter of the distance tests the nearest-neighbour launches really execute; null = off
+    unsigned long long *nn_tests = nullptr;
     // scratch kept across calls (grown on demand, never shrunk) so steady-state updates do not allocate
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -114,12 +112,6 @@ int64_t nn_ws_bytes(int64_t M, int64_t N);
 // accurate enough (affinity.hip: use_expansion).
 #define GINGR_AUX 8
 void launch_cloud_centroid(gingr_ctx *ctx, Cloud c, double *out3);
-int64_t cpd_colsum_mfma_ws_doubles(int64_t M, int64_t N);
-int64_t cpd_rowstats_mfma_ws_doubles(int64_t M, int64_t N);
-int launch_cpd_colsum_mfma(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux, double *ws,
-                           int *nchunks_out);
-int launch_cpd_rowstats_mfma(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
-                             const double *inv_den, double *ws, int *nchunks_out);
 void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, const double *ctr, double *slot);
 // boxes[tile] = {lo[3], hi[3]} of every 256-point tile of a cloud: input of the exact-zero tile culling
 // with absmax_slot != nullptr also *absmax_slot = max |coordinate - ctr| (same value launch_cloud_absmax produces); the slot

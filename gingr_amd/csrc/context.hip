@@ -78,7 +78,6 @@ int gingr_ctx_create(int device, gingr_ctx **out) {
         return GINGR_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
-    if (const char *m = getenv("GINGR_AFFINITY")) ctx->affinity_mfma = (strcmp(m, "mfma") == 0) ? 1 : 0;
     if (const char *m = getenv("GINGR_CULL")) ctx->cull = (strcmp(m, "0") == 0) ? 0 : 1;
     if (const char *m = getenv("GINGR_FINE_CULL")) ctx->fine_override = (strcmp(m, "1") == 0) ? 1 : (strcmp(m, "0") == 0 ? 0 : -1);
     void *hp = nullptr, *dp = nullptr;
@@ -103,6 +102,7 @@ void gingr_ctx_destroy(gingr_ctx *ctx) {
     timing_resolve(ctx);
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->nn_tests) (void)hipFree(ctx->nn_tests);
     if (ctx->regime_host) (void)hipHostFree(ctx->regime_host);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -137,6 +137,35 @@ int gingr_ctx_timing_read(gingr_ctx *ctx, int32_t which, double *total_ms, int64
     timing_resolve(ctx);
     if (total_ms) *total_ms = ctx->t_ms[which];
     if (launches) *launches = ctx->t_n[which];
+    return GINGR_OK;
+}
+
+int gingr_ctx_nn_counting(gingr_ctx *ctx, int32_t enable) {
+    if (!ctx) return GINGR_ERR_BAD_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (enable && !ctx->nn_tests) {
+        void *p = nullptr;
+        HIP_TRY(ctx, hipMalloc(&p, sizeof(unsigned long long)));
+        ctx->nn_tests = static_cast<unsigned long long *>(p);
+    }
+    if (ctx->nn_tests) HIP_TRY(ctx, hipMemset(ctx->nn_tests, 0, sizeof(unsigned long long)));
+    if (!enable && ctx->nn_tests) {
+        (void)hipFree(ctx->nn_tests);
+        ctx->nn_tests = nullptr;
+    }
+    return GINGR_OK;
+}
+
+int gingr_ctx_nn_tests(gingr_ctx *ctx, int64_t *tests) {
+    if (!ctx || !tests) return GINGR_ERR_BAD_ARGUMENT;
+    *tests = 0;
+    if (!ctx->nn_tests) return gingr_set_error(ctx, GINGR_ERR_STATE, "nn_tests: counting is off (gingr_ctx_nn_counting)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long v = 0;
+    HIP_TRY(ctx, hipMemcpy(&v, ctx->nn_tests, sizeof(v), hipMemcpyDeviceToHost));
+    *tests = (int64_t)v;
     return GINGR_OK;
 }
 

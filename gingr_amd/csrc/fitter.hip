@@ -473,7 +473,11 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
     }
     {
         const int32_t init = GINGR_RETRY_INIT;
-        HIP_TRY(ctx, hipMemcpy(f->retry, &init, sizeof(init), hipMemcpyHostToDevice));
+        if (hipMemcpy(f->retry, &init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            gingr_fitter_destroy(f);
+            return gingr_set_error(ctx, GINGR_ERR_HIP, "fitter_create: retry counter upload");
+        }
     }
     (void)hipMemsetAsync(f->lm_mask, 0, (size_t)M * sizeof(int32_t), ctx->stream);
     (void)hipMemsetAsync(f->alpha, 0, (size_t)rp * sizeof(double), ctx->stream);
@@ -1047,7 +1051,8 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
             // the posterior mean of the uniform-weight case comes from the model's eigen-decomposition (no factorisation); a sampled
             // proposal needs the Cholesky factor itself (its square root of the covariance is part of the parity contract)
             static const int eig_env = getenv("GINGR_EIG_SOLVE") ? atoi(getenv("GINGR_EIG_SOLVE")) : 1;
-            if (eig_env && icp && !f->icp_surface && !f->reversed && f->n_lm == 0 && !f->zrand_active && r <= 512)
+            const bool eig = eig_env && icp && !f->icp_surface && !f->reversed && f->n_lm == 0 && !f->zrand_active && r <= 512;
+            if (eig)
                 launch_posterior_solve_eig(ctx, r, rp, m->eigV, m->eigL, &f->st->sigma2, rhs, f->acoef, f->st);
             else
                 launch_posterior_solve(ctx, r, rp, G, rhs, f->zrand_active ? f->zrand : nullptr, f->work, f->acoef, f->st);
@@ -1133,6 +1138,38 @@ int gingr_fitter_update_icp_async(gingr_fitter *f, const gingr_icp_params *p, in
         for (int ph = 0; ph < GINGR_NUM_PHASES; ++ph) GINGR_TRY(gingr_fitter_icp_phase_async(f, p, ph));
     }
     return GINGR_OK;
+}
+
+static int sharded_update(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations,
+                          gingr_allreduce_fn reduce, void *user) {
+    GINGR_TRY(check_ready(f));
+    if (n_iterations < 0 || !reduce) return gingr_set_error(f->ctx, GINGR_ERR_BAD_ARGUMENT, "sharded update: bad arguments");
+    if (f->partial_out) return gingr_set_error(f->ctx, GINGR_ERR_STATE, "sharded update: this fitter belongs to a device group");
+    for (int32_t it = 0; it < n_iterations; ++it) {
+        TimerScope ts(f->ctx, 3);
+        for (int ph = 0; ph < GINGR_NUM_PHASES; ++ph) {
+            GINGR_TRY(icp ? gingr_fitter_icp_phase_async(f, ip, ph) : gingr_fitter_cpd_phase_async(f, cp, ph));
+            if (ph < GINGR_NUM_SEGMENTS && !(icp && ph == 0)) {
+                TimerScope tx(f->ctx, 6 + ph);  // the exchange of segment ph as this shard sees it (includes waiting for the peers)
+                if (reduce(user, ph, f->xch + f->off[ph], f->cnt[ph]) != 0)
+                    return gingr_set_error(f->ctx, GINGR_ERR_STATE, "sharded update: the all-reduce callback failed (segment %d)", ph);
+            }
+        }
+    }
+    return GINGR_OK;
+}
+
+int gingr_fitter_update_cpd_sharded_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t n_iterations, gingr_allreduce_fn reduce,
+                                          void *user) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    return sharded_update(f, false, p, nullptr, n_iterations, reduce, user);
+}
+
+int gingr_fitter_update_icp_sharded_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations, gingr_allreduce_fn reduce,
+                                          void *user) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    f->icp_surface = false;
+    return sharded_update(f, true, nullptr, p, n_iterations, reduce, user);
 }
 
 // ------------------------------------------------------------------------------------------ ICP, surface correspondence

@@ -930,6 +930,10 @@ __device__ __forceinline__ void lds_load_spd(double *A, int ld, int r, int n, co
 // updates (Cholesky of the bordered matrix), so on return they hold (L^-1 b)^T.
 // NT threads (a multiple of 256): the panel solves and the trailing updates spread over NT / 64 waves.  With one wave per SIMD
 // every stage is bound by the number of instructions that wave issues (~5 cycles each).
+// Round 3: look-ahead.  The diagonal block of step k + 1 only needs block COLUMN k + 1 of the trailing update of step k, and it is
+// factored by one wave while the others have nothing to do; so the trailing update is split: first the tiles of column k + 1 (all
+// waves), then -- behind one more barrier -- wave 0 factors diagonal block k + 1 WHILE waves 1 .. NW-1 update the remaining tiles.
+// Per step max(diagonal block, remaining tiles) replaces their sum: 79k -> 67k cycles at r = 100 (tools/ubench_solve.hip), 38 -> 33 us.
 template <int NT>
 __device__ __forceinline__ void lds_cholesky(double *A, int ld, int n, double *rd, int *bad_spd, int xr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -937,49 +941,68 @@ __device__ __forceinline__ void lds_cholesky(double *A, int ld, int n, double *r
     constexpr int PU = NT >= 1024 ? 2 : 4;  // matrix rows interleaved per 16-lane group in the panel solve
     constexpr int PR = (NT / 16) * PU;     // matrix rows per panel pass
     const int rows = n + xr;
-    for (int kb = 0; kb < n; kb += kNB) {
-        // (1) diagonal block in registers, wave 0 (all four 16-lane rows do the same work: DPP needs the source lanes active).
-        // No masks anywhere: the upper part of the block is loaded, carried and stored as it comes -- lane i's entries right of the
-        // diagonal only ever feed lane i's own entries right of the diagonal, and nobody reads the upper part of A (the selects,
-        // compares and exec-mask juggling of a masked version were a third of this stage's instructions).  The stage is bound by
-        // the NUMBER of instructions the one wave issues, not by the dependent chain: a fraction-free variant (no reciprocal square
-        // root on the chain, one more multiply per entry) measured slower, 24.5k against 21.4k cycles for seven blocks.
-        if (wave == 0) {
-            const int l15 = lane & 15;
-            double row[kNB];
+    // (1) diagonal block in registers, ONE wave (all four 16-lane rows do the same work: DPP needs the source lanes active).
+    // No masks anywhere: the upper part of the block is loaded, carried and stored as it comes -- lane i's entries right of the
+    // diagonal only ever feed lane i's own entries right of the diagonal, and nobody reads the upper part of A (the selects,
+    // compares and exec-mask juggling of a masked version were a third of this stage's instructions).  The stage is bound by
+    // the NUMBER of instructions the one wave issues, not by the dependent chain: a fraction-free variant (no reciprocal square
+    // root on the chain, one more multiply per entry) measured slower, 24.5k against 21.4k cycles for seven blocks.
+    auto diag_block = [&](int kb) {
+        const int l15 = lane & 15;
+        double row[kNB];
 #pragma unroll
-            for (int k = 0; k < kNB; ++k) row[k] = A[(kb + l15) * ld + kb + k];
-            static_for<0, kNB>([&](auto cc) {
-                constexpr int c = decltype(cc)::value;
-                // the pivot, from lane c of this 16-lane row.  A non-positive or non-finite pivot is not tested here (the test
-                // would sit on the sequential chain): it turns lc into NaN (rsq(d <= 0) * d, rsq(inf) * inf), the NaN reaches every
-                // later diagonal entry of the block, and the check after the loop sees it.
-                const double d = row_bcast<c>(row[c]);
-                // 1/sqrt(d) by v_rsq_f64 + two Newton steps; lane c's own element d * rsqrt(d) is sqrt(d): the IEEE sqrt and
-                // divide sequences are ~40 dependent instructions and would sit on the sequential chain of every column
-                double rdk = __builtin_amdgcn_rsq(d);
-                const double hd = 0.5 * d;
-                rdk = rdk * __builtin_fma(-hd * rdk, rdk, 1.5);
-                rdk = rdk * __builtin_fma(-hd * rdk, rdk, 1.5);
-                const double lc = row[c] * rdk;
-                const double nlc = -lc;
-                row[c] = lc;
-                rd[kb + c] = rdk;  // 1 / L[c][c]; the same value from every lane
-                // row[j] -= L[lane][c] * L[j][c]: L[j][c] is lane j's lc, fetched by the DPP of the FMA itself
-                static_for<c + 1, kNB>([&](auto jj) {
-                    constexpr int j = decltype(jj)::value;
-                    fmac_row_bcast<j, j == c + 1>(row[j], lc, nlc);
-                });
+        for (int k = 0; k < kNB; ++k) row[k] = A[(kb + l15) * ld + kb + k];
+        static_for<0, kNB>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            // the pivot, from lane c of this 16-lane row.  A non-positive or non-finite pivot is not tested here (the test
+            // would sit on the sequential chain): it turns lc into NaN (rsq(d <= 0) * d, rsq(inf) * inf), the NaN reaches every
+            // later diagonal entry of the block, and the check after the loop sees it.
+            const double d = row_bcast<c>(row[c]);
+            // 1/sqrt(d) by v_rsq_f64 + two Newton steps; lane c's own element d * rsqrt(d) is sqrt(d): the IEEE sqrt and
+            // divide sequences are ~40 dependent instructions and would sit on the sequential chain of every column
+            double rdk = __builtin_amdgcn_rsq(d);
+            const double hd = 0.5 * d;
+            rdk = rdk * __builtin_fma(-hd * rdk, rdk, 1.5);
+            rdk = rdk * __builtin_fma(-hd * rdk, rdk, 1.5);
+            const double lc = row[c] * rdk;
+            const double nlc = -lc;
+            row[c] = lc;
+            rd[kb + c] = rdk;  // 1 / L[c][c]; the same value from every lane
+            // row[j] -= L[lane][c] * L[j][c]: L[j][c] is lane j's lc, fetched by the DPP of the FMA itself
+            static_for<c + 1, kNB>([&](auto jj) {
+                constexpr int j = decltype(jj)::value;
+                fmac_row_bcast<j, j == c + 1>(row[j], lc, nlc);
             });
-            if (lane < kNB) {
+        });
+        if (lane < kNB) {
 #pragma unroll
-                for (int k = 0; k < kNB; ++k) A[(kb + lane) * ld + kb + k] = row[k];
-                // L[lane][lane] = row[lane]: a register array cannot be indexed by the lane; read it back
-                const double diag = A[(kb + lane) * ld + kb + lane];
-                if (!(diag > 0.0) || !finite_d(diag)) *bad_spd = 1;
-            }
+            for (int k = 0; k < kNB; ++k) A[(kb + lane) * ld + kb + k] = row[k];
+            // L[lane][lane] = row[lane]: a register array cannot be indexed by the lane; read it back
+            const double diag = A[(kb + lane) * ld + kb + lane];
+            if (!(diag > 0.0) || !finite_d(diag)) *bad_spd = 1;
         }
-        __syncthreads();
+    };
+    // (3) one 16x16 tile of the trailing update on the matrix pipe: D = C - L_I L_J^T as four v_mfma_f64_16x16x4 (k = 16).
+    // Fragment layout as in gram_kernel: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; it holds
+    // D[i = (l >> 4) + 4 reg][j = l & 15].  All tiles are full; the upper half of a diagonal tile is updated too (nobody reads it).
+    // (measured in round 2: bound by the LDS traffic of the fragments -- C in, A, B, C out = 8 KB per tile -- not by latency)
+    auto tile_update = [&](int kb, int ti, int tj) {
+        const int t0 = kb + kNB;
+        const int l15 = lane & 15, l4 = lane >> 4;
+        const int i0 = t0 + 16 * ti, j0 = t0 + 16 * tj;
+        const double *pa = A + (i0 + l15) * ld + kb + l4, *pb = A + (j0 + l15) * ld + kb + l4;
+        double *pc = A + (i0 + l4) * ld + j0 + l15;
+        v4f64 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = pc[4 * g * ld];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * q], pb[4 * q], acc, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pc[4 * g * ld] = acc[g];
+    };
+    if (wave == 0) diag_block(0);
+    __syncthreads();
+    for (int kb = 0; kb < n; kb += kNB) {
         GINGR_STAGE_CLOCK(1)
         // (2) panel below the diagonal block: x L11^T = A[i][kb:kb+16].  Sixteen lanes per matrix row: lane c keeps x[c] and
         // row c of L11 in registers; at step k every lane with c > k takes x[k] / L[k][k] from lane k through the DPP of its
@@ -1017,31 +1040,22 @@ __device__ __forceinline__ void lds_cholesky(double *A, int ld, int n, double *r
         }
         __syncthreads();
         GINGR_STAGE_CLOCK(2)
-        // (3) trailing update on the matrix pipe: one wave per 16x16 output tile, D = C - L_I L_J^T as four
-        // v_mfma_f64_16x16x4 (k = 16).  Fragment layout as in gram_kernel: lane l supplies A[i = l & 15][k = l >> 4] and
-        // B[k = l >> 4][j = l & 15]; it holds D[i = (l >> 4) + 4 reg][j = l & 15].  All tiles are full; the upper half of a
-        // diagonal tile is updated too (nobody reads it).
-        {
-            const int t0 = kb + kNB;
-            const int nti = (rows - t0) >> 4, ntj = (n - t0) >> 4;
-            const int l15 = lane & 15, l4 = lane >> 4;
-            // (measured: bound by the LDS traffic of the fragments -- C in, A, B, C out = 8 KB per tile -- not by latency: issuing
-            // two tiles' loads ahead of their MFMA chains changed nothing)
+        const int t0 = kb + kNB;
+        const int nti = (rows - t0) >> 4, ntj = (n - t0) >> 4;
+        // (3a) block column kb + 16 of the trailing matrix (tj = 0): what the next diagonal block and the next panel read
+        if (ntj > 0)
+            for (int ti = wave; ti < nti; ti += NW) tile_update(kb, ti, 0);
+        __syncthreads();
+        // (3b) wave 0 factors the next diagonal block while the other waves update the remaining tiles (tj >= 1).  One wave only
+        // (NW == 1): everything in sequence.
+        if (wave == 0 && ntj > 0) diag_block(t0);
+        if (NW == 1 || wave > 0) {
+            constexpr int NR = NW > 1 ? NW - 1 : 1;
+            const int me = NW > 1 ? wave - 1 : 0;
             int tcount = 0;
-            for (int ti = 0; ti < nti; ++ti)
-                for (int tj = 0; tj <= ti && tj < ntj; ++tj, ++tcount) {
-                    if (tcount % NW != wave) continue;  // wave-uniform
-                    const int i0 = t0 + 16 * ti, j0 = t0 + 16 * tj;
-                    const double *pa = A + (i0 + l15) * ld + kb + l4, *pb = A + (j0 + l15) * ld + kb + l4;
-                    double *pc = A + (i0 + l4) * ld + j0 + l15;
-                    v4f64 acc;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[g] = pc[4 * g * ld];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * q], pb[4 * q], acc, 0, 0, 0);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) pc[4 * g * ld] = acc[g];
-                }
+            for (int ti = 1; ti < nti; ++ti)
+                for (int tj = 1; tj <= ti && tj < ntj; ++tj, ++tcount)
+                    if (tcount % NR == me) tile_update(kb, ti, tj);  // wave-uniform
         }
         __syncthreads();
         GINGR_STAGE_CLOCK(3)
@@ -1158,27 +1172,20 @@ constexpr int kSolveThreads = 256;
 // GW = false: the workspace is the dynamic LDS block and nothing else -- the compiler then proves every access of the building
 // blocks to be address space 3 and emits ds_read / ds_write.  (With one kernel choosing between LDS and a global pointer at run
 // time every access was a FLAT instruction: ~3x the latency of the LDS path, 64-bit address arithmetic, SGPR spills.)
-template <bool GW>
-__global__ __launch_bounds__(kSolveThreads) void posterior_solve_lds_kernel(int r, int rp, const double *__restrict__ G,
-                                                                  const double *__restrict__ rhs,
-                                                                  const double *__restrict__ zrand, double *__restrict__ a,
-                                                                  DevState *__restrict__ st, double *gwork) {
-    extern __shared__ double lds_sm[];
-    double *sm;
-    if constexpr (GW)
-        sm = gwork;
-    else
-        sm = lds_sm;
+// The solve on a workspace `sm` (LDS or global, see below); all kSolveThreads threads.  bad_spd / bad: two ints of LDS.
+template <typename PtrD>
+__device__ __forceinline__ void posterior_solve_body(PtrD sm, int r, int rp, const double *__restrict__ G, const double *__restrict__ rhs,
+                                                     const double *__restrict__ zrand, double *__restrict__ a, DevState *__restrict__ st,
+                                                     int *bad_spd, int *bad) {
     const int n = rp, ld = n | 1;  // odd leading dimension: column walks hit distinct banks
-    double *A = sm;
-    double *y = sm + (size_t)n * ld;   // row n of the bordered matrix: the right-hand side (rows n+1 .. n+15 are zero)
-    double *rd = sm + (size_t)(n + kNB) * ld;  // reciprocal diagonal of L
-    double *y2 = rd + n;                       // sampling direction
-    __shared__ int bad_spd, bad;
+    auto A = sm;
+    auto y = sm + (size_t)n * ld;   // row n of the bordered matrix: the right-hand side (rows n+1 .. n+15 are zero)
+    auto rd = sm + (size_t)(n + kNB) * ld;  // reciprocal diagonal of L
+    auto y2 = rd + n;                       // sampling direction
     const int tid = threadIdx.x;
     if (tid == 0) {
-        bad_spd = 0;
-        bad = 0;
+        *bad_spd = 0;
+        *bad = 0;
     }
     for (int k = tid; k < kNB * ld; k += kSolveThreads) y[k] = k < r ? rhs[k] : 0.0;
     for (int k = tid; k < n; k += kSolveThreads) y2[k] = (zrand && k < r) ? zrand[k] : 0.0;
@@ -1186,7 +1193,7 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_solve_lds_kernel(int 
     GINGR_STAGE_CLOCK(7)
     lds_load_spd<kSolveThreads>(A, ld, r, n, G, 1.0, nullptr, 0.0, 1.0);
     GINGR_STAGE_CLOCK(0)
-    lds_cholesky<kSolveThreads>(A, ld, n, rd, &bad_spd, kNB);  // y <- L^-1 y on the way
+    lds_cholesky<kSolveThreads>(A, ld, n, rd, bad_spd, kNB);  // y <- L^-1 y on the way
     GINGR_STAGE_CLOCK(4)
     lds_backward<kSolveThreads>(A, ld, n, rd, y);
     GINGR_STAGE_CLOCK(5)
@@ -1195,15 +1202,28 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_solve_lds_kernel(int 
     for (int k = tid; k < rp; k += kSolveThreads) {
         const double v = k < r ? y[k] + y2[k] : 0.0;
         a[k] = v;
-        if (!finite_d(v)) bad = 1;
+        if (!finite_d(v)) *bad = 1;
     }
     __syncthreads();
     if (tid == 0) {
-        if (bad_spd)
+        if (*bad_spd)
             st->err = GINGR_ERR_NOT_SPD;
-        else if (bad)
+        else if (*bad)
             st->err = GINGR_ERR_NONFINITE;
     }
+}
+
+template <bool GW>
+__global__ __launch_bounds__(kSolveThreads) void posterior_solve_lds_kernel(int r, int rp, const double *__restrict__ G,
+                                                                  const double *__restrict__ rhs,
+                                                                  const double *__restrict__ zrand, double *__restrict__ a,
+                                                                  DevState *__restrict__ st, double *gwork) {
+    extern __shared__ double lds_sm[];
+    __shared__ int bad_spd, bad;
+    if constexpr (GW)
+        posterior_solve_body(gwork, r, rp, G, rhs, zrand, a, st, &bad_spd, &bad);
+    else
+        posterior_solve_body(lds_sm, r, rp, G, rhs, zrand, a, st, &bad_spd, &bad);
 }
 
 // ---- pieces shared by the three transition-density kernels (256 threads: 128 entries x 2 column halves) -------------------------
@@ -1605,8 +1625,127 @@ __global__ __launch_bounds__(256) void post_matvecs_kernel(int r, int rp, const 
     if (lane16 == 0) zbuf[(int64_t)b * rp + i] = i < r ? s : 0.0;
 }
 
+// The one-thread part of the post-solve: Umeyama between the current shape and the blended posterior mean from the 36 dot
+// products (moment form), then the 3x3 quantities of the second projection.  dots: [0..2] W[d].alpha, [3..5] W[d].alpha_c,
+// [6..14] V[b][d].alpha (index d*3+b), [15..23] V[d][b].alpha_c, [24..32] alpha_c.za[d][b], [33..35] alpha.za[d][d].
+__device__ void post_pose_step(const PostSolveArgs &A, const DevState *st, const double *dots, DevPose &P, double *Bm, double *BmI,
+                               double *hv, int *bad) {
+    // u~_i = p~_i + Q0_i alpha (current shape, unposed), v~_i = p~_i + Q0_i alpha_c, newshape - c0 = R v~_i + g~
+    const double *R = st->R;
+    double su[3], sv[3], Mvu[9], gt[3], sums[16];
+    for (int d = 0; d < 3; ++d) {
+        su[d] = A.Ps[d] + dots[d];
+        sv[d] = A.Ps[d] + dots[3 + d];
+    }
+    for (int d = 0; d < 3; ++d)
+        for (int b = 0; b < 3; ++b) Mvu[d * 3 + b] = A.Pp[d * 3 + b] + dots[6 + d * 3 + b] + dots[15 + d * 3 + b] + dots[24 + d * 3 + b];
+    for (int a = 0; a < 3; ++a) {
+        const double q0 = A.c0[0] - st->center[0], q1 = A.c0[1] - st->center[1], q2 = A.c0[2] - st->center[2];
+        gt[a] = R[a * 3] * q0 + R[a * 3 + 1] * q1 + R[a * 3 + 2] * q2 + st->center[a] + st->t[a] - A.c0[a];
+    }
+    for (int a = 0; a < 3; ++a) {
+        sums[a] = su[a];
+        sums[3 + a] = R[a * 3] * sv[0] + R[a * 3 + 1] * sv[1] + R[a * 3 + 2] * sv[2] + A.n_total * gt[a];
+        for (int b = 0; b < 3; ++b)
+            sums[6 + a * 3 + b] = R[a * 3] * Mvu[b] + R[a * 3 + 1] * Mvu[3 + b] + R[a * 3 + 2] * Mvu[6 + b] + gt[a] * su[b];
+    }
+    sums[15] = 0.0;
+    for (int d = 0; d < 3; ++d) sums[15] += A.Pp[d * 3 + d] + 2.0 * dots[6 + d * 3 + d] + dots[33 + d];
+    DevPose Pl;
+    const bool fin = umeyama_from_sums(sums, A.n_total, A.c0, A.global_transform, Pl);
+    if (!fin) *bad = 1;
+    P = Pl;
+    // e_i = R2^T (newshape_i - t2) - p_i = (B - I) p~_i + B Q0_i alpha_c + h,  B = R2^T R
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            const double v = Pl.R[a] * R[b] + Pl.R[3 + a] * R[3 + b] + Pl.R[6 + a] * R[6 + b];
+            Bm[a * 3 + b] = v;
+            BmI[a * 3 + b] = v - (a == b ? 1.0 : 0.0);
+        }
+    double w3[3];
+    for (int a = 0; a < 3; ++a) w3[a] = gt[a] + A.c0[a] - Pl.t[a];
+    for (int a = 0; a < 3; ++a) {
+        const double rt = Pl.R[a] * w3[0] + Pl.R[3 + a] * w3[1] + Pl.R[6 + a] * w3[2];
+        hv[a] = rt - A.c0[a];  // h = R2^T (g~ + c0 - t2) - c0   (p_i = p~_i + c0)
+    }
+}
+
+// The one-thread commit of an update (alpha itself is written by all threads when !failed).
+// Failure semantics of GingrAlgorithm.update (G/api/GingrAlgorithm.scala:192-254):
+//   posterior failed (Try of computePosterior, here: the solve flagged st->err)
+//       iteration 0                      -> state unchanged                                          (:206-208)
+//       iteration > 0, deterministic     -> ModelFlexibilityError                                    (:203-205)
+//       iteration > 0, probabilistic     -> retryCounter == 0 ? ModelFlexibilityError
+//                                           : { retryCounter -= 1; state unchanged }                  (:196-202)
+//   posterior fine                       -> retryCounter = min(10, retryCounter + 1)                  (:210)
+//       a coefficients() projection (or the alignment between them) failed -> ModelFlexibilityError at ANY iteration
+//                                                                                                     (:248-251)
+// Non-finite values count as failures: in the reference they make Breeze's SVD throw inside the Try.
+__device__ void post_commit_step(const PostSolveArgs &A, DevState *st, const DevPose &P, bool posterior_failed, bool bad) {
+    const bool failed = posterior_failed || bad;
+    if (posterior_failed) {
+        if (st->iteration > 0) {
+            if (A.probabilistic && A.retry && *A.retry > 0)
+                *A.retry -= 1;
+            else
+                st->status = GINGR_FIT_MODEL_FLEXIBILITY_ERROR;
+        }
+    } else {
+        if (A.retry) *A.retry = *A.retry + 1 < GINGR_RETRY_INIT ? *A.retry + 1 : GINGR_RETRY_INIT;
+        if (bad) st->status = GINGR_FIT_MODEL_FLEXIBILITY_ERROR;
+    }
+    if (!failed) {
+        for (int q = 0; q < 9; ++q) st->R[q] = P.R[q];
+        for (int q = 0; q < 3; ++q) {
+            st->euler[q] = P.euler[q];
+            st->center[q] = 0.0;  // Umeyama about Point(0,0,0), GingrAlgorithm.scala:81,266
+            st->t[q] = P.t[q];
+        }
+        st->scale = P.scale;
+        if (A.is_icp) {
+            const double ns = st->sigma2 - A.icp_step;       // ICP.scala:96-99
+            st->sigma2 = ns > A.icp_end ? ns : A.icp_end;
+        } else {
+            const double *sc = A.scalars;                    // CPD.scala:142-145
+            st->sigma2 = (sc[1] - 2 * sc[2] + sc[3]) / (sc[0] * 3.0);
+        }
+    }
+    st->pad = failed ? (st->err != 0 ? st->err : GINGR_ERR_NONFINITE) : 0;  // last error, readable by the host
+    st->err = 0;
+    st->iteration += 1;  // GingrGeneratorWrapper.propose: updateIteration()
+}
+
 constexpr int kPostThreads = 1024;
 
+// out[k] = sum_j Mat[j*rp + k] * x[j] with Mat, x and out in LDS (block_matvec_T for LDS-resident operands)
+__device__ __forceinline__ void lds_matvec_T(const double *Mat, const double *x, double *out, int r, int rp, double *scratch) {
+    int width = 16;
+    while (width < rp) width <<= 1;
+    const int parts = kPostThreads / width > 0 ? kPostThreads / width : 1;
+    const int k = threadIdx.x % width, part = threadIdx.x / width;
+    double s = 0.0;
+    if (part < parts && k < rp)
+        for (int j = part; j < r; j += parts) s = __builtin_fma(Mat[j * rp + k], x[j], s);
+    if (part < parts && k < rp) scratch[part * rp + k] = s;
+    __syncthreads();
+    for (int kk = threadIdx.x; kk < rp; kk += kPostThreads) {
+        double t = 0.0;
+        for (int p = 0; p < parts; ++p) t += scratch[p * rp + kk];
+        out[kk] = t;
+    }
+    __syncthreads();
+}
+
+// Everything after the 19 mat-vecs in one workgroup.  The kernel starts behind a kernel boundary with cold caches (at 50k points the
+// all-pairs passes and the basis sweeps have pushed Binv and the moment vectors out of L2 and out of the Infinity Cache), and a lone
+// workgroup pays the full memory latency for every DEPENDENT batch of loads: the round-2 version read Binv inside the mat-vec loop
+// (13 batches) and the moment vectors inside the dot products (6 batches).  Here every global operand is requested in the first
+// instructions (PRELOAD: Binv too, 12 loads per thread), lands in LDS after ONE round trip, and the arithmetic runs on LDS alone.
+// PRELOAD = false (rp > 112: Binv does not fit beside the vectors): Binv stays in global memory as before.
+// (Measured: the kernel stays at ~18 us at 50k points against 6 us at femur size -- what it waits for is not its data but its CODE:
+// ~30 KB of straight-line float64 code run once by one wave behind cold instruction caches; see svd3.h for the part of that which
+// could be shared)
+template <bool PRELOAD>
 __global__ __launch_bounds__(kPostThreads) void post_solve_kernel(PostSolveArgs A) {
     extern __shared__ double sm[];
     const int r = A.r, rp = A.rp, tid = threadIdx.x;
@@ -1616,41 +1755,95 @@ __global__ __launch_bounds__(kPostThreads) void post_solve_kernel(PostSolveArgs 
     double *valpha = sm, *vac = valpha + rp, *proj = vac + rp, *anew = proj + rp;
     double *za = anew + rp;       // [9][rp]  S[d][e] alpha
     double *zc = za + 9 * rp;     // [9][rp]  S[d][e] alpha_c
-    double *scratch = zc + 9 * rp;
+    double *Vm = zc + 9 * rp;     // [9][rp] V[d][e] then [3][rp] W[d]: the layout of mom from V(0, 0) on
+    int width = 16;
+    while (width < rp) width <<= 1;
+    const int parts = kPostThreads / width > 0 ? kPostThreads / width : 1;
+    double *scratch = Vm + 12 * rp;
+    double *Bl = scratch + parts * rp;  // [rp][rp] Binv (PRELOAD)
     __shared__ double dots[40];
     __shared__ DevPose P;
     __shared__ double Bm[9], BmI[9], hv[3];
     __shared__ int bad;
-    for (int k = tid; k < rp; k += kPostThreads) valpha[k] = k < r ? A.alpha[k] : 0.0;
-    if (tid == 0) bad = 0;
-    __syncthreads();
-    // alpha_1 = Binv (S_tot a) / eps = C a: coefficients of the posterior mean (transformedModelInit.coefficients,
-    // :212-216; Q^T (Q a) = S_tot a and the R / R^T round trip of the displacement cancels); then the step blend (:218-220)
-    for (int k = tid; k < rp; k += kPostThreads) {
-        const double a1 = A.zbuf[18 * rp + k];
-        vac[k] = k < r ? valpha[k] + (a1 - valpha[k]) * A.step : 0.0;
+    // ---- all global operands in flight at once
+    constexpr int kB = 16;  // Binv elements per thread and batch (rp <= 112: 12.25 per thread)
+    double bl[kB];
+    if (PRELOAD) {
+#pragma unroll
+        for (int q = 0; q < kB; ++q) {
+            const int e = tid + q * kPostThreads;
+            bl[q] = e < rp * rp ? A.Binv[e] : 0.0;
+        }
     }
-    // z_alpha = S[d][e] alpha; z_c = S[d][e] alpha_c = (1 - step) S[d][e] alpha + step T[d][e] a
-    for (int q = tid; q < 9 * rp; q += kPostThreads) {
-        const double zal = A.zbuf[q], zt = A.zbuf[9 * rp + q];
-        za[q] = zal;
-        zc[q] = (1.0 - A.step) * zal + A.step * zt;
+    // PRELOAD implies rp <= 112: 9 rp <= 1008 elements per z block (one per thread), 12 rp <= 1344 moment entries (two per thread)
+    double zal = 0.0, zt = 0.0, vm[2] = {0.0, 0.0}, a1 = 0.0, al = 0.0;
+    if (PRELOAD) {
+        if (tid < 9 * rp) {
+            zal = A.zbuf[tid];
+            zt = A.zbuf[9 * rp + tid];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + q * kPostThreads;
+            vm[q] = e < 12 * rp ? A.mom[ml.V(0, 0) + e] : 0.0;
+        }
+        if (tid < rp) {
+            a1 = A.zbuf[18 * rp + tid];
+            al = tid < r ? A.alpha[tid] : 0.0;
+        }
+    }
+    if (tid == 0) bad = 0;
+    // ---- into LDS.  z_alpha = S[d][e] alpha; z_c = S[d][e] alpha_c = (1 - step) S[d][e] alpha + step T[d][e] a;
+    // alpha_1 = Binv (S_tot a) / eps = C a: coefficients of the posterior mean (transformedModelInit.coefficients, :212-216; Q^T (Q a) =
+    // S_tot a and the R / R^T round trip of the displacement cancels); then the step blend (:218-220)
+    if (PRELOAD) {
+#pragma unroll
+        for (int q = 0; q < kB; ++q) {
+            const int e = tid + q * kPostThreads;
+            if (e < rp * rp) Bl[e] = bl[q];
+        }
+        if (tid < 9 * rp) {
+            za[tid] = zal;
+            zc[tid] = (1.0 - A.step) * zal + A.step * zt;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + q * kPostThreads;
+            if (e < 12 * rp) Vm[e] = vm[q];
+        }
+        if (tid < rp) {
+            valpha[tid] = al;
+            vac[tid] = tid < r ? al + (a1 - al) * A.step : 0.0;
+        }
+    } else {
+        for (int q = tid; q < 9 * rp; q += kPostThreads) {
+            const double z0 = A.zbuf[q], z1 = A.zbuf[9 * rp + q];
+            za[q] = z0;
+            zc[q] = (1.0 - A.step) * z0 + A.step * z1;
+        }
+        for (int e = tid; e < 12 * rp; e += kPostThreads) Vm[e] = A.mom[ml.V(0, 0) + e];
+        for (int k = tid; k < rp; k += kPostThreads) {
+            const double x = k < r ? A.alpha[k] : 0.0;
+            valpha[k] = x;
+            vac[k] = k < r ? x + (A.zbuf[18 * rp + k] - x) * A.step : 0.0;
+        }
     }
     __syncthreads();
     // 36 dot products, one wave each: [0..2] W[d].alpha, [3..5] W[d].alpha_c, [6..14] V[b][d].alpha (index d*3+b),
     // [15..23] V[d][b].alpha_c, [24..32] alpha_c.za[d][b], [33..35] alpha.za[d][d]
+    const double *Wm = Vm + 9 * rp;
     for (int t = tid >> 6; t < 36; t += kPostThreads / 64) {
         double v;
         if (t < 3)
-            v = wave_dot(A.mom + ml.W(t), valpha, r);
+            v = wave_dot(Wm + t * rp, valpha, r);
         else if (t < 6)
-            v = wave_dot(A.mom + ml.W(t - 3), vac, r);
+            v = wave_dot(Wm + (t - 3) * rp, vac, r);
         else if (t < 15) {
             const int d = (t - 6) / 3, b = (t - 6) % 3;
-            v = wave_dot(A.mom + ml.V(b, d), valpha, r);
+            v = wave_dot(Vm + (b * 3 + d) * rp, valpha, r);
         } else if (t < 24) {
             const int d = (t - 15) / 3, b = (t - 15) % 3;
-            v = wave_dot(A.mom + ml.V(d, b), vac, r);
+            v = wave_dot(Vm + (d * 3 + b) * rp, vac, r);
         } else if (t < 33) {
             v = wave_dot(vac, za + (t - 24) * rp, r);
         } else {
@@ -1660,114 +1853,37 @@ __global__ __launch_bounds__(kPostThreads) void post_solve_kernel(PostSolveArgs 
         if ((tid & 63) == 0) dots[t] = v;
     }
     __syncthreads();
-    if (tid == 0) {
-        // u~_i = p~_i + Q0_i alpha (current shape, unposed), v~_i = p~_i + Q0_i alpha_c, newshape - c0 = R v~_i + g~
-        const double *R = st->R;
-        double su[3], sv[3], Mvu[9], gt[3], sums[16];
-        for (int d = 0; d < 3; ++d) {
-            su[d] = A.Ps[d] + dots[d];
-            sv[d] = A.Ps[d] + dots[3 + d];
-        }
-        for (int d = 0; d < 3; ++d)
-            for (int b = 0; b < 3; ++b) Mvu[d * 3 + b] = A.Pp[d * 3 + b] + dots[6 + d * 3 + b] + dots[15 + d * 3 + b] + dots[24 + d * 3 + b];
-        for (int a = 0; a < 3; ++a) {
-            const double q0 = A.c0[0] - st->center[0], q1 = A.c0[1] - st->center[1], q2 = A.c0[2] - st->center[2];
-            gt[a] = R[a * 3] * q0 + R[a * 3 + 1] * q1 + R[a * 3 + 2] * q2 + st->center[a] + st->t[a] - A.c0[a];
-        }
-        for (int a = 0; a < 3; ++a) {
-            sums[a] = su[a];
-            sums[3 + a] = R[a * 3] * sv[0] + R[a * 3 + 1] * sv[1] + R[a * 3 + 2] * sv[2] + A.n_total * gt[a];
-            for (int b = 0; b < 3; ++b)
-                sums[6 + a * 3 + b] = R[a * 3] * Mvu[b] + R[a * 3 + 1] * Mvu[3 + b] + R[a * 3 + 2] * Mvu[6 + b] + gt[a] * su[b];
-        }
-        sums[15] = 0.0;
-        for (int d = 0; d < 3; ++d) sums[15] += A.Pp[d * 3 + d] + 2.0 * dots[6 + d * 3 + d] + dots[33 + d];
-        DevPose Pl;
-        const bool fin = umeyama_from_sums(sums, A.n_total, A.c0, A.global_transform, Pl);
-        if (!fin) bad = 1;
-        P = Pl;
-        // e_i = R2^T (newshape_i - t2) - p_i = (B - I) p~_i + B Q0_i alpha_c + h,  B = R2^T R
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) {
-                const double v = Pl.R[a] * R[b] + Pl.R[3 + a] * R[3 + b] + Pl.R[6 + a] * R[6 + b];
-                Bm[a * 3 + b] = v;
-                BmI[a * 3 + b] = v - (a == b ? 1.0 : 0.0);
-            }
-        double w3[3];
-        for (int a = 0; a < 3; ++a) w3[a] = gt[a] + A.c0[a] - Pl.t[a];
-        for (int a = 0; a < 3; ++a) {
-            const double rt = Pl.R[a] * w3[0] + Pl.R[3 + a] * w3[1] + Pl.R[6 + a] * w3[2];
-            hv[a] = rt - A.c0[a];  // h = R2^T (g~ + c0 - t2) - c0   (p_i = p~_i + c0)
-        }
-    }
+    if (tid == 0) post_pose_step(A, st, dots, P, Bm, BmI, hv, &bad);
     __syncthreads();
     // second projection Q^T e from the moments (transformedModel.coefficients(newshape), :234-237)
     for (int k = tid; k < rp; k += kPostThreads) {
         double s = 0.0;
         for (int d = 0; d < 3; ++d) {
             for (int e = 0; e < 3; ++e) {
-                s = __builtin_fma(BmI[d * 3 + e], A.mom[ml.V(d, e) + k], s);
+                s = __builtin_fma(BmI[d * 3 + e], Vm[(d * 3 + e) * rp + k], s);
                 s = __builtin_fma(Bm[d * 3 + e], zc[(d * 3 + e) * rp + k], s);
             }
-            s = __builtin_fma(hv[d], A.mom[ml.W(d) + k], s);
+            s = __builtin_fma(hv[d], Wm[d * rp + k], s);
         }
         proj[k] = k < r ? s : 0.0;
     }
     __syncthreads();
-    block_matvec_T(A.Binv, proj, anew, r, rp, scratch);
+    if (PRELOAD)
+        lds_matvec_T(Bl, proj, anew, r, rp, scratch);
+    else
+        block_matvec_T(A.Binv, proj, anew, r, rp, scratch);
     for (int k = tid; k < rp; k += kPostThreads) {
         const double v = k < r ? anew[k] / GINGR_COEFF_NOISE : 0.0;
         anew[k] = v;
         if (!finite_d(v)) bad = 1;
     }
     __syncthreads();
-    // Failure semantics of GingrAlgorithm.update (G/api/GingrAlgorithm.scala:192-254):
-    //   posterior failed (Try of computePosterior, here: the solve flagged st->err)
-    //       iteration 0                      -> state unchanged                                          (:206-208)
-    //       iteration > 0, deterministic     -> ModelFlexibilityError                                    (:203-205)
-    //       iteration > 0, probabilistic     -> retryCounter == 0 ? ModelFlexibilityError
-    //                                           : { retryCounter -= 1; state unchanged }                  (:196-202)
-    //   posterior fine                       -> retryCounter = min(10, retryCounter + 1)                  (:210)
-    //       a coefficients() projection (or the alignment between them) failed -> ModelFlexibilityError at ANY iteration
-    //                                                                                                     (:248-251)
-    // Non-finite values count as failures: in the reference they make Breeze's SVD throw inside the Try.
-    const bool posterior_failed = st->err != 0;
+    const bool posterior_failed = st->err != 0;  // failure semantics: post_commit_step
     const bool failed = posterior_failed || bad;
     __syncthreads();
     if (!failed)
         for (int k = tid; k < rp; k += kPostThreads) A.alpha[k] = anew[k];
-    if (tid == 0) {
-        if (posterior_failed) {
-            if (st->iteration > 0) {
-                if (A.probabilistic && A.retry && *A.retry > 0)
-                    *A.retry -= 1;
-                else
-                    st->status = GINGR_FIT_MODEL_FLEXIBILITY_ERROR;
-            }
-        } else {
-            if (A.retry) *A.retry = *A.retry + 1 < GINGR_RETRY_INIT ? *A.retry + 1 : GINGR_RETRY_INIT;
-            if (bad) st->status = GINGR_FIT_MODEL_FLEXIBILITY_ERROR;
-        }
-        if (!failed) {
-            for (int q = 0; q < 9; ++q) st->R[q] = P.R[q];
-            for (int q = 0; q < 3; ++q) {
-                st->euler[q] = P.euler[q];
-                st->center[q] = 0.0;  // Umeyama about Point(0,0,0), GingrAlgorithm.scala:81,266
-                st->t[q] = P.t[q];
-            }
-            st->scale = P.scale;
-            if (A.is_icp) {
-                const double ns = st->sigma2 - A.icp_step;       // ICP.scala:96-99
-                st->sigma2 = ns > A.icp_end ? ns : A.icp_end;
-            } else {
-                const double *sc = A.scalars;                    // CPD.scala:142-145
-                st->sigma2 = (sc[1] - 2 * sc[2] + sc[3]) / (sc[0] * 3.0);
-            }
-        }
-        st->pad = failed ? (st->err != 0 ? st->err : GINGR_ERR_NONFINITE) : 0;  // last error, readable by the host
-        st->err = 0;
-        st->iteration += 1;  // GingrGeneratorWrapper.propose: updateIteration()
-    }
+    if (tid == 0) post_commit_step(A, st, P, posterior_failed, bad != 0);
 }
 
 __global__ void state_init_kernel(DevState *st, const gingr_state_scalars *h) {
@@ -2084,11 +2200,23 @@ void launch_post_solve(gingr_ctx *ctx, const PostSolveArgs &a) {
     int width = 16;
     while (width < a.rp) width <<= 1;
     const int parts = kPostThreads / width > 0 ? kPostThreads / width : 1;
-    const size_t lds = (size_t)((4 + 18 + parts) * a.rp) * sizeof(double);
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&post_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-    hipLaunchKernelGGL(post_solve_kernel, dim3(1), dim3(kPostThreads), lds, ctx->stream, a);
+    // Binv rides in LDS while everything fits into the 160 KB of a compute unit (rp <= 112, and 16 elements per thread cover it)
+    static const int pre_env = getenv("GINGR_POST_PRELOAD") ? atoi(getenv("GINGR_POST_PRELOAD")) : 1;
+    const size_t base = (size_t)(4 + 18 + 12 + parts) * a.rp, full = base + (size_t)a.rp * a.rp;
+    const bool preload = pre_env && a.rp * a.rp <= 16 * kPostThreads && full * sizeof(double) + 1024 <= 160 * 1024 && a.rp <= 112;
+    const size_t lds = (preload ? full : base) * sizeof(double);
+    auto go = [&](auto kern, size_t &granted) {
+        if (lds > granted) {  // the attribute is per function, not per launch
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            granted = lds;
+        }
+        hipLaunchKernelGGL(kern, dim3(1), dim3(kPostThreads), lds, ctx->stream, a);
+    };
+    static size_t granted_pre = 48 * 1024, granted_plain = 48 * 1024;
+    if (preload)
+        go(post_solve_kernel<true>, granted_pre);
+    else
+        go(post_solve_kernel<false>, granted_plain);
 }
 
 void launch_post_matvecs(gingr_ctx *ctx, const gingr_model *m, const double *alpha, const double *a, double *zbuf) {

@@ -23,6 +23,7 @@
 // scope.  Several shards may live on ONE device (devices = {0, 0}): that is how the protocol is tested on a one-GPU box.
 #include "gp.h"
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -55,6 +56,19 @@ __global__ __launch_bounds__(256) void peer_sum_kernel(double *__restrict__ out,
     }
 }
 
+// restores the calling thread's current device: the group's host-side set-up selects its devices one after the other, and a JVM / C /
+// torch host must find its own device selection untouched when the call returns
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() {
+        if (hipGetDevice(&saved) != hipSuccess) saved = -1;
+        (void)hipGetLastError();
+    }
+    ~DeviceGuard() {
+        if (saved >= 0) (void)hipSetDevice(saved);
+    }
+};
+
 struct SpinBarrier {
     std::atomic<int> count{0}, gen{0};
     int n = 1;
@@ -86,6 +100,8 @@ struct gingr_group {
     std::vector<double *> xch;                                  // the fitters' exchange buffers
     int64_t off[GINGR_NUM_SEGMENTS] = {0, 0}, cnt[GINGR_NUM_SEGMENTS] = {0, 0};
     int64_t iteration = 0;                                      // parity of the send buffers
+    bool fine_grained = false;                                  // the send buffers are fine-grained device allocations
+    int distinct_devices = 1;
     SpinBarrier bar;
     // workers
     std::vector<std::thread> workers;
@@ -152,6 +168,7 @@ void shard_rows(int64_t M, int n, int r, int64_t *b, int64_t *e) {  // the first
 }
 
 void free_exchange(gingr_group *g) {
+    DeviceGuard guard;
     for (int p = 0; p < 2; ++p) {
         for (size_t r = 0; r < g->send[p].size(); ++r)
             if (g->send[p][r]) {
@@ -184,32 +201,87 @@ void free_models(gingr_group *g) {
     }
 }
 
-// after every shard's model exists: sum the one-off basis moments over the shards (host, rank order) and finalize
+// Peer-readable device memory on the CURRENT device.  Fine-grained (coherent for the peers' reads across xGMI).  Plain device memory
+// is only acceptable when every shard of the group sits on the same device (logical shards: no peer ever reads across devices);
+// with distinct devices a coarse-grained buffer would make the peers' reads non-coherent without any warning, so that is an error.
+int alloc_peer_readable(gingr_group *g, size_t bytes, void **out, bool *fine) {
+    *out = nullptr;
+    if (hipExtMallocWithFlags(out, bytes, hipDeviceMallocFinegrained) == hipSuccess) {
+        *fine = true;
+        return GINGR_OK;
+    }
+    (void)hipGetLastError();
+    *out = nullptr;
+    if (g->distinct_devices > 1)
+        return group_fail(g, GINGR_ERR_HIP,
+                          "group: fine-grained device memory (hipDeviceMallocFinegrained) is not available; peers on other devices cannot "
+                          "read a coarse-grained send buffer coherently");
+    if (hipMalloc(out, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return group_fail(g, GINGR_ERR_HIP, "group: out of device memory (send buffer)");
+    }
+    *fine = false;
+    return GINGR_OK;
+}
+
+// after every shard's model exists: sum the one-off basis moments over the shards and finalize.  Same one-shot all-reduce over peer
+// pointers as the per-iteration exchange: every shard copies its partial moments into a peer-readable buffer, everybody meets, and
+// every shard adds the n buffers in rank order into its own moments (bit-identical on every device, no host copy of the moments).
 int finish_models(gingr_group *g) {
     const int n = g->n;
     if (n > 1) {
-        void *p0 = nullptr;
+        DeviceGuard guard;
         int64_t count = 0;
-        GINGR_TRY(gingr_model_gram_exchange(g->model[0], &p0, &count));
-        std::vector<double> tot((size_t)count, 0.0), part((size_t)count);
+        std::vector<double *> mom((size_t)n, nullptr), tmp((size_t)n, nullptr);
+        auto release = [&]() {
+            for (int r = 0; r < n; ++r)
+                if (tmp[(size_t)r]) {
+                    (void)hipSetDevice(g->dev[(size_t)r]);
+                    (void)hipFree(tmp[(size_t)r]);
+                }
+        };
         for (int r = 0; r < n; ++r) {
             void *p = nullptr;
             int64_t c = 0;
             GINGR_TRY(gingr_model_gram_exchange(g->model[(size_t)r], &p, &c));
+            if (r == 0) count = c;
             if (c != count) return group_fail(g, GINGR_ERR_STATE, "group: shards disagree on the model rank");
-            if (hipSetDevice(g->dev[(size_t)r]) != hipSuccess ||
-                hipMemcpy(part.data(), p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
-                return group_fail(g, GINGR_ERR_HIP, "group: moment download failed");
-            for (int64_t i = 0; i < count; ++i) tot[(size_t)i] += part[(size_t)i];
+            mom[(size_t)r] = static_cast<double *>(p);
         }
         for (int r = 0; r < n; ++r) {
-            void *p = nullptr;
-            int64_t c = 0;
-            GINGR_TRY(gingr_model_gram_exchange(g->model[(size_t)r], &p, &c));
-            if (hipSetDevice(g->dev[(size_t)r]) != hipSuccess ||
-                hipMemcpy(p, tot.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
-                return group_fail(g, GINGR_ERR_HIP, "group: moment upload failed");
+            void *buf = nullptr;
+            bool fine = false;
+            if (hipSetDevice(g->dev[(size_t)r]) != hipSuccess) {
+                release();
+                return group_fail(g, GINGR_ERR_HIP, "group: hipSetDevice failed");
+            }
+            const int rc = alloc_peer_readable(g, (size_t)count * sizeof(double), &buf, &fine);
+            if (rc) {
+                release();
+                return rc;
+            }
+            tmp[(size_t)r] = static_cast<double *>(buf);
         }
+        // copy (own stream), wait, sum (own stream), wait: a one-off, so the host may wait between the steps
+        int rc = g->run([&](int r) {
+            gingr_ctx *ctx = g->ctx[(size_t)r];
+            if (hipMemcpyAsync(tmp[(size_t)r], mom[(size_t)r], (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+                return gingr_set_error(ctx, GINGR_ERR_HIP, "group: moment copy failed");
+            return gingr_ctx_synchronize(ctx);
+        });
+        if (!rc)
+            rc = g->run([&](int r) {
+                gingr_ctx *ctx = g->ctx[(size_t)r];
+                PeerPtrs src;
+                for (int q = 0; q < n; ++q) src.p[q] = tmp[(size_t)q];
+                hipLaunchKernelGGL(peer_sum_kernel, dim3((unsigned)ceil_div(ceil_div(count, 2), 256)), dim3(256), 0, ctx->stream,
+                                   mom[(size_t)r], src, n, count);
+                if (hipGetLastError() != hipSuccess) return gingr_set_error(ctx, GINGR_ERR_HIP, "group: moment all-reduce launch failed");
+                return gingr_ctx_synchronize(ctx);
+            });
+        release();
+        if (rc) return rc;
         GINGR_TRY(g->run([&](int r) { return gingr_model_finalize(g->ctx[(size_t)r], g->model[(size_t)r]); }));
     }
     g->rank = gingr_model_rank(g->model[0]);
@@ -239,6 +311,12 @@ int exchange_segment(gingr_group *g, int r, int s, int parity, bool ok) {
     if (hipGetLastError() != hipSuccess) return gingr_set_error(ctx, GINGR_ERR_HIP, "group: all-reduce kernel launch failed");
     return GINGR_OK;
 }
+// timer slots of the exchanges (gingr_ctx_timing_read): 6 = segment 0 (column sums), 7 = segment 1 (Gram bundle); the span runs from
+// the record of the shard's own event to the end of its sum kernel, i.e. it includes the wait for the slowest peer
+int timed_exchange_segment(gingr_group *g, int r, int s, int parity, bool ok) {
+    TimerScope ts(g->ctx[(size_t)r], 6 + s);
+    return exchange_segment(g, r, s, parity, ok);
+}
 
 int group_update(gingr_group *g, bool icp, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations) {
     if (!g || n_iterations < 0) return GINGR_ERR_BAD_ARGUMENT;
@@ -260,7 +338,7 @@ int group_update(gingr_group *g, bool icp, const gingr_cpd_params *cp, const gin
                 if (!rc) rc = icp ? gingr_fitter_icp_phase_async(f, ip, ph) : gingr_fitter_cpd_phase_async(f, cp, ph);
                 // ICP: the nearest-neighbour phase has nothing to exchange (rows are independent)
                 if (ph < GINGR_NUM_SEGMENTS && !(icp && ph == 0)) {
-                    const int xrc = exchange_segment(g, r, ph, parity, rc == GINGR_OK);
+                    const int xrc = timed_exchange_segment(g, r, ph, parity, rc == GINGR_OK);
                     if (!rc) rc = xrc;
                 }
             }
@@ -291,6 +369,12 @@ int gingr_group_create(int32_t ndev, const int32_t *devices, gingr_group **out) 
     g->end.assign((size_t)ndev, 0);
     g->status.assign((size_t)ndev, GINGR_OK);
     g->bar.n = ndev;
+    {
+        std::vector<int> uniq(g->dev);
+        std::sort(uniq.begin(), uniq.end());
+        g->distinct_devices = (int)(std::unique(uniq.begin(), uniq.end()) - uniq.begin());
+    }
+    DeviceGuard guard;
     for (int r = 0; r < ndev; ++r) {
         const int rc = gingr_ctx_create(devices[r], &g->ctx[(size_t)r]);
         if (rc) {
@@ -401,25 +485,38 @@ int gingr_group_set_target(gingr_group *g, int64_t N, const double *target_xyz) 
     }
     if (g->n == 1) return GINGR_OK;
     const int64_t total = round_up(g->off[GINGR_NUM_SEGMENTS - 1] + g->cnt[GINGR_NUM_SEGMENTS - 1], 32);
+    DeviceGuard guard;
+    // any failure below leaves NO exchange behind (free_exchange): group_update then refuses to run instead of handing null send
+    // buffers / events to the kernels
+    auto fail = [&](int code, const char *what) {
+        free_exchange(g);
+        return what ? group_fail(g, code, what) : code;
+    };
+    g->fine_grained = true;
     for (int p = 0; p < 2; ++p) {
         g->send[p].assign((size_t)g->n, nullptr);
         for (int s = 0; s < GINGR_NUM_SEGMENTS; ++s) g->ready[p][s].assign((size_t)g->n, nullptr);
         for (int r = 0; r < g->n; ++r) {
-            if (hipSetDevice(g->dev[(size_t)r]) != hipSuccess) return group_fail(g, GINGR_ERR_HIP, "group: hipSetDevice failed");
+            if (hipSetDevice(g->dev[(size_t)r]) != hipSuccess) return fail(GINGR_ERR_HIP, "group: hipSetDevice failed");
             void *buf = nullptr;
-            // fine-grained: coherent for the peers' reads; plain device memory if the flag is not supported
-            if (hipExtMallocWithFlags(&buf, (size_t)total * sizeof(double), hipDeviceMallocFinegrained) != hipSuccess) {
-                (void)hipGetLastError();
-                if (hipMalloc(&buf, (size_t)total * sizeof(double)) != hipSuccess)
-                    return group_fail(g, GINGR_ERR_HIP, "group: out of device memory (send buffer)");
-            }
-            if (hipMemset(buf, 0, (size_t)total * sizeof(double)) != hipSuccess) return group_fail(g, GINGR_ERR_HIP, "group: memset failed");
+            bool fine = false;
+            const int rc = alloc_peer_readable(g, (size_t)total * sizeof(double), &buf, &fine);
+            if (rc) return fail(rc, nullptr);
             g->send[p][(size_t)r] = static_cast<double *>(buf);
+            g->fine_grained = g->fine_grained && fine;
+            if (hipMemset(buf, 0, (size_t)total * sizeof(double)) != hipSuccess) return fail(GINGR_ERR_HIP, "group: memset failed");
             for (int s = 0; s < GINGR_NUM_SEGMENTS; ++s)
                 if (hipEventCreateWithFlags(&g->ready[p][s][(size_t)r], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess)
-                    return group_fail(g, GINGR_ERR_HIP, "group: hipEventCreate failed");
+                    return fail(GINGR_ERR_HIP, "group: hipEventCreate failed");
         }
     }
+    return GINGR_OK;
+}
+
+int gingr_group_exchange_info(const gingr_group *g, int32_t *distinct_devices, int32_t *fine_grained) {
+    if (!g) return GINGR_ERR_BAD_ARGUMENT;
+    if (distinct_devices) *distinct_devices = g->distinct_devices;
+    if (fine_grained) *fine_grained = (g->n > 1 && !g->send[0].empty() && g->fine_grained) ? 1 : 0;
     return GINGR_OK;
 }
 

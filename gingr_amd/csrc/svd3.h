@@ -3,12 +3,39 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// The float64 sine, cosine, arctangent and arcsine are each ~150-250 instructions when inlined, and the Euler round trip below calls
+// them ten times from ONE thread of a kernel that starts with a cold instruction cache behind the long all-pairs kernels (the
+// post-solve kernel was 33 KB of straight-line code executed once per launch).  On the device they are real calls to one copy
+// each: less code to fetch, the same values.
+#if defined(__HIP_DEVICE_COMPILE__)
+struct GingrSinCos {
+    double s, c;
+};
+__device__ __attribute__((noinline)) inline GingrSinCos gingr_sincos(double x) {
+    GingrSinCos r;
+    r.s = sin(x);
+    r.c = cos(x);
+    return r;
+}
+__device__ __attribute__((noinline)) inline double gingr_atan2(double y, double x) { return atan2(y, x); }
+__device__ __attribute__((noinline)) inline double gingr_asin(double x) { return asin(x); }
+#define GINGR_SINCOS(x, sv, cv)                \
+    const GingrSinCos sc_##sv = gingr_sincos(x); \
+    const double sv = sc_##sv.s, cv = sc_##sv.c
+#define GINGR_ATAN2(y, x) gingr_atan2((y), (x))
+#define GINGR_ASIN(x) gingr_asin(x)
+#else
+#define GINGR_SINCOS(x, sv, cv) const double sv = sin(x), cv = cos(x)
+#define GINGR_ATAN2(y, x) atan2((y), (x))
+#define GINGR_ASIN(x) asin(x)
+#endif
+
 // ------------------------------------------------------------------------------------------ rotation conventions
 // scalismo RotationSpace3D: R = Rz(phi) Ry(theta) Rx(psi) ("x-convention"), and Slabaugh's inverse.
 __host__ __device__ inline void euler_to_rot(const double e[3], double R[9]) {
-    const double cphi = cos(e[0]), sphi = sin(e[0]);
-    const double cth = cos(e[1]), sth = sin(e[1]);
-    const double cpsi = cos(e[2]), spsi = sin(e[2]);
+    GINGR_SINCOS(e[0], sphi, cphi);
+    GINGR_SINCOS(e[1], sth, cth);
+    GINGR_SINCOS(e[2], spsi, cpsi);
     R[0] = cth * cphi;
     R[1] = spsi * sth * cphi - cpsi * sphi;
     R[2] = spsi * sphi + cpsi * sth * cphi;
@@ -22,26 +49,28 @@ __host__ __device__ inline void euler_to_rot(const double e[3], double R[9]) {
 
 __host__ __device__ inline void rot_to_euler(const double R[9], double e[3]) {
     if (fabs(fabs(R[6]) - 1) > 0.0001) {
-        const double theta = asin(-R[6]);
-        const double ct = cos(theta);
-        e[2] = atan2(R[7] / ct, R[8] / ct);
-        e[0] = atan2(R[3] / ct, R[0] / ct);
+        const double theta = GINGR_ASIN(-R[6]);
+        GINGR_SINCOS(theta, st_unused, ct);
+        (void)st_unused;
+        e[2] = GINGR_ATAN2(R[7] / ct, R[8] / ct);
+        e[0] = GINGR_ATAN2(R[3] / ct, R[0] / ct);
         e[1] = theta;
     } else {
         e[0] = 0.0;  // gimbal lock: phi := 0
         if (fabs(R[6] + 1) < 0.0001) {
             e[1] = 3.14159265358979323846 / 2.0;
-            e[2] = e[0] + atan2(R[1], R[2]);
+            e[2] = e[0] + GINGR_ATAN2(R[1], R[2]);
         } else {
             e[1] = -3.14159265358979323846 / 2.0;
-            e[2] = -e[0] + atan2(-R[1], -R[2]);
+            e[2] = -e[0] + GINGR_ATAN2(-R[1], -R[2]);
         }
     }
 }
 
 
-// one-sided Jacobi SVD of a 3x3 matrix: A = U diag(s) V^T, s descending
-__device__ inline void svd3(const double Ain[9], double U[9], double s[3], double V[9]) {
+// one-sided Jacobi SVD of a 3x3 matrix: A = U diag(s) V^T, s descending.  Out of line: it is the rarely taken fallback of
+// polar3_rotation, and its dynamically indexed arrays would otherwise put the whole calling kernel on scratch memory.
+__device__ __attribute__((noinline)) inline void svd3(const double Ain[9], double U[9], double s[3], double V[9]) {
     double A[9];
     for (int q = 0; q < 9; ++q) {
         A[q] = Ain[q];

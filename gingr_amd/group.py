@@ -108,6 +108,13 @@ class DeviceGroup:
     def synchronize(self):
         self._check(self._lib.gingr_group_synchronize(self.handle), "gingr_group_synchronize")
 
+    def exchange_info(self) -> dict:
+        """How the shards exchange: physical devices behind them, and whether the peer-read send buffers are fine-grained device
+        memory (gingr_group_exchange_info; always true once shards sit on more than one device)."""
+        nd, fg = ctypes.c_int32(0), ctypes.c_int32(0)
+        self._check(self._lib.gingr_group_exchange_info(self.handle, ctypes.byref(nd), ctypes.byref(fg)), "gingr_group_exchange_info")
+        return {"distinct_devices": int(nd.value), "fine_grained_send_buffers": bool(fg.value)}
+
     def close(self):
         if getattr(self, "handle", None):
             self._lib.gingr_group_destroy(self.handle)

@@ -165,17 +165,39 @@ class ShardedFitter:
         self.all_reduce(self._segment(seg))
         torch.cuda.current_stream(self.ctx.device).synchronize()    # the sums are in place before the next phase reads them
 
+    def _reduce_callback(self):
+        """The gingr_allreduce_fn handed to the library (kept alive as long as the fitter): segment index -> all-reduce of that
+        segment of the exchange buffer, ordered against the library's stream (_exchange).  An exception raised by the collective
+        is kept and re-raised by the caller of the update; the library sees a non-zero status and stops enqueuing."""
+        if getattr(self, "_reduce_cb", None) is None:
+            def cb(_user, seg, _ptr, _count):
+                try:
+                    self._exchange(int(seg))
+                    return 0
+                except BaseException as e:  # must not propagate through the C frame
+                    self._cb_error = e
+                    return 1
+            self._reduce_cb = nat.ALLREDUCE_FN(cb)
+        self._cb_error = None
+        return self._reduce_cb
+
+    def _sharded_call(self, fn_name: str, params, n_iterations: int):
+        cb = self._reduce_callback()
+        rc = getattr(self._lib, fn_name)(self.handle, ctypes.byref(params), int(n_iterations), cb, None)
+        if self._cb_error is not None:
+            err, self._cb_error = self._cb_error, None
+            raise err
+        _check(self.ctx.handle, rc, fn_name)
+
     def update_cpd(self, w: float = 0.0, lambda_: float = 1.0, n_iterations: int = 1):
+        """n iterations; world > 1: ONE library call that runs the three phases per iteration and calls back for the two all-reduces
+        (gingr_fitter_update_cpd_sharded_async) -- no Python between the kernels of an iteration except inside the collective."""
         p = nat.CpdParams(w, lambda_)
         if self.world == 1:
             _check(self.ctx.handle, self._lib.gingr_fitter_update_cpd_async(self.handle, ctypes.byref(p), n_iterations),
                    "gingr_fitter_update_cpd_async")
             return
-        for _ in range(n_iterations):
-            drive_update(
-                lambda ph: _check(self.ctx.handle, self._lib.gingr_fitter_cpd_phase_async(self.handle, ctypes.byref(p), ph),
-                                  "gingr_fitter_cpd_phase_async"),
-                self._exchange, self.world)
+        self._sharded_call("gingr_fitter_update_cpd_sharded_async", p, n_iterations)
 
     def update_icp(self, initial_sigma: float, end_sigma: float, max_iterations: int, n_iterations: int = 1):
         p = nat.IcpParams(initial_sigma, end_sigma, max_iterations)
@@ -183,11 +205,17 @@ class ShardedFitter:
             _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_async(self.handle, ctypes.byref(p), n_iterations),
                    "gingr_fitter_update_icp_async")
             return
+        self._sharded_call("gingr_fitter_update_icp_sharded_async", p, n_iterations)
+
+    def update_cpd_by_phases(self, w: float = 0.0, lambda_: float = 1.0, n_iterations: int = 1):
+        """The same iterations driven phase by phase from the host (three library calls + two collectives per iteration): the
+        protocol spelled out, kept for tests and for hosts without callbacks."""
+        p = nat.CpdParams(w, lambda_)
         for _ in range(n_iterations):
             drive_update(
-                lambda ph: _check(self.ctx.handle, self._lib.gingr_fitter_icp_phase_async(self.handle, ctypes.byref(p), ph),
-                                  "gingr_fitter_icp_phase_async"),
-                self._exchange, self.world, skip_segment0=True)
+                lambda ph: _check(self.ctx.handle, self._lib.gingr_fitter_cpd_phase_async(self.handle, ctypes.byref(p), ph),
+                                  "gingr_fitter_cpd_phase_async"),
+                self._exchange, self.world)
 
     def close(self):
         if getattr(self, "handle", None):

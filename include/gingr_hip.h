@@ -349,6 +349,19 @@ int gingr_fitter_exchange(gingr_fitter *f, void **dev_ptr, int64_t offsets[GINGR
                           int64_t counts[GINGR_NUM_SEGMENTS]);
 int gingr_fitter_cpd_phase_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t phase);
 int gingr_fitter_icp_phase_async(gingr_fitter *f, const gingr_icp_params *p, int32_t phase);
+/* The same protocol as ONE call per n iterations: the library runs the phases and calls `reduce(user, segment, device_ptr, count)`
+ * wherever a segment has to be summed across the shards; the callback enqueues an in-place float64 sum all-reduce of those
+ * `count` elements, ordered after everything already on the context's stream and before whatever is enqueued on it afterwards
+ * (RCCL on that stream, or torch.distributed with that stream current), and returns 0 -- any other value aborts the update and
+ * is returned as GINGR_ERR_STATE.  Nothing waits for the GPU: with an asynchronous collective all n iterations are enqueued
+ * back to back.  ICP point-cloud correspondences need no segment-0 exchange (the rows are independent) and the callback is not
+ * called for it.  Replaces the host loop of three phase calls + two collectives per iteration (gingr_amd/sharded.py);
+ * reference: the per-iteration work of G/api/GingrAlgorithm.scala:192-254 on a row shard. */
+typedef int (*gingr_allreduce_fn)(void *user, int32_t segment, void *device_ptr, int64_t count);
+int gingr_fitter_update_cpd_sharded_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t n_iterations, gingr_allreduce_fn reduce,
+                                          void *user);
+int gingr_fitter_update_icp_sharded_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations, gingr_allreduce_fn reduce,
+                                          void *user);
 
 /* ---- device group: the row-sharded update across the GPUs of ONE node from ONE host process (multi-GPU for a C / JVM host) ----
  * SURVEY.md section 8b "gingr_group_create(ndev, devs[], ...) wrapping the same calls with row-sharding".  The group owns one
@@ -385,15 +398,28 @@ int gingr_group_get_state(gingr_group *g, double *alpha, gingr_state_scalars *s,
 int gingr_group_update_cpd_async(gingr_group *g, const gingr_cpd_params *p, int32_t n_iterations);
 int gingr_group_update_icp_async(gingr_group *g, const gingr_icp_params *p, int32_t n_iterations);
 int gingr_group_synchronize(gingr_group *g);
+/* How the group exchanges (diagnostics for a first run on real multi-GPU hardware): *distinct_devices = physical devices behind
+ * the shards; *fine_grained = 1 when the peer-read send buffers are fine-grained device allocations (always the case when
+ * distinct_devices > 1: gingr_group_set_target fails with GINGR_ERR_HIP instead of falling back to coarse-grained memory, which
+ * a peer could not read coherently).  Either pointer may be NULL.  No reference counterpart (the reference is single-device). */
+int gingr_group_exchange_info(const gingr_group *g, int32_t *distinct_devices, int32_t *fine_grained);
 
 /* -------------------------------------------------------------- timing hooks
  * HIP-event timing of the dominant kernels on the context's stream (bench.py's live roofline measurement).
  * which: 0 = cpd_colsum, 1 = cpd_rowstats, 2 = gram, 3 = whole update, 4 = basis sweep (one streaming pass over Q0),
- * 5 = posterior solve.  Returns accumulated ms and launches since
+ * 5 = posterior solve (unfused tail only), 6 / 7 = the device group's exchange of segment 0 / 1 on this shard (from the record of
+ * the shard's own event to the end of its sum kernel: includes the wait for the slowest peer; the host-driven sharded update records its two collectives there too), 8 = the
+ * nearest-neighbour scan kernel alone.  Returns accumulated ms and launches since
  * the last reset.  Enabling adds two event records per launch. */
 int gingr_ctx_timing_enable(gingr_ctx *ctx, int32_t enable);
 int gingr_ctx_timing_read(gingr_ctx *ctx, int32_t which, double *total_ms, int64_t *launches);
 int gingr_ctx_timing_reset(gingr_ctx *ctx);
+/* Diagnostics of the nearest-neighbour scan (ClosestPointRegistrator.scala:139-145 is an unpruned scan of every pair; this one prunes
+ * exactly): with counting enabled every gingr_nn / ICP launch on this context adds the distance tests it really executed to a device
+ * counter (a second instantiation of the kernel; the default one carries no counter).  gingr_ctx_nn_counting(ctx, 1) switches it on
+ * and clears the counter, (ctx, 0) switches it off; gingr_ctx_nn_tests waits for the stream and returns the count. */
+int gingr_ctx_nn_counting(gingr_ctx *ctx, int32_t enable);
+int gingr_ctx_nn_tests(gingr_ctx *ctx, int64_t *tests);
 
 /* ---- classic Coherent Point Drift (the reference's `other/` CPD family as a second consumer of the
  * affinity statistics and of the Gaussian kernel block) ----------------------------------------------------------------------

@@ -446,6 +446,16 @@ JFN(jint, groupUpdateIcp)(JNIEnv *, jclass, jlong g, jdouble initialSigma, jdoub
     return gingr_group_update_icp_async(P<gingr_group>(g), &p, n);
 }
 JFN(jint, groupSynchronize)(JNIEnv *, jclass, jlong g) { return gingr_group_synchronize(P<gingr_group>(g)); }
+// out2 = {physical devices behind the shards, 1 if the peer-read send buffers are fine-grained}: what a first multi-GPU run is read by
+JFN(jint, groupExchangeInfo)(JNIEnv *env, jclass, jlong g, jintArray out2) {
+    int32_t nd = 0, fg = 0;
+    const int rc = gingr_group_exchange_info(P<gingr_group>(g), &nd, &fg);
+    if (out2 && env->GetArrayLength(out2) >= 2) {
+        const jint v[2] = {nd, fg};
+        env->SetIntArrayRegion(out2, 0, 2, v);
+    }
+    return rc;
+}
 #else
 // No JDK headers on this machine: the shim is not built (the C ABI it wraps is still covered by the Python tests).
 #endif

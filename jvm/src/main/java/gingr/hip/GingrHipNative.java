@@ -138,4 +138,6 @@ public final class GingrHipNative {
     public static native int groupUpdateCpd(long group, double w, double lambda, int nIterations);
     public static native int groupUpdateIcp(long group, double initialSigma, double endSigma, int maxIterations, int nIterations);
     public static native int groupSynchronize(long group);
+    /** out2 = {physical devices behind the shards, 1 if the peer-read send buffers are fine-grained device memory} */
+    public static native int groupExchangeInfo(long group, int[] out2);
 }

@@ -2,7 +2,9 @@
 //> using dep "ch.unibas.cs.gravis::gingr:1.0-RC1"
 //> using dep "ch.unibas.cs.gravis::scalismo:1.0-RC1"
 /*
- * Reference dump for a maintainer WITH a JVM:   scala-cli run jvm/tools/RefDump.scala -- <data dir> <out dir>
+ * Reference dump for a maintainer WITH a JVM:   scala-cli run jvm/tools/RefDump.scala -- <data dir> <out dir> [--hot-path-only]
+ * (--hot-path-only: the deterministic CPD and point-cloud-ICP cases only -- enough to pin the hot path; the surface-ICP case adds
+ *  bit-sensitive accept / reject decisions that can only be agreement-rate-checked, INTEGRATION.md section 5)
  *
  * NOT RUN IN THIS REPOSITORY'S IMAGE (no JVM here or on the GPU boxes, SURVEY.md 8c) -- which is exactly why oracle/ says
  * "parity unpinned".  Running this once against the real GiNGR 1.0-RC1 / scalismo 1.0-RC1 produces the golden vectors that pin it:
@@ -86,7 +88,8 @@ def dump[S <: GingrRegistrationState[S]](out: File, caseName: String, configJson
   w.close()
   println(s"wrote $out  (${seconds / nIterations} s per update)")
 
-@main def RefDump(dataDir: String, outDir: String): Unit =
+@main def RefDump(dataDir: String, outDir: String, flags: String*): Unit =
+  val hotPathOnly = flags.contains("--hot-path-only")
   new File(outDir).mkdirs()
   val reference = MeshIO.readMesh(new File(dataDir, "femur.stl")).get
   val target = MeshIO.readMesh(new File(dataDir, "femur_target.stl")).get
@@ -114,7 +117,8 @@ def dump[S <: GingrRegistrationState[S]](out: File, caseName: String, configJson
       })
 
   // ---- ICP: point-cloud and surface correspondence, no global transform / rigid
-  for (method, tr, tag) <- Seq((PointcloudClosestPoint, NoTransforms, "icp_pointcloud"), (TriangularClosestPoint, RigidTransforms, "icp_surface")) do
+  for (method, tr, tag) <- Seq((PointcloudClosestPoint, NoTransforms, "icp_pointcloud"), (TriangularClosestPoint, RigidTransforms, "icp_surface"))
+      if !(hotPathOnly && method == TriangularClosestPoint) do
     val cfg = IcpConfiguration(maxIterations = 10, initialSigma = 100.0, endSigma = 1.0, correspondenceMethod = method, useLandmarkCorrespondence = false)
     val alg = new IcpRegistration()
     val init = alg.initializeState(general(tr, false), cfg)

@@ -32,3 +32,26 @@ def test_bench_launch_line_with_ranks_sharing_the_device(world, points):
     assert sc["iterations"] == 1 + 4 + 3            # warm-up + timed + roofline steps
     assert sc["sigma2_rel"] < 1e-10 and sc["alpha_max_abs"] < 1e-9, sc
     assert out["valid"] is True
+    # who took part and what the exchanges cost: the fields a first run on real multi-GPU hardware is read by
+    rr = out["rccl_ranks"]
+    assert rr["world_size"] == world and len(rr["ranks"]) == world and sorted(g["rank"] for g in rr["ranks"]) == list(range(world))
+    assert rr["backend"] == "gloo" and rr["distinct_device_uuids"] == 1        # this test: every rank on device 0
+    ex = out["exchange"]
+    assert ex["segment0_column_sums_ms"] > 0.0 and ex["segment1_gram_bundle_ms"] > 0.0
+    assert ex["bytes"]["segment0"] == 8 * points
+
+
+def test_bench_group_mode_reports_the_exchange():
+    """`bench.py --group --logical-shards 2`: the in-library device group prints the same two fields."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--group", "--logical-shards", "2", "--steps", "4", "--warmup", "1",
+                        "--points", "6000", "--rank", "40", "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    rr = out["rccl_ranks"]
+    assert rr["world_size"] == 2 and rr["distinct_devices"] == 1 and rr["distinct_device_uuids"] == 1
+    ex = out["exchange"]
+    assert ex["segment0_column_sums_ms"] > 0.0 and ex["segment1_gram_bundle_ms"] > 0.0

@@ -129,3 +129,51 @@ def test_group_device_built_gpmm_and_failure_status(ctx):
     a2, sc2, _ = g.get_state(fit=False)
     assert sc2.status == ga.FittingStatuses.ModelFlexibilityError and np.array_equal(a2, a)
     g.close()
+
+
+def test_group_exchange_info_and_callers_device_untouched(ctx):
+    """Logical shards on one device may use plain device memory; the diagnostics say what was allocated, and the group's host-side
+    set-up leaves the caller's current device where it was (finish_models / set_target selected devices on the
+    caller's thread)."""
+    import torch
+    import gingr_amd as ga
+    mo, target = _case(M=700, N=650, rank=24)
+    before = torch.cuda.current_device()
+    g = ga.DeviceGroup([0, 0])
+    g.upload_model(mo.ref, mo.mean, mo.U, mo.lam)
+    g.set_target(target)
+    info = g.exchange_info()
+    assert info["distinct_devices"] == 1 and isinstance(info["fine_grained_send_buffers"], bool)
+    assert torch.cuda.current_device() == before
+    g.close()
+
+
+def test_two_physical_devices_equal_one_device(ctx):
+    """The peer path proper (hipDeviceEnablePeerAccess, cross-device event waits, remote loads of fine-grained send buffers): a
+    group over two PHYSICAL devices against one device.  Skipped on the one-GPU boxes of the pool; runs wherever two GPUs are
+    visible (no scaling curve has been measured yet)."""
+    import gingr_amd as ga
+    from gingr_amd import _native as nat
+    from gingr_amd.sharded import ShardedFitter
+    if nat.load().gingr_device_count() < 2:
+        pytest.skip("one GPU visible: the two-device peer path cannot run here")
+    mo, target = _case()
+    model = ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam)
+    s2 = ctx.cpd_initial_sigma2(mo.ref, target)
+    single = ShardedFitter(ctx, model, target)
+    single.set_state(np.zeros(mo.rank), s2)
+    single.update_cpd(0.1, 1.0, 5)
+    a1, sc1, fit1 = single.get_state()
+    single.close()
+    g = ga.DeviceGroup([0, 1])
+    g.upload_model(mo.ref, mo.mean, mo.U, mo.lam)
+    g.set_target(target)
+    info = g.exchange_info()
+    assert info["distinct_devices"] == 2 and info["fine_grained_send_buffers"] is True
+    g.set_options(1, 1.0)
+    g.set_state(np.zeros(mo.rank), s2)
+    g.update_cpd(0.1, 1.0, 5)
+    a, sc, fit = g.get_state()
+    g.close()
+    assert sc.iteration == 5 and sc.status == 0
+    assert abs(sc.sigma2 - sc1.sigma2) < 1e-9 * sc1.sigma2 and rel(fit, fit1) < 1e-9

@@ -163,11 +163,38 @@ def replay_hip(ctx, path):
     algo.close()
 
 
+def hot_path_flavours(files):
+    """Which flavours of the hot path the dumps present cover.  A PARTIAL dump is enough to pin the hot path: the two deterministic
+    flavours without bit-sensitive accept / reject decisions -- CPD and ICP with the point-cloud correspondence
+    (`scala-cli run jvm/tools/RefDump.scala -- <data> <out> --hot-path-only`) -- are replayed with the full north-star tolerances;
+    the surface-ICP file only adds an agreement-rate check."""
+    got = set()
+    for f in files:
+        c = json.load(open(f))["config"]
+        got.add("cpd" if c["algorithm"] == "cpd" else ("icp_pointcloud" if c.get("method") == "PointcloudClosestPoint" else "icp_surface"))
+    return got
+
+
 def test_reference_dump_status():
-    """Always runs: states in the test report whether parity is pinned."""
+    """Always runs: states in the test report whether parity is pinned, and for which flavours of the hot path."""
     if not FILES:
         pytest.skip(UNPINNED)
     assert all(json.load(open(f))["schema"] == "gingr-refdump-1" for f in FILES)
+    got = hot_path_flavours(FILES)
+    missing = {"cpd", "icp_pointcloud"} - got
+    if missing:
+        pytest.skip("parity pinned for %s only; hot path still unpinned for %s" % (sorted(got), sorted(missing)))
+
+
+def test_partial_dump_is_enough_for_the_hot_path(tmp_path):
+    """The consumer accepts any subset of the RefDump files: CPD + point-cloud ICP alone count as the hot path pinned."""
+    a, b, c = (str(tmp_path / n) for n in ("femur_cpd_w01.json", "femur_icp_pointcloud.json", "femur_icp_surface.json"))
+    _write_oracle_dump(a, "cpd")
+    _write_oracle_dump(b, "icp_pointcloud")
+    assert hot_path_flavours([a, b]) == {"cpd", "icp_pointcloud"}
+    assert hot_path_flavours([a]) == {"cpd"}
+    replay_oracle(a)
+    replay_oracle(b)
 
 
 # ------------------------------------------------------------------------------------------------ self-check of the consumer
