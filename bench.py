@@ -279,7 +279,14 @@ def main():
     ap.add_argument("--config1-stock-structure", choices=["cpu", "gpu"], default=None,
                     help="instead of the benchmark: config 1 (femur) stock-structure emulation (SURVEY 8d mode B); 'gpu' "
                          "also times the HIP path on the same inputs")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
+                    help="one measurement line for BASELINE.json config N (tools/bench_configs.py) instead of the headline benchmark")
     args = ap.parse_args()
+    if args.config:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_configs
+        print(json.dumps(bench_configs.CONFIGS[args.config]()), flush=True)
+        return 0
     if args.config1_stock_structure:
         cpu_baseline_stock_structure(args.config1_stock_structure == "gpu")
         return 0
@@ -516,7 +523,38 @@ def main():
         kernels.append({"kernel": "posterior_solve_lds_kernel", "avg_ms": ms / n, "launches": n, "bound": "latency"})
     ms, n = timing(3)
     upd_ms = ms / n if n else None
+    # ---- the two exchanges of an iteration as this rank / shard 0 sees them (HIP events on the kernels' stream around the collective
+    # resp. around the group's wait + peer-sum kernel: includes waiting for the slowest peer); N > 1: maximum over the ranks
+    exchange = None
+    if n_shards > 1 or use_dist:
+        ex = []
+        for seg in (0, 1):
+            ms, n = timing(6 + seg)
+            ex.append(ms / n if n else 0.0)
+        if use_dist:
+            te = torch.tensor(ex, dtype=torch.float64, device="cpu" if shared_device else f"cuda:{local_rank}")
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            ex = [float(v) for v in te.tolist()]
+        exchange = {"segment0_column_sums_ms": ex[0], "segment1_gram_bundle_ms": ex[1],
+                    "bytes": {"segment0": 8 * N, "segment1": 8 * (((args.rank + 15) // 16 * 16) ** 2 + (args.rank + 15) // 16 * 16 + 8)},
+                    "how": "HIP events around each all-reduce on the stream the kernels run on, averaged over the roofline "
+                           "iterations, max over ranks; includes the wait for the slowest peer"}
     timing(enable=False)
+    # ---- who took part: the world the collective library saw and the physical devices behind the ranks / shards
+    ranks_info = None
+    if use_dist:
+        props = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "local_rank": local_rank, "device": props.name, "uuid": str(getattr(props, "uuid", "")),
+                "pci_bus_id": getattr(props, "pci_bus_id", None)}
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, mine)
+        ranks_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                      "distinct_device_uuids": len({g["uuid"] for g in gathered}), "ranks": gathered}
+    elif args.group:
+        info = group.exchange_info()
+        uu = [str(getattr(torch.cuda.get_device_properties(d), "uuid", d)) for d in devices]
+        ranks_info = {"world_size": n_shards, "backend": "in-library device group (peer pointers, one-shot all-reduce)",
+                      "distinct_device_uuids": len(set(uu)), "devices": devices, "uuids": uu, **info}
     dom = max((k for k in kernels if k["bound"] == "valu_f64"), key=lambda k: k["avg_ms"], default=None)
     if dom is not None:
         tr, src = (load_pmc_traffic(dom["kernel"], M, args.rank)
@@ -532,7 +570,7 @@ def main():
                         "HBM and MFMA are not the binding resource.  In the contract's hbm|mfma vocabulary this is the "
                         "compute side: the peak used, 78.6 TFLOP/s, is also the dense f64 MFMA peak -- on gfx950 the f64 "
                         "vector and matrix pipes share the issue slots (profiles/r01_ubench_mfma_valu_overlap.txt), so "
-                        "moving the K=3 contraction to MFMA does not raise the ceiling (GINGR_AFFINITY=mfma measures it)"}
+                        "moving the K=3 contraction to MFMA does not raise the ceiling (measured in rounds 1-2: tools/experiment_affinity_mfma.hip)"}
 
     # ---- parity of the state the measurements ended in (outside every timed region): ONE more update on the device, then the
     # affinity statistics of that evaluation (P1, PX of this rank's rows; den, Np) and the sigma2 it committed against the strict
@@ -610,6 +648,8 @@ def main():
             "update_ms_device": upd_ms,
             # host time to enqueue one step (12 kernel launches, no synchronisation inside): what a HIP graph could save at most
             "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
+            "rccl_ranks": ranks_info,
+            "exchange": exchange,
             "roofline": roof,
             "kernels": kernels,
             "cpu_baseline": cpu,

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Same-box comparison of several builds / settings of the library (boxes of the pool differ by +-5 % in sustained clock, so
+# variants are only comparable within ONE gpurun call).  Each variant is "name=library.so[,ENV=VALUE...]" (library relative to
+# gingr_amd/; empty = the in-tree build); runs alternate, three rounds.
+# usage: tools/abn.sh "r02=libgingr_hip_r02.so" "cur=" "cur_notail=,GINGR_FUSED_TAIL=0" -- [bench.py arguments]
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+VARS=()
+while [ $# -gt 0 ] && [ "$1" != "--" ]; do VARS+=("$1"); shift; done
+shift
+O=$R/gpurun_out/abn; rm -rf $O; mkdir -p $O
+for i in 1 2 3; do
+  for v in "${VARS[@]}"; do
+    name=${v%%=*}; spec=${v#*=}
+    lib=${spec%%,*}; envs=""
+    if [[ "$spec" == *,* ]]; then envs=${spec#*,}; fi
+    (
+      if [ -n "$lib" ]; then export GINGR_HIP_LIB=$R/gingr_amd/$lib; fi
+      IFS=',' read -ra E <<< "$envs"; for e in "${E[@]}"; do [ -n "$e" ] && export "$e"; done
+      python3 $R/bench.py --no-cpu-baseline --no-parity-check "$@" 2> $O/$name$i.err | tail -1 > $O/$name$i.json
+    )
+  done
+done
+python3 - "$O" "${VARS[@]}" <<'PY'
+import json, glob, sys
+O = sys.argv[1]
+for v in sys.argv[2:]:
+    name = v.split("=")[0]
+    rows = []
+    for f in sorted(glob.glob(f"{O}/{name}?.json")):
+        try: rows.append(json.load(open(f)))
+        except Exception as e: rows.append({"ms_per_step": float("nan"), "kernels": []})
+    print(f"{name:14s}", " ".join("%.4f" % r["ms_per_step"] for r in rows), "| valid", [r.get("valid") for r in rows][-1], "| kernels (ms):",
+          {k["kernel"].replace("_kernel", ""): round(k["avg_ms"], 4) for k in rows[-1].get("kernels", [])})
+PY
