@@ -33,6 +33,7 @@ class RigidCPD:
                                                                       dptr(self.target), float(factory.lambda_), float(factory.beta),
                                                                       float(factory.w), ctypes.byref(h)), "gingr_classic_cpd_create")
         self._h = h
+        self._sigma2_init = self.sigma2()      # initializeGaussianKernel of the factory's template against this target
 
     def close(self):
         if self._h:
@@ -84,7 +85,10 @@ class RigidCPD:
     def Registration(self, max_iteration: int, tolerance: float = 0.001, verbose: bool = False) -> np.ndarray:
         """RigidCPD.Registration (:59-83): iterate until |sigma2' - sigma2| < tolerance or max_iteration non-converged iterations."""
         i, converged = 0, False
-        current = self.sigma2()
+        # the reference always starts from cpd.template and the initial variance (RigidCPD.scala:59-62), whatever Iteration or an
+        # earlier Registration left on the device
+        self.set_state(self.cpd.template, self._sigma2_init)
+        current = self._sigma2_init
         while i < max_iteration and not converged:
             if verbose:
                 print(f"CPD, iteration: {i}, variance: {current}")

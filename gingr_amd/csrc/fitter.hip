@@ -238,11 +238,28 @@ int model_finalize_impl(gingr_ctx *ctx, gingr_model *m) {
         for (int e = 0; e < 3; ++e)
             launch_small_gemm(ctx, m->r, m->rp, m->mom + ml.S(d, e), m->cmat, 1.0, m->cmat + (1 + d * 3 + e) * rr);
     GINGR_TRY(check_launch(ctx));
-    // S_tot = V diag(lam) V^T once per model: the uniform-weight posterior (I + S_tot / sigma2)^-1 rhs is two mat-vecs then
-    if (m->r <= 512) GINGR_TRY(launch_jacobi_eig(ctx, m->mom + ml.stot(), m->rp, m->r, m->eigL, m->eigV));
+    // (the eigen-decomposition of S_tot for the uniform-weight posterior is computed on first use: ensure_model_eig)
+    m->eig_ready = m->eig_failed = false;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     m->finalized = true;
     return GINGR_OK;
+}
+
+// S_tot = V diag(lam) V^T, once per model and only for the flavour that reads it (point-cloud ICP without landmarks: the posterior
+// (I + S_tot / sigma2)^-1 rhs is two mat-vecs then).  Computed on the first such update, not at model creation: CPD-only models,
+// the decimated models of runDecimated and the shards of a group never pay the one-workgroup Jacobi (0.6-1.2 ms at rank 100, 2 r^2
+// doubles of scratch, a stream synchronisation) and cannot fail on its account.  false: not available -- the caller takes the Cholesky path.
+bool ensure_model_eig(gingr_ctx *ctx, const gingr_model *m) {
+    if (m->eig_ready) return true;
+    if (m->eig_failed || m->r > 512) return false;
+    const MomentLayout ml{m->rp};
+    if (launch_jacobi_eig(ctx, m->mom + ml.stot(), m->rp, m->r, m->eigL, m->eigV) != GINGR_OK) {
+        (void)hipGetLastError();
+        m->eig_failed = true;
+        return false;
+    }
+    m->eig_ready = true;
+    return true;
 }
 
 }  // namespace
@@ -1051,7 +1068,8 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
             // the posterior mean of the uniform-weight case comes from the model's eigen-decomposition (no factorisation); a sampled
             // proposal needs the Cholesky factor itself (its square root of the covariance is part of the parity contract)
             static const int eig_env = getenv("GINGR_EIG_SOLVE") ? atoi(getenv("GINGR_EIG_SOLVE")) : 1;
-            const bool eig = eig_env && icp && !f->icp_surface && !f->reversed && f->n_lm == 0 && !f->zrand_active && r <= 512;
+            const bool eig = eig_env && icp && !f->icp_surface && !f->reversed && f->n_lm == 0 && !f->zrand_active && r <= 512 &&
+                             ensure_model_eig(ctx, m);
             if (eig)
                 launch_posterior_solve_eig(ctx, r, rp, m->eigV, m->eigL, &f->st->sigma2, rhs, f->acoef, f->st);
             else

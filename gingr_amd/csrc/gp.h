@@ -64,7 +64,8 @@ struct gingr_model {
     std::vector<int32_t> hperm, hiperm;  // host copies: device position -> original, original -> device position
     double *Binv = nullptr;   // [rp*rp] (S_tot/eps + I)^-1, valid after finalize
     double *eigV = nullptr;   // [r*r] eigenvectors of S_tot = Q^T Q (column k, row stride r) and
-    double *eigL = nullptr;   // [r] its eigenvalues (descending), valid after finalize: uniform-weight posterior (launch_posterior_solve_eig)
+    double *eigL = nullptr;   // [r] its eigenvalues (descending): uniform-weight posterior (launch_posterior_solve_eig); filled on first use
+    mutable bool eig_ready = false, eig_failed = false;  // fitter.hip: ensure_model_eig
     double *cmat = nullptr;   // [10][rp*rp], valid after finalize: [0] C = Binv S_tot / eps (alpha_1 = C a),
                               // [1 + 3d + e] T[d][e] = S[d][e] C  (S[d][e] alpha_1 = T[d][e] a)
     double c0[3] = {0, 0, 0};  // centroid of the FULL reference: fixed centring point of the Umeyama sums

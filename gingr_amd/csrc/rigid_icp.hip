@@ -33,6 +33,10 @@ __global__ __launch_bounds__(256) void icp_sums_kernel(Cloud p, Cloud t0, const 
     for (int q = 0; q < kSums; ++q) s[q] = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.n; i += (int64_t)kIcpBlocks * 256) {
         const int64_t j = idx[i];
+        if (j < 0 || j >= t0.n) {  // the scan leaves -1 for a query whose distances are all NaN (non-finite coordinates): no read out
+            s[0] += __builtin_nan("");  // of bounds; the NaN makes the transform non-finite, which the caller reports
+            continue;
+        }
         const double x0 = p.x[i] - c0x, x1 = p.y[i] - c0y, x2 = p.z[i] - c0z;
         const double y0 = t0.x[j] - c0x, y1 = t0.y[j] - c0y, y2 = t0.z[j] - c0z;
         s[0] += x0; s[1] += x1; s[2] += x2;

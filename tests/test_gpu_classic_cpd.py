@@ -73,6 +73,11 @@ def test_registration_loop(ctx, kind):
     gTY = reg.Registration(60)
     assert (reg.iterations, reg.converged) == (oit, oconv)
     assert rel(gTY, oTY) < 1e-6, rel(gTY, oTY)
+    # the reference's Registration always restarts from the template and the initial variance (RigidCPD.scala:59-62): a second call,
+    # or one after an Iteration has moved the device state, gives the same result
+    reg.Iteration()
+    again = reg.Registration(60)
+    assert (reg.iterations, reg.converged) == (oit, oconv) and np.array_equal(again, gTY)
     reg.close()
     wrapper = {"rigid": cl.RigidCPDRegistration, "affine": cl.AffineCPDRegistration, "nonrigid": cl.NonRigidCPDRegistration}[kind]
     assert rel(wrapper(ctx, Y, beta=8.0, max_iterations=60).register(X), oTY) < 1e-6
