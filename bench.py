@@ -234,11 +234,23 @@ def spawn_ranks(n_gpus: int, argv) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def _latest_profile(suffix: str):
+    """profiles/rNN_<suffix> of the highest round present (tracked artefacts of tools/final_profile.sh), or None"""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)):
+        m = re.match(r"r(\d\d)_", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
+
+
 def load_pmc_traffic(kernel: str, points: int, rank: int):
     """HBM bytes per launch of `kernel` from the tracked PMC artefact tools/pmc_traffic.sh produced for THIS workload
-    (profiles/r02_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes, as the
+    (profiles/rNN_pmc_traffic.json, newest round: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes, as the
     microarchitecture guide prescribes).  None when no artefact matches -- bench.py never invents the number."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = _latest_profile("pmc_traffic.json")
     try:
         d = json.load(open(path))
     except Exception:
@@ -249,7 +261,25 @@ def load_pmc_traffic(kernel: str, points: int, rank: int):
     k = d.get("kernels", {}).get(kernel)
     if not k:
         return None, None
-    return float(k["hbm_bytes_per_launch"]), f"profiles/r02_pmc_traffic.json ({k.get('note', 'FETCH_SIZE + WRITE_SIZE per launch')})"
+    rel = os.path.relpath(path, ROOT)
+    return float(k["hbm_bytes_per_launch"]), f"{rel} ({k.get('note', 'FETCH_SIZE + WRITE_SIZE per launch')})"
+
+
+def load_pmc_mfma(kernel: str, points: int, rank: int):
+    """Matrix-pipe counters of `kernel` (SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_MFMA, ... from tools/pmc_sq.sh's third pass) out of the
+    tracked artefact profiles/rNN_pmc_mfma.json for THIS workload; None when there is none."""
+    path = _latest_profile("pmc_mfma.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    wl = d.get("workload", {})
+    if wl.get("points") != points or wl.get("rank") != rank:
+        return None
+    k = d.get("kernels", {}).get(kernel)
+    if not k:
+        return None
+    return dict(k, source=os.path.relpath(path, ROOT))
 
 
 def main():
@@ -508,7 +538,10 @@ def main():
                         "frac": ach / F64_MFMA_PEAK_TFLOPS,
                         "note": "algorithmic flops of the full symmetric product (6 M rp^2); the kernel multiplies the upper triangle "
                                 "only, so the matrix pipe issues about half of them",
-                        "issued_flops_frac_of_peak": (ach * (rp / 16 + 1) / (2.0 * rp / 16)) / F64_MFMA_PEAK_TFLOPS})
+                        "issued_flops_frac_of_peak": (ach * (rp / 16 + 1) / (2.0 * rp / 16)) / F64_MFMA_PEAK_TFLOPS,
+                        # busy cycles of the matrix pipe / (SIMDs x kernel cycles) from the SQ counters (tracked artefact), next to
+                        # the time-derived fractions above
+                        "mfma_counters": load_pmc_mfma("gram_tri_kernel", M, args.rank) if n_shards == 1 and not args.emulate_world else None})
     ms, n = timing(4)
     if n:
         avg = ms / n

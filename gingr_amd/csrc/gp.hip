@@ -1745,9 +1745,20 @@ __device__ __forceinline__ void lds_matvec_T(const double *Mat, const double *x,
 // (Measured: the kernel stays at ~18 us at 50k points against 6 us at femur size -- what it waits for is not its data but its CODE:
 // ~30 KB of straight-line float64 code run once by one wave behind cold instruction caches; see svd3.h for the part of that which
 // could be shared)
+// -DGINGR_POST_STAMPS (diagnostic builds only): thread 0 prints where the kernel's wall time goes (100 MHz real-time counter)
+#ifdef GINGR_POST_STAMPS
+#define POST_STAMP(k) \
+    if (threadIdx.x == 0) stamp[k] = __builtin_amdgcn_s_memrealtime();
+#else
+#define POST_STAMP(k)
+#endif
 template <bool PRELOAD>
 __global__ __launch_bounds__(kPostThreads) void post_solve_kernel(PostSolveArgs A) {
     extern __shared__ double sm[];
+#ifdef GINGR_POST_STAMPS
+    __shared__ unsigned long long stamp[8];
+#endif
+    POST_STAMP(0)
     const int r = A.r, rp = A.rp, tid = threadIdx.x;
     const MomentLayout ml{rp};
     DevState *st = A.state;
@@ -1829,6 +1840,7 @@ __global__ __launch_bounds__(kPostThreads) void post_solve_kernel(PostSolveArgs 
         }
     }
     __syncthreads();
+    POST_STAMP(1)
     // 36 dot products, one wave each: [0..2] W[d].alpha, [3..5] W[d].alpha_c, [6..14] V[b][d].alpha (index d*3+b),
     // [15..23] V[d][b].alpha_c, [24..32] alpha_c.za[d][b], [33..35] alpha.za[d][d]
     const double *Wm = Vm + 9 * rp;
@@ -1853,8 +1865,10 @@ __global__ __launch_bounds__(kPostThreads) void post_solve_kernel(PostSolveArgs 
         if ((tid & 63) == 0) dots[t] = v;
     }
     __syncthreads();
+    POST_STAMP(2)
     if (tid == 0) post_pose_step(A, st, dots, P, Bm, BmI, hv, &bad);
     __syncthreads();
+    POST_STAMP(3)
     // second projection Q^T e from the moments (transformedModel.coefficients(newshape), :234-237)
     for (int k = tid; k < rp; k += kPostThreads) {
         double s = 0.0;
@@ -1881,9 +1895,17 @@ __global__ __launch_bounds__(kPostThreads) void post_solve_kernel(PostSolveArgs 
     const bool posterior_failed = st->err != 0;  // failure semantics: post_commit_step
     const bool failed = posterior_failed || bad;
     __syncthreads();
+    POST_STAMP(4)
     if (!failed)
         for (int k = tid; k < rp; k += kPostThreads) A.alpha[k] = anew[k];
     if (tid == 0) post_commit_step(A, st, P, posterior_failed, bad != 0);
+#ifdef GINGR_POST_STAMPS
+    if (tid == 0 && (st->iteration % 7) == 5) {
+        const unsigned long long e = __builtin_amdgcn_s_memrealtime();
+        printf("post_solve stamps (x10 ns): loads+lds %llu  dots %llu  pose(thread 0) %llu  proj+matvec %llu  commit %llu\n", stamp[1] - stamp[0],
+               stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], e - stamp[4]);
+    }
+#endif
 }
 
 __global__ void state_init_kernel(DevState *st, const gingr_state_scalars *h) {

@@ -7,7 +7,7 @@ import shutil
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "03"
 F, P = os.path.join(root, "gpurun_out", "final"), os.path.join(root, "profiles")
 
 
@@ -19,6 +19,9 @@ shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, f"r{rnd}_bench50k_fin
 shutil.copy(os.path.join(F, "kernel_stats.csv"), os.path.join(P, f"r{rnd}_bench50k_kernel_stats_final.csv"))
 shutil.copy(os.path.join(F, "pmc_traffic.json"), os.path.join(P, f"r{rnd}_pmc_traffic.json"))
 shutil.copy(os.path.join(F, "pmc_sq.txt"), os.path.join(P, f"r{rnd}_pmc_sq_counters.txt"))
+for name, dst in (("pmc_mfma.json", f"r{rnd}_pmc_mfma.json"), ("configs.json", f"r{rnd}_configs.json")):
+    if os.path.exists(os.path.join(F, name)):
+        shutil.copy(os.path.join(F, name), os.path.join(P, dst))
 
 e50 = {str(n): load(f"emu{n}.json")["ms_per_step"] for n in (1, 2, 4, 8)}
 one100 = load("bench_100k.json")

@@ -30,4 +30,30 @@ for p in ("p1", "p2", "p3"):
                 for c, v in d.items():
                     o.write(f"   {c:28s} mean {sum(v)/len(v):16.1f}  n={len(v)}\n")
 PY
-cat gpurun_out/pmc_sq/p1_summary.txt gpurun_out/pmc_sq/p2_summary.txt gpurun_out/pmc_sq/p3_summary.txt; cat gpurun_out/pmc_sq/mfma_counters_available.txt
+cat gpurun_out/pmc_sq/p1_summary.txt gpurun_out/pmc_sq/p2_summary.txt gpurun_out/pmc_sq/p3_summary.txt
+# the matrix-pipe figures bench.py reports next to its time-derived ones: gpurun_out/pmc_mfma.json (copy to profiles/rNN_pmc_mfma.json)
+python3 - <<'PY'
+import csv, glob, collections, json
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/pmc_sq/p3/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = next((n for n in ("gram_tri_kernel", "posterior_solve_lds_kernel", "chol_trailing_kernel") if n in row["Kernel_Name"]), None)
+        if k:
+            acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+out = {"workload": {"points": 50000, "rank": 100, "gpus": 1},
+       "method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY ... "
+                 "--kernel-trace only, bench.py --steps 3; means per launch summed over the chip.  SQ_BUSY_CYCLES is summed over the 32 "
+                 "shader engines that were busy; SQ_VALU_MFMA_BUSY_CYCLES counts cycles (64 per v_mfma_f64_16x16x4)", "kernels": {}}
+for k, d in acc.items():
+    m = {c: sum(v) / len(v) for c, v in d.items()}
+    e = {"counters": m, "launches": len(next(iter(d.values())))}
+    if k == "gram_tri_kernel" and m.get("SQ_BUSY_CYCLES"):
+        cyc = m["SQ_BUSY_CYCLES"] / 32.0                     # every shader engine is busy for the whole launch (256 workgroups)
+        e["kernel_cycles"] = cyc
+        e["mfma_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)
+        e["mfma_instructions"] = m.get("SQ_INSTS_MFMA")
+        e["note"] = "busy cycles of the matrix pipes / (1024 SIMDs x kernel cycles)"
+    out["kernels"][k] = e
+json.dump(out, open("gpurun_out/pmc_mfma.json", "w"), indent=1)
+print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters"} for k, v in out["kernels"].items()}))
+PY
