@@ -204,6 +204,13 @@ int main(int argc, char **argv) {
         GCHECK(gingr_group_shard_rows(g, 1, &rb, &re));
         if (re != M || gingr_group_model_rank(g) != r) return 14;
         GCHECK(gingr_group_set_target(g, N, target));
+        {   /* how the group exchanges: logical shards on one device may live in plain device memory, two devices must not */
+            int32_t nd = -1, fg = -1;
+            GCHECK(gingr_group_exchange_info(g, &nd, &fg));
+            if (nd != (devs[0] == devs[1] ? 1 : 2) || (nd > 1 && fg != 1)) return 14;
+            const double info[2] = {(double)nd, (double)fg};
+            put("C_exchange_info", info, 2);
+        }
         GCHECK(gingr_group_set_landmarks(g, 0, NULL, NULL, NULL));
         GCHECK(gingr_group_set_options(g, GINGR_RIGID_TRANSFORMS, 1.0));
         GCHECK(gingr_group_set_state(g, zero, &s0));
@@ -361,6 +368,20 @@ int main(int argc, char **argv) {
         put("G_sym_basis", ob, 3 * M * 14);
         gingr_model_destroy(moved);
         gingr_model_destroy(sym);
+        /* the nearest-neighbour scan with its diagnostic counter: the stateless entry point scans every pair */
+        {
+            int32_t *nidx = xmalloc(4 * M);
+            int64_t tests = -1;
+            double md = 0.0;
+            CHECK(gingr_ctx_nn_counting(ctx, 1));
+            CHECK(gingr_nn(ctx, M, ref, N, target, nidx, NULL, &md));
+            CHECK(gingr_ctx_nn_tests(ctx, &tests));
+            CHECK(gingr_ctx_nn_counting(ctx, 0));
+            if (tests < M * N) return 18;          /* 64 lanes per wave: M rounded up to whole waves */
+            const double nt[2] = {(double)tests, md};
+            put("G_nn_tests", nt, 2);
+            free(nidx);
+        }
         /* two iterations of the classic rigid ICP */
         gingr_rigid_icp *icp = NULL;
         double dist[2], tr13[13];

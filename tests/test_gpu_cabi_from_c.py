@@ -169,6 +169,12 @@ def test_plain_c_consumer_of_the_fused_path(tmp_path):
         fit_i, dd, _ = go.rigid_icp_iteration(fit_i, target)
         dists.append(dd)
     assert np.allclose(got["G_icp_dist"], dists, rtol=1e-11) and np.abs(got["G_icp_points"].reshape(M, 3) - fit_i).max() < 1e-9
+    # diagnostics reached from C: the stateless scan executes every pair (queries rounded up to whole 64-lane waves), and the group
+    # says what it exchanges through
+    tests, md = got["G_nn_tests"]
+    assert M * target.shape[0] <= tests <= (M + 63) // 64 * 64 * target.shape[0]
+    assert abs(md - go.icp_closest_point(mo.ref, target)[2]) < 1e-12 * max(md, 1.0)
+    assert got["C_exchange_info"][0] in (1.0, 2.0)
     # one N-ICP-T and one N-ICP-A iteration of the model reference (explicit points through gingr_fitter_set_fit_points)
     edges = go.nicp_edges(cells)
     lm_ids, ul = np.array([5, 17]), target[[11, 18]]
