@@ -120,17 +120,20 @@ def config2():
     ctx = ga.Context(0)
     idx, d2, md = ctx.nn(query, target)                              # warm-up + parity
     exact = bool(np.array_equal(idx, e["nn_idx"]))
-    ctx.nn_counting(True)
+    # timing and counting in separate passes: the counting instantiation of the kernel ends every wave with an atomic on ONE word
+    # (8 000 serialised atomics are ~90 us, ten times the kernel itself)
     ctx.timing_enable(True)
     ctx.timing_reset()
     reps = 50
     for _ in range(reps):
         ctx.nn(query, target)
     ms, k = ctx.timing_read(8)
-    tests = ctx.nn_tests() / max(k, 1)
-    ctx.nn_counting(False)
     ctx.timing_enable(False)
     avg_ms = ms / max(k, 1)
+    ctx.nn_counting(True)
+    ctx.nn(query, target)
+    tests = float(ctx.nn_tests())
+    ctx.nn_counting(False)
     ach = 9.0 * tests / (avg_ms * 1e-3) / 1e12
     t0 = time.perf_counter()
     co.nn(query, target)
@@ -145,8 +148,8 @@ def config2():
            "roofline": {"bound": "valu_f64", "kernel": "nn_kernel", "achieved": ach, "peak": F64_PEAK, "unit": "TFLOP/s", "frac": ach / F64_PEAK,
                         "traffic": None, "distance_tests_per_launch": tests, "all_pairs": float(M) * N,
                         "algorithmic_flops_per_test": 9.0,
-                        "note": "25e6 tests are ~12 us of one wave per SIMD: the launch is a single round of 79 workgroups, bound by "
-                                "latency (tile staging, one wave per SIMD), not by VALU issue"},
+                        "note": "a single launch round of short workgroups (79 query blocks x target chunks): bound by launch and staging "
+                                "latency, not by VALU issue; the pruned scan of the ICP path does 50k x 50k in the same time"},
            "cpu_baseline": {"value": M / cpu_s, "unit": "queries/s", "cores": 1, "kind": "port", "sample": "all 5 000 queries, oracle/cpd_oracle.c"}}
     ctx.close()
     return out
@@ -181,7 +184,8 @@ def config5():
             "data": "reference demo data (femur STL pair)",
             "config_detail": {"workload": "Metropolis-Hastings chain, surface-ICP proposals (posterior sample) + random walks, DemoICP settings; "
                                           "8 chains = 8 independent replicas, one context per GPU, no communication"},
-            "valid": bool(c["status"] == 0 and c["log_value_best"] >= c["log_value_initial"]),
+            # the chain ends with MaxIteration (2) or Converged (1); 3 = ModelFlexibilityError
+            "valid": bool(c["status"] != 3 and c["log_value_best"] >= c["log_value_initial"]),
             "parity_check": {"against": "tests/test_gpu_sampling.py: a 25-step chain reproduces the oracle's accept / reject sequence",
                              "log_value_initial": c["log_value_initial"], "log_value_best": c["log_value_best"]},
             "roofline": None, "cpu_baseline": None, "detail": c}
