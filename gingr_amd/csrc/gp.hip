@@ -377,92 +377,203 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ Q0
 // per SIMD: 112 accumulator registers per wave stay in VGPRs.  (One wave holding all 28 tiles needs the AGPR half of the file and
 // the compiler then copies all 224 accumulator registers to and from it in every step: 85 us at 50k points instead of 59 us.)
 // The K groups are summed through LDS in a fixed order.  Same fragment layout and output layout as gram_kernel.
-#ifndef GINGR_GRAM_DEPTH
-#define GINGR_GRAM_DEPTH 2
-#endif
-template <int NT, int HALF>
+// compile-time loop: f(std::integral_constant<int, I>) for I = BEGIN .. END-1 (DPP controls must be immediates)
+template <int BEGIN, int END, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (BEGIN < END) {
+        f(std::integral_constant<int, BEGIN>{});
+        static_for<BEGIN + 1, END>(f);
+    }
+}
+
+// upper-triangle tile q (row-major over t <= u) -> (t, u)
+template <int NT>
+__host__ __device__ constexpr int tri_row(int q) {
+    int t = 0;
+    while (q >= NT - t) q -= NT - t, ++t;
+    return t;
+}
+template <int NT>
+__host__ __device__ constexpr int tri_col(int q) {
+    int t = 0;
+    while (q >= NT - t) q -= NT - t, ++t;
+    return t + q;
+}
+
+template <int NT, int HALF, bool FULL>
 __device__ __forceinline__ void gram_tri_half(const double *__restrict__ Q0, int rp, const double *__restrict__ weight, int64_t r0,
                                               int64_t r1, int kgroup, int kq, int cl, int lane, double *red, double *xchg,
                                               double *__restrict__ out, const double *__restrict__ evec, int64_t npts,
                                               double *__restrict__ rhs_out, double *rsh) {
     constexpr int kTiles = NT * (NT + 1) / 2;
     constexpr int kMine = HALF == 0 ? (kTiles + 1) / 2 : kTiles / 2;
-    v4f64 acc[kMine > 0 ? kMine : 1];
+    constexpr int kM = kMine > 0 ? kMine : 1;
+    v4f64 acc[kM];
 #pragma unroll
     for (int q = 0; q < kMine; ++q) acc[q] = v4f64{0, 0, 0, 0};
     // The two waves of a K group need the SAME NT fragments of every 4-row step.  Each loads only every other one (HALF 0: tiles
     // 0, 2, 4, ...; HALF 1: 1, 3, 5, ...) and the pair exchanges them through LDS -- loading all of them in both waves fetched every
     // basis row twice from the fabric (PMC FETCH_SIZE 221 MB for 134 MB of basis at 50k points, rank 100: the second request for
-    // a line arrives while the first is still in flight and is not merged).  Global loads run kDepth steps ahead of the step
-    // being multiplied (a step lasts ~1 800 cycles of matrix work at two waves per SIMD, less than an HBM round trip under load);
-    // the LDS hand-over is double buffered, one workgroup barrier per step.
-    constexpr int kDepth = GINGR_GRAM_DEPTH;
+    // a line arrives while the first is still in flight and is not merged).
+    //
+    // What bounds this loop (tools/ubench_mfma_f64_fill.hip, profiles/r03_ubench_mfma_f64_fill.txt): while a float64 MFMA runs, its
+    // SIMD issues NO other vector instruction -- integer, move or float64, from either wave; each one adds its full issue time to
+    // the MFMA stream (2.3-5.2 ns), whereas LDS traffic, the barrier and most of a global load's issue are free beside it.  So the
+    // time of a step is (28 MFMAs of the SIMD's two waves) + (every VALU instruction of both waves), wherever those are placed,
+    // and the loop is built to issue as few as possible:
+    //   * the PRODUCER of a fragment scales it (w * fragment, the A operand) and adds it to the right-hand side; both forms go
+    //     through LDS, the consumers read 2 NT values and multiply nothing;
+    //   * addresses advance incrementally (16 rows per step: pointer += 16 rp, point index += 5 or 6); the from-scratch form (64-bit
+    //     multiplies, a division by 3) cost ~45 instructions per step and wave;
+    //   * rows past the slab are handled on a wave-uniform slow path (last step of the last slab, prefetches past the end), the
+    //     fast path has no selects;
+    //   * two operand sets (cur, a) and two prefetch slots alternate, the loop is unrolled by two instead of moving registers.
+    // The hand-over of step s+1 is issued between the MFMAs of step s (its latencies hide there); global loads run two steps ahead.
     constexpr int kOwn = HALF == 0 ? (NT + 1) / 2 : NT / 2;  // fragments this wave loads
-    // evec != nullptr (HALF 0 only): the right-hand side Q0^T evec rides along -- the wave holds every fragment of the rows it
-    // multiplies anyway, so the separate pass over the basis (SWEEP_RHS) is NT FMAs per step here.  evec: SoA planes [3][npts].
-    const bool with_rhs = HALF == 0 && evec != nullptr;
-    auto load_own = [&](int64_t row, double (&f)[kOwn > 0 ? kOwn : 1], double &w, double &ev) {
-        const int64_t rr = row + kq;
-        const bool valid = rr < r1;
-        const int64_t rc = valid ? rr : r0;
-        const int64_t pt = rc / 3;
-        w = valid ? (weight ? weight[pt] : 1.0) : 0.0;
-        ev = (with_rhs && valid) ? evec[(rc - 3 * pt) * npts + pt] : 0.0;
-        const double *p = Q0 + rc * rp + cl;
+    constexpr int kO = kOwn > 0 ? kOwn : 1;
+    // evec != nullptr: the right-hand side Q0^T evec rides along (each wave for the fragments it loads).  evec: SoA planes [3][npts].
+    const bool with_rhs = evec != nullptr;
+    const bool with_w = weight != nullptr;
+    const int kgu = __builtin_amdgcn_readfirstlane(kgroup);
+    const int64_t ubase = r0 + 4 * kgu;       // wave-uniform: row of lane group kq = 0 in step 0; 16 rows further per step
+    const int64_t first = ubase + kq;
+    const double *pclamp = Q0 + r0 * rp + cl;  // rows past the slab read row r0 (finite); the consumer sets their w and e to 0
+    const double *pnext = Q0 + first * rp + cl;
+    const int64_t pstep = 16 * (int64_t)rp;
+    int64_t left_u = r1 - ubase;  // wave-uniform: rows from the first row of the next step to load to the slab's end
+    // row -> (point, coordinate) = (row / 3, row % 3); 16 rows further: (point + 5, coordinate + 1) or (point + 6, coordinate - 2).
+    // `third` = coordinate * ceil(2^32 / 3): adding ceil(2^32 / 3) carries exactly when the coordinate wraps (the excess of 2 per
+    // wrap stays below the margin for 7e8 wraps).  evec is SoA [3][npts]: entry (coordinate, point).
+    const int64_t pt_first = first / 3;
+    const int rem_first = (int)(first - 3 * pt_first);
+    constexpr unsigned kThird = 0x55555556u;
+    unsigned third = (unsigned)rem_first * kThird;
+    const double *wclamp = with_w ? weight + r0 / 3 : pclamp;
+    const double *eclamp = with_rhs ? evec + r0 / 3 : pclamp;
+    const double *wp = with_w ? weight + pt_first : pclamp;  // without weights / evec: any readable address, the value is not used
+    const double *ep = with_rhs ? evec + rem_first * npts + pt_first : pclamp;
+    const int64_t estep = with_rhs ? 5 + npts : 0, ewrap = with_rhs ? 6 - 2 * npts : 0;
+    double fn[2][kO], wn[2], en[2];
+    int vrows[2];  // wave-uniform, per prefetch slot: how many of the step's four rows are inside the slab (4 = all)
+    // Both paths issue the same loads in the same order, and nothing touches the loaded values here: the waits at the consumer stay
+    // counted (vmcnt(n) leaves the younger slot in flight).
+    auto load_next = [&](auto slot) __attribute__((always_inline)) {
+        constexpr int L = decltype(slot)::value;
+        if (left_u >= 4) {  // wave-uniform: all four rows of the step inside the slab
+            vrows[L] = 4;
 #pragma unroll
-        for (int k = 0; k < kOwn; ++k) f[k] = p[16 * (2 * k + HALF)];
+            for (int k = 0; k < kOwn; ++k) fn[L][k] = pnext[16 * (2 * k + HALF)];
+            wn[L] = *wp;
+            en[L] = *ep;
+        } else {  // rows past the slab (last step of the last slab, prefetches past the end): clamped addresses
+            vrows[L] = (int)max((int64_t)0, left_u);
+            const bool valid = left_u > kq;
+            const double *p = valid ? pnext : pclamp;
+#pragma unroll
+            for (int k = 0; k < kOwn; ++k) fn[L][k] = p[16 * (2 * k + HALF)];
+            wn[L] = *(valid ? wp : wclamp);
+            en[L] = *(valid ? ep : eclamp);
+        }
+        left_u -= 16;
+        pnext += pstep;
+        const unsigned t2 = third + kThird;
+        const bool wrap = t2 < third;
+        third = t2;
+        wp += wrap ? 6 : 5;
+        ep += wrap ? ewrap : estep;
     };
-    double ring[kDepth + 1][kOwn > 0 ? kOwn : 1], wr[kDepth + 1], er[kDepth + 1];
-    double racc[NT];
+    double racc[kO];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) racc[t] = 0.0;
-    const int64_t row0 = r0 + 4 * kgroup;
+    for (int k = 0; k < kOwn; ++k) racc[k] = 0.0;
     // every wave of the workgroup runs the same number of steps (the barrier inside is workgroup wide): the K group with the
     // most rows sets it; steps past a wave's own rows multiply zeros (w = 0, clamped addresses)
     const int64_t nsteps = (r1 - r0 + 15) / 16;
+    constexpr int kBufStride = 4 * 2 * NT * 64;  // xchg: [2 buffers][4 K groups][plain, scaled][NT][64 lanes]
+    double *xbuf = xchg + (size_t)kgu * 2 * NT * 64 + lane;
+    double cur[2][NT], a[2][NT];
+    auto hand_over_write = [&](auto slot) __attribute__((always_inline)) {  // fragments of slot L go to buffer L (step parity = slot = buffer)
+        constexpr int L = decltype(slot)::value;
+        double w = wn[L], e = en[L];
+        if constexpr (!FULL) {  // without weights / evec the loads above read a placeholder
+            w = with_w ? w : 1.0;
+            e = with_rhs ? e : 0.0;
+        }
+        if (vrows[L] < 4) {  // wave-uniform
+            asm volatile("; rows past the slab");  // (keeps this a scalar branch: as selects it is 5 VALU in every step)
+            const bool valid = vrows[L] > kq;
+            w = valid ? w : 0.0;
+            e = valid ? e : 0.0;
+        }
 #pragma unroll
-    for (int d = 0; d <= kDepth; ++d) {
-        wr[d] = 0.0;
-        er[d] = 0.0;
-        if (d < kDepth) load_own(row0 + 16 * d, ring[d], wr[d], er[d]);
-    }
-    double *xbuf = xchg + (size_t)kgroup * NT * 64;  // [2 buffers][4 K groups][NT][64 lanes]
-    for (int64_t st = 0; st < nsteps; ++st) {
-        double *xb = xbuf + (size_t)(st & 1) * 4 * NT * 64;
-#pragma unroll
-        for (int k = 0; k < kOwn; ++k) xb[(2 * k + HALF) * 64 + lane] = ring[0][k];
-        __syncthreads();
-        load_own(row0 + 16 * (st + kDepth), ring[kDepth], wr[kDepth], er[kDepth]);
-        double cur[NT], a[NT];
+        for (int k = 0; k < kOwn; ++k) {
+            xbuf[L * kBufStride + (2 * k + HALF) * 64] = fn[L][k];
+            xbuf[L * kBufStride + (NT + 2 * k + HALF) * 64] = fn[L][k] * w;
+            racc[k] = __builtin_fma(fn[L][k], e, racc[k]);  // e = 0 without evec
+        }
+    };
+    auto hand_over_read = [&](auto set) __attribute__((always_inline)) {
+        constexpr int S = decltype(set)::value;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            cur[t] = xb[t * 64 + lane];
-            a[t] = cur[t] * wr[0];  // invalid rows: w = 0
-            if (HALF == 0) racc[t] = __builtin_fma(cur[t], er[0], racc[t]);  // er = 0 without evec / past the rows
+            cur[S][t] = xbuf[S * kBufStride + t * 64];
+            a[S][t] = xbuf[S * kBufStride + (NT + t) * 64];
         }
-        int q = 0;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int u = t; u < NT; ++u, ++q)
-                if ((q & 1) == HALF) acc[q >> 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], cur[u], acc[q >> 1], 0, 0, 0);
-#pragma unroll
-        for (int d = 0; d < kDepth; ++d) {
-#pragma unroll
-            for (int k = 0; k < kOwn; ++k) ring[d][k] = ring[d + 1][k];
-            wr[d] = wr[d + 1];
-            er[d] = er[d + 1];
-        }
+    };
+    auto mfmas = [&](auto set, auto begin, auto endq) __attribute__((always_inline)) {  // tiles [begin, end) of this wave's share, operands of `set`
+        constexpr int S = decltype(set)::value;
+        static_for<decltype(begin)::value, decltype(endq)::value>([&](auto m) {
+            constexpr int mi = decltype(m)::value, q = 2 * mi + HALF, tr = tri_row<NT>(q), tc = tri_col<NT>(q);
+            acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[S][tr], cur[S][tc], acc[mi], 0, 0, 0);
+        });
+    };
+    using std::integral_constant;
+    constexpr integral_constant<int, 0> c0{};
+    constexpr integral_constant<int, 1> c1{};
+    constexpr int kQ1 = kMine / 4, kQ2 = kMine / 2, kQ3 = (3 * kMine) / 4;
+    // prologue: steps 0 and 1 requested, step 0 through LDS into set 0, step 2 requested
+    load_next(c0);
+    load_next(c1);
+    hand_over_write(c0);
+    __syncthreads();
+    load_next(c0);
+    hand_over_read(c0);
+    // one step: the MFMAs of set S with the hand-over of the next step (set T = 1 - S) slotted between them
+    auto step = [&](auto set) __attribute__((always_inline)) {
+        constexpr int S = decltype(set)::value, T = 1 - S;
+        constexpr integral_constant<int, T> other{};
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(set, integral_constant<int, 0>{}, integral_constant<int, kQ1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        hand_over_write(other);  // own fragments of the next step (requested two steps ago)
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(set, integral_constant<int, kQ1>{}, integral_constant<int, kQ2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        load_next(other);  // the step after the next two, into the slot just written out
+        hand_over_read(other);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(set, integral_constant<int, kQ2>{}, integral_constant<int, kQ3>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(set, integral_constant<int, kQ3>{}, integral_constant<int, kMine>{});
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // (the step after the last one is handed over too and never multiplied: w = 0 rows, one barrier more, no branch in the loop)
+    int64_t st = 0;
+    for (; st + 1 < nsteps; st += 2) {
+        step(c0);
+        step(c1);
     }
+    if (st < nsteps) step(c0);
+    __syncthreads();  // the exchange buffers are free: slot 1 of the K-group reduction below reuses them
     if (evec) {  // workgroup-uniform.  Right-hand side: lanes of a column (the four kq) first, then the K groups 0..3 in order
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            racc[t] += __shfl_xor(racc[t], 16);
-            racc[t] += __shfl_xor(racc[t], 32);
+        for (int k = 0; k < kOwn; ++k) {
+            racc[k] += __shfl_xor(racc[k], 16);
+            racc[k] += __shfl_xor(racc[k], 32);
         }
-        if (HALF == 0 && kq == 0)
+        if (kq == 0)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) rsh[kgroup * (NT * 16) + t * 16 + cl] = racc[t];
+            for (int k = 0; k < kOwn; ++k) rsh[kgroup * (NT * 16) + (2 * k + HALF) * 16 + cl] = racc[k];
         __syncthreads();
         if (HALF == 0 && kgroup == 0 && kq == 0)
 #pragma unroll
@@ -471,24 +582,29 @@ __device__ __forceinline__ void gram_tri_half(const double *__restrict__ Q0, int
                 rhs_out[c] = ((rsh[c] + rsh[NT * 16 + c]) + rsh[2 * NT * 16 + c]) + rsh[3 * NT * 16 + c];
             }
     }
-    // K groups 1..3 are added into group 0 in order (both halves at once, disjoint parts of `red`)
-    double *mine = red + HALF * ((kTiles + 1) / 2) * 256;
-    for (int w = 1; w < 4; ++w) {
-        __syncthreads();
-        if (kgroup == w) {
+    // K groups: (0 + 2) + (1 + 3), two rounds through LDS (both halves at once, disjoint parts of a slot); slot 1 is the exchange area
+    // (1 024 NT doubles >= the 128 NT (NT + 1) (+ 256) of a slot for NT <= 7)
+    static_assert(((kTiles + 1) / 2) * 2 * 256 <= 2 * kBufStride, "the exchange area must hold one slot of the K-group reduction");
+    double *slot0 = red + HALF * ((kTiles + 1) / 2) * 256, *slot1 = xchg + HALF * ((kTiles + 1) / 2) * 256;
+    auto put = [&](double *slot) {
 #pragma unroll
-            for (int q = 0; q < kMine; ++q)
+        for (int q = 0; q < kMine; ++q)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) mine[(q * 4 + reg) * 64 + lane] = acc[q][reg];
-        }
-        __syncthreads();
-        if (kgroup == 0) {
+            for (int reg = 0; reg < 4; ++reg) slot[(q * 4 + reg) * 64 + lane] = acc[q][reg];
+    };
+    auto add = [&](const double *slot) {
 #pragma unroll
-            for (int q = 0; q < kMine; ++q)
+        for (int q = 0; q < kMine; ++q)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) acc[q][reg] += mine[(q * 4 + reg) * 64 + lane];
-        }
-    }
+            for (int reg = 0; reg < 4; ++reg) acc[q][reg] += slot[(q * 4 + reg) * 64 + lane];
+    };
+    if (kgroup >= 2) put(kgroup == 2 ? slot0 : slot1);
+    __syncthreads();
+    if (kgroup < 2) add(kgroup == 0 ? slot0 : slot1);
+    __syncthreads();
+    if (kgroup == 1) put(slot0);
+    __syncthreads();
+    if (kgroup == 0) add(slot0);
     if (kgroup != 0) return;
     // D[i][j] of tile (t, u): i = kq + 4 reg is the A-side index (column 16 t + i of Q0), j = cl the B-side index
     int q = 0;
@@ -501,14 +617,15 @@ __device__ __forceinline__ void gram_tri_half(const double *__restrict__ Q0, int
                 for (int reg = 0; reg < 4; ++reg) out[(int64_t)(16 * t + kq + 4 * reg) * rp + 16 * u + cl] = acc[q >> 1][reg];
 }
 
-template <int NT>
+// FULL: weight and evec are both given (the per-iteration call) -- their loads are unconditional
+template <int NT, bool FULL>
 __global__ __launch_bounds__(512) void gram_tri_kernel(const double *__restrict__ Q0, int64_t rows, int rp,
                                                        const double *__restrict__ weight, int64_t rows_per_slab,
                                                        double *__restrict__ partial, const double *__restrict__ evec, int64_t npts,
                                                        double *__restrict__ rhs_partial) {
     constexpr int kTiles = NT * (NT + 1) / 2;
     __shared__ double red[(kTiles + 1) * 256];
-    __shared__ double xchg[2 * 4 * NT * 64];
+    __shared__ double xchg[2 * 4 * 2 * NT * 64];
     __shared__ double rsh[4 * NT * 16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kq = lane >> 4, cl = lane & 15;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
@@ -516,9 +633,9 @@ __global__ __launch_bounds__(512) void gram_tri_kernel(const double *__restrict_
     double *out = partial + (int64_t)blockIdx.x * rp * rp;
     double *rhs_out = rhs_partial ? rhs_partial + (int64_t)blockIdx.x * rp : nullptr;  // one row of right-hand-side partials per slab
     if ((wave >> 2) == 0)
-        gram_tri_half<NT, 0>(Q0, rp, weight, r0, r1, wave & 3, kq, cl, lane, red, xchg, out, evec, npts, rhs_out, rsh);
+        gram_tri_half<NT, 0, FULL>(Q0, rp, weight, r0, r1, wave & 3, kq, cl, lane, red, xchg, out, evec, npts, rhs_out, rsh);
     else
-        gram_tri_half<NT, 1>(Q0, rp, weight, r0, r1, wave & 3, kq, cl, lane, red, xchg, out, evec, npts, rhs_out, rsh);
+        gram_tri_half<NT, 1, FULL>(Q0, rp, weight, r0, r1, wave & 3, kq, cl, lane, red, xchg, out, evec, npts, rhs_out, rsh);
 }
 
 // G[i][j] = sum over slabs (fixed order): 32 consecutive elements x 8 slab groups per workgroup, so every load instruction
@@ -802,14 +919,6 @@ constexpr int kNB = 16;
 #define GINGR_STAGE_CLOCK(slot)
 #endif
 
-// compile-time loop: f(std::integral_constant<int, I>) for I = BEGIN .. END-1 (DPP controls must be immediates)
-template <int BEGIN, int END, typename F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (BEGIN < END) {
-        f(std::integral_constant<int, BEGIN>{});
-        static_for<BEGIN + 1, END>(f);
-    }
-}
 
 // value of lane J of the caller's 16-lane row, in every lane of that row: one v_mov_b64_dpp (gfx90a+ row_newbcast) instead of
 // two v_readlane_b32 through the scalar file.  A VGPR written by a VALU instruction may be read through DPP only two wait
@@ -2017,15 +2126,25 @@ int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const d
                 hipLaunchKernelGGL(kern, dim3(nslabs), dim3(512), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, ws,
                                    fuse ? evec : (const double *)nullptr, M, fuse ? rhs_partial : (double *)nullptr);
             };
+            const bool full = fuse && weight;
+#define GINGR_GRAM_TRI(n) \
+    case n: \
+        if (full) go(gram_tri_kernel<n, true>); \
+        else go(gram_tri_kernel<n, false>); \
+        break;
             switch (nt) {
-                case 1: go(gram_tri_kernel<1>); break;
-                case 2: go(gram_tri_kernel<2>); break;
-                case 3: go(gram_tri_kernel<3>); break;
-                case 4: go(gram_tri_kernel<4>); break;
-                case 5: go(gram_tri_kernel<5>); break;
-                case 6: go(gram_tri_kernel<6>); break;
-                default: go(gram_tri_kernel<7>); break;
+                GINGR_GRAM_TRI(1)
+                GINGR_GRAM_TRI(2)
+                GINGR_GRAM_TRI(3)
+                GINGR_GRAM_TRI(4)
+                GINGR_GRAM_TRI(5)
+                GINGR_GRAM_TRI(6)
+                default:
+                    if (full) go(gram_tri_kernel<7, true>);
+                    else go(gram_tri_kernel<7, false>);
+                    break;
             }
+#undef GINGR_GRAM_TRI
         } else {
             hipLaunchKernelGGL(gram_kernel, dim3(nslabs, npatch), dim3(256), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, nbp,
                                1, 0, 0, 0, ws);
