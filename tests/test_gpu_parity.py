@@ -302,3 +302,38 @@ def test_run_converges_and_matches_oracle_loop(ctx):
         st = go.cpd_update(mo, target, st)
     assert rel(final.general.fit, st.fit) < REL_MESH
     algo.close()
+
+
+# ------------------------------------------------------------------------------------------ weighted Gram kernel, every tile count
+@pytest.mark.parametrize("rank,M", [(5, 37), (16, 129), (20, 700), (33, 1030), (48, 2049), (50, 333), (72, 1500), (80, 1111), (90, 2500),
+                                    (96, 515), (100, 4099), (112, 3001)])
+def test_weighted_gram_every_tile_count(ctx, rank, M):
+    """gram_tri_kernel<NT, FULL> for NT = 1..7 (rank padded to 16 NT), row counts off the 16-row step grid and off the slab grid:
+    (a) the weight-only launch behind posterior_mean (FULL = false), (b) the fused weight + right-hand-side launch of a CPD update
+    (FULL = true), each against the oracle."""
+    import gingr_amd as ga
+    rng = np.random.default_rng(rank + M)
+    U, _ = np.linalg.qr(rng.normal(0, 1, (3 * M, rank)))
+    lam = np.sort(rng.uniform(1.0, 400.0, rank))[::-1].copy()
+    mo = go.PDM(ref=rng.normal(0, 30, (M, 3)), mean=rng.normal(0, 0.1, (M, 3)), U=U, lam=lam)
+    dm = ga.DeviceModel(ctx, to_ga(mo))
+    obs = mo.instance(rng.normal(0, 1, mo.rank)) + rng.normal(0, 0.3, (mo.M, 3))
+    var = rng.uniform(0.5, 4.0, mo.M)
+    var[rng.integers(0, mo.M, max(1, mo.M // 50))] = 1e12     # a few rows with (nearly) zero weight
+    want_mesh, want_a = mo.posterior_mean(np.arange(mo.M), obs, var[:, None, None] * np.eye(3)[None])
+    got_mesh, got_a = dm.posterior_mean(obs, 1.0 / var)
+    assert rel(got_a, want_a) < 1e-7
+    assert rel(got_mesh, want_mesh) < 1e-8
+    dm.close()
+    target = mo.instance(rng.normal(0, 0.7, mo.rank)) + rng.normal(0, 0.5, (mo.M, 3))
+    target = target[rng.permutation(mo.M)[: max(1, (3 * mo.M) // 4)]]
+    algo = ga.CpdRegistration(ctx)
+    state = algo.createInitialState(to_ga(mo), target, ga.CpdConfiguration(maxIterations=10, w=0.1, initialSigma=50.0))
+    st = go.initial_state(mo, 50.0)
+    for _ in range(2):
+        state = algo.update(state)
+        st = go.cpd_update(mo, target, st, w=0.1)
+        assert state.general.status == st.status == 0
+        assert rel(state.general.fit, st.fit) < 1e-7
+        assert abs(state.general.sigma2 - st.sigma2) < 1e-8 * abs(st.sigma2)
+    algo.close()
