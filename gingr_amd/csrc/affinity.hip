@@ -1042,7 +1042,14 @@ __global__ __launch_bounds__(kNNBlock) void nn_kernel(Cloud q, Cloud tgt, const 
                                                       const double *__restrict__ tgt_boxes, int64_t cols_per_chunk,
                                                       double *__restrict__ pd2, int32_t *__restrict__ pidx,
                                                       int32_t *__restrict__ porig, const int32_t *__restrict__ warm,
-                                                      unsigned long long *tests) {
+                                                      unsigned long long *tests, const uint8_t *__restrict__ mask,
+                                                      const int32_t *__restrict__ nmask) {
+    // masked launch (the queries the grid search of nn_grid.hip left over): nothing to do at all, or nothing for these 64 queries
+    if (nmask && *nmask == 0) return;
+    if (mask) {
+        const int64_t iq = (int64_t)blockIdx.x * kNNThreads + (threadIdx.x & 63);
+        if (!__any(iq < q.n && mask[iq] != 0)) return;  // the four waves hold the same queries: a workgroup-uniform exit
+    }
     unsigned long long scanned = 0;  // wave-uniform
     __shared__ P4 tile[kTile];
     __shared__ double sbest[4][kNNThreads], sorig[4][kNNThreads];
@@ -1176,9 +1183,12 @@ __global__ __launch_bounds__(kNNBlock) void nn_kernel(Cloud q, Cloud tgt, const 
 
 __global__ void nn_reduce_kernel(const double *__restrict__ pd2, const int32_t *__restrict__ pidx,
                                  const int32_t *__restrict__ porig, int nchunks, int64_t M, int32_t *__restrict__ idx,
-                                 double *__restrict__ d2) {
+                                 double *__restrict__ d2, const uint8_t *__restrict__ mask, int32_t *__restrict__ nmask) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (the scan kernel has read *nmask; no thread of this one does, so the first can clear it for the next grid search)
+    if (nmask && i == 0) *nmask = 0;
     if (i >= M) return;
+    if (mask && !mask[i]) return;  // answered by the grid search; the scan's partials may not even exist
     double best = pd2[i];
     int32_t bi = pidx[i], bo = porig[i];
     for (int c = 1; c < nchunks; ++c) {
@@ -1566,7 +1576,7 @@ static void plan_nn(int64_t nq, int64_t nt_points, bool pruned, int *nchunks, in
 }
 
 void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, const double *tgt_boxes, void *ws,
-               int32_t *idx, double *d2, const int32_t *warm) {
+               int32_t *idx, double *d2, const int32_t *warm, const uint8_t *mask, int32_t *nmask) {
     static const int warm_env = getenv("GINGR_NN_WARM") ? atoi(getenv("GINGR_NN_WARM")) : 1;
     if (!warm_env) warm = nullptr;
     int nch;
@@ -1581,13 +1591,14 @@ void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_
         TimerScope ts(ctx, 8);
         if (ctx->nn_tests)
             hipLaunchKernelGGL(nn_kernel<true>, grid, dim3(kNNBlock), 0, ctx->stream, query, target, target_orig,
-                               pruned ? tgt_boxes : (const double *)nullptr, len, pd2, pidx, porig, warm, ctx->nn_tests);
+                               pruned ? tgt_boxes : (const double *)nullptr, len, pd2, pidx, porig, warm, ctx->nn_tests, mask, nmask);
         else
             hipLaunchKernelGGL(nn_kernel<false>, grid, dim3(kNNBlock), 0, ctx->stream, query, target, target_orig,
-                               pruned ? tgt_boxes : (const double *)nullptr, len, pd2, pidx, porig, warm, (unsigned long long *)nullptr);
+                               pruned ? tgt_boxes : (const double *)nullptr, len, pd2, pidx, porig, warm, (unsigned long long *)nullptr,
+                               mask, nmask);
     }
     hipLaunchKernelGGL(nn_reduce_kernel, dim3((unsigned)ceil_div(query.n, 256)), dim3(256), 0, ctx->stream, pd2, pidx, porig,
-                       nch, query.n, idx, d2);
+                       nch, query.n, idx, d2, mask, nmask);
 }
 
 void launch_gauss_block(gingr_ctx *ctx, Cloud A, Cloud B, double sigma, double scaling, double *out) {

@@ -112,6 +112,7 @@ struct gingr_fitter {
     int32_t *surf_tri_pos = nullptr;  // per model vertex: position (in ttri) of its closest target triangle of the last scan
     bool surf_tri_warm = false;
     bool nn_warm = false, surf_nn_warm = false;  // nn_idx / surf_nn hold last time's matches against the CURRENT target
+    NNGrid tgrid;  // uniform grid over the target cloud (set_target): the point-cloud ICP's closest-point search (nn_grid.hip)
     void forget_posteriors() {
         post_stage = 0;
         alt_stage = 0;
@@ -537,6 +538,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->retry);
     dev_free(f->part);
     dev_free(f->absmax);
+    nn_grid_free(&f->tgrid);
     dev_free(f->tperm);
     dev_free(f->tboxes);
     dev_free(f->fboxes);
@@ -607,6 +609,7 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
     f->aos = aos;
     HIP_TRY(ctx, hipMemcpyAsync(aos, target_xyz, (size_t)3 * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     morton_order(target_xyz, N, f->h_tperm);
+    GINGR_TRY(nn_grid_build(ctx, target_xyz, N, f->h_tperm.data(), M, &f->tgrid));
     GINGR_TRY(dev_alloc(ctx, &f->tperm, (size_t)N));
     HIP_TRY(ctx, hipMemcpyAsync(f->tperm, f->h_tperm.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     GINGR_TRY(dev_alloc(ctx, &f->tboxes, (size_t)ceil_div(N, 256) * 30));  // tile boxes + four quarter boxes per tile
@@ -984,7 +987,15 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 launch_self_intersect(ctx, fit, f->surf_cp, f->mtri, f->Tm, f->mtboxes, f->surf_pre, f->surf_hit, f->mtribox);
                 launch_surface_weight(ctx, M, f->surf_pre, f->surf_hit, &f->st->sigma2, f->surf_w01, f->surf_win);
             } else if (icp) {
-                launch_nn(ctx, fit, tgt, f->tperm, f->tboxes, f->ws, f->nn_idx, f->nn_d2, f->nn_warm ? f->nn_idx : nullptr);
+                static const int grid_env = getenv("GINGR_NN_GRID") ? atoi(getenv("GINGR_NN_GRID")) : 1;
+                const int32_t *warm = f->nn_warm ? f->nn_idx : nullptr;
+                if (grid_env && f->tgrid.ready && ctx->cull) {
+                    // grid search first; what it cannot certify (flagged) goes through the masked full scan, a no-op when nothing is
+                    launch_nn_grid(ctx, fit, tgt, f->tperm, f->tgrid, warm, f->nn_idx, f->nn_d2);
+                    launch_nn(ctx, fit, tgt, f->tperm, f->tboxes, f->ws, f->nn_idx, f->nn_d2, f->nn_idx, f->tgrid.flag, f->tgrid.nflag);
+                } else {
+                    launch_nn(ctx, fit, tgt, f->tperm, f->tboxes, f->ws, f->nn_idx, f->nn_d2, warm);
+                }
                 f->nn_warm = true;
             } else {
                 // boxes of the fit tiles + its |coordinate - centroid| maximum (slot cleared by the pass that wrote the fit)

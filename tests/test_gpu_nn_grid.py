@@ -1,0 +1,98 @@
+"""The ICP update's closest-point search (grid search + masked full scan, gingr_amd/csrc/nn_grid.hip) against the oracle's linear
+argmin on geometries chosen to break a grid: exact ties (duplicates, lattices), queries on cell boundaries, flat and clustered target
+clouds, queries far from every target (the masked full scan answers those), single points.
+
+Bar: indices bit-exact, lowest original index on equal distances (G/api/registration/utils/ClosestPointRegistrator.scala:33-44).
+"""
+import numpy as np
+import pytest
+
+from oracle import gingr_oracle as go
+
+pytestmark = pytest.mark.gpu
+
+
+def tiny_model(ref, seed):
+    rng = np.random.default_rng(seed)
+    M = ref.shape[0]
+    r = min(3, 3 * M)
+    U, _ = np.linalg.qr(rng.normal(0, 1, (3 * M, r)))
+    return go.PDM(ref=ref, mean=np.zeros_like(ref), U=U, lam=np.array([9.0, 4.0, 1.0])[:r])
+
+
+def shell(n, seed, radius=40.0):
+    rng = np.random.default_rng(seed)
+    v = rng.normal(0, 1, (n, 3))
+    return radius * v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+def cases():
+    rng = np.random.default_rng(5)
+    out = {}
+    t = shell(3000, 1)
+    out["surface"] = (t[rng.permutation(3000)[:2500]] + rng.normal(0, 0.4, (2500, 3)), t)
+    # every target twice (and a few three times), in shuffled order: the lower original index must win every tie
+    t2 = np.concatenate([t[:800], t[:800], t[:50]])[rng.permutation(1650)]
+    out["duplicates"] = (t[:800] + rng.normal(0, 0.2, (800, 3)), t2)
+    # integer lattice, queries on cell centres / edges / vertices: 2, 4 or 8 targets at exactly the same distance
+    g = np.stack(np.meshgrid(np.arange(8.0), np.arange(8.0), np.arange(8.0), indexing="ij"), -1).reshape(-1, 3)
+    lat = g[rng.permutation(g.shape[0])]
+    off = np.array([[0.5, 0, 0], [0.5, 0.5, 0], [0.5, 0.5, 0.5], [0, 0, 0], [0.25, 0.5, 0.0]])
+    out["lattice_ties"] = (np.concatenate([g[:300] + o for o in off]), lat)
+    flat = np.column_stack([rng.uniform(-50, 50, 2000), rng.uniform(-50, 50, 2000), np.zeros(2000)])
+    out["flat_target"] = (flat[:1500] + np.array([0.0, 0.0, 1.5]) + rng.normal(0, 0.3, (1500, 3)), flat)
+    line = np.column_stack([np.linspace(-100, 100, 900), np.zeros(900), np.zeros(900)])
+    out["line_target"] = (line[::2] + rng.normal(0, 0.5, (450, 3)), line)
+    out["far_queries"] = (t[:700] * 3.0 + 500.0, t)                       # nothing within reach of the grid search
+    mixed = t[:1200] + rng.normal(0, 0.3, (1200, 3))
+    mixed[::3] += 400.0
+    out["near_and_far"] = (mixed, t)
+    two = np.concatenate([rng.normal(0, 1.0, (600, 3)), rng.normal(0, 1.0, (600, 3)) + 5000.0])
+    out["two_clusters"] = (two[rng.permutation(1200)[:900]] + rng.normal(0, 0.05, (900, 3)), two)
+    out["identical_targets"] = (rng.normal(0, 1, (70, 3)), np.tile(np.array([[1.0, 2.0, 3.0]]), (33, 1)))
+    out["on_the_targets"] = (t2[:500].copy(), t2)                          # distance 0, duplicates
+    out["one_target"] = (rng.normal(0, 5, (40, 3)), np.array([[0.5, -1.0, 2.0]]))
+    out["one_query"] = (np.array([[3.0, 1.0, -2.0]]), t[:300])
+    out["two_points"] = (np.array([[0.0, 0.0, 0.0], [1.0, 1.0, 1.0]]), np.array([[1.0, 1.0, 1.0], [0.0, 0.0, 0.0]]))
+    return out
+
+
+CASES = cases()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_closest_point_indices_are_the_linear_argmin(ctx, name):
+    import gingr_amd as ga
+    ref, target = CASES[name]
+    mo = tiny_model(ref, seed=len(name))
+    algo = ga.IcpRegistration(ctx)
+    cfg = ga.IcpConfiguration(maxIterations=10, initialSigma=4.0, endSigma=1.0, correspondenceMethod="PointcloudClosestPoint")
+    state = algo.createInitialState(ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam), target, cfg)
+    for it in range(4):  # the first search starts cold, the later ones from the previous matches
+        fit_before = np.array(state.general.fit)
+        state = algo.update(state)
+        want, _, _ = go.icp_closest_point(fit_before, target)
+        got = algo.last_correspondence_indices()
+        assert np.array_equal(got, want), (name, it, int(np.sum(got != want)))
+        if state.general.status != 0:  # (a degenerate pair may stop the registration; the search above was still checked)
+            break
+    algo.close()
+
+
+def test_the_grid_search_is_what_runs(ctx):
+    """On a surface-like pair the search executes a small fraction of the all-pairs distance tests (the counter of
+    gingr_ctx_nn_counting sees the grid kernel and the masked scan)."""
+    import gingr_amd as ga
+    ref, target = CASES["surface"]
+    mo = tiny_model(ref, seed=3)
+    algo = ga.IcpRegistration(ctx)
+    cfg = ga.IcpConfiguration(maxIterations=10, initialSigma=4.0, endSigma=1.0, correspondenceMethod="PointcloudClosestPoint")
+    state = algo.createInitialState(ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam), target, cfg)
+    state = algo.update(state)
+    ctx.nn_counting(True)
+    state = algo.update(state)
+    ctx.synchronize()
+    tests = ctx.nn_tests()
+    ctx.nn_counting(False)
+    algo.close()
+    assert 0 < tests < 0.05 * ref.shape[0] * target.shape[0], tests

@@ -13,6 +13,7 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 y, x = synth_clouds(M)
 basis, lam = synth_gpmm(y, 100)
 ctx = ga.Context(0)
+COUNT = os.environ.get("GINGR_BENCH_NN_COUNT", "0") == "1"
 f = ShardedFitter(ctx, ga.PointDistributionModel(y, np.zeros_like(y), basis, lam), x)
 f.set_state(np.zeros(100), 100.0)
 f.update_icp(100.0, 1.0, 100, 3)
@@ -23,6 +24,14 @@ f.update_icp(100.0, 1.0, 100, n)
 ctx.synchronize()
 dt = time.perf_counter() - t0
 a, sc, fit = f.get_state()
+tests = None
+if COUNT:  # distance tests per closest-point search (a separate, untimed iteration: the counter serialises atomics)
+    ctx.nn_counting(True)
+    f.update_icp(100.0, 1.0, 100, 1)
+    ctx.synchronize()
+    tests = ctx.nn_tests()
+    ctx.nn_counting(False)
 print(json.dumps({"what": "ICP update (nn + GP), synthetic clouds", "points": M, "iterations_per_s": n / dt,
-                  "ms_per_iteration": dt / n * 1e3, "cull": os.environ.get("GINGR_CULL", "1"), "status": sc.status,
+                  "ms_per_iteration": dt / n * 1e3, "cull": os.environ.get("GINGR_CULL", "1"),
+                  "nn_grid": os.environ.get("GINGR_NN_GRID", "1"), "distance_tests_per_search": tests, "status": sc.status,
                   "fit_checksum": float(np.abs(fit).sum())}))
