@@ -1043,7 +1043,8 @@ __global__ __launch_bounds__(kNNBlock) void nn_kernel(Cloud q, Cloud tgt, const 
                                                       double *__restrict__ pd2, int32_t *__restrict__ pidx,
                                                       int32_t *__restrict__ porig, const int32_t *__restrict__ warm,
                                                       unsigned long long *tests, const uint8_t *__restrict__ mask,
-                                                      const int32_t *__restrict__ nmask) {
+                                                      const int32_t *__restrict__ nmask, int32_t *__restrict__ idx_out,
+                                                      double *__restrict__ d2_out) {
     // masked launch (the queries the grid search of nn_grid.hip left over): nothing to do at all, or nothing for these 64 queries
     if (nmask && *nmask == 0) return;
     if (mask) {
@@ -1174,19 +1175,21 @@ __global__ __launch_bounds__(kNNBlock) void nn_kernel(Cloud q, Cloud tgt, const 
         for (int k = 1; k < 4; ++k)
             if (sbest[k][lane] < sbest[w][lane] || (sbest[k][lane] == sbest[w][lane] && sorig[k][lane] < sorig[w][lane])) w = k;
         const double wo = sorig[w][lane];
-        pd2[(int64_t)blockIdx.y * q.n + i] = sbest[w][lane];
-        pidx[(int64_t)blockIdx.y * q.n + i] = sidx[w][lane];
-        porig[(int64_t)blockIdx.y * q.n + i] = (int32_t)(wo < 2147483648.0 ? wo : -1.0);
+        if (idx_out) {  // masked launch over ONE chunk: this is the answer (no reduction kernel follows); unflagged queries stay as they are
+            if (mask[i]) idx_out[i] = sidx[w][lane], d2_out[i] = sbest[w][lane];
+        } else {
+            pd2[(int64_t)blockIdx.y * q.n + i] = sbest[w][lane];
+            pidx[(int64_t)blockIdx.y * q.n + i] = sidx[w][lane];
+            porig[(int64_t)blockIdx.y * q.n + i] = (int32_t)(wo < 2147483648.0 ? wo : -1.0);
+        }
     }
     if (COUNT && lane == 0 && scanned) atomicAdd(tests, scanned);
 }
 
 __global__ void nn_reduce_kernel(const double *__restrict__ pd2, const int32_t *__restrict__ pidx,
                                  const int32_t *__restrict__ porig, int nchunks, int64_t M, int32_t *__restrict__ idx,
-                                 double *__restrict__ d2, const uint8_t *__restrict__ mask, int32_t *__restrict__ nmask) {
+                                 double *__restrict__ d2, const uint8_t *__restrict__ mask) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // (the scan kernel has read *nmask; no thread of this one does, so the first can clear it for the next grid search)
-    if (nmask && i == 0) *nmask = 0;
     if (i >= M) return;
     if (mask && !mask[i]) return;  // answered by the grid search; the scan's partials may not even exist
     double best = pd2[i];
@@ -1576,13 +1579,17 @@ static void plan_nn(int64_t nq, int64_t nt_points, bool pruned, int *nchunks, in
 }
 
 void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, const double *tgt_boxes, void *ws,
-               int32_t *idx, double *d2, const int32_t *warm, const uint8_t *mask, int32_t *nmask) {
+               int32_t *idx, double *d2, const int32_t *warm, const uint8_t *mask, const int32_t *nmask) {
     static const int warm_env = getenv("GINGR_NN_WARM") ? atoi(getenv("GINGR_NN_WARM")) : 1;
     if (!warm_env) warm = nullptr;
     int nch;
     int64_t len;
     const bool pruned = ctx->cull && tgt_boxes != nullptr;
     plan_nn(query.n, target.n, pruned, &nch, &len);
+    // masked (the leftovers of the grid search, normally none): one chunk from 4096 queries on, and then the scan kernel writes the
+    // answers itself -- one launch that exits at once instead of two
+    if (mask && pruned && query.n >= 4096) nch = 1, len = round_up(target.n, kTile);
+    const bool direct = mask && nch == 1;
     double *pd2 = reinterpret_cast<double *>(ws);
     int32_t *pidx = reinterpret_cast<int32_t *>(pd2 + (int64_t)nch * query.n);
     int32_t *porig = pidx + (int64_t)nch * query.n;
@@ -1591,14 +1598,16 @@ void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_
         TimerScope ts(ctx, 8);
         if (ctx->nn_tests)
             hipLaunchKernelGGL(nn_kernel<true>, grid, dim3(kNNBlock), 0, ctx->stream, query, target, target_orig,
-                               pruned ? tgt_boxes : (const double *)nullptr, len, pd2, pidx, porig, warm, ctx->nn_tests, mask, nmask);
+                               pruned ? tgt_boxes : (const double *)nullptr, len, pd2, pidx, porig, warm, ctx->nn_tests, mask, nmask,
+                               direct ? idx : (int32_t *)nullptr, direct ? d2 : (double *)nullptr);
         else
             hipLaunchKernelGGL(nn_kernel<false>, grid, dim3(kNNBlock), 0, ctx->stream, query, target, target_orig,
                                pruned ? tgt_boxes : (const double *)nullptr, len, pd2, pidx, porig, warm, (unsigned long long *)nullptr,
-                               mask, nmask);
+                               mask, nmask, direct ? idx : (int32_t *)nullptr, direct ? d2 : (double *)nullptr);
     }
+    if (direct) return;
     hipLaunchKernelGGL(nn_reduce_kernel, dim3((unsigned)ceil_div(query.n, 256)), dim3(256), 0, ctx->stream, pd2, pidx, porig,
-                       nch, query.n, idx, d2, mask, nmask);
+                       nch, query.n, idx, d2, mask);
 }
 
 void launch_gauss_block(gingr_ctx *ctx, Cloud A, Cloud B, double sigma, double scaling, double *out) {

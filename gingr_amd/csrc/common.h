@@ -150,9 +150,10 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
 // index, taken from target_orig[position] (nullptr: the device order is the original order).
 // tgt_boxes (nullable): bounding boxes of the 256-point target tiles (launch_tile_bbox) for exact nearest-first pruning.
 // mask / nmask (nullable, device): only queries with mask[i] != 0 are answered (idx / d2 of the others are left alone) and the
-// launch is a no-op when *nmask == 0; the last kernel of the launch resets *nmask to 0 (launch_nn_grid leaves both behind).
+// launch is a no-op when *nmask == 0 (launch_nn_grid leaves both behind: NNGrid::flag, NNGrid::cur_nflag()).
 void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, const double *tgt_boxes, void *ws,
-               int32_t *idx, double *d2, const int32_t *warm = nullptr, const uint8_t *mask = nullptr, int32_t *nmask = nullptr);
+               int32_t *idx, double *d2, const int32_t *warm = nullptr, const uint8_t *mask = nullptr,
+               const int32_t *nmask = nullptr);
 // ---------------------------------------------------------------------------- nn_grid.hip (closest point over a uniform grid)
 struct GridPoint {  // one target, in cell order: coordinates, original index (tie rule), position in the device order of the cloud
     double x, y, z;
@@ -170,13 +171,17 @@ struct NNGrid {  // owner
     int32_t *cell_start = nullptr;
     void *pts = nullptr;
     uint8_t *flag = nullptr;   // [max_queries]: queries the grid could not certify (launch_nn_grid writes every entry)
-    int32_t *nflag = nullptr;  // how many of them
+    // how many of them: two counters used alternately -- a search counts into one and clears the other for the next search, so the
+    // masked scan that follows only reads (no reset kernel, no reset by a kernel that others still read)
+    int32_t *nflag = nullptr;
+    int parity = 0;
     int64_t n = 0, max_queries = 0;
     bool ready = false;
+    const int32_t *cur_nflag() const { return nflag + parity; }  // the counter of the LAST launch_nn_grid
 };
 int nn_grid_build(gingr_ctx *ctx, const double *target_xyz, int64_t N, const int32_t *perm, int64_t max_queries, NNGrid *g);
 void nn_grid_free(NNGrid *g);
-void launch_nn_grid(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, const NNGrid &g, const int32_t *warm,
+void launch_nn_grid(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, NNGrid &g, const int32_t *warm,
                     int32_t *idx, double *d2);
 void launch_gauss_block(gingr_ctx *ctx, Cloud A, Cloud B, double sigma, double scaling, double *out);
 void launch_sumsq_pairs(gingr_ctx *ctx, Cloud A, Cloud B, double *ws, double *out_scalar);

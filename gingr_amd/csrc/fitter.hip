@@ -992,7 +992,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 if (grid_env && f->tgrid.ready && ctx->cull) {
                     // grid search first; what it cannot certify (flagged) goes through the masked full scan, a no-op when nothing is
                     launch_nn_grid(ctx, fit, tgt, f->tperm, f->tgrid, warm, f->nn_idx, f->nn_d2);
-                    launch_nn(ctx, fit, tgt, f->tperm, f->tboxes, f->ws, f->nn_idx, f->nn_d2, f->nn_idx, f->tgrid.flag, f->tgrid.nflag);
+                    launch_nn(ctx, fit, tgt, f->tperm, f->tboxes, f->ws, f->nn_idx, f->nn_d2, f->nn_idx, f->tgrid.flag, f->tgrid.cur_nflag());
                 } else {
                     launch_nn(ctx, fit, tgt, f->tperm, f->tboxes, f->ws, f->nn_idx, f->nn_d2, warm);
                 }

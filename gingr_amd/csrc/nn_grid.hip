@@ -31,15 +31,19 @@ __device__ __forceinline__ int clamp_cell(double f, int g) {  // floor(f) clampe
 
 // kLanes lanes serve one query: each takes every kLanes-th row (a run of cells along x at fixed y, z) of the block of cells being
 // scanned, then the lanes combine their candidates (smallest distance, then lowest original index).  One lane per query leaves the
-// chip with < 1 wave per SIMD at 50k queries and a chain of ~35 dependent loads per lane (measured 68 us); 16 lanes per query give 12
-// waves per SIMD and 2-4 dependent loads per lane.
-constexpr int kLanes = 16;
+// chip with < 1 wave per SIMD at 50k queries and a chain of ~35 dependent loads per lane (measured 68 us at 50k); 16 lanes per query:
+// 23 us; 8 lanes (lane 0 takes two rows of the first pass): 20.7 us at 50k and 5 % faster per ICP iteration at 100k, 2 % slower at
+// 15k -- the launcher picks by the number of queries.  Past that the kernel is bound by the number of distinct cache lines its
+// scattered loads touch (~40 per query), not by latency or instructions: forcing 8 waves per SIMD changes nothing.
 
-template <bool COUNT>
+
+template <bool COUNT, int kLanes>
 __global__ __launch_bounds__(kGridBlock) void nn_grid_kernel(Cloud q, Cloud tgt, const int32_t *__restrict__ orig, NNGridDev g,
                                                              const int32_t *__restrict__ warm, int32_t *__restrict__ idx,
                                                              double *__restrict__ d2out, uint8_t *__restrict__ flag,
-                                                             int32_t *__restrict__ nflag, unsigned long long *tests) {
+                                                             int32_t *__restrict__ nflag, int32_t *__restrict__ nflag_next,
+                                                             unsigned long long *tests) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nflag_next = 0;  // the counter of the NEXT search (nobody reads it during this one)
     const int sub = threadIdx.x % kLanes;
     const int64_t i = (int64_t)blockIdx.x * (kGridBlock / kLanes) + threadIdx.x / kLanes;
     const bool ok = i < q.n;
@@ -47,18 +51,10 @@ __global__ __launch_bounds__(kGridBlock) void nn_grid_kernel(Cloud q, Cloud tgt,
     double best = __builtin_huge_val();
     int32_t bo = INT32_MAX, bi = -1;
     unsigned long long ntests = 0;
-    // the position this query matched last time: a valid candidate, its distance bounds the search from the first row on
-    // (every lane of the query evaluates it: same addresses, and each lane prunes its rows with it)
-    if (warm && ok) {
-        const int32_t p = warm[i];
-        if (p >= 0 && p < tgt.n) {
-            const double d = grid_norm2_exact(tgt.x[p] - qx, tgt.y[p] - qy, tgt.z[p] - qz);
-            if (d == d) best = d, bo = orig ? orig[p] : p, bi = p;
-        }
-    }
     const double fx = (qx - g.lo[0]) * g.inv_h, fy = (qy - g.lo[1]) * g.inv_h, fz = (qz - g.lo[2]) * g.inv_h;
     const bool finite = fabs(fx) < 1e15 && fabs(fy) < 1e15 && fabs(fz) < 1e15;  // false for NaN / infinite queries
     bool flagged = ok && !finite;
+    const bool active = ok && finite;
     const double cxf = floor(fx), cyf = floor(fy), czf = floor(fz);
     const double h2 = g.h * g.h;
     auto combine = [&]() {  // the kLanes lanes of a query agree on the best candidate (all lanes of the wave take part)
@@ -69,45 +65,111 @@ __global__ __launch_bounds__(kGridBlock) void nn_grid_kernel(Cloud q, Cloud tgt,
             if (d < best || (d == best && o < bo)) best = d, bo = o, bi = p;
         }
     };
-    auto scan = [&](int R) {
-        // cells [c - R, c + R] per axis, clamped to the grid (an interval wholly outside the grid is empty)
+    auto test = [&](const GridPoint &p) {
+        const double d = grid_norm2_exact(p.x - qx, p.y - qy, p.z - qz);
+        if (d < best || (d == best && p.orig < bo)) best = d, bo = p.orig, bi = p.pos;
+    };
+    // the block of cells [c - R, c + R] per axis, clamped to the grid (an interval wholly outside the grid is empty: nrows = 0)
+    struct Block {
+        int x0, x1, y0, z0, ny, nrows;
+    };
+    auto block_of = [&](int R) {
+        Block b{0, 0, 0, 0, 1, 0};
         const double xl = cxf - R, xh = cxf + R, yl = cyf - R, yh = cyf + R, zl = czf - R, zh = czf + R;
         if (xh < 0.0 || yh < 0.0 || zh < 0.0 || xl > (double)(g.g[0] - 1) || yl > (double)(g.g[1] - 1) || zl > (double)(g.g[2] - 1))
-            return;
-        const int x0 = clamp_cell(xl, g.g[0]), x1 = clamp_cell(xh, g.g[0]);
-        const int y0 = clamp_cell(yl, g.g[1]), y1 = clamp_cell(yh, g.g[1]);
-        const int z0 = clamp_cell(zl, g.g[2]), z1 = clamp_cell(zh, g.g[2]);
-        const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
-        for (int r = sub; r < nrows; r += kLanes) {
-            const int cz = z0 + r / ny, cy = y0 + r % ny;
-            const double gz = fmax(fmax((double)cz - fz, fz - (double)(cz + 1)), 0.0);
-            const double gy = fmax(fmax((double)cy - fy, fy - (double)(cy + 1)), 0.0);
-            // every target of the row is at least this far (cell units -> length); the slack keeps a row whose nearest point could tie
-            // with the best
-            if ((gy * gy + gz * gz) * h2 * (1.0 - 1e-9) > best) continue;
-            const int64_t row = ((int64_t)cz * g.g[1] + cy) * g.g[0];
-            const int32_t s = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
-            if (COUNT) ntests += (unsigned long long)(e - s);
-            for (int32_t j = s; j < e; ++j) {
-                const GridPoint p = g.pts[j];
-                const double d = grid_norm2_exact(p.x - qx, p.y - qy, p.z - qz);
-                if (d < best || (d == best && p.orig < bo)) best = d, bo = p.orig, bi = p.pos;
-            }
+            return b;
+        b.x0 = clamp_cell(xl, g.g[0]), b.x1 = clamp_cell(xh, g.g[0]);
+        b.y0 = clamp_cell(yl, g.g[1]), b.z0 = clamp_cell(zl, g.g[2]);
+        b.ny = clamp_cell(yh, g.g[1]) - b.y0 + 1;
+        b.nrows = b.ny * (clamp_cell(zh, g.g[2]) - b.z0 + 1);
+        return b;
+    };
+    // row r of a block: the targets [s, e) of its run of cells along x, and a lower bound (squared) of their distance to the query
+    auto row_bounds = [&](const Block &b, int r, int32_t &s, int32_t &e, double &gap2) {
+        const int cz = b.z0 + r / b.ny, cy = b.y0 + r % b.ny;
+        const double gz = fmax(fmax((double)cz - fz, fz - (double)(cz + 1)), 0.0);
+        const double gy = fmax(fmax((double)cy - fy, fy - (double)(cy + 1)), 0.0);
+        gap2 = (gy * gy + gz * gz) * h2 * (1.0 - 1e-9);  // (the slack keeps a row whose nearest point could tie with the best)
+        const int64_t row = ((int64_t)cz * g.g[1] + cy) * g.g[0];
+        s = g.cell_start[row + b.x0], e = g.cell_start[row + b.x1 + 1];
+    };
+    auto scan_row = [&](int32_t s, int32_t e) {
+        if (COUNT) ntests += (unsigned long long)(e - s);
+        int32_t j = s;
+        for (; j + 4 <= e; j += 4) {  // four loads in flight
+            const GridPoint p0 = g.pts[j], p1 = g.pts[j + 1], p2 = g.pts[j + 2], p3 = g.pts[j + 3];
+            test(p0), test(p1), test(p2), test(p3);
+        }
+        if (j < e) {  // up to three left: loads first (clamped addresses), tests under the count
+            const GridPoint p0 = g.pts[j], p1 = g.pts[min(j + 1, e - 1)], p2 = g.pts[min(j + 2, e - 1)];
+            test(p0);
+            if (j + 1 < e) test(p1);
+            if (j + 2 < e) test(p2);
         }
     };
-    const bool active = ok && finite;
-    if (active) scan(1);
+    // first pass, R = 1: the 3 x 3 rows around the query's cell, one per lane (lanes 9.. idle), in 32-bit integer arithmetic -- this
+    // is the path every query takes, and its instruction count is what the kernel's time is made of (16 lanes repeat the set-up).
+    // The row's bounds are requested BEFORE the warm start below is evaluated: the two chains of dependent loads
+    // (warm -> its coordinates; cell_start -> points) then overlap.
+    static_assert(kLanes >= 9 || kLanes == 8, "one lane per row of the first pass (8 lanes: lane 0 takes the ninth row too)");
+    const int cxi = (int)fmin(fmax(cxf, -2.0), (double)(g.g[0] + 1)), cyi = (int)fmin(fmax(cyf, -2.0), (double)(g.g[1] + 1)),
+              czi = (int)fmin(fmax(czf, -2.0), (double)(g.g[2] + 1));  // (clamped two cells outside the grid: such rows do not exist)
+    const int dz = sub / 3 - 1, dy = sub - 3 * (sub / 3) - 1;
+    const int cy1 = cyi + dy, cz1 = czi + dz;
+    const bool row1 = active && sub < (kLanes == 8 ? 8 : 9) && cy1 >= 0 && cy1 < g.g[1] && cz1 >= 0 && cz1 < g.g[2] && cxi + 1 >= 0 && cxi - 1 < g.g[0];
+    int32_t s1 = 0, e1 = 0;
+    double gap1 = 0.0;
+    if (row1) {
+        const int rowbase = (cz1 * g.g[1] + cy1) * g.g[0];
+        s1 = g.cell_start[rowbase + max(cxi - 1, 0)];
+        e1 = g.cell_start[rowbase + min(cxi + 1, g.g[0] - 1) + 1];  // (at most 3 entries further: the same cache line, mostly)
+        const double gz = fmax(fmax((double)cz1 - fz, fz - (double)(cz1 + 1)), 0.0);
+        const double gy = fmax(fmax((double)cy1 - fy, fy - (double)(cy1 + 1)), 0.0);
+        gap1 = (gy * gy + gz * gz) * h2 * (1.0 - 1e-9);
+    }
+    // the position this query matched last time: a valid candidate, its distance bounds the search from the first row on
+    // (every lane of the query evaluates it: same addresses, and each lane prunes its rows with it)
+    if (warm && ok) {
+        const int32_t p = warm[i];
+        if (p >= 0 && p < tgt.n) {
+            const double d = grid_norm2_exact(tgt.x[p] - qx, tgt.y[p] - qy, tgt.z[p] - qz);
+            if (d == d) best = d, bo = orig ? orig[p] : p, bi = p;
+        }
+    }
+    if (row1 && !(gap1 > best)) scan_row(s1, e1);
+    if (kLanes == 8) {  // ninth row (dy = dz = +1) by lane 0
+        const int cy9 = cyi + 1, cz9 = czi + 1;
+        if (active && sub == 0 && cy9 >= 0 && cy9 < g.g[1] && cz9 >= 0 && cz9 < g.g[2] && cxi + 1 >= 0 && cxi - 1 < g.g[0]) {
+            const int rowbase = (cz9 * g.g[1] + cy9) * g.g[0];
+            const int32_t s9 = g.cell_start[rowbase + max(cxi - 1, 0)], e9 = g.cell_start[rowbase + min(cxi + 1, g.g[0] - 1) + 1];
+            const double gz = fmax(fmax((double)cz9 - fz, fz - (double)(cz9 + 1)), 0.0);
+            const double gy = fmax(fmax((double)cy9 - fy, fy - (double)(cy9 + 1)), 0.0);
+            if (!((gy * gy + gz * gz) * h2 * (1.0 - 1e-9) > best)) scan_row(s9, e9);
+        }
+    }
+    auto scan = [&](int R) {
+        const Block b = block_of(R);
+        for (int r = sub; r < b.nrows; r += kLanes) {
+            int32_t s, e;
+            double gap2;
+            row_bounds(b, r, s, e, gap2);
+            if (!(gap2 > best)) scan_row(s, e);
+        }
+    };
     combine();
     // the 27 cells certify the minimum when best <= h^2; otherwise one pass over the block that covers sqrt(best), if a query may scan
     // that much (the decision is the same in the kLanes lanes of the query: they hold the same best)
-    if (active && !(best <= h2 * (1.0 - 1e-9))) {
-        const double need = ceil(sqrt(best) * g.inv_h * (1.0 + 1e-9));  // +inf when nothing was found; best is never NaN
-        if (need <= (double)kMaxR)
-            scan((int)need);
-        else
-            flagged = true;
+    const bool more = active && !(best <= h2 * (1.0 - 1e-9));
+    if (__any(more)) {  // (rare: none of the wave's four queries in the steady state of a registration)
+        if (more) {
+            const double need = ceil(sqrt(best) * g.inv_h * (1.0 + 1e-9));  // +inf when nothing was found; best is never NaN
+            if (need <= (double)kMaxR)
+                scan((int)need);
+            else
+                flagged = true;
+        }
+        combine();
     }
-    combine();
     if (ok && sub == 0) {
         if (!flagged || bi >= 0) idx[i] = bi;  // a flagged query keeps a valid warm start for the masked full scan
         if (!flagged) d2out[i] = best;
@@ -167,7 +229,7 @@ int nn_grid_build(gingr_ctx *ctx, const double *target_xyz, int64_t N, const int
             cells *= std::min(c, 1e9);
             if (c > 1024.0) cells = 1e30;  // too fine along this axis
         }
-        if (cells <= 8.0 * (double)N + 4096.0) break;
+        if (cells <= std::min(8.0 * (double)N + 4096.0, 1073741824.0)) break;  // (cell indices are 32-bit on the device)
         h *= 1.25;
     }
     const int64_t ncells = (int64_t)gd[0] * gd[1] * gd[2];
@@ -197,11 +259,11 @@ int nn_grid_build(gingr_ctx *ctx, const double *target_xyz, int64_t N, const int
     HIP_TRY(ctx, hipMalloc(&g->cell_start, start.size() * sizeof(int32_t)));
     HIP_TRY(ctx, hipMalloc(&g->pts, pts.size() * sizeof(GridPoint)));
     HIP_TRY(ctx, hipMalloc(&g->flag, (size_t)max_queries));
-    HIP_TRY(ctx, hipMalloc(&g->nflag, sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc(&g->nflag, 2 * sizeof(int32_t)));
     HIP_TRY(ctx, hipMemcpy(g->cell_start, start.data(), start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(g->pts, pts.data(), pts.size() * sizeof(GridPoint), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemset(g->flag, 0, (size_t)max_queries));
-    HIP_TRY(ctx, hipMemset(g->nflag, 0, sizeof(int32_t)));
+    HIP_TRY(ctx, hipMemset(g->nflag, 0, 2 * sizeof(int32_t)));
     for (int d = 0; d < 3; ++d) g->v.lo[d] = lo[d], g->v.g[d] = gd[d];
     g->v.h = h;
     g->v.inv_h = inv_h;
@@ -213,15 +275,22 @@ int nn_grid_build(gingr_ctx *ctx, const double *target_xyz, int64_t N, const int
     return GINGR_OK;
 }
 
-// idx / d2 of every query the grid certifies; the others are flagged (g.flag, g.nflag) for the masked launch_nn that must follow
-void launch_nn_grid(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, const NNGrid &g, const int32_t *warm,
-                    int32_t *idx, double *d2) {
-    const dim3 grid((unsigned)ceil_div(query.n, kGridBlock / kLanes));
+// idx / d2 of every query the grid certifies; the others are flagged (g.flag, g.cur_nflag()) for the masked launch_nn that must follow
+void launch_nn_grid(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, NNGrid &g, const int32_t *warm, int32_t *idx,
+                    double *d2) {
+    g.parity ^= 1;
+    int32_t *cur = g.nflag + g.parity, *next = g.nflag + (g.parity ^ 1);
     TimerScope ts(ctx, 8);
-    if (ctx->nn_tests)
-        hipLaunchKernelGGL(nn_grid_kernel<true>, grid, dim3(kGridBlock), 0, ctx->stream, query, target, target_orig, g.v, warm, idx, d2,
-                           g.flag, g.nflag, ctx->nn_tests);
-    else
-        hipLaunchKernelGGL(nn_grid_kernel<false>, grid, dim3(kGridBlock), 0, ctx->stream, query, target, target_orig, g.v, warm, idx, d2,
-                           g.flag, g.nflag, (unsigned long long *)nullptr);
+    auto go = [&](auto kern, int lanes) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(query.n, kGridBlock / lanes)), dim3(kGridBlock), 0, ctx->stream, query, target,
+                           target_orig, g.v, warm, idx, d2, g.flag, cur, next, ctx->nn_tests);
+    };
+    const bool many = query.n >= 32768;
+    if (ctx->nn_tests) {
+        if (many) go(nn_grid_kernel<true, 8>, 8);
+        else go(nn_grid_kernel<true, 16>, 16);
+    } else {
+        if (many) go(nn_grid_kernel<false, 8>, 8);
+        else go(nn_grid_kernel<false, 16>, 16);
+    }
 }

@@ -18,6 +18,8 @@ struct gingr_rigid_icp {
     double c0[3] = {0, 0, 0};  // fixed centring point of the sums (centroid of the initial template)
     double last_distance = 0.0;
     bool warm = false;  // idx holds the previous iteration's matches
+    NNGrid tgrid;       // uniform grid over the target (nn_grid.hip)
+    ~gingr_rigid_icp() { nn_grid_free(&tgrid); }
 };
 
 namespace {
@@ -171,6 +173,7 @@ int gingr_rigid_icp_create(gingr_ctx *ctx, int32_t kind, int64_t M, const double
     launch_tile_bbox(ctx, Cloud{t, t + N, t + 2 * N, N}, h->tboxes.as<double>());
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
         return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "rigid_icp_create: set-up kernels failed"));
+    if (nn_grid_build(ctx, target_xyz, N, order.data(), M, &h->tgrid) != GINGR_OK) return fail(GINGR_ERR_HIP);  // (message set)
     *out = h;
     return GINGR_OK;
 }
@@ -193,8 +196,15 @@ int gingr_rigid_icp_iterate(gingr_rigid_icp *h, int32_t n_iterations, double *di
     const double *t = h->tgt.as<double>();
     const Cloud cp{p, p + M, p + 2 * M, M}, ct{t, t + N, t + 2 * N, N};
     for (int32_t k = 0; k < n_iterations; ++k) {
-        launch_nn(ctx, cp, ct, h->torig.as<int32_t>(), h->tboxes.as<double>(), h->ws.p, h->idx.as<int32_t>(), h->d2.as<double>(),
-                  h->warm ? h->idx.as<int32_t>() : nullptr);
+        static const int grid_env = getenv("GINGR_NN_GRID") ? atoi(getenv("GINGR_NN_GRID")) : 1;
+        const int32_t *warm = h->warm ? h->idx.as<int32_t>() : nullptr;
+        if (grid_env && h->tgrid.ready && ctx->cull) {  // grid search, then the masked tile scan for what it flagged (fitter.hip, ICP)
+            launch_nn_grid(ctx, cp, ct, h->torig.as<int32_t>(), h->tgrid, warm, h->idx.as<int32_t>(), h->d2.as<double>());
+            launch_nn(ctx, cp, ct, h->torig.as<int32_t>(), h->tboxes.as<double>(), h->ws.p, h->idx.as<int32_t>(), h->d2.as<double>(),
+                      h->idx.as<int32_t>(), h->tgrid.flag, h->tgrid.cur_nflag());
+        } else {
+            launch_nn(ctx, cp, ct, h->torig.as<int32_t>(), h->tboxes.as<double>(), h->ws.p, h->idx.as<int32_t>(), h->d2.as<double>(), warm);
+        }
         h->warm = true;  // the next iteration starts every query from this one's match
         hipLaunchKernelGGL(icp_sums_kernel, dim3(kIcpBlocks), dim3(256), 0, ctx->stream, cp, ct, h->idx.as<int32_t>(), h->d2.as<double>(),
                            h->c0[0], h->c0[1], h->c0[2], h->part.as<double>());
