@@ -851,6 +851,20 @@ int gingr_fitter_exchange(gingr_fitter *f, void **dev_ptr, int64_t offsets[GINGR
     }
     return GINGR_OK;
 }
+// idx / d2 = nearest TARGET vertex of every query (positions in the target's device order; lowest original index on ties): the grid
+// search over the fixed target cloud first (nn_grid.hip), then the tile scan masked to the queries the grid could not certify -- a
+// launch that exits at once when there are none.  warm: idx holds the previous matches of the same queries.
+static void nearest_target_vertex(gingr_ctx *ctx, gingr_fitter *f, Cloud query, Cloud tgt, int32_t *idx, double *d2, bool warm) {
+    static const int grid_env = getenv("GINGR_NN_GRID") ? atoi(getenv("GINGR_NN_GRID")) : 1;
+    const int32_t *w = warm ? idx : nullptr;
+    if (grid_env && f->tgrid.ready && ctx->cull && query.n <= f->tgrid.max_queries) {
+        launch_nn_grid(ctx, query, tgt, f->tperm, f->tgrid, w, idx, d2);
+        launch_nn(ctx, query, tgt, f->tperm, f->tboxes, f->ws, idx, d2, idx, f->tgrid.flag, f->tgrid.cur_nflag());
+    } else {
+        launch_nn(ctx, query, tgt, f->tperm, f->tboxes, f->ws, idx, d2, w);
+    }
+}
+
 
 }  // extern "C"
 
@@ -979,23 +993,14 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                                                  f->surf_tri_pos, f->surf_tri_warm, f->ttribox);
                     f->surf_tri_warm = true;
                 }
-                launch_nn(ctx, cloud_of(f->surf_cp, M), tgt, f->tperm, f->tboxes, f->ws, f->surf_nn, f->surf_nnd2,
-                          f->surf_nn_warm ? f->surf_nn : nullptr);
+                nearest_target_vertex(ctx, f, cloud_of(f->surf_cp, M), tgt, f->surf_nn, f->surf_nnd2, f->surf_nn_warm);
                 f->surf_nn_warm = true;
                 launch_surface_prereject(ctx, M, f->surf_nn, f->tboundary, f->mvn, f->tvn, f->N, along ? f->surf_hit : nullptr,
                                          f->surf_pre);
                 launch_self_intersect(ctx, fit, f->surf_cp, f->mtri, f->Tm, f->mtboxes, f->surf_pre, f->surf_hit, f->mtribox);
                 launch_surface_weight(ctx, M, f->surf_pre, f->surf_hit, &f->st->sigma2, f->surf_w01, f->surf_win);
             } else if (icp) {
-                static const int grid_env = getenv("GINGR_NN_GRID") ? atoi(getenv("GINGR_NN_GRID")) : 1;
-                const int32_t *warm = f->nn_warm ? f->nn_idx : nullptr;
-                if (grid_env && f->tgrid.ready && ctx->cull) {
-                    // grid search first; what it cannot certify (flagged) goes through the masked full scan, a no-op when nothing is
-                    launch_nn_grid(ctx, fit, tgt, f->tperm, f->tgrid, warm, f->nn_idx, f->nn_d2);
-                    launch_nn(ctx, fit, tgt, f->tperm, f->tboxes, f->ws, f->nn_idx, f->nn_d2, f->nn_idx, f->tgrid.flag, f->tgrid.cur_nflag());
-                } else {
-                    launch_nn(ctx, fit, tgt, f->tperm, f->tboxes, f->ws, f->nn_idx, f->nn_d2, warm);
-                }
+                nearest_target_vertex(ctx, f, fit, tgt, f->nn_idx, f->nn_d2, f->nn_warm);
                 f->nn_warm = true;
             } else {
                 // boxes of the fit tiles + its |coordinate - centroid| maximum (slot cleared by the pass that wrote the fit)
