@@ -96,3 +96,48 @@ def test_the_grid_search_is_what_runs(ctx):
     ctx.nn_counting(False)
     algo.close()
     assert 0 < tests < 0.05 * ref.shape[0] * target.shape[0], tests
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_geometries(ctx, seed):
+    """Random sizes, anisotropic extents, large coordinate offsets (rounding of the cell index), float32-rounded coordinates (many
+    exact ties), clusters and a sprinkling of far outliers among the queries."""
+    import gingr_amd as ga
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.integers(1, 3000))
+    M = int(rng.integers(1, 2500))
+    scale = 10.0 ** rng.uniform(-3, 3, 3) if seed % 3 == 0 else np.full(3, 10.0 ** rng.uniform(-2, 3))
+    offset = rng.normal(0, 1, 3) * (1e6 if seed % 4 == 1 else 1.0)
+    kind = seed % 5
+    if kind == 0:
+        t = rng.normal(0, 1, (N, 3))
+    elif kind == 1:
+        t = shell(N, seed, radius=1.0)
+    elif kind == 2:
+        centres = rng.normal(0, 5, (4, 3))
+        t = centres[rng.integers(0, 4, N)] + rng.normal(0, 0.05, (N, 3))
+    elif kind == 3:
+        t = np.round(rng.normal(0, 2, (N, 3)))            # a coarse lattice: many coincident targets and equidistant pairs
+    else:
+        t = rng.uniform(-1, 1, (N, 3)) * np.array([1.0, 1.0, 1e-7])   # nearly flat
+    target = t * scale + offset
+    if seed % 2:
+        target = target.astype(np.float32).astype(np.float64)
+    q = target[rng.integers(0, N, M)] + rng.normal(0, 1, (M, 3)) * scale * 10.0 ** rng.uniform(-3, 0)
+    far = rng.random(M) < 0.02
+    q[far] += rng.normal(0, 1, (int(far.sum()), 3)) * scale * 300.0
+    if seed % 2:
+        q = q.astype(np.float32).astype(np.float64)
+    mo = tiny_model(q, seed)
+    algo = ga.IcpRegistration(ctx)
+    cfg = ga.IcpConfiguration(maxIterations=10, initialSigma=4.0, endSigma=1.0, correspondenceMethod="PointcloudClosestPoint")
+    state = algo.createInitialState(ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam), target, cfg)
+    for it in range(3):
+        fit_before = np.array(state.general.fit)
+        state = algo.update(state)
+        want, _, _ = go.icp_closest_point(fit_before, target)
+        got = algo.last_correspondence_indices()
+        assert np.array_equal(got, want), (seed, it, int(np.sum(got != want)), N, M)
+        if state.general.status != 0:
+            break
+    algo.close()
