@@ -2,14 +2,16 @@
 // (G/api/registration/utils/ClosestPointRegistrator.scala:33-44: closest target point per model vertex; ties -> lowest original
 // index, as the reference's linear argmin).  Same distances and the same answer as nn_kernel (affinity.hip) -- separately rounded
 // dx*dx + dy*dy + dz*dz, lowest original index on equal distances -- but each query tests the targets of a few grid cells instead of
-// whole 64-point tiles: ~40 tests per query instead of ~5 000 at 50k points.
+// whole 64-point tiles: ~15 tests per query instead of ~740 at 50k points.
 //
 // Exactness.  Targets are binned on the host by c = floor((x - lo) * inv_h) per axis (clamped to the grid); the device evaluates the
-// same expression for the query.  After scanning the cells [c - R, c + R]^3 every target not scanned is farther than R * h from the
-// query (up to the rounding of the cell index, covered by the factor (1 - 1e-9)), so the running minimum is the exact minimum as soon
-// as best <= (R h)^2 (1 - 1e-9).  R = 1 first; if that does not certify the minimum, one more pass with the R that covers sqrt(best),
-// up to kMaxR; a query that needs more (far from every target, nothing in its 27 cells, not finite) is FLAGGED and left to nn_kernel,
-// which runs masked right after (workgroups without a flagged query exit at once).
+// same expression for the query.  With the previous match as warm start and its distance r <= one cell, the query scans the cells the
+// ball of radius r overlaps (1-8 cells): every target within r is binned in one of them (a slack of 1e-9 covers the rounding of the
+// cell index), so the minimum over them and the warm candidate is the exact minimum.  Without such a bound: the cells
+// [c - 1, c + 1]^3; after scanning [c - R, c + R]^3 every target not scanned is farther than R * h from the query, so the running
+// minimum is exact as soon as best <= (R h)^2 (1 - 1e-9); if R = 1 does not certify it, one more pass with the R that covers
+// sqrt(best), up to kMaxR; a query that needs more (far from every target, nothing in its 27 cells, not finite) is FLAGGED and left
+// to nn_kernel, which runs masked right after (workgroups without a flagged query exit at once).
 #include "common.h"
 
 #include <algorithm>
@@ -107,28 +109,8 @@ __global__ __launch_bounds__(kGridBlock) void nn_grid_kernel(Cloud q, Cloud tgt,
             if (j + 2 < e) test(p2);
         }
     };
-    // first pass, R = 1: the 3 x 3 rows around the query's cell, one per lane (lanes 9.. idle), in 32-bit integer arithmetic -- this
-    // is the path every query takes, and its instruction count is what the kernel's time is made of (16 lanes repeat the set-up).
-    // The row's bounds are requested BEFORE the warm start below is evaluated: the two chains of dependent loads
-    // (warm -> its coordinates; cell_start -> points) then overlap.
-    static_assert(kLanes >= 9 || kLanes == 8, "one lane per row of the first pass (8 lanes: lane 0 takes the ninth row too)");
-    const int cxi = (int)fmin(fmax(cxf, -2.0), (double)(g.g[0] + 1)), cyi = (int)fmin(fmax(cyf, -2.0), (double)(g.g[1] + 1)),
-              czi = (int)fmin(fmax(czf, -2.0), (double)(g.g[2] + 1));  // (clamped two cells outside the grid: such rows do not exist)
-    const int dz = sub / 3 - 1, dy = sub - 3 * (sub / 3) - 1;
-    const int cy1 = cyi + dy, cz1 = czi + dz;
-    const bool row1 = active && sub < (kLanes == 8 ? 8 : 9) && cy1 >= 0 && cy1 < g.g[1] && cz1 >= 0 && cz1 < g.g[2] && cxi + 1 >= 0 && cxi - 1 < g.g[0];
-    int32_t s1 = 0, e1 = 0;
-    double gap1 = 0.0;
-    if (row1) {
-        const int rowbase = (cz1 * g.g[1] + cy1) * g.g[0];
-        s1 = g.cell_start[rowbase + max(cxi - 1, 0)];
-        e1 = g.cell_start[rowbase + min(cxi + 1, g.g[0] - 1) + 1];  // (at most 3 entries further: the same cache line, mostly)
-        const double gz = fmax(fmax((double)cz1 - fz, fz - (double)(cz1 + 1)), 0.0);
-        const double gy = fmax(fmax((double)cy1 - fy, fy - (double)(cy1 + 1)), 0.0);
-        gap1 = (gy * gy + gz * gz) * h2 * (1.0 - 1e-9);
-    }
-    // the position this query matched last time: a valid candidate, its distance bounds the search from the first row on
-    // (every lane of the query evaluates it: same addresses, and each lane prunes its rows with it)
+    // The position this query matched last time: a valid candidate whose distance bounds the search (every lane of the query
+    // evaluates it: same addresses).
     if (warm && ok) {
         const int32_t p = warm[i];
         if (p >= 0 && p < tgt.n) {
@@ -136,16 +118,35 @@ __global__ __launch_bounds__(kGridBlock) void nn_grid_kernel(Cloud q, Cloud tgt,
             if (d == d) best = d, bo = orig ? orig[p] : p, bi = p;
         }
     }
-    if (row1 && !(gap1 > best)) scan_row(s1, e1);
-    if (kLanes == 8) {  // ninth row (dy = dz = +1) by lane 0
-        const int cy9 = cyi + 1, cz9 = czi + 1;
-        if (active && sub == 0 && cy9 >= 0 && cy9 < g.g[1] && cz9 >= 0 && cz9 < g.g[2] && cxi + 1 >= 0 && cxi - 1 < g.g[0]) {
-            const int rowbase = (cz9 * g.g[1] + cy9) * g.g[0];
-            const int32_t s9 = g.cell_start[rowbase + max(cxi - 1, 0)], e9 = g.cell_start[rowbase + min(cxi + 1, g.g[0] - 1) + 1];
-            const double gz = fmax(fmax((double)cz9 - fz, fz - (double)(cz9 + 1)), 0.0);
-            const double gy = fmax(fmax((double)cy9 - fy, fy - (double)(cy9 + 1)), 0.0);
-            if (!((gy * gy + gz * gz) * h2 * (1.0 - 1e-9) > best)) scan_row(s9, e9);
-        }
+    // First pass, in 32-bit integer arithmetic (this is the path every query takes; kLanes lanes repeat its set-up).
+    //   * With a warm bound no longer than one cell: the cells the BALL of radius sqrt(best) around the query overlaps -- per axis the
+    //     query's cell and possibly one neighbour, so 1-8 cells instead of 27.  Every target at distance <= sqrt(best) is binned in
+    //     one of them (the slack covers the rounding of its cell index), so the minimum over them and the warm candidate is exact;
+    //     no certificate is needed.
+    //   * Otherwise (first search, or the previous match is far): the block of 3 x 3 x 3 cells, certified afterwards.
+    const int cxi = (int)fmin(fmax(cxf, -2.0), (double)(g.g[0] + 1)), cyi = (int)fmin(fmax(cyf, -2.0), (double)(g.g[1] + 1)),
+              czi = (int)fmin(fmax(czf, -2.0), (double)(g.g[2] + 1));  // (clamped two cells outside the grid: such rows do not exist)
+    const double rc = sqrt(best) * g.inv_h * (1.0 + 1e-9) + 1e-9;  // radius in cells; +inf without a warm start
+    const bool ball = active && rc <= 1.0;
+    int xlo = cxi - 1, xhi = cxi + 1, ylo = cyi - 1, yhi = cyi + 1, zlo = czi - 1, zhi = czi + 1;
+    if (ball) {  // floor(f - rc) and floor(f + rc), which lie within one cell of floor(f)
+        xlo = cxi - (fx - rc < cxf ? 1 : 0), xhi = cxi + (fx + rc >= cxf + 1.0 ? 1 : 0);
+        ylo = cyi - (fy - rc < cyf ? 1 : 0), yhi = cyi + (fy + rc >= cyf + 1.0 ? 1 : 0);
+        zlo = czi - (fz - rc < czf ? 1 : 0), zhi = czi + (fz + rc >= czf + 1.0 ? 1 : 0);
+    }
+    xlo = max(xlo, 0), ylo = max(ylo, 0), zlo = max(zlo, 0);
+    xhi = min(xhi, g.g[0] - 1), yhi = min(yhi, g.g[1] - 1), zhi = min(zhi, g.g[2] - 1);
+    const int ny = yhi - ylo + 1, nz = zhi - zlo + 1;  // <= 3 each
+    const int nrows1 = (active && ny > 0 && nz > 0 && xhi >= xlo) ? ny * nz : 0;
+    for (int r = sub; r < nrows1; r += kLanes) {
+        const int rz = ny == 1 ? r : (ny == 2 ? r >> 1 : (r * 11) >> 5);  // r / ny for r < 16
+        const int cy = ylo + (r - rz * ny), cz = zlo + rz;
+        const double gz = fmax(fmax((double)cz - fz, fz - (double)(cz + 1)), 0.0);
+        const double gy = fmax(fmax((double)cy - fy, fy - (double)(cy + 1)), 0.0);
+        if ((gy * gy + gz * gz) * h2 * (1.0 - 1e-9) > best) continue;  // the row's nearest point is farther than the bound
+        const int rowbase = (cz * g.g[1] + cy) * g.g[0];
+        const int32_t s = g.cell_start[rowbase + xlo], e = g.cell_start[rowbase + xhi + 1];  // (the same cache line, mostly)
+        scan_row(s, e);
     }
     auto scan = [&](int R) {
         const Block b = block_of(R);
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(kGridBlock) void nn_grid_kernel(Cloud q, Cloud tgt,
     combine();
     // the 27 cells certify the minimum when best <= h^2; otherwise one pass over the block that covers sqrt(best), if a query may scan
     // that much (the decision is the same in the kLanes lanes of the query: they hold the same best)
-    const bool more = active && !(best <= h2 * (1.0 - 1e-9));
+    const bool more = active && !ball && !(best <= h2 * (1.0 - 1e-9));
     if (__any(more)) {  // (rare: none of the wave's four queries in the steady state of a registration)
         if (more) {
             const double need = ceil(sqrt(best) * g.inv_h * (1.0 + 1e-9));  // +inf when nothing was found; best is never NaN
