@@ -165,13 +165,6 @@ __global__ void pose_of_state_kernel(const DevState *__restrict__ st, DevPose *_
     if (t == 0) pose->scale = 1.0;
 }
 
-// out = contribute ? in / sigma2 : 0   (as weight * in with weight = 1 / sigma2, the value the observation kernels use)
-__global__ void scaled_copy_kernel(const double *__restrict__ in, int64_t n, const double *__restrict__ sigma2, int contribute,
-                                   double *__restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = contribute ? in[i] * (1.0 / sigma2[0]) : 0.0;
-}
-
 Cloud cloud_of(const double *soa, int64_t n) { return Cloud{soa, soa + n, soa + 2 * n, n}; }
 
 SweepArgs base_args(const gingr_fitter *f) {
@@ -1058,9 +1051,11 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 // point-cloud ICP without landmarks: every row has the same weight 1 / sigma2 (ICP.scala:90-92), so the weighted Gram
                 // is the model's one-off moment Q^T Q scaled -- no pass over the basis.  mom holds the total over ALL shards: the
                 // shard that owns row 0 contributes it, the others contribute zero to the exchange.
-                hipLaunchKernelGGL(scaled_copy_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 256)), dim3(256), 0, ctx->stream,
-                                   m->mom + MomentLayout{rp}.stot(), (int64_t)rp * rp, &f->st->sigma2, m->row_begin == 0 ? 1 : 0, Gw);
+                // (written by the phase-1 finalize kernel below: one launch less than a copy kernel of its own)
                 fa.nslabs = 0;
+                fa.scaled_src = m->mom + MomentLayout{rp}.stot();
+                fa.sigma2 = &f->st->sigma2;
+                fa.scaled_contribute = m->row_begin == 0 ? 1 : 0;
             } else {
                 fa.gram_partial = gram_ws;
                 fa.nslabs = launch_gram(ctx, m->Q0, M, rp, f->weight, gram_ws, nullptr, f->evec, sweep_ws, &rhs_done);

@@ -135,8 +135,12 @@ int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const d
 // one launch for the reductions at the end of phase 1 (gp.hip: phase1_finalize_kernel)
 struct Phase1FinalizeArgs {
     int32_t rp;
-    const double *gram_partial;   // [nslabs][rp*rp] (upper patches); nslabs == 0: G is not touched
+    const double *gram_partial;   // [nslabs][rp*rp] (upper patches); nslabs == 0: G is not touched, unless scaled_src is given
     int32_t nslabs;
+    // nslabs == 0 and scaled_src != nullptr: G = scaled_contribute ? scaled_src / sigma2 : 0 (uniform-weight ICP: the model's Q^T Q)
+    const double *scaled_src;
+    const double *sigma2;
+    int32_t scaled_contribute;
     double *G;
     const double *sweep_partial;  // [sweep_blocks][rp]
     int32_t sweep_blocks;

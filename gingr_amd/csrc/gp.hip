@@ -673,11 +673,15 @@ __global__ __launch_bounds__(256) void phase1_finalize_kernel(Phase1FinalizeArgs
     __shared__ double sh[8][33];
     __shared__ double sv[256];
     const int rp = A.rp, rr = rp * rp;
-    const int nG = A.nslabs > 0 ? (rr + 31) / 32 : 0;
+    const int nG = (A.nslabs > 0 || A.scaled_src) ? (rr + 31) / 32 : 0;
     const int b = blockIdx.x;
     if (b < nG) {
         const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
         const int idx = b * 32 + el;
+        if (A.nslabs <= 0) {  // no Gram pass: every row carries the weight 1 / sigma2, G is the model's moment scaled
+            if (g == 0 && idx < rr) A.G[idx] = A.scaled_contribute ? A.scaled_src[idx] * (1.0 / A.sigma2[0]) : 0.0;
+            return;
+        }
         const int i = idx / rp, j = idx - i * rp;
         const bool need = idx < rr && !(i > j);
         double s = 0.0;
@@ -2157,7 +2161,7 @@ int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const d
 }
 
 void launch_phase1_finalize(gingr_ctx *ctx, const Phase1FinalizeArgs &a) {
-    const int nG = a.nslabs > 0 ? (a.rp * a.rp + 31) / 32 : 0;
+    const int nG = (a.nslabs > 0 || a.scaled_src) ? (a.rp * a.rp + 31) / 32 : 0;
     hipLaunchKernelGGL(phase1_finalize_kernel, dim3((unsigned)(nG + a.rp + 1)), dim3(256), 0, ctx->stream, a);
 }
 
