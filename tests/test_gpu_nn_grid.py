@@ -141,3 +141,25 @@ def test_random_geometries(ctx, seed):
         if state.general.status != 0:
             break
     algo.close()
+
+
+def test_benchmark_size_against_the_stateless_tile_scan(ctx):
+    """50k <-> 50k (bench.py's clouds): the fitter's search (grid + masked tile scan, warm-started) must give the indices of the stateless
+    gingr_nn (tile scan from scratch, no grid) -- two exact searches of different structure, so equal indices including every tie."""
+    import gingr_amd as ga
+    from bench import synth_clouds
+    y, x = synth_clouds(50000)
+    rng = np.random.default_rng(2)
+    r = 8
+    U, _ = np.linalg.qr(rng.normal(0, 1, (3 * y.shape[0], r)))
+    model = ga.PointDistributionModel(y, np.zeros_like(y), U, np.linspace(400.0, 50.0, r))
+    algo = ga.IcpRegistration(ctx)
+    cfg = ga.IcpConfiguration(maxIterations=10, initialSigma=20.0, endSigma=1.0, correspondenceMethod="PointcloudClosestPoint")
+    state = algo.createInitialState(model, x, cfg)
+    for it in range(3):
+        fit_before = np.array(state.general.fit)
+        state = algo.update(state)
+        want, _, _ = ctx.nn(fit_before, x)
+        got = algo.last_correspondence_indices()
+        assert np.array_equal(got, want), (it, int(np.sum(got != want)))
+    algo.close()
