@@ -8,4 +8,4 @@ for g in 0 1; do GINGR_NN_GRID=$g python3 tools/bench_icp.py 15000 2>/dev/null |
 for g in 0 1; do GINGR_NN_GRID=$g python3 tools/bench_icp.py 100000 2>/dev/null | tail -1 >> $O/icp100k.txt; done
 for g in 0 1; do GINGR_NN_GRID=$g python3 tools/bench_icp.py 1622 2>/dev/null | tail -1 >> $O/icp1622.txt; done
 cat $O/icp50k.txt $O/icp15k.txt $O/icp100k.txt $O/icp1622.txt | cut -c1-260
-bash tools/r03_step22.sh | grep "nn_\|== grid"
+bash tools/r03_steps/r03_step22.sh | grep "nn_\|== grid"
