@@ -1017,7 +1017,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                     launch_obs_points(ctx, m, f->st, f->robs, f->rwin, f->weight, f->evec, f->lm_mask);
                 else if (f->icp_surface)  // only the weight-1 pairs are observed (ICP.scala:50): weight 0 drops the row
                     launch_obs_points(ctx, m, f->st, f->surf_cp, f->surf_win, f->weight, f->evec, f->lm_mask);
-                else
+                else if (f->n_lm != 0)  // (without landmarks the observation is formed inside the right-hand-side pass below)
                     launch_obs_icp(ctx, m, f->st, tgt, f->nn_idx, f->lm_mask, f->weight, f->evec);
                 fa.scalar_mode = 0;
             } else {
@@ -1068,7 +1068,16 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 a.evec = f->evec;
                 a.partial = sweep_ws;
                 a.no_reduce = 1;
-                launch_sweep(ctx, SWEEP_RHS, a);
+                if (icp && !f->icp_surface && !f->reversed && f->n_lm == 0) {  // point-cloud ICP: observation + Q^T e in one pass
+                    a.state = f->st;
+                    a.icp_idx = f->nn_idx;
+                    a.tx = tgt.x, a.ty = tgt.y, a.tz = tgt.z;
+                    a.lm_mask = f->lm_mask;
+                    a.weight_out = f->weight, a.evec_out = f->evec;
+                    launch_sweep(ctx, SWEEP_RHS_ICP, a);
+                } else {
+                    launch_sweep(ctx, SWEEP_RHS, a);
+                }
                 fa.sweep_blocks = sweep_num_blocks(M);
             }
             launch_phase1_finalize(ctx, fa);

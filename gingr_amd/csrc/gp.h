@@ -96,7 +96,8 @@ enum SweepMode {
     SWEEP_SHAPES = 2,   // F(alpha_c, alpha): newshape planes + Umeyama partial sums
     SWEEP_PROJ2 = 3,    // T: e = R2^T (newshape - t2) - ref - mean
     SWEEP_FIT = 4,      // F(alpha): xyz = s (R (ref + mean + v - c) + c + t) from DevState
-    SWEEP_POSED = 5     // F(a): xyz = R (ref + mean + v - c) + c + t  (posterior mean mesh; no scale)
+    SWEEP_POSED = 5,    // F(a): xyz = R (ref + mean + v - c) + c + t  (posterior mean mesh; no scale)
+    SWEEP_RHS_ICP = 6   // T with e formed in the pass: the ICP observation of row i is target[icp_idx[i]], weight 1 / sigma2 (obs_points_kernel)
 };
 
 struct SweepArgs {
@@ -117,6 +118,11 @@ struct SweepArgs {
     double *out;           // reduced result: [rp] or [24]
     double *zero_slot;     // nullable: one double the pass clears (consumed by a LATER launch on the stream)
     int32_t no_reduce;     // != 0: leave the [nblocks][rp] partials in `partial` (the phase-1 finalize kernel adds them up)
+    // SWEEP_RHS_ICP: matched target positions, the target planes, the landmark mask (nullable); weight / e are also written out
+    const int32_t *icp_idx;
+    const double *tx, *ty, *tz;
+    const int32_t *lm_mask;
+    double *weight_out, *evec_out;
 };
 
 int sweep_num_blocks(int64_t M);

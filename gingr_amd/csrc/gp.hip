@@ -81,7 +81,7 @@ template <int MODE, int KMAX>
 __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepArgs a) {
     constexpr bool FWD = (MODE == SWEEP_PROJ1 || MODE == SWEEP_SHAPES || MODE == SWEEP_FIT || MODE == SWEEP_POSED);
     constexpr bool FWD2 = (MODE == SWEEP_SHAPES);
-    constexpr bool TRANS = (MODE == SWEEP_RHS || MODE == SWEEP_PROJ1 || MODE == SWEEP_PROJ2);
+    constexpr bool TRANS = (MODE == SWEEP_RHS || MODE == SWEEP_PROJ1 || MODE == SWEEP_PROJ2 || MODE == SWEEP_RHS_ICP);
     extern __shared__ double lds[];  // [2*rp] coefficients, then [kGroups*rp] reduction scratch
     const int tid = threadIdx.x, lane16 = tid & 15, grp = tid >> 4;
     const int rp = a.rp, km = rp >> 4;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepArgs a) {
     }
     // pose scalars (wave-uniform loads)
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tr[3] = {0, 0, 0}, cen[3] = {0, 0, 0}, scale = 1.0;
-    if (MODE == SWEEP_SHAPES || MODE == SWEEP_FIT || MODE == SWEEP_POSED) {
+    if (MODE == SWEEP_SHAPES || MODE == SWEEP_FIT || MODE == SWEEP_POSED || MODE == SWEEP_RHS_ICP) {
         for (int q = 0; q < 9; ++q) R[q] = a.state->R[q];
         for (int q = 0; q < 3; ++q) {
             tr[q] = a.state->t[q];
@@ -156,6 +156,26 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepArgs a) {
             e[0] = a.evec[pc];
             e[1] = a.evec[M + pc];
             e[2] = a.evec[2 * M + pc];
+        } else if (MODE == SWEEP_RHS_ICP) {
+            // the observation of obs_points_kernel (ICP branch), formed here: one launch and one round trip of e less per iteration.
+            // Same expressions, so the same e; weight and e are still written out for whoever reads them later.
+            const int32_t j = a.icp_idx[pc];
+            const double ox = a.tx[j], oy = a.ty[j], oz = a.tz[j];
+            const double w = 1.0 / a.state->sigma2;
+            const bool off = (a.lm_mask && a.lm_mask[pc]) || w == 0.0;
+            const double dx = ox - cen[0] - tr[0], dy = oy - cen[1] - tr[1], dz = oz - cen[2] - tr[2];
+            const double ex = R[0] * dx + R[3] * dy + R[6] * dz - (rx - cen[0]) - mx;
+            const double ey = R[1] * dx + R[4] * dy + R[7] * dz - (ry - cen[1]) - my;
+            const double ez = R[2] * dx + R[5] * dy + R[8] * dz - (rz - cen[2]) - mz;
+            e[0] = off ? 0.0 : w * ex;
+            e[1] = off ? 0.0 : w * ey;
+            e[2] = off ? 0.0 : w * ez;
+            if (valid && lane16 == 0) {
+                a.weight_out[p] = off ? 0.0 : w;
+                a.evec_out[p] = e[0];
+                a.evec_out[M + p] = e[1];
+                a.evec_out[2 * M + p] = e[2];
+            }
         } else if (MODE == SWEEP_PROJ1) {
             // shape - ref' - mean' = R (Q0_i a); projecting back multiplies by R^T: e = Q0_i a
             e[0] = f0[0];
@@ -2077,6 +2097,7 @@ void launch_sweep(gingr_ctx *ctx, SweepMode mode, const SweepArgs &a) {
         case SWEEP_PROJ2: launch_sweep_mode<SWEEP_PROJ2>(ctx, a, a.rp); break;
         case SWEEP_FIT: launch_sweep_mode<SWEEP_FIT>(ctx, a, 0); break;
         case SWEEP_POSED: launch_sweep_mode<SWEEP_POSED>(ctx, a, 0); break;
+        case SWEEP_RHS_ICP: launch_sweep_mode<SWEEP_RHS_ICP>(ctx, a, a.rp); break;
     }
 }
 
