@@ -359,10 +359,13 @@ def main():
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        import datetime
+        patience = datetime.timedelta(seconds=300)  # a rank that never shows up fails the run in minutes, not after the default half hour
         if shared_device:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=patience)
         else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, timeout=patience,
+                                    device_id=torch.device(f"cuda:{local_rank}"))
 
     M = N = args.points
     y, x = synth_clouds(M)
