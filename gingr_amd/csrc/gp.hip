@@ -1630,6 +1630,8 @@ __global__ __launch_bounds__(256) void coeff_solve_kernel(int r, int rp, const d
 
 // sums: [0..2] sum x~, [3..5] sum y~, [6..14] sum y~ x~^T (row-major), [15] sum |x~|^2; x~ = x - c0, y~ = y - c0.
 // Returns false when the result is not finite.
+// WAVE: the whole wave runs this with the same arguments (svd3.h: *_wave conversions)
+template <bool WAVE = false>
 __device__ bool umeyama_from_sums(const double *sums, double n, const double c0[3], int global_transform, DevPose &P) {
     if (global_transform == GINGR_NO_TRANSFORMS) {  // identityTransformation, GingrAlgorithm.scala:230
         for (int q = 0; q < 9; ++q) P.R[q] = (q % 4 == 0) ? 1.0 : 0.0;
@@ -1670,8 +1672,13 @@ __device__ bool umeyama_from_sums(const double *sums, double n, const double c0[
     }
     for (int a = 0; a < 3; ++a) P.t[a] = mya[a] - c * (R[a * 3] * mxa[0] + R[a * 3 + 1] * mxa[1] + R[a * 3 + 2] * mxa[2]);
     // the registration result carries its rotation as Euler angles (rigid3DLandmarkRegistration builds Rotation3D)
-    rot_to_euler(R, P.euler);
-    euler_to_rot(P.euler, P.R);
+    if (WAVE) {
+        rot_to_euler_wave(R, P.euler);
+        euler_to_rot_wave(P.euler, P.R);
+    } else {
+        rot_to_euler(R, P.euler);
+        euler_to_rot(P.euler, P.R);
+    }
     P.center[0] = P.center[1] = P.center[2] = 0.0;  // estimate*Transform(..., Point(0,0,0))
     P.scale = c;
     bool fin = finite_d(c);
@@ -1785,7 +1792,7 @@ __device__ void post_pose_step(const PostSolveArgs &A, const DevState *st, const
     sums[15] = 0.0;
     for (int d = 0; d < 3; ++d) sums[15] += A.Pp[d * 3 + d] + 2.0 * dots[6 + d * 3 + d] + dots[33 + d];
     DevPose Pl;
-    const bool fin = umeyama_from_sums(sums, A.n_total, A.c0, A.global_transform, Pl);
+    const bool fin = umeyama_from_sums<true>(sums, A.n_total, A.c0, A.global_transform, Pl);  // (called by a whole wave)
     if (!fin) *bad = 1;
     P = Pl;
     // e_i = R2^T (newshape_i - t2) - p_i = (B - I) p~_i + B Q0_i alpha_c + h,  B = R2^T R
@@ -1999,7 +2006,9 @@ __global__ __launch_bounds__(kPostThreads) void post_solve_kernel(PostSolveArgs 
     }
     __syncthreads();
     POST_STAMP(2)
-    if (tid == 0) post_pose_step(A, st, dots, P, Bm, BmI, hv, &bad);
+    // one wave, every lane with the same data and the same stores (same values to the same LDS words): the independent
+    // transcendental calls of the Euler round trip spread over its lanes (svd3.h)
+    if (tid < 64) post_pose_step(A, st, dots, P, Bm, BmI, hv, &bad);
     __syncthreads();
     POST_STAMP(3)
     // second projection Q^T e from the moments (transformedModel.coefficients(newshape), :234-237)

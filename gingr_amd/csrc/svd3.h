@@ -68,6 +68,46 @@ __host__ __device__ inline void rot_to_euler(const double R[9], double e[3]) {
 }
 
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same two conversions for a caller whose WHOLE wave executes them with the same arguments (the pose step of the post-solve
+// kernel): the independent transcendental calls run in different lanes at the same time -- three sincos of euler_to_rot in lanes
+// 0..2, the two arctangents of rot_to_euler in lanes 0..1 -- and are broadcast; 4 call times instead of 7 on the one-wave chain.
+// Same functions on the same arguments, so the same bits as the scalar forms above.
+__device__ inline void euler_to_rot_wave(const double e[3], double R[9]) {
+    const int l = (int)(__lane_id() % 3u);
+    const GingrSinCos sc = gingr_sincos(l == 0 ? e[0] : (l == 1 ? e[1] : e[2]));
+    const double sphi = __shfl(sc.s, 0), cphi = __shfl(sc.c, 0), sth = __shfl(sc.s, 1), cth = __shfl(sc.c, 1), spsi = __shfl(sc.s, 2),
+                 cpsi = __shfl(sc.c, 2);
+    R[0] = cth * cphi;
+    R[1] = spsi * sth * cphi - cpsi * sphi;
+    R[2] = spsi * sphi + cpsi * sth * cphi;
+    R[3] = cth * sphi;
+    R[4] = cpsi * cphi + spsi * sth * sphi;
+    R[5] = cpsi * sth * sphi - spsi * cphi;
+    R[6] = -sth;
+    R[7] = spsi * cth;
+    R[8] = cpsi * cth;
+}
+
+__device__ inline void rot_to_euler_wave(const double R[9], double e[3]) {
+    if (fabs(fabs(R[6]) - 1) > 0.0001) {  // (the same branch in every lane: same R)
+        const double theta = GINGR_ASIN(-R[6]);
+        GINGR_SINCOS(theta, st_unused, ct);
+        (void)st_unused;
+        const bool odd = (__lane_id() & 1u) != 0;  // even lanes: psi = atan2(R7 / ct, R8 / ct); odd lanes: phi = atan2(R3 / ct, R0 / ct)
+        const double a = GINGR_ATAN2((odd ? R[3] : R[7]) / ct, (odd ? R[0] : R[8]) / ct);
+        e[2] = __shfl(a, 0);
+        e[0] = __shfl(a, 1);
+        e[1] = theta;
+    } else {
+        rot_to_euler(R, e);  // gimbal lock: one arctangent
+    }
+}
+#else  // (the host pass of a kernel that names them)
+__host__ __device__ inline void euler_to_rot_wave(const double e[3], double R[9]) { euler_to_rot(e, R); }
+__host__ __device__ inline void rot_to_euler_wave(const double R[9], double e[3]) { rot_to_euler(R, e); }
+#endif
+
 // one-sided Jacobi SVD of a 3x3 matrix: A = U diag(s) V^T, s descending.  Out of line: it is the rarely taken fallback of
 // polar3_rotation, and its dynamically indexed arrays would otherwise put the whole calling kernel on scratch memory.
 __device__ __attribute__((noinline)) inline void svd3(const double Ain[9], double U[9], double s[3], double V[9]) {
