@@ -21,6 +21,9 @@ namespace {
 
 constexpr int kGridBlock = 256;
 constexpr int kMaxR = 3;  // largest half-width (in cells) of the block a query scans itself: 7^3 cells
+// A row of cells that holds more targets than this (heaps of coincident points, a cloud that is one dense blob plus a far outlier) is
+// not scanned by its one lane: the query is flagged and the tile scan, which spreads the work over a workgroup, answers it.
+constexpr int kMaxRowTargets = 1024;
 
 __device__ __forceinline__ double grid_norm2_exact(double dx, double dy, double dz) {
     return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
@@ -56,6 +59,7 @@ __global__ __launch_bounds__(kGridBlock) void nn_grid_kernel(Cloud q, Cloud tgt,
     const double fx = (qx - g.lo[0]) * g.inv_h, fy = (qy - g.lo[1]) * g.inv_h, fz = (qz - g.lo[2]) * g.inv_h;
     const bool finite = fabs(fx) < 1e15 && fabs(fy) < 1e15 && fabs(fz) < 1e15;  // false for NaN / infinite queries
     bool flagged = ok && !finite;
+    bool crowded = false;  // this lane skipped a row that holds too many targets (scan_row)
     const bool active = ok && finite;
     const double cxf = floor(fx), cyf = floor(fy), czf = floor(fz);
     const double h2 = g.h * g.h;
@@ -65,7 +69,10 @@ __global__ __launch_bounds__(kGridBlock) void nn_grid_kernel(Cloud q, Cloud tgt,
             const double d = __shfl_xor(best, off);
             const int32_t o = __shfl_xor(bo, off), p = __shfl_xor(bi, off);
             if (d < best || (d == best && o < bo)) best = d, bo = o, bi = p;
+            const int other = __shfl_xor((int)crowded, off);
+            crowded = crowded || other != 0;
         }
+        if (crowded) flagged = true;  // a row was left out: the answer may be incomplete
     };
     auto test = [&](const GridPoint &p) {
         const double d = grid_norm2_exact(p.x - qx, p.y - qy, p.z - qz);
@@ -96,6 +103,10 @@ __global__ __launch_bounds__(kGridBlock) void nn_grid_kernel(Cloud q, Cloud tgt,
         s = g.cell_start[row + b.x0], e = g.cell_start[row + b.x1 + 1];
     };
     auto scan_row = [&](int32_t s, int32_t e) {
+        if (e - s > kMaxRowTargets) {
+            crowded = true;
+            return;
+        }
         if (COUNT) ntests += (unsigned long long)(e - s);
         int32_t j = s;
         for (; j + 4 <= e; j += 4) {  // four loads in flight

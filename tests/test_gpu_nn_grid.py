@@ -163,3 +163,26 @@ def test_benchmark_size_against_the_stateless_tile_scan(ctx):
         got = algo.last_correspondence_indices()
         assert np.array_equal(got, want), (it, int(np.sum(got != want)))
     algo.close()
+
+
+def test_heaps_of_coincident_targets(ctx):
+    """Thousands of targets in one grid cell (a blob of coincident points plus a far outlier that stretches the grid): the row is too
+    crowded for one lane, the query is handed to the tile scan -- still the linear argmin, lowest index among the coincident points."""
+    import gingr_amd as ga
+    rng = np.random.default_rng(11)
+    blob = np.tile(np.array([[1.0, 2.0, 3.0]]), (3000, 1))
+    blob[::7] += 1e-9                                   # nearly coincident too
+    target = np.concatenate([blob, rng.normal(0, 1, (200, 3)) * 50.0 + 500.0, np.array([[1e4, 0.0, 0.0]])])
+    ref = np.concatenate([rng.normal(0, 0.5, (300, 3)) + np.array([1.0, 2.0, 3.0]), rng.normal(0, 1, (100, 3)) * 50.0 + 500.0])
+    mo = tiny_model(ref, seed=4)
+    algo = ga.IcpRegistration(ctx)
+    cfg = ga.IcpConfiguration(maxIterations=10, initialSigma=4.0, endSigma=1.0, correspondenceMethod="PointcloudClosestPoint")
+    state = algo.createInitialState(ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam), target, cfg)
+    for it in range(3):
+        fit_before = np.array(state.general.fit)
+        state = algo.update(state)
+        want, _, _ = go.icp_closest_point(fit_before, target)
+        assert np.array_equal(algo.last_correspondence_indices(), want), it
+        if state.general.status != 0:
+            break
+    algo.close()
