@@ -311,6 +311,9 @@ def main():
                          "also times the HIP path on the same inputs")
     ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
                     help="one measurement line for BASELINE.json config N (tools/bench_configs.py) instead of the headline benchmark")
+    ap.add_argument("--ctx-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="same-box comparisons: gingr_ctx_set_option on the context, NAME in cull | fine_cull | nn_grid (all select "
+                         "between code paths with identical results)")
     args = ap.parse_args()
     if args.config:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -423,6 +426,9 @@ def main():
                 return ms.value, n.value
     else:
         ctx = ga.Context(local_rank)
+        for kv in args.ctx_option:
+            name, _, val = kv.partition("=")
+            ctx.set_option({"cull": 0, "fine_cull": 1, "nn_grid": 2}[name], int(val))
         stream = torch.cuda.Stream(device=local_rank)
         ctx.set_stream(stream.cuda_stream)
         if args.host_gpmm:
@@ -606,7 +612,7 @@ def main():
                         "HBM and MFMA are not the binding resource.  In the contract's hbm|mfma vocabulary this is the "
                         "compute side: the peak used, 78.6 TFLOP/s, is also the dense f64 MFMA peak -- on gfx950 the f64 "
                         "vector and matrix pipes share the issue slots (profiles/r01_ubench_mfma_valu_overlap.txt), so "
-                        "moving the K=3 contraction to MFMA does not raise the ceiling (measured in rounds 1-2: tools/experiment_affinity_mfma.hip)"}
+                        "moving the K=3 contraction to MFMA does not raise the ceiling (measured in rounds 1-2: tools/experiments/experiment_affinity_mfma.hip)"}
 
     # ---- parity of the state the measurements ended in (outside every timed region): ONE more update on the device, then the
     # affinity statistics of that evaluation (P1, PX of this rank's rows; den, Np) and the sigma2 it committed against the strict

@@ -54,6 +54,7 @@ _dp = POINTER(c_double)
 _ip = POINTER(c_int32)
 
 KERNEL_GAUSSIAN_MIXTURE, KERNEL_DOT, KERNEL_LOOKUP = 0, 1, 2
+OPT_CULL, OPT_FINE_CULL, OPT_NN_GRID = 0, 1, 2  # gingr_ctx_option
 
 
 class ScalarKernel(ctypes.Structure):
@@ -72,6 +73,8 @@ SIGNATURES = {
     "gingr_ctx_get_stream": (c_void_p, [c_void_p]),
     "gingr_ctx_synchronize": (c_int, [c_void_p]),
     "gingr_build_info": (c_char_p, []),
+    "gingr_ctx_set_option": (c_int, [c_void_p, c_int32, c_int32]),
+    "gingr_ctx_get_option": (c_int, [c_void_p, c_int32, POINTER(c_int32)]),
     "gingr_cpd_stats": (c_int, [c_void_p, c_int64, _dp, c_int64, _dp, c_double, c_double, _dp, _dp, _dp, _dp, _dp]),
     "gingr_cpd_initial_sigma2": (c_int, [c_void_p, c_int64, _dp, c_int64, _dp, _dp]),
     "gingr_nn": (c_int, [c_void_p, c_int64, _dp, c_int64, _dp, _ip, _dp, _dp]),
@@ -176,18 +179,24 @@ def load():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback)")
         lib = ctypes.CDLL(LIB_PATH)
-        # GINGR_HIP_LIB (same-box A/B timing against an OLDER build of the library, tools/abn.sh) tolerates symbols that build does
-        # not have yet; the in-tree library must export every declared symbol
-        older_build = bool(os.environ.get("GINGR_HIP_LIB"))
+        # GINGR_HIP_LIB_ALLOW_OLDER=1 (set by tools/abn.sh only: same-box A/B timing against an OLDER build of the library)
+        # tolerates symbols that build does not have yet and says which; any other library -- the in-tree one, or a user's
+        # GINGR_HIP_LIB override -- must export every declared symbol
+        older_build = os.environ.get("GINGR_HIP_LIB_ALLOW_OLDER") == "1"
+        skipped = []
         for name, (res, args) in SIGNATURES.items():
             try:
                 fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
             except AttributeError:
                 if older_build:
+                    skipped.append(name)
                     continue
                 raise
             fn.restype = res
             fn.argtypes = args
+        if skipped:
+            import sys
+            print(f"gingr_amd: {LIB_PATH} lacks {len(skipped)} declared symbols (older build): {', '.join(skipped)}", file=sys.stderr)
         _LIB = lib
     return _LIB
 

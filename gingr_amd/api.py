@@ -97,6 +97,15 @@ class Context:
         _check(self.handle, self._lib.gingr_ctx_timing_read(self.handle, which, ctypes.byref(ms), ctypes.byref(n)), "timing_read")
         return ms.value, n.value
 
+    def set_option(self, option: int, value: int):
+        """gingr_ctx_set_option: nat.OPT_CULL / OPT_FINE_CULL / OPT_NN_GRID -- code paths with identical results (tests, A/B timing)."""
+        _check(self.handle, self._lib.gingr_ctx_set_option(self.handle, int(option), int(value)), "gingr_ctx_set_option")
+
+    def get_option(self, option: int) -> int:
+        v = ctypes.c_int32()
+        _check(self.handle, self._lib.gingr_ctx_get_option(self.handle, int(option), ctypes.byref(v)), "gingr_ctx_get_option")
+        return int(v.value)
+
     def nn_counting(self, on: bool = True):
         """Diagnostics: count the distance tests the nearest-neighbour launches of this context really execute (clears the counter)."""
         _check(self.handle, self._lib.gingr_ctx_nn_counting(self.handle, 1 if on else 0), "nn_counting")

@@ -1041,9 +1041,9 @@ template <bool COUNT>
 __global__ __launch_bounds__(kNNBlock) void nn_kernel(Cloud q, Cloud tgt, const int32_t *__restrict__ orig,
                                                       const double *__restrict__ tgt_boxes, int64_t cols_per_chunk,
                                                       double *__restrict__ pd2, int32_t *__restrict__ pidx,
-                                                      int32_t *__restrict__ porig, const int32_t *__restrict__ warm,
+                                                      int32_t *__restrict__ porig, const int32_t *warm /* may alias idx_out */,
                                                       unsigned long long *tests, const uint8_t *__restrict__ mask,
-                                                      const int32_t *__restrict__ nmask, int32_t *__restrict__ idx_out,
+                                                      const int32_t *__restrict__ nmask, int32_t *idx_out,
                                                       double *__restrict__ d2_out) {
     // masked launch (the queries the grid search of nn_grid.hip left over): nothing to do at all, or nothing for these 64 queries
     if (nmask && *nmask == 0) return;
@@ -1290,12 +1290,32 @@ constexpr int kPT = GINGR_PT_DEFAULT;     // points per thread in both CPD passe
 // workgroup per CU).  With round 2's work split (a workgroup owns 256 rows whatever PT is) four points per thread win from a few
 // thousand rows on: 8-GPU shard of the 50k workload (6250 rows) 0.50 ms per iteration with PT = 2, 0.49 ms with PT = 4.
 constexpr int64_t kSmallShardRows = 2048;
-inline int env_int_early(const char *name) {
-    const char *e = getenv(name);
-    return e ? atoi(e) : 0;
-}
+// Build-time knobs of the chunk planner (the sweeps behind the defaults: tools/chunk_sweep.sh, tools/small_chunk_sweep.sh build the
+// library with -DGINGR_...=v through tools/abn.sh; none of them is read from the environment):
+//   GINGR_ROWSTATS_PT        2 or 4 points per thread in the row-statistics pass whatever the shard size (0: by shard size)
+//   GINGR_COLSUM_QUARTERS / GINGR_ROWSTATS_QUARTERS   fixed chunk length in 64-point quarters (0: planner)
+//   GINGR_COLSUM_CHUNKS / GINGR_ROWSTATS_CHUNKS       exactly n chunks balanced to a quarter (0: planner)
+//   GINGR_FAIR_PRIORITY      0 never, 1 in one-round launches (default), 2 always: waves lower their issue priority as they advance
+#ifndef GINGR_ROWSTATS_PT
+#define GINGR_ROWSTATS_PT 0
+#endif
+#ifndef GINGR_COLSUM_QUARTERS
+#define GINGR_COLSUM_QUARTERS 0
+#endif
+#ifndef GINGR_ROWSTATS_QUARTERS
+#define GINGR_ROWSTATS_QUARTERS 0
+#endif
+#ifndef GINGR_COLSUM_CHUNKS
+#define GINGR_COLSUM_CHUNKS 0
+#endif
+#ifndef GINGR_ROWSTATS_CHUNKS
+#define GINGR_ROWSTATS_CHUNKS 0
+#endif
+#ifndef GINGR_FAIR_PRIORITY
+#define GINGR_FAIR_PRIORITY 1
+#endif
 inline int rowstats_pt(int64_t rows) {
-    static const int forced = env_int_early("GINGR_ROWSTATS_PT");  // developer knob: 2 or 4 points per thread whatever the shard size
+    constexpr int forced = GINGR_ROWSTATS_PT;
     if (forced == 2 || forced == kPT) return forced;
     return (kPT > 2 && rows <= kSmallShardRows) ? 2 : kPT;
 }
@@ -1313,22 +1333,7 @@ constexpr int kMinChunk = GINGR_MIN_CHUNK;  // shortest chunk the planner picks 
 // split `stream_len` into chunks so that block_cols * nchunks ~ kTargetBlocks.  A chunk is a whole number of tiles, or -- when
 // even one tile per chunk leaves too few workgroups (small shards) -- a half or a quarter of a tile: 64-point quarters are the
 // unit of the culling boxes, and a chunk that divides a tile never straddles two tiles' boxes.
-// `quarters_override` > 0 (developer knob, environment GINGR_COLSUM_TILES / GINGR_ROWSTATS_TILES, in tiles, may be 0.25 / 0.5)
-// fixes the chunk length.
-inline int env_int(const char *name) {
-    const char *e = getenv(name);
-    return e ? atoi(e) : 0;
-}
-struct ChunkShape {  // developer knob GINGR_CHUNK_SHAPE="big_tiles,fraction,tail_tiles": long chunks over `fraction` of the stream
-    double big = 0, frac = 0, tail = 0;
-};
-inline ChunkShape env_chunk_shape() {
-    ChunkShape c;
-    if (const char *e = getenv("GINGR_CHUNK_SHAPE")) {
-        if (sscanf(e, "%lf,%lf,%lf", &c.big, &c.frac, &c.tail) != 3) c = ChunkShape();
-    }
-    return c;
-}
+// `quarters_override` > 0 (build-time knob GINGR_COLSUM_QUARTERS / GINGR_ROWSTATS_QUARTERS) fixes the chunk length.
 // Resident workgroups of the chip for one of the all-pairs kernels (compute units x workgroups per unit), queried once.  Launches
 // come in rounds of that many workgroups and the last, partly filled round costs almost a full one (measured at 50k x 50k:
 // 4.79 -> 4.98 rounds of the column-sum pass is 2.7 % FASTER, 6.38 -> 5.87 rounds of the row-statistics pass 3 %), so the chunk
@@ -1377,18 +1382,12 @@ inline ChunkPlan plan_chunks(int64_t owned, int owned_per_block, int64_t stream_
         len = 64;
     if (quarters_override <= 0 && len < kMinChunk) len = kMinChunk;
     ChunkPlan p{len, len, (int32_t)ceil_div(n, len), 0};
-    static const ChunkShape shape = env_chunk_shape();
-    if (shape.big >= 1 && shape.tail >= 1 && shape.frac > 0 && shape.frac < 1 && quarters_override <= 0) {
-        p.len_big = (int64_t)shape.big * kTile;
-        p.len_tail = (int64_t)shape.tail * kTile;
-        p.n_big = (int32_t)((double)n * shape.frac / (double)p.len_big);
-    }
-    // developer knobs GINGR_COLSUM_CHUNKS / GINGR_ROWSTATS_CHUNKS=<n>: exactly n chunks balanced to a 64-point quarter (lengths
+    // build-time knobs GINGR_COLSUM_CHUNKS / GINGR_ROWSTATS_CHUNKS=<n>: exactly n chunks balanced to a 64-point quarter (lengths
     // differ by at most 64; the kernels handle chunks that start inside a tile).  Default (no knob, `resident` known): the
     // largest chunk count whose workgroups fill k whole launch rounds, k = kTargetBlocks / resident rounded -- see
     // resident_workgroups -- with the same balanced lengths.
     int forced = forced_chunks;
-    if (forced <= 0 && quarters_override <= 0 && resident > 0 && shape.big < 1) {
+    if (forced <= 0 && quarters_override <= 0 && resident > 0) {
         // rounds: as many as kTargetBlocks asks for (finer balancing when culling makes workgroup costs uneven), but not so many that
         // a chunk drops below ~1024 streamed points -- every workgroup pays ~3-4 us of prologue (table fill, owned points, boxes),
         // which short chunks do not amortise (8-GPU shard of the 50k workload: 0.52 -> 0.49 ms per iteration with one round)
@@ -1418,30 +1417,14 @@ inline ChunkPlan plan_chunks(int64_t owned, int owned_per_block, int64_t stream_
         }
     }
     *nchunks = p.chunks(n);
-    static const int fair_env = getenv("GINGR_FAIR_PRIORITY") ? atoi(getenv("GINGR_FAIR_PRIORITY")) : 1;
+    constexpr int fair_env = GINGR_FAIR_PRIORITY;
     p.fair = (fair_env == 2 || (fair_env == 1 && resident > 0 && (int64_t)*nchunks * bx <= resident)) ? 1 : 0;
     return p;
 }
-inline int env_tiles(const char *name) {  // tiles -> quarters
-    const char *e = getenv(name);
-    return e ? (int)(atof(e) * 4.0 + 0.5) : 0;
-}
-inline int colsum_tiles_override() {
-    static const int v = env_tiles("GINGR_COLSUM_TILES");
-    return v;
-}
-inline int colsum_chunks_override() {
-    static const int v = env_int("GINGR_COLSUM_CHUNKS");
-    return v;
-}
-inline int rowstats_chunks_override() {
-    static const int v = env_int("GINGR_ROWSTATS_CHUNKS");
-    return v;
-}
-inline int rowstats_tiles_override() {
-    static const int v = env_tiles("GINGR_ROWSTATS_TILES");
-    return v;
-}
+inline int colsum_tiles_override() { return GINGR_COLSUM_QUARTERS; }
+inline int colsum_chunks_override() { return GINGR_COLSUM_CHUNKS; }
+inline int rowstats_chunks_override() { return GINGR_ROWSTATS_CHUNKS; }
+inline int rowstats_tiles_override() { return GINGR_ROWSTATS_QUARTERS; }
 
 }  // namespace
 
@@ -1580,8 +1563,6 @@ static void plan_nn(int64_t nq, int64_t nt_points, bool pruned, int *nchunks, in
 
 void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, const double *tgt_boxes, void *ws,
                int32_t *idx, double *d2, const int32_t *warm, const uint8_t *mask, const int32_t *nmask) {
-    static const int warm_env = getenv("GINGR_NN_WARM") ? atoi(getenv("GINGR_NN_WARM")) : 1;
-    if (!warm_env) warm = nullptr;
     int nch;
     int64_t len;
     const bool pruned = ctx->cull && tgt_boxes != nullptr;

@@ -29,13 +29,15 @@ struct gingr_ctx {
     std::vector<hipEvent_t> pool;  // recycled events
     double t_ms[GINGR_TIMERS] = {0};
     int64_t t_n[GINGR_TIMERS] = {0};
-    // exact-zero tile culling of the CPD passes (affinity.hip); GINGR_CULL=0 disables it (results must stay bit-identical)
+    // exact-zero tile culling of the CPD passes and exact pruning of the closest-point scans (affinity.hip); gingr_ctx_set_option
+    // (GINGR_OPT_CULL, 0) disables both (results must stay bit-identical: the culling test compares the two)
     int cull = 1;
+    int nn_grid = 1;  // GINGR_OPT_NN_GRID: closest point over the target's uniform grid (nn_grid.hip); 0 = the tile scan alone
     // Culling regime of the CPD passes as the DEVICE last saw it (0 plain, 1 quarter-tile culling pays): pinned host word the
     // all-pairs kernels write, read -- unsynchronised, possibly a few launches stale -- when the next launch picks its kernel
     // variant.  Both variants compute bit-identical results, so a stale value only costs time.  Null: always the plain variant.
     int32_t *regime_host = nullptr, *regime_dev = nullptr;
-    int fine_override = -1;  // GINGR_FINE_CULL=0|1 pins the variant (tests: both must give bit-identical results); -1: by regime
+    int fine_override = -1;  // GINGR_OPT_FINE_CULL 0|1 pins the variant (tests: both must give bit-identical results); -1: by regime
     // diagnostics (gingr_ctx_nn_counting): device counter of the distance tests the nearest-neighbour launches really execute; null = off
     unsigned long long *nn_tests = nullptr;
     // scratch kept across calls (grown on demand, never shrunk) so steady-state updates do not allocate

@@ -1,7 +1,6 @@
 // Context, error handling, timing hooks and the stateless all-pairs operators of the C ABI (include/gingr_hip.h).
 #include "common.h"
 
-#include <cstdlib>
 
 int gingr_set_error(gingr_ctx *ctx, int code, const char *fmt, ...) {
     if (ctx) {
@@ -78,8 +77,6 @@ int gingr_ctx_create(int device, gingr_ctx **out) {
         return GINGR_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
-    if (const char *m = getenv("GINGR_CULL")) ctx->cull = (strcmp(m, "0") == 0) ? 0 : 1;
-    if (const char *m = getenv("GINGR_FINE_CULL")) ctx->fine_override = (strcmp(m, "1") == 0) ? 1 : (strcmp(m, "0") == 0 ? 0 : -1);
     void *hp = nullptr, *dp = nullptr;
     if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
         memset(hp, 0, 64);
@@ -124,6 +121,26 @@ int gingr_ctx_synchronize(gingr_ctx *ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GINGR_OK;
+}
+
+int gingr_ctx_set_option(gingr_ctx *ctx, int32_t option, int32_t value) {
+    if (!ctx) return GINGR_ERR_BAD_ARGUMENT;
+    switch (option) {
+        case GINGR_OPT_CULL: ctx->cull = value != 0; return GINGR_OK;
+        case GINGR_OPT_FINE_CULL: ctx->fine_override = value < 0 ? -1 : (value != 0); return GINGR_OK;
+        case GINGR_OPT_NN_GRID: ctx->nn_grid = value != 0; return GINGR_OK;
+        default: return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "ctx_set_option: unknown option %d", option);
+    }
+}
+
+int gingr_ctx_get_option(gingr_ctx *ctx, int32_t option, int32_t *value) {
+    if (!ctx || !value) return GINGR_ERR_BAD_ARGUMENT;
+    switch (option) {
+        case GINGR_OPT_CULL: *value = ctx->cull; return GINGR_OK;
+        case GINGR_OPT_FINE_CULL: *value = ctx->fine_override; return GINGR_OK;
+        case GINGR_OPT_NN_GRID: *value = ctx->nn_grid; return GINGR_OK;
+        default: return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "ctx_get_option: unknown option %d", option);
+    }
 }
 
 int gingr_ctx_timing_enable(gingr_ctx *ctx, int32_t enable) {

@@ -224,36 +224,45 @@ int model_finalize_impl(gingr_ctx *ctx, gingr_model *m) {
     HIP_TRY(ctx, hipMemcpyAsync(&err, flag.p, sizeof(err), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (err) return gingr_set_error(ctx, GINGR_ERR_NOT_SPD, "model finalize: Q^T Q / 1e-5 + I is not positive definite");
-    // constant products of the moment form: C = Binv S_tot / eps, T[d][e] = S[d][e] C
+    // constant products of the moment form (gp.h: cmat, PostVec): C = Binv S_tot / eps, Binv S[d][e], Binv S[d][e] C (work = S[d][e] C)
     const MomentLayout ml{m->rp};
     const int64_t rr = (int64_t)m->rp * m->rp;
     launch_small_gemm(ctx, m->r, m->rp, m->Binv, m->mom + ml.stot(), 1.0 / GINGR_COEFF_NOISE, m->cmat);
     for (int d = 0; d < 3; ++d)
-        for (int e = 0; e < 3; ++e)
-            launch_small_gemm(ctx, m->r, m->rp, m->mom + ml.S(d, e), m->cmat, 1.0, m->cmat + (1 + d * 3 + e) * rr);
+        for (int e = 0; e < 3; ++e) {
+            launch_small_gemm(ctx, m->r, m->rp, m->Binv, m->mom + ml.S(d, e), 1.0, m->cmat + (1 + d * 3 + e) * rr);
+            launch_small_gemm(ctx, m->r, m->rp, m->mom + ml.S(d, e), m->cmat, 1.0, work.as<double>());
+            launch_small_gemm(ctx, m->r, m->rp, m->Binv, work.as<double>(), 1.0, m->cmat + (10 + d * 3 + e) * rr);
+        }
+    // the moment vectors V[d][e], W[d] (contiguous in mom from V(0, 0) on) and Binv times them; then the scalars of the full model
+    const PostVec pvl{m->rp};
+    launch_postvec(ctx, m->r, m->rp, m->Binv, m->mom + ml.V(0, 0), m->pvec);
+    {
+        double cst[16];
+        for (int q = 0; q < 9; ++q) cst[q] = m->Pp[q];
+        for (int q = 0; q < 3; ++q) {
+            cst[9 + q] = m->Ps[q];
+            cst[12 + q] = m->c0[q];
+        }
+        cst[15] = (double)m->M_total;
+        HIP_TRY(ctx, hipMemcpyAsync(m->pvec + pvl.consts(), cst, sizeof(cst), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // cst leaves scope
+    }
     GINGR_TRY(check_launch(ctx));
-    // (the eigen-decomposition of S_tot for the uniform-weight posterior is computed on first use: ensure_model_eig)
-    m->eig_ready = m->eig_failed = false;
+    // The eigen-decomposition S_tot = V diag(lam) V^T for the uniform-weight posterior (point-cloud ICP without landmarks: the
+    // posterior (I + S_tot / sigma2)^-1 rhs is two mat-vecs then).  Decided HERE, once, outside every asynchronous update: S_tot is
+    // the all-reduced moment, bit-identical on every shard, and the one-workgroup Jacobi is deterministic, so all shards of a
+    // sharded model take the same path.  0.6-1.2 ms at rank 100; above rank 256 (tens of ms) the Cholesky path serves.
+    m->eig_ready = false;
+    if (m->r <= 256) {
+        if (launch_jacobi_eig(ctx, m->mom + ml.stot(), m->rp, m->r, m->eigL, m->eigV) == GINGR_OK)
+            m->eig_ready = true;
+        else
+            (void)hipGetLastError();
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     m->finalized = true;
     return GINGR_OK;
-}
-
-// S_tot = V diag(lam) V^T, once per model and only for the flavour that reads it (point-cloud ICP without landmarks: the posterior
-// (I + S_tot / sigma2)^-1 rhs is two mat-vecs then).  Computed on the first such update, not at model creation: CPD-only models,
-// the decimated models of runDecimated and the shards of a group never pay the one-workgroup Jacobi (0.6-1.2 ms at rank 100, 2 r^2
-// doubles of scratch, a stream synchronisation) and cannot fail on its account.  false: not available -- the caller takes the Cholesky path.
-bool ensure_model_eig(gingr_ctx *ctx, const gingr_model *m) {
-    if (m->eig_ready) return true;
-    if (m->eig_failed || m->r > 512) return false;
-    const MomentLayout ml{m->rp};
-    if (launch_jacobi_eig(ctx, m->mom + ml.stot(), m->rp, m->r, m->eigL, m->eigV) != GINGR_OK) {
-        (void)hipGetLastError();
-        m->eig_failed = true;
-        return false;
-    }
-    m->eig_ready = true;
-    return true;
 }
 
 }  // namespace
@@ -305,7 +314,8 @@ int model_create_impl(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doubl
         (rc = dev_alloc(ctx, &m->mean, (size_t)3 * M)) || (rc = dev_alloc(ctx, &m->mom, (size_t)MomentLayout{m->rp}.total())) ||
         (rc = dev_alloc(ctx, &m->Binv, (size_t)m->rp * m->rp)) || (rc = dev_alloc(ctx, &m->eigV, (size_t)m->r * m->r)) ||
         (rc = dev_alloc(ctx, &m->eigL, (size_t)m->r)) ||
-        (rc = dev_alloc(ctx, &m->cmat, (size_t)10 * m->rp * m->rp)))
+        (rc = dev_alloc(ctx, &m->cmat, (size_t)19 * m->rp * m->rp)) ||
+        (rc = dev_alloc(ctx, &m->pvec, (size_t)PostVec{m->rp}.total())))
         return fail(rc);
     if (aos.alloc((size_t)3 * M * sizeof(double)) != hipSuccess)
         return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: out of device memory"));
@@ -421,6 +431,7 @@ void gingr_model_destroy(gingr_model *m) {
     dev_free(m->eigV);
     dev_free(m->eigL);
     dev_free(m->cmat);
+    dev_free(m->pvec);
     dev_free(m->perm);
     delete m;
 }
@@ -461,7 +472,7 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
         (rc = dev_alloc(ctx, &f->state_block, (size_t)rp + kScalarsDoubles + kDevStateDoubles)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
         (rc = dev_alloc(ctx, &f->small, (size_t)8)) || (rc = dev_alloc(ctx, &f->fxbuf[0], (size_t)rp * rp + 2 * rp)) || (rc = dev_alloc(ctx, &f->fxbuf[1], (size_t)rp * rp + 2 * rp)) ||
         (rc = dev_alloc(ctx, &f->alt_seg, (size_t)rp * rp + rp + 8)) || (rc = dev_alloc(ctx, &f->lp_sync, (size_t)2)) ||
-        (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->zbuf, (size_t)19 * rp)) || (rc = dev_alloc(ctx, &f->zrand, (size_t)rp)) ||
+        (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->zbuf, (size_t)PostVec::kZRows * rp)) || (rc = dev_alloc(ctx, &f->zrand, (size_t)rp)) ||
         (rc = dev_alloc(ctx, &f->pose, 1)) ||
         (rc = dev_alloc(ctx, &f->scalars, 8)) || (rc = dev_alloc(ctx, &f->part, GINGR_SCALAR_PART)) || (rc = dev_alloc(ctx, &f->absmax, GINGR_AUX)) || (rc = dev_alloc(ctx, &f->work, (size_t)std::max<int64_t>((int64_t)rp * rp, posterior_work_doubles(rp)))) ||
         (rc = dev_alloc(ctx, &f->lm_mask, (size_t)M))) {
@@ -848,9 +859,8 @@ int gingr_fitter_exchange(gingr_fitter *f, void **dev_ptr, int64_t offsets[GINGR
 // search over the fixed target cloud first (nn_grid.hip), then the tile scan masked to the queries the grid could not certify -- a
 // launch that exits at once when there are none.  warm: idx holds the previous matches of the same queries.
 static void nearest_target_vertex(gingr_ctx *ctx, gingr_fitter *f, Cloud query, Cloud tgt, int32_t *idx, double *d2, bool warm) {
-    static const int grid_env = getenv("GINGR_NN_GRID") ? atoi(getenv("GINGR_NN_GRID")) : 1;
     const int32_t *w = warm ? idx : nullptr;
-    if (grid_env && f->tgrid.ready && ctx->cull && query.n <= f->tgrid.max_queries) {
+    if (ctx->nn_grid && f->tgrid.ready && ctx->cull && query.n <= f->tgrid.max_queries) {
         launch_nn_grid(ctx, query, tgt, f->tperm, f->tgrid, w, idx, d2);
         launch_nn(ctx, query, tgt, f->tperm, f->tboxes, f->ws, idx, d2, idx, f->tgrid.flag, f->tgrid.cur_nflag());
     } else {
@@ -1072,6 +1082,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                     a.state = f->st;
                     a.icp_idx = f->nn_idx;
                     a.tx = tgt.x, a.ty = tgt.y, a.tz = tgt.z;
+                    a.n_targets = tgt.n;
                     a.lm_mask = f->lm_mask;
                     a.weight_out = f->weight, a.evec_out = f->evec;
                     launch_sweep(ctx, SWEEP_RHS_ICP, a);
@@ -1087,9 +1098,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
         case 2: {
             // the posterior mean of the uniform-weight case comes from the model's eigen-decomposition (no factorisation); a sampled
             // proposal needs the Cholesky factor itself (its square root of the covariance is part of the parity contract)
-            static const int eig_env = getenv("GINGR_EIG_SOLVE") ? atoi(getenv("GINGR_EIG_SOLVE")) : 1;
-            const bool eig = eig_env && icp && !f->icp_surface && !f->reversed && f->n_lm == 0 && !f->zrand_active && r <= 512 &&
-                             ensure_model_eig(ctx, m);
+            const bool eig = icp && !f->icp_surface && !f->reversed && f->n_lm == 0 && !f->zrand_active && m->eig_ready;
             if (eig)
                 launch_posterior_solve_eig(ctx, r, rp, m->eigV, m->eigL, &f->st->sigma2, rhs, f->acoef, f->st);
             else
@@ -1099,8 +1108,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
             memset(&a, 0, sizeof(a));
             a.r = r;
             a.rp = rp;
-            a.mom = m->mom;
-            a.Binv = m->Binv;
+            a.pvec = m->pvec;
             a.zbuf = f->zbuf;
             a.alpha = f->alpha;
             a.scalars = sc8;
@@ -1111,12 +1119,6 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
             }
             a.step = f->step_length;
             a.global_transform = f->global_transform;
-            a.n_total = (double)m->M_total;
-            for (int q = 0; q < 3; ++q) {
-                a.c0[q] = m->c0[q];
-                a.Ps[q] = m->Ps[q];
-            }
-            for (int q = 0; q < 9; ++q) a.Pp[q] = m->Pp[q];
             a.state = f->st;
             a.retry = f->retry;
             a.probabilistic = f->zrand_active ? 1 : 0;

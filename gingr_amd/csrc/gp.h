@@ -50,6 +50,27 @@ struct MomentLayout {
     __host__ __device__ int64_t total() const { return (int64_t)rp * rp * 10 + (int64_t)rp * 12; }
 };
 
+// What the post-solve kernel reads besides the state (gp.hip: post_solve_kernel).  Binv = (S_tot / eps + I)^-1 is applied to every
+// term of the second coefficient projection up front -- to the constant moment vectors once per model (pvec), to S[d][e] alpha and
+// S[d][e] alpha_1 by the mat-vec launch (zbuf) -- so that the kernel itself touches no r x r matrix.
+struct PostVec {
+    int32_t rp;
+    // vectors of gingr_model::pvec (entry-major: entry i of vector v at pvec[i * kRows + v]; then 16 scalars)
+    static constexpr int kV = 0;    // [9]  V[d][e]
+    static constexpr int kW = 9;    // [3]  W[d]
+    static constexpr int kBV = 12;  // [9]  Binv V[d][e]
+    static constexpr int kBW = 21;  // [3]  Binv W[d]
+    static constexpr int kRows = 24;
+    __host__ __device__ int64_t consts() const { return (int64_t)kRows * rp; }  // Pp[9] = sum p~ p~^T, Ps[3] = sum p~, c0[3], n = M_total
+    __host__ __device__ int64_t total() const { return consts() + 16; }
+    // vectors of the fitter's zbuf (entry-major [rp][28], written by launch_post_matvecs)
+    static constexpr int kZa = 0;    // [9]  S[d][e] alpha
+    static constexpr int kBSa = 9;   // [9]  (Binv S[d][e]) alpha
+    static constexpr int kBTa = 18;  // [9]  (Binv S[d][e] C) a
+    static constexpr int kA1 = 27;   //      alpha_1 = C a
+    static constexpr int kZRows = 28;
+};
+
 struct gingr_model {
     gingr_ctx *ctx = nullptr;
     int64_t M_total = 0, row_begin = 0, row_end = 0, M = 0;  // M = local points
@@ -64,10 +85,11 @@ struct gingr_model {
     std::vector<int32_t> hperm, hiperm;  // host copies: device position -> original, original -> device position
     double *Binv = nullptr;   // [rp*rp] (S_tot/eps + I)^-1, valid after finalize
     double *eigV = nullptr;   // [r*r] eigenvectors of S_tot = Q^T Q (column k, row stride r) and
-    double *eigL = nullptr;   // [r] its eigenvalues (descending): uniform-weight posterior (launch_posterior_solve_eig); filled on first use
-    mutable bool eig_ready = false, eig_failed = false;  // fitter.hip: ensure_model_eig
-    double *cmat = nullptr;   // [10][rp*rp], valid after finalize: [0] C = Binv S_tot / eps (alpha_1 = C a),
-                              // [1 + 3d + e] T[d][e] = S[d][e] C  (S[d][e] alpha_1 = T[d][e] a)
+    double *eigL = nullptr;   // [r] its eigenvalues (descending): uniform-weight posterior (launch_posterior_solve_eig); rank <= 256
+    bool eig_ready = false;  // decided once by model_finalize_impl (fitter.hip), identically on every shard
+    double *cmat = nullptr;   // [19][rp*rp], valid after finalize: [0] C = Binv S_tot / eps (alpha_1 = C a),
+                              // [1 + 3d + e] Binv S[d][e], [10 + 3d + e] Binv S[d][e] C  (Binv S[d][e] alpha_1 = (Binv S[d][e] C) a)
+    double *pvec = nullptr;   // PostVec: the r-vectors and scalars the post-solve kernel reads, valid after finalize
     double c0[3] = {0, 0, 0};  // centroid of the FULL reference: fixed centring point of the Umeyama sums
     double Pp[9] = {0};        // sum_i p~_i p~_i^T over the FULL model (host, identical on every shard)
     double Ps[3] = {0};        // sum_i p~_i
@@ -118,9 +140,12 @@ struct SweepArgs {
     double *out;           // reduced result: [rp] or [24]
     double *zero_slot;     // nullable: one double the pass clears (consumed by a LATER launch on the stream)
     int32_t no_reduce;     // != 0: leave the [nblocks][rp] partials in `partial` (the phase-1 finalize kernel adds them up)
-    // SWEEP_RHS_ICP: matched target positions, the target planes, the landmark mask (nullable); weight / e are also written out
+    // SWEEP_RHS_ICP: matched target positions, the target planes (n_targets points), the landmark mask (nullable); weight / e are
+    // also written out.  A position outside [0, n_targets) -- the searches leave -1 for a query whose distances are all NaN -- gives
+    // a NaN observation (the posterior then fails through the normal status path) instead of a read outside the target allocation.
     const int32_t *icp_idx;
     const double *tx, *ty, *tz;
+    int64_t n_targets;
     const int32_t *lm_mask;
     double *weight_out, *evec_out;
 };
@@ -209,27 +234,26 @@ void launch_centered_mean(gingr_ctx *ctx, const gingr_model *m, double *ptil);
 // alpha', state commit / failure status, sigma2 update (GingrAlgorithm.scala:212-246).
 struct PostSolveArgs {
     int32_t r, rp;
-    const double *mom;
-    const double *Binv;
-    const double *zbuf;     // [19][rp] from launch_post_matvecs: [0..8] S[d][e] alpha, [9..17] T[d][e] a, [18] alpha_1 = C a
+    const double *pvec;     // gingr_model::pvec (PostVec)
+    const double *zbuf;     // [rp][28] from launch_post_matvecs (PostVec::kZa ...)
     double *alpha;          // in/out: shape coefficients of the state
     const double *scalars;  // reduced {Np, xPx, trPXY, yPy, ...} (CPD) or nullptr
     int32_t is_icp;
     double icp_step, icp_end;
     double step;
     int32_t global_transform;
-    double n_total;
-    double c0[3], Pp[9], Ps[3];
     DevState *state;
     int32_t *retry;         // retryCounter of the algorithm instance (GingrAlgorithm.scala:69-70), device word; nullable
     int32_t probabilistic;  // update(current, probabilistic = true)
 };
 #define GINGR_RETRY_INIT 10 /* retryCounterInitialize, GingrAlgorithm.scala:69 */
 void launch_post_solve(gingr_ctx *ctx, const PostSolveArgs &a);
-// the 19 independent r x r mat-vecs the fused kernel consumes, one workgroup each (they only depend on alpha and a)
+// the 28 independent r x r mat-vecs the post-solve kernel consumes (they only depend on alpha and a); zbuf: [rp][PostVec::kZRows]
 void launch_post_matvecs(gingr_ctx *ctx, const gingr_model *m, const double *alpha, const double *a, double *zbuf);
 // out = scale * A B (r x r, leading dimension rp); one-off products at model finalisation
 void launch_small_gemm(gingr_ctx *ctx, int32_t r, int32_t rp, const double *A, const double *B, double scale, double *out);
+// the vector part of the model's PostVec block from the 12 moment vectors V[d][e], W[d] ([12][rp]); one-off at model finalisation
+void launch_postvec(gingr_ctx *ctx, int32_t r, int32_t rp, const double *Binv, const double *moment_vectors, double *pvec);
 
 // basis packing: stage is column-major [r][3M] (local rows, ORIGINAL order), out Q0 [3M][rp] in device (perm) order
 void launch_pack_basis(gingr_ctx *ctx, const double *stage_colmajor, const double *variance_dev, int64_t M, int32_t r,

@@ -160,7 +160,10 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepArgs a) {
             // the observation of obs_points_kernel (ICP branch), formed here: one launch and one round trip of e less per iteration.
             // Same expressions, so the same e; weight and e are still written out for whoever reads them later.
             const int32_t j = a.icp_idx[pc];
-            const double ox = a.tx[j], oy = a.ty[j], oz = a.tz[j];
+            const bool inside = j >= 0 && (int64_t)j < a.n_targets;  // -1: no finite distance (non-finite fit)
+            const int32_t jc = inside ? j : 0;
+            const double nanv = __builtin_nan("");
+            const double ox = inside ? a.tx[jc] : nanv, oy = inside ? a.ty[jc] : nanv, oz = inside ? a.tz[jc] : nanv;
             const double w = 1.0 / a.state->sigma2;
             const bool off = (a.lm_mask && a.lm_mask[pc]) || w == 0.0;
             const double dx = ox - cen[0] - tr[0], dy = oy - cen[1] - tr[1], dz = oz - cen[2] - tr[2];
@@ -808,9 +811,13 @@ __global__ void obs_points_kernel(const double *__restrict__ ref, const double *
     double ox, oy, oz;
     if (idx) {  // ICP: closest target point, cov = I3 * sigma2 (ICP.scala:90-92)
         const int32_t j = idx[i];
-        ox = target.x[j];
-        oy = target.y[j];
-        oz = target.z[j];
+        if (j >= 0 && (int64_t)j < target.n) {
+            ox = target.x[j];
+            oy = target.y[j];
+            oz = target.z[j];
+        } else {  // the searches leave -1 when no distance is finite: a NaN observation fails the posterior through the status path
+            ox = oy = oz = __builtin_nan("");
+        }
         w = 1.0 / st->sigma2;
     } else {
         ox = obs[i];
@@ -1628,102 +1635,7 @@ __global__ __launch_bounds__(256) void coeff_solve_kernel(int r, int rp, const d
     if (i < rp && lane16 == 0) out[i] = i < r ? v : 0.0;
 }
 
-// sums: [0..2] sum x~, [3..5] sum y~, [6..14] sum y~ x~^T (row-major), [15] sum |x~|^2; x~ = x - c0, y~ = y - c0.
-// Returns false when the result is not finite.
-// WAVE: the whole wave runs this with the same arguments (svd3.h: *_wave conversions)
-template <bool WAVE = false>
-__device__ bool umeyama_from_sums(const double *sums, double n, const double c0[3], int global_transform, DevPose &P) {
-    if (global_transform == GINGR_NO_TRANSFORMS) {  // identityTransformation, GingrAlgorithm.scala:230
-        for (int q = 0; q < 9; ++q) P.R[q] = (q % 4 == 0) ? 1.0 : 0.0;
-        P.euler[0] = P.euler[1] = P.euler[2] = 0.0;
-        P.t[0] = P.t[1] = P.t[2] = 0.0;
-        P.center[0] = P.center[1] = P.center[2] = 0.0;
-        P.scale = 1.0;
-        return true;
-    }
-    double mux[3], muy[3];
-    for (int a = 0; a < 3; ++a) {
-        mux[a] = sums[a] / n;
-        muy[a] = sums[3 + a] / n;
-    }
-    double Sxy[9];
-    for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) Sxy[a * 3 + b] = sums[6 + a * 3 + b] / n - muy[a] * mux[b];
-    const double sig2x = sums[15] / n - (mux[0] * mux[0] + mux[1] * mux[1] + mux[2] * mux[2]);
-    // R = U diag(1, 1, sign det) V^T and, for similarity transforms, c = (d1 + d2 + sign d3) / var_x.  With det > 0 (every
-    // non-degenerate registration) R is the polar factor of Sxy and d1 + d2 + d3 = trace(R^T Sxy): no SVD (svd3.h)
-    double R[9], trace_ds = 0.0;
-    if (!polar3_rotation(Sxy, R, &trace_ds)) {
-        double U[9], D[3], V[9];
-        svd3(Sxy, U, D, V);
-        const double det = Sxy[0] * (Sxy[4] * Sxy[8] - Sxy[5] * Sxy[7]) - Sxy[1] * (Sxy[3] * Sxy[8] - Sxy[5] * Sxy[6]) +
-                           Sxy[2] * (Sxy[3] * Sxy[7] - Sxy[4] * Sxy[6]);
-        const double s3 = det < 0 ? -1.0 : 1.0;
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) R[a * 3 + b] = U[a * 3] * V[b * 3] + U[a * 3 + 1] * V[b * 3 + 1] + s3 * U[a * 3 + 2] * V[b * 3 + 2];
-        trace_ds = D[0] + D[1] + s3 * D[2];
-    }
-    const double c = (global_transform == GINGR_SIMILARITY_TRANSFORMS) ? trace_ds / sig2x : 1.0;
-    // t = mu_y - c R mu_x in absolute coordinates (rotation about the origin)
-    double mxa[3], mya[3];
-    for (int a = 0; a < 3; ++a) {
-        mxa[a] = mux[a] + c0[a];
-        mya[a] = muy[a] + c0[a];
-    }
-    for (int a = 0; a < 3; ++a) P.t[a] = mya[a] - c * (R[a * 3] * mxa[0] + R[a * 3 + 1] * mxa[1] + R[a * 3 + 2] * mxa[2]);
-    // the registration result carries its rotation as Euler angles (rigid3DLandmarkRegistration builds Rotation3D)
-    if (WAVE) {
-        rot_to_euler_wave(R, P.euler);
-        euler_to_rot_wave(P.euler, P.R);
-    } else {
-        rot_to_euler(R, P.euler);
-        euler_to_rot(P.euler, P.R);
-    }
-    P.center[0] = P.center[1] = P.center[2] = 0.0;  // estimate*Transform(..., Point(0,0,0))
-    P.scale = c;
-    bool fin = finite_d(c);
-    for (int q = 0; q < 9; ++q) fin = fin && finite_d(P.R[q]);
-    for (int q = 0; q < 3; ++q) fin = fin && finite_d(P.t[q]);
-    return fin;
-}
-
-
 // ------------------------------------------------------------------------------------------------- fused post-solve
-// out[k] = sum_j Mat[j*rp + k] * x[j]   (i.e. Mat^T x; pass the transposed partner for a non-symmetric matrix).
-// All threads of the workgroup take part: `parts` row strips are accumulated in parallel and combined in a fixed order.
-__device__ void block_matvec_T(const double *__restrict__ Mat, const double *x, double *out, int r, int rp, double *scratch) {
-    const int nt = blockDim.x;
-    int width = 16;
-    while (width < rp) width <<= 1;
-    const int parts = nt / width > 0 ? nt / width : 1;
-    const int k = threadIdx.x % width, part = threadIdx.x / width;
-    double s = 0.0;
-    if (part < parts && k < rp)
-        for (int j = part; j < r; j += parts) s = __builtin_fma(Mat[(int64_t)j * rp + k], x[j], s);
-    __syncthreads();
-    if (part < parts && k < rp) scratch[part * rp + k] = s;
-    __syncthreads();
-    for (int kk = threadIdx.x; kk < rp; kk += nt) {
-        double t = 0.0;
-        for (int p = 0; p < parts; ++p) t += scratch[p * rp + kk];
-        out[kk] = t;
-    }
-    __syncthreads();
-}
-
-// dot of two LDS vectors by one wave; every lane returns the result
-__device__ __forceinline__ double wave_dot(const double *x, const double *y, int r) {
-    double s = 0.0;
-    for (int k = threadIdx.x & 63; k < r; k += 64) s = __builtin_fma(x[k], y[k], s);
-    s += __shfl_xor(s, 32);
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 8);
-    s += __shfl_xor(s, 4);
-    s += __shfl_xor(s, 2);
-    s += __shfl_xor(s, 1);
-    return s;
-}
-
 // one-off r x r products at finalisation
 __global__ void small_gemm_kernel(int r, int rp, const double *__restrict__ A, const double *__restrict__ B, double scale,
                                   double *__restrict__ out) {
@@ -1736,16 +1648,33 @@ __global__ void small_gemm_kernel(int r, int rp, const double *__restrict__ A, c
     out[idx] = s * scale;
 }
 
-// zbuf[b] = M_b x_b, b = blockIdx.x: b < 9: S[d][e] alpha; 9 <= b < 18: T[d][e] a; b == 18: C a.  blockIdx.y picks a strip of
-// 16 output rows, 16 lanes per row; a lane's (up to 8) matrix elements are all requested before the first FMA -- the matrices
-// live in L2 and a dependent load-FMA chain costs one round trip per element.
+// one-off, the model's PostVec block (column-major for the post-solve kernel: entry i of vector v at pvec[i * kRows + v]):
+// v = blockIdx.x < 12: the moment vector in[v] itself (V[d][e], W[d]); v >= 12: Binv in[v - 12]
+__global__ __launch_bounds__(256) void postvec_kernel(int r, int rp, const double *__restrict__ Binv, const double *__restrict__ in,
+                                                      double *__restrict__ pvec) {
+    const int v = blockIdx.x;
+    const double *x = in + (int64_t)(v % 12) * rp;
+    for (int i = threadIdx.x; i < rp; i += 256) {
+        double s = 0.0;
+        if (v < 12)
+            s = x[i];
+        else if (i < r)
+            for (int j = 0; j < r; ++j) s = __builtin_fma(Binv[(int64_t)i * rp + j], x[j], s);
+        pvec[(int64_t)i * PostVec::kRows + v] = s;
+    }
+}
+
+// zbuf[b] = M_b x_b, b = blockIdx.x (PostVec layout: gp.h): b < 9: S[d][e] alpha; 9 <= b < 18: (Binv S[d][e]) alpha; 18 <= b < 27:
+// (Binv S[d][e] C) a; b == 27: C a.  blockIdx.y picks a strip of 16 output rows, 16 lanes per row; a lane's (up to 32) matrix
+// elements are all requested before the first FMA -- the matrices live in L2 / the Infinity Cache and a dependent load-FMA chain
+// costs one round trip per element.
 __global__ __launch_bounds__(256) void post_matvecs_kernel(int r, int rp, const double *__restrict__ mom,
                                                            const double *__restrict__ cmat, const double *__restrict__ alpha,
                                                            const double *__restrict__ a, double *__restrict__ zbuf) {
     const int b = blockIdx.x;
     const MomentLayout ml{rp};
-    const double *Mat = b < 9 ? mom + ml.S(b / 3, b % 3) : (b < 18 ? cmat + (int64_t)(1 + (b - 9)) * rp * rp : cmat);
-    const double *src = b < 9 ? alpha : a;
+    const double *Mat = b < 9 ? mom + ml.S(b / 3, b % 3) : (b < 27 ? cmat + (int64_t)(b - 8) * rp * rp : cmat);
+    const double *src = b < 18 ? alpha : a;
     const int lane16 = threadIdx.x & 15;
     const int i = blockIdx.y * 16 + (threadIdx.x >> 4);  // < rp (the grid covers rp / 16 strips)
     const double *row = Mat + (int64_t)i * rp;
@@ -1762,55 +1691,27 @@ __global__ __launch_bounds__(256) void post_matvecs_kernel(int r, int rp, const 
     for (int jj = 0; jj < 32; ++jj)
         if (jj < nj) s = __builtin_fma(m[jj], x[jj], s);
     s = group16_sum(s);
-    if (lane16 == 0) zbuf[(int64_t)b * rp + i] = i < r ? s : 0.0;
+    if (lane16 == 0) zbuf[(int64_t)i * PostVec::kZRows + b] = i < r ? s : 0.0;  // column-major: entry i of all 28 vectors is contiguous
 }
 
-// The one-thread part of the post-solve: Umeyama between the current shape and the blended posterior mean from the 36 dot
-// products (moment form), then the 3x3 quantities of the second projection.  dots: [0..2] W[d].alpha, [3..5] W[d].alpha_c,
-// [6..14] V[b][d].alpha (index d*3+b), [15..23] V[d][b].alpha_c, [24..32] alpha_c.za[d][b], [33..35] alpha.za[d][d].
-__device__ void post_pose_step(const PostSolveArgs &A, const DevState *st, const double *dots, DevPose &P, double *Bm, double *BmI,
-                               double *hv, int *bad) {
-    // u~_i = p~_i + Q0_i alpha (current shape, unposed), v~_i = p~_i + Q0_i alpha_c, newshape - c0 = R v~_i + g~
-    const double *R = st->R;
-    double su[3], sv[3], Mvu[9], gt[3], sums[16];
-    for (int d = 0; d < 3; ++d) {
-        su[d] = A.Ps[d] + dots[d];
-        sv[d] = A.Ps[d] + dots[3 + d];
-    }
-    for (int d = 0; d < 3; ++d)
-        for (int b = 0; b < 3; ++b) Mvu[d * 3 + b] = A.Pp[d * 3 + b] + dots[6 + d * 3 + b] + dots[15 + d * 3 + b] + dots[24 + d * 3 + b];
-    for (int a = 0; a < 3; ++a) {
-        const double q0 = A.c0[0] - st->center[0], q1 = A.c0[1] - st->center[1], q2 = A.c0[2] - st->center[2];
-        gt[a] = R[a * 3] * q0 + R[a * 3 + 1] * q1 + R[a * 3 + 2] * q2 + st->center[a] + st->t[a] - A.c0[a];
-    }
-    for (int a = 0; a < 3; ++a) {
-        sums[a] = su[a];
-        sums[3 + a] = R[a * 3] * sv[0] + R[a * 3 + 1] * sv[1] + R[a * 3 + 2] * sv[2] + A.n_total * gt[a];
-        for (int b = 0; b < 3; ++b)
-            sums[6 + a * 3 + b] = R[a * 3] * Mvu[b] + R[a * 3 + 1] * Mvu[3 + b] + R[a * 3 + 2] * Mvu[6 + b] + gt[a] * su[b];
-    }
-    sums[15] = 0.0;
-    for (int d = 0; d < 3; ++d) sums[15] += A.Pp[d * 3 + d] + 2.0 * dots[6 + d * 3 + d] + dots[33 + d];
-    DevPose Pl;
-    const bool fin = umeyama_from_sums<true>(sums, A.n_total, A.c0, A.global_transform, Pl);  // (called by a whole wave)
-    if (!fin) *bad = 1;
-    P = Pl;
-    // e_i = R2^T (newshape_i - t2) - p_i = (B - I) p~_i + B Q0_i alpha_c + h,  B = R2^T R
-    for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) {
-            const double v = Pl.R[a] * R[b] + Pl.R[3 + a] * R[3 + b] + Pl.R[6 + a] * R[6 + b];
-            Bm[a * 3 + b] = v;
-            BmI[a * 3 + b] = v - (a == b ? 1.0 : 0.0);
-        }
-    double w3[3];
-    for (int a = 0; a < 3; ++a) w3[a] = gt[a] + A.c0[a] - Pl.t[a];
-    for (int a = 0; a < 3; ++a) {
-        const double rt = Pl.R[a] * w3[0] + Pl.R[3 + a] * w3[1] + Pl.R[6 + a] * w3[2];
-        hv[a] = rt - A.c0[a];  // h = R2^T (g~ + c0 - t2) - c0   (p_i = p~_i + c0)
-    }
-}
-
-// The one-thread commit of an update (alpha itself is written by all threads when !failed).
+// ---- post-solve: everything of GingrAlgorithm.update after the posterior coefficients (GingrAlgorithm.scala:212-246) in one small
+// workgroup.  Round 4 rebuilt it around one measured fact (profiles/r03_exp_post_solve_code_touch.txt): run behind the long all-pairs
+// kernels the round-3 kernel took 16-18 us against 6-9 us with warm caches -- it waited for its own CODE (20 KB of run-once
+// straight-line float64 code through a cold instruction cache), not for its data.  So this version is built to EXECUTE few bytes:
+//   * the second coefficient projection alpha' = Binv proj / eps is linear in the 3 x 3 pose quantities, proj = sum (B - I)_de V[d][e]
+//     + sum B_de S[d][e] alpha_c + sum h_d W[d], so Binv is applied BEFORE the pose is known: Binv V / Binv W once per model
+//     (gingr_model::pvec), (Binv S[d][e]) alpha and (Binv S[d][e] C) a by the mat-vec launch in front of this kernel.  No r x r matrix is
+//     read here (round 3 copied the 100 KB of Binv through LDS and ran a mat-vec on it), one variant serves every rank <= 512;
+//   * thread k keeps entry k of all 52 input vectors in registers: zbuf and pvec are stored entry-major ([rp][28], [rp][24]), so a
+//     thread reads two contiguous runs with 16-byte loads at immediate offsets, all in flight at once; the 36 dot products of the
+//     Umeyama sums are 36 multiplies per thread and ONE transposed reduction through LDS ([rp][37] products, 144 threads add a
+//     quarter of a column each, fixed order) instead of 36 wave reductions;
+//   * the 3 x 3 algebra of the pose step runs with one matrix entry per lane (a 3 x 3 product is three multiply-adds per lane, the
+//     16 divisions by n are one division in 16 lanes) instead of every lane repeating all of it; the polar iteration and the
+//     Euler round trip (svd3.h; the reference rebuilds R from the stored angles, so it cannot be dropped) are as before;
+//   * the state is committed by 20 lanes from a staged copy instead of ~40 scalar stores of one thread.
+// 16.5 KB + 3.9 KB of callees (1 024 threads, 138 KB of LDS)  ->  see tools/kernel_resources.sh / DESIGN.md section 4 for the figures.
+//
 // Failure semantics of GingrAlgorithm.update (G/api/GingrAlgorithm.scala:192-254):
 //   posterior failed (Try of computePosterior, here: the solve flagged st->err)
 //       iteration 0                      -> state unchanged                                          (:206-208)
@@ -1821,233 +1722,236 @@ __device__ void post_pose_step(const PostSolveArgs &A, const DevState *st, const
 //       a coefficients() projection (or the alignment between them) failed -> ModelFlexibilityError at ANY iteration
 //                                                                                                     (:248-251)
 // Non-finite values count as failures: in the reference they make Breeze's SVD throw inside the Try.
-__device__ void post_commit_step(const PostSolveArgs &A, DevState *st, const DevPose &P, bool posterior_failed, bool bad) {
-    const bool failed = posterior_failed || bad;
-    if (posterior_failed) {
-        if (st->iteration > 0) {
-            if (A.probabilistic && A.retry && *A.retry > 0)
-                *A.retry -= 1;
-            else
-                st->status = GINGR_FIT_MODEL_FLEXIBILITY_ERROR;
-        }
-    } else {
-        if (A.retry) *A.retry = *A.retry + 1 < GINGR_RETRY_INIT ? *A.retry + 1 : GINGR_RETRY_INIT;
-        if (bad) st->status = GINGR_FIT_MODEL_FLEXIBILITY_ERROR;
+
+// scratch of the pose step (doubles in LDS)
+struct PoseLds {
+    double D[36];     // the dot products: [0..2] W[d].alpha, [3..5] W[d].alpha_c, [6..14] V[b][d].alpha (index d*3+b),
+                      // [15..23] V[d][b].alpha_c, [24..32] alpha_c.za[d][b], [33..35] alpha.za[d][d]
+    double R[9];      // rotation of the current state
+    double su[3], sv[3], gt[3], q[3];
+    double Mvu[9];
+    double sums[16];  // [0..2] sum x~, [3..5] sum y~, [6..14] sum y~ x~^T (row-major), [15] sum |x~|^2; x~ = x - c0, y~ = y - c0
+    double qn[16];    // sums / n
+    double Sxy[9];
+    double R2[9];
+    double coef[21];  // (B - I)[9], B[9], h[3]: the 3 x 3 quantities of the second projection, B = R2^T R
+    double stage[20]; // the committed DevState: R[9], euler[3], center[3], t[3], scale, sigma2
+};
+
+// One wave: Umeyama between the current shape u~_i = p~_i + Q0_i alpha (unposed) and the blended posterior mean
+// newshape - c0 = R v~_i + g~, v~_i = p~_i + Q0_i alpha_c, from the 36 dot products (moment form), then the 3 x 3 quantities of the
+// second projection e_i = R2^T (newshape_i - t2) - p_i = (B - I) p~_i + B Q0_i alpha_c + h.  Lane l < 9 owns matrix entry (l / 3, l % 3).
+// cst (device): Pp[9] = sum p~ p~^T, Ps[3] = sum p~, c0[3], n  (PostVec::consts)
+__device__ void post_pose_step(const PostSolveArgs &A, const DevState *st, const double *__restrict__ cst, PoseLds &L, int *bad) {
+    const int l = threadIdx.x & 63;
+    const int l9 = l < 9 ? l : 8, a = l9 / 3, b = l9 - 3 * a, l3 = l < 3 ? l : 2;
+    const double Ppl = cst[l9], Psl = cst[9 + l3], c0l = cst[12 + l3], n = cst[15];
+    const double Rl = st->R[l9], cenl = st->center[l3], tl = st->t[l3];
+    if (l < 9) {
+        L.R[l] = Rl;
+        L.Mvu[l] = Ppl + L.D[6 + l] + L.D[15 + l] + L.D[24 + l];
     }
-    if (!failed) {
-        for (int q = 0; q < 9; ++q) st->R[q] = P.R[q];
+    if (l < 3) {
+        L.su[l] = Psl + L.D[l];
+        L.sv[l] = Psl + L.D[3 + l];
+        L.q[l] = c0l - cenl;
+    }
+    double s15 = 0.0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) s15 += cst[4 * d] + 2.0 * L.D[6 + 4 * d] + L.D[33 + d];
+    __builtin_amdgcn_wave_barrier();
+    if (l < 3) L.gt[l] = L.R[3 * l] * L.q[0] + L.R[3 * l + 1] * L.q[1] + L.R[3 * l + 2] * L.q[2] + cenl + tl - c0l;
+    __builtin_amdgcn_wave_barrier();
+    if (l < 3) {
+        L.sums[l] = L.su[l];
+        L.sums[3 + l] = L.R[3 * l] * L.sv[0] + L.R[3 * l + 1] * L.sv[1] + L.R[3 * l + 2] * L.sv[2] + n * L.gt[l];
+    }
+    if (l < 9) L.sums[6 + l] = L.R[3 * a] * L.Mvu[b] + L.R[3 * a + 1] * L.Mvu[3 + b] + L.R[3 * a + 2] * L.Mvu[6 + b] + L.gt[a] * L.su[b];
+    if (l == 15) L.sums[15] = s15;
+    __builtin_amdgcn_wave_barrier();
+    double R2[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, eul[3] = {0, 0, 0}, t2[3] = {0, 0, 0}, c = 1.0;
+    const double c0[3] = {cst[12], cst[13], cst[14]};
+    bool fin = true;
+    if (A.global_transform != GINGR_NO_TRANSFORMS) {  // (identityTransformation otherwise, GingrAlgorithm.scala:230)
+        L.qn[l & 15] = L.sums[l & 15] / n;  // mu_x, mu_y, the second moments and the variance term: one division in 16 lanes
+        __builtin_amdgcn_wave_barrier();
+        if (l < 9) L.Sxy[l] = L.qn[6 + l] - L.qn[3 + a] * L.qn[b];
+        const double mux[3] = {L.qn[0], L.qn[1], L.qn[2]}, muy[3] = {L.qn[3], L.qn[4], L.qn[5]};
+        const double sig2x = L.qn[15] - (mux[0] * mux[0] + mux[1] * mux[1] + mux[2] * mux[2]);
+        __builtin_amdgcn_wave_barrier();
+        double S[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) S[q] = L.Sxy[q];
+        // R = U diag(1, 1, sign det) V^T and, for similarity transforms, c = (d1 + d2 + sign d3) / var_x.  With det > 0 (every
+        // non-degenerate registration) R is the polar factor of Sxy and d1 + d2 + d3 = trace(R^T Sxy): no SVD (svd3.h)
+        double Rr[9], trace_ds = 0.0;
+        if (!polar3_rotation(S, Rr, &trace_ds)) {
+            double U[9], Dg[3], V[9];
+            svd3(S, U, Dg, V);
+            const double det = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+            const double s3 = det < 0 ? -1.0 : 1.0;
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) Rr[i * 3 + j] = U[i * 3] * V[j * 3] + U[i * 3 + 1] * V[j * 3 + 1] + s3 * U[i * 3 + 2] * V[j * 3 + 2];
+            trace_ds = Dg[0] + Dg[1] + s3 * Dg[2];
+        }
+        c = (A.global_transform == GINGR_SIMILARITY_TRANSFORMS) ? trace_ds / sig2x : 1.0;
+        // t = mu_y - c R mu_x in absolute coordinates (rotation about the origin)
+        double mxa[3], mya[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            mxa[i] = mux[i] + c0[i];
+            mya[i] = muy[i] + c0[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t2[i] = mya[i] - c * (Rr[i * 3] * mxa[0] + Rr[i * 3 + 1] * mxa[1] + Rr[i * 3 + 2] * mxa[2]);
+        // the registration result carries its rotation as Euler angles (rigid3DLandmarkRegistration builds Rotation3D)
+        rot_to_euler_wave(Rr, eul);
+        euler_to_rot_wave(eul, R2);
+        fin = finite_d(c);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) fin = fin && finite_d(R2[q]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fin = fin && finite_d(t2[q]);
+    }
+    if (l == 0) {
+        if (!fin) *bad = 1;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            L.R2[q] = R2[q];
+            L.stage[q] = R2[q];
+        }
+#pragma unroll
         for (int q = 0; q < 3; ++q) {
-            st->euler[q] = P.euler[q];
-            st->center[q] = 0.0;  // Umeyama about Point(0,0,0), GingrAlgorithm.scala:81,266
-            st->t[q] = P.t[q];
+            L.stage[9 + q] = eul[q];
+            L.stage[12 + q] = 0.0;  // Umeyama about Point(0,0,0), GingrAlgorithm.scala:81,266
+            L.stage[15 + q] = t2[q];
         }
-        st->scale = P.scale;
+        L.stage[18] = c;
         if (A.is_icp) {
-            const double ns = st->sigma2 - A.icp_step;       // ICP.scala:96-99
-            st->sigma2 = ns > A.icp_end ? ns : A.icp_end;
+            const double ns = st->sigma2 - A.icp_step;  // ICP.scala:96-99
+            L.stage[19] = ns > A.icp_end ? ns : A.icp_end;
         } else {
-            const double *sc = A.scalars;                    // CPD.scala:142-145
-            st->sigma2 = (sc[1] - 2 * sc[2] + sc[3]) / (sc[0] * 3.0);
+            const double *sc = A.scalars;  // CPD.scala:142-145
+            L.stage[19] = (sc[1] - 2 * sc[2] + sc[3]) / (sc[0] * 3.0);
         }
     }
-    st->pad = failed ? (st->err != 0 ? st->err : GINGR_ERR_NONFINITE) : 0;  // last error, readable by the host
-    st->err = 0;
-    st->iteration += 1;  // GingrGeneratorWrapper.propose: updateIteration()
-}
-
-constexpr int kPostThreads = 1024;
-
-// out[k] = sum_j Mat[j*rp + k] * x[j] with Mat, x and out in LDS (block_matvec_T for LDS-resident operands)
-__device__ __forceinline__ void lds_matvec_T(const double *Mat, const double *x, double *out, int r, int rp, double *scratch) {
-    int width = 16;
-    while (width < rp) width <<= 1;
-    const int parts = kPostThreads / width > 0 ? kPostThreads / width : 1;
-    const int k = threadIdx.x % width, part = threadIdx.x / width;
-    double s = 0.0;
-    if (part < parts && k < rp)
-        for (int j = part; j < r; j += parts) s = __builtin_fma(Mat[j * rp + k], x[j], s);
-    if (part < parts && k < rp) scratch[part * rp + k] = s;
-    __syncthreads();
-    for (int kk = threadIdx.x; kk < rp; kk += kPostThreads) {
-        double t = 0.0;
-        for (int p = 0; p < parts; ++p) t += scratch[p * rp + kk];
-        out[kk] = t;
+    __builtin_amdgcn_wave_barrier();
+    // B = R2^T R, h = R2^T (g~ + c0 - t2) - c0   (p_i = p~_i + c0)
+    if (l < 9) {
+        const double v = L.R2[a] * L.R[b] + L.R2[3 + a] * L.R[3 + b] + L.R2[6 + a] * L.R[6 + b];
+        L.coef[l] = v - (a == b ? 1.0 : 0.0);
+        L.coef[9 + l] = v;
     }
-    __syncthreads();
+    if (l < 3) {
+        const double w0 = L.gt[0] + c0[0] - t2[0], w1 = L.gt[1] + c0[1] - t2[1], w2 = L.gt[2] + c0[2] - t2[2];
+        L.coef[18 + l] = (L.R2[l] * w0 + L.R2[3 + l] * w1 + L.R2[6 + l] * w2) - c0l;
+    }
 }
 
-// Everything after the 19 mat-vecs in one workgroup.  The kernel starts behind a kernel boundary with cold caches (at 50k points the
-// all-pairs passes and the basis sweeps have pushed Binv and the moment vectors out of L2 and out of the Infinity Cache), and a lone
-// workgroup pays the full memory latency for every DEPENDENT batch of loads: the round-2 version read Binv inside the mat-vec loop
-// (13 batches) and the moment vectors inside the dot products (6 batches).  Here every global operand is requested in the first
-// instructions (PRELOAD: Binv too, 12 loads per thread), lands in LDS after ONE round trip, and the arithmetic runs on LDS alone.
-// PRELOAD = false (rp > 112: Binv does not fit beside the vectors): Binv stays in global memory as before.
-// (Measured: the kernel stays at ~18 us at 50k points against 6 us at femur size -- what it waits for is not its data but its CODE:
-// ~30 KB of straight-line float64 code run once by one wave behind cold instruction caches; see svd3.h for the part of that which
-// could be shared)
-// -DGINGR_POST_STAMPS (diagnostic builds only): thread 0 prints where the kernel's wall time goes (100 MHz real-time counter)
-#ifdef GINGR_POST_STAMPS
-#define POST_STAMP(k) \
-    if (threadIdx.x == 0) stamp[k] = __builtin_amdgcn_s_memrealtime();
-#else
-#define POST_STAMP(k)
-#endif
-template <bool PRELOAD>
-__global__ __launch_bounds__(kPostThreads) void post_solve_kernel(PostSolveArgs A) {
-    extern __shared__ double sm[];
-#ifdef GINGR_POST_STAMPS
-    __shared__ unsigned long long stamp[8];
-#endif
-    POST_STAMP(0)
+constexpr int kPostMinThreads = 256;
+
+// A.zbuf: [rp][28] of launch_post_matvecs; A.pvec: the model's PostVec block.  blockDim = max(256, rp rounded up to 64);
+// dynamic LDS: 37 rp doubles.
+__global__ __launch_bounds__(512) void post_solve_kernel(PostSolveArgs A) {
+    extern __shared__ double prod[];  // [rp][37]: the 36 products of entry k (odd row stride: the column sums below spread over the banks)
+    __shared__ PoseLds L;
+    __shared__ int bad;
+    constexpr int ld = 37;
     const int r = A.r, rp = A.rp, tid = threadIdx.x;
-    const MomentLayout ml{rp};
     DevState *st = A.state;
     if (st->status == GINGR_FIT_MODEL_FLEXIBILITY_ERROR) return;  // a failed fit stays as it is (run stops, :149-157)
-    double *valpha = sm, *vac = valpha + rp, *proj = vac + rp, *anew = proj + rp;
-    double *za = anew + rp;       // [9][rp]  S[d][e] alpha
-    double *zc = za + 9 * rp;     // [9][rp]  S[d][e] alpha_c
-    double *Vm = zc + 9 * rp;     // [9][rp] V[d][e] then [3][rp] W[d]: the layout of mom from V(0, 0) on
-    int width = 16;
-    while (width < rp) width <<= 1;
-    const int parts = kPostThreads / width > 0 ? kPostThreads / width : 1;
-    double *scratch = Vm + 12 * rp;
-    double *Bl = scratch + parts * rp;  // [rp][rp] Binv (PRELOAD)
-    __shared__ double dots[40];
-    __shared__ DevPose P;
-    __shared__ double Bm[9], BmI[9], hv[3];
-    __shared__ int bad;
-    // ---- all global operands in flight at once
-    constexpr int kB = 16;  // Binv elements per thread and batch (rp <= 112: 12.25 per thread)
-    double bl[kB];
-    if (PRELOAD) {
+    const PostVec pvl{rp};
+    // ---- column tid of every input vector: all loads in flight at once
+    double za[9], bz[9], V[9], W[3], BV[9], BW[3], al = 0.0, ac = 0.0;
+    if (tid < rp) {
+        const double *zb = A.zbuf + (int64_t)tid * PostVec::kZRows, *pv = A.pvec + (int64_t)tid * PostVec::kRows;
+        double bs[9], bt[9];
 #pragma unroll
-        for (int q = 0; q < kB; ++q) {
-            const int e = tid + q * kPostThreads;
-            bl[q] = e < rp * rp ? A.Binv[e] : 0.0;
-        }
-    }
-    // PRELOAD implies rp <= 112: 9 rp <= 1008 elements per z block (one per thread), 12 rp <= 1344 moment entries (two per thread)
-    double zal = 0.0, zt = 0.0, vm[2] = {0.0, 0.0}, a1 = 0.0, al = 0.0;
-    if (PRELOAD) {
-        if (tid < 9 * rp) {
-            zal = A.zbuf[tid];
-            zt = A.zbuf[9 * rp + tid];
+        for (int q = 0; q < 9; ++q) {
+            za[q] = zb[PostVec::kZa + q];
+            bs[q] = zb[PostVec::kBSa + q];
+            bt[q] = zb[PostVec::kBTa + q];
+            V[q] = pv[PostVec::kV + q];
+            BV[q] = pv[PostVec::kBV + q];
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int e = tid + q * kPostThreads;
-            vm[q] = e < 12 * rp ? A.mom[ml.V(0, 0) + e] : 0.0;
+        for (int q = 0; q < 3; ++q) {
+            W[q] = pv[PostVec::kW + q];
+            BW[q] = pv[PostVec::kBW + q];
         }
-        if (tid < rp) {
-            a1 = A.zbuf[18 * rp + tid];
-            al = tid < r ? A.alpha[tid] : 0.0;
+        const double a1 = zb[PostVec::kA1];  // alpha_1 = C a: coefficients of the posterior mean (transformedModelInit.coefficients,
+        al = tid < r ? A.alpha[tid] : 0.0;        // :212-216; Q^T (Q a) = S_tot a and the R / R^T round trip of the displacement cancels)
+        ac = tid < r ? al + (a1 - al) * A.step : 0.0;  // the step blend (:218-220)
+        // Binv S[d][e] alpha_c = (1 - step) (Binv S[d][e]) alpha + step (Binv S[d][e] C) a
+#pragma unroll
+        for (int q = 0; q < 9; ++q) bz[q] = (1.0 - A.step) * bs[q] + A.step * bt[q];
+        // ---- the 36 products of the dot products (PoseLds::D), column tid
+        double *p = prod + tid * ld;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            p[d] = W[d] * al;
+            p[3 + d] = W[d] * ac;
+            p[33 + d] = al * za[4 * d];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                p[6 + d * 3 + b] = V[b * 3 + d] * al;
+                p[15 + d * 3 + b] = V[d * 3 + b] * ac;
+                p[24 + d * 3 + b] = ac * za[d * 3 + b];
+            }
         }
     }
     if (tid == 0) bad = 0;
-    // ---- into LDS.  z_alpha = S[d][e] alpha; z_c = S[d][e] alpha_c = (1 - step) S[d][e] alpha + step T[d][e] a;
-    // alpha_1 = Binv (S_tot a) / eps = C a: coefficients of the posterior mean (transformedModelInit.coefficients, :212-216; Q^T (Q a) =
-    // S_tot a and the R / R^T round trip of the displacement cancels); then the step blend (:218-220)
-    if (PRELOAD) {
-#pragma unroll
-        for (int q = 0; q < kB; ++q) {
-            const int e = tid + q * kPostThreads;
-            if (e < rp * rp) Bl[e] = bl[q];
-        }
-        if (tid < 9 * rp) {
-            za[tid] = zal;
-            zc[tid] = (1.0 - A.step) * zal + A.step * zt;
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int e = tid + q * kPostThreads;
-            if (e < 12 * rp) Vm[e] = vm[q];
-        }
-        if (tid < rp) {
-            valpha[tid] = al;
-            vac[tid] = tid < r ? al + (a1 - al) * A.step : 0.0;
-        }
-    } else {
-        for (int q = tid; q < 9 * rp; q += kPostThreads) {
-            const double z0 = A.zbuf[q], z1 = A.zbuf[9 * rp + q];
-            za[q] = z0;
-            zc[q] = (1.0 - A.step) * z0 + A.step * z1;
-        }
-        for (int e = tid; e < 12 * rp; e += kPostThreads) Vm[e] = A.mom[ml.V(0, 0) + e];
-        for (int k = tid; k < rp; k += kPostThreads) {
-            const double x = k < r ? A.alpha[k] : 0.0;
-            valpha[k] = x;
-            vac[k] = k < r ? x + (A.zbuf[18 * rp + k] - x) * A.step : 0.0;
-        }
-    }
     __syncthreads();
-    POST_STAMP(1)
-    // 36 dot products, one wave each: [0..2] W[d].alpha, [3..5] W[d].alpha_c, [6..14] V[b][d].alpha (index d*3+b),
-    // [15..23] V[d][b].alpha_c, [24..32] alpha_c.za[d][b], [33..35] alpha.za[d][d]
-    const double *Wm = Vm + 9 * rp;
-    for (int t = tid >> 6; t < 36; t += kPostThreads / 64) {
-        double v;
-        if (t < 3)
-            v = wave_dot(Wm + t * rp, valpha, r);
-        else if (t < 6)
-            v = wave_dot(Wm + (t - 3) * rp, vac, r);
-        else if (t < 15) {
-            const int d = (t - 6) / 3, b = (t - 6) % 3;
-            v = wave_dot(Vm + (b * 3 + d) * rp, valpha, r);
-        } else if (t < 24) {
-            const int d = (t - 15) / 3, b = (t - 15) % 3;
-            v = wave_dot(Vm + (d * 3 + b) * rp, vac, r);
-        } else if (t < 33) {
-            v = wave_dot(vac, za + (t - 24) * rp, r);
-        } else {
-            const int d = t - 33;
-            v = wave_dot(valpha, za + (d * 3 + d) * rp, r);
-        }
-        if ((tid & 63) == 0) dots[t] = v;
-    }
-    __syncthreads();
-    POST_STAMP(2)
-    // one wave, every lane with the same data and the same stores (same values to the same LDS words): the independent
-    // transcendental calls of the Euler round trip spread over its lanes (svd3.h)
-    if (tid < 64) post_pose_step(A, st, dots, P, Bm, BmI, hv, &bad);
-    __syncthreads();
-    POST_STAMP(3)
-    // second projection Q^T e from the moments (transformedModel.coefficients(newshape), :234-237)
-    for (int k = tid; k < rp; k += kPostThreads) {
+    if (tid < 144) {  // thread (t, part) adds the products k = part, part + 4, ... of dot product t; then (p0 + p1) + (p2 + p3)
+        const int t = tid >> 2, part = tid & 3;
+        const double *colp = prod + part * ld + t;
         double s = 0.0;
-        for (int d = 0; d < 3; ++d) {
-            for (int e = 0; e < 3; ++e) {
-                s = __builtin_fma(BmI[d * 3 + e], Vm[(d * 3 + e) * rp + k], s);
-                s = __builtin_fma(Bm[d * 3 + e], zc[(d * 3 + e) * rp + k], s);
-            }
-            s = __builtin_fma(hv[d], Wm[d * rp + k], s);
+        for (int k = 0; k < rp; k += 4) s += colp[k * ld];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (part == 0) L.D[t] = s;
+    }
+    __syncthreads();
+    if (tid < 64) post_pose_step(A, st, A.pvec + pvl.consts(), L, &bad);
+    __syncthreads();
+    // ---- second projection (transformedModel.coefficients(newshape), :234-237), Binv already applied to every term
+    double anew = 0.0;
+    if (tid < rp) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            s = __builtin_fma(L.coef[q], BV[q], s);
+            s = __builtin_fma(L.coef[9 + q], bz[q], s);
         }
-        proj[k] = k < r ? s : 0.0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) s = __builtin_fma(L.coef[18 + d], BW[d], s);
+        anew = tid < r ? s / GINGR_COEFF_NOISE : 0.0;
+        if (!finite_d(anew)) bad = 1;
     }
     __syncthreads();
-    if (PRELOAD)
-        lds_matvec_T(Bl, proj, anew, r, rp, scratch);
-    else
-        block_matvec_T(A.Binv, proj, anew, r, rp, scratch);
-    for (int k = tid; k < rp; k += kPostThreads) {
-        const double v = k < r ? anew[k] / GINGR_COEFF_NOISE : 0.0;
-        anew[k] = v;
-        if (!finite_d(v)) bad = 1;
+    const bool posterior_failed = st->err != 0;
+    const bool failed = posterior_failed || bad != 0;
+    __syncthreads();  // (every thread has read st->err before thread 0 clears it)
+    if (!failed) {
+        if (tid < rp) A.alpha[tid] = anew;
+        if (tid < 20) reinterpret_cast<double *>(st)[tid] = L.stage[tid];  // R, euler, center, t, scale, sigma2
     }
-    __syncthreads();
-    const bool posterior_failed = st->err != 0;  // failure semantics: post_commit_step
-    const bool failed = posterior_failed || bad;
-    __syncthreads();
-    POST_STAMP(4)
-    if (!failed)
-        for (int k = tid; k < rp; k += kPostThreads) A.alpha[k] = anew[k];
-    if (tid == 0) post_commit_step(A, st, P, posterior_failed, bad != 0);
-#ifdef GINGR_POST_STAMPS
-    if (tid == 0 && (st->iteration % 7) == 5) {
-        const unsigned long long e = __builtin_amdgcn_s_memrealtime();
-        printf("post_solve stamps (x10 ns): loads+lds %llu  dots %llu  pose(thread 0) %llu  proj+matvec %llu  commit %llu\n", stamp[1] - stamp[0],
-               stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], e - stamp[4]);
+    if (tid == 0) {
+        if (posterior_failed) {
+            if (st->iteration > 0) {
+                if (A.probabilistic && A.retry && *A.retry > 0)
+                    *A.retry -= 1;
+                else
+                    st->status = GINGR_FIT_MODEL_FLEXIBILITY_ERROR;
+            }
+        } else {
+            if (A.retry) *A.retry = *A.retry + 1 < GINGR_RETRY_INIT ? *A.retry + 1 : GINGR_RETRY_INIT;
+            if (bad != 0) st->status = GINGR_FIT_MODEL_FLEXIBILITY_ERROR;
+        }
+        st->pad = failed ? (st->err != 0 ? st->err : GINGR_ERR_NONFINITE) : 0;  // last error, readable by the host
+        st->err = 0;
+        st->iteration += 1;  // GingrGeneratorWrapper.propose: updateIteration()
     }
-#endif
 }
 
 __global__ void state_init_kernel(DevState *st, const gingr_state_scalars *h) {
@@ -2153,8 +2057,7 @@ int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const d
             // whole upper triangle per wave: one workgroup per slab; ~3 slabs' worth of waves per SIMD is not needed (one wave per
             // SIMD, deep prefetch), so 256 slabs = one workgroup per CU
             gram_tri_plan(M, &nslabs, &rps);
-            static const int fuse_env = getenv("GINGR_GRAM_RHS") ? atoi(getenv("GINGR_GRAM_RHS")) : 1;
-            const bool fuse = fuse_env && evec && rhs_partial && rhs_done;  // Q0^T evec out of the same pass: [nslabs][rp] partials
+            const bool fuse = evec && rhs_partial && rhs_done;  // Q0^T evec out of the same pass: [nslabs][rp] partials
             if (fuse) *rhs_done = true;
             auto go = [&](auto kern) {
                 hipLaunchKernelGGL(kern, dim3(nslabs), dim3(512), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, ws,
@@ -2243,12 +2146,10 @@ int64_t posterior_work_doubles(int32_t rp) { return (int64_t)lds_solve_doubles(r
 
 void launch_chol_block64(gingr_ctx *ctx, double *Aw, int64_t ld, int k, double *Linv, int32_t *flag) {
     const size_t lds = lds_solve_doubles(64, 64) * sizeof(double);
-    static bool granted = false;  // the attribute is per function, not per launch
-    if (!granted) {
+    // (the attribute is per function AND per device, and the group's worker threads launch concurrently: set whenever needed)
+    if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_block64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        granted = true;
-    }
     hipLaunchKernelGGL(chol_block64_kernel, dim3(1), dim3(256), lds, ctx->stream, Aw, ld, k, Linv, flag);
 }
 
@@ -2257,12 +2158,9 @@ void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
     TimerScope ts(ctx, 5);
     if (r <= 128) {
         const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
-        static size_t lds_granted = 48 * 1024;  // the attribute is per function, not per launch
-        if (lds > lds_granted) {
+        if (lds > 48 * 1024)  // per function and per device: set whenever needed
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_solve_lds_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            lds_granted = lds;
-        }
         hipLaunchKernelGGL(posterior_solve_lds_kernel<false>, dim3(1), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a,
                            st, (double *)nullptr);
         return;
@@ -2316,26 +2214,19 @@ int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
     // the log-density kernels keep 14 KB of static LDS (mat-vec scratch) next to the bordered matrix: with rp = 128 the two exceed the
     // 160 KB of a compute unit, so ranks above 112 take the global-workspace variants (the plain solve fits up to rp = 128)
     const bool in_lds = rp <= 112;
-    static const int split_env = getenv("GINGR_LOGPDF_SPLIT") ? atoi(getenv("GINGR_LOGPDF_SPLIT")) : 1;
-    if (!cached && in_lds && fx && sync && split_env) {  // the two factorisations side by side
-        static size_t lds_granted = 48 * 1024;
-        if (lds > lds_granted) {
+    if (!cached && in_lds && fx && sync) {  // the two factorisations side by side
+        if (lds > 48 * 1024)  // per function and per device: set whenever needed
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds);
-            lds_granted = lds;
-        }
         hipLaunchKernelGGL(posterior_logpdf_split_kernel, dim3(2), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte, fx,
                            out2, sync, epoch);
         return GINGR_OK;
     }
     if (cached) {  // fx holds what an earlier launch for this state left
         if (in_lds) {
-            static size_t lds_granted = 48 * 1024;  // the attribute is per function, not per launch
-            if (lds > lds_granted) {
+            if (lds > 48 * 1024)  // per function and per device: set whenever needed
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_cached_kernel<false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                lds_granted = lds;
-            }
             hipLaunchKernelGGL(posterior_logpdf_cached_kernel<false>, dim3(1), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, G, Stot,
                                qte, fx, out2, (double *)nullptr);
         } else {
@@ -2345,12 +2236,9 @@ int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
         return GINGR_OK;
     }
     if (in_lds) {
-        static size_t lds_granted = 48 * 1024;  // the attribute is per function, not per launch
-        if (lds > lds_granted) {
+        if (lds > 48 * 1024)  // per function and per device: set whenever needed
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_lds_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            lds_granted = lds;
-        }
         hipLaunchKernelGGL(posterior_logpdf_lds_kernel<false>, dim3(1), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte,
                            fx, out2, (double *)nullptr);
     } else {
@@ -2372,31 +2260,20 @@ void launch_coeff_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *Bin
 
 
 void launch_post_solve(gingr_ctx *ctx, const PostSolveArgs &a) {
-    int width = 16;
-    while (width < a.rp) width <<= 1;
-    const int parts = kPostThreads / width > 0 ? kPostThreads / width : 1;
-    // Binv rides in LDS while everything fits into the 160 KB of a compute unit (rp <= 112, and 16 elements per thread cover it)
-    static const int pre_env = getenv("GINGR_POST_PRELOAD") ? atoi(getenv("GINGR_POST_PRELOAD")) : 1;
-    const size_t base = (size_t)(4 + 18 + 12 + parts) * a.rp, full = base + (size_t)a.rp * a.rp;
-    const bool preload = pre_env && a.rp * a.rp <= 16 * kPostThreads && full * sizeof(double) + 1024 <= 160 * 1024 && a.rp <= 112;
-    const size_t lds = (preload ? full : base) * sizeof(double);
-    auto go = [&](auto kern, size_t &granted) {
-        if (lds > granted) {  // the attribute is per function, not per launch
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            granted = lds;
-        }
-        hipLaunchKernelGGL(kern, dim3(1), dim3(kPostThreads), lds, ctx->stream, a);
-    };
-    static size_t granted_pre = 48 * 1024, granted_plain = 48 * 1024;
-    if (preload)
-        go(post_solve_kernel<true>, granted_pre);
-    else
-        go(post_solve_kernel<false>, granted_plain);
+    const size_t lds = (size_t)37 * a.rp * sizeof(double);
+    const int nt = std::max<int>(kPostMinThreads, (int)round_up(a.rp, 64));
+    if (lds > 48 * 1024)  // (per function AND per device: set whenever it is needed, never cached in a process-wide static)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&post_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(post_solve_kernel, dim3(1), dim3(nt), lds, ctx->stream, a);
 }
 
 void launch_post_matvecs(gingr_ctx *ctx, const gingr_model *m, const double *alpha, const double *a, double *zbuf) {
-    hipLaunchKernelGGL(post_matvecs_kernel, dim3(19, (unsigned)(m->rp / 16)), dim3(256), 0, ctx->stream, (int)m->r, (int)m->rp,
+    hipLaunchKernelGGL(post_matvecs_kernel, dim3(PostVec::kZRows, (unsigned)(m->rp / 16)), dim3(256), 0, ctx->stream, (int)m->r, (int)m->rp,
                        m->mom, m->cmat, alpha, a, zbuf);
+}
+
+void launch_postvec(gingr_ctx *ctx, int32_t r, int32_t rp, const double *Binv, const double *moment_vectors, double *pvec) {
+    hipLaunchKernelGGL(postvec_kernel, dim3((unsigned)PostVec::kRows), dim3(256), 0, ctx->stream, (int)r, (int)rp, Binv, moment_vectors, pvec);
 }
 
 void launch_small_gemm(gingr_ctx *ctx, int32_t r, int32_t rp, const double *A, const double *B, double scale, double *out) {

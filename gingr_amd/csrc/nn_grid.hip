@@ -44,7 +44,7 @@ __device__ __forceinline__ int clamp_cell(double f, int g) {  // floor(f) clampe
 
 template <bool COUNT, int kLanes>
 __global__ __launch_bounds__(kGridBlock) void nn_grid_kernel(Cloud q, Cloud tgt, const int32_t *__restrict__ orig, NNGridDev g,
-                                                             const int32_t *__restrict__ warm, int32_t *__restrict__ idx,
+                                                             const int32_t *warm /* may alias idx: in-place warm start */, int32_t *idx,
                                                              double *__restrict__ d2out, uint8_t *__restrict__ flag,
                                                              int32_t *__restrict__ nflag, int32_t *__restrict__ nflag_next,
                                                              unsigned long long *tests) {

@@ -196,9 +196,8 @@ int gingr_rigid_icp_iterate(gingr_rigid_icp *h, int32_t n_iterations, double *di
     const double *t = h->tgt.as<double>();
     const Cloud cp{p, p + M, p + 2 * M, M}, ct{t, t + N, t + 2 * N, N};
     for (int32_t k = 0; k < n_iterations; ++k) {
-        static const int grid_env = getenv("GINGR_NN_GRID") ? atoi(getenv("GINGR_NN_GRID")) : 1;
         const int32_t *warm = h->warm ? h->idx.as<int32_t>() : nullptr;
-        if (grid_env && h->tgrid.ready && ctx->cull) {  // grid search, then the masked tile scan for what it flagged (fitter.hip, ICP)
+        if (ctx->nn_grid && h->tgrid.ready && ctx->cull) {  // grid search, then the masked tile scan for what it flagged (fitter.hip, ICP)
             launch_nn_grid(ctx, cp, ct, h->torig.as<int32_t>(), h->tgrid, warm, h->idx.as<int32_t>(), h->d2.as<double>());
             launch_nn(ctx, cp, ct, h->torig.as<int32_t>(), h->tboxes.as<double>(), h->ws.p, h->idx.as<int32_t>(), h->d2.as<double>(),
                       h->idx.as<int32_t>(), h->tgrid.flag, h->tgrid.cur_nflag());

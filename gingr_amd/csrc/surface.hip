@@ -160,18 +160,6 @@ struct Tri9 {
     double ax, ay, az, bx, by, bz, cx, cy, cz, orig;
 };
 
-// squared distance from p to the axis-aligned box of a staged triangle: a lower bound of the distance to the triangle, ~12
-// instructions against the ~150 (closest point) or ~60 (line intersection) of the exact test; the exact test runs only if some
-// lane of the wave could still gain from this triangle
-__device__ __forceinline__ double tri_box_gap2(const Tri9 &t, V3 p) {
-    const double lx = fmin(fmin(t.ax, t.bx), t.cx), hx = fmax(fmax(t.ax, t.bx), t.cx);
-    const double ly = fmin(fmin(t.ay, t.by), t.cy), hy = fmax(fmax(t.ay, t.by), t.cy);
-    const double lz = fmin(fmin(t.az, t.bz), t.cz), hz = fmax(fmax(t.az, t.bz), t.cz);
-    const double gx = fmax(fmax(lx - p.x, p.x - hx), 0.0), gy = fmax(fmax(ly - p.y, p.y - hy), 0.0),
-                 gz = fmax(fmax(lz - p.z, p.z - hz), 0.0);
-    return __builtin_fma(gz, gz, __builtin_fma(gy, gy, gx * gx));
-}
-
 __device__ __forceinline__ void stage_tile(Tri9 *tile, Cloud v, const int32_t *__restrict__ tri,
                                            const int32_t *__restrict__ tri_orig, int64_t tb, int64_t T, int lane) {
 #pragma unroll
@@ -221,123 +209,12 @@ __device__ __forceinline__ double box_box_gap2(const double a[6], const double *
 // works on quarters instead of tiles.
 constexpr int kCpThreads = 256;
 
-// H = 1: 64 queries per workgroup, one per lane.  H = 2: 32 queries per workgroup, held twice (lane and lane + 32); the two half-waves
-// take alternate triangles of the quarter.  Same arithmetic per (query, triangle) pair, half the scan per workgroup and twice the
-// workgroups: the kernel is bound by its longest workgroups, not by the vector ALU (a third busy at 64 queries per workgroup).
-template <int H>
-__global__ __launch_bounds__(kCpThreads) void surface_cp_kernel(Cloud q, Cloud v, const int32_t *__restrict__ tri,
-                                                               const int32_t *__restrict__ tri_orig, int64_t T,
-                                                               const double *__restrict__ boxes, double *__restrict__ cp,
-                                                               double *__restrict__ d2out, int32_t *__restrict__ tri_out) {
-    __shared__ Tri9 tile[kTriTile];
-    constexpr int QPB = 64 / H;      // queries per workgroup
-    __shared__ double sbest[4 * H][QPB], sorig[4 * H][QPB], spt[4 * H][3][QPB];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ql = lane & (QPB - 1), half = lane / QPB, slot = wave * H + half;
-    const int64_t i = (int64_t)blockIdx.x * QPB + ql;
-    const bool ok = i < q.n;
-    const double qx = ok ? q.x[i] : 0.0, qy = ok ? q.y[i] : 0.0, qz = ok ? q.z[i] : 0.0;
-    const V3 p{qx, qy, qz};
-    double best = __builtin_huge_val(), bo = __builtin_huge_val(), bound = __builtin_huge_val();
-    V3 bp{qx, qy, qz};
-    double wb[6];
-    wave_box(ok, qx, qy, qz, wb);
-    const int nt = (int)((T + kTriTile - 1) / kTriTile);
-    const double *qboxes = boxes + (int64_t)nt * 6;
-    // Sweep 0 must produce a finite bound or sweep 1 degenerates into a full scan: two surfaces a few units apart have thin tile
-    // boxes that often do not touch the queries' box at all.  So sweep 0 = the tiles at the SMALLEST box-to-box gap (usually gap
-    // 0 = the touching tiles), sweep 1 = the rest under the bound.  Both sweeps find their tiles with the lanes testing 64 tile
-    // boxes at a time against the queries' box (a ballot, then a scalar walk over the set bits): the per-query quarter test runs
-    // on the few candidates only, not on every tile of the mesh.
-    double gmin = __builtin_huge_val();
-    for (int t = lane; t < nt; t += 64) gmin = fmin(gmin, box_box_gap2(wb, boxes + (int64_t)t * 6));
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) gmin = fmin(gmin, __shfl_xor(gmin, off));
-    gmin = uniform_dd(gmin);
-    for (int phase = 0; phase < 2; ++phase) {
-        // the largest bound of the wave's queries: no query can gain from a tile whose box is farther from the queries' box
-        double bmax = ok ? bound : 0.0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) bmax = fmax(bmax, __shfl_xor(bmax, off));
-        bmax = uniform_dd(bmax) * (1.0 + 1e-12);
-        for (int tc = 0; tc < nt; tc += 64) {
-            const int tl = tc + lane;
-            const double g = tl < nt ? box_box_gap2(wb, boxes + (int64_t)tl * 6) : __builtin_huge_val();
-            unsigned long long cand = __ballot(tl < nt && (phase == 0 ? !(g > gmin) : (g > gmin && !(g > bmax))));
-            while (cand) {  // workgroup-uniform (same queries, same bound in every wave)
-                const int t = tc + __builtin_ctzll(cand);
-                cand &= cand - 1;
-            // this wave's quarter of the tile
-            const int64_t tb = (int64_t)t * kTriTile, q0 = tb + 64 * wave;
-            const double pd = point_box_gap2(qx, qy, qz, qboxes + ((int64_t)t * 4 + wave) * 6);
-            const bool need = ok && q0 < T && !(pd > fmin(best, bound) * (1.0 + 1e-12));
-            const bool wave_needs = __any(need);
-            if (!__syncthreads_or(wave_needs)) continue;
-            {
-                const int64_t tt = tb + threadIdx.x;
-                if (tt < T) {
-                    const int32_t a = tri[3 * tt], b = tri[3 * tt + 1], c = tri[3 * tt + 2];
-                    tile[threadIdx.x] = Tri9{v.x[a], v.y[a], v.z[a], v.x[b], v.y[b], v.z[b], v.x[c], v.y[c], v.z[c],
-                                             (double)(tri_orig ? tri_orig[tt] : (int32_t)tt)};
-                }
-            }
-            __syncthreads();
-            if (wave_needs) {
-                const int cnt = (int)min((int64_t)64, T - q0);
-                // Box test and exact test in ONE loop: the exact test runs when any of the 64 (query, triangle) pairs of a step
-                // survives (55 % of the steps at a pair survival rate of 1.2 %, 41k x 82k).  Splitting it -- survivors into per-lane
-                // bit masks, then every lane evaluating its own survivors -- was measured twice and is slower (1 470 -> 1 340
-                // iterations/s): the masks are built against the bound at the start of the quarter, while here every improvement of
-                // `best` prunes the rest of the quarter at once.  What does pay is compacting the surviving PAIRS across the wave:
-                // surface_cp_queue_kernel below (the default; this kernel stays as GINGR_SURFACE_QUEUE=0 for same-box comparisons).
-                for (int j0 = 0; j0 < cnt; j0 += H) {
-                    const int jj = j0 + half;
-                    const bool live = jj < cnt;
-                    const Tri9 tr = tile[64 * wave + (live ? jj : cnt - 1)];
-                    if (!__any(ok && live && !(tri_box_gap2(tr, p) > fmin(best, bound) * (1.0 + 1e-12)))) continue;
-                    const V3 c = closest_on_triangle(p, V3{tr.ax, tr.ay, tr.az}, V3{tr.bx, tr.by, tr.bz}, V3{tr.cx, tr.cy, tr.cz});
-                    const V3 dd = sub(c, p);
-                    const double dist = (dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z;
-                    if (live && (dist < best || (dist == best && tr.orig < bo))) {
-                        best = dist;
-                        bo = tr.orig;
-                        bp = c;
-                    }
-                }
-            }
-            __syncthreads();  // the tile is restaged by the next visited tile
-            }
-        }
-        if (phase == 0) {  // share the distance bound of sweep 0
-            sbest[slot][ql] = best;
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 4 * H; ++k) bound = fmin(bound, sbest[k][ql]);
-            __syncthreads();
-        }
-    }
-    // combine the four waves: smallest distance, ties -> lowest original triangle
-    sbest[slot][ql] = best;
-    sorig[slot][ql] = bo;
-    spt[slot][0][ql] = bp.x;
-    spt[slot][1][ql] = bp.y;
-    spt[slot][2][ql] = bp.z;
-    __syncthreads();
-    if (wave == 0 && half == 0 && ok) {
-        int w = 0;
-        for (int k = 1; k < 4 * H; ++k)
-            if (sbest[k][ql] < sbest[w][ql] || (sbest[k][ql] == sbest[w][ql] && sorig[k][ql] < sorig[w][ql])) w = k;
-        cp[i] = spt[w][0][ql];
-        cp[q.n + i] = spt[w][1][ql];
-        cp[2 * q.n + i] = spt[w][2][ql];
-        d2out[i] = sbest[w][ql];
-        if (tri_out) tri_out[i] = (int32_t)sorig[w][ql];  // the winning ORIGINAL triangle (lowest on exact ties)
-    }
-}
-
-// QUEUED variant of surface_cp_kernel (same interface, bit-identical results).  In the kernel above the exact closest-point test
-// (~170 instructions) runs for all 64 lanes whenever ANY of a step's 64 (query, triangle) pairs survives its box test -- 55 % of
-// the steps at a pair survival rate of 1.2 % (41k queries x 82k triangles): 98 % of the exact tests are wasted lanes.  Here the
+// H copies of every query per workgroup: 64 / H queries, each held by H lanes that take alternate triangles of the quarter.  Same
+// arithmetic per (query, triangle) pair, a shorter scan per workgroup and more workgroups: the kernel is bound by its longest
+// workgroups, not by the vector ALU.
+// The exact closest-point test (~170 instructions) is not run where the box test passes: a step's 64 (query, triangle) pairs
+// survive their box tests at a rate of 1.2 % (41k queries x 82k triangles), so running it for the whole wave whenever ANY pair
+// survives wastes 98 % of the lanes (the first version of this kernel did; 232 us against 147 us).  Instead the
 // survivors of the box tests are COMPACTED across the wave: every lane appends its surviving pair to a per-wave LDS queue (ballot
 // + prefix count), and as soon as 64 pairs are queued every lane pops one and runs the exact test on ITS pair -- a different
 // query and a different triangle in every lane.  The result goes to the owning query through LDS: an atomic minimum on the
@@ -568,103 +445,10 @@ __global__ __launch_bounds__(256) void barycentric_kernel(Cloud q, Cloud v, cons
 
 // flag[i] = 1 when the line through fit_i along fit_i - cp_i meets the mesh (v, tri) in a point != fit_i that is closer to fit_i
 // than cp_i is (ClosestPointRegistrator.scala:62-72).  Lanes with skip[i] != 0 do no work (their weight is already 0).
-template <int H>  // 64 / H points per workgroup, as surface_cp_kernel
-__global__ __launch_bounds__(kCpThreads) void self_intersect_kernel(Cloud fit, const double *__restrict__ cp, Cloud v,
-                                                                   const int32_t *__restrict__ tri, int64_t T,
-                                                                   const double *__restrict__ boxes,
-                                                                   const int32_t *__restrict__ skip,
-                                                                   int32_t *__restrict__ flag) {
-    __shared__ Tri9 tile[kTriTile];
-    constexpr int QPB = 64 / H;
-    __shared__ int shit[4 * H][QPB];
-    // four waves hold the same 64 points; each scans one 64-triangle quarter of a staged tile (as surface_cp_kernel); "some
-    // triangle holds a closer intersection" does not depend on the order, so the waves' flags are OR-ed at the end
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ql = lane & (QPB - 1), half = lane / QPB;
-    const int64_t i = (int64_t)blockIdx.x * QPB + ql;
-    const bool ok = i < fit.n && !(skip && skip[i]);
-    const int64_t ic = i < fit.n ? i : 0;
-    const V3 p{fit.x[ic], fit.y[ic], fit.z[ic]};
-    const V3 dir = sub(p, V3{cp[ic], cp[fit.n + ic], cp[2 * fit.n + ic]});
-    const double vv = dot3(dir, dir);
-    const double vnorm = sqrt(vv);
-    int hit = 0;
-    const int nt = (int)((T + kTriTile - 1) / kTriTile);
-    const double *qboxes = boxes + (int64_t)nt * 6;
-    // the lanes test 64 tile boxes at a time against the box of the wave's points grown by the largest radius; the per-point test
-    // below runs on those candidates only
-    double wb[6];
-    wave_box(ok, p.x, p.y, p.z, wb);
-    double vmax = ok ? vv : 0.0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vmax = fmax(vmax, __shfl_xor(vmax, off));
-    vmax = uniform_dd(vmax) * (1.0 + 1e-12);
-    for (int tc = 0; tc < nt; tc += 64) {
-        const int tl = tc + lane;
-        unsigned long long cand = __ballot(tl < nt && !(box_box_gap2(wb, boxes + (int64_t)tl * 6) > vmax));
-        while (cand) {  // workgroup-uniform
-            const int t = tc + __builtin_ctzll(cand);
-            cand &= cand - 1;
-            // an intersection point closer than |v| lies inside the ball of radius |v| around p
-            const int64_t tb = (int64_t)t * kTriTile, q0 = tb + 64 * wave;
-            const double pd = point_box_gap2(p.x, p.y, p.z, qboxes + ((int64_t)t * 4 + wave) * 6);
-            const bool need = ok && !hit && q0 < T && !(pd > vv * (1.0 + 1e-12));
-            const bool wave_needs = __any(need);
-            if (!__syncthreads_or(wave_needs)) continue;
-            {
-                const int64_t tt = tb + threadIdx.x;
-                if (tt < T) {
-                    const int32_t a = tri[3 * tt], b = tri[3 * tt + 1], c = tri[3 * tt + 2];
-                    tile[threadIdx.x] = Tri9{v.x[a], v.y[a], v.z[a], v.x[b], v.y[b], v.z[b], v.x[c], v.y[c], v.z[c], 0.0};
-                }
-            }
-            __syncthreads();
-            if (wave_needs) {
-                const int cnt = (int)min((int64_t)64, T - q0);
-                for (int jb = 0; jb < cnt; jb += H) {
-                    const int jj = jb + half;
-                    const bool live = jj < cnt;
-                    const Tri9 tr = tile[64 * wave + (live ? jj : cnt - 1)];
-                    // only triangles reaching into the ball of radius |v| around p can hold a closer intersection point
-                    if (!__any(need && live && !hit && !(tri_box_gap2(tr, p) > vv * (1.0 + 1e-9)))) continue;
-                    if (need && live && !hit) {
-                        const V3 A{tr.ax, tr.ay, tr.az};
-                        const V3 e1 = sub(V3{tr.bx, tr.by, tr.bz}, A), e2 = sub(V3{tr.cx, tr.cy, tr.cz}, A);
-                        const V3 pv = cross3(dir, e2);
-                        const double det = dot3(e1, pv);
-                        const double inv = 1.0 / det;
-                        const V3 tv = sub(p, A);
-                        const double u = dot3(tv, pv) * inv;
-                        const V3 qv = cross3(tv, e1);
-                        const double w = dot3(qv, dir) * inv;
-                        const double tt = dot3(e2, qv) * inv;
-                        if (det != 0.0 && u >= 0.0 && u <= 1.0 && w >= 0.0 && u + w <= 1.0) {
-                            const V3 ip{p.x + tt * dir.x, p.y + tt * dir.y, p.z + tt * dir.z};
-                            if (ip.x != p.x || ip.y != p.y || ip.z != p.z) {
-                                const V3 dd = sub(ip, p);
-                                if (sqrt((dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z) < vnorm) hit = 1;
-                            }
-                        }
-                    }
-                }
-            }
-            __syncthreads();  // the tile is restaged by the next visited tile
-        }
-    }
-    shit[wave * H + half][ql] = hit;
-    __syncthreads();
-    if (wave == 0 && half == 0 && i < fit.n) {
-        int any = 0;
-#pragma unroll
-        for (int q2 = 0; q2 < 4 * H; ++q2) any |= shit[q2][ql];
-        flag[i] = any;
-    }
-}
-
-// QUEUED variant of self_intersect_kernel (see surface_cp_queue_kernel): the staged tile holds bounding boxes only, (point,
+// Same structure as surface_cp_queue_kernel: the staged tile holds bounding boxes only, (point,
 // triangle) pairs whose box reaches into the ball of radius |v| around the point are compacted across the wave, and every lane runs
 // the line / triangle test on its own pair, reading the triangle from memory.  A hit is OR-ed into the point's flag in LDS; points
-// that are already hit stop producing pairs.
+// that are already hit stop producing pairs ("some triangle holds a closer intersection" does not depend on the order).
 template <int H>
 __global__ __launch_bounds__(kCpThreads) void self_intersect_queue_kernel(Cloud fit, const double *__restrict__ cp, Cloud v,
                                                                          const int32_t *__restrict__ tri, int64_t T,
@@ -1039,10 +823,8 @@ void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T
     if (T <= 0) return;
     hipLaunchKernelGGL(tri_tile_bbox_kernel, dim3((unsigned)ceil_div(T, kTriTile)), dim3(256), 0, ctx->stream, v, tri, T, boxes, tribox);
 }
-// copies of every query held per workgroup (see surface_cp_kernel); default from the number of queries
+// copies of every query held per workgroup (see surface_cp_queue_kernel), from the number of queries
 static int surface_h(int64_t nq) {
-    static const int forced = getenv("GINGR_SURFACE_H") ? atoi(getenv("GINGR_SURFACE_H")) : 0;
-    if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) return forced;
     // measured (femur chain, 1 622 queries x 3 240 triangles: 1 007 / 1 151 / 1 237 / 1 257 steps per second at H = 2 / 4 / 8 / 16;
     // 41k queries x 82k triangles: 1 452 / 1 470 / 1 441 / 1 275 iterations per second): small meshes want many short workgroups
     return nq <= 4096 ? 16 : (nq <= 16384 ? 8 : 4);
@@ -1053,44 +835,21 @@ void launch_barycentric(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri_by_
 void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T,
                                   const double *boxes, double *cp_soa, double *d2, int32_t *tri_out, int32_t *warm, bool warm_valid,
                                   const double *tribox) {
-    // queries per workgroup = 64 / H (developer knob GINGR_SURFACE_H = 1 | 2 | 4 | 8 | 16).  The kernel is bound by its longest
-    // workgroups: fewer queries per workgroup = more, shorter workgroups and a tighter query box for the tile pruning.
+    // queries per workgroup = 64 / H.  The kernel is bound by its longest workgroups: fewer queries per workgroup = more, shorter
+    // workgroups and a tighter query box for the tile pruning.
     const int h = surface_h(q.n);
+    // warm: one int32 per query, read as last call's winning triangles when warm_valid, rewritten with this call's
+    const int32_t *win = (warm && warm_valid) ? warm : (const int32_t *)nullptr;
     auto go = [&](auto kern, int qpb) {
         hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(q.n, qpb)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig, T, boxes,
-                           cp_soa, d2, tri_out);
+                           cp_soa, d2, tri_out, win, warm, tribox);
     };
-    static const int queued = getenv("GINGR_SURFACE_QUEUE") ? atoi(getenv("GINGR_SURFACE_QUEUE")) : 1;
-    if (queued) {
-        // warm: one int32 per query, read as last call's winning triangles when warm_valid, rewritten with this call's
-        static const int warm_env = getenv("GINGR_SURFACE_WARM") ? atoi(getenv("GINGR_SURFACE_WARM")) : 1;
-        const int32_t *win = (warm && warm_valid && warm_env) ? warm : (const int32_t *)nullptr;
-        auto goq = [&](auto kern, int qpb) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(q.n, qpb)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig, T, boxes,
-                               cp_soa, d2, tri_out, win, warm, (getenv("GINGR_TRIBOX") && !atoi(getenv("GINGR_TRIBOX"))) ? (const double *)nullptr : tribox);
-        };
-        if (h == 1)
-            goq(surface_cp_queue_kernel<1>, 64);
-        else if (h == 2)
-            goq(surface_cp_queue_kernel<2>, 32);
-        else if (h == 8)
-            goq(surface_cp_queue_kernel<8>, 8);
-        else if (h == 16)
-            goq(surface_cp_queue_kernel<16>, 4);
-        else
-            goq(surface_cp_queue_kernel<4>, 16);
-        return;
-    }
-    if (h == 1)
-        go(surface_cp_kernel<1>, 64);
-    else if (h == 2)
-        go(surface_cp_kernel<2>, 32);
-    else if (h == 8)
-        go(surface_cp_kernel<8>, 8);
+    if (h == 8)
+        go(surface_cp_queue_kernel<8>, 8);
     else if (h == 16)
-        go(surface_cp_kernel<16>, 4);
+        go(surface_cp_queue_kernel<16>, 4);
     else
-        go(surface_cp_kernel<4>, 16);
+        go(surface_cp_queue_kernel<4>, 16);
 }
 int distance_stats_ws_doubles() { return kStatBlocks * 4; }
 void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const int32_t *orig, int64_t orig_limit, const int32_t *nn,
@@ -1105,38 +864,14 @@ void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, cons
     const int h = surface_h(fit.n);
     auto go = [&](auto kern, int qpb) {
         hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(fit.n, qpb)), dim3(kCpThreads), 0, ctx->stream, fit, cp_soa, fit, tri, T, boxes,
-                           skip, flag);
+                           skip, flag, tribox);
     };
-    static const int queued = getenv("GINGR_SURFACE_QUEUE") ? atoi(getenv("GINGR_SURFACE_QUEUE")) : 1;
-    if (queued) {
-        static const int tb_env = getenv("GINGR_TRIBOX") ? atoi(getenv("GINGR_TRIBOX")) : 1;
-        const double *tbx = tb_env ? tribox : (const double *)nullptr;
-        auto goq = [&](auto kern, int qpb) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(fit.n, qpb)), dim3(kCpThreads), 0, ctx->stream, fit, cp_soa, fit, tri, T,
-                               boxes, skip, flag, tbx);
-        };
-        if (h == 1)
-            goq(self_intersect_queue_kernel<1>, 64);
-        else if (h == 2)
-            goq(self_intersect_queue_kernel<2>, 32);
-        else if (h == 8)
-            goq(self_intersect_queue_kernel<8>, 8);
-        else if (h == 16)
-            goq(self_intersect_queue_kernel<16>, 4);
-        else
-            goq(self_intersect_queue_kernel<4>, 16);
-        return;
-    }
-    if (h == 1)
-        go(self_intersect_kernel<1>, 64);
-    else if (h == 2)
-        go(self_intersect_kernel<2>, 32);
-    else if (h == 8)
-        go(self_intersect_kernel<8>, 8);
+    if (h == 8)
+        go(self_intersect_queue_kernel<8>, 8);
     else if (h == 16)
-        go(self_intersect_kernel<16>, 4);
+        go(self_intersect_queue_kernel<16>, 4);
     else
-        go(self_intersect_kernel<4>, 16);
+        go(self_intersect_queue_kernel<4>, 16);
 }
 void launch_surface_prereject(gingr_ctx *ctx, int64_t M, const int32_t *nn_vertex, const int32_t *tgt_boundary,
                               const double *fit_vn, const double *tgt_vn, int64_t N, const int32_t *found, int32_t *pre) {

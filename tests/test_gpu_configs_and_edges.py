@@ -170,21 +170,18 @@ def test_nan_input_is_reported_not_hidden(ctx):
 @pytest.mark.parametrize("sigma2,w", [(1.0, 0.1), (0.25, 0.3), (30.0, 0.0)])
 def test_tile_culling_is_bit_identical(sigma2, w):
     """Model rows and targets live in Morton order on the device and tile pairs whose every K underflows to exactly +0 are
-    skipped.  Skipping must not change a single bit: compare against a context created with GINGR_CULL=0."""
-    import os
+    skipped.  Skipping must not change a single bit: compare against a context with GINGR_OPT_CULL = 0."""
     import gingr_amd as ga
+    from gingr_amd import _native as nat
     mo, rng = synth_model(6000, 24, seed=77, spread=60.0)
     target = (mo.ref + rng.normal(0, 0.4, mo.ref.shape))[rng.permutation(mo.M)[:5500]]
     results = []
     # culling on with the kernel variant picked by the device-reported regime (possibly stale), culling off, and culling on with
     # each of the two variants pinned (tile-level only / quarter-tile x slot): all four must agree bit for bit
-    for env in ({"GINGR_CULL": "1"}, {"GINGR_CULL": "0"}, {"GINGR_FINE_CULL": "0"}, {"GINGR_FINE_CULL": "1"}):
-        os.environ.update(env)
-        try:
-            c = ga.Context(0)
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
+    for opt, val in ((nat.OPT_CULL, 1), (nat.OPT_CULL, 0), (nat.OPT_FINE_CULL, 0), (nat.OPT_FINE_CULL, 1)):
+        c = ga.Context(0)
+        c.set_option(opt, val)
+        assert c.get_option(opt) == val
         algo = ga.CpdRegistration(c)
         state = algo.createInitialState(to_ga(mo), target, ga.CpdConfiguration(maxIterations=10, w=w, initialSigma=sigma2))
         for _ in range(3):

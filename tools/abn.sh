@@ -1,8 +1,11 @@
 #!/bin/bash
 # Same-box comparison of several builds / settings of the library (boxes of the pool differ by +-5 % in sustained clock, so
 # variants are only comparable within ONE gpurun call).  Each variant is "name=library.so[,ENV=VALUE...]" (library relative to
-# gingr_amd/; empty = the in-tree build); runs alternate, three rounds.
-# usage: tools/abn.sh "r02=libgingr_hip_r02.so" "cur=" "cur_notail=,GINGR_FUSED_TAIL=0" -- [bench.py arguments]
+# the repository root, e.g. tools/bin/libgingr_hip_r03.so -- tools/bin/ is ignored by git and emptied at round end; empty = the
+# in-tree build); runs alternate, three rounds.
+# Variants that differ by a build-time knob are separate libraries: `make -C gingr_amd/csrc variant NAME=x DEFS="-DGINGR_...=v"`
+# writes gingr_amd/libgingr_hip_x.so (nothing in the library reads the environment).
+# usage: tools/abn.sh "r03=tools/bin/libgingr_hip_r03.so" "cur=" "chunks3=gingr_amd/libgingr_hip_chunks3.so" -- [bench.py arguments]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 VARS=()
 while [ $# -gt 0 ] && [ "$1" != "--" ]; do VARS+=("$1"); shift; done
@@ -14,7 +17,7 @@ for i in 1 2 3; do
     lib=${spec%%,*}; envs=""
     if [[ "$spec" == *,* ]]; then envs=${spec#*,}; fi
     (
-      if [ -n "$lib" ]; then export GINGR_HIP_LIB=$R/gingr_amd/$lib; fi
+      if [ -n "$lib" ]; then export GINGR_HIP_LIB=$R/$lib GINGR_HIP_LIB_ALLOW_OLDER=1; fi
       IFS=',' read -ra E <<< "$envs"; for e in "${E[@]}"; do [ -n "$e" ] && export "$e"; done
       python3 $R/bench.py --no-cpu-baseline --no-parity-check "$@" 2> $O/$name$i.err | tail -1 > $O/$name$i.json
     )
