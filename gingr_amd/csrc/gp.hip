@@ -993,10 +993,29 @@ __device__ __forceinline__ void panel_step4(double (&x)[4], double rdl, double n
         : "v"(rdl), "v"(nl), "n"(K));
 }
 
+// sum over the 16-lane row of the caller, the same bits in every lane of the row: the butterfly 1, 2, 4, 8 on the DPP crossbar
+// (quad permutes, half-row mirror, row mirror) -- __shfl_xor goes through ds_bpermute (~100 cycles per step), which is too long for
+// the one-workgroup kernels where it sits on the critical path
+__device__ __forceinline__ double row16_sum_dpp(double v) {
+    auto step = [&](auto ctrl) {
+        constexpr int c = decltype(ctrl)::value;
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, c, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), c, 0xf, 0xf, false);
+        v += __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+    };
+    step(std::integral_constant<int, 0xB1>{});   // quad_perm [1, 0, 3, 2]
+    step(std::integral_constant<int, 0x4E>{});   // quad_perm [2, 3, 0, 1]
+    step(std::integral_constant<int, 0x141>{});  // row_half_mirror
+    step(std::integral_constant<int, 0x140>{});  // row_mirror
+    return v;
+}
+
 // ---- building blocks: all 256 threads call them.  A is (n + xr) x n in LDS, n and xr multiples of 16, odd leading dimension ld.
 
 // doubles of LDS the blocks need for an r x r system with xr extra rows
-__host__ __device__ inline size_t lds_solve_doubles(int rp, int xr) { return (size_t)(rp + xr) * (rp | 1) + 2 * (size_t)rp; }
+__host__ __device__ inline int solve_ld(int n) { return n | 1; }  // odd leading dimension: column walks hit distinct banks
+__host__ __device__ inline size_t lds_solve_doubles(int rp, int xr) { return (size_t)(rp + xr) * solve_ld(rp) + 2 * (size_t)rp; }
 
 // A (lower triangle of the leading r x r) = ca * G + cs * S + ci * I from global r x rp matrices (S may be nullptr), identity
 // on the padding r <= i < n.  16 x 16 element blocks, one element per thread and block, eight blocks in flight; the loads are
@@ -1074,13 +1093,16 @@ __device__ __forceinline__ void lds_load_spd(double *A, int ld, int r, int n, co
 // factored by one wave while the others have nothing to do; so the trailing update is split: first the tiles of column k + 1 (all
 // waves), then -- behind one more barrier -- wave 0 factors diagonal block k + 1 WHILE waves 1 .. NW-1 update the remaining tiles.
 // Per step max(diagonal block, remaining tiles) replaces their sum: 79k -> 67k cycles at r = 100 (tools/ubench_solve.hip), 38 -> 33 us.
+// wr (round 4): that many further rows behind the xr bordered ones take part in the panel solves ONLY (no trailing update).  Set to
+// the tiled identity (row c: ones in the columns c, 16 + c, 32 + c, ...) they come back holding W_k = L_kk^-T, the transposed inverse
+// of every diagonal block, in the columns of block k -- what lds_backward_w multiplies with instead of running the 16-step recurrence.
 template <int NT>
-__device__ __forceinline__ void lds_cholesky(double *A, int ld, int n, double *rd, int *bad_spd, int xr) {
+__device__ __forceinline__ void lds_cholesky(double *A, int ld, int n, double *rd, int *bad_spd, int xr, int wr = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = NT / 64;           // waves
     constexpr int PU = NT >= 1024 ? 2 : 4;  // matrix rows interleaved per 16-lane group in the panel solve
     constexpr int PR = (NT / 16) * PU;     // matrix rows per panel pass
-    const int rows = n + xr;
+    const int rows = n + xr, prows = rows + wr;
     // (1) diagonal block in registers, ONE wave (all four 16-lane rows do the same work: DPP needs the source lanes active).
     // No masks anywhere: the upper part of the block is loaded, carried and stored as it comes -- lane i's entries right of the
     // diagonal only ever feed lane i's own entries right of the diagonal, and nobody reads the upper part of A (the selects,
@@ -1156,11 +1178,11 @@ __device__ __forceinline__ void lds_cholesky(double *A, int ld, int n, double *r
                 nL[k] = k < c16 ? -v : 0.0;
             }
             const double rdl = rd[kb + c16];
-            for (int ib = kb + kNB; ib < rows; ib += PR) {  // workgroup-uniform trip count
+            for (int ib = kb + kNB; ib < prows; ib += PR) {  // workgroup-uniform trip count
                 const int i0 = ib + grp;
                 double x[PU];
 #pragma unroll
-                for (int u = 0; u < PU; ++u) x[u] = A[min(i0 + (NT / 16) * u, rows - 1) * ld + kb + c16];
+                for (int u = 0; u < PU; ++u) x[u] = A[min(i0 + (NT / 16) * u, prows - 1) * ld + kb + c16];
                 static_for<0, kNB>([&](auto kk) {
                     constexpr int k = decltype(kk)::value;
                     if constexpr (PU == 4) {
@@ -1175,7 +1197,7 @@ __device__ __forceinline__ void lds_cholesky(double *A, int ld, int n, double *r
                 });
 #pragma unroll
                 for (int u = 0; u < PU; ++u)
-                    if (i0 + (NT / 16) * u < rows) A[(i0 + (NT / 16) * u) * ld + kb + c16] = x[u] * rdl;
+                    if (i0 + (NT / 16) * u < prows) A[(i0 + (NT / 16) * u) * ld + kb + c16] = x[u] * rdl;
             }
         }
         __syncthreads();
@@ -1236,6 +1258,31 @@ __device__ __forceinline__ void lds_backward(const double *A, int ld, int n, con
     }
 }
 
+// x = L^-T y with the transposed inverses of the diagonal blocks at hand (lds_cholesky, wr = 16: W points at the first identity row,
+// W[c * ld + kb + j] = (L_kk^-T)[c][j], exact zeros left of the diagonal).  Per block a 16 x 16 mat-vec (one product per thread, DPP
+// row sum) replaces the 16-step sequential recurrence of lds_backward, and x goes to its own array so that one barrier per stage is
+// enough: 12k -> see tools/ubench_solve.hip (cycles of seven blocks at r = 100).  NT == 256; y is destroyed.
+template <int NT>
+__device__ __forceinline__ void lds_backward_w(const double *A, int ld, int n, const double *W, double *y, double *x) {
+    static_assert(NT == 256, "one product of the 16 x 16 block per thread");
+    const int tid = threadIdx.x, c = tid >> 4, j = tid & 15;
+    for (int kb = n - kNB; kb >= 0; kb -= kNB) {
+        const double p = row16_sum_dpp(W[c * ld + kb + j] * y[kb + j]);
+        if (j == 0) x[kb + c] = p;
+        __syncthreads();
+        if (tid < kb) {  // y[i] -= sum_k L[kb + k][i] x[kb + k]: two interleaved chains of eight
+            double s0 = y[tid], s1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < kNB; k += 2) {
+                s0 = __builtin_fma(-A[(kb + k) * ld + tid], x[kb + k], s0);
+                s1 = __builtin_fma(-A[(kb + k + 1) * ld + tid], x[kb + k + 1], s1);
+            }
+            y[tid] = s0 + s1;
+        }
+        __syncthreads();
+    }
+}
+
 // y <- L^-1 y for the n entries of y (blocked, top down): the mirror image of lds_backward -- lane c of wave 0 holds ROW c of the
 // diagonal block, at step c every lane below takes x_c from lane c through the DPP of its FMA.
 template <int NT>
@@ -1276,7 +1323,7 @@ __device__ __forceinline__ void lds_forward(const double *A, int ld, int n, cons
 __global__ __launch_bounds__(256) void chol_block64_kernel(double *__restrict__ Aw, int64_t ld, int k, double *__restrict__ Linv,
                                                            int32_t *__restrict__ flag) {
     extern __shared__ double lds_sm[];
-    constexpr int n = 64, lda = 65;
+    constexpr int n = 64, lda = 65;  // solve_ld(64)
     double *A = lds_sm, *rd = A + 2 * n * lda;
     __shared__ int bad;
     const int tid = threadIdx.x;
@@ -1313,14 +1360,16 @@ constexpr int kSolveThreads = 256;
 // blocks to be address space 3 and emits ds_read / ds_write.  (With one kernel choosing between LDS and a global pointer at run
 // time every access was a FLAT instruction: ~3x the latency of the LDS path, 64-bit address arithmetic, SGPR spills.)
 // The solve on a workspace `sm` (LDS or global, see below); all kSolveThreads threads.  bad_spd / bad: two ints of LDS.
-template <typename PtrD>
+// FAST (LDS-resident, rp <= 112: sixteen more rows fit into the 160 KB): the identity rows of lds_cholesky / lds_backward_w.
+template <bool FAST, typename PtrD>
 __device__ __forceinline__ void posterior_solve_body(PtrD sm, int r, int rp, const double *__restrict__ G, const double *__restrict__ rhs,
                                                      const double *__restrict__ zrand, double *__restrict__ a, DevState *__restrict__ st,
                                                      int *bad_spd, int *bad) {
-    const int n = rp, ld = n | 1;  // odd leading dimension: column walks hit distinct banks
+    const int n = rp, ld = solve_ld(n);
+    constexpr int XR = FAST ? 2 * kNB : kNB;
     auto A = sm;
     auto y = sm + (size_t)n * ld;   // row n of the bordered matrix: the right-hand side (rows n+1 .. n+15 are zero)
-    auto rd = sm + (size_t)(n + kNB) * ld;  // reciprocal diagonal of L
+    auto rd = sm + (size_t)(n + XR) * ld;  // reciprocal diagonal of L
     auto y2 = rd + n;                       // sampling direction
     const int tid = threadIdx.x;
     if (tid == 0) {
@@ -1329,16 +1378,33 @@ __device__ __forceinline__ void posterior_solve_body(PtrD sm, int r, int rp, con
     }
     for (int k = tid; k < kNB * ld; k += kSolveThreads) y[k] = k < r ? rhs[k] : 0.0;
     for (int k = tid; k < n; k += kSolveThreads) y2[k] = (zrand && k < r) ? zrand[k] : 0.0;
+    if (FAST)  // rows n+16 .. n+31: the tiled identity
+        for (int k = tid; k < kNB * ld; k += kSolveThreads) {
+            const int c = k / ld, j = k - c * ld;
+            y[kNB * ld + k] = (j < n && (j & 15) == c) ? 1.0 : 0.0;
+        }
     // Mm = QtL Q + I     (scalismo genericRegressionComputations)
     GINGR_STAGE_CLOCK(7)
     lds_load_spd<kSolveThreads>(A, ld, r, n, G, 1.0, nullptr, 0.0, 1.0);
     GINGR_STAGE_CLOCK(0)
-    lds_cholesky<kSolveThreads>(A, ld, n, rd, bad_spd, kNB);  // y <- L^-1 y on the way
+    lds_cholesky<kSolveThreads>(A, ld, n, rd, bad_spd, kNB, FAST ? kNB : 0);  // y <- L^-1 y on the way
     GINGR_STAGE_CLOCK(4)
-    lds_backward<kSolveThreads>(A, ld, n, rd, y);
+    if constexpr (FAST) {
+        // x = L^-T y into rd (the reciprocal diagonal is not needed any more); the sampling direction L^-T z the same way
+        if (zrand) {  // (before y: the second call reuses rd for its result, so the first result moves to y2's place afterwards)
+            lds_backward_w<kSolveThreads>(A, ld, n, y + kNB * ld, y2, rd);
+            for (int k = tid; k < n; k += kSolveThreads) y2[k] = rd[k];
+            __syncthreads();
+        }
+        lds_backward_w<kSolveThreads>(A, ld, n, y + kNB * ld, y, rd);
+        for (int k = tid; k < n; k += kSolveThreads) y[k] = rd[k];
+        __syncthreads();
+    } else {
+        lds_backward<kSolveThreads>(A, ld, n, rd, y);
+        if (zrand) lds_backward<kSolveThreads>(A, ld, n, rd, y2);
+    }
     GINGR_STAGE_CLOCK(5)
     GINGR_STAGE_CLOCK(6)
-    if (zrand) lds_backward<kSolveThreads>(A, ld, n, rd, y2);
     for (int k = tid; k < rp; k += kSolveThreads) {
         const double v = k < r ? y[k] + y2[k] : 0.0;
         a[k] = v;
@@ -1353,17 +1419,25 @@ __device__ __forceinline__ void posterior_solve_body(PtrD sm, int r, int rp, con
     }
 }
 
-template <bool GW>
+// MODE 0: LDS, identity rows (rp <= 112); 1: LDS (rp = 128); 2: global workspace (r > 128)
+template <int MODE>
 __global__ __launch_bounds__(kSolveThreads) void posterior_solve_lds_kernel(int r, int rp, const double *__restrict__ G,
                                                                   const double *__restrict__ rhs,
                                                                   const double *__restrict__ zrand, double *__restrict__ a,
                                                                   DevState *__restrict__ st, double *gwork) {
     extern __shared__ double lds_sm[];
     __shared__ int bad_spd, bad;
-    if constexpr (GW)
-        posterior_solve_body(gwork, r, rp, G, rhs, zrand, a, st, &bad_spd, &bad);
+#ifdef GINGR_SOLVE_TWICE  // tools/ubench_solve.hip only: the second pass runs with the kernel's code in the instruction cache
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#endif
+    if constexpr (MODE == 2)
+        posterior_solve_body<false>(gwork, r, rp, G, rhs, zrand, a, st, &bad_spd, &bad);
     else
-        posterior_solve_body(lds_sm, r, rp, G, rhs, zrand, a, st, &bad_spd, &bad);
+        posterior_solve_body<MODE == 0>(lds_sm, r, rp, G, rhs, zrand, a, st, &bad_spd, &bad);
+#ifdef GINGR_SOLVE_TWICE
+    }
+#endif
 }
 
 // ---- pieces shared by the three transition-density kernels (256 threads: 128 entries x 2 column halves) -------------------------
@@ -1441,7 +1515,7 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_lds_kernel(int
         sm = gwork;
     else
         sm = lds_sm;
-    const int n = rp, ld = n | 1;
+    const int n = rp, ld = solve_ld(n);
     double *A = sm;
     double *u = sm + (size_t)n * ld;  // extra row block of the bordered matrix
     double *rd = sm + (size_t)(n + kNB) * ld;
@@ -1496,7 +1570,7 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_split_kernel(i
                                                                      const double *__restrict__ qte, double *__restrict__ fx,
                                                                      double *__restrict__ out2, unsigned *sync, unsigned epoch) {
     extern __shared__ double sm[];
-    const int n = rp, ld = n | 1;
+    const int n = rp, ld = solve_ld(n);
     double *A = sm;
     double *u = sm + (size_t)n * ld;
     double *rd = sm + (size_t)(n + kNB) * ld;
@@ -1560,7 +1634,7 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_cached_kernel(
         sm = gwork;
     else
         sm = lds_sm;
-    const int n = rp, ld = n | 1;
+    const int n = rp, ld = solve_ld(n);
     double *A = sm;
     double *u = sm + (size_t)n * ld;
     double *rd = sm + (size_t)(n + kNB) * ld;
@@ -2157,16 +2231,21 @@ void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
                             double *work, double *a, DevState *st) {
     TimerScope ts(ctx, 5);
     if (r <= 128) {
-        const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
-        if (lds > 48 * 1024)  // per function and per device: set whenever needed
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_solve_lds_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(posterior_solve_lds_kernel<false>, dim3(1), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a,
-                           st, (double *)nullptr);
+        const bool fast = rp <= 112;  // sixteen identity rows fit beside the bordered matrix
+        const size_t lds = lds_solve_doubles(rp, fast ? 2 * kNB : kNB) * sizeof(double);
+        auto go = [&](auto kern) {
+            if (lds > 48 * 1024)  // per function and per device: set whenever needed
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(1), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a, st, (double *)nullptr);
+        };
+        if (fast)
+            go(posterior_solve_lds_kernel<0>);
+        else
+            go(posterior_solve_lds_kernel<1>);
         return;
     }
     // r > 128: the bordered matrix does not fit the LDS; same kernel on the global workspace (posterior_work_doubles)
-    hipLaunchKernelGGL(posterior_solve_lds_kernel<true>, dim3(1), dim3(kSolveThreads), 0, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a, st, work);
+    hipLaunchKernelGGL(posterior_solve_lds_kernel<2>, dim3(1), dim3(kSolveThreads), 0, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a, st, work);
 }
 
 namespace {

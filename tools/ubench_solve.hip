@@ -52,8 +52,8 @@ int main() {
     hipMemset(st, 0, sizeof(DevState));
     hipMemcpy(dG, G.data(), G.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(drhs, rhs.data(), rp * 8, hipMemcpyHostToDevice);
-    const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_solve_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    const size_t lds = lds_solve_doubles(rp, 2 * kNB) * sizeof(double);  // MODE 0: identity rows
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_solve_lds_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
     const int reps = 50;
     unsigned long long zero[8] = {0};
@@ -64,7 +64,7 @@ int main() {
         hipMemcpyToSymbol(HIP_SYMBOL(g_stage), zero, sizeof(zero));
         hipEventRecord(a);
         for (int i = 0; i < reps; ++i)
-            hipLaunchKernelGGL(posterior_solve_lds_kernel<false>, dim3(1), dim3(kSolveThreads), lds, 0, r, rp, dG, drhs, (const double *)nullptr, da, st, (double *)nullptr);
+            hipLaunchKernelGGL(posterior_solve_lds_kernel<0>, dim3(1), dim3(kSolveThreads), lds, 0, r, rp, dG, drhs, (const double *)nullptr, da, st, (double *)nullptr);
         hipEventRecord(b);
         hipDeviceSynchronize();
     }
