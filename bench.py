@@ -234,6 +234,30 @@ def spawn_ranks(n_gpus: int, argv) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def run_group_mode(args, world: int, shared_device: bool):
+    """The same workload once more through the in-library device group (ONE process, one worker thread per GPU, peer-pointer
+    all-reduce) so that one multi-GPU run carries RCCL and the group side by side: a CHILD process (this one has initialised the
+    GPU and must not exec), started when the ranks are done with their devices.  Returns the digest of the child's line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--group", "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--points", str(args.points), "--rank", str(args.rank), "--w", str(args.w), "--roofline-steps", str(args.roofline_steps),
+           "--no-cpu-baseline", "--no-parity-check"]
+    if shared_device:
+        cmd += ["--logical-shards", str(world)]   # the one-GPU test mode: the shards share device 0
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        return {"ms_per_step": d["ms_per_step"], "value": d["value"], "valid": d["valid"], "n_gpus": d["n_gpus"],
+                "exchange": d.get("exchange"), "devices": (d.get("rccl_ranks") or {}).get("devices"),
+                "distinct_device_uuids": (d.get("rccl_ranks") or {}).get("distinct_device_uuids"),
+                "how": "child process `bench.py --group` on the same devices after the headline measurement"}
+    except Exception as e:  # the headline line must come out whatever happens here
+        return {"error": f"{type(e).__name__}: {e}"[:400]}
+
+
 def _latest_profile(suffix: str):
     """profiles/rNN_<suffix> of the highest round present (tracked artefacts of tools/final_profile.sh), or None"""
     import glob
@@ -311,6 +335,12 @@ def main():
                          "also times the HIP path on the same inputs")
     ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
                     help="one measurement line for BASELINE.json config N (tools/bench_configs.py) instead of the headline benchmark")
+    ap.add_argument("--exchange", choices=["rccl-native", "torch"], default="rccl-native",
+                    help="N > 1 (one process per GPU): who runs the two all-reduces of an iteration -- the library itself (ncclAllReduce on "
+                         "its own stream, gingr_fitter_update_cpd_rccl_async; default) or torch.distributed called back once per exchange")
+    ap.add_argument("--no-group-mode", action="store_true",
+                    help="N > 1: skip the second measurement through the in-library device group (a child process started by rank 0 after "
+                         "the headline measurement; its line is folded into the output as `group_mode`)")
     ap.add_argument("--ctx-option", action="append", default=[], metavar="NAME=VALUE",
                     help="same-box comparisons: gingr_ctx_set_option on the context, NAME in cull | fine_cull | nn_grid (all select "
                          "between code paths with identical results)")
@@ -447,11 +477,27 @@ def main():
             else:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
+        # The exchange of the N > 1 run.  Default: the library's own RCCL communicator (one per rank, bootstrapped through the process
+        # group that torch.distributed.run set up: rank 0 creates the ncclUniqueId, everybody receives its 128 bytes) -- the two
+        # all-reduces of an iteration are then ncclAllReduce calls enqueued by libgingr_hip on the kernels' stream.  The shared-device
+        # test mode cannot have one (RCCL refuses two ranks on one GPU): there, and with --exchange torch, torch.distributed is
+        # called back once per exchange.
+        native = use_dist and args.exchange == "rccl-native" and not shared_device
+        exchange_path = None
+        if use_dist:
+            exchange_path = ("rccl-native" if native else
+                             ("gloo on host copies (shared-device test mode)" if shared_device else "torch.distributed (nccl) callback"))
+        if native:
+            comm_world = world if not args.emulate_world else 1
+            uid = [ctx.rccl_unique_id() if rank == 0 else None]
+            if comm_world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            ctx.rccl_init(uid[0], comm_world, rank if comm_world > 1 else 0)
         with torch.cuda.stream(stream):
             shard_world = args.emulate_world if args.emulate_world > 1 else world
             fitter = ShardedFitter(ctx, model, x, rank=rank, world=shard_world, all_reduce=all_reduce if use_dist else None,
-                                   global_transform=ga.GlobalTranformationType.RigidTransforms, step_length=1.0)
-            if args.force_dist and shard_world == 1:      # exercise the phase + all-reduce driver with one rank
+                                   global_transform=ga.GlobalTranformationType.RigidTransforms, step_length=1.0, rccl=native)
+            if args.force_dist and shard_world == 1 and not native:      # exercise the phase + all-reduce driver with one rank
                 from gingr_amd.sharded import as_torch, NUM_SEGMENTS
                 import ctypes
                 from ctypes import c_int64, c_void_p
@@ -577,7 +623,9 @@ def main():
             te = torch.tensor(ex, dtype=torch.float64, device="cpu" if shared_device else f"cuda:{local_rank}")
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             ex = [float(v) for v in te.tolist()]
-        exchange = {"segment0_column_sums_ms": ex[0], "segment1_gram_bundle_ms": ex[1],
+        exchange = {"path": exchange_path if use_dist else "in-library device group (peer pointers)",
+                    "rccl": ctx.rccl_info() if (use_dist and native) else None,
+                    "segment0_column_sums_ms": ex[0], "segment1_gram_bundle_ms": ex[1],
                     "bytes": {"segment0": 8 * N, "segment1": 8 * (((args.rank + 15) // 16 * 16) ** 2 + (args.rank + 15) // 16 * 16 + 8)},
                     "how": "HIP events around each all-reduce on the stream the kernels run on, averaged over the roofline "
                            "iterations, max over ranks; includes the wait for the slowest peer"}
@@ -665,7 +713,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         mode = ("in-library device group, one process" + (" (logical shards on device 0)" if args.logical_shards > 0 else "")
-                if args.group else ("torch.distributed (RCCL), one process per GPU" if n_shards > 1 else "single shard"))
+                if args.group else ((f"one process per GPU, {exchange_path}") if (n_shards > 1 or use_dist) else "single shard"))
         out = {
             "metric": "GiNGR update iters/sec, 50k<->50k CPD",
             "value": args.steps / elapsed,
@@ -705,6 +753,8 @@ def main():
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0 and world > 1 and not args.group and not args.no_group_mode and not args.emulate_world:
+        out["group_mode"] = run_group_mode(args, world, shared_device)
     if rank == 0:
         # RCCL prints a version banner through C stdio; flush it first so that the JSON is the LAST line on stdout
         import ctypes

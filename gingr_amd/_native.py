@@ -19,6 +19,7 @@ GINGR_OK = 0
 ERR_BAD_ARGUMENT, ERR_HIP, ERR_NONFINITE, ERR_NOT_SPD, ERR_NO_DEVICE, ERR_STATE = 1, 2, 3, 4, 5, 6
 NUM_PHASES = 3
 NUM_SEGMENTS = 2
+RCCL_UNIQUE_ID_BYTES = 128
 
 _STATUS_NAMES = {
     1: "GINGR_ERR_BAD_ARGUMENT", 2: "GINGR_ERR_HIP", 3: "GINGR_ERR_NONFINITE", 4: "GINGR_ERR_NOT_SPD",
@@ -141,6 +142,13 @@ SIGNATURES = {
     "gingr_fitter_update_cpd_sharded_async": (c_int, [c_void_p, POINTER(CpdParams), c_int32, ALLREDUCE_FN, c_void_p]),
     "gingr_fitter_update_icp_sharded_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32, ALLREDUCE_FN, c_void_p]),
     "gingr_fitter_icp_phase_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32]),
+    "gingr_rccl_load": (c_int, [c_void_p, c_char_p]),
+    "gingr_rccl_unique_id": (c_int, [c_void_p, c_void_p]),
+    "gingr_ctx_rccl_init": (c_int, [c_void_p, c_void_p, c_int32, c_int32]),
+    "gingr_ctx_rccl_info": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), c_char_p, c_int32]),
+    "gingr_ctx_rccl_allreduce_async": (c_int, [c_void_p, c_void_p, c_int64]),
+    "gingr_fitter_update_cpd_rccl_async": (c_int, [c_void_p, POINTER(CpdParams), c_int32]),
+    "gingr_fitter_update_icp_rccl_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32]),
     "gingr_group_create": (c_int, [c_int32, _ip, POINTER(c_void_p)]),
     "gingr_group_destroy": (None, [c_void_p]),
     "gingr_group_size": (c_int32, [c_void_p]),

@@ -106,6 +106,35 @@ class Context:
         _check(self.handle, self._lib.gingr_ctx_get_option(self.handle, int(option), ctypes.byref(v)), "gingr_ctx_get_option")
         return int(v.value)
 
+    # ---- native RCCL exchange (one process per GPU; the library enqueues ncclAllReduce on this context's stream)
+    def rccl_load(self, path: Optional[str] = None):
+        """Bind a specific librccl (default: the copy already loaded in the process, e.g. torch's, else the loader's search path)."""
+        _check(self.handle, self._lib.gingr_rccl_load(self.handle, path.encode() if path else None), "gingr_rccl_load")
+
+    def rccl_unique_id(self) -> bytes:
+        """ncclGetUniqueId: rank 0 creates it, the host distributes the 128 bytes to every rank."""
+        buf = ctypes.create_string_buffer(nat.RCCL_UNIQUE_ID_BYTES)
+        _check(self.handle, self._lib.gingr_rccl_unique_id(self.handle, buf), "gingr_rccl_unique_id")
+        return bytes(buf.raw)
+
+    def rccl_init(self, unique_id: bytes, world: int, rank: int):
+        """ncclCommInitRank on this context's device (collective over the `world` ranks); the communicator dies with the context."""
+        assert len(unique_id) == nat.RCCL_UNIQUE_ID_BYTES
+        buf = ctypes.create_string_buffer(unique_id, nat.RCCL_UNIQUE_ID_BYTES)
+        _check(self.handle, self._lib.gingr_ctx_rccl_init(self.handle, buf, int(world), int(rank)), "gingr_ctx_rccl_init")
+
+    def rccl_info(self) -> dict:
+        w, r, v = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        path = ctypes.create_string_buffer(512)
+        _check(self.handle, self._lib.gingr_ctx_rccl_info(self.handle, ctypes.byref(w), ctypes.byref(r), ctypes.byref(v), path, 512),
+               "gingr_ctx_rccl_info")
+        return {"world": int(w.value), "rank": int(r.value), "version": int(v.value), "library": path.value.decode()}
+
+    def rccl_allreduce(self, device_ptr: int, count: int):
+        """In-place float64 sum all-reduce of `count` elements at `device_ptr`, enqueued on this context's stream."""
+        _check(self.handle, self._lib.gingr_ctx_rccl_allreduce_async(self.handle, c_void_p(int(device_ptr)), int(count)),
+               "gingr_ctx_rccl_allreduce_async")
+
     def nn_counting(self, on: bool = True):
         """Diagnostics: count the distance tests the nearest-neighbour launches of this context really execute (clears the counter)."""
         _check(self.handle, self._lib.gingr_ctx_nn_counting(self.handle, 1 if on else 0), "nn_counting")

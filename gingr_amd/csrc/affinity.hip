@@ -905,17 +905,20 @@ __global__ __launch_bounds__(kBlock, (PT >= 4 ? 3 : 4)) void cpd_rowstats_kernel
 // obs.weight != nullptr: the CPD observations of the rows (CPDCorrespondence.estimate + getUncertainty, CPD.scala:36-46,120-128)
 // are produced in the same pass -- weight_i = P1_i / (sigma2 lambda), e_i = weight_i (R^T (yhat_i - c - t) - (ref_i - c) - mean_i)
 // with yhat_i = y_i + (PX_i / P1_i - y_i); rows overridden by a landmark get weight 0 (GingrAlgorithm.scala:289-292).
-constexpr int kRowReduceThreads = 1024;
-__global__ __launch_bounds__(kRowReduceThreads) void rowstats_reduce_kernel(const double *__restrict__ partial, int nchunks, Cloud fit,
-                                                                            double *__restrict__ P1, double *__restrict__ PX,
-                                                                            double *__restrict__ part, CpdObsArgs obs) {
-    __shared__ double sh[256];
-    __shared__ double quart[3][4][256];  // [quarter 1..3][plane][row]
+// ROWS (round 4): rows per workgroup step, 256 or 64 (4 ROWS threads).  With 256 a shard of 6 250 rows keeps only 25 of the 256
+// workgroups -- 25 compute units -- busy reading its 6 MB of partials (9.2 us, a sixth of the rows in three quarters of the full
+// cloud's time); 64 rows per workgroup spread the same rows over 98.  Same order of additions per row either way.
+template <int ROWS>
+__global__ __launch_bounds__(4 * ROWS) void rowstats_reduce_kernel(const double *__restrict__ partial, int nchunks, Cloud fit,
+                                                                   double *__restrict__ P1, double *__restrict__ PX,
+                                                                   double *__restrict__ part, CpdObsArgs obs) {
+    __shared__ double sh[ROWS];
+    __shared__ double quart[3][4][ROWS];  // [quarter 1..3][plane][row]
     const int64_t M = fit.n;
-    const int row = threadIdx.x & 255, g = threadIdx.x >> 8;
+    const int row = threadIdx.x % ROWS, g = threadIdx.x / ROWS;
     const int c0 = (int)((int64_t)g * nchunks / 4), c1 = (int)((int64_t)(g + 1) * nchunks / 4);
     double np = 0.0, tr = 0.0, ypy = 0.0;
-    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < M; i0 += (int64_t)kScalarBlocks * 256) {
+    for (int64_t i0 = (int64_t)blockIdx.x * ROWS; i0 < M; i0 += (int64_t)kScalarBlocks * ROWS) {
         const int64_t i = i0 + row;
         const bool ok = i < M;
         double v[4] = {0.0, 0.0, 0.0, 0.0};
@@ -982,7 +985,7 @@ __global__ __launch_bounds__(kRowReduceThreads) void rowstats_reduce_kernel(cons
         }
         __syncthreads();  // quart is rewritten by the next group of rows
     }
-    // the scalar partials of the block: only the 256 finishing threads hold values
+    // the scalar partials of the block: only the ROWS finishing threads hold values
     double tot[3] = {0.0, 0.0, 0.0};
     const double vals[3] = {np, tr, ypy};
 #pragma unroll
@@ -990,7 +993,7 @@ __global__ __launch_bounds__(kRowReduceThreads) void rowstats_reduce_kernel(cons
         if (g == 0) sh[row] = vals[q];
         __syncthreads();
 #pragma unroll
-        for (int st = 128; st > 0; st >>= 1) {
+        for (int st = ROWS / 2; st > 0; st >>= 1) {
             if (g == 0 && row < st) sh[row] += sh[row + st];
             __syncthreads();
         }
@@ -1540,8 +1543,12 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
     }
     CpdObsArgs none;
     memset(&none, 0, sizeof(none));
-    hipLaunchKernelGGL(rowstats_reduce_kernel, dim3(kScalarBlocks), dim3(kRowReduceThreads), 0, ctx->stream, ws, nch, fit, P1, PX_soa,
-                       part, obs ? *obs : none);
+    if (fit.n <= (int64_t)kScalarBlocks * 64)  // up to 16 384 rows: a quarter of the rows per workgroup, four times the workgroups
+        hipLaunchKernelGGL(rowstats_reduce_kernel<64>, dim3(kScalarBlocks), dim3(256), 0, ctx->stream, ws, nch, fit, P1, PX_soa, part,
+                           obs ? *obs : none);
+    else
+        hipLaunchKernelGGL(rowstats_reduce_kernel<256>, dim3(kScalarBlocks), dim3(1024), 0, ctx->stream, ws, nch, fit, P1, PX_soa, part,
+                           obs ? *obs : none);
     if (finish_scalars)  // otherwise the caller's phase-1 finalize kernel sums the block partials (cpd_scalar_partials_layout)
         hipLaunchKernelGGL(cpd_scalars_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, part, scalars_dev, xch8, contribute_xpx);
 }

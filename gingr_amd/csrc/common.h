@@ -40,12 +40,16 @@ struct gingr_ctx {
     int fine_override = -1;  // GINGR_OPT_FINE_CULL 0|1 pins the variant (tests: both must give bit-identical results); -1: by regime
     // diagnostics (gingr_ctx_nn_counting): device counter of the distance tests the nearest-neighbour launches really execute; null = off
     unsigned long long *nn_tests = nullptr;
+    // native RCCL exchange (rccl_exchange.hip): the communicator of this rank, owned by the context; null = none
+    void *rccl_comm = nullptr;
+    int32_t rccl_world = 0, rccl_rank = 0;
     // scratch kept across calls (grown on demand, never shrunk) so steady-state updates do not allocate
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
 };
 
 int gingr_set_error(gingr_ctx *ctx, int code, const char *fmt, ...);
+void gingr_ctx_rccl_release(gingr_ctx *ctx);  // rccl_exchange.hip: destroys the context's communicator, if any
 
 #define HIP_TRY(ctx, expr)                                                                                   \
     do {                                                                                                     \

@@ -97,6 +97,7 @@ void gingr_ctx_destroy(gingr_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     timing_resolve(ctx);
+    gingr_ctx_rccl_release(ctx);
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->nn_tests) (void)hipFree(ctx->nn_tests);

@@ -184,13 +184,27 @@ SweepArgs base_args(const gingr_fitter *f) {
     return a;
 }
 
+// boxes + |coordinate - centre| maximum of a fit that was NOT written by refresh_fit (explicit fit points; a target set after the state)
+void fit_boxes_now(gingr_fitter *f) {
+    if (!f->fboxes) return;
+    (void)hipMemsetAsync(f->absmax + 1, 0, sizeof(double), f->ctx->stream);
+    launch_tile_bbox(f->ctx, cloud_of(f->fit, f->m->M), f->fboxes, f->absmax + 2, f->absmax + 1);
+}
+
 // fit = modelInstanceShapePoseScale(model, state)
 void refresh_fit(gingr_fitter *f) {
     SweepArgs a = base_args(f);
     a.coef0 = f->alpha;
     a.shape_out = f->fit;
-    a.zero_slot = f->absmax + 1;
-    launch_sweep(f->ctx, SWEEP_FIT, a);
+    if (f->fboxes && f->m->rp <= 128) {  // a target is set: the pass also leaves the quarter boxes and the |coordinate - centre| maximum
+        a.qboxes = f->fboxes + 6 * ceil_div(f->m->M, 256);
+        a.box_centre = f->absmax + 2;
+        a.absmax_slot = f->absmax + 1;
+        launch_sweep(f->ctx, SWEEP_FIT, a);
+    } else {
+        launch_sweep(f->ctx, SWEEP_FIT, a);
+        fit_boxes_now(f);  // rank > 128: the generic pass, the boxes by a launch of their own
+    }
 }
 
 void free_meshes(gingr_fitter *f) {
@@ -623,6 +637,7 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
     launch_tile_bbox(ctx, cloud_of(f->target, N), f->tboxes);
     launch_cloud_centroid(ctx, cloud_of(f->target, N), f->absmax + 2);
     launch_cloud_absmax(ctx, cloud_of(f->target, N), f->absmax + 2, f->absmax);
+    if (f->has_state) fit_boxes_now(f);  // the fit on the device predates this target (its centre)
     GINGR_TRY(check_launch(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GINGR_OK;
@@ -685,7 +700,7 @@ int gingr_fitter_set_state(gingr_fitter *f, const double *alpha, const gingr_sta
     memcpy(f->pin, alpha, (size_t)r * sizeof(double));
     memcpy(f->pin + rp, s, sizeof(*s));
     HIP_TRY(ctx, hipMemcpyAsync(f->state_block, f->pin, ((size_t)rp + kScalarsDoubles) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    launch_state_init(ctx, f->st, f->hs_dev);
+    launch_state_init(ctx, f->st, f->hs_dev, f->absmax + 1);
     if (!f->ws) {  // no target yet: allocate the sweep workspace so the fit can be instantiated
         f->ws_doubles = sweep_ws_doubles(f->m->M, rp);
         GINGR_TRY(dev_alloc(ctx, &f->ws, (size_t)f->ws_doubles));
@@ -715,6 +730,7 @@ int gingr_fitter_set_fit_points(gingr_fitter *f, const double *fit_xyz) {
     double *stage = reinterpret_cast<double *>(f->aos);
     HIP_TRY(ctx, hipMemcpyAsync(stage, fit_xyz, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     launch_aos_to_soa(ctx, stage, M, f->fit, f->m->perm);
+    fit_boxes_now(f);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the caller's buffer is free again
     // the shape on the device is no instance of the model any more: nothing memoised describes it
     f->forget_posteriors();
@@ -1006,8 +1022,8 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 nearest_target_vertex(ctx, f, fit, tgt, f->nn_idx, f->nn_d2, f->nn_warm);
                 f->nn_warm = true;
             } else {
-                // boxes of the fit tiles + its |coordinate - centroid| maximum (slot cleared by the pass that wrote the fit)
-                launch_tile_bbox(ctx, fit, f->fboxes, f->absmax + 2, f->absmax + 1);
+                // (the quarter boxes of the fit and its |coordinate - centroid| maximum were left by the pass that wrote the fit:
+                // refresh_fit / fit_boxes_now)
                 // single shard: nothing is exchanged, so the chunk partials stay in ws and phase 1's den_finalize adds them up
                 const bool alone = m->M == m->M_total && !f->partial_out;
                 f->colsum_chunks = launch_cpd_colsum(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->fboxes, f->ws, alone ? nullptr : seg0w);
@@ -1121,6 +1137,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
             a.global_transform = f->global_transform;
             a.state = f->st;
             a.retry = f->retry;
+            a.zero_slot = f->absmax + 1;
             a.probabilistic = f->zrand_active ? 1 : 0;
             launch_post_solve(ctx, a);
             refresh_fit(f);

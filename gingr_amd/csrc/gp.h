@@ -139,6 +139,12 @@ struct SweepArgs {
     double *partial;       // [nblocks][rp] transposed partials or [nblocks][24] Umeyama partials
     double *out;           // reduced result: [rp] or [24]
     double *zero_slot;     // nullable: one double the pass clears (consumed by a LATER launch on the stream)
+    // SWEEP_FIT, nullable (round 4): qboxes[q] = {lo[3], hi[3]} of the 64-point quarter q of the shape written (the quarter boxes of
+    // launch_tile_bbox, i.e. boxes + 6 ntiles), box_centre[3] on the device, and *absmax_slot = max(*absmax_slot, largest
+    // |coordinate - centre|) -- the slot must have been cleared by an EARLIER launch on the stream (post_solve_kernel, state_init_kernel)
+    double *qboxes;
+    const double *box_centre;
+    double *absmax_slot;
     int32_t no_reduce;     // != 0: leave the [nblocks][rp] partials in `partial` (the phase-1 finalize kernel adds them up)
     // SWEEP_RHS_ICP: matched target positions, the target planes (n_targets points), the landmark mask (nullable); weight / e are
     // also written out.  A position outside [0, n_targets) -- the searches leave -1 for a query whose distances are all NaN -- gives
@@ -223,7 +229,7 @@ int64_t posterior_work_doubles(int32_t rp);
 void launch_binv(gingr_ctx *ctx, int32_t r, int32_t rp, const double *S, double *work, double *Binv, int32_t *err_flag);
 // out = Binv (p/eps)
 void launch_coeff_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *Binv, const double *p, double *out);
-void launch_state_init(gingr_ctx *ctx, DevState *st, const gingr_state_scalars *host_scalars_dev);
+void launch_state_init(gingr_ctx *ctx, DevState *st, const gingr_state_scalars *host_scalars_dev, double *zero_slot = nullptr);
 
 // moment Gram S[d][e] (all patches, no symmetry): ws sized like gram_ws_doubles
 void launch_moment_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, int d, int e, double *ws, double *out);
@@ -243,6 +249,7 @@ struct PostSolveArgs {
     double step;
     int32_t global_transform;
     DevState *state;
+    double *zero_slot;      // nullable: cleared by thread 0 (SweepArgs::absmax_slot of the fit pass that follows)
     int32_t *retry;         // retryCounter of the algorithm instance (GingrAlgorithm.scala:69-70), device word; nullable
     int32_t probabilistic;  // update(current, probabilistic = true)
 };

@@ -69,11 +69,23 @@ constexpr int kSweepThreads = 256;
 constexpr int kGroups = kSweepThreads / 16;  // points per block step
 constexpr int kSweepMaxBlocks = 1024;
 
+// sum over the caller's 16-lane group, the same bits in every lane: the butterfly 8, 4, 2, 1.  Round 4: on the DPP crossbar (row
+// rotations) instead of __shfl_xor, which goes through ds_bpermute (~100 cycles per step; twelve of these sums sit on the critical
+// path of a one-wave-per-SIMD launch like the fit pass of a small model).  Bit-identical to the shuffle butterfly: after the step
+// with distance 2d every lane holds the same bits as the lane 2d away, so the lane d "behind" (what a rotation delivers) holds
+// exactly what the xor partner holds, and a + b = b + a.
 __device__ __forceinline__ double group16_sum(double v) {
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 1);
+    auto step = [&](auto ctrl) {
+        constexpr int c = decltype(ctrl)::value;
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, c, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), c, 0xf, 0xf, false);
+        v += __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+    };
+    step(std::integral_constant<int, 0x128>{});  // row_ror:8
+    step(std::integral_constant<int, 0x124>{});  // row_ror:4
+    step(std::integral_constant<int, 0x122>{});  // row_ror:2
+    step(std::integral_constant<int, 0x121>{});  // row_ror:1
     return v;
 }
 
@@ -276,6 +288,102 @@ __global__ __launch_bounds__(256) void block_partials_reduce_kernel(const double
         __syncthreads();
     }
     if (threadIdx.x == 0) out[k] = sh[0];
+}
+
+// SWEEP_FIT with quarter boxes (round 4): fit = s (R (ref + mean + Q0 alpha - c) + c + t) as in sweep_kernel<SWEEP_FIT>, but a
+// workgroup owns whole 64-point QUARTERS of the fit -- sixteen 16-lane groups x four points each, the basis rows of all four
+// requested before the first is used -- and leaves the bounding box of each quarter behind, plus the largest |coordinate - centre|
+// of the cloud: what tile_bbox_kernel computed for the column-sum pass of the next iteration in a launch of its own (5 us + a kernel
+// boundary per iteration; exact minima / maxima, so the same bits).  KM >= rp / 16.
+template <int KM>
+__global__ __launch_bounds__(kSweepThreads) void sweep_fit_boxes_kernel(SweepArgs a) {
+    extern __shared__ double lds[];  // [rp] coefficients, then [16][8] box scratch + 8
+    const int tid = threadIdx.x, lane16 = tid & 15, grp = tid >> 4;
+    const int rp = a.rp, km = rp >> 4;
+    const int64_t M = a.M;
+    double *coef = lds, *red = lds + rp;
+    for (int k = tid; k < rp; k += kSweepThreads) coef[k] = a.coef0[k];
+    double R[9], tr[3], cen[3];
+    for (int q = 0; q < 9; ++q) R[q] = a.state->R[q];
+    for (int q = 0; q < 3; ++q) {
+        tr[q] = a.state->t[q];
+        cen[q] = a.state->center[q];
+    }
+    const double scale = a.state->scale;
+    double cf[KM];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < KM; ++m) cf[m] = m < km ? coef[m * 16 + lane16] : 0.0;
+    double amax = 0.0;
+    for (int64_t qd = blockIdx.x; qd * 64 < M; qd += gridDim.x) {
+        double u[4][3][KM], rm[4][3];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {  // every load of the quarter in flight
+            const int64_t p = qd * 64 + s * kGroups + grp;
+            const int64_t pc = p < M ? p : 0;
+            const double *q0 = a.Q0 + (3 * pc) * rp + lane16;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+#pragma unroll
+                for (int m = 0; m < KM; ++m) u[s][d][m] = m < km ? q0[d * rp + m * 16] : 0.0;
+                rm[s][d] = a.ref[d * M + pc] + a.mean[d * M + pc];
+            }
+        }
+        double lo[3] = {__builtin_huge_val(), __builtin_huge_val(), __builtin_huge_val()};
+        double hi[3] = {-__builtin_huge_val(), -__builtin_huge_val(), -__builtin_huge_val()};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int64_t p = qd * 64 + s * kGroups + grp;
+            double f[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                double acc = 0.0;
+#pragma unroll
+                for (int m = 0; m < KM; ++m) acc = __builtin_fma(u[s][d][m], cf[m], acc);  // (m >= km: 0 * 0)
+                f[d] = group16_sum(acc);
+            }
+            // fit = s * (R (inst - c) + c + t)       ModelFittingParameters.scala:130-143
+            const double ix = rm[s][0] + f[0] - cen[0], iy = rm[s][1] + f[1] - cen[1], iz = rm[s][2] + f[2] - cen[2];
+            const double nx = scale * (R[0] * ix + R[1] * iy + R[2] * iz + cen[0] + tr[0]);
+            const double ny = scale * (R[3] * ix + R[4] * iy + R[5] * iz + cen[1] + tr[1]);
+            const double nz = scale * (R[6] * ix + R[7] * iy + R[8] * iz + cen[2] + tr[2]);
+            if (p < M) {
+                if (lane16 == 0) {
+                    a.shape_out[p] = nx;
+                    a.shape_out[M + p] = ny;
+                    a.shape_out[2 * M + p] = nz;
+                }
+                // (fmin / fmax skip a NaN coordinate: it never widens a box, as in tile_bbox_kernel)
+                lo[0] = fmin(lo[0], nx), lo[1] = fmin(lo[1], ny), lo[2] = fmin(lo[2], nz);
+                hi[0] = fmax(hi[0], nx), hi[1] = fmax(hi[1], ny), hi[2] = fmax(hi[2], nz);
+            }
+        }
+        if (lane16 == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                red[grp * 8 + d] = lo[d];
+                red[grp * 8 + 3 + d] = hi[d];
+            }
+        }
+        __syncthreads();
+        if (tid < 6) {
+            double v = red[tid];
+            for (int g = 1; g < kGroups; ++g) v = tid < 3 ? fmin(v, red[g * 8 + tid]) : fmax(v, red[g * 8 + tid]);
+            a.qboxes[qd * 6 + tid] = v;
+            red[kGroups * 8 + tid] = fabs(v - a.box_centre[tid % 3]);
+        }
+        __syncthreads();
+        if (tid == 0)
+            for (int q = 0; q < 6; ++q) amax = fmax(amax, red[kGroups * 8 + q]);
+        __syncthreads();  // red is rewritten by the next quarter
+    }
+    if (tid == 0 && a.absmax_slot) {
+        // non-negative doubles order like their bit patterns; only a value above what is already there needs the atomic (the slot was
+        // cleared by an EARLIER launch on the stream: post_solve_kernel / state_init_kernel)
+        const unsigned long long mb = __builtin_bit_cast(unsigned long long, amax);
+        if (mb > __hip_atomic_load(reinterpret_cast<unsigned long long *>(a.absmax_slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(reinterpret_cast<unsigned long long *>(a.absmax_slot), mb);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------- weighted Gram
@@ -1933,6 +2041,7 @@ __global__ __launch_bounds__(512) void post_solve_kernel(PostSolveArgs A) {
     constexpr int ld = 37;
     const int r = A.r, rp = A.rp, tid = threadIdx.x;
     DevState *st = A.state;
+    if (tid == 0 && A.zero_slot) *A.zero_slot = 0.0;  // see SweepArgs::absmax_slot: the fit pass behind this kernel takes a maximum into it
     if (st->status == GINGR_FIT_MODEL_FLEXIBILITY_ERROR) return;  // a failed fit stays as it is (run stops, :149-157)
     const PostVec pvl{rp};
     // ---- column tid of every input vector: all loads in flight at once
@@ -2028,8 +2137,9 @@ __global__ __launch_bounds__(512) void post_solve_kernel(PostSolveArgs A) {
     }
 }
 
-__global__ void state_init_kernel(DevState *st, const gingr_state_scalars *h) {
+__global__ void state_init_kernel(DevState *st, const gingr_state_scalars *h, double *zero_slot) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (zero_slot) *zero_slot = 0.0;  // see SweepArgs::absmax_slot
     for (int q = 0; q < 3; ++q) {
         st->euler[q] = h->euler[q];
         st->center[q] = h->center[q];
@@ -2059,6 +2169,18 @@ int64_t sweep_ws_doubles(int64_t M, int32_t rp) {
 
 template <int MODE>
 static void launch_sweep_mode(gingr_ctx *ctx, const SweepArgs &a, int width) {
+    if (MODE == SWEEP_FIT && a.qboxes && a.rp <= 128) {  // one workgroup per 64-point quarter (gp.h: SweepArgs::qboxes)
+        const int nq = (int)std::min<int64_t>(4096, ceil_div(a.M, 64));
+        const size_t l2 = (size_t)(a.rp + kGroups * 8 + 8) * sizeof(double);
+        TimerScope ts(ctx, 4);
+        if (a.rp <= 64)
+            hipLaunchKernelGGL(sweep_fit_boxes_kernel<4>, dim3(nq), dim3(kSweepThreads), l2, ctx->stream, a);
+        else if (a.rp <= 112)  // (rank 100: 84 basis values per thread in flight; eight column blocks would spill into AGPRs)
+            hipLaunchKernelGGL(sweep_fit_boxes_kernel<7>, dim3(nq), dim3(kSweepThreads), l2, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(sweep_fit_boxes_kernel<8>, dim3(nq), dim3(kSweepThreads), l2, ctx->stream, a);
+        return;
+    }
     const int nb = sweep_num_blocks(a.M);
     const size_t lds = (size_t)(2 * a.rp + kGroups * (a.rp > 16 ? a.rp : 16)) * sizeof(double);
     TimerScope ts(ctx, 4);
@@ -2361,8 +2483,8 @@ void launch_small_gemm(gingr_ctx *ctx, int32_t r, int32_t rp, const double *A, c
 }
 
 
-void launch_state_init(gingr_ctx *ctx, DevState *st, const gingr_state_scalars *host_scalars_dev) {
-    hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, ctx->stream, st, host_scalars_dev);
+void launch_state_init(gingr_ctx *ctx, DevState *st, const gingr_state_scalars *host_scalars_dev, double *zero_slot) {
+    hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, ctx->stream, st, host_scalars_dev, zero_slot);
 }
 
 void launch_interp_pack(gingr_ctx *ctx, const double *Qs, int32_t rp, const int32_t *inv_src, const int32_t *ids, const double *w,

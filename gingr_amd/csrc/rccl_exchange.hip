@@ -1,0 +1,160 @@
+// Native RCCL exchange of the row-sharded update (one process per GPU): the library itself enqueues ncclAllReduce on the context's
+// stream between the phases of an iteration -- "RCCL all-reduce over xGMI for CPD column sums" (BASELINE.json north_star) with no
+// callback into the host, no stream hop and no Python between the kernels.  librccl is bound at run time (dlopen): a single-GPU
+// host never needs it, and a host that already carries one (torch ships its own librccl.so.1) shares that copy.
+// Reference: none -- the reference is single-process / single-device; the protocol is the one of
+// gingr_fitter_update_*_sharded_async (include/gingr_hip.h), the collective is RCCL's.
+#include "gp.h"
+
+#include <dlfcn.h>
+
+#include <mutex>
+
+namespace {
+
+// the six entry points used, with RCCL's C signatures (rccl.h): ncclResult_t is an int enum (0 = success), ncclComm_t a pointer,
+// ncclUniqueId 128 opaque bytes passed BY VALUE, ncclFloat64 = 8, ncclSum = 0
+struct UniqueId {
+    char internal[GINGR_RCCL_UNIQUE_ID_BYTES];
+};
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(UniqueId *) = nullptr;
+    int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
+    std::string path;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+
+int load_rccl(gingr_ctx *ctx, const char *path) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.handle) return GINGR_OK;
+    void *h = nullptr;
+    if (path && *path) {
+        h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!h) return gingr_set_error(ctx, GINGR_ERR_STATE, "rccl: cannot load %s: %s", path, dlerror());
+        g_rccl.path = path;
+    } else {
+        // the copy the process already carries (matched by SONAME), else the loader's search path
+        h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+        g_rccl.path = h ? "librccl.so.1 (already loaded in this process)" : "librccl.so.1";
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return gingr_set_error(ctx, GINGR_ERR_STATE, "rccl: librccl.so.1 not found (%s); pass its path to gingr_rccl_load", dlerror());
+    }
+    Rccl r;
+    r.handle = h;
+    r.path = g_rccl.path;
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(h, "ncclGetVersion"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) {
+        dlclose(h);
+        return gingr_set_error(ctx, GINGR_ERR_STATE, "rccl: %s lacks an entry point (ncclGetUniqueId / CommInitRank / CommDestroy / AllReduce)",
+                               r.path.c_str());
+    }
+    g_rccl = r;
+    return GINGR_OK;
+}
+
+int rccl_fail(gingr_ctx *ctx, const char *what, int rc) {
+    return gingr_set_error(ctx, GINGR_ERR_HIP, "rccl: %s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+}
+
+// the gingr_allreduce_fn of the native path: user = the context
+int native_allreduce(void *user, int32_t, void *device_ptr, int64_t count) {
+    gingr_ctx *ctx = static_cast<gingr_ctx *>(user);
+    const int rc = g_rccl.AllReduce(device_ptr, device_ptr, (size_t)count, /* ncclFloat64 */ 8, /* ncclSum */ 0, ctx->rccl_comm, ctx->stream);
+    if (rc != 0) {
+        (void)rccl_fail(ctx, "ncclAllReduce", rc);
+        return 1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+void gingr_ctx_rccl_release(gingr_ctx *ctx) {  // gingr_ctx_destroy
+    if (ctx->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->rccl_comm);
+    ctx->rccl_comm = nullptr;
+    ctx->rccl_world = 0;
+}
+
+extern "C" {
+
+int gingr_rccl_load(gingr_ctx *ctx, const char *librccl_path) {
+    if (!ctx) return GINGR_ERR_BAD_ARGUMENT;
+    return load_rccl(ctx, librccl_path);
+}
+
+int gingr_rccl_unique_id(gingr_ctx *ctx, void *id_bytes) {
+    if (!ctx || !id_bytes) return GINGR_ERR_BAD_ARGUMENT;
+    GINGR_TRY(load_rccl(ctx, nullptr));
+    UniqueId id;
+    memset(&id, 0, sizeof(id));
+    const int rc = g_rccl.GetUniqueId(&id);
+    if (rc != 0) return rccl_fail(ctx, "ncclGetUniqueId", rc);
+    memcpy(id_bytes, id.internal, sizeof(id.internal));
+    return GINGR_OK;
+}
+
+int gingr_ctx_rccl_init(gingr_ctx *ctx, const void *id_bytes, int32_t world, int32_t rank) {
+    if (!ctx || !id_bytes || world < 1 || rank < 0 || rank >= world)
+        return ctx ? gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "rccl_init: need 0 <= rank < world") : GINGR_ERR_BAD_ARGUMENT;
+    if (ctx->rccl_comm) return gingr_set_error(ctx, GINGR_ERR_STATE, "rccl_init: this context already has a communicator");
+    GINGR_TRY(load_rccl(ctx, nullptr));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    UniqueId id;
+    memcpy(id.internal, id_bytes, sizeof(id.internal));
+    void *comm = nullptr;
+    const int rc = g_rccl.CommInitRank(&comm, (int)world, id, (int)rank);
+    if (rc != 0) return rccl_fail(ctx, "ncclCommInitRank", rc);
+    ctx->rccl_comm = comm;
+    ctx->rccl_world = world;
+    ctx->rccl_rank = rank;
+    return GINGR_OK;
+}
+
+int gingr_ctx_rccl_info(gingr_ctx *ctx, int32_t *world, int32_t *rank, int32_t *version, char *library_path, int32_t path_capacity) {
+    if (!ctx) return GINGR_ERR_BAD_ARGUMENT;
+    if (world) *world = ctx->rccl_comm ? ctx->rccl_world : 0;
+    if (rank) *rank = ctx->rccl_comm ? ctx->rccl_rank : -1;
+    if (version) {
+        int v = 0;
+        if (g_rccl.GetVersion) (void)g_rccl.GetVersion(&v);
+        *version = v;
+    }
+    if (library_path && path_capacity > 0) snprintf(library_path, (size_t)path_capacity, "%s", g_rccl.path.c_str());
+    return GINGR_OK;
+}
+
+int gingr_ctx_rccl_allreduce_async(gingr_ctx *ctx, void *device_ptr, int64_t count) {
+    if (!ctx || !device_ptr || count < 0) return GINGR_ERR_BAD_ARGUMENT;
+    if (!ctx->rccl_comm) return gingr_set_error(ctx, GINGR_ERR_STATE, "rccl_allreduce: no communicator (gingr_ctx_rccl_init)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return native_allreduce(ctx, 0, device_ptr, count) == 0 ? GINGR_OK : GINGR_ERR_HIP;
+}
+
+int gingr_fitter_update_cpd_rccl_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t n_iterations) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = fitter_ctx(f);
+    if (!ctx->rccl_comm) return gingr_set_error(ctx, GINGR_ERR_STATE, "update_cpd_rccl: no communicator (gingr_ctx_rccl_init)");
+    return gingr_fitter_update_cpd_sharded_async(f, p, n_iterations, native_allreduce, ctx);
+}
+
+int gingr_fitter_update_icp_rccl_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = fitter_ctx(f);
+    if (!ctx->rccl_comm) return gingr_set_error(ctx, GINGR_ERR_STATE, "update_icp_rccl: no communicator (gingr_ctx_rccl_init)");
+    return gingr_fitter_update_icp_sharded_async(f, p, n_iterations, native_allreduce, ctx);
+}
+
+}  // extern "C"

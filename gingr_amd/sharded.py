@@ -10,9 +10,13 @@ sums in exchange segment p are all-reduced (sum, float64) across ranks:
 Everything after the posterior solve is replicated O(r^2) algebra on one-off moments of the basis (all-reduced once at
 model finalisation), so phase 2 needs no collective.
 
-The collective itself is plumbing: `torch.distributed.all_reduce` on a tensor that aliases the library's exchange
-buffer (backend "nccl" = RCCL over xGMI on the GPU box).  The r x r solve and the 3x3 SVD are replicated on every rank
-(deterministic, so no broadcast is needed).
+Two ways to run the collective:
+  * native (`rccl=True`, what bench.py --gpus N uses): the context owns an RCCL communicator (Context.rccl_init) and the LIBRARY
+    enqueues ncclAllReduce on its own stream between the phases (gingr_fitter_update_*_rccl_async) -- n iterations with no callback,
+    no stream hop and no Python between the kernels;
+  * host-driven (`all_reduce=callable`): `torch.distributed.all_reduce` (or anything else, e.g. gloo on host copies in the CPU test)
+    on a tensor that aliases the library's exchange buffer, called back once per exchange.
+The r x r solve and the 3x3 SVD are replicated on every rank (deterministic, so no broadcast is needed).
 """
 from __future__ import annotations
 
@@ -71,17 +75,22 @@ class ShardedFitter:
 
     def __init__(self, ctx: Context, model: PointDistributionModel, target, rank: int = 0, world: int = 1,
                  all_reduce: Optional[Callable] = None, global_transform: int = 1, step_length: float = 1.0,
-                 defer_setup: bool = False):
+                 defer_setup: bool = False, rccl: bool = False):
         self.ctx, self.rank, self.world = ctx, rank, world
         self._lib = ctx._lib
         self.all_reduce = all_reduce
+        self.rccl = bool(rccl)  # the context's own RCCL communicator does the exchanges (Context.rccl_init was called)
         self.begin, self.end = shard_rows(model.numberOfPoints, world, rank)
         self.dev_model = DeviceModel(ctx, model, self.begin, self.end)
         self.model = model
         self._target, self._opts = target, (global_transform, step_length)
         self.handle = None
         if not defer_setup:
-            if world > 1:
+            if self.rccl:  # (also with a one-rank communicator: the native path end to end)
+                ptr, n = self.dev_model.gram_exchange()
+                ctx.rccl_allreduce(ptr, n)
+                ctx.synchronize()
+            elif world > 1:
                 g = self.gram_tensor()
                 ctx.synchronize()
                 all_reduce(g)
@@ -193,6 +202,10 @@ class ShardedFitter:
         """n iterations; world > 1: ONE library call that runs the three phases per iteration and calls back for the two all-reduces
         (gingr_fitter_update_cpd_sharded_async) -- no Python between the kernels of an iteration except inside the collective."""
         p = nat.CpdParams(w, lambda_)
+        if self.rccl:
+            _check(self.ctx.handle, self._lib.gingr_fitter_update_cpd_rccl_async(self.handle, ctypes.byref(p), n_iterations),
+                   "gingr_fitter_update_cpd_rccl_async")
+            return
         if self.world == 1:
             _check(self.ctx.handle, self._lib.gingr_fitter_update_cpd_async(self.handle, ctypes.byref(p), n_iterations),
                    "gingr_fitter_update_cpd_async")
@@ -201,6 +214,10 @@ class ShardedFitter:
 
     def update_icp(self, initial_sigma: float, end_sigma: float, max_iterations: int, n_iterations: int = 1):
         p = nat.IcpParams(initial_sigma, end_sigma, max_iterations)
+        if self.rccl:
+            _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_rccl_async(self.handle, ctypes.byref(p), n_iterations),
+                   "gingr_fitter_update_icp_rccl_async")
+            return
         if self.world == 1:
             _check(self.ctx.handle, self._lib.gingr_fitter_update_icp_async(self.handle, ctypes.byref(p), n_iterations),
                    "gingr_fitter_update_icp_async")

@@ -372,6 +372,31 @@ int gingr_fitter_update_cpd_sharded_async(gingr_fitter *f, const gingr_cpd_param
 int gingr_fitter_update_icp_sharded_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations, gingr_allreduce_fn reduce,
                                           void *user);
 
+/* ---- native RCCL exchange: the row-sharded update with one process per GPU and the collective enqueued by the LIBRARY ------------
+ * BASELINE.json north_star: "the N x M affinity/distance matrix shards by reference-point rows across the 8 GPUs of one node with an
+ * RCCL all-reduce over xGMI for CPD column sums".  Every rank owns one context (one device, one stream), one row shard of the model
+ * and one fitter, as with gingr_fitter_update_*_sharded_async; here the two per-iteration all-reduces are ncclAllReduce calls the
+ * library itself places on the context's stream between the phase kernels -- n iterations are enqueued with no callback, no stream
+ * hop and no host synchronisation.  librccl is bound at run time (dlopen; a copy already loaded in the process -- e.g. torch's -- is
+ * shared), so a single-GPU host does not need it.
+ *   bootstrap: rank 0 calls gingr_rccl_unique_id (128 bytes), the HOST distributes them to all ranks (a JVM host: its own channel;
+ *   bench.py: the torch.distributed store), every rank calls gingr_ctx_rccl_init(ctx, id, world, rank) -- collective, returns when the
+ *   communicator of the `world` ranks exists.  The communicator belongs to the context and dies with it.
+ *   one-off: gingr_ctx_rccl_allreduce_async sums the basis moments (gingr_model_gram_exchange) before gingr_model_finalize.
+ *   per n iterations: gingr_fitter_update_{cpd,icp}_rccl_async.
+ * gingr_rccl_load (optional, before anything else): bind a specific librccl by path instead of the default search
+ * (already-loaded librccl.so.1, then the loader's path).  gingr_ctx_rccl_info: what was bound (diagnostics; any pointer may be NULL).
+ * Reference: none (the reference is single-process / single-device); the protocol is that of G/api/GingrAlgorithm.scala:192-254 on
+ * a row shard as in the host-driven section above. */
+#define GINGR_RCCL_UNIQUE_ID_BYTES 128
+int gingr_rccl_load(gingr_ctx *ctx, const char *librccl_path);
+int gingr_rccl_unique_id(gingr_ctx *ctx, void *id_bytes);
+int gingr_ctx_rccl_init(gingr_ctx *ctx, const void *id_bytes, int32_t world, int32_t rank);
+int gingr_ctx_rccl_info(gingr_ctx *ctx, int32_t *world, int32_t *rank, int32_t *version, char *library_path, int32_t path_capacity);
+int gingr_ctx_rccl_allreduce_async(gingr_ctx *ctx, void *device_ptr, int64_t count);
+int gingr_fitter_update_cpd_rccl_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t n_iterations);
+int gingr_fitter_update_icp_rccl_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations);
+
 /* ---- device group: the row-sharded update across the GPUs of ONE node from ONE host process (multi-GPU for a C / JVM host) ----
  * SURVEY.md section 8b "gingr_group_create(ndev, devs[], ...) wrapping the same calls with row-sharding".  The group owns one
  * context, one model shard (contiguous rows, the first M mod n shards hold one extra row) and one fitter per entry of `devices`;

@@ -456,6 +456,37 @@ JFN(jint, groupExchangeInfo)(JNIEnv *env, jclass, jlong g, jintArray out2) {
     }
     return rc;
 }
+
+// ---- native RCCL exchange (gingr_ctx_rccl_*): one JVM process per GPU, the library enqueues the collectives itself.  The 128 bytes
+// of the ncclUniqueId travel as int[32]; how rank 0's id reaches the other JVMs is the host's business (a socket, a file, MPI ...)
+JFN(jint, rcclUniqueId)(JNIEnv *env, jclass, jlong ctx, jintArray id32) {
+    Arr<int32_t> id(env, id32, false);
+    if (id.buf.size() * sizeof(int32_t) < GINGR_RCCL_UNIQUE_ID_BYTES) return GINGR_ERR_BAD_ARGUMENT;
+    return gingr_rccl_unique_id(P<gingr_ctx>(ctx), id.ptr());
+}
+JFN(jint, ctxRcclInit)(JNIEnv *env, jclass, jlong ctx, jintArray id32, jint world, jint rank) {
+    Arr<int32_t> id(env, id32, true);
+    if (id.buf.size() * sizeof(int32_t) < GINGR_RCCL_UNIQUE_ID_BYTES) return GINGR_ERR_BAD_ARGUMENT;
+    return gingr_ctx_rccl_init(P<gingr_ctx>(ctx), id.ptr(), world, rank);
+}
+// the one-off sum of the basis moments of a row-sharded model across the ranks (before modelFinalize)
+JFN(jint, ctxRcclAllreduceModelMoments)(JNIEnv *, jclass, jlong ctx, jlong model) {
+    void *p = nullptr;
+    int64_t n = 0;
+    const int rc = gingr_model_gram_exchange(P<gingr_model>(model), &p, &n);
+    if (rc != GINGR_OK) return rc;
+    const int rc2 = gingr_ctx_rccl_allreduce_async(P<gingr_ctx>(ctx), p, n);
+    return rc2 != GINGR_OK ? rc2 : gingr_ctx_synchronize(P<gingr_ctx>(ctx));
+}
+JFN(jint, fitterUpdateCpdRccl)(JNIEnv *, jclass, jlong f, jdouble w, jdouble lambda, jint n) {
+    const gingr_cpd_params p{w, lambda};
+    return gingr_fitter_update_cpd_rccl_async(P<gingr_fitter>(f), &p, n);
+}
+JFN(jint, fitterUpdateIcpRccl)(JNIEnv *, jclass, jlong f, jdouble initialSigma, jdouble endSigma, jint maxIterations, jint n) {
+    const gingr_icp_params p{initialSigma, endSigma, maxIterations};
+    return gingr_fitter_update_icp_rccl_async(P<gingr_fitter>(f), &p, n);
+}
+JFN(jint, ctxSetOption)(JNIEnv *, jclass, jlong ctx, jint option, jint value) { return gingr_ctx_set_option(P<gingr_ctx>(ctx), option, value); }
 #else
 // No JDK headers on this machine: the shim is not built (the C ABI it wraps is still covered by the Python tests).
 #endif

@@ -140,4 +140,16 @@ public final class GingrHipNative {
     public static native int groupSynchronize(long group);
     /** out2 = {physical devices behind the shards, 1 if the peer-read send buffers are fine-grained device memory} */
     public static native int groupExchangeInfo(long group, int[] out2);
+
+    // ---- native RCCL exchange: one JVM process per GPU, the library enqueues ncclAllReduce on the context's stream itself
+    // (gingr_ctx_rccl_*, include/gingr_hip.h).  id32 = the 128 bytes of the ncclUniqueId as int[32]: rank 0 creates it, the host
+    // application hands it to the other ranks (socket, file, MPI ...), every rank calls ctxRcclInit (collective).
+    public static native int rcclUniqueId(long ctx, int[] id32);
+    public static native int ctxRcclInit(long ctx, int[] id32, int world, int rank);
+    /** one-off: sum the basis moments of the row shards (between modelUpload of a shard and modelFinalize) */
+    public static native int ctxRcclAllreduceModelMoments(long ctx, long model);
+    public static native int fitterUpdateCpdRccl(long fitter, double w, double lambda, int nIterations);
+    public static native int fitterUpdateIcpRccl(long fitter, double initialSigma, double endSigma, int maxIterations, int nIterations);
+    /** gingr_ctx_option: 0 cull, 1 fine cull, 2 closest-point grid -- code paths with identical results (tests, timing comparisons) */
+    public static native int ctxSetOption(long ctx, int option, int value);
 }

@@ -39,6 +39,31 @@ def test_bench_launch_line_with_ranks_sharing_the_device(world, points):
     ex = out["exchange"]
     assert ex["segment0_column_sums_ms"] > 0.0 and ex["segment1_gram_bundle_ms"] > 0.0
     assert ex["bytes"]["segment0"] == 8 * points
+    assert ex["path"].startswith("gloo")            # two ranks on ONE device: RCCL cannot run here, the host-driven exchange does
+    # the same workload once more through the in-library device group, started by rank 0 after the ranks are done (one SCALE record
+    # then carries RCCL and the group side by side)
+    gm = out["group_mode"]
+    assert "error" not in gm, gm
+    assert gm["valid"] is True and gm["n_gpus"] == world and gm["ms_per_step"] > 0.0
+    assert gm["exchange"]["segment0_column_sums_ms"] > 0.0 and gm["exchange"]["path"].startswith("in-library device group")
+
+
+def test_bench_native_rccl_exchange_with_a_one_rank_communicator():
+    """`bench.py --force-dist` on one GPU: the N > 1 code path with a ONE-rank RCCL communicator owned by the library's context --
+    unique id, ncclCommInitRank, the one-off moment all-reduce and gingr_fitter_update_cpd_rccl_async (ncclAllReduce enqueued by the
+    library on the kernels' stream between the phases).  The measured state must pass the oracle parity check of the line."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GINGR_BENCH_SHARED_DEVICE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "4", "--warmup", "1", "--points", "6000",
+                        "--rank", "40", "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    ex = out["exchange"]
+    assert ex["path"] == "rccl-native"
+    assert ex["rccl"]["world"] == 1 and ex["rccl"]["rank"] == 0 and ex["rccl"]["version"] > 0 and "rccl" in ex["rccl"]["library"]
+    assert out["valid"] is True and out["parity_check"]["ok"], out["parity_check"]
+    assert "one process per GPU, rccl-native" in out["config"]["exchange"]
 
 
 def test_bench_group_mode_reports_the_exchange():

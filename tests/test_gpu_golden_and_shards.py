@@ -295,3 +295,34 @@ def test_two_logical_shards_through_sharded_fitter_update_itself(ctx):
     assert rel(fit, fit1) < 1e-9
     for c in ctxs:
         c.close()
+
+
+def test_native_rccl_exchange_equals_the_single_shard():
+    """The library's own RCCL exchange (Context.rccl_init + gingr_fitter_update_{cpd,icp}_rccl_async) with a one-rank communicator:
+    unique id, communicator, the one-off moment all-reduce and the two per-iteration ncclAllReduce calls on the context's stream must
+    leave exactly the state the plain single-shard update reaches (a one-rank in-place sum is the identity)."""
+    import gingr_amd as ga
+    from gingr_amd.sharded import ShardedFitter
+    from test_gpu_configs_and_edges import synth_model, to_ga
+    mo, rng = synth_model(3000, 24, seed=5)
+    target = mo.ref[rng.permutation(mo.M)[:2800]] + rng.normal(0, 0.5, (2800, 3))
+    states = {}
+    for mode in ("plain", "rccl"):
+        ctx = ga.Context(0)
+        if mode == "rccl":
+            ctx.rccl_init(ctx.rccl_unique_id(), 1, 0)
+            info = ctx.rccl_info()
+            assert info["world"] == 1 and info["rank"] == 0 and info["version"] > 0
+        f = ShardedFitter(ctx, to_ga(mo), target, rank=0, world=1, rccl=(mode == "rccl"))
+        f.set_state(np.zeros(mo.rank), 30.0)
+        f.update_cpd(0.1, 1.0, 3)
+        f.update_icp(2.0, 1.0, 10, 2)
+        ctx.synchronize()
+        a, sc, fit = f.get_state()
+        states[mode] = (a.copy(), float(sc.sigma2), int(sc.iteration), int(sc.status), fit.copy())
+        f.close()
+        ctx.close()
+    p, q = states["plain"], states["rccl"]
+    assert p[2] == q[2] == 5 and p[3] == q[3] == 0
+    assert np.max(np.abs(p[0] - q[0])) <= 1e-12 and abs(p[1] - q[1]) <= 1e-12 * abs(p[1])
+    assert np.max(np.abs(p[4] - q[4])) <= 1e-12 * np.max(np.abs(p[4]))
