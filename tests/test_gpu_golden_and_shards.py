@@ -303,8 +303,10 @@ def test_native_rccl_exchange_equals_the_single_shard():
     leave exactly the state the plain single-shard update reaches (a one-rank in-place sum is the identity)."""
     import gingr_amd as ga
     from gingr_amd.sharded import ShardedFitter
-    from test_gpu_configs_and_edges import synth_model, to_ga
-    mo, rng = synth_model(3000, 24, seed=5)
+    rng = np.random.default_rng(5)
+    ref = rng.normal(0, 50.0, (3000, 3)).astype(np.float32).astype(np.float64)
+    mo = go.build_gaussian_gpmm(ref, 70.0, 50.0, rel_tol=1e-12, max_rank=24)
+    to_ga = lambda m: ga.PointDistributionModel(m.ref, m.mean, m.U, m.lam)
     target = mo.ref[rng.permutation(mo.M)[:2800]] + rng.normal(0, 0.5, (2800, 3))
     states = {}
     for mode in ("plain", "rccl"):
