@@ -310,7 +310,39 @@ int gingr_nn(gingr_ctx *ctx, int64_t M, const double *query, int64_t N, const do
     HIP_TRY(ctx, dws.alloc((size_t)nn_ws_bytes(M, N)));
     HIP_TRY(ctx, didx.alloc(M * sizeof(int32_t)));
     HIP_TRY(ctx, dd2.alloc(M * sizeof(double)));
-    launch_nn(ctx, cq, ct, nullptr, nullptr, dws.p, didx.as<int32_t>(), dd2.as<double>());
+    // From a few thousand targets on the search runs over a uniform grid of the target cloud, built here on the host from the
+    // caller's array (round 4: the grid search of the fitter's ICP path, nn_grid.hip, for the stateless call as well -- the tile scan
+    // alone is one round of ~80 short workgroups at 5 000 x 5 000, 29.7 us, 25 M distance tests; the grid search tests ~15 targets per
+    // query).  Queries the grid cannot certify are flagged and answered by the masked tile scan behind it, which exits at once when
+    // there are none.  Same distances, same lowest-index tie rule: the indices are bit-identical either way (GINGR_OPT_NN_GRID = 0
+    // keeps the scan alone; tests/test_gpu_nn_grid.py compares the two).
+    NNGrid grid;
+    if (ctx->nn_grid && ctx->cull && N >= 2048 && M >= 256) {
+        std::vector<int32_t> ident((size_t)N);
+        for (int64_t k = 0; k < N; ++k) ident[(size_t)k] = (int32_t)k;
+        const int rc = nn_grid_build(ctx, target, N, ident.data(), M, &grid);
+        if (rc != GINGR_OK) {
+            nn_grid_free(&grid);
+            return rc;
+        }
+    }
+    if (grid.ready) {
+        launch_nn_grid(ctx, cq, ct, nullptr, grid, nullptr, didx.as<int32_t>(), dd2.as<double>());
+        launch_nn(ctx, cq, ct, nullptr, nullptr, dws.p, didx.as<int32_t>(), dd2.as<double>(), nullptr, grid.flag, grid.cur_nflag());
+    } else {
+        launch_nn(ctx, cq, ct, nullptr, nullptr, dws.p, didx.as<int32_t>(), dd2.as<double>());
+    }
+    const int launch_rc = check_launch(ctx);
+    if (launch_rc != GINGR_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        nn_grid_free(&grid);
+        return launch_rc;
+    }
+    {
+        const hipError_t se = hipStreamSynchronize(ctx->stream);  // the grid's device arrays are freed below
+        nn_grid_free(&grid);
+        HIP_TRY(ctx, se);
+    }
     GINGR_TRY(check_launch(ctx));
     std::vector<double> hd2((size_t)M);
     if (idx) HIP_TRY(ctx, hipMemcpyAsync(idx, didx.p, M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

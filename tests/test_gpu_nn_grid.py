@@ -147,8 +147,11 @@ def test_benchmark_size_against_the_stateless_tile_scan(ctx):
     """50k <-> 50k (bench.py's clouds): the fitter's search (grid + masked tile scan, warm-started) must give the indices of the stateless
     gingr_nn (tile scan from scratch, no grid) -- two exact searches of different structure, so equal indices including every tie."""
     import gingr_amd as ga
+    from gingr_amd import _native as nat
     from bench import synth_clouds
     y, x = synth_clouds(50000)
+    scan = ga.Context(0)
+    scan.set_option(nat.OPT_NN_GRID, 0)     # the stateless call searches the grid too since round 4: this context keeps the tile scan alone
     rng = np.random.default_rng(2)
     r = 8
     U, _ = np.linalg.qr(rng.normal(0, 1, (3 * y.shape[0], r)))
@@ -159,10 +162,39 @@ def test_benchmark_size_against_the_stateless_tile_scan(ctx):
     for it in range(3):
         fit_before = np.array(state.general.fit)
         state = algo.update(state)
-        want, _, _ = ctx.nn(fit_before, x)
+        want, wd2, _ = scan.nn(fit_before, x)
         got = algo.last_correspondence_indices()
         assert np.array_equal(got, want), (it, int(np.sum(got != want)))
+        # ... and the stateless call with its own grid (built per call from the caller's arrays, no warm start): the same again
+        again, ad2, _ = ctx.nn(fit_before, x)
+        assert np.array_equal(again, want) and np.array_equal(ad2, wd2), it
     algo.close()
+    scan.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_stateless_grid_search_equals_the_tile_scan(ctx, seed):
+    """gingr_nn with and without the grid on awkward inputs (ties on a lattice, a flat cloud, far queries, NaN queries): identical
+    indices and distances; below the size threshold both take the scan."""
+    import gingr_amd as ga
+    from gingr_amd import _native as nat
+    rng = np.random.default_rng(100 + seed)
+    n = 4096
+    if seed % 3 == 0:
+        target = np.stack(np.meshgrid(np.arange(16.0), np.arange(16.0), np.arange(16.0), indexing="ij"), -1).reshape(-1, 3)   # lattice: ties
+    elif seed % 3 == 1:
+        target = np.concatenate([rng.normal(0, 30, (n, 2)), np.zeros((n, 1))], 1)                                             # flat
+    else:
+        target = rng.normal(0, 40, (n, 3)).astype(np.float32).astype(np.float64)
+    query = np.concatenate([target[rng.integers(0, n, 1500)] + rng.normal(0, 0.7, (1500, 3)),      # near the cloud
+                            np.round(rng.uniform(0, 15, (600, 3)) * 2) / 2,                        # half-integer points: exact ties on the lattice
+                            rng.normal(0, 1, (50, 3)) * 1e4])                                      # far away
+    scan = ga.Context(0)
+    scan.set_option(nat.OPT_NN_GRID, 0)
+    want, wd2, wmd = scan.nn(query, target)
+    got, gd2, gmd = ctx.nn(query, target)
+    assert np.array_equal(got, want) and np.array_equal(gd2, wd2) and gmd == wmd
+    scan.close()
 
 
 def test_heaps_of_coincident_targets(ctx):
