@@ -19,6 +19,8 @@ GINGR_OK = 0
 ERR_BAD_ARGUMENT, ERR_HIP, ERR_NONFINITE, ERR_NOT_SPD, ERR_NO_DEVICE, ERR_STATE = 1, 2, 3, 4, 5, 6
 NUM_PHASES = 3
 NUM_SEGMENTS = 2
+SEGMENT_FULLFIT = 2   # the gather of a sharded surface update (gingr_hip.h)
+FLAVOUR_CPD, FLAVOUR_ICP, FLAVOUR_ICP_SURFACE = 0, 1, 2
 RCCL_UNIQUE_ID_BYTES = 128
 
 _STATUS_NAMES = {
@@ -142,6 +144,15 @@ SIGNATURES = {
     "gingr_fitter_update_cpd_sharded_async": (c_int, [c_void_p, POINTER(CpdParams), c_int32, ALLREDUCE_FN, c_void_p]),
     "gingr_fitter_update_icp_sharded_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32, ALLREDUCE_FN, c_void_p]),
     "gingr_fitter_icp_phase_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32]),
+    "gingr_fitter_update_sharded_async": (c_int, [c_void_p, c_int32, POINTER(CpdParams), POINTER(IcpParams), c_int32, _dp, ALLREDUCE_FN, c_void_p]),
+    "gingr_fitter_posterior_logpdf_sharded": (c_int, [c_void_p, c_int32, POINTER(CpdParams), POINTER(IcpParams), _dp, ALLREDUCE_FN, c_void_p, _dp]),
+    "gingr_fitter_fullfit_exchange": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),
+    "gingr_fitter_update_rccl_async": (c_int, [c_void_p, c_int32, POINTER(CpdParams), POINTER(IcpParams), c_int32, _dp]),
+    "gingr_fitter_posterior_logpdf_rccl": (c_int, [c_void_p, c_int32, POINTER(CpdParams), POINTER(IcpParams), _dp, _dp]),
+    "gingr_group_set_meshes": (c_int, [c_void_p, c_int64, _ip, c_int64, _ip]),
+    "gingr_group_set_surface_method": (c_int, [c_void_p, c_int32]),
+    "gingr_group_update_async": (c_int, [c_void_p, c_int32, POINTER(CpdParams), POINTER(IcpParams), c_int32, _dp]),
+    "gingr_group_posterior_logpdf": (c_int, [c_void_p, c_int32, POINTER(CpdParams), POINTER(IcpParams), _dp, _dp]),
     "gingr_rccl_load": (c_int, [c_void_p, c_char_p]),
     "gingr_rccl_unique_id": (c_int, [c_void_p, c_void_p]),
     "gingr_ctx_rccl_init": (c_int, [c_void_p, c_void_p, c_int32, c_int32]),

@@ -1576,7 +1576,7 @@ void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_
     plan_nn(query.n, target.n, pruned, &nch, &len);
     // masked (the leftovers of the grid search, normally none): one chunk from 4096 queries on, and then the scan kernel writes the
     // answers itself -- one launch that exits at once instead of two
-    if (mask && query.n >= 4096) nch = 1, len = round_up(target.n, kTile);
+    if (mask && pruned && query.n >= 4096) nch = 1, len = round_up(target.n, kTile);
     const bool direct = mask && nch == 1;
     double *pd2 = reinterpret_cast<double *>(ws);
     int32_t *pidx = reinterpret_cast<int32_t *>(pd2 + (int64_t)nch * query.n);

@@ -211,8 +211,9 @@ void launch_chol_block64(gingr_ctx *ctx, double *Aw, int64_t ld, int k, double *
 int distance_stats_ws_doubles();
 void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const int32_t *orig, int64_t orig_limit, const int32_t *nn,
                            const int32_t *boundary, double sdev, double *partial, double *out4);
+// mesh (nullable): the cloud the triangles index when it is not the query cloud itself (row shard: the gathered fit of all shards)
 void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, const int32_t *tri, int64_t T, const double *boxes,
-                           const int32_t *skip, int32_t *flag, const double *tribox = nullptr);
+                           const int32_t *skip, int32_t *flag, const double *tribox = nullptr, const Cloud *mesh = nullptr);
 // found (nullable): along-normal flavour, 0 = no intersection (rejected)
 void launch_surface_prereject(gingr_ctx *ctx, int64_t M, const int32_t *nn_vertex, const int32_t *tgt_boundary,
                               const double *fit_vn, const double *tgt_vn, int64_t N, const int32_t *found, int32_t *pre);

@@ -303,32 +303,48 @@ int gingr_nn(gingr_ctx *ctx, int64_t M, const double *query, int64_t N, const do
     if (M < 1 || N < 1 || !query || !target) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "nn: M, N must be >= 1");
     if (N > INT32_MAX) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "nn: N exceeds int32 index range");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf sq, st, dq, dt, dws, didx, dd2;
+    DevBuf sq, st, dq, dt, dws, didx, dd2, dperm, dboxes;
     Cloud cq, ct;
     GINGR_TRY(upload_cloud(ctx, M, query, sq, dq, &cq));
-    GINGR_TRY(upload_cloud(ctx, N, target, st, dt, &ct));
-    HIP_TRY(ctx, dws.alloc((size_t)nn_ws_bytes(M, N)));
-    HIP_TRY(ctx, didx.alloc(M * sizeof(int32_t)));
-    HIP_TRY(ctx, dd2.alloc(M * sizeof(double)));
     // From a few thousand targets on the search runs over a uniform grid of the target cloud, built here on the host from the
     // caller's array (round 4: the grid search of the fitter's ICP path, nn_grid.hip, for the stateless call as well -- the tile scan
-    // alone is one round of ~80 short workgroups at 5 000 x 5 000, 29.7 us, 25 M distance tests; the grid search tests ~15 targets per
-    // query).  Queries the grid cannot certify are flagged and answered by the masked tile scan behind it, which exits at once when
-    // there are none.  Same distances, same lowest-index tie rule: the indices are bit-identical either way (GINGR_OPT_NN_GRID = 0
-    // keeps the scan alone; tests/test_gpu_nn_grid.py compares the two).
+    // alone is one round of ~80 short workgroups at 5 000 x 5 000, 29.7 us, 25 M distance tests).  As in the fitter the targets then
+    // live in the spatial (k-d leaf) order on the device, with their tile boxes: queries the grid cannot certify are flagged and
+    // answered by the masked, box-pruned tile scan behind it, which exits at once when there are none.  Same distances, same
+    // lowest-original-index tie rule: the indices are bit-identical either way (GINGR_OPT_NN_GRID = 0 keeps the scan alone;
+    // tests/test_gpu_nn_grid.py compares the two).
+    const bool use_grid = ctx->nn_grid && ctx->cull && N >= 2048 && M >= 256;
+    std::vector<int32_t> perm;
     NNGrid grid;
-    if (ctx->nn_grid && ctx->cull && N >= 2048 && M >= 256) {
-        std::vector<int32_t> ident((size_t)N);
-        for (int64_t k = 0; k < N; ++k) ident[(size_t)k] = (int32_t)k;
-        const int rc = nn_grid_build(ctx, target, N, ident.data(), M, &grid);
+    if (use_grid) {
+        morton_order(target, N, perm);
+        HIP_TRY(ctx, st.alloc((size_t)N * 3 * sizeof(double)));
+        HIP_TRY(ctx, dt.alloc((size_t)N * 3 * sizeof(double)));
+        HIP_TRY(ctx, dperm.alloc((size_t)N * sizeof(int32_t)));
+        HIP_TRY(ctx, dboxes.alloc((size_t)ceil_div(N, 256) * 30 * sizeof(double)));
+        HIP_TRY(ctx, hipMemcpyAsync(st.p, target, (size_t)N * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dperm.p, perm.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        launch_aos_to_soa(ctx, st.as<double>(), N, dt.as<double>(), dperm.as<int32_t>());
+        double *sp = dt.as<double>();
+        ct = Cloud{sp, sp + N, sp + 2 * N, N};
+        launch_tile_bbox(ctx, ct, dboxes.as<double>());
+        const int rc = nn_grid_build(ctx, target, N, perm.data(), M, &grid);
         if (rc != GINGR_OK) {
             nn_grid_free(&grid);
             return rc;
         }
+    } else {
+        GINGR_TRY(upload_cloud(ctx, N, target, st, dt, &ct));
     }
+    HIP_TRY(ctx, dws.alloc((size_t)nn_ws_bytes(M, N)));
+    HIP_TRY(ctx, didx.alloc(M * sizeof(int32_t)));
+    HIP_TRY(ctx, dd2.alloc(M * sizeof(double)));
     if (grid.ready) {
-        launch_nn_grid(ctx, cq, ct, nullptr, grid, nullptr, didx.as<int32_t>(), dd2.as<double>());
-        launch_nn(ctx, cq, ct, nullptr, nullptr, dws.p, didx.as<int32_t>(), dd2.as<double>(), nullptr, grid.flag, grid.cur_nflag());
+        launch_nn_grid(ctx, cq, ct, dperm.as<int32_t>(), grid, nullptr, didx.as<int32_t>(), dd2.as<double>());
+        launch_nn(ctx, cq, ct, dperm.as<int32_t>(), dboxes.as<double>(), dws.p, didx.as<int32_t>(), dd2.as<double>(), nullptr, grid.flag,
+                  grid.cur_nflag());
+    } else if (use_grid) {  // (no grid could be built: degenerate extents) the box-pruned scan over the ordered cloud
+        launch_nn(ctx, cq, ct, dperm.as<int32_t>(), dboxes.as<double>(), dws.p, didx.as<int32_t>(), dd2.as<double>());
     } else {
         launch_nn(ctx, cq, ct, nullptr, nullptr, dws.p, didx.as<int32_t>(), dd2.as<double>());
     }
@@ -343,12 +359,13 @@ int gingr_nn(gingr_ctx *ctx, int64_t M, const double *query, int64_t N, const do
         nn_grid_free(&grid);
         HIP_TRY(ctx, se);
     }
-    GINGR_TRY(check_launch(ctx));
     std::vector<double> hd2((size_t)M);
     if (idx) HIP_TRY(ctx, hipMemcpyAsync(idx, didx.p, M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(hd2.data(), dd2.p, M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (d2) memcpy(d2, hd2.data(), M * sizeof(double));
+    if (idx && use_grid)  // positions in the ordered cloud -> the caller's numbering
+        for (int64_t i = 0; i < M; ++i) idx[i] = (idx[i] >= 0 && idx[i] < N) ? perm[(size_t)idx[i]] : -1;
     if (mean_distance) {
         // distance += (p - closestPoint).norm in index order; / numberOfPoints    ClosestPointRegistrator.scala:143,146
         double s = 0.0;

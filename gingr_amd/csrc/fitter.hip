@@ -122,6 +122,13 @@ struct gingr_fitter {
     // host that all-reduces xch in place -- torch.distributed).  The device group (group.hip) points it at the shard's send
     // buffer: peers read that while the summed result lands in xch, so nobody overwrites what a peer may still be reading.
     double *partial_out = nullptr;
+    // Row-sharded surface ICP: the tests against the template itself (vertex normals, self-intersection) need the WHOLE posed template,
+    // so every iteration starts with a gather -- each shard contributes its rows of the fit to a [3][M_total] buffer in ORIGINAL
+    // point order (zeros elsewhere), the buffers are summed across the shards (exchange segment 2: an all-gather spelled as the
+    // all-reduce the other segments already use) -- and the template triangles index that buffer.  partial_fullfit: where the
+    // contribution goes when the sum lands elsewhere (device group); nullptr = in place.
+    double *fullfit = nullptr, *partial_fullfit = nullptr;
+    bool sharded() const { return m->M != m->M_total; }
     int32_t *retry = nullptr;  // device word: retryCounter of the algorithm instance this fitter stands for (GingrAlgorithm.scala:69-70)
 };
 
@@ -136,6 +143,18 @@ __global__ __launch_bounds__(256) void swap_segments_kernel(double *__restrict__
     const double va = a[i], vb = b[i];
     a[i] = vb;
     if (exchange) b[i] = va;
+}
+
+// full[d][g] = this shard's fit of original point g (device position iperm[g - row_begin]) or 0 for the points of other shards
+__global__ __launch_bounds__(256) void fit_contribution_kernel(const double *__restrict__ fit, const int32_t *__restrict__ iperm, int64_t M,
+                                                               int64_t row_begin, int64_t M_total, double *__restrict__ full) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= M_total) return;
+    const int64_t l = g - row_begin;
+    const bool mine = l >= 0 && l < M;
+    const int64_t pos = mine ? iperm[l] : 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) full[d * M_total + g] = mine ? fit[d * M + pos] : 0.0;
 }
 
 template <typename T>
@@ -340,8 +359,9 @@ int model_create_impl(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doubl
         morton_order(pts.data(), M, m->hperm);
         m->hiperm.resize((size_t)M);
         for (int64_t sidx = 0; sidx < M; ++sidx) m->hiperm[(size_t)m->hperm[(size_t)sidx]] = (int32_t)sidx;
-        if ((rc = dev_alloc(ctx, &m->perm, (size_t)M))) return fail(rc);
-        if (hipMemcpy(m->perm, m->hperm.data(), (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+        if ((rc = dev_alloc(ctx, &m->perm, (size_t)M)) || (rc = dev_alloc(ctx, &m->iperm, (size_t)M))) return fail(rc);
+        if (hipMemcpy(m->perm, m->hperm.data(), (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(m->iperm, m->hiperm.data(), (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
             return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: permutation copy failed"));
     }
     if ((rc = fill_basis(m))) return fail(rc);
@@ -391,6 +411,10 @@ int model_create_impl(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doubl
     // host moments of p~ over the FULL model (identical on every shard)
     for (int q = 0; q < 9; ++q) m->Pp[q] = 0.0;
     for (int q = 0; q < 3; ++q) m->Ps[q] = 0.0;
+    if (M != M_total) {  // a shard keeps the mean shape of the whole model on the host (gingr_fitter_set_meshes: triangle order)
+        m->h_full_pts.resize((size_t)3 * M_total);
+        for (int64_t i = 0; i < 3 * M_total; ++i) m->h_full_pts[(size_t)i] = ref[i] + mean[i];
+    }
     for (int64_t i = 0; i < M_total; ++i) {
         double pt[3];
         for (int d = 0; d < 3; ++d) pt[d] = ref[3 * i + d] + mean[3 * i + d] - m->c0[d];
@@ -447,6 +471,7 @@ void gingr_model_destroy(gingr_model *m) {
     dev_free(m->cmat);
     dev_free(m->pvec);
     dev_free(m->perm);
+    dev_free(m->iperm);
     delete m;
 }
 
@@ -562,6 +587,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->fboxes);
     dev_free(f->tile_bad);
     dev_free(f->xch);
+    dev_free(f->fullfit);
     dev_free(f->ws);
     dev_free(f->work);
     dev_free(f->aos);
@@ -603,7 +629,7 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
     GINGR_TRY(dev_alloc(ctx, &f->Pt1, (size_t)N));
     // exchange segments (float64 elements)
     f->cnt[0] = N;
-    f->cnt[1] = (int64_t)rp * rp + rp + 8;
+    f->cnt[1] = (int64_t)rp * rp + rp + 8 + rp;  // G, rhs, the scalar sums, and Q0^T e of a sharded transition-density query
     int64_t o = 0;
     for (int s = 0; s < GINGR_NUM_SEGMENTS; ++s) {
         f->off[s] = o;
@@ -889,6 +915,15 @@ static void nearest_target_vertex(gingr_ctx *ctx, gingr_fitter *f, Cloud query, 
 
 // --------------------------------------------------------------------------------------------------- internal hooks (group.hip)
 void fitter_set_partial_output(gingr_fitter *f, double *base) { f->partial_out = base; }
+void fitter_set_partial_fullfit(gingr_fitter *f, double *base) { f->partial_fullfit = base; }
+double *fitter_fullfit(gingr_fitter *f) { return f->fullfit; }
+void fitter_set_zrand(gingr_fitter *f, const double *z) {  // (pageable source: consumed when the copy call returns)
+    f->zrand_active = z != nullptr;
+    if (!z) return;
+    std::vector<double> zz((size_t)f->m->rp, 0.0);
+    memcpy(zz.data(), z, (size_t)f->m->r * sizeof(double));
+    (void)hipMemcpyAsync(f->zrand, zz.data(), zz.size() * sizeof(double), hipMemcpyHostToDevice, f->ctx->stream);
+}
 gingr_ctx *fitter_ctx(gingr_fitter *f) { return f->ctx; }
 const gingr_model *fitter_model(gingr_fitter *f) { return f->m; }
 
@@ -913,6 +948,15 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
     double *sc8w = rhsw + rp;
     const Cloud fit = cloud_of(f->fit, M);
     const Cloud tgt = cloud_of(f->target, f->N);
+    if (phase == GINGR_PHASE_GATHER) {  // sharded surface ICP: this shard's rows of the fit into the full-fit buffer (gingr_fitter::fullfit)
+        if (!f->sharded()) return GINGR_OK;
+        if (!f->fullfit) return gingr_set_error(ctx, GINGR_ERR_STATE, "gather phase: no meshes set (gingr_fitter_set_meshes)");
+        hipLaunchKernelGGL(fit_contribution_kernel, dim3((unsigned)ceil_div(m->M_total, 256)), dim3(256), 0, ctx->stream, f->fit, m->iperm, M,
+                           m->row_begin, m->M_total, f->partial_fullfit ? f->partial_fullfit : f->fullfit);
+        return check_launch(ctx);
+    }
+    // the template mesh of the surface tests: the fit itself, or -- on a row shard -- the gathered fit of all shards (original order)
+    const Cloud meshc = f->sharded() && f->fullfit ? cloud_of(f->fullfit, m->M_total) : fit;
     // posterior memo (see gingr_fitter::Key): skip phases 0 and 1 when their results for exactly this state are still in place
     if (phase == 0) {
         f->skip_phase1 = false;
@@ -973,6 +1017,8 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
     }
     switch (phase) {
         case 0: {
+            if (icp && f->reversed && f->sharded())
+                return gingr_set_error(ctx, GINGR_ERR_STATE, "reversed correspondence direction: single shard only");
             if (icp && f->reversed) {
                 // closestPointCorrespondenceReversal (ClosestPointRegistrator.scala:34-49): the roles of the two meshes are swapped,
                 // then every accepted target vertex becomes an observation of the template vertex nearest to its match
@@ -1000,9 +1046,9 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 }
             } else if (icp && f->icp_surface) {
                 // ClosestPointTriangleMesh3D.closestPointCorrespondence (ClosestPointRegistrator.scala:75-100)
-                launch_cell_normals(ctx, fit, f->mtri, f->Tm, f->mcn);
+                launch_cell_normals(ctx, meshc, f->mtri, f->Tm, f->mcn);
                 launch_vertex_normals(ctx, f->madj_ptr, f->madj_tri, f->mcn, f->Tm, M, f->mvn);
-                launch_tri_tile_bbox(ctx, fit, f->mtri, f->Tm, f->mtboxes, f->mtribox);
+                launch_tri_tile_bbox(ctx, meshc, f->mtri, f->Tm, f->mtboxes, f->mtribox);
                 const bool along = f->surface_method == 1;  // ClosestPointAlongNormalTriangleMesh3D (:102-131)
                 if (along)
                     launch_line_nearest(ctx, fit, f->mvn, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, f->surf_cp, f->surf_hit);
@@ -1016,7 +1062,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 f->surf_nn_warm = true;
                 launch_surface_prereject(ctx, M, f->surf_nn, f->tboundary, f->mvn, f->tvn, f->N, along ? f->surf_hit : nullptr,
                                          f->surf_pre);
-                launch_self_intersect(ctx, fit, f->surf_cp, f->mtri, f->Tm, f->mtboxes, f->surf_pre, f->surf_hit, f->mtribox);
+                launch_self_intersect(ctx, fit, f->surf_cp, f->mtri, f->Tm, f->mtboxes, f->surf_pre, f->surf_hit, f->mtribox, &meshc);
                 launch_surface_weight(ctx, M, f->surf_pre, f->surf_hit, &f->st->sigma2, f->surf_w01, f->surf_win);
             } else if (icp) {
                 nearest_target_vertex(ctx, f, fit, tgt, f->nn_idx, f->nn_d2, f->nn_warm);
@@ -1197,36 +1243,80 @@ int gingr_fitter_update_icp_async(gingr_fitter *f, const gingr_icp_params *p, in
     return GINGR_OK;
 }
 
-static int sharded_update(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations,
-                          gingr_allreduce_fn reduce, void *user) {
+}  // extern "C"
+
+// One phase of flavour 0 CPD / 1 ICP point cloud / 2 ICP surface (GINGR_PHASE_GATHER included)
+int fitter_run_phase(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int phase) {
+    if (flavour == 0) return gingr_fitter_cpd_phase_async(f, cp, phase);
+    if (flavour == 1) return gingr_fitter_icp_phase_async(f, ip, phase);
+    return gingr_fitter_icp_surface_phase_async(f, ip, phase);
+}
+
+// The row-sharded update of any flavour, deterministic (z == nullptr) or with a sampled proposal (z: rank standard normals, one
+// iteration): per iteration [surface: gather phase, all-reduce of the full fit], phase 0, [CPD: all-reduce of the column sums],
+// phase 1, all-reduce of the Gram bundle, phase 2.  The posterior solve, the sample a + L^-T z and everything behind them are
+// replicated r x r algebra, so z is the same on every shard and nothing else is exchanged.
+int fitter_sharded_update(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations,
+                          const double *z, gingr_allreduce_fn reduce, void *user) {
     GINGR_TRY(check_ready(f));
-    if (n_iterations < 0 || !reduce) return gingr_set_error(f->ctx, GINGR_ERR_BAD_ARGUMENT, "sharded update: bad arguments");
-    if (f->partial_out) return gingr_set_error(f->ctx, GINGR_ERR_STATE, "sharded update: this fitter belongs to a device group");
-    for (int32_t it = 0; it < n_iterations; ++it) {
-        TimerScope ts(f->ctx, 3);
-        for (int ph = 0; ph < GINGR_NUM_PHASES; ++ph) {
-            GINGR_TRY(icp ? gingr_fitter_icp_phase_async(f, ip, ph) : gingr_fitter_cpd_phase_async(f, cp, ph));
-            if (ph < GINGR_NUM_SEGMENTS && !(icp && ph == 0)) {
-                TimerScope tx(f->ctx, 6 + ph);  // the exchange of segment ph as this shard sees it (includes waiting for the peers)
+    gingr_ctx *ctx = f->ctx;
+    if (n_iterations < 0 || !reduce || flavour < 0 || flavour > 2) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "sharded update: bad arguments");
+    if (f->partial_out) return gingr_set_error(ctx, GINGR_ERR_STATE, "sharded update: this fitter belongs to a device group");
+    if (z && n_iterations != 1) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "sharded update: a sampled proposal is one iteration");
+    const int32_t r = f->m->r, rp = f->m->rp;
+    if (z) {  // (pageable on purpose, see sample_update)
+        std::vector<double> zz((size_t)rp, 0.0);
+        memcpy(zz.data(), z, (size_t)r * sizeof(double));
+        HIP_TRY(ctx, hipMemcpyAsync(f->zrand, zz.data(), (size_t)rp * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    f->zrand_active = z != nullptr;
+    int rc = GINGR_OK;
+    for (int32_t it = 0; it < n_iterations && rc == GINGR_OK; ++it) {
+        TimerScope ts(ctx, 3);
+        if (flavour == 2 && f->sharded()) {
+            rc = fitter_run_phase(f, flavour, cp, ip, GINGR_PHASE_GATHER);
+            if (!rc && reduce(user, GINGR_SEGMENT_FULLFIT, f->fullfit, 3 * f->m->M_total) != 0)
+                rc = gingr_set_error(ctx, GINGR_ERR_STATE, "sharded update: the all-reduce callback failed (full fit)");
+        }
+        for (int ph = 0; ph < GINGR_NUM_PHASES && rc == GINGR_OK; ++ph) {
+            rc = fitter_run_phase(f, flavour, cp, ip, ph);
+            if (!rc && ph < GINGR_NUM_SEGMENTS && !(flavour != 0 && ph == 0)) {
+                TimerScope tx(ctx, 6 + ph);  // the exchange of segment ph as this shard sees it (includes waiting for the peers)
                 if (reduce(user, ph, f->xch + f->off[ph], f->cnt[ph]) != 0)
-                    return gingr_set_error(f->ctx, GINGR_ERR_STATE, "sharded update: the all-reduce callback failed (segment %d)", ph);
+                    rc = gingr_set_error(ctx, GINGR_ERR_STATE, "sharded update: the all-reduce callback failed (segment %d)", ph);
             }
         }
     }
-    return GINGR_OK;
+    f->zrand_active = false;
+    return rc;
 }
+
+extern "C" {
 
 int gingr_fitter_update_cpd_sharded_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t n_iterations, gingr_allreduce_fn reduce,
                                           void *user) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
-    return sharded_update(f, false, p, nullptr, n_iterations, reduce, user);
+    return fitter_sharded_update(f, 0, p, nullptr, n_iterations, nullptr, reduce, user);
 }
 
 int gingr_fitter_update_icp_sharded_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations, gingr_allreduce_fn reduce,
                                           void *user) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
-    f->icp_surface = false;
-    return sharded_update(f, true, nullptr, p, n_iterations, reduce, user);
+    return fitter_sharded_update(f, 1, nullptr, p, n_iterations, nullptr, reduce, user);
+}
+
+int gingr_fitter_update_sharded_async(gingr_fitter *f, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,
+                                      int32_t n_iterations, const double *z, gingr_allreduce_fn reduce, void *user) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    return fitter_sharded_update(f, flavour, cp, ip, n_iterations, z, reduce, user);
+}
+
+int gingr_fitter_fullfit_exchange(gingr_fitter *f, void **dev_ptr, int64_t *count) {
+    if (!f || !dev_ptr || !count) return GINGR_ERR_BAD_ARGUMENT;
+    if (!f->fullfit) return gingr_set_error(f->ctx, GINGR_ERR_STATE, "fullfit_exchange: not a row shard with meshes (gingr_fitter_set_meshes)");
+    *dev_ptr = f->fullfit;
+    *count = 3 * f->m->M_total;
+    return GINGR_OK;
 }
 
 // ------------------------------------------------------------------------------------------ ICP, surface correspondence
@@ -1236,12 +1326,15 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
     f->forget_posteriors();  // the posterior memos describe other inputs
     gingr_ctx *ctx = f->ctx;
     if (!f->target) return gingr_set_error(ctx, GINGR_ERR_STATE, "set_meshes: no target set (gingr_fitter_set_target)");
-    if (f->m->M != f->m->M_total) return gingr_set_error(ctx, GINGR_ERR_STATE, "set_meshes: single shard only");
     if (n_model_tri < 1 || n_target_tri < 1 || !model_tri || !target_tri)
         return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_meshes: need at least one triangle per mesh");
-    const int64_t M = f->m->M, N = f->N;
+    // A row shard takes the triangles of the WHOLE template (vertex ids of the full model): its queries are its own rows, but the
+    // tests against the template itself -- vertex normals, self-intersection -- see all of it, through the gathered fit
+    // (gingr_fitter::fullfit, original point order).  A single shard indexes its own fit (device order).
+    const bool sharded = f->sharded();
+    const int64_t M = f->m->M, N = f->N, Mt = f->m->M_total, rb = f->m->row_begin;
     for (int64_t k = 0; k < 3 * n_model_tri; ++k)
-        if (model_tri[k] < 0 || model_tri[k] >= M) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_meshes: model vertex id out of range");
+        if (model_tri[k] < 0 || model_tri[k] >= Mt) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_meshes: model vertex id out of range");
     for (int64_t k = 0; k < 3 * n_target_tri; ++k)
         if (target_tri[k] < 0 || target_tri[k] >= N) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_meshes: target vertex id out of range");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1258,13 +1351,14 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
     struct Built {
         std::vector<int32_t> tri, orig, adj_ptr, adj_tri;
     };
-    auto build = [&](int64_t T, const int32_t *tri, const std::vector<int32_t> &inv, const std::vector<double> &soa, int64_t n,
-                     Built &b) {
+    // coord(v, d): coordinate d of vertex v; mesh_pos(v): its position in the cloud the triangles index; adj_slot(v): its slot in the
+    // vertex -> triangles lists (n_adj slots) or -1 for a vertex this fitter does not own
+    auto build = [&](int64_t T, const int32_t *tri, auto coord, auto mesh_pos, auto adj_slot, int64_t n_adj, Built &b) {
         std::vector<double> cen((size_t)3 * T);
         for (int64_t t = 0; t < T; ++t)
             for (int d = 0; d < 3; ++d) {
                 double c = 0.0;
-                for (int k = 0; k < 3; ++k) c += soa[(size_t)d * n + inv[(size_t)tri[3 * t + k]]];
+                for (int k = 0; k < 3; ++k) c += coord(tri[3 * t + k], d);
                 cen[(size_t)3 * t + d] = c / 3.0;
             }
         morton_order(cen.data(), T, b.orig);  // orig[s] = original index of the triangle at device position s
@@ -1273,21 +1367,38 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
         for (int64_t s2 = 0; s2 < T; ++s2) {
             const int32_t t = b.orig[(size_t)s2];
             tpos2[(size_t)t] = (int32_t)s2;
-            for (int k = 0; k < 3; ++k) b.tri[(size_t)3 * s2 + k] = inv[(size_t)tri[3 * t + k]];
+            for (int k = 0; k < 3; ++k) b.tri[(size_t)3 * s2 + k] = mesh_pos(tri[3 * t + k]);
         }
         // vertex -> triangles, in ascending ORIGINAL triangle index (the order the normals are averaged in)
-        std::vector<int32_t> cnt((size_t)n + 1, 0);
-        for (int64_t k = 0; k < 3 * T; ++k) cnt[(size_t)inv[(size_t)tri[k]] + 1]++;
-        for (int64_t v = 0; v < n; ++v) cnt[(size_t)v + 1] += cnt[(size_t)v];
+        std::vector<int32_t> cnt((size_t)n_adj + 1, 0);
+        int64_t total = 0;
+        for (int64_t k = 0; k < 3 * T; ++k) {
+            const int32_t sl = adj_slot(tri[k]);
+            if (sl >= 0) cnt[(size_t)sl + 1]++, ++total;
+        }
+        for (int64_t v = 0; v < n_adj; ++v) cnt[(size_t)v + 1] += cnt[(size_t)v];
         b.adj_ptr = cnt;
-        b.adj_tri.resize((size_t)3 * T);
+        b.adj_tri.resize((size_t)(total > 0 ? total : 1));
         std::vector<int32_t> fill(cnt.begin(), cnt.end() - 1);
         for (int64_t t = 0; t < T; ++t)
-            for (int k = 0; k < 3; ++k) b.adj_tri[(size_t)fill[(size_t)inv[(size_t)tri[3 * t + k]]]++] = tpos2[(size_t)t];
+            for (int k = 0; k < 3; ++k) {
+                const int32_t sl = adj_slot(tri[3 * t + k]);
+                if (sl >= 0) b.adj_tri[(size_t)fill[(size_t)sl]++] = tpos2[(size_t)t];
+            }
     };
     Built bm, bt;
-    build(n_model_tri, model_tri, f->m->hiperm, mpos, M, bm);
-    build(n_target_tri, target_tri, tinv, tpos, N, bt);
+    const std::vector<int32_t> &hip = f->m->hiperm;
+    if (sharded) {
+        const std::vector<double> &full = f->m->h_full_pts;
+        if ((int64_t)full.size() != 3 * Mt) return gingr_set_error(ctx, GINGR_ERR_STATE, "set_meshes: the shard holds no copy of the full mean shape");
+        build(n_model_tri, model_tri, [&](int32_t v, int d) { return full[(size_t)3 * v + d]; }, [&](int32_t v) { return v; },
+              [&](int32_t v) { return (v >= rb && v < rb + M) ? hip[(size_t)(v - rb)] : -1; }, M, bm);
+    } else {
+        build(n_model_tri, model_tri, [&](int32_t v, int d) { return mpos[(size_t)d * M + hip[(size_t)v]]; }, [&](int32_t v) { return hip[(size_t)v]; },
+              [&](int32_t v) { return hip[(size_t)v]; }, M, bm);
+    }
+    build(n_target_tri, target_tri, [&](int32_t v, int d) { return tpos[(size_t)d * N + tinv[(size_t)v]]; }, [&](int32_t v) { return tinv[(size_t)v]; },
+          [&](int32_t v) { return tinv[(size_t)v]; }, N, bt);
     // target boundary vertices: on an edge with exactly one adjacent triangle (TriangleMesh3DOperations.pointIsOnBoundary)
     std::vector<int32_t> bnd((size_t)N, 0);
     {
@@ -1311,7 +1422,7 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
     }
     // model boundary vertices (reversed direction: the rejection rules run on the template side)
     std::vector<int32_t> mbnd((size_t)M, 0);
-    {
+    if (!sharded) {
         std::vector<uint64_t> edges;
         edges.reserve((size_t)3 * n_model_tri);
         for (int64_t t = 0; t < n_model_tri; ++t)
@@ -1336,7 +1447,7 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
     int rc;
     if ((rc = dev_alloc(ctx, &f->mtri, (size_t)3 * f->Tm)) || (rc = dev_alloc(ctx, &f->ttri, (size_t)3 * f->Tt)) ||
         (rc = dev_alloc(ctx, &f->ttri_orig, (size_t)f->Tt)) || (rc = dev_alloc(ctx, &f->madj_ptr, (size_t)M + 1)) ||
-        (rc = dev_alloc(ctx, &f->madj_tri, (size_t)3 * f->Tm)) || (rc = dev_alloc(ctx, &f->tadj_ptr, (size_t)N + 1)) ||
+        (rc = dev_alloc(ctx, &f->madj_tri, bm.adj_tri.size())) || (rc = dev_alloc(ctx, &f->tadj_ptr, (size_t)N + 1)) ||
         (rc = dev_alloc(ctx, &f->tadj_tri, (size_t)3 * f->Tt)) || (rc = dev_alloc(ctx, &f->mcn, (size_t)3 * f->Tm)) ||
         (rc = dev_alloc(ctx, &f->tcn, (size_t)3 * f->Tt)) || (rc = dev_alloc(ctx, &f->mvn, (size_t)3 * M)) ||
         (rc = dev_alloc(ctx, &f->tvn, (size_t)3 * N)) || (rc = dev_alloc(ctx, &f->mtboxes, (size_t)30 * ntm)) ||
@@ -1362,6 +1473,10 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
     HIP_TRY(ctx, up(f->tboundary, bnd));
     HIP_TRY(ctx, up(f->mtri_orig, bm.orig));
     HIP_TRY(ctx, up(f->mboundary, mbnd));
+    if (sharded && !f->fullfit) {
+        GINGR_TRY(dev_alloc(ctx, &f->fullfit, (size_t)3 * Mt));
+        HIP_TRY(ctx, hipMemsetAsync(f->fullfit, 0, (size_t)3 * Mt * sizeof(double), ctx->stream));
+    }
     // static target side: cell normals, vertex normals, triangle tile boxes
     const Cloud tgt = cloud_of(f->target, N);
     launch_cell_normals(ctx, tgt, f->ttri, f->Tt, f->tcn);
@@ -1439,6 +1554,8 @@ int gingr_fitter_icp_surface_phase_async(gingr_fitter *f, const gingr_icp_params
 
 int gingr_fitter_update_icp_surface_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations) {
     GINGR_TRY(check_ready(f));
+    if (f->sharded())
+        return gingr_set_error(f->ctx, GINGR_ERR_STATE, "update_icp_surface_async: a row shard needs the sharded update (gingr_fitter_update_sharded_async / _rccl_async / the device group)");
     for (int32_t it = 0; it < n_iterations; ++it) {
         TimerScope ts(f->ctx, 3);
         for (int ph = 0; ph < GINGR_NUM_PHASES; ++ph) GINGR_TRY(gingr_fitter_icp_surface_phase_async(f, p, ph));
@@ -1567,6 +1684,80 @@ int gingr_fitter_posterior_logpdf_icp_surface(gingr_fitter *f, const gingr_icp_p
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
     if (!p || p->max_iterations < 1) return gingr_set_error(f->ctx, GINGR_ERR_BAD_ARGUMENT, "icp params: max_iterations < 1");
     return posterior_logpdf(f, 2, nullptr, p, mesh_xyz, logpdf);
+}
+
+}  // extern "C"
+
+// ---- transition density on a row shard: the two halves around the exchange of segment 1 (the device group drives them itself)
+// prepare: this shard's rows of the mesh (host, the FULL mesh in the caller's point order) -> e = R^T (mesh - c - t) - (ref - c) - mean
+// in the pose of the state -> the partial Q0^T e into the tail of exchange segment 1 (summed with the Gram bundle).
+int fitter_logpdf_prepare(gingr_fitter *f, const double *mesh_xyz_full) {
+    gingr_ctx *ctx = f->ctx;
+    const gingr_model *m = f->m;
+    const int64_t M = m->M;
+    const int32_t rp = m->rp;
+    double *aos = reinterpret_cast<double *>(f->aos);
+    memcpy(f->pin, mesh_xyz_full + 3 * m->row_begin, (size_t)3 * M * sizeof(double));
+    HIP_TRY(ctx, hipMemcpyAsync(aos, f->pin, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    launch_aos_to_soa(ctx, aos, M, f->newshape, m->perm);
+    hipLaunchKernelGGL(pose_of_state_kernel, dim3(1), dim3(64), 0, ctx->stream, f->st, f->pose);
+    SweepArgs a = base_args(f);
+    a.shape_in = f->newshape;
+    a.out = (f->partial_out ? f->partial_out : f->xch) + f->off[1] + (int64_t)rp * rp + rp + 8;
+    launch_sweep(ctx, SWEEP_PROJ2, a);
+    return check_launch(ctx);
+}
+
+// finish (segment 1 reduced): the replicated log-density kernel, read-back, and the tail of segment 1 back to zero
+int fitter_logpdf_finish(gingr_fitter *f, double *logpdf) {
+    gingr_ctx *ctx = f->ctx;
+    const gingr_model *m = f->m;
+    const int32_t r = m->r, rp = m->rp;
+    double *G = f->xch + f->off[1];
+    double *rhs = G + (int64_t)rp * rp, *qte = rhs + rp + 8;
+    GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, rhs, m->mom + MomentLayout{rp}.stot(), qte, nullptr, false, f->work, f->small));
+    GINGR_TRY(check_launch(ctx));
+    double *res = f->pin + (size_t)3 * m->M;
+    HIP_TRY(ctx, hipMemcpyAsync(res, f->small, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(qte, 0, (size_t)rp * sizeof(double), ctx->stream));
+    if (f->partial_out) HIP_TRY(ctx, hipMemsetAsync(f->partial_out + f->off[1] + (int64_t)rp * rp + rp + 8, 0, (size_t)rp * sizeof(double), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (res[1] != 0.0) return gingr_set_error(ctx, GINGR_ERR_NOT_SPD, "posterior_logpdf: posterior of the current state failed");
+    if (!std::isfinite(res[0])) return gingr_set_error(ctx, GINGR_ERR_NONFINITE, "posterior_logpdf: non-finite result");
+    *logpdf = res[0];
+    return GINGR_OK;
+}
+
+// posterior(of the current state).gp.logpdf(posterior.coefficients(mesh)) on a row shard (GeneratorWrapperStochastic.scala:42-63):
+// phases 0 and 1 with their exchanges; Q0^T e rides in segment 1; the log-density kernel is replicated.
+int fitter_sharded_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, const double *mesh_xyz_full,
+                          gingr_allreduce_fn reduce, void *user, double *logpdf) {
+    GINGR_TRY(check_ready(f));
+    gingr_ctx *ctx = f->ctx;
+    if (!mesh_xyz_full || !logpdf || !reduce || flavour < 0 || flavour > 2)
+        return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "sharded posterior_logpdf: bad arguments");
+    if (f->partial_out) return gingr_set_error(ctx, GINGR_ERR_STATE, "sharded posterior_logpdf: this fitter belongs to a device group");
+    if (flavour == 2 && f->sharded()) {
+        GINGR_TRY(fitter_run_phase(f, flavour, cp, ip, GINGR_PHASE_GATHER));
+        if (reduce(user, GINGR_SEGMENT_FULLFIT, f->fullfit, 3 * f->m->M_total) != 0)
+            return gingr_set_error(ctx, GINGR_ERR_STATE, "sharded posterior_logpdf: the all-reduce callback failed (full fit)");
+    }
+    GINGR_TRY(fitter_run_phase(f, flavour, cp, ip, 0));
+    if (flavour == 0 && reduce(user, 0, f->xch + f->off[0], f->cnt[0]) != 0)
+        return gingr_set_error(ctx, GINGR_ERR_STATE, "sharded posterior_logpdf: the all-reduce callback failed (segment 0)");
+    GINGR_TRY(fitter_run_phase(f, flavour, cp, ip, 1));
+    GINGR_TRY(fitter_logpdf_prepare(f, mesh_xyz_full));
+    if (reduce(user, 1, f->xch + f->off[1], f->cnt[1]) != 0)
+        return gingr_set_error(ctx, GINGR_ERR_STATE, "sharded posterior_logpdf: the all-reduce callback failed (segment 1)");
+    return fitter_logpdf_finish(f, logpdf);
+}
+
+extern "C" {
+
+int gingr_fitter_posterior_logpdf_sharded(gingr_fitter *f, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,
+                                          const double *mesh_xyz_full, gingr_allreduce_fn reduce, void *user, double *logpdf) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    return fitter_sharded_logpdf(f, flavour, cp, ip, mesh_xyz_full, reduce, user, logpdf);
 }
 
 // ===================================================================================== stateless model operators

@@ -83,6 +83,8 @@ struct gingr_model {
     // spatially coherent (exact-zero tile culling in the CPD passes).  perm[s] = original local index of device row s.
     int32_t *perm = nullptr;
     std::vector<int32_t> hperm, hiperm;  // host copies: device position -> original, original -> device position
+    int32_t *iperm = nullptr;            // device copy of hiperm (local original index -> device position): the fit gather of a shard
+    std::vector<double> h_full_pts;      // host: ref + mean of ALL M_total points, interleaved xyz (spatial order of a shard's triangles)
     double *Binv = nullptr;   // [rp*rp] (S_tot/eps + I)^-1, valid after finalize
     double *eigV = nullptr;   // [r*r] eigenvectors of S_tot = Q^T Q (column k, row stride r) and
     double *eigL = nullptr;   // [r] its eigenvalues (descending): uniform-weight posterior (launch_posterior_solve_eig); rank <= 256
@@ -106,8 +108,20 @@ int model_create_impl(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doubl
                       const double *variance, int64_t row_begin, int64_t row_end,
                       const std::function<int(gingr_model *)> &fill_basis, gingr_model **out);
 
-// fitter.hip hooks for the device group (group.hip): where phases 0 / 1 write this shard's partial exchange segments
+// fitter.hip hooks for the device group (group.hip): where phases 0 / 1 write this shard's partial exchange segments, and where
+// the gather step of a sharded surface update writes the shard's contribution to the full fit (nullptr: in place)
 void fitter_set_partial_output(gingr_fitter *f, double *base);
+void fitter_set_partial_fullfit(gingr_fitter *f, double *base);
+// the sharded update (fitter.hip) for the other translation units: flavour 0 CPD, 1 ICP point cloud, 2 ICP surface; z nullable (sampled proposal)
+int fitter_sharded_update(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations,
+                          const double *z, gingr_allreduce_fn reduce, void *user);
+int fitter_sharded_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, const double *mesh_xyz_full,
+                          gingr_allreduce_fn reduce, void *user, double *logpdf);
+int fitter_run_phase(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int phase);
+int fitter_logpdf_prepare(gingr_fitter *f, const double *mesh_xyz_full);  // before the exchange of segment 1
+int fitter_logpdf_finish(gingr_fitter *f, double *logpdf);                // behind it
+void fitter_set_zrand(gingr_fitter *f, const double *z);                   // nullable: the next phase 2 draws a sample (device group)
+double *fitter_fullfit(gingr_fitter *f);                                   // [3][M_total] or nullptr
 gingr_ctx *fitter_ctx(gingr_fitter *f);
 const gingr_model *fitter_model(gingr_fitter *f);
 

@@ -99,6 +99,10 @@ struct gingr_group {
     std::vector<hipEvent_t> ready[2][GINGR_NUM_SEGMENTS];       // [parity][segment][shard]
     std::vector<double *> xch;                                  // the fitters' exchange buffers
     int64_t off[GINGR_NUM_SEGMENTS] = {0, 0}, cnt[GINGR_NUM_SEGMENTS] = {0, 0};
+    // the gather of a sharded surface update (exchange segment GINGR_SEGMENT_FULLFIT): contributions [3 M_total] per shard and parity
+    std::vector<double *> sendfit[2];
+    std::vector<hipEvent_t> readyfit[2];
+    bool meshes = false;
     int64_t iteration = 0;                                      // parity of the send buffers
     bool fine_grained = false;                                  // the send buffers are fine-grained device allocations
     int distinct_devices = 1;
@@ -182,6 +186,18 @@ void free_exchange(gingr_group *g) {
             g->ready[p][s].clear();
         }
     }
+    for (int p = 0; p < 2; ++p) {
+        for (size_t r = 0; r < g->sendfit[p].size(); ++r)
+            if (g->sendfit[p][r]) {
+                (void)hipSetDevice(g->dev[r]);
+                (void)hipFree(g->sendfit[p][r]);
+            }
+        g->sendfit[p].clear();
+        for (size_t r = 0; r < g->readyfit[p].size(); ++r)
+            if (g->readyfit[p][r]) (void)hipEventDestroy(g->readyfit[p][r]);
+        g->readyfit[p].clear();
+    }
+    g->meshes = false;
     g->xch.clear();
 }
 
@@ -290,26 +306,29 @@ int finish_models(gingr_group *g) {
     return g->run([&](int r) { return gingr_fitter_create(g->ctx[(size_t)r], g->model[(size_t)r], &g->fit[(size_t)r]); });
 }
 
-// all-reduce of exchange segment s (partials in send[parity], sums into the fitters' xch); called by every worker.
+// One-shot all-reduce over peer pointers, called by every worker: the shard has written its contribution to src[r]; it records
+// ev[r], everybody meets, the stream waits for the peers' events and one kernel adds the n contributions in rank order into dst.
 // `ok` false: the worker still takes part in the barrier (so nobody deadlocks) but enqueues nothing.
-int exchange_segment(gingr_group *g, int r, int s, int parity, bool ok) {
+int exchange_buffers(gingr_group *g, int r, std::vector<hipEvent_t> &ev, const std::vector<double *> &src_base, int64_t src_off, double *dst,
+                     int64_t count, bool ok) {
     gingr_ctx *ctx = g->ctx[(size_t)r];
     int rc = GINGR_OK;
-    if (ok && hipEventRecord(g->ready[parity][s][(size_t)r], ctx->stream) != hipSuccess)
-        rc = gingr_set_error(ctx, GINGR_ERR_HIP, "group: hipEventRecord failed");
+    if (ok && hipEventRecord(ev[(size_t)r], ctx->stream) != hipSuccess) rc = gingr_set_error(ctx, GINGR_ERR_HIP, "group: hipEventRecord failed");
     g->bar.wait();  // every peer has RECORDED its event (a wait on a never-recorded event would be a no-op)
     if (!ok || rc) return rc;
     PeerPtrs src;
     for (int q = 0; q < g->n; ++q) {
-        if (q != r && hipStreamWaitEvent(ctx->stream, g->ready[parity][s][(size_t)q], 0) != hipSuccess)
+        if (q != r && hipStreamWaitEvent(ctx->stream, ev[(size_t)q], 0) != hipSuccess)
             return gingr_set_error(ctx, GINGR_ERR_HIP, "group: hipStreamWaitEvent failed");
-        src.p[q] = g->send[parity][(size_t)q] + g->off[s];
+        src.p[q] = src_base[(size_t)q] + src_off;
     }
-    const int64_t count = g->cnt[s];
-    hipLaunchKernelGGL(peer_sum_kernel, dim3((unsigned)ceil_div(ceil_div(count, 2), 256)), dim3(256), 0, ctx->stream,
-                       g->xch[(size_t)r] + g->off[s], src, g->n, count);
+    hipLaunchKernelGGL(peer_sum_kernel, dim3((unsigned)ceil_div(ceil_div(count, 2), 256)), dim3(256), 0, ctx->stream, dst, src, g->n, count);
     if (hipGetLastError() != hipSuccess) return gingr_set_error(ctx, GINGR_ERR_HIP, "group: all-reduce kernel launch failed");
     return GINGR_OK;
+}
+// all-reduce of exchange segment s (partials in send[parity], sums into the fitters' xch)
+int exchange_segment(gingr_group *g, int r, int s, int parity, bool ok) {
+    return exchange_buffers(g, r, g->ready[parity][s], g->send[parity], g->off[s], g->xch[(size_t)r] + g->off[s], g->cnt[s], ok);
 }
 // timer slots of the exchanges (gingr_ctx_timing_read): 6 = segment 0 (column sums), 7 = segment 1 (Gram bundle); the span runs from
 // the record of the shard's own event to the end of its sum kernel, i.e. it includes the wait for the slowest peer
@@ -317,34 +336,98 @@ int timed_exchange_segment(gingr_group *g, int r, int s, int parity, bool ok) {
     TimerScope ts(g->ctx[(size_t)r], 6 + s);
     return exchange_segment(g, r, s, parity, ok);
 }
+// the gather of a sharded surface iteration: contributions in sendfit[parity], the full fit into every fitter's own buffer
+int exchange_fullfit(gingr_group *g, int r, int parity, bool ok) {
+    return exchange_buffers(g, r, g->readyfit[parity], g->sendfit[parity], 0, fitter_fullfit(g->fit[(size_t)r]), 3 * g->M_total, ok);
+}
 
-int group_update(gingr_group *g, bool icp, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations) {
-    if (!g || n_iterations < 0) return GINGR_ERR_BAD_ARGUMENT;
+// flavour 0 CPD, 1 ICP point cloud, 2 ICP surface; z (nullable): the draws of a sampled proposal (one iteration)
+int group_update(gingr_group *g, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations, const double *z) {
+    if (!g || n_iterations < 0 || flavour < 0 || flavour > 2) return GINGR_ERR_BAD_ARGUMENT;
     if (g->fit.empty() || !g->fit[0] || g->xch.empty()) return group_fail(g, GINGR_ERR_STATE, "group update: no model / target set");
+    if (flavour == 2 && !g->meshes) return group_fail(g, GINGR_ERR_STATE, "group update: no meshes set (gingr_group_set_meshes)");
+    if (z && n_iterations != 1) return group_fail(g, GINGR_ERR_BAD_ARGUMENT, "group update: a sampled proposal is one iteration");
     if (g->n == 1)
         return g->run([&](int) {
-            return icp ? gingr_fitter_update_icp_async(g->fit[0], ip, n_iterations) : gingr_fitter_update_cpd_async(g->fit[0], cp, n_iterations);
+            gingr_fitter *f = g->fit[0];
+            if (z) {
+                if (flavour == 0) return gingr_fitter_update_cpd_sample_async(f, cp, z);
+                return flavour == 1 ? gingr_fitter_update_icp_sample_async(f, ip, z) : gingr_fitter_update_icp_surface_sample_async(f, ip, z);
+            }
+            if (flavour == 0) return gingr_fitter_update_cpd_async(f, cp, n_iterations);
+            return flavour == 1 ? gingr_fitter_update_icp_async(f, ip, n_iterations) : gingr_fitter_update_icp_surface_async(f, ip, n_iterations);
         });
     const int64_t it0 = g->iteration;
     g->iteration += n_iterations;
     return g->run([&](int r) {
         int rc = GINGR_OK;
         gingr_fitter *f = g->fit[(size_t)r];
+        fitter_set_zrand(f, z);
         for (int32_t it = 0; it < n_iterations; ++it) {
             const int parity = (int)((it0 + it) & 1);
             if (!rc) fitter_set_partial_output(f, g->send[parity][(size_t)r]);
             TimerScope ts(g->ctx[(size_t)r], 3);
+            if (flavour == 2) {  // the whole posed template for the tests against it: gather the shards' rows of the fit
+                if (!rc) fitter_set_partial_fullfit(f, g->sendfit[parity][(size_t)r]);
+                if (!rc) rc = fitter_run_phase(f, flavour, cp, ip, GINGR_PHASE_GATHER);
+                const int xrc = exchange_fullfit(g, r, parity, rc == GINGR_OK);
+                if (!rc) rc = xrc;
+            }
             for (int ph = 0; ph < GINGR_NUM_PHASES; ++ph) {
-                if (!rc) rc = icp ? gingr_fitter_icp_phase_async(f, ip, ph) : gingr_fitter_cpd_phase_async(f, cp, ph);
-                // ICP: the nearest-neighbour phase has nothing to exchange (rows are independent)
-                if (ph < GINGR_NUM_SEGMENTS && !(icp && ph == 0)) {
+                if (!rc) rc = fitter_run_phase(f, flavour, cp, ip, ph);
+                // ICP: the correspondence phase has nothing to exchange (rows are independent)
+                if (ph < GINGR_NUM_SEGMENTS && !(flavour != 0 && ph == 0)) {
                     const int xrc = timed_exchange_segment(g, r, ph, parity, rc == GINGR_OK);
                     if (!rc) rc = xrc;
                 }
             }
         }
+        fitter_set_zrand(f, nullptr);
         return rc;
     });
+}
+
+// posterior(state).gp.logpdf(posterior.coefficients(mesh)): phases 0 and 1 with their exchanges, Q0^T e in the tail of segment 1, the
+// log-density kernel replicated on every shard (shard 0's value is returned; they are bit-identical)
+int group_logpdf(gingr_group *g, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, const double *mesh_xyz_full,
+                 double *logpdf) {
+    if (!g || !mesh_xyz_full || !logpdf || flavour < 0 || flavour > 2) return GINGR_ERR_BAD_ARGUMENT;
+    if (g->fit.empty() || !g->fit[0] || g->xch.empty()) return group_fail(g, GINGR_ERR_STATE, "group posterior_logpdf: no model / target set");
+    if (flavour == 2 && !g->meshes) return group_fail(g, GINGR_ERR_STATE, "group posterior_logpdf: no meshes set (gingr_group_set_meshes)");
+    if (g->n == 1)
+        return g->run([&](int) {
+            gingr_fitter *f = g->fit[0];
+            if (flavour == 0) return gingr_fitter_posterior_logpdf_cpd(f, cp, mesh_xyz_full, logpdf);
+            return flavour == 1 ? gingr_fitter_posterior_logpdf_icp(f, ip, mesh_xyz_full, logpdf)
+                                : gingr_fitter_posterior_logpdf_icp_surface(f, ip, mesh_xyz_full, logpdf);
+        });
+    const int parity = (int)(g->iteration & 1);
+    g->iteration += 1;
+    std::vector<double> out((size_t)g->n, 0.0);
+    GINGR_TRY(g->run([&](int r) {
+        int rc = GINGR_OK;
+        gingr_fitter *f = g->fit[(size_t)r];
+        fitter_set_partial_output(f, g->send[parity][(size_t)r]);
+        if (flavour == 2) {
+            fitter_set_partial_fullfit(f, g->sendfit[parity][(size_t)r]);
+            rc = fitter_run_phase(f, flavour, cp, ip, GINGR_PHASE_GATHER);
+            const int xrc = exchange_fullfit(g, r, parity, rc == GINGR_OK);
+            if (!rc) rc = xrc;
+        }
+        if (!rc) rc = fitter_run_phase(f, flavour, cp, ip, 0);
+        if (flavour == 0) {
+            const int xrc = exchange_segment(g, r, 0, parity, rc == GINGR_OK);
+            if (!rc) rc = xrc;
+        }
+        if (!rc) rc = fitter_run_phase(f, flavour, cp, ip, 1);
+        if (!rc) rc = fitter_logpdf_prepare(f, mesh_xyz_full);
+        const int xrc = exchange_segment(g, r, 1, parity, rc == GINGR_OK);
+        if (!rc) rc = xrc;
+        if (!rc) rc = fitter_logpdf_finish(f, &out[(size_t)r]);
+        return rc;
+    }));
+    *logpdf = out[0];
+    return GINGR_OK;
 }
 
 }  // namespace
@@ -513,6 +596,53 @@ int gingr_group_set_target(gingr_group *g, int64_t N, const double *target_xyz) 
     return GINGR_OK;
 }
 
+int gingr_group_set_meshes(gingr_group *g, int64_t n_model_triangles, const int32_t *model_triangles, int64_t n_target_triangles,
+                           const int32_t *target_triangles) {
+    if (!g) return GINGR_ERR_BAD_ARGUMENT;
+    if (g->fit.empty() || !g->fit[0] || g->xch.empty()) return group_fail(g, GINGR_ERR_STATE, "group set_meshes: no model / target set");
+    GINGR_TRY(gingr_group_synchronize(g));
+    GINGR_TRY(g->run([&](int r) {
+        return gingr_fitter_set_meshes(g->fit[(size_t)r], n_model_triangles, model_triangles, n_target_triangles, target_triangles);
+    }));
+    g->meshes = true;
+    if (g->n == 1 || !g->sendfit[0].empty()) return GINGR_OK;
+    // the contributions to the gathered fit, peer-readable and double buffered like the other send buffers
+    DeviceGuard guard;
+    const size_t bytes = (size_t)3 * g->M_total * sizeof(double);
+    for (int p = 0; p < 2; ++p) {
+        g->sendfit[p].assign((size_t)g->n, nullptr);
+        g->readyfit[p].assign((size_t)g->n, nullptr);
+        for (int r = 0; r < g->n; ++r) {
+            if (hipSetDevice(g->dev[(size_t)r]) != hipSuccess) return group_fail(g, GINGR_ERR_HIP, "group: hipSetDevice failed");
+            void *buf = nullptr;
+            bool fine = false;
+            GINGR_TRY(alloc_peer_readable(g, bytes, &buf, &fine));
+            g->sendfit[p][(size_t)r] = static_cast<double *>(buf);
+            g->fine_grained = g->fine_grained && fine;
+            if (hipMemset(buf, 0, bytes) != hipSuccess) return group_fail(g, GINGR_ERR_HIP, "group: memset failed");
+            if (hipEventCreateWithFlags(&g->readyfit[p][(size_t)r], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess)
+                return group_fail(g, GINGR_ERR_HIP, "group: hipEventCreate failed");
+        }
+    }
+    return GINGR_OK;
+}
+
+int gingr_group_set_surface_method(gingr_group *g, int32_t method) {
+    if (!g) return GINGR_ERR_BAD_ARGUMENT;
+    if (g->fit.empty() || !g->fit[0]) return group_fail(g, GINGR_ERR_STATE, "group set_surface_method: no model");
+    return g->run([&](int r) { return gingr_fitter_set_surface_method(g->fit[(size_t)r], method); });
+}
+
+int gingr_group_update_async(gingr_group *g, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations,
+                             const double *z) {
+    return group_update(g, flavour, cp, ip, n_iterations, z);
+}
+
+int gingr_group_posterior_logpdf(gingr_group *g, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,
+                                 const double *mesh_xyz_full, double *logpdf) {
+    return group_logpdf(g, flavour, cp, ip, mesh_xyz_full, logpdf);
+}
+
 int gingr_group_exchange_info(const gingr_group *g, int32_t *distinct_devices, int32_t *fine_grained) {
     if (!g) return GINGR_ERR_BAD_ARGUMENT;
     if (distinct_devices) *distinct_devices = g->distinct_devices;
@@ -550,12 +680,12 @@ int gingr_group_get_state(gingr_group *g, double *alpha, gingr_state_scalars *s,
 
 int gingr_group_update_cpd_async(gingr_group *g, const gingr_cpd_params *p, int32_t n_iterations) {
     if (!g || !p) return GINGR_ERR_BAD_ARGUMENT;
-    return group_update(g, false, p, nullptr, n_iterations);
+    return group_update(g, 0, p, nullptr, n_iterations, nullptr);
 }
 
 int gingr_group_update_icp_async(gingr_group *g, const gingr_icp_params *p, int32_t n_iterations) {
     if (!g || !p) return GINGR_ERR_BAD_ARGUMENT;
-    return group_update(g, true, nullptr, p, n_iterations);
+    return group_update(g, 1, nullptr, p, n_iterations, nullptr);
 }
 
 int gingr_group_synchronize(gingr_group *g) {

@@ -157,4 +157,20 @@ int gingr_fitter_update_icp_rccl_async(gingr_fitter *f, const gingr_icp_params *
     return gingr_fitter_update_icp_sharded_async(f, p, n_iterations, native_allreduce, ctx);
 }
 
+int gingr_fitter_update_rccl_async(gingr_fitter *f, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations,
+                                   const double *z) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = fitter_ctx(f);
+    if (!ctx->rccl_comm) return gingr_set_error(ctx, GINGR_ERR_STATE, "update_rccl: no communicator (gingr_ctx_rccl_init)");
+    return fitter_sharded_update(f, flavour, cp, ip, n_iterations, z, native_allreduce, ctx);
+}
+
+int gingr_fitter_posterior_logpdf_rccl(gingr_fitter *f, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,
+                                       const double *mesh_xyz_full, double *logpdf) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = fitter_ctx(f);
+    if (!ctx->rccl_comm) return gingr_set_error(ctx, GINGR_ERR_STATE, "posterior_logpdf_rccl: no communicator (gingr_ctx_rccl_init)");
+    return fitter_sharded_logpdf(f, flavour, cp, ip, mesh_xyz_full, native_allreduce, ctx, logpdf);
+}
+
 }  // extern "C"

@@ -860,10 +860,11 @@ void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const in
     hipLaunchKernelGGL(dist_stats_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, partial, out4);
 }
 void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, const int32_t *tri, int64_t T, const double *boxes,
-                           const int32_t *skip, int32_t *flag, const double *tribox) {
+                           const int32_t *skip, int32_t *flag, const double *tribox, const Cloud *mesh) {
     const int h = surface_h(fit.n);
+    const Cloud v = mesh ? *mesh : fit;
     auto go = [&](auto kern, int qpb) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(fit.n, qpb)), dim3(kCpThreads), 0, ctx->stream, fit, cp_soa, fit, tri, T, boxes,
+        hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(fit.n, qpb)), dim3(kCpThreads), 0, ctx->stream, fit, cp_soa, v, tri, T, boxes,
                            skip, flag, tribox);
     };
     if (h == 8)

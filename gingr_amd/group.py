@@ -105,6 +105,38 @@ class DeviceGroup:
         p = nat.IcpParams(initial_sigma, end_sigma, max_iterations)
         self._check(self._lib.gingr_group_update_icp_async(self.handle, ctypes.byref(p), int(n_iterations)), "gingr_group_update_icp_async")
 
+    # -- round 4: surface correspondence, sampled proposal, transition density through the group ------------------------
+    def set_meshes(self, model_triangles, target_triangles, method: int = 0):
+        """Triangles of the WHOLE template (vertex ids of the full model) and of the target (gingr_group_set_meshes)."""
+        mt = np.ascontiguousarray(model_triangles, dtype=np.int32)
+        tt = np.ascontiguousarray(target_triangles, dtype=np.int32)
+        self._check(self._lib.gingr_group_set_meshes(self.handle, mt.shape[0], iptr(mt), tt.shape[0], iptr(tt)), "gingr_group_set_meshes")
+        self._check(self._lib.gingr_group_set_surface_method(self.handle, int(method)), "gingr_group_set_surface_method")
+
+    @staticmethod
+    def _params(flavour: int, params):
+        cp = nat.CpdParams(*params) if flavour == nat.FLAVOUR_CPD else None
+        ip = nat.IcpParams(*params) if flavour != nat.FLAVOUR_CPD else None
+        return cp, ip
+
+    def update(self, flavour: int, params, n_iterations: int = 1, z=None):
+        """flavour 0 CPD (params = (w, lambda)), 1 ICP point cloud, 2 ICP surface (params = (initialSigma, endSigma, maxIterations));
+        z: rank standard normals = the sampled proposal (one iteration)."""
+        cp, ip = self._params(flavour, params)
+        zz = None if z is None else f64(z)
+        self._check(self._lib.gingr_group_update_async(self.handle, int(flavour), ctypes.byref(cp) if cp else None,
+                                                       ctypes.byref(ip) if ip else None, int(n_iterations), dptr(zz)),
+                    "gingr_group_update_async")
+
+    def posterior_logpdf(self, flavour: int, params, mesh) -> float:
+        cp, ip = self._params(flavour, params)
+        m = f64(mesh)
+        out = ctypes.c_double()
+        self._check(self._lib.gingr_group_posterior_logpdf(self.handle, int(flavour), ctypes.byref(cp) if cp else None,
+                                                           ctypes.byref(ip) if ip else None, dptr(m), ctypes.byref(out)),
+                    "gingr_group_posterior_logpdf")
+        return float(out.value)
+
     def synchronize(self):
         self._check(self._lib.gingr_group_synchronize(self.handle), "gingr_group_synchronize")
 

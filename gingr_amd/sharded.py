@@ -157,9 +157,6 @@ class ShardedFitter:
                "gingr_fitter_get_cpd_stats")
         return {"P1": P1, "PX": PX, "den": den, "Np": float(sc[0]), "sigma2_next": float(sc[4]), "c": float(sc[5])}
 
-    def _segment(self, seg: int):
-        return self.xch[self.offsets[seg]: self.offsets[seg] + self.counts[seg]]
-
     def _same_stream(self) -> bool:
         import torch
         return int(self.ctx.get_stream() or 0) == int(torch.cuda.current_stream(self.ctx.device).cuda_stream or 0)
@@ -223,6 +220,66 @@ class ShardedFitter:
                    "gingr_fitter_update_icp_async")
             return
         self._sharded_call("gingr_fitter_update_icp_sharded_async", p, n_iterations)
+
+    # ---- round 4: any flavour / sampled proposal / transition density on a row shard -----------------------------------------
+    def set_meshes(self, model_triangles, target_triangles, method: int = 0):
+        """Triangles of the WHOLE template (vertex ids of the full model) and of the target; on every shard."""
+        mt = np.ascontiguousarray(model_triangles, dtype=np.int32)
+        tt = np.ascontiguousarray(target_triangles, dtype=np.int32)
+        _check(self.ctx.handle, self._lib.gingr_fitter_set_meshes(self.handle, mt.shape[0], nat.iptr(mt), tt.shape[0], nat.iptr(tt)),
+               "gingr_fitter_set_meshes")
+        _check(self.ctx.handle, self._lib.gingr_fitter_set_surface_method(self.handle, int(method)), "gingr_fitter_set_surface_method")
+        self._fullfit = None
+        if self.world > 1 and not self.rccl:
+            p, n = c_void_p(), c_int64()
+            _check(self.ctx.handle, self._lib.gingr_fitter_fullfit_exchange(self.handle, ctypes.byref(p), ctypes.byref(n)),
+                   "gingr_fitter_fullfit_exchange")
+            self._fullfit = as_torch(p.value, n.value, self.ctx.device)
+
+    def _segment(self, seg: int):
+        if seg == nat.SEGMENT_FULLFIT:
+            return self._fullfit
+        return self.xch[self.offsets[seg]: self.offsets[seg] + self.counts[seg]]
+
+    @staticmethod
+    def _params(flavour: int, params):
+        cp = nat.CpdParams(*params) if flavour == nat.FLAVOUR_CPD else None
+        ip = nat.IcpParams(*params) if flavour != nat.FLAVOUR_CPD else None
+        return (ctypes.byref(cp) if cp else None), (ctypes.byref(ip) if ip else None), (cp, ip)
+
+    def update(self, flavour: int, params, n_iterations: int = 1, z=None):
+        """flavour 0 CPD (params = (w, lambda)), 1 ICP point cloud, 2 ICP surface (params = (initialSigma, endSigma, maxIterations));
+        z: rank standard normals = update(current, probabilistic = true), one iteration, the same on every rank."""
+        cpp, ipp, _keep = self._params(flavour, params)
+        zz = None if z is None else f64(z)
+        if self.rccl:
+            _check(self.ctx.handle, self._lib.gingr_fitter_update_rccl_async(self.handle, int(flavour), cpp, ipp, int(n_iterations), dptr(zz)),
+                   "gingr_fitter_update_rccl_async")
+            return
+        assert self.world > 1, "a single shard uses the plain entry points (gingr_amd.api)"
+        cb = self._reduce_callback()
+        rc = self._lib.gingr_fitter_update_sharded_async(self.handle, int(flavour), cpp, ipp, int(n_iterations), dptr(zz), cb, None)
+        if self._cb_error is not None:
+            err, self._cb_error = self._cb_error, None
+            raise err
+        _check(self.ctx.handle, rc, "gingr_fitter_update_sharded_async")
+
+    def posterior_logpdf(self, flavour: int, params, mesh_full) -> float:
+        """posterior(state).gp.logpdf(posterior.coefficients(mesh)); mesh_full = the FULL mesh [M_total, 3] on every rank."""
+        cpp, ipp, _keep = self._params(flavour, params)
+        m = f64(mesh_full)
+        out = ctypes.c_double()
+        if self.rccl:
+            _check(self.ctx.handle, self._lib.gingr_fitter_posterior_logpdf_rccl(self.handle, int(flavour), cpp, ipp, dptr(m), ctypes.byref(out)),
+                   "gingr_fitter_posterior_logpdf_rccl")
+            return float(out.value)
+        cb = self._reduce_callback()
+        rc = self._lib.gingr_fitter_posterior_logpdf_sharded(self.handle, int(flavour), cpp, ipp, dptr(m), cb, None, ctypes.byref(out))
+        if self._cb_error is not None:
+            err, self._cb_error = self._cb_error, None
+            raise err
+        _check(self.ctx.handle, rc, "gingr_fitter_posterior_logpdf_sharded")
+        return float(out.value)
 
     def update_cpd_by_phases(self, w: float = 0.0, lambda_: float = 1.0, n_iterations: int = 1):
         """The same iterations driven phase by phase from the host (three library calls + two collectives per iteration): the

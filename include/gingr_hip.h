@@ -252,7 +252,8 @@ int gingr_fitter_update_icp_async(gingr_fitter *f, const gingr_icp_params *p, in
  * SURFACE, rejected (weight 0) when the nearest target vertex is a boundary vertex, when the vertex normals are opposite, or
  * when the line through the template vertex along the closest-point vector meets the template itself first.
  * gingr_fitter_set_meshes: triangle lists (vertex ids of the model reference resp. of the target set by
- * gingr_fitter_set_target, 3 ids per triangle); call it after gingr_fitter_set_target.  Single shard only.
+ * gingr_fitter_set_target, 3 ids per triangle); call it after gingr_fitter_set_target.  On a row shard the model triangles are those
+ * of the WHOLE template (ids of the full model) and the update runs through the sharded entry points further down.
  * The self-intersection test restates scalismo's getIntersectionPoints as a Moeller-Trumbore line/triangle test
  * (semantics unpinned without the scalismo source). */
 int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_triangles, const int32_t *model_triangles,
@@ -354,6 +355,13 @@ int gingr_fitter_retry_counter(gingr_fitter *f, int32_t set_to, int32_t *value_o
  */
 #define GINGR_NUM_PHASES 3
 #define GINGR_NUM_SEGMENTS 2
+/* Row-sharded SURFACE ICP only (round 4): the rejection tests against the template itself need the whole posed template, so an
+ * iteration starts with one more step -- phase GINGR_PHASE_GATHER writes this shard's rows of the fit into the full-fit buffer
+ * ([3][M_total] planes, original point order, zeros elsewhere; gingr_fitter_fullfit_exchange gives its address), the host
+ * all-reduces (sum) it across the shards = an all-gather, then phases 0, 1, 2 as above.  In the one-call protocols below it is
+ * exchange segment GINGR_SEGMENT_FULLFIT of the callback. */
+#define GINGR_PHASE_GATHER 3
+#define GINGR_SEGMENT_FULLFIT 2
 int gingr_fitter_exchange(gingr_fitter *f, void **dev_ptr, int64_t offsets[GINGR_NUM_SEGMENTS],
                           int64_t counts[GINGR_NUM_SEGMENTS]);
 int gingr_fitter_cpd_phase_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t phase);
@@ -371,6 +379,24 @@ int gingr_fitter_update_cpd_sharded_async(gingr_fitter *f, const gingr_cpd_param
                                           void *user);
 int gingr_fitter_update_icp_sharded_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations, gingr_allreduce_fn reduce,
                                           void *user);
+
+/* Any flavour, deterministic or sampled, as ONE call (round 4: the surface correspondence -- the reference's default ICP method,
+ * G/api/registration/config/ICP.scala:63 -- the probabilistic proposal and the transition density are row-sharded too).
+ *   flavour 0 CPD (cp), 1 ICP point cloud (ip), 2 ICP surface (ip; gingr_fitter_set_meshes on every shard with the triangles of the
+ *   WHOLE template -- vertex ids of the full model -- and of the target; the shard's queries are its own rows, the tests against the
+ *   template itself see all of it through the gathered fit, exchange segment GINGR_SEGMENT_FULLFIT).
+ *   z (nullable): rank standard-normal draws = update(current, probabilistic = true), n_iterations must be 1; the same z on every
+ *   shard (the sample a + L^-T z is replicated r x r algebra).
+ * gingr_fitter_posterior_logpdf_sharded: posterior(state).gp.logpdf(posterior.coefficients(mesh))
+ * (G/api/sampling/generators/GeneratorWrapperStochastic.scala:42-63) with mesh_xyz_full = the FULL mesh [3 M_total] on every shard
+ * (each takes its rows); Q0^T e travels in the tail of segment 1, the log-density kernel is replicated; synchronises.
+ * Reversed correspondence direction (ICP.scala:46-48) remains single shard.
+ * gingr_fitter_fullfit_exchange: address / element count of the full-fit buffer for a host that drives the phases itself. */
+int gingr_fitter_update_sharded_async(gingr_fitter *f, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,
+                                      int32_t n_iterations, const double *z, gingr_allreduce_fn reduce, void *user);
+int gingr_fitter_posterior_logpdf_sharded(gingr_fitter *f, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,
+                                          const double *mesh_xyz_full, gingr_allreduce_fn reduce, void *user, double *logpdf);
+int gingr_fitter_fullfit_exchange(gingr_fitter *f, void **dev_ptr, int64_t *count);
 
 /* ---- native RCCL exchange: the row-sharded update with one process per GPU and the collective enqueued by the LIBRARY ------------
  * BASELINE.json north_star: "the N x M affinity/distance matrix shards by reference-point rows across the 8 GPUs of one node with an
@@ -396,6 +422,12 @@ int gingr_ctx_rccl_info(gingr_ctx *ctx, int32_t *world, int32_t *rank, int32_t *
 int gingr_ctx_rccl_allreduce_async(gingr_ctx *ctx, void *device_ptr, int64_t count);
 int gingr_fitter_update_cpd_rccl_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t n_iterations);
 int gingr_fitter_update_icp_rccl_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations);
+/* any flavour / sampled proposal / transition density over the context's communicator: gingr_fitter_update_sharded_async and
+ * gingr_fitter_posterior_logpdf_sharded with the library's own ncclAllReduce as the exchange */
+int gingr_fitter_update_rccl_async(gingr_fitter *f, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,
+                                   int32_t n_iterations, const double *z);
+int gingr_fitter_posterior_logpdf_rccl(gingr_fitter *f, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,
+                                       const double *mesh_xyz_full, double *logpdf);
 
 /* ---- device group: the row-sharded update across the GPUs of ONE node from ONE host process (multi-GPU for a C / JVM host) ----
  * SURVEY.md section 8b "gingr_group_create(ndev, devs[], ...) wrapping the same calls with row-sharding".  The group owns one
@@ -431,6 +463,17 @@ int gingr_group_set_state(gingr_group *g, const double *alpha, const gingr_state
 int gingr_group_get_state(gingr_group *g, double *alpha, gingr_state_scalars *s, double *fit_xyz);
 int gingr_group_update_cpd_async(gingr_group *g, const gingr_cpd_params *p, int32_t n_iterations);
 int gingr_group_update_icp_async(gingr_group *g, const gingr_icp_params *p, int32_t n_iterations);
+/* Round 4: the surface correspondence, the sampled proposal and the transition density through the group (the mirror of
+ * gingr_fitter_set_meshes / _set_surface_method / gingr_fitter_update_sharded_async / gingr_fitter_posterior_logpdf_sharded; same
+ * argument meaning: flavour 0 CPD, 1 ICP point cloud, 2 ICP surface; z nullable, then one iteration; triangles in the vertex ids of
+ * the FULL model / target).  gingr_group_posterior_logpdf synchronises. */
+int gingr_group_set_meshes(gingr_group *g, int64_t n_model_triangles, const int32_t *model_triangles, int64_t n_target_triangles,
+                           const int32_t *target_triangles);
+int gingr_group_set_surface_method(gingr_group *g, int32_t method);
+int gingr_group_update_async(gingr_group *g, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations,
+                             const double *z);
+int gingr_group_posterior_logpdf(gingr_group *g, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,
+                                 const double *mesh_xyz_full, double *logpdf);
 int gingr_group_synchronize(gingr_group *g);
 /* How the group exchanges (diagnostics for a first run on real multi-GPU hardware): *distinct_devices = physical devices behind
  * the shards; *fine_grained = 1 when the peer-read send buffers are fine-grained device allocations (always the case when

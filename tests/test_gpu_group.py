@@ -177,3 +177,120 @@ def test_two_physical_devices_equal_one_device(ctx):
     g.close()
     assert sc.iteration == 5 and sc.status == 0
     assert abs(sc.sigma2 - sc1.sigma2) < 1e-9 * sc1.sigma2 and rel(fit, fit1) < 1e-9
+
+
+# ------------------------------------------------------------------------------------------ round 4: surface ICP, sampled proposal, log density
+def _femur_case(rank=24):
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    d = np.load(os.path.join(here, "golden", "inputs.npz"))
+    m = np.load(os.path.join(here, "golden", "femur_mesh.npz"))
+    ref, cells = d["femur"].astype(np.float64), m["femur_cells"].astype(np.int32)
+    target, tcells = d["femur_target"].astype(np.float64), m["femur_target_cells"].astype(np.int32)
+    mo = go.build_gaussian_gpmm(ref, 60.0, 20.0, rel_tol=1e-9, max_rank=rank)
+    return mo, cells, target, tcells
+
+
+def _group(devs, mo, target, cells=None, tcells=None, transform=1):
+    import gingr_amd as ga
+    g = ga.DeviceGroup(devs)
+    g.upload_model(mo.ref, mo.mean, mo.U, mo.lam)
+    g.set_target(target)
+    if cells is not None:
+        g.set_meshes(cells, tcells)
+    g.set_options(transform, 1.0)
+    return g
+
+
+def _set(g, alpha, sc):
+    g.set_state(alpha, sc.sigma2, euler=tuple(sc.euler[:]), center=tuple(sc.center[:]), translation=tuple(sc.translation[:]), scale=sc.scale,
+                iteration=sc.iteration, status=sc.status)
+
+
+@pytest.mark.parametrize("nshards", [2, 3, 8])
+def test_group_surface_icp_sample_and_logpdf_equal_single_shard(nshards):
+    """The reference's default ICP correspondence (closest point on the target SURFACE with the rejection rules,
+    ClosestPointRegistrator.scala:75-100), the sampled proposal and the transition density on row shards: the queries are a shard's
+    own rows, the tests against the template itself (vertex normals, self-intersection) see the gathered fit of all shards.  Compared
+    update by update from IDENTICAL input states (the accept / reject rules are discontinuous in the fit: trajectories that differ in
+    the last bit may part ways, one update from the same state may not)."""
+    from gingr_amd import _native as nat
+    mo, cells, target, tcells = _femur_case()
+    params = (20.0, 1.0, 30)
+    single = _group([0], mo, target, cells, tcells)
+    multi = _group(_devices(nshards), mo, target, cells, tcells)
+    single.set_state(np.zeros(mo.rank), 20.0, translation=(1.0, -2.0, 0.5), euler=(0.02, -0.03, 0.01))
+    for it in range(3):
+        a0, sc0, fit0 = single.get_state()
+        _set(multi, a0, sc0)
+        single.update(nat.FLAVOUR_ICP_SURFACE, params, 1)
+        multi.update(nat.FLAVOUR_ICP_SURFACE, params, 1)
+        a1, sc1, fit1 = single.get_state()
+        a2, sc2, fit2 = multi.get_state()
+        assert sc1.status == sc2.status == 0 and sc1.iteration == sc2.iteration
+        assert rel(fit2, fit1) < 1e-9 and rel(a2, a1) < 1e-7 and sc2.sigma2 == sc1.sigma2, (it, rel(fit2, fit1))
+        if it == 0:  # ... and against the oracle's update of the same state
+            st_in = go.State(alpha=a0.copy(), euler=tuple(sc0.euler[:]), center=np.array(sc0.center[:]), translation=np.array(sc0.translation[:]),
+                             scale=sc0.scale, sigma2=sc0.sigma2, fit=fit0.copy(), iteration=sc0.iteration, status=0, global_transformation=1,
+                             step_length=1.0)
+            st, (ocp, ow) = go.icp_surface_update(mo, cells, target, tcells, st_in, *params)
+            assert 0 < ow.sum() < ow.shape[0] and rel(fit2, st.fit) < 1e-5
+    # sampled proposal: update(current, probabilistic = true) with the same draws
+    a0, sc0, fit0 = single.get_state()
+    _set(multi, a0, sc0)
+    z = np.random.default_rng(3).standard_normal(mo.rank)
+    single.update(nat.FLAVOUR_ICP_SURFACE, params, 1, z=z)
+    multi.update(nat.FLAVOUR_ICP_SURFACE, params, 1, z=z)
+    a1, sc1, fit1 = single.get_state()
+    a2, sc2, fit2 = multi.get_state()
+    assert sc1.status == sc2.status == 0 and rel(fit2, fit1) < 1e-9 and rel(a2, a1) < 1e-7
+    assert rel(fit1, fit0) > 1e-6                      # the draw did move the proposal
+    # transition density of the sampled shape from the state before it
+    _set(single, a0, sc0)
+    _set(multi, a0, sc0)
+    l1 = single.posterior_logpdf(nat.FLAVOUR_ICP_SURFACE, params, fit1)
+    l2 = multi.posterior_logpdf(nat.FLAVOUR_ICP_SURFACE, params, fit1)
+    assert np.isfinite(l1) and abs(l2 - l1) < 1e-8 * abs(l1), (l1, l2)
+    # the group is still usable for plain updates afterwards (the log-density tail of segment 1 is cleared)
+    multi.update(nat.FLAVOUR_ICP_SURFACE, params, 1)
+    single.update(nat.FLAVOUR_ICP_SURFACE, params, 1)
+    assert rel(multi.get_state()[2], single.get_state()[2]) < 1e-9
+    single.close()
+    multi.close()
+
+
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_group_cpd_and_pointcloud_sample_and_logpdf(flavour):
+    """The probabilistic proposal and log transition density of the CPD / point-cloud ICP flavours through three logical shards
+    against a single shard and the oracle."""
+    mo, target = _case()
+    params = (0.1, 1.0) if flavour == 0 else (4.0, 1.0, 20)
+    single = _group([0], mo, target)
+    multi = _group(_devices(3), mo, target)
+    s2 = 30.0 if flavour == 0 else 4.0
+    for g in (single, multi):
+        g.set_state(np.zeros(mo.rank), s2)
+        g.update(flavour, params, 2)
+    a0, sc0, fit0 = single.get_state()
+    am, scm, fitm = multi.get_state()
+    assert rel(fitm, fit0) < 1e-9
+    _set(multi, a0, sc0)
+    z = np.random.default_rng(8).standard_normal(mo.rank)
+    single.update(flavour, params, 1, z=z)
+    multi.update(flavour, params, 1, z=z)
+    a1, sc1, fit1 = single.get_state()
+    a2, sc2, fit2 = multi.get_state()
+    assert sc1.status == sc2.status == 0 and rel(fit2, fit1) < 1e-9 and rel(fit1, fit0) > 1e-6
+    _set(single, a0, sc0)
+    _set(multi, a0, sc0)
+    l1 = single.posterior_logpdf(flavour, params, fit1)
+    l2 = multi.posterior_logpdf(flavour, params, fit1)
+    assert np.isfinite(l1) and abs(l2 - l1) < 1e-8 * abs(l1), (l1, l2)
+    # oracle: the same sampled update from the same state
+    st_in = go.State(alpha=a0.copy(), euler=tuple(sc0.euler[:]), center=np.array(sc0.center[:]), translation=np.array(sc0.translation[:]),
+                     scale=sc0.scale, sigma2=sc0.sigma2, fit=fit0.copy(), iteration=sc0.iteration, status=0, global_transformation=1,
+                     step_length=1.0)
+    st = go.cpd_update(mo, target, st_in, w=0.1, z=z) if flavour == 0 else go.icp_update(mo, target, st_in, 4.0, 1.0, 20, z=z)[0]
+    assert rel(fit2, st.fit) < 1e-5
+    single.close()
+    multi.close()
