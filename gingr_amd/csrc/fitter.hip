@@ -1719,8 +1719,10 @@ int fitter_logpdf_finish(gingr_fitter *f, double *logpdf) {
     GINGR_TRY(check_launch(ctx));
     double *res = f->pin + (size_t)3 * m->M;
     HIP_TRY(ctx, hipMemcpyAsync(res, f->small, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(qte, 0, (size_t)rp * sizeof(double), ctx->stream));
-    if (f->partial_out) HIP_TRY(ctx, hipMemsetAsync(f->partial_out + f->off[1] + (int64_t)rp * rp + rp + 8, 0, (size_t)rp * sizeof(double), ctx->stream));
+    // in-place exchanges (RCCL, host callback) would keep adding a stale tail up, so it goes back to zero.  NOT the device group's send
+    // buffer: a slower peer may still be reading it (double buffering protects the next WRITE, two exchanges later, not a write now);
+    // its stale partial is harmless -- the group's sum is out of place, and updates never read the tail.
+    if (!f->partial_out) HIP_TRY(ctx, hipMemsetAsync(qte, 0, (size_t)rp * sizeof(double), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (res[1] != 0.0) return gingr_set_error(ctx, GINGR_ERR_NOT_SPD, "posterior_logpdf: posterior of the current state failed");
     if (!std::isfinite(res[0])) return gingr_set_error(ctx, GINGR_ERR_NONFINITE, "posterior_logpdf: non-finite result");

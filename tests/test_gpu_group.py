@@ -285,6 +285,12 @@ def test_group_cpd_and_pointcloud_sample_and_logpdf(flavour):
     _set(multi, a0, sc0)
     l1 = single.posterior_logpdf(flavour, params, fit1)
     l2 = multi.posterior_logpdf(flavour, params, fit1)
+    if flavour == 0:
+        st0 = go.State(alpha=a0.copy(), euler=tuple(sc0.euler[:]), center=np.array(sc0.center[:]), translation=np.array(sc0.translation[:]),
+                       scale=sc0.scale, sigma2=sc0.sigma2, fit=fit0.copy(), iteration=sc0.iteration, status=0, global_transformation=1,
+                       step_length=1.0)
+        want = go.posterior_logpdf_of_mesh(mo, st0, *go.cpd_observations(mo, target, st0, w=0.1), mesh=fit1)
+        assert abs(l1 - want) < 1e-5 * abs(want) and abs(l2 - want) < 1e-5 * abs(want), (l1, l2, want)
     assert np.isfinite(l1) and abs(l2 - l1) < 1e-8 * abs(l1), (l1, l2)
     # oracle: the same sampled update from the same state
     st_in = go.State(alpha=a0.copy(), euler=tuple(sc0.euler[:]), center=np.array(sc0.center[:]), translation=np.array(sc0.translation[:]),
