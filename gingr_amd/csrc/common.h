@@ -32,7 +32,7 @@ struct gingr_ctx {
     // exact-zero tile culling of the CPD passes and exact pruning of the closest-point scans (affinity.hip); gingr_ctx_set_option
     // (GINGR_OPT_CULL, 0) disables both (results must stay bit-identical: the culling test compares the two)
     int cull = 1;
-    int nn_grid = 1;  // GINGR_OPT_NN_GRID: closest point over the target's uniform grid (nn_grid.hip); 0 = the tile scan alone
+    int nn_grid = 1;  // GINGR_OPT_NN_GRID: closest point over the target's uniform grid (nn_grid.hip); 0 = the tile scan alone; 2 = gingr_nn too
     // Culling regime of the CPD passes as the DEVICE last saw it (0 plain, 1 quarter-tile culling pays): pinned host word the
     // all-pairs kernels write, read -- unsynchronised, possibly a few launches stale -- when the next launch picks its kernel
     // variant.  Both variants compute bit-identical results, so a stale value only costs time.  Null: always the plain variant.

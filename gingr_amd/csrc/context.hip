@@ -129,7 +129,7 @@ int gingr_ctx_set_option(gingr_ctx *ctx, int32_t option, int32_t value) {
     switch (option) {
         case GINGR_OPT_CULL: ctx->cull = value != 0; return GINGR_OK;
         case GINGR_OPT_FINE_CULL: ctx->fine_override = value < 0 ? -1 : (value != 0); return GINGR_OK;
-        case GINGR_OPT_NN_GRID: ctx->nn_grid = value != 0; return GINGR_OK;
+        case GINGR_OPT_NN_GRID: ctx->nn_grid = value < 0 ? 0 : (value > 2 ? 2 : value); return GINGR_OK;
         default: return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "ctx_set_option: unknown option %d", option);
     }
 }
@@ -167,7 +167,10 @@ int gingr_ctx_nn_counting(gingr_ctx *ctx, int32_t enable) {
         HIP_TRY(ctx, hipMalloc(&p, sizeof(unsigned long long)));
         ctx->nn_tests = static_cast<unsigned long long *>(p);
     }
-    if (ctx->nn_tests) HIP_TRY(ctx, hipMemset(ctx->nn_tests, 0, sizeof(unsigned long long)));
+    if (ctx->nn_tests) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->nn_tests, 0, sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (!enable && ctx->nn_tests) {
         (void)hipFree(ctx->nn_tests);
         ctx->nn_tests = nullptr;
@@ -303,37 +306,49 @@ int gingr_nn(gingr_ctx *ctx, int64_t M, const double *query, int64_t N, const do
     if (M < 1 || N < 1 || !query || !target) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "nn: M, N must be >= 1");
     if (N > INT32_MAX) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "nn: N exceeds int32 index range");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf sq, st, dq, dt, dws, didx, dd2, dperm, dboxes;
+    DevBuf sq, st, dq, dt, dws, didx, dd2, dperm, dqperm, dboxes;
     Cloud cq, ct;
-    GINGR_TRY(upload_cloud(ctx, M, query, sq, dq, &cq));
-    // From a few thousand targets on the search runs over a uniform grid of the target cloud, built here on the host from the
-    // caller's array (round 4: the grid search of the fitter's ICP path, nn_grid.hip, for the stateless call as well -- the tile scan
-    // alone is one round of ~80 short workgroups at 5 000 x 5 000, 29.7 us, 25 M distance tests).  As in the fitter the targets then
-    // live in the spatial (k-d leaf) order on the device, with their tile boxes: queries the grid cannot certify are flagged and
-    // answered by the masked, box-pruned tile scan behind it, which exits at once when there are none.  Same distances, same
-    // lowest-original-index tie rule: the indices are bit-identical either way (GINGR_OPT_NN_GRID = 0 keeps the scan alone;
-    // tests/test_gpu_nn_grid.py compares the two).
-    const bool use_grid = ctx->nn_grid && ctx->cull && N >= 2048 && M >= 256;
-    std::vector<int32_t> perm;
+    // From a few thousand points on both clouds are put into the spatial (k-d leaf) order of the fitter on the way to the device
+    // (round 4; the host has the arrays anyway): the tile scan then prunes by the 256-target tile boxes and their quarter boxes against
+    // spatially coherent waves of queries, exactly as inside a registration, instead of testing all pairs (5 000 x 5 000: 25 M distance
+    // tests in one round of ~80 short workgroups, 29.7 us).  GINGR_OPT_NN_GRID additionally searches a uniform grid of the targets
+    // first (nn_grid.hip) and leaves the scan only the queries the grid cannot certify -- the fitter's warm-started search; from a
+    // cold start it is slower than the pruned scan (64 us at 5 000 x 5 000), so the stateless call does not use it unless the option
+    // is set to 2.  Same distances, same lowest-original-index tie rule in every variant: the indices are bit-identical
+    // (tests/test_gpu_nn_grid.py compares them; GINGR_OPT_CULL = 0 is the plain scan of all pairs).
+    const bool ordered = ctx->cull && N >= 2048 && M >= 256;
+    const bool use_grid = ordered && ctx->nn_grid == 2;
+    std::vector<int32_t> perm, qperm;
     NNGrid grid;
-    if (use_grid) {
+    if (ordered) {
         morton_order(target, N, perm);
+        morton_order(query, M, qperm);
         HIP_TRY(ctx, st.alloc((size_t)N * 3 * sizeof(double)));
         HIP_TRY(ctx, dt.alloc((size_t)N * 3 * sizeof(double)));
+        HIP_TRY(ctx, sq.alloc((size_t)M * 3 * sizeof(double)));
+        HIP_TRY(ctx, dq.alloc((size_t)M * 3 * sizeof(double)));
         HIP_TRY(ctx, dperm.alloc((size_t)N * sizeof(int32_t)));
+        HIP_TRY(ctx, dqperm.alloc((size_t)M * sizeof(int32_t)));
         HIP_TRY(ctx, dboxes.alloc((size_t)ceil_div(N, 256) * 30 * sizeof(double)));
         HIP_TRY(ctx, hipMemcpyAsync(st.p, target, (size_t)N * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(sq.p, query, (size_t)M * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(dperm.p, perm.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dqperm.p, qperm.data(), (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
         launch_aos_to_soa(ctx, st.as<double>(), N, dt.as<double>(), dperm.as<int32_t>());
-        double *sp = dt.as<double>();
+        launch_aos_to_soa(ctx, sq.as<double>(), M, dq.as<double>(), dqperm.as<int32_t>());
+        double *sp = dt.as<double>(), *qp = dq.as<double>();
         ct = Cloud{sp, sp + N, sp + 2 * N, N};
+        cq = Cloud{qp, qp + M, qp + 2 * M, M};
         launch_tile_bbox(ctx, ct, dboxes.as<double>());
-        const int rc = nn_grid_build(ctx, target, N, perm.data(), M, &grid);
-        if (rc != GINGR_OK) {
-            nn_grid_free(&grid);
-            return rc;
+        if (use_grid) {
+            const int rc = nn_grid_build(ctx, target, N, perm.data(), M, &grid);
+            if (rc != GINGR_OK) {
+                nn_grid_free(&grid);
+                return rc;
+            }
         }
     } else {
+        GINGR_TRY(upload_cloud(ctx, M, query, sq, dq, &cq));
         GINGR_TRY(upload_cloud(ctx, N, target, st, dt, &ct));
     }
     HIP_TRY(ctx, dws.alloc((size_t)nn_ws_bytes(M, N)));
@@ -343,7 +358,7 @@ int gingr_nn(gingr_ctx *ctx, int64_t M, const double *query, int64_t N, const do
         launch_nn_grid(ctx, cq, ct, dperm.as<int32_t>(), grid, nullptr, didx.as<int32_t>(), dd2.as<double>());
         launch_nn(ctx, cq, ct, dperm.as<int32_t>(), dboxes.as<double>(), dws.p, didx.as<int32_t>(), dd2.as<double>(), nullptr, grid.flag,
                   grid.cur_nflag());
-    } else if (use_grid) {  // (no grid could be built: degenerate extents) the box-pruned scan over the ordered cloud
+    } else if (ordered) {
         launch_nn(ctx, cq, ct, dperm.as<int32_t>(), dboxes.as<double>(), dws.p, didx.as<int32_t>(), dd2.as<double>());
     } else {
         launch_nn(ctx, cq, ct, nullptr, nullptr, dws.p, didx.as<int32_t>(), dd2.as<double>());
@@ -360,12 +375,23 @@ int gingr_nn(gingr_ctx *ctx, int64_t M, const double *query, int64_t N, const do
         HIP_TRY(ctx, se);
     }
     std::vector<double> hd2((size_t)M);
-    if (idx) HIP_TRY(ctx, hipMemcpyAsync(idx, didx.p, M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<int32_t> hidx((size_t)M);
+    HIP_TRY(ctx, hipMemcpyAsync(hidx.data(), didx.p, M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(hd2.data(), dd2.p, M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ordered) {  // device positions of queries and targets -> the caller's numbering
+        std::vector<double> t2((size_t)M);
+        std::vector<int32_t> ti((size_t)M);
+        for (int64_t s2 = 0; s2 < M; ++s2) {
+            const int32_t row = qperm[(size_t)s2], pos = hidx[(size_t)s2];
+            ti[(size_t)row] = (pos >= 0 && pos < N) ? perm[(size_t)pos] : -1;
+            t2[(size_t)row] = hd2[(size_t)s2];
+        }
+        hidx.swap(ti);
+        hd2.swap(t2);
+    }
+    if (idx) memcpy(idx, hidx.data(), M * sizeof(int32_t));
     if (d2) memcpy(d2, hd2.data(), M * sizeof(double));
-    if (idx && use_grid)  // positions in the ordered cloud -> the caller's numbering
-        for (int64_t i = 0; i < M; ++i) idx[i] = (idx[i] >= 0 && idx[i] < N) ? perm[(size_t)idx[i]] : -1;
     if (mean_distance) {
         // distance += (p - closestPoint).norm in index order; / numberOfPoints    ClosestPointRegistrator.scala:143,146
         double s = 0.0;

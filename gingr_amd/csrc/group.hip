@@ -587,7 +587,9 @@ int gingr_group_set_target(gingr_group *g, int64_t N, const double *target_xyz) 
             if (rc) return fail(rc, nullptr);
             g->send[p][(size_t)r] = static_cast<double *>(buf);
             g->fine_grained = g->fine_grained && fine;
-            if (hipMemset(buf, 0, (size_t)total * sizeof(double)) != hipSuccess) return fail(GINGR_ERR_HIP, "group: memset failed");
+            // (hipMemset runs on the null stream, which the contexts' non-blocking streams do not order against: wait for it here)
+            if (hipMemset(buf, 0, (size_t)total * sizeof(double)) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+                return fail(GINGR_ERR_HIP, "group: memset failed");
             for (int s = 0; s < GINGR_NUM_SEGMENTS; ++s)
                 if (hipEventCreateWithFlags(&g->ready[p][s][(size_t)r], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess)
                     return fail(GINGR_ERR_HIP, "group: hipEventCreate failed");
@@ -619,7 +621,8 @@ int gingr_group_set_meshes(gingr_group *g, int64_t n_model_triangles, const int3
             GINGR_TRY(alloc_peer_readable(g, bytes, &buf, &fine));
             g->sendfit[p][(size_t)r] = static_cast<double *>(buf);
             g->fine_grained = g->fine_grained && fine;
-            if (hipMemset(buf, 0, bytes) != hipSuccess) return group_fail(g, GINGR_ERR_HIP, "group: memset failed");
+            if (hipMemset(buf, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+                return group_fail(g, GINGR_ERR_HIP, "group: memset failed");
             if (hipEventCreateWithFlags(&g->readyfit[p][(size_t)r], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess)
                 return group_fail(g, GINGR_ERR_HIP, "group: hipEventCreate failed");
         }

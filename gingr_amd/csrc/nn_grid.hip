@@ -272,10 +272,13 @@ int nn_grid_build(gingr_ctx *ctx, const double *target_xyz, int64_t N, const int
     HIP_TRY(ctx, hipMalloc(&g->pts, pts.size() * sizeof(GridPoint)));
     HIP_TRY(ctx, hipMalloc(&g->flag, (size_t)max_queries));
     HIP_TRY(ctx, hipMalloc(&g->nflag, 2 * sizeof(int32_t)));
-    HIP_TRY(ctx, hipMemcpy(g->cell_start, start.data(), start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(g->pts, pts.data(), pts.size() * sizeof(GridPoint), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemset(g->flag, 0, (size_t)max_queries));
-    HIP_TRY(ctx, hipMemset(g->nflag, 0, 2 * sizeof(int32_t)));
+    // on the CONTEXT's stream (a non-blocking stream does not order against the null stream a plain hipMemset runs on: a search
+    // launched right behind the build -- the stateless gingr_nn -- could count its flagged queries before the counters were cleared)
+    HIP_TRY(ctx, hipMemcpyAsync(g->cell_start, start.data(), start.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(g->pts, pts.data(), pts.size() * sizeof(GridPoint), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(g->flag, 0, (size_t)max_queries, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(g->nflag, 0, 2 * sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the host arrays above go out of scope
     for (int d = 0; d < 3; ++d) g->v.lo[d] = lo[d], g->v.g[d] = gd[d];
     g->v.h = h;
     g->v.inv_h = inv_h;

@@ -70,7 +70,9 @@ const char *gingr_build_info(void);
  * they exist for those tests and for same-box timing comparisons, not for tuning -- nothing in the library reads the environment.
  *   GINGR_OPT_CULL       1 (default) / 0: exact-zero tile culling of the CPD passes and exact pruning of the closest-point scans
  *   GINGR_OPT_FINE_CULL  -1 (default: by the regime the device reports) / 0 / 1: quarter-tile culling variant of the CPD passes
- *   GINGR_OPT_NN_GRID    1 (default) / 0: the ICP closest point searches the target's uniform grid first / tile scan only
+ *   GINGR_OPT_NN_GRID    1 (default) / 0: the ICP closest point searches the target's uniform grid first / tile scan only;
+ *                        2: as 1, and the stateless gingr_nn searches a grid too (built per call; from a cold start the
+ *                        box-pruned scan it uses by default is faster)
  * No reference counterpart (the reference has one code path per operation). */
 typedef enum gingr_ctx_option { GINGR_OPT_CULL = 0, GINGR_OPT_FINE_CULL = 1, GINGR_OPT_NN_GRID = 2 } gingr_ctx_option;
 int gingr_ctx_set_option(gingr_ctx *ctx, int32_t option, int32_t value);

@@ -150,8 +150,9 @@ def test_benchmark_size_against_the_stateless_tile_scan(ctx):
     from gingr_amd import _native as nat
     from bench import synth_clouds
     y, x = synth_clouds(50000)
-    scan = ga.Context(0)
-    scan.set_option(nat.OPT_NN_GRID, 0)     # the stateless call searches the grid too since round 4: this context keeps the tile scan alone
+    scan = ga.Context(0)                    # the stateless call: box-pruned tile scan over spatially ordered clouds, no grid
+    grid = ga.Context(0)
+    grid.set_option(nat.OPT_NN_GRID, 2)     # ... and with a grid of its own, built per call, cold start
     rng = np.random.default_rng(2)
     r = 8
     U, _ = np.linalg.qr(rng.normal(0, 1, (3 * y.shape[0], r)))
@@ -166,16 +167,18 @@ def test_benchmark_size_against_the_stateless_tile_scan(ctx):
         got = algo.last_correspondence_indices()
         assert np.array_equal(got, want), (it, int(np.sum(got != want)))
         # ... and the stateless call with its own grid (built per call from the caller's arrays, no warm start): the same again
-        again, ad2, _ = ctx.nn(fit_before, x)
+        again, ad2, _ = grid.nn(fit_before, x)
         assert np.array_equal(again, want) and np.array_equal(ad2, wd2), it
     algo.close()
     scan.close()
+    grid.close()
 
 
 @pytest.mark.parametrize("seed", range(6))
 def test_stateless_grid_search_equals_the_tile_scan(ctx, seed):
-    """gingr_nn with and without the grid on awkward inputs (ties on a lattice, a flat cloud, far queries, NaN queries): identical
-    indices and distances; below the size threshold both take the scan."""
+    """gingr_nn as the plain scan of all pairs (GINGR_OPT_CULL = 0), as the box-pruned scan over ordered clouds (default) and with a
+    per-call grid (GINGR_OPT_NN_GRID = 2) on awkward inputs (ties on a lattice, a flat cloud, far queries): identical indices, distances
+    and mean distance."""
     import gingr_amd as ga
     from gingr_amd import _native as nat
     rng = np.random.default_rng(100 + seed)
@@ -189,12 +192,16 @@ def test_stateless_grid_search_equals_the_tile_scan(ctx, seed):
     query = np.concatenate([target[rng.integers(0, n, 1500)] + rng.normal(0, 0.7, (1500, 3)),      # near the cloud
                             np.round(rng.uniform(0, 15, (600, 3)) * 2) / 2,                        # half-integer points: exact ties on the lattice
                             rng.normal(0, 1, (50, 3)) * 1e4])                                      # far away
-    scan = ga.Context(0)
-    scan.set_option(nat.OPT_NN_GRID, 0)
-    want, wd2, wmd = scan.nn(query, target)
-    got, gd2, gmd = ctx.nn(query, target)
-    assert np.array_equal(got, want) and np.array_equal(gd2, wd2) and gmd == wmd
-    scan.close()
+    brute = ga.Context(0)
+    brute.set_option(nat.OPT_CULL, 0)
+    grid = ga.Context(0)
+    grid.set_option(nat.OPT_NN_GRID, 2)
+    want, wd2, wmd = brute.nn(query, target)
+    for c in (ctx, grid):
+        got, gd2, gmd = c.nn(query, target)
+        assert np.array_equal(got, want) and np.array_equal(gd2, wd2) and gmd == wmd
+    brute.close()
+    grid.close()
 
 
 def test_heaps_of_coincident_targets(ctx):

@@ -129,7 +129,20 @@ def config2():
         ctx.nn(query, target)
     ms, k = ctx.timing_read(8)
     ctx.timing_enable(False)
-    avg_ms = ms / reps                                                # per CALL: the grid search and the masked scan behind it (k = 2 launches per call)
+    avg_ms = ms / reps                                                # per CALL (all search launches of a call)
+    variants = {}
+    from gingr_amd import _native as nat
+    for name, opt, val in (("all_pairs_scan_unordered", nat.OPT_CULL, 0), ("per_call_grid_cold_start", nat.OPT_NN_GRID, 2)):
+        c2 = ga.Context(0)
+        c2.set_option(opt, val)
+        i2, _, _ = c2.nn(query, target)
+        c2.timing_enable(True)
+        c2.timing_reset()
+        for _ in range(reps):
+            c2.nn(query, target)
+        ms2, k2 = c2.timing_read(8)
+        variants[name] = {"us_per_call": ms2 / reps * 1e3, "launches_per_call": int(k2 // reps), "indices_equal": bool(np.array_equal(i2, idx))}
+        c2.close()
     ctx.nn_counting(True)
     ctx.nn(query, target)
     tests = float(ctx.nn_tests())
@@ -173,13 +186,12 @@ def config2():
            "unit": "queries/s", "n_gpus": 1, "steps": reps, "ms_per_step": avg_ms, "higher_is_better": True, "dtype": "f64",
            "data": "reference demo data (bunny PLY, 5 000 vertices sub-sampled, seed 7) + perturbed copy as queries",
            "config_detail": {"workload": f"gingr_nn kernels, {M} queries x {N} targets, exact f64 distances (separately rounded products), "
-                                          "lowest index on ties; stateless entry point: uniform grid of the targets built per call on the "
-                                          "host, grid search + masked tile scan for what the grid cannot certify (round 4; the tile scan "
-                                          "alone: 29.7 us, 25 M distance tests)",
-                             "launches_per_call": int(k // max(reps, 1))},
+                                          "lowest index on ties; stateless entry point (round 4): both clouds in the fitter's spatial order, "
+                                          "tile scan pruned by tile / quarter boxes",
+                             "launches_per_call": int(k // max(reps, 1)), "other_variants": variants},
            "valid": exact, "parity_check": {"against": "tests/golden/expected.npz nn_idx (oracle brute force)", "indices_bit_exact": exact,
                                             "mean_distance": md},
-           "roofline": {"bound": "latency", "kernel": "nn_grid_kernel (+ masked nn_kernel)", "achieved": ach, "peak": F64_PEAK, "unit": "TFLOP/s",
+           "roofline": {"bound": "latency", "kernel": "nn_kernel (box-pruned) + nn_reduce_kernel", "achieved": ach, "peak": F64_PEAK, "unit": "TFLOP/s",
                         "frac": ach / F64_PEAK, "traffic": None, "distance_tests_per_call": tests, "all_pairs": float(M) * N,
                         "algorithmic_flops_per_test": 9.0, "all_pairs_equivalent_tflops": 9.0 * float(M) * N / (avg_ms * 1e-3) / 1e12,
                         "note": "the exact search no longer evaluates all pairs (distance tests per call above), so flops / peak says "
