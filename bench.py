@@ -602,8 +602,8 @@ def main():
         avg = ms / n
         rp = (args.rank + 15) // 16 * 16
         gbs = 24.0 * m_loc * rp / (avg * 1e-3) / 1e9
-        tr, src = load_pmc_traffic("sweep_kernel", M, args.rank) if n_shards == 1 else (None, None)
-        kernels.append({"kernel": "sweep_kernel", "avg_ms": avg, "launches": n, "bound": "hbm", "achieved": gbs,
+        tr, src = load_pmc_traffic("sweep_fit_boxes_kernel", M, args.rank) if n_shards == 1 else (None, None)
+        kernels.append({"kernel": "sweep_fit_boxes_kernel", "avg_ms": avg, "launches": n, "bound": "hbm", "achieved": gbs,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "algorithmic_bytes": 24.0 * m_loc * rp, "traffic": tr, "traffic_source": src})
     ms, n = timing(5)
@@ -626,7 +626,7 @@ def main():
         exchange = {"path": exchange_path if use_dist else "in-library device group (peer pointers)",
                     "rccl": ctx.rccl_info() if (use_dist and native) else None,
                     "segment0_column_sums_ms": ex[0], "segment1_gram_bundle_ms": ex[1],
-                    "bytes": {"segment0": 8 * N, "segment1": 8 * (((args.rank + 15) // 16 * 16) ** 2 + (args.rank + 15) // 16 * 16 + 8)},
+                    "bytes": {"segment0": 8 * N, "segment1": 8 * (((args.rank + 15) // 16 * 16) ** 2 + 2 * ((args.rank + 15) // 16 * 16) + 8)},
                     "how": "HIP events around each all-reduce on the stream the kernels run on, averaged over the roofline "
                            "iterations, max over ranks; includes the wait for the slowest peer"}
     timing(enable=False)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One reproducible measurement line per BASELINE.json config (`python bench.py --config N` prints line N; run as a script it
-runs all five and writes gpurun_out/r03_configs.json -- copy it to profiles/).
+runs all five and writes gpurun_out/r04_configs.json -- copy it to profiles/).
 
   1  femur CPD, 1 622 <-> 1 622 vertices of the reference's own demo data (tests/golden/inputs.npz), Gaussian GPMM (70, 50) built on the
      device, DemoCPD settings (examples/DemoCPD.scala:11-25: CpdConfiguration defaults, NoTransforms) -- the reference's CPU-runnable case
@@ -254,7 +254,7 @@ def main():
         print(json.dumps(o), flush=True)
     if len(which) > 1:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        json.dump(lines, open(os.path.join(ROOT, "gpurun_out", "r03_configs.json"), "w"), indent=1)
+        json.dump(lines, open(os.path.join(ROOT, "gpurun_out", "r04_configs.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

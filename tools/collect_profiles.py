@@ -7,7 +7,7 @@ import shutil
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "04"
 F, P = os.path.join(root, "gpurun_out", "final"), os.path.join(root, "profiles")
 
 
@@ -27,8 +27,9 @@ e50 = {str(n): load(f"emu{n}.json")["ms_per_step"] for n in (1, 2, 4, 8)}
 one100 = load("bench_100k.json")
 e100 = {"1": one100["ms_per_step"], **{str(n): load(f"emu100k_{n}.json")["ms_per_step"] for n in (2, 4, 8)}}
 json.dump({
-    "what": "emulated per-rank iteration time of a row shard (one GPU runs rank 0's share of an N-rank job; exchange = 1-rank "
-            "all-reduce through torch.distributed; timing experiment, not a valid registration)",
+    "what": "emulated per-rank iteration time of a row shard (one GPU runs rank 0's share of an N-rank job; exchange = the library's "
+            "native RCCL path with a ONE-rank communicator, i.e. ncclAllReduce enqueued by libgingr_hip between the phases, no Python "
+            "in the loop -- rounds 1-3 measured this through a torch.distributed callback; timing experiment, not a valid registration)",
     "command": "python bench.py --emulate-world N --no-cpu-baseline --no-parity-check --steps 100 --warmup 10 --roofline-steps 0 "
                "(100k: --points 100000 --steps 40 --warmup 5)",
     "ms_per_iteration_50k": e50,

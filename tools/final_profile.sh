@@ -7,8 +7,8 @@ R=$GRAFT_REPO_ROOT
 F=$R/gpurun_out/final
 rm -rf $F; mkdir -p $F
 cd $R
-bash tools/pmc_traffic.sh > $F/pmc_traffic.txt 2>&1 && cp gpurun_out/pmc_traffic.json $F/pmc_traffic.json && cp gpurun_out/pmc_traffic.json profiles/r03_pmc_traffic.json
-bash tools/pmc_sq.sh > $F/pmc_sq.txt 2>&1; cp gpurun_out/pmc_mfma.json $F/pmc_mfma.json; cp gpurun_out/pmc_mfma.json profiles/r03_pmc_mfma.json
+bash tools/pmc_traffic.sh > $F/pmc_traffic.txt 2>&1 && cp gpurun_out/pmc_traffic.json $F/pmc_traffic.json && cp gpurun_out/pmc_traffic.json profiles/r04_pmc_traffic.json
+bash tools/pmc_sq.sh > $F/pmc_sq.txt 2>&1; cp gpurun_out/pmc_mfma.json $F/pmc_mfma.json; cp gpurun_out/pmc_mfma.json profiles/r04_pmc_mfma.json
 python3 bench.py 2> $F/bench.err | tail -1 > $F/bench.json
 bash tools/prof_stats.sh final > $F/kernel_stats.txt 2>&1; cp gpurun_out/prof_final/kernel_stats.csv $F/kernel_stats.csv
 for n in 1 2 4 8; do python3 bench.py --emulate-world $n --no-cpu-baseline --no-parity-check --steps 100 --warmup 10 --roofline-steps 0 2>/dev/null | tail -1 > $F/emu$n.json; done
@@ -17,7 +17,7 @@ python3 bench.py --points 15000 --no-cpu-baseline 2>/dev/null | tail -1 > $F/ben
 python3 bench.py --points 100000 --no-cpu-baseline 2>/dev/null | tail -1 > $F/bench_100k.json
 for n in 2 4 8; do python3 bench.py --points 100000 --emulate-world $n --no-cpu-baseline --no-parity-check --steps 40 --warmup 5 --roofline-steps 0 2>/dev/null | tail -1 > $F/emu100k_$n.json; done
 python3 bench.py --group --logical-shards 2 --no-cpu-baseline 2>/dev/null | tail -1 > $F/bench_group_logical2.json
-timeout 1500 python3 tools/bench_configs.py > $F/configs.txt 2> $F/configs.err; cp gpurun_out/r03_configs.json $F/configs.json
+timeout 1500 python3 tools/bench_configs.py > $F/configs.txt 2> $F/configs.err; cp gpurun_out/r04_configs.json $F/configs.json
 python3 - <<'PY'
 import json
 d = json.load(open("gpurun_out/final/bench.json"))
