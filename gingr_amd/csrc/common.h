@@ -32,6 +32,7 @@ struct gingr_ctx {
     // exact-zero tile culling of the CPD passes and exact pruning of the closest-point scans (affinity.hip); gingr_ctx_set_option
     // (GINGR_OPT_CULL, 0) disables both (results must stay bit-identical: the culling test compares the two)
     int cull = 1;
+    int tri_grid = 1;  // GINGR_OPT_TRI_GRID: closest surface point over the target's triangle grid (surface.hip); 0 = the tile scan alone
     int nn_grid = 1;  // GINGR_OPT_NN_GRID: closest point over the target's uniform grid (nn_grid.hip); 0 = the tile scan alone; 2 = gingr_nn too
     // Culling regime of the CPD passes as the DEVICE last saw it (0 plain, 1 quarter-tile culling pays): pinned host word the
     // all-pairs kernels write, read -- unsynchronised, possibly a few launches stale -- when the next launch picks its kernel
@@ -198,9 +199,34 @@ void launch_vertex_normals(gingr_ctx *ctx, const int32_t *adj_ptr, const int32_t
                            int64_t n, double *vn_soa);
 void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *boxes, double *tribox = nullptr);
 // closest point of the triangle soup to every query (SoA out); exact ties: lowest tri_orig
+// mask / nmask (nullable, device): only queries with mask[i] != 0 are answered and the launch is a no-op when *nmask == 0 (what
+// launch_surface_cp_grid leaves behind: TriGrid::flag, TriGrid::cur_nflag())
 void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T,
                                   const double *boxes, double *cp_soa, double *d2, int32_t *tri_out = nullptr, int32_t *warm = nullptr,
-                                  bool warm_valid = false, const double *tribox = nullptr);
+                                  bool warm_valid = false, const double *tribox = nullptr, const uint8_t *mask = nullptr,
+                                  const int32_t *nmask = nullptr);
+// uniform grid over the (fixed) triangles of a mesh: cell -> triangles whose box overlaps it (surface.hip)
+struct TriGridDev {
+    double lo[3];
+    double h, inv_h;
+    int32_t g[3];
+    const int32_t *cell_start;  // [g0 g1 g2 + 1], x fastest
+    const int32_t *tris;        // triangle positions (in the device's triangle order), cell after cell
+};
+struct TriGrid {
+    TriGridDev v{};
+    int32_t *cell_start = nullptr, *tris = nullptr;
+    uint8_t *flag = nullptr;   // [max_queries]: queries the grid search could not certify
+    int32_t *nflag = nullptr;  // two counters used alternately (as NNGrid)
+    int parity = 0;
+    int64_t max_queries = 0, list_entries = 0;
+    bool ready = false;
+    const int32_t *cur_nflag() const { return nflag + parity; }
+};
+int tri_grid_build(gingr_ctx *ctx, const double *vsoa_host, int64_t n, const int32_t *tri_host, int64_t T, int64_t max_queries, TriGrid *g);
+void tri_grid_free(TriGrid *g);
+void launch_surface_cp_grid(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T, TriGrid &g,
+                            const double *tribox, double *cp_soa, double *d2, int32_t *tri_out, int32_t *warm);
 // bary[3 i + k] = weight of corner k of triangle tri_id[i] at the closest point of that triangle to query i; tri_by_orig [3 T]:
 // corner positions in the cloud v, indexed by ORIGINAL triangle number
 void launch_barycentric(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri_by_orig, const int32_t *tri_id, double *bary);

@@ -130,6 +130,7 @@ int gingr_ctx_set_option(gingr_ctx *ctx, int32_t option, int32_t value) {
         case GINGR_OPT_CULL: ctx->cull = value != 0; return GINGR_OK;
         case GINGR_OPT_FINE_CULL: ctx->fine_override = value < 0 ? -1 : (value != 0); return GINGR_OK;
         case GINGR_OPT_NN_GRID: ctx->nn_grid = value < 0 ? 0 : (value > 2 ? 2 : value); return GINGR_OK;
+        case GINGR_OPT_TRI_GRID: ctx->tri_grid = value != 0; return GINGR_OK;
         default: return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "ctx_set_option: unknown option %d", option);
     }
 }
@@ -140,6 +141,7 @@ int gingr_ctx_get_option(gingr_ctx *ctx, int32_t option, int32_t *value) {
         case GINGR_OPT_CULL: *value = ctx->cull; return GINGR_OK;
         case GINGR_OPT_FINE_CULL: *value = ctx->fine_override; return GINGR_OK;
         case GINGR_OPT_NN_GRID: *value = ctx->nn_grid; return GINGR_OK;
+        case GINGR_OPT_TRI_GRID: *value = ctx->tri_grid; return GINGR_OK;
         default: return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "ctx_get_option: unknown option %d", option);
     }
 }

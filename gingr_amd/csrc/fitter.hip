@@ -113,6 +113,7 @@ struct gingr_fitter {
     bool surf_tri_warm = false;
     bool nn_warm = false, surf_nn_warm = false;  // nn_idx / surf_nn hold last time's matches against the CURRENT target
     NNGrid tgrid;  // uniform grid over the target cloud (set_target): the point-cloud ICP's closest-point search (nn_grid.hip)
+    TriGrid ttgrid;  // uniform grid over the target TRIANGLES (set_meshes): the surface ICP's closest surface point (surface.hip)
     void forget_posteriors() {
         post_stage = 0;
         alt_stage = 0;
@@ -244,6 +245,7 @@ void free_meshes(gingr_fitter *f) {
     f->surf_cp = f->surf_d2 = f->surf_w01 = f->surf_win = f->surf_nnd2 = nullptr;
     f->surf_nn = f->surf_pre = f->surf_hit = f->surf_tri_pos = nullptr;
     f->surf_tri_warm = f->surf_nn_warm = false;
+    tri_grid_free(&f->ttgrid);
     f->Tm = f->Tt = 0;
 }
 
@@ -582,6 +584,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->part);
     dev_free(f->absmax);
     nn_grid_free(&f->tgrid);
+    tri_grid_free(&f->ttgrid);
     dev_free(f->tperm);
     dev_free(f->tboxes);
     dev_free(f->fboxes);
@@ -1052,8 +1055,13 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 const bool along = f->surface_method == 1;  // ClosestPointAlongNormalTriangleMesh3D (:102-131)
                 if (along)
                     launch_line_nearest(ctx, fit, f->mvn, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, f->surf_cp, f->surf_hit);
-                else
-                {
+                else if (ctx->tri_grid && ctx->cull && f->ttgrid.ready && f->surf_tri_warm && M <= f->ttgrid.max_queries) {
+                    // grid search from the previous iteration's triangles, then the masked tile scan for what it flagged
+                    launch_surface_cp_grid(ctx, fit, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttgrid, f->ttribox, f->surf_cp, f->surf_d2, nullptr,
+                                           f->surf_tri_pos);
+                    launch_surface_closest_point(ctx, fit, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, f->surf_cp, f->surf_d2, nullptr,
+                                                 f->surf_tri_pos, true, f->ttribox, f->ttgrid.flag, f->ttgrid.cur_nflag());
+                } else {
                     launch_surface_closest_point(ctx, fit, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, f->surf_cp, f->surf_d2, nullptr,
                                                  f->surf_tri_pos, f->surf_tri_warm, f->ttribox);
                     f->surf_tri_warm = true;
@@ -1484,6 +1492,8 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
     launch_tri_tile_bbox(ctx, tgt, f->ttri, f->Tt, f->ttboxes, f->ttribox);
     GINGR_TRY(check_launch(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // the target triangles do not move: bin them once (the surface ICP's warm-started closest-point search)
+    GINGR_TRY(tri_grid_build(ctx, tpos.data(), N, bt.tri.data(), n_target_tri, M, &f->ttgrid));
     return GINGR_OK;
 }
 

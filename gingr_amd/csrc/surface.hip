@@ -19,6 +19,9 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+#include <cmath>
+
 namespace {
 
 constexpr int kTriTile = 256;
@@ -227,7 +230,11 @@ __global__ __launch_bounds__(kCpThreads) void surface_cp_queue_kernel(Cloud q, C
                                                                      const double *__restrict__ boxes, double *__restrict__ cp,
                                                                      double *__restrict__ d2out, int32_t *__restrict__ tri_out,
                                                                      const int32_t *warm_in, int32_t *pos_out /* may alias warm_in */,
-                                                                     const double *__restrict__ tribox) {
+                                                                     const double *__restrict__ tribox,
+                                                                     const uint8_t *__restrict__ mask, const int32_t *__restrict__ nmask) {
+    // mask / nmask (nullable): only the queries with mask[i] != 0 are answered -- what the triangle-grid search in front of this
+    // launch could not certify (surface_cp_grid_kernel) -- and the whole launch is a no-op when *nmask == 0
+    if (nmask && *nmask == 0) return;
     __shared__ double tbox[kTriTile][6];  // staged tile: the triangles' bounding boxes only (the exact test reads memory)
     constexpr int QPB = 64 / H;  // queries per workgroup
     __shared__ unsigned long long qbest[4][QPB];  // per wave and query: bits of the best squared distance so far
@@ -240,7 +247,8 @@ __global__ __launch_bounds__(kCpThreads) void surface_cp_queue_kernel(Cloud q, C
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ql = lane & (QPB - 1), half = lane / QPB;
     const int64_t i = (int64_t)blockIdx.x * QPB + ql;
-    const bool ok = i < q.n;
+    const bool ok = i < q.n && (!mask || mask[i] != 0);
+    if (mask && !__syncthreads_or(ok)) return;  // nothing flagged in this workgroup
     const double qx = ok ? q.x[i] : 0.0, qy = ok ? q.y[i] : 0.0, qz = ok ? q.z[i] : 0.0;
     const unsigned long long kInfBits = 0x7FF0000000000000ull;
     // Warm start (nullable): the triangle (position in `tri`) that was closest to this query LAST time -- a template vertex moves
@@ -400,6 +408,120 @@ __global__ __launch_bounds__(kCpThreads) void surface_cp_queue_kernel(Cloud q, C
         if (tri_out) tri_out[i] = (int32_t)qorig[w][ql];
         if (pos_out) pos_out[i] = qpos[w][ql];
     }
+}
+
+// ---- closest surface point over a uniform grid of the (fixed) target triangles (round 4) -------------------------------------------
+// The target mesh of a registration does not move, so gingr_fitter_set_meshes bins its triangles once: cell c lists (positions in
+// `tri` of) the triangles whose bounding box overlaps it.  A query starts from the triangle that was closest to it in the previous
+// scan (warm start; a template vertex moves little between two iterations): its exact distance r bounds the answer, and every
+// triangle that holds a point within r of the query has a bounding box that overlaps a cell the ball of radius r overlaps -- the
+// cell of that point -- so scanning the triangle lists of the cells [cell(q - r), cell(q + r)] (a slack of 1e-9 r covers the
+// rounding of the cell index; host and device evaluate the same floor((x - lo) * inv_h), which is monotone in x) finds the exact
+// minimum and, by the (distance, original triangle id) order, the same winner on ties as the tile scan.  Same point-triangle routine,
+// same separately rounded distance: bit-identical closest points.  A query whose ball covers more than kTriGridMaxCells cells (far
+// from the surface, the early iterations), a cold start, or a non-finite query is FLAGGED and answered by the masked tile scan
+// (surface_cp_queue_kernel) that follows.  kLanes lanes per query take the cells of the block in turn; a triangle listed in several
+// cells is evaluated more than once with the same result.
+constexpr int kTriGridMaxCells = 64;
+
+template <int kLanes>
+__global__ __launch_bounds__(256) void surface_cp_grid_kernel(Cloud q, Cloud v, const int32_t *__restrict__ tri,
+                                                             const int32_t *__restrict__ tri_orig, int64_t T, TriGridDev g,
+                                                             const double *__restrict__ tribox, double *__restrict__ cp,
+                                                             double *__restrict__ d2out, int32_t *__restrict__ tri_out,
+                                                             int32_t *warm /* in: last closest triangle, out: this one's */,
+                                                             uint8_t *__restrict__ flag, int32_t *__restrict__ nflag,
+                                                             int32_t *__restrict__ nflag_next) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nflag_next = 0;  // the counter of the NEXT search (nobody reads it during this one)
+    const int ql = threadIdx.x % kLanes;
+    const int64_t i = (int64_t)blockIdx.x * (256 / kLanes) + threadIdx.x / kLanes;
+    const bool ok = i < q.n;
+    const double qx = ok ? q.x[i] : 0.0, qy = ok ? q.y[i] : 0.0, qz = ok ? q.z[i] : 0.0;
+    const V3 p{qx, qy, qz};
+    double best = __builtin_huge_val();
+    unsigned bo = 0xFFFFFFFFu;
+    int bpos = -1;
+    V3 bp{qx, qy, qz};
+    auto consider = [&](int64_t pos) {
+        const int32_t va = tri[3 * pos], vb = tri[3 * pos + 1], vc = tri[3 * pos + 2];
+        const V3 c = closest_on_triangle(p, V3{v.x[va], v.y[va], v.z[va]}, V3{v.x[vb], v.y[vb], v.z[vb]}, V3{v.x[vc], v.y[vc], v.z[vc]});
+        const V3 dd = sub(c, p);
+        const double dist = (dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z;
+        const unsigned o = (unsigned)(tri_orig ? tri_orig[pos] : (int32_t)pos);
+        if (dist < best || (dist == best && o < bo)) {
+            best = dist;
+            bo = o;
+            bpos = (int)pos;
+            bp = c;
+        }
+    };
+    bool fl = ok;  // flagged unless the block below certifies the answer
+    if (ok) {
+        const int32_t tg = warm[i];
+        if (tg >= 0 && tg < T) consider(tg);
+        if (best < __builtin_huge_val()) {  // (NaN / no warm triangle: stays flagged)
+            const double r = sqrt(best) * (1.0 + 1e-9) + 1e-300;
+            const double f0[3] = {(qx - r - g.lo[0]) * g.inv_h, (qy - r - g.lo[1]) * g.inv_h, (qz - r - g.lo[2]) * g.inv_h};
+            const double f1[3] = {(qx + r - g.lo[0]) * g.inv_h, (qy + r - g.lo[1]) * g.inv_h, (qz + r - g.lo[2]) * g.inv_h};
+            bool fin = true;
+            int c0[3], c1[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                fin = fin && fabs(f0[d]) < 1e15 && fabs(f1[d]) < 1e15;
+                const double a = floor(f0[d]), b = floor(f1[d]);
+                c0[d] = a >= (double)(g.g[d] - 1) ? g.g[d] - 1 : (a > 0.0 ? (int)a : 0);
+                c1[d] = b >= (double)(g.g[d] - 1) ? g.g[d] - 1 : (b > 0.0 ? (int)b : 0);
+            }
+            const int nx = c1[0] - c0[0] + 1, ny = c1[1] - c0[1] + 1, nz = c1[2] - c0[2] + 1;
+            if (fin && (int64_t)nx * ny * nz <= kTriGridMaxCells) {
+                fl = false;
+                const int ncell = nx * ny * nz;
+                for (int k = ql; k < ncell; k += kLanes) {
+                    const int cz = k / (nx * ny), rem = k - cz * nx * ny, cy = rem / nx, cx = rem - cy * nx;
+                    const int64_t c = ((int64_t)(c0[2] + cz) * g.g[1] + (c0[1] + cy)) * g.g[0] + (c0[0] + cx);
+                    const int32_t e1 = g.cell_start[c + 1];
+                    for (int32_t e = g.cell_start[c]; e < e1; ++e) {
+                        const int32_t pos = g.tris[e];
+                        if (point_box_gap2(qx, qy, qz, tribox + 6 * (int64_t)pos) > best) continue;  // (equal: a possible tie, evaluated)
+                        consider(pos);
+                    }
+                }
+            }
+        }
+    }
+    // combine the lanes of the query: smallest distance, then lowest original triangle
+#pragma unroll
+    for (int off = kLanes / 2; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off);
+        const unsigned oo = (unsigned)__shfl_xor((int)bo, off);
+        const int op = __shfl_xor(bpos, off);
+        const double ox = __shfl_xor(bp.x, off), oy = __shfl_xor(bp.y, off), oz = __shfl_xor(bp.z, off);
+        if (ob < best || (ob == best && oo < bo)) {
+            best = ob;
+            bo = oo;
+            bpos = op;
+            bp = V3{ox, oy, oz};
+        }
+    }
+    if (ok && ql == 0) {
+        flag[i] = fl ? 1 : 0;
+        if (!fl) {
+            cp[i] = bp.x;
+            cp[q.n + i] = bp.y;
+            cp[2 * q.n + i] = bp.z;
+            d2out[i] = best;
+            if (tri_out) tri_out[i] = (int32_t)bo;
+            warm[i] = bpos;
+        }
+    }
+    // flagged queries of the workgroup: one atomic
+    const unsigned long long m = __ballot(ok && ql == 0 && fl);
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt, __builtin_popcountll(m));
+    __syncthreads();
+    if (threadIdx.x == 0 && cnt) atomicAdd(nflag, cnt);
 }
 
 // Barycentric weights (of A, B, C) of the closest point of triangle (A, B, C) to p: the region logic of closest_on_triangle with
@@ -834,7 +956,7 @@ void launch_barycentric(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri_by_
 }
 void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T,
                                   const double *boxes, double *cp_soa, double *d2, int32_t *tri_out, int32_t *warm, bool warm_valid,
-                                  const double *tribox) {
+                                  const double *tribox, const uint8_t *mask, const int32_t *nmask) {
     // queries per workgroup = 64 / H.  The kernel is bound by its longest workgroups: fewer queries per workgroup = more, shorter
     // workgroups and a tighter query box for the tile pruning.
     const int h = surface_h(q.n);
@@ -842,7 +964,7 @@ void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_
     const int32_t *win = (warm && warm_valid) ? warm : (const int32_t *)nullptr;
     auto go = [&](auto kern, int qpb) {
         hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(q.n, qpb)), dim3(kCpThreads), 0, ctx->stream, q, v, tri, tri_orig, T, boxes,
-                           cp_soa, d2, tri_out, win, warm, tribox);
+                           cp_soa, d2, tri_out, win, warm, tribox, mask, nmask);
     };
     if (h == 8)
         go(surface_cp_queue_kernel<8>, 8);
@@ -851,6 +973,119 @@ void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_
     else
         go(surface_cp_queue_kernel<4>, 16);
 }
+
+void tri_grid_free(TriGrid *g) {
+    if (g->cell_start) (void)hipFree(g->cell_start);
+    if (g->tris) (void)hipFree(g->tris);
+    if (g->flag) (void)hipFree(g->flag);
+    if (g->nflag) (void)hipFree(g->nflag);
+    *g = TriGrid{};
+}
+
+// vsoa: host, the mesh vertices as SoA planes [3][n] in DEVICE order; tri: host, [3 T] vertex positions in the (spatially sorted)
+// triangle order of the device.  Synchronous.  No grid (g->ready false) for degenerate extents: the callers keep the tile scan.
+int tri_grid_build(gingr_ctx *ctx, const double *vsoa, int64_t n, const int32_t *tri, int64_t T, int64_t max_queries, TriGrid *g) {
+    tri_grid_free(g);
+    if (T < 1 || T > INT32_MAX || n < 1 || max_queries < 1) return GINGR_OK;
+    double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+    std::vector<double> tb((size_t)6 * T);
+    std::vector<char> good((size_t)T, 0);
+    double ext_sum = 0.0;
+    int64_t ngood = 0;
+    for (int64_t t = 0; t < T; ++t) {
+        double bl[3], bh[3];
+        bool fin = true;
+        for (int d = 0; d < 3; ++d) {
+            const double a = vsoa[(size_t)d * n + tri[3 * t]], b = vsoa[(size_t)d * n + tri[3 * t + 1]], c = vsoa[(size_t)d * n + tri[3 * t + 2]];
+            fin = fin && std::isfinite(a) && std::isfinite(b) && std::isfinite(c);
+            bl[d] = std::min(a, std::min(b, c));
+            bh[d] = std::max(a, std::max(b, c));
+        }
+        if (!fin) continue;  // a triangle with a non-finite corner is never the closest one (its distance is NaN)
+        good[(size_t)t] = 1;
+        ++ngood;
+        double ext = 0.0;
+        for (int d = 0; d < 3; ++d) {
+            tb[(size_t)6 * t + d] = bl[d];
+            tb[(size_t)6 * t + 3 + d] = bh[d];
+            lo[d] = std::min(lo[d], bl[d]);
+            hi[d] = std::max(hi[d], bh[d]);
+            ext = std::max(ext, bh[d] - bl[d]);
+        }
+        ext_sum += ext;
+    }
+    if (ngood == 0) return GINGR_OK;
+    double size[3], maxext = 0.0;
+    for (int d = 0; d < 3; ++d) size[d] = hi[d] - lo[d], maxext = std::max(maxext, size[d]);
+    if (!(maxext > 0.0) || !(maxext < 1e300)) return GINGR_OK;
+    // cell edge = the mean extent of a triangle's box: a triangle then overlaps ~4 cells of a surface, a cell lists ~10 triangles
+    double h = ext_sum / (double)ngood;
+    if (!(h > 1e-9 * maxext)) h = 1e-9 * maxext;
+    int32_t gd[3];
+    for (;;) {
+        double cells = 1.0;
+        for (int d = 0; d < 3; ++d) {
+            const double c = std::floor(size[d] / h) + 1.0;
+            gd[d] = (int32_t)std::min(c, 512.0);
+            cells *= std::min(c, 1e9);
+            if (c > 512.0) cells = 1e30;
+        }
+        if (cells <= std::min(16.0 * (double)T + 4096.0, 134217728.0)) break;
+        h *= 1.25;
+    }
+    const double inv_h = 1.0 / h;
+    auto cell_of = [&](double x, int d) {  // the expression the kernel evaluates (clamped floor)
+        const double c = std::floor((x - lo[d]) * inv_h);
+        return c >= (double)(gd[d] - 1) ? gd[d] - 1 : (c > 0.0 ? (int32_t)c : 0);
+    };
+    const int64_t ncells = (int64_t)gd[0] * gd[1] * gd[2];
+    std::vector<int32_t> start((size_t)ncells + 1, 0);
+    auto for_cells = [&](int64_t t, auto fn) {
+        int32_t a[3], b[3];
+        for (int d = 0; d < 3; ++d) a[d] = cell_of(tb[(size_t)6 * t + d], d), b[d] = cell_of(tb[(size_t)6 * t + 3 + d], d);
+        for (int32_t z = a[2]; z <= b[2]; ++z)
+            for (int32_t y = a[1]; y <= b[1]; ++y)
+                for (int32_t x = a[0]; x <= b[0]; ++x) fn(((int64_t)z * gd[1] + y) * gd[0] + x);
+    };
+    int64_t total = 0;
+    for (int64_t t = 0; t < T; ++t)
+        if (good[(size_t)t]) for_cells(t, [&](int64_t c) { start[(size_t)c + 1]++; ++total; });
+    if (total > 64 * T + 4096 || total > INT32_MAX) return GINGR_OK;  // huge triangles in a fine grid: keep the tile scan
+    for (int64_t c = 0; c < ncells; ++c) start[(size_t)c + 1] += start[(size_t)c];
+    std::vector<int32_t> list((size_t)(total > 0 ? total : 1)), fill(start.begin(), start.end() - 1);
+    for (int64_t t = 0; t < T; ++t)  // ascending triangle position inside a cell
+        if (good[(size_t)t]) for_cells(t, [&](int64_t c) { list[(size_t)fill[(size_t)c]++] = (int32_t)t; });
+    HIP_TRY(ctx, hipMalloc(&g->cell_start, start.size() * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc(&g->tris, list.size() * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc(&g->flag, (size_t)max_queries));
+    HIP_TRY(ctx, hipMalloc(&g->nflag, 2 * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMemcpyAsync(g->cell_start, start.data(), start.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(g->tris, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(g->flag, 0, (size_t)max_queries, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(g->nflag, 0, 2 * sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int d = 0; d < 3; ++d) g->v.lo[d] = lo[d], g->v.g[d] = gd[d];
+    g->v.h = h;
+    g->v.inv_h = inv_h;
+    g->v.cell_start = g->cell_start;
+    g->v.tris = g->tris;
+    g->max_queries = max_queries;
+    g->list_entries = total;
+    g->ready = true;
+    return GINGR_OK;
+}
+
+// closest point of every query the grid certifies (warm start required: `warm` holds last scan's triangles); the others are flagged
+// (g.flag, g.cur_nflag()) for the masked launch_surface_closest_point that must follow
+void launch_surface_cp_grid(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T, TriGrid &g,
+                            const double *tribox, double *cp_soa, double *d2, int32_t *tri_out, int32_t *warm) {
+    g.parity ^= 1;
+    int32_t *cur = g.nflag + g.parity, *next = g.nflag + (g.parity ^ 1);
+    constexpr int kLanes = 8;
+    hipLaunchKernelGGL(surface_cp_grid_kernel<kLanes>, dim3((unsigned)ceil_div(q.n, 256 / kLanes)), dim3(256), 0, ctx->stream, q, v, tri, tri_orig,
+                       T, g.v, tribox, cp_soa, d2, tri_out, warm, g.flag, cur, next);
+}
+
 int distance_stats_ws_doubles() { return kStatBlocks * 4; }
 void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const int32_t *orig, int64_t orig_limit, const int32_t *nn,
                            const int32_t *boundary, double sdev, double *partial, double *out4) {

@@ -2,7 +2,7 @@
 """ICP update rate with the SURFACE correspondence (the reference's default ICP method) on a synthetic closed mesh:
 icosphere of subdivision level L (L=6: 40 962 vertices, 81 920 triangles), bumpy and posed copy as the target; one step =
 cell/vertex normals + closest point on the target surface + nearest target vertex + the three rejection tests + GP update.
-    PYTHONPATH=. python tools/bench_icp_surface.py [level]
+    PYTHONPATH=. python tools/bench_icp_surface.py [level] [tri_grid=0|1]      (tri_grid=0: the tile scan alone, for same-box comparisons)
 """
 import json
 import sys
@@ -40,7 +40,9 @@ def icosphere(level):
     return np.asarray(v), np.asarray(f, dtype=np.int32)
 
 
-level = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+OPTS = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
+POS = [a for a in sys.argv[1:] if "=" not in a]
+level = int(POS[0]) if POS else 6
 verts, cells = icosphere(level)
 ref = verts * 80.0
 bump = 1.0 + 0.08 * np.sin(3 * verts[:, 0]) * np.cos(2 * verts[:, 1]) + 0.05 * np.sin(5 * verts[:, 2])
@@ -48,6 +50,8 @@ c, s = np.cos(0.05), np.sin(0.05)
 R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
 target = (ref * bump[:, None]) @ R.T + np.array([1.5, -1.0, 0.5])
 ctx = ga.Context(0)
+from gingr_amd import _native as nat
+ctx.set_option(nat.OPT_TRI_GRID, int(OPTS.get("tri_grid", 1)))
 model = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.0, maxRank=100).Gaussian(40.0, 10.0)
 model.cells = cells
 algo = ga.IcpRegistration(ctx)
@@ -56,7 +60,7 @@ state = algo.createInitialState(model, target, cfg, targetCells=cells)
 state = algo.update(state)          # binds, uploads the meshes, first launch
 cp, w = algo.surfaceCorrespondence(state)
 ctx.synchronize()
-n = 10
+n = int(OPTS.get("n", 10))
 t0 = time.perf_counter()
 for _ in range(n):
     state = algo.update(state)      # host-boundary call per iteration (push state, update, pull the fit)
@@ -66,4 +70,5 @@ print(json.dumps({"what": "ICP update, surface correspondence (closest point on 
                   "vertices": int(ref.shape[0]), "triangles": int(cells.shape[0]), "rank": model.rank,
                   "iterations_per_s_host_boundary": n / dt, "ms_per_iteration": dt / n * 1e3,
                   "accepted_fraction_first_iteration": float(w.mean()), "status": int(state.general.status),
-                  "sigma2": float(state.general.sigma2)}))
+                  "sigma2": float(state.general.sigma2), "tri_grid": int(OPTS.get("tri_grid", 1)),
+                  "fit_checksum": float(np.abs(np.asarray(state.general.fit)).sum())}))
