@@ -32,7 +32,9 @@ struct gingr_ctx {
     // exact-zero tile culling of the CPD passes and exact pruning of the closest-point scans (affinity.hip); gingr_ctx_set_option
     // (GINGR_OPT_CULL, 0) disables both (results must stay bit-identical: the culling test compares the two)
     int cull = 1;
-    int tri_grid = 1;  // GINGR_OPT_TRI_GRID: closest surface point over the target's triangle grid (surface.hip); 0 = the tile scan alone
+    // GINGR_OPT_TRI_GRID: closest surface point over the target's triangle grid (surface.hip) in front of the tile scan.  OFF by
+    // default: built, bit-identical, but slower than the warm-started tile scan alone at 41k x 82k (133 + 26 us against 94 us, round 4)
+    int tri_grid = 0;
     int nn_grid = 1;  // GINGR_OPT_NN_GRID: closest point over the target's uniform grid (nn_grid.hip); 0 = the tile scan alone; 2 = gingr_nn too
     // Culling regime of the CPD passes as the DEVICE last saw it (0 plain, 1 quarter-tile culling pays): pinned host word the
     // all-pairs kernels write, read -- unsynchronised, possibly a few launches stale -- when the next launch picks its kernel

@@ -322,3 +322,25 @@ def test_benchmark_size_correspondence_against_sampled_oracle(ctx):
     assert bnd.any() and (want == 0).sum() > 20 and (want == 1).sum() > 500
     differ = (w[ids] != want) & ~unsure
     assert not differ.any(), (ids[differ][:10], w[ids][differ][:10], want[differ][:10])
+
+
+def test_triangle_grid_search_is_bit_identical_to_the_tile_scan():
+    """GINGR_OPT_TRI_GRID = 1: the closest surface point searched over a grid of the (fixed) target triangles, warm-started from the
+    previous iteration, with the masked tile scan for what the grid cannot certify -- same closest points, same weights, same
+    trajectory bit for bit as the tile scan alone (the default)."""
+    import gingr_amd as ga
+    from gingr_amd import _native as nat
+    ref, cells, target, tcells = femur()
+    out = []
+    for tri_grid in (0, 1):
+        c = ga.Context(0)
+        c.set_option(nat.OPT_TRI_GRID, tri_grid)
+        mo, algo, state = make_state(c, ref, cells, target, tcells, rank=20, initial_pose=((0.02, -0.03, 0.01), (1.0, -2.0, 0.5)))
+        for _ in range(5):
+            state = algo.update(state)
+        cp, w = algo.surfaceCorrespondence(state)
+        out.append((np.array(state.general.fit), cp.copy(), w.copy(), state.general.sigma2))
+        algo.close()
+        c.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert out[0][3] == out[1][3]
