@@ -487,6 +487,44 @@ JFN(jint, fitterUpdateIcpRccl)(JNIEnv *, jclass, jlong f, jdouble initialSigma, 
     return gingr_fitter_update_icp_rccl_async(P<gingr_fitter>(f), &p, n);
 }
 JFN(jint, ctxSetOption)(JNIEnv *, jclass, jlong ctx, jint option, jint value) { return gingr_ctx_set_option(P<gingr_ctx>(ctx), option, value); }
+// ---- round 4: every flavour of the update (0 CPD, 1 ICP point cloud, 2 ICP surface), the sampled proposal (z = r standard normals,
+// null for the mean update) and the transition density on ROW SHARDS -- through the device group and through the context's RCCL
+// communicator (gingr_group_update_async / _posterior_logpdf, gingr_fitter_update_rccl_async / _posterior_logpdf_rccl)
+JFN(jint, groupSetMeshes)(JNIEnv *env, jclass, jlong g, jintArray modelTriangles, jintArray targetTriangles) {
+    Arr<int32_t> a(env, modelTriangles, true), b(env, targetTriangles, true);
+    return gingr_group_set_meshes(P<gingr_group>(g), (int64_t)a.buf.size() / 3, a.ptr(), (int64_t)b.buf.size() / 3, b.ptr());
+}
+JFN(jint, groupSetSurfaceMethod)(JNIEnv *, jclass, jlong g, jint method) { return gingr_group_set_surface_method(P<gingr_group>(g), method); }
+JFN(jint, groupUpdate)(JNIEnv *env, jclass, jlong g, jint flavour, jdouble w, jdouble lambda, jdouble initialSigma, jdouble endSigma,
+                       jint maxIterations, jint n, jdoubleArray z) {
+    const gingr_cpd_params cp{w, lambda};
+    const gingr_icp_params ip{initialSigma, endSigma, maxIterations};
+    Arr<double> zz(env, z, true);
+    return gingr_group_update_async(P<gingr_group>(g), flavour, &cp, &ip, n, zz.ptr());
+}
+JFN(jint, groupPosteriorLogpdf)(JNIEnv *env, jclass, jlong g, jint flavour, jdouble w, jdouble lambda, jdouble initialSigma, jdouble endSigma,
+                                jint maxIterations, jdoubleArray meshXyzFull, jdoubleArray out1) {
+    const gingr_cpd_params cp{w, lambda};
+    const gingr_icp_params ip{initialSigma, endSigma, maxIterations};
+    Arr<double> m(env, meshXyzFull, true), o(env, out1, false);
+    if (o.buf.empty()) return GINGR_ERR_BAD_ARGUMENT;
+    return gingr_group_posterior_logpdf(P<gingr_group>(g), flavour, &cp, &ip, m.ptr(), o.ptr());
+}
+JFN(jint, fitterUpdateRccl)(JNIEnv *env, jclass, jlong f, jint flavour, jdouble w, jdouble lambda, jdouble initialSigma, jdouble endSigma,
+                            jint maxIterations, jint n, jdoubleArray z) {
+    const gingr_cpd_params cp{w, lambda};
+    const gingr_icp_params ip{initialSigma, endSigma, maxIterations};
+    Arr<double> zz(env, z, true);
+    return gingr_fitter_update_rccl_async(P<gingr_fitter>(f), flavour, &cp, &ip, n, zz.ptr());
+}
+JFN(jint, fitterPosteriorLogpdfRccl)(JNIEnv *env, jclass, jlong f, jint flavour, jdouble w, jdouble lambda, jdouble initialSigma,
+                                     jdouble endSigma, jint maxIterations, jdoubleArray meshXyzFull, jdoubleArray out1) {
+    const gingr_cpd_params cp{w, lambda};
+    const gingr_icp_params ip{initialSigma, endSigma, maxIterations};
+    Arr<double> m(env, meshXyzFull, true), o(env, out1, false);
+    if (o.buf.empty()) return GINGR_ERR_BAD_ARGUMENT;
+    return gingr_fitter_posterior_logpdf_rccl(P<gingr_fitter>(f), flavour, &cp, &ip, m.ptr(), o.ptr());
+}
 #else
 // No JDK headers on this machine: the shim is not built (the C ABI it wraps is still covered by the Python tests).
 #endif

@@ -150,6 +150,20 @@ public final class GingrHipNative {
     public static native int ctxRcclAllreduceModelMoments(long ctx, long model);
     public static native int fitterUpdateCpdRccl(long fitter, double w, double lambda, int nIterations);
     public static native int fitterUpdateIcpRccl(long fitter, double initialSigma, double endSigma, int maxIterations, int nIterations);
-    /** gingr_ctx_option: 0 cull, 1 fine cull, 2 closest-point grid -- code paths with identical results (tests, timing comparisons) */
+    /** gingr_ctx_option: 0 cull, 1 fine cull, 2 closest-point grid, 3 triangle grid -- code paths with identical results (tests, timing comparisons) */
     public static native int ctxSetOption(long ctx, int option, int value);
+
+    // ---- round 4: every flavour of the update on row shards (0 CPD, 1 ICP point cloud, 2 ICP surface), the sampled proposal
+    // (z = r standard normals, the SAME on every shard; null = mean update) and the log transition density
+    // (GeneratorWrapperStochastic.scala:42-63).  Triangles index the vertices of the FULL template / target.
+    public static native int groupSetMeshes(long group, int[] modelTriangles, int[] targetTriangles);
+    public static native int groupSetSurfaceMethod(long group, int method);
+    public static native int groupUpdate(long group, int flavour, double w, double lambda, double initialSigma, double endSigma,
+                                         int maxIterations, int nIterations, double[] z);
+    public static native int groupPosteriorLogpdf(long group, int flavour, double w, double lambda, double initialSigma, double endSigma,
+                                                  int maxIterations, double[] meshXyzFull, double[] out1);
+    public static native int fitterUpdateRccl(long fitter, int flavour, double w, double lambda, double initialSigma, double endSigma,
+                                              int maxIterations, int nIterations, double[] z);
+    public static native int fitterPosteriorLogpdfRccl(long fitter, int flavour, double w, double lambda, double initialSigma,
+                                                       double endSigma, int maxIterations, double[] meshXyzFull, double[] out1);
 }
