@@ -40,12 +40,21 @@ def shard_rows(M: int, world: int, rank: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < extra else 0)
 
 
+PHASE_GATHER = 3        # GINGR_PHASE_GATHER / GINGR_SEGMENT_FULLFIT of gingr_hip.h
+SEGMENT_FULLFIT = nat.SEGMENT_FULLFIT
+
+
 def drive_update(run_phase: Callable[[int], None], all_reduce_segment: Callable[[int], None], world: int,
-                 skip_segment0: bool = False) -> None:
-    """One iteration: phase p, then (for p < NUM_SEGMENTS) the all-reduce of exchange segment p."""
+                 skip_segment0: bool = False, flavour: int = 0) -> None:
+    """One iteration in the order of fitter_sharded_update (gingr_amd/csrc/fitter.hip): for the surface correspondence (flavour 2)
+    the gather of the fit first; then phase p followed (for p < 2) by the all-reduce of exchange segment p -- the ICP flavours
+    exchange nothing after phase 0 (their closest-point search is local to the shard's rows)."""
+    if flavour == 2 and world > 1:
+        run_phase(PHASE_GATHER)
+        all_reduce_segment(SEGMENT_FULLFIT)
     for ph in range(NUM_PHASES):
         run_phase(ph)
-        if world > 1 and ph < NUM_SEGMENTS and not (skip_segment0 and ph == 0):
+        if world > 1 and ph < 2 and not ((skip_segment0 or flavour != 0) and ph == 0):
             all_reduce_segment(ph)
 
 

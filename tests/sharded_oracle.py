@@ -2,8 +2,11 @@
 
 Mirrors gingr_amd/csrc/fitter.hip phase by phase with numpy so that the sharding algebra -- which partial sums are
 exchanged, in which order, and what is replicated -- can be exercised across real processes (gloo) without a GPU.
-Segment layout = gingr_fitter_exchange: [den N] [G rp*rp | rhs rp | 8 scalars], with rp = r here (no MFMA padding on
-the CPU).  Phase 2 is the "moment form": everything after the posterior solve is computed from one-off moments of the
+Segment layout = gingr_fitter_exchange: [den N] [G rp*rp | rhs rp | 8 scalars | Q0^T e rp] [full fit 3 M_total], with rp = r
+here (no MFMA padding on the CPU).  Flavours as in gingr_fitter_update_sharded_async: 0 CPD, 1 ICP with the point-cloud closest
+point, 2 ICP with the surface correspondence (phase 3 = GINGR_PHASE_GATHER writes the shard's rows of the fit into segment 2,
+whose sum all-reduce is the all-gather); z = the replicated standard-normal draw of posterior.sample(); logpdf_* = the transition
+density of gingr_fitter_posterior_logpdf_sharded (Q0^T e rides in the tail of segment 1).  Phase 2 is the "moment form": everything after the posterior solve is computed from one-off moments of the
 basis (summed over all shards once, like gingr_model_gram_exchange + gingr_model_finalize) with no further exchange.
 """
 import numpy as np
@@ -15,13 +18,16 @@ EPS = 1e-5
 
 
 class OracleShard:
-    def __init__(self, model: go.PDM, target, begin, end, global_transform=go.RIGID_TRANSFORMS, step_length=1.0, w=0.0, lam=1.0):
+    def __init__(self, model: go.PDM, target, begin, end, global_transform=go.RIGID_TRANSFORMS, step_length=1.0, w=0.0, lam=1.0,
+                 flavour=0, icp=(1.0, 1.0, 1), tmpl_tris=None, tgt_tris=None):
         self.m, self.x = model, np.asarray(target, dtype=np.float64)
         self.b, self.e = begin, end
         self.gt, self.step, self.w, self.lam = global_transform, step_length, w, lam
+        self.flavour, self.icp, self.tmpl_tris, self.tgt_tris = flavour, icp, tmpl_tris, tgt_tris
+        self.z = None                                                 # set for ONE sampled proposal, the same on every shard
         r, N = model.rank, self.x.shape[0]
-        self.counts = [N, r * r + r + 8]
-        self.offsets = [0, N]
+        self.counts = [N, r * r + r + 8 + r, 3 * model.M]
+        self.offsets = [0, N, N + self.counts[1]]
         self.xch = np.zeros(sum(self.counts))
         rows = slice(3 * begin, 3 * end)
         self.Q0 = model.U[rows] * np.sqrt(model.lam)[None, :]         # local rows of Q0
@@ -59,8 +65,25 @@ class OracleShard:
         m, st, r = self.m, self.st, self.m.rank
         M_total, N = m.M, self.x.shape[0]
         R = st.rotation()
-        if ph == 0:
+        if ph == 3:      # GINGR_PHASE_GATHER: own rows into zeros, [3][M_total] planes in the original vertex order
+            full = self.seg(2).reshape(3, M_total)
+            full[:] = 0.0
+            full[:, self.b:self.e] = self.fit.T
+        elif ph == 0 and self.flavour == 1:
+            idx, _, _ = go.icp_closest_point(self.fit, self.x)          # the shard's own rows against the replicated target
+            self.obs, self.acc = self.x[idx], np.ones(self.fit.shape[0])
+        elif ph == 0 and self.flavour == 2:
+            self.obs, self.acc = self._surface_rows(self.seg(2).reshape(3, M_total).T.copy())
+        elif ph == 0:
             self.seg(0)[:] = co.cpd_colsum_partial(self.fit, self.x, st.sigma2, 0, self.fit.shape[0])
+        elif ph == 1 and self.flavour != 0:
+            # uniform weight 1 / sigma2 on the accepted correspondences (ICP.scala:90-92), nothing for the sigma^2 update
+            wgt = self.acc / st.sigma2
+            e = wgt[:, None] * ((self.obs - st.center - st.translation) @ R - (self.ref - st.center) - self.mean)
+            s = self.seg(1)
+            s[: r * r] = (self.Q0.T @ (self.Q0 * np.repeat(wgt, 3)[:, None])).reshape(-1)
+            s[r * r: r * r + r] = self.Q0.T @ e.reshape(-1)
+            s[r * r + r:] = 0.0
         elif ph == 1:
             c = go.cpd_outlier_constant(M_total, N, st.sigma2, self.w)
             colsum = self.seg(0).copy()
@@ -77,11 +100,14 @@ class OracleShard:
             s[: r * r] = G.reshape(-1)
             s[r * r: r * r + r] = rhs
             xpx = float(Pt1 @ (self.x ** 2).sum(1)) if self.b == 0 else 0.0   # replicated quantity: counted once
-            s[r * r + r:] = [P1.sum(), xpx, float((self.fit * PX).sum()), float(P1 @ (self.fit ** 2).sum(1)), 0, 0, 0, 0]
+            s[r * r + r: r * r + r + 8] = [P1.sum(), xpx, float((self.fit * PX).sum()), float(P1 @ (self.fit ** 2).sum(1)), 0, 0, 0, 0]
+            s[r * r + r + 8:] = 0.0
         elif ph == 2:
             s = self.seg(1)
             G, rhs = s[: r * r].reshape(r, r), s[r * r: r * r + r]
             a = np.linalg.solve(np.eye(r) + G, rhs)
+            if self.z is not None:                                           # posterior.sample(): a + L^-T z, replicated
+                a = a + np.linalg.solve(np.linalg.cholesky(np.eye(r) + G).T, np.asarray(self.z, dtype=np.float64))
             alpha = st.alpha
             alpha1 = self.Binv @ (self.S_tot @ a) / EPS                      # Q^T (Q a) = S_tot a
             ac = alpha + (alpha1 - alpha) * self.step
@@ -115,9 +141,56 @@ class OracleShard:
             h = R2.T @ (gt + self.c0 - t2) - self.c0
             proj = np.einsum("de,dek->k", B - np.eye(3), self.V) + np.einsum("de,dekl,l->k", B, self.S, ac) + h @ self.W
             alpha_new = self.Binv @ proj / EPS
-            sc = s[r * r + r:]
-            s2n = (sc[1] - 2 * sc[2] + sc[3]) / (sc[0] * 3.0)
+            sc = s[r * r + r: r * r + r + 8]
+            if self.flavour == 0:
+                s2n = (sc[1] - 2 * sc[2] + sc[3]) / (sc[0] * 3.0)
+            else:
+                s2n = go.icp_update_sigma2(st.sigma2, *self.icp)
             new = go.State(alpha=alpha_new, euler=go.rot_to_euler(R2), center=np.zeros(3), translation=t2, scale=s2,
                            sigma2=float(s2n), fit=np.zeros((m.M, 3)), iteration=st.iteration + 1,
                            global_transformation=st.global_transformation, step_length=st.step_length)
             self.set_state(new)
+
+    def _surface_rows(self, full_fit):
+        """ClosestPointTriangleMesh3D.closestPointCorrespondence (ClosestPointRegistrator.scala:75-100) for the shard's rows: the
+        queries are the shard's own fit vertices, the template mesh (vertex normals, self-intersection test) is the GATHERED fit."""
+        import math
+        tgt, tt, mt = self.x, self.tgt_tris, self.tmpl_tris
+        cp, _ = go.mesh_closest_point(self.fit, tgt, tt)
+        nn_idx, _, _ = go.icp_closest_point(cp, tgt)
+        bnd = go.boundary_vertices(tgt.shape[0], tt)
+        n_tmpl, n_tgt = go.vertex_normals(full_fit, mt)[self.b:self.e], go.vertex_normals(tgt, tt)
+        w = np.ones(self.fit.shape[0])
+        for i in range(self.fit.shape[0]):
+            j, p = int(nn_idx[i]), full_fit[self.b + i]
+            if bnd[j] or float(n_tmpl[i] @ n_tgt[j]) < 0:
+                w[i] = 0.0
+                continue
+            v = p - cp[i]
+            ips = go.line_mesh_intersections(p, v, full_fit, mt)
+            keep = np.any(ips != p, axis=1)
+            if keep.any():
+                dd = ips[keep] - p
+                if math.sqrt(float((dd * dd).sum(1).min())) < math.sqrt(float(v @ v)):
+                    w[i] = 0.0
+        return cp, w
+
+    # ---- transition density: posterior(state).gp.logpdf(posterior.coefficients(mesh)) (GeneratorWrapperStochastic.scala:42-63)
+    def logpdf_prepare(self, mesh_full):
+        """after phase 1, before the exchange of segment 1: the shard's part of Q0^T e for the OTHER state's mesh"""
+        st, r = self.st, self.m.rank
+        R = st.rotation()
+        e = (np.asarray(mesh_full, dtype=np.float64)[self.b:self.e] - st.center - st.translation) @ R - (self.ref - st.center) - self.mean
+        self.seg(1)[r * r + r + 8:] = self.Q0.T @ e.reshape(-1)
+
+    def logpdf_finish(self):
+        """segment 1 summed: replicated.  Posterior basis Q_p = Q L^-T (any orthogonal mixing leaves c.c unchanged), L L^T = I + G"""
+        r = self.m.rank
+        s = self.seg(1)
+        G, rhs, qte = s[: r * r].reshape(r, r), s[r * r: r * r + r], s[r * r + r + 8:]
+        L = np.linalg.cholesky(np.eye(r) + G)
+        a = np.linalg.solve(L.T, np.linalg.solve(L, rhs))
+        Li = np.linalg.inv(L)
+        A = Li @ self.S_tot @ Li.T
+        c = np.linalg.solve(A / EPS + np.eye(r), Li @ (qte - self.S_tot @ a) / EPS)
+        return go.gp_logpdf(c)
