@@ -51,6 +51,23 @@ class IcpParams(ctypes.Structure):
     _fields_ = [("initial_sigma", c_double), ("end_sigma", c_double), ("max_iterations", c_int32)]
 
 
+class MhRequest(ctypes.Structure):
+    """gingr_mh_request"""
+    _fields_ = [
+        ("flavour", c_int32), ("kind", c_int32), ("cpd", POINTER(CpdParams)), ("icp", POINTER(IcpParams)),
+        ("z", POINTER(c_double)), ("alpha", POINTER(c_double)), ("scalars", POINTER(StateScalars)),
+        ("eval_sdev", c_double), ("eval_points", c_int64), ("need_forward", c_int32),
+    ]
+
+
+class MhResult(ctypes.Structure):
+    """gingr_mh_result"""
+    _fields_ = [
+        ("scalars", StateScalars), ("log_value", c_double), ("dist_sum", c_double), ("dist_max", c_double), ("count", c_int64),
+        ("log_q_forward", c_double), ("log_q_backward", c_double), ("forward_status", c_int32), ("backward_status", c_int32),
+    ]
+
+
 # int (*gingr_allreduce_fn)(void *user, int32_t segment, void *device_ptr, int64_t count)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int32, c_void_p, c_int64)
 _dp = POINTER(c_double)
@@ -94,6 +111,8 @@ SIGNATURES = {
     "gingr_fitter_icp_surface_phase_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32]),
     "gingr_fitter_get_surface_correspondence": (c_int, [c_void_p, _dp, _dp]),
     "gingr_fitter_surface_distance_stats": (c_int, [c_void_p, c_int32, c_int64, _dp, c_int32, c_double, _dp]),
+    "gingr_fitter_mh_step": (c_int, [c_void_p, POINTER(MhRequest), _dp, _dp, POINTER(MhResult)]),
+    "gingr_fitter_mh_restore": (c_int, [c_void_p]),
     "gingr_classic_cpd_create": (c_int, [c_void_p, c_int32, c_int64, _dp, c_int64, _dp, c_double, c_double, c_double, POINTER(c_void_p)]),
     "gingr_classic_cpd_destroy": (None, [c_void_p]),
     "gingr_classic_cpd_iterate": (c_int, [c_void_p, c_int32]),

@@ -732,6 +732,8 @@ class GingrAlgorithm:
         self._bound_lm = None
         self._bound_mesh = None
         self._device_state = None         # the python state currently mirrored on the device (strong reference, compared with `is`)
+        self._mh = None                   # fused Metropolis-Hastings steps: {"sdev", "points"} of the likelihood evaluated with them
+        self._mh_last = None              # what the last fused step measured: {"from", "to", "stats", "fw", "bw"}
 
     # -- native plumbing ------------------------------------------------------------------
     def _bind(self, general: GeneralRegistrationState, use_landmarks: bool):
@@ -838,6 +840,8 @@ class GingrAlgorithm:
         probabilistic=True proposes posterior.sample() instead of posterior.mean (:211); the standard-normal draws come from
         `rnd` (the reference's `implicit rnd: Random`)."""
         g = current.general
+        if probabilistic and rnd is not None and self._mh_usable(current):
+            return self._mh_step(current, 0, f64(rnd.standard_normal(g.model.rank)), None, self.name)
         self._bind(g, current.config.useLandmarkCorrespondence)
         if self._device_state is not current:
             self._push_state(g)
@@ -852,6 +856,87 @@ class GingrAlgorithm:
         self._device_state = out
         return out
 
+    # -- one Metropolis-Hastings step per native call (gingr_fitter_mh_step) ---------------------------------------------------
+    def enableFusedSteps(self, uncertainty: float, modelPointCount: int = 0):
+        """From now on a probabilistic `update` / `proposeParameters` runs the WHOLE device side of a Metropolis-Hastings step in one
+        native call -- proposal, model-to-target likelihood N(0, uncertainty) over the first modelPointCount vertices (0 = all), both
+        transition densities of the informed proposal -- and the queries MetropolisHastings.next makes afterwards
+        (`surfaceDistanceStats`, `logTransitionProbability`) are answered from what that call measured.  Same numbers, same order
+        of random draws as the call-by-call path; states with stepLength != 1 or without meshes keep using that path."""
+        self._mh = {"sdev": float(uncertainty), "points": int(modelPointCount or 0)}
+        self._mh_last = None
+
+    def disableFusedSteps(self):
+        self._mh = self._mh_last = None
+
+    def _mh_flavour(self, state):
+        """(flavour, CpdParams | None, IcpParams | None) of gingr_mh_request; None when this configuration has no fused step"""
+        return None
+
+    def _mh_prepare(self, state):
+        pass
+
+    def _mh_usable(self, state) -> bool:
+        g = state.general
+        return (self._mh is not None and g.stepLength == 1.0 and getattr(g.model, "cells", None) is not None
+                and g.targetCells is not None and self._mh_flavour(state) is not None)
+
+    def _adopt_state(self, old, new):
+        """`new` is `old` with host-side fields rewritten (generatedBy): it stands for the same device state and measurements"""
+        if self._device_state is old:
+            self._device_state = new
+        if self._mh_last is not None and self._mh_last["to"] is old:
+            self._mh_last["to"] = new
+
+    def _mh_step(self, current, kind: int, z, modelParameters, generatedBy: str):
+        g = current.general
+        self._bind(g, current.config.useLandmarkCorrespondence)
+        last = self._mh_last
+        if self._device_state is not current:
+            if last is not None and last["from"] is current and self._device_state is last["to"]:
+                _check(self.ctx.handle, self._lib.gingr_fitter_mh_restore(self._fitter), "gingr_fitter_mh_restore")   # rejected
+            else:
+                self._push_state(g)
+            self._device_state = current
+        self._mh_prepare(current)
+        flavour, cp, ip = self._mh_flavour(current)
+        req = nat.MhRequest()
+        req.flavour, req.kind = flavour, kind
+        req.cpd = ctypes.pointer(cp) if cp is not None else None
+        req.icp = ctypes.pointer(ip) if ip is not None else None
+        req.eval_sdev, req.eval_points = self._mh["sdev"], self._mh["points"]
+        # q(.|current) projects current.fit (step length 1): a number of `current` alone, known when a fused step produced or started
+        # from this very state
+        fw = last["bw"] if last is not None and last["to"] is current else (last["fw"] if last is not None and last["from"] is current else None)
+        req.need_forward = 1 if fw is None else 0
+        keep = None
+        if kind == 0:
+            req.z = dptr(z)
+        else:
+            mp = modelParameters
+            keep = (f64(mp.shape), nat.StateScalars())
+            sc = keep[1]
+            sc.euler[:] = [mp.rotation.phi, mp.rotation.theta, mp.rotation.psi]
+            sc.center[:] = list(mp.center)
+            sc.translation[:] = list(mp.translation)
+            sc.scale, sc.sigma2, sc.iteration, sc.status = mp.scale, g.sigma2, g.iteration + 1, g.status
+            req.alpha, req.scalars = dptr(keep[0]), ctypes.pointer(sc)
+        r, M = g.model.rank, g.model.numberOfPoints
+        alpha, fit, res = np.empty(r), np.empty((M, 3)), nat.MhResult()
+        _check(self.ctx.handle, self._lib.gingr_fitter_mh_step(self._fitter, ctypes.byref(req), dptr(alpha), dptr(fit), ctypes.byref(res)),
+               "gingr_fitter_mh_step")
+        s = res.scalars
+        mp = ModelFittingParameters(scale=s.scale, translation=tuple(s.translation), rotation=EulerAngles(*list(s.euler)),
+                                    center=tuple(s.center), shape=alpha)
+        new_general = dataclasses.replace(g, modelParameters=mp, fit=fit, sigma2=s.sigma2, iteration=s.iteration, status=s.status,
+                                          generatedBy=generatedBy)
+        out = current.updateGeneral(new_general)
+        self._device_state = out
+        self._mh_last = {"from": current, "to": out, "sdev": self._mh["sdev"], "points": self._mh["points"],
+                         "stats": (float(res.dist_sum), float(res.dist_max), int(res.count), float(res.log_value)),
+                         "fw": float(res.log_q_forward) if fw is None else fw, "bw": float(res.log_q_backward)}
+        return out
+
     def _ensure_device_state(self, state):
         """Make the fitter hold `state` (model, target, meshes, parameters; the fit is re-instantiated on the device)."""
         g = state.general
@@ -863,6 +948,8 @@ class GingrAlgorithm:
     def proposeParameters(self, current, modelParameters: ModelFittingParameters, generatedBy: str):
         """GingrGeneratorWrapper.propose for a proposal that only rewrites the parameters (GingrGeneratorWrapper.scala:28-39):
         fit = modelInstanceShapePoseScale(model, parameters) -- instantiated on the device -- and iteration + 1."""
+        if self._mh_usable(current):
+            return self._mh_step(current, 1, None, modelParameters, generatedBy)
         g = dataclasses.replace(current.general, modelParameters=modelParameters, iteration=current.general.iteration + 1)
         self._bind(g, current.config.useLandmarkCorrespondence)
         self._push_state(g)
@@ -878,6 +965,10 @@ class GingrAlgorithm:
         g = state.general
         if getattr(g.model, "cells", None) is None or g.targetCells is None:
             raise ValueError("surface distances need model.cells and targetCells")
+        last = self._mh_last
+        if (last is not None and last["to"] is state and direction == 0 and points is None and not boundary_aware
+                and float(sdev) == last["sdev"] and int(n_points or 0) == last["points"]):
+            return last["stats"]          # measured by the fused step that produced this state
         self._ensure_device_state(state)
         out = np.zeros(4)
         pts = None if points is None else f64(points)
@@ -892,6 +983,12 @@ class GingrAlgorithm:
         the posterior model of `from_state`, of the mesh the reference projects -- from.fit when stepLength == 1, otherwise
         the unposed instance of the step-compensated coefficients.  -inf when the posterior cannot be computed."""
         g = from_state.general
+        last = self._mh_last
+        if last is not None and g.stepLength == 1.0:   # both densities of the step that made `to` from `from` came with it
+            if last["from"] is from_state and last["to"] is to_state:
+                return last["fw"]
+            if last["from"] is to_state and last["to"] is from_state:
+                return last["bw"]
         if g.stepLength != 1.0:
             a0, a1 = f64(g.modelParameters.shape), f64(to_state.general.modelParameters.shape)
             comp = a0 + (a1 - a0) / g.stepLength
@@ -1020,6 +1117,9 @@ class CpdRegistration(GingrAlgorithm):
         _check(self.ctx.handle, self._lib.gingr_fitter_update_cpd_async(self._fitter, ctypes.byref(p), n),
                "gingr_fitter_update_cpd_async")
 
+    def _mh_flavour(self, state: CpdRegistrationState):
+        return 0, nat.CpdParams(state.config.w, state.config.lambda_), None
+
     def _native_update_sample(self, current: CpdRegistrationState, z: np.ndarray):
         p = nat.CpdParams(current.config.w, current.config.lambda_)
         _check(self.ctx.handle, self._lib.gingr_fitter_update_cpd_sample_async(self._fitter, ctypes.byref(p), dptr(z)),
@@ -1139,6 +1239,17 @@ class IcpRegistration(GingrAlgorithm):
         _check(self.ctx.handle, self._lib.gingr_fitter_get_surface_correspondence(self._fitter, dptr(cp), dptr(w)),
                "gingr_fitter_get_surface_correspondence")
         return cp, w
+
+    def _mh_flavour(self, state: IcpRegistrationState):
+        c = state.config
+        if c.reverseCorrespondenceDirection:
+            return None
+        return (2 if self._surface(c) else 1), None, nat.IcpParams(c.initialSigma, c.endSigma, c.maxIterations)
+
+    def _mh_prepare(self, state: IcpRegistrationState):
+        self._select_direction(state.config)
+        if self._surface(state.config):
+            self._select_surface_method(state.config)
 
     def _native_update_sample(self, current: IcpRegistrationState, z: np.ndarray):
         c = current.config

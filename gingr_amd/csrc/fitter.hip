@@ -131,6 +131,14 @@ struct gingr_fitter {
     double *fullfit = nullptr, *partial_fullfit = nullptr;
     bool sharded() const { return m->M != m->M_total; }
     int32_t *retry = nullptr;  // device word: retryCounter of the algorithm instance this fitter stands for (GingrAlgorithm.scala:69-70)
+    // ---- one Metropolis-Hastings step per call (gingr_fitter_mh_step): the state x the step started from stays on the device --
+    // [alpha | scalars | DevState] in mh_save, its fit in fit_alt (the proposal's fit is written to the OTHER buffer and the two
+    // pointers are exchanged, no copy) -- so that a rejected proposal costs one small copy and one pass over the basis.  The states
+    // a step produces on the device are unknown to the host until it reads them: the posterior memo keys them by a serial number.
+    double *fit_alt = nullptr, *mh_save = nullptr;
+    Key mh_key;
+    bool mh_saved = false;
+    uint64_t mh_serial = 0;
 };
 
 constexpr size_t kScalarsDoubles = (sizeof(gingr_state_scalars) + 7) / 8, kDevStateDoubles = (sizeof(DevState) + 7) / 8;
@@ -514,7 +522,8 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
         (rc = dev_alloc(ctx, &f->small, (size_t)8)) || (rc = dev_alloc(ctx, &f->fxbuf[0], (size_t)rp * rp + 2 * rp)) || (rc = dev_alloc(ctx, &f->fxbuf[1], (size_t)rp * rp + 2 * rp)) ||
         (rc = dev_alloc(ctx, &f->alt_seg, (size_t)rp * rp + rp + 8)) || (rc = dev_alloc(ctx, &f->lp_sync, (size_t)2)) ||
         (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->zbuf, (size_t)PostVec::kZRows * rp)) || (rc = dev_alloc(ctx, &f->zrand, (size_t)rp)) ||
-        (rc = dev_alloc(ctx, &f->pose, 1)) ||
+        (rc = dev_alloc(ctx, &f->pose, 1)) || (rc = dev_alloc(ctx, &f->fit_alt, (size_t)3 * M)) ||
+        (rc = dev_alloc(ctx, &f->mh_save, (size_t)rp + kScalarsDoubles + kDevStateDoubles)) ||
         (rc = dev_alloc(ctx, &f->scalars, 8)) || (rc = dev_alloc(ctx, &f->part, GINGR_SCALAR_PART)) || (rc = dev_alloc(ctx, &f->absmax, GINGR_AUX)) || (rc = dev_alloc(ctx, &f->work, (size_t)std::max<int64_t>((int64_t)rp * rp, posterior_work_doubles(rp)))) ||
         (rc = dev_alloc(ctx, &f->lm_mask, (size_t)M))) {
         gingr_fitter_destroy(f);
@@ -523,7 +532,7 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
     f->alpha = f->state_block;
     f->hs_dev = reinterpret_cast<gingr_state_scalars *>(f->state_block + rp);
     f->st = reinterpret_cast<DevState *>(f->state_block + rp + kScalarsDoubles);
-    f->pin_doubles = (size_t)3 * M + rp + kScalarsDoubles + kDevStateDoubles;
+    f->pin_doubles = (size_t)3 * M + rp + kScalarsDoubles + kDevStateDoubles + 16;  // (+ the eight results of gingr_fitter_mh_step)
     if (hipHostMalloc(reinterpret_cast<void **>(&f->pin), f->pin_doubles * sizeof(double), hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         f->pin = nullptr;
@@ -560,6 +569,8 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->inv_den);
     dev_free(f->Pt1);
     dev_free(f->fit);
+    dev_free(f->fit_alt);
+    dev_free(f->mh_save);
     dev_free(f->P1);
     dev_free(f->PX);
     dev_free(f->nn_idx);
@@ -738,6 +749,7 @@ int gingr_fitter_set_state(gingr_fitter *f, const double *alpha, const gingr_sta
     GINGR_TRY(check_launch(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     f->has_state = true;
+    f->mh_saved = false;
     f->state_key.v.assign(alpha, alpha + r);
     for (int q = 0; q < 3; ++q) f->state_key.v.push_back(s->euler[q]);
     for (int q = 0; q < 3; ++q) f->state_key.v.push_back(s->center[q]);
@@ -764,6 +776,7 @@ int gingr_fitter_set_fit_points(gingr_fitter *f, const double *fit_xyz) {
     // the shape on the device is no instance of the model any more: nothing memoised describes it
     f->forget_posteriors();
     f->state_key_valid = false;
+    f->mh_saved = false;
     return GINGR_OK;
 }
 
@@ -1017,6 +1030,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
         if (f->post_stage == 1) f->post_stage = 2;
     } else {
         f->state_key_valid = false;  // the commit moves the device state away from the key
+        f->mh_saved = false;
     }
     switch (phase) {
         case 0: {
@@ -2013,6 +2027,201 @@ int gingr_fitter_surface_distance_stats(gingr_fitter *f, int32_t direction, int6
     HIP_TRY(ctx, hipMemcpyAsync(q.p, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     return run_distance_stats(ctx, cloud_of(q.as<double>(), n_points), fit, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, nullptr, 0, m->perm,
                               f->fboxes, bnd, sdev, sc, out);
+}
+
+// ------------------------------------------------------------------------------------------ one Metropolis-Hastings step
+// What MetropolisHastings.next asks of the device for ONE step of GingrAlgorithm.run's chain (G/api/GingrAlgorithm.scala:115-190,
+// generators/GeneratorWrapperStochastic.scala:28-63, evaluators/IndependentPointDistanceEvaluator.scala:54-70), enqueued as one
+// sequence with one synchronisation at the end:
+//   x  = the device state                         (its posterior inputs come from the memo: every state's are computed once)
+//   x' = update(x, probabilistic = true) with z   (kind 0)   or   the parameters the host's random walk proposes (kind 1)
+//   q(x'|x)  = posterior(x).logpdf(coefficients(x.fit))       -- with step length 1 the reference projects from.fit, NOT to.fit
+//              (GeneratorWrapperStochastic.scala:50-55): a function of x alone, so only asked for when the host does not hold it
+//   posterior inputs of x' (correspondences, Gram, right-hand side)
+//   L(x')    = sum over the first n fit vertices of log N(|v - closest point of the target surface|; 0, sdev)
+//              -- with the surface correspondence these distances ARE the ones the correspondences of x' just measured
+//   q(x|x')  = posterior(x').logpdf(coefficients(x'.fit))     -- the q(.|x') of every later step that starts from x'
+// The host decides; a rejection is gingr_fitter_mh_restore (x becomes the device state again, nothing waits).
+static void mh_tag_state(gingr_fitter *f) {
+    f->state_key.v.assign({-1.2345678901234567e300, (double)++f->mh_serial});
+    f->state_key_valid = true;
+}
+
+static int mh_logpdf_enqueue(gingr_fitter *f, const DevState *frame, const double *mesh_soa, double *out2) {
+    gingr_ctx *ctx = f->ctx;
+    const gingr_model *m = f->m;
+    const int32_t r = m->r, rp = m->rp;
+    double *G = f->xch + f->off[1], *rhs = G + (int64_t)rp * rp;
+    if (f->lp_epoch == 0) HIP_TRY(ctx, hipMemsetAsync(f->lp_sync, 0, 2 * sizeof(unsigned), ctx->stream));
+    const bool cached = f->fx_valid[f->live];
+    hipLaunchKernelGGL(pose_of_state_kernel, dim3(1), dim3(64), 0, ctx->stream, frame, f->pose);
+    SweepArgs a = base_args(f);
+    a.shape_in = mesh_soa;
+    a.out = f->alpha_c;
+    launch_sweep(ctx, SWEEP_PROJ2, a);
+    GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, rhs, m->mom + MomentLayout{rp}.stot(), f->alpha_c, f->fxbuf[f->live], cached, f->work, out2,
+                                      f->lp_sync, ++f->lp_epoch));
+    if (f->post_stage == 2) f->fx_valid[f->live] = true;  // (taken back after the synchronisation when the kernel reports a failure)
+    return check_launch(ctx);
+}
+
+int gingr_fitter_mh_step(gingr_fitter *f, const gingr_mh_request *q, double *alpha_out, double *fit_out, gingr_mh_result *res) {
+    GINGR_TRY(check_ready(f));
+    gingr_ctx *ctx = f->ctx;
+    const gingr_model *m = f->m;
+    if (!q || !res || !alpha_out || q->flavour < 0 || q->flavour > 2 || (q->kind != 0 && q->kind != 1) || !(q->eval_sdev > 0.0) ||
+        q->eval_points < 0 || q->eval_points > m->M || (q->flavour == 0 ? !q->cpd : !q->icp) || (q->kind == 0 ? !q->z : (!q->alpha || !q->scalars)))
+        return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "mh_step: bad request");
+    if (q->flavour == 0 && (!(q->cpd->w >= 0.0 && q->cpd->w < 1.0) || !(q->cpd->lambda > 0.0)))
+        return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "cpd params: need 0 <= w < 1 and lambda > 0");
+    if (q->flavour != 0 && q->icp->max_iterations < 1) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "icp params: max_iterations < 1");
+    if (m->M != m->M_total || f->partial_out) return gingr_set_error(ctx, GINGR_ERR_STATE, "mh_step: single shard only");
+    if (!f->Tm || !f->Tt) return gingr_set_error(ctx, GINGR_ERR_STATE, "mh_step: no meshes set (gingr_fitter_set_meshes)");
+    if (f->step_length != 1.0) return gingr_set_error(ctx, GINGR_ERR_STATE, "mh_step: step length 1 only (the transition density projects from.fit)");
+    if (!f->state_key_valid)
+        return gingr_set_error(ctx, GINGR_ERR_STATE, "mh_step: the device state is not one the host set or read (gingr_fitter_set_state)");
+    const int64_t M = m->M;
+    const int32_t r = m->r, rp = m->rp;
+    const size_t head = (size_t)rp + kScalarsDoubles + kDevStateDoubles;
+    const int flavour = q->flavour;
+    int rc = GINGR_OK;
+    f->allow_alt = true;
+    struct Restore {  // whatever happens below, the entry-point-scoped switches go back
+        gingr_fitter *f;
+        ~Restore() { f->allow_alt = false, f->zrand_active = false; }
+    } restore{f};
+    // (1) the posterior inputs of x (memo: they exist unless x is the first state of the chain)
+    for (int ph = 0; ph < 2 && rc == GINGR_OK; ++ph) rc = flavour_phase(f, flavour, q->cpd, q->icp, ph);
+    GINGR_TRY(rc);
+    // (2) x stays: parameters + device state in mh_save, the fit by exchanging the two fit buffers
+    HIP_TRY(ctx, hipMemcpyAsync(f->mh_save, f->state_block, head * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    f->mh_key = f->state_key;
+    std::swap(f->fit, f->fit_alt);
+    const DevState *x_state = reinterpret_cast<const DevState *>(f->mh_save + rp + kScalarsDoubles);
+    // (3) the proposal
+    memset(f->pin, 0, ((size_t)rp + kScalarsDoubles) * sizeof(double));
+    if (q->kind == 0) {
+        memcpy(f->pin, q->z, (size_t)r * sizeof(double));
+        HIP_TRY(ctx, hipMemcpyAsync(f->zrand, f->pin, (size_t)rp * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        f->zrand_active = true;
+        rc = flavour_phase(f, flavour, q->cpd, q->icp, 2);
+        f->zrand_active = false;
+        GINGR_TRY(rc);
+        mh_tag_state(f);
+    } else {
+        memcpy(f->pin, q->alpha, (size_t)r * sizeof(double));
+        memcpy(f->pin + rp, q->scalars, sizeof(*q->scalars));
+        HIP_TRY(ctx, hipMemcpyAsync(f->state_block, f->pin, ((size_t)rp + kScalarsDoubles) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        launch_state_init(ctx, f->st, f->hs_dev, f->absmax + 1);
+        refresh_fit(f);
+        GINGR_TRY(check_launch(ctx));
+        const gingr_state_scalars *s = q->scalars;  // the host knows this state: keyed by value, like gingr_fitter_set_state
+        f->state_key.v.assign(q->alpha, q->alpha + r);
+        for (int k = 0; k < 3; ++k) f->state_key.v.push_back(s->euler[k]);
+        for (int k = 0; k < 3; ++k) f->state_key.v.push_back(s->center[k]);
+        for (int k = 0; k < 3; ++k) f->state_key.v.push_back(s->translation[k]);
+        f->state_key.v.push_back(s->scale);
+        f->state_key.v.push_back(s->sigma2);
+        f->state_key_valid = true;
+    }
+    // (4) q(x'|x): the live posterior slot still holds x; frame and mesh of x
+    const int slot_fw = f->live;
+    if (q->need_forward) GINGR_TRY(mh_logpdf_enqueue(f, x_state, f->fit_alt, f->small));
+    // (5) the posterior inputs of x' (x's are parked in the second slot)
+    rc = flavour_phase(f, flavour, q->cpd, q->icp, 0);
+    const bool memo_hit = f->skip_phase1;
+    if (rc == GINGR_OK) rc = flavour_phase(f, flavour, q->cpd, q->icp, 1);
+    GINGR_TRY(rc);
+    // (6) the likelihood of x'
+    if (!f->stat_scratch) f->stat_scratch = new StatScratch;
+    StatScratch &sc = *static_cast<StatScratch *>(f->stat_scratch);
+    HIP_TRY(ctx, ensure(sc.part, (size_t)distance_stats_ws_doubles() * sizeof(double)));
+    const double *d2 = f->surf_d2;
+    if (!(flavour == 2 && !memo_hit && !f->reversed && f->surface_method == 0)) {  // no fresh closest-point scan of x' to share
+        const Cloud fit = cloud_of(f->fit, M), tgt = cloud_of(f->target, f->N);
+        HIP_TRY(ctx, ensure(sc.cp, (size_t)3 * M * sizeof(double)));
+        HIP_TRY(ctx, ensure(sc.d2, (size_t)M * sizeof(double)));
+        HIP_TRY(ctx, ensure(sc.pos, (size_t)M * sizeof(int32_t)));
+        const bool warm = sc.pos_K == M && sc.pos_T == f->Tt && sc.pos_tri == f->ttri;
+        launch_surface_closest_point(ctx, fit, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, sc.cp.as<double>(), sc.d2.as<double>(), nullptr,
+                                     sc.pos.as<int32_t>(), warm, f->ttribox);
+        sc.pos_K = M, sc.pos_T = f->Tt, sc.pos_tri = f->ttri;
+        d2 = sc.d2.as<double>();
+    }
+    const bool all = q->eval_points == 0 || q->eval_points == M;
+    launch_distance_stats(ctx, M, d2, all ? nullptr : m->perm, q->eval_points, nullptr, nullptr, q->eval_sdev, sc.part.as<double>(), f->small + 4);
+    // (7) q(x|x'): frame, posterior and mesh of x'
+    const int slot_bw = f->live;
+    GINGR_TRY(mh_logpdf_enqueue(f, f->st, f->fit, f->small + 2));
+    // (8) one transfer back: [alpha | scalars | DevState] of x', the eight results, the fit on request
+    HIP_TRY(ctx, hipMemcpyAsync(f->pin, f->state_block, head * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(f->pin + head, f->small, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (fit_out) {
+        double *stage = reinterpret_cast<double *>(f->aos);
+        launch_soa_to_aos(ctx, f->fit, M, stage, m->perm);
+        HIP_TRY(ctx, hipMemcpyAsync(f->pin + head + 8, stage, (size_t)3 * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    GINGR_TRY(check_launch(ctx));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    f->mh_saved = true;
+    DevState hst;
+    memcpy(&hst, f->pin + rp + kScalarsDoubles, sizeof(hst));
+    memcpy(alpha_out, f->pin, (size_t)r * sizeof(double));
+    if (fit_out) memcpy(fit_out, f->pin + head + 8, (size_t)3 * M * sizeof(double));
+    memset(res, 0, sizeof(*res));
+    for (int k = 0; k < 3; ++k) {
+        res->scalars.euler[k] = hst.euler[k];
+        res->scalars.center[k] = hst.center[k];
+        res->scalars.translation[k] = hst.t[k];
+    }
+    res->scalars.scale = hst.scale;
+    res->scalars.sigma2 = hst.sigma2;
+    res->scalars.iteration = hst.iteration;
+    res->scalars.status = hst.status;
+    const double *o = f->pin + head;
+    auto density = [&](const double *v, int slot, double *lp, int32_t *status) {
+        *status = v[1] != 0.0 ? GINGR_ERR_NOT_SPD : (std::isfinite(v[0]) ? GINGR_OK : GINGR_ERR_NONFINITE);
+        *lp = *status == GINGR_OK ? v[0] : -INFINITY;
+        if (*status != GINGR_OK) f->fx_valid[slot] = false;  // nothing usable was left behind for the cached form
+    };
+    if (q->need_forward) {
+        density(o, slot_fw, &res->log_q_forward, &res->forward_status);
+    } else {
+        res->log_q_forward = NAN;
+        res->forward_status = -1;  // not asked for
+    }
+    density(o + 2, slot_bw, &res->log_q_backward, &res->backward_status);
+    res->dist_sum = o[4];
+    res->dist_max = o[5];
+    res->count = (int64_t)o[6];
+    res->log_value = o[7];
+    if (q->kind == 0) {  // the host now knows the state the update produced: value key, so that set_state of the same numbers finds its memo
+        gingr_fitter::Key k = f->state_key;
+        k.v.assign(alpha_out, alpha_out + r);
+        for (int d = 0; d < 3; ++d) k.v.push_back(hst.euler[d]);
+        for (int d = 0; d < 3; ++d) k.v.push_back(hst.center[d]);
+        for (int d = 0; d < 3; ++d) k.v.push_back(hst.t[d]);
+        k.v.push_back(hst.scale);
+        k.v.push_back(hst.sigma2);
+        if (f->post_stage == 2 && f->post_key.v == f->state_key.v) f->post_key.v = k.v;
+        if (f->alt_stage == 2 && f->alt_key.v == f->state_key.v) f->alt_key.v = k.v;
+        f->state_key.v = k.v;
+    }
+    return GINGR_OK;
+}
+
+int gingr_fitter_mh_restore(gingr_fitter *f) {
+    GINGR_TRY(check_ready(f));
+    gingr_ctx *ctx = f->ctx;
+    if (!f->mh_saved) return gingr_set_error(ctx, GINGR_ERR_STATE, "mh_restore: no gingr_fitter_mh_step since the state was last set");
+    const size_t head = (size_t)f->m->rp + kScalarsDoubles + kDevStateDoubles;
+    HIP_TRY(ctx, hipMemcpyAsync(f->state_block, f->mh_save, head * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    refresh_fit(f);  // (recomputed rather than taken from fit_alt: the pass also leaves the boxes the CPD passes prune with)
+    GINGR_TRY(check_launch(ctx));
+    f->state_key = f->mh_key;
+    f->state_key_valid = true;
+    f->mh_saved = false;
+    return GINGR_OK;
 }
 
 int gingr_mesh_distance_stats(gingr_ctx *ctx, int64_t n_points, const double *points, int64_t n_vertices, const double *vertices,

@@ -190,6 +190,7 @@ class EvaluatorWrapper:
 class ProbabilisticSettings:
     evaluators: AcceptAll
     randomMixture: float = 0.5
+    fusedSteps: bool = True      # (no reference counterpart) one native call per Metropolis-Hastings step where the set-up allows it
 
     def __post_init__(self):
         if not (0.0 <= self.randomMixture <= 1.0):
@@ -348,7 +349,7 @@ class GeneratorWrapperStochastic:
     def propose(self, current):
         new = self.algorithm.update(current, True, self.rnd.scalaRandom)
         out = new.updateGeneral(dataclasses.replace(new.general, generatedBy=self.generatedBy))
-        self.algorithm._device_state = out
+        self.algorithm._adopt_state(new, out)
         return out
 
     def logTransitionProbability(self, frm, to) -> float:
@@ -362,7 +363,7 @@ class GeneratorWrapperDeterministic:
     def propose(self, current):
         new = self.algorithm.update(current, False)
         out = new.updateGeneral(dataclasses.replace(new.general, generatedBy=self.generatedBy))
-        self.algorithm._device_state = out
+        self.algorithm._adopt_state(new, out)
         return out
 
     def logTransitionProbability(self, frm, to) -> float:
@@ -520,21 +521,33 @@ def run(algorithm: GingrAlgorithm, initialState, acceptRejectLogger=None, callBa
     generator = generatorCombined(algorithm, probabilisticSettings, generators, rnd)
     best = BestAndCurrentSampleLogger(evaluator)
     chain = MetropolisHastings(generator, evaluator, rnd)
-    if acceptRejectLogger is not None:
-        acceptRejectLogger.accept(initialState, initialState, generator, evaluator)
-    state, last_general, converged, k = initialState, None, False, 0
-    while True:
-        if callBackLogger is not None:
-            callBackLogger(state)
-        best.logState(state)
-        if not probabilistic and last_general is not None:
-            converged = bool(state.config.converged(last_general, state.general, state.config.threshold))
-        error = state.general.status == FittingStatuses.ModelFlexibilityError
-        last_general = state.general
-        k += 1
-        if converged or error or k >= state.config.maxIterations:
-            break
-        state = chain.next(state, acceptRejectLogger)
+    # One native call per step (GingrAlgorithm.enableFusedSteps) when the likelihood is the model-to-target point distance of this
+    # algorithm: the call measures it together with the proposal and both transition densities.  Same draws, same decisions.
+    fused = False
+    if probabilistic and settings.fusedSteps:
+        dist = [e.evaluator for e in settings.evaluators.evaluator() if isinstance(e.evaluator, IndependentPointDistanceEvaluator)]
+        if len(dist) == 1 and dist[0].algorithm is algorithm and dist[0].evaluationMode == ModelToTargetEvaluation:
+            algorithm.enableFusedSteps(dist[0].uncertainty, dist[0].modelPointCount or 0)
+            fused = True
+    try:
+        if acceptRejectLogger is not None:
+            acceptRejectLogger.accept(initialState, initialState, generator, evaluator)
+        state, last_general, converged, k = initialState, None, False, 0
+        while True:
+            if callBackLogger is not None:
+                callBackLogger(state)
+            best.logState(state)
+            if not probabilistic and last_general is not None:
+                converged = bool(state.config.converged(last_general, state.general, state.config.threshold))
+            error = state.general.status == FittingStatuses.ModelFlexibilityError
+            last_general = state.general
+            k += 1
+            if converged or error or k >= state.config.maxIterations:
+                break
+            state = chain.next(state, acceptRejectLogger)
+    finally:
+        if fused:
+            algorithm.disableFusedSteps()
     fit = best.currentBestSample() if probabilistic else best.currentSample()
     if fit.general.status == FittingStatuses.None_:
         fit = fit.updateGeneral(fit.general.updateStatus(FittingStatuses.Converged if converged else FittingStatuses.MaxIteration))

@@ -403,6 +403,45 @@ int gingr_fitter_posterior_logpdf_sharded(gingr_fitter *f, int32_t flavour, cons
                                           const double *mesh_xyz_full, gingr_allreduce_fn reduce, void *user, double *logpdf);
 int gingr_fitter_fullfit_exchange(gingr_fitter *f, void **dev_ptr, int64_t *count);
 
+/* ---- one Metropolis-Hastings step of GingrAlgorithm.run's chain in ONE call (G/api/GingrAlgorithm.scala:115-190; scalismo
+ * MetropolisHastings.next = propose, evaluate both, transition ratio, accept / reject) ---------------------------------------------
+ * The device state x (gingr_fitter_set_state, or what the previous step left) is the current sample.  The call enqueues
+ *   x' = kind 0: update(x, probabilistic = true) with the r standard normals z (GeneratorWrapperStochastic.propose,
+ *        G/api/sampling/generators/GeneratorWrapperStochastic.scala:28-40), or
+ *        kind 1: the parameters a random-walk proposal chose (alpha, scalars incl. iteration + 1; the fit is re-instantiated on the
+ *        device: GingrGeneratorWrapper.scala:28-39)
+ *   log_q_forward  = logTransitionProbability(x, x') = posterior(x).gp.logpdf(posterior.coefficients(x.fit)): with step length 1 the
+ *                    reference projects FROM.fit (GeneratorWrapperStochastic.scala:42-63), so this is a function of x alone -- the
+ *                    log_q_backward of the step that produced x -- and is computed only with need_forward != 0 (else NaN, status -1)
+ *   log_q_backward = logTransitionProbability(x', x) = posterior(x').gp.logpdf(posterior.coefficients(x'.fit))
+ *   log_value      = sum over the first eval_points fit vertices of x' (0 = all) of log N(|v - closestPointOnSurface(v)|; 0, eval_sdev)
+ *                    against the target surface (IndependentPointDistanceEvaluator.scala:54-70, ModelToTargetEvaluation)
+ * and synchronises ONCE.  x' is the device state on return; alpha_out[r] / fit_out[3 M] (nullable) / res->scalars describe it.  A
+ * density is -inf with its status GINGR_ERR_NOT_SPD / GINGR_ERR_NONFINITE when the posterior it needs fails (what the reference's Try
+ * turns into Double.NegativeInfinity).  The host combines these with the densities of its random-walk components and decides; after a
+ * rejection gingr_fitter_mh_restore makes x the device state again (asynchronous).  Every state's correspondences and Gram are
+ * computed once (two-slot posterior memo).  Single shard, meshes set, flavour as in gingr_fitter_update_sharded_async. */
+typedef struct gingr_mh_request {
+    int32_t flavour, kind;
+    const gingr_cpd_params *cpd; /* flavour 0 */
+    const gingr_icp_params *icp; /* flavours 1, 2 */
+    const double *z;             /* kind 0 */
+    const double *alpha;         /* kind 1 */
+    const gingr_state_scalars *scalars;
+    double eval_sdev;
+    int64_t eval_points;
+    int32_t need_forward;
+} gingr_mh_request;
+typedef struct gingr_mh_result {
+    gingr_state_scalars scalars; /* of x' */
+    double log_value, dist_sum, dist_max;
+    int64_t count;
+    double log_q_forward, log_q_backward;
+    int32_t forward_status, backward_status;
+} gingr_mh_result;
+int gingr_fitter_mh_step(gingr_fitter *f, const gingr_mh_request *request, double *alpha_out, double *fit_out, gingr_mh_result *result);
+int gingr_fitter_mh_restore(gingr_fitter *f);
+
 /* ---- native RCCL exchange: the row-sharded update with one process per GPU and the collective enqueued by the LIBRARY ------------
  * BASELINE.json north_star: "the N x M affinity/distance matrix shards by reference-point rows across the 8 GPUs of one node with an
  * RCCL all-reduce over xGMI for CPD column sums".  Every rank owns one context (one device, one stream), one row shard of the model

@@ -5,7 +5,7 @@ correspondence, evaluatorUncertainty = 5, randomMixture = 0.5, model-to-target l
 both meshes to 100 points with scalismo's decimation, which is not restated: the full 1 622-vertex meshes are used).
 One step = proposal (informed: surface ICP update with a posterior sample; or a random walk re-instantiated on the device)
 + likelihood of the proposal + both transition densities + accept / reject.
-    PYTHONPATH=. python tools/bench_mh_chain.py [steps] [seed]
+    PYTHONPATH=. python tools/bench_mh_chain.py [steps] [seed] [nofuse]     (nofuse: the call-by-call path instead of one native call per step)
 Config 5 proper is 8 such chains, one per GPU, no communication ("replicas only")."""
 import json
 import os
@@ -22,6 +22,7 @@ from gingr_amd import sampling as sp
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+fused = not (len(sys.argv) > 3 and sys.argv[3] == "nofuse")
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 d, m = np.load(os.path.join(root, "inputs.npz")), np.load(os.path.join(root, "femur_mesh.npz"))
 ref, target = d["femur"].astype(np.float64), d["femur_target"].astype(np.float64)
@@ -31,7 +32,7 @@ model.cells = m["femur_cells"]
 algo = ga.IcpRegistration(ctx)
 cfg = ga.IcpConfiguration(maxIterations=steps + 1, initialSigma=1.0, endSigma=1.0, correspondenceMethod="TriangularClosestPoint")
 s0 = algo.createInitialState(model, target, cfg, targetCells=m["femur_target_cells"])
-settings = sp.ProbabilisticSettings(sp.IndependentPoints(algo, s0, 5.0), randomMixture=0.5)
+settings = sp.ProbabilisticSettings(sp.IndependentPoints(algo, s0, 5.0), randomMixture=0.5, fusedSteps=fused)
 counts = {}
 
 
@@ -54,7 +55,7 @@ rc = ga.RegistrationComparison(ctx, verbose=False)
 fit = ga.TriangleMesh3D(np.asarray(best.general.fit), model.cells)
 avg, mx = rc.evaluateReconstruction2GroundTruthBoundaryAware("", fit, ga.TriangleMesh3D(target, m["femur_target_cells"]))
 print(json.dumps({"what": "MH-in-GiNGR chain, femur, surface ICP proposals (config 5, one chain)", "vertices": int(ref.shape[0]),
-                  "rank": int(model.rank), "steps": steps, "steps_per_s": steps / dt, "ms_per_step": dt / steps * 1e3,
+                  "rank": int(model.rank), "steps": steps, "fused_steps": fused, "steps_per_s": steps / dt, "ms_per_step": dt / steps * 1e3,
                   "log_value_initial": v0, "log_value_best": ev.logValue(best),
                   "accepted_rejected_by_proposal": counts, "avg_surface_distance_best": avg, "max_surface_distance_best": mx,
                   "status": int(best.general.status)}))
