@@ -139,6 +139,9 @@ struct gingr_fitter {
     Key mh_key;
     bool mh_saved = false;
     uint64_t mh_serial = 0;
+    // The quarter boxes / |coordinate - centre| maximum of the fit are read by the two CPD pair loops only: the pass that writes the
+    // fit produces them once a CPD phase has asked for them (cpd_seen), an ICP-only fitter runs the plain, shorter pass.
+    bool cpd_seen = false, fit_boxes_valid = false;
 };
 
 constexpr size_t kScalarsDoubles = (sizeof(gingr_state_scalars) + 7) / 8, kDevStateDoubles = (sizeof(DevState) + 7) / 8;
@@ -217,6 +220,7 @@ void fit_boxes_now(gingr_fitter *f) {
     if (!f->fboxes) return;
     (void)hipMemsetAsync(f->absmax + 1, 0, sizeof(double), f->ctx->stream);
     launch_tile_bbox(f->ctx, cloud_of(f->fit, f->m->M), f->fboxes, f->absmax + 2, f->absmax + 1);
+    f->fit_boxes_valid = true;
 }
 
 // fit = modelInstanceShapePoseScale(model, state)
@@ -224,14 +228,16 @@ void refresh_fit(gingr_fitter *f) {
     SweepArgs a = base_args(f);
     a.coef0 = f->alpha;
     a.shape_out = f->fit;
-    if (f->fboxes && f->m->rp <= 128) {  // a target is set: the pass also leaves the quarter boxes and the |coordinate - centre| maximum
+    if (f->fboxes && f->m->rp <= 128 && f->cpd_seen) {  // the pass also leaves the quarter boxes and the |coordinate - centre| maximum
         a.qboxes = f->fboxes + 6 * ceil_div(f->m->M, 256);
         a.box_centre = f->absmax + 2;
         a.absmax_slot = f->absmax + 1;
         launch_sweep(f->ctx, SWEEP_FIT, a);
+        f->fit_boxes_valid = true;
     } else {
         launch_sweep(f->ctx, SWEEP_FIT, a);
-        fit_boxes_now(f);  // rank > 128: the generic pass, the boxes by a launch of their own
+        f->fit_boxes_valid = false;
+        if (f->cpd_seen) fit_boxes_now(f);  // rank > 128: the generic pass, the boxes by a launch of their own
     }
 }
 
@@ -518,8 +524,8 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
         (rc = dev_alloc(ctx, &f->PX, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->nn_idx, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->nn_d2, (size_t)M)) || (rc = dev_alloc(ctx, &f->weight, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->evec, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->newshape, (size_t)3 * M)) ||
-        (rc = dev_alloc(ctx, &f->state_block, (size_t)rp + kScalarsDoubles + kDevStateDoubles)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
-        (rc = dev_alloc(ctx, &f->small, (size_t)8)) || (rc = dev_alloc(ctx, &f->fxbuf[0], (size_t)rp * rp + 2 * rp)) || (rc = dev_alloc(ctx, &f->fxbuf[1], (size_t)rp * rp + 2 * rp)) ||
+        (rc = dev_alloc(ctx, &f->state_block, (size_t)rp + kScalarsDoubles + kDevStateDoubles + 8)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
+        (rc = dev_alloc(ctx, &f->fxbuf[0], (size_t)rp * rp + 2 * rp)) || (rc = dev_alloc(ctx, &f->fxbuf[1], (size_t)rp * rp + 2 * rp)) ||
         (rc = dev_alloc(ctx, &f->alt_seg, (size_t)rp * rp + rp + 8)) || (rc = dev_alloc(ctx, &f->lp_sync, (size_t)2)) ||
         (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->zbuf, (size_t)PostVec::kZRows * rp)) || (rc = dev_alloc(ctx, &f->zrand, (size_t)rp)) ||
         (rc = dev_alloc(ctx, &f->pose, 1)) || (rc = dev_alloc(ctx, &f->fit_alt, (size_t)3 * M)) ||
@@ -532,6 +538,7 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
     f->alpha = f->state_block;
     f->hs_dev = reinterpret_cast<gingr_state_scalars *>(f->state_block + rp);
     f->st = reinterpret_cast<DevState *>(f->state_block + rp + kScalarsDoubles);
+    f->small = f->state_block + rp + kScalarsDoubles + kDevStateDoubles;  // behind the state: one transfer brings both back (mh_step)
     f->pin_doubles = (size_t)3 * M + rp + kScalarsDoubles + kDevStateDoubles + 16;  // (+ the eight results of gingr_fitter_mh_step)
     if (hipHostMalloc(reinterpret_cast<void **>(&f->pin), f->pin_doubles * sizeof(double), hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
@@ -586,7 +593,6 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->zrand);
     dev_free(f->pose);
     dev_free(f->scalars);
-    dev_free(f->small);
     dev_free(f->fxbuf[0]);
     dev_free(f->fxbuf[1]);
     dev_free(f->alt_seg);
@@ -672,6 +678,7 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
     HIP_TRY(ctx, hipMemcpyAsync(f->tperm, f->h_tperm.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     GINGR_TRY(dev_alloc(ctx, &f->tboxes, (size_t)ceil_div(N, 256) * 30));  // tile boxes + four quarter boxes per tile
     GINGR_TRY(dev_alloc(ctx, &f->fboxes, (size_t)ceil_div(M, 256) * 30));
+    f->fit_boxes_valid = false;
     GINGR_TRY(dev_alloc(ctx, &f->tile_bad, (size_t)ceil_div(N, 256)));
     launch_aos_to_soa(ctx, aos, N, f->target, f->tperm);
     launch_tile_bbox(ctx, cloud_of(f->target, N), f->tboxes);
@@ -1092,6 +1099,8 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
             } else {
                 // (the quarter boxes of the fit and its |coordinate - centroid| maximum were left by the pass that wrote the fit:
                 // refresh_fit / fit_boxes_now)
+                f->cpd_seen = true;
+                if (!f->fit_boxes_valid) fit_boxes_now(f);  // (first CPD phase of this fitter, or the fit was written while it ran ICP)
                 // single shard: nothing is exchanged, so the chunk partials stay in ws and phase 1's den_finalize adds them up
                 const bool alone = m->M == m->M_total && !f->partial_out;
                 f->colsum_chunks = launch_cpd_colsum(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->fboxes, f->ws, alone ? nullptr : seg0w);
@@ -2047,7 +2056,7 @@ static void mh_tag_state(gingr_fitter *f) {
     f->state_key_valid = true;
 }
 
-static int mh_logpdf_enqueue(gingr_fitter *f, const DevState *frame, const double *mesh_soa, double *out2) {
+static int mh_logpdf_enqueue(gingr_fitter *f, const DevState *frame, const double *mesh_soa, double *out2, bool keep_factor) {
     gingr_ctx *ctx = f->ctx;
     const gingr_model *m = f->m;
     const int32_t r = m->r, rp = m->rp;
@@ -2060,8 +2069,9 @@ static int mh_logpdf_enqueue(gingr_fitter *f, const DevState *frame, const doubl
     a.out = f->alpha_c;
     launch_sweep(ctx, SWEEP_PROJ2, a);
     GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, rhs, m->mom + MomentLayout{rp}.stot(), f->alpha_c, f->fxbuf[f->live], cached, f->work, out2,
-                                      f->lp_sync, ++f->lp_epoch));
-    if (f->post_stage == 2) f->fx_valid[f->live] = true;  // (taken back after the synchronisation when the kernel reports a failure)
+                                      f->lp_sync, ++f->lp_epoch, keep_factor));
+    // (taken back after the synchronisation when the kernel reports a failure; ranks above 112 always leave the factor behind)
+    if (f->post_stage == 2 && (keep_factor || rp > 112)) f->fx_valid[f->live] = true;
     return check_launch(ctx);
 }
 
@@ -2126,7 +2136,7 @@ int gingr_fitter_mh_step(gingr_fitter *f, const gingr_mh_request *q, double *alp
     }
     // (4) q(x'|x): the live posterior slot still holds x; frame and mesh of x
     const int slot_fw = f->live;
-    if (q->need_forward) GINGR_TRY(mh_logpdf_enqueue(f, x_state, f->fit_alt, f->small));
+    if (q->need_forward) GINGR_TRY(mh_logpdf_enqueue(f, x_state, f->fit_alt, f->small, true));
     // (5) the posterior inputs of x' (x's are parked in the second slot)
     rc = flavour_phase(f, flavour, q->cpd, q->icp, 0);
     const bool memo_hit = f->skip_phase1;
@@ -2152,10 +2162,10 @@ int gingr_fitter_mh_step(gingr_fitter *f, const gingr_mh_request *q, double *alp
     launch_distance_stats(ctx, M, d2, all ? nullptr : m->perm, q->eval_points, nullptr, nullptr, q->eval_sdev, sc.part.as<double>(), f->small + 4);
     // (7) q(x|x'): frame, posterior and mesh of x'
     const int slot_bw = f->live;
-    GINGR_TRY(mh_logpdf_enqueue(f, f->st, f->fit, f->small + 2));
+    // (this state's density is asked for once: the host keeps the number, so the factor need not be left behind)
+    GINGR_TRY(mh_logpdf_enqueue(f, f->st, f->fit, f->small + 2, false));
     // (8) one transfer back: [alpha | scalars | DevState] of x', the eight results, the fit on request
-    HIP_TRY(ctx, hipMemcpyAsync(f->pin, f->state_block, head * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(f->pin + head, f->small, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(f->pin, f->state_block, (head + 8) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));  // (small follows)
     if (fit_out) {
         double *stage = reinterpret_cast<double *>(f->aos);
         launch_soa_to_aos(ctx, f->fit, M, stage, m->perm);

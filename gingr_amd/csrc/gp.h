@@ -226,10 +226,11 @@ void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
 // out2[0] = posterior.gp.logpdf(posterior.coefficients(mesh)), out2[1] != 0: the posterior failed; qte = Q0^T e (model-frame
 // residual).  fx ([rp*rp + 2*rp], nullable): receives the state-only part of the computation (cached == false) or provides it
 // (cached == true: only the mesh-dependent part runs).  sync (2 zero-initialised words on the device) + a launch number `epoch`
-// that never repeats: r <= 128 then runs the two factorisations on two workgroups.
+// that never repeats: r <= 128 then runs the two factorisations on two workgroups; keep_factor == false lets that form skip the
+// write-back of the state-only part (fx then only carries the posterior coefficients between the two workgroups).
 int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *Stot,
                             const double *qte, double *fx, bool cached, double *work, double *out2, unsigned *sync = nullptr,
-                            unsigned epoch = 0);
+                            unsigned epoch = 0, bool keep_factor = true);
 // a = (I + S_tot / sigma2)^-1 rhs through the one-off eigen-decomposition S_tot = V diag(lam) V^T: a = V ((V^T rhs) / (1 + lam / sigma2)).
 // The posterior of point-cloud ICP without landmarks -- every row weighs 1 / sigma2 (ICP.scala:90-92) -- needs no factorisation.
 void launch_posterior_solve_eig(gingr_ctx *ctx, int32_t r, int32_t rp, const double *eigV, const double *eigL, const double *sigma2,

@@ -1667,16 +1667,21 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_lds_kernel(int
     }
 }
 
-// posterior_logpdf_lds_kernel on TWO workgroups (r <= 128): the factor of S_tot + eps (I + G) does not depend on the posterior
-// coefficients a -- only its right-hand side does -- so workgroup 1 factors it while workgroup 0 factors I + G and solves for a;
-// workgroup 1 then picks a up (agent-scope release / acquire on sync[0], the value `epoch` of this launch; sync[1] carries workgroup
-// 0's failure flag), forms b and finishes as posterior_logpdf_cached_kernel does.  87 -> ~55 us.  Workgroup 0 is dispatched first, so
-// workgroup 1 never waits for a workgroup that has no compute unit.
+// posterior_logpdf_lds_kernel on TWO workgroups (r <= 128): the factor of K = S_tot + eps (I + G) does not depend on the posterior
+// coefficients a, so workgroup 1 factors it while workgroup 0 factors N = I + G and solves N a = rhs.  Round 4: neither does the
+// right-hand side have to wait for a -- S_tot a = K a - eps N a = K a - eps rhs, hence
+//     u = K^-1 (Q0^T e - S_tot a) = K^-1 (Q0^T e + eps rhs) - a =: w - a,        |c|^2 = u^T N u = u^T (N w - rhs)
+// -- so workgroup 1 lets the forward solve of (Q0^T e + eps rhs) ride through its factorisation, substitutes back, forms N w - rhs,
+// and only then picks a up (agent-scope release / acquire on sync[0], the value `epoch` of this launch; sync[1] carries workgroup 0's
+// failure flag) for two vector operations: the mat-vec with S_tot, the forward solve and every wait are off the critical path
+// (87 us in one workgroup -> 60 -> ~45).  keep != 0 leaves the factor of K, its reciprocal diagonal and a in fx for
+// posterior_logpdf_cached_kernel (a Metropolis-Hastings step that asks again about the same state); a always travels through fx.
+// Workgroup 0 is dispatched first, so workgroup 1 never waits for a workgroup that has no compute unit.
 __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_split_kernel(int r, int rp, const double *__restrict__ G,
                                                                      const double *__restrict__ rhs,
                                                                      const double *__restrict__ Stot,
                                                                      const double *__restrict__ qte, double *__restrict__ fx,
-                                                                     double *__restrict__ out2, unsigned *sync, unsigned epoch) {
+                                                                     double *__restrict__ out2, unsigned *sync, unsigned epoch, int keep) {
     extern __shared__ double sm[];
     const int n = rp, ld = solve_ld(n);
     double *A = sm;
@@ -1701,30 +1706,54 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_split_kernel(i
         }
         return;
     }
-    for (int k = tid; k < kNB * ld; k += kSolveThreads) u[k] = 0.0;
+    for (int k = tid; k < kNB * ld; k += kSolveThreads) u[k] = k < r ? __builtin_fma(GINGR_COEFF_NOISE, rhs[k], qte[k]) : 0.0;
     lds_load_spd<kSolveThreads>(A, ld, r, n, G, GINGR_COEFF_NOISE, Stot, 1.0, GINGR_COEFF_NOISE);
-    lds_cholesky<kSolveThreads>(A, ld, n, rd, &bad_spd, kNB);
-    for (int i = tid >> 6; i < n; i += kSolveThreads / 64)  // the state-only part for posterior_logpdf_cached_kernel
-        for (int j = tid & 63; j < n; j += 64) fx[(int64_t)i * rp + j] = A[i * ld + j];
-    for (int k = tid; k < n; k += kSolveThreads) fx[(int64_t)rp * rp + rp + k] = rd[k];
+    lds_cholesky<kSolveThreads>(A, ld, n, rd, &bad_spd, kNB);  // u <- L_K^-1 (Q0^T e + eps rhs) on the way
+    lds_backward<kSolveThreads>(A, ld, n, rd, u);              // u = w
+    __syncthreads();
+    {   // hv[0] + hv[1] = G w (two halves of the row range per column, coalesced over the column)
+        const int k = tid & 127, half = tid >> 7;
+        for (int kk = k; kk < r; kk += 128) {
+            const int j0 = half ? (r + 1) / 2 : 0, j1 = half ? r : (r + 1) / 2;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int j = j0;
+            for (; j + 3 < j1; j += 4) {
+                s0 = __builtin_fma(G[(int64_t)j * rp + kk], u[j], s0);
+                s1 = __builtin_fma(G[(int64_t)(j + 1) * rp + kk], u[j + 1], s1);
+                s2 = __builtin_fma(G[(int64_t)(j + 2) * rp + kk], u[j + 2], s2);
+                s3 = __builtin_fma(G[(int64_t)(j + 3) * rp + kk], u[j + 3], s3);
+            }
+            for (; j < j1; ++j) s0 = __builtin_fma(G[(int64_t)j * rp + kk], u[j], s0);
+            hv[half][kk] = (s0 + s1) + (s2 + s3);
+        }
+    }
+    if (keep) {  // the state-only part for posterior_logpdf_cached_kernel
+        for (int i = tid >> 6; i < n; i += kSolveThreads / 64)
+            for (int j = tid & 63; j < n; j += 64) fx[(int64_t)i * rp + j] = A[i * ld + j];
+        for (int k = tid; k < n; k += kSolveThreads) fx[(int64_t)rp * rp + rp + k] = rd[k];
+    }
     if (tid == 0) {
         while (__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
         if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) bad_spd = 1;
     }
     __syncthreads();
-    for (int k = tid; k < rp; k += kSolveThreads)
-        av[k] = k < r ? __hip_atomic_load(&fx[(int64_t)rp * rp + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    double part = 0.0;
+    for (int k = tid; k < r; k += kSolveThreads) {
+        const double a = __hip_atomic_load(&fx[(int64_t)rp * rp + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double nw = (hv[0][k] + hv[1][k]) + u[k];  // (N w)_k
+        part = __builtin_fma(u[k] - a, nw - rhs[k], part);
+    }
+    red[tid] = part;
     __syncthreads();
-    logpdf_rhs(r, rp, Stot, qte, av, hv, u);
-    __syncthreads();
-    lds_forward<kSolveThreads>(A, ld, n, rd, u);
-    lds_backward<kSolveThreads>(A, ld, n, rd, u);
-    __syncthreads();
-    const double n2 = logpdf_quadratic(r, rp, G, u, red);
+    for (int st2 = kSolveThreads / 2; st2 > 0; st2 >>= 1) {
+        if (tid < st2) red[tid] += red[tid + st2];
+        __syncthreads();
+    }
     if (tid == 0) {
-        out2[0] = bad_spd ? __builtin_nan("") : -0.5 * n2 - 0.5 * (double)r * 1.8378770664093454836;  // log(2 pi)
+        out2[0] = bad_spd ? __builtin_nan("") : -0.5 * red[0] - 0.5 * (double)r * 1.8378770664093454836;  // log(2 pi)
         out2[1] = bad_spd ? 1.0 : 0.0;
     }
+    (void)av;
 }
 
 // The same log-density for a state whose posterior_logpdf_lds_kernel has run before (fx: its posterior coefficients and the factor
@@ -2410,7 +2439,8 @@ void launch_posterior_solve_eig(gingr_ctx *ctx, int32_t r, int32_t rp, const dou
 }
 
 int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *Stot,
-                            const double *qte, double *fx, bool cached, double *work, double *out2, unsigned *sync, unsigned epoch) {
+                            const double *qte, double *fx, bool cached, double *work, double *out2, unsigned *sync, unsigned epoch,
+                            bool keep_factor) {
     const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
     // the log-density kernels keep 14 KB of static LDS (mat-vec scratch) next to the bordered matrix: with rp = 128 the two exceed the
     // 160 KB of a compute unit, so ranks above 112 take the global-workspace variants (the plain solve fits up to rp = 128)
@@ -2420,7 +2450,7 @@ int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds);
         hipLaunchKernelGGL(posterior_logpdf_split_kernel, dim3(2), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte, fx,
-                           out2, sync, epoch);
+                           out2, sync, epoch, keep_factor ? 1 : 0);
         return GINGR_OK;
     }
     if (cached) {  // fx holds what an earlier launch for this state left

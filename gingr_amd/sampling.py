@@ -207,13 +207,15 @@ def _same_except(a: ModelFittingParameters, b: ModelFittingParameters, skip: Tup
     """a == b in every field but `skip` -- what `to.copy(field = from.field) == from` of the reference's proposals tests, without
     building the copy (a Metropolis-Hastings step asks nine random-walk components twice; the shape vectors of two states that
     differ by a pose proposal are the same object)."""
+    if a is b:
+        return True
     if "scale" not in skip and a.scale != b.scale:
         return False
-    if "translation" not in skip and tuple(a.translation) != tuple(b.translation):
+    if "translation" not in skip and a.translation is not b.translation and tuple(a.translation) != tuple(b.translation):
         return False
-    if "rotation" not in skip and a.rotation != b.rotation:
+    if "rotation" not in skip and a.rotation is not b.rotation and a.rotation != b.rotation:
         return False
-    if "center" not in skip and tuple(a.center) != tuple(b.center):
+    if "center" not in skip and a.center is not b.center and tuple(a.center) != tuple(b.center):
         return False
     if "shape" not in skip and a.shape is not b.shape and not np.array_equal(np.asarray(a.shape), np.asarray(b.shape)):
         return False
@@ -296,10 +298,13 @@ class MixtureProposal:
         return self.generators[i].propose(current)
 
     def logTransitionProbability(self, frm, to) -> float:
-        ts = [g.logTransitionProbability(frm, to) for g in self.generators]
-        if any(math.isnan(t) for t in ts):
-            raise ArithmeticError("NaN transition probability encountered!")
-        s = sum(f * math.exp(t) for f, t in zip(self.factors, ts))
+        s = 0.0
+        for f, g in zip(self.factors, self.generators):
+            t = g.logTransitionProbability(frm, to)
+            if t != t:
+                raise ArithmeticError("NaN transition probability encountered!")
+            if t != -math.inf:
+                s += f * math.exp(t)
         return math.log(s) if s > 0 else -math.inf
 
 
