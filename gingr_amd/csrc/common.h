@@ -174,6 +174,7 @@ struct NNGridDev {  // what the kernel needs, by value
     int32_t g[3];
     const int32_t *cell_start;  // [g0 g1 g2 + 1], x fastest
     const GridPoint *pts;       // [n]
+    int32_t brute_n;            // n when the cloud is small enough for uncertified queries to scan all of it in the kernel, else 0
 };
 struct NNGrid {  // owner
     NNGridDev v{};
@@ -190,7 +191,7 @@ struct NNGrid {  // owner
 };
 int nn_grid_build(gingr_ctx *ctx, const double *target_xyz, int64_t N, const int32_t *perm, int64_t max_queries, NNGrid *g);
 void nn_grid_free(NNGrid *g);
-void launch_nn_grid(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, NNGrid &g, const int32_t *warm,
+bool launch_nn_grid(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, NNGrid &g, const int32_t *warm,
                     int32_t *idx, double *d2);
 void launch_gauss_block(gingr_ctx *ctx, Cloud A, Cloud B, double sigma, double scaling, double *out);
 void launch_sumsq_pairs(gingr_ctx *ctx, Cloud A, Cloud B, double *ws, double *out_scalar);

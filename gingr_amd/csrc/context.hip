@@ -357,8 +357,8 @@ int gingr_nn(gingr_ctx *ctx, int64_t M, const double *query, int64_t N, const do
     HIP_TRY(ctx, didx.alloc(M * sizeof(int32_t)));
     HIP_TRY(ctx, dd2.alloc(M * sizeof(double)));
     if (grid.ready) {
-        launch_nn_grid(ctx, cq, ct, dperm.as<int32_t>(), grid, nullptr, didx.as<int32_t>(), dd2.as<double>());
-        launch_nn(ctx, cq, ct, dperm.as<int32_t>(), dboxes.as<double>(), dws.p, didx.as<int32_t>(), dd2.as<double>(), nullptr, grid.flag,
+        if (!launch_nn_grid(ctx, cq, ct, dperm.as<int32_t>(), grid, nullptr, didx.as<int32_t>(), dd2.as<double>()))
+            launch_nn(ctx, cq, ct, dperm.as<int32_t>(), dboxes.as<double>(), dws.p, didx.as<int32_t>(), dd2.as<double>(), nullptr, grid.flag,
                   grid.cur_nflag());
     } else if (ordered) {
         launch_nn(ctx, cq, ct, dperm.as<int32_t>(), dboxes.as<double>(), dws.p, didx.as<int32_t>(), dd2.as<double>());

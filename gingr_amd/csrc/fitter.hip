@@ -101,6 +101,11 @@ struct gingr_fitter {
     // fxbuf[live] / fxbuf[live ^ 1] go with the live / alt slot: [rp*rp] factor of S_tot + eps (I + G), [rp] posterior
     // coefficients, [rp] reciprocal diagonal -- what posterior_logpdf_lds_kernel leaves for posterior_logpdf_cached_kernel.
     double *alt_seg = nullptr;
+    // The two memo slots exchange ROLES, not contents: seg_swapped = the live [G, rhs, scalars] segment is alt_seg and the parked one
+    // sits in the exchange buffer.  Entry points that work on the exchange buffer itself (deterministic, sharded) move it back first.
+    bool seg_swapped = false;
+    double *seg1_live() const { return seg_swapped ? alt_seg : xch + off[1]; }
+    double *seg1_parked() const { return seg_swapped ? xch + off[1] : alt_seg; }
     Key alt_key;
     int alt_stage = 0;
     bool allow_alt = false, corr_stale = false;
@@ -526,7 +531,7 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
         (rc = dev_alloc(ctx, &f->evec, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->newshape, (size_t)3 * M)) ||
         (rc = dev_alloc(ctx, &f->state_block, (size_t)rp + kScalarsDoubles + kDevStateDoubles + 8)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
         (rc = dev_alloc(ctx, &f->fxbuf[0], (size_t)rp * rp + 2 * rp)) || (rc = dev_alloc(ctx, &f->fxbuf[1], (size_t)rp * rp + 2 * rp)) ||
-        (rc = dev_alloc(ctx, &f->alt_seg, (size_t)rp * rp + rp + 8)) || (rc = dev_alloc(ctx, &f->lp_sync, (size_t)2)) ||
+        (rc = dev_alloc(ctx, &f->alt_seg, (size_t)rp * rp + 2 * rp + 8)) || (rc = dev_alloc(ctx, &f->lp_sync, (size_t)2)) ||
         (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->zbuf, (size_t)PostVec::kZRows * rp)) || (rc = dev_alloc(ctx, &f->zrand, (size_t)rp)) ||
         (rc = dev_alloc(ctx, &f->pose, 1)) || (rc = dev_alloc(ctx, &f->fit_alt, (size_t)3 * M)) ||
         (rc = dev_alloc(ctx, &f->mh_save, (size_t)rp + kScalarsDoubles + kDevStateDoubles)) ||
@@ -656,6 +661,7 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
         o += round_up(f->cnt[s], 32);  // 256-byte aligned segments
     }
     GINGR_TRY(dev_alloc(ctx, &f->xch, (size_t)o));
+    f->seg_swapped = false;  // (the posterior memos were forgotten above: nothing lives in either slot)
     HIP_TRY(ctx, hipMemsetAsync(f->xch, 0, (size_t)o * sizeof(double), ctx->stream));
     int64_t w = cpd_colsum_ws_doubles(M, N);
     auto mx = [&](int64_t v) {
@@ -859,7 +865,7 @@ int gingr_fitter_get_cpd_stats(gingr_fitter *f, double *P1, double *PX, double *
         HIP_TRY(ctx, hipMemcpyAsync(den, tmpd.p, (size_t)f->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
     double sc[8];
-    const double *red = f->xch + f->off[1] + (int64_t)f->m->rp * f->m->rp + f->m->rp;
+    const double *red = f->seg1_live() + (int64_t)f->m->rp * f->m->rp + f->m->rp;
     HIP_TRY(ctx, hipMemcpyAsync(sc, red, sizeof(sc), hipMemcpyDeviceToHost, ctx->stream));
     double loc[8];
     HIP_TRY(ctx, hipMemcpyAsync(loc, f->scalars, sizeof(loc), hipMemcpyDeviceToHost, ctx->stream));
@@ -926,8 +932,8 @@ int gingr_fitter_exchange(gingr_fitter *f, void **dev_ptr, int64_t offsets[GINGR
 static void nearest_target_vertex(gingr_ctx *ctx, gingr_fitter *f, Cloud query, Cloud tgt, int32_t *idx, double *d2, bool warm) {
     const int32_t *w = warm ? idx : nullptr;
     if (ctx->nn_grid && f->tgrid.ready && ctx->cull && query.n <= f->tgrid.max_queries) {
-        launch_nn_grid(ctx, query, tgt, f->tperm, f->tgrid, w, idx, d2);
-        launch_nn(ctx, query, tgt, f->tperm, f->tboxes, f->ws, idx, d2, idx, f->tgrid.flag, f->tgrid.cur_nflag());
+        if (!launch_nn_grid(ctx, query, tgt, f->tperm, f->tgrid, w, idx, d2))  // (true: a small cloud, nothing left to scan)
+            launch_nn(ctx, query, tgt, f->tperm, f->tboxes, f->ws, idx, d2, idx, f->tgrid.flag, f->tgrid.cur_nflag());
     } else {
         launch_nn(ctx, query, tgt, f->tperm, f->tboxes, f->ws, idx, d2, w);
     }
@@ -958,15 +964,23 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
     const gingr_model *m = f->m;
     const int64_t M = m->M;
     const int32_t r = m->r, rp = m->rp;
+    if (f->seg_swapped && !f->allow_alt) {  // this entry point works on the exchange buffer itself: the live segment moves back
+        const int64_t seg = (int64_t)rp * rp + rp + 8;
+        hipLaunchKernelGGL(swap_segments_kernel, dim3((unsigned)ceil_div(seg, 256)), dim3(256), 0, ctx->stream, f->xch + f->off[1], f->alt_seg,
+                           seg, 0);
+        f->seg_swapped = false;
+        f->alt_stage = 0;  // (what was parked there is given up)
+        f->fx_valid[f->live ^ 1] = false;
+    }
     // reduced (summed over shards) segments, read by phases 1 and 2 ...
     double *seg0 = f->xch + f->off[0];
-    double *G = f->xch + f->off[1];
+    double *G = f->seg1_live();
     double *rhs = G + (int64_t)rp * rp;
     double *sc8 = rhs + rp;
     // ... and where this shard's partial sums are written by phases 0 and 1
     double *wbase = f->partial_out ? f->partial_out : f->xch;
     double *seg0w = wbase + f->off[0];
-    double *Gw = wbase + f->off[1];
+    double *Gw = f->partial_out ? wbase + f->off[1] : G;
     double *rhsw = Gw + (int64_t)rp * rp;
     double *sc8w = rhsw + rp;
     const Cloud fit = cloud_of(f->fit, M);
@@ -996,17 +1010,16 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 f->skip_phase1 = true;
                 return GINGR_OK;
             }
-            const int64_t seg = (int64_t)rp * rp + rp + 8;  // G, rhs, scalars: contiguous from off[1]
             if (f->allow_alt && !f->partial_out && f->alt_stage == 2 && f->alt_key.same(k)) {
-                // the other slot holds this state: exchange the two (or copy, when the live slot holds nothing finished)
+                // the other slot holds this state: the two slots exchange roles (no copy)
                 const bool both = f->post_stage == 2;
-                hipLaunchKernelGGL(swap_segments_kernel, dim3((unsigned)ceil_div(seg, 256)), dim3(256), 0, ctx->stream, Gw, f->alt_seg,
-                                   seg, both ? 1 : 0);
+                f->seg_swapped = !f->seg_swapped;
                 if (both) {
                     std::swap(f->post_key, f->alt_key);
-                } else {
+                } else {  // the live slot held nothing finished: nothing is parked now
                     f->post_key = f->alt_key;
-                    f->fx_valid[f->live] = false;  // becomes the alt slot's buffer: the alt segment stays, its factors move over
+                    f->alt_stage = 0;
+                    f->fx_valid[f->live] = false;
                 }
                 f->live ^= 1;
                 f->post_stage = 2;
@@ -1014,9 +1027,8 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 f->skip_phase1 = true;
                 return GINGR_OK;
             }
-            if (f->allow_alt && !f->partial_out && f->post_stage == 2) {  // keep what is about to be overwritten
-                hipLaunchKernelGGL(swap_segments_kernel, dim3((unsigned)ceil_div(seg, 256)), dim3(256), 0, ctx->stream, f->alt_seg, Gw, seg,
-                                   0);
+            if (f->allow_alt && !f->partial_out && f->post_stage == 2) {  // keep what is about to be overwritten: it becomes the parked slot
+                f->seg_swapped = !f->seg_swapped;
                 f->alt_key = f->post_key;
                 f->alt_stage = 2;
                 f->live ^= 1;  // its factors stay with it
@@ -1673,7 +1685,7 @@ static int posterior_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params
     GINGR_TRY(prc);
     if (f->lp_epoch == 0) HIP_TRY(ctx, hipMemsetAsync(f->lp_sync, 0, 2 * sizeof(unsigned), ctx->stream));  // before the first hand-over
     const bool cached = f->fx_valid[f->live];  // this state's factors are on the device: only the mesh-dependent part is left
-    double *G = f->xch + f->off[1];
+    double *G = f->seg1_live();
     double *rhs = G + (int64_t)rp * rp;
     // Q0^T e with e = R^T(mesh - c - t) - (ref - c) - mean in the pose of the state (copied on the device, no host round trip)
     double *out2 = f->small;
@@ -2060,11 +2072,11 @@ static int mh_logpdf_enqueue(gingr_fitter *f, const DevState *frame, const doubl
     gingr_ctx *ctx = f->ctx;
     const gingr_model *m = f->m;
     const int32_t r = m->r, rp = m->rp;
-    double *G = f->xch + f->off[1], *rhs = G + (int64_t)rp * rp;
+    double *G = f->seg1_live(), *rhs = G + (int64_t)rp * rp;
     if (f->lp_epoch == 0) HIP_TRY(ctx, hipMemsetAsync(f->lp_sync, 0, 2 * sizeof(unsigned), ctx->stream));
     const bool cached = f->fx_valid[f->live];
-    hipLaunchKernelGGL(pose_of_state_kernel, dim3(1), dim3(64), 0, ctx->stream, frame, f->pose);
     SweepArgs a = base_args(f);
+    a.frame = frame;
     a.shape_in = mesh_soa;
     a.out = f->alpha_c;
     launch_sweep(ctx, SWEEP_PROJ2, a);

@@ -168,6 +168,7 @@ struct SweepArgs {
     int64_t n_targets;
     const int32_t *lm_mask;
     double *weight_out, *evec_out;
+    const DevState *frame;  // SWEEP_PROJ2 (nullable): project in the rigid frame of this state instead of `pose`
 };
 
 int sweep_num_blocks(int64_t M);

@@ -118,10 +118,18 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepArgs a) {
         }
         scale = a.state->scale;
     } else if (MODE == SWEEP_PROJ2) {
-        for (int q = 0; q < 9; ++q) R[q] = a.pose->R[q];
-        for (int q = 0; q < 3; ++q) {
-            tr[q] = a.pose->t[q];
-            cen[q] = a.pose->center[q];
+        if (a.frame) {  // the rigid part of a device state directly (scale 1): no pose object has to be filled first
+            for (int q = 0; q < 9; ++q) R[q] = a.frame->R[q];
+            for (int q = 0; q < 3; ++q) {
+                tr[q] = a.frame->t[q];
+                cen[q] = a.frame->center[q];
+            }
+        } else {
+            for (int q = 0; q < 9; ++q) R[q] = a.pose->R[q];
+            for (int q = 0; q < 3; ++q) {
+                tr[q] = a.pose->t[q];
+                cen[q] = a.pose->center[q];
+            }
         }
     }
     double acc[KMAX];

@@ -24,6 +24,7 @@ constexpr int kMaxR = 3;  // largest half-width (in cells) of the block a query 
 // A row of cells that holds more targets than this (heaps of coincident points, a cloud that is one dense blob plus a far outlier) is
 // not scanned by its one lane: the query is flagged and the tile scan, which spreads the work over a workgroup, answers it.
 constexpr int kMaxRowTargets = 1024;
+constexpr int64_t kBruteTargets = 4096;  // target clouds up to this size: uncertified queries scan everything inside nn_grid_kernel
 
 __device__ __forceinline__ double grid_norm2_exact(double dx, double dy, double dz) {
     return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
@@ -182,6 +183,17 @@ __global__ __launch_bounds__(kGridBlock) void nn_grid_kernel(Cloud q, Cloud tgt,
         }
         combine();
     }
+    // Small target clouds: a query the grid could not certify looks at EVERY target right here (same distances, same tie rule as the
+    // masked tile scan), so no second launch has to follow (NNGridDev::brute_n; launch_nn_grid tells the caller).
+    if (g.brute_n > 0 && __any(flagged)) {
+        if (flagged) {
+            for (int32_t j = sub; j < g.brute_n; j += kLanes) test(g.pts[j]);
+            if (COUNT) ntests += (unsigned long long)((g.brute_n - sub + kLanes - 1) / kLanes);
+            crowded = false;
+        }
+        combine();
+        flagged = false;
+    }
     if (ok && sub == 0) {
         if (!flagged || bi >= 0) idx[i] = bi;  // a flagged query keeps a valid warm start for the masked full scan
         if (!flagged) d2out[i] = best;
@@ -284,6 +296,7 @@ int nn_grid_build(gingr_ctx *ctx, const double *target_xyz, int64_t N, const int
     g->v.inv_h = inv_h;
     g->v.cell_start = g->cell_start;
     g->v.pts = static_cast<const GridPoint *>(g->pts);
+    g->v.brute_n = N <= kBruteTargets ? (int32_t)N : 0;
     g->n = N;
     g->max_queries = max_queries;
     g->ready = true;
@@ -291,7 +304,8 @@ int nn_grid_build(gingr_ctx *ctx, const double *target_xyz, int64_t N, const int
 }
 
 // idx / d2 of every query the grid certifies; the others are flagged (g.flag, g.cur_nflag()) for the masked launch_nn that must follow
-void launch_nn_grid(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, NNGrid &g, const int32_t *warm, int32_t *idx,
+// -- unless the call returns true: the target cloud is small enough that the kernel answered them itself (nothing is flagged)
+bool launch_nn_grid(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, NNGrid &g, const int32_t *warm, int32_t *idx,
                     double *d2) {
     g.parity ^= 1;
     int32_t *cur = g.nflag + g.parity, *next = g.nflag + (g.parity ^ 1);
@@ -308,4 +322,5 @@ void launch_nn_grid(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *ta
         if (many) go(nn_grid_kernel<false, 8>, 8);
         else go(nn_grid_kernel<false, 16>, 16);
     }
+    return g.v.brute_n > 0;
 }

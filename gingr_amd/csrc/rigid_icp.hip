@@ -198,8 +198,8 @@ int gingr_rigid_icp_iterate(gingr_rigid_icp *h, int32_t n_iterations, double *di
     for (int32_t k = 0; k < n_iterations; ++k) {
         const int32_t *warm = h->warm ? h->idx.as<int32_t>() : nullptr;
         if (ctx->nn_grid && h->tgrid.ready && ctx->cull) {  // grid search, then the masked tile scan for what it flagged (fitter.hip, ICP)
-            launch_nn_grid(ctx, cp, ct, h->torig.as<int32_t>(), h->tgrid, warm, h->idx.as<int32_t>(), h->d2.as<double>());
-            launch_nn(ctx, cp, ct, h->torig.as<int32_t>(), h->tboxes.as<double>(), h->ws.p, h->idx.as<int32_t>(), h->d2.as<double>(),
+            if (!launch_nn_grid(ctx, cp, ct, h->torig.as<int32_t>(), h->tgrid, warm, h->idx.as<int32_t>(), h->d2.as<double>()))
+                launch_nn(ctx, cp, ct, h->torig.as<int32_t>(), h->tboxes.as<double>(), h->ws.p, h->idx.as<int32_t>(), h->d2.as<double>(),
                       h->idx.as<int32_t>(), h->tgrid.flag, h->tgrid.cur_nflag());
         } else {
             launch_nn(ctx, cp, ct, h->torig.as<int32_t>(), h->tboxes.as<double>(), h->ws.p, h->idx.as<int32_t>(), h->d2.as<double>(), warm);
