@@ -200,7 +200,7 @@ void launch_sumsq_pairs(gingr_ctx *ctx, Cloud A, Cloud B, double *ws, double *ou
 void launch_cell_normals(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *cn_soa);
 void launch_vertex_normals(gingr_ctx *ctx, const int32_t *adj_ptr, const int32_t *adj_tri, const double *cn_soa, int64_t T,
                            int64_t n, double *vn_soa);
-void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *boxes, double *tribox = nullptr);
+void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *boxes, double *tribox = nullptr, double *cell_normals = nullptr);
 // closest point of the triangle soup to every query (SoA out); exact ties: lowest tri_orig
 // mask / nmask (nullable, device): only queries with mask[i] != 0 are answered and the launch is a no-op when *nmask == 0 (what
 // launch_surface_cp_grid leaves behind: TriGrid::flag, TriGrid::cur_nflag())

@@ -113,6 +113,10 @@ struct gingr_fitter {
     unsigned *lp_sync = nullptr;  // hand-over words of posterior_logpdf_split_kernel
     unsigned lp_epoch = 0;
     bool fx_valid[2] = {false, false};
+    // nfac[slot]: [rp*rp] Cholesky factor of I + G, [16*rp] the transposed inverses of its diagonal blocks -- left by the two-workgroup log-density kernel for the
+    // sampled proposal that may start from this state (a + L^-T z without factoring again); a sits in fxbuf[slot] + rp*rp
+    double *nfac[2] = {nullptr, nullptr};
+    bool nf_valid[2] = {false, false};
     int live = 0;
     int32_t *surf_tri_pos = nullptr;  // per model vertex: position (in ttri) of its closest target triangle of the last scan
     bool surf_tri_warm = false;
@@ -123,6 +127,7 @@ struct gingr_fitter {
         post_stage = 0;
         alt_stage = 0;
         fx_valid[0] = fx_valid[1] = false;
+        nf_valid[0] = nf_valid[1] = false;
     }
     // Where phases 0 / 1 put THIS shard's partial sums (same segment layout as xch).  nullptr: into xch itself (single shard, or a
     // host that all-reduces xch in place -- torch.distributed).  The device group (group.hip) points it at the shard's send
@@ -531,6 +536,7 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
         (rc = dev_alloc(ctx, &f->evec, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->newshape, (size_t)3 * M)) ||
         (rc = dev_alloc(ctx, &f->state_block, (size_t)rp + kScalarsDoubles + kDevStateDoubles + 8)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
         (rc = dev_alloc(ctx, &f->fxbuf[0], (size_t)rp * rp + 2 * rp)) || (rc = dev_alloc(ctx, &f->fxbuf[1], (size_t)rp * rp + 2 * rp)) ||
+        (rc = dev_alloc(ctx, &f->nfac[0], (size_t)(rp + 16) * rp)) || (rc = dev_alloc(ctx, &f->nfac[1], (size_t)(rp + 16) * rp)) ||
         (rc = dev_alloc(ctx, &f->alt_seg, (size_t)rp * rp + 2 * rp + 8)) || (rc = dev_alloc(ctx, &f->lp_sync, (size_t)2)) ||
         (rc = dev_alloc(ctx, &f->alpha_c, (size_t)rp)) || (rc = dev_alloc(ctx, &f->zbuf, (size_t)PostVec::kZRows * rp)) || (rc = dev_alloc(ctx, &f->zrand, (size_t)rp)) ||
         (rc = dev_alloc(ctx, &f->pose, 1)) || (rc = dev_alloc(ctx, &f->fit_alt, (size_t)3 * M)) ||
@@ -601,6 +607,8 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->fxbuf[0]);
     dev_free(f->fxbuf[1]);
     dev_free(f->alt_seg);
+    dev_free(f->nfac[0]);
+    dev_free(f->nfac[1]);
     dev_free(f->lp_sync);
     dev_free(f->retry);
     dev_free(f->part);
@@ -970,7 +978,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                            seg, 0);
         f->seg_swapped = false;
         f->alt_stage = 0;  // (what was parked there is given up)
-        f->fx_valid[f->live ^ 1] = false;
+        f->fx_valid[f->live ^ 1] = f->nf_valid[f->live ^ 1] = false;
     }
     // reduced (summed over shards) segments, read by phases 1 and 2 ...
     double *seg0 = f->xch + f->off[0];
@@ -1019,7 +1027,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 } else {  // the live slot held nothing finished: nothing is parked now
                     f->post_key = f->alt_key;
                     f->alt_stage = 0;
-                    f->fx_valid[f->live] = false;
+                    f->fx_valid[f->live] = f->nf_valid[f->live] = false;
                 }
                 f->live ^= 1;
                 f->post_stage = 2;
@@ -1033,12 +1041,12 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 f->alt_stage = 2;
                 f->live ^= 1;  // its factors stay with it
             }
-            f->fx_valid[f->live] = false;
+            f->fx_valid[f->live] = f->nf_valid[f->live] = false;
             f->post_key = k;
             f->post_stage = 1;
         } else {
             f->post_stage = 0;
-            f->fx_valid[f->live] = false;
+            f->fx_valid[f->live] = f->nf_valid[f->live] = false;
         }
         f->corr_stale = false;  // phase 0 recomputes the correspondences of this state
     } else if (phase == 1) {
@@ -1082,9 +1090,8 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 }
             } else if (icp && f->icp_surface) {
                 // ClosestPointTriangleMesh3D.closestPointCorrespondence (ClosestPointRegistrator.scala:75-100)
-                launch_cell_normals(ctx, meshc, f->mtri, f->Tm, f->mcn);
+                launch_tri_tile_bbox(ctx, meshc, f->mtri, f->Tm, f->mtboxes, f->mtribox, f->mcn);  // boxes + cell normals of the template
                 launch_vertex_normals(ctx, f->madj_ptr, f->madj_tri, f->mcn, f->Tm, M, f->mvn);
-                launch_tri_tile_bbox(ctx, meshc, f->mtri, f->Tm, f->mtboxes, f->mtribox);
                 const bool along = f->surface_method == 1;  // ClosestPointAlongNormalTriangleMesh3D (:102-131)
                 if (along)
                     launch_line_nearest(ctx, fit, f->mvn, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, f->surf_cp, f->surf_hit);
@@ -1206,6 +1213,9 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
             const bool eig = icp && !f->icp_surface && !f->reversed && f->n_lm == 0 && !f->zrand_active && m->eig_ready;
             if (eig)
                 launch_posterior_solve_eig(ctx, r, rp, m->eigV, m->eigL, &f->st->sigma2, rhs, f->acoef, f->st);
+            else if (f->zrand_active && f->allow_alt && f->post_stage == 2 && f->nf_valid[f->live] && m->M == m->M_total && !f->partial_out)
+                // the log-density query that first met this state left the factor of I + G and the posterior coefficients behind
+                launch_posterior_sample_cached(ctx, r, rp, f->nfac[f->live], f->fxbuf[f->live] + (int64_t)rp * rp, f->zrand, f->acoef, f->st);
             else
                 launch_posterior_solve(ctx, r, rp, G, rhs, f->zrand_active ? f->zrand : nullptr, f->work, f->acoef, f->st);
             launch_post_matvecs(ctx, m, f->alpha, f->acoef, f->zbuf);
@@ -2080,8 +2090,10 @@ static int mh_logpdf_enqueue(gingr_fitter *f, const DevState *frame, const doubl
     a.shape_in = mesh_soa;
     a.out = f->alpha_c;
     launch_sweep(ctx, SWEEP_PROJ2, a);
+    const bool split = !cached && rp <= 112;  // (launch_posterior_logpdf's own choice: the two-workgroup form also leaves the factor of I + G)
     GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, rhs, m->mom + MomentLayout{rp}.stot(), f->alpha_c, f->fxbuf[f->live], cached, f->work, out2,
-                                      f->lp_sync, ++f->lp_epoch, keep_factor));
+                                      f->lp_sync, ++f->lp_epoch, keep_factor, f->nfac[f->live]));
+    if (split && f->post_stage == 2) f->nf_valid[f->live] = true;
     // (taken back after the synchronisation when the kernel reports a failure; ranks above 112 always leave the factor behind)
     if (f->post_stage == 2 && (keep_factor || rp > 112)) f->fx_valid[f->live] = true;
     return check_launch(ctx);
@@ -2204,7 +2216,7 @@ int gingr_fitter_mh_step(gingr_fitter *f, const gingr_mh_request *q, double *alp
     auto density = [&](const double *v, int slot, double *lp, int32_t *status) {
         *status = v[1] != 0.0 ? GINGR_ERR_NOT_SPD : (std::isfinite(v[0]) ? GINGR_OK : GINGR_ERR_NONFINITE);
         *lp = *status == GINGR_OK ? v[0] : -INFINITY;
-        if (*status != GINGR_OK) f->fx_valid[slot] = false;  // nothing usable was left behind for the cached form
+        if (*status != GINGR_OK) f->fx_valid[slot] = f->nf_valid[slot] = false;  // nothing usable was left behind for the cached forms
     };
     if (q->need_forward) {
         density(o, slot_fw, &res->log_q_forward, &res->forward_status);

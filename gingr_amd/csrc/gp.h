@@ -231,7 +231,11 @@ void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
 // write-back of the state-only part (fx then only carries the posterior coefficients between the two workgroups).
 int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *Stot,
                             const double *qte, double *fx, bool cached, double *work, double *out2, unsigned *sync = nullptr,
-                            unsigned epoch = 0, bool keep_factor = true);
+                            unsigned epoch = 0, bool keep_factor = true, double *nfac = nullptr);
+// a + L^-T z from what the two-workgroup log-density kernel left behind (nfac: [rp*rp] factor of I + G, [16*rp] W rows; a_mean:
+// the posterior coefficients): the sampled proposal of a state whose posterior has been factored already
+void launch_posterior_sample_cached(gingr_ctx *ctx, int32_t r, int32_t rp, const double *nfac, const double *a_mean, const double *zrand,
+                                    double *a, DevState *st);
 // a = (I + S_tot / sigma2)^-1 rhs through the one-off eigen-decomposition S_tot = V diag(lam) V^T: a = V ((V^T rhs) / (1 + lam / sigma2)).
 // The posterior of point-cloud ICP without landmarks -- every row weighs 1 / sigma2 (ICP.scala:90-92) -- needs no factorisation.
 void launch_posterior_solve_eig(gingr_ctx *ctx, int32_t r, int32_t rp, const double *eigV, const double *eigL, const double *sigma2,

@@ -1689,7 +1689,8 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_split_kernel(i
                                                                      const double *__restrict__ rhs,
                                                                      const double *__restrict__ Stot,
                                                                      const double *__restrict__ qte, double *__restrict__ fx,
-                                                                     double *__restrict__ out2, unsigned *sync, unsigned epoch, int keep) {
+                                                                     double *__restrict__ out2, unsigned *sync, unsigned epoch, int keep,
+                                                                     double *__restrict__ nfac) {
     extern __shared__ double sm[];
     const int n = rp, ld = solve_ld(n);
     double *A = sm;
@@ -1702,11 +1703,25 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_split_kernel(i
     const int tid = threadIdx.x;
     if (tid == 0) bad_spd = 0;
     if (blockIdx.x == 0) {
-        for (int k = tid; k < kNB * ld; k += kSolveThreads) u[k] = k < r ? rhs[k] : 0.0;
+        // exactly the arithmetic of posterior_solve_lds_kernel<0> (identity rows through the panel solves, W-form backward substitution):
+        // the coefficients a -- and the factor a later sampled proposal a + L^-T z is formed from -- carry the bits the solve kernel
+        // would produce for this state
+        double *y = u, *W = u + kNB * ld, *x = sm + (size_t)(n + 2 * kNB) * ld;
+        for (int k = tid; k < kNB * ld; k += kSolveThreads) {
+            y[k] = k < r ? rhs[k] : 0.0;
+            const int c = k / ld, j = k - c * ld;
+            W[k] = (j < n && (j & 15) == c) ? 1.0 : 0.0;
+        }
         lds_load_spd<kSolveThreads>(A, ld, r, n, G, 1.0, nullptr, 0.0, 1.0);
-        lds_cholesky<kSolveThreads>(A, ld, n, rd, &bad_spd, kNB);  // u <- L^-1 rhs on the way
-        lds_backward<kSolveThreads>(A, ld, n, rd, u);
-        for (int k = tid; k < rp; k += kSolveThreads) fx[(int64_t)rp * rp + k] = k < r ? u[k] : 0.0;
+        lds_cholesky<kSolveThreads>(A, ld, n, x, &bad_spd, kNB, kNB);  // y <- L^-1 rhs, W <- the transposed inverses of the diagonal blocks
+        if (nfac) {  // the factor for posterior_sample_cached_kernel: L, then the 16 W rows
+            for (int i = tid >> 6; i < n + kNB; i += kSolveThreads / 64) {
+                const double *src = i < n ? A + i * ld : W + (i - n) * ld;
+                for (int j = tid & 63; j < n; j += 64) nfac[(int64_t)i * rp + j] = src[j];
+            }
+        }
+        lds_backward_w<kSolveThreads>(A, ld, n, W, y, x);
+        for (int k = tid; k < rp; k += kSolveThreads) fx[(int64_t)rp * rp + k] = k < r ? x[k] : 0.0;
         __syncthreads();
         if (tid == 0) {
             sync[1] = (unsigned)bad_spd;
@@ -1762,6 +1777,37 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_split_kernel(i
         out2[1] = bad_spd ? 1.0 : 0.0;
     }
     (void)av;
+}
+
+// The sampled proposal a + L^-T z of a state whose I + G the two-workgroup log-density kernel has factored already (nfac: [rp*rp] L,
+// [16*rp] the W rows; a_mean): one load and one W-form backward substitution instead of the factorisation (32 -> ~12 us at r = 100),
+// with the bits posterior_solve_lds_kernel<0> gives (same routines on the same factor, same order of the final addition).
+__global__ __launch_bounds__(kSolveThreads) void posterior_sample_cached_kernel(int r, int rp, const double *__restrict__ nfac,
+                                                                      const double *__restrict__ a_mean,
+                                                                      const double *__restrict__ zrand, double *__restrict__ a,
+                                                                      DevState *__restrict__ st) {
+    extern __shared__ double sm[];
+    const int n = rp, ld = solve_ld(n);
+    double *A = sm;
+    double *W = sm + (size_t)n * ld;
+    double *y2 = sm + (size_t)(n + kNB) * ld;
+    double *x = y2 + n;
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    for (int i = tid >> 6; i < n + kNB; i += kSolveThreads / 64)  // (rows n .. n+15 of the copy are the W rows: same stride)
+        for (int j = tid & 63; j < n; j += 64) A[i * ld + j] = nfac[(int64_t)i * rp + j];
+    for (int k = tid; k < n; k += kSolveThreads) y2[k] = k < r ? zrand[k] : 0.0;
+    __syncthreads();
+    lds_backward_w<kSolveThreads>(A, ld, n, W, y2, x);
+    __syncthreads();
+    for (int k = tid; k < rp; k += kSolveThreads) {
+        const double v = k < r ? a_mean[k] + x[k] : 0.0;
+        a[k] = v;
+        if (!finite_d(v)) bad = 1;
+    }
+    __syncthreads();
+    if (tid == 0 && bad) st->err = GINGR_ERR_NONFINITE;
 }
 
 // The same log-density for a state whose posterior_logpdf_lds_kernel has run before (fx: its posterior coefficients and the factor
@@ -2448,17 +2494,18 @@ void launch_posterior_solve_eig(gingr_ctx *ctx, int32_t r, int32_t rp, const dou
 
 int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *Stot,
                             const double *qte, double *fx, bool cached, double *work, double *out2, unsigned *sync, unsigned epoch,
-                            bool keep_factor) {
+                            bool keep_factor, double *nfac) {
     const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
     // the log-density kernels keep 14 KB of static LDS (mat-vec scratch) next to the bordered matrix: with rp = 128 the two exceed the
     // 160 KB of a compute unit, so ranks above 112 take the global-workspace variants (the plain solve fits up to rp = 128)
     const bool in_lds = rp <= 112;
     if (!cached && in_lds && fx && sync) {  // the two factorisations side by side
-        if (lds > 48 * 1024)  // per function and per device: set whenever needed
+        const size_t lds2 = lds_solve_doubles(rp, 2 * kNB) * sizeof(double);  // (workgroup 0 carries the identity rows of the solve kernel)
+        if (lds2 > 48 * 1024)  // per function and per device: set whenever needed
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds);
-        hipLaunchKernelGGL(posterior_logpdf_split_kernel, dim3(2), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte, fx,
-                           out2, sync, epoch, keep_factor ? 1 : 0);
+                                      (int)lds2);
+        hipLaunchKernelGGL(posterior_logpdf_split_kernel, dim3(2), dim3(kSolveThreads), lds2, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte, fx,
+                           out2, sync, epoch, keep_factor ? 1 : 0, nfac);
         return GINGR_OK;
     }
     if (cached) {  // fx holds what an earlier launch for this state left
@@ -2485,6 +2532,15 @@ int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
                            out2, work);
     }
     return GINGR_OK;
+}
+
+void launch_posterior_sample_cached(gingr_ctx *ctx, int32_t r, int32_t rp, const double *nfac, const double *a_mean, const double *zrand,
+                                    double *a, DevState *st) {
+    const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_sample_cached_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    hipLaunchKernelGGL(posterior_sample_cached_kernel, dim3(1), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, nfac, a_mean, zrand, a, st);
 }
 
 void launch_binv(gingr_ctx *ctx, int32_t r, int32_t rp, const double *S, double *work, double *Binv, int32_t *err_flag) {

@@ -109,21 +109,34 @@ __global__ __launch_bounds__(256) void vertex_normals_kernel(const int32_t *__re
 
 // boxes[tile] = {lo[3], hi[3]} over the corners of the triangles [tile*256, tile*256+256), followed (at boxes + 6 * ntiles) by the
 // boxes of its four 64-triangle quarters [tile*4 + q] (the triangle order is a k-d order down to 64-triangle leaves)
+// cn (nullable, SoA [3][T]): the unit cell normals as cell_normals_kernel writes them (same expressions), from the corners this kernel
+// reads anyway -- one launch less per surface correspondence.
 __global__ __launch_bounds__(256) void tri_tile_bbox_kernel(Cloud v, const int32_t *__restrict__ tri, int64_t T,
-                                                            double *__restrict__ boxes, double *__restrict__ tribox) {
+                                                            double *__restrict__ boxes, double *__restrict__ tribox,
+                                                            double *__restrict__ cn) {
     __shared__ double sh[6][256];
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double lo[3] = {__builtin_huge_val(), __builtin_huge_val(), __builtin_huge_val()};
     double hi[3] = {-__builtin_huge_val(), -__builtin_huge_val(), -__builtin_huge_val()};
-    if (t < T)
+    if (t < T) {
+        V3 P[3];
         for (int c = 0; c < 3; ++c) {
             const int32_t a = tri[3 * t + c];
             const double p[3] = {v.x[a], v.y[a], v.z[a]};
+            P[c] = V3{p[0], p[1], p[2]};
             for (int d = 0; d < 3; ++d) {
                 lo[d] = fmin(lo[d], p[d]);
                 hi[d] = fmax(hi[d], p[d]);
             }
         }
+        if (cn) {
+            const V3 n = cross3(sub(P[1], P[0]), sub(P[2], P[0]));
+            const double len = sqrt((n.x * n.x + n.y * n.y) + n.z * n.z);
+            cn[t] = n.x / len;
+            cn[T + t] = n.y / len;
+            cn[2 * T + t] = n.z / len;
+        }
+    }
     if (tribox && t < T) {  // per-triangle boxes: the scan kernels stage these (one 48-byte read) instead of rebuilding them from
         double *tb = tribox + 6 * t;  // three index loads and nine gathered coordinates per visited triangle and workgroup
         tb[0] = lo[0], tb[1] = lo[1], tb[2] = lo[2], tb[3] = hi[0], tb[4] = hi[1], tb[5] = hi[2];
@@ -952,9 +965,10 @@ void launch_vertex_normals(gingr_ctx *ctx, const int32_t *adj_ptr, const int32_t
     hipLaunchKernelGGL(vertex_normals_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, adj_ptr, adj_tri, cn,
                        T, n, vn);
 }
-void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *boxes, double *tribox) {
+void launch_tri_tile_bbox(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *boxes, double *tribox, double *cell_normals) {
     if (T <= 0) return;
-    hipLaunchKernelGGL(tri_tile_bbox_kernel, dim3((unsigned)ceil_div(T, kTriTile)), dim3(256), 0, ctx->stream, v, tri, T, boxes, tribox);
+    hipLaunchKernelGGL(tri_tile_bbox_kernel, dim3((unsigned)ceil_div(T, kTriTile)), dim3(256), 0, ctx->stream, v, tri, T, boxes, tribox,
+                       cell_normals);
 }
 // copies of every query held per workgroup (see surface_cp_queue_kernel), from the number of queries
 static int surface_h(int64_t nq) {
