@@ -525,6 +525,43 @@ JFN(jint, fitterPosteriorLogpdfRccl)(JNIEnv *env, jclass, jlong f, jint flavour,
     if (o.buf.empty()) return GINGR_ERR_BAD_ARGUMENT;
     return gingr_fitter_posterior_logpdf_rccl(P<gingr_fitter>(f), flavour, &cp, &ip, m.ptr(), o.ptr());
 }
+// ---- one Metropolis-Hastings step per call (gingr_fitter_mh_step): flavour as above; kind 0 = informed proposal with the r draws z,
+// kind 1 = the parameters a random-walk proposal chose (alpha, pose11 = euler, center, translation, scale, sigma2; iteration / status).
+// alphaOut[r], fitOut[3 M] (nullable), poseOut[11], intOut = {iteration, status, forward status, backward status},
+// dblOut = {log value, dist sum, dist max, count, log q forward, log q backward}
+JFN(jint, fitterMhStep)(JNIEnv *env, jclass, jlong f, jint flavour, jint kind, jdouble w, jdouble lambda, jdouble initialSigma, jdouble endSigma,
+                        jint maxIterations, jdoubleArray z, jdoubleArray alpha, jdoubleArray pose11, jint iteration, jint status,
+                        jdouble evalSdev, jlong evalPoints, jboolean needForward, jdoubleArray alphaOut, jdoubleArray fitOut,
+                        jdoubleArray poseOut, jintArray intOut, jdoubleArray dblOut) {
+    const gingr_cpd_params cp{w, lambda};
+    const gingr_icp_params ip{initialSigma, endSigma, maxIterations};
+    Arr<double> zz(env, z, true), aa(env, alpha, true), pp(env, pose11, true);
+    Arr<double> ao(env, alphaOut, false), fo(env, fitOut, false), po(env, poseOut, false), d(env, dblOut, false);
+    Arr<int32_t> io(env, intOut, false);
+    if (ao.buf.empty() || po.buf.size() < 11 || io.buf.size() < 4 || d.buf.size() < 6 || (kind == 1 && pp.buf.size() < 11))
+        return GINGR_ERR_BAD_ARGUMENT;
+    gingr_state_scalars s{};
+    if (kind == 1) {
+        const double *p = pp.ptr();
+        for (int q = 0; q < 3; ++q) s.euler[q] = p[q], s.center[q] = p[3 + q], s.translation[q] = p[6 + q];
+        s.scale = p[9], s.sigma2 = p[10], s.iteration = iteration, s.status = status;
+    }
+    gingr_mh_request req{};
+    req.flavour = flavour, req.kind = kind, req.cpd = &cp, req.icp = &ip, req.z = zz.ptr(), req.alpha = aa.ptr();
+    req.scalars = kind == 1 ? &s : nullptr;
+    req.eval_sdev = evalSdev, req.eval_points = evalPoints, req.need_forward = needForward ? 1 : 0;
+    gingr_mh_result res{};
+    const int rc = gingr_fitter_mh_step(P<gingr_fitter>(f), &req, ao.ptr(), fo.ptr(), &res);
+    if (rc != GINGR_OK) return rc;
+    double *p = po.ptr();
+    for (int q = 0; q < 3; ++q) p[q] = res.scalars.euler[q], p[3 + q] = res.scalars.center[q], p[6 + q] = res.scalars.translation[q];
+    p[9] = res.scalars.scale, p[10] = res.scalars.sigma2;
+    io.ptr()[0] = res.scalars.iteration, io.ptr()[1] = res.scalars.status, io.ptr()[2] = res.forward_status, io.ptr()[3] = res.backward_status;
+    d.ptr()[0] = res.log_value, d.ptr()[1] = res.dist_sum, d.ptr()[2] = res.dist_max, d.ptr()[3] = (double)res.count;
+    d.ptr()[4] = res.log_q_forward, d.ptr()[5] = res.log_q_backward;
+    return rc;
+}
+JFN(jint, fitterMhRestore)(JNIEnv *, jclass, jlong f) { return gingr_fitter_mh_restore(P<gingr_fitter>(f)); }
 #else
 // No JDK headers on this machine: the shim is not built (the C ABI it wraps is still covered by the Python tests).
 #endif

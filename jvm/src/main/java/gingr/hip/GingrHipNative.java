@@ -166,4 +166,15 @@ public final class GingrHipNative {
                                               int maxIterations, int nIterations, double[] z);
     public static native int fitterPosteriorLogpdfRccl(long fitter, int flavour, double w, double lambda, double initialSigma,
                                                        double endSigma, int maxIterations, double[] meshXyzFull, double[] out1);
+
+    // ---- one Metropolis-Hastings step per call (gingr_fitter_mh_step, include/gingr_hip.h): proposal (kind 0: update(x, probabilistic =
+    // true) with the draws z; kind 1: the parameters of a random-walk proposal), model-to-target likelihood of the proposal and the
+    // transition densities of the informed proposal, one synchronisation.  intOut = {iteration, status, forward status, backward status},
+    // dblOut = {log value, distance sum, distance max, count, log q(x'|x) (NaN unless needForward), log q(x|x')}.
+    // fitterMhRestore: the proposal was rejected, the state the step started from is the device state again.
+    public static native int fitterMhStep(long fitter, int flavour, int kind, double w, double lambda, double initialSigma, double endSigma,
+                                          int maxIterations, double[] z, double[] alpha, double[] poseScalars11, int iteration, int status,
+                                          double evalSdev, long evalPoints, boolean needForward, double[] alphaOut, double[] fitOut,
+                                          double[] poseOut11, int[] intOut4, double[] dblOut6);
+    public static native int fitterMhRestore(long fitter);
 }

@@ -222,19 +222,27 @@ def config4():
 
 
 def config5():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_mh_chain.py"), "300", "0"], capture_output=True, text=True,
-                         timeout=1800, cwd=ROOT)
-    if out.returncode != 0:
-        raise RuntimeError(out.stderr[-2000:])
-    c = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    def chain(*extra):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_mh_chain.py"), "300", "0", *extra], capture_output=True,
+                             text=True, timeout=1800, cwd=ROOT)
+        if out.returncode != 0:
+            raise RuntimeError(out.stderr[-2000:])
+        return json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    c = chain()                 # one native call per step (gingr_fitter_mh_step), the default of GingrAlgorithm.run
+    slow = chain("nofuse")      # the call-by-call path of rounds 1-3: same draws, same decisions
     return {"config": 5, "metric": "MH-in-GiNGR chain steps/sec, femur (one chain)", "value": c["steps_per_s"], "unit": "steps/s", "n_gpus": 1,
             "steps": c["steps"], "ms_per_step": c["ms_per_step"], "higher_is_better": True, "dtype": "f64",
             "data": "reference demo data (femur STL pair)",
             "config_detail": {"workload": "Metropolis-Hastings chain, surface-ICP proposals (posterior sample) + random walks, DemoICP settings; "
-                                          "8 chains = 8 independent replicas, one context per GPU, no communication"},
+                                          "one native call per step (proposal, likelihood, transition density; round 4); "
+                                          "8 chains = 8 independent replicas, one context per GPU, no communication",
+                              "call_by_call_steps_per_s": slow["steps_per_s"],
+                              "same_best_sample_as_call_by_call": bool(slow["log_value_best"] == c["log_value_best"])},
             # the chain ends with MaxIteration (2) or Converged (1); 3 = ModelFlexibilityError
-            "valid": bool(c["status"] != 3 and c["log_value_best"] >= c["log_value_initial"]),
-            "parity_check": {"against": "tests/test_gpu_sampling.py: a 25-step chain reproduces the oracle's accept / reject sequence",
+            "valid": bool(c["status"] != 3 and c["log_value_best"] >= c["log_value_initial"]
+                          and slow["log_value_best"] == c["log_value_best"]),
+            "parity_check": {"against": "tests/test_gpu_sampling.py: a 25-step chain reproduces the oracle's accept / reject sequence; "
+                                        "tests/test_gpu_mh_step.py: fused steps = call-by-call steps (decisions, states <= 1e-9)",
                              "log_value_initial": c["log_value_initial"], "log_value_best": c["log_value_best"]},
             "roofline": None, "cpu_baseline": None, "detail": c}
 
