@@ -1210,6 +1210,86 @@ __global__ void nn_reduce_kernel(const double *__restrict__ pd2, const int32_t *
     d2[i] = best;
 }
 
+// ---- small problems (the stateless gingr_nn of a few thousand points each; BASELINE config 2): all pairs, no boxes, no tiles.
+// Pass 1: a workgroup = 512 queries (two per lane) x one slice of the targets in the CALLER's order; the whole slice goes to LDS with
+// every load in flight at once, then every lane walks it with wave-uniform (broadcast) LDS reads.  Per pair the separately rounded
+// expression of norm2_exact (3 subtractions, 3 products, 2 sums) and ONE minimum -- 9 instructions; which target it was is not
+// tracked (a compare, a select and a move per pair for an answer 1 / nslices of the slices contribute to).
+// Pass 2: sixteen lanes per query pick the first slice that holds the overall minimum (ascending slices, strict <) and search THAT
+// slice again for the first target at exactly this distance (same expression, same bits): the lowest index on ties, as the full scan.
+// A NaN distance never wins (v_min returns the other operand); a query with no finite distance keeps index -1, distance +inf.
+__global__ __launch_bounds__(256) void nn_small_kernel(Cloud q, const double *__restrict__ tx, const double *__restrict__ ty,
+                                                       const double *__restrict__ tz, int32_t n_targets, int32_t slice_len,
+                                                       double *__restrict__ pd2) {
+    extern __shared__ double sh[];  // [3][slice_len]
+    const int tid = threadIdx.x;
+    const int32_t j0 = (int32_t)blockIdx.y * slice_len, n = min(slice_len, n_targets - j0);
+    double *sx = sh, *sy = sh + slice_len, *sz = sh + 2 * slice_len;
+    for (int32_t k = tid; k < n; k += 256) sx[k] = tx[j0 + k], sy[k] = ty[j0 + k], sz[k] = tz[j0 + k];
+    const int64_t ia = (int64_t)blockIdx.x * 512 + tid, ib = ia + 256;
+    const bool oka = ia < q.n, okb = ib < q.n;
+    const double ax = oka ? q.x[ia] : 0.0, ay = oka ? q.y[ia] : 0.0, az = oka ? q.z[ia] : 0.0;
+    const double bx = okb ? q.x[ib] : 0.0, by = okb ? q.y[ib] : 0.0, bz = okb ? q.z[ib] : 0.0;
+    __syncthreads();
+    double besta = __builtin_huge_val(), bestb = __builtin_huge_val();
+    int32_t j = 0;
+    for (; j + 4 <= n; j += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double x = sx[j + k], y = sy[j + k], z = sz[j + k];
+            besta = fmin(besta, norm2_exact(x - ax, y - ay, z - az));
+            bestb = fmin(bestb, norm2_exact(x - bx, y - by, z - bz));
+        }
+    }
+    for (; j < n; ++j) {
+        const double x = sx[j], y = sy[j], z = sz[j];
+        besta = fmin(besta, norm2_exact(x - ax, y - ay, z - az));
+        bestb = fmin(bestb, norm2_exact(x - bx, y - by, z - bz));
+    }
+    if (oka) pd2[(int64_t)blockIdx.y * q.n + ia] = besta;
+    if (okb) pd2[(int64_t)blockIdx.y * q.n + ib] = bestb;
+}
+
+__global__ void nn_small_count_kernel(unsigned long long *tests, unsigned long long n) { *tests += n; }
+
+__global__ __launch_bounds__(256) void nn_small_reduce_kernel(Cloud q, const double *__restrict__ tx, const double *__restrict__ ty,
+                                                              const double *__restrict__ tz, int32_t n_targets, int32_t slice_len,
+                                                              const double *__restrict__ pd2, int nslices, int32_t *__restrict__ idx,
+                                                              double *__restrict__ d2) {
+    const int l = threadIdx.x & 15;
+    const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4), M = q.n;
+    const bool ok = i < M;
+    double best = __builtin_huge_val();
+    int32_t bs = INT32_MAX;  // the first slice that holds `best`
+    if (ok)
+        for (int c = l; c < nslices; c += 16) {
+            const double v = pd2[(int64_t)c * M + i];
+            if (v < best) best = v, bs = c;
+        }
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+        const double v = __shfl_xor(best, off);
+        const int32_t o = __shfl_xor(bs, off);
+        if (v < best || (v == best && o < bs)) best = v, bs = o;
+    }
+    int32_t bi = INT32_MAX;
+    if (ok && bs != INT32_MAX) {  // (best < +inf) the first target of slice bs at exactly this distance
+        const double qx = q.x[i], qy = q.y[i], qz = q.z[i];
+        const int32_t j0 = bs * slice_len, j1 = min(j0 + slice_len, n_targets);
+        for (int32_t j = j0 + l; j < j1; j += 16)
+            if (norm2_exact(tx[j] - qx, ty[j] - qy, tz[j] - qz) == best) {
+                bi = j;
+                break;
+            }
+    }
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) bi = min(bi, __shfl_xor(bi, off));
+    if (ok && l == 0) {
+        idx[i] = bi == INT32_MAX ? -1 : bi;
+        d2[i] = best;
+    }
+}
+
 // ---------------------------------------------------------------- Gaussian kernel block
 __global__ __launch_bounds__(kBlock) void gauss_block_kernel(Cloud A, Cloud B, double sigma, double scaling,
                                                              double *__restrict__ out) {
@@ -1596,6 +1676,34 @@ void launch_nn(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_
     if (direct) return;
     hipLaunchKernelGGL(nn_reduce_kernel, dim3((unsigned)ceil_div(query.n, 256)), dim3(256), 0, ctx->stream, pd2, pidx, porig,
                        nch, query.n, idx, d2, mask);
+}
+
+// all pairs of two small clouds in the caller's order (see nn_small_kernel); ws: nn_small_ws_bytes(M, N)
+static int nn_small_slices(int64_t M, int64_t N) {
+    const int64_t groups = ceil_div(M, 512);
+#ifndef GINGR_NN_SMALL_WGS
+#define GINGR_NN_SMALL_WGS 768
+#endif
+    int64_t s = GINGR_NN_SMALL_WGS / (groups > 0 ? groups : 1);  // at most three workgroups (12 waves) per compute unit: no fourth round
+    const int64_t max_s = ceil_div(N, 32);               // at least 32 targets per slice
+    if (s > max_s) s = max_s;
+    return (int)(s < 1 ? 1 : s);
+}
+bool nn_small_applies(int64_t M, int64_t N) { return M >= 1 && N >= 1 && N <= INT32_MAX / 2 && M * N <= (int64_t)1 << 26; }
+int64_t nn_small_ws_bytes(int64_t M, int64_t N) { return (int64_t)nn_small_slices(M, N) * M * sizeof(double); }
+void launch_nn_small(gingr_ctx *ctx, Cloud query, Cloud target, void *ws, int32_t *idx, double *d2) {
+    const int ns = nn_small_slices(query.n, target.n);
+    const int32_t len = (int32_t)ceil_div(target.n, ns);
+    const int nslices = (int)ceil_div(target.n, len);
+    double *pd2 = reinterpret_cast<double *>(ws);
+    TimerScope ts(ctx, 8);  // (both launches: the slices mean nothing before they are combined)
+    hipLaunchKernelGGL(nn_small_kernel, dim3((unsigned)ceil_div(query.n, 512), (unsigned)nslices), dim3(256), (size_t)3 * len * sizeof(double),
+                       ctx->stream, query, target.x, target.y, target.z, (int32_t)target.n, len, pd2);
+    hipLaunchKernelGGL(nn_small_reduce_kernel, dim3((unsigned)ceil_div(query.n, 16)), dim3(256), 0, ctx->stream, query, target.x, target.y,
+                       target.z, (int32_t)target.n, len, pd2, nslices, idx, d2);
+    if (ctx->nn_tests)  // diagnostics (gingr_ctx_nn_counting): every lane of every wave tests every target
+        hipLaunchKernelGGL(nn_small_count_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->nn_tests,
+                           (unsigned long long)round_up(query.n, 64) * (unsigned long long)target.n);
 }
 
 void launch_gauss_block(gingr_ctx *ctx, Cloud A, Cloud B, double sigma, double scaling, double *out) {

@@ -113,6 +113,11 @@ struct Cloud {
 int64_t cpd_colsum_ws_doubles(int64_t M, int64_t N);
 int64_t cpd_rowstats_ws_doubles(int64_t M, int64_t N);
 int64_t nn_ws_bytes(int64_t M, int64_t N);
+// all pairs of two small clouds, both in the caller's order: one launch of ~4 000 single-wave workgroups + the combination of their
+// slices (affinity.hip: nn_small_kernel); the stateless gingr_nn uses it where it applies
+bool nn_small_applies(int64_t M, int64_t N);
+int64_t nn_small_ws_bytes(int64_t M, int64_t N);
+void launch_nn_small(gingr_ctx *ctx, Cloud query, Cloud target, void *ws, int32_t *idx, double *d2);
 
 // den_partial[N] = sum_{i in fit} exp(-|x_j - y_i|^2 / (2 sigma2))   (no outlier constant)
 // aux (GINGR_AUX doubles on the device): [2..4] centroid of the target cloud (launch_cloud_centroid); [0] / [1] largest

@@ -318,7 +318,11 @@ int gingr_nn(gingr_ctx *ctx, int64_t M, const double *query, int64_t N, const do
     // cold start it is slower than the pruned scan (64 us at 5 000 x 5 000), so the stateless call does not use it unless the option
     // is set to 2.  Same distances, same lowest-original-index tie rule in every variant: the indices are bit-identical
     // (tests/test_gpu_nn_grid.py compares them; GINGR_OPT_CULL = 0 is the plain scan of all pairs).
-    const bool ordered = ctx->cull && N >= 2048 && M >= 256;
+    // Up to 2^26 pairs (8 000 x 8 000) nothing of that pays: nn_small_kernel tests all pairs straight from the caller's order with
+    // wave-uniform target loads in ~4 000 single-wave workgroups (5 000 x 5 000: ~10 us for both of its launches against 30 us for
+    // either scan).  GINGR_OPT_NN_GRID = 2 and GINGR_OPT_CULL = 0 still select the other variants (timing comparisons, tests).
+    const bool small = ctx->cull && ctx->nn_grid != 2 && nn_small_applies(M, N);
+    const bool ordered = !small && ctx->cull && N >= 2048 && M >= 256;
     const bool use_grid = ordered && ctx->nn_grid == 2;
     std::vector<int32_t> perm, qperm;
     NNGrid grid;
@@ -353,10 +357,12 @@ int gingr_nn(gingr_ctx *ctx, int64_t M, const double *query, int64_t N, const do
         GINGR_TRY(upload_cloud(ctx, M, query, sq, dq, &cq));
         GINGR_TRY(upload_cloud(ctx, N, target, st, dt, &ct));
     }
-    HIP_TRY(ctx, dws.alloc((size_t)nn_ws_bytes(M, N)));
+    HIP_TRY(ctx, dws.alloc((size_t)(small ? nn_small_ws_bytes(M, N) : nn_ws_bytes(M, N))));
     HIP_TRY(ctx, didx.alloc(M * sizeof(int32_t)));
     HIP_TRY(ctx, dd2.alloc(M * sizeof(double)));
-    if (grid.ready) {
+    if (small) {
+        launch_nn_small(ctx, cq, ct, dws.p, didx.as<int32_t>(), dd2.as<double>());
+    } else if (grid.ready) {
         if (!launch_nn_grid(ctx, cq, ct, dperm.as<int32_t>(), grid, nullptr, didx.as<int32_t>(), dd2.as<double>()))
             launch_nn(ctx, cq, ct, dperm.as<int32_t>(), dboxes.as<double>(), dws.p, didx.as<int32_t>(), dd2.as<double>(), nullptr, grid.flag,
                   grid.cur_nflag());
