@@ -49,4 +49,18 @@ json.dump({
     "late_regime_sigma2_4_50k": load("bench_sigma2_4.json")["ms_per_step"],
     "device_group_two_logical_shards_50k": load("bench_group_logical2.json")["ms_per_step"],
 }, open(os.path.join(P, f"r{rnd}_configs_3_4_and_variants.json"), "w"), indent=1)
+for src, dst in (("emu8_kernel_stats.csv", f"r{rnd}_emulated_8gpu_shard_kernel_stats.csv"), ("emu8_kernels.txt", f"r{rnd}_emulated_8gpu_shard_kernel_stats.txt"),
+                 ("chain_kernel_stats.csv", f"r{rnd}_mh_chain_femur_kernel_stats.csv"), ("icp50k.json", f"r{rnd}_icp_pointcloud_50k.json"),
+                 ("icp_surface.json", f"r{rnd}_icp_surface_41k.json")):
+    if os.path.exists(os.path.join(F, src)) and os.path.getsize(os.path.join(F, src)) > 0:
+        shutil.copy(os.path.join(F, src), os.path.join(P, dst))
+if os.path.exists(os.path.join(F, "chain_1.json")):
+    runs = [load(f"chain_{i}.json") for i in range(1, 6) if os.path.exists(os.path.join(F, f"chain_{i}.json"))]
+    best = sorted(runs, key=lambda c: c["steps_per_s"])[len(runs) // 2]     # the median run
+    best["runs_steps_per_s"] = sorted(c["steps_per_s"] for c in runs)
+    if os.path.exists(os.path.join(F, "chain_call_by_call.json")):
+        best["call_by_call_steps_per_s"] = load("chain_call_by_call.json")["steps_per_s"]
+    json.dump(best, open(os.path.join(P, f"r{rnd}_mh_chain_femur.json"), "w"))
+if os.path.exists(os.path.join(F, "bench_1622.json")):
+    shutil.copy(os.path.join(F, "bench_1622.json"), os.path.join(P, f"r{rnd}_bench_1622.json"))
 print("profiles updated from", F)

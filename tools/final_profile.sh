@@ -18,6 +18,14 @@ python3 bench.py --points 100000 --no-cpu-baseline 2>/dev/null | tail -1 > $F/be
 for n in 2 4 8; do python3 bench.py --points 100000 --emulate-world $n --no-cpu-baseline --no-parity-check --steps 40 --warmup 5 --roofline-steps 0 2>/dev/null | tail -1 > $F/emu100k_$n.json; done
 python3 bench.py --group --logical-shards 2 --no-cpu-baseline 2>/dev/null | tail -1 > $F/bench_group_logical2.json
 timeout 1500 python3 tools/bench_configs.py > $F/configs.txt 2> $F/configs.err; cp gpurun_out/r04_configs.json $F/configs.json
+# the 8-rank shard's kernels (the Amdahl table of DESIGN.md section 7), the Metropolis-Hastings chain and the two ICP flavours
+bash tools/prof_stats.sh final_emu8 --emulate-world 8 --steps 100 --warmup 10 --roofline-steps 0 > $F/emu8_kernels.txt 2>&1; cp gpurun_out/prof_final_emu8/kernel_stats.csv $F/emu8_kernel_stats.csv
+python3 bench.py --points 1622 --steps 300 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $F/bench_1622.json
+for i in 1 2 3 4 5; do python3 tools/bench_mh_chain.py 300 0 2>/dev/null | tail -1 > $F/chain_$i.json; done
+python3 tools/bench_mh_chain.py 300 0 nofuse 2>/dev/null | tail -1 > $F/chain_call_by_call.json
+bash tools/prof_mh_chain.sh final_chain 300 0 > $F/chain_kernels.txt 2>&1; cp gpurun_out/prof_final_chain/kernel_stats.csv $F/chain_kernel_stats.csv
+python3 tools/bench_icp.py 2>/dev/null | tail -1 > $F/icp50k.json
+python3 tools/bench_icp_surface.py 2>/dev/null | tail -1 > $F/icp_surface.json
 python3 - <<'PY'
 import json
 d = json.load(open("gpurun_out/final/bench.json"))
@@ -32,4 +40,14 @@ for t in ("15k", "100k"):
     print(t, d["ms_per_step"], d["valid"], d["parity_check"] and d["parity_check"]["ok"])
 for n in (2, 4, 8):
     print("emulated 100k", n, json.load(open(f"gpurun_out/final/emu100k_{n}.json"))["ms_per_step"])
+print("1622", json.load(open("gpurun_out/final/bench_1622.json"))["ms_per_step"])
+print("chain steps/s", [round(json.load(open(f"gpurun_out/final/chain_{i}.json"))["steps_per_s"]) for i in range(1, 6)],
+      "call by call", round(json.load(open("gpurun_out/final/chain_call_by_call.json"))["steps_per_s"]))
+for t in ("icp50k", "icp_surface"):
+    try:
+        print(t, json.load(open(f"gpurun_out/final/{t}.json")).get("ms_per_iteration"))
+    except Exception as ex:
+        print(t, "failed", ex)
+for c in json.load(open("gpurun_out/final/configs.json")):
+    print("config", c["config"], c["value"], c["unit"], c["ms_per_step"], c["valid"])
 PY
