@@ -170,6 +170,7 @@ SIGNATURES = {
     "gingr_fitter_posterior_logpdf_rccl": (c_int, [c_void_p, c_int32, POINTER(CpdParams), POINTER(IcpParams), _dp, _dp]),
     "gingr_group_set_meshes": (c_int, [c_void_p, c_int64, _ip, c_int64, _ip]),
     "gingr_group_set_surface_method": (c_int, [c_void_p, c_int32]),
+    "gingr_group_set_correspondence_direction": (c_int, [c_void_p, c_int32]),
     "gingr_group_update_async": (c_int, [c_void_p, c_int32, POINTER(CpdParams), POINTER(IcpParams), c_int32, _dp]),
     "gingr_group_posterior_logpdf": (c_int, [c_void_p, c_int32, POINTER(CpdParams), POINTER(IcpParams), _dp, _dp]),
     "gingr_rccl_load": (c_int, [c_void_p, c_char_p]),

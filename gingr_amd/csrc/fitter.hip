@@ -62,6 +62,12 @@ struct gingr_fitter {
     int32_t surface_method = 0;                    // 0 TriangularClosestPoint, 1 AlongNormalClosestPoint (ICP.scala:32-34)
     // reversed correspondence direction (ICP.scala:46-48): per TARGET vertex buffers, then one observation per model vertex
     bool reversed = false;
+    // ... on a row shard the correspondence itself is replicated work (its queries are the replicated target) against the GATHERED
+    // template, so the per-template-vertex arrays cover the whole template in ORIGINAL vertex order (set_meshes builds them); the
+    // observations of this shard's rows are picked out afterwards (reversal_local_kernel)
+    int32_t *radj_ptr = nullptr, *radj_tri = nullptr, *rmbnd = nullptr;
+    double *rmvn = nullptr, *rfboxes = nullptr, *robs_full = nullptr, *rwin_full = nullptr;
+    void *rws = nullptr;
     int32_t *mtri_orig = nullptr, *mboundary = nullptr;
     double *rcp = nullptr, *rd2 = nullptr, *rnnd2 = nullptr, *rw01 = nullptr, *robs = nullptr, *rwin = nullptr;
     int32_t *rnn = nullptr, *rpre = nullptr, *rhit = nullptr, *rkeys = nullptr, *rvals = nullptr, *rskeys = nullptr, *rsvals = nullptr;
@@ -179,6 +185,19 @@ __global__ __launch_bounds__(256) void fit_contribution_kernel(const double *__r
     for (int d = 0; d < 3; ++d) full[d * M_total + g] = mine ? fit[d * M + pos] : 0.0;
 }
 
+// the observations of this shard's rows out of the per-template-vertex arrays of the whole template (original vertex order): device
+// position p of the shard holds original vertex row_begin + perm[p]
+__global__ __launch_bounds__(256) void reversal_local_kernel(int64_t M, int64_t row_begin, const int32_t *__restrict__ perm, int64_t M_total,
+                                                             const double *__restrict__ obs_full, const double *__restrict__ win_full,
+                                                             double *__restrict__ obs, double *__restrict__ win) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= M) return;
+    const int64_t g = row_begin + perm[p];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) obs[d * M + p] = obs_full[d * M_total + g];
+    win[p] = win_full[g];
+}
+
 template <typename T>
 int dev_alloc(gingr_ctx *ctx, T **p, size_t count) {
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(p), (count ? count : 1) * sizeof(T)));
@@ -253,8 +272,12 @@ void refresh_fit(gingr_fitter *f) {
 
 void free_meshes(gingr_fitter *f) {
     void *rptrs[] = {f->mtri_orig, f->mboundary, f->rcp, f->rd2, f->rnnd2, f->rw01, f->robs, f->rwin, f->rnn, f->rpre, f->rhit,
-                     f->rkeys, f->rvals, f->rskeys, f->rsvals, f->rsort};
+                     f->rkeys, f->rvals, f->rskeys, f->rsvals, f->rsort, f->radj_ptr, f->radj_tri, f->rmbnd, f->rmvn, f->rfboxes,
+                     f->robs_full, f->rwin_full, f->rws};
     for (void *p : rptrs) dev_free(p);
+    f->radj_ptr = f->radj_tri = f->rmbnd = nullptr;
+    f->rmvn = f->rfboxes = f->robs_full = f->rwin_full = nullptr;
+    f->rws = nullptr;
     f->mtri_orig = f->mboundary = f->rnn = f->rpre = f->rhit = f->rkeys = f->rvals = f->rskeys = f->rsvals = nullptr;
     f->rcp = f->rd2 = f->rnnd2 = f->rw01 = f->robs = f->rwin = nullptr;
     f->rsort = nullptr;
@@ -962,6 +985,7 @@ void fitter_set_zrand(gingr_fitter *f, const double *z) {  // (pageable source: 
     (void)hipMemcpyAsync(f->zrand, zz.data(), zz.size() * sizeof(double), hipMemcpyHostToDevice, f->ctx->stream);
 }
 gingr_ctx *fitter_ctx(gingr_fitter *f) { return f->ctx; }
+bool fitter_reversed(gingr_fitter *f) { return f->reversed; }
 const gingr_model *fitter_model(gingr_fitter *f) { return f->m; }
 
 // --------------------------------------------------------------------------------------------------- phases
@@ -1061,9 +1085,37 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
     }
     switch (phase) {
         case 0: {
-            if (icp && f->reversed && f->sharded())
-                return gingr_set_error(ctx, GINGR_ERR_STATE, "reversed correspondence direction: single shard only");
-            if (icp && f->reversed) {
+            if (icp && f->reversed && f->sharded()) {
+                // the same correspondence as below, replicated on every shard against the GATHERED template (meshc: original vertex
+                // order, so a matched vertex IS its original id and ties go to the lowest id as on a single shard); then this
+                // shard's rows of the per-template-vertex observations
+                if (!f->fullfit || !f->robs_full)
+                    return gingr_set_error(ctx, GINGR_ERR_STATE, "reversed correspondence direction on a row shard: meshes / direction not set");
+                const int64_t N = f->N, Mt = m->M_total;
+                launch_tile_bbox(ctx, meshc, f->rfboxes);
+                if (f->icp_surface) {
+                    const bool along = f->surface_method == 1;
+                    launch_cell_normals(ctx, meshc, f->mtri, f->Tm, f->mcn);
+                    launch_vertex_normals(ctx, f->radj_ptr, f->radj_tri, f->mcn, f->Tm, Mt, f->rmvn);
+                    launch_tri_tile_bbox(ctx, meshc, f->mtri, f->Tm, f->mtboxes, f->mtribox);
+                    if (along)
+                        launch_line_nearest(ctx, tgt, f->tvn, meshc, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, f->rcp, f->rhit);
+                    else
+                        launch_surface_closest_point(ctx, tgt, meshc, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, f->rcp, f->rd2, nullptr, nullptr,
+                                                     false, f->mtribox);
+                    launch_nn(ctx, cloud_of(f->rcp, N), meshc, nullptr, f->rfboxes, f->rws, f->rnn, f->rnnd2);
+                    launch_surface_prereject(ctx, N, f->rnn, f->rmbnd, f->tvn, f->rmvn, Mt, along ? f->rhit : nullptr, f->rpre);
+                    launch_self_intersect(ctx, tgt, f->rcp, f->ttri, f->Tt, f->ttboxes, f->rpre, f->rhit, f->ttribox);
+                    launch_reversal_observations(ctx, Mt, tgt, f->rnn, f->rpre, f->rhit, &f->st->sigma2, f->rkeys, f->rvals, f->rskeys,
+                                                 f->rsvals, f->rsort, f->rsort_bytes, f->rw01, f->robs_full, f->rwin_full);
+                } else {
+                    launch_nn(ctx, tgt, meshc, nullptr, f->rfboxes, f->rws, f->rnn, f->rnnd2);
+                    launch_reversal_observations(ctx, Mt, tgt, f->rnn, nullptr, nullptr, &f->st->sigma2, f->rkeys, f->rvals, f->rskeys,
+                                                 f->rsvals, f->rsort, f->rsort_bytes, f->rw01, f->robs_full, f->rwin_full);
+                }
+                hipLaunchKernelGGL(reversal_local_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, ctx->stream, M, m->row_begin, m->perm, Mt,
+                                   f->robs_full, f->rwin_full, f->robs, f->rwin);
+            } else if (icp && f->reversed) {
                 // closestPointCorrespondenceReversal (ClosestPointRegistrator.scala:34-49): the roles of the two meshes are swapped,
                 // then every accepted target vertex becomes an observation of the template vertex nearest to its match
                 const int64_t N = f->N;
@@ -1326,7 +1378,7 @@ int fitter_sharded_update(gingr_fitter *f, int flavour, const gingr_cpd_params *
     int rc = GINGR_OK;
     for (int32_t it = 0; it < n_iterations && rc == GINGR_OK; ++it) {
         TimerScope ts(ctx, 3);
-        if (flavour == 2 && f->sharded()) {
+        if ((flavour == 2 || (flavour == 1 && f->reversed)) && f->sharded()) {
             rc = fitter_run_phase(f, flavour, cp, ip, GINGR_PHASE_GATHER);
             if (!rc && reduce(user, GINGR_SEGMENT_FULLFIT, f->fullfit, 3 * f->m->M_total) != 0)
                 rc = gingr_set_error(ctx, GINGR_ERR_STATE, "sharded update: the all-reduce callback failed (full fit)");
@@ -1494,6 +1546,30 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
             i = j;
         }
     }
+    // (row shard) the whole template's vertex -> triangle lists and boundary flags in original vertex order: the reversed
+    // correspondence direction tests the template vertex nearest to a match, which may belong to any shard
+    Built bfull;
+    std::vector<int32_t> mbnd_full;
+    if (sharded) {
+        const std::vector<double> &full = f->m->h_full_pts;
+        build(n_model_tri, model_tri, [&](int32_t v, int d) { return full[(size_t)3 * v + d]; }, [&](int32_t v) { return v; },
+              [&](int32_t v) { return v; }, Mt, bfull);
+        mbnd_full.assign((size_t)Mt, 0);
+        std::vector<uint64_t> edges;
+        edges.reserve((size_t)3 * n_model_tri);
+        for (int64_t t = 0; t < n_model_tri; ++t)
+            for (int k = 0; k < 3; ++k) {
+                const uint64_t a = (uint64_t)model_tri[3 * t + k], b = (uint64_t)model_tri[3 * t + (k + 1) % 3];
+                edges.push_back((a < b ? a : b) << 32 | (a < b ? b : a));
+            }
+        std::sort(edges.begin(), edges.end());
+        for (size_t i = 0; i < edges.size();) {
+            size_t j = i;
+            while (j < edges.size() && edges[j] == edges[i]) ++j;
+            if (j - i == 1) mbnd_full[(size_t)(edges[i] >> 32)] = 1, mbnd_full[(size_t)(edges[i] & 0xffffffffu)] = 1;
+            i = j;
+        }
+    }
     f->Tm = n_model_tri;
     f->Tt = n_target_tri;
     const int64_t ntm = ceil_div(f->Tm, 256), ntt = ceil_div(f->Tt, 256);
@@ -1530,6 +1606,15 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
         GINGR_TRY(dev_alloc(ctx, &f->fullfit, (size_t)3 * Mt));
         HIP_TRY(ctx, hipMemsetAsync(f->fullfit, 0, (size_t)3 * Mt * sizeof(double), ctx->stream));
     }
+    if (sharded) {
+        if ((rc = dev_alloc(ctx, &f->radj_ptr, (size_t)Mt + 1)) || (rc = dev_alloc(ctx, &f->radj_tri, bfull.adj_tri.size())) ||
+            (rc = dev_alloc(ctx, &f->rmbnd, (size_t)Mt)) || (rc = dev_alloc(ctx, &f->rmvn, (size_t)3 * Mt)) ||
+            (rc = dev_alloc(ctx, &f->rfboxes, (size_t)ceil_div(Mt, 256) * 30)))
+            return rc;
+        HIP_TRY(ctx, up(f->radj_ptr, bfull.adj_ptr));
+        HIP_TRY(ctx, up(f->radj_tri, bfull.adj_tri));
+        HIP_TRY(ctx, up(f->rmbnd, mbnd_full));
+    }
     // static target side: cell normals, vertex normals, triangle tile boxes
     const Cloud tgt = cloud_of(f->target, N);
     launch_cell_normals(ctx, tgt, f->ttri, f->Tt, f->tcn);
@@ -1557,7 +1642,16 @@ int gingr_fitter_set_correspondence_direction(gingr_fitter *f, int32_t reversed)
         return GINGR_OK;
     }
     if (!f->target) return gingr_set_error(ctx, GINGR_ERR_STATE, "set_correspondence_direction: no target set");
-    if (f->m->M != f->m->M_total) return gingr_set_error(ctx, GINGR_ERR_STATE, "set_correspondence_direction: single shard only");
+    if (f->sharded() && !f->radj_ptr)
+        return gingr_set_error(ctx, GINGR_ERR_STATE, "set_correspondence_direction: a row shard needs the meshes first (gingr_fitter_set_meshes: "
+                                                     "the reversed direction works on the gathered template)");
+    if (f->sharded() && !f->robs_full) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        const int64_t Mt = f->m->M_total;
+        int rc;
+        if ((rc = dev_alloc(ctx, &f->robs_full, (size_t)3 * Mt)) || (rc = dev_alloc(ctx, &f->rwin_full, (size_t)Mt))) return rc;
+        HIP_TRY(ctx, hipMalloc(&f->rws, (size_t)nn_ws_bytes(f->N, Mt)));
+    }
     if (!f->rnn) {  // buffers per target vertex + the sort workspace, once per target
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         const int64_t M = f->m->M, N = f->N;
@@ -1593,7 +1687,9 @@ int gingr_fitter_get_reversed_correspondence(gingr_fitter *f, int32_t *template_
     for (int64_t s2 = 0; s2 < N; ++s2) {  // device target position -> original target id; device model row -> original vertex id
         const int32_t j = f->h_tperm[(size_t)s2];
         const int32_t row = hid[(size_t)s2];
-        if (template_id) template_id[j] = (row >= 0 && row < f->m->M) ? f->m->hperm[(size_t)row] : -1;
+        if (template_id)  // (a row shard searched the gathered template: original vertex ids already)
+            template_id[j] = f->sharded() ? ((row >= 0 && row < f->m->M_total) ? row : -1)
+                                          : ((row >= 0 && row < f->m->M) ? f->m->hperm[(size_t)row] : -1);
         if (w) w[j] = hw[(size_t)s2];
     }
     return GINGR_OK;
@@ -1794,7 +1890,7 @@ int fitter_sharded_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params *
     if (!mesh_xyz_full || !logpdf || !reduce || flavour < 0 || flavour > 2)
         return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "sharded posterior_logpdf: bad arguments");
     if (f->partial_out) return gingr_set_error(ctx, GINGR_ERR_STATE, "sharded posterior_logpdf: this fitter belongs to a device group");
-    if (flavour == 2 && f->sharded()) {
+    if ((flavour == 2 || (flavour == 1 && f->reversed)) && f->sharded()) {
         GINGR_TRY(fitter_run_phase(f, flavour, cp, ip, GINGR_PHASE_GATHER));
         if (reduce(user, GINGR_SEGMENT_FULLFIT, f->fullfit, 3 * f->m->M_total) != 0)
             return gingr_set_error(ctx, GINGR_ERR_STATE, "sharded posterior_logpdf: the all-reduce callback failed (full fit)");

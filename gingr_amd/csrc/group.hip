@@ -103,6 +103,7 @@ struct gingr_group {
     std::vector<double *> sendfit[2];
     std::vector<hipEvent_t> readyfit[2];
     bool meshes = false;
+    bool reversed = false;  // reversed correspondence direction (gingr_group_set_correspondence_direction): gathers the fit like flavour 2
     int64_t iteration = 0;                                      // parity of the send buffers
     bool fine_grained = false;                                  // the send buffers are fine-grained device allocations
     int distinct_devices = 1;
@@ -345,7 +346,8 @@ int exchange_fullfit(gingr_group *g, int r, int parity, bool ok) {
 int group_update(gingr_group *g, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations, const double *z) {
     if (!g || n_iterations < 0 || flavour < 0 || flavour > 2) return GINGR_ERR_BAD_ARGUMENT;
     if (g->fit.empty() || !g->fit[0] || g->xch.empty()) return group_fail(g, GINGR_ERR_STATE, "group update: no model / target set");
-    if (flavour == 2 && !g->meshes) return group_fail(g, GINGR_ERR_STATE, "group update: no meshes set (gingr_group_set_meshes)");
+    const bool gather = flavour == 2 || (flavour == 1 && g->reversed);  // the tests against the template need all of it
+    if (gather && !g->meshes) return group_fail(g, GINGR_ERR_STATE, "group update: no meshes set (gingr_group_set_meshes)");
     if (z && n_iterations != 1) return group_fail(g, GINGR_ERR_BAD_ARGUMENT, "group update: a sampled proposal is one iteration");
     if (g->n == 1)
         return g->run([&](int) {
@@ -367,7 +369,7 @@ int group_update(gingr_group *g, int flavour, const gingr_cpd_params *cp, const 
             const int parity = (int)((it0 + it) & 1);
             if (!rc) fitter_set_partial_output(f, g->send[parity][(size_t)r]);
             TimerScope ts(g->ctx[(size_t)r], 3);
-            if (flavour == 2) {  // the whole posed template for the tests against it: gather the shards' rows of the fit
+            if (gather) {  // the whole posed template for the tests against it: gather the shards' rows of the fit
                 if (!rc) fitter_set_partial_fullfit(f, g->sendfit[parity][(size_t)r]);
                 if (!rc) rc = fitter_run_phase(f, flavour, cp, ip, GINGR_PHASE_GATHER);
                 const int xrc = exchange_fullfit(g, r, parity, rc == GINGR_OK);
@@ -393,7 +395,8 @@ int group_logpdf(gingr_group *g, int flavour, const gingr_cpd_params *cp, const 
                  double *logpdf) {
     if (!g || !mesh_xyz_full || !logpdf || flavour < 0 || flavour > 2) return GINGR_ERR_BAD_ARGUMENT;
     if (g->fit.empty() || !g->fit[0] || g->xch.empty()) return group_fail(g, GINGR_ERR_STATE, "group posterior_logpdf: no model / target set");
-    if (flavour == 2 && !g->meshes) return group_fail(g, GINGR_ERR_STATE, "group posterior_logpdf: no meshes set (gingr_group_set_meshes)");
+    const bool gather = flavour == 2 || (flavour == 1 && g->reversed);
+    if (gather && !g->meshes) return group_fail(g, GINGR_ERR_STATE, "group posterior_logpdf: no meshes set (gingr_group_set_meshes)");
     if (g->n == 1)
         return g->run([&](int) {
             gingr_fitter *f = g->fit[0];
@@ -408,7 +411,7 @@ int group_logpdf(gingr_group *g, int flavour, const gingr_cpd_params *cp, const 
         int rc = GINGR_OK;
         gingr_fitter *f = g->fit[(size_t)r];
         fitter_set_partial_output(f, g->send[parity][(size_t)r]);
-        if (flavour == 2) {
+        if (gather) {
             fitter_set_partial_fullfit(f, g->sendfit[parity][(size_t)r]);
             rc = fitter_run_phase(f, flavour, cp, ip, GINGR_PHASE_GATHER);
             const int xrc = exchange_fullfit(g, r, parity, rc == GINGR_OK);
@@ -634,6 +637,16 @@ int gingr_group_set_surface_method(gingr_group *g, int32_t method) {
     if (!g) return GINGR_ERR_BAD_ARGUMENT;
     if (g->fit.empty() || !g->fit[0]) return group_fail(g, GINGR_ERR_STATE, "group set_surface_method: no model");
     return g->run([&](int r) { return gingr_fitter_set_surface_method(g->fit[(size_t)r], method); });
+}
+
+int gingr_group_set_correspondence_direction(gingr_group *g, int32_t reversed) {
+    if (!g) return GINGR_ERR_BAD_ARGUMENT;
+    if (g->fit.empty() || !g->fit[0]) return group_fail(g, GINGR_ERR_STATE, "group set_correspondence_direction: no model");
+    if (reversed && g->n > 1 && !g->meshes)
+        return group_fail(g, GINGR_ERR_STATE, "group set_correspondence_direction: set the meshes first (the reversed direction works on the gathered template)");
+    GINGR_TRY(g->run([&](int r) { return gingr_fitter_set_correspondence_direction(g->fit[(size_t)r], reversed); }));
+    g->reversed = reversed != 0;
+    return GINGR_OK;
 }
 
 int gingr_group_update_async(gingr_group *g, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations,

@@ -113,6 +113,12 @@ class DeviceGroup:
         self._check(self._lib.gingr_group_set_meshes(self.handle, mt.shape[0], iptr(mt), tt.shape[0], iptr(tt)), "gingr_group_set_meshes")
         self._check(self._lib.gingr_group_set_surface_method(self.handle, int(method)), "gingr_group_set_surface_method")
 
+    def set_correspondence_direction(self, reversed: bool):
+        """IcpConfiguration.reverseCorrespondenceDirection (ICP.scala:46-48) for the ICP flavours of `update`; with more than one shard
+        the meshes must have been set (the correspondence runs replicated against the gathered template)."""
+        self._check(self._lib.gingr_group_set_correspondence_direction(self.handle, 1 if reversed else 0),
+                    "gingr_group_set_correspondence_direction")
+
     @staticmethod
     def _params(flavour: int, params):
         cp = nat.CpdParams(*params) if flavour == nat.FLAVOUR_CPD else None

@@ -245,6 +245,12 @@ class ShardedFitter:
                    "gingr_fitter_fullfit_exchange")
             self._fullfit = as_torch(p.value, n.value, self.ctx.device)
 
+    def set_correspondence_direction(self, reversed: bool):
+        """IcpConfiguration.reverseCorrespondenceDirection on this shard (after set_meshes: the correspondence runs replicated against the
+        gathered template, the shard keeps the observations of its own rows)."""
+        _check(self.ctx.handle, self._lib.gingr_fitter_set_correspondence_direction(self.handle, 1 if reversed else 0),
+               "gingr_fitter_set_correspondence_direction")
+
     def _segment(self, seg: int):
         if seg == nat.SEGMENT_FULLFIT:
             return self._fullfit

@@ -395,7 +395,8 @@ int gingr_fitter_update_icp_sharded_async(gingr_fitter *f, const gingr_icp_param
  * gingr_fitter_posterior_logpdf_sharded: posterior(state).gp.logpdf(posterior.coefficients(mesh))
  * (G/api/sampling/generators/GeneratorWrapperStochastic.scala:42-63) with mesh_xyz_full = the FULL mesh [3 M_total] on every shard
  * (each takes its rows); Q0^T e travels in the tail of segment 1, the log-density kernel is replicated; synchronises.
- * Reversed correspondence direction (ICP.scala:46-48) remains single shard.
+ * Reversed correspondence direction (ICP.scala:46-48; gingr_fitter_set_correspondence_direction after gingr_fitter_set_meshes): the
+ * correspondence is replicated on every shard against the gathered template, the observations of the shard's rows are its own.
  * gingr_fitter_fullfit_exchange: address / element count of the full-fit buffer for a host that drives the phases itself. */
 int gingr_fitter_update_sharded_async(gingr_fitter *f, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,
                                       int32_t n_iterations, const double *z, gingr_allreduce_fn reduce, void *user);
@@ -514,6 +515,10 @@ int gingr_group_update_icp_async(gingr_group *g, const gingr_icp_params *p, int3
 int gingr_group_set_meshes(gingr_group *g, int64_t n_model_triangles, const int32_t *model_triangles, int64_t n_target_triangles,
                            const int32_t *target_triangles);
 int gingr_group_set_surface_method(gingr_group *g, int32_t method);
+/* gingr_fitter_set_correspondence_direction for every shard (ICP.scala:46-48).  With more than one shard the correspondence itself is
+ * replicated work -- its queries are the replicated target, its answers may lie in any shard's rows -- against the gathered template
+ * (set the meshes first, also for the vertex-to-vertex flavour 1); Gram, right-hand side and everything behind them stay sharded. */
+int gingr_group_set_correspondence_direction(gingr_group *g, int32_t reversed);
 int gingr_group_update_async(gingr_group *g, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations,
                              const double *z);
 int gingr_group_posterior_logpdf(gingr_group *g, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,

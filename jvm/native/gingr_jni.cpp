@@ -495,6 +495,9 @@ JFN(jint, groupSetMeshes)(JNIEnv *env, jclass, jlong g, jintArray modelTriangles
     return gingr_group_set_meshes(P<gingr_group>(g), (int64_t)a.buf.size() / 3, a.ptr(), (int64_t)b.buf.size() / 3, b.ptr());
 }
 JFN(jint, groupSetSurfaceMethod)(JNIEnv *, jclass, jlong g, jint method) { return gingr_group_set_surface_method(P<gingr_group>(g), method); }
+JFN(jint, groupSetCorrespondenceDirection)(JNIEnv *, jclass, jlong g, jboolean reversed) {
+    return gingr_group_set_correspondence_direction(P<gingr_group>(g), reversed ? 1 : 0);
+}
 JFN(jint, groupUpdate)(JNIEnv *env, jclass, jlong g, jint flavour, jdouble w, jdouble lambda, jdouble initialSigma, jdouble endSigma,
                        jint maxIterations, jint n, jdoubleArray z) {
     const gingr_cpd_params cp{w, lambda};

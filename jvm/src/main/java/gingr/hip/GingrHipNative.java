@@ -158,6 +158,8 @@ public final class GingrHipNative {
     // (GeneratorWrapperStochastic.scala:42-63).  Triangles index the vertices of the FULL template / target.
     public static native int groupSetMeshes(long group, int[] modelTriangles, int[] targetTriangles);
     public static native int groupSetSurfaceMethod(long group, int method);
+    /** IcpConfiguration.reverseCorrespondenceDirection for the group's ICP flavours (set the meshes first when there is more than one shard) */
+    public static native int groupSetCorrespondenceDirection(long group, boolean reversed);
     public static native int groupUpdate(long group, int flavour, double w, double lambda, double initialSigma, double endSigma,
                                          int maxIterations, int nIterations, double[] z);
     public static native int groupPosteriorLogpdf(long group, int flavour, double w, double lambda, double initialSigma, double endSigma,

@@ -259,6 +259,60 @@ def test_group_surface_icp_sample_and_logpdf_equal_single_shard(nshards):
     multi.close()
 
 
+@pytest.mark.parametrize("nshards,flavour", [(2, 2), (3, 2), (8, 2), (3, 1)])
+def test_group_reversed_direction_equals_single_shard(nshards, flavour):
+    """IcpConfiguration.reverseCorrespondenceDirection (ICP.scala:46-48, ClosestPointRegistrator.scala:34-49) on row shards: the
+    correspondence -- target vertices looking for their match on the TEMPLATE -- runs replicated on every shard against the gathered
+    fit (a match may lie in any shard's rows), each shard keeps the observations of its own rows; Gram, right-hand side and the rest
+    stay sharded.  flavour 2: closest point on the template surface + the rejection rules; flavour 1: nearest template vertex.
+    Update by update from identical states (see the surface test above), and the first update against the oracle."""
+    from gingr_amd import _native as nat
+    mo, cells, target, tcells = _femur_case()
+    params = (20.0, 1.0, 30)
+    single = _group([0], mo, target, cells, tcells)
+    multi = _group(_devices(nshards), mo, target, cells, tcells)
+    for g in (single, multi):
+        g.set_correspondence_direction(True)
+    single.set_state(np.zeros(mo.rank), 20.0, translation=(1.0, -2.0, 0.5), euler=(0.02, -0.03, 0.01))
+    for it in range(3):
+        a0, sc0, fit0 = single.get_state()
+        _set(multi, a0, sc0)
+        single.update(flavour, params, 1)
+        multi.update(flavour, params, 1)
+        a1, sc1, fit1 = single.get_state()
+        a2, sc2, fit2 = multi.get_state()
+        assert sc1.status == sc2.status == 0 and sc1.iteration == sc2.iteration
+        assert rel(fit2, fit1) < 1e-9 and rel(a2, a1) < 1e-7 and sc2.sigma2 == sc1.sigma2, (it, rel(fit2, fit1))
+        assert rel(fit1, fit0) > 1e-6
+        if it == 0:
+            st_in = go.State(alpha=a0.copy(), euler=tuple(sc0.euler[:]), center=np.array(sc0.center[:]), translation=np.array(sc0.translation[:]),
+                             scale=sc0.scale, sigma2=sc0.sigma2, fit=fit0.copy(), iteration=sc0.iteration, status=0, global_transformation=1,
+                             step_length=1.0)
+            method = "TriangularClosestPoint" if flavour == 2 else "PointcloudClosestPoint"
+            st, (tid, w) = go.icp_reversed_update(mo, cells, target, tcells, st_in, *params, method=method)
+            assert w.sum() > 0 and rel(fit2, st.fit) < 1e-5
+    # the sampled proposal and the transition density take the same route
+    a0, sc0, fit0 = single.get_state()
+    _set(multi, a0, sc0)
+    z = np.random.default_rng(5).standard_normal(mo.rank)
+    single.update(flavour, params, 1, z=z)
+    multi.update(flavour, params, 1, z=z)
+    fit1, fit2 = single.get_state()[2], multi.get_state()[2]
+    assert rel(fit2, fit1) < 1e-9
+    _set(single, a0, sc0)
+    _set(multi, a0, sc0)
+    l1, l2 = single.posterior_logpdf(flavour, params, fit1), multi.posterior_logpdf(flavour, params, fit1)
+    assert np.isfinite(l1) and abs(l2 - l1) < 1e-8 * abs(l1)
+    # back to the forward direction: the group forgets the gather for flavour 1
+    for g in (single, multi):
+        g.set_correspondence_direction(False)
+        _set(g, a0, sc0)
+        g.update(flavour, params, 1)
+    assert rel(multi.get_state()[2], single.get_state()[2]) < 1e-9
+    single.close()
+    multi.close()
+
+
 @pytest.mark.parametrize("flavour", [0, 1])
 def test_group_cpd_and_pointcloud_sample_and_logpdf(flavour):
     """The probabilistic proposal and log transition density of the CPD / point-cloud ICP flavours through three logical shards
