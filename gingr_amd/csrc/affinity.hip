@@ -1687,6 +1687,8 @@ static int nn_small_slices(int64_t M, int64_t N) {
     int64_t s = GINGR_NN_SMALL_WGS / (groups > 0 ? groups : 1);  // at most three workgroups (12 waves) per compute unit: no fourth round
     const int64_t max_s = ceil_div(N, 32);               // at least 32 targets per slice
     if (s > max_s) s = max_s;
+    const int64_t min_s = ceil_div(N, 2048);             // at most 2 048 targets (48 KB of LDS) per slice
+    if (s < min_s) s = min_s;
     return (int)(s < 1 ? 1 : s);
 }
 bool nn_small_applies(int64_t M, int64_t N) { return M >= 1 && N >= 1 && N <= INT32_MAX / 2 && M * N <= (int64_t)1 << 26; }

@@ -225,3 +225,54 @@ def test_heaps_of_coincident_targets(ctx):
         if state.general.status != 0:
             break
     algo.close()
+
+
+def _argmin_lowest_index(q, t):
+    """the reference's linear scan: d2 = dx*dx + dy*dy + dz*dz (separately rounded), strict <, targets in index order"""
+    idx, d2 = np.empty(q.shape[0], dtype=np.int64), np.empty(q.shape[0])
+    for i, p in enumerate(q):
+        d = t - p
+        v = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        ok = ~np.isnan(v)
+        if not ok.any() or not (v[ok].min() < np.inf):
+            idx[i], d2[i] = -1, np.inf
+        else:
+            j = int(np.flatnonzero(v == v[ok].min())[0])
+            idx[i], d2[i] = j, v[j]
+    return idx, d2
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_stateless_all_pairs_form_on_the_tie_cases(ctx, name):
+    """gingr_nn up to 2^26 pairs is the all-pairs form of round 4 (nn_small_kernel: the index is not tracked in the pair loop, the
+    combination pass finds the first slice with the minimum and searches it again): same indices and the same distance BITS as the
+    linear scan on every tie / degenerate case of this file."""
+    q, t = CASES[name]
+    idx, d2, md = ctx.nn(q, t)
+    want, wd2 = _argmin_lowest_index(q, t)
+    assert np.array_equal(idx, want), (name, int((idx != want).sum()))
+    assert np.array_equal(d2, wd2)
+    assert abs(md - np.sqrt(wd2).mean()) <= 1e-12 * max(1.0, md)
+
+
+def test_stateless_all_pairs_form_shapes_and_non_finite_input(ctx):
+    rng = np.random.default_rng(21)
+    # one query against many targets (slices of at most 2 048 targets), many queries against one slice, sizes that are no multiples of anything
+    for M, N in ((1, 100_003), (3, 40_000), (5_000, 33), (513, 2_049), (257, 6_151)):
+        q, t = rng.normal(0, 10, (M, 3)), rng.normal(0, 10, (N, 3))
+        t[N // 2] = t[0]                                  # an exact duplicate: the lower index wins
+        q[0] = t[0]
+        idx, d2, _ = ctx.nn(q, t)
+        want, wd2 = _argmin_lowest_index(q, t)
+        assert np.array_equal(idx, want) and np.array_equal(d2, wd2), (M, N)
+        assert idx[0] == 0 and d2[0] == 0.0
+    # NaN / infinite coordinates: a NaN distance never wins; a query with no finite distance gets -1 / +inf
+    q, t = rng.normal(0, 1, (70, 3)), rng.normal(0, 1, (90, 3))
+    t[5, 1] = np.nan
+    t[17] = np.inf
+    q[3, 0] = np.nan
+    q[9] = np.inf
+    idx, d2, _ = ctx.nn(q, t)
+    want, wd2 = _argmin_lowest_index(q, t)
+    assert np.array_equal(idx, want) and np.array_equal(d2, wd2)
+    assert idx[3] == -1 and idx[9] == -1 and np.isinf(d2[3]) and not np.any(idx == 5)
