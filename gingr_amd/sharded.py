@@ -45,11 +45,11 @@ SEGMENT_FULLFIT = nat.SEGMENT_FULLFIT
 
 
 def drive_update(run_phase: Callable[[int], None], all_reduce_segment: Callable[[int], None], world: int,
-                 skip_segment0: bool = False, flavour: int = 0) -> None:
+                 skip_segment0: bool = False, flavour: int = 0, reversed_direction: bool = False) -> None:
     """One iteration in the order of fitter_sharded_update (gingr_amd/csrc/fitter.hip): for the surface correspondence (flavour 2)
     the gather of the fit first; then phase p followed (for p < 2) by the all-reduce of exchange segment p -- the ICP flavours
     exchange nothing after phase 0 (their closest-point search is local to the shard's rows)."""
-    if flavour == 2 and world > 1:
+    if (flavour == 2 or (flavour == 1 and reversed_direction)) and world > 1:   # (the reversed direction works on the gathered template)
         run_phase(PHASE_GATHER)
         all_reduce_segment(SEGMENT_FULLFIT)
     for ph in range(NUM_PHASES):

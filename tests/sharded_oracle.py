@@ -19,11 +19,12 @@ EPS = 1e-5
 
 class OracleShard:
     def __init__(self, model: go.PDM, target, begin, end, global_transform=go.RIGID_TRANSFORMS, step_length=1.0, w=0.0, lam=1.0,
-                 flavour=0, icp=(1.0, 1.0, 1), tmpl_tris=None, tgt_tris=None):
+                 flavour=0, icp=(1.0, 1.0, 1), tmpl_tris=None, tgt_tris=None, reversed_direction=False):
         self.m, self.x = model, np.asarray(target, dtype=np.float64)
         self.b, self.e = begin, end
         self.gt, self.step, self.w, self.lam = global_transform, step_length, w, lam
         self.flavour, self.icp, self.tmpl_tris, self.tgt_tris = flavour, icp, tmpl_tris, tgt_tris
+        self.reversed = bool(reversed_direction)                     # ICP.scala:46-48; gathers the fit like flavour 2
         self.z = None                                                 # set for ONE sampled proposal, the same on every shard
         r, N = model.rank, self.x.shape[0]
         self.counts = [N, r * r + r + 8 + r, 3 * model.M]
@@ -69,6 +70,14 @@ class OracleShard:
             full = self.seg(2).reshape(3, M_total)
             full[:] = 0.0
             full[:, self.b:self.e] = self.fit.T
+        elif ph == 0 and self.reversed and self.flavour != 0:
+            # the reversed correspondence is replicated work: the target's vertices look for their match on the GATHERED template
+            # (any shard's rows); this shard keeps the accepted pairs whose template vertex it owns -- several per vertex are possible
+            full = self.seg(2).reshape(3, M_total).T.copy()
+            method = "TriangularClosestPoint" if self.flavour == 2 else "PointcloudClosestPoint"
+            tid, pts, w = go.correspondence_reversal(full, self.tmpl_tris, self.x, self.tgt_tris, method)
+            keep = (w == 1.0) & (tid >= self.b) & (tid < self.e)
+            self.rev = (tid[keep] - self.b, pts[keep])
         elif ph == 0 and self.flavour == 1:
             idx, _, _ = go.icp_closest_point(self.fit, self.x)          # the shard's own rows against the replicated target
             self.obs, self.acc = self.x[idx], np.ones(self.fit.shape[0])
@@ -76,6 +85,14 @@ class OracleShard:
             self.obs, self.acc = self._surface_rows(self.seg(2).reshape(3, M_total).T.copy())
         elif ph == 0:
             self.seg(0)[:] = co.cpd_colsum_partial(self.fit, self.x, st.sigma2, 0, self.fit.shape[0])
+        elif ph == 1 and self.flavour != 0 and self.reversed:
+            rows, pts = self.rev                                             # one observation per accepted TARGET vertex
+            Q3 = self.Q0.reshape(-1, 3, r)[rows]
+            e = ((pts - st.center - st.translation) @ R - (self.ref[rows] - st.center) - self.mean[rows]) / st.sigma2
+            s = self.seg(1)
+            s[: r * r] = (np.einsum("idk,idl->kl", Q3, Q3) / st.sigma2).reshape(-1)
+            s[r * r: r * r + r] = np.einsum("idk,id->k", Q3, e)
+            s[r * r + r:] = 0.0
         elif ph == 1 and self.flavour != 0:
             # uniform weight 1 / sigma2 on the accepted correspondences (ICP.scala:90-92), nothing for the sigma^2 update
             wgt = self.acc / st.sigma2

@@ -107,7 +107,10 @@ def _mesh_problem():
     return mo, cells, tgt, tcells
 
 
-def _oracle_step(go, mo, cells, tgt, tcells, st, flavour, z):
+def _oracle_step(go, mo, cells, tgt, tcells, st, flavour, z, reversed_direction=False):
+    if reversed_direction:
+        method = "TriangularClosestPoint" if flavour == 2 else "PointcloudClosestPoint"
+        return go.icp_reversed_update(mo, cells, tgt, tcells, st, *ICP_PARAMS, method=method)[0]
     if flavour == 0:
         return go.cpd_update(mo, tgt, st, w=0.1, z=z)
     if flavour == 1:
@@ -203,6 +206,52 @@ def test_gloo_surface_icp_sample_and_logpdf_equal_unsharded(tmp_path, world, fla
     for p in parts:
         assert abs(float(p["logpdf"]) - want) <= 1e-8 * abs(want), (float(p["logpdf"]), want)
     assert all(float(parts[0]["logpdf"]) == float(p["logpdf"]) for p in parts[1:])
+
+
+def _reversed_worker(rank, world, port, flavour, out_dir):
+    import torch
+    import torch.distributed as dist
+    from gingr_amd.sharded import drive_update, shard_rows
+    from oracle import gingr_oracle as go
+    from tests.sharded_oracle import OracleShard
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mo, cells, tgt, tcells = _mesh_problem()
+    b, e = shard_rows(mo.M, world, rank)
+    sh = OracleShard(mo, tgt, b, e, global_transform=1, flavour=flavour, icp=ICP_PARAMS, tmpl_tris=cells, tgt_tris=tcells,
+                     reversed_direction=True)
+    mom = torch.from_numpy(sh.mom_local.copy())
+    dist.all_reduce(mom)
+    sh.finalize(mom.numpy())
+    st = go.initial_state(mo, ICP_PARAMS[0], global_transformation=1)
+    out = {"b": b, "e": e}
+    for it in range(2):
+        sh.set_state(st)
+        drive_update(sh.phase, lambda k: dist.all_reduce(torch.from_numpy(sh.seg(k))), world, flavour=flavour, reversed_direction=True)
+        out[f"fit{it}"], out[f"alpha{it}"] = sh.fit, sh.st.alpha
+        st = _oracle_step(go, mo, cells, tgt, tcells, st, flavour, None, reversed_direction=True)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,flavour", [(2, 2), (3, 1)])
+def test_gloo_reversed_direction_equals_unsharded(tmp_path, world, flavour):
+    """IcpConfiguration.reverseCorrespondenceDirection on row shards: the correspondence is replicated against the gathered template,
+    every rank keeps the observations of its own rows (gingr_amd/csrc/fitter.hip, run_phase, reversed && sharded)."""
+    import torch.multiprocessing as mp
+    from oracle import gingr_oracle as go
+    mp.spawn(_reversed_worker, args=(world, _free_port(), flavour, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    mo, cells, tgt, tcells = _mesh_problem()
+    st = go.initial_state(mo, ICP_PARAMS[0], global_transformation=1)
+    for it in range(2):
+        st = _oracle_step(go, mo, cells, tgt, tcells, st, flavour, None, reversed_direction=True)
+        assert st.status == 0
+        fit = np.concatenate([p[f"fit{it}"] for p in parts])
+        assert np.linalg.norm(fit - st.fit) / np.linalg.norm(st.fit) < 1e-9, (it, flavour)
+        assert all(np.array_equal(parts[0][f"alpha{it}"], p[f"alpha{it}"]) for p in parts[1:])
 
 
 def test_shard_rows_partition():
