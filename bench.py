@@ -487,12 +487,37 @@ def main():
         if use_dist:
             exchange_path = ("rccl-native" if native else
                              ("gloo on host copies (shared-device test mode)" if shared_device else "torch.distributed (nccl) callback"))
+        native_error = None
         if native:
             comm_world = world if not args.emulate_world else 1
-            uid = [ctx.rccl_unique_id() if rank == 0 else None]
+            try:
+                uid = [ctx.rccl_unique_id() if rank == 0 else None]
+            except Exception as ex:          # (librccl not loadable on rank 0: everybody must learn it)
+                uid, native_error = [None], repr(ex)
             if comm_world > 1:
                 dist.broadcast_object_list(uid, src=0)
-            ctx.rccl_init(uid[0], comm_world, rank if comm_world > 1 else 0)
+            ok = uid[0] is not None
+            if ok:
+                try:
+                    ctx.rccl_init(uid[0], comm_world, rank if comm_world > 1 else 0)
+                    # one all-reduce through the new communicator before anything depends on it: every rank contributes 1
+                    probe = torch.ones(4, dtype=torch.float64, device=f"cuda:{local_rank}")
+                    torch.cuda.synchronize(local_rank)
+                    ctx.rccl_allreduce(probe.data_ptr(), 4)
+                    ctx.synchronize()
+                    ok = bool(torch.all(probe == float(comm_world)).item())
+                    if not ok:
+                        native_error = f"probe all-reduce returned {probe.tolist()} for {comm_world} ranks"
+                except Exception as ex:
+                    ok, native_error = False, repr(ex)
+            if comm_world > 1:               # all ranks take the same path: native only if it works everywhere
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=f"cuda:{local_rank}")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = bool(flag.item())
+            if not ok:
+                native = False
+                exchange_path = f"torch.distributed (nccl) callback -- native RCCL exchange unavailable: {native_error or 'failed on another rank'}"
+                print(f"[bench] rank {rank}: {exchange_path}", file=sys.stderr)
         with torch.cuda.stream(stream):
             shard_world = args.emulate_world if args.emulate_world > 1 else world
             fitter = ShardedFitter(ctx, model, x, rank=rank, world=shard_world, all_reduce=all_reduce if use_dist else None,
