@@ -32,9 +32,9 @@ struct gingr_ctx {
     // exact-zero tile culling of the CPD passes and exact pruning of the closest-point scans (affinity.hip); gingr_ctx_set_option
     // (GINGR_OPT_CULL, 0) disables both (results must stay bit-identical: the culling test compares the two)
     int cull = 1;
-    // GINGR_OPT_TRI_GRID: closest surface point over the target's triangle grid (surface.hip) in front of the tile scan.  OFF by
-    // default: built, bit-identical, but slower than the warm-started tile scan alone at 41k x 82k (133 + 26 us against 94 us, round 4)
-    int tri_grid = 0;
+    // GINGR_OPT_TRI_GRID: closest surface point over the target's triangle grid (surface.hip) in front of the tile scan: 0 never, 1 from
+    // kTriGridMinTriangles target triangles on (default), 2 always.  Bit-identical results either way.
+    int tri_grid = 1;
     int nn_grid = 1;  // GINGR_OPT_NN_GRID: closest point over the target's uniform grid (nn_grid.hip); 0 = the tile scan alone; 2 = gingr_nn too
     // Culling regime of the CPD passes as the DEVICE last saw it (0 plain, 1 quarter-tile culling pays): pinned host word the
     // all-pairs kernels write, read -- unsynchronised, possibly a few launches stale -- when the next launch picks its kernel
@@ -218,12 +218,16 @@ struct TriGridDev {
     double lo[3];
     double h, inv_h;
     int32_t g[3];
-    const int32_t *cell_start;  // [g0 g1 g2 + 1], x fastest
-    const int32_t *tris;        // triangle positions (in the device's triangle order), cell after cell
+    int32_t span[3];            // largest extent (in cell steps) of a listed triangle's box per axis
+    int32_t n_listed, n_big;    // entries [0, n_listed) are listed by cell, [n_listed, n_listed + n_big) is the short list of wide triangles
+    const int32_t *cell_start;  // [g0 g1 g2 + 1], x fastest: a triangle is listed in the cell of its box's lower corner
+    const double *boxes;        // [entries][6]: box lo / hi of every entry
+    const double *recs;         // [entries][10]: corners A, B, C, {position | original index << 32} (surface.hip: kTriRec)
 };
 struct TriGrid {
     TriGridDev v{};
-    int32_t *cell_start = nullptr, *tris = nullptr;
+    int32_t *cell_start = nullptr;
+    double *boxes = nullptr, *recs = nullptr;
     uint8_t *flag = nullptr;   // [max_queries]: queries the grid search could not certify
     int32_t *nflag = nullptr;  // two counters used alternately (as NNGrid)
     int parity = 0;
@@ -231,10 +235,11 @@ struct TriGrid {
     bool ready = false;
     const int32_t *cur_nflag() const { return nflag + parity; }
 };
-int tri_grid_build(gingr_ctx *ctx, const double *vsoa_host, int64_t n, const int32_t *tri_host, int64_t T, int64_t max_queries, TriGrid *g);
+int tri_grid_build(gingr_ctx *ctx, const double *vsoa_host, int64_t n, const int32_t *tri_host, const int32_t *tri_orig_host, int64_t T,
+                   int64_t max_queries, TriGrid *g);
 void tri_grid_free(TriGrid *g);
 void launch_surface_cp_grid(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T, TriGrid &g,
-                            const double *tribox, double *cp_soa, double *d2, int32_t *tri_out, int32_t *warm);
+                            double *cp_soa, double *d2, int32_t *tri_out, int32_t *warm);
 // bary[3 i + k] = weight of corner k of triangle tri_id[i] at the closest point of that triangle to query i; tri_by_orig [3 T]:
 // corner positions in the cloud v, indexed by ORIGINAL triangle number
 void launch_barycentric(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri_by_orig, const int32_t *tri_id, double *bary);

@@ -130,7 +130,7 @@ int gingr_ctx_set_option(gingr_ctx *ctx, int32_t option, int32_t value) {
         case GINGR_OPT_CULL: ctx->cull = value != 0; return GINGR_OK;
         case GINGR_OPT_FINE_CULL: ctx->fine_override = value < 0 ? -1 : (value != 0); return GINGR_OK;
         case GINGR_OPT_NN_GRID: ctx->nn_grid = value < 0 ? 0 : (value > 2 ? 2 : value); return GINGR_OK;
-        case GINGR_OPT_TRI_GRID: ctx->tri_grid = value != 0; return GINGR_OK;
+        case GINGR_OPT_TRI_GRID: ctx->tri_grid = value < 0 ? 0 : (value > 2 ? 2 : value); return GINGR_OK;
         default: return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "ctx_set_option: unknown option %d", option);
     }
 }

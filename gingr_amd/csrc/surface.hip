@@ -435,19 +435,32 @@ __global__ __launch_bounds__(kCpThreads) void surface_cp_queue_kernel(Cloud q, C
 // from the surface, the early iterations), a cold start, or a non-finite query is FLAGGED and answered by the masked tile scan
 // (surface_cp_queue_kernel) that follows.  kLanes lanes per query take the cells of the block in turn; a triangle listed in several
 // cells is evaluated more than once with the same result.
-constexpr int kTriGridMaxCells = 64;
+#ifndef GINGR_TRI_GRID_LANES
+#define GINGR_TRI_GRID_LANES 16
+#endif
+#ifndef GINGR_TRI_GRID_CELLS
+#define GINGR_TRI_GRID_CELLS 64
+#endif
+constexpr int kTriGridMaxCells = GINGR_TRI_GRID_CELLS;
+constexpr int kTriGridCand = 96;  // candidates (entries that pass the box test and the home-cell rule) kept per query; more: the tile scan
+constexpr int kTriRec = 10;       // doubles per grid entry behind its box: corners A, B, C, {position | original index << 32}
+constexpr int kTriGridMaxSpan = 3;  // a listed triangle's box spans at most this many cell steps per axis (wider ones: the short list)
 
 template <int kLanes>
 __global__ __launch_bounds__(256) void surface_cp_grid_kernel(Cloud q, Cloud v, const int32_t *__restrict__ tri,
                                                              const int32_t *__restrict__ tri_orig, int64_t T, TriGridDev g,
-                                                             const double *__restrict__ tribox, double *__restrict__ cp,
-                                                             double *__restrict__ d2out, int32_t *__restrict__ tri_out,
+                                                             double *__restrict__ cp, double *__restrict__ d2out,
+                                                             int32_t *__restrict__ tri_out,
                                                              int32_t *warm /* in: last closest triangle, out: this one's */,
                                                              uint8_t *__restrict__ flag, int32_t *__restrict__ nflag,
                                                              int32_t *__restrict__ nflag_next) {
+    static_assert(kLanes == 32 || kLanes == 16 || kLanes == 8, "sub-wave ballots below");
+    constexpr int QPB = 256 / kLanes;
+    __shared__ int32_t cell_s[QPB][kTriGridMaxCells], cell_off[QPB][kTriGridMaxCells + 1];
+    __shared__ int32_t cand[QPB][kTriGridCand];
     if (blockIdx.x == 0 && threadIdx.x == 0) *nflag_next = 0;  // the counter of the NEXT search (nobody reads it during this one)
-    const int ql = threadIdx.x % kLanes;
-    const int64_t i = (int64_t)blockIdx.x * (256 / kLanes) + threadIdx.x / kLanes;
+    const int ql = threadIdx.x % kLanes, qi = threadIdx.x / kLanes, wslot = (threadIdx.x & 63) / kLanes;  // wslot: the query's slot in its wave
+    const int64_t i = (int64_t)blockIdx.x * QPB + qi;
     const bool ok = i < q.n;
     const double qx = ok ? q.x[i] : 0.0, qy = ok ? q.y[i] : 0.0, qz = ok ? q.z[i] : 0.0;
     const V3 p{qx, qy, qz};
@@ -455,25 +468,28 @@ __global__ __launch_bounds__(256) void surface_cp_grid_kernel(Cloud q, Cloud v, 
     unsigned bo = 0xFFFFFFFFu;
     int bpos = -1;
     V3 bp{qx, qy, qz};
-    auto consider = [&](int64_t pos) {
-        const int32_t va = tri[3 * pos], vb = tri[3 * pos + 1], vc = tri[3 * pos + 2];
-        const V3 c = closest_on_triangle(p, V3{v.x[va], v.y[va], v.z[va]}, V3{v.x[vb], v.y[vb], v.z[vb]}, V3{v.x[vc], v.y[vc], v.z[vc]});
+    auto consider = [&](V3 A, V3 B, V3 C, int pos, unsigned o) {
+        const V3 c = closest_on_triangle(p, A, B, C);
         const V3 dd = sub(c, p);
         const double dist = (dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z;
-        const unsigned o = (unsigned)(tri_orig ? tri_orig[pos] : (int32_t)pos);
         if (dist < best || (dist == best && o < bo)) {
             best = dist;
             bo = o;
-            bpos = (int)pos;
+            bpos = pos;
             bp = c;
         }
     };
     bool fl = ok;  // flagged unless the block below certifies the answer
-    if (ok) {
+    if (ok) {  // (uniform over the kLanes lanes of a query)
         const int32_t tg = warm[i];
-        if (tg >= 0 && tg < T) consider(tg);
+        if (tg >= 0 && tg < T) {  // every lane of the query evaluates the warm triangle: the same bound everywhere
+            const int32_t va = tri[3 * (int64_t)tg], vb = tri[3 * (int64_t)tg + 1], vc = tri[3 * (int64_t)tg + 2];
+            consider(V3{v.x[va], v.y[va], v.z[va]}, V3{v.x[vb], v.y[vb], v.z[vb]}, V3{v.x[vc], v.y[vc], v.z[vc]}, (int)tg,
+                     (unsigned)(tri_orig ? tri_orig[tg] : tg));
+        }
         if (best < __builtin_huge_val()) {  // (NaN / no warm triangle: stays flagged)
-            const double r = sqrt(best) * (1.0 + 1e-9) + 1e-300;
+            const double bound = best;  // the ball every candidate is tested against (the running best only shrinks inside it)
+            const double r = sqrt(bound) * (1.0 + 1e-9) + 1e-300;
             const double f0[3] = {(qx - r - g.lo[0]) * g.inv_h, (qy - r - g.lo[1]) * g.inv_h, (qz - r - g.lo[2]) * g.inv_h};
             const double f1[3] = {(qx + r - g.lo[0]) * g.inv_h, (qy + r - g.lo[1]) * g.inv_h, (qz + r - g.lo[2]) * g.inv_h};
             bool fin = true;
@@ -485,31 +501,69 @@ __global__ __launch_bounds__(256) void surface_cp_grid_kernel(Cloud q, Cloud v, 
                 c0[d] = a >= (double)(g.g[d] - 1) ? g.g[d] - 1 : (a > 0.0 ? (int)a : 0);
                 c1[d] = b >= (double)(g.g[d] - 1) ? g.g[d] - 1 : (b > 0.0 ? (int)b : 0);
             }
-            const int nx = c1[0] - c0[0] + 1, ny = c1[1] - c0[1] + 1, nz = c1[2] - c0[2] + 1;
-            if (fin && (int64_t)nx * ny * nz <= kTriGridMaxCells) {
-                fl = false;
-                const int ncell = nx * ny * nz;
-                for (int k = ql; k < ncell; k += kLanes) {
-                    const int cz = k / (nx * ny), rem = k - cz * nx * ny, cy = rem / nx, cx = rem - cy * nx;
-                    const int64_t c = ((int64_t)(c0[2] + cz) * g.g[1] + (c0[1] + cy)) * g.g[0] + (c0[0] + cx);
-                    const int32_t e1 = g.cell_start[c + 1];
-                    for (int32_t e = g.cell_start[c]; e < e1; ++e) {
-                        const int32_t pos = g.tris[e];
-                        const double *bx = tribox + 6 * (int64_t)pos;
-                        if (point_box_gap2(qx, qy, qz, bx) > best) continue;  // (equal: a possible tie, evaluated)
-                        // a triangle listed in several cells of the block is evaluated in ONE of them: the cell that holds the
-                        // lower corner of (its box clipped to the block) -- the same clamped floor as the binning
-                        const double fx = floor((bx[0] - g.lo[0]) * g.inv_h), fy = floor((bx[1] - g.lo[1]) * g.inv_h),
-                                     fz = floor((bx[2] - g.lo[2]) * g.inv_h);
-                        const int hx = fx >= (double)(g.g[0] - 1) ? g.g[0] - 1 : (fx > 0.0 ? (int)fx : 0);
-                        const int hy = fy >= (double)(g.g[1] - 1) ? g.g[1] - 1 : (fy > 0.0 ? (int)fy : 0);
-                        const int hz = fz >= (double)(g.g[2] - 1) ? g.g[2] - 1 : (fz > 0.0 ? (int)fz : 0);
-                        if ((hx > c0[0] ? hx : c0[0]) != c0[0] + cx || (hy > c0[1] ? hy : c0[1]) != c0[1] + cy ||
-                            (hz > c0[2] ? hz : c0[2]) != c0[2] + cz)
-                            continue;
-                        consider(pos);
+            // every listed triangle sits in the cell of its box's lower corner: the cells [c0 - span, c1] hold all that reach the ball;
+            // along x they are ONE contiguous run of entries per (y, z) row
+            const int x0 = c0[0] > g.span[0] ? c0[0] - g.span[0] : 0, y0 = c0[1] > g.span[1] ? c0[1] - g.span[1] : 0,
+                      z0 = c0[2] > g.span[2] ? c0[2] - g.span[2] : 0;
+            const int ny = c1[1] - y0 + 1, nz = c1[2] - z0 + 1;
+            if (fin && ny * nz + 1 <= kTriGridMaxCells) {
+                const int nrow = ny * nz, nrun = nrow + (g.n_big > 0 ? 1 : 0);
+                // (1) the entry run of every row, one row per lane; the short list of wide triangles is one more run
+                for (int k = ql; k < nrun; k += kLanes) {
+                    int32_t s0, n0;
+                    if (k < nrow) {
+                        const int rz = k / ny, ry = k - rz * ny;
+                        const int64_t rowbase = ((int64_t)(z0 + rz) * g.g[1] + (y0 + ry)) * g.g[0];
+                        s0 = g.cell_start[rowbase + x0];
+                        n0 = g.cell_start[rowbase + c1[0] + 1] - s0;
+                    } else {
+                        s0 = g.n_listed;
+                        n0 = g.n_big;
                     }
+                    cell_s[qi][k] = s0;
+                    cell_off[qi][k + 1] = n0;
                 }
+                __threadfence_block();
+                if (ql == 0) {  // exclusive prefix over at most 64 counts
+                    int32_t off = 0;
+                    for (int k = 0; k < nrun; ++k) {
+                        const int32_t n = cell_off[qi][k + 1];
+                        cell_off[qi][k] = off;
+                        off += n;
+                    }
+                    cell_off[qi][nrun] = off;
+                }
+                __threadfence_block();
+                const int32_t total = cell_off[qi][nrun];
+                // (2) all entries of the runs, flattened over the lanes: the box against the ball; survivors go to the query's list
+                int ncand = 0, k = 0;
+                bool overflow = false;
+                for (int32_t base = 0; base < total; base += kLanes) {
+                    const int32_t idx = base + ql;
+                    bool pass = false;
+                    int32_t e = 0;
+                    if (idx < total) {
+                        while (cell_off[qi][k + 1] <= idx) ++k;
+                        e = cell_s[qi][k] + (idx - cell_off[qi][k]);
+                        pass = !(point_box_gap2(qx, qy, qz, g.boxes + (int64_t)e * 6) > bound);  // (equal: a possible tie, evaluated)
+                    }
+                    const unsigned hm = (unsigned)(__ballot(pass) >> (kLanes * wslot)) & (kLanes == 32 ? 0xffffffffu : ((1u << (kLanes & 31)) - 1u));
+                    if (pass) {
+                        const int slot = ncand + __builtin_popcount(hm & ((1u << ql) - 1u));
+                        if (slot < kTriGridCand) cand[qi][slot] = e;
+                    }
+                    ncand += __builtin_popcount(hm);
+                }
+                if (ncand > kTriGridCand) overflow = true, ncand = 0;
+                __threadfence_block();
+                // (3) the exact routine on the survivors, one per lane
+                for (int c = ql; c < ncand; c += kLanes) {
+                    const double *rc = g.recs + (int64_t)cand[qi][c] * kTriRec;
+                    const long long meta = __builtin_bit_cast(long long, rc[9]);
+                    consider(V3{rc[0], rc[1], rc[2]}, V3{rc[3], rc[4], rc[5]}, V3{rc[6], rc[7], rc[8]}, (int)(meta & 0xffffffffLL),
+                             (unsigned)((unsigned long long)meta >> 32));
+                }
+                fl = overflow;
             }
         }
     }
@@ -1001,7 +1055,8 @@ void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_
 
 void tri_grid_free(TriGrid *g) {
     if (g->cell_start) (void)hipFree(g->cell_start);
-    if (g->tris) (void)hipFree(g->tris);
+    if (g->boxes) (void)hipFree(g->boxes);
+    if (g->recs) (void)hipFree(g->recs);
     if (g->flag) (void)hipFree(g->flag);
     if (g->nflag) (void)hipFree(g->nflag);
     *g = TriGrid{};
@@ -1009,7 +1064,8 @@ void tri_grid_free(TriGrid *g) {
 
 // vsoa: host, the mesh vertices as SoA planes [3][n] in DEVICE order; tri: host, [3 T] vertex positions in the (spatially sorted)
 // triangle order of the device.  Synchronous.  No grid (g->ready false) for degenerate extents: the callers keep the tile scan.
-int tri_grid_build(gingr_ctx *ctx, const double *vsoa, int64_t n, const int32_t *tri, int64_t T, int64_t max_queries, TriGrid *g) {
+int tri_grid_build(gingr_ctx *ctx, const double *vsoa, int64_t n, const int32_t *tri, const int32_t *tri_orig, int64_t T, int64_t max_queries,
+                   TriGrid *g) {
     tri_grid_free(g);
     if (T < 1 || T > INT32_MAX || n < 1 || max_queries < 1) return GINGR_OK;
     double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
@@ -1043,7 +1099,7 @@ int tri_grid_build(gingr_ctx *ctx, const double *vsoa, int64_t n, const int32_t 
     double size[3], maxext = 0.0;
     for (int d = 0; d < 3; ++d) size[d] = hi[d] - lo[d], maxext = std::max(maxext, size[d]);
     if (!(maxext > 0.0) || !(maxext < 1e300)) return GINGR_OK;
-    // cell edge = the mean extent of a triangle's box: a triangle then overlaps ~4 cells of a surface, a cell lists ~10 triangles
+    // cell edge = the mean extent of a triangle's box
     double h = ext_sum / (double)ngood;
     if (!(h > 1e-9 * maxext)) h = 1e-9 * maxext;
     int32_t gd[3];
@@ -1064,36 +1120,66 @@ int tri_grid_build(gingr_ctx *ctx, const double *vsoa, int64_t n, const int32_t 
         return c >= (double)(gd[d] - 1) ? gd[d] - 1 : (c > 0.0 ? (int32_t)c : 0);
     };
     const int64_t ncells = (int64_t)gd[0] * gd[1] * gd[2];
-    std::vector<int32_t> start((size_t)ncells + 1, 0);
-    auto for_cells = [&](int64_t t, auto fn) {
-        int32_t a[3], b[3];
-        for (int d = 0; d < 3; ++d) a[d] = cell_of(tb[(size_t)6 * t + d], d), b[d] = cell_of(tb[(size_t)6 * t + 3 + d], d);
-        for (int32_t z = a[2]; z <= b[2]; ++z)
-            for (int32_t y = a[1]; y <= b[1]; ++y)
-                for (int32_t x = a[0]; x <= b[0]; ++x) fn(((int64_t)z * gd[1] + y) * gd[0] + x);
-    };
-    int64_t total = 0;
-    for (int64_t t = 0; t < T; ++t)
-        if (good[(size_t)t]) for_cells(t, [&](int64_t c) { start[(size_t)c + 1]++; ++total; });
-    if (total > 64 * T + 4096 || total > INT32_MAX) return GINGR_OK;  // huge triangles in a fine grid: keep the tile scan
+    // Every triangle is listed ONCE, in the cell of its box's lower corner; a query then looks at the cells [c0 - E, c1] per axis,
+    // E = the largest extent (in cells) of a listed triangle's box -- any triangle whose box reaches into the ball [c0, c1] has its
+    // lower corner there.  Triangles spanning more than kTriGridMaxSpan cells of an axis go to a short list every query tests.
+    std::vector<int32_t> start((size_t)ncells + 1, 0), hcell((size_t)T, -1), big;
+    int32_t E[3] = {0, 0, 0};
+    for (int64_t t = 0; t < T; ++t) {
+        if (!good[(size_t)t]) continue;
+        int32_t a[3], ex[3];
+        bool wide = false;
+        for (int d = 0; d < 3; ++d) {
+            a[d] = cell_of(tb[(size_t)6 * t + d], d);
+            ex[d] = cell_of(tb[(size_t)6 * t + 3 + d], d) - a[d];
+            wide = wide || ex[d] > kTriGridMaxSpan;
+        }
+        if (wide) {
+            big.push_back((int32_t)t);
+            continue;
+        }
+        for (int d = 0; d < 3; ++d) E[d] = std::max(E[d], ex[d]);
+        hcell[(size_t)t] = (int32_t)(((int64_t)a[2] * gd[1] + a[1]) * gd[0] + a[0]);
+        start[(size_t)hcell[(size_t)t] + 1]++;
+    }
+    if (big.size() > 256) return GINGR_OK;  // many huge triangles in a fine grid: keep the tile scan
     for (int64_t c = 0; c < ncells; ++c) start[(size_t)c + 1] += start[(size_t)c];
+    const int64_t n_listed = start[(size_t)ncells], total = n_listed + (int64_t)big.size();
     std::vector<int32_t> list((size_t)(total > 0 ? total : 1)), fill(start.begin(), start.end() - 1);
     for (int64_t t = 0; t < T; ++t)  // ascending triangle position inside a cell
-        if (good[(size_t)t]) for_cells(t, [&](int64_t c) { list[(size_t)fill[(size_t)c]++] = (int32_t)t; });
+        if (hcell[(size_t)t] >= 0) list[(size_t)fill[(size_t)hcell[(size_t)t]]++] = (int32_t)t;
+    for (size_t k = 0; k < big.size(); ++k) list[(size_t)n_listed + k] = big[k];
+    // per ENTRY, contiguous in cell order: the box (48 bytes, all the first test reads) and, apart from it, corners + {device position |
+    // original index} (80 bytes, read for the survivors).  The mesh is fixed (the target), so nothing is chased through vertex ids.
+    std::vector<double> boxes(list.size() * (size_t)6, 0.0), recs(list.size() * (size_t)kTriRec, 0.0);
+    for (size_t e2 = 0; e2 < (size_t)total; ++e2) {
+        const int64_t t = list[e2];
+        for (int d = 0; d < 6; ++d) boxes[e2 * 6 + d] = tb[(size_t)6 * t + d];
+        double *rc = recs.data() + e2 * kTriRec;
+        for (int c = 0; c < 3; ++c)
+            for (int d = 0; d < 3; ++d) rc[3 * c + d] = vsoa[(size_t)d * n + tri[3 * t + c]];
+        const long long meta = (long long)(((unsigned long long)(uint32_t)(tri_orig ? tri_orig[t] : (int32_t)t) << 32) | (unsigned long long)(uint32_t)t);
+        memcpy(rc + 9, &meta, sizeof(meta));
+    }
+    HIP_TRY(ctx, hipMalloc(&g->boxes, boxes.size() * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpyAsync(g->boxes, boxes.data(), boxes.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMalloc(&g->recs, recs.size() * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpyAsync(g->recs, recs.data(), recs.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMalloc(&g->cell_start, start.size() * sizeof(int32_t)));
-    HIP_TRY(ctx, hipMalloc(&g->tris, list.size() * sizeof(int32_t)));
     HIP_TRY(ctx, hipMalloc(&g->flag, (size_t)max_queries));
     HIP_TRY(ctx, hipMalloc(&g->nflag, 2 * sizeof(int32_t)));
     HIP_TRY(ctx, hipMemcpyAsync(g->cell_start, start.data(), start.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(g->tris, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(g->flag, 0, (size_t)max_queries, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(g->nflag, 0, 2 * sizeof(int32_t), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (int d = 0; d < 3; ++d) g->v.lo[d] = lo[d], g->v.g[d] = gd[d];
+    for (int d = 0; d < 3; ++d) g->v.lo[d] = lo[d], g->v.g[d] = gd[d], g->v.span[d] = E[d];
     g->v.h = h;
     g->v.inv_h = inv_h;
     g->v.cell_start = g->cell_start;
-    g->v.tris = g->tris;
+    g->v.boxes = g->boxes;
+    g->v.recs = g->recs;
+    g->v.n_listed = (int32_t)n_listed;
+    g->v.n_big = (int32_t)big.size();
     g->max_queries = max_queries;
     g->list_entries = total;
     g->ready = true;
@@ -1103,12 +1189,12 @@ int tri_grid_build(gingr_ctx *ctx, const double *vsoa, int64_t n, const int32_t 
 // closest point of every query the grid certifies (warm start required: `warm` holds last scan's triangles); the others are flagged
 // (g.flag, g.cur_nflag()) for the masked launch_surface_closest_point that must follow
 void launch_surface_cp_grid(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T, TriGrid &g,
-                            const double *tribox, double *cp_soa, double *d2, int32_t *tri_out, int32_t *warm) {
+                            double *cp_soa, double *d2, int32_t *tri_out, int32_t *warm) {
     g.parity ^= 1;
     int32_t *cur = g.nflag + g.parity, *next = g.nflag + (g.parity ^ 1);
-    constexpr int kLanes = 32;  // (8 lanes: 120 us at 41k x 82k -- a lane then walks ~8 cells' lists one dependent load after the other)
+    constexpr int kLanes = GINGR_TRI_GRID_LANES;  // queries per wave = 64 / kLanes: their entries and candidates are spread over the lanes
     hipLaunchKernelGGL(surface_cp_grid_kernel<kLanes>, dim3((unsigned)ceil_div(q.n, 256 / kLanes)), dim3(256), 0, ctx->stream, q, v, tri, tri_orig,
-                       T, g.v, tribox, cp_soa, d2, tri_out, warm, g.flag, cur, next);
+                       T, g.v, cp_soa, d2, tri_out, warm, g.flag, cur, next);
 }
 
 int distance_stats_ws_doubles() { return kStatBlocks * 4; }

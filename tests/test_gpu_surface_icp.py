@@ -325,16 +325,18 @@ def test_benchmark_size_correspondence_against_sampled_oracle(ctx):
 
 
 def test_triangle_grid_search_is_bit_identical_to_the_tile_scan():
-    """GINGR_OPT_TRI_GRID = 1: the closest surface point searched over a grid of the (fixed) target triangles, warm-started from the
+    """GINGR_OPT_TRI_GRID: the closest surface point searched over a grid of the (fixed) target triangles, warm-started from the
     previous iteration, with the masked tile scan for what the grid cannot certify -- same closest points, same weights, same
-    trajectory bit for bit as the tile scan alone (the default)."""
+    trajectory bit for bit as the tile scan alone (0).  2 forces the grid on this small mesh (1, the default, takes it from 16 384
+    target triangles on); the sphere pair below is large enough for the default."""
     import gingr_amd as ga
     from gingr_amd import _native as nat
     ref, cells, target, tcells = femur()
     out = []
-    for tri_grid in (0, 1):
+    for tri_grid in (0, 2):
         c = ga.Context(0)
         c.set_option(nat.OPT_TRI_GRID, tri_grid)
+        assert c.get_option(nat.OPT_TRI_GRID) == tri_grid
         mo, algo, state = make_state(c, ref, cells, target, tcells, rank=20, initial_pose=((0.02, -0.03, 0.01), (1.0, -2.0, 0.5)))
         for _ in range(5):
             state = algo.update(state)
@@ -344,3 +346,28 @@ def test_triangle_grid_search_is_bit_identical_to_the_tile_scan():
         c.close()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
     assert out[0][3] == out[1][3]
+
+
+def test_triangle_grid_default_on_a_large_mesh_equals_the_tile_scan():
+    """20 480 target triangles (icosphere level 5): the default takes the grid; wide balls at the start (flagged queries go to the masked
+    tile scan), narrow ones later; a few huge triangles would go to the short list (none here).  Bit-identical to the tile scan."""
+    import gingr_amd as ga
+    from gingr_amd import _native as nat
+    tv, tt = _icosphere(5)
+    rv, rt = _icosphere(4)
+    target = 30.0 * tv * (1.0 + 0.05 * np.sin(3.0 * tv[:, :1]) * np.cos(2.0 * tv[:, 1:2]))
+    ref = 29.0 * rv
+    assert tt.shape[0] >= 16384
+    out = []
+    for tri_grid in (0, 1):
+        c = ga.Context(0)
+        c.set_option(nat.OPT_TRI_GRID, tri_grid)
+        mo, algo, state = make_state(c, ref, rt, target, tt, rank=16, initial_pose=((0.03, -0.02, 0.01), (0.8, -0.5, 0.3)), sigma=(4.0, 1.0))
+        for _ in range(6):
+            state = algo.update(state)
+        cp, w = algo.surfaceCorrespondence(state)
+        out.append((np.array(state.general.fit), cp.copy(), w.copy(), state.general.sigma2))
+        algo.close()
+        c.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert out[0][3] == out[1][3] and out[0][2].sum() > 0

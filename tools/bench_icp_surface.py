@@ -51,7 +51,7 @@ R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
 target = (ref * bump[:, None]) @ R.T + np.array([1.5, -1.0, 0.5])
 ctx = ga.Context(0)
 from gingr_amd import _native as nat
-ctx.set_option(nat.OPT_TRI_GRID, int(OPTS.get("tri_grid", 0)))
+ctx.set_option(nat.OPT_TRI_GRID, int(OPTS.get("tri_grid", 1)))
 model = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.0, maxRank=100).Gaussian(40.0, 10.0)
 model.cells = cells
 algo = ga.IcpRegistration(ctx)
@@ -70,5 +70,5 @@ print(json.dumps({"what": "ICP update, surface correspondence (closest point on 
                   "vertices": int(ref.shape[0]), "triangles": int(cells.shape[0]), "rank": model.rank,
                   "iterations_per_s_host_boundary": n / dt, "ms_per_iteration": dt / n * 1e3,
                   "accepted_fraction_first_iteration": float(w.mean()), "status": int(state.general.status),
-                  "sigma2": float(state.general.sigma2), "tri_grid": int(OPTS.get("tri_grid", 0)),
+                  "sigma2": float(state.general.sigma2), "tri_grid": int(OPTS.get("tri_grid", 1)),
                   "fit_checksum": float(np.abs(np.asarray(state.general.fit)).sum())}))

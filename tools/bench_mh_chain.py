@@ -20,13 +20,18 @@ import torch  # noqa: F401  (first: one HIP runtime per process)
 import gingr_amd as ga
 from gingr_amd import sampling as sp
 
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-fused = not (len(sys.argv) > 3 and sys.argv[3] == "nofuse")
+OPTS = dict(a.split("=") for a in sys.argv[1:] if "=" in a)       # tri_grid=0|1: GINGR_OPT_TRI_GRID for this run
+POS = [a for a in sys.argv[1:] if "=" not in a]
+steps = int(POS[0]) if len(POS) > 0 else 300
+seed = int(POS[1]) if len(POS) > 1 else 0
+fused = not (len(POS) > 2 and POS[2] == "nofuse")
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 d, m = np.load(os.path.join(root, "inputs.npz")), np.load(os.path.join(root, "femur_mesh.npz"))
 ref, target = d["femur"].astype(np.float64), d["femur_target"].astype(np.float64)
 ctx = ga.Context(0)
+if "tri_grid" in OPTS:
+    from gingr_amd import _native as nat
+    ctx.set_option(nat.OPT_TRI_GRID, int(OPTS["tri_grid"]))
 model = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.01).Gaussian(sigma=70.0, scaling=50.0)
 model.cells = m["femur_cells"]
 algo = ga.IcpRegistration(ctx)
