@@ -71,12 +71,12 @@ const char *gingr_build_info(void);
  *   GINGR_OPT_CULL       1 (default) / 0: exact-zero tile culling of the CPD passes and exact pruning of the closest-point scans
  *   GINGR_OPT_FINE_CULL  -1 (default: by the regime the device reports) / 0 / 1: quarter-tile culling variant of the CPD passes
  *   GINGR_OPT_NN_GRID    1 (default) / 0: the ICP closest point searches the target's uniform grid first / tile scan only;
- *                        2: as 1, and the stateless gingr_nn searches a grid too (built per call; from a cold start the
- *                        box-pruned scan it uses by default is faster)
+ *                        2: as 1, and the stateless gingr_nn searches a grid too (built per call; from a cold start its
+ *                        default forms -- all pairs up to 2^26 of them, the box-pruned scan above -- are faster)
  *   GINGR_OPT_TRI_GRID   0 / 1 (default) / 2: the surface ICP's closest surface point searches a grid of the (fixed) target triangles
  *                        first, warm-started from the previous iteration, and the tile scan only answers what the grid cannot certify:
  *                        never / from 16 384 target triangles on / always
- */
+ * No reference counterpart (the reference has one code path per operation). */
 typedef enum gingr_ctx_option { GINGR_OPT_CULL = 0, GINGR_OPT_FINE_CULL = 1, GINGR_OPT_NN_GRID = 2, GINGR_OPT_TRI_GRID = 3 } gingr_ctx_option;
 int gingr_ctx_set_option(gingr_ctx *ctx, int32_t option, int32_t value);
 int gingr_ctx_get_option(gingr_ctx *ctx, int32_t option, int32_t *value);
