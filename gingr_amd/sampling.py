@@ -74,8 +74,12 @@ class _Memoize:
         self.f, self.n, self.keys, self.vals = f, n, [], []
 
     def __call__(self, state):
-        for k, v in zip(self.keys, self.vals):
+        for i, k in enumerate(self.keys):
             if k is state:
+                v = self.vals[i]
+                if i != len(self.keys) - 1:      # least recently USED goes first: the current sample of a chain is asked about every
+                    self.keys.append(self.keys.pop(i))   # step and must not age out behind three rejected proposals (a cache only:
+                    self.vals.append(self.vals.pop(i))   # the values are the same either way)
                 return v
         v = self.f(state)
         self.keys.append(state)
