@@ -371,3 +371,38 @@ def test_triangle_grid_default_on_a_large_mesh_equals_the_tile_scan():
         c.close()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
     assert out[0][3] == out[1][3] and out[0][2].sum() > 0
+
+
+def test_triangle_grid_with_wide_triangles_and_a_flat_mesh_equals_the_tile_scan():
+    """The corners of the grid's binning: a few triangles far wider than a cell (the short list every query tests), a target that is
+    flat along one axis (one layer of cells), queries far outside the grid (clamped cells, big balls: flagged for the tile scan).
+    Forced grid against the tile scan, bit for bit."""
+    import gingr_amd as ga
+    from gingr_amd import _native as nat
+    tv, tt = _icosphere(4)
+    target = 30.0 * tv
+    n0 = target.shape[0]
+    # two huge triangles cutting through the sphere's neighbourhood + a fan of three more sharing a far apex
+    extra = np.array([[-80.0, -80.0, 31.0], [80.0, -80.0, 31.5], [0.0, 90.0, 30.5], [0.0, 0.0, 140.0]])
+    target = np.concatenate([target, extra])
+    tt = np.concatenate([tt, np.array([[n0, n0 + 1, n0 + 2], [n0, n0 + 1, n0 + 3], [n0 + 1, n0 + 2, n0 + 3], [n0 + 2, n0, n0 + 3]],
+                                      dtype=np.int32)])
+    rv, rt = _icosphere(3)
+    cases = [(28.0 * rv, rt, target, tt, ((0.02, -0.01, 0.03), (0.5, -0.4, 2.5)))]
+    gv, gt = grid_mesh(40, 50.0, 0.0, 3)                      # a flat sheet as target, the template hovering over it and beyond it
+    gv[:, 2] = 0.0
+    sv, st = grid_mesh(24, 70.0, 2.0, 4)
+    cases.append((sv + np.array([0.0, 0.0, 1.5]), st, gv, gt, ((0.0, 0.0, 0.02), (0.3, 0.2, 0.0))))
+    for ref, cells, tgt, tcells, pose in cases:
+        out = []
+        for tri_grid in (0, 2):
+            c = ga.Context(0)
+            c.set_option(nat.OPT_TRI_GRID, tri_grid)
+            mo, algo, state = make_state(c, ref, cells, tgt, tcells, rank=12, initial_pose=pose, sigma=(4.0, 1.0))
+            for _ in range(4):
+                state = algo.update(state)
+            cp, w = algo.surfaceCorrespondence(state)
+            out.append((np.array(state.general.fit), cp.copy(), w.copy()))
+            algo.close()
+            c.close()
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
