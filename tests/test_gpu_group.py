@@ -191,13 +191,13 @@ def _femur_case(rank=24):
     return mo, cells, target, tcells
 
 
-def _group(devs, mo, target, cells=None, tcells=None, transform=1):
+def _group(devs, mo, target, cells=None, tcells=None, transform=1, method=0):
     import gingr_amd as ga
     g = ga.DeviceGroup(devs)
     g.upload_model(mo.ref, mo.mean, mo.U, mo.lam)
     g.set_target(target)
     if cells is not None:
-        g.set_meshes(cells, tcells)
+        g.set_meshes(cells, tcells, method)
     g.set_options(transform, 1.0)
     return g
 
@@ -309,6 +309,32 @@ def test_group_reversed_direction_equals_single_shard(nshards, flavour):
         _set(g, a0, sc0)
         g.update(flavour, params, 1)
     assert rel(multi.get_state()[2], single.get_state()[2]) < 1e-9
+    single.close()
+    multi.close()
+
+
+@pytest.mark.parametrize("reversed_direction", [False, True])
+def test_group_along_normal_correspondence_equals_single_shard(reversed_direction):
+    """correspondenceMethod = AlongNormalClosestPoint (ClosestPointRegistrator.scala:102-131: the intersection of the vertex normal with the
+    other mesh nearest to the vertex) on three row shards, forward and reversed, update by update from identical states."""
+    from gingr_amd import _native as nat
+    mo, cells, target, tcells = _femur_case()
+    params = (20.0, 1.0, 30)
+    single = _group([0], mo, target, cells, tcells, method=1)
+    multi = _group(_devices(3), mo, target, cells, tcells, method=1)
+    for g in (single, multi):
+        g.set_correspondence_direction(reversed_direction)
+    single.set_state(np.zeros(mo.rank), 20.0, translation=(0.6, -1.0, 0.4), euler=(0.01, -0.02, 0.01))
+    for it in range(3):
+        a0, sc0, fit0 = single.get_state()
+        _set(multi, a0, sc0)
+        single.update(nat.FLAVOUR_ICP_SURFACE, params, 1)
+        multi.update(nat.FLAVOUR_ICP_SURFACE, params, 1)
+        a1, sc1, fit1 = single.get_state()
+        a2, sc2, fit2 = multi.get_state()
+        assert sc1.status == sc2.status == 0
+        assert rel(fit2, fit1) < 1e-9 and rel(a2, a1) < 1e-7, (it, rel(fit2, fit1))
+        assert rel(fit1, fit0) > 1e-7
     single.close()
     multi.close()
 
