@@ -1372,7 +1372,14 @@ constexpr int kPT = GINGR_PT_DEFAULT;     // points per thread in both CPD passe
 // Row statistics of a TINY shard: two points per thread halve the workgroup's rows (more workgroups along the row axis, a fourth
 // workgroup per CU).  With round 2's work split (a workgroup owns 256 rows whatever PT is) four points per thread win from a few
 // thousand rows on: 8-GPU shard of the 50k workload (6250 rows) 0.50 ms per iteration with PT = 2, 0.49 ms with PT = 4.
-constexpr int64_t kSmallShardRows = 2048;
+#ifndef GINGR_SMALL_COLSUM_COLS
+#define GINGR_SMALL_COLSUM_COLS 16384
+#endif
+#ifndef GINGR_SMALL_SHARD_ROWS
+#define GINGR_SMALL_SHARD_ROWS 2048
+#endif
+constexpr int64_t kSmallShardRows = GINGR_SMALL_SHARD_ROWS;
+constexpr int64_t kSmallColsumCols = GINGR_SMALL_COLSUM_COLS;
 // Build-time knobs of the chunk planner (the sweeps behind the defaults: tools/chunk_sweep.sh, tools/small_chunk_sweep.sh build the
 // library with -DGINGR_...=v through tools/abn.sh; none of them is read from the environment):
 //   GINGR_ROWSTATS_PT        2 or 4 points per thread in the row-statistics pass whatever the shard size (0: by shard size)
@@ -1397,10 +1404,22 @@ constexpr int64_t kSmallShardRows = 2048;
 #ifndef GINGR_FAIR_PRIORITY
 #define GINGR_FAIR_PRIORITY 1
 #endif
-inline int rowstats_pt(int64_t rows) {
+#ifndef GINGR_COLSUM_PT
+#define GINGR_COLSUM_PT 0
+#endif
+// owned points (targets) per thread of the column-sum pass: small target clouds take 2 -- twice the workgroups of a launch that
+// fills a fifth of the chip at femur size (GINGR_COLSUM_PT: build-time override for the sweep)
+inline int colsum_pt(int64_t cols) {
+    constexpr int forced = GINGR_COLSUM_PT;
+    if (forced == 2 || forced == kPT) return forced;
+    return (kPT > 2 && cols <= kSmallColsumCols) ? 2 : kPT;
+}
+// owned points (rows) per thread of the row-statistics pass: 2 on short shards (few row blocks whatever the target count) and on
+// problems that are small on BOTH sides (15k x 15k: 0.354 -> 0.348 ms; a 6 250-row shard of 50k targets is slower with 2: 0.421 -> 0.435)
+inline int rowstats_pt(int64_t rows, int64_t cols) {
     constexpr int forced = GINGR_ROWSTATS_PT;
     if (forced == 2 || forced == kPT) return forced;
-    return (kPT > 2 && rows <= kSmallShardRows) ? 2 : kPT;
+    return (kPT > 2 && (rows <= kSmallShardRows || (rows <= kSmallColsumCols && cols <= kSmallColsumCols))) ? 2 : kPT;
 }
 // Workgroups per all-pairs launch.  A CU holds 3-4 of them and one lives for (tiles per chunk) x ~30 us, so the launch ends with
 // a tail of about one workgroup's life: many short workgroups beat few long ones until the per-chunk partials (written here,
@@ -1513,14 +1532,14 @@ inline int rowstats_tiles_override() { return GINGR_ROWSTATS_QUARTERS; }
 
 int64_t cpd_colsum_ws_doubles(int64_t M, int64_t N) {
     int nch;
-    plan_chunks(N, 64 * kPT, M, &nch, colsum_tiles_override(), colsum_chunks_override(), resident_workgroups(0));
+    plan_chunks(N, 64 * colsum_pt(N), M, &nch, colsum_tiles_override(), colsum_chunks_override(), resident_workgroups(0));
     return (int64_t)nch * N;
 }
 
 int64_t cpd_rowstats_ws_doubles(int64_t M, int64_t N) {
     int nch;
-    plan_chunks(M, 64 * rowstats_pt(M), N, &nch, rowstats_tiles_override(), rowstats_chunks_override(),
-                resident_workgroups(rowstats_pt(M) == 2 ? 1 : 2));
+    plan_chunks(M, 64 * rowstats_pt(M, N), N, &nch, rowstats_tiles_override(), rowstats_chunks_override(),
+                resident_workgroups(rowstats_pt(M, N) == 2 ? 1 : 2));
     return (int64_t)nch * 4 * M;
 }
 
@@ -1556,15 +1575,19 @@ int launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sig
     {
         TimerScope ts(ctx, 0);
         {
-            const ChunkPlan len = plan_chunks(target.n, 64 * kPT, fit.n, &nch, colsum_tiles_override(), colsum_chunks_override(),
+            const int pt = colsum_pt(target.n);
+            const ChunkPlan len = plan_chunks(target.n, 64 * pt, fit.n, &nch, colsum_tiles_override(), colsum_chunks_override(),
                                               resident_workgroups(0));
-            dim3 grid((unsigned)ceil_div(target.n, 64 * kPT), (unsigned)nch);
+            dim3 grid((unsigned)ceil_div(target.n, 64 * pt), (unsigned)nch);
             const double *boxes = ctx->cull ? fit_boxes : (const double *)nullptr;
             // one variant, picked from the regime the device last reported (stale at worst: the results are the same)
             const bool fine = boxes && (ctx->fine_override >= 0 ? ctx->fine_override != 0
                                                                 : (fit.n >= kFineMinStream && ctx->regime_host &&
                                                                    *(volatile int32_t *)ctx->regime_host != 0));
-            if (fine)
+            if (pt == 2)  // (small clouds never take the quarter-tile culling variant: kFineMinStream)
+                hipLaunchKernelGGL((cpd_colsum_kernel<2, false>), grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux, boxes, len,
+                                   ws, boxes ? ctx->regime_dev : (int32_t *)nullptr);
+            else if (fine)
                 hipLaunchKernelGGL((cpd_colsum_kernel<kPT, true>), grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux,
                                    boxes, len, ws, ctx->regime_dev);
             else
@@ -1593,7 +1616,7 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
     {
         TimerScope ts(ctx, 1);
         {
-            const int pt = rowstats_pt(fit.n);
+            const int pt = rowstats_pt(fit.n, target.n);
             const ChunkPlan len = plan_chunks(fit.n, 64 * pt, target.n, &nch, rowstats_tiles_override(), rowstats_chunks_override(),
                                               resident_workgroups(pt == 2 ? 1 : 2));
             dim3 grid((unsigned)ceil_div(fit.n, 64 * pt), (unsigned)nch);
