@@ -1380,6 +1380,7 @@ constexpr int kPT = GINGR_PT_DEFAULT;     // points per thread in both CPD passe
 #endif
 constexpr int64_t kSmallShardRows = GINGR_SMALL_SHARD_ROWS;
 constexpr int64_t kSmallColsumCols = GINGR_SMALL_COLSUM_COLS;
+constexpr int64_t kTinyCols = 2048;
 // Build-time knobs of the chunk planner (the sweeps behind the defaults: tools/chunk_sweep.sh, tools/small_chunk_sweep.sh build the
 // library with -DGINGR_...=v through tools/abn.sh; none of them is read from the environment):
 //   GINGR_ROWSTATS_PT        2 or 4 points per thread in the row-statistics pass whatever the shard size (0: by shard size)
@@ -1407,18 +1408,20 @@ constexpr int64_t kSmallColsumCols = GINGR_SMALL_COLSUM_COLS;
 #ifndef GINGR_COLSUM_PT
 #define GINGR_COLSUM_PT 0
 #endif
-// owned points (targets) per thread of the column-sum pass: small target clouds take 2 -- twice the workgroups of a launch that
-// fills a fifth of the chip at femur size (GINGR_COLSUM_PT: build-time override for the sweep)
+// owned points (targets) per thread of the column-sum pass: small target clouds take 2, tiny ones 1 -- two / four times the
+// workgroups of a launch that fills a fifth of the chip at femur size (GINGR_COLSUM_PT: build-time override for the sweep)
 inline int colsum_pt(int64_t cols) {
     constexpr int forced = GINGR_COLSUM_PT;
-    if (forced == 2 || forced == kPT) return forced;
+    if (forced == 1 || forced == 2 || forced == kPT) return forced;
+    if (kPT > 2 && cols <= kTinyCols) return 1;  // femur size: 0.0973 -> 0.0950 ms per iteration against 2
     return (kPT > 2 && cols <= kSmallColsumCols) ? 2 : kPT;
 }
-// owned points (rows) per thread of the row-statistics pass: 2 on short shards (few row blocks whatever the target count) and on
+// owned points (rows) per thread of the row-statistics pass: 1 where both clouds are tiny (femur), 2 on short shards (few row blocks whatever the target count) and on
 // problems that are small on BOTH sides (15k x 15k: 0.354 -> 0.348 ms; a 6 250-row shard of 50k targets is slower with 2: 0.421 -> 0.435)
 inline int rowstats_pt(int64_t rows, int64_t cols) {
     constexpr int forced = GINGR_ROWSTATS_PT;
-    if (forced == 2 || forced == kPT) return forced;
+    if (forced == 1 || forced == 2 || forced == kPT) return forced;
+    if (kPT > 2 && rows <= kTinyCols && cols <= kTinyCols) return 1;  // femur size: 0.0950 -> 0.0932 ms per iteration against 2
     return (kPT > 2 && (rows <= kSmallShardRows || (rows <= kSmallColsumCols && cols <= kSmallColsumCols))) ? 2 : kPT;
 }
 // Workgroups per all-pairs launch.  A CU holds 3-4 of them and one lives for (tiles per chunk) x ~30 us, so the launch ends with
@@ -1584,7 +1587,10 @@ int launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sig
             const bool fine = boxes && (ctx->fine_override >= 0 ? ctx->fine_override != 0
                                                                 : (fit.n >= kFineMinStream && ctx->regime_host &&
                                                                    *(volatile int32_t *)ctx->regime_host != 0));
-            if (pt == 2)  // (small clouds never take the quarter-tile culling variant: kFineMinStream)
+            if (pt == 1)
+                hipLaunchKernelGGL((cpd_colsum_kernel<1, false>), grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux, boxes, len,
+                                   ws, boxes ? ctx->regime_dev : (int32_t *)nullptr);
+            else if (pt == 2)  // (small clouds never take the quarter-tile culling variant: kFineMinStream)
                 hipLaunchKernelGGL((cpd_colsum_kernel<2, false>), grid, dim3(kBlock), 0, ctx->stream, fit, target, sigma2_dev, aux, boxes, len,
                                    ws, boxes ? ctx->regime_dev : (int32_t *)nullptr);
             else if (fine)
@@ -1631,7 +1637,9 @@ void launch_cpd_rowstats(gingr_ctx *ctx, Cloud fit, Cloud target, const double *
                                    len, ws, regime_out);
             };
             // one variant, picked from the regime the device last reported (stale at worst: the results are the same)
-            if (pt == 2) {
+            if (pt == 1) {
+                launch(cpd_rowstats_kernel<1, false>);
+            } else if (pt == 2) {
                 if (fine)
                     launch(cpd_rowstats_kernel<2, true>);
                 else
