@@ -16,6 +16,8 @@ wl_args() {
     emu2)  echo "--emulate-world 2 --steps 100 --warmup 10 --roofline-steps 0";;
     15k)   echo "--points 15000 --steps 200 --warmup 10 --roofline-steps 0";;
     1622)  echo "--points 1622 --steps 300 --warmup 20 --roofline-steps 0";;
+    4k)    echo "--points 4000 --steps 300 --warmup 20 --roofline-steps 0";;
+    8k)    echo "--points 8000 --steps 300 --warmup 20 --roofline-steps 0";;
     100k)  echo "--points 100000 --steps 30 --warmup 5 --roofline-steps 0";;
     late)  echo "--sigma2 4 --steps 50 --warmup 5 --roofline-steps 0";;
     *)     echo "$1";;
