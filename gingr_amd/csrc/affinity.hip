@@ -38,6 +38,49 @@ struct __attribute__((aligned(32))) P4 {
 constexpr int kTB = 11;
 constexpr int kTabN = 1 << kTB;
 
+// -DGINGR_STAMPS (diagnostic builds only: `make variant NAME=stamps DEFS=-DGINGR_STAMPS`, tools/stamps_shard.py): every wave of the
+// two CPD pair loops leaves eight 64-bit words per launch in a device buffer -- the 100 MHz wall clock at entry / owned points and
+// boxes ready / table barrier passed / first quarter staged / pair loop done / exit, the core-clock cycles of the whole wave, and
+// its hardware id -- so that a one-round launch (a short row shard) can be taken apart per wave.  Nothing of it exists in the product build.
+#ifdef GINGR_STAMPS
+__device__ unsigned long long *g_stamp_buf = nullptr;   // [2 kernels][kStampWaves][8]
+constexpr int kStampWaves = 1 << 15;
+struct Stamps {
+    unsigned long long *p;
+    long long c0;
+    __device__ __forceinline__ void begin(int kernel) {
+        const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned w = wg * 4 + (threadIdx.x >> 6);
+        p = (g_stamp_buf && w < kStampWaves) ? g_stamp_buf + ((size_t)kernel * kStampWaves + w) * 8 : nullptr;
+        c0 = clock64();
+        mark(0);
+    }
+    __device__ __forceinline__ void mark(int slot) {
+        const unsigned long long t = wall_clock64();
+        if (p && (threadIdx.x & 63) == 0) p[slot] = t;
+    }
+    __device__ __forceinline__ void end() {
+        mark(5);
+        if (p && (threadIdx.x & 63) == 0) {
+            p[6] = (unsigned long long)(clock64() - c0);
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            p[7] = ((unsigned long long)xcc << 32) | hw;
+        }
+    }
+};
+#define STAMP_DECL Stamps stamps__;
+#define STAMP_BEGIN(k) stamps__.begin(k);
+#define STAMP(slot) stamps__.mark(slot);
+#define STAMP_END stamps__.end();
+#else
+#define STAMP_DECL
+#define STAMP_BEGIN(k)
+#define STAMP(slot)
+#define STAMP_END
+#endif
+
 // ---------------------------------------------------------------- exact-zero culling
 // K_ij = 2^(c d2 / table size) is flushed to exactly +0 by v_ldexp_f64 once c*d2/size < -1076, i.e. d2 > 1491.7 sigma2.  When the
 // bounding boxes of the owned block and of a streamed 256-point tile are farther apart than that (with margin: 1500
@@ -436,19 +479,13 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
     __shared__ P4 tile[kTile];
     __shared__ double sred[4][64 * PT];  // the waves' accumulators, combined in the epilogue
     __shared__ double sfrac[64 * PT];    // per owned point: fraction of c|x~|^2 (expansion form), parked until the epilogue
-    const double c = fastexp_scale_for_variance<kTB>(2.0 * sigma2[0]);
-    const double am = aux[0] + aux[1];
-    // regime of the fine culling: the zero-flush radius is well inside the clouds' extent (3 am^2 bounds every squared distance)
-    if (regime_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        *regime_out = (fit_boxes && 3.0 * am * am * (-c) > kFineCullRatio * GINGR_CULL_SCALED(kTabN)) ? 1 : 0;
-        __threadfence_system();
-    }
-    fastexp_floor_table_init(T);
-    const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);               // wave-uniform
-    const bool expand = use_expansion(fmax(aux[0], aux[1]), c);             // wave-uniform
-    const double lim = fastexp_d2_limit<kTB>(c);
-    const double cx = aux[2], cy = aux[3], cz = aux[4];
-    const double m2c = -2.0 * c;
+    STAMP_DECL
+    STAMP_BEGIN(0)
+    // Everything the prologue needs from memory is requested up front -- the exponential table, the owned points, the scalars -- so
+    // that a workgroup of a one-round launch (a short row shard, a small cloud) waits for ONE round trip, not for a chain of them.
+    FloorTableRegs trom;
+    fastexp_floor_table_fetch256(trom);
+    const double s2in = sigma2[0], aux0 = aux[0], aux1 = aux[1], cx = aux[2], cy = aux[3], cz = aux[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave's number, provably uniform: loop bounds and LDS bases stay scalar
     // the workgroup's 64*PT CONSECUTIVE points (one 256-point k-d leaf at PT = 4: a compact box), the same in every wave
@@ -464,6 +501,33 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         y[t] = ok ? tgt.y[j] : 0.0;
         z[t] = ok ? tgt.z[j] : 0.0;
     }
+    // ... and the first quarter this wave will most likely stage (the first tile part of its chunk: the walk below confirms it or
+    // picks another one when that part is culled)
+    int64_t i0, i1;
+    plan.range(blockIdx.y, fit.n, &i0, &i1);
+    const int q0 = q * 64;
+    double lx = 0.0, ly = 0.0, lz = 0.0;  // the staged point of the quarter about to be computed (in flight during the previous one)
+    const int64_t spec_ib = i0;
+    {
+        const int64_t e = min((i0 / kTile + 1) * kTile, i1), i = i0 + q0 + lane;
+        if (i < e) {
+            lx = fit.x[i];
+            ly = fit.y[i];
+            lz = fit.z[i];
+        }
+    }
+    const double c = fastexp_scale_for_variance<kTB>(2.0 * s2in);
+    const double am = aux0 + aux1;
+    // regime of the fine culling: the zero-flush radius is well inside the clouds' extent (3 am^2 bounds every squared distance)
+    if (regime_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        *regime_out = (fit_boxes && 3.0 * am * am * (-c) > kFineCullRatio * GINGR_CULL_SCALED(kTabN)) ? 1 : 0;
+        __threadfence_system();
+    }
+    const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);               // wave-uniform
+    const bool expand = use_expansion(fmax(aux0, aux1), c);                 // wave-uniform
+    const double lim = fastexp_d2_limit<kTB>(c);
+    const double m2c = -2.0 * c;
+    fastexp_floor_table_park256(T, trom);
     const Box own = wave_bbox<PT>(x, y, z, okv);  // raw coordinates, before any centring
     constexpr unsigned kAllSlots = (1u << PT) - 1u;
     Box sown[PT];  // per owned slot (64 consecutive points)
@@ -481,15 +545,14 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         if (q == 0) sfrac[t * 64 + lane] = fr;
         acc[t] = 0.0;
     }
-    int64_t i0, i1;
-    plan.range(blockIdx.y, fit.n, &i0, &i1);
+    STAMP(1)
     __syncthreads();       // the exponential table (filled by all four waves) and sfrac are complete
+    STAMP(2)
     fastexp_round_down();  // the floor form of the exponential needs it; every float64 result up to the epilogue rounds down
     // A chunk starts and ends on 64-point quarters, not necessarily on tiles: every step handles the part of ONE box tile that lies
     // inside the chunk, so the tile / quarter boxes apply unchanged.  Of each part wave q takes the quarter q: it stages those 64
     // entries itself into its own slice of `tile` and is the only reader, so the pair loop has no workgroup barrier -- the waves
     // run decoupled -- and the loads of the wave's NEXT quarter are issued before the pairs of the current one are computed.
-    const int q0 = q * 64;
     struct Work {
         int64_t ib, ie;
         unsigned mask;
@@ -502,7 +565,6 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         w.valid = walk.next(own, sown, &w.ib, &w.ie, &w.mask);
         return w;
     };
-    double lx = 0.0, ly = 0.0, lz = 0.0;  // the staged point of the quarter about to be computed (in flight during the previous one)
     auto issue = [&](const Work &w) {
         const int64_t i = w.ib + q0 + lane;
         if (i < w.ie) {
@@ -512,7 +574,10 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         }
     };
     Work cur = find();
-    if (cur.valid) issue(cur);
+    if (cur.valid && cur.ib != spec_ib) issue(cur);  // (otherwise the prologue's request was the right one)
+#ifdef GINGR_STAMPS
+    bool first__ = true;
+#endif
     while (cur.valid) {
         if (plan.fair) fair_priority(cur.ib - i0, i1 - i0);
         __builtin_amdgcn_wave_barrier();  // (compiler fence) the previous quarter's reads are issued before the slice is rewritten
@@ -525,6 +590,9 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
             }
         }
         __builtin_amdgcn_wave_barrier();  // LDS serves one wave's accesses in order: its reads below see its own writes
+#ifdef GINGR_STAMPS
+        if (first__) { STAMP(3) first__ = false; }
+#endif
         const Work nxt = find();
         if (nxt.valid) issue(nxt);
         const int q1 = min((int)(cur.ie - cur.ib), q0 + 64);
@@ -548,6 +616,7 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         cur = nxt;
     }
     fastexp_round_nearest();
+    STAMP(4)
 #pragma unroll
     for (int t = 0; t < PT; ++t) sred[q][t * 64 + lane] = acc[t];
     __syncthreads();
@@ -557,6 +626,7 @@ __global__ __launch_bounds__(kBlock) void cpd_colsum_kernel(Cloud fit, Cloud tgt
         const int64_t j = (int64_t)blockIdx.x * (64 * PT) + p;
         if (j < tgt.n) partial[(int64_t)blockIdx.y * tgt.n + j] = v;
     }
+    STAMP_END
 }
 
 // centroid of a cloud into out[0..2] (single workgroup, fixed order)
@@ -746,18 +816,11 @@ __global__ __launch_bounds__(kBlock, (PT >= 4 ? 3 : 4)) void cpd_rowstats_kernel
     double *T = smem;
     P4 *tile = reinterpret_cast<P4 *>(smem + kTabN);
     P4 *tw = reinterpret_cast<P4 *>(smem + kTabN + 4 * kTile);
-    const double c = fastexp_scale_for_variance<kTB>(2.0 * sigma2[0]);
-    const double am = aux[0] + aux[1];
-    if (regime_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        *regime_out = (tgt_boxes && 3.0 * am * am * (-c) > kFineCullRatio * GINGR_CULL_SCALED(kTabN)) ? 1 : 0;
-        __threadfence_system();
-    }
-    fastexp_floor_table_init(T);
-    const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);               // wave-uniform
-    const bool expand = use_expansion(fmax(aux[0], aux[1]), c);             // wave-uniform
-    const double lim = fastexp_d2_limit<kTB>(c);
-    const double cx = aux[2], cy = aux[3], cz = aux[4];
-    const double m2c = -2.0 * c;
+    STAMP_DECL
+    STAMP_BEGIN(1)
+    FloorTableRegs trom;  // table, owned points, scalars and the first quarter are requested together: see cpd_colsum_kernel
+    fastexp_floor_table_fetch256(trom);
+    const double s2in = sigma2[0], aux0 = aux[0], aux1 = aux[1], cx = aux[2], cy = aux[3], cz = aux[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave's number, provably uniform: loop bounds and LDS bases stay scalar
     const int64_t ibase = (int64_t)blockIdx.x * (64 * PT) + lane;
@@ -772,6 +835,31 @@ __global__ __launch_bounds__(kBlock, (PT >= 4 ? 3 : 4)) void cpd_rowstats_kernel
         y[t] = ok ? fit.y[i] : 0.0;
         z[t] = ok ? fit.z[i] : 0.0;
     }
+    int64_t j0, j1;
+    plan.range(blockIdx.y, tgt.n, &j0, &j1);
+    const int q0 = q * 64;
+    double lx = 0.0, ly = 0.0, lz = 0.0, linv = 0.0;
+    const int64_t spec_jb = j0;
+    {
+        const int64_t e = min((j0 / kTile + 1) * kTile, j1), j = j0 + q0 + lane;
+        if (j < e) {
+            lx = tgt.x[j];
+            ly = tgt.y[j];
+            lz = tgt.z[j];
+            linv = inv_den[j];
+        }
+    }
+    const double c = fastexp_scale_for_variance<kTB>(2.0 * s2in);
+    const double am = aux0 + aux1;
+    if (regime_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        *regime_out = (tgt_boxes && 3.0 * am * am * (-c) > kFineCullRatio * GINGR_CULL_SCALED(kTabN)) ? 1 : 0;
+        __threadfence_system();
+    }
+    const bool clamp = fastexp_needs_clamp(3.0 * am * am, c);               // wave-uniform
+    const bool expand = use_expansion(fmax(aux0, aux1), c);                 // wave-uniform
+    const double lim = fastexp_d2_limit<kTB>(c);
+    const double m2c = -2.0 * c;
+    fastexp_floor_table_park256(T, trom);
     const Box own = wave_bbox<PT>(x, y, z, okv);  // raw coordinates, before any centring; identical in every wave
     constexpr unsigned kAllSlots = (1u << PT) - 1u;
     Box sown[PT];  // per owned slot (64 consecutive points)
@@ -789,13 +877,12 @@ __global__ __launch_bounds__(kBlock, (PT >= 4 ? 3 : 4)) void cpd_rowstats_kernel
         if (q == 0) sfrac[t * 64 + lane] = fr;
         a1[t] = ax[t] = ay[t] = az[t] = 0.0;
     }
-    int64_t j0, j1;
-    plan.range(blockIdx.y, tgt.n, &j0, &j1);
+    STAMP(1)
     __syncthreads();       // the exponential table (filled by all four waves) and sfrac are complete
+    STAMP(2)
     fastexp_round_down();  // see cpd_colsum_kernel
     // one box tile (or the part of it inside the chunk) per step, wave q on quarter q, next quarter's loads in flight: see
     // cpd_colsum_kernel
-    const int q0 = q * 64;
     struct Work {
         int64_t jb, je;
         unsigned mask;
@@ -808,7 +895,6 @@ __global__ __launch_bounds__(kBlock, (PT >= 4 ? 3 : 4)) void cpd_rowstats_kernel
         w.valid = walk.next(own, sown, &w.jb, &w.je, &w.mask);
         return w;
     };
-    double lx = 0.0, ly = 0.0, lz = 0.0, linv = 0.0;
     auto issue = [&](const Work &w) {
         const int64_t j = w.jb + q0 + lane;
         if (j < w.je) {
@@ -819,7 +905,10 @@ __global__ __launch_bounds__(kBlock, (PT >= 4 ? 3 : 4)) void cpd_rowstats_kernel
         }
     };
     Work cur = find();
-    if (cur.valid) issue(cur);
+    if (cur.valid && cur.jb != spec_jb) issue(cur);  // (otherwise the prologue's request was the right one)
+#ifdef GINGR_STAMPS
+    bool first__ = true;
+#endif
     while (cur.valid) {
         if (plan.fair) fair_priority(cur.jb - j0, j1 - j0);
         __builtin_amdgcn_wave_barrier();
@@ -836,6 +925,9 @@ __global__ __launch_bounds__(kBlock, (PT >= 4 ? 3 : 4)) void cpd_rowstats_kernel
             }
         }
         __builtin_amdgcn_wave_barrier();
+#ifdef GINGR_STAMPS
+        if (first__) { STAMP(3) first__ = false; }
+#endif
         const Work nxt = find();
         if (nxt.valid) issue(nxt);
         const int q1 = min((int)(cur.je - cur.jb), q0 + 64);
@@ -859,6 +951,7 @@ __global__ __launch_bounds__(kBlock, (PT >= 4 ? 3 : 4)) void cpd_rowstats_kernel
         cur = nxt;
     }
     fastexp_round_nearest();
+    STAMP(4)
     // combine the four waves in a fixed order; the LDS block is reused, so everybody must be done with T / tile / tw first
     __syncthreads();
     constexpr int kPts = 64 * PT;
@@ -892,6 +985,7 @@ __global__ __launch_bounds__(kBlock, (PT >= 4 ? 3 : 4)) void cpd_rowstats_kernel
             base[3 * M + i] = expand ? __builtin_fma(cz, v[0], back * v[3]) : v[3];
         }
     }
+    STAMP_END
 }
 
 // P1 / PX from chunk partials plus per-block partials of
@@ -1816,3 +1910,23 @@ void morton_order(const double *xyz, int64_t n, std::vector<int32_t> &perm) {
         for (int64_t q = 0; q < m; q += 64) std::sort(perm.begin() + b + q, perm.begin() + b + (q + 64 < m ? q + 64 : m));
     }
 }
+
+#ifdef GINGR_STAMPS
+// diagnostic build only (not in include/gingr_hip.h): allocate / read back the stamp buffer of the two pair loops
+extern "C" int gingr_debug_stamps_enable(gingr_ctx *ctx) {
+    unsigned long long *buf = nullptr;
+    const size_t bytes = (size_t)2 * kStampWaves * 8 * sizeof(unsigned long long);
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&buf), bytes));
+    HIP_TRY(ctx, hipMemset(buf, 0, bytes));
+    HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)));
+    return GINGR_OK;
+}
+extern "C" int gingr_debug_stamps_read(gingr_ctx *ctx, unsigned long long *host /* [2][32768][8] */) {
+    unsigned long long *buf = nullptr;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpyFromSymbol(&buf, HIP_SYMBOL(g_stamp_buf), sizeof(buf)));
+    if (!buf) return gingr_set_error(ctx, GINGR_ERR_STATE, "stamps not enabled");
+    HIP_TRY(ctx, hipMemcpy(host, buf, (size_t)2 * kStampWaves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return GINGR_OK;
+}
+#endif

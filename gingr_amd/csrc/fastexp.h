@@ -102,10 +102,32 @@ struct ExpFloor11 {
 __device__ __forceinline__ void fastexp_round_down() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\ts_nop 3" ::: "memory"); }
 __device__ __forceinline__ void fastexp_round_nearest() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0\n\ts_nop 3" ::: "memory"); }
 
-// table of the floor form: T'[j] = 2^(j/2048) * S; every thread of the block must call it, followed by __syncthreads()
-__device__ __forceinline__ void fastexp_floor_table_init(double *T) {
-    for (int j = threadIdx.x + threadIdx.y * blockDim.x; j < 2048; j += blockDim.x * blockDim.y)
-        T[j] = gingr_exp_table_rom[j] * ExpFloor11::S;
+// Table of the floor form, T'[j] = 2^(j/2048) * S, multiplied out at build time (exp_floor_table.inc).  A 256-thread workgroup copies it
+// to LDS in two halves: fetch256 only ISSUES the four 16-byte loads of a thread -- the caller requests its other prologue data
+// (owned points, boxes) behind them, so that everything is one memory round trip -- and park256 writes them to LDS; every thread of
+// the block calls both, then __syncthreads().  (Until round 4 this was a loop over blockDim with the multiplication inside: eight
+// DEPENDENT load -> wait -> multiply -> store rounds, 4-5 us of the 6.8 us prologue of a one-round launch:
+// profiles/r05_shard_pair_loop_stamps.txt.)
+__device__ static const double gingr_exp_floor_table_rom[2048] __attribute__((aligned(16))) = {
+#include "exp_floor_table.inc"
+};
+typedef double fastexp_v2f64 __attribute__((ext_vector_type(2)));
+struct FloorTableRegs {
+    fastexp_v2f64 v0, v1, v2, v3;
+};
+__device__ __forceinline__ void fastexp_floor_table_fetch256(FloorTableRegs &r) {
+    const fastexp_v2f64 *rom = reinterpret_cast<const fastexp_v2f64 *>(gingr_exp_floor_table_rom) + threadIdx.x;
+    r.v0 = rom[0];
+    r.v1 = rom[256];
+    r.v2 = rom[512];
+    r.v3 = rom[768];
+}
+__device__ __forceinline__ void fastexp_floor_table_park256(double *T, const FloorTableRegs &r) {
+    fastexp_v2f64 *t2 = reinterpret_cast<fastexp_v2f64 *>(T) + threadIdx.x;
+    t2[0] = r.v0;
+    t2[256] = r.v1;
+    t2[512] = r.v2;
+    t2[768] = r.v3;
 }
 
 // The magic constant of the floor form is 1.5 * 2^49 (ulp 1/8): tm = u + MAGIC8 then holds floor(8u) = 8 floor(u) + s in its low

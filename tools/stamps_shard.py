@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Per-wave time stamps of the two CPD pair loops on a row shard (diagnostic build, see affinity.hip: GINGR_STAMPS).
+
+usage (GPU box):  make -C gingr_amd/csrc variant NAME=stamps DEFS=-DGINGR_STAMPS        (here, cross-compiled)
+                  GINGR_HIP_LIB=gingr_amd/libgingr_hip_stamps.so python3 tools/stamps_shard.py [world] [points] > profile.txt
+
+Runs the bench workload (synthetic 50k <-> 50k, rank 100) as rank 0 of `world` ranks for a few iterations, reads the stamps of
+the LAST launch of cpd_colsum_kernel / cpd_rowstats_kernel and prints where a one-round launch spends its time: dispatch skew,
+prologue stages, pair loop, epilogue, how the waves of one SIMD finish, workgroups per compute unit, the clock the waves saw."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: F401,E402  (first: one HIP runtime per process)
+import gingr_amd as ga  # noqa: E402
+from gingr_amd.sharded import ShardedFitter  # noqa: E402
+from bench import synth_clouds  # noqa: E402
+
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+points = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+y, x = synth_clouds(points)
+ctx = ga.Context(0)
+lib = ctx._lib
+lib.gingr_debug_stamps_enable.argtypes = [ctypes.c_void_p]
+lib.gingr_debug_stamps_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+model = ga.GPMMTriangleMesh3D(ctx, y, relativeTolerance=0.0, maxRank=100).Gaussian(70.0, 50.0)
+uid = ctx.rccl_unique_id()
+ctx.rccl_init(uid, 1, 0)
+fitter = ShardedFitter(ctx, model, x, rank=0, world=world, all_reduce=None, rccl=True)
+s2 = ctx.cpd_initial_sigma2(y, x)
+fitter.set_state(np.zeros(100), s2)
+fitter.update_cpd(0.1, 1.0, 5)
+ctx.synchronize()
+assert lib.gingr_debug_stamps_enable(ctx.handle) == 0
+fitter.update_cpd(0.1, 1.0, 3)
+ctx.synchronize()
+W = 1 << 15
+buf = np.zeros((2, W, 8), dtype=np.uint64)
+assert lib.gingr_debug_stamps_read(ctx.handle, buf.ctypes.data) == 0
+m_loc = fitter.end - fitter.begin
+print(f"# row shard: rank 0 of {world}, {m_loc} local rows x {points} targets, rank 100; stamps of the last launch of each pair loop")
+print("# wall clock = 100 MHz (10 ns); all times in us relative to the first wave's entry")
+
+for k, name in enumerate(("cpd_colsum_kernel", "cpd_rowstats_kernel")):
+    b = buf[k]
+    used = b[:, 0] != 0
+    nw = int(used.sum())
+    if nw == 0:
+        print(f"\n== {name}: no stamps")
+        continue
+    b = b[used].astype(np.int64)
+    t0 = b[:, 0].min()
+    T = (b[:, :6] - t0) / 100.0            # us
+    cyc = b[:, 6]
+    hw = b[:, 7] & 0xFFFFFFFF
+    xcc = (b[:, 7] >> 32) & 0xF
+    # gfx9 HW_ID: wave_id [3:0], simd_id [5:4], pipe [7:6], cu_id [11:8], sh_id [12], se_id [15:13] (gfx950: se 3 bits)
+    simd = (hw >> 4) & 3
+    cu = (hw >> 8) & 15
+    sh = (hw >> 12) & 1
+    se = (hw >> 13) & 7
+    cu_key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    simd_key = cu_key * 4 + simd
+    dur = T[:, 5] - T[:, 0]
+    q = lambda v, p: float(np.percentile(v, p))
+    print(f"\n== {name}: {nw} waves = {nw // 4} workgroups; launch spans {T[:, 5].max():.1f} us (first entry to last exit)")
+    print(f"entry skew (dispatch):           median {q(T[:, 0], 50):6.2f}  p90 {q(T[:, 0], 90):6.2f}  max {T[:, 0].max():6.2f}")
+    st = [("owned points + boxes ready", 1, 0), ("table barrier passed", 2, 1), ("first quarter staged", 3, 2), ("pair loop", 4, 3),
+          ("epilogue (combine + store)", 5, 4)]
+    for label, a, bb in st:
+        d = T[:, a] - T[:, bb]
+        print(f"{label:32s} median {q(d, 50):6.2f}  p10 {q(d, 10):6.2f}  p90 {q(d, 90):6.2f}  max {d.max():6.2f}")
+    pro = T[:, 3] - T[:, 0]
+    print(f"whole prologue (entry -> first pairs) median {q(pro, 50):6.2f}  p90 {q(pro, 90):6.2f}  max {pro.max():6.2f}")
+    print(f"pair loop END times:             median {q(T[:, 4], 50):6.2f}  p10 {q(T[:, 4], 10):6.2f}  p90 {q(T[:, 4], 90):6.2f}  max {T[:, 4].max():6.2f}")
+    ghz = cyc / (dur * 1e3)
+    print(f"core clock seen by the waves (cycles / wall): median {q(ghz, 50):.3f} GHz  p10 {q(ghz, 10):.3f}  p90 {q(ghz, 90):.3f}")
+    # waves per SIMD and their finishing order
+    order = np.argsort(simd_key, kind="stable")
+    keys, starts, counts = np.unique(simd_key[order], return_index=True, return_counts=True)
+    hist = np.bincount(counts)
+    print("waves per SIMD: " + ", ".join(f"{c} on {n}" for c, n in enumerate(hist) if n))
+    cuk, cuc = np.unique(cu_key, return_counts=True)
+    h2 = np.bincount(cuc // 4)
+    print(f"compute units used: {len(cuk)}; workgroups per unit: " + ", ".join(f"{c} on {n}" for c, n in enumerate(h2) if n))
+    fin = []
+    full = counts.max()
+    for s, c in zip(starts, counts):
+        if c == full:
+            fin.append(np.sort(T[order[s:s + c], 4]))
+    if fin:
+        fin = np.array(fin)
+        print(f"SIMDs with {full} waves: mean pair-loop end of the 1st..{full}th finisher: " + " / ".join(f"{v:.1f}" for v in fin.mean(0)))
+    # issue-slot use: the pair loop's VALU issue cycles against what the SIMD had
+    loop = T[:, 4] - T[:, 3]
+    print(f"sum over a SIMD's waves of pair-loop time / (waves x launch span): {loop.sum() / (nw * T[:, 5].max()):.3f}")
+ctx_close = getattr(ctx, "close", None)
+fitter.close()
+if ctx_close:
+    ctx_close()
