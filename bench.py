@@ -241,7 +241,7 @@ def run_group_mode(args, world: int, shared_device: bool):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--group", "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--points", str(args.points), "--rank", str(args.rank), "--w", str(args.w), "--roofline-steps", str(args.roofline_steps),
-           "--no-cpu-baseline", "--no-parity-check"]
+           "--sustained-steps", str(args.sustained_steps), "--no-cpu-baseline", "--no-parity-check"]
     if shared_device:
         cmd += ["--logical-shards", str(world)]   # the one-GPU test mode: the shards share device 0
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
@@ -318,6 +318,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=3)
+    ap.add_argument("--sustained-steps", type=int, default=200,
+                    help="a second, longer timed run of the same workload reported as `sustained` next to the contract's K steps (0: skip)")
     ap.add_argument("--sigma2", type=float, default=0.0,
                     help="experiment: start from this sigma2 instead of the CPD initial value (late-iteration regime)")
     ap.add_argument("--group", action="store_true",
@@ -342,13 +344,16 @@ def main():
                     help="N > 1: skip the second measurement through the in-library device group (a child process started by rank 0 after "
                          "the headline measurement; its line is folded into the output as `group_mode`)")
     ap.add_argument("--ctx-option", action="append", default=[], metavar="NAME=VALUE",
-                    help="same-box comparisons: gingr_ctx_set_option on the context, NAME in cull | fine_cull | nn_grid (all select "
-                         "between code paths with identical results)")
+                    help="same-box comparisons: gingr_ctx_set_option on the context, NAME in cull | fine_cull | nn_grid | tri_grid "
+                         "(all select between code paths with identical results)")
     args = ap.parse_args()
     if args.config:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_configs
-        print(json.dumps(bench_configs.CONFIGS[args.config]()), flush=True)
+        # config 5 = independent chains: `--gpus N` starts N chain processes, process i with HIP_VISIBLE_DEVICES=i (this process
+        # stays a launcher and touches no GPU)
+        line = bench_configs.CONFIGS[5](gpus=args.gpus) if args.config == 5 else bench_configs.CONFIGS[args.config]()
+        print(json.dumps(line), flush=True)
         return 0
     if args.config1_stock_structure:
         cpu_baseline_stock_structure(args.config1_stock_structure == "gpu")
@@ -458,7 +463,8 @@ def main():
         ctx = ga.Context(local_rank)
         for kv in args.ctx_option:
             name, _, val = kv.partition("=")
-            ctx.set_option({"cull": 0, "fine_cull": 1, "nn_grid": 2}[name], int(val))
+            from gingr_amd import _native as _nat
+            ctx.set_option(getattr(_nat, "OPT_" + name.upper()), int(val))   # cull | fine_cull | nn_grid | tri_grid
         stream = torch.cuda.Stream(device=local_rank)
         ctx.set_stream(stream.cuda_stream)
         if args.host_gpmm:
@@ -490,12 +496,25 @@ def main():
         native_error = None
         if native:
             comm_world = world if not args.emulate_world else 1
+            # ncclCommInitRank is collective: a rank that cannot even bind librccl would leave the others blocked inside it until a
+            # time-out, so every rank loads the library first and all of them learn whether everybody could
             try:
-                uid = [ctx.rccl_unique_id() if rank == 0 else None]
-            except Exception as ex:          # (librccl not loadable on rank 0: everybody must learn it)
-                uid, native_error = [None], repr(ex)
+                ctx.rccl_load()
+                loaded = True
+            except Exception as ex:
+                loaded, native_error = False, repr(ex)
             if comm_world > 1:
-                dist.broadcast_object_list(uid, src=0)
+                lf = torch.tensor([1 if loaded else 0], dtype=torch.int32, device=f"cuda:{local_rank}")
+                dist.all_reduce(lf, op=dist.ReduceOp.MIN)
+                loaded = bool(lf.item())
+            uid = [None]
+            if loaded:
+                try:
+                    uid = [ctx.rccl_unique_id() if rank == 0 else None]
+                except Exception as ex:      # (everybody must learn it)
+                    uid, native_error = [None], repr(ex)
+                if comm_world > 1:
+                    dist.broadcast_object_list(uid, src=0)
             ok = uid[0] is not None
             if ok:
                 try:
@@ -575,26 +594,89 @@ def main():
     runner.reset(sigma2_0)
     runner.update(3)
     runner.sync()
-    runner.reset(sigma2_0)
-    runner.update(args.warmup)
-    runner.sync()
-    t0 = time.perf_counter()
-    runner.update(args.steps)
-    enqueue_s = time.perf_counter() - t0          # the call returns when the K steps are ENQUEUED: host cost of the launches
-    runner.sync()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared_device else f"cuda:{local_rank}")
+
+    def max_over_ranks(v):
+        if not use_dist:
+            return v
+        tt = torch.tensor([v], dtype=torch.float64, device="cpu" if shared_device else f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    alpha, sc, fit = runner.state()
-    ok = bool(np.all(np.isfinite(fit)) and sc.status == 0 and sc.iteration == args.warmup + args.steps
-              and args.emulate_world <= 1)
+        return float(tt.item())
+
+    def timed_updates(steps, warmup):
+        """W warm-up + K timed updates from sigma2_0.  Every timed update must be one of a LIVE registration: an update of a state
+        that has failed (ModelFlexibilityError: the state is frozen, GingrAlgorithm.scala:194-210) runs in a fully culled regime
+        and times nothing of the workload.  A probe run of the same W + K updates says whether the registration survives them
+        (the trajectory is deterministic); if it collapses after L < W + K updates the K timed updates are taken in blocks of
+        `reset, w warm-up, n timed` with w + n < L, each block bracketed by a synchronisation, and the block times are added up.
+        Returns (seconds of the K updates [max over ranks], host enqueue seconds, info dict, final state, why-invalid or None)."""
+        runner.reset(sigma2_0)
+        runner.update(warmup + steps)
+        runner.sync()
+        _, scp, _ = runner.state()
+        info = {"steps": steps, "warmup": warmup, "blocks": 1, "live_iterations_from_sigma2_0": None}
+        if scp.status == 0 and scp.iteration == warmup + steps:
+            plan = [(warmup, steps)]
+        else:
+            live = int(scp.iteration)             # updates that succeeded before the failing one
+            usable = live - 1                     # one update of margin to the collapse
+            w = min(warmup, max(1, usable // 5))
+            n = usable - w
+            info.update({"live_iterations_from_sigma2_0": live, "status_at_collapse": int(scp.status)})
+            if n < 1:
+                return None, None, info, runner.state(), (f"the registration fails after {live} updates from sigma2_0 "
+                                                          f"(status {int(scp.status)}): nothing live to time")
+            plan = []
+            left = steps
+            while left > 0:
+                plan.append((w, min(n, left)))
+                left -= plan[-1][1]
+            info.update({"blocks": len(plan), "warmup_per_block": w, "timed_per_block": n,
+                         "note": f"collapse after {live} updates: timed in {len(plan)} block(s) of reset + {w} warm-up + <= {n} timed updates, "
+                                 "every timed update is one of a live registration"})
+        total, enq, bad = 0.0, 0.0, None
+        st = None
+        for (w, n) in plan:
+            runner.reset(sigma2_0)
+            runner.update(w)
+            runner.sync()
+            t0 = time.perf_counter()
+            runner.update(n)
+            enq += time.perf_counter() - t0       # the call returns when the n steps are ENQUEUED: host cost of the launches
+            runner.sync()
+            total += time.perf_counter() - t0
+            st = runner.state()
+            if st[1].status != 0 or st[1].iteration != w + n:
+                bad = (f"a timed block ended in status {int(st[1].status)} after {int(st[1].iteration)} of {w + n} updates "
+                       "(failed / frozen state: not a timing of the workload)")
+        return max_over_ranks(total), enq, info, st, bad
+
+    elapsed, enqueue_s, timing_info, (alpha, sc, fit), reason = timed_updates(args.steps, args.warmup)
+    if reason is None and not np.all(np.isfinite(fit)):
+        reason = "non-finite fit after the timed steps"
+    if reason is None and args.emulate_world > 1:
+        reason = ("emulated shard (--emulate-world): the other ranks' partial sums are missing, a per-rank cost experiment and not "
+                  "a registration")
+    ok = reason is None
     sigma2_timed = float(sc.sigma2)
+    # the driver's contract fixes K = 20 (46 ms at 50k): a longer run of the same workload next to it, same rules
+    sustained = None
+    if elapsed is not None and args.sustained_steps > 0:
+        s_el, _, s_info, s_state, s_bad = timed_updates(args.sustained_steps, args.warmup)
+        sustained = {"steps": args.sustained_steps, "valid": s_bad is None and s_el is not None and ok, "timing": s_info, "reason": s_bad}
+        if s_el is not None:
+            sustained.update({"ms_per_step": s_el / args.sustained_steps * 1e3, "value": args.sustained_steps / s_el,
+                              "unit": "iterations/s", "sigma2_after": float(s_state[1].sigma2)})
+    if elapsed is None:                           # nothing could be timed: keep the line well-formed
+        elapsed, enqueue_s = float("nan"), float("nan")
 
     # ---- live roofline of the dominant kernels (HIP events on the kernels' stream, extra iterations)
     roof = None
     kernels = []
+    # (from a defined, live spot of the same trajectory: sigma2_0 + the warm-up of the timed blocks)
+    w_roof = int(timing_info.get("warmup_per_block", args.warmup))
+    runner.reset(sigma2_0)
+    runner.update(w_roof)
+    runner.sync()
     timing(enable=True, reset=True)
     runner.update(args.roofline_steps)
     runner.sync()
@@ -693,7 +775,7 @@ def main():
     parity = None
     if not args.no_parity_check and args.emulate_world <= 1 and rank == 0 and not args.group and world == 1:
         from oracle import c_oracle as co
-        _, sc, fit = runner.state()                            # the state after the timed + roofline iterations
+        _, sc, fit = runner.state()                            # the state after the warm-up + roofline iterations
         runner.update(1)
         runner.sync()
         _, sc_next, _ = runner.state()
@@ -703,14 +785,16 @@ def main():
         e_px = float(np.linalg.norm(got["PX"] - want.PX) / np.linalg.norm(want.PX))
         e_den = float(np.max(np.abs(got["den"] - want.den) / want.den))
         e_s2 = float(abs(sc_next.sigma2 - want.sigma2_next) / want.sigma2_next)
-        parity = {"against": "oracle/cpd_oracle.c (strict C restatement, parity unpinned), one update from the state after the timed + roofline steps",
+        parity = {"against": f"oracle/cpd_oracle.c (strict C restatement, parity unpinned), one update from the state {w_roof} warm-up + {args.roofline_steps} roofline updates after sigma2_0",
                   "rows_checked": int(want.P1.shape[0]), "P1_max_rel": e_p1, "PX_rel_l2": e_px, "den_max_rel": e_den,
                   "sigma2_next_rel": e_s2, "tolerance": 1e-8}
-        parity["ok"] = bool(max(e_p1, e_px, e_den, e_s2) < 1e-8)
+        parity["ok"] = bool(max(e_p1, e_px, e_den, e_s2) < 1e-8) and sc_next.status == 0
+        if not parity["ok"] and reason is None:
+            reason = "parity check against the strict C oracle failed (see parity_check)"
         ok = ok and parity["ok"]
 
     # ---- N > 1: the sharded run must land on the state a single shard reaches from the same start (outside every timed region;
-    # rank 0 replays warm-up + timed + roofline iterations on its own GPU: milliseconds).  Same arithmetic, different order of
+    # rank 0 replays the warm-up + roofline iterations the sharded state went through on its own GPU: milliseconds).  Same arithmetic, different order of
     # the partial sums, so agreement is ~1e-12; a wrong exchange shows up as O(1)
     shard_check = None
     if n_shards > 1 and rank == 0 and not args.emulate_world and not args.group and not args.no_parity_check:
@@ -719,7 +803,7 @@ def main():
             single = ShardedFitter(ctx, model, x, rank=0, world=1, all_reduce=None,
                                    global_transform=ga.GlobalTranformationType.RigidTransforms, step_length=1.0)
             single.set_state(np.zeros(args.rank), sigma2_0)
-            single.update_cpd(args.w, 1.0, args.warmup + args.steps + args.roofline_steps)
+            single.update_cpd(args.w, 1.0, w_roof + args.roofline_steps)
         torch.cuda.synchronize(local_rank)
         a_1, sc_1, _ = single.get_state()
         single.close()
@@ -729,6 +813,8 @@ def main():
         shard_check = {"against": "the same iterations on ONE shard (rank 0's GPU)", "iterations": int(sc_1.iteration),
                        "sigma2_rel": e_s2, "alpha_max_abs": e_a, "translation_max_abs": e_t, "tolerance": 1e-8,
                        "ok": bool(max(e_s2, e_a, e_t) < 1e-8 and sc_sh.iteration == sc_1.iteration)}
+        if not shard_check["ok"] and reason is None:
+            reason = "the sharded run does not land on the single-shard state (see shard_consistency)"
         ok = ok and shard_check["ok"]
 
     cpu = None
@@ -757,6 +843,9 @@ def main():
                        "points": M, "targets": N, "rank": args.rank, "parallelism": f"row-shard x{n_shards}",
                        "exchange": mode, "emulated_world": args.emulate_world or None},
             "valid": ok,
+            "reason": reason,
+            "timing": timing_info,
+            "sustained": sustained,
             "parity_check": parity,
             "shard_consistency": shard_check,
             "sigma2_after_timed_steps": sigma2_timed,

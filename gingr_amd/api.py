@@ -923,8 +923,15 @@ class GingrAlgorithm:
             req.alpha, req.scalars = dptr(keep[0]), ctypes.pointer(sc)
         r, M = g.model.rank, g.model.numberOfPoints
         alpha, fit, res = np.empty(r), np.empty((M, 3)), nat.MhResult()
-        _check(self.ctx.handle, self._lib.gingr_fitter_mh_step(self._fitter, ctypes.byref(req), dptr(alpha), dptr(fit), ctypes.byref(res)),
-               "gingr_fitter_mh_step")
+        try:
+            _check(self.ctx.handle, self._lib.gingr_fitter_mh_step(self._fitter, ctypes.byref(req), dptr(alpha), dptr(fit), ctypes.byref(res)),
+                   "gingr_fitter_mh_step")
+        except BaseException:
+            # a step that failed half way leaves the device state undefined (the library refuses to continue from it): forget what
+            # this object believes to be mirrored there, so that the next call pushes a state again
+            self._device_state = None
+            self._mh_last = None
+            raise
         s = res.scalars
         mp = ModelFittingParameters(scale=s.scale, translation=tuple(s.translation), rotation=EulerAngles(*list(s.euler)),
                                     center=tuple(s.center), shape=alpha)

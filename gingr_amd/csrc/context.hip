@@ -326,6 +326,16 @@ int gingr_nn(gingr_ctx *ctx, int64_t M, const double *query, int64_t N, const do
     const bool use_grid = ordered && ctx->nn_grid == 2;
     std::vector<int32_t> perm, qperm;
     NNGrid grid;
+    struct GridGuard {  // the per-call grid's device arrays go away on every way out (the early returns of HIP_TRY included) ...
+        gingr_ctx *ctx;
+        NNGrid *g;
+        ~GridGuard() {
+            if (g->ready || g->cell_start || g->pts || g->flag || g->nflag) {
+                (void)hipStreamSynchronize(ctx->stream);  // ... once nothing enqueued can still read them
+                nn_grid_free(g);
+            }
+        }
+    } grid_guard{ctx, &grid};
     if (ordered) {
         morton_order(target, N, perm);
         morton_order(query, M, qperm);
@@ -347,11 +357,7 @@ int gingr_nn(gingr_ctx *ctx, int64_t M, const double *query, int64_t N, const do
         cq = Cloud{qp, qp + M, qp + 2 * M, M};
         launch_tile_bbox(ctx, ct, dboxes.as<double>());
         if (use_grid) {
-            const int rc = nn_grid_build(ctx, target, N, perm.data(), M, &grid);
-            if (rc != GINGR_OK) {
-                nn_grid_free(&grid);
-                return rc;
-            }
+            GINGR_TRY(nn_grid_build(ctx, target, N, perm.data(), M, &grid));
         }
     } else {
         GINGR_TRY(upload_cloud(ctx, M, query, sq, dq, &cq));
@@ -371,17 +377,7 @@ int gingr_nn(gingr_ctx *ctx, int64_t M, const double *query, int64_t N, const do
     } else {
         launch_nn(ctx, cq, ct, nullptr, nullptr, dws.p, didx.as<int32_t>(), dd2.as<double>());
     }
-    const int launch_rc = check_launch(ctx);
-    if (launch_rc != GINGR_OK) {
-        (void)hipStreamSynchronize(ctx->stream);
-        nn_grid_free(&grid);
-        return launch_rc;
-    }
-    {
-        const hipError_t se = hipStreamSynchronize(ctx->stream);  // the grid's device arrays are freed below
-        nn_grid_free(&grid);
-        HIP_TRY(ctx, se);
-    }
+    GINGR_TRY(check_launch(ctx));
     std::vector<double> hd2((size_t)M);
     std::vector<int32_t> hidx((size_t)M);
     HIP_TRY(ctx, hipMemcpyAsync(hidx.data(), didx.p, M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -28,6 +28,11 @@ struct gingr_fitter {
     double *alpha = nullptr, *acoef = nullptr, *alpha_c = nullptr, *zbuf = nullptr;
     double *zrand = nullptr;     // [rp] standard-normal draws of a probabilistic update (posterior.sample())
     bool zrand_active = false;
+    // upload of the draws by the asynchronous entry points: a pinned buffer of its own (the synchronous entry points rewrite `pin`),
+    // guarded by an event -- the buffer is rewritten only after the previous upload has left it, and nothing depends on when a copy
+    // from pageable memory happens to consume its source
+    double *zpin = nullptr;
+    hipEvent_t zpin_done = nullptr;
     DevState *st = nullptr;
     DevPose *pose = nullptr;
     gingr_state_scalars *hs_dev = nullptr;
@@ -624,6 +629,8 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->newshape);
     dev_free(f->state_block);
     if (f->pin) (void)hipHostFree(f->pin);
+    if (f->zpin) (void)hipHostFree(f->zpin);
+    if (f->zpin_done) (void)hipEventDestroy(f->zpin_done);
     dev_free(f->acoef);
     dev_free(f->alpha_c);
     dev_free(f->zbuf);
@@ -980,12 +987,32 @@ static void nearest_target_vertex(gingr_ctx *ctx, gingr_fitter *f, Cloud query, 
 void fitter_set_partial_output(gingr_fitter *f, double *base) { f->partial_out = base; }
 void fitter_set_partial_fullfit(gingr_fitter *f, double *base) { f->partial_fullfit = base; }
 double *fitter_fullfit(gingr_fitter *f) { return f->fullfit; }
-void fitter_set_zrand(gingr_fitter *f, const double *z) {  // (pageable source: consumed when the copy call returns)
-    f->zrand_active = z != nullptr;
-    if (!z) return;
-    std::vector<double> zz((size_t)f->m->rp, 0.0);
-    memcpy(zz.data(), z, (size_t)f->m->r * sizeof(double));
-    (void)hipMemcpyAsync(f->zrand, zz.data(), zz.size() * sizeof(double), hipMemcpyHostToDevice, f->ctx->stream);
+// z (r standard normals, host) -> f->zrand (rp doubles, zero padded) on the context's stream, without waiting for the stream
+int fitter_upload_zrand(gingr_fitter *f, const double *z) {
+    gingr_ctx *ctx = f->ctx;
+    const size_t bytes = (size_t)f->m->rp * sizeof(double);
+    if (!f->zpin) {
+        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&f->zpin), bytes, hipHostMallocDefault));
+        if (hipEventCreateWithFlags(&f->zpin_done, hipEventDisableTiming) != hipSuccess) {
+            (void)hipHostFree(f->zpin);
+            f->zpin = nullptr, f->zpin_done = nullptr;
+            return gingr_set_error(ctx, GINGR_ERR_HIP, "upload of the posterior draws: hipEventCreate failed");
+        }
+    } else {
+        HIP_TRY(ctx, hipEventSynchronize(f->zpin_done));  // the previous upload has read the buffer (long ago, in practice)
+    }
+    memset(f->zpin, 0, bytes);
+    memcpy(f->zpin, z, (size_t)f->m->r * sizeof(double));
+    HIP_TRY(ctx, hipMemcpyAsync(f->zrand, f->zpin, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(f->zpin_done, ctx->stream));
+    return GINGR_OK;
+}
+int fitter_set_zrand(gingr_fitter *f, const double *z) {
+    f->zrand_active = false;
+    if (!z) return GINGR_OK;
+    GINGR_TRY(fitter_upload_zrand(f, z));
+    f->zrand_active = true;  // only once the draws are on their way: a failed upload must not sample from stale ones
+    return GINGR_OK;
 }
 gingr_ctx *fitter_ctx(gingr_fitter *f) { return f->ctx; }
 bool fitter_reversed(gingr_fitter *f) { return f->reversed; }
@@ -1371,12 +1398,7 @@ int fitter_sharded_update(gingr_fitter *f, int flavour, const gingr_cpd_params *
     if (n_iterations < 0 || !reduce || flavour < 0 || flavour > 2) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "sharded update: bad arguments");
     if (f->partial_out) return gingr_set_error(ctx, GINGR_ERR_STATE, "sharded update: this fitter belongs to a device group");
     if (z && n_iterations != 1) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "sharded update: a sampled proposal is one iteration");
-    const int32_t r = f->m->r, rp = f->m->rp;
-    if (z) {  // (pageable on purpose, see sample_update)
-        std::vector<double> zz((size_t)rp, 0.0);
-        memcpy(zz.data(), z, (size_t)r * sizeof(double));
-        HIP_TRY(ctx, hipMemcpyAsync(f->zrand, zz.data(), (size_t)rp * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    }
+    if (z) GINGR_TRY(fitter_upload_zrand(f, z));
     f->zrand_active = z != nullptr;
     int rc = GINGR_OK;
     for (int32_t it = 0; it < n_iterations && rc == GINGR_OK; ++it) {
@@ -1750,12 +1772,9 @@ static int sample_update(gingr_fitter *f, int flavour, const gingr_cpd_params *c
     gingr_ctx *ctx = f->ctx;
     if (!z) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "update_sample: z is null");
     if (f->m->M != f->m->M_total) return gingr_set_error(ctx, GINGR_ERR_STATE, "update_sample: single shard only");
-    const int32_t r = f->m->r, rp = f->m->rp;
-    // (pageable on purpose: this entry point returns without synchronising, and a copy from pageable memory has consumed its source
-    // when the call returns -- the pinned buffer of the synchronous entry points must not be rewritten under a pending transfer)
-    std::vector<double> zz((size_t)rp, 0.0);
-    memcpy(zz.data(), z, (size_t)r * sizeof(double));
-    HIP_TRY(ctx, hipMemcpyAsync(f->zrand, zz.data(), (size_t)rp * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    // (this entry point returns without synchronising: the draws go through the fitter's own event-guarded pinned buffer, not
+    // through `pin`, which the synchronous entry points rewrite)
+    GINGR_TRY(fitter_upload_zrand(f, z));
     f->zrand_active = true;
     int rc = GINGR_OK;
     f->allow_alt = true;
@@ -2230,6 +2249,19 @@ int gingr_fitter_mh_step(gingr_fitter *f, const gingr_mh_request *q, double *alp
     HIP_TRY(ctx, hipMemcpyAsync(f->mh_save, f->state_block, head * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     f->mh_key = f->state_key;
     std::swap(f->fit, f->fit_alt);
+    // From here on the device state is in flux (fit pointers exchanged, state block and memo keys about to be rewritten): a failure
+    // on the way must not leave something behind that the next mh_step / mh_restore would take for a consistent state -- the
+    // caller is sent back through gingr_fitter_set_state.
+    struct Poison {
+        gingr_fitter *f;
+        bool armed = true;
+        ~Poison() {
+            if (!armed) return;
+            f->state_key_valid = false;
+            f->mh_saved = false;
+            f->forget_posteriors();
+        }
+    } poison{f};
     const DevState *x_state = reinterpret_cast<const DevState *>(f->mh_save + rp + kScalarsDoubles);
     // (3) the proposal
     memset(f->pin, 0, ((size_t)rp + kScalarsDoubles) * sizeof(double));
@@ -2296,6 +2328,7 @@ int gingr_fitter_mh_step(gingr_fitter *f, const gingr_mh_request *q, double *alp
     }
     GINGR_TRY(check_launch(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    poison.armed = false;
     f->mh_saved = true;
     DevState hst;
     memcpy(&hst, f->pin + rp + kScalarsDoubles, sizeof(hst));

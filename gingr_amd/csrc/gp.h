@@ -120,7 +120,7 @@ int fitter_sharded_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params *
 int fitter_run_phase(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int phase);
 int fitter_logpdf_prepare(gingr_fitter *f, const double *mesh_xyz_full);  // before the exchange of segment 1
 int fitter_logpdf_finish(gingr_fitter *f, double *logpdf);                // behind it
-void fitter_set_zrand(gingr_fitter *f, const double *z);                   // nullable: the next phase 2 draws a sample (device group)
+int fitter_set_zrand(gingr_fitter *f, const double *z);                    // nullable: the next phase 2 draws a sample (device group)
 double *fitter_fullfit(gingr_fitter *f);                                   // [3][M_total] or nullptr
 gingr_ctx *fitter_ctx(gingr_fitter *f);
 const gingr_model *fitter_model(gingr_fitter *f);

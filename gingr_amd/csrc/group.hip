@@ -199,6 +199,7 @@ void free_exchange(gingr_group *g) {
         g->readyfit[p].clear();
     }
     g->meshes = false;
+    g->reversed = false;  // (the fitters forget their direction with their meshes: a new target starts in the forward direction)
     g->xch.clear();
 }
 
@@ -362,9 +363,8 @@ int group_update(gingr_group *g, int flavour, const gingr_cpd_params *cp, const 
     const int64_t it0 = g->iteration;
     g->iteration += n_iterations;
     return g->run([&](int r) {
-        int rc = GINGR_OK;
         gingr_fitter *f = g->fit[(size_t)r];
-        fitter_set_zrand(f, z);
+        int rc = fitter_set_zrand(f, z);  // (a shard that failed here still takes part in every exchange below, flagged not-ok)
         for (int32_t it = 0; it < n_iterations; ++it) {
             const int parity = (int)((it0 + it) & 1);
             if (!rc) fitter_set_partial_output(f, g->send[parity][(size_t)r]);
@@ -384,7 +384,7 @@ int group_update(gingr_group *g, int flavour, const gingr_cpd_params *cp, const 
                 }
             }
         }
-        fitter_set_zrand(f, nullptr);
+        (void)fitter_set_zrand(f, nullptr);
         return rc;
     });
 }
@@ -609,27 +609,50 @@ int gingr_group_set_meshes(gingr_group *g, int64_t n_model_triangles, const int3
     GINGR_TRY(g->run([&](int r) {
         return gingr_fitter_set_meshes(g->fit[(size_t)r], n_model_triangles, model_triangles, n_target_triangles, target_triangles);
     }));
-    g->meshes = true;
-    if (g->n == 1 || !g->sendfit[0].empty()) return GINGR_OK;
-    // the contributions to the gathered fit, peer-readable and double buffered like the other send buffers
+    if (g->n == 1 || !g->sendfit[0].empty()) {
+        g->meshes = true;
+        return GINGR_OK;
+    }
+    // the contributions to the gathered fit, peer-readable and double buffered like the other send buffers.  `meshes` is set only
+    // once every buffer and event exists; a failure on the way leaves none of them behind (group_update then refuses to gather
+    // instead of handing null peer pointers to the exchange kernel)
     DeviceGuard guard;
     const size_t bytes = (size_t)3 * g->M_total * sizeof(double);
-    for (int p = 0; p < 2; ++p) {
-        g->sendfit[p].assign((size_t)g->n, nullptr);
-        g->readyfit[p].assign((size_t)g->n, nullptr);
-        for (int r = 0; r < g->n; ++r) {
-            if (hipSetDevice(g->dev[(size_t)r]) != hipSuccess) return group_fail(g, GINGR_ERR_HIP, "group: hipSetDevice failed");
-            void *buf = nullptr;
-            bool fine = false;
-            GINGR_TRY(alloc_peer_readable(g, bytes, &buf, &fine));
-            g->sendfit[p][(size_t)r] = static_cast<double *>(buf);
-            g->fine_grained = g->fine_grained && fine;
-            if (hipMemset(buf, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
-                return group_fail(g, GINGR_ERR_HIP, "group: memset failed");
-            if (hipEventCreateWithFlags(&g->readyfit[p][(size_t)r], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess)
-                return group_fail(g, GINGR_ERR_HIP, "group: hipEventCreate failed");
+    auto build = [&]() -> int {
+        for (int p = 0; p < 2; ++p) {
+            g->sendfit[p].assign((size_t)g->n, nullptr);
+            g->readyfit[p].assign((size_t)g->n, nullptr);
+            for (int r = 0; r < g->n; ++r) {
+                if (hipSetDevice(g->dev[(size_t)r]) != hipSuccess) return group_fail(g, GINGR_ERR_HIP, "group: hipSetDevice failed");
+                void *buf = nullptr;
+                bool fine = false;
+                GINGR_TRY(alloc_peer_readable(g, bytes, &buf, &fine));
+                g->sendfit[p][(size_t)r] = static_cast<double *>(buf);
+                g->fine_grained = g->fine_grained && fine;
+                if (hipMemset(buf, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+                    return group_fail(g, GINGR_ERR_HIP, "group: memset failed");
+                if (hipEventCreateWithFlags(&g->readyfit[p][(size_t)r], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess)
+                    return group_fail(g, GINGR_ERR_HIP, "group: hipEventCreate failed");
+            }
         }
+        return GINGR_OK;
+    };
+    const int rc = build();
+    if (rc != GINGR_OK) {
+        for (int p = 0; p < 2; ++p) {
+            for (size_t r = 0; r < g->sendfit[p].size(); ++r)
+                if (g->sendfit[p][r]) {
+                    (void)hipSetDevice(g->dev[r]);
+                    (void)hipFree(g->sendfit[p][r]);
+                }
+            g->sendfit[p].clear();
+            for (size_t r = 0; r < g->readyfit[p].size(); ++r)
+                if (g->readyfit[p][r]) (void)hipEventDestroy(g->readyfit[p][r]);
+            g->readyfit[p].clear();
+        }
+        return rc;
     }
+    g->meshes = true;
     return GINGR_OK;
 }
 

@@ -32,7 +32,12 @@ std::mutex g_rccl_mutex;
 
 int load_rccl(gingr_ctx *ctx, const char *path) {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
-    if (g_rccl.handle) return GINGR_OK;
+    if (g_rccl.handle) {
+        // one librccl per process: an explicit request for ANOTHER file is refused, not silently ignored
+        if (path && *path && g_rccl.path != path)
+            return gingr_set_error(ctx, GINGR_ERR_STATE, "rccl: %s is already bound in this process, cannot bind %s", g_rccl.path.c_str(), path);
+        return GINGR_OK;
+    }
     void *h = nullptr;
     if (path && *path) {
         h = dlopen(path, RTLD_NOW | RTLD_LOCAL);

@@ -19,7 +19,7 @@ for i in 1 2 3; do
     (
       if [ -n "$lib" ]; then export GINGR_HIP_LIB=$R/$lib GINGR_HIP_LIB_ALLOW_OLDER=1; fi
       IFS=',' read -ra E <<< "$envs"; for e in "${E[@]}"; do [ -n "$e" ] && export "$e"; done
-      python3 $R/bench.py --no-cpu-baseline --no-parity-check "$@" 2> $O/$name$i.err | tail -1 > $O/$name$i.json
+      python3 $R/bench.py --no-cpu-baseline --no-parity-check --sustained-steps 0 "$@" 2> $O/$name$i.err | tail -1 > $O/$name$i.json
     )
   done
 done

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One reproducible measurement line per BASELINE.json config (`python bench.py --config N` prints line N; run as a script it
-runs all five and writes gpurun_out/r04_configs.json -- copy it to profiles/).
+runs all five and writes gpurun_out/r05_configs.json -- copy it to profiles/).
 
   1  femur CPD, 1 622 <-> 1 622 vertices of the reference's own demo data (tests/golden/inputs.npz), Gaussian GPMM (70, 50) built on the
      device, DemoCPD settings (examples/DemoCPD.scala:11-25: CpdConfiguration defaults, NoTransforms) -- the reference's CPU-runnable case
@@ -223,7 +223,64 @@ def config4():
     return o
 
 
-def config5():
+def run_chains(n: int, devices, steps: int = 3000):
+    """n Metropolis-Hastings chains side by side, chain i in its own process with HIP_VISIBLE_DEVICES=devices[i] (the parent never
+    touches a GPU), seeds 0..n-1, chain loops released together through a file barrier.  GingrAlgorithm.run is one sequential loop
+    per chain (G/api/GingrAlgorithm.scala:115-175), so 8 chains are 8 independent replicas -- nothing is exchanged."""
+    import tempfile
+    bdir = tempfile.mkdtemp(prefix="gingr_chains_")
+    procs = []
+    for i in range(n):
+        env = dict(os.environ)
+        env["HIP_VISIBLE_DEVICES"] = str(devices[i])
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "bench_mh_chain.py"), str(steps), str(i), f"barrier={bdir}",
+                                       f"index={i}"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
+    t_wait = time.time()
+    while not all(os.path.exists(os.path.join(bdir, f"ready_{i}")) for i in range(n)):
+        if any(p.poll() is not None for p in procs) or time.time() - t_wait > 900:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            errs = [p.communicate()[1][-600:] for p in procs]
+            raise RuntimeError("a chain process ended before the start barrier: " + " | ".join(errs))
+        time.sleep(0.01)
+    t0 = time.time()
+    open(os.path.join(bdir, "go"), "w").close()
+    outs = [p.communicate(timeout=1800) for p in procs]
+    wall = time.time() - t0
+    lines = []
+    for p, (so, se) in zip(procs, outs):
+        if p.returncode != 0:
+            raise RuntimeError(se[-2000:])
+        lines.append(json.loads([ln for ln in so.splitlines() if ln.strip().startswith("{")][-1]))
+    starts = [c["loop_started_unix"] for c in lines]
+    ends = [c["loop_started_unix"] + c["loop_seconds"] for c in lines]
+    overlap = max(0.0, min(ends) - max(starts)) / max(1e-9, max(ends) - min(starts))
+    return {"chains": n, "devices": [str(d) for d in devices[:n]], "steps_per_chain": steps,
+            "per_chain_steps_per_s": [round(c["steps_per_s"], 1) for c in lines],
+            "aggregate_steps_per_s": sum(c["steps_per_s"] for c in lines),
+            "aggregate_steps_per_s_wall": n * steps / (max(ends) - min(starts)),
+            "loops_overlap_fraction": overlap, "wall_s_release_to_exit": wall,
+            "device_uuids": [c["device"]["uuid"] for c in lines], "distinct_device_uuids": len({c["device"]["uuid"] for c in lines}),
+            "statuses": [c["status"] for c in lines], "log_value_best": [c["log_value_best"] for c in lines],
+            "log_value_initial": lines[0]["log_value_initial"]}
+
+
+def config5(gpus: int = 1):
+    # how many devices are there?  (device_count does not initialise the GPU: this process stays a pure launcher)
+    import torch
+    visible = torch.cuda.device_count()
+    multi = None
+    if gpus > 1 and visible >= gpus:
+        multi = dict(run_chains(gpus, list(range(gpus))), mode="one chain per GPU (BASELINE config 5 as stated)")
+    elif gpus > 1:
+        multi = {"mode": f"asked for {gpus} GPUs, {visible} visible: the chains are PACKED on device 0 (they share the GPU: not config 5 as "
+                         "stated, a protocol run of the same launcher)",
+                 **run_chains(gpus, [0] * gpus)}
+    packed = None
+    if visible == 1:    # one-GPU box: what several replicas sharing the device give (a chain leaves most of the GPU idle)
+        packed = [run_chains(n, [0] * n) for n in (2, 4, 8)]
+
     def chain(*extra):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_mh_chain.py"), "300", "0", *extra], capture_output=True,
                              text=True, timeout=1800, cwd=ROOT)
@@ -246,7 +303,9 @@ def config5():
             "parity_check": {"against": "tests/test_gpu_sampling.py: a 25-step chain reproduces the oracle's accept / reject sequence; "
                                         "tests/test_gpu_mh_step.py: fused steps = call-by-call steps (decisions, states <= 1e-9)",
                              "log_value_initial": c["log_value_initial"], "log_value_best": c["log_value_best"]},
-            "roofline": None, "cpu_baseline": None, "detail": c}
+            "roofline": None, "cpu_baseline": None, "detail": c,
+            # `--config 5 --gpus N`: N chain processes, one per GPU; on a one-GPU box also 2 / 4 / 8 replicas packed on the device
+            "chains_one_per_gpu": multi, "chains_packed_on_one_gpu": packed}
 
 
 CONFIGS = {1: config1, 2: config2, 3: config3, 4: config4, 5: config5}
@@ -257,14 +316,14 @@ def main():
     lines = []
     for c in which:
         try:
-            o = CONFIGS[c]()
+            o = CONFIGS[c]()   # (config 5 with --gpus N: python bench.py --config 5 --gpus N)
         except Exception as ex:  # a failing config must not hide the others
             o = {"config": c, "error": repr(ex)[:2000], "valid": False}
         lines.append(o)
         print(json.dumps(o), flush=True)
     if len(which) > 1:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        json.dump(lines, open(os.path.join(ROOT, "gpurun_out", "r04_configs.json"), "w"), indent=1)
+        json.dump(lines, open(os.path.join(ROOT, "gpurun_out", "r05_configs.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -6,7 +6,9 @@ both meshes to 100 points with scalismo's decimation, which is not restated: the
 One step = proposal (informed: surface ICP update with a posterior sample; or a random walk re-instantiated on the device)
 + likelihood of the proposal + both transition densities + accept / reject.
     PYTHONPATH=. python tools/bench_mh_chain.py [steps] [seed] [nofuse]     (nofuse: the call-by-call path instead of one native call per step)
-Config 5 proper is 8 such chains, one per GPU, no communication ("replicas only")."""
+Config 5 proper is 8 such chains, one per GPU, no communication ("replicas only"): `python bench.py --config 5
+--gpus N` starts N of these processes, process i with HIP_VISIBLE_DEVICES=i, and passes barrier=<dir> index=<i> so that the chains
+start together (every process writes <dir>/ready_<i> when it is set up and waits for <dir>/go)."""
 import json
 import os
 import sys
@@ -53,6 +55,16 @@ class Log:
 
 ev = sp.EvaluatorWrapper(True, settings.evaluators)
 v0 = ev.logValue(s0)
+t_go = None
+if "barrier" in OPTS:       # several chains side by side: start the chain loops together
+    bdir, bidx = OPTS["barrier"], OPTS.get("index", "0")
+    open(os.path.join(bdir, f"ready_{bidx}"), "w").close()
+    t_wait = time.time()
+    while not os.path.exists(os.path.join(bdir, "go")):
+        if time.time() - t_wait > 600:
+            sys.exit("barrier: no go file after 600 s")
+        time.sleep(0.002)
+    t_go = time.time()
 t0 = time.perf_counter()
 best = algo.run(s0, acceptRejectLogger=Log(), probabilisticSettings=settings, rnd=sp.Random(seed))
 dt = time.perf_counter() - t0
@@ -63,4 +75,7 @@ print(json.dumps({"what": "MH-in-GiNGR chain, femur, surface ICP proposals (conf
                   "rank": int(model.rank), "steps": steps, "fused_steps": fused, "steps_per_s": steps / dt, "ms_per_step": dt / steps * 1e3,
                   "log_value_initial": v0, "log_value_best": ev.logValue(best),
                   "accepted_rejected_by_proposal": counts, "avg_surface_distance_best": avg, "max_surface_distance_best": mx,
-                  "status": int(best.general.status)}))
+                  "status": int(best.general.status), "seed": seed,
+                  "device": {"name": torch.cuda.get_device_properties(0).name, "uuid": str(getattr(torch.cuda.get_device_properties(0), "uuid", "")),
+                             "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES")},
+                  "loop_started_unix": t_go, "loop_seconds": dt}))
