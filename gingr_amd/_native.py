@@ -20,6 +20,7 @@ ERR_BAD_ARGUMENT, ERR_HIP, ERR_NONFINITE, ERR_NOT_SPD, ERR_NO_DEVICE, ERR_STATE 
 NUM_PHASES = 3
 NUM_SEGMENTS = 2
 SEGMENT_FULLFIT = 2   # the gather of a sharded surface update (gingr_hip.h)
+SEGMENT_REVSUM = 3    # per-template-vertex sums of the sharded reversed correspondence direction
 FLAVOUR_CPD, FLAVOUR_ICP, FLAVOUR_ICP_SURFACE = 0, 1, 2
 RCCL_UNIQUE_ID_BYTES = 128
 
@@ -166,6 +167,9 @@ SIGNATURES = {
     "gingr_fitter_update_sharded_async": (c_int, [c_void_p, c_int32, POINTER(CpdParams), POINTER(IcpParams), c_int32, _dp, ALLREDUCE_FN, c_void_p]),
     "gingr_fitter_posterior_logpdf_sharded": (c_int, [c_void_p, c_int32, POINTER(CpdParams), POINTER(IcpParams), _dp, ALLREDUCE_FN, c_void_p, _dp]),
     "gingr_fitter_fullfit_exchange": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),
+    "gingr_fitter_reversal_exchange": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),
+    "gingr_fitter_gather_stage": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64)]),
+    "gingr_fitter_gather_finish": (c_int, [c_void_p, c_int32]),
     "gingr_fitter_update_rccl_async": (c_int, [c_void_p, c_int32, POINTER(CpdParams), POINTER(IcpParams), c_int32, _dp]),
     "gingr_fitter_posterior_logpdf_rccl": (c_int, [c_void_p, c_int32, POINTER(CpdParams), POINTER(IcpParams), _dp, _dp]),
     "gingr_group_set_meshes": (c_int, [c_void_p, c_int64, _ip, c_int64, _ip]),

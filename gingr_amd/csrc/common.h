@@ -270,6 +270,12 @@ void launch_reversal_observations(gingr_ctx *ctx, int64_t M, Cloud tgt, const in
                                   int32_t *svals, void *sort_temp, size_t sort_temp_bytes, double *w01_targets, double *obs_soa,
                                   double *weight_in);
 
+// the same for a RANGE of the target queries (tgt = that range), left as sums: sums4 [4][M] = {sum x, sum y, sum z, count} per
+// template vertex (a row shard's contribution to the all-reduce of the reversed direction); tgt.n may be 0
+void launch_reversal_sums(gingr_ctx *ctx, int64_t M, Cloud tgt, const int32_t *nn_vertex, const int32_t *pre, const int32_t *hit,
+                          int32_t *keys, int32_t *vals, int32_t *skeys, int32_t *svals, void *sort_temp, size_t sort_temp_bytes,
+                          double *w01_targets, double *sums4);
+
 // interleaved xyz (n*3) <-> SoA planes; perm (nullable) maps device position -> original index:
 // soa[s] = aos[perm[s]] resp. aos[perm[s]] = soa[s]
 void launch_aos_to_soa(gingr_ctx *ctx, const double *aos, int64_t n, double *soa, const int32_t *perm = nullptr);

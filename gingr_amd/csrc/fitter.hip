@@ -71,8 +71,25 @@ struct gingr_fitter {
     // template, so the per-template-vertex arrays cover the whole template in ORIGINAL vertex order (set_meshes builds them); the
     // observations of this shard's rows are picked out afterwards (reversal_local_kernel)
     int32_t *radj_ptr = nullptr, *radj_tri = nullptr, *rmbnd = nullptr;
-    double *rmvn = nullptr, *rfboxes = nullptr, *robs_full = nullptr, *rwin_full = nullptr;
+    double *rmvn = nullptr, *rfboxes = nullptr;
     void *rws = nullptr;
+    // Round 5: the SCAN of the reversed direction is sharded too.  Its queries are the replicated target, so they partition by index
+    // range -- this shard takes the device positions [rq0, rq0 + rqn) of the target, the fraction of the cloud that its rows are of
+    // the template -- and every shard accumulates, per TEMPLATE vertex of the whole template (original ids), the sum of its accepted
+    // target points and their number: revsum [4][M_total] = {sum x, sum y, sum z, count}.  One all-reduce (sum) of that buffer
+    // (exchange segment GINGR_SEGMENT_REVSUM, between phases 0 and 1) gives every shard the totals; it keeps its own rows
+    // (reversal_local_kernel).  partial_revsum: where the contribution goes when the sum lands elsewhere (device group).
+    int64_t rq0 = 0, rqn = 0;
+    double *rtvn_loc = nullptr;   // [3][rqn] vertex normals of the target's query range (the target is fixed: built once)
+    double *revsum = nullptr, *partial_revsum = nullptr;
+    // The nearest-template-VERTEX search of that direction runs against a spatially ordered copy of the gathered template: the
+    // gathered fit is in original vertex order (the triangles index it), whose 256-vertex tiles are not compact, so the box-pruned
+    // scan degenerated to all pairs (100 us for 5 121 queries x 40 962 vertices).  gperm (k-d leaf order of the first gathered fit,
+    // fixed afterwards: a deforming template stays coherent) / gsorted [3][M_total]; matches are mapped back to original ids.
+    int32_t *gperm = nullptr;
+    double *gsorted = nullptr;
+    int32_t *rnn_pos = nullptr;  // last search's matches as POSITIONS in gsorted: the warm start of the next one (queries and order are fixed)
+    bool rnn_warm = false;
     int32_t *mtri_orig = nullptr, *mboundary = nullptr;
     double *rcp = nullptr, *rd2 = nullptr, *rnnd2 = nullptr, *rw01 = nullptr, *robs = nullptr, *rwin = nullptr;
     int32_t *rnn = nullptr, *rpre = nullptr, *rhit = nullptr, *rkeys = nullptr, *rvals = nullptr, *rskeys = nullptr, *rsvals = nullptr;
@@ -150,6 +167,11 @@ struct gingr_fitter {
     // all-reduce the other segments already use) -- and the template triangles index that buffer.  partial_fullfit: where the
     // contribution goes when the sum lands elsewhere (device group); nullptr = in place.
     double *fullfit = nullptr, *partial_fullfit = nullptr;
+    // ... or, where the host has a real all-gather (RCCL: rccl_exchange.hip; gingr_fitter_gather_stage / _finish): the shard's rows go
+    // into ITS slot of gstage [world][3][chunk] (original row order, chunk = ceil(M_total / world)), the slots are all-gathered in
+    // place and one kernel spreads them over the planes of `fullfit` -- half the wire bytes of the zero-padded all-reduce, no sum
+    double *gstage = nullptr;
+    int gstage_world = 0;
     bool sharded() const { return m->M != m->M_total; }
     int32_t *retry = nullptr;  // device word: retryCounter of the algorithm instance this fitter stands for (GingrAlgorithm.scala:69-70)
     // ---- one Metropolis-Hastings step per call (gingr_fitter_mh_step): the state x the step started from stays on the device --
@@ -193,17 +215,71 @@ __global__ __launch_bounds__(256) void fit_contribution_kernel(const double *__r
     for (int d = 0; d < 3; ++d) full[d * M_total + g] = mine ? fit[d * M + pos] : 0.0;
 }
 
+// stage[d][l] = this shard's fit of its l-th row in ORIGINAL order (device position iperm[l]); l < M
+__global__ __launch_bounds__(256) void fit_to_stage_kernel(const double *__restrict__ fit, const int32_t *__restrict__ iperm, int64_t M, int64_t chunk,
+                                                           double *__restrict__ stage) {
+    const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= M) return;
+    const int64_t pos = iperm[l];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) stage[d * chunk + l] = fit[d * M + pos];
+}
+// full[d][g] = stage[q][d][g - begin(q)], q = the shard that owns row g under the balanced contiguous partition of M_total rows over
+// `world` shards (the first M_total % world shards hold one row more)
+__global__ __launch_bounds__(256) void stage_to_fullfit_kernel(const double *__restrict__ stage, int world, int64_t chunk, int64_t M_total,
+                                                               double *__restrict__ full) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= M_total) return;
+    const int64_t base = M_total / world, extra = M_total % world;
+    const int64_t cut = extra * (base + 1);  // rows below `cut` sit in shards of base + 1 rows
+    const int64_t q = g < cut ? g / (base + 1) : extra + (g - cut) / (base > 0 ? base : 1);
+    const int64_t b = q * base + (q < extra ? q : extra);
+    const double *p = stage + q * 3 * chunk + (g - b);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) full[d * M_total + g] = p[d * chunk];
+}
+
 // the observations of this shard's rows out of the per-template-vertex arrays of the whole template (original vertex order): device
 // position p of the shard holds original vertex row_begin + perm[p]
+// (sums: [4][M_total] = {sum x, sum y, sum z, count} of the accepted target points per template vertex, summed over all shards'
+// query ranges: the observation of a vertex is their mean, its weight count / sigma2 -- k isotropic observations of one point)
 __global__ __launch_bounds__(256) void reversal_local_kernel(int64_t M, int64_t row_begin, const int32_t *__restrict__ perm, int64_t M_total,
-                                                             const double *__restrict__ obs_full, const double *__restrict__ win_full,
+                                                             const double *__restrict__ sums, const double *__restrict__ sigma2,
                                                              double *__restrict__ obs, double *__restrict__ win) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= M) return;
     const int64_t g = row_begin + perm[p];
+    const double k = sums[3 * M_total + g];
+    const double kk = k > 0.0 ? k : 1.0;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) obs[d * M + p] = obs_full[d * M_total + g];
-    win[p] = win_full[g];
+    for (int d = 0; d < 3; ++d) obs[d * M + p] = sums[d * M_total + g] / kk;
+    win[p] = k / sigma2[0];
+}
+
+// dst[d][p] = src[d][perm[p]] (SoA planes of n points)
+__global__ __launch_bounds__(256) void soa_permute_kernel(const double *__restrict__ src, const int32_t *__restrict__ perm, int64_t n,
+                                                          double *__restrict__ dst) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int64_t g = perm[p];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) dst[d * n + p] = src[d * n + g];
+}
+// idx[j] = map[pos[j]] (positions in the spatially ordered template -> original vertex ids); negative entries stay
+__global__ __launch_bounds__(256) void index_map_kernel(const int32_t *__restrict__ pos, int64_t n, const int32_t *__restrict__ map,
+                                                        int32_t *__restrict__ idx) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int32_t v = pos[j];
+    idx[j] = v >= 0 ? map[v] : v;
+}
+
+// dst[d][i] = src[d][q0 + i]: a compact copy of the planes of an SoA array for the index range [q0, q0 + n)
+__global__ __launch_bounds__(256) void soa_range_kernel(const double *__restrict__ src, int64_t stride, int64_t q0, int64_t n, double *__restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) dst[d * n + i] = src[d * stride + q0 + i];
 }
 
 template <typename T>
@@ -281,10 +357,13 @@ void refresh_fit(gingr_fitter *f) {
 void free_meshes(gingr_fitter *f) {
     void *rptrs[] = {f->mtri_orig, f->mboundary, f->rcp, f->rd2, f->rnnd2, f->rw01, f->robs, f->rwin, f->rnn, f->rpre, f->rhit,
                      f->rkeys, f->rvals, f->rskeys, f->rsvals, f->rsort, f->radj_ptr, f->radj_tri, f->rmbnd, f->rmvn, f->rfboxes,
-                     f->robs_full, f->rwin_full, f->rws};
+                     f->rtvn_loc, f->revsum, f->rws, f->gperm, f->gsorted, f->rnn_pos};
     for (void *p : rptrs) dev_free(p);
     f->radj_ptr = f->radj_tri = f->rmbnd = nullptr;
-    f->rmvn = f->rfboxes = f->robs_full = f->rwin_full = nullptr;
+    f->rmvn = f->rfboxes = f->rtvn_loc = f->revsum = f->gsorted = nullptr;
+    f->gperm = f->rnn_pos = nullptr;
+    f->rnn_warm = false;
+    f->rq0 = f->rqn = 0;
     f->rws = nullptr;
     f->mtri_orig = f->mboundary = f->rnn = f->rpre = f->rhit = f->rkeys = f->rvals = f->rskeys = f->rsvals = nullptr;
     f->rcp = f->rd2 = f->rnnd2 = f->rw01 = f->robs = f->rwin = nullptr;
@@ -654,6 +733,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->tile_bad);
     dev_free(f->xch);
     dev_free(f->fullfit);
+    dev_free(f->gstage);
     dev_free(f->ws);
     dev_free(f->work);
     dev_free(f->aos);
@@ -987,6 +1067,8 @@ static void nearest_target_vertex(gingr_ctx *ctx, gingr_fitter *f, Cloud query, 
 void fitter_set_partial_output(gingr_fitter *f, double *base) { f->partial_out = base; }
 void fitter_set_partial_fullfit(gingr_fitter *f, double *base) { f->partial_fullfit = base; }
 double *fitter_fullfit(gingr_fitter *f) { return f->fullfit; }
+void fitter_set_partial_revsum(gingr_fitter *f, double *base) { f->partial_revsum = base; }
+double *fitter_revsum(gingr_fitter *f) { return f->revsum; }
 // z (r standard normals, host) -> f->zrand (rp doubles, zero padded) on the context's stream, without waiting for the stream
 int fitter_upload_zrand(gingr_fitter *f, const double *z) {
     gingr_ctx *ctx = f->ctx;
@@ -1116,35 +1198,60 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
     switch (phase) {
         case 0: {
             if (icp && f->reversed && f->sharded()) {
-                // the same correspondence as below, replicated on every shard against the GATHERED template (meshc: original vertex
-                // order, so a matched vertex IS its original id and ties go to the lowest id as on a single shard); then this
-                // shard's rows of the per-template-vertex observations
-                if (!f->fullfit || !f->robs_full)
+                // The same correspondence as below against the GATHERED template (meshc: original vertex order, so a matched vertex IS
+                // its original id and ties go to the lowest id as on a single shard), for THIS shard's range of the target queries
+                // only; what leaves the phase is the per-template-vertex sums of the range (see gingr_fitter::revsum).  The tests that
+                // involve the target mesh itself (self-intersection) see the whole target.
+                if (!f->fullfit || !f->revsum)
                     return gingr_set_error(ctx, GINGR_ERR_STATE, "reversed correspondence direction on a row shard: meshes / direction not set");
-                const int64_t N = f->N, Mt = m->M_total;
-                launch_tile_bbox(ctx, meshc, f->rfboxes);
+                const int64_t Mt = m->M_total, q0 = f->rq0, nq = f->rqn;
+                const Cloud tq{tgt.x + q0, tgt.y + q0, tgt.z + q0, nq};
+                double *sums = f->partial_revsum ? f->partial_revsum : f->revsum;
+                if (!f->gperm) {  // one-off (synchronises once): the spatial order of the gathered template for the vertex search
+                    std::vector<double> soa((size_t)3 * Mt), aosv((size_t)3 * Mt);
+                    HIP_TRY(ctx, hipMemcpyAsync(soa.data(), f->fullfit, soa.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                    for (int64_t g = 0; g < Mt; ++g)
+                        for (int d = 0; d < 3; ++d) aosv[(size_t)(3 * g + d)] = soa[(size_t)(d * Mt + g)];
+                    std::vector<int32_t> order;
+                    morton_order(aosv.data(), Mt, order);
+                    GINGR_TRY(dev_alloc(ctx, &f->gperm, (size_t)Mt));
+                    GINGR_TRY(dev_alloc(ctx, &f->gsorted, (size_t)3 * Mt));
+                    GINGR_TRY(dev_alloc(ctx, &f->rnn_pos, (size_t)(f->N > 0 ? f->N : 1)));
+                    HIP_TRY(ctx, hipMemcpy(f->gperm, order.data(), (size_t)Mt * sizeof(int32_t), hipMemcpyHostToDevice));
+                }
+                hipLaunchKernelGGL(soa_permute_kernel, dim3((unsigned)ceil_div(Mt, 256)), dim3(256), 0, ctx->stream, f->fullfit, f->gperm, Mt, f->gsorted);
+                const Cloud msort = cloud_of(f->gsorted, Mt);
+                launch_tile_bbox(ctx, msort, f->rfboxes);
+                auto nearest_template_vertex = [&](Cloud q) {  // -> f->rnn: ORIGINAL vertex ids (lowest id on exact ties)
+                    // (warm start from the last search: the queries are the same target vertices, the template moved a little -- with it the
+                    // chunks a small query range is split into all start from a tight bound)
+                    launch_nn(ctx, q, msort, f->gperm, f->rfboxes, f->rws, f->rnn_pos, f->rnnd2, f->rnn_warm ? f->rnn_pos : nullptr);
+                    f->rnn_warm = true;
+                    hipLaunchKernelGGL(index_map_kernel, dim3((unsigned)ceil_div(q.n, 256)), dim3(256), 0, ctx->stream, f->rnn_pos, q.n, f->gperm, f->rnn);
+                };
                 if (f->icp_surface) {
                     const bool along = f->surface_method == 1;
                     launch_cell_normals(ctx, meshc, f->mtri, f->Tm, f->mcn);
                     launch_vertex_normals(ctx, f->radj_ptr, f->radj_tri, f->mcn, f->Tm, Mt, f->rmvn);
                     launch_tri_tile_bbox(ctx, meshc, f->mtri, f->Tm, f->mtboxes, f->mtribox);
-                    if (along)
-                        launch_line_nearest(ctx, tgt, f->tvn, meshc, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, f->rcp, f->rhit);
-                    else
-                        launch_surface_closest_point(ctx, tgt, meshc, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, f->rcp, f->rd2, nullptr, nullptr,
-                                                     false, f->mtribox);
-                    launch_nn(ctx, cloud_of(f->rcp, N), meshc, nullptr, f->rfboxes, f->rws, f->rnn, f->rnnd2);
-                    launch_surface_prereject(ctx, N, f->rnn, f->rmbnd, f->tvn, f->rmvn, Mt, along ? f->rhit : nullptr, f->rpre);
-                    launch_self_intersect(ctx, tgt, f->rcp, f->ttri, f->Tt, f->ttboxes, f->rpre, f->rhit, f->ttribox);
-                    launch_reversal_observations(ctx, Mt, tgt, f->rnn, f->rpre, f->rhit, &f->st->sigma2, f->rkeys, f->rvals, f->rskeys,
-                                                 f->rsvals, f->rsort, f->rsort_bytes, f->rw01, f->robs_full, f->rwin_full);
+                    if (nq > 0) {
+                        if (along)
+                            launch_line_nearest(ctx, tq, f->rtvn_loc, meshc, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, f->rcp, f->rhit);
+                        else
+                            launch_surface_closest_point(ctx, tq, meshc, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, f->rcp, f->rd2, nullptr, nullptr,
+                                                         false, f->mtribox);
+                        nearest_template_vertex(cloud_of(f->rcp, nq));
+                        launch_surface_prereject(ctx, nq, f->rnn, f->rmbnd, f->rtvn_loc, f->rmvn, Mt, along ? f->rhit : nullptr, f->rpre);
+                        launch_self_intersect(ctx, tq, f->rcp, f->ttri, f->Tt, f->ttboxes, f->rpre, f->rhit, f->ttribox, &tgt);
+                    }
+                    launch_reversal_sums(ctx, Mt, tq, f->rnn, f->rpre, f->rhit, f->rkeys, f->rvals, f->rskeys, f->rsvals, f->rsort, f->rsort_bytes,
+                                         f->rw01 + q0, sums);
                 } else {
-                    launch_nn(ctx, tgt, meshc, nullptr, f->rfboxes, f->rws, f->rnn, f->rnnd2);
-                    launch_reversal_observations(ctx, Mt, tgt, f->rnn, nullptr, nullptr, &f->st->sigma2, f->rkeys, f->rvals, f->rskeys,
-                                                 f->rsvals, f->rsort, f->rsort_bytes, f->rw01, f->robs_full, f->rwin_full);
+                    if (nq > 0) nearest_template_vertex(tq);
+                    launch_reversal_sums(ctx, Mt, tq, f->rnn, nullptr, nullptr, f->rkeys, f->rvals, f->rskeys, f->rsvals, f->rsort, f->rsort_bytes,
+                                         f->rw01 + q0, sums);
                 }
-                hipLaunchKernelGGL(reversal_local_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, ctx->stream, M, m->row_begin, m->perm, Mt,
-                                   f->robs_full, f->rwin_full, f->robs, f->rwin);
             } else if (icp && f->reversed) {
                 // closestPointCorrespondenceReversal (ClosestPointRegistrator.scala:34-49): the roles of the two meshes are swapped,
                 // then every accepted target vertex becomes an observation of the template vertex nearest to its match
@@ -1217,6 +1324,9 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
             fa.rhs = rhsw;
             fa.sc8 = sc8w;
             if (icp) {
+                if (f->reversed && f->sharded())  // the totals over all shards' query ranges are in place: this shard's rows of them
+                    hipLaunchKernelGGL(reversal_local_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, ctx->stream, M, m->row_begin, m->perm,
+                                       m->M_total, f->revsum, &f->st->sigma2, f->robs, f->rwin);
                 if (f->reversed)  // one observation per template vertex: mean of its accepted targets, weight count / sigma2
                     launch_obs_points(ctx, m, f->st, f->robs, f->rwin, f->weight, f->evec, f->lm_mask);
                 else if (f->icp_surface)  // only the weight-1 pairs are observed (ICP.scala:50): weight 0 drops the row
@@ -1391,8 +1501,24 @@ int fitter_run_phase(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, c
 // iteration): per iteration [surface: gather phase, all-reduce of the full fit], phase 0, [CPD: all-reduce of the column sums],
 // phase 1, all-reduce of the Gram bundle, phase 2.  The posterior solve, the sample a + L^-T z and everything behind them are
 // replicated r x r algebra, so z is the same on every shard and nothing else is exchanged.
+// gather (nullable): does the whole gather of the fit itself (stage, all-gather, unpack: rccl_exchange.hip) and returns 0; a positive
+// value means "not possible here" and the zero-padded all-reduce through `reduce` is used instead
+static int gather_fit(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, gingr_allreduce_fn reduce, void *user,
+                      fitter_gather_fn gather, const char *who) {
+    gingr_ctx *ctx = f->ctx;
+    if (gather) {
+        const int g = gather(user, f);
+        if (g == 0) return GINGR_OK;
+        if (g < 0) return gingr_set_error(ctx, GINGR_ERR_STATE, "%s: the all-gather of the fit failed", who);
+    }
+    GINGR_TRY(fitter_run_phase(f, flavour, cp, ip, GINGR_PHASE_GATHER));
+    if (reduce(user, GINGR_SEGMENT_FULLFIT, f->fullfit, 3 * f->m->M_total) != 0)
+        return gingr_set_error(ctx, GINGR_ERR_STATE, "%s: the all-reduce callback failed (full fit)", who);
+    return GINGR_OK;
+}
+
 int fitter_sharded_update(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations,
-                          const double *z, gingr_allreduce_fn reduce, void *user) {
+                          const double *z, gingr_allreduce_fn reduce, void *user, fitter_gather_fn gather) {
     GINGR_TRY(check_ready(f));
     gingr_ctx *ctx = f->ctx;
     if (n_iterations < 0 || !reduce || flavour < 0 || flavour > 2) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "sharded update: bad arguments");
@@ -1403,11 +1529,7 @@ int fitter_sharded_update(gingr_fitter *f, int flavour, const gingr_cpd_params *
     int rc = GINGR_OK;
     for (int32_t it = 0; it < n_iterations && rc == GINGR_OK; ++it) {
         TimerScope ts(ctx, 3);
-        if ((flavour == 2 || (flavour == 1 && f->reversed)) && f->sharded()) {
-            rc = fitter_run_phase(f, flavour, cp, ip, GINGR_PHASE_GATHER);
-            if (!rc && reduce(user, GINGR_SEGMENT_FULLFIT, f->fullfit, 3 * f->m->M_total) != 0)
-                rc = gingr_set_error(ctx, GINGR_ERR_STATE, "sharded update: the all-reduce callback failed (full fit)");
-        }
+        if ((flavour == 2 || (flavour == 1 && f->reversed)) && f->sharded()) rc = gather_fit(f, flavour, cp, ip, reduce, user, gather, "sharded update");
         for (int ph = 0; ph < GINGR_NUM_PHASES && rc == GINGR_OK; ++ph) {
             rc = fitter_run_phase(f, flavour, cp, ip, ph);
             if (!rc && ph < GINGR_NUM_SEGMENTS && !(flavour != 0 && ph == 0)) {
@@ -1415,6 +1537,9 @@ int fitter_sharded_update(gingr_fitter *f, int flavour, const gingr_cpd_params *
                 if (reduce(user, ph, f->xch + f->off[ph], f->cnt[ph]) != 0)
                     rc = gingr_set_error(ctx, GINGR_ERR_STATE, "sharded update: the all-reduce callback failed (segment %d)", ph);
             }
+            if (!rc && ph == 0 && flavour != 0 && f->reversed && f->sharded() &&
+                reduce(user, GINGR_SEGMENT_REVSUM, f->revsum, 4 * f->m->M_total) != 0)
+                rc = gingr_set_error(ctx, GINGR_ERR_STATE, "sharded update: the all-reduce callback failed (reversal sums)");
         }
     }
     f->zrand_active = false;
@@ -1426,19 +1551,67 @@ extern "C" {
 int gingr_fitter_update_cpd_sharded_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t n_iterations, gingr_allreduce_fn reduce,
                                           void *user) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
-    return fitter_sharded_update(f, 0, p, nullptr, n_iterations, nullptr, reduce, user);
+    return fitter_sharded_update(f, 0, p, nullptr, n_iterations, nullptr, reduce, user, nullptr);
 }
 
 int gingr_fitter_update_icp_sharded_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations, gingr_allreduce_fn reduce,
                                           void *user) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
-    return fitter_sharded_update(f, 1, nullptr, p, n_iterations, nullptr, reduce, user);
+    return fitter_sharded_update(f, 1, nullptr, p, n_iterations, nullptr, reduce, user, nullptr);
 }
 
 int gingr_fitter_update_sharded_async(gingr_fitter *f, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,
                                       int32_t n_iterations, const double *z, gingr_allreduce_fn reduce, void *user) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
-    return fitter_sharded_update(f, flavour, cp, ip, n_iterations, z, reduce, user);
+    return fitter_sharded_update(f, flavour, cp, ip, n_iterations, z, reduce, user, nullptr);
+}
+
+int gingr_fitter_gather_stage(gingr_fitter *f, int32_t world, int32_t rank, void **send_ptr, void **recv_ptr, int64_t *count_per_rank) {
+    if (!f || !send_ptr || !recv_ptr || !count_per_rank) return GINGR_ERR_BAD_ARGUMENT;
+    GINGR_TRY(check_ready(f));
+    gingr_ctx *ctx = f->ctx;
+    const gingr_model *m = f->m;
+    if (!f->fullfit) return gingr_set_error(ctx, GINGR_ERR_STATE, "gather_stage: not a row shard with meshes (gingr_fitter_set_meshes)");
+    if (world < 1 || rank < 0 || rank >= world) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gather_stage: need 0 <= rank < world");
+    const int64_t Mt = m->M_total, base = Mt / world, extra = Mt % world;
+    const int64_t b = rank * base + (rank < extra ? rank : extra), e = b + base + (rank < extra ? 1 : 0);
+    if (b != m->row_begin || e - b != m->M)
+        return gingr_set_error(ctx, GINGR_ERR_STATE, "gather_stage: rows [%lld, %lld) are not shard %d of the balanced partition over %d shards",
+                               (long long)m->row_begin, (long long)(m->row_begin + m->M), (int)rank, (int)world);
+    const int64_t chunk = ceil_div(Mt, world);
+    if (!f->gstage || f->gstage_world != world) {
+        dev_free(f->gstage);
+        f->gstage = nullptr;
+        GINGR_TRY(dev_alloc(ctx, &f->gstage, (size_t)world * 3 * chunk));
+        HIP_TRY(ctx, hipMemsetAsync(f->gstage, 0, (size_t)world * 3 * chunk * sizeof(double), ctx->stream));
+        f->gstage_world = world;
+    }
+    double *mine = f->gstage + (int64_t)rank * 3 * chunk;
+    hipLaunchKernelGGL(fit_to_stage_kernel, dim3((unsigned)ceil_div(m->M, 256)), dim3(256), 0, ctx->stream, f->fit, m->iperm, m->M, chunk, mine);
+    *send_ptr = mine;
+    *recv_ptr = f->gstage;
+    *count_per_rank = 3 * chunk;
+    return check_launch(ctx);
+}
+
+int gingr_fitter_gather_finish(gingr_fitter *f, int32_t world) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = f->ctx;
+    if (!f->fullfit || !f->gstage || f->gstage_world != world)
+        return gingr_set_error(ctx, GINGR_ERR_STATE, "gather_finish: no gather staged for %d shards (gingr_fitter_gather_stage)", (int)world);
+    const int64_t Mt = f->m->M_total;
+    hipLaunchKernelGGL(stage_to_fullfit_kernel, dim3((unsigned)ceil_div(Mt, 256)), dim3(256), 0, ctx->stream, f->gstage, (int)world, ceil_div(Mt, world),
+                       Mt, f->fullfit);
+    return check_launch(ctx);
+}
+
+int gingr_fitter_reversal_exchange(gingr_fitter *f, void **dev_ptr, int64_t *count) {
+    if (!f || !dev_ptr || !count) return GINGR_ERR_BAD_ARGUMENT;
+    if (!f->revsum)
+        return gingr_set_error(f->ctx, GINGR_ERR_STATE, "reversal_exchange: not a row shard with the reversed direction set (gingr_fitter_set_correspondence_direction)");
+    *dev_ptr = f->revsum;
+    *count = 4 * f->m->M_total;
+    return GINGR_OK;
 }
 
 int gingr_fitter_fullfit_exchange(gingr_fitter *f, void **dev_ptr, int64_t *count) {
@@ -1670,11 +1843,19 @@ int gingr_fitter_set_correspondence_direction(gingr_fitter *f, int32_t reversed)
     if (f->sharded() && !f->radj_ptr)
         return gingr_set_error(ctx, GINGR_ERR_STATE, "set_correspondence_direction: a row shard needs the meshes first (gingr_fitter_set_meshes: "
                                                      "the reversed direction works on the gathered template)");
-    if (f->sharded() && !f->robs_full) {
+    if (f->sharded() && !f->revsum) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
-        const int64_t Mt = f->m->M_total;
+        const int64_t Mt = f->m->M_total, N = f->N;
+        // this shard's range of the target queries: the same fraction of the (replicated) target as its rows are of the template --
+        // the row ranges tile [0, M_total), so the query ranges tile [0, N), whatever the number of shards
+        const int64_t q0 = (int64_t)((__int128)N * f->m->row_begin / Mt), q1 = (int64_t)((__int128)N * (f->m->row_begin + f->m->M) / Mt);
+        f->rq0 = q0;
+        f->rqn = q1 - q0;
         int rc;
-        if ((rc = dev_alloc(ctx, &f->robs_full, (size_t)3 * Mt)) || (rc = dev_alloc(ctx, &f->rwin_full, (size_t)Mt))) return rc;
+        if ((rc = dev_alloc(ctx, &f->revsum, (size_t)4 * Mt)) || (rc = dev_alloc(ctx, &f->rtvn_loc, (size_t)3 * (f->rqn > 0 ? f->rqn : 1)))) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(f->revsum, 0, (size_t)4 * Mt * sizeof(double), ctx->stream));
+        if (f->tvn && f->rqn > 0)
+            hipLaunchKernelGGL(soa_range_kernel, dim3((unsigned)ceil_div(f->rqn, 256)), dim3(256), 0, ctx->stream, f->tvn, N, q0, f->rqn, f->rtvn_loc);
         HIP_TRY(ctx, hipMalloc(&f->rws, (size_t)nn_ws_bytes(f->N, Mt)));
     }
     if (!f->rnn) {  // buffers per target vertex + the sort workspace, once per target
@@ -1704,18 +1885,24 @@ int gingr_fitter_get_reversed_correspondence(gingr_fitter *f, int32_t *template_
     if (!f->rnn) return gingr_set_error(ctx, GINGR_ERR_STATE, "get_reversed_correspondence: direction not reversed");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t N = f->N;
-    std::vector<int32_t> hid((size_t)N);
-    std::vector<double> hw((size_t)N);
-    HIP_TRY(ctx, hipMemcpyAsync(hid.data(), f->rnn, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(hw.data(), f->rw01, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    // a row shard scanned ITS range of the target queries only (device positions [rq0, rq0 + rqn)): the others come back as
+    // (-1, 0) -- the shards' answers are disjoint and together cover the target
+    const int64_t q0 = f->sharded() ? f->rq0 : 0, nq = f->sharded() ? f->rqn : N;
+    std::vector<int32_t> hid((size_t)(nq > 0 ? nq : 1));
+    std::vector<double> hw((size_t)(nq > 0 ? nq : 1));
+    if (nq > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(hid.data(), f->rnn, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(hw.data(), f->rw01 + q0, (size_t)nq * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int64_t s2 = 0; s2 < N; ++s2) {  // device target position -> original target id; device model row -> original vertex id
         const int32_t j = f->h_tperm[(size_t)s2];
-        const int32_t row = hid[(size_t)s2];
+        const bool mine = s2 >= q0 && s2 < q0 + nq;
+        const int32_t row = mine ? hid[(size_t)(s2 - q0)] : -1;
         if (template_id)  // (a row shard searched the gathered template: original vertex ids already)
             template_id[j] = f->sharded() ? ((row >= 0 && row < f->m->M_total) ? row : -1)
                                           : ((row >= 0 && row < f->m->M) ? f->m->hperm[(size_t)row] : -1);
-        if (w) w[j] = hw[(size_t)s2];
+        if (w) w[j] = mine ? hw[(size_t)(s2 - q0)] : 0.0;
     }
     return GINGR_OK;
 }
@@ -1906,20 +2093,18 @@ int fitter_logpdf_finish(gingr_fitter *f, double *logpdf) {
 // posterior(of the current state).gp.logpdf(posterior.coefficients(mesh)) on a row shard (GeneratorWrapperStochastic.scala:42-63):
 // phases 0 and 1 with their exchanges; Q0^T e rides in segment 1; the log-density kernel is replicated.
 int fitter_sharded_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, const double *mesh_xyz_full,
-                          gingr_allreduce_fn reduce, void *user, double *logpdf) {
+                          gingr_allreduce_fn reduce, void *user, double *logpdf, fitter_gather_fn gather) {
     GINGR_TRY(check_ready(f));
     gingr_ctx *ctx = f->ctx;
     if (!mesh_xyz_full || !logpdf || !reduce || flavour < 0 || flavour > 2)
         return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "sharded posterior_logpdf: bad arguments");
     if (f->partial_out) return gingr_set_error(ctx, GINGR_ERR_STATE, "sharded posterior_logpdf: this fitter belongs to a device group");
-    if ((flavour == 2 || (flavour == 1 && f->reversed)) && f->sharded()) {
-        GINGR_TRY(fitter_run_phase(f, flavour, cp, ip, GINGR_PHASE_GATHER));
-        if (reduce(user, GINGR_SEGMENT_FULLFIT, f->fullfit, 3 * f->m->M_total) != 0)
-            return gingr_set_error(ctx, GINGR_ERR_STATE, "sharded posterior_logpdf: the all-reduce callback failed (full fit)");
-    }
+    if ((flavour == 2 || (flavour == 1 && f->reversed)) && f->sharded()) GINGR_TRY(gather_fit(f, flavour, cp, ip, reduce, user, gather, "sharded posterior_logpdf"));
     GINGR_TRY(fitter_run_phase(f, flavour, cp, ip, 0));
     if (flavour == 0 && reduce(user, 0, f->xch + f->off[0], f->cnt[0]) != 0)
         return gingr_set_error(ctx, GINGR_ERR_STATE, "sharded posterior_logpdf: the all-reduce callback failed (segment 0)");
+    if (flavour != 0 && f->reversed && f->sharded() && reduce(user, GINGR_SEGMENT_REVSUM, f->revsum, 4 * f->m->M_total) != 0)
+        return gingr_set_error(ctx, GINGR_ERR_STATE, "sharded posterior_logpdf: the all-reduce callback failed (reversal sums)");
     GINGR_TRY(fitter_run_phase(f, flavour, cp, ip, 1));
     GINGR_TRY(fitter_logpdf_prepare(f, mesh_xyz_full));
     if (reduce(user, 1, f->xch + f->off[1], f->cnt[1]) != 0)
@@ -1932,7 +2117,7 @@ extern "C" {
 int gingr_fitter_posterior_logpdf_sharded(gingr_fitter *f, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,
                                           const double *mesh_xyz_full, gingr_allreduce_fn reduce, void *user, double *logpdf) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
-    return fitter_sharded_logpdf(f, flavour, cp, ip, mesh_xyz_full, reduce, user, logpdf);
+    return fitter_sharded_logpdf(f, flavour, cp, ip, mesh_xyz_full, reduce, user, logpdf, nullptr);
 }
 
 // ===================================================================================== stateless model operators

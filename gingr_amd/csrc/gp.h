@@ -113,15 +113,19 @@ int model_create_impl(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doubl
 void fitter_set_partial_output(gingr_fitter *f, double *base);
 void fitter_set_partial_fullfit(gingr_fitter *f, double *base);
 // the sharded update (fitter.hip) for the other translation units: flavour 0 CPD, 1 ICP point cloud, 2 ICP surface; z nullable (sampled proposal)
+// gather (nullable): the host's own all-gather of the fit -- 0 done, > 0 not possible here (fall back to the zero-padded all-reduce), < 0 failed
+typedef int (*fitter_gather_fn)(void *user, gingr_fitter *f);
 int fitter_sharded_update(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations,
-                          const double *z, gingr_allreduce_fn reduce, void *user);
+                          const double *z, gingr_allreduce_fn reduce, void *user, fitter_gather_fn gather = nullptr);
 int fitter_sharded_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, const double *mesh_xyz_full,
-                          gingr_allreduce_fn reduce, void *user, double *logpdf);
+                          gingr_allreduce_fn reduce, void *user, double *logpdf, fitter_gather_fn gather = nullptr);
 int fitter_run_phase(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int phase);
 int fitter_logpdf_prepare(gingr_fitter *f, const double *mesh_xyz_full);  // before the exchange of segment 1
 int fitter_logpdf_finish(gingr_fitter *f, double *logpdf);                // behind it
 int fitter_set_zrand(gingr_fitter *f, const double *z);                    // nullable: the next phase 2 draws a sample (device group)
 double *fitter_fullfit(gingr_fitter *f);                                   // [3][M_total] or nullptr
+void fitter_set_partial_revsum(gingr_fitter *f, double *base);             // where phase 0 of the reversed direction leaves its sums
+double *fitter_revsum(gingr_fitter *f);                                    // [4][M_total] or nullptr
 gingr_ctx *fitter_ctx(gingr_fitter *f);
 const gingr_model *fitter_model(gingr_fitter *f);
 

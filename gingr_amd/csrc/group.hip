@@ -56,6 +56,22 @@ __global__ __launch_bounds__(256) void peer_sum_kernel(double *__restrict__ out,
     }
 }
 
+// The gather of the fit (exchange segment GINGR_SEGMENT_FULLFIT): every shard has written its rows into ITS send buffer ([3][M_total]
+// planes, original point order); out[d][g] is read from the buffer of the shard that owns row g -- one remote read per element, not a
+// sum over n buffers of which n - 1 hold a zero there (round 4).  bounds.b[q] = first row of shard q, b[n] = M_total.
+struct RowBounds {
+    int64_t b[kMaxGroup + 1];
+};
+__global__ __launch_bounds__(256) void peer_gather_rows_kernel(double *__restrict__ out, PeerPtrs src, RowBounds bounds, int n, int64_t M_total) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= M_total) return;
+    int q = 0;
+    while (q + 1 < n && g >= bounds.b[q + 1]) ++q;
+    const double *p = src.p[q];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) out[d * M_total + g] = p[d * M_total + g];
+}
+
 // restores the calling thread's current device: the group's host-side set-up selects its devices one after the other, and a JVM / C /
 // torch host must find its own device selection untouched when the call returns
 struct DeviceGuard {
@@ -102,6 +118,9 @@ struct gingr_group {
     // the gather of a sharded surface update (exchange segment GINGR_SEGMENT_FULLFIT): contributions [3 M_total] per shard and parity
     std::vector<double *> sendfit[2];
     std::vector<hipEvent_t> readyfit[2];
+    // the per-template-vertex sums of the sharded reversed direction (GINGR_SEGMENT_REVSUM): contributions [4 M_total] per shard and parity
+    std::vector<double *> sendrev[2];
+    std::vector<hipEvent_t> readyrev[2];
     bool meshes = false;
     bool reversed = false;  // reversed correspondence direction (gingr_group_set_correspondence_direction): gathers the fit like flavour 2
     int64_t iteration = 0;                                      // parity of the send buffers
@@ -197,6 +216,15 @@ void free_exchange(gingr_group *g) {
         for (size_t r = 0; r < g->readyfit[p].size(); ++r)
             if (g->readyfit[p][r]) (void)hipEventDestroy(g->readyfit[p][r]);
         g->readyfit[p].clear();
+        for (size_t r = 0; r < g->sendrev[p].size(); ++r)
+            if (g->sendrev[p][r]) {
+                (void)hipSetDevice(g->dev[r]);
+                (void)hipFree(g->sendrev[p][r]);
+            }
+        g->sendrev[p].clear();
+        for (size_t r = 0; r < g->readyrev[p].size(); ++r)
+            if (g->readyrev[p][r]) (void)hipEventDestroy(g->readyrev[p][r]);
+        g->readyrev[p].clear();
     }
     g->meshes = false;
     g->reversed = false;  // (the fitters forget their direction with their meshes: a new target starts in the forward direction)
@@ -312,7 +340,7 @@ int finish_models(gingr_group *g) {
 // ev[r], everybody meets, the stream waits for the peers' events and one kernel adds the n contributions in rank order into dst.
 // `ok` false: the worker still takes part in the barrier (so nobody deadlocks) but enqueues nothing.
 int exchange_buffers(gingr_group *g, int r, std::vector<hipEvent_t> &ev, const std::vector<double *> &src_base, int64_t src_off, double *dst,
-                     int64_t count, bool ok) {
+                     int64_t count, bool ok, bool gather_rows = false) {
     gingr_ctx *ctx = g->ctx[(size_t)r];
     int rc = GINGR_OK;
     if (ok && hipEventRecord(ev[(size_t)r], ctx->stream) != hipSuccess) rc = gingr_set_error(ctx, GINGR_ERR_HIP, "group: hipEventRecord failed");
@@ -324,7 +352,14 @@ int exchange_buffers(gingr_group *g, int r, std::vector<hipEvent_t> &ev, const s
             return gingr_set_error(ctx, GINGR_ERR_HIP, "group: hipStreamWaitEvent failed");
         src.p[q] = src_base[(size_t)q] + src_off;
     }
-    hipLaunchKernelGGL(peer_sum_kernel, dim3((unsigned)ceil_div(ceil_div(count, 2), 256)), dim3(256), 0, ctx->stream, dst, src, g->n, count);
+    if (gather_rows) {  // (count = 3 M_total: every row comes from the one shard that owns it)
+        RowBounds rb;
+        for (int q = 0; q < g->n; ++q) rb.b[q] = g->begin[(size_t)q];
+        rb.b[g->n] = g->M_total;
+        hipLaunchKernelGGL(peer_gather_rows_kernel, dim3((unsigned)ceil_div(g->M_total, 256)), dim3(256), 0, ctx->stream, dst, src, rb, g->n, g->M_total);
+    } else {
+        hipLaunchKernelGGL(peer_sum_kernel, dim3((unsigned)ceil_div(ceil_div(count, 2), 256)), dim3(256), 0, ctx->stream, dst, src, g->n, count);
+    }
     if (hipGetLastError() != hipSuccess) return gingr_set_error(ctx, GINGR_ERR_HIP, "group: all-reduce kernel launch failed");
     return GINGR_OK;
 }
@@ -340,7 +375,11 @@ int timed_exchange_segment(gingr_group *g, int r, int s, int parity, bool ok) {
 }
 // the gather of a sharded surface iteration: contributions in sendfit[parity], the full fit into every fitter's own buffer
 int exchange_fullfit(gingr_group *g, int r, int parity, bool ok) {
-    return exchange_buffers(g, r, g->readyfit[parity], g->sendfit[parity], 0, fitter_fullfit(g->fit[(size_t)r]), 3 * g->M_total, ok);
+    return exchange_buffers(g, r, g->readyfit[parity], g->sendfit[parity], 0, fitter_fullfit(g->fit[(size_t)r]), 3 * g->M_total, ok, true);
+}
+// the reversed direction's per-template-vertex sums: contributions in sendrev[parity], the totals into every fitter's own buffer
+int exchange_revsum(gingr_group *g, int r, int parity, bool ok) {
+    return exchange_buffers(g, r, g->readyrev[parity], g->sendrev[parity], 0, fitter_revsum(g->fit[(size_t)r]), 4 * g->M_total, ok);
 }
 
 // flavour 0 CPD, 1 ICP point cloud, 2 ICP surface; z (nullable): the draws of a sampled proposal (one iteration)
@@ -375,11 +414,17 @@ int group_update(gingr_group *g, int flavour, const gingr_cpd_params *cp, const 
                 const int xrc = exchange_fullfit(g, r, parity, rc == GINGR_OK);
                 if (!rc) rc = xrc;
             }
+            if (!rc && g->reversed && flavour != 0) fitter_set_partial_revsum(f, g->sendrev[parity][(size_t)r]);
             for (int ph = 0; ph < GINGR_NUM_PHASES; ++ph) {
                 if (!rc) rc = fitter_run_phase(f, flavour, cp, ip, ph);
-                // ICP: the correspondence phase has nothing to exchange (rows are independent)
+                // ICP: the correspondence phase has nothing to exchange (rows are independent) ...
                 if (ph < GINGR_NUM_SEGMENTS && !(flavour != 0 && ph == 0)) {
                     const int xrc = timed_exchange_segment(g, r, ph, parity, rc == GINGR_OK);
+                    if (!rc) rc = xrc;
+                }
+                // ... except in the reversed direction: every shard scanned its range of the target queries, the sums are totalled
+                if (ph == 0 && flavour != 0 && g->reversed) {
+                    const int xrc = exchange_revsum(g, r, parity, rc == GINGR_OK);
                     if (!rc) rc = xrc;
                 }
             }
@@ -417,9 +462,13 @@ int group_logpdf(gingr_group *g, int flavour, const gingr_cpd_params *cp, const 
             const int xrc = exchange_fullfit(g, r, parity, rc == GINGR_OK);
             if (!rc) rc = xrc;
         }
+        if (!rc && g->reversed && flavour != 0) fitter_set_partial_revsum(f, g->sendrev[parity][(size_t)r]);
         if (!rc) rc = fitter_run_phase(f, flavour, cp, ip, 0);
         if (flavour == 0) {
             const int xrc = exchange_segment(g, r, 0, parity, rc == GINGR_OK);
+            if (!rc) rc = xrc;
+        } else if (g->reversed) {
+            const int xrc = exchange_revsum(g, r, parity, rc == GINGR_OK);
             if (!rc) rc = xrc;
         }
         if (!rc) rc = fitter_run_phase(f, flavour, cp, ip, 1);
@@ -668,6 +717,46 @@ int gingr_group_set_correspondence_direction(gingr_group *g, int32_t reversed) {
     if (reversed && g->n > 1 && !g->meshes)
         return group_fail(g, GINGR_ERR_STATE, "group set_correspondence_direction: set the meshes first (the reversed direction works on the gathered template)");
     GINGR_TRY(g->run([&](int r) { return gingr_fitter_set_correspondence_direction(g->fit[(size_t)r], reversed); }));
+    if (reversed && g->n > 1 && g->sendrev[0].empty()) {
+        // the shards' contributions to the per-template-vertex sums, peer-readable and double buffered like the other send buffers;
+        // `reversed` is set only once all of them exist
+        DeviceGuard guard;
+        const size_t bytes = (size_t)4 * g->M_total * sizeof(double);
+        auto build = [&]() -> int {
+            for (int p = 0; p < 2; ++p) {
+                g->sendrev[p].assign((size_t)g->n, nullptr);
+                g->readyrev[p].assign((size_t)g->n, nullptr);
+                for (int r = 0; r < g->n; ++r) {
+                    if (hipSetDevice(g->dev[(size_t)r]) != hipSuccess) return group_fail(g, GINGR_ERR_HIP, "group: hipSetDevice failed");
+                    void *buf = nullptr;
+                    bool fine = false;
+                    GINGR_TRY(alloc_peer_readable(g, bytes, &buf, &fine));
+                    g->sendrev[p][(size_t)r] = static_cast<double *>(buf);
+                    g->fine_grained = g->fine_grained && fine;
+                    if (hipMemset(buf, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+                        return group_fail(g, GINGR_ERR_HIP, "group: memset failed");
+                    if (hipEventCreateWithFlags(&g->readyrev[p][(size_t)r], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess)
+                        return group_fail(g, GINGR_ERR_HIP, "group: hipEventCreate failed");
+                }
+            }
+            return GINGR_OK;
+        };
+        const int rc = build();
+        if (rc != GINGR_OK) {
+            for (int p = 0; p < 2; ++p) {
+                for (size_t r = 0; r < g->sendrev[p].size(); ++r)
+                    if (g->sendrev[p][r]) {
+                        (void)hipSetDevice(g->dev[r]);
+                        (void)hipFree(g->sendrev[p][r]);
+                    }
+                g->sendrev[p].clear();
+                for (size_t r = 0; r < g->readyrev[p].size(); ++r)
+                    if (g->readyrev[p][r]) (void)hipEventDestroy(g->readyrev[p][r]);
+                g->readyrev[p].clear();
+            }
+            return rc;
+        }
+    }
     g->reversed = reversed != 0;
     return GINGR_OK;
 }

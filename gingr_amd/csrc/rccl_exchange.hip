@@ -12,7 +12,7 @@
 
 namespace {
 
-// the six entry points used, with RCCL's C signatures (rccl.h): ncclResult_t is an int enum (0 = success), ncclComm_t a pointer,
+// the entry points used, with RCCL's C signatures (rccl.h): ncclResult_t is an int enum (0 = success), ncclComm_t a pointer,
 // ncclUniqueId 128 opaque bytes passed BY VALUE, ncclFloat64 = 8, ncclSum = 0
 struct UniqueId {
     char internal[GINGR_RCCL_UNIQUE_ID_BYTES];
@@ -23,6 +23,7 @@ struct Rccl {
     int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;  // (optional: the gather falls back to AllReduce)
     const char *(*GetErrorString)(int) = nullptr;
     int (*GetVersion)(int *) = nullptr;
     std::string path;
@@ -59,6 +60,7 @@ int load_rccl(gingr_ctx *ctx, const char *path) {
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
     r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(h, "ncclGetVersion"));
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) {
@@ -83,6 +85,23 @@ int native_allreduce(void *user, int32_t, void *device_ptr, int64_t count) {
         return 1;
     }
     return 0;
+}
+
+// the fitter_gather_fn of the native path: the shard's rows into its slot of the staging buffer, ncclAllGather in place (every rank
+// sends the same count: slots are padded to ceil(M_total / world) rows), one kernel spreads the slots over the planes of the full
+// fit.  Half the wire bytes of the zero-padded all-reduce and no reduction (round 4 spelled the gather as a sum).
+int native_gather(void *user, gingr_fitter *f) {
+    gingr_ctx *ctx = static_cast<gingr_ctx *>(user);
+    if (!g_rccl.AllGather) return 1;
+    void *send = nullptr, *recv = nullptr;
+    int64_t count = 0;
+    if (gingr_fitter_gather_stage(f, ctx->rccl_world, ctx->rccl_rank, &send, &recv, &count) != GINGR_OK) return 1;  // (not the balanced partition)
+    const int rc = g_rccl.AllGather(send, recv, (size_t)count, /* ncclFloat64 */ 8, ctx->rccl_comm, ctx->stream);
+    if (rc != 0) {
+        (void)rccl_fail(ctx, "ncclAllGather", rc);
+        return -1;
+    }
+    return gingr_fitter_gather_finish(f, ctx->rccl_world) == GINGR_OK ? 0 : -1;
 }
 
 }  // namespace
@@ -167,7 +186,7 @@ int gingr_fitter_update_rccl_async(gingr_fitter *f, int32_t flavour, const gingr
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
     gingr_ctx *ctx = fitter_ctx(f);
     if (!ctx->rccl_comm) return gingr_set_error(ctx, GINGR_ERR_STATE, "update_rccl: no communicator (gingr_ctx_rccl_init)");
-    return fitter_sharded_update(f, flavour, cp, ip, n_iterations, z, native_allreduce, ctx);
+    return fitter_sharded_update(f, flavour, cp, ip, n_iterations, z, native_allreduce, ctx, native_gather);
 }
 
 int gingr_fitter_posterior_logpdf_rccl(gingr_fitter *f, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,
@@ -175,7 +194,7 @@ int gingr_fitter_posterior_logpdf_rccl(gingr_fitter *f, int32_t flavour, const g
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
     gingr_ctx *ctx = fitter_ctx(f);
     if (!ctx->rccl_comm) return gingr_set_error(ctx, GINGR_ERR_STATE, "posterior_logpdf_rccl: no communicator (gingr_ctx_rccl_init)");
-    return fitter_sharded_logpdf(f, flavour, cp, ip, mesh_xyz_full, native_allreduce, ctx, logpdf);
+    return fitter_sharded_logpdf(f, flavour, cp, ip, mesh_xyz_full, native_allreduce, ctx, logpdf, native_gather);
 }
 
 }  // extern "C"

@@ -931,6 +931,35 @@ __global__ __launch_bounds__(256) void reversal_gather_kernel(int64_t M, int64_t
     weight_in[i] = (double)k / sigma2[0];
 }
 
+// Row shard (round 5): the same runs, for a RANGE of the target queries, left as sums -- out[4][M] = {sum x, sum y, sum z, count} per
+// template vertex of the WHOLE template -- so that the shards' ranges add up to the totals with one all-reduce; every entry is
+// written (zeros where no accepted query of the range maps to the vertex).
+__global__ __launch_bounds__(256) void reversal_sums_kernel(int64_t M, int64_t N, const int32_t *__restrict__ skeys,
+                                                            const int32_t *__restrict__ svals, Cloud tgt, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    int64_t lo = 0, hi = N;  // first position with key >= i
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (skeys[mid] < (int32_t)i)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    int64_t k = 0;
+    for (int64_t p = lo; p < N && skeys[p] == (int32_t)i; ++p, ++k) {
+        const int32_t j = svals[p];
+        sx += tgt.x[j];
+        sy += tgt.y[j];
+        sz += tgt.z[j];
+    }
+    out[i] = sx;
+    out[M + i] = sy;
+    out[2 * M + i] = sz;
+    out[3 * M + i] = (double)k;
+}
+
 // ---------------------------------------------------------------------------------------- surface distance statistics
 // IndependentPointDistanceEvaluator (G/api/sampling/evaluators/IndependentPointDistanceEvaluator.scala:54-70) and the accuracy
 // metrics of RegistrationComparison (G/api/helper/RegistrationComparison.scala:24-73) are reductions over
@@ -1008,6 +1037,18 @@ void launch_reversal_observations(gingr_ctx *ctx, int64_t M, Cloud tgt, const in
     (void)hipcub::DeviceRadixSort::SortPairs(sort_temp, sort_temp_bytes, keys, skeys, vals, svals, (int)N, 0, 32, ctx->stream);
     hipLaunchKernelGGL(reversal_gather_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, ctx->stream, M, N, skeys, svals, tgt,
                        sigma2_dev, obs_soa, weight_in);
+}
+
+void launch_reversal_sums(gingr_ctx *ctx, int64_t M, Cloud tgt, const int32_t *nn_vertex, const int32_t *pre, const int32_t *hit,
+                          int32_t *keys, int32_t *vals, int32_t *skeys, int32_t *svals, void *sort_temp, size_t sort_temp_bytes,
+                          double *w01_targets, double *sums4) {
+    const int64_t N = tgt.n;
+    if (N > 0) {
+        hipLaunchKernelGGL(reversal_keys_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, N, nn_vertex, pre, hit,
+                           (int32_t)M, keys, vals, w01_targets);
+        (void)hipcub::DeviceRadixSort::SortPairs(sort_temp, sort_temp_bytes, keys, skeys, vals, svals, (int)N, 0, 32, ctx->stream);
+    }
+    hipLaunchKernelGGL(reversal_sums_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, ctx->stream, M, N, skeys, svals, tgt, sums4);
 }
 
 void launch_cell_normals(gingr_ctx *ctx, Cloud v, const int32_t *tri, int64_t T, double *cn) {

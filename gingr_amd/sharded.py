@@ -42,6 +42,7 @@ def shard_rows(M: int, world: int, rank: int) -> Tuple[int, int]:
 
 PHASE_GATHER = 3        # GINGR_PHASE_GATHER / GINGR_SEGMENT_FULLFIT of gingr_hip.h
 SEGMENT_FULLFIT = nat.SEGMENT_FULLFIT
+SEGMENT_REVSUM = nat.SEGMENT_REVSUM
 
 
 def drive_update(run_phase: Callable[[int], None], all_reduce_segment: Callable[[int], None], world: int,
@@ -56,6 +57,9 @@ def drive_update(run_phase: Callable[[int], None], all_reduce_segment: Callable[
         run_phase(ph)
         if world > 1 and ph < 2 and not ((skip_segment0 or flavour != 0) and ph == 0):
             all_reduce_segment(ph)
+        if world > 1 and ph == 0 and flavour != 0 and reversed_direction:
+            # every shard scanned its index range of the target queries: the per-template-vertex sums are totalled
+            all_reduce_segment(SEGMENT_REVSUM)
 
 
 class _DevArray:
@@ -246,14 +250,23 @@ class ShardedFitter:
             self._fullfit = as_torch(p.value, n.value, self.ctx.device)
 
     def set_correspondence_direction(self, reversed: bool):
-        """IcpConfiguration.reverseCorrespondenceDirection on this shard (after set_meshes: the correspondence runs replicated against the
-        gathered template, the shard keeps the observations of its own rows)."""
+        """IcpConfiguration.reverseCorrespondenceDirection on this shard (after set_meshes): the shard scans its index range of the target
+        queries against the gathered template, the per-template-vertex sums are all-reduced (SEGMENT_REVSUM) and the shard keeps the
+        observations of its own rows."""
         _check(self.ctx.handle, self._lib.gingr_fitter_set_correspondence_direction(self.handle, 1 if reversed else 0),
                "gingr_fitter_set_correspondence_direction")
+        self._revsum = None
+        if reversed and self.world > 1 and not self.rccl:
+            p, n = c_void_p(), c_int64()
+            _check(self.ctx.handle, self._lib.gingr_fitter_reversal_exchange(self.handle, ctypes.byref(p), ctypes.byref(n)),
+                   "gingr_fitter_reversal_exchange")
+            self._revsum = as_torch(p.value, n.value, self.ctx.device)
 
     def _segment(self, seg: int):
         if seg == nat.SEGMENT_FULLFIT:
             return self._fullfit
+        if seg == nat.SEGMENT_REVSUM:
+            return self._revsum
         return self.xch[self.offsets[seg]: self.offsets[seg] + self.counts[seg]]
 
     @staticmethod

@@ -367,6 +367,12 @@ int gingr_fitter_retry_counter(gingr_fitter *f, int32_t set_to, int32_t *value_o
  * exchange segment GINGR_SEGMENT_FULLFIT of the callback. */
 #define GINGR_PHASE_GATHER 3
 #define GINGR_SEGMENT_FULLFIT 2
+/* Reversed correspondence direction on row shards (round 5; G/api/registration/utils/ClosestPointRegistrator.scala:34-49): the queries
+ * of that direction are the vertices of the (replicated) target, so they partition by index range -- every shard scans its range
+ * against the gathered template and leaves, per vertex of the WHOLE template, the sum of its accepted target points and their
+ * number ([4][M_total] = sum x, sum y, sum z, count; gingr_fitter_reversal_exchange gives the address).  Between phases 0 and 1 the
+ * host all-reduces (sum) that buffer = exchange segment GINGR_SEGMENT_REVSUM of the callback; phase 1 then takes the shard's rows. */
+#define GINGR_SEGMENT_REVSUM 3
 int gingr_fitter_exchange(gingr_fitter *f, void **dev_ptr, int64_t offsets[GINGR_NUM_SEGMENTS],
                           int64_t counts[GINGR_NUM_SEGMENTS]);
 int gingr_fitter_cpd_phase_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t phase);
@@ -395,14 +401,28 @@ int gingr_fitter_update_icp_sharded_async(gingr_fitter *f, const gingr_icp_param
  * gingr_fitter_posterior_logpdf_sharded: posterior(state).gp.logpdf(posterior.coefficients(mesh))
  * (G/api/sampling/generators/GeneratorWrapperStochastic.scala:42-63) with mesh_xyz_full = the FULL mesh [3 M_total] on every shard
  * (each takes its rows); Q0^T e travels in the tail of segment 1, the log-density kernel is replicated; synchronises.
- * Reversed correspondence direction (ICP.scala:46-48; gingr_fitter_set_correspondence_direction after gingr_fitter_set_meshes): the
- * correspondence is replicated on every shard against the gathered template, the observations of the shard's rows are its own.
- * gingr_fitter_fullfit_exchange: address / element count of the full-fit buffer for a host that drives the phases itself. */
+ * Reversed correspondence direction (ICP.scala:46-48; gingr_fitter_set_correspondence_direction after gingr_fitter_set_meshes): every
+ * shard scans its index range of the target queries against the gathered template; the per-template-vertex sums are all-reduced
+ * (GINGR_SEGMENT_REVSUM, between phases 0 and 1) and every shard keeps the observations of its own rows.
+ * gingr_fitter_fullfit_exchange / gingr_fitter_reversal_exchange: address / element count of the full-fit buffer / the reversal sums
+ * for a host that drives the phases itself. */
 int gingr_fitter_update_sharded_async(gingr_fitter *f, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,
                                       int32_t n_iterations, const double *z, gingr_allreduce_fn reduce, void *user);
 int gingr_fitter_posterior_logpdf_sharded(gingr_fitter *f, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,
                                           const double *mesh_xyz_full, gingr_allreduce_fn reduce, void *user, double *logpdf);
 int gingr_fitter_fullfit_exchange(gingr_fitter *f, void **dev_ptr, int64_t *count);
+int gingr_fitter_reversal_exchange(gingr_fitter *f, void **dev_ptr, int64_t *count);
+/* The gather of the fit through a real ALL-GATHER instead of the zero-padded all-reduce (half the wire bytes, no reduction) for hosts
+ * that have one (the library's own RCCL path uses ncclAllGather this way).  The shards must be the balanced contiguous partition of
+ * the rows over `world` shards (the first M_total % world shards hold one row more -- what gingr_group_* and gingr_amd.sharded use).
+ *   gingr_fitter_gather_stage   enqueues the copy of this shard's rows (original order) into its slot of a staging buffer
+ *                               [world][3][chunk], chunk = ceil(M_total / world), and returns the slot (send), the buffer (recv) and
+ *                               the element count per rank (3 chunk): the host runs an in-place all-gather of exactly that shape on
+ *                               the context's stream (ncclAllGather(send, recv, count, ncclDouble, ...));
+ *   gingr_fitter_gather_finish  enqueues the kernel that spreads the slots over the planes of the full-fit buffer.
+ * Together they replace phase GINGR_PHASE_GATHER + the all-reduce of segment GINGR_SEGMENT_FULLFIT; then phases 0, 1, 2 as above. */
+int gingr_fitter_gather_stage(gingr_fitter *f, int32_t world, int32_t rank, void **send_ptr, void **recv_ptr, int64_t *count_per_rank);
+int gingr_fitter_gather_finish(gingr_fitter *f, int32_t world);
 
 /* ---- one Metropolis-Hastings step of GingrAlgorithm.run's chain in ONE call (G/api/GingrAlgorithm.scala:115-190; scalismo
  * MetropolisHastings.next = propose, evaluate both, transition ratio, accept / reject) ---------------------------------------------

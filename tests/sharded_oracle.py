@@ -2,7 +2,7 @@
 
 Mirrors gingr_amd/csrc/fitter.hip phase by phase with numpy so that the sharding algebra -- which partial sums are
 exchanged, in which order, and what is replicated -- can be exercised across real processes (gloo) without a GPU.
-Segment layout = gingr_fitter_exchange: [den N] [G rp*rp | rhs rp | 8 scalars | Q0^T e rp] [full fit 3 M_total], with rp = r
+Segment layout = gingr_fitter_exchange: [den N] [G rp*rp | rhs rp | 8 scalars | Q0^T e rp] [full fit 3 M_total] [reversal sums 4 M_total], with rp = r
 here (no MFMA padding on the CPU).  Flavours as in gingr_fitter_update_sharded_async: 0 CPD, 1 ICP with the point-cloud closest
 point, 2 ICP with the surface correspondence (phase 3 = GINGR_PHASE_GATHER writes the shard's rows of the fit into segment 2,
 whose sum all-reduce is the all-gather); z = the replicated standard-normal draw of posterior.sample(); logpdf_* = the transition
@@ -27,8 +27,9 @@ class OracleShard:
         self.reversed = bool(reversed_direction)                     # ICP.scala:46-48; gathers the fit like flavour 2
         self.z = None                                                 # set for ONE sampled proposal, the same on every shard
         r, N = model.rank, self.x.shape[0]
-        self.counts = [N, r * r + r + 8 + r, 3 * model.M]
-        self.offsets = [0, N, N + self.counts[1]]
+        # segments 0, 1 (gingr_fitter_exchange), 2 = GINGR_SEGMENT_FULLFIT, 3 = GINGR_SEGMENT_REVSUM ([4][M_total] sums of the reversed direction)
+        self.counts = [N, r * r + r + 8 + r, 3 * model.M, 4 * model.M]
+        self.offsets = [0, N, N + self.counts[1], N + self.counts[1] + 3 * model.M]
         self.xch = np.zeros(sum(self.counts))
         rows = slice(3 * begin, 3 * end)
         self.Q0 = model.U[rows] * np.sqrt(model.lam)[None, :]         # local rows of Q0
@@ -71,13 +72,23 @@ class OracleShard:
             full[:] = 0.0
             full[:, self.b:self.e] = self.fit.T
         elif ph == 0 and self.reversed and self.flavour != 0:
-            # the reversed correspondence is replicated work: the target's vertices look for their match on the GATHERED template
-            # (any shard's rows); this shard keeps the accepted pairs whose template vertex it owns -- several per vertex are possible
+            # the reversed correspondence, sharded by QUERY range (round 5): the target's vertices look for their match on the GATHERED
+            # template (any shard's rows); this shard answers for its index range of the target -- the fraction of the cloud its rows are
+            # of the template -- and leaves, per template vertex of the whole template, the sum of the accepted target points and their
+            # number (segment 3, summed across the shards between phases 0 and 1)
             full = self.seg(2).reshape(3, M_total).T.copy()
             method = "TriangularClosestPoint" if self.flavour == 2 else "PointcloudClosestPoint"
             tid, pts, w = go.correspondence_reversal(full, self.tmpl_tris, self.x, self.tgt_tris, method)
-            keep = (w == 1.0) & (tid >= self.b) & (tid < self.e)
-            self.rev = (tid[keep] - self.b, pts[keep])
+            q0, q1 = N * self.b // M_total, N * self.e // M_total
+            mine = np.zeros(N, dtype=bool)
+            mine[q0:q1] = True
+            keep = (w == 1.0) & mine
+            sums = self.seg(3).reshape(4, M_total)
+            sums[:] = 0.0
+            np.add.at(sums[0], tid[keep], pts[keep, 0])
+            np.add.at(sums[1], tid[keep], pts[keep, 1])
+            np.add.at(sums[2], tid[keep], pts[keep, 2])
+            np.add.at(sums[3], tid[keep], 1.0)
         elif ph == 0 and self.flavour == 1:
             idx, _, _ = go.icp_closest_point(self.fit, self.x)          # the shard's own rows against the replicated target
             self.obs, self.acc = self.x[idx], np.ones(self.fit.shape[0])
@@ -86,11 +97,17 @@ class OracleShard:
         elif ph == 0:
             self.seg(0)[:] = co.cpd_colsum_partial(self.fit, self.x, st.sigma2, 0, self.fit.shape[0])
         elif ph == 1 and self.flavour != 0 and self.reversed:
-            rows, pts = self.rev                                             # one observation per accepted TARGET vertex
+            # the totals are in place: this shard's rows of them -- k accepted targets of a vertex = one observation of their mean with
+            # k-fold precision (algebraically the reference's k observations)
+            sums = self.seg(3).reshape(4, M_total)[:, self.b:self.e]
+            rows = np.flatnonzero(sums[3] > 0)
+            k = sums[3, rows]
+            pts = (sums[:3, rows] / k).T
             Q3 = self.Q0.reshape(-1, 3, r)[rows]
-            e = ((pts - st.center - st.translation) @ R - (self.ref[rows] - st.center) - self.mean[rows]) / st.sigma2
+            wgt = k / st.sigma2
+            e = wgt[:, None] * ((pts - st.center - st.translation) @ R - (self.ref[rows] - st.center) - self.mean[rows])
             s = self.seg(1)
-            s[: r * r] = (np.einsum("idk,idl->kl", Q3, Q3) / st.sigma2).reshape(-1)
+            s[: r * r] = np.einsum("i,idk,idl->kl", wgt, Q3, Q3).reshape(-1)
             s[r * r: r * r + r] = np.einsum("idk,id->k", Q3, e)
             s[r * r + r:] = 0.0
         elif ph == 1 and self.flavour != 0:

@@ -380,3 +380,61 @@ def test_group_cpd_and_pointcloud_sample_and_logpdf(flavour):
     assert rel(fit2, st.fit) < 1e-5
     single.close()
     multi.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_all_gather_staging_equals_the_zero_padded_all_reduce(world):
+    """gingr_fitter_gather_stage / _finish (what the native RCCL path wraps around ncclAllGather): `world` logical shards on one device,
+    the in-place all-gather of the padded slots emulated with device copies.  The full-fit buffer must come out bit-identical to what
+    phase GINGR_PHASE_GATHER + a sum of the zero-padded buffers gives: the posed template in original vertex order."""
+    import ctypes
+    from ctypes import c_int64, c_void_p
+    import torch
+    import gingr_amd as ga
+    from gingr_amd.sharded import ShardedFitter, as_torch
+    mo, cells, target, tcells = _femur_case()
+    model = ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam)
+    ctxs = [ga.Context(0) for _ in range(world)]
+    fs = [ShardedFitter(ctxs[r], model, target, rank=r, world=world, all_reduce=None, defer_setup=True) for r in range(world)]
+    mom = None
+    for f in fs:                                           # the one-off moment all-reduce, summed on the host here
+        g = f.gram_tensor()
+        f.ctx.synchronize()
+        mom = g.clone() if mom is None else mom + g
+    for f in fs:
+        f.gram_tensor().copy_(mom)
+        torch.cuda.synchronize()
+        f.finish_setup()
+        f.set_meshes(cells, tcells)
+        f.set_state(0.3 * np.arange(mo.rank) / mo.rank, 20.0, translation=(1.0, -2.0, 0.5), euler=(0.02, -0.03, 0.01))
+    lib = fs[0]._lib
+    stages, counts = [], []
+    for r, f in enumerate(fs):
+        send, recv, cnt = c_void_p(), c_void_p(), c_int64()
+        assert lib.gingr_fitter_gather_stage(f.handle, world, r, ctypes.byref(send), ctypes.byref(recv), ctypes.byref(cnt)) == 0
+        assert send.value == recv.value + r * cnt.value * 8
+        stages.append(as_torch(recv.value, world * cnt.value, 0))
+        counts.append(cnt.value)
+        f.ctx.synchronize()
+    assert len(set(counts)) == 1 and counts[0] == 3 * -(-mo.M // world)
+    c = counts[0]
+    for i in range(world):                                 # the all-gather: slot j of every buffer <- slot j of shard j's buffer
+        for j in range(world):
+            if i != j:
+                stages[i][j * c:(j + 1) * c].copy_(stages[j][j * c:(j + 1) * c])
+    torch.cuda.synchronize()
+    want = np.concatenate([f.get_state()[2] for f in fs])   # rows of all shards, original order
+    for f in fs:
+        assert lib.gingr_fitter_gather_finish(f.handle, world) == 0
+        f.ctx.synchronize()
+        p, n = c_void_p(), c_int64()
+        assert lib.gingr_fitter_fullfit_exchange(f.handle, ctypes.byref(p), ctypes.byref(n)) == 0
+        full = as_torch(p.value, n.value, 0).cpu().numpy().reshape(3, mo.M).T
+        assert np.array_equal(full, want)
+    # a shard that is not part of the balanced partition is refused (the caller then falls back to the all-reduce form)
+    send, recv, cnt = c_void_p(), c_void_p(), c_int64()
+    assert lib.gingr_fitter_gather_stage(fs[0].handle, world + 1, 0, ctypes.byref(send), ctypes.byref(recv), ctypes.byref(cnt)) != 0
+    for f in fs:
+        f.close()
+    for cx in ctxs:
+        cx.close()

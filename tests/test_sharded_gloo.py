@@ -238,8 +238,9 @@ def _reversed_worker(rank, world, port, flavour, out_dir):
 
 @pytest.mark.parametrize("world,flavour", [(2, 2), (3, 1)])
 def test_gloo_reversed_direction_equals_unsharded(tmp_path, world, flavour):
-    """IcpConfiguration.reverseCorrespondenceDirection on row shards: the correspondence is replicated against the gathered template,
-    every rank keeps the observations of its own rows (gingr_amd/csrc/fitter.hip, run_phase, reversed && sharded)."""
+    """IcpConfiguration.reverseCorrespondenceDirection on row shards: every rank scans its index range of the target queries against
+    the gathered template, the per-template-vertex sums are all-reduced between phases 0 and 1 (GINGR_SEGMENT_REVSUM) and every rank
+    keeps the observations of its own rows (gingr_amd/csrc/fitter.hip, run_phase, reversed && sharded)."""
     import torch.multiprocessing as mp
     from oracle import gingr_oracle as go
     mp.spawn(_reversed_worker, args=(world, _free_port(), flavour, str(tmp_path)), nprocs=world, join=True)

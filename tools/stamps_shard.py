@@ -95,6 +95,22 @@ for k, name in enumerate(("cpd_colsum_kernel", "cpd_rowstats_kernel")):
     if fin:
         fin = np.array(fin)
         print(f"SIMDs with {full} waves: mean pair-loop end of the 1st..{full}th finisher: " + " / ".join(f"{v:.1f}" for v in fin.mean(0)))
+    # where the late finishers sit: per XCD (each has its own clock domain / L2) and the latest waves one by one
+    print("per XCD: waves, median core clock GHz, median / max pair-loop end, median pair-loop duration")
+    for xc in sorted(set(xcc.tolist())):
+        m = xcc == xc
+        print(f"  xcd {xc}: {int(m.sum()):5d}  {np.median(ghz[m]):.3f}  {np.median(T[m, 4]):7.1f} / {T[m, 4].max():7.1f}  {np.median((T[:, 4] - T[:, 3])[m]):7.1f}")
+    late = np.argsort(-T[:, 4])[:12]
+    wgid = np.flatnonzero(used)[late] // 4
+    print("latest pair-loop ends: " + ", ".join(f"{T[i, 4]:.1f}us(xcd{xcc[i]} se{se[i]} cu{cu[i]} simd{simd[i]} wg{w} start{T[i, 3]:.1f} clk{ghz[i]:.2f})" for i, w in zip(late, wgid)))
+    # per SIMD: total pair-loop time of its waves vs its last end (is a late SIMD one with more work, or a slower one?)
+    tot = np.array([(T[order[s:s + c], 4] - T[order[s:s + c], 3]).sum() for s, c in zip(starts, counts)])
+    last = np.array([T[order[s:s + c], 4].max() for s, c in zip(starts, counts)])
+    fullm = counts == full
+    if fullm.sum() > 4:
+        cc = np.corrcoef(tot[fullm], last[fullm])[0, 1]
+        print(f"SIMDs with {full} waves: last end p10 {np.percentile(last[fullm], 10):.1f} median {np.median(last[fullm]):.1f} p90 {np.percentile(last[fullm], 90):.1f} "
+              f"max {last[fullm].max():.1f}; correlation(sum of loop times, last end) {cc:.2f}")
     # issue-slot use: the pair loop's VALU issue cycles against what the SIMD had
     loop = T[:, 4] - T[:, 3]
     print(f"sum over a SIMD's waves of pair-loop time / (waves x launch span): {loop.sum() / (nw * T[:, 5].max()):.3f}")
