@@ -729,11 +729,15 @@ __global__ __launch_bounds__(kCpThreads) void self_intersect_queue_kernel(Cloud 
             const double pd = point_box_gap2(p.x, p.y, p.z, qboxes + ((int64_t)t * 4 + wave) * 6);
             const bool need = ok && !hit && q0 < T && !(pd > vv * (1.0 + 1e-12));
             const bool wave_needs = __any(need);
-            if (!__syncthreads_or(wave_needs)) continue;
-            {
-                const int64_t tt = tb + threadIdx.x;
+            // Round 5: a wave stages only ITS quarter of the tile (64 boxes into its own slice of tbox) and only when one of its queries
+            // reaches into that quarter's box: no workgroup barrier in the tile loop -- the four waves walk the candidate list (identical
+            // in all of them: same queries, same tile boxes) decoupled -- and a quarter nobody needs is never read.  (Until round 4 all
+            // 256 boxes of a tile were staged, between two barriers, as soon as ANY wave needed one quarter: 67 us at 41k x 82k.)
+            if (wave_needs) {
+                __builtin_amdgcn_wave_barrier();  // (the previous quarter's reads of the slice are issued before it is rewritten)
+                const int64_t tt = q0 + lane;
                 if (tt < T) {
-                    double *bb = tbox[threadIdx.x];
+                    double *bb = tbox[64 * wave + lane];
                     if (tribox) {  // precomputed by tri_tile_bbox_kernel
                         const double *sb = tribox + 6 * tt;
                         bb[0] = sb[0], bb[1] = sb[1], bb[2] = sb[2], bb[3] = sb[3], bb[4] = sb[4], bb[5] = sb[5];
@@ -745,9 +749,7 @@ __global__ __launch_bounds__(kCpThreads) void self_intersect_queue_kernel(Cloud 
                         bb[3] = fmax(fmax(ax, bx), cx), bb[4] = fmax(fmax(ay, by), cy), bb[5] = fmax(fmax(az, bz), cz);
                     }
                 }
-            }
-            __syncthreads();
-            if (wave_needs) {
+                __builtin_amdgcn_wave_barrier();  // LDS serves one wave's accesses in order: the reads below see the writes above
                 const int cnt = (int)min((int64_t)64, T - q0);
                 for (int jb = 0; jb < cnt; jb += H) {
                     const int jj = jb + half;
@@ -762,7 +764,6 @@ __global__ __launch_bounds__(kCpThreads) void self_intersect_queue_kernel(Cloud 
                     }
                 }
             }
-            __syncthreads();  // the tile is restaged by the next visited tile
         }
     }
     if (tail > 0) flush(tail);
