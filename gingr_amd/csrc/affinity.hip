@@ -1632,6 +1632,11 @@ int64_t cpd_colsum_ws_doubles(int64_t M, int64_t N) {
     plan_chunks(N, 64 * colsum_pt(N), M, &nch, colsum_tiles_override(), colsum_chunks_override(), resident_workgroups(0));
     return (int64_t)nch * N;
 }
+int cpd_colsum_chunks(int64_t M, int64_t N) {
+    int nch;
+    plan_chunks(N, 64 * colsum_pt(N), M, &nch, colsum_tiles_override(), colsum_chunks_override(), resident_workgroups(0));
+    return nch;
+}
 
 int64_t cpd_rowstats_ws_doubles(int64_t M, int64_t N) {
     int nch;
@@ -1667,14 +1672,14 @@ void launch_tile_bbox(gingr_ctx *ctx, Cloud c, double *boxes, const double *ctr,
 }
 
 int launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
-                      const double *fit_boxes, double *ws, double *den_partial) {
+                      const double *fit_boxes, double *ws, double *den_partial, int forced_chunks) {
     int nch;
     {
         TimerScope ts(ctx, 0);
         {
             const int pt = colsum_pt(target.n);
-            const ChunkPlan len = plan_chunks(target.n, 64 * pt, fit.n, &nch, colsum_tiles_override(), colsum_chunks_override(),
-                                              resident_workgroups(0));
+            const ChunkPlan len = plan_chunks(target.n, 64 * pt, fit.n, &nch, colsum_tiles_override(),
+                                              forced_chunks > 0 ? forced_chunks : colsum_chunks_override(), resident_workgroups(0));
             dim3 grid((unsigned)ceil_div(target.n, 64 * pt), (unsigned)nch);
             const double *boxes = ctx->cull ? fit_boxes : (const double *)nullptr;
             // one variant, picked from the regime the device last reported (stale at worst: the results are the same)

@@ -46,6 +46,12 @@ struct gingr_ctx {
     // native RCCL exchange (rccl_exchange.hip): the communicator of this rank, owned by the context; null = none
     void *rccl_comm = nullptr;
     int32_t rccl_world = 0, rccl_rank = 0;
+    // GINGR_OPT_SPLIT_EXCHANGE: the column-sum exchange in two halves, the first on a second stream of the context behind the first
+    // half of pass 1 (fitter.hip: fitter_sharded_update).  side_stream / the events are created on first use; exchange_stream is
+    // where the native all-reduce is enqueued right now (nullptr = the context's stream).
+    int split_exchange = 0;
+    hipStream_t side_stream = nullptr, exchange_stream = nullptr;
+    hipEvent_t split_ev[2] = {nullptr, nullptr};
     // scratch kept across calls (grown on demand, never shrunk) so steady-state updates do not allocate
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -133,8 +139,11 @@ void launch_cloud_absmax(gingr_ctx *ctx, Cloud c, const double *ctr, double *slo
 void launch_tile_bbox(gingr_ctx *ctx, Cloud c, double *boxes, const double *ctr = nullptr, double *absmax_slot = nullptr);
 // returns the number of chunk partials left in ws ([chunk][N]); den_partial == nullptr skips their reduction (the caller passes
 // ws and the count to launch_cpd_den_finalize, which then adds them up itself: single shard, one launch less)
+// forced_chunks > 0: exactly that many chunks of the streamed rows, balanced to a quarter (a half of a split column-sum pass keeps
+// the launch's workgroup count by taking twice the chunks of the whole pass)
 int launch_cpd_colsum(gingr_ctx *ctx, Cloud fit, Cloud target, const double *sigma2_dev, const double *aux,
-                      const double *fit_boxes, double *ws, double *den_partial);
+                      const double *fit_boxes, double *ws, double *den_partial, int forced_chunks = 0);
+int cpd_colsum_chunks(int64_t M, int64_t N);  // chunks of the planner's own choice
 // den[j] += c; inv_den[j] = 1/den[j]; Pt1[j] = (den[j]-c)/den[j]; xPx block partials -> part[0..256)
 // M_total enters the outlier constant c = w/(1-w) (2 pi sigma2)^1.5 M_total/N.  part: GINGR_SCALAR_PART doubles.
 // tile_bad[tile] (nullable) is set when a 1/den of the tile is not finite: such tiles are never culled.

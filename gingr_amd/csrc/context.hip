@@ -102,6 +102,12 @@ void gingr_ctx_destroy(gingr_ctx *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->nn_tests) (void)hipFree(ctx->nn_tests);
     if (ctx->regime_host) (void)hipHostFree(ctx->regime_host);
+    if (ctx->side_stream) {
+        (void)hipStreamSynchronize(ctx->side_stream);
+        (void)hipStreamDestroy(ctx->side_stream);
+    }
+    for (hipEvent_t e : ctx->split_ev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -131,6 +137,7 @@ int gingr_ctx_set_option(gingr_ctx *ctx, int32_t option, int32_t value) {
         case GINGR_OPT_FINE_CULL: ctx->fine_override = value < 0 ? -1 : (value != 0); return GINGR_OK;
         case GINGR_OPT_NN_GRID: ctx->nn_grid = value < 0 ? 0 : (value > 2 ? 2 : value); return GINGR_OK;
         case GINGR_OPT_TRI_GRID: ctx->tri_grid = value < 0 ? 0 : (value > 2 ? 2 : value); return GINGR_OK;
+        case GINGR_OPT_SPLIT_EXCHANGE: ctx->split_exchange = value != 0; return GINGR_OK;
         default: return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "ctx_set_option: unknown option %d", option);
     }
 }
@@ -142,6 +149,7 @@ int gingr_ctx_get_option(gingr_ctx *ctx, int32_t option, int32_t *value) {
         case GINGR_OPT_FINE_CULL: *value = ctx->fine_override; return GINGR_OK;
         case GINGR_OPT_NN_GRID: *value = ctx->nn_grid; return GINGR_OK;
         case GINGR_OPT_TRI_GRID: *value = ctx->tri_grid; return GINGR_OK;
+        case GINGR_OPT_SPLIT_EXCHANGE: *value = ctx->split_exchange; return GINGR_OK;
         default: return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "ctx_get_option: unknown option %d", option);
     }
 }

@@ -185,6 +185,9 @@ struct gingr_fitter {
     // The quarter boxes / |coordinate - centre| maximum of the fit are read by the two CPD pair loops only: the pass that writes the
     // fit produces them once a CPD phase has asked for them (cpd_seen), an ICP-only fitter runs the plain, shorter pass.
     bool cpd_seen = false, fit_boxes_valid = false;
+    // GINGR_OPT_SPLIT_EXCHANGE (fitter_sharded_update): 0 the whole column-sum pass; 1 / 2 only the first / second half of the target
+    // tiles (phase 0 is then run twice, with the all-reduce of the first half in between on the context's second stream)
+    int split_half = 0;
 };
 
 // The triangle grid pays from a few ten thousand target triangles on (41k x 82k: 94 -> 27 + 10 us per closest-point search); on a
@@ -310,6 +313,9 @@ __global__ void pose_of_state_kernel(const DevState *__restrict__ st, DevPose *_
 }
 
 Cloud cloud_of(const double *soa, int64_t n) { return Cloud{soa, soa + n, soa + 2 * n, n}; }
+
+// where GINGR_OPT_SPLIT_EXCHANGE cuts the target cloud: half of its 256-point tiles
+int64_t split_cut(int64_t N) { return (N / 512) * 256; }
 
 SweepArgs base_args(const gingr_fitter *f) {
     SweepArgs a;
@@ -1311,6 +1317,18 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 if (!f->fit_boxes_valid) fit_boxes_now(f);  // (first CPD phase of this fitter, or the fit was written while it ran ICP)
                 // single shard: nothing is exchanged, so the chunk partials stay in ws and phase 1's den_finalize adds them up
                 const bool alone = m->M == m->M_total && !f->partial_out;
+                if (f->split_half != 0 && !alone) {
+                    // one half of the target tiles (tile-aligned cut): its own launch, chunk plan and slice of the workspace
+                    const int64_t NA = split_cut(tgt.n);
+                    const bool first = f->split_half == 1;
+                    const Cloud th = first ? Cloud{tgt.x, tgt.y, tgt.z, NA} : Cloud{tgt.x + NA, tgt.y + NA, tgt.z + NA, tgt.n - NA};
+                    // (twice the chunks of the whole pass: half the targets x half-length chunks = the same number of workgroups)
+                    const int nch2 = 2 * cpd_colsum_chunks(M, tgt.n);
+                    (void)launch_cpd_colsum(ctx, fit, th, &f->st->sigma2, f->absmax, f->fboxes, first ? f->ws : f->ws + (int64_t)nch2 * NA,
+                                            seg0w + (first ? 0 : NA), nch2);
+                    f->colsum_chunks = 0;
+                    break;
+                }
                 f->colsum_chunks = launch_cpd_colsum(ctx, fit, tgt, &f->st->sigma2, f->absmax, f->fboxes, f->ws, alone ? nullptr : seg0w);
                 if (!alone) f->colsum_chunks = 0;
             }
@@ -1518,7 +1536,7 @@ static int gather_fit(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, 
 }
 
 int fitter_sharded_update(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations,
-                          const double *z, gingr_allreduce_fn reduce, void *user, fitter_gather_fn gather) {
+                          const double *z, gingr_allreduce_fn reduce, void *user, fitter_gather_fn gather, bool split_native) {
     GINGR_TRY(check_ready(f));
     gingr_ctx *ctx = f->ctx;
     if (n_iterations < 0 || !reduce || flavour < 0 || flavour > 2) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "sharded update: bad arguments");
@@ -1527,10 +1545,56 @@ int fitter_sharded_update(gingr_fitter *f, int flavour, const gingr_cpd_params *
     if (z) GINGR_TRY(fitter_upload_zrand(f, z));
     f->zrand_active = z != nullptr;
     int rc = GINGR_OK;
+    // GINGR_OPT_SPLIT_EXCHANGE: pass 1 in two halves of the target tiles; the all-reduce of the first half runs on the context's second
+    // stream (ordered by events, same communicator) while the second half computes, so only the second half's all-reduce is exposed
+    bool split = split_native && flavour == 0 && f->sharded() && f->N >= 8192;
+    if (split) {
+        const int64_t NA = split_cut(f->N);
+        if ((int64_t)2 * cpd_colsum_chunks(f->m->M, f->N) * f->N > f->ws_doubles) split = false;  // (the halves take twice the chunks of the whole pass)
+    }
+    if (split && !ctx->side_stream) {
+        if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->split_ev[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->split_ev[1], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            split = false;
+        }
+    }
     for (int32_t it = 0; it < n_iterations && rc == GINGR_OK; ++it) {
         TimerScope ts(ctx, 3);
         if ((flavour == 2 || (flavour == 1 && f->reversed)) && f->sharded()) rc = gather_fit(f, flavour, cp, ip, reduce, user, gather, "sharded update");
         for (int ph = 0; ph < GINGR_NUM_PHASES && rc == GINGR_OK; ++ph) {
+            if (ph == 0 && split) {
+                const int64_t NA = split_cut(f->N);
+                double *seg0 = f->xch + f->off[0];
+                f->split_half = 1;
+                rc = fitter_run_phase(f, flavour, cp, ip, 0);
+                {
+                    TimerScope tx(ctx, 6);
+                    if (!rc && (hipEventRecord(ctx->split_ev[0], ctx->stream) != hipSuccess ||
+                                hipStreamWaitEvent(ctx->side_stream, ctx->split_ev[0], 0) != hipSuccess))
+                        rc = gingr_set_error(ctx, GINGR_ERR_HIP, "sharded update: event ordering of the split exchange failed");
+                    if (!rc) {
+                        ctx->exchange_stream = ctx->side_stream;
+                        const int xr = reduce(user, 0, seg0, NA);
+                        ctx->exchange_stream = nullptr;
+                        if (xr != 0) rc = gingr_set_error(ctx, GINGR_ERR_STATE, "sharded update: the all-reduce callback failed (segment 0, first half)");
+                    }
+                    if (!rc && hipEventRecord(ctx->split_ev[1], ctx->side_stream) != hipSuccess)
+                        rc = gingr_set_error(ctx, GINGR_ERR_HIP, "sharded update: event ordering of the split exchange failed");
+                }
+                f->split_half = 2;
+                if (!rc) rc = fitter_run_phase(f, flavour, cp, ip, 0);
+                f->split_half = 0;
+                {
+                    TimerScope tx(ctx, 6);
+                    if (!rc && reduce(user, 0, seg0 + NA, f->N - NA) != 0)
+                        rc = gingr_set_error(ctx, GINGR_ERR_STATE, "sharded update: the all-reduce callback failed (segment 0, second half)");
+                    if (!rc && hipStreamWaitEvent(ctx->stream, ctx->split_ev[1], 0) != hipSuccess)
+                        rc = gingr_set_error(ctx, GINGR_ERR_HIP, "sharded update: event ordering of the split exchange failed");
+                }
+                continue;
+            }
             rc = fitter_run_phase(f, flavour, cp, ip, ph);
             if (!rc && ph < GINGR_NUM_SEGMENTS && !(flavour != 0 && ph == 0)) {
                 TimerScope tx(ctx, 6 + ph);  // the exchange of segment ph as this shard sees it (includes waiting for the peers)
@@ -1551,19 +1615,19 @@ extern "C" {
 int gingr_fitter_update_cpd_sharded_async(gingr_fitter *f, const gingr_cpd_params *p, int32_t n_iterations, gingr_allreduce_fn reduce,
                                           void *user) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
-    return fitter_sharded_update(f, 0, p, nullptr, n_iterations, nullptr, reduce, user, nullptr);
+    return fitter_sharded_update(f, 0, p, nullptr, n_iterations, nullptr, reduce, user, nullptr, false);
 }
 
 int gingr_fitter_update_icp_sharded_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations, gingr_allreduce_fn reduce,
                                           void *user) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
-    return fitter_sharded_update(f, 1, nullptr, p, n_iterations, nullptr, reduce, user, nullptr);
+    return fitter_sharded_update(f, 1, nullptr, p, n_iterations, nullptr, reduce, user, nullptr, false);
 }
 
 int gingr_fitter_update_sharded_async(gingr_fitter *f, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,
                                       int32_t n_iterations, const double *z, gingr_allreduce_fn reduce, void *user) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
-    return fitter_sharded_update(f, flavour, cp, ip, n_iterations, z, reduce, user, nullptr);
+    return fitter_sharded_update(f, flavour, cp, ip, n_iterations, z, reduce, user, nullptr, false);
 }
 
 int gingr_fitter_gather_stage(gingr_fitter *f, int32_t world, int32_t rank, void **send_ptr, void **recv_ptr, int64_t *count_per_rank) {

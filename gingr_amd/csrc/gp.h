@@ -115,8 +115,10 @@ void fitter_set_partial_fullfit(gingr_fitter *f, double *base);
 // the sharded update (fitter.hip) for the other translation units: flavour 0 CPD, 1 ICP point cloud, 2 ICP surface; z nullable (sampled proposal)
 // gather (nullable): the host's own all-gather of the fit -- 0 done, > 0 not possible here (fall back to the zero-padded all-reduce), < 0 failed
 typedef int (*fitter_gather_fn)(void *user, gingr_fitter *f);
+// split_native: the caller's `reduce` is the library's own RCCL all-reduce (user = the context) and honours ctx->exchange_stream:
+// GINGR_OPT_SPLIT_EXCHANGE may then run the CPD column-sum exchange in two halves
 int fitter_sharded_update(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations,
-                          const double *z, gingr_allreduce_fn reduce, void *user, fitter_gather_fn gather = nullptr);
+                          const double *z, gingr_allreduce_fn reduce, void *user, fitter_gather_fn gather = nullptr, bool split_native = false);
 int fitter_sharded_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, const double *mesh_xyz_full,
                           gingr_allreduce_fn reduce, void *user, double *logpdf, fitter_gather_fn gather = nullptr);
 int fitter_run_phase(gingr_fitter *f, int flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int phase);

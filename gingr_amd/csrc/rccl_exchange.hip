@@ -79,7 +79,9 @@ int rccl_fail(gingr_ctx *ctx, const char *what, int rc) {
 // the gingr_allreduce_fn of the native path: user = the context
 int native_allreduce(void *user, int32_t, void *device_ptr, int64_t count) {
     gingr_ctx *ctx = static_cast<gingr_ctx *>(user);
-    const int rc = g_rccl.AllReduce(device_ptr, device_ptr, (size_t)count, /* ncclFloat64 */ 8, /* ncclSum */ 0, ctx->rccl_comm, ctx->stream);
+    // (exchange_stream: the first half of a split column-sum exchange runs on the context's second stream, fitter.hip)
+    const int rc = g_rccl.AllReduce(device_ptr, device_ptr, (size_t)count, /* ncclFloat64 */ 8, /* ncclSum */ 0, ctx->rccl_comm,
+                                    ctx->exchange_stream ? ctx->exchange_stream : ctx->stream);
     if (rc != 0) {
         (void)rccl_fail(ctx, "ncclAllReduce", rc);
         return 1;
@@ -171,7 +173,7 @@ int gingr_fitter_update_cpd_rccl_async(gingr_fitter *f, const gingr_cpd_params *
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
     gingr_ctx *ctx = fitter_ctx(f);
     if (!ctx->rccl_comm) return gingr_set_error(ctx, GINGR_ERR_STATE, "update_cpd_rccl: no communicator (gingr_ctx_rccl_init)");
-    return gingr_fitter_update_cpd_sharded_async(f, p, n_iterations, native_allreduce, ctx);
+    return fitter_sharded_update(f, 0, p, nullptr, n_iterations, nullptr, native_allreduce, ctx, nullptr, ctx->split_exchange != 0);
 }
 
 int gingr_fitter_update_icp_rccl_async(gingr_fitter *f, const gingr_icp_params *p, int32_t n_iterations) {
@@ -186,7 +188,7 @@ int gingr_fitter_update_rccl_async(gingr_fitter *f, int32_t flavour, const gingr
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
     gingr_ctx *ctx = fitter_ctx(f);
     if (!ctx->rccl_comm) return gingr_set_error(ctx, GINGR_ERR_STATE, "update_rccl: no communicator (gingr_ctx_rccl_init)");
-    return fitter_sharded_update(f, flavour, cp, ip, n_iterations, z, native_allreduce, ctx, native_gather);
+    return fitter_sharded_update(f, flavour, cp, ip, n_iterations, z, native_allreduce, ctx, native_gather, ctx->split_exchange != 0);
 }
 
 int gingr_fitter_posterior_logpdf_rccl(gingr_fitter *f, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip,

@@ -76,8 +76,20 @@ const char *gingr_build_info(void);
  *   GINGR_OPT_TRI_GRID   0 / 1 (default) / 2: the surface ICP's closest surface point searches a grid of the (fixed) target triangles
  *                        first, warm-started from the previous iteration, and the tile scan only answers what the grid cannot certify:
  *                        never / from 16 384 target triangles on / always
+ *   GINGR_OPT_SPLIT_EXCHANGE  0 (default) / 1: row-sharded CPD through the library's own RCCL exchange (gingr_fitter_update_*_rccl_async):
+ *                        the column-sum pass runs in two halves of the target tiles and the all-reduce of the first half is enqueued on a
+ *                        second stream of the context (event-ordered, same communicator) while the second half computes, so that only
+ *                        the second half's all-reduce is exposed.  Costs two short launches instead of one (the emulated per-rank time
+ *                        rises by a few microseconds); whether it pays depends on the all-reduce latency of the node.
+ *                        Same sums up to the order of the chunk partials (<= 1e-12 on the state).
  * No reference counterpart (the reference has one code path per operation). */
-typedef enum gingr_ctx_option { GINGR_OPT_CULL = 0, GINGR_OPT_FINE_CULL = 1, GINGR_OPT_NN_GRID = 2, GINGR_OPT_TRI_GRID = 3 } gingr_ctx_option;
+typedef enum gingr_ctx_option {
+    GINGR_OPT_CULL = 0,
+    GINGR_OPT_FINE_CULL = 1,
+    GINGR_OPT_NN_GRID = 2,
+    GINGR_OPT_TRI_GRID = 3,
+    GINGR_OPT_SPLIT_EXCHANGE = 4
+} gingr_ctx_option;
 int gingr_ctx_set_option(gingr_ctx *ctx, int32_t option, int32_t value);
 int gingr_ctx_get_option(gingr_ctx *ctx, int32_t option, int32_t *value);
 

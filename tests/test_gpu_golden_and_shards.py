@@ -328,3 +328,45 @@ def test_native_rccl_exchange_equals_the_single_shard():
     assert p[2] == q[2] == 5 and p[3] == q[3] == 0
     assert np.max(np.abs(p[0] - q[0])) <= 1e-12 and abs(p[1] - q[1]) <= 1e-12 * abs(p[1])
     assert np.max(np.abs(p[4] - q[4])) <= 1e-12 * np.max(np.abs(p[4]))
+
+
+def test_split_column_sum_exchange_gives_the_same_shard_state():
+    """GINGR_OPT_SPLIT_EXCHANGE: pass 1 in two halves of the target tiles, the all-reduce of the first half on the context's second
+    stream behind the second half (same communicator, event-ordered).  On the one GPU of the pool the exchange is a one-rank
+    communicator and the fitter rank 0 of a two-rank row shard (the other rank's sums are missing: an emulated shard, as in
+    bench.py --emulate-world) -- what must hold is that the split run lands on the state of the unsplit run of the same shard up to
+    the order of the chunk partials, iteration after iteration, and that the event ordering does not lose a half."""
+    import gingr_amd as ga
+    from gingr_amd import _native as nat
+    from gingr_amd.sharded import ShardedFitter
+    rng = np.random.default_rng(11)
+    ref = rng.normal(0, 50.0, (9000, 3)).astype(np.float32).astype(np.float64)
+    mo = go.build_gaussian_gpmm(ref, 70.0, 50.0, rel_tol=1e-12, max_rank=24)
+    target = mo.ref[rng.permutation(mo.M)[:8800]] + rng.normal(0, 0.5, (8800, 3))
+    states = {}
+    for split in (0, 1):
+        ctx = ga.Context(0)
+        ctx.set_option(nat.OPT_SPLIT_EXCHANGE, split)
+        assert ctx.get_option(nat.OPT_SPLIT_EXCHANGE) == split
+        ctx.rccl_init(ctx.rccl_unique_id(), 1, 0)
+        f = ShardedFitter(ctx, ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam), target, rank=0, world=2, rccl=True)
+        f.set_state(np.zeros(mo.rank), ctx.cpd_initial_sigma2(mo.ref, target))
+        per_it = []
+        for _ in range(4):
+            f.update_cpd(0.1, 1.0, 1)
+            ctx.synchronize()
+            a, sc, fit = f.get_state()
+            st = f.get_cpd_stats()
+            per_it.append((a.copy(), float(sc.sigma2), int(sc.status), fit.copy(), st["den"].copy()))
+        f.update_cpd(0.1, 1.0, 6)                                     # several iterations enqueued back to back
+        ctx.synchronize()
+        a, sc, fit = f.get_state()
+        per_it.append((a.copy(), float(sc.sigma2), int(sc.status), fit.copy(), f.get_cpd_stats()["den"].copy()))
+        states[split] = per_it
+        f.close()
+        ctx.close()
+    for (a0, s0, st0, fit0, den0), (a1, s1, st1, fit1, den1) in zip(states[0], states[1]):
+        assert st0 == st1 == 0
+        assert np.max(np.abs(den1 - den0) / np.abs(den0)) < 1e-12      # both halves of the column sums arrived, in the right places
+        assert abs(s1 - s0) <= 1e-11 * abs(s0) and np.max(np.abs(a1 - a0)) <= 1e-9
+        assert np.max(np.abs(fit1 - fit0)) <= 1e-9 * np.max(np.abs(fit0))
