@@ -7,7 +7,7 @@ import shutil
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "04"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "05"
 F, P = os.path.join(root, "gpurun_out", "final"), os.path.join(root, "profiles")
 
 
@@ -51,7 +51,8 @@ json.dump({
 }, open(os.path.join(P, f"r{rnd}_configs_3_4_and_variants.json"), "w"), indent=1)
 for src, dst in (("emu8_kernel_stats.csv", f"r{rnd}_emulated_8gpu_shard_kernel_stats.csv"), ("emu8_kernels.txt", f"r{rnd}_emulated_8gpu_shard_kernel_stats.txt"),
                  ("chain_kernel_stats.csv", f"r{rnd}_mh_chain_femur_kernel_stats.csv"), ("icp50k.json", f"r{rnd}_icp_pointcloud_50k.json"),
-                 ("icp_surface.json", f"r{rnd}_icp_surface_41k.json")):
+                 ("icp_surface.json", f"r{rnd}_icp_surface_41k.json"), ("icp_surface_n50.json", f"r{rnd}_icp_surface_41k_50_iterations.json"),
+                 ("stamps_emu8.txt", f"r{rnd}_shard_pair_loop_stamps_final.txt")):
     if os.path.exists(os.path.join(F, src)) and os.path.getsize(os.path.join(F, src)) > 0:
         shutil.copy(os.path.join(F, src), os.path.join(P, dst))
 if os.path.exists(os.path.join(F, "chain_1.json")):
