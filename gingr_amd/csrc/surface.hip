@@ -1249,7 +1249,11 @@ void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const in
 }
 void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, const int32_t *tri, int64_t T, const double *boxes,
                            const int32_t *skip, int32_t *flag, const double *tribox, const Cloud *mesh) {
+#ifdef GINGR_SI_H
+    const int h = GINGR_SI_H;
+#else
     const int h = surface_h(fit.n);
+#endif
     const Cloud v = mesh ? *mesh : fit;
     auto go = [&](auto kern, int qpb) {
         hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(fit.n, qpb)), dim3(kCpThreads), 0, ctx->stream, fit, cp_soa, v, tri, T, boxes,
