@@ -244,6 +244,40 @@ struct TriGrid {
     bool ready = false;
     const int32_t *cur_nflag() const { return nflag + parity; }
 };
+// The same grid for a MOVING mesh (the template), rebuilt on the device in front of every use (round 5): the description lives in
+// device memory (params: the TriGridDev the kernels read, + validity), geometry and lists are recomputed from the per-triangle boxes
+// the iteration has computed anyway (tri_tile_bbox_kernel).  Four short launches: set-up (bounding box of the tile boxes, grid
+// dimensions at the fixed cell edge h, counters zeroed), count (cell of every triangle's lower corner, wide triangles to the short
+// list), scan (128 workgroups with a look-back over their totals, up to 2^20 cells), fill (entries, boxes and corner records in cell order).  Entry order inside a cell
+// is whatever the atomics give: the queries' results do not depend on it (self-intersection is an OR; closest points break ties by
+// original triangle id).
+struct MovGridParams {
+    TriGridDev v;
+    int32_t valid, pad;
+};
+struct MovGrid {
+    MovGridParams *params = nullptr;  // device
+    int32_t *cell_cnt = nullptr, *cell_start = nullptr, *tri_cell = nullptr, *big = nullptr;
+    double *boxes = nullptr, *recs = nullptr;
+    uint8_t *flag = nullptr;          // [max_queries]: queries the grid could not certify
+    int32_t *nflag = nullptr;         // two counters used alternately (as TriGrid)
+    unsigned long long *scan_agg = nullptr;  // per scan workgroup: (epoch << 32 | total) of the build in flight
+    unsigned epoch = 0;
+    int parity = 0;
+    int32_t ncap = 0;                 // cells allocated
+    int64_t T = 0, max_queries = 0;
+    double h = 0.0;                   // cell edge (mean extent of a triangle's box when the grid was set up; any value is correct)
+    bool ready = false;
+    const int32_t *cur_nflag() const { return nflag + parity; }
+};
+int mov_grid_alloc(gingr_ctx *ctx, int64_t T, int64_t max_queries, MovGrid *g);
+void mov_grid_free(MovGrid *g);
+// (re)build for the current vertex positions; tribox [T][6] and tile_boxes [ceil(T / 256)][6] as tri_tile_bbox_kernel left them
+void launch_mov_grid_build(gingr_ctx *ctx, MovGrid &g, Cloud v, const int32_t *tri, const int32_t *tri_orig, const double *tribox,
+                           const double *tile_boxes);
+// self-intersection flags (see launch_self_intersect) over the moving grid: certified queries get their flag, the others are marked
+// in g.flag / counted in g.cur_nflag() for the masked launch_self_intersect that must follow
+void launch_self_intersect_grid(gingr_ctx *ctx, Cloud fit, const double *cp_soa, MovGrid &g, const int32_t *skip, int32_t *flag);
 int tri_grid_build(gingr_ctx *ctx, const double *vsoa_host, int64_t n, const int32_t *tri_host, const int32_t *tri_orig_host, int64_t T,
                    int64_t max_queries, TriGrid *g);
 void tri_grid_free(TriGrid *g);
@@ -260,8 +294,10 @@ int distance_stats_ws_doubles();
 void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const int32_t *orig, int64_t orig_limit, const int32_t *nn,
                            const int32_t *boundary, double sdev, double *partial, double *out4);
 // mesh (nullable): the cloud the triangles index when it is not the query cloud itself (row shard: the gathered fit of all shards)
+// only / nonly (nullable, device): only queries with only[i] != 0 are processed and written, and the launch is a no-op when *nonly == 0
 void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, const int32_t *tri, int64_t T, const double *boxes,
-                           const int32_t *skip, int32_t *flag, const double *tribox = nullptr, const Cloud *mesh = nullptr);
+                           const int32_t *skip, int32_t *flag, const double *tribox = nullptr, const Cloud *mesh = nullptr,
+                           const uint8_t *only = nullptr, const int32_t *nonly = nullptr);
 // found (nullable): along-normal flavour, 0 = no intersection (rejected)
 void launch_surface_prereject(gingr_ctx *ctx, int64_t M, const int32_t *nn_vertex, const int32_t *tgt_boundary,
                               const double *fit_vn, const double *tgt_vn, int64_t N, const int32_t *found, int32_t *pre);

@@ -151,6 +151,7 @@ struct gingr_fitter {
     bool nn_warm = false, surf_nn_warm = false;  // nn_idx / surf_nn hold last time's matches against the CURRENT target
     NNGrid tgrid;  // uniform grid over the target cloud (set_target): the point-cloud ICP's closest-point search (nn_grid.hip)
     TriGrid ttgrid;  // uniform grid over the target TRIANGLES (set_meshes): the surface ICP's closest surface point (surface.hip)
+    MovGrid mgrid;   // the same over the TEMPLATE's triangles, rebuilt on the device every iteration: the self-intersection test (round 5)
     void forget_posteriors() {
         post_stage = 0;
         alt_stage = 0;
@@ -386,6 +387,7 @@ void free_meshes(gingr_fitter *f) {
     f->surf_nn = f->surf_pre = f->surf_hit = f->surf_tri_pos = nullptr;
     f->surf_tri_warm = f->surf_nn_warm = false;
     tri_grid_free(&f->ttgrid);
+    mov_grid_free(&f->mgrid);
     f->Tm = f->Tt = 0;
 }
 
@@ -1305,7 +1307,18 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 f->surf_nn_warm = true;
                 launch_surface_prereject(ctx, M, f->surf_nn, f->tboundary, f->mvn, f->tvn, f->N, along ? f->surf_hit : nullptr,
                                          f->surf_pre);
-                launch_self_intersect(ctx, fit, f->surf_cp, f->mtri, f->Tm, f->mtboxes, f->surf_pre, f->surf_hit, f->mtribox, &meshc);
+                if (ctx->tri_grid == 2 && ctx->cull && f->mgrid.ready && M <= f->mgrid.max_queries) {
+                    // GINGR_OPT_TRI_GRID = 2 only: the template's triangles binned for THIS iteration (boxes and tile boxes are the ones
+                    // computed above), the test over the cells the segment's ball reaches, the tile scan for what that could not
+                    // certify.  Same decisions; NOT the default -- at 41k x 82k the four build launches (setup, count, scan, fill:
+                    // ~30 us) + the query (31 us) lose to the barrier-free tile scan (50 us): tools/experiments/README.md, round 5
+                    launch_mov_grid_build(ctx, f->mgrid, meshc, f->mtri, nullptr, f->mtribox, f->mtboxes);
+                    launch_self_intersect_grid(ctx, fit, f->surf_cp, f->mgrid, f->surf_pre, f->surf_hit);
+                    launch_self_intersect(ctx, fit, f->surf_cp, f->mtri, f->Tm, f->mtboxes, f->surf_pre, f->surf_hit, f->mtribox, &meshc,
+                                          f->mgrid.flag, f->mgrid.cur_nflag());
+                } else {
+                    launch_self_intersect(ctx, fit, f->surf_cp, f->mtri, f->Tm, f->mtboxes, f->surf_pre, f->surf_hit, f->mtribox, &meshc);
+                }
                 launch_surface_weight(ctx, M, f->surf_pre, f->surf_hit, &f->st->sigma2, f->surf_w01, f->surf_win);
             } else if (icp) {
                 nearest_target_vertex(ctx, f, fit, tgt, f->nn_idx, f->nn_d2, f->nn_warm);
@@ -1886,6 +1899,8 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     // the target triangles do not move: bin them once (the surface ICP's warm-started closest-point search)
     GINGR_TRY(tri_grid_build(ctx, tpos.data(), N, bt.tri.data(), bt.orig.data(), n_target_tri, M, &f->ttgrid));
+    // the template's triangles move: their grid is rebuilt on the device every iteration (self-intersection test); buffers only here
+    GINGR_TRY(mov_grid_alloc(ctx, n_model_tri, M, &f->mgrid));
     return GINGR_OK;
 }
 

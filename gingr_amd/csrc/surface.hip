@@ -654,7 +654,9 @@ __global__ __launch_bounds__(kCpThreads) void self_intersect_queue_kernel(Cloud 
                                                                          const int32_t *__restrict__ tri, int64_t T,
                                                                          const double *__restrict__ boxes,
                                                                          const int32_t *__restrict__ skip,
-                                                                         int32_t *__restrict__ flag, const double *__restrict__ tribox) {
+                                                                         int32_t *__restrict__ flag, const double *__restrict__ tribox,
+                                                                         const uint8_t *__restrict__ only, const int32_t *__restrict__ nonly) {
+    if (nonly && *nonly == 0) return;  // masked launch (what the grid kernel could not certify): nothing left over
     __shared__ double tbox[kTriTile][6];
     constexpr int QPB = 64 / H;
     __shared__ int qhit[QPB];
@@ -663,7 +665,9 @@ __global__ __launch_bounds__(kCpThreads) void self_intersect_queue_kernel(Cloud 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ql = lane & (QPB - 1), half = lane / QPB;
     const int64_t i = (int64_t)blockIdx.x * QPB + ql;
-    const bool ok = i < fit.n && !(skip && skip[i]);
+    const bool mine = i < fit.n && (!only || only[i] != 0);
+    if (only && !__syncthreads_or(mine)) return;  // none of this workgroup's queries was left over
+    const bool ok = mine && !(skip && skip[i]);
     const int64_t ic = i < fit.n ? i : 0;
     const V3 p{fit.x[ic], fit.y[ic], fit.z[ic]};
     const V3 dir = sub(p, V3{cp[ic], cp[fit.n + ic], cp[2 * fit.n + ic]});
@@ -768,7 +772,7 @@ __global__ __launch_bounds__(kCpThreads) void self_intersect_queue_kernel(Cloud 
     }
     if (tail > 0) flush(tail);
     __syncthreads();
-    if (wave == 0 && half == 0 && i < fit.n) flag[i] = qhit[ql];
+    if (wave == 0 && half == 0 && mine) flag[i] = qhit[ql];
 }
 
 // ClosestPointAlongNormalTriangleMesh3D (ClosestPointRegistrator.scala:102-131): for every fit vertex the intersection of the
@@ -1018,6 +1022,356 @@ __global__ void dist_stats_finish_kernel(const double *__restrict__ partial, dou
     out[threadIdx.x] = v;
 }
 
+// ---------------------------------------------------------------------------- grid over a MOVING mesh, rebuilt on the device (round 5)
+constexpr int kMovGridSetupBlocks = 256;
+constexpr int kMovGridScanBlocks = 128;      // all resident at once (the scan's look-back spins on the predecessors' totals)
+constexpr int32_t kMovGridMinCells = kMovGridScanBlocks * 1024;  // cell capacity: a power of two between these
+constexpr int32_t kMovGridMaxCells = 1 << 20;
+constexpr int kMovGridMaxBig = 256;
+
+__device__ __forceinline__ int32_t mov_cell_of(double x, double lo, double inv_h, int32_t gd) {  // the clamped floor every user evaluates
+    const double c = floor((x - lo) * inv_h);
+    return c >= (double)(gd - 1) ? gd - 1 : (c > 0.0 ? (int32_t)c : 0);
+}
+
+// block 0: bounding box of the tile boxes -> geometry at cell edge h (grown until the cells fit), counters of the description zeroed;
+// all blocks: the cell counters zeroed
+__global__ __launch_bounds__(256) void mov_grid_setup_kernel(const double *__restrict__ tile_boxes, int ntiles, int64_t T, double h, int32_t ncap,
+                                                             MovGridParams *__restrict__ P, int32_t *__restrict__ cnt,
+                                                             const int32_t *cell_start, const double *boxes, const double *recs) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k <= ncap; k += (int64_t)gridDim.x * 256) cnt[k] = 0;
+    if (blockIdx.x != 0) return;
+    __shared__ double sh[6][256];
+    double lo[3] = {__builtin_huge_val(), __builtin_huge_val(), __builtin_huge_val()};
+    double hi[3] = {-__builtin_huge_val(), -__builtin_huge_val(), -__builtin_huge_val()};
+    for (int t = threadIdx.x; t < ntiles; t += 256)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = fmin(lo[d], tile_boxes[(int64_t)t * 6 + d]);   // (fmin / fmax skip NaN: a tile of non-finite triangles does not poison the box)
+            hi[d] = fmax(hi[d], tile_boxes[(int64_t)t * 6 + 3 + d]);
+        }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) sh[d][threadIdx.x] = lo[d], sh[3 + d][threadIdx.x] = hi[d];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                sh[d][threadIdx.x] = fmin(sh[d][threadIdx.x], sh[d][threadIdx.x + st]);
+                sh[3 + d][threadIdx.x] = fmax(sh[3 + d][threadIdx.x], sh[3 + d][threadIdx.x + st]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    double size[3], maxext = 0.0;
+    bool fin = true;
+    for (int d = 0; d < 3; ++d) {
+        size[d] = sh[3 + d][0] - sh[d][0];
+        fin = fin && fabs(sh[d][0]) < 1e300 && fabs(sh[3 + d][0]) < 1e300 && size[d] >= 0.0;
+        maxext = fmax(maxext, size[d]);
+    }
+    int32_t gd[3] = {1, 1, 1};
+    // cell edge: the caller's, or about the edge of a triangle of a closed surface that fills the box (T triangles on the box's surface
+    // area); any value is correct -- the spans measured by the count pass make the queries look far enough
+    double hh = h > 0.0 ? h : 0.75 * sqrt(4.0 * (size[0] * size[1] + size[1] * size[2] + size[0] * size[2]) / (double)(T > 0 ? T : 1));
+    if (fin && maxext > 0.0 && hh > 0.0) {
+        if (!(hh > 1e-9 * maxext)) hh = 1e-9 * maxext;
+        for (int it = 0; it < 200; ++it) {
+            double cells = 1.0;
+            for (int d = 0; d < 3; ++d) {
+                const double c = floor(size[d] / hh) + 1.0;
+                gd[d] = (int32_t)fmin(c, 512.0);
+                cells *= fmin(c, 1e9);
+                if (c > 512.0) cells = 1e30;
+            }
+            if (cells <= (double)ncap) break;
+            hh *= 1.25;
+        }
+        if ((double)gd[0] * gd[1] * gd[2] > (double)ncap) fin = false;
+    } else {
+        fin = false;
+    }
+    for (int d = 0; d < 3; ++d) {
+        P->v.lo[d] = fin ? sh[d][0] : 0.0;
+        P->v.g[d] = fin ? gd[d] : 1;
+        P->v.span[d] = 0;
+    }
+    P->v.h = hh;
+    P->v.inv_h = fin ? 1.0 / hh : 0.0;
+    P->v.n_listed = 0;
+    P->v.n_big = 0;
+    P->v.cell_start = cell_start;
+    P->v.boxes = boxes;
+    P->v.recs = recs;
+    P->valid = fin ? 1 : 0;
+}
+
+// tri_cell[t]: the cell of the lower corner of triangle t's box (>= 0), -1 a triangle with a non-finite corner (never a candidate),
+// -2 - k the k-th entry of the short list of wide triangles
+__global__ __launch_bounds__(256) void mov_grid_count_kernel(int64_t T, const double *__restrict__ tribox, MovGridParams *P,
+                                                             int32_t *__restrict__ cnt, int32_t *__restrict__ tri_cell) {
+    __shared__ int wspan[3][4];
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int valid = P->valid;
+    const double lo[3] = {P->v.lo[0], P->v.lo[1], P->v.lo[2]}, inv_h = P->v.inv_h;
+    const int32_t gd[3] = {P->v.g[0], P->v.g[1], P->v.g[2]};
+    int32_t ex[3] = {0, 0, 0};
+    int32_t code = -1;
+    bool listed = false;
+    if (t < T && valid) {
+        const double *b = tribox + 6 * t;
+        bool fin = true, wide = false;
+        int32_t a[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            fin = fin && fabs(b[d]) < 1e300 && fabs(b[3 + d]) < 1e300;
+            a[d] = mov_cell_of(b[d], lo[d], inv_h, gd[d]);
+            ex[d] = mov_cell_of(b[3 + d], lo[d], inv_h, gd[d]) - a[d];
+            wide = wide || ex[d] > kTriGridMaxSpan;
+        }
+        if (fin && wide) {
+            const int32_t k = atomicAdd(&P->v.n_big, 1);
+            if (k >= kMovGridMaxBig) P->valid = 0;  // many huge triangles in a fine grid: every query falls back to the tile scan
+            code = -2 - k;
+        } else if (fin) {
+            code = (a[2] * gd[1] + a[1]) * gd[0] + a[0];
+            listed = true;
+        }
+    }
+    if (t < T) tri_cell[t] = code;
+    if (listed) atomicAdd(&cnt[code], 1);
+    // the largest extent of a listed triangle's box, per axis: one atomic per workgroup (every triangle of the mesh would otherwise
+    // meet in three words of one cache line: measured 41-90 us for 82k triangles)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int m = listed ? ex[d] : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+        if ((threadIdx.x & 63) == 0) wspan[d][threadIdx.x >> 6] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int d = threadIdx.x;
+        const int m = max(max(wspan[d][0], wspan[d][1]), max(wspan[d][2], wspan[d][3]));
+        if (m > 0) atomicMax(&P->v.span[d], m);
+    }
+}
+
+// start[c] = number of listed triangles in cells < c: exclusive scan of cnt over all ncap cells (cells past the grid hold zeros) by
+// kMovGridScanBlocks workgroups in ONE launch -- every workgroup sums its slice, publishes the total tagged with this build's epoch,
+// adds up its predecessors' totals (they are all resident: spinning on them is safe) and scans its slice again from there; cnt is
+// zeroed on the way (the fill pass uses it as the cursor of every cell); the last workgroup leaves the number of listed entries.
+__global__ __launch_bounds__(256) void mov_grid_scan_kernel(MovGridParams *P, int32_t *__restrict__ cnt, int32_t *__restrict__ start, int32_t ncap,
+                                                            unsigned long long *agg, unsigned epoch) {
+    __shared__ int32_t sh[256];
+    __shared__ int32_t s_prefix;
+    const int nb = gridDim.x, b = blockIdx.x, t = threadIdx.x;
+    const int32_t per = ncap / nb;  // a multiple of 1024
+    const int4 *src = reinterpret_cast<const int4 *>(cnt + (int64_t)b * per);
+    const int nchunk = per / 1024;
+    int32_t tot = 0;
+    for (int k = 0; k < nchunk; ++k) {
+        const int4 v = src[k * 256 + t];
+        tot += (v.x + v.y) + (v.z + v.w);
+    }
+    sh[t] = tot;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (t < st) sh[t] += sh[t + st];
+        __syncthreads();
+    }
+    const int32_t block_total = sh[0];
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&agg[b], ((unsigned long long)epoch << 32) | (unsigned)block_total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    int32_t mine = 0;
+    if (t < b) {  // (b <= 127 < 256: one predecessor per thread)
+        unsigned long long a;
+        while ((unsigned)((a = __hip_atomic_load(&agg[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch) __builtin_amdgcn_s_sleep(1);
+        mine = (int32_t)(unsigned)a;
+    }
+    sh[t] = mine;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (t < st) sh[t] += sh[t + st];
+        __syncthreads();
+    }
+    if (t == 0) s_prefix = sh[0];
+    __syncthreads();
+    int32_t carry = s_prefix;
+    int4 *dst = reinterpret_cast<int4 *>(start + (int64_t)b * per);
+    int4 *zero = reinterpret_cast<int4 *>(cnt + (int64_t)b * per);
+    for (int k = 0; k < nchunk; ++k) {
+        const int4 v = src[k * 256 + t];
+        const int32_t local = (v.x + v.y) + (v.z + v.w);
+        sh[t] = local;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {  // inclusive scan of the 256 thread sums
+            const int32_t u = t >= off ? sh[t - off] : 0;
+            __syncthreads();
+            sh[t] += u;
+            __syncthreads();
+        }
+        const int32_t excl = carry + sh[t] - local;
+        const int32_t chunk_total = sh[255];
+        dst[k * 256 + t] = int4{excl, excl + v.x, excl + v.x + v.y, excl + v.x + v.y + v.z};
+        zero[k * 256 + t] = int4{0, 0, 0, 0};
+        carry += chunk_total;
+        __syncthreads();
+    }
+    if (b == nb - 1 && t == 0) {
+        start[ncap] = carry;
+        P->v.n_listed = carry;
+        if (P->v.n_big > kMovGridMaxBig) P->v.n_big = kMovGridMaxBig;  // (valid is 0 then: nobody reads the list)
+    }
+}
+
+__global__ __launch_bounds__(256) void mov_grid_fill_kernel(int64_t T, Cloud v, const int32_t *__restrict__ tri,
+                                                            const int32_t *__restrict__ tri_orig, const double *__restrict__ tribox,
+                                                            const MovGridParams *__restrict__ P, const int32_t *__restrict__ start,
+                                                            int32_t *__restrict__ cursor, const int32_t *__restrict__ tri_cell,
+                                                            double *__restrict__ boxes, double *__restrict__ recs) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T || !P->valid) return;
+    const int32_t c = tri_cell[t];
+    if (c == -1) return;
+    int64_t slot;
+    if (c >= 0) {
+        slot = start[c] + atomicAdd(&cursor[c], 1);
+    } else {
+        const int32_t k = -2 - c;
+        if (k >= kMovGridMaxBig) return;
+        slot = (int64_t)P->v.n_listed + k;
+    }
+#pragma unroll
+    for (int d = 0; d < 6; ++d) boxes[slot * 6 + d] = tribox[6 * t + d];
+    double *rc = recs + slot * kTriRec;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int32_t a = tri[3 * t + k];
+        rc[3 * k] = v.x[a];
+        rc[3 * k + 1] = v.y[a];
+        rc[3 * k + 2] = v.z[a];
+    }
+    const long long meta = (long long)(((unsigned long long)(uint32_t)(tri_orig ? tri_orig[t] : (int32_t)t) << 32) | (unsigned long long)(uint32_t)t);
+    rc[9] = __builtin_bit_cast(double, meta);
+}
+
+// Self-intersection test (see self_intersect_queue_kernel: same line / triangle arithmetic on the same corner coordinates, same
+// margins) over the moving grid: kLanes lanes per query share the entries of the cells the ball of radius |v| around the query reaches.
+// A query whose ball covers more than kTriGridMaxCells rows of cells, a non-finite query or an invalid grid is flagged for the
+// masked tile scan.  "Some triangle holds a closer intersection" does not depend on the order the entries are visited in.
+template <int kLanes>
+__global__ __launch_bounds__(256) void self_intersect_grid_kernel(Cloud fit, const double *__restrict__ cp, const MovGridParams *__restrict__ P,
+                                                                 const int32_t *__restrict__ skip, int32_t *__restrict__ out,
+                                                                 uint8_t *__restrict__ flag, int32_t *__restrict__ nflag,
+                                                                 int32_t *__restrict__ nflag_next) {
+    constexpr int QPB = 256 / kLanes;
+    __shared__ int32_t cell_s[QPB][kTriGridMaxCells], cell_off[QPB][kTriGridMaxCells + 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nflag_next = 0;
+    const TriGridDev g = P->v;
+    const bool valid = P->valid != 0;
+    const int ql = threadIdx.x % kLanes, qi = threadIdx.x / kLanes;
+    const int64_t i = (int64_t)blockIdx.x * QPB + qi;
+    const bool inr = i < fit.n;
+    const bool ok = inr && !(skip && skip[i]);
+    const int64_t ic = inr ? i : 0;
+    const V3 pp{fit.x[ic], fit.y[ic], fit.z[ic]};
+    const V3 dd0 = sub(pp, V3{cp[ic], cp[fit.n + ic], cp[2 * fit.n + ic]});
+    const double vv = dot3(dd0, dd0);
+    const double vnorm = sqrt(vv);
+    bool fl = ok;  // flagged unless the block below certifies the answer
+    int hit = 0;
+    if (ok && valid) {
+        const double r = vnorm * (1.0 + 1e-9) + 1e-300;
+        const double f0[3] = {(pp.x - r - g.lo[0]) * g.inv_h, (pp.y - r - g.lo[1]) * g.inv_h, (pp.z - r - g.lo[2]) * g.inv_h};
+        const double f1[3] = {(pp.x + r - g.lo[0]) * g.inv_h, (pp.y + r - g.lo[1]) * g.inv_h, (pp.z + r - g.lo[2]) * g.inv_h};
+        bool fin = true;
+        int c0[3], c1[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            fin = fin && fabs(f0[d]) < 1e15 && fabs(f1[d]) < 1e15;
+            const double a = floor(f0[d]), b = floor(f1[d]);
+            c0[d] = a >= (double)(g.g[d] - 1) ? g.g[d] - 1 : (a > 0.0 ? (int)a : 0);
+            c1[d] = b >= (double)(g.g[d] - 1) ? g.g[d] - 1 : (b > 0.0 ? (int)b : 0);
+        }
+        const int x0 = c0[0] > g.span[0] ? c0[0] - g.span[0] : 0, y0 = c0[1] > g.span[1] ? c0[1] - g.span[1] : 0,
+                  z0 = c0[2] > g.span[2] ? c0[2] - g.span[2] : 0;
+        const int ny = c1[1] - y0 + 1, nz = c1[2] - z0 + 1;
+        if (fin && ny * nz + 1 <= kTriGridMaxCells) {
+            const int nrow = ny * nz, nrun = nrow + (g.n_big > 0 ? 1 : 0);
+            for (int k = ql; k < nrun; k += kLanes) {
+                int32_t s0, n0;
+                if (k < nrow) {
+                    const int rz = k / ny, ry = k - rz * ny;
+                    const int64_t rowbase = ((int64_t)(z0 + rz) * g.g[1] + (y0 + ry)) * g.g[0];
+                    s0 = g.cell_start[rowbase + x0];
+                    n0 = g.cell_start[rowbase + c1[0] + 1] - s0;
+                } else {
+                    s0 = g.n_listed;
+                    n0 = g.n_big;
+                }
+                cell_s[qi][k] = s0;
+                cell_off[qi][k + 1] = n0;
+            }
+            __threadfence_block();
+            if (ql == 0) {
+                int32_t off = 0;
+                for (int k = 0; k < nrun; ++k) {
+                    const int32_t n = cell_off[qi][k + 1];
+                    cell_off[qi][k] = off;
+                    off += n;
+                }
+                cell_off[qi][nrun] = off;
+            }
+            __threadfence_block();
+            const int32_t total = cell_off[qi][nrun];
+            int k = 0;
+            for (int32_t base = 0; base < total && !hit; base += kLanes) {
+                const int32_t idx = base + ql;
+                if (idx < total) {
+                    while (cell_off[qi][k + 1] <= idx) ++k;
+                    const int64_t e = cell_s[qi][k] + (idx - cell_off[qi][k]);
+                    if (!(point_box_gap2(pp.x, pp.y, pp.z, g.boxes + e * 6) > vv * (1.0 + 1e-9))) {
+                        const double *rc = g.recs + e * kTriRec;
+                        const V3 A{rc[0], rc[1], rc[2]};
+                        const V3 e1 = sub(V3{rc[3], rc[4], rc[5]}, A), e2 = sub(V3{rc[6], rc[7], rc[8]}, A);
+                        const V3 pv = cross3(dd0, e2);
+                        const double det = dot3(e1, pv);
+                        const double inv = 1.0 / det;
+                        const V3 tv = sub(pp, A);
+                        const double u = dot3(tv, pv) * inv;
+                        const V3 qv = cross3(tv, e1);
+                        const double w = dot3(qv, dd0) * inv;
+                        const double tt = dot3(e2, qv) * inv;
+                        if (det != 0.0 && u >= 0.0 && u <= 1.0 && w >= 0.0 && u + w <= 1.0) {
+                            const V3 ip{pp.x + tt * dd0.x, pp.y + tt * dd0.y, pp.z + tt * dd0.z};
+                            if (ip.x != pp.x || ip.y != pp.y || ip.z != pp.z) {
+                                const V3 dd = sub(ip, pp);
+                                if (sqrt((dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z) < vnorm) hit = 1;
+                            }
+                        }
+                    }
+                }
+                // any lane of the query found one: done (sub-wave OR over the query's lanes)
+#pragma unroll
+                for (int off = kLanes / 2; off > 0; off >>= 1) hit |= __shfl_xor(hit, off);
+            }
+            fl = false;
+        }
+    }
+    if (inr && ql == 0) {
+        flag[i] = fl ? 1 : 0;
+        if (!fl) out[i] = ok ? hit : 0;  // (a skipped query: 0, as the tile scan writes)
+    }
+    const unsigned long long m = __ballot(inr && ql == 0 && fl);
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt, __builtin_popcountll(m));
+    __syncthreads();
+    if (threadIdx.x == 0 && cnt) atomicAdd(nflag, cnt);
+}
+
 }  // namespace
 
 size_t reversal_sort_temp_bytes(int64_t N) {
@@ -1093,6 +1447,57 @@ void launch_surface_closest_point(gingr_ctx *ctx, Cloud q, Cloud v, const int32_
         go(surface_cp_queue_kernel<16>, 4);
     else
         go(surface_cp_queue_kernel<4>, 16);
+}
+
+int mov_grid_alloc(gingr_ctx *ctx, int64_t T, int64_t max_queries, MovGrid *g) {
+    mov_grid_free(g);
+    if (T < 1 || T > INT32_MAX || max_queries < 1) return GINGR_OK;
+    int64_t ncap = kMovGridMinCells;  // a power of two (the scan splits it evenly): about 4 cells per triangle -- a surface fills few of a box's cells
+    while (ncap < 4 * T && ncap < kMovGridMaxCells) ncap *= 2;
+    g->ncap = (int32_t)ncap;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->scan_agg), kMovGridScanBlocks * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(g->scan_agg, 0, kMovGridScanBlocks * sizeof(unsigned long long), ctx->stream));
+    g->T = T;
+    g->max_queries = max_queries;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->params), sizeof(MovGridParams)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->cell_cnt), (size_t)(ncap + 1) * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->cell_start), (size_t)(ncap + 1) * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->tri_cell), (size_t)T * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->boxes), (size_t)(T + kMovGridMaxBig) * 6 * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->recs), (size_t)(T + kMovGridMaxBig) * kTriRec * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->flag), (size_t)max_queries));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->nflag), 2 * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMemsetAsync(g->params, 0, sizeof(MovGridParams), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(g->flag, 0, (size_t)max_queries, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(g->nflag, 0, 2 * sizeof(int32_t), ctx->stream));
+    g->h = 0.0;
+    g->ready = true;
+    return GINGR_OK;
+}
+void mov_grid_free(MovGrid *g) {
+    void *ptrs[] = {g->params, g->cell_cnt, g->cell_start, g->tri_cell, g->big, g->boxes, g->recs, g->flag, g->nflag, g->scan_agg};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    *g = MovGrid{};
+}
+void launch_mov_grid_build(gingr_ctx *ctx, MovGrid &g, Cloud v, const int32_t *tri, const int32_t *tri_orig, const double *tribox,
+                           const double *tile_boxes) {
+    const int64_t T = g.T;
+    const int ntiles = (int)ceil_div(T, kTriTile);
+    hipLaunchKernelGGL(mov_grid_setup_kernel, dim3(kMovGridSetupBlocks), dim3(256), 0, ctx->stream, tile_boxes, ntiles, T, g.h, g.ncap, g.params,
+                       g.cell_cnt, g.cell_start, g.boxes, g.recs);
+    hipLaunchKernelGGL(mov_grid_count_kernel, dim3((unsigned)ceil_div(T, 256)), dim3(256), 0, ctx->stream, T, tribox, g.params, g.cell_cnt, g.tri_cell);
+    hipLaunchKernelGGL(mov_grid_scan_kernel, dim3(kMovGridScanBlocks), dim3(256), 0, ctx->stream, g.params, g.cell_cnt, g.cell_start, g.ncap,
+                       g.scan_agg, ++g.epoch);
+    hipLaunchKernelGGL(mov_grid_fill_kernel, dim3((unsigned)ceil_div(T, 256)), dim3(256), 0, ctx->stream, T, v, tri, tri_orig, tribox, g.params,
+                       g.cell_start, g.cell_cnt, g.tri_cell, g.boxes, g.recs);
+}
+void launch_self_intersect_grid(gingr_ctx *ctx, Cloud fit, const double *cp_soa, MovGrid &g, const int32_t *skip, int32_t *flag) {
+    g.parity ^= 1;
+    int32_t *cur = g.nflag + g.parity, *next = g.nflag + (g.parity ^ 1);
+    constexpr int kLanes = 8;
+    hipLaunchKernelGGL(self_intersect_grid_kernel<kLanes>, dim3((unsigned)ceil_div(fit.n, 256 / kLanes)), dim3(256), 0, ctx->stream, fit, cp_soa,
+                       g.params, skip, flag, g.flag, cur, next);
 }
 
 void tri_grid_free(TriGrid *g) {
@@ -1248,7 +1653,8 @@ void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const in
     hipLaunchKernelGGL(dist_stats_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, partial, out4);
 }
 void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, const int32_t *tri, int64_t T, const double *boxes,
-                           const int32_t *skip, int32_t *flag, const double *tribox, const Cloud *mesh) {
+                           const int32_t *skip, int32_t *flag, const double *tribox, const Cloud *mesh, const uint8_t *only,
+                           const int32_t *nonly) {
 #ifdef GINGR_SI_H
     const int h = GINGR_SI_H;
 #else
@@ -1257,7 +1663,7 @@ void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, cons
     const Cloud v = mesh ? *mesh : fit;
     auto go = [&](auto kern, int qpb) {
         hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(fit.n, qpb)), dim3(kCpThreads), 0, ctx->stream, fit, cp_soa, v, tri, T, boxes,
-                           skip, flag, tribox);
+                           skip, flag, tribox, only, nonly);
     };
     if (h == 8)
         go(self_intersect_queue_kernel<8>, 8);

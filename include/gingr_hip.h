@@ -75,7 +75,8 @@ const char *gingr_build_info(void);
  *                        default forms -- all pairs up to 2^26 of them, the box-pruned scan above -- are faster)
  *   GINGR_OPT_TRI_GRID   0 / 1 (default) / 2: the surface ICP's closest surface point searches a grid of the (fixed) target triangles
  *                        first, warm-started from the previous iteration, and the tile scan only answers what the grid cannot certify:
- *                        never / from 16 384 target triangles on / always
+ *                        never / from 16 384 target triangles on / always.  2 also bins the MOVING template's triangles on the device
+ *                        in front of every self-intersection test (round 5; same decisions, measured slower than the tile scan at 41k x 82k)
  *   GINGR_OPT_SPLIT_EXCHANGE  0 (default) / 1: row-sharded CPD through the library's own RCCL exchange (gingr_fitter_update_*_rccl_async):
  *                        the column-sum pass runs in two halves of the target tiles and the all-reduce of the first half is enqueued on a
  *                        second stream of the context (event-ordered, same communicator) while the second half computes, so that only
