@@ -180,6 +180,7 @@ struct gingr_fitter {
     // pointers are exchanged, no copy) -- so that a rejected proposal costs one small copy and one pass over the basis.  The states
     // a step produces on the device are unknown to the host until it reads them: the posterior memo keys them by a serial number.
     double *fit_alt = nullptr, *mh_save = nullptr;
+    double *mh_rb = nullptr;  // [head + 8 + 3M]: what one step sends back, gathered for one copy
     Key mh_key;
     bool mh_saved = false;
     uint64_t mh_serial = 0;
@@ -205,6 +206,37 @@ __global__ __launch_bounds__(256) void swap_segments_kernel(double *__restrict__
     const double va = a[i], vb = b[i];
     a[i] = vb;
     if (exchange) b[i] = va;
+}
+
+// ---- one Metropolis-Hastings step: small transfers as kernels (round 5).  A blit copy on this stack costs 4-8 us on the device
+// timeline with the barrier packets around it; the step had 4.7 of them.  (a) the proposal's draws / parameters travel in the
+// kernel's ARGUMENT (<= 160 doubles) and the same launch parks the current state; (b) the state block, the eight results and the
+// fit (original order, interleaved) are gathered into ONE buffer for ONE device-to-host copy.
+constexpr int kMhPayload = 160;
+struct MhPayload {
+    double v[kMhPayload];
+};
+// save[0..m) = src[0..m), THEN dst[0..n) = payload (dst may be src: the random-walk parameters overwrite the state block that was just parked)
+__global__ __launch_bounds__(256) void mh_begin_kernel(MhPayload payload, int n, double *dst, const double *src, int m, double *__restrict__ save) {
+    const int t = threadIdx.x;
+    double keep = 0.0;
+    if (t < m) keep = src[t];
+    __syncthreads();
+    if (t < m) save[t] = keep;
+    if (t < n) dst[t] = payload.v[t];
+}
+// out[0..nblock) = block; out[nblock + 3 perm[i] + d] = fit[d][i]
+__global__ __launch_bounds__(256) void mh_readback_kernel(const double *__restrict__ block, int nblock, const double *__restrict__ fit, int64_t M,
+                                                         const int32_t *__restrict__ perm, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nblock) out[i] = block[i];
+    if (fit && i < M) {
+        const int64_t o = perm ? perm[i] : i;
+        double *dst = out + nblock + 3 * o;
+        dst[0] = fit[i];
+        dst[1] = fit[M + i];
+        dst[2] = fit[2 * M + i];
+    }
 }
 
 // full[d][g] = this shard's fit of original point g (device position iperm[g - row_begin]) or 0 for the points of other shards
@@ -707,6 +739,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->fit);
     dev_free(f->fit_alt);
     dev_free(f->mh_save);
+    dev_free(f->mh_rb);
     dev_free(f->P1);
     dev_free(f->PX);
     dev_free(f->nn_idx);
@@ -2509,8 +2542,10 @@ int gingr_fitter_mh_step(gingr_fitter *f, const gingr_mh_request *q, double *alp
     // (1) the posterior inputs of x (memo: they exist unless x is the first state of the chain)
     for (int ph = 0; ph < 2 && rc == GINGR_OK; ++ph) rc = flavour_phase(f, flavour, q->cpd, q->icp, ph);
     GINGR_TRY(rc);
-    // (2) x stays: parameters + device state in mh_save, the fit by exchanging the two fit buffers
-    HIP_TRY(ctx, hipMemcpyAsync(f->mh_save, f->state_block, head * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    // (2) x stays: parameters + device state in mh_save (parked by the launch that also brings the proposal's draws / parameters, or
+    // by a copy where those do not fit a kernel argument), the fit by exchanging the two fit buffers
+    const bool by_kernel = (size_t)rp + kScalarsDoubles <= (size_t)kMhPayload && head <= 256;
+    if (!by_kernel) HIP_TRY(ctx, hipMemcpyAsync(f->mh_save, f->state_block, head * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     f->mh_key = f->state_key;
     std::swap(f->fit, f->fit_alt);
     // From here on the device state is in flux (fit pointers exchanged, state block and memo keys about to be rewritten): a failure
@@ -2529,18 +2564,32 @@ int gingr_fitter_mh_step(gingr_fitter *f, const gingr_mh_request *q, double *alp
     const DevState *x_state = reinterpret_cast<const DevState *>(f->mh_save + rp + kScalarsDoubles);
     // (3) the proposal
     memset(f->pin, 0, ((size_t)rp + kScalarsDoubles) * sizeof(double));
+    MhPayload payload;
+    if (by_kernel) memset(&payload, 0, sizeof(payload));
     if (q->kind == 0) {
-        memcpy(f->pin, q->z, (size_t)r * sizeof(double));
-        HIP_TRY(ctx, hipMemcpyAsync(f->zrand, f->pin, (size_t)rp * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        if (by_kernel) {
+            memcpy(payload.v, q->z, (size_t)r * sizeof(double));
+            hipLaunchKernelGGL(mh_begin_kernel, dim3(1), dim3(256), 0, ctx->stream, payload, (int)rp, f->zrand, f->state_block, (int)head, f->mh_save);
+        } else {
+            memcpy(f->pin, q->z, (size_t)r * sizeof(double));
+            HIP_TRY(ctx, hipMemcpyAsync(f->zrand, f->pin, (size_t)rp * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        }
         f->zrand_active = true;
         rc = flavour_phase(f, flavour, q->cpd, q->icp, 2);
         f->zrand_active = false;
         GINGR_TRY(rc);
         mh_tag_state(f);
     } else {
-        memcpy(f->pin, q->alpha, (size_t)r * sizeof(double));
-        memcpy(f->pin + rp, q->scalars, sizeof(*q->scalars));
-        HIP_TRY(ctx, hipMemcpyAsync(f->state_block, f->pin, ((size_t)rp + kScalarsDoubles) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        if (by_kernel) {
+            memcpy(payload.v, q->alpha, (size_t)r * sizeof(double));
+            memcpy(payload.v + rp, q->scalars, sizeof(*q->scalars));
+            hipLaunchKernelGGL(mh_begin_kernel, dim3(1), dim3(256), 0, ctx->stream, payload, (int)(rp + kScalarsDoubles), f->state_block, f->state_block,
+                               (int)head, f->mh_save);
+        } else {
+            memcpy(f->pin, q->alpha, (size_t)r * sizeof(double));
+            memcpy(f->pin + rp, q->scalars, sizeof(*q->scalars));
+            HIP_TRY(ctx, hipMemcpyAsync(f->state_block, f->pin, ((size_t)rp + kScalarsDoubles) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        }
         launch_state_init(ctx, f->st, f->hs_dev, f->absmax + 1);
         refresh_fit(f);
         GINGR_TRY(check_launch(ctx));
@@ -2583,12 +2632,14 @@ int gingr_fitter_mh_step(gingr_fitter *f, const gingr_mh_request *q, double *alp
     const int slot_bw = f->live;
     // (this state's density is asked for once: the host keeps the number, so the factor need not be left behind)
     GINGR_TRY(mh_logpdf_enqueue(f, f->st, f->fit, f->small + 2, false));
-    // (8) one transfer back: [alpha | scalars | DevState] of x', the eight results, the fit on request
-    HIP_TRY(ctx, hipMemcpyAsync(f->pin, f->state_block, (head + 8) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));  // (small follows)
-    if (fit_out) {
-        double *stage = reinterpret_cast<double *>(f->aos);
-        launch_soa_to_aos(ctx, f->fit, M, stage, m->perm);
-        HIP_TRY(ctx, hipMemcpyAsync(f->pin + head + 8, stage, (size_t)3 * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    // (8) ONE transfer back: [alpha | scalars | DevState] of x', the eight results (small follows the state block) and, on request, the fit,
+    // gathered by one launch
+    if (!f->mh_rb) GINGR_TRY(dev_alloc(ctx, &f->mh_rb, head + 8 + (size_t)3 * M));
+    {
+        const int64_t n = fit_out ? std::max<int64_t>(M, (int64_t)head + 8) : (int64_t)head + 8;
+        hipLaunchKernelGGL(mh_readback_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, f->state_block, (int)(head + 8),
+                           fit_out ? f->fit : (const double *)nullptr, M, m->perm, f->mh_rb);
+        HIP_TRY(ctx, hipMemcpyAsync(f->pin, f->mh_rb, (head + 8 + (fit_out ? (size_t)3 * M : 0)) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
     GINGR_TRY(check_launch(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
