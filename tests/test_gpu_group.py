@@ -438,3 +438,89 @@ def test_all_gather_staging_equals_the_zero_padded_all_reduce(world):
         f.close()
     for cx in ctxs:
         cx.close()
+
+
+@pytest.mark.parametrize("world,flavour", [(3, 2), (2, 1)])
+def test_phase_driven_reversed_direction_and_its_getter_on_shards(world, flavour):
+    """The reversed direction through the host-driven PHASE protocol (what a host without callbacks runs: gather phase, sum of the
+    full-fit buffer, phase 0, sum of gingr_fitter_reversal_exchange's buffer, phase 1, sum of segment 1, phase 2) on `world` logical
+    shards, summed here with torch: the fit must equal the single shard's, and gingr_fitter_get_reversed_correspondence of the shards
+    must answer for disjoint query ranges that together are the single shard's answer."""
+    import ctypes
+    import torch
+    import gingr_amd as ga
+    from gingr_amd import _native as nat
+    from gingr_amd.sharded import ShardedFitter, PHASE_GATHER
+    mo, cells, target, tcells = _femur_case()
+    model = ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam)
+    params = nat.IcpParams(20.0, 1.0, 30)
+    N = target.shape[0]
+
+    def start(f):
+        f.set_meshes(cells, tcells)
+        f.set_correspondence_direction(True)
+        f.set_state(np.zeros(mo.rank), 20.0, translation=(1.0, -2.0, 0.5), euler=(0.02, -0.03, 0.01))
+
+    def getter(f):
+        tid, w = np.empty(N, dtype=np.int32), np.empty(N)
+        assert f._lib.gingr_fitter_get_reversed_correspondence(f.handle, nat.iptr(tid), nat.dptr(w)) == 0
+        return tid, w
+    # the single shard
+    c1 = ga.Context(0)
+    one = ShardedFitter(c1, model, target)
+    start(one)
+    lib = one._lib
+    phase = lib.gingr_fitter_icp_surface_phase_async if flavour == 2 else lib.gingr_fitter_icp_phase_async
+    for ph in range(3):
+        assert phase(one.handle, ctypes.byref(params), ph) == 0
+    c1.synchronize()
+    tid1, w1 = getter(one)
+    fit1 = one.get_state()[2]
+    # the shards, every phase on all of them before the sums
+    ctxs = [ga.Context(0) for _ in range(world)]
+    fs = [ShardedFitter(ctxs[r], model, target, rank=r, world=world, all_reduce=lambda t: None, defer_setup=True) for r in range(world)]
+    mom = None
+    for f in fs:
+        g = f.gram_tensor()
+        f.ctx.synchronize()
+        mom = g.clone() if mom is None else mom + g
+    for f in fs:
+        f.gram_tensor().copy_(mom)
+        torch.cuda.synchronize()
+        f.finish_setup()
+        start(f)
+
+    def total(views):
+        for f in fs:
+            f.ctx.synchronize()
+        tot = sum(v.clone() for v in views)
+        for v in views:
+            v.copy_(tot)
+        torch.cuda.synchronize()
+    for f in fs:
+        assert phase(f.handle, ctypes.byref(params), PHASE_GATHER) == 0
+    total([f._fullfit for f in fs])
+    for f in fs:
+        assert phase(f.handle, ctypes.byref(params), 0) == 0
+    total([f._revsum for f in fs])
+    for f in fs:
+        assert phase(f.handle, ctypes.byref(params), 1) == 0
+    total([f.xch[f.offsets[1]: f.offsets[1] + f.counts[1]] for f in fs])
+    for f in fs:
+        assert phase(f.handle, ctypes.byref(params), 2) == 0
+        f.ctx.synchronize()
+    fit = np.concatenate([f.get_state()[2] for f in fs])
+    assert rel(fit, fit1) < 1e-9
+    answered = np.zeros(N, dtype=int)
+    for f in fs:
+        tid, w = getter(f)
+        mine = tid >= 0
+        answered += mine
+        assert np.array_equal(tid[mine], tid1[mine]) and np.array_equal(w[mine], w1[mine])
+        assert not np.any(w[~mine])
+    assert np.all(answered[tid1 >= 0] == 1) and answered.max() <= 1      # every query answered by exactly one shard
+    for f in fs:
+        f.close()
+    one.close()
+    for c in ctxs + [c1]:
+        c.close()
