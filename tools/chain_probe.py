@@ -1,6 +1,10 @@
+"""How often does a Metropolis-Hastings step of the femur chain accept WITHOUT consuming the accept test's uniform draw (a > 0 in
+`a > 0 || rnd.nextDouble() < exp(a)`), and where does the host time of a step go?  (why a batch of k steps per native
+call cannot be exact.)   python tools/chain_probe.py      -> COUNTS {steps, a_pos, acc} + a cProfile of the chain"""
 import cProfile, pstats, io, sys, os, math, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.argv = ["x", "600", "0"]
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, ROOT)
 from gingr_amd import sampling as sp
 cnt = {"steps": 0, "a_pos": 0, "acc": 0}
 orig_next = sp.MetropolisHastings.next
@@ -24,7 +28,7 @@ def next2(self, current, logger=None):
 sp.MetropolisHastings.next = next2
 pr = cProfile.Profile()
 pr.enable()
-exec(open("/root/repo/tools/bench_mh_chain.py").read())
+exec(compile(open(os.path.join(ROOT, "tools", "bench_mh_chain.py")).read(), os.path.join(ROOT, "tools", "bench_mh_chain.py"), "exec"), {"__file__": os.path.join(ROOT, "tools", "bench_mh_chain.py"), "__name__": "__main__"})
 pr.disable()
 print("COUNTS", cnt)
 s = io.StringIO()
