@@ -90,6 +90,10 @@ struct gingr_fitter {
     double *gsorted = nullptr;
     int32_t *rnn_pos = nullptr;  // last search's matches as POSITIONS in gsorted: the warm start of the next one (queries and order are fixed)
     bool rnn_warm = false;
+    // ... and the closest-point scan of that direction (target vertices against the MOVING template's triangles) starts every query
+    // from the triangle that was closest to it last time (round 5; the forward direction has done so since round 2): positions in mtri
+    int32_t *rtri_pos = nullptr;
+    bool rtri_warm = false;
     int32_t *mtri_orig = nullptr, *mboundary = nullptr;
     double *rcp = nullptr, *rd2 = nullptr, *rnnd2 = nullptr, *rw01 = nullptr, *robs = nullptr, *rwin = nullptr;
     int32_t *rnn = nullptr, *rpre = nullptr, *rhit = nullptr, *rkeys = nullptr, *rvals = nullptr, *rskeys = nullptr, *rsvals = nullptr;
@@ -396,12 +400,12 @@ void refresh_fit(gingr_fitter *f) {
 void free_meshes(gingr_fitter *f) {
     void *rptrs[] = {f->mtri_orig, f->mboundary, f->rcp, f->rd2, f->rnnd2, f->rw01, f->robs, f->rwin, f->rnn, f->rpre, f->rhit,
                      f->rkeys, f->rvals, f->rskeys, f->rsvals, f->rsort, f->radj_ptr, f->radj_tri, f->rmbnd, f->rmvn, f->rfboxes,
-                     f->rtvn_loc, f->revsum, f->rws, f->gperm, f->gsorted, f->rnn_pos};
+                     f->rtvn_loc, f->revsum, f->rws, f->gperm, f->gsorted, f->rnn_pos, f->rtri_pos};
     for (void *p : rptrs) dev_free(p);
     f->radj_ptr = f->radj_tri = f->rmbnd = nullptr;
     f->rmvn = f->rfboxes = f->rtvn_loc = f->revsum = f->gsorted = nullptr;
-    f->gperm = f->rnn_pos = nullptr;
-    f->rnn_warm = false;
+    f->gperm = f->rnn_pos = f->rtri_pos = nullptr;
+    f->rnn_warm = f->rtri_warm = false;
     f->rq0 = f->rqn = 0;
     f->rws = nullptr;
     f->mtri_orig = f->mboundary = f->rnn = f->rpre = f->rhit = f->rkeys = f->rvals = f->rskeys = f->rsvals = nullptr;
@@ -1280,8 +1284,11 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                         if (along)
                             launch_line_nearest(ctx, tq, f->rtvn_loc, meshc, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, f->rcp, f->rhit);
                         else
-                            launch_surface_closest_point(ctx, tq, meshc, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, f->rcp, f->rd2, nullptr, nullptr,
-                                                         false, f->mtribox);
+                        {
+                            launch_surface_closest_point(ctx, tq, meshc, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, f->rcp, f->rd2, nullptr, f->rtri_pos,
+                                                         f->rtri_warm, f->mtribox);
+                            f->rtri_warm = true;
+                        }
                         nearest_template_vertex(cloud_of(f->rcp, nq));
                         launch_surface_prereject(ctx, nq, f->rnn, f->rmbnd, f->rtvn_loc, f->rmvn, Mt, along ? f->rhit : nullptr, f->rpre);
                         launch_self_intersect(ctx, tq, f->rcp, f->ttri, f->Tt, f->ttboxes, f->rpre, f->rhit, f->ttribox, &tgt);
@@ -1306,8 +1313,11 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                     if (along)
                         launch_line_nearest(ctx, tgt, f->tvn, fit, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, f->rcp, f->rhit);
                     else
-                        launch_surface_closest_point(ctx, tgt, fit, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, f->rcp, f->rd2, nullptr, nullptr,
-                                                     false, f->mtribox);
+                    {
+                        launch_surface_closest_point(ctx, tgt, fit, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, f->rcp, f->rd2, nullptr, f->rtri_pos,
+                                                     f->rtri_warm, f->mtribox);
+                        f->rtri_warm = true;
+                    }
                     launch_nn(ctx, cloud_of(f->rcp, N), fit, f->m->perm, f->fboxes, f->ws, f->rnn, f->rnnd2);
                     launch_surface_prereject(ctx, N, f->rnn, f->mboundary, f->tvn, f->mvn, M, along ? f->rhit : nullptr, f->rpre);
                     launch_self_intersect(ctx, tgt, f->rcp, f->ttri, f->Tt, f->ttboxes, f->rpre, f->rhit, f->ttribox);
@@ -1980,8 +1990,9 @@ int gingr_fitter_set_correspondence_direction(gingr_fitter *f, int32_t reversed)
             (rc = dev_alloc(ctx, &f->rnn, (size_t)N)) || (rc = dev_alloc(ctx, &f->rpre, (size_t)N)) ||
             (rc = dev_alloc(ctx, &f->rhit, (size_t)N)) || (rc = dev_alloc(ctx, &f->rkeys, (size_t)N)) ||
             (rc = dev_alloc(ctx, &f->rvals, (size_t)N)) || (rc = dev_alloc(ctx, &f->rskeys, (size_t)N)) ||
-            (rc = dev_alloc(ctx, &f->rsvals, (size_t)N)))
+            (rc = dev_alloc(ctx, &f->rsvals, (size_t)N)) || (rc = dev_alloc(ctx, &f->rtri_pos, (size_t)N)))
             return rc;
+        f->rtri_warm = false;
         f->rsort_bytes = reversal_sort_temp_bytes(N);
         HIP_TRY(ctx, hipMalloc(&f->rsort, f->rsort_bytes ? f->rsort_bytes : 8));
     }
