@@ -1318,13 +1318,15 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                                                      f->rtri_warm, f->mtribox);
                         f->rtri_warm = true;
                     }
-                    launch_nn(ctx, cloud_of(f->rcp, N), fit, f->m->perm, f->fboxes, f->ws, f->rnn, f->rnnd2);
+                    launch_nn(ctx, cloud_of(f->rcp, N), fit, f->m->perm, f->fboxes, f->ws, f->rnn, f->rnnd2, f->rnn_warm ? f->rnn : nullptr);
+                    f->rnn_warm = true;  // (rnn: positions in the fit's device order -- last iteration's matches start this one's scan)
                     launch_surface_prereject(ctx, N, f->rnn, f->mboundary, f->tvn, f->mvn, M, along ? f->rhit : nullptr, f->rpre);
                     launch_self_intersect(ctx, tgt, f->rcp, f->ttri, f->Tt, f->ttboxes, f->rpre, f->rhit, f->ttribox);
                     launch_reversal_observations(ctx, M, tgt, f->rnn, f->rpre, f->rhit, &f->st->sigma2, f->rkeys, f->rvals, f->rskeys,
                                                  f->rsvals, f->rsort, f->rsort_bytes, f->rw01, f->robs, f->rwin);
                 } else {  // ClosestPointTriangleMesh3DSimple: nearest template vertex, weight 1
-                    launch_nn(ctx, tgt, fit, f->m->perm, f->fboxes, f->ws, f->rnn, f->rnnd2);
+                    launch_nn(ctx, tgt, fit, f->m->perm, f->fboxes, f->ws, f->rnn, f->rnnd2, f->rnn_warm ? f->rnn : nullptr);
+                    f->rnn_warm = true;
                     launch_reversal_observations(ctx, M, tgt, f->rnn, nullptr, nullptr, &f->st->sigma2, f->rkeys, f->rvals, f->rskeys,
                                                  f->rsvals, f->rsort, f->rsort_bytes, f->rw01, f->robs, f->rwin);
                 }
