@@ -1374,6 +1374,13 @@ __global__ __launch_bounds__(256) void self_intersect_grid_kernel(Cloud fit, con
 
 }  // namespace
 
+// bits of the largest sort key of the reversed direction (template vertex ids 0 .. M - 1 and the sentinel M)
+static int key_bits(int64_t M) {
+    int b = 1;
+    while (b < 31 && ((int64_t)1 << b) <= M) ++b;
+    return b;
+}
+
 size_t reversal_sort_temp_bytes(int64_t N) {
     size_t bytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const int32_t *)nullptr, (int32_t *)nullptr, (const int32_t *)nullptr,
@@ -1388,8 +1395,8 @@ void launch_reversal_observations(gingr_ctx *ctx, int64_t M, Cloud tgt, const in
     const int64_t N = tgt.n;
     hipLaunchKernelGGL(reversal_keys_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, N, nn_vertex, pre, hit,
                        (int32_t)M, keys, vals, w01_targets);
-    // LSD radix sort: stable, so equal keys keep ascending target positions
-    (void)hipcub::DeviceRadixSort::SortPairs(sort_temp, sort_temp_bytes, keys, skeys, vals, svals, (int)N, 0, 32, ctx->stream);
+    // LSD radix sort: stable, so equal keys keep ascending target positions; only the bits a key can have (keys <= M, the sentinel)
+    (void)hipcub::DeviceRadixSort::SortPairs(sort_temp, sort_temp_bytes, keys, skeys, vals, svals, (int)N, 0, key_bits(M), ctx->stream);
     hipLaunchKernelGGL(reversal_gather_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, ctx->stream, M, N, skeys, svals, tgt,
                        sigma2_dev, obs_soa, weight_in);
 }
@@ -1401,7 +1408,7 @@ void launch_reversal_sums(gingr_ctx *ctx, int64_t M, Cloud tgt, const int32_t *n
     if (N > 0) {
         hipLaunchKernelGGL(reversal_keys_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, N, nn_vertex, pre, hit,
                            (int32_t)M, keys, vals, w01_targets);
-        (void)hipcub::DeviceRadixSort::SortPairs(sort_temp, sort_temp_bytes, keys, skeys, vals, svals, (int)N, 0, 32, ctx->stream);
+        (void)hipcub::DeviceRadixSort::SortPairs(sort_temp, sort_temp_bytes, keys, skeys, vals, svals, (int)N, 0, key_bits(M), ctx->stream);
     }
     hipLaunchKernelGGL(reversal_sums_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, ctx->stream, M, N, skeys, svals, tgt, sums4);
 }
