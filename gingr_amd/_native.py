@@ -109,6 +109,8 @@ SIGNATURES = {
     "gingr_fitter_set_correspondence_direction": (c_int, [c_void_p, c_int32]),
     "gingr_fitter_get_reversed_correspondence": (c_int, [c_void_p, POINTER(c_int32), _dp]),
     "gingr_fitter_update_icp_surface_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32]),
+    "gingr_fitter_set_stop_threshold": (c_int, [c_void_p, c_double]),
+    "gingr_fitter_stop_rule_hit": (c_int, [c_void_p, POINTER(c_int32)]),
     "gingr_fitter_icp_surface_phase_async": (c_int, [c_void_p, POINTER(IcpParams), c_int32]),
     "gingr_fitter_get_surface_correspondence": (c_int, [c_void_p, _dp, _dp]),
     "gingr_fitter_surface_distance_stats": (c_int, [c_void_p, c_int32, c_int64, _dp, c_int32, c_double, _dp]),

@@ -1050,27 +1050,43 @@ class GingrAlgorithm:
 
 def _run_resident_impl(self, state):
     """The deterministic loop of `run` with the state resident on the device: nobody watches the intermediate states (no
-    call-back) and the convergence rule is one of the reference's own (|sigma2 - last sigma2| < threshold for CPD, never for ICP),
-    so an iteration only reads back the scalars; shape coefficients and fit come back once, at the end.  Same states, same stopping
-    iteration as the generic loop below."""
+    call-back) and the convergence rule is one of the reference's own (|sigma2 - last sigma2| < threshold for CPD, never for ICP).
+    Updates are enqueued in blocks and only the state a block ends in is looked at; coefficients and fit come back once, at the end.
+    That is sound because the chain cannot run past its last state on the device: a failed fit stays as it is (post_solve_kernel commits
+    nothing once the status is ModelFlexibilityError; GingrAlgorithm.scala:149-157 stops at that very state), and so does a state the
+    CPD rule stopped at (gingr_fitter_set_stop_threshold: the comparison the dropWhile makes, made by the kernel that commits sigma2).
+    ICP has no rule: the whole run is one block.  CPD: updates enqueued behind the stopping state are wasted work, so the block is
+    one update where an update is long and a few where the synchronisation would be a fifth of it.
+    Same states, same stopping iteration, same status as the generic loop."""
     g = state.general
     self._bind(g, state.config.useLandmarkCorrespondence)
     if self._device_state is not state:
         self._push_state(g)
     cpd_rule = state.config.converged is _cpd_converged
-    last_sigma2, k, converged = g.sigma2, 1, False
-    sc = nat.StateScalars()
-    while k < state.config.maxIterations:
-        self._native_update(state, 1)
-        _check(self.ctx.handle, self._lib.gingr_fitter_get_state(self._fitter, None, ctypes.byref(sc), None), "gingr_fitter_get_state")
-        k += 1
-        if cpd_rule:
-            converged = abs(last_sigma2 - sc.sigma2) < state.config.threshold
-        last_sigma2 = sc.sigma2
-        if converged or sc.status == FittingStatuses.ModelFlexibilityError:
-            break
+    left = state.config.maxIterations - 1
+    if cpd_rule:
+        pairs = float(g.model.numberOfPoints) * float(np.asarray(g.target).shape[0])
+        block = 4 if pairs <= 4e6 else (2 if pairs <= 3e7 else 1)
+    else:
+        block = left
+    hit, sc = ctypes.c_int32(0), nat.StateScalars()
+    _check(self.ctx.handle, self._lib.gingr_fitter_set_stop_threshold(self._fitter, float(state.config.threshold) if cpd_rule else -1.0),
+           "gingr_fitter_set_stop_threshold")
+    try:
+        while left > 0:
+            n = min(block, left)
+            self._native_update(state, n)
+            left -= n
+            _check(self.ctx.handle, self._lib.gingr_fitter_get_state(self._fitter, None, ctypes.byref(sc), None), "gingr_fitter_get_state")
+            _check(self.ctx.handle, self._lib.gingr_fitter_stop_rule_hit(self._fitter, ctypes.byref(hit)), "gingr_fitter_stop_rule_hit")
+            if hit.value or sc.status == FittingStatuses.ModelFlexibilityError:
+                break
+    finally:
+        # (also clears the mark: the state on the device takes updates again)
+        self._lib.gingr_fitter_set_stop_threshold(self._fitter, -1.0)
     out = state.updateGeneral(self._pull_state(g))
     self._device_state = out
+    converged = bool(hit.value)
     if out.general.status == FittingStatuses.None_:
         out = out.updateGeneral(out.general.updateStatus(FittingStatuses.Converged if converged else FittingStatuses.MaxIteration))
     return out

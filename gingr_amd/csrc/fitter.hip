@@ -61,6 +61,8 @@ struct gingr_fitter {
     int32_t *lm_mask = nullptr;
     int32_t global_transform = GINGR_RIGID_TRANSFORMS;
     double step_length = 1.0;
+    double stop_threshold = -1.0;  // gingr_fitter_set_stop_threshold: the run's stopping rule, applied by post_solve_kernel (< 0: none)
+    int32_t stop_hit = 0;          // DevState::stopped as of the last gingr_fitter_get_state
     bool has_state = false;
     // ---- ICP surface correspondence (surface.hip): triangles in device vertex positions and a spatial triangle order
     bool icp_surface = false;                      // correspondence flavour of the ICP phases
@@ -910,6 +912,24 @@ int gingr_fitter_set_options(gingr_fitter *f, int32_t global_transform, double s
     return GINGR_OK;
 }
 
+int gingr_fitter_set_stop_threshold(gingr_fitter *f, double threshold) {
+    if (!f) return GINGR_ERR_BAD_ARGUMENT;
+    gingr_ctx *ctx = f->ctx;
+    if (threshold != threshold) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "set_stop_threshold: NaN");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    f->stop_threshold = threshold < 0.0 ? -1.0 : threshold;
+    f->stop_hit = 0;
+    // a state the rule stopped at earlier takes updates again
+    if (f->has_state) HIP_TRY(ctx, hipMemsetAsync(&f->st->stopped, 0, sizeof(int32_t), ctx->stream));
+    return GINGR_OK;
+}
+
+int gingr_fitter_stop_rule_hit(gingr_fitter *f, int32_t *hit) {
+    if (!f || !hit) return GINGR_ERR_BAD_ARGUMENT;
+    *hit = f->stop_hit;
+    return GINGR_OK;
+}
+
 int gingr_fitter_set_state(gingr_fitter *f, const double *alpha, const gingr_state_scalars *s) {
     if (!f || !alpha || !s) return GINGR_ERR_BAD_ARGUMENT;
     gingr_ctx *ctx = f->ctx;
@@ -994,6 +1014,7 @@ int gingr_fitter_get_state(gingr_fitter *f, double *alpha, gingr_state_scalars *
         s->iteration = hst.iteration;
         s->status = hst.status;
     }
+    f->stop_hit = hst.stopped;
     if (alpha) {  // what was just read IS the device state: the posterior memo can recognise it without a gingr_fitter_set_state
         f->state_key.v.assign(alpha, alpha + f->m->r);
         for (int q = 0; q < 3; ++q) f->state_key.v.push_back(hst.euler[q]);
@@ -1506,6 +1527,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
             a.retry = f->retry;
             a.zero_slot = f->absmax + 1;
             a.probabilistic = f->zrand_active ? 1 : 0;
+            a.stop_threshold = f->stop_threshold;
             launch_post_solve(ctx, a);
             refresh_fit(f);
             break;
@@ -1606,10 +1628,8 @@ int fitter_sharded_update(gingr_fitter *f, int flavour, const gingr_cpd_params *
     // GINGR_OPT_SPLIT_EXCHANGE: pass 1 in two halves of the target tiles; the all-reduce of the first half runs on the context's second
     // stream (ordered by events, same communicator) while the second half computes, so only the second half's all-reduce is exposed
     bool split = split_native && flavour == 0 && f->sharded() && f->N >= 8192;
-    if (split) {
-        const int64_t NA = split_cut(f->N);
-        if ((int64_t)2 * cpd_colsum_chunks(f->m->M, f->N) * f->N > f->ws_doubles) split = false;  // (the halves take twice the chunks of the whole pass)
-    }
+    // (the halves take twice the chunks of the whole pass)
+    if (split && (int64_t)2 * cpd_colsum_chunks(f->m->M, f->N) * f->N > f->ws_doubles) split = false;
     if (split && !ctx->side_stream) {
         if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->split_ev[0], hipEventDisableTiming) != hipSuccess ||

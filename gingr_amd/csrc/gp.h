@@ -21,7 +21,9 @@ struct DevState {
     int32_t iteration;
     int32_t status;  // gingr_fitting_status
     int32_t err;     // sticky numerical-failure flag of the CURRENT update (0 ok, GINGR_ERR_NONFINITE, GINGR_ERR_NOT_SPD)
-    int32_t pad;
+    int32_t pad;     // error code of the last update (0: none), for the host
+    int32_t stopped; // the run's stopping rule fired on this state (PostSolveArgs::stop_threshold): later updates leave it as it is
+    int32_t pad2;
 };
 
 // Candidate global alignment produced by the Umeyama step (R2 went through the Euler parameterisation).
@@ -278,6 +280,7 @@ struct PostSolveArgs {
     double *zero_slot;      // nullable: cleared by thread 0 (SweepArgs::absmax_slot of the fit pass that follows)
     int32_t *retry;         // retryCounter of the algorithm instance (GingrAlgorithm.scala:69-70), device word; nullable
     int32_t probabilistic;  // update(current, probabilistic = true)
+    double stop_threshold;  // >= 0: mark the state as stopped when this update moved sigma2 by less (CPD.scala:108-110); < 0: no rule
 };
 #define GINGR_RETRY_INIT 10 /* retryCounterInitialize, GingrAlgorithm.scala:69 */
 void launch_post_solve(gingr_ctx *ctx, const PostSolveArgs &a);

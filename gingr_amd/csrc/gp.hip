@@ -2125,7 +2125,8 @@ __global__ __launch_bounds__(512) void post_solve_kernel(PostSolveArgs A) {
     const int r = A.r, rp = A.rp, tid = threadIdx.x;
     DevState *st = A.state;
     if (tid == 0 && A.zero_slot) *A.zero_slot = 0.0;  // see SweepArgs::absmax_slot: the fit pass behind this kernel takes a maximum into it
-    if (st->status == GINGR_FIT_MODEL_FLEXIBILITY_ERROR) return;  // a failed fit stays as it is (run stops, :149-157)
+    if (st->status == GINGR_FIT_MODEL_FLEXIBILITY_ERROR || st->stopped) return;  // a failed fit stays as it is (run stops, :149-157);
+                                                                                 // so does one the run's own rule stopped at
     const PostVec pvl{rp};
     // ---- column tid of every input vector: all loads in flight at once
     double za[9], bz[9], V[9], W[3], BV[9], BW[3], al = 0.0, ac = 0.0;
@@ -2197,7 +2198,8 @@ __global__ __launch_bounds__(512) void post_solve_kernel(PostSolveArgs A) {
     __syncthreads();
     const bool posterior_failed = st->err != 0;
     const bool failed = posterior_failed || bad != 0;
-    __syncthreads();  // (every thread has read st->err before thread 0 clears it)
+    const double sigma2_before = st->sigma2;
+    __syncthreads();  // (every thread has read st->err and sigma2 before they are rewritten)
     if (!failed) {
         if (tid < rp) A.alpha[tid] = anew;
         if (tid < 20) reinterpret_cast<double *>(st)[tid] = L.stage[tid];  // R, euler, center, t, scale, sigma2
@@ -2217,6 +2219,8 @@ __global__ __launch_bounds__(512) void post_solve_kernel(PostSolveArgs A) {
         st->pad = failed ? (st->err != 0 ? st->err : GINGR_ERR_NONFINITE) : 0;  // last error, readable by the host
         st->err = 0;
         st->iteration += 1;  // GingrGeneratorWrapper.propose: updateIteration()
+        // the dropWhile of GingrAlgorithm.run (:142-153) looks at (last state, this state): converged -- or failed -- and the chain ends HERE
+        if (A.stop_threshold >= 0.0 && fabs(sigma2_before - (failed ? sigma2_before : L.stage[19])) < A.stop_threshold) st->stopped = 1;
     }
 }
 
@@ -2235,6 +2239,8 @@ __global__ void state_init_kernel(DevState *st, const gingr_state_scalars *h, do
     st->status = h->status;
     st->err = 0;
     st->pad = 0;
+    st->stopped = 0;
+    st->pad2 = 0;
 }
 
 }  // namespace

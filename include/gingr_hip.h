@@ -252,6 +252,14 @@ int gingr_fitter_set_target(gingr_fitter *f, int64_t N, const double *target_xyz
 int gingr_fitter_set_landmarks(gingr_fitter *f, int32_t n_lm, const int32_t *lm_pid, const double *lm_xyz,
                                const double *lm_cov);
 int gingr_fitter_set_options(gingr_fitter *f, int32_t global_transform, double step_length);
+/* The stopping rule of a run, applied on the device (GingrAlgorithm.run's dropWhile, G/api/GingrAlgorithm.scala:142-153, with the
+ * CPD rule |sigma2 - last sigma2| < threshold, G/api/registration/config/CPD.scala:108-110): with threshold >= 0 an update that
+ * moves sigma2 by less than threshold marks the device state as stopped, and every later update enqueued on it leaves it as it is
+ * -- exactly like a failed fit -- so a host can enqueue all updates of a run in ONE call and read the state it stopped at.
+ * threshold < 0 (the default): no rule.  The call also clears the mark; so does gingr_fitter_set_state.
+ * gingr_fitter_stop_rule_hit: the mark as of the last gingr_fitter_get_state (no transfer of its own). */
+int gingr_fitter_set_stop_threshold(gingr_fitter *f, double threshold);
+int gingr_fitter_stop_rule_hit(gingr_fitter *f, int32_t *hit);
 /* state in: alpha[r] + scalars; the fit is recomputed on the device (modelInstanceShapePoseScale). */
 int gingr_fitter_set_state(gingr_fitter *f, const double *alpha, const gingr_state_scalars *s);
 /* state out (synchronises): alpha[r], scalars, fit_xyz[3*M_local]; any pointer may be NULL. */

@@ -119,6 +119,14 @@ JFN(jint, fitterSetLandmarks)(JNIEnv *env, jclass, jlong f, jintArray pid, jdoub
 JFN(jint, fitterSetOptions)(JNIEnv *, jclass, jlong f, jint gt, jdouble step) {
     return gingr_fitter_set_options(P<gingr_fitter>(f), gt, step);
 }
+JFN(jint, fitterSetStopThreshold)(JNIEnv *, jclass, jlong f, jdouble threshold) {
+    return gingr_fitter_set_stop_threshold(P<gingr_fitter>(f), threshold);
+}
+JFN(jint, fitterStopRuleHit)(JNIEnv *, jclass, jlong f) {  // >= 0: the mark; < 0: -(error code)
+    int32_t hit = 0;
+    const int rc = gingr_fitter_stop_rule_hit(P<gingr_fitter>(f), &hit);
+    return rc == GINGR_OK ? hit : -rc;
+}
 JFN(jint, fitterSetState)(JNIEnv *env, jclass, jlong f, jdoubleArray alpha, jdoubleArray pose, jint iteration, jint status) {
     Arr<double> a(env, alpha, true); Arr<double> b(env, pose, true);
     const double *p = b.ptr();

@@ -37,6 +37,11 @@ public final class GingrHipNative {
     public static native int fitterSetTarget(long fitter, double[] targetXyz);
     public static native int fitterSetLandmarks(long fitter, int[] pid, double[] xyz, double[] cov9);
     public static native int fitterSetOptions(long fitter, int globalTransform, double stepLength);
+    /** The run's stopping rule on the device (GingrAlgorithm.run's dropWhile with CPD's |sigma2 - last| < threshold): an update that moves
+     *  sigma2 by less marks the state, later updates leave it as it is, so a whole run can be ONE fitterUpdateCpd call.  threshold < 0: off;
+     *  the call also clears the mark.  fitterStopRuleHit: the mark as of the last fitterGetState (negative: an error code). */
+    public static native int fitterSetStopThreshold(long fitter, double threshold);
+    public static native int fitterStopRuleHit(long fitter);
     /** poseScalars = { phi, theta, psi, cx, cy, cz, tx, ty, tz, scale, sigma2 } */
     public static native int fitterSetState(long fitter, double[] alpha, double[] poseScalars11, int iteration, int status);
     public static native int fitterUpdateCpd(long fitter, double w, double lambda, int nIterations);

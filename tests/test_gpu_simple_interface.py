@@ -250,3 +250,64 @@ def test_resident_run_loop_equals_the_generic_loop(ctx, femur):
         assert fast.general.modelParameters.rotation == slow.general.modelParameters.rotation
     # the CPD run above stopped on its threshold, well before maxIterations
     assert len(seen) == 2
+
+
+def test_stop_threshold_freezes_the_state_the_rule_fired_on(ctx, femur):
+    """gingr_fitter_set_stop_threshold: with a threshold the kernel that commits sigma2 marks the state whose update moved sigma2 by less,
+    and every update enqueued behind it is a no-op; clearing the rule lets the state move again (CPD.scala:108-110 as the run's
+    dropWhile applies it, GingrAlgorithm.scala:142-153)."""
+    import ctypes
+    import gingr_amd as ga
+    from gingr_amd import _native as nat
+    from gingr_amd.sharded import ShardedFitter
+    model, target, _, _ = femur
+    f = ShardedFitter(ctx, model, np.asarray(target.points))
+    s2 = ctx.cpd_initial_sigma2(np.asarray(model.reference), np.asarray(target.points))
+    lib, hit = f._lib, ctypes.c_int32(-1)
+    # the trajectory one update at a time
+    f.set_state(np.zeros(model.rank), s2)
+    sig = [s2]
+    for _ in range(12):
+        f.update_cpd(0.05, 1.0, 1)
+        sig.append(f.get_state()[1].sigma2)
+    d = np.abs(np.diff(sig))
+    k = 6
+    thr = float(0.5 * (d[k - 1] + d[k])) if d[k] < d[k - 1] else float(d[k - 1] * 1.0000001)
+    first = int(np.argmax(d < thr)) + 1          # the first update that moves sigma2 by less than thr
+    assert 1 <= first < 12
+    # all twelve in one call under the rule: the chain ends at `first`
+    f.set_state(np.zeros(model.rank), s2)
+    assert lib.gingr_fitter_set_stop_threshold(f.handle, thr) == 0
+    f.update_cpd(0.05, 1.0, 12)
+    a, sc, fit = f.get_state()
+    assert lib.gingr_fitter_stop_rule_hit(f.handle, ctypes.byref(hit)) == 0 and hit.value == 1
+    assert sc.iteration == first and sc.sigma2 == sig[first] and sc.status == 0
+    f.update_cpd(0.05, 1.0, 2)                   # still stopped
+    assert f.get_state()[1].iteration == first
+    assert lib.gingr_fitter_set_stop_threshold(f.handle, -1.0) == 0     # rule off, mark cleared
+    f.update_cpd(0.05, 1.0, 1)
+    a2, sc2, _ = f.get_state()
+    assert sc2.iteration == first + 1 and sc2.sigma2 == sig[first + 1]
+    assert lib.gingr_fitter_stop_rule_hit(f.handle, ctypes.byref(hit)) == 0 and hit.value == 0
+    f.close()
+
+
+def test_resident_icp_run_stops_at_the_failed_state(ctx, femur):
+    """The resident ICP loop enqueues every remaining update in one native call; a failure on the way must leave exactly the state the
+    per-iteration loop stops at (GingrAlgorithm.scala:149-157): a failed fit is never touched again on the device."""
+    import gingr_amd as ga
+    model, target, _, _ = femur
+    algo = ga.IcpRegistration(ctx)
+    # an infinite step length makes the blended coefficients non-finite: the projection fails, which is a ModelFlexibilityError at
+    # any iteration (GingrAlgorithm.scala:248-251) -- the first of the eleven enqueued updates fails, ten more follow it on the device
+    cfg = ga.IcpConfiguration(maxIterations=12, initialSigma=5.0, endSigma=1.0, correspondenceMethod="PointcloudClosestPoint")
+    init = algo.createInitialState(model, target.points, cfg, stepLength=float("inf"))
+    fast = algo.run(init)
+    seen = []
+    slow = algo.run(init, callBackLogger=lambda s: seen.append((s.general.iteration, s.general.status)))
+    assert slow.general.status == ga.FittingStatuses.ModelFlexibilityError and 1 < len(seen) < cfg.maxIterations, seen
+    assert fast.general.status == slow.general.status and fast.general.iteration == slow.general.iteration
+    assert fast.general.sigma2 == slow.general.sigma2
+    assert np.array_equal(fast.general.modelParameters.shape, slow.general.modelParameters.shape)
+    assert np.array_equal(fast.general.fit, slow.general.fit, equal_nan=True)
+    algo.close()

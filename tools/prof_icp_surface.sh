@@ -9,7 +9,7 @@ cd $R
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/prof_icp_surface/**/*kernel_stats.csv", recursive=True)[0]
-for r in list(csv.DictReader(open(f)))[:16]:
+for r in list(csv.DictReader(open(f)))[:30]:
     print(f'{r["Name"][:72]:72s} calls {r["Calls"]:>5s} avg_us {float(r["AverageNs"])/1e3:9.1f} {r["Percentage"]}%')
 PY
 tail -1 $OUT/log.txt | cut -c1-300
