@@ -293,11 +293,22 @@ void launch_chol_block64(gingr_ctx *ctx, double *Aw, int64_t ld, int k, double *
 int distance_stats_ws_doubles();
 void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const int32_t *orig, int64_t orig_limit, const int32_t *nn,
                            const int32_t *boundary, double sdev, double *partial, double *out4);
+// What the self-intersection launch can take over from the launches around it (both are one value per query, computed where the query
+// is held anyway):  nn_vertex != nullptr -- the first two rejection tests of launch_surface_prereject are made in the prologue (pre_out
+// is written, `skip` is not read);  w01 != nullptr -- launch_surface_weight's outputs are written in the epilogue.
+struct SelfIntersectFuse {
+    const int32_t *nn_vertex = nullptr, *boundary = nullptr, *found = nullptr;
+    const double *q_vn = nullptr, *t_vn = nullptr;  // vertex normals of the queries' mesh [3][n] and of the other mesh [3][Nt]
+    int64_t Nt = 0;
+    int32_t *pre_out = nullptr;
+    const double *sigma2 = nullptr;
+    double *w01 = nullptr, *weight_in = nullptr;
+};
 // mesh (nullable): the cloud the triangles index when it is not the query cloud itself (row shard: the gathered fit of all shards)
 // only / nonly (nullable, device): only queries with only[i] != 0 are processed and written, and the launch is a no-op when *nonly == 0
 void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, const int32_t *tri, int64_t T, const double *boxes,
                            const int32_t *skip, int32_t *flag, const double *tribox = nullptr, const Cloud *mesh = nullptr,
-                           const uint8_t *only = nullptr, const int32_t *nonly = nullptr);
+                           const uint8_t *only = nullptr, const int32_t *nonly = nullptr, const SelfIntersectFuse *fuse = nullptr);
 // found (nullable): along-normal flavour, 0 = no intersection (rejected)
 void launch_surface_prereject(gingr_ctx *ctx, int64_t M, const int32_t *nn_vertex, const int32_t *tgt_boundary,
                               const double *fit_vn, const double *tgt_vn, int64_t N, const int32_t *found, int32_t *pre);

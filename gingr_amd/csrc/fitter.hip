@@ -1311,8 +1311,10 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                             f->rtri_warm = true;
                         }
                         nearest_template_vertex(cloud_of(f->rcp, nq));
-                        launch_surface_prereject(ctx, nq, f->rnn, f->rmbnd, f->rtvn_loc, f->rmvn, Mt, along ? f->rhit : nullptr, f->rpre);
-                        launch_self_intersect(ctx, tq, f->rcp, f->ttri, f->Tt, f->ttboxes, f->rpre, f->rhit, f->ttribox, &tgt);
+                        SelfIntersectFuse fu;  // (the first two rejection tests ride in the self-intersection launch)
+                        fu.nn_vertex = f->rnn, fu.boundary = f->rmbnd, fu.q_vn = f->rtvn_loc, fu.t_vn = f->rmvn, fu.Nt = Mt;
+                        fu.found = along ? f->rhit : nullptr, fu.pre_out = f->rpre;
+                        launch_self_intersect(ctx, tq, f->rcp, f->ttri, f->Tt, f->ttboxes, nullptr, f->rhit, f->ttribox, &tgt, nullptr, nullptr, &fu);
                     }
                     launch_reversal_sums(ctx, Mt, tq, f->rnn, f->rpre, f->rhit, f->rkeys, f->rvals, f->rskeys, f->rsvals, f->rsort, f->rsort_bytes,
                                          f->rw01 + q0, sums);
@@ -1341,8 +1343,10 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                     }
                     launch_nn(ctx, cloud_of(f->rcp, N), fit, f->m->perm, f->fboxes, f->ws, f->rnn, f->rnnd2, f->rnn_warm ? f->rnn : nullptr);
                     f->rnn_warm = true;  // (rnn: positions in the fit's device order -- last iteration's matches start this one's scan)
-                    launch_surface_prereject(ctx, N, f->rnn, f->mboundary, f->tvn, f->mvn, M, along ? f->rhit : nullptr, f->rpre);
-                    launch_self_intersect(ctx, tgt, f->rcp, f->ttri, f->Tt, f->ttboxes, f->rpre, f->rhit, f->ttribox);
+                    SelfIntersectFuse fu;
+                    fu.nn_vertex = f->rnn, fu.boundary = f->mboundary, fu.q_vn = f->tvn, fu.t_vn = f->mvn, fu.Nt = M;
+                    fu.found = along ? f->rhit : nullptr, fu.pre_out = f->rpre;
+                    launch_self_intersect(ctx, tgt, f->rcp, f->ttri, f->Tt, f->ttboxes, nullptr, f->rhit, f->ttribox, nullptr, nullptr, nullptr, &fu);
                     launch_reversal_observations(ctx, M, tgt, f->rnn, f->rpre, f->rhit, &f->st->sigma2, f->rkeys, f->rvals, f->rskeys,
                                                  f->rsvals, f->rsort, f->rsort_bytes, f->rw01, f->robs, f->rwin);
                 } else {  // ClosestPointTriangleMesh3DSimple: nearest template vertex, weight 1
@@ -1371,9 +1375,9 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 }
                 nearest_target_vertex(ctx, f, cloud_of(f->surf_cp, M), tgt, f->surf_nn, f->surf_nnd2, f->surf_nn_warm);
                 f->surf_nn_warm = true;
-                launch_surface_prereject(ctx, M, f->surf_nn, f->tboundary, f->mvn, f->tvn, f->N, along ? f->surf_hit : nullptr,
-                                         f->surf_pre);
                 if (ctx->tri_grid == 2 && ctx->cull && f->mgrid.ready && M <= f->mgrid.max_queries) {
+                    launch_surface_prereject(ctx, M, f->surf_nn, f->tboundary, f->mvn, f->tvn, f->N, along ? f->surf_hit : nullptr,
+                                             f->surf_pre);
                     // GINGR_OPT_TRI_GRID = 2 only: the template's triangles binned for THIS iteration (boxes and tile boxes are the ones
                     // computed above), the test over the cells the segment's ball reaches, the tile scan for what that could not
                     // certify.  Same decisions; NOT the default -- at 41k x 82k the four build launches (setup, count, scan, fill:
@@ -1382,10 +1386,16 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                     launch_self_intersect_grid(ctx, fit, f->surf_cp, f->mgrid, f->surf_pre, f->surf_hit);
                     launch_self_intersect(ctx, fit, f->surf_cp, f->mtri, f->Tm, f->mtboxes, f->surf_pre, f->surf_hit, f->mtribox, &meshc,
                                           f->mgrid.flag, f->mgrid.cur_nflag());
+                    launch_surface_weight(ctx, M, f->surf_pre, f->surf_hit, &f->st->sigma2, f->surf_w01, f->surf_win);
                 } else {
-                    launch_self_intersect(ctx, fit, f->surf_cp, f->mtri, f->Tm, f->mtboxes, f->surf_pre, f->surf_hit, f->mtribox, &meshc);
+                    // one launch: the first two rejection tests in its prologue, the third (self-intersection) in its tile scan, the
+                    // weights in its epilogue (until round 5: surface_prereject_kernel + this + surface_weight_kernel)
+                    SelfIntersectFuse fu;
+                    fu.nn_vertex = f->surf_nn, fu.boundary = f->tboundary, fu.q_vn = f->mvn, fu.t_vn = f->tvn, fu.Nt = f->N;
+                    fu.found = along ? f->surf_hit : nullptr, fu.pre_out = f->surf_pre;
+                    fu.sigma2 = &f->st->sigma2, fu.w01 = f->surf_w01, fu.weight_in = f->surf_win;
+                    launch_self_intersect(ctx, fit, f->surf_cp, f->mtri, f->Tm, f->mtboxes, nullptr, f->surf_hit, f->mtribox, &meshc, nullptr, nullptr, &fu);
                 }
-                launch_surface_weight(ctx, M, f->surf_pre, f->surf_hit, &f->st->sigma2, f->surf_w01, f->surf_win);
             } else if (icp) {
                 nearest_target_vertex(ctx, f, fit, tgt, f->nn_idx, f->nn_d2, f->nn_warm);
                 f->nn_warm = true;

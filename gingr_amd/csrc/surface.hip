@@ -655,7 +655,8 @@ __global__ __launch_bounds__(kCpThreads) void self_intersect_queue_kernel(Cloud 
                                                                          const double *__restrict__ boxes,
                                                                          const int32_t *__restrict__ skip,
                                                                          int32_t *__restrict__ flag, const double *__restrict__ tribox,
-                                                                         const uint8_t *__restrict__ only, const int32_t *__restrict__ nonly) {
+                                                                         const uint8_t *__restrict__ only, const int32_t *__restrict__ nonly,
+                                                                         SelfIntersectFuse F) {
     if (nonly && *nonly == 0) return;  // masked launch (what the grid kernel could not certify): nothing left over
     __shared__ double tbox[kTriTile][6];
     constexpr int QPB = 64 / H;
@@ -667,7 +668,24 @@ __global__ __launch_bounds__(kCpThreads) void self_intersect_queue_kernel(Cloud 
     const int64_t i = (int64_t)blockIdx.x * QPB + ql;
     const bool mine = i < fit.n && (!only || only[i] != 0);
     if (only && !__syncthreads_or(mine)) return;  // none of this workgroup's queries was left over
-    const bool ok = mine && !(skip && skip[i]);
+    bool rejected = false;
+    if (F.nn_vertex) {  // the first two rejection tests (surface_prereject_kernel: boundary vertex, opposite normals), made here
+        if (mine) {
+            const int32_t j = F.nn_vertex[i];
+            if (F.found && !F.found[i])
+                rejected = true;
+            else if (j < 0)
+                rejected = true;
+            else if (F.boundary[j])
+                rejected = true;
+            else
+                rejected = (F.q_vn[i] * F.t_vn[j] + F.q_vn[fit.n + i] * F.t_vn[F.Nt + j]) + F.q_vn[2 * fit.n + i] * F.t_vn[2 * F.Nt + j] < 0.0;
+            if (wave == 0 && half == 0) F.pre_out[i] = rejected ? 1 : 0;
+        }
+    } else {
+        rejected = skip && mine && skip[i];
+    }
+    const bool ok = mine && !rejected;
     const int64_t ic = i < fit.n ? i : 0;
     const V3 p{fit.x[ic], fit.y[ic], fit.z[ic]};
     const V3 dir = sub(p, V3{cp[ic], cp[fit.n + ic], cp[2 * fit.n + ic]});
@@ -772,7 +790,14 @@ __global__ __launch_bounds__(kCpThreads) void self_intersect_queue_kernel(Cloud 
     }
     if (tail > 0) flush(tail);
     __syncthreads();
-    if (wave == 0 && half == 0 && mine) flag[i] = qhit[ql];
+    if (wave == 0 && half == 0 && mine) {
+        flag[i] = qhit[ql];
+        if (F.w01) {  // surface_weight_kernel: w in {0, 1}, weight_in = w / sigma2
+            const double w = (rejected || qhit[ql]) ? 0.0 : 1.0;
+            F.w01[i] = w;
+            F.weight_in[i] = w / F.sigma2[0];
+        }
+    }
 }
 
 // ClosestPointAlongNormalTriangleMesh3D (ClosestPointRegistrator.scala:102-131): for every fit vertex the intersection of the
@@ -1661,7 +1686,7 @@ void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const in
 }
 void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, const int32_t *tri, int64_t T, const double *boxes,
                            const int32_t *skip, int32_t *flag, const double *tribox, const Cloud *mesh, const uint8_t *only,
-                           const int32_t *nonly) {
+                           const int32_t *nonly, const SelfIntersectFuse *fuse) {
 #ifdef GINGR_SI_H
     const int h = GINGR_SI_H;
 #else
@@ -1670,7 +1695,7 @@ void launch_self_intersect(gingr_ctx *ctx, Cloud fit, const double *cp_soa, cons
     const Cloud v = mesh ? *mesh : fit;
     auto go = [&](auto kern, int qpb) {
         hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(fit.n, qpb)), dim3(kCpThreads), 0, ctx->stream, fit, cp_soa, v, tri, T, boxes,
-                           skip, flag, tribox, only, nonly);
+                           skip, flag, tribox, only, nonly, fuse ? *fuse : SelfIntersectFuse{});
     };
     if (h == 8)
         go(self_intersect_queue_kernel<8>, 8);
