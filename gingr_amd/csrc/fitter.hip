@@ -8,6 +8,10 @@
 //   1  den, row statistics, observations, weighted Gram + right-hand side (+ landmarks), sigma2 sums -> segment 1
 //   2  replicated O(r^2) algebra: posterior solve, then (moment form, gp.h) alpha_1, step blend, Umeyama, second
 //      projection, alpha', state commit or failure status; finally the new fit of the local rows (one pass over Q0)
+#ifdef GINGR_MH_TRACE
+#include <chrono>
+#include <cstdio>
+#endif
 #include "gp.h"
 
 #include <algorithm>
@@ -2557,7 +2561,33 @@ static int mh_logpdf_enqueue(gingr_fitter *f, const DevState *frame, const doubl
     return check_launch(ctx);
 }
 
+#ifdef GINGR_MH_TRACE  // diagnostic build only (tools/mkvar.sh mhtrace fitter -DGINGR_MH_TRACE): where the host side of a step goes
+static double g_mh_t[4];  // between calls, enqueue, wait, after the wait (seconds)
+static long g_mh_n;
+static std::chrono::steady_clock::time_point g_mh_last;
+static bool g_mh_has_last;
+struct MhTrace {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), t1, t2;
+    MhTrace() {
+        if (g_mh_has_last) g_mh_t[0] += std::chrono::duration<double>(t0 - g_mh_last).count();
+    }
+    ~MhTrace() {
+        const auto t3 = std::chrono::steady_clock::now();
+        g_mh_t[1] += std::chrono::duration<double>(t1 - t0).count();
+        g_mh_t[2] += std::chrono::duration<double>(t2 - t1).count();
+        g_mh_t[3] += std::chrono::duration<double>(t3 - t2).count();
+        g_mh_last = t3, g_mh_has_last = true;
+        if (++g_mh_n % 100 == 0)
+            fprintf(stderr, "mh_step x%ld: between calls %.1f us, enqueue %.1f, wait %.1f, after %.1f\n", g_mh_n, 1e6 * g_mh_t[0] / g_mh_n,
+                    1e6 * g_mh_t[1] / g_mh_n, 1e6 * g_mh_t[2] / g_mh_n, 1e6 * g_mh_t[3] / g_mh_n);
+    }
+};
+#endif
+
 int gingr_fitter_mh_step(gingr_fitter *f, const gingr_mh_request *q, double *alpha_out, double *fit_out, gingr_mh_result *res) {
+#ifdef GINGR_MH_TRACE
+    MhTrace trace;
+#endif
     GINGR_TRY(check_ready(f));
     gingr_ctx *ctx = f->ctx;
     const gingr_model *m = f->m;
@@ -2685,7 +2715,13 @@ int gingr_fitter_mh_step(gingr_fitter *f, const gingr_mh_request *q, double *alp
         HIP_TRY(ctx, hipMemcpyAsync(f->pin, f->mh_rb, (head + 8 + (fit_out ? (size_t)3 * M : 0)) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
     GINGR_TRY(check_launch(ctx));
+#ifdef GINGR_MH_TRACE
+    trace.t1 = std::chrono::steady_clock::now();
+#endif
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+#ifdef GINGR_MH_TRACE
+    trace.t2 = std::chrono::steady_clock::now();
+#endif
     poison.armed = false;
     f->mh_saved = true;
     DevState hst;

@@ -241,6 +241,8 @@ def _shapes_equal(x, y) -> bool:
 
 
 class RandomShapeUpdateProposal:
+    symmetric = True   # q(to | from) is a function of (to - from)^2 and of which fields agree: the same bits for the swapped pair
+
     def __init__(self, algorithm: GingrAlgorithm, stdev: float, rnd: Random, generatedBy: str = "RandomShapeUpdateProposal"):
         self.algorithm, self.stdev, self.rnd, self.generatedBy = algorithm, float(stdev), rnd, generatedBy
 
@@ -265,6 +267,8 @@ RollAxis, PitchAxis, YawAxis = "phi", "theta", "psi"
 
 
 class GaussianAxisRotationProposal:
+    symmetric = True   # q(to | from) is a function of (to - from)^2 and of which fields agree: the same bits for the swapped pair
+
     def __init__(self, algorithm: GingrAlgorithm, sdevRot: float, axis: str, rnd: Random, generatedBy: str = "RotationProposal"):
         self.algorithm, self.sdev, self.axis, self.rnd, self.generatedBy = algorithm, float(sdevRot), axis, rnd, generatedBy
 
@@ -281,6 +285,8 @@ class GaussianAxisRotationProposal:
 
 
 class GaussianAxisTranslationProposal:
+    symmetric = True   # q(to | from) is a function of (to - from)^2 and of which fields agree: the same bits for the swapped pair
+
     def __init__(self, algorithm: GingrAlgorithm, sdevTrans: float, axis: int, rnd: Random, generatedBy: str = "TranslationProposal"):
         if not axis < 3:
             raise ValueError("requirement failed")
@@ -309,6 +315,10 @@ class MixtureProposal:
         self.generators = [g for _, g in components]
         self.cumulative = list(np.cumsum(self.factors))
         self.rnd = rnd
+        # a mixture of symmetric random walks is symmetric: a Metropolis-Hastings step asks for q(to | from) and q(from | to) of the same
+        # pair of state objects, the second answer is the first (thirteen component calls less per step for the stock mixture)
+        self.symmetric = all(getattr(g, "symmetric", False) for g in self.generators)
+        self._sym = None
 
     def propose(self, current):
         r = self.rnd.nextDouble()
@@ -316,6 +326,10 @@ class MixtureProposal:
         return self.generators[i].propose(current)
 
     def logTransitionProbability(self, frm, to) -> float:
+        if self.symmetric:
+            m = self._sym
+            if m is not None and ((m[0] is frm and m[1] is to) or (m[0] is to and m[1] is frm)):
+                return m[2]
         s = 0.0
         for f, g in zip(self.factors, self.generators):
             t = g.logTransitionProbability(frm, to)
@@ -323,7 +337,10 @@ class MixtureProposal:
                 raise ArithmeticError("NaN transition probability encountered!")
             if t != -math.inf:
                 s += f * math.exp(t)
-        return math.log(s) if s > 0 else -math.inf
+        out = math.log(s) if s > 0 else -math.inf
+        if self.symmetric:
+            self._sym = (frm, to, out)
+        return out
 
 
 class Generator:

@@ -32,5 +32,5 @@ exec(compile(open(os.path.join(ROOT, "tools", "bench_mh_chain.py")).read(), os.p
 pr.disable()
 print("COUNTS", cnt)
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
-print(s.getvalue()[:6000])
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats("gingr_amd|numpy|method|built-in", 60)
+print(s.getvalue()[:12000])
