@@ -227,13 +227,20 @@ struct MhPayload {
     double v[kMhPayload];
 };
 // save[0..m) = src[0..m), THEN dst[0..n) = payload (dst may be src: the random-walk parameters overwrite the state block that was just parked)
-__global__ __launch_bounds__(256) void mh_begin_kernel(MhPayload payload, int n, double *dst, const double *src, int m, double *__restrict__ save) {
+// st != nullptr: the payload was [alpha | scalars] of a random-walk proposal -- the device state is initialised from it in the same launch
+// (state_init_kernel's work: one launch less per such step)
+__global__ __launch_bounds__(256) void mh_begin_kernel(MhPayload payload, int n, double *dst, const double *src, int m, double *__restrict__ save,
+                                                       DevState *st, const gingr_state_scalars *hs, double *zero_slot) {
     const int t = threadIdx.x;
     double keep = 0.0;
     if (t < m) keep = src[t];
     __syncthreads();
     if (t < m) save[t] = keep;
     if (t < n) dst[t] = payload.v[t];
+    if (st) {
+        __syncthreads();  // (the scalars just written by this workgroup are read back by its thread 0)
+        if (t == 0) state_init_body(st, hs, zero_slot);
+    }
 }
 // out[0..nblock) = block; out[nblock + 3 perm[i] + d] = fit[d][i]
 __global__ __launch_bounds__(256) void mh_readback_kernel(const double *__restrict__ block, int nblock, const double *__restrict__ fit, int64_t M,
@@ -2642,7 +2649,8 @@ int gingr_fitter_mh_step(gingr_fitter *f, const gingr_mh_request *q, double *alp
     if (q->kind == 0) {
         if (by_kernel) {
             memcpy(payload.v, q->z, (size_t)r * sizeof(double));
-            hipLaunchKernelGGL(mh_begin_kernel, dim3(1), dim3(256), 0, ctx->stream, payload, (int)rp, f->zrand, f->state_block, (int)head, f->mh_save);
+            hipLaunchKernelGGL(mh_begin_kernel, dim3(1), dim3(256), 0, ctx->stream, payload, (int)rp, f->zrand, f->state_block, (int)head, f->mh_save,
+                               (DevState *)nullptr, (const gingr_state_scalars *)nullptr, (double *)nullptr);
         } else {
             memcpy(f->pin, q->z, (size_t)r * sizeof(double));
             HIP_TRY(ctx, hipMemcpyAsync(f->zrand, f->pin, (size_t)rp * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -2657,13 +2665,13 @@ int gingr_fitter_mh_step(gingr_fitter *f, const gingr_mh_request *q, double *alp
             memcpy(payload.v, q->alpha, (size_t)r * sizeof(double));
             memcpy(payload.v + rp, q->scalars, sizeof(*q->scalars));
             hipLaunchKernelGGL(mh_begin_kernel, dim3(1), dim3(256), 0, ctx->stream, payload, (int)(rp + kScalarsDoubles), f->state_block, f->state_block,
-                               (int)head, f->mh_save);
+                               (int)head, f->mh_save, f->st, (const gingr_state_scalars *)f->hs_dev, f->absmax + 1);
         } else {
             memcpy(f->pin, q->alpha, (size_t)r * sizeof(double));
             memcpy(f->pin + rp, q->scalars, sizeof(*q->scalars));
             HIP_TRY(ctx, hipMemcpyAsync(f->state_block, f->pin, ((size_t)rp + kScalarsDoubles) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            launch_state_init(ctx, f->st, f->hs_dev, f->absmax + 1);
         }
-        launch_state_init(ctx, f->st, f->hs_dev, f->absmax + 1);
         refresh_fit(f);
         GINGR_TRY(check_launch(ctx));
         const gingr_state_scalars *s = q->scalars;  // the host knows this state: keyed by value, like gingr_fitter_set_state

@@ -2,6 +2,7 @@
 #pragma once
 
 #include "common.h"
+#include "svd3.h"
 
 #include <functional>
 
@@ -25,6 +26,26 @@ struct DevState {
     int32_t stopped; // the run's stopping rule fired on this state (PostSolveArgs::stop_threshold): later updates leave it as it is
     int32_t pad2;
 };
+
+// DevState from the scalars the host pushed (one thread; state_init_kernel, and the tail of the launch that brings a Metropolis-Hastings
+// step's random-walk parameters: fitter.hip, mh_begin_kernel)
+__device__ inline void state_init_body(DevState *st, const gingr_state_scalars *h, double *zero_slot) {
+    if (zero_slot) *zero_slot = 0.0;  // see SweepArgs::absmax_slot
+    for (int q = 0; q < 3; ++q) {
+        st->euler[q] = h->euler[q];
+        st->center[q] = h->center[q];
+        st->t[q] = h->translation[q];
+    }
+    euler_to_rot(st->euler, st->R);
+    st->scale = h->scale;
+    st->sigma2 = h->sigma2;
+    st->iteration = h->iteration;
+    st->status = h->status;
+    st->err = 0;
+    st->pad = 0;
+    st->stopped = 0;
+    st->pad2 = 0;
+}
 
 // Candidate global alignment produced by the Umeyama step (R2 went through the Euler parameterisation).
 struct DevPose {

@@ -2226,21 +2226,7 @@ __global__ __launch_bounds__(512) void post_solve_kernel(PostSolveArgs A) {
 
 __global__ void state_init_kernel(DevState *st, const gingr_state_scalars *h, double *zero_slot) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (zero_slot) *zero_slot = 0.0;  // see SweepArgs::absmax_slot
-    for (int q = 0; q < 3; ++q) {
-        st->euler[q] = h->euler[q];
-        st->center[q] = h->center[q];
-        st->t[q] = h->translation[q];
-    }
-    euler_to_rot(st->euler, st->R);
-    st->scale = h->scale;
-    st->sigma2 = h->sigma2;
-    st->iteration = h->iteration;
-    st->status = h->status;
-    st->err = 0;
-    st->pad = 0;
-    st->stopped = 0;
-    st->pad2 = 0;
+    state_init_body(st, h, zero_slot);
 }
 
 }  // namespace

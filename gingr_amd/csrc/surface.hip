@@ -1047,6 +1047,62 @@ __global__ void dist_stats_finish_kernel(const double *__restrict__ partial, dou
     out[threadIdx.x] = v;
 }
 
+// Both launches in one for up to kStatBlocks * 256 points (a Metropolis-Hastings step evaluates the likelihood of ~1 600 vertices:
+// two dependent launches of 4 us each were all latency).  One wave stands for one block of dist_stats_kernel -- lane l holds the
+// elements t = l, l + 64, l + 128, l + 192 of its block -- and adds them in the order of that kernel's LDS tree ((t, t + 128), (t, t + 64),
+// then the lanes 32, 16, ... 1 apart), the blocks are added in ascending order as dist_stats_finish_kernel does: the same bits.
+__global__ __launch_bounds__(1024) void dist_stats_small_kernel(int64_t n, const double *__restrict__ d2, const int32_t *__restrict__ orig,
+                                                                int64_t orig_limit, const int32_t *__restrict__ nn,
+                                                                const int32_t *__restrict__ boundary, double sdev, double lognorm,
+                                                                double *__restrict__ out) {
+    __shared__ double part[kStatBlocks][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nblocks = (int)((n + 255) / 256);  // (blocks past the last point hold zeros: adding them changes nothing)
+    for (int b = wave; b < nblocks; b += 16) {
+        double s[4], mx[4], cnt[4], ll[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = (int64_t)b * 256 + k * 64 + lane;
+            s[k] = mx[k] = cnt[k] = ll[k] = 0.0;
+            bool take = i < n && (!orig || orig[i] < orig_limit);
+            if (take && boundary) {
+                const int32_t j = nn[i];
+                take = j >= 0 && !boundary[j];
+            }
+            if (take) {
+                const double d = sqrt(d2[i]);
+                s[k] = 0.0 + d;
+                mx[k] = fmax(0.0, d);
+                cnt[k] = 1.0;
+                if (sdev > 0.0) {
+                    const double u = d / sdev;
+                    ll[k] = 0.0 + (-u * u / 2.0 - lognorm);
+                }
+            }
+        }
+        // off = 128, 64: between the four elements of a lane; off = 32 .. 1: between lanes
+        double a = (s[0] + s[2]) + (s[1] + s[3]), m = fmax(fmax(mx[0], mx[2]), fmax(mx[1], mx[3])), c = (cnt[0] + cnt[2]) + (cnt[1] + cnt[3]),
+               l = (ll[0] + ll[2]) + (ll[1] + ll[3]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_down(a, off);
+            m = fmax(m, __shfl_down(m, off));
+            c += __shfl_down(c, off);
+            l += __shfl_down(l, off);
+        }
+        if (lane == 0) part[b][0] = a, part[b][1] = m, part[b][2] = c, part[b][3] = l;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double v = 0.0;
+        for (int b = 0; b < nblocks; ++b) {
+            const double x = part[b][threadIdx.x];
+            v = threadIdx.x == 1 ? fmax(v, x) : v + x;
+        }
+        out[threadIdx.x] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------- grid over a MOVING mesh, rebuilt on the device (round 5)
 constexpr int kMovGridSetupBlocks = 256;
 constexpr int kMovGridScanBlocks = 128;      // all resident at once (the scan's look-back spins on the predecessors' totals)
@@ -1680,6 +1736,10 @@ int distance_stats_ws_doubles() { return kStatBlocks * 4; }
 void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const int32_t *orig, int64_t orig_limit, const int32_t *nn,
                            const int32_t *boundary, double sdev, double *partial, double *out4) {
     const double lognorm = sdev > 0.0 ? log(sqrt(2.0 * M_PI)) + log(sdev) : 0.0;
+    if (n <= (int64_t)kStatBlocks * 256) {  // every (block, thread) of the two-launch form holds at most one point
+        hipLaunchKernelGGL(dist_stats_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, d2, orig, orig_limit, nn, boundary, sdev, lognorm, out4);
+        return;
+    }
     hipLaunchKernelGGL(dist_stats_kernel, dim3(kStatBlocks), dim3(256), 0, ctx->stream, n, d2, orig, orig_limit, nn, boundary, sdev,
                        lognorm, partial);
     hipLaunchKernelGGL(dist_stats_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, partial, out4);
