@@ -27,16 +27,39 @@ ctx = ga.Context(0)
 lib = ctx._lib
 lib.gingr_debug_stamps_enable.argtypes = [ctypes.c_void_p]
 lib.gingr_debug_stamps_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+SINGLE = len(sys.argv) > 3 and sys.argv[3] == "single"
+if SINGLE:
+    # the same number of rows as rank 0 of `world` ranks, but as a registration of its own on one shard: the same pair loops and the same
+    # narrow tail, no exchange kernels between them
+    y = y[: (points + world - 1) // world]
 model = ga.GPMMTriangleMesh3D(ctx, y, relativeTolerance=0.0, maxRank=100).Gaussian(70.0, 50.0)
-uid = ctx.rccl_unique_id()
-ctx.rccl_init(uid, 1, 0)
-fitter = ShardedFitter(ctx, model, x, rank=0, world=world, all_reduce=None, rccl=True)
+if SINGLE:
+    fitter = ShardedFitter(ctx, model, x)
+else:
+    uid = ctx.rccl_unique_id()
+    ctx.rccl_init(uid, 1, 0)
+    fitter = ShardedFitter(ctx, model, x, rank=0, world=world, all_reduce=None, rccl=True)
 s2 = ctx.cpd_initial_sigma2(y, x)
 fitter.set_state(np.zeros(100), s2)
 fitter.update_cpd(0.1, 1.0, 5)
 ctx.synchronize()
 assert lib.gingr_debug_stamps_enable(ctx.handle) == 0
-fitter.update_cpd(0.1, 1.0, 3)
+if len(sys.argv) > 3 and sys.argv[3] == "colsum_back_to_back":
+    # the column-sum pass alone, N launches back to back (phase 0 of the phase API): what clock do its waves see when nothing short and
+    # narrow runs between the launches?  (the full iteration has ~60 us of single-workgroup kernels per 0.4 ms)
+    from gingr_amd import _native as nat
+    p = nat.CpdParams(0.1, 1.0)
+    for _ in range(int(sys.argv[4]) if len(sys.argv) > 4 else 200):
+        assert lib.gingr_fitter_cpd_phase_async(fitter.handle, ctypes.byref(p), 0) == 0
+elif len(sys.argv) > 3 and sys.argv[3] in ("phases01", "phases012"):
+    # phases 0 and 1 (both pair loops, the reductions, the Gram pass) without / with phase 2 (the replicated narrow tail), no exchange
+    from gingr_amd import _native as nat
+    p = nat.CpdParams(0.1, 1.0)
+    for _ in range(int(sys.argv[4]) if len(sys.argv) > 4 else 100):
+        for ph in ((0, 1) if sys.argv[3] == "phases01" else (0, 1, 2)):
+            assert lib.gingr_fitter_cpd_phase_async(fitter.handle, ctypes.byref(p), ph) == 0
+else:
+    fitter.update_cpd(0.1, 1.0, 3)
 ctx.synchronize()
 W = 1 << 15
 buf = np.zeros((2, W, 8), dtype=np.uint64)
