@@ -103,7 +103,7 @@ print(json.dumps({"what": "ICP update, surface correspondence (closest point on 
                   "ms_per_iteration_run_resident": dt_run / nres * 1e3,
                   "ms_per_iteration_host_boundary": dt / n * 1e3, "iterations_per_s_host_boundary": n / dt,
                   "timing": "ms_per_iteration: %d updates in one native call, state resident; run_resident: GingrAlgorithm.run without a "
-                            "call-back (scalars read back per iteration); host_boundary: update(state) per iteration, the fit (%d x 3 "
+                            "call-back (the whole ICP loop is one native call, the state comes back once); host_boundary: update(state) per iteration, the fit (%d x 3 "
                             "doubles) pulled every time" % (nres, ref.shape[0]),
                   "accepted_fraction_first_iteration": float(w.mean()), "status": int(state.general.status),
                   "run_status": int(end.general.status), "run_iterations": int(end.general.iteration),
