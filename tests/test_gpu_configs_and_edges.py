@@ -265,3 +265,24 @@ def test_point_cloud_icp_at_the_rank_limits(ctx, rank):
         assert state.general.status == st.status == 0
         assert rel(state.general.fit, st.fit) < 1e-6 and state.general.sigma2 == st.sigma2, (rank, it)
     algo.close()
+
+
+@pytest.mark.parametrize("M,N", [(3000, 3000), (5600, 5600)])
+def test_resident_cpd_run_in_blocks_equals_the_per_iteration_loop(ctx, M, N):
+    """`run` without a call-back enqueues CPD updates in blocks (4 / 2 / 1 by problem size) under the device-side stopping rule
+    (gingr_fitter_set_stop_threshold); these sizes take the 2-update and the 1-update block.  Same stopping iteration, same state and
+    status as the per-iteration loop with a call-back -- whether the run converges inside a block or runs out of iterations."""
+    import gingr_amd as ga
+    mo, rng = synth_model(M, 16, seed=M + 5, spread=40.0)
+    target = (mo.ref + rng.normal(0, 0.5, mo.ref.shape))[rng.permutation(M)[:N]]
+    algo = ga.CpdRegistration(ctx)
+    for cfg in (ga.CpdConfiguration(maxIterations=40, threshold=5e-3, w=0.05), ga.CpdConfiguration(maxIterations=6, threshold=1e-12, w=0.0)):
+        init = algo.createInitialState(to_ga(mo), target, cfg)
+        fast = algo.run(init)
+        seen = []
+        slow = algo.run(init, callBackLogger=lambda s: seen.append(s.general.iteration))
+        assert fast.general.iteration == slow.general.iteration == seen[-1] and fast.general.status == slow.general.status
+        assert fast.general.sigma2 == slow.general.sigma2
+        assert np.array_equal(fast.general.modelParameters.shape, slow.general.modelParameters.shape)
+        assert np.array_equal(fast.general.fit, slow.general.fit)
+    algo.close()
