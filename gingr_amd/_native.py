@@ -75,7 +75,7 @@ _dp = POINTER(c_double)
 _ip = POINTER(c_int32)
 
 KERNEL_GAUSSIAN_MIXTURE, KERNEL_DOT, KERNEL_LOOKUP = 0, 1, 2
-OPT_CULL, OPT_FINE_CULL, OPT_NN_GRID, OPT_TRI_GRID, OPT_SPLIT_EXCHANGE = 0, 1, 2, 3, 4  # gingr_ctx_option
+OPT_CULL, OPT_FINE_CULL, OPT_NN_GRID, OPT_TRI_GRID, OPT_SPLIT_EXCHANGE, OPT_GRAM_DOWNDATE = 0, 1, 2, 3, 4, 5  # gingr_ctx_option
 
 
 class ScalarKernel(ctypes.Structure):

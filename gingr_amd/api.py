@@ -545,7 +545,9 @@ class DeviceModel:
 
     def close(self):
         if getattr(self, "handle", None):
-            if self._owner:
+            # (a model that outlives its context -- e.g. collected after Context.close() -- must not call into the freed context: its
+            # device memory went with the context's process state; dropping the handle is all that is left to do)
+            if self._owner and getattr(self.ctx, "handle", None):
                 self._lib.gingr_model_destroy(self.handle)
             self.handle = None
 
@@ -778,7 +780,8 @@ class GingrAlgorithm:
 
     def _release(self):
         if self._fitter:
-            self._lib.gingr_fitter_destroy(self._fitter)
+            if getattr(self.ctx, "handle", None):   # (never into a context that has been closed)
+                self._lib.gingr_fitter_destroy(self._fitter)
             self._fitter = None
         if self._dev_model is not None:
             self._dev_model.close()

@@ -50,6 +50,7 @@ struct gingr_ctx {
     // half of pass 1 (fitter.hip: fitter_sharded_update).  side_stream / the events are created on first use; exchange_stream is
     // where the native all-reduce is enqueued right now (nullptr = the context's stream).
     int split_exchange = 0;
+    int gram_downdate = -1;  // GINGR_OPT_GRAM_DOWNDATE: 0 / 1 weights of the surface ICP -> the model's moment minus the rejected rows (fitter.hip, phase 1); -1: by size
     hipStream_t side_stream = nullptr, exchange_stream = nullptr;
     hipEvent_t split_ev[2] = {nullptr, nullptr};
     // scratch kept across calls (grown on demand, never shrunk) so steady-state updates do not allocate

@@ -138,6 +138,7 @@ int gingr_ctx_set_option(gingr_ctx *ctx, int32_t option, int32_t value) {
         case GINGR_OPT_NN_GRID: ctx->nn_grid = value < 0 ? 0 : (value > 2 ? 2 : value); return GINGR_OK;
         case GINGR_OPT_TRI_GRID: ctx->tri_grid = value < 0 ? 0 : (value > 2 ? 2 : value); return GINGR_OK;
         case GINGR_OPT_SPLIT_EXCHANGE: ctx->split_exchange = value != 0; return GINGR_OK;
+        case GINGR_OPT_GRAM_DOWNDATE: ctx->gram_downdate = value < 0 ? -1 : (value != 0); return GINGR_OK;
         default: return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "ctx_set_option: unknown option %d", option);
     }
 }
@@ -150,6 +151,7 @@ int gingr_ctx_get_option(gingr_ctx *ctx, int32_t option, int32_t *value) {
         case GINGR_OPT_NN_GRID: *value = ctx->nn_grid; return GINGR_OK;
         case GINGR_OPT_TRI_GRID: *value = ctx->tri_grid; return GINGR_OK;
         case GINGR_OPT_SPLIT_EXCHANGE: *value = ctx->split_exchange; return GINGR_OK;
+        case GINGR_OPT_GRAM_DOWNDATE: *value = ctx->gram_downdate; return GINGR_OK;
         default: return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "ctx_get_option: unknown option %d", option);
     }
 }

@@ -202,6 +202,11 @@ struct gingr_fitter {
     int split_half = 0;
 };
 
+// GINGR_OPT_GRAM_DOWNDATE by default: from this many local rows on.  The downdate pays while fewer than ~20 % of the rows have weight 0
+// (41k: 15 + 17.5 us of downdate + right-hand-side sweep against 44 us of the weighted Gram pass at 0.2 % rejected; it costs one memory
+// round trip per four zero-weight vertices of a slab); small meshes -- the femur chain rejects a fifth of its 1 622 vertices -- keep
+// the pass over the basis, which is cheap there (13.6 us).  A fixed rule, not a measured one: both forms round differently.
+constexpr int64_t kGramDowndateMinRows = 16384;
 // The triangle grid pays from a few ten thousand target triangles on (41k x 82k: 94 -> 27 + 10 us per closest-point search); on a
 // small mesh the tile scan with its sixteen query copies per workgroup is faster (femur, 3 240 triangles: 16 us against 15 + 7).
 constexpr int64_t kTriGridMinTriangles = 16384;
@@ -1485,6 +1490,17 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 // shard that owns row 0 contributes it, the others contribute zero to the exchange.
                 // (written by the phase-1 finalize kernel below: one launch less than a copy kernel of its own)
                 fa.nslabs = 0;
+                fa.scaled_src = m->mom + MomentLayout{rp}.stot();
+                fa.sigma2 = &f->st->sigma2;
+                fa.scaled_contribute = m->row_begin == 0 ? 1 : 0;
+            } else if (icp && f->icp_surface && !f->reversed && rp <= 112 &&
+                       (ctx->gram_downdate == 1 || (ctx->gram_downdate < 0 && M >= kGramDowndateMinRows))) {
+                // surface correspondence: an accepted pair has the weight 1 / sigma2, a rejected one (and a vertex a landmark overrides) 0
+                // (ICP.scala:50,90-92) -- the weighted Gram is the model's moment minus the rows of the zero-weight vertices, scaled.
+                // One pass over THOSE rows (0.2 % of them at 41k x 82k) instead of the MFMA pass over the whole basis (44 us); the
+                // right-hand side takes the sweep below.  On row shards the moment is the total: the shard of row 0 contributes it.
+                fa.gram_partial = gram_ws;
+                fa.nslabs = launch_gram_downdate(ctx, m->Q0, M, rp, f->weight, gram_ws);
                 fa.scaled_src = m->mom + MomentLayout{rp}.stot();
                 fa.sigma2 = &f->st->sigma2;
                 fa.scaled_contribute = m->row_begin == 0 ? 1 : 0;

@@ -219,6 +219,8 @@ struct Phase1FinalizeArgs {
     const double *gram_partial;   // [nslabs][rp*rp] (upper patches); nslabs == 0: G is not touched, unless scaled_src is given
     int32_t nslabs;
     // nslabs == 0 and scaled_src != nullptr: G = scaled_contribute ? scaled_src / sigma2 : 0 (uniform-weight ICP: the model's Q^T Q)
+    // nslabs  > 0 and scaled_src != nullptr: G = ((scaled_contribute ? scaled_src : 0) - sum of the partials) / sigma2 (0 / 1 weights of
+    //                                        the surface ICP: the partials hold Q^T Q of the zero-weight rows, launch_gram_downdate)
     const double *scaled_src;
     const double *sigma2;
     int32_t scaled_contribute;
@@ -233,6 +235,9 @@ struct Phase1FinalizeArgs {
     int32_t contribute_xpx;
 };
 void launch_phase1_finalize(gingr_ctx *ctx, const Phase1FinalizeArgs &a);
+// partial[b] = sum over the vertices i of slab b with weight[i] == 0 of Q0_i^T Q0_i (full rp x rp, zeros when the slab has none);
+// returns the slab count (<= 256: the workspace of launch_gram is large enough).  rp <= 112.
+int launch_gram_downdate(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws);
 
 // ---- observations ------------------------------------------------------------------------------------------
 // CPD: yhat = y + (PX/P1 - y), weight = 1/(sigma2*lambda/P1)  (CPD.scala:37-46,126); e = w (R^T(yhat - c - t) - (ref - c) - mean)

@@ -832,7 +832,9 @@ __global__ __launch_bounds__(256) void phase1_finalize_kernel(Phase1FinalizeArgs
         sh[g][el] = s;
         __syncthreads();
         if (g == 0 && need) {
-            const double t = ((sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el])) + ((sh[4][el] + sh[5][el]) + (sh[6][el] + sh[7][el]));
+            double t = ((sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el])) + ((sh[4][el] + sh[5][el]) + (sh[6][el] + sh[7][el]));
+            if (A.scaled_src)  // the partials are Q^T Q of the zero-weight rows: the model's moment minus them, every other row at 1 / sigma2
+                t = ((A.scaled_contribute ? A.scaled_src[idx] : 0.0) - t) * (1.0 / A.sigma2[0]);
             A.G[i * rp + j] = t;
             A.G[j * rp + i] = t;
         }
@@ -875,6 +877,84 @@ __global__ __launch_bounds__(256) void phase1_finalize_kernel(Phase1FinalizeArgs
     } else if (threadIdx.x < 8) {
         A.sc8[threadIdx.x] = 0.0;
     }
+}
+
+// Q^T Q of the vertices whose weight is exactly 0, slab by slab (launch_gram_downdate).  A workgroup owns the whole rp x rp matrix:
+// thread (ti, tj) of a 16 x 16 arrangement keeps the entries (ti + 16 a, tj + 16 b), a, b < 7, in registers.  It walks its slab's
+// vertices 256 at a time -- a ballot finds the zero-weight ones -- and adds, for each of them in ascending order, the three rows of the
+// basis (staged in LDS four vertices at a time: 14 reads per row and thread) as outer products: fixed order, no atomics.  rp <= 112.
+__global__ __launch_bounds__(256) void gram_downdate_kernel(const double *__restrict__ Q0, int64_t M, int rp, const double *__restrict__ weight,
+                                                            int64_t verts_per_slab, double *__restrict__ partial) {
+    constexpr int kBatch = 4;  // zero-weight vertices staged together: their rows are requested at once (a slab with several of them
+                               // would otherwise pay one memory round trip per vertex, and the launch ends with its slowest slab)
+    __shared__ double q[kBatch][3][112];
+    __shared__ unsigned long long zmask[16];
+    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;  // (tj fastest: the sixteen lanes of a row write 128 contiguous bytes)
+    const int64_t v0 = (int64_t)blockIdx.x * verts_per_slab, v1 = v0 + verts_per_slab < M ? v0 + verts_per_slab : M;
+    double acc[7][7];
+#pragma unroll
+    for (int a = 0; a < 7; ++a)
+#pragma unroll
+        for (int b = 0; b < 7; ++b) acc[a][b] = 0.0;
+    constexpr int kRounds = 4;  // 1 024 vertices per pass: their weights are requested together (one memory round trip, not four)
+    for (int64_t base = v0; base < v1; base += 256 * kRounds) {
+        double wv[kRounds];
+#pragma unroll
+        for (int r2 = 0; r2 < kRounds; ++r2) {
+            const int64_t v = base + 256 * r2 + tid;
+            wv[r2] = v < v1 ? weight[v] : 1.0;
+        }
+        __syncthreads();  // (the previous pass's readers of zmask are done)
+#pragma unroll
+        for (int r2 = 0; r2 < kRounds; ++r2) {
+            const unsigned long long m = __ballot(wv[r2] == 0.0);
+            if ((tid & 63) == 0) zmask[4 * r2 + (tid >> 6)] = m;
+        }
+        __syncthreads();
+        unsigned long long bits[4 * kRounds];  // workgroup-uniform
+#pragma unroll
+        for (int k = 0; k < 4 * kRounds; ++k) bits[k] = zmask[k];
+        int w = 0;
+        for (;;) {
+            int64_t vz[kBatch];
+            int nb = 0;
+            while (nb < kBatch && w < 4 * kRounds) {  // the next (up to) kBatch zero-weight vertices, ascending
+                if (bits[w] == 0) {
+                    ++w;
+                    continue;
+                }
+                vz[nb++] = base + 64 * w + __builtin_ctzll(bits[w]);
+                bits[w] &= bits[w] - 1;
+            }
+            if (nb == 0) break;
+            __syncthreads();  // (the previous batch's rows have been used)
+            for (int t = tid; t < kBatch * 3 * 112; t += 256) {
+                const int s2 = t / (3 * 112), r2 = t - s2 * (3 * 112), d = r2 / 112, k = r2 - 112 * d;
+                if (s2 < nb) q[s2][d][k] = k < rp ? Q0[(3 * vz[s2] + d) * (int64_t)rp + k] : 0.0;
+            }
+            __syncthreads();
+            for (int s2 = 0; s2 < nb; ++s2) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    double qi[7], qj[7];
+#pragma unroll
+                    for (int a = 0; a < 7; ++a) qi[a] = q[s2][d][ti + 16 * a], qj[a] = q[s2][d][tj + 16 * a];
+#pragma unroll
+                    for (int a = 0; a < 7; ++a)
+#pragma unroll
+                        for (int b = 0; b < 7; ++b) acc[a][b] = __builtin_fma(qi[a], qj[b], acc[a][b]);
+                }
+            }
+        }
+    }
+    double *out = partial + (int64_t)blockIdx.x * rp * rp;
+#pragma unroll
+    for (int a = 0; a < 7; ++a)
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            const int i = ti + 16 * a, j = tj + 16 * b;
+            if (i < rp && j < rp) out[i * rp + j] = acc[a][b];
+        }
 }
 
 __global__ void centered_mean_kernel(const double *__restrict__ ref, const double *__restrict__ mean, int64_t M, double c0x,
@@ -2361,6 +2441,17 @@ int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const d
     if (G)  // nullptr: the caller reduces the slab partials itself (launch_phase1_finalize with the returned slab count)
         hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 32)), dim3(256), 0, ctx->stream, ws,
                            nslabs, (int)rp, 1, G);
+    return nslabs;
+}
+
+int launch_gram_downdate(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws) {
+    int nslabs_tri;  // never more slabs than the weighted Gram pass would write: the workspace behind them belongs to the right-hand-side sweep
+    int64_t rows_per_slab;
+    gram_tri_plan(M, &nslabs_tri, &rows_per_slab);
+    const int64_t want = std::max<int64_t>(1, std::min<int64_t>(std::min(nslabs_tri, 128), ceil_div(M, 64)));
+    const int64_t vps = ceil_div(M, want);
+    const int nslabs = (int)ceil_div(M, vps);
+    hipLaunchKernelGGL(gram_downdate_kernel, dim3((unsigned)nslabs), dim3(256), 0, ctx->stream, Q0, M, (int)rp, weight, vps, ws);
     return nslabs;
 }
 

@@ -321,7 +321,8 @@ class ShardedFitter:
 
     def close(self):
         if getattr(self, "handle", None):
-            self._lib.gingr_fitter_destroy(self.handle)
+            if getattr(self.ctx, "handle", None):   # (never into a context that has been closed)
+                self._lib.gingr_fitter_destroy(self.handle)
             self.handle = None
         if getattr(self, "dev_model", None) is not None:
             self.dev_model.close()

@@ -83,13 +83,19 @@ const char *gingr_build_info(void);
  *                        the second half's all-reduce is exposed.  Costs two short launches instead of one (the emulated per-rank time
  *                        rises by a few microseconds); whether it pays depends on the all-reduce latency of the node.
  *                        Same sums up to the order of the chunk partials (<= 1e-12 on the state).
+ *   GINGR_OPT_GRAM_DOWNDATE  -1 (default: from 16 384 local rows on) / 1 / 0: ICP with a surface correspondence gives every accepted pair
+ *                        the weight 1 / sigma2 and every rejected one 0 (ICP.scala:50,90-92), so its weighted Gram matrix is the model's
+ *                        one-off moment Q^T Q minus the rows of the rejected vertices, scaled: one pass over the rejected rows (0.2 % of
+ *                        them at 41k) instead of one over the basis / 0: the pass over the basis.  Same matrix up to the rounding of the
+ *                        subtraction (<= 1e-12); pays while fewer than about a fifth of the rows are rejected.
  * No reference counterpart (the reference has one code path per operation). */
 typedef enum gingr_ctx_option {
     GINGR_OPT_CULL = 0,
     GINGR_OPT_FINE_CULL = 1,
     GINGR_OPT_NN_GRID = 2,
     GINGR_OPT_TRI_GRID = 3,
-    GINGR_OPT_SPLIT_EXCHANGE = 4
+    GINGR_OPT_SPLIT_EXCHANGE = 4,
+    GINGR_OPT_GRAM_DOWNDATE = 5
 } gingr_ctx_option;
 int gingr_ctx_set_option(gingr_ctx *ctx, int32_t option, int32_t value);
 int gingr_ctx_get_option(gingr_ctx *ctx, int32_t option, int32_t *value);

@@ -156,7 +156,8 @@ public final class GingrHipNative {
     public static native int fitterUpdateCpdRccl(long fitter, double w, double lambda, int nIterations);
     public static native int fitterUpdateIcpRccl(long fitter, double initialSigma, double endSigma, int maxIterations, int nIterations);
     /** gingr_ctx_option: 0 cull, 1 fine cull, 2 closest-point grid, 3 triangle grid -- code paths with identical results (tests, timing comparisons);
-     *  4 split column-sum exchange of the native RCCL path (round 5, default off: the first half's all-reduce behind the second half of pass 1) */
+     *  4 split column-sum exchange of the native RCCL path (round 5, default off: the first half's all-reduce behind the second half of pass 1);
+     *  5 surface-ICP Gram matrix as the model's moment minus the rejected rows (-1 default: from 16 384 rows on, 0 never, 1 always) */
     public static native int ctxSetOption(long ctx, int option, int value);
 
     // ---- round 4: every flavour of the update on row shards (0 CPD, 1 ICP point cloud, 2 ICP surface), the sampled proposal

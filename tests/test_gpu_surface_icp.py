@@ -406,3 +406,56 @@ def test_triangle_grid_with_wide_triangles_and_a_flat_mesh_equals_the_tile_scan(
             algo.close()
             c.close()
         assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+def test_gram_downdate_equals_the_pass_over_the_basis(ctx):
+    """GINGR_OPT_GRAM_DOWNDATE: with 0 / 1 weights the weighted Gram matrix is the model's moment minus the rows of the zero-weight
+    vertices (rejected pairs, landmark vertices).  The exchange segment (Gram matrix + right-hand side) of the same state is the one
+    the MFMA pass over the whole basis gives, up to the rounding of the subtraction -- with a quarter of the template rejected (open
+    target) and with landmarks -- and so is the state after an update.  (Trajectories are not compared further: the self-intersection
+    test keeps `intersection point != vertex` as an exact comparison, like the reference, and flips on last-bit differences.)"""
+    import ctypes
+    import gingr_amd as ga
+    from gingr_amd import _native as nat
+    from gingr_amd.sharded import ShardedFitter, as_torch
+    verts, cells = _icosphere(3)
+    ref = np.asarray(verts, dtype=np.float64) * 60.0
+    cells = np.asarray(cells, dtype=np.int32)
+    rng = np.random.default_rng(5)
+    bump = 1.0 + 0.1 * np.sin(4 * verts[:, 0]) * np.cos(3 * verts[:, 1])
+    target = ref * bump[:, None] + np.array([1.0, -0.5, 0.8]) + rng.normal(0, 0.3, ref.shape)
+    tcells = cells[~np.all(verts[cells][:, :, 2] > 0.55, axis=1)]       # a cap removed: the vertices over the hole map to its rim
+    lm_pid = np.array([3, 77, 200], dtype=np.int32)
+    states = ((np.zeros(40), 6.0), (np.linspace(-0.3, 0.3, 40), 5.5))
+    model = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.0, maxRank=40).Gaussian(30.0, 8.0).to_host()   # (built once, on the session's context)
+    got = {}
+    for val in (1, 0):
+        c = ga.Context(0)
+        c.set_option(nat.OPT_GRAM_DOWNDATE, val)
+        assert c.get_option(nat.OPT_GRAM_DOWNDATE) == val
+        f = ShardedFitter(c, model, target)
+        f.set_meshes(cells, tcells)
+        lx, lc = np.ascontiguousarray(target[lm_pid]), np.ascontiguousarray(np.tile(np.eye(3) * 0.5, (3, 1, 1)))
+        assert f._lib.gingr_fitter_set_landmarks(f.handle, 3, nat.iptr(lm_pid), nat.dptr(lx), nat.dptr(lc)) == 0
+        ip = nat.IcpParams(6.0, 1.0, 20)
+        for k, (alpha, s2) in enumerate(states):
+            f.set_state(alpha, s2, iteration=k)
+            for ph in (0, 1):
+                assert f._lib.gingr_fitter_icp_surface_phase_async(f.handle, ctypes.byref(ip), ph) == 0
+            p, offs, cnts = ctypes.c_void_p(), (ctypes.c_int64 * nat.NUM_SEGMENTS)(), (ctypes.c_int64 * nat.NUM_SEGMENTS)()
+            assert f._lib.gingr_fitter_exchange(f.handle, ctypes.byref(p), offs, cnts) == 0
+            c.synchronize()
+            w, cp = np.zeros(len(ref)), np.zeros((len(ref), 3))
+            assert f._lib.gingr_fitter_get_surface_correspondence(f.handle, nat.dptr(cp), nat.dptr(w)) == 0
+            seg = as_torch(p.value, offs[1] + cnts[1], 0).cpu().numpy()[offs[1]:].copy()      # (the whole exchange buffer from its base pointer)
+            assert f._lib.gingr_fitter_icp_surface_phase_async(f.handle, ctypes.byref(ip), 2) == 0
+            a1, sc1, fit1 = f.get_state()
+            got[(val, k)] = (seg, w, a1.copy(), fit1.copy(), sc1.status)
+        f.close()
+        c.close()
+    for k in range(len(states)):
+        (sa, wa, aa, fa, sta), (sb, wb, ab, fb, stb) = got[(1, k)], got[(0, k)]
+        assert np.array_equal(wa, wb) and 0.1 < 1.0 - wb.mean() < 0.6          # the same pairs, a good part of them rejected
+        assert np.max(np.abs(sa - sb)) <= 1e-12 * np.max(np.abs(sb))
+        assert sta == stb == 0
+        assert np.max(np.abs(aa - ab)) <= 1e-10 * max(1.0, np.max(np.abs(ab))) and np.max(np.abs(fa - fb)) <= 1e-10 * np.max(np.abs(fb))
