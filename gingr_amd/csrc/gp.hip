@@ -911,20 +911,26 @@ __global__ __launch_bounds__(256) void gram_downdate_kernel(const double *__rest
             if ((tid & 63) == 0) zmask[4 * r2 + (tid >> 6)] = m;
         }
         __syncthreads();
-        unsigned long long bits[4 * kRounds];  // workgroup-uniform
-#pragma unroll
-        for (int k = 0; k < 4 * kRounds; ++k) bits[k] = zmask[k];
+        // the mask words are walked in scalar registers (workgroup-uniform: a dynamically indexed per-lane copy of the sixteen words
+        // would be a chain of selects per access -- it was most of this kernel's time)
+        auto word = [&](int k) {
+            const unsigned long long v = zmask[k];
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)), lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+            return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+        };
         int w = 0;
+        unsigned long long cur = word(0);
         for (;;) {
             int64_t vz[kBatch];
             int nb = 0;
-            while (nb < kBatch && w < 4 * kRounds) {  // the next (up to) kBatch zero-weight vertices, ascending
-                if (bits[w] == 0) {
-                    ++w;
+            while (nb < kBatch) {  // the next (up to) kBatch zero-weight vertices, ascending
+                if (cur == 0) {
+                    if (++w >= 4 * kRounds) break;
+                    cur = word(w);
                     continue;
                 }
-                vz[nb++] = base + 64 * w + __builtin_ctzll(bits[w]);
-                bits[w] &= bits[w] - 1;
+                vz[nb++] = base + 64 * w + __builtin_ctzll(cur);
+                cur &= cur - 1;
             }
             if (nb == 0) break;
             __syncthreads();  // (the previous batch's rows have been used)
