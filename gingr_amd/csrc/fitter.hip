@@ -402,7 +402,7 @@ void refresh_fit(gingr_fitter *f) {
     SweepArgs a = base_args(f);
     a.coef0 = f->alpha;
     a.shape_out = f->fit;
-    if (f->fboxes && f->m->rp <= 128 && f->cpd_seen) {  // the pass also leaves the quarter boxes and the |coordinate - centre| maximum
+    if (f->fboxes && f->m->rp <= 512 && f->cpd_seen) {  // the pass also leaves the quarter boxes and the |coordinate - centre| maximum
         a.qboxes = f->fboxes + 6 * ceil_div(f->m->M, 256);
         a.box_centre = f->absmax + 2;
         a.absmax_slot = f->absmax + 1;
@@ -411,7 +411,7 @@ void refresh_fit(gingr_fitter *f) {
     } else {
         launch_sweep(f->ctx, SWEEP_FIT, a);
         f->fit_boxes_valid = false;
-        if (f->cpd_seen) fit_boxes_now(f);  // rank > 128: the generic pass, the boxes by a launch of their own
+        if (f->cpd_seen) fit_boxes_now(f);  // rank > 512: the generic pass, the boxes by a launch of their own
     }
 }
 
@@ -541,7 +541,7 @@ int model_create_impl(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doubl
         gingr_model_destroy(m);
         return code;
     };
-    if ((rc = dev_alloc(ctx, &m->Q0, (size_t)3 * M * m->rp)) || (rc = dev_alloc(ctx, &m->ref, (size_t)3 * M)) ||
+    if ((rc = dev_alloc(ctx, &m->Q0, (size_t)(3 * M + kBasisRowSlack) * m->rp)) || (rc = dev_alloc(ctx, &m->ref, (size_t)3 * M)) ||
         (rc = dev_alloc(ctx, &m->mean, (size_t)3 * M)) || (rc = dev_alloc(ctx, &m->mom, (size_t)MomentLayout{m->rp}.total())) ||
         (rc = dev_alloc(ctx, &m->Binv, (size_t)m->rp * m->rp)) || (rc = dev_alloc(ctx, &m->eigV, (size_t)m->r * m->r)) ||
         (rc = dev_alloc(ctx, &m->eigL, (size_t)m->r)) ||
@@ -562,6 +562,7 @@ int model_create_impl(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doubl
             hipMemcpy(m->iperm, m->hiperm.data(), (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
             return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: permutation copy failed"));
     }
+    (void)hipMemsetAsync(m->Q0 + (size_t)3 * M * m->rp, 0, (size_t)kBasisRowSlack * m->rp * sizeof(double), ctx->stream);
     if ((rc = fill_basis(m))) return fail(rc);
     (void)hipMemcpyAsync(aos.p, ref + 3 * row_begin, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     launch_aos_to_soa(ctx, aos.as<double>(), M, m->ref, m->perm);

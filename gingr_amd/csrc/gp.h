@@ -94,11 +94,15 @@ struct PostVec {
     static constexpr int kZRows = 28;
 };
 
+// Zero rows behind the last basis row of every model (model_create_impl allocates and clears them): the wide Gram pass
+// (gp_wide.hip) fetches whole 16-row steps, two of them ahead, without clamping its addresses.
+constexpr int kBasisRowSlack = 48;
+
 struct gingr_model {
     gingr_ctx *ctx = nullptr;
     int64_t M_total = 0, row_begin = 0, row_end = 0, M = 0;  // M = local points
     int32_t r = 0, rp = 0;                                    // rank and rank padded to a multiple of 16
-    double *Q0 = nullptr;     // [3M][rp] row-major, Q0[row][k] = U[row][k] * sqrt(lambda_k), zero padded
+    double *Q0 = nullptr;     // [3M + kBasisRowSlack][rp] row-major, Q0[row][k] = U[row][k] * sqrt(lambda_k), zero padded
     double *ref = nullptr;    // SoA [3][M]
     double *mean = nullptr;   // SoA [3][M]
     double *mom = nullptr;    // MomentLayout: local sums until finalize (the exchange buffer of the one-off all-reduce)
@@ -212,6 +216,13 @@ int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const d
                 const double *evec = nullptr, double *rhs_partial = nullptr, bool *rhs_done = nullptr);
 // evec ([3][M] planes) + rhs_partial ([slabs][rp]) + rhs_done: when the triangle kernel runs (rp <= 112) it also leaves the slab
 // partials of Q0^T evec and sets *rhs_done -- the caller then skips its SWEEP_RHS pass and reduces over the returned slab count.
+
+// gp_wide.hip: the same partials for rp >= 128 (eight waves share the triangle, several workgroups per slab past 136 tiles); the
+// right-hand-side partials always ride along when rhs_partial is given.  ws: gram_wide_ws_doubles(M, rp) doubles (slab partials, then
+// the row-indexed {w, e} array of row_expand_kernel).  Returns the slab count.
+int64_t gram_wide_ws_doubles(int64_t M, int32_t rp);
+int launch_gram_wide(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, const double *evec,
+                     double *rhs_partial);
 
 // one launch for the reductions at the end of phase 1 (gp.hip: phase1_finalize_kernel)
 struct Phase1FinalizeArgs {

@@ -303,8 +303,13 @@ __global__ __launch_bounds__(256) void block_partials_reduce_kernel(const double
 // requested before the first is used -- and leaves the bounding box of each quarter behind, plus the largest |coordinate - centre|
 // of the cloud: what tile_bbox_kernel computed for the column-sum pass of the next iteration in a launch of its own (5 us + a kernel
 // boundary per iteration; exact minima / maxima, so the same bits).  KM >= rp / 16.
-template <int KM>
+// S points per 16-lane group in flight (4 for KM <= 8: the whole quarter at once; 1 above: the basis rows of a point are 3 KM values
+// per lane, requested eight column blocks at a time -- ranks above 128 keep the quarter-box form with the registers of three waves per
+// SIMD instead of falling back to the generic pass + a box launch of its own).
+template <int KM, int S>
 __global__ __launch_bounds__(kSweepThreads) void sweep_fit_boxes_kernel(SweepArgs a) {
+    constexpr int CH = KM < 8 ? KM : 8;  // column blocks per request
+    static_assert(4 % S == 0, "points per group and round");
     extern __shared__ double lds[];  // [rp] coefficients, then [16][8] box scratch + 8
     const int tid = threadIdx.x, lane16 = tid & 15, grp = tid >> 4;
     const int rp = a.rp, km = rp >> 4;
@@ -324,46 +329,59 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_fit_boxes_kernel(SweepArg
     for (int m = 0; m < KM; ++m) cf[m] = m < km ? coef[m * 16 + lane16] : 0.0;
     double amax = 0.0;
     for (int64_t qd = blockIdx.x; qd * 64 < M; qd += gridDim.x) {
-        double u[4][3][KM], rm[4][3];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {  // every load of the quarter in flight
-            const int64_t p = qd * 64 + s * kGroups + grp;
-            const int64_t pc = p < M ? p : 0;
-            const double *q0 = a.Q0 + (3 * pc) * rp + lane16;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-#pragma unroll
-                for (int m = 0; m < KM; ++m) u[s][d][m] = m < km ? q0[d * rp + m * 16] : 0.0;
-                rm[s][d] = a.ref[d * M + pc] + a.mean[d * M + pc];
-            }
-        }
         double lo[3] = {__builtin_huge_val(), __builtin_huge_val(), __builtin_huge_val()};
         double hi[3] = {-__builtin_huge_val(), -__builtin_huge_val(), -__builtin_huge_val()};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int64_t p = qd * 64 + s * kGroups + grp;
-            double f[3];
+        for (int s0 = 0; s0 < 4; s0 += S) {
+            double facc[S][3], rm[S][3];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                double acc = 0.0;
+            for (int s = 0; s < S; ++s)
 #pragma unroll
-                for (int m = 0; m < KM; ++m) acc = __builtin_fma(u[s][d][m], cf[m], acc);  // (m >= km: 0 * 0)
-                f[d] = group16_sum(acc);
-            }
-            // fit = s * (R (inst - c) + c + t)       ModelFittingParameters.scala:130-143
-            const double ix = rm[s][0] + f[0] - cen[0], iy = rm[s][1] + f[1] - cen[1], iz = rm[s][2] + f[2] - cen[2];
-            const double nx = scale * (R[0] * ix + R[1] * iy + R[2] * iz + cen[0] + tr[0]);
-            const double ny = scale * (R[3] * ix + R[4] * iy + R[5] * iz + cen[1] + tr[1]);
-            const double nz = scale * (R[6] * ix + R[7] * iy + R[8] * iz + cen[2] + tr[2]);
-            if (p < M) {
-                if (lane16 == 0) {
-                    a.shape_out[p] = nx;
-                    a.shape_out[M + p] = ny;
-                    a.shape_out[2 * M + p] = nz;
+                for (int d = 0; d < 3; ++d) facc[s][d] = 0.0;
+#pragma unroll
+            for (int mc = 0; mc < KM; mc += CH) {
+                double u[S][3][CH];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {  // every load of the round's column blocks in flight
+                    const int64_t p = qd * 64 + (s0 + s) * kGroups + grp;
+                    const int64_t pc = p < M ? p : 0;
+                    const double *q0 = a.Q0 + (3 * pc) * rp + lane16;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+                        for (int m = 0; m < CH; ++m) u[s][d][m] = (mc + m < KM && mc + m < km) ? q0[d * rp + (mc + m) * 16] : 0.0;
+                        if (mc == 0) rm[s][d] = a.ref[d * M + pc] + a.mean[d * M + pc];
+                    }
                 }
-                // (fmin / fmax skip a NaN coordinate: it never widens a box, as in tile_bbox_kernel)
-                lo[0] = fmin(lo[0], nx), lo[1] = fmin(lo[1], ny), lo[2] = fmin(lo[2], nz);
-                hi[0] = fmax(hi[0], nx), hi[1] = fmax(hi[1], ny), hi[2] = fmax(hi[2], nz);
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+#pragma unroll
+                        for (int m = 0; m < CH; ++m)
+                            if (mc + m < KM) facc[s][d] = __builtin_fma(u[s][d][m], cf[mc + m], facc[s][d]);  // (m >= km: 0 * 0)
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int64_t p = qd * 64 + (s0 + s) * kGroups + grp;
+                double f[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) f[d] = group16_sum(facc[s][d]);
+                // fit = s * (R (inst - c) + c + t)       ModelFittingParameters.scala:130-143
+                const double ix = rm[s][0] + f[0] - cen[0], iy = rm[s][1] + f[1] - cen[1], iz = rm[s][2] + f[2] - cen[2];
+                const double nx = scale * (R[0] * ix + R[1] * iy + R[2] * iz + cen[0] + tr[0]);
+                const double ny = scale * (R[3] * ix + R[4] * iy + R[5] * iz + cen[1] + tr[1]);
+                const double nz = scale * (R[6] * ix + R[7] * iy + R[8] * iz + cen[2] + tr[2]);
+                if (p < M) {
+                    if (lane16 == 0) {
+                        a.shape_out[p] = nx;
+                        a.shape_out[M + p] = ny;
+                        a.shape_out[2 * M + p] = nz;
+                    }
+                    // (fmin / fmax skip a NaN coordinate: it never widens a box, as in tile_bbox_kernel)
+                    lo[0] = fmin(lo[0], nx), lo[1] = fmin(lo[1], ny), lo[2] = fmin(lo[2], nz);
+                    hi[0] = fmax(hi[0], nx), hi[1] = fmax(hi[1], ny), hi[2] = fmax(hi[2], nz);
+                }
             }
         }
         if (lane16 == 0) {
@@ -1642,6 +1660,199 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_solve_lds_kernel(int 
 #endif
 }
 
+// ---- ranks above 128: the bordered matrix (n + 16 rows) does not fit the LDS.  One workgroup of eight waves factors it by SUPER-PANELS
+// of SW columns, left-looking: for panel k (columns kb .. kb + SW) every 16 x 16 tile of the rows kb .. n + 16 is formed as
+//     (I + G)[tile] - L[rows, 0 : kb] L[panel rows, 0 : kb]^T
+// on the matrix pipe straight from the factor already written to the global workspace (L2 resident; fragments read as in
+// lds_cholesky's tile_update) and lands in LDS, where lds_cholesky factors the SW x SW head and lets the rows below ride along -- the
+// same building blocks, the same bordered form (row n carries the right-hand side through the forward substitution).  The panel then
+// goes back to the workspace.  The backward substitution walks the panels bottom-up: a mat-vec with the rows below from the
+// workspace, lds_backward on the diagonal block.  Until round 5 the LDS kernel ran on the global workspace through flat addressing,
+// one 16-column panel at a time: 265 us at r = 256, 1.46 ms at r = 512 (profiles/r06_base_rank256_512_kernel_stats.txt).
+constexpr int kWideSolveThreads = 512;
+
+template <int SW>
+__global__ __launch_bounds__(kWideSolveThreads) void posterior_solve_wide_kernel(int r, int n, const double *__restrict__ G,
+                                                                                 const double *__restrict__ rhs,
+                                                                                 const double *__restrict__ zrand, double *__restrict__ a,
+                                                                                 DevState *__restrict__ st, double *gw) {
+    extern __shared__ double P[];  // the panel: [rows][SW + 1]
+    constexpr int ldp = SW + 1, NW = kWideSolveThreads / 64;
+    __shared__ double rdl[SW];
+    __shared__ double red[2][NW][SW];
+    __shared__ double xs[2][512];  // x = L^-T y and, when sampling, L^-T z (n <= 512)
+    __shared__ double yv[2][SW];
+    __shared__ int bad_spd, bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    double *Lg = gw;                          // [(n + 16)][n]: the factor, then the bordered rows
+    double *rdg = gw + (size_t)(n + kNB) * n;  // [n] reciprocal diagonal
+    const int nvec = zrand ? 2 : 1;
+    if (tid == 0) bad_spd = 0, bad = 0;
+    GINGR_STAGE_CLOCK(7)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    constexpr int NTJ = SW / 16;                                // tile columns of a panel
+    constexpr int TSTEP = NW / NTJ;                             // wave w owns tile column w % NTJ, tile rows w / NTJ + TSTEP q
+    constexpr int TACC = SW == 64 ? 9 : 9;                      // tiles per wave, at most: ceil((n + 16) / 16 / TSTEP), n <= 256 (512)
+    constexpr int HALF = SW / 2;                                // 16-byte units per staged row
+    constexpr int RSTEP = kWideSolveThreads / HALF;             // rows a staging round covers
+    constexpr int PRE = 17;                                     // staging rounds, at most: ceil((n + 16) / RSTEP), n <= 256 (512)
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int my_tj = wv % NTJ, ti0 = wv / NTJ;
+    // the bordered rows of the workspace: the right-hand side, fifteen zero rows (they ride through every panel)
+    for (int e = tid; e < kNB * n; e += kWideSolveThreads) Lg[(size_t)n * n + e] = e < r ? rhs[e] : 0.0;
+    __syncthreads();
+    const int srow = tid / HALF, scp = tid % HALF;              // this thread's row (per round) and column pair of a staged slice
+    for (int kb = 0; kb < n; kb += SW) {
+        const int sw = min(SW, n - kb), rows = n - kb + kNB;
+        const int nti = rows >> 4, ntj = sw >> 4;
+        // The panel's tiles, C - L[rows, 0 : kb] L[panel rows, 0 : kb]^T, accumulate in registers while the panel's LDS block stages
+        // the operands: the factor's columns go through it SW at a time (coalesced 16-byte loads, the next slice requested before the
+        // MFMAs of the current one), and C = I + G (bordered rows: the right-hand side) goes through it last and stays, minus the
+        // accumulated products.
+        // (Fragments fetched straight from the workspace, 8 bytes per lane and sixteen rows per instruction, made this stage 62 % of
+        // the kernel: 354k cycles at r = 256.)
+        v4f64 acc[TACC];
+#pragma unroll
+        for (int q = 0; q < TACC; ++q) acc[q] = v4f64{0, 0, 0, 0};
+        const bool col_live = my_tj < ntj;
+        const int nsl = kb / SW;  // slices of the factor; slice nsl is C
+        d2 pre[PRE];
+        auto fetch_slice = [&](int sl) __attribute__((always_inline)) {
+            // slice nsl is C itself: the same rows and row stride, read from G; the bordered rows always come from the workspace
+            const bool is_c = sl == nsl;
+            const int col = sl * SW + 2 * scp;  // (== kb + 2 scp for C)
+            const double *base = (is_c ? G : Lg) + col;
+#pragma unroll
+            for (int u = 0; u < PRE; ++u) {
+                const int gi = kb + srow + u * RSTEP;
+                if (gi < n + kNB) pre[u] = *reinterpret_cast<const d2 *>((gi < n ? base : Lg + col) + (size_t)gi * n);
+            }
+            if (is_c) {  // workgroup-uniform.  Mm = QtL Q + I, identity on the padding   (scalismo genericRegressionComputations)
+#pragma unroll
+                for (int u = 0; u < PRE; ++u) {
+                    const int gi = kb + srow + u * RSTEP;
+                    if (gi < n) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const double one = gi == col + h ? 1.0 : 0.0;
+                            pre[u][h] = (gi < r && col + h < r) ? pre[u][h] + one : one;
+                        }
+                    }
+                }
+            }
+        };
+        fetch_slice(0);
+        for (int sl = 0; sl <= nsl; ++sl) {
+            __syncthreads();  // (the previous slice, or the previous panel's write-back, has been read)
+#pragma unroll
+            for (int u = 0; u < PRE; ++u)
+                if (srow + u * RSTEP < rows) {
+                    P[(srow + u * RSTEP) * ldp + 2 * scp] = pre[u][0];
+                    P[(srow + u * RSTEP) * ldp + 2 * scp + 1] = pre[u][1];
+                }
+            __syncthreads();
+            if (sl == nsl) break;
+            fetch_slice(sl + 1);
+            if (col_live) {  // wave-uniform
+                const double *pb = P + (16 * my_tj + l15) * ldp + l4;
+#pragma unroll
+                for (int q = 0; q < TACC; ++q) {
+                    const int ti = ti0 + TSTEP * q;
+                    if (ti < nti && ti >= my_tj) {  // wave-uniform; strictly above the diagonal: nobody reads it
+                        const double *pa = P + (16 * ti + l15) * ldp + l4;
+#pragma unroll 8
+                        for (int u = 0; u < SW / 4; ++u) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * u], pb[4 * u], acc[q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (kb > 0 && col_live) {
+#pragma unroll
+            for (int q = 0; q < TACC; ++q) {
+                const int ti = ti0 + TSTEP * q;
+                if (ti < nti && ti >= my_tj) {
+                    double *pc = P + (16 * ti + l4) * ldp + 16 * my_tj + l15;  // D[i = l4 + 4 g][j = l15]
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) pc[4 * g * ldp] -= acc[q][g];
+                }
+            }
+        }
+        __syncthreads();
+        GINGR_STAGE_CLOCK(0)
+        lds_cholesky<kWideSolveThreads>(P, ldp, sw, rdl, &bad_spd, rows - sw);
+        {   // the panel goes back to the workspace
+            const int j = tid % SW;
+            if (j < sw)
+                for (int i = tid / SW; i < rows; i += kWideSolveThreads / SW) Lg[(size_t)(kb + i) * n + kb + j] = P[i * ldp + j];
+        }
+        if (tid < sw) rdg[kb + tid] = rdl[tid];
+        GINGR_STAGE_CLOCK(4)
+    }
+    __syncthreads();
+    // x = L^-T y: y = row n of the workspace (L^-1 rhs); the sampling direction L^-T z rides along
+    const int kb_last = ((n - 1) / SW) * SW;
+    for (int kb = kb_last; kb >= 0; kb -= SW) {
+        const int sw = min(SW, n - kb);
+        {   // t_c = y_c - sum over the rows j below the block of L[j][kb + c] x_j: NW row groups, combined in order
+            const int c = tid % SW, g = tid / SW;
+            constexpr int NG = kWideSolveThreads / SW;
+            double s0 = 0.0, s1 = 0.0;
+            if (c < sw)
+                for (int j = kb + sw + g; j < n; j += NG) {
+                    const double l = Lg[(size_t)j * n + kb + c];
+                    s0 = __builtin_fma(l, xs[0][j], s0);
+                    if (nvec == 2) s1 = __builtin_fma(l, xs[1][j], s1);
+                }
+            // (NG row groups of SW columns: the first NW of them land in red, the others are added by their owners below)
+            static_assert(NG == NW || NG == 2 * NW, "row groups of the backward mat-vec");
+            if (NG == 2 * NW) {
+                s0 += __shfl_xor(s0, 32);  // SW = 32: groups g and g + 1 share a wave
+                s1 += __shfl_xor(s1, 32);
+            }
+            if (NG == NW || (lane < 32)) {
+                red[0][wave][c] = s0;
+                red[1][wave][c] = s1;
+            }
+        }
+        {
+            const int j = tid % SW;
+            if (j < sw)
+                for (int i = tid / SW; i < sw; i += kWideSolveThreads / SW) P[i * ldp + j] = Lg[(size_t)(kb + i) * n + kb + j];
+        }
+        if (tid < sw) rdl[tid] = rdg[kb + tid];
+        __syncthreads();
+        if (tid < sw) {
+            for (int v = 0; v < nvec; ++v) {
+                double t = v == 0 ? Lg[(size_t)n * n + kb + tid] : (kb + tid < r ? zrand[kb + tid] : 0.0);
+                for (int w = 0; w < NW; ++w) t -= red[v][w][tid];
+                yv[v][tid] = t;
+            }
+        }
+        __syncthreads();
+        lds_backward<kWideSolveThreads>(P, ldp, sw, rdl, yv[0]);
+        if (nvec == 2) lds_backward<kWideSolveThreads>(P, ldp, sw, rdl, yv[1]);
+        if (tid < sw) {
+            xs[0][kb + tid] = yv[0][tid];
+            xs[1][kb + tid] = nvec == 2 ? yv[1][tid] : 0.0;
+        }
+        __syncthreads();
+    }
+    GINGR_STAGE_CLOCK(5)
+    GINGR_STAGE_CLOCK(6)
+    for (int k = tid; k < n; k += kWideSolveThreads) {
+        const double v = k < r ? xs[0][k] + xs[1][k] : 0.0;
+        a[k] = v;
+        if (!finite_d(v)) bad = 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (bad_spd)
+            st->err = GINGR_ERR_NOT_SPD;
+        else if (bad)
+            st->err = GINGR_ERR_NONFINITE;
+    }
+}
+
 // ---- pieces shared by the three transition-density kernels (256 threads: 128 entries x 2 column halves) -------------------------
 // u[k] = qte[k] - (S_tot a)[k]: two threads per entry (column halves of the symmetric S_tot: coalesced), four loads in flight.
 // Ends with the entries written but NOT yet synchronised.
@@ -2330,16 +2541,24 @@ int64_t sweep_ws_doubles(int64_t M, int32_t rp) {
 
 template <int MODE>
 static void launch_sweep_mode(gingr_ctx *ctx, const SweepArgs &a, int width) {
-    if (MODE == SWEEP_FIT && a.qboxes && a.rp <= 128) {  // one workgroup per 64-point quarter (gp.h: SweepArgs::qboxes)
+    if (MODE == SWEEP_FIT && a.qboxes && a.rp <= 512) {  // one workgroup per 64-point quarter (gp.h: SweepArgs::qboxes)
         const int nq = (int)std::min<int64_t>(4096, ceil_div(a.M, 64));
         const size_t l2 = (size_t)(a.rp + kGroups * 8 + 8) * sizeof(double);
         TimerScope ts(ctx, 4);
         if (a.rp <= 64)
-            hipLaunchKernelGGL(sweep_fit_boxes_kernel<4>, dim3(nq), dim3(kSweepThreads), l2, ctx->stream, a);
+            hipLaunchKernelGGL((sweep_fit_boxes_kernel<4, 4>), dim3(nq), dim3(kSweepThreads), l2, ctx->stream, a);
         else if (a.rp <= 112)  // (rank 100: 84 basis values per thread in flight; eight column blocks would spill into AGPRs)
-            hipLaunchKernelGGL(sweep_fit_boxes_kernel<7>, dim3(nq), dim3(kSweepThreads), l2, ctx->stream, a);
+            hipLaunchKernelGGL((sweep_fit_boxes_kernel<7, 4>), dim3(nq), dim3(kSweepThreads), l2, ctx->stream, a);
+        else if (a.rp <= 128)
+            hipLaunchKernelGGL((sweep_fit_boxes_kernel<8, 4>), dim3(nq), dim3(kSweepThreads), l2, ctx->stream, a);
+        else if (a.rp <= 192)
+            hipLaunchKernelGGL((sweep_fit_boxes_kernel<12, 1>), dim3(nq), dim3(kSweepThreads), l2, ctx->stream, a);
+        else if (a.rp <= 256)
+            hipLaunchKernelGGL((sweep_fit_boxes_kernel<16, 1>), dim3(nq), dim3(kSweepThreads), l2, ctx->stream, a);
+        else if (a.rp <= 384)
+            hipLaunchKernelGGL((sweep_fit_boxes_kernel<24, 1>), dim3(nq), dim3(kSweepThreads), l2, ctx->stream, a);
         else
-            hipLaunchKernelGGL(sweep_fit_boxes_kernel<8>, dim3(nq), dim3(kSweepThreads), l2, ctx->stream, a);
+            hipLaunchKernelGGL((sweep_fit_boxes_kernel<32, 1>), dim3(nq), dim3(kSweepThreads), l2, ctx->stream, a);
         return;
     }
     const int nb = sweep_num_blocks(a.M);
@@ -2398,7 +2617,8 @@ int64_t gram_ws_doubles(int64_t M, int32_t rp) {
     int64_t rps;
     gram_plan(M, rp, &nbp, &npatch, &nslabs, &rps);
     gram_tri_plan(M, &nslabs_tri, &rps);
-    return (int64_t)std::max(nslabs, nslabs_tri) * rp * rp;
+    const int64_t n = (int64_t)std::max(nslabs, nslabs_tri) * rp * rp;
+    return rp >= 128 ? std::max(n, gram_wide_ws_doubles(M, rp)) : n;
 }
 
 int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, double *G, const double *evec,
@@ -2440,8 +2660,10 @@ int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const d
             }
 #undef GINGR_GRAM_TRI
         } else {
-            hipLaunchKernelGGL(gram_kernel, dim3(nslabs, npatch), dim3(256), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, nbp,
-                               1, 0, 0, 0, ws);
+            // rp >= 128: eight waves share the triangle (gp_wide.hip); the right-hand side rides along whenever it is asked for
+            const bool fuse = evec && rhs_partial && rhs_done;
+            if (fuse) *rhs_done = true;
+            nslabs = launch_gram_wide(ctx, Q0, M, rp, weight, ws, fuse ? evec : nullptr, fuse ? rhs_partial : nullptr);
         }
     }
     if (G)  // nullptr: the caller reduces the slab partials itself (launch_phase1_finalize with the returned slab count)
@@ -2538,8 +2760,17 @@ void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
             go(posterior_solve_lds_kernel<1>);
         return;
     }
-    // r > 128: the bordered matrix does not fit the LDS; same kernel on the global workspace (posterior_work_doubles)
-    hipLaunchKernelGGL(posterior_solve_lds_kernel<2>, dim3(1), dim3(kSolveThreads), 0, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a, st, work);
+    // r > 128: the bordered matrix does not fit the LDS; super-panels of 64 (rp <= 256) or 32 columns on the global workspace
+    // (posterior_work_doubles)
+    auto gow = [&](auto kern, int sw) {
+        const size_t lds = (size_t)(rp + kNB) * (sw + 1) * sizeof(double);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(kWideSolveThreads), lds, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a, st, work);
+    };
+    if (rp <= 256)
+        gow(posterior_solve_wide_kernel<64>, 64);
+    else
+        gow(posterior_solve_wide_kernel<32>, 32);
 }
 
 namespace {
