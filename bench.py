@@ -690,32 +690,48 @@ def main():
             kernels.append({"kernel": name, "avg_ms": avg, "launches": n, "bound": "valu_f64",
                             "achieved": ach, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / F64_VALU_PEAK_TFLOPS, "algorithmic_flops_per_pair": flops_per_pair})
+    # Secondary kernels, with SURVEY 8d's formulas at the MODEL rank r (not the padded rank rp the kernels stream and multiply):
+    #   Gram: 3 M r^2 flops SYRK-halved -- what a triangle-only kernel has to issue, and `frac`; 6 M r^2 (full symmetric) as a note;
+    #         its pass over the basis is 24 M r bytes, quoted against the HBM peak next to it (neither bound is near saturation
+    #         at r = 100; the matrix pipe is the binding one from r = 256 on);
+    #   sweeps: 24 M r bytes.
+    r_model = args.rank
+    rp = (args.rank + 15) // 16 * 16
+    wide = rp >= 128
     ms, n = timing(2)
     if n:
         avg = ms / n
-        rp = (args.rank + 15) // 16 * 16
-        ach = 6.0 * m_loc * rp * rp / (avg * 1e-3) / 1e12
-        kernels.append({"kernel": "gram_kernel", "avg_ms": avg, "launches": n, "bound": "mfma",
-                        "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / F64_MFMA_PEAK_TFLOPS,
-                        "note": "algorithmic flops of the full symmetric product (6 M rp^2); the kernel multiplies the upper triangle "
-                                "only, so the matrix pipe issues about half of them",
-                        "issued_flops_frac_of_peak": (ach * (rp / 16 + 1) / (2.0 * rp / 16)) / F64_MFMA_PEAK_TFLOPS,
+        gram_name = "gram_wide_kernel" if wide else "gram_tri_kernel"
+        ach_half = 3.0 * m_loc * r_model * r_model / (avg * 1e-3) / 1e12
+        hbm = 24.0 * m_loc * r_model / (avg * 1e-3) / 1e9
+        kernels.append({"kernel": gram_name, "avg_ms": avg, "launches": n, "bound": "mfma",
+                        "achieved": ach_half, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach_half / F64_MFMA_PEAK_TFLOPS,
+                        "algorithmic_flops": 3.0 * m_loc * r_model * r_model,
+                        "note": "SYRK-halved count 3 M r^2 at the model rank (the kernel multiplies the upper triangle only); "
+                                "full_symmetric_* is SURVEY 8d's 6 M r^2 count of the same launch",
+                        "full_symmetric_achieved": 2.0 * ach_half, "full_symmetric_frac": 2.0 * ach_half / F64_MFMA_PEAK_TFLOPS,
+                        "hbm_achieved_GBs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS, "algorithmic_bytes": 24.0 * m_loc * r_model,
+                        "padded_rank": rp,
                         # busy cycles of the matrix pipe / (SIMDs x kernel cycles) from the SQ counters (tracked artefact), next to
                         # the time-derived fractions above
-                        "mfma_counters": load_pmc_mfma("gram_tri_kernel", M, args.rank) if n_shards == 1 and not args.emulate_world else None})
+                        "mfma_counters": load_pmc_mfma(gram_name, M, args.rank) if n_shards == 1 and not args.emulate_world else None})
     ms, n = timing(4)
     if n:
         avg = ms / n
-        rp = (args.rank + 15) // 16 * 16
-        gbs = 24.0 * m_loc * rp / (avg * 1e-3) / 1e9
+        gbs = 24.0 * m_loc * r_model / (avg * 1e-3) / 1e9
         tr, src = load_pmc_traffic("sweep_fit_boxes_kernel", M, args.rank) if n_shards == 1 else (None, None)
         kernels.append({"kernel": "sweep_fit_boxes_kernel", "avg_ms": avg, "launches": n, "bound": "hbm", "achieved": gbs,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "algorithmic_bytes": 24.0 * m_loc * rp, "traffic": tr, "traffic_source": src})
+                        "algorithmic_bytes": 24.0 * m_loc * r_model, "padded_rank": rp, "traffic": tr, "traffic_source": src})
     ms, n = timing(5)
     if n:
-        kernels.append({"kernel": "posterior_solve_lds_kernel", "avg_ms": ms / n, "launches": n, "bound": "latency"})
+        solve_name = ("posterior_solve_wide_kernel" if rp > 128 else "posterior_solve_lds_kernel")
+        kernels.append({"kernel": solve_name, "avg_ms": ms / n, "launches": n, "bound": "latency",
+                        "note": "one workgroup: r^3 / 3 flops on the critical path of the iteration"})
+    # (the whole update as HIP events see it DURING these instrumented iterations: the per-kernel event pairs serialise the
+    # launches, and the iterations sit at a later sigma2 than the timed ones -- so it is an upper bracket of ms_per_step, not a
+    # second measurement of it)
     ms, n = timing(3)
     upd_ms = ms / n if n else None
     # ---- the two exchanges of an iteration as this rank / shard 0 sees them (HIP events on the kernels' stream around the collective
@@ -849,7 +865,8 @@ def main():
             "parity_check": parity,
             "shard_consistency": shard_check,
             "sigma2_after_timed_steps": sigma2_timed,
-            "update_ms_device": upd_ms,
+            "instrumented_update_ms": {"value": upd_ms, "note": "mean of the roofline iterations with per-kernel HIP events on (they "
+                                       "serialise the launches; later sigma2 than the timed steps): an upper bracket of ms_per_step"},
             # host time to enqueue one step (12 kernel launches, no synchronisation inside): what a HIP graph could save at most
             "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
             "rccl_ranks": ranks_info,

@@ -181,8 +181,12 @@ struct gingr_fitter {
     // ... or, where the host has a real all-gather (RCCL: rccl_exchange.hip; gingr_fitter_gather_stage / _finish): the shard's rows go
     // into ITS slot of gstage [world][3][chunk] (original row order, chunk = ceil(M_total / world)), the slots are all-gathered in
     // place and one kernel spreads them over the planes of `fullfit` -- half the wire bytes of the zero-padded all-reduce, no sum
+    int32_t *zero_counts = nullptr;  // [ceil(M / 256)] zero-weight vertices per block of the surface observations (gp.h: ZeroGate)
     double *gstage = nullptr;
     int gstage_world = 0;
+    // what the ranks agreed on for this (model, meshes, world): -1 not asked yet, 0 the zero-padded all-reduce, 1 the all-gather
+    // (rccl_exchange.hip: the choice between two different collectives must be the same on every rank)
+    int gather_agreed = -1, gather_agreed_world = 0;
     bool sharded() const { return m->M != m->M_total; }
     int32_t *retry = nullptr;  // device word: retryCounter of the algorithm instance this fitter stands for (GingrAlgorithm.scala:69-70)
     // ---- one Metropolis-Hastings step per call (gingr_fitter_mh_step): the state x the step started from stays on the device --
@@ -424,6 +428,7 @@ void free_meshes(gingr_fitter *f) {
     f->rmvn = f->rfboxes = f->rtvn_loc = f->revsum = f->gsorted = nullptr;
     f->gperm = f->rnn_pos = f->rtri_pos = nullptr;
     f->rnn_warm = f->rtri_warm = false;
+    f->gather_agreed = -1;  // (new meshes: the ranks agree again)
     f->rq0 = f->rqn = 0;
     f->rws = nullptr;
     f->mtri_orig = f->mboundary = f->rnn = f->rpre = f->rhit = f->rkeys = f->rvals = f->rskeys = f->rsvals = nullptr;
@@ -706,6 +711,7 @@ int gingr_fitter_create(gingr_ctx *ctx, const gingr_model *model, gingr_fitter *
     if ((rc = dev_alloc(ctx, &f->fit, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->P1, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->PX, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->nn_idx, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->nn_d2, (size_t)M)) || (rc = dev_alloc(ctx, &f->weight, (size_t)M)) ||
+        (rc = dev_alloc(ctx, &f->zero_counts, (size_t)ceil_div(M, 256))) ||
         (rc = dev_alloc(ctx, &f->evec, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->newshape, (size_t)3 * M)) ||
         (rc = dev_alloc(ctx, &f->state_block, (size_t)rp + kScalarsDoubles + kDevStateDoubles + 8)) || (rc = dev_alloc(ctx, &f->acoef, (size_t)rp)) ||
         (rc = dev_alloc(ctx, &f->fxbuf[0], (size_t)rp * rp + 2 * rp)) || (rc = dev_alloc(ctx, &f->fxbuf[1], (size_t)rp * rp + 2 * rp)) ||
@@ -798,6 +804,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->xch);
     dev_free(f->fullfit);
     dev_free(f->gstage);
+    dev_free(f->zero_counts);
     dev_free(f->ws);
     dev_free(f->work);
     dev_free(f->aos);
@@ -1180,6 +1187,19 @@ int fitter_set_zrand(gingr_fitter *f, const double *z) {
     return GINGR_OK;
 }
 gingr_ctx *fitter_ctx(gingr_fitter *f) { return f->ctx; }
+// this shard's rows are shard `rank` of the balanced partition over `world` shards, and it has the gathered-fit buffer (pure check)
+bool fitter_gather_possible(gingr_fitter *f, int32_t world, int32_t rank) {
+    if (!f || !f->fullfit || world < 1 || rank < 0 || rank >= world) return false;
+    const gingr_model *m = f->m;
+    const int64_t Mt = m->M_total, base = Mt / world, extra = Mt % world;
+    const int64_t b = rank * base + (rank < extra ? rank : extra), e = b + base + (rank < extra ? 1 : 0);
+    return b == m->row_begin && e - b == m->M;
+}
+int fitter_gather_agreed(gingr_fitter *f, int32_t world) { return f->gather_agreed_world == world ? f->gather_agreed : -1; }
+void fitter_set_gather_agreed(gingr_fitter *f, int32_t world, int agreed) {
+    f->gather_agreed = agreed;
+    f->gather_agreed_world = world;
+}
 bool fitter_reversed(gingr_fitter *f) { return f->reversed; }
 const gingr_model *fitter_model(gingr_fitter *f) { return f->m; }
 
@@ -1298,10 +1318,20 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                         for (int d = 0; d < 3; ++d) aosv[(size_t)(3 * g + d)] = soa[(size_t)(d * Mt + g)];
                     std::vector<int32_t> order;
                     morton_order(aosv.data(), Mt, order);
-                    GINGR_TRY(dev_alloc(ctx, &f->gperm, (size_t)Mt));
-                    GINGR_TRY(dev_alloc(ctx, &f->gsorted, (size_t)3 * Mt));
-                    GINGR_TRY(dev_alloc(ctx, &f->rnn_pos, (size_t)(f->N > 0 ? f->N : 1)));
-                    HIP_TRY(ctx, hipMemcpy(f->gperm, order.data(), (size_t)Mt * sizeof(int32_t), hipMemcpyHostToDevice));
+                    // (failure-atomic: the three members are set together, once everything exists and the order is on the device --
+                    // a half-built set would make every later phase 0 skip this block and index with garbage)
+                    int32_t *gperm = nullptr, *rnn_pos = nullptr;
+                    double *gsorted = nullptr;
+                    int rc = dev_alloc(ctx, &gperm, (size_t)Mt);
+                    if (!rc) rc = dev_alloc(ctx, &gsorted, (size_t)3 * Mt);
+                    if (!rc) rc = dev_alloc(ctx, &rnn_pos, (size_t)(f->N > 0 ? f->N : 1));
+                    if (!rc && hipMemcpy(gperm, order.data(), (size_t)Mt * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+                        rc = gingr_set_error(ctx, GINGR_ERR_HIP, "reversed direction: copying the template order failed");
+                    if (rc) {
+                        dev_free(gperm), dev_free(gsorted), dev_free(rnn_pos);
+                        return rc;
+                    }
+                    f->gperm = gperm, f->gsorted = gsorted, f->rnn_pos = rnn_pos;
                 }
                 hipLaunchKernelGGL(soa_permute_kernel, dim3((unsigned)ceil_div(Mt, 256)), dim3(256), 0, ctx->stream, f->fullfit, f->gperm, Mt, f->gsorted);
                 const Cloud msort = cloud_of(f->gsorted, Mt);
@@ -1454,7 +1484,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 if (f->reversed)  // one observation per template vertex: mean of its accepted targets, weight count / sigma2
                     launch_obs_points(ctx, m, f->st, f->robs, f->rwin, f->weight, f->evec, f->lm_mask);
                 else if (f->icp_surface)  // only the weight-1 pairs are observed (ICP.scala:50): weight 0 drops the row
-                    launch_obs_points(ctx, m, f->st, f->surf_cp, f->surf_win, f->weight, f->evec, f->lm_mask);
+                    launch_obs_points(ctx, m, f->st, f->surf_cp, f->surf_win, f->weight, f->evec, f->lm_mask, f->zero_counts);
                 else if (f->n_lm != 0)  // (without landmarks the observation is formed inside the right-hand-side pass below)
                     launch_obs_icp(ctx, m, f->st, tgt, f->nn_idx, f->lm_mask, f->weight, f->evec);
                 fa.scalar_mode = 0;
@@ -1485,6 +1515,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
             }
             double *gram_ws = f->ws, *sweep_ws = f->ws + gram_ws_doubles(M, rp);
             bool rhs_done = false;
+            ZeroGate rhs_gate{};  // (no gate)
             if (icp && !f->icp_surface && !f->reversed && f->n_lm == 0) {
                 // point-cloud ICP without landmarks: every row has the same weight 1 / sigma2 (ICP.scala:90-92), so the weighted Gram
                 // is the model's one-off moment Q^T Q scaled -- no pass over the basis.  mom holds the total over ALL shards: the
@@ -1500,11 +1531,24 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 // (ICP.scala:50,90-92) -- the weighted Gram is the model's moment minus the rows of the zero-weight vertices, scaled.
                 // One pass over THOSE rows (0.2 % of them at 41k x 82k) instead of the MFMA pass over the whole basis (44 us); the
                 // right-hand side takes the sweep below.  On row shards the moment is the total: the shard of row 0 contributes it.
+                // By size (the default) the choice is made again on the DEVICE, per iteration: the observation launch counted the
+                // zero-weight vertices; with more than one in eight of them (open targets, partial overlap:
+                // ClosestPointRegistrator.scala:84-91) the downdate launch and the right-hand-side sweep leave at once and the
+                // weighted pass over the basis -- launched behind them, gated the other way -- does the work, as without the option.
+                const bool gated = ctx->gram_downdate != 1;
+                ZeroGate few{f->zero_counts, (int32_t)ceil_div(M, 256), 0, M}, many = few;
+                many.run_if_many = 1;
                 fa.gram_partial = gram_ws;
-                fa.nslabs = launch_gram_downdate(ctx, m->Q0, M, rp, f->weight, gram_ws);
+                fa.nslabs = launch_gram_downdate(ctx, m->Q0, M, rp, f->weight, gram_ws, gated ? &few : nullptr);
                 fa.scaled_src = m->mom + MomentLayout{rp}.stot();
                 fa.sigma2 = &f->st->sigma2;
                 fa.scaled_contribute = m->row_begin == 0 ? 1 : 0;
+                if (gated) {
+                    bool alt_rhs = false;
+                    fa.alt_nslabs = launch_gram(ctx, m->Q0, M, rp, f->weight, gram_ws, nullptr, f->evec, sweep_ws, &alt_rhs, &many);
+                    fa.gate = many;
+                    rhs_gate = few;
+                }
             } else {
                 fa.gram_partial = gram_ws;
                 fa.nslabs = launch_gram(ctx, m->Q0, M, rp, f->weight, gram_ws, nullptr, f->evec, sweep_ws, &rhs_done);
@@ -1517,6 +1561,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 a.evec = f->evec;
                 a.partial = sweep_ws;
                 a.no_reduce = 1;
+                a.gate = rhs_gate;
                 if (icp && !f->icp_surface && !f->reversed && f->n_lm == 0) {  // point-cloud ICP: observation + Q^T e in one pass
                     a.state = f->st;
                     a.icp_idx = f->nn_idx;

@@ -156,7 +156,22 @@ double *fitter_fullfit(gingr_fitter *f);                                   // [3
 void fitter_set_partial_revsum(gingr_fitter *f, double *base);             // where phase 0 of the reversed direction leaves its sums
 double *fitter_revsum(gingr_fitter *f);                                    // [4][M_total] or nullptr
 gingr_ctx *fitter_ctx(gingr_fitter *f);
+// the all-gather of the fit (rccl_exchange.hip): whether THIS shard could take part, and what all ranks agreed on (-1: not yet)
+bool fitter_gather_possible(gingr_fitter *f, int32_t world, int32_t rank);
+int fitter_gather_agreed(gingr_fitter *f, int32_t world);
+void fitter_set_gather_agreed(gingr_fitter *f, int32_t world, int agreed);
 const gingr_model *fitter_model(gingr_fitter *f);
+
+// ---- the device-side choice between the Gram downdate and the pass over the basis (surface ICP) -----------
+// counts[b] = zero-weight vertices of block b of obs_points_kernel (256 vertices each; every launch rewrites all of them: nothing to
+// clear).  A kernel that carries a gate sums the counts in its prologue; "many" = more than one vertex in eight has weight 0 -- a
+// fixed rule, independent of timing: both forms of the Gram matrix round differently (fitter.hip: kGramDowndateMinRows).
+struct ZeroGate {          // (plain data: ZeroGate{} and memset-zeroed argument blocks mean "no gate")
+    const int32_t *counts;  // nullptr: no gate (the kernel always runs)
+    int32_t nblocks;
+    int32_t run_if_many;    // the kernel runs when "many" == (run_if_many != 0)
+    int64_t M;
+};
 
 // ---- basis sweeps ------------------------------------------------------------------------------------------
 enum SweepMode {
@@ -202,6 +217,7 @@ struct SweepArgs {
     const int32_t *lm_mask;
     double *weight_out, *evec_out;
     const DevState *frame;  // SWEEP_PROJ2 (nullable): project in the rigid frame of this state instead of `pose`
+    ZeroGate gate;          // SWEEP_RHS: the pass leaves at once when the gate says so (memset-zeroed args: no gate)
 };
 
 int sweep_num_blocks(int64_t M);
@@ -213,7 +229,7 @@ int64_t gram_ws_doubles(int64_t M, int32_t rp);
 // G[rp*rp] (full symmetric) = sum_i w_i Q0_i^T Q0_i over local points; weight == nullptr means w = 1
 // returns the number of slab partials in ws; G == nullptr leaves them unreduced (launch_phase1_finalize adds them up)
 int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, double *G,
-                const double *evec = nullptr, double *rhs_partial = nullptr, bool *rhs_done = nullptr);
+                const double *evec = nullptr, double *rhs_partial = nullptr, bool *rhs_done = nullptr, const ZeroGate *gate = nullptr);
 // evec ([3][M] planes) + rhs_partial ([slabs][rp]) + rhs_done: when the triangle kernel runs (rp <= 112) it also leaves the slab
 // partials of Q0^T evec and sets *rhs_done -- the caller then skips its SWEEP_RHS pass and reduces over the returned slab count.
 
@@ -244,11 +260,16 @@ struct Phase1FinalizeArgs {
     double *scalars_local;        // nullable: the shard's own copy {Np, xPx, trPXY, yPy}
     double *sc8;                  // the 8 scalars of the exchange segment
     int32_t contribute_xpx;
+    // gate.counts != nullptr: when the gate says "many" the launch in front was the weighted pass over the basis instead of the downdate:
+    // alt_nslabs slab partials hold the weighted Gram itself (no scaled_src), the right-hand-side partials are alt_nslabs rows
+    ZeroGate gate;
+    int32_t alt_nslabs;
 };
 void launch_phase1_finalize(gingr_ctx *ctx, const Phase1FinalizeArgs &a);
 // partial[b] = sum over the vertices i of slab b with weight[i] == 0 of Q0_i^T Q0_i (full rp x rp, zeros when the slab has none);
 // returns the slab count (<= 256: the workspace of launch_gram is large enough).  rp <= 112.
-int launch_gram_downdate(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws);
+int launch_gram_downdate(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws,
+                         const ZeroGate *gate = nullptr);
 
 // ---- observations ------------------------------------------------------------------------------------------
 // CPD: yhat = y + (PX/P1 - y), weight = 1/(sigma2*lambda/P1)  (CPD.scala:37-46,126); e = w (R^T(yhat - c - t) - (ref - c) - mean)
@@ -258,8 +279,10 @@ void launch_obs_cpd(gingr_ctx *ctx, const gingr_model *m, const DevState *st, Cl
 void launch_obs_icp(gingr_ctx *ctx, const gingr_model *m, const DevState *st, Cloud target, const int32_t *idx,
                     const int32_t *lm_mask, double *weight, double *evec);
 // generic: obs points given as SoA planes with per-point weights
+// zero_counts (nullable, [ceil(M / 256)]): the number of zero-weight vertices per 256-vertex block (ZeroGate::counts)
 void launch_obs_points(gingr_ctx *ctx, const gingr_model *m, const DevState *st, const double *obs_soa,
-                       const double *weight_in, double *weight, double *evec, const int32_t *lm_mask = nullptr);
+                       const double *weight_in, double *weight, double *evec, const int32_t *lm_mask = nullptr,
+                       int32_t *zero_counts = nullptr);
 // landmarks with full 3x3 covariance added into G and rhs of the (reduced) exchange segment; local pids, local rows only
 void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, int32_t n_lm, const int32_t *lm_pid_local,
                       const double *lm_xyz, const double *lm_cov, double *G, double *rhs);

@@ -28,6 +28,23 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= 1.79769313486231570815e308; }
 
+// ZeroGate (gp.h): does this launch run?  Called by ALL threads of the workgroup (one barrier pair); the same answer in every workgroup
+// of every launch that carries the same gate.
+__device__ __forceinline__ bool gate_open(const ZeroGate &g) {
+    if (!g.counts) return true;
+    __shared__ int gate_sum;
+    if (threadIdx.x == 0) gate_sum = 0;
+    __syncthreads();
+    int s = 0;
+    for (int b = threadIdx.x; b < g.nblocks; b += blockDim.x) s += g.counts[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(&gate_sum, s);  // (integers: the order does not matter)
+    __syncthreads();
+    const bool many = (int64_t)gate_sum * 8 > g.M;
+    return many == (g.run_if_many != 0);
+}
+
 // Basis of a model on a NEW reference whose every point takes a fixed convex combination of three source points (nearest
 // neighbour: weights (1,0,0); triangle-mesh interpolation: barycentric weights of the closest surface point):
 //   Q0_new[(3 s + d) rp + q] = sum_k w[3 o + k] Q0_src[(3 inv_src[ids[3 o + k]] + d) rp + q],   o = row_begin + perm_new[s]
@@ -100,6 +117,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(SweepArgs a) {
     const int64_t M = a.M;
     double *coef = lds;
     double *red = lds + 2 * rp;
+    if (MODE == SWEEP_RHS && !gate_open(a.gate)) return;  // (workgroup-uniform)
     if (a.zero_slot && blockIdx.x == 0 && tid == 0) *a.zero_slot = 0.0;  // e.g. the |coordinate| maximum of the fit this pass rewrites
     if (FWD) {
         for (int k = tid; k < rp; k += kSweepThreads) {
@@ -779,8 +797,9 @@ template <int NT, bool FULL>
 __global__ __launch_bounds__(512) void gram_tri_kernel(const double *__restrict__ Q0, int64_t rows, int rp,
                                                        const double *__restrict__ weight, int64_t rows_per_slab,
                                                        double *__restrict__ partial, const double *__restrict__ evec, int64_t npts,
-                                                       double *__restrict__ rhs_partial) {
+                                                       double *__restrict__ rhs_partial, ZeroGate gate) {
     constexpr int kTiles = NT * (NT + 1) / 2;
+    if (!gate_open(gate)) return;  // (workgroup-uniform: the downdate launch in front did the work)
     __shared__ double red[(kTiles + 1) * 256];
     __shared__ double xchg[2 * 4 * 2 * NT * 64];
     __shared__ double rsh[4 * NT * 16];
@@ -832,6 +851,11 @@ __global__ __launch_bounds__(256) void phase1_finalize_kernel(Phase1FinalizeArgs
     const int rp = A.rp, rr = rp * rp;
     const int nG = (A.nslabs > 0 || A.scaled_src) ? (rr + 31) / 32 : 0;
     const int b = blockIdx.x;
+    if (A.gate.counts && gate_open(A.gate)) {  // (gate.run_if_many = 1) the weighted pass over the basis ran instead of the downdate
+        A.nslabs = A.alt_nslabs;
+        A.scaled_src = nullptr;
+        A.sweep_blocks = A.alt_nslabs;
+    }
     if (b < nG) {
         const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
         const int idx = b * 32 + el;
@@ -902,7 +926,8 @@ __global__ __launch_bounds__(256) void phase1_finalize_kernel(Phase1FinalizeArgs
 // vertices 256 at a time -- a ballot finds the zero-weight ones -- and adds, for each of them in ascending order, the three rows of the
 // basis (staged in LDS four vertices at a time: 14 reads per row and thread) as outer products: fixed order, no atomics.  rp <= 112.
 __global__ __launch_bounds__(256) void gram_downdate_kernel(const double *__restrict__ Q0, int64_t M, int rp, const double *__restrict__ weight,
-                                                            int64_t verts_per_slab, double *__restrict__ partial) {
+                                                            int64_t verts_per_slab, double *__restrict__ partial, ZeroGate gate) {
+    if (!gate_open(gate)) return;  // (workgroup-uniform: too many zero-weight rows, the pass over the basis behind this launch runs)
     constexpr int kBatch = 4;  // zero-weight vertices staged together: their rows are requested at once (a slab with several of them
                                // would otherwise pay one memory round trip per vertex, and the launch ends with its slowest slab)
     __shared__ double q[kBatch][3][112];
@@ -1024,8 +1049,13 @@ __global__ void obs_points_kernel(const double *__restrict__ ref, const double *
                                   const DevState *__restrict__ st, const double *__restrict__ obs, Cloud target,
                                   const int32_t *__restrict__ idx, const double *__restrict__ weight_in,
                                   const int32_t *__restrict__ lm_mask, double *__restrict__ weight,
-                                  double *__restrict__ evec) {
+                                  double *__restrict__ evec, int32_t *__restrict__ zero_counts) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero_counts) {  // the zero-weight vertices of this block (ZeroGate::counts); the same test as below
+        const bool zero = i < M && ((lm_mask && lm_mask[i]) || (idx ? 1.0 / st->sigma2 : weight_in[i]) == 0.0);
+        const int cnt = __syncthreads_count(zero);
+        if (threadIdx.x == 0) zero_counts[blockIdx.x] = cnt;
+    }
     if (i >= M) return;
     double w;
     double ox, oy, oz;
@@ -2622,15 +2652,15 @@ int64_t gram_ws_doubles(int64_t M, int32_t rp) {
 }
 
 int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, double *G, const double *evec,
-                double *rhs_partial, bool *rhs_done) {
+                double *rhs_partial, bool *rhs_done, const ZeroGate *gate) {
     if (rhs_done) *rhs_done = false;
     int nbp, npatch, nslabs;
     int64_t rps;
     gram_plan(M, rp, &nbp, &npatch, &nslabs, &rps);
     {
-        TimerScope ts(ctx, 2);
         const int nt = rp / 16;
         if (nt <= 7) {
+            TimerScope ts(ctx, 2);
             // whole upper triangle per wave: one workgroup per slab; ~3 slabs' worth of waves per SIMD is not needed (one wave per
             // SIMD, deep prefetch), so 256 slabs = one workgroup per CU
             gram_tri_plan(M, &nslabs, &rps);
@@ -2638,7 +2668,7 @@ int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const d
             if (fuse) *rhs_done = true;
             auto go = [&](auto kern) {
                 hipLaunchKernelGGL(kern, dim3(nslabs), dim3(512), 0, ctx->stream, Q0, 3 * M, (int)rp, weight, rps, ws,
-                                   fuse ? evec : (const double *)nullptr, M, fuse ? rhs_partial : (double *)nullptr);
+                                   fuse ? evec : (const double *)nullptr, M, fuse ? rhs_partial : (double *)nullptr, gate ? *gate : ZeroGate{});
             };
             const bool full = fuse && weight;
 #define GINGR_GRAM_TRI(n) \
@@ -2672,14 +2702,15 @@ int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const d
     return nslabs;
 }
 
-int launch_gram_downdate(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws) {
+int launch_gram_downdate(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, const ZeroGate *gate) {
     int nslabs_tri;  // never more slabs than the weighted Gram pass would write: the workspace behind them belongs to the right-hand-side sweep
     int64_t rows_per_slab;
     gram_tri_plan(M, &nslabs_tri, &rows_per_slab);
     const int64_t want = std::max<int64_t>(1, std::min<int64_t>(std::min(nslabs_tri, 128), ceil_div(M, 64)));
     const int64_t vps = ceil_div(M, want);
     const int nslabs = (int)ceil_div(M, vps);
-    hipLaunchKernelGGL(gram_downdate_kernel, dim3((unsigned)nslabs), dim3(256), 0, ctx->stream, Q0, M, (int)rp, weight, vps, ws);
+    hipLaunchKernelGGL(gram_downdate_kernel, dim3((unsigned)nslabs), dim3(256), 0, ctx->stream, Q0, M, (int)rp, weight, vps, ws,
+                       gate ? *gate : ZeroGate{});
     return nslabs;
 }
 
@@ -2715,14 +2746,14 @@ void launch_obs_cpd(gingr_ctx *ctx, const gingr_model *m, const DevState *st, Cl
 void launch_obs_icp(gingr_ctx *ctx, const gingr_model *m, const DevState *st, Cloud target, const int32_t *idx,
                     const int32_t *lm_mask, double *weight, double *evec) {
     hipLaunchKernelGGL(obs_points_kernel, dim3((unsigned)ceil_div(m->M, 256)), dim3(256), 0, ctx->stream, m->ref, m->mean,
-                       m->M, st, (const double *)nullptr, target, idx, (const double *)nullptr, lm_mask, weight, evec);
+                       m->M, st, (const double *)nullptr, target, idx, (const double *)nullptr, lm_mask, weight, evec, (int32_t *)nullptr);
 }
 
 void launch_obs_points(gingr_ctx *ctx, const gingr_model *m, const DevState *st, const double *obs_soa,
-                       const double *weight_in, double *weight, double *evec, const int32_t *lm_mask) {
+                       const double *weight_in, double *weight, double *evec, const int32_t *lm_mask, int32_t *zero_counts) {
     Cloud none{nullptr, nullptr, nullptr, 0};
     hipLaunchKernelGGL(obs_points_kernel, dim3((unsigned)ceil_div(m->M, 256)), dim3(256), 0, ctx->stream, m->ref, m->mean,
-                       m->M, st, obs_soa, none, (const int32_t *)nullptr, weight_in, lm_mask, weight, evec);
+                       m->M, st, obs_soa, none, (const int32_t *)nullptr, weight_in, lm_mask, weight, evec, zero_counts);
 }
 
 void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, int32_t n_lm, const int32_t *lm_pid_local,

@@ -296,6 +296,7 @@ int launch_gram_wide(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, co
     const dim3 grid((unsigned)(p.nslabs * p.nparts)), block(64 * kWaves);
     auto go = [&](auto kern) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        TimerScope ts(ctx, 2);  // (the Gram pass itself: row_expand_kernel stays outside, as in the rocprof statistics)
         hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, a);
     };
 #define GINGR_WIDE(t, sub) \

@@ -655,6 +655,9 @@ int gingr_group_set_meshes(gingr_group *g, int64_t n_model_triangles, const int3
     if (!g) return GINGR_ERR_BAD_ARGUMENT;
     if (g->fit.empty() || !g->fit[0] || g->xch.empty()) return group_fail(g, GINGR_ERR_STATE, "group set_meshes: no model / target set");
     GINGR_TRY(gingr_group_synchronize(g));
+    // every shard's set_meshes drops its direction and frees its reversed-direction sums (fitter.hip: free_meshes): the group forgets
+    // the direction with them, or the next update would hand a null total buffer to the peer-sum kernel
+    g->reversed = false;
     GINGR_TRY(g->run([&](int r) {
         return gingr_fitter_set_meshes(g->fit[(size_t)r], n_model_triangles, model_triangles, n_target_triangles, target_triangles);
     }));

@@ -94,10 +94,39 @@ int native_allreduce(void *user, int32_t, void *device_ptr, int64_t count) {
 // fit.  Half the wire bytes of the zero-padded all-reduce and no reduction (round 4 spelled the gather as a sum).
 int native_gather(void *user, gingr_fitter *f) {
     gingr_ctx *ctx = static_cast<gingr_ctx *>(user);
-    if (!g_rccl.AllGather) return 1;
+    if (!g_rccl.AllGather) return 1;  // (the same library on every rank of a node: a uniform answer)
+    // Gather or zero-padded all-reduce is a choice between two DIFFERENT collectives on one communicator: it has to come out the same
+    // on every rank.  Whether a rank can gather depends on its own rows only (the balanced partition), so the ranks agree once per
+    // (meshes, world) with a MIN all-reduce of a flag; a rank that cannot stage after the agreement is an error, never a silent
+    // switch to the other collective (the peers would wait in ncclAllGather for ever).
+    int agreed = fitter_gather_agreed(f, ctx->rccl_world);
+    if (agreed < 0) {
+        double flag = fitter_gather_possible(f, ctx->rccl_world, ctx->rccl_rank) ? 1.0 : 0.0, *dflag = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&dflag), sizeof(double)) != hipSuccess ||
+            hipMemcpyAsync(dflag, &flag, sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            (void)hipFree(dflag);
+            (void)gingr_set_error(ctx, GINGR_ERR_HIP, "rccl gather: no device word for the agreement");
+            return -1;
+        }
+        const int rc = g_rccl.AllReduce(dflag, dflag, 1, /* ncclFloat64 */ 8, /* ncclMin */ 3, ctx->rccl_comm, ctx->stream);
+        const bool copied = rc == 0 && hipMemcpyAsync(&flag, dflag, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                            hipStreamSynchronize(ctx->stream) == hipSuccess;
+        (void)hipFree(dflag);
+        if (rc != 0) {
+            (void)rccl_fail(ctx, "ncclAllReduce (gather agreement)", rc);
+            return -1;
+        }
+        if (!copied) {
+            (void)gingr_set_error(ctx, GINGR_ERR_HIP, "rccl gather: reading the agreement back failed");
+            return -1;
+        }
+        agreed = flag > 0.5 ? 1 : 0;
+        fitter_set_gather_agreed(f, ctx->rccl_world, agreed);
+    }
+    if (!agreed) return 1;  // every rank falls back to the zero-padded all-reduce
     void *send = nullptr, *recv = nullptr;
     int64_t count = 0;
-    if (gingr_fitter_gather_stage(f, ctx->rccl_world, ctx->rccl_rank, &send, &recv, &count) != GINGR_OK) return 1;  // (not the balanced partition)
+    if (gingr_fitter_gather_stage(f, ctx->rccl_world, ctx->rccl_rank, &send, &recv, &count) != GINGR_OK) return -1;  // (the error text is set)
     const int rc = g_rccl.AllGather(send, recv, (size_t)count, /* ncclFloat64 */ 8, ctx->rccl_comm, ctx->stream);
     if (rc != 0) {
         (void)rccl_fail(ctx, "ncclAllGather", rc);

@@ -654,7 +654,7 @@ __global__ __launch_bounds__(kCpThreads) void self_intersect_queue_kernel(Cloud 
                                                                          const int32_t *__restrict__ tri, int64_t T,
                                                                          const double *__restrict__ boxes,
                                                                          const int32_t *__restrict__ skip,
-                                                                         int32_t *__restrict__ flag, const double *__restrict__ tribox,
+                                                                         int32_t *flag /* may alias F.found (the along-normal flavour) */, const double *__restrict__ tribox,
                                                                          const uint8_t *__restrict__ only, const int32_t *__restrict__ nonly,
                                                                          SelfIntersectFuse F) {
     if (nonly && *nonly == 0) return;  // masked launch (what the grid kernel could not certify): nothing left over

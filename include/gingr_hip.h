@@ -562,9 +562,11 @@ int gingr_group_update_icp_async(gingr_group *g, const gingr_icp_params *p, int3
 int gingr_group_set_meshes(gingr_group *g, int64_t n_model_triangles, const int32_t *model_triangles, int64_t n_target_triangles,
                            const int32_t *target_triangles);
 int gingr_group_set_surface_method(gingr_group *g, int32_t method);
-/* gingr_fitter_set_correspondence_direction for every shard (ICP.scala:46-48).  With more than one shard the correspondence itself is
- * replicated work -- its queries are the replicated target, its answers may lie in any shard's rows -- against the gathered template
- * (set the meshes first, also for the vertex-to-vertex flavour 1); Gram, right-hand side and everything behind them stay sharded. */
+/* gingr_fitter_set_correspondence_direction for every shard (ICP.scala:46-48).  With more than one shard the correspondence runs
+ * against the GATHERED template (set the meshes first, also for the vertex-to-vertex flavour 1) and is sharded by QUERY range: every
+ * shard scans its slice of the replicated target's vertices, the per-template-vertex sums of the slices are totalled by one more
+ * exchange (GINGR_SEGMENT_REVSUM), and each shard then forms the observations of its own rows; Gram, right-hand side and everything
+ * behind them stay sharded by rows.  gingr_group_set_meshes drops the direction again (as gingr_fitter_set_meshes does). */
 int gingr_group_set_correspondence_direction(gingr_group *g, int32_t reversed);
 int gingr_group_update_async(gingr_group *g, int32_t flavour, const gingr_cpd_params *cp, const gingr_icp_params *ip, int32_t n_iterations,
                              const double *z);

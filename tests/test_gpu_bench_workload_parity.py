@@ -70,6 +70,21 @@ def test_fused_update_at_bench_size_against_oracle(ctx, n, steps):
     f.close()
 
 
+def test_fused_update_at_bench_size_rank256_against_oracle(ctx):
+    """SURVEY 8d's second model rank at the metric size: 50k <-> 50k, rank 256 -- the wide Gram pass
+    (gp_wide.hip), the super-panel posterior solve and the rank-256 fit pass inside full `update` iterations, from the initial
+    state and from the state after eight device iterations, against the oracle (GingrAlgorithm.scala:192-254, :297-301)."""
+    from gingr_amd.sharded import ShardedFitter
+    y, x, model, mo = _workload(ctx, 50000, 256)
+    assert mo.rank == 256
+    f = ShardedFitter(ctx, model, x)
+    f.set_state(np.zeros(mo.rank), ctx.cpd_initial_sigma2(y, x))
+    _check_one_update(f, mo, x, 0.1, "n=50000 rank 256, first update")
+    f.update_cpd(0.1, 1.0, 7)
+    _check_one_update(f, mo, x, 0.1, "n=50000 rank 256 after 8 steps")
+    f.close()
+
+
 def test_fused_update_50k_two_logical_shards_against_oracle(ctx):
     """The phase / exchange protocol on two row shards of the metric workload (hand-rolled all-reduce on one device), one
     iteration from the state after 5 single-shard steps, against the oracle's unsharded update."""
