@@ -2056,11 +2056,14 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_split_kernel(i
         }
         return;
     }
+    GINGR_STAGE_CLOCK(7)
     for (int k = tid; k < kNB * ld; k += kSolveThreads) u[k] = k < r ? __builtin_fma(GINGR_COEFF_NOISE, rhs[k], qte[k]) : 0.0;
     lds_load_spd<kSolveThreads>(A, ld, r, n, G, GINGR_COEFF_NOISE, Stot, 1.0, GINGR_COEFF_NOISE);
+    GINGR_STAGE_CLOCK(0)
     lds_cholesky<kSolveThreads>(A, ld, n, rd, &bad_spd, kNB);  // u <- L_K^-1 (Q0^T e + eps rhs) on the way
     lds_backward<kSolveThreads>(A, ld, n, rd, u);              // u = w
     __syncthreads();
+    GINGR_STAGE_CLOCK(4)
     {   // hv[0] + hv[1] = G w (two halves of the row range per column, coalesced over the column)
         const int k = tid & 127, half = tid >> 7;
         for (int kk = k; kk < r; kk += 128) {
@@ -2103,6 +2106,8 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_split_kernel(i
         out2[0] = bad_spd ? __builtin_nan("") : -0.5 * red[0] - 0.5 * (double)r * 1.8378770664093454836;  // log(2 pi)
         out2[1] = bad_spd ? 1.0 : 0.0;
     }
+    GINGR_STAGE_CLOCK(5)
+    GINGR_STAGE_CLOCK(6)
     (void)av;
 }
 

@@ -18,6 +18,9 @@ CFLAGS = ["-O3", "-march=native", "-fopenmp", "-fPIC", "-shared"]
 
 
 def build() -> str:
+    if os.environ.get("GINGR_ORACLE_SANITIZED") == "1":  # tests/test_oracle_sanitized.py (the sanitizer runtime must be preloaded)
+        subprocess.check_call(["make", "-C", _HERE, "libcpd_baseline_asan.so"], stdout=subprocess.DEVNULL)
+        return os.path.join(_HERE, "libcpd_baseline_asan.so")
     out_dir = os.path.join(tempfile.gettempdir(), f"gingr_cpu_baseline_{os.getuid()}")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libcpd_baseline.so")

@@ -13,6 +13,9 @@ _LIB = None
 
 
 def build() -> str:
+    if os.environ.get("GINGR_ORACLE_SANITIZED") == "1":  # tests/test_oracle_sanitized.py (the sanitizer runtime must be preloaded)
+        subprocess.check_call(["make", "-C", _HERE, "libcpd_oracle_asan.so"], stdout=subprocess.DEVNULL)
+        return os.path.join(_HERE, "libcpd_oracle_asan.so")
     so = os.path.join(_HERE, "libcpd_oracle.so")
     src = os.path.join(_HERE, "cpd_oracle.c")
     if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(so) < os.path.getmtime(src)):
