@@ -234,6 +234,14 @@ def spawn_ranks(n_gpus: int, argv) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def _child_env():
+    """The environment of a child run started by rank 0: nothing of THIS launch's rendezvous may leak into it (with
+    TORCHELASTIC_USE_AGENT_STORE left set, a child's own init_process_group waits for the parent's store until its time-out)."""
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE",
+            "GROUP_WORLD_SIZE", "ROLE_NAME")
+    return {k: v for k, v in os.environ.items() if k not in drop and not k.startswith("TORCHELASTIC_")}
+
+
 def run_group_mode(args, world: int, shared_device: bool):
     """The same workload once more through the in-library device group (ONE process, one worker thread per GPU, peer-pointer
     all-reduce) so that one multi-GPU run carries RCCL and the group side by side: a CHILD process (this one has initialised the
@@ -244,8 +252,7 @@ def run_group_mode(args, world: int, shared_device: bool):
            "--sustained-steps", str(args.sustained_steps), "--no-cpu-baseline", "--no-parity-check"]
     if shared_device:
         cmd += ["--logical-shards", str(world)]   # the one-GPU test mode: the shards share device 0
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
-                                                            "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    env = _child_env()
     try:
         p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
@@ -256,6 +263,35 @@ def run_group_mode(args, world: int, shared_device: bool):
                 "how": "child process `bench.py --group` on the same devices after the headline measurement"}
     except Exception as e:  # the headline line must come out whatever happens here
         return {"error": f"{type(e).__name__}: {e}"[:400]}
+
+
+def run_variants(args, world: int, shared_device: bool):
+    """Two more runs of the same workload as CHILD processes once the ranks are done with their devices (this process has initialised
+    the GPU and must not exec): (a) `--emulate-world N` on one GPU -- the per-rank compute without any exchange; (b) the N-rank run
+    again with `--ctx-option split_exchange=1`.  Returns digests; never raises (the headline line must come out)."""
+    import subprocess
+    env = _child_env()
+    common = ["--steps", str(args.steps), "--warmup", str(args.warmup), "--points", str(args.points), "--rank", str(args.rank), "--w", str(args.w),
+              "--roofline-steps", str(args.roofline_steps), "--sustained-steps", "0", "--no-cpu-baseline", "--no-parity-check", "--no-group-mode",
+              "--no-variants"]
+    out = {}
+
+    def digest(cmd, what):
+        p = None
+        try:
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+            return {"ms_per_step": d["ms_per_step"], "value": d["value"], "valid": d["valid"], "reason": d.get("reason"), "n_gpus": d["n_gpus"],
+                    "exchange": d.get("exchange"), "how": what}
+        except Exception as e:
+            return {"error": f"{type(e).__name__}: {e}"[:400], "stderr_tail": (p.stderr[-600:] if p is not None else None), "how": what}
+    out["emulated_shard_no_exchange"] = digest([sys.executable, os.path.abspath(__file__), "--emulate-world", str(world)] + common,
+                                               f"child `bench.py --emulate-world {world}` on GPU 0: rank 0's shard, the other ranks' partial sums missing "
+                                               "(a per-rank cost figure, not a registration)")
+    out["split_exchange"] = digest([sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--ctx-option", "split_exchange=1"] + common,
+                                   f"child `bench.py --gpus {world} --ctx-option split_exchange=1`: the column-sum all-reduce in two halves, the first "
+                                   "on the context's second stream beside the second half of the pass")
+    return out
 
 
 def _latest_profile(suffix: str):
@@ -343,9 +379,11 @@ def main():
     ap.add_argument("--no-group-mode", action="store_true",
                     help="N > 1: skip the second measurement through the in-library device group (a child process started by rank 0 after "
                          "the headline measurement; its line is folded into the output as `group_mode`)")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="N > 1: skip the two child runs behind the headline (emulated shard without exchange, split column-sum exchange)")
     ap.add_argument("--ctx-option", action="append", default=[], metavar="NAME=VALUE",
-                    help="same-box comparisons: gingr_ctx_set_option on the context, NAME in cull | fine_cull | nn_grid | tri_grid "
-                         "(all select between code paths with identical results)")
+                    help="same-box comparisons: gingr_ctx_set_option on the context, NAME in cull | fine_cull | nn_grid | tri_grid | "
+                         "split_exchange | gram_downdate (all select between code paths with the same results)")
     args = ap.parse_args()
     if args.config:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -742,11 +780,21 @@ def main():
         for seg in (0, 1):
             ms, n = timing(6 + seg)
             ex.append(ms / n if n else 0.0)
+        per_rank = None
         if use_dist:
+            # every rank's own view first (events around each collective on ITS stream: its wait for the slowest peer included), with the
+            # two pair loops it ran next to them -- the first 8-GPU line has to be readable rank by rank
+            mine = {"rank": rank, "segment0_column_sums_ms": ex[0], "segment1_gram_bundle_ms": ex[1]}
+            for which, name in ((0, "cpd_colsum_kernel_ms"), (1, "cpd_rowstats_kernel_ms"), (3, "instrumented_update_ms")):
+                ms_k, n_k = timing(which)
+                mine[name] = ms_k / n_k if n_k else None
+            per_rank = [None] * dist.get_world_size()
+            dist.all_gather_object(per_rank, mine)
             te = torch.tensor(ex, dtype=torch.float64, device="cpu" if shared_device else f"cuda:{local_rank}")
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             ex = [float(v) for v in te.tolist()]
         exchange = {"path": exchange_path if use_dist else "in-library device group (peer pointers)",
+                    "per_rank": per_rank,
                     "rccl": ctx.rccl_info() if (use_dist and native) else None,
                     "segment0_column_sums_ms": ex[0], "segment1_gram_bundle_ms": ex[1],
                     "bytes": {"segment0": 8 * N, "segment1": 8 * (((args.rank + 15) // 16 * 16) ** 2 + 2 * ((args.rank + 15) // 16 * 16) + 8)},
@@ -886,6 +934,11 @@ def main():
         dist.destroy_process_group()
     if rank == 0 and world > 1 and not args.group and not args.no_group_mode and not args.emulate_world:
         out["group_mode"] = run_group_mode(args, world, shared_device)
+    if rank == 0 and world > 1 and not args.group and not args.no_variants and not args.emulate_world:
+        # next to the headline, from child processes on the same devices: what one rank's shard costs with the exchanges taken out
+        # (an emulated shard on one GPU), and the same N-rank run with the column-sum exchange split in two halves
+        # (GINGR_OPT_SPLIT_EXCHANGE = 1; off by default: 26-35 us slower in the single-GPU emulation, never seen on real links)
+        out["variants"] = run_variants(args, world, shared_device)
     if rank == 0:
         # RCCL prints a version banner through C stdio; flush it first so that the JSON is the LAST line on stdout
         import ctypes

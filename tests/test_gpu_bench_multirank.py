@@ -46,6 +46,17 @@ def test_bench_launch_line_with_ranks_sharing_the_device(world, points):
     assert "error" not in gm, gm
     assert gm["valid"] is True and gm["n_gpus"] == world and gm["ms_per_step"] > 0.0
     assert gm["exchange"]["segment0_column_sums_ms"] > 0.0 and gm["exchange"]["path"].startswith("in-library device group")
+    # round 6: every rank's own exchange times next to the two pair loops it ran, and the two variant runs behind the headline (the
+    # emulated shard without exchange; the split column-sum exchange -- here through gloo, where the option changes nothing but must run)
+    pr = ex["per_rank"]
+    assert sorted(p["rank"] for p in pr) == list(range(world))
+    assert all(p["segment0_column_sums_ms"] > 0.0 and p["cpd_colsum_kernel_ms"] > 0.0 and p["cpd_rowstats_kernel_ms"] > 0.0 for p in pr), pr
+    assert ex["segment0_column_sums_ms"] == pytest.approx(max(p["segment0_column_sums_ms"] for p in pr))
+    va = out["variants"]
+    assert "error" not in va["emulated_shard_no_exchange"], va
+    assert va["emulated_shard_no_exchange"]["ms_per_step"] > 0.0 and va["emulated_shard_no_exchange"]["valid"] is False   # (never a registration)
+    assert "error" not in va["split_exchange"], va
+    assert va["split_exchange"]["valid"] is True and va["split_exchange"]["n_gpus"] == world
 
 
 def test_bench_native_rccl_exchange_with_a_one_rank_communicator():
