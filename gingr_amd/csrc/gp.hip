@@ -1270,7 +1270,10 @@ __host__ __device__ inline size_t lds_solve_doubles(int rp, int xr) { return (si
 // A (lower triangle of the leading r x r) = ca * G + cs * S + ci * I from global r x rp matrices (S may be nullptr), identity
 // on the padding r <= i < n.  16 x 16 element blocks, one element per thread and block, eight blocks in flight; the loads are
 // unconditional (clamped indices), only the value is selected.
-template <int NT>
+// HAS_S (round 6): whether the second matrix is there is known at every call site -- as a run-time test of the pointer it sat between
+// the loads of the two matrices for each of the 36 blocks, and the request of the next block waited for the previous block's value
+// (one memory round trip per block: 19k cycles of the transition-density kernel's 93k, tools/ubench_logpdf_split.hip).
+template <int NT, bool HAS_S = false>
 __device__ __forceinline__ void lds_load_spd(double *A, int ld, int r, int n, const double *__restrict__ G, double ca,
                                              const double *__restrict__ S, double cs, double ci) {
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -1278,19 +1281,24 @@ __device__ __forceinline__ void lds_load_spd(double *A, int ld, int r, int n, co
     if (RB == 16 && n <= 128) {
         // The LDS-resident case: all (at most 36) lower blocks are requested before the first value is used.  A lone workgroup
         // sees the full memory latency per dependent batch; with batches of eight blocks this stage was four round trips.
-        double v[36];
+        double v[36], vs[HAS_S ? 36 : 1];
         int idx = 0;
 #pragma unroll
         for (int bi = 0; bi < 8; ++bi)
 #pragma unroll
             for (int bj = 0; bj <= bi; ++bj, ++idx) {
                 const int i = bi * 16 + ty, j = bj * 16 + tx;
-                double t = 0.0;
-                if (bi * 16 < n) {  // workgroup-uniform
-                    const int g = min(i, r - 1) * n + min(j, r - 1);  // the global matrices have row stride rp == n
-                    t = ca * G[g];
-                    if (S) t = __builtin_fma(cs, S[g], t);
-                }
+                const int g = min(min(i, r - 1), n - 1) * n + min(j, r - 1);  // the global matrices have row stride rp == n
+                v[idx] = G[g];  // (blocks past n: a clamped, valid address; the value is not stored)
+                if (HAS_S) vs[idx] = S[g];
+            }
+        idx = 0;
+#pragma unroll
+        for (int bi = 0; bi < 8; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj, ++idx) {
+                double t = ca * v[idx];
+                if (HAS_S) t = __builtin_fma(cs, vs[idx], t);
                 v[idx] = t;
             }
         idx = 0;
@@ -1317,7 +1325,7 @@ __device__ __forceinline__ void lds_load_spd(double *A, int ld, int r, int n, co
             const int i = ib + ty, j = jb + tx;
             const int g = min(i, r - 1) * n + min(j, r - 1);  // the global matrices have row stride rp == n
             double t = ca * G[g];
-            if (S) t = __builtin_fma(cs, S[g], t);
+            if (HAS_S) t = __builtin_fma(cs, S[g], t);
             if (i == j) t += ci;
             v[u] = (i < r && j < r) ? t : (i == j ? 1.0 : 0.0);
             off[u] = (ib < n && i < n && j <= i) ? i * ld + j : -1;
@@ -1702,22 +1710,33 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_solve_lds_kernel(int 
 constexpr int kWideSolveThreads = 512;
 
 template <int SW>
-__global__ __launch_bounds__(kWideSolveThreads) void posterior_solve_wide_kernel(int r, int n, const double *__restrict__ G,
-                                                                                 const double *__restrict__ rhs,
-                                                                                 const double *__restrict__ zrand, double *__restrict__ a,
-                                                                                 DevState *__restrict__ st, double *gw) {
-    extern __shared__ double P[];  // the panel: [rows][SW + 1]
+struct WideSolveLds {
+    double rdl[SW];
+    double red[2][kWideSolveThreads / 64][SW];
+    double xs[2][512];  // x = L^-T y and, when sampling, L^-T z (n <= 512)
+    double yv[2][SW];
+    int bad_spd;
+};
+
+// The body: factor C = ca G + cs S + ci I (identity on the padding r <= i < n) in the workspace gw, with the bordered row
+// b1 + cb b2 riding through the forward substitution, then substitute back.  On return Ls.xs[0] = C^-1 (b1 + cb b2), Ls.xs[1] =
+// L^-T zrand (zeros without zrand), the factor and its reciprocal diagonal are in gw ([(n + 16)][n], then [n]), Ls.bad_spd is set on
+// a non-positive / non-finite pivot.  All kWideSolveThreads threads; P = the dynamic LDS block [(n + 16)][SW + 1].
+template <int SW, bool HAS_S>
+__device__ __forceinline__ void wide_solve_body(double *P, WideSolveLds<SW> &Ls, int r, int n, const double *__restrict__ G, double ca,
+                                                const double *__restrict__ S, double cs, double ci, const double *__restrict__ b1,
+                                                const double *__restrict__ b2, double cb, const double *__restrict__ zrand, double *gw) {
     constexpr int ldp = SW + 1, NW = kWideSolveThreads / 64;
-    __shared__ double rdl[SW];
-    __shared__ double red[2][NW][SW];
-    __shared__ double xs[2][512];  // x = L^-T y and, when sampling, L^-T z (n <= 512)
-    __shared__ double yv[2][SW];
-    __shared__ int bad_spd, bad;
+    double *rdl = Ls.rdl;
+    auto &red = Ls.red;
+    auto &xs = Ls.xs;
+    auto &yv = Ls.yv;
+    int &bad_spd = Ls.bad_spd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     double *Lg = gw;                          // [(n + 16)][n]: the factor, then the bordered rows
     double *rdg = gw + (size_t)(n + kNB) * n;  // [n] reciprocal diagonal
     const int nvec = zrand ? 2 : 1;
-    if (tid == 0) bad_spd = 0, bad = 0;
+    if (tid == 0) bad_spd = 0;
     GINGR_STAGE_CLOCK(7)
     typedef double d2 __attribute__((ext_vector_type(2)));
     constexpr int NTJ = SW / 16;                                // tile columns of a panel
@@ -1729,7 +1748,7 @@ __global__ __launch_bounds__(kWideSolveThreads) void posterior_solve_wide_kernel
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int my_tj = wv % NTJ, ti0 = wv / NTJ;
     // the bordered rows of the workspace: the right-hand side, fifteen zero rows (they ride through every panel)
-    for (int e = tid; e < kNB * n; e += kWideSolveThreads) Lg[(size_t)n * n + e] = e < r ? rhs[e] : 0.0;
+    for (int e = tid; e < kNB * n; e += kWideSolveThreads) Lg[(size_t)n * n + e] = e < r ? (b2 ? __builtin_fma(cb, b2[e], b1[e]) : b1[e]) : 0.0;
     __syncthreads();
     const int srow = tid / HALF, scp = tid % HALF;              // this thread's row (per round) and column pair of a staged slice
     for (int kb = 0; kb < n; kb += SW) {
@@ -1758,6 +1777,14 @@ __global__ __launch_bounds__(kWideSolveThreads) void posterior_solve_wide_kernel
                 if (gi < n + kNB) pre[u] = *reinterpret_cast<const d2 *>((gi < n ? base : Lg + col) + (size_t)gi * n);
             }
             if (is_c) {  // workgroup-uniform.  Mm = QtL Q + I, identity on the padding   (scalismo genericRegressionComputations)
+                d2 ps[HAS_S ? PRE : 1];
+                if (HAS_S) {  // the second matrix of the transition density's system, same rows: one more batch of loads per panel
+#pragma unroll
+                    for (int u = 0; u < PRE; ++u) {
+                        const int gi = kb + srow + u * RSTEP;
+                        if (gi < n) ps[u] = *reinterpret_cast<const d2 *>(S + col + (size_t)gi * n);
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < PRE; ++u) {
                     const int gi = kb + srow + u * RSTEP;
@@ -1765,7 +1792,9 @@ __global__ __launch_bounds__(kWideSolveThreads) void posterior_solve_wide_kernel
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const double one = gi == col + h ? 1.0 : 0.0;
-                            pre[u][h] = (gi < r && col + h < r) ? pre[u][h] + one : one;
+                            double t = ca * pre[u][h];
+                            if (HAS_S) t = __builtin_fma(cs, ps[u][h], t);
+                            pre[u][h] = (gi < r && col + h < r) ? t + ci * one : one;
                         }
                     }
                 }
@@ -1867,19 +1896,112 @@ __global__ __launch_bounds__(kWideSolveThreads) void posterior_solve_wide_kernel
         }
         __syncthreads();
     }
+}
+
+template <int SW>
+__global__ __launch_bounds__(kWideSolveThreads) void posterior_solve_wide_kernel(int r, int n, const double *__restrict__ G,
+                                                                                 const double *__restrict__ rhs,
+                                                                                 const double *__restrict__ zrand, double *__restrict__ a,
+                                                                                 DevState *__restrict__ st, double *gw) {
+    extern __shared__ double P[];  // the panel: [rows][SW + 1]
+    __shared__ WideSolveLds<SW> Ls;
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    wide_solve_body<SW, false>(P, Ls, r, n, G, 1.0, nullptr, 0.0, 1.0, rhs, nullptr, 0.0, zrand, gw);
     GINGR_STAGE_CLOCK(5)
     GINGR_STAGE_CLOCK(6)
     for (int k = tid; k < n; k += kWideSolveThreads) {
-        const double v = k < r ? xs[0][k] + xs[1][k] : 0.0;
+        const double v = k < r ? Ls.xs[0][k] + Ls.xs[1][k] : 0.0;
         a[k] = v;
         if (!finite_d(v)) bad = 1;
     }
     __syncthreads();
     if (tid == 0) {
-        if (bad_spd)
+        if (Ls.bad_spd)
             st->err = GINGR_ERR_NOT_SPD;
         else if (bad)
             st->err = GINGR_ERR_NONFINITE;
+    }
+}
+
+// posterior_logpdf_split_kernel for ranks above 112 (round 6; until then posterior_logpdf_lds_kernel<true>: both factorisations one
+// after the other in ONE workgroup of 256 threads, 16-column panels over the global workspace).  Two workgroups of eight waves, the
+// same algebra: workgroup 0 factors N = I + G and solves N a = rhs; workgroup 1 factors K = S_tot + eps N with the bordered row
+// Q0^T e + eps rhs, so that w = K^-1 (Q0^T e + eps rhs), u = w - a and |c|^2 = u^T (N w - rhs); a travels through fx under the
+// release / acquire pair on sync[0] (the launch number `epoch`), sync[1] carries workgroup 0's failure flag.  The factor of K, its
+// reciprocal diagonal and a are left in fx ([n x n][n][n]) for posterior_logpdf_cached_kernel.  gw: two workspaces of
+// posterior_work_doubles(n) / 2 doubles each.
+template <int SW>
+__global__ __launch_bounds__(kWideSolveThreads) void posterior_logpdf_wide_kernel(int r, int n, const double *__restrict__ G,
+                                                                                  const double *__restrict__ rhs,
+                                                                                  const double *__restrict__ Stot,
+                                                                                  const double *__restrict__ qte, double *__restrict__ fx,
+                                                                                  double *__restrict__ out2, unsigned *sync, unsigned epoch,
+                                                                                  double *gw, int64_t gw_stride) {
+    extern __shared__ double P[];
+    __shared__ WideSolveLds<SW> Ls;
+    __shared__ int failed0;
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
+        wide_solve_body<SW, false>(P, Ls, r, n, G, 1.0, nullptr, 0.0, 1.0, rhs, nullptr, 0.0, nullptr, gw);
+        for (int k = tid; k < n; k += kWideSolveThreads) fx[(int64_t)n * n + k] = k < r ? Ls.xs[0][k] : 0.0;
+        __syncthreads();
+        if (tid == 0) {
+            sync[1] = (unsigned)Ls.bad_spd;
+            __hip_atomic_store(&sync[0], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // a and the flag are visible before it
+        }
+        return;
+    }
+    double *gw1 = gw + gw_stride;
+    wide_solve_body<SW, true>(P, Ls, r, n, G, GINGR_COEFF_NOISE, Stot, 1.0, GINGR_COEFF_NOISE, qte, rhs, GINGR_COEFF_NOISE, nullptr, gw1);
+    const double *w = Ls.xs[0];
+    // (G w)_k: the thread's column k (G is symmetric: coalesced over k), two halves of the row range, four chains each
+    double *hv = P;  // [2][512] (the panel block is free)
+    __syncthreads();
+    for (int kk = tid & 255; kk < r; kk += 256) {
+        const int half = tid >> 8;
+        const int j0 = half ? (r + 1) / 2 : 0, j1 = half ? r : (r + 1) / 2;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int j = j0;
+        for (; j + 3 < j1; j += 4) {
+            s0 = __builtin_fma(G[(int64_t)j * n + kk], w[j], s0);
+            s1 = __builtin_fma(G[(int64_t)(j + 1) * n + kk], w[j + 1], s1);
+            s2 = __builtin_fma(G[(int64_t)(j + 2) * n + kk], w[j + 2], s2);
+            s3 = __builtin_fma(G[(int64_t)(j + 3) * n + kk], w[j + 3], s3);
+        }
+        for (; j < j1; ++j) s0 = __builtin_fma(G[(int64_t)j * n + kk], w[j], s0);
+        hv[half * 512 + kk] = (s0 + s1) + (s2 + s3);
+    }
+    // the state-only part for posterior_logpdf_cached_kernel: the factor of K (lower part; the workspace rows have stride n) and its
+    // reciprocal diagonal
+    for (int64_t e = tid; e < (int64_t)n * n / 2; e += kWideSolveThreads) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        reinterpret_cast<d2 *>(fx)[e] = reinterpret_cast<const d2 *>(gw1)[e];
+    }
+    for (int k = tid; k < n; k += kWideSolveThreads) fx[(int64_t)n * n + n + k] = gw1[(size_t)(n + kNB) * n + k];
+    if (tid == 0) {
+        while (__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+        failed0 = (int)__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    double part = 0.0;
+    for (int k = tid; k < r; k += kWideSolveThreads) {
+        const double av = __hip_atomic_load(&fx[(int64_t)n * n + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double nw = (hv[k] + hv[512 + k]) + w[k];  // (N w)_k
+        part = __builtin_fma(w[k] - av, nw - rhs[k], part);
+    }
+    double *redv = P + 1024;  // [kWideSolveThreads]
+    redv[tid] = part;
+    __syncthreads();
+    for (int st2 = kWideSolveThreads / 2; st2 > 0; st2 >>= 1) {
+        if (tid < st2) redv[tid] += redv[tid + st2];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const bool bad = Ls.bad_spd || failed0;
+        out2[0] = bad ? __builtin_nan("") : -0.5 * redv[0] - 0.5 * (double)r * 1.8378770664093454836;  // log(2 pi)
+        out2[1] = bad ? 1.0 : 0.0;
     }
 }
 
@@ -1984,7 +2106,7 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_lds_kernel(int
     __syncthreads();
     logpdf_rhs(r, rp, Stot, qte, av, hv, u);
     // (3) u = (S_tot + eps (I + G))^-1 b
-    lds_load_spd<kSolveThreads>(A, ld, r, n, G, GINGR_COEFF_NOISE, Stot, 1.0, GINGR_COEFF_NOISE);
+    lds_load_spd<kSolveThreads, true>(A, ld, r, n, G, GINGR_COEFF_NOISE, Stot, 1.0, GINGR_COEFF_NOISE);
     lds_cholesky<kSolveThreads>(A, ld, n, rd, &bad_spd, kNB);                                        // u <- L2^-1 u on the way
     lds_backward<kSolveThreads>(A, ld, n, rd, u);
     __syncthreads();
@@ -2041,12 +2163,6 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_split_kernel(i
         }
         lds_load_spd<kSolveThreads>(A, ld, r, n, G, 1.0, nullptr, 0.0, 1.0);
         lds_cholesky<kSolveThreads>(A, ld, n, x, &bad_spd, kNB, kNB);  // y <- L^-1 rhs, W <- the transposed inverses of the diagonal blocks
-        if (nfac) {  // the factor for posterior_sample_cached_kernel: L, then the 16 W rows
-            for (int i = tid >> 6; i < n + kNB; i += kSolveThreads / 64) {
-                const double *src = i < n ? A + i * ld : W + (i - n) * ld;
-                for (int j = tid & 63; j < n; j += 64) nfac[(int64_t)i * rp + j] = src[j];
-            }
-        }
         lds_backward_w<kSolveThreads>(A, ld, n, W, y, x);
         for (int k = tid; k < rp; k += kSolveThreads) fx[(int64_t)rp * rp + k] = k < r ? x[k] : 0.0;
         __syncthreads();
@@ -2054,15 +2170,31 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_split_kernel(i
             sync[1] = (unsigned)bad_spd;
             __hip_atomic_store(&sync[0], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // a and the flag are visible before it
         }
+        if (nfac) {  // the factor for posterior_sample_cached_kernel: L, then the 16 W rows (the substitution above left both as they
+                     // were) -- written BEHIND the hand-over of a (round 6): 115 KB that workgroup 1 does not have to wait for
+            for (int i = tid >> 6; i < n + kNB; i += kSolveThreads / 64) {
+                const double *src = i < n ? A + i * ld : W + (i - n) * ld;
+                for (int j = tid & 63; j < n; j += 64) nfac[(int64_t)i * rp + j] = src[j];
+            }
+        }
         return;
     }
     GINGR_STAGE_CLOCK(7)
-    for (int k = tid; k < kNB * ld; k += kSolveThreads) u[k] = k < r ? __builtin_fma(GINGR_COEFF_NOISE, rhs[k], qte[k]) : 0.0;
-    lds_load_spd<kSolveThreads>(A, ld, r, n, G, GINGR_COEFF_NOISE, Stot, 1.0, GINGR_COEFF_NOISE);
+    // (round 6: the W form of the backward substitution here too -- sixteen identity rows ride through the panel solves and come back
+    // as the transposed inverses of the diagonal blocks, as in workgroup 0; 12.5k -> ~6k cycles of this workgroup's critical path)
+    double *Wk = u + kNB * ld, *rdk = sm + (size_t)(n + 2 * kNB) * ld, *wv = rdk + n;
+    for (int k = tid; k < kNB * ld; k += kSolveThreads) {
+        u[k] = k < r ? __builtin_fma(GINGR_COEFF_NOISE, rhs[k], qte[k]) : 0.0;
+        const int c = k / ld, j = k - c * ld;
+        Wk[k] = (j < n && (j & 15) == c) ? 1.0 : 0.0;
+    }
+    lds_load_spd<kSolveThreads, true>(A, ld, r, n, G, GINGR_COEFF_NOISE, Stot, 1.0, GINGR_COEFF_NOISE);
     GINGR_STAGE_CLOCK(0)
-    lds_cholesky<kSolveThreads>(A, ld, n, rd, &bad_spd, kNB);  // u <- L_K^-1 (Q0^T e + eps rhs) on the way
-    lds_backward<kSolveThreads>(A, ld, n, rd, u);              // u = w
+    lds_cholesky<kSolveThreads>(A, ld, n, rdk, &bad_spd, kNB, kNB);  // u <- L_K^-1 (Q0^T e + eps rhs) on the way
+    lds_backward_w<kSolveThreads>(A, ld, n, Wk, u, wv);              // wv = w
     __syncthreads();
+    rd = rdk;
+    u = wv;
     GINGR_STAGE_CLOCK(4)
     {   // hv[0] + hv[1] = G w (two halves of the row range per column, coalesced over the column)
         const int k = tid & 127, half = tid >> 7;
@@ -2768,7 +2900,8 @@ void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, 
                        (int)n_lm, lm_pid_local, lm_xyz, lm_cov, G, rhs);
 }
 
-int64_t posterior_work_doubles(int32_t rp) { return (int64_t)lds_solve_doubles(rp, kNB); }
+// (two workspaces from rp = 128 on: the two workgroups of posterior_logpdf_wide_kernel factor side by side)
+int64_t posterior_work_doubles(int32_t rp) { return (int64_t)lds_solve_doubles(rp, kNB) * (rp >= 128 ? 2 : 1); }
 
 void launch_chol_block64(gingr_ctx *ctx, double *Aw, int64_t ld, int k, double *Linv, int32_t *flag) {
     const size_t lds = lds_solve_doubles(64, 64) * sizeof(double);
@@ -2862,6 +2995,20 @@ int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
                                       (int)lds2);
         hipLaunchKernelGGL(posterior_logpdf_split_kernel, dim3(2), dim3(kSolveThreads), lds2, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte, fx,
                            out2, sync, epoch, keep_factor ? 1 : 0, nfac);
+        return GINGR_OK;
+    }
+    if (!cached && !in_lds && fx && sync) {  // ranks above 112: the two factorisations side by side on the global workspaces
+        const int64_t stride = posterior_work_doubles(rp) / 2;
+        auto gow = [&](auto kern, int sw) {
+            const size_t ldsw = (size_t)(rp + kNB) * (sw + 1) * sizeof(double);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+            hipLaunchKernelGGL(kern, dim3(2), dim3(kWideSolveThreads), ldsw, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte, fx, out2, sync, epoch,
+                               work, stride);
+        };
+        if (rp <= 256)
+            gow(posterior_logpdf_wide_kernel<64>, 64);
+        else
+            gow(posterior_logpdf_wide_kernel<32>, 32);
         return GINGR_OK;
     }
     if (cached) {  // fx holds what an earlier launch for this state left

@@ -99,3 +99,27 @@ def test_sampled_proposal_at_wide_ranks(ctx, rank):
     assert rel(state.general.fit, st.fit) < 1e-5
     assert rel(state.general.modelParameters.shape, st.alpha) < 1e-4
     algo.close()
+
+
+@pytest.mark.parametrize("rank", [128, 150, 256, 300, 512])
+def test_log_transition_density_at_wide_ranks(ctx, rank):
+    """posterior.gp.logpdf(posterior.coefficients(mesh)) (G/api/sampling/generators/GeneratorWrapperStochastic.scala:42-63) at r >= 128:
+    the two factorisations side by side on the global workspaces (posterior_logpdf_wide_kernel), then the cached form for a second
+    query about the same state -- both against the oracle; a state whose posterior fails reports -inf."""
+    import gingr_amd as ga
+    M = 450
+    mo, rng = _model(M, rank, seed=11 * rank)
+    target = mo.instance(rng.normal(0, 1.0, rank)) + rng.normal(0, 0.3, (M, 3))
+    algo = ga.CpdRegistration(ctx)
+    cfg = ga.CpdConfiguration(maxIterations=50, w=0.05)
+    s0 = algo.createInitialState(_to_ga(mo), target, cfg)
+    s1 = algo.update(s0)
+    st = go.cpd_update(mo, target, go.initial_state(mo, s0.general.sigma2), w=0.05)
+    assert rel(s1.general.fit, st.fit) < 1e-6
+    s2 = algo.update(s1, probabilistic=True, rnd=np.random.default_rng(5))
+    want = go.posterior_logpdf_of_mesh(mo, st, *go.cpd_observations(mo, target, st, w=0.05), mesh=st.fit)
+    got = algo.logTransitionProbability(s1, s2)
+    assert np.isfinite(got) and abs(got - want) < 1e-5 * abs(want), (rank, got, want)
+    again = algo.logTransitionProbability(s1, s2)       # the memo / cached form answers the second query
+    assert abs(again - want) < 1e-5 * abs(want), (rank, again, want)
+    algo.close()
