@@ -310,36 +310,40 @@ def load_pmc_traffic(kernel: str, points: int, rank: int):
     """HBM bytes per launch of `kernel` from the tracked PMC artefact tools/pmc_traffic.sh produced for THIS workload
     (profiles/rNN_pmc_traffic.json, newest round: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes, as the
     microarchitecture guide prescribes).  None when no artefact matches -- bench.py never invents the number."""
-    path = _latest_profile("pmc_traffic.json")
-    try:
-        d = json.load(open(path))
-    except Exception:
-        return None, None
-    wl = d.get("workload", {})
-    if wl.get("points") != points or wl.get("rank") != rank or wl.get("gpus", 1) != 1:
-        return None, None
-    k = d.get("kernels", {}).get(kernel)
-    if not k:
-        return None, None
-    rel = os.path.relpath(path, ROOT)
-    return float(k["hbm_bytes_per_launch"]), f"{rel} ({k.get('note', 'FETCH_SIZE + WRITE_SIZE per launch')})"
+    for suffix in ("pmc_traffic.json", "pmc_wide_r256.json"):   # (the metric workload; the same workload at model rank 256: tools/pmc_wide.sh)
+        path = _latest_profile(suffix)
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        wl = d.get("workload", {})
+        if wl.get("points") != points or wl.get("rank") != rank or wl.get("gpus", 1) != 1:
+            continue
+        k = d.get("kernels", {}).get(kernel)
+        if not k or "hbm_bytes_per_launch" not in k:
+            continue
+        rel = os.path.relpath(path, ROOT)
+        return float(k["hbm_bytes_per_launch"]), f"{rel} ({k.get('note', 'FETCH_SIZE x 2 + WRITE_SIZE per launch')})"
+    return None, None
 
 
 def load_pmc_mfma(kernel: str, points: int, rank: int):
     """Matrix-pipe counters of `kernel` (SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_MFMA, ... from tools/pmc_sq.sh's third pass) out of the
     tracked artefact profiles/rNN_pmc_mfma.json for THIS workload; None when there is none."""
-    path = _latest_profile("pmc_mfma.json")
-    try:
-        d = json.load(open(path))
-    except Exception:
-        return None
-    wl = d.get("workload", {})
-    if wl.get("points") != points or wl.get("rank") != rank:
-        return None
-    k = d.get("kernels", {}).get(kernel)
-    if not k:
-        return None
-    return dict(k, source=os.path.relpath(path, ROOT))
+    for suffix in ("pmc_mfma.json", "pmc_wide_r256.json"):
+        path = _latest_profile(suffix)
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        wl = d.get("workload", {})
+        if wl.get("points") != points or wl.get("rank") != rank:
+            continue
+        k = d.get("kernels", {}).get(kernel)
+        if not k or "counters" not in k:
+            continue
+        return dict(k, source=os.path.relpath(path, ROOT))
+    return None
 
 
 def main():
@@ -751,6 +755,7 @@ def main():
                         "full_symmetric_achieved": 2.0 * ach_half, "full_symmetric_frac": 2.0 * ach_half / F64_MFMA_PEAK_TFLOPS,
                         "hbm_achieved_GBs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS, "algorithmic_bytes": 24.0 * m_loc * r_model,
                         "padded_rank": rp,
+                        "traffic": (load_pmc_traffic(gram_name, M, args.rank) if n_shards == 1 and not args.emulate_world else (None, None))[0],
                         # busy cycles of the matrix pipe / (SIMDs x kernel cycles) from the SQ counters (tracked artefact), next to
                         # the time-derived fractions above
                         "mfma_counters": load_pmc_mfma(gram_name, M, args.rank) if n_shards == 1 and not args.emulate_world else None})

@@ -1898,27 +1898,185 @@ __device__ __forceinline__ void wide_solve_body(double *P, WideSolveLds<SW> &Ls,
     }
 }
 
+// The solve itself keeps its own, specialised copy of the body (C = I + G, one right-hand side known at compile time): instantiating
+// wide_solve_body for it costs 45 more spilled registers and 15 % of the kernel (135 -> 155 us at r = 256, tools/ubench_solve_wide.hip) --
+// the register allocator's doing, not the arithmetic's; the transition density above ranks 112 uses the general body.
 template <int SW>
 __global__ __launch_bounds__(kWideSolveThreads) void posterior_solve_wide_kernel(int r, int n, const double *__restrict__ G,
                                                                                  const double *__restrict__ rhs,
                                                                                  const double *__restrict__ zrand, double *__restrict__ a,
                                                                                  DevState *__restrict__ st, double *gw) {
     extern __shared__ double P[];  // the panel: [rows][SW + 1]
-    __shared__ WideSolveLds<SW> Ls;
-    __shared__ int bad;
-    const int tid = threadIdx.x;
-    if (tid == 0) bad = 0;
-    wide_solve_body<SW, false>(P, Ls, r, n, G, 1.0, nullptr, 0.0, 1.0, rhs, nullptr, 0.0, zrand, gw);
+    constexpr int ldp = SW + 1, NW = kWideSolveThreads / 64;
+    __shared__ double rdl[SW];
+    __shared__ double red[2][NW][SW];
+    __shared__ double xs[2][512];  // x = L^-T y and, when sampling, L^-T z (n <= 512)
+    __shared__ double yv[2][SW];
+    __shared__ int bad_spd, bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    double *Lg = gw;                          // [(n + 16)][n]: the factor, then the bordered rows
+    double *rdg = gw + (size_t)(n + kNB) * n;  // [n] reciprocal diagonal
+    const int nvec = zrand ? 2 : 1;
+    if (tid == 0) bad_spd = 0, bad = 0;
+    GINGR_STAGE_CLOCK(7)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    constexpr int NTJ = SW / 16;                                // tile columns of a panel
+    constexpr int TSTEP = NW / NTJ;                             // wave w owns tile column w % NTJ, tile rows w / NTJ + TSTEP q
+    constexpr int TACC = SW == 64 ? 9 : 9;                      // tiles per wave, at most: ceil((n + 16) / 16 / TSTEP), n <= 256 (512)
+    constexpr int HALF = SW / 2;                                // 16-byte units per staged row
+    constexpr int RSTEP = kWideSolveThreads / HALF;             // rows a staging round covers
+    constexpr int PRE = 17;                                     // staging rounds, at most: ceil((n + 16) / RSTEP), n <= 256 (512)
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int my_tj = wv % NTJ, ti0 = wv / NTJ;
+    // the bordered rows of the workspace: the right-hand side, fifteen zero rows (they ride through every panel)
+    for (int e = tid; e < kNB * n; e += kWideSolveThreads) Lg[(size_t)n * n + e] = e < r ? rhs[e] : 0.0;
+    __syncthreads();
+    const int srow = tid / HALF, scp = tid % HALF;              // this thread's row (per round) and column pair of a staged slice
+    for (int kb = 0; kb < n; kb += SW) {
+        const int sw = min(SW, n - kb), rows = n - kb + kNB;
+        const int nti = rows >> 4, ntj = sw >> 4;
+        // The panel's tiles, C - L[rows, 0 : kb] L[panel rows, 0 : kb]^T, accumulate in registers while the panel's LDS block stages
+        // the operands: the factor's columns go through it SW at a time (coalesced 16-byte loads, the next slice requested before the
+        // MFMAs of the current one), and C = I + G (bordered rows: the right-hand side) goes through it last and stays, minus the
+        // accumulated products.
+        // (Fragments fetched straight from the workspace, 8 bytes per lane and sixteen rows per instruction, made this stage 62 % of
+        // the kernel: 354k cycles at r = 256.)
+        v4f64 acc[TACC];
+#pragma unroll
+        for (int q = 0; q < TACC; ++q) acc[q] = v4f64{0, 0, 0, 0};
+        const bool col_live = my_tj < ntj;
+        const int nsl = kb / SW;  // slices of the factor; slice nsl is C
+        d2 pre[PRE];
+        auto fetch_slice = [&](int sl) __attribute__((always_inline)) {
+            // slice nsl is C itself: the same rows and row stride, read from G; the bordered rows always come from the workspace
+            const bool is_c = sl == nsl;
+            const int col = sl * SW + 2 * scp;  // (== kb + 2 scp for C)
+            const double *base = (is_c ? G : Lg) + col;
+#pragma unroll
+            for (int u = 0; u < PRE; ++u) {
+                const int gi = kb + srow + u * RSTEP;
+                if (gi < n + kNB) pre[u] = *reinterpret_cast<const d2 *>((gi < n ? base : Lg + col) + (size_t)gi * n);
+            }
+            if (is_c) {  // workgroup-uniform.  Mm = QtL Q + I, identity on the padding   (scalismo genericRegressionComputations)
+#pragma unroll
+                for (int u = 0; u < PRE; ++u) {
+                    const int gi = kb + srow + u * RSTEP;
+                    if (gi < n) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const double one = gi == col + h ? 1.0 : 0.0;
+                            pre[u][h] = (gi < r && col + h < r) ? pre[u][h] + one : one;
+                        }
+                    }
+                }
+            }
+        };
+        fetch_slice(0);
+        for (int sl = 0; sl <= nsl; ++sl) {
+            __syncthreads();  // (the previous slice, or the previous panel's write-back, has been read)
+#pragma unroll
+            for (int u = 0; u < PRE; ++u)
+                if (srow + u * RSTEP < rows) {
+                    P[(srow + u * RSTEP) * ldp + 2 * scp] = pre[u][0];
+                    P[(srow + u * RSTEP) * ldp + 2 * scp + 1] = pre[u][1];
+                }
+            __syncthreads();
+            if (sl == nsl) break;
+            fetch_slice(sl + 1);
+            if (col_live) {  // wave-uniform
+                const double *pb = P + (16 * my_tj + l15) * ldp + l4;
+#pragma unroll
+                for (int q = 0; q < TACC; ++q) {
+                    const int ti = ti0 + TSTEP * q;
+                    if (ti < nti && ti >= my_tj) {  // wave-uniform; strictly above the diagonal: nobody reads it
+                        const double *pa = P + (16 * ti + l15) * ldp + l4;
+#pragma unroll 8
+                        for (int u = 0; u < SW / 4; ++u) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * u], pb[4 * u], acc[q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (kb > 0 && col_live) {
+#pragma unroll
+            for (int q = 0; q < TACC; ++q) {
+                const int ti = ti0 + TSTEP * q;
+                if (ti < nti && ti >= my_tj) {
+                    double *pc = P + (16 * ti + l4) * ldp + 16 * my_tj + l15;  // D[i = l4 + 4 g][j = l15]
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) pc[4 * g * ldp] -= acc[q][g];
+                }
+            }
+        }
+        __syncthreads();
+        GINGR_STAGE_CLOCK(0)
+        lds_cholesky<kWideSolveThreads>(P, ldp, sw, rdl, &bad_spd, rows - sw);
+        {   // the panel goes back to the workspace
+            const int j = tid % SW;
+            if (j < sw)
+                for (int i = tid / SW; i < rows; i += kWideSolveThreads / SW) Lg[(size_t)(kb + i) * n + kb + j] = P[i * ldp + j];
+        }
+        if (tid < sw) rdg[kb + tid] = rdl[tid];
+        GINGR_STAGE_CLOCK(4)
+    }
+    __syncthreads();
+    // x = L^-T y: y = row n of the workspace (L^-1 rhs); the sampling direction L^-T z rides along
+    const int kb_last = ((n - 1) / SW) * SW;
+    for (int kb = kb_last; kb >= 0; kb -= SW) {
+        const int sw = min(SW, n - kb);
+        {   // t_c = y_c - sum over the rows j below the block of L[j][kb + c] x_j: NW row groups, combined in order
+            const int c = tid % SW, g = tid / SW;
+            constexpr int NG = kWideSolveThreads / SW;
+            double s0 = 0.0, s1 = 0.0;
+            if (c < sw)
+                for (int j = kb + sw + g; j < n; j += NG) {
+                    const double l = Lg[(size_t)j * n + kb + c];
+                    s0 = __builtin_fma(l, xs[0][j], s0);
+                    if (nvec == 2) s1 = __builtin_fma(l, xs[1][j], s1);
+                }
+            // (NG row groups of SW columns: the first NW of them land in red, the others are added by their owners below)
+            static_assert(NG == NW || NG == 2 * NW, "row groups of the backward mat-vec");
+            if (NG == 2 * NW) {
+                s0 += __shfl_xor(s0, 32);  // SW = 32: groups g and g + 1 share a wave
+                s1 += __shfl_xor(s1, 32);
+            }
+            if (NG == NW || (lane < 32)) {
+                red[0][wave][c] = s0;
+                red[1][wave][c] = s1;
+            }
+        }
+        {
+            const int j = tid % SW;
+            if (j < sw)
+                for (int i = tid / SW; i < sw; i += kWideSolveThreads / SW) P[i * ldp + j] = Lg[(size_t)(kb + i) * n + kb + j];
+        }
+        if (tid < sw) rdl[tid] = rdg[kb + tid];
+        __syncthreads();
+        if (tid < sw) {
+            for (int v = 0; v < nvec; ++v) {
+                double t = v == 0 ? Lg[(size_t)n * n + kb + tid] : (kb + tid < r ? zrand[kb + tid] : 0.0);
+                for (int w = 0; w < NW; ++w) t -= red[v][w][tid];
+                yv[v][tid] = t;
+            }
+        }
+        __syncthreads();
+        lds_backward<kWideSolveThreads>(P, ldp, sw, rdl, yv[0]);
+        if (nvec == 2) lds_backward<kWideSolveThreads>(P, ldp, sw, rdl, yv[1]);
+        if (tid < sw) {
+            xs[0][kb + tid] = yv[0][tid];
+            xs[1][kb + tid] = nvec == 2 ? yv[1][tid] : 0.0;
+        }
+        __syncthreads();
+    }
     GINGR_STAGE_CLOCK(5)
     GINGR_STAGE_CLOCK(6)
     for (int k = tid; k < n; k += kWideSolveThreads) {
-        const double v = k < r ? Ls.xs[0][k] + Ls.xs[1][k] : 0.0;
+        const double v = k < r ? xs[0][k] + xs[1][k] : 0.0;
         a[k] = v;
         if (!finite_d(v)) bad = 1;
     }
     __syncthreads();
     if (tid == 0) {
-        if (Ls.bad_spd)
+        if (bad_spd)
             st->err = GINGR_ERR_NOT_SPD;
         else if (bad)
             st->err = GINGR_ERR_NONFINITE;

@@ -87,7 +87,13 @@ const char *gingr_build_info(void);
  *                        the weight 1 / sigma2 and every rejected one 0 (ICP.scala:50,90-92), so its weighted Gram matrix is the model's
  *                        one-off moment Q^T Q minus the rows of the rejected vertices, scaled: one pass over the rejected rows (0.2 % of
  *                        them at 41k) instead of one over the basis / 0: the pass over the basis.  Same matrix up to the rounding of the
- *                        subtraction (<= 1e-12); pays while fewer than about a fifth of the rows are rejected.
+ *                        subtraction (<= 1e-12).  -1 also decides again on the DEVICE in every iteration: with more than one zero-weight
+ *                        vertex in eight (open targets, partial overlap) the pass over the basis runs, exactly as with 0 (round 6; a
+ *                        fixed rule -- the choice never depends on timing); 1 forces the downdate whatever the rejected fraction is.
+ *                        Results are therefore NOT bit-stable across the 16 384-row threshold, across the one-in-eight rule or across
+ *                        this option: the two forms round differently, and the exact `intersection point != vertex` comparison of the
+ *                        self-intersection test (ClosestPointRegistrator.scala:67) can turn a last-bit difference into a different
+ *                        accept / reject decision in the next iteration.
  * No reference counterpart (the reference has one code path per operation). */
 typedef enum gingr_ctx_option {
     GINGR_OPT_CULL = 0,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One reproducible measurement line per BASELINE.json config (`python bench.py --config N` prints line N; run as a script it
-runs all five and writes gpurun_out/r05_configs.json -- copy it to profiles/).
+runs all five (+ the metric workload at SURVEY 8d's second model rank, 256) and writes gpurun_out/r06_configs.json -- copy it to profiles/).
 
   1  femur CPD, 1 622 <-> 1 622 vertices of the reference's own demo data (tests/golden/inputs.npz), Gaussian GPMM (70, 50) built on the
      device, DemoCPD settings (examples/DemoCPD.scala:11-25: CpdConfiguration defaults, NoTransforms) -- the reference's CPU-runnable case
@@ -308,11 +308,22 @@ def config5(gpus: int = 1):
             "chains_one_per_gpu": multi, "chains_packed_on_one_gpu": packed}
 
 
-CONFIGS = {1: config1, 2: config2, 3: config3, 4: config4, 5: config5}
+def metric_rank256():
+    """The metric workload (50k <-> 50k CPD) at SURVEY 8d's second model rank, r = 256: bench.py's own line (child process: bench.py
+    owns its context), with the kernels of the wide path (gram_wide_kernel, posterior_solve_wide_kernel, sweep_fit_boxes_kernel<16, 1>)."""
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rank", "256", "--no-cpu-baseline"], capture_output=True, text=True,
+                       timeout=1200, cwd=ROOT)
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    d["config"] = "metric workload at model rank 256 (SURVEY 8d: r in {100, 256})"
+    return d
+
+
+CONFIGS = {1: config1, 2: config2, 3: config3, 4: config4, 5: config5, 6: metric_rank256}
 
 
 def main():
-    which = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 5]
+    which = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 5, 6]
     lines = []
     for c in which:
         try:
@@ -323,7 +334,7 @@ def main():
         print(json.dumps(o), flush=True)
     if len(which) > 1:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        json.dump(lines, open(os.path.join(ROOT, "gpurun_out", "r05_configs.json"), "w"), indent=1)
+        json.dump(lines, open(os.path.join(ROOT, "gpurun_out", "r06_configs.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ import shutil
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "05"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "06"
 F, P = os.path.join(root, "gpurun_out", "final"), os.path.join(root, "profiles")
 
 
@@ -19,9 +19,23 @@ shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, f"r{rnd}_bench50k_fin
 shutil.copy(os.path.join(F, "kernel_stats.csv"), os.path.join(P, f"r{rnd}_bench50k_kernel_stats_final.csv"))
 shutil.copy(os.path.join(F, "pmc_traffic.json"), os.path.join(P, f"r{rnd}_pmc_traffic.json"))
 shutil.copy(os.path.join(F, "pmc_sq.txt"), os.path.join(P, f"r{rnd}_pmc_sq_counters.txt"))
-for name, dst in (("pmc_mfma.json", f"r{rnd}_pmc_mfma.json"), ("configs.json", f"r{rnd}_configs.json")):
+for name, dst in (("pmc_mfma.json", f"r{rnd}_pmc_mfma.json"), ("configs.json", f"r{rnd}_configs.json"), ("pmc_wide_r256.json", f"r{rnd}_pmc_wide_r256.json")):
     if os.path.exists(os.path.join(F, name)):
         shutil.copy(os.path.join(F, name), os.path.join(P, dst))
+
+if os.path.exists(os.path.join(F, "kernel_stats_r256.csv")):
+    shutil.copy(os.path.join(F, "kernel_stats_r256.csv"), os.path.join(P, f"r{rnd}_bench50k_r256_kernel_stats.csv"))
+ranks = {}
+for r in (128, 200, 256, 512):
+    if os.path.exists(os.path.join(F, f"bench_rank{r}.json")) and os.path.getsize(os.path.join(F, f"bench_rank{r}.json")) > 0:
+        d = load(f"bench_rank{r}.json")
+        ranks[str(r)] = {"ms_per_step": d["ms_per_step"], "iterations_per_s": d["value"], "valid": d["valid"], "parity_check": d["parity_check"],
+                         "kernels": d["kernels"]}
+        if r == 256:
+            shutil.copy(os.path.join(F, "bench_rank256.json"), os.path.join(P, f"r{rnd}_bench50k_r256.json"))
+if ranks:
+    json.dump({"what": "the metric workload (50k <-> 50k CPD) at model ranks above 112: python bench.py --rank R --no-cpu-baseline", "ranks": ranks},
+              open(os.path.join(P, f"r{rnd}_bench50k_wide_ranks.json"), "w"), indent=1)
 
 e50 = {str(n): load(f"emu{n}.json")["ms_per_step"] for n in (1, 2, 4, 8)}
 one100 = load("bench_100k.json")

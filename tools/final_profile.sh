@@ -7,17 +7,21 @@ R=$GRAFT_REPO_ROOT
 F=$R/gpurun_out/final
 rm -rf $F; mkdir -p $F
 cd $R
-bash tools/pmc_traffic.sh > $F/pmc_traffic.txt 2>&1 && cp gpurun_out/pmc_traffic.json $F/pmc_traffic.json && cp gpurun_out/pmc_traffic.json profiles/r05_pmc_traffic.json
-bash tools/pmc_sq.sh > $F/pmc_sq.txt 2>&1; cp gpurun_out/pmc_mfma.json $F/pmc_mfma.json; cp gpurun_out/pmc_mfma.json profiles/r05_pmc_mfma.json
+bash tools/pmc_traffic.sh > $F/pmc_traffic.txt 2>&1 && cp gpurun_out/pmc_traffic.json $F/pmc_traffic.json && cp gpurun_out/pmc_traffic.json profiles/r06_pmc_traffic.json
+bash tools/pmc_sq.sh > $F/pmc_sq.txt 2>&1; cp gpurun_out/pmc_mfma.json $F/pmc_mfma.json; cp gpurun_out/pmc_mfma.json profiles/r06_pmc_mfma.json
 python3 bench.py 2> $F/bench.err | tail -1 > $F/bench.json
 bash tools/prof_stats.sh final > $F/kernel_stats.txt 2>&1; cp gpurun_out/prof_final/kernel_stats.csv $F/kernel_stats.csv
+# model ranks above 112 (the wide Gram / super-panel solve / rank-256 fit pass): bench lines and the kernel statistics of the rank-256 run
+for r in 128 200 256 512; do python3 bench.py --rank $r --no-cpu-baseline 2>/dev/null | tail -1 > $F/bench_rank$r.json; done
+bash tools/pmc_wide.sh > $F/pmc_wide_r256.txt 2>&1; cp gpurun_out/pmc_wide_r256.json $F/pmc_wide_r256.json
+bash tools/prof_stats.sh final_r256 --rank 256 > $F/kernel_stats_r256.txt 2>&1; cp gpurun_out/prof_final_r256/kernel_stats.csv $F/kernel_stats_r256.csv
 for n in 1 2 4 8; do python3 bench.py --emulate-world $n --no-cpu-baseline --no-parity-check --steps 100 --warmup 10 --roofline-steps 0 --sustained-steps 0 2>/dev/null | tail -1 > $F/emu$n.json; done
 python3 bench.py --sigma2 4 --no-cpu-baseline --no-parity-check 2>/dev/null | tail -1 > $F/bench_sigma2_4.json
 python3 bench.py --points 15000 --no-cpu-baseline 2>/dev/null | tail -1 > $F/bench_15k.json
 python3 bench.py --points 100000 --no-cpu-baseline 2>/dev/null | tail -1 > $F/bench_100k.json
 for n in 2 4 8; do python3 bench.py --points 100000 --emulate-world $n --no-cpu-baseline --no-parity-check --steps 40 --warmup 5 --roofline-steps 0 --sustained-steps 0 2>/dev/null | tail -1 > $F/emu100k_$n.json; done
 python3 bench.py --group --logical-shards 2 --no-cpu-baseline 2>/dev/null | tail -1 > $F/bench_group_logical2.json
-timeout 1500 python3 tools/bench_configs.py > $F/configs.txt 2> $F/configs.err; cp gpurun_out/r05_configs.json $F/configs.json
+timeout 1500 python3 tools/bench_configs.py > $F/configs.txt 2> $F/configs.err; cp gpurun_out/r06_configs.json $F/configs.json
 # the 8-rank shard's kernels (the Amdahl table of DESIGN.md section 7), the Metropolis-Hastings chain and the two ICP flavours
 bash tools/prof_stats.sh final_emu8 --emulate-world 8 --steps 100 --warmup 10 --roofline-steps 0 > $F/emu8_kernels.txt 2>&1; cp gpurun_out/prof_final_emu8/kernel_stats.csv $F/emu8_kernel_stats.csv
 python3 bench.py --points 1622 --steps 300 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $F/bench_1622.json
@@ -35,6 +39,12 @@ import json
 d = json.load(open("gpurun_out/final/bench.json"))
 print("bench", d["value"], d["ms_per_step"], d["valid"], d["reason"], d["roofline"]["frac"], d["roofline"]["traffic"], d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"])
 print("sustained", d["sustained"])
+for r in (128, 200, 256, 512):
+    try:
+        dr = json.load(open(f"gpurun_out/final/bench_rank{r}.json"))
+        print("rank", r, dr["ms_per_step"], dr["valid"], {k["kernel"]: round(k["avg_ms"], 4) for k in dr["kernels"]})
+    except Exception as ex:
+        print("rank", r, "failed", ex)
 print({k["kernel"]: round(k["avg_ms"], 4) for k in d["kernels"]})
 for n in (1, 2, 4, 8):
     print("emulated", n, json.load(open(f"gpurun_out/final/emu{n}.json"))["ms_per_step"])

@@ -20,7 +20,7 @@ python3 - "$POINTS" "$RANK" <<'PY'
 import csv, glob, collections, json, sys
 points, rank = int(sys.argv[1]), int(sys.argv[2])
 names = {"cpd_colsum_kernel": "cpd_colsum", "cpd_rowstats_kernel": "cpd_rowstats", "rowstats_reduce_kernel": "rowstats_reduce",
-         "cpd_den_finalize_kernel": "cpd_den_finalize", "gram_kernel": "gram_tri", "phase1_finalize_kernel": "phase1_finalize",
+         "cpd_den_finalize_kernel": "cpd_den_finalize", "gram_tri_kernel": "gram_tri", "phase1_finalize_kernel": "phase1_finalize",
          "sweep_kernel": "sweep_kernel<", "sweep_fit_boxes_kernel": "sweep_fit_boxes", "posterior_solve_lds_kernel": "posterior_solve", "tile_bbox_kernel": "tile_bbox"}
 wide = set(names)       # FETCH_SIZE x 2 on gfx950 for EVERY load width this library uses: calibrated with tools/pmc_fetch_calibration.sh
                         # (16 B / lane, 8 B / lane contiguous and the Gram kernel's 4 x 128-byte row segments all report exactly half)

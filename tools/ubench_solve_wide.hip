@@ -29,8 +29,13 @@ int launch_gram_wide(gingr_ctx *, const double *, int64_t, int32_t, const double
 #include <random>
 #include <vector>
 
+// evicts the caches between two launches (the solve of an iteration runs behind 2 ms of pair loops: its code, G and the workspace are cold)
+__global__ void thrash_kernel(double *buf, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) buf[i] = buf[i] * 1.0000001 + 1.0;
+}
+
 template <int SW>
-static void run(int r, int rp) {
+static void run(int r, int rp, bool cold = false) {
     std::mt19937_64 rng(1);
     std::normal_distribution<double> nd;
     std::vector<double> B((size_t)rp * rp, 0.0), G((size_t)rp * rp, 0.0), rhs(rp, 0.0);
@@ -57,14 +62,19 @@ static void run(int r, int rp) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_solve_wide_kernel<SW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int reps = 20;
     unsigned long long zero[8] = {0};
+    double *junk = nullptr;
+    const size_t njunk = (size_t)64 << 20;  // 512 MB: past L2 and the Infinity Cache
+    if (cold) hipMalloc(&junk, njunk * 8), hipMemset(junk, 0, njunk * 8);
     hipEvent_t a, b;
     hipEventCreate(&a);
     hipEventCreate(&b);
     for (int w = 0; w < 2; ++w) {
         hipMemcpyToSymbol(HIP_SYMBOL(g_stage), zero, sizeof(zero));
         hipEventRecord(a);
-        for (int i = 0; i < reps; ++i)
+        for (int i = 0; i < reps; ++i) {
+            if (cold) hipLaunchKernelGGL(thrash_kernel, dim3(2048), dim3(256), 0, 0, junk, njunk);
             hipLaunchKernelGGL(posterior_solve_wide_kernel<SW>, dim3(1), dim3(kWideSolveThreads), lds, 0, r, rp, dG, drhs, (const double *)nullptr, da, st, work);
+        }
         hipEventRecord(b);
         hipDeviceSynchronize();
     }
@@ -73,7 +83,8 @@ static void run(int r, int rp) {
     unsigned long long h[8];
     hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stage), sizeof(h));
     const char *names[8] = {"tiles: G - L L^T -> LDS", "diag 16x16 factor", "panel", "trailing update", "write-back", "backward", "-", "-"};
-    printf("posterior_solve_wide_kernel<%d> r=%d rp=%d: %.1f us per launch (back-to-back launches, instrumented)\n", SW, r, rp, ms * 1e3 / reps);
+    printf("posterior_solve_wide_kernel<%d> r=%d rp=%d%s: %.1f us per launch (%s, instrumented)\n", SW, r, rp, cold ? " COLD" : "", ms * 1e3 / reps,
+           cold ? "a 512 MB read-modify-write between launches; the stage cycles below are the solve's own" : "back-to-back launches");
     unsigned long long tot = 0;
     for (int i = 0; i < 6; ++i) tot += h[i];
     for (int i = 0; i < 6; ++i) printf("  %-26s %9.0f cycles  %5.1f %%\n", names[i], (double)h[i] / reps, 100.0 * h[i] / tot);
@@ -92,6 +103,7 @@ static void run(int r, int rp) {
 
 int main() {
     run<64>(256, 256);
+    run<64>(256, 256, true);
     run<64>(200, 208);
     run<32>(512, 512);
     return 0;
