@@ -2019,41 +2019,65 @@ __global__ __launch_bounds__(kWideSolveThreads) void posterior_solve_wide_kernel
         GINGR_STAGE_CLOCK(4)
     }
     __syncthreads();
-    // x = L^-T y: y = row n of the workspace (L^-1 rhs); the sampling direction L^-T z rides along
+    // x = L^-T y: y = row n of the workspace (L^-1 rhs); the sampling direction L^-T z rides along.  Everything a block reads from
+    // the workspace -- the rows below it for the mat-vec, its diagonal block, its reciprocal diagonal -- does not depend on the x of the
+    // blocks behind it, so it is requested one block AHEAD, before the sequential substitution of the current block, and waits in
+    // registers (round 6: two exposed memory round trips per block less).
     const int kb_last = ((n - 1) / SW) * SW;
+    constexpr int NG = kWideSolveThreads / SW;          // row groups of the mat-vec
+    constexpr int LV = SW == 64 ? 24 : 30;              // rows a thread takes below a block, at most: (n - SW) / NG
+    constexpr int DV = SW * SW / kWideSolveThreads;     // diagonal-block entries per thread
+    static_assert(NG == NW || NG == 2 * NW, "row groups of the backward mat-vec");
+    const int bc = tid % SW, bg = tid / SW;
+    double lv[LV], dv[DV], rdv = 0.0;
+    auto prefetch_block = [&](int kb) __attribute__((always_inline)) {
+        const int sw = min(SW, n - kb);
+#pragma unroll
+        for (int q = 0; q < LV; ++q) {
+            const int j = kb + sw + bg + q * NG;
+            lv[q] = (bc < sw && j < n) ? Lg[(size_t)j * n + kb + bc] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < DV; ++q) {
+            const int i = bg + q * NG;
+            dv[q] = (bc < sw && i < sw) ? Lg[(size_t)(kb + i) * n + kb + bc] : 0.0;
+        }
+        rdv = tid < sw ? rdg[kb + tid] : 0.0;
+    };
+    prefetch_block(kb_last);
     for (int kb = kb_last; kb >= 0; kb -= SW) {
         const int sw = min(SW, n - kb);
-        {   // t_c = y_c - sum over the rows j below the block of L[j][kb + c] x_j: NW row groups, combined in order
-            const int c = tid % SW, g = tid / SW;
-            constexpr int NG = kWideSolveThreads / SW;
+        {   // t_c = y_c - sum over the rows j below the block of L[j][kb + c] x_j: NG row groups, combined in order
             double s0 = 0.0, s1 = 0.0;
-            if (c < sw)
-                for (int j = kb + sw + g; j < n; j += NG) {
-                    const double l = Lg[(size_t)j * n + kb + c];
-                    s0 = __builtin_fma(l, xs[0][j], s0);
-                    if (nvec == 2) s1 = __builtin_fma(l, xs[1][j], s1);
+#pragma unroll
+            for (int q = 0; q < LV; ++q) {
+                const int j = kb + sw + bg + q * NG;
+                if (j < n) {
+                    s0 = __builtin_fma(lv[q], xs[0][j], s0);
+                    if (nvec == 2) s1 = __builtin_fma(lv[q], xs[1][j], s1);
                 }
-            // (NG row groups of SW columns: the first NW of them land in red, the others are added by their owners below)
-            static_assert(NG == NW || NG == 2 * NW, "row groups of the backward mat-vec");
+            }
             if (NG == 2 * NW) {
                 s0 += __shfl_xor(s0, 32);  // SW = 32: groups g and g + 1 share a wave
                 s1 += __shfl_xor(s1, 32);
             }
             if (NG == NW || (lane < 32)) {
-                red[0][wave][c] = s0;
-                red[1][wave][c] = s1;
+                red[0][wave][bc] = s0;
+                red[1][wave][bc] = s1;
             }
         }
-        {
-            const int j = tid % SW;
-            if (j < sw)
-                for (int i = tid / SW; i < sw; i += kWideSolveThreads / SW) P[i * ldp + j] = Lg[(size_t)(kb + i) * n + kb + j];
+#pragma unroll
+        for (int q = 0; q < DV; ++q) {
+            const int i = bg + q * NG;
+            if (bc < sw && i < sw) P[i * ldp + bc] = dv[q];
         }
-        if (tid < sw) rdl[tid] = rdg[kb + tid];
+        if (tid < sw) rdl[tid] = rdv;
+        const double ybase = tid < sw ? Lg[(size_t)n * n + kb + tid] : 0.0;  // (the forward-substituted right-hand side: written long ago)
+        if (kb > 0) prefetch_block(kb - SW);
         __syncthreads();
         if (tid < sw) {
             for (int v = 0; v < nvec; ++v) {
-                double t = v == 0 ? Lg[(size_t)n * n + kb + tid] : (kb + tid < r ? zrand[kb + tid] : 0.0);
+                double t = v == 0 ? ybase : (kb + tid < r ? zrand[kb + tid] : 0.0);
                 for (int w = 0; w < NW; ++w) t -= red[v][w][tid];
                 yv[v][tid] = t;
             }
