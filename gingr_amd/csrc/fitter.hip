@@ -149,6 +149,8 @@ struct gingr_fitter {
     bool allow_alt = false, corr_stale = false;
     double *fxbuf[2] = {nullptr, nullptr};
     unsigned *lp_sync = nullptr;  // hand-over words of posterior_logpdf_split_kernel
+    double *lp_scratch = nullptr;  // [rp*rp + 2 rp], ranks >= 128 on a row shard: where the two-workgroup transition density leaves its
+                                   // state-only part when no memo slot wants it (fitter_logpdf_finish; allocated on first use)
     unsigned lp_epoch = 0;
     bool fx_valid[2] = {false, false};
     // nfac[slot]: [rp*rp] Cholesky factor of I + G, [16*rp] the transposed inverses of its diagonal blocks -- left by the two-workgroup log-density kernel for the
@@ -792,6 +794,7 @@ void gingr_fitter_destroy(gingr_fitter *f) {
     dev_free(f->nfac[0]);
     dev_free(f->nfac[1]);
     dev_free(f->lp_sync);
+    dev_free(f->lp_scratch);
     dev_free(f->retry);
     dev_free(f->part);
     dev_free(f->absmax);
@@ -2303,7 +2306,15 @@ int fitter_logpdf_finish(gingr_fitter *f, double *logpdf) {
     const int32_t r = m->r, rp = m->rp;
     double *G = f->xch + f->off[1];
     double *rhs = G + (int64_t)rp * rp, *qte = rhs + rp + 8;
-    GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, rhs, m->mom + MomentLayout{rp}.stot(), qte, nullptr, false, f->work, f->small));
+    double *fx = nullptr;
+    unsigned *sync = nullptr;
+    unsigned epoch = 0;
+    if (rp >= 128) {  // the two factorisations side by side on the super-panel solve (gp.hip: posterior_logpdf_wide_kernel)
+        if (!f->lp_scratch) GINGR_TRY(dev_alloc(ctx, &f->lp_scratch, (size_t)rp * rp + 2 * rp));
+        if (f->lp_epoch == 0) HIP_TRY(ctx, hipMemsetAsync(f->lp_sync, 0, 2 * sizeof(unsigned), ctx->stream));  // before the first hand-over
+        fx = f->lp_scratch, sync = f->lp_sync, epoch = ++f->lp_epoch;
+    }
+    GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, rhs, m->mom + MomentLayout{rp}.stot(), qte, fx, false, f->work, f->small, sync, epoch));
     GINGR_TRY(check_launch(ctx));
     double *res = f->pin + (size_t)3 * m->M;
     HIP_TRY(ctx, hipMemcpyAsync(res, f->small, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -339,11 +339,13 @@ def test_group_along_normal_correspondence_equals_single_shard(reversed_directio
     multi.close()
 
 
-@pytest.mark.parametrize("flavour", [0, 1])
-def test_group_cpd_and_pointcloud_sample_and_logpdf(flavour):
+@pytest.mark.parametrize("flavour,rank", [(0, 40), (1, 40), (0, 150)])
+def test_group_cpd_and_pointcloud_sample_and_logpdf(flavour, rank):
     """The probabilistic proposal and log transition density of the CPD / point-cloud ICP flavours through three logical shards
-    against a single shard and the oracle."""
-    mo, target = _case()
+    against a single shard and the oracle.  Rank 150: the wide Gram pass, the super-panel solve and the two-workgroup transition
+    density on the global workspaces (rank >= 128) on row shards."""
+    mo, target = _case(rank=rank)
+    assert mo.rank == rank
     params = (0.1, 1.0) if flavour == 0 else (4.0, 1.0, 20)
     single = _group([0], mo, target)
     multi = _group(_devices(3), mo, target)
