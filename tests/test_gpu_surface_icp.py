@@ -104,14 +104,14 @@ def oracle_state_of(g, transform):
                     iteration=int(g.iteration), status=int(g.status), global_transformation=transform, step_length=g.stepLength)
 
 
-@pytest.mark.parametrize("transform", [0, 1])
-def test_icp_surface_updates_match_oracle(ctx, transform):
+@pytest.mark.parametrize("transform,rank", [(0, 30), (1, 30), (1, 130)])
+def test_icp_surface_updates_match_oracle(ctx, transform, rank):
     """Every update is checked against the oracle's update of the SAME input state: the accept / reject decisions are
     discontinuous in the fit, so two trajectories that differ by 1e-10 may legitimately part ways after a borderline pair flips;
     what must hold is that one update maps identical states to identical states."""
     import gingr_amd as ga
     ref, cells, target, tcells = femur()
-    mo, algo, state = make_state(ctx, ref, cells, target, tcells, rank=30)
+    mo, algo, state = make_state(ctx, ref, cells, target, tcells, rank=rank)   # (rank 130: 0 / 1 weights through the wide Gram pass)
     if transform != 1:
         state = algo.createInitialState(ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam, cells=cells), target, state.config,
                                         transform=transform, targetCells=tcells)

@@ -58,7 +58,8 @@ def test_posterior_mean_at_wide_ranks(ctx, rank):
     dm.close()
 
 
-@pytest.mark.parametrize("M,N,rank", [(700, 650, 128), (800, 700, 200), (900, 850, 256), (1000, 900, 330), (1200, 1100, 512)])
+@pytest.mark.parametrize("M,N,rank", [(700, 650, 128), (800, 700, 200), (900, 850, 256), (1000, 900, 330), (1200, 1100, 512),
+                                      (48, 40, 130), (171, 160, 512)])    # (the last two: barely more basis rows than columns)
 def test_cpd_updates_at_wide_ranks(ctx, M, N, rank):
     """Three fused CPD updates (fit pass with quarter boxes at rp > 128 included: the second update's culling reads them)."""
     import gingr_amd as ga
