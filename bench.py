@@ -346,6 +346,25 @@ def load_pmc_mfma(kernel: str, points: int, rank: int):
     return None
 
 
+def load_rocprof_avg_ms(kernel: str, points: int, rank: int):
+    """Average duration of `kernel` in the tracked rocprofv3 --kernel-trace --stats summary of THIS workload (profiles/rNN_bench50k_
+    kernel_stats_final.csv for the metric workload, rNN_bench50k_r256_kernel_stats.csv for model rank 256), next to the live HIP-event
+    figure: an event pair around a launch adds 2-3 us, which is 5 % of a 50 us kernel and nothing of a 1.2 ms one.  None when no summary
+    of this workload is tracked."""
+    import csv
+    if points != 50000 or rank not in (100, 256):
+        return None, None
+    path = _latest_profile("bench50k_kernel_stats_final.csv" if rank == 100 else "bench50k_r256_kernel_stats.csv")
+    try:
+        best = None
+        for row in csv.DictReader(open(path)):
+            if kernel in row["Name"] and (best is None or int(row["Calls"]) > best[1]):
+                best = (float(row["AverageNs"]) * 1e-6, int(row["Calls"]))
+        return (best[0], os.path.relpath(path, ROOT)) if best else (None, None)
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -772,6 +791,14 @@ def main():
         solve_name = ("posterior_solve_wide_kernel" if rp > 128 else "posterior_solve_lds_kernel")
         kernels.append({"kernel": solve_name, "avg_ms": ms / n, "launches": n, "bound": "latency",
                         "note": "one workgroup: r^3 / 3 flops on the critical path of the iteration"})
+    if n_shards == 1 and not args.emulate_world:
+        for k in kernels:   # the tracked rocprof summary of the same workload, where there is one
+            ms_r, src_r = load_rocprof_avg_ms(k["kernel"], M, args.rank)
+            if ms_r is not None:
+                k["rocprof_avg_ms"] = ms_r
+                k["rocprof_source"] = src_r
+                if "achieved" in k and k.get("avg_ms"):
+                    k["frac_from_rocprof"] = k["frac"] * k["avg_ms"] / ms_r
     # (the whole update as HIP events see it DURING these instrumented iterations: the per-kernel event pairs serialise the
     # launches, and the iterations sit at a later sigma2 than the timed ones -- so it is an upper bracket of ms_per_step, not a
     # second measurement of it)
