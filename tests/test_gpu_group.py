@@ -526,3 +526,43 @@ def test_phase_driven_reversed_direction_and_its_getter_on_shards(world, flavour
     one.close()
     for c in ctxs + [c1]:
         c.close()
+
+
+@pytest.mark.parametrize("zcut", [-0.6, 0.3])
+def test_group_surface_icp_downdate_and_its_guard_on_shards(ctx, zcut):
+    """Surface ICP at 41k vertices on two row shards (20k local rows each: GINGR_OPT_GRAM_DOWNDATE is on by size): with few rejected
+    rows (z cut -0.6: a small hole) every shard takes "moment minus its zero-weight rows", with two thirds rejected (z cut 0.3) the
+    device-side guard sends every shard to the pass over the basis -- both against one shard from the same state
+    (ClosestPointRegistrator.scala:84-91, ICP.scala:50,90-92)."""
+    import gingr_amd as ga
+    from gingr_amd import _native as nat
+    from tests.test_gpu_surface_icp import _icosphere
+    verts, cells = _icosphere(6)
+    ref = np.asarray(verts, dtype=np.float64) * 60.0
+    cells = np.asarray(cells, dtype=np.int32)
+    bump = 1.0 + 0.05 * np.sin(4 * verts[:, 0]) * np.cos(3 * verts[:, 1])
+    target = ref * bump[:, None] + np.array([0.5, -0.3, 0.4])
+    tcells = cells[np.all(verts[cells][:, :, 2] > zcut, axis=1)]
+    host = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.0, maxRank=40).Gaussian(30.0, 8.0).to_host()
+    params = (6.0, 1.0, 200)
+    groups = []
+    for devs in ([0], _devices(2)):
+        g = ga.DeviceGroup(devs)
+        g.upload_model(host.reference, host.mean, np.ascontiguousarray(host.basis), host.variance)
+        g.set_target(target)
+        g.set_meshes(cells, tcells, 0)
+        g.set_options(1, 1.0)
+        g.set_state(np.linspace(-0.2, 0.2, 40), 6.0)
+        groups.append(g)
+    single, multi = groups
+    for it in range(2):
+        a0, sc0, _ = single.get_state()
+        _set(multi, a0, sc0)
+        single.update(nat.FLAVOUR_ICP_SURFACE, params, 1)
+        multi.update(nat.FLAVOUR_ICP_SURFACE, params, 1)
+        a1, sc1, fit1 = single.get_state()
+        a2, sc2, fit2 = multi.get_state()
+        assert sc1.status == sc2.status == 0
+        assert rel(fit2, fit1) < 1e-9 and rel(a2, a1) < 1e-7, (it, rel(fit2, fit1), rel(a2, a1))
+    single.close()
+    multi.close()
