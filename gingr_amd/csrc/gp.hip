@@ -2511,18 +2511,20 @@ __global__ __launch_bounds__(kDenseThreads) void binv_kernel(int r, int rp, cons
     __syncthreads();
     const bool ok = block_cholesky(work, r, rp);
     if (threadIdx.x == 0) *err_flag = ok ? 0 : GINGR_ERR_NOT_SPD;
-    // thread c solves L L^T x = e_c; Binv is symmetric, column c is stored as row c (contiguous)
+    // thread c solves L L^T x = e_c and keeps x as COLUMN c of Binv (entry k at Binv[k * rp + c]): the threads of a wave then touch
+    // consecutive words (round 6; as row c -- a stride of rp between neighbouring threads -- this loop was 12 ms at r = 256); the
+    // factor's entries are the same address for every thread (broadcast)
     for (int c = threadIdx.x; c < r; c += blockDim.x) {
-        double *x = Binv + (int64_t)c * rp;
+        double *x = Binv + c;
         for (int k = 0; k < r; ++k) {
             double s = (k == c) ? 1.0 : 0.0;
-            for (int j = 0; j < k; ++j) s -= work[k * rp + j] * x[j];
-            x[k] = s / work[k * rp + k];
+            for (int j = 0; j < k; ++j) s -= work[k * rp + j] * x[(int64_t)j * rp];
+            x[(int64_t)k * rp] = s / work[k * rp + k];
         }
         for (int k = r - 1; k >= 0; --k) {
-            double s = x[k];
-            for (int j = k + 1; j < r; ++j) s -= work[j * rp + k] * x[j];
-            x[k] = s / work[k * rp + k];
+            double s = x[(int64_t)k * rp];
+            for (int j = k + 1; j < r; ++j) s -= work[j * rp + k] * x[(int64_t)j * rp];
+            x[(int64_t)k * rp] = s / work[k * rp + k];
         }
     }
 }
