@@ -1528,7 +1528,7 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 fa.scaled_src = m->mom + MomentLayout{rp}.stot();
                 fa.sigma2 = &f->st->sigma2;
                 fa.scaled_contribute = m->row_begin == 0 ? 1 : 0;
-            } else if (icp && f->icp_surface && !f->reversed && rp <= 112 &&
+            } else if (icp && f->icp_surface && !f->reversed &&
                        (ctx->gram_downdate == 1 || (ctx->gram_downdate < 0 && M >= kGramDowndateMinRows))) {
                 // surface correspondence: an accepted pair has the weight 1 / sigma2, a rejected one (and a vertex a landmark overrides) 0
                 // (ICP.scala:50,90-92) -- the weighted Gram is the model's moment minus the rows of the zero-weight vertices, scaled.

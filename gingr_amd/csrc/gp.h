@@ -173,6 +173,23 @@ struct ZeroGate {          // (plain data: ZeroGate{} and memset-zeroed argument
     int64_t M;
 };
 
+// ZeroGate (gp.h): does this launch run?  Called by ALL threads of the workgroup (one barrier pair); the same answer in every workgroup
+// of every launch that carries the same gate.
+__device__ __forceinline__ bool gate_open(const ZeroGate &g) {
+    if (!g.counts) return true;
+    __shared__ int gate_sum;
+    if (threadIdx.x == 0) gate_sum = 0;
+    __syncthreads();
+    int s = 0;
+    for (int b = threadIdx.x; b < g.nblocks; b += blockDim.x) s += g.counts[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(&gate_sum, s);  // (integers: the order does not matter)
+    __syncthreads();
+    const bool many = (int64_t)gate_sum * 8 > g.M;
+    return many == (g.run_if_many != 0);
+}
+
 // ---- basis sweeps ------------------------------------------------------------------------------------------
 enum SweepMode {
     SWEEP_RHS = 0,      // T only: out[k] = sum_i Q0_i^T e_i, e from evec planes
@@ -238,7 +255,7 @@ int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const d
 // the row-indexed {w, e} array of row_expand_kernel).  Returns the slab count.
 int64_t gram_wide_ws_doubles(int64_t M, int32_t rp);
 int launch_gram_wide(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, const double *evec,
-                     double *rhs_partial);
+                     double *rhs_partial, const ZeroGate *gate = nullptr);
 
 // one launch for the reductions at the end of phase 1 (gp.hip: phase1_finalize_kernel)
 struct Phase1FinalizeArgs {
@@ -267,7 +284,7 @@ struct Phase1FinalizeArgs {
 };
 void launch_phase1_finalize(gingr_ctx *ctx, const Phase1FinalizeArgs &a);
 // partial[b] = sum over the vertices i of slab b with weight[i] == 0 of Q0_i^T Q0_i (full rp x rp, zeros when the slab has none);
-// returns the slab count (<= 256: the workspace of launch_gram is large enough).  rp <= 112.
+// returns the slab count (<= 256: the workspace of launch_gram is large enough).  Any rp (112-column patches above 112).
 int launch_gram_downdate(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws,
                          const ZeroGate *gate = nullptr);
 

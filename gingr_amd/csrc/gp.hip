@@ -28,23 +28,6 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= 1.79769313486231570815e308; }
 
-// ZeroGate (gp.h): does this launch run?  Called by ALL threads of the workgroup (one barrier pair); the same answer in every workgroup
-// of every launch that carries the same gate.
-__device__ __forceinline__ bool gate_open(const ZeroGate &g) {
-    if (!g.counts) return true;
-    __shared__ int gate_sum;
-    if (threadIdx.x == 0) gate_sum = 0;
-    __syncthreads();
-    int s = 0;
-    for (int b = threadIdx.x; b < g.nblocks; b += blockDim.x) s += g.counts[b];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(&gate_sum, s);  // (integers: the order does not matter)
-    __syncthreads();
-    const bool many = (int64_t)gate_sum * 8 > g.M;
-    return many == (g.run_if_many != 0);
-}
-
 // Basis of a model on a NEW reference whose every point takes a fixed convex combination of three source points (nearest
 // neighbour: weights (1,0,0); triangle-mesh interpolation: barycentric weights of the closest surface point):
 //   Q0_new[(3 s + d) rp + q] = sum_k w[3 o + k] Q0_src[(3 inv_src[ids[3 o + k]] + d) rp + q],   o = row_begin + perm_new[s]
@@ -924,13 +907,29 @@ __global__ __launch_bounds__(256) void phase1_finalize_kernel(Phase1FinalizeArgs
 // Q^T Q of the vertices whose weight is exactly 0, slab by slab (launch_gram_downdate).  A workgroup owns the whole rp x rp matrix:
 // thread (ti, tj) of a 16 x 16 arrangement keeps the entries (ti + 16 a, tj + 16 b), a, b < 7, in registers.  It walks its slab's
 // vertices 256 at a time -- a ballot finds the zero-weight ones -- and adds, for each of them in ascending order, the three rows of the
-// basis (staged in LDS four vertices at a time: 14 reads per row and thread) as outer products: fixed order, no atomics.  rp <= 112.
+// basis (staged in LDS four vertices at a time: 14 reads per row and thread) as outer products: fixed order, no atomics.
 __global__ __launch_bounds__(256) void gram_downdate_kernel(const double *__restrict__ Q0, int64_t M, int rp, const double *__restrict__ weight,
                                                             int64_t verts_per_slab, double *__restrict__ partial, ZeroGate gate) {
     if (!gate_open(gate)) return;  // (workgroup-uniform: too many zero-weight rows, the pass over the basis behind this launch runs)
     constexpr int kBatch = 4;  // zero-weight vertices staged together: their rows are requested at once (a slab with several of them
                                // would otherwise pay one memory round trip per vertex, and the launch ends with its slowest slab)
-    __shared__ double q[kBatch][3][112];
+    // Ranks above 112 (round 6): the matrix is cut into 112-column patches and blockIdx.y picks one of the upper ones (pa <= pb); a
+    // workgroup then keeps the 7 x 7 entries per thread of ITS patch and stages the two column ranges of the rows.  One patch for
+    // rp <= 112: the code (and the bits) of round 5.
+    int pa = 0, pb = 0;
+    {
+        const int np = (rp + 111) / 112;
+        int t = blockIdx.y;
+        for (pa = 0; pa < np; ++pa) {
+            if (t < np - pa) {
+                pb = pa + t;
+                break;
+            }
+            t -= np - pa;
+        }
+    }
+    const int ca0 = 112 * pa, cb0 = 112 * pb;
+    __shared__ double q[kBatch][3][112], qb[kBatch][3][112];
     __shared__ unsigned long long zmask[16];
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;  // (tj fastest: the sixteen lanes of a row write 128 contiguous bytes)
     const int64_t v0 = (int64_t)blockIdx.x * verts_per_slab, v1 = v0 + verts_per_slab < M ? v0 + verts_per_slab : M;
@@ -979,15 +978,20 @@ __global__ __launch_bounds__(256) void gram_downdate_kernel(const double *__rest
             __syncthreads();  // (the previous batch's rows have been used)
             for (int t = tid; t < kBatch * 3 * 112; t += 256) {
                 const int s2 = t / (3 * 112), r2 = t - s2 * (3 * 112), d = r2 / 112, k = r2 - 112 * d;
-                if (s2 < nb) q[s2][d][k] = k < rp ? Q0[(3 * vz[s2] + d) * (int64_t)rp + k] : 0.0;
+                if (s2 < nb) {
+                    const double *row = Q0 + (3 * vz[s2] + d) * (int64_t)rp;
+                    q[s2][d][k] = ca0 + k < rp ? row[ca0 + k] : 0.0;
+                    if (pb != pa) qb[s2][d][k] = cb0 + k < rp ? row[cb0 + k] : 0.0;
+                }
             }
             __syncthreads();
+            const double(*qcol)[3][112] = pb != pa ? qb : q;  // (workgroup-uniform)
             for (int s2 = 0; s2 < nb; ++s2) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
                     double qi[7], qj[7];
 #pragma unroll
-                    for (int a = 0; a < 7; ++a) qi[a] = q[s2][d][ti + 16 * a], qj[a] = q[s2][d][tj + 16 * a];
+                    for (int a = 0; a < 7; ++a) qi[a] = q[s2][d][ti + 16 * a], qj[a] = qcol[s2][d][tj + 16 * a];
 #pragma unroll
                     for (int a = 0; a < 7; ++a)
 #pragma unroll
@@ -1001,7 +1005,7 @@ __global__ __launch_bounds__(256) void gram_downdate_kernel(const double *__rest
     for (int a = 0; a < 7; ++a)
 #pragma unroll
         for (int b = 0; b < 7; ++b) {
-            const int i = ti + 16 * a, j = tj + 16 * b;
+            const int i = ca0 + ti + 16 * a, j = cb0 + tj + 16 * b;
             if (i < rp && j < rp) out[i * rp + j] = acc[a][b];
         }
 }
@@ -3014,7 +3018,7 @@ int launch_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const d
             // rp >= 128: eight waves share the triangle (gp_wide.hip); the right-hand side rides along whenever it is asked for
             const bool fuse = evec && rhs_partial && rhs_done;
             if (fuse) *rhs_done = true;
-            nslabs = launch_gram_wide(ctx, Q0, M, rp, weight, ws, fuse ? evec : nullptr, fuse ? rhs_partial : nullptr);
+            nslabs = launch_gram_wide(ctx, Q0, M, rp, weight, ws, fuse ? evec : nullptr, fuse ? rhs_partial : nullptr, gate);
         }
     }
     if (G)  // nullptr: the caller reduces the slab partials itself (launch_phase1_finalize with the returned slab count)
@@ -3030,8 +3034,9 @@ int launch_gram_downdate(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp
     const int64_t want = std::max<int64_t>(1, std::min<int64_t>(std::min(nslabs_tri, 128), ceil_div(M, 64)));
     const int64_t vps = ceil_div(M, want);
     const int nslabs = (int)ceil_div(M, vps);
-    hipLaunchKernelGGL(gram_downdate_kernel, dim3((unsigned)nslabs), dim3(256), 0, ctx->stream, Q0, M, (int)rp, weight, vps, ws,
-                       gate ? *gate : ZeroGate{});
+    const int np = (rp + 111) / 112;  // 112-column patches; the upper ones only
+    hipLaunchKernelGGL(gram_downdate_kernel, dim3((unsigned)nslabs, (unsigned)(np * (np + 1) / 2)), dim3(256), 0, ctx->stream, Q0, M, (int)rp, weight,
+                       vps, ws, gate ? *gate : ZeroGate{});
     return nslabs;
 }
 

@@ -58,6 +58,7 @@ struct GramWideArgs {
     double *partial;        // [nslabs][rp * rp]
     double *rhs_partial;    // nullable: [nslabs][rp]
     int32_t nparts, tiles_per_part;
+    ZeroGate gate;  // (surface ICP: this pass runs only when the downdate in front of it left at once, gp.h)
 };
 
 // T: tiles per wave; SUB: 4-row sub-steps per barrier; the LDS buffers are laid out for NTCAP = 32 / SUB column tiles
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(64 * kWaves) void gram_wide_kernel(GramWideArgs A) 
     constexpr int FO = 4;              // fragments a wave fetches per step, at most: SUB * NTCAP / kWaves
     constexpr int kStepRows = 4 * SUB;
     extern __shared__ double xb[];     // [2][SUB][NTCAP][2][64]
+    if (!gate_open(A.gate)) return;    // (workgroup-uniform)
     const int lane = threadIdx.x & 63, kq = lane >> 4, cl = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NT = A.NT, rp = A.rp;
@@ -277,7 +279,7 @@ int64_t gram_wide_ws_doubles(int64_t M, int32_t rp) {
 
 // see gp.h; ws: gram_wide_ws_doubles(M, rp) doubles
 int launch_gram_wide(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, const double *evec,
-                     double *rhs_partial) {
+                     double *rhs_partial, const ZeroGate *gate) {
     const WidePlan p = wide_plan(M, rp);
     d2 *we = reinterpret_cast<d2 *>(ws + (int64_t)p.nslabs * rp * rp);
     hipLaunchKernelGGL(row_expand_kernel, dim3((unsigned)ceil_div(3 * M + kRowPad, 256)), dim3(256), 0, ctx->stream, weight, evec, M, we);
@@ -292,6 +294,7 @@ int launch_gram_wide(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, co
     a.rhs_partial = rhs_partial;
     a.nparts = p.nparts;
     a.tiles_per_part = p.tiles_per_part;
+    a.gate = gate ? *gate : ZeroGate{};
     const size_t lds = (size_t)2 * 4096 * sizeof(double);
     const dim3 grid((unsigned)(p.nslabs * p.nparts)), block(64 * kWaves);
     auto go = [&](auto kern) {

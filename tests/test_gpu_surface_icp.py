@@ -408,7 +408,8 @@ def test_triangle_grid_with_wide_triangles_and_a_flat_mesh_equals_the_tile_scan(
         assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
 
 
-def test_gram_downdate_equals_the_pass_over_the_basis(ctx):
+@pytest.mark.parametrize("rank", [40, 130])
+def test_gram_downdate_equals_the_pass_over_the_basis(ctx, rank):
     """GINGR_OPT_GRAM_DOWNDATE: with 0 / 1 weights the weighted Gram matrix is the model's moment minus the rows of the zero-weight
     vertices (rejected pairs, landmark vertices).  The exchange segment (Gram matrix + right-hand side) of the same state is the one
     the MFMA pass over the whole basis gives, up to the rounding of the subtraction -- with a quarter of the template rejected (open
@@ -426,8 +427,9 @@ def test_gram_downdate_equals_the_pass_over_the_basis(ctx):
     target = ref * bump[:, None] + np.array([1.0, -0.5, 0.8]) + rng.normal(0, 0.3, ref.shape)
     tcells = cells[~np.all(verts[cells][:, :, 2] > 0.55, axis=1)]       # a cap removed: the vertices over the hole map to its rim
     lm_pid = np.array([3, 77, 200], dtype=np.int32)
-    states = ((np.zeros(40), 6.0), (np.linspace(-0.3, 0.3, 40), 5.5))
-    model = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.0, maxRank=40).Gaussian(30.0, 8.0).to_host()   # (built once, on the session's context)
+    states = ((np.zeros(rank), 6.0), (np.linspace(-0.3, 0.3, rank), 5.5))
+    # (built once, on the session's context; rank 130: the downdate in 112-column patches against the wide Gram pass)
+    model = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.0, maxRank=rank).Gaussian(30.0, 8.0).to_host()
     got = {}
     for val in (1, 0):
         c = ga.Context(0)
@@ -461,8 +463,8 @@ def test_gram_downdate_equals_the_pass_over_the_basis(ctx):
         assert np.max(np.abs(aa - ab)) <= 1e-10 * max(1.0, np.max(np.abs(ab))) and np.max(np.abs(fa - fb)) <= 1e-10 * np.max(np.abs(fb))
 
 
-@pytest.mark.parametrize("zcut,lo,hi", [(0.30, 0.45, 0.85), (0.97, 0.95, 1.0)])
-def test_gram_downdate_leaves_to_the_pass_over_the_basis_when_many_rows_are_rejected(ctx, zcut, lo, hi):
+@pytest.mark.parametrize("zcut,lo,hi,rank", [(0.30, 0.45, 0.85, 40), (0.97, 0.95, 1.0, 40), (0.30, 0.45, 0.85, 130)])
+def test_gram_downdate_leaves_to_the_pass_over_the_basis_when_many_rows_are_rejected(ctx, zcut, lo, hi, rank):
     """The device-side guard of GINGR_OPT_GRAM_DOWNDATE (rule served: ClosestPointRegistrator.scala:84-91 -- a pair
     whose target point lies on the boundary is rejected, ICP.scala:50 gives it weight 0).  A 41k template against a target that is
     only a CAP of the sphere: most template vertices map to the rim and are rejected.  By size (the default) the option is on at 41k
@@ -483,7 +485,7 @@ def test_gram_downdate_leaves_to_the_pass_over_the_basis_when_many_rows_are_reje
     bump = 1.0 + 0.05 * np.sin(4 * verts[:, 0]) * np.cos(3 * verts[:, 1])
     target = ref * bump[:, None] + np.array([0.5, -0.3, 0.4])
     tcells = cells[np.all(verts[cells][:, :, 2] > zcut, axis=1)]             # only the cap above z = zcut is there
-    model = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.0, maxRank=40).Gaussian(30.0, 8.0).to_host()
+    model = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.0, maxRank=rank).Gaussian(30.0, 8.0).to_host()
     got, per_it = {}, {}
     for val in (-1, 0):
         c = ga.Context(0)
@@ -491,7 +493,7 @@ def test_gram_downdate_leaves_to_the_pass_over_the_basis_when_many_rows_are_reje
         f = ShardedFitter(c, model, target)
         f.set_meshes(cells, tcells)
         ip = nat.IcpParams(6.0, 1.0, 200)
-        f.set_state(np.linspace(-0.2, 0.2, 40), 6.0)
+        f.set_state(np.linspace(-0.2, 0.2, rank), 6.0)
         for ph in (0, 1):
             assert f._lib.gingr_fitter_icp_surface_phase_async(f.handle, ctypes.byref(ip), ph) == 0
         p, offs, cnts = ctypes.c_void_p(), (ctypes.c_int64 * nat.NUM_SEGMENTS)(), (ctypes.c_int64 * nat.NUM_SEGMENTS)()
@@ -505,7 +507,7 @@ def test_gram_downdate_leaves_to_the_pass_over_the_basis_when_many_rows_are_reje
         got[val] = (seg, w, a1.copy(), fit1.copy(), sc1.status)
         best = float("inf")
         for _ in range(5):                                                   # iteration time: 20 updates in one native call, best of five
-            f.set_state(np.linspace(-0.2, 0.2, 40), 6.0)
+            f.set_state(np.linspace(-0.2, 0.2, rank), 6.0)
             c.synchronize()
             t0 = time.perf_counter()
             assert f._lib.gingr_fitter_update_icp_surface_async(f.handle, ctypes.byref(ip), 20) == 0
@@ -523,7 +525,8 @@ def test_gram_downdate_leaves_to_the_pass_over_the_basis_when_many_rows_are_reje
     rec = {"rejected_fraction": rejected, "ms_per_iteration_guarded_default": per_it[-1] * 1e3, "ms_per_iteration_option_off": per_it[0] * 1e3,
            "extra_us": (per_it[-1] - per_it[0]) * 1e6}
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/r06_gram_downdate_guard_zcut{zcut}.json", "w") as fh:
+    rec["rank"] = rank
+    with open(f"gpurun_out/r06_gram_downdate_guard_zcut{zcut}_rank{rank}.json", "w") as fh:
         json.dump(rec, fh)
     # loose bound here (a wall-clock figure in a test); the measured difference is recorded above and in profiles/
     assert per_it[-1] <= 1.25 * per_it[0] + 10e-6, rec

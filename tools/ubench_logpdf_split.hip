@@ -23,7 +23,7 @@ TimerScope::TimerScope(gingr_ctx *c, int w) : ctx(c), which(w) {}
 void TimerScope::stop() {}
 TimerScope::~TimerScope() {}
 int64_t gram_wide_ws_doubles(int64_t, int32_t) { return 0; }
-int launch_gram_wide(gingr_ctx *, const double *, int64_t, int32_t, const double *, double *, const double *, double *) { return 0; }
+int launch_gram_wide(gingr_ctx *, const double *, int64_t, int32_t, const double *, double *, const double *, double *, const ZeroGate *) { return 0; }
 
 #include <cstdio>
 #include <random>
