@@ -342,9 +342,11 @@ __global__ void nonrigid_finish_kernel(const double *__restrict__ partial, doubl
     if (!(fabs(ns) <= 1.79769313486231570815e308)) *flag = GINGR_ERR_NONFINITE;
 }
 
+}  // namespace
+
 // Aw ((Mp + 64) x Mp, lower triangle of an SPD matrix + three right-hand sides in the border rows Mp .. Mp + 2, see
 // build_system_kernel) -> W (three planes of stride Mp): blocked right-looking Cholesky, then the blocked backward substitution.
-// *flag receives GINGR_ERR_NOT_SPD when a diagonal block fails.
+// *flag receives GINGR_ERR_NOT_SPD when a diagonal block fails.  (Also the posterior solve above rank 256: gp.hip, common.h.)
 void dense_spd_solve3(gingr_ctx *ctx, double *Aw, int64_t Mp, double *Linv, double *W, int32_t *flag) {
     const int nb = (int)(Mp / kNBc);
     for (int k = 0; k < nb; ++k) {
@@ -357,6 +359,8 @@ void dense_spd_solve3(gingr_ctx *ctx, double *Aw, int64_t Mp, double *Linv, doub
     for (int k = nb - 1; k >= 0; --k)
         hipLaunchKernelGGL(chol_backward_kernel, dim3((unsigned)(k + 1)), dim3(256), 0, ctx->stream, Aw, Mp, Mp, k, Linv, W);
 }
+
+namespace {
 
 // ------------------------------------------------------------------------------------------------ optimal-step non-rigid ICP
 // Normal equations of the stacked least-squares systems of NonRigidOptimalStepICP.scala (the reference solves `A \ B` on the sparse

@@ -3101,9 +3101,57 @@ void launch_chol_block64(gingr_ctx *ctx, double *Aw, int64_t ld, int k, double *
     hipLaunchKernelGGL(chol_block64_kernel, dim3(1), dim3(256), lds, ctx->stream, Aw, ld, k, Linv, flag);
 }
 
+namespace {
+// From rank 241 on the posterior mean takes the multi-workgroup blocked solve of the classic non-rigid CPD (classic_cpd.hip:
+// dense_spd_solve3 -- 64-column panels, the trailing update spread over the chip, one launch per stage): one compute unit's matrix
+// pipe is the floor of the one-workgroup kernel (380k cycles of MFMA at r = 512), the launches of this form cost ~6 us each.
+// Aw: (Mp + 64) x Mp, lower triangle of I + G with the identity on the padding, the right-hand side in border row Mp.
+__global__ __launch_bounds__(256) void solve_system_kernel(int r, int n, int64_t Mp, const double *__restrict__ G, const double *__restrict__ rhs,
+                                                           double *__restrict__ Aw, int32_t *__restrict__ flag) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    if (c == 0 && row == 0) *flag = 0;
+    if (c >= Mp) return;
+    double v = 0.0;
+    if (row < Mp) {
+        if (c <= row) v = (row < r && c < r) ? G[row * n + c] + (row == c ? 1.0 : 0.0) : (row == c ? 1.0 : 0.0);
+    } else if (row == Mp && c < r) {
+        v = rhs[c];
+    }
+    Aw[row * Mp + c] = v;
+}
+__global__ __launch_bounds__(256) void solve_finish_kernel(int r, int rp, const double *__restrict__ W, const int32_t *__restrict__ flag,
+                                                           double *__restrict__ a, DevState *__restrict__ st) {
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < rp; k += 256) {
+        const double v = k < r ? W[k] : 0.0;
+        a[k] = v;
+        if (!finite_d(v)) bad = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (*flag == GINGR_ERR_NOT_SPD)
+            st->err = GINGR_ERR_NOT_SPD;
+        else if (bad)
+            st->err = GINGR_ERR_NONFINITE;
+    }
+}
+}  // namespace
+
 void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *G, const double *rhs, const double *zrand,
                             double *work, double *a, DevState *st) {
     TimerScope ts(ctx, 5);
+    if (rp > 240 && !zrand) {  // (from rp = 256 on: 138 us against 145 there, 277 against 709 at rp = 512; a sampled proposal needs L^-T z as well: the one-workgroup kernel below)
+        const int64_t Mp = round_up(rp, 64), nb = Mp / 64;
+        double *Aw = work, *Linv = Aw + (Mp + 64) * Mp, *W = Linv + nb * 64 * 64;
+        int32_t *flag = reinterpret_cast<int32_t *>(W + 3 * Mp);
+        hipLaunchKernelGGL(solve_system_kernel, dim3((unsigned)ceil_div(Mp, 256), (unsigned)(Mp + 64)), dim3(256), 0, ctx->stream, (int)r, (int)rp, Mp, G,
+                           rhs, Aw, flag);
+        dense_spd_solve3(ctx, Aw, Mp, Linv, W, flag);
+        hipLaunchKernelGGL(solve_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, (int)r, (int)rp, W, flag, a, st);
+        return;
+    }
     if (r <= 128) {
         const bool fast = rp <= 112;  // sixteen identity rows fit beside the bordered matrix
         const size_t lds = lds_solve_doubles(rp, fast ? 2 * kNB : kNB) * sizeof(double);
