@@ -356,6 +356,7 @@ void dense_spd_solve3(gingr_ctx *ctx, double *Aw, int64_t Mp, double *Linv, doub
             hipLaunchKernelGGL(chol_trailing_kernel, dim3((unsigned)(nb - k - 1), (unsigned)(nb - k)), dim3(256), 0, ctx->stream, Aw, Mp, k,
                                nb);
     }
+    if (!W) return;  // (the factor alone: the lower triangle of Aw then holds L; gp.hip: launch_binv)
     for (int k = nb - 1; k >= 0; --k)
         hipLaunchKernelGGL(chol_backward_kernel, dim3((unsigned)(k + 1)), dim3(256), 0, ctx->stream, Aw, Mp, Mp, k, Linv, W);
 }

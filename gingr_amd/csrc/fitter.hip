@@ -454,7 +454,7 @@ void free_meshes(gingr_fitter *f) {
 
 int model_finalize_impl(gingr_ctx *ctx, gingr_model *m) {
     DevBuf work, flag;
-    HIP_TRY(ctx, work.alloc((size_t)m->rp * m->rp * sizeof(double)));
+    HIP_TRY(ctx, work.alloc((size_t)binv_work_doubles(m->rp) * sizeof(double)));
     HIP_TRY(ctx, flag.alloc(sizeof(int32_t)));
     launch_binv(ctx, m->r, m->rp, m->mom, work.as<double>(), m->Binv, flag.as<int32_t>());
     GINGR_TRY(check_launch(ctx));

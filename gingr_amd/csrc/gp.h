@@ -331,6 +331,8 @@ int launch_jacobi_eig(gingr_ctx *ctx, const double *G, int32_t ldg, int32_t n, d
 // doubles of the `work` buffer launch_posterior_solve / launch_posterior_logpdf need (used when r > 128)
 int64_t posterior_work_doubles(int32_t rp);
 // Binv = (S/eps + I)^-1  (work: [rp*rp]); *err_flag != 0 on failure
+// (work: binv_work_doubles(rp) doubles)
+int64_t binv_work_doubles(int32_t rp);
 void launch_binv(gingr_ctx *ctx, int32_t r, int32_t rp, const double *S, double *work, double *Binv, int32_t *err_flag);
 // out = Binv (p/eps)
 void launch_coeff_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *Binv, const double *p, double *out);

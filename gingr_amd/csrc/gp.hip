@@ -3283,8 +3283,79 @@ void launch_posterior_sample_cached(gingr_ctx *ctx, int32_t r, int32_t rp, const
     hipLaunchKernelGGL(posterior_sample_cached_kernel, dim3(1), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, nfac, a_mean, zrand, a, st);
 }
 
+namespace {
+// Binv above rank 112 (round 6; binv_kernel is one workgroup with one column of the inverse per thread held in global memory: 10 ms at
+// r = 256, 80 ms at r = 512).  The factor comes from the multi-workgroup blocked Cholesky (dense_spd_solve3 without right-hand sides);
+// then a workgroup of CB threads owns CB columns of the inverse: thread t solves L L^T x = e_c with ITS x in LDS (entry k of all CB
+// columns side by side: consecutive words) and the factor's entries -- the same address for every thread -- from L2.
+__global__ __launch_bounds__(256) void binv_system_kernel(int r, int rp, int64_t Mp, const double *__restrict__ S, double *__restrict__ Aw,
+                                                          double *__restrict__ Binv, int32_t *__restrict__ flag) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    if (c == 0 && row == 0) *flag = 0;
+    if (c >= Mp) return;
+    double v = 0.0;  // M = Q^T Q / eps + I, identity on the padding, a zero border block
+    if (row < Mp && c <= row) v = (row < r && c < r) ? S[row * rp + c] / GINGR_COEFF_NOISE + (row == c ? 1.0 : 0.0) : (row == c ? 1.0 : 0.0);
+    Aw[row * Mp + c] = v;
+    if (row < rp && c < rp) Binv[row * rp + c] = 0.0;
+}
+template <int CB>
+__global__ __launch_bounds__(CB) void binv_columns_kernel(int r, int rp, int64_t Mp, const double *__restrict__ L, double *__restrict__ Binv) {
+    extern __shared__ double xs[];  // [r][CB]
+    const int t = threadIdx.x, c = blockIdx.x * CB + t;
+    const int c0 = blockIdx.x * CB;  // entries above the block's first column are zero for every column of the block
+    for (int k = 0; k < r; ++k) xs[k * CB + t] = 0.0;
+    for (int k = c0; k < r; ++k) {  // L y = e_c
+        double s0 = (k == c) ? 1.0 : 0.0, s1 = 0.0;
+        const double *lk = L + (int64_t)k * Mp;
+        int j = c0;
+        for (; j + 1 < k; j += 2) {
+            s0 = __builtin_fma(-lk[j], xs[j * CB + t], s0);
+            s1 = __builtin_fma(-lk[j + 1], xs[(j + 1) * CB + t], s1);
+        }
+        if (j < k) s0 = __builtin_fma(-lk[j], xs[j * CB + t], s0);
+        xs[k * CB + t] = (s0 + s1) / lk[k];
+    }
+    for (int k = r - 1; k >= 0; --k) {  // L^T x = y
+        double s0 = xs[k * CB + t], s1 = 0.0;
+        int j = k + 1;
+        for (; j + 1 < r; j += 2) {
+            s0 = __builtin_fma(-L[(int64_t)j * Mp + k], xs[j * CB + t], s0);
+            s1 = __builtin_fma(-L[(int64_t)(j + 1) * Mp + k], xs[(j + 1) * CB + t], s1);
+        }
+        if (j < r) s0 = __builtin_fma(-L[(int64_t)j * Mp + k], xs[j * CB + t], s0);
+        xs[k * CB + t] = (s0 + s1) / L[(int64_t)k * Mp + k];
+    }
+    if (c < r)
+        for (int k = 0; k < r; ++k) Binv[(int64_t)k * rp + c] = xs[k * CB + t];  // column c (Binv is symmetric)
+}
+}  // namespace
+
+int64_t binv_work_doubles(int32_t rp) {
+    const int64_t Mp = round_up(rp, 64);
+    return std::max<int64_t>((int64_t)rp * rp, (Mp + 64) * Mp + (Mp / 64) * 64 * 64);
+}
+
 void launch_binv(gingr_ctx *ctx, int32_t r, int32_t rp, const double *S, double *work, double *Binv, int32_t *err_flag) {
-    hipLaunchKernelGGL(binv_kernel, dim3(1), dim3(kDenseThreads), 0, ctx->stream, (int)r, (int)rp, S, work, Binv, err_flag);
+    if (rp <= 112) {
+        hipLaunchKernelGGL(binv_kernel, dim3(1), dim3(kDenseThreads), 0, ctx->stream, (int)r, (int)rp, S, work, Binv, err_flag);
+        return;
+    }
+    const int64_t Mp = round_up(rp, 64);
+    double *Aw = work, *Linv = Aw + (Mp + 64) * Mp;
+    hipLaunchKernelGGL(binv_system_kernel, dim3((unsigned)ceil_div(Mp, 256), (unsigned)(Mp + 64)), dim3(256), 0, ctx->stream, (int)r, (int)rp, Mp, S, Aw,
+                       Binv, err_flag);
+    dense_spd_solve3(ctx, Aw, Mp, Linv, nullptr, err_flag);
+    if (r <= 256) {
+        constexpr int CB = 64;
+        const size_t lds = (size_t)r * CB * sizeof(double);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&binv_columns_kernel<CB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(binv_columns_kernel<CB>, dim3((unsigned)ceil_div(r, CB)), dim3(CB), lds, ctx->stream, (int)r, (int)rp, Mp, Aw, Binv);
+    } else {
+        constexpr int CB = 32;  // (64 columns of 512 entries would not fit the LDS)
+        const size_t lds = (size_t)r * CB * sizeof(double);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&binv_columns_kernel<CB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(binv_columns_kernel<CB>, dim3((unsigned)ceil_div(r, CB)), dim3(CB), lds, ctx->stream, (int)r, (int)rp, Mp, Aw, Binv);
+    }
 }
 
 
