@@ -788,9 +788,15 @@ def main():
                         "algorithmic_bytes": 24.0 * m_loc * r_model, "padded_rank": rp, "traffic": tr, "traffic_source": src})
     ms, n = timing(5)
     if n:
-        solve_name = ("posterior_solve_wide_kernel" if rp > 128 else "posterior_solve_lds_kernel")
-        kernels.append({"kernel": solve_name, "avg_ms": ms / n, "launches": n, "bound": "latency",
-                        "note": "one workgroup: r^3 / 3 flops on the critical path of the iteration"})
+        if rp > 240:    # the multi-workgroup blocked solve (gp.hip: launch_posterior_solve): one event pair around all of its launches
+            kernels.append({"kernel": "posterior solve (solve_system + per 64-column panel chol_block64 / chol_panel / chol_trailing / "
+                                      "chol_backward + solve_finish)", "avg_ms": ms / n, "launches": n, "bound": "latency",
+                            "note": "r^3 / 3 flops on the critical path of the iteration; ~6 us per launch, the 64 x 64 diagonal block "
+                                    "(one workgroup, 17 us) per panel"})
+        else:
+            solve_name = ("posterior_solve_wide_kernel" if rp > 128 else "posterior_solve_lds_kernel")
+            kernels.append({"kernel": solve_name, "avg_ms": ms / n, "launches": n, "bound": "latency",
+                            "note": "one workgroup: r^3 / 3 flops on the critical path of the iteration"})
     if n_shards == 1 and not args.emulate_world:
         for k in kernels:   # the tracked rocprof summary of the same workload, where there is one
             ms_r, src_r = load_rocprof_avg_ms(k["kernel"], M, args.rank)
