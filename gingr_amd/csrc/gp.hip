@@ -3090,7 +3090,11 @@ void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, 
 }
 
 // (two workspaces from rp = 128 on: the two workgroups of posterior_logpdf_wide_kernel factor side by side)
-int64_t posterior_work_doubles(int32_t rp) { return (int64_t)lds_solve_doubles(rp, kNB) * (rp >= 128 ? 2 : 1); }
+int64_t posterior_work_doubles(int32_t rp) {
+    const int64_t two_panel_workspaces = (int64_t)lds_solve_doubles(rp, kNB) * (rp >= 128 ? 2 : 1);
+    const int64_t two_dense_systems = rp > 240 ? 2 * (round_up(rp, 64) + 64) * round_up(rp, 64) + 2 * (round_up(rp, 64) / 64) * 4096 + 6 * round_up(rp, 64) + 4 : 0;
+    return std::max(two_panel_workspaces, two_dense_systems);
+}
 
 void launch_chol_block64(gingr_ctx *ctx, double *Aw, int64_t ld, int k, double *Linv, int32_t *flag) {
     const size_t lds = lds_solve_doubles(64, 64) * sizeof(double);
@@ -3135,6 +3139,82 @@ __global__ __launch_bounds__(256) void solve_finish_kernel(int r, int rp, const 
             st->err = GINGR_ERR_NOT_SPD;
         else if (bad)
             st->err = GINGR_ERR_NONFINITE;
+    }
+}
+}  // namespace
+
+namespace {
+// The transition density above padded rank 384 on the same multi-workgroup solve, twice: N a = rhs (solve_system_kernel) and K w = Q0^T e + eps
+// rhs with K = S_tot + eps N (this kernel builds its bordered system), then one workgroup forms |c|^2 = (w - a)^T (N w - rhs) and leaves
+// the factor of K, its reciprocal diagonal and a in fx for posterior_logpdf_cached_kernel.
+__global__ __launch_bounds__(256) void logpdf_system_kernel(int r, int n, int64_t Mp, const double *__restrict__ G, const double *__restrict__ Stot,
+                                                            const double *__restrict__ rhs, const double *__restrict__ qte, double *__restrict__ Aw,
+                                                            int32_t *__restrict__ flag) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    if (c == 0 && row == 0) *flag = 0;
+    if (c >= Mp) return;
+    double v = 0.0;
+    if (row < Mp) {
+        if (c <= row) {
+            if (row < r && c < r) {
+                v = __builtin_fma(GINGR_COEFF_NOISE, G[row * n + c], Stot[row * n + c]);
+                if (row == c) v += GINGR_COEFF_NOISE;
+            } else {
+                v = row == c ? 1.0 : 0.0;
+            }
+        }
+    } else if (row == Mp && c < r) {
+        v = __builtin_fma(GINGR_COEFF_NOISE, rhs[c], qte[c]);
+    }
+    Aw[row * Mp + c] = v;
+}
+__global__ __launch_bounds__(512) void logpdf_finish_kernel(int r, int n, int64_t Mp, const double *__restrict__ G, const double *__restrict__ rhs,
+                                                            const double *__restrict__ Wn, const double *__restrict__ Wk, const double *__restrict__ Lk,
+                                                            const int32_t *__restrict__ flag_n, const int32_t *__restrict__ flag_k,
+                                                            double *__restrict__ fx, double *__restrict__ out2) {
+    __shared__ double w[512], hv[2][512], red[512];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < n; k += 512) w[k] = k < r ? Wk[k] : 0.0;
+    __syncthreads();
+    for (int kk = tid & 255; kk < r; kk += 256) {  // (G w)_k: column k of the symmetric G, two halves of the row range, four chains each
+        const int half = tid >> 8;
+        const int j0 = half ? (r + 1) / 2 : 0, j1 = half ? r : (r + 1) / 2;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int j = j0;
+        for (; j + 3 < j1; j += 4) {
+            s0 = __builtin_fma(G[(int64_t)j * n + kk], w[j], s0);
+            s1 = __builtin_fma(G[(int64_t)(j + 1) * n + kk], w[j + 1], s1);
+            s2 = __builtin_fma(G[(int64_t)(j + 2) * n + kk], w[j + 2], s2);
+            s3 = __builtin_fma(G[(int64_t)(j + 3) * n + kk], w[j + 3], s3);
+        }
+        for (; j < j1; ++j) s0 = __builtin_fma(G[(int64_t)j * n + kk], w[j], s0);
+        hv[half][kk] = (s0 + s1) + (s2 + s3);
+    }
+    // the state-only part for the cached form: factor of K (rows of stride n), its reciprocal diagonal, a
+    for (int64_t e = tid; e < (int64_t)n * n; e += 512) {
+        const int64_t i = e / n, j = e - i * n;
+        fx[e] = j <= i ? Lk[i * Mp + j] : 0.0;
+    }
+    for (int k = tid; k < n; k += 512) {
+        fx[(int64_t)n * n + k] = k < r ? Wn[k] : 0.0;
+        fx[(int64_t)n * n + n + k] = 1.0 / Lk[(int64_t)k * Mp + k];
+    }
+    __syncthreads();
+    double part = 0.0;
+    for (int k = tid; k < r; k += 512) {
+        const double nw = (hv[0][k] + hv[1][k]) + w[k];  // (N w)_k
+        part = __builtin_fma(w[k] - Wn[k], nw - rhs[k], part);
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (int st2 = 256; st2 > 0; st2 >>= 1) {
+        if (tid < st2) red[tid] += red[tid + st2];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const bool bad = *flag_n != 0 || *flag_k != 0;
+        out2[0] = bad ? __builtin_nan("") : -0.5 * red[0] - 0.5 * (double)r * 1.8378770664093454836;  // log(2 pi)
+        out2[1] = bad ? 1.0 : 0.0;
     }
 }
 }  // namespace
@@ -3232,6 +3312,20 @@ int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
                                       (int)lds2);
         hipLaunchKernelGGL(posterior_logpdf_split_kernel, dim3(2), dim3(kSolveThreads), lds2, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte, fx,
                            out2, sync, epoch, keep_factor ? 1 : 0, nfac);
+        return GINGR_OK;
+    }
+    if (!cached && rp > 384 && fx) {  // above padded rank 384: both systems through the multi-workgroup blocked solve, one after the other
+                                      // (r = 512: 743 us against 1 024 for the two workgroups below; r = 300: 460 against 366, hence the limit)
+        const int64_t Mp = round_up(rp, 64), nb = Mp / 64, sys = (Mp + 64) * Mp + nb * 4096 + 3 * Mp + 2;
+        double *Aw0 = work, *Li0 = Aw0 + (Mp + 64) * Mp, *W0 = Li0 + nb * 4096;
+        double *Aw1 = work + sys, *Li1 = Aw1 + (Mp + 64) * Mp, *W1 = Li1 + nb * 4096;
+        int32_t *f0 = reinterpret_cast<int32_t *>(W0 + 3 * Mp), *f1 = reinterpret_cast<int32_t *>(W1 + 3 * Mp);
+        const dim3 grid((unsigned)ceil_div(Mp, 256), (unsigned)(Mp + 64));
+        hipLaunchKernelGGL(solve_system_kernel, grid, dim3(256), 0, ctx->stream, (int)r, (int)rp, Mp, G, rhs, Aw0, f0);
+        dense_spd_solve3(ctx, Aw0, Mp, Li0, W0, f0);
+        hipLaunchKernelGGL(logpdf_system_kernel, grid, dim3(256), 0, ctx->stream, (int)r, (int)rp, Mp, G, Stot, rhs, qte, Aw1, f1);
+        dense_spd_solve3(ctx, Aw1, Mp, Li1, W1, f1);
+        hipLaunchKernelGGL(logpdf_finish_kernel, dim3(1), dim3(512), 0, ctx->stream, (int)r, (int)rp, Mp, G, rhs, W0, W1, Aw1, f0, f1, fx, out2);
         return GINGR_OK;
     }
     if (!cached && !in_lds && fx && sync) {  // ranks above 112: the two factorisations side by side on the global workspaces
