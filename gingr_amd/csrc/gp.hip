@@ -1358,13 +1358,16 @@ __device__ __forceinline__ void lds_load_spd(double *A, int ld, int r, int n, co
 // wr (round 4): that many further rows behind the xr bordered ones take part in the panel solves ONLY (no trailing update).  Set to
 // the tiled identity (row c: ones in the columns c, 16 + c, 32 + c, ...) they come back holding W_k = L_kk^-T, the transposed inverse
 // of every diagonal block, in the columns of block k -- what lds_backward_w multiplies with instead of running the 16-step recurrence.
-template <int NT>
+// IDENT (round 6; chol_block64_kernel): the xr = n extra rows are the identity (they come back as L^-1).  Row n + c then stays zero in
+// every column left of c, so panel kb only has to carry the rows n .. n + kb + 16: the others' panel solves and trailing updates are
+// multiplications by zero (62 % of the riding work of four panels instead of all of it).
+template <int NT, bool IDENT = false>
 __device__ __forceinline__ void lds_cholesky(double *A, int ld, int n, double *rd, int *bad_spd, int xr, int wr = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = NT / 64;           // waves
     constexpr int PU = NT >= 1024 ? 2 : 4;  // matrix rows interleaved per 16-lane group in the panel solve
     constexpr int PR = (NT / 16) * PU;     // matrix rows per panel pass
-    const int rows = n + xr, prows = rows + wr;
+    const int rows_all = n + xr;
     // (1) diagonal block in registers, ONE wave (all four 16-lane rows do the same work: DPP needs the source lanes active).
     // No masks anywhere: the upper part of the block is loaded, carried and stored as it comes -- lane i's entries right of the
     // diagonal only ever feed lane i's own entries right of the diagonal, and nobody reads the upper part of A (the selects,
@@ -1427,6 +1430,7 @@ __device__ __forceinline__ void lds_cholesky(double *A, int ld, int n, double *r
     if (wave == 0) diag_block(0);
     __syncthreads();
     for (int kb = 0; kb < n; kb += kNB) {
+        const int rows = IDENT ? n + min(xr, kb + kNB) : rows_all, prows = rows + wr;
         GINGR_STAGE_CLOCK(1)
         // (2) panel below the diagonal block: x L11^T = A[i][kb:kb+16].  Sixteen lanes per matrix row: lane c keeps x[c] and
         // row c of L11 in registers; at step k every lane with c > k takes x[k] / L[k][k] from lane k through the DPP of its
@@ -1590,14 +1594,33 @@ __global__ __launch_bounds__(256) void chol_block64_kernel(double *__restrict__ 
     __shared__ int bad;
     const int tid = threadIdx.x;
     double *blk = Aw + ((int64_t)k * n) * ld + (int64_t)k * n;
-    for (int e = tid; e < n * n; e += 256) {
-        const int r = e >> 6, c = e & 63;
-        A[r * lda + c] = blk[(int64_t)r * ld + c];
-        A[(n + r) * lda + c] = r == c ? 1.0 : 0.0;
+#ifdef GINGR_CHOL64_STAMPS
+    GINGR_STAGE_CLOCK(7)
+#endif
+    {   // the sixteen entries of a thread requested together (one memory round trip; as a load-store loop this stage was 8.6k of
+        // the kernel's 40k cycles: every iteration waited for its own load)
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q;
+            v[q] = blk[(int64_t)(e >> 6) * ld + (e & 63)];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+            A[r * lda + c] = v[q];
+            A[(n + r) * lda + c] = r == c ? 1.0 : 0.0;
+        }
     }
     if (tid == 0) bad = 0;
     __syncthreads();
-    lds_cholesky<256>(A, lda, n, rd, &bad, n);
+#ifdef GINGR_CHOL64_STAMPS  // tools/ubench_chol_block64.hip only
+    GINGR_STAGE_CLOCK(0)
+#endif
+    lds_cholesky<256, true>(A, lda, n, rd, &bad, n);
+#ifdef GINGR_CHOL64_STAMPS
+    GINGR_STAGE_CLOCK(1)
+#endif
     double *li = Linv + (int64_t)k * n * n;
     for (int e = tid; e < n * n; e += 256) {
         const int r = e >> 6, c = e & 63;
@@ -1605,6 +1628,10 @@ __global__ __launch_bounds__(256) void chol_block64_kernel(double *__restrict__ 
         li[e] = c <= r ? A[(n + c) * lda + r] : 0.0;
     }
     if (tid == 0 && bad) *flag = GINGR_ERR_NOT_SPD;
+#ifdef GINGR_CHOL64_STAMPS
+    GINGR_STAGE_CLOCK(4)
+    GINGR_STAGE_CLOCK(6)
+#endif
 }
 
 // a = (I + G)^-1 rhs; with zrand != nullptr a posterior SAMPLE of the coefficients: a + L^-T z, z ~ N(0, I)
