@@ -1583,6 +1583,32 @@ __device__ __forceinline__ void lds_forward(const double *A, int ld, int n, cons
     }
 }
 
+// nrows x ncols (ncols <= 128) doubles from a row-major global matrix into the LDS matrix A, sixteen loads per thread requested
+// before the first store (round 6: as a plain load-store loop each element waits for its own memory round trip -- the lone
+// workgroup of these kernels has nothing else to hide it behind; chol_block64_kernel's copy went from 8.6k to 2.8k cycles this way)
+template <int NT>
+__device__ __forceinline__ void lds_fill_rows(double *A, int ld, const double *__restrict__ src, int64_t ld_src, int nrows, int ncols) {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int NW = NT / 64;
+    for (int i0 = w; i0 < nrows; i0 += NW * 8) {  // (workgroup-uniform trip count)
+        double v[8][2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = i0 + NW * q, j = l + 64 * h;
+                v[q][h] = (i < nrows && j < ncols) ? src[(int64_t)i * ld_src + j] : 0.0;
+            }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = i0 + NW * q, j = l + 64 * h;
+                if (i < nrows && j < ncols) A[i * ld + j] = v[q][h];
+            }
+    }
+}
+
 // Diagonal block of a blocked Cholesky that runs over many workgroups (classic_cpd.hip): factor the 64 x 64 block k of the
 // row-major matrix Aw in LDS with the building blocks above and invert the factor on the way -- the identity rides along as 64
 // extra rows, which come back as (L^-1 e_c)^T = row c of L^-T.  Aw block <- L (upper part zeroed), Linv[k] <- L^-1 (64 x 64, dense).
@@ -2472,8 +2498,7 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_sample_cached_kernel(
     __shared__ int bad;
     const int tid = threadIdx.x;
     if (tid == 0) bad = 0;
-    for (int i = tid >> 6; i < n + kNB; i += kSolveThreads / 64)  // (rows n .. n+15 of the copy are the W rows: same stride)
-        for (int j = tid & 63; j < n; j += 64) A[i * ld + j] = nfac[(int64_t)i * rp + j];
+    lds_fill_rows<kSolveThreads>(A, ld, nfac, rp, n + kNB, n);  // (rows n .. n+15 of the copy are the W rows: same stride)
     for (int k = tid; k < n; k += kSolveThreads) y2[k] = k < r ? zrand[k] : 0.0;
     __syncthreads();
     lds_backward_w<kSolveThreads>(A, ld, n, W, y2, x);
@@ -2510,8 +2535,12 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_cached_kernel(
     __shared__ double av[512];
     __shared__ double hv[2][512];
     const int tid = threadIdx.x;
-    for (int i = tid >> 6; i < n; i += kSolveThreads / 64)
-        for (int j = tid & 63; j < n; j += 64) A[i * ld + j] = fx[(int64_t)i * rp + j];
+    if constexpr (GW) {
+        for (int i = tid >> 6; i < n; i += kSolveThreads / 64)
+            for (int j = tid & 63; j < n; j += 64) A[i * ld + j] = fx[(int64_t)i * rp + j];
+    } else {
+        lds_fill_rows<kSolveThreads>(A, ld, fx, rp, n, n);
+    }
     for (int k = tid; k < n; k += kSolveThreads) {
         rd[k] = fx[(int64_t)rp * rp + rp + k];
         av[k] = k < r ? fx[(int64_t)rp * rp + k] : 0.0;
