@@ -1096,57 +1096,98 @@ __global__ void obs_points_kernel(const double *__restrict__ ref, const double *
 }
 
 // Landmark observations with a full 3x3 covariance: QtL block = Q_p^T Sigma^-1 in the posed frame, i.e.
-// W = R^T Sigma^-1 R in the model frame.  One block, landmarks applied sequentially (fixed order).
-__global__ __launch_bounds__(256) void landmarks_kernel(const double *__restrict__ Q0, const double *__restrict__ ref,
-                                                        const double *__restrict__ mean, int64_t M, int rp,
-                                                        const DevState *__restrict__ st, int n_lm,
-                                                        const int32_t *__restrict__ pid, const double *__restrict__ xyz,
-                                                        const double *__restrict__ cov, double *__restrict__ G,
-                                                        double *__restrict__ rhs) {
-    __shared__ double W[9], Wv[3];
-    for (int l = 0; l < n_lm; ++l) {
-        const int32_t p = pid[l];
-        if (p < 0 || p >= M) continue;  // owned by another shard
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const double *C = cov + 9 * l;
-            const double det = C[0] * (C[4] * C[8] - C[5] * C[7]) - C[1] * (C[3] * C[8] - C[5] * C[6]) +
-                               C[2] * (C[3] * C[7] - C[4] * C[6]);
-            double Ci[9];
-            Ci[0] = (C[4] * C[8] - C[5] * C[7]) / det;
-            Ci[1] = (C[2] * C[7] - C[1] * C[8]) / det;
-            Ci[2] = (C[1] * C[5] - C[2] * C[4]) / det;
-            Ci[3] = (C[5] * C[6] - C[3] * C[8]) / det;
-            Ci[4] = (C[0] * C[8] - C[2] * C[6]) / det;
-            Ci[5] = (C[2] * C[3] - C[0] * C[5]) / det;
-            Ci[6] = (C[3] * C[7] - C[4] * C[6]) / det;
-            Ci[7] = (C[1] * C[6] - C[0] * C[7]) / det;
-            Ci[8] = (C[0] * C[4] - C[1] * C[3]) / det;
-            const double *R = st->R;
-            double T[9];  // Ci * R
-            for (int a = 0; a < 3; ++a)
-                for (int b = 0; b < 3; ++b) T[a * 3 + b] = Ci[a * 3] * R[b] + Ci[a * 3 + 1] * R[3 + b] + Ci[a * 3 + 2] * R[6 + b];
-            for (int a = 0; a < 3; ++a)
-                for (int b = 0; b < 3; ++b) W[a * 3 + b] = R[a] * T[b] + R[3 + a] * T[3 + b] + R[6 + a] * T[6 + b];
-            const double dx = xyz[3 * l] - st->center[0] - st->t[0], dy = xyz[3 * l + 1] - st->center[1] - st->t[1],
-                         dz = xyz[3 * l + 2] - st->center[2] - st->t[2];
-            double v[3];
-            v[0] = R[0] * dx + R[3] * dy + R[6] * dz - (ref[p] - st->center[0]) - mean[p];
-            v[1] = R[1] * dx + R[4] * dy + R[7] * dz - (ref[M + p] - st->center[1]) - mean[M + p];
-            v[2] = R[2] * dx + R[5] * dy + R[8] * dz - (ref[2 * M + p] - st->center[2]) - mean[2 * M + p];
-            for (int a = 0; a < 3; ++a) Wv[a] = W[a * 3] * v[0] + W[a * 3 + 1] * v[1] + W[a * 3 + 2] * v[2];
+// W = R^T Sigma^-1 R in the model frame.  Workgroup a < rp owns row a of G, workgroup rp owns rhs; every entry sums
+// its landmarks in registers in landmark order and touches G once (the per-landmark read-modify-write of one
+// workgroup cost 16 us a landmark).  The 3x3 algebra of a landmark is repeated by one lane of every workgroup.
+constexpr int kLmChunk = 256;
+__global__ __launch_bounds__(kLmChunk) void landmarks_kernel(const double *__restrict__ Q0, const double *__restrict__ ref,
+                                                             const double *__restrict__ mean, int64_t M, int rp,
+                                                             const DevState *__restrict__ st, int n_lm,
+                                                             const int32_t *__restrict__ pid,
+                                                             const double *__restrict__ xyz,
+                                                             const double *__restrict__ cov, double *__restrict__ G,
+                                                             double *__restrict__ rhs) {
+    __shared__ double u[kLmChunk][3];  // row a: sum_d q[d][a] W[d][.]   |   rhs workgroup: W v
+    __shared__ int32_t row[kLmChunk];
+    const int a = blockIdx.x;
+    const bool is_rhs = a == rp;
+    constexpr int kCols = 2;  // columns per lane and pass (ranks up to 512 in one pass)
+    for (int b0 = 0; b0 < rp; b0 += kCols * kLmChunk) {
+        double s[kCols];
+        for (int c = 0; c < kCols; ++c) s[c] = 0.0;
+        for (int l0 = 0; l0 < n_lm; l0 += kLmChunk) {
+            __syncthreads();
+            const int l = l0 + (int)threadIdx.x;
+            int32_t p = l < n_lm ? pid[l] : -1;
+            if (p < 0 || p >= M) p = -1;  // owned by another shard
+            double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+            if (p >= 0) {
+                const double *C = cov + 9 * (int64_t)l;
+                const double det = C[0] * (C[4] * C[8] - C[5] * C[7]) - C[1] * (C[3] * C[8] - C[5] * C[6]) +
+                                   C[2] * (C[3] * C[7] - C[4] * C[6]);
+                double Ci[9];
+                Ci[0] = (C[4] * C[8] - C[5] * C[7]) / det;
+                Ci[1] = (C[2] * C[7] - C[1] * C[8]) / det;
+                Ci[2] = (C[1] * C[5] - C[2] * C[4]) / det;
+                Ci[3] = (C[5] * C[6] - C[3] * C[8]) / det;
+                Ci[4] = (C[0] * C[8] - C[2] * C[6]) / det;
+                Ci[5] = (C[2] * C[3] - C[0] * C[5]) / det;
+                Ci[6] = (C[3] * C[7] - C[4] * C[6]) / det;
+                Ci[7] = (C[1] * C[6] - C[0] * C[7]) / det;
+                Ci[8] = (C[0] * C[4] - C[1] * C[3]) / det;
+                const double *R = st->R;
+                double T[9], W[9];  // T = Ci * R
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j)
+                        T[i * 3 + j] = Ci[i * 3] * R[j] + Ci[i * 3 + 1] * R[3 + j] + Ci[i * 3 + 2] * R[6 + j];
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) W[i * 3 + j] = R[i] * T[j] + R[3 + i] * T[3 + j] + R[6 + i] * T[6 + j];
+                if (is_rhs) {
+                    const double dx = xyz[3 * l] - st->center[0] - st->t[0], dy = xyz[3 * l + 1] - st->center[1] - st->t[1],
+                                 dz = xyz[3 * l + 2] - st->center[2] - st->t[2];
+                    double v[3];
+                    v[0] = R[0] * dx + R[3] * dy + R[6] * dz - (ref[p] - st->center[0]) - mean[p];
+                    v[1] = R[1] * dx + R[4] * dy + R[7] * dz - (ref[M + p] - st->center[1]) - mean[M + p];
+                    v[2] = R[2] * dx + R[5] * dy + R[8] * dz - (ref[2 * M + p] - st->center[2]) - mean[2 * M + p];
+                    o0 = W[0] * v[0] + W[1] * v[1] + W[2] * v[2];
+                    o1 = W[3] * v[0] + W[4] * v[1] + W[5] * v[2];
+                    o2 = W[6] * v[0] + W[7] * v[1] + W[8] * v[2];
+                } else {
+                    const double *q = Q0 + (int64_t)3 * p * rp + a;
+                    const double q0 = q[0], q1 = q[rp], q2 = q[2 * rp];
+                    o0 = q0 * W[0] + q1 * W[3] + q2 * W[6];
+                    o1 = q0 * W[1] + q1 * W[4] + q2 * W[7];
+                    o2 = q0 * W[2] + q1 * W[5] + q2 * W[8];
+                }
+            }
+            u[threadIdx.x][0] = o0;
+            u[threadIdx.x][1] = o1;
+            u[threadIdx.x][2] = o2;
+            row[threadIdx.x] = p;
+            __syncthreads();
+            const int nl = min(kLmChunk, n_lm - l0);
+            for (int k = 0; k < nl; ++k) {
+                const int32_t pk = row[k];
+                if (pk < 0) continue;
+                const double *q = Q0 + (int64_t)3 * pk * rp;
+                const double u0 = u[k][0], u1 = u[k][1], u2 = u[k][2];
+#pragma unroll
+                for (int c = 0; c < kCols; ++c) {
+                    const int b = b0 + c * kLmChunk + (int)threadIdx.x;
+                    if (b < rp) s[c] += u0 * q[b] + u1 * q[rp + b] + u2 * q[2 * rp + b];
+                }
+            }
         }
-        __syncthreads();
-        const double *q = Q0 + (int64_t)3 * p * rp;
-        for (int idx = threadIdx.x; idx < rp * rp; idx += blockDim.x) {
-            const int a = idx / rp, b = idx - a * rp;
-            double s = 0.0;
-            for (int d = 0; d < 3; ++d)
-                for (int e = 0; e < 3; ++e) s += q[d * rp + a] * W[d * 3 + e] * q[e * rp + b];
-            G[idx] += s;
+#pragma unroll
+        for (int c = 0; c < kCols; ++c) {
+            const int b = b0 + c * kLmChunk + (int)threadIdx.x;
+            if (b < rp) {
+                if (is_rhs)
+                    rhs[b] += s[c];
+                else
+                    G[(int64_t)a * rp + b] += s[c];
+            }
         }
-        for (int a = threadIdx.x; a < rp; a += blockDim.x)
-            rhs[a] += q[a] * Wv[0] + q[rp + a] * Wv[1] + q[2 * rp + a] * Wv[2];
     }
 }
 
@@ -3141,7 +3182,7 @@ void launch_obs_points(gingr_ctx *ctx, const gingr_model *m, const DevState *st,
 void launch_landmarks(gingr_ctx *ctx, const gingr_model *m, const DevState *st, int32_t n_lm, const int32_t *lm_pid_local,
                       const double *lm_xyz, const double *lm_cov, double *G, double *rhs) {
     if (n_lm <= 0) return;
-    hipLaunchKernelGGL(landmarks_kernel, dim3(1), dim3(256), 0, ctx->stream, m->Q0, m->ref, m->mean, m->M, (int)m->rp, st,
+    hipLaunchKernelGGL(landmarks_kernel, dim3((unsigned)m->rp + 1), dim3(kLmChunk), 0, ctx->stream, m->Q0, m->ref, m->mean, m->M, (int)m->rp, st,
                        (int)n_lm, lm_pid_local, lm_xyz, lm_cov, G, rhs);
 }
 
