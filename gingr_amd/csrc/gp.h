@@ -328,6 +328,11 @@ void launch_posterior_solve_eig(gingr_ctx *ctx, int32_t r, int32_t rp, const dou
 // eigen-decomposition of the leading n x n block of the symmetric G (row stride ldg): evals [n] descending, Vs [n*n] (Vs[i*n + k] =
 // component i of eigenvector k); one workgroup, cyclic Jacobi (gpmm.hip)
 int launch_jacobi_eig(gingr_ctx *ctx, const double *G, int32_t ldg, int32_t n, double *evals, double *Vs);
+// eig.hip: one-sided register Jacobi on the Cholesky factor, n <= kSymEigColsMaxN, up to three problems per launch (see sym_eig, gpmm.hip)
+constexpr int kSymEigColsMaxN = 192;
+int64_t sym_eig_cols_work_doubles(int32_t n);
+void launch_sym_eig_cols(gingr_ctx *ctx, int count, const double *const *G, const int32_t *ldg, const int32_t *n, double *const *work,
+                         double *const *evals, double *const *Vs, int32_t *const *info);
 // doubles of the `work` buffer launch_posterior_solve / launch_posterior_logpdf need (used when r > 128)
 int64_t posterior_work_doubles(int32_t rp);
 // Binv = (S/eps + I)^-1  (work: [rp*rp]); *err_flag != 0 on failure

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kJacThreads) void jacobi_eig_kernel(const double *_
             __syncthreads();
             // columns of A and V
             for (int idx = t; idx < half * n; idx += kJacThreads) {
-                const int m = idx / n, i = idx - m * n;
+                const int i = idx / half, m = idx - i * half;  // neighbouring lanes: one row, different pairs
                 const int p = pq[m][0], q = pq[m][1];
                 const double c = cs[m][0], s = cs[m][1];
                 if (q < 0 || s == 0.0) continue;
@@ -497,20 +497,71 @@ int check(gingr_ctx *ctx) {
 
 }  // namespace
 
-int launch_jacobi_eig(gingr_ctx *ctx, const double *G, int32_t ldg, int32_t n, double *evals, double *Vs) {
-    if (n < 1 || n > kJacMaxN) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "jacobi_eig: n = %d outside 1..%d", (int)n, kJacMaxN);
-    DevBuf wA, wV, sw;
+// One decomposition with the two-sided kernel (any n <= 512; the fallback of sym_eig, and its path above kSymEigColsMaxN)
+static int jacobi_two_sided(gingr_ctx *ctx, const double *G, int32_t ldg, int32_t n, double *evals, double *Vs, int32_t *sweeps) {
+    DevBuf wA, wV;
     HIP_TRY(ctx, wA.alloc((size_t)n * n * sizeof(double)));
     HIP_TRY(ctx, wV.alloc((size_t)n * n * sizeof(double)));
-    HIP_TRY(ctx, sw.alloc(sizeof(int32_t)));
     hipLaunchKernelGGL(jacobi_eig_kernel, dim3(1), dim3(kJacThreads), 0, ctx->stream, G, ldg, n, wA.as<double>(), wV.as<double>(), evals, Vs,
-                       sw.as<int32_t>());
+                       sweeps);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the work buffers go out of scope
     return GINGR_OK;
 }
 
+// Eigen-decompositions of up to three symmetric positive semi-definite matrices (leading n[q] x n[q] block of G[q], row stride ldg[q]):
+// evals[q] descending, Vs[q][:, k] the matching eigenvectors.  Up to kSymEigColsMaxN the register kernel of eig.hip, all problems in
+// one launch; a problem it reports as numerically singular or not converged -- and anything larger -- goes through the two-sided
+// kernel.  Synchronises the stream.  GINGR_ERR_NONFINITE when a decomposition does not converge.
+static int sym_eig(gingr_ctx *ctx, int count, const double *const *G, const int32_t *ldg, const int32_t *n, double *const *evals,
+            double *const *Vs) {
+    if (count < 1 || count > 3) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "sym_eig: 1..3 problems");
+    bool redo[3] = {false, false, false};
+    DevBuf work[3], info;
+    HIP_TRY(ctx, info.alloc(3 * 2 * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMemsetAsync(info.p, 0, 3 * 2 * sizeof(int32_t), ctx->stream));
+    const double *fG[3];
+    int32_t fld[3], fn[3];
+    double *fw[3], *fe[3], *fv[3];
+    int32_t *fi[3];
+    int fast = 0, fast_of[3];
+    for (int q = 0; q < count; ++q) {
+        if (n[q] < 1 || n[q] > kJacMaxN) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "sym_eig: n = %d outside 1..%d", (int)n[q], kJacMaxN);
+        if (n[q] > kSymEigColsMaxN) {
+            redo[q] = true;
+            continue;
+        }
+        HIP_TRY(ctx, work[q].alloc((size_t)sym_eig_cols_work_doubles(n[q]) * sizeof(double)));
+        fG[fast] = G[q], fld[fast] = ldg[q], fn[fast] = n[q], fw[fast] = work[q].as<double>(), fe[fast] = evals[q], fv[fast] = Vs[q];
+        fi[fast] = info.as<int32_t>() + 2 * q;
+        fast_of[fast++] = q;
+    }
+    if (fast) {
+        launch_sym_eig_cols(ctx, fast, fG, fld, fn, fw, fe, fv, fi);
+        HIP_TRY(ctx, hipGetLastError());
+        int32_t h[6];
+        HIP_TRY(ctx, hipMemcpyAsync(h, info.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (int f = 0; f < fast; ++f) {
+            const int q = fast_of[f];
+            if (h[2 * q] >= 60 || h[2 * q + 1]) redo[q] = true;
+        }
+    }
+    for (int q = 0; q < count; ++q) {
+        if (!redo[q]) continue;
+        GINGR_TRY(jacobi_two_sided(ctx, G[q], ldg[q], n[q], evals[q], Vs[q], info.as<int32_t>() + 2 * q));
+        int32_t sw = 0;
+        HIP_TRY(ctx, hipMemcpy(&sw, info.as<int32_t>() + 2 * q, sizeof(sw), hipMemcpyDeviceToHost));
+        if (sw >= 60) return gingr_set_error(ctx, GINGR_ERR_NONFINITE, "sym_eig: Jacobi did not converge (n = %d)", (int)n[q]);
+    }
+    return GINGR_OK;
+}
 
+int launch_jacobi_eig(gingr_ctx *ctx, const double *G, int32_t ldg, int32_t n, double *evals, double *Vs) {
+    const double *Gs[1] = {G};
+    double *es[1] = {evals}, *vs[1] = {Vs};
+    return sym_eig(ctx, 1, Gs, &ldg, &n, es, vs);
+}
 
 extern "C" {
 
@@ -729,27 +780,24 @@ int gingr_gpmm_build_diagonal(gingr_ctx *ctx, int64_t M_total, const double *ref
         GINGR_TRY(fg.run_to_tolerance(relative_tolerance));
         const int32_t n = fg.ks;
         if (n < 1) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "gpmm_build: empty model (tolerance too large)");
-        DevBuf G, wA, wV, ev, V, B, sw;
+        DevBuf G, ev, V, B;
         HIP_TRY(ctx, G.alloc((size_t)n * n * sizeof(double)));
-        HIP_TRY(ctx, wA.alloc((size_t)n * n * sizeof(double)));
-        HIP_TRY(ctx, wV.alloc((size_t)n * n * sizeof(double)));
         HIP_TRY(ctx, ev.alloc((size_t)(n + 1) * sizeof(double)));
         HIP_TRY(ctx, V.alloc((size_t)(n * n + 1) * sizeof(double)));
         HIP_TRY(ctx, B.alloc((size_t)n * 3 * M * sizeof(double)));
-        HIP_TRY(ctx, sw.alloc(sizeof(int32_t)));
-        HIP_TRY(ctx, hipMemsetAsync(sw.p, 0, sizeof(int32_t), ctx->stream));
         hipLaunchKernelGGL(pc_gram_kernel, dim3(n, n), dim3(kPcBlock), 0, ctx->stream, fg.Lb.as<double>(), 3 * M, n, G.as<double>());
-        hipLaunchKernelGGL(jacobi_eig_kernel, dim3(1), dim3(kJacThreads), 0, ctx->stream, G.as<double>(), n, n, wA.as<double>(),
-                           wV.as<double>(), ev.as<double>(), V.as<double>(), sw.as<int32_t>());
+        {
+            const double *Gs[1] = {G.as<double>()};
+            double *es[1] = {ev.as<double>()}, *vs[1] = {V.as<double>()};
+            const int32_t ns[1] = {n};
+            GINGR_TRY(sym_eig(ctx, 1, Gs, ns, ns, es, vs));
+        }
         hipLaunchKernelGGL(lv_kernel, dim3((unsigned)ceil_div(3 * M, 256), n), dim3(256), 0, ctx->stream, fg.Lb.as<double>(), 3 * M, n,
                            V.as<double>(), B.as<double>());
         GINGR_TRY(check(ctx));
         std::vector<double> hev((size_t)n);
-        int32_t hsw = 0;
         HIP_TRY(ctx, hipMemcpyAsync(hev.data(), ev.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(&hsw, sw.p, sizeof(hsw), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (hsw >= 60) return gingr_set_error(ctx, GINGR_ERR_NONFINITE, "gpmm_build: Jacobi did not converge");
         for (auto &v : hev) v = v > 0.0 ? v : 0.0;
         auto fill = [&](gingr_model *m) -> int {
             const int64_t total = 3 * m->M * m->rp;
@@ -796,38 +844,36 @@ int gingr_gpmm_build_diagonal(gingr_ctx *ctx, int64_t M_total, const double *ref
         if (b < 0) b = nblocks++, block_n[b] = cnt[d];
         dim_block[d] = b;
     }
-    DevBuf G[3], wA, wV, ev[3], V[3], B[3], sw;
+    DevBuf G[3], ev[3], V[3], B[3];
     int32_t kkmax = 0;
     for (int b = 0; b < nblocks; ++b) kkmax = std::max(kkmax, block_n[b]);
-    HIP_TRY(ctx, wA.alloc((size_t)kkmax * kkmax * sizeof(double)));
-    HIP_TRY(ctx, wV.alloc((size_t)kkmax * kkmax * sizeof(double)));
-    HIP_TRY(ctx, sw.alloc(4 * sizeof(int32_t)));
-    HIP_TRY(ctx, hipMemsetAsync(sw.p, 0, 4 * sizeof(int32_t), ctx->stream));
     int32_t set_kk[3] = {kkmax, 0, 0};
     HIP_TRY(ctx, G[0].alloc((size_t)kkmax * kkmax * sizeof(double)));
     hipLaunchKernelGGL(pc_gram_kernel, dim3(kkmax, kkmax), dim3(kPcBlock), 0, ctx->stream, fac[0].Lb.as<double>(), M, kkmax,
                        G[0].as<double>());
     std::vector<double> hev[3];
-    for (int b = 0; b < nblocks; ++b) {
-        const int32_t nb_ = block_n[b];
-        const int q = block_set[b];
-        HIP_TRY(ctx, ev[b].alloc((size_t)(nb_ + 1) * sizeof(double)));
-        HIP_TRY(ctx, V[b].alloc((size_t)(nb_ * nb_ + 1) * sizeof(double)));
-        HIP_TRY(ctx, B[b].alloc(((size_t)nb_ * M + 1) * sizeof(double)));
-        hipLaunchKernelGGL(jacobi_eig_kernel, dim3(1), dim3(kJacThreads), 0, ctx->stream, G[q].as<double>(), set_kk[q], nb_,
-                           wA.as<double>(), wV.as<double>(), ev[b].as<double>(), V[b].as<double>(), sw.as<int32_t>() + b);
-        hipLaunchKernelGGL(lv_kernel, dim3((unsigned)ceil_div(M, 256), nb_), dim3(256), 0, ctx->stream, fac[q].Lb.as<double>(), M, nb_,
-                           V[b].as<double>(), B[b].as<double>());
-        hev[b].resize((size_t)nb_);
+    {
+        const double *Gs[3];
+        double *es[3], *vs[3];
+        int32_t lds[3], ns[3];
+        for (int b = 0; b < nblocks; ++b) {
+            const int32_t nb_ = block_n[b];
+            const int q = block_set[b];
+            HIP_TRY(ctx, ev[b].alloc((size_t)(nb_ + 1) * sizeof(double)));
+            HIP_TRY(ctx, V[b].alloc((size_t)(nb_ * nb_ + 1) * sizeof(double)));
+            HIP_TRY(ctx, B[b].alloc(((size_t)nb_ * M + 1) * sizeof(double)));
+            Gs[b] = G[q].as<double>(), lds[b] = set_kk[q], ns[b] = nb_, es[b] = ev[b].as<double>(), vs[b] = V[b].as<double>();
+            hev[b].resize((size_t)nb_);
+        }
+        GINGR_TRY(sym_eig(ctx, nblocks, Gs, lds, ns, es, vs));  // the blocks side by side, one workgroup each
     }
+    for (int b = 0; b < nblocks; ++b)
+        hipLaunchKernelGGL(lv_kernel, dim3((unsigned)ceil_div(M, 256), block_n[b]), dim3(256), 0, ctx->stream,
+                           fac[block_set[b]].Lb.as<double>(), M, block_n[b], V[b].as<double>(), B[b].as<double>());
     GINGR_TRY(check(ctx));
-    int32_t hsw[4] = {0, 0, 0, 0};
     for (int b = 0; b < nblocks; ++b)
         HIP_TRY(ctx, hipMemcpyAsync(hev[b].data(), ev[b].p, hev[b].size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(hsw, sw.p, sizeof(hsw), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (int b = 0; b < nblocks; ++b)
-        if (hsw[b] >= 60) return gingr_set_error(ctx, GINGR_ERR_NONFINITE, "gpmm_build: Jacobi did not converge");
 
     // merged eigenpairs, descending; equal eigenvalues keep coordinate order (x, y, z)
     struct Col {

@@ -8,6 +8,6 @@ F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -
 /opt/rocm/bin/hipcc $F $DA -c $UA.hip -o build_$NAME/$UA.o &
 /opt/rocm/bin/hipcc $F $DB -c $UB.hip -o build_$NAME/$UB.o &
 wait
-OBJS=$(for o in context affinity nn_grid gp gp_wide fitter group rccl_exchange gpmm surface classic_cpd rigid_icp; do if [ $o = $UA ] || [ $o = $UB ]; then echo build_$NAME/$o.o; else echo $o.o; fi; done)
+OBJS=$(for o in context affinity nn_grid gp gp_wide eig fitter group rccl_exchange gpmm surface classic_cpd rigid_icp; do if [ $o = $UA ] || [ $o = $UB ]; then echo build_$NAME/$o.o; else echo $o.o; fi; done)
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../libgingr_hip_$NAME.so $OBJS -lpthread -ldl
 echo built $NAME
