@@ -17,6 +17,7 @@
 #include "fastexp.h"
 
 #include <algorithm>
+#include <thread>
 #include <cstdlib>
 #include <utility>
 
@@ -1874,12 +1875,20 @@ void launch_scatter(gingr_ctx *ctx, const double *in, int64_t n, const int32_t *
 // tree laid out in leaf order).  Every aligned run of 256 * 2^k points is one tree node, i.e. a compact box, which is what
 // the per-tile / per-workgroup bounding boxes of the CPD kernels need (a Z-curve order has seams whose chunks span the
 // whole domain).  Deterministic: ties are broken by the original index.
-static void kd_split(const double *xyz, int32_t *idx, int64_t n, int64_t leaf) {
+// The points travel with their index (32-byte records, permuted in place): every pass is a contiguous sweep, and the two halves of
+// the upper levels go to separate threads.  The result does not depend on either -- each split is the unique median cut of the total
+// order (coordinate, original index), and the quarters are sorted by index at the end.
+struct KdPoint {
+    double c[3];
+    int64_t idx;
+};
+
+static void kd_split(KdPoint *p, int64_t n, int64_t leaf, int par_levels) {
     if (n <= leaf) return;
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (int64_t i = 0; i < n; ++i)
         for (int d = 0; d < 3; ++d) {
-            const double v = xyz[3 * (int64_t)idx[i] + d];
+            const double v = p[i].c[d];
             if (v == v) {
                 if (v < lo[d]) lo[d] = v;
                 if (v > hi[d]) hi[d] = v;
@@ -1891,28 +1900,44 @@ static void kd_split(const double *xyz, int32_t *idx, int64_t n, int64_t leaf) {
     // left half gets a multiple of `leaf` points so that leaves stay aligned to 256-point tiles
     int64_t half = ((n / leaf + 1) / 2) * leaf;
     if (half >= n) half = n / 2;
-    auto key = [&](int32_t i) {
-        const double v = xyz[3 * (int64_t)i + ax];
-        return v == v ? v : 1e300;  // NaN coordinates sort last
-    };
-    std::nth_element(idx, idx + half, idx + n, [&](int32_t a, int32_t b) {
-        const double ka = key(a), kb = key(b);
-        return ka < kb || (ka == kb && a < b);
+    std::nth_element(p, p + half, p + n, [ax](const KdPoint &a, const KdPoint &b) {
+        const double ka = a.c[ax] == a.c[ax] ? a.c[ax] : 1e300, kb = b.c[ax] == b.c[ax] ? b.c[ax] : 1e300;  // NaN coordinates sort last
+        return ka < kb || (ka == kb && a.idx < b.idx);
     });
-    kd_split(xyz, idx, half, leaf);
-    kd_split(xyz, idx + half, n - half, leaf);
+    if (par_levels > 0 && n >= 16384) {
+        std::thread left([=] { kd_split(p, half, leaf, par_levels - 1); });
+        kd_split(p + half, n - half, leaf, par_levels - 1);
+        left.join();
+    } else {
+        kd_split(p, half, leaf, 0);
+        kd_split(p + half, n - half, leaf, 0);
+    }
 }
 
 void morton_order(const double *xyz, int64_t n, std::vector<int32_t> &perm) {
-    perm.resize((size_t)n);
-    for (int64_t i = 0; i < n; ++i) perm[(size_t)i] = (int32_t)i;
-    kd_split(xyz, perm.data(), n, 256);
+    std::vector<KdPoint> pts((size_t)n);
+    for (int64_t i = 0; i < n; ++i) pts[(size_t)i] = KdPoint{{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]}, i};
+    kd_split(pts.data(), n, 256, 4);  // up to sixteen threads
     // every 256-point leaf is split further into four spatially compact 64-point quarters (the unit of the fine exact-zero
     // culling: one owned slot of a wave, one quarter of a streamed tile); original order inside a quarter (reproducible)
-    for (int64_t b = 0; b < n; b += 256) {
-        const int64_t m = b + 256 < n ? 256 : n - b;
-        kd_split(xyz, perm.data() + b, m, 64);
-        for (int64_t q = 0; q < m; q += 64) std::sort(perm.begin() + b + q, perm.begin() + b + (q + 64 < m ? q + 64 : m));
+    perm.resize((size_t)n);
+    auto leaves = [&](int64_t b0, int64_t b1) {
+        for (int64_t b = b0; b < b1; b += 256) {
+            const int64_t m = b + 256 < n ? 256 : n - b;
+            kd_split(pts.data() + b, m, 64, 0);
+            for (int64_t i = 0; i < m; ++i) perm[(size_t)(b + i)] = (int32_t)pts[(size_t)(b + i)].idx;
+            for (int64_t q = 0; q < m; q += 64) std::sort(perm.begin() + b + q, perm.begin() + b + (q + 64 < m ? q + 64 : m));
+        }
+    };
+    const int64_t nleaves = (n + 255) / 256;
+    if (n >= 16384) {
+        const int nt = 8;
+        std::thread th[nt - 1];
+        for (int t = 1; t < nt; ++t) th[t - 1] = std::thread(leaves, nleaves * t / nt * 256, nleaves * (t + 1) / nt * 256);
+        leaves(0, nleaves / nt * 256);
+        for (int t = 1; t < nt; ++t) th[t - 1].join();
+    } else {
+        leaves(0, nleaves * 256);
     }
 }
 

@@ -241,16 +241,20 @@ __device__ __forceinline__ void tile_abt(const double *Ap, int64_t lda, const do
 }
 
 // panel solve: L_ik = A_ik L_kk^-T for the row blocks i > k (the last one is the border with the right-hand sides)
-__global__ __launch_bounds__(256) void chol_panel_kernel(double *__restrict__ Aw, int64_t ld, int k, const double *__restrict__ Linv) {
+// (inverse: the border is an identity block of nb block rows -- dense_spd_inverse -- whose block row b is still zero left of column b)
+__global__ __launch_bounds__(256) void chol_panel_kernel(double *__restrict__ Aw, int64_t ld, int k, const double *__restrict__ Linv, int nb,
+                                                         bool inverse) {
     const int64_t i = k + 1 + blockIdx.x;
+    if (inverse && i >= nb && i - nb > k) return;
     double *aik = Aw + i * kNBc * ld + (int64_t)k * kNBc;
     tile_abt(aik, ld, Linv + (int64_t)k * kNBc * kNBc, kNBc, aik, ld, false, 1.0);
 }
 
 // trailing update: A_ij -= L_ik L_jk^T for k < j <= i (j a matrix block, i up to the border block)
-__global__ __launch_bounds__(256) void chol_trailing_kernel(double *__restrict__ Aw, int64_t ld, int k, int nb) {
+__global__ __launch_bounds__(256) void chol_trailing_kernel(double *__restrict__ Aw, int64_t ld, int k, int nb, bool inverse) {
     const int64_t i = k + 1 + blockIdx.y, j = k + 1 + blockIdx.x;
     if (j > i || j >= nb) return;
+    if (inverse && i >= nb && i - nb > k) return;
     tile_abt(Aw + i * kNBc * ld + (int64_t)k * kNBc, ld, Aw + j * kNBc * ld + (int64_t)k * kNBc, ld, Aw + i * kNBc * ld + j * kNBc, ld, true,
              -1.0);
 }
@@ -347,18 +351,49 @@ __global__ void nonrigid_finish_kernel(const double *__restrict__ partial, doubl
 // Aw ((Mp + 64) x Mp, lower triangle of an SPD matrix + three right-hand sides in the border rows Mp .. Mp + 2, see
 // build_system_kernel) -> W (three planes of stride Mp): blocked right-looking Cholesky, then the blocked backward substitution.
 // *flag receives GINGR_ERR_NOT_SPD when a diagonal block fails.  (Also the posterior solve above rank 256: gp.hip, common.h.)
-void dense_spd_solve3(gingr_ctx *ctx, double *Aw, int64_t Mp, double *Linv, double *W, int32_t *flag) {
+static void blocked_cholesky(gingr_ctx *ctx, double *Aw, int64_t Mp, double *Linv, int32_t *flag, bool inverse) {
     const int nb = (int)(Mp / kNBc);
+    const int nrows = inverse ? 2 * nb : nb + 1;  // block rows: the matrix, then the border
     for (int k = 0; k < nb; ++k) {
         launch_chol_block64(ctx, Aw, Mp, k, Linv, flag);
-        hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)(nb - k)), dim3(256), 0, ctx->stream, Aw, Mp, k, Linv);
+        const int below = inverse ? nb + k + 1 : nrows;  // (inverse: border block rows past k are still zero)
+        hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)(below - k - 1)), dim3(256), 0, ctx->stream, Aw, Mp, k, Linv, nb, inverse);
         if (k + 1 < nb)
-            hipLaunchKernelGGL(chol_trailing_kernel, dim3((unsigned)(nb - k - 1), (unsigned)(nb - k)), dim3(256), 0, ctx->stream, Aw, Mp, k,
-                               nb);
+            hipLaunchKernelGGL(chol_trailing_kernel, dim3((unsigned)(nb - k - 1), (unsigned)(below - k - 1)), dim3(256), 0, ctx->stream, Aw, Mp,
+                               k, nb, inverse);
     }
-    if (!W) return;  // (the factor alone: the lower triangle of Aw then holds L; gp.hip: launch_binv)
+}
+
+void dense_spd_solve3(gingr_ctx *ctx, double *Aw, int64_t Mp, double *Linv, double *W, int32_t *flag) {
+    blocked_cholesky(ctx, Aw, Mp, Linv, flag, false);
+    const int nb = (int)(Mp / kNBc);
+    if (!W) return;  // (the factor alone: the lower triangle of Aw then holds L)
     for (int k = nb - 1; k >= 0; --k)
         hipLaunchKernelGGL(chol_backward_kernel, dim3((unsigned)(k + 1)), dim3(256), 0, ctx->stream, Aw, Mp, Mp, k, Linv, W);
+}
+
+namespace {
+// C tile (a, b) = sum over the column blocks kb >= max(a, b) of X_a,kb X_b,kb^T, X = L^-T (upper triangular, row stride ld)
+__global__ __launch_bounds__(256) void inverse_product_kernel(const double *__restrict__ X, int64_t ld, int nb, double *__restrict__ C) {
+    const int a = blockIdx.y, b = blockIdx.x;
+    double *c = C + (int64_t)a * kNBc * ld + (int64_t)b * kNBc;
+    bool first = true;
+    for (int kb = a > b ? a : b; kb < nb; ++kb) {
+        tile_abt(X + (int64_t)a * kNBc * ld + (int64_t)kb * kNBc, ld, X + (int64_t)b * kNBc * ld + (int64_t)kb * kNBc, ld, c, ld, !first, 1.0);
+        first = false;
+        __syncthreads();
+    }
+}
+}  // namespace
+
+// The inverse of an SPD matrix on the matrix pipe.  Aw: (2 Mp) x Mp, Mp a multiple of 64 -- the lower triangle of A on top of an
+// IDENTITY: the blocked Cholesky takes the identity along as border rows, which leaves L^-T there (the rows of a border X become
+// X L^-T), and A^-1 = L^-T L^-1 is one product of that triangle with itself.  C: Mp x Mp, all of it written (exactly symmetric).
+// *flag receives GINGR_ERR_NOT_SPD when a diagonal block fails.  Linv: (Mp / 64) blocks of 64 x 64.
+void dense_spd_inverse(gingr_ctx *ctx, double *Aw, int64_t Mp, double *Linv, double *C, int32_t *flag) {
+    blocked_cholesky(ctx, Aw, Mp, Linv, flag, true);
+    const int nb = (int)(Mp / kNBc);
+    hipLaunchKernelGGL(inverse_product_kernel, dim3((unsigned)nb, (unsigned)nb), dim3(256), 0, ctx->stream, Aw + Mp * Mp, Mp, nb, C);
 }
 
 namespace {

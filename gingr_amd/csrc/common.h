@@ -292,6 +292,8 @@ void launch_barycentric(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri_by_
 void launch_chol_block64(gingr_ctx *ctx, double *Aw, int64_t ld, int k, double *Linv, int32_t *flag);
 // classic_cpd.hip: the multi-workgroup blocked Cholesky solve of a bordered SPD system (64-column panels, one launch per stage)
 void dense_spd_solve3(gingr_ctx *ctx, double *Aw, int64_t Mp, double *Linv, double *W, int32_t *flag);
+// A^-1 of an SPD matrix: Aw = [lower triangle of A; identity] ((2 Mp) x Mp), C = Mp x Mp (classic_cpd.hip)
+void dense_spd_inverse(gingr_ctx *ctx, double *Aw, int64_t Mp, double *Linv, double *C, int32_t *flag);
 // out4 = {sum of sqrt(d2), max, count, sum of log N(sqrt(d2); 0, sdev)} over the counted points (surface.hip)
 int distance_stats_ws_doubles();
 void launch_distance_stats(gingr_ctx *ctx, int64_t n, const double *d2, const int32_t *orig, int64_t orig_limit, const int32_t *nn,

@@ -1192,41 +1192,6 @@ __global__ __launch_bounds__(kLmChunk) void landmarks_kernel(const double *__res
 }
 
 // ------------------------------------------------------------------------------------------------- small dense
-constexpr int kDenseThreads = 256;
-
-// in-place lower Cholesky of the r x r leading block of A (row-major, leading dimension ld). returns false on a
-// non-positive / non-finite pivot.  Called by ALL threads of one block.
-__device__ bool block_cholesky(double *A, int r, int ld) {
-    __shared__ int ok_flag;
-    if (threadIdx.x == 0) ok_flag = 1;
-    __syncthreads();
-    for (int k = 0; k < r; ++k) {
-        if (threadIdx.x == 0) {
-            const double d = A[k * ld + k];
-            if (!(d > 0.0) || !finite_d(d)) {
-                ok_flag = 0;
-                A[k * ld + k] = 1.0;
-            } else {
-                A[k * ld + k] = sqrt(d);
-            }
-        }
-        __syncthreads();
-        const double dk = A[k * ld + k];
-        for (int i = k + 1 + threadIdx.x; i < r; i += blockDim.x) A[i * ld + k] /= dk;
-        __syncthreads();
-        {
-            const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, ny = blockDim.x >> 4;
-            for (int i = k + 1 + ty; i < r; i += ny) {
-                const double lik = A[i * ld + k];
-                for (int j = k + 1 + tx; j <= i; j += 16) A[i * ld + j] -= lik * A[j * ld + k];
-            }
-        }
-        __syncthreads();
-    }
-    return ok_flag != 0;
-}
-
-
 // Blocked Cholesky solve in one workgroup (256 threads = one wave per SIMD, 16-wide panels); the bordered matrix is LDS resident
 // for r <= 128 and lives in an L2-resident global workspace above that (same code through flat addressing).
 // With one wave per SIMD the kernel is bound by the NUMBER of instructions it issues (5-8 cycles each), so everything is
@@ -2600,36 +2565,6 @@ __global__ __launch_bounds__(kSolveThreads) void posterior_logpdf_cached_kernel(
     }
 }
 
-__global__ __launch_bounds__(kDenseThreads) void binv_kernel(int r, int rp, const double *__restrict__ S,
-                                                             double *__restrict__ work, double *__restrict__ Binv,
-                                                             int32_t *__restrict__ err_flag) {
-    // M = Q^T Q / eps + I
-    for (int idx = threadIdx.x; idx < r * r; idx += blockDim.x) {
-        const int i = idx / r, j = idx - i * r;
-        work[i * rp + j] = S[i * rp + j] / GINGR_COEFF_NOISE + (i == j ? 1.0 : 0.0);
-    }
-    for (int idx = threadIdx.x; idx < rp * rp; idx += blockDim.x) Binv[idx] = 0.0;
-    __syncthreads();
-    const bool ok = block_cholesky(work, r, rp);
-    if (threadIdx.x == 0) *err_flag = ok ? 0 : GINGR_ERR_NOT_SPD;
-    // thread c solves L L^T x = e_c and keeps x as COLUMN c of Binv (entry k at Binv[k * rp + c]): the threads of a wave then touch
-    // consecutive words (round 6; as row c -- a stride of rp between neighbouring threads -- this loop was 12 ms at r = 256); the
-    // factor's entries are the same address for every thread (broadcast)
-    for (int c = threadIdx.x; c < r; c += blockDim.x) {
-        double *x = Binv + c;
-        for (int k = 0; k < r; ++k) {
-            double s = (k == c) ? 1.0 : 0.0;
-            for (int j = 0; j < k; ++j) s -= work[k * rp + j] * x[(int64_t)j * rp];
-            x[(int64_t)k * rp] = s / work[k * rp + k];
-        }
-        for (int k = r - 1; k >= 0; --k) {
-            double s = x[(int64_t)k * rp];
-            for (int j = k + 1; j < r; ++j) s -= work[j * rp + k] * x[(int64_t)j * rp];
-            x[(int64_t)k * rp] = s / work[k * rp + k];
-        }
-    }
-}
-
 // out[i] = (sum_j Binv[i][j] * p[j]) / eps: 16 lanes per output row, fixed-order shuffle reduction.
 // Every lane of the 16-lane group returns the result.
 __device__ __forceinline__ double binv_row_apply16(const double *__restrict__ Binv, const double *__restrict__ p, int r, int rp,
@@ -3475,78 +3410,43 @@ void launch_posterior_sample_cached(gingr_ctx *ctx, int32_t r, int32_t rp, const
 }
 
 namespace {
-// Binv above rank 112 (round 6; binv_kernel is one workgroup with one column of the inverse per thread held in global memory: 10 ms at
-// r = 256, 80 ms at r = 512).  The factor comes from the multi-workgroup blocked Cholesky (dense_spd_solve3 without right-hand sides);
-// then a workgroup of CB threads owns CB columns of the inverse: thread t solves L L^T x = e_c with ITS x in LDS (entry k of all CB
-// columns side by side: consecutive words) and the factor's entries -- the same address for every thread -- from L2.
+// Binv = (Q^T Q / eps + I)^-1 on the matrix pipe (round 6; until then one workgroup with a column of the inverse per thread: 1.4 ms
+// at r = 100, 80 ms at r = 512; then a blocked factor with a column per thread behind it: 11 ms at r = 512).  The system with an
+// identity below it goes through the multi-workgroup blocked Cholesky, which leaves L^-T in place of the identity, and the inverse is
+// one product of that triangle with itself (classic_cpd.hip dense_spd_inverse).
 __global__ __launch_bounds__(256) void binv_system_kernel(int r, int rp, int64_t Mp, const double *__restrict__ S, double *__restrict__ Aw,
-                                                          double *__restrict__ Binv, int32_t *__restrict__ flag) {
+                                                          int32_t *__restrict__ flag) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
     if (c == 0 && row == 0) *flag = 0;
     if (c >= Mp) return;
-    double v = 0.0;  // M = Q^T Q / eps + I, identity on the padding, a zero border block
-    if (row < Mp && c <= row) v = (row < r && c < r) ? S[row * rp + c] / GINGR_COEFF_NOISE + (row == c ? 1.0 : 0.0) : (row == c ? 1.0 : 0.0);
+    double v = 0.0;  // M = Q^T Q / eps + I, identity on the padding; below it the identity the inverse grows from
+    if (row >= Mp)
+        v = row - Mp == c ? 1.0 : 0.0;
+    else if (c <= row)
+        v = (row < r && c < r) ? S[row * rp + c] / GINGR_COEFF_NOISE + (row == c ? 1.0 : 0.0) : (row == c ? 1.0 : 0.0);
     Aw[row * Mp + c] = v;
-    if (row < rp && c < rp) Binv[row * rp + c] = 0.0;
 }
-template <int CB>
-__global__ __launch_bounds__(CB) void binv_columns_kernel(int r, int rp, int64_t Mp, const double *__restrict__ L, double *__restrict__ Binv) {
-    extern __shared__ double xs[];  // [r][CB]
-    const int t = threadIdx.x, c = blockIdx.x * CB + t;
-    const int c0 = blockIdx.x * CB;  // entries above the block's first column are zero for every column of the block
-    for (int k = 0; k < r; ++k) xs[k * CB + t] = 0.0;
-    for (int k = c0; k < r; ++k) {  // L y = e_c
-        double s0 = (k == c) ? 1.0 : 0.0, s1 = 0.0;
-        const double *lk = L + (int64_t)k * Mp;
-        int j = c0;
-        for (; j + 1 < k; j += 2) {
-            s0 = __builtin_fma(-lk[j], xs[j * CB + t], s0);
-            s1 = __builtin_fma(-lk[j + 1], xs[(j + 1) * CB + t], s1);
-        }
-        if (j < k) s0 = __builtin_fma(-lk[j], xs[j * CB + t], s0);
-        xs[k * CB + t] = (s0 + s1) / lk[k];
-    }
-    for (int k = r - 1; k >= 0; --k) {  // L^T x = y
-        double s0 = xs[k * CB + t], s1 = 0.0;
-        int j = k + 1;
-        for (; j + 1 < r; j += 2) {
-            s0 = __builtin_fma(-L[(int64_t)j * Mp + k], xs[j * CB + t], s0);
-            s1 = __builtin_fma(-L[(int64_t)(j + 1) * Mp + k], xs[(j + 1) * CB + t], s1);
-        }
-        if (j < r) s0 = __builtin_fma(-L[(int64_t)j * Mp + k], xs[j * CB + t], s0);
-        xs[k * CB + t] = (s0 + s1) / L[(int64_t)k * Mp + k];
-    }
-    if (c < r)
-        for (int k = 0; k < r; ++k) Binv[(int64_t)k * rp + c] = xs[k * CB + t];  // column c (Binv is symmetric)
+// Binv [rp][rp]: the r x r block of C, zero on the padding
+__global__ __launch_bounds__(256) void binv_store_kernel(int r, int rp, int64_t Mp, const double *__restrict__ C, double *__restrict__ Binv) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rp * rp) return;
+    const int row = idx / rp, c = idx - row * rp;
+    Binv[idx] = (row < r && c < r) ? C[(int64_t)row * Mp + c] : 0.0;
 }
 }  // namespace
 
 int64_t binv_work_doubles(int32_t rp) {
     const int64_t Mp = round_up(rp, 64);
-    return std::max<int64_t>((int64_t)rp * rp, (Mp + 64) * Mp + (Mp / 64) * 64 * 64);
+    return 3 * Mp * Mp + (Mp / 64) * 64 * 64;  // the system over the identity, the product, the inverses of the diagonal blocks
 }
 
 void launch_binv(gingr_ctx *ctx, int32_t r, int32_t rp, const double *S, double *work, double *Binv, int32_t *err_flag) {
-    if (rp <= 112) {
-        hipLaunchKernelGGL(binv_kernel, dim3(1), dim3(kDenseThreads), 0, ctx->stream, (int)r, (int)rp, S, work, Binv, err_flag);
-        return;
-    }
     const int64_t Mp = round_up(rp, 64);
-    double *Aw = work, *Linv = Aw + (Mp + 64) * Mp;
-    hipLaunchKernelGGL(binv_system_kernel, dim3((unsigned)ceil_div(Mp, 256), (unsigned)(Mp + 64)), dim3(256), 0, ctx->stream, (int)r, (int)rp, Mp, S, Aw,
-                       Binv, err_flag);
-    dense_spd_solve3(ctx, Aw, Mp, Linv, nullptr, err_flag);
-    if (r <= 256) {
-        constexpr int CB = 64;
-        const size_t lds = (size_t)r * CB * sizeof(double);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&binv_columns_kernel<CB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(binv_columns_kernel<CB>, dim3((unsigned)ceil_div(r, CB)), dim3(CB), lds, ctx->stream, (int)r, (int)rp, Mp, Aw, Binv);
-    } else {
-        constexpr int CB = 32;  // (64 columns of 512 entries would not fit the LDS)
-        const size_t lds = (size_t)r * CB * sizeof(double);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&binv_columns_kernel<CB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(binv_columns_kernel<CB>, dim3((unsigned)ceil_div(r, CB)), dim3(CB), lds, ctx->stream, (int)r, (int)rp, Mp, Aw, Binv);
-    }
+    double *Aw = work, *C = Aw + 2 * Mp * Mp, *Linv = C + Mp * Mp;
+    hipLaunchKernelGGL(binv_system_kernel, dim3((unsigned)ceil_div(Mp, 256), (unsigned)(2 * Mp)), dim3(256), 0, ctx->stream, (int)r, (int)rp, Mp,
+                       S, Aw, err_flag);
+    dense_spd_inverse(ctx, Aw, Mp, Linv, C, err_flag);
+    hipLaunchKernelGGL(binv_store_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 256)), dim3(256), 0, ctx->stream, (int)r, (int)rp, Mp, C, Binv);
 }
 
 
