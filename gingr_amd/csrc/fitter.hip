@@ -580,13 +580,12 @@ int model_create_impl(gingr_ctx *ctx, int64_t M_total, int32_t rank, const doubl
     {
         const MomentLayout ml{m->rp};
         DevBuf gws, sws, ptil, ev;
-        if (gws.alloc((size_t)gram_ws_doubles(M, m->rp) * sizeof(double)) != hipSuccess ||
+        if (gws.alloc((size_t)std::max(gram_ws_doubles(M, m->rp), moment_grams_ws_doubles(M, m->rp)) * sizeof(double)) != hipSuccess ||
             sws.alloc((size_t)sweep_ws_doubles(M, m->rp) * sizeof(double)) != hipSuccess ||
             ptil.alloc((size_t)3 * M * sizeof(double)) != hipSuccess || ev.alloc((size_t)3 * M * sizeof(double)) != hipSuccess)
             return fail(gingr_set_error(ctx, GINGR_ERR_HIP, "model_upload: out of device memory"));
         launch_gram(ctx, m->Q0, M, m->rp, nullptr, gws.as<double>(), m->mom + ml.stot());
-        for (int d = 0; d < 3; ++d)
-            for (int e = 0; e < 3; ++e) launch_moment_gram(ctx, m->Q0, M, m->rp, d, e, gws.as<double>(), m->mom + ml.S(d, e));
+        launch_moment_grams(ctx, m->Q0, M, m->rp, gws.as<double>(), m->mom);
         launch_centered_mean(ctx, m, ptil.as<double>());
         std::vector<double> ones((size_t)M, 1.0);
         DevBuf dones;

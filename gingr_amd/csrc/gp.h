@@ -95,8 +95,9 @@ struct PostVec {
 };
 
 // Zero rows behind the last basis row of every model (model_create_impl allocates and clears them): the wide Gram pass
-// (gp_wide.hip) fetches whole 16-row steps, two of them ahead, without clamping its addresses.
-constexpr int kBasisRowSlack = 48;
+// (gp_wide.hip) fetches whole 16-row steps, two of them ahead, without clamping its addresses -- 48 rows; three times that for the
+// moment blocks, which take the basis as M rows of width 3 rp (launch_moment_grams).
+constexpr int kBasisRowSlack = 144;
 
 struct gingr_model {
     gingr_ctx *ctx = nullptr;
@@ -257,6 +258,10 @@ int64_t gram_wide_ws_doubles(int64_t M, int32_t rp);
 int launch_gram_wide(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, const double *evec,
                      double *rhs_partial, const ZeroGate *gate = nullptr);
 
+// the same pass over `rows` plain rows of width rp (unweighted, 48 zero rows behind them); ws: gram_rows_ws_doubles(rows, rp)
+int64_t gram_rows_ws_doubles(int64_t rows, int32_t rp);
+int launch_gram_rows(gingr_ctx *ctx, const double *Z, int64_t rows, int32_t rp, double *ws);
+
 // one launch for the reductions at the end of phase 1 (gp.hip: phase1_finalize_kernel)
 struct Phase1FinalizeArgs {
     int32_t rp;
@@ -343,8 +348,9 @@ void launch_binv(gingr_ctx *ctx, int32_t r, int32_t rp, const double *S, double 
 void launch_coeff_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double *Binv, const double *p, double *out);
 void launch_state_init(gingr_ctx *ctx, DevState *st, const gingr_state_scalars *host_scalars_dev, double *zero_slot = nullptr);
 
-// moment Gram S[d][e] (all patches, no symmetry): ws sized like gram_ws_doubles
-void launch_moment_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, int d, int e, double *ws, double *out);
+// the nine moment blocks S[d][e] = sum_i q_{3i+d} q_{3i+e}^T into mom (MomentLayout); ws: moment_grams_ws_doubles(M, rp)
+int64_t moment_grams_ws_doubles(int64_t M, int32_t rp);
+void launch_moment_grams(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, double *ws, double *mom);
 // p~ planes = ref + mean - c0
 void launch_centered_mean(gingr_ctx *ctx, const gingr_model *m, double *ptil);
 

@@ -2586,15 +2586,34 @@ __global__ __launch_bounds__(256) void coeff_solve_kernel(int r, int rp, const d
 
 // ------------------------------------------------------------------------------------------------- fused post-solve
 // one-off r x r products at finalisation
-__global__ void small_gemm_kernel(int r, int rp, const double *__restrict__ A, const double *__restrict__ B, double scale,
-                                  double *__restrict__ out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rp * rp) return;
-    const int i = idx / rp, j = idx - i * rp;
-    double s = 0.0;
-    if (i < r && j < r)
-        for (int k = 0; k < r; ++k) s = __builtin_fma(A[i * rp + k], B[k * rp + j], s);
-    out[idx] = s * scale;
+// out = scale * A B on the r x r block, zero on the padding (A, B, out: [rp][rp], rp a multiple of 16, zero padded).  One wave per
+// 16 x 16 tile on the matrix pipe; the operands are L2 resident (one thread per entry with a serial dot product was 160 us at
+// rank 512, 28 of them per model).
+__global__ __launch_bounds__(256) void small_gemm_kernel(int r, int rp, const double *__restrict__ A, const double *__restrict__ B, double scale,
+                                                         double *__restrict__ out) {
+    const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int nt = rp >> 4;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= nt * nt) return;
+    const int ti = tile / nt, tj = tile - ti * nt;
+    const double *pa = A + (int64_t)(16 * ti + l15) * rp + l4;  // A[i = l15][k = l4]
+    const double *pb = B + (int64_t)l4 * rp + 16 * tj + l15;    // B[k = l4][j = l15]
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < rp; k0 += 16) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = pa[k0 + 4 * u];
+            b[u] = pb[(int64_t)(k0 + 4 * u) * rp];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int row = 16 * ti + l4 + 4 * g, col = 16 * tj + l15;
+        out[(int64_t)row * rp + col] = (row < r && col < r) ? acc[g] * scale : 0.0;
+    }
 }
 
 // one-off, the model's PostVec block (column-major for the post-solve kernel: entry i of vector v at pvec[i * kRows + v]):
@@ -3077,17 +3096,61 @@ void launch_phase1_finalize(gingr_ctx *ctx, const Phase1FinalizeArgs &a) {
     hipLaunchKernelGGL(phase1_finalize_kernel, dim3((unsigned)(nG + a.rp + 1)), dim3(256), 0, ctx->stream, a);
 }
 
-void launch_moment_gram(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, int d, int e, double *ws, double *out) {
+namespace {
+// S[d][e][a][b] = T[d rp + a][e rp + b], T the (3 rp) x (3 rp) product of the three-rows-per-point view
+__global__ __launch_bounds__(256) void moment_scatter_kernel(const double *__restrict__ T, int rp, MomentLayout ml, double *__restrict__ mom) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t w = 3 * (int64_t)rp;
+    if (idx >= w * w) return;
+    const int I = (int)(idx / w), J = (int)(idx - (int64_t)I * w);
+    const int d = I / rp, a = I - d * rp, e = J / rp, b = J - e * rp;
+    mom[ml.S(d, e) + (int64_t)a * rp + b] = T[idx];
+}
+// out = in^T ([rp][rp])
+__global__ __launch_bounds__(256) void transpose_kernel(const double *__restrict__ in, int rp, double *__restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rp * rp) return;
+    const int i = idx / rp, j = idx - i * rp;
+    out[idx] = in[j * rp + i];
+}
+bool moments_as_rows(int32_t rp) { return 3 * rp >= 128 && 3 * rp <= 512; }
+}  // namespace
+
+int64_t moment_grams_ws_doubles(int64_t M, int32_t rp) {
+    if (moments_as_rows(rp)) return gram_rows_ws_doubles(M, 3 * rp) + 9 * (int64_t)rp * rp;
+    return gram_ws_doubles(M, rp);
+}
+
+// The nine blocks are the blocks of Z^T Z with Z the basis read as M rows of width 3 rp (the rows 3i, 3i+1, 3i+2 of a point are
+// contiguous), so for 3 rp in 128 .. 512 (ranks 43 .. 170) they are ONE symmetric product on the triangle kernel of gp_wide.hip
+// instead of nine general ones (0.9 ms -> 0.1 ms at rank 100).  Outside that range: the six blocks d <= e by gram_kernel, the other
+// three by transposition.
+void launch_moment_grams(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, double *ws, double *mom) {
+    const MomentLayout ml{rp};
+    if (moments_as_rows(rp)) {
+        const int32_t w = 3 * rp;
+        double *T = ws + gram_rows_ws_doubles(M, w);
+        const int nslabs = launch_gram_rows(ctx, Q0, M, w, ws);
+        hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)ceil_div((int64_t)w * w, 32)), dim3(256), 0, ctx->stream, ws, nslabs, (int)w, 1, T);
+        hipLaunchKernelGGL(moment_scatter_kernel, dim3((unsigned)ceil_div((int64_t)w * w, 256)), dim3(256), 0, ctx->stream, T, (int)rp, ml, mom);
+        return;
+    }
     // logical rows = points; same slab plan as the weighted Gram (its workspace is large enough: nslabs is capped by rows/64)
     int nbp, npatch, nslabs;
     int64_t rps;
     gram_plan(M, rp, &nbp, &npatch, &nslabs, &rps);
     rps = round_up(ceil_div(M, nslabs), 16);
     nslabs = (int)ceil_div(M, rps);
-    hipLaunchKernelGGL(gram_kernel, dim3(nslabs, nbp * nbp), dim3(256), 0, ctx->stream, Q0, M, (int)rp,
-                       (const double *)nullptr, rps, nbp, 3, d, e, 1, ws);
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 32)), dim3(256), 0, ctx->stream, ws,
-                       nslabs, (int)rp, 0, out);
+    for (int d = 0; d < 3; ++d)
+        for (int e = d; e < 3; ++e) {
+            hipLaunchKernelGGL(gram_kernel, dim3(nslabs, nbp * nbp), dim3(256), 0, ctx->stream, Q0, M, (int)rp, (const double *)nullptr, rps, nbp,
+                               3, d, e, 1, ws);
+            hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 32)), dim3(256), 0, ctx->stream, ws, nslabs, (int)rp, 0,
+                               mom + ml.S(d, e));
+            if (e > d)
+                hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 256)), dim3(256), 0, ctx->stream, mom + ml.S(d, e),
+                                   (int)rp, mom + ml.S(e, d));
+        }
 }
 
 void launch_centered_mean(gingr_ctx *ctx, const gingr_model *m, double *ptil) {
@@ -3474,8 +3537,8 @@ void launch_postvec(gingr_ctx *ctx, int32_t r, int32_t rp, const double *Binv, c
 }
 
 void launch_small_gemm(gingr_ctx *ctx, int32_t r, int32_t rp, const double *A, const double *B, double scale, double *out) {
-    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)ceil_div((int64_t)rp * rp, 256)), dim3(256), 0, ctx->stream, (int)r,
-                       (int)rp, A, B, scale, out);
+    const int64_t tiles = (int64_t)(rp / 16) * (rp / 16);
+    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)ceil_div(tiles, 4)), dim3(256), 0, ctx->stream, (int)r, (int)rp, A, B, scale, out);
 }
 
 

@@ -32,7 +32,8 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int kWaves = 8;
-constexpr int kRowPad = kBasisRowSlack;  // {w, e} entries behind the last basis row (zeros): what the steps past the end read
+constexpr int kRowPad = 48;  // {w, e} entries behind the last basis row (zeros): what the steps past the end read
+static_assert(kBasisRowSlack >= 3 * kRowPad, "the three-rows-per-point view of the basis (launch_gram_rows) reads 48 of ITS rows past the end");
 
 // we[row] = {weight of the row's point (1 without weights), right-hand-side value of the row (0 without evec)}; zeros behind 3 M
 __global__ __launch_bounds__(256) void row_expand_kernel(const double *__restrict__ weight, const double *__restrict__ evec, int64_t M,
@@ -47,6 +48,13 @@ __global__ __launch_bounds__(256) void row_expand_kernel(const double *__restric
         v[1] = evec ? evec[c * M + pt] : 0.0;
     }
     we[row] = v;
+}
+
+// the unweighted product of plain rows: we[row] = {1, 0}, zeros behind `rows`
+__global__ __launch_bounds__(256) void row_ones_kernel(int64_t rows, d2 *__restrict__ we) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows + kRowPad) return;
+    we[row] = d2{row < rows ? 1.0 : 0.0, 0.0};
 }
 
 struct GramWideArgs {
@@ -253,7 +261,7 @@ struct WidePlan {
 };
 
 // T <= 17 accumulator tiles per wave (136 registers): parts = workgroups per slab so that a part's tiles fit eight waves
-WidePlan wide_plan(int64_t M, int32_t rp) {
+WidePlan wide_plan_rows(int64_t rows, int32_t rp, int max_workgroups) {
     WidePlan p;
     p.NT = rp / 16;
     p.SUB = p.NT <= 8 ? 4 : (p.NT <= 16 ? 2 : 1);
@@ -261,14 +269,14 @@ WidePlan wide_plan(int64_t M, int32_t rp) {
     p.nparts = (total + kWaves * 17 - 1) / (kWaves * 17);
     p.tiles_per_part = (total + p.nparts - 1) / p.nparts;
     p.T = (p.tiles_per_part + kWaves - 1) / kWaves;
-    const int64_t rows = 3 * M;
     // one workgroup per compute unit; small shards keep at least 64 rows per slab (never more slabs than gram_tri_kernel's plan:
     // the right-hand-side partials live in the sweep workspace)
-    const int64_t want = std::min<int64_t>(std::max(1, 256 / p.nparts), std::max<int64_t>(1, ceil_div(rows, 64)));
+    const int64_t want = std::min<int64_t>(std::max(1, max_workgroups / p.nparts), std::max<int64_t>(1, ceil_div(rows, 64)));
     p.rows_per_slab = round_up(ceil_div(rows, want), 4 * p.SUB);
     p.nslabs = (int)ceil_div(rows, p.rows_per_slab);
     return p;
 }
+WidePlan wide_plan(int64_t M, int32_t rp) { return wide_plan_rows(3 * M, rp, 256); }
 
 }  // namespace
 
@@ -278,14 +286,11 @@ int64_t gram_wide_ws_doubles(int64_t M, int32_t rp) {
 }
 
 // see gp.h; ws: gram_wide_ws_doubles(M, rp) doubles
-int launch_gram_wide(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, const double *evec,
-                     double *rhs_partial, const ZeroGate *gate) {
-    const WidePlan p = wide_plan(M, rp);
-    d2 *we = reinterpret_cast<d2 *>(ws + (int64_t)p.nslabs * rp * rp);
-    hipLaunchKernelGGL(row_expand_kernel, dim3((unsigned)ceil_div(3 * M + kRowPad, 256)), dim3(256), 0, ctx->stream, weight, evec, M, we);
+static int gram_wide_go(gingr_ctx *ctx, const double *Q0, int64_t rows, int32_t rp, const WidePlan &p, const d2 *we, double *ws,
+                        double *rhs_partial, const ZeroGate *gate) {
     GramWideArgs a;
     a.Q0 = Q0;
-    a.rows = 3 * M;
+    a.rows = rows;
     a.rp = rp;
     a.NT = p.NT;
     a.we = we;
@@ -319,4 +324,27 @@ int launch_gram_wide(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, co
     }
 #undef GINGR_WIDE
     return p.nslabs;
+}
+
+int launch_gram_wide(gingr_ctx *ctx, const double *Q0, int64_t M, int32_t rp, const double *weight, double *ws, const double *evec,
+                     double *rhs_partial, const ZeroGate *gate) {
+    const WidePlan p = wide_plan(M, rp);
+    d2 *we = reinterpret_cast<d2 *>(ws + (int64_t)p.nslabs * rp * rp);
+    hipLaunchKernelGGL(row_expand_kernel, dim3((unsigned)ceil_div(3 * M + kRowPad, 256)), dim3(256), 0, ctx->stream, weight, evec, M, we);
+    return gram_wide_go(ctx, Q0, 3 * M, rp, p, we, ws, rhs_partial, gate);
+}
+
+// Z^T Z of `rows` plain rows of width rp (128 .. 512, a multiple of 16; 48 zero rows behind them), unweighted: slab partials of the
+// upper tiles in ws, the slab count returned.  One-off products (the model's moment blocks: fitter.hip): at most 96 workgroups, so
+// that the partials stay small.
+constexpr int kRowsWorkgroups = 96;
+int64_t gram_rows_ws_doubles(int64_t rows, int32_t rp) {
+    const WidePlan p = wide_plan_rows(rows, rp, kRowsWorkgroups);
+    return (int64_t)p.nslabs * rp * rp + 2 * (rows + kRowPad);
+}
+int launch_gram_rows(gingr_ctx *ctx, const double *Z, int64_t rows, int32_t rp, double *ws) {
+    const WidePlan p = wide_plan_rows(rows, rp, kRowsWorkgroups);
+    d2 *we = reinterpret_cast<d2 *>(ws + (int64_t)p.nslabs * rp * rp);
+    hipLaunchKernelGGL(row_ones_kernel, dim3((unsigned)ceil_div(rows + kRowPad, 256)), dim3(256), 0, ctx->stream, rows, we);
+    return gram_wide_go(ctx, Z, rows, rp, p, we, ws, nullptr, nullptr);
 }
