@@ -200,3 +200,27 @@ def test_registration_from_a_model_file_read_back_from_disk(ctx, tmp_path):
     rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
     assert g64.status == 0 and rel(g64.fit, direct.fit) < 1e-12 and g64.sigma2 == direct.sigma2
     assert g32.status == 0 and rel(g32.fit, direct.fit) < 1e-5
+
+
+@pytest.mark.parametrize("max_rank", [192, 300, 400, 512])
+def test_wide_models_through_the_register_eigen_kernels(ctx, max_rank):
+    """Ranks 192 .. 512 of a single Gaussian kernel: the per-coordinate blocks have 64 .. 171 columns, i.e. one, two and three
+    values per lane in eig.hip's one-sided Jacobi (two blocks side by side in one launch)."""
+    import gingr_amd as ga
+    ref = cloud(1200, 21)
+    mo = go.build_gpmm_mixture(ref, [18.0], [10.0], 0.0, max_rank)
+    dm = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.0, maxRank=max_rank).Gaussian(18.0, 10.0)
+    assert dm.rank == mo.rank == max_rank
+    check_model_against_oracle(dm.to_host(), mo)
+
+
+@pytest.mark.parametrize("max_rank", [150, 250])
+def test_wide_two_kernel_models(ctx, max_rank):
+    """Two kernels (mirrored Gaussian): ONE eigen-problem of `rank` columns -- 150: three values per lane of the register kernel;
+    250: past its 192 columns, the two-sided kernel."""
+    import gingr_amd as ga
+    ref = cloud(700, 22)
+    mo = go.build_gpmm_diagonal(ref, go.symmetric_gauss_kernel_fun(ref, 20.0, 10.0), 0.0, max_rank)
+    dm = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.0, maxRank=max_rank).GaussianSymmetry(20.0, 10.0)
+    assert dm.rank == mo.rank == max_rank
+    check_model_against_oracle(dm.to_host(), mo)

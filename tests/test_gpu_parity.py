@@ -256,6 +256,23 @@ def test_icp_update_trajectory(ctx):
         assert state.general.sigma2 == st.sigma2
 
 
+@pytest.mark.parametrize("rank,sigma,duplicate", [(36, 60.0, True), (130, 22.0, False), (170, 18.0, False)])
+def test_icp_update_through_the_moment_eigenbasis(ctx, rank, sigma, duplicate):
+    """Point-cloud ICP without landmarks takes its posterior from the eigenbasis of the model's moment Q^T Q (eig.hip at finalize):
+    ranks 130 / 170 are the two- and three-values-per-lane kernels; two identical basis columns make the moment singular, the
+    Cholesky in front of the one-sided Jacobi fails and the two-sided kernel (complete V) serves."""
+    mo = make_model(M=500, rank=rank, seed=43, sigma=sigma, scaling=20.0)
+    assert mo.rank == rank
+    if duplicate:
+        mo.U[:, 5] = mo.U[:, 4]
+    rng = np.random.default_rng(44)
+    target = mo.instance(rng.normal(0, 0.8, mo.rank)) + rng.normal(0, 0.1, (mo.M, 3))
+    traj = run_pair(ctx, mo, target, "icp", 3, 1, dict(maxIterations=10, initialSigma=20.0, endSigma=1.0))
+    for k, (state, st) in enumerate(traj):
+        assert state.general.status == st.status == 0
+        assert rel(state.general.fit, st.fit) < REL_MESH, (k, rel(state.general.fit, st.fit))
+
+
 def test_model_flexibility_error_status(ctx):
     # sigma2 tiny + w = 0 + a far-away target point: den underflows -> NaN -> posterior fails.
     # iteration 0: state returned unchanged; iteration > 0: ModelFlexibilityError (GingrAlgorithm.scala:194-208)
