@@ -489,10 +489,11 @@ int model_finalize_impl(gingr_ctx *ctx, gingr_model *m) {
     GINGR_TRY(check_launch(ctx));
     // The eigen-decomposition S_tot = V diag(lam) V^T for the uniform-weight posterior (point-cloud ICP without landmarks: the
     // posterior (I + S_tot / sigma2)^-1 rhs is two mat-vecs then).  Decided HERE, once, outside every asynchronous update: S_tot is
-    // the all-reduced moment, bit-identical on every shard, and the one-workgroup Jacobi is deterministic, so all shards of a
-    // sharded model take the same path.  0.6-1.2 ms at rank 100; above rank 256 (tens of ms) the Cholesky path serves.
+    // the all-reduced moment, bit-identical on every shard, and the decomposition is deterministic, so all shards of a sharded model
+    // take the same path.  Up to the 192 columns of the register kernel (eig.hip: 0.24 ms at rank 100, 3.5 ms at 192); above that the
+    // two-sided kernel would take tens of ms of every model's set-up, more than the Cholesky path costs an ICP run (0.1 ms an iteration).
     m->eig_ready = false;
-    if (m->r <= 256) {
+    if (m->r <= kSymEigColsMaxN) {
         if (launch_jacobi_eig(ctx, m->mom + ml.stot(), m->rp, m->r, m->eigL, m->eigV) == GINGR_OK)
             m->eig_ready = true;
         else

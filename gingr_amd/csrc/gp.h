@@ -115,7 +115,7 @@ struct gingr_model {
     std::vector<double> h_full_pts;      // host: ref + mean of ALL M_total points, interleaved xyz (spatial order of a shard's triangles)
     double *Binv = nullptr;   // [rp*rp] (S_tot/eps + I)^-1, valid after finalize
     double *eigV = nullptr;   // [r*r] eigenvectors of S_tot = Q^T Q (column k, row stride r) and
-    double *eigL = nullptr;   // [r] its eigenvalues (descending): uniform-weight posterior (launch_posterior_solve_eig); rank <= 256
+    double *eigL = nullptr;   // [r] its eigenvalues (descending): uniform-weight posterior (launch_posterior_solve_eig); rank <= 192
     bool eig_ready = false;  // decided once by model_finalize_impl (fitter.hip), identically on every shard
     double *cmat = nullptr;   // [19][rp*rp], valid after finalize: [0] C = Binv S_tot / eps (alpha_1 = C a),
                               // [1 + 3d + e] Binv S[d][e], [10 + 3d + e] Binv S[d][e] C  (Binv S[d][e] alpha_1 = (Binv S[d][e] C) a)

@@ -69,6 +69,11 @@ for src, dst in (("emu8_kernel_stats.csv", f"r{rnd}_emulated_8gpu_shard_kernel_s
                  ("stamps_emu8.txt", f"r{rnd}_shard_pair_loop_stamps_final.txt")):
     if os.path.exists(os.path.join(F, src)) and os.path.getsize(os.path.join(F, src)) > 0:
         shutil.copy(os.path.join(F, src), os.path.join(P, dst))
+for src, dst in (("gpmm_build.json", f"r{rnd}_gpmm_build.json"), ("gpmm_kernel_stats.csv", f"r{rnd}_gpmm_build_kernel_stats.csv"),
+                 ("registration_timeline.txt", f"r{rnd}_registration_timeline.txt"),
+                 ("landmarks_kernel_stats.csv", f"r{rnd}_landmarks_cpd50k_kernel_stats.csv"), ("ubench_sym_eig.txt", f"r{rnd}_ubench_sym_eig.txt")):
+    if os.path.exists(os.path.join(F, src)) and os.path.getsize(os.path.join(F, src)) > 0:
+        shutil.copy(os.path.join(F, src), os.path.join(P, dst))
 if os.path.exists(os.path.join(F, "chain_1.json")):
     runs = [load(f"chain_{i}.json") for i in range(1, 6) if os.path.exists(os.path.join(F, f"chain_{i}.json"))]
     best = sorted(runs, key=lambda c: c["steps_per_s"])[len(runs) // 2]     # the median run

@@ -32,6 +32,12 @@ python3 tools/bench_icp.py 2>/dev/null | tail -1 > $F/icp50k.json
 python3 tools/bench_icp_surface.py 2>/dev/null | tail -1 > $F/icp_surface.json
 python3 tools/bench_icp_surface.py 6 n=50 2>/dev/null | tail -1 > $F/icp_surface_n50.json
 for fl in 2 1; do python3 tools/bench_reversed_shard.py 8 $fl 2>/dev/null | grep "^{" | tail -1 > $F/reversed_shard8_flavour$fl.json; done
+# model set-up (one-off): on-device GPMM builds, the whole-registration timeline, the landmark iteration, the register eigen kernel
+python3 tools/bench_gpmm.py 2>/dev/null | tail -1 > $F/gpmm_build.json
+bash tools/experiments/prof_tool.sh final_gpmm tools/bench_gpmm.py > $F/gpmm_kernels.txt 2>&1; cp gpurun_out/prof_final_gpmm/kernel_stats.csv $F/gpmm_kernel_stats.csv
+python3 tools/experiments/registration_timeline.py 2>/dev/null | grep "^rep" > $F/registration_timeline.txt
+bash tools/experiments/prof_landmarks.sh > $F/landmarks_kernels.txt 2>&1; cp gpurun_out/prof_landmarks/kernel_stats.csv $F/landmarks_kernel_stats.csv
+if [ -x tools/bin/ubench_sym_eig ]; then tools/bin/ubench_sym_eig > $F/ubench_sym_eig.txt 2>&1; fi
 # per-wave stamps of the two pair loops on the 8-rank shard (diagnostic build: make -C gingr_amd/csrc variant NAME=stamps DEFS=-DGINGR_STAMPS)
 if [ -f gingr_amd/libgingr_hip_stamps.so ]; then GINGR_HIP_LIB=$R/gingr_amd/libgingr_hip_stamps.so python3 tools/stamps_shard.py 8 50000 2>/dev/null | grep -v "^RCCL\|^HIP v\|^ROCm\|^Hostn\|^Librccl" > $F/stamps_emu8.txt; fi
 python3 - <<'PY'
