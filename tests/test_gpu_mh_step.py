@@ -61,7 +61,10 @@ def _compare(a, b, tol):
 @pytest.mark.parametrize("points", [0, 700])
 def test_fused_surface_icp_chain_equals_the_call_by_call_chain(ctx, points):
     """DemoICP's configuration on the femur (surface ICP proposals + the stock random walks, model-to-target likelihood over all /
-    the first 700 vertices): 60 steps, same draws."""
+    the first 700 vertices): 60 steps, same draws.  (Seed 17: five and seven rejected informed proposals in these 60 steps -- a chain's
+    realisation changes with the last bits of the model's constants, because the surface correspondence's rejection rules are
+    discontinuous (DESIGN.md section 5), so the check that both outcomes occur wants a realisation with some margin;
+    tools/experiments/chain_seeds.py.)"""
     import gingr_amd as ga
     from gingr_amd import sampling as sp
     ref, cells, target, tcells = femur()
@@ -70,7 +73,7 @@ def test_fused_surface_icp_chain_equals_the_call_by_call_chain(ctx, points):
         mo, algo, s0 = make_state(ctx, ref, cells, target, tcells, rank=24, sigma=(1.0, 1.0), iters=61)
         settings = sp.ProbabilisticSettings(sp.IndependentPoints(algo, s0, 5.0, modelPointCount=points or None), randomMixture=0.5,
                                             fusedSteps=fused)
-        runs.append(_run(algo, s0, settings, 11))
+        runs.append(_run(algo, s0, settings, 17))
         assert algo._mh is None and algo._mh_last is None          # run() switches the mode off again
         algo.close()
     _compare(runs[0], runs[1], 1e-9)
