@@ -109,7 +109,7 @@ struct gingr_fitter {
     int32_t *mtri = nullptr, *ttri = nullptr, *ttri_orig = nullptr;
     int32_t *madj_ptr = nullptr, *madj_tri = nullptr, *tadj_ptr = nullptr, *tadj_tri = nullptr;  // vertex -> triangles
     double *mcn = nullptr, *tcn = nullptr, *mvn = nullptr, *tvn = nullptr;  // cell / vertex normals (SoA)
-    double *mtboxes = nullptr, *ttboxes = nullptr;  // triangle tile boxes
+    double *mtboxes = nullptr, *ttboxes = nullptr;  // triangle tile boxes [nt][6], quarter boxes [4 nt][6], group boxes [nt / 16 + 1][6] (line_nearest)
     double *mtribox = nullptr, *ttribox = nullptr;  // per-triangle boxes [T][6] (tri_tile_bbox_kernel), staged by the scan kernels
     int32_t *tboundary = nullptr;                   // target boundary vertices (device target positions)
     double *surf_cp = nullptr, *surf_d2 = nullptr, *surf_w01 = nullptr, *surf_win = nullptr, *surf_nnd2 = nullptr;
@@ -2005,8 +2005,8 @@ int gingr_fitter_set_meshes(gingr_fitter *f, int64_t n_model_tri, const int32_t 
         (rc = dev_alloc(ctx, &f->madj_tri, bm.adj_tri.size())) || (rc = dev_alloc(ctx, &f->tadj_ptr, (size_t)N + 1)) ||
         (rc = dev_alloc(ctx, &f->tadj_tri, (size_t)3 * f->Tt)) || (rc = dev_alloc(ctx, &f->mcn, (size_t)3 * f->Tm)) ||
         (rc = dev_alloc(ctx, &f->tcn, (size_t)3 * f->Tt)) || (rc = dev_alloc(ctx, &f->mvn, (size_t)3 * M)) ||
-        (rc = dev_alloc(ctx, &f->tvn, (size_t)3 * N)) || (rc = dev_alloc(ctx, &f->mtboxes, (size_t)30 * ntm)) ||
-        (rc = dev_alloc(ctx, &f->ttboxes, (size_t)30 * ntt)) || (rc = dev_alloc(ctx, &f->tboundary, (size_t)N)) ||
+        (rc = dev_alloc(ctx, &f->tvn, (size_t)3 * N)) || (rc = dev_alloc(ctx, &f->mtboxes, (size_t)30 * ntm + 6 * (ntm / 16 + 1))) ||
+        (rc = dev_alloc(ctx, &f->ttboxes, (size_t)30 * ntt + 6 * (ntt / 16 + 1))) || (rc = dev_alloc(ctx, &f->tboundary, (size_t)N)) ||
         (rc = dev_alloc(ctx, &f->surf_cp, (size_t)3 * M)) || (rc = dev_alloc(ctx, &f->surf_d2, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->surf_w01, (size_t)M)) || (rc = dev_alloc(ctx, &f->surf_win, (size_t)M)) ||
         (rc = dev_alloc(ctx, &f->surf_nnd2, (size_t)M)) || (rc = dev_alloc(ctx, &f->surf_nn, (size_t)M)) ||

@@ -176,19 +176,6 @@ struct Tri9 {
     double ax, ay, az, bx, by, bz, cx, cy, cz, orig;
 };
 
-__device__ __forceinline__ void stage_tile(Tri9 *tile, Cloud v, const int32_t *__restrict__ tri,
-                                           const int32_t *__restrict__ tri_orig, int64_t tb, int64_t T, int lane) {
-#pragma unroll
-    for (int u = 0; u < kTriTile / kSurfThreads; ++u) {
-        const int64_t t = tb + u * kSurfThreads + lane;
-        if (t < T) {
-            const int32_t a = tri[3 * t], b = tri[3 * t + 1], c = tri[3 * t + 2];
-            tile[u * kSurfThreads + lane] = Tri9{v.x[a], v.y[a], v.z[a], v.x[b], v.y[b], v.z[b], v.x[c], v.y[c], v.z[c],
-                                                 (double)(tri_orig ? tri_orig[t] : (int32_t)t)};
-        }
-    }
-}
-
 // wave-wide bounding box of the valid lanes' points
 __device__ __forceinline__ void wave_box(bool ok, double qx, double qy, double qz, double wb[6]) {
     double lo[3] = {ok ? qx : __builtin_huge_val(), ok ? qy : __builtin_huge_val(), ok ? qz : __builtin_huge_val()};
@@ -802,78 +789,214 @@ __global__ __launch_bounds__(kCpThreads) void self_intersect_queue_kernel(Cloud 
 
 // ClosestPointAlongNormalTriangleMesh3D (ClosestPointRegistrator.scala:102-131): for every fit vertex the intersection of the
 // line {p + t n} (n = its vertex normal, both directions) with the mesh (v, tri) that is closest to p and != p; found[i] = 0 and
-// cp = p when there is none.  A tile is visited only if some lane's line passes through its (slightly inflated) box and the box
-// is not farther from p than the lane's current hit; exact ties go to the lowest ORIGINAL triangle.
+// cp = p when there is none.  A 256-triangle tile is visited only if some lane's line passes through its (slightly inflated) box and
+// the box is not farther from p than the lane's current hit; then the same test on its four 64-triangle quarters (boxes behind the
+// tile boxes: tri_tile_bbox_kernel), and only a quarter some lane needs is staged.  Exact ties go to the lowest ORIGINAL triangle.
+// Round 6 (1 067 -> see DESIGN.md at 41k x 82k, where it was 85 % of an iteration of this ICP flavour): the slab test multiplies by
+// the line's reciprocal direction (six float64 divisions per box before), quarters instead of whole tiles, and a triangle whose
+// barycentric numerators are clearly outside [0, det] is dropped before the division of the Moeller-Trumbore test -- the survivors go
+// through the same expressions as before.
+struct LineSlab {
+    double p[3], inv[3];
+    bool par[3];  // direction component exactly zero
+    __device__ __forceinline__ bool hits(const double *bx) const {
+        double tmin = -__builtin_huge_val(), tmax = __builtin_huge_val();
+        bool miss = false;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double eps = 1e-9 * (fabs(bx[d]) + fabs(bx[3 + d]) + fabs(p[d]) + 1e-300);
+            const double lo = bx[d] - eps, hi = bx[3 + d] + eps;
+            if (par[d]) {
+                if (p[d] < lo || p[d] > hi) miss = true;
+            } else {
+                const double t1 = (lo - p[d]) * inv[d], t2 = (hi - p[d]) * inv[d];
+                tmin = fmax(tmin, fmin(t1, t2));
+                tmax = fmin(tmax, fmax(t1, t2));
+            }
+        }
+        return !(miss || tmin > tmax);
+    }
+};
+
+constexpr int kLineGroup = 16;       // tiles per group box
+constexpr int kLineCopies = 4;       // lanes per query: they take alternate triangles of a staged quarter and alternate group boxes
+constexpr int kLineQueries = kSurfThreads / kLineCopies;
+
+// boxes of the groups of 16 tiles (the triangle order is a k-d order: aligned runs are compact), behind the tile and quarter boxes
+__global__ __launch_bounds__(64) void line_group_boxes_kernel(double *__restrict__ boxes, int nt) {
+    const int idx = blockIdx.x * 64 + threadIdx.x, g = idx / 6, d = idx - 6 * g;
+    if (g >= (nt + kLineGroup - 1) / kLineGroup) return;
+    double vals[kLineGroup];
+#pragma unroll
+    for (int u = 0; u < kLineGroup; ++u) {
+        const int t = min(g * kLineGroup + u, nt - 1);
+        vals[u] = boxes[(int64_t)t * 6 + d];
+    }
+    double r = vals[0];
+#pragma unroll
+    for (int u = 1; u < kLineGroup; ++u) r = d < 3 ? fmin(r, vals[u]) : fmax(r, vals[u]);
+    boxes[(int64_t)nt * 30 + (int64_t)g * 6 + d] = r;
+}
+
+// Four lanes per query (16 queries a wave): the union of the quarters the lines of a wave pierce is smaller, a staged quarter costs 16
+// steps instead of 64, and there are four times the waves to hide each other's staging latency (one wave per SIMD otherwise).
 __global__ __launch_bounds__(kSurfThreads) void line_nearest_kernel(Cloud fit, const double *__restrict__ dirs, Cloud v,
                                                                    const int32_t *__restrict__ tri,
                                                                    const int32_t *__restrict__ tri_orig, int64_t T,
                                                                    const double *__restrict__ boxes, double *__restrict__ cp,
                                                                    int32_t *__restrict__ found) {
-    __shared__ Tri9 tile[kTriTile];
-    const int lane = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * kSurfThreads + lane;
+    __shared__ Tri9 quarter[64];
+    const int lane = threadIdx.x, copy = lane & (kLineCopies - 1);
+    const int64_t i = (int64_t)blockIdx.x * kLineQueries + (lane >> 2);
     const bool ok = i < fit.n;
     const int64_t ic = ok ? i : 0;
     const V3 p{fit.x[ic], fit.y[ic], fit.z[ic]};
     const V3 dir{dirs[ic], dirs[fit.n + ic], dirs[2 * fit.n + ic]};
-    const double pa[3] = {p.x, p.y, p.z}, da[3] = {dir.x, dir.y, dir.z};
-    double best = __builtin_huge_val(), bo = __builtin_huge_val();  // distance |p - ip| and the original triangle that holds it
-    V3 bp = p;
-    const int nt = (int)((T + kTriTile - 1) / kTriTile);
-    for (int t = 0; t < nt; ++t) {
-        const double *bx = boxes + (int64_t)t * 6;
-        // slab test of the infinite line against the box inflated by a relative rounding margin
-        double tmin = -__builtin_huge_val(), tmax = __builtin_huge_val();
-        bool miss = false;
+    LineSlab line;
+    line.p[0] = p.x, line.p[1] = p.y, line.p[2] = p.z;
+    {
+        const double da[3] = {dir.x, dir.y, dir.z};
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const double eps = 1e-9 * (fabs(bx[d]) + fabs(bx[3 + d]) + fabs(pa[d]) + 1e-300);
-            const double lo = bx[d] - eps, hi = bx[3 + d] + eps;
-            if (da[d] == 0.0) {
-                if (pa[d] < lo || pa[d] > hi) miss = true;
-            } else {
-                const double t1 = (lo - pa[d]) / da[d], t2 = (hi - pa[d]) / da[d];
-                tmin = fmax(tmin, fmin(t1, t2));
-                tmax = fmin(tmax, fmax(t1, t2));
-            }
+            line.par[d] = da[d] == 0.0;
+            line.inv[d] = line.par[d] ? 0.0 : 1.0 / da[d];
         }
-        if (tmin > tmax) miss = true;
-        const double pd = point_box_gap2(p.x, p.y, p.z, bx);
-        const bool need = ok && !miss && !(pd > best * best * (1.0 + 1e-12));
-        if (!__any(need)) continue;
-        const int64_t tb = (int64_t)t * kTriTile;
-        __syncthreads();
-        stage_tile(tile, v, tri, tri_orig, tb, T, lane);
-        __syncthreads();
-        const int cnt = (int)min((int64_t)kTriTile, T - tb);
-        if (need)
-            for (int jj = 0; jj < cnt; ++jj) {
-                const Tri9 tr = tile[jj];
-                const V3 A{tr.ax, tr.ay, tr.az};
-                const V3 e1 = sub(V3{tr.bx, tr.by, tr.bz}, A), e2 = sub(V3{tr.cx, tr.cy, tr.cz}, A);
-                const V3 pv = cross3(dir, e2);
-                const double det = dot3(e1, pv);
-                const double inv = 1.0 / det;
-                const V3 tv = sub(p, A);
-                const double u = dot3(tv, pv) * inv;
-                const V3 qv = cross3(tv, e1);
-                const double w = dot3(qv, dir) * inv;
-                const double tt = dot3(e2, qv) * inv;
-                if (det != 0.0 && u >= 0.0 && u <= 1.0 && w >= 0.0 && u + w <= 1.0) {
-                    const V3 ip{p.x + tt * dir.x, p.y + tt * dir.y, p.z + tt * dir.z};
-                    if (ip.x != p.x || ip.y != p.y || ip.z != p.z) {
-                        const V3 dd = sub(ip, p);
-                        const double dist = sqrt((dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z);
-                        if (dist < best || (dist == best && tr.orig < bo)) {
-                            best = dist;
-                            bo = tr.orig;
-                            bp = ip;
-                        }
-                    }
+    }
+    const int nt = (int)((T + kTriTile - 1) / kTriTile);
+    const double *qboxes = boxes + (int64_t)nt * 6;
+    const double *gboxes = boxes + (int64_t)nt * 30;  // line_group_boxes_kernel
+    // Sweeps over shells round the workgroup's own points, the radius doubling: tiles come roughly nearest first, so a line's hit in
+    // one shell culls (by distance) what it pierces in the later ones -- the far side of a closed mesh, the fat boxes of slanted
+    // patches.  A tile belongs to the shell its box's gap from the points' centre falls into; the sweeps end when every line has a hit
+    // nearer than the shell reached, or the farthest box corner is inside it.
+    const int ngroups = (nt + kLineGroup - 1) / kLineGroup;
+    double wb[6];
+    wave_box(ok, p.x, p.y, p.z, wb);
+    const double cx = 0.5 * (wb[0] + wb[3]), cy = 0.5 * (wb[1] + wb[4]), cz = 0.5 * (wb[2] + wb[5]);
+    const double ext = sqrt((wb[3] - wb[0]) * (wb[3] - wb[0]) + (wb[4] - wb[1]) * (wb[4] - wb[1]) + (wb[5] - wb[2]) * (wb[5] - wb[2]));
+    double gmin2 = __builtin_huge_val(), gfar2 = 0.0;  // nearest gap / farthest corner of the group boxes from the centre
+    for (int g = 0; g < ngroups; ++g) {
+        const double *gb = gboxes + (int64_t)g * 6;
+        gmin2 = fmin(gmin2, point_box_gap2(cx, cy, cz, gb));
+        const double fx = fmax(fabs(cx - gb[0]), fabs(cx - gb[3])), fy = fmax(fabs(cy - gb[1]), fabs(cy - gb[4])),
+                     fz = fmax(fabs(cz - gb[2]), fabs(cz - gb[5]));
+        gfar2 = fmax(gfar2, fx * fx + fy * fy + fz * fz);
+    }
+    double radius = fmax(fmax(3.0 * ext, 1.5 * sqrt(gmin2)), sqrt(gfar2) * (1.0 / 64.0));
+    double inner2 = -1.0;  // tiles with inner2 < gap2 <= radius^2 belong to the sweep
+    double best = __builtin_huge_val(), bo = __builtin_huge_val();  // distance |p - ip| and the original triangle that holds it
+    V3 bp = p;
+    double bound = __builtin_huge_val();  // the smallest `best` of the query's four lanes (culling only)
+    for (;;) {
+        const double outer2 = radius * radius;
+        for (int g0 = 0; g0 < nt; g0 += kLineGroup) {
+            const int g = g0 / kLineGroup;
+            {
+                const double *gb = gboxes + (int64_t)g * 6;
+                if (point_box_gap2(cx, cy, cz, gb) > outer2) continue;  // (uniform) the whole group lies in a later shell
+                // one of the query's four lanes tests the group (the wave only needs the union)
+                const bool need_group = ok && (g & (kLineCopies - 1)) == copy && line.hits(gb) &&
+                                        !(point_box_gap2(p.x, p.y, p.z, gb) > bound * bound * (1.0 + 1e-12));
+                if (!__any(need_group)) continue;
+            }
+            // the query's four lanes share the box tests of the group's 16 tiles (four each) and of a tile's four quarters (one each);
+            // two shuffles give every lane the query's whole mask
+            unsigned tmask = 0;
+#pragma unroll
+            for (int u = 0; u < kLineGroup / kLineCopies; ++u) {
+                const int k = kLineCopies * u + copy, t = g0 + k;
+                if (t < nt) {
+                    const double *bx = boxes + (int64_t)t * 6;
+                    const double cg2 = point_box_gap2(cx, cy, cz, bx);
+                    if (cg2 > inner2 && cg2 <= outer2 && ok && line.hits(bx) &&
+                        !(point_box_gap2(p.x, p.y, p.z, bx) > bound * bound * (1.0 + 1e-12)))
+                        tmask |= 1u << k;
                 }
             }
+            tmask |= __shfl_xor(tmask, 1);
+            tmask |= __shfl_xor(tmask, 2);
+            for (int k = 0; k < kLineGroup && g0 + k < nt; ++k) {
+                if (!__any((tmask >> k) & 1u)) continue;
+                const int t = g0 + k;
+                const bool need_tile = (tmask >> k) & 1u;
+                unsigned qmask = 0;
+                {
+                    const int64_t q0 = (int64_t)t * kTriTile + 64 * copy;
+                    const double *qb = qboxes + ((int64_t)t * 4 + copy) * 6;
+                    if (q0 < T && need_tile && line.hits(qb) && !(point_box_gap2(p.x, p.y, p.z, qb) > bound * bound * (1.0 + 1e-12)))
+                        qmask = 1u << copy;
+                }
+                qmask |= __shfl_xor(qmask, 1);
+                qmask |= __shfl_xor(qmask, 2);
+                for (int q = 0; q < kTriTile / 64; ++q) {
+                    if (!__any((qmask >> q) & 1u)) continue;
+                    const int64_t q0 = (int64_t)t * kTriTile + 64 * q;
+                    // (the bound may have dropped since the mask was made)
+                    const bool need = ((qmask >> q) & 1u) &&
+                                      !(point_box_gap2(p.x, p.y, p.z, qboxes + ((int64_t)t * 4 + q) * 6) > bound * bound * (1.0 + 1e-12));
+                    __syncthreads();
+                    if (q0 + lane < T) {
+                        const int64_t tq = q0 + lane;
+                        const int32_t a = tri[3 * tq], b = tri[3 * tq + 1], c = tri[3 * tq + 2];
+                        quarter[lane] = Tri9{v.x[a], v.y[a], v.z[a], v.x[b], v.y[b], v.z[b], v.x[c], v.y[c], v.z[c],
+                                             (double)(tri_orig ? tri_orig[tq] : (int32_t)tq)};
+                    }
+                    __syncthreads();
+                    const int cnt = (int)min((int64_t)64, T - q0);
+                    if (need)
+                        for (int jj = copy; jj < cnt; jj += kLineCopies) {
+                            const Tri9 tr = quarter[jj];
+                            const V3 A{tr.ax, tr.ay, tr.az};
+                            const V3 e1 = sub(V3{tr.bx, tr.by, tr.bz}, A), e2 = sub(V3{tr.cx, tr.cy, tr.cz}, A);
+                            const V3 pv = cross3(dir, e2);
+                            const double det = dot3(e1, pv);
+                            const V3 tv = sub(p, A);
+                            const double nu = dot3(tv, pv);
+                            const double ad = fabs(det), su = det > 0.0 ? nu : -nu;
+                            if (su < -1e-9 * ad || su > ad * (1.0 + 1e-9)) continue;  // u clearly outside [0, 1]
+                            const V3 qv = cross3(tv, e1);
+                            const double nw = dot3(qv, dir);
+                            const double sw = det > 0.0 ? nw : -nw;
+                            if (sw < -1e-9 * ad || su + sw > ad * (1.0 + 2e-9)) continue;  // w < 0 or u + w > 1, clearly
+                            const double inv = 1.0 / det;
+                            const double u = nu * inv;
+                            const double w = nw * inv;
+                            const double tt = dot3(e2, qv) * inv;
+                            if (det != 0.0 && u >= 0.0 && u <= 1.0 && w >= 0.0 && u + w <= 1.0) {
+                                const V3 ip{p.x + tt * dir.x, p.y + tt * dir.y, p.z + tt * dir.z};
+                                if (ip.x != p.x || ip.y != p.y || ip.z != p.z) {
+                                    const V3 dd = sub(ip, p);
+                                    const double dist = sqrt((dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z);
+                                    if (dist < best || (dist == best && tr.orig < bo)) {
+                                        best = dist;
+                                        bo = tr.orig;
+                                        bp = ip;
+                                    }
+                                }
+                            }
+                        }
+                    bound = fmin(best, __shfl_xor(best, 1));
+                    bound = fmin(bound, __shfl_xor(bound, 2));
+                }
+            }
+        }
+        if (outer2 >= gfar2) break;                                    // every tile has been in a shell
+        if (__all(!ok || bound <= radius - ext)) break;                // what is left is farther than every line's hit
+        inner2 = outer2;
+        radius *= 2.0;
     }
-    if (ok) {
+    // the best of the four lanes: smallest distance, exact ties to the lowest original triangle
+#pragma unroll
+    for (int off = 1; off < kLineCopies; off <<= 1) {
+        const double od = __shfl_xor(best, off), oo = __shfl_xor(bo, off);
+        const double ox = __shfl_xor(bp.x, off), oy = __shfl_xor(bp.y, off), oz = __shfl_xor(bp.z, off);
+        if (od < best || (od == best && oo < bo)) {
+            best = od;
+            bo = oo;
+            bp = V3{ox, oy, oz};
+        }
+    }
+    if (ok && copy == 0) {
         cp[i] = bp.x;
         cp[fit.n + i] = bp.y;
         cp[2 * fit.n + i] = bp.z;
@@ -1770,8 +1893,11 @@ void launch_surface_prereject(gingr_ctx *ctx, int64_t M, const int32_t *nn_verte
                        tgt_boundary, fit_vn, tgt_vn, N, found, pre);
 }
 void launch_line_nearest(gingr_ctx *ctx, Cloud fit, const double *dirs_soa, Cloud v, const int32_t *tri, const int32_t *tri_orig,
-                         int64_t T, const double *boxes, double *cp_soa, int32_t *found) {
-    hipLaunchKernelGGL(line_nearest_kernel, dim3((unsigned)ceil_div(fit.n, kSurfThreads)), dim3(kSurfThreads), 0, ctx->stream, fit,
+                         int64_t T, double *boxes, double *cp_soa, int32_t *found) {
+    const int nt = (int)ceil_div(T, kTriTile);
+    hipLaunchKernelGGL(line_group_boxes_kernel, dim3((unsigned)ceil_div((int64_t)6 * ceil_div(nt, kLineGroup), 64)), dim3(64), 0, ctx->stream,
+                       boxes, nt);
+    hipLaunchKernelGGL(line_nearest_kernel, dim3((unsigned)ceil_div(fit.n, kLineQueries)), dim3(kSurfThreads), 0, ctx->stream, fit,
                        dirs_soa, v, tri, tri_orig, T, boxes, cp_soa, found);
 }
 void launch_surface_weight(gingr_ctx *ctx, int64_t M, const int32_t *pre, const int32_t *hit, const double *sigma2_dev, double *w01,

@@ -201,6 +201,39 @@ def test_along_normal_flavour(ctx):
         algo.close()
 
 
+@pytest.mark.parametrize("case", ["inside", "offset", "flat"])
+def test_along_normal_search_orders_and_culls_exactly(ctx, case):
+    """The along-normal search visits the target's triangle tiles in shells round a workgroup's points and culls by the hits found so
+    far (surface.hip line_nearest_kernel): a template well INSIDE the target (no hit in the first shells, both sides of the closed
+    target pierced), one offset so that lines leave the target on one side only, and an exactly flat template (vertex normals exactly
+    (0, 0, 1): the lines are parallel to an axis, the slab test's zero-direction branch) -- all against the oracle's exhaustive search."""
+    import gingr_amd as ga
+    rng = np.random.default_rng(7)
+    if case == "flat":
+        ref, cells = grid_mesh(40, 30.0, 0.0, 3)
+        ref[:, 2] = 0.0
+        target, tcells = grid_mesh(48, 45.0, 5.0, 4)
+        target = target + np.array([0.7, -0.4, 3.0])
+        rank = 10
+    else:
+        v, f = _icosphere(4)                      # 2 562 vertices, 5 120 triangles: 20 tiles, two groups of tile boxes
+        bump = 1.0 + 0.1 * np.sin(3 * v[:, 0]) * np.cos(2 * v[:, 1]) + 0.05 * np.sin(5 * v[:, 2])
+        target, tcells = v * 80.0 * bump[:, None], f
+        ref, cells = (v * 35.0 if case == "inside" else v * 60.0 + np.array([30.0, -12.0, 8.0])), f
+        rank = 12
+    mo = model_over(ref, cells, rank)
+    model = ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam, cells=cells)
+    algo = ga.IcpRegistration(ctx)
+    cfg = ga.IcpConfiguration(maxIterations=30, initialSigma=20.0, endSigma=1.0, correspondenceMethod="AlongNormalClosestPoint")
+    state = algo.createInitialState(model, target, cfg, targetCells=tcells)
+    cp, w = algo.surfaceCorrespondence(state)
+    ocp, ow, _ = go.along_normal_correspondence(np.asarray(state.general.fit), cells, target, tcells)
+    assert np.array_equal(w, ow), (case, int((w != ow).sum()))
+    assert np.abs(cp - ocp).max() < 1e-9 * max(1.0, np.abs(target).max()), case
+    assert w.sum() > 0, case
+    algo.close()
+
+
 @pytest.mark.parametrize("method", ["TriangularClosestPoint", "AlongNormalClosestPoint", "PointcloudClosestPoint"])
 def test_reversed_correspondence_direction(ctx, method):
     """reverseCorrespondenceDirection = true (ICP.scala:46-48): per-target assignments and one update against the oracle."""

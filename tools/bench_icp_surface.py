@@ -2,7 +2,8 @@
 """ICP update rate with the SURFACE correspondence (the reference's default ICP method) on a synthetic closed mesh:
 icosphere of subdivision level L (L=6: 40 962 vertices, 81 920 triangles), bumpy and posed copy as the target; one step =
 cell/vertex normals + closest point on the target surface + nearest target vertex + the three rejection tests + GP update.
-    PYTHONPATH=. python tools/bench_icp_surface.py [level] [tri_grid=0|1]      (tri_grid=0: the tile scan alone, for same-box comparisons)
+    PYTHONPATH=. python tools/bench_icp_surface.py [level] [tri_grid=0|1] [method=TriangularClosestPoint|AlongNormalClosestPoint]
+    (tri_grid=0: the tile scan alone, for same-box comparisons; method: ICP.scala:40-44)
 """
 import json
 import sys
@@ -43,6 +44,7 @@ def icosphere(level):
 OPTS = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
 POS = [a for a in sys.argv[1:] if "=" not in a]
 level = int(POS[0]) if POS else 6
+METHOD = OPTS.get("method", "TriangularClosestPoint")
 verts, cells = icosphere(level)
 ref = verts * 80.0
 bump = 1.0 + 0.08 * np.sin(3 * verts[:, 0]) * np.cos(2 * verts[:, 1]) + 0.05 * np.sin(5 * verts[:, 2])
@@ -55,7 +57,7 @@ ctx.set_option(nat.OPT_TRI_GRID, int(OPTS.get("tri_grid", 1)))
 model = ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.0, maxRank=100).Gaussian(40.0, 10.0)
 model.cells = cells
 algo = ga.IcpRegistration(ctx)
-cfg = ga.IcpConfiguration(maxIterations=100, initialSigma=10.0, endSigma=1.0, correspondenceMethod="TriangularClosestPoint")
+cfg = ga.IcpConfiguration(maxIterations=100, initialSigma=10.0, endSigma=1.0, correspondenceMethod=METHOD)
 state = algo.createInitialState(model, target, cfg, targetCells=cells)
 state = algo.update(state)          # binds, uploads the meshes, first launch
 cp, w = algo.surfaceCorrespondence(state)
@@ -69,7 +71,7 @@ dt = time.perf_counter() - t0
 # the same iterations the way GingrAlgorithm.run takes them when nobody watches the intermediate states (api.py: _run_resident): the
 # state stays on the device, an iteration reads back its scalars only, coefficients and fit come back once at the end
 nres = int(OPTS.get("resident", 50))
-cfg_run = ga.IcpConfiguration(maxIterations=nres + 1, initialSigma=10.0, endSigma=1.0, correspondenceMethod="TriangularClosestPoint")
+cfg_run = ga.IcpConfiguration(maxIterations=nres + 1, initialSigma=10.0, endSigma=1.0, correspondenceMethod=METHOD)
 s0 = algo.createInitialState(model, target, cfg_run, targetCells=cells)
 algo.run(s0)                         # warm (the first run also uploads the state)
 ctx.synchronize()
@@ -81,6 +83,8 @@ dt_run = time.perf_counter() - t0
 from gingr_amd.sharded import ShardedFitter
 f = ShardedFitter(ctx, model, target)
 f.set_meshes(cells, cells)
+if METHOD == "AlongNormalClosestPoint":
+    assert f._lib.gingr_fitter_set_surface_method(f.handle, 1) == 0
 f.set_state(np.zeros(model.rank), 10.0)
 import ctypes
 ip = nat.IcpParams(10.0, 1.0, 100)
@@ -107,5 +111,5 @@ print(json.dumps({"what": "ICP update, surface correspondence (closest point on 
                             "doubles) pulled every time" % (nres, ref.shape[0]),
                   "accepted_fraction_first_iteration": float(w.mean()), "status": int(state.general.status),
                   "run_status": int(end.general.status), "run_iterations": int(end.general.iteration),
-                  "sigma2": float(state.general.sigma2), "tri_grid": int(OPTS.get("tri_grid", 1)),
+                  "sigma2": float(state.general.sigma2), "tri_grid": int(OPTS.get("tri_grid", 1)), "method": METHOD,
                   "fit_checksum": float(np.abs(np.asarray(state.general.fit)).sum())}))
