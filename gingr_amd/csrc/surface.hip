@@ -819,7 +819,10 @@ struct LineSlab {
 };
 
 constexpr int kLineGroup = 16;       // tiles per group box
-constexpr int kLineCopies = 4;       // lanes per query: they take alternate triangles of a staged quarter and alternate group boxes
+#ifndef GINGR_LINE_COPIES
+#define GINGR_LINE_COPIES 4
+#endif
+constexpr int kLineCopies = GINGR_LINE_COPIES;  // lanes per query: they take alternate triangles of a staged quarter and alternate group boxes
 constexpr int kLineQueries = kSurfThreads / kLineCopies;
 
 // boxes of the groups of 16 tiles (the triangle order is a k-d order: aligned runs are compact), behind the tile and quarter boxes
@@ -847,7 +850,7 @@ __global__ __launch_bounds__(kSurfThreads) void line_nearest_kernel(Cloud fit, c
                                                                    int32_t *__restrict__ found) {
     __shared__ Tri9 quarter[64];
     const int lane = threadIdx.x, copy = lane & (kLineCopies - 1);
-    const int64_t i = (int64_t)blockIdx.x * kLineQueries + (lane >> 2);
+    const int64_t i = (int64_t)blockIdx.x * kLineQueries + lane / kLineCopies;
     const bool ok = i < fit.n;
     const int64_t ic = ok ? i : 0;
     const V3 p{fit.x[ic], fit.y[ic], fit.z[ic]};
@@ -903,9 +906,9 @@ __global__ __launch_bounds__(kSurfThreads) void line_nearest_kernel(Cloud fit, c
             // two shuffles give every lane the query's whole mask
             unsigned tmask = 0;
 #pragma unroll
-            for (int u = 0; u < kLineGroup / kLineCopies; ++u) {
+            for (int u = 0; u < (kLineGroup + kLineCopies - 1) / kLineCopies; ++u) {
                 const int k = kLineCopies * u + copy, t = g0 + k;
-                if (t < nt) {
+                if (k < kLineGroup && t < nt) {
                     const double *bx = boxes + (int64_t)t * 6;
                     const double cg2 = point_box_gap2(cx, cy, cz, bx);
                     if (cg2 > inner2 && cg2 <= outer2 && ok && line.hits(bx) &&
@@ -913,21 +916,25 @@ __global__ __launch_bounds__(kSurfThreads) void line_nearest_kernel(Cloud fit, c
                         tmask |= 1u << k;
                 }
             }
-            tmask |= __shfl_xor(tmask, 1);
-            tmask |= __shfl_xor(tmask, 2);
+#pragma unroll
+            for (int off = 1; off < kLineCopies; off <<= 1) tmask |= __shfl_xor(tmask, off);
             for (int k = 0; k < kLineGroup && g0 + k < nt; ++k) {
                 if (!__any((tmask >> k) & 1u)) continue;
                 const int t = g0 + k;
                 const bool need_tile = (tmask >> k) & 1u;
                 unsigned qmask = 0;
-                {
-                    const int64_t q0 = (int64_t)t * kTriTile + 64 * copy;
-                    const double *qb = qboxes + ((int64_t)t * 4 + copy) * 6;
-                    if (q0 < T && need_tile && line.hits(qb) && !(point_box_gap2(p.x, p.y, p.z, qb) > bound * bound * (1.0 + 1e-12)))
-                        qmask = 1u << copy;
+#pragma unroll
+                for (int u = 0; u < (kTriTile / 64 + kLineCopies - 1) / kLineCopies; ++u) {
+                    const int q = kLineCopies * u + copy;
+                    if (q < kTriTile / 64) {
+                        const int64_t q0 = (int64_t)t * kTriTile + 64 * q;
+                        const double *qb = qboxes + ((int64_t)t * 4 + q) * 6;
+                        if (q0 < T && need_tile && line.hits(qb) && !(point_box_gap2(p.x, p.y, p.z, qb) > bound * bound * (1.0 + 1e-12)))
+                            qmask |= 1u << q;
+                    }
                 }
-                qmask |= __shfl_xor(qmask, 1);
-                qmask |= __shfl_xor(qmask, 2);
+#pragma unroll
+                for (int off = 1; off < kLineCopies; off <<= 1) qmask |= __shfl_xor(qmask, off);
                 for (int q = 0; q < kTriTile / 64; ++q) {
                     if (!__any((qmask >> q) & 1u)) continue;
                     const int64_t q0 = (int64_t)t * kTriTile + 64 * q;
@@ -975,8 +982,9 @@ __global__ __launch_bounds__(kSurfThreads) void line_nearest_kernel(Cloud fit, c
                                 }
                             }
                         }
-                    bound = fmin(best, __shfl_xor(best, 1));
-                    bound = fmin(bound, __shfl_xor(bound, 2));
+                    bound = best;
+#pragma unroll
+                    for (int off = 1; off < kLineCopies; off <<= 1) bound = fmin(bound, __shfl_xor(bound, off));
                 }
             }
         }
