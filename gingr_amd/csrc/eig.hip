@@ -4,22 +4,25 @@
 // basis of a kernel model: G/api/registration/utils/GPMMHelper.scala:39-69, E/CreateBunnyGPMM.scala), and the eigenbasis of the
 // model's moment S_tot = Q^T Q the uniform-weight posterior uses (gp.hip posterior_solve_eig_kernel).
 //
-// The two-sided cyclic Jacobi it takes over from (gpmm.hip jacobi_eig_kernel, still the path above n = 192) keeps A and V in
-// global memory and spends a round trip to L2 per load-store of every rotation round: 40 us a round at n = 171, 61 ms a
-// decomposition.  Here the method is the ONE-SIDED (Hestenes) Jacobi applied to the columns of G itself: rotations from the right
-// make the columns of H = G V mutually orthogonal; for a symmetric positive semi-definite G that means V holds the eigenvectors and
-// H = V diag(lambda), so the eigenvalues are the column norms and the eigenvectors the normalised columns -- no V to accumulate.
-// A rotation only needs three dot products of two columns, so:
+// The two-sided cyclic Jacobi it takes over from (gpmm.hip jacobi_eig_kernel, still the path above n = 192 and for numerically
+// singular matrices) keeps A and V in global memory and spends a round trip to L2 per load-store of every rotation round: 40 us a
+// round at n = 171, 61 ms a decomposition.  Here:
+//   * G = C C^T first (right-looking Cholesky, a column at a time through LDS), then the ONE-SIDED (Hestenes) Jacobi on the columns
+//     of C: rotations from the right make the columns of C V mutually orthogonal, so they are the eigenvectors of G scaled by the
+//     roots of the eigenvalues -- eigenvalue = squared length, eigenvector = normalised column, no V to accumulate, and the
+//     accuracy is governed by the condition number of C (the root of G's).  A failed pivot leaves the columns of G itself to rotate
+//     (eigenvalue = length), and info[1] reports the matrix as numerically singular: the callers then take the two-sided kernel,
+//     whose V starts from the identity and is complete whatever the spectrum.
 //   * a column lives in the registers of ONE wave, E values per lane (row = e * 64 + lane); a wave owns P pairs of columns;
-//   * a round = every wave rotates its P pairs (dot products by DPP + two cross-row shuffles), then the round-robin tournament
-//     moves every column one place: inside a wave that is a register rename, between neighbouring waves one column each way
-//     through LDS -- one barrier per round, two LDS buffers;
-//   * up to 16 waves x 6 pairs x 2 columns = 192 columns of 192 rows.
-// Rotation threshold |p.q| > sqrt(n) eps |p| |q| (LAPACK dgesvj's), at most 60 sweeps.  Accuracy of an eigenvector is
-// eps * lambda_max / lambda_i (the column G v_i is what gets normalised); the matrices here have condition numbers of a few
-// hundred (a truncated pivoted Cholesky factor's Gram) -- and a NUMERICALLY SINGULAR matrix (smallest column norm below
-// n eps lambda_max) is reported in info[1], upon which the callers take the two-sided kernel, whose V starts from the identity
-// and is complete whatever the spectrum.
+//   * a round = ONE dot product per pair (the squared norms travel with the columns, updated by the rotation formulas and
+//     recomputed once a sweep), summed for all P pairs at once by v_permlane32_swap / v_permlane16_swap + DPP so that the lanes
+//     8 j .. 8 j + 7 hold pair j's; these lanes work out the rotation (two v_rsq_f64 with Newton steps instead of three divisions
+//     and three roots), which reaches the wave through scalar registers; then the round-robin tournament moves every column one
+//     place: inside a wave a register rename, between neighbouring waves one column each way through LDS -- one barrier per round,
+//     two LDS buffers;
+//   * 16 waves x 6 pairs x 2 columns = 192 columns of 192 rows at most; up to three problems per launch, one workgroup each.
+// Rotation threshold |p.q| > sqrt(n) eps |p| |q| (LAPACK dgesvj's), at most 60 sweeps (8 at n = 171; the two-sided kernel needs 10).
+// n = 34 / 100 / 171: 0.26 / 1.3 / 3.2 ms (tools/ubench_sym_eig.hip, profiles/r06_ubench_sym_eig.txt).
 #include "gp.h"
 
 namespace {

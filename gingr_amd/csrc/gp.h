@@ -331,7 +331,8 @@ void launch_posterior_sample_cached(gingr_ctx *ctx, int32_t r, int32_t rp, const
 void launch_posterior_solve_eig(gingr_ctx *ctx, int32_t r, int32_t rp, const double *eigV, const double *eigL, const double *sigma2,
                                 const double *rhs, double *a, DevState *st);
 // eigen-decomposition of the leading n x n block of the symmetric G (row stride ldg): evals [n] descending, Vs [n*n] (Vs[i*n + k] =
-// component i of eigenvector k); one workgroup, cyclic Jacobi (gpmm.hip)
+// component i of eigenvector k); the register kernel of eig.hip up to 192 columns, the two-sided cyclic Jacobi of gpmm.hip above that
+// and for numerically singular matrices (gpmm.hip sym_eig); synchronises the stream
 int launch_jacobi_eig(gingr_ctx *ctx, const double *G, int32_t ldg, int32_t n, double *evals, double *Vs);
 // eig.hip: one-sided register Jacobi on the Cholesky factor, n <= kSymEigColsMaxN, up to three problems per launch (see sym_eig, gpmm.hip)
 constexpr int kSymEigColsMaxN = 192;
