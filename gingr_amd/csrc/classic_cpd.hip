@@ -544,7 +544,7 @@ int gingr_classic_cpd_create(gingr_ctx *ctx, int32_t kind, int64_t M, const doub
     CC_TRY(h->P1.alloc((size_t)M * sizeof(double)));
     CC_TRY(h->PX.alloc((size_t)3 * M * sizeof(double)));
     const int64_t ws1 = cpd_colsum_ws_doubles(M, N), ws2 = cpd_rowstats_ws_doubles(M, N);
-    CC_TRY(h->ws.alloc((size_t)(ws1 > ws2 ? ws1 : ws2) * sizeof(double)));
+    CC_TRY(h->ws.alloc((size_t)std::max(std::max(ws1, ws2), sumsq_pairs_ws_doubles(M)) * sizeof(double)));
     CC_TRY(h->part.alloc(GINGR_SCALAR_PART * sizeof(double)));
     CC_TRY(h->sc.alloc(16 * sizeof(double)));
     CC_TRY(h->aux.alloc(GINGR_AUX * sizeof(double)));

@@ -209,6 +209,8 @@ void nn_grid_free(NNGrid *g);
 bool launch_nn_grid(gingr_ctx *ctx, Cloud query, Cloud target, const int32_t *target_orig, NNGrid &g, const int32_t *warm,
                     int32_t *idx, double *d2);
 void launch_gauss_block(gingr_ctx *ctx, Cloud A, Cloud B, double sigma, double scaling, double *out);
+// sum over all pairs of |a_i - b_j|^2 (computeInitialSigma2, CPD.scala:81-90); ws: sumsq_pairs_ws_doubles(A.n) doubles
+int64_t sumsq_pairs_ws_doubles(int64_t nA);
 void launch_sumsq_pairs(gingr_ctx *ctx, Cloud A, Cloud B, double *ws, double *out_scalar);
 // ---------------------------------------------------------------------------- surface.hip (ICP surface correspondence)
 // tri: [3*T] vertex POSITIONS in the cloud `v`, in a spatial triangle order; boxes: one {lo, hi} per 256 triangles

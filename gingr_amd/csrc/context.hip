@@ -301,7 +301,7 @@ int gingr_cpd_initial_sigma2(gingr_ctx *ctx, int64_t M, const double *ref, int64
     Cloud ca, cb;
     GINGR_TRY(upload_cloud(ctx, M, ref, sa, da, &ca));
     GINGR_TRY(upload_cloud(ctx, N, target, sb, db, &cb));
-    HIP_TRY(ctx, dws.alloc((size_t)ceil_div(M, 256) * sizeof(double)));
+    HIP_TRY(ctx, dws.alloc((size_t)sumsq_pairs_ws_doubles(M) * sizeof(double)));
     HIP_TRY(ctx, dout.alloc(sizeof(double)));
     launch_sumsq_pairs(ctx, ca, cb, dws.as<double>(), dout.as<double>());
     GINGR_TRY(check_launch(ctx));

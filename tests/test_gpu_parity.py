@@ -88,6 +88,16 @@ def test_initial_sigma2(ctx):
     assert abs(ctx.cpd_initial_sigma2(y, x) - go.cpd_initial_sigma2(y, x)) < 1e-11 * go.cpd_initial_sigma2(y, x)
 
 
+@pytest.mark.parametrize("offset", [0.0, 1e4])
+def test_initial_sigma2_from_moments(ctx, offset):
+    """From 2^20 pairs on the sum over all pairs comes from the clouds' moments about the first point (affinity.hip
+    cloud_moments_kernel); clouds 10^4 away from the origin (200 times their extent) must not cost digits."""
+    y, x = clouds(2100, 3000, seed=6)
+    y, x = y + offset, x + offset + 3.0
+    want = go.cpd_initial_sigma2(y, x)
+    assert abs(ctx.cpd_initial_sigma2(y, x) - want) < 1e-11 * want
+
+
 @pytest.mark.parametrize("M,N", [(1, 1), (5, 1), (300, 257), (2000, 5000), (5000, 333)])
 def test_nn_bit_exact(ctx, M, N):
     rng = np.random.default_rng(M + 13 * N)
