@@ -17,6 +17,7 @@
 #include "fastexp.h"
 
 #include <algorithm>
+#include <system_error>
 #include <thread>
 #include <cstdlib>
 #include <utility>
@@ -1944,9 +1945,14 @@ static void kd_split(KdPoint *p, int64_t n, int64_t leaf, int par_levels) {
         return ka < kb || (ka == kb && a.idx < b.idx);
     });
     if (par_levels > 0 && n >= 16384) {
-        std::thread left([=] { kd_split(p, half, leaf, par_levels - 1); });
+        std::thread left;
+        try {
+            left = std::thread([=] { kd_split(p, half, leaf, par_levels - 1); });
+        } catch (const std::system_error &) {  // no thread to be had: this half inline as well
+            kd_split(p, half, leaf, 0);
+        }
         kd_split(p + half, n - half, leaf, par_levels - 1);
-        left.join();
+        if (left.joinable()) left.join();
     } else {
         kd_split(p, half, leaf, 0);
         kd_split(p + half, n - half, leaf, 0);
@@ -1972,9 +1978,17 @@ void morton_order(const double *xyz, int64_t n, std::vector<int32_t> &perm) {
     if (n >= 16384) {
         const int nt = 8;
         std::thread th[nt - 1];
-        for (int t = 1; t < nt; ++t) th[t - 1] = std::thread(leaves, nleaves * t / nt * 256, nleaves * (t + 1) / nt * 256);
+        for (int t = 1; t < nt; ++t) {
+            const int64_t b0 = nleaves * t / nt * 256, b1 = nleaves * (t + 1) / nt * 256;
+            try {
+                th[t - 1] = std::thread(leaves, b0, b1);
+            } catch (const std::system_error &) {
+                leaves(b0, b1);
+            }
+        }
         leaves(0, nleaves / nt * 256);
-        for (int t = 1; t < nt; ++t) th[t - 1].join();
+        for (int t = 1; t < nt; ++t)
+            if (th[t - 1].joinable()) th[t - 1].join();
     } else {
         leaves(0, nleaves * 256);
     }
