@@ -1,5 +1,6 @@
 // Internal definitions shared by the translation units of libgingr_hip.so (gfx950 only).
 #pragma once
+#include <cstdlib>
 
 #include <hip/hip_runtime.h>
 
@@ -89,13 +90,29 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         bytes = n;
-        return hipMalloc(&p, n ? n : 8);
+        const hipError_t e = hipMalloc(&p, n ? n : 8);
+        static const bool poison = getenv("GINGR_DEBUG_POISON") != nullptr;  // (diagnostic: see dev_alloc, fitter.hip)
+        if (e == hipSuccess && poison) {
+            (void)hipMemset(p, 0xFF, n ? n : 8);
+            (void)hipDeviceSynchronize();
+        }
+        return e;
     }
     template <typename T>
     T *as() const {
         return reinterpret_cast<T *>(p);
     }
 };
+
+// Raise a kernel's dynamic-LDS limit -- ONCE per device, function and size, under a lock.  hipFuncSetAttribute in front of every launch
+// (rounds 1-5) is a race in a device group, where one host thread per shard launches the same kernels: a launch that overlaps another
+// thread's hipFuncSetAttribute on the same function can be rejected, nothing runs, and the consumer reads the previous iteration's
+// partials (a 0.2 % flake of the three-shard rank-150 tests, unmasked by tools/experiments/stress_group2.py).
+void set_dynamic_lds(const void *func, int bytes);
+template <typename K>
+inline void set_dynamic_lds(K *kern, size_t bytes) {
+    set_dynamic_lds(reinterpret_cast<const void *>(kern), (int)bytes);
+}
 
 struct TimerScope {
     gingr_ctx *ctx;

@@ -1,6 +1,22 @@
 // Context, error handling, timing hooks and the stateless all-pairs operators of the C ABI (include/gingr_hip.h).
 #include "common.h"
 
+#include <map>
+#include <mutex>
+void set_dynamic_lds(const void *func, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, int> limit;  // (device, function) -> bytes already granted
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    int &have = limit[std::make_pair(dev, func)];
+    if (have >= bytes) return;
+    if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess)
+        have = bytes;
+    else
+        (void)hipGetLastError();
+}
+
 
 int gingr_set_error(gingr_ctx *ctx, int code, const char *fmt, ...) {
     if (ctx) {

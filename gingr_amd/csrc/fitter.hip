@@ -15,6 +15,7 @@
 #include "gp.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <functional>
 
@@ -349,6 +350,13 @@ __global__ __launch_bounds__(256) void soa_range_kernel(const double *__restrict
 template <typename T>
 int dev_alloc(gingr_ctx *ctx, T **p, size_t count) {
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(p), (count ? count : 1) * sizeof(T)));
+    // diagnostic (GINGR_DEBUG_POISON=1): new buffers start as NaN / 0xFFFFFFFF instead of whatever the allocator hands out, so that a
+    // read of something never written shows instead of depending on what ran before
+    static const bool poison = getenv("GINGR_DEBUG_POISON") != nullptr;
+    if (poison) {  // (memsets of device memory are asynchronous to the host and not ordered with the context's non-blocking stream)
+        HIP_TRY(ctx, hipMemset(*p, 0xFF, (count ? count : 1) * sizeof(T)));
+        HIP_TRY(ctx, hipDeviceSynchronize());
+    }
     return GINGR_OK;
 }
 

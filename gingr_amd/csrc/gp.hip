@@ -1909,8 +1909,11 @@ __device__ __forceinline__ void wide_solve_body(double *P, WideSolveLds<SW> &Ls,
         }
         if (tid < sw) rdg[kb + tid] = rdl[tid];
         GINGR_STAGE_CLOCK(4)
+        // The next panel's first slice is requested straight away, and at kb = SW that slice IS the panel just written, by other
+        // threads: without this barrier a rare race (one posterior in ~1 500 at rank 150 when other kernels share the device; found
+        // through the three-shard tests, tools/experiments/stress_group2.py / stress_group3.py).
+        __syncthreads();
     }
-    __syncthreads();
     // x = L^-T y: y = row n of the workspace (L^-1 rhs); the sampling direction L^-T z rides along
     const int kb_last = ((n - 1) / SW) * SW;
     for (int kb = kb_last; kb >= 0; kb -= SW) {
@@ -2080,8 +2083,11 @@ __global__ __launch_bounds__(kWideSolveThreads) void posterior_solve_wide_kernel
         }
         if (tid < sw) rdg[kb + tid] = rdl[tid];
         GINGR_STAGE_CLOCK(4)
+        // The next panel's first slice is requested straight away, and at kb = SW that slice IS the panel just written, by other
+        // threads: without this barrier a rare race (one posterior in ~1 500 at rank 150 when other kernels share the device; found
+        // through the three-shard tests, tools/experiments/stress_group2.py / stress_group3.py).
+        __syncthreads();
     }
-    __syncthreads();
     // x = L^-T y: y = row n of the workspace (L^-1 rhs); the sampling direction L^-T z rides along.  Everything a block reads from
     // the workspace -- the rows below it for the mat-vec, its diagonal block, its reciprocal diagonal -- does not depend on the x of the
     // blocks behind it, so it is requested one block AHEAD, before the sequential substitution of the current block, and waits in
@@ -2974,8 +2980,7 @@ static void launch_sweep_mode(gingr_ctx *ctx, const SweepArgs &a, int width) {
         hipLaunchKernelGGL((sweep_kernel<MODE, 8>), dim3(nb), dim3(kSweepThreads), lds, ctx->stream, a);
     } else {
         if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_kernel<MODE, 32>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            set_dynamic_lds(&sweep_kernel<MODE, 32>, (size_t)(lds));
         hipLaunchKernelGGL((sweep_kernel<MODE, 32>), dim3(nb), dim3(kSweepThreads), lds, ctx->stream, a);
     }
     ts.stop();
@@ -3195,8 +3200,7 @@ void launch_chol_block64(gingr_ctx *ctx, double *Aw, int64_t ld, int k, double *
     const size_t lds = lds_solve_doubles(64, 64) * sizeof(double);
     // (the attribute is per function AND per device, and the group's worker threads launch concurrently: set whenever needed)
     if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_block64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+        set_dynamic_lds(&chol_block64_kernel, (size_t)(lds));
     hipLaunchKernelGGL(chol_block64_kernel, dim3(1), dim3(256), lds, ctx->stream, Aw, ld, k, Linv, flag);
 }
 
@@ -3332,7 +3336,7 @@ void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
         const size_t lds = lds_solve_doubles(rp, fast ? 2 * kNB : kNB) * sizeof(double);
         auto go = [&](auto kern) {
             if (lds > 48 * 1024)  // per function and per device: set whenever needed
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                set_dynamic_lds(kern, (size_t)(lds));
             hipLaunchKernelGGL(kern, dim3(1), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a, st, (double *)nullptr);
         };
         if (fast)
@@ -3345,7 +3349,7 @@ void launch_posterior_solve(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
     // (posterior_work_doubles)
     auto gow = [&](auto kern, int sw) {
         const size_t lds = (size_t)(rp + kNB) * (sw + 1) * sizeof(double);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set_dynamic_lds(kern, (size_t)(lds));
         hipLaunchKernelGGL(kern, dim3(1), dim3(kWideSolveThreads), lds, ctx->stream, (int)r, (int)rp, G, rhs, zrand, a, st, work);
     };
     if (rp <= 256)
@@ -3403,8 +3407,7 @@ int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
     if (!cached && in_lds && fx && sync) {  // the two factorisations side by side
         const size_t lds2 = lds_solve_doubles(rp, 2 * kNB) * sizeof(double);  // (workgroup 0 carries the identity rows of the solve kernel)
         if (lds2 > 48 * 1024)  // per function and per device: set whenever needed
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds2);
+            set_dynamic_lds(&posterior_logpdf_split_kernel, (size_t)(lds2));
         hipLaunchKernelGGL(posterior_logpdf_split_kernel, dim3(2), dim3(kSolveThreads), lds2, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte, fx,
                            out2, sync, epoch, keep_factor ? 1 : 0, nfac);
         return GINGR_OK;
@@ -3427,7 +3430,7 @@ int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
         const int64_t stride = posterior_work_doubles(rp) / 2;
         auto gow = [&](auto kern, int sw) {
             const size_t ldsw = (size_t)(rp + kNB) * (sw + 1) * sizeof(double);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+            set_dynamic_lds(kern, (size_t)(ldsw));
             hipLaunchKernelGGL(kern, dim3(2), dim3(kWideSolveThreads), ldsw, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte, fx, out2, sync, epoch,
                                work, stride);
         };
@@ -3440,8 +3443,7 @@ int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
     if (cached) {  // fx holds what an earlier launch for this state left
         if (in_lds) {
             if (lds > 48 * 1024)  // per function and per device: set whenever needed
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_cached_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                set_dynamic_lds(&posterior_logpdf_cached_kernel<false>, (size_t)(lds));
             hipLaunchKernelGGL(posterior_logpdf_cached_kernel<false>, dim3(1), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, G, Stot,
                                qte, fx, out2, (double *)nullptr);
         } else {
@@ -3452,8 +3454,7 @@ int launch_posterior_logpdf(gingr_ctx *ctx, int32_t r, int32_t rp, const double 
     }
     if (in_lds) {
         if (lds > 48 * 1024)  // per function and per device: set whenever needed
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_logpdf_lds_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            set_dynamic_lds(&posterior_logpdf_lds_kernel<false>, (size_t)(lds));
         hipLaunchKernelGGL(posterior_logpdf_lds_kernel<false>, dim3(1), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, G, rhs, Stot, qte,
                            fx, out2, (double *)nullptr);
     } else {
@@ -3467,8 +3468,7 @@ void launch_posterior_sample_cached(gingr_ctx *ctx, int32_t r, int32_t rp, const
                                     double *a, DevState *st) {
     const size_t lds = lds_solve_doubles(rp, kNB) * sizeof(double);
     if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&posterior_sample_cached_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+        set_dynamic_lds(&posterior_sample_cached_kernel, (size_t)(lds));
     hipLaunchKernelGGL(posterior_sample_cached_kernel, dim3(1), dim3(kSolveThreads), lds, ctx->stream, (int)r, (int)rp, nfac, a_mean, zrand, a, st);
 }
 
@@ -3523,7 +3523,7 @@ void launch_post_solve(gingr_ctx *ctx, const PostSolveArgs &a) {
     const size_t lds = (size_t)37 * a.rp * sizeof(double);
     const int nt = std::max<int>(kPostMinThreads, (int)round_up(a.rp, 64));
     if (lds > 48 * 1024)  // (per function AND per device: set whenever it is needed, never cached in a process-wide static)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&post_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set_dynamic_lds(&post_solve_kernel, (size_t)(lds));
     hipLaunchKernelGGL(post_solve_kernel, dim3(1), dim3(nt), lds, ctx->stream, a);
 }
 

@@ -303,7 +303,7 @@ static int gram_wide_go(gingr_ctx *ctx, const double *Q0, int64_t rows, int32_t 
     const size_t lds = (size_t)2 * 4096 * sizeof(double);
     const dim3 grid((unsigned)(p.nslabs * p.nparts)), block(64 * kWaves);
     auto go = [&](auto kern) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set_dynamic_lds(kern, (size_t)(lds));
         TimerScope ts(ctx, 2);  // (the Gram pass itself: row_expand_kernel stays outside, as in the rocprof statistics)
         hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, a);
     };

@@ -384,6 +384,36 @@ def test_group_cpd_and_pointcloud_sample_and_logpdf(flavour, rank):
     multi.close()
 
 
+@pytest.mark.parametrize("rank", [40, 150, 200])
+def test_group_results_do_not_depend_on_timing(rank):
+    """Updates of three logical shards (three host threads, kernels of three streams sharing the device), ALTERNATING between five
+    states, each against the single shard's result for that state.  Alternating matters: a kernel that reads something too early finds
+    the previous update's numbers there, and with identical repetitions those are the right ones.  (Round 6: the one-workgroup
+    super-panel solve of ranks 129-240 requested the next panel's first slice without a barrier behind the write-back of the panel
+    before -- one posterior in ~1 500 came out 1e-6 off when other kernels shared the device, nothing when it ran alone.)"""
+    mo, target = _case(rank=rank)
+    single = _group([0], mo, target)
+    multi = _group([0, 0, 0], mo, target)
+    rng = np.random.default_rng(1)
+    states = [(rng.normal(0, 0.5, mo.rank), float(s2)) for s2 in (30.0, 12.0, 50.0, 20.0, 8.0)]
+    want = []
+    for a, s2 in states:
+        single.set_state(a, s2)
+        single.update(0, (0.1, 1.0), 1)
+        want.append(single.get_state()[2].copy())
+    bad = []
+    for k in range(2500 if rank == 150 else 600):  # (the race was one in ~1 500 at rank 150)
+        j = int(rng.integers(0, len(states)))
+        multi.set_state(*states[j])
+        multi.update(0, (0.1, 1.0), 1)
+        e = rel(multi.get_state()[2], want[j])
+        if e > 1e-9:
+            bad.append((k, j, e))
+    single.close()
+    multi.close()
+    assert not bad, bad[:5]
+
+
 @pytest.mark.parametrize("world", [2, 3, 5])
 def test_all_gather_staging_equals_the_zero_padded_all_reduce(world):
     """gingr_fitter_gather_stage / _finish (what the native RCCL path wraps around ncclAllGather): `world` logical shards on one device,
