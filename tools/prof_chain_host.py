@@ -1,5 +1,8 @@
+"""cProfile of the Metropolis-Hastings chain's host side (tools/bench_mh_chain.py 300): the functions of gingr_amd/ by own time."""
 import cProfile, pstats, sys, os, runpy, io
 sys.argv = ["bench_mh_chain.py", "300"]
+import torch  # noqa: F401  (outside the profile)
+import numpy  # noqa: F401
 pr = cProfile.Profile()
 pr.enable()
 try:
@@ -8,5 +11,6 @@ except SystemExit:
     pass
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
-print(s.getvalue()[:9000])
+st = pstats.Stats(pr, stream=s)
+st.sort_stats("tottime").print_stats("gingr_amd|ctypes|numpy", 40)
+print(s.getvalue()[:12000])
