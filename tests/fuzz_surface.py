@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One-off randomized sweep of the surface kernels (development aid, not collected by pytest; lives under tests/ because it uses
 the oracle): random open / closed meshes of random sizes and poses, closest point on the surface + weights of the three
-rejection rules + distance statistics (both directions, boundary-aware) + nearest neighbour, HIP path vs the oracle.
+rejection rules + distance statistics (both directions, boundary-aware) + nearest neighbour + the along-normal flavour's intersections,
+HIP path vs the oracle.
     PYTHONPATH=. python tests/fuzz_surface.py [n] [seed]"""
 import sys
 
@@ -37,7 +38,7 @@ def grid(n, m, size, amp, closed):
     return P.reshape(-1, 3), np.concatenate([np.stack([a, b, c], 1), np.stack([b, d, c], 1)]).astype(np.int32)
 
 
-worst = 0.0
+worst = worst_along = 0.0
 for case in range(n_cases):
     closed = bool(rng.integers(0, 2))
     n, m = int(rng.integers(8, 40)), int(rng.integers(8, 40))
@@ -71,4 +72,15 @@ for case in range(n_cases):
     algo.close()
     if not ok:
         sys.exit(1)
-print("worst closest-point error / size:", worst)
+    # the along-normal flavour on the same pair (ClosestPointRegistrator.scala:102-131): nearest intersection of the normal line
+    algo = ga.IcpRegistration(ctx)
+    state = algo.createInitialState(model, v2, ga.IcpConfiguration(maxIterations=5, initialSigma=2.0, endSigma=1.0, correspondenceMethod="AlongNormalClosestPoint"), targetCells=t2)
+    cp, w = algo.surfaceCorrespondence(state)
+    ocp, ow, _ = go.along_normal_correspondence(np.asarray(state.general.fit), t1, v2, t2)
+    ea, bad_w = float(np.abs(cp - ocp).max() / size), int((w != ow).sum())
+    algo.close()
+    worst_along = max(worst_along, ea)
+    if not (ea < 1e-9 and bad_w == 0):
+        print(f"case {case:3d} along the normal: cp err {ea:.1e} weights differing {bad_w} MISMATCH", flush=True)
+        sys.exit(1)
+print("worst closest-point error / size:", worst, " along the normal:", worst_along)
