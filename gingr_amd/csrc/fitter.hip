@@ -1049,9 +1049,30 @@ int gingr_fitter_get_state(gingr_fitter *f, double *alpha, gingr_state_scalars *
     const int64_t M = f->m->M;
     const int32_t rp_ = f->m->rp;
     const size_t head = (size_t)rp_ + kScalarsDoubles + kDevStateDoubles;  // [alpha | scalars | DevState], one transfer
-    HIP_TRY(ctx, hipMemcpyAsync(f->pin, f->state_block, head * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    bool seen = false;
+    if (f->pin_dev && M <= 8192) {
+        // small templates: one launch gathers state and fit straight into the pinned buffer and the call spins on the flag word (as
+        // gingr_fitter_mh_step does) instead of two copies, a reordering launch and a stream synchronisation
+        volatile double *flag = f->pin + f->pin_doubles - 1;
+        const double epoch = (double)(++f->mh_epoch);
+        const int64_t n = fit_xyz ? std::max<int64_t>(M, (int64_t)head) : (int64_t)head;
+        hipLaunchKernelGGL(mh_readback_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, f->state_block, (int)head,
+                           fit_xyz ? f->fit : (const double *)nullptr, M, f->m->perm, f->pin_dev, f->pin_dev + f->pin_doubles - 1, f->mh_done, epoch);
+        GINGR_TRY(check_launch(ctx));
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+        for (unsigned spins = 0;; ++spins) {
+            if (*flag == epoch) {
+                seen = true;
+                break;
+            }
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() > deadline) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (!seen) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (a launch that never finished: the error is reported here)
+    }
+    if (!seen) HIP_TRY(ctx, hipMemcpyAsync(f->pin, f->state_block, head * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     DevBuf tmp;
-    if (fit_xyz) {
+    if (fit_xyz && !seen) {
         double *stage = reinterpret_cast<double *>(f->aos);  // the fitter's interleaved staging buffer (max(3M, 3N) doubles)
         if (!stage) {                                        // no target yet: a temporary
             HIP_TRY(ctx, tmp.alloc((size_t)3 * M * sizeof(double)));
@@ -1060,7 +1081,7 @@ int gingr_fitter_get_state(gingr_fitter *f, double *alpha, gingr_state_scalars *
         launch_soa_to_aos(ctx, f->fit, M, stage, f->m->perm);
         HIP_TRY(ctx, hipMemcpyAsync(f->pin + head, stage, (size_t)3 * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!seen) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     DevState hst;
     memcpy(&hst, f->pin + rp_ + kScalarsDoubles, sizeof(hst));
     if (alpha) memcpy(alpha, f->pin, (size_t)f->m->r * sizeof(double));
