@@ -1041,6 +1041,35 @@ int gingr_fitter_set_fit_points(gingr_fitter *f, const double *fit_xyz) {
     return GINGR_OK;
 }
 
+// n doubles from the device into the pinned buffer at `dst` (a pointer INTO f->pin) without a copy + stream synchronisation: one small
+// launch writes them through the buffer's device address and stores the launch number into the flag word, the host spins on it (see
+// mh_readback_kernel).  Everything enqueued before on the stream is complete when this returns.
+static int pull_small(gingr_fitter *f, const double *src, int n, double *dst) {
+    gingr_ctx *ctx = f->ctx;
+    if (!f->pin_dev) {
+        HIP_TRY(ctx, hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return GINGR_OK;
+    }
+    volatile double *flag = f->pin + f->pin_doubles - 1;
+    const double epoch = (double)(++f->mh_epoch);
+    hipLaunchKernelGGL(mh_readback_kernel, dim3(1), dim3(256), 0, ctx->stream, src, n, (const double *)nullptr, (int64_t)0, (const int32_t *)nullptr,
+                       f->pin_dev + (dst - f->pin), f->pin_dev + f->pin_doubles - 1, f->mh_done, epoch);
+    GINGR_TRY(check_launch(ctx));
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+    bool seen = false;
+    for (unsigned spins = 0;; ++spins) {
+        if (*flag == epoch) {
+            seen = true;
+            break;
+        }
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() > deadline) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GINGR_OK;
+}
+
 int gingr_fitter_get_state(gingr_fitter *f, double *alpha, gingr_state_scalars *s, double *fit_xyz) {
     if (!f) return GINGR_ERR_BAD_ARGUMENT;
     gingr_ctx *ctx = f->ctx;
@@ -2305,8 +2334,7 @@ static int posterior_logpdf(gingr_fitter *f, int flavour, const gingr_cpd_params
                                       out2, f->lp_sync, ++f->lp_epoch));
     GINGR_TRY(check_launch(ctx));
     double *res = f->pin + (size_t)3 * M;  // behind the mesh (pin holds 3M + rp + ... doubles)
-    HIP_TRY(ctx, hipMemcpyAsync(res, out2, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    GINGR_TRY(pull_small(f, out2, 2, res));
     if (res[1] != 0.0) return gingr_set_error(ctx, GINGR_ERR_NOT_SPD, "posterior_logpdf: posterior of the current state failed");
     if (!std::isfinite(res[0])) return gingr_set_error(ctx, GINGR_ERR_NONFINITE, "posterior_logpdf: non-finite result");
     if (f->post_stage == 2) f->fx_valid[f->live] = true;  // (not memoised: sharded / state unknown to the host -> nothing to key it by)
@@ -2373,12 +2401,11 @@ int fitter_logpdf_finish(gingr_fitter *f, double *logpdf) {
     GINGR_TRY(launch_posterior_logpdf(ctx, r, rp, G, rhs, m->mom + MomentLayout{rp}.stot(), qte, fx, false, f->work, f->small, sync, epoch));
     GINGR_TRY(check_launch(ctx));
     double *res = f->pin + (size_t)3 * m->M;
-    HIP_TRY(ctx, hipMemcpyAsync(res, f->small, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     // in-place exchanges (RCCL, host callback) would keep adding a stale tail up, so it goes back to zero.  NOT the device group's send
     // buffer: a slower peer may still be reading it (double buffering protects the next WRITE, two exchanges later, not a write now);
     // its stale partial is harmless -- the group's sum is out of place, and updates never read the tail.
     if (!f->partial_out) HIP_TRY(ctx, hipMemsetAsync(qte, 0, (size_t)rp * sizeof(double), ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    GINGR_TRY(pull_small(f, f->small, 2, res));
     if (res[1] != 0.0) return gingr_set_error(ctx, GINGR_ERR_NOT_SPD, "posterior_logpdf: posterior of the current state failed");
     if (!std::isfinite(res[0])) return gingr_set_error(ctx, GINGR_ERR_NONFINITE, "posterior_logpdf: non-finite result");
     *logpdf = res[0];
@@ -2581,7 +2608,7 @@ hipError_t ensure(DevBuf &b, size_t bytes) { return b.p && b.bytes >= bytes ? hi
 int run_distance_stats(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, const int32_t *tri_orig, int64_t T, const double *tboxes,
                        const int32_t *q_orig, int64_t q_limit, const int32_t *v_orig, const double *v_boxes,
                        const int32_t *boundary, double sdev, StatScratch &sc, double out4[4], double *pinned4 = nullptr,
-                       const double *tribox = nullptr) {
+                       const double *tribox = nullptr, gingr_fitter *spin_on = nullptr) {
     const int64_t K = q.n;
     HIP_TRY(ctx, ensure(sc.cp, (size_t)3 * K * sizeof(double)));
     HIP_TRY(ctx, ensure(sc.d2, (size_t)K * sizeof(double)));
@@ -2601,8 +2628,12 @@ int run_distance_stats(gingr_ctx *ctx, Cloud q, Cloud v, const int32_t *tri, con
     launch_distance_stats(ctx, K, sc.d2.as<double>(), q_orig, q_limit, boundary ? sc.nn.as<int32_t>() : nullptr, boundary, sdev,
                           sc.part.as<double>(), sc.out.as<double>());
     GINGR_TRY(check_launch(ctx));
-    HIP_TRY(ctx, hipMemcpyAsync(pinned4 ? pinned4 : out4, sc.out.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (spin_on && pinned4) {  // (the fitter's pinned buffer: pull_small)
+        GINGR_TRY(pull_small(spin_on, sc.out.as<double>(), 4, pinned4));
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(pinned4 ? pinned4 : out4, sc.out.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (pinned4) memcpy(out4, pinned4, 4 * sizeof(double));
     return GINGR_OK;
 }
@@ -2637,7 +2668,7 @@ int gingr_fitter_surface_distance_stats(gingr_fitter *f, int32_t direction, int6
         if (n_points > M) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "surface_distance_stats: more points than model vertices");
         const bool all = n_points == 0 || n_points == M;
         return run_distance_stats(ctx, fit, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, all ? nullptr : m->perm, n_points, f->tperm,
-                                  f->tboxes, boundary_aware ? f->tboundary : nullptr, sdev, sc, out, f->pin, f->ttribox);
+                                  f->tboxes, boundary_aware ? f->tboundary : nullptr, sdev, sc, out, f->pin, f->ttribox, f);
     }
     // `points` (null: every target vertex) against the surface of the current fit
     launch_tri_tile_bbox(ctx, fit, f->mtri, f->Tm, f->mtboxes, f->mtribox);
@@ -2645,7 +2676,7 @@ int gingr_fitter_surface_distance_stats(gingr_fitter *f, int32_t direction, int6
     const int32_t *bnd = boundary_aware ? f->mboundary : nullptr;
     if (!points)
         return run_distance_stats(ctx, tgt, fit, f->mtri, f->mtri_orig, f->Tm, f->mtboxes, nullptr, 0, m->perm, f->fboxes, bnd, sdev, sc,
-                                  out, f->pin, f->mtribox);
+                                  out, f->pin, f->mtribox, f);
     if (n_points < 1) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "surface_distance_stats: empty point list");
     std::vector<int32_t> order;
     morton_order(points, n_points, order);
