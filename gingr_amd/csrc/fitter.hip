@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <thread>
 #include <chrono>
 #include <cstdlib>
 #include <cmath>
@@ -1063,7 +1064,10 @@ static int pull_small(gingr_fitter *f, const double *src, int n, double *dst) {
             seen = true;
             break;
         }
-        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() > deadline) break;
+        if ((spins & 1023u) == 1023u) {
+            if (std::chrono::steady_clock::now() > deadline) break;
+            if (spins > 65536u) std::this_thread::yield();  // (a long wait: leave the core to whoever else needs it)
+        }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     if (!seen) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1094,7 +1098,10 @@ int gingr_fitter_get_state(gingr_fitter *f, double *alpha, gingr_state_scalars *
                 seen = true;
                 break;
             }
-            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() > deadline) break;
+            if ((spins & 1023u) == 1023u) {
+                if (std::chrono::steady_clock::now() > deadline) break;
+                if (spins > 65536u) std::this_thread::yield();  // (a long wait: leave the core to whoever else needs it)
+            }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         if (!seen) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (a launch that never finished: the error is reported here)
@@ -2904,7 +2911,10 @@ int gingr_fitter_mh_step(gingr_fitter *f, const gingr_mh_request *q, double *alp
                 seen = true;
                 break;
             }
-            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() > deadline) break;
+            if ((spins & 1023u) == 1023u) {
+                if (std::chrono::steady_clock::now() > deadline) break;
+                if (spins > 65536u) std::this_thread::yield();  // (a long wait: leave the core to whoever else needs it)
+            }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
