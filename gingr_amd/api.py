@@ -736,6 +736,7 @@ class GingrAlgorithm:
         self._device_state = None         # the python state currently mirrored on the device (strong reference, compared with `is`)
         self._mh = None                   # fused Metropolis-Hastings steps: {"sdev", "points"} of the likelihood evaluated with them
         self._mh_last = None              # what the last fused step measured: {"from", "to", "stats", "fw", "bw"}
+        self._sel = {}                    # selections already made on the current fitter (options, direction, surface method): set again only when they change
 
     # -- native plumbing ------------------------------------------------------------------
     def _bind(self, general: GeneralRegistrationState, use_landmarks: bool):
@@ -746,6 +747,7 @@ class GingrAlgorithm:
             _check(self.ctx.handle, self._lib.gingr_fitter_create(self.ctx.handle, self._dev_model.handle, ctypes.byref(h)),
                    "gingr_fitter_create")
             self._fitter = h
+            self._sel = {}
             self._bound_model = general.model
             self._bound_target = None
             self._bound_lm = None
@@ -756,6 +758,7 @@ class GingrAlgorithm:
             self._bound_target = general.target
             self._device_state = None
             self._bound_mesh = None
+            self._sel = {}
         mcells = getattr(general.model, "cells", None)
         if mcells is not None and general.targetCells is not None and not (
                 self._bound_mesh is not None and self._bound_mesh[0] is mcells and self._bound_mesh[1] is general.targetCells):
@@ -764,6 +767,7 @@ class GingrAlgorithm:
             _check(self.ctx.handle, self._lib.gingr_fitter_set_meshes(self._fitter, mt.shape[0], iptr(mt), tt.shape[0], iptr(tt)),
                    "gingr_fitter_set_meshes")
             self._bound_mesh = (mcells, general.targetCells)
+            self._sel = {}                # (new meshes: the library starts from the forward direction again)
         lm = general.landmarkCorrespondences if use_landmarks else None
         if not (self._bound_lm is not None and self._bound_lm[0] is lm and self._bound_lm[1] == use_landmarks):
             if lm is not None and len(lm.pids) > 0:
@@ -775,8 +779,10 @@ class GingrAlgorithm:
                 _check(self.ctx.handle, self._lib.gingr_fitter_set_landmarks(self._fitter, 0, None, None, None),
                        "gingr_fitter_set_landmarks")
             self._bound_lm = (lm, use_landmarks)
-        _check(self.ctx.handle, self._lib.gingr_fitter_set_options(self._fitter, int(general.globalTransformation),
-                                                                   float(general.stepLength)), "gingr_fitter_set_options")
+        opts = (int(general.globalTransformation), float(general.stepLength))
+        if self._sel.get("options") != opts:        # (one native call less per Metropolis-Hastings step)
+            _check(self.ctx.handle, self._lib.gingr_fitter_set_options(self._fitter, opts[0], opts[1]), "gingr_fitter_set_options")
+            self._sel["options"] = opts
 
     def _release(self):
         if self._fitter:
@@ -788,6 +794,7 @@ class GingrAlgorithm:
             self._dev_model = None
         self._bound_model = self._bound_target = self._bound_lm = self._bound_mesh = None
         self._device_state = None
+        self._sel = {}
 
     def close(self):
         self._release()
@@ -1191,12 +1198,17 @@ class IcpRegistration(GingrAlgorithm):
         return config.correspondenceMethod in ("TriangularClosestPoint", "AlongNormalClosestPoint")
 
     def _select_surface_method(self, config: IcpConfiguration):
-        _check(self.ctx.handle, self._lib.gingr_fitter_set_surface_method(
-            self._fitter, 1 if config.correspondenceMethod == "AlongNormalClosestPoint" else 0), "gingr_fitter_set_surface_method")
+        method = 1 if config.correspondenceMethod == "AlongNormalClosestPoint" else 0
+        if self._sel.get("method") != method:
+            _check(self.ctx.handle, self._lib.gingr_fitter_set_surface_method(self._fitter, method), "gingr_fitter_set_surface_method")
+            self._sel["method"] = method
 
     def _select_direction(self, config: IcpConfiguration):
-        _check(self.ctx.handle, self._lib.gingr_fitter_set_correspondence_direction(
-            self._fitter, 1 if config.reverseCorrespondenceDirection else 0), "gingr_fitter_set_correspondence_direction")
+        rev = 1 if config.reverseCorrespondenceDirection else 0
+        if self._sel.get("direction") != rev:
+            _check(self.ctx.handle, self._lib.gingr_fitter_set_correspondence_direction(self._fitter, rev),
+                   "gingr_fitter_set_correspondence_direction")
+            self._sel["direction"] = rev
 
     def _phase0(self, state: "IcpRegistrationState"):
         g, c = state.general, state.config
