@@ -339,6 +339,8 @@ void launch_surface_prereject(gingr_ctx *ctx, int64_t M, const int32_t *nn_verte
 // nearest intersection (!= the vertex) of the line through every fit vertex along dirs with the mesh; cp = the vertex, found = 0 if none
 void launch_line_nearest(gingr_ctx *ctx, Cloud fit, const double *dirs_soa, Cloud v, const int32_t *tri, const int32_t *tri_orig,
                          int64_t T, double *boxes, double *cp_soa, int32_t *found);
+// the same over the triangle grid of the mesh (static meshes: the target of the forward direction)
+void launch_line_nearest_grid(gingr_ctx *ctx, Cloud fit, const double *dirs_soa, const TriGrid &g, double *cp_soa, int32_t *found);
 void launch_surface_weight(gingr_ctx *ctx, int64_t M, const int32_t *pre, const int32_t *hit, const double *sigma2_dev, double *w01,
                            double *weight_in);
 

@@ -1502,7 +1502,9 @@ int run_phase(gingr_fitter *f, bool icp, const gingr_cpd_params *cp, const gingr
                 launch_tri_tile_bbox(ctx, meshc, f->mtri, f->Tm, f->mtboxes, f->mtribox, f->mcn);  // boxes + cell normals of the template
                 launch_vertex_normals(ctx, f->madj_ptr, f->madj_tri, f->mcn, f->Tm, M, f->mvn);
                 const bool along = f->surface_method == 1;  // ClosestPointAlongNormalTriangleMesh3D (:102-131)
-                if (along)
+                if (along && ctx->tri_grid && (ctx->tri_grid == 2 || f->Tt >= kTriGridMinTriangles) && ctx->cull && f->ttgrid.ready)
+                    launch_line_nearest_grid(ctx, fit, f->mvn, f->ttgrid, f->surf_cp, f->surf_hit);
+                else if (along)
                     launch_line_nearest(ctx, fit, f->mvn, tgt, f->ttri, f->ttri_orig, f->Tt, f->ttboxes, f->surf_cp, f->surf_hit);
                 else if (ctx->tri_grid && (ctx->tri_grid == 2 || f->Tt >= kTriGridMinTriangles) && ctx->cull && f->ttgrid.ready &&
                          f->surf_tri_warm && M <= f->ttgrid.max_queries) {

@@ -15,6 +15,9 @@ from oracle import gingr_oracle as go
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 ctx = ga.Context(0)
+ctx_grid = ga.Context(0)
+from gingr_amd import _native as _nat  # noqa: E402
+ctx_grid.set_option(_nat.OPT_TRI_GRID, 2)
 
 
 def grid(n, m, size, amp, closed):
@@ -73,14 +76,17 @@ for case in range(n_cases):
     if not ok:
         sys.exit(1)
     # the along-normal flavour on the same pair (ClosestPointRegistrator.scala:102-131): nearest intersection of the normal line
-    algo = ga.IcpRegistration(ctx)
-    state = algo.createInitialState(model, v2, ga.IcpConfiguration(maxIterations=5, initialSigma=2.0, endSigma=1.0, correspondenceMethod="AlongNormalClosestPoint"), targetCells=t2)
-    cp, w = algo.surfaceCorrespondence(state)
-    ocp, ow, _ = go.along_normal_correspondence(np.asarray(state.general.fit), t1, v2, t2)
-    ea, bad_w = float(np.abs(cp - ocp).max() / size), int((w != ow).sum())
-    algo.close()
-    worst_along = max(worst_along, ea)
-    if not (ea < 1e-9 and bad_w == 0):
-        print(f"case {case:3d} along the normal: cp err {ea:.1e} weights differing {bad_w} MISMATCH", flush=True)
-        sys.exit(1)
+    ocp = None
+    for c_along in (ctx, ctx_grid):   # the tile scan (meshes below the grid's size threshold) and the walk over the triangle grid
+        algo = ga.IcpRegistration(c_along)
+        state = algo.createInitialState(model, v2, ga.IcpConfiguration(maxIterations=5, initialSigma=2.0, endSigma=1.0, correspondenceMethod="AlongNormalClosestPoint"), targetCells=t2)
+        cp, w = algo.surfaceCorrespondence(state)
+        if ocp is None:
+            ocp, ow, _ = go.along_normal_correspondence(np.asarray(state.general.fit), t1, v2, t2)
+        ea, bad_w = float(np.abs(cp - ocp).max() / size), int((w != ow).sum())
+        algo.close()
+        worst_along = max(worst_along, ea)
+        if not (ea < 1e-9 and bad_w == 0):
+            print(f"case {case:3d} along the normal (grid walk: {c_along is ctx_grid}): cp err {ea:.1e} weights differing {bad_w} MISMATCH", flush=True)
+            sys.exit(1)
 print("worst closest-point error / size:", worst, " along the normal:", worst_along)

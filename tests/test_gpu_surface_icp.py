@@ -221,17 +221,24 @@ def test_along_normal_search_orders_and_culls_exactly(ctx, case):
         target, tcells = v * 80.0 * bump[:, None], f
         ref, cells = (v * 35.0 if case == "inside" else v * 60.0 + np.array([30.0, -12.0, 8.0])), f
         rank = 12
+    from gingr_amd import _native as nat
     mo = model_over(ref, cells, rank)
     model = ga.PointDistributionModel(mo.ref, mo.mean, mo.U, mo.lam, cells=cells)
-    algo = ga.IcpRegistration(ctx)
-    cfg = ga.IcpConfiguration(maxIterations=30, initialSigma=20.0, endSigma=1.0, correspondenceMethod="AlongNormalClosestPoint")
-    state = algo.createInitialState(model, target, cfg, targetCells=tcells)
-    cp, w = algo.surfaceCorrespondence(state)
-    ocp, ow, _ = go.along_normal_correspondence(np.asarray(state.general.fit), cells, target, tcells)
-    assert np.array_equal(w, ow), (case, int((w != ow).sum()))
-    assert np.abs(cp - ocp).max() < 1e-9 * max(1.0, np.abs(target).max()), case
-    assert w.sum() > 0, case
-    algo.close()
+    ocp = ow = None
+    for tri_grid in (1, 2):   # 1: these meshes are below the grid's size threshold -> the tile scan; 2: the walk over the triangle grid
+        c = ga.Context(0)
+        c.set_option(nat.OPT_TRI_GRID, tri_grid)
+        algo = ga.IcpRegistration(c)
+        cfg = ga.IcpConfiguration(maxIterations=30, initialSigma=20.0, endSigma=1.0, correspondenceMethod="AlongNormalClosestPoint")
+        state = algo.createInitialState(model, target, cfg, targetCells=tcells)
+        cp, w = algo.surfaceCorrespondence(state)
+        if ocp is None:
+            ocp, ow, _ = go.along_normal_correspondence(np.asarray(state.general.fit), cells, target, tcells)
+        assert np.array_equal(w, ow), (case, tri_grid, int((w != ow).sum()))
+        assert np.abs(cp - ocp).max() < 1e-9 * max(1.0, np.abs(target).max()), (case, tri_grid)
+        assert w.sum() > 0, case
+        algo.close()
+        c.close()
 
 
 @pytest.mark.parametrize("method", ["TriangularClosestPoint", "AlongNormalClosestPoint", "PointcloudClosestPoint"])
