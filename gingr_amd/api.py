@@ -715,6 +715,16 @@ class IcpRegistrationState:
         return dataclasses.replace(self, general=update)
 
 
+def _with_fields(obj, **changes):
+    """dataclasses.replace for the plain frozen dataclasses above (no __post_init__, no slots), without its per-field machinery: 1 us
+    instead of 7 for a GeneralRegistrationState -- the fused Metropolis-Hastings step builds two objects per step."""
+    new = object.__new__(type(obj))
+    d = new.__dict__
+    d.update(obj.__dict__)
+    d.update(changes)
+    return new
+
+
 # ----------------------------------------------------------------------------- the algorithm
 class GingrAlgorithm:
     """HIP-backed GingrAlgorithm: `update` is ONE native call sequence per iteration
@@ -736,6 +746,8 @@ class GingrAlgorithm:
         self._device_state = None         # the python state currently mirrored on the device (strong reference, compared with `is`)
         self._mh = None                   # fused Metropolis-Hastings steps: {"sdev", "points"} of the likelihood evaluated with them
         self._mh_last = None              # what the last fused step measured: {"from", "to", "stats", "fw", "bw"}
+        self._mh_plan_memo = None         # (config object, what _mh_flavour said about it + ctypes pointers)
+        self._mh_req = None               # the request / result structs of the fused step, reused (the call is synchronous)
         self._sel = {}                    # selections already made on the current fitter (options, direction, surface method): set again only when they change
 
     # -- native plumbing ------------------------------------------------------------------
@@ -886,10 +898,25 @@ class GingrAlgorithm:
     def _mh_prepare(self, state):
         pass
 
+    def _mh_plan(self, state):
+        """_mh_flavour(state) with its ctypes pointers, remembered for the configuration OBJECT (frozen dataclasses shared by all the
+        states of a chain): one Metropolis-Hastings step asks twice."""
+        c = state.config
+        memo = self._mh_plan_memo
+        if memo is not None and memo[0] is c:
+            return memo[1]
+        fl = self._mh_flavour(state)
+        plan = None
+        if fl is not None:
+            flavour, cp, ip = fl
+            plan = (flavour, cp, ip, ctypes.pointer(cp) if cp is not None else None, ctypes.pointer(ip) if ip is not None else None)
+        self._mh_plan_memo = (c, plan)
+        return plan
+
     def _mh_usable(self, state) -> bool:
         g = state.general
         return (self._mh is not None and g.stepLength == 1.0 and getattr(g.model, "cells", None) is not None
-                and g.targetCells is not None and self._mh_flavour(state) is not None)
+                and g.targetCells is not None and self._mh_plan(state) is not None)
 
     def _adopt_state(self, old, new):
         """`new` is `old` with host-side fields rewritten (generatedBy): it stands for the same device state and measurements"""
@@ -909,11 +936,14 @@ class GingrAlgorithm:
                 self._push_state(g)
             self._device_state = current
         self._mh_prepare(current)
-        flavour, cp, ip = self._mh_flavour(current)
-        req = nat.MhRequest()
+        flavour, _, _, cpp, ipp = self._mh_plan(current)
+        if self._mh_req is None:
+            self._mh_req = (nat.MhRequest(), nat.MhResult())
+        req, res = self._mh_req
         req.flavour, req.kind = flavour, kind
-        req.cpd = ctypes.pointer(cp) if cp is not None else None
-        req.icp = ctypes.pointer(ip) if ip is not None else None
+        req.cpd, req.icp = cpp, ipp
+        req.z = req.alpha = None
+        req.scalars = None
         req.eval_sdev, req.eval_points = self._mh["sdev"], self._mh["points"]
         # q(.|current) projects current.fit (step length 1): a number of `current` alone, known when a fused step produced or started
         # from this very state
@@ -932,7 +962,7 @@ class GingrAlgorithm:
             sc.scale, sc.sigma2, sc.iteration, sc.status = mp.scale, g.sigma2, g.iteration + 1, g.status
             req.alpha, req.scalars = dptr(keep[0]), ctypes.pointer(sc)
         r, M = g.model.rank, g.model.numberOfPoints
-        alpha, fit, res = np.empty(r), np.empty((M, 3)), nat.MhResult()
+        alpha, fit = np.empty(r), np.empty((M, 3))
         try:
             _check(self.ctx.handle, self._lib.gingr_fitter_mh_step(self._fitter, ctypes.byref(req), dptr(alpha), dptr(fit), ctypes.byref(res)),
                    "gingr_fitter_mh_step")
@@ -943,11 +973,12 @@ class GingrAlgorithm:
             self._mh_last = None
             raise
         s = res.scalars
-        mp = ModelFittingParameters(scale=s.scale, translation=tuple(s.translation), rotation=EulerAngles(*list(s.euler)),
-                                    center=tuple(s.center), shape=alpha)
-        new_general = dataclasses.replace(g, modelParameters=mp, fit=fit, sigma2=s.sigma2, iteration=s.iteration, status=s.status,
-                                          generatedBy=generatedBy)
-        out = current.updateGeneral(new_general)
+        e, t, c0 = s.euler, s.translation, s.center
+        mp = ModelFittingParameters(scale=s.scale, translation=(t[0], t[1], t[2]), rotation=EulerAngles(e[0], e[1], e[2]),
+                                    center=(c0[0], c0[1], c0[2]), shape=alpha)
+        new_general = _with_fields(g, modelParameters=mp, fit=fit, sigma2=s.sigma2, iteration=s.iteration, status=s.status,
+                                   generatedBy=generatedBy)
+        out = _with_fields(current, general=new_general)
         self._device_state = out
         self._mh_last = {"from": current, "to": out, "sdev": self._mh["sdev"], "points": self._mh["points"],
                          "stats": (float(res.dist_sum), float(res.dist_max), int(res.count), float(res.log_value)),

@@ -207,23 +207,41 @@ def _same_parameters(a: ModelFittingParameters, b: ModelFittingParameters) -> bo
             and tuple(a.center) == tuple(b.center) and np.array_equal(np.asarray(a.shape), np.asarray(b.shape)))
 
 
+_last_diff = [None, None, frozenset()]
+_skip_sets: dict = {}
+
+
+def _differing_fields(a: ModelFittingParameters, b: ModelFittingParameters) -> frozenset:
+    """The fields in which two parameter sets differ, remembered for the pair of OBJECTS last asked about (either order): one
+    Metropolis-Hastings step puts the same (from, to) pair to nine random-walk components, twice."""
+    c = _last_diff
+    if (c[0] is a and c[1] is b) or (c[0] is b and c[1] is a):
+        return c[2]
+    d = []
+    if a.scale != b.scale:
+        d.append("scale")
+    if a.translation is not b.translation and tuple(a.translation) != tuple(b.translation):
+        d.append("translation")
+    if a.rotation is not b.rotation and a.rotation != b.rotation:
+        d.append("rotation")
+    if a.center is not b.center and tuple(a.center) != tuple(b.center):
+        d.append("center")
+    if a.shape is not b.shape and not _shapes_equal(a.shape, b.shape):
+        d.append("shape")
+    c[0], c[1], c[2] = a, b, frozenset(d)
+    return c[2]
+
+
 def _same_except(a: ModelFittingParameters, b: ModelFittingParameters, skip: Tuple[str, ...]) -> bool:
     """a == b in every field but `skip` -- what `to.copy(field = from.field) == from` of the reference's proposals tests, without
     building the copy (a Metropolis-Hastings step asks nine random-walk components twice; the shape vectors of two states that
     differ by a pose proposal are the same object)."""
     if a is b:
         return True
-    if "scale" not in skip and a.scale != b.scale:
-        return False
-    if "translation" not in skip and a.translation is not b.translation and tuple(a.translation) != tuple(b.translation):
-        return False
-    if "rotation" not in skip and a.rotation is not b.rotation and a.rotation != b.rotation:
-        return False
-    if "center" not in skip and a.center is not b.center and tuple(a.center) != tuple(b.center):
-        return False
-    if "shape" not in skip and a.shape is not b.shape and not _shapes_equal(a.shape, b.shape):
-        return False
-    return True
+    allowed = _skip_sets.get(skip)
+    if allowed is None:
+        allowed = _skip_sets[skip] = frozenset(skip)
+    return _differing_fields(a, b) <= allowed
 
 
 _last_shape_pair = [None, None, False]
