@@ -406,6 +406,8 @@ class GeneratorWrapperStochastic:
 
     def propose(self, current):
         new = self.algorithm.update(current, True, self.rnd.scalaRandom)
+        if new.general.generatedBy == self.generatedBy:   # (update names its states after the algorithm: the stock set-up's label)
+            return new
         out = new.updateGeneral(dataclasses.replace(new.general, generatedBy=self.generatedBy))
         self.algorithm._adopt_state(new, out)
         return out
@@ -420,6 +422,8 @@ class GeneratorWrapperDeterministic:
 
     def propose(self, current):
         new = self.algorithm.update(current, False)
+        if new.general.generatedBy == self.generatedBy:
+            return new
         out = new.updateGeneral(dataclasses.replace(new.general, generatedBy=self.generatedBy))
         self.algorithm._adopt_state(new, out)
         return out
