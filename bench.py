@@ -242,6 +242,44 @@ def _child_env():
     return {k: v for k, v in os.environ.items() if k not in drop and not k.startswith("TORCHELASTIC_")}
 
 
+_CHILD_DEADLINE = [None]
+
+
+def _run_child(cmd, env, cap_s: float):
+    """One child run behind the headline, bounded whatever it does: its own session (so that a time-out takes the launcher AND the
+    ranks it started down -- killing only the launcher would leave the ranks holding our pipes and this process waiting for their
+    end-of-file), output into temporary files instead of pipes, and one budget for all children of this run
+    (GINGR_BENCH_CHILD_BUDGET_S, default 420 s) so that a hung child can only delay the headline line by that much.  Returns
+    (return code, stdout, stderr); raises TimeoutError."""
+    import signal
+    import subprocess
+    import tempfile
+    import time
+    if _CHILD_DEADLINE[0] is None:
+        _CHILD_DEADLINE[0] = time.monotonic() + float(os.environ.get("GINGR_BENCH_CHILD_BUDGET_S", "420"))
+    left = min(cap_s, _CHILD_DEADLINE[0] - time.monotonic())
+    if left < 20.0:
+        raise TimeoutError("the child runs' time budget is spent")
+    with tempfile.TemporaryFile("w+") as so, tempfile.TemporaryFile("w+") as se:
+        p = subprocess.Popen(cmd, env=env, stdout=so, stderr=se, stdin=subprocess.DEVNULL, start_new_session=True)
+        try:
+            rc = p.wait(timeout=left)
+        except subprocess.TimeoutExpired:
+            for sig in (signal.SIGTERM, signal.SIGKILL):
+                try:
+                    os.killpg(p.pid, sig)
+                except ProcessLookupError:
+                    break
+                try:
+                    p.wait(timeout=10)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+            raise TimeoutError(f"child run exceeded {left:.0f} s and was stopped (process group {p.pid})")
+        so.seek(0), se.seek(0)
+        return rc, so.read(), se.read()
+
+
 def run_group_mode(args, world: int, shared_device: bool):
     """The same workload once more through the in-library device group (ONE process, one worker thread per GPU, peer-pointer
     all-reduce) so that one multi-GPU run carries RCCL and the group side by side: a CHILD process (this one has initialised the
@@ -254,8 +292,8 @@ def run_group_mode(args, world: int, shared_device: bool):
         cmd += ["--logical-shards", str(world)]   # the one-GPU test mode: the shards share device 0
     env = _child_env()
     try:
-        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-        line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+        _, stdout, _ = _run_child(cmd, env, 240.0)
+        line = [l for l in stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
         return {"ms_per_step": d["ms_per_step"], "value": d["value"], "valid": d["valid"], "n_gpus": d["n_gpus"],
                 "exchange": d.get("exchange"), "devices": (d.get("rccl_ranks") or {}).get("devices"),
@@ -277,14 +315,14 @@ def run_variants(args, world: int, shared_device: bool):
     out = {}
 
     def digest(cmd, what):
-        p = None
+        stderr = None
         try:
-            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-            d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+            _, stdout, stderr = _run_child(cmd, env, 180.0)
+            d = json.loads([l for l in stdout.splitlines() if l.startswith("{")][-1])
             return {"ms_per_step": d["ms_per_step"], "value": d["value"], "valid": d["valid"], "reason": d.get("reason"), "n_gpus": d["n_gpus"],
                     "exchange": d.get("exchange"), "how": what}
         except Exception as e:
-            return {"error": f"{type(e).__name__}: {e}"[:400], "stderr_tail": (p.stderr[-600:] if p is not None else None), "how": what}
+            return {"error": f"{type(e).__name__}: {e}"[:400], "stderr_tail": (stderr[-600:] if stderr is not None else None), "how": what}
     out["emulated_shard_no_exchange"] = digest([sys.executable, os.path.abspath(__file__), "--emulate-world", str(world)] + common,
                                                f"child `bench.py --emulate-world {world}` on GPU 0: rank 0's shard, the other ranks' partial sums missing "
                                                "(a per-rank cost figure, not a registration)")

@@ -53,3 +53,35 @@ def test_wide_gram_plan_as_documented():
                 seen += list(range(g0, g0 + max(0, min(T, pend - g0))))
         assert seen == list(range(total)), nt
         assert (nt, T, parts) != (16, 17, 1) or total == 136
+
+
+def test_a_hung_child_run_is_stopped_with_everything_it_started(monkeypatch, tmp_path):
+    """A child launcher whose own child keeps running (and keeps the output open) must not hold the headline line back: the whole
+    session is stopped at the time-out and the budget of all child runs together is one."""
+    import sys
+    import time
+    import pytest
+    b = _bench()
+    monkeypatch.setenv("GINGR_BENCH_CHILD_BUDGET_S", "24")
+    b._CHILD_DEADLINE[0] = None
+    rc, out, err = b._run_child([sys.executable, "-c", "import sys; print('{\"a\": 1}'); print('note', file=sys.stderr)"], dict(os.environ), 60.0)
+    assert rc == 0 and out.strip() == '{"a": 1}' and err.strip() == "note"
+    pidfile = tmp_path / "grandchild.pid"
+    hang = ("import subprocess, sys, time; p = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(600)']); "
+            f"open({str(pidfile)!r}, 'w').write(str(p.pid)); time.sleep(600)")
+    t0 = time.monotonic()
+    with pytest.raises(TimeoutError):
+        b._run_child([sys.executable, "-c", hang], dict(os.environ), 600.0)    # capped by what is left of the 24 s budget
+    assert time.monotonic() - t0 < 40
+    gpid = int(pidfile.read_text())
+    for _ in range(50):
+        try:
+            os.kill(gpid, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError("the hung child's own child survived the time-out")
+    with pytest.raises(TimeoutError):                                           # nothing left: refused at once
+        b._run_child([sys.executable, "-c", "print(1)"], dict(os.environ), 60.0)
+    b._CHILD_DEADLINE[0] = None
