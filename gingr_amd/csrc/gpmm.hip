@@ -447,16 +447,27 @@ __global__ __launch_bounds__(256) void unpack_basis_kernel(const double *__restr
     stage[(int64_t)k * 3 * M + 3 * (int64_t)(perm ? perm[s] : s) + d] = sd > 0.0 ? Q0[row * rp + k] / sd : 0.0;
 }
 
-// all-pairs extrema of |p_i - p_j|^2 (unfused), i != j: per-block partials
-__global__ __launch_bounds__(256) void dist_extrema_kernel(Cloud pts, double *__restrict__ pmax, double *__restrict__ pmin) {
-    __shared__ double tx[256], ty[256], tz[256];
-    __shared__ double sh[256];
+// all-pairs extrema of |p_i - p_j|^2 (unfused), i != j: per-workgroup partials.  The distance of a pair is the same number in both
+// orders (the coordinate differences are exact negations of each other, their squares equal), so only the tile pairs on and above the
+// diagonal are visited: workgroup (bi, c) takes the 256 points of tile bi against the column tiles bi + c ch ... bi + (c + 1) ch - 1;
+// workgroups past the last tile write the neutral pair (0, +inf).  A maximum and a minimum do not depend on the order of the scan: the
+// result is the one-row-per-thread scan's of rounds 1-5 bit for bit (that one ran on ceil(n / 256) workgroups -- 196 for 50k points,
+// fewer than the device has compute units -- and visited every pair twice: 2.5 ms at 50k).  The `j != i` test only exists in the
+// diagonal tile.
+constexpr int kExtTile = 256;
+__global__ __launch_bounds__(kExtTile) void dist_extrema_kernel(Cloud pts, int ch, double *__restrict__ pmax, double *__restrict__ pmin) {
+    __shared__ double tx[kExtTile], ty[kExtTile], tz[kExtTile];
+    __shared__ double sh[kExtTile];
     const int t = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * 256 + t;
+    const int64_t nt = (pts.n + kExtTile - 1) / kExtTile;
+    const int64_t bi = blockIdx.x;
+    const int64_t jt0 = bi + (int64_t)blockIdx.y * ch, jt1 = min(nt, jt0 + ch);  // workgroup-uniform
+    const int64_t i = bi * kExtTile + t;
     const bool ok = i < pts.n;
     const double x = ok ? pts.x[i] : 0.0, y = ok ? pts.y[i] : 0.0, z = ok ? pts.z[i] : 0.0;
     double mx = 0.0, mn = __builtin_huge_val();
-    for (int64_t jb = 0; jb < pts.n; jb += 256) {
+    for (int64_t jt = jt0; jt < jt1; ++jt) {
+        const int64_t jb = jt * kExtTile;
         __syncthreads();
         if (jb + t < pts.n) {
             tx[t] = pts.x[jb + t];
@@ -464,30 +475,43 @@ __global__ __launch_bounds__(256) void dist_extrema_kernel(Cloud pts, double *__
             tz[t] = pts.z[jb + t];
         }
         __syncthreads();
-        const int cnt = (int)min((int64_t)256, pts.n - jb);
-        if (ok)
+        const int cnt = (int)min((int64_t)kExtTile, pts.n - jb);
+        if (!ok) continue;
+        if (jt == bi) {  // the diagonal tile: every pair of it from both sides, the point itself left out of the minimum
+#pragma unroll 4
             for (int jj = 0; jj < cnt; ++jj) {
                 const double dx = x - tx[jj], dy = y - ty[jj], dz = z - tz[jj];
                 const double d2 = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
                 mx = fmax(mx, d2);
-                if (jb + jj != i) mn = fmin(mn, d2);
+                if (jj != t) mn = fmin(mn, d2);
             }
+        } else {
+#pragma unroll 4
+            for (int jj = 0; jj < cnt; ++jj) {
+                const double dx = x - tx[jj], dy = y - ty[jj], dz = z - tz[jj];
+                const double d2 = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+                mx = fmax(mx, d2);
+                mn = fmin(mn, d2);
+            }
+        }
     }
+    const int64_t slot = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    __syncthreads();
     sh[t] = mx;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
+    for (int off = kExtTile / 2; off > 0; off >>= 1) {
         if (t < off) sh[t] = fmax(sh[t], sh[t + off]);
         __syncthreads();
     }
-    if (t == 0) pmax[blockIdx.x] = sh[0];
+    if (t == 0) pmax[slot] = sh[0];
     __syncthreads();
     sh[t] = mn;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
+    for (int off = kExtTile / 2; off > 0; off >>= 1) {
         if (t < off) sh[t] = fmin(sh[t], sh[t + off]);
         __syncthreads();
     }
-    if (t == 0) pmin[blockIdx.x] = sh[0];
+    if (t == 0) pmin[slot] = sh[0];
 }
 
 int check(gingr_ctx *ctx) {
@@ -570,7 +594,13 @@ int gingr_pointset_distance_extrema(gingr_ctx *ctx, const double *xyz, int64_t n
     if (!ctx || !xyz || n < 1 || !max_distance || !min_distance)
         return ctx ? gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "distance_extrema: bad argument") : GINGR_ERR_BAD_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int nb = (int)ceil_div(n, 256);
+    // tiles of 256 points; a workgroup takes `ch` column tiles (eight, more for large clouds so that there are at most 64 chunks per tile
+    // row): about nt^2 / (2 ch) working workgroups -- 2 500 at 50k points
+    const int64_t nt = ceil_div(n, (int64_t)kExtTile);
+    const int ch = (int)std::max<int64_t>(8, ceil_div(nt, (int64_t)64));
+    const int gy = (int)ceil_div(nt, (int64_t)ch);
+    if (nt > 0x7fffffff / 64) return gingr_set_error(ctx, GINGR_ERR_BAD_ARGUMENT, "distance_extrema: %lld points are too many", (long long)n);
+    const int64_t nb = nt * gy;
     DevBuf aos, soa, pm;
     HIP_TRY(ctx, aos.alloc((size_t)3 * n * sizeof(double)));
     HIP_TRY(ctx, soa.alloc((size_t)3 * n * sizeof(double)));
@@ -578,14 +608,14 @@ int gingr_pointset_distance_extrema(gingr_ctx *ctx, const double *xyz, int64_t n
     HIP_TRY(ctx, hipMemcpyAsync(aos.p, xyz, (size_t)3 * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     launch_aos_to_soa(ctx, aos.as<double>(), n, soa.as<double>());
     const double *s = soa.as<double>();
-    hipLaunchKernelGGL(dist_extrema_kernel, dim3(nb), dim3(256), 0, ctx->stream, Cloud{s, s + n, s + 2 * n, n},
+    hipLaunchKernelGGL(dist_extrema_kernel, dim3((unsigned)nt, (unsigned)gy), dim3(kExtTile), 0, ctx->stream, Cloud{s, s + n, s + 2 * n, n}, ch,
                        pm.as<double>(), pm.as<double>() + nb);
     GINGR_TRY(check(ctx));
     std::vector<double> h((size_t)2 * nb);
     HIP_TRY(ctx, hipMemcpyAsync(h.data(), pm.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     double mx = 0.0, mn = HUGE_VAL;
-    for (int b = 0; b < nb; ++b) {
+    for (int64_t b = 0; b < nb; ++b) {
         mx = std::max(mx, h[(size_t)b]);
         mn = std::min(mn, h[(size_t)nb + b]);
     }

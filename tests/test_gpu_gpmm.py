@@ -48,6 +48,15 @@ def test_distance_extrema_bit_exact(ctx):
     P = cloud(300, 4)
     P[17] = P[200]                                  # coincident points: the minimum is 0
     assert ga.PointSetHelper(ctx, P).minimumPointDistance() == 0.0
+    # several column chunks per tile row (more than eight tiles), a last tile of one point, the extreme pairs in different tiles
+    for M, seed in [(2049, 5), (4500, 6)]:
+        P = cloud(M, seed)
+        P[3] = P.mean(axis=0) + 40.0 * (P.max(axis=0) - P.min(axis=0))         # the farthest pair: tile 0 against the last tile
+        P[M - 1] = P.mean(axis=0) - 40.0 * (P.max(axis=0) - P.min(axis=0))
+        P[M - 700] = P[11] + 1e-9                                                # the nearest pair: far below the diagonal tiles' reach
+        h = ga.PointSetHelper(ctx, P)
+        mx, mn = go.pointset_distance_extrema(P)
+        assert h.maximumPointDistance() == mx and h.minimumPointDistance() == mn
 
 
 @pytest.mark.parametrize("sigma,scaling,tol", [(60.0, 30.0, 0.01), (40.0, 5.0, 0.05), (120.0, 100.0, 0.001)])
