@@ -284,24 +284,53 @@ __global__ __launch_bounds__(kPcBlock) void pc_step_kernel(Cloud pts, KSpec3 spe
     }
 }
 
-// G[a][b] = sum_c L[a][c] L[b][c]   (a <= b computed, mirrored); grid (k, k)
+// G[a][b] = sum_c L[a][c] L[b][c]   (blocks on and above the diagonal computed, mirrored); grid (ceil(k / 4), ceil(k / 4)).
+// A workgroup forms a 4 x 4 block of entries: per entry the arithmetic of the one-entry-per-workgroup kernel of rounds 1-5 (thread t
+// adds the columns t, t + 256, ... by fma in ascending order, then the tree over the threads) -- the same bits -- with eight loads per
+// sixteen multiply-adds instead of thirty-two (that kernel read 12 GB through the caches for the 171 columns of a rank-512 model at 50k points).
+constexpr int kPcGramTile = 4;
 __global__ __launch_bounds__(kPcBlock) void pc_gram_kernel(const double *__restrict__ L, int64_t M, int32_t k,
                                                            double *__restrict__ G) {
-    __shared__ double shs[kPcBlock];
-    const int a = blockIdx.x, b = blockIdx.y;
-    if (a > b) return;
-    const double *la = L + (int64_t)a * M, *lb = L + (int64_t)b * M;
-    double s = 0.0;
-    for (int64_t c = threadIdx.x; c < M; c += kPcBlock) s = __builtin_fma(la[c], lb[c], s);
-    shs[threadIdx.x] = s;
+    __shared__ double shs[kPcGramTile * kPcGramTile][kPcBlock];
+    const int a0 = blockIdx.x * kPcGramTile, b0 = blockIdx.y * kPcGramTile;
+    if (a0 > b0) return;
+    const double *la[kPcGramTile], *lb[kPcGramTile];
+#pragma unroll
+    for (int u = 0; u < kPcGramTile; ++u) {  // (columns past k: a clamped, valid column; the entries are not stored)
+        la[u] = L + (int64_t)min(a0 + u, k - 1) * M;
+        lb[u] = L + (int64_t)min(b0 + u, k - 1) * M;
+    }
+    double s[kPcGramTile][kPcGramTile];
+#pragma unroll
+    for (int u = 0; u < kPcGramTile; ++u)
+#pragma unroll
+        for (int v = 0; v < kPcGramTile; ++v) s[u][v] = 0.0;
+    for (int64_t c = threadIdx.x; c < M; c += kPcBlock) {
+        double va[kPcGramTile], vb[kPcGramTile];
+#pragma unroll
+        for (int u = 0; u < kPcGramTile; ++u) va[u] = la[u][c], vb[u] = lb[u][c];
+#pragma unroll
+        for (int u = 0; u < kPcGramTile; ++u)
+#pragma unroll
+            for (int v = 0; v < kPcGramTile; ++v) s[u][v] = __builtin_fma(va[u], vb[v], s[u][v]);
+    }
+#pragma unroll
+    for (int u = 0; u < kPcGramTile; ++u)
+#pragma unroll
+        for (int v = 0; v < kPcGramTile; ++v) shs[u * kPcGramTile + v][threadIdx.x] = s[u][v];
     __syncthreads();
     for (int off = kPcBlock / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) shs[threadIdx.x] += shs[threadIdx.x + off];
+        if ((int)threadIdx.x < off)
+#pragma unroll
+            for (int e = 0; e < kPcGramTile * kPcGramTile; ++e) shs[e][threadIdx.x] += shs[e][threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        G[(int64_t)a * k + b] = shs[0];
-        G[(int64_t)b * k + a] = shs[0];
+    if (threadIdx.x < kPcGramTile * kPcGramTile) {
+        const int a = a0 + (int)threadIdx.x / kPcGramTile, b = b0 + (int)threadIdx.x % kPcGramTile;
+        if (a < k && b < k && a <= b) {  // (below the diagonal of a diagonal block: the mirrored entry's own sum, the same number)
+            G[(int64_t)a * k + b] = shs[threadIdx.x][0];
+            G[(int64_t)b * k + a] = shs[threadIdx.x][0];
+        }
     }
 }
 
@@ -404,14 +433,27 @@ __global__ __launch_bounds__(kJacThreads) void jacobi_eig_kernel(const double *_
 }
 
 // B[i][c] = sum_r L[r][c] V[r][i]   (c over ALL points, i < n): column i of  U sqrt(lambda) = L V
+constexpr int kLvCols = 8;  // columns of B per thread: L is read n / 8 times instead of n times (the same fma sequence per entry)
 __global__ __launch_bounds__(256) void lv_kernel(const double *__restrict__ L, int64_t M, int32_t n,
                                                  const double *__restrict__ V, double *__restrict__ B) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int i = blockIdx.y;
+    const int i0 = blockIdx.y * kLvCols;
     if (c >= M) return;
-    double acc = 0.0;
-    for (int r = 0; r < n; ++r) acc = __builtin_fma(L[(int64_t)r * M + c], V[r * n + i], acc);
-    B[(int64_t)i * M + c] = acc;
+    int col[kLvCols];  // workgroup-uniform; columns past n repeat the last one and are not stored
+#pragma unroll
+    for (int u = 0; u < kLvCols; ++u) col[u] = min(i0 + u, n - 1);
+    double acc[kLvCols];
+#pragma unroll
+    for (int u = 0; u < kLvCols; ++u) acc[u] = 0.0;
+    for (int r = 0; r < n; ++r) {
+        const double l = L[(int64_t)r * M + c];
+        const double *v = V + (int64_t)r * n;
+#pragma unroll
+        for (int u = 0; u < kLvCols; ++u) acc[u] = __builtin_fma(l, v[col[u]], acc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kLvCols; ++u)
+        if (i0 + u < n) B[(int64_t)(i0 + u) * M + c] = acc[u];
 }
 
 // Q0[(3s+d)*rp + q] = B_set(q)[idx(q)][row_begin + perm[s]] when coordinate(q) == d, else 0
@@ -815,14 +857,14 @@ int gingr_gpmm_build_diagonal(gingr_ctx *ctx, int64_t M_total, const double *ref
         HIP_TRY(ctx, ev.alloc((size_t)(n + 1) * sizeof(double)));
         HIP_TRY(ctx, V.alloc((size_t)(n * n + 1) * sizeof(double)));
         HIP_TRY(ctx, B.alloc((size_t)n * 3 * M * sizeof(double)));
-        hipLaunchKernelGGL(pc_gram_kernel, dim3(n, n), dim3(kPcBlock), 0, ctx->stream, fg.Lb.as<double>(), 3 * M, n, G.as<double>());
+        hipLaunchKernelGGL(pc_gram_kernel, dim3((unsigned)ceil_div(n, kPcGramTile), (unsigned)ceil_div(n, kPcGramTile)), dim3(kPcBlock), 0, ctx->stream, fg.Lb.as<double>(), 3 * M, n, G.as<double>());
         {
             const double *Gs[1] = {G.as<double>()};
             double *es[1] = {ev.as<double>()}, *vs[1] = {V.as<double>()};
             const int32_t ns[1] = {n};
             GINGR_TRY(sym_eig(ctx, 1, Gs, ns, ns, es, vs));
         }
-        hipLaunchKernelGGL(lv_kernel, dim3((unsigned)ceil_div(3 * M, 256), n), dim3(256), 0, ctx->stream, fg.Lb.as<double>(), 3 * M, n,
+        hipLaunchKernelGGL(lv_kernel, dim3((unsigned)ceil_div(3 * M, 256), (unsigned)ceil_div(n, kLvCols)), dim3(256), 0, ctx->stream, fg.Lb.as<double>(), 3 * M, n,
                            V.as<double>(), B.as<double>());
         GINGR_TRY(check(ctx));
         std::vector<double> hev((size_t)n);
@@ -879,7 +921,7 @@ int gingr_gpmm_build_diagonal(gingr_ctx *ctx, int64_t M_total, const double *ref
     for (int b = 0; b < nblocks; ++b) kkmax = std::max(kkmax, block_n[b]);
     int32_t set_kk[3] = {kkmax, 0, 0};
     HIP_TRY(ctx, G[0].alloc((size_t)kkmax * kkmax * sizeof(double)));
-    hipLaunchKernelGGL(pc_gram_kernel, dim3(kkmax, kkmax), dim3(kPcBlock), 0, ctx->stream, fac[0].Lb.as<double>(), M, kkmax,
+    hipLaunchKernelGGL(pc_gram_kernel, dim3((unsigned)ceil_div(kkmax, kPcGramTile), (unsigned)ceil_div(kkmax, kPcGramTile)), dim3(kPcBlock), 0, ctx->stream, fac[0].Lb.as<double>(), M, kkmax,
                        G[0].as<double>());
     std::vector<double> hev[3];
     {
@@ -898,7 +940,7 @@ int gingr_gpmm_build_diagonal(gingr_ctx *ctx, int64_t M_total, const double *ref
         GINGR_TRY(sym_eig(ctx, nblocks, Gs, lds, ns, es, vs));  // the blocks side by side, one workgroup each
     }
     for (int b = 0; b < nblocks; ++b)
-        hipLaunchKernelGGL(lv_kernel, dim3((unsigned)ceil_div(M, 256), block_n[b]), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(lv_kernel, dim3((unsigned)ceil_div(M, 256), (unsigned)ceil_div(block_n[b], kLvCols)), dim3(256), 0, ctx->stream,
                            fac[block_set[b]].Lb.as<double>(), M, block_n[b], V[b].as<double>(), B[b].as<double>());
     GINGR_TRY(check(ctx));
     for (int b = 0; b < nblocks; ++b)
