@@ -432,6 +432,167 @@ __global__ __launch_bounds__(kJacThreads) void jacobi_eig_kernel(const double *_
     }
 }
 
+// The same decomposition on several workgroups (n > 128: beyond the register kernel of eig.hip the one-workgroup form above moves
+// 3 n^2 entries per round through ONE compute unit's path to L2 -- 150 ms at n = 301).  Every workgroup works out all rotations of a
+// round itself (the same numbers from the same entries), then forms its share of A' = J^T (A J) entry by entry from the round's
+// source buffer into the other one (an entry needs the four entries at (i | partner of i, j | partner of j); first the column
+// combination, then the row combination: the one-workgroup kernel's arithmetic in its order, so the same bits) and rotates its share
+// of V in place (row-local).  One barrier over the grid per round instead of three workgroup barriers; the grid is far smaller than
+// the device (64 workgroups of 256 threads) so that all of it is resident.  A barrier that is not met within two seconds (a device
+// shared with something that never yields) raises the flag in sync[1]: the call reports a failure instead of hanging.
+constexpr int kJacGridThreads = 256;
+constexpr int kJacGridWgs = 64;
+
+// One wave's thread does the device-scope part for its workgroup (as a cooperative-groups grid barrier does): the workgroup barrier
+// in front has every wave's stores completed, the release fence then writes the compute unit's and the XCD's dirty lines back ONCE,
+// and the acquire fence behind the wait drops the stale lines for the whole compute unit -- with the two fences in every thread the
+// cache maintenance ran eight times per workgroup and round (22 us a round at n = 301 against 12).
+__device__ __forceinline__ bool jac_grid_barrier(unsigned *sync, unsigned target, int *s_ok) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = wall_clock64();  // (100 MHz)
+        int good = 1;
+        unsigned spins = 0;
+        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 255u) == 0u) {
+                if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    good = 0;
+                    break;
+                }
+                if (wall_clock64() - t0 > 200000000LL) {
+                    __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    good = 0;
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *s_ok = good;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+__global__ __launch_bounds__(kJacGridThreads) void jacobi_eig_grid_kernel(const double *__restrict__ G, int32_t ldg, int32_t n, double *A0,
+                                                                          double *A1, double *V, double *__restrict__ evals,
+                                                                          double *__restrict__ Vs, int32_t *__restrict__ sweeps_out,
+                                                                          unsigned *sync) {
+    __shared__ double cs[kJacMaxN / 2][2];
+    __shared__ int32_t pq[kJacMaxN / 2][2];
+    __shared__ int16_t pair_of[kJacMaxN];  // index -> its pair of the round, -1: none (the bye, or a pair that does not rotate)
+    __shared__ int32_t nrot;
+    __shared__ int s_ok;
+    const int t = threadIdx.x;
+    const unsigned nwg = gridDim.x;
+    const unsigned gtid = blockIdx.x * kJacGridThreads + t, gthreads = nwg * kJacGridThreads;  // (n <= 512: 32-bit index arithmetic)
+    const unsigned nn = (unsigned)n * (unsigned)n, un = (unsigned)n;
+    unsigned epoch = 0;
+    for (unsigned idx = gtid; idx < nn; idx += gthreads) {
+        const int i = (int)(idx / un), j = (int)(idx - (unsigned)i * un);
+        A0[idx] = G[(int64_t)i * ldg + j];
+        V[idx] = i == j ? 1.0 : 0.0;
+    }
+    if (!jac_grid_barrier(sync, ++epoch * nwg, &s_ok)) return;
+    double *A = A0, *B = A1;  // source and destination of the round
+    const int np = (n + 1) & ~1;
+    const int half = np / 2;
+    int sweep = 0;
+    for (; sweep < 60 && n > 1; ++sweep) {
+        if (t == 0) nrot = 0;
+        __syncthreads();
+        for (int rd = 0; rd < np - 1; ++rd) {
+            for (int i = t; i < n; i += kJacGridThreads) pair_of[i] = -1;
+            __syncthreads();
+            if (t < half) {  // (the one-workgroup kernel's pairing and rotation, statement by statement)
+                int a = t == 0 ? np - 1 : (rd + t) % (np - 1);
+                int b = (rd + np - 1 - t) % (np - 1);
+                if (a > b) {
+                    const int tmp = a;
+                    a = b;
+                    b = tmp;
+                }
+                double c = 1.0, s = 0.0;
+                if (b < n) {
+                    const double app = A[a * n + a], aqq = A[b * n + b], apq = A[a * n + b];
+                    if (fabs(apq) > 1.1102230246251565e-16 * sqrt(fabs(app) * fabs(aqq)) && apq != 0.0) {
+                        const double theta = (aqq - app) / (2.0 * apq);
+                        const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        c = 1.0 / sqrt(tt * tt + 1.0);
+                        s = tt * c;
+                        atomicAdd(&nrot, 1);
+                    }
+                } else {
+                    b = -1;
+                }
+                cs[t][0] = c;
+                cs[t][1] = s;
+                pq[t][0] = a;
+                pq[t][1] = b;
+                if (b >= 0 && s != 0.0) {
+                    pair_of[a] = (int16_t)t;
+                    pair_of[b] = (int16_t)t;
+                }
+            }
+            __syncthreads();
+            // A' = J^T (A J), entry by entry
+            for (unsigned idx = gtid; idx < nn; idx += gthreads) {
+                const int i = (int)(idx / un), j = (int)(idx - (unsigned)i * un);
+                const int mi = pair_of[i], mj = pair_of[j];
+                // the column combination at row r: (A J)[r][j]
+                auto col = [&](int r) -> double {
+                    if (mj < 0) return A[r * n + j];
+                    const int p = pq[mj][0], q = pq[mj][1];
+                    const double c = cs[mj][0], sn = cs[mj][1];
+                    const double arp = A[r * n + p], arq = A[r * n + q];
+                    return j == p ? c * arp - sn * arq : sn * arp + c * arq;
+                };
+                double out;
+                if (mi < 0) {
+                    out = col(i);
+                } else {
+                    const int p = pq[mi][0], q = pq[mi][1];
+                    const double c = cs[mi][0], sn = cs[mi][1];
+                    const double apj = col(p), aqj = col(q);
+                    out = i == p ? c * apj - sn * aqj : sn * apj + c * aqj;
+                }
+                B[idx] = out;
+            }
+            // V <- V J, in place (an item touches the two entries of its row and pair only)
+            for (unsigned idx = gtid; idx < (unsigned)half * un; idx += gthreads) {
+                const int i = (int)(idx / (unsigned)half), m = (int)(idx - (unsigned)i * (unsigned)half);
+                const int p = pq[m][0], q = pq[m][1];
+                const double c = cs[m][0], sn = cs[m][1];
+                if (q < 0 || sn == 0.0) continue;
+                const double vip = V[i * n + p], viq = V[i * n + q];
+                V[i * n + p] = c * vip - sn * viq;
+                V[i * n + q] = sn * vip + c * viq;
+            }
+            if (!jac_grid_barrier(sync, ++epoch * nwg, &s_ok)) return;
+            double *tmp = A;
+            A = B;
+            B = tmp;
+        }
+        const int done = nrot == 0;
+        __syncthreads();
+        if (done) break;
+    }
+    if (gtid == 0 && sweeps_out) *sweeps_out = sweep;
+    // sort descending (rank sort; ties keep index order)
+    for (int i = (int)gtid; i < n; i += (int)gthreads) {
+        const double li = A[i * n + i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double lj = A[j * n + j];
+            rank += (lj > li || (lj == li && j < i)) ? 1 : 0;
+        }
+        evals[rank] = li;
+        for (int r = 0; r < n; ++r) Vs[r * n + rank] = V[r * n + i];
+    }
+}
+
 // B[i][c] = sum_r L[r][c] V[r][i]   (c over ALL points, i < n): column i of  U sqrt(lambda) = L V
 constexpr int kLvCols = 8;  // columns of B per thread: L is read n / 8 times instead of n times (the same fma sequence per entry)
 __global__ __launch_bounds__(256) void lv_kernel(const double *__restrict__ L, int64_t M, int32_t n,
@@ -568,6 +729,21 @@ static int jacobi_two_sided(gingr_ctx *ctx, const double *G, int32_t ldg, int32_
     DevBuf wA, wV;
     HIP_TRY(ctx, wA.alloc((size_t)n * n * sizeof(double)));
     HIP_TRY(ctx, wV.alloc((size_t)n * n * sizeof(double)));
+    if (n > 128) {  // the same arithmetic on 64 workgroups (a second buffer for A, a barrier word and a failure flag)
+        DevBuf wB, sync;
+        HIP_TRY(ctx, wB.alloc((size_t)n * n * sizeof(double)));
+        HIP_TRY(ctx, sync.alloc(2 * sizeof(unsigned)));
+        HIP_TRY(ctx, hipMemsetAsync(sync.p, 0, 2 * sizeof(unsigned), ctx->stream));
+        hipLaunchKernelGGL(jacobi_eig_grid_kernel, dim3(kJacGridWgs), dim3(kJacGridThreads), 0, ctx->stream, G, ldg, n, wA.as<double>(),
+                           wB.as<double>(), wV.as<double>(), evals, Vs, sweeps, sync.as<unsigned>());
+        HIP_TRY(ctx, hipGetLastError());
+        unsigned h[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpyAsync(h, sync.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the work buffers go out of scope
+        if (h[1])
+            return gingr_set_error(ctx, GINGR_ERR_STATE, "sym_eig: the workgroups of the decomposition did not meet within two seconds (n = %d)", (int)n);
+        return GINGR_OK;
+    }
     hipLaunchKernelGGL(jacobi_eig_kernel, dim3(1), dim3(kJacThreads), 0, ctx->stream, G, ldg, n, wA.as<double>(), wV.as<double>(), evals, Vs,
                        sweeps);
     HIP_TRY(ctx, hipGetLastError());

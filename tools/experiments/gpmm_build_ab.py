@@ -34,6 +34,8 @@ for name, tol, mr in [("g50k_r100", 0.0, 100), ("g50k_r512", 0.01, 0), ("g50k_r3
     keep(name, *timed(lambda: ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=tol, maxRank=mr).Gaussian(70.0, 50.0)))
 keep("sym50k_r100", *timed(lambda: ga.GPMMTriangleMesh3D(ctx, ref, relativeTolerance=0.0, maxRank=100).GaussianSymmetry(70.0, 50.0)))
 keep("sym20k_r301", *timed(lambda: ga.GPMMTriangleMesh3D(ctx, ref[:20000], relativeTolerance=0.0, maxRank=301).GaussianSymmetry(70.0, 50.0)))
+for name, npts, mr in [("sym8k_r193", 8000, 193), ("sym10k_r200", 10000, 200), ("sym20k_r512", 20000, 512)]:   # more than 192 columns
+    keep(name, *timed(lambda: ga.GPMMTriangleMesh3D(ctx, ref[:npts], relativeTolerance=0.0, maxRank=mr).GaussianSymmetry(70.0, 50.0)))
 d = np.load(os.path.join(ROOT, "tests", "golden", "inputs.npz"))
 m = np.load(os.path.join(ROOT, "tests", "golden", "femur_mesh.npz"))
 fem, cells = d["femur"].astype(np.float64), m["femur_cells"]
