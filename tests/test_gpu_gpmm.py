@@ -223,10 +223,10 @@ def test_wide_models_through_the_register_eigen_kernels(ctx, max_rank):
     check_model_against_oracle(dm.to_host(), mo)
 
 
-@pytest.mark.parametrize("max_rank", [150, 250])
+@pytest.mark.parametrize("max_rank", [150, 250, 301])
 def test_wide_two_kernel_models(ctx, max_rank):
     """Two kernels (mirrored Gaussian): ONE eigen-problem of `rank` columns -- 150: three values per lane of the register kernel;
-    250: past its 192 columns, the two-sided kernel."""
+    250 / 301: past its 192 columns, the two-sided kernel on 64 workgroups (301: an odd number of columns, one sits out each round)."""
     import gingr_amd as ga
     ref = cloud(700, 22)
     mo = go.build_gpmm_diagonal(ref, go.symmetric_gauss_kernel_fun(ref, 20.0, 10.0), 0.0, max_rank)
