@@ -98,12 +98,19 @@ struct PosLog {
     int32_t vp, vd, vo;  // virtual entry (vp < 0: none)
 };
 
+// Slot of element e after the logged swaps.  The replay -- "a pivot stays where it was put; a displaced element goes to the pivot's old
+// slot" -- only depends on the step that pivoted e (at most one, and e never moves after it) and otherwise on the LAST step that displaced
+// it, so the loop carries two selects and no branch: its reads do not depend on one another and run pipelined (as a literal replay with
+// an early return every logged step was a dependent round trip, and a mirrored kernel's structural ties replay the log dozens of times
+// per step: pc_step_kernel<true> 131 -> 113 us on average with the log in LDS, -> see profiles/r06_gpmm_build_ab_blocked_kernels.txt).
 __device__ __forceinline__ int32_t log_position(const PosLog &lg, int32_t e) {
-    int32_t q = e;
+    int32_t sp = -1, sl = -1;
     for (int32_t s = 0; s < lg.n; ++s) {
-        if (lg.piv[s] == e) return s;  // pivots stay where they were put (they never compete again)
-        if (lg.dis[s] == e) q = lg.old[s];
+        sp = lg.piv[s] == e ? s : sp;
+        sl = lg.dis[s] == e ? s : sl;
     }
+    if (sp >= 0) return sp;  // pivots stay where they were put (they never compete again)
+    int32_t q = sl >= 0 ? lg.old[sl] : e;
     if (lg.vp >= 0) {
         if (lg.vp == e) return lg.n;
         if (lg.vd == e) q = lg.vo;
@@ -111,12 +118,11 @@ __device__ __forceinline__ int32_t log_position(const PosLog &lg, int32_t e) {
     return q;
 }
 
-// the element in slot `slot` (>= lg.n) after the logged swaps
+// the element in slot `slot` (>= lg.n) after the logged swaps: the one the last swap into that slot put there
 __device__ __forceinline__ int32_t log_occupant(const PosLog &lg, int32_t slot) {
-    int32_t e = slot;
-    for (int32_t s = 0; s < lg.n; ++s)
-        if (lg.old[s] == slot) e = lg.dis[s];
-    return e;
+    int32_t sl = -1;
+    for (int32_t s = 0; s < lg.n; ++s) sl = lg.old[s] == slot ? s : sl;
+    return sl >= 0 ? lg.dis[sl] : slot;
 }
 
 __device__ __forceinline__ Best better(Best a, Best b, const PosLog &lg) {  // larger value; ties -> earlier slot; NaN never wins
@@ -208,13 +214,25 @@ __global__ __launch_bounds__(kPcBlock) void pc_step_kernel(Cloud pts, KSpec3 spe
     __shared__ Best shb[kPcBlock];
     __shared__ double shs[kPcBlock];
     __shared__ double Lp[512];
+    __shared__ int32_t s_piv[512], s_dis[512], s_old[512];
     __shared__ int32_t finished, sh_dis, sh_old;
     const int t = threadIdx.x;
     if (t == 0) finished = ctl[1];  // set by an earlier launch (or, harmlessly, by workgroup 0 of this one)
     __syncthreads();
     if (finished) return;
     fastexp_table_init(T);
-    PosLog lg{pivots, sw_dis, sw_old, k, -1, 0, 0};  // the swaps of steps 0 .. k-1 (written by earlier launches)
+    // The swaps of steps 0 .. k-1 (written by earlier launches), copied to LDS first: every workgroup replays the log twice per step
+    // for this step's swap, and once per candidate for every exact tie (the y and z entries of a point under a mirrored kernel tie
+    // structurally).  Read from global memory the replay was one dependent round trip per logged step -- 0.5 us per step of the
+    // log for a single-kernel model, 0.8 us for a mirrored one: 365 ms of the 11 A/B builds of tools/experiments/gpmm_build_ab.py,
+    // more than everything else of the set-up together.
+    for (int r = t; r < k; r += kPcBlock) {
+        s_piv[r] = pivots[r];
+        s_dis[r] = sw_dis[r];
+        s_old[r] = sw_old[r];
+    }
+    __syncthreads();
+    PosLog lg{s_piv, s_dis, s_old, k, -1, 0, 0};
     Best g{0.0, -1};
     double gtr = 0.0;
     for (int b = t; b < nblocks; b += kPcBlock) {
