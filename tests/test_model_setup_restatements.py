@@ -207,3 +207,24 @@ def test_one_jacobi_round_entry_by_entry_equals_columns_then_rows():
                         B[i, j] = c * col(p) - s * col(q) if i == p else s * col(p) + c * col(q)
             assert np.array_equal(A, B), (n, rd)
             A0 = A
+
+
+def test_blocked_factor_gram_writes_every_entry_once():
+    """pc_gram_kernel: 4 x 4 blocks (a0, b0) with a0 <= b0; of a block only the entries a <= b inside the matrix are stored (and
+    mirrored) -- every entry of the upper triangle exactly once, whatever k is modulo 4."""
+    tile = 4
+    for k in (1, 3, 4, 5, 34, 171):
+        nb = -(-k // tile)
+        written = np.zeros((k, k), dtype=np.int32)
+        for bx in range(nb):
+            for by in range(nb):
+                a0, b0 = bx * tile, by * tile
+                if a0 > b0:
+                    continue
+                for u in range(tile * tile):
+                    a, b = a0 + u // tile, b0 + u % tile
+                    if a < k and b < k and a <= b:
+                        written[a, b] += 1
+                        if a != b:
+                            written[b, a] += 1
+        assert np.array_equal(written, np.ones((k, k), dtype=np.int32)), k
